@@ -1,0 +1,295 @@
+"""ctypes binding of libgsfm.so (include/gsfm.h).  No fallback: a missing library or a missing GPU is
+a hard error — the product path never runs on the CPU."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libgsfm.so"
+
+GSFM_MEM_HOST = 0
+GSFM_MEM_DEVICE = 1
+GSFM_COMM_ID_BYTES = 128
+GSFM_CAMERA_MAX_PARAMS = 8
+
+STATUS_NAMES = {
+    0: "GSFM_OK",
+    -1: "GSFM_ERR_INVALID_ARGUMENT",
+    -2: "GSFM_ERR_HIP",
+    -3: "GSFM_ERR_NO_DEVICE",
+    -4: "GSFM_ERR_NUMERICAL",
+    -5: "GSFM_ERR_EMPTY_PROBLEM",
+    -6: "GSFM_ERR_NOT_USABLE",
+    -7: "GSFM_ERR_UNSUPPORTED",
+    -8: "GSFM_ERR_COMM",
+}
+
+
+class GsfmError(RuntimeError):
+    def __init__(self, status: int, where: str):
+        self.status = status
+        super().__init__(f"{where}: {STATUS_NAMES.get(status, status)}")
+
+
+class Report(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int32),
+        ("iterations_l1", C.c_int32),
+        ("iterations_irls", C.c_int32),
+        ("successful_steps", C.c_int32),
+        ("linear_iterations", C.c_int64),
+        ("initial_cost", C.c_double),
+        ("final_cost", C.c_double),
+        ("termination", C.c_int32),
+        ("hip_error", C.c_int32),
+        ("seconds_total", C.c_double),
+        ("seconds_solve", C.c_double),
+        ("last_step_norm", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+class RaOptions(C.Structure):
+    _fields_ = [
+        ("max_num_l1_iterations", C.c_int32),
+        ("l1_step_convergence_threshold", C.c_double),
+        ("max_num_irls_iterations", C.c_int32),
+        ("irls_step_convergence_threshold", C.c_double),
+        ("irls_loss_parameter_sigma", C.c_double),
+        ("weight_type", C.c_int32),
+        ("skip_initialization", C.c_int32),
+        ("use_weight", C.c_int32),
+        ("use_gravity", C.c_int32),
+        ("l1_admm_max_num_iterations", C.c_int32),
+        ("l1_admm_rho", C.c_double),
+        ("l1_admm_alpha", C.c_double),
+        ("l1_admm_absolute_tolerance", C.c_double),
+        ("l1_admm_relative_tolerance", C.c_double),
+        ("pcg_relative_tolerance", C.c_double),
+        ("pcg_max_iterations", C.c_int32),
+    ]
+
+
+class RaProblemC(C.Structure):
+    _fields_ = [
+        ("mem", C.c_int32),
+        ("num_nodes", C.c_int32),
+        ("num_edges", C.c_int64),
+        ("edge_i", C.c_void_p),
+        ("edge_j", C.c_void_p),
+        ("edge_q", C.c_void_p),
+        ("edge_weight", C.c_void_p),
+        ("edge_ninl", C.c_void_p),
+        ("fixed_node", C.c_int32),
+    ]
+
+
+class LmOptions(C.Structure):
+    _fields_ = [
+        ("max_num_iterations", C.c_int32),
+        ("function_tolerance", C.c_double),
+        ("gradient_tolerance", C.c_double),
+        ("parameter_tolerance", C.c_double),
+        ("initial_trust_region_radius", C.c_double),
+        ("max_trust_region_radius", C.c_double),
+        ("min_trust_region_radius", C.c_double),
+        ("min_relative_decrease", C.c_double),
+        ("min_lm_diagonal", C.c_double),
+        ("max_lm_diagonal", C.c_double),
+        ("jacobi_scaling", C.c_int32),
+        ("max_num_consecutive_invalid_steps", C.c_int32),
+        ("pcg_relative_tolerance", C.c_double),
+        ("pcg_max_iterations", C.c_int32),
+    ]
+
+
+class GpOptions(C.Structure):
+    _fields_ = [
+        ("lm", LmOptions),
+        ("thres_loss_function", C.c_double),
+        ("generate_random_positions", C.c_int32),
+        ("generate_random_points", C.c_int32),
+        ("generate_scales", C.c_int32),
+        ("optimize_positions", C.c_int32),
+        ("optimize_points", C.c_int32),
+        ("optimize_scales", C.c_int32),
+        ("min_num_view_per_track", C.c_int32),
+        ("seed", C.c_uint32),
+        ("constraint_type", C.c_int32),
+    ]
+
+
+class GpProblemC(C.Structure):
+    _fields_ = [
+        ("mem", C.c_int32),
+        ("num_cams", C.c_int32),
+        ("num_pts", C.c_int64),
+        ("num_obs", C.c_int64),
+        ("pt_offset", C.c_void_p),
+        ("obs_cam", C.c_void_p),
+        ("obs_dir", C.c_void_p),
+        ("obs_calibrated", C.c_void_p),
+    ]
+
+
+class BaOptions(C.Structure):
+    _fields_ = [
+        ("lm", LmOptions),
+        ("thres_loss_function", C.c_double),
+        ("optimize_rotations", C.c_int32),
+        ("optimize_translation", C.c_int32),
+        ("optimize_intrinsics", C.c_int32),
+        ("optimize_principal_point", C.c_int32),
+        ("optimize_points", C.c_int32),
+        ("min_num_view_per_track", C.c_int32),
+    ]
+
+
+class BaProblemC(C.Structure):
+    _fields_ = [
+        ("mem", C.c_int32),
+        ("num_cams", C.c_int32),
+        ("num_intr", C.c_int32),
+        ("fixed_cam", C.c_int32),
+        ("num_pts", C.c_int64),
+        ("num_obs", C.c_int64),
+        ("pt_offset", C.c_void_p),
+        ("obs_cam", C.c_void_p),
+        ("obs_xy", C.c_void_p),
+        ("cam_intr", C.c_void_p),
+        ("intr_model", C.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Loads libgsfm.so (building nothing: run __graft_entry__.build() / glomap_amd.build first)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} is missing — build it with `python -m glomap_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback."
+        )
+    lib = C.CDLL(str(LIB_PATH))
+    vp, ip, dp = C.c_void_p, C.c_int, C.POINTER(C.c_double)
+    lib.gsfm_version.restype = ip
+    lib.gsfm_status_string.restype = C.c_char_p
+    lib.gsfm_status_string.argtypes = [ip]
+    lib.gsfm_ctx_create.restype = ip
+    lib.gsfm_ctx_create.argtypes = [ip, C.POINTER(vp)]
+    lib.gsfm_ctx_destroy.restype = None
+    lib.gsfm_ctx_destroy.argtypes = [vp]
+    lib.gsfm_ctx_stream.restype = vp
+    lib.gsfm_ctx_stream.argtypes = [vp]
+    lib.gsfm_ctx_device_name.restype = ip
+    lib.gsfm_ctx_device_name.argtypes = [vp, C.c_char_p, C.c_size_t]
+    lib.gsfm_ctx_profile_enable.restype = ip
+    lib.gsfm_ctx_profile_enable.argtypes = [vp, ip]
+    lib.gsfm_ctx_profile_read.restype = ip
+    lib.gsfm_ctx_profile_read.argtypes = [vp, ip, C.POINTER(C.c_int64), dp]
+    lib.gsfm_comm_unique_id.restype = ip
+    lib.gsfm_comm_unique_id.argtypes = [C.c_char_p]
+    lib.gsfm_comm_init.restype = ip
+    lib.gsfm_comm_init.argtypes = [vp, C.c_char_p, ip, ip]
+    lib.gsfm_comm_destroy.restype = ip
+    lib.gsfm_comm_destroy.argtypes = [vp]
+    lib.gsfm_ra_options_default.restype = None
+    lib.gsfm_ra_options_default.argtypes = [C.POINTER(RaOptions)]
+    lib.gsfm_ra_solve.restype = ip
+    lib.gsfm_ra_solve.argtypes = [vp, C.POINTER(RaProblemC), C.POINTER(RaOptions), vp, C.POINTER(Report)]
+    lib.gsfm_ra_residuals.restype = ip
+    lib.gsfm_ra_residuals.argtypes = [vp, C.POINTER(RaProblemC), C.POINTER(RaOptions), vp, vp, vp]
+    lib.gsfm_ra_laplacian_apply.restype = ip
+    lib.gsfm_ra_laplacian_apply.argtypes = [vp, C.POINTER(RaProblemC), vp, vp, vp, ip, dp]
+    if hasattr(lib, "gsfm_gp_solve"):
+        lib.gsfm_gp_options_default.restype = None
+        lib.gsfm_gp_options_default.argtypes = [C.POINTER(GpOptions)]
+        lib.gsfm_gp_solve.restype = ip
+        lib.gsfm_gp_solve.argtypes = [vp, C.POINTER(GpProblemC), C.POINTER(GpOptions), vp, vp, C.POINTER(Report)]
+    if hasattr(lib, "gsfm_ba_solve"):
+        lib.gsfm_ba_options_default.restype = None
+        lib.gsfm_ba_options_default.argtypes = [C.POINTER(BaOptions)]
+        lib.gsfm_ba_solve.restype = ip
+        lib.gsfm_ba_solve.argtypes = [vp, C.POINTER(BaProblemC), C.POINTER(BaOptions), vp, vp, vp, vp, C.POINTER(Report)]
+    _lib = lib
+    return lib
+
+
+def ptr(a):
+    """Raw address of a numpy array (host) or torch tensor (device); None -> NULL."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"], "array must be C-contiguous"
+        return a.ctypes.data
+    # torch tensor
+    assert a.is_contiguous()
+    return a.data_ptr()
+
+
+class Context:
+    """One GPU, one stream (gsfm_ctx).  Raises if no HIP device is present."""
+
+    def __init__(self, device_id: int = -1):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.gsfm_ctx_create(device_id, C.byref(h))
+        if rc != 0:
+            raise GsfmError(rc, "gsfm_ctx_create")
+        self.handle = h
+        self.rank = 0
+        self.world = 1
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.gsfm_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self) -> int:
+        return int(self.lib.gsfm_ctx_stream(self.handle) or 0)
+
+    def device_name(self) -> str:
+        buf = C.create_string_buffer(256)
+        self.lib.gsfm_ctx_device_name(self.handle, buf, 256)
+        return buf.value.decode()
+
+    def profile_enable(self, on: bool):
+        self.lib.gsfm_ctx_profile_enable(self.handle, int(on))
+
+    def profile_read(self, kernel_id: int):
+        n = C.c_int64(0)
+        ms = C.c_double(0.0)
+        rc = self.lib.gsfm_ctx_profile_read(self.handle, kernel_id, C.byref(n), C.byref(ms))
+        if rc != 0:
+            raise GsfmError(rc, "gsfm_ctx_profile_read")
+        return n.value, ms.value
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        rc = self.lib.gsfm_comm_init(self.handle, unique_id, rank, world)
+        if rc != 0:
+            raise GsfmError(rc, "gsfm_comm_init")
+        self.rank, self.world = rank, world
+
+
+def comm_unique_id() -> bytes:
+    lib = load()
+    buf = C.create_string_buffer(GSFM_COMM_ID_BYTES)
+    rc = lib.gsfm_comm_unique_id(buf)
+    if rc != 0:
+        raise GsfmError(rc, "gsfm_comm_unique_id")
+    return buf.raw

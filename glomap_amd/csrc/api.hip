@@ -1,0 +1,146 @@
+// api.hip — context, communicator and misc entry points of the C ABI (include/gsfm.h).
+#include "common.hpp"
+
+using namespace gsfm;
+
+extern "C" int gsfm_version(void) { return GSFM_VERSION; }
+
+extern "C" const char* gsfm_status_string(int status) {
+  switch (status) {
+    case GSFM_OK: return "ok";
+    case GSFM_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case GSFM_ERR_HIP: return "HIP runtime error";
+    case GSFM_ERR_NO_DEVICE: return "no HIP device";
+    case GSFM_ERR_NUMERICAL: return "numerical failure (NaN)";
+    case GSFM_ERR_EMPTY_PROBLEM: return "empty problem";
+    case GSFM_ERR_NOT_USABLE: return "solution not usable";
+    case GSFM_ERR_UNSUPPORTED: return "unsupported configuration";
+    case GSFM_ERR_COMM: return "RCCL error";
+    default: return "unknown status";
+  }
+}
+
+extern "C" int gsfm_ctx_create(int device_id, gsfm_ctx** out) {
+  if (!out) return GSFM_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    fprintf(stderr, "[gsfm] no HIP device available — libgsfm has no CPU fallback\n");
+    return GSFM_ERR_NO_DEVICE;
+  }
+  gsfm_ctx* ctx = new gsfm_ctx();
+  int rc = guarded(ctx, nullptr, [&] {
+    if (device_id < 0) {
+      GSFM_HIP_CHECK(hipGetDevice(&ctx->device));
+    } else {
+      GSFM_REQUIRE(device_id < count, "device_id out of range");
+      ctx->device = device_id;
+    }
+    GSFM_HIP_CHECK(hipSetDevice(ctx->device));
+    hipDeviceProp_t prop;
+    GSFM_HIP_CHECK(hipGetDeviceProperties(&prop, ctx->device));
+    ctx->num_cus = prop.multiProcessorCount;
+    GSFM_HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    GSFM_HIP_CHECK(hipEventCreate(&ctx->ev0));
+    GSFM_HIP_CHECK(hipEventCreate(&ctx->ev1));
+    GSFM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pinned), 4096 * sizeof(double), hipHostMallocDefault));
+    return (int)GSFM_OK;
+  });
+  if (rc != GSFM_OK) {
+    gsfm_ctx_destroy(ctx);
+    return rc;
+  }
+  *out = ctx;
+  return GSFM_OK;
+}
+
+extern "C" void gsfm_ctx_destroy(gsfm_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->ra_ws && ctx->ra_ws_free) ctx->ra_ws_free(ctx->ra_ws);
+  if (ctx->gp_ws && ctx->gp_ws_free) ctx->gp_ws_free(ctx->gp_ws);
+  if (ctx->ba_ws && ctx->ba_ws_free) ctx->ba_ws_free(ctx->ba_ws);
+  if (ctx->comm.nccl) (void)ncclCommDestroy(ctx->comm.nccl);
+  ctx->prof.destroy();
+  if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" void* gsfm_ctx_stream(gsfm_ctx* ctx) { return ctx ? static_cast<void*>(ctx->stream) : nullptr; }
+
+extern "C" int gsfm_ctx_device_name(gsfm_ctx* ctx, char* buf, size_t buflen) {
+  if (!ctx || !buf || buflen == 0) return GSFM_ERR_INVALID_ARGUMENT;
+  return guarded(ctx, nullptr, [&] {
+    hipDeviceProp_t prop;
+    GSFM_HIP_CHECK(hipGetDeviceProperties(&prop, ctx->device));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return (int)GSFM_OK;
+  });
+}
+
+extern "C" int gsfm_ctx_profile_enable(gsfm_ctx* ctx, int enable) {
+  if (!ctx) return GSFM_ERR_INVALID_ARGUMENT;
+  ctx->prof.enabled = enable != 0;
+  return GSFM_OK;
+}
+
+extern "C" int gsfm_ctx_profile_read(gsfm_ctx* ctx, int kernel_id, int64_t* launches, double* total_ms) {
+  if (!ctx || kernel_id < 0 || kernel_id >= GSFM_KERNEL_COUNT) return GSFM_ERR_INVALID_ARGUMENT;
+  return guarded(ctx, nullptr, [&] {
+    GSFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->prof.harvest();
+    if (launches) *launches = ctx->prof.launches[kernel_id];
+    if (total_ms) *total_ms = ctx->prof.total_ms[kernel_id];
+    ctx->prof.launches[kernel_id] = 0;
+    ctx->prof.total_ms[kernel_id] = 0.0;
+    return (int)GSFM_OK;
+  });
+}
+
+// ---- RCCL communicator -----------------------------------------------------------------------
+static_assert(sizeof(ncclUniqueId) <= GSFM_COMM_ID_BYTES, "ncclUniqueId does not fit GSFM_COMM_ID_BYTES");
+
+extern "C" int gsfm_comm_unique_id(char id[GSFM_COMM_ID_BYTES]) {
+  if (!id) return GSFM_ERR_INVALID_ARGUMENT;
+  return guarded(nullptr, nullptr, [&] {
+    ncclUniqueId uid;
+    GSFM_NCCL_CHECK(ncclGetUniqueId(&uid));
+    std::memset(id, 0, GSFM_COMM_ID_BYTES);
+    std::memcpy(id, &uid, sizeof(uid));
+    return (int)GSFM_OK;
+  });
+}
+
+extern "C" int gsfm_comm_init(gsfm_ctx* ctx, const char id[GSFM_COMM_ID_BYTES], int rank, int world_size) {
+  if (!ctx || !id) return GSFM_ERR_INVALID_ARGUMENT;
+  return guarded(ctx, nullptr, [&] {
+    GSFM_REQUIRE(world_size >= 1 && rank >= 0 && rank < world_size, "comm: bad rank/world_size");
+    GSFM_HIP_CHECK(hipSetDevice(ctx->device));
+    if (ctx->comm.nccl) {
+      GSFM_NCCL_CHECK(ncclCommDestroy(ctx->comm.nccl));
+      ctx->comm.nccl = nullptr;
+    }
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    GSFM_NCCL_CHECK(ncclCommInitRank(&ctx->comm.nccl, world_size, uid, rank));
+    ctx->comm.rank = rank;
+    ctx->comm.world = world_size;
+    return (int)GSFM_OK;
+  });
+}
+
+extern "C" int gsfm_comm_destroy(gsfm_ctx* ctx) {
+  if (!ctx) return GSFM_ERR_INVALID_ARGUMENT;
+  return guarded(ctx, nullptr, [&] {
+    if (ctx->comm.nccl) {
+      GSFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      GSFM_NCCL_CHECK(ncclCommDestroy(ctx->comm.nccl));
+    }
+    ctx->comm = Comm{};
+    return (int)GSFM_OK;
+  });
+}

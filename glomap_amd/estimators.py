@@ -1,0 +1,471 @@
+"""Host-side mirror of the reference's estimator interface on top of the C ABI (libgsfm.so).
+
+Two levels:
+  * flat level  — ra_solve / gp_solve / ba_solve take the SoA problems of glomap_amd.flat (numpy
+    arrays on the host, or torch tensors already resident in HBM) and call the C ABI directly;
+  * scene level — RotationEstimator / GlobalPositioner / BundleAdjuster keep the reference's
+    class names, option names and bool-returning methods
+    (global_rotation_averaging.h:79-87, global_positioning.h:58-68, bundle_adjustment.h:40-51)
+    over dict-based scene containers (glomap_amd.scene), doing the pack / unpack the C++
+    adapter include/gsfm_glomap_adapter.hpp does for the real GLOMAP types.
+
+Nothing here computes on the CPU: without libgsfm.so and a HIP device every call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _lib, so3
+from .flat import CAMERA_MAX_PARAMS, BaProblem, GpProblem, RaProblem
+
+_default_ctx: Optional[_lib.Context] = None
+
+
+def default_context() -> _lib.Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = _lib.Context(-1)
+    return _default_ctx
+
+
+def _is_torch(a) -> bool:
+    return a is not None and not isinstance(a, np.ndarray) and hasattr(a, "data_ptr")
+
+
+def _mem_of(*arrays) -> int:
+    kinds = {_is_torch(a) for a in arrays if a is not None}
+    if len(kinds) != 1:
+        raise ValueError("all problem arrays must live in the same memory space")
+    return _lib.GSFM_MEM_DEVICE if kinds.pop() else _lib.GSFM_MEM_HOST
+
+
+def _h(a, dtype):
+    """numpy: contiguous array of dtype; torch: checked as-is."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return np.ascontiguousarray(a, dtype=dtype)
+    return a.contiguous()
+
+
+# ============================================================================================
+# Options (field names and defaults = the reference's structs)
+# ============================================================================================
+@dataclass
+class RotationEstimatorOptions:
+    """glomap/estimators/global_rotation_averaging.h:39-75."""
+
+    max_num_l1_iterations: int = 5
+    l1_step_convergence_threshold: float = 0.001
+    max_num_irls_iterations: int = 100
+    irls_step_convergence_threshold: float = 0.001
+    irls_loss_parameter_sigma: float = 5.0
+    weight_type: int = 0  # GEMAN_MCCLURE
+    skip_initialization: bool = False
+    use_weight: bool = False
+    use_gravity: bool = False
+    # linear solver (replaces CHOLMOD)
+    pcg_relative_tolerance: float = 1e-10
+    pcg_max_iterations: int = 2000
+
+    GEMAN_MCCLURE = 0
+    HALF_NORM = 1
+
+    def to_c(self) -> _lib.RaOptions:
+        o = _lib.RaOptions()
+        _lib.load().gsfm_ra_options_default(C.byref(o))
+        for name in (
+            "max_num_l1_iterations l1_step_convergence_threshold max_num_irls_iterations "
+            "irls_step_convergence_threshold irls_loss_parameter_sigma weight_type "
+            "pcg_relative_tolerance pcg_max_iterations"
+        ).split():
+            setattr(o, name, getattr(self, name))
+        o.skip_initialization = int(self.skip_initialization)
+        o.use_weight = int(self.use_weight)
+        o.use_gravity = int(self.use_gravity)
+        return o
+
+
+@dataclass
+class SolverOptions:
+    """The ceres::Solver::Options fields the reference touches (optimization_base.h:18-23) plus
+    the linear-solver knobs of the implicit-Schur PCG that replaces SPARSE_SCHUR."""
+
+    max_num_iterations: int = 100
+    function_tolerance: float = 1e-5
+    pcg_relative_tolerance: float = 1e-8
+    pcg_max_iterations: int = 1000
+
+
+@dataclass
+class GlobalPositionerOptions:
+    """glomap/estimators/global_positioning.h:9-54."""
+
+    generate_random_positions: bool = True
+    generate_random_points: bool = True
+    generate_scales: bool = True
+    optimize_positions: bool = True
+    optimize_points: bool = True
+    optimize_scales: bool = True
+    min_num_view_per_track: int = 3
+    seed: int = 1
+    constraint_type: int = 0  # ONLY_POINTS
+    thres_loss_function: float = 1e-1
+    solver_options: SolverOptions = field(default_factory=lambda: SolverOptions(max_num_iterations=100))
+
+    def to_c(self) -> _lib.GpOptions:
+        o = _lib.GpOptions()
+        _lib.load().gsfm_gp_options_default(C.byref(o))
+        for name in (
+            "generate_random_positions generate_random_points generate_scales optimize_positions "
+            "optimize_points optimize_scales min_num_view_per_track seed constraint_type"
+        ).split():
+            setattr(o, name, int(getattr(self, name)))
+        o.thres_loss_function = self.thres_loss_function
+        _fill_lm(o.lm, self.solver_options)
+        return o
+
+
+@dataclass
+class BundleAdjusterOptions:
+    """glomap/estimators/bundle_adjustment.h:12-37."""
+
+    optimize_rig_poses: bool = False
+    optimize_rotations: bool = True
+    optimize_translation: bool = True
+    optimize_intrinsics: bool = True
+    optimize_principal_point: bool = False
+    optimize_points: bool = True
+    min_num_view_per_track: int = 3
+    thres_loss_function: float = 1.0
+    solver_options: SolverOptions = field(default_factory=lambda: SolverOptions(max_num_iterations=200))
+
+    def to_c(self) -> _lib.BaOptions:
+        o = _lib.BaOptions()
+        _lib.load().gsfm_ba_options_default(C.byref(o))
+        for name in (
+            "optimize_rotations optimize_translation optimize_intrinsics optimize_principal_point "
+            "optimize_points min_num_view_per_track"
+        ).split():
+            setattr(o, name, int(getattr(self, name)))
+        o.thres_loss_function = self.thres_loss_function
+        _fill_lm(o.lm, self.solver_options)
+        return o
+
+
+def _fill_lm(lm: _lib.LmOptions, so: SolverOptions):
+    lm.max_num_iterations = so.max_num_iterations
+    lm.function_tolerance = so.function_tolerance
+    lm.pcg_relative_tolerance = so.pcg_relative_tolerance
+    lm.pcg_max_iterations = so.pcg_max_iterations
+
+
+# ============================================================================================
+# Flat level
+# ============================================================================================
+def _ra_problem_c(p: RaProblem, keep: list) -> _lib.RaProblemC:
+    ei, ej = _h(p.edge_i, np.int32), _h(p.edge_j, np.int32)
+    eq, ew = _h(p.edge_q, np.float64), _h(p.edge_weight, np.float64)
+    en = _h(p.edge_ninl, np.int32)
+    keep += [ei, ej, eq, ew, en]
+    c = _lib.RaProblemC()
+    c.mem = _mem_of(ei, ej, eq, ew, en)
+    c.num_nodes = int(p.num_nodes)
+    c.num_edges = int(ei.shape[0])
+    c.edge_i, c.edge_j, c.edge_q = _lib.ptr(ei), _lib.ptr(ej), _lib.ptr(eq)
+    c.edge_weight, c.edge_ninl = _lib.ptr(ew), _lib.ptr(en)
+    c.fixed_node = int(p.fixed_node)
+    return c
+
+
+def ra_solve(p: RaProblem, options: Optional[RotationEstimatorOptions] = None, ctx=None, rot_inout=None):
+    """gsfm_ra_solve.  Returns (status, rot_aa [N,3] (same kind as the inputs), report dict)."""
+    ctx = ctx or default_context()
+    opt = (options or RotationEstimatorOptions()).to_c()
+    keep: list = []
+    c = _ra_problem_c(p, keep)
+    if rot_inout is None:
+        rot_inout = p.node_aa0.copy() if isinstance(p.node_aa0, np.ndarray) else p.node_aa0.clone()
+    rot_inout = _h(rot_inout, np.float64)
+    assert _mem_of(rot_inout) == c.mem
+    rep = _lib.Report()
+    rc = ctx.lib.gsfm_ra_solve(ctx.handle, C.byref(c), C.byref(opt), _lib.ptr(rot_inout), C.byref(rep))
+    return rc, rot_inout, rep.as_dict()
+
+
+def ra_residuals(p: RaProblem, rot_aa: np.ndarray, options: Optional[RotationEstimatorOptions] = None, ctx=None):
+    ctx = ctx or default_context()
+    opt = (options or RotationEstimatorOptions()).to_c()
+    keep: list = []
+    c = _ra_problem_c(p, keep)
+    rot = _h(rot_aa, np.float64)
+    E = c.num_edges
+    res = np.empty((E, 3))
+    w = np.empty(E)
+    assert c.mem == _lib.GSFM_MEM_HOST
+    rc = ctx.lib.gsfm_ra_residuals(ctx.handle, C.byref(c), C.byref(opt), _lib.ptr(rot), _lib.ptr(res), _lib.ptr(w))
+    if rc != 0:
+        raise _lib.GsfmError(rc, "gsfm_ra_residuals")
+    return res, w
+
+
+def ra_laplacian_apply(p: RaProblem, w, x, repeat: int = 1, ctx=None):
+    ctx = ctx or default_context()
+    keep: list = []
+    c = _ra_problem_c(p, keep)
+    w, x = _h(w, np.float64), _h(x, np.float64)
+    if c.mem == _lib.GSFM_MEM_HOST:
+        y = np.empty_like(x)
+    else:
+        y = x.clone()
+    ms = C.c_double(0.0)
+    rc = ctx.lib.gsfm_ra_laplacian_apply(ctx.handle, C.byref(c), _lib.ptr(w), _lib.ptr(x), _lib.ptr(y), repeat, C.byref(ms))
+    if rc != 0:
+        raise _lib.GsfmError(rc, "gsfm_ra_laplacian_apply")
+    return y, ms.value
+
+
+def gp_solve(p: GpProblem, options: Optional[GlobalPositionerOptions] = None, ctx=None):
+    """gsfm_gp_solve.  Returns (status, cam_center [N,3], pt_xyz [P,3], report dict)."""
+    ctx = ctx or default_context()
+    opt = (options or GlobalPositionerOptions()).to_c()
+    off, oc = _h(p.pt_offset, np.int64), _h(p.obs_cam, np.int32)
+    od, cal = _h(p.obs_dir, np.float64), _h(p.obs_calibrated, np.uint8)
+    c = _lib.GpProblemC()
+    c.mem = _mem_of(off, oc, od, cal)
+    c.num_cams, c.num_pts, c.num_obs = int(p.num_cams), int(p.num_pts), int(oc.shape[0])
+    c.pt_offset, c.obs_cam, c.obs_dir, c.obs_calibrated = _lib.ptr(off), _lib.ptr(oc), _lib.ptr(od), _lib.ptr(cal)
+    cen = _h(p.cam_center, np.float64)
+    xyz = _h(p.pt_xyz, np.float64)
+    cen = cen.copy() if isinstance(cen, np.ndarray) else cen.clone()
+    xyz = xyz.copy() if isinstance(xyz, np.ndarray) else xyz.clone()
+    rep = _lib.Report()
+    rc = ctx.lib.gsfm_gp_solve(ctx.handle, C.byref(c), C.byref(opt), _lib.ptr(cen), _lib.ptr(xyz), C.byref(rep))
+    return rc, cen, xyz, rep.as_dict()
+
+
+def ba_solve(p: BaProblem, options: Optional[BundleAdjusterOptions] = None, ctx=None):
+    """gsfm_ba_solve.  Returns (status, cam_q, cam_t, pt_xyz, intr_params, report dict)."""
+    ctx = ctx or default_context()
+    opt = (options or BundleAdjusterOptions()).to_c()
+    off, oc, oxy = _h(p.pt_offset, np.int64), _h(p.obs_cam, np.int32), _h(p.obs_xy, np.float64)
+    ci, im = _h(p.cam_intr, np.int32), _h(p.intr_model, np.int32)
+    c = _lib.BaProblemC()
+    c.mem = _mem_of(off, oc, oxy, ci, im)
+    c.num_cams, c.num_intr, c.fixed_cam = int(p.num_cams), int(p.num_intr), int(p.fixed_cam)
+    c.num_pts, c.num_obs = int(p.num_pts), int(oc.shape[0])
+    c.pt_offset, c.obs_cam, c.obs_xy = _lib.ptr(off), _lib.ptr(oc), _lib.ptr(oxy)
+    c.cam_intr, c.intr_model = _lib.ptr(ci), _lib.ptr(im)
+    outs = []
+    for a in (p.cam_q, p.cam_t, p.pt_xyz, p.intr_params):
+        a = _h(a, np.float64)
+        outs.append(a.copy() if isinstance(a, np.ndarray) else a.clone())
+    rep = _lib.Report()
+    rc = ctx.lib.gsfm_ba_solve(ctx.handle, C.byref(c), C.byref(opt), *[_lib.ptr(a) for a in outs], C.byref(rep))
+    return (rc, *outs, rep.as_dict())
+
+
+# ============================================================================================
+# Scene level (reference class names)
+# ============================================================================================
+class RotationEstimator:
+    """RotationEstimator (global_rotation_averaging.h:77-141), trivial rigs, 3-DoF."""
+
+    def __init__(self, options: RotationEstimatorOptions, ctx=None):
+        self.options_ = options
+        self.ctx = ctx
+        self.report = None
+
+    def EstimateRotations(self, view_graph, rigs, frames, images) -> bool:
+        if self.options_.use_gravity:
+            return False  # 1-DoF path not provided; reference also refuses some rigs here (gra.cc:47-58)
+        # frame -> dense node index over registered frames (gra.cc:193-227); first one is the gauge
+        node_of_frame: Dict[int, int] = {}
+        for fid, fr in frames.items():
+            if fr.is_registered:
+                node_of_frame[fid] = len(node_of_frame)
+        if not node_of_frame:
+            return False
+        N = len(node_of_frame)
+        ei, ej, eq, ew, en = [], [], [], [], []
+        for pair in view_graph.image_pairs.values():
+            if not pair.is_valid:
+                continue
+            i1, i2 = images[pair.image_id1], images[pair.image_id2]
+            if not (frames[i1.frame_id].is_registered and frames[i2.frame_id].is_registered):
+                continue
+            ei.append(node_of_frame[i1.frame_id])
+            ej.append(node_of_frame[i2.frame_id])
+            eq.append(pair.cam2_from_cam1.rotation)
+            ew.append(pair.weight)
+            en.append(pair.inlier_count())
+        aa0 = np.zeros((N, 3))
+        for fid, n in node_of_frame.items():
+            aa0[n] = so3.quat_to_aa(np.asarray(frames[fid].rig_from_world.rotation, dtype=np.float64))
+        prob = RaProblem(
+            num_nodes=N,
+            edge_i=np.asarray(ei, dtype=np.int32),
+            edge_j=np.asarray(ej, dtype=np.int32),
+            edge_q=np.asarray(eq, dtype=np.float64).reshape(-1, 4),
+            edge_weight=np.asarray(ew, dtype=np.float64),
+            edge_ninl=np.asarray(en, dtype=np.int32),
+            node_aa0=aa0,
+            fixed_node=0,
+        )
+        rc, rot, self.report = ra_solve(prob, self.options_, self.ctx)
+        if rc != 0:
+            return False
+        # ConvertResults (gra.cc:774-816): rotation written, translation zeroed
+        quats = so3.aa_to_quat(rot)
+        for fid, n in node_of_frame.items():
+            frames[fid].rig_from_world.rotation = quats[n]
+            frames[fid].rig_from_world.translation = np.zeros(3)
+        return True
+
+
+def _pack_tracks(images, frames, tracks, min_views, need_registered, node_of_frame):
+    """Track-major observation lists as both GP and BA need them (gp.cc:257-292, ba.cc:121-127)."""
+    tids, off, ocam, ofeat, oimg = [], [0], [], [], []
+    for tid, tr in tracks.items():
+        if len(tr.observations) < min_views:
+            continue
+        cnt = 0
+        for image_id, feat in tr.observations:
+            if image_id not in images:
+                continue
+            im = images[image_id]
+            if need_registered and not im.IsRegistered():
+                continue
+            if im.frame_id not in node_of_frame:
+                continue
+            ocam.append(node_of_frame[im.frame_id])
+            ofeat.append(feat)
+            oimg.append(image_id)
+            cnt += 1
+        tids.append(tid)
+        off.append(off[-1] + cnt)
+    return tids, np.asarray(off, dtype=np.int64), np.asarray(ocam, dtype=np.int32), ofeat, oimg
+
+
+class GlobalPositioner:
+    """GlobalPositioner (global_positioning.h:56-133), ONLY_POINTS, trivial rigs."""
+
+    def __init__(self, options: GlobalPositionerOptions, ctx=None):
+        self.options_ = options
+        self.ctx = ctx
+        self.report = None
+
+    def GetOptions(self) -> GlobalPositionerOptions:
+        return self.options_
+
+    def Solve(self, view_graph, rigs, cameras, frames, images, tracks) -> bool:
+        if not images:
+            return False  # gp.cc:37-40
+        if not tracks:
+            return False  # gp.cc:46-50 (ONLY_POINTS)
+        node_of_frame = {fid: n for n, fid in enumerate(frames.keys())}
+        N = len(node_of_frame)
+        tids, off, ocam, ofeat, oimg = _pack_tracks(
+            images, frames, tracks, self.options_.min_num_view_per_track, True, node_of_frame
+        )
+        M = ocam.shape[0]
+        R = np.zeros((N, 3, 3))
+        cen = np.zeros((N, 3))
+        for fid, n in node_of_frame.items():
+            rw = frames[fid].rig_from_world
+            R[n] = so3.quat_to_rotmat(np.asarray(rw.rotation, dtype=np.float64))
+            cen[n] = -R[n].T @ np.asarray(rw.translation, dtype=np.float64)  # CenterFromPose (rigid3d.cc:65-67)
+        odir = np.zeros((M, 3))
+        ocal = np.ones(M, dtype=np.uint8)
+        keep = np.ones(M, dtype=bool)
+        for k in range(M):
+            im = images[oimg[k]]
+            ray = im.features_undist[ofeat[k]]
+            if np.isnan(ray).any():  # gp.cc:286-292
+                keep[k] = False
+                continue
+            odir[k] = R[ocam[k]].T @ ray
+            ocal[k] = 1 if cameras[im.camera_id].has_prior_focal_length else 0
+        if not keep.all():
+            cnt = np.add.reduceat(keep.astype(np.int64), off[:-1]) if M else np.zeros(0, dtype=np.int64)
+            cnt[np.diff(off) == 0] = 0
+            off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+            ocam, odir, ocal = ocam[keep], odir[keep], ocal[keep]
+        xyz = np.array([tracks[t].xyz for t in tids], dtype=np.float64).reshape(-1, 3)
+        prob = GpProblem(
+            num_cams=N, num_pts=len(tids), pt_offset=off, obs_cam=ocam, obs_dir=odir,
+            obs_calibrated=ocal, cam_center=cen, pt_xyz=xyz,
+        )
+        rc, cen, xyz, self.report = gp_solve(prob, self.options_, self.ctx)
+        # ConvertResults (gp.cc:562-572): t = -R c for every frame
+        for fid, n in node_of_frame.items():
+            frames[fid].rig_from_world.translation = -(R[n] @ cen[n])
+        for t, x in zip(tids, xyz):
+            tracks[t].xyz = x
+            if self.options_.optimize_points and self.options_.generate_random_points:
+                tracks[t].is_initialized = True
+        return rc == 0
+
+
+class BundleAdjuster:
+    """BundleAdjuster (bundle_adjustment.h:38-82), trivial rigs."""
+
+    def __init__(self, options: BundleAdjusterOptions, ctx=None):
+        self.options_ = options
+        self.ctx = ctx
+        self.report = None
+
+    def GetOptions(self) -> BundleAdjusterOptions:
+        return self.options_
+
+    def Solve(self, rigs, cameras, frames, images, tracks) -> bool:
+        if not images or not tracks:
+            return False  # ba.cc:17-24
+        node_of_frame = {fid: n for n, fid in enumerate(frames.keys())}
+        N = len(node_of_frame)
+        # BA does not re-check registration (ba.cc:124-127)
+        tids, off, ocam, ofeat, oimg = _pack_tracks(
+            images, frames, tracks, self.options_.min_num_view_per_track, False, node_of_frame
+        )
+        M = ocam.shape[0]
+        intr_of_cam = {cid: k for k, cid in enumerate(cameras.keys())}
+        K = len(intr_of_cam)
+        cam_intr = np.zeros(N, dtype=np.int32)
+        for im in images.values():
+            if im.frame_id in node_of_frame:
+                cam_intr[node_of_frame[im.frame_id]] = intr_of_cam[im.camera_id]
+        oxy = np.zeros((M, 2))
+        for k in range(M):
+            oxy[k] = images[oimg[k]].features[ofeat[k]]
+        q = np.zeros((N, 4))
+        t = np.zeros((N, 3))
+        for fid, n in node_of_frame.items():
+            q[n] = frames[fid].rig_from_world.rotation
+            t[n] = frames[fid].rig_from_world.translation
+        model = np.zeros(K, dtype=np.int32)
+        params = np.zeros((K, CAMERA_MAX_PARAMS))
+        for cid, k in intr_of_cam.items():
+            model[k] = cameras[cid].model_id
+            params[k, : len(cameras[cid].params)] = cameras[cid].params
+        xyz = np.array([tracks[tid].xyz for tid in tids], dtype=np.float64).reshape(-1, 3)
+        # first frame that owns a residual is the constant one (ba.cc:253-269)
+        seen = set(ocam.tolist())
+        fixed = next((n for n in range(N) if n in seen), -1)
+        prob = BaProblem(
+            num_cams=N, num_pts=len(tids), num_intr=K, pt_offset=off, obs_cam=ocam, obs_xy=oxy,
+            cam_intr=cam_intr, cam_q=q, cam_t=t, pt_xyz=xyz, intr_model=model, intr_params=params,
+            fixed_cam=fixed,
+        )
+        rc, q, t, xyz, params, self.report = ba_solve(prob, self.options_, self.ctx)
+        for fid, n in node_of_frame.items():
+            frames[fid].rig_from_world.rotation = q[n]
+            frames[fid].rig_from_world.translation = t[n]
+        for tid, x in zip(tids, xyz):
+            tracks[tid].xyz = x
+        for cid, k in intr_of_cam.items():
+            cameras[cid].params = params[k, : len(cameras[cid].params)].copy()
+        return rc == 0

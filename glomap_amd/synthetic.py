@@ -1,0 +1,297 @@
+"""Synthetic view graphs / track sets with ground truth.
+
+The reference's own tests build their fixtures with ``colmap::SynthesizeDataset``
+(glomap/controllers/global_mapper_test.cc:56-64, rotation_averager_test.cc:131-141), which is
+un-vendored; this module is the stand-in generator.  Pure numpy, deterministic for a given seed.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import so3
+from .flat import (
+    CAMERA_SIMPLE_RADIAL,
+    CAMERA_MAX_PARAMS,
+    BaProblem,
+    GpProblem,
+    RaProblem,
+)
+
+
+# --------------------------------------------------------------------------------------------
+# Rotation averaging (C2)
+# --------------------------------------------------------------------------------------------
+def make_ring_view_graph(
+    num_cams: int = 1000,
+    num_succ: int = 50,
+    noise_deg: float = 1.0,
+    outlier_ratio: float = 0.05,
+    seed: int = 0,
+    init: str = "identity",
+) -> RaProblem:
+    """Ring view graph: camera i is linked to its ``num_succ`` successors (mod N).
+
+    GT rotation i = Exp(U(-0.2,0.2)^3) * RotY(2*pi*i/N);  R_ij = R_j R_i^T Exp(n),
+    n ~ N(0, noise^2 I); ``outlier_ratio`` of the edges get a uniformly random rotation.
+    """
+    rng = np.random.default_rng(seed)
+    N = num_cams
+    yaw = 2 * np.pi * np.arange(N) / N
+    aa_y = np.zeros((N, 3))
+    aa_y[:, 1] = yaw
+    R_gt = so3.aa_to_rotmat(rng.uniform(-0.2, 0.2, (N, 3))) @ so3.aa_to_rotmat(aa_y)
+
+    ii = np.repeat(np.arange(N), num_succ)
+    jj = (ii + np.tile(np.arange(1, num_succ + 1), N)) % N
+    # COLMAP pair ids order the two images (image_id1 < image_id2); keep that invariant.
+    lo = np.minimum(ii, jj)
+    hi = np.maximum(ii, jj)
+    # drop duplicates that appear when 2*num_succ >= N
+    key = lo.astype(np.int64) * N + hi
+    _, uniq = np.unique(key, return_index=True)
+    uniq.sort()
+    lo, hi = lo[uniq], hi[uniq]
+    E = lo.shape[0]
+
+    noise = so3.aa_to_rotmat(rng.normal(0.0, np.radians(noise_deg), (E, 3)))
+    R_rel = R_gt[hi] @ np.transpose(R_gt[lo], (0, 2, 1)) @ noise
+    outlier = rng.random(E) < outlier_ratio
+    n_out = int(outlier.sum())
+    if n_out:
+        q_rand = rng.normal(size=(n_out, 4))
+        q_rand /= np.linalg.norm(q_rand, axis=1, keepdims=True)
+        R_rel[outlier] = so3.quat_to_rotmat(q_rand)
+    edge_q = so3.rotmat_to_quat(R_rel)
+    ninl = rng.integers(30, 501, E).astype(np.int32)
+
+    if init == "identity":
+        aa0 = np.zeros((N, 3))
+    elif init == "gt_noisy":
+        aa0 = so3.quat_to_aa(
+            so3.rotmat_to_quat(R_gt @ so3.aa_to_rotmat(rng.normal(0, np.radians(5.0), (N, 3))))
+        )
+    else:
+        raise ValueError(init)
+    return RaProblem(
+        num_nodes=N,
+        edge_i=lo.astype(np.int32),
+        edge_j=hi.astype(np.int32),
+        edge_q=edge_q,
+        edge_weight=np.ones(E),
+        edge_ninl=ninl,
+        node_aa0=aa0,
+        fixed_node=0,
+        gt_R=R_gt,
+        outlier=outlier,
+    )
+
+
+# --------------------------------------------------------------------------------------------
+# Shared camera / track geometry for C3 / C4
+# --------------------------------------------------------------------------------------------
+def _ring_cameras(rng, N, radius, jitter_deg=5.0):
+    """Cameras on a ring of ``radius`` in the x-z plane looking at the origin (+z optical axis)."""
+    phi = 2 * np.pi * np.arange(N) / N
+    centers = np.stack([radius * np.cos(phi), rng.normal(0, 0.02 * radius, N), radius * np.sin(phi)], 1)
+    zc = -centers / np.linalg.norm(centers, axis=1, keepdims=True)  # optical axis in world
+    up = np.tile(np.array([0.0, 1.0, 0.0]), (N, 1))
+    xc = np.cross(up, zc)
+    xc /= np.linalg.norm(xc, axis=1, keepdims=True)
+    yc = np.cross(zc, xc)
+    R_cw = np.stack([xc, yc, zc], axis=1)  # rows = camera axes in world => cam_from_world
+    R_cw = so3.aa_to_rotmat(rng.normal(0, np.radians(jitter_deg), (N, 3))) @ R_cw
+    return centers, R_cw
+
+
+def _ball_points(rng, P, radius):
+    d = rng.normal(size=(P, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    r = radius * rng.random(P) ** (1.0 / 3.0)
+    return d * r[:, None]
+
+
+def _sample_tracks(rng, centers, R_cw, X, mean_extra, min_len=3, max_len=100, half_fov_deg=30.0, ncand=None):
+    """Pick, per point, L = min(min_len + Poisson(mean_extra), max_len) distinct cameras that see it
+    inside the field of view.  Returns CSR (pt_offset, obs_cam) in track-major order; points that
+    end up with fewer than ``min_len`` views keep what they have (the estimators skip them,
+    reference gp.cc:258 / ba.cc:122)."""
+    P = X.shape[0]
+    N = centers.shape[0]
+    L = np.minimum(min_len + rng.poisson(mean_extra, P), min(max_len, N))
+    if ncand is None:
+        ncand = int(min(N, max(16, 3 * int(L.max()))))
+    cand = rng.integers(0, N, (P, ncand))
+    cand.sort(axis=1)
+    dup = np.zeros_like(cand, dtype=bool)
+    dup[:, 1:] = cand[:, 1:] == cand[:, :-1]
+    d = X[:, None, :] - centers[cand]  # [P,ncand,3]
+    depth = np.einsum("pkj,pkj->pk", d, R_cw[cand][:, :, 2, :])
+    nrm = np.linalg.norm(d, axis=2)
+    vis = (depth > np.cos(np.radians(half_fov_deg)) * nrm) & ~dup
+    # random order among the visible candidates, invisible ones last
+    score = rng.random((P, ncand)) + (~vis) * 10.0
+    order = np.argsort(score, axis=1)
+    cand = np.take_along_axis(cand, order, axis=1)
+    vis = np.take_along_axis(vis, order, axis=1)
+    take = (np.arange(ncand)[None, :] < L[:, None]) & vis
+    counts = take.sum(axis=1)
+    pt_offset = np.zeros(P + 1, dtype=np.int64)
+    np.cumsum(counts, out=pt_offset[1:])
+    obs_cam = cand[take].astype(np.int32)  # row-major boolean indexing == track-major
+    return pt_offset, obs_cam
+
+
+def make_gp_problem(
+    num_cams: int = 5000,
+    num_pts: int = 500_000,
+    mean_extra: float = 3.0,
+    dir_noise: float = 1e-3,
+    outlier_ratio: float = 0.02,
+    uncalibrated_ratio: float = 0.0,
+    seed: int = 0,
+) -> GpProblem:
+    """C3-style global positioning problem (cameras on a radius-50 ring, points in a radius-30 ball)."""
+    rng = np.random.default_rng(seed)
+    centers, R_cw = _ring_cameras(rng, num_cams, 50.0)
+    X = _ball_points(rng, num_pts, 30.0)
+    pt_offset, obs_cam = _sample_tracks(rng, centers, R_cw, X, mean_extra)
+    M = obs_cam.shape[0]
+    obs_pt = np.repeat(np.arange(num_pts), np.diff(pt_offset))
+    d = X[obs_pt] - centers[obs_cam]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    # tangent noise, then renormalise (features_undist are unit rays, image_undistorter.cc:33-38)
+    n = rng.normal(0, dir_noise, (M, 3))
+    n -= np.einsum("mj,mj->m", n, d)[:, None] * d
+    d = d + n
+    out = rng.random(M) < outlier_ratio
+    n_out = int(out.sum())
+    if n_out:
+        r = rng.normal(size=(n_out, 3))
+        d[out] = r
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    calibrated = (rng.random(num_cams) >= uncalibrated_ratio).astype(np.uint8)
+    return GpProblem(
+        num_cams=num_cams,
+        num_pts=num_pts,
+        pt_offset=pt_offset,
+        obs_cam=obs_cam,
+        obs_dir=np.ascontiguousarray(d),
+        obs_calibrated=calibrated[obs_cam],
+        cam_center=np.zeros((num_cams, 3)),
+        pt_xyz=np.zeros((num_pts, 3)),
+        cam_R=R_cw,
+        gt_center=centers,
+        gt_xyz=X,
+    )
+
+
+def project_simple_radial(params, xc):
+    f, cx, cy, k = params[..., 0], params[..., 1], params[..., 2], params[..., 3]
+    u = xc[..., 0] / xc[..., 2]
+    v = xc[..., 1] / xc[..., 2]
+    r2 = u * u + v * v
+    rad = 1.0 + k * r2
+    return np.stack([f * u * rad + cx, f * v * rad + cy], axis=-1)
+
+
+def make_ba_problem(
+    num_cams: int = 10_000,
+    num_pts: int = 1_000_000,
+    mean_extra: float = 2.0,
+    pixel_noise: float = 0.5,
+    outlier_ratio: float = 0.01,
+    shared_intrinsics: bool = False,
+    rot_noise_deg: float = 0.5,
+    pos_noise: float = 0.01,
+    depth_noise: float = 0.01,
+    intr_noise: float = 0.0,
+    seed: int = 0,
+) -> BaProblem:
+    """C4-style bundle-adjustment problem: SIMPLE_RADIAL (f=1200,cx=640,cy=480,k=0.02), state =
+    ground truth perturbed by rotation / position / depth noise."""
+    rng = np.random.default_rng(seed)
+    N, P = num_cams, num_pts
+    radius = 50.0
+    centers, R_cw = _ring_cameras(rng, N, radius)
+    X = _ball_points(rng, P, 30.0)
+    pt_offset, obs_cam = _sample_tracks(rng, centers, R_cw, X, mean_extra, half_fov_deg=25.0)
+    M = obs_cam.shape[0]
+    obs_pt = np.repeat(np.arange(P), np.diff(pt_offset))
+    t_gt = -np.einsum("nij,nj->ni", R_cw, centers)
+    K = 1 if shared_intrinsics else N
+    intr_gt = np.zeros((K, CAMERA_MAX_PARAMS))
+    intr_gt[:, :4] = np.array([1200.0, 640.0, 480.0, 0.02])
+    cam_intr = np.zeros(N, dtype=np.int32) if shared_intrinsics else np.arange(N, dtype=np.int32)
+
+    xc = np.einsum("mij,mj->mi", R_cw[obs_cam], X[obs_pt]) + t_gt[obs_cam]
+    xy = project_simple_radial(intr_gt[cam_intr[obs_cam]], xc)
+    xy += rng.normal(0, pixel_noise, (M, 2))
+    out = rng.random(M) < outlier_ratio
+    n_out = int(out.sum())
+    if n_out:
+        xy[out] = np.stack([rng.uniform(0, 1280, n_out), rng.uniform(0, 960, n_out)], 1)
+
+    # perturbed start
+    R0 = so3.aa_to_rotmat(rng.normal(0, np.radians(rot_noise_deg), (N, 3))) @ R_cw
+    c0 = centers + rng.normal(0, pos_noise * radius, (N, 3))
+    t0 = -np.einsum("nij,nj->ni", R0, c0)
+    X0 = X * (1.0 + rng.normal(0, depth_noise, (P, 1))) + rng.normal(0, depth_noise * 1.0, (P, 3))
+    intr0 = intr_gt.copy()
+    if intr_noise > 0:
+        intr0[:, 0] *= 1.0 + rng.normal(0, intr_noise, K)
+    return BaProblem(
+        num_cams=N,
+        num_pts=P,
+        num_intr=K,
+        pt_offset=pt_offset,
+        obs_cam=obs_cam,
+        obs_xy=np.ascontiguousarray(xy),
+        cam_intr=cam_intr,
+        cam_q=so3.rotmat_to_quat(R0),
+        cam_t=t0,
+        pt_xyz=X0,
+        intr_model=np.full(K, CAMERA_SIMPLE_RADIAL, dtype=np.int32),
+        intr_params=intr0,
+        fixed_cam=0,
+        gt_q=so3.rotmat_to_quat(R_cw),
+        gt_t=t_gt,
+        gt_xyz=X,
+        gt_intr=intr_gt,
+    )
+
+
+# --------------------------------------------------------------------------------------------
+# Gauge-free comparisons (reference: rotation_averager_test.cc:85-106, global_mapper_test.cc:26-38)
+# --------------------------------------------------------------------------------------------
+def align_rotations(R_est: np.ndarray, R_ref: np.ndarray) -> np.ndarray:
+    """Best global right-rotation G (3x3) such that R_est @ G ~= R_ref (chordal mean)."""
+    Mx = np.einsum("nji,njk->ik", R_est, R_ref)
+    U, _, Vt = np.linalg.svd(Mx)
+    D = np.diag([1.0, 1.0, np.sign(np.linalg.det(U @ Vt))])
+    return U @ D @ Vt
+
+
+def rotation_errors_deg(R_est: np.ndarray, R_ref: np.ndarray) -> np.ndarray:
+    G = align_rotations(R_est, R_ref)
+    return so3.rotation_angle_deg(R_est @ G, R_ref)
+
+
+def align_sim3(src: np.ndarray, dst: np.ndarray):
+    """Umeyama similarity: returns (s, R, t) minimising |s R src + t - dst|."""
+    mu_s, mu_d = src.mean(0), dst.mean(0)
+    a, b = src - mu_s, dst - mu_d
+    H = a.T @ b / src.shape[0]
+    U, S, Vt = np.linalg.svd(H)
+    D = np.diag([1.0, 1.0, np.sign(np.linalg.det(Vt.T @ U.T))])
+    R = Vt.T @ D @ U.T
+    s = np.trace(np.diag(S) @ D) / (a * a).sum() * src.shape[0]
+    t = mu_d - s * R @ mu_s
+    return s, R, t
+
+
+def center_errors_after_sim3(est: np.ndarray, ref: np.ndarray) -> np.ndarray:
+    """Per-camera centre error after Sim(3) alignment, relative to the extent of ``ref``."""
+    s, R, t = align_sim3(est, ref)
+    al = (s * (R @ est.T)).T + t
+    extent = np.linalg.norm(ref - ref.mean(0), axis=1).max()
+    return np.linalg.norm(al - ref, axis=1) / extent

@@ -1,0 +1,275 @@
+/* gsfm.h — C ABI of libgsfm: MI355X (gfx950) implementation of GLOMAP's estimator hot path.
+ *
+ * Each entry point replaces one C++ estimator call of the reference (colmap/glomap v1.1.0):
+ *
+ *   gsfm_ra_solve   <->  RotationEstimator::EstimateRotations   glomap/estimators/global_rotation_averaging.h:84-87
+ *                        (called from SolveRotationAveraging, glomap/controllers/rotation_averager.cc:58,165,180,193)
+ *   gsfm_gp_solve   <->  GlobalPositioner::Solve                glomap/estimators/global_positioning.h:63-68
+ *                        (called from GlobalMapper::Solve, glomap/controllers/global_mapper.cc:160)
+ *   gsfm_ba_solve   <->  BundleAdjuster::Solve                  glomap/estimators/bundle_adjustment.h:45-49
+ *                        (called from glomap/controllers/global_mapper.cc:209,221,302,315)
+ *
+ * The reference walks pointer-linked std::unordered_map containers; at this boundary they are
+ * flattened to structure-of-arrays with dense int32 indices.  The header-only adapter
+ * include/gsfm_glomap_adapter.hpp re-creates the three reference classes on top of these calls.
+ *
+ * Conventions
+ *   - plain C, no exceptions, no retained pointers after return; every function returns a
+ *     gsfm_status (0 = ok, < 0 = error) and fills an optional gsfm_report.
+ *   - `mem` says where the problem arrays (and the in/out state arrays) live:
+ *     GSFM_MEM_HOST (the drop-in case: the library does H2D at entry, D2H at exit) or
+ *     GSFM_MEM_DEVICE (arrays already resident in HBM of the ctx's device; used by bench.py).
+ *   - all floating point is IEEE double, as in the reference.
+ *   - one ctx drives one GPU from one host thread (thread-compatible, not re-entrant per ctx).
+ *     Multi-GPU = one process (ctx) per GPU; the track / edge shards are combined with RCCL
+ *     all-reduce on the reduced-system vectors (gsfm_comm_*).
+ */
+#ifndef GSFM_H_
+#define GSFM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSFM_VERSION 100
+
+typedef enum {
+  GSFM_OK = 0,
+  GSFM_ERR_INVALID_ARGUMENT = -1,
+  GSFM_ERR_HIP = -2,           /* a HIP runtime call failed; report.hip_error holds hipError_t */
+  GSFM_ERR_NO_DEVICE = -3,
+  GSFM_ERR_NUMERICAL = -4,     /* NaN step / NaN weight: reference returns false (gra.cc:508-512,590-593) */
+  GSFM_ERR_EMPTY_PROBLEM = -5, /* reference returns false (gp.cc:37-50, ba.cc:17-24) */
+  GSFM_ERR_NOT_USABLE = -6,    /* !summary.IsSolutionUsable() (gp.cc:92, ba.cc:105) */
+  GSFM_ERR_UNSUPPORTED = -7,
+  GSFM_ERR_COMM = -8           /* RCCL failure */
+} gsfm_status;
+
+typedef enum { GSFM_MEM_HOST = 0, GSFM_MEM_DEVICE = 1 } gsfm_mem;
+
+/* Termination reasons (mirrors ceres::TerminationType where a Ceres solve is replaced). */
+typedef enum {
+  GSFM_TERM_CONVERGENCE = 0,
+  GSFM_TERM_NO_CONVERGENCE = 1, /* iteration cap reached; solution still usable */
+  GSFM_TERM_FAILURE = 2
+} gsfm_termination;
+
+typedef struct gsfm_report {
+  int32_t iterations;        /* RA: L1 outer + IRLS iterations; GP/BA: LM iterations (accepted + rejected) */
+  int32_t iterations_l1;     /* RA only */
+  int32_t iterations_irls;   /* RA only */
+  int32_t successful_steps;  /* GP/BA: accepted LM steps */
+  int64_t linear_iterations; /* total PCG iterations */
+  double initial_cost;
+  double final_cost;
+  int32_t termination;       /* gsfm_termination */
+  int32_t hip_error;
+  double seconds_total;      /* wall time inside the call */
+  double seconds_solve;      /* device time of the solve proper (H2D/D2H excluded) */
+  double last_step_norm;     /* RA: mean |delta| of the last iteration (gra.cc:758-772) */
+} gsfm_report;
+
+typedef struct gsfm_ctx gsfm_ctx;
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* device_id = -1 -> current device.  Replaces colmap::SetBestCudaDevice(gpu_indices[0])
+ * (gp.cc:536-541, ba.cc:79-84). */
+int gsfm_ctx_create(int device_id, gsfm_ctx** out);
+void gsfm_ctx_destroy(gsfm_ctx* ctx);
+int gsfm_version(void);
+const char* gsfm_status_string(int status);
+/* HIP stream (hipStream_t) all work of this ctx is enqueued on; callers that time the solve with
+ * HIP events must record on this stream. */
+void* gsfm_ctx_stream(gsfm_ctx* ctx);
+/* Device name + gcnArchName, for reports. Returns GSFM_OK and writes a NUL-terminated string. */
+int gsfm_ctx_device_name(gsfm_ctx* ctx, char* buf, size_t buflen);
+
+/* ---- per-kernel timing (HIP events on the ctx stream) -------------------------------------
+ * When enabled, every launch of the dominant kernel of each solver is bracketed by a HIP event
+ * pair on the ctx stream; bench.py uses this for the roofline line.  Off by default (the event
+ * records cost host time), never needed for correctness. */
+enum {
+  GSFM_KERNEL_RA_LAPLACIAN = 0, /* k_pcg_dir_fused: weighted-Laplacian SpMV (3 RHS) + CG direction update */
+  GSFM_KERNEL_GP_SCHUR = 1,     /* k_gp_schur_matvec: implicit Schur-complement product, BATA blocks */
+  GSFM_KERNEL_BA_SCHUR = 2,     /* k_ba_schur_matvec: implicit Schur-complement product, reprojection blocks */
+  GSFM_KERNEL_COUNT = 3
+};
+int gsfm_ctx_profile_enable(gsfm_ctx* ctx, int enable);
+/* Reads and resets the accumulated launch count / total milliseconds of one kernel id. */
+int gsfm_ctx_profile_read(gsfm_ctx* ctx, int kernel_id, int64_t* launches, double* total_ms);
+
+/* ---- multi-GPU (one process per GPU, RCCL over xGMI) ------------------------------------- */
+#define GSFM_COMM_ID_BYTES 128
+/* Rank 0 calls gsfm_comm_unique_id and broadcasts the bytes out of band (e.g. through
+ * torch.distributed); every rank then calls gsfm_comm_init.  After that every gsfm_*_solve on
+ * this ctx treats its problem as ONE SHARD (a subset of edges / tracks over the full, replicated
+ * node / camera arrays) and all-reduces the reduced-system vectors. */
+int gsfm_comm_unique_id(char id[GSFM_COMM_ID_BYTES]);
+int gsfm_comm_init(gsfm_ctx* ctx, const char id[GSFM_COMM_ID_BYTES], int rank, int world_size);
+int gsfm_comm_destroy(gsfm_ctx* ctx);
+
+/* ---- rotation averaging ------------------------------------------------------------------- */
+/* Options: mirror of RotationEstimatorOptions, global_rotation_averaging.h:39-75. */
+typedef struct gsfm_ra_options {
+  int32_t max_num_l1_iterations;           /* 5 */
+  double l1_step_convergence_threshold;    /* 1e-3 */
+  int32_t max_num_irls_iterations;         /* 100 */
+  double irls_step_convergence_threshold;  /* 1e-3 */
+  double irls_loss_parameter_sigma;        /* 5.0 degrees */
+  int32_t weight_type;                     /* 0 = GEMAN_MCCLURE, 1 = HALF_NORM */
+  int32_t skip_initialization;             /* 0: maximum-spanning-tree init (gra.cc:87-138) */
+  int32_t use_weight;                      /* 0 */
+  int32_t use_gravity;                     /* must be 0 (1-DoF path not implemented -> GSFM_ERR_UNSUPPORTED) */
+  /* colmap::LeastAbsoluteDeviationSolver::Options as set at gra.cc:483-486 */
+  int32_t l1_admm_max_num_iterations;      /* 10 */
+  double l1_admm_rho;                      /* 1.0 */
+  double l1_admm_alpha;                    /* 1.0 */
+  double l1_admm_absolute_tolerance;       /* 1e-4 */
+  double l1_admm_relative_tolerance;       /* 1e-2 */
+  /* linear solver replacing CHOLMOD (gra.cc:547-611): Jacobi-PCG on the weighted Laplacian */
+  double pcg_relative_tolerance;           /* 1e-10: |r|_2 <= tol * |b|_2 per right-hand side */
+  int32_t pcg_max_iterations;              /* 2000 */
+} gsfm_ra_options;
+
+void gsfm_ra_options_default(gsfm_ra_options* opt);
+
+/* View graph, valid edges only (ImagePair::is_valid, image_pair.h:32), largest connected
+ * component already kept (rotation_averager.cc:13).  Node = registered frame with trivial rig. */
+typedef struct gsfm_ra_problem {
+  int32_t mem;              /* gsfm_mem for every pointer below and for rot_aa_inout */
+  int32_t num_nodes;        /* N */
+  int64_t num_edges;        /* E (this rank's shard when a comm is attached) */
+  const int32_t* edge_i;    /* [E] node of image_id1 */
+  const int32_t* edge_j;    /* [E] node of image_id2 */
+  const double* edge_q;     /* [E][4] (w,x,y,z) cam2_from_cam1.rotation: x_2 = R x_1 */
+  const double* edge_weight;/* [E] ImagePair::weight, may be NULL unless use_weight */
+  const int32_t* edge_ninl; /* [E] inliers.size() (MST weight, tree.cc:99,124); may be NULL if skip_initialization */
+  int32_t fixed_node;       /* gauge node (reference: first registered frame in map order, gra.cc:248-257) */
+} gsfm_ra_problem;
+
+/* rot_aa_inout: [N][3] angle-axis of rig_from_world; in = initial estimate, out = result
+ * (reference writes frame.RigFromWorld = (quat(Exp(r)), t = 0), gra.cc:774-816). */
+int gsfm_ra_solve(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_options* opt,
+                  double* rot_aa_inout, gsfm_report* report);
+
+/* Building blocks exposed for parity tests and roofline micro-benchmarks (same kernels the
+ * solver uses).  residual_out [E][3] = -Log(R_j^T R_rel R_i) (gra.cc:715-742), weight_out [E] =
+ * IRLS weight (gra.cc:583-588).  Either output may be NULL. */
+int gsfm_ra_residuals(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_options* opt,
+                      const double* rot_aa, double* residual_out, double* weight_out);
+/* y = (L_w (x) I3 + gauge) x for the IRLS-weighted Laplacian; x,y [N][3]; w [E] edge weights.
+ * `repeat` launches of the SpMV kernel (for timing); reports average kernel milliseconds. */
+int gsfm_ra_laplacian_apply(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const double* w,
+                            const double* x, double* y, int repeat, double* avg_kernel_ms);
+
+/* ---- global positioning ------------------------------------------------------------------ */
+/* Options: mirror of GlobalPositionerOptions (global_positioning.h:9-54) + the Ceres options the
+ * reference sets (optimization_base.h:18-23) + the Ceres defaults it relies on. */
+typedef struct gsfm_lm_options {
+  int32_t max_num_iterations;        /* GP 100, BA 200 */
+  double function_tolerance;         /* 1e-5 */
+  double gradient_tolerance;         /* 1e-10 */
+  double parameter_tolerance;        /* 1e-8 */
+  double initial_trust_region_radius;/* 1e4 */
+  double max_trust_region_radius;    /* 1e16 */
+  double min_trust_region_radius;    /* 1e-32 */
+  double min_relative_decrease;      /* 1e-3 */
+  double min_lm_diagonal;            /* 1e-6 */
+  double max_lm_diagonal;            /* 1e32 */
+  int32_t jacobi_scaling;            /* 1 */
+  int32_t max_num_consecutive_invalid_steps; /* 5 */
+  /* linear solver replacing SPARSE_SCHUR + sparse Cholesky: implicit-Schur block-Jacobi PCG */
+  double pcg_relative_tolerance;     /* 1e-8: |r|_2 <= tol * |b|_2 on the reduced camera system */
+  int32_t pcg_max_iterations;        /* 1000 */
+} gsfm_lm_options;
+
+typedef struct gsfm_gp_options {
+  gsfm_lm_options lm;
+  double thres_loss_function;     /* Huber 0.1 (global_positioning.h:47-49) */
+  int32_t generate_random_positions; /* 1 */
+  int32_t generate_random_points;    /* 1 */
+  int32_t generate_scales;           /* 1: scales start at 1 (gp.cc:298-305) */
+  int32_t optimize_positions;        /* 1 */
+  int32_t optimize_points;           /* 1 */
+  int32_t optimize_scales;           /* 1 */
+  int32_t min_num_view_per_track;    /* 3 */
+  uint32_t seed;                     /* 1 */
+  int32_t constraint_type;           /* 0 = ONLY_POINTS (the only mode `mapper` accepts, gm.cc:145-149) */
+} gsfm_gp_options;
+
+void gsfm_gp_options_default(gsfm_gp_options* opt);
+
+/* Tracks (ONLY_POINTS, trivial rigs). Observations are track-major: track p owns observations
+ * [pt_offset[p], pt_offset[p+1]).  Only observations of registered images with finite rays are
+ * passed (gp.cc:279-292); tracks shorter than min_num_view_per_track are skipped by the library
+ * (gp.cc:258) and their xyz left untouched. */
+typedef struct gsfm_gp_problem {
+  int32_t mem;
+  int32_t num_cams;             /* N frames */
+  int64_t num_pts;              /* P tracks (this rank's shard when a comm is attached) */
+  int64_t num_obs;              /* M */
+  const int64_t* pt_offset;     /* [P+1] */
+  const int32_t* obs_cam;       /* [M] frame index */
+  const double* obs_dir;        /* [M][3] R_cw^T * features_undist (gp.cc:294-296) */
+  const uint8_t* obs_calibrated;/* [M] cameras[..].has_prior_focal_length (gp.cc:313-316); NULL = all 1 */
+} gsfm_gp_problem;
+
+/* cam_center_inout [N][3]: camera centres c = -R^T t (in: used when !generate_random_positions;
+ * out: result; the adapter converts back t = -R c, gp.cc:562-572).
+ * pt_xyz_inout [P][3]: in: used when !generate_random_points; out: result. */
+int gsfm_gp_solve(gsfm_ctx* ctx, const gsfm_gp_problem* prob, const gsfm_gp_options* opt,
+                  double* cam_center_inout, double* pt_xyz_inout, gsfm_report* report);
+
+/* ---- bundle adjustment --------------------------------------------------------------------- */
+/* COLMAP camera model ids (colmap/sensor/models.h) of the supported models. */
+enum {
+  GSFM_CAMERA_SIMPLE_PINHOLE = 0, /* f, cx, cy */
+  GSFM_CAMERA_PINHOLE = 1,        /* fx, fy, cx, cy */
+  GSFM_CAMERA_SIMPLE_RADIAL = 2,  /* f, cx, cy, k */
+  GSFM_CAMERA_RADIAL = 3,         /* f, cx, cy, k1, k2 */
+  GSFM_CAMERA_OPENCV = 4          /* fx, fy, cx, cy, k1, k2, p1, p2 */
+};
+#define GSFM_CAMERA_MAX_PARAMS 8
+
+/* Options: mirror of BundleAdjusterOptions (bundle_adjustment.h:12-37). */
+typedef struct gsfm_ba_options {
+  gsfm_lm_options lm;
+  double thres_loss_function;        /* Huber 1.0 px */
+  int32_t optimize_rotations;        /* 1 */
+  int32_t optimize_translation;      /* 1 */
+  int32_t optimize_intrinsics;       /* 1 */
+  int32_t optimize_principal_point;  /* 0 */
+  int32_t optimize_points;           /* 1 */
+  int32_t min_num_view_per_track;    /* 3 */
+} gsfm_ba_options;
+
+void gsfm_ba_options_default(gsfm_ba_options* opt);
+
+typedef struct gsfm_ba_problem {
+  int32_t mem;
+  int32_t num_cams;           /* N frames (trivial rigs: one image per frame) */
+  int32_t num_intr;           /* K intrinsics blocks (colmap cameras) */
+  int32_t fixed_cam;          /* frame with constant q and t (ba.cc:261-266); -1 = none */
+  int64_t num_pts;            /* P */
+  int64_t num_obs;            /* M */
+  const int64_t* pt_offset;   /* [P+1] track-major */
+  const int32_t* obs_cam;     /* [M] */
+  const double* obs_xy;       /* [M][2] image.features[feat] (distorted pixels, ba.cc:139) */
+  const int32_t* cam_intr;    /* [N] intrinsics block of each frame's image (image.camera_id) */
+  const int32_t* intr_model;  /* [K] GSFM_CAMERA_* */
+} gsfm_ba_problem;
+
+/* cam_q_inout [N][4] (w,x,y,z), cam_t_inout [N][3], pt_xyz_inout [P][3],
+ * intr_params_inout [K][GSFM_CAMERA_MAX_PARAMS]: updated in place like the reference's parameter
+ * blocks (ba.cc:143-146). */
+int gsfm_ba_solve(gsfm_ctx* ctx, const gsfm_ba_problem* prob, const gsfm_ba_options* opt,
+                  double* cam_q_inout, double* cam_t_inout, double* pt_xyz_inout,
+                  double* intr_params_inout, gsfm_report* report);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSFM_H_ */

@@ -1,0 +1,277 @@
+"""ORACLE (test infrastructure only — never imported by the product path).
+
+CPU restatement (numpy/scipy, sparse direct solves) of the reference's rotation averaging,
+3-DoF path with trivial rigs — the path `glomap mapper` exercises (use_gravity = false,
+glomap/estimators/global_rotation_averaging.h:74).
+
+Follows, function by function:
+  maximum_spanning_tree_init : gra.cc:87-138, math/tree.cc:26-153
+  setup_linear_system        : gra.cc:141-477   (A rows: -I3 @ image_id1, +I3 @ image_id2; 3 gauge rows)
+  compute_residuals          : gra.cc:696-756
+  update_global_rotations    : gra.cc:627-644
+  average_step_size          : gra.cc:758-772
+  solve_l1_regression        : gra.cc:479-541 + colmap::LeastAbsoluteDeviationSolver
+                               (COLMAP @ b6b7b54e, src/colmap/optim/least_absolute_deviations.cc —
+                               un-vendored; restated from its published ADMM algorithm)
+  solve_irls                 : gra.cc:543-625
+  estimate_rotations         : gra.cc:40-85
+
+parity unpinned: the reference stores no numeric vectors for RA; its tests only pin ground-truth
+recovery tolerances on synthetic scenes (rotation_averager_test.cc:166-167, 309-310), which
+tests/test_oracle_ra.py reproduces with glomap_amd.synthetic.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from . import so3
+
+GEMAN_MCCLURE = 0
+HALF_NORM = 1
+
+
+@dataclass
+class RotationEstimatorOptions:
+    """Mirror of glomap/estimators/global_rotation_averaging.h:39-75."""
+
+    max_num_l1_iterations: int = 5
+    l1_step_convergence_threshold: float = 0.001
+    max_num_irls_iterations: int = 100
+    irls_step_convergence_threshold: float = 0.001
+    irls_loss_parameter_sigma: float = 5.0  # degrees
+    weight_type: int = GEMAN_MCCLURE
+    skip_initialization: bool = False
+    use_weight: bool = False
+    # colmap::LeastAbsoluteDeviationSolver::Options as set at gra.cc:483-486 (+ upstream defaults)
+    l1_admm_max_num_iterations: int = 10
+    l1_admm_rho: float = 1.0
+    l1_admm_alpha: float = 1.0
+    l1_admm_absolute_tolerance: float = 1e-4
+    l1_admm_relative_tolerance: float = 1e-2
+
+
+@dataclass
+class RaTrace:
+    l1_iterations: int = 0
+    irls_iterations: int = 0
+    l1_steps: list = field(default_factory=list)
+    irls_steps: list = field(default_factory=list)
+
+
+# ------------------------------------------------------------------------------------------
+def maximum_spanning_tree_init(num_nodes, edge_i, edge_j, edge_R, edge_ninl, aa0):
+    """Kruskal maximum spanning tree on #inliers (tree.cc:78-153), BFS from node 0, then
+    R_child = R_rel * R_parent or R_rel^T * R_parent (gra.cc:125-134).  The root is never
+    assigned in the reference loop (gra.cc:120 `continue`), so `cam_from_worlds[root]` is the
+    default-constructed Rigid3d, i.e. the IDENTITY rotation, whatever the comment there says.
+    Ties between equal inlier counts are broken by edge index (stable sort) — boost's order
+    among ties is unspecified, the product uses the same rule."""
+    E = edge_i.shape[0]
+    max_w = float(edge_ninl.max()) if E else 0.0
+    cost = max_w - edge_ninl.astype(np.float64)
+    order = np.argsort(cost, kind="stable")  # boost kruskal sorts by weight
+    parent = np.arange(num_nodes)
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+
+    adj = [[] for _ in range(num_nodes)]
+    for e in order:
+        a, b = int(edge_i[e]), int(edge_j[e])
+        ra, rb = find(a), find(b)
+        if ra != rb:
+            parent[ra] = rb
+            adj[a].append((b, int(e)))
+            adj[b].append((a, int(e)))
+    R = np.tile(np.eye(3), (num_nodes, 1, 1))
+    visited = np.zeros(num_nodes, dtype=bool)
+    visited[0] = True
+    queue = [0]
+    head = 0
+    while head < len(queue):
+        cur = queue[head]
+        head += 1
+        for nb, e in adj[cur]:
+            if visited[nb]:
+                continue
+            visited[nb] = True
+            if int(edge_i[e]) == nb:
+                # curr is image_id1: 1_R_w = 2_R_1^T * 2_R_w
+                R[nb] = edge_R[e].T @ R[cur]
+            else:
+                R[nb] = edge_R[e] @ R[cur]
+            queue.append(nb)
+    # ConvertRotationsFromImageToRig for trivial rigs stores the quaternion of the matrix
+    # (rotation_initializer.cc:7-125); SetupLinearSystem re-reads it as angle-axis (gra.cc:223-224).
+    aa = so3.log_rot(R)
+    # unreached nodes (other components) keep their input value
+    aa[~visited] = aa0[~visited]
+    return aa
+
+
+def setup_linear_system(num_nodes, edge_i, edge_j, fixed_node):
+    """A (3E+3) x 3N with -1 / +1 entries (gra.cc:396-421) and gauge rows (gra.cc:455-460)."""
+    E = edge_i.shape[0]
+    rows = np.arange(3 * E)
+    comp = rows % 3
+    e = rows // 3
+    r = np.concatenate([rows, rows, 3 * E + np.arange(3)])
+    c = np.concatenate([3 * edge_i[e] + comp, 3 * edge_j[e] + comp, 3 * fixed_node + np.arange(3)])
+    v = np.concatenate([-np.ones(3 * E), np.ones(3 * E), np.ones(3)])
+    return sp.csr_matrix((v, (r, c)), shape=(3 * E + 3, 3 * num_nodes))
+
+
+def compute_residuals(rot, edge_i, edge_j, edge_R, fixed_node, fixed_rot):
+    """b_e = -Log(R_j^T R_rel R_i) (gra.cc:741-742); gauge rows Log(R_fix0^T R_fix) (gra.cc:751-755)."""
+    Rn = so3.exp_aa(rot)
+    Ri = Rn[edge_i]
+    Rj = Rn[edge_j]
+    M = np.transpose(Rj, (0, 2, 1)) @ edge_R @ Ri
+    b = -so3.log_rot(M)
+    g = so3.log_rot(so3.exp_aa(fixed_rot).T @ Rn[fixed_node])
+    return np.concatenate([b.reshape(-1), g])
+
+
+def update_global_rotations(rot, step):
+    """r <- Log(Exp(r) * Exp(-delta)) (gra.cc:635-640)."""
+    return so3.log_rot(so3.exp_aa(rot) @ so3.exp_aa(-step))
+
+
+def average_step_size(step):
+    return float(np.linalg.norm(step, axis=1).sum() / step.shape[0])
+
+
+def _shrink(v, k):
+    return np.maximum(0.0, v - k) - np.maximum(0.0, -v - k)
+
+
+class LeastAbsoluteDeviationSolver:
+    """ADMM for min |A x - b|_1 (COLMAP's restatement of Theia's L1Solver; Boyd et al. §6.1)."""
+
+    def __init__(self, A, opt: RotationEstimatorOptions):
+        self.A = A.tocsr()
+        self.At = A.T.tocsr()
+        self.opt = opt
+        self.lu = spla.splu((self.At @ self.A).tocsc())  # LLT in the reference; SPD system
+
+    def solve(self, b):
+        A, At, o = self.A, self.At, self.opt
+        m, n = A.shape
+        z = np.zeros(m)
+        u = np.zeros(m)
+        x = np.zeros(n)
+        rhs_norm = np.linalg.norm(b)
+        primal_abs = np.sqrt(m) * o.l1_admm_absolute_tolerance
+        dual_abs = np.sqrt(n) * o.l1_admm_absolute_tolerance
+        for _ in range(o.l1_admm_max_num_iterations):
+            x = self.lu.solve(At @ (b + z - u))
+            Ax = A @ x
+            Ax_hat = o.l1_admm_alpha * Ax + (1.0 - o.l1_admm_alpha) * (z + b)
+            z_old = z
+            z = _shrink(Ax_hat - b + u, 1.0 / o.l1_admm_rho)
+            u = u + Ax_hat - z - b
+            r_norm = np.linalg.norm(Ax - z - b)
+            s_norm = np.linalg.norm(-o.l1_admm_rho * (At @ (z - z_old)))
+            max_norm = max(np.linalg.norm(Ax), np.linalg.norm(z), rhs_norm)
+            primal_eps = primal_abs + o.l1_admm_relative_tolerance * max_norm
+            dual_eps = dual_abs + o.l1_admm_relative_tolerance * np.linalg.norm(o.l1_admm_rho * (At @ u))
+            if r_norm < primal_eps and s_norm < dual_eps:
+                break
+        return x
+
+
+def estimate_rotations(
+    num_nodes,
+    edge_i,
+    edge_j,
+    edge_q,
+    edge_weight,
+    edge_ninl,
+    node_aa0,
+    fixed_node=0,
+    options: RotationEstimatorOptions | None = None,
+    trace: RaTrace | None = None,
+):
+    """Returns (ok, rot_aa[N,3])."""
+    opt = options or RotationEstimatorOptions()
+    edge_i = np.asarray(edge_i, dtype=np.int64)
+    edge_j = np.asarray(edge_j, dtype=np.int64)
+    edge_R = so3.quat_wxyz_to_rotmat(np.asarray(edge_q, dtype=np.float64))
+    E = edge_i.shape[0]
+    rot = np.array(node_aa0, dtype=np.float64, copy=True)
+    if not opt.skip_initialization:
+        rot = maximum_spanning_tree_init(num_nodes, edge_i, edge_j, edge_R, edge_ninl, rot)
+    # fixed camera keeps its initial (post-MST) rotation (gra.cc:248-257)
+    fixed_rot = rot[fixed_node].copy()
+
+    A = setup_linear_system(num_nodes, edge_i, edge_j, fixed_node)
+    if opt.use_weight:
+        ew = np.where(edge_weight >= 0, edge_weight, 1.0)  # gra.cc:417-420
+        weights = np.concatenate([np.repeat(ew, 3), np.ones(3)])
+    else:
+        weights = np.ones(3 * E + 3)
+
+    def residuals(r):
+        return compute_residuals(r, edge_i, edge_j, edge_R, fixed_node, fixed_rot)
+
+    # ---- L1 (gra.cc:479-541)
+    if opt.max_num_l1_iterations > 0:
+        WA = sp.diags(weights) @ A
+        l1 = LeastAbsoluteDeviationSolver(WA, opt)
+        last_norm = 0.0
+        curr_norm = 0.0
+        b = residuals(rot)
+        it = 0
+        for it in range(opt.max_num_l1_iterations):
+            last_norm = curr_norm
+            step = l1.solve(weights * b)
+            if np.isnan(step).any():
+                return False, rot
+            curr_norm = float(np.linalg.norm(step))
+            step3 = step.reshape(-1, 3)
+            rot = update_global_rotations(rot, step3)
+            b = residuals(rot)
+            avg = average_step_size(step3)
+            if trace is not None:
+                trace.l1_steps.append(avg)
+                trace.l1_iterations = it + 1
+            if avg < opt.l1_step_convergence_threshold or abs(last_norm - curr_norm) < so3.EPS:
+                break
+
+    # ---- IRLS (gra.cc:543-625)
+    if opt.max_num_irls_iterations > 0:
+        sigma = np.radians(opt.irls_loss_parameter_sigma)
+        At = A.T.tocsr()
+        b = residuals(rot)
+        w_irls = np.ones(3 * E + 3)
+        for it in range(opt.max_num_irls_iterations):
+            e2 = (b[: 3 * E].reshape(-1, 3) ** 2).sum(axis=1)
+            if opt.weight_type == GEMAN_MCCLURE:
+                tmp = e2 + sigma * sigma
+                w = sigma * sigma / (tmp * tmp)
+            else:
+                with np.errstate(divide="ignore"):
+                    w = np.power(e2, (0.5 - 2) / 2)
+            if np.isnan(w).any():
+                return False, rot
+            w_irls[: 3 * E] = np.repeat(w, 3)
+            at_weight = At @ sp.diags(w_irls * weights)
+            H = (at_weight @ A).tocsc()
+            step = spla.splu(H).solve(at_weight @ b)
+            step3 = step.reshape(-1, 3)
+            rot = update_global_rotations(rot, step3)
+            b = residuals(rot)
+            avg = average_step_size(step3)
+            if trace is not None:
+                trace.irls_steps.append(avg)
+                trace.irls_iterations = it + 1
+            if avg < opt.irls_step_convergence_threshold:
+                break
+    return True, rot
