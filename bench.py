@@ -10,7 +10,7 @@ A "step" is one full pass of the hot path over one batch of synthetic input:
   workload "gp"     global positioning on a C3-style track set         metric: track-obs/s
   workload "ba"     one bundle-adjustment solve on a C4-style problem  metric: track-obs/s per LM iteration
 
-Inputs are resident in HBM (torch tensors on the GPU) before the timed region starts.  With
+Inputs are resident in HBM (glomap_amd DeviceArrays) before the timed region starts.  With
 --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) the view graph / track set
 grows with N (weak scaling): every rank owns an equal shard of the edges / tracks, node and
 camera vectors are replicated and the reduced-system vectors are all-reduced over RCCL.
@@ -56,25 +56,28 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     build.build_lib(verbose=False)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    ctx = _lib.Context(local_rank)
+    # One HIP runtime per process: libgsfm's (ROCm, the one hipcc/rocprofv3 belong to).  PyTorch
+    # wheels bundle a second copy of the runtime, so torch is used for the control plane only
+    # (torch.distributed rendezvous / barrier / max-over-ranks on the gloo backend); device
+    # memory, streams and the RCCL communicator are libgsfm's own (gsfm_device_*, gsfm_comm_*).
+    # ctx.synchronize() below is the hipStreamSynchronize that torch.cuda.synchronize() would be.
+    ctx = _lib.Context(local_rank)  # raises GSFM_ERR_NO_DEVICE without an MI355X: no CPU fallback
+    dev = None
 
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("gloo")
         uid = [_lib.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(uid[0], rank, world)
 
     def barrier():
+        ctx.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        ctx.synchronize()
 
     if args.workload == "ra_c2":
         out = bench_ra(args, ctx, dev, rank, world, barrier, dist)
@@ -101,7 +104,7 @@ def timed_steps(step_fn, steps, warmup, barrier, dist, dev):
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
@@ -129,19 +132,19 @@ def bench_ra(args, ctx, dev, rank, world, barrier, dist):
     p = full
     pd = type(p)(
         num_nodes=p.num_nodes,
-        edge_i=torch.from_numpy(p.edge_i[lo:hi]).to(dev),
-        edge_j=torch.from_numpy(p.edge_j[lo:hi]).to(dev),
-        edge_q=torch.from_numpy(p.edge_q[lo:hi]).to(dev),
-        edge_weight=torch.from_numpy(p.edge_weight[lo:hi]).to(dev),
-        edge_ninl=torch.from_numpy(p.edge_ninl[lo:hi]).to(dev),
-        node_aa0=torch.from_numpy(p.node_aa0).to(dev),
+        edge_i=ctx.to_device(p.edge_i[lo:hi]),
+        edge_j=ctx.to_device(p.edge_j[lo:hi]),
+        edge_q=ctx.to_device(p.edge_q[lo:hi]),
+        edge_weight=ctx.to_device(p.edge_weight[lo:hi]),
+        edge_ninl=ctx.to_device(p.edge_ninl[lo:hi]),
+        node_aa0=ctx.to_device(p.node_aa0),
         fixed_node=0,
     )
     rot = pd.node_aa0.clone()
     last = {}
 
     def step():
-        rot.copy_(pd.node_aa0)
+        rot.copy_from(pd.node_aa0)
         rc, _, rep = estimators.ra_solve(pd, opt, ctx=ctx, rot_inout=rot)
         if rc != 0:
             raise RuntimeError(f"gsfm_ra_solve failed: {rc}")
@@ -178,7 +181,7 @@ def bench_ra(args, ctx, dev, rank, world, barrier, dist):
     # parity spot-check on the timed configuration: gauge-free ground-truth recovery
     from glomap_amd import so3 as _so3
 
-    err = synthetic.rotation_errors_deg(_so3.aa_to_rotmat(rot.cpu().numpy()), full.gt_R)
+    err = synthetic.rotation_errors_deg(_so3.aa_to_rotmat(rot.numpy()), full.gt_R)
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:

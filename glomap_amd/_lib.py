@@ -191,6 +191,15 @@ def load():
     lib.gsfm_ctx_stream.argtypes = [vp]
     lib.gsfm_ctx_device_name.restype = ip
     lib.gsfm_ctx_device_name.argtypes = [vp, C.c_char_p, C.c_size_t]
+    lib.gsfm_device_alloc.restype = ip
+    lib.gsfm_device_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    lib.gsfm_device_free.restype = ip
+    lib.gsfm_device_free.argtypes = [vp, vp]
+    for name in ("gsfm_memcpy_h2d", "gsfm_memcpy_d2h", "gsfm_memcpy_d2d"):
+        getattr(lib, name).restype = ip
+        getattr(lib, name).argtypes = [vp, vp, vp, C.c_size_t]
+    lib.gsfm_ctx_synchronize.restype = ip
+    lib.gsfm_ctx_synchronize.argtypes = [vp]
     lib.gsfm_ctx_profile_enable.restype = ip
     lib.gsfm_ctx_profile_enable.argtypes = [vp, ip]
     lib.gsfm_ctx_profile_read.restype = ip
@@ -224,15 +233,77 @@ def load():
 
 
 def ptr(a):
-    """Raw address of a numpy array (host) or torch tensor (device); None -> NULL."""
+    """Raw address of a numpy array (host) or DeviceArray (HBM); None -> NULL."""
     if a is None:
         return None
     if isinstance(a, np.ndarray):
         assert a.flags["C_CONTIGUOUS"], "array must be C-contiguous"
         return a.ctypes.data
-    # torch tensor
-    assert a.is_contiguous()
     return a.data_ptr()
+
+
+class DeviceArray:
+    """A dense array resident in the HBM of a Context's GPU, allocated by libgsfm's own HIP
+    runtime (gsfm_device_alloc).  Deliberately not a torch tensor: PyTorch wheels bundle a second
+    copy of the HIP runtime, and pointers must not cross runtimes."""
+
+    def __init__(self, ctx: "Context", shape, dtype):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = C.c_void_p()
+        rc = ctx.lib.gsfm_device_alloc(ctx.handle, self.nbytes, C.byref(p))
+        if rc != 0:
+            raise GsfmError(rc, "gsfm_device_alloc")
+        self._ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, ctx: "Context", a: np.ndarray) -> "DeviceArray":
+        a = np.ascontiguousarray(a)
+        d = cls(ctx, a.shape, a.dtype)
+        rc = ctx.lib.gsfm_memcpy_h2d(ctx.handle, d._ptr, a.ctypes.data, d.nbytes)
+        if rc != 0:
+            raise GsfmError(rc, "gsfm_memcpy_h2d")
+        return d
+
+    def numpy(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=self.dtype)
+        rc = self.ctx.lib.gsfm_memcpy_d2h(self.ctx.handle, out.ctypes.data, self._ptr, self.nbytes)
+        if rc != 0:
+            raise GsfmError(rc, "gsfm_memcpy_d2h")
+        return out
+
+    def copy_from(self, other: "DeviceArray"):
+        assert other.nbytes == self.nbytes
+        rc = self.ctx.lib.gsfm_memcpy_d2d(self.ctx.handle, self._ptr, other._ptr, self.nbytes)
+        if rc != 0:
+            raise GsfmError(rc, "gsfm_memcpy_d2d")
+
+    def clone(self) -> "DeviceArray":
+        d = DeviceArray(self.ctx, self.shape, self.dtype)
+        d.copy_from(self)
+        return d
+
+    def copy(self) -> "DeviceArray":
+        return self.clone()
+
+    def data_ptr(self) -> int:
+        return self._ptr
+
+    def contiguous(self) -> "DeviceArray":
+        return self
+
+    def free(self):
+        if getattr(self, "_ptr", None) and getattr(self.ctx, "handle", None):
+            self.ctx.lib.gsfm_device_free(self.ctx.handle, self._ptr)
+        self._ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class Context:
@@ -267,6 +338,14 @@ class Context:
         buf = C.create_string_buffer(256)
         self.lib.gsfm_ctx_device_name(self.handle, buf, 256)
         return buf.value.decode()
+
+    def synchronize(self):
+        rc = self.lib.gsfm_ctx_synchronize(self.handle)
+        if rc != 0:
+            raise GsfmError(rc, "gsfm_ctx_synchronize")
+
+    def to_device(self, a: np.ndarray) -> "DeviceArray":
+        return DeviceArray.from_numpy(self, a)
 
     def profile_enable(self, on: bool):
         self.lib.gsfm_ctx_profile_enable(self.handle, int(on))

@@ -82,6 +82,42 @@ extern "C" int gsfm_ctx_device_name(gsfm_ctx* ctx, char* buf, size_t buflen) {
   });
 }
 
+extern "C" int gsfm_device_alloc(gsfm_ctx* ctx, size_t bytes, void** out) {
+  if (!ctx || !out) return GSFM_ERR_INVALID_ARGUMENT;
+  return guarded(ctx, nullptr, [&] {
+    GSFM_HIP_CHECK(hipSetDevice(ctx->device));
+    GSFM_HIP_CHECK(hipMalloc(out, bytes ? bytes : 8));
+    return (int)GSFM_OK;
+  });
+}
+extern "C" int gsfm_device_free(gsfm_ctx* ctx, void* ptr) {
+  if (!ctx) return GSFM_ERR_INVALID_ARGUMENT;
+  return guarded(ctx, nullptr, [&] {
+    if (ptr) GSFM_HIP_CHECK(hipFree(ptr));
+    return (int)GSFM_OK;
+  });
+}
+static int copy_sync(gsfm_ctx* ctx, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+  if (!ctx || (bytes && (!dst || !src))) return GSFM_ERR_INVALID_ARGUMENT;
+  return guarded(ctx, nullptr, [&] {
+    if (bytes) {
+      GSFM_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, kind, ctx->stream));
+      GSFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return (int)GSFM_OK;
+  });
+}
+extern "C" int gsfm_memcpy_h2d(gsfm_ctx* ctx, void* d, const void* s, size_t n) { return copy_sync(ctx, d, s, n, hipMemcpyHostToDevice); }
+extern "C" int gsfm_memcpy_d2h(gsfm_ctx* ctx, void* d, const void* s, size_t n) { return copy_sync(ctx, d, s, n, hipMemcpyDeviceToHost); }
+extern "C" int gsfm_memcpy_d2d(gsfm_ctx* ctx, void* d, const void* s, size_t n) { return copy_sync(ctx, d, s, n, hipMemcpyDeviceToDevice); }
+extern "C" int gsfm_ctx_synchronize(gsfm_ctx* ctx) {
+  if (!ctx) return GSFM_ERR_INVALID_ARGUMENT;
+  return guarded(ctx, nullptr, [&] {
+    GSFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return (int)GSFM_OK;
+  });
+}
+
 extern "C" int gsfm_ctx_profile_enable(gsfm_ctx* ctx, int enable) {
   if (!ctx) return GSFM_ERR_INVALID_ARGUMENT;
   ctx->prof.enabled = enable != 0;

@@ -1,0 +1,814 @@
+// gp.hip — global positioning (translation averaging) on MI355X (gfx950).
+//
+// Replaces GlobalPositioner::Solve (glomap/estimators/global_positioning.cc:28-93) for the mode
+// `glomap mapper` uses: ONLY_POINTS, trivial rigs (global_mapper.cc:145-149).
+//   residual   BATAPairwiseDirectionError (cost_function.h:15-41):  r_k = v_k - s_k (X_p - c_i)
+//   unknowns   camera centres c_i (3), points X_p (3), one scale s_k >= 1e-5 per observation
+//   loss       Huber(0.1); ScaledLoss(Huber, 0.5) for cameras without prior focal (gp.cc:242-255,313-316)
+//   gauge      first scale constant (gp.cc:484-489)
+//   solver     Ceres LM + SPARSE_SCHUR  ->  lm.hpp + nested exact elimination + implicit-Schur PCG:
+//              the M scalar scales are eliminated per observation (1x1), the P points per track (3x3),
+//              leaving the 3N reduced camera system  S dc = -g'  that is never formed: its product
+//              with a vector is one sweep over the observations (k_gp_schur_matvec).
+//
+// Analytic blocks (what Ceres' autodiff produces): dr/dc = s I, dr/dX = -s I, dr/ds = -(X - c) =: -d.
+// After eliminating s_k with damped pivot h_ss = w d.d + D_s each observation acts on (c, X) through
+//   Q_k = a_k (I - beta_k d d^T),  a_k = w s^2,  beta_k = w / h_ss            (3x3 symmetric)
+//   q_k = s w (r - beta_k d (d.r))                                             (gradient share)
+// so only (a_k, beta_k) are stored per observation; d is recomputed from X_p and c_i.
+//
+// Data layout in HBM (f64 unless noted; observations are track-major):
+//   pt_offset[P+1] i64, obs_cam[M] i32, obs_dir[M][3], obs_cal[M] u8        inputs
+//   c[N][3], X[P][3], s[M] and their candidates                               state
+//   wrob[M], qa[M], qb[M], jss[M] (Jacobi scale of s_k)                       per observation
+//   hinv[P][6], e[P][3], hppd[P], jsx[P], used[P] u8                          per track
+//   hcc[N], jsc[N], dcam[N*3], gc[N*3], gred[N*3], scc[N][6], minv[N][9]      per camera
+#include <random>
+
+#include "cgvec.hpp"
+#include "lm.hpp"
+
+namespace gsfm {
+namespace {
+
+struct V3 {
+  double x, y, z;
+};
+__device__ __forceinline__ V3 ld3(const double* __restrict__ p) { return V3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ void st3(double* __restrict__ p, const V3& v) {
+  p[0] = v.x;
+  p[1] = v.y;
+  p[2] = v.z;
+}
+__device__ __forceinline__ V3 operator+(const V3& a, const V3& b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(const V3& a, const V3& b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(double s, const V3& a) { return V3{s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ double dot(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// symmetric 3x3: (xx, xy, xz, yy, yz, zz)
+struct S3 {
+  double xx, xy, xz, yy, yz, zz;
+};
+__device__ __forceinline__ V3 mul(const S3& m, const V3& v) {
+  return V3{m.xx * v.x + m.xy * v.y + m.xz * v.z, m.xy * v.x + m.yy * v.y + m.yz * v.z,
+            m.xz * v.x + m.yz * v.y + m.zz * v.z};
+}
+__device__ __forceinline__ S3 inv3(const S3& m) {
+  const double c00 = m.yy * m.zz - m.yz * m.yz;
+  const double c01 = m.xz * m.yz - m.xy * m.zz;
+  const double c02 = m.xy * m.yz - m.xz * m.yy;
+  const double det = m.xx * c00 + m.xy * c01 + m.xz * c02;
+  const double id = 1.0 / det;
+  return S3{c00 * id, c01 * id, c02 * id, (m.xx * m.zz - m.xz * m.xz) * id, (m.xy * m.xz - m.xx * m.yz) * id,
+            (m.xx * m.yy - m.xy * m.xy) * id};
+}
+// Q v = a (v - beta d (d.v))
+__device__ __forceinline__ V3 applyQ(double a, double beta, const V3& d, const V3& v) {
+  const double k = beta * dot(d, v);
+  return V3{a * (v.x - k * d.x), a * (v.y - k * d.y), a * (v.z - k * d.z)};
+}
+
+struct GpParams {
+  int N;
+  long P, M;
+  const long* off;
+  const int* cam;
+  const double* dir;
+  const unsigned char* cal;   // may be null (= all calibrated)
+  const unsigned char* used;  // [P]
+  long fixed_obs;             // observation whose scale is constant (-1: none on this rank)
+  double huber_a;
+  int opt_c, opt_x, opt_s;
+  double lm_lo, lm_hi;
+};
+
+__device__ __forceinline__ void huber(double a, double scale, double sq, double& rho, double& w) {
+  if (sq > a * a) {
+    const double r = sqrt(sq);
+    rho = scale * (2.0 * a * r - a * a);
+    w = scale * (a / r);
+  } else {
+    rho = scale * sq;
+    w = scale;
+  }
+}
+
+__device__ __forceinline__ void atomic_add3(double* p, const V3& v) {
+  unsafeAtomicAdd(p, v.x);
+  unsafeAtomicAdd(p + 1, v.y);
+  unsafeAtomicAdd(p + 2, v.z);
+}
+
+// ---- linearize: cost, robust weights, gradient max-norm, squared column norms ------------------
+// One thread per track.  part[block][2] = {cost, max |g_s|, |g_X|}.
+__global__ void __launch_bounds__(kBlock)
+    k_gp_linearize(GpParams g, const double* __restrict__ c, const double* __restrict__ X,
+                   const double* __restrict__ s, double* __restrict__ wrob, double* __restrict__ hppd,
+                   double* __restrict__ hcc, double* __restrict__ gc, double* __restrict__ part) {
+  __shared__ double smem[8];
+  double cost = 0.0, gmax = 0.0;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.P; p += (long)gridDim.x * blockDim.x) {
+    if (!g.used[p]) continue;
+    const V3 Xp = ld3(X + 3 * p);
+    double hpp = 0.0;
+    V3 gX{0, 0, 0};
+    for (long k = g.off[p]; k < g.off[p + 1]; ++k) {
+      const int n = g.cam[k];
+      const V3 d = Xp - ld3(c + 3 * (long)n);
+      const double sk = s[k];
+      const V3 r = ld3(g.dir + 3 * k) - sk * d;
+      double rho, w;
+      huber(g.huber_a, (g.cal == nullptr || g.cal[k]) ? 1.0 : 0.5, dot(r, r), rho, w);
+      wrob[k] = w;
+      cost += 0.5 * rho;
+      const double ws = w * sk;
+      hpp += ws * sk;
+      gX = gX - ws * r;
+      if (g.opt_c) {
+        unsafeAtomicAdd(hcc + n, ws * sk);
+        atomic_add3(gc + 3 * (long)n, ws * r);
+      }
+      if (g.opt_s && k != g.fixed_obs) gmax = fmax(gmax, fabs(w * dot(d, r)));
+    }
+    hppd[p] = hpp;
+    if (g.opt_x) gmax = fmax(gmax, fmax(fabs(gX.x), fmax(fabs(gX.y), fabs(gX.z))));
+  }
+  // block reduce: sum of cost, max of gmax
+  double v[1] = {cost};
+  block_sum<1>(v, smem);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_down(gmax, off, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) smem[4 + (threadIdx.x >> 6)] = gmax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[blockIdx.x * 2] = v[0];
+    part[blockIdx.x * 2 + 1] = fmax(fmax(smem[4], smem[5]), fmax(smem[6], smem[7]));
+  }
+}
+
+// out[0] = sum part[.][0], out[1] = max(part[.][1], max_i |vec[i]|)
+__global__ void __launch_bounds__(kBlock)
+    k_gp_finalize_lin(const double* __restrict__ part, int nblocks, const double* __restrict__ vec, int nvec,
+                      double* __restrict__ out) {
+  __shared__ double smem[8];
+  double cost = 0.0, gmax = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+    cost += part[2 * b];
+    gmax = fmax(gmax, part[2 * b + 1]);
+  }
+  for (int i = threadIdx.x; i < nvec; i += blockDim.x) gmax = fmax(gmax, fabs(vec[i]));
+  double v[1] = {cost};
+  block_sum<1>(v, smem);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_down(gmax, off, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) smem[4 + (threadIdx.x >> 6)] = gmax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = v[0];
+    out[1] = fmax(fmax(smem[4], smem[5]), fmax(smem[6], smem[7]));
+  }
+}
+
+// Jacobi scaling 1 / (1 + |J_col|) fixed at the initial point (Ceres jacobi_scaling).
+__global__ void __launch_bounds__(kBlock)
+    k_gp_jacobi_obs(GpParams g, int enabled, const double* __restrict__ c, const double* __restrict__ X,
+                    const double* __restrict__ wrob, const double* __restrict__ hppd,
+                    double* __restrict__ jss, double* __restrict__ jsx) {
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.P; p += (long)gridDim.x * blockDim.x) {
+    if (!g.used[p]) continue;
+    const V3 Xp = ld3(X + 3 * p);
+    for (long k = g.off[p]; k < g.off[p + 1]; ++k) {
+      const V3 d = Xp - ld3(c + 3 * (long)g.cam[k]);
+      const bool free_s = g.opt_s && k != g.fixed_obs;
+      jss[k] = (enabled && free_s) ? 1.0 / (1.0 + sqrt(wrob[k] * dot(d, d))) : 1.0;
+    }
+    jsx[p] = (enabled && g.opt_x) ? 1.0 / (1.0 + sqrt(hppd[p])) : 1.0;
+  }
+}
+__global__ void __launch_bounds__(kBlock)
+    k_gp_jacobi_cam(int N, int enabled, const double* __restrict__ hcc, double* __restrict__ jsc) {
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x)
+    jsc[n] = enabled ? 1.0 / (1.0 + sqrt(hcc[n])) : 1.0;
+}
+
+__device__ __forceinline__ double lm_damping(double h, double js, double radius, double lo, double hi) {
+  // clamp(js^2 h, lo, hi) / (radius js^2): the Ceres LM diagonal expressed in unscaled variables
+  const double j2 = js * js;
+  return fmin(fmax(j2 * h, lo), hi) / (radius * j2);
+}
+
+// ---- build (radius dependent): eliminate scales and points, reduced gradient, S_cc blocks ------
+__global__ void __launch_bounds__(kBlock)
+    k_gp_build(GpParams g, double radius, const double* __restrict__ c, const double* __restrict__ X,
+               const double* __restrict__ s, const double* __restrict__ wrob,
+               const double* __restrict__ jss, const double* __restrict__ jsx,
+               const double* __restrict__ hppd, double* __restrict__ qa, double* __restrict__ qb,
+               double* __restrict__ hinv, double* __restrict__ ept, double* __restrict__ gred,
+               double* __restrict__ scc) {
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.P; p += (long)gridDim.x * blockDim.x) {
+    if (!g.used[p]) continue;
+    const V3 Xp = ld3(X + 3 * p);
+    S3 H{0, 0, 0, 0, 0, 0};
+    V3 gp{0, 0, 0};
+    for (long k = g.off[p]; k < g.off[p + 1]; ++k) {
+      const V3 d = Xp - ld3(c + 3 * (long)g.cam[k]);
+      const double sk = s[k], w = wrob[k];
+      const V3 r = ld3(g.dir + 3 * k) - sk * d;
+      const double dd = dot(d, d);
+      double beta = 0.0;
+      if (g.opt_s && k != g.fixed_obs) {
+        const double hraw = w * dd;
+        beta = w / (hraw + lm_damping(hraw, jss[k], radius, g.lm_lo, g.lm_hi));
+      }
+      const double a = w * sk * sk;
+      qa[k] = a;
+      qb[k] = beta;
+      const double ab = a * beta;
+      H.xx += a - ab * d.x * d.x;
+      H.xy += -ab * d.x * d.y;
+      H.xz += -ab * d.x * d.z;
+      H.yy += a - ab * d.y * d.y;
+      H.yz += -ab * d.y * d.z;
+      H.zz += a - ab * d.z * d.z;
+      const V3 q = applyQ(w * sk, beta, d, r);  // s w (r - beta d (d.r))
+      gp = gp - q;
+    }
+    S3 Hi{0, 0, 0, 0, 0, 0};
+    V3 e{0, 0, 0};
+    if (g.opt_x) {
+      const double Dp = lm_damping(hppd[p], jsx[p], radius, g.lm_lo, g.lm_hi);
+      H.xx += Dp;
+      H.yy += Dp;
+      H.zz += Dp;
+      Hi = inv3(H);
+      e = mul(Hi, gp);
+    }
+    double* hp = hinv + 6 * p;
+    hp[0] = Hi.xx;
+    hp[1] = Hi.xy;
+    hp[2] = Hi.xz;
+    hp[3] = Hi.yy;
+    hp[4] = Hi.yz;
+    hp[5] = Hi.zz;
+    st3(ept + 3 * p, e);
+    if (!g.opt_c) continue;
+    for (long k = g.off[p]; k < g.off[p + 1]; ++k) {
+      const long n = g.cam[k];
+      const V3 d = Xp - ld3(c + 3 * n);
+      const double sk = s[k], w = wrob[k], a = qa[k], beta = qb[k];
+      const V3 r = ld3(g.dir + 3 * k) - sk * d;
+      const V3 q = applyQ(w * sk, beta, d, r);
+      // reduced gradient g'_c = sum_k q_k + Q_k H_pp^-1 g_p
+      atomic_add3(gred + 3 * n, q + applyQ(a, beta, d, e));
+      // diagonal block of S: Q_k - Q_k H_pp^-1 Q_k  (block-Jacobi preconditioner)
+      const double ab = a * beta;
+      const S3 Q{a - ab * d.x * d.x, -ab * d.x * d.y, -ab * d.x * d.z, a - ab * d.y * d.y, -ab * d.y * d.z,
+                 a - ab * d.z * d.z};
+      // columns of Hi Q, then Q (Hi Q)
+      const V3 c0 = mul(Q, mul(Hi, V3{Q.xx, Q.xy, Q.xz}));
+      const V3 c1 = mul(Q, mul(Hi, V3{Q.xy, Q.yy, Q.yz}));
+      const V3 c2 = mul(Q, mul(Hi, V3{Q.xz, Q.yz, Q.zz}));
+      double* sp = scc + 6 * n;
+      unsafeAtomicAdd(sp + 0, Q.xx - c0.x);
+      unsafeAtomicAdd(sp + 1, Q.xy - c1.x);
+      unsafeAtomicAdd(sp + 2, Q.xz - c2.x);
+      unsafeAtomicAdd(sp + 3, Q.yy - c1.y);
+      unsafeAtomicAdd(sp + 4, Q.yz - c2.y);
+      unsafeAtomicAdd(sp + 5, Q.zz - c2.z);
+    }
+  }
+}
+
+// per camera: damping, rhs = -g', inverse of the S_cc diagonal block
+__global__ void __launch_bounds__(kBlock)
+    k_gp_cam_finalize(int N, double radius, double lo, double hi, const double* __restrict__ hcc,
+                      const double* __restrict__ jsc, const double* __restrict__ gred,
+                      const double* __restrict__ scc, double* __restrict__ dcam, double* __restrict__ rhs,
+                      double* __restrict__ minv) {
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+    const double D = lm_damping(hcc[n], jsc[n], radius, lo, hi);
+    const double* sp = scc + 6 * (long)n;
+    const S3 Sm{sp[0] + D, sp[1], sp[2], sp[3] + D, sp[4], sp[5] + D};
+    const S3 Mi = inv3(Sm);
+    double* m = minv + 9 * (long)n;
+    m[0] = Mi.xx; m[1] = Mi.xy; m[2] = Mi.xz;
+    m[3] = Mi.xy; m[4] = Mi.yy; m[5] = Mi.yz;
+    m[6] = Mi.xz; m[7] = Mi.yz; m[8] = Mi.zz;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      dcam[3 * (long)n + j] = D;
+      rhs[3 * (long)n + j] = -gred[3 * (long)n + j];
+    }
+  }
+}
+
+// ---- the hot kernel: y += (H_cc - H_cp H_pp^-1 H_pc) p over this rank's tracks ----------------
+// One thread per track: first pass t = H_pp^-1 sum_k Q_k p_{c(k)}, second pass
+// y_{c(k)} += Q_k (p_{c(k)} - t).  Algorithmic bytes per launch (SURVEY.md §8d, K-GP-res):
+// 41 M + 48 P + 48 N.  Camera vectors (24 B x N) are L2-resident gathers; the scatter into y uses
+// hardware f64 atomics (global_atomic_add_f64).
+__global__ void __launch_bounds__(kBlock)
+    k_gp_schur_matvec(GpParams g, const double* __restrict__ c, const double* __restrict__ X,
+                      const double* __restrict__ qa, const double* __restrict__ qb,
+                      const double* __restrict__ hinv, const double* __restrict__ pvec,
+                      double* __restrict__ y) {
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.P; p += (long)gridDim.x * blockDim.x) {
+    if (!g.used[p]) continue;
+    const V3 Xp = ld3(X + 3 * p);
+    const long k0 = g.off[p], k1 = g.off[p + 1];
+    V3 acc{0, 0, 0};
+    for (long k = k0; k < k1; ++k) {
+      const long n = g.cam[k];
+      const V3 d = Xp - ld3(c + 3 * n);
+      acc = acc + applyQ(qa[k], qb[k], d, ld3(pvec + 3 * n));
+    }
+    const double* hp = hinv + 6 * p;
+    const V3 t = mul(S3{hp[0], hp[1], hp[2], hp[3], hp[4], hp[5]}, acc);
+    for (long k = k0; k < k1; ++k) {
+      const long n = g.cam[k];
+      const V3 d = Xp - ld3(c + 3 * n);
+      atomic_add3(y + 3 * n, applyQ(qa[k], qb[k], d, ld3(pvec + 3 * n) - t));
+    }
+  }
+}
+
+// ---- back-substitution, model cost change, candidate point ------------------------------------
+// part[block][3] = {model_cost_change, |dX|^2 + |ds|^2, |X|^2 + |s|^2}
+__global__ void __launch_bounds__(kBlock)
+    k_gp_backsub(GpParams g, const double* __restrict__ c, const double* __restrict__ X,
+                 const double* __restrict__ s, const double* __restrict__ wrob,
+                 const double* __restrict__ qa, const double* __restrict__ qb,
+                 const double* __restrict__ hinv, const double* __restrict__ ept,
+                 const double* __restrict__ dc, double* __restrict__ Xn, double* __restrict__ sn,
+                 double* __restrict__ part) {
+  __shared__ double smem[4 * 3];
+  double acc3[3] = {0, 0, 0};
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.P; p += (long)gridDim.x * blockDim.x) {
+    const V3 Xp = ld3(X + 3 * p);
+    if (!g.used[p]) {
+      st3(Xn + 3 * p, Xp);
+      for (long k = g.off[p]; k < g.off[p + 1]; ++k) sn[k] = s[k];
+      continue;
+    }
+    const long k0 = g.off[p], k1 = g.off[p + 1];
+    V3 dX{0, 0, 0};
+    if (g.opt_x) {
+      V3 acc{0, 0, 0};
+      for (long k = k0; k < k1; ++k) {
+        const long n = g.cam[k];
+        acc = acc + applyQ(qa[k], qb[k], Xp - ld3(c + 3 * n), ld3(dc + 3 * n));
+      }
+      const double* hp = hinv + 6 * p;
+      dX = mul(S3{hp[0], hp[1], hp[2], hp[3], hp[4], hp[5]}, acc) - ld3(ept + 3 * p);
+    }
+    for (long k = k0; k < k1; ++k) {
+      const long n = g.cam[k];
+      const V3 d = Xp - ld3(c + 3 * n);
+      const double sk = s[k], w = wrob[k];
+      const V3 r = ld3(g.dir + 3 * k) - sk * d;
+      const V3 dcx = ld3(dc + 3 * n) - dX;
+      // delta_s = beta (d.r + s d.(dc - dX)),  beta = w / h_ss (0 for a constant scale)
+      const double ds = qb[k] * (dot(d, r) + sk * dot(d, dcx));
+      const V3 m = sk * dcx - ds * d;  // J delta (un-robustified)
+      acc3[0] -= w * (dot(m, r) + 0.5 * dot(m, m));
+      const double s_new = fmax(1e-5, sk + ds);  // SetParameterLowerBound(&scale, 0, 1e-5), gp.cc:373
+      sn[k] = s_new;
+      acc3[1] += (s_new - sk) * (s_new - sk);
+      acc3[2] += sk * sk;
+    }
+    st3(Xn + 3 * p, Xp + dX);
+    acc3[1] += dot(dX, dX);
+    acc3[2] += dot(Xp, Xp);
+  }
+  block_sum<3>(acc3, smem);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) part[blockIdx.x * 3 + k] = acc3[k];
+  }
+}
+
+// cn = c + dc; out (single block) {|dc|^2, |c|^2, #non-finite}
+__global__ void __launch_bounds__(kBlock)
+    k_gp_cam_update(int n3, const double* __restrict__ c, const double* __restrict__ dc,
+                    double* __restrict__ cn, double* __restrict__ out) {
+  __shared__ double smem[4 * 3];
+  double acc[3] = {0, 0, 0};
+  for (int i = threadIdx.x; i < n3; i += blockDim.x) {
+    const double d = dc[i];
+    cn[i] = c[i] + d;
+    acc[0] += d * d;
+    acc[1] += c[i] * c[i];
+    acc[2] += isfinite(d) ? 0.0 : 1.0;
+  }
+  block_sum<3>(acc, smem);
+  if (threadIdx.x == 0) {
+    out[0] = acc[0];
+    out[1] = acc[1];
+    out[2] = acc[2];
+  }
+}
+
+// candidate cost; part[block][1]
+__global__ void __launch_bounds__(kBlock)
+    k_gp_cost(GpParams g, const double* __restrict__ c, const double* __restrict__ X,
+              const double* __restrict__ s, double* __restrict__ part) {
+  __shared__ double smem[4];
+  double v[1] = {0.0};
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.P; p += (long)gridDim.x * blockDim.x) {
+    if (!g.used[p]) continue;
+    const V3 Xp = ld3(X + 3 * p);
+    for (long k = g.off[p]; k < g.off[p + 1]; ++k) {
+      const V3 d = Xp - ld3(c + 3 * (long)g.cam[k]);
+      const V3 r = ld3(g.dir + 3 * k) - s[k] * d;
+      double rho, w;
+      huber(g.huber_a, (g.cal == nullptr || g.cal[k]) ? 1.0 : 0.5, dot(r, r), rho, w);
+      v[0] += 0.5 * rho;
+    }
+  }
+  block_sum<1>(v, smem);
+  if (threadIdx.x == 0) part[blockIdx.x] = v[0];
+}
+
+// s_k = max(1e-5, v.d / d.d) when !generate_scales (gp.cc:300-305)
+__global__ void __launch_bounds__(kBlock)
+    k_gp_init_scales(GpParams g, int generate, const double* __restrict__ c, const double* __restrict__ X,
+                     double* __restrict__ s) {
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.P; p += (long)gridDim.x * blockDim.x) {
+    const V3 Xp = ld3(X + 3 * p);
+    for (long k = g.off[p]; k < g.off[p + 1]; ++k) {
+      double v = 1.0;
+      if (!generate) {
+        const V3 d = Xp - ld3(c + 3 * (long)g.cam[k]);
+        v = fmax(1e-5, dot(ld3(g.dir + 3 * k), d) / dot(d, d));
+      }
+      s[k] = v;
+    }
+  }
+}
+
+template <int K>
+__global__ void __launch_bounds__(kBlock)
+    k_sum_partials(const double* __restrict__ part, int nblocks, double* __restrict__ out) {
+  __shared__ double smem[4 * K + K];
+  double tot[K];
+  reduce_partials<K>(part, nblocks, tot, smem);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) out[k] = tot[k];
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_iota_blocks3(int N, int* __restrict__ elem_blk, int* __restrict__ blk_start,
+                                                         int* __restrict__ blk_size, int* __restrict__ blk_moff) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 3 * N; i += gridDim.x * blockDim.x) {
+    elem_blk[i] = i / 3;
+    if (i % 3 == 0) {
+      blk_start[i / 3] = i;
+      blk_size[i / 3] = 3;
+      blk_moff[i / 3] = 3 * i;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct GpWs {
+  DevBuf<long> off;
+  DevBuf<int> cam, elem_blk, blk_start, blk_size, blk_moff;
+  DevBuf<unsigned char> cal, used;
+  DevBuf<double> dir, c, cn, X, Xn, s, sn, wrob, qa, qb, jss, hinv, ept, hppd, jsx, hcc, jsc, dcam, gc, gred,
+      scc, minv, rhs, cg_x, cg_r, cg_z, cg_p, cg_y, part, scal;
+  DevBuf<CgState> cg;
+  static void destroy(void* p) { delete static_cast<GpWs*>(p); }
+};
+
+GpWs* gp_ws(gsfm_ctx* ctx) {
+  if (!ctx->gp_ws) {
+    ctx->gp_ws = new GpWs();
+    ctx->gp_ws_free = &GpWs::destroy;
+  }
+  return static_cast<GpWs*>(ctx->gp_ws);
+}
+
+class GpSolver final : public LmProblem {
+ public:
+  GpSolver(gsfm_ctx* ctx, const gsfm_gp_options& opt) : ctx_(ctx), ws_(gp_ws(ctx)), opt_(opt) {}
+
+  void setup(const gsfm_gp_problem* prob, const double* cam_center, const double* pt_xyz) {
+    GpWs* ws = ws_;
+    hipStream_t s = ctx_->stream;
+    const int mem = prob->mem;
+    N_ = prob->num_cams;
+    P_ = prob->num_pts;
+    M_ = prob->num_obs;
+    GSFM_REQUIRE(N_ > 0 && P_ >= 0 && M_ >= 0, "GP: bad sizes");
+    // host copies of the track structure: used flags, constrained cameras, gauge observation
+    std::vector<long> h_off;
+    std::vector<int> h_cam;
+    to_host(ctx_, h_off, reinterpret_cast<const long*>(prob->pt_offset), (size_t)P_ + 1, mem);
+    to_host(ctx_, h_cam, prob->obs_cam, (size_t)M_, mem);
+    GSFM_REQUIRE(h_off[0] == 0 && h_off[P_] == M_, "GP: pt_offset must start at 0 and end at num_obs");
+    std::vector<unsigned char> h_used(P_);
+    std::vector<char> constrained(N_, 0);
+    long fixed_obs = -1, m_used = 0;
+    for (long p = 0; p < P_; ++p) {
+      const long len = h_off[p + 1] - h_off[p];
+      GSFM_REQUIRE(len >= 0, "GP: pt_offset must be non-decreasing");
+      h_used[p] = len >= opt_.min_num_view_per_track ? 1 : 0;  // gp.cc:258
+      if (!h_used[p]) continue;
+      m_used += len;
+      if (fixed_obs < 0) fixed_obs = h_off[p];
+      for (long k = h_off[p]; k < h_off[p + 1]; ++k) {
+        GSFM_REQUIRE(h_cam[k] >= 0 && h_cam[k] < N_, "GP: obs_cam out of range");
+        constrained[h_cam[k]] = 1;
+      }
+    }
+    m_used_ = m_used;
+    if (ctx_->comm.rank != 0) fixed_obs = -1;  // one constant scale in the whole problem
+    // state init (gp.cc:123-165, 261-264): cameras by index, then used tracks by index
+    std::vector<double> h_c, h_X;
+    to_host(ctx_, h_c, cam_center, 3 * (size_t)N_, mem);
+    to_host(ctx_, h_X, pt_xyz, 3 * (size_t)P_, mem);
+    std::mt19937 rng;
+    rng.seed(opt_.seed);
+    std::uniform_real_distribution<double> uni(-1.0, 1.0);
+    if (opt_.generate_random_positions && opt_.optimize_positions) {
+      for (int n = 0; n < N_; ++n) {
+        if (!constrained[n] && ctx_->comm.world == 1) continue;
+        for (int j = 0; j < 3; ++j) h_c[3 * (size_t)n + j] = 100.0 * uni(rng);
+      }
+    }
+    // several ranks: same camera draws everywhere (above), decorrelated point draws per shard
+    if (ctx_->comm.world > 1) rng.seed(opt_.seed + 7919u * (unsigned)(ctx_->comm.rank + 1));
+    if (opt_.generate_random_points && opt_.optimize_points) {
+      for (long p = 0; p < P_; ++p) {
+        if (!h_used[p]) continue;
+        for (int j = 0; j < 3; ++j) h_X[3 * (size_t)p + j] = 100.0 * uni(rng);
+      }
+    }
+    copy_in(ctx_, ws->off.ensure(P_ + 1), reinterpret_cast<const long*>(prob->pt_offset), (size_t)P_ + 1, mem);
+    copy_in(ctx_, ws->cam.ensure(M_ + 1), prob->obs_cam, (size_t)M_, mem);
+    copy_in(ctx_, ws->dir.ensure(3 * (size_t)M_ + 3), prob->obs_dir, 3 * (size_t)M_, mem);
+    const unsigned char* d_cal = nullptr;
+    if (prob->obs_calibrated) {
+      copy_in(ctx_, ws->cal.ensure(M_ + 1), prob->obs_calibrated, (size_t)M_, mem);
+      d_cal = ws->cal.get();
+    }
+    GSFM_HIP_CHECK(hipMemcpyAsync(ws->used.ensure(P_ + 1), h_used.data(), (size_t)P_, hipMemcpyHostToDevice, s));
+    GSFM_HIP_CHECK(hipMemcpyAsync(ws->c.ensure(3 * (size_t)N_), h_c.data(), 3 * (size_t)N_ * sizeof(double), hipMemcpyHostToDevice, s));
+    GSFM_HIP_CHECK(hipMemcpyAsync(ws->X.ensure(3 * (size_t)P_ + 3), h_X.data(), 3 * (size_t)P_ * sizeof(double), hipMemcpyHostToDevice, s));
+    GSFM_HIP_CHECK(hipStreamSynchronize(s));
+    ws->cn.ensure(3 * (size_t)N_);
+    ws->Xn.ensure(3 * (size_t)P_ + 3);
+    for (DevBuf<double>* b : {&ws->s, &ws->sn, &ws->wrob, &ws->qa, &ws->qb, &ws->jss}) b->ensure(M_ + 1);
+    ws->hinv.ensure(6 * (size_t)P_ + 6);
+    ws->ept.ensure(3 * (size_t)P_ + 3);
+    ws->hppd.ensure(P_ + 1);
+    ws->jsx.ensure(P_ + 1);
+    ws->hcc.ensure(N_);
+    ws->jsc.ensure(N_);
+    ws->scc.ensure(6 * (size_t)N_);
+    ws->minv.ensure(9 * (size_t)N_);
+    for (DevBuf<double>* b : {&ws->dcam, &ws->gc, &ws->gred, &ws->rhs, &ws->cg_x, &ws->cg_r, &ws->cg_z, &ws->cg_p, &ws->cg_y})
+      b->ensure(3 * (size_t)N_);
+    ws->part.ensure(kMaxBlocks * 4);
+    ws->scal.ensure(64);
+    ws->cg.ensure(1);
+    ws->elem_blk.ensure(3 * (size_t)N_);
+    ws->blk_start.ensure(N_);
+    ws->blk_size.ensure(N_);
+    ws->blk_moff.ensure(N_);
+    gridP_ = grid_for(P_, kBlock);
+    gridN_ = grid_for(N_, kBlock);
+    hipLaunchKernelGGL(k_iota_blocks3, dim3(grid_for(3 * (size_t)N_, kBlock)), dim3(kBlock), 0, s, N_,
+                       ws->elem_blk.get(), ws->blk_start.get(), ws->blk_size.get(), ws->blk_moff.get());
+    g_.N = N_;
+    g_.P = P_;
+    g_.M = M_;
+    g_.off = ws->off.get();
+    g_.cam = ws->cam.get();
+    g_.dir = ws->dir.get();
+    g_.cal = d_cal;
+    g_.used = ws->used.get();
+    g_.fixed_obs = fixed_obs;
+    g_.huber_a = opt_.thres_loss_function;
+    g_.opt_c = opt_.optimize_positions ? 1 : 0;
+    g_.opt_x = opt_.optimize_points ? 1 : 0;
+    g_.opt_s = opt_.optimize_scales ? 1 : 0;
+    g_.lm_lo = opt_.lm.min_lm_diagonal;
+    g_.lm_hi = opt_.lm.max_lm_diagonal;
+    c_ = ws->c.get();
+    cn_ = ws->cn.get();
+    X_ = ws->X.get();
+    Xn_ = ws->Xn.get();
+    s_ = ws->s.get();
+    sn_ = ws->sn.get();
+    hipLaunchKernelGGL(k_gp_init_scales, dim3(gridP_), dim3(kBlock), 0, s, g_, opt_.generate_scales ? 1 : 0, c_, X_, s_);
+    bj_ = BlockJacobi{ws->elem_blk.get(), ws->blk_start.get(), ws->blk_size.get(), ws->blk_moff.get(), ws->minv.get()};
+  }
+
+  long used_observations() const { return m_used_; }
+
+  double linearize(double* grad_max_norm) override {
+    GpWs* ws = ws_;
+    hipStream_t s = ctx_->stream;
+    GSFM_HIP_CHECK(hipMemsetAsync(ws->hcc.get(), 0, (size_t)N_ * sizeof(double), s));
+    GSFM_HIP_CHECK(hipMemsetAsync(ws->gc.get(), 0, 3 * (size_t)N_ * sizeof(double), s));
+    hipLaunchKernelGGL(k_gp_linearize, dim3(gridP_), dim3(kBlock), 0, s, g_, c_, X_, s_, ws->wrob.get(),
+                       ws->hppd.get(), ws->hcc.get(), ws->gc.get(), ws->part.get());
+    if (ctx_->comm.world > 1) {
+      allreduce_sum(ctx_, ws->hcc.get(), N_);
+      allreduce_sum(ctx_, ws->gc.get(), 3 * (size_t)N_);
+    }
+    hipLaunchKernelGGL(k_gp_finalize_lin, dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridP_, ws->gc.get(),
+                       g_.opt_c ? 3 * N_ : 0, ws->scal.get());
+    double h[2];
+    read_scalars(ws->scal.get(), h, 2, /*sum_first=*/1, /*max_from=*/1);
+    *grad_max_norm = h[1];
+    return h[0];
+  }
+
+  void set_jacobi_scaling(bool enabled) override {
+    GpWs* ws = ws_;
+    hipStream_t s = ctx_->stream;
+    hipLaunchKernelGGL(k_gp_jacobi_obs, dim3(gridP_), dim3(kBlock), 0, s, g_, enabled ? 1 : 0, c_, X_,
+                       ws->wrob.get(), ws->hppd.get(), ws->jss.get(), ws->jsx.get());
+    hipLaunchKernelGGL(k_gp_jacobi_cam, dim3(gridN_), dim3(kBlock), 0, s, N_, enabled ? 1 : 0, ws->hcc.get(),
+                       ws->jsc.get());
+  }
+
+  bool step(double radius, double* model_change, double* cand_cost, double* step_norm, double* x_norm,
+            long* linear_iterations) override {
+    GpWs* ws = ws_;
+    hipStream_t s = ctx_->stream;
+    const bool multi = ctx_->comm.world > 1;
+    const int n3 = 3 * N_;
+    GSFM_HIP_CHECK(hipMemsetAsync(ws->gred.get(), 0, (size_t)n3 * sizeof(double), s));
+    GSFM_HIP_CHECK(hipMemsetAsync(ws->scc.get(), 0, 6 * (size_t)N_ * sizeof(double), s));
+    hipLaunchKernelGGL(k_gp_build, dim3(gridP_), dim3(kBlock), 0, s, g_, radius, c_, X_, s_, ws->wrob.get(),
+                       ws->jss.get(), ws->jsx.get(), ws->hppd.get(), ws->qa.get(), ws->qb.get(), ws->hinv.get(),
+                       ws->ept.get(), ws->gred.get(), ws->scc.get());
+    if (multi) {
+      allreduce_sum(ctx_, ws->gred.get(), n3);
+      allreduce_sum(ctx_, ws->scc.get(), 6 * (size_t)N_);
+    }
+    *linear_iterations = 0;
+    if (g_.opt_c) {
+      hipLaunchKernelGGL(k_gp_cam_finalize, dim3(gridN_), dim3(kBlock), 0, s, N_, radius, g_.lm_lo, g_.lm_hi,
+                         ws->hcc.get(), ws->jsc.get(), ws->gred.get(), ws->scc.get(), ws->dcam.get(),
+                         ws->rhs.get(), ws->minv.get());
+      *linear_iterations = pcg();
+    } else {
+      GSFM_HIP_CHECK(hipMemsetAsync(ws->cg_x.get(), 0, (size_t)n3 * sizeof(double), s));
+    }
+    hipLaunchKernelGGL(k_gp_backsub, dim3(gridP_), dim3(kBlock), 0, s, g_, c_, X_, s_, ws->wrob.get(),
+                       ws->qa.get(), ws->qb.get(), ws->hinv.get(), ws->ept.get(), ws->cg_x.get(), Xn_, sn_,
+                       ws->part.get());
+    hipLaunchKernelGGL((k_sum_partials<3>), dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridP_, ws->scal.get());
+    hipLaunchKernelGGL(k_gp_cam_update, dim3(1), dim3(kBlock), 0, s, n3, c_, ws->cg_x.get(), cn_, ws->scal.get() + 3);
+    hipLaunchKernelGGL(k_gp_cost, dim3(gridP_), dim3(kBlock), 0, s, g_, cn_, Xn_, sn_, ws->part.get());
+    hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridP_, ws->scal.get() + 6);
+    if (multi) {
+      // track-local sums: model change, |dX|^2+|ds|^2, |X|^2+|s|^2 and the candidate cost
+      allreduce_sum(ctx_, ws->scal.get(), 3);
+      allreduce_sum(ctx_, ws->scal.get() + 6, 1);
+    }
+    double h[7];
+    GSFM_HIP_CHECK(hipMemcpyAsync(ctx_->h_pinned + 256, ws->scal.get(), 7 * sizeof(double), hipMemcpyDeviceToHost, s));
+    GSFM_HIP_CHECK(hipStreamSynchronize(s));
+    GSFM_HIP_CHECK(hipGetLastError());
+    std::memcpy(h, ctx_->h_pinned + 256, sizeof(h));
+    *model_change = h[0];
+    *step_norm = std::sqrt(h[1] + h[3]);
+    *x_norm = std::sqrt(h[2] + h[4]);
+    *cand_cost = h[6];
+    const bool finite = h[5] == 0.0 && std::isfinite(h[0]) && std::isfinite(h[1]) && std::isfinite(h[6]);
+    return finite;
+  }
+
+  void accept() override {
+    std::swap(c_, cn_);
+    std::swap(X_, Xn_);
+    std::swap(s_, sn_);
+  }
+
+  void write_back(const gsfm_gp_problem* prob, double* cam_center, double* pt_xyz) {
+    copy_out(ctx_, cam_center, c_, 3 * (size_t)N_, prob->mem);
+    copy_out(ctx_, pt_xyz, X_, 3 * (size_t)P_, prob->mem);
+    GSFM_HIP_CHECK(hipStreamSynchronize(ctx_->stream));
+  }
+
+ private:
+  // sum/max scalars are already global for single rank; for several ranks the cost is a sum over
+  // ranks and the gradient norm a max: both handled here.
+  void read_scalars(double* dev, double* out, int n, int sum_first, int max_from) {
+    hipStream_t s = ctx_->stream;
+    if (ctx_->comm.world > 1) {
+      allreduce_sum(ctx_, dev, sum_first);
+      GSFM_NCCL_CHECK(ncclAllReduce(dev + max_from, dev + max_from, n - max_from, ncclDouble, ncclMax,
+                                    ctx_->comm.nccl, s));
+    }
+    GSFM_HIP_CHECK(hipMemcpyAsync(ctx_->h_pinned + 300, dev, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    GSFM_HIP_CHECK(hipStreamSynchronize(s));
+    GSFM_HIP_CHECK(hipGetLastError());
+    std::memcpy(out, ctx_->h_pinned + 300, n * sizeof(double));
+  }
+
+  long pcg() {
+    GpWs* ws = ws_;
+    hipStream_t s = ctx_->stream;
+    const int n3 = 3 * N_;
+    const bool multi = ctx_->comm.world > 1;
+    const double yscale = ctx_->comm.rank == 0 ? 1.0 : 0.0;
+    const double tol = opt_.lm.pcg_relative_tolerance;
+    hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(kCgThreads), 0, s, n3, ws->rhs.get(), ws->cg_x.get(),
+                       ws->cg_r.get(), ws->cg_z.get(), ws->cg_p.get(), ws->cg_y.get(), ws->dcam.get(), bj_,
+                       ws->cg.get(), yscale);
+    CgState* h = reinterpret_cast<CgState*>(ctx_->h_pinned + 400);
+    const int chunk = 8;
+    const int max_iter = opt_.lm.pcg_max_iterations;
+    for (int it = 0; it < max_iter; ++it) {
+      const bool timed = ctx_->prof.begin(s, GSFM_KERNEL_GP_SCHUR);
+      hipLaunchKernelGGL(k_gp_schur_matvec, dim3(gridP_), dim3(kBlock), 0, s, g_, c_, X_, ws->qa.get(),
+                         ws->qb.get(), ws->hinv.get(), ws->cg_p.get(), ws->cg_y.get());
+      if (timed) ctx_->prof.end(s);
+      if (multi) allreduce_sum(ctx_, ws->cg_y.get(), n3);
+      hipLaunchKernelGGL(k_cg_iter, dim3(1), dim3(kCgThreads), 0, s, n3, ws->cg_y.get(), ws->cg_p.get(),
+                         ws->cg_x.get(), ws->cg_r.get(), ws->cg_z.get(), ws->dcam.get(), bj_, ws->cg.get(),
+                         tol * tol, yscale);
+      if ((it + 1) % chunk == 0 || it + 1 == max_iter) {
+        GSFM_HIP_CHECK(hipMemcpyAsync(h, ws->cg.get(), sizeof(CgState), hipMemcpyDeviceToHost, s));
+        GSFM_HIP_CHECK(hipStreamSynchronize(s));
+        GSFM_HIP_CHECK(hipGetLastError());
+        ctx_->prof.harvest();
+        if (h->done) return h->iters;
+      }
+    }
+    return max_iter;
+  }
+
+  gsfm_ctx* ctx_;
+  GpWs* ws_;
+  gsfm_gp_options opt_;
+  GpParams g_{};
+  BlockJacobi bj_{};
+  int N_ = 0;
+  long P_ = 0, M_ = 0, m_used_ = 0;
+  int gridP_ = 1, gridN_ = 1;
+  double *c_ = nullptr, *cn_ = nullptr, *X_ = nullptr, *Xn_ = nullptr, *s_ = nullptr, *sn_ = nullptr;
+};
+
+int gp_solve_impl(gsfm_ctx* ctx, const gsfm_gp_problem* prob, const gsfm_gp_options* opt, double* cam_center,
+                  double* pt_xyz, gsfm_report* rep) {
+  GSFM_REQUIRE(prob && opt && cam_center && pt_xyz, "GP: null argument");
+  if (opt->constraint_type != 0)
+    throw StatusError(GSFM_ERR_UNSUPPORTED, "GP: only ONLY_POINTS is implemented (the mode glomap mapper accepts)");
+  if (prob->num_cams <= 0) throw StatusError(GSFM_ERR_EMPTY_PROBLEM, "GP: no images");   // gp.cc:37-40
+  if (prob->num_pts <= 0 || prob->num_obs <= 0) throw StatusError(GSFM_ERR_EMPTY_PROBLEM, "GP: no tracks");  // gp.cc:46-50
+  const double t0 = now_seconds();
+  GSFM_HIP_CHECK(hipSetDevice(ctx->device));
+  GpSolver solver(ctx, *opt);
+  solver.setup(prob, cam_center, pt_xyz);
+  if (solver.used_observations() == 0 && ctx->comm.world == 1)
+    throw StatusError(GSFM_ERR_EMPTY_PROBLEM, "GP: no track with enough views");
+  const double t1 = now_seconds();
+  const int rc = lm_minimize(solver, opt->lm, rep);
+  solver.write_back(prob, cam_center, pt_xyz);
+  const double t2 = now_seconds();
+  if (rep) {
+    rep->seconds_total = t2 - t0;
+    rep->seconds_solve = t2 - t1;
+  }
+  return rc;
+}
+
+}  // namespace
+}  // namespace gsfm
+
+using namespace gsfm;
+
+extern "C" void gsfm_gp_options_default(gsfm_gp_options* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  lm_options_default(&o->lm, 100);  // optimization_base.h:20
+  o->thres_loss_function = 1e-1;    // global_positioning.h:47-49
+  o->generate_random_positions = 1;
+  o->generate_random_points = 1;
+  o->generate_scales = 1;
+  o->optimize_positions = 1;
+  o->optimize_points = 1;
+  o->optimize_scales = 1;
+  o->min_num_view_per_track = 3;
+  o->seed = 1;
+  o->constraint_type = 0;
+}
+
+extern "C" int gsfm_gp_solve(gsfm_ctx* ctx, const gsfm_gp_problem* prob, const gsfm_gp_options* opt,
+                             double* cam_center_inout, double* pt_xyz_inout, gsfm_report* report) {
+  if (!ctx) return GSFM_ERR_INVALID_ARGUMENT;
+  if (report) std::memset(report, 0, sizeof(*report));
+  return guarded(ctx, report, [&] { return gp_solve_impl(ctx, prob, opt, cam_center_inout, pt_xyz_inout, report); });
+}

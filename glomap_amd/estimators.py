@@ -2,7 +2,7 @@
 
 Two levels:
   * flat level  — ra_solve / gp_solve / ba_solve take the SoA problems of glomap_amd.flat (numpy
-    arrays on the host, or torch tensors already resident in HBM) and call the C ABI directly;
+    arrays on the host, or DeviceArrays already resident in HBM) and call the C ABI directly;
   * scene level — RotationEstimator / GlobalPositioner / BundleAdjuster keep the reference's
     class names, option names and bool-returning methods
     (global_rotation_averaging.h:79-87, global_positioning.h:58-68, bundle_adjustment.h:40-51)
@@ -32,24 +32,27 @@ def default_context() -> _lib.Context:
     return _default_ctx
 
 
-def _is_torch(a) -> bool:
-    return a is not None and not isinstance(a, np.ndarray) and hasattr(a, "data_ptr")
+def _is_dev(a) -> bool:
+    return isinstance(a, _lib.DeviceArray)
 
 
 def _mem_of(*arrays) -> int:
-    kinds = {_is_torch(a) for a in arrays if a is not None}
+    kinds = {_is_dev(a) for a in arrays if a is not None}
     if len(kinds) != 1:
         raise ValueError("all problem arrays must live in the same memory space")
     return _lib.GSFM_MEM_DEVICE if kinds.pop() else _lib.GSFM_MEM_HOST
 
 
 def _h(a, dtype):
-    """numpy: contiguous array of dtype; torch: checked as-is."""
+    """numpy: contiguous array of dtype; DeviceArray: dtype checked, returned as-is."""
     if a is None:
         return None
     if isinstance(a, np.ndarray):
         return np.ascontiguousarray(a, dtype=dtype)
-    return a.contiguous()
+    if not _is_dev(a):
+        raise TypeError("problem arrays must be numpy arrays (host) or glomap_amd DeviceArrays (HBM)")
+    assert a.dtype == np.dtype(dtype), f"device array has dtype {a.dtype}, expected {np.dtype(dtype)}"
+    return a
 
 
 # ============================================================================================
@@ -218,10 +221,7 @@ def ra_laplacian_apply(p: RaProblem, w, x, repeat: int = 1, ctx=None):
     keep: list = []
     c = _ra_problem_c(p, keep)
     w, x = _h(w, np.float64), _h(x, np.float64)
-    if c.mem == _lib.GSFM_MEM_HOST:
-        y = np.empty_like(x)
-    else:
-        y = x.clone()
+    y = np.empty_like(x) if c.mem == _lib.GSFM_MEM_HOST else x.clone()
     ms = C.c_double(0.0)
     rc = ctx.lib.gsfm_ra_laplacian_apply(ctx.handle, C.byref(c), _lib.ptr(w), _lib.ptr(x), _lib.ptr(y), repeat, C.byref(ms))
     if rc != 0:

@@ -87,6 +87,19 @@ void* gsfm_ctx_stream(gsfm_ctx* ctx);
 /* Device name + gcnArchName, for reports. Returns GSFM_OK and writes a NUL-terminated string. */
 int gsfm_ctx_device_name(gsfm_ctx* ctx, char* buf, size_t buflen);
 
+/* ---- device memory ---------------------------------------------------------------------------
+ * libgsfm owns exactly one HIP runtime per process (the ROCm one it is linked against).  Callers
+ * that want problem arrays resident in HBM (GSFM_MEM_DEVICE) allocate and fill them through these
+ * calls, so no second HIP runtime (e.g. the copy bundled inside a PyTorch wheel) ever has to share
+ * pointers with this one. */
+int gsfm_device_alloc(gsfm_ctx* ctx, size_t bytes, void** out);
+int gsfm_device_free(gsfm_ctx* ctx, void* ptr);
+int gsfm_memcpy_h2d(gsfm_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int gsfm_memcpy_d2h(gsfm_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int gsfm_memcpy_d2d(gsfm_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);
+/* Blocks until all work enqueued on the ctx stream has finished (hipStreamSynchronize). */
+int gsfm_ctx_synchronize(gsfm_ctx* ctx);
+
 /* ---- per-kernel timing (HIP events on the ctx stream) -------------------------------------
  * When enabled, every launch of the dominant kernel of each solver is bracketed by a HIP event
  * pair on the ctx stream; bench.py uses this for the roofline line.  Off by default (the event

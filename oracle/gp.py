@@ -1,0 +1,178 @@
+"""ORACLE (test infrastructure only — never imported by the product path).
+
+CPU restatement of GLOMAP's global positioning, ONLY_POINTS with trivial rigs — the only mode
+`glomap mapper` accepts (global_mapper.cc:145-149):
+
+  residual            BATAPairwiseDirectionError          cost_function.h:15-41   r = v - s (X - c)
+  problem build       AddPointToCameraConstraints/AddTrackToProblem   gp.cc:212-375
+                      (tracks >= min_num_view_per_track; scale init 1; lower bound 1e-5 gp.cc:373;
+                       loss Huber(0.1) for calibrated cameras, ScaledLoss(Huber(0.1), 0.5) otherwise,
+                       gp.cc:242-255,313-316)
+  random init         InitializeRandomPositions gp.cc:123-165, gp.cc:261-264:
+                      100 * U(-1,1)^3 from std::mt19937(seed) + std::uniform_real_distribution;
+                      draw order here: cameras by index (only those observed by a used track), then
+                      used tracks by index — the reference's unordered_map order cannot be reproduced
+  gauge               first scale constant                 gp.cc:484-489
+  solver              Ceres LM (oracle/lm.py), exact linear solves
+
+parity unpinned: compared through converged solutions after Sim(3) alignment.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import lm
+
+
+@dataclass
+class GlobalPositionerOptions:
+    """global_positioning.h:9-54 (+ optimization_base.h:18-23)."""
+
+    generate_random_positions: bool = True
+    generate_random_points: bool = True
+    generate_scales: bool = True
+    optimize_positions: bool = True
+    optimize_points: bool = True
+    optimize_scales: bool = True
+    min_num_view_per_track: int = 3
+    seed: int = 1
+    thres_loss_function: float = 1e-1
+    lm: lm.LmOptions = field(default_factory=lambda: lm.LmOptions(max_num_iterations=100))
+
+
+def mt19937_uniform(seed: int, count: int, low: float, high: float) -> np.ndarray:
+    """`count` draws of std::uniform_real_distribution<double>(low, high) fed by std::mt19937(seed)
+    (libstdc++: generate_canonical<double,53> = (g0 + g1 * 2^32) / 2^64 from two 32-bit outputs)."""
+    rs = np.random.RandomState(seed)  # init_genrand(seed): same stream as std::mt19937(seed)
+    g = rs.randint(0, 2**32, 2 * count, dtype=np.uint32).astype(np.float64)
+    u = (g[0::2] + g[1::2] * 4294967296.0) / 18446744073709551616.0
+    u = np.where(u >= 1.0, np.nextafter(1.0, 0.0), u)
+    return u * (high - low) + low
+
+
+class _GpProblem:
+    def __init__(self, N, cam, pt, v, calibrated, opt: GlobalPositionerOptions, npts):
+        self.N, self.P, self.M = N, npts, cam.shape[0]
+        self.cam, self.pt, self.v = cam, pt, v
+        self.opt = opt
+        self.loss_cal = lm.HuberLoss(opt.thres_loss_function, 1.0)
+        self.loss_unc = lm.HuberLoss(opt.thres_loss_function, 0.5)
+        self.cal = calibrated.astype(bool)
+        # ordering groups of the reference (gp.cc:388-429): scales first, then points
+        self.elimination = [(3 * N + 3 * npts, self.M, 1), (3 * N, npts, 3)]
+
+    def _split(self, x):
+        N, P = self.N, self.P
+        return x[: 3 * N].reshape(N, 3), x[3 * N : 3 * N + 3 * P].reshape(P, 3), x[3 * N + 3 * P :]
+
+    def _res(self, x):
+        c, X, s = self._split(x)
+        d = X[self.pt] - c[self.cam]
+        r = self.v - s[:, None] * d
+        sq = (r * r).sum(1)
+        rho0c, rho1c = self.loss_cal.evaluate(sq)
+        rho0u, rho1u = self.loss_unc.evaluate(sq)
+        rho0 = np.where(self.cal, rho0c, rho0u)
+        rho1 = np.where(self.cal, rho1c, rho1u)
+        return r, d, s, rho0, rho1
+
+    def cost(self, x):
+        _, _, _, rho0, _ = self._res(x)
+        return 0.5 * float(rho0.sum())
+
+    def evaluate(self, x):
+        N, P, M, o = self.N, self.P, self.M, self.opt
+        r, d, s, rho0, rho1 = self._res(x)
+        sw = np.sqrt(rho1)
+        rows = np.arange(3 * M).reshape(M, 3)
+        comp = np.arange(3)[None, :]
+        ri, ci, vi = [], [], []
+        if o.optimize_positions:  # d r / d c = +s I
+            ri.append(rows.ravel())
+            ci.append((3 * self.cam[:, None] + comp).ravel())
+            vi.append(np.repeat(sw * s, 3))
+        if o.optimize_points:  # d r / d X = -s I
+            ri.append(rows.ravel())
+            ci.append((3 * N + 3 * self.pt[:, None] + comp).ravel())
+            vi.append(np.repeat(-sw * s, 3))
+        if o.optimize_scales:  # d r / d s = -(X - c); the first scale is constant (gp.cc:484-489)
+            js = -(sw[:, None] * d)
+            js[0] = 0.0
+            ri.append(rows.ravel())
+            ci.append(np.repeat(3 * N + 3 * P + np.arange(M), 3))
+            vi.append(js.ravel())
+        n = 3 * N + 3 * P + M
+        if ri:
+            J = sp.csr_matrix((np.concatenate(vi), (np.concatenate(ri), np.concatenate(ci))), shape=(3 * M, n))
+        else:
+            J = sp.csr_matrix((3 * M, n))
+        return 0.5 * float(rho0.sum()), (sw[:, None] * r).ravel(), J
+
+    def plus(self, x, delta):
+        y = x + delta
+        off = 3 * self.N + 3 * self.P
+        y[off:] = np.maximum(y[off:], 1e-5)  # SetParameterLowerBound(&scale, 0, 1e-5), gp.cc:373
+        return y
+
+    def x_norm(self, x):
+        return float(np.linalg.norm(x))
+
+    def step_norm(self, x, cand):
+        return float(np.linalg.norm(cand - x))
+
+
+def solve(num_cams, pt_offset, obs_cam, obs_dir, obs_calibrated, cam_center, pt_xyz,
+          options: GlobalPositionerOptions | None = None):
+    """Returns (ok, cam_center [N,3], pt_xyz [P,3], LmSummary).  Arrays follow glomap_amd.flat.GpProblem."""
+    opt = options or GlobalPositionerOptions()
+    N = int(num_cams)
+    pt_offset = np.asarray(pt_offset, dtype=np.int64)
+    P_all = pt_offset.shape[0] - 1
+    lens = np.diff(pt_offset)
+    used = lens >= opt.min_num_view_per_track  # gp.cc:258
+    obs_pt_all = np.repeat(np.arange(P_all), lens)
+    keep = used[obs_pt_all]
+    remap = -np.ones(P_all, dtype=np.int64)
+    remap[used] = np.arange(int(used.sum()))
+    cam = np.asarray(obs_cam, dtype=np.int64)[keep]
+    pt = remap[obs_pt_all[keep]]
+    v = np.asarray(obs_dir, dtype=np.float64)[keep]
+    cal = np.ones(cam.shape[0], dtype=np.uint8) if obs_calibrated is None else np.asarray(obs_calibrated)[keep]
+    P = int(used.sum())
+    M = cam.shape[0]
+    c = np.array(cam_center, dtype=np.float64, copy=True)
+    X_all = np.array(pt_xyz, dtype=np.float64, copy=True)
+    if M == 0:
+        return False, c, X_all, lm.LmSummary(usable=False)
+
+    constrained = np.zeros(N, dtype=bool)
+    constrained[cam] = True
+    n_draw = 0
+    if opt.generate_random_positions and opt.optimize_positions:
+        n_draw += 3 * int(constrained.sum())
+    if opt.generate_random_points and opt.optimize_points:
+        n_draw += 3 * P
+    u = mt19937_uniform(opt.seed, n_draw, -1.0, 1.0)
+    k = 0
+    if opt.generate_random_positions and opt.optimize_positions:
+        nc = int(constrained.sum())
+        c[constrained] = 100.0 * u[: 3 * nc].reshape(nc, 3)
+        k = 3 * nc
+    X = X_all[used].copy()
+    if opt.generate_random_points and opt.optimize_points:
+        X = 100.0 * u[k : k + 3 * P].reshape(P, 3)
+    s = np.ones(M)
+    if not opt.generate_scales:
+        # gp.cc:300-305 (only for already-initialised tracks; the flat API treats all as initialised)
+        d = X[pt] - c[cam]
+        s = np.maximum(1e-5, (v * d).sum(1) / (d * d).sum(1))
+
+    prob = _GpProblem(N, cam, pt, v, cal, opt, P)
+    x0 = np.concatenate([c.ravel(), X.ravel(), s])
+    x, summ = lm.solve(prob, x0, opt.lm)
+    c_out, X_out, _ = prob._split(x)
+    X_all[used] = X_out
+    return summ.usable, c_out.copy(), X_all, summ

@@ -101,17 +101,14 @@ def test_ra_config2_full_size_properties(gsfm_ctx):
 
 
 def test_ra_device_resident_inputs(gsfm_ctx):
-    import torch
-
     p = synthetic.make_ring_view_graph(200, 10, seed=4)
     rc, rot_h, _ = estimators.ra_solve(p, ctx=gsfm_ctx)
-    dev = torch.device("cuda:0")
     pd = synthetic.make_ring_view_graph(200, 10, seed=4)
     for name in ("edge_i", "edge_j", "edge_q", "edge_weight", "edge_ninl", "node_aa0"):
-        setattr(pd, name, torch.from_numpy(getattr(pd, name)).to(dev))
+        setattr(pd, name, gsfm_ctx.to_device(getattr(pd, name)))
     rc, rot_d, _ = estimators.ra_solve(pd, ctx=gsfm_ctx)
     assert rc == 0
-    assert np.array_equal(rot_d.cpu().numpy(), rot_h)
+    assert np.array_equal(rot_d.numpy(), rot_h)
 
 
 def test_scene_level_rotation_estimator(gsfm_ctx):
