@@ -1,0 +1,136 @@
+// camera.hpp — COLMAP camera models (ImgFromCam) with analytic derivatives, device side.
+//
+// Replaces the autodiff of colmap::ReprojErrorCostFunctor<CameraModel> that the reference
+// instantiates through colmap::CreateCameraCostFunction (glomap/estimators/bundle_adjustment.cc:135-146).
+// COLMAP (pinned b6b7b54e, thirdparty/CMakeLists.txt:23-28) is un-vendored; the models follow
+// their published definitions (colmap/sensor/models.h), parameter order as in COLMAP:
+//   SIMPLE_PINHOLE f,cx,cy | PINHOLE fx,fy,cx,cy | SIMPLE_RADIAL f,cx,cy,k | RADIAL f,cx,cy,k1,k2
+//   OPENCV fx,fy,cx,cy,k1,k2,p1,p2
+#pragma once
+
+#include "../../include/gsfm.h"
+#include "linalg.hpp"
+
+namespace gsfm {
+
+struct ObsGeom {
+  V3 a;             // R X  (camera-frame point minus translation)
+  double px, py;    // projected pixel
+  double Jx[2][3];  // d pixel / d x_cam
+  double Jp[2][8];  // d pixel / d params
+  bool valid;       // point in front of the camera; otherwise residual and Jacobians are zero
+};
+
+// pixel = f(u, v; params) and its derivatives w.r.t. (u, v) -> Juv[4] = {du/du, du/dv, dv/du, dv/dv}
+__device__ __forceinline__ void distort_project(int model, const double* __restrict__ p, double u, double v,
+                                                double& px, double& py, double (&Juv)[4], double (&Jp)[2][8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    Jp[0][j] = 0.0;
+    Jp[1][j] = 0.0;
+  }
+  const double r2 = u * u + v * v;
+  switch (model) {
+    case GSFM_CAMERA_SIMPLE_PINHOLE: {
+      const double f = p[0];
+      px = f * u + p[1];
+      py = f * v + p[2];
+      Juv[0] = f; Juv[1] = 0.0; Juv[2] = 0.0; Juv[3] = f;
+      Jp[0][0] = u; Jp[1][0] = v;
+      Jp[0][1] = 1.0; Jp[1][2] = 1.0;
+      break;
+    }
+    case GSFM_CAMERA_PINHOLE: {
+      px = p[0] * u + p[2];
+      py = p[1] * v + p[3];
+      Juv[0] = p[0]; Juv[1] = 0.0; Juv[2] = 0.0; Juv[3] = p[1];
+      Jp[0][0] = u; Jp[1][1] = v;
+      Jp[0][2] = 1.0; Jp[1][3] = 1.0;
+      break;
+    }
+    case GSFM_CAMERA_SIMPLE_RADIAL:
+    case GSFM_CAMERA_RADIAL: {
+      const double f = p[0], k1 = p[3];
+      const double k2 = model == GSFM_CAMERA_RADIAL ? p[4] : 0.0;
+      const double rad = k1 * r2 + k2 * r2 * r2;
+      const double drad = k1 + 2.0 * k2 * r2;
+      const double ud = u * (1.0 + rad), vd = v * (1.0 + rad);
+      px = f * ud + p[1];
+      py = f * vd + p[2];
+      Juv[0] = f * (1.0 + rad + 2.0 * u * u * drad);
+      Juv[1] = f * (2.0 * u * v * drad);
+      Juv[2] = Juv[1];
+      Juv[3] = f * (1.0 + rad + 2.0 * v * v * drad);
+      Jp[0][0] = ud; Jp[1][0] = vd;
+      Jp[0][1] = 1.0; Jp[1][2] = 1.0;
+      Jp[0][3] = f * u * r2; Jp[1][3] = f * v * r2;
+      if (model == GSFM_CAMERA_RADIAL) {
+        Jp[0][4] = f * u * r2 * r2;
+        Jp[1][4] = f * v * r2 * r2;
+      }
+      break;
+    }
+    default: {  // GSFM_CAMERA_OPENCV
+      const double fx = p[0], fy = p[1], k1 = p[4], k2 = p[5], p1 = p[6], p2 = p[7];
+      const double rad = k1 * r2 + k2 * r2 * r2;
+      const double drad = k1 + 2.0 * k2 * r2;
+      const double du = u * rad + 2.0 * p1 * u * v + p2 * (r2 + 2.0 * u * u);
+      const double dv = v * rad + 2.0 * p2 * u * v + p1 * (r2 + 2.0 * v * v);
+      px = fx * (u + du) + p[2];
+      py = fy * (v + dv) + p[3];
+      Juv[0] = fx * (1.0 + rad + 2.0 * u * u * drad + 2.0 * p1 * v + 6.0 * p2 * u);
+      Juv[1] = fx * (2.0 * u * v * drad + 2.0 * p1 * u + 2.0 * p2 * v);
+      Juv[2] = fy * (2.0 * u * v * drad + 2.0 * p2 * v + 2.0 * p1 * u);
+      Juv[3] = fy * (1.0 + rad + 2.0 * v * v * drad + 2.0 * p2 * u + 6.0 * p1 * v);
+      Jp[0][0] = u + du; Jp[1][1] = v + dv;
+      Jp[0][2] = 1.0; Jp[1][3] = 1.0;
+      Jp[0][4] = fx * u * r2; Jp[1][4] = fy * v * r2;
+      Jp[0][5] = fx * u * r2 * r2; Jp[1][5] = fy * v * r2 * r2;
+      Jp[0][6] = fx * 2.0 * u * v; Jp[1][6] = fy * (r2 + 2.0 * v * v);
+      Jp[0][7] = fx * (r2 + 2.0 * u * u); Jp[1][7] = fy * 2.0 * u * v;
+      break;
+    }
+  }
+}
+
+// x_cam = R X + t; pixel = ImgFromCam(params, x_cam).  R9 row-major.
+__device__ __forceinline__ void obs_geom(const double* __restrict__ R9, const double* __restrict__ t3, const V3& X,
+                                         int model, const double* __restrict__ par, ObsGeom& g) {
+  g.a = V3{R9[0] * X.x + R9[1] * X.y + R9[2] * X.z, R9[3] * X.x + R9[4] * X.y + R9[5] * X.z,
+           R9[6] * X.x + R9[7] * X.y + R9[8] * X.z};
+  const double xc = g.a.x + t3[0], yc = g.a.y + t3[1], zc = g.a.z + t3[2];
+  g.valid = zc > 2.220446049250313e-16;
+  const double iz = 1.0 / (g.valid ? zc : 1.0);
+  const double u = xc * iz, v = yc * iz;
+  double Juv[4];
+  distort_project(model, par, u, v, g.px, g.py, Juv, g.Jp);
+  // d(u,v)/d x_cam = [1/z, 0, -u/z; 0, 1/z, -v/z]
+  g.Jx[0][0] = Juv[0] * iz;
+  g.Jx[0][1] = Juv[1] * iz;
+  g.Jx[0][2] = -(Juv[0] * u + Juv[1] * v) * iz;
+  g.Jx[1][0] = Juv[2] * iz;
+  g.Jx[1][1] = Juv[3] * iz;
+  g.Jx[1][2] = -(Juv[2] * u + Juv[3] * v) * iz;
+}
+
+__device__ __forceinline__ V3 cross(const V3& a, const V3& b) {
+  return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+// Jx w  (2-vector) and Jx^T g (3-vector)
+__device__ __forceinline__ void jx_mul(const double (&Jx)[2][3], const V3& w, double& o0, double& o1) {
+  o0 = Jx[0][0] * w.x + Jx[0][1] * w.y + Jx[0][2] * w.z;
+  o1 = Jx[1][0] * w.x + Jx[1][1] * w.y + Jx[1][2] * w.z;
+}
+__device__ __forceinline__ V3 jxT_mul(const double (&Jx)[2][3], double g0, double g1) {
+  return V3{Jx[0][0] * g0 + Jx[1][0] * g1, Jx[0][1] * g0 + Jx[1][1] * g1, Jx[0][2] * g0 + Jx[1][2] * g1};
+}
+__device__ __forceinline__ V3 R_mul(const double* __restrict__ R9, const V3& v) {
+  return V3{R9[0] * v.x + R9[1] * v.y + R9[2] * v.z, R9[3] * v.x + R9[4] * v.y + R9[5] * v.z,
+            R9[6] * v.x + R9[7] * v.y + R9[8] * v.z};
+}
+__device__ __forceinline__ V3 RT_mul(const double* __restrict__ R9, const V3& v) {
+  return V3{R9[0] * v.x + R9[3] * v.y + R9[6] * v.z, R9[1] * v.x + R9[4] * v.y + R9[7] * v.z,
+            R9[2] * v.x + R9[5] * v.y + R9[8] * v.z};
+}
+
+}  // namespace gsfm

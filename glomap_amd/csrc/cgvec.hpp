@@ -65,7 +65,7 @@ __device__ __forceinline__ double apply_block_jacobi(const BlockJacobi& bj, int 
 
 // x = 0, r = b, z = M^-1 r, p = z, y = y_init_scale * D p  (D = LM damping of the camera block,
 // the part of S that is not produced by the observation sweep).
-__global__ void __launch_bounds__(kCgThreads)
+static __global__ void __launch_bounds__(kCgThreads)
     k_cg_init(int n, const double* __restrict__ b, double* __restrict__ x, double* __restrict__ r,
               double* __restrict__ z, double* __restrict__ p, double* __restrict__ y,
               const double* __restrict__ dvec, BlockJacobi bj, CgState* __restrict__ st,
@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(kCgThreads)
 // One CG iteration given y = S p (complete, all-reduced):
 //   alpha = rz / p.y;  x += alpha p;  r -= alpha y;  z = M^-1 r;  beta = rz' / rz;  p = z + beta p
 //   done when |r| <= tol |b|;  y is re-initialised to D p for the next mat-vec.
-__global__ void __launch_bounds__(kCgThreads)
+static __global__ void __launch_bounds__(kCgThreads)
     k_cg_iter(int n, double* __restrict__ y, double* __restrict__ p, double* __restrict__ x,
               double* __restrict__ r, double* __restrict__ z, const double* __restrict__ dvec,
               BlockJacobi bj, CgState* __restrict__ st, double tol2, double y_init_scale) {

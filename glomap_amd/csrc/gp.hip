@@ -26,47 +26,11 @@
 #include <random>
 
 #include "cgvec.hpp"
+#include "linalg.hpp"
 #include "lm.hpp"
 
 namespace gsfm {
 namespace {
-
-struct V3 {
-  double x, y, z;
-};
-__device__ __forceinline__ V3 ld3(const double* __restrict__ p) { return V3{p[0], p[1], p[2]}; }
-__device__ __forceinline__ void st3(double* __restrict__ p, const V3& v) {
-  p[0] = v.x;
-  p[1] = v.y;
-  p[2] = v.z;
-}
-__device__ __forceinline__ V3 operator+(const V3& a, const V3& b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
-__device__ __forceinline__ V3 operator-(const V3& a, const V3& b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
-__device__ __forceinline__ V3 operator*(double s, const V3& a) { return V3{s * a.x, s * a.y, s * a.z}; }
-__device__ __forceinline__ double dot(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-
-// symmetric 3x3: (xx, xy, xz, yy, yz, zz)
-struct S3 {
-  double xx, xy, xz, yy, yz, zz;
-};
-__device__ __forceinline__ V3 mul(const S3& m, const V3& v) {
-  return V3{m.xx * v.x + m.xy * v.y + m.xz * v.z, m.xy * v.x + m.yy * v.y + m.yz * v.z,
-            m.xz * v.x + m.yz * v.y + m.zz * v.z};
-}
-__device__ __forceinline__ S3 inv3(const S3& m) {
-  const double c00 = m.yy * m.zz - m.yz * m.yz;
-  const double c01 = m.xz * m.yz - m.xy * m.zz;
-  const double c02 = m.xy * m.yz - m.xz * m.yy;
-  const double det = m.xx * c00 + m.xy * c01 + m.xz * c02;
-  const double id = 1.0 / det;
-  return S3{c00 * id, c01 * id, c02 * id, (m.xx * m.zz - m.xz * m.xz) * id, (m.xy * m.xz - m.xx * m.yz) * id,
-            (m.xx * m.yy - m.xy * m.xy) * id};
-}
-// Q v = a (v - beta d (d.v))
-__device__ __forceinline__ V3 applyQ(double a, double beta, const V3& d, const V3& v) {
-  const double k = beta * dot(d, v);
-  return V3{a * (v.x - k * d.x), a * (v.y - k * d.y), a * (v.z - k * d.z)};
-}
 
 struct GpParams {
   int N;
@@ -81,23 +45,6 @@ struct GpParams {
   int opt_c, opt_x, opt_s;
   double lm_lo, lm_hi;
 };
-
-__device__ __forceinline__ void huber(double a, double scale, double sq, double& rho, double& w) {
-  if (sq > a * a) {
-    const double r = sqrt(sq);
-    rho = scale * (2.0 * a * r - a * a);
-    w = scale * (a / r);
-  } else {
-    rho = scale * sq;
-    w = scale;
-  }
-}
-
-__device__ __forceinline__ void atomic_add3(double* p, const V3& v) {
-  unsafeAtomicAdd(p, v.x);
-  unsafeAtomicAdd(p + 1, v.y);
-  unsafeAtomicAdd(p + 2, v.z);
-}
 
 // ---- linearize: cost, robust weights, gradient max-norm, squared column norms ------------------
 // One thread per track.  part[block][2] = {cost, max |g_s|, |g_X|}.

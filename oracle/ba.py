@@ -1,0 +1,309 @@
+"""ORACLE (test infrastructure only — never imported by the product path).
+
+CPU restatement of GLOMAP's global bundle adjustment for trivial rigs:
+
+  problem build   BundleAdjuster::AddPointToCameraConstraints      ba.cc:115-190  (tracks >= min views, ba.cc:122)
+  residual        colmap::ReprojErrorCostFunctor<CameraModel>       via ba.cc:137-146 — COLMAP @ b6b7b54e is
+                  un-vendored; restated from its published definition:
+                  x_c = R(q) X + t;  (u,v) = CameraModel::ImgFromCam(params, x_c);  r = (u,v) - obs   [pixels]
+                  (residual and Jacobian zero when the point is not in front of the camera)
+  camera models   SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL, RADIAL, OPENCV (colmap/sensor/models.h)
+  parameterisation ba.cc:244-317: EigenQuaternionManifold (q <- [sin|d| d/|d|, cos|d|] * q), first
+                  frame constant, optimize_rotations / optimize_translation flags, principal point
+                  frozen by a SubsetManifold unless optimize_principal_point
+  loss            Huber(1 px)                                       bundle_adjustment.h:30,34-36
+  solver          Ceres LM (oracle/lm.py), points eliminated first (ba.cc:204-208)
+
+parity unpinned: compared through converged solutions.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import lm
+
+SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL, RADIAL, OPENCV = 0, 1, 2, 3, 4
+NUM_PARAMS = {0: 3, 1: 4, 2: 4, 3: 5, 4: 8}
+PP_IDXS = {0: (1, 2), 1: (2, 3), 2: (1, 2), 3: (1, 2), 4: (2, 3)}
+MAXP = 8
+
+
+@dataclass
+class BundleAdjusterOptions:
+    """bundle_adjustment.h:12-37 (+ optimization_base.h:18-23)."""
+
+    optimize_rotations: bool = True
+    optimize_translation: bool = True
+    optimize_intrinsics: bool = True
+    optimize_principal_point: bool = False
+    optimize_points: bool = True
+    min_num_view_per_track: int = 3
+    thres_loss_function: float = 1.0
+    lm: lm.LmOptions = field(default_factory=lambda: lm.LmOptions(max_num_iterations=200))
+
+
+def quat_to_rot(q):
+    w, x, y, z = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    R = np.empty(q.shape[:-1] + (3, 3))
+    R[..., 0, 0] = 1 - 2 * (y * y + z * z)
+    R[..., 0, 1] = 2 * (x * y - w * z)
+    R[..., 0, 2] = 2 * (x * z + w * y)
+    R[..., 1, 0] = 2 * (x * y + w * z)
+    R[..., 1, 1] = 1 - 2 * (x * x + z * z)
+    R[..., 1, 2] = 2 * (y * z - w * x)
+    R[..., 2, 0] = 2 * (x * z - w * y)
+    R[..., 2, 1] = 2 * (y * z + w * x)
+    R[..., 2, 2] = 1 - 2 * (x * x + y * y)
+    return R
+
+
+def quat_mul(a, b):
+    aw, ax, ay, az = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
+    bw, bx, by, bz = b[..., 0], b[..., 1], b[..., 2], b[..., 3]
+    return np.stack([aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw], axis=-1)
+
+
+def project(model, params, xc):
+    """ImgFromCam for per-row model ids.  Returns (uv [m,2], J_xc [m,2,3], J_par [m,2,8], valid [m])."""
+    m = xc.shape[0]
+    x, y, z = xc[:, 0], xc[:, 1], xc[:, 2]
+    valid = z > np.finfo(np.float64).eps
+    zs = np.where(valid, z, 1.0)
+    u, v = x / zs, y / zs
+    r2 = u * u + v * v
+    uv = np.zeros((m, 2))
+    Juv = np.zeros((m, 2, 2))  # d(pixel) / d(u, v)
+    Jp = np.zeros((m, 2, MAXP))
+    p = params
+    for mid in np.unique(model):
+        s = model == mid
+        us, vs, r2s = u[s], v[s], r2[s]
+        ps = p[s]
+        if mid == SIMPLE_PINHOLE:
+            f, cx, cy = ps[:, 0], ps[:, 1], ps[:, 2]
+            uv[s] = np.stack([f * us + cx, f * vs + cy], 1)
+            Juv[s, 0, 0] = f
+            Juv[s, 1, 1] = f
+            Jp[s, 0, 0], Jp[s, 1, 0] = us, vs
+            Jp[s, 0, 1] = 1
+            Jp[s, 1, 2] = 1
+        elif mid == PINHOLE:
+            fx, fy, cx, cy = ps[:, 0], ps[:, 1], ps[:, 2], ps[:, 3]
+            uv[s] = np.stack([fx * us + cx, fy * vs + cy], 1)
+            Juv[s, 0, 0] = fx
+            Juv[s, 1, 1] = fy
+            Jp[s, 0, 0] = us
+            Jp[s, 1, 1] = vs
+            Jp[s, 0, 2] = 1
+            Jp[s, 1, 3] = 1
+        elif mid in (SIMPLE_RADIAL, RADIAL):
+            f, cx, cy, k1 = ps[:, 0], ps[:, 1], ps[:, 2], ps[:, 3]
+            k2 = ps[:, 4] if mid == RADIAL else np.zeros_like(k1)
+            rad = k1 * r2s + k2 * r2s * r2s
+            drad = k1 + 2 * k2 * r2s  # d rad / d r2
+            ud, vd = us * (1 + rad), vs * (1 + rad)
+            uv[s] = np.stack([f * ud + cx, f * vd + cy], 1)
+            Juv[s, 0, 0] = f * (1 + rad + 2 * us * us * drad)
+            Juv[s, 0, 1] = f * (2 * us * vs * drad)
+            Juv[s, 1, 0] = f * (2 * us * vs * drad)
+            Juv[s, 1, 1] = f * (1 + rad + 2 * vs * vs * drad)
+            Jp[s, 0, 0], Jp[s, 1, 0] = ud, vd
+            Jp[s, 0, 1] = 1
+            Jp[s, 1, 2] = 1
+            Jp[s, 0, 3], Jp[s, 1, 3] = f * us * r2s, f * vs * r2s
+            if mid == RADIAL:
+                Jp[s, 0, 4], Jp[s, 1, 4] = f * us * r2s * r2s, f * vs * r2s * r2s
+        elif mid == OPENCV:
+            fx, fy, cx, cy, k1, k2, p1, p2 = (ps[:, i] for i in range(8))
+            rad = k1 * r2s + k2 * r2s * r2s
+            drad = k1 + 2 * k2 * r2s
+            du = us * rad + 2 * p1 * us * vs + p2 * (r2s + 2 * us * us)
+            dv = vs * rad + 2 * p2 * us * vs + p1 * (r2s + 2 * vs * vs)
+            uv[s] = np.stack([fx * (us + du) + cx, fy * (vs + dv) + cy], 1)
+            ddu_du = rad + 2 * us * us * drad + 2 * p1 * vs + 6 * p2 * us
+            ddu_dv = 2 * us * vs * drad + 2 * p1 * us + 2 * p2 * vs
+            ddv_du = 2 * us * vs * drad + 2 * p2 * vs + 2 * p1 * us
+            ddv_dv = rad + 2 * vs * vs * drad + 2 * p2 * us + 6 * p1 * vs
+            Juv[s, 0, 0] = fx * (1 + ddu_du)
+            Juv[s, 0, 1] = fx * ddu_dv
+            Juv[s, 1, 0] = fy * ddv_du
+            Juv[s, 1, 1] = fy * (1 + ddv_dv)
+            Jp[s, 0, 0] = us + du
+            Jp[s, 1, 1] = vs + dv
+            Jp[s, 0, 2] = 1
+            Jp[s, 1, 3] = 1
+            Jp[s, 0, 4], Jp[s, 1, 4] = fx * us * r2s, fy * vs * r2s
+            Jp[s, 0, 5], Jp[s, 1, 5] = fx * us * r2s * r2s, fy * vs * r2s * r2s
+            Jp[s, 0, 6], Jp[s, 1, 6] = fx * 2 * us * vs, fy * (r2s + 2 * vs * vs)
+            Jp[s, 0, 7], Jp[s, 1, 7] = fx * (r2s + 2 * us * us), fy * 2 * us * vs
+        else:
+            raise ValueError(f"camera model {mid} not supported")
+    # d(u,v)/d x_c
+    Jn = np.zeros((m, 2, 3))
+    Jn[:, 0, 0] = 1 / zs
+    Jn[:, 0, 2] = -u / zs
+    Jn[:, 1, 1] = 1 / zs
+    Jn[:, 1, 2] = -v / zs
+    Jx = Juv @ Jn
+    return uv, Jx, Jp, valid
+
+
+def free_param_mask(model, opt: BundleAdjusterOptions):
+    """Which entries of each intrinsics block are optimised (ba.cc:273-293)."""
+    K = model.shape[0]
+    mask = np.zeros((K, MAXP), dtype=bool)
+    for k in range(K):
+        n = NUM_PARAMS[int(model[k])]
+        if not opt.optimize_intrinsics and not opt.optimize_principal_point:
+            continue  # SetParameterBlockConstant
+        mask[k, :n] = True
+        if opt.optimize_intrinsics and not opt.optimize_principal_point:
+            mask[k, list(PP_IDXS[int(model[k])])] = False  # SubsetManifold on the principal point
+    return mask
+
+
+class _BaProblem:
+    def __init__(self, N, cam, pt, xy, cam_intr, model, fixed_cam, P, opt):
+        self.N, self.P, self.M = N, P, cam.shape[0]
+        self.cam, self.pt, self.xy = cam, pt, xy
+        self.cam_intr, self.model = cam_intr, model
+        self.K = model.shape[0]
+        self.opt = opt
+        self.loss = lm.HuberLoss(opt.thres_loss_function)
+        self.fmask = free_param_mask(model, opt)
+        # column layout: [6 per pose | free intrinsics | 3 per point]
+        self.intr_col = -np.ones((self.K, MAXP), dtype=np.int64)
+        nfree = int(self.fmask.sum())
+        self.intr_col[self.fmask] = 6 * N + np.arange(nfree)
+        self.pt_col0 = 6 * N + nfree
+        self.n = self.pt_col0 + 3 * P
+        self.rot_free = np.full(N, bool(opt.optimize_rotations))
+        self.trn_free = np.full(N, bool(opt.optimize_translation))
+        if fixed_cam >= 0:
+            self.rot_free[fixed_cam] = False  # ba.cc:261-266
+            self.trn_free[fixed_cam] = False
+        self.elimination = [(self.pt_col0, P, 3)] if opt.optimize_points else []
+
+    def unpack(self, x):
+        N, P, K = self.N, self.P, self.K
+        o = 0
+        q = x[o : o + 4 * N].reshape(N, 4); o += 4 * N
+        t = x[o : o + 3 * N].reshape(N, 3); o += 3 * N
+        X = x[o : o + 3 * P].reshape(P, 3); o += 3 * P
+        intr = x[o : o + MAXP * K].reshape(K, MAXP)
+        return q, t, X, intr
+
+    @staticmethod
+    def pack(q, t, X, intr):
+        return np.concatenate([q.ravel(), t.ravel(), X.ravel(), intr.ravel()])
+
+    def _geom(self, x):
+        q, t, X, intr = self.unpack(x)
+        R = quat_to_rot(q)
+        RX = np.einsum("mij,mj->mi", R[self.cam], X[self.pt])
+        xc = RX + t[self.cam]
+        ik = self.cam_intr[self.cam]
+        uv, Jx, Jp, valid = project(self.model[ik], intr[ik], xc)
+        r = np.where(valid[:, None], uv - self.xy, 0.0)
+        return R, RX, ik, r, Jx, Jp, valid
+
+    def cost(self, x):
+        r = self._geom(x)[3]
+        rho0, _ = self.loss.evaluate((r * r).sum(1))
+        return 0.5 * float(rho0.sum())
+
+    def evaluate(self, x):
+        N, M = self.N, self.M
+        R, RX, ik, r, Jx, Jp, valid = self._geom(x)
+        rho0, rho1 = self.loss.evaluate((r * r).sum(1))
+        sw = np.sqrt(rho1) * valid
+        Jx = Jx * sw[:, None, None]
+        Jp = Jp * sw[:, None, None]
+        # d x_c / d delta_rot = -2 [R X]_x  (EigenQuaternionManifold: rotation by 2|delta| on the left)
+        a = RX
+        skew = np.zeros((M, 3, 3))
+        skew[:, 0, 1], skew[:, 0, 2] = -a[:, 2], a[:, 1]
+        skew[:, 1, 0], skew[:, 1, 2] = a[:, 2], -a[:, 0]
+        skew[:, 2, 0], skew[:, 2, 1] = -a[:, 1], a[:, 0]
+        Jrot = -2.0 * (Jx @ skew) * self.rot_free[self.cam][:, None, None]
+        Jtrn = Jx * self.trn_free[self.cam][:, None, None]
+        Jpt = (Jx @ R[self.cam]) * (1.0 if self.opt.optimize_points else 0.0)
+        rows = np.arange(2 * M).reshape(M, 2)
+        ri, ci, vi = [], [], []
+
+        def add(block, col0):  # block [M,2,w], col0 [M]
+            w = block.shape[2]
+            ri.append(np.repeat(rows[:, :, None], w, axis=2).ravel())
+            ci.append(np.broadcast_to((col0[:, None] + np.arange(w))[:, None, :], (M, 2, w)).ravel())
+            vi.append(block.ravel())
+
+        add(Jrot, 6 * self.cam)
+        add(Jtrn, 6 * self.cam + 3)
+        add(Jpt, self.pt_col0 + 3 * self.pt)
+        cols = self.intr_col[ik]  # [M,8], -1 where constant
+        for j in range(MAXP):
+            sel = cols[:, j] >= 0
+            if not sel.any():
+                continue
+            ri.append(rows[sel].ravel())
+            ci.append(np.repeat(cols[sel, j], 2))
+            vi.append(Jp[sel, :, j].ravel())
+        J = sp.csr_matrix((np.concatenate(vi), (np.concatenate(ri), np.concatenate(ci))), shape=(2 * M, self.n))
+        return 0.5 * float(rho0.sum()), (sw[:, None] * r).ravel(), J
+
+    def plus(self, x, delta):
+        N = self.N
+        q, t, X, intr = (a.copy() for a in self.unpack(x))
+        d = delta[: 6 * N].reshape(N, 6)
+        dr = d[:, :3]
+        nrm = np.linalg.norm(dr, axis=1)
+        safe = np.where(nrm > 0, nrm, 1.0)
+        k = np.where(nrm > 0, np.sin(nrm) / safe, 1.0)
+        qd = np.concatenate([np.cos(nrm)[:, None], k[:, None] * dr], axis=1)
+        q = quat_mul(qd, q)
+        t = t + d[:, 3:]
+        X = X + delta[self.pt_col0 :].reshape(-1, 3)
+        free = self.fmask
+        intr[free] += delta[6 * N : self.pt_col0]
+        return self.pack(q, t, X, intr)
+
+    def x_norm(self, x):
+        return float(np.linalg.norm(x))
+
+    def step_norm(self, x, cand):
+        return float(np.linalg.norm(cand - x))
+
+
+def solve(num_cams, pt_offset, obs_cam, obs_xy, cam_intr, intr_model, fixed_cam, cam_q, cam_t, pt_xyz,
+          intr_params, options: BundleAdjusterOptions | None = None):
+    """Returns (ok, q [N,4], t [N,3], X [P,3], intr [K,8], LmSummary); arrays as glomap_amd.flat.BaProblem."""
+    opt = options or BundleAdjusterOptions()
+    N = int(num_cams)
+    pt_offset = np.asarray(pt_offset, dtype=np.int64)
+    lens = np.diff(pt_offset)
+    P_all = lens.shape[0]
+    used = lens >= opt.min_num_view_per_track  # ba.cc:122
+    obs_pt_all = np.repeat(np.arange(P_all), lens)
+    keep = used[obs_pt_all]
+    remap = -np.ones(P_all, dtype=np.int64)
+    remap[used] = np.arange(int(used.sum()))
+    cam = np.asarray(obs_cam, dtype=np.int64)[keep]
+    pt = remap[obs_pt_all[keep]]
+    xy = np.asarray(obs_xy, dtype=np.float64)[keep]
+    X_all = np.array(pt_xyz, dtype=np.float64, copy=True)
+    q0 = np.array(cam_q, dtype=np.float64, copy=True)
+    t0 = np.array(cam_t, dtype=np.float64, copy=True)
+    intr0 = np.array(intr_params, dtype=np.float64, copy=True)
+    if cam.shape[0] == 0:
+        return False, q0, t0, X_all, intr0, lm.LmSummary(usable=False)
+    prob = _BaProblem(N, cam, pt, xy, np.asarray(cam_intr, dtype=np.int64), np.asarray(intr_model, dtype=np.int64),
+                      int(fixed_cam), int(used.sum()), opt)
+    x0 = prob.pack(q0, t0, X_all[used], intr0)
+    x, summ = lm.solve(prob, x0, opt.lm)
+    q, t, X, intr = prob.unpack(x)
+    X_all[used] = X
+    return summ.usable, q.copy(), t.copy(), X_all, intr.copy(), summ

@@ -67,6 +67,10 @@ def test_gp_fixed_positions_points_only(gsfm_ctx):
     assert rc == 0
     assert np.array_equal(c_g, p.gt_center)
     used = np.diff(p.pt_offset) >= 3
+    # the first used track carries the constant (gauge) scale s = 1 (gp.cc:484-489), which with
+    # fixed cameras pins that point at unit distance: exclude it
+    first = int(np.argmax(used))
+    used[first] = False
     assert np.abs(X_g[used] - p.gt_xyz[used]).max() < 1e-6
 
 

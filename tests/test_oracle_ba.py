@@ -1,0 +1,103 @@
+"""Oracle (CPU restatement) of global bundle adjustment: analytic reprojection Jacobians checked by
+finite differences for every camera model, and ground-truth recovery with the reference's
+tolerances (glomap/controllers/global_mapper_test.cc:82-86: 1e-2 deg, 1e-4 centre, noise-free)."""
+import numpy as np
+import pytest
+
+from glomap_amd import so3, synthetic
+from oracle import ba
+
+
+def _set_model(p, name):
+    if name == "opencv":
+        p.intr_model[:] = ba.OPENCV
+        p.intr_params[:, :8] = [1200, 1190, 640, 480, 0.02, -0.01, 0.001, -0.002]
+    elif name == "pinhole":
+        p.intr_model[:] = ba.PINHOLE
+        p.intr_params[:] = 0
+        p.intr_params[:, :4] = [1200, 1190, 640, 480]
+    elif name == "radial":
+        p.intr_model[:] = ba.RADIAL
+        p.intr_params[:] = 0
+        p.intr_params[:, :5] = [1200, 640, 480, 0.02, -0.01]
+    elif name == "simple_pinhole":
+        p.intr_model[:] = ba.SIMPLE_PINHOLE
+        p.intr_params[:] = 0
+        p.intr_params[:, :3] = [1200, 640, 480]
+
+
+def _problem(p, opt, fixed=-1):
+    lens = np.diff(p.pt_offset)
+    used = lens >= opt.min_num_view_per_track
+    sel = np.repeat(used, lens)
+    pt = (np.cumsum(used) - 1)[np.repeat(np.arange(p.num_pts), lens)][sel]
+    prob = ba._BaProblem(p.num_cams, p.obs_cam.astype(np.int64)[sel], pt, p.obs_xy[sel], p.cam_intr.astype(np.int64),
+                         p.intr_model.astype(np.int64), fixed, int(used.sum()), opt)
+    return prob, prob.pack(p.cam_q, p.cam_t, p.pt_xyz[used], p.intr_params)
+
+
+@pytest.mark.parametrize("model", ["simple_radial", "opencv", "pinhole", "radial", "simple_pinhole"])
+def test_analytic_jacobian_matches_finite_differences(model):
+    p = synthetic.make_ba_problem(num_cams=8, num_pts=60, seed=1, pixel_noise=0.0, outlier_ratio=0.0,
+                                  shared_intrinsics=(model != "simple_radial"))
+    _set_model(p, model)
+    opt = ba.BundleAdjusterOptions(thres_loss_function=1e9, optimize_principal_point=True)
+    prob, x0 = _problem(p, opt)
+    _, _, J = prob.evaluate(x0)
+    d = np.random.default_rng(0).normal(size=prob.n) * 1e-6
+    num = (prob.evaluate(prob.plus(x0, d))[1] - prob.evaluate(prob.plus(x0, -d))[1]) / 2
+    ana = J @ d
+    assert np.abs(num - ana).max() < 1e-8 * np.abs(ana).max()
+
+
+def test_parameterisation_masks():
+    p = synthetic.make_ba_problem(num_cams=6, num_pts=40, seed=2)
+    # default: principal point frozen (ba.cc:273-285), first frame constant (ba.cc:261-266)
+    prob, x0 = _problem(p, ba.BundleAdjusterOptions(), fixed=0)
+    _, _, J = prob.evaluate(x0)
+    colsq = np.asarray(J.multiply(J).sum(0)).ravel()
+    assert np.all(colsq[:6] == 0) and np.all(colsq[6:12] > 0)
+    assert prob.fmask[0].tolist() == [True, False, False, True, False, False, False, False]
+    # optimize_rotations = false (stage 1 of each BA round, global_mapper.cc:208)
+    prob, x0 = _problem(p, ba.BundleAdjusterOptions(optimize_rotations=False), fixed=0)
+    colsq = np.asarray(prob.evaluate(x0)[2].multiply(prob.evaluate(x0)[2]).sum(0)).ravel()
+    assert np.all(colsq[: 6 * p.num_cams].reshape(-1, 6)[:, :3] == 0)
+    # intrinsics constant
+    assert not ba.free_param_mask(p.intr_model, ba.BundleAdjusterOptions(optimize_intrinsics=False)).any()
+
+
+def _solve(p, **kw):
+    opt = ba.BundleAdjusterOptions(**kw)
+    return ba.solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_xy, p.cam_intr, p.intr_model, p.fixed_cam, p.cam_q,
+                    p.cam_t, p.pt_xyz, p.intr_params, opt)
+
+
+def _centers(q, t):
+    R = so3.quat_to_rotmat(q)
+    return -np.einsum("nji,nj->ni", R, t), R
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_without_noise_recovers_ground_truth(shared):
+    p = synthetic.make_ba_problem(num_cams=20, num_pts=400, seed=0, pixel_noise=0.0, outlier_ratio=0.0,
+                                  shared_intrinsics=shared, intr_noise=0.01)
+    ok, q, t, X, intr, s = _solve(p)
+    assert ok and s.final_cost < 1e-8
+    c, R = _centers(q, t)
+    cg, Rg = _centers(p.gt_q, p.gt_t)
+    assert synthetic.center_errors_after_sim3(c, cg).max() < 1e-4
+    assert synthetic.rotation_errors_deg(R, Rg).max() < 1e-2
+    assert np.abs(intr[:, 0] - 1200).max() < 1e-3
+
+
+def test_with_noise_and_outliers_two_stage():
+    # the controller runs positions-only then full BA (global_mapper.cc:201-223)
+    p = synthetic.make_ba_problem(num_cams=25, num_pts=600, seed=3)
+    ok, q, t, X, intr, s1 = _solve(p, optimize_rotations=False)
+    assert ok and np.allclose(q, p.cam_q)
+    p.cam_t, p.pt_xyz, p.intr_params = t, X, intr
+    ok, q, t, X, intr, s2 = _solve(p)
+    assert ok and s2.final_cost <= s1.final_cost
+    c, R = _centers(q, t)
+    cg, Rg = _centers(p.gt_q, p.gt_t)
+    assert synthetic.center_errors_after_sim3(c, cg).max() < 0.1 and synthetic.rotation_errors_deg(R, Rg).max() < 0.1
