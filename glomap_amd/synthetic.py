@@ -110,34 +110,43 @@ def _ball_points(rng, P, radius):
     return d * r[:, None]
 
 
-def _sample_tracks(rng, centers, R_cw, X, mean_extra, min_len=3, max_len=100, half_fov_deg=30.0, ncand=None):
+def _sample_tracks(rng, centers, R_cw, X, mean_extra, min_len=3, max_len=100, half_fov_deg=30.0, ncand=None,
+                   chunk=65536):
     """Pick, per point, L = min(min_len + Poisson(mean_extra), max_len) distinct cameras that see it
     inside the field of view.  Returns CSR (pt_offset, obs_cam) in track-major order; points that
     end up with fewer than ``min_len`` views keep what they have (the estimators skip them,
-    reference gp.cc:258 / ba.cc:122)."""
+    reference gp.cc:258 / ba.cc:122).  Points are processed in fixed-size chunks (bounded memory;
+    the chunk size is part of the definition of the sequence for a given seed)."""
     P = X.shape[0]
     N = centers.shape[0]
-    L = np.minimum(min_len + rng.poisson(mean_extra, P), min(max_len, N))
-    if ncand is None:
-        ncand = int(min(N, max(16, 3 * int(L.max()))))
-    cand = rng.integers(0, N, (P, ncand))
-    cand.sort(axis=1)
-    dup = np.zeros_like(cand, dtype=bool)
-    dup[:, 1:] = cand[:, 1:] == cand[:, :-1]
-    d = X[:, None, :] - centers[cand]  # [P,ncand,3]
-    depth = np.einsum("pkj,pkj->pk", d, R_cw[cand][:, :, 2, :])
-    nrm = np.linalg.norm(d, axis=2)
-    vis = (depth > np.cos(np.radians(half_fov_deg)) * nrm) & ~dup
-    # random order among the visible candidates, invisible ones last
-    score = rng.random((P, ncand)) + (~vis) * 10.0
-    order = np.argsort(score, axis=1)
-    cand = np.take_along_axis(cand, order, axis=1)
-    vis = np.take_along_axis(vis, order, axis=1)
-    take = (np.arange(ncand)[None, :] < L[:, None]) & vis
-    counts = take.sum(axis=1)
+    cosfov = np.cos(np.radians(half_fov_deg))
+    zaxis = np.ascontiguousarray(R_cw[:, 2, :])
+    counts_all = np.zeros(P, dtype=np.int64)
+    cams_all = []
+    for p0 in range(0, P, chunk):
+        Xc = X[p0 : p0 + chunk]
+        Pc = Xc.shape[0]
+        L = np.minimum(min_len + rng.poisson(mean_extra, Pc), min(max_len, N))
+        nc = ncand if ncand is not None else int(min(N, max(16, 3 * int(L.max()))))
+        cand = rng.integers(0, N, (Pc, nc))
+        cand.sort(axis=1)
+        dup = np.zeros_like(cand, dtype=bool)
+        dup[:, 1:] = cand[:, 1:] == cand[:, :-1]
+        d = Xc[:, None, :] - centers[cand]  # [Pc,nc,3]
+        depth = np.einsum("pkj,pkj->pk", d, zaxis[cand])
+        nrm = np.linalg.norm(d, axis=2)
+        vis = (depth > cosfov * nrm) & ~dup
+        # random order among the visible candidates, invisible ones last
+        score = rng.random((Pc, nc)) + (~vis) * 10.0
+        order = np.argsort(score, axis=1)
+        cand = np.take_along_axis(cand, order, axis=1)
+        vis = np.take_along_axis(vis, order, axis=1)
+        take = (np.arange(nc)[None, :] < L[:, None]) & vis
+        counts_all[p0 : p0 + Pc] = take.sum(axis=1)
+        cams_all.append(cand[take].astype(np.int32))  # row-major boolean indexing == track-major
     pt_offset = np.zeros(P + 1, dtype=np.int64)
-    np.cumsum(counts, out=pt_offset[1:])
-    obs_cam = cand[take].astype(np.int32)  # row-major boolean indexing == track-major
+    np.cumsum(counts_all, out=pt_offset[1:])
+    obs_cam = np.concatenate(cams_all) if cams_all else np.zeros(0, dtype=np.int32)
     return pt_offset, obs_cam
 
 

@@ -116,7 +116,9 @@ def test_ba_two_stage_like_global_mapper(gsfm_ctx):
 def test_ba_config4_scaled_properties(gsfm_ctx):
     """C4-shaped problem at 1/20 scale (500 cameras / 50k tracks / ~250k observations): converges,
     reduces the cost by orders of magnitude, recovers ground truth to the reference's noisy tolerance."""
-    p = synthetic.make_ba_problem(num_cams=500, num_pts=50_000, seed=0)
+    # shared intrinsics: with one free focal length per image the synthetic scene (all cameras
+    # looking at a compact ball) leaves depth / focal weakly determined, which tests noise, not BA
+    p = synthetic.make_ba_problem(num_cams=500, num_pts=50_000, seed=0, shared_intrinsics=True)
     rc, q, t, X, intr, rep = estimators.ba_solve(p, ctx=gsfm_ctx)
     print(rep)
     assert rc == 0 and rep["termination"] == 0
