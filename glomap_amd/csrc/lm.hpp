@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "common.hpp"
 
@@ -62,6 +63,8 @@ inline int lm_minimize(LmProblem& prob, const gsfm_lm_options& o, gsfm_report* r
   bool usable = true;
   double radius = o.initial_trust_region_radius;
   double decrease_factor = 2.0;
+  const bool verbose = std::getenv("GSFM_VERBOSE") != nullptr;  // like minimizer_progress_to_stdout
+  if (verbose) fprintf(stderr, "[gsfm lm] it 0 cost %.9e gmax %.3e\n", cost, gmax);
   if (!(gmax > o.gradient_tolerance)) {
     termination = GSFM_TERM_CONVERGENCE;
   } else {
@@ -79,6 +82,9 @@ inline int lm_minimize(LmProblem& prob, const gsfm_lm_options& o, gsfm_report* r
       long lin = 0;
       bool valid = prob.step(radius, &model_change, &cand_cost, &step_norm, &x_norm, &lin);
       lin_total += lin;
+      if (verbose)
+        fprintf(stderr, "[gsfm lm] it %d radius %.3e pcg %ld model %.6e cand %.9e (cost %.9e) step %.3e\n", iterations,
+                radius, lin, model_change, cand_cost, cost, step_norm);
       valid = valid && std::isfinite(model_change) && model_change > 0.0;
       if (!valid) {
         if (++invalid > o.max_num_consecutive_invalid_steps) {
