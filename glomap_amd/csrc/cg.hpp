@@ -1,0 +1,252 @@
+// cg.hpp — preconditioned conjugate gradients on the reduced camera system (GP: 3N unknowns,
+// BA: 6N pose + 8K intrinsics unknowns), single-reduction (Chronopoulos-Gear) form.
+//
+// Replaces the sparse Cholesky of the Schur complement that Ceres' SPARSE_SCHUR performs for the
+// reference (global_positioning.cc:553, bundle_adjustment.cc:95).  The Schur complement is never
+// formed: the solver supplies `apply` = w <- (S + D) z as sweeps over its observations.
+//
+// Why the single-reduction form: classic PCG needs the global scalar p.Ap BEFORE the vector
+// update and r.z AFTER it, i.e. two dependent grid-wide reductions per iteration.  With
+//     w = A z,  gamma = r.z,  delta = z.w,
+//     beta = gamma / gamma_old,  alpha = gamma / (delta - beta gamma / alpha_old),
+//     p = z + beta p,  s = w + beta s,  x += alpha p,  r -= alpha s,  z = M^-1 r
+// both dot products are available right after the mat-vec, so one iteration is
+//     [apply kernels]  ->  k_cg_update
+// with every scalar resident on the device: partial sums go to fixed per-block slots and each
+// consumer block re-reduces them in a fixed order (deterministic; no atomics, no host round trip).
+//
+// Convergence (|r|^2 <= tol^2 |b|^2) is tested by cg_converged(), which the solver calls at the top
+// of its first apply kernel; it raises status->done and every later kernel of the stream returns
+// at once, so the host only polls the status every few iterations.
+//
+// Multi-rank: `apply` produces this rank's share of w and of delta; the solver all-reduces
+// w[0..n] (delta travels in w[n]) over RCCL, then k_cg_update runs redundantly on every rank.
+#pragma once
+
+#include "device.hpp"
+
+namespace gsfm {
+
+constexpr int kCgMaxBlocks = 512;  // grid cap of the vector kernels (k_cg_init / k_cg_update)
+
+struct CgStatus {
+  int done;
+  int iters;
+  int bad;  // non-finite or non-positive curvature encountered
+  int pad;
+  double bb;  // |b|^2
+  double rr;  // |r|^2 of the last tested iterate
+};
+struct CgScal {
+  double gamma;  // r.z of the previous iteration
+  double alpha;  // step length of the previous iteration
+};
+
+// Device view.  Unknown layout: [PB per camera | 8 per intrinsics block]; block-Jacobi blocks are
+// the PB x PB camera blocks (minv + PB*PB*n) followed by 8 x 8 intrinsics blocks.
+struct CgVec {
+  int n = 0;   // PB*N + 8*K
+  int N = 0, K = 0;
+  int nb_update = 1;  // grid of k_cg_init / k_cg_update  (<= kCgMaxBlocks)
+  int nb_apply = 0;   // number of delta partial slots written by `apply`
+  int delta_in_w = 0; // multi-rank: delta was all-reduced into w[n]
+  const double* b = nullptr;
+  double *x = nullptr, *r = nullptr, *z = nullptr, *p = nullptr, *s = nullptr;
+  double* w = nullptr;         // [n + 2]
+  const double* minv = nullptr;
+  double* vpart = nullptr;     // [2][kCgMaxBlocks][2]  (r.z, r.r) partials, double-buffered by iteration parity
+  double* dpart = nullptr;     // [nb_apply] delta partials
+  CgScal* scal = nullptr;      // [2]
+  CgStatus* st = nullptr;
+};
+
+template <int BS>
+__device__ __forceinline__ void cg_block_init(const CgVec& v, long o, const double* __restrict__ m, double& rz,
+                                              double& rr) {
+  double rb[BS];
+#pragma unroll
+  for (int i = 0; i < BS; ++i) rb[i] = v.b[o + i];
+#pragma unroll
+  for (int i = 0; i < BS; ++i) {
+    double zi = 0.0;
+#pragma unroll
+    for (int j = 0; j < BS; ++j) zi += m[i * BS + j] * rb[j];
+    v.x[o + i] = 0.0;
+    v.r[o + i] = rb[i];
+    v.z[o + i] = zi;
+    v.p[o + i] = 0.0;
+    v.s[o + i] = 0.0;
+    rz += rb[i] * zi;
+    rr += rb[i] * rb[i];
+  }
+}
+
+// x = 0, r = b, z = M^-1 b, p = s = 0; partials of (r.z, r.r) into parity slot 0.
+template <int PB, bool HAS_INTR>
+static __global__ void __launch_bounds__(kBlock) k_cg_init(CgVec v) {
+  __shared__ double smem[4 * 2];
+  double acc[2] = {0.0, 0.0};
+  const int nblk = v.N + (HAS_INTR ? v.K : 0);
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += gridDim.x * blockDim.x) {
+    if (b < v.N) {
+      cg_block_init<PB>(v, (long)PB * b, v.minv + (long)PB * PB * b, acc[0], acc[1]);
+    } else if constexpr (HAS_INTR) {
+      const int k = b - v.N;
+      cg_block_init<8>(v, (long)PB * v.N + 8L * k, v.minv + (long)PB * PB * v.N + 64L * k, acc[0], acc[1]);
+    }
+  }
+  block_sum<2>(acc, smem);
+  if (threadIdx.x == 0) {
+    v.vpart[blockIdx.x * 2] = acc[0];
+    v.vpart[blockIdx.x * 2 + 1] = acc[1];
+    if (blockIdx.x == 0) {
+      v.st->done = 0;
+      v.st->iters = 0;
+      v.st->bad = 0;
+      v.st->bb = 0.0;
+      v.st->rr = 0.0;
+      v.scal[0].gamma = 0.0;
+      v.scal[0].alpha = 0.0;
+    }
+  }
+}
+
+// To be called by ALL threads of EVERY block at the top of the first apply kernel of iteration
+// `it` (kBlock threads).  Returns true when the solve is finished (the caller returns).
+__device__ __forceinline__ bool cg_converged(const CgVec& v, int it, double tol2, double* smem /* >= 4*2+2 */) {
+  if (v.st->done) return true;
+  double t[2];
+  reduce_partials<2>(v.vpart + (size_t)(it & 1) * kCgMaxBlocks * 2, v.nb_update, t, smem);
+  const double bb = it == 0 ? t[1] : v.st->bb;
+  const bool finite = isfinite(t[0]) && isfinite(t[1]);
+  const bool done = !finite || t[1] <= tol2 * bb;
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (it == 0) v.st->bb = bb;
+    v.st->rr = t[1];
+    v.st->iters = it;
+    if (!finite) v.st->bad = 1;
+    if (done) v.st->done = 1;
+  }
+  return done;
+}
+
+template <int BS>
+__device__ __forceinline__ void cg_block_update(const CgVec& v, long o, const double* __restrict__ m, double alpha,
+                                                double beta, double& rz, double& rr) {
+  double rn[BS];
+#pragma unroll
+  for (int i = 0; i < BS; ++i) {
+    const double pi = v.z[o + i] + beta * v.p[o + i];
+    const double si = v.w[o + i] + beta * v.s[o + i];
+    v.p[o + i] = pi;
+    v.s[o + i] = si;
+    v.x[o + i] += alpha * pi;
+    rn[i] = v.r[o + i] - alpha * si;
+    v.r[o + i] = rn[i];
+    rr += rn[i] * rn[i];
+  }
+#pragma unroll
+  for (int i = 0; i < BS; ++i) {
+    double zi = 0.0;
+#pragma unroll
+    for (int j = 0; j < BS; ++j) zi += m[i * BS + j] * rn[j];
+    v.z[o + i] = zi;
+    rz += rn[i] * zi;
+  }
+}
+
+// One CG iteration given w = A z (complete) and the delta partials.
+template <int PB, bool HAS_INTR>
+static __global__ void __launch_bounds__(kBlock) k_cg_update(CgVec v, int it) {
+  __shared__ double smem[4 * 2 + 2];
+  if (v.st->done) return;
+  double g[2];
+  reduce_partials<2>(v.vpart + (size_t)(it & 1) * kCgMaxBlocks * 2, v.nb_update, g, smem);
+  double delta;
+  if (v.delta_in_w) {
+    delta = v.w[v.n];
+  } else {
+    double d[1];
+    reduce_partials<1>(v.dpart, v.nb_apply, d, smem);
+    delta = d[0];
+  }
+  const double gamma = g[0];
+  const CgScal prev = v.scal[it & 1];
+  double beta = 0.0, denom = delta;
+  if (it > 0) {
+    beta = prev.gamma > 0.0 ? gamma / prev.gamma : 0.0;
+    denom = delta - beta * gamma / prev.alpha;
+  }
+  const bool ok = isfinite(denom) && denom > 0.0 && isfinite(gamma) && gamma >= 0.0;
+  const double alpha = ok ? gamma / denom : 0.0;
+  if (!ok) beta = 0.0;
+  double acc[2] = {0.0, 0.0};
+  const int nblk = v.N + (HAS_INTR ? v.K : 0);
+  if (ok) {
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += gridDim.x * blockDim.x) {
+      if (b < v.N) {
+        cg_block_update<PB>(v, (long)PB * b, v.minv + (long)PB * PB * b, alpha, beta, acc[0], acc[1]);
+      } else if constexpr (HAS_INTR) {
+        const int k = b - v.N;
+        cg_block_update<8>(v, (long)PB * v.N + 8L * k, v.minv + (long)PB * PB * v.N + 64L * k, alpha, beta, acc[0],
+                           acc[1]);
+      }
+    }
+  }
+  block_sum<2>(acc, smem);
+  if (threadIdx.x == 0) {
+    double* out = v.vpart + (size_t)((it + 1) & 1) * kCgMaxBlocks * 2;
+    out[blockIdx.x * 2] = acc[0];
+    out[blockIdx.x * 2 + 1] = acc[1];
+    if (blockIdx.x == 0) {
+      v.scal[(it + 1) & 1].gamma = gamma;
+      v.scal[(it + 1) & 1].alpha = alpha;
+      if (!ok) {
+        // gamma == 0 with a zero residual is plain convergence, anything else is a breakdown
+        if (!(gamma == 0.0 && isfinite(delta))) v.st->bad = 1;
+        v.st->done = 1;
+        v.st->iters = it;
+      }
+    }
+  }
+}
+
+// Single-block reduction of the delta partials into w[n] (multi-rank: w[0..n] is all-reduced next).
+static __global__ void __launch_bounds__(kBlock) k_cg_delta_to_w(CgVec v) {
+  __shared__ double smem[4 + 1];
+  if (v.st->done) return;
+  double d[1];
+  reduce_partials<1>(v.dpart, v.nb_apply, d, smem);
+  if (threadIdx.x == 0) v.w[v.n] = d[0];
+}
+
+// Host driver.  `apply(it)` must enqueue the kernels computing w = A z and the delta partials
+// (its first kernel calls cg_converged); it is also responsible for timing its dominant kernel.
+template <int PB, bool HAS_INTR, typename Apply>
+inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& apply) {
+  hipStream_t s = ctx->stream;
+  const bool multi = ctx->comm.world > 1;
+  v.delta_in_w = multi ? 1 : 0;
+  hipLaunchKernelGGL((k_cg_init<PB, HAS_INTR>), dim3(v.nb_update), dim3(kBlock), 0, s, v);
+  CgStatus* h = reinterpret_cast<CgStatus*>(ctx->h_pinned + 400);
+  const int chunk = 8;
+  for (int it = 0; it < max_iter; ++it) {
+    apply(it);
+    if (multi) {
+      hipLaunchKernelGGL(k_cg_delta_to_w, dim3(1), dim3(kBlock), 0, s, v);
+      allreduce_sum(ctx, v.w, (size_t)v.n + 1);
+    }
+    hipLaunchKernelGGL((k_cg_update<PB, HAS_INTR>), dim3(v.nb_update), dim3(kBlock), 0, s, v, it);
+    if ((it + 1) % chunk == 0 || it == max_iter - 1) {
+      GSFM_HIP_CHECK(hipMemcpyAsync(h, v.st, sizeof(CgStatus), hipMemcpyDeviceToHost, s));
+      GSFM_HIP_CHECK(hipStreamSynchronize(s));
+      GSFM_HIP_CHECK(hipGetLastError());
+      ctx->prof.harvest();
+      if (h->done) return h->iters;
+    }
+  }
+  return max_iter;
+}
+
+}  // namespace gsfm

@@ -122,8 +122,8 @@ struct KernelProfiler {
   std::vector<hipEvent_t> ev;  // 2 * kPool
   std::vector<int> tag;        // kernel id of each used pair
   int used = 0;
-  int64_t launches[GSFM_KERNEL_COUNT] = {0, 0, 0};
-  double total_ms[GSFM_KERNEL_COUNT] = {0, 0, 0};
+  int64_t launches[GSFM_KERNEL_COUNT] = {};
+  double total_ms[GSFM_KERNEL_COUNT] = {};
   bool begin(hipStream_t s, int id) {
     if (!enabled || used >= kPool) return false;
     if (ev.empty()) {

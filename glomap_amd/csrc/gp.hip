@@ -9,7 +9,7 @@
 //   solver     Ceres LM + SPARSE_SCHUR  ->  lm.hpp + nested exact elimination + implicit-Schur PCG:
 //              the M scalar scales are eliminated per observation (1x1), the P points per track (3x3),
 //              leaving the 3N reduced camera system  S dc = -g'  that is never formed: its product
-//              with a vector is one sweep over the observations (k_gp_schur_matvec).
+//              with a vector is two sweeps over the observations (k_gp_phaseA / k_gp_phaseB).
 //
 // Analytic blocks (what Ceres' autodiff produces): dr/dc = s I, dr/dX = -s I, dr/ds = -(X - c) =: -d.
 // After eliminating s_k with damped pivot h_ss = w d.d + D_s each observation acts on (c, X) through
@@ -17,50 +17,72 @@
 //   q_k = s w (r - beta_k d (d.r))                                             (gradient share)
 // so only (a_k, beta_k) are stored per observation; d is recomputed from X_p and c_i.
 //
-// Data layout in HBM (f64 unless noted; observations are track-major):
-//   pt_offset[P+1] i64, obs_cam[M] i32, obs_dir[M][3], obs_cal[M] u8        inputs
-//   c[N][3], X[P][3], s[M] and their candidates                               state
-//   wrob[M], qa[M], qb[M], jss[M] (Jacobi scale of s_k)                       per observation
-//   hinv[P][6], e[P][3], hppd[P], jsx[P], used[P] u8                          per track
-//   hcc[N], jsc[N], dcam[N*3], gc[N*3], gred[N*3], scc[N][6], minv[N][9]      per camera
+// Every reduction is atomic-free and in a fixed order: point-side sums run track-major (one lane
+// per observation + segmented wave scan), camera-side sums run camera-major (one wave per camera)
+// over the second copy of the observation lists that obsgraph.hpp derives once per solve.
+//
+// Data layout in HBM (f64 unless noted):
+//   track-major : pt_offset[P+1] i64, obs_cam[M] i32, obs_dir[M][3], obs_cal[M] u8     inputs
+//                 s[M] (+ candidate), wrob[M], qa[M], qb[M], jss[M]                      per observation
+//   camera-major: coff[N+2], c_src[M], c_pt[M] i32, c_dir[M][3], c_cal[M] u8, c_jss[M]  static per solve
+//                 c_qa[M], c_qb[M]                                                       per LM iteration
+//   per track   : X[P][3] (+ candidate), ptb[P][12] = (X, e, H_pp^-1) build record,
+//                 ptrec[P][8] = (X, t_p, pad) 64-byte PCG record, hppd[P], jsx[P], used[P] u8
+//   per camera  : c[N][3] (+ candidate), hcc[N], jsc[N], dcam[3N], gc[3N], gred[3N], scc[N][6], minv[N][9]
+//   PCG vectors : x, r, z, p, s, w [3N] (cg.hpp)
 #include <random>
 
-#include "cgvec.hpp"
+#include "cg.hpp"
 #include "linalg.hpp"
 #include "lm.hpp"
+#include "obsgraph.hpp"
 
 namespace gsfm {
 namespace {
 
-struct GpParams {
-  int N;
-  long P, M;
-  const long* off;
-  const int* cam;
-  const double* dir;
-  const unsigned char* cal;   // may be null (= all calibrated)
-  const unsigned char* used;  // [P]
-  long fixed_obs;             // observation whose scale is constant (-1: none on this rank)
+struct GpDev {
+  ObsGraph g;
+  const double* dir;            // [M][3]  track-major
+  const unsigned char* cal;     // [M] or null (= all calibrated)
+  const double* c_dir;          // [M][3]  camera-major
+  const unsigned char* c_cal;   // [M] or null
+  const double* c_jss;          // [M]     camera-major copy of the scale Jacobi factors
+  long fixed_obs;               // observation whose scale is constant (-1: none on this rank)
   double huber_a;
   int opt_c, opt_x, opt_s;
   double lm_lo, lm_hi;
 };
 
-// ---- linearize: cost, robust weights, gradient max-norm, squared column norms ------------------
-// One thread per track.  part[block][2] = {cost, max |g_s|, |g_X|}.
+__device__ __forceinline__ double lm_damping(double h, double js, double radius, double lo, double hi) {
+  // clamp(js^2 h, lo, hi) / (radius js^2): the Ceres LM diagonal expressed in unscaled variables
+  const double j2 = js * js;
+  return fmin(fmax(j2 * h, lo), hi) / (radius * j2);
+}
+
+__device__ __forceinline__ double block_max(double v, double* smem /* >= 4 */) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmax(fmax(smem[0], smem[1]), fmax(smem[2], smem[3]));  // valid in every thread
+}
+
+// ---- linearize, point side: cost, robust weights, |g_s|, |g_X| max-norms, H_pp trace ----------
+// One thread per track.  part[block][2] = {cost, max gradient entry}.
 __global__ void __launch_bounds__(kBlock)
-    k_gp_linearize(GpParams g, const double* __restrict__ c, const double* __restrict__ X,
+    k_gp_lin_track(GpDev g, const double* __restrict__ c, const double* __restrict__ X,
                    const double* __restrict__ s, double* __restrict__ wrob, double* __restrict__ hppd,
-                   double* __restrict__ hcc, double* __restrict__ gc, double* __restrict__ part) {
+                   double* __restrict__ part) {
   __shared__ double smem[8];
   double cost = 0.0, gmax = 0.0;
-  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.P; p += (long)gridDim.x * blockDim.x) {
-    if (!g.used[p]) continue;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.g.P; p += (long)gridDim.x * blockDim.x) {
+    if (!g.g.used[p]) continue;
     const V3 Xp = ld3(X + 3 * p);
     double hpp = 0.0;
     V3 gX{0, 0, 0};
-    for (long k = g.off[p]; k < g.off[p + 1]; ++k) {
-      const int n = g.cam[k];
+    for (long k = g.g.off[p]; k < g.g.off[p + 1]; ++k) {
+      const int n = g.g.cam[k];
       const V3 d = Xp - ld3(c + 3 * (long)n);
       const double sk = s[k];
       const V3 r = ld3(g.dir + 3 * k) - sk * d;
@@ -71,26 +93,51 @@ __global__ void __launch_bounds__(kBlock)
       const double ws = w * sk;
       hpp += ws * sk;
       gX = gX - ws * r;
-      if (g.opt_c) {
-        unsafeAtomicAdd(hcc + n, ws * sk);
-        atomic_add3(gc + 3 * (long)n, ws * r);
-      }
       if (g.opt_s && k != g.fixed_obs) gmax = fmax(gmax, fabs(w * dot(d, r)));
     }
     hppd[p] = hpp;
     if (g.opt_x) gmax = fmax(gmax, fmax(fabs(gX.x), fmax(fabs(gX.y), fabs(gX.z))));
   }
-  // block reduce: sum of cost, max of gmax
   double v[1] = {cost};
   block_sum<1>(v, smem);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_down(gmax, off, 64));
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) smem[4 + (threadIdx.x >> 6)] = gmax;
-  __syncthreads();
+  const double m = block_max(gmax, smem + 4);
   if (threadIdx.x == 0) {
     part[blockIdx.x * 2] = v[0];
-    part[blockIdx.x * 2 + 1] = fmax(fmax(smem[4], smem[5]), fmax(smem[6], smem[7]));
+    part[blockIdx.x * 2 + 1] = m;
+  }
+}
+
+// ---- linearize, camera side: h_cc = sum w s^2 (Jacobi scaling / LM diagonal), g_c = sum w s r ----
+// One wave per camera over the camera-major lists; wave reduction, no atomics.
+__global__ void __launch_bounds__(kBlock)
+    k_gp_lin_cam(GpDev g, const double* __restrict__ c, const double* __restrict__ X,
+                 const double* __restrict__ s, double* __restrict__ hcc, double* __restrict__ gc) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (kBlock / 64);
+  for (int n = wave; n < g.g.N; n += nwaves) {
+    const V3 cn = ld3(c + 3 * (long)n);
+    double acc[4] = {0, 0, 0, 0};
+    for (int k = g.g.coff[n] + lane; k < g.g.coff[n + 1]; k += 64) {
+      const long src = g.g.c_src[k];
+      const V3 d = ld3(X + 3 * (long)g.g.c_pt[k]) - cn;
+      const double sk = s[src];
+      const V3 r = ld3(g.c_dir + 3 * (long)k) - sk * d;
+      double rho, w;
+      huber(g.huber_a, (g.c_cal == nullptr || g.c_cal[k]) ? 1.0 : 0.5, dot(r, r), rho, w);
+      const double ws = w * sk;
+      acc[0] += ws * sk;
+      acc[1] += ws * r.x;
+      acc[2] += ws * r.y;
+      acc[3] += ws * r.z;
+    }
+    wave_allsum<4>(acc);
+    if (lane == 0) {
+      hcc[n] = acc[0];
+      gc[3 * (long)n] = acc[1];
+      gc[3 * (long)n + 1] = acc[2];
+      gc[3 * (long)n + 2] = acc[3];
+    }
   }
 }
 
@@ -107,27 +154,27 @@ __global__ void __launch_bounds__(kBlock)
   for (int i = threadIdx.x; i < nvec; i += blockDim.x) gmax = fmax(gmax, fabs(vec[i]));
   double v[1] = {cost};
   block_sum<1>(v, smem);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_down(gmax, off, 64));
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) smem[4 + (threadIdx.x >> 6)] = gmax;
-  __syncthreads();
+  const double m = block_max(gmax, smem + 4);
   if (threadIdx.x == 0) {
     out[0] = v[0];
-    out[1] = fmax(fmax(smem[4], smem[5]), fmax(smem[6], smem[7]));
+    out[1] = m;
   }
 }
 
 // Jacobi scaling 1 / (1 + |J_col|) fixed at the initial point (Ceres jacobi_scaling).
 __global__ void __launch_bounds__(kBlock)
-    k_gp_jacobi_obs(GpParams g, int enabled, const double* __restrict__ c, const double* __restrict__ X,
+    k_gp_jacobi_obs(GpDev g, int enabled, const double* __restrict__ c, const double* __restrict__ X,
                     const double* __restrict__ wrob, const double* __restrict__ hppd,
                     double* __restrict__ jss, double* __restrict__ jsx) {
-  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.P; p += (long)gridDim.x * blockDim.x) {
-    if (!g.used[p]) continue;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.g.P; p += (long)gridDim.x * blockDim.x) {
+    if (!g.g.used[p]) {
+      for (long k = g.g.off[p]; k < g.g.off[p + 1]; ++k) jss[k] = 1.0;
+      jsx[p] = 1.0;
+      continue;
+    }
     const V3 Xp = ld3(X + 3 * p);
-    for (long k = g.off[p]; k < g.off[p + 1]; ++k) {
-      const V3 d = Xp - ld3(c + 3 * (long)g.cam[k]);
+    for (long k = g.g.off[p]; k < g.g.off[p + 1]; ++k) {
+      const V3 d = Xp - ld3(c + 3 * (long)g.g.cam[k]);
       const bool free_s = g.opt_s && k != g.fixed_obs;
       jss[k] = (enabled && free_s) ? 1.0 / (1.0 + sqrt(wrob[k] * dot(d, d))) : 1.0;
     }
@@ -140,27 +187,21 @@ __global__ void __launch_bounds__(kBlock)
     jsc[n] = enabled ? 1.0 / (1.0 + sqrt(hcc[n])) : 1.0;
 }
 
-__device__ __forceinline__ double lm_damping(double h, double js, double radius, double lo, double hi) {
-  // clamp(js^2 h, lo, hi) / (radius js^2): the Ceres LM diagonal expressed in unscaled variables
-  const double j2 = js * js;
-  return fmin(fmax(j2 * h, lo), hi) / (radius * j2);
-}
-
-// ---- build (radius dependent): eliminate scales and points, reduced gradient, S_cc blocks ------
+// ---- build, point side (radius dependent): eliminate scales and points --------------------------
+// One thread per track: (a_k, beta_k) per observation, H_pp^-1 and e = H_pp^-1 g_p per track.
 __global__ void __launch_bounds__(kBlock)
-    k_gp_build(GpParams g, double radius, const double* __restrict__ c, const double* __restrict__ X,
-               const double* __restrict__ s, const double* __restrict__ wrob,
-               const double* __restrict__ jss, const double* __restrict__ jsx,
-               const double* __restrict__ hppd, double* __restrict__ qa, double* __restrict__ qb,
-               double* __restrict__ hinv, double* __restrict__ ept, double* __restrict__ gred,
-               double* __restrict__ scc) {
-  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.P; p += (long)gridDim.x * blockDim.x) {
-    if (!g.used[p]) continue;
+    k_gp_build_track(GpDev g, double radius, const double* __restrict__ c, const double* __restrict__ X,
+                     const double* __restrict__ s, const double* __restrict__ wrob,
+                     const double* __restrict__ jss, const double* __restrict__ jsx,
+                     const double* __restrict__ hppd, double* __restrict__ qa, double* __restrict__ qb,
+                     double* __restrict__ ptb, double* __restrict__ ptrec) {
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.g.P; p += (long)gridDim.x * blockDim.x) {
+    if (!g.g.used[p]) continue;
     const V3 Xp = ld3(X + 3 * p);
     S3 H{0, 0, 0, 0, 0, 0};
     V3 gp{0, 0, 0};
-    for (long k = g.off[p]; k < g.off[p + 1]; ++k) {
-      const V3 d = Xp - ld3(c + 3 * (long)g.cam[k]);
+    for (long k = g.g.off[p]; k < g.g.off[p + 1]; ++k) {
+      const V3 d = Xp - ld3(c + 3 * (long)g.g.cam[k]);
       const double sk = s[k], w = wrob[k];
       const V3 r = ld3(g.dir + 3 * k) - sk * d;
       const double dd = dot(d, d);
@@ -192,38 +233,70 @@ __global__ void __launch_bounds__(kBlock)
       Hi = inv3(H);
       e = mul(Hi, gp);
     }
-    double* hp = hinv + 6 * p;
-    hp[0] = Hi.xx;
-    hp[1] = Hi.xy;
-    hp[2] = Hi.xz;
-    hp[3] = Hi.yy;
-    hp[4] = Hi.yz;
-    hp[5] = Hi.zz;
-    st3(ept + 3 * p, e);
-    if (!g.opt_c) continue;
-    for (long k = g.off[p]; k < g.off[p + 1]; ++k) {
-      const long n = g.cam[k];
-      const V3 d = Xp - ld3(c + 3 * n);
-      const double sk = s[k], w = wrob[k], a = qa[k], beta = qb[k];
-      const V3 r = ld3(g.dir + 3 * k) - sk * d;
-      const V3 q = applyQ(w * sk, beta, d, r);
-      // reduced gradient g'_c = sum_k q_k + Q_k H_pp^-1 g_p
-      atomic_add3(gred + 3 * n, q + applyQ(a, beta, d, e));
-      // diagonal block of S: Q_k - Q_k H_pp^-1 Q_k  (block-Jacobi preconditioner)
+    double* b = ptb + 12 * p;
+    st3(b, Xp);
+    st3(b + 3, e);
+    b[6] = Hi.xx; b[7] = Hi.xy; b[8] = Hi.xz; b[9] = Hi.yy; b[10] = Hi.yz; b[11] = Hi.zz;
+    double* pr = ptrec + 8 * p;
+    st3(pr, Xp);
+    pr[3] = pr[4] = pr[5] = 0.0;
+  }
+}
+
+// ---- build, camera side: (a_k, beta_k) in camera-major order, reduced gradient, S_cc blocks -----
+// One wave per camera.  g'_c = sum_k q_k + Q_k e_p;  S_cc = sum_k Q_k - Q_k H_pp^-1 Q_k.
+__global__ void __launch_bounds__(kBlock)
+    k_gp_build_cam(GpDev g, double radius, const double* __restrict__ c, const double* __restrict__ s,
+                   const double* __restrict__ ptb, double* __restrict__ c_qa, double* __restrict__ c_qb,
+                   double* __restrict__ gred, double* __restrict__ scc) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (kBlock / 64);
+  for (int n = wave; n < g.g.N; n += nwaves) {
+    const V3 cn = ld3(c + 3 * (long)n);
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = g.g.coff[n] + lane; k < g.g.coff[n + 1]; k += 64) {
+      const long src = g.g.c_src[k];
+      const double* b = ptb + 12 * (long)g.g.c_pt[k];
+      const V3 d = ld3(b) - cn;
+      const V3 e = ld3(b + 3);
+      const S3 Hi{b[6], b[7], b[8], b[9], b[10], b[11]};
+      const double sk = s[src];
+      const V3 r = ld3(g.c_dir + 3 * (long)k) - sk * d;
+      double rho, w;
+      huber(g.huber_a, (g.c_cal == nullptr || g.c_cal[k]) ? 1.0 : 0.5, dot(r, r), rho, w);
+      double beta = 0.0;
+      if (g.opt_s && src != g.fixed_obs) {
+        const double hraw = w * dot(d, d);
+        beta = w / (hraw + lm_damping(hraw, g.c_jss[k], radius, g.lm_lo, g.lm_hi));
+      }
+      const double a = w * sk * sk;
+      c_qa[k] = a;
+      c_qb[k] = beta;
+      if (!g.opt_c) continue;
+      const V3 q = applyQ(w * sk, beta, d, r) + applyQ(a, beta, d, e);
+      acc[0] += q.x;
+      acc[1] += q.y;
+      acc[2] += q.z;
       const double ab = a * beta;
       const S3 Q{a - ab * d.x * d.x, -ab * d.x * d.y, -ab * d.x * d.z, a - ab * d.y * d.y, -ab * d.y * d.z,
                  a - ab * d.z * d.z};
-      // columns of Hi Q, then Q (Hi Q)
       const V3 c0 = mul(Q, mul(Hi, V3{Q.xx, Q.xy, Q.xz}));
       const V3 c1 = mul(Q, mul(Hi, V3{Q.xy, Q.yy, Q.yz}));
       const V3 c2 = mul(Q, mul(Hi, V3{Q.xz, Q.yz, Q.zz}));
-      double* sp = scc + 6 * n;
-      unsafeAtomicAdd(sp + 0, Q.xx - c0.x);
-      unsafeAtomicAdd(sp + 1, Q.xy - c1.x);
-      unsafeAtomicAdd(sp + 2, Q.xz - c2.x);
-      unsafeAtomicAdd(sp + 3, Q.yy - c1.y);
-      unsafeAtomicAdd(sp + 4, Q.yz - c2.y);
-      unsafeAtomicAdd(sp + 5, Q.zz - c2.z);
+      acc[3] += Q.xx - c0.x;
+      acc[4] += Q.xy - c1.x;
+      acc[5] += Q.xz - c2.x;
+      acc[6] += Q.yy - c1.y;
+      acc[7] += Q.yz - c2.y;
+      acc[8] += Q.zz - c2.z;
+    }
+    wave_allsum<9>(acc);
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) gred[3 * (long)n + j] = acc[j];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) scc[6 * (long)n + j] = acc[3 + j];
     }
   }
 }
@@ -251,67 +324,116 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
-// ---- the hot kernel: y += (H_cc - H_cp H_pp^-1 H_pc) p over this rank's tracks ----------------
-// One thread per track: first pass t = H_pp^-1 sum_k Q_k p_{c(k)}, second pass
-// y_{c(k)} += Q_k (p_{c(k)} - t).  Algorithmic bytes per launch (SURVEY.md §8d, K-GP-res):
-// 41 M + 48 P + 48 N.  Camera vectors (24 B x N) are L2-resident gathers; the scatter into y uses
-// hardware f64 atomics (global_atomic_add_f64).
+// ---- the hot pair: w = (H_cc - H_cp H_pp^-1 H_pc + D) z ------------------------------------------
+// Phase A, track-major, one lane per observation: t_p = H_pp^-1 sum_k Q_k z_{c(k)} -> ptrec[p].t.
+// Algorithmic bytes per observation: qa, qb (16) + cam (4) + pt (4); per track: 24 written; the
+// camera gathers (c_n, z_n: 48 B) are L2-resident, X_p is read from the track's own 64-byte record.
 __global__ void __launch_bounds__(kBlock)
-    k_gp_schur_matvec(GpParams g, const double* __restrict__ c, const double* __restrict__ X,
-                      const double* __restrict__ qa, const double* __restrict__ qb,
-                      const double* __restrict__ hinv, const double* __restrict__ pvec,
-                      double* __restrict__ y) {
-  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.P; p += (long)gridDim.x * blockDim.x) {
-    if (!g.used[p]) continue;
-    const V3 Xp = ld3(X + 3 * p);
-    const long k0 = g.off[p], k1 = g.off[p + 1];
-    V3 acc{0, 0, 0};
-    for (long k = k0; k < k1; ++k) {
-      const long n = g.cam[k];
-      const V3 d = Xp - ld3(c + 3 * n);
-      acc = acc + applyQ(qa[k], qb[k], d, ld3(pvec + 3 * n));
+    k_gp_phaseA(GpDev g, CgVec v, int it, double tol2, const double* __restrict__ c,
+                const double* __restrict__ qa, const double* __restrict__ qb,
+                const double* __restrict__ ptb, double* __restrict__ ptrec) {
+  __shared__ double smem[4 * 2 + 2];
+  if (cg_converged(v, it, tol2, smem)) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (kBlock / 64);
+  for (int tile = wave; tile < g.g.T; tile += nwaves) {
+    const int p0 = g.g.tile[tile], p1 = g.g.tile[tile + 1];
+    const long k0 = g.g.off[p0], k1 = g.g.off[p1];
+    double acc[3] = {0, 0, 0};
+    int key = -1 - lane;
+    for (long k = k0 + lane; k < k1; k += 64) {
+      const int p = g.g.obs_pt[k];
+      key = p;
+      if (!g.g.used[p]) continue;
+      const long n = g.g.cam[k];
+      const V3 d = ld3(ptrec + 8 * (long)p) - ld3(c + 3 * n);
+      const V3 y = applyQ(qa[k], qb[k], d, ld3(v.z + 3 * n));
+      acc[0] += y.x;
+      acc[1] += y.y;
+      acc[2] += y.z;
     }
-    const double* hp = hinv + 6 * p;
-    const V3 t = mul(S3{hp[0], hp[1], hp[2], hp[3], hp[4], hp[5]}, acc);
-    for (long k = k0; k < k1; ++k) {
-      const long n = g.cam[k];
-      const V3 d = Xp - ld3(c + 3 * n);
-      atomic_add3(y + 3 * n, applyQ(qa[k], qb[k], d, ld3(pvec + 3 * n) - t));
+    seg_scan<3>(acc, key, lane);
+    if (seg_is_tail(key, lane) && key >= 0 && g.g.used[key]) {
+      const double* b = ptb + 12 * (long)key;
+      const V3 t = mul(S3{b[6], b[7], b[8], b[9], b[10], b[11]}, V3{acc[0], acc[1], acc[2]});
+      st3(ptrec + 8 * (long)key + 3, t);
     }
   }
+}
+
+// Phase B, camera-major, one wave per camera: w_n = sum_k Q_k (z_n - t_{p(k)}) + D_n z_n and the
+// partial delta = z.w of this block.  Algorithmic bytes per observation: c_qa, c_qb (16) + c_pt (4)
+// + the 64-byte point record gather (X_p, t_p).
+__global__ void __launch_bounds__(kBlock)
+    k_gp_phaseB(GpDev g, CgVec v, double yscale, const double* __restrict__ c,
+                const double* __restrict__ c_qa, const double* __restrict__ c_qb,
+                const double* __restrict__ ptrec, const double* __restrict__ dcam) {
+  __shared__ double sdelta[kBlock / 64];
+  if (v.st->done) return;
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int wave = blockIdx.x * (kBlock / 64) + wid;
+  const int nwaves = gridDim.x * (kBlock / 64);
+  double delta = 0.0;
+  for (int n = wave; n < g.g.N; n += nwaves) {
+    const V3 cn = ld3(c + 3 * (long)n);
+    const V3 zn = ld3(v.z + 3 * (long)n);
+    double acc[3] = {0, 0, 0};
+    for (int k = g.g.coff[n] + lane; k < g.g.coff[n + 1]; k += 64) {
+      const double* pr = ptrec + 8 * (long)g.g.c_pt[k];
+      const V3 d = ld3(pr) - cn;
+      const V3 y = applyQ(c_qa[k], c_qb[k], d, zn - ld3(pr + 3));
+      acc[0] += y.x;
+      acc[1] += y.y;
+      acc[2] += y.z;
+    }
+    wave_allsum<3>(acc);
+    if (lane == 0) {
+      const double w0 = acc[0] + yscale * dcam[3 * (long)n] * zn.x;
+      const double w1 = acc[1] + yscale * dcam[3 * (long)n + 1] * zn.y;
+      const double w2 = acc[2] + yscale * dcam[3 * (long)n + 2] * zn.z;
+      v.w[3 * (long)n] = w0;
+      v.w[3 * (long)n + 1] = w1;
+      v.w[3 * (long)n + 2] = w2;
+      delta += zn.x * w0 + zn.y * w1 + zn.z * w2;
+    }
+  }
+  if (lane == 0) sdelta[wid] = delta;
+  __syncthreads();
+  if (threadIdx.x == 0) v.dpart[blockIdx.x] = (sdelta[0] + sdelta[1]) + (sdelta[2] + sdelta[3]);
 }
 
 // ---- back-substitution, model cost change, candidate point ------------------------------------
 // part[block][3] = {model_cost_change, |dX|^2 + |ds|^2, |X|^2 + |s|^2}
 __global__ void __launch_bounds__(kBlock)
-    k_gp_backsub(GpParams g, const double* __restrict__ c, const double* __restrict__ X,
+    k_gp_backsub(GpDev g, const double* __restrict__ c, const double* __restrict__ X,
                  const double* __restrict__ s, const double* __restrict__ wrob,
                  const double* __restrict__ qa, const double* __restrict__ qb,
-                 const double* __restrict__ hinv, const double* __restrict__ ept,
-                 const double* __restrict__ dc, double* __restrict__ Xn, double* __restrict__ sn,
-                 double* __restrict__ part) {
+                 const double* __restrict__ ptb, const double* __restrict__ dc, double* __restrict__ Xn,
+                 double* __restrict__ sn, double* __restrict__ part) {
   __shared__ double smem[4 * 3];
   double acc3[3] = {0, 0, 0};
-  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.P; p += (long)gridDim.x * blockDim.x) {
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.g.P; p += (long)gridDim.x * blockDim.x) {
     const V3 Xp = ld3(X + 3 * p);
-    if (!g.used[p]) {
+    if (!g.g.used[p]) {
       st3(Xn + 3 * p, Xp);
-      for (long k = g.off[p]; k < g.off[p + 1]; ++k) sn[k] = s[k];
+      for (long k = g.g.off[p]; k < g.g.off[p + 1]; ++k) sn[k] = s[k];
       continue;
     }
-    const long k0 = g.off[p], k1 = g.off[p + 1];
+    const long k0 = g.g.off[p], k1 = g.g.off[p + 1];
     V3 dX{0, 0, 0};
     if (g.opt_x) {
       V3 acc{0, 0, 0};
       for (long k = k0; k < k1; ++k) {
-        const long n = g.cam[k];
+        const long n = g.g.cam[k];
         acc = acc + applyQ(qa[k], qb[k], Xp - ld3(c + 3 * n), ld3(dc + 3 * n));
       }
-      const double* hp = hinv + 6 * p;
-      dX = mul(S3{hp[0], hp[1], hp[2], hp[3], hp[4], hp[5]}, acc) - ld3(ept + 3 * p);
+      const double* b = ptb + 12 * p;
+      dX = mul(S3{b[6], b[7], b[8], b[9], b[10], b[11]}, acc) - ld3(b + 3);
     }
     for (long k = k0; k < k1; ++k) {
-      const long n = g.cam[k];
+      const long n = g.g.cam[k];
       const V3 d = Xp - ld3(c + 3 * n);
       const double sk = s[k], w = wrob[k];
       const V3 r = ld3(g.dir + 3 * k) - sk * d;
@@ -336,13 +458,13 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
-// cn = c + dc; out (single block) {|dc|^2, |c|^2, #non-finite}
+// cn = c + dc; part[block][3] = {|dc|^2, |c|^2, #non-finite}
 __global__ void __launch_bounds__(kBlock)
     k_gp_cam_update(int n3, const double* __restrict__ c, const double* __restrict__ dc,
-                    double* __restrict__ cn, double* __restrict__ out) {
+                    double* __restrict__ cn, double* __restrict__ part) {
   __shared__ double smem[4 * 3];
   double acc[3] = {0, 0, 0};
-  for (int i = threadIdx.x; i < n3; i += blockDim.x) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += gridDim.x * blockDim.x) {
     const double d = dc[i];
     cn[i] = c[i] + d;
     acc[0] += d * d;
@@ -351,28 +473,25 @@ __global__ void __launch_bounds__(kBlock)
   }
   block_sum<3>(acc, smem);
   if (threadIdx.x == 0) {
-    out[0] = acc[0];
-    out[1] = acc[1];
-    out[2] = acc[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) part[blockIdx.x * 3 + k] = acc[k];
   }
 }
 
-// candidate cost; part[block][1]
+// candidate cost, one lane per observation (coalesced); part[block][1]
 __global__ void __launch_bounds__(kBlock)
-    k_gp_cost(GpParams g, const double* __restrict__ c, const double* __restrict__ X,
+    k_gp_cost(GpDev g, const double* __restrict__ c, const double* __restrict__ X,
               const double* __restrict__ s, double* __restrict__ part) {
   __shared__ double smem[4];
   double v[1] = {0.0};
-  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.P; p += (long)gridDim.x * blockDim.x) {
-    if (!g.used[p]) continue;
-    const V3 Xp = ld3(X + 3 * p);
-    for (long k = g.off[p]; k < g.off[p + 1]; ++k) {
-      const V3 d = Xp - ld3(c + 3 * (long)g.cam[k]);
-      const V3 r = ld3(g.dir + 3 * k) - s[k] * d;
-      double rho, w;
-      huber(g.huber_a, (g.cal == nullptr || g.cal[k]) ? 1.0 : 0.5, dot(r, r), rho, w);
-      v[0] += 0.5 * rho;
-    }
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < g.g.M; k += (long)gridDim.x * blockDim.x) {
+    const long p = g.g.obs_pt[k];
+    if (!g.g.used[p]) continue;
+    const V3 d = ld3(X + 3 * p) - ld3(c + 3 * (long)g.g.cam[k]);
+    const V3 r = ld3(g.dir + 3 * k) - s[k] * d;
+    double rho, w;
+    huber(g.huber_a, (g.cal == nullptr || g.cal[k]) ? 1.0 : 0.5, dot(r, r), rho, w);
+    v[0] += 0.5 * rho;
   }
   block_sum<1>(v, smem);
   if (threadIdx.x == 0) part[blockIdx.x] = v[0];
@@ -380,18 +499,15 @@ __global__ void __launch_bounds__(kBlock)
 
 // s_k = max(1e-5, v.d / d.d) when !generate_scales (gp.cc:300-305)
 __global__ void __launch_bounds__(kBlock)
-    k_gp_init_scales(GpParams g, int generate, const double* __restrict__ c, const double* __restrict__ X,
+    k_gp_init_scales(GpDev g, int generate, const double* __restrict__ c, const double* __restrict__ X,
                      double* __restrict__ s) {
-  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.P; p += (long)gridDim.x * blockDim.x) {
-    const V3 Xp = ld3(X + 3 * p);
-    for (long k = g.off[p]; k < g.off[p + 1]; ++k) {
-      double v = 1.0;
-      if (!generate) {
-        const V3 d = Xp - ld3(c + 3 * (long)g.cam[k]);
-        v = fmax(1e-5, dot(ld3(g.dir + 3 * k), d) / dot(d, d));
-      }
-      s[k] = v;
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < g.g.M; k += (long)gridDim.x * blockDim.x) {
+    double v = 1.0;
+    if (!generate) {
+      const V3 d = ld3(X + 3 * (long)g.g.obs_pt[k]) - ld3(c + 3 * (long)g.g.cam[k]);
+      v = fmax(1e-5, dot(ld3(g.dir + 3 * k), d) / dot(d, d));
     }
+    s[k] = v;
   }
 }
 
@@ -407,28 +523,18 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
-__global__ void __launch_bounds__(kBlock) k_iota_blocks3(int N, int* __restrict__ elem_blk, int* __restrict__ blk_start,
-                                                         int* __restrict__ blk_size, int* __restrict__ blk_moff) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 3 * N; i += gridDim.x * blockDim.x) {
-    elem_blk[i] = i / 3;
-    if (i % 3 == 0) {
-      blk_start[i / 3] = i;
-      blk_size[i / 3] = 3;
-      blk_moff[i / 3] = 3 * i;
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 struct GpWs {
+  ObsGraphWs og;
   DevBuf<long> off;
-  DevBuf<int> cam, elem_blk, blk_start, blk_size, blk_moff;
-  DevBuf<unsigned char> cal, used;
-  DevBuf<double> dir, c, cn, X, Xn, s, sn, wrob, qa, qb, jss, hinv, ept, hppd, jsx, hcc, jsc, dcam, gc, gred,
-      scc, minv, rhs, cg_x, cg_r, cg_z, cg_p, cg_y, part, scal;
-  DevBuf<CgState> cg;
+  DevBuf<int> cam;
+  DevBuf<unsigned char> cal, c_cal;
+  DevBuf<double> dir, c_dir, c_jss, c_qa, c_qb, c, cn, X, Xn, s, sn, wrob, qa, qb, jss, ptb, ptrec, hppd, jsx, hcc,
+      jsc, dcam, gc, gred, scc, minv, rhs, cg_x, cg_r, cg_z, cg_p, cg_s, cg_w, vpart, dpart, part, scal;
+  DevBuf<CgStatus> cgst;
+  DevBuf<CgScal> cgsc;
   static void destroy(void* p) { delete static_cast<GpWs*>(p); }
 };
 
@@ -452,50 +558,9 @@ class GpSolver final : public LmProblem {
     P_ = prob->num_pts;
     M_ = prob->num_obs;
     GSFM_REQUIRE(N_ > 0 && P_ >= 0 && M_ >= 0, "GP: bad sizes");
-    // host copies of the track structure: used flags, constrained cameras, gauge observation
     std::vector<long> h_off;
-    std::vector<int> h_cam;
     to_host(ctx_, h_off, reinterpret_cast<const long*>(prob->pt_offset), (size_t)P_ + 1, mem);
-    to_host(ctx_, h_cam, prob->obs_cam, (size_t)M_, mem);
     GSFM_REQUIRE(h_off[0] == 0 && h_off[P_] == M_, "GP: pt_offset must start at 0 and end at num_obs");
-    std::vector<unsigned char> h_used(P_);
-    std::vector<char> constrained(N_, 0);
-    long fixed_obs = -1, m_used = 0;
-    for (long p = 0; p < P_; ++p) {
-      const long len = h_off[p + 1] - h_off[p];
-      GSFM_REQUIRE(len >= 0, "GP: pt_offset must be non-decreasing");
-      h_used[p] = len >= opt_.min_num_view_per_track ? 1 : 0;  // gp.cc:258
-      if (!h_used[p]) continue;
-      m_used += len;
-      if (fixed_obs < 0) fixed_obs = h_off[p];
-      for (long k = h_off[p]; k < h_off[p + 1]; ++k) {
-        GSFM_REQUIRE(h_cam[k] >= 0 && h_cam[k] < N_, "GP: obs_cam out of range");
-        constrained[h_cam[k]] = 1;
-      }
-    }
-    m_used_ = m_used;
-    if (ctx_->comm.rank != 0) fixed_obs = -1;  // one constant scale in the whole problem
-    // state init (gp.cc:123-165, 261-264): cameras by index, then used tracks by index
-    std::vector<double> h_c, h_X;
-    to_host(ctx_, h_c, cam_center, 3 * (size_t)N_, mem);
-    to_host(ctx_, h_X, pt_xyz, 3 * (size_t)P_, mem);
-    std::mt19937 rng;
-    rng.seed(opt_.seed);
-    std::uniform_real_distribution<double> uni(-1.0, 1.0);
-    if (opt_.generate_random_positions && opt_.optimize_positions) {
-      for (int n = 0; n < N_; ++n) {
-        if (!constrained[n] && ctx_->comm.world == 1) continue;
-        for (int j = 0; j < 3; ++j) h_c[3 * (size_t)n + j] = 100.0 * uni(rng);
-      }
-    }
-    // several ranks: same camera draws everywhere (above), decorrelated point draws per shard
-    if (ctx_->comm.world > 1) rng.seed(opt_.seed + 7919u * (unsigned)(ctx_->comm.rank + 1));
-    if (opt_.generate_random_points && opt_.optimize_points) {
-      for (long p = 0; p < P_; ++p) {
-        if (!h_used[p]) continue;
-        for (int j = 0; j < 3; ++j) h_X[3 * (size_t)p + j] = 100.0 * uni(rng);
-      }
-    }
     copy_in(ctx_, ws->off.ensure(P_ + 1), reinterpret_cast<const long*>(prob->pt_offset), (size_t)P_ + 1, mem);
     copy_in(ctx_, ws->cam.ensure(M_ + 1), prob->obs_cam, (size_t)M_, mem);
     copy_in(ctx_, ws->dir.ensure(3 * (size_t)M_ + 3), prob->obs_dir, 3 * (size_t)M_, mem);
@@ -504,42 +569,81 @@ class GpSolver final : public LmProblem {
       copy_in(ctx_, ws->cal.ensure(M_ + 1), prob->obs_calibrated, (size_t)M_, mem);
       d_cal = ws->cal.get();
     }
-    GSFM_HIP_CHECK(hipMemcpyAsync(ws->used.ensure(P_ + 1), h_used.data(), (size_t)P_, hipMemcpyHostToDevice, s));
+    long fixed_obs = -1;
+    m_used_ = build_obs_graph(ctx_, ws->og, N_, P_, M_, h_off, ws->off.get(), ws->cam.get(),
+                              opt_.min_num_view_per_track /* gp.cc:258 */, g_.g, &fixed_obs);
+    if (ctx_->comm.rank != 0) fixed_obs = -1;  // one constant scale in the whole problem
+    // camera-major copies of the per-observation inputs
+    const long Mu = g_.g.Mu;
+    ws->c_dir.ensure(3 * (size_t)M_ + 3);
+    hipLaunchKernelGGL((k_og_gather_f64<3>), dim3(grid_for(Mu, kBlock)), dim3(kBlock), 0, s, Mu, g_.g.c_src,
+                       ws->dir.get(), ws->c_dir.get());
+    const unsigned char* d_ccal = nullptr;
+    if (d_cal) {
+      hipLaunchKernelGGL(k_og_gather_u8, dim3(grid_for(Mu, kBlock)), dim3(kBlock), 0, s, Mu, g_.g.c_src, d_cal,
+                         ws->c_cal.ensure(M_ + 1));
+      d_ccal = ws->c_cal.get();
+    }
+    // which cameras carry at least one used observation (gp.cc:128-162: only those are re-drawn)
+    std::vector<int> h_coff(N_ + 2);
+    GSFM_HIP_CHECK(hipMemcpyAsync(h_coff.data(), g_.g.coff, (size_t)(N_ + 2) * sizeof(int), hipMemcpyDeviceToHost, s));
+    // state init (gp.cc:123-165, 261-264): cameras by index, then used tracks by index
+    std::vector<double> h_c, h_X;
+    to_host(ctx_, h_c, cam_center, 3 * (size_t)N_, mem);
+    to_host(ctx_, h_X, pt_xyz, 3 * (size_t)P_, mem);
+    GSFM_HIP_CHECK(hipStreamSynchronize(s));
+    std::mt19937 rng;
+    rng.seed(opt_.seed);
+    std::uniform_real_distribution<double> uni(-1.0, 1.0);
+    if (opt_.generate_random_positions && opt_.optimize_positions) {
+      for (int n = 0; n < N_; ++n) {
+        const bool constrained = h_coff[n + 1] > h_coff[n];
+        if (!constrained && ctx_->comm.world == 1) continue;
+        for (int j = 0; j < 3; ++j) h_c[3 * (size_t)n + j] = 100.0 * uni(rng);
+      }
+    }
+    // several ranks: same camera draws everywhere (above), decorrelated point draws per shard
+    if (ctx_->comm.world > 1) rng.seed(opt_.seed + 7919u * (unsigned)(ctx_->comm.rank + 1));
+    if (opt_.generate_random_points && opt_.optimize_points) {
+      for (long p = 0; p < P_; ++p) {
+        if (h_off[p + 1] - h_off[p] < opt_.min_num_view_per_track) continue;
+        for (int j = 0; j < 3; ++j) h_X[3 * (size_t)p + j] = 100.0 * uni(rng);
+      }
+    }
     GSFM_HIP_CHECK(hipMemcpyAsync(ws->c.ensure(3 * (size_t)N_), h_c.data(), 3 * (size_t)N_ * sizeof(double), hipMemcpyHostToDevice, s));
     GSFM_HIP_CHECK(hipMemcpyAsync(ws->X.ensure(3 * (size_t)P_ + 3), h_X.data(), 3 * (size_t)P_ * sizeof(double), hipMemcpyHostToDevice, s));
     GSFM_HIP_CHECK(hipStreamSynchronize(s));
     ws->cn.ensure(3 * (size_t)N_);
     ws->Xn.ensure(3 * (size_t)P_ + 3);
-    for (DevBuf<double>* b : {&ws->s, &ws->sn, &ws->wrob, &ws->qa, &ws->qb, &ws->jss}) b->ensure(M_ + 1);
-    ws->hinv.ensure(6 * (size_t)P_ + 6);
-    ws->ept.ensure(3 * (size_t)P_ + 3);
+    for (DevBuf<double>* b : {&ws->s, &ws->sn, &ws->wrob, &ws->qa, &ws->qb, &ws->jss, &ws->c_jss, &ws->c_qa, &ws->c_qb})
+      b->ensure(M_ + 1);
+    ws->ptb.ensure(12 * (size_t)P_ + 12);
+    ws->ptrec.ensure(8 * (size_t)P_ + 8);
     ws->hppd.ensure(P_ + 1);
     ws->jsx.ensure(P_ + 1);
     ws->hcc.ensure(N_);
     ws->jsc.ensure(N_);
     ws->scc.ensure(6 * (size_t)N_);
     ws->minv.ensure(9 * (size_t)N_);
-    for (DevBuf<double>* b : {&ws->dcam, &ws->gc, &ws->gred, &ws->rhs, &ws->cg_x, &ws->cg_r, &ws->cg_z, &ws->cg_p, &ws->cg_y})
+    for (DevBuf<double>* b : {&ws->dcam, &ws->gc, &ws->gred, &ws->rhs, &ws->cg_x, &ws->cg_r, &ws->cg_z, &ws->cg_p, &ws->cg_s})
       b->ensure(3 * (size_t)N_);
-    ws->part.ensure(kMaxBlocks * 4);
+    ws->cg_w.ensure(3 * (size_t)N_ + 2);
+    ws->vpart.ensure(2 * kCgMaxBlocks * 2);
+    ws->dpart.ensure(kMaxBlocks);
+    ws->part.ensure(kMaxBlocks * 8);
     ws->scal.ensure(64);
-    ws->cg.ensure(1);
-    ws->elem_blk.ensure(3 * (size_t)N_);
-    ws->blk_start.ensure(N_);
-    ws->blk_size.ensure(N_);
-    ws->blk_moff.ensure(N_);
+    ws->cgst.ensure(1);
+    ws->cgsc.ensure(2);
     gridP_ = grid_for(P_, kBlock);
     gridN_ = grid_for(N_, kBlock);
-    hipLaunchKernelGGL(k_iota_blocks3, dim3(grid_for(3 * (size_t)N_, kBlock)), dim3(kBlock), 0, s, N_,
-                       ws->elem_blk.get(), ws->blk_start.get(), ws->blk_size.get(), ws->blk_moff.get());
-    g_.N = N_;
-    g_.P = P_;
-    g_.M = M_;
-    g_.off = ws->off.get();
-    g_.cam = ws->cam.get();
+    gridM_ = grid_for(M_, kBlock);
+    gridCam_ = grid_for(N_, kBlock / 64);       // one wave per camera
+    gridTile_ = grid_for(g_.g.T, kBlock / 64);  // one wave per tile
     g_.dir = ws->dir.get();
     g_.cal = d_cal;
-    g_.used = ws->used.get();
+    g_.c_dir = ws->c_dir.get();
+    g_.c_cal = d_ccal;
+    g_.c_jss = ws->c_jss.get();
     g_.fixed_obs = fixed_obs;
     g_.huber_a = opt_.thres_loss_function;
     g_.opt_c = opt_.optimize_positions ? 1 : 0;
@@ -553,8 +657,25 @@ class GpSolver final : public LmProblem {
     Xn_ = ws->Xn.get();
     s_ = ws->s.get();
     sn_ = ws->sn.get();
-    hipLaunchKernelGGL(k_gp_init_scales, dim3(gridP_), dim3(kBlock), 0, s, g_, opt_.generate_scales ? 1 : 0, c_, X_, s_);
-    bj_ = BlockJacobi{ws->elem_blk.get(), ws->blk_start.get(), ws->blk_size.get(), ws->blk_moff.get(), ws->minv.get()};
+    hipLaunchKernelGGL(k_gp_init_scales, dim3(gridM_), dim3(kBlock), 0, s, g_, opt_.generate_scales ? 1 : 0, c_, X_, s_);
+    // PCG view
+    cg_.n = 3 * N_;
+    cg_.N = N_;
+    cg_.K = 0;
+    cg_.nb_update = std::min(kCgMaxBlocks, grid_for(N_, kBlock));
+    cg_.nb_apply = gridCam_;
+    cg_.b = ws->rhs.get();
+    cg_.x = ws->cg_x.get();
+    cg_.r = ws->cg_r.get();
+    cg_.z = ws->cg_z.get();
+    cg_.p = ws->cg_p.get();
+    cg_.s = ws->cg_s.get();
+    cg_.w = ws->cg_w.get();
+    cg_.minv = ws->minv.get();
+    cg_.vpart = ws->vpart.get();
+    cg_.dpart = ws->dpart.get();
+    cg_.scal = ws->cgsc.get();
+    cg_.st = ws->cgst.get();
   }
 
   long used_observations() const { return m_used_; }
@@ -562,10 +683,9 @@ class GpSolver final : public LmProblem {
   double linearize(double* grad_max_norm) override {
     GpWs* ws = ws_;
     hipStream_t s = ctx_->stream;
-    GSFM_HIP_CHECK(hipMemsetAsync(ws->hcc.get(), 0, (size_t)N_ * sizeof(double), s));
-    GSFM_HIP_CHECK(hipMemsetAsync(ws->gc.get(), 0, 3 * (size_t)N_ * sizeof(double), s));
-    hipLaunchKernelGGL(k_gp_linearize, dim3(gridP_), dim3(kBlock), 0, s, g_, c_, X_, s_, ws->wrob.get(),
-                       ws->hppd.get(), ws->hcc.get(), ws->gc.get(), ws->part.get());
+    hipLaunchKernelGGL(k_gp_lin_track, dim3(gridP_), dim3(kBlock), 0, s, g_, c_, X_, s_, ws->wrob.get(),
+                       ws->hppd.get(), ws->part.get());
+    hipLaunchKernelGGL(k_gp_lin_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, c_, X_, s_, ws->hcc.get(), ws->gc.get());
     if (ctx_->comm.world > 1) {
       allreduce_sum(ctx_, ws->hcc.get(), N_);
       allreduce_sum(ctx_, ws->gc.get(), 3 * (size_t)N_);
@@ -583,6 +703,8 @@ class GpSolver final : public LmProblem {
     hipStream_t s = ctx_->stream;
     hipLaunchKernelGGL(k_gp_jacobi_obs, dim3(gridP_), dim3(kBlock), 0, s, g_, enabled ? 1 : 0, c_, X_,
                        ws->wrob.get(), ws->hppd.get(), ws->jss.get(), ws->jsx.get());
+    hipLaunchKernelGGL((k_og_gather_f64<1>), dim3(grid_for(g_.g.Mu, kBlock)), dim3(kBlock), 0, s, g_.g.Mu, g_.g.c_src,
+                       ws->jss.get(), ws->c_jss.get());
     hipLaunchKernelGGL(k_gp_jacobi_cam, dim3(gridN_), dim3(kBlock), 0, s, N_, enabled ? 1 : 0, ws->hcc.get(),
                        ws->jsc.get());
   }
@@ -593,11 +715,11 @@ class GpSolver final : public LmProblem {
     hipStream_t s = ctx_->stream;
     const bool multi = ctx_->comm.world > 1;
     const int n3 = 3 * N_;
-    GSFM_HIP_CHECK(hipMemsetAsync(ws->gred.get(), 0, (size_t)n3 * sizeof(double), s));
-    GSFM_HIP_CHECK(hipMemsetAsync(ws->scc.get(), 0, 6 * (size_t)N_ * sizeof(double), s));
-    hipLaunchKernelGGL(k_gp_build, dim3(gridP_), dim3(kBlock), 0, s, g_, radius, c_, X_, s_, ws->wrob.get(),
-                       ws->jss.get(), ws->jsx.get(), ws->hppd.get(), ws->qa.get(), ws->qb.get(), ws->hinv.get(),
-                       ws->ept.get(), ws->gred.get(), ws->scc.get());
+    hipLaunchKernelGGL(k_gp_build_track, dim3(gridP_), dim3(kBlock), 0, s, g_, radius, c_, X_, s_, ws->wrob.get(),
+                       ws->jss.get(), ws->jsx.get(), ws->hppd.get(), ws->qa.get(), ws->qb.get(), ws->ptb.get(),
+                       ws->ptrec.get());
+    hipLaunchKernelGGL(k_gp_build_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, radius, c_, s_, ws->ptb.get(),
+                       ws->c_qa.get(), ws->c_qb.get(), ws->gred.get(), ws->scc.get());
     if (multi) {
       allreduce_sum(ctx_, ws->gred.get(), n3);
       allreduce_sum(ctx_, ws->scc.get(), 6 * (size_t)N_);
@@ -612,12 +734,15 @@ class GpSolver final : public LmProblem {
       GSFM_HIP_CHECK(hipMemsetAsync(ws->cg_x.get(), 0, (size_t)n3 * sizeof(double), s));
     }
     hipLaunchKernelGGL(k_gp_backsub, dim3(gridP_), dim3(kBlock), 0, s, g_, c_, X_, s_, ws->wrob.get(),
-                       ws->qa.get(), ws->qb.get(), ws->hinv.get(), ws->ept.get(), ws->cg_x.get(), Xn_, sn_,
-                       ws->part.get());
+                       ws->qa.get(), ws->qb.get(), ws->ptb.get(), ws->cg_x.get(), Xn_, sn_, ws->part.get());
     hipLaunchKernelGGL((k_sum_partials<3>), dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridP_, ws->scal.get());
-    hipLaunchKernelGGL(k_gp_cam_update, dim3(1), dim3(kBlock), 0, s, n3, c_, ws->cg_x.get(), cn_, ws->scal.get() + 3);
-    hipLaunchKernelGGL(k_gp_cost, dim3(gridP_), dim3(kBlock), 0, s, g_, cn_, Xn_, sn_, ws->part.get());
-    hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridP_, ws->scal.get() + 6);
+    const int gridU = std::min(64, grid_for(n3, kBlock));
+    double* part2 = ws->part.get() + kMaxBlocks * 3;
+    hipLaunchKernelGGL(k_gp_cam_update, dim3(gridU), dim3(kBlock), 0, s, n3, c_, ws->cg_x.get(), cn_, part2);
+    hipLaunchKernelGGL((k_sum_partials<3>), dim3(1), dim3(kBlock), 0, s, part2, gridU, ws->scal.get() + 3);
+    double* part3 = ws->part.get() + kMaxBlocks * 4;
+    hipLaunchKernelGGL(k_gp_cost, dim3(gridM_), dim3(kBlock), 0, s, g_, cn_, Xn_, sn_, part3);
+    hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(kBlock), 0, s, part3, gridM_, ws->scal.get() + 6);
     if (multi) {
       // track-local sums: model change, |dX|^2+|ds|^2, |X|^2+|s|^2 and the candidate cost
       allreduce_sum(ctx_, ws->scal.get(), 3);
@@ -667,44 +792,28 @@ class GpSolver final : public LmProblem {
   long pcg() {
     GpWs* ws = ws_;
     hipStream_t s = ctx_->stream;
-    const int n3 = 3 * N_;
-    const bool multi = ctx_->comm.world > 1;
     const double yscale = ctx_->comm.rank == 0 ? 1.0 : 0.0;
     const double tol = opt_.lm.pcg_relative_tolerance;
-    hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(kCgThreads), 0, s, n3, ws->rhs.get(), ws->cg_x.get(),
-                       ws->cg_r.get(), ws->cg_z.get(), ws->cg_p.get(), ws->cg_y.get(), ws->dcam.get(), bj_,
-                       ws->cg.get(), yscale);
-    CgState* h = reinterpret_cast<CgState*>(ctx_->h_pinned + 400);
-    const int chunk = 8;
-    const int max_iter = opt_.lm.pcg_max_iterations;
-    for (int it = 0; it < max_iter; ++it) {
-      const bool timed = ctx_->prof.begin(s, GSFM_KERNEL_GP_SCHUR);
-      hipLaunchKernelGGL(k_gp_schur_matvec, dim3(gridP_), dim3(kBlock), 0, s, g_, c_, X_, ws->qa.get(),
-                         ws->qb.get(), ws->hinv.get(), ws->cg_p.get(), ws->cg_y.get());
+    return cg_solve<3, false>(ctx_, cg_, tol, opt_.lm.pcg_max_iterations, [&](int it) {
+      bool timed = ctx_->prof.begin(s, GSFM_KERNEL_GP_SCHUR);
+      hipLaunchKernelGGL(k_gp_phaseA, dim3(gridTile_), dim3(kBlock), 0, s, g_, cg_, it, tol * tol, c_, ws->qa.get(),
+                         ws->qb.get(), ws->ptb.get(), ws->ptrec.get());
       if (timed) ctx_->prof.end(s);
-      if (multi) allreduce_sum(ctx_, ws->cg_y.get(), n3);
-      hipLaunchKernelGGL(k_cg_iter, dim3(1), dim3(kCgThreads), 0, s, n3, ws->cg_y.get(), ws->cg_p.get(),
-                         ws->cg_x.get(), ws->cg_r.get(), ws->cg_z.get(), ws->dcam.get(), bj_, ws->cg.get(),
-                         tol * tol, yscale);
-      if ((it + 1) % chunk == 0 || it + 1 == max_iter) {
-        GSFM_HIP_CHECK(hipMemcpyAsync(h, ws->cg.get(), sizeof(CgState), hipMemcpyDeviceToHost, s));
-        GSFM_HIP_CHECK(hipStreamSynchronize(s));
-        GSFM_HIP_CHECK(hipGetLastError());
-        ctx_->prof.harvest();
-        if (h->done) return h->iters;
-      }
-    }
-    return max_iter;
+      timed = ctx_->prof.begin(s, GSFM_KERNEL_GP_SCHUR_B);
+      hipLaunchKernelGGL(k_gp_phaseB, dim3(gridCam_), dim3(kBlock), 0, s, g_, cg_, yscale, c_, ws->c_qa.get(),
+                         ws->c_qb.get(), ws->ptrec.get(), ws->dcam.get());
+      if (timed) ctx_->prof.end(s);
+    });
   }
 
   gsfm_ctx* ctx_;
   GpWs* ws_;
   gsfm_gp_options opt_;
-  GpParams g_{};
-  BlockJacobi bj_{};
+  GpDev g_{};
+  CgVec cg_{};
   int N_ = 0;
   long P_ = 0, M_ = 0, m_used_ = 0;
-  int gridP_ = 1, gridN_ = 1;
+  int gridP_ = 1, gridN_ = 1, gridM_ = 1, gridCam_ = 1, gridTile_ = 1;
   double *c_ = nullptr, *cn_ = nullptr, *X_ = nullptr, *Xn_ = nullptr, *s_ = nullptr, *sn_ = nullptr;
 };
 

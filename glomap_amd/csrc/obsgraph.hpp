@@ -1,0 +1,210 @@
+// obsgraph.hpp — the observation graph (tracks x cameras) in BOTH orders, shared by gp.hip / ba.hip.
+//
+// The reference hands Ceres one residual block per observation and lets SPARSE_SCHUR sort things
+// out (global_positioning.cc:270-375, bundle_adjustment.cc:115-190).  Here the bipartite graph is
+// laid out twice in HBM so that every reduction is a contiguous, atomic-free, fixed-order sum:
+//
+//   track-major  (the input order): obs of track p are [off[p], off[p+1]).  Point-side sums
+//                (H_pp, g_p, the implicit-Schur "t_p = H_pp^-1 sum_k ..." of PCG phase A) run one
+//                LANE PER OBSERVATION with a segmented wave scan; waves are cut at track
+//                boundaries by the host-built tile table (<= 64 observations per tile, or one long
+//                track per tile), so no segment ever straddles a wave.
+//   camera-major (derived once per solve by a stable device radix sort on the camera index):
+//                obs of camera n are [coff[n], coff[n+1]).  Camera-side sums (gradient, S_cc
+//                blocks, PCG phase B "y_n = sum_k ...") run one WAVE PER CAMERA with the camera
+//                data in registers and a single wave reduction at the end.
+//
+// Observations of tracks shorter than min_num_view_per_track (gp.cc:258, ba.cc:122) are excluded
+// from the camera-major lists (key = N sorts them behind every camera) and contribute zero in
+// track-major sweeps.
+#pragma once
+
+#include <vector>
+
+#include "device.hpp"
+
+namespace gsfm {
+
+void sort_pairs_i32(gsfm_ctx* ctx, DevBuf<unsigned char>& tmp, const int* keys_in, int* keys_out,
+                    const int* vals_in, int* vals_out, size_t n, int key_bits);
+
+struct ObsGraph {  // device view, passed to kernels by value
+  int N = 0;       // cameras
+  int T = 0;       // wave tiles
+  long P = 0, M = 0;
+  long Mu = 0;     // observations of used tracks (= coff[N])
+  const long* off = nullptr;           // [P+1]
+  const int* cam = nullptr;            // [M]
+  const unsigned char* used = nullptr; // [P]
+  const int* obs_pt = nullptr;         // [M]   track of each observation
+  const int* tile = nullptr;           // [T+1] first track of each wave tile
+  const int* coff = nullptr;           // [N+2] camera-major CSR; coff[N] = Mu, coff[N+1] = M
+  const int* c_src = nullptr;          // [M]   track-major index of each camera-major slot
+  const int* c_pt = nullptr;           // [M]   track of each camera-major slot
+};
+
+struct ObsGraphWs {
+  DevBuf<int> obs_pt, tile, keys, keys_sorted, vals, c_src, c_pt, coff, flag;
+  DevBuf<unsigned char> used, sort_tmp;
+};
+
+// ---- device helpers --------------------------------------------------------------------------
+// Inclusive segmented scan over the 64 lanes of a wave: lanes with equal `key` must be contiguous.
+// After the call the LAST lane of every segment holds the segment total (fixed summation order).
+template <int K>
+__device__ __forceinline__ void seg_scan(double (&v)[K], int key, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int ku = __shfl_up(key, d, 64);
+    const bool take = lane >= d && ku == key;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const double vu = __shfl_up(v[k], d, 64);
+      if (take) v[k] += vu;
+    }
+  }
+}
+__device__ __forceinline__ bool seg_is_tail(int key, int lane) {
+  const int kn = __shfl_down(key, 1, 64);
+  return lane == 63 || kn != key;
+}
+
+// Wave-wide sum of K values, result in every lane (xor butterfly, fixed order).
+template <int K>
+__device__ __forceinline__ void wave_allsum(double (&v)[K]) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += __shfl_xor(v[k], off, 64);
+  }
+}
+
+// ---- kernels ------------------------------------------------------------------------------------
+static __global__ void __launch_bounds__(kBlock)
+    k_og_keys(int N, long P, const long* __restrict__ off, const int* __restrict__ cam,
+              const unsigned char* __restrict__ used, int* __restrict__ obs_pt, int* __restrict__ keys,
+              int* __restrict__ vals, int* __restrict__ flag) {
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
+    const bool u = used[p] != 0;
+    for (long k = off[p]; k < off[p + 1]; ++k) {
+      const int n = cam[k];
+      if (n < 0 || n >= N) atomicOr(flag, 1);
+      obs_pt[k] = (int)p;
+      keys[k] = u ? n : N;
+      vals[k] = (int)k;
+    }
+  }
+}
+
+// coff[c] = first sorted slot whose key >= c, for c in [0, N+1]
+static __global__ void __launch_bounds__(kBlock)
+    k_og_offsets(int N, long M, const int* __restrict__ keys_sorted, int* __restrict__ coff) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i <= M; i += (long)gridDim.x * blockDim.x) {
+    const int a = i == 0 ? -1 : keys_sorted[i - 1];
+    const int b = i == M ? N + 1 : keys_sorted[i];
+    for (int c = a + 1; c <= b; ++c) coff[c] = (int)i;
+  }
+}
+
+static __global__ void __launch_bounds__(kBlock)
+    k_og_gather_i32(long n, const int* __restrict__ idx, const int* __restrict__ src, int* __restrict__ dst) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dst[i] = src[idx[i]];
+}
+
+// dst[i][0..W) = src[idx[i]][0..W)   (permuted copy of a per-observation array, W doubles wide)
+template <int W>
+static __global__ void __launch_bounds__(kBlock)
+    k_og_gather_f64(long n, const int* __restrict__ idx, const double* __restrict__ src, double* __restrict__ dst) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long s = idx[i];
+#pragma unroll
+    for (int j = 0; j < W; ++j) dst[W * i + j] = src[W * s + j];
+  }
+}
+static __global__ void __launch_bounds__(kBlock)
+    k_og_gather_u8(long n, const int* __restrict__ idx, const unsigned char* __restrict__ src,
+                   unsigned char* __restrict__ dst) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dst[i] = src[idx[i]];
+}
+
+// ---- host ---------------------------------------------------------------------------------------
+// h_off: host copy of pt_offset.  d_off / d_cam: device copies.  Fills `g`, returns the number of
+// used observations; *first_used_obs receives the first observation of the first used track (-1 if
+// none) — the reference's "first scale constant" gauge (gp.cc:484-489).
+inline long build_obs_graph(gsfm_ctx* ctx, ObsGraphWs& ws, int N, long P, long M, const std::vector<long>& h_off,
+                            const long* d_off, const int* d_cam, int min_len, ObsGraph& g, long* first_used_obs) {
+  GSFM_REQUIRE(M < (1L << 31) - 64, "observation count must fit int32");
+  hipStream_t s = ctx->stream;
+  std::vector<unsigned char> h_used(P);
+  std::vector<int> h_tile;
+  h_tile.reserve((size_t)(M / 48 + 16));
+  long m_used = 0, first = -1;
+  long cur = 0;  // observations in the open tile
+  bool open = false;
+  for (long p = 0; p < P; ++p) {
+    const long len = h_off[p + 1] - h_off[p];
+    GSFM_REQUIRE(len >= 0, "pt_offset must be non-decreasing");
+    h_used[p] = len >= min_len ? 1 : 0;
+    if (h_used[p]) {
+      m_used += len;
+      if (first < 0) first = h_off[p];
+    }
+    if (len > 64) {
+      h_tile.push_back((int)p);  // a long track is a tile of its own
+      open = false;
+      cur = 0;
+    } else if (!open || cur + len > 64) {
+      h_tile.push_back((int)p);
+      open = true;
+      cur = len;
+    } else {
+      cur += len;
+    }
+  }
+  const int T = (int)h_tile.size();
+  h_tile.push_back((int)P);
+  if (first_used_obs) *first_used_obs = first;
+
+  GSFM_HIP_CHECK(hipMemcpyAsync(ws.used.ensure(P + 1), h_used.data(), (size_t)P, hipMemcpyHostToDevice, s));
+  GSFM_HIP_CHECK(hipMemcpyAsync(ws.tile.ensure(T + 2), h_tile.data(), (size_t)(T + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+  ws.obs_pt.ensure(M + 1);
+  ws.keys.ensure(M + 1);
+  ws.keys_sorted.ensure(M + 1);
+  ws.vals.ensure(M + 1);
+  ws.c_src.ensure(M + 1);
+  ws.c_pt.ensure(M + 1);
+  ws.coff.ensure(N + 3);
+  ws.flag.ensure(4);
+  GSFM_HIP_CHECK(hipMemsetAsync(ws.flag.get(), 0, 4 * sizeof(int), s));
+  hipLaunchKernelGGL(k_og_keys, dim3(grid_for(P, kBlock)), dim3(kBlock), 0, s, N, P, d_off, d_cam, ws.used.get(),
+                     ws.obs_pt.get(), ws.keys.get(), ws.vals.get(), ws.flag.get());
+  int bits = 1;
+  while ((1L << bits) <= N) ++bits;
+  sort_pairs_i32(ctx, ws.sort_tmp, ws.keys.get(), ws.keys_sorted.get(), ws.vals.get(), ws.c_src.get(), (size_t)M, bits);
+  hipLaunchKernelGGL(k_og_offsets, dim3(grid_for(M + 1, kBlock)), dim3(kBlock), 0, s, N, M, ws.keys_sorted.get(),
+                     ws.coff.get());
+  hipLaunchKernelGGL(k_og_gather_i32, dim3(grid_for(M, kBlock)), dim3(kBlock), 0, s, M, ws.c_src.get(),
+                     ws.obs_pt.get(), ws.c_pt.get());
+  int* h_flag = reinterpret_cast<int*>(ctx->h_pinned + 512);
+  GSFM_HIP_CHECK(hipMemcpyAsync(h_flag, ws.flag.get(), sizeof(int), hipMemcpyDeviceToHost, s));
+  GSFM_HIP_CHECK(hipStreamSynchronize(s));  // host vectors go out of scope; flag is read
+  GSFM_REQUIRE(h_flag[0] == 0, "obs_cam out of range");
+  g.N = N;
+  g.T = T;
+  g.P = P;
+  g.M = M;
+  g.Mu = m_used;
+  g.off = d_off;
+  g.cam = d_cam;
+  g.used = ws.used.get();
+  g.obs_pt = ws.obs_pt.get();
+  g.tile = ws.tile.get();
+  g.coff = ws.coff.get();
+  g.c_src = ws.c_src.get();
+  g.c_pt = ws.c_pt.get();
+  return m_used;
+}
+
+}  // namespace gsfm

@@ -105,10 +105,12 @@ int gsfm_ctx_synchronize(gsfm_ctx* ctx);
  * pair on the ctx stream; bench.py uses this for the roofline line.  Off by default (the event
  * records cost host time), never needed for correctness. */
 enum {
-  GSFM_KERNEL_RA_LAPLACIAN = 0, /* k_pcg_dir_fused: weighted-Laplacian SpMV (3 RHS) + CG direction update */
-  GSFM_KERNEL_GP_SCHUR = 1,     /* k_gp_schur_matvec: implicit Schur-complement product, BATA blocks */
-  GSFM_KERNEL_BA_SCHUR = 2,     /* k_ba_schur_matvec: implicit Schur-complement product, reprojection blocks */
-  GSFM_KERNEL_COUNT = 3
+  GSFM_KERNEL_RA_LAPLACIAN = 0, /* RA: weighted-Laplacian SpMV (3 RHS) inside the PCG */
+  GSFM_KERNEL_GP_SCHUR = 1,     /* k_gp_phaseA: implicit Schur product, track-major half (BATA blocks) */
+  GSFM_KERNEL_BA_SCHUR = 2,     /* k_ba_phaseA: implicit Schur product, track-major half (stored Jacobian planes) */
+  GSFM_KERNEL_GP_SCHUR_B = 3,   /* k_gp_phaseB: camera-major half */
+  GSFM_KERNEL_BA_SCHUR_B = 4,   /* k_ba_phaseB: camera-major half */
+  GSFM_KERNEL_COUNT = 5
 };
 int gsfm_ctx_profile_enable(gsfm_ctx* ctx, int enable);
 /* Reads and resets the accumulated launch count / total milliseconds of one kernel id. */
