@@ -9,101 +9,73 @@
 //   solver     Ceres LM + SPARSE_SCHUR  ->  lm.hpp + 3x3 point elimination + implicit-Schur PCG on the
 //              reduced camera system (6 per frame + 8 per intrinsics block), block-Jacobi preconditioned.
 //
-// Nothing per-observation is stored except the robust weight: Jacobians are analytic and cheap, so
-// every sweep recomputes them from (R, t) of the frame (96 B, L2-resident gather), the point
-// (24 B, track-contiguous) and the intrinsics.  With a = R X, h = Jx^T g:
-//   J_rot v = Jx (2 v x a),  J_rot^T g = 2 a x h,  J_trn = Jx,  J_pt = Jx R,  J_intr = Jp.
+// With a = R X, h = Jx^T g:  J_rot v = Jx (2 v x a),  J_rot^T g = 2 a x h,  J_trn = Jx,  J_pt = Jx R,
+// J_intr = Jp.  Reduced-system vector layout: [6 per frame (rot, trn) | 8 per intrinsics block];
+// constant or non-existent entries keep a zero Jacobian column (their step is exactly 0).
 //
-// Reduced-system vector layout: [6 per frame (rot, trn) | 8 per intrinsics block]; constant or
-// non-existent entries keep a zero Jacobian column (their step is exactly 0).
+// Every reduction is atomic-free and in a fixed order (obsgraph.hpp):
+//   track-major sweeps (point side)  use the Jacobians STORED once per linearisation as planes of
+//     double2 (row 0, row 1) per column: 6 pose + 3 point + F free-intrinsics columns + the residual,
+//     all pre-scaled by sqrt(rho') — HBM capacity (288 GB) buys a pure streaming PCG phase A;
+//   camera-major sweeps (camera side) run one wave per camera with R, t, intrinsics and the CG
+//     vector of that camera in registers and RECOMPUTE the Jacobian from the gathered 64-byte point
+//     record — cheaper than streaming a second copy of the planes.
 //
-// Data layout in HBM (f64 unless noted; observations track-major):
-//   pt_offset[P+1] i64, obs_cam[M] i32, obs_xy[M][2], cam_intr[N] i32, intr_model[K] i32     inputs
-//   q[N][4], t[N][3], camR[N][9], X[P][3], par[K][8] + candidates                              state
-//   wrob[M]                                                                                    per observation
-//   hinv[P][6], ept[P][3], ptdiag[P][3], ptjs[P][3], used[P] u8                                per track
-//   diag, js, dvec, grad, gred, rhs [6N+8K];  spose[N][21], sintr[K][36], minv[36N+64K]        reduced system
+// Data layout in HBM (f64 unless noted):
+//   track-major : pt_offset[P+1] i64, obs_cam[M] i32, obs_xy[M][2]            inputs
+//                 jt[(10+F) planes][Mp] double2                                 per linearisation
+//   camera-major: coff[N+2], c_src[M], c_pt[M] i32, c_xy[M][2]                 static per solve
+//                 c_w[M] robust weights                                         per linearisation
+//   per track   : X[P][3] (+ candidate), ptH[P][9] = (H_pp, g_p), ptdiag[P][3], ptjs[P][3],
+//                 ptb[P][12] = (X, e, H_pp^-1) build record, ptrec[P][8] = (X, t_p, pad) PCG record
+//   per camera  : q[N][4], t[N][3], camR[N][9] (+ candidates), cam_intr[N] i32, yi_part[N][8]
+//   per intr    : par[K][8] (+ candidate), intr_model[K] i32, intr_free[K] u8, intr_map[K][8] i8,
+//                 ioff[K+1], icams[N] (cameras grouped by intrinsics block)
+//   reduced     : diag, js, dvec, grad, gred, rhs [6N+8K]; spose[N][21], iacc44[K][44], minv[36N+64K];
+//                 PCG vectors x, r, z, p, s, w (cg.hpp)
+#include <algorithm>
+#include <numeric>
+
 #include "camera.hpp"
-#include "cgvec.hpp"
+#include "cg.hpp"
 #include "lm.hpp"
+#include "obsgraph.hpp"
 
 namespace gsfm {
 namespace {
 
-struct BaParams {
-  int N, K;
-  long P, M;
-  const long* off;
-  const int* cam;
+struct BaDev {
+  ObsGraph g;
+  int K, F;
+  long Mp;  // plane stride (observations, padded)
   const double* xy;
+  const double* c_xy;
   const int* cam_intr;
   const int* intr_model;
-  const unsigned char* used;
   const unsigned char* intr_free;  // [K] bit j set = params[j] is optimised
+  const signed char* intr_map;     // [K][8] compact column -> parameter index, -1 = unused column
+  const int* ioff;                 // [K+1]
+  const int* icams;                // [N]
   int fixed_cam;
   int opt_rot, opt_trn, opt_pts;
   double huber_a;
   double lm_lo, lm_hi;
 };
 
+// plane indices of the stored Jacobians
+constexpr int PL_A = 0;  // 6 pose columns
+constexpr int PL_B = 6;  // 3 point columns
+constexpr int PL_I = 9;  // F free-intrinsics columns, then the residual plane
+
 __device__ __forceinline__ int sym6(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
 __device__ __forceinline__ int sym8(int i, int j) { return i * 8 - (i * (i - 1)) / 2 + (j - i); }
-
-// Per-thread accumulator of W values keyed by a small integer (the intrinsics block id): values
-// are added up in registers while consecutive observations share the key and only flushed with
-// atomics when the key changes.  finish() reduces across the block first when every thread ended
-// on the same key — the shared-intrinsics case, where per-observation atomics on one address
-// would serialise the whole sweep.
-template <int W>
-struct RunAcc {
-  int key = -1;
-  double v[W];
-  __device__ __forceinline__ void clear() {
-#pragma unroll
-    for (int i = 0; i < W; ++i) v[i] = 0.0;
-  }
-  __device__ __forceinline__ void flush(double* __restrict__ base) {
-    if (key >= 0) {
-#pragma unroll
-      for (int i = 0; i < W; ++i)
-        if (v[i] != 0.0) unsafeAtomicAdd(base + (long)key * W + i, v[i]);
-    }
-    clear();
-    key = -1;
-  }
-  __device__ __forceinline__ void select(int k, double* __restrict__ base) {
-    if (k != key) {
-      flush(base);
-      key = k;
-    }
-  }
-  // all threads of the block must call this
-  __device__ __forceinline__ void finish(double* __restrict__ base, double* smem /* >= 4*W doubles */, int* skey) {
-    if (threadIdx.x == 0) *skey = -1;
-    __syncthreads();
-    if (key >= 0) atomicMax(skey, key);
-    __syncthreads();
-    const int ref = *skey;
-    const int same = __syncthreads_and(key == ref || key < 0);
-    if (same && ref >= 0) {
-      block_sum<W>(v, smem);
-      if (threadIdx.x == 0) {
-#pragma unroll
-        for (int i = 0; i < W; ++i)
-          if (v[i] != 0.0) unsafeAtomicAdd(base + (long)ref * W + i, v[i]);
-      }
-    } else {
-      flush(base);
-    }
-  }
-};
 
 struct ObsJac {
   double Jpose[2][6];  // [rot | trn], masked
   double Jpt[2][3];    // masked by opt_pts
 };
 
-__device__ __forceinline__ void build_jac(const BaParams& g, int n, const double* __restrict__ R9, const ObsGeom& o,
+__device__ __forceinline__ void build_jac(const BaDev& g, int n, const double* __restrict__ R9, const ObsGeom& o,
                                           ObsJac& J) {
   const bool rf = g.opt_rot && n != g.fixed_cam;
   const bool tf = g.opt_trn && n != g.fixed_cam;
@@ -131,6 +103,39 @@ __device__ __forceinline__ void mask_intr(unsigned char bits, double (&Jp)[2][8]
   }
 }
 
+// v[idx] with a register-resident array and a run-time index (select chain, no scratch)
+__device__ __forceinline__ double sel8(const double (&v)[8], int idx) {
+  double r = 0.0;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) r = (p == idx) ? v[p] : r;
+  return r;
+}
+
+struct Map8 {
+  signed char m[8];
+};
+__device__ __forceinline__ Map8 load_map(const signed char* __restrict__ p) {
+  Map8 r;
+  const unsigned long long bits = *reinterpret_cast<const unsigned long long*>(p);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r.m[j] = (signed char)((bits >> (8 * j)) & 0xff);
+  return r;
+}
+
+__device__ __forceinline__ double lm_damping(double h, double js, double radius, double lo, double hi) {
+  const double j2 = js * js;
+  return fmin(fmax(j2 * h, lo), hi) / (radius * j2);
+}
+
+__device__ __forceinline__ double block_max(double v, double* smem /* >= 4 */) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmax(fmax(smem[0], smem[1]), fmax(smem[2], smem[3]));
+}
+
 __global__ void __launch_bounds__(kBlock)
     k_ba_cam_prepare(int N, const double* __restrict__ q, double* __restrict__ camR) {
   for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
@@ -148,24 +153,23 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
-// ---- linearize ---------------------------------------------------------------------------------
-// cost, robust weights, gradient, squared column norms.  part[block][2] = {cost, max |g_pt|}.
+// ---- linearize, point side ----------------------------------------------------------------------
+// One thread per track: cost, robust weights, the stored Jacobian planes (scaled by sqrt(w)),
+// H_pp / g_p per track.  part[block][2] = {cost, max |g_pt|}.
+template <int F>
 __global__ void __launch_bounds__(kBlock)
-    k_ba_linearize(BaParams g, const double* __restrict__ camR, const double* __restrict__ t,
-                   const double* __restrict__ X, const double* __restrict__ par, double* __restrict__ wrob,
-                   double* __restrict__ ptdiag, double* __restrict__ diag, double* __restrict__ grad,
-                   double* __restrict__ intr_acc /* [K][16]: diag 8 | grad 8 */, double* __restrict__ part) {
-  __shared__ double smem[4 * 16];
-  __shared__ int skey;
+    k_ba_lin_track(BaDev g, const double* __restrict__ camR, const double* __restrict__ t,
+                   const double* __restrict__ X, const double* __restrict__ par, double2* __restrict__ jt,
+                   double* __restrict__ ptdiag, double* __restrict__ ptH, double* __restrict__ part) {
+  __shared__ double smem[8];
   double cost = 0.0, gmax = 0.0;
-  RunAcc<16> ia;
-  ia.clear();
-  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.P; p += (long)gridDim.x * blockDim.x) {
-    if (!g.used[p]) continue;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.g.P; p += (long)gridDim.x * blockDim.x) {
+    if (!g.g.used[p]) continue;
     const V3 Xp = ld3(X + 3 * p);
-    double pd[3] = {0, 0, 0}, pg[3] = {0, 0, 0};
-    for (long k = g.off[p]; k < g.off[p + 1]; ++k) {
-      const int n = g.cam[k];
+    S3 H{0, 0, 0, 0, 0, 0};
+    V3 gp{0, 0, 0};
+    for (long k = g.g.off[p]; k < g.g.off[p + 1]; ++k) {
+      const int n = g.g.cam[k];
       const int ik = g.cam_intr[n];
       const double* R9 = camR + 9 * (long)n;
       ObsGeom o;
@@ -175,52 +179,134 @@ __global__ void __launch_bounds__(kBlock)
       double rho, w;
       huber(g.huber_a, 1.0, r0 * r0 + r1 * r1, rho, w);
       if (!o.valid) w = 0.0;
-      wrob[k] = w;
       cost += 0.5 * rho;
       ObsJac J;
       build_jac(g, n, R9, o, J);
-      mask_intr(g.intr_free[ik], o.Jp);
-      const double g0 = w * r0, g1 = w * r1;
+      const double sw = sqrt(w);
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const double dj = w * (J.Jpose[0][j] * J.Jpose[0][j] + J.Jpose[1][j] * J.Jpose[1][j]);
-        const double gj = J.Jpose[0][j] * g0 + J.Jpose[1][j] * g1;
-        if (dj != 0.0) unsafeAtomicAdd(diag + 6 * (long)n + j, dj);
-        if (gj != 0.0) unsafeAtomicAdd(grad + 6 * (long)n + j, gj);
-      }
+      for (int j = 0; j < 6; ++j) jt[(PL_A + j) * g.Mp + k] = make_double2(sw * J.Jpose[0][j], sw * J.Jpose[1][j]);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        pd[j] += w * (J.Jpt[0][j] * J.Jpt[0][j] + J.Jpt[1][j] * J.Jpt[1][j]);
-        pg[j] += J.Jpt[0][j] * g0 + J.Jpt[1][j] * g1;
-      }
-      ia.select(ik, intr_acc);
+      for (int j = 0; j < 3; ++j) jt[(PL_B + j) * g.Mp + k] = make_double2(sw * J.Jpt[0][j], sw * J.Jpt[1][j]);
+      if constexpr (F > 0) {
+        const Map8 mp = load_map(g.intr_map + 8 * (long)ik);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        ia.v[j] += w * (o.Jp[0][j] * o.Jp[0][j] + o.Jp[1][j] * o.Jp[1][j]);
-        ia.v[8 + j] += o.Jp[0][j] * g0 + o.Jp[1][j] * g1;
+        for (int j = 0; j < F; ++j) {
+          const int pm = mp.m[j];
+          jt[(PL_I + j) * g.Mp + k] = make_double2(sw * sel8(o.Jp[0], pm), sw * sel8(o.Jp[1], pm));
+        }
       }
+      jt[(PL_I + F) * g.Mp + k] = make_double2(sw * r0, sw * r1);
+      H.xx += w * (J.Jpt[0][0] * J.Jpt[0][0] + J.Jpt[1][0] * J.Jpt[1][0]);
+      H.xy += w * (J.Jpt[0][0] * J.Jpt[0][1] + J.Jpt[1][0] * J.Jpt[1][1]);
+      H.xz += w * (J.Jpt[0][0] * J.Jpt[0][2] + J.Jpt[1][0] * J.Jpt[1][2]);
+      H.yy += w * (J.Jpt[0][1] * J.Jpt[0][1] + J.Jpt[1][1] * J.Jpt[1][1]);
+      H.yz += w * (J.Jpt[0][1] * J.Jpt[0][2] + J.Jpt[1][1] * J.Jpt[1][2]);
+      H.zz += w * (J.Jpt[0][2] * J.Jpt[0][2] + J.Jpt[1][2] * J.Jpt[1][2]);
+      gp.x += w * (J.Jpt[0][0] * r0 + J.Jpt[1][0] * r1);
+      gp.y += w * (J.Jpt[0][1] * r0 + J.Jpt[1][1] * r1);
+      gp.z += w * (J.Jpt[0][2] * r0 + J.Jpt[1][2] * r1);
     }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      ptdiag[3 * p + j] = pd[j];
-      gmax = fmax(gmax, fabs(pg[j]));
-    }
+    ptdiag[3 * p] = H.xx;
+    ptdiag[3 * p + 1] = H.yy;
+    ptdiag[3 * p + 2] = H.zz;
+    double* hp = ptH + 9 * p;
+    hp[0] = H.xx; hp[1] = H.xy; hp[2] = H.xz; hp[3] = H.yy; hp[4] = H.yz; hp[5] = H.zz;
+    st3(hp + 6, gp);
+    gmax = fmax(gmax, fmax(fabs(gp.x), fmax(fabs(gp.y), fabs(gp.z))));
   }
-  ia.finish(intr_acc, smem, &skey);
   double v[1] = {cost};
   block_sum<1>(v, smem);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_down(gmax, off, 64));
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) smem[4 + (threadIdx.x >> 6)] = gmax;
-  __syncthreads();
+  const double m = block_max(gmax, smem + 4);
   if (threadIdx.x == 0) {
     part[blockIdx.x * 2] = v[0];
-    part[blockIdx.x * 2 + 1] = fmax(fmax(smem[4], smem[5]), fmax(smem[6], smem[7]));
+    part[blockIdx.x * 2 + 1] = m;
   }
 }
 
-// scatter intr_acc [K][16] into the reduced-vector layout: diag/grad [6N + 8k + j]
+// ---- linearize, camera side -------------------------------------------------------------------------
+// One wave per camera: robust weights in camera-major order (c_w), squared column norms and gradient
+// of the pose block; the intrinsics share of this camera goes to ipart[n][16] = (diag 8 | grad 8).
+__global__ void __launch_bounds__(kBlock)
+    k_ba_lin_cam(BaDev g, const double* __restrict__ camR, const double* __restrict__ t,
+                 const double* __restrict__ X, const double* __restrict__ par, double* __restrict__ c_w,
+                 double* __restrict__ diag, double* __restrict__ grad, double* __restrict__ ipart) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (kBlock / 64);
+  for (int n = wave; n < g.g.N; n += nwaves) {
+    const int ik = g.cam_intr[n];
+    const int model = g.intr_model[ik];
+    const unsigned char bits = g.intr_free[ik];
+    const double* R9 = camR + 9 * (long)n;
+    const double* t3 = t + 3 * (long)n;
+    const double* pp = par + 8 * (long)ik;
+    double acc[28];
+#pragma unroll
+    for (int j = 0; j < 28; ++j) acc[j] = 0.0;
+    for (int k = g.g.coff[n] + lane; k < g.g.coff[n + 1]; k += 64) {
+      ObsGeom o;
+      obs_geom(R9, t3, ld3(X + 3 * (long)g.g.c_pt[k]), model, pp, o);
+      const double r0 = o.valid ? o.px - g.c_xy[2 * (long)k] : 0.0;
+      const double r1 = o.valid ? o.py - g.c_xy[2 * (long)k + 1] : 0.0;
+      double rho, w;
+      huber(g.huber_a, 1.0, r0 * r0 + r1 * r1, rho, w);
+      if (!o.valid) w = 0.0;
+      c_w[k] = w;
+      ObsJac J;
+      build_jac(g, n, R9, o, J);
+      const double g0 = w * r0, g1 = w * r1;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        acc[j] += w * (J.Jpose[0][j] * J.Jpose[0][j] + J.Jpose[1][j] * J.Jpose[1][j]);
+        acc[6 + j] += J.Jpose[0][j] * g0 + J.Jpose[1][j] * g1;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if ((bits >> j) & 1) {
+          acc[12 + j] += w * (o.Jp[0][j] * o.Jp[0][j] + o.Jp[1][j] * o.Jp[1][j]);
+          acc[20 + j] += o.Jp[0][j] * g0 + o.Jp[1][j] * g1;
+        }
+      }
+    }
+    wave_allsum<28>(acc);
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        diag[6 * (long)n + j] = acc[j];
+        grad[6 * (long)n + j] = acc[6 + j];
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) ipart[16 * (long)n + j] = acc[12 + j];
+    }
+  }
+}
+
+// out[k][0..W) = sum over the cameras of intrinsics block k of part[cam][0..W)   (one block per group,
+// fixed order: thread-strided partial sums, then the block tree)
+template <int W>
+__global__ void __launch_bounds__(kBlock)
+    k_ba_group_sum(int K, const int* __restrict__ ioff, const int* __restrict__ icams,
+                   const double* __restrict__ part, double* __restrict__ out) {
+  __shared__ double smem[4 * W];
+  for (int k = blockIdx.x; k < K; k += gridDim.x) {
+    double acc[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) acc[j] = 0.0;
+    for (int i = ioff[k] + threadIdx.x; i < ioff[k + 1]; i += blockDim.x) {
+      const double* s = part + (long)W * icams[i];
+#pragma unroll
+      for (int j = 0; j < W; ++j) acc[j] += s[j];
+    }
+    block_sum<W>(acc, smem);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int j = 0; j < W; ++j) out[(long)W * k + j] = acc[j];
+    }
+    __syncthreads();
+  }
+}
+
+// scatter iacc16 [K][16] into the reduced-vector layout: diag/grad [6N + 8k + j]
 __global__ void __launch_bounds__(kBlock)
     k_ba_intr_unpack16(int N, int K, const double* __restrict__ intr_acc, double* __restrict__ diag,
                        double* __restrict__ grad) {
@@ -244,14 +330,10 @@ __global__ void __launch_bounds__(kBlock)
   for (int i = threadIdx.x; i < nvec; i += blockDim.x) gmax = fmax(gmax, fabs(vec[i]));
   double v[1] = {cost};
   block_sum<1>(v, smem);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_down(gmax, off, 64));
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) smem[4 + (threadIdx.x >> 6)] = gmax;
-  __syncthreads();
+  const double m = block_max(gmax, smem + 4);
   if (threadIdx.x == 0) {
     out[0] = v[0];
-    out[1] = fmax(fmax(smem[4], smem[5]), fmax(smem[6], smem[7]));
+    out[1] = m;
   }
 }
 
@@ -262,50 +344,17 @@ __global__ void __launch_bounds__(kBlock)
     js[i] = enabled ? 1.0 / (1.0 + sqrt(diag[i])) : 1.0;
 }
 
-__device__ __forceinline__ double lm_damping(double h, double js, double radius, double lo, double hi) {
-  const double j2 = js * js;
-  return fmin(fmax(j2 * h, lo), hi) / (radius * j2);
-}
-
-// ---- build (radius dependent) ---------------------------------------------------------------------
-// Per track: H_pp (+ damping) -> inverse, e = H_pp^-1 g_p; per observation the reduced gradient
-// J_a^T w (r - J_pt e) and the diagonal Schur blocks J_a^T W_k J_a, W_k = w (I - w J_pt H_pp^-1 J_pt^T).
+// ---- build, point side (radius dependent) -----------------------------------------------------------
+// One thread per track: H_pp + damping -> inverse, e = H_pp^-1 g_p; writes the two point records.
 __global__ void __launch_bounds__(kBlock)
-    k_ba_build(BaParams g, double radius, const double* __restrict__ camR, const double* __restrict__ t,
-               const double* __restrict__ X, const double* __restrict__ par, const double* __restrict__ wrob,
-               const double* __restrict__ ptdiag, const double* __restrict__ ptjs, double* __restrict__ hinv,
-               double* __restrict__ ept, double* __restrict__ gred, double* __restrict__ spose,
-               double* __restrict__ intr_acc /* [K][44]: gred 8 | S 36 */) {
-  __shared__ double smem[4 * 44];
-  __shared__ int skey;
-  RunAcc<44> ia;
-  ia.clear();
-  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.P; p += (long)gridDim.x * blockDim.x) {
-    if (!g.used[p]) continue;
+    k_ba_build_track(BaDev g, double radius, const double* __restrict__ X, const double* __restrict__ ptH,
+                     const double* __restrict__ ptdiag, const double* __restrict__ ptjs,
+                     double* __restrict__ ptb, double* __restrict__ ptrec) {
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.g.P; p += (long)gridDim.x * blockDim.x) {
+    if (!g.g.used[p]) continue;
     const V3 Xp = ld3(X + 3 * p);
-    S3 H{0, 0, 0, 0, 0, 0};
-    V3 gp{0, 0, 0};
-    for (long k = g.off[p]; k < g.off[p + 1]; ++k) {
-      const int n = g.cam[k];
-      const int ik = g.cam_intr[n];
-      const double* R9 = camR + 9 * (long)n;
-      ObsGeom o;
-      obs_geom(R9, t + 3 * (long)n, Xp, g.intr_model[ik], par + 8 * (long)ik, o);
-      const double w = wrob[k];
-      const double r0 = o.valid ? o.px - g.xy[2 * k] : 0.0;
-      const double r1 = o.valid ? o.py - g.xy[2 * k + 1] : 0.0;
-      ObsJac J;
-      build_jac(g, n, R9, o, J);
-      H.xx += w * (J.Jpt[0][0] * J.Jpt[0][0] + J.Jpt[1][0] * J.Jpt[1][0]);
-      H.xy += w * (J.Jpt[0][0] * J.Jpt[0][1] + J.Jpt[1][0] * J.Jpt[1][1]);
-      H.xz += w * (J.Jpt[0][0] * J.Jpt[0][2] + J.Jpt[1][0] * J.Jpt[1][2]);
-      H.yy += w * (J.Jpt[0][1] * J.Jpt[0][1] + J.Jpt[1][1] * J.Jpt[1][1]);
-      H.yz += w * (J.Jpt[0][1] * J.Jpt[0][2] + J.Jpt[1][1] * J.Jpt[1][2]);
-      H.zz += w * (J.Jpt[0][2] * J.Jpt[0][2] + J.Jpt[1][2] * J.Jpt[1][2]);
-      gp.x += w * (J.Jpt[0][0] * r0 + J.Jpt[1][0] * r1);
-      gp.y += w * (J.Jpt[0][1] * r0 + J.Jpt[1][1] * r1);
-      gp.z += w * (J.Jpt[0][2] * r0 + J.Jpt[1][2] * r1);
-    }
+    const double* hp = ptH + 9 * p;
+    S3 H{hp[0], hp[1], hp[2], hp[3], hp[4], hp[5]};
     S3 Hi{0, 0, 0, 0, 0, 0};
     V3 e{0, 0, 0};
     if (g.opt_pts) {
@@ -313,23 +362,52 @@ __global__ void __launch_bounds__(kBlock)
       H.yy += lm_damping(ptdiag[3 * p + 1], ptjs[3 * p + 1], radius, g.lm_lo, g.lm_hi);
       H.zz += lm_damping(ptdiag[3 * p + 2], ptjs[3 * p + 2], radius, g.lm_lo, g.lm_hi);
       Hi = inv3(H);
-      e = mul(Hi, gp);
+      e = mul(Hi, ld3(hp + 6));
     }
-    double* hp = hinv + 6 * p;
-    hp[0] = Hi.xx; hp[1] = Hi.xy; hp[2] = Hi.xz; hp[3] = Hi.yy; hp[4] = Hi.yz; hp[5] = Hi.zz;
-    st3(ept + 3 * p, e);
-    for (long k = g.off[p]; k < g.off[p + 1]; ++k) {
-      const int n = g.cam[k];
-      const int ik = g.cam_intr[n];
-      const double* R9 = camR + 9 * (long)n;
-      ObsGeom o;
-      obs_geom(R9, t + 3 * (long)n, Xp, g.intr_model[ik], par + 8 * (long)ik, o);
-      const double w = wrob[k];
+    double* b = ptb + 12 * p;
+    st3(b, Xp);
+    st3(b + 3, e);
+    b[6] = Hi.xx; b[7] = Hi.xy; b[8] = Hi.xz; b[9] = Hi.yy; b[10] = Hi.yz; b[11] = Hi.zz;
+    double* pr = ptrec + 8 * p;
+    st3(pr, Xp);
+    pr[3] = pr[4] = pr[5] = 0.0;
+  }
+}
+
+// ---- build, camera side ------------------------------------------------------------------------------
+// One wave per camera: reduced gradient J_a^T w (r - J_pt e) and the diagonal Schur blocks
+// J_a^T W_k J_a, W_k = w (I - w J_pt H_pp^-1 J_pt^T), for the pose block (6 + 21) and this camera's
+// share of its intrinsics block (ipart[n][44] = gred 8 | S 36).
+__global__ void __launch_bounds__(kBlock)
+    k_ba_build_cam(BaDev g, const double* __restrict__ camR, const double* __restrict__ t,
+                   const double* __restrict__ par, const double* __restrict__ c_w,
+                   const double* __restrict__ ptb, double* __restrict__ gred, double* __restrict__ spose,
+                   double* __restrict__ ipart) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (kBlock / 64);
+  for (int n = wave; n < g.g.N; n += nwaves) {
+    const int ik = g.cam_intr[n];
+    const int model = g.intr_model[ik];
+    const unsigned char bits = g.intr_free[ik];
+    const double* R9 = camR + 9 * (long)n;
+    const double* t3 = t + 3 * (long)n;
+    const double* pp = par + 8 * (long)ik;
+    double acc[71];  // gred 6 | spose 21 | igred 8 | sii 36
+#pragma unroll
+    for (int j = 0; j < 71; ++j) acc[j] = 0.0;
+    for (int k = g.g.coff[n] + lane; k < g.g.coff[n + 1]; k += 64) {
+      const double w = c_w[k];
       if (w == 0.0) continue;
-      const double r0 = o.px - g.xy[2 * k], r1 = o.py - g.xy[2 * k + 1];
+      const double* b = ptb + 12 * (long)g.g.c_pt[k];
+      const V3 e = ld3(b + 3);
+      const S3 Hi{b[6], b[7], b[8], b[9], b[10], b[11]};
+      ObsGeom o;
+      obs_geom(R9, t3, ld3(b), model, pp, o);
+      const double r0 = o.px - g.c_xy[2 * (long)k], r1 = o.py - g.c_xy[2 * (long)k + 1];
       ObsJac J;
       build_jac(g, n, R9, o, J);
-      mask_intr(g.intr_free[ik], o.Jp);
+      mask_intr(bits, o.Jp);
       // r - J_pt e
       const double q0 = r0 - (J.Jpt[0][0] * e.x + J.Jpt[0][1] * e.y + J.Jpt[0][2] * e.z);
       const double q1 = r1 - (J.Jpt[1][0] * e.x + J.Jpt[1][1] * e.y + J.Jpt[1][2] * e.z);
@@ -340,32 +418,35 @@ __global__ void __launch_bounds__(kBlock)
       const double T01 = J.Jpt[0][0] * h1.x + J.Jpt[0][1] * h1.y + J.Jpt[0][2] * h1.z;
       const double T11 = J.Jpt[1][0] * h1.x + J.Jpt[1][1] * h1.y + J.Jpt[1][2] * h1.z;
       const double W00 = w * (1.0 - w * T00), W01 = -w * w * T01, W11 = w * (1.0 - w * T11);
-      double* gr = gred + 6 * (long)n;
-      double* sp = spose + 21 * (long)n;
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        const double gi = w * (J.Jpose[0][i] * q0 + J.Jpose[1][i] * q1);
-        if (gi != 0.0) unsafeAtomicAdd(gr + i, gi);
+        acc[i] += w * (J.Jpose[0][i] * q0 + J.Jpose[1][i] * q1);
         const double a0 = W00 * J.Jpose[0][i] + W01 * J.Jpose[1][i];
         const double a1 = W01 * J.Jpose[0][i] + W11 * J.Jpose[1][i];
 #pragma unroll
-        for (int j = i; j < 6; ++j) {
-          const double sij = a0 * J.Jpose[0][j] + a1 * J.Jpose[1][j];
-          if (sij != 0.0) unsafeAtomicAdd(sp + sym6(i, j), sij);
+        for (int j = i; j < 6; ++j) acc[6 + sym6(i, j)] += a0 * J.Jpose[0][j] + a1 * J.Jpose[1][j];
+      }
+      if (bits) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          acc[27 + i] += w * (o.Jp[0][i] * q0 + o.Jp[1][i] * q1);
+          const double a0 = W00 * o.Jp[0][i] + W01 * o.Jp[1][i];
+          const double a1 = W01 * o.Jp[0][i] + W11 * o.Jp[1][i];
+#pragma unroll
+          for (int j = i; j < 8; ++j) acc[35 + sym8(i, j)] += a0 * o.Jp[0][j] + a1 * o.Jp[1][j];
         }
       }
-      ia.select(ik, intr_acc);
+    }
+    wave_allsum<71>(acc);
+    if (lane == 0) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        ia.v[i] += w * (o.Jp[0][i] * q0 + o.Jp[1][i] * q1);
-        const double a0 = W00 * o.Jp[0][i] + W01 * o.Jp[1][i];
-        const double a1 = W01 * o.Jp[0][i] + W11 * o.Jp[1][i];
+      for (int j = 0; j < 6; ++j) gred[6 * (long)n + j] = acc[j];
 #pragma unroll
-        for (int j = i; j < 8; ++j) ia.v[8 + sym8(i, j)] += a0 * o.Jp[0][j] + a1 * o.Jp[1][j];
-      }
+      for (int j = 0; j < 21; ++j) spose[21 * (long)n + j] = acc[6 + j];
+#pragma unroll
+      for (int j = 0; j < 44; ++j) ipart[44 * (long)n + j] = acc[27 + j];
     }
   }
-  ia.finish(intr_acc, smem, &skey);
 }
 
 // One thread per block of the block-Jacobi preconditioner: damping, rhs = -g', dense inverse.
@@ -413,177 +494,242 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// ---- the hot pair: w = (H_aa - H_ap H_pp^-1 H_pa + D) z ---------------------------------------------
+// Phase A, track-major, one lane per observation over the stored planes:
+//   u_k = A_k z_{c(k)} + I_k z_{intr(k)},   t_p = H_pp^-1 sum_k B_k^T u_k  ->  ptrec[p].t
+// Algorithmic bytes per observation: (9 + F) double2 planes = 16 (9 + F), + cam 4 + pt 4; per track 24
+// written; the gathers of z (48 B per camera, 8 F per intrinsics block) are L2-resident.
+template <int F>
 __global__ void __launch_bounds__(kBlock)
-    k_ba_block_desc(int N, int K, int* __restrict__ elem_blk, int* __restrict__ blk_start,
-                    int* __restrict__ blk_size, int* __restrict__ blk_moff) {
-  const int n = 6 * N + 8 * K;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    if (i < 6 * N) {
-      const int b = i / 6;
-      elem_blk[i] = b;
-      if (i % 6 == 0) {
-        blk_start[b] = i;
-        blk_size[b] = 6;
-        blk_moff[b] = 36 * b;
+    k_ba_phaseA(BaDev g, CgVec v, int it, double tol2, const double2* __restrict__ jt,
+                const double* __restrict__ ptb, double* __restrict__ ptrec) {
+  __shared__ double smem[4 * 2 + 2];
+  if (cg_converged(v, it, tol2, smem)) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (kBlock / 64);
+  const double* zintr = v.z + 6 * (long)g.g.N;
+  for (int tile = wave; tile < g.g.T; tile += nwaves) {
+    const int p0 = g.g.tile[tile], p1 = g.g.tile[tile + 1];
+    const long k0 = g.g.off[p0], k1 = g.g.off[p1];
+    double acc[3] = {0, 0, 0};
+    int key = -1 - lane;
+    for (long k = k0 + lane; k < k1; k += 64) {
+      const int p = g.g.obs_pt[k];
+      key = p;
+      if (!g.g.used[p]) continue;
+      const long n = g.g.cam[k];
+      const double2* zp = reinterpret_cast<const double2*>(v.z + 6 * n);
+      const double2 z01 = zp[0], z23 = zp[1], z45 = zp[2];
+      const double zz[6] = {z01.x, z01.y, z23.x, z23.y, z45.x, z45.y};
+      double u0 = 0.0, u1 = 0.0;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const double2 a = jt[(PL_A + j) * g.Mp + k];
+        u0 += a.x * zz[j];
+        u1 += a.y * zz[j];
       }
-    } else {
-      const int k = (i - 6 * N) / 8;
-      elem_blk[i] = N + k;
-      if ((i - 6 * N) % 8 == 0) {
-        blk_start[N + k] = i;
-        blk_size[N + k] = 8;
-        blk_moff[N + k] = 36 * N + 64 * k;
+      if constexpr (F > 0) {
+        const int ik = g.cam_intr[n];
+        const Map8 mp = load_map(g.intr_map + 8 * (long)ik);
+        const double* zi = zintr + 8 * (long)ik;
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+          const int pm = mp.m[j];
+          const double zv = pm >= 0 ? zi[pm] : 0.0;
+          const double2 a = jt[(PL_I + j) * g.Mp + k];
+          u0 += a.x * zv;
+          u1 += a.y * zv;
+        }
       }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const double2 b = jt[(PL_B + j) * g.Mp + k];
+        acc[j] += b.x * u0 + b.y * u1;
+      }
+    }
+    seg_scan<3>(acc, key, lane);
+    if (seg_is_tail(key, lane) && key >= 0 && g.g.used[key]) {
+      const double* b = ptb + 12 * (long)key;
+      const V3 tp = mul(S3{b[6], b[7], b[8], b[9], b[10], b[11]}, V3{acc[0], acc[1], acc[2]});
+      st3(ptrec + 8 * (long)key + 3, tp);
     }
   }
 }
 
-// ---- the hot kernel: y += (H_aa - H_ap H_pp^-1 H_pa) v over this rank's tracks ------------------
-// One thread per track, Jacobians recomputed on the fly.  Algorithmic bytes per launch
-// (SURVEY.md §8d, K-BA-res, matrix-free): 28 M + 392 N + 120 P + 32 K.
+// Phase B, camera-major, one wave per camera, Jacobian recomputed from the gathered point record:
+//   w_n = sum_k J_a^T w_k (J_a z_a - J_pt t_p) + D_n z_n,   yi_part[n] = this camera's intrinsics rows.
+// Algorithmic bytes per observation: c_w 8 + c_pt 4 + the 64-byte point record (X_p, t_p).
 __global__ void __launch_bounds__(kBlock)
-    k_ba_schur_matvec(BaParams g, const double* __restrict__ camR, const double* __restrict__ t,
-                      const double* __restrict__ X, const double* __restrict__ par,
-                      const double* __restrict__ wrob, const double* __restrict__ hinv,
-                      const double* __restrict__ v, double* __restrict__ y) {
-  __shared__ double smem[4 * 8];
-  __shared__ int skey;
-  RunAcc<8> ia;
-  ia.clear();
-  double* yintr = y + 6 * (long)g.N;
-  const double* vintr = v + 6 * (long)g.N;
-  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.P; p += (long)gridDim.x * blockDim.x) {
-    if (!g.used[p]) continue;
-    const V3 Xp = ld3(X + 3 * p);
-    const long k0 = g.off[p], k1 = g.off[p + 1];
-    V3 acc{0, 0, 0};
-    for (long k = k0; k < k1; ++k) {
-      const double w = wrob[k];
+    k_ba_phaseB(BaDev g, CgVec v, double yscale, const double* __restrict__ camR, const double* __restrict__ t,
+                const double* __restrict__ par, const double* __restrict__ c_w,
+                const double* __restrict__ ptrec, const double* __restrict__ dvec, double* __restrict__ yi_part) {
+  __shared__ double sdelta[kBlock / 64];
+  if (v.st->done) return;
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int wave = blockIdx.x * (kBlock / 64) + wid;
+  const int nwaves = gridDim.x * (kBlock / 64);
+  double delta = 0.0;
+  for (int n = wave; n < g.g.N; n += nwaves) {
+    const int ik = g.cam_intr[n];
+    const int model = g.intr_model[ik];
+    const unsigned char bits = g.intr_free[ik];
+    const double* R9 = camR + 9 * (long)n;
+    const double* t3 = t + 3 * (long)n;
+    const double* pp = par + 8 * (long)ik;
+    const bool rf = g.opt_rot && n != g.fixed_cam, tf = g.opt_trn && n != g.fixed_cam;
+    const double* zp = v.z + 6 * (long)n;
+    const V3 zr{zp[0], zp[1], zp[2]}, zt{zp[3], zp[4], zp[5]};
+    double zi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zi[j] = ((bits >> j) & 1) ? v.z[6 * (long)g.g.N + 8 * (long)ik + j] : 0.0;
+    double acc[14];
+#pragma unroll
+    for (int j = 0; j < 14; ++j) acc[j] = 0.0;
+    for (int k = g.g.coff[n] + lane; k < g.g.coff[n + 1]; k += 64) {
+      const double w = c_w[k];
       if (w == 0.0) continue;
-      const int n = g.cam[k];
-      const int ik = g.cam_intr[n];
-      const double* R9 = camR + 9 * (long)n;
+      const double* pr = ptrec + 8 * (long)g.g.c_pt[k];
       ObsGeom o;
-      obs_geom(R9, t + 3 * (long)n, Xp, g.intr_model[ik], par + 8 * (long)ik, o);
-      const bool rf = g.opt_rot && n != g.fixed_cam, tf = g.opt_trn && n != g.fixed_cam;
-      const double* vp = v + 6 * (long)n;
-      V3 om{0, 0, 0};
-      if (rf) om = 2.0 * cross(V3{vp[0], vp[1], vp[2]}, o.a);
-      if (tf) om = om + V3{vp[3], vp[4], vp[5]};
+      obs_geom(R9, t3, ld3(pr), model, pp, o);
+      V3 om = V3{0, 0, 0} - R_mul(R9, ld3(pr + 3));  // - J_pt t_p = - Jx (R t_p)
+      if (rf) om = om + 2.0 * cross(zr, o.a);
+      if (tf) om = om + zt;
       double u0, u1;
       jx_mul(o.Jx, om, u0, u1);
-      const unsigned char bits = g.intr_free[ik];
-      const double* vi = vintr + 8 * (long)ik;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         if ((bits >> j) & 1) {
-          u0 += o.Jp[0][j] * vi[j];
-          u1 += o.Jp[1][j] * vi[j];
-        }
-      }
-      acc = acc + RT_mul(R9, jxT_mul(o.Jx, w * u0, w * u1));  // J_pt^T w u
-    }
-    V3 tp{0, 0, 0};
-    if (g.opt_pts) {
-      const double* hp = hinv + 6 * p;
-      tp = mul(S3{hp[0], hp[1], hp[2], hp[3], hp[4], hp[5]}, acc);
-    }
-    for (long k = k0; k < k1; ++k) {
-      const double w = wrob[k];
-      if (w == 0.0) continue;
-      const int n = g.cam[k];
-      const int ik = g.cam_intr[n];
-      const double* R9 = camR + 9 * (long)n;
-      ObsGeom o;
-      obs_geom(R9, t + 3 * (long)n, Xp, g.intr_model[ik], par + 8 * (long)ik, o);
-      const bool rf = g.opt_rot && n != g.fixed_cam, tf = g.opt_trn && n != g.fixed_cam;
-      const double* vp = v + 6 * (long)n;
-      V3 om{0, 0, 0};
-      if (rf) om = 2.0 * cross(V3{vp[0], vp[1], vp[2]}, o.a);
-      if (tf) om = om + V3{vp[3], vp[4], vp[5]};
-      om = om - R_mul(R9, tp);  // ... - J_pt t_p
-      double u0, u1;
-      jx_mul(o.Jx, om, u0, u1);
-      const unsigned char bits = g.intr_free[ik];
-      const double* vi = vintr + 8 * (long)ik;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if ((bits >> j) & 1) {
-          u0 += o.Jp[0][j] * vi[j];
-          u1 += o.Jp[1][j] * vi[j];
+          u0 += o.Jp[0][j] * zi[j];
+          u1 += o.Jp[1][j] * zi[j];
         }
       }
       const double g0 = w * u0, g1 = w * u1;
       const V3 h = jxT_mul(o.Jx, g0, g1);
-      double* yp = y + 6 * (long)n;
-      if (rf) atomic_add3(yp, 2.0 * cross(o.a, h));
-      if (tf) atomic_add3(yp + 3, h);
-      if (bits) {
-        ia.select(ik, yintr);
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if ((bits >> j) & 1) ia.v[j] += o.Jp[0][j] * g0 + o.Jp[1][j] * g1;
+      if (rf) {
+        const V3 yr = 2.0 * cross(o.a, h);
+        acc[0] += yr.x;
+        acc[1] += yr.y;
+        acc[2] += yr.z;
       }
+      if (tf) {
+        acc[3] += h.x;
+        acc[4] += h.y;
+        acc[5] += h.z;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if ((bits >> j) & 1) acc[6 + j] += o.Jp[0][j] * g0 + o.Jp[1][j] * g1;
+    }
+    wave_allsum<14>(acc);
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const double wv = acc[j] + yscale * dvec[6 * (long)n + j] * zp[j];
+        v.w[6 * (long)n + j] = wv;
+        delta += zp[j] * wv;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) yi_part[8 * (long)n + j] = acc[6 + j];
     }
   }
-  ia.finish(yintr, smem, &skey);
+  if (lane == 0) sdelta[wid] = delta;
+  __syncthreads();
+  if (threadIdx.x == 0) v.dpart[blockIdx.x] = (sdelta[0] + sdelta[1]) + (sdelta[2] + sdelta[3]);
+}
+
+// Intrinsics rows of w: one block per intrinsics block sums its cameras' shares (fixed order), adds the
+// damping term and this block's part of delta = z.w into dpart[slot0 + blockIdx].
+__global__ void __launch_bounds__(kBlock)
+    k_ba_phaseI(BaDev g, CgVec v, double yscale, const double* __restrict__ yi_part,
+                const double* __restrict__ dvec, int slot0) {
+  __shared__ double smem[4 * 8];
+  if (v.st->done) return;
+  double delta = 0.0;
+  for (int k = blockIdx.x; k < g.K; k += gridDim.x) {
+    double acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0;
+    for (int i = g.ioff[k] + threadIdx.x; i < g.ioff[k + 1]; i += blockDim.x) {
+      const double* s = yi_part + 8 * (long)g.icams[i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += s[j];
+    }
+    block_sum<8>(acc, smem);
+    if (threadIdx.x == 0) {
+      const unsigned char bits = g.intr_free[k];
+      const long o = 6 * (long)g.g.N + 8 * (long)k;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const double zj = v.z[o + j];
+        const double wv = (((bits >> j) & 1) ? acc[j] : 0.0) + yscale * dvec[o + j] * zj;
+        v.w[o + j] = wv;
+        delta += zj * wv;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) v.dpart[slot0 + blockIdx.x] = delta;
 }
 
 // ---- back-substitution, model cost change, candidate points ------------------------------------
-// part[block][3] = {model_cost_change, |dX|^2, |X|^2}
+// One thread per track over the stored planes.  part[block][3] = {model_cost_change, |dX|^2, |X|^2}
+template <int F>
 __global__ void __launch_bounds__(kBlock)
-    k_ba_backsub(BaParams g, const double* __restrict__ camR, const double* __restrict__ t,
-                 const double* __restrict__ X, const double* __restrict__ par, const double* __restrict__ wrob,
-                 const double* __restrict__ hinv, const double* __restrict__ ept, const double* __restrict__ dv,
-                 double* __restrict__ Xn, double* __restrict__ part) {
+    k_ba_backsub(BaDev g, const double* __restrict__ X, const double2* __restrict__ jt,
+                 const double* __restrict__ ptb, const double* __restrict__ dv, double* __restrict__ Xn,
+                 double* __restrict__ part) {
   __shared__ double smem[4 * 3];
   double acc3[3] = {0, 0, 0};
-  const double* dintr = dv + 6 * (long)g.N;
-  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.P; p += (long)gridDim.x * blockDim.x) {
+  const double* dintr = dv + 6 * (long)g.g.N;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.g.P; p += (long)gridDim.x * blockDim.x) {
     const V3 Xp = ld3(X + 3 * p);
-    if (!g.used[p]) {
+    if (!g.g.used[p]) {
       st3(Xn + 3 * p, Xp);
       continue;
     }
-    const long k0 = g.off[p], k1 = g.off[p + 1];
+    const long k0 = g.g.off[p], k1 = g.g.off[p + 1];
     V3 dX{0, 0, 0};
     for (int pass = 0; pass < 2; ++pass) {
       V3 acc{0, 0, 0};
       for (long k = k0; k < k1; ++k) {
-        const double w = wrob[k];
-        if (w == 0.0) continue;
-        const int n = g.cam[k];
-        const int ik = g.cam_intr[n];
-        const double* R9 = camR + 9 * (long)n;
-        ObsGeom o;
-        obs_geom(R9, t + 3 * (long)n, Xp, g.intr_model[ik], par + 8 * (long)ik, o);
-        const bool rf = g.opt_rot && n != g.fixed_cam, tf = g.opt_trn && n != g.fixed_cam;
-        const double* vp = dv + 6 * (long)n;
-        V3 om{0, 0, 0};
-        if (rf) om = 2.0 * cross(V3{vp[0], vp[1], vp[2]}, o.a);
-        if (tf) om = om + V3{vp[3], vp[4], vp[5]};
-        if (pass == 1 && g.opt_pts) om = om + R_mul(R9, dX);
-        double u0, u1;
-        jx_mul(o.Jx, om, u0, u1);
-        const unsigned char bits = g.intr_free[ik];
-        const double* vi = dintr + 8 * (long)ik;
+        const long n = g.g.cam[k];
+        const double* vp = dv + 6 * n;
+        double u0 = 0.0, u1 = 0.0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if ((bits >> j) & 1) {
-            u0 += o.Jp[0][j] * vi[j];
-            u1 += o.Jp[1][j] * vi[j];
+        for (int j = 0; j < 6; ++j) {
+          const double2 a = jt[(PL_A + j) * g.Mp + k];
+          u0 += a.x * vp[j];
+          u1 += a.y * vp[j];
+        }
+        if constexpr (F > 0) {
+          const int ik = g.cam_intr[n];
+          const Map8 mp = load_map(g.intr_map + 8 * (long)ik);
+#pragma unroll
+          for (int j = 0; j < F; ++j) {
+            const int pm = mp.m[j];
+            const double zv = pm >= 0 ? dintr[8 * (long)ik + pm] : 0.0;
+            const double2 a = jt[(PL_I + j) * g.Mp + k];
+            u0 += a.x * zv;
+            u1 += a.y * zv;
           }
         }
+        const double2 b0 = jt[(PL_B + 0) * g.Mp + k], b1 = jt[(PL_B + 1) * g.Mp + k], b2 = jt[(PL_B + 2) * g.Mp + k];
         if (pass == 0) {
-          acc = acc + RT_mul(R9, jxT_mul(o.Jx, w * u0, w * u1));
+          acc.x += b0.x * u0 + b0.y * u1;
+          acc.y += b1.x * u0 + b1.y * u1;
+          acc.z += b2.x * u0 + b2.y * u1;
         } else {
-          const double r0 = o.px - g.xy[2 * k], r1 = o.py - g.xy[2 * k + 1];
-          acc3[0] -= w * (u0 * r0 + u1 * r1 + 0.5 * (u0 * u0 + u1 * u1));
+          u0 += b0.x * dX.x + b1.x * dX.y + b2.x * dX.z;
+          u1 += b0.y * dX.x + b1.y * dX.y + b2.y * dX.z;
+          const double2 rw = jt[(PL_I + F) * g.Mp + k];
+          acc3[0] -= u0 * rw.x + u1 * rw.y + 0.5 * (u0 * u0 + u1 * u1);
         }
       }
       if (pass == 0 && g.opt_pts) {
-        const double* hp = hinv + 6 * p;
-        dX = V3{0, 0, 0} - ld3(ept + 3 * p) - mul(S3{hp[0], hp[1], hp[2], hp[3], hp[4], hp[5]}, acc);
+        const double* b = ptb + 12 * p;
+        dX = V3{0, 0, 0} - ld3(b + 3) - mul(S3{b[6], b[7], b[8], b[9], b[10], b[11]}, acc);
       }
     }
     st3(Xn + 3 * p, Xp + dX);
@@ -597,15 +743,15 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
-// Candidate poses / intrinsics (single block): q' = [cos|d|, sin|d| d/|d|] * q (EigenQuaternionManifold),
-// t' = t + dt, par' = par + dpar.  out = {|step|^2, |x|^2, #non-finite}.
-__global__ void __launch_bounds__(kCgThreads)
+// Candidate poses / intrinsics: q' = [cos|d|, sin|d| d/|d|] * q (EigenQuaternionManifold),
+// t' = t + dt, par' = par + dpar.  part[block][3] = {|step|^2, |x|^2, #non-finite}.
+__global__ void __launch_bounds__(kBlock)
     k_ba_param_update(int N, int K, const double* __restrict__ q, const double* __restrict__ t,
                       const double* __restrict__ par, const double* __restrict__ dv, double* __restrict__ qn,
-                      double* __restrict__ tn, double* __restrict__ parn, double* __restrict__ out) {
-  __shared__ double smem[17];
-  double st = 0.0, xn = 0.0, bad = 0.0;
-  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+                      double* __restrict__ tn, double* __restrict__ parn, double* __restrict__ part) {
+  __shared__ double smem[4 * 3];
+  double acc[3] = {0, 0, 0};
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
     const double* d = dv + 6 * (long)n;
     const double th = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
     double s, c;
@@ -615,55 +761,51 @@ __global__ void __launch_bounds__(kCgThreads)
     const Quat q0{q[4 * n], q[4 * n + 1], q[4 * n + 2], q[4 * n + 3]};
     const Quat q1 = qmul(qd, q0);
     qn[4 * n] = q1.w; qn[4 * n + 1] = q1.x; qn[4 * n + 2] = q1.y; qn[4 * n + 3] = q1.z;
-    st += (q1.w - q0.w) * (q1.w - q0.w) + (q1.x - q0.x) * (q1.x - q0.x) + (q1.y - q0.y) * (q1.y - q0.y) +
-          (q1.z - q0.z) * (q1.z - q0.z);
-    xn += q0.w * q0.w + q0.x * q0.x + q0.y * q0.y + q0.z * q0.z;
+    acc[0] += (q1.w - q0.w) * (q1.w - q0.w) + (q1.x - q0.x) * (q1.x - q0.x) + (q1.y - q0.y) * (q1.y - q0.y) +
+              (q1.z - q0.z) * (q1.z - q0.z);
+    acc[1] += q0.w * q0.w + q0.x * q0.x + q0.y * q0.y + q0.z * q0.z;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const double tj = t[3 * n + j];
       tn[3 * n + j] = tj + d[3 + j];
-      st += d[3 + j] * d[3 + j];
-      xn += tj * tj;
+      acc[0] += d[3 + j] * d[3 + j];
+      acc[1] += tj * tj;
     }
 #pragma unroll
-    for (int j = 0; j < 6; ++j) bad += isfinite(d[j]) ? 0.0 : 1.0;
+    for (int j = 0; j < 6; ++j) acc[2] += isfinite(d[j]) ? 0.0 : 1.0;
   }
-  for (int i = threadIdx.x; i < 8 * K; i += blockDim.x) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 8 * K; i += gridDim.x * blockDim.x) {
     const double d = dv[6 * (long)N + i];
     parn[i] = par[i] + d;
-    st += d * d;
-    xn += par[i] * par[i];
-    bad += isfinite(d) ? 0.0 : 1.0;
+    acc[0] += d * d;
+    acc[1] += par[i] * par[i];
+    acc[2] += isfinite(d) ? 0.0 : 1.0;
   }
-  st = block_dot_1024(st, smem);
-  xn = block_dot_1024(xn, smem);
-  bad = block_dot_1024(bad, smem);
+  block_sum<3>(acc, smem);
   if (threadIdx.x == 0) {
-    out[0] = st;
-    out[1] = xn;
-    out[2] = bad;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) part[blockIdx.x * 3 + k] = acc[k];
   }
 }
 
+// candidate cost, one lane per observation; part[block][1]
 __global__ void __launch_bounds__(kBlock)
-    k_ba_cost(BaParams g, const double* __restrict__ camR, const double* __restrict__ t,
+    k_ba_cost(BaDev g, const double* __restrict__ camR, const double* __restrict__ t,
               const double* __restrict__ X, const double* __restrict__ par, double* __restrict__ part) {
   __shared__ double smem[4];
   double v[1] = {0.0};
-  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.P; p += (long)gridDim.x * blockDim.x) {
-    if (!g.used[p]) continue;
-    const V3 Xp = ld3(X + 3 * p);
-    for (long k = g.off[p]; k < g.off[p + 1]; ++k) {
-      const int n = g.cam[k];
-      const int ik = g.cam_intr[n];
-      ObsGeom o;
-      obs_geom(camR + 9 * (long)n, t + 3 * (long)n, Xp, g.intr_model[ik], par + 8 * (long)ik, o);
-      if (!o.valid) continue;
-      const double r0 = o.px - g.xy[2 * k], r1 = o.py - g.xy[2 * k + 1];
-      double rho, w;
-      huber(g.huber_a, 1.0, r0 * r0 + r1 * r1, rho, w);
-      v[0] += 0.5 * rho;
-    }
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < g.g.M; k += (long)gridDim.x * blockDim.x) {
+    const long p = g.g.obs_pt[k];
+    if (!g.g.used[p]) continue;
+    const int n = g.g.cam[k];
+    const int ik = g.cam_intr[n];
+    ObsGeom o;
+    obs_geom(camR + 9 * (long)n, t + 3 * (long)n, ld3(X + 3 * p), g.intr_model[ik], par + 8 * (long)ik, o);
+    if (!o.valid) continue;
+    const double r0 = o.px - g.xy[2 * k], r1 = o.py - g.xy[2 * k + 1];
+    double rho, w;
+    huber(g.huber_a, 1.0, r0 * r0 + r1 * r1, rho, w);
+    v[0] += 0.5 * rho;
   }
   block_sum<1>(v, smem);
   if (threadIdx.x == 0) part[blockIdx.x] = v[0];
@@ -685,12 +827,17 @@ __global__ void __launch_bounds__(kBlock)
 // host side
 // ------------------------------------------------------------------------------------------
 struct BaWs {
+  ObsGraphWs og;
   DevBuf<long> off;
-  DevBuf<int> cam, cam_intr, intr_model, elem_blk, blk_start, blk_size, blk_moff;
-  DevBuf<unsigned char> used, intr_free;
-  DevBuf<double> xy, q, qn, t, tn, camR, camRn, X, Xn, par, parn, wrob, hinv, ept, ptdiag, ptjs, diag, js, dvec,
-      grad, gred, rhs, spose, iacc16, iacc44, minv, cg_x, cg_r, cg_z, cg_p, cg_y, part, scal;
-  DevBuf<CgState> cg;
+  DevBuf<int> cam, cam_intr, intr_model, ioff, icams;
+  DevBuf<unsigned char> intr_free;
+  DevBuf<signed char> intr_map;
+  DevBuf<double2> jt;
+  DevBuf<double> xy, c_xy, c_w, q, qn, t, tn, camR, camRn, X, Xn, par, parn, ptH, ptb, ptrec, ptdiag, ptjs, diag, js,
+      dvec, grad, gred, rhs, spose, ipart, iacc16, iacc44, yi_part, minv, cg_x, cg_r, cg_z, cg_p, cg_s, cg_w, vpart,
+      dpart, part, scal;
+  DevBuf<CgStatus> cgst;
+  DevBuf<CgScal> cgsc;
   static void destroy(void* p) { delete static_cast<BaWs*>(p); }
 };
 
@@ -720,6 +867,16 @@ unsigned pp_mask_of(int model) {
   }
 }
 
+template <typename Fn>
+void dispatch_f(int F, Fn&& fn) {
+  switch (F) {
+    case 0: fn(std::integral_constant<int, 0>{}); break;
+    case 2: fn(std::integral_constant<int, 2>{}); break;
+    case 4: fn(std::integral_constant<int, 4>{}); break;
+    default: fn(std::integral_constant<int, 8>{}); break;
+  }
+}
+
 class BaSolver final : public LmProblem {
  public:
   BaSolver(gsfm_ctx* ctx, const gsfm_ba_options& opt) : ctx_(ctx), ws_(ba_ws(ctx)), opt_(opt) {}
@@ -739,18 +896,12 @@ class BaSolver final : public LmProblem {
     std::vector<long> h_off;
     to_host(ctx_, h_off, reinterpret_cast<const long*>(prob->pt_offset), (size_t)P_ + 1, mem);
     GSFM_REQUIRE(h_off[0] == 0 && h_off[P_] == M_, "BA: pt_offset must start at 0 and end at num_obs");
-    std::vector<unsigned char> h_used(P_);
-    m_used_ = 0;
-    for (long p = 0; p < P_; ++p) {
-      const long len = h_off[p + 1] - h_off[p];
-      GSFM_REQUIRE(len >= 0, "BA: pt_offset must be non-decreasing");
-      h_used[p] = len >= opt_.min_num_view_per_track ? 1 : 0;  // ba.cc:122
-      if (h_used[p]) m_used_ += len;
-    }
     std::vector<int> h_model, h_ci;
     to_host(ctx_, h_model, prob->intr_model, (size_t)K_, mem);
     to_host(ctx_, h_ci, prob->cam_intr, (size_t)N_, mem);
     std::vector<unsigned char> h_free(K_);
+    std::vector<signed char> h_map(8 * (size_t)K_, -1);
+    int fmax = 0;
     for (int k = 0; k < K_; ++k) {
       const int np = num_params_of(h_model[k]);
       if (np < 0) throw StatusError(GSFM_ERR_UNSUPPORTED, "BA: camera model not supported");
@@ -761,8 +912,23 @@ class BaSolver final : public LmProblem {
         if (opt_.optimize_intrinsics && !opt_.optimize_principal_point) bits &= ~pp_mask_of(h_model[k]);
       }
       h_free[k] = (unsigned char)bits;
+      int j = 0;
+      for (int p = 0; p < 8; ++p)
+        if ((bits >> p) & 1) h_map[8 * (size_t)k + j++] = (signed char)p;
+      fmax = std::max(fmax, j);
     }
-    for (int n = 0; n < N_; ++n) GSFM_REQUIRE(h_ci[n] >= 0 && h_ci[n] < K_, "BA: cam_intr out of range");
+    F_ = fmax == 0 ? 0 : (fmax <= 2 ? 2 : (fmax <= 4 ? 4 : 8));
+    // cameras grouped by intrinsics block (counting sort, stable)
+    std::vector<int> h_ioff(K_ + 1, 0), h_icams(N_);
+    for (int n = 0; n < N_; ++n) {
+      GSFM_REQUIRE(h_ci[n] >= 0 && h_ci[n] < K_, "BA: cam_intr out of range");
+      h_ioff[h_ci[n] + 1]++;
+    }
+    for (int k = 0; k < K_; ++k) h_ioff[k + 1] += h_ioff[k];
+    {
+      std::vector<int> fill(h_ioff.begin(), h_ioff.end() - 1);
+      for (int n = 0; n < N_; ++n) h_icams[fill[h_ci[n]]++] = n;
+    }
     copy_in(ctx_, ws->off.ensure(P_ + 1), reinterpret_cast<const long*>(prob->pt_offset), (size_t)P_ + 1, mem);
     copy_in(ctx_, ws->cam.ensure(M_ + 1), prob->obs_cam, (size_t)M_, mem);
     copy_in(ctx_, ws->xy.ensure(2 * (size_t)M_ + 2), prob->obs_xy, 2 * (size_t)M_, mem);
@@ -772,45 +938,62 @@ class BaSolver final : public LmProblem {
     copy_in(ctx_, ws->t.ensure(3 * (size_t)N_), cam_t, 3 * (size_t)N_, mem);
     copy_in(ctx_, ws->X.ensure(3 * (size_t)P_ + 3), pt_xyz, 3 * (size_t)P_, mem);
     copy_in(ctx_, ws->par.ensure(8 * (size_t)K_), intr_params, 8 * (size_t)K_, mem);
-    GSFM_HIP_CHECK(hipMemcpyAsync(ws->used.ensure(P_ + 1), h_used.data(), (size_t)P_, hipMemcpyHostToDevice, s));
     GSFM_HIP_CHECK(hipMemcpyAsync(ws->intr_free.ensure(K_), h_free.data(), (size_t)K_, hipMemcpyHostToDevice, s));
-    GSFM_HIP_CHECK(hipStreamSynchronize(s));
+    GSFM_HIP_CHECK(hipMemcpyAsync(ws->intr_map.ensure(8 * (size_t)K_ + 8), h_map.data(), 8 * (size_t)K_, hipMemcpyHostToDevice, s));
+    GSFM_HIP_CHECK(hipMemcpyAsync(ws->ioff.ensure(K_ + 1), h_ioff.data(), (size_t)(K_ + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+    GSFM_HIP_CHECK(hipMemcpyAsync(ws->icams.ensure(N_), h_icams.data(), (size_t)N_ * sizeof(int), hipMemcpyHostToDevice, s));
+    m_used_ = build_obs_graph(ctx_, ws->og, N_, P_, M_, h_off, ws->off.get(), ws->cam.get(),
+                              opt_.min_num_view_per_track /* ba.cc:122 */, g_.g, nullptr);  // syncs the stream
+    const long Mu = g_.g.Mu;
+    ws->c_xy.ensure(2 * (size_t)M_ + 2);
+    hipLaunchKernelGGL((k_og_gather_f64<2>), dim3(grid_for(Mu, kBlock)), dim3(kBlock), 0, s, Mu, g_.g.c_src,
+                       ws->xy.get(), ws->c_xy.get());
+    ws->c_w.ensure(M_ + 1);
+    Mp_ = ((M_ + 63) / 64) * 64;
+    ws->jt.ensure((size_t)(10 + F_) * Mp_ + 64);
     ws->qn.ensure(4 * (size_t)N_);
     ws->tn.ensure(3 * (size_t)N_);
     ws->camR.ensure(9 * (size_t)N_);
     ws->camRn.ensure(9 * (size_t)N_);
     ws->Xn.ensure(3 * (size_t)P_ + 3);
     ws->parn.ensure(8 * (size_t)K_);
-    ws->wrob.ensure(M_ + 1);
-    ws->hinv.ensure(6 * (size_t)P_ + 6);
-    for (DevBuf<double>* b : {&ws->ept, &ws->ptdiag, &ws->ptjs}) b->ensure(3 * (size_t)P_ + 3);
+    ws->ptH.ensure(9 * (size_t)P_ + 9);
+    ws->ptb.ensure(12 * (size_t)P_ + 12);
+    ws->ptrec.ensure(8 * (size_t)P_ + 8);
+    for (DevBuf<double>* b : {&ws->ptdiag, &ws->ptjs}) b->ensure(3 * (size_t)P_ + 3);
     for (DevBuf<double>* b : {&ws->diag, &ws->js, &ws->dvec, &ws->grad, &ws->gred, &ws->rhs, &ws->cg_x, &ws->cg_r,
-                              &ws->cg_z, &ws->cg_p, &ws->cg_y})
+                              &ws->cg_z, &ws->cg_p, &ws->cg_s})
       b->ensure(n_);
+    ws->cg_w.ensure((size_t)n_ + 2);
     ws->spose.ensure(21 * (size_t)N_);
+    ws->ipart.ensure(44 * (size_t)N_);
+    ws->yi_part.ensure(8 * (size_t)N_);
     ws->iacc16.ensure(16 * (size_t)K_);
     ws->iacc44.ensure(44 * (size_t)K_);
     ws->minv.ensure(36 * (size_t)N_ + 64 * (size_t)K_);
-    ws->part.ensure(kMaxBlocks * 4);
+    ws->vpart.ensure(2 * kCgMaxBlocks * 2);
+    ws->dpart.ensure(2 * kMaxBlocks);
+    ws->part.ensure(kMaxBlocks * 8);
     ws->scal.ensure(64);
-    ws->cg.ensure(1);
-    ws->elem_blk.ensure(n_);
-    for (DevBuf<int>* b : {&ws->blk_start, &ws->blk_size, &ws->blk_moff}) b->ensure(N_ + K_);
+    ws->cgst.ensure(1);
+    ws->cgsc.ensure(2);
     gridP_ = grid_for(P_, kBlock);
     gridN_ = grid_for(N_, kBlock);
-    hipLaunchKernelGGL(k_ba_block_desc, dim3(grid_for(n_, kBlock)), dim3(kBlock), 0, s, N_, K_, ws->elem_blk.get(),
-                       ws->blk_start.get(), ws->blk_size.get(), ws->blk_moff.get());
-    g_.N = N_;
+    gridM_ = grid_for(M_, kBlock);
+    gridCam_ = grid_for(N_, kBlock / 64);
+    gridTile_ = grid_for(g_.g.T, kBlock / 64);
+    gridK_ = grid_for(K_, 1);
     g_.K = K_;
-    g_.P = P_;
-    g_.M = M_;
-    g_.off = ws->off.get();
-    g_.cam = ws->cam.get();
+    g_.F = F_;
+    g_.Mp = Mp_;
     g_.xy = ws->xy.get();
+    g_.c_xy = ws->c_xy.get();
     g_.cam_intr = ws->cam_intr.get();
     g_.intr_model = ws->intr_model.get();
-    g_.used = ws->used.get();
     g_.intr_free = ws->intr_free.get();
+    g_.intr_map = ws->intr_map.get();
+    g_.ioff = ws->ioff.get();
+    g_.icams = ws->icams.get();
     g_.fixed_cam = prob->fixed_cam;
     g_.opt_rot = opt_.optimize_rotations ? 1 : 0;
     g_.opt_trn = opt_.optimize_translation ? 1 : 0;
@@ -824,7 +1007,23 @@ class BaSolver final : public LmProblem {
     X_ = ws->X.get(); Xn_ = ws->Xn.get();
     par_ = ws->par.get(); parn_ = ws->parn.get();
     hipLaunchKernelGGL(k_ba_cam_prepare, dim3(gridN_), dim3(kBlock), 0, s, N_, q_, R_);
-    bj_ = BlockJacobi{ws->elem_blk.get(), ws->blk_start.get(), ws->blk_size.get(), ws->blk_moff.get(), ws->minv.get()};
+    cg_.n = n_;
+    cg_.N = N_;
+    cg_.K = K_;
+    cg_.nb_update = std::min(kCgMaxBlocks, grid_for(N_ + K_, kBlock));
+    cg_.nb_apply = gridCam_ + gridK_;
+    cg_.b = ws->rhs.get();
+    cg_.x = ws->cg_x.get();
+    cg_.r = ws->cg_r.get();
+    cg_.z = ws->cg_z.get();
+    cg_.p = ws->cg_p.get();
+    cg_.s = ws->cg_s.get();
+    cg_.w = ws->cg_w.get();
+    cg_.minv = ws->minv.get();
+    cg_.vpart = ws->vpart.get();
+    cg_.dpart = ws->dpart.get();
+    cg_.scal = ws->cgsc.get();
+    cg_.st = ws->cgst.get();
   }
 
   long used_observations() const { return m_used_; }
@@ -832,11 +1031,14 @@ class BaSolver final : public LmProblem {
   double linearize(double* grad_max_norm) override {
     BaWs* ws = ws_;
     hipStream_t s = ctx_->stream;
-    GSFM_HIP_CHECK(hipMemsetAsync(ws->diag.get(), 0, (size_t)n_ * sizeof(double), s));
-    GSFM_HIP_CHECK(hipMemsetAsync(ws->grad.get(), 0, (size_t)n_ * sizeof(double), s));
-    GSFM_HIP_CHECK(hipMemsetAsync(ws->iacc16.get(), 0, 16 * (size_t)K_ * sizeof(double), s));
-    hipLaunchKernelGGL(k_ba_linearize, dim3(gridP_), dim3(kBlock), 0, s, g_, R_, t_, X_, par_, ws->wrob.get(),
-                       ws->ptdiag.get(), ws->diag.get(), ws->grad.get(), ws->iacc16.get(), ws->part.get());
+    dispatch_f(F_, [&](auto Fc) {
+      hipLaunchKernelGGL((k_ba_lin_track<decltype(Fc)::value>), dim3(gridP_), dim3(kBlock), 0, s, g_, R_, t_, X_, par_,
+                         ws->jt.get(), ws->ptdiag.get(), ws->ptH.get(), ws->part.get());
+    });
+    hipLaunchKernelGGL(k_ba_lin_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, R_, t_, X_, par_, ws->c_w.get(),
+                       ws->diag.get(), ws->grad.get(), ws->ipart.get());
+    hipLaunchKernelGGL((k_ba_group_sum<16>), dim3(gridK_), dim3(kBlock), 0, s, K_, g_.ioff, g_.icams, ws->ipart.get(),
+                       ws->iacc16.get());
     hipLaunchKernelGGL(k_ba_intr_unpack16, dim3(grid_for(8 * (size_t)K_, kBlock)), dim3(kBlock), 0, s, N_, K_,
                        ws->iacc16.get(), ws->diag.get(), ws->grad.get());
     if (ctx_->comm.world > 1) {
@@ -870,12 +1072,12 @@ class BaSolver final : public LmProblem {
     BaWs* ws = ws_;
     hipStream_t s = ctx_->stream;
     const bool multi = ctx_->comm.world > 1;
-    GSFM_HIP_CHECK(hipMemsetAsync(ws->gred.get(), 0, (size_t)n_ * sizeof(double), s));
-    GSFM_HIP_CHECK(hipMemsetAsync(ws->spose.get(), 0, 21 * (size_t)N_ * sizeof(double), s));
-    GSFM_HIP_CHECK(hipMemsetAsync(ws->iacc44.get(), 0, 44 * (size_t)K_ * sizeof(double), s));
-    hipLaunchKernelGGL(k_ba_build, dim3(gridP_), dim3(kBlock), 0, s, g_, radius, R_, t_, X_, par_, ws->wrob.get(),
-                       ws->ptdiag.get(), ws->ptjs.get(), ws->hinv.get(), ws->ept.get(), ws->gred.get(),
-                       ws->spose.get(), ws->iacc44.get());
+    hipLaunchKernelGGL(k_ba_build_track, dim3(gridP_), dim3(kBlock), 0, s, g_, radius, X_, ws->ptH.get(),
+                       ws->ptdiag.get(), ws->ptjs.get(), ws->ptb.get(), ws->ptrec.get());
+    hipLaunchKernelGGL(k_ba_build_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, R_, t_, par_, ws->c_w.get(),
+                       ws->ptb.get(), ws->gred.get(), ws->spose.get(), ws->ipart.get());
+    hipLaunchKernelGGL((k_ba_group_sum<44>), dim3(gridK_), dim3(kBlock), 0, s, K_, g_.ioff, g_.icams, ws->ipart.get(),
+                       ws->iacc44.get());
     if (multi) {
       allreduce_sum(ctx_, ws->gred.get(), 6 * (size_t)N_);
       allreduce_sum(ctx_, ws->spose.get(), 21 * (size_t)N_);
@@ -885,14 +1087,20 @@ class BaSolver final : public LmProblem {
                        g_.lm_lo, g_.lm_hi, ws->diag.get(), ws->js.get(), ws->gred.get(), ws->spose.get(),
                        ws->iacc44.get(), ws->dvec.get(), ws->rhs.get(), ws->minv.get());
     *linear_iterations = pcg();
-    hipLaunchKernelGGL(k_ba_backsub, dim3(gridP_), dim3(kBlock), 0, s, g_, R_, t_, X_, par_, ws->wrob.get(),
-                       ws->hinv.get(), ws->ept.get(), ws->cg_x.get(), Xn_, ws->part.get());
+    dispatch_f(F_, [&](auto Fc) {
+      hipLaunchKernelGGL((k_ba_backsub<decltype(Fc)::value>), dim3(gridP_), dim3(kBlock), 0, s, g_, X_, ws->jt.get(),
+                         ws->ptb.get(), ws->cg_x.get(), Xn_, ws->part.get());
+    });
     hipLaunchKernelGGL((k_ba_sum_partials<3>), dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridP_, ws->scal.get());
-    hipLaunchKernelGGL(k_ba_param_update, dim3(1), dim3(kCgThreads), 0, s, N_, K_, q_, t_, par_, ws->cg_x.get(), qn_,
-                       tn_, parn_, ws->scal.get() + 3);
+    const int gridU = std::min(64, grid_for(N_ + 8 * (size_t)K_, kBlock));
+    double* part2 = ws->part.get() + kMaxBlocks * 3;
+    hipLaunchKernelGGL(k_ba_param_update, dim3(gridU), dim3(kBlock), 0, s, N_, K_, q_, t_, par_, ws->cg_x.get(), qn_,
+                       tn_, parn_, part2);
+    hipLaunchKernelGGL((k_ba_sum_partials<3>), dim3(1), dim3(kBlock), 0, s, part2, gridU, ws->scal.get() + 3);
     hipLaunchKernelGGL(k_ba_cam_prepare, dim3(gridN_), dim3(kBlock), 0, s, N_, qn_, Rn_);
-    hipLaunchKernelGGL(k_ba_cost, dim3(gridP_), dim3(kBlock), 0, s, g_, Rn_, tn_, Xn_, parn_, ws->part.get());
-    hipLaunchKernelGGL((k_ba_sum_partials<1>), dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridP_, ws->scal.get() + 6);
+    double* part3 = ws->part.get() + kMaxBlocks * 4;
+    hipLaunchKernelGGL(k_ba_cost, dim3(gridM_), dim3(kBlock), 0, s, g_, Rn_, tn_, Xn_, parn_, part3);
+    hipLaunchKernelGGL((k_ba_sum_partials<1>), dim3(1), dim3(kBlock), 0, s, part3, gridM_, ws->scal.get() + 6);
     if (multi) {
       allreduce_sum(ctx_, ws->scal.get(), 3);
       allreduce_sum(ctx_, ws->scal.get() + 6, 1);
@@ -929,42 +1137,32 @@ class BaSolver final : public LmProblem {
   long pcg() {
     BaWs* ws = ws_;
     hipStream_t s = ctx_->stream;
-    const bool multi = ctx_->comm.world > 1;
     const double yscale = ctx_->comm.rank == 0 ? 1.0 : 0.0;
     const double tol = opt_.lm.pcg_relative_tolerance;
-    hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(kCgThreads), 0, s, n_, ws->rhs.get(), ws->cg_x.get(), ws->cg_r.get(),
-                       ws->cg_z.get(), ws->cg_p.get(), ws->cg_y.get(), ws->dvec.get(), bj_, ws->cg.get(), yscale);
-    CgState* h = reinterpret_cast<CgState*>(ctx_->h_pinned + 400);
-    const int chunk = 8;
-    const int max_iter = opt_.lm.pcg_max_iterations;
-    for (int it = 0; it < max_iter; ++it) {
-      const bool timed = ctx_->prof.begin(s, GSFM_KERNEL_BA_SCHUR);
-      hipLaunchKernelGGL(k_ba_schur_matvec, dim3(gridP_), dim3(kBlock), 0, s, g_, R_, t_, X_, par_, ws->wrob.get(),
-                         ws->hinv.get(), ws->cg_p.get(), ws->cg_y.get());
+    return cg_solve<6, true>(ctx_, cg_, tol, opt_.lm.pcg_max_iterations, [&](int it) {
+      bool timed = ctx_->prof.begin(s, GSFM_KERNEL_BA_SCHUR);
+      dispatch_f(F_, [&](auto Fc) {
+        hipLaunchKernelGGL((k_ba_phaseA<decltype(Fc)::value>), dim3(gridTile_), dim3(kBlock), 0, s, g_, cg_, it,
+                           tol * tol, ws->jt.get(), ws->ptb.get(), ws->ptrec.get());
+      });
       if (timed) ctx_->prof.end(s);
-      if (multi) allreduce_sum(ctx_, ws->cg_y.get(), n_);
-      hipLaunchKernelGGL(k_cg_iter, dim3(1), dim3(kCgThreads), 0, s, n_, ws->cg_y.get(), ws->cg_p.get(),
-                         ws->cg_x.get(), ws->cg_r.get(), ws->cg_z.get(), ws->dvec.get(), bj_, ws->cg.get(), tol * tol,
-                         yscale);
-      if ((it + 1) % chunk == 0 || it + 1 == max_iter) {
-        GSFM_HIP_CHECK(hipMemcpyAsync(h, ws->cg.get(), sizeof(CgState), hipMemcpyDeviceToHost, s));
-        GSFM_HIP_CHECK(hipStreamSynchronize(s));
-        GSFM_HIP_CHECK(hipGetLastError());
-        ctx_->prof.harvest();
-        if (h->done) return h->iters;
-      }
-    }
-    return max_iter;
+      timed = ctx_->prof.begin(s, GSFM_KERNEL_BA_SCHUR_B);
+      hipLaunchKernelGGL(k_ba_phaseB, dim3(gridCam_), dim3(kBlock), 0, s, g_, cg_, yscale, R_, t_, par_,
+                         ws->c_w.get(), ws->ptrec.get(), ws->dvec.get(), ws->yi_part.get());
+      if (timed) ctx_->prof.end(s);
+      hipLaunchKernelGGL(k_ba_phaseI, dim3(gridK_), dim3(kBlock), 0, s, g_, cg_, yscale, ws->yi_part.get(),
+                         ws->dvec.get(), gridCam_);
+    });
   }
 
   gsfm_ctx* ctx_;
   BaWs* ws_;
   gsfm_ba_options opt_;
-  BaParams g_{};
-  BlockJacobi bj_{};
-  int N_ = 0, K_ = 0, n_ = 0;
-  long P_ = 0, M_ = 0, m_used_ = 0;
-  int gridP_ = 1, gridN_ = 1;
+  BaDev g_{};
+  CgVec cg_{};
+  int N_ = 0, K_ = 0, n_ = 0, F_ = 0;
+  long P_ = 0, M_ = 0, Mp_ = 0, m_used_ = 0;
+  int gridP_ = 1, gridN_ = 1, gridM_ = 1, gridCam_ = 1, gridTile_ = 1, gridK_ = 1;
   double *q_ = nullptr, *qn_ = nullptr, *t_ = nullptr, *tn_ = nullptr, *R_ = nullptr, *Rn_ = nullptr, *X_ = nullptr,
          *Xn_ = nullptr, *par_ = nullptr, *parn_ = nullptr;
 };
