@@ -56,6 +56,7 @@ struct BaDev {
   const signed char* intr_map;     // [K][8] compact column -> parameter index, -1 = unused column
   const int* ioff;                 // [K+1]
   const int* icams;                // [N]
+  const int* obs_ik;               // [M] intrinsics block of each observation (track-major)
   int fixed_cam;
   int opt_rot, opt_trn, opt_pts;
   double huber_a;
@@ -306,6 +307,32 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// Same sum with one THREAD per group, for problems whose groups are small (e.g. one intrinsics
+// block per image): sequential fixed-order sum over the group's cameras.
+template <int W>
+__global__ void __launch_bounds__(kBlock)
+    k_ba_group_sum_small(int K, const int* __restrict__ ioff, const int* __restrict__ icams,
+                         const double* __restrict__ part, double* __restrict__ out) {
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
+    double acc[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) acc[j] = 0.0;
+    for (int i = ioff[k]; i < ioff[k + 1]; ++i) {
+      const double* s = part + (long)W * icams[i];
+#pragma unroll
+      for (int j = 0; j < W; ++j) acc[j] += s[j];
+    }
+#pragma unroll
+    for (int j = 0; j < W; ++j) out[(long)W * k + j] = acc[j];
+  }
+}
+
+static __global__ void __launch_bounds__(kBlock)
+    k_ba_obs_ik(long M, const int* __restrict__ cam, const int* __restrict__ cam_intr, int* __restrict__ obs_ik) {
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < M; k += (long)gridDim.x * blockDim.x)
+    obs_ik[k] = cam_intr[cam[k]];
+}
+
 // scatter iacc16 [K][16] into the reduced-vector layout: diag/grad [6N + 8k + j]
 __global__ void __launch_bounds__(kBlock)
     k_ba_intr_unpack16(int N, int K, const double* __restrict__ intr_acc, double* __restrict__ diag,
@@ -510,14 +537,11 @@ __global__ void __launch_bounds__(kBlock)
   const int nwaves = gridDim.x * (kBlock / 64);
   const double* zintr = v.z + 6 * (long)g.g.N;
   for (int tile = wave; tile < g.g.T; tile += nwaves) {
-    const int p0 = g.g.tile[tile], p1 = g.g.tile[tile + 1];
-    const long k0 = g.g.off[p0], k1 = g.g.off[p1];
+    const long k0 = g.g.tile_k[tile], k1 = g.g.tile_k[tile + 1];
     double acc[3] = {0, 0, 0};
     int key = -1 - lane;
     for (long k = k0 + lane; k < k1; k += 64) {
-      const int p = g.g.obs_pt[k];
-      key = p;
-      if (!g.g.used[p]) continue;
+      key = g.g.obs_pt[k];
       const long n = g.g.cam[k];
       const double2* zp = reinterpret_cast<const double2*>(v.z + 6 * n);
       const double2 z01 = zp[0], z23 = zp[1], z45 = zp[2];
@@ -530,7 +554,7 @@ __global__ void __launch_bounds__(kBlock)
         u1 += a.y * zz[j];
       }
       if constexpr (F > 0) {
-        const int ik = g.cam_intr[n];
+        const int ik = g.obs_ik[k];
         const Map8 mp = load_map(g.intr_map + 8 * (long)ik);
         const double* zi = zintr + 8 * (long)ik;
 #pragma unroll
@@ -590,10 +614,11 @@ __global__ void __launch_bounds__(kBlock)
     for (int k = g.g.coff[n] + lane; k < g.g.coff[n + 1]; k += 64) {
       const double w = c_w[k];
       if (w == 0.0) continue;
-      const double* pr = ptrec + 8 * (long)g.g.c_pt[k];
+      V3 Xp, tp;
+      ld6(ptrec + 8 * (long)g.g.c_pt[k], Xp, tp);  // 64-byte aligned record, three 16-byte gathers
       ObsGeom o;
-      obs_geom(R9, t3, ld3(pr), model, pp, o);
-      V3 om = V3{0, 0, 0} - R_mul(R9, ld3(pr + 3));  // - J_pt t_p = - Jx (R t_p)
+      obs_geom(R9, t3, Xp, model, pp, o);
+      V3 om = V3{0, 0, 0} - R_mul(R9, tp);  // - J_pt t_p = - Jx (R t_p)
       if (rf) om = om + 2.0 * cross(zr, o.a);
       if (tf) om = om + zt;
       double u0, u1;
@@ -671,6 +696,36 @@ __global__ void __launch_bounds__(kBlock)
     __syncthreads();
   }
   if (threadIdx.x == 0) v.dpart[slot0 + blockIdx.x] = delta;
+}
+
+// One thread per intrinsics block (small groups); block partial of delta via the block tree.
+__global__ void __launch_bounds__(kBlock)
+    k_ba_phaseI_small(BaDev g, CgVec v, double yscale, const double* __restrict__ yi_part,
+                      const double* __restrict__ dvec, int slot0) {
+  __shared__ double smem[4];
+  if (v.st->done) return;
+  double delta[1] = {0.0};
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < g.K; k += gridDim.x * blockDim.x) {
+    double acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0;
+    for (int i = g.ioff[k]; i < g.ioff[k + 1]; ++i) {
+      const double* s = yi_part + 8 * (long)g.icams[i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += s[j];
+    }
+    const unsigned char bits = g.intr_free[k];
+    const long o = 6 * (long)g.g.N + 8 * (long)k;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const double zj = v.z[o + j];
+      const double wv = (((bits >> j) & 1) ? acc[j] : 0.0) + yscale * dvec[o + j] * zj;
+      v.w[o + j] = wv;
+      delta[0] += zj * wv;
+    }
+  }
+  block_sum<1>(delta, smem);
+  if (threadIdx.x == 0) v.dpart[slot0 + blockIdx.x] = delta[0];
 }
 
 // ---- back-substitution, model cost change, candidate points ------------------------------------
@@ -829,7 +884,7 @@ __global__ void __launch_bounds__(kBlock)
 struct BaWs {
   ObsGraphWs og;
   DevBuf<long> off;
-  DevBuf<int> cam, cam_intr, intr_model, ioff, icams;
+  DevBuf<int> cam, cam_intr, intr_model, ioff, icams, obs_ik;
   DevBuf<unsigned char> intr_free;
   DevBuf<signed char> intr_map;
   DevBuf<double2> jt;
@@ -924,7 +979,12 @@ class BaSolver final : public LmProblem {
       GSFM_REQUIRE(h_ci[n] >= 0 && h_ci[n] < K_, "BA: cam_intr out of range");
       h_ioff[h_ci[n] + 1]++;
     }
-    for (int k = 0; k < K_; ++k) h_ioff[k + 1] += h_ioff[k];
+    max_group_ = 0;
+    for (int k = 0; k < K_; ++k) {
+      max_group_ = std::max(max_group_, h_ioff[k + 1]);
+      h_ioff[k + 1] += h_ioff[k];
+    }
+    small_groups_ = max_group_ <= 64;
     {
       std::vector<int> fill(h_ioff.begin(), h_ioff.end() - 1);
       for (int n = 0; n < N_; ++n) h_icams[fill[h_ci[n]]++] = n;
@@ -951,6 +1011,12 @@ class BaSolver final : public LmProblem {
     ws->c_w.ensure(M_ + 1);
     Mp_ = ((M_ + 63) / 64) * 64;
     ws->jt.ensure((size_t)(10 + F_) * Mp_ + 64);
+    // planes of unused tracks stay zero: they contribute nothing and phase A needs no `used` test
+    ws->ptrec.ensure(8 * (size_t)P_ + 8);
+    GSFM_HIP_CHECK(hipMemsetAsync(ws->ptrec.get(), 0, (8 * (size_t)P_ + 8) * sizeof(double), s));
+    GSFM_HIP_CHECK(hipMemsetAsync(ws->jt.get(), 0, ((size_t)(10 + F_) * Mp_ + 64) * sizeof(double2), s));
+    hipLaunchKernelGGL(k_ba_obs_ik, dim3(grid_for(M_, kBlock)), dim3(kBlock), 0, s, M_, ws->cam.get(),
+                       ws->cam_intr.get(), ws->obs_ik.ensure(M_ + 1));
     ws->qn.ensure(4 * (size_t)N_);
     ws->tn.ensure(3 * (size_t)N_);
     ws->camR.ensure(9 * (size_t)N_);
@@ -972,7 +1038,7 @@ class BaSolver final : public LmProblem {
     ws->iacc44.ensure(44 * (size_t)K_);
     ws->minv.ensure(36 * (size_t)N_ + 64 * (size_t)K_);
     ws->vpart.ensure(2 * kCgMaxBlocks * 2);
-    ws->dpart.ensure(2 * kMaxBlocks);
+    ws->dpart.ensure(2 * kMaxApplySlots);
     ws->part.ensure(kMaxBlocks * 8);
     ws->scal.ensure(64);
     ws->cgst.ensure(1);
@@ -980,9 +1046,9 @@ class BaSolver final : public LmProblem {
     gridP_ = grid_for(P_, kBlock);
     gridN_ = grid_for(N_, kBlock);
     gridM_ = grid_for(M_, kBlock);
-    gridCam_ = grid_for(N_, kBlock / 64);
-    gridTile_ = grid_for(g_.g.T, kBlock / 64);
-    gridK_ = grid_for(K_, 1);
+    gridCam_ = grid_wide(N_, kBlock / 64, kMaxApplySlots);  // one wave per camera (delta partial per block)
+    gridTile_ = grid_wide(g_.g.T, kBlock / 64);             // one wave per tile
+    gridK_ = small_groups_ ? grid_for(K_, kBlock) : grid_for(K_, 1);
     g_.K = K_;
     g_.F = F_;
     g_.Mp = Mp_;
@@ -994,6 +1060,7 @@ class BaSolver final : public LmProblem {
     g_.intr_map = ws->intr_map.get();
     g_.ioff = ws->ioff.get();
     g_.icams = ws->icams.get();
+    g_.obs_ik = ws->obs_ik.get();
     g_.fixed_cam = prob->fixed_cam;
     g_.opt_rot = opt_.optimize_rotations ? 1 : 0;
     g_.opt_trn = opt_.optimize_translation ? 1 : 0;
@@ -1037,8 +1104,7 @@ class BaSolver final : public LmProblem {
     });
     hipLaunchKernelGGL(k_ba_lin_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, R_, t_, X_, par_, ws->c_w.get(),
                        ws->diag.get(), ws->grad.get(), ws->ipart.get());
-    hipLaunchKernelGGL((k_ba_group_sum<16>), dim3(gridK_), dim3(kBlock), 0, s, K_, g_.ioff, g_.icams, ws->ipart.get(),
-                       ws->iacc16.get());
+    group_sum<16>(ws->ipart.get(), ws->iacc16.get());
     hipLaunchKernelGGL(k_ba_intr_unpack16, dim3(grid_for(8 * (size_t)K_, kBlock)), dim3(kBlock), 0, s, N_, K_,
                        ws->iacc16.get(), ws->diag.get(), ws->grad.get());
     if (ctx_->comm.world > 1) {
@@ -1076,8 +1142,7 @@ class BaSolver final : public LmProblem {
                        ws->ptdiag.get(), ws->ptjs.get(), ws->ptb.get(), ws->ptrec.get());
     hipLaunchKernelGGL(k_ba_build_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, R_, t_, par_, ws->c_w.get(),
                        ws->ptb.get(), ws->gred.get(), ws->spose.get(), ws->ipart.get());
-    hipLaunchKernelGGL((k_ba_group_sum<44>), dim3(gridK_), dim3(kBlock), 0, s, K_, g_.ioff, g_.icams, ws->ipart.get(),
-                       ws->iacc44.get());
+    group_sum<44>(ws->ipart.get(), ws->iacc44.get());
     if (multi) {
       allreduce_sum(ctx_, ws->gred.get(), 6 * (size_t)N_);
       allreduce_sum(ctx_, ws->spose.get(), 21 * (size_t)N_);
@@ -1134,6 +1199,16 @@ class BaSolver final : public LmProblem {
   }
 
  private:
+  template <int W>
+  void group_sum(const double* part, double* out) {
+    hipStream_t s = ctx_->stream;
+    if (small_groups_) {
+      hipLaunchKernelGGL((k_ba_group_sum_small<W>), dim3(gridK_), dim3(kBlock), 0, s, K_, g_.ioff, g_.icams, part, out);
+    } else {
+      hipLaunchKernelGGL((k_ba_group_sum<W>), dim3(gridK_), dim3(kBlock), 0, s, K_, g_.ioff, g_.icams, part, out);
+    }
+  }
+
   long pcg() {
     BaWs* ws = ws_;
     hipStream_t s = ctx_->stream;
@@ -1150,8 +1225,13 @@ class BaSolver final : public LmProblem {
       hipLaunchKernelGGL(k_ba_phaseB, dim3(gridCam_), dim3(kBlock), 0, s, g_, cg_, yscale, R_, t_, par_,
                          ws->c_w.get(), ws->ptrec.get(), ws->dvec.get(), ws->yi_part.get());
       if (timed) ctx_->prof.end(s);
-      hipLaunchKernelGGL(k_ba_phaseI, dim3(gridK_), dim3(kBlock), 0, s, g_, cg_, yscale, ws->yi_part.get(),
-                         ws->dvec.get(), gridCam_);
+      if (small_groups_) {
+        hipLaunchKernelGGL(k_ba_phaseI_small, dim3(gridK_), dim3(kBlock), 0, s, g_, cg_, yscale, ws->yi_part.get(),
+                           ws->dvec.get(), gridCam_);
+      } else {
+        hipLaunchKernelGGL(k_ba_phaseI, dim3(gridK_), dim3(kBlock), 0, s, g_, cg_, yscale, ws->yi_part.get(),
+                           ws->dvec.get(), gridCam_);
+      }
     });
   }
 
@@ -1160,7 +1240,8 @@ class BaSolver final : public LmProblem {
   gsfm_ba_options opt_;
   BaDev g_{};
   CgVec cg_{};
-  int N_ = 0, K_ = 0, n_ = 0, F_ = 0;
+  int N_ = 0, K_ = 0, n_ = 0, F_ = 0, max_group_ = 0;
+  bool small_groups_ = false;
   long P_ = 0, M_ = 0, Mp_ = 0, m_used_ = 0;
   int gridP_ = 1, gridN_ = 1, gridM_ = 1, gridCam_ = 1, gridTile_ = 1, gridK_ = 1;
   double *q_ = nullptr, *qn_ = nullptr, *t_ = nullptr, *tn_ = nullptr, *R_ = nullptr, *Rn_ = nullptr, *X_ = nullptr,

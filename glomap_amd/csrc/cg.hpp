@@ -28,6 +28,7 @@
 namespace gsfm {
 
 constexpr int kCgMaxBlocks = 512;  // grid cap of the vector kernels (k_cg_init / k_cg_update)
+constexpr int kMaxApplySlots = 4096;  // cap of the delta partial slots one apply kernel may write
 
 struct CgStatus {
   int done;
@@ -58,11 +59,16 @@ struct CgVec {
   double* dpart = nullptr;     // [nb_apply] delta partials
   CgScal* scal = nullptr;      // [2]
   CgStatus* st = nullptr;
+  // optional mirror of the camera part of z inside a solver-owned gather record:
+  // zmir[b * zmir_stride + zmir_off + i] = z[PB * b + i]  (lets phase A fetch camera constants and z
+  // of a camera with the same 16-byte gathers)
+  double* zmir = nullptr;
+  int zmir_stride = 0, zmir_off = 0;
 };
 
 template <int BS>
 __device__ __forceinline__ void cg_block_init(const CgVec& v, long o, const double* __restrict__ m, double& rz,
-                                              double& rr) {
+                                              double& rr, double* __restrict__ mir = nullptr) {
   double rb[BS];
 #pragma unroll
   for (int i = 0; i < BS; ++i) rb[i] = v.b[o + i];
@@ -74,6 +80,7 @@ __device__ __forceinline__ void cg_block_init(const CgVec& v, long o, const doub
     v.x[o + i] = 0.0;
     v.r[o + i] = rb[i];
     v.z[o + i] = zi;
+    if (mir) mir[i] = zi;
     v.p[o + i] = 0.0;
     v.s[o + i] = 0.0;
     rz += rb[i] * zi;
@@ -89,7 +96,8 @@ static __global__ void __launch_bounds__(kBlock) k_cg_init(CgVec v) {
   const int nblk = v.N + (HAS_INTR ? v.K : 0);
   for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += gridDim.x * blockDim.x) {
     if (b < v.N) {
-      cg_block_init<PB>(v, (long)PB * b, v.minv + (long)PB * PB * b, acc[0], acc[1]);
+      cg_block_init<PB>(v, (long)PB * b, v.minv + (long)PB * PB * b, acc[0], acc[1],
+                        v.zmir ? v.zmir + (long)b * v.zmir_stride + v.zmir_off : nullptr);
     } else if constexpr (HAS_INTR) {
       const int k = b - v.N;
       cg_block_init<8>(v, (long)PB * v.N + 8L * k, v.minv + (long)PB * PB * v.N + 64L * k, acc[0], acc[1]);
@@ -133,7 +141,8 @@ __device__ __forceinline__ bool cg_converged(const CgVec& v, int it, double tol2
 
 template <int BS>
 __device__ __forceinline__ void cg_block_update(const CgVec& v, long o, const double* __restrict__ m, double alpha,
-                                                double beta, double& rz, double& rr) {
+                                                double beta, double& rz, double& rr,
+                                                double* __restrict__ mir = nullptr) {
   double rn[BS];
 #pragma unroll
   for (int i = 0; i < BS; ++i) {
@@ -152,6 +161,7 @@ __device__ __forceinline__ void cg_block_update(const CgVec& v, long o, const do
 #pragma unroll
     for (int j = 0; j < BS; ++j) zi += m[i * BS + j] * rn[j];
     v.z[o + i] = zi;
+    if (mir) mir[i] = zi;
     rz += rn[i] * zi;
   }
 }
@@ -186,7 +196,8 @@ static __global__ void __launch_bounds__(kBlock) k_cg_update(CgVec v, int it) {
   if (ok) {
     for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += gridDim.x * blockDim.x) {
       if (b < v.N) {
-        cg_block_update<PB>(v, (long)PB * b, v.minv + (long)PB * PB * b, alpha, beta, acc[0], acc[1]);
+        cg_block_update<PB>(v, (long)PB * b, v.minv + (long)PB * PB * b, alpha, beta, acc[0], acc[1],
+                            v.zmir ? v.zmir + (long)b * v.zmir_stride + v.zmir_off : nullptr);
       } else if constexpr (HAS_INTR) {
         const int k = b - v.N;
         cg_block_update<8>(v, (long)PB * v.N + 8L * k, v.minv + (long)PB * PB * v.N + 64L * k, alpha, beta, acc[0],

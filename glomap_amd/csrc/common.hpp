@@ -218,6 +218,16 @@ inline int grid_for(size_t work_items, int items_per_block) {
   return static_cast<int>(g);
 }
 
+// Grid for kernels WITHOUT per-block partial slots: one block per `items_per_block` work items,
+// capped only by `cap` (the hardware dispatcher streams the blocks; more waves in flight hide the
+// dependent-gather latency of the sweeps far better than a grid-stride loop does).
+inline int grid_wide(size_t work_items, int items_per_block, size_t cap = (1u << 22)) {
+  size_t g = (work_items + items_per_block - 1) / items_per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return static_cast<int>(g);
+}
+
 // Translate exceptions to status codes at the C boundary.
 template <typename F>
 inline int guarded(gsfm_ctx* ctx, gsfm_report* rep, F&& f) {

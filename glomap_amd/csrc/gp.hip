@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(kBlock)
     k_gp_cam_finalize(int N, double radius, double lo, double hi, const double* __restrict__ hcc,
                       const double* __restrict__ jsc, const double* __restrict__ gred,
                       const double* __restrict__ scc, double* __restrict__ dcam, double* __restrict__ rhs,
-                      double* __restrict__ minv) {
+                      double* __restrict__ minv, const double* __restrict__ c, double* __restrict__ cz) {
   for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
     const double D = lm_damping(hcc[n], jsc[n], radius, lo, hi);
     const double* sp = scc + 6 * (long)n;
@@ -320,6 +320,7 @@ __global__ void __launch_bounds__(kBlock)
     for (int j = 0; j < 3; ++j) {
       dcam[3 * (long)n + j] = D;
       rhs[3 * (long)n + j] = -gred[3 * (long)n + j];
+      cz[6 * (long)n + j] = c[3 * (long)n + j];  // gather record of PCG phase A: (c_n | z_n)
     }
   }
 }
@@ -329,7 +330,7 @@ __global__ void __launch_bounds__(kBlock)
 // Algorithmic bytes per observation: qa, qb (16) + cam (4) + pt (4); per track: 24 written; the
 // camera gathers (c_n, z_n: 48 B) are L2-resident, X_p is read from the track's own 64-byte record.
 __global__ void __launch_bounds__(kBlock)
-    k_gp_phaseA(GpDev g, CgVec v, int it, double tol2, const double* __restrict__ c,
+    k_gp_phaseA(GpDev g, CgVec v, int it, double tol2, const double* __restrict__ cz,
                 const double* __restrict__ qa, const double* __restrict__ qb,
                 const double* __restrict__ ptb, double* __restrict__ ptrec) {
   __shared__ double smem[4 * 2 + 2];
@@ -338,17 +339,17 @@ __global__ void __launch_bounds__(kBlock)
   const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (kBlock / 64);
   for (int tile = wave; tile < g.g.T; tile += nwaves) {
-    const int p0 = g.g.tile[tile], p1 = g.g.tile[tile + 1];
-    const long k0 = g.g.off[p0], k1 = g.g.off[p1];
+    const long k0 = g.g.tile_k[tile], k1 = g.g.tile_k[tile + 1];
     double acc[3] = {0, 0, 0};
     int key = -1 - lane;
     for (long k = k0 + lane; k < k1; k += 64) {
       const int p = g.g.obs_pt[k];
       key = p;
-      if (!g.g.used[p]) continue;
       const long n = g.g.cam[k];
-      const V3 d = ld3(ptrec + 8 * (long)p) - ld3(c + 3 * n);
-      const V3 y = applyQ(qa[k], qb[k], d, ld3(v.z + 3 * n));
+      V3 cn, zn;
+      ld6(cz + 6 * n, cn, zn);  // (c_n, z_n): one 48-byte record, three 16-byte gathers
+      const V3 d = ld3a(ptrec + 8 * (long)p) - cn;
+      const V3 y = applyQ(qa[k], qb[k], d, zn);
       acc[0] += y.x;
       acc[1] += y.y;
       acc[2] += y.z;
@@ -381,9 +382,10 @@ __global__ void __launch_bounds__(kBlock)
     const V3 zn = ld3(v.z + 3 * (long)n);
     double acc[3] = {0, 0, 0};
     for (int k = g.g.coff[n] + lane; k < g.g.coff[n + 1]; k += 64) {
-      const double* pr = ptrec + 8 * (long)g.g.c_pt[k];
-      const V3 d = ld3(pr) - cn;
-      const V3 y = applyQ(c_qa[k], c_qb[k], d, zn - ld3(pr + 3));
+      V3 Xp, tp;
+      ld6(ptrec + 8 * (long)g.g.c_pt[k], Xp, tp);  // 64-byte aligned record, three 16-byte gathers
+      const V3 d = Xp - cn;
+      const V3 y = applyQ(c_qa[k], c_qb[k], d, zn - tp);
       acc[0] += y.x;
       acc[1] += y.y;
       acc[2] += y.z;
@@ -532,7 +534,7 @@ struct GpWs {
   DevBuf<int> cam;
   DevBuf<unsigned char> cal, c_cal;
   DevBuf<double> dir, c_dir, c_jss, c_qa, c_qb, c, cn, X, Xn, s, sn, wrob, qa, qb, jss, ptb, ptrec, hppd, jsx, hcc,
-      jsc, dcam, gc, gred, scc, minv, rhs, cg_x, cg_r, cg_z, cg_p, cg_s, cg_w, vpart, dpart, part, scal;
+      jsc, dcam, gc, gred, scc, minv, rhs, cz, cg_x, cg_r, cg_z, cg_p, cg_s, cg_w, vpart, dpart, part, scal;
   DevBuf<CgStatus> cgst;
   DevBuf<CgScal> cgsc;
   static void destroy(void* p) { delete static_cast<GpWs*>(p); }
@@ -619,17 +621,22 @@ class GpSolver final : public LmProblem {
       b->ensure(M_ + 1);
     ws->ptb.ensure(12 * (size_t)P_ + 12);
     ws->ptrec.ensure(8 * (size_t)P_ + 8);
+    // observations of unused tracks keep a = beta = 0 (no contribution, no `used` test in phase A)
+    GSFM_HIP_CHECK(hipMemsetAsync(ws->qa.get(), 0, (size_t)(M_ + 1) * sizeof(double), s));
+    GSFM_HIP_CHECK(hipMemsetAsync(ws->qb.get(), 0, (size_t)(M_ + 1) * sizeof(double), s));
+    GSFM_HIP_CHECK(hipMemsetAsync(ws->ptrec.get(), 0, (8 * (size_t)P_ + 8) * sizeof(double), s));
     ws->hppd.ensure(P_ + 1);
     ws->jsx.ensure(P_ + 1);
     ws->hcc.ensure(N_);
     ws->jsc.ensure(N_);
     ws->scc.ensure(6 * (size_t)N_);
     ws->minv.ensure(9 * (size_t)N_);
+    ws->cz.ensure(6 * (size_t)N_ + 2);
     for (DevBuf<double>* b : {&ws->dcam, &ws->gc, &ws->gred, &ws->rhs, &ws->cg_x, &ws->cg_r, &ws->cg_z, &ws->cg_p, &ws->cg_s})
       b->ensure(3 * (size_t)N_);
     ws->cg_w.ensure(3 * (size_t)N_ + 2);
     ws->vpart.ensure(2 * kCgMaxBlocks * 2);
-    ws->dpart.ensure(kMaxBlocks);
+    ws->dpart.ensure(2 * kMaxApplySlots);
     ws->part.ensure(kMaxBlocks * 8);
     ws->scal.ensure(64);
     ws->cgst.ensure(1);
@@ -637,8 +644,8 @@ class GpSolver final : public LmProblem {
     gridP_ = grid_for(P_, kBlock);
     gridN_ = grid_for(N_, kBlock);
     gridM_ = grid_for(M_, kBlock);
-    gridCam_ = grid_for(N_, kBlock / 64);       // one wave per camera
-    gridTile_ = grid_for(g_.g.T, kBlock / 64);  // one wave per tile
+    gridCam_ = grid_wide(N_, kBlock / 64, kMaxApplySlots);  // one wave per camera (delta partial per block)
+    gridTile_ = grid_wide(g_.g.T, kBlock / 64);             // one wave per tile
     g_.dir = ws->dir.get();
     g_.cal = d_cal;
     g_.c_dir = ws->c_dir.get();
@@ -676,6 +683,9 @@ class GpSolver final : public LmProblem {
     cg_.dpart = ws->dpart.get();
     cg_.scal = ws->cgsc.get();
     cg_.st = ws->cgst.get();
+    cg_.zmir = ws->cz.get();
+    cg_.zmir_stride = 6;
+    cg_.zmir_off = 3;
   }
 
   long used_observations() const { return m_used_; }
@@ -728,7 +738,7 @@ class GpSolver final : public LmProblem {
     if (g_.opt_c) {
       hipLaunchKernelGGL(k_gp_cam_finalize, dim3(gridN_), dim3(kBlock), 0, s, N_, radius, g_.lm_lo, g_.lm_hi,
                          ws->hcc.get(), ws->jsc.get(), ws->gred.get(), ws->scc.get(), ws->dcam.get(),
-                         ws->rhs.get(), ws->minv.get());
+                         ws->rhs.get(), ws->minv.get(), c_, ws->cz.get());
       *linear_iterations = pcg();
     } else {
       GSFM_HIP_CHECK(hipMemsetAsync(ws->cg_x.get(), 0, (size_t)n3 * sizeof(double), s));
@@ -796,7 +806,7 @@ class GpSolver final : public LmProblem {
     const double tol = opt_.lm.pcg_relative_tolerance;
     return cg_solve<3, false>(ctx_, cg_, tol, opt_.lm.pcg_max_iterations, [&](int it) {
       bool timed = ctx_->prof.begin(s, GSFM_KERNEL_GP_SCHUR);
-      hipLaunchKernelGGL(k_gp_phaseA, dim3(gridTile_), dim3(kBlock), 0, s, g_, cg_, it, tol * tol, c_, ws->qa.get(),
+      hipLaunchKernelGGL(k_gp_phaseA, dim3(gridTile_), dim3(kBlock), 0, s, g_, cg_, it, tol * tol, ws->cz.get(), ws->qa.get(),
                          ws->qb.get(), ws->ptb.get(), ws->ptrec.get());
       if (timed) ctx_->prof.end(s);
       timed = ctx_->prof.begin(s, GSFM_KERNEL_GP_SCHUR_B);

@@ -9,6 +9,19 @@ struct V3 {
   double x, y, z;
 };
 __device__ __forceinline__ V3 ld3(const double* __restrict__ p) { return V3{p[0], p[1], p[2]}; }
+// Six doubles at a 16-byte aligned address as three 16-byte loads (one gather instruction each).
+__device__ __forceinline__ void ld6(const double* __restrict__ p, V3& a, V3& b) {
+  const double2* q = reinterpret_cast<const double2*>(p);
+  const double2 v0 = q[0], v1 = q[1], v2 = q[2];
+  a = V3{v0.x, v0.y, v1.x};
+  b = V3{v1.y, v2.x, v2.y};
+}
+// First three doubles of a 16-byte aligned record (two 16-byte loads).
+__device__ __forceinline__ V3 ld3a(const double* __restrict__ p) {
+  const double2* q = reinterpret_cast<const double2*>(p);
+  const double2 v0 = q[0], v1 = q[1];
+  return V3{v0.x, v0.y, v1.x};
+}
 __device__ __forceinline__ void st3(double* __restrict__ p, const V3& v) {
   p[0] = v.x;
   p[1] = v.y;

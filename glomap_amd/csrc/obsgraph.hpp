@@ -38,13 +38,14 @@ struct ObsGraph {  // device view, passed to kernels by value
   const unsigned char* used = nullptr; // [P]
   const int* obs_pt = nullptr;         // [M]   track of each observation
   const int* tile = nullptr;           // [T+1] first track of each wave tile
+  const int* tile_k = nullptr;         // [T+1] first observation of each wave tile
   const int* coff = nullptr;           // [N+2] camera-major CSR; coff[N] = Mu, coff[N+1] = M
   const int* c_src = nullptr;          // [M]   track-major index of each camera-major slot
   const int* c_pt = nullptr;           // [M]   track of each camera-major slot
 };
 
 struct ObsGraphWs {
-  DevBuf<int> obs_pt, tile, keys, keys_sorted, vals, c_src, c_pt, coff, flag;
+  DevBuf<int> obs_pt, tile, tile_k, keys, keys_sorted, vals, c_src, c_pt, coff, flag;
   DevBuf<unsigned char> used, sort_tmp;
 };
 
@@ -165,10 +166,13 @@ inline long build_obs_graph(gsfm_ctx* ctx, ObsGraphWs& ws, int N, long P, long M
   }
   const int T = (int)h_tile.size();
   h_tile.push_back((int)P);
+  std::vector<int> h_tile_k(T + 1);
+  for (int i = 0; i <= T; ++i) h_tile_k[i] = (int)h_off[h_tile[i]];
   if (first_used_obs) *first_used_obs = first;
 
   GSFM_HIP_CHECK(hipMemcpyAsync(ws.used.ensure(P + 1), h_used.data(), (size_t)P, hipMemcpyHostToDevice, s));
   GSFM_HIP_CHECK(hipMemcpyAsync(ws.tile.ensure(T + 2), h_tile.data(), (size_t)(T + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+  GSFM_HIP_CHECK(hipMemcpyAsync(ws.tile_k.ensure(T + 2), h_tile_k.data(), (size_t)(T + 1) * sizeof(int), hipMemcpyHostToDevice, s));
   ws.obs_pt.ensure(M + 1);
   ws.keys.ensure(M + 1);
   ws.keys_sorted.ensure(M + 1);
@@ -201,6 +205,7 @@ inline long build_obs_graph(gsfm_ctx* ctx, ObsGraphWs& ws, int N, long P, long M
   g.used = ws.used.get();
   g.obs_pt = ws.obs_pt.get();
   g.tile = ws.tile.get();
+  g.tile_k = ws.tile_k.get();
   g.coff = ws.coff.get();
   g.c_src = ws.c_src.get();
   g.c_pt = ws.c_pt.get();
