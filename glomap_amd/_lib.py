@@ -165,6 +165,8 @@ class BaProblemC(C.Structure):
     ]
 
 
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_int, C.c_void_p)
+
 _lib = None
 
 
@@ -210,6 +212,8 @@ def load():
     lib.gsfm_comm_init.argtypes = [vp, C.c_char_p, ip, ip]
     lib.gsfm_comm_destroy.restype = ip
     lib.gsfm_comm_destroy.argtypes = [vp]
+    lib.gsfm_comm_init_host.restype = ip
+    lib.gsfm_comm_init_host.argtypes = [vp, HOST_ALLREDUCE_FN, vp, ip, ip]
     lib.gsfm_ra_options_default.restype = None
     lib.gsfm_ra_options_default.argtypes = [C.POINTER(RaOptions)]
     lib.gsfm_ra_solve.restype = ip
@@ -363,6 +367,29 @@ class Context:
         if rc != 0:
             raise GsfmError(rc, "gsfm_comm_init")
         self.rank, self.world = rank, world
+
+
+def _comm_init_host(self, allreduce, rank: int, world: int):
+    """Validation transport: `allreduce(np_array, op)` must reduce the array in place across ranks
+    (op 0 = sum, 1 = max), e.g. with torch.distributed on gloo.  See gsfm_comm_init_host."""
+
+    def _cb(buf, n, op, _user):
+        try:
+            a = np.ctypeslib.as_array(buf, shape=(n,))
+            allreduce(a, op)
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            print(f"[gsfm] host all-reduce callback failed: {e!r}")
+            return 1
+
+    self._host_cb = HOST_ALLREDUCE_FN(_cb)  # keep alive
+    rc = self.lib.gsfm_comm_init_host(self.handle, self._host_cb, None, rank, world)
+    if rc != 0:
+        raise GsfmError(rc, "gsfm_comm_init_host")
+    self.rank, self.world = rank, world
+
+
+Context.comm_init_host = _comm_init_host
 
 
 def comm_unique_id() -> bytes:

@@ -169,6 +169,22 @@ extern "C" int gsfm_comm_init(gsfm_ctx* ctx, const char id[GSFM_COMM_ID_BYTES], 
   });
 }
 
+extern "C" int gsfm_comm_init_host(gsfm_ctx* ctx, gsfm_host_allreduce_fn fn, void* user, int rank, int world_size) {
+  if (!ctx || !fn) return GSFM_ERR_INVALID_ARGUMENT;
+  return guarded(ctx, nullptr, [&] {
+    GSFM_REQUIRE(world_size >= 1 && rank >= 0 && rank < world_size, "comm: bad rank/world_size");
+    if (ctx->comm.nccl) {
+      GSFM_NCCL_CHECK(ncclCommDestroy(ctx->comm.nccl));
+      ctx->comm.nccl = nullptr;
+    }
+    ctx->comm.host_fn = fn;
+    ctx->comm.host_user = user;
+    ctx->comm.rank = rank;
+    ctx->comm.world = world_size;
+    return (int)GSFM_OK;
+  });
+}
+
 extern "C" int gsfm_comm_destroy(gsfm_ctx* ctx) {
   if (!ctx) return GSFM_ERR_INVALID_ARGUMENT;
   return guarded(ctx, nullptr, [&] {

@@ -1115,7 +1115,7 @@ class BaSolver final : public LmProblem {
                        ws->scal.get());
     if (ctx_->comm.world > 1) {
       allreduce_sum(ctx_, ws->scal.get(), 1);
-      GSFM_NCCL_CHECK(ncclAllReduce(ws->scal.get() + 1, ws->scal.get() + 1, 1, ncclDouble, ncclMax, ctx_->comm.nccl, s));
+      allreduce_max(ctx_, ws->scal.get() + 1, 1);
     }
     GSFM_HIP_CHECK(hipMemcpyAsync(ctx_->h_pinned + 300, ws->scal.get(), 2 * sizeof(double), hipMemcpyDeviceToHost, s));
     GSFM_HIP_CHECK(hipStreamSynchronize(s));

@@ -108,6 +108,11 @@ struct Comm {
   ncclComm_t nccl = nullptr;
   int rank = 0;
   int world = 1;
+  // host-staged transport (gsfm_comm_init_host): validates the sharded path where RCCL cannot be
+  // used (several ranks on ONE device, CI without xGMI).  Never the production path.
+  gsfm_host_allreduce_fn host_fn = nullptr;
+  void* host_user = nullptr;
+  std::vector<double> host_buf;
 };
 
 }  // namespace gsfm
@@ -179,10 +184,23 @@ namespace gsfm {
 
 // All-reduce (sum) of a device vector over the ranks of the ctx communicator, in place, on the
 // ctx stream.  No-op for a single rank.
-inline void allreduce_sum(gsfm_ctx* ctx, double* dev, size_t n) {
+inline void allreduce(gsfm_ctx* ctx, double* dev, size_t n, int op /* 0 = sum, 1 = max */) {
   if (ctx->comm.world <= 1 || n == 0) return;
-  GSFM_NCCL_CHECK(ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, ctx->comm.nccl, ctx->stream));
+  if (ctx->comm.host_fn) {
+    std::vector<double>& h = ctx->comm.host_buf;
+    h.resize(n);
+    GSFM_HIP_CHECK(hipMemcpyAsync(h.data(), dev, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    GSFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->comm.host_fn(h.data(), (int64_t)n, op, ctx->comm.host_user) != 0)
+      throw StatusError(GSFM_ERR_COMM, "host all-reduce callback failed");
+    GSFM_HIP_CHECK(hipMemcpyAsync(dev, h.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    GSFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return;
+  }
+  GSFM_NCCL_CHECK(ncclAllReduce(dev, dev, n, ncclDouble, op == 0 ? ncclSum : ncclMax, ctx->comm.nccl, ctx->stream));
 }
+inline void allreduce_sum(gsfm_ctx* ctx, double* dev, size_t n) { allreduce(ctx, dev, n, 0); }
+inline void allreduce_max(gsfm_ctx* ctx, double* dev, size_t n) { allreduce(ctx, dev, n, 1); }
 
 // Copies `n` elements host<->device or device<->device depending on the problem's mem space.
 template <typename T>

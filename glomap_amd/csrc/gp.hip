@@ -790,8 +790,7 @@ class GpSolver final : public LmProblem {
     hipStream_t s = ctx_->stream;
     if (ctx_->comm.world > 1) {
       allreduce_sum(ctx_, dev, sum_first);
-      GSFM_NCCL_CHECK(ncclAllReduce(dev + max_from, dev + max_from, n - max_from, ncclDouble, ncclMax,
-                                    ctx_->comm.nccl, s));
+      allreduce_max(ctx_, dev + max_from, (size_t)(n - max_from));
     }
     GSFM_HIP_CHECK(hipMemcpyAsync(ctx_->h_pinned + 300, dev, n * sizeof(double), hipMemcpyDeviceToHost, s));
     GSFM_HIP_CHECK(hipStreamSynchronize(s));

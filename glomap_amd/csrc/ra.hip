@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(kBlock)
                   const double* __restrict__ res, const double* __restrict__ wirls,
                   const double* __restrict__ ew, const double* __restrict__ z,
                   const double* __restrict__ u, const double* __restrict__ dz,
-                  double* __restrict__ inc_w, double* __restrict__ lap_diag,
+                  double* __restrict__ inc_w, double* __restrict__ lap_diag, double* __restrict__ lap_diag_loc,
                   double* __restrict__ rhs, double* __restrict__ gat_s, double* __restrict__ gat_t,
                   int fixed_node, int has_gauge) {
   const int gpb = kBlock / LPR;  // groups (nodes) per block per sweep
@@ -174,7 +174,10 @@ __global__ void __launch_bounds__(kBlock)
         }
         dsum += 1.0;
       }
-      if constexpr (MODE != GATHER_L1RHS) lap_diag[n] = dsum;
+      if constexpr (MODE != GATHER_L1RHS) {
+        lap_diag[n] = dsum;      // all-reduced afterwards when the edges are sharded: Jacobi preconditioner
+        lap_diag_loc[n] = dsum;  // stays local: diagonal of THIS rank's share of the operator (SpMV)
+      }
       if constexpr (MODE != GATHER_L1W) {
         rhs[3 * n] = a0;
         rhs[3 * n + 1] = a1;
@@ -558,7 +561,7 @@ __global__ void __launch_bounds__(kBlock)
 // ------------------------------------------------------------------------------------------
 struct RaWs {
   DevBuf<int> ei, ej, rowptr, inc, nbr, flags;
-  DevBuf<double> eq, ew, inc_w, lap_diag, rot, nq, res, wirls, z, u, dz, rhs, x, r, p, q, zv, wbuf,
+  DevBuf<double> eq, ew, inc_w, lap_diag, lap_diag_loc, rot, nq, res, wirls, z, u, dz, rhs, x, r, p, q, zv, wbuf,
       gat_s, gat_t, fixed_rot0, part0, part1, part2, part_misc, scal;
   DevBuf<PcgStatus> status;
   static void destroy(void* p) { delete static_cast<RaWs*>(p); }
@@ -722,7 +725,7 @@ int pcg_solve(RaDevice& d, bool warm, double tol, int max_iter) {
   if (warm) {
     dispatch_lpr(d.lpr, [&](auto L) {
       hipLaunchKernelGGL((k_spmv<decltype(L)::value>), dim3(gR), dim3(kBlock), 0, s, N, ws->rowptr.get(),
-                         ws->nbr.get(), ws->inc_w.get(), ws->lap_diag.get(), ws->x.get(), ws->wbuf.get());
+                         ws->nbr.get(), ws->inc_w.get(), ws->lap_diag_loc.get(), ws->x.get(), ws->wbuf.get());
     });
     allreduce_sum(ctx, ws->wbuf.get(), 3 * (size_t)N);
     Ax0 = ws->wbuf.get();
@@ -754,7 +757,7 @@ int pcg_solve(RaDevice& d, bool warm, double tol, int max_iter) {
     } else {
       dispatch_lpr(d.lpr, [&](auto L) {
         hipLaunchKernelGGL((k_spmv<decltype(L)::value>), dim3(gR), dim3(kBlock), 0, s, N, ws->rowptr.get(),
-                           ws->nbr.get(), ws->inc_w.get(), ws->lap_diag.get(), ws->zv.get(), ws->wbuf.get());
+                           ws->nbr.get(), ws->inc_w.get(), ws->lap_diag_loc.get(), ws->zv.get(), ws->wbuf.get());
       });
       allreduce_sum(ctx, ws->wbuf.get(), 3 * (size_t)N);
       hipLaunchKernelGGL(k_pcg_dir_split, dim3(gN), dim3(kBlock), 0, s, N, ws->wbuf.get(), ws->zv.get(),
@@ -859,6 +862,7 @@ void setup_device(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
   ws->wirls.ensure(E + 1);
   ws->inc_w.ensure(2 * E + 1);
   ws->lap_diag.ensure(N);
+  ws->lap_diag_loc.ensure(N);
   for (DevBuf<double>* b : {&ws->rhs, &ws->x, &ws->r, &ws->p, &ws->q, &ws->zv, &ws->wbuf, &ws->gat_s, &ws->gat_t})
     b->ensure(3 * (size_t)N);
   ws->part0.ensure(kMaxBlocks * 3);
@@ -875,7 +879,16 @@ int read_nan_flag(RaDevice& d) {
   int* h = reinterpret_cast<int*>(d.ctx->h_pinned + 128);
   GSFM_HIP_CHECK(hipMemcpyAsync(h, d.ws->flags.get(), sizeof(int), hipMemcpyDeviceToHost, d.ctx->stream));
   GSFM_HIP_CHECK(hipStreamSynchronize(d.ctx->stream));
-  return h[0];
+  int flag = h[0];
+  if (d.ctx->comm.world > 1) {  // every rank must take the same exit
+    d.ctx->h_pinned[81] = (double)flag;
+    GSFM_HIP_CHECK(hipMemcpyAsync(d.ws->scal.get() + 9, d.ctx->h_pinned + 81, sizeof(double), hipMemcpyHostToDevice, d.ctx->stream));
+    allreduce_max(d.ctx, d.ws->scal.get() + 9, 1);
+    GSFM_HIP_CHECK(hipMemcpyAsync(d.ctx->h_pinned + 81, d.ws->scal.get() + 9, sizeof(double), hipMemcpyDeviceToHost, d.ctx->stream));
+    GSFM_HIP_CHECK(hipStreamSynchronize(d.ctx->stream));
+    flag = d.ctx->h_pinned[81] != 0.0;
+  }
+  return flag;
 }
 
 template <int MODE>
@@ -885,8 +898,8 @@ void launch_gather(RaDevice& d) {
     hipLaunchKernelGGL((k_node_gather<MODE, decltype(L)::value>), dim3(d.gridRow), dim3(kBlock), 0,
                        d.ctx->stream, d.N, d.E, ws->rowptr.get(), ws->inc.get(), ws->res.get(),
                        ws->wirls.get(), d.ew, ws->z.get(), ws->u.get(), ws->dz.get(), ws->inc_w.get(),
-                       ws->lap_diag.get(), ws->rhs.get(), ws->gat_s.get(), ws->gat_t.get(), d.fixed,
-                       d.has_gauge);
+                       ws->lap_diag.get(), ws->lap_diag_loc.get(), ws->rhs.get(), ws->gat_s.get(), ws->gat_t.get(),
+                       d.fixed, d.has_gauge);
   });
 }
 
@@ -919,12 +932,21 @@ int ra_solve_impl(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
     ws->dz.ensure(rows3);
     launch_gather<GATHER_L1W>(d);  // (WA)^T (WA): factorised once in the reference (gra.cc:491)
     if (multi) {
-      // TODO(multi-rank): lap_diag must be all-reduced; inc_w stays local
-      allreduce_sum(ctx, ws->lap_diag.get(), N);
+      allreduce_sum(ctx, ws->lap_diag.get(), N);  // preconditioner diagonal; inc_w / lap_diag_loc stay local
     }
     double last_norm = 0.0, curr_norm = 0.0;
     launch_residuals(d, false, 0, 0.0);
-    const double rows_total = 3.0 * (double)E + 3.0;  // A.rows() incl. gauge (all ranks: global E below)
+    // A.rows() incl. the gauge rows — of the WHOLE graph when the edges are sharded over ranks
+    double e_glob = (double)E;
+    if (multi) {
+      ctx->h_pinned[80] = e_glob;
+      GSFM_HIP_CHECK(hipMemcpyAsync(ws->scal.get() + 8, ctx->h_pinned + 80, sizeof(double), hipMemcpyHostToDevice, s));
+      allreduce_sum(ctx, ws->scal.get() + 8, 1);
+      GSFM_HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 80, ws->scal.get() + 8, sizeof(double), hipMemcpyDeviceToHost, s));
+      GSFM_HIP_CHECK(hipStreamSynchronize(s));
+      e_glob = ctx->h_pinned[80];
+    }
+    const double rows_total = 3.0 * e_glob + 3.0;
     for (int it = 0; it < opt->max_num_l1_iterations; ++it) {
       last_norm = curr_norm;
       // --- colmap::LeastAbsoluteDeviationSolver::Solve(b' = W b, &x), x starts at 0
@@ -1106,7 +1128,7 @@ extern "C" int gsfm_ra_laplacian_apply(gsfm_ctx* ctx, const gsfm_ra_problem* pro
     for (int r = 0; r < reps; ++r) {
       dispatch_lpr(d.lpr, [&](auto L) {
         hipLaunchKernelGGL((k_spmv<decltype(L)::value>), dim3(d.gridRow), dim3(kBlock), 0, s, d.N,
-                           ws->rowptr.get(), ws->nbr.get(), ws->inc_w.get(), ws->lap_diag.get(),
+                           ws->rowptr.get(), ws->nbr.get(), ws->inc_w.get(), ws->lap_diag_loc.get(),
                            ws->x.get(), ws->wbuf.get());
       });
     }

@@ -125,6 +125,12 @@ int gsfm_ctx_profile_read(gsfm_ctx* ctx, int kernel_id, int64_t* launches, doubl
 int gsfm_comm_unique_id(char id[GSFM_COMM_ID_BYTES]);
 int gsfm_comm_init(gsfm_ctx* ctx, const char id[GSFM_COMM_ID_BYTES], int rank, int world_size);
 int gsfm_comm_destroy(gsfm_ctx* ctx);
+/* Host-staged transport for validation only (several ranks sharing ONE device, or a box without
+ * xGMI): every collective becomes D2H, fn(buf, n, op, user) — which must all-reduce buf in place
+ * across the ranks (op 0 = sum, 1 = max) and return 0 — and H2D.  Same sharding semantics as the
+ * RCCL transport; never the measured path. */
+typedef int (*gsfm_host_allreduce_fn)(double* buf, int64_t n, int op, void* user);
+int gsfm_comm_init_host(gsfm_ctx* ctx, gsfm_host_allreduce_fn fn, void* user, int rank, int world_size);
 
 /* ---- rotation averaging ------------------------------------------------------------------- */
 /* Options: mirror of RotationEstimatorOptions, global_rotation_averaging.h:39-75. */
