@@ -33,7 +33,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
-KERNEL_RA, KERNEL_GP, KERNEL_BA = 0, 1, 2
+KERNEL_RA, KERNEL_GP, KERNEL_BA, KERNEL_GP_B, KERNEL_BA_B = 0, 1, 2, 3, 4
 
 
 def parse():
@@ -71,10 +71,6 @@ def main():
         dist.init_process_group("gloo")
         dist.barrier()  # rank 0 finished building
     ctx = _lib.Context(local_rank)  # raises GSFM_ERR_NO_DEVICE without an MI355X: no CPU fallback
-    if world > 1:
-        uid = [_lib.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(uid[0], rank, world)
 
     def barrier():
         ctx.synchronize()
@@ -85,26 +81,66 @@ def main():
     env = dict(args=args, ctx=ctx, rank=rank, world=world, barrier=barrier, dist=dist)
     if args.workload == "ra_c2":
         out = bench_ra(**env)
-        if not args.no_extra and world == 1:
-            extra = {}
-            sub_args = argparse.Namespace(**{**vars(args), "steps": 1, "warmup": 0})
-            for name, fn in (("gp_c3", bench_gp), ("ba_c4", bench_ba)):
-                try:
-                    sub = fn(**{**env, "args": sub_args})
-                    extra[name] = {k: sub[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline",
-                                                       "cpu_baseline")}
-                except Exception as e:  # report, never hide
-                    extra[name] = {"error": repr(e)}
-            out["extra"] = extra
+        if not args.no_extra:
+            out["extra"] = run_extras(env, args, world, rank, out)
     elif args.workload == "gp_c3":
+        comm_init(ctx, dist, rank, world)
         out = bench_gp(**env)
     else:
+        comm_init(ctx, dist, rank, world)
         out = bench_ba(**env)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
     ctx.close()
+
+
+def comm_init(ctx, dist, rank, world):
+    """RCCL communicator of libgsfm (one rank per GPU): rank 0 creates the unique id, gloo carries it."""
+    if world <= 1 or getattr(ctx, "_comm_ready", False):
+        return
+    from glomap_amd import _lib
+
+    uid = [_lib.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    ctx.comm_init(uid[0], rank, world)
+    ctx._comm_ready = True
+
+
+def run_extras(env, args, world, rank, main_line):
+    """GP (configs[2]) and BA (configs[3]) side measurements: one solve each, track-sharded over the
+    ranks with RCCL when world > 1.  They run under a watchdog: whatever happens in there (RCCL
+    bring-up included), the main JSON line is still printed."""
+    import threading
+
+    extra = {}
+    sub_args = argparse.Namespace(**{**vars(args), "steps": 1, "warmup": 0})
+
+    def work():
+        try:
+            comm_init(env["ctx"], env["dist"], rank, world)
+        except Exception as e:
+            extra["comm"] = {"error": repr(e)}
+            return
+        for name, fn in (("gp_c3", bench_gp), ("ba_c4", bench_ba)):
+            try:
+                sub = fn(**{**env, "args": sub_args})
+                extra[name] = {k: sub[k] for k in ("metric", "value", "unit", "n_gpus", "ms_per_step", "scaling", "config",
+                                                   "roofline", "cpu_baseline")}
+            except Exception as e:  # report, never hide
+                extra[name] = {"error": repr(e)}
+
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    t.join(timeout=float(os.environ.get("GSFM_BENCH_EXTRA_TIMEOUT", "420")))
+    if t.is_alive():
+        extra["watchdog"] = {"error": "extra measurements did not finish in time; main line printed without them"}
+        if rank == 0:
+            main_line["extra"] = extra
+            print(json.dumps(main_line), flush=True)
+        os._exit(0)
+    return extra
 
 
 def timed_steps(step_fn, steps, warmup, barrier, dist):
@@ -125,32 +161,56 @@ def timed_steps(step_fn, steps, warmup, barrier, dist):
     return dt
 
 
-def profiled_step(ctx, kernel_id, step_fn):
-    """One extra, event-instrumented step: every launch of the dominant kernel is bracketed by a HIP
-    event pair on the ctx stream (gsfm_ctx_profile_*).  Returns (launches, avg_ms)."""
+def profiled_step(ctx, kernel_id, step_fn, also=()):
+    """One extra, event-instrumented step: every launch of the timed kernels is bracketed by a HIP
+    event pair on the ctx stream (gsfm_ctx_profile_*).  Returns (launches, avg_ms) of `kernel_id`;
+    the ids in `also` stay readable through kernel_line()."""
     ctx.profile_enable(True)
-    ctx.profile_read(kernel_id)
+    for k in (kernel_id, *also):
+        ctx.profile_read(k)
     step_fn()
-    launches, total_ms = ctx.profile_read(kernel_id)
     ctx.profile_enable(False)
+    launches, total_ms = ctx.profile_read(kernel_id)
     return launches, (total_ms / launches if launches else None)
 
 
-def roofline(kernel, bytes_per_launch, launches, avg_ms, note):
+def pmc_traffic(kernel):
+    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (collected by
+    tools/pmc_traffic.py; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  None when no
+    PMC pass exists for this kernel."""
+    try:
+        d = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+        return d.get(kernel, {}).get("bytes_per_launch")
+    except Exception:
+        return None
+
+
+def roofline(kernel, bytes_per_launch, launches, avg_ms, note, others=None):
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms else None
-    return {
+    r = {
         "bound": "hbm",
         "kernel": kernel,
         "achieved": achieved,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-        "traffic": None,
+        "traffic": pmc_traffic(kernel.split(" ")[0]),
         "bytes_per_launch": bytes_per_launch,
         "avg_kernel_us": avg_ms * 1e3 if avg_ms else None,
         "launches_in_profiled_step": launches,
         "note": note,
     }
+    if others:
+        r["other_kernels"] = others
+    return r
+
+
+def kernel_line(ctx, kid, name, bytes_per_launch):
+    launches, total_ms = ctx.profile_read(kid)
+    avg_ms = total_ms / launches if launches else None
+    gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms else None
+    return {"kernel": name, "avg_kernel_us": avg_ms * 1e3 if avg_ms else None, "bytes_per_launch": bytes_per_launch,
+            "achieved": gbs, "frac": gbs / HBM_PEAK_GBS if gbs else None, "launches": launches}
 
 
 def base_line(metric, value, unit, world, args, dt, config, roof, cpu, ctx):
@@ -182,10 +242,12 @@ def bench_ra(args, ctx, rank, world, barrier, dist):
 
     from glomap_amd import estimators, so3, synthetic
 
-    if world > 1:
-        raise SystemExit("ra_c2 is a single-GPU workload (1.2 MB working set); use --workload ba_c4 / gp_c3 with --gpus N")
+    # configs[1] is a 3.6 MB problem: one PCG iteration (~10 us) is shorter than one xGMI all-reduce, so
+    # sharding it can only slow it down.  With --gpus N every rank solves its own view graph of this
+    # size (replicas only, no collective) — the sharded RA path exists for large
+    # graphs and is exercised by tests/test_multirank_gpu.py.
     N, succ = 1000, 50
-    p = synthetic.make_ring_view_graph(N, succ, seed=0)
+    p = synthetic.make_ring_view_graph(N, succ, seed=rank)
     E = p.num_edges
     opt = estimators.RotationEstimatorOptions()
     pd = type(p)(
@@ -209,14 +271,15 @@ def bench_ra(args, ctx, rank, world, barrier, dist):
         last.update(rep)
 
     dt = timed_steps(step, args.steps, args.warmup, barrier, dist)
-    value = E * args.steps / dt
+    value = world * E * args.steps / dt
     launches, avg_ms = profiled_step(ctx, KERNEL_RA, step)
     roof = roofline(
-        "k_pcg_dir_fused (RA weighted-Laplacian SpMV, 3 RHS)",
-        16.0 * E + 48.0 * N,  # 16 E + 48 N per SpMV
+        "k_pcg_dir_fused (RA weighted-Laplacian SpMV with 3 RHS + PCG direction update)",
+        24.0 * E + 156.0 * N,  # CSR-by-node incidence (2E x 12 B) + node vectors
         launches,
         avg_ms,
-        "configs[1] working set (1.2 MB) is L2-resident: launch/latency-bound at this size, see DESIGN.md",
+        "configs[1] working set (3.6 MB) is L2-resident: this kernel is latency-bound, not HBM-bound; "
+        "see extra.ra_large for the same kernels on a graph that does not fit the caches",
     )
     err = synthetic.rotation_errors_deg(so3.aa_to_rotmat(rot.numpy()), p.gt_R)
     cpu = None if (args.no_cpu_baseline or rank != 0) else cpu_baseline_ra(p)
@@ -225,7 +288,8 @@ def bench_ra(args, ctx, rank, world, barrier, dist):
         "averaging (MST init + L1-ADMM + IRLS, reference defaults)",
         "cameras": N,
         "edges": E,
-        "parallelism": "single GPU",
+        "parallelism": "single GPU" if world == 1 else f"replicas x{world} (no collective)",
+        "seconds_setup_last": last.get("seconds_total", 0.0) - last.get("seconds_solve", 0.0),
         "l1_iterations": last.get("iterations_l1"),
         "irls_iterations": last.get("iterations_irls"),
         "pcg_iterations_per_step": last.get("linear_iterations"),
@@ -262,13 +326,9 @@ def cpu_baseline_ra(p):
 # global positioning, configs[2]
 # ----------------------------------------------------------------------------------------------
 def shard_tracks(pt_offset, rank, world):
-    """Contiguous, observation-balanced track range of this rank."""
-    import numpy as np
+    from glomap_amd import sharding
 
-    M = int(pt_offset[-1])
-    lo = int(np.searchsorted(pt_offset, (M * rank) // world, side="left"))
-    hi = int(np.searchsorted(pt_offset, (M * (rank + 1)) // world, side="left")) if rank + 1 < world else len(pt_offset) - 1
-    return lo, hi
+    return sharding.shard_tracks(pt_offset, rank, world)
 
 
 def bench_gp(args, ctx, rank, world, barrier, dist):
@@ -278,11 +338,21 @@ def bench_gp(args, ctx, rank, world, barrier, dist):
     from glomap_amd.flat import GpProblem
 
     ncam = int(5000 * args.scale)
-    npts = int(500_000 * args.scale) * world  # weak scaling: tracks per GPU fixed
-    p = synthetic.make_gp_problem(ncam, npts, seed=0)
-    lo, hi = shard_tracks(p.pt_offset, rank, world)
-    o0, o1 = int(p.pt_offset[lo]), int(p.pt_offset[hi])
+    npts_rank = int(500_000 * args.scale)  # weak scaling: tracks per GPU fixed
+    npts = npts_rank * world
+    if world == 1:
+        p = synthetic.make_gp_problem(ncam, npts, seed=0)
+    else:  # every rank generates only its own shard (cameras identical everywhere)
+        p = synthetic.make_gp_problem(ncam, npts_rank, seed=0, shard=(rank, world))
+    lo, hi = 0, p.num_pts
+    o0, o1 = 0, p.num_obs
     M_total = p.num_obs
+    if dist is not None:
+        import torch
+
+        tm = torch.tensor([p.num_obs], dtype=torch.int64)
+        dist.all_reduce(tm)
+        M_total = int(tm.item())
     pd = GpProblem(
         num_cams=ncam,
         num_pts=hi - lo,
@@ -307,14 +377,16 @@ def bench_gp(args, ctx, rank, world, barrier, dist):
     dt = timed_steps(step, args.steps, args.warmup, barrier, dist)
     iters = max(1, last["iterations"])
     value = M_total * iters * args.steps / dt  # observations swept per second, per LM iteration
-    launches, avg_ms = profiled_step(ctx, KERNEL_GP, step)
+    launches, avg_ms = profiled_step(ctx, KERNEL_GP, step, also=(KERNEL_GP_B,))
     M_loc, P_loc = o1 - o0, hi - lo
     roof = roofline(
-        "k_gp_schur_matvec (implicit Schur product over BATA observations)",
-        41.0 * M_loc + 48.0 * P_loc + 48.0 * ncam,  # SURVEY.md §8d K-GP-res
+        "k_gp_phaseA (implicit Schur product, track-major half: t_p = Hpp^-1 sum_k Q_k z_c)",
+        24.0 * M_loc + 96.0 * P_loc + 48.0 * ncam,
         launches,
         avg_ms,
-        "one launch = one product of the 3N reduced camera system with a vector",
+        "one PCG iteration = k_gp_phaseA + k_gp_phaseB + k_cg_update",
+        others=[kernel_line(ctx, KERNEL_GP_B, "k_gp_phaseB (camera-major half, 64-byte point-record gathers)",
+                            68.0 * M_loc + 96.0 * ncam)],
     )
     err = synthetic.center_errors_after_sim3(res["cen"].numpy(), p.gt_center)
     cpu = None if (args.no_cpu_baseline or rank != 0) else cpu_baseline_gp()
@@ -364,11 +436,21 @@ def bench_ba(args, ctx, rank, world, barrier, dist):
     from glomap_amd.flat import BaProblem
 
     ncam = int(10_000 * args.scale)
-    npts = int(1_000_000 * args.scale) * world  # weak scaling: tracks per GPU fixed
-    p = synthetic.make_ba_problem(ncam, npts, seed=0, shared_intrinsics=False)
-    lo, hi = shard_tracks(p.pt_offset, rank, world)
-    o0, o1 = int(p.pt_offset[lo]), int(p.pt_offset[hi])
+    npts_rank = int(1_000_000 * args.scale)  # weak scaling: tracks per GPU fixed
+    npts = npts_rank * world
+    if world == 1:
+        p = synthetic.make_ba_problem(ncam, npts, seed=0, shared_intrinsics=False)
+    else:  # every rank generates only its own shard (cameras / intrinsics / start identical everywhere)
+        p = synthetic.make_ba_problem(ncam, npts_rank, seed=0, shared_intrinsics=False, shard=(rank, world))
+    lo, hi = 0, p.num_pts
+    o0, o1 = 0, p.num_obs
     M_total = p.num_obs
+    if dist is not None:
+        import torch
+
+        tm = torch.tensor([p.num_obs], dtype=torch.int64)
+        dist.all_reduce(tm)
+        M_total = int(tm.item())
     pd = BaProblem(
         num_cams=ncam,
         num_pts=hi - lo,
@@ -398,14 +480,17 @@ def bench_ba(args, ctx, rank, world, barrier, dist):
     dt = timed_steps(step, args.steps, args.warmup, barrier, dist)
     iters = max(1, last["iterations"])
     value = M_total * iters * args.steps / dt
-    launches, avg_ms = profiled_step(ctx, KERNEL_BA, step)
+    launches, avg_ms = profiled_step(ctx, KERNEL_BA, step, also=(KERNEL_BA_B,))
     M_loc, P_loc = o1 - o0, hi - lo
+    F = 2  # free intrinsics columns stored per observation (SIMPLE_RADIAL: f, k)
     roof = roofline(
-        "k_ba_schur_matvec (matrix-free implicit Schur product over reprojection observations)",
-        28.0 * M_loc + 392.0 * ncam + 120.0 * P_loc + 32.0 * p.num_intr,  # SURVEY.md §8d K-BA-res
+        "k_ba_phaseA (implicit Schur product, track-major half over the stored Jacobian planes)",
+        (16.0 * (9 + F) + 12.0) * M_loc + 96.0 * P_loc + 48.0 * ncam,
         launches,
         avg_ms,
-        "one launch = one product of the reduced camera system (6N + 8K) with a vector",
+        "one PCG iteration = k_ba_phaseA + k_ba_phaseB + k_ba_phaseI + k_cg_update",
+        others=[kernel_line(ctx, KERNEL_BA_B, "k_ba_phaseB (camera-major half, Jacobians recomputed, 64-byte point-record gathers)",
+                            60.0 * M_loc + 304.0 * ncam + 64.0 * p.num_intr)],
     )
     R = so3.quat_to_rotmat(res["q"].numpy())
     Rg = so3.quat_to_rotmat(p.gt_q)

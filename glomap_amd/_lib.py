@@ -71,6 +71,7 @@ class RaOptions(C.Structure):
         ("l1_admm_relative_tolerance", C.c_double),
         ("pcg_relative_tolerance", C.c_double),
         ("pcg_max_iterations", C.c_int32),
+        ("force_iterative", C.c_int32),
     ]
 
 

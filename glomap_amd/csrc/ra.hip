@@ -25,6 +25,7 @@
 #include <numeric>
 
 #include "device.hpp"
+#include "ra_dense.hpp"
 
 namespace gsfm {
 namespace {
@@ -105,7 +106,8 @@ __global__ void __launch_bounds__(kBlock)
                   const double* __restrict__ u, const double* __restrict__ dz,
                   double* __restrict__ inc_w, double* __restrict__ lap_diag, double* __restrict__ lap_diag_loc,
                   double* __restrict__ rhs, double* __restrict__ gat_s, double* __restrict__ gat_t,
-                  int fixed_node, int has_gauge) {
+                  int fixed_node, int has_gauge, const int* __restrict__ stop) {
+  if (stop != nullptr && *stop) return;
   const int gpb = kBlock / LPR;  // groups (nodes) per block per sweep
   const int g = threadIdx.x / LPR;
   const int l = threadIdx.x % LPR;
@@ -487,8 +489,9 @@ __global__ void __launch_bounds__(kBlock)
                 const int* __restrict__ ej, const double* __restrict__ ew,
                 const double* __restrict__ res, const double* __restrict__ x,
                 double* __restrict__ z, double* __restrict__ u, double* __restrict__ dz, double alpha,
-                double inv_rho, double* __restrict__ part /* [grid][4] */) {
+                double inv_rho, double* __restrict__ part /* [grid][4] */, const int* __restrict__ stop) {
   __shared__ double smem[4 * 4];
+  if (stop != nullptr && *stop) return;
   double acc[4] = {0, 0, 0, 0};
   const long rows = E + (has_gauge ? 1 : 0);
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < rows; e += (long)gridDim.x * blockDim.x) {
@@ -543,6 +546,45 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// Device-side stopping test of colmap::LeastAbsoluteDeviationSolver (primal / dual residual against
+// eps_pri / eps_dual): single block.  part = [nb][4] partial sums of k_admm_edge, gat_s / gat_t =
+// A'^T (z - z_old) and A'^T u.  Raises *stop when converged, else counts the iteration.
+__global__ void __launch_bounds__(1024)
+    k_admm_check(const double* __restrict__ part, int nb, const double* __restrict__ gat_s,
+                 const double* __restrict__ gat_t, int n3, double rows, double abs_tol, double rel_tol, double rho,
+                 int* __restrict__ stop, int* __restrict__ count) {
+  __shared__ double smem[16 * 6];
+  if (*stop) return;
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] += part[4 * b + k];
+  }
+  for (int i = threadIdx.x; i < n3; i += blockDim.x) {
+    acc[4] += gat_s[i] * gat_s[i];
+    acc[5] += gat_t[i] * gat_t[i];
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) acc[k] = wave_sum(acc[k]);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) smem[wave * 6 + k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double h[6] = {0, 0, 0, 0, 0, 0};
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w)
+      for (int k = 0; k < 6; ++k) h[k] += smem[w * 6 + k];
+    const double r_norm = sqrt(h[0]), Ax_norm = sqrt(h[1]), z_norm = sqrt(h[2]), b_norm = sqrt(h[3]);
+    const double s_norm = rho * sqrt(h[4]), dual_norm = rho * sqrt(h[5]);
+    const double primal_eps = sqrt(rows) * abs_tol + rel_tol * fmax(Ax_norm, fmax(z_norm, b_norm));
+    const double dual_eps = sqrt((double)n3) * abs_tol + rel_tol * dual_norm;
+    *count += 1;
+    if (r_norm < primal_eps && s_norm < dual_eps) *stop = 1;
+  }
+}
+
 // Single-block finaliser: out[k] = sum_b part[b*K + k]  (fixed order).
 template <int K>
 __global__ void __launch_bounds__(kBlock)
@@ -560,7 +602,8 @@ __global__ void __launch_bounds__(kBlock)
 // host side
 // ------------------------------------------------------------------------------------------
 struct RaWs {
-  DevBuf<int> ei, ej, rowptr, inc, nbr, flags;
+  DevBuf<int> ei, ej, rowptr, inc, nbr, inc_row, flags;
+  DevBuf<double> dense_a, dense_b, dense_pinv;
   DevBuf<double> eq, ew, inc_w, lap_diag, lap_diag_loc, rot, nq, res, wirls, z, u, dz, rhs, x, r, p, q, zv, wbuf,
       gat_s, gat_t, fixed_rot0, part0, part1, part2, part_misc, scal;
   DevBuf<PcgStatus> status;
@@ -580,9 +623,24 @@ RaWs* ra_ws(gsfm_ctx* ctx) {
 // cam_from_worlds[root], so it stays the default-constructed Rigid3d.
 void mst_init(int N, long E, const int* ei, const int* ej, const double* eq, const int* ninl,
               double* rot /* [N][3] in/out */) {
+  // edges by descending inlier count, ties in input order: counting sort when the value range is
+  // moderate (inlier counts are), comparison sort otherwise
   std::vector<long> order(E);
-  std::iota(order.begin(), order.end(), 0L);
-  std::stable_sort(order.begin(), order.end(), [&](long a, long b) { return ninl[a] > ninl[b]; });
+  int lo = E ? ninl[0] : 0, hi = lo;
+  for (long e = 0; e < E; ++e) {
+    lo = std::min(lo, ninl[e]);
+    hi = std::max(hi, ninl[e]);
+  }
+  const long range = (long)hi - lo + 1;
+  if (range <= (1L << 22)) {
+    std::vector<long> start(range + 1, 0);
+    for (long e = 0; e < E; ++e) start[hi - ninl[e] + 1]++;
+    for (long v = 0; v < range; ++v) start[v + 1] += start[v];
+    for (long e = 0; e < E; ++e) order[start[hi - ninl[e]]++] = e;
+  } else {
+    std::iota(order.begin(), order.end(), 0L);
+    std::stable_sort(order.begin(), order.end(), [&](long a, long b) { return ninl[a] > ninl[b]; });
+  }
   std::vector<int> parent(N);
   std::iota(parent.begin(), parent.end(), 0);
   auto find = [&](int v) {
@@ -657,6 +715,11 @@ struct RaDevice {
   int lpr;
   const double* ew;  // device edge weights or nullptr
   int gridN, gridE, gridRow;
+  // direct (dense) solves for small graphs, ra_dense.hpp
+  bool dense = false;
+  bool dense_valid = false;   // dense_inv holds the inverse of the current weighted Laplacian
+  int Np = 0, T = 0;          // padded size, tiles per side
+  double* dense_inv = nullptr;
 };
 
 template <typename F>
@@ -692,27 +755,73 @@ void build_incidence(RaDevice& d, const int* h_ei, const int* h_ej) {
   }
   for (int n = 0; n < N; ++n) rowptr[n + 1] += rowptr[n];
   std::vector<int> fill(rowptr.begin(), rowptr.end() - 1);
-  std::vector<int> inc(2 * E), nbr(2 * E);
+  std::vector<int> inc(2 * E), nbr(2 * E), inc_row(2 * E);
   for (long e = 0; e < E; ++e) {
     const int i = h_ei[e], j = h_ej[e];
     int k = fill[i]++;
     inc[k] = (int)(e << 1);  // node is image_id1: -I3
     nbr[k] = j;
+    inc_row[k] = i;
     k = fill[j]++;
     inc[k] = (int)(e << 1) | 1;  // node is image_id2: +I3
     nbr[k] = i;
+    inc_row[k] = j;
   }
   RaWs* ws = d.ws;
   hipStream_t s = d.ctx->stream;
   GSFM_HIP_CHECK(hipMemcpyAsync(ws->rowptr.ensure(N + 1), rowptr.data(), (N + 1) * sizeof(int), hipMemcpyHostToDevice, s));
   GSFM_HIP_CHECK(hipMemcpyAsync(ws->inc.ensure(2 * E + 1), inc.data(), 2 * E * sizeof(int), hipMemcpyHostToDevice, s));
   GSFM_HIP_CHECK(hipMemcpyAsync(ws->nbr.ensure(2 * E + 1), nbr.data(), 2 * E * sizeof(int), hipMemcpyHostToDevice, s));
+  if (d.dense)
+    GSFM_HIP_CHECK(hipMemcpyAsync(ws->inc_row.ensure(2 * E + 1), inc_row.data(), 2 * E * sizeof(int), hipMemcpyHostToDevice, s));
   GSFM_HIP_CHECK(hipStreamSynchronize(s));  // host vectors go out of scope
 }
 
 // Solves (L_w (x) I3 + gauge) x = rhs with the weights currently in ws->inc_w / lap_diag.
 // warm: keep the current contents of ws->x as initial guess.  Returns PCG iterations.
+// (L_w + gauge)^-1 by tiled Gauss-Jordan (ra_dense.hpp): T launches of a T x T grid.
+void dense_factor(RaDevice& d) {
+  RaWs* ws = d.ws;
+  hipStream_t s = d.ctx->stream;
+  const int Np = d.Np, T = d.T;
+  const size_t nn = (size_t)Np * Np;
+  double* cur = ws->dense_a.ensure(nn);
+  double* oth = ws->dense_b.ensure(nn);
+  double* pinv = ws->dense_pinv.ensure(2 * kTile * kTile);
+  GSFM_HIP_CHECK(hipMemsetAsync(cur, 0, nn * sizeof(double), s));
+  hipLaunchKernelGGL(k_dense_fill_offdiag, dim3(grid_for(2 * d.E, kBlock)), dim3(kBlock), 0, s, 2 * d.E,
+                     ws->inc_row.get(), ws->nbr.get(), ws->inc_w.get(), Np, cur);
+  hipLaunchKernelGGL(k_dense_fill_diag, dim3(grid_for(Np, kBlock)), dim3(kBlock), 0, s, d.N, Np, ws->lap_diag.get(), Np, cur);
+  hipLaunchKernelGGL(k_dense_pivot0, dim3(1), dim3(kBlock), 0, s, cur, Np, pinv);
+  for (int k = 0; k < T; ++k) {
+    hipLaunchKernelGGL(k_dense_gj_step, dim3(T, T), dim3(kBlock), 0, s, cur, oth, Np, T, k,
+                       pinv + (k & 1) * kTile * kTile, pinv + ((k + 1) & 1) * kTile * kTile);
+    std::swap(cur, oth);
+  }
+  d.dense_inv = cur;
+  d.dense_valid = true;
+}
+
+// x = A^-1 rhs, then (refine) one step of iterative refinement against the sparse operator.
+int dense_solve(RaDevice& d, bool refine = true, const int* stop = nullptr) {
+  RaWs* ws = d.ws;
+  hipStream_t s = d.ctx->stream;
+  const int N = d.N;
+  if (!d.dense_valid) dense_factor(d);
+  const int gA = grid_for(N, kBlock / 64);
+  hipLaunchKernelGGL(k_dense_apply3, dim3(gA), dim3(kBlock), 0, s, N, d.Np, d.dense_inv, ws->rhs.get(), ws->x.get(), 0, stop);
+  if (!refine) return 1;
+  dispatch_lpr(d.lpr, [&](auto L) {
+    hipLaunchKernelGGL((k_spmv<decltype(L)::value>), dim3(d.gridRow), dim3(kBlock), 0, s, N, ws->rowptr.get(),
+                       ws->nbr.get(), ws->inc_w.get(), ws->lap_diag_loc.get(), ws->x.get(), ws->wbuf.get());
+  });
+  hipLaunchKernelGGL(k_dense_residual, dim3(d.gridN), dim3(kBlock), 0, s, 3L * N, ws->rhs.get(), ws->wbuf.get(), ws->r.get());
+  hipLaunchKernelGGL(k_dense_apply3, dim3(gA), dim3(kBlock), 0, s, N, d.Np, d.dense_inv, ws->r.get(), ws->x.get(), 1, stop);
+  return 1;
+}
+
 int pcg_solve(RaDevice& d, bool warm, double tol, int max_iter) {
+  if (d.dense) return dense_solve(d);
   RaWs* ws = d.ws;
   gsfm_ctx* ctx = d.ctx;
   hipStream_t s = ctx->stream;
@@ -814,6 +923,10 @@ void setup_device(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
   d.fixed = prob->fixed_node;
   d.has_gauge = ctx->comm.rank == 0 ? 1 : 0;
   d.lpr = choose_lpr(E, N);
+  d.dense = ctx->comm.world == 1 && N <= kDenseMaxN && opt->pcg_max_iterations > 0 && !opt->force_iterative;
+  d.dense_valid = false;
+  d.T = (N + kTile - 1) / kTile;
+  d.Np = d.T * kTile;
   d.gridN = grid_for(N, kBlock);
   d.gridE = grid_for(E + 1, kBlock);
   d.gridRow = grid_for(N, kBlock / d.lpr);
@@ -892,14 +1005,15 @@ int read_nan_flag(RaDevice& d) {
 }
 
 template <int MODE>
-void launch_gather(RaDevice& d) {
+void launch_gather(RaDevice& d, const int* stop = nullptr) {
   RaWs* ws = d.ws;
+  if (MODE != GATHER_L1RHS) d.dense_valid = false;  // the weighted Laplacian changes
   dispatch_lpr(d.lpr, [&](auto L) {
     hipLaunchKernelGGL((k_node_gather<MODE, decltype(L)::value>), dim3(d.gridRow), dim3(kBlock), 0,
                        d.ctx->stream, d.N, d.E, ws->rowptr.get(), ws->inc.get(), ws->res.get(),
                        ws->wirls.get(), d.ew, ws->z.get(), ws->u.get(), ws->dz.get(), ws->inc_w.get(),
                        ws->lap_diag.get(), ws->lap_diag_loc.get(), ws->rhs.get(), ws->gat_s.get(), ws->gat_t.get(),
-                       d.fixed, d.has_gauge);
+                       d.fixed, d.has_gauge, stop);
   });
 }
 
@@ -957,12 +1071,32 @@ int ra_solve_impl(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
       launch_gather<GATHER_L1RHS>(d);  // rhs = A'^T (b' + 0 - 0)
       if (multi) allreduce_sum(ctx, ws->rhs.get(), 3 * (size_t)N);
       double rows_glob = rows_total;
-      for (int a = 0; a < opt->l1_admm_max_num_iterations; ++a) {
+      if (d.dense) {
+        // The whole ADMM loop is enqueued without a host round trip: k_admm_check raises the stop
+        // flag on the device and every later kernel of this solve returns at once.  The solves of
+        // the inner iterations skip the refinement step (ADMM itself stops at 1e-2 relative).
+        int* stop = ws->flags.get() + 1;
+        int* count = ws->flags.get() + 2;
+        GSFM_HIP_CHECK(hipMemsetAsync(stop, 0, 2 * sizeof(int), s));
+        for (int a = 0; a < opt->l1_admm_max_num_iterations; ++a) {
+          dense_solve(d, /*refine=*/false, stop);
+          hipLaunchKernelGGL(k_admm_edge, dim3(d.gridE), dim3(kBlock), 0, s, E, d.has_gauge, d.fixed,
+                             ws->ei.get(), ws->ej.get(), d.ew, ws->res.get(), ws->x.get(), ws->z.get(),
+                             ws->u.get(), ws->dz.get(), opt->l1_admm_alpha, 1.0 / opt->l1_admm_rho,
+                             ws->part_misc.get(), stop);
+          launch_gather<GATHER_L1RHS>(d, stop);
+          hipLaunchKernelGGL(k_admm_check, dim3(1), dim3(1024), 0, s, ws->part_misc.get(), d.gridE, ws->gat_s.get(),
+                             ws->gat_t.get(), 3 * N, rows_glob, opt->l1_admm_absolute_tolerance,
+                             opt->l1_admm_relative_tolerance, opt->l1_admm_rho, stop, count);
+        }
+        lin_iters += opt->l1_admm_max_num_iterations;
+      }
+      for (int a = 0; !d.dense && a < opt->l1_admm_max_num_iterations; ++a) {
         lin_iters += pcg_solve(d, a > 0, opt->pcg_relative_tolerance, opt->pcg_max_iterations);
         hipLaunchKernelGGL(k_admm_edge, dim3(d.gridE), dim3(kBlock), 0, s, E, d.has_gauge, d.fixed,
                            ws->ei.get(), ws->ej.get(), d.ew, ws->res.get(), ws->x.get(), ws->z.get(),
                            ws->u.get(), ws->dz.get(), opt->l1_admm_alpha, 1.0 / opt->l1_admm_rho,
-                           ws->part_misc.get());
+                           ws->part_misc.get(), nullptr);
         hipLaunchKernelGGL((k_finalize<4>), dim3(1), dim3(kBlock), 0, s, ws->part_misc.get(), d.gridE, ws->scal.get());
         launch_gather<GATHER_L1RHS>(d);  // next rhs + the two dual-residual gathers
         if (multi) {
@@ -1068,6 +1202,7 @@ extern "C" void gsfm_ra_options_default(gsfm_ra_options* o) {
   o->l1_admm_relative_tolerance = 1e-2;
   o->pcg_relative_tolerance = 1e-10;
   o->pcg_max_iterations = 2000;
+  o->force_iterative = 0;
 }
 
 extern "C" int gsfm_ra_solve(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_options* opt,

@@ -1,0 +1,230 @@
+// ra_dense.hpp — direct solves of the rotation-averaging Laplacian for small view graphs.
+//
+// The reference factorises A^T W A with CHOLMOD once for the L1 stage and once per IRLS iteration
+// (global_rotation_averaging.cc:491,547-611).  For a view graph of a few thousand frames the
+// Laplacian (N x N scalar, thanks to A = B (x) I3) is small enough to treat as DENSE, and an
+// iterative solve is the wrong tool: at N = 1000 one PCG iteration is two ~8 us launches, a solve is
+// ~50 of them and the L1 stage alone needs 50 solves.  Here the matrix is inverted explicitly by a
+// tiled Gauss-Jordan sweep — T = N/32 launches per inversion, each a grid of T x T workgroups doing
+// 32x32x32 f64 tile products on the matrix cores (v_mfma_f64_16x16x4_f64) — and every solve is one
+// dense (A^-1)[N x N] x rhs[N x 3] product plus one step of iterative refinement against the sparse
+// operator.  SPD input => the block pivots are Schur complements of an SPD matrix, no pivoting.
+//
+// Block Gauss-Jordan step k (P = A_kk^-1), out-of-place between two buffers so that no tile is
+// read after it was overwritten:
+//     A_kk <- P,   A_kj <- P A_kj,   A_ik <- -A_ik P,   A_ij <- A_ij - A_ik P A_kj      (i, j != k)
+// The workgroup that produces tile (k+1, k+1) also inverts it (in LDS) for the next step.
+#pragma once
+
+#include "device.hpp"
+
+namespace gsfm {
+
+constexpr int kTile = 32;        // tile edge
+constexpr int kTileLd = 33;      // LDS leading dimension (bank spread)
+constexpr int kDenseMaxN = 2048; // largest view graph solved densely
+
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
+// C (32x32) = sign * X (32x32) . Y (32x32) [+ Cin], all tiles in LDS with leading dimension kTileLd.
+// 4 waves, one 16x16 output block each, 8 MFMA (16x16x4 f64) per block.
+// v_mfma_f64_16x16x4_f64 operand map (MI355X guide §3): A: lane l holds A[l & 15][l >> 4],
+// B: lane l holds B[l >> 4][l & 15], C/D: reg i of lane l = C[(l >> 4) + 4 i][l & 15].
+__device__ __forceinline__ void tile_mma(const double* __restrict__ X, const double* __restrict__ Y,
+                                         const double* Cin, double sign, double* Cout) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int br = (wave >> 1) * 16, bc = (wave & 1) * 16;
+  const int lr = lane & 15, lk = lane >> 4;
+  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < kTile; kk += 4) {
+    const double a = X[(br + lr) * kTileLd + kk + lk];
+    const double b = Y[(kk + lk) * kTileLd + bc + lr];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = br + lk + 4 * i, c = bc + lr;
+    const double base = Cin ? Cin[r * kTileLd + c] : 0.0;
+    Cout[r * kTileLd + c] = base + sign * acc[i];
+  }
+}
+
+// In-place inverse of a 32x32 SPD tile in LDS (Gauss-Jordan without pivoting).  The 32 pivot steps
+// are a serial chain that sits on the critical path of every block step, so ONE wave keeps the
+// whole tile in registers (lane l: column l & 31, rows 16 (l >> 5) .. +15) and runs the chain with
+// wave shuffles only — no LDS round trips, no workgroup barriers inside the chain.
+// v of lane `src` (wave-uniform, compile-time after unrolling) in every lane: two v_readlane_b32,
+// no LDS-permute latency on the serial chain.
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ void tile_inverse_lds(double* __restrict__ S, double* __restrict__ /*srow*/,
+                                                 double* __restrict__ /*scol*/) {
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const int c = lane & 31, h = lane >> 5;
+    double a[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = S[(h * 16 + i) * kTileLd + c];
+#pragma unroll
+    for (int p = 0; p < kTile; ++p) {
+      const int ph = p >> 4, pi = p & 15;
+      const double rowv = __shfl(a[pi], c + 32 * ph, 64);  // S[p][c]
+      const double piv = readlane_f64(a[pi], p + 32 * ph);  // S[p][p]
+      double ipiv = __builtin_amdgcn_rcp(piv);              // v_rcp_f64 + two Newton steps (full precision)
+      ipiv = ipiv * (2.0 - piv * ipiv);
+      ipiv = ipiv * (2.0 - piv * ipiv);
+      const bool cp = c == p;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const double c0 = readlane_f64(a[i], p), c1 = readlane_f64(a[i], p + 32);
+        const double colv = h ? c1 : c0;  // S[r][p], r = 16 h + i
+        const bool rp = (i == pi) && (h == ph);
+        double v = a[i] - colv * rowv * ipiv;
+        v = cp ? -colv * ipiv : v;
+        v = rp ? rowv * ipiv : v;
+        v = (rp && cp) ? ipiv : v;
+        a[i] = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) S[(h * 16 + i) * kTileLd + c] = a[i];
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void tile_load(const double* __restrict__ A, int ld, int bi, int bj, double* __restrict__ S) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = threadIdx.x + 256 * e;
+    const int r = idx >> 5, c = idx & 31;
+    S[r * kTileLd + c] = A[(size_t)(bi * kTile + r) * ld + bj * kTile + c];
+  }
+}
+__device__ __forceinline__ void tile_store(double* __restrict__ A, int ld, int bi, int bj, const double* __restrict__ S) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = threadIdx.x + 256 * e;
+    const int r = idx >> 5, c = idx & 31;
+    A[(size_t)(bi * kTile + r) * ld + bj * kTile + c] = S[r * kTileLd + c];
+  }
+}
+
+// P = inverse of tile (0, 0) of A  ->  pinv[32][32] (row-major, ld 32)
+static __global__ void __launch_bounds__(kBlock) k_dense_pivot0(const double* __restrict__ A, int ld, double* __restrict__ pinv) {
+  __shared__ double S[kTile * kTileLd], srow[kTile], scol[kTile];
+  tile_load(A, ld, 0, 0, S);
+  tile_inverse_lds(S, srow, scol);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = threadIdx.x + 256 * e;
+    pinv[idx] = S[(idx >> 5) * kTileLd + (idx & 31)];
+  }
+}
+
+// One block Gauss-Jordan step: out = GJ_k(in), grid (T, T); pinv_in = (in_kk)^-1; the workgroup of
+// tile (k+1, k+1) writes the inverse of its result to pinv_out.
+static __global__ void __launch_bounds__(kBlock)
+    k_dense_gj_step(const double* __restrict__ in, double* __restrict__ out, int ld, int T, int k,
+                    const double* __restrict__ pinv_in, double* __restrict__ pinv_out) {
+  __shared__ double sP[kTile * kTileLd], sX[kTile * kTileLd], sY[kTile * kTileLd], sC[kTile * kTileLd],
+      sM[kTile * kTileLd], srow[kTile], scol[kTile];
+  const int bi = blockIdx.y, bj = blockIdx.x;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = threadIdx.x + 256 * e;
+    sP[(idx >> 5) * kTileLd + (idx & 31)] = pinv_in[idx];
+  }
+  double* res = sC;
+  if (bi == k && bj == k) {
+    res = sP;
+    __syncthreads();
+  } else if (bi == k) {
+    tile_load(in, ld, k, bj, sY);
+    __syncthreads();
+    tile_mma(sP, sY, nullptr, 1.0, sC);  // P A_kj
+  } else if (bj == k) {
+    tile_load(in, ld, bi, k, sX);
+    __syncthreads();
+    tile_mma(sX, sP, nullptr, -1.0, sC);  // -A_ik P
+  } else {
+    tile_load(in, ld, bi, k, sX);
+    tile_load(in, ld, k, bj, sY);
+    tile_load(in, ld, bi, bj, sC);
+    __syncthreads();
+    tile_mma(sX, sP, nullptr, 1.0, sM);  // A_ik P
+    __syncthreads();
+    tile_mma(sM, sY, sC, -1.0, sC);  // A_ij - (A_ik P) A_kj   (each element read and written by its own lane)
+  }
+  __syncthreads();
+  tile_store(out, ld, bi, bj, res);
+  if (bi == k + 1 && bj == k + 1) {  // next pivot
+    tile_inverse_lds(res, srow, scol);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = threadIdx.x + 256 * e;
+      pinv_out[idx] = res[(idx >> 5) * kTileLd + (idx & 31)];
+    }
+  }
+}
+
+// Dense assembly of (L_w + gauge) from the CSR-by-node incidence list: A[n][nbr] -= w (atomics: a
+// pair of nodes may be linked by several edges), diagonal = lap_diag, identity on the padding.
+static __global__ void __launch_bounds__(kBlock)
+    k_dense_fill_offdiag(long nnz, const int* __restrict__ inc_row, const int* __restrict__ nbr,
+                         const double* __restrict__ inc_w, int ld, double* __restrict__ A) {
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (long)gridDim.x * blockDim.x)
+    unsafeAtomicAdd(A + (size_t)inc_row[k] * ld + nbr[k], -inc_w[k]);
+}
+static __global__ void __launch_bounds__(kBlock)
+    k_dense_fill_diag(int N, int Np, const double* __restrict__ lap_diag, int ld, double* __restrict__ A) {
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < Np; n += gridDim.x * blockDim.x)
+    A[(size_t)n * ld + n] = n < N ? A[(size_t)n * ld + n] + lap_diag[n] : 1.0;  // += keeps self-loop terms
+}
+
+// y[n][0..3) (+)= sum_m Ainv[n][m] v[m][0..3): one wave per row.
+static __global__ void __launch_bounds__(kBlock)
+    k_dense_apply3(int N, int ld, const double* __restrict__ Ainv, const double* __restrict__ v,
+                   double* __restrict__ y, int accumulate, const int* __restrict__ stop) {
+  if (stop != nullptr && *stop) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (kBlock / 64);
+  for (int n = wave; n < N; n += nwaves) {
+    const double* row = Ainv + (size_t)n * ld;
+    double a0 = 0, a1 = 0, a2 = 0;
+    for (int m = lane; m < N; m += 64) {
+      const double w = row[m];
+      a0 += w * v[3 * m];
+      a1 += w * v[3 * m + 1];
+      a2 += w * v[3 * m + 2];
+    }
+    a0 = group_sum<64>(a0);
+    a1 = group_sum<64>(a1);
+    a2 = group_sum<64>(a2);
+    if (lane == 0) {
+      if (accumulate) {
+        y[3 * n] += a0;
+        y[3 * n + 1] += a1;
+        y[3 * n + 2] += a2;
+      } else {
+        y[3 * n] = a0;
+        y[3 * n + 1] = a1;
+        y[3 * n + 2] = a2;
+      }
+    }
+  }
+}
+
+// r = b - Ax
+static __global__ void __launch_bounds__(kBlock)
+    k_dense_residual(long n, const double* __restrict__ b, const double* __restrict__ Ax, double* __restrict__ r) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) r[i] = b[i] - Ax[i];
+}
+
+}  // namespace gsfm

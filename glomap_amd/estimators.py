@@ -74,6 +74,7 @@ class RotationEstimatorOptions:
     # linear solver (replaces CHOLMOD)
     pcg_relative_tolerance: float = 1e-10
     pcg_max_iterations: int = 2000
+    force_iterative: bool = False  # True: PCG even where the dense direct solve applies (N <= 2048)
 
     GEMAN_MCCLURE = 0
     HALF_NORM = 1
@@ -90,6 +91,7 @@ class RotationEstimatorOptions:
         o.skip_initialization = int(self.skip_initialization)
         o.use_weight = int(self.use_weight)
         o.use_gravity = int(self.use_gravity)
+        o.force_iterative = int(self.force_iterative)
         return o
 
 

@@ -158,10 +158,18 @@ def make_gp_problem(
     outlier_ratio: float = 0.02,
     uncalibrated_ratio: float = 0.0,
     seed: int = 0,
+    shard=None,
 ) -> GpProblem:
-    """C3-style global positioning problem (cameras on a radius-50 ring, points in a radius-30 ball)."""
+    """C3-style global positioning problem (cameras on a radius-50 ring, points in a radius-30 ball).
+
+    shard = (rank, world): generate only this rank's `num_pts` tracks of a `world * num_pts`-track
+    problem — the cameras come from `seed` alone (identical on every rank), the points from a
+    rank-specific stream — so weak-scaling runs never materialise the whole problem on one host."""
     rng = np.random.default_rng(seed)
     centers, R_cw = _ring_cameras(rng, num_cams, 50.0)
+    if shard is not None:
+        calibrated_all = (rng.random(num_cams) >= uncalibrated_ratio).astype(np.uint8)
+        rng = np.random.default_rng([seed, 7919, int(shard[0])])
     X = _ball_points(rng, num_pts, 30.0)
     pt_offset, obs_cam = _sample_tracks(rng, centers, R_cw, X, mean_extra)
     M = obs_cam.shape[0]
@@ -178,7 +186,7 @@ def make_gp_problem(
         r = rng.normal(size=(n_out, 3))
         d[out] = r
     d /= np.linalg.norm(d, axis=1, keepdims=True)
-    calibrated = (rng.random(num_cams) >= uncalibrated_ratio).astype(np.uint8)
+    calibrated = calibrated_all if shard is not None else (rng.random(num_cams) >= uncalibrated_ratio).astype(np.uint8)
     return GpProblem(
         num_cams=num_cams,
         num_pts=num_pts,
@@ -215,13 +223,21 @@ def make_ba_problem(
     depth_noise: float = 0.01,
     intr_noise: float = 0.0,
     seed: int = 0,
+    shard=None,
 ) -> BaProblem:
     """C4-style bundle-adjustment problem: SIMPLE_RADIAL (f=1200,cx=640,cy=480,k=0.02), state =
-    ground truth perturbed by rotation / position / depth noise."""
+    ground truth perturbed by rotation / position / depth noise.
+
+    shard = (rank, world): only this rank's `num_pts` tracks are generated; cameras, intrinsics and
+    their perturbed start come from `seed` alone and are identical on every rank."""
     rng = np.random.default_rng(seed)
     N, P = num_cams, num_pts
     radius = 50.0
     centers, R_cw = _ring_cameras(rng, N, radius)
+    rng_cam = None
+    if shard is not None:
+        rng_cam = np.random.default_rng([seed, 104729])
+        rng = np.random.default_rng([seed, 7919, int(shard[0])])
     X = _ball_points(rng, P, 30.0)
     pt_offset, obs_cam = _sample_tracks(rng, centers, R_cw, X, mean_extra, half_fov_deg=25.0)
     M = obs_cam.shape[0]
@@ -241,13 +257,14 @@ def make_ba_problem(
         xy[out] = np.stack([rng.uniform(0, 1280, n_out), rng.uniform(0, 960, n_out)], 1)
 
     # perturbed start
-    R0 = so3.aa_to_rotmat(rng.normal(0, np.radians(rot_noise_deg), (N, 3))) @ R_cw
-    c0 = centers + rng.normal(0, pos_noise * radius, (N, 3))
+    rc = rng_cam if rng_cam is not None else rng
+    R0 = so3.aa_to_rotmat(rc.normal(0, np.radians(rot_noise_deg), (N, 3))) @ R_cw
+    c0 = centers + rc.normal(0, pos_noise * radius, (N, 3))
     t0 = -np.einsum("nij,nj->ni", R0, c0)
     X0 = X * (1.0 + rng.normal(0, depth_noise, (P, 1))) + rng.normal(0, depth_noise * 1.0, (P, 3))
     intr0 = intr_gt.copy()
     if intr_noise > 0:
-        intr0[:, 0] *= 1.0 + rng.normal(0, intr_noise, K)
+        intr0[:, 0] *= 1.0 + rc.normal(0, intr_noise, K)
     return BaProblem(
         num_cams=N,
         num_pts=P,

@@ -150,9 +150,12 @@ typedef struct gsfm_ra_options {
   double l1_admm_alpha;                    /* 1.0 */
   double l1_admm_absolute_tolerance;       /* 1e-4 */
   double l1_admm_relative_tolerance;       /* 1e-2 */
-  /* linear solver replacing CHOLMOD (gra.cc:547-611): Jacobi-PCG on the weighted Laplacian */
+  /* linear solver replacing CHOLMOD (gra.cc:547-611): dense tiled Gauss-Jordan inverse on the matrix
+   * cores for num_nodes <= 2048 (a direct solve, like the reference), Jacobi-PCG on the weighted
+   * Laplacian above that, when sharded over ranks, or when force_iterative is set */
   double pcg_relative_tolerance;           /* 1e-10: |r|_2 <= tol * |b|_2 per right-hand side */
   int32_t pcg_max_iterations;              /* 2000 */
+  int32_t force_iterative;                 /* 0 */
 } gsfm_ra_options;
 
 void gsfm_ra_options_default(gsfm_ra_options* opt);
