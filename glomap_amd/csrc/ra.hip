@@ -794,9 +794,15 @@ void dense_factor(RaDevice& d) {
   hipLaunchKernelGGL(k_dense_fill_diag, dim3(grid_for(Np, kBlock)), dim3(kBlock), 0, s, d.N, Np, ws->lap_diag.get(), Np, cur);
   hipLaunchKernelGGL(k_dense_pivot0, dim3(1), dim3(kBlock), 0, s, cur, Np, pinv);
   for (int k = 0; k < T; ++k) {
+    const bool timed = d.ctx->prof.begin(s, GSFM_KERNEL_RA_GJ);
     hipLaunchKernelGGL(k_dense_gj_step, dim3(T, T), dim3(kBlock), 0, s, cur, oth, Np, T, k,
                        pinv + (k & 1) * kTile * kTile, pinv + ((k + 1) & 1) * kTile * kTile);
+    if (timed) d.ctx->prof.end(s);
     std::swap(cur, oth);
+  }
+  if (d.ctx->prof.enabled) {
+    GSFM_HIP_CHECK(hipStreamSynchronize(s));
+    d.ctx->prof.harvest();
   }
   d.dense_inv = cur;
   d.dense_valid = true;

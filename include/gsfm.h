@@ -110,7 +110,8 @@ enum {
   GSFM_KERNEL_BA_SCHUR = 2,     /* k_ba_phaseA: implicit Schur product, track-major half (stored Jacobian planes) */
   GSFM_KERNEL_GP_SCHUR_B = 3,   /* k_gp_phaseB: camera-major half */
   GSFM_KERNEL_BA_SCHUR_B = 4,   /* k_ba_phaseB: camera-major half */
-  GSFM_KERNEL_COUNT = 5
+  GSFM_KERNEL_RA_GJ = 5,        /* k_dense_gj_step: one block Gauss-Jordan step of the dense RA inverse (f64 MFMA) */
+  GSFM_KERNEL_COUNT = 6
 };
 int gsfm_ctx_profile_enable(gsfm_ctx* ctx, int enable);
 /* Reads and resets the accumulated launch count / total milliseconds of one kernel id. */

@@ -1,0 +1,443 @@
+// gsfm_glomap_adapter.hpp — drop-in replacements of GLOMAP's three estimator classes on libgsfm.
+//
+// Compile this header INSIDE a GLOMAP tree (it includes GLOMAP's own scene headers) and link
+// libgsfm.so.  The classes keep the reference's names, constructors, Solve()/EstimateRotations()
+// signatures and bool results, so the only change in the callers is the namespace / include:
+//
+//   glomap/controllers/rotation_averager.cc:58,165,180,193   RotationEstimator::EstimateRotations
+//   glomap/controllers/global_mapper.cc:160                  GlobalPositioner::Solve
+//   glomap/controllers/global_mapper.cc:209,221,302,315      BundleAdjuster::Solve
+//
+// What the adapter does is exactly the pack / unpack the reference performs implicitly by handing
+// Ceres pointers into its containers (bundle_adjustment.cc:143-146, global_positioning.cc:326-328):
+// flatten the unordered_map containers into the SoA problems of include/gsfm.h, call the C ABI, write
+// the results back in place.  Scope = what `glomap mapper` exercises: trivial rigs, 3-DoF rotation
+// averaging, ONLY_POINTS positioning; anything else returns false after logging (the C ABI reports
+// GSFM_ERR_UNSUPPORTED), mirroring the reference's own early returns (gra.cc:47-58, gm.cc:145-149).
+//
+// NOTE: this header cannot be compiled in the libgsfm repository itself (GLOMAP / COLMAP / Eigen are
+// not vendored); tests/adapter/ compiles it against interface-shaped stand-ins of those headers.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "glomap/estimators/bundle_adjustment.h"
+#include "glomap/estimators/global_positioning.h"
+#include "glomap/estimators/global_rotation_averaging.h"
+#include "glomap/scene/types_sfm.h"
+#include "gsfm.h"
+
+namespace gsfm_glomap {
+
+using glomap::camera_t;
+using glomap::frame_t;
+using glomap::image_t;
+using glomap::rig_t;
+using glomap::track_t;
+
+// One libgsfm context per process and device (gpu_index "-1" = current device, as
+// colmap::SetBestCudaDevice does for the reference, gp.cc:536-541 / ba.cc:79-84).
+inline gsfm_ctx* Context(const std::string& gpu_index = "-1") {
+  static gsfm_ctx* ctx = nullptr;
+  if (ctx == nullptr) {
+    int dev = -1;
+    try {
+      dev = std::stoi(gpu_index);  // first entry of the CSV list
+    } catch (...) {
+      dev = -1;
+    }
+    if (gsfm_ctx_create(dev, &ctx) != GSFM_OK) {
+      std::fprintf(stderr, "[gsfm] no MI355X context: %s\n", gsfm_status_string(GSFM_ERR_NO_DEVICE));
+      ctx = nullptr;
+    }
+  }
+  return ctx;
+}
+
+namespace detail {
+
+// COLMAP CameraModelId -> GSFM_CAMERA_* (colmap/sensor/models.h; the ids coincide for the supported models)
+inline int ModelOf(const glomap::Camera& cam) {
+  switch (static_cast<int>(cam.model_id)) {
+    case 0: return GSFM_CAMERA_SIMPLE_PINHOLE;
+    case 1: return GSFM_CAMERA_PINHOLE;
+    case 2: return GSFM_CAMERA_SIMPLE_RADIAL;
+    case 3: return GSFM_CAMERA_RADIAL;
+    case 4: return GSFM_CAMERA_OPENCV;
+    default: return -1;
+  }
+}
+
+template <typename Quat>
+inline void QuatToAngleAxis(const Quat& q, double* aa) {  // RotationToAngleAxis, math/rigid3d.cc:39-43
+  const double n = std::sqrt(q.x() * q.x() + q.y() * q.y() + q.z() * q.z());
+  if (n > 0.0) {
+    const double ang = 2.0 * std::atan2(n, std::fabs(q.w()));
+    const double k = (q.w() < 0.0 ? -ang : ang) / n;
+    aa[0] = k * q.x();
+    aa[1] = k * q.y();
+    aa[2] = k * q.z();
+  } else {
+    aa[0] = aa[1] = aa[2] = 0.0;
+  }
+}
+inline void AngleAxisToQuatWxyz(const double* aa, double* q) {  // AngleAxisToRotation, math/rigid3d.cc:45-63
+  const double th = std::sqrt(aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2]);
+  if (th > 1e-12) {
+    const double k = std::sin(0.5 * th) / th;
+    q[0] = std::cos(0.5 * th);
+    q[1] = k * aa[0];
+    q[2] = k * aa[1];
+    q[3] = k * aa[2];
+  } else {
+    q[0] = 1.0;
+    q[1] = 0.5 * aa[0];
+    q[2] = 0.5 * aa[1];
+    q[3] = 0.5 * aa[2];
+  }
+}
+template <typename Quat, typename Vec3>
+inline void RotateInv(const Quat& q, const Vec3& v, double* out) {  // R(q)^T v
+  const double w = q.w(), x = -q.x(), y = -q.y(), z = -q.z();
+  const double tx = 2.0 * (y * v[2] - z * v[1]), ty = 2.0 * (z * v[0] - x * v[2]), tz = 2.0 * (x * v[1] - y * v[0]);
+  out[0] = v[0] + w * tx + (y * tz - z * ty);
+  out[1] = v[1] + w * ty + (z * tx - x * tz);
+  out[2] = v[2] + w * tz + (x * ty - y * tx);
+}
+template <typename Quat>
+inline void Rotate(const Quat& q, const double* v, double* out) {  // R(q) v
+  const double w = q.w(), x = q.x(), y = q.y(), z = q.z();
+  const double tx = 2.0 * (y * v[2] - z * v[1]), ty = 2.0 * (z * v[0] - x * v[2]), tz = 2.0 * (x * v[1] - y * v[0]);
+  out[0] = v[0] + w * tx + (y * tz - z * ty);
+  out[1] = v[1] + w * ty + (z * tx - x * tz);
+  out[2] = v[2] + w * tz + (x * ty - y * tx);
+}
+
+// Dense frame index over the frames the estimators touch.
+struct FrameIndex {
+  std::unordered_map<frame_t, int> of;
+  std::vector<frame_t> ids;
+  int Add(frame_t f) {
+    auto it = of.find(f);
+    if (it != of.end()) return it->second;
+    const int n = static_cast<int>(ids.size());
+    of.emplace(f, n);
+    ids.push_back(f);
+    return n;
+  }
+};
+
+// Track-major observation lists shared by GP and BA (gp.cc:270-375, ba.cc:115-190).
+struct TrackPack {
+  std::vector<track_t> track_ids;
+  std::vector<int64_t> pt_offset{0};
+  std::vector<int32_t> obs_cam;
+  std::vector<image_t> obs_image;
+  std::vector<uint32_t> obs_feature;
+};
+
+template <typename Keep>
+inline TrackPack PackTracks(std::unordered_map<image_t, glomap::Image>& images,
+                            std::unordered_map<track_t, glomap::Track>& tracks, FrameIndex& fidx, Keep keep) {
+  TrackPack tp;
+  for (auto& [tid, track] : tracks) {
+    const size_t before = tp.obs_cam.size();
+    for (const auto& obs : track.observations) {
+      auto it = images.find(obs.first);
+      if (it == images.end() || !keep(it->second, obs.second)) continue;
+      tp.obs_cam.push_back(fidx.Add(it->second.frame_id));
+      tp.obs_image.push_back(obs.first);
+      tp.obs_feature.push_back(obs.second);
+    }
+    if (tp.obs_cam.size() == before) continue;
+    tp.track_ids.push_back(tid);
+    tp.pt_offset.push_back(static_cast<int64_t>(tp.obs_cam.size()));
+  }
+  return tp;
+}
+
+inline bool AllTrivial(std::unordered_map<image_t, glomap::Image>& images) {
+  for (auto& [id, im] : images)
+    if (im.frame_ptr != nullptr && !im.HasTrivialFrame()) return false;
+  return true;
+}
+
+}  // namespace detail
+
+// ---------------------------------------------------------------------------------------------
+// RotationEstimator (global_rotation_averaging.h:77-141)
+// ---------------------------------------------------------------------------------------------
+class RotationEstimator {
+ public:
+  explicit RotationEstimator(const glomap::RotationEstimatorOptions& options) : options_(options) {}
+
+  bool EstimateRotations(const glomap::ViewGraph& view_graph, std::unordered_map<rig_t, glomap::Rig>& /*rigs*/,
+                         std::unordered_map<frame_t, glomap::Frame>& frames,
+                         std::unordered_map<image_t, glomap::Image>& images) {
+    gsfm_ctx* ctx = Context();
+    if (ctx == nullptr || options_.use_gravity || !detail::AllTrivial(images)) return false;
+    detail::FrameIndex fidx;
+    for (auto& [fid, fr] : frames)
+      if (fr.is_registered) fidx.Add(fid);  // gra.cc:193-227; first one = gauge (gra.cc:248-257)
+    const int N = static_cast<int>(fidx.ids.size());
+    if (N == 0) return false;
+    std::vector<int32_t> ei, ej, en;
+    std::vector<double> eq, ew;
+    for (const auto& [pid, pair] : view_graph.image_pairs) {
+      if (!pair.is_valid) continue;
+      const auto& i1 = images.at(pair.image_id1);
+      const auto& i2 = images.at(pair.image_id2);
+      if (!i1.IsRegistered() || !i2.IsRegistered()) continue;
+      ei.push_back(fidx.of.at(i1.frame_id));
+      ej.push_back(fidx.of.at(i2.frame_id));
+      const auto& q = pair.cam2_from_cam1.rotation;
+      eq.insert(eq.end(), {q.w(), q.x(), q.y(), q.z()});
+      ew.push_back(pair.weight);
+      en.push_back(static_cast<int32_t>(pair.inliers.size()));
+    }
+    std::vector<double> rot(3 * static_cast<size_t>(N));
+    for (int n = 0; n < N; ++n) detail::QuatToAngleAxis(frames.at(fidx.ids[n]).RigFromWorld().rotation, &rot[3 * n]);
+    gsfm_ra_options o;
+    gsfm_ra_options_default(&o);
+    o.max_num_l1_iterations = options_.max_num_l1_iterations;
+    o.l1_step_convergence_threshold = options_.l1_step_convergence_threshold;
+    o.max_num_irls_iterations = options_.max_num_irls_iterations;
+    o.irls_step_convergence_threshold = options_.irls_step_convergence_threshold;
+    o.irls_loss_parameter_sigma = options_.irls_loss_parameter_sigma;
+    o.weight_type = static_cast<int>(options_.weight_type);
+    o.skip_initialization = options_.skip_initialization;
+    o.use_weight = options_.use_weight;
+    gsfm_ra_problem p{};
+    p.mem = GSFM_MEM_HOST;
+    p.num_nodes = N;
+    p.num_edges = static_cast<int64_t>(ei.size());
+    p.edge_i = ei.data();
+    p.edge_j = ej.data();
+    p.edge_q = eq.data();
+    p.edge_weight = ew.data();
+    p.edge_ninl = en.data();
+    p.fixed_node = 0;
+    gsfm_report rep;
+    if (gsfm_ra_solve(ctx, &p, &o, rot.data(), &rep) != GSFM_OK) return false;
+    // ConvertResults (gra.cc:774-816): rotation written, translation zeroed
+    for (int n = 0; n < N; ++n) {
+      double q[4];
+      detail::AngleAxisToQuatWxyz(&rot[3 * n], q);
+      auto& fr = frames.at(fidx.ids[n]);
+      auto pose = fr.RigFromWorld();
+      pose.rotation = decltype(pose.rotation)(q[0], q[1], q[2], q[3]);
+      pose.translation = decltype(pose.translation)(0.0, 0.0, 0.0);
+      fr.SetRigFromWorld(pose);
+    }
+    return true;
+  }
+
+ private:
+  const glomap::RotationEstimatorOptions& options_;  // reference keeps a reference too (global_rotation_averaging.h:140)
+};
+
+// ---------------------------------------------------------------------------------------------
+// GlobalPositioner (global_positioning.h:56-137), ONLY_POINTS
+// ---------------------------------------------------------------------------------------------
+class GlobalPositioner {
+ public:
+  explicit GlobalPositioner(const glomap::GlobalPositionerOptions& options) : options_(options) {}
+  glomap::GlobalPositionerOptions& GetOptions() { return options_; }
+
+  bool Solve(const glomap::ViewGraph& /*view_graph*/, std::unordered_map<rig_t, glomap::Rig>& /*rigs*/,
+             std::unordered_map<camera_t, glomap::Camera>& cameras, std::unordered_map<frame_t, glomap::Frame>& frames,
+             std::unordered_map<image_t, glomap::Image>& images, std::unordered_map<track_t, glomap::Track>& tracks) {
+    gsfm_ctx* ctx = Context(options_.gpu_index);
+    if (ctx == nullptr) return false;
+    if (images.empty() || tracks.empty()) return false;  // gp.cc:37-50
+    if (options_.constraint_type != glomap::GlobalPositionerOptions::ONLY_POINTS || !detail::AllTrivial(images)) return false;
+    detail::FrameIndex fidx;
+    for (auto& [fid, fr] : frames) fidx.Add(fid);  // every frame: ConvertResults rewrites all of them (gp.cc:566-572)
+    auto keep = [](const glomap::Image& im, uint32_t f) {  // gp.cc:279-292
+      if (!im.IsRegistered()) return false;
+      const auto& v = im.features_undist[f];
+      return !(std::isnan(v[0]) || std::isnan(v[1]) || std::isnan(v[2]));
+    };
+    detail::TrackPack tp = detail::PackTracks(images, tracks, fidx, keep);
+    const int N = static_cast<int>(fidx.ids.size());
+    const int64_t P = static_cast<int64_t>(tp.track_ids.size()), M = static_cast<int64_t>(tp.obs_cam.size());
+    if (P == 0) return false;
+    std::vector<double> dir(3 * static_cast<size_t>(M)), cen(3 * static_cast<size_t>(N)), xyz(3 * static_cast<size_t>(P));
+    std::vector<uint8_t> cal(static_cast<size_t>(M));
+    for (int64_t k = 0; k < M; ++k) {
+      const auto& im = images.at(tp.obs_image[k]);
+      detail::RotateInv(im.frame_ptr->RigFromWorld().rotation, im.features_undist[tp.obs_feature[k]], &dir[3 * k]);  // gp.cc:294-296
+      cal[k] = cameras.at(im.camera_id).has_prior_focal_length ? 1 : 0;                                             // gp.cc:313-316
+    }
+    for (int n = 0; n < N; ++n) {  // c = -R^T t
+      const auto& pose = frames.at(fidx.ids[n]).RigFromWorld();
+      double c[3];
+      detail::RotateInv(pose.rotation, pose.translation, c);
+      for (int j = 0; j < 3; ++j) cen[3 * n + j] = -c[j];
+    }
+    for (int64_t p = 0; p < P; ++p)
+      for (int j = 0; j < 3; ++j) xyz[3 * p + j] = tracks.at(tp.track_ids[p]).xyz[j];
+    gsfm_gp_options o;
+    gsfm_gp_options_default(&o);
+    o.lm.max_num_iterations = options_.solver_options.max_num_iterations;
+    o.lm.function_tolerance = options_.solver_options.function_tolerance;
+    o.thres_loss_function = options_.thres_loss_function;
+    o.generate_random_positions = options_.generate_random_positions;
+    o.generate_random_points = options_.generate_random_points;
+    o.generate_scales = options_.generate_scales;
+    o.optimize_positions = options_.optimize_positions;
+    o.optimize_points = options_.optimize_points;
+    o.optimize_scales = options_.optimize_scales;
+    o.min_num_view_per_track = options_.min_num_view_per_track;
+    o.seed = options_.seed;
+    gsfm_gp_problem pr{};
+    pr.mem = GSFM_MEM_HOST;
+    pr.num_cams = N;
+    pr.num_pts = P;
+    pr.num_obs = M;
+    pr.pt_offset = tp.pt_offset.data();
+    pr.obs_cam = tp.obs_cam.data();
+    pr.obs_dir = dir.data();
+    pr.obs_calibrated = cal.data();
+    gsfm_report rep;
+    if (gsfm_gp_solve(ctx, &pr, &o, cen.data(), xyz.data(), &rep) != GSFM_OK) return false;
+    for (int n = 0; n < N; ++n) {  // ConvertResults: t = -R c (gp.cc:566-572)
+      auto& fr = frames.at(fidx.ids[n]);
+      auto pose = fr.RigFromWorld();
+      double t[3];
+      detail::Rotate(pose.rotation, &cen[3 * n], t);
+      pose.translation = decltype(pose.translation)(-t[0], -t[1], -t[2]);
+      fr.SetRigFromWorld(pose);
+    }
+    for (int64_t p = 0; p < P; ++p) {
+      if (tp.pt_offset[p + 1] - tp.pt_offset[p] < options_.min_num_view_per_track) continue;  // untouched (gp.cc:258)
+      auto& tr = tracks.at(tp.track_ids[p]);
+      tr.xyz = decltype(tr.xyz)(xyz[3 * p], xyz[3 * p + 1], xyz[3 * p + 2]);
+      tr.is_initialized = true;  // gp.cc:262-263
+    }
+    return true;
+  }
+
+ private:
+  glomap::GlobalPositionerOptions options_;
+};
+
+// ---------------------------------------------------------------------------------------------
+// BundleAdjuster (bundle_adjustment.h:38-98)
+// ---------------------------------------------------------------------------------------------
+class BundleAdjuster {
+ public:
+  explicit BundleAdjuster(const glomap::BundleAdjusterOptions& options) : options_(options) {}
+  glomap::BundleAdjusterOptions& GetOptions() { return options_; }
+
+  bool Solve(std::unordered_map<rig_t, glomap::Rig>& /*rigs*/, std::unordered_map<camera_t, glomap::Camera>& cameras,
+             std::unordered_map<frame_t, glomap::Frame>& frames, std::unordered_map<image_t, glomap::Image>& images,
+             std::unordered_map<track_t, glomap::Track>& tracks) {
+    gsfm_ctx* ctx = Context(options_.gpu_index);
+    if (ctx == nullptr) return false;
+    if (images.empty() || tracks.empty()) return false;  // ba.cc:17-24
+    if (!detail::AllTrivial(images) || options_.optimize_rig_poses) return false;
+    detail::FrameIndex fidx;
+    // the constant frame is the first frame with a pose in map order (ba.cc:253-269)
+    int fixed = -1;
+    for (auto& [fid, fr] : frames) {
+      if (!fr.HasPose()) continue;
+      const int n = fidx.Add(fid);
+      if (fixed < 0) fixed = n;
+    }
+    auto keep = [](const glomap::Image& im, uint32_t) { return im.frame_ptr != nullptr; };  // ba.cc:124-127: no IsRegistered test
+    detail::TrackPack tp = detail::PackTracks(images, tracks, fidx, keep);
+    const int N = static_cast<int>(fidx.ids.size());
+    const int64_t P = static_cast<int64_t>(tp.track_ids.size()), M = static_cast<int64_t>(tp.obs_cam.size());
+    if (N == 0 || P == 0) return false;
+    // intrinsics blocks = COLMAP cameras
+    std::unordered_map<camera_t, int> intr_of;
+    std::vector<camera_t> intr_ids;
+    std::vector<int32_t> cam_intr(static_cast<size_t>(N), 0), intr_model;
+    std::vector<double> intr;
+    auto intr_index = [&](camera_t cid) {
+      auto it = intr_of.find(cid);
+      if (it != intr_of.end()) return it->second;
+      const int k = static_cast<int>(intr_ids.size());
+      intr_of.emplace(cid, k);
+      intr_ids.push_back(cid);
+      const auto& cam = cameras.at(cid);
+      intr_model.push_back(detail::ModelOf(cam));
+      for (int j = 0; j < GSFM_CAMERA_MAX_PARAMS; ++j) intr.push_back(j < static_cast<int>(cam.params.size()) ? cam.params[j] : 0.0);
+      return k;
+    };
+    std::vector<double> xy(2 * static_cast<size_t>(M)), q(4 * static_cast<size_t>(N)), t(3 * static_cast<size_t>(N)),
+        xyz(3 * static_cast<size_t>(P));
+    for (int64_t k = 0; k < M; ++k) {
+      const auto& im = images.at(tp.obs_image[k]);
+      const auto& f = im.features[tp.obs_feature[k]];  // distorted pixels (ba.cc:139)
+      xy[2 * k] = f[0];
+      xy[2 * k + 1] = f[1];
+      cam_intr[tp.obs_cam[k]] = intr_index(im.camera_id);
+    }
+    for (int m : intr_model)
+      if (m < 0) return false;  // unsupported camera model
+    for (int n = 0; n < N; ++n) {
+      const auto& pose = frames.at(fidx.ids[n]).RigFromWorld();
+      q[4 * n] = pose.rotation.w();
+      q[4 * n + 1] = pose.rotation.x();
+      q[4 * n + 2] = pose.rotation.y();
+      q[4 * n + 3] = pose.rotation.z();
+      for (int j = 0; j < 3; ++j) t[3 * n + j] = pose.translation[j];
+    }
+    for (int64_t p = 0; p < P; ++p)
+      for (int j = 0; j < 3; ++j) xyz[3 * p + j] = tracks.at(tp.track_ids[p]).xyz[j];
+    gsfm_ba_options o;
+    gsfm_ba_options_default(&o);
+    o.lm.max_num_iterations = options_.solver_options.max_num_iterations;
+    o.lm.function_tolerance = options_.solver_options.function_tolerance;
+    o.thres_loss_function = options_.thres_loss_function;
+    o.optimize_rotations = options_.optimize_rotations;
+    o.optimize_translation = options_.optimize_translation;
+    o.optimize_intrinsics = options_.optimize_intrinsics;
+    o.optimize_principal_point = options_.optimize_principal_point;
+    o.optimize_points = options_.optimize_points;
+    o.min_num_view_per_track = options_.min_num_view_per_track;
+    gsfm_ba_problem pr{};
+    pr.mem = GSFM_MEM_HOST;
+    pr.num_cams = N;
+    pr.num_intr = static_cast<int32_t>(intr_ids.size());
+    pr.fixed_cam = fixed;
+    pr.num_pts = P;
+    pr.num_obs = M;
+    pr.pt_offset = tp.pt_offset.data();
+    pr.obs_cam = tp.obs_cam.data();
+    pr.obs_xy = xy.data();
+    pr.cam_intr = cam_intr.data();
+    pr.intr_model = intr_model.data();
+    gsfm_report rep;
+    if (gsfm_ba_solve(ctx, &pr, &o, q.data(), t.data(), xyz.data(), intr.data(), &rep) != GSFM_OK) return false;
+    for (int n = 0; n < N; ++n) {  // parameter blocks are the containers' own storage in the reference (ba.cc:143-146)
+      auto& fr = frames.at(fidx.ids[n]);
+      auto pose = fr.RigFromWorld();
+      pose.rotation = decltype(pose.rotation)(q[4 * n], q[4 * n + 1], q[4 * n + 2], q[4 * n + 3]);
+      pose.translation = decltype(pose.translation)(t[3 * n], t[3 * n + 1], t[3 * n + 2]);
+      fr.SetRigFromWorld(pose);
+    }
+    for (int64_t p = 0; p < P; ++p) {
+      if (tp.pt_offset[p + 1] - tp.pt_offset[p] < options_.min_num_view_per_track) continue;  // ba.cc:122
+      auto& tr = tracks.at(tp.track_ids[p]);
+      tr.xyz = decltype(tr.xyz)(xyz[3 * p], xyz[3 * p + 1], xyz[3 * p + 2]);
+    }
+    for (size_t k = 0; k < intr_ids.size(); ++k) {
+      auto& cam = cameras.at(intr_ids[k]);
+      for (size_t j = 0; j < cam.params.size(); ++j) cam.params[j] = intr[GSFM_CAMERA_MAX_PARAMS * k + j];
+    }
+    return true;
+  }
+
+ private:
+  glomap::BundleAdjusterOptions options_;
+};
+
+}  // namespace gsfm_glomap

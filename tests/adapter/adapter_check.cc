@@ -1,0 +1,164 @@
+// Drives the three reference-named estimator classes of include/gsfm_glomap_adapter.hpp end to end
+// from C++ (the reference's language) through the C ABI of libgsfm.so, on a small synthetic scene
+// held in GLOMAP-shaped containers (tests/adapter/mock).  Prints "ADAPTER OK ..." on success.
+#include <cmath>
+#include <cstdio>
+#include <random>
+
+#include "gsfm_glomap_adapter.hpp"
+
+using namespace glomap;
+
+static void rot_y(double a, double R[9]) {
+  const double c = std::cos(a), s = std::sin(a);
+  const double M[9] = {c, 0, s, 0, 1, 0, -s, 0, c};
+  for (int i = 0; i < 9; ++i) R[i] = M[i];
+}
+static mock_eigen::Quaterniond quat_of(const double R[9]) {  // rotation about y only
+  const double ang = std::atan2(R[2], R[0]);
+  return mock_eigen::Quaterniond(std::cos(0.5 * ang), 0.0, std::sin(0.5 * ang), 0.0);
+}
+
+int main() {
+  const int N = 16, P = 400;
+  std::mt19937 rng(7);
+  std::uniform_real_distribution<double> U(-1.0, 1.0);
+  std::unordered_map<rig_t, Rig> rigs;
+  std::unordered_map<camera_t, Camera> cameras;
+  std::unordered_map<frame_t, Frame> frames;
+  std::unordered_map<image_t, Image> images;
+  std::unordered_map<track_t, Track> tracks;
+  ViewGraph vg;
+  Camera cam;
+  cam.model_id = 1;  // PINHOLE
+  cam.params = {800.0, 800.0, 320.0, 240.0};
+  cameras[1] = cam;
+  // cameras on a ring of radius 10 looking at the origin
+  std::vector<double> Rg(9 * N), tg(3 * N), cg(3 * N);
+  for (int n = 0; n < N; ++n) {
+    const double th = 2.0 * M_PI * n / N;
+    const double c[3] = {10.0 * std::sin(th), 0.0, -10.0 * std::cos(th)};
+    double R[9];
+    rot_y(th, R);  // world -> camera with R c = (0, 0, -10): the optical axis passes through the origin
+    for (int i = 0; i < 9; ++i) Rg[9 * n + i] = R[i];
+    for (int i = 0; i < 3; ++i) {
+      cg[3 * n + i] = c[i];
+      tg[3 * n + i] = -(R[3 * i] * c[0] + R[3 * i + 1] * c[1] + R[3 * i + 2] * c[2]);
+    }
+    Frame fr;
+    fr.is_registered = true;
+    Rigid3d pose;
+    pose.rotation = quat_of(R);
+    pose.translation = mock_eigen::Vector3d(tg[3 * n], tg[3 * n + 1], tg[3 * n + 2]);
+    fr.SetRigFromWorld(pose);
+    frames[n] = fr;
+  }
+  for (int n = 0; n < N; ++n) {
+    Image im;
+    im.image_id = n;
+    im.camera_id = 1;
+    im.frame_id = n;
+    images[n] = im;
+  }
+  for (int n = 0; n < N; ++n) images[n].frame_ptr = &frames[n];
+  // points in a ball of radius 2, observed by every camera
+  for (int p = 0; p < P; ++p) {
+    Track tr;
+    tr.track_id = p;
+    const double X[3] = {2.0 * U(rng), 2.0 * U(rng), 2.0 * U(rng)};
+    tr.xyz = mock_eigen::Vector3d(X[0] + 0.05 * U(rng), X[1] + 0.05 * U(rng), X[2] + 0.05 * U(rng));
+    for (int n = 0; n < N; n += 1 + (p % 3)) {
+      const double* R = &Rg[9 * n];
+      double xc[3];
+      for (int i = 0; i < 3; ++i) xc[i] = R[3 * i] * X[0] + R[3 * i + 1] * X[1] + R[3 * i + 2] * X[2] + tg[3 * n + i];
+      const double nrm = std::sqrt(xc[0] * xc[0] + xc[1] * xc[1] + xc[2] * xc[2]);
+      images[n].features.emplace_back(800.0 * xc[0] / xc[2] + 320.0, 800.0 * xc[1] / xc[2] + 240.0);
+      images[n].features_undist.emplace_back(xc[0] / nrm, xc[1] / nrm, xc[2] / nrm);
+      tr.observations.emplace_back(n, (feature_t)(images[n].features.size() - 1));
+    }
+    tracks[p] = tr;
+  }
+  // view graph: each camera linked to its 4 successors, exact relative rotations
+  for (int i = 0; i < N; ++i)
+    for (int d = 1; d <= 4; ++d) {
+      const int j = (i + d) % N;
+      ImagePair pr;
+      pr.image_id1 = i;
+      pr.image_id2 = j;
+      double Rij[9];
+      rot_y((2.0 * M_PI * j / N) - (2.0 * M_PI * i / N), Rij);  // R_j R_i^T
+      pr.cam2_from_cam1.rotation = quat_of(Rij);
+      pr.inliers.resize(100 + 7 * d);
+      vg.image_pairs[(uint64_t)i * 1000 + j] = pr;
+    }
+
+  // 1) rotation averaging from a perturbed start
+  auto frames_ra = frames;
+  for (auto& [id, fr] : frames_ra) {
+    Rigid3d p = fr.RigFromWorld();
+    p.rotation = mock_eigen::Quaterniond(1, 0, 0, 0);
+    fr.SetRigFromWorld(p);
+  }
+  for (int n = 0; n < N; ++n) images[n].frame_ptr = &frames_ra[n];
+  RotationEstimatorOptions ro;
+  gsfm_glomap::RotationEstimator ra(ro);
+  if (!ra.EstimateRotations(vg, rigs, frames_ra, images)) return std::printf("RA failed\n"), 1;
+  double worst = 0;
+  for (int n = 1; n < N; ++n) {  // relative rotation to frame 0 (gauge free): angle about y
+    auto q0 = frames_ra[0].RigFromWorld().rotation, qn = frames_ra[n].RigFromWorld().rotation;
+    const double a_est = 2.0 * (std::atan2(qn.y(), qn.w()) - std::atan2(q0.y(), q0.w()));
+    const double a_ref = 2.0 * M_PI * n / N;
+    double d = std::fmod(a_est - a_ref, 2.0 * M_PI);
+    if (d > M_PI) d -= 2.0 * M_PI;
+    if (d < -M_PI) d += 2.0 * M_PI;
+    worst = std::fmax(worst, std::fabs(d));
+  }
+  if (worst > 1e-6) return std::printf("RA error %.3e rad\n", worst), 1;
+  for (int n = 0; n < N; ++n) images[n].frame_ptr = &frames[n];
+
+  // 2) global positioning (random init inside) with the ground-truth rotations
+  GlobalPositionerOptions go;
+  gsfm_glomap::GlobalPositioner gp(go);
+  auto frames_gp = frames;
+  for (int n = 0; n < N; ++n) images[n].frame_ptr = &frames_gp[n];
+  auto tracks_gp = tracks;
+  if (!gp.Solve(vg, rigs, cameras, frames_gp, images, tracks_gp)) return std::printf("GP failed\n"), 1;
+  // centres up to similarity: compare ratios of pairwise distances
+  auto center = [&](Frame& f, double* c) {
+    double tmp[3];
+    gsfm_glomap::detail::RotateInv(f.RigFromWorld().rotation, f.RigFromWorld().translation, tmp);
+    for (int i = 0; i < 3; ++i) c[i] = -tmp[i];
+  };
+  double c0[3], c1[3], c8[3];
+  center(frames_gp[0], c0);
+  center(frames_gp[1], c1);
+  center(frames_gp[8], c8);
+  auto dist = [](const double* a, const double* b) {
+    return std::sqrt((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]));
+  };
+  const double ratio = dist(c0, c8) / dist(c0, c1);
+  const double ratio_ref = 20.0 / (2.0 * 10.0 * std::sin(M_PI / N));
+  if (std::fabs(ratio / ratio_ref - 1.0) > 1e-3) return std::printf("GP ratio %.6f vs %.6f\n", ratio, ratio_ref), 1;
+  for (int n = 0; n < N; ++n) images[n].frame_ptr = &frames[n];
+
+  // 3) bundle adjustment from perturbed points: must reach (numerically) zero reprojection error
+  BundleAdjusterOptions bo;
+  gsfm_glomap::BundleAdjuster ba(bo);
+  if (!ba.Solve(rigs, cameras, frames, images, tracks)) return std::printf("BA failed\n"), 1;
+  double maxerr = 0;
+  for (auto& [tid, tr] : tracks)
+    for (auto& ob : tr.observations) {
+      Frame& fr = frames[images[ob.first].frame_id];
+      double xc[3];
+      const double X[3] = {tr.xyz[0], tr.xyz[1], tr.xyz[2]};
+      gsfm_glomap::detail::Rotate(fr.RigFromWorld().rotation, X, xc);
+      for (int i = 0; i < 3; ++i) xc[i] += fr.RigFromWorld().translation[i];
+      const auto& par = cameras[1].params;
+      const double u = par[0] * xc[0] / xc[2] + par[2], v = par[1] * xc[1] / xc[2] + par[3];
+      const auto& f = images[ob.first].features[ob.second];
+      maxerr = std::fmax(maxerr, std::hypot(u - f[0], v - f[1]));
+    }
+  if (maxerr > 1e-3) return std::printf("BA reprojection error %.3e px\n", maxerr), 1;
+  std::printf("ADAPTER OK ra=%.2e rad gp_ratio_err=%.2e ba=%.2e px\n", worst, std::fabs(ratio / ratio_ref - 1.0), maxerr);
+  return 0;
+}

@@ -1,0 +1,137 @@
+// Interface-shaped stand-ins of the GLOMAP / COLMAP / Eigen types that include/gsfm_glomap_adapter.hpp
+// touches (member names, method names and call shapes as in /root/reference/glomap/scene/*.h and the
+// colmap / Eigen types they expose).  They exist only so that the adapter can be compiled and run in
+// a repository that does not vendor GLOMAP: nothing here is reference code.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+namespace mock_eigen {
+struct Vector2d {
+  double v[2] = {0, 0};
+  Vector2d() = default;
+  Vector2d(double a, double b) : v{a, b} {}
+  double& operator[](int i) { return v[i]; }
+  const double& operator[](int i) const { return v[i]; }
+};
+struct Vector3d {
+  double v[3] = {0, 0, 0};
+  Vector3d() = default;
+  Vector3d(double a, double b, double c) : v{a, b, c} {}
+  double& operator[](int i) { return v[i]; }
+  const double& operator[](int i) const { return v[i]; }
+};
+struct Quaterniond {  // Eigen's constructor order: (w, x, y, z)
+  double w_ = 1, x_ = 0, y_ = 0, z_ = 0;
+  Quaterniond() = default;
+  Quaterniond(double w, double x, double y, double z) : w_(w), x_(x), y_(y), z_(z) {}
+  double w() const { return w_; }
+  double x() const { return x_; }
+  double y() const { return y_; }
+  double z() const { return z_; }
+};
+}  // namespace mock_eigen
+
+namespace glomap {
+using camera_t = uint32_t;
+using image_t = uint32_t;
+using frame_t = uint32_t;
+using rig_t = uint32_t;
+using image_pair_t = uint64_t;
+using feature_t = uint32_t;
+using track_t = uint64_t;
+
+struct Rigid3d {
+  mock_eigen::Quaterniond rotation;
+  mock_eigen::Vector3d translation;
+};
+struct Rig {};
+struct Camera {
+  int model_id = 0;
+  std::vector<double> params;
+  bool has_prior_focal_length = true;
+};
+struct Frame {
+  bool is_registered = false;
+  bool has_pose = false;
+  Rigid3d pose;
+  bool HasPose() const { return has_pose; }
+  Rigid3d& RigFromWorld() { return pose; }
+  const Rigid3d& RigFromWorld() const { return pose; }
+  void SetRigFromWorld(const Rigid3d& p) {
+    pose = p;
+    has_pose = true;
+  }
+};
+struct Image {
+  image_t image_id = 0;
+  camera_t camera_id = 0;
+  frame_t frame_id = 0;
+  Frame* frame_ptr = nullptr;
+  std::vector<mock_eigen::Vector2d> features;
+  std::vector<mock_eigen::Vector3d> features_undist;
+  bool IsRegistered() const { return frame_ptr != nullptr && frame_ptr->is_registered; }
+  bool HasTrivialFrame() const { return true; }
+};
+using Observation = std::pair<image_t, feature_t>;
+struct Track {
+  track_t track_id = 0;
+  mock_eigen::Vector3d xyz;
+  bool is_initialized = false;
+  std::vector<Observation> observations;
+};
+struct ImagePair {
+  image_t image_id1 = 0, image_id2 = 0;
+  bool is_valid = true;
+  double weight = -1;
+  Rigid3d cam2_from_cam1;
+  std::vector<int> inliers;
+};
+struct ViewGraph {
+  std::unordered_map<image_pair_t, ImagePair> image_pairs;
+};
+
+struct SolverOptionsShape {  // the ceres::Solver::Options fields the reference sets (optimization_base.h:18-23)
+  int max_num_iterations = 100;
+  double function_tolerance = 1e-5;
+};
+struct OptimizationBaseOptions {
+  double thres_loss_function = 1e-1;
+  SolverOptionsShape solver_options;
+};
+struct RotationEstimatorOptions {
+  int max_num_l1_iterations = 5;
+  double l1_step_convergence_threshold = 0.001;
+  int max_num_irls_iterations = 100;
+  double irls_step_convergence_threshold = 0.001;
+  double irls_loss_parameter_sigma = 5.0;
+  enum WeightType { GEMAN_MCCLURE, HALF_NORM } weight_type = GEMAN_MCCLURE;
+  bool skip_initialization = false;
+  bool use_weight = false;
+  bool use_gravity = false;
+};
+struct GlobalPositionerOptions : public OptimizationBaseOptions {
+  enum ConstraintType { ONLY_POINTS, ONLY_CAMERAS, POINTS_AND_CAMERAS_BALANCED, POINTS_AND_CAMERAS };
+  bool generate_random_positions = true, generate_random_points = true, generate_scales = true;
+  bool optimize_positions = true, optimize_points = true, optimize_scales = true;
+  bool use_gpu = true;
+  std::string gpu_index = "-1";
+  int min_num_view_per_track = 3;
+  unsigned seed = 1;
+  ConstraintType constraint_type = ONLY_POINTS;
+};
+struct BundleAdjusterOptions : public OptimizationBaseOptions {
+  bool optimize_rig_poses = false, optimize_rotations = true, optimize_translation = true, optimize_intrinsics = true,
+       optimize_principal_point = false, optimize_points = true;
+  bool use_gpu = true;
+  std::string gpu_index = "-1";
+  int min_num_view_per_track = 3;
+  BundleAdjusterOptions() {
+    thres_loss_function = 1.0;
+    solver_options.max_num_iterations = 200;
+  }
+};
+}  // namespace glomap
