@@ -155,28 +155,35 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // ---- linearize, point side ----------------------------------------------------------------------
-// One thread per track: cost, robust weights, the stored Jacobian planes (scaled by sqrt(w)),
-// H_pp / g_p per track.  part[block][2] = {cost, max |g_pt|}.
+// One lane per observation (track-major tiles): cost, the stored Jacobian planes (scaled by sqrt(w)),
+// and H_pp / g_p per track through a segmented wave scan.  All plane writes are coalesced.
+// part[block][2] = {cost, max |g_pt|}.
 template <int F>
 __global__ void __launch_bounds__(kBlock)
     k_ba_lin_track(BaDev g, const double* __restrict__ camR, const double* __restrict__ t,
                    const double* __restrict__ X, const double* __restrict__ par, double2* __restrict__ jt,
                    double* __restrict__ ptdiag, double* __restrict__ ptH, double* __restrict__ part) {
   __shared__ double smem[8];
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (kBlock / 64);
   double cost = 0.0, gmax = 0.0;
-  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.g.P; p += (long)gridDim.x * blockDim.x) {
-    if (!g.g.used[p]) continue;
-    const V3 Xp = ld3(X + 3 * p);
-    S3 H{0, 0, 0, 0, 0, 0};
-    V3 gp{0, 0, 0};
-    for (long k = g.g.off[p]; k < g.g.off[p + 1]; ++k) {
+  for (int tile = wave; tile < g.g.T; tile += nwaves) {
+    const long k0 = g.g.tile_k[tile], k1 = g.g.tile_k[tile + 1];
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // H (xx xy xz yy yz zz) | g
+    int key = -1 - lane;
+    for (long k = k0 + lane; k < k1; k += 64) {
+      const int p = g.g.obs_pt[k];
+      key = p;
+      if (!g.g.used[p]) continue;
       const int n = g.g.cam[k];
       const int ik = g.cam_intr[n];
       const double* R9 = camR + 9 * (long)n;
       ObsGeom o;
-      obs_geom(R9, t + 3 * (long)n, Xp, g.intr_model[ik], par + 8 * (long)ik, o);
-      const double r0 = o.valid ? o.px - g.xy[2 * k] : 0.0;
-      const double r1 = o.valid ? o.py - g.xy[2 * k + 1] : 0.0;
+      obs_geom(R9, t + 3 * (long)n, ld3(X + 3 * (long)p), g.intr_model[ik], par + 8 * (long)ik, o);
+      const double2 ob = *reinterpret_cast<const double2*>(g.xy + 2 * k);
+      const double r0 = o.valid ? o.px - ob.x : 0.0;
+      const double r1 = o.valid ? o.py - ob.y : 0.0;
       double rho, w;
       huber(g.huber_a, 1.0, r0 * r0 + r1 * r1, rho, w);
       if (!o.valid) w = 0.0;
@@ -197,23 +204,27 @@ __global__ void __launch_bounds__(kBlock)
         }
       }
       jt[(PL_I + F) * g.Mp + k] = make_double2(sw * r0, sw * r1);
-      H.xx += w * (J.Jpt[0][0] * J.Jpt[0][0] + J.Jpt[1][0] * J.Jpt[1][0]);
-      H.xy += w * (J.Jpt[0][0] * J.Jpt[0][1] + J.Jpt[1][0] * J.Jpt[1][1]);
-      H.xz += w * (J.Jpt[0][0] * J.Jpt[0][2] + J.Jpt[1][0] * J.Jpt[1][2]);
-      H.yy += w * (J.Jpt[0][1] * J.Jpt[0][1] + J.Jpt[1][1] * J.Jpt[1][1]);
-      H.yz += w * (J.Jpt[0][1] * J.Jpt[0][2] + J.Jpt[1][1] * J.Jpt[1][2]);
-      H.zz += w * (J.Jpt[0][2] * J.Jpt[0][2] + J.Jpt[1][2] * J.Jpt[1][2]);
-      gp.x += w * (J.Jpt[0][0] * r0 + J.Jpt[1][0] * r1);
-      gp.y += w * (J.Jpt[0][1] * r0 + J.Jpt[1][1] * r1);
-      gp.z += w * (J.Jpt[0][2] * r0 + J.Jpt[1][2] * r1);
+      acc[0] += w * (J.Jpt[0][0] * J.Jpt[0][0] + J.Jpt[1][0] * J.Jpt[1][0]);
+      acc[1] += w * (J.Jpt[0][0] * J.Jpt[0][1] + J.Jpt[1][0] * J.Jpt[1][1]);
+      acc[2] += w * (J.Jpt[0][0] * J.Jpt[0][2] + J.Jpt[1][0] * J.Jpt[1][2]);
+      acc[3] += w * (J.Jpt[0][1] * J.Jpt[0][1] + J.Jpt[1][1] * J.Jpt[1][1]);
+      acc[4] += w * (J.Jpt[0][1] * J.Jpt[0][2] + J.Jpt[1][1] * J.Jpt[1][2]);
+      acc[5] += w * (J.Jpt[0][2] * J.Jpt[0][2] + J.Jpt[1][2] * J.Jpt[1][2]);
+      acc[6] += w * (J.Jpt[0][0] * r0 + J.Jpt[1][0] * r1);
+      acc[7] += w * (J.Jpt[0][1] * r0 + J.Jpt[1][1] * r1);
+      acc[8] += w * (J.Jpt[0][2] * r0 + J.Jpt[1][2] * r1);
     }
-    ptdiag[3 * p] = H.xx;
-    ptdiag[3 * p + 1] = H.yy;
-    ptdiag[3 * p + 2] = H.zz;
-    double* hp = ptH + 9 * p;
-    hp[0] = H.xx; hp[1] = H.xy; hp[2] = H.xz; hp[3] = H.yy; hp[4] = H.yz; hp[5] = H.zz;
-    st3(hp + 6, gp);
-    gmax = fmax(gmax, fmax(fabs(gp.x), fmax(fabs(gp.y), fabs(gp.z))));
+    seg_scan<9>(acc, key, lane);
+    if (seg_is_tail(key, lane) && key >= 0 && g.g.used[key]) {
+      const long p = key;
+      ptdiag[3 * p] = acc[0];
+      ptdiag[3 * p + 1] = acc[3];
+      ptdiag[3 * p + 2] = acc[5];
+      double* hp = ptH + 9 * p;
+#pragma unroll
+      for (int j = 0; j < 9; ++j) hp[j] = acc[j];
+      gmax = fmax(gmax, fmax(fabs(acc[6]), fmax(fabs(acc[7]), fabs(acc[8]))));
+    }
   }
   double v[1] = {cost};
   block_sum<1>(v, smem);
@@ -405,11 +416,13 @@ __global__ void __launch_bounds__(kBlock)
 // One wave per camera: reduced gradient J_a^T w (r - J_pt e) and the diagonal Schur blocks
 // J_a^T W_k J_a, W_k = w (I - w J_pt H_pp^-1 J_pt^T), for the pose block (6 + 21) and this camera's
 // share of its intrinsics block (ipart[n][44] = gred 8 | S 36).
+template <bool JOINT>
 __global__ void __launch_bounds__(kBlock)
     k_ba_build_cam(BaDev g, const double* __restrict__ camR, const double* __restrict__ t,
                    const double* __restrict__ par, const double* __restrict__ c_w,
                    const double* __restrict__ ptb, double* __restrict__ gred, double* __restrict__ spose,
-                   double* __restrict__ ipart) {
+                   double* __restrict__ ipart, double* __restrict__ scross /* [N][48], JOINT only */) {
+  constexpr int NACC = JOINT ? 71 + 48 : 71;
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (kBlock / 64);
@@ -420,9 +433,9 @@ __global__ void __launch_bounds__(kBlock)
     const double* R9 = camR + 9 * (long)n;
     const double* t3 = t + 3 * (long)n;
     const double* pp = par + 8 * (long)ik;
-    double acc[71];  // gred 6 | spose 21 | igred 8 | sii 36
+    double acc[NACC];  // gred 6 | spose 21 | igred 8 | sii 36 | (JOINT) pose x intrinsics cross block 6 x 8
 #pragma unroll
-    for (int j = 0; j < 71; ++j) acc[j] = 0.0;
+    for (int j = 0; j < NACC; ++j) acc[j] = 0.0;
     for (int k = g.g.coff[n] + lane; k < g.g.coff[n + 1]; k += 64) {
       const double w = c_w[k];
       if (w == 0.0) continue;
@@ -452,6 +465,10 @@ __global__ void __launch_bounds__(kBlock)
         const double a1 = W01 * J.Jpose[0][i] + W11 * J.Jpose[1][i];
 #pragma unroll
         for (int j = i; j < 6; ++j) acc[6 + sym6(i, j)] += a0 * J.Jpose[0][j] + a1 * J.Jpose[1][j];
+        if constexpr (JOINT) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[71 + 8 * i + j] += a0 * o.Jp[0][j] + a1 * o.Jp[1][j];  // Jp masked above
+        }
       }
       if (bits) {
 #pragma unroll
@@ -464,8 +481,12 @@ __global__ void __launch_bounds__(kBlock)
         }
       }
     }
-    wave_allsum<71>(acc);
+    wave_allsum<NACC>(acc);
     if (lane == 0) {
+      if constexpr (JOINT) {
+#pragma unroll
+        for (int j = 0; j < 48; ++j) scross[48 * (long)n + j] = acc[71 + j];
+      }
 #pragma unroll
       for (int j = 0; j < 6; ++j) gred[6 * (long)n + j] = acc[j];
 #pragma unroll
@@ -518,6 +539,57 @@ __global__ void __launch_bounds__(kBlock)
       double* m = minv + 36 * (long)N + 64 * (long)k;
       for (int i = 0; i < 64; ++i) m[i] = A[i];
     }
+  }
+}
+
+// Joint variant (one intrinsics block per camera): damping and rhs as above, and the inverse of the
+// 14 x 14 block [S_pose + D, C; C^T, S_intr + D] of camera n and intrinsics block cam_intr[n], stored
+// transposed (minvj[(i * 14 + j) * N + n]) for coalesced reads in k_cg_update_joint.
+__global__ void __launch_bounds__(kBlock)
+    k_ba_blocks_finalize_joint(int N, double radius, double lo, double hi, const int* __restrict__ cam_intr,
+                               const double* __restrict__ diag, const double* __restrict__ js,
+                               const double* __restrict__ gred, const double* __restrict__ spose,
+                               const double* __restrict__ intr_acc, const double* __restrict__ scross,
+                               double* __restrict__ dvec, double* __restrict__ rhs, double* __restrict__ minvj) {
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+    double A[14 * 14];
+    double Dv[14];
+    const int k = cam_intr[n];
+    const long op = 6 * (long)n, oi = 6 * (long)N + 8 * (long)k;
+    const double* sp = spose + 21 * (long)n;
+    const double* acc = intr_acc + 44 * (long)k;
+    const double* cr = scross + 48 * (long)n;
+    for (int i = 0; i < 6; ++i) {
+      Dv[i] = lm_damping(diag[op + i], js[op + i], radius, lo, hi);
+      dvec[op + i] = Dv[i];
+      rhs[op + i] = -gred[op + i];
+      for (int j = i; j < 6; ++j) {
+        const double v = sp[sym6(i, j)] + (i == j ? Dv[i] : 0.0);
+        A[i * 14 + j] = v;
+        A[j * 14 + i] = v;
+      }
+      for (int j = 0; j < 8; ++j) {
+        A[i * 14 + 6 + j] = cr[8 * i + j];
+        A[(6 + j) * 14 + i] = cr[8 * i + j];
+      }
+    }
+    for (int i = 0; i < 8; ++i) {
+      Dv[6 + i] = lm_damping(diag[oi + i], js[oi + i], radius, lo, hi);
+      dvec[oi + i] = Dv[6 + i];
+      rhs[oi + i] = -acc[i];
+      for (int j = i; j < 8; ++j) {
+        const double v = acc[8 + sym8(i, j)] + (i == j ? Dv[6 + i] : 0.0);
+        A[(6 + i) * 14 + 6 + j] = v;
+        A[(6 + j) * 14 + 6 + i] = v;
+      }
+    }
+    double diag0[14];
+    for (int i = 0; i < 14; ++i) diag0[i] = A[i * 14 + i];
+    if (!spd_inverse<14>(A, 14)) {  // numerically indefinite block: fall back to its diagonal
+      for (int i = 0; i < 14; ++i)
+        for (int j = 0; j < 14; ++j) A[i * 14 + j] = (i == j) ? 1.0 / diag0[i] : 0.0;
+    }
+    for (int i = 0; i < 196; ++i) minvj[(size_t)i * N + n] = A[i];
   }
 }
 
@@ -729,7 +801,38 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // ---- back-substitution, model cost change, candidate points ------------------------------------
-// One thread per track over the stored planes.  part[block][3] = {model_cost_change, |dX|^2, |X|^2}
+// One lane per observation over the stored planes: dX_p = -e_p - H_pp^-1 sum_k B_k^T u_k (segmented wave
+// scan), broadcast back to the track's lanes for the model decrease  -sum_k (m.rw + m.m / 2),
+// m = u_k + B_k dX.  part[block][3] = {model_cost_change, |dX|^2, |X|^2}
+template <int F>
+__device__ __forceinline__ void ba_obs_u(const BaDev& g, const double2* __restrict__ jt, const double* __restrict__ dv,
+                                         const double* __restrict__ dintr, long k, double& u0, double& u1) {
+  const long n = g.g.cam[k];
+  const double2* vp = reinterpret_cast<const double2*>(dv + 6 * n);
+  const double2 v01 = vp[0], v23 = vp[1], v45 = vp[2];
+  const double vv[6] = {v01.x, v01.y, v23.x, v23.y, v45.x, v45.y};
+  u0 = 0.0;
+  u1 = 0.0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const double2 a = jt[(PL_A + j) * g.Mp + k];
+    u0 += a.x * vv[j];
+    u1 += a.y * vv[j];
+  }
+  if constexpr (F > 0) {
+    const int ik = g.obs_ik[k];
+    const Map8 mp = load_map(g.intr_map + 8 * (long)ik);
+#pragma unroll
+    for (int j = 0; j < F; ++j) {
+      const int pm = mp.m[j];
+      const double zv = pm >= 0 ? dintr[8 * (long)ik + pm] : 0.0;
+      const double2 a = jt[(PL_I + j) * g.Mp + k];
+      u0 += a.x * zv;
+      u1 += a.y * zv;
+    }
+  }
+}
+
 template <int F>
 __global__ void __launch_bounds__(kBlock)
     k_ba_backsub(BaDev g, const double* __restrict__ X, const double2* __restrict__ jt,
@@ -738,58 +841,55 @@ __global__ void __launch_bounds__(kBlock)
   __shared__ double smem[4 * 3];
   double acc3[3] = {0, 0, 0};
   const double* dintr = dv + 6 * (long)g.g.N;
-  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.g.P; p += (long)gridDim.x * blockDim.x) {
-    const V3 Xp = ld3(X + 3 * p);
-    if (!g.g.used[p]) {
-      st3(Xn + 3 * p, Xp);
-      continue;
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (kBlock / 64);
+  for (int tile = wave; tile < g.g.T; tile += nwaves) {
+    const long k0 = g.g.tile_k[tile], k1 = g.g.tile_k[tile + 1];
+    double acc[3] = {0, 0, 0};
+    int key = -1 - lane;
+    for (long k = k0 + lane; k < k1; k += 64) {
+      key = g.g.obs_pt[k];
+      double u0, u1;
+      ba_obs_u<F>(g, jt, dv, dintr, k, u0, u1);  // planes of unused tracks are zero
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const double2 b = jt[(PL_B + j) * g.Mp + k];
+        acc[j] += b.x * u0 + b.y * u1;
+      }
     }
-    const long k0 = g.g.off[p], k1 = g.g.off[p + 1];
+    seg_scan<3>(acc, key, lane);
+    const bool tail = seg_is_tail(key, lane) && key >= 0;
     V3 dX{0, 0, 0};
-    for (int pass = 0; pass < 2; ++pass) {
-      V3 acc{0, 0, 0};
-      for (long k = k0; k < k1; ++k) {
-        const long n = g.g.cam[k];
-        const double* vp = dv + 6 * n;
-        double u0 = 0.0, u1 = 0.0;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          const double2 a = jt[(PL_A + j) * g.Mp + k];
-          u0 += a.x * vp[j];
-          u1 += a.y * vp[j];
-        }
-        if constexpr (F > 0) {
-          const int ik = g.cam_intr[n];
-          const Map8 mp = load_map(g.intr_map + 8 * (long)ik);
-#pragma unroll
-          for (int j = 0; j < F; ++j) {
-            const int pm = mp.m[j];
-            const double zv = pm >= 0 ? dintr[8 * (long)ik + pm] : 0.0;
-            const double2 a = jt[(PL_I + j) * g.Mp + k];
-            u0 += a.x * zv;
-            u1 += a.y * zv;
-          }
-        }
-        const double2 b0 = jt[(PL_B + 0) * g.Mp + k], b1 = jt[(PL_B + 1) * g.Mp + k], b2 = jt[(PL_B + 2) * g.Mp + k];
-        if (pass == 0) {
-          acc.x += b0.x * u0 + b0.y * u1;
-          acc.y += b1.x * u0 + b1.y * u1;
-          acc.z += b2.x * u0 + b2.y * u1;
-        } else {
-          u0 += b0.x * dX.x + b1.x * dX.y + b2.x * dX.z;
-          u1 += b0.y * dX.x + b1.y * dX.y + b2.y * dX.z;
-          const double2 rw = jt[(PL_I + F) * g.Mp + k];
-          acc3[0] -= u0 * rw.x + u1 * rw.y + 0.5 * (u0 * u0 + u1 * u1);
-        }
-      }
-      if (pass == 0 && g.opt_pts) {
+    if (tail) {
+      const long p = key;
+      const V3 Xp = ld3(X + 3 * p);
+      if (g.g.used[p] && g.opt_pts) {
         const double* b = ptb + 12 * p;
-        dX = V3{0, 0, 0} - ld3(b + 3) - mul(S3{b[6], b[7], b[8], b[9], b[10], b[11]}, acc);
+        dX = V3{0, 0, 0} - ld3(b + 3) - mul(S3{b[6], b[7], b[8], b[9], b[10], b[11]}, V3{acc[0], acc[1], acc[2]});
+      }
+      st3(Xn + 3 * p, Xp + dX);
+      if (g.g.used[p]) {
+        acc3[1] += dot(dX, dX);
+        acc3[2] += dot(Xp, Xp);
       }
     }
-    st3(Xn + 3 * p, Xp + dX);
-    acc3[1] += dot(dX, dX);
-    acc3[2] += dot(Xp, Xp);
+    // broadcast dX of each segment from its tail lane to all its lanes
+    const unsigned long long tmask = __ballot(tail);
+    const unsigned long long above = tmask >> lane;
+    const int src = above ? lane + __ffsll((long long)above) - 1 : lane;
+    dX.x = __shfl(dX.x, src, 64);
+    dX.y = __shfl(dX.y, src, 64);
+    dX.z = __shfl(dX.z, src, 64);
+    for (long k = k0 + lane; k < k1; k += 64) {
+      double u0, u1;
+      ba_obs_u<F>(g, jt, dv, dintr, k, u0, u1);
+      const double2 b0 = jt[(PL_B + 0) * g.Mp + k], b1 = jt[(PL_B + 1) * g.Mp + k], b2 = jt[(PL_B + 2) * g.Mp + k];
+      u0 += b0.x * dX.x + b1.x * dX.y + b2.x * dX.z;
+      u1 += b0.y * dX.x + b1.y * dX.y + b2.y * dX.z;
+      const double2 rw = jt[(PL_I + F) * g.Mp + k];
+      acc3[0] -= u0 * rw.x + u1 * rw.y + 0.5 * (u0 * u0 + u1 * u1);
+    }
   }
   block_sum<3>(acc3, smem);
   if (threadIdx.x == 0) {
@@ -889,7 +989,7 @@ struct BaWs {
   DevBuf<signed char> intr_map;
   DevBuf<double2> jt;
   DevBuf<double> xy, c_xy, c_w, q, qn, t, tn, camR, camRn, X, Xn, par, parn, ptH, ptb, ptrec, ptdiag, ptjs, diag, js,
-      dvec, grad, gred, rhs, spose, ipart, iacc16, iacc44, yi_part, minv, cg_x, cg_r, cg_z, cg_p, cg_s, cg_w, vpart,
+      dvec, grad, gred, rhs, spose, scross, minvj, ipart, iacc16, iacc44, yi_part, minv, cg_x, cg_r, cg_z, cg_p, cg_s, cg_w, vpart,
       dpart, part, scal;
   DevBuf<CgStatus> cgst;
   DevBuf<CgScal> cgsc;
@@ -985,6 +1085,9 @@ class BaSolver final : public LmProblem {
       h_ioff[k + 1] += h_ioff[k];
     }
     small_groups_ = max_group_ <= 64;
+    // one intrinsics block per camera (COLMAP's default for unordered photo collections): pose and
+    // intrinsics of a camera are strongly coupled, so they share ONE 14 x 14 block-Jacobi block
+    joint_ = K_ == N_ && max_group_ == 1 && F_ > 0 && std::getenv("GSFM_BA_SEPARATE_BLOCKS") == nullptr;
     {
       std::vector<int> fill(h_ioff.begin(), h_ioff.end() - 1);
       for (int n = 0; n < N_; ++n) h_icams[fill[h_ci[n]]++] = n;
@@ -1032,6 +1135,10 @@ class BaSolver final : public LmProblem {
       b->ensure(n_);
     ws->cg_w.ensure((size_t)n_ + 2);
     ws->spose.ensure(21 * (size_t)N_);
+    if (joint_) {
+      ws->scross.ensure(48 * (size_t)N_);
+      ws->minvj.ensure(196 * (size_t)N_);
+    }
     ws->ipart.ensure(44 * (size_t)N_);
     ws->yi_part.ensure(8 * (size_t)N_);
     ws->iacc16.ensure(16 * (size_t)K_);
@@ -1049,6 +1156,7 @@ class BaSolver final : public LmProblem {
     gridCam_ = grid_wide(N_, kBlock / 64, kMaxApplySlots);  // one wave per camera (delta partial per block)
     gridTile_ = grid_wide(g_.g.T, kBlock / 64);             // one wave per tile
     gridK_ = small_groups_ ? grid_for(K_, kBlock) : grid_for(K_, 1);
+    gridTileP_ = grid_wide(g_.g.T, kBlock / 64, kMaxBlocks);  // tile sweeps that write per-block partials
     g_.K = K_;
     g_.F = F_;
     g_.Mp = Mp_;
@@ -1074,10 +1182,15 @@ class BaSolver final : public LmProblem {
     X_ = ws->X.get(); Xn_ = ws->Xn.get();
     par_ = ws->par.get(); parn_ = ws->parn.get();
     hipLaunchKernelGGL(k_ba_cam_prepare, dim3(gridN_), dim3(kBlock), 0, s, N_, q_, R_);
+    // tracks without observations are never visited by the lane-per-observation sweeps: both point
+    // buffers start equal, so such tracks keep their input xyz whichever buffer ends up current
+    GSFM_HIP_CHECK(hipMemcpyAsync(Xn_, X_, 3 * (size_t)P_ * sizeof(double), hipMemcpyDeviceToDevice, s));
     cg_.n = n_;
     cg_.N = N_;
     cg_.K = K_;
-    cg_.nb_update = std::min(kCgMaxBlocks, grid_for(N_ + K_, kBlock));
+    cg_.nb_update = std::min(kCgMaxBlocks, grid_for(joint_ ? N_ : N_ + K_, kBlock));
+    cg_.joint_map = joint_ ? ws->cam_intr.get() : nullptr;
+    cg_.minv_joint = joint_ ? ws->minvj.get() : nullptr;
     cg_.nb_apply = gridCam_ + gridK_;
     cg_.b = ws->rhs.get();
     cg_.x = ws->cg_x.get();
@@ -1099,7 +1212,7 @@ class BaSolver final : public LmProblem {
     BaWs* ws = ws_;
     hipStream_t s = ctx_->stream;
     dispatch_f(F_, [&](auto Fc) {
-      hipLaunchKernelGGL((k_ba_lin_track<decltype(Fc)::value>), dim3(gridP_), dim3(kBlock), 0, s, g_, R_, t_, X_, par_,
+      hipLaunchKernelGGL((k_ba_lin_track<decltype(Fc)::value>), dim3(gridTileP_), dim3(kBlock), 0, s, g_, R_, t_, X_, par_,
                          ws->jt.get(), ws->ptdiag.get(), ws->ptH.get(), ws->part.get());
     });
     hipLaunchKernelGGL(k_ba_lin_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, R_, t_, X_, par_, ws->c_w.get(),
@@ -1111,7 +1224,7 @@ class BaSolver final : public LmProblem {
       allreduce_sum(ctx_, ws->diag.get(), n_);
       allreduce_sum(ctx_, ws->grad.get(), n_);
     }
-    hipLaunchKernelGGL(k_ba_finalize_lin, dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridP_, ws->grad.get(), n_,
+    hipLaunchKernelGGL(k_ba_finalize_lin, dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridTileP_, ws->grad.get(), n_,
                        ws->scal.get());
     if (ctx_->comm.world > 1) {
       allreduce_sum(ctx_, ws->scal.get(), 1);
@@ -1140,23 +1253,34 @@ class BaSolver final : public LmProblem {
     const bool multi = ctx_->comm.world > 1;
     hipLaunchKernelGGL(k_ba_build_track, dim3(gridP_), dim3(kBlock), 0, s, g_, radius, X_, ws->ptH.get(),
                        ws->ptdiag.get(), ws->ptjs.get(), ws->ptb.get(), ws->ptrec.get());
-    hipLaunchKernelGGL(k_ba_build_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, R_, t_, par_, ws->c_w.get(),
-                       ws->ptb.get(), ws->gred.get(), ws->spose.get(), ws->ipart.get());
+    if (joint_) {
+      hipLaunchKernelGGL((k_ba_build_cam<true>), dim3(gridCam_), dim3(kBlock), 0, s, g_, R_, t_, par_, ws->c_w.get(),
+                         ws->ptb.get(), ws->gred.get(), ws->spose.get(), ws->ipart.get(), ws->scross.get());
+    } else {
+      hipLaunchKernelGGL((k_ba_build_cam<false>), dim3(gridCam_), dim3(kBlock), 0, s, g_, R_, t_, par_, ws->c_w.get(),
+                         ws->ptb.get(), ws->gred.get(), ws->spose.get(), ws->ipart.get(), (double*)nullptr);
+    }
     group_sum<44>(ws->ipart.get(), ws->iacc44.get());
     if (multi) {
       allreduce_sum(ctx_, ws->gred.get(), 6 * (size_t)N_);
       allreduce_sum(ctx_, ws->spose.get(), 21 * (size_t)N_);
       allreduce_sum(ctx_, ws->iacc44.get(), 44 * (size_t)K_);
+      if (joint_) allreduce_sum(ctx_, ws->scross.get(), 48 * (size_t)N_);
     }
+    if (joint_) {
+      hipLaunchKernelGGL(k_ba_blocks_finalize_joint, dim3(grid_for(N_, kBlock)), dim3(kBlock), 0, s, N_, radius, g_.lm_lo,
+                         g_.lm_hi, g_.cam_intr, ws->diag.get(), ws->js.get(), ws->gred.get(), ws->spose.get(),
+                         ws->iacc44.get(), ws->scross.get(), ws->dvec.get(), ws->rhs.get(), ws->minvj.get());
+    } else
     hipLaunchKernelGGL(k_ba_blocks_finalize, dim3(grid_for(N_ + K_, kBlock)), dim3(kBlock), 0, s, N_, K_, radius,
                        g_.lm_lo, g_.lm_hi, ws->diag.get(), ws->js.get(), ws->gred.get(), ws->spose.get(),
                        ws->iacc44.get(), ws->dvec.get(), ws->rhs.get(), ws->minv.get());
     *linear_iterations = pcg();
     dispatch_f(F_, [&](auto Fc) {
-      hipLaunchKernelGGL((k_ba_backsub<decltype(Fc)::value>), dim3(gridP_), dim3(kBlock), 0, s, g_, X_, ws->jt.get(),
+      hipLaunchKernelGGL((k_ba_backsub<decltype(Fc)::value>), dim3(gridTileP_), dim3(kBlock), 0, s, g_, X_, ws->jt.get(),
                          ws->ptb.get(), ws->cg_x.get(), Xn_, ws->part.get());
     });
-    hipLaunchKernelGGL((k_ba_sum_partials<3>), dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridP_, ws->scal.get());
+    hipLaunchKernelGGL((k_ba_sum_partials<3>), dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridTileP_, ws->scal.get());
     const int gridU = std::min(64, grid_for(N_ + 8 * (size_t)K_, kBlock));
     double* part2 = ws->part.get() + kMaxBlocks * 3;
     hipLaunchKernelGGL(k_ba_param_update, dim3(gridU), dim3(kBlock), 0, s, N_, K_, q_, t_, par_, ws->cg_x.get(), qn_,
@@ -1241,9 +1365,9 @@ class BaSolver final : public LmProblem {
   BaDev g_{};
   CgVec cg_{};
   int N_ = 0, K_ = 0, n_ = 0, F_ = 0, max_group_ = 0;
-  bool small_groups_ = false;
+  bool small_groups_ = false, joint_ = false;
   long P_ = 0, M_ = 0, Mp_ = 0, m_used_ = 0;
-  int gridP_ = 1, gridN_ = 1, gridM_ = 1, gridCam_ = 1, gridTile_ = 1, gridK_ = 1;
+  int gridP_ = 1, gridN_ = 1, gridM_ = 1, gridCam_ = 1, gridTile_ = 1, gridTileP_ = 1, gridK_ = 1;
   double *q_ = nullptr, *qn_ = nullptr, *t_ = nullptr, *tn_ = nullptr, *R_ = nullptr, *Rn_ = nullptr, *X_ = nullptr,
          *Xn_ = nullptr, *par_ = nullptr, *parn_ = nullptr;
 };

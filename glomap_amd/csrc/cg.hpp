@@ -64,6 +64,11 @@ struct CgVec {
   // of a camera with the same 16-byte gathers)
   double* zmir = nullptr;
   int zmir_stride = 0, zmir_off = 0;
+  // joint preconditioner (BA with one intrinsics block per camera): camera n and intrinsics block
+  // joint_map[n] form ONE (PB + 8) x (PB + 8) block-Jacobi block; minv_joint is stored transposed,
+  // minv_joint[(i * BJ + j) * N + n], so that one thread per camera reads it fully coalesced.
+  const int* joint_map = nullptr;
+  const double* minv_joint = nullptr;
 };
 
 template <int BS>
@@ -223,6 +228,129 @@ static __global__ void __launch_bounds__(kBlock) k_cg_update(CgVec v, int it) {
   }
 }
 
+
+// ---- joint (pose + intrinsics) blocks ----------------------------------------------------------
+template <int PB>
+__device__ __forceinline__ long cg_joint_index(const CgVec& v, int n, int i) {
+  return i < PB ? (long)PB * n + i : (long)PB * v.N + 8L * v.joint_map[n] + (i - PB);
+}
+template <int PB>
+__device__ __forceinline__ void cg_joint_precond(const CgVec& v, int n, const double (&r)[PB + 8], double (&z)[PB + 8]) {
+  constexpr int BJ = PB + 8;
+  const double* m = v.minv_joint + n;
+#pragma unroll
+  for (int i = 0; i < BJ; ++i) {
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) acc += m[(size_t)(i * BJ + j) * v.N] * r[j];
+    z[i] = acc;
+  }
+}
+
+template <int PB>
+static __global__ void __launch_bounds__(kBlock) k_cg_init_joint(CgVec v) {
+  constexpr int BJ = PB + 8;
+  __shared__ double smem[4 * 2];
+  double acc[2] = {0.0, 0.0};
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < v.N; n += gridDim.x * blockDim.x) {
+    double rb[BJ], zb[BJ];
+#pragma unroll
+    for (int i = 0; i < BJ; ++i) rb[i] = v.b[cg_joint_index<PB>(v, n, i)];
+    cg_joint_precond<PB>(v, n, rb, zb);
+#pragma unroll
+    for (int i = 0; i < BJ; ++i) {
+      const long o = cg_joint_index<PB>(v, n, i);
+      v.x[o] = 0.0;
+      v.r[o] = rb[i];
+      v.z[o] = zb[i];
+      v.p[o] = 0.0;
+      v.s[o] = 0.0;
+      acc[0] += rb[i] * zb[i];
+      acc[1] += rb[i] * rb[i];
+    }
+  }
+  block_sum<2>(acc, smem);
+  if (threadIdx.x == 0) {
+    v.vpart[blockIdx.x * 2] = acc[0];
+    v.vpart[blockIdx.x * 2 + 1] = acc[1];
+    if (blockIdx.x == 0) {
+      v.st->done = 0;
+      v.st->iters = 0;
+      v.st->bad = 0;
+      v.st->bb = 0.0;
+      v.st->rr = 0.0;
+      v.scal[0].gamma = 0.0;
+      v.scal[0].alpha = 0.0;
+    }
+  }
+}
+
+template <int PB>
+static __global__ void __launch_bounds__(kBlock) k_cg_update_joint(CgVec v, int it) {
+  constexpr int BJ = PB + 8;
+  __shared__ double smem[4 * 2 + 2];
+  if (v.st->done) return;
+  double g[2];
+  reduce_partials<2>(v.vpart + (size_t)(it & 1) * kCgMaxBlocks * 2, v.nb_update, g, smem);
+  double delta;
+  if (v.delta_in_w) {
+    delta = v.w[v.n];
+  } else {
+    double d[1];
+    reduce_partials<1>(v.dpart, v.nb_apply, d, smem);
+    delta = d[0];
+  }
+  const double gamma = g[0];
+  const CgScal prev = v.scal[it & 1];
+  double beta = 0.0, denom = delta;
+  if (it > 0) {
+    beta = prev.gamma > 0.0 ? gamma / prev.gamma : 0.0;
+    denom = delta - beta * gamma / prev.alpha;
+  }
+  const bool ok = isfinite(denom) && denom > 0.0 && isfinite(gamma) && gamma >= 0.0;
+  const double alpha = ok ? gamma / denom : 0.0;
+  if (!ok) beta = 0.0;
+  double acc[2] = {0.0, 0.0};
+  if (ok) {
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < v.N; n += gridDim.x * blockDim.x) {
+      double rn[BJ], zn[BJ];
+#pragma unroll
+      for (int i = 0; i < BJ; ++i) {
+        const long o = cg_joint_index<PB>(v, n, i);
+        const double pi = v.z[o] + beta * v.p[o];
+        const double si = v.w[o] + beta * v.s[o];
+        v.p[o] = pi;
+        v.s[o] = si;
+        v.x[o] += alpha * pi;
+        rn[i] = v.r[o] - alpha * si;
+        v.r[o] = rn[i];
+        acc[1] += rn[i] * rn[i];
+      }
+      cg_joint_precond<PB>(v, n, rn, zn);
+#pragma unroll
+      for (int i = 0; i < BJ; ++i) {
+        v.z[cg_joint_index<PB>(v, n, i)] = zn[i];
+        acc[0] += rn[i] * zn[i];
+      }
+    }
+  }
+  block_sum<2>(acc, smem);
+  if (threadIdx.x == 0) {
+    double* out = v.vpart + (size_t)((it + 1) & 1) * kCgMaxBlocks * 2;
+    out[blockIdx.x * 2] = acc[0];
+    out[blockIdx.x * 2 + 1] = acc[1];
+    if (blockIdx.x == 0) {
+      v.scal[(it + 1) & 1].gamma = gamma;
+      v.scal[(it + 1) & 1].alpha = alpha;
+      if (!ok) {
+        if (!(gamma == 0.0 && isfinite(delta))) v.st->bad = 1;
+        v.st->done = 1;
+        v.st->iters = it;
+      }
+    }
+  }
+}
+
 // Single-block reduction of the delta partials into w[n] (multi-rank: w[0..n] is all-reduced next).
 static __global__ void __launch_bounds__(kBlock) k_cg_delta_to_w(CgVec v) {
   __shared__ double smem[4 + 1];
@@ -239,7 +367,11 @@ inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& 
   hipStream_t s = ctx->stream;
   const bool multi = ctx->comm.world > 1;
   v.delta_in_w = multi ? 1 : 0;
-  hipLaunchKernelGGL((k_cg_init<PB, HAS_INTR>), dim3(v.nb_update), dim3(kBlock), 0, s, v);
+  const bool joint = HAS_INTR && v.joint_map != nullptr;
+  if constexpr (HAS_INTR) {
+    if (joint) hipLaunchKernelGGL((k_cg_init_joint<PB>), dim3(v.nb_update), dim3(kBlock), 0, s, v);
+  }
+  if (!joint) hipLaunchKernelGGL((k_cg_init<PB, HAS_INTR>), dim3(v.nb_update), dim3(kBlock), 0, s, v);
   CgStatus* h = reinterpret_cast<CgStatus*>(ctx->h_pinned + 400);
   const int chunk = 8;
   for (int it = 0; it < max_iter; ++it) {
@@ -248,7 +380,10 @@ inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& 
       hipLaunchKernelGGL(k_cg_delta_to_w, dim3(1), dim3(kBlock), 0, s, v);
       allreduce_sum(ctx, v.w, (size_t)v.n + 1);
     }
-    hipLaunchKernelGGL((k_cg_update<PB, HAS_INTR>), dim3(v.nb_update), dim3(kBlock), 0, s, v, it);
+    if constexpr (HAS_INTR) {
+      if (joint) hipLaunchKernelGGL((k_cg_update_joint<PB>), dim3(v.nb_update), dim3(kBlock), 0, s, v, it);
+    }
+    if (!joint) hipLaunchKernelGGL((k_cg_update<PB, HAS_INTR>), dim3(v.nb_update), dim3(kBlock), 0, s, v, it);
     if ((it + 1) % chunk == 0 || it == max_iter - 1) {
       GSFM_HIP_CHECK(hipMemcpyAsync(h, v.st, sizeof(CgStatus), hipMemcpyDeviceToHost, s));
       GSFM_HIP_CHECK(hipStreamSynchronize(s));
