@@ -57,6 +57,7 @@ struct BaDev {
   const int* ioff;                 // [K+1]
   const int* icams;                // [N]
   const int* obs_ik;               // [M] intrinsics block of each observation (track-major)
+  const double* zrec;              // joint mode: [N][6 + F] gather record (z pose | z free intrinsics), else null
   int fixed_cam;
   int opt_rot, opt_trn, opt_pts;
   double huber_a;
@@ -615,27 +616,51 @@ __global__ void __launch_bounds__(kBlock)
     for (long k = k0 + lane; k < k1; k += 64) {
       key = g.g.obs_pt[k];
       const long n = g.g.cam[k];
-      const double2* zp = reinterpret_cast<const double2*>(v.z + 6 * n);
-      const double2 z01 = zp[0], z23 = zp[1], z45 = zp[2];
-      const double zz[6] = {z01.x, z01.y, z23.x, z23.y, z45.x, z45.y};
       double u0 = 0.0, u1 = 0.0;
+      if (g.zrec != nullptr) {
+        // joint mode: z of the pose and of the free intrinsics of camera n in ONE (6 + F)-double record
+        const double2* zp = reinterpret_cast<const double2*>(g.zrec + (6 + F) * n);
+        double zz[6 + F];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const double2 a = jt[(PL_A + j) * g.Mp + k];
-        u0 += a.x * zz[j];
-        u1 += a.y * zz[j];
-      }
-      if constexpr (F > 0) {
-        const int ik = g.obs_ik[k];
-        const Map8 mp = load_map(g.intr_map + 8 * (long)ik);
-        const double* zi = zintr + 8 * (long)ik;
+        for (int j = 0; j < (6 + F) / 2; ++j) {
+          const double2 t2 = zp[j];
+          zz[2 * j] = t2.x;
+          zz[2 * j + 1] = t2.y;
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const double2 a = jt[(PL_A + j) * g.Mp + k];
+          u0 += a.x * zz[j];
+          u1 += a.y * zz[j];
+        }
 #pragma unroll
         for (int j = 0; j < F; ++j) {
-          const int pm = mp.m[j];
-          const double zv = pm >= 0 ? zi[pm] : 0.0;
           const double2 a = jt[(PL_I + j) * g.Mp + k];
-          u0 += a.x * zv;
-          u1 += a.y * zv;
+          u0 += a.x * zz[6 + j];
+          u1 += a.y * zz[6 + j];
+        }
+      } else {
+        const double2* zp = reinterpret_cast<const double2*>(v.z + 6 * n);
+        const double2 z01 = zp[0], z23 = zp[1], z45 = zp[2];
+        const double zz[6] = {z01.x, z01.y, z23.x, z23.y, z45.x, z45.y};
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const double2 a = jt[(PL_A + j) * g.Mp + k];
+          u0 += a.x * zz[j];
+          u1 += a.y * zz[j];
+        }
+        if constexpr (F > 0) {
+          const int ik = g.obs_ik[k];
+          const Map8 mp = load_map(g.intr_map + 8 * (long)ik);
+          const double* zi = zintr + 8 * (long)ik;
+#pragma unroll
+          for (int j = 0; j < F; ++j) {
+            const int pm = mp.m[j];
+            const double zv = pm >= 0 ? zi[pm] : 0.0;
+            const double2 a = jt[(PL_I + j) * g.Mp + k];
+            u0 += a.x * zv;
+            u1 += a.y * zv;
+          }
         }
       }
 #pragma unroll
@@ -986,10 +1011,10 @@ struct BaWs {
   DevBuf<long> off;
   DevBuf<int> cam, cam_intr, intr_model, ioff, icams, obs_ik;
   DevBuf<unsigned char> intr_free;
-  DevBuf<signed char> intr_map;
+  DevBuf<signed char> intr_map, intr_slot;
   DevBuf<double2> jt;
   DevBuf<double> xy, c_xy, c_w, q, qn, t, tn, camR, camRn, X, Xn, par, parn, ptH, ptb, ptrec, ptdiag, ptjs, diag, js,
-      dvec, grad, gred, rhs, spose, scross, minvj, ipart, iacc16, iacc44, yi_part, minv, cg_x, cg_r, cg_z, cg_p, cg_s, cg_w, vpart,
+      dvec, grad, gred, rhs, spose, scross, minvj, zrec, ipart, iacc16, iacc44, yi_part, minv, cg_x, cg_r, cg_z, cg_p, cg_s, cg_w, vpart,
       dpart, part, scal;
   DevBuf<CgStatus> cgst;
   DevBuf<CgScal> cgsc;
@@ -1055,7 +1080,7 @@ class BaSolver final : public LmProblem {
     to_host(ctx_, h_model, prob->intr_model, (size_t)K_, mem);
     to_host(ctx_, h_ci, prob->cam_intr, (size_t)N_, mem);
     std::vector<unsigned char> h_free(K_);
-    std::vector<signed char> h_map(8 * (size_t)K_, -1);
+    std::vector<signed char> h_map(8 * (size_t)K_, -1), h_slot(8 * (size_t)K_, -1);
     int fmax = 0;
     for (int k = 0; k < K_; ++k) {
       const int np = num_params_of(h_model[k]);
@@ -1069,7 +1094,10 @@ class BaSolver final : public LmProblem {
       h_free[k] = (unsigned char)bits;
       int j = 0;
       for (int p = 0; p < 8; ++p)
-        if ((bits >> p) & 1) h_map[8 * (size_t)k + j++] = (signed char)p;
+        if ((bits >> p) & 1) {
+          h_slot[8 * (size_t)k + p] = (signed char)j;
+          h_map[8 * (size_t)k + j++] = (signed char)p;
+        }
       fmax = std::max(fmax, j);
     }
     F_ = fmax == 0 ? 0 : (fmax <= 2 ? 2 : (fmax <= 4 ? 4 : 8));
@@ -1103,6 +1131,7 @@ class BaSolver final : public LmProblem {
     copy_in(ctx_, ws->par.ensure(8 * (size_t)K_), intr_params, 8 * (size_t)K_, mem);
     GSFM_HIP_CHECK(hipMemcpyAsync(ws->intr_free.ensure(K_), h_free.data(), (size_t)K_, hipMemcpyHostToDevice, s));
     GSFM_HIP_CHECK(hipMemcpyAsync(ws->intr_map.ensure(8 * (size_t)K_ + 8), h_map.data(), 8 * (size_t)K_, hipMemcpyHostToDevice, s));
+    GSFM_HIP_CHECK(hipMemcpyAsync(ws->intr_slot.ensure(8 * (size_t)K_ + 8), h_slot.data(), 8 * (size_t)K_, hipMemcpyHostToDevice, s));
     GSFM_HIP_CHECK(hipMemcpyAsync(ws->ioff.ensure(K_ + 1), h_ioff.data(), (size_t)(K_ + 1) * sizeof(int), hipMemcpyHostToDevice, s));
     GSFM_HIP_CHECK(hipMemcpyAsync(ws->icams.ensure(N_), h_icams.data(), (size_t)N_ * sizeof(int), hipMemcpyHostToDevice, s));
     m_used_ = build_obs_graph(ctx_, ws->og, N_, P_, M_, h_off, ws->off.get(), ws->cam.get(),
@@ -1138,6 +1167,8 @@ class BaSolver final : public LmProblem {
     if (joint_) {
       ws->scross.ensure(48 * (size_t)N_);
       ws->minvj.ensure(196 * (size_t)N_);
+      ws->zrec.ensure((size_t)(6 + F_) * N_ + 2);
+      GSFM_HIP_CHECK(hipMemsetAsync(ws->zrec.get(), 0, ((size_t)(6 + F_) * N_ + 2) * sizeof(double), s));
     }
     ws->ipart.ensure(44 * (size_t)N_);
     ws->yi_part.ensure(8 * (size_t)N_);
@@ -1169,6 +1200,7 @@ class BaSolver final : public LmProblem {
     g_.ioff = ws->ioff.get();
     g_.icams = ws->icams.get();
     g_.obs_ik = ws->obs_ik.get();
+    g_.zrec = joint_ ? ws->zrec.get() : nullptr;
     g_.fixed_cam = prob->fixed_cam;
     g_.opt_rot = opt_.optimize_rotations ? 1 : 0;
     g_.opt_trn = opt_.optimize_translation ? 1 : 0;
@@ -1188,7 +1220,10 @@ class BaSolver final : public LmProblem {
     cg_.n = n_;
     cg_.N = N_;
     cg_.K = K_;
-    cg_.nb_update = std::min(kCgMaxBlocks, grid_for(joint_ ? N_ : N_ + K_, kBlock));
+    cg_.nb_update = joint_ ? std::min(kCgMaxBlocks, grid_for(N_, kJointCams)) : std::min(kCgMaxBlocks, grid_for(N_ + K_, kBlock));
+    cg_.zrec = joint_ ? ws->zrec.get() : nullptr;
+    cg_.zrec_stride = 6 + F_;
+    cg_.zrec_slot = joint_ ? ws->intr_slot.get() : nullptr;
     cg_.joint_map = joint_ ? ws->cam_intr.get() : nullptr;
     cg_.minv_joint = joint_ ? ws->minvj.get() : nullptr;
     cg_.nb_apply = gridCam_ + gridK_;

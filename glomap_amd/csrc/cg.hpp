@@ -69,6 +69,12 @@ struct CgVec {
   // minv_joint[(i * BJ + j) * N + n], so that one thread per camera reads it fully coalesced.
   const int* joint_map = nullptr;
   const double* minv_joint = nullptr;
+  // joint mode only: per-camera gather record of phase A, zrec[n * zrec_stride + (0..PB-1 | PB + column)]
+  // = z of the pose and of the FREE intrinsics of camera n in stored-column order;
+  // zrec_slot[8 k + param] = stored column of that parameter of intrinsics block k, or -1
+  double* zrec = nullptr;
+  int zrec_stride = 0;
+  const signed char* zrec_slot = nullptr;
 };
 
 template <int BS>
@@ -247,26 +253,55 @@ __device__ __forceinline__ void cg_joint_precond(const CgVec& v, int n, const do
   }
 }
 
+// Joint kernels: 16 lanes per camera (PB + 8 <= 16 active), 16 cameras per workgroup.  Lane (c, i)
+// owns element i of camera c's joint block; the preconditioner row product reads the block's
+// residual from LDS.  minv_joint[(i * BJ + j) * N + n]: for a fixed (i, j) the 16 cameras of a
+// workgroup read 16 consecutive doubles.
+constexpr int kJointCams = kBlock / 16;
+
+template <int PB>
+__device__ __forceinline__ void cg_joint_mirror(const CgVec& v, int n, int i, double zi) {
+  if (v.zrec == nullptr) return;
+  if (i < PB) {
+    v.zrec[(long)n * v.zrec_stride + i] = zi;
+  } else {
+    const int slot = v.zrec_slot[8 * v.joint_map[n] + (i - PB)];
+    if (slot >= 0) v.zrec[(long)n * v.zrec_stride + PB + slot] = zi;
+  }
+}
+
 template <int PB>
 static __global__ void __launch_bounds__(kBlock) k_cg_init_joint(CgVec v) {
   constexpr int BJ = PB + 8;
   __shared__ double smem[4 * 2];
+  __shared__ double sr[kJointCams][16];
+  const int c = threadIdx.x >> 4, i = threadIdx.x & 15;
   double acc[2] = {0.0, 0.0};
-  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < v.N; n += gridDim.x * blockDim.x) {
-    double rb[BJ], zb[BJ];
+  for (int n0 = blockIdx.x * kJointCams; n0 < v.N; n0 += gridDim.x * kJointCams) {
+    const int n = n0 + c;
+    const bool act = n < v.N && i < BJ;
+    long o = 0;
+    double ri = 0.0;
+    if (act) {
+      o = cg_joint_index<PB>(v, n, i);
+      ri = v.b[o];
+    }
+    __syncthreads();
+    sr[c][i] = ri;
+    __syncthreads();
+    if (act) {
+      const double* m = v.minv_joint + n;
+      double zi = 0.0;
 #pragma unroll
-    for (int i = 0; i < BJ; ++i) rb[i] = v.b[cg_joint_index<PB>(v, n, i)];
-    cg_joint_precond<PB>(v, n, rb, zb);
-#pragma unroll
-    for (int i = 0; i < BJ; ++i) {
-      const long o = cg_joint_index<PB>(v, n, i);
+      for (int j = 0; j < BJ; ++j) zi += m[(size_t)(i * BJ + j) * v.N] * sr[c][j];
       v.x[o] = 0.0;
-      v.r[o] = rb[i];
-      v.z[o] = zb[i];
+      v.r[o] = ri;
+      v.z[o] = zi;
       v.p[o] = 0.0;
       v.s[o] = 0.0;
-      acc[0] += rb[i] * zb[i];
-      acc[1] += rb[i] * rb[i];
+      cg_joint_mirror<PB>(v, n, i, zi);
+      acc[0] += ri * zi;
+      acc[1] += ri * ri;
     }
   }
   block_sum<2>(acc, smem);
@@ -289,6 +324,7 @@ template <int PB>
 static __global__ void __launch_bounds__(kBlock) k_cg_update_joint(CgVec v, int it) {
   constexpr int BJ = PB + 8;
   __shared__ double smem[4 * 2 + 2];
+  __shared__ double sr[kJointCams][16];
   if (v.st->done) return;
   double g[2];
   reduce_partials<2>(v.vpart + (size_t)(it & 1) * kCgMaxBlocks * 2, v.nb_update, g, smem);
@@ -311,26 +347,35 @@ static __global__ void __launch_bounds__(kBlock) k_cg_update_joint(CgVec v, int 
   const double alpha = ok ? gamma / denom : 0.0;
   if (!ok) beta = 0.0;
   double acc[2] = {0.0, 0.0};
+  const int c = threadIdx.x >> 4, i = threadIdx.x & 15;
   if (ok) {
-    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < v.N; n += gridDim.x * blockDim.x) {
-      double rn[BJ], zn[BJ];
-#pragma unroll
-      for (int i = 0; i < BJ; ++i) {
-        const long o = cg_joint_index<PB>(v, n, i);
+    for (int n0 = blockIdx.x * kJointCams; n0 < v.N; n0 += gridDim.x * kJointCams) {
+      const int n = n0 + c;
+      const bool act = n < v.N && i < BJ;
+      long o = 0;
+      double ri = 0.0;
+      if (act) {
+        o = cg_joint_index<PB>(v, n, i);
         const double pi = v.z[o] + beta * v.p[o];
         const double si = v.w[o] + beta * v.s[o];
         v.p[o] = pi;
         v.s[o] = si;
         v.x[o] += alpha * pi;
-        rn[i] = v.r[o] - alpha * si;
-        v.r[o] = rn[i];
-        acc[1] += rn[i] * rn[i];
+        ri = v.r[o] - alpha * si;
+        v.r[o] = ri;
+        acc[1] += ri * ri;
       }
-      cg_joint_precond<PB>(v, n, rn, zn);
+      __syncthreads();
+      sr[c][i] = ri;
+      __syncthreads();
+      if (act) {
+        const double* m = v.minv_joint + n;
+        double zi = 0.0;
 #pragma unroll
-      for (int i = 0; i < BJ; ++i) {
-        v.z[cg_joint_index<PB>(v, n, i)] = zn[i];
-        acc[0] += rn[i] * zn[i];
+        for (int j = 0; j < BJ; ++j) zi += m[(size_t)(i * BJ + j) * v.N] * sr[c][j];
+        v.z[o] = zi;
+        cg_joint_mirror<PB>(v, n, i, zi);
+        acc[0] += ri * zi;
       }
     }
   }
