@@ -37,6 +37,7 @@ struct CgStatus {
   int pad;
   double bb;  // |b|^2
   double rr;  // |r|^2 of the last tested iterate
+  double gamma;  // single-workgroup mode: r.z of the current iterate
 };
 struct CgScal {
   double gamma;  // r.z of the previous iteration
@@ -51,6 +52,9 @@ struct CgVec {
   int nb_update = 1;  // grid of k_cg_init / k_cg_update  (<= kCgMaxBlocks)
   int nb_apply = 0;   // number of delta partial slots written by `apply`
   int delta_in_w = 0; // multi-rank: delta was all-reduced into w[n]
+  int single = 0;     // small systems: the vector update runs in ONE 1024-thread workgroup (k_cg_*1) that
+                      // also owns every scalar and the convergence flag — no partial slots to re-reduce
+  double tol2 = 0.0;  // squared relative tolerance (single mode: tested inside k_cg_update1)
   const double* b = nullptr;
   double *x = nullptr, *r = nullptr, *z = nullptr, *p = nullptr, *s = nullptr;
   double* w = nullptr;         // [n + 2]
@@ -133,9 +137,26 @@ static __global__ void __launch_bounds__(kBlock) k_cg_init(CgVec v) {
 // To be called by ALL threads of EVERY block at the top of the first apply kernel of iteration
 // `it` (kBlock threads).  Returns true when the solve is finished (the caller returns).
 __device__ __forceinline__ bool cg_converged(const CgVec& v, int it, double tol2, double* smem /* >= 4*2+2 */) {
-  if (v.st->done) return true;
-  double t[2];
-  reduce_partials<2>(v.vpart + (size_t)(it & 1) * kCgMaxBlocks * 2, v.nb_update, t, smem);
+  if (v.single) return v.st->done != 0;  // k_cg_init1 / k_cg_update1 already tested |r| and raised `done`
+  double t[2] = {0.0, 0.0};
+  {
+    const double* vp = v.vpart + (size_t)(it & 1) * kCgMaxBlocks * 2;
+    for (int b = threadIdx.x; b < v.nb_update; b += blockDim.x) {  // issued before the `done` round trip
+      t[0] += vp[2 * b];
+      t[1] += vp[2 * b + 1];
+    }
+  }
+  const int done0 = v.st->done;
+  if (done0) return true;
+  block_sum<2>(t, smem);
+  if (threadIdx.x == 0) {
+    smem[8] = t[0];
+    smem[9] = t[1];
+  }
+  __syncthreads();
+  t[0] = smem[8];
+  t[1] = smem[9];
+  __syncthreads();
   const double bb = it == 0 ? t[1] : v.st->bb;
   const bool finite = isfinite(t[0]) && isfinite(t[1]);
   const bool done = !finite || t[1] <= tol2 * bb;
@@ -180,20 +201,33 @@ __device__ __forceinline__ void cg_block_update(const CgVec& v, long o, const do
 // One CG iteration given w = A z (complete) and the delta partials.
 template <int PB, bool HAS_INTR>
 static __global__ void __launch_bounds__(kBlock) k_cg_update(CgVec v, int it) {
-  __shared__ double smem[4 * 2 + 2];
-  if (v.st->done) return;
-  double g[2];
-  reduce_partials<2>(v.vpart + (size_t)(it & 1) * kCgMaxBlocks * 2, v.nb_update, g, smem);
-  double delta;
-  if (v.delta_in_w) {
-    delta = v.w[v.n];
-  } else {
-    double d[1];
-    reduce_partials<1>(v.dpart, v.nb_apply, d, smem);
-    delta = d[0];
+  __shared__ double smem[4 * 3 + 3];
+  // one pass over both sets of partial slots (r.z | r.r of the previous update, delta of this apply);
+  // the loads are issued before the `done` test so that they overlap its round trip
+  double t3[3] = {0.0, 0.0, 0.0};
+  {
+    const double* vp = v.vpart + (size_t)(it & 1) * kCgMaxBlocks * 2;
+    for (int b = threadIdx.x; b < v.nb_update; b += blockDim.x) {
+      t3[0] += vp[2 * b];
+      t3[1] += vp[2 * b + 1];
+    }
+    if (!v.delta_in_w)
+      for (int b = threadIdx.x; b < v.nb_apply; b += blockDim.x) t3[2] += v.dpart[b];
   }
-  const double gamma = g[0];
   const CgScal prev = v.scal[it & 1];
+  const int done = v.st->done;
+  if (done) return;
+  __shared__ double sbc[3];
+  block_sum<3>(t3, smem);
+  if (threadIdx.x == 0) {
+    sbc[0] = t3[0];
+    sbc[1] = t3[1];
+    sbc[2] = t3[2];
+  }
+  __syncthreads();
+  const double gamma = sbc[0];
+  const double delta = v.delta_in_w ? v.w[v.n] : sbc[2];
+  __syncthreads();
   double beta = 0.0, denom = delta;
   if (it > 0) {
     beta = prev.gamma > 0.0 ? gamma / prev.gamma : 0.0;
@@ -234,6 +268,105 @@ static __global__ void __launch_bounds__(kBlock) k_cg_update(CgVec v, int it) {
   }
 }
 
+
+
+// ---- single-workgroup vector kernels (small systems: RA node vectors, GP with few thousand cameras) ----
+constexpr int kCgSingleThreads = 1024;
+constexpr int kCgSingleMaxBlocks = 1024;  // block-Jacobi blocks handled by one workgroup (one CU's bandwidth beyond that)
+
+template <int K>
+__device__ __forceinline__ void block_sum_1024(double (&v)[K], double* smem /* >= 16 K + K */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) smem[wave * K + k] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = blockDim.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      double t = 0.0;
+      for (int w = 0; w < nw; ++w) t += smem[w * K + k];
+      smem[16 * K + k] = t;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = smem[16 * K + k];
+  __syncthreads();
+}
+
+template <int PB>
+static __global__ void __launch_bounds__(kCgSingleThreads) k_cg_init1(CgVec v) {
+  __shared__ double smem[16 * 2 + 2];
+  double acc[2] = {0.0, 0.0};
+  for (int b = threadIdx.x; b < v.N; b += blockDim.x)
+    cg_block_init<PB>(v, (long)PB * b, v.minv + (long)PB * PB * b, acc[0], acc[1],
+                      v.zmir ? v.zmir + (long)b * v.zmir_stride + v.zmir_off : nullptr);
+  block_sum_1024<2>(acc, smem);
+  if (threadIdx.x == 0) {
+    v.st->done = (acc[1] == 0.0 || !isfinite(acc[1])) ? 1 : 0;
+    v.st->iters = 0;
+    v.st->bad = isfinite(acc[1]) ? 0 : 1;
+    v.st->bb = acc[1];
+    v.st->rr = acc[1];
+    v.st->gamma = acc[0];
+    v.scal[0].gamma = 0.0;
+    v.scal[0].alpha = 0.0;
+  }
+}
+
+template <int PB>
+static __global__ void __launch_bounds__(kCgSingleThreads) k_cg_update1(CgVec v, int it) {
+  __shared__ double smem[16 * 2 + 2];
+  if (v.st->done) return;
+  double d[1] = {0.0};
+  if (v.delta_in_w) {
+    d[0] = v.w[v.n];
+  } else {
+    for (int b = threadIdx.x; b < v.nb_apply; b += blockDim.x) d[0] += v.dpart[b];
+    block_sum_1024<1>(d, smem);
+  }
+  const double delta = d[0];
+  const double gamma = v.st->gamma;
+  const double bb = v.st->bb;
+  const CgScal prev = v.scal[it & 1];
+  __syncthreads();  // everyone has read the scalars thread 0 rewrites below
+  double beta = 0.0, denom = delta;
+  if (it > 0) {
+    beta = prev.gamma > 0.0 ? gamma / prev.gamma : 0.0;
+    denom = delta - beta * gamma / prev.alpha;
+  }
+  const bool ok = isfinite(denom) && denom > 0.0 && isfinite(gamma) && gamma >= 0.0;
+  const double alpha = ok ? gamma / denom : 0.0;
+  double acc[2] = {0.0, 0.0};
+  if (ok) {
+    for (int b = threadIdx.x; b < v.N; b += blockDim.x)
+      cg_block_update<PB>(v, (long)PB * b, v.minv + (long)PB * PB * b, alpha, beta, acc[0], acc[1],
+                          v.zmir ? v.zmir + (long)b * v.zmir_stride + v.zmir_off : nullptr);
+  }
+  block_sum_1024<2>(acc, smem);
+  if (threadIdx.x == 0) {
+    v.scal[(it + 1) & 1].gamma = gamma;
+    v.scal[(it + 1) & 1].alpha = alpha;
+    if (!ok) {
+      if (!(gamma == 0.0 && isfinite(delta))) v.st->bad = 1;
+      v.st->done = 1;
+      v.st->iters = it;
+    } else {
+      const bool finite = isfinite(acc[0]) && isfinite(acc[1]);
+      v.st->gamma = acc[0];
+      v.st->rr = acc[1];
+      v.st->iters = it + 1;
+      if (!finite) v.st->bad = 1;
+      if (!finite || acc[1] <= v.tol2 * bb) v.st->done = 1;
+    }
+  }
+}
 
 // ---- joint (pose + intrinsics) blocks ----------------------------------------------------------
 template <int PB>
@@ -413,10 +546,14 @@ inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& 
   const bool multi = ctx->comm.world > 1;
   v.delta_in_w = multi ? 1 : 0;
   const bool joint = HAS_INTR && v.joint_map != nullptr;
+  v.tol2 = tol * tol;
+  v.single = (!HAS_INTR && v.N <= kCgSingleMaxBlocks) ? 1 : 0;
   if constexpr (HAS_INTR) {
     if (joint) hipLaunchKernelGGL((k_cg_init_joint<PB>), dim3(v.nb_update), dim3(kBlock), 0, s, v);
+  } else {
+    if (v.single) hipLaunchKernelGGL((k_cg_init1<PB>), dim3(1), dim3(kCgSingleThreads), 0, s, v);
   }
-  if (!joint) hipLaunchKernelGGL((k_cg_init<PB, HAS_INTR>), dim3(v.nb_update), dim3(kBlock), 0, s, v);
+  if (!joint && !v.single) hipLaunchKernelGGL((k_cg_init<PB, HAS_INTR>), dim3(v.nb_update), dim3(kBlock), 0, s, v);
   CgStatus* h = reinterpret_cast<CgStatus*>(ctx->h_pinned + 400);
   const int chunk = 8;
   for (int it = 0; it < max_iter; ++it) {
@@ -427,8 +564,10 @@ inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& 
     }
     if constexpr (HAS_INTR) {
       if (joint) hipLaunchKernelGGL((k_cg_update_joint<PB>), dim3(v.nb_update), dim3(kBlock), 0, s, v, it);
+    } else {
+      if (v.single) hipLaunchKernelGGL((k_cg_update1<PB>), dim3(1), dim3(kCgSingleThreads), 0, s, v, it);
     }
-    if (!joint) hipLaunchKernelGGL((k_cg_update<PB, HAS_INTR>), dim3(v.nb_update), dim3(kBlock), 0, s, v, it);
+    if (!joint && !v.single) hipLaunchKernelGGL((k_cg_update<PB, HAS_INTR>), dim3(v.nb_update), dim3(kBlock), 0, s, v, it);
     if ((it + 1) % chunk == 0 || it == max_iter - 1) {
       GSFM_HIP_CHECK(hipMemcpyAsync(h, v.st, sizeof(CgStatus), hipMemcpyDeviceToHost, s));
       GSFM_HIP_CHECK(hipStreamSynchronize(s));

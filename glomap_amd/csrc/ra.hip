@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <numeric>
 
+#include "cg.hpp"
 #include "device.hpp"
 #include "ra_dense.hpp"
 
@@ -243,213 +244,53 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
-// ---- Jacobi-PCG with three independent right-hand sides (columns) ----------------------------
-// Device-resident scalars: no host round trip per iteration.  Per iteration two kernels:
-//   K1 (k_pcg_dir):  beta_c = rz_new/rz_old;  q = A z + beta q;  p = z + beta p;  partial p.q
-//   K2 (k_pcg_step): alpha_c = rz/pq;  x += alpha p;  r -= alpha q;  z = r/diag;  partial r.z, r.r
-// (q = A p follows from linearity: A(z + beta p_old) = A z + beta q_old.)
-// Partial sums go to per-block slots, double-buffered by iteration parity; each consumer block
-// re-reduces them in fixed order (device.hpp).  K1 sets status->done once |r_c| <= tol |b_c| for
-// all three columns; every later kernel of the chunk then exits at once.
-struct PcgStatus {
-  int done;
-  int iters;
-  double bb[3];
-};
-
-__global__ void __launch_bounds__(kBlock)
-    k_pcg_init(int N, const double* __restrict__ rhs, const double* __restrict__ Ax0,
-               const double* __restrict__ lap_diag, double* __restrict__ x, double* __restrict__ r,
-               double* __restrict__ zv, double* __restrict__ p, double* __restrict__ q,
-               double* __restrict__ part2 /* parity 1 slot: [grid][6] */,
-               double* __restrict__ part0 /* [grid][3] */, PcgStatus* __restrict__ status) {
-  __shared__ double smem[4 * 9];
-  double acc[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) acc[k] = 0.0;
-  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
-    const double dinv = 1.0 / lap_diag[n];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const long i = 3 * (long)n + c;
-      const double b = rhs[i];
-      double rr = b;
-      if (Ax0 != nullptr) {
-        rr -= Ax0[i];
-      } else {
-        x[i] = 0.0;
-      }
-      const double zz = rr * dinv;
-      r[i] = rr;
-      zv[i] = zz;
-      p[i] = 0.0;
-      q[i] = 0.0;
-      acc[c] += rr * zz;
-      acc[3 + c] += rr * rr;
-      acc[6 + c] += b * b;
-    }
-  }
-  block_sum<9>(acc, smem);
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) part2[blockIdx.x * 6 + k] = acc[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) part0[blockIdx.x * 3 + k] = acc[6 + k];
-    if (blockIdx.x == 0) {
-      status->done = 0;
-      status->iters = 0;
-    }
-  }
-}
-
-// Shared prologue of K1: totals of the newest r.z / r.r partials, convergence test, beta.
-// Returns true when the solve is finished (caller must return).  nb2 = grid of the producer.
-__device__ __forceinline__ bool pcg_dir_prologue(const double* __restrict__ part2_new,
-                                                 const double* __restrict__ part2_old,
-                                                 const double* __restrict__ part0, int nb2, int first,
-                                                 int it, double tol2, PcgStatus* __restrict__ status,
-                                                 double* smem, double (&beta)[3]) {
-  if (status->done) return true;
-  double tn[6];
-  reduce_partials<6>(part2_new, nb2, tn, smem);
-  double bb[3];
-  if (first) {
-    reduce_partials<3>(part0, nb2, bb, smem);
-  } else {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) bb[c] = status->bb[c];
-  }
-  bool done = true;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) done = done && (tn[3 + c] <= tol2 * bb[c]);
-  if (first) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) beta[c] = 0.0;
-  } else {
-    double to[6];
-    reduce_partials<6>(part2_old, nb2, to, smem);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) beta[c] = to[c] > 0.0 ? tn[c] / to[c] : 0.0;
-  }
-  // All blocks agree on `done` (bit-identical reductions).  Block 0 publishes it for the kernels
-  // that follow; nobody reads status->done/bb again inside this launch after this point.
-  __syncthreads();
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (first) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) status->bb[c] = bb[c];
-    }
-    if (done) {
-      status->done = 1;
-      status->iters = it;
-    }
-  }
-  return done;
-}
-
+// ---- Jacobi-PCG (cg.hpp) on the 3N system  (L_w (x) I3 + gauge) x = rhs ---------------------------
+// The three right-hand sides share the operator, so they are solved as ONE SPD system of 3N unknowns
+// (block-diagonal in the column index) with the single-reduction PCG of cg.hpp: per iteration the
+// SpMV below (w = A z and this block's share of delta = z.w) and k_cg_update<3, false> whose 3 x 3
+// "camera blocks" are the Jacobi preconditioner diag(1/d_n) I3.  With edges sharded over ranks the
+// driver all-reduces w; the diagonal used here is then the LOCAL one (lap_diag_loc).
 template <int LPR>
 __global__ void __launch_bounds__(kBlock)
-    k_pcg_dir_fused(int N, const int* __restrict__ rowptr, const int* __restrict__ nbr,
-                    const double* __restrict__ inc_w, const double* __restrict__ lap_diag,
-                    const double* __restrict__ zv, double* __restrict__ p, double* __restrict__ q,
-                    const double* __restrict__ part2_new, const double* __restrict__ part2_old,
-                    const double* __restrict__ part0, int nb2, double* __restrict__ part1, int first,
-                    int it, double tol2, PcgStatus* __restrict__ status) {
-  __shared__ double smem[4 * 6 + 6];
-  double beta[3];
-  if (pcg_dir_prologue(part2_new, part2_old, part0, nb2, first, it, tol2, status, smem, beta)) return;
+    k_ra_apply(int N, const int* __restrict__ rowptr, const int* __restrict__ nbr,
+               const double* __restrict__ inc_w, const double* __restrict__ lap_diag_loc, CgVec v, int it,
+               double tol2) {
+  __shared__ double smem[4 * 2 + 2];
+  if (cg_converged(v, it, tol2, smem)) return;
   const int gpb = kBlock / LPR;
   const int g = threadIdx.x / LPR, l = threadIdx.x % LPR;
-  double acc[3] = {0.0, 0.0, 0.0};
+  double acc[1] = {0.0};
   for (int n = blockIdx.x * gpb + g; n < N; n += gridDim.x * gpb) {
     double w0, w1, w2;
-    laplacian_row<LPR>(n, l, rowptr, nbr, inc_w, lap_diag, zv, w0, w1, w2);
+    laplacian_row<LPR>(n, l, rowptr, nbr, inc_w, lap_diag_loc, v.z, w0, w1, w2);
     if (l == 0) {
       const long i = 3 * (long)n;
-      const double q0 = w0 + beta[0] * q[i], q1 = w1 + beta[1] * q[i + 1], q2 = w2 + beta[2] * q[i + 2];
-      const double p0 = zv[i] + beta[0] * p[i], p1 = zv[i + 1] + beta[1] * p[i + 1],
-                   p2 = zv[i + 2] + beta[2] * p[i + 2];
-      q[i] = q0;
-      q[i + 1] = q1;
-      q[i + 2] = q2;
-      p[i] = p0;
-      p[i + 1] = p1;
-      p[i + 2] = p2;
-      acc[0] += p0 * q0;
-      acc[1] += p1 * q1;
-      acc[2] += p2 * q2;
+      v.w[i] = w0;
+      v.w[i + 1] = w1;
+      v.w[i + 2] = w2;
+      acc[0] += v.z[i] * w0 + v.z[i + 1] * w1 + v.z[i + 2] * w2;
     }
   }
-  block_sum<3>(acc, smem);
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) part1[blockIdx.x * 3 + c] = acc[c];
+  block_sum<1>(acc, smem);
+  if (threadIdx.x == 0) v.dpart[blockIdx.x] = acc[0];
+}
+
+// Jacobi preconditioner as 3 x 3 blocks for cg.hpp: minv[n] = (1 / d_n) I3
+__global__ void __launch_bounds__(kBlock)
+    k_ra_minv(int N, const double* __restrict__ lap_diag, double* __restrict__ minv) {
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+    const double di = 1.0 / lap_diag[n];
+    double* m = minv + 9 * (long)n;
+    m[0] = di; m[1] = 0; m[2] = 0;
+    m[3] = 0; m[4] = di; m[5] = 0;
+    m[6] = 0; m[7] = 0; m[8] = di;
   }
 }
 
-// Split form of K1 for the multi-rank path: wbuf = all-reduced A z.
+// x = x0 + dx
 __global__ void __launch_bounds__(kBlock)
-    k_pcg_dir_split(int N, const double* __restrict__ wbuf, const double* __restrict__ zv,
-                    double* __restrict__ p, double* __restrict__ q,
-                    const double* __restrict__ part2_new, const double* __restrict__ part2_old,
-                    const double* __restrict__ part0, int nb2, double* __restrict__ part1, int first,
-                    int it, double tol2, PcgStatus* __restrict__ status) {
-  __shared__ double smem[4 * 6 + 6];
-  double beta[3];
-  if (pcg_dir_prologue(part2_new, part2_old, part0, nb2, first, it, tol2, status, smem, beta)) return;
-  double acc[3] = {0.0, 0.0, 0.0};
-  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const long i = 3 * (long)n + c;
-      const double qq = wbuf[i] + beta[c] * q[i];
-      const double pp = zv[i] + beta[c] * p[i];
-      q[i] = qq;
-      p[i] = pp;
-      acc[c] += pp * qq;
-    }
-  }
-  block_sum<3>(acc, smem);
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) part1[blockIdx.x * 3 + c] = acc[c];
-  }
-}
-
-__global__ void __launch_bounds__(kBlock)
-    k_pcg_step(int N, const double* __restrict__ lap_diag, double* __restrict__ x,
-               double* __restrict__ r, double* __restrict__ zv, const double* __restrict__ p,
-               const double* __restrict__ q, const double* __restrict__ part1, int nb1,
-               const double* __restrict__ part2_cur, int nb2, double* __restrict__ part2_out,
-               const PcgStatus* __restrict__ status) {
-  __shared__ double smem[4 * 6 + 6];
-  if (status->done) return;
-  double pq[3], rz[6];
-  reduce_partials<3>(part1, nb1, pq, smem);
-  reduce_partials<6>(part2_cur, nb2, rz, smem);
-  double alpha[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) alpha[c] = pq[c] > 0.0 ? rz[c] / pq[c] : 0.0;
-  double acc[6] = {0, 0, 0, 0, 0, 0};
-  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
-    const double dinv = 1.0 / lap_diag[n];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const long i = 3 * (long)n + c;
-      x[i] += alpha[c] * p[i];
-      const double rr = r[i] - alpha[c] * q[i];
-      const double zz = rr * dinv;
-      r[i] = rr;
-      zv[i] = zz;
-      acc[c] += rr * zz;
-      acc[3 + c] += rr * rr;
-    }
-  }
-  block_sum<6>(acc, smem);
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) part2_out[blockIdx.x * 6 + k] = acc[k];
-  }
+    k_ra_add(long n, const double* x0, const double* __restrict__ dx, double* x) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] = x0[i] + dx[i];
 }
 
 // r_n <- Log(Exp(r_n) Exp(-delta_n)) (gra.cc:635-640) + the per-iteration scalars:
@@ -605,8 +446,9 @@ struct RaWs {
   DevBuf<int> ei, ej, rowptr, inc, nbr, inc_row, flags;
   DevBuf<double> dense_a, dense_b, dense_pinv;
   DevBuf<double> eq, ew, inc_w, lap_diag, lap_diag_loc, rot, nq, res, wirls, z, u, dz, rhs, x, r, p, q, zv, wbuf,
-      gat_s, gat_t, fixed_rot0, part0, part1, part2, part_misc, scal;
-  DevBuf<PcgStatus> status;
+      gat_s, gat_t, fixed_rot0, part_misc, scal, cg_b, cg_x, cg_r, cg_z, cg_p, cg_s, cg_w, cg_minv, vpart, dpart;
+  DevBuf<CgStatus> cgst;
+  DevBuf<CgScal> cgsc;
   static void destroy(void* p) { delete static_cast<RaWs*>(p); }
 };
 
@@ -832,65 +674,48 @@ int pcg_solve(RaDevice& d, bool warm, double tol, int max_iter) {
   gsfm_ctx* ctx = d.ctx;
   hipStream_t s = ctx->stream;
   const int N = d.N;
-  const bool multi = ctx->comm.world > 1;
-  double* part2[2] = {ws->part2.get(), ws->part2.get() + kMaxBlocks * 6};
-  double* part1[2] = {ws->part1.get(), ws->part1.get() + kMaxBlocks * 3};
-  const int gN = d.gridN, gR = d.gridRow;
-  const double* Ax0 = nullptr;
+  const long n3 = 3L * N;
+  // warm start: solve A dx = rhs - A x0 and add (the ADMM iterates of one L1 solve are close)
+  const double* b = ws->rhs.get();
   if (warm) {
     dispatch_lpr(d.lpr, [&](auto L) {
-      hipLaunchKernelGGL((k_spmv<decltype(L)::value>), dim3(gR), dim3(kBlock), 0, s, N, ws->rowptr.get(),
+      hipLaunchKernelGGL((k_spmv<decltype(L)::value>), dim3(d.gridRow), dim3(kBlock), 0, s, N, ws->rowptr.get(),
                          ws->nbr.get(), ws->inc_w.get(), ws->lap_diag_loc.get(), ws->x.get(), ws->wbuf.get());
     });
-    allreduce_sum(ctx, ws->wbuf.get(), 3 * (size_t)N);
-    Ax0 = ws->wbuf.get();
+    allreduce_sum(ctx, ws->wbuf.get(), (size_t)n3);
+    hipLaunchKernelGGL(k_dense_residual, dim3(d.gridN), dim3(kBlock), 0, s, n3, ws->rhs.get(), ws->wbuf.get(), ws->cg_b.get());
+    b = ws->cg_b.get();
   }
-  hipLaunchKernelGGL(k_pcg_init, dim3(gN), dim3(kBlock), 0, s, N, ws->rhs.get(), Ax0, ws->lap_diag.get(),
-                     ws->x.get(), ws->r.get(), ws->zv.get(), ws->p.get(), ws->q.get(), part2[1],
-                     ws->part0.get(), ws->status.get());
-  const double tol2 = tol * tol;
-  int* h_status = reinterpret_cast<int*>(ctx->h_pinned);
-  const int chunk = 16;
-  int it = 0;
-  for (; it < max_iter; ++it) {
-    const int par = it & 1;
-    const double* p2new = part2[par ^ 1];
-    const double* p2old = part2[par];
-    const int first = it == 0;
-    if (!multi) {
-      const bool timed = ctx->prof.begin(s, GSFM_KERNEL_RA_LAPLACIAN);
-      dispatch_lpr(d.lpr, [&](auto L) {
-        hipLaunchKernelGGL((k_pcg_dir_fused<decltype(L)::value>), dim3(gR), dim3(kBlock), 0, s, N,
-                           ws->rowptr.get(), ws->nbr.get(), ws->inc_w.get(), ws->lap_diag.get(),
-                           ws->zv.get(), ws->p.get(), ws->q.get(), p2new, p2old, ws->part0.get(), gN,
-                           part1[par], first, it, tol2, ws->status.get());
-      });
-      if (timed) ctx->prof.end(s);
-      hipLaunchKernelGGL(k_pcg_step, dim3(gN), dim3(kBlock), 0, s, N, ws->lap_diag.get(), ws->x.get(),
-                         ws->r.get(), ws->zv.get(), ws->p.get(), ws->q.get(), part1[par], gR, p2new, gN,
-                         part2[par], ws->status.get());
-    } else {
-      dispatch_lpr(d.lpr, [&](auto L) {
-        hipLaunchKernelGGL((k_spmv<decltype(L)::value>), dim3(gR), dim3(kBlock), 0, s, N, ws->rowptr.get(),
-                           ws->nbr.get(), ws->inc_w.get(), ws->lap_diag_loc.get(), ws->zv.get(), ws->wbuf.get());
-      });
-      allreduce_sum(ctx, ws->wbuf.get(), 3 * (size_t)N);
-      hipLaunchKernelGGL(k_pcg_dir_split, dim3(gN), dim3(kBlock), 0, s, N, ws->wbuf.get(), ws->zv.get(),
-                         ws->p.get(), ws->q.get(), p2new, p2old, ws->part0.get(), gN, part1[par], first, it,
-                         tol2, ws->status.get());
-      hipLaunchKernelGGL(k_pcg_step, dim3(gN), dim3(kBlock), 0, s, N, ws->lap_diag.get(), ws->x.get(),
-                         ws->r.get(), ws->zv.get(), ws->p.get(), ws->q.get(), part1[par], gN, p2new, gN,
-                         part2[par], ws->status.get());
-    }
-    if ((it + 1) % chunk == 0 || it + 1 == max_iter) {
-      GSFM_HIP_CHECK(hipMemcpyAsync(h_status, ws->status.get(), 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-      GSFM_HIP_CHECK(hipStreamSynchronize(s));
-      GSFM_HIP_CHECK(hipGetLastError());
-      ctx->prof.harvest();
-      if (h_status[0]) return h_status[1];
-    }
-  }
-  return max_iter;
+  hipLaunchKernelGGL(k_ra_minv, dim3(d.gridN), dim3(kBlock), 0, s, N, ws->lap_diag.get(), ws->cg_minv.get());
+  CgVec v;
+  v.n = (int)n3;
+  v.N = N;
+  v.K = 0;
+  v.nb_update = std::min(kCgMaxBlocks, grid_for(N, kBlock));
+  const int gA = grid_wide(N, kBlock / d.lpr, kMaxApplySlots);
+  v.nb_apply = gA;
+  v.b = b;
+  v.x = warm ? ws->cg_x.get() : ws->x.get();
+  v.r = ws->cg_r.get();
+  v.z = ws->cg_z.get();
+  v.p = ws->cg_p.get();
+  v.s = ws->cg_s.get();
+  v.w = ws->cg_w.get();
+  v.minv = ws->cg_minv.get();
+  v.vpart = ws->vpart.get();
+  v.dpart = ws->dpart.get();
+  v.scal = ws->cgsc.get();
+  v.st = ws->cgst.get();
+  const long iters = cg_solve<3, false>(ctx, v, tol, max_iter, [&](int it) {
+    const bool timed = ctx->prof.begin(s, GSFM_KERNEL_RA_LAPLACIAN);
+    dispatch_lpr(d.lpr, [&](auto L) {
+      hipLaunchKernelGGL((k_ra_apply<decltype(L)::value>), dim3(gA), dim3(kBlock), 0, s, N, ws->rowptr.get(),
+                         ws->nbr.get(), ws->inc_w.get(), ws->lap_diag_loc.get(), v, it, tol * tol);
+    });
+    if (timed) ctx->prof.end(s);
+  });
+  if (warm) hipLaunchKernelGGL(k_ra_add, dim3(d.gridN), dim3(kBlock), 0, s, n3, ws->x.get(), ws->cg_x.get(), ws->x.get());
+  return (int)iters;
 }
 
 void launch_residuals(RaDevice& d, bool with_weights, int weight_type, double sigma2) {
@@ -984,12 +809,16 @@ void setup_device(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
   ws->lap_diag_loc.ensure(N);
   for (DevBuf<double>* b : {&ws->rhs, &ws->x, &ws->r, &ws->p, &ws->q, &ws->zv, &ws->wbuf, &ws->gat_s, &ws->gat_t})
     b->ensure(3 * (size_t)N);
-  ws->part0.ensure(kMaxBlocks * 3);
-  ws->part1.ensure(2 * kMaxBlocks * 3);
-  ws->part2.ensure(2 * kMaxBlocks * 6);
+  for (DevBuf<double>* b : {&ws->cg_b, &ws->cg_x, &ws->cg_r, &ws->cg_z, &ws->cg_p, &ws->cg_s})
+    b->ensure(3 * (size_t)N);
+  ws->cg_w.ensure(3 * (size_t)N + 2);
+  ws->cg_minv.ensure(9 * (size_t)N);
+  ws->vpart.ensure(2 * kCgMaxBlocks * 2);
+  ws->dpart.ensure(kMaxApplySlots);
+  ws->cgst.ensure(1);
+  ws->cgsc.ensure(2);
   ws->part_misc.ensure(kMaxBlocks * 8);
   ws->scal.ensure(64);
-  ws->status.ensure(1);
   ws->flags.ensure(4);
   GSFM_HIP_CHECK(hipMemsetAsync(ws->flags.get(), 0, 4 * sizeof(int), s));
 }
