@@ -40,8 +40,8 @@ F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix, AMD datasheet (the local guid
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="ra_c2", choices=["ra_c2", "gp_c3", "ba_c4"])
     ap.add_argument("--scale", type=float, default=1.0, help="scale the GP/BA problem size (cameras and tracks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -71,7 +71,10 @@ def main():
 
         dist.init_process_group("gloo")
         dist.barrier()  # rank 0 finished building
-    ctx = _lib.Context(local_rank)  # raises GSFM_ERR_NO_DEVICE without an MI355X: no CPU fallback
+    # GSFM_BENCH_SINGLE_DEVICE=1 (validation only): every rank uses GPU 0 — lets the N > 1 control flow run
+    # on a one-GPU box together with GSFM_BENCH_HOST_COMM=1 (host-staged all-reduce instead of RCCL).
+    dev = 0 if os.environ.get("GSFM_BENCH_SINGLE_DEVICE") else local_rank
+    ctx = _lib.Context(dev)  # raises GSFM_ERR_NO_DEVICE without an MI355X: no CPU fallback
 
     def barrier():
         ctx.synchronize()
@@ -101,11 +104,14 @@ def comm_init(ctx, dist, rank, world):
     """RCCL communicator of libgsfm (one rank per GPU): rank 0 creates the unique id, gloo carries it."""
     if world <= 1 or getattr(ctx, "_comm_ready", False):
         return
-    from glomap_amd import _lib
+    from glomap_amd import _lib, sharding
 
-    uid = [_lib.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(uid, src=0)
-    ctx.comm_init(uid[0], rank, world)
+    if os.environ.get("GSFM_BENCH_HOST_COMM"):  # validation transport, never the measured configuration
+        ctx.comm_init_host(sharding.host_allreduce(dist), rank, world)
+    else:
+        uid = [_lib.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(uid[0], rank, world)
     ctx._comm_ready = True
 
 
@@ -117,11 +123,14 @@ def run_extras(env, args, world, rank, main_line):
 
     extra = {}
     sub_args = argparse.Namespace(**{**vars(args), "steps": 1, "warmup": 0})
-    if rank == 0:
+    if rank == 0:  # single-GPU side measurements, before the communicator is attached to the ctx
         try:
             extra["ra_large"] = bench_ra_large(env["ctx"])
+            # rotation averaging at the camera counts of configs[2] / configs[3] (iterative solver: N > 2048)
+            extra["ra_c3"] = bench_ra_sized(env["ctx"], 5000, 50)
+            extra["ra_c4"] = bench_ra_sized(env["ctx"], 10000, 50)
         except Exception as e:
-            extra["ra_large"] = {"error": repr(e)}
+            extra["ra_side"] = {"error": repr(e)}
 
     def work():
         try:
@@ -136,6 +145,19 @@ def run_extras(env, args, world, rank, main_line):
                                                    "roofline", "cpu_baseline")}
             except Exception as e:  # report, never hide
                 extra[name] = {"error": repr(e)}
+        if rank == 0 and world == 1:
+            # global positioning at the size of configs[3], then the full hot path of configs[3] on one GPU
+            try:
+                g4 = bench_gp(**{**env, "args": argparse.Namespace(**{**vars(sub_args), "scale": 2.0, "no_cpu_baseline": True})})
+                extra["gp_c4"] = {k: g4[k] for k in ("metric", "value", "unit", "ms_per_step", "config")}
+                if "error" not in extra.get("ba_c4", {"error": 1}) and "ra_c4" in extra:
+                    extra["pipeline_c4_ms"] = {
+                        "ra": extra["ra_c4"]["ms_per_solve"], "gp": g4["ms_per_step"], "ba": extra["ba_c4"]["ms_per_step"],
+                        "total": extra["ra_c4"]["ms_per_solve"] + g4["ms_per_step"] + extra["ba_c4"]["ms_per_step"],
+                        "note": "one RA + one GP + one BA solve on 10k cameras (500k edges; 1M tracks / ~6M and ~5M observations)",
+                    }
+            except Exception as e:
+                extra["gp_c4"] = {"error": repr(e)}
 
     t = threading.Thread(target=work, daemon=True)
     t.start()
@@ -312,6 +334,35 @@ def bench_ra(args, ctx, rank, world, barrier, dist):
         "median_rot_err_deg_vs_gt": float(np.median(err)),
     }
     return base_line("view-graph edges/sec (RA)", value, "edges/s", world, args, dt, config, roof, cpu, ctx)
+
+
+def bench_ra_sized(ctx, N, succ):
+    """One full RA solve (reference defaults) of a ring view graph with N cameras, inputs resident in HBM."""
+    import numpy as np
+
+    from glomap_amd import estimators, so3, synthetic
+
+    p = synthetic.make_ring_view_graph(N, succ, seed=0)
+    pd = type(p)(num_nodes=p.num_nodes, edge_i=ctx.to_device(p.edge_i), edge_j=ctx.to_device(p.edge_j),
+                 edge_q=ctx.to_device(p.edge_q), edge_weight=ctx.to_device(p.edge_weight),
+                 edge_ninl=ctx.to_device(p.edge_ninl), node_aa0=ctx.to_device(p.node_aa0), fixed_node=0)
+    rot = pd.node_aa0.clone()
+    best, rep = None, None
+    for _ in range(2):
+        rot.copy_from(pd.node_aa0)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        rc, _, rep = estimators.ra_solve(pd, estimators.RotationEstimatorOptions(), ctx=ctx, rot_inout=rot)
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        if rc != 0:
+            raise RuntimeError(f"gsfm_ra_solve failed: {rc}")
+        best = dt if best is None else min(best, dt)
+    err = synthetic.rotation_errors_deg(so3.aa_to_rotmat(rot.numpy()), p.gt_R)
+    return {"cameras": N, "edges": p.num_edges, "ms_per_solve": best * 1e3, "value": p.num_edges / best, "unit": "edges/s",
+            "linear_solver": "dense direct (f64 MFMA)" if N <= 2048 else "3-RHS Jacobi-PCG",
+            "l1_iterations": rep["iterations_l1"], "irls_iterations": rep["iterations_irls"],
+            "pcg_iterations": rep["linear_iterations"], "median_rot_err_deg_vs_gt": float(np.median(err))}
 
 
 def bench_ra_large(ctx):
