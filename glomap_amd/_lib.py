@@ -168,6 +168,27 @@ class BaProblemC(C.Structure):
 
 HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_int, C.c_void_p)
 
+class SceneViewC(C.Structure):
+    _fields_ = [
+        ("mem", C.c_int32),
+        ("num_cams", C.c_int32),
+        ("num_pts", C.c_int64),
+        ("num_obs", C.c_int64),
+        ("pt_offset", C.c_void_p),
+        ("obs_cam", C.c_void_p),
+        ("obs_undist", C.c_void_p),
+        ("obs_xy", C.c_void_p),
+        ("cam_q", C.c_void_p),
+        ("cam_t", C.c_void_p),
+        ("pt_xyz", C.c_void_p),
+        ("cam_calibrated", C.c_void_p),
+        ("num_intr", C.c_int32),
+        ("cam_intr", C.c_void_p),
+        ("intr_model", C.c_void_p),
+        ("intr_params", C.c_void_p),
+    ]
+
+
 _lib = None
 
 
@@ -233,6 +254,18 @@ def load():
         lib.gsfm_ba_options_default.argtypes = [C.POINTER(BaOptions)]
         lib.gsfm_ba_solve.restype = ip
         lib.gsfm_ba_solve.argtypes = [vp, C.POINTER(BaProblemC), C.POINTER(BaOptions), vp, vp, vp, vp, C.POINTER(Report)]
+    i64p = C.POINTER(C.c_int64)
+    lib.gsfm_filter_tracks_by_reprojection.restype = ip
+    lib.gsfm_filter_tracks_by_reprojection.argtypes = [vp, C.POINTER(SceneViewC), C.c_double, ip, vp, i64p]
+    lib.gsfm_filter_tracks_by_angle.restype = ip
+    lib.gsfm_filter_tracks_by_angle.argtypes = [vp, C.POINTER(SceneViewC), C.c_double, vp, i64p]
+    lib.gsfm_filter_tracks_triangulation_angle.restype = ip
+    lib.gsfm_filter_tracks_triangulation_angle.argtypes = [vp, C.POINTER(SceneViewC), C.c_double, vp, i64p]
+    lib.gsfm_normalize_reconstruction.restype = ip
+    lib.gsfm_normalize_reconstruction.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, C.c_int64, vp, C.c_int32, C.c_double,
+                                                  C.c_double, C.c_double, dp]
+    lib.gsfm_filter_rotations.restype = ip
+    lib.gsfm_filter_rotations.argtypes = [vp, C.c_int32, C.c_int32, vp, C.c_int64, vp, vp, vp, C.c_double, vp, i64p]
     _lib = lib
     return lib
 

@@ -61,6 +61,7 @@ extern "C" void gsfm_ctx_destroy(gsfm_ctx* ctx) {
   if (ctx->ra_ws && ctx->ra_ws_free) ctx->ra_ws_free(ctx->ra_ws);
   if (ctx->gp_ws && ctx->gp_ws_free) ctx->gp_ws_free(ctx->gp_ws);
   if (ctx->ba_ws && ctx->ba_ws_free) ctx->ba_ws_free(ctx->ba_ws);
+  if (ctx->fl_ws && ctx->fl_ws_free) ctx->fl_ws_free(ctx->fl_ws);
   if (ctx->comm.nccl) (void)ncclCommDestroy(ctx->comm.nccl);
   ctx->prof.destroy();
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);

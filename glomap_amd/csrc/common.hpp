@@ -175,6 +175,8 @@ struct gsfm_ctx {
   void* ra_ws = nullptr;
   void* gp_ws = nullptr;
   void* ba_ws = nullptr;
+  void* fl_ws = nullptr;
+  void (*fl_ws_free)(void*) = nullptr;
   void (*ra_ws_free)(void*) = nullptr;
   void (*gp_ws_free)(void*) = nullptr;
   void (*ba_ws_free)(void*) = nullptr;

@@ -1,0 +1,441 @@
+// filters.hip — the per-observation / per-edge processors that run between the estimator calls
+// (SURVEY.md section 8f rows 1-2), on MI355X (gfx950).
+//
+//   TrackFilter::FilterTracksByReprojection     glomap/processors/track_filter.cc:7-52
+//   TrackFilter::FilterTracksByAngle            glomap/processors/track_filter.cc:54-90
+//   TrackFilter::FilterTrackTriangulationAngle  glomap/processors/track_filter.cc:92-127
+//   NormalizeReconstruction                     glomap/processors/reconstruction_normalizer.cc:5-85
+//   RelPoseFilter::FilterRotations              glomap/processors/relpose_filter.cc:7-33
+//
+// They sit between every GP / BA solve of GlobalMapper::Solve (global_mapper.cc:164-186, 231-275,
+// 309-333).  All of them are single sweeps: one lane per observation (coalesced 24-byte ray / 16-byte
+// pixel reads, L2-resident camera gathers, the track's point read by its own consecutive lanes), or one
+// thread per track / edge.  Results are keep masks (bytes) + the counter the reference returns; counters
+// are integer sums, so results are bit-reproducible.
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+#include "camera.hpp"
+#include "device.hpp"
+
+namespace gsfm {
+namespace {
+
+constexpr double kEps = 1e-12;  // glomap/types.h:14
+
+struct ViewDev {
+  int N;
+  long P, M;
+  const long* off;
+  const int* cam;
+  const double* undist;
+  const double* xy;
+  const double* q;
+  const double* t;
+  const double* X;
+  const unsigned char* calibrated;
+  const int* cam_intr;
+  const int* intr_model;
+  const double* intr_params;
+};
+
+__device__ __forceinline__ void quat_to_R9(const double* __restrict__ q, double (&R)[9]) {
+  const double w = q[0], x = q[1], y = q[2], z = q[3];
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
+  R[3] = 2 * (x * y + w * z); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+  R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = 1 - 2 * (x * x + y * y);
+}
+
+// point of observation k: binary search of the track in pt_offset (no extra index array needed)
+__device__ __forceinline__ long track_of(const long* __restrict__ off, long P, long k) {
+  long lo = 0, hi = P;
+  while (hi - lo > 1) {
+    const long mid = (lo + hi) >> 1;
+    if (off[mid] <= k) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// mode 0: reprojection error in normalised image coordinates; 1: in pixels; 2: angle test
+__global__ void __launch_bounds__(kBlock)
+    k_filter_obs(ViewDev v, int mode, double thr, double thr_uncalib, unsigned char* __restrict__ keep) {
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < v.M; k += (long)gridDim.x * blockDim.x) {
+    const long p = track_of(v.off, v.P, k);
+    const int n = v.cam[k];
+    double R[9];
+    quat_to_R9(v.q + 4 * (long)n, R);
+    const V3 Xp = ld3(v.X + 3 * p);
+    const V3 tc = ld3(v.t + 3 * (long)n);
+    const V3 pc{R[0] * Xp.x + R[1] * Xp.y + R[2] * Xp.z + tc.x, R[3] * Xp.x + R[4] * Xp.y + R[5] * Xp.z + tc.y,
+                R[6] * Xp.x + R[7] * Xp.y + R[8] * Xp.z + tc.z};
+    bool ok = false;
+    if (!(pc.z < kEps)) {  // track_filter.cc:21,72
+      if (mode == 0) {
+        const V3 u = ld3(v.undist + 3 * k);
+        const double ex = pc.x / pc.z - u.x / (u.z + kEps), ey = pc.y / pc.z - u.y / (u.z + kEps);
+        ok = sqrt(ex * ex + ey * ey) < thr;
+      } else if (mode == 1) {
+        const int ik = v.cam_intr[n];
+        const double iz = 1.0 / pc.z;
+        double px = 0.0, py = 0.0, Juv[4], Jp[2][8];
+        // Camera::ImgFromCam(...).value_or(Zero): projection fails for points at / behind the camera
+        if (pc.z > 2.220446049250313e-16)
+          distort_project(v.intr_model[ik], v.intr_params + 8 * (long)ik, pc.x * iz, pc.y * iz, px, py, Juv, Jp);
+        const double ex = px - v.xy[2 * k], ey = py - v.xy[2 * k + 1];
+        ok = sqrt(ex * ex + ey * ey) < thr;
+      } else {
+        const V3 u = ld3(v.undist + 3 * k);
+        const double inv = 1.0 / sqrt(dot(pc, pc));
+        const double c = (pc.x * u.x + pc.y * u.y + pc.z * u.z) * inv;
+        const bool cal = v.calibrated == nullptr || v.calibrated[n];
+        ok = c > (cal ? thr : thr_uncalib);
+      }
+    }
+    keep[k] = ok ? 1 : 0;
+  }
+}
+
+// number of tracks that lost at least one observation
+__global__ void __launch_bounds__(kBlock)
+    k_count_changed(long P, const long* __restrict__ off, const unsigned char* __restrict__ keep,
+                    unsigned long long* __restrict__ counter) {
+  unsigned long long c = 0;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
+    bool changed = false;
+    for (long k = off[p]; k < off[p + 1]; ++k) changed = changed || keep[k] == 0;
+    c += changed ? 1 : 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(counter, c);
+}
+
+// Triangulation angle: a track stays iff some pair of its viewing rays (from the camera centres) spans
+// more than min_angle.  One thread per track, O(L^2) like the reference (L <= a few dozen).
+__global__ void __launch_bounds__(kBlock)
+    k_filter_tri(ViewDev v, double cos_thr, unsigned char* __restrict__ keep_track, unsigned long long* __restrict__ counter) {
+  unsigned long long c = 0;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < v.P; p += (long)gridDim.x * blockDim.x) {
+    const V3 Xp = ld3(v.X + 3 * p);
+    const long k0 = v.off[p], k1 = v.off[p + 1];
+    bool status = false;
+    for (long a = k0; a < k1 && !status; ++a) {
+      const int na = v.cam[a];
+      double Ra[9];
+      quat_to_R9(v.q + 4 * (long)na, Ra);
+      const V3 ta = ld3(v.t + 3 * (long)na);
+      // Image::Center() = -R^T t  (image.h)
+      V3 da = Xp - V3{-(Ra[0] * ta.x + Ra[3] * ta.y + Ra[6] * ta.z), -(Ra[1] * ta.x + Ra[4] * ta.y + Ra[7] * ta.z),
+                      -(Ra[2] * ta.x + Ra[5] * ta.y + Ra[8] * ta.z)};
+      da = (1.0 / sqrt(dot(da, da))) * da;
+      for (long b = a + 1; b < k1; ++b) {
+        const int nb = v.cam[b];
+        double Rb[9];
+        quat_to_R9(v.q + 4 * (long)nb, Rb);
+        const V3 tb = ld3(v.t + 3 * (long)nb);
+        V3 db = Xp - V3{-(Rb[0] * tb.x + Rb[3] * tb.y + Rb[6] * tb.z), -(Rb[1] * tb.x + Rb[4] * tb.y + Rb[7] * tb.z),
+                        -(Rb[2] * tb.x + Rb[5] * tb.y + Rb[8] * tb.z)};
+        db = (1.0 / sqrt(dot(db, db))) * db;
+        if (dot(da, db) < cos_thr) {
+          status = true;
+          break;
+        }
+      }
+    }
+    keep_track[p] = status ? 1 : 0;
+    c += status ? 0 : 1;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(counter, c);
+}
+
+// camera centres of the registered images as float (reconstruction_normalizer.cc:24-30)
+__global__ void __launch_bounds__(kBlock)
+    k_centers_f32(int N, const double* __restrict__ q, const double* __restrict__ t, float* __restrict__ c) {
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+    double R[9];
+    quat_to_R9(q + 4 * (long)n, R);
+    const V3 tt = ld3(t + 3 * (long)n);
+    c[3 * (long)n] = (float)(-(R[0] * tt.x + R[3] * tt.y + R[6] * tt.z));
+    c[3 * (long)n + 1] = (float)(-(R[1] * tt.x + R[4] * tt.y + R[7] * tt.z));
+    c[3 * (long)n + 2] = (float)(-(R[2] * tt.x + R[5] * tt.y + R[8] * tt.z));
+  }
+}
+// TransformCameraWorld(Sim3(scale, I, -scale mean), cam_from_world): t' = scale (t + R mean)
+__global__ void __launch_bounds__(kBlock)
+    k_transform_cams(int N, double scale, double mx, double my, double mz, const double* __restrict__ q, double* __restrict__ t) {
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+    double R[9];
+    quat_to_R9(q + 4 * (long)n, R);
+    double* tt = t + 3 * (long)n;
+    const double a = tt[0] + R[0] * mx + R[1] * my + R[2] * mz;
+    const double b = tt[1] + R[3] * mx + R[4] * my + R[5] * mz;
+    const double c = tt[2] + R[6] * mx + R[7] * my + R[8] * mz;
+    tt[0] = scale * a;
+    tt[1] = scale * b;
+    tt[2] = scale * c;
+  }
+}
+// X' = scale X - scale mean
+__global__ void __launch_bounds__(kBlock)
+    k_transform_pts(long P, double scale, double mx, double my, double mz, double* __restrict__ X) {
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
+    X[3 * p] = scale * X[3 * p] - scale * mx;
+    X[3 * p + 1] = scale * X[3 * p + 1] - scale * my;
+    X[3 * p + 2] = scale * X[3 * p + 2] - scale * mz;
+  }
+}
+
+// FilterRotations: angle between R_j R_i^T and the measured R_ij (Eigen angularDistance), in degrees
+__global__ void __launch_bounds__(kBlock)
+    k_filter_rot(long E, const int* __restrict__ ei, const int* __restrict__ ej, const double* __restrict__ eq,
+                 const double* __restrict__ nq, double max_deg, unsigned char* __restrict__ keep,
+                 unsigned long long* __restrict__ counter) {
+  unsigned long long c = 0;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long)gridDim.x * blockDim.x) {
+    const Quat qi = load_quat(nq + 4 * (long)ei[e]), qj = load_quat(nq + 4 * (long)ej[e]);
+    const Quat calc = qmul(qj, qconj(qi));
+    const Quat d = qmul(qconj(calc), load_quat(eq + 4 * e));
+    const double vn = sqrt(d.x * d.x + d.y * d.y + d.z * d.z);
+    const double ang = 2.0 * atan2(vn, fabs(d.w)) * (180.0 / M_PI);
+    const bool bad = ang > max_deg;
+    keep[e] = bad ? 0 : 1;
+    c += bad ? 1 : 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(counter, c);
+}
+
+struct FilterWs {
+  DevBuf<long> off;
+  DevBuf<int> cam, cam_intr, intr_model, ei, ej;
+  DevBuf<double> undist, xy, q, t, X, intr, eq, nq;
+  DevBuf<float> cen;
+  DevBuf<unsigned char> cal, keep, reg;
+  DevBuf<unsigned long long> counter;
+  static void destroy(void* p) { delete static_cast<FilterWs*>(p); }
+};
+
+FilterWs* filter_ws(gsfm_ctx* ctx) {
+  if (!ctx->fl_ws) {
+    ctx->fl_ws = new FilterWs();
+    ctx->fl_ws_free = &FilterWs::destroy;
+  }
+  return static_cast<FilterWs*>(ctx->fl_ws);
+}
+
+void stage_view(gsfm_ctx* ctx, FilterWs* ws, const gsfm_scene_view* v, bool need_undist, bool need_pixels, ViewDev& d) {
+  GSFM_REQUIRE(v && v->pt_offset && v->obs_cam && v->cam_q && v->cam_t && v->pt_xyz, "filter: null argument");
+  GSFM_REQUIRE(v->num_cams > 0 && v->num_pts >= 0 && v->num_obs >= 0, "filter: bad sizes");
+  const int mem = v->mem;
+  const long P = v->num_pts, M = v->num_obs;
+  const int N = v->num_cams;
+  copy_in(ctx, ws->off.ensure(P + 1), reinterpret_cast<const long*>(v->pt_offset), (size_t)P + 1, mem);
+  copy_in(ctx, ws->cam.ensure(M + 1), v->obs_cam, (size_t)M, mem);
+  copy_in(ctx, ws->q.ensure(4 * (size_t)N), v->cam_q, 4 * (size_t)N, mem);
+  copy_in(ctx, ws->t.ensure(3 * (size_t)N), v->cam_t, 3 * (size_t)N, mem);
+  copy_in(ctx, ws->X.ensure(3 * (size_t)P + 3), v->pt_xyz, 3 * (size_t)P, mem);
+  d = ViewDev{};
+  d.N = N;
+  d.P = P;
+  d.M = M;
+  d.off = ws->off.get();
+  d.cam = ws->cam.get();
+  d.q = ws->q.get();
+  d.t = ws->t.get();
+  d.X = ws->X.get();
+  if (need_undist) {
+    GSFM_REQUIRE(v->obs_undist != nullptr, "filter: obs_undist required");
+    copy_in(ctx, ws->undist.ensure(3 * (size_t)M + 3), v->obs_undist, 3 * (size_t)M, mem);
+    d.undist = ws->undist.get();
+  }
+  if (need_pixels) {
+    GSFM_REQUIRE(v->obs_xy && v->cam_intr && v->intr_model && v->intr_params && v->num_intr > 0,
+                 "filter: pixel-space reprojection needs obs_xy and the intrinsics arrays");
+    copy_in(ctx, ws->xy.ensure(2 * (size_t)M + 2), v->obs_xy, 2 * (size_t)M, mem);
+    copy_in(ctx, ws->cam_intr.ensure(N), v->cam_intr, (size_t)N, mem);
+    copy_in(ctx, ws->intr_model.ensure(v->num_intr), v->intr_model, (size_t)v->num_intr, mem);
+    copy_in(ctx, ws->intr.ensure(8 * (size_t)v->num_intr), v->intr_params, 8 * (size_t)v->num_intr, mem);
+    d.xy = ws->xy.get();
+    d.cam_intr = ws->cam_intr.get();
+    d.intr_model = ws->intr_model.get();
+    d.intr_params = ws->intr.get();
+  }
+  if (v->cam_calibrated) {
+    copy_in(ctx, ws->cal.ensure(N), v->cam_calibrated, (size_t)N, mem);
+    d.calibrated = ws->cal.get();
+  }
+}
+
+long read_counter(gsfm_ctx* ctx, FilterWs* ws) {
+  unsigned long long* h = reinterpret_cast<unsigned long long*>(ctx->h_pinned + 600);
+  GSFM_HIP_CHECK(hipMemcpyAsync(h, ws->counter.get(), sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+  GSFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  GSFM_HIP_CHECK(hipGetLastError());
+  return (long)h[0];
+}
+
+int filter_obs_impl(gsfm_ctx* ctx, const gsfm_scene_view* view, int mode, double thr, double thr2, uint8_t* keep_out,
+                    int64_t* changed) {
+  GSFM_REQUIRE(keep_out != nullptr, "filter: null output");
+  GSFM_HIP_CHECK(hipSetDevice(ctx->device));
+  FilterWs* ws = filter_ws(ctx);
+  ViewDev d;
+  stage_view(ctx, ws, view, mode != 1, mode == 1, d);
+  hipStream_t s = ctx->stream;
+  ws->keep.ensure(d.M + 1);
+  ws->counter.ensure(1);
+  GSFM_HIP_CHECK(hipMemsetAsync(ws->counter.get(), 0, sizeof(unsigned long long), s));
+  if (d.M > 0) {
+    hipLaunchKernelGGL(k_filter_obs, dim3(grid_wide(d.M, kBlock, 1 << 16)), dim3(kBlock), 0, s, d, mode, thr, thr2, ws->keep.get());
+    hipLaunchKernelGGL(k_count_changed, dim3(grid_for(d.P, kBlock)), dim3(kBlock), 0, s, d.P, d.off, ws->keep.get(), ws->counter.get());
+  }
+  copy_out(ctx, keep_out, ws->keep.get(), (size_t)d.M, view->mem);
+  const long c = read_counter(ctx, ws);
+  if (changed) *changed = c;
+  return GSFM_OK;
+}
+
+}  // namespace
+}  // namespace gsfm
+
+using namespace gsfm;
+
+extern "C" int gsfm_filter_tracks_by_reprojection(gsfm_ctx* ctx, const gsfm_scene_view* view, double max_reprojection_error,
+                                                  int in_normalized_image, uint8_t* obs_keep_out, int64_t* tracks_changed) {
+  if (!ctx) return GSFM_ERR_INVALID_ARGUMENT;
+  return guarded(ctx, nullptr, [&] {
+    return filter_obs_impl(ctx, view, in_normalized_image ? 0 : 1, max_reprojection_error, 0.0, obs_keep_out, tracks_changed);
+  });
+}
+
+extern "C" int gsfm_filter_tracks_by_angle(gsfm_ctx* ctx, const gsfm_scene_view* view, double max_angle_error_deg,
+                                           uint8_t* obs_keep_out, int64_t* tracks_changed) {
+  if (!ctx) return GSFM_ERR_INVALID_ARGUMENT;
+  return guarded(ctx, nullptr, [&] {
+    const double thr = std::cos(max_angle_error_deg * M_PI / 180.0);
+    const double thr_u = std::cos(2.0 * max_angle_error_deg * M_PI / 180.0);  // track_filter.cc:61-62
+    return filter_obs_impl(ctx, view, 2, thr, thr_u, obs_keep_out, tracks_changed);
+  });
+}
+
+extern "C" int gsfm_filter_tracks_triangulation_angle(gsfm_ctx* ctx, const gsfm_scene_view* view, double min_angle_deg,
+                                                      uint8_t* track_keep_out, int64_t* tracks_removed) {
+  if (!ctx) return GSFM_ERR_INVALID_ARGUMENT;
+  return guarded(ctx, nullptr, [&] {
+    GSFM_REQUIRE(track_keep_out != nullptr, "filter: null output");
+    GSFM_HIP_CHECK(hipSetDevice(ctx->device));
+    FilterWs* ws = filter_ws(ctx);
+    ViewDev d;
+    stage_view(ctx, ws, view, false, false, d);
+    hipStream_t s = ctx->stream;
+    ws->keep.ensure(d.P + 1);
+    ws->counter.ensure(1);
+    GSFM_HIP_CHECK(hipMemsetAsync(ws->counter.get(), 0, sizeof(unsigned long long), s));
+    if (d.P > 0)
+      hipLaunchKernelGGL(k_filter_tri, dim3(grid_wide(d.P, kBlock, 1 << 16)), dim3(kBlock), 0, s, d,
+                         std::cos(min_angle_deg * M_PI / 180.0), ws->keep.get(), ws->counter.get());
+    copy_out(ctx, track_keep_out, ws->keep.get(), (size_t)d.P, view->mem);
+    const long c = read_counter(ctx, ws);
+    if (tracks_removed) *tracks_removed = c;
+    return (int)GSFM_OK;
+  });
+}
+
+extern "C" int gsfm_normalize_reconstruction(gsfm_ctx* ctx, int32_t mem, int32_t num_cams, const uint8_t* cam_registered,
+                                             const double* cam_q, double* cam_t_inout, int64_t num_pts, double* pt_xyz_inout,
+                                             int32_t fixed_scale, double extent, double p0, double p1, double sim3_out[4]) {
+  if (!ctx) return GSFM_ERR_INVALID_ARGUMENT;
+  return guarded(ctx, nullptr, [&] {
+    GSFM_REQUIRE(cam_q && cam_t_inout && (num_pts == 0 || pt_xyz_inout) && num_cams > 0, "normalize: null argument");
+    GSFM_HIP_CHECK(hipSetDevice(ctx->device));
+    FilterWs* ws = filter_ws(ctx);
+    hipStream_t s = ctx->stream;
+    const int N = num_cams;
+    const long P = num_pts;
+    copy_in(ctx, ws->q.ensure(4 * (size_t)N), cam_q, 4 * (size_t)N, mem);
+    copy_in(ctx, ws->t.ensure(3 * (size_t)N), cam_t_inout, 3 * (size_t)N, mem);
+    copy_in(ctx, ws->X.ensure(3 * (size_t)P + 3), pt_xyz_inout, 3 * (size_t)P, mem);
+    hipLaunchKernelGGL(k_centers_f32, dim3(grid_for(N, kBlock)), dim3(kBlock), 0, s, N, ws->q.get(), ws->t.get(), ws->cen.ensure(3 * (size_t)N));
+    // the percentile selection works on N floats per axis: host (N log N on a few thousand values)
+    std::vector<float> cen(3 * (size_t)N);
+    std::vector<unsigned char> reg;
+    if (cam_registered) to_host(ctx, reg, cam_registered, (size_t)N, mem);
+    GSFM_HIP_CHECK(hipMemcpyAsync(cen.data(), ws->cen.get(), cen.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+    GSFM_HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<float> cx, cy, cz;
+    for (int n = 0; n < N; ++n) {
+      if (cam_registered && !reg[n]) continue;
+      cx.push_back(cen[3 * (size_t)n]);
+      cy.push_back(cen[3 * (size_t)n + 1]);
+      cz.push_back(cen[3 * (size_t)n + 2]);
+    }
+    GSFM_REQUIRE(!cx.empty(), "normalize: no registered image");
+    std::sort(cx.begin(), cx.end());
+    std::sort(cy.begin(), cy.end());
+    std::sort(cz.begin(), cz.end());
+    const size_t n = cx.size();
+    const size_t P0 = static_cast<size_t>((n > 3) ? p0 * (n - 1) : 0);
+    const size_t P1 = static_cast<size_t>((n > 3) ? p1 * (n - 1) : n - 1);
+    const double bmin[3] = {cx[P0], cy[P0], cz[P0]}, bmax[3] = {cx[P1], cy[P1], cz[P1]};
+    double mean[3] = {0, 0, 0};
+    for (size_t i = P0; i <= P1; ++i) {
+      mean[0] += cx[i];
+      mean[1] += cy[i];
+      mean[2] += cz[i];
+    }
+    for (double& m : mean) m /= (double)(P1 - P0 + 1);
+    double scale = 1.0;
+    if (!fixed_scale) {
+      const double old_extent = std::sqrt((bmax[0] - bmin[0]) * (bmax[0] - bmin[0]) + (bmax[1] - bmin[1]) * (bmax[1] - bmin[1]) +
+                                          (bmax[2] - bmin[2]) * (bmax[2] - bmin[2]));
+      if (old_extent >= std::numeric_limits<double>::epsilon()) scale = extent / old_extent;
+    }
+    hipLaunchKernelGGL(k_transform_cams, dim3(grid_for(N, kBlock)), dim3(kBlock), 0, s, N, scale, mean[0], mean[1], mean[2],
+                       ws->q.get(), ws->t.get());
+    if (P > 0)
+      hipLaunchKernelGGL(k_transform_pts, dim3(grid_wide(P, kBlock, 1 << 16)), dim3(kBlock), 0, s, P, scale, mean[0], mean[1],
+                         mean[2], ws->X.get());
+    copy_out(ctx, cam_t_inout, ws->t.get(), 3 * (size_t)N, mem);
+    copy_out(ctx, pt_xyz_inout, ws->X.get(), 3 * (size_t)P, mem);
+    GSFM_HIP_CHECK(hipStreamSynchronize(s));
+    GSFM_HIP_CHECK(hipGetLastError());
+    if (sim3_out) {
+      sim3_out[0] = scale;
+      sim3_out[1] = -scale * mean[0];
+      sim3_out[2] = -scale * mean[1];
+      sim3_out[3] = -scale * mean[2];
+    }
+    return (int)GSFM_OK;
+  });
+}
+
+extern "C" int gsfm_filter_rotations(gsfm_ctx* ctx, int32_t mem, int32_t num_nodes, const double* node_q, int64_t num_edges,
+                                     const int32_t* edge_i, const int32_t* edge_j, const double* edge_q, double max_angle_deg,
+                                     uint8_t* edge_keep_out, int64_t* num_invalid) {
+  if (!ctx) return GSFM_ERR_INVALID_ARGUMENT;
+  return guarded(ctx, nullptr, [&] {
+    GSFM_REQUIRE(node_q && edge_i && edge_j && edge_q && edge_keep_out && num_nodes > 0 && num_edges >= 0, "filter: null argument");
+    GSFM_HIP_CHECK(hipSetDevice(ctx->device));
+    FilterWs* ws = filter_ws(ctx);
+    hipStream_t s = ctx->stream;
+    const long E = num_edges;
+    copy_in(ctx, ws->nq.ensure(4 * (size_t)num_nodes), node_q, 4 * (size_t)num_nodes, mem);
+    copy_in(ctx, ws->ei.ensure(E + 1), edge_i, (size_t)E, mem);
+    copy_in(ctx, ws->ej.ensure(E + 1), edge_j, (size_t)E, mem);
+    copy_in(ctx, ws->eq.ensure(4 * (size_t)E + 4), edge_q, 4 * (size_t)E, mem);
+    ws->keep.ensure(E + 1);
+    ws->counter.ensure(1);
+    GSFM_HIP_CHECK(hipMemsetAsync(ws->counter.get(), 0, sizeof(unsigned long long), s));
+    if (E > 0)
+      hipLaunchKernelGGL(k_filter_rot, dim3(grid_wide(E, kBlock, 1 << 16)), dim3(kBlock), 0, s, E, ws->ei.get(), ws->ej.get(),
+                         ws->eq.get(), ws->nq.get(), max_angle_deg, ws->keep.get(), ws->counter.get());
+    copy_out(ctx, edge_keep_out, ws->keep.get(), (size_t)E, mem);
+    const long c = read_counter(ctx, ws);
+    if (num_invalid) *num_invalid = c;
+    return (int)GSFM_OK;
+  });
+}

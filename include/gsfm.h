@@ -294,6 +294,52 @@ int gsfm_ba_solve(gsfm_ctx* ctx, const gsfm_ba_problem* prob, const gsfm_ba_opti
                   double* cam_q_inout, double* cam_t_inout, double* pt_xyz_inout,
                   double* intr_params_inout, gsfm_report* report);
 
+
+/* ---- processors that run between the estimator calls ("next" rows 1-2) -------------
+ * gsfm_filter_*   <->  TrackFilter::FilterTracksByReprojection / FilterTracksByAngle / FilterTrackTriangulationAngle
+ *                      glomap/processors/track_filter.cc:7-52, 54-90, 92-127   (called global_mapper.cc:164-183,
+ *                      244-271, 309-333) and RelPoseFilter::FilterRotations relpose_filter.cc:7-33 (gm.cc:94,106)
+ * gsfm_normalize_reconstruction  <->  NormalizeReconstruction  glomap/processors/reconstruction_normalizer.cc:5-85
+ *                      (global_mapper.cc:186,231,322)
+ * The reference rewrites Track::observations / ImagePair::is_valid in place; at the flat boundary the result is
+ * a keep mask per observation / track / edge (1 = stays) plus the counter the reference logs and returns. */
+typedef struct gsfm_scene_view {
+  int32_t mem;
+  int32_t num_cams;               /* N images (trivial rigs: cam_from_world = rig_from_world) */
+  int64_t num_pts;                /* P tracks */
+  int64_t num_obs;                /* M */
+  const int64_t* pt_offset;       /* [P+1] track-major */
+  const int32_t* obs_cam;         /* [M] */
+  const double* obs_undist;       /* [M][3] image.features_undist[feat]; may be NULL for pixel-space reprojection */
+  const double* obs_xy;           /* [M][2] image.features[feat]; only read when in_normalized_image == 0 */
+  const double* cam_q;            /* [N][4] (w,x,y,z) cam_from_world */
+  const double* cam_t;            /* [N][3] */
+  const double* pt_xyz;           /* [P][3] */
+  const uint8_t* cam_calibrated;  /* [N] cameras[...].has_prior_focal_length; NULL = all 1 */
+  int32_t num_intr;               /* pixel-space reprojection only */
+  const int32_t* cam_intr;        /* [N] */
+  const int32_t* intr_model;      /* [K] GSFM_CAMERA_* */
+  const double* intr_params;      /* [K][GSFM_CAMERA_MAX_PARAMS] */
+} gsfm_scene_view;
+
+/* obs_keep_out [M]; *tracks_changed = number of tracks that lost at least one observation. */
+int gsfm_filter_tracks_by_reprojection(gsfm_ctx* ctx, const gsfm_scene_view* view, double max_reprojection_error,
+                                       int in_normalized_image, uint8_t* obs_keep_out, int64_t* tracks_changed);
+int gsfm_filter_tracks_by_angle(gsfm_ctx* ctx, const gsfm_scene_view* view, double max_angle_error_deg,
+                                uint8_t* obs_keep_out, int64_t* tracks_changed);
+/* track_keep_out [P]: 0 = the reference clears the track's observations; *tracks_removed counts them. */
+int gsfm_filter_tracks_triangulation_angle(gsfm_ctx* ctx, const gsfm_scene_view* view, double min_angle_deg,
+                                           uint8_t* track_keep_out, int64_t* tracks_removed);
+/* Robust-bounding-box similarity of the registered camera centres (extent 10, 10-90 percentiles by default);
+ * cam_t and pt_xyz are transformed in place, sim3_out = {scale, tx, ty, tz} with X' = scale * X + t. */
+int gsfm_normalize_reconstruction(gsfm_ctx* ctx, int32_t mem, int32_t num_cams, const uint8_t* cam_registered,
+                                  const double* cam_q, double* cam_t_inout, int64_t num_pts, double* pt_xyz_inout,
+                                  int32_t fixed_scale, double extent, double p0, double p1, double sim3_out[4]);
+/* edge_keep_out [E]: 0 where angularDistance(R_j R_i^T, R_ij) > max_angle_deg (the reference sets is_valid = false). */
+int gsfm_filter_rotations(gsfm_ctx* ctx, int32_t mem, int32_t num_nodes, const double* node_q, int64_t num_edges,
+                          const int32_t* edge_i, const int32_t* edge_j, const double* edge_q, double max_angle_deg,
+                          uint8_t* edge_keep_out, int64_t* num_invalid);
+
 #ifdef __cplusplus
 }
 #endif

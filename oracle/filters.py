@@ -1,0 +1,117 @@
+"""CPU restatement (test infrastructure) of the processors that run between the estimator calls:
+
+  TrackFilter::FilterTracksByReprojection     glomap/processors/track_filter.cc:7-52
+  TrackFilter::FilterTracksByAngle            glomap/processors/track_filter.cc:54-90
+  TrackFilter::FilterTrackTriangulationAngle  glomap/processors/track_filter.cc:92-127
+  NormalizeReconstruction                     glomap/processors/reconstruction_normalizer.cc:5-85
+  RelPoseFilter::FilterRotations              glomap/processors/relpose_filter.cc:7-33
+
+Flat arrays as in include/gsfm.h (gsfm_scene_view).  Only tests/, smoke() and bench.py's cpu_baseline leg
+may import this module."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import ba as oba
+from . import so3
+
+EPS = 1e-12  # glomap/types.h:14
+
+
+def _cam_points(pt_offset, obs_cam, cam_q, cam_t, pt_xyz):
+    lens = np.diff(pt_offset)
+    pt = np.repeat(np.arange(len(lens)), lens)
+    R = so3.quat_wxyz_to_rotmat(np.asarray(cam_q, dtype=np.float64))
+    pc = np.einsum("mij,mj->mi", R[obs_cam], pt_xyz[pt]) + cam_t[obs_cam]
+    return pt, pc, R
+
+
+def _changed(pt, keep, P):
+    dropped = np.bincount(pt, weights=(~keep).astype(np.float64), minlength=P)
+    return int((dropped > 0).sum())
+
+
+def filter_tracks_by_reprojection(pt_offset, obs_cam, cam_q, cam_t, pt_xyz, max_err=1e-2, in_normalized_image=True,
+                                  obs_undist=None, obs_xy=None, cam_intr=None, intr_model=None, intr_params=None):
+    """track_filter.cc:7-52.  Returns (keep [M] bool, tracks_changed)."""
+    pt, pc, _ = _cam_points(pt_offset, obs_cam, cam_q, cam_t, pt_xyz)
+    front = ~(pc[:, 2] < EPS)
+    z = np.where(front, pc[:, 2], 1.0)
+    if in_normalized_image:
+        u = obs_undist
+        e = pc[:, :2] / z[:, None] - u[:, :2] / (u[:, 2:3] + EPS)
+    else:
+        ik = cam_intr[obs_cam]
+        uv, _, _, valid = oba.project(intr_model[ik], intr_params[ik], np.where(front[:, None], pc, [0.0, 0.0, 1.0]))
+        uv = np.where(valid[:, None], uv, 0.0)  # ImgFromCam(...).value_or(Zero)
+        e = uv - obs_xy
+    keep = front & (np.sqrt((e * e).sum(1)) < max_err)
+    return keep, _changed(pt, keep, len(pt_offset) - 1)
+
+
+def filter_tracks_by_angle(pt_offset, obs_cam, cam_q, cam_t, pt_xyz, obs_undist, max_angle_deg=1.0, cam_calibrated=None):
+    """track_filter.cc:54-90.  Returns (keep [M] bool, tracks_changed)."""
+    pt, pc, _ = _cam_points(pt_offset, obs_cam, cam_q, cam_t, pt_xyz)
+    front = ~(pc[:, 2] < EPS)
+    thr = np.cos(np.radians(max_angle_deg))
+    thr_u = np.cos(np.radians(2.0 * max_angle_deg))
+    n = pc / np.linalg.norm(pc, axis=1, keepdims=True)
+    c = (n * obs_undist).sum(1)
+    cal = np.ones(len(cam_q), bool) if cam_calibrated is None else np.asarray(cam_calibrated, bool)
+    keep = front & (c > np.where(cal[obs_cam], thr, thr_u))
+    return keep, _changed(pt, keep, len(pt_offset) - 1)
+
+
+def filter_tracks_triangulation_angle(pt_offset, obs_cam, cam_q, cam_t, pt_xyz, min_angle_deg=1.0):
+    """track_filter.cc:92-127.  Returns (keep_track [P] bool, tracks_removed)."""
+    R = so3.quat_wxyz_to_rotmat(np.asarray(cam_q, dtype=np.float64))
+    centers = -np.einsum("nji,nj->ni", R, cam_t)
+    thr = np.cos(np.radians(min_angle_deg))
+    P = len(pt_offset) - 1
+    keep = np.zeros(P, bool)
+    for p in range(P):
+        k0, k1 = int(pt_offset[p]), int(pt_offset[p + 1])
+        if k1 - k0 < 2:
+            continue
+        d = pt_xyz[p] - centers[obs_cam[k0:k1]]
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        g = d @ d.T
+        iu = np.triu_indices(k1 - k0, 1)
+        keep[p] = bool((g[iu] < thr).any())
+    return keep, int((~keep).sum())
+
+
+def normalize_reconstruction(cam_q, cam_t, pt_xyz, cam_registered=None, fixed_scale=False, extent=10.0, p0=0.1, p1=0.9):
+    """reconstruction_normalizer.cc:5-85.  Returns (cam_t', pt_xyz', (scale, translation))."""
+    R = so3.quat_wxyz_to_rotmat(np.asarray(cam_q, dtype=np.float64))
+    centers = -np.einsum("nji,nj->ni", R, cam_t)
+    reg = np.ones(len(cam_q), bool) if cam_registered is None else np.asarray(cam_registered, bool)
+    c = np.sort(centers[reg].astype(np.float32), axis=0)  # the reference keeps floats and sorts each axis
+    n = c.shape[0]
+    P0 = int(p0 * (n - 1)) if n > 3 else 0
+    P1 = int(p1 * (n - 1)) if n > 3 else n - 1
+    bmin, bmax = c[P0].astype(np.float64), c[P1].astype(np.float64)
+    mean = np.zeros(3)
+    for i in range(P0, P1 + 1):  # accumulate in double, in order, like the reference
+        mean += c[i].astype(np.float64)
+    mean /= P1 - P0 + 1
+    scale = 1.0
+    if not fixed_scale:
+        old = np.linalg.norm(bmax - bmin)
+        if old >= np.finfo(np.float64).eps:
+            scale = extent / old
+    t_new = scale * (cam_t + np.einsum("nij,j->ni", R, mean))  # TransformCameraWorld
+    X_new = scale * pt_xyz - scale * mean
+    return t_new, X_new, (scale, -scale * mean)
+
+
+def filter_rotations(node_q, edge_i, edge_j, edge_q, max_angle_deg):
+    """relpose_filter.cc:7-33 (registered images, valid pairs).  Returns (keep [E] bool, num_invalid)."""
+    Rn = so3.quat_wxyz_to_rotmat(np.asarray(node_q, dtype=np.float64))
+    Re = so3.quat_wxyz_to_rotmat(np.asarray(edge_q, dtype=np.float64))
+    calc = np.einsum("eij,ekj->eik", Rn[edge_j], Rn[edge_i])  # R_j R_i^T
+    rel = np.einsum("eji,ejk->eik", calc, Re)
+    cos = np.clip((np.trace(rel, axis1=1, axis2=2) - 1.0) / 2.0, -1.0, 1.0)
+    ang = np.degrees(np.arccos(cos))
+    keep = ~(ang > max_angle_deg)
+    return keep, int((~keep).sum())

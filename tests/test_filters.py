@@ -1,0 +1,125 @@
+"""Processors between the estimator calls: track filters, reconstruction
+normaliser, relative-rotation filter.  CPU: the oracle restatement against hand-checkable properties.
+GPU: the HIP kernels through the C ABI against the oracle — masks and counters bit-exact, transformed
+coordinates to 1e-12 relative."""
+import numpy as np
+import pytest
+
+from glomap_amd import so3, synthetic
+from oracle import filters as of
+
+
+def _scene(seed=0, ncam=40, npts=3000, noise=2e-3, outliers=0.05):
+    p = synthetic.make_gp_problem(ncam, npts, seed=seed, dir_noise=noise, outlier_ratio=outliers)
+    q = so3.rotmat_to_quat(p.cam_R)
+    t = -np.einsum("nij,nj->ni", p.cam_R, p.gt_center)
+    undist = np.einsum("mij,mj->mi", p.cam_R[p.obs_cam], p.obs_dir)  # world rays -> camera rays
+    X = p.gt_xyz + np.random.default_rng(seed).normal(0, 0.02, p.gt_xyz.shape)
+    return p, q, t, undist, X
+
+
+def test_oracle_reprojection_and_angle_filters_drop_outliers():
+    p, q, t, undist, X = _scene()
+    keep, changed = of.filter_tracks_by_reprojection(p.pt_offset, p.obs_cam, q, t, X, 2e-2, True, obs_undist=undist)
+    frac = 1.0 - keep.mean()
+    assert 0.03 < frac < 0.15 and changed > 0  # ~5 % outlier rays
+    keep_a, changed_a = of.filter_tracks_by_angle(p.pt_offset, p.obs_cam, q, t, X, undist, 1.0)
+    assert abs(keep_a.mean() - keep.mean()) < 0.03
+    # uncalibrated cameras get twice the angle: never fewer observations kept
+    keep_u, _ = of.filter_tracks_by_angle(p.pt_offset, p.obs_cam, q, t, X, undist, 1.0, cam_calibrated=np.zeros(p.num_cams, np.uint8))
+    assert (keep_u | ~keep_a).all()
+    # points behind a camera are dropped whatever the threshold
+    t2 = t.copy()
+    t2[:, 2] -= 1e3
+    k3, _ = of.filter_tracks_by_reprojection(p.pt_offset, p.obs_cam, q, t2, X, 1e9, True, obs_undist=undist)
+    assert not k3.any()
+
+
+def test_oracle_triangulation_angle():
+    p, q, t, undist, X = _scene()
+    keep, removed = of.filter_tracks_triangulation_angle(p.pt_offset, p.obs_cam, q, t, X, 1.0)
+    assert keep.mean() > 0.9 and removed == (~keep).sum()
+    # a point very far away subtends no angle
+    X2 = X.copy()
+    X2[0] = X[0] * 1e6
+    keep2, _ = of.filter_tracks_triangulation_angle(p.pt_offset, p.obs_cam, q, t, X2, 1.0)
+    assert not keep2[0]
+
+
+def test_oracle_normalizer_properties():
+    p, q, t, undist, X = _scene(seed=3)
+    t2, X2, (scale, trans) = of.normalize_reconstruction(q, t, X)
+    R = so3.quat_to_rotmat(q)
+    c1 = -np.einsum("nji,nj->ni", R, t)
+    c2 = -np.einsum("nji,nj->ni", R, t2)
+    assert np.allclose(c2, scale * c1 + trans, atol=1e-9)  # centres follow the similarity
+    assert np.allclose(X2, scale * X + trans, atol=1e-9)
+    # robust extent of the normalised centres is 10 (reconstruction_normalizer.cc defaults)
+    cs = np.sort(c2, axis=0)
+    n = cs.shape[0]
+    ext = np.linalg.norm(cs[int(0.9 * (n - 1))] - cs[int(0.1 * (n - 1))])
+    assert abs(ext - 10.0) < 1e-3
+    # reprojection is invariant: x_c scales by `scale`
+    pc1 = np.einsum("nij,nj->ni", R[p.obs_cam[:50]], X[np.repeat(np.arange(p.num_pts), np.diff(p.pt_offset))[:50]]) + t[p.obs_cam[:50]]
+    pc2 = np.einsum("nij,nj->ni", R[p.obs_cam[:50]], X2[np.repeat(np.arange(p.num_pts), np.diff(p.pt_offset))[:50]]) + t2[p.obs_cam[:50]]
+    assert np.allclose(pc2, scale * pc1, atol=1e-9)
+
+
+def test_oracle_filter_rotations():
+    g = synthetic.make_ring_view_graph(100, 8, seed=5)
+    nq = so3.rotmat_to_quat(g.gt_R)
+    keep, ninv = of.filter_rotations(nq, g.edge_i, g.edge_j, g.edge_q, 5.0)
+    assert ninv == (~keep).sum()
+    assert (~keep[g.outlier]).mean() > 0.9 and keep[~g.outlier].mean() > 0.99
+
+
+# ---- GPU parity --------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1])
+def test_gpu_track_filters_match_oracle(gsfm_ctx, seed):
+    from glomap_amd import processors as pr
+
+    p, q, t, undist, X = _scene(seed=seed)
+    cal = (np.random.default_rng(seed).random(p.num_cams) > 0.3).astype(np.uint8)
+    view = pr.SceneView(p.num_cams, p.pt_offset, p.obs_cam, q, t, X, obs_undist=undist, cam_calibrated=cal)
+    k_o, c_o = of.filter_tracks_by_reprojection(p.pt_offset, p.obs_cam, q, t, X, 1e-2, True, obs_undist=undist)
+    k_g, c_g = pr.TrackFilter.FilterTracksByReprojection(view, 1e-2, True, ctx=gsfm_ctx)
+    assert np.array_equal(k_g.astype(bool), k_o) and c_g == c_o
+    k_o, c_o = of.filter_tracks_by_angle(p.pt_offset, p.obs_cam, q, t, X, undist, 1.0, cam_calibrated=cal)
+    k_g, c_g = pr.TrackFilter.FilterTracksByAngle(view, 1.0, ctx=gsfm_ctx)
+    assert np.array_equal(k_g.astype(bool), k_o) and c_g == c_o
+    k_o, c_o = of.filter_tracks_triangulation_angle(p.pt_offset, p.obs_cam, q, t, X, 1.0)
+    k_g, c_g = pr.TrackFilter.FilterTrackTriangulationAngle(view, 1.0, ctx=gsfm_ctx)
+    assert np.array_equal(k_g.astype(bool), k_o) and c_g == c_o
+
+
+@pytest.mark.gpu
+def test_gpu_pixel_reprojection_filter_matches_oracle(gsfm_ctx):
+    from glomap_amd import processors as pr
+
+    b = synthetic.make_ba_problem(num_cams=25, num_pts=1500, seed=6, shared_intrinsics=False, outlier_ratio=0.05)
+    view = pr.SceneView(b.num_cams, b.pt_offset, b.obs_cam, b.gt_q, b.gt_t, b.gt_xyz, obs_xy=b.obs_xy, cam_intr=b.cam_intr,
+                        intr_model=b.intr_model, intr_params=b.gt_intr)
+    k_o, c_o = of.filter_tracks_by_reprojection(b.pt_offset, b.obs_cam, b.gt_q, b.gt_t, b.gt_xyz, 4.0, False, obs_xy=b.obs_xy,
+                                                cam_intr=b.cam_intr, intr_model=b.intr_model, intr_params=b.gt_intr)
+    k_g, c_g = pr.TrackFilter.FilterTracksByReprojection(view, 4.0, False, ctx=gsfm_ctx)
+    assert np.array_equal(k_g.astype(bool), k_o) and c_g == c_o
+    assert 0.02 < 1 - k_o.mean() < 0.1
+
+
+@pytest.mark.gpu
+def test_gpu_normalizer_and_rotation_filter_match_oracle(gsfm_ctx):
+    from glomap_amd import processors as pr
+
+    p, q, t, undist, X = _scene(seed=4)
+    reg = np.ones(p.num_cams, np.uint8)
+    reg[::7] = 0
+    t_o, X_o, (s_o, tr_o) = of.normalize_reconstruction(q, t, X, cam_registered=reg)
+    t_g, X_g, (s_g, tr_g) = pr.NormalizeReconstruction(q, t, X, cam_registered=reg, ctx=gsfm_ctx)
+    assert abs(s_g - s_o) <= 1e-12 * s_o and np.allclose(tr_g, tr_o, rtol=1e-12, atol=1e-12)
+    assert np.allclose(t_g, t_o, rtol=1e-12, atol=1e-10) and np.allclose(X_g, X_o, rtol=1e-12, atol=1e-10)
+    g = synthetic.make_ring_view_graph(300, 10, seed=7)
+    nq = so3.rotmat_to_quat(g.gt_R)
+    k_o, n_o = of.filter_rotations(nq, g.edge_i, g.edge_j, g.edge_q, 5.0)
+    k_g, n_g = pr.RelPoseFilter.FilterRotations(nq, g.edge_i, g.edge_j, g.edge_q, 5.0, ctx=gsfm_ctx)
+    assert np.array_equal(k_g.astype(bool), k_o) and n_g == n_o
