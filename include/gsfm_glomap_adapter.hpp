@@ -19,6 +19,7 @@
 // not vendored); tests/adapter/ compiles it against interface-shaped stand-ins of those headers.
 #pragma once
 
+#include <array>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -438,6 +439,229 @@ class BundleAdjuster {
 
  private:
   glomap::BundleAdjusterOptions options_;
+};
+
+
+// ---------------------------------------------------------------------------------------------
+// TrackFilter (glomap/processors/track_filter.h:9-31), NormalizeReconstruction
+// (glomap/processors/reconstruction_normalizer.h), RelPoseFilter::FilterRotations
+// (glomap/processors/relpose_filter.h): same signatures and in-place semantics as the reference.
+// ---------------------------------------------------------------------------------------------
+namespace detail {
+
+struct ViewPack {
+  TrackPack tp;
+  FrameIndex fidx;
+  std::vector<double> undist, xy, q, t, xyz;
+  std::vector<uint8_t> cal;
+  gsfm_scene_view view{};
+};
+
+// every observation of every track, images looked up with .at() like the reference (track_filter.cc:18)
+inline void PackView(const std::unordered_map<camera_t, glomap::Camera>* cameras,
+                     const std::unordered_map<image_t, glomap::Image>& images,
+                     std::unordered_map<track_t, glomap::Track>& tracks, bool with_undist, ViewPack& vp) {
+  for (auto& [tid, track] : tracks) {
+    if (track.observations.empty()) continue;
+    for (const auto& obs : track.observations) {
+      const auto& im = images.at(obs.first);
+      vp.tp.obs_cam.push_back(vp.fidx.Add(im.frame_id));
+      vp.tp.obs_image.push_back(obs.first);
+      vp.tp.obs_feature.push_back(obs.second);
+    }
+    vp.tp.track_ids.push_back(tid);
+    vp.tp.pt_offset.push_back(static_cast<int64_t>(vp.tp.obs_cam.size()));
+  }
+  const size_t N = vp.fidx.ids.size(), P = vp.tp.track_ids.size(), M = vp.tp.obs_cam.size();
+  vp.q.resize(4 * N);
+  vp.t.resize(3 * N);
+  vp.cal.assign(N, 1);
+  vp.xyz.resize(3 * P);
+  if (with_undist) vp.undist.resize(3 * M);
+  for (size_t k = 0; k < M; ++k) {
+    const auto& im = images.at(vp.tp.obs_image[k]);
+    const int n = vp.tp.obs_cam[k];
+    const auto& pose = im.frame_ptr->RigFromWorld();  // trivial rigs: cam_from_world
+    vp.q[4 * n] = pose.rotation.w();
+    vp.q[4 * n + 1] = pose.rotation.x();
+    vp.q[4 * n + 2] = pose.rotation.y();
+    vp.q[4 * n + 3] = pose.rotation.z();
+    for (int j = 0; j < 3; ++j) vp.t[3 * n + j] = pose.translation[j];
+    if (cameras) vp.cal[n] = cameras->at(im.camera_id).has_prior_focal_length ? 1 : 0;
+    if (with_undist)
+      for (int j = 0; j < 3; ++j) vp.undist[3 * k + j] = im.features_undist[vp.tp.obs_feature[k]][j];
+  }
+  for (size_t p = 0; p < P; ++p)
+    for (int j = 0; j < 3; ++j) vp.xyz[3 * p + j] = tracks.at(vp.tp.track_ids[p]).xyz[j];
+  vp.view.mem = GSFM_MEM_HOST;
+  vp.view.num_cams = static_cast<int32_t>(N);
+  vp.view.num_pts = static_cast<int64_t>(P);
+  vp.view.num_obs = static_cast<int64_t>(M);
+  vp.view.pt_offset = vp.tp.pt_offset.data();
+  vp.view.obs_cam = vp.tp.obs_cam.data();
+  vp.view.obs_undist = with_undist ? vp.undist.data() : nullptr;
+  vp.view.cam_q = vp.q.data();
+  vp.view.cam_t = vp.t.data();
+  vp.view.pt_xyz = vp.xyz.data();
+  vp.view.cam_calibrated = vp.cal.data();
+}
+
+// rewrite Track::observations from an observation keep mask; returns nothing (the counter comes from the C ABI)
+inline void ApplyObsMask(const ViewPack& vp, const std::vector<uint8_t>& keep, std::unordered_map<track_t, glomap::Track>& tracks) {
+  for (size_t p = 0; p < vp.tp.track_ids.size(); ++p) {
+    auto& tr = tracks.at(vp.tp.track_ids[p]);
+    std::vector<glomap::Observation> kept;
+    for (int64_t k = vp.tp.pt_offset[p]; k < vp.tp.pt_offset[p + 1]; ++k)
+      if (keep[k]) kept.emplace_back(vp.tp.obs_image[k], vp.tp.obs_feature[k]);
+    if (kept.size() != tr.observations.size()) tr.observations = kept;
+  }
+}
+
+}  // namespace detail
+
+struct TrackFilter {
+  // track_filter.cc:7-52 (normalised image coordinates; the pixel-space variant needs the camera model: use the C ABI)
+  static int FilterTracksByReprojection(const glomap::ViewGraph& /*view_graph*/,
+                                        const std::unordered_map<camera_t, glomap::Camera>& cameras,
+                                        const std::unordered_map<image_t, glomap::Image>& images,
+                                        std::unordered_map<track_t, glomap::Track>& tracks,
+                                        double max_reprojection_error = 1e-2, bool in_normalized_image = true) {
+    gsfm_ctx* ctx = Context();
+    if (ctx == nullptr || !in_normalized_image) return -1;
+    detail::ViewPack vp;
+    detail::PackView(&cameras, images, tracks, true, vp);
+    if (vp.view.num_obs == 0) return 0;
+    std::vector<uint8_t> keep(static_cast<size_t>(vp.view.num_obs));
+    int64_t changed = 0;
+    if (gsfm_filter_tracks_by_reprojection(ctx, &vp.view, max_reprojection_error, 1, keep.data(), &changed) != GSFM_OK) return -1;
+    detail::ApplyObsMask(vp, keep, tracks);
+    return static_cast<int>(changed);
+  }
+
+  // track_filter.cc:54-90
+  static int FilterTracksByAngle(const glomap::ViewGraph& /*view_graph*/,
+                                 const std::unordered_map<camera_t, glomap::Camera>& cameras,
+                                 const std::unordered_map<image_t, glomap::Image>& images,
+                                 std::unordered_map<track_t, glomap::Track>& tracks, double max_angle_error = 1.) {
+    gsfm_ctx* ctx = Context();
+    if (ctx == nullptr) return -1;
+    detail::ViewPack vp;
+    detail::PackView(&cameras, images, tracks, true, vp);
+    if (vp.view.num_obs == 0) return 0;
+    std::vector<uint8_t> keep(static_cast<size_t>(vp.view.num_obs));
+    int64_t changed = 0;
+    if (gsfm_filter_tracks_by_angle(ctx, &vp.view, max_angle_error, keep.data(), &changed) != GSFM_OK) return -1;
+    detail::ApplyObsMask(vp, keep, tracks);
+    return static_cast<int>(changed);
+  }
+
+  // track_filter.cc:92-127: tracks whose rays never span min_angle lose ALL observations
+  static int FilterTrackTriangulationAngle(const glomap::ViewGraph& /*view_graph*/,
+                                           const std::unordered_map<image_t, glomap::Image>& images,
+                                           std::unordered_map<track_t, glomap::Track>& tracks, double min_angle = 1.) {
+    gsfm_ctx* ctx = Context();
+    if (ctx == nullptr) return -1;
+    detail::ViewPack vp;
+    detail::PackView(nullptr, images, tracks, false, vp);
+    if (vp.view.num_pts == 0) return 0;
+    std::vector<uint8_t> keep(static_cast<size_t>(vp.view.num_pts));
+    int64_t removed = 0;
+    if (gsfm_filter_tracks_triangulation_angle(ctx, &vp.view, min_angle, keep.data(), &removed) != GSFM_OK) return -1;
+    for (size_t p = 0; p < vp.tp.track_ids.size(); ++p)
+      if (!keep[p]) tracks.at(vp.tp.track_ids[p]).observations.clear();
+    return static_cast<int>(removed);
+  }
+};
+
+// reconstruction_normalizer.cc:5-85 (trivial rigs).  Returns {scale, tx, ty, tz} of X' = scale X + t.
+inline std::array<double, 4> NormalizeReconstruction(std::unordered_map<rig_t, glomap::Rig>& /*rigs*/,
+                                                     std::unordered_map<camera_t, glomap::Camera>& /*cameras*/,
+                                                     std::unordered_map<frame_t, glomap::Frame>& frames,
+                                                     std::unordered_map<image_t, glomap::Image>& images,
+                                                     std::unordered_map<track_t, glomap::Track>& tracks,
+                                                     bool fixed_scale = false, double extent = 10., double p0 = 0.1,
+                                                     double p1 = 0.9) {
+  std::array<double, 4> sim{1.0, 0.0, 0.0, 0.0};
+  gsfm_ctx* ctx = Context();
+  if (ctx == nullptr) return sim;
+  detail::FrameIndex fidx;
+  for (auto& [fid, fr] : frames)
+    if (fr.HasPose()) fidx.Add(fid);
+  const size_t N = fidx.ids.size();
+  if (N == 0) return sim;
+  std::vector<uint8_t> reg(N, 0);
+  for (auto& [iid, im] : images)  // the bounding box uses the registered IMAGES (reconstruction_normalizer.cc:24-30)
+    if (im.IsRegistered() && fidx.of.count(im.frame_id)) reg[fidx.of.at(im.frame_id)] = 1;
+  std::vector<double> q(4 * N), t(3 * N);
+  for (size_t n = 0; n < N; ++n) {
+    const auto& pose = frames.at(fidx.ids[n]).RigFromWorld();
+    q[4 * n] = pose.rotation.w();
+    q[4 * n + 1] = pose.rotation.x();
+    q[4 * n + 2] = pose.rotation.y();
+    q[4 * n + 3] = pose.rotation.z();
+    for (int j = 0; j < 3; ++j) t[3 * n + j] = pose.translation[j];
+  }
+  std::vector<track_t> tids;
+  std::vector<double> xyz;
+  for (auto& [tid, tr] : tracks) {  // every track is transformed, initialised or not (:80-82)
+    tids.push_back(tid);
+    for (int j = 0; j < 3; ++j) xyz.push_back(tr.xyz[j]);
+  }
+  if (gsfm_normalize_reconstruction(ctx, GSFM_MEM_HOST, static_cast<int32_t>(N), reg.data(), q.data(), t.data(),
+                                    static_cast<int64_t>(tids.size()), xyz.data(), fixed_scale, extent, p0, p1, sim.data()) != GSFM_OK)
+    return sim;
+  for (size_t n = 0; n < N; ++n) {
+    auto& fr = frames.at(fidx.ids[n]);
+    auto pose = fr.RigFromWorld();
+    pose.translation = decltype(pose.translation)(t[3 * n], t[3 * n + 1], t[3 * n + 2]);
+    fr.SetRigFromWorld(pose);
+  }
+  for (size_t p = 0; p < tids.size(); ++p) {
+    auto& tr = tracks.at(tids[p]);
+    tr.xyz = decltype(tr.xyz)(xyz[3 * p], xyz[3 * p + 1], xyz[3 * p + 2]);
+  }
+  return sim;
+}
+
+struct RelPoseFilter {
+  // relpose_filter.cc:7-33: invalidates pairs whose measured rotation disagrees with the estimated one
+  static void FilterRotations(glomap::ViewGraph& view_graph, const std::unordered_map<image_t, glomap::Image>& images,
+                              double max_angle = 5.0) {
+    gsfm_ctx* ctx = Context();
+    if (ctx == nullptr) return;
+    detail::FrameIndex fidx;
+    std::vector<int32_t> ei, ej;
+    std::vector<double> eq, nq;
+    std::vector<glomap::ImagePair*> pairs;
+    auto node = [&](const glomap::Image& im) {
+      const size_t before = fidx.ids.size();
+      const int n = fidx.Add(im.frame_id);
+      if (fidx.ids.size() != before) {
+        const auto& r = im.frame_ptr->RigFromWorld().rotation;
+        nq.insert(nq.end(), {r.w(), r.x(), r.y(), r.z()});
+      }
+      return n;
+    };
+    for (auto& [pid, pair] : view_graph.image_pairs) {
+      if (!pair.is_valid) continue;
+      const auto& i1 = images.at(pair.image_id1);
+      const auto& i2 = images.at(pair.image_id2);
+      if (!i1.IsRegistered() || !i2.IsRegistered()) continue;
+      ei.push_back(node(i1));
+      ej.push_back(node(i2));
+      const auto& r = pair.cam2_from_cam1.rotation;
+      eq.insert(eq.end(), {r.w(), r.x(), r.y(), r.z()});
+      pairs.push_back(&pair);
+    }
+    if (pairs.empty()) return;
+    std::vector<uint8_t> keep(pairs.size());
+    int64_t ninv = 0;
+    if (gsfm_filter_rotations(ctx, GSFM_MEM_HOST, static_cast<int32_t>(fidx.ids.size()), nq.data(), static_cast<int64_t>(pairs.size()),
+                              ei.data(), ej.data(), eq.data(), max_angle, keep.data(), &ninv) != GSFM_OK)
+      return;
+    for (size_t e = 0; e < pairs.size(); ++e)
+      if (!keep[e]) pairs[e]->is_valid = false;
+  }
 };
 
 }  // namespace gsfm_glomap

@@ -159,6 +159,36 @@ int main() {
       maxerr = std::fmax(maxerr, std::hypot(u - f[0], v - f[1]));
     }
   if (maxerr > 1e-3) return std::printf("BA reprojection error %.3e px\n", maxerr), 1;
+  // 4) processors: a corrupted observation is filtered, a far point has no triangulation angle,
+  //    a wrong relative rotation is invalidated, normalisation scales the ring of centres to extent 10
+  {
+    auto& im0 = images[0];
+    im0.features_undist[0] = mock_eigen::Vector3d(0.6, 0.0, 0.8);  // first observation of some track in image 0
+    const int changed = gsfm_glomap::TrackFilter::FilterTracksByAngle(vg, cameras, images, tracks, 1.0);
+    if (changed != 1) return std::printf("FilterTracksByAngle changed %d tracks\n", changed), 1;
+    const int changed2 = gsfm_glomap::TrackFilter::FilterTracksByReprojection(vg, cameras, images, tracks, 1e-2, true);
+    if (changed2 != 0) return std::printf("FilterTracksByReprojection changed %d tracks\n", changed2), 1;
+    tracks[5].xyz = mock_eigen::Vector3d(1e7, 2e7, 3e7);
+    const int removed = gsfm_glomap::TrackFilter::FilterTrackTriangulationAngle(vg, images, tracks, 1.0);
+    if (removed != 1 || !tracks[5].observations.empty()) return std::printf("triangulation filter removed %d\n", removed), 1;
+    auto& bad = vg.image_pairs.begin()->second;
+    bad.cam2_from_cam1.rotation = mock_eigen::Quaterniond(0.0, 1.0, 0.0, 0.0);  // 180 degrees about x
+    gsfm_glomap::RelPoseFilter::FilterRotations(vg, images, 5.0);
+    int ninvalid = 0;
+    for (auto& [id, pr] : vg.image_pairs) ninvalid += pr.is_valid ? 0 : 1;
+    if (ninvalid != 1 || bad.is_valid) return std::printf("FilterRotations invalidated %d pairs\n", ninvalid), 1;
+    double c0b[3], c8b[3], c0n[3], c8n[3];
+    center(frames[0], c0b);
+    center(frames[8], c8b);
+    const double diam_before = dist(c0b, c8b);
+    const auto sim = gsfm_glomap::NormalizeReconstruction(rigs, cameras, frames, images, tracks);
+    center(frames[0], c0n);
+    center(frames[8], c8n);
+    // every distance between camera centres scales by the returned factor
+    const double diam = dist(c0n, c8n);
+    if (!(sim[0] > 0.0) || std::fabs(diam / (diam_before * sim[0]) - 1.0) > 1e-9)
+      return std::printf("normalizer scale %.9f diam %.9f (before %.9f)\n", sim[0], diam, diam_before), 1;
+  }
   std::printf("ADAPTER OK ra=%.2e rad gp_ratio_err=%.2e ba=%.2e px\n", worst, std::fabs(ratio / ratio_ref - 1.0), maxerr);
   return 0;
 }
