@@ -33,7 +33,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
-KERNEL_RA, KERNEL_GP, KERNEL_BA, KERNEL_GP_B, KERNEL_BA_B, KERNEL_RA_GJ = 0, 1, 2, 3, 4, 5
+KERNEL_RA, KERNEL_GP, KERNEL_BA, KERNEL_GP_B, KERNEL_BA_B, KERNEL_RA_GJ, KERNEL_FILTER = 0, 1, 2, 3, 4, 5, 6
 F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix, AMD datasheet (the local guide lists no f64 MFMA figure)
 
 
@@ -129,6 +129,7 @@ def run_extras(env, args, world, rank, main_line):
             # rotation averaging at the camera counts of configs[2] / configs[3] (iterative solver: N > 2048)
             extra["ra_c3"] = bench_ra_sized(env["ctx"], 5000, 50)
             extra["ra_c4"] = bench_ra_sized(env["ctx"], 10000, 50)
+            extra["track_filters_c3"] = bench_filters(env["ctx"])
         except Exception as e:
             extra["ra_side"] = {"error": repr(e)}
 
@@ -334,6 +335,44 @@ def bench_ra(args, ctx, rank, world, barrier, dist):
         "median_rot_err_deg_vs_gt": float(np.median(err)),
     }
     return base_line("view-graph edges/sec (RA)", value, "edges/s", world, args, dt, config, roof, cpu, ctx)
+
+
+def bench_filters(ctx):
+    """Track filters on the observation lists of configs[2] (5k cameras / 500k tracks /
+    ~3M observations), arrays resident in HBM: FilterTracksByAngle + FilterTracksByReprojection sweeps."""
+    import numpy as np
+
+    from glomap_amd import processors as pr
+    from glomap_amd import so3, synthetic
+
+    p = synthetic.make_gp_problem(5000, 500_000, seed=0)
+    q = so3.rotmat_to_quat(p.cam_R)
+    t = -np.einsum("nij,nj->ni", p.cam_R, p.gt_center)
+    undist = np.einsum("mij,mj->mi", p.cam_R[p.obs_cam], p.obs_dir)
+    dv = pr.SceneView(p.num_cams, ctx.to_device(p.pt_offset), ctx.to_device(p.obs_cam), ctx.to_device(q), ctx.to_device(t),
+                      ctx.to_device(p.gt_xyz), obs_undist=ctx.to_device(undist))
+    M = p.num_obs
+    out = {}
+    for name, fn in (("FilterTracksByAngle", lambda: pr.TrackFilter.FilterTracksByAngle(dv, 1.0, ctx=ctx)),
+                     ("FilterTracksByReprojection", lambda: pr.TrackFilter.FilterTracksByReprojection(dv, 1e-2, True, ctx=ctx))):
+        fn()
+        ctx.profile_enable(True)
+        ctx.profile_read(KERNEL_FILTER)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            keep, changed = fn()
+        ctx.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        ctx.profile_enable(False)
+        n, ms = ctx.profile_read(KERNEL_FILTER)
+        kbytes = 33.0 * M + 32.0 * p.num_pts  # ray 24 + cam 4 + obs_pt 4 + keep 1 per observation; X_p 24 + off 8 per track
+        out[name] = {"observations": M, "tracks_changed": int(changed), "call_ms": dt * 1e3, "value": M / dt, "unit": "obs/s",
+                     "k_filter_obs_avg_us": ms / n * 1e3 if n else None,
+                     "k_filter_obs_GBps": kbytes / (ms / n * 1e-3) / 1e9 if n else None,
+                     "frac_of_hbm_peak": kbytes / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS if n else None}
+    return out
 
 
 def bench_ra_sized(ctx, N, succ):

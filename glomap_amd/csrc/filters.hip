@@ -57,11 +57,21 @@ __device__ __forceinline__ long track_of(const long* __restrict__ off, long P, l
   return lo;
 }
 
-// mode 0: reprojection error in normalised image coordinates; 1: in pixels; 2: angle test
+// obs_pt[k] = track of observation k (one thread per track writes its run)
 __global__ void __launch_bounds__(kBlock)
-    k_filter_obs(ViewDev v, int mode, double thr, double thr_uncalib, unsigned char* __restrict__ keep) {
+    k_fill_obs_pt(long P, const long* __restrict__ off, int* __restrict__ obs_pt) {
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x)
+    for (long k = off[p]; k < off[p + 1]; ++k) obs_pt[k] = (int)p;
+}
+
+// mode 0: reprojection error in normalised image coordinates; 1: in pixels; 2: angle test.
+// One lane per observation: coalesced ray / pixel / index reads, L2-resident camera gathers, the point of
+// the track read by its consecutive lanes.
+__global__ void __launch_bounds__(kBlock)
+    k_filter_obs(ViewDev v, const int* __restrict__ obs_pt, int mode, double thr, double thr_uncalib,
+                 unsigned char* __restrict__ keep) {
   for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < v.M; k += (long)gridDim.x * blockDim.x) {
-    const long p = track_of(v.off, v.P, k);
+    const long p = obs_pt[k];
     const int n = v.cam[k];
     double R[9];
     quat_to_R9(v.q + 4 * (long)n, R);
@@ -211,7 +221,7 @@ __global__ void __launch_bounds__(kBlock)
 
 struct FilterWs {
   DevBuf<long> off;
-  DevBuf<int> cam, cam_intr, intr_model, ei, ej;
+  DevBuf<int> cam, cam_intr, intr_model, ei, ej, obs_pt;
   DevBuf<double> undist, xy, q, t, X, intr, eq, nq;
   DevBuf<float> cen;
   DevBuf<unsigned char> cal, keep, reg;
@@ -227,47 +237,43 @@ FilterWs* filter_ws(gsfm_ctx* ctx) {
   return static_cast<FilterWs*>(ctx->fl_ws);
 }
 
+// Arrays already resident in HBM are used in place; host arrays are staged into the ctx workspace.
+template <typename T>
+const T* dev_in(gsfm_ctx* ctx, DevBuf<T>& buf, const T* src, size_t n, int mem) {
+  if (mem == GSFM_MEM_DEVICE) return src;
+  T* dst = buf.ensure(n + 1);
+  copy_in(ctx, dst, src, n, mem);
+  return dst;
+}
+
 void stage_view(gsfm_ctx* ctx, FilterWs* ws, const gsfm_scene_view* v, bool need_undist, bool need_pixels, ViewDev& d) {
   GSFM_REQUIRE(v && v->pt_offset && v->obs_cam && v->cam_q && v->cam_t && v->pt_xyz, "filter: null argument");
   GSFM_REQUIRE(v->num_cams > 0 && v->num_pts >= 0 && v->num_obs >= 0, "filter: bad sizes");
   const int mem = v->mem;
   const long P = v->num_pts, M = v->num_obs;
   const int N = v->num_cams;
-  copy_in(ctx, ws->off.ensure(P + 1), reinterpret_cast<const long*>(v->pt_offset), (size_t)P + 1, mem);
-  copy_in(ctx, ws->cam.ensure(M + 1), v->obs_cam, (size_t)M, mem);
-  copy_in(ctx, ws->q.ensure(4 * (size_t)N), v->cam_q, 4 * (size_t)N, mem);
-  copy_in(ctx, ws->t.ensure(3 * (size_t)N), v->cam_t, 3 * (size_t)N, mem);
-  copy_in(ctx, ws->X.ensure(3 * (size_t)P + 3), v->pt_xyz, 3 * (size_t)P, mem);
   d = ViewDev{};
   d.N = N;
   d.P = P;
   d.M = M;
-  d.off = ws->off.get();
-  d.cam = ws->cam.get();
-  d.q = ws->q.get();
-  d.t = ws->t.get();
-  d.X = ws->X.get();
+  d.off = dev_in(ctx, ws->off, reinterpret_cast<const long*>(v->pt_offset), (size_t)P + 1, mem);
+  d.cam = dev_in(ctx, ws->cam, v->obs_cam, (size_t)M, mem);
+  d.q = dev_in(ctx, ws->q, v->cam_q, 4 * (size_t)N, mem);
+  d.t = dev_in(ctx, ws->t, v->cam_t, 3 * (size_t)N, mem);
+  d.X = dev_in(ctx, ws->X, v->pt_xyz, 3 * (size_t)P, mem);
   if (need_undist) {
     GSFM_REQUIRE(v->obs_undist != nullptr, "filter: obs_undist required");
-    copy_in(ctx, ws->undist.ensure(3 * (size_t)M + 3), v->obs_undist, 3 * (size_t)M, mem);
-    d.undist = ws->undist.get();
+    d.undist = dev_in(ctx, ws->undist, v->obs_undist, 3 * (size_t)M, mem);
   }
   if (need_pixels) {
     GSFM_REQUIRE(v->obs_xy && v->cam_intr && v->intr_model && v->intr_params && v->num_intr > 0,
                  "filter: pixel-space reprojection needs obs_xy and the intrinsics arrays");
-    copy_in(ctx, ws->xy.ensure(2 * (size_t)M + 2), v->obs_xy, 2 * (size_t)M, mem);
-    copy_in(ctx, ws->cam_intr.ensure(N), v->cam_intr, (size_t)N, mem);
-    copy_in(ctx, ws->intr_model.ensure(v->num_intr), v->intr_model, (size_t)v->num_intr, mem);
-    copy_in(ctx, ws->intr.ensure(8 * (size_t)v->num_intr), v->intr_params, 8 * (size_t)v->num_intr, mem);
-    d.xy = ws->xy.get();
-    d.cam_intr = ws->cam_intr.get();
-    d.intr_model = ws->intr_model.get();
-    d.intr_params = ws->intr.get();
+    d.xy = dev_in(ctx, ws->xy, v->obs_xy, 2 * (size_t)M, mem);
+    d.cam_intr = dev_in(ctx, ws->cam_intr, v->cam_intr, (size_t)N, mem);
+    d.intr_model = dev_in(ctx, ws->intr_model, v->intr_model, (size_t)v->num_intr, mem);
+    d.intr_params = dev_in(ctx, ws->intr, v->intr_params, 8 * (size_t)v->num_intr, mem);
   }
-  if (v->cam_calibrated) {
-    copy_in(ctx, ws->cal.ensure(N), v->cam_calibrated, (size_t)N, mem);
-    d.calibrated = ws->cal.get();
-  }
+  if (v->cam_calibrated) d.calibrated = dev_in(ctx, ws->cal, v->cam_calibrated, (size_t)N, mem);
 }
 
 long read_counter(gsfm_ctx* ctx, FilterWs* ws) {
@@ -286,14 +292,18 @@ int filter_obs_impl(gsfm_ctx* ctx, const gsfm_scene_view* view, int mode, double
   ViewDev d;
   stage_view(ctx, ws, view, mode != 1, mode == 1, d);
   hipStream_t s = ctx->stream;
-  ws->keep.ensure(d.M + 1);
+  const bool dev = view->mem == GSFM_MEM_DEVICE;
+  unsigned char* keep = dev ? keep_out : ws->keep.ensure(d.M + 1);
   ws->counter.ensure(1);
   GSFM_HIP_CHECK(hipMemsetAsync(ws->counter.get(), 0, sizeof(unsigned long long), s));
   if (d.M > 0) {
-    hipLaunchKernelGGL(k_filter_obs, dim3(grid_wide(d.M, kBlock, 1 << 16)), dim3(kBlock), 0, s, d, mode, thr, thr2, ws->keep.get());
-    hipLaunchKernelGGL(k_count_changed, dim3(grid_for(d.P, kBlock)), dim3(kBlock), 0, s, d.P, d.off, ws->keep.get(), ws->counter.get());
+    hipLaunchKernelGGL(k_fill_obs_pt, dim3(grid_wide(d.P, kBlock, 1 << 16)), dim3(kBlock), 0, s, d.P, d.off, ws->obs_pt.ensure(d.M + 1));
+    const bool timed = ctx->prof.begin(s, GSFM_KERNEL_FILTER_OBS);
+    hipLaunchKernelGGL(k_filter_obs, dim3(grid_wide(d.M, kBlock, 1 << 16)), dim3(kBlock), 0, s, d, ws->obs_pt.get(), mode, thr, thr2, keep);
+    if (timed) ctx->prof.end(s);
+    hipLaunchKernelGGL(k_count_changed, dim3(grid_for(d.P, kBlock)), dim3(kBlock), 0, s, d.P, d.off, keep, ws->counter.get());
   }
-  copy_out(ctx, keep_out, ws->keep.get(), (size_t)d.M, view->mem);
+  if (!dev) copy_out(ctx, keep_out, keep, (size_t)d.M, view->mem);
   const long c = read_counter(ctx, ws);
   if (changed) *changed = c;
   return GSFM_OK;

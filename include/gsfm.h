@@ -111,7 +111,8 @@ enum {
   GSFM_KERNEL_GP_SCHUR_B = 3,   /* k_gp_phaseB: camera-major half */
   GSFM_KERNEL_BA_SCHUR_B = 4,   /* k_ba_phaseB: camera-major half */
   GSFM_KERNEL_RA_GJ = 5,        /* k_dense_gj_step: one block Gauss-Jordan step of the dense RA inverse (f64 MFMA) */
-  GSFM_KERNEL_COUNT = 6
+  GSFM_KERNEL_FILTER_OBS = 6,   /* k_filter_obs: per-observation reprojection / angle test of the track filters */
+  GSFM_KERNEL_COUNT = 7
 };
 int gsfm_ctx_profile_enable(gsfm_ctx* ctx, int enable);
 /* Reads and resets the accumulated launch count / total milliseconds of one kernel id. */
