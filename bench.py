@@ -209,7 +209,10 @@ def pmc_traffic(kernel):
     PMC pass exists for this kernel."""
     try:
         d = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
-        return d.get(kernel, {}).get("bytes_per_launch")
+        for name, rec in d.items():  # template instances carry their arguments: "k_ba_phaseA<2>"
+            if name == kernel or name.startswith(kernel + "<"):
+                return rec.get("bytes_per_launch")
+        return None
     except Exception:
         return None
 
