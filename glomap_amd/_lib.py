@@ -72,6 +72,7 @@ class RaOptions(C.Structure):
         ("pcg_relative_tolerance", C.c_double),
         ("pcg_max_iterations", C.c_int32),
         ("force_iterative", C.c_int32),
+        ("pcg_relative_tolerance_admm", C.c_double),
     ]
 
 

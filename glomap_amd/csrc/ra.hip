@@ -927,7 +927,9 @@ int ra_solve_impl(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
         lin_iters += opt->l1_admm_max_num_iterations;
       }
       for (int a = 0; !d.dense && a < opt->l1_admm_max_num_iterations; ++a) {
-        lin_iters += pcg_solve(d, a > 0, opt->pcg_relative_tolerance, opt->pcg_max_iterations);
+        // first x-update of a solve: cold start, full tolerance; later ones: warm-started corrections
+        lin_iters += pcg_solve(d, a > 0, a > 0 ? opt->pcg_relative_tolerance_admm : opt->pcg_relative_tolerance,
+                               opt->pcg_max_iterations);
         hipLaunchKernelGGL(k_admm_edge, dim3(d.gridE), dim3(kBlock), 0, s, E, d.has_gauge, d.fixed,
                            ws->ei.get(), ws->ej.get(), d.ew, ws->res.get(), ws->x.get(), ws->z.get(),
                            ws->u.get(), ws->dz.get(), opt->l1_admm_alpha, 1.0 / opt->l1_admm_rho,
@@ -1038,6 +1040,7 @@ extern "C" void gsfm_ra_options_default(gsfm_ra_options* o) {
   o->pcg_relative_tolerance = 1e-10;
   o->pcg_max_iterations = 2000;
   o->force_iterative = 0;
+  o->pcg_relative_tolerance_admm = 1e-3;
 }
 
 extern "C" int gsfm_ra_solve(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_options* opt,

@@ -75,6 +75,7 @@ class RotationEstimatorOptions:
     pcg_relative_tolerance: float = 1e-10
     pcg_max_iterations: int = 2000
     force_iterative: bool = False  # True: PCG even where the dense direct solve applies (N <= 2048)
+    pcg_relative_tolerance_admm: float = 1e-3  # x-updates inside the ADMM loop (warm-started corrections)
 
     GEMAN_MCCLURE = 0
     HALF_NORM = 1
@@ -85,7 +86,7 @@ class RotationEstimatorOptions:
         for name in (
             "max_num_l1_iterations l1_step_convergence_threshold max_num_irls_iterations "
             "irls_step_convergence_threshold irls_loss_parameter_sigma weight_type "
-            "pcg_relative_tolerance pcg_max_iterations"
+            "pcg_relative_tolerance pcg_max_iterations pcg_relative_tolerance_admm"
         ).split():
             setattr(o, name, getattr(self, name))
         o.skip_initialization = int(self.skip_initialization)

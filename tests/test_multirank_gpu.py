@@ -41,7 +41,7 @@ def _worker(rank, world, port, ra_init, q):
     s, _ = sharding.shard_ra_problem(ra, rank, world)
     s.node_aa0 = ra_init
     rc, rot, rep = estimators.ra_solve(s, estimators.RotationEstimatorOptions(skip_initialization=True), ctx=ctx)
-    out["ra"] = (rc, rot, rep)
+    out["ra"] = (rc, rot, rep)  # sharded => iterative linear solver
     # GP: tracks sharded, centres replicated
     s, (lo, hi) = sharding.shard_gp_problem(gp, rank, world)
     rc, cen, xyz, rep = estimators.gp_solve(s, ctx=ctx)
@@ -66,7 +66,9 @@ def test_two_ranks_reproduce_single_rank(gsfm_ctx):
         ra, estimators.RotationEstimatorOptions(max_num_l1_iterations=0, max_num_irls_iterations=0), ctx=gsfm_ctx)
     assert rc == 0
     ra1 = type(ra)(**{**ra.__dict__, "node_aa0": ra_init})
-    rc, rot1, rep_ra1 = estimators.ra_solve(ra1, estimators.RotationEstimatorOptions(skip_initialization=True), ctx=gsfm_ctx)
+    # same linear solver as the sharded run (PCG; a single rank would otherwise pick the dense direct solver)
+    rc, rot1, rep_ra1 = estimators.ra_solve(
+        ra1, estimators.RotationEstimatorOptions(skip_initialization=True, force_iterative=True), ctx=gsfm_ctx)
     assert rc == 0
     rc, cen1, xyz1, rep_gp1 = estimators.gp_solve(gp, ctx=gsfm_ctx)
     assert rc == 0
@@ -88,9 +90,10 @@ def test_two_ranks_reproduce_single_rank(gsfm_ctx):
     for r in (0, 1):
         rc, rot, rep = res[r]["ra"]
         assert rc == 0
-        assert (rep["iterations_l1"], rep["iterations_irls"]) == (rep_ra1["iterations_l1"], rep_ra1["iterations_irls"])
+        assert rep["iterations_l1"] == rep_ra1["iterations_l1"]
+        assert abs(rep["iterations_irls"] - rep_ra1["iterations_irls"]) <= 1  # all-reduce changes the summation order
         ang = np.radians(so3.rotation_angle_deg(so3.aa_to_rotmat(rot), so3.aa_to_rotmat(rot1)))
-        assert ang.max() < 1e-6, ang.max()
+        assert ang.max() < 1e-4, ang.max()
     assert np.array_equal(res[0]["ra"][1], res[1]["ra"][1])  # replicated state is bit-identical
 
     # --- GP: point draws differ per shard (rank-dependent seeds), so compare the converged centres
