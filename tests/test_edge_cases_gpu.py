@@ -1,0 +1,120 @@
+"""Edge cases through the C ABI on the GPU: long tracks (> 64 observations: the multi-round path of the
+wave tiles), ragged tracks incl. empty and too-short ones, empty problems and bad indices (status codes
+instead of crashes), a single camera."""
+import numpy as np
+import pytest
+
+from glomap_amd import _lib, estimators, so3, synthetic
+from glomap_amd.flat import BaProblem, GpProblem
+from oracle import ba as oba
+from oracle import gp as ogp
+
+pytestmark = pytest.mark.gpu
+
+
+def _dense_visibility_gp(ncam=96, npts=60, seed=0, short=25):
+    """Every point is seen by EVERY camera (track length 96 > 64) plus `short` ragged tracks (0..4 views)."""
+    rng = np.random.default_rng(seed)
+    p = synthetic.make_gp_problem(ncam, npts, seed=seed, outlier_ratio=0.0)
+    centers, R = p.gt_center, p.cam_R
+    X = rng.normal(0, 3.0, (npts + short, 3))
+    lens = np.concatenate([np.full(npts, ncam), rng.integers(0, 5, short)])
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    cam = np.concatenate([np.arange(ncam)] * npts + [rng.choice(ncam, int(l), replace=False) for l in lens[npts:]]).astype(np.int32)
+    pt = np.repeat(np.arange(npts + short), lens)
+    d = X[pt] - centers[cam]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return GpProblem(ncam, npts + short, off, cam, d, np.ones(len(cam), np.uint8), np.zeros((ncam, 3)), np.zeros((npts + short, 3)),
+                     cam_R=R, gt_center=centers, gt_xyz=X), lens
+
+
+def test_gp_long_and_ragged_tracks_match_oracle(gsfm_ctx):
+    p, lens = _dense_visibility_gp()
+    ok, c_o, X_o, s = ogp.solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated, p.cam_center, p.pt_xyz)
+    rc, c_g, X_g, rep = estimators.gp_solve(p, ctx=gsfm_ctx)
+    assert ok and rc == 0
+    extent = np.linalg.norm(c_o - c_o.mean(0), axis=1).max()
+    assert synthetic.center_errors_after_sim3(c_g, c_o).max() / extent < 1e-3
+    assert synthetic.center_errors_after_sim3(c_g, p.gt_center).max() / extent < 1e-6  # noise-free
+    # tracks shorter than min_num_view_per_track (gp.cc:258), the empty ones included, are left untouched
+    untouched = lens < 3
+    assert untouched.any() and np.array_equal(X_g[untouched], p.pt_xyz[untouched])
+
+
+def test_ba_long_and_ragged_tracks_match_oracle(gsfm_ctx):
+    b = synthetic.make_ba_problem(num_cams=80, num_pts=40, seed=2, pixel_noise=0.3, outlier_ratio=0.0, shared_intrinsics=True)
+    rng = np.random.default_rng(2)
+    ncam, npts, short = 80, 40, 20
+    R = so3.quat_to_rotmat(b.gt_q)
+    X = np.concatenate([b.gt_xyz, rng.normal(0, 5.0, (short, 3))])
+    lens = np.concatenate([np.full(npts, ncam), rng.integers(0, 5, short)])
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    cam = np.concatenate([np.arange(ncam)] * npts + [rng.choice(ncam, int(l), replace=False) for l in lens[npts:]]).astype(np.int32)
+    pt = np.repeat(np.arange(npts + short), lens)
+    xc = np.einsum("mij,mj->mi", R[cam], X[pt]) + b.gt_t[cam]
+    front = xc[:, 2] > 1.0  # keep the synthetic scene physical: drop views from behind
+    keep_obs = front | (pt >= npts)
+    xy = synthetic.project_simple_radial(b.gt_intr[np.zeros(len(cam), int)], np.where(xc[:, 2:3] > 0.1, xc, [0, 0, 1.0]))
+    xy += rng.normal(0, 0.3, xy.shape)
+    # rebuild ragged arrays after dropping back-facing views of the long tracks
+    cam, xy, pt = cam[keep_obs], xy[keep_obs], pt[keep_obs]
+    lens = np.bincount(pt, minlength=npts + short)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    assert lens.max() > 64
+    X0 = X + rng.normal(0, 0.05, X.shape)
+    p = BaProblem(num_cams=ncam, num_pts=npts + short, num_intr=1, pt_offset=off, obs_cam=cam, obs_xy=xy,
+                  cam_intr=b.cam_intr, cam_q=b.cam_q, cam_t=b.cam_t, pt_xyz=X0, intr_model=b.intr_model,
+                  intr_params=b.intr_params, fixed_cam=0)
+    ok, q_o, t_o, X_o, i_o, s = oba.solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_xy, p.cam_intr, p.intr_model, p.fixed_cam,
+                                          p.cam_q, p.cam_t, p.pt_xyz, p.intr_params)
+    rc, q_g, t_g, X_g, i_g, rep = estimators.ba_solve(p, ctx=gsfm_ctx)
+    assert ok and rc == 0
+    assert abs(rep["final_cost"] - s.final_cost) <= 1e-4 * s.final_cost
+    ang = np.radians(so3.rotation_angle_deg(so3.quat_to_rotmat(q_g), so3.quat_to_rotmat(q_o)))
+    assert ang.max() < 1e-4
+    untouched = lens < 3
+    assert untouched.any() and np.array_equal(X_g[untouched], X0[untouched])  # ba.cc:122
+
+
+def test_empty_and_invalid_inputs_return_status_codes(gsfm_ctx):
+    # no tracks: reference returns false (gp.cc:46-50, ba.cc:21-24)
+    p = GpProblem(4, 0, np.zeros(1, np.int64), np.zeros(0, np.int32), np.zeros((0, 3)), np.zeros(0, np.uint8),
+                  np.zeros((4, 3)), np.zeros((0, 3)))
+    rc, *_ = estimators.gp_solve(p, ctx=gsfm_ctx)
+    assert rc == -5  # GSFM_ERR_EMPTY_PROBLEM
+    # only too-short tracks
+    p = GpProblem(4, 2, np.array([0, 2, 4], np.int64), np.array([0, 1, 2, 3], np.int32), np.ones((4, 3)) / np.sqrt(3),
+                  np.ones(4, np.uint8), np.zeros((4, 3)), np.zeros((2, 3)))
+    rc, *_ = estimators.gp_solve(p, ctx=gsfm_ctx)
+    assert rc == -5
+    # camera index out of range
+    p = GpProblem(4, 1, np.array([0, 3], np.int64), np.array([0, 1, 7], np.int32), np.ones((3, 3)) / np.sqrt(3),
+                  np.ones(3, np.uint8), np.zeros((4, 3)), np.zeros((1, 3)))
+    rc, *_ = estimators.gp_solve(p, ctx=gsfm_ctx)
+    assert rc == -1  # GSFM_ERR_INVALID_ARGUMENT
+    # unsupported camera model
+    b = synthetic.make_ba_problem(num_cams=5, num_pts=40, seed=1, shared_intrinsics=True)
+    b.intr_model = np.array([17], np.int32)
+    rc, *_ = estimators.ba_solve(b, ctx=gsfm_ctx)
+    assert rc == -7  # GSFM_ERR_UNSUPPORTED
+    # rotation averaging: gravity path is refused like the reference refuses unsupported rigs (gra.cc:47-58)
+    g = synthetic.make_ring_view_graph(20, 3, seed=0)
+    rc, *_ = estimators.ra_solve(g, estimators.RotationEstimatorOptions(use_gravity=True), ctx=gsfm_ctx)
+    assert rc == -7
+    # the context is still usable afterwards
+    rc, rot, rep = estimators.ra_solve(g, ctx=gsfm_ctx)
+    assert rc == 0
+
+
+def test_ra_two_nodes_one_edge(gsfm_ctx):
+    """Smallest possible view graph."""
+    q = so3.aa_to_quat(np.array([[0.0, 0.3, 0.0]]))
+    from glomap_amd.flat import RaProblem
+
+    p = RaProblem(2, np.array([0], np.int32), np.array([1], np.int32), q, np.array([1.0]), np.array([50], np.int32),
+                  np.zeros((2, 3)), 0)
+    rc, rot, rep = estimators.ra_solve(p, ctx=gsfm_ctx)
+    assert rc == 0
+    R = so3.aa_to_rotmat(rot)
+    rel = R[1] @ R[0].T
+    assert np.allclose(rel, so3.quat_to_rotmat(q)[0], atol=1e-9)
