@@ -546,51 +546,77 @@ __global__ void __launch_bounds__(kBlock)
 // Joint variant (one intrinsics block per camera): damping and rhs as above, and the inverse of the
 // 14 x 14 block [S_pose + D, C; C^T, S_intr + D] of camera n and intrinsics block cam_intr[n], stored
 // transposed (minvj[(i * 14 + j) * N + n]) for coalesced reads in k_cg_update_joint.
+// 16 lanes per camera: lane i < 14 keeps row i in registers, Gauss-Jordan (SPD: no pivoting) with the
+// pivot row broadcast by wave shuffles — no scratch, 4 cameras per wave.
 __global__ void __launch_bounds__(kBlock)
     k_ba_blocks_finalize_joint(int N, double radius, double lo, double hi, const int* __restrict__ cam_intr,
                                const double* __restrict__ diag, const double* __restrict__ js,
                                const double* __restrict__ gred, const double* __restrict__ spose,
                                const double* __restrict__ intr_acc, const double* __restrict__ scross,
                                double* __restrict__ dvec, double* __restrict__ rhs, double* __restrict__ minvj) {
-  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
-    double A[14 * 14];
-    double Dv[14];
-    const int k = cam_intr[n];
-    const long op = 6 * (long)n, oi = 6 * (long)N + 8 * (long)k;
-    const double* sp = spose + 21 * (long)n;
-    const double* acc = intr_acc + 44 * (long)k;
-    const double* cr = scross + 48 * (long)n;
-    for (int i = 0; i < 6; ++i) {
-      Dv[i] = lm_damping(diag[op + i], js[op + i], radius, lo, hi);
-      dvec[op + i] = Dv[i];
-      rhs[op + i] = -gred[op + i];
-      for (int j = i; j < 6; ++j) {
-        const double v = sp[sym6(i, j)] + (i == j ? Dv[i] : 0.0);
-        A[i * 14 + j] = v;
-        A[j * 14 + i] = v;
-      }
-      for (int j = 0; j < 8; ++j) {
-        A[i * 14 + 6 + j] = cr[8 * i + j];
-        A[(6 + j) * 14 + i] = cr[8 * i + j];
+  const int lane = threadIdx.x & 63;
+  const int base = lane & ~15;
+  const int c = threadIdx.x >> 4, i = threadIdx.x & 15;
+  for (int n0 = blockIdx.x * (kBlock / 16); n0 < N; n0 += gridDim.x * (kBlock / 16)) {
+    const int n = n0 + c;
+    const bool cam_ok = n < N;
+    const bool act = cam_ok && i < 14;
+    double a[14];
+#pragma unroll
+    for (int j = 0; j < 14; ++j) a[j] = (j == i) ? 1.0 : 0.0;  // idle lanes / cameras: identity rows
+    if (act) {
+      const int k = cam_intr[n];
+      const long op = 6 * (long)n, oi = 6 * (long)N + 8 * (long)k;
+      const double* sp = spose + 21 * (long)n;
+      const double* acc = intr_acc + 44 * (long)k;
+      const double* cr = scross + 48 * (long)n;
+      if (i < 6) {
+        const double D = lm_damping(diag[op + i], js[op + i], radius, lo, hi);
+        dvec[op + i] = D;
+        rhs[op + i] = -gred[op + i];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) a[j] = sp[sym6(i < j ? i : j, i < j ? j : i)] + (i == j ? D : 0.0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[6 + j] = cr[8 * i + j];
+      } else {
+        const int ii = i - 6;
+        const double D = lm_damping(diag[oi + ii], js[oi + ii], radius, lo, hi);
+        dvec[oi + ii] = D;
+        rhs[oi + ii] = -acc[ii];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) a[j] = cr[8 * j + ii];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[6 + j] = acc[8 + sym8(ii < j ? ii : j, ii < j ? j : ii)] + (ii == j ? D : 0.0);
       }
     }
-    for (int i = 0; i < 8; ++i) {
-      Dv[6 + i] = lm_damping(diag[oi + i], js[oi + i], radius, lo, hi);
-      dvec[oi + i] = Dv[6 + i];
-      rhs[oi + i] = -acc[i];
-      for (int j = i; j < 8; ++j) {
-        const double v = acc[8 + sym8(i, j)] + (i == j ? Dv[6 + i] : 0.0);
-        A[(6 + i) * 14 + 6 + j] = v;
-        A[(6 + j) * 14 + 6 + i] = v;
+    double d0 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 14; ++j) d0 = (j == i) ? a[j] : d0;  // own diagonal entry (fallback)
+    bool bad = false;
+#pragma unroll
+    for (int p = 0; p < 14; ++p) {
+      double rowp[14];
+#pragma unroll
+      for (int j = 0; j < 14; ++j) rowp[j] = __shfl(a[j], base + p, 64);
+      const double piv = rowp[p];
+      bad = bad || !(piv > 0.0) || !isfinite(piv);
+      const double ipiv = 1.0 / piv;
+      const double colv = a[p];
+      const bool is_p = i == p;
+#pragma unroll
+      for (int j = 0; j < 14; ++j) {
+        double v = is_p ? rowp[j] * ipiv : a[j] - colv * rowp[j] * ipiv;
+        if (j == p) v = is_p ? ipiv : -colv * ipiv;
+        a[j] = v;
       }
     }
-    double diag0[14];
-    for (int i = 0; i < 14; ++i) diag0[i] = A[i * 14 + i];
-    if (!spd_inverse<14>(A, 14)) {  // numerically indefinite block: fall back to its diagonal
-      for (int i = 0; i < 14; ++i)
-        for (int j = 0; j < 14; ++j) A[i * 14 + j] = (i == j) ? 1.0 / diag0[i] : 0.0;
+    if (act) {
+#pragma unroll
+      for (int j = 0; j < 14; ++j) {
+        const double v = bad ? ((j == i) ? 1.0 / d0 : 0.0) : a[j];  // indefinite block: fall back to its diagonal
+        minvj[(size_t)(i * 14 + j) * N + n] = v;
+      }
     }
-    for (int i = 0; i < 196; ++i) minvj[(size_t)i * N + n] = A[i];
   }
 }
 
@@ -1303,7 +1329,7 @@ class BaSolver final : public LmProblem {
       if (joint_) allreduce_sum(ctx_, ws->scross.get(), 48 * (size_t)N_);
     }
     if (joint_) {
-      hipLaunchKernelGGL(k_ba_blocks_finalize_joint, dim3(grid_for(N_, kBlock)), dim3(kBlock), 0, s, N_, radius, g_.lm_lo,
+      hipLaunchKernelGGL(k_ba_blocks_finalize_joint, dim3(grid_for(N_, kBlock / 16)), dim3(kBlock), 0, s, N_, radius, g_.lm_lo,
                          g_.lm_hi, g_.cam_intr, ws->diag.get(), ws->js.get(), ws->gred.get(), ws->spose.get(),
                          ws->iacc44.get(), ws->scross.get(), ws->dvec.get(), ws->rhs.get(), ws->minvj.get());
     } else

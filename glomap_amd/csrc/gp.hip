@@ -69,21 +69,27 @@ __device__ __forceinline__ double block_max(double v, double* smem /* >= 4 */) {
 }
 
 // ---- linearize, point side: cost, robust weights, |g_s|, |g_X| max-norms, H_pp trace ----------
-// One thread per track.  part[block][2] = {cost, max gradient entry}.
+// One lane per observation (track-major tiles), per-track sums by segmented wave scan.
+// part[block][2] = {cost, max gradient entry}.
 __global__ void __launch_bounds__(kBlock)
     k_gp_lin_track(GpDev g, const double* __restrict__ c, const double* __restrict__ X,
                    const double* __restrict__ s, double* __restrict__ wrob, double* __restrict__ hppd,
                    double* __restrict__ part) {
   __shared__ double smem[8];
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (kBlock / 64);
   double cost = 0.0, gmax = 0.0;
-  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.g.P; p += (long)gridDim.x * blockDim.x) {
-    if (!g.g.used[p]) continue;
-    const V3 Xp = ld3(X + 3 * p);
-    double hpp = 0.0;
-    V3 gX{0, 0, 0};
-    for (long k = g.g.off[p]; k < g.g.off[p + 1]; ++k) {
+  for (int tile = wave; tile < g.g.T; tile += nwaves) {
+    const long k0 = g.g.tile_k[tile], k1 = g.g.tile_k[tile + 1];
+    double acc[4] = {0, 0, 0, 0};  // hpp | gX
+    int key = -1 - lane;
+    for (long k = k0 + lane; k < k1; k += 64) {
+      const int p = g.g.obs_pt[k];
+      key = p;
+      if (!g.g.used[p]) continue;
       const int n = g.g.cam[k];
-      const V3 d = Xp - ld3(c + 3 * (long)n);
+      const V3 d = ld3(X + 3 * (long)p) - ld3(c + 3 * (long)n);
       const double sk = s[k];
       const V3 r = ld3(g.dir + 3 * k) - sk * d;
       double rho, w;
@@ -91,12 +97,17 @@ __global__ void __launch_bounds__(kBlock)
       wrob[k] = w;
       cost += 0.5 * rho;
       const double ws = w * sk;
-      hpp += ws * sk;
-      gX = gX - ws * r;
+      acc[0] += ws * sk;
+      acc[1] -= ws * r.x;
+      acc[2] -= ws * r.y;
+      acc[3] -= ws * r.z;
       if (g.opt_s && k != g.fixed_obs) gmax = fmax(gmax, fabs(w * dot(d, r)));
     }
-    hppd[p] = hpp;
-    if (g.opt_x) gmax = fmax(gmax, fmax(fabs(gX.x), fmax(fabs(gX.y), fabs(gX.z))));
+    seg_scan<4>(acc, key, lane);
+    if (seg_is_tail(key, lane) && key >= 0 && g.g.used[key]) {
+      hppd[key] = acc[0];
+      if (g.opt_x) gmax = fmax(gmax, fmax(fabs(acc[1]), fmax(fabs(acc[2]), fabs(acc[3]))));
+    }
   }
   double v[1] = {cost};
   block_sum<1>(v, smem);
@@ -188,58 +199,71 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // ---- build, point side (radius dependent): eliminate scales and points --------------------------
-// One thread per track: (a_k, beta_k) per observation, H_pp^-1 and e = H_pp^-1 g_p per track.
+// One lane per observation: (a_k, beta_k) per observation (coalesced writes); H_pp and g_p per track by a
+// segmented wave scan; the tail lane of a track inverts H_pp and writes the two point records.
 __global__ void __launch_bounds__(kBlock)
     k_gp_build_track(GpDev g, double radius, const double* __restrict__ c, const double* __restrict__ X,
                      const double* __restrict__ s, const double* __restrict__ wrob,
                      const double* __restrict__ jss, const double* __restrict__ jsx,
                      const double* __restrict__ hppd, double* __restrict__ qa, double* __restrict__ qb,
                      double* __restrict__ ptb, double* __restrict__ ptrec) {
-  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.g.P; p += (long)gridDim.x * blockDim.x) {
-    if (!g.g.used[p]) continue;
-    const V3 Xp = ld3(X + 3 * p);
-    S3 H{0, 0, 0, 0, 0, 0};
-    V3 gp{0, 0, 0};
-    for (long k = g.g.off[p]; k < g.g.off[p + 1]; ++k) {
-      const V3 d = Xp - ld3(c + 3 * (long)g.g.cam[k]);
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (kBlock / 64);
+  for (int tile = wave; tile < g.g.T; tile += nwaves) {
+    const long k0 = g.g.tile_k[tile], k1 = g.g.tile_k[tile + 1];
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // H (xx xy xz yy yz zz) | g_p
+    int key = -1 - lane;
+    for (long k = k0 + lane; k < k1; k += 64) {
+      const int p = g.g.obs_pt[k];
+      key = p;
+      if (!g.g.used[p]) continue;
+      const V3 d = ld3(X + 3 * (long)p) - ld3(c + 3 * (long)g.g.cam[k]);
       const double sk = s[k], w = wrob[k];
       const V3 r = ld3(g.dir + 3 * k) - sk * d;
-      const double dd = dot(d, d);
       double beta = 0.0;
       if (g.opt_s && k != g.fixed_obs) {
-        const double hraw = w * dd;
+        const double hraw = w * dot(d, d);
         beta = w / (hraw + lm_damping(hraw, jss[k], radius, g.lm_lo, g.lm_hi));
       }
       const double a = w * sk * sk;
       qa[k] = a;
       qb[k] = beta;
       const double ab = a * beta;
-      H.xx += a - ab * d.x * d.x;
-      H.xy += -ab * d.x * d.y;
-      H.xz += -ab * d.x * d.z;
-      H.yy += a - ab * d.y * d.y;
-      H.yz += -ab * d.y * d.z;
-      H.zz += a - ab * d.z * d.z;
+      acc[0] += a - ab * d.x * d.x;
+      acc[1] += -ab * d.x * d.y;
+      acc[2] += -ab * d.x * d.z;
+      acc[3] += a - ab * d.y * d.y;
+      acc[4] += -ab * d.y * d.z;
+      acc[5] += a - ab * d.z * d.z;
       const V3 q = applyQ(w * sk, beta, d, r);  // s w (r - beta d (d.r))
-      gp = gp - q;
+      acc[6] -= q.x;
+      acc[7] -= q.y;
+      acc[8] -= q.z;
     }
-    S3 Hi{0, 0, 0, 0, 0, 0};
-    V3 e{0, 0, 0};
-    if (g.opt_x) {
-      const double Dp = lm_damping(hppd[p], jsx[p], radius, g.lm_lo, g.lm_hi);
-      H.xx += Dp;
-      H.yy += Dp;
-      H.zz += Dp;
-      Hi = inv3(H);
-      e = mul(Hi, gp);
+    seg_scan<9>(acc, key, lane);
+    if (seg_is_tail(key, lane) && key >= 0 && g.g.used[key]) {
+      const long p = key;
+      const V3 Xp = ld3(X + 3 * p);
+      S3 H{acc[0], acc[1], acc[2], acc[3], acc[4], acc[5]};
+      S3 Hi{0, 0, 0, 0, 0, 0};
+      V3 e{0, 0, 0};
+      if (g.opt_x) {
+        const double Dp = lm_damping(hppd[p], jsx[p], radius, g.lm_lo, g.lm_hi);
+        H.xx += Dp;
+        H.yy += Dp;
+        H.zz += Dp;
+        Hi = inv3(H);
+        e = mul(Hi, V3{acc[6], acc[7], acc[8]});
+      }
+      double* b = ptb + 12 * p;
+      st3(b, Xp);
+      st3(b + 3, e);
+      b[6] = Hi.xx; b[7] = Hi.xy; b[8] = Hi.xz; b[9] = Hi.yy; b[10] = Hi.yz; b[11] = Hi.zz;
+      double* pr = ptrec + 8 * p;
+      st3(pr, Xp);
+      pr[3] = pr[4] = pr[5] = 0.0;
     }
-    double* b = ptb + 12 * p;
-    st3(b, Xp);
-    st3(b + 3, e);
-    b[6] = Hi.xx; b[7] = Hi.xy; b[8] = Hi.xz; b[9] = Hi.yy; b[10] = Hi.yz; b[11] = Hi.zz;
-    double* pr = ptrec + 8 * p;
-    st3(pr, Xp);
-    pr[3] = pr[4] = pr[5] = 0.0;
   }
 }
 
@@ -407,6 +431,8 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // ---- back-substitution, model cost change, candidate point ------------------------------------
+// One lane per observation: dX_p = H_pp^-1 sum_k Q_k dc - e_p (segmented scan, broadcast back to the
+// track's lanes), then per observation the scale step, the model decrease and the candidate scale.
 // part[block][3] = {model_cost_change, |dX|^2 + |ds|^2, |X|^2 + |s|^2}
 __global__ void __launch_bounds__(kBlock)
     k_gp_backsub(GpDev g, const double* __restrict__ c, const double* __restrict__ X,
@@ -416,28 +442,55 @@ __global__ void __launch_bounds__(kBlock)
                  double* __restrict__ sn, double* __restrict__ part) {
   __shared__ double smem[4 * 3];
   double acc3[3] = {0, 0, 0};
-  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.g.P; p += (long)gridDim.x * blockDim.x) {
-    const V3 Xp = ld3(X + 3 * p);
-    if (!g.g.used[p]) {
-      st3(Xn + 3 * p, Xp);
-      for (long k = g.g.off[p]; k < g.g.off[p + 1]; ++k) sn[k] = s[k];
-      continue;
-    }
-    const long k0 = g.g.off[p], k1 = g.g.off[p + 1];
-    V3 dX{0, 0, 0};
-    if (g.opt_x) {
-      V3 acc{0, 0, 0};
-      for (long k = k0; k < k1; ++k) {
-        const long n = g.g.cam[k];
-        acc = acc + applyQ(qa[k], qb[k], Xp - ld3(c + 3 * n), ld3(dc + 3 * n));
-      }
-      const double* b = ptb + 12 * p;
-      dX = mul(S3{b[6], b[7], b[8], b[9], b[10], b[11]}, acc) - ld3(b + 3);
-    }
-    for (long k = k0; k < k1; ++k) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (kBlock / 64);
+  for (int tile = wave; tile < g.g.T; tile += nwaves) {
+    const long k0 = g.g.tile_k[tile], k1 = g.g.tile_k[tile + 1];
+    double acc[3] = {0, 0, 0};
+    int key = -1 - lane;
+    for (long k = k0 + lane; k < k1; k += 64) {
+      const int p = g.g.obs_pt[k];
+      key = p;
+      if (!g.g.used[p] || !g.opt_x) continue;
       const long n = g.g.cam[k];
-      const V3 d = Xp - ld3(c + 3 * n);
-      const double sk = s[k], w = wrob[k];
+      const V3 y = applyQ(qa[k], qb[k], ld3(X + 3 * (long)p) - ld3(c + 3 * n), ld3(dc + 3 * n));
+      acc[0] += y.x;
+      acc[1] += y.y;
+      acc[2] += y.z;
+    }
+    seg_scan<3>(acc, key, lane);
+    const bool tail = seg_is_tail(key, lane) && key >= 0;
+    V3 dX{0, 0, 0};
+    if (tail) {
+      const long p = key;
+      const V3 Xp = ld3(X + 3 * p);
+      if (g.g.used[p]) {
+        if (g.opt_x) {
+          const double* b = ptb + 12 * p;
+          dX = mul(S3{b[6], b[7], b[8], b[9], b[10], b[11]}, V3{acc[0], acc[1], acc[2]}) - ld3(b + 3);
+        }
+        acc3[1] += dot(dX, dX);
+        acc3[2] += dot(Xp, Xp);
+      }
+      st3(Xn + 3 * p, Xp + dX);
+    }
+    const unsigned long long tmask = __ballot(tail);
+    const unsigned long long above = tmask >> lane;
+    const int src = above ? lane + __ffsll((long long)above) - 1 : lane;
+    dX.x = __shfl(dX.x, src, 64);
+    dX.y = __shfl(dX.y, src, 64);
+    dX.z = __shfl(dX.z, src, 64);
+    for (long k = k0 + lane; k < k1; k += 64) {
+      const int p = g.g.obs_pt[k];
+      const double sk = s[k];
+      if (!g.g.used[p]) {
+        sn[k] = sk;
+        continue;
+      }
+      const long n = g.g.cam[k];
+      const V3 d = ld3(X + 3 * (long)p) - ld3(c + 3 * n);
+      const double w = wrob[k];
       const V3 r = ld3(g.dir + 3 * k) - sk * d;
       const V3 dcx = ld3(dc + 3 * n) - dX;
       // delta_s = beta (d.r + s d.(dc - dX)),  beta = w / h_ss (0 for a constant scale)
@@ -449,9 +502,6 @@ __global__ void __launch_bounds__(kBlock)
       acc3[1] += (s_new - sk) * (s_new - sk);
       acc3[2] += sk * sk;
     }
-    st3(Xn + 3 * p, Xp + dX);
-    acc3[1] += dot(dX, dX);
-    acc3[2] += dot(Xp, Xp);
   }
   block_sum<3>(acc3, smem);
   if (threadIdx.x == 0) {
@@ -646,6 +696,7 @@ class GpSolver final : public LmProblem {
     gridM_ = grid_for(M_, kBlock);
     gridCam_ = grid_wide(N_, kBlock / 64, kMaxApplySlots);  // one wave per camera (delta partial per block)
     gridTile_ = grid_wide(g_.g.T, kBlock / 64);             // one wave per tile
+    gridTileP_ = grid_wide(g_.g.T, kBlock / 64, kMaxBlocks);  // tile sweeps that write per-block partials
     g_.dir = ws->dir.get();
     g_.cal = d_cal;
     g_.c_dir = ws->c_dir.get();
@@ -665,6 +716,8 @@ class GpSolver final : public LmProblem {
     s_ = ws->s.get();
     sn_ = ws->sn.get();
     hipLaunchKernelGGL(k_gp_init_scales, dim3(gridM_), dim3(kBlock), 0, s, g_, opt_.generate_scales ? 1 : 0, c_, X_, s_);
+    // tracks without observations are never visited by the lane-per-observation sweeps: both point buffers start equal
+    GSFM_HIP_CHECK(hipMemcpyAsync(Xn_, X_, 3 * (size_t)P_ * sizeof(double), hipMemcpyDeviceToDevice, s));
     // PCG view
     cg_.n = 3 * N_;
     cg_.N = N_;
@@ -693,14 +746,14 @@ class GpSolver final : public LmProblem {
   double linearize(double* grad_max_norm) override {
     GpWs* ws = ws_;
     hipStream_t s = ctx_->stream;
-    hipLaunchKernelGGL(k_gp_lin_track, dim3(gridP_), dim3(kBlock), 0, s, g_, c_, X_, s_, ws->wrob.get(),
+    hipLaunchKernelGGL(k_gp_lin_track, dim3(gridTileP_), dim3(kBlock), 0, s, g_, c_, X_, s_, ws->wrob.get(),
                        ws->hppd.get(), ws->part.get());
     hipLaunchKernelGGL(k_gp_lin_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, c_, X_, s_, ws->hcc.get(), ws->gc.get());
     if (ctx_->comm.world > 1) {
       allreduce_sum(ctx_, ws->hcc.get(), N_);
       allreduce_sum(ctx_, ws->gc.get(), 3 * (size_t)N_);
     }
-    hipLaunchKernelGGL(k_gp_finalize_lin, dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridP_, ws->gc.get(),
+    hipLaunchKernelGGL(k_gp_finalize_lin, dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridTileP_, ws->gc.get(),
                        g_.opt_c ? 3 * N_ : 0, ws->scal.get());
     double h[2];
     read_scalars(ws->scal.get(), h, 2, /*sum_first=*/1, /*max_from=*/1);
@@ -725,7 +778,7 @@ class GpSolver final : public LmProblem {
     hipStream_t s = ctx_->stream;
     const bool multi = ctx_->comm.world > 1;
     const int n3 = 3 * N_;
-    hipLaunchKernelGGL(k_gp_build_track, dim3(gridP_), dim3(kBlock), 0, s, g_, radius, c_, X_, s_, ws->wrob.get(),
+    hipLaunchKernelGGL(k_gp_build_track, dim3(gridTile_), dim3(kBlock), 0, s, g_, radius, c_, X_, s_, ws->wrob.get(),
                        ws->jss.get(), ws->jsx.get(), ws->hppd.get(), ws->qa.get(), ws->qb.get(), ws->ptb.get(),
                        ws->ptrec.get());
     hipLaunchKernelGGL(k_gp_build_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, radius, c_, s_, ws->ptb.get(),
@@ -743,9 +796,9 @@ class GpSolver final : public LmProblem {
     } else {
       GSFM_HIP_CHECK(hipMemsetAsync(ws->cg_x.get(), 0, (size_t)n3 * sizeof(double), s));
     }
-    hipLaunchKernelGGL(k_gp_backsub, dim3(gridP_), dim3(kBlock), 0, s, g_, c_, X_, s_, ws->wrob.get(),
+    hipLaunchKernelGGL(k_gp_backsub, dim3(gridTileP_), dim3(kBlock), 0, s, g_, c_, X_, s_, ws->wrob.get(),
                        ws->qa.get(), ws->qb.get(), ws->ptb.get(), ws->cg_x.get(), Xn_, sn_, ws->part.get());
-    hipLaunchKernelGGL((k_sum_partials<3>), dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridP_, ws->scal.get());
+    hipLaunchKernelGGL((k_sum_partials<3>), dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridTileP_, ws->scal.get());
     const int gridU = std::min(64, grid_for(n3, kBlock));
     double* part2 = ws->part.get() + kMaxBlocks * 3;
     hipLaunchKernelGGL(k_gp_cam_update, dim3(gridU), dim3(kBlock), 0, s, n3, c_, ws->cg_x.get(), cn_, part2);
@@ -822,7 +875,7 @@ class GpSolver final : public LmProblem {
   CgVec cg_{};
   int N_ = 0;
   long P_ = 0, M_ = 0, m_used_ = 0;
-  int gridP_ = 1, gridN_ = 1, gridM_ = 1, gridCam_ = 1, gridTile_ = 1;
+  int gridP_ = 1, gridN_ = 1, gridM_ = 1, gridCam_ = 1, gridTile_ = 1, gridTileP_ = 1;
   double *c_ = nullptr, *cn_ = nullptr, *X_ = nullptr, *Xn_ = nullptr, *s_ = nullptr, *sn_ = nullptr;
 };
 
