@@ -623,6 +623,12 @@ def bench_ba(args, ctx, rank, world, barrier, dist):
         others=[kernel_line(ctx, KERNEL_BA_B, "k_ba_phaseB (camera-major half, Jacobians recomputed, 64-byte point-record gathers)",
                             60.0 * M_loc + 304.0 * ncam + 64.0 * p.num_intr)],
     )
+    # drop-in case: the same solve with every array handed over in HOST memory (H2D at entry, D2H at exit)
+    host_ms = None
+    if world == 1:
+        t0 = time.perf_counter()
+        rc, *_ = estimators.ba_solve(p, opt, ctx=ctx)
+        host_ms = (time.perf_counter() - t0) * 1e3 if rc == 0 else None
     R = so3.quat_to_rotmat(res["q"].numpy())
     Rg = so3.quat_to_rotmat(p.gt_q)
     rot_err = synthetic.rotation_errors_deg(R, Rg)
@@ -640,6 +646,7 @@ def bench_ba(args, ctx, rank, world, barrier, dist):
         "initial_cost": last["initial_cost"],
         "final_cost": last["final_cost"],
         "median_rot_err_deg_vs_gt": float(np.median(rot_err)),
+        "ms_per_solve_host_arrays_pcie_inclusive": host_ms,
     }
     return base_line("track-obs/sec per BA iteration", value, "obs/s", world, args, dt, config, roof, cpu, ctx)
 

@@ -373,19 +373,6 @@ template <int PB>
 __device__ __forceinline__ long cg_joint_index(const CgVec& v, int n, int i) {
   return i < PB ? (long)PB * n + i : (long)PB * v.N + 8L * v.joint_map[n] + (i - PB);
 }
-template <int PB>
-__device__ __forceinline__ void cg_joint_precond(const CgVec& v, int n, const double (&r)[PB + 8], double (&z)[PB + 8]) {
-  constexpr int BJ = PB + 8;
-  const double* m = v.minv_joint + n;
-#pragma unroll
-  for (int i = 0; i < BJ; ++i) {
-    double acc = 0.0;
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) acc += m[(size_t)(i * BJ + j) * v.N] * r[j];
-    z[i] = acc;
-  }
-}
-
 // Joint kernels: 16 lanes per camera (PB + 8 <= 16 active), 16 cameras per workgroup.  Lane (c, i)
 // owns element i of camera c's joint block; the preconditioner row product reads the block's
 // residual from LDS.  minv_joint[(i * BJ + j) * N + n]: for a fixed (i, j) the 16 cameras of a

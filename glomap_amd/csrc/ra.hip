@@ -6,7 +6,8 @@
 //   device: ComputeResiduals                                gra.cc:696-756      -> k_node_quat, k_edge_residual
 //           L1 stage, colmap::LeastAbsoluteDeviationSolver  gra.cc:479-541      -> k_admm_edge, k_node_gather<L1*>
 //           IRLS stage (Geman-McClure / half-norm weights)  gra.cc:543-625      -> k_node_gather<IRLS>
-//           CHOLMOD solve of A^T W A x = A^T W b            gra.cc:603-611      -> Jacobi-PCG, 3 right-hand sides
+//           CHOLMOD solve of A^T W A x = A^T W b            gra.cc:603-611      -> dense direct (ra_dense.hpp, N <= 2048)
+//                                                                                  or Jacobi-PCG (cg.hpp), 3 right-hand sides
 //           UpdateGlobalRotations / ComputeAverageStepSize  gra.cc:627-644,758-772 -> k_node_update
 //
 // Structure exploited: A = B (x) I3 with B the signed incidence matrix of the view graph and the
@@ -20,7 +21,8 @@
 //   rot[N][3], nq[N][4]                                 node state (angle-axis) + its quaternion
 //   res[E+1][3] (row E = gauge rows), wirls[E]          residuals / IRLS weights
 //   z,u,dz[E+1][3]                                      ADMM state
-//   rhs,x,r,p,q,zv[N][3], lap_diag[N]                   PCG vectors
+//   rhs,x[N][3], lap_diag[N], lap_diag_loc[N]           right-hand side / solution, Laplacian diagonal (global / this rank)
+//   cg_*[N][3]                                          PCG vectors (cg.hpp);  dense_a/b[Np][Np] dense Laplacian / inverse
 #include <algorithm>
 #include <numeric>
 
@@ -445,7 +447,7 @@ __global__ void __launch_bounds__(kBlock)
 struct RaWs {
   DevBuf<int> ei, ej, rowptr, inc, nbr, inc_row, flags;
   DevBuf<double> dense_a, dense_b, dense_pinv;
-  DevBuf<double> eq, ew, inc_w, lap_diag, lap_diag_loc, rot, nq, res, wirls, z, u, dz, rhs, x, r, p, q, zv, wbuf,
+  DevBuf<double> eq, ew, inc_w, lap_diag, lap_diag_loc, rot, nq, res, wirls, z, u, dz, rhs, x, r, wbuf,
       gat_s, gat_t, fixed_rot0, part_misc, scal, cg_b, cg_x, cg_r, cg_z, cg_p, cg_s, cg_w, cg_minv, vpart, dpart;
   DevBuf<CgStatus> cgst;
   DevBuf<CgScal> cgsc;
@@ -807,7 +809,7 @@ void setup_device(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
   ws->inc_w.ensure(2 * E + 1);
   ws->lap_diag.ensure(N);
   ws->lap_diag_loc.ensure(N);
-  for (DevBuf<double>* b : {&ws->rhs, &ws->x, &ws->r, &ws->p, &ws->q, &ws->zv, &ws->wbuf, &ws->gat_s, &ws->gat_t})
+  for (DevBuf<double>* b : {&ws->rhs, &ws->x, &ws->r, &ws->wbuf, &ws->gat_s, &ws->gat_t})
     b->ensure(3 * (size_t)N);
   for (DevBuf<double>* b : {&ws->cg_b, &ws->cg_x, &ws->cg_r, &ws->cg_z, &ws->cg_p, &ws->cg_s})
     b->ensure(3 * (size_t)N);
