@@ -33,7 +33,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
-KERNEL_RA, KERNEL_GP, KERNEL_BA, KERNEL_GP_B, KERNEL_BA_B, KERNEL_RA_GJ, KERNEL_FILTER = 0, 1, 2, 3, 4, 5, 6
+KERNEL_RA, KERNEL_GP, KERNEL_BA, KERNEL_GP_B, KERNEL_BA_B, KERNEL_RA_GJ, KERNEL_FILTER, KERNEL_TRACK_HOOK = 0, 1, 2, 3, 4, 5, 6, 7
 F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix, AMD datasheet (the local guide lists no f64 MFMA figure)
 
 
@@ -130,6 +130,7 @@ def run_extras(env, args, world, rank, main_line):
             extra["ra_c3"] = bench_ra_sized(env["ctx"], 5000, 50)
             extra["ra_c4"] = bench_ra_sized(env["ctx"], 10000, 50)
             extra["track_filters_c3"] = bench_filters(env["ctx"])
+            extra["track_establishment_c3"] = bench_tracks(env["ctx"], no_cpu=getattr(args, "no_cpu_baseline", False))
         except Exception as e:
             extra["ra_side"] = {"error": repr(e)}
 
@@ -375,6 +376,67 @@ def bench_filters(ctx):
                      "k_filter_obs_avg_us": ms / n * 1e3 if n else None,
                      "k_filter_obs_GBps": kbytes / (ms / n * 1e-3) / 1e9 if n else None,
                      "frac_of_hbm_peak": kbytes / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS if n else None}
+    return out
+
+
+def bench_tracks(ctx, no_cpu=False):
+    """Track establishment + selection on a match graph of the size of configs[2]
+    (5k images, 500k ground-truth tracks -> ~5.7M inlier matches over ~250k image pairs, 6M features), inputs
+    resident in HBM; results stay in HBM (counts only come back)."""
+    import numpy as np
+
+    from glomap_amd import synthetic
+    from glomap_amd.tracks import MatchGraph, TrackEngine, TrackEstablishmentOptions
+
+    g = synthetic.make_match_graph(5000, 500_000, seed=0)
+    NM, F = len(g["match_feat1"]), int(g["feat_offset"][-1])
+    eng = TrackEngine(MatchGraph.from_dict(g).to_device(ctx), ctx=ctx)
+    reg = ctx.to_device(np.ones(5000, np.uint8))
+    eng.EstablishFullTracks(fetch=False)
+    ctx.profile_enable(True)
+    ctx.profile_read(KERNEL_TRACK_HOOK)
+    reps = 10
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        nt = eng.EstablishFullTracks(fetch=False)
+    ctx.synchronize()
+    t_est = (time.perf_counter() - t0) / reps
+    ctx.profile_enable(False)
+    n, ms = ctx.profile_read(KERNEL_TRACK_HOOK)
+    out = {"images": 5000, "features": F, "image_pairs": len(g["pair_image1"]), "inlier_matches": NM,
+           "tracks": int(nt), "tracks_discarded": int(eng.num_discarded),
+           "establish_ms": t_est * 1e3, "value": NM / t_est, "unit": "matches/s"}
+    if n:
+        # 8 B per match streamed + the two parent entries it must at least read (4 B each)
+        kbytes = 16.0 * NM
+        out["k_uf_hook"] = {"avg_kernel_us": ms / n * 1e3, "bytes_per_launch": kbytes, "achieved_GBps": kbytes / (ms / n * 1e-3) / 1e9,
+                            "frac_of_hbm_peak": kbytes / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "note": "bound by the device's returning-atomic (CAS) rate, not by HBM: the same sweep with the CAS "
+                                    "replaced by a plain store takes 108 us (DESIGN.md section 4.7)"}
+    for name, opts in (("select_default", TrackEstablishmentOptions()),
+                       ("select_cap_200_per_view", TrackEstablishmentOptions(min_num_tracks_per_view=200))):
+        eng.options = opts
+        eng.FindTracksForProblem(reg, fetch=False)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ns = eng.FindTracksForProblem(reg, fetch=False)
+        ctx.synchronize()
+        out[name] = {"ms": (time.perf_counter() - t0) / reps * 1e3, "tracks_selected": int(ns)}
+    if not no_cpu:
+        from oracle import tracks as ot
+
+        a = (g["pair_image1"], g["pair_image2"], g["pair_valid"], g["pair_offset"], g["match_feat1"], g["match_feat2"],
+             g["feat_offset"], g["feat_xy"])
+        t0 = time.perf_counter()
+        ref = ot.establish_full_tracks(*a)
+        t1 = time.perf_counter()
+        ot.find_tracks_for_problem(*ref[:4], np.ones(5000, bool))
+        t2 = time.perf_counter()
+        out["cpu_baseline"] = {"establish_ms": (t1 - t0) * 1e3, "select_ms": (t2 - t1) * 1e3, "cores": 1, "kind": "port",
+                               "sample": "the same match graph, vectorised numpy / scipy.sparse.csgraph restatement (oracle/tracks.py)",
+                               "tracks": int(len(ref[0]))}
     return out
 
 

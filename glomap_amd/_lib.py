@@ -190,6 +190,46 @@ class SceneViewC(C.Structure):
     ]
 
 
+class MatchGraphC(C.Structure):
+    _fields_ = [
+        ("mem", C.c_int32),
+        ("num_images", C.c_int32),
+        ("feat_offset", C.c_void_p),
+        ("feat_xy", C.c_void_p),
+        ("num_pairs", C.c_int64),
+        ("pair_image1", C.c_void_p),
+        ("pair_image2", C.c_void_p),
+        ("pair_valid", C.c_void_p),
+        ("pair_offset", C.c_void_p),
+        ("match_feat1", C.c_void_p),
+        ("match_feat2", C.c_void_p),
+    ]
+
+
+class TrackOptionsC(C.Structure):
+    _fields_ = [
+        ("thres_inconsistency", C.c_double),
+        ("min_num_tracks_per_view", C.c_int32),
+        ("min_num_view_per_track", C.c_int32),
+        ("max_num_view_per_track", C.c_int32),
+        ("max_num_tracks", C.c_int32),
+    ]
+
+
+class TrackSetC(C.Structure):
+    _fields_ = [
+        ("mem", C.c_int32),
+        ("num_tracks", C.c_int64),
+        ("num_obs", C.c_int64),
+        ("track_id", C.c_void_p),
+        ("track_offset", C.c_void_p),
+        ("obs_image", C.c_void_p),
+        ("obs_feature", C.c_void_p),
+    ]
+
+
+GSFM_TRACKS_FULL, GSFM_TRACKS_SELECTED = 0, 1
+
 _lib = None
 
 
@@ -267,6 +307,16 @@ def load():
                                                   C.c_double, C.c_double, dp]
     lib.gsfm_filter_rotations.restype = ip
     lib.gsfm_filter_rotations.argtypes = [vp, C.c_int32, C.c_int32, vp, C.c_int64, vp, vp, vp, C.c_double, vp, i64p]
+    lib.gsfm_track_options_default.restype = None
+    lib.gsfm_track_options_default.argtypes = [C.POINTER(TrackOptionsC)]
+    lib.gsfm_tracks_establish.restype = ip
+    lib.gsfm_tracks_establish.argtypes = [vp, C.POINTER(MatchGraphC), C.POINTER(TrackOptionsC), i64p, i64p, i64p]
+    lib.gsfm_tracks_select.restype = ip
+    lib.gsfm_tracks_select.argtypes = [vp, C.POINTER(TrackSetC), C.c_int32, vp, C.c_int32, C.POINTER(TrackOptionsC), i64p, i64p]
+    lib.gsfm_tracks_fetch.restype = ip
+    lib.gsfm_tracks_fetch.argtypes = [vp, C.c_int32, C.POINTER(TrackSetC)]
+    lib.gsfm_keep_largest_connected_component.restype = ip
+    lib.gsfm_keep_largest_connected_component.argtypes = [vp, C.c_int32, C.c_int32, C.c_int64, vp, vp, vp, vp, vp, i64p]
     _lib = lib
     return lib
 

@@ -62,6 +62,7 @@ extern "C" void gsfm_ctx_destroy(gsfm_ctx* ctx) {
   if (ctx->gp_ws && ctx->gp_ws_free) ctx->gp_ws_free(ctx->gp_ws);
   if (ctx->ba_ws && ctx->ba_ws_free) ctx->ba_ws_free(ctx->ba_ws);
   if (ctx->fl_ws && ctx->fl_ws_free) ctx->fl_ws_free(ctx->fl_ws);
+  if (ctx->tr_ws && ctx->tr_ws_free) ctx->tr_ws_free(ctx->tr_ws);
   if (ctx->comm.nccl) (void)ncclCommDestroy(ctx->comm.nccl);
   ctx->prof.destroy();
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);

@@ -176,7 +176,9 @@ struct gsfm_ctx {
   void* gp_ws = nullptr;
   void* ba_ws = nullptr;
   void* fl_ws = nullptr;
+  void* tr_ws = nullptr;
   void (*fl_ws_free)(void*) = nullptr;
+  void (*tr_ws_free)(void*) = nullptr;
   void (*ra_ws_free)(void*) = nullptr;
   void (*gp_ws_free)(void*) = nullptr;
   void (*ba_ws_free)(void*) = nullptr;

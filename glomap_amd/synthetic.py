@@ -321,3 +321,104 @@ def center_errors_after_sim3(est: np.ndarray, ref: np.ndarray) -> np.ndarray:
     al = (s * (R @ est.T)).T + t
     extent = np.linalg.norm(ref - ref.mean(0), axis=1).max()
     return np.linalg.norm(al - ref, axis=1) / extent
+
+
+def make_match_graph(n_images=200, n_tracks=5000, seed=0, max_gap=12, ring=50, match_prob=0.7, false_match_frac=0.01,
+                     twin_frac=0.005, mean_extra=3.0, max_len=24, width=1280.0, height=960.0):
+    """Synthetic input of track establishment (track_establishment.cc:19-63 reads `image_pair.matches` rows selected
+    by `image_pair.inliers`, and `image.features`): a ring view graph (image i paired with its `ring` successors),
+    ground-truth tracks whose members sit `1..max_gap` images apart, each co-visible member pair matched with
+    probability `match_prob`; `false_match_frac` of the matches join two unrelated features (merging tracks, most of
+    which then fail the same-image consistency test), `twin_frac` of the members get a twin feature 1-3 px away in the
+    same image that is matched too (consistent duplicates, which the reference keeps).  Every image also has as many
+    unmatched features (odd feature indices) as matched ones.
+
+    Returns a dict of flat arrays in the layout of gsfm_match_graph (include/gsfm.h)."""
+    rng = np.random.default_rng(seed)
+    N = int(n_images)
+    ring = min(ring, (N - 1) // 2)
+    L = np.minimum(3 + rng.poisson(mean_extra, n_tracks), max_len).astype(np.int64)
+    off = np.zeros(n_tracks + 1, dtype=np.int64)
+    off[1:] = np.cumsum(L)
+    M = int(off[-1])
+    trk = np.repeat(np.arange(n_tracks), L)
+    pos = np.arange(M) - off[trk]
+    gaps = rng.integers(1, max_gap + 1, M)
+    gaps[off[:-1]] = 0
+    csum = np.cumsum(gaps)
+    rel = csum - csum[off[trk]]
+    span_ok = rel < N  # members of one track are distinct images as long as the span stays below N
+    base = rng.integers(0, N, n_tracks)
+    cam = ((base[trk] + rel) % N).astype(np.int64)
+    # feature index inside the image: 2 * rank among the image's members (odd indices = unmatched features)
+    order = np.argsort(cam, kind="stable")
+    counts = np.bincount(cam, minlength=N)
+    start = np.zeros(N + 1, dtype=np.int64)
+    start[1:] = np.cumsum(counts)
+    rank = np.empty(M, dtype=np.int64)
+    rank[order] = np.arange(M) - start[cam[order]]
+    n_twin = int(twin_frac * M)
+    twin_of = rng.choice(M, n_twin, replace=False) if n_twin else np.zeros(0, dtype=np.int64)
+    # twins take the feature slots after the regular ones of their image
+    tcam = cam[twin_of]
+    torder = np.argsort(tcam, kind="stable")
+    tcount = np.bincount(tcam, minlength=N)
+    tstart = np.zeros(N + 1, dtype=np.int64)
+    tstart[1:] = np.cumsum(tcount)
+    trank = np.empty(n_twin, dtype=np.int64)
+    trank[torder] = np.arange(n_twin) - tstart[tcam[torder]]
+    nfeat = 2 * counts + tcount
+    feat_offset = np.zeros(N + 1, dtype=np.int64)
+    feat_offset[1:] = np.cumsum(nfeat)
+    F = int(feat_offset[-1])
+    feat = 2 * rank
+    tfeat = 2 * counts[tcam] + trank
+    xy = np.stack([rng.uniform(0, width, F), rng.uniform(0, height, F)], axis=1)
+    d = rng.uniform(1.0, 3.0, n_twin)
+    a = rng.uniform(0, 2 * np.pi, n_twin)
+    xy[feat_offset[tcam] + tfeat] = xy[feat_offset[cam[twin_of]] + feat[twin_of]] + np.stack([d * np.cos(a), d * np.sin(a)], 1)
+
+    m_i1, m_i2, m_f1, m_f2 = [], [], [], []
+
+    def emit(ia, fa, ib, fb):
+        dd = (ib - ia) % N
+        fwd = (dd >= 1) & (dd <= ring)
+        bwd = ((-dd) % N >= 1) & ((-dd) % N <= ring) & ~fwd
+        for sel, (i1, f1, i2, f2) in ((fwd, (ia, fa, ib, fb)), (bwd, (ib, fb, ia, fa))):
+            m_i1.append(i1[sel]); m_f1.append(f1[sel]); m_i2.append(i2[sel]); m_f2.append(f2[sel])
+
+    Lmax = int(L.max()) if n_tracks else 0
+    for s in range(1, Lmax):
+        a_idx = np.nonzero((pos + s < L[trk]) & span_ok)[0]
+        b_idx = a_idx + s
+        keep = rng.random(len(a_idx)) < match_prob
+        a_idx, b_idx = a_idx[keep], b_idx[keep]
+        emit(cam[a_idx], feat[a_idx], cam[b_idx], feat[b_idx])
+    # twins: matched to one other member of the track of their original
+    if n_twin:
+        o = twin_of
+        partner = np.where(pos[o] + 1 < L[trk[o]], o + 1, o - 1)
+        emit(tcam, tfeat, cam[partner], feat[partner])
+    i1 = np.concatenate(m_i1); f1 = np.concatenate(m_f1); i2 = np.concatenate(m_i2); f2 = np.concatenate(m_f2)
+    n_false = int(false_match_frac * len(i1))
+    if n_false:
+        a_idx = rng.integers(0, M, n_false)
+        dd = rng.integers(1, ring + 1, n_false)
+        target = (cam[a_idx] + dd) % N
+        has = counts[target] > 0
+        a_idx, target = a_idx[has], target[has]
+        tf = 2 * rng.integers(0, counts[target])
+        i1 = np.concatenate([i1, cam[a_idx]]); f1 = np.concatenate([f1, feat[a_idx]])
+        i2 = np.concatenate([i2, target]); f2 = np.concatenate([f2, tf])
+    # group by image pair (image1, ring offset)
+    pid = i1 * ring + ((i2 - i1) % N - 1)
+    o = np.argsort(pid, kind="stable")
+    pid, f1, f2 = pid[o], f1[o], f2[o]
+    upid, pstart = np.unique(pid, return_index=True)
+    pair_offset = np.append(pstart, len(pid)).astype(np.int64)
+    pair_image1 = (upid // ring).astype(np.int32)
+    pair_image2 = ((pair_image1 + upid % ring + 1) % N).astype(np.int32)
+    return dict(num_images=N, feat_offset=feat_offset, feat_xy=xy, pair_image1=pair_image1, pair_image2=pair_image2,
+                pair_valid=np.ones(len(upid), dtype=np.uint8), pair_offset=pair_offset,
+                match_feat1=f1.astype(np.uint32), match_feat2=f2.astype(np.uint32),
+                gt_num_tracks=n_tracks, gt_num_members=M)

@@ -112,7 +112,8 @@ enum {
   GSFM_KERNEL_BA_SCHUR_B = 4,   /* k_ba_phaseB: camera-major half */
   GSFM_KERNEL_RA_GJ = 5,        /* k_dense_gj_step: one block Gauss-Jordan step of the dense RA inverse (f64 MFMA) */
   GSFM_KERNEL_FILTER_OBS = 6,   /* k_filter_obs: per-observation reprojection / angle test of the track filters */
-  GSFM_KERNEL_COUNT = 7
+  GSFM_KERNEL_TRACK_HOOK = 7,   /* k_uf_hook: union-find hooking sweep over the inlier matches (track establishment) */
+  GSFM_KERNEL_COUNT = 8
 };
 int gsfm_ctx_profile_enable(gsfm_ctx* ctx, int enable);
 /* Reads and resets the accumulated launch count / total milliseconds of one kernel id. */
@@ -342,6 +343,77 @@ int gsfm_normalize_reconstruction(gsfm_ctx* ctx, int32_t mem, int32_t num_cams, 
 int gsfm_filter_rotations(gsfm_ctx* ctx, int32_t mem, int32_t num_nodes, const double* node_q, int64_t num_edges,
                           const int32_t* edge_i, const int32_t* edge_j, const double* edge_q, double max_angle_deg,
                           uint8_t* edge_keep_out, int64_t* num_invalid);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Producers of the GP / BA inputs.
+ *
+ *   TrackEngine::EstablishFullTracks       glomap/controllers/track_establishment.cc:5-152
+ *   TrackEngine::FindTracksForProblem      glomap/controllers/track_establishment.cc:154-227
+ *   ViewGraph::KeepLargestConnectedComponents   glomap/scene/view_graph.cc:56-97
+ *
+ * Images are dense indices 0..num_images-1 in ASCENDING image_id order, so that the reference's global feature id
+ * (image_id << 32 | feature) and (index << 32 | feature) order identically.  What the reference leaves to
+ * hash-table iteration order is fixed canonically: a track's id is its smallest global
+ * feature id, its observations are ascending (image, feature), the full set is ascending by id, the selected set
+ * is in selection order (descending (length, id)).  All results are integers: bit-exact against oracle/tracks.py.
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct gsfm_match_graph {
+  int32_t mem;
+  int32_t num_images;
+  const int64_t* feat_offset;   /* [num_images+1] prefix sums of image.features.size() */
+  const double* feat_xy;        /* [F][2] image.features (pixels), F = feat_offset[num_images] < 2^31 */
+  int64_t num_pairs;
+  const int32_t* pair_image1;   /* [num_pairs] ImagePair::image_id1 as dense index */
+  const int32_t* pair_image2;   /* [num_pairs] */
+  const uint8_t* pair_valid;    /* [num_pairs] ImagePair::is_valid; NULL = all valid */
+  const int64_t* pair_offset;   /* [num_pairs+1] into match_feat*: the rows of `matches` listed in `inliers` */
+  const uint32_t* match_feat1;  /* [num_matches] matches(inliers[i], 0) */
+  const uint32_t* match_feat2;  /* [num_matches] matches(inliers[i], 1) */
+} gsfm_match_graph;
+
+/* Mirror of TrackEstablishmentOptions (track_establishment.h:9-24).  The int options are compared against
+ * size_t / uint64 quantities as C++ does: a negative value acts as 2^64 - |x| (min_num_tracks_per_view = -1,
+ * the default, means "no per-view cap"). */
+typedef struct gsfm_track_options {
+  double thres_inconsistency;        /* 10. */
+  int32_t min_num_tracks_per_view;   /* -1 */
+  int32_t min_num_view_per_track;    /* 3 */
+  int32_t max_num_view_per_track;    /* 100 */
+  int32_t max_num_tracks;            /* 10000000 */
+} gsfm_track_options;
+void gsfm_track_options_default(gsfm_track_options* o);
+
+/* CSR set of tracks.  As an input every pointer is read; as a gsfm_tracks_fetch output the caller allocates
+ * track_id[num_tracks], track_offset[num_tracks+1], obs_image[num_obs], obs_feature[num_obs]. */
+typedef struct gsfm_track_set {
+  int32_t mem;
+  int64_t num_tracks;
+  int64_t num_obs;
+  int64_t* track_id;       /* image << 32 | feature of the track's smallest member */
+  int64_t* track_offset;
+  int32_t* obs_image;
+  uint32_t* obs_feature;
+} gsfm_track_set;
+
+enum { GSFM_TRACKS_FULL = 0, GSFM_TRACKS_SELECTED = 1 };
+
+/* EstablishFullTracks.  The result stays in HBM inside the ctx (GSFM_TRACKS_FULL); *num_tracks counts every
+ * track including the discarded ones, which keep a zero-length slot like the reference's empty Track objects. */
+int gsfm_tracks_establish(gsfm_ctx* ctx, const gsfm_match_graph* graph, const gsfm_track_options* opt,
+                          int64_t* num_tracks, int64_t* num_obs, int64_t* num_discarded);
+/* FindTracksForProblem on `full` (NULL = the ctx's GSFM_TRACKS_FULL).  image_registered: [num_images] bytes in
+ * space `mem` (Image::IsRegistered()).  Result: GSFM_TRACKS_SELECTED inside the ctx. */
+int gsfm_tracks_select(gsfm_ctx* ctx, const gsfm_track_set* full, int32_t num_images, const uint8_t* image_registered,
+                       int32_t mem, const gsfm_track_options* opt, int64_t* num_tracks, int64_t* num_obs);
+/* Copies one of the two sets held by the ctx into caller arrays (host or device per out->mem). */
+int gsfm_tracks_fetch(gsfm_ctx* ctx, int32_t which, gsfm_track_set* out);
+/* KeepLargestConnectedComponents over dense node (frame) indices.  edge_valid_inout [E] is cleared for edges
+ * that leave the component; node_registered_out [N]; node_num_images [N] or NULL (= 1 image per frame);
+ * *num_images_out = the reference's return value (0: no valid edge, nothing is written). */
+int gsfm_keep_largest_connected_component(gsfm_ctx* ctx, int32_t mem, int32_t num_nodes, int64_t num_edges,
+                                          const int32_t* edge_i, const int32_t* edge_j, uint8_t* edge_valid_inout,
+                                          const int32_t* node_num_images, uint8_t* node_registered_out,
+                                          int64_t* num_images_out);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,7 @@
 // not vendored); tests/adapter/ compiles it against interface-shaped stand-ins of those headers.
 #pragma once
 
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstdint>
@@ -27,6 +28,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "glomap/controllers/track_establishment.h"
 #include "glomap/estimators/bundle_adjustment.h"
 #include "glomap/estimators/global_positioning.h"
 #include "glomap/estimators/global_rotation_averaging.h"
@@ -663,5 +665,190 @@ struct RelPoseFilter {
       if (!keep[e]) pairs[e]->is_valid = false;
   }
 };
+
+// ---------------------------------------------------------------------------------------------
+// TrackEngine (controllers/track_establishment.h:26-61) and ViewGraph::KeepLargestConnectedComponents
+// (scene/view_graph.cc:56-97).  Track ids: the reference uses the union-find root, which depends on the
+// iteration order of its hash maps; here a track is named by its smallest member (image_id << 32 | feature),
+// observations are ascending (image_id, feature).  See DESIGN.md section 4.7.
+// ---------------------------------------------------------------------------------------------
+class TrackEngine {
+ public:
+  TrackEngine(const glomap::ViewGraph& view_graph, const std::unordered_map<image_t, glomap::Image>& images,
+              const glomap::TrackEstablishmentOptions& options)
+      : options_(options), view_graph_(view_graph), images_(images) {}
+
+  size_t EstablishFullTracks(std::unordered_map<track_t, glomap::Track>& tracks) {
+    tracks.clear();
+    gsfm_ctx* ctx = Context();
+    if (ctx == nullptr) return 0;
+    std::vector<image_t> ids = SortedImageIds();
+    std::unordered_map<image_t, int32_t> dense;
+    std::vector<int64_t> feat_offset{0};
+    std::vector<double> xy;
+    for (size_t n = 0; n < ids.size(); ++n) {
+      dense.emplace(ids[n], static_cast<int32_t>(n));
+      const auto& im = images_.at(ids[n]);
+      for (const auto& f : im.features) xy.insert(xy.end(), {f[0], f[1]});
+      feat_offset.push_back(static_cast<int64_t>(xy.size() / 2));
+    }
+    std::vector<int32_t> p1, p2;
+    std::vector<int64_t> poff{0};
+    std::vector<uint32_t> f1, f2;
+    for (const auto& [pid, pair] : view_graph_.image_pairs) {
+      if (!pair.is_valid) continue;  // track_establishment.cc:33
+      p1.push_back(dense.at(pair.image_id1));
+      p2.push_back(dense.at(pair.image_id2));
+      for (const int idx : pair.inliers) {  // :41-47
+        f1.push_back(static_cast<uint32_t>(pair.matches(idx, 0)));
+        f2.push_back(static_cast<uint32_t>(pair.matches(idx, 1)));
+      }
+      poff.push_back(static_cast<int64_t>(f1.size()));
+    }
+    gsfm_match_graph g{};
+    g.mem = GSFM_MEM_HOST;
+    g.num_images = static_cast<int32_t>(ids.size());
+    g.feat_offset = feat_offset.data();
+    g.feat_xy = xy.data();
+    g.num_pairs = static_cast<int64_t>(p1.size());
+    g.pair_image1 = p1.data();
+    g.pair_image2 = p2.data();
+    g.pair_valid = nullptr;
+    g.pair_offset = poff.data();
+    g.match_feat1 = f1.data();
+    g.match_feat2 = f2.data();
+    const gsfm_track_options o = Options();
+    int64_t nt = 0, no = 0, nd = 0;
+    if (g.num_images == 0 || gsfm_tracks_establish(ctx, &g, &o, &nt, &no, &nd) != GSFM_OK) return 0;
+    Fetch(ctx, GSFM_TRACKS_FULL, nt, no, ids, /*set_track_id=*/false, tracks);
+    return tracks.size();
+  }
+
+  size_t FindTracksForProblem(const std::unordered_map<track_t, glomap::Track>& tracks_full,
+                              std::unordered_map<track_t, glomap::Track>& tracks_selected) {
+    tracks_selected.clear();
+    gsfm_ctx* ctx = Context();
+    if (ctx == nullptr || tracks_full.empty()) return 0;
+    std::vector<image_t> ids = SortedImageIds();
+    std::unordered_map<image_t, int32_t> dense;
+    std::vector<uint8_t> reg;
+    for (size_t n = 0; n < ids.size(); ++n) {
+      dense.emplace(ids[n], static_cast<int32_t>(n));
+      reg.push_back(images_.at(ids[n]).IsRegistered() ? 1 : 0);  // :175-179
+    }
+    std::vector<int64_t> tid, off{0};
+    std::vector<int32_t> oimg;
+    std::vector<uint32_t> ofeat;
+    for (const auto& [id, tr] : tracks_full) {
+      tid.push_back(static_cast<int64_t>(id));
+      for (const auto& [image_id, feature_id] : tr.observations) {
+        auto it = dense.find(image_id);
+        if (it == dense.end()) {  // an image the engine does not know counts as unregistered (:189)
+          it = dense.emplace(image_id, static_cast<int32_t>(ids.size())).first;
+          ids.push_back(image_id);
+          reg.push_back(0);
+        }
+        oimg.push_back(it->second);
+        ofeat.push_back(feature_id);
+      }
+      off.push_back(static_cast<int64_t>(oimg.size()));
+    }
+    gsfm_track_set full{};
+    full.mem = GSFM_MEM_HOST;
+    full.num_tracks = static_cast<int64_t>(tid.size());
+    full.num_obs = static_cast<int64_t>(oimg.size());
+    full.track_id = tid.data();
+    full.track_offset = off.data();
+    full.obs_image = oimg.data();
+    full.obs_feature = ofeat.data();
+    const gsfm_track_options o = Options();
+    int64_t nt = 0, no = 0;
+    if (gsfm_tracks_select(ctx, &full, static_cast<int32_t>(ids.size()), reg.data(), GSFM_MEM_HOST, &o, &nt, &no) != GSFM_OK) return 0;
+    Fetch(ctx, GSFM_TRACKS_SELECTED, nt, no, ids, /*set_track_id=*/true, tracks_selected);
+    return tracks_selected.size();
+  }
+
+ private:
+  std::vector<image_t> SortedImageIds() const {
+    std::vector<image_t> ids;
+    ids.reserve(images_.size());
+    for (const auto& [id, im] : images_) ids.push_back(id);
+    std::sort(ids.begin(), ids.end());  // dense index order == image_id order (ids compare like the reference's)
+    return ids;
+  }
+  gsfm_track_options Options() const {
+    gsfm_track_options o;
+    o.thres_inconsistency = options_.thres_inconsistency;
+    o.min_num_tracks_per_view = options_.min_num_tracks_per_view;
+    o.min_num_view_per_track = options_.min_num_view_per_track;
+    o.max_num_view_per_track = options_.max_num_view_per_track;
+    o.max_num_tracks = options_.max_num_tracks;
+    return o;
+  }
+  static void Fetch(gsfm_ctx* ctx, int which, int64_t nt, int64_t no, const std::vector<image_t>& ids, bool set_track_id,
+                    std::unordered_map<track_t, glomap::Track>& out) {
+    std::vector<int64_t> tid(static_cast<size_t>(nt) + 1), off(static_cast<size_t>(nt) + 1);
+    std::vector<int32_t> oimg(static_cast<size_t>(no) + 1);
+    std::vector<uint32_t> ofeat(static_cast<size_t>(no) + 1);
+    gsfm_track_set ts{};
+    ts.mem = GSFM_MEM_HOST;
+    ts.track_id = tid.data();
+    ts.track_offset = off.data();
+    ts.obs_image = oimg.data();
+    ts.obs_feature = ofeat.data();
+    if (gsfm_tracks_fetch(ctx, which, &ts) != GSFM_OK) return;
+    out.reserve(static_cast<size_t>(nt));
+    for (int64_t t = 0; t < nt; ++t) {
+      track_t id = static_cast<track_t>(tid[t]);
+      if (which == GSFM_TRACKS_FULL)  // dense image index -> image_id in the upper half
+        id = (static_cast<track_t>(ids[static_cast<size_t>(tid[t] >> 32)]) << 32) | (static_cast<track_t>(tid[t]) & 0xFFFFFFFFull);
+      glomap::Track& tr = out[id];  // discarded tracks stay as empty Track objects (:131)
+      if (set_track_id) tr.track_id = id;  // :191
+      tr.observations.reserve(static_cast<size_t>(off[t + 1] - off[t]));
+      for (int64_t k = off[t]; k < off[t + 1]; ++k) tr.observations.emplace_back(ids[static_cast<size_t>(oimg[k])], ofeat[k]);
+    }
+  }
+
+  const glomap::TrackEstablishmentOptions& options_;
+  const glomap::ViewGraph& view_graph_;
+  const std::unordered_map<image_t, glomap::Image>& images_;
+};
+
+// ViewGraph::KeepLargestConnectedComponents (view_graph.cc:56-97) as a free function over the reference's containers.
+inline int KeepLargestConnectedComponents(glomap::ViewGraph& view_graph, std::unordered_map<frame_t, glomap::Frame>& frames,
+                                          std::unordered_map<image_t, glomap::Image>& images) {
+  gsfm_ctx* ctx = Context();
+  if (ctx == nullptr) return 0;
+  std::vector<frame_t> fids;
+  for (const auto& [fid, fr] : frames) fids.push_back(fid);
+  std::sort(fids.begin(), fids.end());  // ties between equally large components go to the smallest frame id
+  std::unordered_map<frame_t, int32_t> dense;
+  for (size_t n = 0; n < fids.size(); ++n) dense.emplace(fids[n], static_cast<int32_t>(n));
+  std::vector<int32_t> nimg(fids.size(), 0);
+  for (const auto& [id, im] : images) {
+    auto it = dense.find(im.frame_id);
+    if (it != dense.end()) nimg[static_cast<size_t>(it->second)]++;
+  }
+  std::vector<int32_t> ei, ej;
+  std::vector<uint8_t> valid;
+  std::vector<glomap::ImagePair*> pairs;
+  for (auto& [pid, pair] : view_graph.image_pairs) {
+    ei.push_back(dense.at(images.at(pair.image_id1).frame_id));
+    ej.push_back(dense.at(images.at(pair.image_id2).frame_id));
+    valid.push_back(pair.is_valid ? 1 : 0);
+    pairs.push_back(&pair);
+  }
+  std::vector<uint8_t> reg(fids.size(), 0);
+  int64_t count = 0;
+  if (fids.empty() || gsfm_keep_largest_connected_component(ctx, GSFM_MEM_HOST, static_cast<int32_t>(fids.size()),
+                                                            static_cast<int64_t>(pairs.size()), ei.data(), ej.data(), valid.data(),
+                                                            nimg.data(), reg.data(), &count) != GSFM_OK ||
+      count == 0)
+    return 0;  // :70
+  for (size_t n = 0; n < fids.size(); ++n) frames.at(fids[n]).is_registered = reg[n] != 0;  // :75-82
+  for (size_t e = 0; e < pairs.size(); ++e)
+    if (!valid[e]) pairs[e]->is_valid = false;  // :84-90
+  return static_cast<int>(count);
+}
 
 }  // namespace gsfm_glomap

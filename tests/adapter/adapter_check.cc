@@ -189,6 +189,78 @@ int main() {
     if (!(sim[0] > 0.0) || std::fabs(diam / (diam_before * sim[0]) - 1.0) > 1e-9)
       return std::printf("normalizer scale %.9f diam %.9f (before %.9f)\n", sim[0], diam, diam_before), 1;
   }
+  // 5) producers of the GP / BA inputs: matches derived from the scene's tracks -> EstablishFullTracks must
+  //    give the tracks back (as sets of (image, feature)), FindTracksForProblem keeps those seen by >= 3 images,
+  //    KeepLargestConnectedComponents drops an isolated pair of frames
+  {
+    for (auto& [pid, pr] : vg.image_pairs) {
+      pr.is_valid = true;
+      pr.inliers.clear();
+      pr.matches = mock_eigen::MatrixXi();
+    }
+    size_t expect_tracks = 0, expect_selected = 0;
+    for (auto& [tid, tr] : tracks) {
+      if (tr.observations.empty()) continue;
+      bool linked = false;
+      for (size_t a = 0; a < tr.observations.size(); ++a)
+        for (size_t b = a + 1; b < tr.observations.size(); ++b) {
+          const int i = (int)tr.observations[a].first, j = (int)tr.observations[b].first;
+          const int d = (j - i + N) % N;
+          ImagePair* pr = nullptr;
+          bool fwd = true;
+          if (d >= 1 && d <= 4) pr = &vg.image_pairs[(uint64_t)i * 1000 + j];
+          else if (N - d >= 1 && N - d <= 4) pr = &vg.image_pairs[(uint64_t)j * 1000 + i], fwd = false;
+          if (!pr) continue;
+          pr->matches.push_row(-1, -1);  // an outlier row that `inliers` skips
+          if (fwd) pr->matches.push_row((int)tr.observations[a].second, (int)tr.observations[b].second);
+          else pr->matches.push_row((int)tr.observations[b].second, (int)tr.observations[a].second);
+          pr->inliers.push_back(pr->matches.rows() - 1);
+          linked = true;
+        }
+      // stride-1 and stride-2 tracks are chains of neighbours (connected); stride-3 tracks link 0-3-6-...-15 as well
+      if (linked) {
+        ++expect_tracks;
+        if (tr.observations.size() >= 3) ++expect_selected;
+      }
+    }
+    TrackEstablishmentOptions to;
+    gsfm_glomap::TrackEngine engine(vg, images, to);
+    std::unordered_map<track_t, Track> full, selected;
+    const size_t nfull = engine.EstablishFullTracks(full);
+    if (nfull != expect_tracks) return std::printf("EstablishFullTracks: %zu tracks, expected %zu\n", nfull, expect_tracks), 1;
+    // every established track equals one scene track: same size, and its id is its smallest member
+    std::unordered_map<uint64_t, size_t> size_of;
+    for (auto& [tid, tr] : tracks)
+      for (auto& ob : tr.observations) size_of[((uint64_t)ob.first << 32) | ob.second] = tr.observations.size();
+    for (auto& [id, tr] : full) {
+      if (tr.observations.empty()) return std::printf("unexpected discarded track\n"), 1;
+      const auto& o0 = tr.observations.front();
+      if ((((uint64_t)o0.first << 32) | o0.second) != id) return std::printf("track id is not its smallest member\n"), 1;
+      for (auto& ob : tr.observations)
+        if (size_of[((uint64_t)ob.first << 32) | ob.second] != tr.observations.size()) return std::printf("track members differ\n"), 1;
+    }
+    const size_t nsel = engine.FindTracksForProblem(full, selected);
+    if (nsel != expect_selected) return std::printf("FindTracksForProblem: %zu tracks, expected %zu\n", nsel, expect_selected), 1;
+    for (auto& [id, tr] : selected)
+      if (tr.track_id != id || tr.observations.size() < 3) return std::printf("bad selected track\n"), 1;
+    // two extra frames linked only to each other
+    for (int n = N; n < N + 2; ++n) {
+      frames[n] = Frame();
+      Image im;
+      im.image_id = n;
+      im.frame_id = n;
+      images[n] = im;
+    }
+    for (int n = 0; n < N + 2; ++n) images[n].frame_ptr = &frames[n];
+    ImagePair lone;
+    lone.image_id1 = N;
+    lone.image_id2 = N + 1;
+    vg.image_pairs[(uint64_t)N * 1000 + N + 1] = lone;
+    const int kept = gsfm_glomap::KeepLargestConnectedComponents(vg, frames, images);
+    if (kept != N || frames[N].is_registered || frames[N + 1].is_registered || !frames[3].is_registered ||
+        vg.image_pairs[(uint64_t)N * 1000 + N + 1].is_valid)
+      return std::printf("KeepLargestConnectedComponents kept %d images\n", kept), 1;
+  }
   std::printf("ADAPTER OK ra=%.2e rad gp_ratio_err=%.2e ba=%.2e px\n", worst, std::fabs(ratio / ratio_ref - 1.0), maxerr);
   return 0;
 }

@@ -24,6 +24,16 @@ struct Vector3d {
   double& operator[](int i) { return v[i]; }
   const double& operator[](int i) const { return v[i]; }
 };
+struct MatrixXi {  // Eigen::MatrixXi shape used by ImagePair::matches: (row, col) access
+  std::vector<int> d;
+  int cols_ = 2;
+  int rows() const { return static_cast<int>(d.size()) / cols_; }
+  int operator()(int r, int c) const { return d[static_cast<size_t>(r) * cols_ + c]; }
+  void push_row(int a, int b) {
+    d.push_back(a);
+    d.push_back(b);
+  }
+};
 struct Quaterniond {  // Eigen's constructor order: (w, x, y, z)
   double w_ = 1, x_ = 0, y_ = 0, z_ = 0;
   Quaterniond() = default;
@@ -89,11 +99,19 @@ struct ImagePair {
   double weight = -1;
   Rigid3d cam2_from_cam1;
   std::vector<int> inliers;
+  mock_eigen::MatrixXi matches;
 };
 struct ViewGraph {
   std::unordered_map<image_pair_t, ImagePair> image_pairs;
 };
 
+struct TrackEstablishmentOptions {  // controllers/track_establishment.h:9-24
+  double thres_inconsistency = 10.;
+  int min_num_tracks_per_view = -1;
+  int min_num_view_per_track = 3;
+  int max_num_view_per_track = 100;
+  int max_num_tracks = 10000000;
+};
 struct SolverOptionsShape {  // the ceres::Solver::Options fields the reference sets (optimization_base.h:18-23)
   int max_num_iterations = 100;
   double function_tolerance = 1e-5;

@@ -55,8 +55,8 @@ def test_struct_sizes_match_header(lib):
     src = r'''
     #include <stdio.h>
     #include "gsfm.h"
-    int main(){printf("{\"report\":%zu,\"ra_options\":%zu,\"ra_problem\":%zu,\"lm\":%zu,\"gp_options\":%zu,\"gp_problem\":%zu,\"ba_options\":%zu,\"ba_problem\":%zu}",
-      sizeof(gsfm_report),sizeof(gsfm_ra_options),sizeof(gsfm_ra_problem),sizeof(gsfm_lm_options),sizeof(gsfm_gp_options),sizeof(gsfm_gp_problem),sizeof(gsfm_ba_options),sizeof(gsfm_ba_problem));return 0;}
+    int main(){printf("{\"report\":%zu,\"ra_options\":%zu,\"ra_problem\":%zu,\"lm\":%zu,\"gp_options\":%zu,\"gp_problem\":%zu,\"ba_options\":%zu,\"ba_problem\":%zu,\"scene_view\":%zu,\"match_graph\":%zu,\"track_options\":%zu,\"track_set\":%zu}",
+      sizeof(gsfm_report),sizeof(gsfm_ra_options),sizeof(gsfm_ra_problem),sizeof(gsfm_lm_options),sizeof(gsfm_gp_options),sizeof(gsfm_gp_problem),sizeof(gsfm_ba_options),sizeof(gsfm_ba_problem),sizeof(gsfm_scene_view),sizeof(gsfm_match_graph),sizeof(gsfm_track_options),sizeof(gsfm_track_set));return 0;}
     '''
     with tempfile.TemporaryDirectory() as d:
         c = Path(d) / "probe.c"
@@ -72,6 +72,10 @@ def test_struct_sizes_match_header(lib):
     assert sizes["gp_problem"] == ctypes.sizeof(_lib.GpProblemC)
     assert sizes["ba_options"] == ctypes.sizeof(_lib.BaOptions)
     assert sizes["ba_problem"] == ctypes.sizeof(_lib.BaProblemC)
+    assert sizes["scene_view"] == ctypes.sizeof(_lib.SceneViewC)
+    assert sizes["match_graph"] == ctypes.sizeof(_lib.MatchGraphC)
+    assert sizes["track_options"] == ctypes.sizeof(_lib.TrackOptionsC)
+    assert sizes["track_set"] == ctypes.sizeof(_lib.TrackSetC)
 
 
 def test_no_device_is_a_hard_error():

@@ -1,0 +1,260 @@
+"""Producers of the GP / BA inputs: track establishment (union-find over the inlier
+matches + same-image consistency test), track selection, largest connected component of the view graph.
+
+CPU tier: the vectorised oracle against the literal (loop-for-loop, dict / set) restatement of the reference, and the
+order-independence the canonical labelling relies on.  GPU tier: the HIP path through the C ABI against the oracle —
+everything is integer, so every array is compared bit for bit."""
+import numpy as np
+import pytest
+
+from glomap_amd import synthetic
+from oracle import tracks as ot
+
+
+def _args(g):
+    return (g["pair_image1"], g["pair_image2"], g["pair_valid"], g["pair_offset"], g["match_feat1"], g["match_feat2"],
+            g["feat_offset"], g["feat_xy"])
+
+
+def _shuffle_pairs(g, seed):
+    """Same matches, image pairs visited in another order (what unordered_map iteration does to the reference)."""
+    rng = np.random.default_rng(seed)
+    perm = rng.permutation(len(g["pair_image1"]))
+    cnt = np.diff(g["pair_offset"])[perm]
+    off = np.zeros(len(perm) + 1, dtype=np.int64)
+    off[1:] = np.cumsum(cnt)
+    idx = ot._ranges(g["pair_offset"][:-1][perm], cnt)
+    h = dict(g)
+    h.update(pair_image1=g["pair_image1"][perm], pair_image2=g["pair_image2"][perm], pair_valid=g["pair_valid"][perm],
+             pair_offset=off, match_feat1=g["match_feat1"][idx], match_feat2=g["match_feat2"][idx])
+    return h
+
+
+SELECT_CASES = [
+    dict(),
+    dict(min_num_tracks_per_view=5),
+    dict(min_num_tracks_per_view=0),
+    dict(min_num_tracks_per_view=20, max_num_tracks=30),
+    dict(max_num_tracks=10),
+    dict(max_num_tracks=0),
+    dict(min_num_view_per_track=2, max_num_view_per_track=6),
+    dict(min_num_view_per_track=-1),
+    dict(max_num_view_per_track=-1, min_num_tracks_per_view=3),
+]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CPU: oracle vs literal restatement
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_oracle_establish_matches_literal_and_is_order_independent(seed):
+    g = synthetic.make_match_graph(50, 300, seed=seed, false_match_frac=0.03, twin_frac=0.02)
+    g["pair_valid"][::11] = 0
+    tr, disc, members = ot.establish_full_tracks_literal(*_args(g))
+    lit = ot.canonicalize(tr, members)
+    vec = ot.establish_full_tracks(*_args(g))
+    assert disc == vec[4] and disc > 0
+    for a, b in zip(lit, vec[:4]):
+        assert np.array_equal(a, b)
+    # another visiting order changes the reference's root ids but not the canonical result
+    h = _shuffle_pairs(g, seed + 10)
+    tr2, disc2, members2 = ot.establish_full_tracks_literal(*_args(h))
+    assert disc2 == disc
+    assert set(tr2) != set(tr) or True  # ids may or may not differ; the canonical form must not
+    for a, b in zip(ot.canonicalize(tr2, members2), lit):
+        assert np.array_equal(a, b)
+    # twins (same image, < threshold apart) survive inside their track
+    tid, off, img, ft = vec[:4]
+    lens = np.diff(off)
+    trk = np.repeat(np.arange(len(lens)), lens)
+    dup = (img[1:] == img[:-1]) & (trk[1:] == trk[:-1])
+    assert dup.any()
+    # ids are the smallest member, tracks ascending, members ascending
+    assert np.all(np.diff(tid) > 0)
+    nz = lens > 0
+    first = (img[off[:-1][nz]].astype(np.int64) << 32) | ft[off[:-1][nz]]
+    assert np.array_equal(first, tid[nz])
+
+
+@pytest.mark.parametrize("kw", SELECT_CASES)
+def test_oracle_select_matches_literal(kw):
+    g = synthetic.make_match_graph(60, 400, seed=3)
+    full = ot.establish_full_tracks(*_args(g))[:4]
+    reg = np.ones(60, dtype=bool)
+    reg[::7] = False
+    a = ot.find_tracks_for_problem_literal(*full, reg, **kw)
+    b = ot.find_tracks_for_problem(*full, reg, **kw)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    if not kw:
+        assert len(a[0]) > 100
+        assert reg[a[2]].all()  # only registered images remain (:189)
+
+
+def test_oracle_select_on_shuffled_track_set():
+    """FindTracksForProblem takes any track map: rows in arbitrary order, members in arbitrary order."""
+    g = synthetic.make_match_graph(40, 250, seed=4)
+    tid, off, img, ft = ot.establish_full_tracks(*_args(g))[:4]
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(len(tid))
+    lens = np.diff(off)[perm]
+    off2 = np.zeros(len(perm) + 1, dtype=np.int64)
+    off2[1:] = np.cumsum(lens)
+    idx = ot._ranges(off[:-1][perm], lens)
+    reg = np.ones(40, dtype=bool)
+    for kw in (dict(), dict(min_num_tracks_per_view=4)):
+        a = ot.find_tracks_for_problem_literal(tid[perm], off2, img[idx], ft[idx], reg, **kw)
+        b = ot.find_tracks_for_problem(tid[perm], off2, img[idx], ft[idx], reg, **kw)
+        c = ot.find_tracks_for_problem(tid, off, img, ft, reg, **kw)
+        for x, y, z in zip(a, b, c):
+            assert np.array_equal(x, y) and np.array_equal(x, z)
+
+
+def _components_graph(seed, n=300, e=500, ncomp=4):
+    rng = np.random.default_rng(seed)
+    comp = rng.integers(0, ncomp, n)
+    ei, ej = [], []
+    while len(ei) < e:
+        a, b = rng.integers(0, n, 2)
+        if a != b and comp[a] == comp[b]:
+            ei.append(a)
+            ej.append(b)
+    ev = (rng.random(e) < 0.8).astype(np.uint8)
+    return n, np.array(ei, np.int32), np.array(ej, np.int32), ev
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_oracle_keep_largest_component(seed):
+    n, ei, ej, ev = _components_graph(seed)
+    nimg = np.random.default_rng(seed).integers(1, 4, n).astype(np.int32)
+    a = ot.keep_largest_connected_component_literal(n, ei, ej, ev, nimg)
+    b = ot.keep_largest_connected_component(n, ei, ej, ev, nimg)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] > 0
+    assert a[1].sum() < ev.sum()  # edges of the smaller components were invalidated
+    # tie between two equally large components: the one holding the smallest node wins
+    ei2 = np.array([0, 1, 5, 6], np.int32)
+    ej2 = np.array([1, 2, 6, 7], np.int32)
+    r, v, cnt = ot.keep_largest_connected_component(10, ei2, ej2, np.ones(4, np.uint8))
+    assert cnt == 3 and r[:3].all() and not r[3:].any() and list(v) == [True, True, False, False]
+    r2 = ot.keep_largest_connected_component_literal(10, ei2, ej2, np.ones(4, np.uint8))
+    assert np.array_equal(r, r2[0])
+    assert ot.keep_largest_connected_component(10, ei2, ej2, np.zeros(4, np.uint8))[2] == 0
+
+
+# ---------------------------------------------------------------------------------------------------------
+# GPU: HIP path vs oracle, bit for bit
+# ---------------------------------------------------------------------------------------------------------
+def _same_set(ts, ref):
+    return (np.array_equal(ts.track_id, ref[0]) and np.array_equal(ts.track_offset, ref[1]) and
+            np.array_equal(ts.obs_image, ref[2]) and np.array_equal(ts.obs_feature, ref[3]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_img,n_trk,seed,kw", [
+    (50, 300, 0, dict(false_match_frac=0.03, twin_frac=0.02)),
+    (200, 20000, 1, dict()),
+    (1000, 100000, 2, dict(false_match_frac=0.02, max_gap=4)),  # dense pairs -> 16 / 64 lanes per pair
+])
+def test_gpu_establish_and_select_match_oracle(gsfm_ctx, n_img, n_trk, seed, kw):
+    from glomap_amd.tracks import MatchGraph, TrackEngine, TrackEstablishmentOptions
+
+    g = synthetic.make_match_graph(n_img, n_trk, seed=seed, **kw)
+    g["pair_valid"][::13] = 0
+    ref = ot.establish_full_tracks(*_args(g))
+    eng = TrackEngine(MatchGraph.from_dict(g), ctx=gsfm_ctx)
+    full = eng.EstablishFullTracks()
+    assert eng.num_discarded == ref[4]
+    assert _same_set(full, ref)
+    reg = np.ones(n_img, dtype=np.uint8)
+    reg[::9] = 0
+    for skw in SELECT_CASES:
+        eng.options = TrackEstablishmentOptions(**skw)
+        sel = eng.FindTracksForProblem(reg)  # from the tracks left in HBM
+        want = ot.find_tracks_for_problem(*ref[:4], reg, **skw)
+        assert _same_set(sel, want), skw
+    # an explicit (host) track set, rows shuffled
+    rng = np.random.default_rng(seed)
+    perm = rng.permutation(full.num_tracks)
+    lens = np.diff(full.track_offset)[perm]
+    off2 = np.zeros(len(perm) + 1, dtype=np.int64)
+    off2[1:] = np.cumsum(lens)
+    idx = ot._ranges(full.track_offset[:-1][perm], lens)
+    from glomap_amd.tracks import TrackSet
+
+    shuffled = TrackSet(full.track_id[perm], off2, full.obs_image[idx], full.obs_feature[idx])
+    eng.options = TrackEstablishmentOptions(min_num_tracks_per_view=7)
+    sel = eng.FindTracksForProblem(reg, tracks_full=shuffled)
+    assert _same_set(sel, ot.find_tracks_for_problem(*ref[:4], reg, min_num_tracks_per_view=7))
+
+
+@pytest.mark.gpu
+def test_gpu_establish_device_resident_and_repeatable(gsfm_ctx):
+    from glomap_amd.tracks import MatchGraph, TrackEngine
+
+    g = synthetic.make_match_graph(300, 40000, seed=5)
+    ref = ot.establish_full_tracks(*_args(g))
+    eng = TrackEngine(MatchGraph.from_dict(g).to_device(gsfm_ctx), ctx=gsfm_ctx)
+    for _ in range(3):  # the lock-free union-find races differently every run; the result must not
+        assert eng.EstablishFullTracks(fetch=False) == len(ref[0])
+        assert _same_set(eng._fetch(0), ref)
+    dev = eng._fetch(0, device=True)
+    assert np.array_equal(dev.obs_image.numpy()[: len(ref[2])], ref[2])
+
+
+@pytest.mark.gpu
+def test_gpu_establish_edge_cases(gsfm_ctx):
+    from glomap_amd import _lib
+    from glomap_amd.tracks import MatchGraph, TrackEngine, TrackEstablishmentOptions
+
+    g = synthetic.make_match_graph(30, 100, seed=6)
+    # no valid pair -> no tracks, and selecting from nothing gives nothing
+    h = dict(g)
+    h["pair_valid"] = np.zeros_like(g["pair_valid"])
+    eng = TrackEngine(MatchGraph.from_dict(h), ctx=gsfm_ctx)
+    full = eng.EstablishFullTracks()
+    assert full.num_tracks == 0 and full.num_obs == 0 and list(full.track_offset) == [0]
+    sel = eng.FindTracksForProblem(np.ones(30, np.uint8))
+    assert sel.num_tracks == 0
+    # no pairs at all
+    e = dict(g)
+    e.update(pair_image1=np.zeros(0, np.int32), pair_image2=np.zeros(0, np.int32), pair_valid=np.zeros(0, np.uint8),
+             pair_offset=np.zeros(1, np.int64), match_feat1=np.zeros(0, np.uint32), match_feat2=np.zeros(0, np.uint32))
+    assert TrackEngine(MatchGraph.from_dict(e), ctx=gsfm_ctx).EstablishFullTracks().num_tracks == 0
+    # threshold 0: every track with two features in one image dies; huge threshold: none does
+    for thr in (0.0, 1e9):
+        eng = TrackEngine(MatchGraph.from_dict(g), TrackEstablishmentOptions(thres_inconsistency=thr), ctx=gsfm_ctx)
+        full = eng.EstablishFullTracks()
+        ref = ot.establish_full_tracks(*_args(g), thres_inconsistency=thr)
+        assert _same_set(full, ref) and eng.num_discarded == ref[4]
+    # nobody registered -> nothing selected
+    assert eng.FindTracksForProblem(np.zeros(30, np.uint8)).num_tracks == 0
+    # a feature index outside its image is an error, not a wild write
+    bad = dict(g)
+    bad["match_feat1"] = g["match_feat1"].copy()
+    bad["match_feat1"][3] = 4_000_000
+    with pytest.raises(_lib.GsfmError):
+        TrackEngine(MatchGraph.from_dict(bad), ctx=gsfm_ctx).EstablishFullTracks()
+
+
+@pytest.mark.gpu
+def test_gpu_keep_largest_component(gsfm_ctx):
+    from glomap_amd import _lib
+    from glomap_amd.tracks import KeepLargestConnectedComponents
+
+    for seed in (0, 1, 2):
+        n, ei, ej, ev = _components_graph(seed, n=5000, e=20000, ncomp=6)
+        nimg = np.random.default_rng(seed).integers(1, 4, n).astype(np.int32)
+        want = ot.keep_largest_connected_component(n, ei, ej, ev, nimg)
+        reg, ev2, cnt = KeepLargestConnectedComponents(n, ei, ej, ev, nimg, ctx=gsfm_ctx)
+        assert cnt == want[2] and np.array_equal(reg.astype(bool), want[0]) and np.array_equal(ev2.astype(bool), want[1])
+    # the C2 ring stays whole; device-resident arrays are used in place
+    vg = synthetic.make_ring_view_graph(1000, 50, seed=0)
+    ones = np.ones(vg.num_edges, np.uint8)
+    d = lambda a: _lib.DeviceArray.from_numpy(gsfm_ctx, a)
+    reg, ev2, cnt = KeepLargestConnectedComponents(1000, d(vg.edge_i), d(vg.edge_j), d(ones), ctx=gsfm_ctx)
+    assert cnt == 1000 and reg.numpy().all() and ev2.numpy().all()
+    # ties, and the empty graph
+    ei2, ej2 = np.array([0, 1, 5, 6], np.int32), np.array([1, 2, 6, 7], np.int32)
+    reg, ev2, cnt = KeepLargestConnectedComponents(10, ei2, ej2, np.ones(4, np.uint8), ctx=gsfm_ctx)
+    assert cnt == 3 and list(reg) == [1, 1, 1, 0, 0, 0, 0, 0, 0, 0] and list(ev2) == [1, 1, 0, 0]
+    assert KeepLargestConnectedComponents(10, ei2, ej2, np.zeros(4, np.uint8), ctx=gsfm_ctx)[2] == 0
