@@ -562,6 +562,9 @@ struct RaDevice {
   // direct (dense) solves for small graphs, ra_dense.hpp
   bool dense = false;
   bool dense_valid = false;   // dense_inv holds the inverse of the current weighted Laplacian
+  bool dense_have = false;    // dense_inv holds the inverse of SOME earlier weighted Laplacian (preconditioner)
+  bool dense_refresh = false; // the stale inverse needed too many PCG iterations: re-invert at the next solve
+  bool dense_always_factor = false;  // GSFM_RA_DENSE_REFACTOR=1: re-invert for every new weighting (the round-1 behaviour)
   int Np = 0, T = 0;          // padded size, tiles per side
   double* dense_inv = nullptr;
 };
@@ -650,6 +653,8 @@ void dense_factor(RaDevice& d) {
   }
   d.dense_inv = cur;
   d.dense_valid = true;
+  d.dense_have = true;
+  d.dense_refresh = false;
 }
 
 // x = A^-1 rhs, then (refine) one step of iterative refinement against the sparse operator.
@@ -670,8 +675,51 @@ int dense_solve(RaDevice& d, bool refine = true, const int* stop = nullptr) {
   return 1;
 }
 
+// (L_w + gauge) x = rhs by PCG with the stale dense inverse as preconditioner (ra_dense.hpp).  Returns the number
+// of iterations, or -1 when it did not converge (the caller re-inverts).
+int dense_pcg_solve(RaDevice& d, double tol) {
+  RaWs* ws = d.ws;
+  gsfm_ctx* ctx = d.ctx;
+  hipStream_t s = ctx->stream;
+  const int N = d.N, n3 = 3 * N;
+  DpcgState* st = reinterpret_cast<DpcgState*>(ws->cgst.get());
+  double* u = ws->cg_z.get();
+  double* w = ws->cg_w.get();
+  hipLaunchKernelGGL(k_dpcg_init, dim3(1), dim3(kBlock), 0, s, n3, ws->rhs.get(), ws->x.get(), ws->cg_r.get(), ws->cg_p.get(),
+                     ws->cg_s.get(), st);
+  const int gA = grid_for(N, kBlock / 64);
+  constexpr int kBatch = 10, kMaxIters = 40;
+  DpcgState h;
+  for (int done = 0; done < kMaxIters; done += kBatch) {
+    for (int it = 0; it < kBatch; ++it) {
+      hipLaunchKernelGGL(k_dense_apply3, dim3(gA), dim3(kBlock), 0, s, N, d.Np, d.dense_inv, ws->cg_r.get(), u, 0, &st->done);
+      dispatch_lpr(d.lpr, [&](auto L) {
+        hipLaunchKernelGGL((k_spmv<decltype(L)::value>), dim3(d.gridRow), dim3(kBlock), 0, s, N, ws->rowptr.get(),
+                           ws->nbr.get(), ws->inc_w.get(), ws->lap_diag_loc.get(), u, w);
+      });
+      hipLaunchKernelGGL(k_dpcg_update, dim3(1), dim3(kBlock), 0, s, n3, tol * tol, u, w, ws->x.get(), ws->cg_r.get(),
+                         ws->cg_p.get(), ws->cg_s.get(), st);
+    }
+    GSFM_HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 96, st, sizeof(DpcgState), hipMemcpyDeviceToHost, s));
+    GSFM_HIP_CHECK(hipStreamSynchronize(s));
+    std::memcpy(&h, ctx->h_pinned + 96, sizeof(DpcgState));
+    if (h.done) break;
+  }
+  if (!h.done || h.bad) return -1;
+  if (h.iters > 24) d.dense_refresh = true;  // the weights have drifted: refresh the preconditioner next time
+  return h.iters;
+}
+
 int pcg_solve(RaDevice& d, bool warm, double tol, int max_iter) {
-  if (d.dense) return dense_solve(d);
+  if (d.dense) {
+    // a stale inverse (same graph, earlier weights) preconditions the new system; fall back to a fresh inversion
+    if (!d.dense_valid && d.dense_have && !d.dense_refresh && !d.dense_always_factor) {
+      const int it = dense_pcg_solve(d, tol);
+      if (it >= 0) return it;
+      d.dense_refresh = true;
+    }
+    return dense_solve(d);
+  }
   RaWs* ws = d.ws;
   gsfm_ctx* ctx = d.ctx;
   hipStream_t s = ctx->stream;
@@ -758,6 +806,12 @@ void setup_device(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
   d.lpr = choose_lpr(E, N);
   d.dense = ctx->comm.world == 1 && N <= kDenseMaxN && opt->pcg_max_iterations > 0 && !opt->force_iterative;
   d.dense_valid = false;
+  d.dense_have = false;
+  d.dense_refresh = false;
+  {
+    static const bool always = getenv("GSFM_RA_DENSE_REFACTOR") != nullptr;
+    d.dense_always_factor = always;
+  }
   d.T = (N + kTile - 1) / kTile;
   d.Np = d.T * kTile;
   d.gridN = grid_for(N, kBlock);
