@@ -422,3 +422,96 @@ def make_match_graph(n_images=200, n_tracks=5000, seed=0, max_gap=12, ring=50, m
                 pair_valid=np.ones(len(upid), dtype=np.uint8), pair_offset=pair_offset,
                 match_feat1=f1.astype(np.uint32), match_feat2=f2.astype(np.uint32),
                 gt_num_tracks=n_tracks, gt_num_members=M)
+
+
+def make_pipeline_scene(n_images=14, n_points=50, seed=0, pixel_noise=0.0, num_succ=6, rot_outlier_pairs=0,
+                        false_match_frac=0.0, isolated_pair=False, radius=10.0, ball=2.5, focal=1200.0):
+    """A whole-pipeline scene in flat form (what `GlobalMapper::Solve` holds after relative-pose estimation,
+    global_mapper.cc:85): images on a ring looking at the origin, two shared PINHOLE cameras, 3-D points seen by
+    every image that has them in view, per-image feature lists (pixels + undistorted rays), a view graph linking
+    each image to its `num_succ` successors with the exact relative rotation and the inlier matches of the shared
+    points.  `rot_outlier_pairs` pairs get a random relative rotation (RelPoseFilter::FilterRotations must drop
+    them), `false_match_frac` adds matches between unrelated features, `isolated_pair` appends two images that are
+    linked only to each other (KeepLargestConnectedComponents must drop them).  Mirrors the role of
+    colmap::SynthesizeDataset in global_mapper_test.cc:56-66 (un-vendored; own generator)."""
+    rng = np.random.default_rng(seed)
+    N0 = int(n_images)
+    centers, R_cw = _ring_cameras(rng, N0, radius, jitter_deg=3.0)
+    X = _ball_points(rng, n_points, ball)
+    extra = 2 if isolated_pair else 0
+    if extra:  # far away, looking elsewhere: they share no point with the ring
+        c2 = np.array([[100.0, 0.0, 0.0], [101.0, 0.0, 0.0]])
+        centers = np.vstack([centers, c2])
+        R_cw = np.concatenate([R_cw, np.tile(np.eye(3), (2, 1, 1))])
+    N = N0 + extra
+    K = 2
+    cam_intr = (np.arange(N) % K).astype(np.int32)
+    intr_params = np.zeros((K, 8))
+    intr_params[:, :4] = [[focal, focal, 640.0, 480.0], [1.1 * focal, 1.1 * focal, 620.0, 500.0]]
+    # visibility: inside a 35 degree half-angle cone and in front
+    d = X[None, :, :] - centers[:, None, :]  # [N,P,3]
+    xc = np.einsum("nij,npj->npi", R_cw, d)
+    vis = (xc[:, :, 2] > 0.1) & (xc[:, :, 2] > np.cos(np.radians(35.0)) * np.linalg.norm(xc, axis=2))
+    vis[N0:] = False
+    img_of, pt_of = np.nonzero(vis)  # image-major
+    feat_count = np.bincount(img_of, minlength=N)
+    # the two isolated images get private features so that they can be matched to each other
+    priv = 30 if extra else 0
+    feat_count[N0:] = priv
+    feat_offset = np.zeros(N + 1, dtype=np.int64)
+    feat_offset[1:] = np.cumsum(feat_count)
+    F = int(feat_offset[-1])
+    feat_xy = np.zeros((F, 2))
+    feat_undist = np.zeros((F, 3))
+    feat_pt = np.full(F, -1, dtype=np.int64)
+    fidx = np.arange(len(img_of))  # image-major nonzero(): the ring images' features are laid out in this order
+    p = intr_params[cam_intr[img_of]]
+    xcv = xc[img_of, pt_of]
+    uv = np.stack([p[:, 0] * xcv[:, 0] / xcv[:, 2] + p[:, 2], p[:, 1] * xcv[:, 1] / xcv[:, 2] + p[:, 3]], 1)
+    uv += rng.normal(0, pixel_noise, uv.shape) if pixel_noise > 0 else 0.0
+    feat_xy[fidx] = uv
+    ray = np.stack([(uv[:, 0] - p[:, 2]) / p[:, 0], (uv[:, 1] - p[:, 3]) / p[:, 1], np.ones(len(uv))], 1)
+    feat_undist[fidx] = ray / np.linalg.norm(ray, axis=1, keepdims=True)
+    feat_pt[fidx] = pt_of
+    for n in range(N0, N):
+        sl = slice(feat_offset[n], feat_offset[n + 1])
+        feat_xy[sl] = rng.uniform(100, 1000, (priv, 2))
+        feat_undist[sl] = [0.0, 0.0, 1.0]
+    # feature index of point p in image n (or -1)
+    feat_of = np.full((N, n_points), -1, dtype=np.int64)
+    feat_of[img_of, pt_of] = fidx - feat_offset[img_of]
+    # view graph
+    pi, pj, pq, poff, f1, f2 = [], [], [], [0], [], []
+    pairs = [(i, (i + dlt) % N0) for i in range(N0) for dlt in range(1, num_succ + 1)]
+    pairs = sorted({(min(a, b), max(a, b)) for a, b in pairs if a != b})
+    if extra:
+        pairs.append((N0, N0 + 1))
+    bad_pairs = set(rng.choice(len(pairs) - (1 if extra else 0), rot_outlier_pairs, replace=False).tolist()) if rot_outlier_pairs else set()
+    for k, (i, j) in enumerate(pairs):
+        Rij = R_cw[j] @ R_cw[i].T
+        if k in bad_pairs:
+            Rij = so3.aa_to_rotmat(rng.normal(0, 1.0, (1, 3)))[0]
+        if i >= N0:
+            a = np.arange(priv)
+            m1, m2 = a, a
+        else:
+            shared = np.nonzero((feat_of[i] >= 0) & (feat_of[j] >= 0))[0]
+            m1, m2 = feat_of[i, shared], feat_of[j, shared]
+            nf = int(rng.poisson(false_match_frac * len(shared))) if false_match_frac > 0 else 0
+            if nf and feat_count[i] and feat_count[j]:
+                m1 = np.concatenate([m1, rng.integers(0, feat_count[i], nf)])
+                m2 = np.concatenate([m2, rng.integers(0, feat_count[j], nf)])
+        if len(m1) < 5:
+            continue
+        pi.append(i); pj.append(j); pq.append(so3.rotmat_to_quat(Rij[None])[0])
+        f1.append(m1); f2.append(m2)
+        poff.append(poff[-1] + len(m1))
+    return dict(
+        num_images=N, num_ring_images=N0, gt_R=R_cw, gt_center=centers, gt_xyz=X,
+        cam_intr=cam_intr, intr_model=np.full(K, 1, dtype=np.int32), intr_params=intr_params,
+        feat_offset=feat_offset, feat_xy=feat_xy, feat_undist=feat_undist, feat_point=feat_pt,
+        pair_image1=np.array(pi, dtype=np.int32), pair_image2=np.array(pj, dtype=np.int32),
+        pair_q=np.array(pq), pair_offset=np.array(poff, dtype=np.int64),
+        match_feat1=np.concatenate(f1).astype(np.uint32), match_feat2=np.concatenate(f2).astype(np.uint32),
+        pair_rot_outlier=np.array([k in bad_pairs for k in range(len(pairs))])[: len(pi)] if len(pi) == len(pairs) else None,
+    )

@@ -1,0 +1,154 @@
+"""The whole hot path chained the way `GlobalMapper::Solve` chains it (glomap/controllers/global_mapper.cc:85-333),
+every stage through the C ABI on flat arrays:
+
+    KeepLargestConnectedComponents -> RotationEstimator -> RelPoseFilter::FilterRotations -> (again)      :92-110
+    TrackEngine::EstablishFullTracks / FindTracksForProblem                                                :127-134
+    GlobalPositioner (random init) -> TrackFilter x3 -> NormalizeReconstruction                            :152-186
+    [BundleAdjuster positions-only, BundleAdjuster full, Normalize, FilterTracksByReprojection] x 3        :201-275
+
+The controller itself is out of scope (control plane); this driver lives in tests/ only.  Pins: the tolerances of the
+reference's own end-to-end tests on synthetic scenes — rotations 1e-2 deg and projection centres 1e-4 noise-free
+(global_mapper_test.cc:82-86), 0.1 deg / 0.1 with noise and outliers (:211-215) — with our own scene generator
+(colmap::SynthesizeDataset is un-vendored)."""
+import numpy as np
+import pytest
+
+from glomap_amd import estimators, processors, so3, synthetic
+from glomap_amd.flat import BaProblem, GpProblem, RaProblem
+from glomap_amd.tracks import KeepLargestConnectedComponents, MatchGraph, TrackEngine, TrackEstablishmentOptions
+
+
+def _compact(mask):
+    idx = np.full(len(mask), -1, dtype=np.int32)
+    idx[mask] = np.arange(int(mask.sum()), dtype=np.int32)
+    return idx
+
+
+def _drop_observations(off, keep, *arrays):
+    lens = np.diff(off)
+    trk = np.repeat(np.arange(len(lens)), lens)
+    new_len = np.bincount(trk[keep], minlength=len(lens))
+    off2 = np.zeros(len(lens) + 1, dtype=np.int64)
+    off2[1:] = np.cumsum(new_len)
+    return (off2, *[a[keep] for a in arrays])
+
+
+def run_pipeline(s, ctx, log=None):
+    """Returns (registered image mask, R_est [Nr,3,3], centre_est [Nr,3], stats)."""
+    N = s["num_images"]
+    stats = {}
+    ei, ej = s["pair_image1"], s["pair_image2"]
+    ev = np.ones(len(ei), dtype=np.uint8)
+    ninl = np.diff(s["pair_offset"]).astype(np.int32)
+
+    # ---- 3. rotation averaging, twice, with the rotation filter in between (global_mapper.cc:92-110)
+    reg, ev, nimg = KeepLargestConnectedComponents(N, ei, ej, ev, ctx=ctx)
+    assert nimg > 0
+    R = None
+    for _ in range(2):
+        regb = reg.astype(bool)
+        node = _compact(regb)
+        use = ev.astype(bool)
+        p = RaProblem(int(regb.sum()), node[ei[use]], node[ej[use]], s["pair_q"][use], np.ones(int(use.sum())), ninl[use],
+                      np.zeros((int(regb.sum()), 3)), 0)
+        rc, rot, rep = estimators.ra_solve(p, estimators.RotationEstimatorOptions(), ctx=ctx)
+        assert rc == 0
+        keep, ninv = processors.RelPoseFilter.FilterRotations(so3.aa_to_quat(rot), p.edge_i, p.edge_j, p.edge_q, 10.0, ctx=ctx)
+        stats.setdefault("rotation_filtered", []).append(int(ninv))
+        ev2 = ev.copy()
+        ev2[np.nonzero(use)[0][keep == 0]] = 0
+        reg, ev, nimg = KeepLargestConnectedComponents(N, ei, ej, ev2, ctx=ctx)
+        assert nimg > 0
+        R = np.zeros((N, 3, 3))
+        R[regb] = so3.aa_to_rotmat(rot)
+    regb = reg.astype(bool)
+    stats["registered"] = int(regb.sum())
+
+    # ---- 4. track establishment and selection (:127-134)
+    g = MatchGraph(N, s["feat_offset"], s["feat_xy"], ei, ej, s["pair_offset"], s["match_feat1"], s["match_feat2"], pair_valid=ev)
+    eng = TrackEngine(g, TrackEstablishmentOptions(), ctx=ctx)
+    full = eng.EstablishFullTracks()
+    sel = eng.FindTracksForProblem(reg)
+    stats["tracks_full"], stats["tracks_discarded"], stats["tracks_selected"] = full.num_tracks, eng.num_discarded, sel.num_tracks
+    node = _compact(regb)
+    Nr = int(regb.sum())
+    Rr = R[regb]
+    off = sel.track_offset.copy()
+    ocam = node[sel.obs_image]
+    ofeat = s["feat_offset"][sel.obs_image] + sel.obs_feature.astype(np.int64)
+    assert (ocam >= 0).all()
+
+    # ---- 5. global positioning (:152-160) and the filters after it (:164-186)
+    undist = s["feat_undist"][ofeat]
+    obs_dir = np.einsum("mji,mj->mi", Rr[ocam], undist)  # R^T v
+    gp = GpProblem(Nr, len(off) - 1, off, ocam, obs_dir, np.ones(len(ocam), np.uint8), np.zeros((Nr, 3)), np.zeros((len(off) - 1, 3)))
+    rc, cen, X, rep = estimators.gp_solve(gp, estimators.GlobalPositionerOptions(), ctx=ctx)
+    assert rc == 0, rc
+    q = so3.rotmat_to_quat(Rr)
+    t = -np.einsum("nij,nj->ni", Rr, cen)
+
+    def view():
+        return processors.SceneView(Nr, off, ocam, q, t, X, obs_undist=s["feat_undist"][ofeat])
+
+    def apply_obs(keep):
+        nonlocal off, ocam, ofeat
+        off, ocam, ofeat = _drop_observations(off, np.asarray(keep, bool), ocam, ofeat)
+
+    keep, _ = processors.TrackFilter.FilterTracksByAngle(view(), 1.0, ctx=ctx)
+    apply_obs(keep)
+    tkeep, _ = processors.TrackFilter.FilterTrackTriangulationAngle(view(), 1.0, ctx=ctx)
+    apply_obs(np.repeat(np.asarray(tkeep, bool), np.diff(off)))
+    keep, _ = processors.TrackFilter.FilterTracksByReprojection(view(), 10 * 1e-2, True, ctx=ctx)
+    apply_obs(keep)
+    t, X, _ = processors.NormalizeReconstruction(q, t, X, ctx=ctx)
+
+    # ---- 6. bundle adjustment, staged, three rounds (:201-275)
+    intr = s["intr_params"].copy()
+    ci = s["cam_intr"][regb]
+    for ite in range(3):
+        for optimize_rotations in (False, True):
+            ba = BaProblem(num_cams=Nr, num_pts=len(off) - 1, num_intr=len(intr), pt_offset=off, obs_cam=ocam,
+                           obs_xy=s["feat_xy"][ofeat], cam_intr=ci, cam_q=q, cam_t=t, pt_xyz=X, intr_model=s["intr_model"],
+                           intr_params=intr, fixed_cam=0)
+            rc, q, t, X, intr, rep = estimators.ba_solve(ba, estimators.BundleAdjusterOptions(optimize_rotations=optimize_rotations), ctx=ctx)
+            assert rc == 0, rc
+        t, X, _ = processors.NormalizeReconstruction(q, t, X, ctx=ctx)
+        keep, changed = processors.TrackFilter.FilterTracksByReprojection(view(), max(3 - ite, 1) * 1e-2, True, ctx=ctx)
+        apply_obs(keep)
+        stats.setdefault("ba_filtered_tracks", []).append(int(changed))
+    stats["final_cost"] = rep["final_cost"]
+    stats["observations"] = int(len(ocam))
+    Rf = so3.quat_to_rotmat(q)
+    return regb, Rf, -np.einsum("nji,nj->ni", Rf, t), stats
+
+
+@pytest.mark.gpu
+def test_pipeline_without_noise(gsfm_ctx):
+    """global_mapper_test.cc:56-86 (2 x 7 images, 50 points, no noise): 1e-2 deg, 1e-4 centre error."""
+    s = synthetic.make_pipeline_scene(14, 50, seed=0)
+    regb, R, C, stats = run_pipeline(s, gsfm_ctx)
+    assert regb.all() and stats["tracks_selected"] == 50 and stats["tracks_discarded"] == 0
+    rot_err = synthetic.rotation_errors_deg(R, s["gt_R"])
+    cen_err = synthetic.center_errors_after_sim3(C, s["gt_center"])
+    print(stats, rot_err.max(), cen_err.max())
+    assert rot_err.max() < 1e-2
+    assert cen_err.max() < 1e-4
+    assert stats["observations"] == 14 * 50  # num_obs_tolerance = 0
+
+
+@pytest.mark.gpu
+def test_pipeline_with_noise_outliers_and_a_stray_component(gsfm_ctx):
+    """global_mapper_test.cc:176-215 in spirit: pixel noise, wrong relative rotations, false matches, plus two images
+    that only see each other.  0.1 deg / 0.1 centre error (relative to the ring's extent here)."""
+    s = synthetic.make_pipeline_scene(40, 1500, seed=1, pixel_noise=0.5, rot_outlier_pairs=6, false_match_frac=2e-4,
+                                      isolated_pair=True)
+    regb, R, C, stats = run_pipeline(s, gsfm_ctx)
+    print(stats)
+    assert regb[:40].all() and not regb[40:].any()  # the stray pair is gone
+    assert stats["rotation_filtered"][0] == 6  # exactly the corrupted pairs
+    assert stats["tracks_discarded"] > 0 and stats["tracks_selected"] > 1000
+    rot_err = synthetic.rotation_errors_deg(R, s["gt_R"][:40])
+    cen_err = synthetic.center_errors_after_sim3(C, s["gt_center"][:40])
+    print(rot_err.max(), cen_err.max())
+    assert rot_err.max() < 0.1
+    assert cen_err.max() < 1e-2
