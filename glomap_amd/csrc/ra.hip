@@ -372,6 +372,110 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+
+// ---- fused ADMM sweep of the dense (single-GPU, N <= 2048) L1 stage -------------------------------------
+// One launch = k_admm_edge + k_node_gather<GATHER_L1RHS> + k_admm_check.  Node-centric: the wave(s) of node n
+// walk its incidence list and evaluate the z / u update of every incident edge — each edge is evaluated by
+// BOTH endpoints with the same operand order (bit-identical values), so the gathers need no second pass; the
+// endpoint that is image_id1 owns the edge: it stores the new z / u (double-buffered: the other endpoint may
+// still be reading the old ones) and accounts the edge in the norm partials.  The block that finishes last
+// (ticket counter) re-reduces the partials and evaluates LeastAbsoluteDeviationSolver's stopping test.
+template <int LPR>
+__global__ void __launch_bounds__(kBlock)
+    k_admm_node(int N, long E, const int* __restrict__ rowptr, const int* __restrict__ inc, const int* __restrict__ nbr,
+                const double* __restrict__ ew, const double* __restrict__ res, const double* __restrict__ x,
+                const double* __restrict__ z_in, const double* __restrict__ u_in, double* __restrict__ z_out,
+                double* __restrict__ u_out, double alpha, double inv_rho, double* __restrict__ rhs, int fixed_node,
+                int has_gauge, double* part /* [grid][6] */, unsigned* ticket, double rows, double abs_tol, double rel_tol,
+                double rho, int* stop, int* count) {
+  __shared__ double smem[4 * 6 + 6];
+  __shared__ int last_s;
+  if (*stop) return;
+  const int gpb = kBlock / LPR;
+  const int g = threadIdx.x / LPR;
+  const int l = threadIdx.x % LPR;
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  auto edge = [&](long e, double w, double sgn, const double (&xi)[3], const double (&xj)[3], bool gauge, bool owner,
+                  double (&a)[3], double (&sv)[3], double (&tv)[3]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double Ax = gauge ? xj[c] : w * (xj[c] - xi[c]);
+      const double b = w * res[3 * e + c];
+      const double zo = z_in[3 * e + c];
+      const double uo = u_in[3 * e + c];
+      const double Ax_hat = alpha * Ax + (1.0 - alpha) * (zo + b);
+      const double v = Ax_hat - b + uo;
+      const double zn = fmax(0.0, v - inv_rho) - fmax(0.0, -v - inv_rho);
+      const double un = uo + Ax_hat - zn - b;
+      if (owner) {
+        z_out[3 * e + c] = zn;
+        u_out[3 * e + c] = un;
+        const double rn = Ax - zn - b;
+        acc[0] += rn * rn;
+        acc[1] += Ax * Ax;
+        acc[2] += zn * zn;
+        acc[3] += b * b;
+      }
+      const double sc = sgn * w;
+      a[c] += sc * (b + zn - un);
+      sv[c] += sc * (zn - zo);
+      tv[c] += sc * un;
+    }
+  };
+  for (int n = blockIdx.x * gpb + g; n < N; n += gridDim.x * gpb) {
+    const int k0 = rowptr[n], k1 = rowptr[n + 1];
+    const double xn[3] = {x[3 * (long)n], x[3 * (long)n + 1], x[3 * (long)n + 2]};
+    double a[3] = {0, 0, 0}, sv[3] = {0, 0, 0}, tv[3] = {0, 0, 0};
+    for (int k = k0 + l; k < k1; k += LPR) {
+      const int code = inc[k];
+      const long e = code >> 1;
+      const long m = nbr[k];
+      const double xm[3] = {x[3 * m], x[3 * m + 1], x[3 * m + 2]};
+      const double w = ew ? ew[e] : 1.0;
+      if (code & 1)  // this node is image_id2 (+I3): Ax = w (x_n - x_m)
+        edge(e, w, 1.0, xm, xn, false, false, a, sv, tv);
+      else  // this node is image_id1 (-I3): it owns the edge
+        edge(e, w, -1.0, xn, xm, false, true, a, sv, tv);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      a[c] = group_sum<LPR>(a[c]);
+      sv[c] = group_sum<LPR>(sv[c]);
+      tv[c] = group_sum<LPR>(tv[c]);
+    }
+    if (l == 0) {
+      if (has_gauge && n == fixed_node) edge(E, 1.0, 1.0, xn, xn, true, true, a, sv, tv);  // gauge rows (gra.cc:455-460)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        rhs[3 * (long)n + c] = a[c];
+        acc[4] += sv[c] * sv[c];
+        acc[5] += tv[c] * tv[c];
+      }
+    }
+  }
+  block_sum<6>(acc, smem);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) part[blockIdx.x * 6 + k] = acc[k];
+    __threadfence();
+    last_s = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last_s) return;
+  __threadfence();
+  double h[6];
+  reduce_partials<6>(part, gridDim.x, h, smem);
+  if (threadIdx.x == 0) {
+    const double r_norm = sqrt(h[0]), Ax_norm = sqrt(h[1]), z_norm = sqrt(h[2]), b_norm = sqrt(h[3]);
+    const double s_norm = rho * sqrt(h[4]), dual_norm = rho * sqrt(h[5]);
+    const double primal_eps = sqrt(rows) * abs_tol + rel_tol * fmax(Ax_norm, fmax(z_norm, b_norm));
+    const double dual_eps = sqrt(3.0 * N) * abs_tol + rel_tol * dual_norm;
+    *count += 1;
+    if (r_norm < primal_eps && s_norm < dual_eps) *stop = 1;
+    *ticket = 0u;
+  }
+}
+
 // partial sums of squares of two N*3 vectors -> part[grid][2]
 __global__ void __launch_bounds__(kBlock)
     k_sumsq2(long n, const double* __restrict__ a, const double* __restrict__ b,
@@ -448,7 +552,7 @@ struct RaWs {
   DevBuf<int> ei, ej, rowptr, inc, nbr, inc_row, flags;
   DevBuf<double> dense_a, dense_b, dense_pinv;
   DevBuf<double> eq, ew, inc_w, lap_diag, lap_diag_loc, rot, nq, res, wirls, z, u, dz, rhs, x, r, wbuf,
-      gat_s, gat_t, fixed_rot0, part_misc, scal, cg_b, cg_x, cg_r, cg_z, cg_p, cg_s, cg_w, cg_minv, vpart, dpart;
+      gat_s, gat_t, fixed_rot0, part_misc, z2, u2, scal, cg_b, cg_x, cg_r, cg_z, cg_p, cg_s, cg_w, cg_minv, vpart, dpart;
   DevBuf<CgStatus> cgst;
   DevBuf<CgScal> cgsc;
   static void destroy(void* p) { delete static_cast<RaWs*>(p); }
@@ -968,17 +1072,22 @@ int ra_solve_impl(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
         // the inner iterations skip the refinement step (ADMM itself stops at 1e-2 relative).
         int* stop = ws->flags.get() + 1;
         int* count = ws->flags.get() + 2;
-        GSFM_HIP_CHECK(hipMemsetAsync(stop, 0, 2 * sizeof(int), s));
+        GSFM_HIP_CHECK(hipMemsetAsync(stop, 0, 3 * sizeof(int), s));  // stop, count, ticket
+        // two launches per ADMM iteration: x = A^-1 rhs, then the fused edge / gather / stopping-test sweep
+        double *z_cur = ws->z.get(), *u_cur = ws->u.get();
+        double *z_nxt = ws->z2.ensure(rows3), *u_nxt = ws->u2.ensure(rows3);
+        unsigned* ticket = reinterpret_cast<unsigned*>(ws->flags.get() + 3);
         for (int a = 0; a < opt->l1_admm_max_num_iterations; ++a) {
           dense_solve(d, /*refine=*/false, stop);
-          hipLaunchKernelGGL(k_admm_edge, dim3(d.gridE), dim3(kBlock), 0, s, E, d.has_gauge, d.fixed,
-                             ws->ei.get(), ws->ej.get(), d.ew, ws->res.get(), ws->x.get(), ws->z.get(),
-                             ws->u.get(), ws->dz.get(), opt->l1_admm_alpha, 1.0 / opt->l1_admm_rho,
-                             ws->part_misc.get(), stop);
-          launch_gather<GATHER_L1RHS>(d, stop);
-          hipLaunchKernelGGL(k_admm_check, dim3(1), dim3(1024), 0, s, ws->part_misc.get(), d.gridE, ws->gat_s.get(),
-                             ws->gat_t.get(), 3 * N, rows_glob, opt->l1_admm_absolute_tolerance,
-                             opt->l1_admm_relative_tolerance, opt->l1_admm_rho, stop, count);
+          dispatch_lpr(d.lpr, [&](auto L) {
+            hipLaunchKernelGGL((k_admm_node<decltype(L)::value>), dim3(d.gridRow), dim3(kBlock), 0, s, N, E, ws->rowptr.get(),
+                               ws->inc.get(), ws->nbr.get(), d.ew, ws->res.get(), ws->x.get(), z_cur, u_cur, z_nxt, u_nxt,
+                               opt->l1_admm_alpha, 1.0 / opt->l1_admm_rho, ws->rhs.get(), d.fixed, d.has_gauge,
+                               ws->part_misc.get(), ticket, rows_glob, opt->l1_admm_absolute_tolerance,
+                               opt->l1_admm_relative_tolerance, opt->l1_admm_rho, stop, count);
+          });
+          std::swap(z_cur, z_nxt);
+          std::swap(u_cur, u_nxt);
         }
         lin_iters += opt->l1_admm_max_num_iterations;
       }
