@@ -246,6 +246,36 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// w = (L_w (x) I3 + gauge) u plus this block's share of gamma = r.u and delta = w.u  (block-dense PCG, ra_dense.hpp)
+template <int LPR>
+__global__ void __launch_bounds__(kBlock)
+    k_bd_spmv(int N, const int* __restrict__ rowptr, const int* __restrict__ nbr, const double* __restrict__ inc_w,
+              const double* __restrict__ lap_diag, const double* __restrict__ u, const double* __restrict__ r,
+              double* __restrict__ w, double* __restrict__ dpart, const DpcgState* __restrict__ st) {
+  __shared__ double smem[4 * 2];
+  if (st->done) return;
+  const int gpb = kBlock / LPR;
+  const int g = threadIdx.x / LPR, l = threadIdx.x % LPR;
+  double acc[2] = {0.0, 0.0};
+  for (int n = blockIdx.x * gpb + g; n < N; n += gridDim.x * gpb) {
+    double y0, y1, y2;
+    laplacian_row<LPR>(n, l, rowptr, nbr, inc_w, lap_diag, u, y0, y1, y2);
+    if (l == 0) {
+      const long o = 3 * (long)n;
+      w[o] = y0;
+      w[o + 1] = y1;
+      w[o + 2] = y2;
+      acc[0] += r[o] * u[o] + r[o + 1] * u[o + 1] + r[o + 2] * u[o + 2];
+      acc[1] += y0 * u[o] + y1 * u[o + 1] + y2 * u[o + 2];
+    }
+  }
+  block_sum<2>(acc, smem);
+  if (threadIdx.x == 0) {
+    dpart[2 * blockIdx.x] = acc[0];
+    dpart[2 * blockIdx.x + 1] = acc[1];
+  }
+}
+
 // ---- Jacobi-PCG (cg.hpp) on the 3N system  (L_w (x) I3 + gauge) x = rhs ---------------------------
 // The three right-hand sides share the operator, so they are solved as ONE SPD system of 3N unknowns
 // (block-diagonal in the column index) with the single-reduction PCG of cg.hpp: per iteration the
@@ -550,7 +580,8 @@ __global__ void __launch_bounds__(kBlock)
 // ------------------------------------------------------------------------------------------
 struct RaWs {
   DevBuf<int> ei, ej, rowptr, inc, nbr, inc_row, flags;
-  DevBuf<double> dense_a, dense_b, dense_pinv;
+  DevBuf<double> dense_a, dense_b, dense_pinv, bd_inv, rot_out;
+  DevBuf<int> order;
   DevBuf<double> eq, ew, inc_w, lap_diag, lap_diag_loc, rot, nq, res, wirls, z, u, dz, rhs, x, r, wbuf,
       gat_s, gat_t, fixed_rot0, part_misc, z2, u2, scal, cg_b, cg_x, cg_r, cg_z, cg_p, cg_s, cg_w, cg_minv, vpart, dpart;
   DevBuf<CgStatus> cgst;
@@ -570,7 +601,7 @@ RaWs* ra_ws(gsfm_ctx* ctx) {
 // The root (node 0 = first registered image) gets the identity: the reference never assigns
 // cam_from_worlds[root], so it stays the default-constructed Rigid3d.
 void mst_init(int N, long E, const int* ei, const int* ej, const double* eq, const int* ninl,
-              double* rot /* [N][3] in/out */) {
+              double* rot /* [N][3] in/out */, int root = 0) {
   // edges by descending inlier count, ties in input order: counting sort when the value range is
   // moderate (inlier counts are), comparison sort otherwise
   std::vector<long> order(E);
@@ -619,8 +650,8 @@ void mst_init(int N, long E, const int* ei, const int* ej, const double* eq, con
   std::vector<char> vis(N, 0);
   std::vector<int> queue;
   queue.reserve(N);
-  queue.push_back(0);
-  vis[0] = 1;
+  queue.push_back(root);
+  vis[root] = 1;
   for (size_t h = 0; h < queue.size(); ++h) {
     const int cur = queue[h];
     for (auto [nb, e] : adj[cur]) {
@@ -668,6 +699,13 @@ struct RaDevice {
   bool dense_valid = false;   // dense_inv holds the inverse of the current weighted Laplacian
   bool dense_have = false;    // dense_inv holds the inverse of SOME earlier weighted Laplacian (preconditioner)
   bool dense_refresh = false; // the stale inverse needed too many PCG iterations: re-invert at the next solve
+  // 2048 < N <= kBlockDenseMaxN, one rank: PCG preconditioned by dense inverses of index-contiguous diagonal blocks;
+  // the node ids of the whole solve are BFS positions (ws->order maps them back)
+  bool blockdense = false;
+  bool bd_have = false, bd_refresh = false;
+  bool bd_fresh = false;   // the factored blocks belong to the weights currently in inc_w / lap_diag
+  int bd_base_iters = 0;   // iterations of the first cold solve with a matching preconditioner (stale budget = 2.5x)
+  int bd_nb = 0, bd_nblk = 0;
   bool dense_always_factor = false;  // GSFM_RA_DENSE_REFACTOR=1: re-invert for every new weighting (the round-1 behaviour)
   int Np = 0, T = 0;          // padded size, tiles per side
   double* dense_inv = nullptr;
@@ -723,7 +761,7 @@ void build_incidence(RaDevice& d, const int* h_ei, const int* h_ej) {
   GSFM_HIP_CHECK(hipMemcpyAsync(ws->rowptr.ensure(N + 1), rowptr.data(), (N + 1) * sizeof(int), hipMemcpyHostToDevice, s));
   GSFM_HIP_CHECK(hipMemcpyAsync(ws->inc.ensure(2 * E + 1), inc.data(), 2 * E * sizeof(int), hipMemcpyHostToDevice, s));
   GSFM_HIP_CHECK(hipMemcpyAsync(ws->nbr.ensure(2 * E + 1), nbr.data(), 2 * E * sizeof(int), hipMemcpyHostToDevice, s));
-  if (d.dense)
+  if (d.dense || d.blockdense)
     GSFM_HIP_CHECK(hipMemcpyAsync(ws->inc_row.ensure(2 * E + 1), inc_row.data(), 2 * E * sizeof(int), hipMemcpyHostToDevice, s));
   GSFM_HIP_CHECK(hipStreamSynchronize(s));  // host vectors go out of scope
 }
@@ -789,7 +827,7 @@ int dense_pcg_solve(RaDevice& d, double tol) {
   DpcgState* st = reinterpret_cast<DpcgState*>(ws->cgst.get());
   double* u = ws->cg_z.get();
   double* w = ws->cg_w.get();
-  hipLaunchKernelGGL(k_dpcg_init, dim3(1), dim3(kBlock), 0, s, n3, ws->rhs.get(), ws->x.get(), ws->cg_r.get(), ws->cg_p.get(),
+  hipLaunchKernelGGL(k_dpcg_init, dim3(1), dim3(1024), 0, s, n3, ws->rhs.get(), ws->x.get(), ws->cg_r.get(), ws->cg_p.get(),
                      ws->cg_s.get(), st);
   const int gA = grid_for(N, kBlock / 64);
   constexpr int kBatch = 10, kMaxIters = 40;
@@ -801,7 +839,7 @@ int dense_pcg_solve(RaDevice& d, double tol) {
         hipLaunchKernelGGL((k_spmv<decltype(L)::value>), dim3(d.gridRow), dim3(kBlock), 0, s, N, ws->rowptr.get(),
                            ws->nbr.get(), ws->inc_w.get(), ws->lap_diag_loc.get(), u, w);
       });
-      hipLaunchKernelGGL(k_dpcg_update, dim3(1), dim3(kBlock), 0, s, n3, tol * tol, u, w, ws->x.get(), ws->cg_r.get(),
+      hipLaunchKernelGGL(k_dpcg_update, dim3(1), dim3(1024), 0, s, n3, tol * tol, u, w, ws->x.get(), ws->cg_r.get(),
                          ws->cg_p.get(), ws->cg_s.get(), st);
     }
     GSFM_HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 96, st, sizeof(DpcgState), hipMemcpyDeviceToHost, s));
@@ -814,6 +852,118 @@ int dense_pcg_solve(RaDevice& d, double tol) {
   return h.iters;
 }
 
+// Inverts the diagonal blocks of the CURRENT weighted Laplacian (ra_dense.hpp), block by block through the two
+// ping-pong buffers of the Gauss-Jordan sweep.
+void bd_factor(RaDevice& d) {
+  RaWs* ws = d.ws;
+  hipStream_t s = d.ctx->stream;
+  const int nb = d.bd_nb, T = nb / kTile;
+  const size_t nn = (size_t)nb * nb;
+  double* inv = ws->bd_inv.ensure((size_t)d.bd_nblk * nn);
+  double* pinv = ws->dense_pinv.ensure(2 * kTile * kTile);
+  double* bufa = ws->dense_a.ensure(nn);
+  double* bufb = ws->dense_b.ensure(nn);
+  for (int b = 0; b < d.bd_nblk; ++b) {
+    double *cur = bufa, *oth = bufb;
+    GSFM_HIP_CHECK(hipMemsetAsync(cur, 0, nn * sizeof(double), s));
+    hipLaunchKernelGGL(k_bd_fill_offdiag, dim3(grid_for(2 * d.E, kBlock)), dim3(kBlock), 0, s, 2 * d.E, ws->inc_row.get(),
+                       ws->nbr.get(), ws->inc_w.get(), b * nb, nb, cur);
+    hipLaunchKernelGGL(k_bd_fill_diag, dim3(grid_for(nb, kBlock)), dim3(kBlock), 0, s, d.N, b * nb, nb, ws->lap_diag.get(), cur);
+    hipLaunchKernelGGL(k_dense_pivot0, dim3(1), dim3(kBlock), 0, s, cur, nb, pinv);
+    for (int k = 0; k < T; ++k) {
+      hipLaunchKernelGGL(k_dense_gj_step, dim3(T, T), dim3(kBlock), 0, s, cur, oth, nb, T, k, pinv + (k & 1) * kTile * kTile,
+                         pinv + ((k + 1) & 1) * kTile * kTile);
+      std::swap(cur, oth);
+    }
+    GSFM_HIP_CHECK(hipMemcpyAsync(inv + (size_t)b * nn, cur, nn * sizeof(double), hipMemcpyDeviceToDevice, s));
+  }
+  d.bd_have = true;
+  d.bd_refresh = false;
+  d.bd_fresh = true;
+  d.bd_base_iters = 0;
+}
+
+// PCG with the block-diagonal dense preconditioner; same contract as the Jacobi path of pcg_solve.
+// A preconditioner factored from EARLIER weights is tried first (the L1 stage never changes its weights, IRLS changes
+// them little once it is converging); when that takes more than ~2.5x the iterations of a matching preconditioner —
+// the first IRLS systems, whose weights of a few nodes differ by orders of magnitude from the L1 ones, do — the solve is
+// abandoned, the blocks are re-inverted with the current weights and the solve restarts.
+int bd_pcg_solve(RaDevice& d, bool warm, double tol, int max_iter) {
+  RaWs* ws = d.ws;
+  gsfm_ctx* ctx = d.ctx;
+  hipStream_t s = ctx->stream;
+  const int N = d.N, n3 = 3 * N;
+  static const bool trace = getenv("GSFM_RA_TRACE") != nullptr;
+  if (!d.bd_have || d.bd_refresh) bd_factor(d);
+  const double* b = ws->rhs.get();
+  double* x = ws->x.get();
+  if (warm) {  // solve A dx = rhs - A x0 and add (the ADMM iterates of one L1 solve are close)
+    dispatch_lpr(d.lpr, [&](auto L) {
+      hipLaunchKernelGGL((k_spmv<decltype(L)::value>), dim3(d.gridRow), dim3(kBlock), 0, s, N, ws->rowptr.get(), ws->nbr.get(),
+                         ws->inc_w.get(), ws->lap_diag_loc.get(), ws->x.get(), ws->wbuf.get());
+    });
+    hipLaunchKernelGGL(k_dense_residual, dim3(d.gridN), dim3(kBlock), 0, s, (long)n3, ws->rhs.get(), ws->wbuf.get(), ws->cg_b.get());
+    b = ws->cg_b.get();
+    x = ws->cg_x.get();
+  }
+  DpcgState* st = reinterpret_cast<DpcgState*>(ws->cgst.get());
+  BdScal* scal = reinterpret_cast<BdScal*>(ws->cgsc.get());
+  double* u = ws->cg_z.get();
+  double* w = ws->cg_w.get();
+  double* rpart = ws->vpart.get();
+  double* dpart = ws->dpart.get();
+  const int gA = grid_wide(N, kBlock / 64, 1 << 14);
+  const int gS = std::min(d.gridRow, kMaxApplySlots / 2);
+  const int batch = tol > 1e-6 ? 6 : 12;  // inexact (ADMM) solves stop after a handful of iterations
+  DpcgState h{};
+  int total = 0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    // a stale preconditioner gets a bounded budget; a fresh one the caller's
+    const int budget = d.bd_fresh ? max_iter : std::min(max_iter, std::max(40, (5 * d.bd_base_iters) / 2));
+    hipLaunchKernelGGL(k_dpcg_init, dim3(1), dim3(1024), 0, s, n3, b, x, ws->cg_r.get(), ws->cg_p.get(), ws->cg_s.get(), st);
+    h = DpcgState{};
+    for (int done = 0; done < budget && !h.done; done += batch) {
+      for (int it = done; it < done + batch; ++it) {
+        hipLaunchKernelGGL(k_bd_apply3, dim3(gA), dim3(kBlock), 0, s, N, d.bd_nb, ws->bd_inv.get(), ws->cg_r.get(), u, it,
+                           tol * tol, rpart, st);
+        const bool timed = ctx->prof.begin(s, GSFM_KERNEL_RA_LAPLACIAN);
+        dispatch_lpr(d.lpr, [&](auto L) {
+          hipLaunchKernelGGL((k_bd_spmv<decltype(L)::value>), dim3(gS), dim3(kBlock), 0, s, N, ws->rowptr.get(), ws->nbr.get(),
+                             ws->inc_w.get(), ws->lap_diag_loc.get(), u, ws->cg_r.get(), w, dpart, st);
+        });
+        if (timed) ctx->prof.end(s);
+        hipLaunchKernelGGL(k_bd_update, dim3(kBdUpdateBlocks), dim3(kBlock), 0, s, n3, gS, dpart, u, w, x, ws->cg_r.get(),
+                           ws->cg_p.get(), ws->cg_s.get(), it, scal + (it & 1), scal + ((it + 1) & 1), rpart, st);
+      }
+      // one more convergence test for the last update of the batch (k_bd_apply3 of the next iteration would do it)
+      GSFM_HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 96, st, sizeof(DpcgState), hipMemcpyDeviceToHost, s));
+      GSFM_HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 104, rpart, kBdUpdateBlocks * sizeof(double), hipMemcpyDeviceToHost, s));
+      GSFM_HIP_CHECK(hipStreamSynchronize(s));
+      std::memcpy(&h, ctx->h_pinned + 96, sizeof(DpcgState));
+      if (!h.done) {
+        double rr = 0.0;
+        for (int i = 0; i < kBdUpdateBlocks; ++i) rr += ctx->h_pinned[104 + i];
+        if (rr <= tol * tol * h.bb) {
+          h.done = 1;
+          h.rr = rr;
+        }
+      }
+    }
+    total += h.iters;
+    if (trace)
+      fprintf(stderr, "[ra] bd_pcg warm=%d tol=%.1e fresh=%d iters=%d done=%d bad=%d rr/bb=%.3e\n", (int)warm, tol, (int)d.bd_fresh,
+              h.iters, h.done, h.bad, h.bb > 0 ? h.rr / h.bb : 0.0);
+    if (h.done && !h.bad) {
+      if (d.bd_fresh && !warm && d.bd_base_iters == 0) d.bd_base_iters = std::max(h.iters, 1);
+      break;
+    }
+    if (d.bd_fresh) break;  // a matching preconditioner did not converge within the caller's limit: report as is
+    bd_factor(d);           // stale preconditioner out of budget: re-invert with the current weights and restart
+  }
+  if (warm) hipLaunchKernelGGL(k_ra_add, dim3(d.gridN), dim3(kBlock), 0, s, (long)n3, ws->x.get(), ws->cg_x.get(), ws->x.get());
+  return total;
+}
+
 int pcg_solve(RaDevice& d, bool warm, double tol, int max_iter) {
   if (d.dense) {
     // a stale inverse (same graph, earlier weights) preconditions the new system; fall back to a fresh inversion
@@ -824,6 +974,7 @@ int pcg_solve(RaDevice& d, bool warm, double tol, int max_iter) {
     }
     return dense_solve(d);
   }
+  if (d.blockdense) return bd_pcg_solve(d, warm, tol, max_iter);
   RaWs* ws = d.ws;
   gsfm_ctx* ctx = d.ctx;
   hipStream_t s = ctx->stream;
@@ -896,8 +1047,43 @@ void update_rotations(RaDevice& d, double out[3]) {
   out[2] = d.ctx->h_pinned[66];
 }
 
+// BFS order of the view graph from `root` (unreached nodes appended): order[p] = node, pos[node] = p.
+void bfs_order(int N, long E, const int* ei, const int* ej, int root, std::vector<int>& order, std::vector<int>& pos) {
+  std::vector<int> rowptr(N + 1, 0);
+  for (long e = 0; e < E; ++e) {
+    rowptr[ei[e] + 1]++;
+    rowptr[ej[e] + 1]++;
+  }
+  for (int n = 0; n < N; ++n) rowptr[n + 1] += rowptr[n];
+  std::vector<int> fill(rowptr.begin(), rowptr.end() - 1), adj(2 * E);
+  for (long e = 0; e < E; ++e) {
+    adj[fill[ei[e]]++] = ej[e];
+    adj[fill[ej[e]]++] = ei[e];
+  }
+  order.clear();
+  order.reserve(N);
+  pos.assign(N, -1);
+  auto visit = [&](int start) {
+    pos[start] = (int)order.size();
+    order.push_back(start);
+    for (size_t h = order.size() - 1; h < order.size(); ++h) {
+      const int cur = order[h];
+      for (int k = rowptr[cur]; k < rowptr[cur + 1]; ++k) {
+        const int nb = adj[k];
+        if (pos[nb] < 0) {
+          pos[nb] = (int)order.size();
+          order.push_back(nb);
+        }
+      }
+    }
+  };
+  visit(root);
+  for (int n = 0; n < N; ++n)
+    if (pos[n] < 0) visit(n);
+}
+
 void setup_device(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_options* opt,
-                  const double* rot_in, RaDevice& d) {
+                  const double* rot_in, RaDevice& d, bool allow_blockdense = false) {
   RaWs* ws = ra_ws(ctx);
   const int N = prob->num_nodes;
   const long E = prob->num_edges;
@@ -912,6 +1098,14 @@ void setup_device(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
   d.dense_valid = false;
   d.dense_have = false;
   d.dense_refresh = false;
+  d.blockdense = allow_blockdense && !d.dense && ctx->comm.world == 1 && N <= kBlockDenseMaxN && opt->pcg_max_iterations > 0 &&
+                 !opt->force_iterative && getenv("GSFM_RA_NO_BLOCKDENSE") == nullptr;
+  d.bd_have = d.bd_refresh = d.bd_fresh = false;
+  d.bd_base_iters = 0;
+  if (d.blockdense) {
+    d.bd_nblk = (N + kDenseMaxN - 1) / kDenseMaxN;
+    d.bd_nb = (((N + d.bd_nblk - 1) / d.bd_nblk + kTile - 1) / kTile) * kTile;
+  }
   {
     static const bool always = getenv("GSFM_RA_DENSE_REFACTOR") != nullptr;
     d.dense_always_factor = always;
@@ -943,10 +1137,34 @@ void setup_device(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
   std::vector<int> h_ei, h_ej;
   to_host(ctx, h_ei, prob->edge_i, E, mem);
   to_host(ctx, h_ej, prob->edge_j, E, mem);
+  std::vector<int> pos;
+  int mst_root = 0;
+  if (d.blockdense) {  // relabel the nodes in BFS order for the whole solve: index-contiguous blocks become graph-local
+    for (long e = 0; e < E; ++e)
+      GSFM_REQUIRE(h_ei[e] >= 0 && h_ei[e] < N && h_ej[e] >= 0 && h_ej[e] < N, "RA: edge index out of range");
+    std::vector<int> order;
+    bfs_order(N, E, h_ei.data(), h_ej.data(), d.fixed, order, pos);
+    for (long e = 0; e < E; ++e) {
+      h_ei[e] = pos[h_ei[e]];
+      h_ej[e] = pos[h_ej[e]];
+    }
+    GSFM_HIP_CHECK(hipMemcpyAsync(ws->ei.get(), h_ei.data(), E * sizeof(int), hipMemcpyHostToDevice, s));
+    GSFM_HIP_CHECK(hipMemcpyAsync(ws->ej.get(), h_ej.data(), E * sizeof(int), hipMemcpyHostToDevice, s));
+    GSFM_HIP_CHECK(hipMemcpyAsync(ws->order.ensure(N), order.data(), N * sizeof(int), hipMemcpyHostToDevice, s));
+    GSFM_HIP_CHECK(hipStreamSynchronize(s));
+    d.fixed = pos[d.fixed];
+    mst_root = pos[0];
+  }
   build_incidence(d, h_ei.data(), h_ej.data());
 
   std::vector<double> h_rot;
   to_host(ctx, h_rot, rot_in, 3 * (size_t)N, mem);
+  if (d.blockdense) {
+    std::vector<double> tmp(h_rot.size());
+    for (int n = 0; n < N; ++n)
+      for (int c = 0; c < 3; ++c) tmp[3 * (size_t)pos[n] + c] = h_rot[3 * (size_t)n + c];
+    h_rot.swap(tmp);
+  }
   if (!opt->skip_initialization) {
     GSFM_REQUIRE(prob->edge_ninl != nullptr, "RA: MST initialisation requires edge_ninl");
     GSFM_REQUIRE(ctx->comm.world == 1, "RA: MST initialisation needs the whole graph; initialise before sharding");
@@ -954,7 +1172,7 @@ void setup_device(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
     std::vector<int> h_ninl;
     to_host(ctx, h_eq, prob->edge_q, 4 * (size_t)E, mem);
     to_host(ctx, h_ninl, prob->edge_ninl, E, mem);
-    mst_init(N, E, h_ei.data(), h_ej.data(), h_eq.data(), h_ninl.data(), h_rot.data());
+    mst_init(N, E, h_ei.data(), h_ej.data(), h_eq.data(), h_ninl.data(), h_rot.data(), mst_root);
   }
   GSFM_HIP_CHECK(hipMemcpyAsync(ws->rot.ensure(3 * (size_t)N), h_rot.data(), 3 * (size_t)N * sizeof(double), hipMemcpyHostToDevice, s));
   // the gauge node is held at its (post-initialisation) rotation (gra.cc:248-257)
@@ -1002,7 +1220,10 @@ int read_nan_flag(RaDevice& d) {
 template <int MODE>
 void launch_gather(RaDevice& d, const int* stop = nullptr) {
   RaWs* ws = d.ws;
-  if (MODE != GATHER_L1RHS) d.dense_valid = false;  // the weighted Laplacian changes
+  if (MODE != GATHER_L1RHS) {  // the weighted Laplacian changes
+    d.dense_valid = false;
+    d.bd_fresh = false;
+  }
   dispatch_lpr(d.lpr, [&](auto L) {
     hipLaunchKernelGGL((k_node_gather<MODE, decltype(L)::value>), dim3(d.gridRow), dim3(kBlock), 0,
                        d.ctx->stream, d.N, d.E, ws->rowptr.get(), ws->inc.get(), ws->res.get(),
@@ -1021,7 +1242,7 @@ int ra_solve_impl(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
   const double t0 = now_seconds();
   GSFM_HIP_CHECK(hipSetDevice(ctx->device));
   RaDevice d;
-  setup_device(ctx, prob, opt, rot_inout, d);
+  setup_device(ctx, prob, opt, rot_inout, d, /*allow_blockdense=*/true);
   RaWs* ws = d.ws;
   hipStream_t s = ctx->stream;
   const int N = d.N;
@@ -1161,7 +1382,12 @@ int ra_solve_impl(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
     }
   }
 
-  copy_out(ctx, rot_inout, ws->rot.get(), 3 * (size_t)N, prob->mem);
+  if (d.blockdense) {  // back from BFS positions to the caller's node ids
+    hipLaunchKernelGGL(k_unpermute3, dim3(d.gridN), dim3(kBlock), 0, s, N, ws->order.get(), ws->rot.get(), ws->rot_out.ensure(3 * (size_t)N));
+    copy_out(ctx, rot_inout, ws->rot_out.get(), 3 * (size_t)N, prob->mem);
+  } else {
+    copy_out(ctx, rot_inout, ws->rot.get(), 3 * (size_t)N, prob->mem);
+  }
   GSFM_HIP_CHECK(hipStreamSynchronize(s));
   const double t2 = now_seconds();
   if (rep) {
@@ -1205,7 +1431,7 @@ extern "C" void gsfm_ra_options_default(gsfm_ra_options* o) {
   o->pcg_relative_tolerance = 1e-10;
   o->pcg_max_iterations = 2000;
   o->force_iterative = 0;
-  o->pcg_relative_tolerance_admm = 1e-3;
+  o->pcg_relative_tolerance_admm = 1e-6;
 }
 
 extern "C" int gsfm_ra_solve(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_options* opt,

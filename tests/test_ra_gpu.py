@@ -127,3 +127,46 @@ def test_scene_level_rotation_estimator(gsfm_ctx):
     R = so3.quat_to_rotmat(np.array([frames[100 + n].rig_from_world.rotation for n in range(p.num_nodes)]))
     assert synthetic.rotation_errors_deg(R, p.gt_R).max() < 1e-2
     assert all(np.all(f.rig_from_world.translation == 0) for f in frames.values())  # gra.cc:793-798
+
+
+def _relabel(p, seed):
+    """The same view graph with randomly permuted node ids (what arbitrary image ids look like to the solver)."""
+    import copy
+
+    rng = np.random.default_rng(seed)
+    perm = rng.permutation(p.num_nodes)  # new id of old node n = perm[n]
+    q = copy.deepcopy(p)
+    q.edge_i = perm[p.edge_i].astype(np.int32)
+    q.edge_j = perm[p.edge_j].astype(np.int32)
+    q.node_aa0 = np.zeros_like(p.node_aa0)
+    q.node_aa0[perm] = p.node_aa0
+    q.gt_R = np.zeros_like(p.gt_R)
+    q.gt_R[perm] = p.gt_R
+    return q, perm
+
+
+@pytest.mark.parametrize("n,succ,shuffle,fixed", [(2500, 20, False, 0), (3000, 12, True, 17), (4500, 20, True, 4000)])
+def test_ra_block_dense_preconditioner_path(gsfm_ctx, n, succ, shuffle, fixed):
+    """2048 < N <= 16384 on one GPU: PCG preconditioned by dense inverses of BFS-ordered diagonal blocks (nodes are
+    relabelled internally).  Must agree with the Jacobi-PCG path and, where the oracle is affordable, with the oracle —
+    for arbitrary node labels and gauge node."""
+    p = synthetic.make_ring_view_graph(n, succ, noise_deg=1.0, outlier_ratio=0.05, seed=11)
+    if shuffle:
+        p, _ = _relabel(p, 5)
+    p.fixed_node = fixed
+    rc, rot_bd, rep = estimators.ra_solve(p, ctx=gsfm_ctx)
+    assert rc == 0
+    rc, rot_it, rep_it = estimators.ra_solve(p, estimators.RotationEstimatorOptions(force_iterative=True), ctx=gsfm_ctx)
+    assert rc == 0
+    assert rep["iterations_l1"] == rep_it["iterations_l1"]
+    assert rep["linear_iterations"] < 0.25 * rep_it["linear_iterations"]  # the point of the preconditioner
+    assert rep["iterations_irls"] == rep_it["iterations_irls"]
+    assert _angle_between(rot_bd, rot_it).max() < 1e-6  # both reproduce the direct solves far below the parity tolerance
+    err = synthetic.rotation_errors_deg(oso3.exp_aa(rot_bd), p.gt_R)
+    print("GT error deg: max %.3f median %.3f" % (err.max(), np.median(err)))
+    assert err.max() < 3.0  # the reference's noisy-scene pin (rotation_averager_test.cc:309-310)
+    if n <= 3000:
+        rot_o, tr = _oracle(p)
+        assert rep["iterations_l1"] == tr.l1_iterations and rep["iterations_irls"] == tr.irls_iterations
+        assert _angle_between(rot_o, rot_bd).max() < 1e-6
+        assert _angle_between(rot_o, rot_it).max() < 1e-6
