@@ -464,19 +464,19 @@ def bench_ra_sized(ctx, N, succ):
         best = dt if best is None else min(best, dt)
     err = synthetic.rotation_errors_deg(so3.aa_to_rotmat(rot.numpy()), p.gt_R)
     return {"cameras": N, "edges": p.num_edges, "ms_per_solve": best * 1e3, "value": p.num_edges / best, "unit": "edges/s",
-            "linear_solver": "dense direct (f64 MFMA)" if N <= 2048 else "3-RHS Jacobi-PCG",
+            "linear_solver": "dense direct (f64 MFMA)" if N <= 2048 else ("PCG, dense diagonal-block preconditioner (f64 MFMA block inverses)" if N <= 16384 else "3-RHS Jacobi-PCG"),
             "l1_iterations": rep["iterations_l1"], "irls_iterations": rep["iterations_irls"],
             "pcg_iterations": rep["linear_iterations"], "median_rot_err_deg_vs_gt": float(np.median(err))}
 
 
 def bench_ra_large(ctx):
-    """The RA sweep kernels on a view graph that does not fit the caches (200k cameras / 5M edges):
+    """The RA sweep kernels on a view graph that does not fit the caches (200k cameras / 10M edges):
     per-edge residual + IRLS weight sweep and the weighted-Laplacian SpMV with 3 right-hand sides."""
     import numpy as np
 
     from glomap_amd import estimators, synthetic
 
-    N, succ = 200_000, 25
+    N, succ = 200_000, 50  # E = 10^7 (SURVEY.md section 8d: a scaled-up run for a true HBM number)
     p = synthetic.make_ring_view_graph(N, succ, seed=0)
     E = p.num_edges
     w = np.ones(E)
