@@ -53,7 +53,7 @@ def _set_model(p, name):
 @pytest.mark.parametrize(
     "ncam,npts,noise,outl,shared,seed",
     [(20, 400, 0.0, 0.0, False, 0), (20, 400, 0.0, 0.0, True, 0), (30, 800, 0.5, 0.01, False, 3),
-     (30, 800, 0.5, 0.01, True, 4)],
+     (30, 800, 0.5, 0.01, True, 4), (120, 6000, 0.5, 0.01, False, 6)],  # the last one: mid-size, joint 14x14 blocks
 )
 def test_ba_matches_oracle(gsfm_ctx, ncam, npts, noise, outl, shared, seed):
     p = synthetic.make_ba_problem(num_cams=ncam, num_pts=npts, seed=seed, pixel_noise=noise, outlier_ratio=outl,

@@ -69,3 +69,49 @@ def test_ba_config4_full(gsfm_ctx):
     assert abs(rep2["initial_cost"] - rep["final_cost"]) <= 1e-9 * rep["final_cost"]
     assert rep2["final_cost"] <= rep["final_cost"] * (1 + 1e-9)
     assert rep2["final_cost"] >= 0.97 * rep["final_cost"]
+
+
+def test_ra_config3_cameras_block_preconditioned_path(gsfm_ctx):
+    """5k cameras / 250k edges (the camera count of configs[2]): the block-preconditioned PCG path.  The oracle's sparse
+    Cholesky of a 15k x 15k degree-100 Laplacian is out of test time, so: ground-truth recovery, agreement with the
+    Jacobi-PCG path (a different preconditioner and node order solving the same systems), idempotence."""
+    p = synthetic.make_ring_view_graph(5000, 50, seed=0)
+    rc, rot, rep = estimators.ra_solve(p, ctx=gsfm_ctx)
+    assert rc == 0
+    err = synthetic.rotation_errors_deg(so3.aa_to_rotmat(rot), p.gt_R)
+    assert np.median(err) < 0.5 and err.max() < 3.0
+    rc, rot_it, rep_it = estimators.ra_solve(p, estimators.RotationEstimatorOptions(force_iterative=True), ctx=gsfm_ctx)
+    assert rc == 0 and rep_it["iterations_l1"] == rep["iterations_l1"] and rep_it["iterations_irls"] == rep["iterations_irls"]
+    d = np.radians(so3.rotation_angle_deg(so3.aa_to_rotmat(rot), so3.aa_to_rotmat(rot_it)))
+    assert d.max() < 1e-6
+    assert rep["linear_iterations"] < 0.3 * rep_it["linear_iterations"]
+    p2 = type(p)(**{**p.__dict__, "node_aa0": rot})
+    rc, rot2, rep2 = estimators.ra_solve(
+        p2, estimators.RotationEstimatorOptions(skip_initialization=True, max_num_l1_iterations=0), ctx=gsfm_ctx)
+    assert rc == 0 and rep2["iterations_irls"] == 1
+
+
+def test_track_establishment_config3_full(gsfm_ctx):
+    """Match graph of the size of configs[2] (5k images, ~5.7M inlier matches): integer work, so the full-size result
+    is compared with the (vectorised) oracle bit for bit."""
+    from glomap_amd.tracks import MatchGraph, TrackEngine
+    from oracle import tracks as ot
+
+    g = synthetic.make_match_graph(5000, 500_000, seed=0)
+    ref = ot.establish_full_tracks(g["pair_image1"], g["pair_image2"], g["pair_valid"], g["pair_offset"], g["match_feat1"],
+                                   g["match_feat2"], g["feat_offset"], g["feat_xy"])
+    eng = TrackEngine(MatchGraph.from_dict(g), ctx=gsfm_ctx)
+    full = eng.EstablishFullTracks()
+    assert eng.num_discarded == ref[4] > 10000
+    for a, b in zip((full.track_id, full.track_offset, full.obs_image, full.obs_feature), ref[:4]):
+        assert np.array_equal(a, b)
+    reg = np.ones(5000, np.uint8)
+    reg[::11] = 0
+    from glomap_amd.tracks import TrackEstablishmentOptions
+
+    for kw in (dict(), dict(min_num_tracks_per_view=150, max_num_tracks=200000)):
+        eng.options = TrackEstablishmentOptions(**kw)
+        sel = eng.FindTracksForProblem(reg)
+        want = ot.find_tracks_for_problem(*ref[:4], reg, **kw)
+        for a, b in zip((sel.track_id, sel.track_offset, sel.obs_image, sel.obs_feature), want):
+            assert np.array_equal(a, b)

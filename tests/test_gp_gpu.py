@@ -23,7 +23,8 @@ def _rel_diff(a, b):
 
 @pytest.mark.parametrize(
     "ncam,npts,noise,outl,unc,seed",
-    [(30, 400, 0.0, 0.0, 0.0, 0), (40, 800, 1e-3, 0.02, 0.2, 1), (80, 3000, 1e-3, 0.02, 0.0, 3)],
+    [(30, 400, 0.0, 0.0, 0.0, 0), (40, 800, 1e-3, 0.02, 0.2, 1), (80, 3000, 1e-3, 0.02, 0.0, 3),
+     (300, 20000, 1e-3, 0.02, 0.1, 5)],  # the last one: ~120k observations, the largest the oracle solves in seconds
 )
 def test_gp_matches_oracle(gsfm_ctx, ncam, npts, noise, outl, unc, seed):
     p = synthetic.make_gp_problem(num_cams=ncam, num_pts=npts, seed=seed, dir_noise=noise, outlier_ratio=outl,
