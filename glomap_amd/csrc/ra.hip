@@ -580,7 +580,8 @@ __global__ void __launch_bounds__(kBlock)
 // ------------------------------------------------------------------------------------------
 struct RaWs {
   DevBuf<int> ei, ej, rowptr, inc, nbr, inc_row, flags;
-  DevBuf<double> dense_a, dense_b, dense_pinv, bd_inv, rot_out;
+  DevBuf<double> dense_a, dense_b, dense_pinv, rot_out;
+  DevBuf<float> bd_inv;
   DevBuf<int> order;
   DevBuf<double> eq, ew, inc_w, lap_diag, lap_diag_loc, rot, nq, res, wirls, z, u, dz, rhs, x, r, wbuf,
       gat_s, gat_t, fixed_rot0, part_misc, z2, u2, scal, cg_b, cg_x, cg_r, cg_z, cg_p, cg_s, cg_w, cg_minv, vpart, dpart;
@@ -859,7 +860,7 @@ void bd_factor(RaDevice& d) {
   hipStream_t s = d.ctx->stream;
   const int nb = d.bd_nb, T = nb / kTile;
   const size_t nn = (size_t)nb * nb;
-  double* inv = ws->bd_inv.ensure((size_t)d.bd_nblk * nn);
+  float* inv = ws->bd_inv.ensure((size_t)d.bd_nblk * nn);
   double* pinv = ws->dense_pinv.ensure(2 * kTile * kTile);
   double* bufa = ws->dense_a.ensure(nn);
   double* bufb = ws->dense_b.ensure(nn);
@@ -875,7 +876,7 @@ void bd_factor(RaDevice& d) {
                          pinv + ((k + 1) & 1) * kTile * kTile);
       std::swap(cur, oth);
     }
-    GSFM_HIP_CHECK(hipMemcpyAsync(inv + (size_t)b * nn, cur, nn * sizeof(double), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_bd_to_f32, dim3(grid_wide(nn, kBlock, 1 << 14)), dim3(kBlock), 0, s, nb, cur, inv + (size_t)b * nn);
   }
   d.bd_have = true;
   d.bd_refresh = false;

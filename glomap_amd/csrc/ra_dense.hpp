@@ -362,8 +362,19 @@ __device__ __forceinline__ double bd_reduce1(const double* __restrict__ part, in
 }
 
 // v / y are [N][3] in the (BFS) node order the blocks are cut in; one wave per row.
+// The block inverses are only a preconditioner, so they are stored in fp32 (symmetrised before rounding: CG needs a
+// symmetric M) — the apply is a pure stream of the blocks, half the bytes is nearly half the time; sums stay in f64.
 static __global__ void __launch_bounds__(kBlock)
-    k_bd_apply3(int N, int nb, const double* __restrict__ inv, const double* __restrict__ v, double* __restrict__ y, int it,
+    k_bd_to_f32(int nb, const double* __restrict__ inv, float* __restrict__ out) {
+  const size_t nn = (size_t)nb * nb;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / nb, c = i % nb;
+    out[i] = (float)(0.5 * (inv[i] + inv[c * nb + r]));
+  }
+}
+
+static __global__ void __launch_bounds__(kBlock)
+    k_bd_apply3(int N, int nb, const float* __restrict__ inv, const double* __restrict__ v, double* __restrict__ y, int it,
                 double tol2, const double* __restrict__ rpart, DpcgState* st) {
   __shared__ double smem[5];
   if (st->done) return;
@@ -383,11 +394,11 @@ static __global__ void __launch_bounds__(kBlock)
   for (int n = wave; n < N; n += nwaves) {
     const int b = n / nb, b0 = b * nb;
     const int cols = min(nb, N - b0);
-    const double* row = inv + (size_t)b * nb * nb + (size_t)(n - b0) * nb;
+    const float* row = inv + (size_t)b * nb * nb + (size_t)(n - b0) * nb;
     const double* vb = v + 3 * (size_t)b0;
     double a0 = 0, a1 = 0, a2 = 0;
     for (int m = lane; m < cols; m += 64) {
-      const double w = row[m];
+      const double w = (double)row[m];
       a0 += w * vb[3 * m];
       a1 += w * vb[3 * m + 1];
       a2 += w * vb[3 * m + 2];
