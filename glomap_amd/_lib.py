@@ -307,6 +307,8 @@ def load():
                                                   C.c_double, C.c_double, dp]
     lib.gsfm_filter_rotations.restype = ip
     lib.gsfm_filter_rotations.argtypes = [vp, C.c_int32, C.c_int32, vp, C.c_int64, vp, vp, vp, C.c_double, vp, i64p]
+    lib.gsfm_ctx_set_dump_dir.restype = ip
+    lib.gsfm_ctx_set_dump_dir.argtypes = [vp, C.c_char_p]
     lib.gsfm_track_options_default.restype = None
     lib.gsfm_track_options_default.argtypes = [C.POINTER(TrackOptionsC)]
     lib.gsfm_tracks_establish.restype = ip
@@ -435,6 +437,13 @@ class Context:
 
     def to_device(self, a: np.ndarray) -> "DeviceArray":
         return DeviceArray.from_numpy(self, a)
+
+    def set_dump_dir(self, directory):
+        """Every solve on this context writes its flat problem + result to `directory` (None disables); glomap_amd/flatio.py
+        reads the files back."""
+        rc = self.lib.gsfm_ctx_set_dump_dir(self.handle, None if directory is None else str(directory).encode())
+        if rc != 0:
+            raise GsfmError(rc, "gsfm_ctx_set_dump_dir")
 
     def profile_enable(self, on: bool):
         self.lib.gsfm_ctx_profile_enable(self.handle, int(on))

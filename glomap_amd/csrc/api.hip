@@ -44,6 +44,7 @@ extern "C" int gsfm_ctx_create(int device_id, gsfm_ctx** out) {
     GSFM_HIP_CHECK(hipEventCreate(&ctx->ev0));
     GSFM_HIP_CHECK(hipEventCreate(&ctx->ev1));
     GSFM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pinned), 4096 * sizeof(double), hipHostMallocDefault));
+    if (const char* dd = getenv("GSFM_DUMP_DIR")) ctx->dump_dir = dd;
     return (int)GSFM_OK;
   });
   if (rc != GSFM_OK) {
@@ -197,4 +198,10 @@ extern "C" int gsfm_comm_destroy(gsfm_ctx* ctx) {
     ctx->comm = Comm{};
     return (int)GSFM_OK;
   });
+}
+
+extern "C" int gsfm_ctx_set_dump_dir(gsfm_ctx* ctx, const char* directory) {
+  if (!ctx) return GSFM_ERR_INVALID_ARGUMENT;
+  ctx->dump_dir = directory ? directory : "";
+  return GSFM_OK;
 }

@@ -38,6 +38,7 @@
 
 #include "camera.hpp"
 #include "cg.hpp"
+#include "dump.hpp"
 #include "lm.hpp"
 #include "obsgraph.hpp"
 
@@ -1477,8 +1478,46 @@ extern "C" int gsfm_ba_solve(gsfm_ctx* ctx, const gsfm_ba_problem* prob, const g
                              double* cam_q_inout, double* cam_t_inout, double* pt_xyz_inout,
                              double* intr_params_inout, gsfm_report* report) {
   if (!ctx) return GSFM_ERR_INVALID_ARGUMENT;
-  if (report) std::memset(report, 0, sizeof(*report));
-  return guarded(ctx, report, [&] {
+  gsfm_report local{};
+  if (!report) report = &local;
+  std::memset(report, 0, sizeof(*report));
+  FlatDump dump(ctx, "ba");
+  const bool dumping = dump.active() && prob && opt && cam_q_inout && cam_t_inout && pt_xyz_inout && intr_params_inout;
+  if (dumping) {
+    const int64_t N = prob->num_cams, K = prob->num_intr, P = prob->num_pts, M = prob->num_obs;
+    dump.scalar("num_cams", (double)N);
+    dump.scalar("num_intr", (double)K);
+    dump.scalar("fixed_cam", prob->fixed_cam);
+    dump.scalar("comm_rank", ctx->comm.rank);
+    dump.scalar("comm_world", ctx->comm.world);
+    dump.array("pt_offset", prob->pt_offset, {P + 1}, prob->mem);
+    dump.array("obs_cam", prob->obs_cam, {M}, prob->mem);
+    dump.array("obs_xy", prob->obs_xy, {M, 2}, prob->mem);
+    dump.array("cam_intr", prob->cam_intr, {N}, prob->mem);
+    dump.array("intr_model", prob->intr_model, {K}, prob->mem);
+    dump.array("cam_q", cam_q_inout, {N, 4}, prob->mem);
+    dump.array("cam_t", cam_t_inout, {N, 3}, prob->mem);
+    dump.array("pt_xyz", pt_xyz_inout, {P, 3}, prob->mem);
+    dump.array("intr_params", intr_params_inout, {K, GSFM_CAMERA_MAX_PARAMS}, prob->mem);
+    dump_lm_options(dump, &opt->lm);
+    GSFM_DUMP_OPT(dump, opt, thres_loss_function);
+    GSFM_DUMP_OPT(dump, opt, optimize_rotations);
+    GSFM_DUMP_OPT(dump, opt, optimize_translation);
+    GSFM_DUMP_OPT(dump, opt, optimize_intrinsics);
+    GSFM_DUMP_OPT(dump, opt, optimize_principal_point);
+    GSFM_DUMP_OPT(dump, opt, optimize_points);
+    GSFM_DUMP_OPT(dump, opt, min_num_view_per_track);
+  }
+  const int rc = guarded(ctx, report, [&] {
     return ba_solve_impl(ctx, prob, opt, cam_q_inout, cam_t_inout, pt_xyz_inout, intr_params_inout, report);
   });
+  if (dumping) {
+    const int64_t N = prob->num_cams, K = prob->num_intr, P = prob->num_pts;
+    dump.array("out_cam_q", cam_q_inout, {N, 4}, prob->mem);
+    dump.array("out_cam_t", cam_t_inout, {N, 3}, prob->mem);
+    dump.array("out_pt_xyz", pt_xyz_inout, {P, 3}, prob->mem);
+    dump.array("out_intr_params", intr_params_inout, {K, GSFM_CAMERA_MAX_PARAMS}, prob->mem);
+    dump.write(report, rc);
+  }
+  return rc;
 }

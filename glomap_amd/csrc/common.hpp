@@ -169,6 +169,8 @@ struct gsfm_ctx {
   gsfm::Comm comm;
   int num_cus = 256;
   std::string last_error;
+  std::string dump_dir;  // non-empty: every solve writes its flat problem + result there (dump.hpp)
+  int dump_seq = 0;
   // pinned host staging for small status read-backs
   double* h_pinned = nullptr;  // 4096 doubles
   // opaque per-solver workspaces (allocated lazily, freed by destroy)

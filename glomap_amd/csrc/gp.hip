@@ -33,6 +33,7 @@
 #include <random>
 
 #include "cg.hpp"
+#include "dump.hpp"
 #include "linalg.hpp"
 #include "lm.hpp"
 #include "obsgraph.hpp"
@@ -927,6 +928,39 @@ extern "C" void gsfm_gp_options_default(gsfm_gp_options* o) {
 extern "C" int gsfm_gp_solve(gsfm_ctx* ctx, const gsfm_gp_problem* prob, const gsfm_gp_options* opt,
                              double* cam_center_inout, double* pt_xyz_inout, gsfm_report* report) {
   if (!ctx) return GSFM_ERR_INVALID_ARGUMENT;
-  if (report) std::memset(report, 0, sizeof(*report));
-  return guarded(ctx, report, [&] { return gp_solve_impl(ctx, prob, opt, cam_center_inout, pt_xyz_inout, report); });
+  gsfm_report local{};
+  if (!report) report = &local;
+  std::memset(report, 0, sizeof(*report));
+  FlatDump dump(ctx, "gp");
+  const bool dumping = dump.active() && prob && opt && cam_center_inout && pt_xyz_inout;
+  if (dumping) {
+    const int64_t N = prob->num_cams, P = prob->num_pts, M = prob->num_obs;
+    dump.scalar("num_cams", (double)N);
+    dump.scalar("comm_rank", ctx->comm.rank);
+    dump.scalar("comm_world", ctx->comm.world);
+    dump.array("pt_offset", prob->pt_offset, {P + 1}, prob->mem);
+    dump.array("obs_cam", prob->obs_cam, {M}, prob->mem);
+    dump.array("obs_dir", prob->obs_dir, {M, 3}, prob->mem);
+    dump.array("obs_calibrated", prob->obs_calibrated, {M}, prob->mem);
+    dump.array("cam_center", cam_center_inout, {N, 3}, prob->mem);
+    dump.array("pt_xyz", pt_xyz_inout, {P, 3}, prob->mem);
+    dump_lm_options(dump, &opt->lm);
+    GSFM_DUMP_OPT(dump, opt, thres_loss_function);
+    GSFM_DUMP_OPT(dump, opt, generate_random_positions);
+    GSFM_DUMP_OPT(dump, opt, generate_random_points);
+    GSFM_DUMP_OPT(dump, opt, generate_scales);
+    GSFM_DUMP_OPT(dump, opt, optimize_positions);
+    GSFM_DUMP_OPT(dump, opt, optimize_points);
+    GSFM_DUMP_OPT(dump, opt, optimize_scales);
+    GSFM_DUMP_OPT(dump, opt, min_num_view_per_track);
+    GSFM_DUMP_OPT(dump, opt, seed);
+    GSFM_DUMP_OPT(dump, opt, constraint_type);
+  }
+  const int rc = guarded(ctx, report, [&] { return gp_solve_impl(ctx, prob, opt, cam_center_inout, pt_xyz_inout, report); });
+  if (dumping) {
+    dump.array("out_cam_center", cam_center_inout, {(int64_t)prob->num_cams, 3}, prob->mem);
+    dump.array("out_pt_xyz", pt_xyz_inout, {(int64_t)prob->num_pts, 3}, prob->mem);
+    dump.write(report, rc);
+  }
+  return rc;
 }

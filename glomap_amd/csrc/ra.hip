@@ -28,6 +28,7 @@
 
 #include "cg.hpp"
 #include "device.hpp"
+#include "dump.hpp"
 #include "ra_dense.hpp"
 
 namespace gsfm {
@@ -1438,8 +1439,47 @@ extern "C" void gsfm_ra_options_default(gsfm_ra_options* o) {
 extern "C" int gsfm_ra_solve(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_options* opt,
                              double* rot_aa_inout, gsfm_report* report) {
   if (!ctx) return GSFM_ERR_INVALID_ARGUMENT;
-  if (report) std::memset(report, 0, sizeof(*report));
-  return guarded(ctx, report, [&] { return ra_solve_impl(ctx, prob, opt, rot_aa_inout, report); });
+  gsfm_report local{};
+  if (!report) report = &local;
+  std::memset(report, 0, sizeof(*report));
+  FlatDump dump(ctx, "ra");
+  if (dump.active() && prob && opt && rot_aa_inout) {
+    const int64_t N = prob->num_nodes, E = prob->num_edges;
+    dump.scalar("num_nodes", (double)N);
+    dump.scalar("fixed_node", prob->fixed_node);
+    dump.scalar("comm_rank", ctx->comm.rank);
+    dump.scalar("comm_world", ctx->comm.world);
+    dump.array("edge_i", prob->edge_i, {E}, prob->mem);
+    dump.array("edge_j", prob->edge_j, {E}, prob->mem);
+    dump.array("edge_q", prob->edge_q, {E, 4}, prob->mem);
+    dump.array("edge_weight", prob->edge_weight, {E}, prob->mem);
+    dump.array("edge_ninl", prob->edge_ninl, {E}, prob->mem);
+    dump.array("node_aa0", rot_aa_inout, {N, 3}, prob->mem);
+    GSFM_DUMP_OPT(dump, opt, max_num_l1_iterations);
+    GSFM_DUMP_OPT(dump, opt, l1_step_convergence_threshold);
+    GSFM_DUMP_OPT(dump, opt, max_num_irls_iterations);
+    GSFM_DUMP_OPT(dump, opt, irls_step_convergence_threshold);
+    GSFM_DUMP_OPT(dump, opt, irls_loss_parameter_sigma);
+    GSFM_DUMP_OPT(dump, opt, weight_type);
+    GSFM_DUMP_OPT(dump, opt, skip_initialization);
+    GSFM_DUMP_OPT(dump, opt, use_weight);
+    GSFM_DUMP_OPT(dump, opt, use_gravity);
+    GSFM_DUMP_OPT(dump, opt, l1_admm_max_num_iterations);
+    GSFM_DUMP_OPT(dump, opt, l1_admm_rho);
+    GSFM_DUMP_OPT(dump, opt, l1_admm_alpha);
+    GSFM_DUMP_OPT(dump, opt, l1_admm_absolute_tolerance);
+    GSFM_DUMP_OPT(dump, opt, l1_admm_relative_tolerance);
+    GSFM_DUMP_OPT(dump, opt, pcg_relative_tolerance);
+    GSFM_DUMP_OPT(dump, opt, pcg_max_iterations);
+    GSFM_DUMP_OPT(dump, opt, force_iterative);
+    GSFM_DUMP_OPT(dump, opt, pcg_relative_tolerance_admm);
+  }
+  const int rc = guarded(ctx, report, [&] { return ra_solve_impl(ctx, prob, opt, rot_aa_inout, report); });
+  if (dump.active() && prob && rot_aa_inout) {
+    dump.array("out_rot_aa", rot_aa_inout, {(int64_t)prob->num_nodes, 3}, prob->mem);
+    dump.write(report, rc);
+  }
+  return rc;
 }
 
 extern "C" int gsfm_ra_residuals(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_options* opt,

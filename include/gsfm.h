@@ -119,6 +119,12 @@ int gsfm_ctx_profile_enable(gsfm_ctx* ctx, int enable);
 /* Reads and resets the accumulated launch count / total milliseconds of one kernel id. */
 int gsfm_ctx_profile_read(gsfm_ctx* ctx, int kernel_id, int64_t* launches, double* total_ms);
 
+/* Flat on-disk problem format.  With a directory set — here, or through GSFM_DUMP_DIR in the
+ * environment when the ctx is created — every gsfm_{ra,gp,ba}_solve on this ctx writes <directory>/<kind>_<seq>.gsfm:
+ * the flat problem as it crossed this ABI, the options, the results and the report (layout: glomap_amd/csrc/dump.hpp,
+ * reader: glomap_amd/flatio.py, replay: tools/replay.py).  NULL or "" disables. */
+int gsfm_ctx_set_dump_dir(gsfm_ctx* ctx, const char* directory);
+
 /* ---- multi-GPU (one process per GPU, RCCL over xGMI) ------------------------------------- */
 #define GSFM_COMM_ID_BYTES 128
 /* Rank 0 calls gsfm_comm_unique_id and broadcasts the bytes out of band (e.g. through
@@ -154,8 +160,9 @@ typedef struct gsfm_ra_options {
   double l1_admm_absolute_tolerance;       /* 1e-4 */
   double l1_admm_relative_tolerance;       /* 1e-2 */
   /* linear solver replacing CHOLMOD (gra.cc:547-611): dense tiled Gauss-Jordan inverse on the matrix
-   * cores for num_nodes <= 2048 (a direct solve, like the reference), Jacobi-PCG on the weighted
-   * Laplacian above that, when sharded over ranks, or when force_iterative is set */
+   * cores for num_nodes <= 2048 (a direct solve, like the reference); PCG preconditioned by dense diagonal
+   * blocks of the BFS-relabelled graph up to 16384 nodes; Jacobi-PCG on the weighted Laplacian above
+   * that, when sharded over ranks, or when force_iterative is set */
   double pcg_relative_tolerance;           /* 1e-10: |r|_2 <= tol * |b|_2 per right-hand side */
   int32_t pcg_max_iterations;              /* 2000 */
   int32_t force_iterative;                 /* 0 */

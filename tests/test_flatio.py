@@ -1,0 +1,67 @@
+"""Flat on-disk problem format: files written by libgsfm at the C ABI boundary
+(`gsfm_ctx_set_dump_dir` / GSFM_DUMP_DIR) hold the problem, the options and the result; glomap_amd/flatio.py reads
+them back and a replay through the C ABI reproduces the stored result."""
+import numpy as np
+import pytest
+
+from glomap_amd import estimators, flatio, so3, synthetic
+
+
+def test_python_round_trip(tmp_path):
+    for p, opt in ((synthetic.make_ring_view_graph(30, 4, seed=1), estimators.RotationEstimatorOptions(max_num_irls_iterations=7)),
+                   (synthetic.make_gp_problem(8, 60, seed=2), estimators.GlobalPositionerOptions(seed=5)),
+                   (synthetic.make_ba_problem(num_cams=6, num_pts=50, seed=3), estimators.BundleAdjusterOptions(optimize_rotations=False))):
+        rec = flatio.from_problem(p, opt)
+        path = tmp_path / f"{rec.kind}.gsfm"
+        flatio.save(path, rec)
+        back = flatio.load(path)
+        assert back.kind == rec.kind and back.scalars == {k: float(v) for k, v in rec.scalars.items()} or back.scalars == rec.scalars
+        for k, a in rec.arrays.items():
+            assert back.arrays[k].dtype == a.dtype and np.array_equal(back.arrays[k], a)
+        p2, o2 = flatio.to_problem(back)
+        assert type(p2) is type(p)
+        if rec.kind == "ra":
+            assert o2.max_num_irls_iterations == 7 and p2.num_edges == p.num_edges
+        elif rec.kind == "gp":
+            assert o2.seed == 5 and p2.num_obs == p.num_obs
+        else:
+            assert o2.optimize_rotations is False and p2.num_obs == p.num_obs
+
+
+@pytest.mark.gpu
+def test_dump_and_replay(gsfm_ctx, tmp_path):
+    ra = synthetic.make_ring_view_graph(80, 8, seed=1)
+    gp = synthetic.make_gp_problem(20, 400, seed=2, dir_noise=1e-3)
+    ba = synthetic.make_ba_problem(num_cams=15, num_pts=300, seed=3, pixel_noise=0.5)
+    gsfm_ctx.set_dump_dir(tmp_path)
+    try:
+        rc, rot, rep_ra = estimators.ra_solve(ra, estimators.RotationEstimatorOptions(irls_loss_parameter_sigma=4.0), ctx=gsfm_ctx)
+        rc, cen, X, rep_gp = estimators.gp_solve(gp, ctx=gsfm_ctx)
+        rc, q, t, Xb, intr, rep_ba = estimators.ba_solve(ba, estimators.BundleAdjusterOptions(optimize_principal_point=True), ctx=gsfm_ctx)
+    finally:
+        gsfm_ctx.set_dump_dir(None)
+    files = sorted(tmp_path.glob("*.gsfm"))
+    assert [f.name for f in files] == ["ba_0002.gsfm", "gp_0001.gsfm", "ra_0000.gsfm"]
+    # --- RA: inputs, options, outputs and report as they crossed the ABI
+    rec = flatio.load(tmp_path / "ra_0000.gsfm")
+    assert rec.status == 0 and rec.options["irls_loss_parameter_sigma"] == 4.0 and rec.scalars["num_nodes"] == 80
+    assert np.array_equal(rec.arrays["edge_i"], ra.edge_i) and np.array_equal(rec.arrays["edge_q"], ra.edge_q)
+    assert np.array_equal(rec.arrays["node_aa0"], ra.node_aa0) and np.array_equal(rec.arrays["out_rot_aa"], rot)
+    assert rec.report["iterations_irls"] == rep_ra["iterations_irls"]
+    p, opt = flatio.to_problem(rec)
+    rc, rot2, rep2 = estimators.ra_solve(p, opt, ctx=gsfm_ctx)
+    assert rc == 0 and np.abs(rot2 - rot).max() < 1e-12
+    # --- GP
+    rec = flatio.load(tmp_path / "gp_0001.gsfm")
+    assert np.array_equal(rec.arrays["obs_dir"], gp.obs_dir) and np.array_equal(rec.arrays["out_cam_center"], cen)
+    p, opt = flatio.to_problem(rec)
+    rc, cen2, X2, rep2 = estimators.gp_solve(p, opt, ctx=gsfm_ctx)
+    assert rc == 0 and rep2["iterations"] == rep_gp["iterations"] and np.abs(cen2 - cen).max() < 1e-9
+    # --- BA
+    rec = flatio.load(tmp_path / "ba_0002.gsfm")
+    assert rec.options["optimize_principal_point"] == 1.0 and np.array_equal(rec.arrays["out_cam_q"], q)
+    assert np.array_equal(rec.arrays["cam_q"], ba.cam_q)  # the in/out arrays are stored as they came IN
+    p, opt = flatio.to_problem(rec)
+    assert opt.optimize_principal_point is True
+    rc, q2, t2, X2, intr2, rep2 = estimators.ba_solve(p, opt, ctx=gsfm_ctx)
+    assert rc == 0 and rep2["iterations"] == rep_ba["iterations"] and np.abs(q2 - q).max() < 1e-9
