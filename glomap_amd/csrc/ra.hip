@@ -1084,8 +1084,18 @@ void bfs_order(int N, long E, const int* ei, const int* ej, int root, std::vecto
     if (pos[n] < 0) visit(n);
 }
 
+// Host-side copies that outlive setup (the rotation upload of finish_init is asynchronous).
+struct RaHostInit {
+  std::vector<int> h_ei, h_ej, h_ninl, pos;
+  std::vector<double> h_eq, h_rot;
+  int mst_root = 0;
+};
+
+// Phase 1 of the setup: everything the linear algebra needs (edges, incidence structure, workspaces) plus the
+// device-to-host copies of what the initialisation needs.  The caller may enqueue the L1-stage factorisation right
+// after it; finish_init then computes the maximum-spanning-tree initialisation on the host WHILE the GPU inverts.
 void setup_device(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_options* opt,
-                  const double* rot_in, RaDevice& d, bool allow_blockdense = false) {
+                  const double* rot_in, RaDevice& d, RaHostInit& hi, bool allow_blockdense = false) {
   RaWs* ws = ra_ws(ctx);
   const int N = prob->num_nodes;
   const long E = prob->num_edges;
@@ -1119,68 +1129,6 @@ void setup_device(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
   d.gridRow = grid_for(N, kBlock / d.lpr);
   hipStream_t s = ctx->stream;
   const int mem = prob->mem;
-
-  copy_in(ctx, ws->ei.ensure(E + 1), prob->edge_i, E, mem);
-  copy_in(ctx, ws->ej.ensure(E + 1), prob->edge_j, E, mem);
-  copy_in(ctx, ws->eq.ensure(4 * (E + 1)), prob->edge_q, 4 * E, mem);
-  d.ew = nullptr;
-  if (opt->use_weight) {
-    GSFM_REQUIRE(prob->edge_weight != nullptr, "RA: use_weight requires edge_weight");
-    // negative weights mean "unset" -> 1 (gra.cc:417-420)
-    std::vector<double> hw;
-    to_host(ctx, hw, prob->edge_weight, E, mem);
-    for (auto& w : hw)
-      if (!(w >= 0)) w = 1.0;
-    GSFM_HIP_CHECK(hipMemcpyAsync(ws->ew.ensure(E + 1), hw.data(), E * sizeof(double), hipMemcpyHostToDevice, s));
-    GSFM_HIP_CHECK(hipStreamSynchronize(s));
-    d.ew = ws->ew.get();
-  }
-  // host copies of the topology for the incidence build (and the MST)
-  std::vector<int> h_ei, h_ej;
-  to_host(ctx, h_ei, prob->edge_i, E, mem);
-  to_host(ctx, h_ej, prob->edge_j, E, mem);
-  std::vector<int> pos;
-  int mst_root = 0;
-  if (d.blockdense) {  // relabel the nodes in BFS order for the whole solve: index-contiguous blocks become graph-local
-    for (long e = 0; e < E; ++e)
-      GSFM_REQUIRE(h_ei[e] >= 0 && h_ei[e] < N && h_ej[e] >= 0 && h_ej[e] < N, "RA: edge index out of range");
-    std::vector<int> order;
-    bfs_order(N, E, h_ei.data(), h_ej.data(), d.fixed, order, pos);
-    for (long e = 0; e < E; ++e) {
-      h_ei[e] = pos[h_ei[e]];
-      h_ej[e] = pos[h_ej[e]];
-    }
-    GSFM_HIP_CHECK(hipMemcpyAsync(ws->ei.get(), h_ei.data(), E * sizeof(int), hipMemcpyHostToDevice, s));
-    GSFM_HIP_CHECK(hipMemcpyAsync(ws->ej.get(), h_ej.data(), E * sizeof(int), hipMemcpyHostToDevice, s));
-    GSFM_HIP_CHECK(hipMemcpyAsync(ws->order.ensure(N), order.data(), N * sizeof(int), hipMemcpyHostToDevice, s));
-    GSFM_HIP_CHECK(hipStreamSynchronize(s));
-    d.fixed = pos[d.fixed];
-    mst_root = pos[0];
-  }
-  build_incidence(d, h_ei.data(), h_ej.data());
-
-  std::vector<double> h_rot;
-  to_host(ctx, h_rot, rot_in, 3 * (size_t)N, mem);
-  if (d.blockdense) {
-    std::vector<double> tmp(h_rot.size());
-    for (int n = 0; n < N; ++n)
-      for (int c = 0; c < 3; ++c) tmp[3 * (size_t)pos[n] + c] = h_rot[3 * (size_t)n + c];
-    h_rot.swap(tmp);
-  }
-  if (!opt->skip_initialization) {
-    GSFM_REQUIRE(prob->edge_ninl != nullptr, "RA: MST initialisation requires edge_ninl");
-    GSFM_REQUIRE(ctx->comm.world == 1, "RA: MST initialisation needs the whole graph; initialise before sharding");
-    std::vector<double> h_eq;
-    std::vector<int> h_ninl;
-    to_host(ctx, h_eq, prob->edge_q, 4 * (size_t)E, mem);
-    to_host(ctx, h_ninl, prob->edge_ninl, E, mem);
-    mst_init(N, E, h_ei.data(), h_ej.data(), h_eq.data(), h_ninl.data(), h_rot.data(), mst_root);
-  }
-  GSFM_HIP_CHECK(hipMemcpyAsync(ws->rot.ensure(3 * (size_t)N), h_rot.data(), 3 * (size_t)N * sizeof(double), hipMemcpyHostToDevice, s));
-  // the gauge node is held at its (post-initialisation) rotation (gra.cc:248-257)
-  GSFM_HIP_CHECK(hipMemcpyAsync(ws->fixed_rot0.ensure(4), h_rot.data() + 3 * (size_t)d.fixed, 3 * sizeof(double), hipMemcpyHostToDevice, s));
-  GSFM_HIP_CHECK(hipStreamSynchronize(s));
-
   ws->nq.ensure(4 * (size_t)N);
   ws->res.ensure(3 * (size_t)(E + 1));
   ws->wirls.ensure(E + 1);
@@ -1201,6 +1149,75 @@ void setup_device(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
   ws->scal.ensure(64);
   ws->flags.ensure(4);
   GSFM_HIP_CHECK(hipMemsetAsync(ws->flags.get(), 0, 4 * sizeof(int), s));
+
+  copy_in(ctx, ws->ei.ensure(E + 1), prob->edge_i, E, mem);
+  copy_in(ctx, ws->ej.ensure(E + 1), prob->edge_j, E, mem);
+  copy_in(ctx, ws->eq.ensure(4 * (E + 1)), prob->edge_q, 4 * E, mem);
+  d.ew = nullptr;
+  if (opt->use_weight) {
+    GSFM_REQUIRE(prob->edge_weight != nullptr, "RA: use_weight requires edge_weight");
+    // negative weights mean "unset" -> 1 (gra.cc:417-420)
+    std::vector<double> hw;
+    to_host(ctx, hw, prob->edge_weight, E, mem);
+    for (auto& w : hw)
+      if (!(w >= 0)) w = 1.0;
+    GSFM_HIP_CHECK(hipMemcpyAsync(ws->ew.ensure(E + 1), hw.data(), E * sizeof(double), hipMemcpyHostToDevice, s));
+    GSFM_HIP_CHECK(hipStreamSynchronize(s));
+    d.ew = ws->ew.get();
+  }
+  // host copies of the topology for the incidence build (and the MST)
+  std::vector<int>&h_ei = hi.h_ei, &h_ej = hi.h_ej;
+  to_host(ctx, h_ei, prob->edge_i, E, mem);
+  to_host(ctx, h_ej, prob->edge_j, E, mem);
+  std::vector<int>& pos = hi.pos;
+  pos.clear();
+  hi.mst_root = 0;
+  if (d.blockdense) {  // relabel the nodes in BFS order for the whole solve: index-contiguous blocks become graph-local
+    for (long e = 0; e < E; ++e)
+      GSFM_REQUIRE(h_ei[e] >= 0 && h_ei[e] < N && h_ej[e] >= 0 && h_ej[e] < N, "RA: edge index out of range");
+    std::vector<int> order;
+    bfs_order(N, E, h_ei.data(), h_ej.data(), d.fixed, order, pos);
+    for (long e = 0; e < E; ++e) {
+      h_ei[e] = pos[h_ei[e]];
+      h_ej[e] = pos[h_ej[e]];
+    }
+    GSFM_HIP_CHECK(hipMemcpyAsync(ws->ei.get(), h_ei.data(), E * sizeof(int), hipMemcpyHostToDevice, s));
+    GSFM_HIP_CHECK(hipMemcpyAsync(ws->ej.get(), h_ej.data(), E * sizeof(int), hipMemcpyHostToDevice, s));
+    GSFM_HIP_CHECK(hipMemcpyAsync(ws->order.ensure(N), order.data(), N * sizeof(int), hipMemcpyHostToDevice, s));
+    GSFM_HIP_CHECK(hipStreamSynchronize(s));
+    d.fixed = pos[d.fixed];
+    hi.mst_root = pos[0];
+  }
+  build_incidence(d, h_ei.data(), h_ej.data());
+
+  // device-to-host copies for the initialisation, all BEFORE any solver kernel is enqueued
+  to_host(ctx, hi.h_rot, rot_in, 3 * (size_t)N, mem);
+  if (!opt->skip_initialization) {
+    GSFM_REQUIRE(prob->edge_ninl != nullptr, "RA: MST initialisation requires edge_ninl");
+    GSFM_REQUIRE(ctx->comm.world == 1, "RA: MST initialisation needs the whole graph; initialise before sharding");
+    to_host(ctx, hi.h_eq, prob->edge_q, 4 * (size_t)E, mem);
+    to_host(ctx, hi.h_ninl, prob->edge_ninl, E, mem);
+  }
+}
+
+// Phase 2: initial rotations (maximum spanning tree, gra.cc:87-138) on the host, uploaded asynchronously.
+void finish_init(gsfm_ctx* ctx, const gsfm_ra_options* opt, RaDevice& d, RaHostInit& hi) {
+  RaWs* ws = d.ws;
+  hipStream_t s = ctx->stream;
+  const int N = d.N;
+  const long E = d.E;
+  std::vector<double>& h_rot = hi.h_rot;
+  if (d.blockdense) {
+    std::vector<double> tmp(h_rot.size());
+    for (int n = 0; n < N; ++n)
+      for (int c = 0; c < 3; ++c) tmp[3 * (size_t)hi.pos[n] + c] = h_rot[3 * (size_t)n + c];
+    h_rot.swap(tmp);
+  }
+  if (!opt->skip_initialization)
+    mst_init(N, E, hi.h_ei.data(), hi.h_ej.data(), hi.h_eq.data(), hi.h_ninl.data(), h_rot.data(), hi.mst_root);
+  GSFM_HIP_CHECK(hipMemcpyAsync(ws->rot.ensure(3 * (size_t)N), h_rot.data(), 3 * (size_t)N * sizeof(double), hipMemcpyHostToDevice, s));
+  // the gauge node is held at its (post-initialisation) rotation (gra.cc:248-257)
+  GSFM_HIP_CHECK(hipMemcpyAsync(ws->fixed_rot0.ensure(4), h_rot.data() + 3 * (size_t)d.fixed, 3 * sizeof(double), hipMemcpyHostToDevice, s));
 }
 
 int read_nan_flag(RaDevice& d) {
@@ -1244,12 +1261,22 @@ int ra_solve_impl(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
   const double t0 = now_seconds();
   GSFM_HIP_CHECK(hipSetDevice(ctx->device));
   RaDevice d;
-  setup_device(ctx, prob, opt, rot_inout, d, /*allow_blockdense=*/true);
+  RaHostInit hi;
+  setup_device(ctx, prob, opt, rot_inout, d, hi, /*allow_blockdense=*/true);
   RaWs* ws = d.ws;
   hipStream_t s = ctx->stream;
   const int N = d.N;
   const long E = d.E;
   const bool multi = ctx->comm.world > 1;
+  // The L1-stage matrix (WA)^T (WA) depends on the topology and the edge weights only: enqueue its (block)
+  // inversion now, so that the GPU factorises while the host computes the maximum-spanning-tree initialisation.
+  bool l1w_ready = false;
+  if (opt->max_num_l1_iterations > 0 && !multi && (d.dense || d.blockdense)) {
+    launch_gather<GATHER_L1W>(d);
+    if (d.dense) dense_factor(d); else bd_factor(d);
+    l1w_ready = true;
+  }
+  finish_init(ctx, opt, d, hi);
   const double t1 = now_seconds();
   long lin_iters = 0;
   int it_l1 = 0, it_irls = 0;
@@ -1262,7 +1289,7 @@ int ra_solve_impl(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
     ws->z.ensure(rows3);
     ws->u.ensure(rows3);
     ws->dz.ensure(rows3);
-    launch_gather<GATHER_L1W>(d);  // (WA)^T (WA): factorised once in the reference (gra.cc:491)
+    if (!l1w_ready) launch_gather<GATHER_L1W>(d);  // (WA)^T (WA): factorised once in the reference (gra.cc:491)
     if (multi) {
       allreduce_sum(ctx, ws->lap_diag.get(), N);  // preconditioner diagonal; inc_w / lap_diag_loc stay local
     }
@@ -1491,7 +1518,10 @@ extern "C" int gsfm_ra_residuals(gsfm_ctx* ctx, const gsfm_ra_problem* prob, con
     gsfm_ra_options o = *opt;
     o.skip_initialization = 1;
     RaDevice d;
-    setup_device(ctx, prob, &o, rot_aa, d);
+    RaHostInit hi;
+    setup_device(ctx, prob, &o, rot_aa, d, hi);
+    finish_init(ctx, &o, d, hi);
+    GSFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     const double sigma = o.irls_loss_parameter_sigma * M_PI / 180.0;
     launch_residuals(d, true, o.weight_type, sigma * sigma);
     if (residual_out) copy_out(ctx, residual_out, d.ws->res.get(), 3 * (size_t)d.E, prob->mem);
@@ -1519,7 +1549,10 @@ extern "C" int gsfm_ra_laplacian_apply(gsfm_ctx* ctx, const gsfm_ra_problem* pro
       GSFM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&rot_tmp), zeros.size() * sizeof(double)));
       GSFM_HIP_CHECK(hipMemset(rot_tmp, 0, zeros.size() * sizeof(double)));
     }
-    setup_device(ctx, &p2, &o, prob->mem == GSFM_MEM_DEVICE ? rot_tmp : zeros.data(), d);
+    RaHostInit hi;
+    setup_device(ctx, &p2, &o, prob->mem == GSFM_MEM_DEVICE ? rot_tmp : zeros.data(), d, hi);
+    finish_init(ctx, &o, d, hi);
+    GSFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (rot_tmp) (void)hipFree(rot_tmp);
     RaWs* ws = d.ws;
     hipStream_t s = ctx->stream;
