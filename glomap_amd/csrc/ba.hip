@@ -626,7 +626,19 @@ __global__ void __launch_bounds__(kBlock)
 //   u_k = A_k z_{c(k)} + I_k z_{intr(k)},   t_p = H_pp^-1 sum_k B_k^T u_k  ->  ptrec[p].t
 // Algorithmic bytes per observation: (9 + F) double2 planes = 16 (9 + F), + cam 4 + pt 4; per track 24
 // written; the gathers of z (48 B per camera, 8 F per intrinsics block) are L2-resident.
-template <int F>
+// 16-byte plane load; NT = non-temporal (the planes are read once per sweep and never fit a cache)
+typedef double ba_d2v __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ double2 ld_plane(const double2* __restrict__ p) {
+  if constexpr (NT) {
+    const ba_d2v v = __builtin_nontemporal_load(reinterpret_cast<const ba_d2v*>(p));
+    return make_double2(v.x, v.y);
+  } else {
+    return *p;
+  }
+}
+
+template <int F, bool NT>
 __global__ void __launch_bounds__(kBlock)
     k_ba_phaseA(BaDev g, CgVec v, int it, double tol2, const double2* __restrict__ jt,
                 const double* __restrict__ ptb, double* __restrict__ ptrec) {
@@ -641,6 +653,15 @@ __global__ void __launch_bounds__(kBlock)
     double acc[3] = {0, 0, 0};
     int key = -1 - lane;
     for (long k = k0 + lane; k < k1; k += 64) {
+      // all (9 + F) plane loads are issued before the dependent camera gathers: the streams are what bounds the
+      // sweep, so they must be in flight while the index -> z-record chain resolves
+      double2 pa[6], pi[F > 0 ? F : 1], pb[3];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) pa[j] = ld_plane<NT>(jt + (PL_A + j) * g.Mp + k);
+#pragma unroll
+      for (int j = 0; j < F; ++j) pi[j] = ld_plane<NT>(jt + (PL_I + j) * g.Mp + k);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) pb[j] = ld_plane<NT>(jt + (PL_B + j) * g.Mp + k);
       key = g.g.obs_pt[k];
       const long n = g.g.cam[k];
       double u0 = 0.0, u1 = 0.0;
@@ -656,15 +677,13 @@ __global__ void __launch_bounds__(kBlock)
         }
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-          const double2 a = jt[(PL_A + j) * g.Mp + k];
-          u0 += a.x * zz[j];
-          u1 += a.y * zz[j];
+          u0 += pa[j].x * zz[j];
+          u1 += pa[j].y * zz[j];
         }
 #pragma unroll
         for (int j = 0; j < F; ++j) {
-          const double2 a = jt[(PL_I + j) * g.Mp + k];
-          u0 += a.x * zz[6 + j];
-          u1 += a.y * zz[6 + j];
+          u0 += pi[j].x * zz[6 + j];
+          u1 += pi[j].y * zz[6 + j];
         }
       } else {
         const double2* zp = reinterpret_cast<const double2*>(v.z + 6 * n);
@@ -672,9 +691,8 @@ __global__ void __launch_bounds__(kBlock)
         const double zz[6] = {z01.x, z01.y, z23.x, z23.y, z45.x, z45.y};
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-          const double2 a = jt[(PL_A + j) * g.Mp + k];
-          u0 += a.x * zz[j];
-          u1 += a.y * zz[j];
+          u0 += pa[j].x * zz[j];
+          u1 += pa[j].y * zz[j];
         }
         if constexpr (F > 0) {
           const int ik = g.obs_ik[k];
@@ -684,17 +702,13 @@ __global__ void __launch_bounds__(kBlock)
           for (int j = 0; j < F; ++j) {
             const int pm = mp.m[j];
             const double zv = pm >= 0 ? zi[pm] : 0.0;
-            const double2 a = jt[(PL_I + j) * g.Mp + k];
-            u0 += a.x * zv;
-            u1 += a.y * zv;
+            u0 += pi[j].x * zv;
+            u1 += pi[j].y * zv;
           }
         }
       }
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const double2 b = jt[(PL_B + j) * g.Mp + k];
-        acc[j] += b.x * u0 + b.y * u1;
-      }
+      for (int j = 0; j < 3; ++j) acc[j] += pb[j].x * u0 + pb[j].y * u1;
     }
     seg_scan<3>(acc, key, lane);
     if (seg_is_tail(key, lane) && key >= 0 && g.g.used[key]) {
@@ -1403,8 +1417,13 @@ class BaSolver final : public LmProblem {
     return cg_solve<6, true>(ctx_, cg_, tol, opt_.lm.pcg_max_iterations, [&](int it) {
       bool timed = ctx_->prof.begin(s, GSFM_KERNEL_BA_SCHUR);
       dispatch_f(F_, [&](auto Fc) {
-        hipLaunchKernelGGL((k_ba_phaseA<decltype(Fc)::value>), dim3(gridTile_), dim3(kBlock), 0, s, g_, cg_, it,
-                           tol * tol, ws->jt.get(), ws->ptb.get(), ws->ptrec.get());
+        static const bool nt = getenv("GSFM_BA_NO_NT") == nullptr;  // measured on C4: 240 us -> 210 (loads first) -> 193 (+ non-temporal)
+        if (nt)
+          hipLaunchKernelGGL((k_ba_phaseA<decltype(Fc)::value, true>), dim3(gridTile_), dim3(kBlock), 0, s, g_, cg_, it,
+                             tol * tol, ws->jt.get(), ws->ptb.get(), ws->ptrec.get());
+        else
+          hipLaunchKernelGGL((k_ba_phaseA<decltype(Fc)::value, false>), dim3(gridTile_), dim3(kBlock), 0, s, g_, cg_, it,
+                             tol * tol, ws->jt.get(), ws->ptb.get(), ws->ptrec.get());
       });
       if (timed) ctx_->prof.end(s);
       timed = ctx_->prof.begin(s, GSFM_KERNEL_BA_SCHUR_B);

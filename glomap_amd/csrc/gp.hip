@@ -371,10 +371,11 @@ __global__ void __launch_bounds__(kBlock)
       const int p = g.g.obs_pt[k];
       key = p;
       const long n = g.g.cam[k];
+      const double ak = qa[k], bk = qb[k];
       V3 cn, zn;
       ld6(cz + 6 * n, cn, zn);  // (c_n, z_n): one 48-byte record, three 16-byte gathers
       const V3 d = ld3a(ptrec + 8 * (long)p) - cn;
-      const V3 y = applyQ(qa[k], qb[k], d, zn);
+      const V3 y = applyQ(ak, bk, d, zn);
       acc[0] += y.x;
       acc[1] += y.y;
       acc[2] += y.z;
@@ -407,10 +408,12 @@ __global__ void __launch_bounds__(kBlock)
     const V3 zn = ld3(v.z + 3 * (long)n);
     double acc[3] = {0, 0, 0};
     for (int k = g.g.coff[n] + lane; k < g.g.coff[n + 1]; k += 64) {
+      const long p = g.g.c_pt[k];
+      const double ak = c_qa[k], bk = c_qb[k];
       V3 Xp, tp;
-      ld6(ptrec + 8 * (long)g.g.c_pt[k], Xp, tp);  // 64-byte aligned record, three 16-byte gathers
+      ld6(ptrec + 8 * p, Xp, tp);  // 64-byte aligned record, three 16-byte gathers
       const V3 d = Xp - cn;
-      const V3 y = applyQ(c_qa[k], c_qb[k], d, zn - tp);
+      const V3 y = applyQ(ak, bk, d, zn - tp);
       acc[0] += y.x;
       acc[1] += y.y;
       acc[2] += y.z;
