@@ -749,11 +749,24 @@ __global__ void __launch_bounds__(kBlock)
     double acc[14];
 #pragma unroll
     for (int j = 0; j < 14; ++j) acc[j] = 0.0;
-    for (int k = g.g.coff[n] + lane; k < g.g.coff[n + 1]; k += 64) {
-      const double w = c_w[k];
+    // software-pipelined: the index -> 64-byte record gather of observation k + 64 is in flight while observation k
+    // goes through its ~300 flops
+    const int kend = g.g.coff[n + 1];
+    int k = g.g.coff[n] + lane;
+    double w_nx = 0.0;
+    V3 X_nx{0, 0, 0}, t_nx{0, 0, 0};
+    if (k < kend) {
+      w_nx = c_w[k];
+      ld6(ptrec + 8 * (long)g.g.c_pt[k], X_nx, t_nx);  // 64-byte aligned record, three 16-byte gathers
+    }
+    for (; k < kend; k += 64) {
+      const double w = w_nx;
+      const V3 Xp = X_nx, tp = t_nx;
+      if (k + 64 < kend) {
+        w_nx = c_w[k + 64];
+        ld6(ptrec + 8 * (long)g.g.c_pt[k + 64], X_nx, t_nx);
+      }
       if (w == 0.0) continue;
-      V3 Xp, tp;
-      ld6(ptrec + 8 * (long)g.g.c_pt[k], Xp, tp);  // 64-byte aligned record, three 16-byte gathers
       ObsGeom o;
       obs_geom(R9, t3, Xp, model, pp, o);
       V3 om = V3{0, 0, 0} - R_mul(R9, tp);  // - J_pt t_p = - Jx (R t_p)
