@@ -389,7 +389,7 @@ __global__ void __launch_bounds__(kBlock)
 __global__ void __launch_bounds__(kBlock)
     k_ba_build_track(BaDev g, double radius, const double* __restrict__ X, const double* __restrict__ ptH,
                      const double* __restrict__ ptdiag, const double* __restrict__ ptjs,
-                     double* __restrict__ ptb, double* __restrict__ ptrec) {
+                     double* __restrict__ ptb, double* __restrict__ ptrec, double* __restrict__ pth) {
   for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < g.g.P; p += (long)gridDim.x * blockDim.x) {
     if (!g.g.used[p]) continue;
     const V3 Xp = ld3(X + 3 * p);
@@ -408,6 +408,8 @@ __global__ void __launch_bounds__(kBlock)
     st3(b, Xp);
     st3(b + 3, e);
     b[6] = Hi.xx; b[7] = Hi.xy; b[8] = Hi.xz; b[9] = Hi.yy; b[10] = Hi.yz; b[11] = Hi.zz;
+    double* hc = pth + 6 * p;  // compact copy for phase A: consecutive tracks -> one coalesced 48-byte stream
+    hc[0] = Hi.xx; hc[1] = Hi.xy; hc[2] = Hi.xz; hc[3] = Hi.yy; hc[4] = Hi.yz; hc[5] = Hi.zz;
     double* pr = ptrec + 8 * p;
     st3(pr, Xp);
     pr[3] = pr[4] = pr[5] = 0.0;
@@ -641,7 +643,7 @@ __device__ __forceinline__ double2 ld_plane(const double2* __restrict__ p) {
 template <int F, bool NT>
 __global__ void __launch_bounds__(kBlock)
     k_ba_phaseA(BaDev g, CgVec v, int it, double tol2, const double2* __restrict__ jt,
-                const double* __restrict__ ptb, double* __restrict__ ptrec) {
+                const double* __restrict__ pth, double* __restrict__ ptrec) {
   __shared__ double smem[4 * 2 + 2];
   if (cg_converged(v, it, tol2, smem)) return;
   const int lane = threadIdx.x & 63;
@@ -712,8 +714,8 @@ __global__ void __launch_bounds__(kBlock)
     }
     seg_scan<3>(acc, key, lane);
     if (seg_is_tail(key, lane) && key >= 0 && g.g.used[key]) {
-      const double* b = ptb + 12 * (long)key;
-      const V3 tp = mul(S3{b[6], b[7], b[8], b[9], b[10], b[11]}, V3{acc[0], acc[1], acc[2]});
+      const double* b = pth + 6 * (long)key;
+      const V3 tp = mul(S3{b[0], b[1], b[2], b[3], b[4], b[5]}, V3{acc[0], acc[1], acc[2]});
       st3(ptrec + 8 * (long)key + 3, tp);
     }
   }
@@ -1067,7 +1069,7 @@ struct BaWs {
   DevBuf<unsigned char> intr_free;
   DevBuf<signed char> intr_map, intr_slot;
   DevBuf<double2> jt;
-  DevBuf<double> xy, c_xy, c_w, q, qn, t, tn, camR, camRn, X, Xn, par, parn, ptH, ptb, ptrec, ptdiag, ptjs, diag, js,
+  DevBuf<double> xy, c_xy, c_w, q, qn, t, tn, camR, camRn, X, Xn, par, parn, ptH, ptb, pth, ptrec, ptdiag, ptjs, diag, js,
       dvec, grad, gred, rhs, spose, scross, minvj, zrec, ipart, iacc16, iacc44, yi_part, minv, cg_x, cg_r, cg_z, cg_p, cg_s, cg_w, vpart,
       dpart, part, scal;
   DevBuf<CgStatus> cgst;
@@ -1211,6 +1213,7 @@ class BaSolver final : public LmProblem {
     ws->parn.ensure(8 * (size_t)K_);
     ws->ptH.ensure(9 * (size_t)P_ + 9);
     ws->ptb.ensure(12 * (size_t)P_ + 12);
+    ws->pth.ensure(6 * (size_t)P_ + 6);
     ws->ptrec.ensure(8 * (size_t)P_ + 8);
     for (DevBuf<double>* b : {&ws->ptdiag, &ws->ptjs}) b->ensure(3 * (size_t)P_ + 3);
     for (DevBuf<double>* b : {&ws->diag, &ws->js, &ws->dvec, &ws->grad, &ws->gred, &ws->rhs, &ws->cg_x, &ws->cg_r,
@@ -1341,7 +1344,7 @@ class BaSolver final : public LmProblem {
     hipStream_t s = ctx_->stream;
     const bool multi = ctx_->comm.world > 1;
     hipLaunchKernelGGL(k_ba_build_track, dim3(gridP_), dim3(kBlock), 0, s, g_, radius, X_, ws->ptH.get(),
-                       ws->ptdiag.get(), ws->ptjs.get(), ws->ptb.get(), ws->ptrec.get());
+                       ws->ptdiag.get(), ws->ptjs.get(), ws->ptb.get(), ws->ptrec.get(), ws->pth.get());
     if (joint_) {
       hipLaunchKernelGGL((k_ba_build_cam<true>), dim3(gridCam_), dim3(kBlock), 0, s, g_, R_, t_, par_, ws->c_w.get(),
                          ws->ptb.get(), ws->gred.get(), ws->spose.get(), ws->ipart.get(), ws->scross.get());
@@ -1433,10 +1436,10 @@ class BaSolver final : public LmProblem {
         static const bool nt = getenv("GSFM_BA_NO_NT") == nullptr;  // measured on C4: 240 us -> 210 (loads first) -> 193 (+ non-temporal)
         if (nt)
           hipLaunchKernelGGL((k_ba_phaseA<decltype(Fc)::value, true>), dim3(gridTile_), dim3(kBlock), 0, s, g_, cg_, it,
-                             tol * tol, ws->jt.get(), ws->ptb.get(), ws->ptrec.get());
+                             tol * tol, ws->jt.get(), ws->pth.get(), ws->ptrec.get());
         else
           hipLaunchKernelGGL((k_ba_phaseA<decltype(Fc)::value, false>), dim3(gridTile_), dim3(kBlock), 0, s, g_, cg_, it,
-                             tol * tol, ws->jt.get(), ws->ptb.get(), ws->ptrec.get());
+                             tol * tol, ws->jt.get(), ws->pth.get(), ws->ptrec.get());
       });
       if (timed) ctx_->prof.end(s);
       timed = ctx_->prof.begin(s, GSFM_KERNEL_BA_SCHUR_B);

@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(kBlock)
                      const double* __restrict__ s, const double* __restrict__ wrob,
                      const double* __restrict__ jss, const double* __restrict__ jsx,
                      const double* __restrict__ hppd, double* __restrict__ qa, double* __restrict__ qb,
-                     double* __restrict__ ptb, double* __restrict__ ptrec) {
+                     double* __restrict__ ptb, double* __restrict__ ptrec, double* __restrict__ pth) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (kBlock / 64);
@@ -261,6 +261,8 @@ __global__ void __launch_bounds__(kBlock)
       st3(b, Xp);
       st3(b + 3, e);
       b[6] = Hi.xx; b[7] = Hi.xy; b[8] = Hi.xz; b[9] = Hi.yy; b[10] = Hi.yz; b[11] = Hi.zz;
+      double* hc = pth + 6 * p;  // compact copy for phase A: consecutive tracks -> one coalesced 48-byte stream
+      hc[0] = Hi.xx; hc[1] = Hi.xy; hc[2] = Hi.xz; hc[3] = Hi.yy; hc[4] = Hi.yz; hc[5] = Hi.zz;
       double* pr = ptrec + 8 * p;
       st3(pr, Xp);
       pr[3] = pr[4] = pr[5] = 0.0;
@@ -357,7 +359,7 @@ __global__ void __launch_bounds__(kBlock)
 __global__ void __launch_bounds__(kBlock)
     k_gp_phaseA(GpDev g, CgVec v, int it, double tol2, const double* __restrict__ cz,
                 const double* __restrict__ qa, const double* __restrict__ qb,
-                const double* __restrict__ ptb, double* __restrict__ ptrec) {
+                const double* __restrict__ pth, double* __restrict__ ptrec) {
   __shared__ double smem[4 * 2 + 2];
   if (cg_converged(v, it, tol2, smem)) return;
   const int lane = threadIdx.x & 63;
@@ -382,8 +384,8 @@ __global__ void __launch_bounds__(kBlock)
     }
     seg_scan<3>(acc, key, lane);
     if (seg_is_tail(key, lane) && key >= 0 && g.g.used[key]) {
-      const double* b = ptb + 12 * (long)key;
-      const V3 t = mul(S3{b[6], b[7], b[8], b[9], b[10], b[11]}, V3{acc[0], acc[1], acc[2]});
+      const double* b = pth + 6 * (long)key;
+      const V3 t = mul(S3{b[0], b[1], b[2], b[3], b[4], b[5]}, V3{acc[0], acc[1], acc[2]});
       st3(ptrec + 8 * (long)key + 3, t);
     }
   }
@@ -587,7 +589,7 @@ struct GpWs {
   DevBuf<long> off;
   DevBuf<int> cam;
   DevBuf<unsigned char> cal, c_cal;
-  DevBuf<double> dir, c_dir, c_jss, c_qa, c_qb, c, cn, X, Xn, s, sn, wrob, qa, qb, jss, ptb, ptrec, hppd, jsx, hcc,
+  DevBuf<double> dir, c_dir, c_jss, c_qa, c_qb, c, cn, X, Xn, s, sn, wrob, qa, qb, jss, ptb, pth, ptrec, hppd, jsx, hcc,
       jsc, dcam, gc, gred, scc, minv, rhs, cz, cg_x, cg_r, cg_z, cg_p, cg_s, cg_w, vpart, dpart, part, scal;
   DevBuf<CgStatus> cgst;
   DevBuf<CgScal> cgsc;
@@ -674,6 +676,7 @@ class GpSolver final : public LmProblem {
     for (DevBuf<double>* b : {&ws->s, &ws->sn, &ws->wrob, &ws->qa, &ws->qb, &ws->jss, &ws->c_jss, &ws->c_qa, &ws->c_qb})
       b->ensure(M_ + 1);
     ws->ptb.ensure(12 * (size_t)P_ + 12);
+    ws->pth.ensure(6 * (size_t)P_ + 6);
     ws->ptrec.ensure(8 * (size_t)P_ + 8);
     // observations of unused tracks keep a = beta = 0 (no contribution, no `used` test in phase A)
     GSFM_HIP_CHECK(hipMemsetAsync(ws->qa.get(), 0, (size_t)(M_ + 1) * sizeof(double), s));
@@ -784,7 +787,7 @@ class GpSolver final : public LmProblem {
     const int n3 = 3 * N_;
     hipLaunchKernelGGL(k_gp_build_track, dim3(gridTile_), dim3(kBlock), 0, s, g_, radius, c_, X_, s_, ws->wrob.get(),
                        ws->jss.get(), ws->jsx.get(), ws->hppd.get(), ws->qa.get(), ws->qb.get(), ws->ptb.get(),
-                       ws->ptrec.get());
+                       ws->ptrec.get(), ws->pth.get());
     hipLaunchKernelGGL(k_gp_build_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, radius, c_, s_, ws->ptb.get(),
                        ws->c_qa.get(), ws->c_qb.get(), ws->gred.get(), ws->scc.get());
     if (multi) {
@@ -863,7 +866,7 @@ class GpSolver final : public LmProblem {
     return cg_solve<3, false>(ctx_, cg_, tol, opt_.lm.pcg_max_iterations, [&](int it) {
       bool timed = ctx_->prof.begin(s, GSFM_KERNEL_GP_SCHUR);
       hipLaunchKernelGGL(k_gp_phaseA, dim3(gridTile_), dim3(kBlock), 0, s, g_, cg_, it, tol * tol, ws->cz.get(), ws->qa.get(),
-                         ws->qb.get(), ws->ptb.get(), ws->ptrec.get());
+                         ws->qb.get(), ws->pth.get(), ws->ptrec.get());
       if (timed) ctx_->prof.end(s);
       timed = ctx_->prof.begin(s, GSFM_KERNEL_GP_SCHUR_B);
       hipLaunchKernelGGL(k_gp_phaseB, dim3(gridCam_), dim3(kBlock), 0, s, g_, cg_, yscale, c_, ws->c_qa.get(),
