@@ -152,6 +152,8 @@ def run_extras(env, args, world, rank, main_line):
             try:
                 g4 = bench_gp(**{**env, "args": argparse.Namespace(**{**vars(sub_args), "scale": 2.0, "no_cpu_baseline": True})})
                 extra["gp_c4"] = {k: g4[k] for k in ("metric", "value", "unit", "ms_per_step", "config")}
+                bs = bench_ba(**{**env, "args": argparse.Namespace(**{**vars(sub_args), "shared_intrinsics": True, "no_cpu_baseline": True})})
+                extra["ba_c4_shared_intrinsics"] = {k: bs[k] for k in ("metric", "value", "unit", "ms_per_step", "config")}
                 if "error" not in extra.get("ba_c4", {"error": 1}) and "ra_c4" in extra:
                     extra["pipeline_c4_ms"] = {
                         "ra": extra["ra_c4"]["ms_per_solve"], "gp": g4["ms_per_step"], "ba": extra["ba_c4"]["ms_per_step"],
@@ -631,10 +633,11 @@ def bench_ba(args, ctx, rank, world, barrier, dist):
     ncam = int(10_000 * args.scale)
     npts_rank = int(1_000_000 * args.scale)  # weak scaling: tracks per GPU fixed
     npts = npts_rank * world
+    shared = bool(getattr(args, "shared_intrinsics", False))  # configs[3] has both variants
     if world == 1:
-        p = synthetic.make_ba_problem(ncam, npts, seed=0, shared_intrinsics=False)
+        p = synthetic.make_ba_problem(ncam, npts, seed=0, shared_intrinsics=shared)
     else:  # every rank generates only its own shard (cameras / intrinsics / start identical everywhere)
-        p = synthetic.make_ba_problem(ncam, npts_rank, seed=0, shared_intrinsics=False, shard=(rank, world))
+        p = synthetic.make_ba_problem(ncam, npts_rank, seed=0, shared_intrinsics=shared, shard=(rank, world))
     lo, hi = 0, p.num_pts
     o0, o1 = 0, p.num_obs
     M_total = p.num_obs
@@ -687,7 +690,7 @@ def bench_ba(args, ctx, rank, world, barrier, dist):
     )
     # drop-in case: the same solve with every array handed over in HOST memory (H2D at entry, D2H at exit)
     host_ms = None
-    if world == 1:
+    if world == 1 and not shared:
         t0 = time.perf_counter()
         rc, *_ = estimators.ba_solve(p, opt, ctx=ctx)
         host_ms = (time.perf_counter() - t0) * 1e3 if rc == 0 else None
@@ -697,7 +700,9 @@ def bench_ba(args, ctx, rank, world, barrier, dist):
     cpu = None if (args.no_cpu_baseline or rank != 0) else cpu_baseline_ba()
     config = {
         "workload": "configs[3] on one GPU per rank: synthetic 10k cameras / 1M tracks / ~5M observations per GPU, "
-        "bundle adjustment (SIMPLE_RADIAL per image, Huber 1 px, reference defaults), start = GT + noise",
+        f"bundle adjustment (SIMPLE_RADIAL, {'ONE camera shared by all images' if shared else 'one camera per image'}, Huber 1 px, "
+        "reference defaults), start = GT + noise",
+        "intrinsics_blocks": int(p.num_intr),
         "cameras": ncam,
         "tracks": npts,
         "observations": M_total,
