@@ -273,6 +273,8 @@ def load():
     lib.gsfm_comm_unique_id.argtypes = [C.c_char_p]
     lib.gsfm_comm_init.restype = ip
     lib.gsfm_comm_init.argtypes = [vp, C.c_char_p, ip, ip]
+    lib.gsfm_comm_selftest.restype = ip
+    lib.gsfm_comm_selftest.argtypes = [vp, dp]
     lib.gsfm_comm_destroy.restype = ip
     lib.gsfm_comm_destroy.argtypes = [vp]
     lib.gsfm_comm_init_host.restype = ip
@@ -461,6 +463,14 @@ class Context:
         if rc != 0:
             raise GsfmError(rc, "gsfm_comm_init")
         self.rank, self.world = rank, world
+
+    def comm_selftest(self) -> float:
+        """One checked RCCL all-reduce on the context's stream; returns the world size it observed."""
+        out = C.c_double(0.0)
+        rc = self.lib.gsfm_comm_selftest(self.handle, C.byref(out))
+        if rc != 0:
+            raise GsfmError(rc, "gsfm_comm_selftest")
+        return out.value
 
 
 def _comm_init_host(self, allreduce, rank: int, world: int):

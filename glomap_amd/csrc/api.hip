@@ -172,6 +172,33 @@ extern "C" int gsfm_comm_init(gsfm_ctx* ctx, const char id[GSFM_COMM_ID_BYTES], 
   });
 }
 
+// One RCCL all-reduce of a small device buffer on the ctx stream (works for world_size == 1 too): checks that the
+// communicator, the library's stream and its device memory work together in THIS process.
+extern "C" int gsfm_comm_selftest(gsfm_ctx* ctx, double* sum_out) {
+  if (!ctx) return GSFM_ERR_INVALID_ARGUMENT;
+  return guarded(ctx, nullptr, [&] {
+    GSFM_REQUIRE(ctx->comm.nccl != nullptr, "comm selftest: no RCCL communicator attached");
+    GSFM_HIP_CHECK(hipSetDevice(ctx->device));
+    double* dev = nullptr;
+    GSFM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dev), 256 * sizeof(double)));
+    std::vector<double> h(256);
+    for (int i = 0; i < 256; ++i) h[i] = 1.0 + i;
+    GSFM_HIP_CHECK(hipMemcpyAsync(dev, h.data(), 256 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    const ncclResult_t r = ncclAllReduce(dev, dev, 256, ncclDouble, ncclSum, ctx->comm.nccl, ctx->stream);
+    if (r == ncclSuccess) {
+      GSFM_HIP_CHECK(hipMemcpyAsync(h.data(), dev, 256 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      GSFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    (void)hipFree(dev);
+    GSFM_NCCL_CHECK(r);
+    bool ok = true;
+    for (int i = 0; i < 256; ++i) ok = ok && h[i] == ctx->comm.world * (1.0 + i);
+    if (sum_out) *sum_out = h[0];
+    if (!ok) throw StatusError(GSFM_ERR_COMM, "comm selftest: wrong all-reduce result");
+    return (int)GSFM_OK;
+  });
+}
+
 extern "C" int gsfm_comm_init_host(gsfm_ctx* ctx, gsfm_host_allreduce_fn fn, void* user, int rank, int world_size) {
   if (!ctx || !fn) return GSFM_ERR_INVALID_ARGUMENT;
   return guarded(ctx, nullptr, [&] {

@@ -134,6 +134,9 @@ int gsfm_ctx_set_dump_dir(gsfm_ctx* ctx, const char* directory);
 int gsfm_comm_unique_id(char id[GSFM_COMM_ID_BYTES]);
 int gsfm_comm_init(gsfm_ctx* ctx, const char id[GSFM_COMM_ID_BYTES], int rank, int world_size);
 int gsfm_comm_destroy(gsfm_ctx* ctx);
+/* One small RCCL all-reduce (sum of 1 + i over the ranks) on the ctx stream, checked: a cheap probe that communicator,
+ * stream and device memory work together in this process (world_size 1 included).  *sum_out = world_size. */
+int gsfm_comm_selftest(gsfm_ctx* ctx, double* sum_out);
 /* Host-staged transport for validation only (several ranks sharing ONE device, or a box without
  * xGMI): every collective becomes D2H, fn(buf, n, op, user) — which must all-reduce buf in place
  * across the ranks (op 0 = sum, 1 = max) and return 0 — and H2D.  Same sharding semantics as the

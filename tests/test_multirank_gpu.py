@@ -118,3 +118,25 @@ def test_two_ranks_reproduce_single_rank(gsfm_ctx):
         assert np.abs(intr_ - intr1).max() < 1e-6
         assert np.abs(X_ - X1[lo:hi]).max() < 1e-6 * (1 + np.abs(X1).max())
     assert np.array_equal(res[0]["ba"][1], res[1]["ba"][1])
+
+
+@pytest.mark.gpu
+def test_rccl_transport_in_a_process_that_also_imports_torch():
+    """bench.py imports torch (rendezvous) and libgsfm (RCCL inside the library) into one process.  PyTorch wheels
+    bundle their own HIP runtime and RCCL; this checks that libgsfm's communicator, stream and device memory still
+    belong together there: a world-size-1 communicator is created from a fresh unique id and one checked all-reduce
+    runs on the context's stream, followed by a sharded-API solve with the communicator attached."""
+    import numpy as np
+    import torch  # noqa: F401  (the point of the test)
+
+    from glomap_amd import _lib, estimators, synthetic
+
+    ctx = _lib.Context(-1)
+    try:
+        ctx.comm_init(_lib.comm_unique_id(), 0, 1)
+        assert ctx.comm_selftest() == 1.0
+        p = synthetic.make_gp_problem(12, 150, seed=3)
+        rc, cen, X, rep = estimators.gp_solve(p, ctx=ctx)
+        assert rc == 0 and np.isfinite(cen).all()
+    finally:
+        ctx.close()
