@@ -49,8 +49,27 @@ def parse():
     return ap.parse_args()
 
 
+_RESULT_FD = None
+
+
+def emit_result(line: dict):
+    """The ONE JSON line of the contract, on the process's original stdout."""
+    data = (json.dumps(line) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, data)
+
+
 def main():
+    global _RESULT_FD
     args = parse()
+    # stdout carries exactly one JSON line: whatever libraries print from here on (RCCL prints a version banner to
+    # stdout when a communicator is created) goes to stderr, the result goes to the saved descriptor.
+    sys.stdout.flush()
+    _RESULT_FD = os.dup(1)
+    os.dup2(2, 1)
     from glomap_amd import _lib, build
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,7 +113,7 @@ def main():
         comm_init(ctx, dist, rank, world)
         out = bench_ba(**env)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit_result(out)
     if dist is not None:
         dist.destroy_process_group()
     ctx.close()
@@ -170,7 +189,7 @@ def run_extras(env, args, world, rank, main_line):
         extra["watchdog"] = {"error": "extra measurements did not finish in time; main line printed without them"}
         if rank == 0:
             main_line["extra"] = extra
-            print(json.dumps(main_line), flush=True)
+            emit_result(main_line)
         os._exit(0)
     return extra
 
