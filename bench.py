@@ -485,7 +485,7 @@ def bench_ra_sized(ctx, N, succ):
         best = dt if best is None else min(best, dt)
     err = synthetic.rotation_errors_deg(so3.aa_to_rotmat(rot.numpy()), p.gt_R)
     return {"cameras": N, "edges": p.num_edges, "ms_per_solve": best * 1e3, "value": p.num_edges / best, "unit": "edges/s",
-            "linear_solver": "dense direct (f64 MFMA)" if N <= 2048 else ("PCG, dense diagonal-block preconditioner (f64 MFMA block inverses)" if N <= 16384 else "3-RHS Jacobi-PCG"),
+            "linear_solver": "dense direct (f64 MFMA)" if N <= 2048 else ("PCG, dense diagonal-block preconditioner (f64 MFMA block inverses)" if N <= 32768 else "3-RHS Jacobi-PCG"),
             "l1_iterations": rep["iterations_l1"], "irls_iterations": rep["iterations_irls"],
             "pcg_iterations": rep["linear_iterations"], "median_rot_err_deg_vs_gt": float(np.median(err))}
 

@@ -1013,15 +1013,42 @@ int pcg_solve(RaDevice& d, bool warm, double tol, int max_iter) {
   v.dpart = ws->dpart.get();
   v.scal = ws->cgsc.get();
   v.st = ws->cgst.get();
-  const long iters = cg_solve<3, false>(ctx, v, tol, max_iter, [&](int it) {
-    const bool timed = ctx->prof.begin(s, GSFM_KERNEL_RA_LAPLACIAN);
-    dispatch_lpr(d.lpr, [&](auto L) {
-      hipLaunchKernelGGL((k_ra_apply<decltype(L)::value>), dim3(gA), dim3(kBlock), 0, s, N, ws->rowptr.get(),
-                         ws->nbr.get(), ws->inc_w.get(), ws->lap_diag_loc.get(), v, it, tol * tol);
+  auto run_cg = [&](double tol_pass) {
+    return cg_solve<3, false>(ctx, v, tol_pass, max_iter, [&](int it) {
+      const bool timed = ctx->prof.begin(s, GSFM_KERNEL_RA_LAPLACIAN);
+      dispatch_lpr(d.lpr, [&](auto L) {
+        hipLaunchKernelGGL((k_ra_apply<decltype(L)::value>), dim3(gA), dim3(kBlock), 0, s, N, ws->rowptr.get(),
+                           ws->nbr.get(), ws->inc_w.get(), ws->lap_diag_loc.get(), v, it, tol_pass * tol_pass);
+      });
+      if (timed) ctx->prof.end(s);
     });
-    if (timed) ctx->prof.end(s);
-  });
+  };
+  long iters = run_cg(tol);
   if (warm) hipLaunchKernelGGL(k_ra_add, dim3(d.gridN), dim3(kBlock), 0, s, n3, ws->x.get(), ws->cg_x.get(), ws->x.get());
+  // The recurrence residual of a long Jacobi-PCG run drifts away from b - A x (measured: ring graph, 20k nodes,
+  // ~600 iterations per solve: the solves "converged" to 1e-10 while the final rotations differed from the
+  // direct-solve oracle on half of the nodes).  So the TRUE residual is verified and, where it misses the tolerance,
+  // the correction equation A dx = b - A x is solved and added (at most three times).
+  const double* bref = b;  // what `tol` is relative to: rhs, or the warm-start residual
+  for (int pass = 0; pass < 3; ++pass) {
+    dispatch_lpr(d.lpr, [&](auto L) {
+      hipLaunchKernelGGL((k_spmv<decltype(L)::value>), dim3(d.gridRow), dim3(kBlock), 0, s, N, ws->rowptr.get(),
+                         ws->nbr.get(), ws->inc_w.get(), ws->lap_diag_loc.get(), ws->x.get(), ws->wbuf.get());
+    });
+    allreduce_sum(ctx, ws->wbuf.get(), (size_t)n3);
+    hipLaunchKernelGGL(k_dense_residual, dim3(d.gridN), dim3(kBlock), 0, s, n3, ws->rhs.get(), ws->wbuf.get(), ws->r.get());
+    hipLaunchKernelGGL(k_sumsq2, dim3(d.gridN), dim3(kBlock), 0, s, n3, ws->r.get(), bref, ws->part_misc.get());
+    hipLaunchKernelGGL((k_finalize<2>), dim3(1), dim3(kBlock), 0, s, ws->part_misc.get(), d.gridN, ws->scal.get() + 16);
+    GSFM_HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 200, ws->scal.get() + 16, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    GSFM_HIP_CHECK(hipStreamSynchronize(s));
+    const double rr = ctx->h_pinned[200], bb = ctx->h_pinned[201];
+    if (!(rr > tol * tol * bb) || !(bb > 0.0)) break;  // also leaves on NaN
+    const double tol_pass = std::min(0.1, std::max(1e-12, 0.5 * tol * std::sqrt(bb / rr)));
+    v.b = ws->r.get();
+    v.x = ws->cg_x.get();
+    iters += run_cg(tol_pass);
+    hipLaunchKernelGGL(k_ra_add, dim3(d.gridN), dim3(kBlock), 0, s, n3, ws->x.get(), ws->cg_x.get(), ws->x.get());
+  }
   return (int)iters;
 }
 
@@ -1460,7 +1487,7 @@ extern "C" void gsfm_ra_options_default(gsfm_ra_options* o) {
   o->pcg_relative_tolerance = 1e-10;
   o->pcg_max_iterations = 2000;
   o->force_iterative = 0;
-  o->pcg_relative_tolerance_admm = 1e-6;
+  o->pcg_relative_tolerance_admm = 1e-10;
 }
 
 extern "C" int gsfm_ra_solve(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_options* opt,

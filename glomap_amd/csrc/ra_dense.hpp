@@ -23,7 +23,7 @@ namespace gsfm {
 constexpr int kTile = 32;        // tile edge
 constexpr int kTileLd = 33;      // LDS leading dimension (bank spread)
 constexpr int kDenseMaxN = 2048; // largest view graph solved densely
-constexpr int kBlockDenseMaxN = 16384;  // largest view graph preconditioned by dense diagonal blocks of <= kDenseMaxN nodes
+constexpr int kBlockDenseMaxN = 32768;  // largest view graph preconditioned by dense diagonal blocks of <= kDenseMaxN nodes
 
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 
@@ -321,7 +321,7 @@ static __global__ void __launch_bounds__(1024)
 }
 
 
-// ---- block-diagonal dense preconditioner for 2048 < N <= 16384 (ra.hip: bd_*) -----------------------------
+// ---- block-diagonal dense preconditioner for 2048 < N <= 32768 (ra.hip: bd_*) -----------------------------
 // Nodes are relabelled in BFS order at setup, so index-contiguous blocks of nb <= 2048 nodes capture almost every
 // edge of a view graph with any locality; each diagonal block of (L_w + gauge) is inverted with the same tiled
 // Gauss-Jordan sweep, and M = blockdiag(A_bb^-1) preconditions the PCG (C4 ring graph: 38 iterations instead of

@@ -75,7 +75,7 @@ class RotationEstimatorOptions:
     pcg_relative_tolerance: float = 1e-10
     pcg_max_iterations: int = 2000
     force_iterative: bool = False  # True: PCG even where the dense direct solve applies (N <= 2048)
-    pcg_relative_tolerance_admm: float = 1e-6  # x-updates inside the ADMM loop (warm-started corrections)
+    pcg_relative_tolerance_admm: float = 1e-10  # x-updates inside the ADMM loop (warm-started corrections)
 
     GEMAN_MCCLURE = 0
     HALF_NORM = 1

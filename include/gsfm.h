@@ -164,15 +164,17 @@ typedef struct gsfm_ra_options {
   double l1_admm_relative_tolerance;       /* 1e-2 */
   /* linear solver replacing CHOLMOD (gra.cc:547-611): dense tiled Gauss-Jordan inverse on the matrix
    * cores for num_nodes <= 2048 (a direct solve, like the reference); PCG preconditioned by dense diagonal
-   * blocks of the BFS-relabelled graph up to 16384 nodes; Jacobi-PCG on the weighted Laplacian above
+   * blocks of the BFS-relabelled graph up to 32768 nodes; Jacobi-PCG on the weighted Laplacian above
    * that, when sharded over ranks, or when force_iterative is set */
   double pcg_relative_tolerance;           /* 1e-10: |r|_2 <= tol * |b|_2 per right-hand side */
   int32_t pcg_max_iterations;              /* 2000 */
   int32_t force_iterative;                 /* 0 */
-  double pcg_relative_tolerance_admm;      /* 1e-6 on the residual of the warm start: x-updates INSIDE the ADMM loop of the L1 stage
-                                              (warm-started corrections).  Measured (tools/exp_ra_bd_check.py): 1e-3 moves the
-                                              final rotations by up to 1.3e-3 rad against the direct-solve oracle, <= 1e-5
-                                              reproduces it to 4e-8 rad */
+  double pcg_relative_tolerance_admm;      /* 1e-10 on the residual of the warm start: x-updates INSIDE the ADMM loop of the L1 stage
+                                              (warm-started corrections).  Looser values are a parity hazard that grows with the
+                                              condition number: 1e-3 moved the final rotations by 1.3e-3 rad at 2 500 nodes, 1e-6
+                                              is exact to 4e-8 rad there but off by radians on a 20 000-node ring with the Jacobi
+                                              preconditioner (tools/exp_ra_bd_check.py, exp_ra_save.py); the tight value costs < 3 %
+                                              more PCG iterations */
 } gsfm_ra_options;
 
 void gsfm_ra_options_default(gsfm_ra_options* opt);

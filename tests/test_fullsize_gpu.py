@@ -71,24 +71,39 @@ def test_ba_config4_full(gsfm_ctx):
     assert rep2["final_cost"] >= 0.97 * rep["final_cost"]
 
 
-def test_ra_config3_cameras_block_preconditioned_path(gsfm_ctx):
-    """5k cameras / 250k edges (the camera count of configs[2]): the block-preconditioned PCG path.  The oracle's sparse
-    Cholesky of a 15k x 15k degree-100 Laplacian is out of test time, so: ground-truth recovery, agreement with the
-    Jacobi-PCG path (a different preconditioner and node order solving the same systems), idempotence."""
-    p = synthetic.make_ring_view_graph(5000, 50, seed=0)
+@pytest.mark.parametrize("n", [5000, 16000])
+def test_ra_large_graphs_match_the_oracle(gsfm_ctx, n):
+    """5k cameras / 250k edges (the camera count of configs[2]) and 16k / 800k: the block-preconditioned PCG path against
+    the oracle (its sparse LU is banded on the ring graphs: 7 s and 36 s on one host core), and against the Jacobi-PCG
+    path (another preconditioner and node order solving the same systems).  At 16k the reference algorithm itself leaves
+    a few nodes more than 100 degrees off — a sub-tree that the spanning-tree initialisation hung on an outlier edge and
+    ten ADMM iterations per L1 solve do not repair — and the HIP path must reproduce exactly that."""
+    from oracle import ra as ora
+
+    p = synthetic.make_ring_view_graph(n, 50, seed=0)
     rc, rot, rep = estimators.ra_solve(p, ctx=gsfm_ctx)
     assert rc == 0
+    tr = ora.RaTrace()
+    ok, rot_o = ora.estimate_rotations(p.num_nodes, p.edge_i, p.edge_j, p.edge_q, p.edge_weight, p.edge_ninl, p.node_aa0,
+                                       p.fixed_node, ora.RotationEstimatorOptions(), tr)
+    assert ok and rep["iterations_l1"] == tr.l1_iterations and rep["iterations_irls"] == tr.irls_iterations
+    d = np.radians(so3.rotation_angle_deg(so3.aa_to_rotmat(rot), so3.aa_to_rotmat(rot_o)))
+    assert d.max() < 1e-6
     err = synthetic.rotation_errors_deg(so3.aa_to_rotmat(rot), p.gt_R)
-    assert np.median(err) < 0.5 and err.max() < 3.0
+    err_o = synthetic.rotation_errors_deg(so3.aa_to_rotmat(rot_o), p.gt_R)
+    assert np.median(err) < 0.5 and np.array_equal(err > 5.0, err_o > 5.0)
+    if n == 5000:
+        assert err.max() < 3.0
     rc, rot_it, rep_it = estimators.ra_solve(p, estimators.RotationEstimatorOptions(force_iterative=True), ctx=gsfm_ctx)
     assert rc == 0 and rep_it["iterations_l1"] == rep["iterations_l1"] and rep_it["iterations_irls"] == rep["iterations_irls"]
-    d = np.radians(so3.rotation_angle_deg(so3.aa_to_rotmat(rot), so3.aa_to_rotmat(rot_it)))
+    d = np.radians(so3.rotation_angle_deg(so3.aa_to_rotmat(rot_it), so3.aa_to_rotmat(rot_o)))
     assert d.max() < 1e-6
     assert rep["linear_iterations"] < 0.3 * rep_it["linear_iterations"]
-    p2 = type(p)(**{**p.__dict__, "node_aa0": rot})
-    rc, rot2, rep2 = estimators.ra_solve(
-        p2, estimators.RotationEstimatorOptions(skip_initialization=True, max_num_l1_iterations=0), ctx=gsfm_ctx)
-    assert rc == 0 and rep2["iterations_irls"] == 1
+    if n == 5000:  # idempotence
+        p2 = type(p)(**{**p.__dict__, "node_aa0": rot})
+        rc, rot2, rep2 = estimators.ra_solve(
+            p2, estimators.RotationEstimatorOptions(skip_initialization=True, max_num_l1_iterations=0), ctx=gsfm_ctx)
+        assert rc == 0 and rep2["iterations_irls"] == 1
 
 
 def test_track_establishment_config3_full(gsfm_ctx):

@@ -147,7 +147,7 @@ def _relabel(p, seed):
 
 @pytest.mark.parametrize("n,succ,shuffle,fixed", [(2049, 20, True, 5), (2500, 20, False, 0), (3000, 12, True, 17), (4500, 20, True, 4000)])
 def test_ra_block_dense_preconditioner_path(gsfm_ctx, n, succ, shuffle, fixed):
-    """2048 < N <= 16384 on one GPU: PCG preconditioned by dense inverses of BFS-ordered diagonal blocks (nodes are
+    """2048 < N <= 32768 on one GPU: PCG preconditioned by dense inverses of BFS-ordered diagonal blocks (nodes are
     relabelled internally).  Must agree with the Jacobi-PCG path and, where the oracle is affordable, with the oracle —
     for arbitrary node labels and gauge node."""
     p = synthetic.make_ring_view_graph(n, succ, noise_deg=1.0, outlier_ratio=0.05, seed=11)
