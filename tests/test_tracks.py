@@ -258,3 +258,73 @@ def test_gpu_keep_largest_component(gsfm_ctx):
     reg, ev2, cnt = KeepLargestConnectedComponents(10, ei2, ej2, np.ones(4, np.uint8), ctx=gsfm_ctx)
     assert cnt == 3 and list(reg) == [1, 1, 1, 0, 0, 0, 0, 0, 0, 0] and list(ev2) == [1, 1, 0, 0]
     assert KeepLargestConnectedComponents(10, ei2, ej2, np.zeros(4, np.uint8), ctx=gsfm_ctx)[2] == 0
+
+
+# ---------------------------------------------------------------------------------------------------------
+# random tiny graphs: corner cases the structured generator does not produce (repeated pairs, a feature matched to
+# several features of one image, pairs listed in either orientation, empty pairs, unregistered images, ...)
+# ---------------------------------------------------------------------------------------------------------
+def _random_match_graph(rng):
+    n_img = int(rng.integers(2, 8))
+    nfeat = rng.integers(1, 7, n_img)
+    feat_offset = np.zeros(n_img + 1, dtype=np.int64)
+    feat_offset[1:] = np.cumsum(nfeat)
+    # coarse pixel grid: plenty of exact ties and same-image distances on both sides of the threshold
+    feat_xy = rng.integers(0, 4, (int(feat_offset[-1]), 2)).astype(np.float64) * 6.0
+    n_pairs = int(rng.integers(0, 10))
+    p1, p2, off, f1, f2 = [], [], [0], [], []
+    for _ in range(n_pairs):
+        a, b = rng.choice(n_img, 2, replace=False)
+        m = int(rng.integers(0, 6))
+        p1.append(a); p2.append(b)
+        f1 += list(rng.integers(0, nfeat[a], m)); f2 += list(rng.integers(0, nfeat[b], m))
+        off.append(off[-1] + m)
+    return dict(num_images=n_img, feat_offset=feat_offset, feat_xy=feat_xy, pair_image1=np.array(p1, dtype=np.int32),
+                pair_image2=np.array(p2, dtype=np.int32), pair_valid=(rng.random(n_pairs) < 0.85).astype(np.uint8),
+                pair_offset=np.array(off, dtype=np.int64), match_feat1=np.array(f1, dtype=np.uint32),
+                match_feat2=np.array(f2, dtype=np.uint32))
+
+
+def _random_options(rng):
+    return dict(min_num_tracks_per_view=int(rng.choice([-1, 0, 1, 2, 5])), min_num_view_per_track=int(rng.choice([1, 2, 3])),
+                max_num_view_per_track=int(rng.choice([2, 3, 5, 100])), max_num_tracks=int(rng.choice([0, 1, 3, 10000000])))
+
+
+def test_oracle_random_tiny_graphs_literal_vs_vectorised():
+    rng = np.random.default_rng(123)
+    nonempty = 0
+    for _ in range(300):
+        g = _random_match_graph(rng)
+        thr = float(rng.choice([0.0, 6.0, 8.5, 100.0]))
+        tr, disc, members = ot.establish_full_tracks_literal(*_args(g), thres_inconsistency=thr)
+        lit = ot.canonicalize(tr, members)
+        vec = ot.establish_full_tracks(*_args(g), thres_inconsistency=thr)
+        assert disc == vec[4]
+        for a, b in zip(lit, vec[:4]):
+            assert np.array_equal(a, b)
+        nonempty += len(vec[0]) > 0
+        reg = rng.random(g["num_images"]) < 0.8
+        kw = _random_options(rng)
+        a = ot.find_tracks_for_problem_literal(*vec[:4], reg, **kw)
+        b = ot.find_tracks_for_problem(*vec[:4], reg, **kw)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), (kw, x, y)
+    assert nonempty > 150
+
+
+@pytest.mark.gpu
+def test_gpu_random_tiny_graphs(gsfm_ctx):
+    from glomap_amd.tracks import MatchGraph, TrackEngine, TrackEstablishmentOptions
+
+    rng = np.random.default_rng(321)
+    for _ in range(150):
+        g = _random_match_graph(rng)
+        thr = float(rng.choice([0.0, 6.0, 8.5, 100.0]))
+        kw = _random_options(rng)
+        ref = ot.establish_full_tracks(*_args(g), thres_inconsistency=thr)
+        eng = TrackEngine(MatchGraph.from_dict(g), TrackEstablishmentOptions(thres_inconsistency=thr, **kw), ctx=gsfm_ctx)
+        full = eng.EstablishFullTracks()
+        assert eng.num_discarded == ref[4] and _same_set(full, ref), g
+        reg = (rng.random(g["num_images"]) < 0.8).astype(np.uint8)
+        sel = eng.FindTracksForProblem(reg)
+        assert _same_set(sel, ot.find_tracks_for_problem(*ref[:4], reg, **kw)), (g, kw)
