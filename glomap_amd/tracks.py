@@ -175,6 +175,8 @@ def KeepLargestConnectedComponents(num_nodes, edge_i, edge_j, edge_valid, node_n
                                                        _lib.ptr(ev2), _lib.ptr(ni), _lib.ptr(reg), C.byref(n))
     if rc != 0:
         raise _lib.GsfmError(rc, "gsfm_keep_largest_connected_component")
-    if n.value == 0:
-        return None, ev2, 0
+    if n.value == 0:  # no valid edge at all (nothing written), or a component whose frames hold no image
+        any_reg = bool((reg if isinstance(reg, np.ndarray) else reg.numpy()).any())
+        if not any_reg:
+            return None, ev2, 0
     return reg, ev2, n.value

@@ -328,3 +328,40 @@ def test_gpu_random_tiny_graphs(gsfm_ctx):
         reg = (rng.random(g["num_images"]) < 0.8).astype(np.uint8)
         sel = eng.FindTracksForProblem(reg)
         assert _same_set(sel, ot.find_tracks_for_problem(*ref[:4], reg, **kw)), (g, kw)
+
+
+def _random_view_graph(rng):
+    n = int(rng.integers(2, 12))
+    e = int(rng.integers(0, 16))
+    ei = rng.integers(0, n, e).astype(np.int32)
+    ej = rng.integers(0, n, e).astype(np.int32)
+    ok = ei != ej
+    ei, ej = ei[ok], ej[ok]
+    return n, ei, ej, (rng.random(len(ei)) < 0.7).astype(np.uint8), rng.integers(0, 4, n).astype(np.int32)
+
+
+def test_oracle_random_view_graphs_components():
+    rng = np.random.default_rng(7)
+    for _ in range(300):
+        n, ei, ej, ev, nimg = _random_view_graph(rng)
+        a = ot.keep_largest_connected_component_literal(n, ei, ej, ev, nimg)
+        b = ot.keep_largest_connected_component(n, ei, ej, ev, nimg)
+        assert a[2] == b[2] and np.array_equal(a[1], b[1])
+        assert (a[0] is None and b[0] is None) or np.array_equal(a[0], b[0])
+
+
+@pytest.mark.gpu
+def test_gpu_random_view_graphs_components(gsfm_ctx):
+    from glomap_amd.tracks import KeepLargestConnectedComponents
+
+    rng = np.random.default_rng(8)
+    for _ in range(100):
+        n, ei, ej, ev, nimg = _random_view_graph(rng)
+        want = ot.keep_largest_connected_component(n, ei, ej, ev, nimg)
+        reg, ev2, cnt = KeepLargestConnectedComponents(n, ei, ej, ev, nimg, ctx=gsfm_ctx)
+        if want[0] is None:
+            assert reg is None and np.array_equal(ev2.astype(bool), want[1])
+            continue
+        # (a component whose frames hold no image returns 0 images like the reference, yet is applied)
+        assert cnt == want[2] and reg is not None
+        assert np.array_equal(reg.astype(bool), want[0]) and np.array_equal(ev2.astype(bool), want[1])
