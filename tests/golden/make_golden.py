@@ -7,7 +7,7 @@ restatement (oracle/) on seeded synthetic problems: inputs + the oracle's output
 generation.  They pin BOTH sides afterwards: tests/test_golden.py checks that today's oracle still
 reproduces them (CPU) and that the HIP path matches them through the C ABI (GPU).
 
-Usage: python tests/golden/make_golden.py        (rewrites the three .npz files)
+Usage: python tests/golden/make_golden.py        (rewrites the .npz files)
 """
 import sys
 from pathlib import Path
@@ -56,7 +56,26 @@ def ba_fixture():
                         out_final_cost=s.final_cost, out_iterations=s.iterations)
 
 
+def tracks_fixture():
+    """Match graph -> established tracks -> selected tracks (integer results: frozen bit for bit)."""
+    from oracle import tracks as ot
+
+    g = synthetic.make_match_graph(40, 300, seed=24, false_match_frac=0.03, twin_frac=0.02)
+    g["pair_valid"][::9] = 0
+    full = ot.establish_full_tracks(g["pair_image1"], g["pair_image2"], g["pair_valid"], g["pair_offset"], g["match_feat1"],
+                                    g["match_feat2"], g["feat_offset"], g["feat_xy"])
+    reg = np.ones(40, dtype=np.uint8)
+    reg[::6] = 0
+    sel = ot.find_tracks_for_problem(*full[:4], reg, min_num_tracks_per_view=6)
+    np.savez_compressed(OUT / "tracks_40x300.npz", **{k: g[k] for k in ("num_images", "feat_offset", "feat_xy", "pair_image1",
+                        "pair_image2", "pair_valid", "pair_offset", "match_feat1", "match_feat2")},
+                        image_registered=reg, min_num_tracks_per_view=6,
+                        full_id=full[0], full_offset=full[1], full_image=full[2], full_feature=full[3], discarded=full[4],
+                        sel_id=sel[0], sel_offset=sel[1], sel_image=sel[2], sel_feature=sel[3])
+
+
 if __name__ == "__main__":
+    tracks_fixture()
     ra_fixture()
     gp_fixture()
     ba_fixture()
