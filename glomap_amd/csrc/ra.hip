@@ -707,6 +707,7 @@ struct RaDevice {
   bool bd_have = false, bd_refresh = false;
   bool bd_fresh = false;   // the factored blocks belong to the weights currently in inc_w / lap_diag
   int bd_base_iters = 0;   // iterations of the first cold solve with a matching preconditioner (stale budget = 2.5x)
+  int bd_skip_stale = 0;   // after a stale preconditioner ran out of budget: re-invert directly for this many solves
   int bd_nb = 0, bd_nblk = 0;
   bool dense_always_factor = false;  // GSFM_RA_DENSE_REFACTOR=1: re-invert for every new weighting (the round-1 behaviour)
   int Np = 0, T = 0;          // padded size, tiles per side
@@ -896,6 +897,10 @@ int bd_pcg_solve(RaDevice& d, bool warm, double tol, int max_iter) {
   hipStream_t s = ctx->stream;
   const int N = d.N, n3 = 3 * N;
   static const bool trace = getenv("GSFM_RA_TRACE") != nullptr;
+  if (!d.bd_fresh && d.bd_skip_stale > 0) {  // the weights are still moving fast (the last stale attempt failed)
+    --d.bd_skip_stale;
+    d.bd_refresh = true;
+  }
   if (!d.bd_have || d.bd_refresh) bd_factor(d);
   const double* b = ws->rhs.get();
   double* x = ws->x.get();
@@ -961,6 +966,7 @@ int bd_pcg_solve(RaDevice& d, bool warm, double tol, int max_iter) {
     }
     if (d.bd_fresh) break;  // a matching preconditioner did not converge within the caller's limit: report as is
     bd_factor(d);           // stale preconditioner out of budget: re-invert with the current weights and restart
+    d.bd_skip_stale = 2;
   }
   if (warm) hipLaunchKernelGGL(k_ra_add, dim3(d.gridN), dim3(kBlock), 0, s, (long)n3, ws->x.get(), ws->cg_x.get(), ws->x.get());
   return total;
@@ -1141,6 +1147,7 @@ void setup_device(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
                  !opt->force_iterative && getenv("GSFM_RA_NO_BLOCKDENSE") == nullptr;
   d.bd_have = d.bd_refresh = d.bd_fresh = false;
   d.bd_base_iters = 0;
+  d.bd_skip_stale = 0;
   if (d.blockdense) {
     d.bd_nblk = (N + kDenseMaxN - 1) / kDenseMaxN;
     d.bd_nb = (((N + d.bd_nblk - 1) / d.bd_nblk + kTile - 1) / kTile) * kTile;
