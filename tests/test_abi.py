@@ -93,3 +93,35 @@ def test_product_never_imports_oracle():
     for py in (ROOT / "glomap_amd").rglob("*.py"):
         text = py.read_text()
         assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f"{py} imports the oracle"
+
+
+def test_python_option_defaults_match_the_library():
+    """The dataclasses of glomap_amd/estimators.py and tracks.py must start from the same defaults as
+    gsfm_*_options_default (two copies of the reference's option structs would otherwise drift apart)."""
+    import ctypes as C
+
+    from glomap_amd import _lib, estimators
+    from glomap_amd.tracks import TrackEstablishmentOptions
+
+    lib = _lib.load()
+
+    def fields(cobj, prefix=""):
+        out = {}
+        for name, ctype in cobj._fields_:
+            v = getattr(cobj, name)
+            if isinstance(v, C.Structure):
+                out.update(fields(v, prefix + name + "."))
+            else:
+                out[prefix + name] = v
+        return out
+
+    for default_fn, ctype, pyobj in ((lib.gsfm_ra_options_default, _lib.RaOptions, estimators.RotationEstimatorOptions()),
+                                     (lib.gsfm_gp_options_default, _lib.GpOptions, estimators.GlobalPositionerOptions()),
+                                     (lib.gsfm_ba_options_default, _lib.BaOptions, estimators.BundleAdjusterOptions()),
+                                     (lib.gsfm_track_options_default, _lib.TrackOptionsC, TrackEstablishmentOptions())):
+        ref = ctype()
+        default_fn(C.byref(ref))
+        want, got = fields(ref), fields(pyobj.to_c())
+        assert want.keys() == got.keys()
+        for k in want:
+            assert want[k] == got[k], (ctype.__name__, k, want[k], got[k])
