@@ -87,7 +87,8 @@ inline int lm_minimize(LmProblem& prob, const gsfm_lm_options& o, gsfm_report* r
                 radius, lin, model_change, cand_cost, cost, step_norm);
       valid = valid && std::isfinite(model_change) && model_change > 0.0;
       if (!valid) {
-        if (++invalid > o.max_num_consecutive_invalid_steps) {
+        // Ceres fails on the max_num_consecutive_invalid_steps-th consecutive invalid step (trust_region_minimizer.cc)
+        if (++invalid >= o.max_num_consecutive_invalid_steps) {
           termination = GSFM_TERM_FAILURE;
           usable = false;
           break;

@@ -1,0 +1,286 @@
+"""ORACLE (test infrastructure only — never imported by the product path).
+
+ctypes front end of oracle/liboracle_cpu.so, the multithreaded C++ restatement of the three
+estimators (oracle/csrc/orc_{ra,gp,ba}.cc; built by oracle/Makefile, g++ + OpenMP, no third-party
+code).  It exists for two jobs the numpy oracle is too slow for:
+
+  * full-size oracle: the same algorithm as oracle/{ra,gp,ba}.py (LM decisions identical to
+    oracle/lm.py, exact block elimination, reduced system solved to 1e-14) at the sizes of
+    BASELINE.json configs[2] / configs[3], so that the `-m gpu` parity tests can compare poses at
+    the sizes the tolerance is stated for;
+  * cpu_baseline of bench.py: timed on all host cores of the GPU box, labelled "restated CPU
+    oracle — not Ceres" (kind = "port").
+
+tests/test_oracle_cpu.py cross-validates it against the numpy oracle on small problems.
+Signatures follow oracle.gp.solve / oracle.ba.solve / oracle.ra.estimate_rotations.
+
+parity unpinned: see oracle/__init__.py.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from dataclasses import dataclass
+from pathlib import Path
+
+import numpy as np
+
+from . import ba as _ba
+from . import gp as _gp
+from . import lm as _lm
+from . import ra as _ra
+
+_DIR = Path(__file__).resolve().parent
+_LIB = None
+
+
+class _LmFields(C.Structure):
+    _fields_ = [
+        ("max_num_iterations", C.c_int32),
+        ("function_tolerance", C.c_double),
+        ("gradient_tolerance", C.c_double),
+        ("parameter_tolerance", C.c_double),
+        ("initial_trust_region_radius", C.c_double),
+        ("max_trust_region_radius", C.c_double),
+        ("min_trust_region_radius", C.c_double),
+        ("min_relative_decrease", C.c_double),
+        ("min_lm_diagonal", C.c_double),
+        ("max_lm_diagonal", C.c_double),
+        ("jacobi_scaling", C.c_int32),
+        ("max_num_consecutive_invalid_steps", C.c_int32),
+        ("pcg_relative_tolerance", C.c_double),
+        ("pcg_max_iterations", C.c_int32),
+        ("order", C.c_int32),
+        ("verbose", C.c_int32),
+    ]
+
+
+class _GpOptions(C.Structure):
+    _fields_ = _LmFields._fields_ + [
+        ("thres_loss_function", C.c_double),
+        ("generate_random_positions", C.c_int32),
+        ("generate_random_points", C.c_int32),
+        ("generate_scales", C.c_int32),
+        ("optimize_positions", C.c_int32),
+        ("optimize_points", C.c_int32),
+        ("optimize_scales", C.c_int32),
+        ("min_num_view_per_track", C.c_int32),
+        ("seed", C.c_uint32),
+    ]
+
+
+class _BaOptions(C.Structure):
+    _fields_ = _LmFields._fields_ + [
+        ("thres_loss_function", C.c_double),
+        ("optimize_rotations", C.c_int32),
+        ("optimize_translation", C.c_int32),
+        ("optimize_intrinsics", C.c_int32),
+        ("optimize_principal_point", C.c_int32),
+        ("optimize_points", C.c_int32),
+        ("min_num_view_per_track", C.c_int32),
+    ]
+
+
+class _Report(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int32),
+        ("successful_steps", C.c_int32),
+        ("termination", C.c_int32),
+        ("usable", C.c_int32),
+        ("linear_iterations", C.c_int64),
+        ("initial_cost", C.c_double),
+        ("final_cost", C.c_double),
+        ("max_linear_residual", C.c_double),
+        ("seconds_total", C.c_double),
+        ("seconds_linear", C.c_double),
+        ("threads", C.c_int32),
+        ("pad", C.c_int32),
+    ]
+
+
+class _RaOptions(C.Structure):
+    _fields_ = [
+        ("max_num_l1_iterations", C.c_int32),
+        ("l1_step_convergence_threshold", C.c_double),
+        ("max_num_irls_iterations", C.c_int32),
+        ("irls_step_convergence_threshold", C.c_double),
+        ("irls_loss_parameter_sigma", C.c_double),
+        ("weight_type", C.c_int32),
+        ("skip_initialization", C.c_int32),
+        ("use_weight", C.c_int32),
+        ("l1_admm_max_num_iterations", C.c_int32),
+        ("l1_admm_rho", C.c_double),
+        ("l1_admm_alpha", C.c_double),
+        ("l1_admm_absolute_tolerance", C.c_double),
+        ("l1_admm_relative_tolerance", C.c_double),
+    ]
+
+
+class _RaReport(C.Structure):
+    _fields_ = [
+        ("l1_iterations", C.c_int32),
+        ("irls_iterations", C.c_int32),
+        ("factorizations", C.c_int32),
+        ("threads", C.c_int32),
+        ("profile_entries", C.c_int64),
+        ("seconds_total", C.c_double),
+        ("seconds_factor", C.c_double),
+    ]
+
+
+@dataclass
+class CpuSummary:
+    """LmSummary-compatible result of the C++ solves (+ timing)."""
+
+    iterations: int = 0
+    successful_steps: int = 0
+    linear_iterations: int = 0
+    initial_cost: float = 0.0
+    final_cost: float = 0.0
+    termination: int = 1
+    usable: bool = True
+    max_linear_residual: float = 0.0
+    seconds_total: float = 0.0
+    seconds_linear: float = 0.0
+    threads: int = 0
+
+
+def lib_path() -> Path:
+    return _DIR / "liboracle_cpu.so"
+
+
+def build(force: bool = False) -> Path:
+    """make -C oracle (g++ -O3 -fopenmp); a prebuilt .so is used as is when the sources are not newer."""
+    so = lib_path()
+    srcs = list((_DIR / "csrc").glob("*"))
+    stale = (not so.exists()) or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs)
+    if force or stale:
+        subprocess.run(["make", "-C", str(_DIR), "-s"] + (["-B"] if force else []), check=True)
+    return so
+
+
+def load():
+    global _LIB
+    if _LIB is None:
+        lib = C.CDLL(str(build()))
+        lib.orc_gp_solve.restype = C.c_int
+        lib.orc_ba_solve.restype = C.c_int
+        lib.orc_ra_solve.restype = C.c_int
+        lib.orc_num_threads.restype = C.c_int
+        _LIB = lib
+    return _LIB
+
+
+def num_threads() -> int:
+    return int(load().orc_num_threads())
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _fill_lm(o, lmo: _lm.LmOptions, pcg_tol, pcg_max, order, verbose):
+    for name in ("max_num_iterations", "function_tolerance", "gradient_tolerance", "parameter_tolerance",
+                 "initial_trust_region_radius", "max_trust_region_radius", "min_trust_region_radius",
+                 "min_relative_decrease", "min_lm_diagonal", "max_lm_diagonal", "max_num_consecutive_invalid_steps"):
+        setattr(o, name, getattr(lmo, name))
+    o.jacobi_scaling = int(lmo.jacobi_scaling)
+    o.pcg_relative_tolerance = pcg_tol
+    o.pcg_max_iterations = pcg_max
+    o.order = order
+    o.verbose = int(verbose)
+
+
+def _summary(rep) -> CpuSummary:
+    return CpuSummary(rep.iterations, rep.successful_steps, rep.linear_iterations, rep.initial_cost, rep.final_cost,
+                      rep.termination, bool(rep.usable), rep.max_linear_residual, rep.seconds_total, rep.seconds_linear,
+                      rep.threads)
+
+
+def gp_solve(num_cams, pt_offset, obs_cam, obs_dir, obs_calibrated, cam_center, pt_xyz,
+             options: _gp.GlobalPositionerOptions | None = None, threads: int = 0, pcg_tol: float = 1e-14,
+             pcg_max: int = 20000, order: int = 0, verbose: bool = False):
+    """Same contract as oracle.gp.solve: returns (ok, cam_center [N,3], pt_xyz [P,3], CpuSummary)."""
+    opt = options or _gp.GlobalPositionerOptions()
+    lib = load()
+    o = _GpOptions()
+    _fill_lm(o, opt.lm, pcg_tol, pcg_max, order, verbose)
+    o.thres_loss_function = opt.thres_loss_function
+    for name in ("generate_random_positions", "generate_random_points", "generate_scales", "optimize_positions",
+                 "optimize_points", "optimize_scales", "min_num_view_per_track", "seed"):
+        setattr(o, name, int(getattr(opt, name)))
+    off = np.ascontiguousarray(pt_offset, dtype=np.int64)
+    cam = np.ascontiguousarray(obs_cam, dtype=np.int32)
+    v = np.ascontiguousarray(obs_dir, dtype=np.float64)
+    cal = None if obs_calibrated is None else np.ascontiguousarray(obs_calibrated, dtype=np.uint8)
+    c = np.array(cam_center, dtype=np.float64, copy=True, order="C")
+    X = np.array(pt_xyz, dtype=np.float64, copy=True, order="C")
+    rep = _Report()
+    rc = lib.orc_gp_solve(C.c_int32(int(num_cams)), C.c_int64(off.shape[0] - 1), _p(off, C.c_int64), _p(cam, C.c_int32),
+                          _p(v, C.c_double), None if cal is None else _p(cal, C.c_uint8), C.byref(o), _p(c, C.c_double),
+                          _p(X, C.c_double), C.byref(rep), C.c_int32(threads))
+    s = _summary(rep)
+    if rc == -5:
+        s.usable = False
+    return rc == 0, c, X, s
+
+
+def ba_solve(num_cams, pt_offset, obs_cam, obs_xy, cam_intr, intr_model, fixed_cam, cam_q, cam_t, pt_xyz, intr_params,
+             options: _ba.BundleAdjusterOptions | None = None, threads: int = 0, pcg_tol: float = 1e-14,
+             pcg_max: int = 20000, order: int = 0, verbose: bool = False):
+    """Same contract as oracle.ba.solve: returns (ok, q [N,4], t [N,3], X [P,3], intr [K,8], CpuSummary)."""
+    opt = options or _ba.BundleAdjusterOptions()
+    lib = load()
+    o = _BaOptions()
+    _fill_lm(o, opt.lm, pcg_tol, pcg_max, order, verbose)
+    o.thres_loss_function = opt.thres_loss_function
+    for name in ("optimize_rotations", "optimize_translation", "optimize_intrinsics", "optimize_principal_point",
+                 "optimize_points", "min_num_view_per_track"):
+        setattr(o, name, int(getattr(opt, name)))
+    off = np.ascontiguousarray(pt_offset, dtype=np.int64)
+    cam = np.ascontiguousarray(obs_cam, dtype=np.int32)
+    xy = np.ascontiguousarray(obs_xy, dtype=np.float64)
+    ci = np.ascontiguousarray(cam_intr, dtype=np.int32)
+    mdl = np.ascontiguousarray(intr_model, dtype=np.int32)
+    q = np.array(cam_q, dtype=np.float64, copy=True, order="C")
+    t = np.array(cam_t, dtype=np.float64, copy=True, order="C")
+    X = np.array(pt_xyz, dtype=np.float64, copy=True, order="C")
+    intr = np.array(intr_params, dtype=np.float64, copy=True, order="C")
+    rep = _Report()
+    rc = lib.orc_ba_solve(C.c_int32(int(num_cams)), C.c_int32(mdl.shape[0]), C.c_int32(int(fixed_cam)),
+                          C.c_int64(off.shape[0] - 1), _p(off, C.c_int64), _p(cam, C.c_int32), _p(xy, C.c_double),
+                          _p(ci, C.c_int32), _p(mdl, C.c_int32), C.byref(o), _p(q, C.c_double), _p(t, C.c_double),
+                          _p(X, C.c_double), _p(intr, C.c_double), C.byref(rep), C.c_int32(threads))
+    s = _summary(rep)
+    if rc == -5:
+        s.usable = False
+    return rc == 0, q, t, X, intr, s
+
+
+def ra_estimate_rotations(num_nodes, edge_i, edge_j, edge_q, edge_weight, edge_ninl, node_aa0, fixed_node=0,
+                          options: _ra.RotationEstimatorOptions | None = None, threads: int = 0, report: dict | None = None):
+    """Same contract as oracle.ra.estimate_rotations: returns (ok, rot_aa [N,3]).  Raises NotImplementedError
+    when the graph's reverse-Cuthill-McKee profile is too large for the skyline factor (use oracle.ra then)."""
+    opt = options or _ra.RotationEstimatorOptions()
+    lib = load()
+    o = _RaOptions()
+    for name, _ in _RaOptions._fields_:
+        setattr(o, name, type(getattr(o, name))(getattr(opt, name)))
+    ei = np.ascontiguousarray(edge_i, dtype=np.int32)
+    ej = np.ascontiguousarray(edge_j, dtype=np.int32)
+    eq = np.ascontiguousarray(edge_q, dtype=np.float64)
+    E = ei.shape[0]
+    ew = np.ones(E) if edge_weight is None else np.ascontiguousarray(edge_weight, dtype=np.float64)
+    ninl = np.ones(E, np.int32) if edge_ninl is None else np.ascontiguousarray(edge_ninl, dtype=np.int32)
+    rot = np.array(node_aa0, dtype=np.float64, copy=True, order="C")
+    rep = _RaReport()
+    rc = lib.orc_ra_solve(C.c_int32(int(num_nodes)), C.c_int64(E), _p(ei, C.c_int32), _p(ej, C.c_int32), _p(eq, C.c_double),
+                          _p(ew, C.c_double), _p(ninl, C.c_int32), C.c_int32(int(fixed_node)), C.byref(o),
+                          _p(rot, C.c_double), C.byref(rep), C.c_int32(threads))
+    if report is not None:
+        report.update(l1_iterations=rep.l1_iterations, irls_iterations=rep.irls_iterations,
+                      factorizations=rep.factorizations, threads=rep.threads, profile_entries=rep.profile_entries,
+                      seconds_total=rep.seconds_total, seconds_factor=rep.seconds_factor)
+    if rc == -7:
+        raise NotImplementedError(f"skyline profile too large ({rep.profile_entries} entries)")
+    return rc == 0, rot

@@ -1,0 +1,741 @@
+// ORACLE (test infrastructure only — never linked into or called by the product path).
+//
+// orc_ba.cc — multithreaded C++ CPU restatement of GLOMAP's global bundle adjustment for trivial
+// rigs.  Same algorithm as oracle/ba.py (cross-validated against it on small problems), written so
+// that it runs at the full benchmark size (10k cameras / 5M observations) on all host cores:
+//
+//   problem      BundleAdjuster::AddPointToCameraConstraints, glomap/estimators/bundle_adjustment.cc:115-190
+//                (tracks >= min_num_view_per_track :122)
+//   residual     colmap::ReprojErrorCostFunctor<CameraModel> via bundle_adjustment.cc:137-146 (COLMAP @ b6b7b54e
+//                is un-vendored; restated from its published definition):
+//                x_c = R(q) X + t; (u, v) = CameraModel::ImgFromCam(params, x_c); r = (u, v) - obs  [pixels];
+//                residual and Jacobian are zero when the point is not in front of the camera
+//   models       SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL, RADIAL, OPENCV (colmap/sensor/models.h)
+//   manifolds    bundle_adjustment.cc:244-317: EigenQuaternionManifold (q <- [sin|d| d/|d|, cos|d|] * q), first frame
+//                constant, optimize_rotations / optimize_translation, principal point frozen by a SubsetManifold
+//   loss         Huber(1 px), bundle_adjustment.h:30,34-36
+//   ordering     points first (bundle_adjustment.cc:204-208)
+//   solver       Ceres LM (orc_lm.hpp); the 3x3 point blocks are eliminated in closed form (what SPARSE_SCHUR does)
+//                and the reduced system over poses + intrinsics is solved by block-Jacobi PCG to 1e-14
+//
+// parity unpinned: compared through converged solutions.
+#include "orc_lm.hpp"
+
+namespace orc {
+
+constexpr int MAXP = 8;
+enum { SIMPLE_PINHOLE = 0, PINHOLE = 1, SIMPLE_RADIAL = 2, RADIAL = 3, OPENCV = 4 };
+const int kNumParams[5] = {3, 4, 4, 5, 8};
+const int kPP[5][2] = {{1, 2}, {2, 3}, {1, 2}, {1, 2}, {2, 3}};
+
+struct BaOptionsC {
+  int32_t max_num_iterations;
+  double function_tolerance, gradient_tolerance, parameter_tolerance;
+  double initial_trust_region_radius, max_trust_region_radius, min_trust_region_radius, min_relative_decrease;
+  double min_lm_diagonal, max_lm_diagonal;
+  int32_t jacobi_scaling, max_num_consecutive_invalid_steps;
+  double pcg_relative_tolerance;
+  int32_t pcg_max_iterations, order, verbose;
+  double thres_loss_function;
+  int32_t optimize_rotations, optimize_translation, optimize_intrinsics, optimize_principal_point, optimize_points;
+  int32_t min_num_view_per_track;
+};
+
+struct BaReport {
+  int32_t iterations, successful_steps, termination, usable;
+  i64 linear_iterations;
+  double initial_cost, final_cost, max_linear_residual, seconds_total, seconds_linear;
+  int32_t threads, pad;
+};
+
+namespace {
+
+inline void quat_to_rot(const double* q, double* R) {
+  const double w = q[0], x = q[1], y = q[2], z = q[3];
+  R[0] = 1 - 2 * (y * y + z * z);
+  R[1] = 2 * (x * y - w * z);
+  R[2] = 2 * (x * z + w * y);
+  R[3] = 2 * (x * y + w * z);
+  R[4] = 1 - 2 * (x * x + z * z);
+  R[5] = 2 * (y * z - w * x);
+  R[6] = 2 * (x * z - w * y);
+  R[7] = 2 * (y * z + w * x);
+  R[8] = 1 - 2 * (x * x + y * y);
+}
+
+// ImgFromCam with analytic Jacobians: uv[2], Jx[2][3] = d(uv)/d(x_c), Jp[2][8] = d(uv)/d(params).
+inline bool project(int model, const double* p, const double* xc, double* uv, double* Jx, double* Jp) {
+  for (int i = 0; i < 16; ++i) Jp[i] = 0.0;
+  const double z = xc[2];
+  if (!(z > 2.220446049250313e-16)) return false;
+  const double u = xc[0] / z, v = xc[1] / z;
+  const double r2 = u * u + v * v;
+  double J00, J01, J10, J11;  // d(pixel)/d(u, v)
+  switch (model) {
+    case SIMPLE_PINHOLE: {
+      const double f = p[0];
+      uv[0] = f * u + p[1];
+      uv[1] = f * v + p[2];
+      J00 = f; J01 = 0; J10 = 0; J11 = f;
+      Jp[0] = u; Jp[8] = v;
+      Jp[1] = 1; Jp[8 + 2] = 1;
+      break;
+    }
+    case PINHOLE: {
+      uv[0] = p[0] * u + p[2];
+      uv[1] = p[1] * v + p[3];
+      J00 = p[0]; J01 = 0; J10 = 0; J11 = p[1];
+      Jp[0] = u; Jp[8 + 1] = v;
+      Jp[2] = 1; Jp[8 + 3] = 1;
+      break;
+    }
+    case SIMPLE_RADIAL:
+    case RADIAL: {
+      const double f = p[0], k1 = p[3], k2 = model == RADIAL ? p[4] : 0.0;
+      const double rad = k1 * r2 + k2 * r2 * r2;
+      const double drad = k1 + 2 * k2 * r2;
+      const double ud = u * (1 + rad), vd = v * (1 + rad);
+      uv[0] = f * ud + p[1];
+      uv[1] = f * vd + p[2];
+      J00 = f * (1 + rad + 2 * u * u * drad);
+      J01 = f * (2 * u * v * drad);
+      J10 = J01;
+      J11 = f * (1 + rad + 2 * v * v * drad);
+      Jp[0] = ud; Jp[8] = vd;
+      Jp[1] = 1; Jp[8 + 2] = 1;
+      Jp[3] = f * u * r2; Jp[8 + 3] = f * v * r2;
+      if (model == RADIAL) {
+        Jp[4] = f * u * r2 * r2;
+        Jp[8 + 4] = f * v * r2 * r2;
+      }
+      break;
+    }
+    case OPENCV: {
+      const double fx = p[0], fy = p[1], k1 = p[4], k2 = p[5], p1 = p[6], p2 = p[7];
+      const double rad = k1 * r2 + k2 * r2 * r2;
+      const double drad = k1 + 2 * k2 * r2;
+      const double du = u * rad + 2 * p1 * u * v + p2 * (r2 + 2 * u * u);
+      const double dv = v * rad + 2 * p2 * u * v + p1 * (r2 + 2 * v * v);
+      uv[0] = fx * (u + du) + p[2];
+      uv[1] = fy * (v + dv) + p[3];
+      const double ddu_du = rad + 2 * u * u * drad + 2 * p1 * v + 6 * p2 * u;
+      const double ddu_dv = 2 * u * v * drad + 2 * p1 * u + 2 * p2 * v;
+      const double ddv_du = 2 * u * v * drad + 2 * p2 * v + 2 * p1 * u;
+      const double ddv_dv = rad + 2 * v * v * drad + 2 * p2 * u + 6 * p1 * v;
+      J00 = fx * (1 + ddu_du); J01 = fx * ddu_dv; J10 = fy * ddv_du; J11 = fy * (1 + ddv_dv);
+      Jp[0] = u + du; Jp[8 + 1] = v + dv;
+      Jp[2] = 1; Jp[8 + 3] = 1;
+      Jp[4] = fx * u * r2; Jp[8 + 4] = fy * v * r2;
+      Jp[5] = fx * u * r2 * r2; Jp[8 + 5] = fy * v * r2 * r2;
+      Jp[6] = fx * 2 * u * v; Jp[8 + 6] = fy * (r2 + 2 * v * v);
+      Jp[7] = fx * (r2 + 2 * u * u); Jp[8 + 7] = fy * 2 * u * v;
+      break;
+    }
+    default:
+      return false;
+  }
+  // d(u,v)/d(x_c) = [[1/z, 0, -u/z], [0, 1/z, -v/z]]
+  const double iz = 1.0 / z;
+  Jx[0] = J00 * iz; Jx[1] = J01 * iz; Jx[2] = -(J00 * u + J01 * v) * iz;
+  Jx[3] = J10 * iz; Jx[4] = J11 * iz; Jx[5] = -(J10 * u + J11 * v) * iz;
+  return true;
+}
+
+struct Ba : LmProblem {
+  i64 N, P, M, K;
+  std::vector<int32_t> cam, pt, ik;  // per observation: camera, point, intrinsics block
+  std::vector<i64> poff;
+  std::vector<double> xy;
+  std::vector<int32_t> cam_intr, model;
+  OwnerLists bycam, byintr;
+  Huber loss;
+  std::vector<uint8_t> rot_free, trn_free;
+  std::vector<uint8_t> free_par;      // [K][8]
+  std::vector<int32_t> icol;          // [K][8] -> compact column or -1
+  i64 nfree = 0, nred = 0;            // reduced system = 6N + nfree
+  double mpt;                         // optimize_points
+  double lm_lo, lm_hi;
+  bool rev;
+  double pcg_tol;
+  int pcg_max;
+  // joint / separate preconditioner blocks
+  std::vector<int32_t> intr_owner;    // [K]: the single camera using this block, or -1 when shared / unused
+  // state
+  std::vector<double> q, t, X, intr, q2, t2, X2, intr2;
+  // linearisation (robustified, tangent space)
+  std::vector<double> rt;             // [M][2]
+  std::vector<double> Jc;             // [M][2][6]
+  std::vector<double> Jp;             // [M][2][3]
+  std::vector<double> Ji;             // [M][2][8]
+  std::vector<double> gred, gpt;      // J^T r~ : [nred], [3P]
+  std::vector<double> hred, hpt;      // column squared norms
+  std::vector<double> jred, jpt;      // Jacobi scales
+  // per step
+  std::vector<double> dred, Hinv /*[P][9]*/, tp, ak /*[M][2]*/;
+  std::vector<double> Mblk;           // block-Jacobi: per camera 14x14 (joint) ...
+  std::vector<double> Miblk;          // ... per shared intrinsics block 8x8
+
+  inline i64 ccol(i64 n) const { return 6 * n; }
+  inline double damp(double h, double j, double radius) const {
+    const double j2 = j * j;
+    return std::min(std::max(j2 * h, lm_lo), lm_hi) / (radius * j2);
+  }
+
+  void residual(i64 k, const std::vector<double>& qq, const std::vector<double>& tt, const std::vector<double>& XX,
+                const std::vector<double>& in, double* r, double* R, double* RX, double* Jx, double* Jpar, bool* valid) const {
+    const i64 n = cam[k], p = pt[k], b = ik[k];
+    quat_to_rot(&qq[4 * n], R);
+    const double* x = &XX[3 * p];
+    for (int i = 0; i < 3; ++i) RX[i] = R[3 * i] * x[0] + R[3 * i + 1] * x[1] + R[3 * i + 2] * x[2];
+    const double xc[3] = {RX[0] + tt[3 * n], RX[1] + tt[3 * n + 1], RX[2] + tt[3 * n + 2]};
+    double uv[2];
+    *valid = project(model[b], &in[MAXP * b], xc, uv, Jx, Jpar);
+    if (*valid) {
+      r[0] = uv[0] - xy[2 * k];
+      r[1] = uv[1] - xy[2 * k + 1];
+    } else {
+      r[0] = r[1] = 0.0;
+      for (int i = 0; i < 6; ++i) Jx[i] = 0.0;
+    }
+  }
+
+  double cost_at(const std::vector<double>& qq, const std::vector<double>& tt, const std::vector<double>& XX,
+                 const std::vector<double>& in) const {
+    return 0.5 * chunked_sum(M, [&](i64 k) {
+      double r[2], R[9], RX[3], Jx[6], Jpar[16];
+      bool valid;
+      residual(k, qq, tt, XX, in, r, R, RX, Jx, Jpar, &valid);
+      double r0, r1;
+      loss.eval(r[0] * r[0] + r[1] * r[1], r0, r1);
+      return r0;
+    });
+  }
+
+  double linearize(double* gmax_out) override {
+    rt.resize(2 * M);
+    Jc.resize(12 * M);
+    Jp.resize(6 * M);
+    Ji.resize(16 * M);
+    std::vector<double> rho(M);
+#pragma omp parallel for schedule(static)
+    for (i64 k = 0; k < M; ++k) {
+      double r[2], R[9], RX[3], Jx[6], Jpar[16];
+      bool valid;
+      residual(k, q, t, X, intr, r, R, RX, Jx, Jpar, &valid);
+      double r0, r1;
+      loss.eval(r[0] * r[0] + r[1] * r[1], r0, r1);
+      rho[k] = r0;
+      const double sw = valid ? std::sqrt(r1) : 0.0;
+      rt[2 * k] = sw * r[0];
+      rt[2 * k + 1] = sw * r[1];
+      const i64 n = cam[k], b = ik[k];
+      const double fr = rot_free[n] ? 1.0 : 0.0, ft = trn_free[n] ? 1.0 : 0.0;
+      // d x_c / d delta_rot = -2 [R X]_x  (EigenQuaternionManifold: rotation by 2|delta| on the left)
+      const double a0 = RX[0], a1 = RX[1], a2 = RX[2];
+      for (int i = 0; i < 2; ++i) {
+        const double j0 = sw * Jx[3 * i], j1 = sw * Jx[3 * i + 1], j2 = sw * Jx[3 * i + 2];
+        // (Jx skew)[i][:] with skew = [[0,-a2,a1],[a2,0,-a0],[-a1,a0,0]]
+        Jc[12 * k + 6 * i + 0] = fr * -2.0 * (j1 * a2 - j2 * a1);
+        Jc[12 * k + 6 * i + 1] = fr * -2.0 * (-j0 * a2 + j2 * a0);
+        Jc[12 * k + 6 * i + 2] = fr * -2.0 * (j0 * a1 - j1 * a0);
+        Jc[12 * k + 6 * i + 3] = ft * j0;
+        Jc[12 * k + 6 * i + 4] = ft * j1;
+        Jc[12 * k + 6 * i + 5] = ft * j2;
+        for (int j = 0; j < 3; ++j) Jp[6 * k + 3 * i + j] = mpt * (j0 * R[j] + j1 * R[3 + j] + j2 * R[6 + j]);
+        for (int j = 0; j < MAXP; ++j) Ji[16 * k + 8 * i + j] = free_par[MAXP * b + j] ? sw * Jpar[8 * i + j] : 0.0;
+      }
+    }
+    const double cost = 0.5 * chunked_sum(M, [&](i64 k) { return rho[k]; });
+    gred.assign(nred, 0.0);
+    hred.assign(nred, 0.0);
+    gpt.assign(3 * P, 0.0);
+    hpt.assign(3 * P, 0.0);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (i64 p = 0; p < P; ++p) {
+      double g[3] = {0, 0, 0}, h[3] = {0, 0, 0};
+      auto body = [&](i64 k) {
+        for (int j = 0; j < 3; ++j) {
+          g[j] += Jp[6 * k + j] * rt[2 * k] + Jp[6 * k + 3 + j] * rt[2 * k + 1];
+          h[j] += Jp[6 * k + j] * Jp[6 * k + j] + Jp[6 * k + 3 + j] * Jp[6 * k + 3 + j];
+        }
+      };
+      if (!rev)
+        for (i64 k = poff[p]; k < poff[p + 1]; ++k) body(k);
+      else
+        for (i64 k = poff[p + 1] - 1; k >= poff[p]; --k) body(k);
+      for (int j = 0; j < 3; ++j) {
+        gpt[3 * p + j] = g[j];
+        hpt[3 * p + j] = h[j];
+      }
+    }
+    std::vector<double> acc(12 * N);
+    bycam.reduce<12>(acc.data(), rev, [&](i64 k, double* a) {
+      for (int j = 0; j < 6; ++j) {
+        a[j] += Jc[12 * k + j] * rt[2 * k] + Jc[12 * k + 6 + j] * rt[2 * k + 1];
+        a[6 + j] += Jc[12 * k + j] * Jc[12 * k + j] + Jc[12 * k + 6 + j] * Jc[12 * k + 6 + j];
+      }
+    });
+    for (i64 n = 0; n < N; ++n)
+      for (int j = 0; j < 6; ++j) {
+        gred[6 * n + j] = acc[12 * n + j];
+        hred[6 * n + j] = acc[12 * n + 6 + j];
+      }
+    std::vector<double> acci(16 * K);
+    byintr.reduce<16>(acci.data(), rev, [&](i64 k, double* a) {
+      for (int j = 0; j < 8; ++j) {
+        a[j] += Ji[16 * k + j] * rt[2 * k] + Ji[16 * k + 8 + j] * rt[2 * k + 1];
+        a[8 + j] += Ji[16 * k + j] * Ji[16 * k + j] + Ji[16 * k + 8 + j] * Ji[16 * k + 8 + j];
+      }
+    });
+    for (i64 b = 0; b < K; ++b)
+      for (int j = 0; j < 8; ++j)
+        if (icol[MAXP * b + j] >= 0) {
+          gred[icol[MAXP * b + j]] = acci[16 * b + j];
+          hred[icol[MAXP * b + j]] = acci[16 * b + 8 + j];
+        }
+    double gmax = chunked_max(nred, [&](i64 i) { return std::fabs(gred[i]); });
+    gmax = std::max(gmax, chunked_max(3 * P, [&](i64 i) { return std::fabs(gpt[i]); }));
+    *gmax_out = gmax;
+    return cost;
+  }
+
+  void set_jacobi_scaling(bool enabled) override {
+    jred.assign(nred, 1.0);
+    jpt.assign(3 * P, 1.0);
+    if (enabled) {
+      for (i64 i = 0; i < nred; ++i) jred[i] = 1.0 / (1.0 + std::sqrt(hred[i]));
+      for (i64 i = 0; i < 3 * P; ++i) jpt[i] = 1.0 / (1.0 + std::sqrt(hpt[i]));
+    }
+  }
+
+  // a_k = Jc_k z_c + Ji_k z_i
+  inline void cam_side(i64 k, const std::vector<double>& z, double* a) const {
+    const i64 n = cam[k], b = ik[k];
+    a[0] = a[1] = 0.0;
+    for (int j = 0; j < 6; ++j) {
+      a[0] += Jc[12 * k + j] * z[6 * n + j];
+      a[1] += Jc[12 * k + 6 + j] * z[6 * n + j];
+    }
+    for (int j = 0; j < MAXP; ++j) {
+      const int32_t col = icol[MAXP * b + j];
+      if (col >= 0) {
+        a[0] += Ji[16 * k + j] * z[col];
+        a[1] += Ji[16 * k + 8 + j] * z[col];
+      }
+    }
+  }
+
+  // tp = Hpp^-1 sum_k Jp_k^T a_k(z); ak <- a_k - Jp_k tp
+  void point_pass(const std::vector<double>& z) {
+    ak.resize(2 * M);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (i64 p = 0; p < P; ++p) {
+      double b[3] = {0, 0, 0};
+      auto body = [&](i64 k) {
+        double a[2];
+        cam_side(k, z, a);
+        ak[2 * k] = a[0];
+        ak[2 * k + 1] = a[1];
+        for (int j = 0; j < 3; ++j) b[j] += Jp[6 * k + j] * a[0] + Jp[6 * k + 3 + j] * a[1];
+      };
+      if (!rev)
+        for (i64 k = poff[p]; k < poff[p + 1]; ++k) body(k);
+      else
+        for (i64 k = poff[p + 1] - 1; k >= poff[p]; --k) body(k);
+      const double* H = &Hinv[9 * p];
+      double tv[3];
+      for (int i = 0; i < 3; ++i) tv[i] = H[3 * i] * b[0] + H[3 * i + 1] * b[1] + H[3 * i + 2] * b[2];
+      for (int i = 0; i < 3; ++i) tp[3 * p + i] = tv[i];
+      for (i64 k = poff[p]; k < poff[p + 1]; ++k) {
+        ak[2 * k] -= Jp[6 * k] * tv[0] + Jp[6 * k + 1] * tv[1] + Jp[6 * k + 2] * tv[2];
+        ak[2 * k + 1] -= Jp[6 * k + 3] * tv[0] + Jp[6 * k + 4] * tv[1] + Jp[6 * k + 5] * tv[2];
+      }
+    }
+  }
+
+  // out = [Jc Ji]^T e  over all observations, e [M][2]
+  void cam_transpose(const std::vector<double>& e, std::vector<double>& out) {
+    std::vector<double> acc(6 * N);
+    bycam.reduce<6>(acc.data(), rev, [&](i64 k, double* a) {
+      for (int j = 0; j < 6; ++j) a[j] += Jc[12 * k + j] * e[2 * k] + Jc[12 * k + 6 + j] * e[2 * k + 1];
+    });
+    std::copy(acc.begin(), acc.end(), out.begin());
+    if (nfree > 0) {
+      std::vector<double> acci(8 * K);
+      byintr.reduce<8>(acci.data(), rev, [&](i64 k, double* a) {
+        for (int j = 0; j < 8; ++j) a[j] += Ji[16 * k + j] * e[2 * k] + Ji[16 * k + 8 + j] * e[2 * k + 1];
+      });
+      for (i64 b = 0; b < K; ++b)
+        for (int j = 0; j < 8; ++j)
+          if (icol[MAXP * b + j] >= 0) out[icol[MAXP * b + j]] = acci[8 * b + j];
+    }
+  }
+
+  void apply(const std::vector<double>& z, std::vector<double>& out) {
+    point_pass(z);
+    cam_transpose(ak, out);
+#pragma omp parallel for schedule(static)
+    for (i64 i = 0; i < nred; ++i) out[i] += dred[i] * z[i];
+  }
+
+  bool step(double radius, double* model_change, double* cand_cost, double* step_norm, double* x_norm, i64* lin,
+            double* relres) override {
+    dred.resize(nred);
+    for (i64 i = 0; i < nred; ++i) dred[i] = damp(hred[i], jred[i], radius);
+    Hinv.resize(9 * P);
+    tp.assign(3 * P, 0.0);
+    bool ok = true;
+#pragma omp parallel for schedule(dynamic, 256)
+    for (i64 p = 0; p < P; ++p) {
+      double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      auto body = [&](i64 k) {
+        for (int i = 0; i < 3; ++i)
+          for (int j = i; j < 3; ++j) H[3 * i + j] += Jp[6 * k + i] * Jp[6 * k + j] + Jp[6 * k + 3 + i] * Jp[6 * k + 3 + j];
+      };
+      if (!rev)
+        for (i64 k = poff[p]; k < poff[p + 1]; ++k) body(k);
+      else
+        for (i64 k = poff[p + 1] - 1; k >= poff[p]; --k) body(k);
+      H[3] = H[1];
+      H[6] = H[2];
+      H[7] = H[5];
+      for (int j = 0; j < 3; ++j) H[4 * j] += damp(hpt[3 * p + j], jpt[3 * p + j], radius);
+      if (!spd_inverse(H, 3)) {
+#pragma omp atomic write
+        ok = false;
+      }
+      std::memcpy(&Hinv[9 * p], H, sizeof H);
+    }
+    if (!ok) return false;
+    // rhs = -[Jc Ji]^T (r~ - Jp u), u = Hpp^-1 gpt
+    std::vector<double> u(3 * P), e(2 * M), rhs(nred);
+#pragma omp parallel for schedule(static)
+    for (i64 p = 0; p < P; ++p) {
+      const double* H = &Hinv[9 * p];
+      for (int i = 0; i < 3; ++i) u[3 * p + i] = H[3 * i] * gpt[3 * p] + H[3 * i + 1] * gpt[3 * p + 1] + H[3 * i + 2] * gpt[3 * p + 2];
+      for (i64 k = poff[p]; k < poff[p + 1]; ++k) {
+        e[2 * k] = rt[2 * k] - (Jp[6 * k] * u[3 * p] + Jp[6 * k + 1] * u[3 * p + 1] + Jp[6 * k + 2] * u[3 * p + 2]);
+        e[2 * k + 1] = rt[2 * k + 1] - (Jp[6 * k + 3] * u[3 * p] + Jp[6 * k + 4] * u[3 * p + 1] + Jp[6 * k + 5] * u[3 * p + 2]);
+      }
+    }
+    cam_transpose(e, rhs);
+    for (i64 i = 0; i < nred; ++i) rhs[i] = -rhs[i];
+    if (!build_preconditioner()) return false;
+    std::vector<double> dy(nred, 0.0);
+    *relres = 0.0;
+    *lin = pcg(
+        nred, rhs, dy, pcg_tol, pcg_max, [&](const std::vector<double>& z, std::vector<double>& o) { apply(z, o); },
+        [&](const std::vector<double>& r, std::vector<double>& z) { precond(r, z); }, relres);
+    // back-substitution: dX = -u - tp(dy)
+    point_pass(dy);
+    std::vector<double> dX(3 * P);
+#pragma omp parallel for schedule(static)
+    for (i64 i = 0; i < 3 * P; ++i) dX[i] = -u[i] - tp[i];
+    // model change: J delta = a_k(dy) + Jp dX
+    std::vector<double> mterm(M);
+#pragma omp parallel for schedule(static)
+    for (i64 k = 0; k < M; ++k) {
+      double a[2];
+      cam_side(k, dy, a);
+      const i64 p = pt[k];
+      const double j0 = a[0] + Jp[6 * k] * dX[3 * p] + Jp[6 * k + 1] * dX[3 * p + 1] + Jp[6 * k + 2] * dX[3 * p + 2];
+      const double j1 = a[1] + Jp[6 * k + 3] * dX[3 * p] + Jp[6 * k + 4] * dX[3 * p + 1] + Jp[6 * k + 5] * dX[3 * p + 2];
+      mterm[k] = j0 * (rt[2 * k] + 0.5 * j0) + j1 * (rt[2 * k + 1] + 0.5 * j1);
+    }
+    *model_change = -chunked_sum(M, [&](i64 k) { return mterm[k]; });
+    // candidate = Plus(x, delta)
+    q2 = q;
+    t2 = t;
+    X2 = X;
+    intr2 = intr;
+    for (i64 n = 0; n < N; ++n) {
+      const double* d = &dy[6 * n];
+      const double nr = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+      const double kk = nr > 0 ? std::sin(nr) / nr : 1.0;
+      const double a[4] = {std::cos(nr), kk * d[0], kk * d[1], kk * d[2]};
+      const double* b = &q[4 * n];
+      q2[4 * n] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+      q2[4 * n + 1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+      q2[4 * n + 2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+      q2[4 * n + 3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+      for (int j = 0; j < 3; ++j) t2[3 * n + j] = t[3 * n + j] + d[3 + j];
+    }
+#pragma omp parallel for schedule(static)
+    for (i64 i = 0; i < 3 * P; ++i) X2[i] = X[i] + dX[i];
+    for (i64 b = 0; b < K; ++b)
+      for (int j = 0; j < MAXP; ++j)
+        if (icol[MAXP * b + j] >= 0) intr2[MAXP * b + j] = intr[MAXP * b + j] + dy[icol[MAXP * b + j]];
+    auto diff2 = [&](const std::vector<double>& a, const std::vector<double>& b) {
+      return chunked_sum((i64)a.size(), [&](i64 i) { const double d = a[i] - b[i]; return d * d; });
+    };
+    auto sq = [&](const std::vector<double>& a) { return chunked_sum((i64)a.size(), [&](i64 i) { return a[i] * a[i]; }); };
+    const double sn = diff2(q2, q) + diff2(t2, t) + diff2(X2, X) + diff2(intr2, intr);
+    *step_norm = std::sqrt(sn);
+    *x_norm = std::sqrt(sq(q) + sq(t) + sq(X) + sq(intr));
+    *cand_cost = cost_at(q2, t2, X2, intr2);
+    return std::isfinite(sn);
+  }
+
+  // Block-Jacobi preconditioner of the reduced system: per camera a joint block over its 6 pose columns and the
+  // free columns of an intrinsics block only it uses; a separate block per shared intrinsics block.
+  // Diagonal blocks of S assembled per observation: W^T W - W^T Jp Hpp^-1 Jp^T W, W = [Jc Ji] (exact for the pose
+  // part; for shared intrinsics it drops the cross terms between observations of one point — it is a preconditioner).
+  bool build_preconditioner() {
+    Mblk.assign((size_t)196 * N, 0.0);
+    std::vector<double> acc((size_t)196 * N);
+    bycam.reduce<196>(acc.data(), rev, [&](i64 k, double* a) {
+      const i64 n = cam[k], b = ik[k];
+      const bool joint = intr_owner[b] == n;
+      double W[2][14];
+      for (int j = 0; j < 6; ++j) {
+        W[0][j] = Jc[12 * k + j];
+        W[1][j] = Jc[12 * k + 6 + j];
+      }
+      for (int j = 0; j < 8; ++j) {
+        W[0][6 + j] = joint ? Ji[16 * k + j] : 0.0;
+        W[1][6 + j] = joint ? Ji[16 * k + 8 + j] : 0.0;
+      }
+      const double* H = &Hinv[9 * (i64)pt[k]];
+      // G = Jp Hpp^-1 Jp^T (2x2)
+      double JH[2][3];
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 3; ++j)
+          JH[i][j] = Jp[6 * k + 3 * i] * H[j] + Jp[6 * k + 3 * i + 1] * H[3 + j] + Jp[6 * k + 3 * i + 2] * H[6 + j];
+      double G[2][2];
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+          G[i][j] = JH[i][0] * Jp[6 * k + 3 * j] + JH[i][1] * Jp[6 * k + 3 * j + 1] + JH[i][2] * Jp[6 * k + 3 * j + 2];
+      const double A00 = 1.0 - G[0][0], A01 = -G[0][1], A10 = -G[1][0], A11 = 1.0 - G[1][1];
+      const int w = joint ? 14 : 6;
+      for (int i = 0; i < w; ++i) {
+        const double l0 = W[0][i] * A00 + W[1][i] * A10, l1 = W[0][i] * A01 + W[1][i] * A11;
+        for (int j = 0; j < w; ++j) a[14 * i + j] += l0 * W[0][j] + l1 * W[1][j];
+      }
+    });
+    bool ok = true;
+#pragma omp parallel for schedule(static)
+    for (i64 n = 0; n < N; ++n) {
+      double B[196];
+      for (int i = 0; i < 14; ++i)
+        for (int j = 0; j < 14; ++j) B[14 * i + j] = 0.5 * (acc[(size_t)196 * n + 14 * i + j] + acc[(size_t)196 * n + 14 * j + i]);
+      const i64 b = cam_intr[n];
+      const bool joint = intr_owner[b] == n;
+      for (int j = 0; j < 6; ++j) B[15 * j] += dred[6 * n + j];
+      for (int j = 0; j < 8; ++j) {
+        const int32_t col = joint ? icol[MAXP * b + j] : -1;
+        if (col >= 0)
+          B[15 * (6 + j)] += dred[col];
+        else {  // not part of this block: identity row / column
+          for (int i = 0; i < 14; ++i) B[14 * (6 + j) + i] = B[14 * i + 6 + j] = 0.0;
+          B[15 * (6 + j)] = 1.0;
+        }
+      }
+      if (!spd_inverse(B, 14)) {
+#pragma omp atomic write
+        ok = false;
+      }
+      std::memcpy(&Mblk[(size_t)196 * n], B, sizeof B);
+    }
+    if (!ok) return false;
+    Miblk.assign((size_t)64 * K, 0.0);
+    bool any_shared = false;
+    for (i64 b = 0; b < K; ++b) any_shared = any_shared || intr_owner[b] < 0;
+    if (any_shared && nfree > 0) {
+      std::vector<double> acci((size_t)64 * K);
+      byintr.reduce<64>(acci.data(), rev, [&](i64 k, double* a) {
+        if (intr_owner[ik[k]] >= 0) return;
+        const double* H = &Hinv[9 * (i64)pt[k]];
+        double JH[2][3];
+        for (int i = 0; i < 2; ++i)
+          for (int j = 0; j < 3; ++j)
+            JH[i][j] = Jp[6 * k + 3 * i] * H[j] + Jp[6 * k + 3 * i + 1] * H[3 + j] + Jp[6 * k + 3 * i + 2] * H[6 + j];
+        double G[2][2];
+        for (int i = 0; i < 2; ++i)
+          for (int j = 0; j < 2; ++j)
+            G[i][j] = JH[i][0] * Jp[6 * k + 3 * j] + JH[i][1] * Jp[6 * k + 3 * j + 1] + JH[i][2] * Jp[6 * k + 3 * j + 2];
+        const double A00 = 1.0 - G[0][0], A01 = -G[0][1], A10 = -G[1][0], A11 = 1.0 - G[1][1];
+        for (int i = 0; i < 8; ++i) {
+          const double l0 = Ji[16 * k + i] * A00 + Ji[16 * k + 8 + i] * A10, l1 = Ji[16 * k + i] * A01 + Ji[16 * k + 8 + i] * A11;
+          for (int j = 0; j < 8; ++j) a[8 * i + j] += l0 * Ji[16 * k + j] + l1 * Ji[16 * k + 8 + j];
+        }
+      });
+      for (i64 b = 0; b < K; ++b) {
+        if (intr_owner[b] >= 0) continue;
+        double B[64];
+        for (int i = 0; i < 8; ++i)
+          for (int j = 0; j < 8; ++j) B[8 * i + j] = 0.5 * (acci[(size_t)64 * b + 8 * i + j] + acci[(size_t)64 * b + 8 * j + i]);
+        for (int j = 0; j < 8; ++j) {
+          const int32_t col = icol[MAXP * b + j];
+          if (col >= 0)
+            B[9 * j] += dred[col];
+          else {
+            for (int i = 0; i < 8; ++i) B[8 * j + i] = B[8 * i + j] = 0.0;
+            B[9 * j] = 1.0;
+          }
+        }
+        if (!spd_inverse(B, 8)) return false;
+        std::memcpy(&Miblk[(size_t)64 * b], B, sizeof B);
+      }
+    }
+    return true;
+  }
+
+  void precond(const std::vector<double>& r, std::vector<double>& z) {
+#pragma omp parallel for schedule(static)
+    for (i64 n = 0; n < N; ++n) {
+      const i64 b = cam_intr[n];
+      const bool joint = intr_owner[b] == n;
+      double rv[14], zv[14];
+      for (int j = 0; j < 6; ++j) rv[j] = r[6 * n + j];
+      for (int j = 0; j < 8; ++j) {
+        const int32_t col = joint ? icol[MAXP * b + j] : -1;
+        rv[6 + j] = col >= 0 ? r[col] : 0.0;
+      }
+      const double* B = &Mblk[(size_t)196 * n];
+      for (int i = 0; i < 14; ++i) {
+        double s = 0.0;
+        for (int j = 0; j < 14; ++j) s += B[14 * i + j] * rv[j];
+        zv[i] = s;
+      }
+      for (int j = 0; j < 6; ++j) z[6 * n + j] = zv[j];
+      for (int j = 0; j < 8; ++j) {
+        const int32_t col = joint ? icol[MAXP * b + j] : -1;
+        if (col >= 0) z[col] = zv[6 + j];
+      }
+    }
+    for (i64 b = 0; b < K; ++b) {
+      if (intr_owner[b] >= 0) continue;
+      const double* B = &Miblk[(size_t)64 * b];
+      for (int i = 0; i < 8; ++i) {
+        const int32_t ci = icol[MAXP * b + i];
+        if (ci < 0) continue;
+        double s = 0.0;
+        for (int j = 0; j < 8; ++j) {
+          const int32_t cj = icol[MAXP * b + j];
+          if (cj >= 0) s += B[8 * i + j] * r[cj];
+        }
+        z[ci] = s;
+      }
+    }
+  }
+
+  void accept() override {
+    q.swap(q2);
+    t.swap(t2);
+    X.swap(X2);
+    intr.swap(intr2);
+  }
+};
+
+}  // namespace
+}  // namespace orc
+
+extern "C" {
+using orc::i64;
+
+// Arrays as gsfm_ba_problem (include/gsfm.h); cam_q (w,x,y,z), intr_params [K][8].
+int orc_ba_solve(int32_t num_cams, int32_t num_intr, int32_t fixed_cam, i64 num_pts, const i64* pt_offset,
+                 const int32_t* obs_cam, const double* obs_xy, const int32_t* cam_intr, const int32_t* intr_model,
+                 const orc::BaOptionsC* o, double* cam_q_inout, double* cam_t_inout, double* pt_xyz_inout,
+                 double* intr_params_inout, orc::BaReport* rep, int32_t num_threads) {
+  using namespace orc;
+  const double t0 = omp_get_wtime();
+  if (num_threads > 0) omp_set_num_threads(num_threads);
+  Ba g;
+  g.N = num_cams;
+  g.K = num_intr;
+  std::vector<i64> used_pts;
+  g.poff.push_back(0);
+  for (i64 p = 0; p < num_pts; ++p) {
+    if (pt_offset[p + 1] - pt_offset[p] < o->min_num_view_per_track) continue;  // ba.cc:122
+    const i64 id = (i64)used_pts.size();
+    used_pts.push_back(p);
+    for (i64 k = pt_offset[p]; k < pt_offset[p + 1]; ++k) {
+      g.cam.push_back(obs_cam[k]);
+      g.pt.push_back((int32_t)id);
+      g.ik.push_back(cam_intr[obs_cam[k]]);
+      g.xy.push_back(obs_xy[2 * k]);
+      g.xy.push_back(obs_xy[2 * k + 1]);
+    }
+    g.poff.push_back((i64)g.cam.size());
+  }
+  g.P = (i64)used_pts.size();
+  g.M = (i64)g.cam.size();
+  std::memset(rep, 0, sizeof *rep);
+  rep->threads = omp_get_max_threads();
+  if (g.M == 0) return -5;
+  g.cam_intr.assign(cam_intr, cam_intr + g.N);
+  g.model.assign(intr_model, intr_model + g.K);
+  for (i64 b = 0; b < g.K; ++b)
+    if (g.model[b] < 0 || g.model[b] > 4) return -7;
+  g.bycam.build(g.N, g.M, g.cam.data());
+  g.byintr.build(g.K, g.M, g.ik.data());
+  g.loss = {o->thres_loss_function, 1.0};
+  g.rot_free.assign(g.N, o->optimize_rotations ? 1 : 0);
+  g.trn_free.assign(g.N, o->optimize_translation ? 1 : 0);
+  if (fixed_cam >= 0) g.rot_free[fixed_cam] = g.trn_free[fixed_cam] = 0;  // ba.cc:261-266
+  g.free_par.assign(MAXP * g.K, 0);
+  g.icol.assign(MAXP * g.K, -1);
+  g.nfree = 0;
+  for (i64 b = 0; b < g.K; ++b) {
+    if (!o->optimize_intrinsics && !o->optimize_principal_point) continue;  // SetParameterBlockConstant, ba.cc:273-293
+    const int m = g.model[b];
+    for (int j = 0; j < kNumParams[m]; ++j) g.free_par[MAXP * b + j] = 1;
+    if (o->optimize_intrinsics && !o->optimize_principal_point) g.free_par[MAXP * b + kPP[m][0]] = g.free_par[MAXP * b + kPP[m][1]] = 0;
+    for (int j = 0; j < MAXP; ++j)
+      if (g.free_par[MAXP * b + j]) g.icol[MAXP * b + j] = (int32_t)(6 * g.N + g.nfree++);
+  }
+  g.nred = 6 * g.N + g.nfree;
+  g.intr_owner.assign(g.K, -2);
+  for (i64 n = 0; n < g.N; ++n) {
+    int32_t& ow = g.intr_owner[cam_intr[n]];
+    ow = (ow == -2) ? (int32_t)n : -1;
+  }
+  for (i64 b = 0; b < g.K; ++b)
+    if (g.intr_owner[b] == -2) g.intr_owner[b] = -1;
+  g.mpt = o->optimize_points ? 1.0 : 0.0;
+  g.lm_lo = o->min_lm_diagonal;
+  g.lm_hi = o->max_lm_diagonal;
+  g.rev = o->order != 0;
+  g.pcg_tol = o->pcg_relative_tolerance;
+  g.pcg_max = o->pcg_max_iterations;
+  g.q.assign(cam_q_inout, cam_q_inout + 4 * g.N);
+  g.t.assign(cam_t_inout, cam_t_inout + 3 * g.N);
+  g.intr.assign(intr_params_inout, intr_params_inout + MAXP * g.K);
+  g.X.resize(3 * g.P);
+  for (i64 i = 0; i < g.P; ++i)
+    for (int j = 0; j < 3; ++j) g.X[3 * i + j] = pt_xyz_inout[3 * used_pts[i] + j];
+  LmOptions lo;
+  lo.max_num_iterations = o->max_num_iterations;
+  lo.function_tolerance = o->function_tolerance;
+  lo.gradient_tolerance = o->gradient_tolerance;
+  lo.parameter_tolerance = o->parameter_tolerance;
+  lo.initial_trust_region_radius = o->initial_trust_region_radius;
+  lo.max_trust_region_radius = o->max_trust_region_radius;
+  lo.min_trust_region_radius = o->min_trust_region_radius;
+  lo.min_relative_decrease = o->min_relative_decrease;
+  lo.min_lm_diagonal = o->min_lm_diagonal;
+  lo.max_lm_diagonal = o->max_lm_diagonal;
+  lo.jacobi_scaling = o->jacobi_scaling;
+  lo.max_num_consecutive_invalid_steps = o->max_num_consecutive_invalid_steps;
+  lo.verbose = o->verbose;
+  LmSummary s;
+  lm_minimize(g, lo, &s);
+  std::memcpy(cam_q_inout, g.q.data(), sizeof(double) * 4 * g.N);
+  std::memcpy(cam_t_inout, g.t.data(), sizeof(double) * 3 * g.N);
+  std::memcpy(intr_params_inout, g.intr.data(), sizeof(double) * MAXP * g.K);
+  for (i64 i = 0; i < g.P; ++i)
+    for (int j = 0; j < 3; ++j) pt_xyz_inout[3 * used_pts[i] + j] = g.X[3 * i + j];
+  rep->iterations = s.iterations;
+  rep->successful_steps = s.successful_steps;
+  rep->termination = s.termination;
+  rep->usable = s.usable;
+  rep->linear_iterations = s.linear_iterations;
+  rep->initial_cost = s.initial_cost;
+  rep->final_cost = s.final_cost;
+  rep->max_linear_residual = s.max_linear_residual;
+  rep->seconds_linear = s.seconds_linear;
+  rep->seconds_total = omp_get_wtime() - t0;
+  return s.usable ? 0 : -6;
+}
+}

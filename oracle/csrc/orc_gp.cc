@@ -1,0 +1,533 @@
+// ORACLE (test infrastructure only — never linked into or called by the product path).
+//
+// orc_gp.cc — multithreaded C++ CPU restatement of GLOMAP's global positioning, ONLY_POINTS with
+// trivial rigs (the only mode `glomap mapper` accepts, glomap/controllers/global_mapper.cc:145-149).
+// Same algorithm as oracle/gp.py (which it is cross-validated against on small problems), written
+// so that it also runs at the full benchmark sizes and can be timed on all host cores:
+//
+//   residual      BATAPairwiseDirectionError, glomap/estimators/cost_function.h:15-41: r = v - s (X - c)
+//   problem       AddTrackToProblem, global_positioning.cc:212-375 (tracks >= min_num_view_per_track :258;
+//                 scales start at 1 :298-305, lower bound 1e-5 :373; Huber(0.1) for cameras with a prior
+//                 focal length, ScaledLoss(Huber(0.1), 0.5) otherwise :242-255,313-316)
+//   random init   global_positioning.cc:123-165,261-264: 100 * U(-1,1)^3 from std::mt19937(seed) and
+//                 std::uniform_real_distribution<double>; draw order: constrained cameras by index, then
+//                 used tracks by index (the reference's unordered_map order cannot be reproduced)
+//   gauge         the first scale is constant, global_positioning.cc:484-489
+//   ordering      scales, then points, then camera centres (global_positioning.cc:388-429)
+//   solver        Ceres LM (orc_lm.hpp).  The scales (1x1) and the points (3x3) are eliminated in closed
+//                 form — the step SPARSE_SCHUR computes — and the 3N camera system is solved by block-Jacobi
+//                 PCG to 1e-14.
+//
+// parity unpinned: Ceres is un-vendored; compared through converged solutions.
+#include <random>
+
+#include "orc_lm.hpp"
+
+namespace orc {
+
+struct GpOptionsC {  // mirrors the python-side ctypes struct (oracle/cpu.py)
+  int32_t max_num_iterations;
+  double function_tolerance, gradient_tolerance, parameter_tolerance;
+  double initial_trust_region_radius, max_trust_region_radius, min_trust_region_radius, min_relative_decrease;
+  double min_lm_diagonal, max_lm_diagonal;
+  int32_t jacobi_scaling, max_num_consecutive_invalid_steps;
+  double pcg_relative_tolerance;
+  int32_t pcg_max_iterations, order, verbose;
+  double thres_loss_function;
+  int32_t generate_random_positions, generate_random_points, generate_scales;
+  int32_t optimize_positions, optimize_points, optimize_scales;
+  int32_t min_num_view_per_track;
+  uint32_t seed;
+};
+
+struct GpReport {
+  int32_t iterations, successful_steps, termination, usable;
+  i64 linear_iterations;
+  double initial_cost, final_cost, max_linear_residual, seconds_total, seconds_linear;
+  int32_t threads, pad;
+};
+
+namespace {
+
+struct Gp : LmProblem {
+  i64 N, P, M;
+  std::vector<int32_t> cam, pt;   // [M] track-major
+  std::vector<i64> poff;          // [P+1]
+  const double* v;                // [M][3] (compacted copy)
+  std::vector<double> vbuf;
+  std::vector<uint8_t> cal;
+  OwnerLists bycam;
+  Huber loss_cal, loss_unc;
+  double mc, mx, ms;  // 1 / 0: optimize_positions / points / scales
+  double lm_lo, lm_hi;
+  bool rev;
+  double pcg_tol;
+  int pcg_max;
+  // state
+  std::vector<double> c, X, s, c2, X2, s2;
+  // linearisation
+  std::vector<double> w;        // [M] rho'
+  std::vector<double> gc, gX;   // gradients [3N], [3P]
+  std::vector<double> hc, hx;   // diag of J^T J per camera / point (one value: same for the 3 components)
+  std::vector<double> jc, jx, js;  // Jacobi scales
+  bool have_scale = false;
+  // per-step
+  std::vector<double> qa, qb;   // per observation: Q_k = qa (I - qb d d^T)
+  std::vector<double> Hinv;     // [P][6] inverse of H_pp (symmetric, xx xy xz yy yz zz)
+  std::vector<double> tp;       // [P][3]
+  std::vector<double> Minv;     // [N][9] block-Jacobi
+  std::vector<double> dcam;     // [N] LM damping of the camera blocks
+
+  inline V3 dvec(i64 k, const std::vector<double>& cc, const std::vector<double>& XX) const {
+    return ld3(&XX[3 * (i64)pt[k]]) - ld3(&cc[3 * (i64)cam[k]]);
+  }
+  inline double damp(double h, double j, double radius) const {
+    const double j2 = j * j;
+    return std::min(std::max(j2 * h, lm_lo), lm_hi) / (radius * j2);
+  }
+
+  double cost_at(const std::vector<double>& cc, const std::vector<double>& XX, const std::vector<double>& ss) const {
+    const Gp* g = this;
+    return 0.5 * chunked_sum(M, [=, &cc, &XX, &ss](i64 k) {
+      const V3 d = g->dvec(k, cc, XX);
+      const V3 r = ld3(g->v + 3 * k) - ss[k] * d;
+      double r0, r1;
+      (g->cal[k] ? g->loss_cal : g->loss_unc).eval(dot(r, r), r0, r1);
+      return r0;
+    });
+  }
+
+  double linearize(double* gmax_out) override {
+    w.resize(M);
+    gc.assign(3 * N, 0.0);
+    gX.assign(3 * P, 0.0);
+    hc.assign(N, 0.0);
+    hx.assign(P, 0.0);
+    std::vector<double> rho(M), gs(M);
+#pragma omp parallel for schedule(static)
+    for (i64 k = 0; k < M; ++k) {
+      const V3 d = dvec(k, c, X);
+      const V3 r = ld3(v + 3 * k) - s[k] * d;
+      double r0, r1;
+      (cal[k] ? loss_cal : loss_unc).eval(dot(r, r), r0, r1);
+      rho[k] = r0;
+      w[k] = r1;
+      gs[k] = (k == 0 ? 0.0 : ms) * (-r1 * dot(d, r));  // the first scale is constant
+    }
+    const double cost = 0.5 * chunked_sum(M, [&](i64 k) { return rho[k]; });
+    // point side: g_X = -sum w s r, h_X = sum w s^2  (track-major, serial inside a track)
+#pragma omp parallel for schedule(dynamic, 256)
+    for (i64 p = 0; p < P; ++p) {
+      double a[4] = {0, 0, 0, 0};
+      auto body = [&](i64 k) {
+        const V3 d = dvec(k, c, X);
+        const V3 r = ld3(v + 3 * k) - s[k] * d;
+        const double ws = w[k] * s[k];
+        a[0] += ws * s[k];
+        a[1] -= ws * r.x;
+        a[2] -= ws * r.y;
+        a[3] -= ws * r.z;
+      };
+      if (!rev)
+        for (i64 k = poff[p]; k < poff[p + 1]; ++k) body(k);
+      else
+        for (i64 k = poff[p + 1] - 1; k >= poff[p]; --k) body(k);
+      hx[p] = mx * a[0];
+      gX[3 * p] = mx * a[1];
+      gX[3 * p + 1] = mx * a[2];
+      gX[3 * p + 2] = mx * a[3];
+    }
+    // camera side
+    std::vector<double> acc(4 * N);
+    bycam.reduce<4>(acc.data(), rev, [&](i64 k, double* a) {
+      const V3 d = dvec(k, c, X);
+      const V3 r = ld3(v + 3 * k) - s[k] * d;
+      const double ws = w[k] * s[k];
+      a[0] += ws * s[k];
+      a[1] += ws * r.x;
+      a[2] += ws * r.y;
+      a[3] += ws * r.z;
+    });
+#pragma omp parallel for schedule(static)
+    for (i64 n = 0; n < N; ++n) {
+      hc[n] = mc * acc[4 * n];
+      gc[3 * n] = mc * acc[4 * n + 1];
+      gc[3 * n + 1] = mc * acc[4 * n + 2];
+      gc[3 * n + 2] = mc * acc[4 * n + 3];
+    }
+    double gmax = chunked_max(M, [&](i64 k) { return std::fabs(gs[k]); });
+    gmax = std::max(gmax, chunked_max(3 * N, [&](i64 i) { return std::fabs(gc[i]); }));
+    gmax = std::max(gmax, chunked_max(3 * P, [&](i64 i) { return std::fabs(gX[i]); }));
+    *gmax_out = gmax;
+    return cost;
+  }
+
+  void set_jacobi_scaling(bool enabled) override {
+    jc.assign(N, 1.0);
+    jx.assign(P, 1.0);
+    js.assign(M, 1.0);
+    if (enabled) {
+      for (i64 n = 0; n < N; ++n) jc[n] = 1.0 / (1.0 + std::sqrt(hc[n]));
+      for (i64 p = 0; p < P; ++p) jx[p] = 1.0 / (1.0 + std::sqrt(hx[p]));
+#pragma omp parallel for schedule(static)
+      for (i64 k = 0; k < M; ++k) {
+        const V3 d = dvec(k, c, X);
+        const double h = (k == 0 ? 0.0 : ms) * w[k] * dot(d, d);
+        js[k] = 1.0 / (1.0 + std::sqrt(h));
+      }
+    }
+    have_scale = true;
+  }
+
+  // w_out = S z  (S = reduced camera system), two sweeps
+  void apply(const std::vector<double>& z, std::vector<double>& out) {
+#pragma omp parallel for schedule(dynamic, 256)
+    for (i64 p = 0; p < P; ++p) {
+      double a[3] = {0, 0, 0};
+      auto body = [&](i64 k) {
+        const V3 d = dvec(k, c, X);
+        const V3 zc = ld3(&z[3 * (i64)cam[k]]);
+        const V3 q = qa[k] * (zc - (qb[k] * dot(d, zc)) * d);
+        a[0] += q.x;
+        a[1] += q.y;
+        a[2] += q.z;
+      };
+      if (!rev)
+        for (i64 k = poff[p]; k < poff[p + 1]; ++k) body(k);
+      else
+        for (i64 k = poff[p + 1] - 1; k >= poff[p]; --k) body(k);
+      const double* H = &Hinv[6 * p];
+      // t_p = mc mx Hpp^-1 sum Q z   (H_pc = -mc mx Q)
+      const double f = mc * mx;
+      tp[3 * p] = f * (H[0] * a[0] + H[1] * a[1] + H[2] * a[2]);
+      tp[3 * p + 1] = f * (H[1] * a[0] + H[3] * a[1] + H[4] * a[2]);
+      tp[3 * p + 2] = f * (H[2] * a[0] + H[4] * a[1] + H[5] * a[2]);
+    }
+    std::vector<double> acc(3 * N);
+    bycam.reduce<3>(acc.data(), rev, [&](i64 k, double* a) {
+      const V3 d = dvec(k, c, X);
+      const V3 e = mc * ld3(&z[3 * (i64)cam[k]]) - mx * ld3(&tp[3 * (i64)pt[k]]);
+      const V3 q = qa[k] * (e - (qb[k] * dot(d, e)) * d);
+      a[0] += q.x;
+      a[1] += q.y;
+      a[2] += q.z;
+    });
+#pragma omp parallel for schedule(static)
+    for (i64 n = 0; n < N; ++n)
+      for (int j = 0; j < 3; ++j) out[3 * n + j] = mc * acc[3 * n + j] + dcam[n] * z[3 * n + j];
+  }
+
+  bool step(double radius, double* model_change, double* cand_cost, double* step_norm, double* x_norm, i64* lin,
+            double* relres) override {
+    qa.resize(M);
+    qb.resize(M);
+    std::vector<double> qg(3 * M);  // q_k = s w (r - beta d (d.r))
+    std::vector<double> hss(M);
+#pragma omp parallel for schedule(static)
+    for (i64 k = 0; k < M; ++k) {
+      const V3 d = dvec(k, c, X);
+      const V3 r = ld3(v + 3 * k) - s[k] * d;
+      const double m = (k == 0 ? 0.0 : ms);
+      const double h = m * w[k] * dot(d, d);
+      const double ht = h + damp(h, js[k], radius);
+      hss[k] = ht;
+      const double beta = m * w[k] / ht;
+      qa[k] = w[k] * s[k] * s[k];
+      qb[k] = beta;
+      st3(&qg[3 * k], (s[k] * w[k]) * (r - (beta * dot(d, r)) * d));
+    }
+    // points: H_pp = mx^2 sum Q + D_X, reduced gradient gX' = -mx sum q
+    Hinv.resize(6 * P);
+    tp.assign(3 * P, 0.0);
+    std::vector<double> gXr(3 * P);
+    bool ok = true;
+#pragma omp parallel for schedule(dynamic, 256)
+    for (i64 p = 0; p < P; ++p) {
+      double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      double g[3] = {0, 0, 0};
+      auto body = [&](i64 k) {
+        const V3 d = dvec(k, c, X);
+        const double a = qa[k], ab = qa[k] * qb[k];
+        H[0] += a - ab * d.x * d.x;
+        H[1] += -ab * d.x * d.y;
+        H[2] += -ab * d.x * d.z;
+        H[4] += a - ab * d.y * d.y;
+        H[5] += -ab * d.y * d.z;
+        H[8] += a - ab * d.z * d.z;
+        g[0] -= qg[3 * k];
+        g[1] -= qg[3 * k + 1];
+        g[2] -= qg[3 * k + 2];
+      };
+      if (!rev)
+        for (i64 k = poff[p]; k < poff[p + 1]; ++k) body(k);
+      else
+        for (i64 k = poff[p + 1] - 1; k >= poff[p]; --k) body(k);
+      const double dx = damp(hx[p], jx[p], radius);
+      H[0] = mx * H[0] + dx;
+      H[4] = mx * H[4] + dx;
+      H[8] = mx * H[8] + dx;
+      H[1] *= mx;
+      H[2] *= mx;
+      H[5] *= mx;
+      H[3] = H[1];
+      H[6] = H[2];
+      H[7] = H[5];
+      if (!spd_inverse(H, 3)) {
+#pragma omp atomic write
+        ok = false;
+      }
+      double* o = &Hinv[6 * p];
+      o[0] = H[0];
+      o[1] = H[1];
+      o[2] = H[2];
+      o[3] = H[4];
+      o[4] = H[5];
+      o[5] = H[8];
+      for (int j = 0; j < 3; ++j) gXr[3 * p + j] = mx * g[j];
+    }
+    if (!ok) return false;
+    // cameras: damping, rhs = -(g_c' - H_cp Hpp^-1 g_X'), g_c' = mc sum q,  H_cp = -mc mx Q
+    dcam.resize(N);
+    for (i64 n = 0; n < N; ++n) dcam[n] = damp(hc[n], jc[n], radius);
+    std::vector<double> u(3 * P);  // Hpp^-1 gX'
+#pragma omp parallel for schedule(static)
+    for (i64 p = 0; p < P; ++p) {
+      const double* H = &Hinv[6 * p];
+      const double* g = &gXr[3 * p];
+      u[3 * p] = H[0] * g[0] + H[1] * g[1] + H[2] * g[2];
+      u[3 * p + 1] = H[1] * g[0] + H[3] * g[1] + H[4] * g[2];
+      u[3 * p + 2] = H[2] * g[0] + H[4] * g[1] + H[5] * g[2];
+    }
+    std::vector<double> acc(12 * N);
+    bycam.reduce<12>(acc.data(), rev, [&](i64 k, double* a) {
+      const V3 d = dvec(k, c, X);
+      const double qa_ = qa[k], ab = qa[k] * qb[k];
+      // gradient share: q_k + mx Q_k u_p   (rhs = -(mc sum q + mc mx sum Q u))
+      const V3 up = ld3(&u[3 * (i64)pt[k]]);
+      const V3 Qu = qa_ * (up - (qb[k] * dot(d, up)) * d);
+      a[0] += qg[3 * k] + mx * Qu.x;
+      a[1] += qg[3 * k + 1] + mx * Qu.y;
+      a[2] += qg[3 * k + 2] + mx * Qu.z;
+      // diagonal block of S: Q - mx^2 Q Hpp^-1 Q
+      const double* H = &Hinv[6 * (i64)pt[k]];
+      double Q[9] = {qa_ - ab * d.x * d.x, -ab * d.x * d.y, -ab * d.x * d.z, 0, qa_ - ab * d.y * d.y, -ab * d.y * d.z, 0, 0,
+                     qa_ - ab * d.z * d.z};
+      Q[3] = Q[1];
+      Q[6] = Q[2];
+      Q[7] = Q[5];
+      const double Hf[9] = {H[0], H[1], H[2], H[1], H[3], H[4], H[2], H[4], H[5]};
+      double HQ[9];
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) HQ[3 * i + j] = Hf[3 * i] * Q[j] + Hf[3 * i + 1] * Q[3 + j] + Hf[3 * i + 2] * Q[6 + j];
+      const double f = mx * mx;
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+          a[3 + 3 * i + j] += Q[3 * i + j] - f * (Q[3 * i] * HQ[j] + Q[3 * i + 1] * HQ[3 + j] + Q[3 * i + 2] * HQ[6 + j]);
+    });
+    std::vector<double> rhs(3 * N);
+    Minv.resize(9 * N);
+    for (i64 n = 0; n < N; ++n) {
+      for (int j = 0; j < 3; ++j) rhs[3 * n + j] = -mc * acc[12 * n + j];
+      double B[9];
+      for (int j = 0; j < 9; ++j) B[j] = mc * mc * acc[12 * n + 3 + j];
+      // symmetrise (rounding) and damp
+      B[1] = B[3] = 0.5 * (B[1] + B[3]);
+      B[2] = B[6] = 0.5 * (B[2] + B[6]);
+      B[5] = B[7] = 0.5 * (B[5] + B[7]);
+      B[0] += dcam[n];
+      B[4] += dcam[n];
+      B[8] += dcam[n];
+      if (!spd_inverse(B, 3)) return false;
+      std::memcpy(&Minv[9 * n], B, sizeof B);
+    }
+    std::vector<double> dc(3 * N, 0.0);
+    *relres = 0.0;
+    *lin = pcg(
+        3 * N, rhs, dc, pcg_tol, pcg_max, [&](const std::vector<double>& z, std::vector<double>& o) { apply(z, o); },
+        [&](const std::vector<double>& r, std::vector<double>& z) {
+#pragma omp parallel for schedule(static)
+          for (i64 n = 0; n < N; ++n) {
+            const double* B = &Minv[9 * n];
+            for (int i = 0; i < 3; ++i) z[3 * n + i] = B[3 * i] * r[3 * n] + B[3 * i + 1] * r[3 * n + 1] + B[3 * i + 2] * r[3 * n + 2];
+          }
+        },
+        relres);
+    // back-substitution: dX_p = Hpp^-1 (-gX' + mc mx sum Q dc) ; ds_k = beta (d.(r + s (mc dc - mx dX)))
+    std::vector<double> dX(3 * P);
+    apply_points_only(dc);  // tp = mc mx Hpp^-1 sum Q dc
+#pragma omp parallel for schedule(static)
+    for (i64 i = 0; i < 3 * P; ++i) dX[i] = tp[i] - u[i];
+    std::vector<double> ds(M);
+    std::vector<double> mterm(M);
+#pragma omp parallel for schedule(static)
+    for (i64 k = 0; k < M; ++k) {
+      const V3 d = dvec(k, c, X);
+      const V3 r = ld3(v + 3 * k) - s[k] * d;
+      const V3 e = mc * ld3(&dc[3 * (i64)cam[k]]) - mx * ld3(&dX[3 * (i64)pt[k]]);
+      const double m = (k == 0 ? 0.0 : ms);
+      ds[k] = qb[k] * dot(d, r + s[k] * e);  // qb = m w / h~ss
+      (void)m;
+      // model: J delta = sqrt(w) (s e - m d ds), r~ = sqrt(w) r
+      const V3 jd = s[k] * e - (m * ds[k]) * d;
+      mterm[k] = w[k] * (dot(jd, r) + 0.5 * dot(jd, jd));
+    }
+    *model_change = -chunked_sum(M, [&](i64 k) { return mterm[k]; });
+    // candidate = Plus(x, delta), scales projected on their lower bound
+    c2.resize(3 * N);
+    X2.resize(3 * P);
+    s2.resize(M);
+    for (i64 i = 0; i < 3 * N; ++i) c2[i] = c[i] + mc * dc[i];
+#pragma omp parallel for schedule(static)
+    for (i64 i = 0; i < 3 * P; ++i) X2[i] = X[i] + mx * dX[i];
+#pragma omp parallel for schedule(static)
+    for (i64 k = 0; k < M; ++k) s2[k] = std::max(s[k] + (k == 0 ? 0.0 : ms) * ds[k], 1e-5);
+    double sn = chunked_sum(3 * N, [&](i64 i) { const double d = c2[i] - c[i]; return d * d; });
+    sn += chunked_sum(3 * P, [&](i64 i) { const double d = X2[i] - X[i]; return d * d; });
+    sn += chunked_sum(M, [&](i64 k) { const double d = s2[k] - s[k]; return d * d; });
+    double xn = chunked_sum(3 * N, [&](i64 i) { return c[i] * c[i]; });
+    xn += chunked_sum(3 * P, [&](i64 i) { return X[i] * X[i]; });
+    xn += chunked_sum(M, [&](i64 k) { return s[k] * s[k]; });
+    *step_norm = std::sqrt(sn);
+    *x_norm = std::sqrt(xn);
+    *cand_cost = cost_at(c2, X2, s2);
+    bool finite = std::isfinite(sn);
+    return finite;
+  }
+
+  void apply_points_only(const std::vector<double>& z) {
+#pragma omp parallel for schedule(dynamic, 256)
+    for (i64 p = 0; p < P; ++p) {
+      double a[3] = {0, 0, 0};
+      auto body = [&](i64 k) {
+        const V3 d = dvec(k, c, X);
+        const V3 zc = ld3(&z[3 * (i64)cam[k]]);
+        const V3 q = qa[k] * (zc - (qb[k] * dot(d, zc)) * d);
+        a[0] += q.x;
+        a[1] += q.y;
+        a[2] += q.z;
+      };
+      if (!rev)
+        for (i64 k = poff[p]; k < poff[p + 1]; ++k) body(k);
+      else
+        for (i64 k = poff[p + 1] - 1; k >= poff[p]; --k) body(k);
+      const double* H = &Hinv[6 * p];
+      const double f = mc * mx;
+      tp[3 * p] = f * (H[0] * a[0] + H[1] * a[1] + H[2] * a[2]);
+      tp[3 * p + 1] = f * (H[1] * a[0] + H[3] * a[1] + H[4] * a[2]);
+      tp[3 * p + 2] = f * (H[2] * a[0] + H[4] * a[1] + H[5] * a[2]);
+    }
+  }
+
+  void accept() override {
+    c.swap(c2);
+    X.swap(X2);
+    s.swap(s2);
+  }
+};
+
+}  // namespace
+}  // namespace orc
+
+extern "C" {
+using orc::i64;
+
+// Arrays as gsfm_gp_problem (include/gsfm.h).  cam_center_inout [N][3], pt_xyz_inout [P][3].
+// Returns 0 when the solution is usable, -5 for an empty problem, -6 when not usable.
+int orc_gp_solve(int32_t num_cams, i64 num_pts, const i64* pt_offset, const int32_t* obs_cam, const double* obs_dir,
+                 const uint8_t* obs_calibrated, const orc::GpOptionsC* o, double* cam_center_inout, double* pt_xyz_inout,
+                 orc::GpReport* rep, int32_t num_threads) {
+  using namespace orc;
+  const double t0 = omp_get_wtime();
+  if (num_threads > 0) omp_set_num_threads(num_threads);
+  Gp g;
+  g.N = num_cams;
+  std::vector<i64> used_pts;
+  g.poff.push_back(0);
+  for (i64 p = 0; p < num_pts; ++p) {
+    const i64 len = pt_offset[p + 1] - pt_offset[p];
+    if (len < o->min_num_view_per_track) continue;  // gp.cc:258
+    const i64 id = (i64)used_pts.size();
+    used_pts.push_back(p);
+    for (i64 k = pt_offset[p]; k < pt_offset[p + 1]; ++k) {
+      g.cam.push_back(obs_cam[k]);
+      g.pt.push_back((int32_t)id);
+      g.vbuf.push_back(obs_dir[3 * k]);
+      g.vbuf.push_back(obs_dir[3 * k + 1]);
+      g.vbuf.push_back(obs_dir[3 * k + 2]);
+      g.cal.push_back(obs_calibrated ? obs_calibrated[k] : 1);
+    }
+    g.poff.push_back((i64)g.cam.size());
+  }
+  g.P = (i64)used_pts.size();
+  g.M = (i64)g.cam.size();
+  std::memset(rep, 0, sizeof *rep);
+  rep->threads = omp_get_max_threads();
+  if (g.M == 0) return -5;
+  g.v = g.vbuf.data();
+  g.bycam.build(g.N, g.M, g.cam.data());
+  g.loss_cal = {o->thres_loss_function, 1.0};
+  g.loss_unc = {o->thres_loss_function, 0.5};
+  g.mc = o->optimize_positions ? 1.0 : 0.0;
+  g.mx = o->optimize_points ? 1.0 : 0.0;
+  g.ms = o->optimize_scales ? 1.0 : 0.0;
+  g.lm_lo = o->min_lm_diagonal;
+  g.lm_hi = o->max_lm_diagonal;
+  g.rev = o->order != 0;
+  g.pcg_tol = o->pcg_relative_tolerance;
+  g.pcg_max = o->pcg_max_iterations;
+  g.c.assign(cam_center_inout, cam_center_inout + 3 * g.N);
+  g.X.resize(3 * g.P);
+  for (i64 i = 0; i < g.P; ++i)
+    for (int j = 0; j < 3; ++j) g.X[3 * i + j] = pt_xyz_inout[3 * used_pts[i] + j];
+  // random initialisation, gp.cc:123-165,261-264
+  std::mt19937 gen(o->seed);
+  std::uniform_real_distribution<double> uni(-1.0, 1.0);
+  if (o->generate_random_positions && o->optimize_positions) {
+    std::vector<uint8_t> constrained(g.N, 0);
+    for (i64 k = 0; k < g.M; ++k) constrained[g.cam[k]] = 1;
+    for (i64 n = 0; n < g.N; ++n)
+      if (constrained[n])
+        for (int j = 0; j < 3; ++j) g.c[3 * n + j] = 100.0 * uni(gen);
+  }
+  if (o->generate_random_points && o->optimize_points)
+    for (i64 i = 0; i < 3 * g.P; ++i) g.X[i] = 100.0 * uni(gen);
+  g.s.assign(g.M, 1.0);
+  if (!o->generate_scales)
+    for (i64 k = 0; k < g.M; ++k) {
+      const V3 d = g.dvec(k, g.c, g.X);
+      g.s[k] = std::max(1e-5, dot(ld3(g.v + 3 * k), d) / dot(d, d));
+    }
+  LmOptions lo;
+  lo.max_num_iterations = o->max_num_iterations;
+  lo.function_tolerance = o->function_tolerance;
+  lo.gradient_tolerance = o->gradient_tolerance;
+  lo.parameter_tolerance = o->parameter_tolerance;
+  lo.initial_trust_region_radius = o->initial_trust_region_radius;
+  lo.max_trust_region_radius = o->max_trust_region_radius;
+  lo.min_trust_region_radius = o->min_trust_region_radius;
+  lo.min_relative_decrease = o->min_relative_decrease;
+  lo.min_lm_diagonal = o->min_lm_diagonal;
+  lo.max_lm_diagonal = o->max_lm_diagonal;
+  lo.jacobi_scaling = o->jacobi_scaling;
+  lo.max_num_consecutive_invalid_steps = o->max_num_consecutive_invalid_steps;
+  lo.verbose = o->verbose;
+  LmSummary s;
+  lm_minimize(g, lo, &s);
+  std::memcpy(cam_center_inout, g.c.data(), sizeof(double) * 3 * g.N);
+  for (i64 i = 0; i < g.P; ++i)
+    for (int j = 0; j < 3; ++j) pt_xyz_inout[3 * used_pts[i] + j] = g.X[3 * i + j];
+  rep->iterations = s.iterations;
+  rep->successful_steps = s.successful_steps;
+  rep->termination = s.termination;
+  rep->usable = s.usable;
+  rep->linear_iterations = s.linear_iterations;
+  rep->initial_cost = s.initial_cost;
+  rep->final_cost = s.final_cost;
+  rep->max_linear_residual = s.max_linear_residual;
+  rep->seconds_linear = s.seconds_linear;
+  rep->seconds_total = omp_get_wtime() - t0;
+  return s.usable ? 0 : -6;
+}
+
+int orc_num_threads(void) { return omp_get_max_threads(); }
+}

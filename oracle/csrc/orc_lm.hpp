@@ -1,0 +1,193 @@
+// ORACLE (test infrastructure only — never linked into or called by the product path).
+//
+// orc_lm.hpp — the Ceres trust-region Levenberg-Marquardt loop that GlobalPositioner and
+// BundleAdjuster run through ceres::Solve (glomap/estimators/global_positioning.cc:83,
+// bundle_adjustment.cc:99; options optimization_base.h:18-23 + Ceres defaults),
+// restated decision by decision exactly as oracle/lm.py states it (that file's header lists the
+// Ceres sources followed).  The linear system of every step is solved "exactly": the problem
+// eliminates its independent blocks (GP: scales, then points; BA: points) in closed form and
+// solves the reduced camera system by preconditioned CG to a relative residual of 1e-14 (or
+// until the residual stops decreasing), where oracle/lm.py uses a dense / SuperLU solve.
+//
+// parity unpinned: no reference test pins LM iterates.
+#pragma once
+
+#include "orc_common.hpp"
+
+namespace orc {
+
+struct LmOptions {
+  int max_num_iterations = 100;
+  double function_tolerance = 1e-5;
+  double gradient_tolerance = 1e-10;
+  double parameter_tolerance = 1e-8;
+  double initial_trust_region_radius = 1e4;
+  double max_trust_region_radius = 1e16;
+  double min_trust_region_radius = 1e-32;
+  double min_relative_decrease = 1e-3;
+  double min_lm_diagonal = 1e-6;
+  double max_lm_diagonal = 1e32;
+  int jacobi_scaling = 1;
+  int max_num_consecutive_invalid_steps = 5;
+  // reduced-system solve (replaces the exact factorisation)
+  double pcg_relative_tolerance = 1e-14;
+  int pcg_max_iterations = 20000;
+  int order = 0;    // 1: reverse the summation order of every owner-side reduction (rounding experiments)
+  int verbose = 0;
+};
+
+struct LmSummary {
+  int iterations = 0;
+  int successful_steps = 0;
+  i64 linear_iterations = 0;
+  double initial_cost = 0.0, final_cost = 0.0;
+  int termination = 1;  // 0 convergence, 1 no convergence (iteration cap), 2 failure
+  int usable = 1;
+  double max_linear_residual = 0.0;  // largest TRUE relative residual |b - S x| / |b| over all linear solves
+  double seconds_linear = 0.0;
+};
+
+struct LmProblem {
+  virtual ~LmProblem() = default;
+  virtual double linearize(double* grad_max_norm) = 0;
+  virtual void set_jacobi_scaling(bool enabled) = 0;
+  virtual bool step(double radius, double* model_change, double* cand_cost, double* step_norm, double* x_norm,
+                    i64* linear_iterations, double* true_rel_residual) = 0;
+  virtual void accept() = 0;
+};
+
+inline void lm_minimize(LmProblem& prob, const LmOptions& o, LmSummary* s) {
+  double gmax = 0.0;
+  double cost = prob.linearize(&gmax);
+  prob.set_jacobi_scaling(o.jacobi_scaling != 0);
+  s->initial_cost = cost;
+  double radius = o.initial_trust_region_radius;
+  double decrease_factor = 2.0;
+  int invalid = 0;
+  if (o.verbose) fprintf(stderr, "[orc lm] it 0 cost %.9e gmax %.3e\n", cost, gmax);
+  if (!(gmax > o.gradient_tolerance)) {
+    s->termination = 0;
+  } else {
+    while (true) {
+      if (s->iterations >= o.max_num_iterations) {
+        s->termination = 1;
+        break;
+      }
+      if (radius < o.min_trust_region_radius) {
+        s->termination = 0;
+        break;
+      }
+      ++s->iterations;
+      double model_change = 0.0, cand_cost = 0.0, step_norm = 0.0, x_norm = 0.0, relres = 0.0;
+      i64 lin = 0;
+      const double t0 = omp_get_wtime();
+      bool valid = prob.step(radius, &model_change, &cand_cost, &step_norm, &x_norm, &lin, &relres);
+      s->seconds_linear += omp_get_wtime() - t0;
+      s->linear_iterations += lin;
+      s->max_linear_residual = std::max(s->max_linear_residual, relres);
+      if (o.verbose)
+        fprintf(stderr, "[orc lm] it %d radius %.3e pcg %lld (true relres %.2e) model %.6e cand %.9e (cost %.9e) step %.3e\n",
+                s->iterations, radius, lin, relres, model_change, cand_cost, cost, step_norm);
+      valid = valid && std::isfinite(model_change) && model_change > 0.0;
+      if (!valid) {
+        // Ceres: ++num_consecutive_invalid_steps >= max_num_consecutive_invalid_steps -> failure
+        if (++invalid >= o.max_num_consecutive_invalid_steps) {
+          s->termination = 2;
+          s->usable = 0;
+          break;
+        }
+        radius *= 0.5;
+        continue;
+      }
+      invalid = 0;
+      if (step_norm <= o.parameter_tolerance * (x_norm + o.parameter_tolerance)) {
+        s->termination = 0;
+        break;
+      }
+      const double cost_change = cost - cand_cost;
+      if (std::fabs(cost_change) <= o.function_tolerance * cost) {
+        s->termination = 0;
+        break;
+      }
+      const double rho = cost_change / model_change;
+      if (rho > o.min_relative_decrease) {
+        prob.accept();
+        cost = prob.linearize(&gmax);
+        ++s->successful_steps;
+        if (!(gmax > o.gradient_tolerance)) {
+          s->termination = 0;
+          break;
+        }
+        const double t = 2.0 * rho - 1.0;
+        radius = radius / std::max(1.0 / 3.0, 1.0 - t * t * t);
+        radius = std::min(o.max_trust_region_radius, radius);
+        decrease_factor = 2.0;
+      } else {
+        radius = radius / decrease_factor;
+        decrease_factor *= 2.0;
+      }
+    }
+  }
+  s->final_cost = cost;
+}
+
+// Preconditioned conjugate gradients on an SPD operator, classic two-reduction form.
+//   apply(z, w): w = S z;   precond(r, z): z = M^-1 r.
+// Stops at |r| <= tol |b| (recurrence residual), at max_it, or when the residual has not improved
+// by a factor 0.999 over 50 iterations (rounding floor).  Returns the iteration count and writes the
+// TRUE relative residual |b - S x| / |b| of the returned x.
+template <class Apply, class Precond>
+i64 pcg(i64 n, const std::vector<double>& b, std::vector<double>& x, double tol, int max_it, Apply apply, Precond precond,
+        double* true_relres) {
+  std::vector<double> r(b), z(n), p(n), w(n);
+  std::fill(x.begin(), x.end(), 0.0);
+  const double bnorm = std::sqrt(vdot(b, b));
+  *true_relres = 0.0;
+  if (!(bnorm > 0.0)) return 0;
+  precond(r, z);
+  p = z;
+  double rz = vdot(r, z);
+  double best = bnorm;
+  int since_best = 0;
+  i64 it = 0;
+  while (it < max_it) {
+    apply(p, w);
+    const double pw = vdot(p, w);
+    if (!(pw > 0.0) || !std::isfinite(pw)) break;
+    const double alpha = rz / pw;
+    double *px = x.data(), *pr = r.data();
+    const double *pp = p.data(), *pwv = w.data();
+#pragma omp parallel for schedule(static)
+    for (i64 i = 0; i < n; ++i) {
+      px[i] += alpha * pp[i];
+      pr[i] -= alpha * pwv[i];
+    }
+    ++it;
+    const double rnorm = std::sqrt(vdot(r, r));
+    if (rnorm <= tol * bnorm) break;
+    if (rnorm < 0.999 * best) {
+      best = rnorm;
+      since_best = 0;
+    } else if (++since_best >= 50) {
+      break;
+    }
+    precond(r, z);
+    const double rz_new = vdot(r, z);
+    const double beta = rz_new / rz;
+    rz = rz_new;
+    double* ppm = p.data();
+    const double* pz = z.data();
+#pragma omp parallel for schedule(static)
+    for (i64 i = 0; i < n; ++i) ppm[i] = pz[i] + beta * ppm[i];
+  }
+  apply(x, w);
+  const double *pb = b.data(), *pwv = w.data();
+  const double rr = chunked_sum(n, [=](i64 i) {
+    const double d = pb[i] - pwv[i];
+    return d * d;
+  });
+  *true_relres = std::sqrt(rr) / bnorm;
+  return it;
+}
+
+}  // namespace orc

@@ -183,7 +183,8 @@ def solve(problem, x0, options: LmOptions):
             valid = model_change > 0.0
         if not valid:
             invalid += 1
-            if invalid > o.max_num_consecutive_invalid_steps:
+            # Ceres: ++num_consecutive_invalid_steps >= max_num_consecutive_invalid_steps -> FAILURE
+            if invalid >= o.max_num_consecutive_invalid_steps:
                 summ.termination = "FAILURE (invalid steps)"
                 summ.usable = False
                 break
