@@ -285,6 +285,8 @@ def load():
     lib.gsfm_ra_solve.argtypes = [vp, C.POINTER(RaProblemC), C.POINTER(RaOptions), vp, C.POINTER(Report)]
     lib.gsfm_ra_residuals.restype = ip
     lib.gsfm_ra_residuals.argtypes = [vp, C.POINTER(RaProblemC), C.POINTER(RaOptions), vp, vp, vp]
+    lib.gsfm_ra_residuals_timed.restype = ip
+    lib.gsfm_ra_residuals_timed.argtypes = [vp, C.POINTER(RaProblemC), C.POINTER(RaOptions), vp, ip, dp]
     lib.gsfm_ra_laplacian_apply.restype = ip
     lib.gsfm_ra_laplacian_apply.argtypes = [vp, C.POINTER(RaProblemC), vp, vp, vp, ip, dp]
     if hasattr(lib, "gsfm_gp_solve"):

@@ -246,6 +246,36 @@ const T* dev_in(gsfm_ctx* ctx, DevBuf<T>& buf, const T* src, size_t n, int mem) 
   return dst;
 }
 
+// Index sanity of the flat arrays (a malformed view must come back as GSFM_ERR_INVALID_ARGUMENT, not as out-of-bounds
+// device reads): pt_offset starts at 0, is monotone and ends at M; every obs_cam / cam_intr / edge endpoint is in range.
+__global__ void __launch_bounds__(kBlock)
+    k_validate_view(long P, long M, int N, const long* __restrict__ off, const int* __restrict__ cam,
+                    const int* __restrict__ cam_intr, int K, unsigned long long* __restrict__ bad) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  bool err = false;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < M || i <= P || i < N; i += stride) {
+    if (i < M && (cam[i] < 0 || cam[i] >= N)) err = true;
+    if (i < P && (off[i] > off[i + 1] || off[i] < 0)) err = true;
+    if (i == P && (off[P] != M || off[0] != 0)) err = true;
+    if (cam_intr != nullptr && i < N && (cam_intr[i] < 0 || cam_intr[i] >= K)) err = true;
+  }
+  if (err) *bad = 1ull;
+}
+__global__ void __launch_bounds__(kBlock)
+    k_validate_edges(long E, int N, const int* __restrict__ ei, const int* __restrict__ ej, unsigned long long* __restrict__ bad) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  bool err = false;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < E; e += stride)
+    if (ei[e] < 0 || ei[e] >= N || ej[e] < 0 || ej[e] >= N) err = true;
+  if (err) *bad = 1ull;
+}
+
+long read_counter(gsfm_ctx* ctx, FilterWs* ws);
+
+void require_valid(gsfm_ctx* ctx, FilterWs* ws, const char* what) {
+  GSFM_REQUIRE(read_counter(ctx, ws) == 0, what);
+}
+
 void stage_view(gsfm_ctx* ctx, FilterWs* ws, const gsfm_scene_view* v, bool need_undist, bool need_pixels, ViewDev& d) {
   GSFM_REQUIRE(v && v->pt_offset && v->obs_cam && v->cam_q && v->cam_t && v->pt_xyz, "filter: null argument");
   GSFM_REQUIRE(v->num_cams > 0 && v->num_pts >= 0 && v->num_obs >= 0, "filter: bad sizes");
@@ -274,6 +304,12 @@ void stage_view(gsfm_ctx* ctx, FilterWs* ws, const gsfm_scene_view* v, bool need
     d.intr_params = dev_in(ctx, ws->intr, v->intr_params, 8 * (size_t)v->num_intr, mem);
   }
   if (v->cam_calibrated) d.calibrated = dev_in(ctx, ws->cal, v->cam_calibrated, (size_t)N, mem);
+  ws->counter.ensure(1);
+  GSFM_HIP_CHECK(hipMemsetAsync(ws->counter.get(), 0, sizeof(unsigned long long), ctx->stream));
+  const long span = std::max<long>(std::max<long>(M, P + 1), N);
+  hipLaunchKernelGGL(k_validate_view, dim3(grid_wide(span, kBlock, 1 << 16)), dim3(kBlock), 0, ctx->stream, P, M, N, d.off,
+                     d.cam, need_pixels ? d.cam_intr : nullptr, need_pixels ? v->num_intr : 0, ws->counter.get());
+  require_valid(ctx, ws, "filter: pt_offset / obs_cam / cam_intr out of range");
 }
 
 long read_counter(gsfm_ctx* ctx, FilterWs* ws) {
@@ -440,6 +476,11 @@ extern "C" int gsfm_filter_rotations(gsfm_ctx* ctx, int32_t mem, int32_t num_nod
     ws->keep.ensure(E + 1);
     ws->counter.ensure(1);
     GSFM_HIP_CHECK(hipMemsetAsync(ws->counter.get(), 0, sizeof(unsigned long long), s));
+    if (E > 0) {
+      hipLaunchKernelGGL(k_validate_edges, dim3(grid_wide(E, kBlock, 1 << 16)), dim3(kBlock), 0, s, E, num_nodes, ws->ei.get(),
+                         ws->ej.get(), ws->counter.get());
+      require_valid(ctx, ws, "filter: edge endpoint out of range");
+    }
     if (E > 0)
       hipLaunchKernelGGL(k_filter_rot, dim3(grid_wide(E, kBlock, 1 << 16)), dim3(kBlock), 0, s, E, ws->ei.get(), ws->ej.get(),
                          ws->eq.get(), ws->nq.get(), max_angle_deg, ws->keep.get(), ws->counter.get());

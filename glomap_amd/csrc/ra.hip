@@ -1565,6 +1565,41 @@ extern "C" int gsfm_ra_residuals(gsfm_ctx* ctx, const gsfm_ra_problem* prob, con
   });
 }
 
+// `repeat` back-to-back launches of the per-edge residual + IRLS-weight sweep (k_edge_residual) between two HIP events on
+// the ctx stream: the roofline measurement of SURVEY.md section 8d's K-RA-res on a graph that does not fit the caches.
+extern "C" int gsfm_ra_residuals_timed(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_options* opt,
+                                       const double* rot_aa, int repeat, double* avg_kernel_ms) {
+  if (!ctx) return GSFM_ERR_INVALID_ARGUMENT;
+  return guarded(ctx, nullptr, [&] {
+    GSFM_REQUIRE(prob && opt && rot_aa, "RA: null argument");
+    GSFM_HIP_CHECK(hipSetDevice(ctx->device));
+    gsfm_ra_options o = *opt;
+    o.skip_initialization = 1;
+    RaDevice d;
+    RaHostInit hi;
+    setup_device(ctx, prob, &o, rot_aa, d, hi);
+    finish_init(ctx, &o, d, hi);
+    RaWs* ws = d.ws;
+    hipStream_t s = ctx->stream;
+    const double sigma = o.irls_loss_parameter_sigma * M_PI / 180.0;
+    launch_residuals(d, true, o.weight_type, sigma * sigma);  // node quaternions + one warm-up sweep
+    GSFM_HIP_CHECK(hipStreamSynchronize(s));
+    const int reps = repeat > 0 ? repeat : 1;
+    GSFM_HIP_CHECK(hipEventRecord(ctx->ev0, s));
+    for (int r = 0; r < reps; ++r)
+      hipLaunchKernelGGL(k_edge_residual, dim3(d.gridE), dim3(kBlock), 0, s, d.E, ws->ei.get(), ws->ej.get(), ws->eq.get(),
+                         ws->nq.get(), ws->res.get(), ws->wirls.get(), o.weight_type, sigma * sigma, ws->flags.get());
+    GSFM_HIP_CHECK(hipEventRecord(ctx->ev1, s));
+    GSFM_HIP_CHECK(hipStreamSynchronize(s));
+    if (avg_kernel_ms) {
+      float ms = 0.f;
+      GSFM_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+      *avg_kernel_ms = ms / reps;
+    }
+    return (int)GSFM_OK;
+  });
+}
+
 extern "C" int gsfm_ra_laplacian_apply(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const double* w,
                                        const double* x, double* y, int repeat, double* avg_kernel_ms) {
   if (!ctx) return GSFM_ERR_INVALID_ARGUMENT;

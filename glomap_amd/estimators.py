@@ -219,6 +219,21 @@ def ra_residuals(p: RaProblem, rot_aa: np.ndarray, options: Optional[RotationEst
     return res, w
 
 
+def ra_residuals_timed(p: RaProblem, rot_aa, repeat: int = 10, options: Optional[RotationEstimatorOptions] = None, ctx=None):
+    """Average kernel milliseconds of the per-edge residual + IRLS-weight sweep (gsfm_ra_residuals_timed)."""
+    ctx = ctx or default_context()
+    opt = (options or RotationEstimatorOptions()).to_c()
+    keep: list = []
+    c = _ra_problem_c(p, keep)
+    rot = _h(rot_aa, np.float64)
+    assert _mem_of(rot) == c.mem
+    ms = C.c_double(0.0)
+    rc = ctx.lib.gsfm_ra_residuals_timed(ctx.handle, C.byref(c), C.byref(opt), _lib.ptr(rot), repeat, C.byref(ms))
+    if rc != 0:
+        raise _lib.GsfmError(rc, "gsfm_ra_residuals_timed")
+    return ms.value
+
+
 def ra_laplacian_apply(p: RaProblem, w, x, repeat: int = 1, ctx=None):
     ctx = ctx or default_context()
     keep: list = []

@@ -203,6 +203,10 @@ int gsfm_ra_solve(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
  * IRLS weight (gra.cc:583-588).  Either output may be NULL. */
 int gsfm_ra_residuals(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_options* opt,
                       const double* rot_aa, double* residual_out, double* weight_out);
+/* `repeat` launches of the per-edge residual / IRLS-weight sweep (the kernel behind gsfm_ra_residuals) for timing;
+ * reports the average kernel milliseconds (HIP events on the ctx stream). */
+int gsfm_ra_residuals_timed(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_options* opt,
+                            const double* rot_aa, int repeat, double* avg_kernel_ms);
 /* y = (L_w (x) I3 + gauge) x for the IRLS-weighted Laplacian; x,y [N][3]; w [E] edge weights.
  * `repeat` launches of the SpMV kernel (for timing); reports average kernel milliseconds. */
 int gsfm_ra_laplacian_apply(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const double* w,

@@ -144,11 +144,17 @@ struct TrackPack {
   std::vector<uint32_t> obs_feature;
 };
 
+// `min_views` is tested on the RAW observation count like the reference does (track.observations.size(), gp.cc:258 /
+// ba.cc:122) — BEFORE unregistered images / failed undistortions are dropped — so a track with 3 raw observations of
+// which one is unusable is still optimised.  Shorter tracks are not packed at all (the estimators leave them untouched);
+// the library is then called with min_num_view_per_track = 1.
 template <typename Keep>
 inline TrackPack PackTracks(std::unordered_map<image_t, glomap::Image>& images,
-                            std::unordered_map<track_t, glomap::Track>& tracks, FrameIndex& fidx, Keep keep) {
+                            std::unordered_map<track_t, glomap::Track>& tracks, FrameIndex& fidx, Keep keep,
+                            size_t min_views = 0) {
   TrackPack tp;
   for (auto& [tid, track] : tracks) {
+    if (track.observations.size() < min_views) continue;
     const size_t before = tp.obs_cam.size();
     for (const auto& obs : track.observations) {
       auto it = images.find(obs.first);
@@ -204,7 +210,11 @@ class RotationEstimator {
       en.push_back(static_cast<int32_t>(pair.inliers.size()));
     }
     std::vector<double> rot(3 * static_cast<size_t>(N));
-    for (int n = 0; n < N; ++n) detail::QuatToAngleAxis(frames.at(fidx.ids[n]).RigFromWorld().rotation, &rot[3 * n]);
+    for (int n = 0; n < N; ++n) {
+      auto& fr = frames.at(fidx.ids[n]);
+      if (!fr.HasPose()) fr.SetRigFromWorld(glomap::Rigid3d());  // gra.cc:219-222 (colmap::Frame::RigFromWorld() throws without a pose)
+      detail::QuatToAngleAxis(fr.RigFromWorld().rotation, &rot[3 * n]);
+    }
     gsfm_ra_options o;
     gsfm_ra_options_default(&o);
     o.max_num_l1_iterations = options_.max_num_l1_iterations;
@@ -266,7 +276,7 @@ class GlobalPositioner {
       const auto& v = im.features_undist[f];
       return !(std::isnan(v[0]) || std::isnan(v[1]) || std::isnan(v[2]));
     };
-    detail::TrackPack tp = detail::PackTracks(images, tracks, fidx, keep);
+    detail::TrackPack tp = detail::PackTracks(images, tracks, fidx, keep, static_cast<size_t>(options_.min_num_view_per_track));
     const int N = static_cast<int>(fidx.ids.size());
     const int64_t P = static_cast<int64_t>(tp.track_ids.size()), M = static_cast<int64_t>(tp.obs_cam.size());
     if (P == 0) return false;
@@ -296,7 +306,7 @@ class GlobalPositioner {
     o.optimize_positions = options_.optimize_positions;
     o.optimize_points = options_.optimize_points;
     o.optimize_scales = options_.optimize_scales;
-    o.min_num_view_per_track = options_.min_num_view_per_track;
+    o.min_num_view_per_track = 1;  // the raw-count rule was applied by PackTracks
     o.seed = options_.seed;
     gsfm_gp_problem pr{};
     pr.mem = GSFM_MEM_HOST;
@@ -317,8 +327,7 @@ class GlobalPositioner {
       pose.translation = decltype(pose.translation)(-t[0], -t[1], -t[2]);
       fr.SetRigFromWorld(pose);
     }
-    for (int64_t p = 0; p < P; ++p) {
-      if (tp.pt_offset[p + 1] - tp.pt_offset[p] < options_.min_num_view_per_track) continue;  // untouched (gp.cc:258)
+    for (int64_t p = 0; p < P; ++p) {  // every packed track passed the raw-count rule (gp.cc:258)
       auto& tr = tracks.at(tp.track_ids[p]);
       tr.xyz = decltype(tr.xyz)(xyz[3 * p], xyz[3 * p + 1], xyz[3 * p + 2]);
       tr.is_initialized = true;  // gp.cc:262-263
@@ -346,18 +355,25 @@ class BundleAdjuster {
     if (images.empty() || tracks.empty()) return false;  // ba.cc:17-24
     if (!detail::AllTrivial(images) || options_.optimize_rig_poses) return false;
     detail::FrameIndex fidx;
-    // the constant frame is the first frame with a pose in map order (ba.cc:253-269)
-    int fixed = -1;
-    for (auto& [fid, fr] : frames) {
-      if (!fr.HasPose()) continue;
-      const int n = fidx.Add(fid);
-      if (fixed < 0) fixed = n;
-    }
+    for (auto& [fid, fr] : frames)
+      if (fr.HasPose()) fidx.Add(fid);  // dense indices in map order, the order ParameterizeVariables walks (ba.cc:253)
+    const int num_posed = static_cast<int>(fidx.ids.size());
     auto keep = [](const glomap::Image& im, uint32_t) { return im.frame_ptr != nullptr; };  // ba.cc:124-127: no IsRegistered test
-    detail::TrackPack tp = detail::PackTracks(images, tracks, fidx, keep);
+    detail::TrackPack tp = detail::PackTracks(images, tracks, fidx, keep, static_cast<size_t>(options_.min_num_view_per_track));
     const int N = static_cast<int>(fidx.ids.size());
     const int64_t P = static_cast<int64_t>(tp.track_ids.size()), M = static_cast<int64_t>(tp.obs_cam.size());
     if (N == 0 || P == 0) return false;
+    // The constant frame is the first frame IN THE PROBLEM in map order: the reference's counter only advances for
+    // frames that own a parameter block (ba.cc:253-269), i.e. frames observed by a track that passed ba.cc:122.  A posed
+    // but unobserved leading frame (GLOMAP gives every frame a pose, also those outside the largest component) must not
+    // take the gauge away from the optimised cameras.
+    int fixed = -1;
+    {
+      std::vector<uint8_t> in_problem(static_cast<size_t>(N), 0);
+      for (int32_t n : tp.obs_cam) in_problem[n] = 1;
+      for (int n = 0; n < num_posed && fixed < 0; ++n)
+        if (in_problem[n]) fixed = n;
+    }
     // intrinsics blocks = COLMAP cameras
     std::unordered_map<camera_t, int> intr_of;
     std::vector<camera_t> intr_ids;
@@ -405,7 +421,7 @@ class BundleAdjuster {
     o.optimize_intrinsics = options_.optimize_intrinsics;
     o.optimize_principal_point = options_.optimize_principal_point;
     o.optimize_points = options_.optimize_points;
-    o.min_num_view_per_track = options_.min_num_view_per_track;
+    o.min_num_view_per_track = 1;  // the raw-count rule was applied by PackTracks
     gsfm_ba_problem pr{};
     pr.mem = GSFM_MEM_HOST;
     pr.num_cams = N;
@@ -427,8 +443,7 @@ class BundleAdjuster {
       pose.translation = decltype(pose.translation)(t[3 * n], t[3 * n + 1], t[3 * n + 2]);
       fr.SetRigFromWorld(pose);
     }
-    for (int64_t p = 0; p < P; ++p) {
-      if (tp.pt_offset[p + 1] - tp.pt_offset[p] < options_.min_num_view_per_track) continue;  // ba.cc:122
+    for (int64_t p = 0; p < P; ++p) {  // every packed track passed the raw-count rule (ba.cc:122)
       auto& tr = tracks.at(tp.track_ids[p]);
       tr.xyz = decltype(tr.xyz)(xyz[3 * p], xyz[3 * p + 1], xyz[3 * p + 2]);
     }

@@ -141,10 +141,44 @@ int main() {
   if (std::fabs(ratio / ratio_ref - 1.0) > 1e-3) return std::printf("GP ratio %.6f vs %.6f\n", ratio, ratio_ref), 1;
   for (int n = 0; n < N; ++n) images[n].frame_ptr = &frames[n];
 
-  // 3) bundle adjustment from perturbed points: must reach (numerically) zero reprojection error
+  // 3) bundle adjustment from perturbed points: must reach (numerically) zero reprojection error.
+  //    A posed frame that no track observes is added LAST (libstdc++ iterates it FIRST): the reference's gauge is the first
+  //    frame that owns a parameter block (bundle_adjustment.cc:253-269), so exactly one OBSERVED frame must stay bit-identical
+  //    and the unobserved one must not be touched; a track with 3 raw observations of which one points to an image that is
+  //    not in `images` is still optimised (raw-count rule, bundle_adjustment.cc:122-125).
+  {
+    Frame extra;
+    Rigid3d pe;
+    pe.translation = mock_eigen::Vector3d(1.0, 2.0, 3.0);
+    extra.SetRigFromWorld(pe);
+    frames[1000] = extra;
+    for (int n = 0; n < N; ++n) images[n].frame_ptr = &frames[n];
+  }
+  const track_t short_id = 7;  // stride 2 -> 8 observations: cut to 2 usable + 1 dangling
+  {
+    auto& tr = tracks[short_id];
+    tr.observations.resize(2);
+    tr.observations.emplace_back((image_t)4242, (feature_t)0);
+  }
+  const auto short_xyz_before = tracks[short_id].xyz;
+  auto frames_before = frames;
   BundleAdjusterOptions bo;
   gsfm_glomap::BundleAdjuster ba(bo);
   if (!ba.Solve(rigs, cameras, frames, images, tracks)) return std::printf("BA failed\n"), 1;
+  {
+    int untouched = 0;
+    for (int n = 0; n < N; ++n) {
+      const auto &a = frames[n].RigFromWorld(), &b = frames_before[n].RigFromWorld();
+      if (a.rotation.w() == b.rotation.w() && a.rotation.y() == b.rotation.y() && a.translation[0] == b.translation[0] &&
+          a.translation[2] == b.translation[2])
+        ++untouched;
+    }
+    if (untouched != 1) return std::printf("BA gauge: %d observed frames constant, expected 1\n", untouched), 1;
+    if (frames[1000].RigFromWorld().translation[1] != 2.0) return std::printf("BA touched an unobserved frame\n"), 1;
+    const auto& x = tracks[short_id].xyz;
+    if (x[0] == short_xyz_before[0] && x[1] == short_xyz_before[1]) return std::printf("BA skipped the 3-raw-observation track\n"), 1;
+    tracks[short_id].observations.pop_back();  // the checks below look every image up
+  }
   double maxerr = 0;
   for (auto& [tid, tr] : tracks)
     for (auto& ob : tr.observations) {

@@ -4,6 +4,7 @@
 // a repository that does not vendor GLOMAP: nothing here is reference code.
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 #include <unordered_map>
 #include <utility>
@@ -69,8 +70,15 @@ struct Frame {
   bool has_pose = false;
   Rigid3d pose;
   bool HasPose() const { return has_pose; }
-  Rigid3d& RigFromWorld() { return pose; }
-  const Rigid3d& RigFromWorld() const { return pose; }
+  // colmap::Frame::RigFromWorld() THROW_CHECKs that the pose is set; the stand-in aborts so that tests notice
+  Rigid3d& RigFromWorld() {
+    if (!has_pose) std::abort();
+    return pose;
+  }
+  const Rigid3d& RigFromWorld() const {
+    if (!has_pose) std::abort();
+    return pose;
+  }
   void SetRigFromWorld(const Rigid3d& p) {
     pose = p;
     has_pose = true;

@@ -123,3 +123,33 @@ def test_gpu_normalizer_and_rotation_filter_match_oracle(gsfm_ctx):
     k_o, n_o = of.filter_rotations(nq, g.edge_i, g.edge_j, g.edge_q, 5.0)
     k_g, n_g = pr.RelPoseFilter.FilterRotations(nq, g.edge_i, g.edge_j, g.edge_q, 5.0, ctx=gsfm_ctx)
     assert np.array_equal(k_g.astype(bool), k_o) and n_g == n_o
+
+
+@pytest.mark.gpu
+def test_gpu_filters_reject_malformed_views(gsfm_ctx):
+    """Out-of-range indices must come back as GSFM_ERR_INVALID_ARGUMENT, not as out-of-bounds device reads."""
+    from glomap_amd import _lib
+    from glomap_amd import processors as pr
+
+    p, q, t, undist, X = _scene(seed=0, ncam=20, npts=400)
+    bad_cam = p.obs_cam.copy()
+    bad_cam[17] = p.num_cams  # one past the end
+    bad_off = p.pt_offset.copy()
+    bad_off[5], bad_off[6] = bad_off[6], bad_off[5] - 1  # not monotone
+    short_off = p.pt_offset.copy()
+    short_off[-1] -= 1  # does not end at num_obs
+    for off, cam in ((p.pt_offset, bad_cam), (bad_off, p.obs_cam), (short_off, p.obs_cam)):
+        view = pr.SceneView(p.num_cams, off, cam, q, t, X, obs_undist=undist)
+        with pytest.raises(_lib.GsfmError) as e:
+            pr.TrackFilter.FilterTracksByAngle(view, 1.0, ctx=gsfm_ctx)
+        assert e.value.status == -1  # GSFM_ERR_INVALID_ARGUMENT
+    g = synthetic.make_ring_view_graph(50, 5, seed=1)
+    ej = g.edge_j.copy()
+    ej[3] = -1
+    with pytest.raises(_lib.GsfmError) as e:
+        pr.RelPoseFilter.FilterRotations(so3.rotmat_to_quat(g.gt_R), g.edge_i, ej, g.edge_q, 5.0, ctx=gsfm_ctx)
+    assert e.value.status == -1  # GSFM_ERR_INVALID_ARGUMENT
+    # the context is still usable afterwards
+    view = pr.SceneView(p.num_cams, p.pt_offset, p.obs_cam, q, t, X, obs_undist=undist)
+    k, c = pr.TrackFilter.FilterTracksByAngle(view, 1.0, ctx=gsfm_ctx)
+    assert k.shape[0] == p.num_obs
