@@ -247,7 +247,8 @@ __global__ void __launch_bounds__(kBlock)
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (kBlock / 64);
-  for (int n = wave; n < g.g.N; n += nwaves) {
+  for (int sg = wave; sg < g.g.S; sg += nwaves) {
+    const int n = g.g.seg_cam[sg];
     const int ik = g.cam_intr[n];
     const int model = g.intr_model[ik];
     const unsigned char bits = g.intr_free[ik];
@@ -257,7 +258,7 @@ __global__ void __launch_bounds__(kBlock)
     double acc[28];
 #pragma unroll
     for (int j = 0; j < 28; ++j) acc[j] = 0.0;
-    for (int k = g.g.coff[n] + lane; k < g.g.coff[n + 1]; k += 64) {
+    for (int k = g.g.seg_k[sg] + lane; k < g.g.seg_k[sg + 1]; k += 64) {
       ObsGeom o;
       obs_geom(R9, t3, ld3(X + 3 * (long)g.g.c_pt[k]), model, pp, o);
       const double r0 = o.valid ? o.px - g.c_xy[2 * (long)k] : 0.0;
@@ -283,6 +284,7 @@ __global__ void __launch_bounds__(kBlock)
       }
     }
     wave_allsum<28>(acc);
+    if (!cam_seg_total<28>(g.g, sg, n, acc, lane)) continue;
     if (lane == 0) {
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
@@ -430,7 +432,8 @@ __global__ void __launch_bounds__(kBlock)
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (kBlock / 64);
-  for (int n = wave; n < g.g.N; n += nwaves) {
+  for (int sg = wave; sg < g.g.S; sg += nwaves) {
+    const int n = g.g.seg_cam[sg];
     const int ik = g.cam_intr[n];
     const int model = g.intr_model[ik];
     const unsigned char bits = g.intr_free[ik];
@@ -440,7 +443,7 @@ __global__ void __launch_bounds__(kBlock)
     double acc[NACC];  // gred 6 | spose 21 | igred 8 | sii 36 | (JOINT) pose x intrinsics cross block 6 x 8
 #pragma unroll
     for (int j = 0; j < NACC; ++j) acc[j] = 0.0;
-    for (int k = g.g.coff[n] + lane; k < g.g.coff[n + 1]; k += 64) {
+    for (int k = g.g.seg_k[sg] + lane; k < g.g.seg_k[sg + 1]; k += 64) {
       const double w = c_w[k];
       if (w == 0.0) continue;
       const double* b = ptb + 12 * (long)g.g.c_pt[k];
@@ -486,6 +489,7 @@ __global__ void __launch_bounds__(kBlock)
       }
     }
     wave_allsum<NACC>(acc);
+    if (!cam_seg_total<NACC>(g.g, sg, n, acc, lane)) continue;
     if (lane == 0) {
       if constexpr (JOINT) {
 #pragma unroll
@@ -727,7 +731,8 @@ __global__ void __launch_bounds__(kBlock)
 __global__ void __launch_bounds__(kBlock)
     k_ba_phaseB(BaDev g, CgVec v, double yscale, const double* __restrict__ camR, const double* __restrict__ t,
                 const double* __restrict__ par, const double* __restrict__ c_w,
-                const double* __restrict__ ptrec, const double* __restrict__ dvec, double* __restrict__ yi_part) {
+                const double* __restrict__ ptrec, const double* __restrict__ dvec, double* __restrict__ yi_part,
+                int multi_slot0) {
   __shared__ double sdelta[kBlock / 64];
   if (v.st->done) return;
   const int lane = threadIdx.x & 63;
@@ -735,7 +740,8 @@ __global__ void __launch_bounds__(kBlock)
   const int wave = blockIdx.x * (kBlock / 64) + wid;
   const int nwaves = gridDim.x * (kBlock / 64);
   double delta = 0.0;
-  for (int n = wave; n < g.g.N; n += nwaves) {
+  for (int sg = wave; sg < g.g.S; sg += nwaves) {
+    const int n = g.g.seg_cam[sg];
     const int ik = g.cam_intr[n];
     const int model = g.intr_model[ik];
     const unsigned char bits = g.intr_free[ik];
@@ -753,8 +759,8 @@ __global__ void __launch_bounds__(kBlock)
     for (int j = 0; j < 14; ++j) acc[j] = 0.0;
     // software-pipelined: the index -> 64-byte record gather of observation k + 64 is in flight while observation k
     // goes through its ~300 flops
-    const int kend = g.g.coff[n + 1];
-    int k = g.g.coff[n] + lane;
+    const int kend = g.g.seg_k[sg + 1];
+    int k = g.g.seg_k[sg] + lane;
     double w_nx = 0.0;
     V3 X_nx{0, 0, 0}, t_nx{0, 0, 0};
     if (k < kend) {
@@ -801,13 +807,22 @@ __global__ void __launch_bounds__(kBlock)
         if ((bits >> j) & 1) acc[6 + j] += o.Jp[0][j] * g0 + o.Jp[1][j] * g1;
     }
     wave_allsum<14>(acc);
+    if (!cam_seg_total<14>(g.g, sg, n, acc, lane)) continue;
     if (lane == 0) {
+      double dn = 0.0;
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
         const double wv = acc[j] + yscale * dvec[6 * (long)n + j] * zp[j];
         v.w[6 * (long)n + j] = wv;
-        delta += zp[j] * wv;
+        dn += zp[j] * wv;
       }
+      // a cut camera is finished by whichever slice arrives last: its share of delta goes to a slot of its own
+      // (behind the per-block slots and the phase-I slots), so that the sum does not depend on the arrival order
+      const int mi = g.g.seg_multi[sg];
+      if (mi < 0)
+        delta += dn;
+      else
+        v.dpart[multi_slot0 + mi] = dn;
 #pragma unroll
       for (int j = 0; j < 8; ++j) yi_part[8 * (long)n + j] = acc[6 + j];
     }
@@ -1241,7 +1256,7 @@ class BaSolver final : public LmProblem {
     gridP_ = grid_for(P_, kBlock);
     gridN_ = grid_for(N_, kBlock);
     gridM_ = grid_for(M_, kBlock);
-    gridCam_ = grid_wide(N_, kBlock / 64, kMaxApplySlots);  // one wave per camera (delta partial per block)
+    gridCam_ = grid_wide(g_.g.S, kBlock / 64, kMaxApplySlots);  // one wave per camera segment (delta partial per block)
     gridTile_ = grid_wide(g_.g.T, kBlock / 64);             // one wave per tile
     gridK_ = small_groups_ ? grid_for(K_, kBlock) : grid_for(K_, 1);
     gridTileP_ = grid_wide(g_.g.T, kBlock / 64, kMaxBlocks);  // tile sweeps that write per-block partials
@@ -1283,7 +1298,7 @@ class BaSolver final : public LmProblem {
     cg_.zrec_slot = joint_ ? ws->intr_slot.get() : nullptr;
     cg_.joint_map = joint_ ? ws->cam_intr.get() : nullptr;
     cg_.minv_joint = joint_ ? ws->minvj.get() : nullptr;
-    cg_.nb_apply = gridCam_ + gridK_;
+    cg_.nb_apply = gridCam_ + gridK_ + g_.g.nmulti;  // per-block slots | phase-I slots | one slot per cut camera
     cg_.b = ws->rhs.get();
     cg_.x = ws->cg_x.get();
     cg_.r = ws->cg_r.get();
@@ -1444,7 +1459,7 @@ class BaSolver final : public LmProblem {
       if (timed) ctx_->prof.end(s);
       timed = ctx_->prof.begin(s, GSFM_KERNEL_BA_SCHUR_B);
       hipLaunchKernelGGL(k_ba_phaseB, dim3(gridCam_), dim3(kBlock), 0, s, g_, cg_, yscale, R_, t_, par_,
-                         ws->c_w.get(), ws->ptrec.get(), ws->dvec.get(), ws->yi_part.get());
+                         ws->c_w.get(), ws->ptrec.get(), ws->dvec.get(), ws->yi_part.get(), gridCam_ + gridK_);
       if (timed) ctx_->prof.end(s);
       if (small_groups_) {
         hipLaunchKernelGGL(k_ba_phaseI_small, dim3(gridK_), dim3(kBlock), 0, s, g_, cg_, yscale, ws->yi_part.get(),

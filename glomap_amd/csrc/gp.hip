@@ -127,10 +127,11 @@ __global__ void __launch_bounds__(kBlock)
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (kBlock / 64);
-  for (int n = wave; n < g.g.N; n += nwaves) {
+  for (int sg = wave; sg < g.g.S; sg += nwaves) {
+    const int n = g.g.seg_cam[sg];
     const V3 cn = ld3(c + 3 * (long)n);
     double acc[4] = {0, 0, 0, 0};
-    for (int k = g.g.coff[n] + lane; k < g.g.coff[n + 1]; k += 64) {
+    for (int k = g.g.seg_k[sg] + lane; k < g.g.seg_k[sg + 1]; k += 64) {
       const long src = g.g.c_src[k];
       const V3 d = ld3(X + 3 * (long)g.g.c_pt[k]) - cn;
       const double sk = s[src];
@@ -144,6 +145,7 @@ __global__ void __launch_bounds__(kBlock)
       acc[3] += ws * r.z;
     }
     wave_allsum<4>(acc);
+    if (!cam_seg_total<4>(g.g, sg, n, acc, lane)) continue;
     if (lane == 0) {
       hcc[n] = acc[0];
       gc[3 * (long)n] = acc[1];
@@ -279,10 +281,11 @@ __global__ void __launch_bounds__(kBlock)
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (kBlock / 64);
-  for (int n = wave; n < g.g.N; n += nwaves) {
+  for (int sg = wave; sg < g.g.S; sg += nwaves) {
+    const int n = g.g.seg_cam[sg];
     const V3 cn = ld3(c + 3 * (long)n);
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int k = g.g.coff[n] + lane; k < g.g.coff[n + 1]; k += 64) {
+    for (int k = g.g.seg_k[sg] + lane; k < g.g.seg_k[sg + 1]; k += 64) {
       const long src = g.g.c_src[k];
       const double* b = ptb + 12 * (long)g.g.c_pt[k];
       const V3 d = ld3(b) - cn;
@@ -319,6 +322,7 @@ __global__ void __launch_bounds__(kBlock)
       acc[8] += Q.zz - c2.z;
     }
     wave_allsum<9>(acc);
+    if (!cam_seg_total<9>(g.g, sg, n, acc, lane)) continue;
     if (lane == 0) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) gred[3 * (long)n + j] = acc[j];
@@ -405,11 +409,12 @@ __global__ void __launch_bounds__(kBlock)
   const int wave = blockIdx.x * (kBlock / 64) + wid;
   const int nwaves = gridDim.x * (kBlock / 64);
   double delta = 0.0;
-  for (int n = wave; n < g.g.N; n += nwaves) {
+  for (int sg = wave; sg < g.g.S; sg += nwaves) {
+    const int n = g.g.seg_cam[sg];
     const V3 cn = ld3(c + 3 * (long)n);
     const V3 zn = ld3(v.z + 3 * (long)n);
     double acc[3] = {0, 0, 0};
-    for (int k = g.g.coff[n] + lane; k < g.g.coff[n + 1]; k += 64) {
+    for (int k = g.g.seg_k[sg] + lane; k < g.g.seg_k[sg + 1]; k += 64) {
       const long p = g.g.c_pt[k];
       const double ak = c_qa[k], bk = c_qb[k];
       V3 Xp, tp;
@@ -421,6 +426,7 @@ __global__ void __launch_bounds__(kBlock)
       acc[2] += y.z;
     }
     wave_allsum<3>(acc);
+    if (!cam_seg_total<3>(g.g, sg, n, acc, lane)) continue;
     if (lane == 0) {
       const double w0 = acc[0] + yscale * dcam[3 * (long)n] * zn.x;
       const double w1 = acc[1] + yscale * dcam[3 * (long)n + 1] * zn.y;
@@ -428,7 +434,14 @@ __global__ void __launch_bounds__(kBlock)
       v.w[3 * (long)n] = w0;
       v.w[3 * (long)n + 1] = w1;
       v.w[3 * (long)n + 2] = w2;
-      delta += zn.x * w0 + zn.y * w1 + zn.z * w2;
+      const double dn = zn.x * w0 + zn.y * w1 + zn.z * w2;
+      // a cut camera is finished by whichever slice arrives last: its share of delta goes to a slot of its own, so
+      // that the sum over the slots does not depend on the arrival order
+      const int mi = g.g.seg_multi[sg];
+      if (mi < 0)
+        delta += dn;
+      else
+        v.dpart[gridDim.x + mi] = dn;
     }
   }
   if (lane == 0) sdelta[wid] = delta;
@@ -653,15 +666,37 @@ class GpSolver final : public LmProblem {
     std::mt19937 rng;
     rng.seed(opt_.seed);
     std::uniform_real_distribution<double> uni(-1.0, 1.0);
+    // Track shards over several ranks draw EXACTLY the numbers the unsharded problem would: a camera is constrained when
+    // any rank observes it, and a rank's point draws start where the lower ranks' used tracks end in the one global
+    // std::mt19937 stream (two 32-bit outputs per double, libstdc++ generate_canonical).
+    std::vector<char> constrained(N_);
+    long used_before = 0;
+    {
+      long used_here = 0;
+      for (long p = 0; p < P_; ++p) used_here += (h_off[p + 1] - h_off[p] >= opt_.min_num_view_per_track) ? 1 : 0;
+      for (int n = 0; n < N_; ++n) constrained[n] = h_coff[n + 1] > h_coff[n];
+      const int W = ctx_->comm.world;
+      if (W > 1) {
+        std::vector<double> h((size_t)N_ + W, 0.0);
+        for (int n = 0; n < N_; ++n) h[n] = constrained[n] ? 1.0 : 0.0;
+        h[(size_t)N_ + ctx_->comm.rank] = (double)used_here;
+        DevBuf<double> tmp;
+        tmp.ensure(h.size());
+        GSFM_HIP_CHECK(hipMemcpyAsync(tmp.get(), h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, s));
+        allreduce_sum(ctx_, tmp.get(), h.size());
+        GSFM_HIP_CHECK(hipMemcpyAsync(h.data(), tmp.get(), h.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        GSFM_HIP_CHECK(hipStreamSynchronize(s));
+        for (int n = 0; n < N_; ++n) constrained[n] = h[n] > 0.0;
+        for (int r = 0; r < ctx_->comm.rank; ++r) used_before += (long)h[(size_t)N_ + r];
+      }
+    }
     if (opt_.generate_random_positions && opt_.optimize_positions) {
       for (int n = 0; n < N_; ++n) {
-        const bool constrained = h_coff[n + 1] > h_coff[n];
-        if (!constrained && ctx_->comm.world == 1) continue;
+        if (!constrained[n]) continue;
         for (int j = 0; j < 3; ++j) h_c[3 * (size_t)n + j] = 100.0 * uni(rng);
       }
     }
-    // several ranks: same camera draws everywhere (above), decorrelated point draws per shard
-    if (ctx_->comm.world > 1) rng.seed(opt_.seed + 7919u * (unsigned)(ctx_->comm.rank + 1));
+    if (used_before > 0 && opt_.generate_random_points && opt_.optimize_points) rng.discard(6ull * (unsigned long long)used_before);
     if (opt_.generate_random_points && opt_.optimize_points) {
       for (long p = 0; p < P_; ++p) {
         if (h_off[p + 1] - h_off[p] < opt_.min_num_view_per_track) continue;
@@ -701,7 +736,7 @@ class GpSolver final : public LmProblem {
     gridP_ = grid_for(P_, kBlock);
     gridN_ = grid_for(N_, kBlock);
     gridM_ = grid_for(M_, kBlock);
-    gridCam_ = grid_wide(N_, kBlock / 64, kMaxApplySlots);  // one wave per camera (delta partial per block)
+    gridCam_ = grid_wide(g_.g.S, kBlock / 64, kMaxApplySlots);  // one wave per camera segment (delta partial per block)
     gridTile_ = grid_wide(g_.g.T, kBlock / 64);             // one wave per tile
     gridTileP_ = grid_wide(g_.g.T, kBlock / 64, kMaxBlocks);  // tile sweeps that write per-block partials
     g_.dir = ws->dir.get();
@@ -730,7 +765,7 @@ class GpSolver final : public LmProblem {
     cg_.N = N_;
     cg_.K = 0;
     cg_.nb_update = std::min(kCgMaxBlocks, grid_for(N_, kBlock));
-    cg_.nb_apply = gridCam_;
+    cg_.nb_apply = gridCam_ + g_.g.nmulti;  // + one delta slot per cut camera (k_gp_phaseB)
     cg_.b = ws->rhs.get();
     cg_.x = ws->cg_x.get();
     cg_.r = ws->cg_r.get();

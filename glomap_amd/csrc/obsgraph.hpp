@@ -11,8 +11,15 @@
 //                track per tile), so no segment ever straddles a wave.
 //   camera-major (derived once per solve by a stable device radix sort on the camera index):
 //                obs of camera n are [coff[n], coff[n+1]).  Camera-side sums (gradient, S_cc
-//                blocks, PCG phase B "y_n = sum_k ...") run one WAVE PER CAMERA with the camera
-//                data in registers and a single wave reduction at the end.
+//                blocks, PCG phase B "y_n = sum_k ...") run one WAVE PER CAMERA SEGMENT with the
+//                camera data in registers and a single wave reduction at the end.  A segment is a
+//                camera's whole list when it is short (the common case: nothing else happens) or
+//                a slice of at most `seg_len` observations of a long one: real images differ by
+//                10-100x in how many tracks they see, and one wave walking a 13 000-observation
+//                list would set the duration of the whole sweep.  The slices of a long camera put
+//                their partial sums into fixed slots; the wave that arrives last (device-scope
+//                ticket) adds them in slice order — still no floating-point atomics, still a
+//                fixed summation order.
 //
 // Observations of tracks shorter than min_num_view_per_track (gp.cc:258, ba.cc:122) are excluded
 // from the camera-major lists (key = N sorts them behind every camera) and contribute zero in
@@ -42,11 +49,28 @@ struct ObsGraph {  // device view, passed to kernels by value
   const int* coff = nullptr;           // [N+2] camera-major CSR; coff[N] = Mu, coff[N+1] = M
   const int* c_src = nullptr;          // [M]   track-major index of each camera-major slot
   const int* c_pt = nullptr;           // [M]   track of each camera-major slot
+  // camera segments (see the header comment): S >= N segments in camera order
+  int S = 0;                           // number of segments
+  int nmulti = 0;                      // cameras cut into more than one segment (<= kMaxMultiCams)
+  const int* seg_cam = nullptr;        // [S]   camera of the segment
+  const int* seg_k = nullptr;          // [S+1] first camera-major slot of the segment (seg_k[S] = Mu)
+  const int* seg_first = nullptr;      // [S]   first segment of this segment's camera
+  const int* seg_cnt = nullptr;        // [S]   number of segments of this segment's camera
+  const int* seg_multi = nullptr;      // [S]   index of the camera among the cut ones, -1 for whole cameras
+  double* segpart = nullptr;           // [S][kSegPartW] partial sums of cut cameras
+  int* cam_cnt = nullptr;              // [N]   arrival tickets, zero between launches
 };
+
+constexpr int kSegPartW = 128;     // widest per-camera accumulator (k_ba_build_cam<true>: 119 values)
+constexpr int kSegLenMin = 1024;   // observations per segment: 16 trips of a wave
+constexpr int kMaxMultiCams = 1024;
 
 struct ObsGraphWs {
   DevBuf<int> obs_pt, tile, tile_k, keys, keys_sorted, vals, c_src, c_pt, coff, flag;
+  DevBuf<int> seg_cam, seg_k, seg_first, seg_cnt, seg_multi, cam_cnt;
+  DevBuf<double> segpart;
   DevBuf<unsigned char> used, sort_tmp;
+  std::vector<int> h_coff;  // host copy of the camera-major offsets
 };
 
 // ---- device helpers --------------------------------------------------------------------------
@@ -78,6 +102,36 @@ __device__ __forceinline__ void wave_allsum(double (&v)[K]) {
 #pragma unroll
     for (int k = 0; k < K; ++k) v[k] += __shfl_xor(v[k], off, 64);
   }
+}
+
+// Camera total of a segment's wave sum.  Call with `acc` = the wave-reduced partial of segment `sg` (camera n).
+// Returns true in the wave that owns the camera's complete sum, which then sits in lane 0's `acc`: at once for a
+// whole camera; for a cut camera only in the wave that arrives last, after it added the slices in slice order.
+template <int W>
+__device__ __forceinline__ bool cam_seg_total(const ObsGraph& g, int sg, int n, double (&acc)[W], int lane) {
+  static_assert(W <= kSegPartW, "accumulator wider than the partial-sum slots");
+  const int cnt = g.seg_cnt[sg];
+  if (cnt == 1) return true;
+  int last = 0;
+  if (lane == 0) {
+    double* dst = g.segpart + (size_t)sg * kSegPartW;
+#pragma unroll
+    for (int j = 0; j < W; ++j) dst[j] = acc[j];
+    __threadfence();
+    last = atomicAdd(g.cam_cnt + n, 1) == cnt - 1;
+    if (last) {
+      g.cam_cnt[n] = 0;  // ready for the next launch
+      __threadfence();
+      const double* src = g.segpart + (size_t)g.seg_first[sg] * kSegPartW;
+#pragma unroll
+      for (int j = 0; j < W; ++j) acc[j] = 0.0;
+      for (int q = 0; q < cnt; ++q) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) acc[j] += __builtin_nontemporal_load(src + (size_t)q * kSegPartW + j);
+      }
+    }
+  }
+  return __shfl(last, 0, 64) != 0;
 }
 
 // ---- kernels ------------------------------------------------------------------------------------
@@ -193,8 +247,56 @@ inline long build_obs_graph(gsfm_ctx* ctx, ObsGraphWs& ws, int N, long P, long M
                      ws.obs_pt.get(), ws.c_pt.get());
   int* h_flag = reinterpret_cast<int*>(ctx->h_pinned + 512);
   GSFM_HIP_CHECK(hipMemcpyAsync(h_flag, ws.flag.get(), sizeof(int), hipMemcpyDeviceToHost, s));
+  ws.h_coff.resize((size_t)N + 2);
+  GSFM_HIP_CHECK(hipMemcpyAsync(ws.h_coff.data(), ws.coff.get(), (size_t)(N + 2) * sizeof(int), hipMemcpyDeviceToHost, s));
   GSFM_HIP_CHECK(hipStreamSynchronize(s));  // host vectors go out of scope; flag is read
   GSFM_REQUIRE(h_flag[0] == 0, "obs_cam out of range");
+  // camera segments: the shortest power-of-two slice length >= kSegLenMin that cuts at most kMaxMultiCams cameras
+  {
+    const std::vector<int>& co = ws.h_coff;
+    int seg_len = kSegLenMin;
+    for (;;) {
+      int cut = 0;
+      for (int n = 0; n < N; ++n) cut += (co[n + 1] - co[n] > seg_len) ? 1 : 0;
+      if (cut <= kMaxMultiCams) break;
+      seg_len *= 2;
+    }
+    // host layout: 5 arrays back to back (cam | k | first | cnt | multi), S + 1 entries each
+    std::vector<int> cam, k0, first, cnt, multi;
+    int nmulti = 0;
+    for (int n = 0; n < N; ++n) {
+      const int len = co[n + 1] - co[n];
+      const int c = len > seg_len ? (len + seg_len - 1) / seg_len : 1;
+      const int f = (int)cam.size();
+      for (int q = 0; q < c; ++q) {
+        cam.push_back(n);
+        k0.push_back(co[n] + (int)(((long)len * q) / c));  // equal slices
+        first.push_back(f);
+        cnt.push_back(c);
+        multi.push_back(c > 1 ? nmulti : -1);
+      }
+      nmulti += c > 1 ? 1 : 0;
+    }
+    const int S = (int)cam.size();
+    k0.push_back(co[N]);
+    GSFM_HIP_CHECK(hipMemcpyAsync(ws.seg_cam.ensure(S + 1), cam.data(), (size_t)S * sizeof(int), hipMemcpyHostToDevice, s));
+    GSFM_HIP_CHECK(hipMemcpyAsync(ws.seg_k.ensure(S + 2), k0.data(), (size_t)(S + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+    GSFM_HIP_CHECK(hipMemcpyAsync(ws.seg_first.ensure(S + 1), first.data(), (size_t)S * sizeof(int), hipMemcpyHostToDevice, s));
+    GSFM_HIP_CHECK(hipMemcpyAsync(ws.seg_cnt.ensure(S + 1), cnt.data(), (size_t)S * sizeof(int), hipMemcpyHostToDevice, s));
+    GSFM_HIP_CHECK(hipMemcpyAsync(ws.seg_multi.ensure(S + 1), multi.data(), (size_t)S * sizeof(int), hipMemcpyHostToDevice, s));
+    GSFM_HIP_CHECK(hipMemsetAsync(ws.cam_cnt.ensure(N + 1), 0, (size_t)(N + 1) * sizeof(int), s));
+    ws.segpart.ensure(nmulti > 0 ? (size_t)S * kSegPartW : 1);
+    GSFM_HIP_CHECK(hipStreamSynchronize(s));  // the host vectors above go out of scope
+    g.S = S;
+    g.nmulti = nmulti;
+    g.seg_cam = ws.seg_cam.get();
+    g.seg_k = ws.seg_k.get();
+    g.seg_first = ws.seg_first.get();
+    g.seg_cnt = ws.seg_cnt.get();
+    g.seg_multi = ws.seg_multi.get();
+    g.segpart = ws.segpart.get();
+    g.cam_cnt = ws.cam_cnt.get();
+  }
   g.N = N;
   g.T = T;
   g.P = P;

@@ -86,6 +86,94 @@ def make_ring_view_graph(
     )
 
 
+def make_view_graph(
+    kind: str = "geometric",
+    num_cams: int = 1000,
+    degree: int = 20,
+    noise_deg: float = 1.0,
+    outlier_ratio: float = 0.05,
+    seed: int = 0,
+    shuffle: bool = True,
+    num_hubs: int = 8,
+    chord_ratio: float = 0.05,
+) -> RaProblem:
+    """View graphs that are NOT banded rings (real view graphs have hubs, loop closures and arbitrary image ids):
+
+      "geometric"  cameras scattered in the unit square, each linked to its `degree` nearest neighbours
+      "hub"        the geometric graph plus `num_hubs` images linked to a quarter of all images each
+      "chords"     a thin ring (`degree` // 2 successors) plus `chord_ratio` * E random long-range loop closures
+
+    Same noise / outlier / inlier-count model as make_ring_view_graph.  `shuffle` permutes the node ids, so nothing can
+    rely on index locality; node 0 of the result is the gauge node as everywhere else."""
+    rng = np.random.default_rng(seed)
+    N = num_cams
+    R_gt = so3.aa_to_rotmat(rng.uniform(-np.pi / 2, np.pi / 2, (N, 3)) * np.array([0.3, 1.0, 0.3]))
+    if kind in ("geometric", "hub"):
+        from scipy.spatial import cKDTree
+
+        xy = rng.random((N, 2))
+        _, nb = cKDTree(xy).query(xy, k=min(N, degree // 2 + 1))
+        ii = np.repeat(np.arange(N), nb.shape[1] - 1)
+        jj = nb[:, 1:].reshape(-1)
+        if kind == "hub":
+            hubs = rng.choice(N, size=min(num_hubs, N), replace=False)
+            for h in hubs:
+                others = rng.choice(N, size=N // 4, replace=False)
+                ii = np.concatenate([ii, np.full(others.shape[0], h)])
+                jj = np.concatenate([jj, others])
+    elif kind == "chords":
+        succ = max(1, degree // 2)
+        ii = np.repeat(np.arange(N), succ)
+        jj = (ii + np.tile(np.arange(1, succ + 1), N)) % N
+        nch = int(chord_ratio * ii.shape[0])
+        ii = np.concatenate([ii, rng.integers(0, N, nch)])
+        jj = np.concatenate([jj, rng.integers(0, N, nch)])
+    else:
+        raise ValueError(kind)
+    keep = ii != jj
+    lo, hi = np.minimum(ii[keep], jj[keep]), np.maximum(ii[keep], jj[keep])
+    key = lo.astype(np.int64) * N + hi
+    _, uniq = np.unique(key, return_index=True)
+    uniq.sort()
+    lo, hi = lo[uniq], hi[uniq]
+    # keep the graph connected whatever the sampling did: a spanning chain over the (shuffled) node order
+    if shuffle:
+        perm = rng.permutation(N)
+        R_gt = R_gt[np.argsort(perm)]
+        lo, hi = perm[lo], perm[hi]
+        lo, hi = np.minimum(lo, hi), np.maximum(lo, hi)
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import connected_components
+
+    ncomp, lab = connected_components(sp.coo_matrix((np.ones(lo.shape[0]), (lo, hi)), shape=(N, N)), directed=False)
+    if ncomp > 1:  # link component representatives in a chain
+        reps = np.array([np.nonzero(lab == c)[0][0] for c in range(ncomp)])
+        a, b = reps[:-1], reps[1:]
+        lo = np.concatenate([lo, np.minimum(a, b)])
+        hi = np.concatenate([hi, np.maximum(a, b)])
+    E = lo.shape[0]
+    noise = so3.aa_to_rotmat(rng.normal(0.0, np.radians(noise_deg), (E, 3)))
+    R_rel = R_gt[hi] @ np.transpose(R_gt[lo], (0, 2, 1)) @ noise
+    outlier = rng.random(E) < outlier_ratio
+    n_out = int(outlier.sum())
+    if n_out:
+        q_rand = rng.normal(size=(n_out, 4))
+        q_rand /= np.linalg.norm(q_rand, axis=1, keepdims=True)
+        R_rel[outlier] = so3.quat_to_rotmat(q_rand)
+    return RaProblem(
+        num_nodes=N,
+        edge_i=lo.astype(np.int32),
+        edge_j=hi.astype(np.int32),
+        edge_q=so3.rotmat_to_quat(R_rel),
+        edge_weight=np.ones(E),
+        edge_ninl=rng.integers(30, 501, E).astype(np.int32),
+        node_aa0=np.zeros((N, 3)),
+        fixed_node=0,
+        gt_R=R_gt,
+        outlier=outlier,
+    )
+
+
 # --------------------------------------------------------------------------------------------
 # Shared camera / track geometry for C3 / C4
 # --------------------------------------------------------------------------------------------
@@ -110,8 +198,17 @@ def _ball_points(rng, P, radius):
     return d * r[:, None]
 
 
+def _zipf_popularity(N, zipf, seed):
+    """Per-camera popularity ~ rank^-zipf over a seeded random ranking (None when zipf == 0): real images differ by an
+    order of magnitude and more in how many tracks they see; uniform synthetic visibility hides that."""
+    if not zipf:
+        return None
+    rank = np.random.default_rng([seed, 424243]).permutation(N) + 1.0
+    return rank ** (-float(zipf))
+
+
 def _sample_tracks(rng, centers, R_cw, X, mean_extra, min_len=3, max_len=100, half_fov_deg=30.0, ncand=None,
-                   chunk=65536):
+                   chunk=65536, cam_popularity=None):
     """Pick, per point, L = min(min_len + Poisson(mean_extra), max_len) distinct cameras that see it
     inside the field of view.  Returns CSR (pt_offset, obs_cam) in track-major order; points that
     end up with fewer than ``min_len`` views keep what they have (the estimators skip them,
@@ -128,7 +225,11 @@ def _sample_tracks(rng, centers, R_cw, X, mean_extra, min_len=3, max_len=100, ha
         Pc = Xc.shape[0]
         L = np.minimum(min_len + rng.poisson(mean_extra, Pc), min(max_len, N))
         nc = ncand if ncand is not None else int(min(N, max(16, 3 * int(L.max()))))
-        cand = rng.integers(0, N, (Pc, nc))
+        if cam_popularity is None:
+            cand = rng.integers(0, N, (Pc, nc))
+        else:  # skewed visibility: candidates drawn with probability proportional to the camera's popularity
+            cdf = np.cumsum(cam_popularity / cam_popularity.sum())
+            cand = np.minimum(np.searchsorted(cdf, rng.random((Pc, nc))), N - 1)
         cand.sort(axis=1)
         dup = np.zeros_like(cand, dtype=bool)
         dup[:, 1:] = cand[:, 1:] == cand[:, :-1]
@@ -159,6 +260,7 @@ def make_gp_problem(
     uncalibrated_ratio: float = 0.0,
     seed: int = 0,
     shard=None,
+    zipf: float = 0.0,
 ) -> GpProblem:
     """C3-style global positioning problem (cameras on a radius-50 ring, points in a radius-30 ball).
 
@@ -171,7 +273,7 @@ def make_gp_problem(
         calibrated_all = (rng.random(num_cams) >= uncalibrated_ratio).astype(np.uint8)
         rng = np.random.default_rng([seed, 7919, int(shard[0])])
     X = _ball_points(rng, num_pts, 30.0)
-    pt_offset, obs_cam = _sample_tracks(rng, centers, R_cw, X, mean_extra)
+    pt_offset, obs_cam = _sample_tracks(rng, centers, R_cw, X, mean_extra, cam_popularity=_zipf_popularity(num_cams, zipf, seed))
     M = obs_cam.shape[0]
     obs_pt = np.repeat(np.arange(num_pts), np.diff(pt_offset))
     d = X[obs_pt] - centers[obs_cam]
@@ -224,6 +326,7 @@ def make_ba_problem(
     intr_noise: float = 0.0,
     seed: int = 0,
     shard=None,
+    zipf: float = 0.0,
 ) -> BaProblem:
     """C4-style bundle-adjustment problem: SIMPLE_RADIAL (f=1200,cx=640,cy=480,k=0.02), state =
     ground truth perturbed by rotation / position / depth noise.
@@ -239,7 +342,8 @@ def make_ba_problem(
         rng_cam = np.random.default_rng([seed, 104729])
         rng = np.random.default_rng([seed, 7919, int(shard[0])])
     X = _ball_points(rng, P, 30.0)
-    pt_offset, obs_cam = _sample_tracks(rng, centers, R_cw, X, mean_extra, half_fov_deg=25.0)
+    pt_offset, obs_cam = _sample_tracks(rng, centers, R_cw, X, mean_extra, half_fov_deg=25.0,
+                                        cam_popularity=_zipf_popularity(N, zipf, seed))
     M = obs_cam.shape[0]
     obs_pt = np.repeat(np.arange(P), np.diff(pt_offset))
     t_gt = -np.einsum("nij,nj->ni", R_cw, centers)

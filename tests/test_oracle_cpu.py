@@ -142,3 +142,16 @@ def test_ra_cpp_shuffled_node_ids():
     assert ok and ok2
     assert rep["profile_entries"] < 400 * 45
     assert np.abs(rot - rot2).max() < 1e-9
+
+
+@pytest.mark.parametrize("kind", ["geometric", "hub", "chords"])
+def test_ra_cpp_matches_numpy_oracle_on_non_ring_graphs(kind):
+    p = synthetic.make_view_graph(kind, 600, 16, seed=2)
+    args = (p.num_nodes, p.edge_i, p.edge_j, p.edge_q, p.edge_weight, p.edge_ninl, p.node_aa0, p.fixed_node)
+    tr = ora.RaTrace()
+    ok, rot = ora.estimate_rotations(*args, trace=tr)
+    rep = {}
+    ok2, rot2 = cpu.ra_estimate_rotations(*args, report=rep)
+    assert ok and ok2
+    assert (rep["l1_iterations"], rep["irls_iterations"]) == (tr.l1_iterations, tr.irls_iterations)
+    assert np.abs(rot - rot2).max() < 1e-9
