@@ -155,6 +155,7 @@ def run_extras(env, args, world, rank, main_line):
             ("gp_c3", lambda: {k: v for k, v in bench_gp(**{**env, "args": sub()}).items() if k in keys}),
             ("ba_c4_shared_intrinsics", lambda: {k: v for k, v in bench_ba(**{**env, "args": sub(shared_intrinsics=True)}).items()
                                                  if k in keys}),
+            ("gp_c3_skewed_visibility", lambda: {k: v for k, v in bench_gp(**{**env, "args": sub(zipf=0.8)}).items() if k in keys}),
             ("ra_large", lambda: bench_ra_large(ctx)),
             ("ra_c3", lambda: bench_ra_sized(ctx, 5000, 50)),
             ("track_filters_c3", lambda: bench_filters(ctx)),
@@ -427,7 +428,8 @@ def cpu_baseline_pipeline(p_ra, p_gp, p_ba, gpu_rep):
     Restated CPU oracle — NOT Ceres / CHOLMOD (the reference cannot be built here)."""
     from oracle import cpu
 
-    out = {"unit": "obs/s", "cores": cpu.num_threads(), "host_cores_available": os.cpu_count(), "kind": "port"}
+    out = {"unit": "obs/s", "cores": cpu.num_threads(), "host_hw_threads": os.cpu_count(), "kind": "port",
+           "cores_note": "cores = the CPUs this process may use (scheduler affinity capped by the cgroup CPU quota of the box)"}
     t0 = time.perf_counter()
     rr = {}
     ok, _ = cpu.ra_estimate_rotations(p_ra.num_nodes, p_ra.edge_i, p_ra.edge_j, p_ra.edge_q, p_ra.edge_weight, p_ra.edge_ninl,
@@ -695,7 +697,7 @@ def cpu_baseline_ra(p):
         dt = time.perf_counter() - t0
         if dt > 10.0 or n >= 8:
             break
-    return {"value": p.num_edges * n / dt, "unit": "edges/s", "cores": cpu.num_threads(), "host_cores_available": os.cpu_count(),
+    return {"value": p.num_edges * n / dt, "unit": "edges/s", "cores": cpu.num_threads(), "host_hw_threads": os.cpu_count(),
             "kind": "port",
             "sample": f"{n} full RA solves of the same view graph (restated C++/OpenMP CPU oracle, single-threaded skyline "
                       "Cholesky; not Ceres/CHOLMOD)"}
@@ -719,10 +721,11 @@ def bench_gp(args, ctx, rank, world, barrier, dist):
     ncam = int(5000 * args.scale)
     npts_rank = int(500_000 * args.scale)  # weak scaling: tracks per GPU fixed
     npts = npts_rank * world
+    zipf = float(getattr(args, "zipf", 0.0))  # > 0: Zipf-distributed per-camera observation counts (skewed visibility)
     if world == 1:
-        p = synthetic.make_gp_problem(ncam, npts, seed=0)
+        p = synthetic.make_gp_problem(ncam, npts, seed=0, zipf=zipf)
     else:  # every rank generates only its own shard (cameras identical everywhere)
-        p = synthetic.make_gp_problem(ncam, npts_rank, seed=0, shard=(rank, world))
+        p = synthetic.make_gp_problem(ncam, npts_rank, seed=0, shard=(rank, world), zipf=zipf)
     lo, hi = 0, p.num_pts
     o0, o1 = 0, p.num_obs
     M_total = p.num_obs
@@ -783,6 +786,10 @@ def bench_gp(args, ctx, rank, world, barrier, dist):
         "solves_per_s_in_obs": M_total * args.steps / dt,
         "median_center_err_vs_gt": float(np.median(err)),
     }
+    if zipf:
+        per_cam = np.bincount(p.obs_cam, minlength=ncam)
+        config["skewed_visibility"] = {"zipf_exponent": zipf, "obs_per_camera_median": int(np.median(per_cam)),
+                                       "obs_per_camera_max": int(per_cam.max())}
     return base_line("track-obs/sec per LM iteration (GP)", value, "obs/s", world, args, dt, config, roof, cpu, ctx)
 
 
@@ -793,7 +800,7 @@ def cpu_baseline_gp(p):
     ok, c, X, s = cpu.gp_solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated, p.cam_center, p.pt_xyz)
     dt = time.perf_counter() - t0
     return {"value": p.num_obs * max(1, s.iterations) / dt, "unit": "obs/s", "cores": cpu.num_threads(),
-            "host_cores_available": os.cpu_count(), "kind": "port", "seconds": dt,
+            "host_hw_threads": os.cpu_count(), "kind": "port", "seconds": dt,
             "sample": f"one GP solve of the SAME input ({p.num_obs} observations, {s.iterations} LM iterations; restated "
                       "C++/OpenMP CPU oracle with exact elimination, not Ceres)"}
 
@@ -903,7 +910,7 @@ def cpu_baseline_ba(p):
                      p.pt_xyz, p.intr_params)
     dt = time.perf_counter() - t0
     return {"value": p.num_obs * max(1, r[5].iterations) / dt, "unit": "obs/s", "cores": cpu.num_threads(),
-            "host_cores_available": os.cpu_count(), "kind": "port", "seconds": dt,
+            "host_hw_threads": os.cpu_count(), "kind": "port", "seconds": dt,
             "sample": f"one BA solve of the SAME input ({p.num_obs} observations, {r[5].iterations} LM iterations; restated "
                       "C++/OpenMP CPU oracle with exact elimination, not Ceres)"}
 

@@ -171,8 +171,41 @@ def load():
     return _LIB
 
 
+def effective_cores() -> int:
+    """Host cores this process may actually use: the scheduler affinity capped by the cgroup CPU quota (the GPU boxes
+    expose 256 hardware threads but run inside a 16-CPU quota — an OpenMP team of 256 spinning threads in there is
+    ~100x slower than a team of 16)."""
+    import os
+
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:  # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:  # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota)))
+    return max(1, n)
+
+
 def num_threads() -> int:
-    return int(load().orc_num_threads())
+    """Threads the solves use by default (threads=0)."""
+    return effective_cores()
+
+
+def _threads(t: int) -> int:
+    return int(t) if t and t > 0 else effective_cores()
 
 
 def _p(a, t):
@@ -218,7 +251,7 @@ def gp_solve(num_cams, pt_offset, obs_cam, obs_dir, obs_calibrated, cam_center, 
     rep = _Report()
     rc = lib.orc_gp_solve(C.c_int32(int(num_cams)), C.c_int64(off.shape[0] - 1), _p(off, C.c_int64), _p(cam, C.c_int32),
                           _p(v, C.c_double), None if cal is None else _p(cal, C.c_uint8), C.byref(o), _p(c, C.c_double),
-                          _p(X, C.c_double), C.byref(rep), C.c_int32(threads))
+                          _p(X, C.c_double), C.byref(rep), C.c_int32(_threads(threads)))
     s = _summary(rep)
     if rc == -5:
         s.usable = False
@@ -250,7 +283,7 @@ def ba_solve(num_cams, pt_offset, obs_cam, obs_xy, cam_intr, intr_model, fixed_c
     rc = lib.orc_ba_solve(C.c_int32(int(num_cams)), C.c_int32(mdl.shape[0]), C.c_int32(int(fixed_cam)),
                           C.c_int64(off.shape[0] - 1), _p(off, C.c_int64), _p(cam, C.c_int32), _p(xy, C.c_double),
                           _p(ci, C.c_int32), _p(mdl, C.c_int32), C.byref(o), _p(q, C.c_double), _p(t, C.c_double),
-                          _p(X, C.c_double), _p(intr, C.c_double), C.byref(rep), C.c_int32(threads))
+                          _p(X, C.c_double), _p(intr, C.c_double), C.byref(rep), C.c_int32(_threads(threads)))
     s = _summary(rep)
     if rc == -5:
         s.usable = False
@@ -276,7 +309,7 @@ def ra_estimate_rotations(num_nodes, edge_i, edge_j, edge_q, edge_weight, edge_n
     rep = _RaReport()
     rc = lib.orc_ra_solve(C.c_int32(int(num_nodes)), C.c_int64(E), _p(ei, C.c_int32), _p(ej, C.c_int32), _p(eq, C.c_double),
                           _p(ew, C.c_double), _p(ninl, C.c_int32), C.c_int32(int(fixed_node)), C.byref(o),
-                          _p(rot, C.c_double), C.byref(rep), C.c_int32(threads))
+                          _p(rot, C.c_double), C.byref(rep), C.c_int32(_threads(threads)))
     if report is not None:
         report.update(l1_iterations=rep.l1_iterations, irls_iterations=rep.irls_iterations,
                       factorizations=rep.factorizations, threads=rep.threads, profile_entries=rep.profile_entries,
