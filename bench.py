@@ -158,6 +158,7 @@ def run_extras(env, args, world, rank, main_line):
             ("gp_c3_skewed_visibility", lambda: {k: v for k, v in bench_gp(**{**env, "args": sub(zipf=0.8)}).items() if k in keys}),
             ("ra_large", lambda: bench_ra_large(ctx)),
             ("ra_c3", lambda: bench_ra_sized(ctx, 5000, 50)),
+            ("ra_c4_non_ring_graphs", lambda: bench_ra_nonring(ctx)),
             ("track_filters_c3", lambda: bench_filters(ctx)),
             ("track_establishment_c3", lambda: bench_tracks(ctx, no_cpu=True)),
         )
@@ -652,6 +653,38 @@ def bench_ra_sized(ctx, N, succ):
             "linear_solver": "dense direct (f64 MFMA)" if N <= 2048 else ("PCG, dense diagonal-block preconditioner (f64 MFMA block inverses)" if N <= 32768 else "3-RHS Jacobi-PCG"),
             "l1_iterations": rep["iterations_l1"], "irls_iterations": rep["iterations_irls"],
             "pcg_iterations": rep["linear_iterations"], "median_rot_err_deg_vs_gt": float(np.median(err))}
+
+
+def bench_ra_nonring(ctx, N=10_000, degree=100):
+    """Full RA solves on view graphs that are not banded rings, at the camera count of configs[3]: k-nearest-neighbour
+    graph, the same plus 8 hub images linked to a quarter of all images, and a thin ring with random long-range loop
+    closures — node ids shuffled.  Reports time and the PCG iteration counts of the block-preconditioned path."""
+    import numpy as np
+
+    from glomap_amd import estimators, so3, synthetic
+
+    out = {}
+    for kind in ("geometric", "hub", "chords"):
+        p = synthetic.make_view_graph(kind, N, degree, seed=0)
+        pd = _dev_ra(ctx, p)
+        rot = pd.node_aa0.clone()
+        times, rep = [], None
+        for i in range(3):  # one warm-up + two timed solves
+            rot.copy_from(pd.node_aa0)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            rc, _, rep = estimators.ra_solve(pd, estimators.RotationEstimatorOptions(), ctx=ctx, rot_inout=rot)
+            ctx.synchronize()
+            if rc != 0:
+                raise RuntimeError(f"gsfm_ra_solve failed on the {kind} graph: {rc}")
+            if i:
+                times.append(time.perf_counter() - t0)
+        err = synthetic.rotation_errors_deg(so3.aa_to_rotmat(rot.numpy()), p.gt_R)
+        deg = np.bincount(np.concatenate([p.edge_i, p.edge_j]), minlength=N)
+        out[kind] = {"cameras": N, "edges": p.num_edges, "max_degree": int(deg.max()), "ms_per_solve": float(np.median(times)) * 1e3,
+                     "l1_iterations": rep["iterations_l1"], "irls_iterations": rep["iterations_irls"],
+                     "pcg_iterations": rep["linear_iterations"], "median_rot_err_deg_vs_gt": float(np.median(err))}
+    return out
 
 
 def bench_ra_large(ctx):

@@ -247,7 +247,8 @@ __global__ void __launch_bounds__(kBlock)
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (kBlock / 64);
-  for (int sg = wave; sg < g.g.S; sg += nwaves) {
+  for (int it = wave; it < cam_seg_count(g.g); it += nwaves) {
+    const int sg = cam_seg_index(g.g, it);
     const int n = g.g.seg_cam[sg];
     const int ik = g.cam_intr[n];
     const int model = g.intr_model[ik];
@@ -258,7 +259,7 @@ __global__ void __launch_bounds__(kBlock)
     double acc[28];
 #pragma unroll
     for (int j = 0; j < 28; ++j) acc[j] = 0.0;
-    for (int k = g.g.seg_k[sg] + lane; k < g.g.seg_k[sg + 1]; k += 64) {
+    for (int k = cam_seg_k0(g.g, sg) + lane; k < cam_seg_k1(g.g, sg); k += 64) {
       ObsGeom o;
       obs_geom(R9, t3, ld3(X + 3 * (long)g.g.c_pt[k]), model, pp, o);
       const double r0 = o.valid ? o.px - g.c_xy[2 * (long)k] : 0.0;
@@ -284,7 +285,7 @@ __global__ void __launch_bounds__(kBlock)
       }
     }
     wave_allsum<28>(acc);
-    if (!cam_seg_total<28>(g.g, sg, n, acc, lane)) continue;
+    if (!cam_seg_total<28>(g.g, sg, acc, lane)) continue;
     if (lane == 0) {
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
@@ -432,7 +433,8 @@ __global__ void __launch_bounds__(kBlock)
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (kBlock / 64);
-  for (int sg = wave; sg < g.g.S; sg += nwaves) {
+  for (int it = wave; it < cam_seg_count(g.g); it += nwaves) {
+    const int sg = cam_seg_index(g.g, it);
     const int n = g.g.seg_cam[sg];
     const int ik = g.cam_intr[n];
     const int model = g.intr_model[ik];
@@ -443,7 +445,7 @@ __global__ void __launch_bounds__(kBlock)
     double acc[NACC];  // gred 6 | spose 21 | igred 8 | sii 36 | (JOINT) pose x intrinsics cross block 6 x 8
 #pragma unroll
     for (int j = 0; j < NACC; ++j) acc[j] = 0.0;
-    for (int k = g.g.seg_k[sg] + lane; k < g.g.seg_k[sg + 1]; k += 64) {
+    for (int k = cam_seg_k0(g.g, sg) + lane; k < cam_seg_k1(g.g, sg); k += 64) {
       const double w = c_w[k];
       if (w == 0.0) continue;
       const double* b = ptb + 12 * (long)g.g.c_pt[k];
@@ -489,7 +491,7 @@ __global__ void __launch_bounds__(kBlock)
       }
     }
     wave_allsum<NACC>(acc);
-    if (!cam_seg_total<NACC>(g.g, sg, n, acc, lane)) continue;
+    if (!cam_seg_total<NACC>(g.g, sg, acc, lane)) continue;
     if (lane == 0) {
       if constexpr (JOINT) {
 #pragma unroll
@@ -732,7 +734,7 @@ __global__ void __launch_bounds__(kBlock)
     k_ba_phaseB(BaDev g, CgVec v, double yscale, const double* __restrict__ camR, const double* __restrict__ t,
                 const double* __restrict__ par, const double* __restrict__ c_w,
                 const double* __restrict__ ptrec, const double* __restrict__ dvec, double* __restrict__ yi_part,
-                int multi_slot0) {
+                int dslot0 /* first delta slot of this launch: 0, or behind the other slots for the combine pass */) {
   __shared__ double sdelta[kBlock / 64];
   if (v.st->done) return;
   const int lane = threadIdx.x & 63;
@@ -740,7 +742,8 @@ __global__ void __launch_bounds__(kBlock)
   const int wave = blockIdx.x * (kBlock / 64) + wid;
   const int nwaves = gridDim.x * (kBlock / 64);
   double delta = 0.0;
-  for (int sg = wave; sg < g.g.S; sg += nwaves) {
+  for (int it = wave; it < cam_seg_count(g.g); it += nwaves) {
+    const int sg = cam_seg_index(g.g, it);
     const int n = g.g.seg_cam[sg];
     const int ik = g.cam_intr[n];
     const int model = g.intr_model[ik];
@@ -759,8 +762,8 @@ __global__ void __launch_bounds__(kBlock)
     for (int j = 0; j < 14; ++j) acc[j] = 0.0;
     // software-pipelined: the index -> 64-byte record gather of observation k + 64 is in flight while observation k
     // goes through its ~300 flops
-    const int kend = g.g.seg_k[sg + 1];
-    int k = g.g.seg_k[sg] + lane;
+    const int kend = cam_seg_k1(g.g, sg);
+    int k = cam_seg_k0(g.g, sg) + lane;
     double w_nx = 0.0;
     V3 X_nx{0, 0, 0}, t_nx{0, 0, 0};
     if (k < kend) {
@@ -807,7 +810,7 @@ __global__ void __launch_bounds__(kBlock)
         if ((bits >> j) & 1) acc[6 + j] += o.Jp[0][j] * g0 + o.Jp[1][j] * g1;
     }
     wave_allsum<14>(acc);
-    if (!cam_seg_total<14>(g.g, sg, n, acc, lane)) continue;
+    if (!cam_seg_total<14>(g.g, sg, acc, lane)) continue;
     if (lane == 0) {
       double dn = 0.0;
 #pragma unroll
@@ -816,20 +819,14 @@ __global__ void __launch_bounds__(kBlock)
         v.w[6 * (long)n + j] = wv;
         dn += zp[j] * wv;
       }
-      // a cut camera is finished by whichever slice arrives last: its share of delta goes to a slot of its own
-      // (behind the per-block slots and the phase-I slots), so that the sum does not depend on the arrival order
-      const int mi = g.g.seg_multi[sg];
-      if (mi < 0)
-        delta += dn;
-      else
-        v.dpart[multi_slot0 + mi] = dn;
+      delta += dn;
 #pragma unroll
       for (int j = 0; j < 8; ++j) yi_part[8 * (long)n + j] = acc[6 + j];
     }
   }
   if (lane == 0) sdelta[wid] = delta;
   __syncthreads();
-  if (threadIdx.x == 0) v.dpart[blockIdx.x] = (sdelta[0] + sdelta[1]) + (sdelta[2] + sdelta[3]);
+  if (threadIdx.x == 0) v.dpart[dslot0 + blockIdx.x] = (sdelta[0] + sdelta[1]) + (sdelta[2] + sdelta[3]);
 }
 
 // Intrinsics rows of w: one block per intrinsics block sums its cameras' shares (fixed order), adds the
@@ -1257,6 +1254,7 @@ class BaSolver final : public LmProblem {
     gridN_ = grid_for(N_, kBlock);
     gridM_ = grid_for(M_, kBlock);
     gridCam_ = grid_wide(g_.g.S, kBlock / 64, kMaxApplySlots);  // one wave per camera segment (delta partial per block)
+    gridMulti_ = g_.g.nmulti > 0 ? grid_for(g_.g.nmulti, kBlock / 64) : 0;  // combine pass: one wave per cut camera
     gridTile_ = grid_wide(g_.g.T, kBlock / 64);             // one wave per tile
     gridK_ = small_groups_ ? grid_for(K_, kBlock) : grid_for(K_, 1);
     gridTileP_ = grid_wide(g_.g.T, kBlock / 64, kMaxBlocks);  // tile sweeps that write per-block partials
@@ -1280,6 +1278,8 @@ class BaSolver final : public LmProblem {
     g_.huber_a = opt_.thres_loss_function;
     g_.lm_lo = opt_.lm.min_lm_diagonal;
     g_.lm_hi = opt_.lm.max_lm_diagonal;
+    g1_ = g_;
+    g1_.g.pass = 1;  // device view of the combine pass of the camera-major kernels (obsgraph.hpp)
     q_ = ws->q.get(); qn_ = ws->qn.get();
     t_ = ws->t.get(); tn_ = ws->tn.get();
     R_ = ws->camR.get(); Rn_ = ws->camRn.get();
@@ -1298,7 +1298,7 @@ class BaSolver final : public LmProblem {
     cg_.zrec_slot = joint_ ? ws->intr_slot.get() : nullptr;
     cg_.joint_map = joint_ ? ws->cam_intr.get() : nullptr;
     cg_.minv_joint = joint_ ? ws->minvj.get() : nullptr;
-    cg_.nb_apply = gridCam_ + gridK_ + g_.g.nmulti;  // per-block slots | phase-I slots | one slot per cut camera
+    cg_.nb_apply = gridCam_ + gridK_ + gridMulti_;  // per-block slots | phase-I slots | slots of the combine pass
     cg_.b = ws->rhs.get();
     cg_.x = ws->cg_x.get();
     cg_.r = ws->cg_r.get();
@@ -1324,6 +1324,9 @@ class BaSolver final : public LmProblem {
     });
     hipLaunchKernelGGL(k_ba_lin_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, R_, t_, X_, par_, ws->c_w.get(),
                        ws->diag.get(), ws->grad.get(), ws->ipart.get());
+    if (gridMulti_)  // combine pass over the cameras whose lists were cut into slices
+      hipLaunchKernelGGL(k_ba_lin_cam, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, R_, t_, X_, par_, ws->c_w.get(),
+                         ws->diag.get(), ws->grad.get(), ws->ipart.get());
     group_sum<16>(ws->ipart.get(), ws->iacc16.get());
     hipLaunchKernelGGL(k_ba_intr_unpack16, dim3(grid_for(8 * (size_t)K_, kBlock)), dim3(kBlock), 0, s, N_, K_,
                        ws->iacc16.get(), ws->diag.get(), ws->grad.get());
@@ -1363,9 +1366,15 @@ class BaSolver final : public LmProblem {
     if (joint_) {
       hipLaunchKernelGGL((k_ba_build_cam<true>), dim3(gridCam_), dim3(kBlock), 0, s, g_, R_, t_, par_, ws->c_w.get(),
                          ws->ptb.get(), ws->gred.get(), ws->spose.get(), ws->ipart.get(), ws->scross.get());
+      if (gridMulti_)
+        hipLaunchKernelGGL((k_ba_build_cam<true>), dim3(gridMulti_), dim3(kBlock), 0, s, g1_, R_, t_, par_, ws->c_w.get(),
+                           ws->ptb.get(), ws->gred.get(), ws->spose.get(), ws->ipart.get(), ws->scross.get());
     } else {
       hipLaunchKernelGGL((k_ba_build_cam<false>), dim3(gridCam_), dim3(kBlock), 0, s, g_, R_, t_, par_, ws->c_w.get(),
                          ws->ptb.get(), ws->gred.get(), ws->spose.get(), ws->ipart.get(), (double*)nullptr);
+      if (gridMulti_)
+        hipLaunchKernelGGL((k_ba_build_cam<false>), dim3(gridMulti_), dim3(kBlock), 0, s, g1_, R_, t_, par_, ws->c_w.get(),
+                           ws->ptb.get(), ws->gred.get(), ws->spose.get(), ws->ipart.get(), (double*)nullptr);
     }
     group_sum<44>(ws->ipart.get(), ws->iacc44.get());
     if (multi) {
@@ -1459,7 +1468,10 @@ class BaSolver final : public LmProblem {
       if (timed) ctx_->prof.end(s);
       timed = ctx_->prof.begin(s, GSFM_KERNEL_BA_SCHUR_B);
       hipLaunchKernelGGL(k_ba_phaseB, dim3(gridCam_), dim3(kBlock), 0, s, g_, cg_, yscale, R_, t_, par_,
-                         ws->c_w.get(), ws->ptrec.get(), ws->dvec.get(), ws->yi_part.get(), gridCam_ + gridK_);
+                         ws->c_w.get(), ws->ptrec.get(), ws->dvec.get(), ws->yi_part.get(), 0);
+      if (gridMulti_)
+        hipLaunchKernelGGL(k_ba_phaseB, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, cg_, yscale, R_, t_, par_,
+                           ws->c_w.get(), ws->ptrec.get(), ws->dvec.get(), ws->yi_part.get(), gridCam_ + gridK_);
       if (timed) ctx_->prof.end(s);
       if (small_groups_) {
         hipLaunchKernelGGL(k_ba_phaseI_small, dim3(gridK_), dim3(kBlock), 0, s, g_, cg_, yscale, ws->yi_part.get(),
@@ -1474,12 +1486,12 @@ class BaSolver final : public LmProblem {
   gsfm_ctx* ctx_;
   BaWs* ws_;
   gsfm_ba_options opt_;
-  BaDev g_{};
+  BaDev g_{}, g1_{};
   CgVec cg_{};
   int N_ = 0, K_ = 0, n_ = 0, F_ = 0, max_group_ = 0;
   bool small_groups_ = false, joint_ = false;
   long P_ = 0, M_ = 0, Mp_ = 0, m_used_ = 0;
-  int gridP_ = 1, gridN_ = 1, gridM_ = 1, gridCam_ = 1, gridTile_ = 1, gridTileP_ = 1, gridK_ = 1;
+  int gridP_ = 1, gridN_ = 1, gridM_ = 1, gridCam_ = 1, gridMulti_ = 0, gridTile_ = 1, gridTileP_ = 1, gridK_ = 1;
   double *q_ = nullptr, *qn_ = nullptr, *t_ = nullptr, *tn_ = nullptr, *R_ = nullptr, *Rn_ = nullptr, *X_ = nullptr,
          *Xn_ = nullptr, *par_ = nullptr, *parn_ = nullptr;
 };

@@ -127,11 +127,12 @@ __global__ void __launch_bounds__(kBlock)
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (kBlock / 64);
-  for (int sg = wave; sg < g.g.S; sg += nwaves) {
+  for (int it = wave; it < cam_seg_count(g.g); it += nwaves) {
+    const int sg = cam_seg_index(g.g, it);
     const int n = g.g.seg_cam[sg];
     const V3 cn = ld3(c + 3 * (long)n);
     double acc[4] = {0, 0, 0, 0};
-    for (int k = g.g.seg_k[sg] + lane; k < g.g.seg_k[sg + 1]; k += 64) {
+    for (int k = cam_seg_k0(g.g, sg) + lane; k < cam_seg_k1(g.g, sg); k += 64) {
       const long src = g.g.c_src[k];
       const V3 d = ld3(X + 3 * (long)g.g.c_pt[k]) - cn;
       const double sk = s[src];
@@ -145,7 +146,7 @@ __global__ void __launch_bounds__(kBlock)
       acc[3] += ws * r.z;
     }
     wave_allsum<4>(acc);
-    if (!cam_seg_total<4>(g.g, sg, n, acc, lane)) continue;
+    if (!cam_seg_total<4>(g.g, sg, acc, lane)) continue;
     if (lane == 0) {
       hcc[n] = acc[0];
       gc[3 * (long)n] = acc[1];
@@ -281,11 +282,12 @@ __global__ void __launch_bounds__(kBlock)
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (kBlock / 64);
-  for (int sg = wave; sg < g.g.S; sg += nwaves) {
+  for (int it = wave; it < cam_seg_count(g.g); it += nwaves) {
+    const int sg = cam_seg_index(g.g, it);
     const int n = g.g.seg_cam[sg];
     const V3 cn = ld3(c + 3 * (long)n);
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int k = g.g.seg_k[sg] + lane; k < g.g.seg_k[sg + 1]; k += 64) {
+    for (int k = cam_seg_k0(g.g, sg) + lane; k < cam_seg_k1(g.g, sg); k += 64) {
       const long src = g.g.c_src[k];
       const double* b = ptb + 12 * (long)g.g.c_pt[k];
       const V3 d = ld3(b) - cn;
@@ -322,7 +324,7 @@ __global__ void __launch_bounds__(kBlock)
       acc[8] += Q.zz - c2.z;
     }
     wave_allsum<9>(acc);
-    if (!cam_seg_total<9>(g.g, sg, n, acc, lane)) continue;
+    if (!cam_seg_total<9>(g.g, sg, acc, lane)) continue;
     if (lane == 0) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) gred[3 * (long)n + j] = acc[j];
@@ -401,7 +403,8 @@ __global__ void __launch_bounds__(kBlock)
 __global__ void __launch_bounds__(kBlock)
     k_gp_phaseB(GpDev g, CgVec v, double yscale, const double* __restrict__ c,
                 const double* __restrict__ c_qa, const double* __restrict__ c_qb,
-                const double* __restrict__ ptrec, const double* __restrict__ dcam) {
+                const double* __restrict__ ptrec, const double* __restrict__ dcam,
+                int dslot0 /* first delta slot of this launch: 0, or gridCam for the combine pass */) {
   __shared__ double sdelta[kBlock / 64];
   if (v.st->done) return;
   const int lane = threadIdx.x & 63;
@@ -409,12 +412,13 @@ __global__ void __launch_bounds__(kBlock)
   const int wave = blockIdx.x * (kBlock / 64) + wid;
   const int nwaves = gridDim.x * (kBlock / 64);
   double delta = 0.0;
-  for (int sg = wave; sg < g.g.S; sg += nwaves) {
+  for (int it = wave; it < cam_seg_count(g.g); it += nwaves) {
+    const int sg = cam_seg_index(g.g, it);
     const int n = g.g.seg_cam[sg];
     const V3 cn = ld3(c + 3 * (long)n);
     const V3 zn = ld3(v.z + 3 * (long)n);
     double acc[3] = {0, 0, 0};
-    for (int k = g.g.seg_k[sg] + lane; k < g.g.seg_k[sg + 1]; k += 64) {
+    for (int k = cam_seg_k0(g.g, sg) + lane; k < cam_seg_k1(g.g, sg); k += 64) {
       const long p = g.g.c_pt[k];
       const double ak = c_qa[k], bk = c_qb[k];
       V3 Xp, tp;
@@ -426,7 +430,7 @@ __global__ void __launch_bounds__(kBlock)
       acc[2] += y.z;
     }
     wave_allsum<3>(acc);
-    if (!cam_seg_total<3>(g.g, sg, n, acc, lane)) continue;
+    if (!cam_seg_total<3>(g.g, sg, acc, lane)) continue;
     if (lane == 0) {
       const double w0 = acc[0] + yscale * dcam[3 * (long)n] * zn.x;
       const double w1 = acc[1] + yscale * dcam[3 * (long)n + 1] * zn.y;
@@ -434,19 +438,12 @@ __global__ void __launch_bounds__(kBlock)
       v.w[3 * (long)n] = w0;
       v.w[3 * (long)n + 1] = w1;
       v.w[3 * (long)n + 2] = w2;
-      const double dn = zn.x * w0 + zn.y * w1 + zn.z * w2;
-      // a cut camera is finished by whichever slice arrives last: its share of delta goes to a slot of its own, so
-      // that the sum over the slots does not depend on the arrival order
-      const int mi = g.g.seg_multi[sg];
-      if (mi < 0)
-        delta += dn;
-      else
-        v.dpart[gridDim.x + mi] = dn;
+      delta += zn.x * w0 + zn.y * w1 + zn.z * w2;
     }
   }
   if (lane == 0) sdelta[wid] = delta;
   __syncthreads();
-  if (threadIdx.x == 0) v.dpart[blockIdx.x] = (sdelta[0] + sdelta[1]) + (sdelta[2] + sdelta[3]);
+  if (threadIdx.x == 0) v.dpart[dslot0 + blockIdx.x] = (sdelta[0] + sdelta[1]) + (sdelta[2] + sdelta[3]);
 }
 
 // ---- back-substitution, model cost change, candidate point ------------------------------------
@@ -737,6 +734,7 @@ class GpSolver final : public LmProblem {
     gridN_ = grid_for(N_, kBlock);
     gridM_ = grid_for(M_, kBlock);
     gridCam_ = grid_wide(g_.g.S, kBlock / 64, kMaxApplySlots);  // one wave per camera segment (delta partial per block)
+    gridMulti_ = g_.g.nmulti > 0 ? grid_for(g_.g.nmulti, kBlock / 64) : 0;  // combine pass: one wave per cut camera
     gridTile_ = grid_wide(g_.g.T, kBlock / 64);             // one wave per tile
     gridTileP_ = grid_wide(g_.g.T, kBlock / 64, kMaxBlocks);  // tile sweeps that write per-block partials
     g_.dir = ws->dir.get();
@@ -751,6 +749,8 @@ class GpSolver final : public LmProblem {
     g_.opt_s = opt_.optimize_scales ? 1 : 0;
     g_.lm_lo = opt_.lm.min_lm_diagonal;
     g_.lm_hi = opt_.lm.max_lm_diagonal;
+    g1_ = g_;
+    g1_.g.pass = 1;  // device view of the combine pass of the camera-major kernels
     c_ = ws->c.get();
     cn_ = ws->cn.get();
     X_ = ws->X.get();
@@ -765,7 +765,7 @@ class GpSolver final : public LmProblem {
     cg_.N = N_;
     cg_.K = 0;
     cg_.nb_update = std::min(kCgMaxBlocks, grid_for(N_, kBlock));
-    cg_.nb_apply = gridCam_ + g_.g.nmulti;  // + one delta slot per cut camera (k_gp_phaseB)
+    cg_.nb_apply = gridCam_ + gridMulti_;  // + the delta slots of the combine pass (k_gp_phaseB)
     cg_.b = ws->rhs.get();
     cg_.x = ws->cg_x.get();
     cg_.r = ws->cg_r.get();
@@ -791,6 +791,8 @@ class GpSolver final : public LmProblem {
     hipLaunchKernelGGL(k_gp_lin_track, dim3(gridTileP_), dim3(kBlock), 0, s, g_, c_, X_, s_, ws->wrob.get(),
                        ws->hppd.get(), ws->part.get());
     hipLaunchKernelGGL(k_gp_lin_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, c_, X_, s_, ws->hcc.get(), ws->gc.get());
+    if (gridMulti_)  // combine pass over the cameras whose lists were cut into slices (obsgraph.hpp)
+      hipLaunchKernelGGL(k_gp_lin_cam, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, c_, X_, s_, ws->hcc.get(), ws->gc.get());
     if (ctx_->comm.world > 1) {
       allreduce_sum(ctx_, ws->hcc.get(), N_);
       allreduce_sum(ctx_, ws->gc.get(), 3 * (size_t)N_);
@@ -825,6 +827,9 @@ class GpSolver final : public LmProblem {
                        ws->ptrec.get(), ws->pth.get());
     hipLaunchKernelGGL(k_gp_build_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, radius, c_, s_, ws->ptb.get(),
                        ws->c_qa.get(), ws->c_qb.get(), ws->gred.get(), ws->scc.get());
+    if (gridMulti_)
+      hipLaunchKernelGGL(k_gp_build_cam, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, radius, c_, s_, ws->ptb.get(),
+                         ws->c_qa.get(), ws->c_qb.get(), ws->gred.get(), ws->scc.get());
     if (multi) {
       allreduce_sum(ctx_, ws->gred.get(), n3);
       allreduce_sum(ctx_, ws->scc.get(), 6 * (size_t)N_);
@@ -905,7 +910,10 @@ class GpSolver final : public LmProblem {
       if (timed) ctx_->prof.end(s);
       timed = ctx_->prof.begin(s, GSFM_KERNEL_GP_SCHUR_B);
       hipLaunchKernelGGL(k_gp_phaseB, dim3(gridCam_), dim3(kBlock), 0, s, g_, cg_, yscale, c_, ws->c_qa.get(),
-                         ws->c_qb.get(), ws->ptrec.get(), ws->dcam.get());
+                         ws->c_qb.get(), ws->ptrec.get(), ws->dcam.get(), 0);
+      if (gridMulti_)
+        hipLaunchKernelGGL(k_gp_phaseB, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, cg_, yscale, c_, ws->c_qa.get(),
+                           ws->c_qb.get(), ws->ptrec.get(), ws->dcam.get(), gridCam_);
       if (timed) ctx_->prof.end(s);
     });
   }
@@ -913,11 +921,11 @@ class GpSolver final : public LmProblem {
   gsfm_ctx* ctx_;
   GpWs* ws_;
   gsfm_gp_options opt_;
-  GpDev g_{};
+  GpDev g_{}, g1_{};
   CgVec cg_{};
   int N_ = 0;
   long P_ = 0, M_ = 0, m_used_ = 0;
-  int gridP_ = 1, gridN_ = 1, gridM_ = 1, gridCam_ = 1, gridTile_ = 1, gridTileP_ = 1;
+  int gridP_ = 1, gridN_ = 1, gridM_ = 1, gridCam_ = 1, gridMulti_ = 0, gridTile_ = 1, gridTileP_ = 1;
   double *c_ = nullptr, *cn_ = nullptr, *X_ = nullptr, *Xn_ = nullptr, *s_ = nullptr, *sn_ = nullptr;
 };
 

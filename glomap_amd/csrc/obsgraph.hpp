@@ -17,15 +17,19 @@
 //                a slice of at most `seg_len` observations of a long one: real images differ by
 //                10-100x in how many tracks they see, and one wave walking a 13 000-observation
 //                list would set the duration of the whole sweep.  The slices of a long camera put
-//                their partial sums into fixed slots; the wave that arrives last (device-scope
-//                ticket) adds them in slice order — still no floating-point atomics, still a
-//                fixed summation order.
+//                their partial sums into fixed slots and a second, tiny launch of the same kernel
+//                (pass 1, one wave per cut camera, only when there are cut cameras) adds them in
+//                slice order and finishes the camera — no floating-point atomics, a fixed
+//                summation order, and no device-scope fences inside the sweep (a ticket / last-
+//                arriver variant was measured first: its fences invalidate the XCD's L2 and made
+//                the skewed sweep 3x slower than the uniform one).
 //
 // Observations of tracks shorter than min_num_view_per_track (gp.cc:258, ba.cc:122) are excluded
 // from the camera-major lists (key = N sorts them behind every camera) and contribute zero in
 // track-major sweeps.
 #pragma once
 
+#include <cstdlib>
 #include <vector>
 
 #include "device.hpp"
@@ -57,8 +61,9 @@ struct ObsGraph {  // device view, passed to kernels by value
   const int* seg_first = nullptr;      // [S]   first segment of this segment's camera
   const int* seg_cnt = nullptr;        // [S]   number of segments of this segment's camera
   const int* seg_multi = nullptr;      // [S]   index of the camera among the cut ones, -1 for whole cameras
+  const int* multi_first = nullptr;    // [nmulti] first segment of each cut camera
   double* segpart = nullptr;           // [S][kSegPartW] partial sums of cut cameras
-  int* cam_cnt = nullptr;              // [N]   arrival tickets, zero between launches
+  int pass = 0;                        // 0: sweep over the segments; 1: combine pass over the cut cameras (see cam_seg_*)
 };
 
 constexpr int kSegPartW = 128;     // widest per-camera accumulator (k_ba_build_cam<true>: 119 values)
@@ -67,7 +72,7 @@ constexpr int kMaxMultiCams = 1024;
 
 struct ObsGraphWs {
   DevBuf<int> obs_pt, tile, tile_k, keys, keys_sorted, vals, c_src, c_pt, coff, flag;
-  DevBuf<int> seg_cam, seg_k, seg_first, seg_cnt, seg_multi, cam_cnt;
+  DevBuf<int> seg_cam, seg_k, seg_first, seg_cnt, seg_multi, multi_first;
   DevBuf<double> segpart;
   DevBuf<unsigned char> used, sort_tmp;
   std::vector<int> h_coff;  // host copy of the camera-major offsets
@@ -104,34 +109,39 @@ __device__ __forceinline__ void wave_allsum(double (&v)[K]) {
   }
 }
 
-// Camera total of a segment's wave sum.  Call with `acc` = the wave-reduced partial of segment `sg` (camera n).
-// Returns true in the wave that owns the camera's complete sum, which then sits in lane 0's `acc`: at once for a
-// whole camera; for a cut camera only in the wave that arrives last, after it added the slices in slice order.
+// Camera-major kernels run as   for (it = wave; it < cam_seg_count(g); it += nwaves) { sg = cam_seg_index(g, it); ... }
+// Pass 0 walks all segments; a cut camera's slices only park their wave sums (cam_seg_total returns false).  Pass 1
+// walks the cut cameras: the observation loop is empty there (cam_seg_k0 == cam_seg_k1) and cam_seg_total loads the
+// parked sums in slice order into lane 0's `acc`, after which the kernel's own per-camera epilogue runs unchanged.
+__device__ __forceinline__ int cam_seg_count(const ObsGraph& g) { return g.pass == 0 ? g.S : g.nmulti; }
+__device__ __forceinline__ int cam_seg_index(const ObsGraph& g, int it) { return g.pass == 0 ? it : g.multi_first[it]; }
+__device__ __forceinline__ int cam_seg_k0(const ObsGraph& g, int sg) { return g.seg_k[sg]; }
+__device__ __forceinline__ int cam_seg_k1(const ObsGraph& g, int sg) { return g.pass == 0 ? g.seg_k[sg + 1] : g.seg_k[sg]; }
+
+// Returns true when lane 0's `acc` holds the camera's complete sum (call after wave_allsum).
 template <int W>
-__device__ __forceinline__ bool cam_seg_total(const ObsGraph& g, int sg, int n, double (&acc)[W], int lane) {
+__device__ __forceinline__ bool cam_seg_total(const ObsGraph& g, int sg, double (&acc)[W], int lane) {
   static_assert(W <= kSegPartW, "accumulator wider than the partial-sum slots");
   const int cnt = g.seg_cnt[sg];
-  if (cnt == 1) return true;
-  int last = 0;
+  if (g.pass == 0) {
+    if (cnt == 1) return true;
+    if (lane == 0) {
+      double* dst = g.segpart + (size_t)sg * kSegPartW;
+#pragma unroll
+      for (int j = 0; j < W; ++j) dst[j] = acc[j];
+    }
+    return false;
+  }
   if (lane == 0) {
-    double* dst = g.segpart + (size_t)sg * kSegPartW;
+    const double* src = g.segpart + (size_t)sg * kSegPartW;  // sg = the camera's first segment in pass 1
 #pragma unroll
-    for (int j = 0; j < W; ++j) dst[j] = acc[j];
-    __threadfence();
-    last = atomicAdd(g.cam_cnt + n, 1) == cnt - 1;
-    if (last) {
-      g.cam_cnt[n] = 0;  // ready for the next launch
-      __threadfence();
-      const double* src = g.segpart + (size_t)g.seg_first[sg] * kSegPartW;
+    for (int j = 0; j < W; ++j) acc[j] = 0.0;
+    for (int q = 0; q < cnt; ++q) {
 #pragma unroll
-      for (int j = 0; j < W; ++j) acc[j] = 0.0;
-      for (int q = 0; q < cnt; ++q) {
-#pragma unroll
-        for (int j = 0; j < W; ++j) acc[j] += __builtin_nontemporal_load(src + (size_t)q * kSegPartW + j);
-      }
+      for (int j = 0; j < W; ++j) acc[j] += src[(size_t)q * kSegPartW + j];
     }
   }
-  return __shfl(last, 0, 64) != 0;
+  return true;
 }
 
 // ---- kernels ------------------------------------------------------------------------------------
@@ -255,6 +265,7 @@ inline long build_obs_graph(gsfm_ctx* ctx, ObsGraphWs& ws, int N, long P, long M
   {
     const std::vector<int>& co = ws.h_coff;
     int seg_len = kSegLenMin;
+    if (const char* e = std::getenv("GSFM_SEG_LEN")) seg_len = std::max(64, std::atoi(e));  // diagnostics / A-B runs
     for (;;) {
       int cut = 0;
       for (int n = 0; n < N; ++n) cut += (co[n + 1] - co[n] > seg_len) ? 1 : 0;
@@ -262,7 +273,7 @@ inline long build_obs_graph(gsfm_ctx* ctx, ObsGraphWs& ws, int N, long P, long M
       seg_len *= 2;
     }
     // host layout: 5 arrays back to back (cam | k | first | cnt | multi), S + 1 entries each
-    std::vector<int> cam, k0, first, cnt, multi;
+    std::vector<int> cam, k0, first, cnt, multi, mfirst;
     int nmulti = 0;
     for (int n = 0; n < N; ++n) {
       const int len = co[n + 1] - co[n];
@@ -275,7 +286,10 @@ inline long build_obs_graph(gsfm_ctx* ctx, ObsGraphWs& ws, int N, long P, long M
         cnt.push_back(c);
         multi.push_back(c > 1 ? nmulti : -1);
       }
-      nmulti += c > 1 ? 1 : 0;
+      if (c > 1) {
+        mfirst.push_back(f);
+        ++nmulti;
+      }
     }
     const int S = (int)cam.size();
     k0.push_back(co[N]);
@@ -284,7 +298,9 @@ inline long build_obs_graph(gsfm_ctx* ctx, ObsGraphWs& ws, int N, long P, long M
     GSFM_HIP_CHECK(hipMemcpyAsync(ws.seg_first.ensure(S + 1), first.data(), (size_t)S * sizeof(int), hipMemcpyHostToDevice, s));
     GSFM_HIP_CHECK(hipMemcpyAsync(ws.seg_cnt.ensure(S + 1), cnt.data(), (size_t)S * sizeof(int), hipMemcpyHostToDevice, s));
     GSFM_HIP_CHECK(hipMemcpyAsync(ws.seg_multi.ensure(S + 1), multi.data(), (size_t)S * sizeof(int), hipMemcpyHostToDevice, s));
-    GSFM_HIP_CHECK(hipMemsetAsync(ws.cam_cnt.ensure(N + 1), 0, (size_t)(N + 1) * sizeof(int), s));
+    ws.multi_first.ensure(nmulti + 1);
+    if (nmulti > 0)
+      GSFM_HIP_CHECK(hipMemcpyAsync(ws.multi_first.get(), mfirst.data(), (size_t)nmulti * sizeof(int), hipMemcpyHostToDevice, s));
     ws.segpart.ensure(nmulti > 0 ? (size_t)S * kSegPartW : 1);
     GSFM_HIP_CHECK(hipStreamSynchronize(s));  // the host vectors above go out of scope
     g.S = S;
@@ -294,8 +310,9 @@ inline long build_obs_graph(gsfm_ctx* ctx, ObsGraphWs& ws, int N, long P, long M
     g.seg_first = ws.seg_first.get();
     g.seg_cnt = ws.seg_cnt.get();
     g.seg_multi = ws.seg_multi.get();
+    g.multi_first = ws.multi_first.get();
     g.segpart = ws.segpart.get();
-    g.cam_cnt = ws.cam_cnt.get();
+    g.pass = 0;
   }
   g.N = N;
   g.T = T;

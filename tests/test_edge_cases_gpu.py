@@ -120,51 +120,53 @@ def test_ra_two_nodes_one_edge(gsfm_ctx):
     assert np.allclose(rel, so3.quat_to_rotmat(q)[0], atol=1e-9)
 
 
-# ---- skewed visibility: a few images see 50-100x more tracks than the median image ------------------------------
-
-
+# ---- skewed visibility: a few images see 10-100x more tracks than the median image ------------------------------
 def test_gp_skewed_visibility_matches_oracle(gsfm_ctx):
-    """Cameras with > 1024 observations are cut into slices handled by different waves (obsgraph.hpp); the slices'
-    partial sums are combined in slice order by the wave that arrives last.  Parity with the oracle and run-to-run
-    bit-identity (no floating-point atomics, no arrival-order dependence) on a problem where the busiest camera holds
-    ~20 % of all observations."""
-    import numpy as np
-
-    from glomap_amd import estimators, synthetic
+    """Cameras with > 1024 observations are cut into slices handled by different waves and combined in slice order by a
+    second pass of the same kernel (obsgraph.hpp).  Parity with the exact-solve oracle and run-to-run bit-identity (no
+    floating-point atomics) on a problem where the busiest camera holds 10 x the median.  The reduced systems are
+    solved to 1e-10 here: at the default 1e-8 this problem's LM path is sensitive enough to take 38 instead of 36
+    iterations (centres still within 2e-5) — measured with and without slicing, tools/exp_skew.py."""
     from oracle import cpu
 
     p = synthetic.make_gp_problem(num_cams=80, num_pts=25_000, seed=4, zipf=1.3)
     per_cam = np.bincount(p.obs_cam, minlength=p.num_cams)
     assert per_cam.max() > 4 * 1024 and np.median(per_cam) < 1024  # cut and whole cameras side by side
-    rc, cen, xyz, rep = estimators.gp_solve(p, ctx=gsfm_ctx)
+    opt = estimators.GlobalPositionerOptions()
+    opt.solver_options.pcg_relative_tolerance = 1e-10
+    rc, cen, xyz, rep = estimators.gp_solve(p, opt, ctx=gsfm_ctx)
     assert rc == 0
     ok, c_o, X_o, s = cpu.gp_solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated, p.cam_center, p.pt_xyz)
-    assert ok and rep["iterations"] == s.iterations
-    assert abs(rep["final_cost"] - s.final_cost) <= 1e-6 * s.final_cost
+    assert ok and (rep["iterations"], rep["successful_steps"]) == (s.iterations, s.successful_steps)
+    assert abs(rep["final_cost"] - s.final_cost) <= 1e-5 * s.final_cost
     ext = np.linalg.norm(c_o - c_o.mean(0), axis=1).max()
-    assert synthetic.center_errors_after_sim3(cen, c_o).max() / ext < 1e-3
-    rc, cen2, xyz2, rep2 = estimators.gp_solve(p, ctx=gsfm_ctx)
+    assert synthetic.center_errors_after_sim3(cen, c_o).max() / ext < 1e-4
+    rc, cen2, xyz2, rep2 = estimators.gp_solve(p, opt, ctx=gsfm_ctx)
     assert np.array_equal(cen, cen2) and np.array_equal(xyz, xyz2) and rep2["final_cost"] == rep["final_cost"]
 
 
 @pytest.mark.parametrize("shared", [False, True])
 def test_ba_skewed_visibility_matches_oracle(gsfm_ctx, shared):
-    import numpy as np
-
-    from glomap_amd import estimators, so3, synthetic
+    """Same for BA.  One shared camera: 80 images with 50 ... 8 000 observations, 1 % gross outliers.  One camera per image
+    (the joint 14 x 14 block path): every image needs enough observations to pin its own focal length, and no gross
+    outliers — otherwise the oracle itself is not reproducible (its translations move by > 1 unit along the free scale
+    gauge when only the summation order changes)."""
     from oracle import cpu
 
-    p = synthetic.make_ba_problem(num_cams=80, num_pts=25_000, seed=4, zipf=1.3, shared_intrinsics=shared)
+    if shared:
+        p = synthetic.make_ba_problem(num_cams=80, num_pts=25_000, seed=4, zipf=1.3, shared_intrinsics=True)
+    else:
+        p = synthetic.make_ba_problem(num_cams=60, num_pts=40_000, seed=4, zipf=1.0, shared_intrinsics=False, outlier_ratio=0.0)
     per_cam = np.bincount(p.obs_cam, minlength=p.num_cams)
-    assert per_cam.max() > 4 * 1024 and np.median(per_cam) < 1024
+    assert per_cam.max() > 4 * 1024 and per_cam.min() < 2048
     rc, q, t, X, intr, rep = estimators.ba_solve(p, ctx=gsfm_ctx)
     assert rc == 0
     r = cpu.ba_solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_xy, p.cam_intr, p.intr_model, p.fixed_cam, p.cam_q, p.cam_t,
                      p.pt_xyz, p.intr_params)
-    assert r[0] and rep["iterations"] == r[5].iterations
+    assert r[0] and (rep["iterations"], rep["successful_steps"]) == (r[5].iterations, r[5].successful_steps)
     assert abs(rep["final_cost"] - r[5].final_cost) <= 1e-6 * r[5].final_cost
     ang = np.radians(so3.rotation_angle_deg(so3.quat_to_rotmat(q), so3.quat_to_rotmat(r[1])))
-    assert ang.max() < 1e-4
-    assert np.abs(t - r[2]).max() < 1e-3 * 50.0
+    assert ang.max() < 1e-6
+    assert np.abs(t - r[2]).max() < 1e-5 * 50.0
     rc, q2, t2, X2, intr2, rep2 = estimators.ba_solve(p, ctx=gsfm_ctx)
     assert np.array_equal(q, q2) and np.array_equal(t, t2) and rep2["final_cost"] == rep["final_cost"]
