@@ -25,7 +25,7 @@ mkdir -p $OUT/summary
 for wl in $WLS; do
   python tools/rocpd_stats.py $OUT/${wl}_results.db > $OUT/summary/${wl}_kernel_stats.csv
   python tools/pmc_traffic.py $OUT/${wl} > $OUT/summary/${wl}_pmc.csv 2> $OUT/summary/${wl}_pmc.err
-  tail -1 $OUT/${wl}_trace.log > $OUT/summary/${wl}_bench_line.json
+  grep "\"metric\"" $OUT/${wl}_trace.log > $OUT/summary/${wl}_bench_line.json
 done
 cp profiles/pmc_traffic.json $OUT/summary/ 2>/dev/null
 rm -f $OUT/*.db
