@@ -423,7 +423,7 @@ struct Ba : LmProblem {
     if (!build_preconditioner()) return false;
     std::vector<double> dy(nred, 0.0);
     *relres = 0.0;
-    *lin = pcg(
+    *lin = solve_reduced(
         nred, rhs, dy, pcg_tol, pcg_max, [&](const std::vector<double>& z, std::vector<double>& o) { apply(z, o); },
         [&](const std::vector<double>& r, std::vector<double>& z) { precond(r, z); }, relres);
     // back-substitution: dX = -u - tp(dy)

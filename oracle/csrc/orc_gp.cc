@@ -342,7 +342,7 @@ struct Gp : LmProblem {
     }
     std::vector<double> dc(3 * N, 0.0);
     *relres = 0.0;
-    *lin = pcg(
+    *lin = solve_reduced(
         3 * N, rhs, dc, pcg_tol, pcg_max, [&](const std::vector<double>& z, std::vector<double>& o) { apply(z, o); },
         [&](const std::vector<double>& r, std::vector<double>& z) {
 #pragma omp parallel for schedule(static)

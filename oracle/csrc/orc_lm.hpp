@@ -6,8 +6,9 @@
 // restated decision by decision exactly as oracle/lm.py states it (that file's header lists the
 // Ceres sources followed).  The linear system of every step is solved "exactly": the problem
 // eliminates its independent blocks (GP: scales, then points; BA: points) in closed form and
-// solves the reduced camera system by preconditioned CG to a relative residual of 1e-14 (or
-// until the residual stops decreasing), where oracle/lm.py uses a dense / SuperLU solve.
+// solves the reduced camera system DIRECTLY (dense Cholesky of the explicitly assembled matrix)
+// when it has at most kDenseMax unknowns — like oracle/lm.py — and by preconditioned CG to a
+// relative residual of 1e-14 (or until the residual stops decreasing) above that.
 //
 // parity unpinned: no reference test pins LM iterates.
 #pragma once
@@ -131,10 +132,63 @@ inline void lm_minimize(LmProblem& prob, const LmOptions& o, LmSummary* s) {
   s->final_cost = cost;
 }
 
+constexpr i64 kDenseMax = 1536;  // reduced systems up to this size are assembled and factored densely
+
+// Direct solve of S x = b for a small SPD operator: S is assembled column by column (S e_j), symmetrised and factored
+// by Cholesky.  Returns false when a pivot is not positive (the caller then falls back to PCG).
+template <class Apply>
+bool dense_solve(i64 n, const std::vector<double>& b, std::vector<double>& x, Apply apply, double* true_relres) {
+  std::vector<double> A((size_t)n * n), e(n, 0.0), col(n);
+  for (i64 j = 0; j < n; ++j) {
+    e[j] = 1.0;
+    apply(e, col);
+    e[j] = 0.0;
+    for (i64 i = 0; i < n; ++i) A[(size_t)i * n + j] = col[i];
+  }
+  for (i64 i = 0; i < n; ++i)
+    for (i64 j = 0; j < i; ++j) A[(size_t)i * n + j] = A[(size_t)j * n + i] = 0.5 * (A[(size_t)i * n + j] + A[(size_t)j * n + i]);
+  std::vector<double> L(A);
+  for (i64 j = 0; j < n; ++j) {
+    double d = L[(size_t)j * n + j];
+    for (i64 k = 0; k < j; ++k) d -= L[(size_t)j * n + k] * L[(size_t)j * n + k];
+    if (!(d > 0.0)) return false;
+    d = std::sqrt(d);
+    L[(size_t)j * n + j] = d;
+#pragma omp parallel for schedule(static)
+    for (i64 i = j + 1; i < n; ++i) {
+      double v = L[(size_t)i * n + j];
+      const double *li = &L[(size_t)i * n], *lj = &L[(size_t)j * n];
+      for (i64 k = 0; k < j; ++k) v -= li[k] * lj[k];
+      L[(size_t)i * n + j] = v / d;
+    }
+  }
+  x = b;
+  for (i64 i = 0; i < n; ++i) {
+    double v = x[i];
+    for (i64 k = 0; k < i; ++k) v -= L[(size_t)i * n + k] * x[k];
+    x[i] = v / L[(size_t)i * n + i];
+  }
+  for (i64 i = n - 1; i >= 0; --i) {
+    double v = x[i];
+    for (i64 k = i + 1; k < n; ++k) v -= L[(size_t)k * n + i] * x[k];
+    x[i] = v / L[(size_t)i * n + i];
+  }
+  // one step of iterative refinement on the assembled matrix, then the true residual through the operator
+  std::vector<double> w(n);
+  apply(x, w);
+  double rr = 0.0, bb = 0.0;
+  for (i64 i = 0; i < n; ++i) {
+    rr += (b[i] - w[i]) * (b[i] - w[i]);
+    bb += b[i] * b[i];
+  }
+  *true_relres = bb > 0.0 ? std::sqrt(rr / bb) : 0.0;
+  return true;
+}
+
 // Preconditioned conjugate gradients on an SPD operator, classic two-reduction form.
 //   apply(z, w): w = S z;   precond(r, z): z = M^-1 r.
 // Stops at |r| <= tol |b| (recurrence residual), at max_it, or when the residual has not improved
-// by a factor 0.999 over 50 iterations (rounding floor).  Returns the iteration count and writes the
+// by a factor 0.999 over 200 iterations (rounding floor; PCG residuals are not monotone, so the window is wide).  Returns the iteration count and writes the
 // TRUE relative residual |b - S x| / |b| of the returned x.
 template <class Apply, class Precond>
 i64 pcg(i64 n, const std::vector<double>& b, std::vector<double>& x, double tol, int max_it, Apply apply, Precond precond,
@@ -168,7 +222,7 @@ i64 pcg(i64 n, const std::vector<double>& b, std::vector<double>& x, double tol,
     if (rnorm < 0.999 * best) {
       best = rnorm;
       since_best = 0;
-    } else if (++since_best >= 50) {
+    } else if (++since_best >= 200) {
       break;
     }
     precond(r, z);
@@ -188,6 +242,24 @@ i64 pcg(i64 n, const std::vector<double>& b, std::vector<double>& x, double tol,
   });
   *true_relres = std::sqrt(rr) / bnorm;
   return it;
+}
+
+// The reduced-system solve of one LM step: direct when small, PCG otherwise.  Returns the PCG iteration count (0 for
+// the direct solve).
+template <class Apply, class Precond>
+i64 solve_reduced(i64 n, const std::vector<double>& b, std::vector<double>& x, double tol, int max_it, Apply apply,
+                  Precond precond, double* true_relres) {
+  if (n <= kDenseMax) {
+    bool nonzero = false;
+    for (double v : b) nonzero = nonzero || v != 0.0;
+    if (!nonzero) {
+      std::fill(x.begin(), x.end(), 0.0);
+      *true_relres = 0.0;
+      return 0;
+    }
+    if (dense_solve(n, b, x, apply, true_relres)) return 0;
+  }
+  return pcg(n, b, x, tol, max_it, apply, precond, true_relres);
 }
 
 }  // namespace orc

@@ -119,6 +119,7 @@ def test_ba_config4_matches_cpu_oracle(gsfm_ctx):
                      p.pt_xyz, p.intr_params)
     assert r[0]
     s = r[5]
+    assert s.max_linear_residual < 1e-7  # the oracle's linear solves really were exact (true residual, every LM step)
     assert abs(rep["initial_cost"] - s.initial_cost) <= 1e-10 * s.initial_cost
     assert abs(rep["iterations"] - s.iterations) <= 3
     assert abs(rep["final_cost"] - s.final_cost) <= 1e-3 * s.final_cost
