@@ -135,6 +135,9 @@ class GpProblemC(C.Structure):
         ("obs_cam", C.c_void_p),
         ("obs_dir", C.c_void_p),
         ("obs_calibrated", C.c_void_p),
+        ("num_images", C.c_int32),
+        ("image_frame", C.c_void_p),
+        ("image_offset", C.c_void_p),
     ]
 
 
@@ -164,6 +167,10 @@ class BaProblemC(C.Structure):
         ("obs_xy", C.c_void_p),
         ("cam_intr", C.c_void_p),
         ("intr_model", C.c_void_p),
+        ("num_images", C.c_int32),
+        ("image_frame", C.c_void_p),
+        ("image_cam_from_rig", C.c_void_p),
+        ("image_intr", C.c_void_p),
     ]
 
 

@@ -261,6 +261,10 @@ def gp_solve(p: GpProblem, options: Optional[GlobalPositionerOptions] = None, ct
     xyz = _h(p.pt_xyz, np.float64)
     cen = cen.copy() if isinstance(cen, np.ndarray) else cen.clone()
     xyz = xyz.copy() if isinstance(xyz, np.ndarray) else xyz.clone()
+    if getattr(p, "image_frame", None) is not None:  # calibrated rigs: obs_cam indexes images
+        imf, imo = _h(p.image_frame, np.int32), _h(p.image_offset, np.float64)
+        assert _mem_of(imf, imo) == c.mem
+        c.num_images, c.image_frame, c.image_offset = int(imf.shape[0]), _lib.ptr(imf), _lib.ptr(imo)
     rep = _lib.Report()
     rc = ctx.lib.gsfm_gp_solve(ctx.handle, C.byref(c), C.byref(opt), _lib.ptr(cen), _lib.ptr(xyz), C.byref(rep))
     return rc, cen, xyz, rep.as_dict()
@@ -278,6 +282,11 @@ def ba_solve(p: BaProblem, options: Optional[BundleAdjusterOptions] = None, ctx=
     c.num_pts, c.num_obs = int(p.num_pts), int(oc.shape[0])
     c.pt_offset, c.obs_cam, c.obs_xy = _lib.ptr(off), _lib.ptr(oc), _lib.ptr(oxy)
     c.cam_intr, c.intr_model = _lib.ptr(ci), _lib.ptr(im)
+    if getattr(p, "image_frame", None) is not None:  # calibrated rigs: obs_cam indexes images
+        imf, imc, imi = _h(p.image_frame, np.int32), _h(p.image_cam_from_rig, np.float64), _h(p.image_intr, np.int32)
+        assert _mem_of(imf, imc, imi) == c.mem
+        c.num_images = int(imf.shape[0])
+        c.image_frame, c.image_cam_from_rig, c.image_intr = _lib.ptr(imf), _lib.ptr(imc), _lib.ptr(imi)
     outs = []
     for a in (p.cam_q, p.cam_t, p.pt_xyz, p.intr_params):
         a = _h(a, np.float64)

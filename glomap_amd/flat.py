@@ -62,10 +62,18 @@ class GpProblem:
     cam_R: Optional[np.ndarray] = None  # [N,3,3] cam_from_world rotations (for tests / conversion)
     gt_center: Optional[np.ndarray] = None
     gt_xyz: Optional[np.ndarray] = None
+    # Known (calibrated) rigs, gp.cc:318-350 RigBATAPairwiseDirectionError: when given, obs_cam indexes IMAGES,
+    # num_cams / cam_center are the FRAMES (rigs in time) and image_offset = R_cam_from_world^T t_cam_from_rig
+    image_frame: Optional[np.ndarray] = None  # [I] int32
+    image_offset: Optional[np.ndarray] = None  # [I,3] f64
 
     @property
     def num_obs(self) -> int:
         return int(self.obs_cam.shape[0])
+
+    @property
+    def num_images(self) -> int:
+        return 0 if self.image_frame is None else int(self.image_frame.shape[0])
 
 
 @dataclass
@@ -89,10 +97,19 @@ class BaProblem:
     gt_t: Optional[np.ndarray] = None
     gt_xyz: Optional[np.ndarray] = None
     gt_intr: Optional[np.ndarray] = None
+    # Known (calibrated) rigs, ba.cc:147-160 RigReprojErrorConstantRigCostFunctor: when given, obs_cam indexes IMAGES,
+    # cam_q / cam_t are the FRAMES' rig_from_world, cam_intr is unused (each image carries its own intrinsics block)
+    image_frame: Optional[np.ndarray] = None  # [I] int32
+    image_cam_from_rig: Optional[np.ndarray] = None  # [I,7] f64 (qw,qx,qy,qz,tx,ty,tz), identity for reference sensors
+    image_intr: Optional[np.ndarray] = None  # [I] int32
 
     @property
     def num_obs(self) -> int:
         return int(self.obs_cam.shape[0])
+
+    @property
+    def num_images(self) -> int:
+        return 0 if self.image_frame is None else int(self.image_frame.shape[0])
 
     def copy(self) -> "BaProblem":
         import copy

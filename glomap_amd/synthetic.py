@@ -391,6 +391,88 @@ def make_ba_problem(
 
 
 # --------------------------------------------------------------------------------------------
+# Calibrated multi-camera rigs (the shape of global_mapper_test.cc:89-126 WithoutNoiseWithNonTrivialKnownRig)
+# --------------------------------------------------------------------------------------------
+def make_rig_problems(
+    num_frames: int = 14,
+    cams_per_rig: int = 2,
+    num_pts: int = 400,
+    num_rigs: int = 2,
+    sensor_rot_deg: float = 5.0,
+    sensor_trans: float = 0.1,
+    pixel_noise: float = 0.0,
+    dir_noise: float = 0.0,
+    outlier_ratio: float = 0.0,
+    seed: int = 0,
+    mean_extra: float = 3.0,
+):
+    """Frames (rig poses) on the usual ring, `cams_per_rig` sensors per frame: sensor 0 is the reference sensor
+    (cam_from_rig = identity), the others are rotated by ~`sensor_rot_deg` and shifted by ~`sensor_trans` * ring radius / 50.
+    Frames alternate between `num_rigs` rigs with different calibrations.  Images = frames x sensors, one SIMPLE_RADIAL
+    camera per (rig, sensor).  Returns (GpProblem, BaProblem, info) over the SAME images and tracks:
+    GP with image_frame / image_offset, BA with image_frame / image_cam_from_rig / image_intr; info holds ground truth."""
+    rng = np.random.default_rng(seed)
+    N, S = num_frames, cams_per_rig
+    radius = 50.0
+    centers_f, R_f = _ring_cameras(rng, N, radius)  # rig_from_world rotation, rig centre
+    t_f = -np.einsum("nij,nj->ni", R_f, centers_f)
+    rig_of_frame = np.arange(N) % num_rigs
+    # calibrations: [rig][sensor] cam_from_rig
+    Rs = np.tile(np.eye(3), (num_rigs, S, 1, 1))
+    ts = np.zeros((num_rigs, S, 3))
+    for r in range(num_rigs):
+        for s_ in range(1, S):
+            Rs[r, s_] = so3.aa_to_rotmat(rng.normal(0, np.radians(sensor_rot_deg), 3))
+            ts[r, s_] = rng.normal(0, sensor_trans * radius / 50.0 * 10.0, 3)
+    I = N * S
+    image_frame = np.repeat(np.arange(N), S).astype(np.int32)
+    image_sensor = np.tile(np.arange(S), N)
+    R_s = Rs[rig_of_frame[image_frame], image_sensor]
+    t_s = ts[rig_of_frame[image_frame], image_sensor]
+    R_cw = R_s @ R_f[image_frame]
+    t_cw = np.einsum("iab,ib->ia", R_s, t_f[image_frame]) + t_s
+    c_img = -np.einsum("iba,ib->ia", R_cw, t_cw)
+    X = _ball_points(rng, num_pts, 30.0)
+    pt_offset, obs_img = _sample_tracks(rng, c_img, R_cw, X, mean_extra, half_fov_deg=28.0)
+    M = obs_img.shape[0]
+    obs_pt = np.repeat(np.arange(num_pts), np.diff(pt_offset))
+    K = num_rigs * S
+    image_intr = (rig_of_frame[image_frame] * S + image_sensor).astype(np.int32)
+    intr_gt = np.zeros((K, CAMERA_MAX_PARAMS))
+    intr_gt[:, :4] = np.array([1200.0, 640.0, 480.0, 0.02])
+    xc = np.einsum("mij,mj->mi", R_cw[obs_img], X[obs_pt]) + t_cw[obs_img]
+    xy = project_simple_radial(intr_gt[image_intr[obs_img]], xc)
+    xy += rng.normal(0, pixel_noise, (M, 2)) if pixel_noise else 0.0
+    out = rng.random(M) < outlier_ratio
+    if out.any():
+        xy[out] = np.stack([rng.uniform(0, 1280, int(out.sum())), rng.uniform(0, 960, int(out.sum()))], 1)
+    ray = xc / np.linalg.norm(xc, axis=1, keepdims=True)
+    if dir_noise:
+        n = rng.normal(0, dir_noise, (M, 3))
+        n -= np.einsum("mj,mj->m", n, ray)[:, None] * ray
+        ray = ray + n
+        ray /= np.linalg.norm(ray, axis=1, keepdims=True)
+    obs_dir = np.einsum("mji,mj->mi", R_cw[obs_img], ray)  # R_cw^T * features_undist (gp.cc:294-296)
+    image_offset = np.einsum("iba,ib->ia", R_cw, t_s)  # R_cw^T t_cam_from_rig (gp.cc:329-333)
+    q_s = so3.rotmat_to_quat(R_s)
+    gp = GpProblem(num_cams=N, num_pts=num_pts, pt_offset=pt_offset, obs_cam=obs_img.astype(np.int32),
+                   obs_dir=np.ascontiguousarray(obs_dir), obs_calibrated=np.ones(M, np.uint8), cam_center=np.zeros((N, 3)),
+                   pt_xyz=np.zeros((num_pts, 3)), cam_R=R_f, gt_center=centers_f, gt_xyz=X,
+                   image_frame=image_frame, image_offset=np.ascontiguousarray(image_offset))
+    # BA start: perturbed frame poses / points, exact calibration
+    R0 = so3.aa_to_rotmat(rng.normal(0, np.radians(0.5), (N, 3))) @ R_f
+    c0 = centers_f + rng.normal(0, 0.01 * radius, (N, 3))
+    ba = BaProblem(num_cams=N, num_pts=num_pts, num_intr=K, pt_offset=pt_offset, obs_cam=obs_img.astype(np.int32),
+                   obs_xy=np.ascontiguousarray(xy), cam_intr=np.zeros(N, np.int32), cam_q=so3.rotmat_to_quat(R0),
+                   cam_t=-np.einsum("nij,nj->ni", R0, c0), pt_xyz=X * (1.0 + rng.normal(0, 0.01, (num_pts, 1))),
+                   intr_model=np.full(K, CAMERA_SIMPLE_RADIAL, dtype=np.int32), intr_params=intr_gt.copy(), fixed_cam=0,
+                   gt_q=so3.rotmat_to_quat(R_f), gt_t=t_f, gt_xyz=X, gt_intr=intr_gt, image_frame=image_frame,
+                   image_cam_from_rig=np.ascontiguousarray(np.concatenate([q_s, t_s], axis=1)), image_intr=image_intr)
+    info = dict(R_cw=R_cw, t_cw=t_cw, R_s=R_s, t_s=t_s, image_sensor=image_sensor, rig_of_frame=rig_of_frame)
+    return gp, ba, info
+
+
+# --------------------------------------------------------------------------------------------
 # Gauge-free comparisons (reference: rotation_averager_test.cc:85-106, global_mapper_test.cc:26-38)
 # --------------------------------------------------------------------------------------------
 def align_rotations(R_est: np.ndarray, R_ref: np.ndarray) -> np.ndarray:

@@ -262,6 +262,17 @@ typedef struct gsfm_gp_problem {
   const int32_t* obs_cam;       /* [M] frame index */
   const double* obs_dir;        /* [M][3] R_cw^T * features_undist (gp.cc:294-296) */
   const uint8_t* obs_calibrated;/* [M] cameras[..].has_prior_focal_length (gp.cc:313-316); NULL = all 1 */
+  /* Calibrated (known) multi-camera rigs — RigBATAPairwiseDirectionError, cost_function.h:49-82, added at
+   * global_positioning.cc:318-350 with the rig scale held constant at 1 (:470-478).  num_images = 0 (and NULL pointers):
+   * trivial rigs, obs_cam indexes frames.  num_images = I > 0: obs_cam indexes IMAGES, num_cams / cam_center_inout are
+   * the FRAMES (rig_from_world per time step), and for every image
+   *   image_frame[i]   its frame,
+   *   image_offset[i]  = R_cam_from_world^T * t_cam_from_rig  (translation_rig at gp.cc:329-333; zero for reference sensors),
+   * so that the residual is  v - s (X - c_frame + image_offset).  Rigs whose cam_from_rig is unknown (NaN translation,
+   * RigUnknownBATAPairwiseDirectionError) are not implemented: the adapter returns false for them. */
+  int32_t num_images;
+  const int32_t* image_frame;   /* [I] */
+  const double* image_offset;   /* [I][3] */
 } gsfm_gp_problem;
 
 /* cam_center_inout [N][3]: camera centres c = -R^T t (in: used when !generate_random_positions;
@@ -307,6 +318,16 @@ typedef struct gsfm_ba_problem {
   const double* obs_xy;       /* [M][2] image.features[feat] (distorted pixels, ba.cc:139) */
   const int32_t* cam_intr;    /* [N] intrinsics block of each frame's image (image.camera_id) */
   const int32_t* intr_model;  /* [K] GSFM_CAMERA_* */
+  /* Calibrated (known) multi-camera rigs — colmap::RigReprojErrorConstantRigCostFunctor as added at
+   * bundle_adjustment.cc:147-160 (optimize_rig_poses = false, the default): x_c = cam_from_rig * (rig_from_world * X).
+   * num_images = 0: trivial rigs.  num_images = I > 0: obs_cam indexes IMAGES, cam_q / cam_t are the FRAMES'
+   * rig_from_world, cam_intr is ignored and every image carries
+   *   image_frame[i], image_cam_from_rig[i] = (qw,qx,qy,qz,tx,ty,tz) — identity for reference sensors —, image_intr[i].
+   * optimize_rig_poses = true (RigReprojErrorCostFunctor, bundle_adjustment.cc:161-179) is not implemented. */
+  int32_t num_images;
+  const int32_t* image_frame;        /* [I] */
+  const double* image_cam_from_rig;  /* [I][7] */
+  const int32_t* image_intr;         /* [I] */
 } gsfm_ba_problem;
 
 /* cam_q_inout [N][4] (w,x,y,z), cam_t_inout [N][3], pt_xyz_inout [P][3],

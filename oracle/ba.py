@@ -167,10 +167,13 @@ def free_param_mask(model, opt: BundleAdjusterOptions):
 
 
 class _BaProblem:
-    def __init__(self, N, cam, pt, xy, cam_intr, model, fixed_cam, P, opt):
+    def __init__(self, N, cam, pt, xy, cam_intr, model, fixed_cam, P, opt, obs_ik=None, Rs=None, ts=None):
         self.N, self.P, self.M = N, P, cam.shape[0]
         self.cam, self.pt, self.xy = cam, pt, xy
         self.cam_intr, self.model = cam_intr, model
+        # known rigs: RigReprojErrorConstantRigCostFunctor (ba.cc:147-160): x_c = cam_from_rig * (rig_from_world * X)
+        # with a CONSTANT cam_from_rig per observation (Rs, ts) and the image's own intrinsics block (obs_ik)
+        self.obs_ik, self.Rs, self.ts = obs_ik, Rs, ts
         self.K = model.shape[0]
         self.opt = opt
         self.loss = lm.HuberLoss(opt.thres_loss_function)
@@ -206,8 +209,12 @@ class _BaProblem:
         R = quat_to_rot(q)
         RX = np.einsum("mij,mj->mi", R[self.cam], X[self.pt])
         xc = RX + t[self.cam]
-        ik = self.cam_intr[self.cam]
+        ik = self.cam_intr[self.cam] if self.obs_ik is None else self.obs_ik
+        if self.Rs is not None:
+            xc = np.einsum("mij,mj->mi", self.Rs, xc) + self.ts
         uv, Jx, Jp, valid = project(self.model[ik], intr[ik], xc)
+        if self.Rs is not None:
+            Jx = Jx @ self.Rs  # d(uv)/d(x_rig): everything downstream differentiates through the rig-frame point
         r = np.where(valid[:, None], uv - self.xy, 0.0)
         return R, RX, ik, r, Jx, Jp, valid
 
@@ -279,8 +286,11 @@ class _BaProblem:
 
 
 def solve(num_cams, pt_offset, obs_cam, obs_xy, cam_intr, intr_model, fixed_cam, cam_q, cam_t, pt_xyz,
-          intr_params, options: BundleAdjusterOptions | None = None):
-    """Returns (ok, q [N,4], t [N,3], X [P,3], intr [K,8], LmSummary); arrays as glomap_amd.flat.BaProblem."""
+          intr_params, options: BundleAdjusterOptions | None = None, image_frame=None, image_cam_from_rig=None,
+          image_intr=None):
+    """Returns (ok, q [N,4], t [N,3], X [P,3], intr [K,8], LmSummary); arrays as glomap_amd.flat.BaProblem.
+    Known rigs: with `image_frame` [I], `image_cam_from_rig` [I,7] (qw,qx,qy,qz,tx,ty,tz) and `image_intr` [I] given,
+    obs_cam indexes IMAGES; the pose blocks are the frames' rig_from_world."""
     opt = options or BundleAdjusterOptions()
     N = int(num_cams)
     pt_offset = np.asarray(pt_offset, dtype=np.int64)
@@ -292,6 +302,13 @@ def solve(num_cams, pt_offset, obs_cam, obs_xy, cam_intr, intr_model, fixed_cam,
     remap = -np.ones(P_all, dtype=np.int64)
     remap[used] = np.arange(int(used.sum()))
     cam = np.asarray(obs_cam, dtype=np.int64)[keep]
+    obs_ik = Rs = ts = None
+    if image_frame is not None:
+        cfr = np.asarray(image_cam_from_rig, dtype=np.float64)
+        obs_ik = np.asarray(image_intr, dtype=np.int64)[cam]
+        Rs = quat_to_rot(cfr[cam, :4])
+        ts = cfr[cam, 4:7]
+        cam = np.asarray(image_frame, dtype=np.int64)[cam]
     pt = remap[obs_pt_all[keep]]
     xy = np.asarray(obs_xy, dtype=np.float64)[keep]
     X_all = np.array(pt_xyz, dtype=np.float64, copy=True)
@@ -300,8 +317,8 @@ def solve(num_cams, pt_offset, obs_cam, obs_xy, cam_intr, intr_model, fixed_cam,
     intr0 = np.array(intr_params, dtype=np.float64, copy=True)
     if cam.shape[0] == 0:
         return False, q0, t0, X_all, intr0, lm.LmSummary(usable=False)
-    prob = _BaProblem(N, cam, pt, xy, np.asarray(cam_intr, dtype=np.int64), np.asarray(intr_model, dtype=np.int64),
-                      int(fixed_cam), int(used.sum()), opt)
+    prob = _BaProblem(N, cam, pt, xy, None if cam_intr is None else np.asarray(cam_intr, dtype=np.int64),
+                      np.asarray(intr_model, dtype=np.int64), int(fixed_cam), int(used.sum()), opt, obs_ik, Rs, ts)
     x0 = prob.pack(q0, t0, X_all[used], intr0)
     x, summ = lm.solve(prob, x0, opt.lm)
     q, t, X, intr = prob.unpack(x)

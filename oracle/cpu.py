@@ -232,7 +232,7 @@ def _summary(rep) -> CpuSummary:
 
 def gp_solve(num_cams, pt_offset, obs_cam, obs_dir, obs_calibrated, cam_center, pt_xyz,
              options: _gp.GlobalPositionerOptions | None = None, threads: int = 0, pcg_tol: float = 1e-14,
-             pcg_max: int = 20000, order: int = 0, verbose: bool = False):
+             pcg_max: int = 20000, order: int = 0, verbose: bool = False, image_frame=None, image_offset=None):
     """Same contract as oracle.gp.solve: returns (ok, cam_center [N,3], pt_xyz [P,3], CpuSummary)."""
     opt = options or _gp.GlobalPositionerOptions()
     lib = load()
@@ -249,9 +249,12 @@ def gp_solve(num_cams, pt_offset, obs_cam, obs_dir, obs_calibrated, cam_center, 
     c = np.array(cam_center, dtype=np.float64, copy=True, order="C")
     X = np.array(pt_xyz, dtype=np.float64, copy=True, order="C")
     rep = _Report()
+    imf = None if image_frame is None else np.ascontiguousarray(image_frame, dtype=np.int32)
+    imo = None if image_frame is None else np.ascontiguousarray(image_offset, dtype=np.float64)
     rc = lib.orc_gp_solve(C.c_int32(int(num_cams)), C.c_int64(off.shape[0] - 1), _p(off, C.c_int64), _p(cam, C.c_int32),
                           _p(v, C.c_double), None if cal is None else _p(cal, C.c_uint8), C.byref(o), _p(c, C.c_double),
-                          _p(X, C.c_double), C.byref(rep), C.c_int32(_threads(threads)))
+                          _p(X, C.c_double), C.byref(rep), C.c_int32(_threads(threads)),
+                          None if imf is None else _p(imf, C.c_int32), None if imo is None else _p(imo, C.c_double))
     s = _summary(rep)
     if rc == -5:
         s.usable = False
@@ -260,7 +263,8 @@ def gp_solve(num_cams, pt_offset, obs_cam, obs_dir, obs_calibrated, cam_center, 
 
 def ba_solve(num_cams, pt_offset, obs_cam, obs_xy, cam_intr, intr_model, fixed_cam, cam_q, cam_t, pt_xyz, intr_params,
              options: _ba.BundleAdjusterOptions | None = None, threads: int = 0, pcg_tol: float = 1e-14,
-             pcg_max: int = 20000, order: int = 0, verbose: bool = False):
+             pcg_max: int = 20000, order: int = 0, verbose: bool = False, image_frame=None, image_cam_from_rig=None,
+             image_intr=None):
     """Same contract as oracle.ba.solve: returns (ok, q [N,4], t [N,3], X [P,3], intr [K,8], CpuSummary)."""
     opt = options or _ba.BundleAdjusterOptions()
     lib = load()
@@ -273,7 +277,10 @@ def ba_solve(num_cams, pt_offset, obs_cam, obs_xy, cam_intr, intr_model, fixed_c
     off = np.ascontiguousarray(pt_offset, dtype=np.int64)
     cam = np.ascontiguousarray(obs_cam, dtype=np.int32)
     xy = np.ascontiguousarray(obs_xy, dtype=np.float64)
-    ci = np.ascontiguousarray(cam_intr, dtype=np.int32)
+    ci = np.zeros(int(num_cams), np.int32) if cam_intr is None else np.ascontiguousarray(cam_intr, dtype=np.int32)
+    imf = None if image_frame is None else np.ascontiguousarray(image_frame, dtype=np.int32)
+    imc = None if image_frame is None else np.ascontiguousarray(image_cam_from_rig, dtype=np.float64)
+    imi = None if image_frame is None else np.ascontiguousarray(image_intr, dtype=np.int32)
     mdl = np.ascontiguousarray(intr_model, dtype=np.int32)
     q = np.array(cam_q, dtype=np.float64, copy=True, order="C")
     t = np.array(cam_t, dtype=np.float64, copy=True, order="C")
@@ -283,7 +290,9 @@ def ba_solve(num_cams, pt_offset, obs_cam, obs_xy, cam_intr, intr_model, fixed_c
     rc = lib.orc_ba_solve(C.c_int32(int(num_cams)), C.c_int32(mdl.shape[0]), C.c_int32(int(fixed_cam)),
                           C.c_int64(off.shape[0] - 1), _p(off, C.c_int64), _p(cam, C.c_int32), _p(xy, C.c_double),
                           _p(ci, C.c_int32), _p(mdl, C.c_int32), C.byref(o), _p(q, C.c_double), _p(t, C.c_double),
-                          _p(X, C.c_double), _p(intr, C.c_double), C.byref(rep), C.c_int32(_threads(threads)))
+                          _p(X, C.c_double), _p(intr, C.c_double), C.byref(rep), C.c_int32(_threads(threads)),
+                          None if imf is None else _p(imf, C.c_int32), None if imc is None else _p(imc, C.c_double),
+                          None if imi is None else _p(imi, C.c_int32))
     s = _summary(rep)
     if rc == -5:
         s.usable = False

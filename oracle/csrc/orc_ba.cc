@@ -146,6 +146,7 @@ struct Ba : LmProblem {
   std::vector<int32_t> cam, pt, ik;  // per observation: camera, point, intrinsics block
   std::vector<i64> poff;
   std::vector<double> xy;
+  std::vector<double> sens;           // [M][12] known rigs: cam_from_rig (R row-major 9 | t 3) of the observation's image, else empty
   std::vector<int32_t> cam_intr, model;
   OwnerLists bycam, byintr;
   Huber loss;
@@ -187,9 +188,20 @@ struct Ba : LmProblem {
     quat_to_rot(&qq[4 * n], R);
     const double* x = &XX[3 * p];
     for (int i = 0; i < 3; ++i) RX[i] = R[3 * i] * x[0] + R[3 * i + 1] * x[1] + R[3 * i + 2] * x[2];
-    const double xc[3] = {RX[0] + tt[3 * n], RX[1] + tt[3 * n + 1], RX[2] + tt[3 * n + 2]};
+    double xc[3] = {RX[0] + tt[3 * n], RX[1] + tt[3 * n + 1], RX[2] + tt[3 * n + 2]};
+    const double* S = sens.empty() ? nullptr : &sens[12 * k];
+    if (S) {  // RigReprojErrorConstantRigCostFunctor (bundle_adjustment.cc:147-160): x_c = cam_from_rig * (rig_from_world * X)
+      const double xr[3] = {xc[0], xc[1], xc[2]};
+      for (int i = 0; i < 3; ++i) xc[i] = S[3 * i] * xr[0] + S[3 * i + 1] * xr[1] + S[3 * i + 2] * xr[2] + S[9 + i];
+    }
     double uv[2];
     *valid = project(model[b], &in[MAXP * b], xc, uv, Jx, Jpar);
+    if (*valid && S) {  // d(uv)/d(x_rig) = d(uv)/d(x_c) R_s: everything downstream differentiates through the rig-frame point
+      double J2[6];
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 3; ++j) J2[3 * i + j] = Jx[3 * i] * S[j] + Jx[3 * i + 1] * S[3 + j] + Jx[3 * i + 2] * S[6 + j];
+      for (int i = 0; i < 6; ++i) Jx[i] = J2[i];
+    }
     if (*valid) {
       r[0] = uv[0] - xy[2 * k];
       r[1] = uv[1] - xy[2 * k + 1];
@@ -634,10 +646,13 @@ extern "C" {
 using orc::i64;
 
 // Arrays as gsfm_ba_problem (include/gsfm.h); cam_q (w,x,y,z), intr_params [K][8].
+// Known rigs: image_frame [I], image_cam_from_rig [I][7] (qw,qx,qy,qz,tx,ty,tz), image_intr [I] (all NULL = trivial
+// rigs): obs_cam then indexes images and cam_intr is ignored.
 int orc_ba_solve(int32_t num_cams, int32_t num_intr, int32_t fixed_cam, i64 num_pts, const i64* pt_offset,
                  const int32_t* obs_cam, const double* obs_xy, const int32_t* cam_intr, const int32_t* intr_model,
                  const orc::BaOptionsC* o, double* cam_q_inout, double* cam_t_inout, double* pt_xyz_inout,
-                 double* intr_params_inout, orc::BaReport* rep, int32_t num_threads) {
+                 double* intr_params_inout, orc::BaReport* rep, int32_t num_threads, const int32_t* image_frame,
+                 const double* image_cam_from_rig, const int32_t* image_intr) {
   using namespace orc;
   const double t0 = omp_get_wtime();
   if (num_threads > 0) omp_set_num_threads(num_threads);
@@ -651,9 +666,19 @@ int orc_ba_solve(int32_t num_cams, int32_t num_intr, int32_t fixed_cam, i64 num_
     const i64 id = (i64)used_pts.size();
     used_pts.push_back(p);
     for (i64 k = pt_offset[p]; k < pt_offset[p + 1]; ++k) {
-      g.cam.push_back(obs_cam[k]);
       g.pt.push_back((int32_t)id);
-      g.ik.push_back(cam_intr[obs_cam[k]]);
+      if (image_frame) {
+        const i64 im = obs_cam[k];
+        g.cam.push_back(image_frame[im]);
+        g.ik.push_back(image_intr[im]);
+        double R[9];
+        quat_to_rot(image_cam_from_rig + 7 * im, R);
+        for (int j = 0; j < 9; ++j) g.sens.push_back(R[j]);
+        for (int j = 0; j < 3; ++j) g.sens.push_back(image_cam_from_rig[7 * im + 4 + j]);
+      } else {
+        g.cam.push_back(obs_cam[k]);
+        g.ik.push_back(cam_intr[obs_cam[k]]);
+      }
       g.xy.push_back(obs_xy[2 * k]);
       g.xy.push_back(obs_xy[2 * k + 1]);
     }
@@ -664,7 +689,10 @@ int orc_ba_solve(int32_t num_cams, int32_t num_intr, int32_t fixed_cam, i64 num_
   std::memset(rep, 0, sizeof *rep);
   rep->threads = omp_get_max_threads();
   if (g.M == 0) return -5;
-  g.cam_intr.assign(cam_intr, cam_intr + g.N);
+  if (image_frame)
+    g.cam_intr.assign(g.N, 0);  // unused with rigs (every intrinsics block counts as shared: separate preconditioner blocks)
+  else
+    g.cam_intr.assign(cam_intr, cam_intr + g.N);
   g.model.assign(intr_model, intr_model + g.K);
   for (i64 b = 0; b < g.K; ++b)
     if (g.model[b] < 0 || g.model[b] > 4) return -7;
@@ -687,10 +715,11 @@ int orc_ba_solve(int32_t num_cams, int32_t num_intr, int32_t fixed_cam, i64 num_
   }
   g.nred = 6 * g.N + g.nfree;
   g.intr_owner.assign(g.K, -2);
-  for (i64 n = 0; n < g.N; ++n) {
-    int32_t& ow = g.intr_owner[cam_intr[n]];
-    ow = (ow == -2) ? (int32_t)n : -1;
-  }
+  if (!image_frame)
+    for (i64 n = 0; n < g.N; ++n) {
+      int32_t& ow = g.intr_owner[cam_intr[n]];
+      ow = (ow == -2) ? (int32_t)n : -1;
+    }
   for (i64 b = 0; b < g.K; ++b)
     if (g.intr_owner[b] == -2) g.intr_owner[b] = -1;
   g.mpt = o->optimize_points ? 1.0 : 0.0;

@@ -55,6 +55,7 @@ struct Gp : LmProblem {
   std::vector<i64> poff;          // [P+1]
   const double* v;                // [M][3] (compacted copy)
   std::vector<double> vbuf;
+  std::vector<double> off;        // [M][3] known rigs: R_cw^T t_cam_from_rig of the observation's image (else empty)
   std::vector<uint8_t> cal;
   OwnerLists bycam;
   Huber loss_cal, loss_unc;
@@ -78,8 +79,11 @@ struct Gp : LmProblem {
   std::vector<double> Minv;     // [N][9] block-Jacobi
   std::vector<double> dcam;     // [N] LM damping of the camera blocks
 
+  // d = X - c, or X - c_rig + t_rig for an image of a calibrated rig (RigBATAPairwiseDirectionError,
+  // cost_function.h:49-82, with the rig scale constant at 1: global_positioning.cc:470-478)
   inline V3 dvec(i64 k, const std::vector<double>& cc, const std::vector<double>& XX) const {
-    return ld3(&XX[3 * (i64)pt[k]]) - ld3(&cc[3 * (i64)cam[k]]);
+    const V3 d = ld3(&XX[3 * (i64)pt[k]]) - ld3(&cc[3 * (i64)cam[k]]);
+    return off.empty() ? d : d + ld3(&off[3 * k]);
   }
   inline double damp(double h, double j, double radius) const {
     const double j2 = j * j;
@@ -433,9 +437,10 @@ using orc::i64;
 
 // Arrays as gsfm_gp_problem (include/gsfm.h).  cam_center_inout [N][3], pt_xyz_inout [P][3].
 // Returns 0 when the solution is usable, -5 for an empty problem, -6 when not usable.
+// Known rigs: image_frame [I] / image_offset [I][3] (NULL = trivial rigs): obs_cam then indexes images.
 int orc_gp_solve(int32_t num_cams, i64 num_pts, const i64* pt_offset, const int32_t* obs_cam, const double* obs_dir,
                  const uint8_t* obs_calibrated, const orc::GpOptionsC* o, double* cam_center_inout, double* pt_xyz_inout,
-                 orc::GpReport* rep, int32_t num_threads) {
+                 orc::GpReport* rep, int32_t num_threads, const int32_t* image_frame, const double* image_offset) {
   using namespace orc;
   const double t0 = omp_get_wtime();
   if (num_threads > 0) omp_set_num_threads(num_threads);
@@ -449,7 +454,12 @@ int orc_gp_solve(int32_t num_cams, i64 num_pts, const i64* pt_offset, const int3
     const i64 id = (i64)used_pts.size();
     used_pts.push_back(p);
     for (i64 k = pt_offset[p]; k < pt_offset[p + 1]; ++k) {
-      g.cam.push_back(obs_cam[k]);
+      if (image_frame) {
+        g.cam.push_back(image_frame[obs_cam[k]]);
+        for (int j = 0; j < 3; ++j) g.off.push_back(image_offset[3 * (i64)obs_cam[k] + j]);
+      } else {
+        g.cam.push_back(obs_cam[k]);
+      }
       g.pt.push_back((int32_t)id);
       g.vbuf.push_back(obs_dir[3 * k]);
       g.vbuf.push_back(obs_dir[3 * k + 1]);

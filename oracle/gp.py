@@ -54,9 +54,12 @@ def mt19937_uniform(seed: int, count: int, low: float, high: float) -> np.ndarra
 
 
 class _GpProblem:
-    def __init__(self, N, cam, pt, v, calibrated, opt: GlobalPositionerOptions, npts):
+    def __init__(self, N, cam, pt, v, calibrated, opt: GlobalPositionerOptions, npts, off=None):
         self.N, self.P, self.M = N, npts, cam.shape[0]
         self.cam, self.pt, self.v = cam, pt, v
+        # RigBATAPairwiseDirectionError (cost_function.h:49-82) with the rig scale constant at 1 (gp.cc:470-478):
+        # r = v - s (X - c_rig + t_rig), t_rig = R_cw^T t_cam_from_rig — a constant per-observation offset
+        self.off = np.zeros((self.M, 3)) if off is None else off
         self.opt = opt
         self.loss_cal = lm.HuberLoss(opt.thres_loss_function, 1.0)
         self.loss_unc = lm.HuberLoss(opt.thres_loss_function, 0.5)
@@ -70,7 +73,7 @@ class _GpProblem:
 
     def _res(self, x):
         c, X, s = self._split(x)
-        d = X[self.pt] - c[self.cam]
+        d = X[self.pt] - c[self.cam] + self.off
         r = self.v - s[:, None] * d
         sq = (r * r).sum(1)
         rho0c, rho1c = self.loss_cal.evaluate(sq)
@@ -125,8 +128,10 @@ class _GpProblem:
 
 
 def solve(num_cams, pt_offset, obs_cam, obs_dir, obs_calibrated, cam_center, pt_xyz,
-          options: GlobalPositionerOptions | None = None):
-    """Returns (ok, cam_center [N,3], pt_xyz [P,3], LmSummary).  Arrays follow glomap_amd.flat.GpProblem."""
+          options: GlobalPositionerOptions | None = None, image_frame=None, image_offset=None):
+    """Returns (ok, cam_center [N,3], pt_xyz [P,3], LmSummary).  Arrays follow glomap_amd.flat.GpProblem.
+    Known rigs (gp.cc:318-350): with `image_frame` [I] / `image_offset` [I,3] given, obs_cam indexes IMAGES, the
+    unknown centre is the one of the image's frame (rig) and image_offset = R_cam_from_world^T t_cam_from_rig."""
     opt = options or GlobalPositionerOptions()
     N = int(num_cams)
     pt_offset = np.asarray(pt_offset, dtype=np.int64)
@@ -138,6 +143,10 @@ def solve(num_cams, pt_offset, obs_cam, obs_dir, obs_calibrated, cam_center, pt_
     remap = -np.ones(P_all, dtype=np.int64)
     remap[used] = np.arange(int(used.sum()))
     cam = np.asarray(obs_cam, dtype=np.int64)[keep]
+    off = None
+    if image_frame is not None:
+        off = np.asarray(image_offset, dtype=np.float64)[cam]
+        cam = np.asarray(image_frame, dtype=np.int64)[cam]
     pt = remap[obs_pt_all[keep]]
     v = np.asarray(obs_dir, dtype=np.float64)[keep]
     cal = np.ones(cam.shape[0], dtype=np.uint8) if obs_calibrated is None else np.asarray(obs_calibrated)[keep]
@@ -167,10 +176,10 @@ def solve(num_cams, pt_offset, obs_cam, obs_dir, obs_calibrated, cam_center, pt_
     s = np.ones(M)
     if not opt.generate_scales:
         # gp.cc:300-305 (only for already-initialised tracks; the flat API treats all as initialised)
-        d = X[pt] - c[cam]
+        d = X[pt] - c[cam] + (0.0 if off is None else off)
         s = np.maximum(1e-5, (v * d).sum(1) / (d * d).sum(1))
 
-    prob = _GpProblem(N, cam, pt, v, cal, opt, P)
+    prob = _GpProblem(N, cam, pt, v, cal, opt, P, off)
     x0 = np.concatenate([c.ravel(), X.ravel(), s])
     x, summ = lm.solve(prob, x0, opt.lm)
     c_out, X_out, _ = prob._split(x)
