@@ -60,6 +60,7 @@ struct BaDev {
   const int* obs_ik;               // [M] intrinsics block of each observation (track-major)
   const double* zrec;              // joint mode: [N][6 + F] gather record (z pose | z free intrinsics), else null
   int fixed_cam;
+  const unsigned char* img_fixed;  // calibrated rigs: [images] 1 = image of the constant frame (fixed_cam is -1 then); else null
   int opt_rot, opt_trn, opt_pts;
   double huber_a;
   double lm_lo, lm_hi;
@@ -80,8 +81,9 @@ struct ObsJac {
 
 __device__ __forceinline__ void build_jac(const BaDev& g, int n, const double* __restrict__ R9, const ObsGeom& o,
                                           ObsJac& J) {
-  const bool rf = g.opt_rot && n != g.fixed_cam;
-  const bool tf = g.opt_trn && n != g.fixed_cam;
+  const bool fixed = g.img_fixed ? g.img_fixed[n] != 0 : n == g.fixed_cam;
+  const bool rf = g.opt_rot && !fixed;
+  const bool tf = g.opt_trn && !fixed;
   const V3 a = o.a;
   // C = -2 [a]x
   const double C[3][3] = {{0.0, 2.0 * a.z, -2.0 * a.y}, {-2.0 * a.z, 0.0, 2.0 * a.x}, {2.0 * a.y, -2.0 * a.x, 0.0}};
@@ -243,7 +245,8 @@ __global__ void __launch_bounds__(kBlock)
 __global__ void __launch_bounds__(kBlock)
     k_ba_lin_cam(BaDev g, const double* __restrict__ camR, const double* __restrict__ t,
                  const double* __restrict__ X, const double* __restrict__ par, double* __restrict__ c_w,
-                 double* __restrict__ diag, double* __restrict__ grad, double* __restrict__ ipart) {
+                 double* __restrict__ diag, double* __restrict__ grad, double* __restrict__ ipart,
+                 const double* __restrict__ sensR /* calibrated rigs: [images][12] cam_from_rig (R row-major | t), else null */) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (kBlock / 64);
@@ -270,6 +273,20 @@ __global__ void __launch_bounds__(kBlock)
       c_w[k] = w;
       ObsJac J;
       build_jac(g, n, R9, o, J);
+      if (sensR != nullptr) {
+        // the pose unknown is the FRAME's: its tangent d_f maps to this image's tangent as (R_s d_rot, R_s d_trn), so the
+        // columns of the frame Jacobian are J_image R_s — squared norms and gradient are accumulated in that basis
+        const double* Rs = sensR + 12 * (long)n;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const double a0 = J.Jpose[r][3 * h], a1 = J.Jpose[r][3 * h + 1], a2 = J.Jpose[r][3 * h + 2];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) J.Jpose[r][3 * h + j] = a0 * Rs[j] + a1 * Rs[3 + j] + a2 * Rs[6 + j];
+          }
+        }
+      }
       const double g0 = w * r0, g1 = w * r1;
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
@@ -751,7 +768,8 @@ __global__ void __launch_bounds__(kBlock)
     const double* R9 = camR + 9 * (long)n;
     const double* t3 = t + 3 * (long)n;
     const double* pp = par + 8 * (long)ik;
-    const bool rf = g.opt_rot && n != g.fixed_cam, tf = g.opt_trn && n != g.fixed_cam;
+    const bool fixed = g.img_fixed ? g.img_fixed[n] != 0 : n == g.fixed_cam;
+    const bool rf = g.opt_rot && !fixed, tf = g.opt_trn && !fixed;
     const double* zp = v.z + 6 * (long)n;
     const V3 zr{zp[0], zp[1], zp[2]}, zt{zp[3], zp[4], zp[5]};
     double zi[8];
@@ -1086,6 +1104,10 @@ struct BaWs {
       dpart, part, scal;
   DevBuf<CgStatus> cgst;
   DevBuf<CgScal> cgsc;
+  // calibrated rigs: image tables and the image-space twins of the per-camera arrays
+  DevBuf<int> img_frame, foff, fimg;
+  DevBuf<unsigned char> img_fixed;
+  DevBuf<double> sens, Ri, Rin, ti, tin, diag_i, grad_i, gred_i, spose_i, dvec_i, zimg, wimg, ximg;
   static void destroy(void* p) { delete static_cast<BaWs*>(p); }
 };
 
@@ -1125,6 +1147,167 @@ void dispatch_f(int F, Fn&& fn) {
   }
 }
 
+// ---- calibrated rigs -------------------------------------------------------------------------------------------
+// colmap::RigReprojErrorConstantRigCostFunctor (bundle_adjustment.cc:147-160): x_c = R_s (R_f X + t_f) + t_s with a
+// constant cam_from_rig (R_s, t_s) per image.  Every sweep above keeps working on "cameras" = IMAGES with the composed
+// pose (R_s R_f, R_s t_f + t_s) and its own left-multiplicative tangent; the unknown is the FRAME's pose, whose tangent
+// (d_rot, d_trn) maps to the image's as T_s d = (R_s d_rot, R_s d_trn)  [R_s [a]x R_s^T = [R_s a]x].  So the LM diagonal,
+// the block-Jacobi blocks and the PCG vectors live per frame, and small kernels translate around the sweeps:
+// z_image = T_s z_frame before them, w_frame = sum_images T_s^T w_image after them.  T_s is orthogonal, hence
+// z_frame . w_frame = sum z_image . w_image: the delta partials of the image-space sweeps are the frame-space ones.
+__global__ void __launch_bounds__(kBlock)
+    k_ba_rig_poses(int NI, const int* __restrict__ img_frame, const double* __restrict__ sens /* [NI][12] R_s | t_s */,
+                   const double* __restrict__ Rf, const double* __restrict__ tf, double* __restrict__ Ri,
+                   double* __restrict__ ti) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < NI; i += gridDim.x * blockDim.x) {
+    const double* S = sens + 12 * (long)i;
+    const double* R = Rf + 9 * (long)img_frame[i];
+    const double* t = tf + 3 * (long)img_frame[i];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int b = 0; b < 3; ++b) Ri[9 * (long)i + 3 * a + b] = S[3 * a] * R[b] + S[3 * a + 1] * R[3 + b] + S[3 * a + 2] * R[6 + b];
+      ti[3 * (long)i + a] = S[3 * a] * t[0] + S[3 * a + 1] * t[1] + S[3 * a + 2] * t[2] + S[9 + a];
+    }
+  }
+}
+
+// dst_image = (T_s src_frame | intrinsics part copied): z and the step dy
+__global__ void __launch_bounds__(kBlock)
+    k_ba_rig_expand(int NI, int N, int K, const int* __restrict__ img_frame, const double* __restrict__ sens,
+                    const double* __restrict__ src, double* __restrict__ dst) {
+  const int total = NI + K;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    if (i < NI) {
+      const double* S = sens + 12 * (long)i;
+      const double* v = src + 6 * (long)img_frame[i];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+          dst[6 * (long)i + 3 * h + a] = S[3 * a] * v[3 * h] + S[3 * a + 1] * v[3 * h + 1] + S[3 * a + 2] * v[3 * h + 2];
+    } else {
+      const int k = i - NI;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dst[6 * (long)NI + 8 * (long)k + j] = src[6 * (long)N + 8 * (long)k + j];
+    }
+  }
+}
+
+// plain fixed-order sums over the images of a frame (the quantities lin_cam already produced in the frame tangent)
+template <int W>
+__global__ void __launch_bounds__(kBlock)
+    k_ba_rig_sum(int N, const int* __restrict__ foff, const int* __restrict__ fimg, const double* __restrict__ src,
+                 double* __restrict__ dst) {
+  for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < N; f += gridDim.x * blockDim.x) {
+    double acc[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) acc[j] = 0.0;
+    for (int a = foff[f]; a < foff[f + 1]; ++a) {
+      const double* sp = src + (long)W * fimg[a];
+#pragma unroll
+      for (int j = 0; j < W; ++j) acc[j] += sp[j];
+    }
+#pragma unroll
+    for (int j = 0; j < W; ++j) dst[(long)W * f + j] = acc[j];
+  }
+}
+
+// reduced gradient and diagonal Schur block of a frame: sum over its images of T_s^T g and T_s^T S T_s
+__global__ void __launch_bounds__(kBlock)
+    k_ba_rig_reduce_blocks(int N, const int* __restrict__ foff, const int* __restrict__ fimg, const double* __restrict__ sens,
+                           const double* __restrict__ gred_i, const double* __restrict__ spose_i,
+                           double* __restrict__ gred_f, double* __restrict__ spose_f) {
+  for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < N; f += gridDim.x * blockDim.x) {
+    double g[6] = {0, 0, 0, 0, 0, 0};
+    double B[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) B[i][j] = 0.0;
+    for (int a = foff[f]; a < foff[f + 1]; ++a) {
+      const int im = fimg[a];
+      const double* S = sens + 12 * (long)im;
+      const double* gi = gred_i + 6 * (long)im;
+      const double* sp = spose_i + 21 * (long)im;
+      // T^T g: (R_s^T g_rot, R_s^T g_trn)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) g[3 * h + j] += S[j] * gi[3 * h] + S[3 + j] * gi[3 * h + 1] + S[6 + j] * gi[3 * h + 2];
+      // full 6 x 6 of the image, then T^T A T block by block (3 x 3 blocks: R_s^T A_hk R_s)
+      double A[6][6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) A[i][j] = A[j][i] = sp[sym6(i, j)];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          double M1[3][3];  // A_hk R_s
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+              M1[i][j] = A[3 * h + i][3 * k] * S[j] + A[3 * h + i][3 * k + 1] * S[3 + j] + A[3 * h + i][3 * k + 2] * S[6 + j];
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) B[3 * h + i][3 * k + j] += S[i] * M1[0][j] + S[3 + i] * M1[1][j] + S[6 + i] * M1[2][j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) gred_f[6 * (long)f + j] = g[j];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = i; j < 6; ++j) spose_f[21 * (long)f + sym6(i, j)] = 0.5 * (B[i][j] + B[j][i]);
+  }
+}
+
+// image-space diagonal for the sweeps: zero for the pose columns (their damping is a frame-space term), the
+// frame-space values for the intrinsics columns
+__global__ void __launch_bounds__(kBlock)
+    k_ba_rig_dvec(int NI, int N, int K, const double* __restrict__ dvec_f, double* __restrict__ dvec_i) {
+  const long total = 6 * (long)NI + 8 * (long)K;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    dvec_i[i] = i < 6 * (long)NI ? 0.0 : dvec_f[6 * (long)N + (i - 6 * (long)NI)];
+}
+
+// w_frame (pose) = sum_images T_s^T w_image + D z_frame; intrinsics rows copied; the damping share of delta goes to its
+// own partial slot.  One workgroup: the number of frames is small.
+__global__ void __launch_bounds__(kBlock)
+    k_ba_rig_reduce_w(CgVec v, int NI, double yscale, const int* __restrict__ foff, const int* __restrict__ fimg,
+                      const double* __restrict__ sens, const double* __restrict__ w_img, const double* __restrict__ dvec,
+                      int dslot) {
+  __shared__ double smem[4];
+  if (v.st->done) return;
+  double d[1] = {0.0};
+  for (int f = threadIdx.x; f < v.N; f += blockDim.x) {
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int a = foff[f]; a < foff[f + 1]; ++a) {
+      const int im = fimg[a];
+      const double* S = sens + 12 * (long)im;
+      const double* wi = w_img + 6 * (long)im;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[3 * h + j] += S[j] * wi[3 * h] + S[3 + j] * wi[3 * h + 1] + S[6 + j] * wi[3 * h + 2];
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const double z = v.z[6 * (long)f + j];
+      const double dz = yscale * dvec[6 * (long)f + j] * z;
+      v.w[6 * (long)f + j] = acc[j] + dz;
+      d[0] += z * dz;
+    }
+  }
+  for (int i = threadIdx.x; i < 8 * v.K; i += blockDim.x) v.w[6 * (long)v.N + i] = w_img[6 * (long)NI + i];
+  block_sum<1>(d, smem);
+  if (threadIdx.x == 0) v.dpart[dslot] = d[0];
+}
+
 class BaSolver final : public LmProblem {
  public:
   BaSolver(gsfm_ctx* ctx, const gsfm_ba_options& opt) : ctx_(ctx), ws_(ba_ws(ctx)), opt_(opt) {}
@@ -1141,12 +1324,22 @@ class BaSolver final : public LmProblem {
     n_ = 6 * N_ + 8 * K_;
     GSFM_REQUIRE(N_ > 0 && K_ > 0 && P_ >= 0 && M_ >= 0, "BA: bad sizes");
     GSFM_REQUIRE(prob->fixed_cam >= -1 && prob->fixed_cam < N_, "BA: fixed_cam out of range");
+    // calibrated rigs: the observation graph is over IMAGES (NI_ cameras), the pose unknowns are the N_ frames
+    rig_ = prob->num_images > 0;
+    NI_ = rig_ ? prob->num_images : N_;
+    ni_ = 6 * NI_ + 8 * K_;
+    std::vector<int> h_imf;
+    if (rig_) {
+      GSFM_REQUIRE(prob->image_frame && prob->image_cam_from_rig && prob->image_intr, "BA: image tables missing");
+      to_host(ctx_, h_imf, prob->image_frame, (size_t)NI_, mem);
+      for (int i = 0; i < NI_; ++i) GSFM_REQUIRE(h_imf[i] >= 0 && h_imf[i] < N_, "BA: image_frame out of range");
+    }
     std::vector<long> h_off;
     to_host(ctx_, h_off, reinterpret_cast<const long*>(prob->pt_offset), (size_t)P_ + 1, mem);
     GSFM_REQUIRE(h_off[0] == 0 && h_off[P_] == M_, "BA: pt_offset must start at 0 and end at num_obs");
     std::vector<int> h_model, h_ci;
     to_host(ctx_, h_model, prob->intr_model, (size_t)K_, mem);
-    to_host(ctx_, h_ci, prob->cam_intr, (size_t)N_, mem);
+    to_host(ctx_, h_ci, rig_ ? prob->image_intr : prob->cam_intr, (size_t)NI_, mem);  // intrinsics block per graph camera
     std::vector<unsigned char> h_free(K_);
     std::vector<signed char> h_map(8 * (size_t)K_, -1), h_slot(8 * (size_t)K_, -1);
     int fmax = 0;
@@ -1170,8 +1363,8 @@ class BaSolver final : public LmProblem {
     }
     F_ = fmax == 0 ? 0 : (fmax <= 2 ? 2 : (fmax <= 4 ? 4 : 8));
     // cameras grouped by intrinsics block (counting sort, stable)
-    std::vector<int> h_ioff(K_ + 1, 0), h_icams(N_);
-    for (int n = 0; n < N_; ++n) {
+    std::vector<int> h_ioff(K_ + 1, 0), h_icams(NI_);
+    for (int n = 0; n < NI_; ++n) {
       GSFM_REQUIRE(h_ci[n] >= 0 && h_ci[n] < K_, "BA: cam_intr out of range");
       h_ioff[h_ci[n] + 1]++;
     }
@@ -1183,15 +1376,15 @@ class BaSolver final : public LmProblem {
     small_groups_ = max_group_ <= 64;
     // one intrinsics block per camera (COLMAP's default for unordered photo collections): pose and
     // intrinsics of a camera are strongly coupled, so they share ONE 14 x 14 block-Jacobi block
-    joint_ = K_ == N_ && max_group_ == 1 && F_ > 0 && std::getenv("GSFM_BA_SEPARATE_BLOCKS") == nullptr;
+    joint_ = !rig_ && K_ == N_ && max_group_ == 1 && F_ > 0 && std::getenv("GSFM_BA_SEPARATE_BLOCKS") == nullptr;
     {
       std::vector<int> fill(h_ioff.begin(), h_ioff.end() - 1);
-      for (int n = 0; n < N_; ++n) h_icams[fill[h_ci[n]]++] = n;
+      for (int n = 0; n < NI_; ++n) h_icams[fill[h_ci[n]]++] = n;
     }
     copy_in(ctx_, ws->off.ensure(P_ + 1), reinterpret_cast<const long*>(prob->pt_offset), (size_t)P_ + 1, mem);
     copy_in(ctx_, ws->cam.ensure(M_ + 1), prob->obs_cam, (size_t)M_, mem);
     copy_in(ctx_, ws->xy.ensure(2 * (size_t)M_ + 2), prob->obs_xy, 2 * (size_t)M_, mem);
-    copy_in(ctx_, ws->cam_intr.ensure(N_), prob->cam_intr, (size_t)N_, mem);
+    copy_in(ctx_, ws->cam_intr.ensure(NI_), rig_ ? prob->image_intr : prob->cam_intr, (size_t)NI_, mem);
     copy_in(ctx_, ws->intr_model.ensure(K_), prob->intr_model, (size_t)K_, mem);
     copy_in(ctx_, ws->q.ensure(4 * (size_t)N_), cam_q, 4 * (size_t)N_, mem);
     copy_in(ctx_, ws->t.ensure(3 * (size_t)N_), cam_t, 3 * (size_t)N_, mem);
@@ -1201,8 +1394,8 @@ class BaSolver final : public LmProblem {
     GSFM_HIP_CHECK(hipMemcpyAsync(ws->intr_map.ensure(8 * (size_t)K_ + 8), h_map.data(), 8 * (size_t)K_, hipMemcpyHostToDevice, s));
     GSFM_HIP_CHECK(hipMemcpyAsync(ws->intr_slot.ensure(8 * (size_t)K_ + 8), h_slot.data(), 8 * (size_t)K_, hipMemcpyHostToDevice, s));
     GSFM_HIP_CHECK(hipMemcpyAsync(ws->ioff.ensure(K_ + 1), h_ioff.data(), (size_t)(K_ + 1) * sizeof(int), hipMemcpyHostToDevice, s));
-    GSFM_HIP_CHECK(hipMemcpyAsync(ws->icams.ensure(N_), h_icams.data(), (size_t)N_ * sizeof(int), hipMemcpyHostToDevice, s));
-    m_used_ = build_obs_graph(ctx_, ws->og, N_, P_, M_, h_off, ws->off.get(), ws->cam.get(),
+    GSFM_HIP_CHECK(hipMemcpyAsync(ws->icams.ensure(NI_), h_icams.data(), (size_t)NI_ * sizeof(int), hipMemcpyHostToDevice, s));
+    m_used_ = build_obs_graph(ctx_, ws->og, NI_, P_, M_, h_off, ws->off.get(), ws->cam.get(),
                               opt_.min_num_view_per_track /* ba.cc:122 */, g_.g, nullptr);  // syncs the stream
     const long Mu = g_.g.Mu;
     ws->c_xy.ensure(2 * (size_t)M_ + 2);
@@ -1239,8 +1432,44 @@ class BaSolver final : public LmProblem {
       ws->zrec.ensure((size_t)(6 + F_) * N_ + 2);
       GSFM_HIP_CHECK(hipMemsetAsync(ws->zrec.get(), 0, ((size_t)(6 + F_) * N_ + 2) * sizeof(double), s));
     }
-    ws->ipart.ensure(44 * (size_t)N_);
-    ws->yi_part.ensure(8 * (size_t)N_);
+    ws->ipart.ensure(44 * (size_t)NI_);
+    ws->yi_part.ensure(8 * (size_t)NI_);
+    if (rig_) {
+      // image tables: frame of each image, its constant cam_from_rig as (R row-major | t), the images of the constant
+      // frame, and the frame -> images lists (ascending image order: a fixed summation order)
+      std::vector<double> h_cfr, h_sens(12 * (size_t)NI_);
+      to_host(ctx_, h_cfr, prob->image_cam_from_rig, 7 * (size_t)NI_, mem);
+      std::vector<unsigned char> h_fix((size_t)NI_, 0);
+      std::vector<int> foff((size_t)N_ + 1, 0), fimg((size_t)NI_);
+      for (int i = 0; i < NI_; ++i) {
+        const double* qv = &h_cfr[7 * (size_t)i];
+        const double w = qv[0], x = qv[1], y = qv[2], z = qv[3];
+        double* S = &h_sens[12 * (size_t)i];
+        S[0] = 1 - 2 * (y * y + z * z); S[1] = 2 * (x * y - w * z); S[2] = 2 * (x * z + w * y);
+        S[3] = 2 * (x * y + w * z); S[4] = 1 - 2 * (x * x + z * z); S[5] = 2 * (y * z - w * x);
+        S[6] = 2 * (x * z - w * y); S[7] = 2 * (y * z + w * x); S[8] = 1 - 2 * (x * x + y * y);
+        S[9] = qv[4]; S[10] = qv[5]; S[11] = qv[6];
+        h_fix[i] = h_imf[i] == prob->fixed_cam ? 1 : 0;
+        foff[h_imf[i] + 1]++;
+      }
+      for (int f = 0; f < N_; ++f) foff[f + 1] += foff[f];
+      std::vector<int> cur(foff.begin(), foff.end() - 1);
+      for (int i = 0; i < NI_; ++i) fimg[cur[h_imf[i]]++] = i;
+      GSFM_HIP_CHECK(hipMemcpyAsync(ws->img_frame.ensure(NI_), h_imf.data(), (size_t)NI_ * sizeof(int), hipMemcpyHostToDevice, s));
+      GSFM_HIP_CHECK(hipMemcpyAsync(ws->foff.ensure(N_ + 1), foff.data(), (size_t)(N_ + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+      GSFM_HIP_CHECK(hipMemcpyAsync(ws->fimg.ensure(NI_), fimg.data(), (size_t)NI_ * sizeof(int), hipMemcpyHostToDevice, s));
+      GSFM_HIP_CHECK(hipMemcpyAsync(ws->img_fixed.ensure(NI_), h_fix.data(), (size_t)NI_, hipMemcpyHostToDevice, s));
+      GSFM_HIP_CHECK(hipMemcpyAsync(ws->sens.ensure(12 * (size_t)NI_), h_sens.data(), 12 * (size_t)NI_ * sizeof(double), hipMemcpyHostToDevice, s));
+      GSFM_HIP_CHECK(hipStreamSynchronize(s));  // the host vectors above go out of scope
+      for (DevBuf<double>* b : {&ws->Ri, &ws->Rin}) b->ensure(9 * (size_t)NI_);
+      for (DevBuf<double>* b : {&ws->ti, &ws->tin}) b->ensure(3 * (size_t)NI_);
+      for (DevBuf<double>* b : {&ws->diag_i, &ws->grad_i, &ws->dvec_i, &ws->zimg, &ws->ximg}) b->ensure((size_t)ni_);
+      ws->wimg.ensure((size_t)ni_ + 2);
+      ws->gred_i.ensure(6 * (size_t)NI_);
+      ws->spose_i.ensure(21 * (size_t)NI_);
+      GSFM_HIP_CHECK(hipMemsetAsync(ws->diag_i.get(), 0, (size_t)ni_ * sizeof(double), s));
+      GSFM_HIP_CHECK(hipMemsetAsync(ws->grad_i.get(), 0, (size_t)ni_ * sizeof(double), s));
+    }
     ws->iacc16.ensure(16 * (size_t)K_);
     ws->iacc44.ensure(44 * (size_t)K_);
     ws->minv.ensure(36 * (size_t)N_ + 64 * (size_t)K_);
@@ -1252,6 +1481,7 @@ class BaSolver final : public LmProblem {
     ws->cgsc.ensure(2);
     gridP_ = grid_for(P_, kBlock);
     gridN_ = grid_for(N_, kBlock);
+    gridNI_ = grid_for(NI_, kBlock);
     gridM_ = grid_for(M_, kBlock);
     gridCam_ = grid_wide(g_.g.S, kBlock / 64, kMaxApplySlots);  // one wave per camera segment (delta partial per block)
     gridMulti_ = g_.g.nmulti > 0 ? grid_for(g_.g.nmulti, kBlock / 64) : 0;  // combine pass: one wave per cut camera
@@ -1271,7 +1501,8 @@ class BaSolver final : public LmProblem {
     g_.icams = ws->icams.get();
     g_.obs_ik = ws->obs_ik.get();
     g_.zrec = joint_ ? ws->zrec.get() : nullptr;
-    g_.fixed_cam = prob->fixed_cam;
+    g_.fixed_cam = rig_ ? -1 : prob->fixed_cam;
+    g_.img_fixed = rig_ ? ws->img_fixed.get() : nullptr;
     g_.opt_rot = opt_.optimize_rotations ? 1 : 0;
     g_.opt_trn = opt_.optimize_translation ? 1 : 0;
     g_.opt_pts = opt_.optimize_points ? 1 : 0;
@@ -1286,6 +1517,12 @@ class BaSolver final : public LmProblem {
     X_ = ws->X.get(); Xn_ = ws->Xn.get();
     par_ = ws->par.get(); parn_ = ws->parn.get();
     hipLaunchKernelGGL(k_ba_cam_prepare, dim3(gridN_), dim3(kBlock), 0, s, N_, q_, R_);
+    // what the sweeps see as camera poses: the frames' own, or the images' cam_from_rig * rig_from_world
+    Rk_ = rig_ ? ws->Ri.get() : R_;
+    Rkn_ = rig_ ? ws->Rin.get() : Rn_;
+    tk_ = rig_ ? ws->ti.get() : t_;
+    tkn_ = rig_ ? ws->tin.get() : tn_;
+    if (rig_) image_poses(R_, t_, Rk_, tk_);
     // tracks without observations are never visited by the lane-per-observation sweeps: both point
     // buffers start equal, so such tracks keep their input xyz whichever buffer ends up current
     GSFM_HIP_CHECK(hipMemcpyAsync(Xn_, X_, 3 * (size_t)P_ * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -1298,7 +1535,7 @@ class BaSolver final : public LmProblem {
     cg_.zrec_slot = joint_ ? ws->intr_slot.get() : nullptr;
     cg_.joint_map = joint_ ? ws->cam_intr.get() : nullptr;
     cg_.minv_joint = joint_ ? ws->minvj.get() : nullptr;
-    cg_.nb_apply = gridCam_ + gridK_ + gridMulti_;  // per-block slots | phase-I slots | slots of the combine pass
+    cg_.nb_apply = gridCam_ + gridK_ + gridMulti_ + (rig_ ? 1 : 0);  // per-block | phase-I | combine pass | rig damping share
     cg_.b = ws->rhs.get();
     cg_.x = ws->cg_x.get();
     cg_.r = ws->cg_r.get();
@@ -1315,18 +1552,33 @@ class BaSolver final : public LmProblem {
 
   long used_observations() const { return m_used_; }
 
+  // image poses = cam_from_rig * rig_from_world
+  void image_poses(const double* Rf, const double* tf, double* Ri, double* ti) {
+    hipLaunchKernelGGL(k_ba_rig_poses, dim3(gridNI_), dim3(kBlock), 0, ctx_->stream, NI_, ws_->img_frame.get(),
+                       ws_->sens.get(), Rf, tf, Ri, ti);
+  }
+
   double linearize(double* grad_max_norm) override {
     BaWs* ws = ws_;
     hipStream_t s = ctx_->stream;
+    double* diag_k = rig_ ? ws->diag_i.get() : ws->diag.get();  // per graph camera (image); summed per frame below
+    double* grad_k = rig_ ? ws->grad_i.get() : ws->grad.get();
+    const double* sens = rig_ ? ws->sens.get() : nullptr;
     dispatch_f(F_, [&](auto Fc) {
-      hipLaunchKernelGGL((k_ba_lin_track<decltype(Fc)::value>), dim3(gridTileP_), dim3(kBlock), 0, s, g_, R_, t_, X_, par_,
+      hipLaunchKernelGGL((k_ba_lin_track<decltype(Fc)::value>), dim3(gridTileP_), dim3(kBlock), 0, s, g_, Rk_, tk_, X_, par_,
                          ws->jt.get(), ws->ptdiag.get(), ws->ptH.get(), ws->part.get());
     });
-    hipLaunchKernelGGL(k_ba_lin_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, R_, t_, X_, par_, ws->c_w.get(),
-                       ws->diag.get(), ws->grad.get(), ws->ipart.get());
+    hipLaunchKernelGGL(k_ba_lin_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, Rk_, tk_, X_, par_, ws->c_w.get(),
+                       diag_k, grad_k, ws->ipart.get(), sens);
     if (gridMulti_)  // combine pass over the cameras whose lists were cut into slices
-      hipLaunchKernelGGL(k_ba_lin_cam, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, R_, t_, X_, par_, ws->c_w.get(),
-                         ws->diag.get(), ws->grad.get(), ws->ipart.get());
+      hipLaunchKernelGGL(k_ba_lin_cam, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, Rk_, tk_, X_, par_, ws->c_w.get(),
+                         diag_k, grad_k, ws->ipart.get(), sens);
+    if (rig_) {  // lin_cam accumulated in the frame tangent: the frame's values are plain sums over its images
+      hipLaunchKernelGGL((k_ba_rig_sum<6>), dim3(gridN_), dim3(kBlock), 0, s, N_, ws->foff.get(), ws->fimg.get(), diag_k,
+                         ws->diag.get());
+      hipLaunchKernelGGL((k_ba_rig_sum<6>), dim3(gridN_), dim3(kBlock), 0, s, N_, ws->foff.get(), ws->fimg.get(), grad_k,
+                         ws->grad.get());
+    }
     group_sum<16>(ws->ipart.get(), ws->iacc16.get());
     hipLaunchKernelGGL(k_ba_intr_unpack16, dim3(grid_for(8 * (size_t)K_, kBlock)), dim3(kBlock), 0, s, N_, K_,
                        ws->iacc16.get(), ws->diag.get(), ws->grad.get());
@@ -1370,11 +1622,17 @@ class BaSolver final : public LmProblem {
         hipLaunchKernelGGL((k_ba_build_cam<true>), dim3(gridMulti_), dim3(kBlock), 0, s, g1_, R_, t_, par_, ws->c_w.get(),
                            ws->ptb.get(), ws->gred.get(), ws->spose.get(), ws->ipart.get(), ws->scross.get());
     } else {
-      hipLaunchKernelGGL((k_ba_build_cam<false>), dim3(gridCam_), dim3(kBlock), 0, s, g_, R_, t_, par_, ws->c_w.get(),
-                         ws->ptb.get(), ws->gred.get(), ws->spose.get(), ws->ipart.get(), (double*)nullptr);
+      double* gred_k = rig_ ? ws->gred_i.get() : ws->gred.get();
+      double* spose_k = rig_ ? ws->spose_i.get() : ws->spose.get();
+      hipLaunchKernelGGL((k_ba_build_cam<false>), dim3(gridCam_), dim3(kBlock), 0, s, g_, Rk_, tk_, par_, ws->c_w.get(),
+                         ws->ptb.get(), gred_k, spose_k, ws->ipart.get(), (double*)nullptr);
       if (gridMulti_)
-        hipLaunchKernelGGL((k_ba_build_cam<false>), dim3(gridMulti_), dim3(kBlock), 0, s, g1_, R_, t_, par_, ws->c_w.get(),
-                           ws->ptb.get(), ws->gred.get(), ws->spose.get(), ws->ipart.get(), (double*)nullptr);
+        hipLaunchKernelGGL((k_ba_build_cam<false>), dim3(gridMulti_), dim3(kBlock), 0, s, g1_, Rk_, tk_, par_, ws->c_w.get(),
+                           ws->ptb.get(), gred_k, spose_k, ws->ipart.get(), (double*)nullptr);
+      if (rig_)  // frame blocks: sum over the frame's images of T^T g and T^T S T (cross blocks between two images of
+                 // one frame are left to the PCG: this is the preconditioner and the right-hand side)
+        hipLaunchKernelGGL(k_ba_rig_reduce_blocks, dim3(gridN_), dim3(kBlock), 0, s, N_, ws->foff.get(), ws->fimg.get(),
+                           ws->sens.get(), gred_k, spose_k, ws->gred.get(), ws->spose.get());
     }
     group_sum<44>(ws->ipart.get(), ws->iacc44.get());
     if (multi) {
@@ -1391,10 +1649,19 @@ class BaSolver final : public LmProblem {
     hipLaunchKernelGGL(k_ba_blocks_finalize, dim3(grid_for(N_ + K_, kBlock)), dim3(kBlock), 0, s, N_, K_, radius,
                        g_.lm_lo, g_.lm_hi, ws->diag.get(), ws->js.get(), ws->gred.get(), ws->spose.get(),
                        ws->iacc44.get(), ws->dvec.get(), ws->rhs.get(), ws->minv.get());
+    if (rig_)
+      hipLaunchKernelGGL(k_ba_rig_dvec, dim3(grid_for((size_t)ni_, kBlock)), dim3(kBlock), 0, s, NI_, N_, K_, ws->dvec.get(),
+                         ws->dvec_i.get());
     *linear_iterations = pcg();
+    const double* dy_k = ws->cg_x.get();
+    if (rig_) {  // the step of an image's pose is T_s times the step of its frame
+      hipLaunchKernelGGL(k_ba_rig_expand, dim3(grid_for((size_t)NI_ + K_, kBlock)), dim3(kBlock), 0, s, NI_, N_, K_,
+                         ws->img_frame.get(), ws->sens.get(), ws->cg_x.get(), ws->ximg.get());
+      dy_k = ws->ximg.get();
+    }
     dispatch_f(F_, [&](auto Fc) {
       hipLaunchKernelGGL((k_ba_backsub<decltype(Fc)::value>), dim3(gridTileP_), dim3(kBlock), 0, s, g_, X_, ws->jt.get(),
-                         ws->ptb.get(), ws->cg_x.get(), Xn_, ws->part.get());
+                         ws->ptb.get(), dy_k, Xn_, ws->part.get());
     });
     hipLaunchKernelGGL((k_ba_sum_partials<3>), dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridTileP_, ws->scal.get());
     const int gridU = std::min(64, grid_for(N_ + 8 * (size_t)K_, kBlock));
@@ -1403,8 +1670,9 @@ class BaSolver final : public LmProblem {
                        tn_, parn_, part2);
     hipLaunchKernelGGL((k_ba_sum_partials<3>), dim3(1), dim3(kBlock), 0, s, part2, gridU, ws->scal.get() + 3);
     hipLaunchKernelGGL(k_ba_cam_prepare, dim3(gridN_), dim3(kBlock), 0, s, N_, qn_, Rn_);
+    if (rig_) image_poses(Rn_, tn_, Rkn_, tkn_);
     double* part3 = ws->part.get() + kMaxBlocks * 4;
-    hipLaunchKernelGGL(k_ba_cost, dim3(gridM_), dim3(kBlock), 0, s, g_, Rn_, tn_, Xn_, parn_, part3);
+    hipLaunchKernelGGL(k_ba_cost, dim3(gridM_), dim3(kBlock), 0, s, g_, Rkn_, tkn_, Xn_, parn_, part3);
     hipLaunchKernelGGL((k_ba_sum_partials<1>), dim3(1), dim3(kBlock), 0, s, part3, gridM_, ws->scal.get() + 6);
     if (multi) {
       allreduce_sum(ctx_, ws->scal.get(), 3);
@@ -1426,6 +1694,8 @@ class BaSolver final : public LmProblem {
     std::swap(q_, qn_);
     std::swap(t_, tn_);
     std::swap(R_, Rn_);
+    std::swap(Rk_, Rkn_);  // (trivial rigs: the same buffers as R_ / t_)
+    std::swap(tk_, tkn_);
     std::swap(X_, Xn_);
     std::swap(par_, parn_);
   }
@@ -1455,31 +1725,43 @@ class BaSolver final : public LmProblem {
     const double yscale = ctx_->comm.rank == 0 ? 1.0 : 0.0;
     const double tol = opt_.lm.pcg_relative_tolerance;
     return cg_solve<6, true>(ctx_, cg_, tol, opt_.lm.pcg_max_iterations, [&](int it) {
+      // rigs: the sweeps run on per-image vectors (z_image = T_s z_frame) with a zero pose diagonal; everything else of
+      // the PCG state (partials, status, scalars — set by cg_solve on cg_) is shared with the frame-space solve
+      CgVec vk = cg_;
+      const double* dk = ws->dvec.get();
+      if (rig_) {
+        hipLaunchKernelGGL(k_ba_rig_expand, dim3(grid_for((size_t)NI_ + K_, kBlock)), dim3(kBlock), 0, s, NI_, N_, K_,
+                           ws->img_frame.get(), ws->sens.get(), cg_.z, ws->zimg.get());
+        vk.z = ws->zimg.get();
+        vk.w = ws->wimg.get();
+        dk = ws->dvec_i.get();
+      }
       bool timed = ctx_->prof.begin(s, GSFM_KERNEL_BA_SCHUR);
       dispatch_f(F_, [&](auto Fc) {
         static const bool nt = getenv("GSFM_BA_NO_NT") == nullptr;  // measured on C4: 240 us -> 210 (loads first) -> 193 (+ non-temporal)
         if (nt)
-          hipLaunchKernelGGL((k_ba_phaseA<decltype(Fc)::value, true>), dim3(gridTile_), dim3(kBlock), 0, s, g_, cg_, it,
+          hipLaunchKernelGGL((k_ba_phaseA<decltype(Fc)::value, true>), dim3(gridTile_), dim3(kBlock), 0, s, g_, vk, it,
                              tol * tol, ws->jt.get(), ws->pth.get(), ws->ptrec.get());
         else
-          hipLaunchKernelGGL((k_ba_phaseA<decltype(Fc)::value, false>), dim3(gridTile_), dim3(kBlock), 0, s, g_, cg_, it,
+          hipLaunchKernelGGL((k_ba_phaseA<decltype(Fc)::value, false>), dim3(gridTile_), dim3(kBlock), 0, s, g_, vk, it,
                              tol * tol, ws->jt.get(), ws->pth.get(), ws->ptrec.get());
       });
       if (timed) ctx_->prof.end(s);
       timed = ctx_->prof.begin(s, GSFM_KERNEL_BA_SCHUR_B);
-      hipLaunchKernelGGL(k_ba_phaseB, dim3(gridCam_), dim3(kBlock), 0, s, g_, cg_, yscale, R_, t_, par_,
-                         ws->c_w.get(), ws->ptrec.get(), ws->dvec.get(), ws->yi_part.get(), 0);
+      hipLaunchKernelGGL(k_ba_phaseB, dim3(gridCam_), dim3(kBlock), 0, s, g_, vk, yscale, Rk_, tk_, par_,
+                         ws->c_w.get(), ws->ptrec.get(), dk, ws->yi_part.get(), 0);
       if (gridMulti_)
-        hipLaunchKernelGGL(k_ba_phaseB, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, cg_, yscale, R_, t_, par_,
-                           ws->c_w.get(), ws->ptrec.get(), ws->dvec.get(), ws->yi_part.get(), gridCam_ + gridK_);
+        hipLaunchKernelGGL(k_ba_phaseB, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, vk, yscale, Rk_, tk_, par_,
+                           ws->c_w.get(), ws->ptrec.get(), dk, ws->yi_part.get(), gridCam_ + gridK_);
       if (timed) ctx_->prof.end(s);
       if (small_groups_) {
-        hipLaunchKernelGGL(k_ba_phaseI_small, dim3(gridK_), dim3(kBlock), 0, s, g_, cg_, yscale, ws->yi_part.get(),
-                           ws->dvec.get(), gridCam_);
+        hipLaunchKernelGGL(k_ba_phaseI_small, dim3(gridK_), dim3(kBlock), 0, s, g_, vk, yscale, ws->yi_part.get(), dk, gridCam_);
       } else {
-        hipLaunchKernelGGL(k_ba_phaseI, dim3(gridK_), dim3(kBlock), 0, s, g_, cg_, yscale, ws->yi_part.get(),
-                           ws->dvec.get(), gridCam_);
+        hipLaunchKernelGGL(k_ba_phaseI, dim3(gridK_), dim3(kBlock), 0, s, g_, vk, yscale, ws->yi_part.get(), dk, gridCam_);
       }
+      if (rig_)
+        hipLaunchKernelGGL(k_ba_rig_reduce_w, dim3(1), dim3(kBlock), 0, s, cg_, NI_, yscale, ws->foff.get(), ws->fimg.get(),
+                           ws->sens.get(), ws->wimg.get(), ws->dvec.get(), gridCam_ + gridK_ + gridMulti_);
     });
   }
 
@@ -1489,6 +1771,9 @@ class BaSolver final : public LmProblem {
   BaDev g_{}, g1_{};
   CgVec cg_{};
   int N_ = 0, K_ = 0, n_ = 0, F_ = 0, max_group_ = 0;
+  int NI_ = 0, ni_ = 0, gridNI_ = 1;  // cameras of the observation graph (= N_, or the images of calibrated rigs)
+  bool rig_ = false;
+  double *Rk_ = nullptr, *Rkn_ = nullptr, *tk_ = nullptr, *tkn_ = nullptr;  // poses the sweeps see (frames or images)
   bool small_groups_ = false, joint_ = false;
   long P_ = 0, M_ = 0, Mp_ = 0, m_used_ = 0;
   int gridP_ = 1, gridN_ = 1, gridM_ = 1, gridCam_ = 1, gridMulti_ = 0, gridTile_ = 1, gridTileP_ = 1, gridK_ = 1;
@@ -1555,7 +1840,13 @@ extern "C" int gsfm_ba_solve(gsfm_ctx* ctx, const gsfm_ba_problem* prob, const g
     dump.array("pt_offset", prob->pt_offset, {P + 1}, prob->mem);
     dump.array("obs_cam", prob->obs_cam, {M}, prob->mem);
     dump.array("obs_xy", prob->obs_xy, {M, 2}, prob->mem);
-    dump.array("cam_intr", prob->cam_intr, {N}, prob->mem);
+    if (prob->cam_intr) dump.array("cam_intr", prob->cam_intr, {N}, prob->mem);
+    if (prob->num_images > 0 && prob->image_frame && prob->image_cam_from_rig && prob->image_intr) {
+      const int64_t I = prob->num_images;
+      dump.array("image_frame", prob->image_frame, {I}, prob->mem);
+      dump.array("image_cam_from_rig", prob->image_cam_from_rig, {I, 7}, prob->mem);
+      dump.array("image_intr", prob->image_intr, {I}, prob->mem);
+    }
     dump.array("intr_model", prob->intr_model, {K}, prob->mem);
     dump.array("cam_q", cam_q_inout, {N, 4}, prob->mem);
     dump.array("cam_t", cam_t_inout, {N, 3}, prob->mem);

@@ -591,6 +591,75 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// ---- calibrated rigs -----------------------------------------------------------------------------------------
+// RigBATAPairwiseDirectionError with the rig scale constant (cost_function.h:49-82, global_positioning.cc:318-350,
+// 470-478): r = v - s (X - c_frame + t_rig), t_rig = R_cw^T t_cam_from_rig per IMAGE.  Every sweep above keeps working
+// on "cameras" = images with centre c_image = c_frame - t_rig; the unknowns, the LM diagonal, the block-Jacobi blocks
+// and the PCG vectors live per FRAME.  Two small kernels translate: frame -> image (gather: state, z, dc) and image ->
+// frame (fixed-order sum over the frame's images: gradient, diagonal, Schur blocks, w).  Since z_image = z_frame, the
+// delta = z.w partials of the image-space sweep are already the frame-space ones.
+__global__ void __launch_bounds__(kBlock)
+    k_rig_expand3(int NI, const int* __restrict__ img_frame, const double* __restrict__ src_frame,
+                  const double* __restrict__ img_off /* null: plain gather */, double* __restrict__ dst_img,
+                  double* __restrict__ cz /* null, or the (c | z) gather records */, int cz_slot) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < NI; i += gridDim.x * blockDim.x) {
+    const long f = img_frame[i];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double v = src_frame[3 * f + j];
+      if (img_off) v -= img_off[3 * (long)i + j];
+      dst_img[3 * (long)i + j] = v;
+      if (cz) cz[6 * (long)i + cz_slot + j] = v;
+    }
+  }
+}
+
+template <int W>
+__global__ void __launch_bounds__(kBlock)
+    k_rig_reduce(int N, const int* __restrict__ foff, const int* __restrict__ fimg, const double* __restrict__ src_img,
+                 double* __restrict__ dst_frame) {
+  for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < N; f += gridDim.x * blockDim.x) {
+    double acc[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) acc[j] = 0.0;
+    for (int a = foff[f]; a < foff[f + 1]; ++a) {
+      const double* sp = src_img + (long)W * fimg[a];
+#pragma unroll
+      for (int j = 0; j < W; ++j) acc[j] += sp[j];
+    }
+#pragma unroll
+    for (int j = 0; j < W; ++j) dst_frame[(long)W * f + j] = acc[j];
+  }
+}
+
+// w_frame = sum over the frame's images of w_image + D_frame z_frame (the image-space sweep ran without the damping
+// term); the damping share of delta, sum_f z_f . D_f z_f, goes to its own partial slot.  One workgroup: N is small.
+__global__ void __launch_bounds__(kBlock)
+    k_rig_reduce_w(CgVec v, double yscale, const int* __restrict__ foff, const int* __restrict__ fimg,
+                   const double* __restrict__ w_img, const double* __restrict__ dcam, int dslot) {
+  __shared__ double smem[4];
+  if (v.st->done) return;
+  double d[1] = {0.0};
+  for (int f = threadIdx.x; f < v.N; f += blockDim.x) {
+    double acc[3] = {0, 0, 0};
+    for (int a = foff[f]; a < foff[f + 1]; ++a) {
+      const double* sp = w_img + 3 * (long)fimg[a];
+      acc[0] += sp[0];
+      acc[1] += sp[1];
+      acc[2] += sp[2];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const double z = v.z[3 * (long)f + j];
+      const double dz = yscale * dcam[3 * (long)f + j] * z;
+      v.w[3 * (long)f + j] = acc[j] + dz;
+      d[0] += z * dz;
+    }
+  }
+  block_sum<1>(d, smem);
+  if (threadIdx.x == 0) v.dpart[dslot] = d[0];
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -603,6 +672,9 @@ struct GpWs {
       jsc, dcam, gc, gred, scc, minv, rhs, cz, cg_x, cg_r, cg_z, cg_p, cg_s, cg_w, vpart, dpart, part, scal;
   DevBuf<CgStatus> cgst;
   DevBuf<CgScal> cgsc;
+  // calibrated rigs: image tables and the image-space twins of the per-camera arrays
+  DevBuf<int> img_frame, foff, fimg;
+  DevBuf<double> img_off, ci, cin, hcc_i, gc_i, gred_i, scc_i, zimg, wimg, ximg, zero_i, cz_f;
   static void destroy(void* p) { delete static_cast<GpWs*>(p); }
 };
 
@@ -626,6 +698,15 @@ class GpSolver final : public LmProblem {
     P_ = prob->num_pts;
     M_ = prob->num_obs;
     GSFM_REQUIRE(N_ > 0 && P_ >= 0 && M_ >= 0, "GP: bad sizes");
+    // calibrated rigs: the observation graph is over IMAGES (NI_ cameras), the unknowns are the N_ frames
+    rig_ = prob->num_images > 0;
+    NI_ = rig_ ? prob->num_images : N_;
+    std::vector<int> h_imf;
+    if (rig_) {
+      GSFM_REQUIRE(prob->image_frame && prob->image_offset, "GP: image tables missing");
+      to_host(ctx_, h_imf, prob->image_frame, (size_t)NI_, mem);
+      for (int i = 0; i < NI_; ++i) GSFM_REQUIRE(h_imf[i] >= 0 && h_imf[i] < N_, "GP: image_frame out of range");
+    }
     std::vector<long> h_off;
     to_host(ctx_, h_off, reinterpret_cast<const long*>(prob->pt_offset), (size_t)P_ + 1, mem);
     GSFM_REQUIRE(h_off[0] == 0 && h_off[P_] == M_, "GP: pt_offset must start at 0 and end at num_obs");
@@ -638,7 +719,7 @@ class GpSolver final : public LmProblem {
       d_cal = ws->cal.get();
     }
     long fixed_obs = -1;
-    m_used_ = build_obs_graph(ctx_, ws->og, N_, P_, M_, h_off, ws->off.get(), ws->cam.get(),
+    m_used_ = build_obs_graph(ctx_, ws->og, NI_, P_, M_, h_off, ws->off.get(), ws->cam.get(),
                               opt_.min_num_view_per_track /* gp.cc:258 */, g_.g, &fixed_obs);
     if (ctx_->comm.rank != 0) fixed_obs = -1;  // one constant scale in the whole problem
     // camera-major copies of the per-observation inputs
@@ -653,8 +734,8 @@ class GpSolver final : public LmProblem {
       d_ccal = ws->c_cal.get();
     }
     // which cameras carry at least one used observation (gp.cc:128-162: only those are re-drawn)
-    std::vector<int> h_coff(N_ + 2);
-    GSFM_HIP_CHECK(hipMemcpyAsync(h_coff.data(), g_.g.coff, (size_t)(N_ + 2) * sizeof(int), hipMemcpyDeviceToHost, s));
+    std::vector<int> h_coff(NI_ + 2);
+    GSFM_HIP_CHECK(hipMemcpyAsync(h_coff.data(), g_.g.coff, (size_t)(NI_ + 2) * sizeof(int), hipMemcpyDeviceToHost, s));
     // state init (gp.cc:123-165, 261-264): cameras by index, then used tracks by index
     std::vector<double> h_c, h_X;
     to_host(ctx_, h_c, cam_center, 3 * (size_t)N_, mem);
@@ -666,12 +747,13 @@ class GpSolver final : public LmProblem {
     // Track shards over several ranks draw EXACTLY the numbers the unsharded problem would: a camera is constrained when
     // any rank observes it, and a rank's point draws start where the lower ranks' used tracks end in the one global
     // std::mt19937 stream (two 32-bit outputs per double, libstdc++ generate_canonical).
-    std::vector<char> constrained(N_);
+    std::vector<char> constrained(N_, 0);
     long used_before = 0;
     {
       long used_here = 0;
       for (long p = 0; p < P_; ++p) used_here += (h_off[p + 1] - h_off[p] >= opt_.min_num_view_per_track) ? 1 : 0;
-      for (int n = 0; n < N_; ++n) constrained[n] = h_coff[n + 1] > h_coff[n];
+      for (int i = 0; i < NI_; ++i)  // a frame is constrained when one of its images carries a used observation
+        if (h_coff[i + 1] > h_coff[i]) constrained[rig_ ? h_imf[i] : i] = 1;
       const int W = ctx_->comm.world;
       if (W > 1) {
         std::vector<double> h((size_t)N_ + W, 0.0);
@@ -720,7 +802,27 @@ class GpSolver final : public LmProblem {
     ws->jsc.ensure(N_);
     ws->scc.ensure(6 * (size_t)N_);
     ws->minv.ensure(9 * (size_t)N_);
-    ws->cz.ensure(6 * (size_t)N_ + 2);
+    ws->cz.ensure(6 * (size_t)NI_ + 2);
+    if (rig_) {
+      // image tables + frame -> images lists (images of a frame in ascending image order: a fixed summation order)
+      std::vector<int> foff((size_t)N_ + 1, 0), fimg((size_t)NI_);
+      for (int i = 0; i < NI_; ++i) foff[h_imf[i] + 1]++;
+      for (int f = 0; f < N_; ++f) foff[f + 1] += foff[f];
+      std::vector<int> cur(foff.begin(), foff.end() - 1);
+      for (int i = 0; i < NI_; ++i) fimg[cur[h_imf[i]]++] = i;
+      GSFM_HIP_CHECK(hipMemcpyAsync(ws->img_frame.ensure(NI_), h_imf.data(), (size_t)NI_ * sizeof(int), hipMemcpyHostToDevice, s));
+      GSFM_HIP_CHECK(hipMemcpyAsync(ws->foff.ensure(N_ + 1), foff.data(), (size_t)(N_ + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+      GSFM_HIP_CHECK(hipMemcpyAsync(ws->fimg.ensure(NI_), fimg.data(), (size_t)NI_ * sizeof(int), hipMemcpyHostToDevice, s));
+      copy_in(ctx_, ws->img_off.ensure(3 * (size_t)NI_), prob->image_offset, 3 * (size_t)NI_, mem);
+      GSFM_HIP_CHECK(hipStreamSynchronize(s));  // the host vectors above go out of scope
+      for (DevBuf<double>* b : {&ws->ci, &ws->cin, &ws->gc_i, &ws->gred_i, &ws->zimg, &ws->ximg, &ws->zero_i})
+        b->ensure(3 * (size_t)NI_);
+      ws->wimg.ensure(3 * (size_t)NI_ + 2);
+      ws->hcc_i.ensure(NI_);
+      ws->scc_i.ensure(6 * (size_t)NI_);
+      ws->cz_f.ensure(6 * (size_t)N_ + 2);
+      GSFM_HIP_CHECK(hipMemsetAsync(ws->zero_i.get(), 0, 3 * (size_t)NI_ * sizeof(double), s));
+    }
     for (DevBuf<double>* b : {&ws->dcam, &ws->gc, &ws->gred, &ws->rhs, &ws->cg_x, &ws->cg_r, &ws->cg_z, &ws->cg_p, &ws->cg_s})
       b->ensure(3 * (size_t)N_);
     ws->cg_w.ensure(3 * (size_t)N_ + 2);
@@ -732,6 +834,7 @@ class GpSolver final : public LmProblem {
     ws->cgsc.ensure(2);
     gridP_ = grid_for(P_, kBlock);
     gridN_ = grid_for(N_, kBlock);
+    gridNI_ = grid_for(NI_, kBlock);
     gridM_ = grid_for(M_, kBlock);
     gridCam_ = grid_wide(g_.g.S, kBlock / 64, kMaxApplySlots);  // one wave per camera segment (delta partial per block)
     gridMulti_ = g_.g.nmulti > 0 ? grid_for(g_.g.nmulti, kBlock / 64) : 0;  // combine pass: one wave per cut camera
@@ -757,7 +860,11 @@ class GpSolver final : public LmProblem {
     Xn_ = ws->Xn.get();
     s_ = ws->s.get();
     sn_ = ws->sn.get();
-    hipLaunchKernelGGL(k_gp_init_scales, dim3(gridM_), dim3(kBlock), 0, s, g_, opt_.generate_scales ? 1 : 0, c_, X_, s_);
+    // what the sweeps see as "camera centres": the frames' own, or the images' (c_frame - t_rig) for calibrated rigs
+    ci_ = rig_ ? ws->ci.get() : c_;
+    cin_ = rig_ ? ws->cin.get() : cn_;
+    if (rig_) expand_centres(c_, ci_, /*also_cz=*/false);
+    hipLaunchKernelGGL(k_gp_init_scales, dim3(gridM_), dim3(kBlock), 0, s, g_, opt_.generate_scales ? 1 : 0, ci_, X_, s_);
     // tracks without observations are never visited by the lane-per-observation sweeps: both point buffers start equal
     GSFM_HIP_CHECK(hipMemcpyAsync(Xn_, X_, 3 * (size_t)P_ * sizeof(double), hipMemcpyDeviceToDevice, s));
     // PCG view
@@ -778,9 +885,23 @@ class GpSolver final : public LmProblem {
     cg_.dpart = ws->dpart.get();
     cg_.scal = ws->cgsc.get();
     cg_.st = ws->cgst.get();
-    cg_.zmir = ws->cz.get();
+    cg_.zmir = rig_ ? nullptr : ws->cz.get();  // rigs: z reaches the (c | z) records through expand_z()
     cg_.zmir_stride = 6;
     cg_.zmir_off = 3;
+    if (rig_) {
+      cg_.nb_apply = gridCam_ + gridMulti_ + 1;  // + the damping share of delta (k_rig_reduce_w)
+    }
+  }
+
+  // image centres = frame centres - t_rig (and, on request, the c part of the (c | z) gather records)
+  void expand_centres(const double* c_frame, double* c_img, bool also_cz) {
+    hipLaunchKernelGGL(k_rig_expand3, dim3(gridNI_), dim3(kBlock), 0, ctx_->stream, NI_, ws_->img_frame.get(), c_frame,
+                       ws_->img_off.get(), c_img, also_cz ? ws_->cz.get() : nullptr, 0);
+  }
+  template <int W>
+  void reduce_to_frames(const double* src_img, double* dst_frame) {
+    hipLaunchKernelGGL((k_rig_reduce<W>), dim3(gridN_), dim3(kBlock), 0, ctx_->stream, N_, ws_->foff.get(), ws_->fimg.get(),
+                       src_img, dst_frame);
   }
 
   long used_observations() const { return m_used_; }
@@ -788,11 +909,17 @@ class GpSolver final : public LmProblem {
   double linearize(double* grad_max_norm) override {
     GpWs* ws = ws_;
     hipStream_t s = ctx_->stream;
-    hipLaunchKernelGGL(k_gp_lin_track, dim3(gridTileP_), dim3(kBlock), 0, s, g_, c_, X_, s_, ws->wrob.get(),
+    double* hcc_k = rig_ ? ws->hcc_i.get() : ws->hcc.get();  // per graph camera (image); reduced to frames below
+    double* gc_k = rig_ ? ws->gc_i.get() : ws->gc.get();
+    hipLaunchKernelGGL(k_gp_lin_track, dim3(gridTileP_), dim3(kBlock), 0, s, g_, ci_, X_, s_, ws->wrob.get(),
                        ws->hppd.get(), ws->part.get());
-    hipLaunchKernelGGL(k_gp_lin_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, c_, X_, s_, ws->hcc.get(), ws->gc.get());
+    hipLaunchKernelGGL(k_gp_lin_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, ci_, X_, s_, hcc_k, gc_k);
     if (gridMulti_)  // combine pass over the cameras whose lists were cut into slices (obsgraph.hpp)
-      hipLaunchKernelGGL(k_gp_lin_cam, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, c_, X_, s_, ws->hcc.get(), ws->gc.get());
+      hipLaunchKernelGGL(k_gp_lin_cam, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, ci_, X_, s_, hcc_k, gc_k);
+    if (rig_) {
+      reduce_to_frames<1>(hcc_k, ws->hcc.get());
+      reduce_to_frames<3>(gc_k, ws->gc.get());
+    }
     if (ctx_->comm.world > 1) {
       allreduce_sum(ctx_, ws->hcc.get(), N_);
       allreduce_sum(ctx_, ws->gc.get(), 3 * (size_t)N_);
@@ -808,7 +935,7 @@ class GpSolver final : public LmProblem {
   void set_jacobi_scaling(bool enabled) override {
     GpWs* ws = ws_;
     hipStream_t s = ctx_->stream;
-    hipLaunchKernelGGL(k_gp_jacobi_obs, dim3(gridP_), dim3(kBlock), 0, s, g_, enabled ? 1 : 0, c_, X_,
+    hipLaunchKernelGGL(k_gp_jacobi_obs, dim3(gridP_), dim3(kBlock), 0, s, g_, enabled ? 1 : 0, ci_, X_,
                        ws->wrob.get(), ws->hppd.get(), ws->jss.get(), ws->jsx.get());
     hipLaunchKernelGGL((k_og_gather_f64<1>), dim3(grid_for(g_.g.Mu, kBlock)), dim3(kBlock), 0, s, g_.g.Mu, g_.g.c_src,
                        ws->jss.get(), ws->c_jss.get());
@@ -822,14 +949,22 @@ class GpSolver final : public LmProblem {
     hipStream_t s = ctx_->stream;
     const bool multi = ctx_->comm.world > 1;
     const int n3 = 3 * N_;
-    hipLaunchKernelGGL(k_gp_build_track, dim3(gridTile_), dim3(kBlock), 0, s, g_, radius, c_, X_, s_, ws->wrob.get(),
+    double* gred_k = rig_ ? ws->gred_i.get() : ws->gred.get();
+    double* scc_k = rig_ ? ws->scc_i.get() : ws->scc.get();
+    hipLaunchKernelGGL(k_gp_build_track, dim3(gridTile_), dim3(kBlock), 0, s, g_, radius, ci_, X_, s_, ws->wrob.get(),
                        ws->jss.get(), ws->jsx.get(), ws->hppd.get(), ws->qa.get(), ws->qb.get(), ws->ptb.get(),
                        ws->ptrec.get(), ws->pth.get());
-    hipLaunchKernelGGL(k_gp_build_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, radius, c_, s_, ws->ptb.get(),
-                       ws->c_qa.get(), ws->c_qb.get(), ws->gred.get(), ws->scc.get());
+    hipLaunchKernelGGL(k_gp_build_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, radius, ci_, s_, ws->ptb.get(),
+                       ws->c_qa.get(), ws->c_qb.get(), gred_k, scc_k);
     if (gridMulti_)
-      hipLaunchKernelGGL(k_gp_build_cam, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, radius, c_, s_, ws->ptb.get(),
-                         ws->c_qa.get(), ws->c_qb.get(), ws->gred.get(), ws->scc.get());
+      hipLaunchKernelGGL(k_gp_build_cam, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, radius, ci_, s_, ws->ptb.get(),
+                         ws->c_qa.get(), ws->c_qb.get(), gred_k, scc_k);
+    if (rig_) {
+      // reduced gradient of a frame = sum over its images; its block-Jacobi block = sum of the images' diagonal Schur
+      // blocks (the cross blocks between two images of one frame are left to the PCG: it is a preconditioner)
+      reduce_to_frames<3>(gred_k, ws->gred.get());
+      reduce_to_frames<6>(scc_k, ws->scc.get());
+    }
     if (multi) {
       allreduce_sum(ctx_, ws->gred.get(), n3);
       allreduce_sum(ctx_, ws->scc.get(), 6 * (size_t)N_);
@@ -838,20 +973,28 @@ class GpSolver final : public LmProblem {
     if (g_.opt_c) {
       hipLaunchKernelGGL(k_gp_cam_finalize, dim3(gridN_), dim3(kBlock), 0, s, N_, radius, g_.lm_lo, g_.lm_hi,
                          ws->hcc.get(), ws->jsc.get(), ws->gred.get(), ws->scc.get(), ws->dcam.get(),
-                         ws->rhs.get(), ws->minv.get(), c_, ws->cz.get());
+                         ws->rhs.get(), ws->minv.get(), c_, rig_ ? ws->cz_f.get() : ws->cz.get());
+      if (rig_) expand_centres(c_, ci_, /*also_cz=*/true);  // the c part of the per-image (c | z) records
       *linear_iterations = pcg();
     } else {
       GSFM_HIP_CHECK(hipMemsetAsync(ws->cg_x.get(), 0, (size_t)n3 * sizeof(double), s));
     }
-    hipLaunchKernelGGL(k_gp_backsub, dim3(gridTileP_), dim3(kBlock), 0, s, g_, c_, X_, s_, ws->wrob.get(),
-                       ws->qa.get(), ws->qb.get(), ws->ptb.get(), ws->cg_x.get(), Xn_, sn_, ws->part.get());
+    const double* dc_k = ws->cg_x.get();
+    if (rig_) {  // the step of an image's centre is the step of its frame
+      hipLaunchKernelGGL(k_rig_expand3, dim3(gridNI_), dim3(kBlock), 0, s, NI_, ws->img_frame.get(), ws->cg_x.get(),
+                         (const double*)nullptr, ws->ximg.get(), (double*)nullptr, 0);
+      dc_k = ws->ximg.get();
+    }
+    hipLaunchKernelGGL(k_gp_backsub, dim3(gridTileP_), dim3(kBlock), 0, s, g_, ci_, X_, s_, ws->wrob.get(),
+                       ws->qa.get(), ws->qb.get(), ws->ptb.get(), dc_k, Xn_, sn_, ws->part.get());
     hipLaunchKernelGGL((k_sum_partials<3>), dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridTileP_, ws->scal.get());
     const int gridU = std::min(64, grid_for(n3, kBlock));
     double* part2 = ws->part.get() + kMaxBlocks * 3;
     hipLaunchKernelGGL(k_gp_cam_update, dim3(gridU), dim3(kBlock), 0, s, n3, c_, ws->cg_x.get(), cn_, part2);
     hipLaunchKernelGGL((k_sum_partials<3>), dim3(1), dim3(kBlock), 0, s, part2, gridU, ws->scal.get() + 3);
     double* part3 = ws->part.get() + kMaxBlocks * 4;
-    hipLaunchKernelGGL(k_gp_cost, dim3(gridM_), dim3(kBlock), 0, s, g_, cn_, Xn_, sn_, part3);
+    if (rig_) expand_centres(cn_, cin_, /*also_cz=*/false);
+    hipLaunchKernelGGL(k_gp_cost, dim3(gridM_), dim3(kBlock), 0, s, g_, cin_, Xn_, sn_, part3);
     hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(kBlock), 0, s, part3, gridM_, ws->scal.get() + 6);
     if (multi) {
       // track-local sums: model change, |dX|^2+|ds|^2, |X|^2+|s|^2 and the candidate cost
@@ -873,6 +1016,7 @@ class GpSolver final : public LmProblem {
 
   void accept() override {
     std::swap(c_, cn_);
+    std::swap(ci_, cin_);  // (trivial rigs: the same two buffers)
     std::swap(X_, Xn_);
     std::swap(s_, sn_);
   }
@@ -904,17 +1048,31 @@ class GpSolver final : public LmProblem {
     const double yscale = ctx_->comm.rank == 0 ? 1.0 : 0.0;
     const double tol = opt_.lm.pcg_relative_tolerance;
     return cg_solve<3, false>(ctx_, cg_, tol, opt_.lm.pcg_max_iterations, [&](int it) {
+      if (rig_)  // z of an image = z of its frame: into the per-image vector and the (c | z) gather records
+        hipLaunchKernelGGL(k_rig_expand3, dim3(gridNI_), dim3(kBlock), 0, s, NI_, ws->img_frame.get(), cg_.z,
+                           (const double*)nullptr, ws->zimg.get(), ws->cz.get(), 3);
+      CgVec vk = cg_;  // (cg_solve sets the solve-time fields of cg_; the image-space view shares all of them)
+      if (rig_) {
+        vk.z = ws->zimg.get();
+        vk.w = ws->wimg.get();
+      }
       bool timed = ctx_->prof.begin(s, GSFM_KERNEL_GP_SCHUR);
-      hipLaunchKernelGGL(k_gp_phaseA, dim3(gridTile_), dim3(kBlock), 0, s, g_, cg_, it, tol * tol, ws->cz.get(), ws->qa.get(),
+      hipLaunchKernelGGL(k_gp_phaseA, dim3(gridTile_), dim3(kBlock), 0, s, g_, vk, it, tol * tol, ws->cz.get(), ws->qa.get(),
                          ws->qb.get(), ws->pth.get(), ws->ptrec.get());
       if (timed) ctx_->prof.end(s);
       timed = ctx_->prof.begin(s, GSFM_KERNEL_GP_SCHUR_B);
-      hipLaunchKernelGGL(k_gp_phaseB, dim3(gridCam_), dim3(kBlock), 0, s, g_, cg_, yscale, c_, ws->c_qa.get(),
-                         ws->c_qb.get(), ws->ptrec.get(), ws->dcam.get(), 0);
+      // rigs: the damping D z is a frame-space term, added by k_rig_reduce_w (the sweep runs with a zero diagonal)
+      const double* dk = rig_ ? ws->zero_i.get() : ws->dcam.get();
+      const double ys = rig_ ? 0.0 : yscale;
+      hipLaunchKernelGGL(k_gp_phaseB, dim3(gridCam_), dim3(kBlock), 0, s, g_, vk, ys, ci_, ws->c_qa.get(),
+                         ws->c_qb.get(), ws->ptrec.get(), dk, 0);
       if (gridMulti_)
-        hipLaunchKernelGGL(k_gp_phaseB, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, cg_, yscale, c_, ws->c_qa.get(),
-                           ws->c_qb.get(), ws->ptrec.get(), ws->dcam.get(), gridCam_);
+        hipLaunchKernelGGL(k_gp_phaseB, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, vk, ys, ci_, ws->c_qa.get(),
+                           ws->c_qb.get(), ws->ptrec.get(), dk, gridCam_);
       if (timed) ctx_->prof.end(s);
+      if (rig_)
+        hipLaunchKernelGGL(k_rig_reduce_w, dim3(1), dim3(kBlock), 0, s, cg_, yscale, ws->foff.get(), ws->fimg.get(),
+                           ws->wimg.get(), ws->dcam.get(), gridCam_ + gridMulti_);
     });
   }
 
@@ -923,7 +1081,11 @@ class GpSolver final : public LmProblem {
   gsfm_gp_options opt_;
   GpDev g_{}, g1_{};
   CgVec cg_{};
-  int N_ = 0;
+  int N_ = 0;        // unknown camera blocks (frames)
+  int NI_ = 0;       // cameras of the observation graph (= N_, or the images of calibrated rigs)
+  bool rig_ = false;
+  int gridNI_ = 1;
+  double *ci_ = nullptr, *cin_ = nullptr;
   long P_ = 0, M_ = 0, m_used_ = 0;
   int gridP_ = 1, gridN_ = 1, gridM_ = 1, gridCam_ = 1, gridMulti_ = 0, gridTile_ = 1, gridTileP_ = 1;
   double *c_ = nullptr, *cn_ = nullptr, *X_ = nullptr, *Xn_ = nullptr, *s_ = nullptr, *sn_ = nullptr;
@@ -991,6 +1153,10 @@ extern "C" int gsfm_gp_solve(gsfm_ctx* ctx, const gsfm_gp_problem* prob, const g
     dump.array("obs_cam", prob->obs_cam, {M}, prob->mem);
     dump.array("obs_dir", prob->obs_dir, {M, 3}, prob->mem);
     dump.array("obs_calibrated", prob->obs_calibrated, {M}, prob->mem);
+    if (prob->num_images > 0 && prob->image_frame && prob->image_offset) {
+      dump.array("image_frame", prob->image_frame, {(int64_t)prob->num_images}, prob->mem);
+      dump.array("image_offset", prob->image_offset, {(int64_t)prob->num_images, 3}, prob->mem);
+    }
     dump.array("cam_center", cam_center_inout, {N, 3}, prob->mem);
     dump.array("pt_xyz", pt_xyz_inout, {P, 3}, prob->mem);
     dump_lm_options(dump, &opt->lm);

@@ -89,15 +89,18 @@ def to_problem(rec: FlatRecord):
     if rec.kind == "gp":
         M = len(a["obs_cam"])
         p = GpProblem(int(s["num_cams"]), len(a["pt_offset"]) - 1, a["pt_offset"], a["obs_cam"], a["obs_dir"],
-                      a.get("obs_calibrated", np.ones(M, np.uint8)), a["cam_center"], a["pt_xyz"])
+                      a.get("obs_calibrated", np.ones(M, np.uint8)), a["cam_center"], a["pt_xyz"],
+                      image_frame=a.get("image_frame"), image_offset=a.get("image_offset"))  # calibrated rigs
         opt = _fill(estimators.GlobalPositionerOptions(), o)
         _lm(opt.solver_options, o)
         return p, opt
     if rec.kind == "ba":
         p = BaProblem(num_cams=int(s["num_cams"]), num_pts=len(a["pt_offset"]) - 1, num_intr=int(s["num_intr"]),
-                      pt_offset=a["pt_offset"], obs_cam=a["obs_cam"], obs_xy=a["obs_xy"], cam_intr=a["cam_intr"], cam_q=a["cam_q"],
+                      pt_offset=a["pt_offset"], obs_cam=a["obs_cam"], obs_xy=a["obs_xy"],
+                      cam_intr=a.get("cam_intr", np.zeros(int(s["num_cams"]), np.int32)), cam_q=a["cam_q"],
                       cam_t=a["cam_t"], pt_xyz=a["pt_xyz"], intr_model=a["intr_model"], intr_params=a["intr_params"],
-                      fixed_cam=int(s["fixed_cam"]))
+                      fixed_cam=int(s["fixed_cam"]), image_frame=a.get("image_frame"),
+                      image_cam_from_rig=a.get("image_cam_from_rig"), image_intr=a.get("image_intr"))
         opt = _fill(estimators.BundleAdjusterOptions(), o)
         _lm(opt.solver_options, o)
         return p, opt
@@ -115,12 +118,17 @@ def from_problem(p, options=None) -> FlatRecord:
         arrs = dict(pt_offset=np.asarray(p.pt_offset, np.int64), obs_cam=np.asarray(p.obs_cam, np.int32),
                     obs_dir=np.asarray(p.obs_dir, np.float64), obs_calibrated=np.asarray(p.obs_calibrated, np.uint8),
                     cam_center=np.asarray(p.cam_center, np.float64), pt_xyz=np.asarray(p.pt_xyz, np.float64))
+        if p.image_frame is not None:
+            arrs.update(image_frame=np.asarray(p.image_frame, np.int32), image_offset=np.asarray(p.image_offset, np.float64))
         return FlatRecord("gp", {"num_cams": p.num_cams}, _opts(options), arrays=arrs)
     if isinstance(p, BaProblem):
         arrs = dict(pt_offset=np.asarray(p.pt_offset, np.int64), obs_cam=np.asarray(p.obs_cam, np.int32), obs_xy=np.asarray(p.obs_xy, np.float64),
                     cam_intr=np.asarray(p.cam_intr, np.int32), intr_model=np.asarray(p.intr_model, np.int32),
                     cam_q=np.asarray(p.cam_q, np.float64), cam_t=np.asarray(p.cam_t, np.float64), pt_xyz=np.asarray(p.pt_xyz, np.float64),
                     intr_params=np.asarray(p.intr_params, np.float64))
+        if p.image_frame is not None:
+            arrs.update(image_frame=np.asarray(p.image_frame, np.int32), image_intr=np.asarray(p.image_intr, np.int32),
+                        image_cam_from_rig=np.asarray(p.image_cam_from_rig, np.float64))
         return FlatRecord("ba", {"num_cams": p.num_cams, "num_intr": p.num_intr, "fixed_cam": p.fixed_cam}, _opts(options), arrays=arrs)
     raise TypeError(type(p))
 

@@ -1,0 +1,129 @@
+"""Calibrated (known) multi-camera rigs — the shape of the reference's WithoutNoiseWithNonTrivialKnownRig mapper test
+(glomap/controllers/global_mapper_test.cc:89-126): frames of 2-3 cameras with known cam_from_rig.
+
+  GP: RigBATAPairwiseDirectionError with the rig scale constant (cost_function.h:49-82, global_positioning.cc:318-350, 470-478)
+  BA: colmap::RigReprojErrorConstantRigCostFunctor (bundle_adjustment.cc:147-160, optimize_rig_poses = false)
+
+CPU: the two oracles against each other and against ground truth.  GPU: the HIP path (sweeps over images, LM / PCG state
+per frame) through the C ABI against the oracles."""
+import numpy as np
+import pytest
+
+from glomap_amd import so3, synthetic
+from oracle import ba as oba
+from oracle import cpu
+from oracle import gp as ogp
+
+
+def _gp_kw(p):
+    return dict(image_frame=p.image_frame, image_offset=p.image_offset)
+
+
+def _ba_kw(p):
+    return dict(image_frame=p.image_frame, image_cam_from_rig=p.image_cam_from_rig, image_intr=p.image_intr)
+
+
+def _gp_args(p):
+    return (p.num_cams, p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated, p.cam_center, p.pt_xyz)
+
+
+def _ba_args(p):
+    return (p.num_cams, p.pt_offset, p.obs_cam, p.obs_xy, None, p.intr_model, p.fixed_cam, p.cam_q, p.cam_t, p.pt_xyz,
+            p.intr_params)
+
+
+def test_oracles_agree_on_rig_problems_and_recover_ground_truth():
+    gp, ba, info = synthetic.make_rig_problems(14, 2, 400, seed=0)
+    a = ogp.solve(*_gp_args(gp), **_gp_kw(gp))
+    b = cpu.gp_solve(*_gp_args(gp), **_gp_kw(gp))
+    assert a[0] and b[0] and a[3].iterations == b[3].iterations
+    assert np.abs(a[1] - b[1]).max() < 1e-7
+    # the rig translations are metric: the solution is fixed up to a RIGID motion, the Sim(3) fit must find scale 1
+    scale, _, _ = synthetic.align_sim3(a[1], gp.gt_center)
+    assert abs(scale - 1.0) < 2e-2
+    assert synthetic.center_errors_after_sim3(a[1], gp.gt_center).max() < 0.1
+    a = oba.solve(*_ba_args(ba), **_ba_kw(ba))
+    b = cpu.ba_solve(*_ba_args(ba), **_ba_kw(ba))
+    assert a[0] and b[0] and a[5].iterations == b[5].iterations
+    assert a[5].final_cost < 1e-9 * a[5].initial_cost  # noise-free: zero reprojection error
+    assert np.abs(a[1] - b[1]).max() < 1e-9 and np.abs(a[2] - b[2]).max() < 1e-7
+
+
+def test_identity_rigs_reduce_to_the_trivial_problem():
+    """One reference sensor per frame with identity cam_from_rig: bit-for-bit the plain problems in the oracle."""
+    p = synthetic.make_ba_problem(12, 250, seed=1)
+    ident = np.zeros((12, 7))
+    ident[:, 0] = 1
+    a = oba.solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_xy, p.cam_intr, p.intr_model, p.fixed_cam, p.cam_q, p.cam_t,
+                  p.pt_xyz, p.intr_params)
+    b = oba.solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_xy, None, p.intr_model, p.fixed_cam, p.cam_q, p.cam_t, p.pt_xyz,
+                  p.intr_params, image_frame=np.arange(12), image_cam_from_rig=ident, image_intr=p.cam_intr)
+    assert a[5].iterations == b[5].iterations and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frames,cams,pts,noise", [(14, 2, 400, 0.0), (40, 3, 4000, 1.0)])
+def test_gp_with_known_rigs_matches_oracle(gsfm_ctx, frames, cams, pts, noise):
+    from glomap_amd import estimators
+
+    gp, _, _ = synthetic.make_rig_problems(frames, cams, pts, seed=2, dir_noise=1e-3 * noise, outlier_ratio=0.01 * noise)
+    opt = estimators.GlobalPositionerOptions()
+    opt.solver_options.pcg_relative_tolerance = 1e-10
+    rc, cen, xyz, rep = estimators.gp_solve(gp, opt, ctx=gsfm_ctx)
+    assert rc == 0
+    ok, c_o, X_o, s = cpu.gp_solve(*_gp_args(gp), **_gp_kw(gp))
+    assert ok
+    assert abs(rep["initial_cost"] - s.initial_cost) <= 1e-12 * s.initial_cost  # same random start
+    assert abs(rep["iterations"] - s.iterations) <= 2
+    assert abs(rep["final_cost"] - s.final_cost) <= 1e-3 * s.final_cost + 1e-9
+    ext = np.linalg.norm(c_o - c_o.mean(0), axis=1).max()
+    assert synthetic.center_errors_after_sim3(cen, c_o).max() / ext < 1e-3
+    scale, _, _ = synthetic.align_sim3(cen, gp.gt_center)
+    assert abs(scale - 1.0) < 3e-2  # metric rig offsets fix the scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frames,cams,pts,noise", [(14, 2, 400, 0.0), (40, 3, 4000, 0.5)])
+def test_ba_with_known_rigs_matches_oracle(gsfm_ctx, frames, cams, pts, noise):
+    from glomap_amd import estimators
+
+    _, ba, _ = synthetic.make_rig_problems(frames, cams, pts, seed=3, pixel_noise=noise)
+    rc, q, t, X, intr, rep = estimators.ba_solve(ba, ctx=gsfm_ctx)
+    assert rc == 0
+    r = cpu.ba_solve(*_ba_args(ba), **_ba_kw(ba))
+    assert r[0]
+    assert abs(rep["initial_cost"] - r[5].initial_cost) <= 1e-10 * r[5].initial_cost
+    assert rep["iterations"] == r[5].iterations
+    if noise == 0.0:
+        assert rep["final_cost"] < 1e-9 * rep["initial_cost"]
+    else:
+        assert abs(rep["final_cost"] - r[5].final_cost) <= 1e-6 * r[5].final_cost
+    ang = np.radians(so3.rotation_angle_deg(so3.quat_to_rotmat(q), so3.quat_to_rotmat(r[1])))
+    assert ang.max() < 1e-6
+    assert np.abs(t - r[2]).max() < 1e-5 * 50.0
+    assert np.abs(intr - r[4]).max() < 1e-4
+    # the constant frame is untouched (ba.cc:261-266)
+    assert np.array_equal(q[ba.fixed_cam], ba.cam_q[ba.fixed_cam]) and np.array_equal(t[ba.fixed_cam], ba.cam_t[ba.fixed_cam])
+
+
+@pytest.mark.gpu
+def test_identity_rig_tables_give_the_trivial_solution(gsfm_ctx):
+    """The rig path with one identity sensor per frame solves the same problem as the trivial path (other block-Jacobi
+    blocks — no joint pose + intrinsics blocks — so equal to solver tolerance, not bit for bit)."""
+    from glomap_amd import estimators
+
+    p = synthetic.make_ba_problem(20, 600, seed=5, shared_intrinsics=True)
+    rc, q, t, X, intr, rep = estimators.ba_solve(p, ctx=gsfm_ctx)
+    pr = p.copy()
+    ident = np.zeros((p.num_cams, 7))
+    ident[:, 0] = 1
+    pr.image_frame, pr.image_cam_from_rig, pr.image_intr = np.arange(p.num_cams, dtype=np.int32), ident, p.cam_intr.copy()
+    rc2, q2, t2, X2, intr2, rep2 = estimators.ba_solve(pr, ctx=gsfm_ctx)
+    assert rc == 0 and rc2 == 0 and rep["iterations"] == rep2["iterations"]
+    assert np.abs(q - q2).max() < 1e-8 and np.abs(t - t2).max() < 1e-6 and np.abs(intr - intr2).max() < 1e-5
+    g = synthetic.make_gp_problem(20, 600, seed=5)
+    rc, cen, xyz, rep = estimators.gp_solve(g, ctx=gsfm_ctx)
+    g.image_frame, g.image_offset = np.arange(20, dtype=np.int32), np.zeros((20, 3))
+    rc2, cen2, xyz2, rep2 = estimators.gp_solve(g, ctx=gsfm_ctx)
+    assert rc == 0 and rc2 == 0 and rep["iterations"] == rep2["iterations"]
+    assert np.abs(cen - cen2).max() < 1e-6 * np.abs(cen).max()
