@@ -247,6 +247,61 @@ def ra_laplacian_apply(p: RaProblem, w, x, repeat: int = 1, ctx=None):
     return y, ms.value
 
 
+def average_quaternions(q: np.ndarray) -> np.ndarray:
+    """colmap::AverageQuaternions with unit weights: principal eigenvector of sum q q^T (w,x,y,z rows)."""
+    A = q.T @ q
+    w, v = np.linalg.eigh(A)
+    out = v[:, -1]
+    return out if out[0] >= 0 else -out
+
+
+def ra_solve_known_rigs(num_frames: int, image_frame, image_cam_from_rig, pair_i, pair_j, pair_q, pair_ninl,
+                        pair_weight=None, options: Optional[RotationEstimatorOptions] = None, ctx=None, fixed_frame: int = 0):
+    """Rotation averaging of FRAMES (rigs in time) from IMAGE pairs when every cam_from_rig is known — what
+    RotationEstimator::EstimateRotations does for calibrated rigs:
+
+      * initialisation (unless skip_initialization): maximum spanning tree over the IMAGES (gra.cc:87-138), then
+        ConvertRotationsFromImageToRig (rotation_initializer.cc:86-121): rig_from_world of a frame = quaternion average of
+        cam_from_rig^-1 * cam_from_world over its images;
+      * system: one node per frame, R_rel = R_cam2_from_rig2^T * R_cam2_from_cam1 * R_cam1_from_rig1 (gra.cc:306-309), pairs
+        inside one frame skipped (gra.cc:300-304);
+    both on the C ABI (gsfm_ra_solve): the first as a zero-iteration solve of the image-level graph, the second as a
+    normal solve with skip_initialization.  Returns (status, frame rotations as angle-axis [F,3], report)."""
+    from . import so3
+
+    ctx = ctx or default_context()
+    opt = options or RotationEstimatorOptions()
+    imf = np.asarray(image_frame, np.int64)
+    cfr = np.asarray(image_cam_from_rig, np.float64)
+    R_s = so3.quat_to_rotmat(cfr[:, :4])
+    pi, pj = np.asarray(pair_i, np.int64), np.asarray(pair_j, np.int64)
+    E = pi.shape[0]
+    w = np.ones(E) if pair_weight is None else np.asarray(pair_weight, np.float64)
+    ninl = np.asarray(pair_ninl, np.int32)
+    aa0 = np.zeros((num_frames, 3))
+    if not opt.skip_initialization:
+        img = RaProblem(int(imf.shape[0]), pi.astype(np.int32), pj.astype(np.int32), np.asarray(pair_q, np.float64), w, ninl,
+                        np.zeros((imf.shape[0], 3)), 0)
+        o0 = RotationEstimatorOptions(**{**vars(opt), "max_num_l1_iterations": 0, "max_num_irls_iterations": 0})
+        rc, rot_img, _ = ra_solve(img, o0, ctx=ctx)
+        if rc != 0:
+            return rc, aa0, {}
+        R_img = so3.aa_to_rotmat(rot_img)
+        q_rig = so3.rotmat_to_quat(np.transpose(R_s, (0, 2, 1)) @ R_img)  # cam_from_rig^-1 * cam_from_world
+        for f in range(num_frames):
+            sel = np.nonzero(imf == f)[0]
+            if sel.size:
+                qs = q_rig[sel]
+                qs = qs * np.where(qs @ qs[0] < 0, -1.0, 1.0)[:, None]
+                aa0[f] = so3.quat_to_aa(average_quaternions(qs)[None])[0]
+    keep = imf[pi] != imf[pj]
+    R_rel = np.transpose(R_s[pj[keep]], (0, 2, 1)) @ so3.quat_to_rotmat(np.asarray(pair_q, np.float64)[keep]) @ R_s[pi[keep]]
+    p = RaProblem(int(num_frames), imf[pi[keep]].astype(np.int32), imf[pj[keep]].astype(np.int32), so3.rotmat_to_quat(R_rel),
+                  w[keep], ninl[keep], aa0, int(fixed_frame))
+    o1 = RotationEstimatorOptions(**{**vars(opt), "skip_initialization": True})
+    return ra_solve(p, o1, ctx=ctx)
+
+
 def gp_solve(p: GpProblem, options: Optional[GlobalPositionerOptions] = None, ctx=None):
     """gsfm_gp_solve.  Returns (status, cam_center [N,3], pt_xyz [P,3], report dict)."""
     ctx = ctx or default_context()

@@ -11,9 +11,10 @@
 // What the adapter does is exactly the pack / unpack the reference performs implicitly by handing
 // Ceres pointers into its containers (bundle_adjustment.cc:143-146, global_positioning.cc:326-328):
 // flatten the unordered_map containers into the SoA problems of include/gsfm.h, call the C ABI, write
-// the results back in place.  Scope = what `glomap mapper` exercises: trivial rigs, 3-DoF rotation
-// averaging, ONLY_POINTS positioning; anything else returns false after logging (the C ABI reports
-// GSFM_ERR_UNSUPPORTED), mirroring the reference's own early returns (gra.cc:47-58, gm.cc:145-149).
+// the results back in place.  Scope = what `glomap mapper` exercises: trivial rigs and rigs whose
+// cam_from_rig is KNOWN (calibrated multi-camera rigs), 3-DoF rotation averaging, ONLY_POINTS positioning;
+// anything else (unknown cam_from_rig, optimize_rig_poses, the 1-DoF gravity branch) returns false after
+// logging, mirroring the reference's own early returns (gra.cc:47-58, gm.cc:145-149).
 //
 // NOTE: this header cannot be compiled in the libgsfm repository itself (GLOMAP / COLMAP / Eigen are
 // not vendored); tests/adapter/ compiles it against interface-shaped stand-ins of those headers.
@@ -121,7 +122,80 @@ inline void Rotate(const Quat& q, const double* v, double* out) {  // R(q) v
   out[2] = v[2] + w * tz + (x * ty - y * tx);
 }
 
-// Dense frame index over the frames the estimators touch.
+// (w,x,y,z) Hamilton product a * b
+inline void QuatMul(const double* a, const double* b, double* o) {
+  o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  o[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  o[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+}
+template <typename Quat>
+inline void QuatWxyz(const Quat& q, double* o) {
+  o[0] = q.w();
+  o[1] = q.x();
+  o[2] = q.y();
+  o[3] = q.z();
+}
+
+// cam_from_rig of an image as (qw,qx,qy,qz,tx,ty,tz): identity for the reference sensor of its rig.  Returns false
+// when the sensor is not calibrated (no value, or the NaN translation RotationEstimator leaves behind for estimated
+// sensors, gra.cc:803-815) — those cases (RigUnknownBATA, cam-from-rig unknowns of RA) are not implemented.
+inline bool KnownCamFromRig(const glomap::Image& im, std::unordered_map<rig_t, glomap::Rig>& rigs, double* cfr) {
+  cfr[0] = 1.0;
+  for (int j = 1; j < 7; ++j) cfr[j] = 0.0;
+  if (im.HasTrivialFrame()) return true;
+  const glomap::sensor_t sid(glomap::SensorType::CAMERA, im.camera_id);
+  const auto opt = rigs.at(im.frame_ptr->RigId()).MaybeSensorFromRig(sid);
+  if (!opt.has_value()) return false;
+  QuatWxyz(opt->rotation, cfr);
+  for (int j = 0; j < 3; ++j) {
+    cfr[4 + j] = opt->translation[j];
+    if (std::isnan(cfr[4 + j])) return false;
+  }
+  return true;
+}
+
+// colmap::AverageQuaternions with unit weights: principal eigenvector of sum q q^T (cyclic Jacobi on the 4 x 4).
+inline void AverageQuaternions(const std::vector<std::array<double, 4>>& qs, double* out) {
+  double A[4][4] = {{0}}, V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+  for (const auto& q : qs)
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) A[i][j] += q[i] * q[j];
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = 0.0;
+    for (int i = 0; i < 4; ++i)
+      for (int j = i + 1; j < 4; ++j) off += A[i][j] * A[i][j];
+    if (off < 1e-30) break;
+    for (int p = 0; p < 4; ++p)
+      for (int q = p + 1; q < 4; ++q) {
+        if (std::fabs(A[p][q]) < 1e-300) continue;
+        const double th = 0.5 * std::atan2(2.0 * A[p][q], A[q][q] - A[p][p]);
+        const double c = std::cos(th), sn = std::sin(th);
+        for (int k = 0; k < 4; ++k) {  // A <- A G
+          const double akp = A[k][p], akq = A[k][q];
+          A[k][p] = c * akp - sn * akq;
+          A[k][q] = sn * akp + c * akq;
+        }
+        for (int k = 0; k < 4; ++k) {  // A <- G^T A
+          const double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = c * apk - sn * aqk;
+          A[q][k] = sn * apk + c * aqk;
+        }
+        for (int k = 0; k < 4; ++k) {
+          const double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - sn * vkq;
+          V[k][q] = sn * vkp + c * vkq;
+        }
+      }
+  }
+  int best = 0;
+  for (int i = 1; i < 4; ++i)
+    if (A[i][i] > A[best][best]) best = i;
+  const double sg = V[0][best] < 0.0 ? -1.0 : 1.0;
+  for (int i = 0; i < 4; ++i) out[i] = sg * V[i][best];
+}
+
+// Dense frame index over the frames the estimators touch.// Dense frame index over the frames the estimators touch.
 struct FrameIndex {
   std::unordered_map<frame_t, int> of;
   std::vector<frame_t> ids;
@@ -185,11 +259,12 @@ class RotationEstimator {
  public:
   explicit RotationEstimator(const glomap::RotationEstimatorOptions& options) : options_(options) {}
 
-  bool EstimateRotations(const glomap::ViewGraph& view_graph, std::unordered_map<rig_t, glomap::Rig>& /*rigs*/,
+  bool EstimateRotations(const glomap::ViewGraph& view_graph, std::unordered_map<rig_t, glomap::Rig>& rigs,
                          std::unordered_map<frame_t, glomap::Frame>& frames,
                          std::unordered_map<image_t, glomap::Image>& images) {
     gsfm_ctx* ctx = Context();
-    if (ctx == nullptr || options_.use_gravity || !detail::AllTrivial(images)) return false;
+    if (ctx == nullptr || options_.use_gravity) return false;
+    const bool rigged = !detail::AllTrivial(images);
     detail::FrameIndex fidx;
     for (auto& [fid, fr] : frames)
       if (fr.is_registered) fidx.Add(fid);  // gra.cc:193-227; first one = gauge (gra.cc:248-257)
@@ -197,15 +272,44 @@ class RotationEstimator {
     if (N == 0) return false;
     std::vector<int32_t> ei, ej, en;
     std::vector<double> eq, ew;
+    // image-level copy of the view graph (calibrated rigs only): the spanning-tree initialisation runs over IMAGES
+    std::unordered_map<image_t, int> img_of;
+    std::vector<image_t> img_ids;
+    std::vector<int32_t> ii, ij, in_;
+    std::vector<double> iq, iw;
+    auto image_index = [&](image_t id) {
+      auto it = img_of.find(id);
+      if (it != img_of.end()) return it->second;
+      img_of.emplace(id, static_cast<int>(img_ids.size()));
+      img_ids.push_back(id);
+      return static_cast<int>(img_ids.size()) - 1;
+    };
     for (const auto& [pid, pair] : view_graph.image_pairs) {
       if (!pair.is_valid) continue;
       const auto& i1 = images.at(pair.image_id1);
       const auto& i2 = images.at(pair.image_id2);
       if (!i1.IsRegistered() || !i2.IsRegistered()) continue;
+      double q21[4], qrel[4];
+      detail::QuatWxyz(pair.cam2_from_cam1.rotation, q21);
+      for (int j = 0; j < 4; ++j) qrel[j] = q21[j];
+      if (rigged) {
+        // R_rel = R_cam2_from_rig2^T * R_cam2_from_cam1 * R_cam1_from_rig1 (gra.cc:306-309); the cam-from-rig unknowns of
+        // uncalibrated sensors (gra.cc:173-191, 311-340) are not implemented
+        double c1[7], c2[7], tmp[4];
+        if (!detail::KnownCamFromRig(i1, rigs, c1) || !detail::KnownCamFromRig(i2, rigs, c2)) return false;
+        ii.push_back(image_index(pair.image_id1));
+        ij.push_back(image_index(pair.image_id2));
+        iq.insert(iq.end(), q21, q21 + 4);
+        iw.push_back(pair.weight);
+        in_.push_back(static_cast<int32_t>(pair.inliers.size()));
+        if (i1.frame_id == i2.frame_id) continue;  // both sensors of one frame: no constraint (gra.cc:300-304)
+        const double c2inv[4] = {c2[0], -c2[1], -c2[2], -c2[3]};
+        detail::QuatMul(c2inv, q21, tmp);
+        detail::QuatMul(tmp, c1, qrel);
+      }
       ei.push_back(fidx.of.at(i1.frame_id));
       ej.push_back(fidx.of.at(i2.frame_id));
-      const auto& q = pair.cam2_from_cam1.rotation;
-      eq.insert(eq.end(), {q.w(), q.x(), q.y(), q.z()});
+      eq.insert(eq.end(), qrel, qrel + 4);
       ew.push_back(pair.weight);
       en.push_back(static_cast<int32_t>(pair.inliers.size()));
     }
@@ -215,6 +319,59 @@ class RotationEstimator {
       if (!fr.HasPose()) fr.SetRigFromWorld(glomap::Rigid3d());  // gra.cc:219-222 (colmap::Frame::RigFromWorld() throws without a pose)
       detail::QuatToAngleAxis(fr.RigFromWorld().rotation, &rot[3 * n]);
     }
+    bool skip_init = options_.skip_initialization;
+    if (rigged && !skip_init) {
+      // InitializeFromMaximumSpanningTree over the images (gra.cc:87-138) — a zero-iteration gsfm_ra_solve of the
+      // image-level graph — then ConvertRotationsFromImageToRig (rotation_initializer.cc:86-121): rig_from_world of a
+      // frame = average over its images of cam_from_rig^-1 * cam_from_world
+      const int NI = static_cast<int>(img_ids.size());
+      if (NI > 0) {
+        std::vector<double> irot(3 * static_cast<size_t>(NI), 0.0);
+        gsfm_ra_options o0;
+        gsfm_ra_options_default(&o0);
+        o0.max_num_l1_iterations = 0;
+        o0.max_num_irls_iterations = 0;
+        gsfm_ra_problem p0{};
+        p0.mem = GSFM_MEM_HOST;
+        p0.num_nodes = NI;
+        p0.num_edges = static_cast<int64_t>(ii.size());
+        p0.edge_i = ii.data();
+        p0.edge_j = ij.data();
+        p0.edge_q = iq.data();
+        p0.edge_weight = iw.data();
+        p0.edge_ninl = in_.data();
+        p0.fixed_node = 0;
+        gsfm_report r0;
+        if (gsfm_ra_solve(ctx, &p0, &o0, irot.data(), &r0) != GSFM_OK) return false;
+        std::vector<std::vector<std::array<double, 4>>> per_frame(static_cast<size_t>(N));
+        for (int i = 0; i < NI; ++i) {
+          const auto& im = images.at(img_ids[i]);
+          double cfr[7], qcw[4], qrw[4];
+          detail::KnownCamFromRig(im, rigs, cfr);
+          detail::AngleAxisToQuatWxyz(&irot[3 * i], qcw);
+          const double cinv[4] = {cfr[0], -cfr[1], -cfr[2], -cfr[3]};
+          detail::QuatMul(cinv, qcw, qrw);
+          auto& list = per_frame[static_cast<size_t>(fidx.of.at(im.frame_id))];
+          if (!list.empty() && list[0][0] * qrw[0] + list[0][1] * qrw[1] + list[0][2] * qrw[2] + list[0][3] * qrw[3] < 0.0)
+            for (double& v : qrw) v = -v;
+          list.push_back({qrw[0], qrw[1], qrw[2], qrw[3]});
+        }
+        for (int n = 0; n < N; ++n) {
+          if (per_frame[n].empty()) continue;
+          double qa[4];
+          detail::AverageQuaternions(per_frame[n], qa);
+          struct Q {
+            double w_, x_, y_, z_;
+            double w() const { return w_; }
+            double x() const { return x_; }
+            double y() const { return y_; }
+            double z() const { return z_; }
+          } qq{qa[0], qa[1], qa[2], qa[3]};
+          detail::QuatToAngleAxis(qq, &rot[3 * n]);
+        }
+      }
+      skip_init = true;
+    }
     gsfm_ra_options o;
     gsfm_ra_options_default(&o);
     o.max_num_l1_iterations = options_.max_num_l1_iterations;
@@ -223,7 +380,7 @@ class RotationEstimator {
     o.irls_step_convergence_threshold = options_.irls_step_convergence_threshold;
     o.irls_loss_parameter_sigma = options_.irls_loss_parameter_sigma;
     o.weight_type = static_cast<int>(options_.weight_type);
-    o.skip_initialization = options_.skip_initialization;
+    o.skip_initialization = skip_init;
     o.use_weight = options_.use_weight;
     gsfm_ra_problem p{};
     p.mem = GSFM_MEM_HOST;
@@ -262,13 +419,14 @@ class GlobalPositioner {
   explicit GlobalPositioner(const glomap::GlobalPositionerOptions& options) : options_(options) {}
   glomap::GlobalPositionerOptions& GetOptions() { return options_; }
 
-  bool Solve(const glomap::ViewGraph& /*view_graph*/, std::unordered_map<rig_t, glomap::Rig>& /*rigs*/,
+  bool Solve(const glomap::ViewGraph& /*view_graph*/, std::unordered_map<rig_t, glomap::Rig>& rigs,
              std::unordered_map<camera_t, glomap::Camera>& cameras, std::unordered_map<frame_t, glomap::Frame>& frames,
              std::unordered_map<image_t, glomap::Image>& images, std::unordered_map<track_t, glomap::Track>& tracks) {
     gsfm_ctx* ctx = Context(options_.gpu_index);
     if (ctx == nullptr) return false;
     if (images.empty() || tracks.empty()) return false;  // gp.cc:37-50
-    if (options_.constraint_type != glomap::GlobalPositionerOptions::ONLY_POINTS || !detail::AllTrivial(images)) return false;
+    if (options_.constraint_type != glomap::GlobalPositionerOptions::ONLY_POINTS) return false;
+    const bool rigged = !detail::AllTrivial(images);  // calibrated multi-camera rigs: observations are keyed by image
     detail::FrameIndex fidx;
     for (auto& [fid, fr] : frames) fidx.Add(fid);  // every frame: ConvertResults rewrites all of them (gp.cc:566-572)
     auto keep = [](const glomap::Image& im, uint32_t f) {  // gp.cc:279-292
@@ -282,10 +440,27 @@ class GlobalPositioner {
     if (P == 0) return false;
     std::vector<double> dir(3 * static_cast<size_t>(M)), cen(3 * static_cast<size_t>(N)), xyz(3 * static_cast<size_t>(P));
     std::vector<uint8_t> cal(static_cast<size_t>(M));
+    // known rigs (gp.cc:318-350, RigBATAPairwiseDirectionError with the rig scale constant at 1, :470-478): images become
+    // the cameras of the flat problem, each with its frame and the offset R_cam_from_world^T t_cam_from_rig
+    std::unordered_map<image_t, int> img_of;
+    std::vector<int32_t> image_frame;
+    std::vector<double> image_offset;
     for (int64_t k = 0; k < M; ++k) {
       const auto& im = images.at(tp.obs_image[k]);
-      detail::RotateInv(im.frame_ptr->RigFromWorld().rotation, im.features_undist[tp.obs_feature[k]], &dir[3 * k]);  // gp.cc:294-296
-      cal[k] = cameras.at(im.camera_id).has_prior_focal_length ? 1 : 0;                                             // gp.cc:313-316
+      const auto cam_from_world = im.CamFromWorld();
+      detail::RotateInv(cam_from_world.rotation, im.features_undist[tp.obs_feature[k]], &dir[3 * k]);  // gp.cc:294-296
+      cal[k] = cameras.at(im.camera_id).has_prior_focal_length ? 1 : 0;                                 // gp.cc:313-316
+      if (!rigged) continue;
+      auto it = img_of.find(tp.obs_image[k]);
+      if (it == img_of.end()) {
+        double cfr[7], off[3];
+        if (!detail::KnownCamFromRig(im, rigs, cfr)) return false;  // RigUnknownBATAPairwiseDirectionError: not implemented
+        detail::RotateInv(cam_from_world.rotation, cfr + 4, off);   // translation_rig, gp.cc:329-333
+        it = img_of.emplace(tp.obs_image[k], static_cast<int>(image_frame.size())).first;
+        image_frame.push_back(tp.obs_cam[k]);
+        image_offset.insert(image_offset.end(), off, off + 3);
+      }
+      tp.obs_cam[k] = it->second;
     }
     for (int n = 0; n < N; ++n) {  // c = -R^T t
       const auto& pose = frames.at(fidx.ids[n]).RigFromWorld();
@@ -317,6 +492,11 @@ class GlobalPositioner {
     pr.obs_cam = tp.obs_cam.data();
     pr.obs_dir = dir.data();
     pr.obs_calibrated = cal.data();
+    if (rigged) {
+      pr.num_images = static_cast<int32_t>(image_frame.size());
+      pr.image_frame = image_frame.data();
+      pr.image_offset = image_offset.data();
+    }
     gsfm_report rep;
     if (gsfm_gp_solve(ctx, &pr, &o, cen.data(), xyz.data(), &rep) != GSFM_OK) return false;
     for (int n = 0; n < N; ++n) {  // ConvertResults: t = -R c (gp.cc:566-572)
@@ -347,13 +527,14 @@ class BundleAdjuster {
   explicit BundleAdjuster(const glomap::BundleAdjusterOptions& options) : options_(options) {}
   glomap::BundleAdjusterOptions& GetOptions() { return options_; }
 
-  bool Solve(std::unordered_map<rig_t, glomap::Rig>& /*rigs*/, std::unordered_map<camera_t, glomap::Camera>& cameras,
+  bool Solve(std::unordered_map<rig_t, glomap::Rig>& rigs, std::unordered_map<camera_t, glomap::Camera>& cameras,
              std::unordered_map<frame_t, glomap::Frame>& frames, std::unordered_map<image_t, glomap::Image>& images,
              std::unordered_map<track_t, glomap::Track>& tracks) {
     gsfm_ctx* ctx = Context(options_.gpu_index);
     if (ctx == nullptr) return false;
     if (images.empty() || tracks.empty()) return false;  // ba.cc:17-24
-    if (!detail::AllTrivial(images) || options_.optimize_rig_poses) return false;
+    const bool rigged = !detail::AllTrivial(images);  // RigReprojErrorConstantRigCostFunctor, ba.cc:147-160
+    if (rigged && options_.optimize_rig_poses) return false;  // RigReprojErrorCostFunctor (ba.cc:161-179): not implemented
     detail::FrameIndex fidx;
     for (auto& [fid, fr] : frames)
       if (fr.HasPose()) fidx.Add(fid);  // dense indices in map order, the order ParameterizeVariables walks (ba.cc:253)
@@ -392,12 +573,29 @@ class BundleAdjuster {
     };
     std::vector<double> xy(2 * static_cast<size_t>(M)), q(4 * static_cast<size_t>(N)), t(3 * static_cast<size_t>(N)),
         xyz(3 * static_cast<size_t>(P));
+    // known rigs: images become the cameras of the flat problem — frame, constant cam_from_rig, intrinsics block each
+    std::unordered_map<image_t, int> img_of;
+    std::vector<int32_t> image_frame, image_intr;
+    std::vector<double> image_cfr;
     for (int64_t k = 0; k < M; ++k) {
       const auto& im = images.at(tp.obs_image[k]);
       const auto& f = im.features[tp.obs_feature[k]];  // distorted pixels (ba.cc:139)
       xy[2 * k] = f[0];
       xy[2 * k + 1] = f[1];
-      cam_intr[tp.obs_cam[k]] = intr_index(im.camera_id);
+      if (!rigged) {
+        cam_intr[tp.obs_cam[k]] = intr_index(im.camera_id);
+        continue;
+      }
+      auto it = img_of.find(tp.obs_image[k]);
+      if (it == img_of.end()) {
+        double cfr[7];
+        if (!detail::KnownCamFromRig(im, rigs, cfr)) return false;
+        it = img_of.emplace(tp.obs_image[k], static_cast<int>(image_frame.size())).first;
+        image_frame.push_back(tp.obs_cam[k]);
+        image_intr.push_back(intr_index(im.camera_id));
+        image_cfr.insert(image_cfr.end(), cfr, cfr + 7);
+      }
+      tp.obs_cam[k] = it->second;
     }
     for (int m : intr_model)
       if (m < 0) return false;  // unsupported camera model
@@ -434,6 +632,12 @@ class BundleAdjuster {
     pr.obs_xy = xy.data();
     pr.cam_intr = cam_intr.data();
     pr.intr_model = intr_model.data();
+    if (rigged) {
+      pr.num_images = static_cast<int32_t>(image_frame.size());
+      pr.image_frame = image_frame.data();
+      pr.image_cam_from_rig = image_cfr.data();
+      pr.image_intr = image_intr.data();
+    }
     gsfm_report rep;
     if (gsfm_ba_solve(ctx, &pr, &o, q.data(), t.data(), xyz.data(), intr.data(), &rep) != GSFM_OK) return false;
     for (int n = 0; n < N; ++n) {  // parameter blocks are the containers' own storage in the reference (ba.cc:143-146)

@@ -3,6 +3,7 @@
 // held in GLOMAP-shaped containers (tests/adapter/mock).  Prints "ADAPTER OK ..." on success.
 #include <cmath>
 #include <cstdio>
+#include <algorithm>
 #include <random>
 
 #include "gsfm_glomap_adapter.hpp"
@@ -295,6 +296,160 @@ int main() {
         vg.image_pairs[(uint64_t)N * 1000 + N + 1].is_valid)
       return std::printf("KeepLargestConnectedComponents kept %d images\n", kept), 1;
   }
-  std::printf("ADAPTER OK ra=%.2e rad gp_ratio_err=%.2e ba=%.2e px\n", worst, std::fabs(ratio / ratio_ref - 1.0), maxerr);
+  // 6) calibrated rigs (the shape of global_mapper_test.cc:89-126): 12 frames of a 2-camera rig — reference sensor
+  //    (camera 11) and a second sensor (camera 12) with a KNOWN cam_from_rig (10 degrees about y, a metric baseline).
+  //    RotationEstimator, GlobalPositioner and BundleAdjuster must handle them through the same three calls.
+  double rig_ra = 0, rig_gp = 0, rig_ba = 0;
+  {
+    const int NF = 12, NP = 300;
+    std::unordered_map<rig_t, Rig> rigs2;
+    std::unordered_map<camera_t, Camera> cams2;
+    std::unordered_map<frame_t, Frame> fr2;
+    std::unordered_map<image_t, Image> im2;
+    std::unordered_map<track_t, Track> tr2;
+    ViewGraph vg2;
+    Camera c2;
+    c2.model_id = 1;
+    c2.params = {800.0, 800.0, 320.0, 240.0};
+    cams2[11] = c2;
+    cams2[12] = c2;
+    const double s_ang = 10.0 * M_PI / 180.0;
+    double Rs[9];
+    rot_y(s_ang, Rs);
+    const double ts[3] = {0.8, 0.1, -0.2};
+    {
+      Rig rig;
+      rig.SetRigId(1);
+      rig.AddRefSensor(sensor_t(SensorType::CAMERA, 11));
+      Rigid3d cfr;
+      cfr.rotation = quat_of(Rs);
+      cfr.translation = mock_eigen::Vector3d(ts[0], ts[1], ts[2]);
+      rig.AddSensor(sensor_t(SensorType::CAMERA, 12), cfr);
+      rigs2[1] = rig;
+    }
+    std::vector<double> Rf(9 * NF), tf(3 * NF), cf(3 * NF), Rc(9 * 2 * NF), tc(3 * 2 * NF), ang_c(2 * NF);
+    for (int f = 0; f < NF; ++f) {
+      const double th = 2.0 * M_PI * f / NF;
+      rot_y(th, &Rf[9 * f]);
+      const double c[3] = {10.0 * std::sin(th), 0.0, -10.0 * std::cos(th)};
+      for (int i = 0; i < 3; ++i) {
+        cf[3 * f + i] = c[i];
+        tf[3 * f + i] = -(Rf[9 * f + 3 * i] * c[0] + Rf[9 * f + 3 * i + 1] * c[1] + Rf[9 * f + 3 * i + 2] * c[2]);
+      }
+      Frame fr;
+      fr.is_registered = true;
+      fr.SetRigId(1);
+      Rigid3d pose;
+      pose.rotation = quat_of(&Rf[9 * f]);
+      pose.translation = mock_eigen::Vector3d(tf[3 * f], tf[3 * f + 1], tf[3 * f + 2]);
+      fr.SetRigFromWorld(pose);
+      fr2[f] = fr;
+      for (int sn = 0; sn < 2; ++sn) {
+        const int id = 2 * f + sn;
+        Image im;
+        im.image_id = id;
+        im.camera_id = 11 + sn;
+        im.frame_id = f;
+        im2[id] = im;
+        // cam_from_world = cam_from_rig * rig_from_world
+        ang_c[id] = th + (sn ? s_ang : 0.0);
+        rot_y(ang_c[id], &Rc[9 * id]);
+        for (int i = 0; i < 3; ++i) {
+          double v = tf[3 * f + i];
+          if (sn) v = Rs[3 * i] * tf[3 * f] + Rs[3 * i + 1] * tf[3 * f + 1] + Rs[3 * i + 2] * tf[3 * f + 2] + ts[i];
+          tc[3 * id + i] = v;
+        }
+      }
+    }
+    for (int f = 0; f < NF; ++f) {
+      fr2[f].SetRigPtr(&rigs2[1]);
+      for (int sn = 0; sn < 2; ++sn) {
+        im2[2 * f + sn].frame_ptr = &fr2[f];
+        fr2[f].AddDataId(data_t(sensor_t(SensorType::CAMERA, 11 + sn), 2 * f + sn));
+      }
+    }
+    std::vector<double> Xg(3 * NP);
+    for (int p = 0; p < NP; ++p) {
+      Track tr;
+      tr.track_id = p;
+      for (int i = 0; i < 3; ++i) Xg[3 * p + i] = 2.0 * U(rng);
+      tr.xyz = mock_eigen::Vector3d(Xg[3 * p] + 0.05 * U(rng), Xg[3 * p + 1] + 0.05 * U(rng), Xg[3 * p + 2] + 0.05 * U(rng));
+      for (int id = 0; id < 2 * NF; id += 1 + (p % 3)) {
+        const double* R = &Rc[9 * id];
+        double xc[3];
+        for (int i = 0; i < 3; ++i) xc[i] = R[3 * i] * Xg[3 * p] + R[3 * i + 1] * Xg[3 * p + 1] + R[3 * i + 2] * Xg[3 * p + 2] + tc[3 * id + i];
+        const double nrm = std::sqrt(xc[0] * xc[0] + xc[1] * xc[1] + xc[2] * xc[2]);
+        im2[id].features.emplace_back(800.0 * xc[0] / xc[2] + 320.0, 800.0 * xc[1] / xc[2] + 240.0);
+        im2[id].features_undist.emplace_back(xc[0] / nrm, xc[1] / nrm, xc[2] / nrm);
+        tr.observations.emplace_back(id, (feature_t)(im2[id].features.size() - 1));
+      }
+      tr2[p] = tr;
+    }
+    for (int a = 0; a < 2 * NF; ++a)
+      for (int b = a + 1; b < 2 * NF; ++b) {
+        const int d = std::abs(a / 2 - b / 2), dr = std::min(d, NF - d);
+        if (dr > 2) continue;
+        ImagePair pr;
+        pr.image_id1 = a;
+        pr.image_id2 = b;
+        double Rab[9];
+        rot_y(ang_c[b] - ang_c[a], Rab);
+        pr.cam2_from_cam1.rotation = quat_of(Rab);
+        pr.inliers.resize(50 + (a * 7 + b * 3) % 40);
+        vg2.image_pairs[(uint64_t)a * 1000 + b] = pr;
+      }
+    // RA from identity rotations
+    auto fr_ra = fr2;
+    for (auto& [id, fr] : fr_ra) {
+      Rigid3d p0;
+      fr.SetRigFromWorld(p0);
+    }
+    for (int id = 0; id < 2 * NF; ++id) im2[id].frame_ptr = &fr_ra[id / 2];
+    RotationEstimatorOptions ro2;
+    gsfm_glomap::RotationEstimator ra2(ro2);
+    if (!ra2.EstimateRotations(vg2, rigs2, fr_ra, im2)) return std::printf("rig RA failed\n"), 1;
+    for (int f = 1; f < NF; ++f) {
+      auto q0 = fr_ra[0].RigFromWorld().rotation, qn = fr_ra[f].RigFromWorld().rotation;
+      double dd = std::fmod(2.0 * (std::atan2(qn.y(), qn.w()) - std::atan2(q0.y(), q0.w())) - 2.0 * M_PI * f / NF, 2.0 * M_PI);
+      if (dd > M_PI) dd -= 2.0 * M_PI;
+      if (dd < -M_PI) dd += 2.0 * M_PI;
+      rig_ra = std::fmax(rig_ra, std::fabs(dd));
+    }
+    if (rig_ra > 1e-6) return std::printf("rig RA error %.3e rad\n", rig_ra), 1;
+    // GP with the ground-truth rotations: the metric rig baseline fixes the scale, so distances come out ABSOLUTE
+    auto fr_gp = fr2;
+    for (int id = 0; id < 2 * NF; ++id) im2[id].frame_ptr = &fr_gp[id / 2];
+    auto tr_gp = tr2;
+    GlobalPositionerOptions go2;
+    gsfm_glomap::GlobalPositioner gp2(go2);
+    if (!gp2.Solve(vg2, rigs2, cams2, fr_gp, im2, tr_gp)) return std::printf("rig GP failed\n"), 1;
+    double a0[3], a6[3];
+    center(fr_gp[0], a0);
+    center(fr_gp[6], a6);
+    rig_gp = std::fabs(dist(a0, a6) / 20.0 - 1.0);
+    if (rig_gp > 3e-2) return std::printf("rig GP: |c0 - c6| = %.6f, expected 20 (metric, to the accuracy of the stopping rule)\n", dist(a0, a6)), 1;
+    // BA from perturbed points
+    for (int id = 0; id < 2 * NF; ++id) im2[id].frame_ptr = &fr2[id / 2];
+    BundleAdjusterOptions bo2;
+    gsfm_glomap::BundleAdjuster ba2(bo2);
+    if (!ba2.Solve(rigs2, cams2, fr2, im2, tr2)) return std::printf("rig BA failed\n"), 1;
+    for (auto& [tid, tr] : tr2)
+      for (auto& ob : tr.observations) {
+        const auto cw = im2[ob.first].CamFromWorld();
+        double xc[3];
+        const double X[3] = {tr.xyz[0], tr.xyz[1], tr.xyz[2]};
+        gsfm_glomap::detail::Rotate(cw.rotation, X, xc);
+        for (int i = 0; i < 3; ++i) xc[i] += cw.translation[i];
+        const auto& par = cams2[im2[ob.first].camera_id].params;
+        const auto& f = im2[ob.first].features[ob.second];
+        rig_ba = std::fmax(rig_ba, std::hypot(par[0] * xc[0] / xc[2] + par[2] - f[0], par[1] * xc[1] / xc[2] + par[3] - f[1]));
+      }
+    if (rig_ba > 1e-3) return std::printf("rig BA reprojection error %.3e px\n", rig_ba), 1;
+    // an uncalibrated sensor is refused (RigUnknownBATA / cam-from-rig unknowns are not implemented), not mis-solved
+    rigs2[1].ResetSensorFromRig(sensor_t(SensorType::CAMERA, 12));
+    if (ba2.Solve(rigs2, cams2, fr2, im2, tr2)) return std::printf("BA accepted an uncalibrated rig\n"), 1;
+  }
+  std::printf("ADAPTER OK ra=%.2e rad gp_ratio_err=%.2e ba=%.2e px | rigs: ra=%.2e rad gp_scale_err=%.2e ba=%.2e px\n", worst,
+              std::fabs(ratio / ratio_ref - 1.0), maxerr, rig_ra, rig_gp, rig_ba);
   return 0;
 }

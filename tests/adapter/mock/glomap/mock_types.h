@@ -5,6 +5,8 @@
 #pragma once
 #include <cstdint>
 #include <cstdlib>
+#include <map>
+#include <optional>
 #include <string>
 #include <unordered_map>
 #include <utility>
@@ -59,7 +61,64 @@ struct Rigid3d {
   mock_eigen::Quaterniond rotation;
   mock_eigen::Vector3d translation;
 };
-struct Rig {};
+
+// colmap::sensor_t / data_t / Rig (colmap/sensor/rig.h, colmap/scene/frame.h): the members the estimators touch
+enum class SensorType { INVALID = -1, CAMERA = 0, IMU = 1 };
+struct sensor_t {
+  SensorType type = SensorType::INVALID;
+  uint32_t id = 0xffffffffu;
+  sensor_t() = default;
+  sensor_t(SensorType t, uint32_t i) : type(t), id(i) {}
+  bool operator==(const sensor_t& o) const { return type == o.type && id == o.id; }
+  bool operator<(const sensor_t& o) const { return type != o.type ? type < o.type : id < o.id; }
+};
+struct data_t {
+  sensor_t sensor_id;
+  uint32_t id = 0xffffffffu;
+  data_t() = default;
+  data_t(sensor_t s, uint32_t i) : sensor_id(s), id(i) {}
+};
+}  // namespace glomap
+namespace std {
+template <>
+struct hash<glomap::sensor_t> {
+  size_t operator()(const glomap::sensor_t& s) const { return (static_cast<size_t>(s.type) << 32) ^ s.id; }
+};
+}  // namespace std
+namespace glomap {
+
+class Rig {
+ public:
+  rig_t RigId() const { return rig_id_; }
+  void SetRigId(rig_t id) { rig_id_ = id; }
+  void AddRefSensor(sensor_t s) { ref_ = s; }
+  void AddSensor(sensor_t s, const std::optional<Rigid3d>& sensor_from_rig = std::nullopt) { sensors_[s] = sensor_from_rig; }
+  sensor_t RefSensorId() const { return ref_; }
+  bool IsRefSensor(sensor_t s) const { return s == ref_; }
+  std::map<sensor_t, std::optional<Rigid3d>>& NonRefSensors() { return sensors_; }
+  const std::map<sensor_t, std::optional<Rigid3d>>& NonRefSensors() const { return sensors_; }
+  std::optional<Rigid3d> MaybeSensorFromRig(sensor_t s) const {
+    auto it = sensors_.find(s);
+    return it == sensors_.end() ? std::nullopt : it->second;
+  }
+  Rigid3d& SensorFromRig(sensor_t s) {
+    auto& o = sensors_.at(s);
+    if (!o.has_value()) std::abort();  // colmap THROW_CHECKs
+    return *o;
+  }
+  const Rigid3d& SensorFromRig(sensor_t s) const {
+    const auto& o = sensors_.at(s);
+    if (!o.has_value()) std::abort();
+    return *o;
+  }
+  void SetSensorFromRig(sensor_t s, const Rigid3d& v) { sensors_[s] = v; }
+  void ResetSensorFromRig(sensor_t s) { sensors_[s] = std::nullopt; }
+
+ private:
+  rig_t rig_id_ = 0xffffffffu;
+  sensor_t ref_;
+  std::map<sensor_t, std::optional<Rigid3d>> sensors_;
+};
 struct Camera {
   int model_id = 0;
   std::vector<double> params;
@@ -83,6 +142,19 @@ struct Frame {
     pose = p;
     has_pose = true;
   }
+  // rig membership (colmap::Frame): null rig pointer = a trivial frame of its own
+  rig_t RigId() const { return rig_id_; }
+  void SetRigId(rig_t id) { rig_id_ = id; }
+  Rig* RigPtr() const { return rig_ptr_; }
+  void SetRigPtr(Rig* r) { rig_ptr_ = r; }
+  void AddDataId(const data_t& d) { data_ids_.push_back(d); }
+  const std::vector<data_t>& DataIds() const { return data_ids_; }
+  const std::vector<data_t>& ImageIds() const { return data_ids_; }  // the stand-in holds camera data only
+
+ private:
+  rig_t rig_id_ = 0xffffffffu;
+  Rig* rig_ptr_ = nullptr;
+  std::vector<data_t> data_ids_;
 };
 struct Image {
   image_t image_id = 0;
@@ -92,7 +164,30 @@ struct Image {
   std::vector<mock_eigen::Vector2d> features;
   std::vector<mock_eigen::Vector3d> features_undist;
   bool IsRegistered() const { return frame_ptr != nullptr && frame_ptr->is_registered; }
-  bool HasTrivialFrame() const { return true; }
+  bool HasTrivialFrame() const {
+    return frame_ptr == nullptr || frame_ptr->RigPtr() == nullptr ||
+           frame_ptr->RigPtr()->IsRefSensor(sensor_t(SensorType::CAMERA, camera_id));
+  }
+  // CamFromWorld() = cam_from_rig * rig_from_world (image.h:62-65 through colmap::Frame::SensorFromWorld)
+  Rigid3d CamFromWorld() const {
+    const Rigid3d& rw = frame_ptr->RigFromWorld();
+    if (HasTrivialFrame()) return rw;
+    const Rigid3d& cr = frame_ptr->RigPtr()->SensorFromRig(sensor_t(SensorType::CAMERA, camera_id));
+    const auto &a = cr.rotation, &b = rw.rotation;
+    Rigid3d out;
+    out.rotation = mock_eigen::Quaterniond(a.w() * b.w() - a.x() * b.x() - a.y() * b.y() - a.z() * b.z(),
+                                           a.w() * b.x() + a.x() * b.w() + a.y() * b.z() - a.z() * b.y(),
+                                           a.w() * b.y() - a.x() * b.z() + a.y() * b.w() + a.z() * b.x(),
+                                           a.w() * b.z() + a.x() * b.y() - a.y() * b.x() + a.z() * b.w());
+    // R(a) t_rw + t_cr
+    const double w = a.w(), x = a.x(), y = a.y(), z = a.z();
+    const double* v = rw.translation.v;
+    const double tx = 2.0 * (y * v[2] - z * v[1]), ty = 2.0 * (z * v[0] - x * v[2]), tz = 2.0 * (x * v[1] - y * v[0]);
+    out.translation = mock_eigen::Vector3d(v[0] + w * tx + (y * tz - z * ty) + cr.translation[0],
+                                           v[1] + w * ty + (z * tx - x * tz) + cr.translation[1],
+                                           v[2] + w * tz + (x * ty - y * tx) + cr.translation[2]);
+    return out;
+  }
 };
 using Observation = std::pair<image_t, feature_t>;
 struct Track {

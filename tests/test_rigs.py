@@ -127,3 +127,57 @@ def test_identity_rig_tables_give_the_trivial_solution(gsfm_ctx):
     rc2, cen2, xyz2, rep2 = estimators.gp_solve(g, ctx=gsfm_ctx)
     assert rc == 0 and rc2 == 0 and rep["iterations"] == rep2["iterations"]
     assert np.abs(cen - cen2).max() < 1e-6 * np.abs(cen).max()
+
+
+@pytest.mark.gpu
+def test_known_rig_pipeline_recovers_the_scene(gsfm_ctx):
+    """RA -> GP -> BA chained on a noise-free scene of 2 calibrated rigs x 2 cameras x 7 frames each (the configuration of
+    global_mapper_test.cc:89-126), every stage through the C ABI; pins of that test: rotations 1e-2 deg, projection
+    centres 1e-4 (:121-125)."""
+    from glomap_amd import estimators
+    from glomap_amd.flat import BaProblem, GpProblem
+
+    gp, ba, info = synthetic.make_rig_problems(14, 2, 600, seed=7)
+    N, I = gp.num_cams, gp.num_images
+    R_cw, R_s, t_s = info["R_cw"], info["R_s"], info["t_s"]
+    imf = gp.image_frame.astype(np.int64)
+    # view graph: image pairs whose frames are at most 3 apart on the ring (pairs inside one frame included: the
+    # estimator must skip them), exact relative rotations
+    ii, jj = np.triu_indices(I, 1)
+    d = np.abs(imf[ii] - imf[jj])
+    near = np.minimum(d, N - d) <= 3
+    ii, jj = ii[near], jj[near]
+    q_rel = so3.rotmat_to_quat(R_cw[jj] @ np.transpose(R_cw[ii], (0, 2, 1)))
+    ninl = np.random.default_rng(0).integers(30, 300, ii.shape[0]).astype(np.int32)
+    rc, rot, rep = estimators.ra_solve_known_rigs(N, imf, ba.image_cam_from_rig, ii, jj, q_rel, ninl, ctx=gsfm_ctx)
+    assert rc == 0
+    R_est = so3.aa_to_rotmat(rot)
+    assert synthetic.rotation_errors_deg(R_est, gp.cam_R).max() < 1e-2
+    # global positioning with the ESTIMATED rotations (rays and rig offsets rotated by them, gp.cc:294-296, 329-333)
+    Rcw_est = R_s @ R_est[imf]
+    ray_cam = np.einsum("mij,mj->mi", R_cw[gp.obs_cam], gp.obs_dir)  # back to camera-frame rays (features_undist)
+    gp2 = GpProblem(num_cams=N, num_pts=gp.num_pts, pt_offset=gp.pt_offset, obs_cam=gp.obs_cam,
+                    obs_dir=np.ascontiguousarray(np.einsum("mji,mj->mi", Rcw_est[gp.obs_cam], ray_cam)),
+                    obs_calibrated=gp.obs_calibrated, cam_center=np.zeros((N, 3)), pt_xyz=np.zeros((gp.num_pts, 3)),
+                    image_frame=gp.image_frame, image_offset=np.ascontiguousarray(np.einsum("iba,ib->ia", Rcw_est, t_s)))
+    rc, cen, xyz, rep = estimators.gp_solve(gp2, ctx=gsfm_ctx)
+    assert rc == 0
+    # bundle adjustment from the positioning result (positions only first, then everything: global_mapper.cc:201-223)
+    q0 = so3.rotmat_to_quat(R_est)
+    t0 = -np.einsum("nij,nj->ni", R_est, cen)
+    ba2 = BaProblem(num_cams=N, num_pts=ba.num_pts, num_intr=ba.num_intr, pt_offset=ba.pt_offset, obs_cam=ba.obs_cam,
+                    obs_xy=ba.obs_xy, cam_intr=ba.cam_intr, cam_q=q0, cam_t=t0, pt_xyz=xyz, intr_model=ba.intr_model,
+                    intr_params=ba.intr_params, fixed_cam=0, image_frame=ba.image_frame,
+                    image_cam_from_rig=ba.image_cam_from_rig, image_intr=ba.image_intr)
+    rc, q, t, X, intr, rep = estimators.ba_solve(ba2, estimators.BundleAdjusterOptions(optimize_rotations=False), ctx=gsfm_ctx)
+    assert rc == 0
+    ba2.cam_t, ba2.pt_xyz, ba2.intr_params = t, X, intr
+    rc, q, t, X, intr, rep = estimators.ba_solve(ba2, ctx=gsfm_ctx)
+    assert rc == 0 and rep["final_cost"] < 1e-8 * max(1.0, rep["initial_cost"])
+    R_fin = so3.quat_to_rotmat(q)
+    c_fin = -np.einsum("nji,nj->ni", R_fin, t)
+    assert synthetic.rotation_errors_deg(R_fin, gp.cam_R).max() < 1e-2
+    err = synthetic.center_errors_after_sim3(c_fin, gp.gt_center)
+    assert err.max() < 1e-4
+    scale, _, _ = synthetic.align_sim3(c_fin, gp.gt_center)
+    assert abs(scale - 1.0) < 1e-4  # the metric rig baselines fix the scale of the whole reconstruction
