@@ -151,6 +151,7 @@ class BaOptions(C.Structure):
         ("optimize_principal_point", C.c_int32),
         ("optimize_points", C.c_int32),
         ("min_num_view_per_track", C.c_int32),
+        ("optimize_rig_poses", C.c_int32),
     ]
 
 
@@ -171,6 +172,9 @@ class BaProblemC(C.Structure):
         ("image_frame", C.c_void_p),
         ("image_cam_from_rig", C.c_void_p),
         ("image_intr", C.c_void_p),
+        ("num_sensors", C.c_int32),
+        ("image_sensor", C.c_void_p),
+        ("sensor_cam_from_rig", C.c_void_p),
     ]
 
 

@@ -242,11 +242,17 @@ __global__ void __launch_bounds__(kBlock)
 // ---- linearize, camera side -------------------------------------------------------------------------
 // One wave per camera: robust weights in camera-major order (c_w), squared column norms and gradient
 // of the pose block; the intrinsics share of this camera goes to ipart[n][16] = (diag 8 | grad 8).
+// GRAM (optimised cam_from_rig blocks): the pose part is the full 6 x 6 Gram matrix sum w J^T J of the IMAGE's own
+// tangent (upper triangle, sym6 order) in diag[n][21] and its gradient in grad[n][6]; the frame / sensor column norms
+// and gradients are congruences of it (k_ba_rig_frame_lin, k_ba_rig_sensor_lin).
+template <bool GRAM>
 __global__ void __launch_bounds__(kBlock)
     k_ba_lin_cam(BaDev g, const double* __restrict__ camR, const double* __restrict__ t,
                  const double* __restrict__ X, const double* __restrict__ par, double* __restrict__ c_w,
                  double* __restrict__ diag, double* __restrict__ grad, double* __restrict__ ipart,
                  const double* __restrict__ sensR /* calibrated rigs: [images][12] cam_from_rig (R row-major | t), else null */) {
+  constexpr int PW = GRAM ? 27 : 12;  // pose accumulators
+  constexpr int W = PW + 16;
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (kBlock / 64);
@@ -259,9 +265,9 @@ __global__ void __launch_bounds__(kBlock)
     const double* R9 = camR + 9 * (long)n;
     const double* t3 = t + 3 * (long)n;
     const double* pp = par + 8 * (long)ik;
-    double acc[28];
+    double acc[W];
 #pragma unroll
-    for (int j = 0; j < 28; ++j) acc[j] = 0.0;
+    for (int j = 0; j < W; ++j) acc[j] = 0.0;
     for (int k = cam_seg_k0(g.g, sg) + lane; k < cam_seg_k1(g.g, sg); k += 64) {
       ObsGeom o;
       obs_geom(R9, t3, ld3(X + 3 * (long)g.g.c_pt[k]), model, pp, o);
@@ -273,7 +279,7 @@ __global__ void __launch_bounds__(kBlock)
       c_w[k] = w;
       ObsJac J;
       build_jac(g, n, R9, o, J);
-      if (sensR != nullptr) {
+      if (!GRAM && sensR != nullptr) {
         // the pose unknown is the FRAME's: its tangent d_f maps to this image's tangent as (R_s d_rot, R_s d_trn), so the
         // columns of the frame Jacobian are J_image R_s — squared norms and gradient are accumulated in that basis
         const double* Rs = sensR + 12 * (long)n;
@@ -288,29 +294,46 @@ __global__ void __launch_bounds__(kBlock)
         }
       }
       const double g0 = w * r0, g1 = w * r1;
+      if constexpr (GRAM) {
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        acc[j] += w * (J.Jpose[0][j] * J.Jpose[0][j] + J.Jpose[1][j] * J.Jpose[1][j]);
-        acc[6 + j] += J.Jpose[0][j] * g0 + J.Jpose[1][j] * g1;
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+          for (int j = i; j < 6; ++j)
+            acc[i * 6 - (i * (i - 1)) / 2 + (j - i)] += w * (J.Jpose[0][i] * J.Jpose[0][j] + J.Jpose[1][i] * J.Jpose[1][j]);
+          acc[21 + i] += J.Jpose[0][i] * g0 + J.Jpose[1][i] * g1;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          acc[j] += w * (J.Jpose[0][j] * J.Jpose[0][j] + J.Jpose[1][j] * J.Jpose[1][j]);
+          acc[6 + j] += J.Jpose[0][j] * g0 + J.Jpose[1][j] * g1;
+        }
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         if ((bits >> j) & 1) {
-          acc[12 + j] += w * (o.Jp[0][j] * o.Jp[0][j] + o.Jp[1][j] * o.Jp[1][j]);
-          acc[20 + j] += o.Jp[0][j] * g0 + o.Jp[1][j] * g1;
+          acc[PW + j] += w * (o.Jp[0][j] * o.Jp[0][j] + o.Jp[1][j] * o.Jp[1][j]);
+          acc[PW + 8 + j] += o.Jp[0][j] * g0 + o.Jp[1][j] * g1;
         }
       }
     }
-    wave_allsum<28>(acc);
-    if (!cam_seg_total<28>(g.g, sg, acc, lane)) continue;
+    wave_allsum<W>(acc);
+    if (!cam_seg_total<W>(g.g, sg, acc, lane)) continue;
     if (lane == 0) {
+      if constexpr (GRAM) {
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        diag[6 * (long)n + j] = acc[j];
-        grad[6 * (long)n + j] = acc[6 + j];
+        for (int j = 0; j < 21; ++j) diag[21 * (long)n + j] = acc[j];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) grad[6 * (long)n + j] = acc[21 + j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          diag[6 * (long)n + j] = acc[j];
+          grad[6 * (long)n + j] = acc[6 + j];
+        }
       }
 #pragma unroll
-      for (int j = 0; j < 16; ++j) ipart[16 * (long)n + j] = acc[12 + j];
+      for (int j = 0; j < 16; ++j) ipart[16 * (long)n + j] = acc[PW + j];
     }
   }
 }
@@ -1105,9 +1128,9 @@ struct BaWs {
   DevBuf<CgStatus> cgst;
   DevBuf<CgScal> cgsc;
   // calibrated rigs: image tables and the image-space twins of the per-camera arrays
-  DevBuf<int> img_frame, foff, fimg;
-  DevBuf<unsigned char> img_fixed;
-  DevBuf<double> sens, Ri, Rin, ti, tin, diag_i, grad_i, gred_i, spose_i, dvec_i, zimg, wimg, ximg;
+  DevBuf<int> img_frame, foff, fimg, img_sensor, soff, simg;
+  DevBuf<unsigned char> img_fixed, fmask;
+  DevBuf<double> sens, Ri, Rin, ti, tin, diag_i, grad_i, gred_i, spose_i, dvec_i, zimg, wimg, ximg, lever, gram_i;
   static void destroy(void* p) { delete static_cast<BaWs*>(p); }
 };
 
@@ -1153,16 +1176,53 @@ void dispatch_f(int F, Fn&& fn) {
 // pose (R_s R_f, R_s t_f + t_s) and its own left-multiplicative tangent; the unknown is the FRAME's pose, whose tangent
 // (d_rot, d_trn) maps to the image's as T_s d = (R_s d_rot, R_s d_trn)  [R_s [a]x R_s^T = [R_s a]x].  So the LM diagonal,
 // the block-Jacobi blocks and the PCG vectors live per frame, and small kernels translate around the sweeps:
-// z_image = T_s z_frame before them, w_frame = sum_images T_s^T w_image after them.  T_s is orthogonal, hence
-// z_frame . w_frame = sum z_image . w_image: the delta partials of the image-space sweeps are the frame-space ones.
+// z_image = T_s z_frame before them, w_frame = sum_images T_s^T w_image after them.  z_frame . w_frame =
+// sum z_image . w_image (adjoint maps): the delta partials of the image-space sweeps are the frame-space ones.
+//
+// colmap::RigReprojErrorCostFunctor (bundle_adjustment.cc:161-179, optimize_rig_poses): the cam_from_rig of every
+// non-reference sensor is a parameter block of its own, stored as pose block N + s behind the N frames (same manifold,
+// same update kernel).  Its tangent (d_rot, d_trn) moves the image as
+//   R_i <- Exp(2 d_rot) R_s R_f,   t_i <- Exp(2 d_rot) (R_s t_f) + t_s + d_trn
+// i.e. U_i d = (d_rot, d_trn - 2 b x d_rot) with the lever b = R_s t_f, so z_image = T_s z_frame + U_i z_sensor and
+// w_sensor = sum_images U_i^T w_image, U^T w = (w_rot + 2 b x w_trn, w_trn).  The image Jacobians stay unmasked in this
+// mode (a sensor block is never constant, ba.cc:296-309) and the constant frame / optimize_rotations /
+// optimize_translation act on the frame rows instead (fmask).
+struct RigDev {
+  int NI, N, S;                // images, frames, optimised sensor blocks (pose blocks N .. N + S - 1)
+  const int* img_frame;        // [NI]
+  const int* img_sensor;       // [NI] sensor block of the image or -1; null when S == 0
+  double* sens;                // [NI][12] cam_from_rig (R row-major | t) at the linearisation point
+  double* lever;               // [NI][3] R_s t_frame (S > 0)
+  const int* foff;             // [N + 1] frame -> images (ascending: a fixed summation order)
+  const int* fimg;             // [NI]
+  const int* soff;             // [S + 1] sensor block -> images
+  const int* simg;
+  const unsigned char* fmask;  // [N] bit 0: rotation free, bit 1: translation free; null: the masks live in the image Jacobians
+};
+
+__device__ __forceinline__ void rig_sensor_of(const RigDev& rg, int i, const double* __restrict__ Rp,
+                                              const double* __restrict__ tp, double (&S)[12]) {
+  const int sb = rg.img_sensor ? rg.img_sensor[i] : -1;
+  if (sb >= 0) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j) S[j] = Rp[9 * (long)(rg.N + sb) + j];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) S[9 + j] = tp[3 * (long)(rg.N + sb) + j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) S[j] = rg.sens[12 * (long)i + j];
+  }
+}
+
+// image poses = cam_from_rig * rig_from_world for the pose blocks (Rp, tp): frames, then the optimised sensors
 __global__ void __launch_bounds__(kBlock)
-    k_ba_rig_poses(int NI, const int* __restrict__ img_frame, const double* __restrict__ sens /* [NI][12] R_s | t_s */,
-                   const double* __restrict__ Rf, const double* __restrict__ tf, double* __restrict__ Ri,
+    k_ba_rig_poses(RigDev rg, const double* __restrict__ Rp, const double* __restrict__ tp, double* __restrict__ Ri,
                    double* __restrict__ ti) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < NI; i += gridDim.x * blockDim.x) {
-    const double* S = sens + 12 * (long)i;
-    const double* R = Rf + 9 * (long)img_frame[i];
-    const double* t = tf + 3 * (long)img_frame[i];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rg.NI; i += gridDim.x * blockDim.x) {
+    double S[12];
+    rig_sensor_of(rg, i, Rp, tp, S);
+    const double* R = Rp + 9 * (long)rg.img_frame[i];
+    const double* t = tp + 3 * (long)rg.img_frame[i];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
 #pragma unroll
@@ -1172,24 +1232,51 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
-// dst_image = (T_s src_frame | intrinsics part copied): z and the step dy
+// sensor mode, at every linearisation point: the images' cam_from_rig table and levers from the current pose blocks
 __global__ void __launch_bounds__(kBlock)
-    k_ba_rig_expand(int NI, int N, int K, const int* __restrict__ img_frame, const double* __restrict__ sens,
-                    const double* __restrict__ src, double* __restrict__ dst) {
-  const int total = NI + K;
+    k_ba_rig_refresh(RigDev rg, const double* __restrict__ Rp, const double* __restrict__ tp) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rg.NI; i += gridDim.x * blockDim.x) {
+    double S[12];
+    rig_sensor_of(rg, i, Rp, tp, S);
+    const double* t = tp + 3 * (long)rg.img_frame[i];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) rg.sens[12 * (long)i + j] = S[j];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) rg.lever[3 * (long)i + a] = S[3 * a] * t[0] + S[3 * a + 1] * t[1] + S[3 * a + 2] * t[2];
+  }
+}
+
+// dst_image = T_s src_frame (+ U_i src_sensor) | intrinsics part copied: z and the step dy.  src is laid out
+// [6 per pose block (Np of them) | 8 per intrinsics block], dst [6 per image | 8 per intrinsics block].
+__global__ void __launch_bounds__(kBlock)
+    k_ba_rig_expand(RigDev rg, int Np, int K, const double* __restrict__ src, double* __restrict__ dst) {
+  const int total = rg.NI + K;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    if (i < NI) {
-      const double* S = sens + 12 * (long)i;
-      const double* v = src + 6 * (long)img_frame[i];
+    if (i < rg.NI) {
+      const double* S = rg.sens + 12 * (long)i;
+      const double* v = src + 6 * (long)rg.img_frame[i];
+      double o[6];
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
-          dst[6 * (long)i + 3 * h + a] = S[3 * a] * v[3 * h] + S[3 * a + 1] * v[3 * h + 1] + S[3 * a + 2] * v[3 * h + 2];
-    } else {
-      const int k = i - NI;
+        for (int a = 0; a < 3; ++a) o[3 * h + a] = S[3 * a] * v[3 * h] + S[3 * a + 1] * v[3 * h + 1] + S[3 * a + 2] * v[3 * h + 2];
+      const int sb = rg.img_sensor ? rg.img_sensor[i] : -1;
+      if (sb >= 0) {
+        const double* d = src + 6 * (long)(rg.N + sb);
+        const double* b = rg.lever + 3 * (long)i;
+        o[0] += d[0];
+        o[1] += d[1];
+        o[2] += d[2];
+        o[3] += d[3] - 2.0 * (b[1] * d[2] - b[2] * d[1]);
+        o[4] += d[4] - 2.0 * (b[2] * d[0] - b[0] * d[2]);
+        o[5] += d[5] - 2.0 * (b[0] * d[1] - b[1] * d[0]);
+      }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dst[6 * (long)NI + 8 * (long)k + j] = src[6 * (long)N + 8 * (long)k + j];
+      for (int j = 0; j < 6; ++j) dst[6 * (long)i + j] = o[j];
+    } else {
+      const int k = i - rg.NI;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dst[6 * (long)rg.NI + 8 * (long)k + j] = src[6 * (long)Np + 8 * (long)k + j];
     }
   }
 }
@@ -1213,20 +1300,154 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
-// reduced gradient and diagonal Schur block of a frame: sum over its images of T_s^T g and T_s^T S T_s
+__device__ __forceinline__ void unpack_sym6(const double* __restrict__ sp, double (&A)[6][6]) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = i; j < 6; ++j) A[i][j] = A[j][i] = sp[sym6(i, j)];
+}
+
+// B += V^T A V for a 6 x 6 tangent map V (row-major)
+__device__ __forceinline__ void congruence6(const double (&A)[6][6], const double (&V)[6][6], double (&B)[6][6]) {
+  double M[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      double m = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) m += A[i][k] * V[k][j];
+      M[i][j] = m;
+    }
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      double m = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) m += V[k][i] * M[k][j];
+      B[i][j] += m;
+    }
+}
+
+// U_i = [[I, 0], [-2 [b]x, I]]
+__device__ __forceinline__ void sensor_map(const double* __restrict__ b, double (&U)[6][6]) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) U[i][j] = i == j ? 1.0 : 0.0;
+  U[3][1] = 2.0 * b[2];
+  U[3][2] = -2.0 * b[1];
+  U[4][0] = -2.0 * b[2];
+  U[4][2] = 2.0 * b[0];
+  U[5][0] = 2.0 * b[1];
+  U[5][1] = -2.0 * b[0];
+}
+
+// T_s = diag(R_s, R_s)
+__device__ __forceinline__ void frame_map(const double* __restrict__ S, double (&T)[6][6]) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) T[i][j] = (i / 3 == j / 3) ? S[3 * (i % 3) + (j % 3)] : 0.0;
+}
+
+// g_out += V^T g
+__device__ __forceinline__ void map_t6(const double (&V)[6][6], const double* __restrict__ gi, double (&g)[6]) {
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double m = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) m += V[k][j] * gi[k];
+    g[j] += m;
+  }
+}
+
+__device__ __forceinline__ bool frame_free(const RigDev& rg, int f, int j) {
+  return rg.fmask == nullptr || ((rg.fmask[f] >> (j / 3)) & 1);
+}
+
+// sensor mode: squared column norms and gradient of a frame = masked diagonal of sum T^T G T and sum T^T g over its
+// images (G, g: the image's Gram matrix and gradient from k_ba_lin_cam<true>)
 __global__ void __launch_bounds__(kBlock)
-    k_ba_rig_reduce_blocks(int N, const int* __restrict__ foff, const int* __restrict__ fimg, const double* __restrict__ sens,
-                           const double* __restrict__ gred_i, const double* __restrict__ spose_i,
-                           double* __restrict__ gred_f, double* __restrict__ spose_f) {
-  for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < N; f += gridDim.x * blockDim.x) {
+    k_ba_rig_frame_lin(RigDev rg, const double* __restrict__ gram_i, const double* __restrict__ grad_i,
+                       double* __restrict__ diag, double* __restrict__ grad) {
+  for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < rg.N; f += gridDim.x * blockDim.x) {
     double g[6] = {0, 0, 0, 0, 0, 0};
     double B[6][6];
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
       for (int j = 0; j < 6; ++j) B[i][j] = 0.0;
-    for (int a = foff[f]; a < foff[f + 1]; ++a) {
-      const int im = fimg[a];
+    for (int a = rg.foff[f]; a < rg.foff[f + 1]; ++a) {
+      const int im = rg.fimg[a];
+      double A[6][6], T[6][6];
+      unpack_sym6(gram_i + 21 * (long)im, A);
+      frame_map(rg.sens + 12 * (long)im, T);
+      congruence6(A, T, B);
+      map_t6(T, grad_i + 6 * (long)im, g);
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const bool fr = frame_free(rg, f, j);
+      diag[6 * (long)f + j] = fr ? B[j][j] : 0.0;
+      grad[6 * (long)f + j] = fr ? g[j] : 0.0;
+    }
+  }
+}
+
+// sensor mode: the same for sensor block s (pose block N + s), one workgroup per sensor, fixed-order sums
+__global__ void __launch_bounds__(kBlock)
+    k_ba_rig_sensor_lin(RigDev rg, const double* __restrict__ gram_i, const double* __restrict__ grad_i,
+                        double* __restrict__ diag, double* __restrict__ grad) {
+  __shared__ double smem[4 * 12];
+  for (int sb = blockIdx.x; sb < rg.S; sb += gridDim.x) {
+    double acc[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) acc[j] = 0.0;
+    for (int a = rg.soff[sb] + threadIdx.x; a < rg.soff[sb + 1]; a += blockDim.x) {
+      const int im = rg.simg[a];
+      double A[6][6], U[6][6], B[6][6], g[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) B[i][j] = 0.0;
+      unpack_sym6(gram_i + 21 * (long)im, A);
+      sensor_map(rg.lever + 3 * (long)im, U);
+      congruence6(A, U, B);
+      map_t6(U, grad_i + 6 * (long)im, g);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        acc[j] += B[j][j];
+        acc[6 + j] += g[j];
+      }
+    }
+    block_sum<12>(acc, smem);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        diag[6 * (long)(rg.N + sb) + j] = acc[j];
+        grad[6 * (long)(rg.N + sb) + j] = acc[6 + j];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// reduced gradient and diagonal Schur block of a frame: sum over its images of T_s^T g and T_s^T S T_s
+__global__ void __launch_bounds__(kBlock)
+    k_ba_rig_reduce_blocks(RigDev rg, const double* __restrict__ gred_i, const double* __restrict__ spose_i,
+                           double* __restrict__ gred_f, double* __restrict__ spose_f) {
+  const double* sens = rg.sens;
+  for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < rg.N; f += gridDim.x * blockDim.x) {
+    double g[6] = {0, 0, 0, 0, 0, 0};
+    double B[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) B[i][j] = 0.0;
+    for (int a = rg.foff[f]; a < rg.foff[f + 1]; ++a) {
+      const int im = rg.fimg[a];
       const double* S = sens + 12 * (long)im;
       const double* gi = gred_i + 6 * (long)im;
       const double* sp = spose_i + 21 * (long)im;
@@ -1237,10 +1458,7 @@ __global__ void __launch_bounds__(kBlock)
         for (int j = 0; j < 3; ++j) g[3 * h + j] += S[j] * gi[3 * h] + S[3 + j] * gi[3 * h + 1] + S[6 + j] * gi[3 * h + 2];
       // full 6 x 6 of the image, then T^T A T block by block (3 x 3 blocks: R_s^T A_hk R_s)
       double A[6][6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = i; j < 6; ++j) A[i][j] = A[j][i] = sp[sym6(i, j)];
+      unpack_sym6(sp, A);
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -1258,36 +1476,76 @@ __global__ void __launch_bounds__(kBlock)
         }
     }
 #pragma unroll
-    for (int j = 0; j < 6; ++j) gred_f[6 * (long)f + j] = g[j];
+    for (int j = 0; j < 6; ++j) gred_f[6 * (long)f + j] = frame_free(rg, f, j) ? g[j] : 0.0;
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
-      for (int j = i; j < 6; ++j) spose_f[21 * (long)f + sym6(i, j)] = 0.5 * (B[i][j] + B[j][i]);
+      for (int j = i; j < 6; ++j)
+        spose_f[21 * (long)f + sym6(i, j)] = (frame_free(rg, f, i) && frame_free(rg, f, j)) ? 0.5 * (B[i][j] + B[j][i]) : 0.0;
+  }
+}
+
+// sensor mode: the same for the sensor blocks, sum over the sensor's images of U^T g and U^T S U (one workgroup each)
+__global__ void __launch_bounds__(kBlock)
+    k_ba_rig_sensor_blocks(RigDev rg, const double* __restrict__ gred_i, const double* __restrict__ spose_i,
+                           double* __restrict__ gred, double* __restrict__ spose) {
+  __shared__ double smem[4 * 27];
+  for (int sb = blockIdx.x; sb < rg.S; sb += gridDim.x) {
+    double g[6] = {0, 0, 0, 0, 0, 0};
+    double B[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) B[i][j] = 0.0;
+    for (int a = rg.soff[sb] + threadIdx.x; a < rg.soff[sb + 1]; a += blockDim.x) {
+      const int im = rg.simg[a];
+      double A[6][6], U[6][6];
+      unpack_sym6(spose_i + 21 * (long)im, A);
+      sensor_map(rg.lever + 3 * (long)im, U);
+      congruence6(A, U, B);
+      map_t6(U, gred_i + 6 * (long)im, g);
+    }
+    double acc[27];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[j] = g[j];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = i; j < 6; ++j) acc[6 + i * 6 - (i * (i - 1)) / 2 + (j - i)] = 0.5 * (B[i][j] + B[j][i]);
+    block_sum<27>(acc, smem);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) gred[6 * (long)(rg.N + sb) + j] = acc[j];
+#pragma unroll
+      for (int j = 0; j < 21; ++j) spose[21 * (long)(rg.N + sb) + j] = acc[6 + j];
+    }
+    __syncthreads();
   }
 }
 
 // image-space diagonal for the sweeps: zero for the pose columns (their damping is a frame-space term), the
 // frame-space values for the intrinsics columns
 __global__ void __launch_bounds__(kBlock)
-    k_ba_rig_dvec(int NI, int N, int K, const double* __restrict__ dvec_f, double* __restrict__ dvec_i) {
+    k_ba_rig_dvec(int NI, int Np, int K, const double* __restrict__ dvec_f, double* __restrict__ dvec_i) {
   const long total = 6 * (long)NI + 8 * (long)K;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
-    dvec_i[i] = i < 6 * (long)NI ? 0.0 : dvec_f[6 * (long)N + (i - 6 * (long)NI)];
+    dvec_i[i] = i < 6 * (long)NI ? 0.0 : dvec_f[6 * (long)Np + (i - 6 * (long)NI)];
 }
 
-// w_frame (pose) = sum_images T_s^T w_image + D z_frame; intrinsics rows copied; the damping share of delta goes to its
-// own partial slot.  One workgroup: the number of frames is small.
+// w_frame (pose) = sum_images T_s^T w_image + D z_frame, w_sensor = sum_images U_i^T w_image + D z_sensor; intrinsics rows
+// copied; the damping share of delta goes to its own partial slot.  One workgroup: the number of frames is small.
+// v is the frame-space vector set: v.N = pose blocks (frames + sensor blocks).
 __global__ void __launch_bounds__(kBlock)
-    k_ba_rig_reduce_w(CgVec v, int NI, double yscale, const int* __restrict__ foff, const int* __restrict__ fimg,
-                      const double* __restrict__ sens, const double* __restrict__ w_img, const double* __restrict__ dvec,
+    k_ba_rig_reduce_w(CgVec v, RigDev rg, double yscale, const double* __restrict__ w_img, const double* __restrict__ dvec,
                       int dslot) {
-  __shared__ double smem[4];
+  __shared__ double smem[4 + 4 * 6];
   if (v.st->done) return;
+  const double* sens = rg.sens;
   double d[1] = {0.0};
-  for (int f = threadIdx.x; f < v.N; f += blockDim.x) {
+  for (int f = threadIdx.x; f < rg.N; f += blockDim.x) {
     double acc[6] = {0, 0, 0, 0, 0, 0};
-    for (int a = foff[f]; a < foff[f + 1]; ++a) {
-      const int im = fimg[a];
+    for (int a = rg.foff[f]; a < rg.foff[f + 1]; ++a) {
+      const int im = rg.fimg[a];
       const double* S = sens + 12 * (long)im;
       const double* wi = w_img + 6 * (long)im;
 #pragma unroll
@@ -1299,11 +1557,36 @@ __global__ void __launch_bounds__(kBlock)
     for (int j = 0; j < 6; ++j) {
       const double z = v.z[6 * (long)f + j];
       const double dz = yscale * dvec[6 * (long)f + j] * z;
-      v.w[6 * (long)f + j] = acc[j] + dz;
+      v.w[6 * (long)f + j] = (frame_free(rg, f, j) ? acc[j] : 0.0) + dz;
       d[0] += z * dz;
     }
   }
-  for (int i = threadIdx.x; i < 8 * v.K; i += blockDim.x) v.w[6 * (long)v.N + i] = w_img[6 * (long)NI + i];
+  for (int i = threadIdx.x; i < 8 * v.K; i += blockDim.x) v.w[6 * (long)v.N + i] = w_img[6 * (long)rg.NI + i];
+  for (int sb = 0; sb < rg.S; ++sb) {
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int a = rg.soff[sb] + threadIdx.x; a < rg.soff[sb + 1]; a += blockDim.x) {
+      const int im = rg.simg[a];
+      const double* wi = w_img + 6 * (long)im;
+      const double* b = rg.lever + 3 * (long)im;
+      acc[0] += wi[0] + 2.0 * (b[1] * wi[5] - b[2] * wi[4]);
+      acc[1] += wi[1] + 2.0 * (b[2] * wi[3] - b[0] * wi[5]);
+      acc[2] += wi[2] + 2.0 * (b[0] * wi[4] - b[1] * wi[3]);
+      acc[3] += wi[3];
+      acc[4] += wi[4];
+      acc[5] += wi[5];
+    }
+    block_sum<6>(acc, smem + 4);
+    if (threadIdx.x == 0) {
+      const long o = 6 * (long)(rg.N + sb);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const double z = v.z[o + j];
+        const double dz = yscale * dvec[o + j] * z;
+        v.w[o + j] = acc[j] + dz;
+        d[0] += z * dz;
+      }
+    }
+  }
   block_sum<1>(d, smem);
   if (threadIdx.x == 0) v.dpart[dslot] = d[0];
 }
@@ -1321,19 +1604,30 @@ class BaSolver final : public LmProblem {
     K_ = prob->num_intr;
     P_ = prob->num_pts;
     M_ = prob->num_obs;
-    n_ = 6 * N_ + 8 * K_;
     GSFM_REQUIRE(N_ > 0 && K_ > 0 && P_ >= 0 && M_ >= 0, "BA: bad sizes");
     GSFM_REQUIRE(prob->fixed_cam >= -1 && prob->fixed_cam < N_, "BA: fixed_cam out of range");
     // calibrated rigs: the observation graph is over IMAGES (NI_ cameras), the pose unknowns are the N_ frames
     rig_ = prob->num_images > 0;
     NI_ = rig_ ? prob->num_images : N_;
     ni_ = 6 * NI_ + 8 * K_;
-    std::vector<int> h_imf;
+    std::vector<int> h_imf, h_ims;
+    const int num_sensors = rig_ ? prob->num_sensors : 0;
     if (rig_) {
       GSFM_REQUIRE(prob->image_frame && prob->image_cam_from_rig && prob->image_intr, "BA: image tables missing");
       to_host(ctx_, h_imf, prob->image_frame, (size_t)NI_, mem);
       for (int i = 0; i < NI_; ++i) GSFM_REQUIRE(h_imf[i] >= 0 && h_imf[i] < N_, "BA: image_frame out of range");
+      GSFM_REQUIRE(num_sensors >= 0, "BA: num_sensors negative");
+      if (num_sensors > 0) {
+        GSFM_REQUIRE(prob->image_sensor && prob->sensor_cam_from_rig, "BA: sensor tables missing");
+        to_host(ctx_, h_ims, prob->image_sensor, (size_t)NI_, mem);
+        for (int i = 0; i < NI_; ++i) GSFM_REQUIRE(h_ims[i] >= -1 && h_ims[i] < num_sensors, "BA: image_sensor out of range");
+      }
     }
+    // optimize_rig_poses (ba.cc:161-179): the sensor blocks are pose blocks N_ .. N_ + S_ - 1 behind the frames
+    S_ = opt_.optimize_rig_poses ? num_sensors : 0;
+    sens_ = S_ > 0;
+    Np_ = N_ + S_;
+    n_ = 6 * Np_ + 8 * K_;
     std::vector<long> h_off;
     to_host(ctx_, h_off, reinterpret_cast<const long*>(prob->pt_offset), (size_t)P_ + 1, mem);
     GSFM_REQUIRE(h_off[0] == 0 && h_off[P_] == M_, "BA: pt_offset must start at 0 and end at num_obs");
@@ -1386,8 +1680,8 @@ class BaSolver final : public LmProblem {
     copy_in(ctx_, ws->xy.ensure(2 * (size_t)M_ + 2), prob->obs_xy, 2 * (size_t)M_, mem);
     copy_in(ctx_, ws->cam_intr.ensure(NI_), rig_ ? prob->image_intr : prob->cam_intr, (size_t)NI_, mem);
     copy_in(ctx_, ws->intr_model.ensure(K_), prob->intr_model, (size_t)K_, mem);
-    copy_in(ctx_, ws->q.ensure(4 * (size_t)N_), cam_q, 4 * (size_t)N_, mem);
-    copy_in(ctx_, ws->t.ensure(3 * (size_t)N_), cam_t, 3 * (size_t)N_, mem);
+    copy_in(ctx_, ws->q.ensure(4 * (size_t)Np_), cam_q, 4 * (size_t)N_, mem);
+    copy_in(ctx_, ws->t.ensure(3 * (size_t)Np_), cam_t, 3 * (size_t)N_, mem);
     copy_in(ctx_, ws->X.ensure(3 * (size_t)P_ + 3), pt_xyz, 3 * (size_t)P_, mem);
     copy_in(ctx_, ws->par.ensure(8 * (size_t)K_), intr_params, 8 * (size_t)K_, mem);
     GSFM_HIP_CHECK(hipMemcpyAsync(ws->intr_free.ensure(K_), h_free.data(), (size_t)K_, hipMemcpyHostToDevice, s));
@@ -1410,10 +1704,10 @@ class BaSolver final : public LmProblem {
     GSFM_HIP_CHECK(hipMemsetAsync(ws->jt.get(), 0, ((size_t)(10 + F_) * Mp_ + 64) * sizeof(double2), s));
     hipLaunchKernelGGL(k_ba_obs_ik, dim3(grid_for(M_, kBlock)), dim3(kBlock), 0, s, M_, ws->cam.get(),
                        ws->cam_intr.get(), ws->obs_ik.ensure(M_ + 1));
-    ws->qn.ensure(4 * (size_t)N_);
-    ws->tn.ensure(3 * (size_t)N_);
-    ws->camR.ensure(9 * (size_t)N_);
-    ws->camRn.ensure(9 * (size_t)N_);
+    ws->qn.ensure(4 * (size_t)Np_);
+    ws->tn.ensure(3 * (size_t)Np_);
+    ws->camR.ensure(9 * (size_t)Np_);
+    ws->camRn.ensure(9 * (size_t)Np_);
     ws->Xn.ensure(3 * (size_t)P_ + 3);
     ws->parn.ensure(8 * (size_t)K_);
     ws->ptH.ensure(9 * (size_t)P_ + 9);
@@ -1425,7 +1719,7 @@ class BaSolver final : public LmProblem {
                               &ws->cg_z, &ws->cg_p, &ws->cg_s})
       b->ensure(n_);
     ws->cg_w.ensure((size_t)n_ + 2);
-    ws->spose.ensure(21 * (size_t)N_);
+    ws->spose.ensure(21 * (size_t)Np_);
     if (joint_) {
       ws->scross.ensure(48 * (size_t)N_);
       ws->minvj.ensure(196 * (size_t)N_);
@@ -1439,17 +1733,19 @@ class BaSolver final : public LmProblem {
       // frame, and the frame -> images lists (ascending image order: a fixed summation order)
       std::vector<double> h_cfr, h_sens(12 * (size_t)NI_);
       to_host(ctx_, h_cfr, prob->image_cam_from_rig, 7 * (size_t)NI_, mem);
+      const double* h_sen = prob->sensor_cam_from_rig;  // host by contract
       std::vector<unsigned char> h_fix((size_t)NI_, 0);
       std::vector<int> foff((size_t)N_ + 1, 0), fimg((size_t)NI_);
       for (int i = 0; i < NI_; ++i) {
-        const double* qv = &h_cfr[7 * (size_t)i];
+        // the cam_from_rig of an image with a sensor block is the block's value (start value when it is optimised)
+        const double* qv = (num_sensors > 0 && h_ims[i] >= 0) ? h_sen + 7 * (size_t)h_ims[i] : &h_cfr[7 * (size_t)i];
         const double w = qv[0], x = qv[1], y = qv[2], z = qv[3];
         double* S = &h_sens[12 * (size_t)i];
         S[0] = 1 - 2 * (y * y + z * z); S[1] = 2 * (x * y - w * z); S[2] = 2 * (x * z + w * y);
         S[3] = 2 * (x * y + w * z); S[4] = 1 - 2 * (x * x + z * z); S[5] = 2 * (y * z - w * x);
         S[6] = 2 * (x * z - w * y); S[7] = 2 * (y * z + w * x); S[8] = 1 - 2 * (x * x + y * y);
         S[9] = qv[4]; S[10] = qv[5]; S[11] = qv[6];
-        h_fix[i] = h_imf[i] == prob->fixed_cam ? 1 : 0;
+        h_fix[i] = (!sens_ && h_imf[i] == prob->fixed_cam) ? 1 : 0;  // sensor mode: the masks act on the frame rows
         foff[h_imf[i] + 1]++;
       }
       for (int f = 0; f < N_; ++f) foff[f + 1] += foff[f];
@@ -1460,7 +1756,49 @@ class BaSolver final : public LmProblem {
       GSFM_HIP_CHECK(hipMemcpyAsync(ws->fimg.ensure(NI_), fimg.data(), (size_t)NI_ * sizeof(int), hipMemcpyHostToDevice, s));
       GSFM_HIP_CHECK(hipMemcpyAsync(ws->img_fixed.ensure(NI_), h_fix.data(), (size_t)NI_, hipMemcpyHostToDevice, s));
       GSFM_HIP_CHECK(hipMemcpyAsync(ws->sens.ensure(12 * (size_t)NI_), h_sens.data(), 12 * (size_t)NI_ * sizeof(double), hipMemcpyHostToDevice, s));
+      rg_ = RigDev{};
+      if (sens_) {
+        std::vector<int> soff((size_t)S_ + 1, 0), simg;
+        for (int i = 0; i < NI_; ++i)
+          if (h_ims[i] >= 0) soff[h_ims[i] + 1]++;
+        for (int k = 0; k < S_; ++k) soff[k + 1] += soff[k];
+        simg.resize((size_t)soff[S_] + 1);
+        std::vector<int> scur(soff.begin(), soff.end() - 1);
+        for (int i = 0; i < NI_; ++i)
+          if (h_ims[i] >= 0) simg[scur[h_ims[i]]++] = i;
+        std::vector<unsigned char> h_fm((size_t)N_);
+        for (int f = 0; f < N_; ++f) {
+          const bool fixed = f == prob->fixed_cam;  // ba.cc:261-266
+          h_fm[f] = (unsigned char)((opt_.optimize_rotations && !fixed ? 1 : 0) | (opt_.optimize_translation && !fixed ? 2 : 0));
+        }
+        std::vector<double> h_q(4 * (size_t)S_), h_t(3 * (size_t)S_);
+        for (int k = 0; k < S_; ++k) {
+          for (int j = 0; j < 4; ++j) h_q[4 * (size_t)k + j] = h_sen[7 * (size_t)k + j];
+          for (int j = 0; j < 3; ++j) h_t[3 * (size_t)k + j] = h_sen[7 * (size_t)k + 4 + j];
+        }
+        GSFM_HIP_CHECK(hipMemcpyAsync(ws->img_sensor.ensure(NI_), h_ims.data(), (size_t)NI_ * sizeof(int), hipMemcpyHostToDevice, s));
+        GSFM_HIP_CHECK(hipMemcpyAsync(ws->soff.ensure(S_ + 1), soff.data(), (size_t)(S_ + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+        GSFM_HIP_CHECK(hipMemcpyAsync(ws->simg.ensure(simg.size()), simg.data(), simg.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        GSFM_HIP_CHECK(hipMemcpyAsync(ws->fmask.ensure(N_), h_fm.data(), (size_t)N_, hipMemcpyHostToDevice, s));
+        GSFM_HIP_CHECK(hipMemcpyAsync(ws->q.get() + 4 * (size_t)N_, h_q.data(), h_q.size() * sizeof(double), hipMemcpyHostToDevice, s));
+        GSFM_HIP_CHECK(hipMemcpyAsync(ws->t.get() + 3 * (size_t)N_, h_t.data(), h_t.size() * sizeof(double), hipMemcpyHostToDevice, s));
+        ws->lever.ensure(3 * (size_t)NI_);
+        ws->gram_i.ensure(21 * (size_t)NI_);
+        GSFM_HIP_CHECK(hipMemsetAsync(ws->gram_i.get(), 0, 21 * (size_t)NI_ * sizeof(double), s));
+        rg_.img_sensor = ws->img_sensor.get();
+        rg_.lever = ws->lever.get();
+        rg_.soff = ws->soff.get();
+        rg_.simg = ws->simg.get();
+        rg_.fmask = ws->fmask.get();
+      }
       GSFM_HIP_CHECK(hipStreamSynchronize(s));  // the host vectors above go out of scope
+      rg_.NI = NI_;
+      rg_.N = N_;
+      rg_.S = S_;
+      rg_.img_frame = ws->img_frame.get();
+      rg_.sens = ws->sens.get();
+      rg_.foff = ws->foff.get();
+      rg_.fimg = ws->fimg.get();
       for (DevBuf<double>* b : {&ws->Ri, &ws->Rin}) b->ensure(9 * (size_t)NI_);
       for (DevBuf<double>* b : {&ws->ti, &ws->tin}) b->ensure(3 * (size_t)NI_);
       for (DevBuf<double>* b : {&ws->diag_i, &ws->grad_i, &ws->dvec_i, &ws->zimg, &ws->ximg}) b->ensure((size_t)ni_);
@@ -1472,7 +1810,7 @@ class BaSolver final : public LmProblem {
     }
     ws->iacc16.ensure(16 * (size_t)K_);
     ws->iacc44.ensure(44 * (size_t)K_);
-    ws->minv.ensure(36 * (size_t)N_ + 64 * (size_t)K_);
+    ws->minv.ensure(36 * (size_t)Np_ + 64 * (size_t)K_);
     ws->vpart.ensure(2 * kCgMaxBlocks * 2);
     ws->dpart.ensure(2 * kMaxApplySlots);
     ws->part.ensure(kMaxBlocks * 8);
@@ -1481,6 +1819,7 @@ class BaSolver final : public LmProblem {
     ws->cgsc.ensure(2);
     gridP_ = grid_for(P_, kBlock);
     gridN_ = grid_for(N_, kBlock);
+    gridNp_ = grid_for(Np_, kBlock);
     gridNI_ = grid_for(NI_, kBlock);
     gridM_ = grid_for(M_, kBlock);
     gridCam_ = grid_wide(g_.g.S, kBlock / 64, kMaxApplySlots);  // one wave per camera segment (delta partial per block)
@@ -1502,9 +1841,10 @@ class BaSolver final : public LmProblem {
     g_.obs_ik = ws->obs_ik.get();
     g_.zrec = joint_ ? ws->zrec.get() : nullptr;
     g_.fixed_cam = rig_ ? -1 : prob->fixed_cam;
-    g_.img_fixed = rig_ ? ws->img_fixed.get() : nullptr;
-    g_.opt_rot = opt_.optimize_rotations ? 1 : 0;
-    g_.opt_trn = opt_.optimize_translation ? 1 : 0;
+    g_.img_fixed = (rig_ && !sens_) ? ws->img_fixed.get() : nullptr;
+    // sensor mode: image Jacobians unmasked, the flags act on the frame rows (RigDev::fmask)
+    g_.opt_rot = (sens_ || opt_.optimize_rotations) ? 1 : 0;
+    g_.opt_trn = (sens_ || opt_.optimize_translation) ? 1 : 0;
     g_.opt_pts = opt_.optimize_points ? 1 : 0;
     g_.huber_a = opt_.thres_loss_function;
     g_.lm_lo = opt_.lm.min_lm_diagonal;
@@ -1516,7 +1856,7 @@ class BaSolver final : public LmProblem {
     R_ = ws->camR.get(); Rn_ = ws->camRn.get();
     X_ = ws->X.get(); Xn_ = ws->Xn.get();
     par_ = ws->par.get(); parn_ = ws->parn.get();
-    hipLaunchKernelGGL(k_ba_cam_prepare, dim3(gridN_), dim3(kBlock), 0, s, N_, q_, R_);
+    hipLaunchKernelGGL(k_ba_cam_prepare, dim3(gridNp_), dim3(kBlock), 0, s, Np_, q_, R_);
     // what the sweeps see as camera poses: the frames' own, or the images' cam_from_rig * rig_from_world
     Rk_ = rig_ ? ws->Ri.get() : R_;
     Rkn_ = rig_ ? ws->Rin.get() : Rn_;
@@ -1527,9 +1867,9 @@ class BaSolver final : public LmProblem {
     // buffers start equal, so such tracks keep their input xyz whichever buffer ends up current
     GSFM_HIP_CHECK(hipMemcpyAsync(Xn_, X_, 3 * (size_t)P_ * sizeof(double), hipMemcpyDeviceToDevice, s));
     cg_.n = n_;
-    cg_.N = N_;
+    cg_.N = Np_;
     cg_.K = K_;
-    cg_.nb_update = joint_ ? std::min(kCgMaxBlocks, grid_for(N_, kJointCams)) : std::min(kCgMaxBlocks, grid_for(N_ + K_, kBlock));
+    cg_.nb_update = joint_ ? std::min(kCgMaxBlocks, grid_for(N_, kJointCams)) : std::min(kCgMaxBlocks, grid_for(Np_ + K_, kBlock));
     cg_.zrec = joint_ ? ws->zrec.get() : nullptr;
     cg_.zrec_stride = 6 + F_;
     cg_.zrec_slot = joint_ ? ws->intr_slot.get() : nullptr;
@@ -1553,9 +1893,8 @@ class BaSolver final : public LmProblem {
   long used_observations() const { return m_used_; }
 
   // image poses = cam_from_rig * rig_from_world
-  void image_poses(const double* Rf, const double* tf, double* Ri, double* ti) {
-    hipLaunchKernelGGL(k_ba_rig_poses, dim3(gridNI_), dim3(kBlock), 0, ctx_->stream, NI_, ws_->img_frame.get(),
-                       ws_->sens.get(), Rf, tf, Ri, ti);
+  void image_poses(const double* Rp, const double* tp, double* Ri, double* ti) {
+    hipLaunchKernelGGL(k_ba_rig_poses, dim3(gridNI_), dim3(kBlock), 0, ctx_->stream, rg_, Rp, tp, Ri, ti);
   }
 
   double linearize(double* grad_max_norm) override {
@@ -1564,23 +1903,39 @@ class BaSolver final : public LmProblem {
     double* diag_k = rig_ ? ws->diag_i.get() : ws->diag.get();  // per graph camera (image); summed per frame below
     double* grad_k = rig_ ? ws->grad_i.get() : ws->grad.get();
     const double* sens = rig_ ? ws->sens.get() : nullptr;
+    if (sens_) {  // the images' cam_from_rig and levers at this linearisation point
+      hipLaunchKernelGGL(k_ba_rig_refresh, dim3(gridNI_), dim3(kBlock), 0, s, rg_, R_, t_);
+      diag_k = ws->gram_i.get();
+    }
     dispatch_f(F_, [&](auto Fc) {
       hipLaunchKernelGGL((k_ba_lin_track<decltype(Fc)::value>), dim3(gridTileP_), dim3(kBlock), 0, s, g_, Rk_, tk_, X_, par_,
                          ws->jt.get(), ws->ptdiag.get(), ws->ptH.get(), ws->part.get());
     });
-    hipLaunchKernelGGL(k_ba_lin_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, Rk_, tk_, X_, par_, ws->c_w.get(),
-                       diag_k, grad_k, ws->ipart.get(), sens);
-    if (gridMulti_)  // combine pass over the cameras whose lists were cut into slices
-      hipLaunchKernelGGL(k_ba_lin_cam, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, Rk_, tk_, X_, par_, ws->c_w.get(),
+    if (sens_) {
+      hipLaunchKernelGGL((k_ba_lin_cam<true>), dim3(gridCam_), dim3(kBlock), 0, s, g_, Rk_, tk_, X_, par_, ws->c_w.get(),
                          diag_k, grad_k, ws->ipart.get(), sens);
-    if (rig_) {  // lin_cam accumulated in the frame tangent: the frame's values are plain sums over its images
+      if (gridMulti_)
+        hipLaunchKernelGGL((k_ba_lin_cam<true>), dim3(gridMulti_), dim3(kBlock), 0, s, g1_, Rk_, tk_, X_, par_,
+                           ws->c_w.get(), diag_k, grad_k, ws->ipart.get(), sens);
+      hipLaunchKernelGGL(k_ba_rig_frame_lin, dim3(gridN_), dim3(kBlock), 0, s, rg_, diag_k, grad_k, ws->diag.get(),
+                         ws->grad.get());
+      hipLaunchKernelGGL(k_ba_rig_sensor_lin, dim3(S_), dim3(kBlock), 0, s, rg_, diag_k, grad_k, ws->diag.get(),
+                         ws->grad.get());
+    } else {
+      hipLaunchKernelGGL((k_ba_lin_cam<false>), dim3(gridCam_), dim3(kBlock), 0, s, g_, Rk_, tk_, X_, par_, ws->c_w.get(),
+                         diag_k, grad_k, ws->ipart.get(), sens);
+      if (gridMulti_)  // combine pass over the cameras whose lists were cut into slices
+        hipLaunchKernelGGL((k_ba_lin_cam<false>), dim3(gridMulti_), dim3(kBlock), 0, s, g1_, Rk_, tk_, X_, par_,
+                           ws->c_w.get(), diag_k, grad_k, ws->ipart.get(), sens);
+    }
+    if (rig_ && !sens_) {  // lin_cam accumulated in the frame tangent: the frame's values are plain sums over its images
       hipLaunchKernelGGL((k_ba_rig_sum<6>), dim3(gridN_), dim3(kBlock), 0, s, N_, ws->foff.get(), ws->fimg.get(), diag_k,
                          ws->diag.get());
       hipLaunchKernelGGL((k_ba_rig_sum<6>), dim3(gridN_), dim3(kBlock), 0, s, N_, ws->foff.get(), ws->fimg.get(), grad_k,
                          ws->grad.get());
     }
     group_sum<16>(ws->ipart.get(), ws->iacc16.get());
-    hipLaunchKernelGGL(k_ba_intr_unpack16, dim3(grid_for(8 * (size_t)K_, kBlock)), dim3(kBlock), 0, s, N_, K_,
+    hipLaunchKernelGGL(k_ba_intr_unpack16, dim3(grid_for(8 * (size_t)K_, kBlock)), dim3(kBlock), 0, s, Np_, K_,
                        ws->iacc16.get(), ws->diag.get(), ws->grad.get());
     if (ctx_->comm.world > 1) {
       allreduce_sum(ctx_, ws->diag.get(), n_);
@@ -1631,13 +1986,16 @@ class BaSolver final : public LmProblem {
                            ws->ptb.get(), gred_k, spose_k, ws->ipart.get(), (double*)nullptr);
       if (rig_)  // frame blocks: sum over the frame's images of T^T g and T^T S T (cross blocks between two images of
                  // one frame are left to the PCG: this is the preconditioner and the right-hand side)
-        hipLaunchKernelGGL(k_ba_rig_reduce_blocks, dim3(gridN_), dim3(kBlock), 0, s, N_, ws->foff.get(), ws->fimg.get(),
-                           ws->sens.get(), gred_k, spose_k, ws->gred.get(), ws->spose.get());
+        hipLaunchKernelGGL(k_ba_rig_reduce_blocks, dim3(gridN_), dim3(kBlock), 0, s, rg_, gred_k, spose_k, ws->gred.get(),
+                           ws->spose.get());
+      if (sens_)
+        hipLaunchKernelGGL(k_ba_rig_sensor_blocks, dim3(S_), dim3(kBlock), 0, s, rg_, gred_k, spose_k, ws->gred.get(),
+                           ws->spose.get());
     }
     group_sum<44>(ws->ipart.get(), ws->iacc44.get());
     if (multi) {
-      allreduce_sum(ctx_, ws->gred.get(), 6 * (size_t)N_);
-      allreduce_sum(ctx_, ws->spose.get(), 21 * (size_t)N_);
+      allreduce_sum(ctx_, ws->gred.get(), 6 * (size_t)Np_);
+      allreduce_sum(ctx_, ws->spose.get(), 21 * (size_t)Np_);
       allreduce_sum(ctx_, ws->iacc44.get(), 44 * (size_t)K_);
       if (joint_) allreduce_sum(ctx_, ws->scross.get(), 48 * (size_t)N_);
     }
@@ -1646,17 +2004,17 @@ class BaSolver final : public LmProblem {
                          g_.lm_hi, g_.cam_intr, ws->diag.get(), ws->js.get(), ws->gred.get(), ws->spose.get(),
                          ws->iacc44.get(), ws->scross.get(), ws->dvec.get(), ws->rhs.get(), ws->minvj.get());
     } else
-    hipLaunchKernelGGL(k_ba_blocks_finalize, dim3(grid_for(N_ + K_, kBlock)), dim3(kBlock), 0, s, N_, K_, radius,
+    hipLaunchKernelGGL(k_ba_blocks_finalize, dim3(grid_for(Np_ + K_, kBlock)), dim3(kBlock), 0, s, Np_, K_, radius,
                        g_.lm_lo, g_.lm_hi, ws->diag.get(), ws->js.get(), ws->gred.get(), ws->spose.get(),
                        ws->iacc44.get(), ws->dvec.get(), ws->rhs.get(), ws->minv.get());
     if (rig_)
-      hipLaunchKernelGGL(k_ba_rig_dvec, dim3(grid_for((size_t)ni_, kBlock)), dim3(kBlock), 0, s, NI_, N_, K_, ws->dvec.get(),
+      hipLaunchKernelGGL(k_ba_rig_dvec, dim3(grid_for((size_t)ni_, kBlock)), dim3(kBlock), 0, s, NI_, Np_, K_, ws->dvec.get(),
                          ws->dvec_i.get());
     *linear_iterations = pcg();
     const double* dy_k = ws->cg_x.get();
     if (rig_) {  // the step of an image's pose is T_s times the step of its frame
-      hipLaunchKernelGGL(k_ba_rig_expand, dim3(grid_for((size_t)NI_ + K_, kBlock)), dim3(kBlock), 0, s, NI_, N_, K_,
-                         ws->img_frame.get(), ws->sens.get(), ws->cg_x.get(), ws->ximg.get());
+      hipLaunchKernelGGL(k_ba_rig_expand, dim3(grid_for((size_t)NI_ + K_, kBlock)), dim3(kBlock), 0, s, rg_, Np_, K_,
+                         ws->cg_x.get(), ws->ximg.get());
       dy_k = ws->ximg.get();
     }
     dispatch_f(F_, [&](auto Fc) {
@@ -1664,12 +2022,12 @@ class BaSolver final : public LmProblem {
                          ws->ptb.get(), dy_k, Xn_, ws->part.get());
     });
     hipLaunchKernelGGL((k_ba_sum_partials<3>), dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridTileP_, ws->scal.get());
-    const int gridU = std::min(64, grid_for(N_ + 8 * (size_t)K_, kBlock));
+    const int gridU = std::min(64, grid_for(Np_ + 8 * (size_t)K_, kBlock));
     double* part2 = ws->part.get() + kMaxBlocks * 3;
-    hipLaunchKernelGGL(k_ba_param_update, dim3(gridU), dim3(kBlock), 0, s, N_, K_, q_, t_, par_, ws->cg_x.get(), qn_,
+    hipLaunchKernelGGL(k_ba_param_update, dim3(gridU), dim3(kBlock), 0, s, Np_, K_, q_, t_, par_, ws->cg_x.get(), qn_,
                        tn_, parn_, part2);
     hipLaunchKernelGGL((k_ba_sum_partials<3>), dim3(1), dim3(kBlock), 0, s, part2, gridU, ws->scal.get() + 3);
-    hipLaunchKernelGGL(k_ba_cam_prepare, dim3(gridN_), dim3(kBlock), 0, s, N_, qn_, Rn_);
+    hipLaunchKernelGGL(k_ba_cam_prepare, dim3(gridNp_), dim3(kBlock), 0, s, Np_, qn_, Rn_);
     if (rig_) image_poses(Rn_, tn_, Rkn_, tkn_);
     double* part3 = ws->part.get() + kMaxBlocks * 4;
     hipLaunchKernelGGL(k_ba_cost, dim3(gridM_), dim3(kBlock), 0, s, g_, Rkn_, tkn_, Xn_, parn_, part3);
@@ -1705,7 +2063,16 @@ class BaSolver final : public LmProblem {
     copy_out(ctx_, cam_t, t_, 3 * (size_t)N_, prob->mem);
     copy_out(ctx_, pt_xyz, X_, 3 * (size_t)P_, prob->mem);
     copy_out(ctx_, intr, par_, 8 * (size_t)K_, prob->mem);
+    std::vector<double> h_q(4 * (size_t)S_), h_t(3 * (size_t)S_);
+    if (sens_) {
+      GSFM_HIP_CHECK(hipMemcpyAsync(h_q.data(), q_ + 4 * (size_t)N_, h_q.size() * sizeof(double), hipMemcpyDeviceToHost, ctx_->stream));
+      GSFM_HIP_CHECK(hipMemcpyAsync(h_t.data(), t_ + 3 * (size_t)N_, h_t.size() * sizeof(double), hipMemcpyDeviceToHost, ctx_->stream));
+    }
     GSFM_HIP_CHECK(hipStreamSynchronize(ctx_->stream));
+    for (int k = 0; k < S_; ++k) {  // the optimised cam_from_rig blocks, in place (host table)
+      for (int j = 0; j < 4; ++j) prob->sensor_cam_from_rig[7 * (size_t)k + j] = h_q[4 * (size_t)k + j];
+      for (int j = 0; j < 3; ++j) prob->sensor_cam_from_rig[7 * (size_t)k + 4 + j] = h_t[3 * (size_t)k + j];
+    }
   }
 
  private:
@@ -1730,8 +2097,8 @@ class BaSolver final : public LmProblem {
       CgVec vk = cg_;
       const double* dk = ws->dvec.get();
       if (rig_) {
-        hipLaunchKernelGGL(k_ba_rig_expand, dim3(grid_for((size_t)NI_ + K_, kBlock)), dim3(kBlock), 0, s, NI_, N_, K_,
-                           ws->img_frame.get(), ws->sens.get(), cg_.z, ws->zimg.get());
+        hipLaunchKernelGGL(k_ba_rig_expand, dim3(grid_for((size_t)NI_ + K_, kBlock)), dim3(kBlock), 0, s, rg_, Np_, K_, cg_.z,
+                           ws->zimg.get());
         vk.z = ws->zimg.get();
         vk.w = ws->wimg.get();
         dk = ws->dvec_i.get();
@@ -1760,8 +2127,8 @@ class BaSolver final : public LmProblem {
         hipLaunchKernelGGL(k_ba_phaseI, dim3(gridK_), dim3(kBlock), 0, s, g_, vk, yscale, ws->yi_part.get(), dk, gridCam_);
       }
       if (rig_)
-        hipLaunchKernelGGL(k_ba_rig_reduce_w, dim3(1), dim3(kBlock), 0, s, cg_, NI_, yscale, ws->foff.get(), ws->fimg.get(),
-                           ws->sens.get(), ws->wimg.get(), ws->dvec.get(), gridCam_ + gridK_ + gridMulti_);
+        hipLaunchKernelGGL(k_ba_rig_reduce_w, dim3(1), dim3(kBlock), 0, s, cg_, rg_, yscale, ws->wimg.get(), ws->dvec.get(),
+                           gridCam_ + gridK_ + gridMulti_);
     });
   }
 
@@ -1772,7 +2139,9 @@ class BaSolver final : public LmProblem {
   CgVec cg_{};
   int N_ = 0, K_ = 0, n_ = 0, F_ = 0, max_group_ = 0;
   int NI_ = 0, ni_ = 0, gridNI_ = 1;  // cameras of the observation graph (= N_, or the images of calibrated rigs)
-  bool rig_ = false;
+  int S_ = 0, Np_ = 0, gridNp_ = 1;   // optimised cam_from_rig blocks; pose blocks = frames + sensor blocks
+  bool rig_ = false, sens_ = false;
+  RigDev rg_{};
   double *Rk_ = nullptr, *Rkn_ = nullptr, *tk_ = nullptr, *tkn_ = nullptr;  // poses the sweeps see (frames or images)
   bool small_groups_ = false, joint_ = false;
   long P_ = 0, M_ = 0, Mp_ = 0, m_used_ = 0;
@@ -1819,6 +2188,7 @@ extern "C" void gsfm_ba_options_default(gsfm_ba_options* o) {
   o->optimize_principal_point = 0;
   o->optimize_points = 1;
   o->min_num_view_per_track = 3;
+  o->optimize_rig_poses = 0;  // bundle_adjustment.h:15
 }
 
 extern "C" int gsfm_ba_solve(gsfm_ctx* ctx, const gsfm_ba_problem* prob, const gsfm_ba_options* opt,
@@ -1846,6 +2216,10 @@ extern "C" int gsfm_ba_solve(gsfm_ctx* ctx, const gsfm_ba_problem* prob, const g
       dump.array("image_frame", prob->image_frame, {I}, prob->mem);
       dump.array("image_cam_from_rig", prob->image_cam_from_rig, {I, 7}, prob->mem);
       dump.array("image_intr", prob->image_intr, {I}, prob->mem);
+      if (prob->num_sensors > 0 && prob->image_sensor && prob->sensor_cam_from_rig) {
+        dump.array("image_sensor", prob->image_sensor, {I}, prob->mem);
+        dump.array("sensor_cam_from_rig", prob->sensor_cam_from_rig, {(int64_t)prob->num_sensors, 7}, GSFM_MEM_HOST);
+      }
     }
     dump.array("intr_model", prob->intr_model, {K}, prob->mem);
     dump.array("cam_q", cam_q_inout, {N, 4}, prob->mem);
@@ -1860,6 +2234,7 @@ extern "C" int gsfm_ba_solve(gsfm_ctx* ctx, const gsfm_ba_problem* prob, const g
     GSFM_DUMP_OPT(dump, opt, optimize_principal_point);
     GSFM_DUMP_OPT(dump, opt, optimize_points);
     GSFM_DUMP_OPT(dump, opt, min_num_view_per_track);
+    GSFM_DUMP_OPT(dump, opt, optimize_rig_poses);
   }
   const int rc = guarded(ctx, report, [&] {
     return ba_solve_impl(ctx, prob, opt, cam_q_inout, cam_t_inout, pt_xyz_inout, intr_params_inout, report);
@@ -1870,6 +2245,8 @@ extern "C" int gsfm_ba_solve(gsfm_ctx* ctx, const gsfm_ba_problem* prob, const g
     dump.array("out_cam_t", cam_t_inout, {N, 3}, prob->mem);
     dump.array("out_pt_xyz", pt_xyz_inout, {P, 3}, prob->mem);
     dump.array("out_intr_params", intr_params_inout, {K, GSFM_CAMERA_MAX_PARAMS}, prob->mem);
+    if (prob->num_images > 0 && prob->num_sensors > 0 && prob->sensor_cam_from_rig)
+      dump.array("out_sensor_cam_from_rig", prob->sensor_cam_from_rig, {(int64_t)prob->num_sensors, 7}, GSFM_MEM_HOST);
     dump.write(report, rc);
   }
   return rc;

@@ -155,7 +155,7 @@ class BundleAdjusterOptions:
         _lib.load().gsfm_ba_options_default(C.byref(o))
         for name in (
             "optimize_rotations optimize_translation optimize_intrinsics optimize_principal_point "
-            "optimize_points min_num_view_per_track"
+            "optimize_points min_num_view_per_track optimize_rig_poses"
         ).split():
             setattr(o, name, int(getattr(self, name)))
         o.thres_loss_function = self.thres_loss_function
@@ -326,7 +326,8 @@ def gp_solve(p: GpProblem, options: Optional[GlobalPositionerOptions] = None, ct
 
 
 def ba_solve(p: BaProblem, options: Optional[BundleAdjusterOptions] = None, ctx=None):
-    """gsfm_ba_solve.  Returns (status, cam_q, cam_t, pt_xyz, intr_params, report dict)."""
+    """gsfm_ba_solve.  Returns (status, cam_q, cam_t, pt_xyz, intr_params, report dict); with sensor blocks
+    (p.sensor_cam_from_rig) the report carries their final values as report["sensor_cam_from_rig"] [S,7]."""
     ctx = ctx or default_context()
     opt = (options or BundleAdjusterOptions()).to_c()
     off, oc, oxy = _h(p.pt_offset, np.int64), _h(p.obs_cam, np.int32), _h(p.obs_xy, np.float64)
@@ -342,13 +343,22 @@ def ba_solve(p: BaProblem, options: Optional[BundleAdjusterOptions] = None, ctx=
         assert _mem_of(imf, imc, imi) == c.mem
         c.num_images = int(imf.shape[0])
         c.image_frame, c.image_cam_from_rig, c.image_intr = _lib.ptr(imf), _lib.ptr(imc), _lib.ptr(imi)
+    sens = None
+    if getattr(p, "sensor_cam_from_rig", None) is not None:
+        ims = _h(p.image_sensor, np.int32)
+        assert _mem_of(ims) == c.mem
+        sens = np.array(p.sensor_cam_from_rig, dtype=np.float64, order="C", copy=True)  # host, in/out
+        c.num_sensors, c.image_sensor, c.sensor_cam_from_rig = int(sens.shape[0]), _lib.ptr(ims), _lib.ptr(sens)
     outs = []
     for a in (p.cam_q, p.cam_t, p.pt_xyz, p.intr_params):
         a = _h(a, np.float64)
         outs.append(a.copy() if isinstance(a, np.ndarray) else a.clone())
     rep = _lib.Report()
     rc = ctx.lib.gsfm_ba_solve(ctx.handle, C.byref(c), C.byref(opt), *[_lib.ptr(a) for a in outs], C.byref(rep))
-    return (rc, *outs, rep.as_dict())
+    report = rep.as_dict()
+    if sens is not None:
+        report["sensor_cam_from_rig"] = sens
+    return (rc, *outs, report)
 
 
 # ============================================================================================

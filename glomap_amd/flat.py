@@ -102,6 +102,10 @@ class BaProblem:
     image_frame: Optional[np.ndarray] = None  # [I] int32
     image_cam_from_rig: Optional[np.ndarray] = None  # [I,7] f64 (qw,qx,qy,qz,tx,ty,tz), identity for reference sensors
     image_intr: Optional[np.ndarray] = None  # [I] int32
+    # Sensor blocks, ba.cc:161-179 RigReprojErrorCostFunctor: image i of a non-reference sensor takes its cam_from_rig from
+    # sensor_cam_from_rig[image_sensor[i]] (in/out), optimised when BundleAdjusterOptions.optimize_rig_poses, else constant
+    image_sensor: Optional[np.ndarray] = None  # [I] int32, -1 = reference sensor / constant entry of image_cam_from_rig
+    sensor_cam_from_rig: Optional[np.ndarray] = None  # [S,7] f64 in/out
 
     @property
     def num_obs(self) -> int:
@@ -110,6 +114,10 @@ class BaProblem:
     @property
     def num_images(self) -> int:
         return 0 if self.image_frame is None else int(self.image_frame.shape[0])
+
+    @property
+    def num_sensors(self) -> int:
+        return 0 if self.sensor_cam_from_rig is None else int(self.sensor_cam_from_rig.shape[0])
 
     def copy(self) -> "BaProblem":
         import copy

@@ -468,7 +468,14 @@ def make_rig_problems(
                    intr_model=np.full(K, CAMERA_SIMPLE_RADIAL, dtype=np.int32), intr_params=intr_gt.copy(), fixed_cam=0,
                    gt_q=so3.rotmat_to_quat(R_f), gt_t=t_f, gt_xyz=X, gt_intr=intr_gt, image_frame=image_frame,
                    image_cam_from_rig=np.ascontiguousarray(np.concatenate([q_s, t_s], axis=1)), image_intr=image_intr)
-    info = dict(R_cw=R_cw, t_cw=t_cw, R_s=R_s, t_s=t_s, image_sensor=image_sensor, rig_of_frame=rig_of_frame)
+    # sensor blocks (ba.cc:161-179): one per (rig, non-reference sensor); -1 for the images of reference sensors
+    blk = np.where(image_sensor > 0, rig_of_frame[image_frame] * (S - 1) + image_sensor - 1, -1).astype(np.int32)
+    sens_gt = np.zeros((num_rigs * (S - 1), 7))
+    for r in range(num_rigs):
+        for s_ in range(1, S):
+            sens_gt[r * (S - 1) + s_ - 1] = np.concatenate([so3.rotmat_to_quat(Rs[r, s_][None])[0], ts[r, s_]])
+    info = dict(R_cw=R_cw, t_cw=t_cw, R_s=R_s, t_s=t_s, image_sensor=image_sensor, rig_of_frame=rig_of_frame,
+                sensor_block=blk, sensor_cam_from_rig=sens_gt)
     return gp, ba, info
 
 

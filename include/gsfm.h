@@ -302,6 +302,7 @@ typedef struct gsfm_ba_options {
   int32_t optimize_principal_point;  /* 0 */
   int32_t optimize_points;           /* 1 */
   int32_t min_num_view_per_track;    /* 3 */
+  int32_t optimize_rig_poses;        /* 0: bundle_adjustment.h:15; needs the sensor tables of gsfm_ba_problem */
 } gsfm_ba_options;
 
 void gsfm_ba_options_default(gsfm_ba_options* opt);
@@ -323,11 +324,19 @@ typedef struct gsfm_ba_problem {
    * num_images = 0: trivial rigs.  num_images = I > 0: obs_cam indexes IMAGES, cam_q / cam_t are the FRAMES'
    * rig_from_world, cam_intr is ignored and every image carries
    *   image_frame[i], image_cam_from_rig[i] = (qw,qx,qy,qz,tx,ty,tz) — identity for reference sensors —, image_intr[i].
-   * optimize_rig_poses = true (RigReprojErrorCostFunctor, bundle_adjustment.cc:161-179) is not implemented. */
+   * Sensor blocks — colmap::RigReprojErrorCostFunctor as added at bundle_adjustment.cc:161-179 (optimize_rig_poses):
+   * with num_sensors = S > 0, image i of a non-reference sensor (image_sensor[i] >= 0; -1 = HasTrivialFrame or a
+   * constant entry) takes its cam_from_rig from sensor_cam_from_rig[image_sensor[i]] instead of image_cam_from_rig[i].
+   * The S blocks are parameter blocks (quaternion manifold + translation, never constant: ba.cc:296-309) when
+   * gsfm_ba_options.optimize_rig_poses is set and are then UPDATED IN PLACE like the other in/out arrays; otherwise they
+   * are read as constants.  Always host memory (S is the number of sensors of the rigs, a handful). */
   int32_t num_images;
   const int32_t* image_frame;        /* [I] */
   const double* image_cam_from_rig;  /* [I][7] */
   const int32_t* image_intr;         /* [I] */
+  int32_t num_sensors;
+  const int32_t* image_sensor;       /* [I] */
+  double* sensor_cam_from_rig;       /* [S][7] host, in/out */
 } gsfm_ba_problem;
 
 /* cam_q_inout [N][4] (w,x,y,z), cam_t_inout [N][3], pt_xyz_inout [P][3],

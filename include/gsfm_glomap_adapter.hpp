@@ -12,9 +12,9 @@
 // Ceres pointers into its containers (bundle_adjustment.cc:143-146, global_positioning.cc:326-328):
 // flatten the unordered_map containers into the SoA problems of include/gsfm.h, call the C ABI, write
 // the results back in place.  Scope = what `glomap mapper` exercises: trivial rigs and rigs whose
-// cam_from_rig is KNOWN (calibrated multi-camera rigs), 3-DoF rotation averaging, ONLY_POINTS positioning;
-// anything else (unknown cam_from_rig, optimize_rig_poses, the 1-DoF gravity branch) returns false after
-// logging, mirroring the reference's own early returns (gra.cc:47-58, gm.cc:145-149).
+// cam_from_rig is KNOWN (calibrated multi-camera rigs; BundleAdjuster also refines them with optimize_rig_poses),
+// 3-DoF rotation averaging, ONLY_POINTS positioning; anything else (unknown cam_from_rig, the 1-DoF gravity branch)
+// returns false after logging, mirroring the reference's own early returns (gra.cc:47-58, gm.cc:145-149).
 //
 // NOTE: this header cannot be compiled in the libgsfm repository itself (GLOMAP / COLMAP / Eigen are
 // not vendored); tests/adapter/ compiles it against interface-shaped stand-ins of those headers.
@@ -25,6 +25,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <map>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -534,7 +535,12 @@ class BundleAdjuster {
     if (ctx == nullptr) return false;
     if (images.empty() || tracks.empty()) return false;  // ba.cc:17-24
     const bool rigged = !detail::AllTrivial(images);  // RigReprojErrorConstantRigCostFunctor, ba.cc:147-160
-    if (rigged && options_.optimize_rig_poses) return false;  // RigReprojErrorCostFunctor (ba.cc:161-179): not implemented
+    // optimize_rig_poses: RigReprojErrorCostFunctor (ba.cc:161-179) — one sensor block per (rig, non-reference camera)
+    const bool opt_rig = rigged && options_.optimize_rig_poses;
+    std::map<std::pair<rig_t, camera_t>, int> sensor_of;
+    std::vector<std::pair<rig_t, camera_t>> sensor_ids;
+    std::vector<int32_t> image_sensor;
+    std::vector<double> sensor_cfr;
     detail::FrameIndex fidx;
     for (auto& [fid, fr] : frames)
       if (fr.HasPose()) fidx.Add(fid);  // dense indices in map order, the order ParameterizeVariables walks (ba.cc:253)
@@ -594,6 +600,18 @@ class BundleAdjuster {
         image_frame.push_back(tp.obs_cam[k]);
         image_intr.push_back(intr_index(im.camera_id));
         image_cfr.insert(image_cfr.end(), cfr, cfr + 7);
+        int sb = -1;
+        if (opt_rig && !im.HasTrivialFrame()) {
+          const std::pair<rig_t, camera_t> key(im.frame_ptr->RigId(), im.camera_id);
+          auto st = sensor_of.find(key);
+          if (st == sensor_of.end()) {
+            st = sensor_of.emplace(key, static_cast<int>(sensor_ids.size())).first;
+            sensor_ids.push_back(key);
+            sensor_cfr.insert(sensor_cfr.end(), cfr, cfr + 7);
+          }
+          sb = st->second;
+        }
+        image_sensor.push_back(sb);
       }
       tp.obs_cam[k] = it->second;
     }
@@ -620,6 +638,7 @@ class BundleAdjuster {
     o.optimize_principal_point = options_.optimize_principal_point;
     o.optimize_points = options_.optimize_points;
     o.min_num_view_per_track = 1;  // the raw-count rule was applied by PackTracks
+    o.optimize_rig_poses = opt_rig ? 1 : 0;
     gsfm_ba_problem pr{};
     pr.mem = GSFM_MEM_HOST;
     pr.num_cams = N;
@@ -637,9 +656,20 @@ class BundleAdjuster {
       pr.image_frame = image_frame.data();
       pr.image_cam_from_rig = image_cfr.data();
       pr.image_intr = image_intr.data();
+      if (opt_rig && !sensor_ids.empty()) {
+        pr.num_sensors = static_cast<int32_t>(sensor_ids.size());
+        pr.image_sensor = image_sensor.data();
+        pr.sensor_cam_from_rig = sensor_cfr.data();
+      }
     }
     gsfm_report rep;
     if (gsfm_ba_solve(ctx, &pr, &o, q.data(), t.data(), xyz.data(), intr.data(), &rep) != GSFM_OK) return false;
+    for (size_t k = 0; k < sensor_ids.size(); ++k) {  // the cam_from_rig blocks are the rigs' own storage (ba.cc:163-175)
+      auto& cfr = rigs.at(sensor_ids[k].first).SensorFromRig(glomap::sensor_t(glomap::SensorType::CAMERA, sensor_ids[k].second));
+      const double* v = &sensor_cfr[7 * k];
+      cfr.rotation = decltype(cfr.rotation)(v[0], v[1], v[2], v[3]);
+      cfr.translation = decltype(cfr.translation)(v[4], v[5], v[6]);
+    }
     for (int n = 0; n < N; ++n) {  // parameter blocks are the containers' own storage in the reference (ba.cc:143-146)
       auto& fr = frames.at(fidx.ids[n]);
       auto pose = fr.RigFromWorld();

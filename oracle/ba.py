@@ -40,6 +40,7 @@ class BundleAdjusterOptions:
     optimize_intrinsics: bool = True
     optimize_principal_point: bool = False
     optimize_points: bool = True
+    optimize_rig_poses: bool = False  # bundle_adjustment.h:15
     min_num_view_per_track: int = 3
     thres_loss_function: float = 1.0
     lm: lm.LmOptions = field(default_factory=lambda: lm.LmOptions(max_num_iterations=200))
@@ -167,13 +168,19 @@ def free_param_mask(model, opt: BundleAdjusterOptions):
 
 
 class _BaProblem:
-    def __init__(self, N, cam, pt, xy, cam_intr, model, fixed_cam, P, opt, obs_ik=None, Rs=None, ts=None):
+    def __init__(self, N, cam, pt, xy, cam_intr, model, fixed_cam, P, opt, obs_ik=None, Rs=None, ts=None, obs_sens=None,
+                 num_sensors=0):
+        # N counts ALL pose blocks: the frames and, behind them, the `num_sensors` optimised cam_from_rig blocks
         self.N, self.P, self.M = N, P, cam.shape[0]
         self.cam, self.pt, self.xy = cam, pt, xy
         self.cam_intr, self.model = cam_intr, model
         # known rigs: RigReprojErrorConstantRigCostFunctor (ba.cc:147-160): x_c = cam_from_rig * (rig_from_world * X)
         # with a CONSTANT cam_from_rig per observation (Rs, ts) and the image's own intrinsics block (obs_ik)
         self.obs_ik, self.Rs, self.ts = obs_ik, Rs, ts
+        # optimize_rig_poses: RigReprojErrorCostFunctor (ba.cc:161-179): the cam_from_rig of observation m is the pose
+        # block obs_sens[m] (an index into the pose blocks, -1 = the constant of the tables above)
+        self.obs_sens = obs_sens
+        self.has_sens = None if obs_sens is None else obs_sens >= 0
         self.K = model.shape[0]
         self.opt = opt
         self.loss = lm.HuberLoss(opt.thres_loss_function)
@@ -189,6 +196,9 @@ class _BaProblem:
         if fixed_cam >= 0:
             self.rot_free[fixed_cam] = False  # ba.cc:261-266
             self.trn_free[fixed_cam] = False
+        if num_sensors:  # ba.cc:296-309: the cam_from_rig blocks only get their manifold, never a constant flag
+            self.rot_free[N - num_sensors:] = True
+            self.trn_free[N - num_sensors:] = True
         self.elimination = [(self.pt_col0, P, 3)] if opt.optimize_points else []
 
     def unpack(self, x):
@@ -210,11 +220,19 @@ class _BaProblem:
         RX = np.einsum("mij,mj->mi", R[self.cam], X[self.pt])
         xc = RX + t[self.cam]
         ik = self.cam_intr[self.cam] if self.obs_ik is None else self.obs_ik
-        if self.Rs is not None:
-            xc = np.einsum("mij,mj->mi", self.Rs, xc) + self.ts
+        Rs, ts = self.Rs, self.ts
+        if self.obs_sens is not None:
+            h = self.has_sens
+            Rs, ts = Rs.copy(), ts.copy()
+            Rs[h], ts[h] = R[self.obs_sens[h]], t[self.obs_sens[h]]
+        self._Jcam = self._a_rig = None
+        if Rs is not None:
+            a_rig = np.einsum("mij,mj->mi", Rs, xc)  # R_s x_rig: what the sensor's rotation acts on
+            xc = a_rig + ts
         uv, Jx, Jp, valid = project(self.model[ik], intr[ik], xc)
-        if self.Rs is not None:
-            Jx = Jx @ self.Rs  # d(uv)/d(x_rig): everything downstream differentiates through the rig-frame point
+        if Rs is not None:
+            self._Jcam, self._a_rig = Jx, a_rig
+            Jx = Jx @ Rs  # d(uv)/d(x_rig): everything downstream differentiates through the rig-frame point
         r = np.where(valid[:, None], uv - self.xy, 0.0)
         return R, RX, ik, r, Jx, Jp, valid
 
@@ -250,6 +268,20 @@ class _BaProblem:
 
         add(Jrot, 6 * self.cam)
         add(Jtrn, 6 * self.cam + 3)
+        if self.obs_sens is not None and self.has_sens.any():
+            # x_c = Exp(2 d_rot) (R_s x_rig) + t_s + d_trn for the sensor block
+            h = self.has_sens
+            Jc = self._Jcam[h] * sw[h, None, None]
+            b = self._a_rig[h]
+            sk = np.zeros((b.shape[0], 3, 3))
+            sk[:, 0, 1], sk[:, 0, 2] = -b[:, 2], b[:, 1]
+            sk[:, 1, 0], sk[:, 1, 2] = b[:, 2], -b[:, 0]
+            sk[:, 2, 0], sk[:, 2, 1] = -b[:, 1], b[:, 0]
+            w_ = np.concatenate([-2.0 * (Jc @ sk), Jc], axis=2)  # [m,2,6]
+            rr = rows[h]
+            ri.append(np.repeat(rr[:, :, None], 6, axis=2).ravel())
+            ci.append(np.broadcast_to((6 * self.obs_sens[h][:, None] + np.arange(6))[:, None, :], (rr.shape[0], 2, 6)).ravel())
+            vi.append(w_.ravel())
         add(Jpt, self.pt_col0 + 3 * self.pt)
         cols = self.intr_col[ik]  # [M,8], -1 where constant
         for j in range(MAXP):
@@ -287,10 +319,13 @@ class _BaProblem:
 
 def solve(num_cams, pt_offset, obs_cam, obs_xy, cam_intr, intr_model, fixed_cam, cam_q, cam_t, pt_xyz,
           intr_params, options: BundleAdjusterOptions | None = None, image_frame=None, image_cam_from_rig=None,
-          image_intr=None):
+          image_intr=None, image_sensor=None, sensor_cam_from_rig=None):
     """Returns (ok, q [N,4], t [N,3], X [P,3], intr [K,8], LmSummary); arrays as glomap_amd.flat.BaProblem.
     Known rigs: with `image_frame` [I], `image_cam_from_rig` [I,7] (qw,qx,qy,qz,tx,ty,tz) and `image_intr` [I] given,
-    obs_cam indexes IMAGES; the pose blocks are the frames' rig_from_world."""
+    obs_cam indexes IMAGES; the pose blocks are the frames' rig_from_world.
+    With `image_sensor` [I] (-1 = reference sensor) and `sensor_cam_from_rig` [S,7] the cam_from_rig of image i is the
+    sensor's entry: constant unless options.optimize_rig_poses, else S more pose blocks (RigReprojErrorCostFunctor,
+    ba.cc:161-179) whose result is returned as summary.sensor_cam_from_rig."""
     opt = options or BundleAdjusterOptions()
     N = int(num_cams)
     pt_offset = np.asarray(pt_offset, dtype=np.int64)
@@ -302,9 +337,21 @@ def solve(num_cams, pt_offset, obs_cam, obs_xy, cam_intr, intr_model, fixed_cam,
     remap = -np.ones(P_all, dtype=np.int64)
     remap[used] = np.arange(int(used.sum()))
     cam = np.asarray(obs_cam, dtype=np.int64)[keep]
-    obs_ik = Rs = ts = None
+    obs_ik = Rs = ts = obs_sens = None
+    S = 0
+    q0 = np.array(cam_q, dtype=np.float64, copy=True)
+    t0 = np.array(cam_t, dtype=np.float64, copy=True)
     if image_frame is not None:
-        cfr = np.asarray(image_cam_from_rig, dtype=np.float64)
+        cfr = np.array(image_cam_from_rig, dtype=np.float64, copy=True)
+        if image_sensor is not None:
+            isen = np.asarray(image_sensor, dtype=np.int64)
+            scfr = np.asarray(sensor_cam_from_rig, dtype=np.float64)
+            cfr[isen >= 0] = scfr[isen[isen >= 0]]
+            if opt.optimize_rig_poses:
+                S = scfr.shape[0]
+                obs_sens = np.where(isen[cam] >= 0, N + isen[cam], -1)
+                q0 = np.concatenate([q0, scfr[:, :4]])
+                t0 = np.concatenate([t0, scfr[:, 4:7]])
         obs_ik = np.asarray(image_intr, dtype=np.int64)[cam]
         Rs = quat_to_rot(cfr[cam, :4])
         ts = cfr[cam, 4:7]
@@ -312,15 +359,16 @@ def solve(num_cams, pt_offset, obs_cam, obs_xy, cam_intr, intr_model, fixed_cam,
     pt = remap[obs_pt_all[keep]]
     xy = np.asarray(obs_xy, dtype=np.float64)[keep]
     X_all = np.array(pt_xyz, dtype=np.float64, copy=True)
-    q0 = np.array(cam_q, dtype=np.float64, copy=True)
-    t0 = np.array(cam_t, dtype=np.float64, copy=True)
     intr0 = np.array(intr_params, dtype=np.float64, copy=True)
     if cam.shape[0] == 0:
-        return False, q0, t0, X_all, intr0, lm.LmSummary(usable=False)
-    prob = _BaProblem(N, cam, pt, xy, None if cam_intr is None else np.asarray(cam_intr, dtype=np.int64),
-                      np.asarray(intr_model, dtype=np.int64), int(fixed_cam), int(used.sum()), opt, obs_ik, Rs, ts)
+        return False, q0[:N], t0[:N], X_all, intr0, lm.LmSummary(usable=False)
+    prob = _BaProblem(N + S, cam, pt, xy, None if cam_intr is None else np.asarray(cam_intr, dtype=np.int64),
+                      np.asarray(intr_model, dtype=np.int64), int(fixed_cam), int(used.sum()), opt, obs_ik, Rs, ts,
+                      obs_sens, S)
     x0 = prob.pack(q0, t0, X_all[used], intr0)
     x, summ = lm.solve(prob, x0, opt.lm)
     q, t, X, intr = prob.unpack(x)
     X_all[used] = X
-    return summ.usable, q.copy(), t.copy(), X_all, intr.copy(), summ
+    if S:
+        summ.sensor_cam_from_rig = np.concatenate([q[N:], t[N:]], axis=1)
+    return summ.usable, q[:N].copy(), t[:N].copy(), X_all, intr.copy(), summ

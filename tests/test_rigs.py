@@ -4,8 +4,10 @@
   GP: RigBATAPairwiseDirectionError with the rig scale constant (cost_function.h:49-82, global_positioning.cc:318-350, 470-478)
   BA: colmap::RigReprojErrorConstantRigCostFunctor (bundle_adjustment.cc:147-160, optimize_rig_poses = false)
 
+  BA: colmap::RigReprojErrorCostFunctor (bundle_adjustment.cc:161-179, optimize_rig_poses = true): cam_from_rig blocks
+
 CPU: the two oracles against each other and against ground truth.  GPU: the HIP path (sweeps over images, LM / PCG state
-per frame) through the C ABI against the oracles."""
+per frame and per sensor block) through the C ABI against the oracles."""
 import numpy as np
 import pytest
 
@@ -59,6 +61,94 @@ def test_identity_rigs_reduce_to_the_trivial_problem():
     b = oba.solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_xy, None, p.intr_model, p.fixed_cam, p.cam_q, p.cam_t, p.pt_xyz,
                   p.intr_params, image_frame=np.arange(12), image_cam_from_rig=ident, image_intr=p.cam_intr)
     assert a[5].iterations == b[5].iterations and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def _miscalibrated(info, seed, rot_deg=1.0, trans=0.05):
+    """Sensor blocks of make_rig_problems perturbed: the start values of optimize_rig_poses."""
+    rng = np.random.default_rng(seed)
+    sg = info["sensor_cam_from_rig"]
+    s0 = sg.copy()
+    dq = so3.rotmat_to_quat(so3.aa_to_rotmat(rng.normal(0, np.radians(rot_deg), (sg.shape[0], 3))))
+    s0[:, :4] = oba.quat_mul(dq, sg[:, :4])
+    s0[:, 4:] += rng.normal(0, trans, (sg.shape[0], 3))
+    return s0
+
+
+def _with_sensors(ba, info, s0):
+    p = ba.copy()
+    p.image_sensor = info["sensor_block"].copy()
+    p.sensor_cam_from_rig = s0.copy()
+    return p
+
+
+def _sens_kw(p):
+    return dict(_ba_kw(p), image_sensor=p.image_sensor, sensor_cam_from_rig=p.sensor_cam_from_rig)
+
+
+def test_oracle_refines_miscalibrated_rigs():
+    """optimize_rig_poses in the oracle: from cam_from_rig blocks that are 1 degree / 5 cm off the noise-free problem goes
+    to zero reprojection error and the (observable) cam_from_rig rotations come back; with the option off the same tables
+    are constants and the error stays."""
+    _, ba, info = synthetic.make_rig_problems(14, 3, 500, seed=0)
+    p = _with_sensors(ba, info, _miscalibrated(info, 1))
+    r = oba.solve(*_ba_args(p), **_sens_kw(p))
+    assert r[0] and r[5].final_cost > 0.1 * r[5].initial_cost and not hasattr(r[5], "sensor_cam_from_rig")
+    r = oba.solve(*_ba_args(p), options=oba.BundleAdjusterOptions(optimize_rig_poses=True), **_sens_kw(p))
+    assert r[0] and r[5].final_cost < 1e-9 * r[5].initial_cost
+    sc, sg = r[5].sensor_cam_from_rig, info["sensor_cam_from_rig"]
+    assert so3.rotation_angle_deg(so3.quat_to_rotmat(sc[:, :4]), so3.quat_to_rotmat(sg[:, :4])).max() < 1e-4
+    # the constant frame stays (ba.cc:261-266)
+    assert np.array_equal(r[1][p.fixed_cam], p.cam_q[p.fixed_cam]) and np.array_equal(r[2][p.fixed_cam], p.cam_t[p.fixed_cam])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frames,cams,pts,noise,rot", [(14, 2, 400, 0.0, True), (30, 3, 3000, 0.5, True), (16, 3, 800, 0.3, False)])
+def test_ba_with_optimised_rig_poses_matches_oracle(gsfm_ctx, frames, cams, pts, noise, rot):
+    """RigReprojErrorCostFunctor through the C ABI: frames, cam_from_rig blocks, points and intrinsics against the numpy
+    oracle's exact-solve LM.  rot=False: optimize_rotations off — the frame rotations stay bit for bit, the cam_from_rig
+    rotations are still optimised (ba.cc:296-309 sets their manifold only)."""
+    from glomap_amd import estimators
+
+    _, ba, info = synthetic.make_rig_problems(frames, cams, pts, seed=11, pixel_noise=noise)
+    p = _with_sensors(ba, info, _miscalibrated(info, 12, rot_deg=0.5, trans=0.03))
+    opt = estimators.BundleAdjusterOptions(optimize_rig_poses=True, optimize_rotations=rot)
+    opt.solver_options.pcg_relative_tolerance = 1e-10
+    rc, q, t, X, intr, rep = estimators.ba_solve(p, opt, ctx=gsfm_ctx)
+    assert rc == 0
+    r = oba.solve(*_ba_args(p), options=oba.BundleAdjusterOptions(optimize_rig_poses=True, optimize_rotations=rot), **_sens_kw(p))
+    assert r[0]
+    assert abs(rep["initial_cost"] - r[5].initial_cost) <= 1e-10 * r[5].initial_cost
+    assert abs(rep["iterations"] - r[5].iterations) <= (1 if rot else 3)
+    if noise == 0.0:
+        assert rep["final_cost"] < 1e-9 * rep["initial_cost"]
+    else:
+        assert abs(rep["final_cost"] - r[5].final_cost) <= 1e-6 * r[5].final_cost
+    sc, so = rep["sensor_cam_from_rig"], r[5].sensor_cam_from_rig
+    assert np.radians(so3.rotation_angle_deg(so3.quat_to_rotmat(sc[:, :4]), so3.quat_to_rotmat(so[:, :4]))).max() < 1e-5
+    if rot:
+        ang = np.radians(so3.rotation_angle_deg(so3.quat_to_rotmat(q), so3.quat_to_rotmat(r[1])))
+        assert ang.max() < 1e-5
+    else:
+        assert np.array_equal(q, p.cam_q)
+    if noise > 0.0:  # (noise-free: the free scale of the minimum makes translations path dependent)
+        assert np.abs(t - r[2]).max() < 1e-3 * 50.0 and np.abs(sc[:, 4:] - so[:, 4:]).max() < 1e-3
+    assert np.array_equal(q[p.fixed_cam], p.cam_q[p.fixed_cam]) and np.array_equal(t[p.fixed_cam], p.cam_t[p.fixed_cam])
+
+
+@pytest.mark.gpu
+def test_sensor_tables_are_constants_without_the_option(gsfm_ctx):
+    """optimize_rig_poses off: a sensor table is only another way to write image_cam_from_rig — same solve, table untouched."""
+    from glomap_amd import estimators
+
+    _, ba, info = synthetic.make_rig_problems(14, 2, 400, seed=3, pixel_noise=0.5)
+    a = estimators.ba_solve(ba, ctx=gsfm_ctx)
+    p = _with_sensors(ba, info, info["sensor_cam_from_rig"])
+    p.image_cam_from_rig = p.image_cam_from_rig.copy()
+    p.image_cam_from_rig[p.image_sensor >= 0] = np.array([1.0, 0, 0, 0, 0, 0, 0])  # superseded by the table
+    b = estimators.ba_solve(p, ctx=gsfm_ctx)
+    assert a[0] == 0 and b[0] == 0 and a[5]["iterations"] == b[5]["iterations"]
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[4], b[4])
+    assert np.array_equal(b[5]["sensor_cam_from_rig"], info["sensor_cam_from_rig"])
 
 
 @pytest.mark.gpu
