@@ -66,6 +66,11 @@ class GpProblem:
     # num_cams / cam_center are the FRAMES (rigs in time) and image_offset = R_cam_from_world^T t_cam_from_rig
     image_frame: Optional[np.ndarray] = None  # [I] int32
     image_offset: Optional[np.ndarray] = None  # [I,3] f64
+    # Unknown cam_from_rig, gp.cc:354-368 RigUnknownBATAPairwiseDirectionError: image i of such a sensor has
+    # image_sensor[i] >= 0 (its centre block), image_offset[i] = 0 and image_sensor_rot[i] = R_rig_from_world of its frame
+    image_sensor: Optional[np.ndarray] = None  # [I] int32, -1 = no block
+    image_sensor_rot: Optional[np.ndarray] = None  # [I,3,3] f64
+    sensor_center: Optional[np.ndarray] = None  # [S,3] f64 in/out: camera centre in rig coordinates, -R_cfr^T t_cfr
 
     @property
     def num_obs(self) -> int:

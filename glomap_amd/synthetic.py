@@ -479,6 +479,24 @@ def make_rig_problems(
     return gp, ba, info
 
 
+def forget_rig_translations(gp: GpProblem, info) -> GpProblem:
+    """The GP problem of make_rig_problems with the cam_from_rig TRANSLATIONS of all non-reference sensors unknown
+    (global_positioning.cc:354-368): their images lose the offset and point at a centre block instead; the rotations
+    (folded into obs_dir) stay known, as they are after rotation averaging."""
+    import copy
+
+    p = copy.deepcopy(gp)
+    blk = info["sensor_block"]
+    p.image_sensor = blk.copy()
+    p.image_offset = np.where((blk >= 0)[:, None], 0.0, gp.image_offset)
+    p.image_sensor_rot = np.ascontiguousarray(gp.cam_R[gp.image_frame])
+    sg = info["sensor_cam_from_rig"]
+    Rq = so3.quat_to_rotmat(sg[:, :4])
+    p.sensor_center = np.zeros((sg.shape[0], 3))
+    info["sensor_center"] = -np.einsum("sji,sj->si", Rq, sg[:, 4:])  # ground truth: -R^T t
+    return p
+
+
 # --------------------------------------------------------------------------------------------
 # Gauge-free comparisons (reference: rotation_averager_test.cc:85-106, global_mapper_test.cc:26-38)
 # --------------------------------------------------------------------------------------------

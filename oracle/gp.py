@@ -54,9 +54,15 @@ def mt19937_uniform(seed: int, count: int, low: float, high: float) -> np.ndarra
 
 
 class _GpProblem:
-    def __init__(self, N, cam, pt, v, calibrated, opt: GlobalPositionerOptions, npts, off=None):
+    def __init__(self, N, cam, pt, v, calibrated, opt: GlobalPositionerOptions, npts, off=None, sens=None, Rf=None):
+        # N counts ALL 3-vector blocks: the frames and, behind them, the cam_from_rig centres that are estimated
         self.N, self.P, self.M = N, npts, cam.shape[0]
         self.cam, self.pt, self.v = cam, pt, v
+        # RigUnknownBATAPairwiseDirectionError (cost_function.h:90-136, gp.cc:354-368): r = v - s (X - c_rig - R_rig^T c_s)
+        # with c_s, the camera centre in rig coordinates, a block shared by all images of the sensor (block index sens[m]
+        # or -1; Rf[m] = R_rig_from_world of the observation's frame)
+        self.sens, self.Rf = sens, Rf
+        self.has = None if sens is None else sens >= 0
         # RigBATAPairwiseDirectionError (cost_function.h:49-82) with the rig scale constant at 1 (gp.cc:470-478):
         # r = v - s (X - c_rig + t_rig), t_rig = R_cw^T t_cam_from_rig — a constant per-observation offset
         self.off = np.zeros((self.M, 3)) if off is None else off
@@ -74,6 +80,9 @@ class _GpProblem:
     def _res(self, x):
         c, X, s = self._split(x)
         d = X[self.pt] - c[self.cam] + self.off
+        if self.sens is not None:
+            h = self.has
+            d[h] -= np.einsum("mji,mj->mi", self.Rf[h], c[self.sens[h]])
         r = self.v - s[:, None] * d
         sq = (r * r).sum(1)
         rho0c, rho1c = self.loss_cal.evaluate(sq)
@@ -97,6 +106,12 @@ class _GpProblem:
             ri.append(rows.ravel())
             ci.append((3 * self.cam[:, None] + comp).ravel())
             vi.append(np.repeat(sw * s, 3))
+            if self.sens is not None and self.has.any():  # d r / d c_s = +s R_rig^T
+                h = self.has
+                blk = (sw[h] * s[h])[:, None, None] * np.transpose(self.Rf[h], (0, 2, 1))
+                ri.append(np.repeat(rows[h][:, :, None], 3, axis=2).ravel())
+                ci.append(np.broadcast_to((3 * self.sens[h][:, None] + comp)[:, None, :], (blk.shape[0], 3, 3)).ravel())
+                vi.append(blk.ravel())
         if o.optimize_points:  # d r / d X = -s I
             ri.append(rows.ravel())
             ci.append((3 * N + 3 * self.pt[:, None] + comp).ravel())
@@ -128,10 +143,14 @@ class _GpProblem:
 
 
 def solve(num_cams, pt_offset, obs_cam, obs_dir, obs_calibrated, cam_center, pt_xyz,
-          options: GlobalPositionerOptions | None = None, image_frame=None, image_offset=None):
+          options: GlobalPositionerOptions | None = None, image_frame=None, image_offset=None, image_sensor=None,
+          image_sensor_rot=None, sensor_center=None):
     """Returns (ok, cam_center [N,3], pt_xyz [P,3], LmSummary).  Arrays follow glomap_amd.flat.GpProblem.
     Known rigs (gp.cc:318-350): with `image_frame` [I] / `image_offset` [I,3] given, obs_cam indexes IMAGES, the
-    unknown centre is the one of the image's frame (rig) and image_offset = R_cam_from_world^T t_cam_from_rig."""
+    unknown centre is the one of the image's frame (rig) and image_offset = R_cam_from_world^T t_cam_from_rig.
+    Unknown cam_from_rig (gp.cc:354-368): `image_sensor` [I] names the centre block of the image's sensor (-1: none),
+    `image_sensor_rot` [I,3,3] is R_rig_from_world of its frame, `sensor_center` [S,3] the start values (re-drawn in
+    [-1,1]^3 when optimize_positions, gp.cc:442-456); the result is summary.sensor_center."""
     opt = options or GlobalPositionerOptions()
     N = int(num_cams)
     pt_offset = np.asarray(pt_offset, dtype=np.int64)
@@ -143,9 +162,15 @@ def solve(num_cams, pt_offset, obs_cam, obs_dir, obs_calibrated, cam_center, pt_
     remap = -np.ones(P_all, dtype=np.int64)
     remap[used] = np.arange(int(used.sum()))
     cam = np.asarray(obs_cam, dtype=np.int64)[keep]
-    off = None
+    off = sens = Rf = None
+    S = 0
     if image_frame is not None:
         off = np.asarray(image_offset, dtype=np.float64)[cam]
+        if image_sensor is not None:
+            S = np.asarray(sensor_center).shape[0]
+            isen = np.asarray(image_sensor, dtype=np.int64)[cam]
+            sens = np.where(isen >= 0, N + isen, -1)
+            Rf = np.asarray(image_sensor_rot, dtype=np.float64).reshape(-1, 3, 3)[cam]
         cam = np.asarray(image_frame, dtype=np.int64)[cam]
     pt = remap[obs_pt_all[keep]]
     v = np.asarray(obs_dir, dtype=np.float64)[keep]
@@ -164,6 +189,8 @@ def solve(num_cams, pt_offset, obs_cam, obs_dir, obs_calibrated, cam_center, pt_
         n_draw += 3 * int(constrained.sum())
     if opt.generate_random_points and opt.optimize_points:
         n_draw += 3 * P
+    if S and opt.optimize_positions:
+        n_draw += 3 * S
     u = mt19937_uniform(opt.seed, n_draw, -1.0, 1.0)
     k = 0
     if opt.generate_random_positions and opt.optimize_positions:
@@ -173,15 +200,25 @@ def solve(num_cams, pt_offset, obs_cam, obs_dir, obs_calibrated, cam_center, pt_
     X = X_all[used].copy()
     if opt.generate_random_points and opt.optimize_points:
         X = 100.0 * u[k : k + 3 * P].reshape(P, 3)
+        k += 3 * P
+    if S:
+        cs = np.array(sensor_center, dtype=np.float64, copy=True).reshape(S, 3)
+        if opt.optimize_positions:  # ParameterizeVariables, gp.cc:442-456: RandVector3d(-1, 1), after every other draw
+            cs = u[k : k + 3 * S].reshape(S, 3).copy()
+        c = np.concatenate([c, cs])
     s = np.ones(M)
     if not opt.generate_scales:
         # gp.cc:300-305 (only for already-initialised tracks; the flat API treats all as initialised)
         d = X[pt] - c[cam] + (0.0 if off is None else off)
+        if S:
+            d[sens >= 0] -= np.einsum("mji,mj->mi", Rf[sens >= 0], c[sens[sens >= 0]])
         s = np.maximum(1e-5, (v * d).sum(1) / (d * d).sum(1))
 
-    prob = _GpProblem(N, cam, pt, v, cal, opt, P, off)
+    prob = _GpProblem(N + S, cam, pt, v, cal, opt, P, off, sens, Rf)
     x0 = np.concatenate([c.ravel(), X.ravel(), s])
     x, summ = lm.solve(prob, x0, opt.lm)
     c_out, X_out, _ = prob._split(x)
     X_all[used] = X_out
-    return summ.usable, c_out.copy(), X_all, summ
+    if S:
+        summ.sensor_center = c_out[N:].copy()
+    return summ.usable, c_out[:N].copy(), X_all, summ
