@@ -138,6 +138,10 @@ class GpProblemC(C.Structure):
         ("num_images", C.c_int32),
         ("image_frame", C.c_void_p),
         ("image_offset", C.c_void_p),
+        ("num_sensors", C.c_int32),
+        ("image_sensor", C.c_void_p),
+        ("image_sensor_rot", C.c_void_p),
+        ("sensor_center", C.c_void_p),
     ]
 
 

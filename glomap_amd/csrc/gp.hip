@@ -598,19 +598,88 @@ __global__ void __launch_bounds__(kBlock)
 // and the PCG vectors live per FRAME.  Two small kernels translate: frame -> image (gather: state, z, dc) and image ->
 // frame (fixed-order sum over the frame's images: gradient, diagonal, Schur blocks, w).  Since z_image = z_frame, the
 // delta = z.w partials of the image-space sweep are already the frame-space ones.
+//
+// Unknown cam_from_rig — RigUnknownBATAPairwiseDirectionError (cost_function.h:90-136, global_positioning.cc:354-368):
+// r = v - s (X - c_frame - R_rig^T c_s) with c_s, the camera centre in rig coordinates, one 3-vector block per sensor,
+// stored as block N + s behind the N frames.  c_image = c_frame + R_rig^T c_s is still linear in the unknowns, so the
+// same two translations apply with one more term: z_image = z_frame + R_rig^T z_sensor and
+// w_sensor = sum over the sensor's images of R_rig w_image (one workgroup per sensor, fixed order).
+struct GpRig {
+  int NI, N, S;               // images, frames, sensor centre blocks
+  const int* img_frame;       // [NI]
+  const int* img_sensor;      // [NI] block or -1; null when S == 0
+  const double* img_rot;      // [NI][9] R_rig_from_world of the image's frame, row-major (S > 0)
+  const int* foff;            // frame -> images
+  const int* fimg;
+  const int* soff;            // sensor block -> images
+  const int* simg;
+};
+
 __global__ void __launch_bounds__(kBlock)
-    k_rig_expand3(int NI, const int* __restrict__ img_frame, const double* __restrict__ src_frame,
+    k_rig_expand3(GpRig rg, const double* __restrict__ src /* [N + S][3] */,
                   const double* __restrict__ img_off /* null: plain gather */, double* __restrict__ dst_img,
                   double* __restrict__ cz /* null, or the (c | z) gather records */, int cz_slot) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < NI; i += gridDim.x * blockDim.x) {
-    const long f = img_frame[i];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rg.NI; i += gridDim.x * blockDim.x) {
+    const long f = rg.img_frame[i];
+    double v[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      double v = src_frame[3 * f + j];
-      if (img_off) v -= img_off[3 * (long)i + j];
-      dst_img[3 * (long)i + j] = v;
-      if (cz) cz[6 * (long)i + cz_slot + j] = v;
+      v[j] = src[3 * f + j];
+      if (img_off) v[j] -= img_off[3 * (long)i + j];
     }
+    const int sb = rg.img_sensor ? rg.img_sensor[i] : -1;
+    if (sb >= 0) {  // + R_rig^T c_s
+      const double* R = rg.img_rot + 9 * (long)i;
+      const double* cs = src + 3 * (long)(rg.N + sb);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) v[j] += R[j] * cs[0] + R[3 + j] * cs[1] + R[6 + j] * cs[2];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      dst_img[3 * (long)i + j] = v[j];
+      if (cz) cz[6 * (long)i + cz_slot + j] = v[j];
+    }
+  }
+}
+
+// sensor block s: W = 1: sum of the images' scalars; W = 3: sum R v; W = 6: sum R A R^T (A symmetric: xx xy xz yy yz zz)
+template <int W>
+__global__ void __launch_bounds__(kBlock)
+    k_rig_sensor_reduce(GpRig rg, const double* __restrict__ src_img, double* __restrict__ dst /* block N + s */) {
+  __shared__ double smem[4 * W];
+  for (int sb = blockIdx.x; sb < rg.S; sb += gridDim.x) {
+    double acc[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) acc[j] = 0.0;
+    for (int a = rg.soff[sb] + threadIdx.x; a < rg.soff[sb + 1]; a += blockDim.x) {
+      const int im = rg.simg[a];
+      const double* sp = src_img + (long)W * im;
+      const double* R = rg.img_rot + 9 * (long)im;
+      if constexpr (W == 1) {
+        acc[0] += sp[0];
+      } else if constexpr (W == 3) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] += R[3 * j] * sp[0] + R[3 * j + 1] * sp[1] + R[3 * j + 2] * sp[2];
+      } else {
+        const double A[3][3] = {{sp[0], sp[1], sp[2]}, {sp[1], sp[3], sp[4]}, {sp[2], sp[4], sp[5]}};
+        double M[3][3];  // R A
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) M[i][j] = R[3 * i] * A[0][j] + R[3 * i + 1] * A[1][j] + R[3 * i + 2] * A[2][j];
+        int o = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = i; j < 3; ++j) acc[o++] += M[i][0] * R[3 * j] + M[i][1] * R[3 * j + 1] + M[i][2] * R[3 * j + 2];
+      }
+    }
+    block_sum<W>(acc, smem);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int j = 0; j < W; ++j) dst[(long)W * (rg.N + sb) + j] = acc[j];
+    }
+    __syncthreads();
   }
 }
 
@@ -635,12 +704,35 @@ __global__ void __launch_bounds__(kBlock)
 // w_frame = sum over the frame's images of w_image + D_frame z_frame (the image-space sweep ran without the damping
 // term); the damping share of delta, sum_f z_f . D_f z_f, goes to its own partial slot.  One workgroup: N is small.
 __global__ void __launch_bounds__(kBlock)
-    k_rig_reduce_w(CgVec v, double yscale, const int* __restrict__ foff, const int* __restrict__ fimg,
-                   const double* __restrict__ w_img, const double* __restrict__ dcam, int dslot) {
-  __shared__ double smem[4];
+    k_rig_reduce_w(CgVec v, GpRig rg, double yscale, const double* __restrict__ w_img, const double* __restrict__ dcam,
+                   int dslot) {
+  __shared__ double smem[4 + 4 * 3];
   if (v.st->done) return;
+  const int* foff = rg.foff;
+  const int* fimg = rg.fimg;
   double d[1] = {0.0};
-  for (int f = threadIdx.x; f < v.N; f += blockDim.x) {
+  for (int sb = 0; sb < rg.S; ++sb) {  // w_sensor = sum R_rig w_image + D z
+    double acc[3] = {0, 0, 0};
+    for (int a = rg.soff[sb] + threadIdx.x; a < rg.soff[sb + 1]; a += blockDim.x) {
+      const int im = rg.simg[a];
+      const double* sp = w_img + 3 * (long)im;
+      const double* R = rg.img_rot + 9 * (long)im;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[j] += R[3 * j] * sp[0] + R[3 * j + 1] * sp[1] + R[3 * j + 2] * sp[2];
+    }
+    block_sum<3>(acc, smem + 4);
+    if (threadIdx.x == 0) {
+      const long o = 3 * (long)(rg.N + sb);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const double z = v.z[o + j];
+        const double dz = yscale * dcam[o + j] * z;
+        v.w[o + j] = acc[j] + dz;
+        d[0] += z * dz;
+      }
+    }
+  }
+  for (int f = threadIdx.x; f < rg.N; f += blockDim.x) {
     double acc[3] = {0, 0, 0};
     for (int a = foff[f]; a < foff[f + 1]; ++a) {
       const double* sp = w_img + 3 * (long)fimg[a];
@@ -673,8 +765,8 @@ struct GpWs {
   DevBuf<CgStatus> cgst;
   DevBuf<CgScal> cgsc;
   // calibrated rigs: image tables and the image-space twins of the per-camera arrays
-  DevBuf<int> img_frame, foff, fimg;
-  DevBuf<double> img_off, ci, cin, hcc_i, gc_i, gred_i, scc_i, zimg, wimg, ximg, zero_i, cz_f;
+  DevBuf<int> img_frame, foff, fimg, img_sensor, soff, simg;
+  DevBuf<double> img_off, ci, cin, hcc_i, gc_i, gred_i, scc_i, zimg, wimg, ximg, zero_i, cz_f, img_rot;
   static void destroy(void* p) { delete static_cast<GpWs*>(p); }
 };
 
@@ -701,12 +793,22 @@ class GpSolver final : public LmProblem {
     // calibrated rigs: the observation graph is over IMAGES (NI_ cameras), the unknowns are the N_ frames
     rig_ = prob->num_images > 0;
     NI_ = rig_ ? prob->num_images : N_;
-    std::vector<int> h_imf;
+    std::vector<int> h_imf, h_ims;
+    S_ = rig_ ? prob->num_sensors : 0;
     if (rig_) {
       GSFM_REQUIRE(prob->image_frame && prob->image_offset, "GP: image tables missing");
       to_host(ctx_, h_imf, prob->image_frame, (size_t)NI_, mem);
       for (int i = 0; i < NI_; ++i) GSFM_REQUIRE(h_imf[i] >= 0 && h_imf[i] < N_, "GP: image_frame out of range");
+      GSFM_REQUIRE(S_ >= 0, "GP: num_sensors negative");
+      if (S_ > 0) {
+        GSFM_REQUIRE(prob->image_sensor && prob->image_sensor_rot && prob->sensor_center, "GP: sensor tables missing");
+        if (!opt_.optimize_positions)
+          throw StatusError(GSFM_ERR_UNSUPPORTED, "GP: unknown cam_from_rig centres need optimize_positions");
+        to_host(ctx_, h_ims, prob->image_sensor, (size_t)NI_, mem);
+        for (int i = 0; i < NI_; ++i) GSFM_REQUIRE(h_ims[i] >= -1 && h_ims[i] < S_, "GP: image_sensor out of range");
+      }
     }
+    Np_ = N_ + S_;  // 3-vector blocks: frame centres, then the cam_from_rig centres to estimate
     std::vector<long> h_off;
     to_host(ctx_, h_off, reinterpret_cast<const long*>(prob->pt_offset), (size_t)P_ + 1, mem);
     GSFM_REQUIRE(h_off[0] == 0 && h_off[P_] == M_, "GP: pt_offset must start at 0 and end at num_obs");
@@ -739,6 +841,8 @@ class GpSolver final : public LmProblem {
     // state init (gp.cc:123-165, 261-264): cameras by index, then used tracks by index
     std::vector<double> h_c, h_X;
     to_host(ctx_, h_c, cam_center, 3 * (size_t)N_, mem);
+    h_c.resize(3 * (size_t)Np_);
+    for (int k = 0; k < 3 * S_; ++k) h_c[3 * (size_t)N_ + k] = prob->sensor_center[k];  // host table by contract
     to_host(ctx_, h_X, pt_xyz, 3 * (size_t)P_, mem);
     GSFM_HIP_CHECK(hipStreamSynchronize(s));
     std::mt19937 rng;
@@ -748,7 +852,7 @@ class GpSolver final : public LmProblem {
     // any rank observes it, and a rank's point draws start where the lower ranks' used tracks end in the one global
     // std::mt19937 stream (two 32-bit outputs per double, libstdc++ generate_canonical).
     std::vector<char> constrained(N_, 0);
-    long used_before = 0;
+    long used_before = 0, used_after = 0;
     {
       long used_here = 0;
       for (long p = 0; p < P_; ++p) used_here += (h_off[p + 1] - h_off[p] >= opt_.min_num_view_per_track) ? 1 : 0;
@@ -767,6 +871,7 @@ class GpSolver final : public LmProblem {
         GSFM_HIP_CHECK(hipStreamSynchronize(s));
         for (int n = 0; n < N_; ++n) constrained[n] = h[n] > 0.0;
         for (int r = 0; r < ctx_->comm.rank; ++r) used_before += (long)h[(size_t)N_ + r];
+        for (int r = ctx_->comm.rank + 1; r < W; ++r) used_after += (long)h[(size_t)N_ + r];
       }
     }
     if (opt_.generate_random_positions && opt_.optimize_positions) {
@@ -781,11 +886,14 @@ class GpSolver final : public LmProblem {
         if (h_off[p + 1] - h_off[p] < opt_.min_num_view_per_track) continue;
         for (int j = 0; j < 3; ++j) h_X[3 * (size_t)p + j] = 100.0 * uni(rng);
       }
+      if (used_after > 0) rng.discard(6ull * (unsigned long long)used_after);  // the higher ranks' tracks
     }
-    GSFM_HIP_CHECK(hipMemcpyAsync(ws->c.ensure(3 * (size_t)N_), h_c.data(), 3 * (size_t)N_ * sizeof(double), hipMemcpyHostToDevice, s));
+    // ParameterizeVariables, gp.cc:442-456: the centres to estimate start at RandVector3d(-1, 1), after every other draw
+    for (int k = 0; k < 3 * S_; ++k) h_c[3 * (size_t)N_ + k] = uni(rng);
+    GSFM_HIP_CHECK(hipMemcpyAsync(ws->c.ensure(3 * (size_t)Np_), h_c.data(), 3 * (size_t)Np_ * sizeof(double), hipMemcpyHostToDevice, s));
     GSFM_HIP_CHECK(hipMemcpyAsync(ws->X.ensure(3 * (size_t)P_ + 3), h_X.data(), 3 * (size_t)P_ * sizeof(double), hipMemcpyHostToDevice, s));
     GSFM_HIP_CHECK(hipStreamSynchronize(s));
-    ws->cn.ensure(3 * (size_t)N_);
+    ws->cn.ensure(3 * (size_t)Np_);
     ws->Xn.ensure(3 * (size_t)P_ + 3);
     for (DevBuf<double>* b : {&ws->s, &ws->sn, &ws->wrob, &ws->qa, &ws->qb, &ws->jss, &ws->c_jss, &ws->c_qa, &ws->c_qb})
       b->ensure(M_ + 1);
@@ -798,10 +906,10 @@ class GpSolver final : public LmProblem {
     GSFM_HIP_CHECK(hipMemsetAsync(ws->ptrec.get(), 0, (8 * (size_t)P_ + 8) * sizeof(double), s));
     ws->hppd.ensure(P_ + 1);
     ws->jsx.ensure(P_ + 1);
-    ws->hcc.ensure(N_);
-    ws->jsc.ensure(N_);
-    ws->scc.ensure(6 * (size_t)N_);
-    ws->minv.ensure(9 * (size_t)N_);
+    ws->hcc.ensure(Np_);
+    ws->jsc.ensure(Np_);
+    ws->scc.ensure(6 * (size_t)Np_);
+    ws->minv.ensure(9 * (size_t)Np_);
     ws->cz.ensure(6 * (size_t)NI_ + 2);
     if (rig_) {
       // image tables + frame -> images lists (images of a frame in ascending image order: a fixed summation order)
@@ -814,18 +922,44 @@ class GpSolver final : public LmProblem {
       GSFM_HIP_CHECK(hipMemcpyAsync(ws->foff.ensure(N_ + 1), foff.data(), (size_t)(N_ + 1) * sizeof(int), hipMemcpyHostToDevice, s));
       GSFM_HIP_CHECK(hipMemcpyAsync(ws->fimg.ensure(NI_), fimg.data(), (size_t)NI_ * sizeof(int), hipMemcpyHostToDevice, s));
       copy_in(ctx_, ws->img_off.ensure(3 * (size_t)NI_), prob->image_offset, 3 * (size_t)NI_, mem);
+      rg_ = GpRig{};
+      if (S_ > 0) {
+        std::vector<int> soff((size_t)S_ + 1, 0), simg;
+        for (int i = 0; i < NI_; ++i)
+          if (h_ims[i] >= 0) soff[h_ims[i] + 1]++;
+        for (int k = 0; k < S_; ++k) soff[k + 1] += soff[k];
+        simg.resize((size_t)soff[S_] + 1);
+        std::vector<int> scur(soff.begin(), soff.end() - 1);
+        for (int i = 0; i < NI_; ++i)
+          if (h_ims[i] >= 0) simg[scur[h_ims[i]]++] = i;
+        GSFM_HIP_CHECK(hipMemcpyAsync(ws->img_sensor.ensure(NI_), h_ims.data(), (size_t)NI_ * sizeof(int), hipMemcpyHostToDevice, s));
+        GSFM_HIP_CHECK(hipMemcpyAsync(ws->soff.ensure(S_ + 1), soff.data(), (size_t)(S_ + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+        GSFM_HIP_CHECK(hipMemcpyAsync(ws->simg.ensure(simg.size()), simg.data(), simg.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        copy_in(ctx_, ws->img_rot.ensure(9 * (size_t)NI_), prob->image_sensor_rot, 9 * (size_t)NI_, mem);
+        GSFM_HIP_CHECK(hipStreamSynchronize(s));
+        rg_.img_sensor = ws->img_sensor.get();
+        rg_.img_rot = ws->img_rot.get();
+        rg_.soff = ws->soff.get();
+        rg_.simg = ws->simg.get();
+      }
+      rg_.NI = NI_;
+      rg_.N = N_;
+      rg_.S = S_;
+      rg_.img_frame = ws->img_frame.get();
+      rg_.foff = ws->foff.get();
+      rg_.fimg = ws->fimg.get();
       GSFM_HIP_CHECK(hipStreamSynchronize(s));  // the host vectors above go out of scope
       for (DevBuf<double>* b : {&ws->ci, &ws->cin, &ws->gc_i, &ws->gred_i, &ws->zimg, &ws->ximg, &ws->zero_i})
         b->ensure(3 * (size_t)NI_);
       ws->wimg.ensure(3 * (size_t)NI_ + 2);
       ws->hcc_i.ensure(NI_);
       ws->scc_i.ensure(6 * (size_t)NI_);
-      ws->cz_f.ensure(6 * (size_t)N_ + 2);
+      ws->cz_f.ensure(6 * (size_t)Np_ + 2);
       GSFM_HIP_CHECK(hipMemsetAsync(ws->zero_i.get(), 0, 3 * (size_t)NI_ * sizeof(double), s));
     }
     for (DevBuf<double>* b : {&ws->dcam, &ws->gc, &ws->gred, &ws->rhs, &ws->cg_x, &ws->cg_r, &ws->cg_z, &ws->cg_p, &ws->cg_s})
-      b->ensure(3 * (size_t)N_);
-    ws->cg_w.ensure(3 * (size_t)N_ + 2);
+      b->ensure(3 * (size_t)Np_);
+    ws->cg_w.ensure(3 * (size_t)Np_ + 2);
     ws->vpart.ensure(2 * kCgMaxBlocks * 2);
     ws->dpart.ensure(2 * kMaxApplySlots);
     ws->part.ensure(kMaxBlocks * 8);
@@ -834,6 +968,7 @@ class GpSolver final : public LmProblem {
     ws->cgsc.ensure(2);
     gridP_ = grid_for(P_, kBlock);
     gridN_ = grid_for(N_, kBlock);
+    gridNp_ = grid_for(Np_, kBlock);
     gridNI_ = grid_for(NI_, kBlock);
     gridM_ = grid_for(M_, kBlock);
     gridCam_ = grid_wide(g_.g.S, kBlock / 64, kMaxApplySlots);  // one wave per camera segment (delta partial per block)
@@ -868,10 +1003,10 @@ class GpSolver final : public LmProblem {
     // tracks without observations are never visited by the lane-per-observation sweeps: both point buffers start equal
     GSFM_HIP_CHECK(hipMemcpyAsync(Xn_, X_, 3 * (size_t)P_ * sizeof(double), hipMemcpyDeviceToDevice, s));
     // PCG view
-    cg_.n = 3 * N_;
-    cg_.N = N_;
+    cg_.n = 3 * Np_;
+    cg_.N = Np_;
     cg_.K = 0;
-    cg_.nb_update = std::min(kCgMaxBlocks, grid_for(N_, kBlock));
+    cg_.nb_update = std::min(kCgMaxBlocks, grid_for(Np_, kBlock));
     cg_.nb_apply = gridCam_ + gridMulti_;  // + the delta slots of the combine pass (k_gp_phaseB)
     cg_.b = ws->rhs.get();
     cg_.x = ws->cg_x.get();
@@ -895,13 +1030,16 @@ class GpSolver final : public LmProblem {
 
   // image centres = frame centres - t_rig (and, on request, the c part of the (c | z) gather records)
   void expand_centres(const double* c_frame, double* c_img, bool also_cz) {
-    hipLaunchKernelGGL(k_rig_expand3, dim3(gridNI_), dim3(kBlock), 0, ctx_->stream, NI_, ws_->img_frame.get(), c_frame,
-                       ws_->img_off.get(), c_img, also_cz ? ws_->cz.get() : nullptr, 0);
+    hipLaunchKernelGGL(k_rig_expand3, dim3(gridNI_), dim3(kBlock), 0, ctx_->stream, rg_, c_frame, ws_->img_off.get(), c_img,
+                       also_cz ? ws_->cz.get() : nullptr, 0);
   }
+  // frame blocks: plain sums over the frame's images; sensor blocks: sums over the sensor's images through R_rig
   template <int W>
   void reduce_to_frames(const double* src_img, double* dst_frame) {
     hipLaunchKernelGGL((k_rig_reduce<W>), dim3(gridN_), dim3(kBlock), 0, ctx_->stream, N_, ws_->foff.get(), ws_->fimg.get(),
                        src_img, dst_frame);
+    if (S_ > 0)
+      hipLaunchKernelGGL((k_rig_sensor_reduce<W>), dim3(S_), dim3(kBlock), 0, ctx_->stream, rg_, src_img, dst_frame);
   }
 
   long used_observations() const { return m_used_; }
@@ -921,11 +1059,11 @@ class GpSolver final : public LmProblem {
       reduce_to_frames<3>(gc_k, ws->gc.get());
     }
     if (ctx_->comm.world > 1) {
-      allreduce_sum(ctx_, ws->hcc.get(), N_);
-      allreduce_sum(ctx_, ws->gc.get(), 3 * (size_t)N_);
+      allreduce_sum(ctx_, ws->hcc.get(), Np_);
+      allreduce_sum(ctx_, ws->gc.get(), 3 * (size_t)Np_);
     }
     hipLaunchKernelGGL(k_gp_finalize_lin, dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridTileP_, ws->gc.get(),
-                       g_.opt_c ? 3 * N_ : 0, ws->scal.get());
+                       g_.opt_c ? 3 * Np_ : 0, ws->scal.get());
     double h[2];
     read_scalars(ws->scal.get(), h, 2, /*sum_first=*/1, /*max_from=*/1);
     *grad_max_norm = h[1];
@@ -939,7 +1077,7 @@ class GpSolver final : public LmProblem {
                        ws->wrob.get(), ws->hppd.get(), ws->jss.get(), ws->jsx.get());
     hipLaunchKernelGGL((k_og_gather_f64<1>), dim3(grid_for(g_.g.Mu, kBlock)), dim3(kBlock), 0, s, g_.g.Mu, g_.g.c_src,
                        ws->jss.get(), ws->c_jss.get());
-    hipLaunchKernelGGL(k_gp_jacobi_cam, dim3(gridN_), dim3(kBlock), 0, s, N_, enabled ? 1 : 0, ws->hcc.get(),
+    hipLaunchKernelGGL(k_gp_jacobi_cam, dim3(gridNp_), dim3(kBlock), 0, s, Np_, enabled ? 1 : 0, ws->hcc.get(),
                        ws->jsc.get());
   }
 
@@ -948,7 +1086,7 @@ class GpSolver final : public LmProblem {
     GpWs* ws = ws_;
     hipStream_t s = ctx_->stream;
     const bool multi = ctx_->comm.world > 1;
-    const int n3 = 3 * N_;
+    const int n3 = 3 * Np_;
     double* gred_k = rig_ ? ws->gred_i.get() : ws->gred.get();
     double* scc_k = rig_ ? ws->scc_i.get() : ws->scc.get();
     hipLaunchKernelGGL(k_gp_build_track, dim3(gridTile_), dim3(kBlock), 0, s, g_, radius, ci_, X_, s_, ws->wrob.get(),
@@ -967,11 +1105,11 @@ class GpSolver final : public LmProblem {
     }
     if (multi) {
       allreduce_sum(ctx_, ws->gred.get(), n3);
-      allreduce_sum(ctx_, ws->scc.get(), 6 * (size_t)N_);
+      allreduce_sum(ctx_, ws->scc.get(), 6 * (size_t)Np_);
     }
     *linear_iterations = 0;
     if (g_.opt_c) {
-      hipLaunchKernelGGL(k_gp_cam_finalize, dim3(gridN_), dim3(kBlock), 0, s, N_, radius, g_.lm_lo, g_.lm_hi,
+      hipLaunchKernelGGL(k_gp_cam_finalize, dim3(gridNp_), dim3(kBlock), 0, s, Np_, radius, g_.lm_lo, g_.lm_hi,
                          ws->hcc.get(), ws->jsc.get(), ws->gred.get(), ws->scc.get(), ws->dcam.get(),
                          ws->rhs.get(), ws->minv.get(), c_, rig_ ? ws->cz_f.get() : ws->cz.get());
       if (rig_) expand_centres(c_, ci_, /*also_cz=*/true);  // the c part of the per-image (c | z) records
@@ -981,8 +1119,8 @@ class GpSolver final : public LmProblem {
     }
     const double* dc_k = ws->cg_x.get();
     if (rig_) {  // the step of an image's centre is the step of its frame
-      hipLaunchKernelGGL(k_rig_expand3, dim3(gridNI_), dim3(kBlock), 0, s, NI_, ws->img_frame.get(), ws->cg_x.get(),
-                         (const double*)nullptr, ws->ximg.get(), (double*)nullptr, 0);
+      hipLaunchKernelGGL(k_rig_expand3, dim3(gridNI_), dim3(kBlock), 0, s, rg_, ws->cg_x.get(), (const double*)nullptr,
+                         ws->ximg.get(), (double*)nullptr, 0);
       dc_k = ws->ximg.get();
     }
     hipLaunchKernelGGL(k_gp_backsub, dim3(gridTileP_), dim3(kBlock), 0, s, g_, ci_, X_, s_, ws->wrob.get(),
@@ -1024,6 +1162,9 @@ class GpSolver final : public LmProblem {
   void write_back(const gsfm_gp_problem* prob, double* cam_center, double* pt_xyz) {
     copy_out(ctx_, cam_center, c_, 3 * (size_t)N_, prob->mem);
     copy_out(ctx_, pt_xyz, X_, 3 * (size_t)P_, prob->mem);
+    if (S_ > 0)  // the estimated cam_from_rig centres, in place (host table)
+      GSFM_HIP_CHECK(hipMemcpyAsync(prob->sensor_center, c_ + 3 * (size_t)N_, 3 * (size_t)S_ * sizeof(double),
+                                    hipMemcpyDeviceToHost, ctx_->stream));
     GSFM_HIP_CHECK(hipStreamSynchronize(ctx_->stream));
   }
 
@@ -1049,8 +1190,8 @@ class GpSolver final : public LmProblem {
     const double tol = opt_.lm.pcg_relative_tolerance;
     return cg_solve<3, false>(ctx_, cg_, tol, opt_.lm.pcg_max_iterations, [&](int it) {
       if (rig_)  // z of an image = z of its frame: into the per-image vector and the (c | z) gather records
-        hipLaunchKernelGGL(k_rig_expand3, dim3(gridNI_), dim3(kBlock), 0, s, NI_, ws->img_frame.get(), cg_.z,
-                           (const double*)nullptr, ws->zimg.get(), ws->cz.get(), 3);
+        hipLaunchKernelGGL(k_rig_expand3, dim3(gridNI_), dim3(kBlock), 0, s, rg_, cg_.z, (const double*)nullptr,
+                           ws->zimg.get(), ws->cz.get(), 3);
       CgVec vk = cg_;  // (cg_solve sets the solve-time fields of cg_; the image-space view shares all of them)
       if (rig_) {
         vk.z = ws->zimg.get();
@@ -1071,8 +1212,8 @@ class GpSolver final : public LmProblem {
                            ws->c_qb.get(), ws->ptrec.get(), dk, gridCam_);
       if (timed) ctx_->prof.end(s);
       if (rig_)
-        hipLaunchKernelGGL(k_rig_reduce_w, dim3(1), dim3(kBlock), 0, s, cg_, yscale, ws->foff.get(), ws->fimg.get(),
-                           ws->wimg.get(), ws->dcam.get(), gridCam_ + gridMulti_);
+        hipLaunchKernelGGL(k_rig_reduce_w, dim3(1), dim3(kBlock), 0, s, cg_, rg_, yscale, ws->wimg.get(), ws->dcam.get(),
+                           gridCam_ + gridMulti_);
     });
   }
 
@@ -1084,6 +1225,8 @@ class GpSolver final : public LmProblem {
   int N_ = 0;        // unknown camera blocks (frames)
   int NI_ = 0;       // cameras of the observation graph (= N_, or the images of calibrated rigs)
   bool rig_ = false;
+  int S_ = 0, Np_ = 0, gridNp_ = 1;  // cam_from_rig centre blocks; 3-vector blocks = frames + those
+  GpRig rg_{};
   int gridNI_ = 1;
   double *ci_ = nullptr, *cin_ = nullptr;
   long P_ = 0, M_ = 0, m_used_ = 0;
@@ -1156,6 +1299,11 @@ extern "C" int gsfm_gp_solve(gsfm_ctx* ctx, const gsfm_gp_problem* prob, const g
     if (prob->num_images > 0 && prob->image_frame && prob->image_offset) {
       dump.array("image_frame", prob->image_frame, {(int64_t)prob->num_images}, prob->mem);
       dump.array("image_offset", prob->image_offset, {(int64_t)prob->num_images, 3}, prob->mem);
+      if (prob->num_sensors > 0 && prob->image_sensor && prob->image_sensor_rot && prob->sensor_center) {
+        dump.array("image_sensor", prob->image_sensor, {(int64_t)prob->num_images}, prob->mem);
+        dump.array("image_sensor_rot", prob->image_sensor_rot, {(int64_t)prob->num_images, 3, 3}, prob->mem);
+        dump.array("sensor_center", prob->sensor_center, {(int64_t)prob->num_sensors, 3}, GSFM_MEM_HOST);
+      }
     }
     dump.array("cam_center", cam_center_inout, {N, 3}, prob->mem);
     dump.array("pt_xyz", pt_xyz_inout, {P, 3}, prob->mem);
@@ -1175,6 +1323,8 @@ extern "C" int gsfm_gp_solve(gsfm_ctx* ctx, const gsfm_gp_problem* prob, const g
   if (dumping) {
     dump.array("out_cam_center", cam_center_inout, {(int64_t)prob->num_cams, 3}, prob->mem);
     dump.array("out_pt_xyz", pt_xyz_inout, {(int64_t)prob->num_pts, 3}, prob->mem);
+    if (prob->num_images > 0 && prob->num_sensors > 0 && prob->sensor_center)
+      dump.array("out_sensor_center", prob->sensor_center, {(int64_t)prob->num_sensors, 3}, GSFM_MEM_HOST);
     dump.write(report, rc);
   }
   return rc;

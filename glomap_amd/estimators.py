@@ -303,7 +303,8 @@ def ra_solve_known_rigs(num_frames: int, image_frame, image_cam_from_rig, pair_i
 
 
 def gp_solve(p: GpProblem, options: Optional[GlobalPositionerOptions] = None, ctx=None):
-    """gsfm_gp_solve.  Returns (status, cam_center [N,3], pt_xyz [P,3], report dict)."""
+    """gsfm_gp_solve.  Returns (status, cam_center [N,3], pt_xyz [P,3], report dict); with unknown cam_from_rig centres
+    (p.sensor_center) the report carries the estimates as report["sensor_center"] [S,3]."""
     ctx = ctx or default_context()
     opt = (options or GlobalPositionerOptions()).to_c()
     off, oc = _h(p.pt_offset, np.int64), _h(p.obs_cam, np.int32)
@@ -320,9 +321,19 @@ def gp_solve(p: GpProblem, options: Optional[GlobalPositionerOptions] = None, ct
         imf, imo = _h(p.image_frame, np.int32), _h(p.image_offset, np.float64)
         assert _mem_of(imf, imo) == c.mem
         c.num_images, c.image_frame, c.image_offset = int(imf.shape[0]), _lib.ptr(imf), _lib.ptr(imo)
+    sens = None
+    if getattr(p, "sensor_center", None) is not None:  # unknown cam_from_rig: centre blocks (host table, in/out)
+        ims, imr = _h(p.image_sensor, np.int32), _h(p.image_sensor_rot, np.float64)
+        assert _mem_of(ims, imr) == c.mem
+        sens = np.array(p.sensor_center, dtype=np.float64, order="C", copy=True)
+        c.num_sensors, c.image_sensor, c.image_sensor_rot = int(sens.shape[0]), _lib.ptr(ims), _lib.ptr(imr)
+        c.sensor_center = _lib.ptr(sens)
     rep = _lib.Report()
     rc = ctx.lib.gsfm_gp_solve(ctx.handle, C.byref(c), C.byref(opt), _lib.ptr(cen), _lib.ptr(xyz), C.byref(rep))
-    return rc, cen, xyz, rep.as_dict()
+    report = rep.as_dict()
+    if sens is not None:
+        report["sensor_center"] = sens
+    return rc, cen, xyz, report
 
 
 def ba_solve(p: BaProblem, options: Optional[BundleAdjusterOptions] = None, ctx=None):

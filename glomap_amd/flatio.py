@@ -90,7 +90,9 @@ def to_problem(rec: FlatRecord):
         M = len(a["obs_cam"])
         p = GpProblem(int(s["num_cams"]), len(a["pt_offset"]) - 1, a["pt_offset"], a["obs_cam"], a["obs_dir"],
                       a.get("obs_calibrated", np.ones(M, np.uint8)), a["cam_center"], a["pt_xyz"],
-                      image_frame=a.get("image_frame"), image_offset=a.get("image_offset"))  # calibrated rigs
+                      image_frame=a.get("image_frame"), image_offset=a.get("image_offset"),  # calibrated rigs
+                      image_sensor=a.get("image_sensor"), image_sensor_rot=a.get("image_sensor_rot"),
+                      sensor_center=a.get("sensor_center"))  # unknown cam_from_rig centres
         opt = _fill(estimators.GlobalPositionerOptions(), o)
         _lm(opt.solver_options, o)
         return p, opt
@@ -100,7 +102,8 @@ def to_problem(rec: FlatRecord):
                       cam_intr=a.get("cam_intr", np.zeros(int(s["num_cams"]), np.int32)), cam_q=a["cam_q"],
                       cam_t=a["cam_t"], pt_xyz=a["pt_xyz"], intr_model=a["intr_model"], intr_params=a["intr_params"],
                       fixed_cam=int(s["fixed_cam"]), image_frame=a.get("image_frame"),
-                      image_cam_from_rig=a.get("image_cam_from_rig"), image_intr=a.get("image_intr"))
+                      image_cam_from_rig=a.get("image_cam_from_rig"), image_intr=a.get("image_intr"),
+                      image_sensor=a.get("image_sensor"), sensor_cam_from_rig=a.get("sensor_cam_from_rig"))
         opt = _fill(estimators.BundleAdjusterOptions(), o)
         _lm(opt.solver_options, o)
         return p, opt
@@ -120,6 +123,9 @@ def from_problem(p, options=None) -> FlatRecord:
                     cam_center=np.asarray(p.cam_center, np.float64), pt_xyz=np.asarray(p.pt_xyz, np.float64))
         if p.image_frame is not None:
             arrs.update(image_frame=np.asarray(p.image_frame, np.int32), image_offset=np.asarray(p.image_offset, np.float64))
+        if p.sensor_center is not None:
+            arrs.update(image_sensor=np.asarray(p.image_sensor, np.int32), image_sensor_rot=np.asarray(p.image_sensor_rot, np.float64),
+                        sensor_center=np.asarray(p.sensor_center, np.float64))
         return FlatRecord("gp", {"num_cams": p.num_cams}, _opts(options), arrays=arrs)
     if isinstance(p, BaProblem):
         arrs = dict(pt_offset=np.asarray(p.pt_offset, np.int64), obs_cam=np.asarray(p.obs_cam, np.int32), obs_xy=np.asarray(p.obs_xy, np.float64),
@@ -129,6 +135,9 @@ def from_problem(p, options=None) -> FlatRecord:
         if p.image_frame is not None:
             arrs.update(image_frame=np.asarray(p.image_frame, np.int32), image_intr=np.asarray(p.image_intr, np.int32),
                         image_cam_from_rig=np.asarray(p.image_cam_from_rig, np.float64))
+        if p.sensor_cam_from_rig is not None:
+            arrs.update(image_sensor=np.asarray(p.image_sensor, np.int32),
+                        sensor_cam_from_rig=np.asarray(p.sensor_cam_from_rig, np.float64))
         return FlatRecord("ba", {"num_cams": p.num_cams, "num_intr": p.num_intr, "fixed_cam": p.fixed_cam}, _opts(options), arrays=arrs)
     raise TypeError(type(p))
 

@@ -268,11 +268,21 @@ typedef struct gsfm_gp_problem {
    * the FRAMES (rig_from_world per time step), and for every image
    *   image_frame[i]   its frame,
    *   image_offset[i]  = R_cam_from_world^T * t_cam_from_rig  (translation_rig at gp.cc:329-333; zero for reference sensors),
-   * so that the residual is  v - s (X - c_frame + image_offset).  Rigs whose cam_from_rig is unknown (NaN translation,
-   * RigUnknownBATAPairwiseDirectionError) are not implemented: the adapter returns false for them. */
+   * so that the residual is  v - s (X - c_frame + image_offset).
+   * Sensors whose cam_from_rig translation is unknown (NaN after rotation averaging) — RigUnknownBATAPairwiseDirectionError,
+   * cost_function.h:90-136, added at global_positioning.cc:354-368: residual v - s (X - c_frame - R_rig^T c_s) with the
+   * camera centre in rig coordinates c_s = -R_cam_from_rig^T t_cam_from_rig one 3-vector block per sensor.  num_sensors =
+   * S > 0: image i of such a sensor has image_sensor[i] >= 0 (else -1), image_offset[i] = 0 and image_sensor_rot[i] =
+   * R_rig_from_world of its frame (row-major).  sensor_center [S][3] (host memory, in/out) is re-drawn in [-1,1]^3 from
+   * the solver's random stream after all other draws (gp.cc:442-456) and holds the estimate on return; the caller
+   * converts back t = -R c (gp.cc:576-582).  Needs optimize_positions. */
   int32_t num_images;
   const int32_t* image_frame;   /* [I] */
   const double* image_offset;   /* [I][3] */
+  int32_t num_sensors;
+  const int32_t* image_sensor;     /* [I] */
+  const double* image_sensor_rot;  /* [I][9] */
+  double* sensor_center;           /* [S][3] host, in/out */
 } gsfm_gp_problem;
 
 /* cam_center_inout [N][3]: camera centres c = -R^T t (in: used when !generate_random_positions;

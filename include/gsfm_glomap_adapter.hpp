@@ -156,6 +156,24 @@ inline bool KnownCamFromRig(const glomap::Image& im, std::unordered_map<rig_t, g
   return true;
 }
 
+// 0: cam_from_rig fully known (cfr filled; identity for reference sensors), 1: rotation known but translation NaN — what
+// RotationEstimator leaves behind for estimated sensors (gra.cc:803-815) and GlobalPositioner then estimates
+// (gp.cc:354-368); cfr holds the rotation, a zero translation —, 2: no value at all.
+inline int CamFromRigState(const glomap::Image& im, std::unordered_map<rig_t, glomap::Rig>& rigs, double* cfr) {
+  cfr[0] = 1.0;
+  for (int j = 1; j < 7; ++j) cfr[j] = 0.0;
+  if (im.HasTrivialFrame()) return 0;
+  const glomap::sensor_t sid(glomap::SensorType::CAMERA, im.camera_id);
+  const auto opt = rigs.at(im.frame_ptr->RigId()).MaybeSensorFromRig(sid);
+  if (!opt.has_value()) return 2;
+  QuatWxyz(opt->rotation, cfr);
+  bool nan = false;
+  for (int j = 0; j < 3; ++j) nan = nan || std::isnan(opt->translation[j]);
+  if (nan) return 1;
+  for (int j = 0; j < 3; ++j) cfr[4 + j] = opt->translation[j];
+  return 0;
+}
+
 // colmap::AverageQuaternions with unit weights: principal eigenvector of sum q q^T (cyclic Jacobi on the 4 x 4).
 inline void AverageQuaternions(const std::vector<std::array<double, 4>>& qs, double* out) {
   double A[4][4] = {{0}}, V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
@@ -443,9 +461,12 @@ class GlobalPositioner {
     std::vector<uint8_t> cal(static_cast<size_t>(M));
     // known rigs (gp.cc:318-350, RigBATAPairwiseDirectionError with the rig scale constant at 1, :470-478): images become
     // the cameras of the flat problem, each with its frame and the offset R_cam_from_world^T t_cam_from_rig
+    // unknown cam_from_rig translations (gp.cc:354-368, RigUnknownBATAPairwiseDirectionError): a centre block per sensor
     std::unordered_map<image_t, int> img_of;
-    std::vector<int32_t> image_frame;
-    std::vector<double> image_offset;
+    std::vector<int32_t> image_frame, image_sensor;
+    std::vector<double> image_offset, image_rot;
+    std::vector<std::pair<rig_t, camera_t>> image_key;  // sensor of the images that need a block
+    std::map<std::pair<rig_t, camera_t>, int> sensor_of;
     for (int64_t k = 0; k < M; ++k) {
       const auto& im = images.at(tp.obs_image[k]);
       const auto cam_from_world = im.CamFromWorld();
@@ -454,15 +475,42 @@ class GlobalPositioner {
       if (!rigged) continue;
       auto it = img_of.find(tp.obs_image[k]);
       if (it == img_of.end()) {
-        double cfr[7], off[3];
-        if (!detail::KnownCamFromRig(im, rigs, cfr)) return false;  // RigUnknownBATAPairwiseDirectionError: not implemented
-        detail::RotateInv(cam_from_world.rotation, cfr + 4, off);   // translation_rig, gp.cc:329-333
+        double cfr[7], off[3] = {0.0, 0.0, 0.0}, Rrw[9];
+        const int state = detail::CamFromRigState(im, rigs, cfr);
+        if (state == 2) return false;  // no cam_from_rig at all: the reference dereferences the empty optional (gp.cc:323)
+        if (state == 0) detail::RotateInv(cam_from_world.rotation, cfr + 4, off);  // translation_rig, gp.cc:329-333
+        const auto& rig_from_world = im.frame_ptr->RigFromWorld().rotation;
+        for (int j = 0; j < 3; ++j) {  // row-major R_rig_from_world: column j = R e_j
+          const double e[3] = {j == 0 ? 1.0 : 0.0, j == 1 ? 1.0 : 0.0, j == 2 ? 1.0 : 0.0};
+          double col[3];
+          detail::Rotate(rig_from_world, e, col);
+          for (int i = 0; i < 3; ++i) Rrw[3 * i + j] = col[i];
+        }
         it = img_of.emplace(tp.obs_image[k], static_cast<int>(image_frame.size())).first;
         image_frame.push_back(tp.obs_cam[k]);
         image_offset.insert(image_offset.end(), off, off + 3);
+        image_rot.insert(image_rot.end(), Rrw, Rrw + 9);
+        image_sensor.push_back(state == 1 ? 0 : -1);  // block index assigned below
+        image_key.emplace_back(im.frame_ptr->RigId(), im.camera_id);
+        if (state == 1) sensor_of.emplace(image_key.back(), -1);
       }
       tp.obs_cam[k] = it->second;
     }
+    // block order = the order ParameterizeVariables draws their start values in (gp.cc:442-456): rigs in map order,
+    // sensors in the rig's own (sorted) order, only those that own a parameter block
+    std::vector<std::pair<rig_t, camera_t>> sensor_ids;
+    for (auto& [rig_id, rig] : rigs)
+      for (const auto& [sid, unused] : rig.NonRefSensors()) {
+        (void)unused;
+        if (sid.type != glomap::SensorType::CAMERA) continue;
+        auto st = sensor_of.find({rig_id, static_cast<camera_t>(sid.id)});
+        if (st == sensor_of.end()) continue;
+        st->second = static_cast<int>(sensor_ids.size());
+        sensor_ids.emplace_back(rig_id, static_cast<camera_t>(sid.id));
+      }
+    for (size_t i = 0; i < image_sensor.size(); ++i)
+      if (image_sensor[i] == 0) image_sensor[i] = sensor_of.at(image_key[i]);
+    std::vector<double> sensor_center(3 * sensor_ids.size(), 0.0);
     for (int n = 0; n < N; ++n) {  // c = -R^T t
       const auto& pose = frames.at(fidx.ids[n]).RigFromWorld();
       double c[3];
@@ -497,9 +545,21 @@ class GlobalPositioner {
       pr.num_images = static_cast<int32_t>(image_frame.size());
       pr.image_frame = image_frame.data();
       pr.image_offset = image_offset.data();
+      if (!sensor_ids.empty()) {
+        pr.num_sensors = static_cast<int32_t>(sensor_ids.size());
+        pr.image_sensor = image_sensor.data();
+        pr.image_sensor_rot = image_rot.data();
+        pr.sensor_center = sensor_center.data();
+      }
     }
     gsfm_report rep;
     if (gsfm_gp_solve(ctx, &pr, &o, cen.data(), xyz.data(), &rep) != GSFM_OK) return false;
+    for (size_t k = 0; k < sensor_ids.size(); ++k) {  // ConvertResults: centre -> translation, t = -R c (gp.cc:576-582)
+      auto& cfr = rigs.at(sensor_ids[k].first).SensorFromRig(glomap::sensor_t(glomap::SensorType::CAMERA, sensor_ids[k].second));
+      double t[3];
+      detail::Rotate(cfr.rotation, &sensor_center[3 * k], t);
+      cfr.translation = decltype(cfr.translation)(-t[0], -t[1], -t[2]);
+    }
     for (int n = 0; n < N; ++n) {  // ConvertResults: t = -R c (gp.cc:566-572)
       auto& fr = frames.at(fidx.ids[n]);
       auto pose = fr.RigFromWorld();

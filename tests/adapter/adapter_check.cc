@@ -299,7 +299,7 @@ int main() {
   // 6) calibrated rigs (the shape of global_mapper_test.cc:89-126): 12 frames of a 2-camera rig — reference sensor
   //    (camera 11) and a second sensor (camera 12) with a KNOWN cam_from_rig (10 degrees about y, a metric baseline).
   //    RotationEstimator, GlobalPositioner and BundleAdjuster must handle them through the same three calls.
-  double rig_ra = 0, rig_gp = 0, rig_ba = 0, rig_sens = 0;
+  double rig_ra = 0, rig_gp = 0, rig_ba = 0, rig_sens = 0, rig_unk = 0;
   {
     const int NF = 12, NP = 300;
     std::unordered_map<rig_t, Rig> rigs2;
@@ -476,11 +476,33 @@ int main() {
         }
       if (worst_px > 1e-3) return std::printf("optimize_rig_poses: reprojection error %.3e px\n", worst_px), 1;
     }
-    // an uncalibrated sensor is refused (RigUnknownBATA / cam-from-rig unknowns are not implemented), not mis-solved
+    // unknown cam_from_rig translation (NaN, what rotation averaging leaves behind for an estimated sensor):
+    // GlobalPositioner estimates it (RigUnknownBATAPairwiseDirectionError, gp.cc:354-368) in the scale of the solution
+    {
+      Rigid3d unk;
+      unk.rotation = quat_of(Rs);
+      const double nan = std::nan("");
+      unk.translation = mock_eigen::Vector3d(nan, nan, nan);
+      rigs2[1].SetSensorFromRig(sensor_t(SensorType::CAMERA, 12), unk);
+      auto fr_u = fr_gp;  // ground-truth rotations, positions from the previous run (re-drawn anyway)
+      for (int id = 0; id < 2 * NF; ++id) im2[id].frame_ptr = &fr_u[id / 2];
+      auto tr_u = tr2;
+      gsfm_glomap::GlobalPositioner gp3(go2);
+      if (!gp3.Solve(vg2, rigs2, cams2, fr_u, im2, tr_u)) return std::printf("GP with an unknown cam_from_rig failed\n"), 1;
+      const auto te = rigs2[1].SensorFromRig(sensor_t(SensorType::CAMERA, 12)).translation;
+      double b0[3], b6[3];
+      center(fr_u[0], b0);
+      center(fr_u[6], b6);
+      const double sc = 20.0 / dist(b0, b6);  // the solution's free scale
+      for (int i = 0; i < 3; ++i) rig_unk = std::fmax(rig_unk, std::fabs(sc * te[i] - ts[i]));
+      if (!(rig_unk < 5e-2)) return std::printf("unknown cam_from_rig: translation off by %.3e (scaled)\n", rig_unk), 1;
+      for (int id = 0; id < 2 * NF; ++id) im2[id].frame_ptr = &fr2[id / 2];
+    }
+    // a sensor without any cam_from_rig is refused, not mis-solved
     rigs2[1].ResetSensorFromRig(sensor_t(SensorType::CAMERA, 12));
     if (ba2.Solve(rigs2, cams2, fr2, im2, tr2)) return std::printf("BA accepted an uncalibrated rig\n"), 1;
   }
-  std::printf("ADAPTER OK ra=%.2e rad gp_ratio_err=%.2e ba=%.2e px | rigs: ra=%.2e rad gp_scale_err=%.2e ba=%.2e px cam_from_rig=%.2e rad\n",
-              worst, std::fabs(ratio / ratio_ref - 1.0), maxerr, rig_ra, rig_gp, rig_ba, rig_sens);
+  std::printf("ADAPTER OK ra=%.2e rad gp_ratio_err=%.2e ba=%.2e px | rigs: ra=%.2e rad gp_scale_err=%.2e ba=%.2e px cam_from_rig=%.2e rad unknown_t=%.2e\n",
+              worst, std::fabs(ratio / ratio_ref - 1.0), maxerr, rig_ra, rig_gp, rig_ba, rig_sens, rig_unk);
   return 0;
 }

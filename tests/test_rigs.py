@@ -5,6 +5,7 @@
   BA: colmap::RigReprojErrorConstantRigCostFunctor (bundle_adjustment.cc:147-160, optimize_rig_poses = false)
 
   BA: colmap::RigReprojErrorCostFunctor (bundle_adjustment.cc:161-179, optimize_rig_poses = true): cam_from_rig blocks
+  GP: RigUnknownBATAPairwiseDirectionError (cost_function.h:90-136, global_positioning.cc:354-368): unknown translations
 
 CPU: the two oracles against each other and against ground truth.  GPU: the HIP path (sweeps over images, LM / PCG state
 per frame and per sensor block) through the C ABI against the oracles."""
@@ -99,6 +100,51 @@ def test_oracle_refines_miscalibrated_rigs():
     assert so3.rotation_angle_deg(so3.quat_to_rotmat(sc[:, :4]), so3.quat_to_rotmat(sg[:, :4])).max() < 1e-4
     # the constant frame stays (ba.cc:261-266)
     assert np.array_equal(r[1][p.fixed_cam], p.cam_q[p.fixed_cam]) and np.array_equal(r[2][p.fixed_cam], p.cam_t[p.fixed_cam])
+
+
+def _unk_kw(p):
+    return dict(image_frame=p.image_frame, image_offset=p.image_offset, image_sensor=p.image_sensor,
+                image_sensor_rot=p.image_sensor_rot, sensor_center=p.sensor_center)
+
+
+def test_oracle_estimates_unknown_rig_translations():
+    """RigUnknownBATAPairwiseDirectionError in the oracle (cost_function.h:90-136, gp.cc:354-368): with every non-reference
+    cam_from_rig translation unknown the noise-free problem still goes to zero cost, and frame centres and sensor centres
+    come out in ONE common scale (the scale itself is free again: no metric baseline is left)."""
+    gp, _, info = synthetic.make_rig_problems(14, 3, 500, seed=0)
+    p = synthetic.forget_rig_translations(gp, info)
+    ok, cen, X, summ = ogp.solve(*_gp_args(p), **_unk_kw(p))
+    assert ok and summ.final_cost < 1e-12 * summ.initial_cost
+    scale, _, _ = synthetic.align_sim3(cen, gp.gt_center)
+    assert synthetic.center_errors_after_sim3(cen, gp.gt_center).max() < 1e-6
+    assert np.abs(summ.sensor_center * scale - info["sensor_center"]).max() < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frames,cams,pts,noise", [(14, 3, 500, 0.0), (30, 3, 3000, 1.0)])
+def test_gp_with_unknown_rig_translations_matches_oracle(gsfm_ctx, frames, cams, pts, noise):
+    """The same through the C ABI: centre blocks of the unknown sensors behind the frames, same random start (the sensor
+    draws come last in the stream, gp.cc:442-456), same LM path as the exact-solve oracle."""
+    from glomap_amd import estimators
+
+    gp, _, info = synthetic.make_rig_problems(frames, cams, pts, seed=4, dir_noise=1e-3 * noise, outlier_ratio=0.01 * noise)
+    p = synthetic.forget_rig_translations(gp, info)
+    opt = estimators.GlobalPositionerOptions()
+    opt.solver_options.pcg_relative_tolerance = 1e-10
+    rc, cen, xyz, rep = estimators.gp_solve(p, opt, ctx=gsfm_ctx)
+    assert rc == 0
+    ok, c_o, X_o, s = ogp.solve(*_gp_args(p), **_unk_kw(p))
+    assert ok
+    assert abs(rep["initial_cost"] - s.initial_cost) <= 1e-12 * s.initial_cost  # same random start, sensor centres included
+    assert abs(rep["iterations"] - s.iterations) <= 2
+    assert abs(rep["final_cost"] - s.final_cost) <= 1e-3 * s.final_cost + 1e-9
+    assert synthetic.center_errors_after_sim3(cen, c_o).max() < 1e-3
+    scale, _, _ = synthetic.align_sim3(cen, c_o)
+    cs, cs_o = rep["sensor_center"], s.sensor_center
+    assert np.abs(cs * scale - cs_o).max() < 1e-3 * np.abs(cs_o).max()
+    if noise == 0.0:
+        sc, _, _ = synthetic.align_sim3(cen, gp.gt_center)
+        assert np.abs(cs * sc - info["sensor_center"]).max() < 1e-4
 
 
 @pytest.mark.gpu
