@@ -87,6 +87,11 @@ class RaProblemC(C.Structure):
         ("edge_weight", C.c_void_p),
         ("edge_ninl", C.c_void_p),
         ("fixed_node", C.c_int32),
+        ("num_images", C.c_int32),
+        ("image_frame", C.c_void_p),
+        ("image_cam", C.c_void_p),
+        ("num_cams", C.c_int32),
+        ("cam_rot_aa", C.c_void_p),
     ]
 
 

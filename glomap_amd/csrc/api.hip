@@ -60,6 +60,7 @@ extern "C" void gsfm_ctx_destroy(gsfm_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->ra_ws && ctx->ra_ws_free) ctx->ra_ws_free(ctx->ra_ws);
+  if (ctx->ra_rig_ws && ctx->ra_rig_ws_free) ctx->ra_rig_ws_free(ctx->ra_rig_ws);
   if (ctx->gp_ws && ctx->gp_ws_free) ctx->gp_ws_free(ctx->gp_ws);
   if (ctx->ba_ws && ctx->ba_ws_free) ctx->ba_ws_free(ctx->ba_ws);
   if (ctx->fl_ws && ctx->fl_ws_free) ctx->fl_ws_free(ctx->fl_ws);

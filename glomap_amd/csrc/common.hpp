@@ -179,6 +179,8 @@ struct gsfm_ctx {
   void* ba_ws = nullptr;
   void* fl_ws = nullptr;
   void* tr_ws = nullptr;
+  void* ra_rig_ws = nullptr;
+  void (*ra_rig_ws_free)(void*) = nullptr;
   void (*fl_ws_free)(void*) = nullptr;
   void (*tr_ws_free)(void*) = nullptr;
   void (*ra_ws_free)(void*) = nullptr;

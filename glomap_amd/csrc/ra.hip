@@ -1286,12 +1286,16 @@ void launch_gather(RaDevice& d, const int* stop = nullptr) {
   });
 }
 
+int ra_solve_rig_impl(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_options* opt, double* rot_inout,
+                      gsfm_report* rep);
+
 int ra_solve_impl(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_options* opt,
                   double* rot_inout, gsfm_report* rep) {
   GSFM_REQUIRE(prob && opt && rot_inout, "RA: null argument");
   if (opt->use_gravity) throw StatusError(GSFM_ERR_UNSUPPORTED, "RA: gravity-aligned (1-DoF) path not implemented");
   if (prob->num_nodes <= 0) throw StatusError(GSFM_ERR_EMPTY_PROBLEM, "RA: no nodes");
   GSFM_REQUIRE(prob->fixed_node >= 0 && prob->fixed_node < prob->num_nodes, "RA: fixed_node out of range");
+  if (prob->num_images > 0) return ra_solve_rig_impl(ctx, prob, opt, rot_inout, rep);  // cam_from_rig rotations unknown
   const double t0 = now_seconds();
   GSFM_HIP_CHECK(hipSetDevice(ctx->device));
   RaDevice d;
@@ -1451,6 +1455,530 @@ int ra_solve_impl(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
   } else {
     copy_out(ctx, rot_inout, ws->rot.get(), 3 * (size_t)N, prob->mem);
   }
+  GSFM_HIP_CHECK(hipStreamSynchronize(s));
+  const double t2 = now_seconds();
+  if (rep) {
+    rep->iterations_l1 = it_l1;
+    rep->iterations_irls = it_irls;
+    rep->iterations = it_l1 + it_irls;
+    rep->linear_iterations = lin_iters;
+    rep->termination = GSFM_TERM_CONVERGENCE;
+    rep->seconds_total = t2 - t0;
+    rep->seconds_solve = t2 - t1;
+    rep->last_step_norm = last_step;
+  }
+  return GSFM_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Rigs with cam_from_rig ROTATIONS among the unknowns (gra.cc:173-191, 396-446, 646-693, 718-739)
+// ------------------------------------------------------------------------------------------
+// The view graph stays what it is — nodes = IMAGES, two endpoints per edge — and everything above keeps working on it:
+// the residual sweep sees image quaternions q_cam * q_frame, the gathers and the Laplacian SpMV run per image.  The
+// unknowns are the frames and the C cam blocks; an image's tangent is the SUM of its frame's and its cam's
+// (x_image = V x, V = [frame incidence | cam incidence]): exactly the -1 / +1 pattern gra.cc:396-446 writes, with the
+// cancellation of equal columns for free.  So  A = A_image V,  A^T W A = V^T L_w V  and the linear solves are a
+// Jacobi-PCG on the 3 (N + C) reduced unknowns whose operator is  expand -> image SpMV -> reduce.  The gauge rows sit on
+// an image of the gauge frame that has no cam block (a virtual, edge-less image is appended when the frame has none).
+struct RigRa {
+  int N, C, NI;
+  const int* img_frame;  // [NI]
+  const int* img_cam;    // [NI] block or -1
+  const int* foff;       // [N + 1] frame -> images
+  const int* fimg;
+  const int* coff;       // [C + 1] cam -> images
+  const int* cimg;
+};
+
+// nq[i] = quat(Exp(cam)) * quat(Exp(frame))  (gra.cc:729-738); the gauge rows Log(R_fix0^T R_fix) of the gauge FRAME
+__global__ void __launch_bounds__(kBlock)
+    k_rig_ra_node_quat(RigRa r, const double* __restrict__ rotf, const double* __restrict__ rotc, double* __restrict__ nq,
+                       int fixed_img, const double* __restrict__ fixed_rot0, double* __restrict__ gauge_out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < r.NI; i += gridDim.x * blockDim.x) {
+    const int f = r.img_frame[i], c = r.img_cam[i];
+    const Quat qf = aa_to_quat(rotf[3 * f], rotf[3 * f + 1], rotf[3 * f + 2]);
+    Quat q = qf;
+    if (c >= 0) q = qmul(aa_to_quat(rotc[3 * c], rotc[3 * c + 1], rotc[3 * c + 2]), qf);
+    store_quat(nq + 4 * (long)i, q);
+    if (i == fixed_img) {
+      const Quat q0 = aa_to_quat(fixed_rot0[0], fixed_rot0[1], fixed_rot0[2]);
+      double gx, gy, gz;
+      quat_to_aa(qmul(qconj(q0), qf), gx, gy, gz);
+      gauge_out[0] = gx;
+      gauge_out[1] = gy;
+      gauge_out[2] = gz;
+    }
+  }
+}
+
+// dst_image = V src: frame part + cam part.  As the first kernel of a PCG apply it also runs the convergence test.
+__global__ void __launch_bounds__(kBlock)
+    k_rig_ra_expand(RigRa r, const double* __restrict__ src, double* __restrict__ dst, CgVec v, int it, double tol2,
+                    int test) {
+  __shared__ double smem[4 * 2 + 2];
+  if (test && cg_converged(v, it, tol2, smem)) return;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < r.NI; i += gridDim.x * blockDim.x) {
+    const long f = r.img_frame[i];
+    const int c = r.img_cam[i];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double x = src[3 * f + j];
+      if (c >= 0) x += src[3 * (long)(r.N + c) + j];
+      dst[3 * (long)i + j] = x;
+    }
+  }
+}
+
+// dst = V^T src (W values per image): frames by one thread each, cam blocks by one workgroup each (fixed order)
+template <int W>
+__global__ void __launch_bounds__(kBlock)
+    k_rig_ra_reduce(RigRa r, const double* __restrict__ src, double* __restrict__ dst) {
+  __shared__ double smem[4 * W];
+  const int fblocks = (r.N + kBlock - 1) / kBlock;
+  if ((int)blockIdx.x < fblocks) {
+    const int f = blockIdx.x * kBlock + threadIdx.x;
+    if (f < r.N) {
+      double acc[W];
+#pragma unroll
+      for (int j = 0; j < W; ++j) acc[j] = 0.0;
+      for (int a = r.foff[f]; a < r.foff[f + 1]; ++a) {
+        const double* sp = src + (long)W * r.fimg[a];
+#pragma unroll
+        for (int j = 0; j < W; ++j) acc[j] += sp[j];
+      }
+#pragma unroll
+      for (int j = 0; j < W; ++j) dst[(long)W * f + j] = acc[j];
+    }
+    return;
+  }
+  const int c = blockIdx.x - fblocks;  // gridDim.x = fblocks + C
+  double acc[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) acc[j] = 0.0;
+  for (int a = r.coff[c] + threadIdx.x; a < r.coff[c + 1]; a += blockDim.x) {
+    const double* sp = src + (long)W * r.cimg[a];
+#pragma unroll
+    for (int j = 0; j < W; ++j) acc[j] += sp[j];
+  }
+  block_sum<W>(acc, smem);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < W; ++j) dst[(long)W * (r.N + c) + j] = acc[j];
+  }
+}
+
+// delta partials of a PCG apply: dpart[block] = sum z.w over this block's share
+__global__ void __launch_bounds__(kBlock) k_rig_ra_dot(CgVec v) {
+  __shared__ double smem[4];
+  if (v.st->done) return;
+  double acc[1] = {0.0};
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < v.n; i += (long)gridDim.x * blockDim.x) acc[0] += v.z[i] * v.w[i];
+  block_sum<1>(acc, smem);
+  if (threadIdx.x == 0) v.dpart[blockIdx.x] = acc[0];
+}
+
+// UpdateGlobalRotations for the cam blocks (gra.cc:646-690), after the frames were updated: the new cam rotation is the
+// quaternion average over the cam's images of  R_cam R_f Exp(-step) R_f^T  (principal eigenvector of sum q q^T, cyclic
+// Jacobi on the 4 x 4).  One thread per cam block: there are a handful.
+__global__ void __launch_bounds__(64)
+    k_rig_ra_cam_update(RigRa r, const double* __restrict__ rotf, double* __restrict__ rotc, const double* __restrict__ step) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= r.C || r.coff[c + 1] == r.coff[c]) return;
+  const Quat qc = aa_to_quat(rotc[3 * c], rotc[3 * c + 1], rotc[3 * c + 2]);
+  const double* d = step + 3 * (long)(r.N + c);
+  const Quat qu = aa_to_quat(-d[0], -d[1], -d[2]);
+  double A[4][4];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) A[i][j] = 0.0;
+  for (int a = r.coff[c]; a < r.coff[c + 1]; ++a) {
+    const int f = r.img_frame[r.cimg[a]];
+    const Quat qf = aa_to_quat(rotf[3 * f], rotf[3 * f + 1], rotf[3 * f + 2]);
+    const Quat q = qmul(qmul(qmul(qc, qf), qu), qconj(qf));
+    const double v[4] = {q.w, q.x, q.y, q.z};
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) A[i][j] += v[i] * v[j];
+  }
+  double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    double off = 0.0;
+    for (int i = 0; i < 4; ++i)
+      for (int j = i + 1; j < 4; ++j) off += A[i][j] * A[i][j];
+    if (off < 1e-30) break;
+    for (int p = 0; p < 4; ++p)
+      for (int q = p + 1; q < 4; ++q) {
+        if (fabs(A[p][q]) < 1e-300) continue;
+        const double th = 0.5 * atan2(2.0 * A[p][q], A[q][q] - A[p][p]);
+        const double cs = cos(th), sn = sin(th);
+        for (int k = 0; k < 4; ++k) {
+          const double akp = A[k][p], akq = A[k][q];
+          A[k][p] = cs * akp - sn * akq;
+          A[k][q] = sn * akp + cs * akq;
+        }
+        for (int k = 0; k < 4; ++k) {
+          const double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = cs * apk - sn * aqk;
+          A[q][k] = sn * apk + cs * aqk;
+        }
+        for (int k = 0; k < 4; ++k) {
+          const double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = cs * vkp - sn * vkq;
+          V[k][q] = sn * vkp + cs * vkq;
+        }
+      }
+  }
+  int best = 0;
+  for (int i = 1; i < 4; ++i)
+    if (A[i][i] > A[best][best]) best = i;
+  double ax, ay, az;
+  quat_to_aa(Quat{V[0][best], V[1][best], V[2][best], V[3][best]}, ax, ay, az);
+  rotc[3 * c] = ax;
+  rotc[3 * c + 1] = ay;
+  rotc[3 * c + 2] = az;
+}
+
+struct RigRaWs {
+  DevBuf<int> img_frame, img_cam, foff, fimg, coff, cimg;
+  DevBuf<double> rotf, rotc, rhs, x, r, wbuf, gat_s, gat_t, diag, b, cx, cr, cz, cp, cs, cw, minv, zimg, tmp_rot;
+  static void destroy(void* p) { delete static_cast<RigRaWs*>(p); }
+};
+
+struct RigSolve {
+  RaDevice* d;
+  RigRaWs* rw;
+  RigRa r;
+  int nred;      // N + C
+  int gridRed;   // blocks of the reduce kernels: frames + one per cam
+  int gridI, gridR;
+};
+
+void rig_expand(RigSolve& g, const double* src_red, double* dst_img) {
+  CgVec dummy{};
+  hipLaunchKernelGGL(k_rig_ra_expand, dim3(g.gridI), dim3(kBlock), 0, g.d->ctx->stream, g.r, src_red, dst_img, dummy, 0, 0.0, 0);
+}
+template <int W>
+void rig_reduce(RigSolve& g, const double* src_img, double* dst_red) {
+  hipLaunchKernelGGL((k_rig_ra_reduce<W>), dim3(g.gridRed), dim3(kBlock), 0, g.d->ctx->stream, g.r, src_img, dst_red);
+}
+
+// y_red = V^T (L_w + gauge) V x_red through the image-level SpMV
+void rig_operator(RigSolve& g, const double* x_red, double* y_red) {
+  RaDevice& d = *g.d;
+  RaWs* ws = d.ws;
+  rig_expand(g, x_red, g.rw->zimg.get());
+  dispatch_lpr(d.lpr, [&](auto L) {
+    hipLaunchKernelGGL((k_spmv<decltype(L)::value>), dim3(d.gridRow), dim3(kBlock), 0, d.ctx->stream, d.N, ws->rowptr.get(),
+                       ws->nbr.get(), ws->inc_w.get(), ws->lap_diag_loc.get(), g.rw->zimg.get(), ws->wbuf.get());
+  });
+  rig_reduce<3>(g, ws->wbuf.get(), y_red);
+}
+
+// Solves V^T (L_w + gauge) V x = rhs_red (weights in ws->inc_w / lap_diag, Jacobi blocks from the reduced diagonal) the
+// way pcg_solve does for plain graphs: optional warm start, then true-residual verification passes.
+int rig_pcg_solve(RigSolve& g, bool warm, double tol, int max_iter) {
+  RaDevice& d = *g.d;
+  RaWs* ws = d.ws;
+  RigRaWs* rw = g.rw;
+  gsfm_ctx* ctx = d.ctx;
+  hipStream_t s = ctx->stream;
+  const int n = g.nred;
+  const long n3 = 3L * n;
+  const double* b = rw->rhs.get();
+  if (warm) {
+    rig_operator(g, rw->x.get(), rw->wbuf.get());
+    hipLaunchKernelGGL(k_dense_residual, dim3(g.gridR), dim3(kBlock), 0, s, n3, rw->rhs.get(), rw->wbuf.get(), rw->b.get());
+    b = rw->b.get();
+  }
+  hipLaunchKernelGGL(k_ra_minv, dim3(g.gridR), dim3(kBlock), 0, s, n, rw->diag.get(), rw->minv.get());
+  CgVec v;
+  v.n = (int)n3;
+  v.N = n;
+  v.K = 0;
+  v.nb_update = std::min(kCgMaxBlocks, grid_for(n, kBlock));
+  const int gD = std::min(64, grid_for((size_t)n3, kBlock));
+  v.nb_apply = gD;
+  v.b = b;
+  v.x = warm ? rw->cx.get() : rw->x.get();
+  v.r = rw->cr.get();
+  v.z = rw->cz.get();
+  v.p = rw->cp.get();
+  v.s = rw->cs.get();
+  v.w = rw->cw.get();
+  v.minv = rw->minv.get();
+  v.vpart = ws->vpart.get();
+  v.dpart = ws->dpart.get();
+  v.scal = ws->cgsc.get();
+  v.st = ws->cgst.get();
+  auto run_cg = [&](double tol_pass) {
+    return cg_solve<3, false>(ctx, v, tol_pass, max_iter, [&](int it) {
+      hipLaunchKernelGGL(k_rig_ra_expand, dim3(g.gridI), dim3(kBlock), 0, s, g.r, v.z, rw->zimg.get(), v, it,
+                         tol_pass * tol_pass, 1);
+      dispatch_lpr(d.lpr, [&](auto L) {
+        hipLaunchKernelGGL((k_spmv<decltype(L)::value>), dim3(d.gridRow), dim3(kBlock), 0, s, d.N, ws->rowptr.get(),
+                           ws->nbr.get(), ws->inc_w.get(), ws->lap_diag_loc.get(), rw->zimg.get(), ws->wbuf.get());
+      });
+      rig_reduce<3>(g, ws->wbuf.get(), v.w);
+      hipLaunchKernelGGL(k_rig_ra_dot, dim3(gD), dim3(kBlock), 0, s, v);
+    });
+  };
+  long iters = run_cg(tol);
+  if (warm) hipLaunchKernelGGL(k_ra_add, dim3(g.gridR), dim3(kBlock), 0, s, n3, rw->x.get(), rw->cx.get(), rw->x.get());
+  const double* bref = b;
+  for (int pass = 0; pass < 3; ++pass) {  // true residual, correction solves (see pcg_solve)
+    rig_operator(g, rw->x.get(), rw->wbuf.get());
+    hipLaunchKernelGGL(k_dense_residual, dim3(g.gridR), dim3(kBlock), 0, s, n3, rw->rhs.get(), rw->wbuf.get(), rw->r.get());
+    hipLaunchKernelGGL(k_sumsq2, dim3(g.gridR), dim3(kBlock), 0, s, n3, rw->r.get(), bref, ws->part_misc.get());
+    hipLaunchKernelGGL((k_finalize<2>), dim3(1), dim3(kBlock), 0, s, ws->part_misc.get(), g.gridR, ws->scal.get() + 16);
+    GSFM_HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 200, ws->scal.get() + 16, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    GSFM_HIP_CHECK(hipStreamSynchronize(s));
+    const double rr = ctx->h_pinned[200], bb = ctx->h_pinned[201];
+    if (!(rr > tol * tol * bb) || !(bb > 0.0)) break;
+    const double tol_pass = std::min(0.1, std::max(1e-12, 0.5 * tol * std::sqrt(bb / rr)));
+    v.b = rw->r.get();
+    v.x = rw->cx.get();
+    iters += run_cg(tol_pass);
+    hipLaunchKernelGGL(k_ra_add, dim3(g.gridR), dim3(kBlock), 0, s, n3, rw->x.get(), rw->cx.get(), rw->x.get());
+  }
+  return (int)iters;
+}
+
+void rig_residuals(RigSolve& g, bool with_weights, int weight_type, double sigma2) {
+  RaDevice& d = *g.d;
+  RaWs* ws = d.ws;
+  hipStream_t s = d.ctx->stream;
+  hipLaunchKernelGGL(k_rig_ra_node_quat, dim3(g.gridI), dim3(kBlock), 0, s, g.r, g.rw->rotf.get(), g.rw->rotc.get(),
+                     ws->nq.get(), d.fixed, ws->fixed_rot0.get(), ws->res.get() + 3 * d.E);
+  hipLaunchKernelGGL(k_edge_residual, dim3(d.gridE), dim3(kBlock), 0, s, d.E, ws->ei.get(), ws->ej.get(), ws->eq.get(),
+                     ws->nq.get(), ws->res.get(), with_weights ? ws->wirls.get() : nullptr, weight_type, sigma2,
+                     ws->flags.get());
+}
+
+// frames: r <- Log(Exp(r) Exp(-step)), then the cam blocks from the UPDATED frames.  out = {mean |step| over the FRAMES
+// (gra.cc:758-772), |step|_2 over all unknowns, #NaN}
+void rig_update(RigSolve& g, double out[3]) {
+  RaDevice& d = *g.d;
+  RaWs* ws = d.ws;
+  RigRaWs* rw = g.rw;
+  hipStream_t s = d.ctx->stream;
+  const int gF = grid_for(g.r.N, kBlock);
+  hipLaunchKernelGGL(k_node_update, dim3(gF), dim3(kBlock), 0, s, g.r.N, rw->rotf.get(), rw->x.get(), ws->part_misc.get());
+  hipLaunchKernelGGL((k_finalize<3>), dim3(1), dim3(kBlock), 0, s, ws->part_misc.get(), gF, ws->scal.get());
+  if (g.r.C > 0) {
+    // |step|^2 and NaN count of the cam part (k_node_update on a scratch copy of the cam rotations: only its sums are used)
+    GSFM_HIP_CHECK(hipMemcpyAsync(rw->tmp_rot.get(), rw->rotc.get(), 3 * (size_t)g.r.C * sizeof(double), hipMemcpyDeviceToDevice, s));
+    const int gC = grid_for(g.r.C, kBlock);
+    hipLaunchKernelGGL(k_node_update, dim3(gC), dim3(kBlock), 0, s, g.r.C, rw->tmp_rot.get(), rw->x.get() + 3 * (size_t)g.r.N,
+                       ws->part_misc.get() + 3 * (size_t)gF);
+    hipLaunchKernelGGL((k_finalize<3>), dim3(1), dim3(kBlock), 0, s, ws->part_misc.get() + 3 * (size_t)gF, gC, ws->scal.get() + 3);
+    hipLaunchKernelGGL(k_rig_ra_cam_update, dim3(grid_for(g.r.C, 64)), dim3(64), 0, s, g.r, rw->rotf.get(), rw->rotc.get(),
+                       rw->x.get());
+  } else {
+    GSFM_HIP_CHECK(hipMemsetAsync(ws->scal.get() + 3, 0, 3 * sizeof(double), s));
+  }
+  GSFM_HIP_CHECK(hipMemcpyAsync(d.ctx->h_pinned + 64, ws->scal.get(), 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+  GSFM_HIP_CHECK(hipStreamSynchronize(s));
+  const double* h = d.ctx->h_pinned + 64;
+  out[0] = h[0] / g.r.N;
+  out[1] = std::sqrt(h[1] + h[4]);
+  out[2] = h[2] + h[5];
+}
+
+int ra_solve_rig_impl(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_options* opt, double* rot_inout,
+                      gsfm_report* rep) {
+  GSFM_REQUIRE(prob->image_frame && prob->image_cam, "RA: image tables missing");
+  GSFM_REQUIRE(prob->num_cams >= 0 && (prob->num_cams == 0 || prob->cam_rot_aa), "RA: cam blocks missing");
+  if (ctx->comm.world > 1) throw StatusError(GSFM_ERR_UNSUPPORTED, "RA: cam_from_rig unknowns are solved on one rank");
+  if (!opt->skip_initialization)
+    throw StatusError(GSFM_ERR_UNSUPPORTED,
+                      "RA: cam_from_rig unknowns need skip_initialization (initialise from the image-level spanning tree)");
+  const double t0 = now_seconds();
+  GSFM_HIP_CHECK(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const int mem = prob->mem;
+  const int N = prob->num_nodes, C = prob->num_cams;
+  int NI = prob->num_images;
+  const long E = prob->num_edges;
+  std::vector<int> h_imf, h_imc;
+  to_host(ctx, h_imf, prob->image_frame, (size_t)NI, mem);
+  to_host(ctx, h_imc, prob->image_cam, (size_t)NI, mem);
+  int fixed_img = -1;
+  for (int i = 0; i < NI; ++i) {
+    GSFM_REQUIRE(h_imf[i] >= 0 && h_imf[i] < N, "RA: image_frame out of range");
+    GSFM_REQUIRE(h_imc[i] >= -1 && h_imc[i] < C, "RA: image_cam out of range");
+    if (fixed_img < 0 && h_imf[i] == prob->fixed_node && h_imc[i] < 0) fixed_img = i;
+  }
+  if (fixed_img < 0) {  // the gauge frame has no image without a cam block: a virtual edge-less one carries the gauge rows
+    fixed_img = NI++;
+    h_imf.push_back(prob->fixed_node);
+    h_imc.push_back(-1);
+  }
+  // the image-level graph through the plain machinery: Jacobi-PCG structures only, no initialisation
+  gsfm_ra_problem ip = *prob;
+  ip.num_nodes = NI;
+  ip.fixed_node = fixed_img;
+  ip.num_images = 0;
+  gsfm_ra_options o2 = *opt;
+  o2.force_iterative = 1;
+  o2.skip_initialization = 1;
+  RaDevice d;
+  RaHostInit hi;
+  std::vector<double> zeros_h;
+  DevBuf<double> zeros_d;
+  const double* rot_img0 = nullptr;
+  if (mem == GSFM_MEM_DEVICE) {
+    GSFM_HIP_CHECK(hipMemsetAsync(zeros_d.ensure(3 * (size_t)NI), 0, 3 * (size_t)NI * sizeof(double), s));
+    rot_img0 = zeros_d.get();
+  } else {
+    zeros_h.assign(3 * (size_t)NI, 0.0);
+    rot_img0 = zeros_h.data();
+  }
+  setup_device(ctx, &ip, &o2, rot_img0, d, hi, /*allow_blockdense=*/false);
+  finish_init(ctx, &o2, d, hi);
+  RaWs* ws = d.ws;
+  if (!ctx->ra_rig_ws) {
+    ctx->ra_rig_ws = new RigRaWs();
+    ctx->ra_rig_ws_free = &RigRaWs::destroy;
+  }
+  RigRaWs* rw = static_cast<RigRaWs*>(ctx->ra_rig_ws);
+  // tables
+  std::vector<int> foff((size_t)N + 1, 0), fimg((size_t)NI), coff((size_t)C + 1, 0), cimg;
+  for (int i = 0; i < NI; ++i) {
+    foff[h_imf[i] + 1]++;
+    if (h_imc[i] >= 0) coff[h_imc[i] + 1]++;
+  }
+  for (int f = 0; f < N; ++f) foff[f + 1] += foff[f];
+  for (int c = 0; c < C; ++c) coff[c + 1] += coff[c];
+  cimg.resize((size_t)coff[C] + 1);
+  {
+    std::vector<int> fc(foff.begin(), foff.end() - 1), cc(coff.begin(), coff.end() - 1);
+    for (int i = 0; i < NI; ++i) {
+      fimg[fc[h_imf[i]]++] = i;
+      if (h_imc[i] >= 0) cimg[cc[h_imc[i]]++] = i;
+    }
+  }
+  auto up = [&](DevBuf<int>& b, const std::vector<int>& v) {
+    GSFM_HIP_CHECK(hipMemcpyAsync(b.ensure(v.size() + 1), v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, s));
+  };
+  up(rw->img_frame, h_imf);
+  up(rw->img_cam, h_imc);
+  up(rw->foff, foff);
+  up(rw->fimg, fimg);
+  up(rw->coff, coff);
+  up(rw->cimg, cimg);
+  const int nred = N + C;
+  for (DevBuf<double>* b : {&rw->rhs, &rw->x, &rw->r, &rw->wbuf, &rw->gat_s, &rw->gat_t, &rw->b, &rw->cx, &rw->cr, &rw->cz,
+                            &rw->cp, &rw->cs})
+    b->ensure(3 * (size_t)nred);
+  rw->cw.ensure(3 * (size_t)nred + 2);
+  rw->diag.ensure(nred);
+  rw->minv.ensure(9 * (size_t)nred);
+  rw->zimg.ensure(3 * (size_t)NI);
+  rw->tmp_rot.ensure(3 * (size_t)std::max(C, 1));
+  copy_in(ctx, rw->rotf.ensure(3 * (size_t)N), rot_inout, 3 * (size_t)N, mem);
+  rw->rotc.ensure(3 * (size_t)std::max(C, 1));
+  if (C > 0)
+    GSFM_HIP_CHECK(hipMemcpyAsync(rw->rotc.get(), prob->cam_rot_aa, 3 * (size_t)C * sizeof(double), hipMemcpyHostToDevice, s));
+  // the gauge frame is held at its initial rotation (gra.cc:248-257)
+  GSFM_HIP_CHECK(hipMemcpyAsync(ws->fixed_rot0.get(), rw->rotf.get() + 3 * (size_t)prob->fixed_node, 3 * sizeof(double),
+                                hipMemcpyDeviceToDevice, s));
+  GSFM_HIP_CHECK(hipStreamSynchronize(s));  // host tables go out of scope below
+  RigSolve g;
+  g.d = &d;
+  g.rw = rw;
+  g.r = RigRa{N, C, NI, rw->img_frame.get(), rw->img_cam.get(), rw->foff.get(), rw->fimg.get(), rw->coff.get(), rw->cimg.get()};
+  g.nred = nred;
+  g.gridRed = (N + kBlock - 1) / kBlock + C;
+  g.gridI = grid_for(NI, kBlock);
+  g.gridR = grid_for(nred, kBlock);
+  const double t1 = now_seconds();
+  long lin_iters = 0;
+  int it_l1 = 0, it_irls = 0;
+  double last_step = 0.0;
+  double upd[3];
+  const size_t n3 = 3 * (size_t)nred;
+
+  // ---------------- L1 stage (gra.cc:479-541)
+  if (opt->max_num_l1_iterations > 0) {
+    const size_t rows3 = 3 * (size_t)(E + 1);
+    ws->z.ensure(rows3);
+    ws->u.ensure(rows3);
+    ws->dz.ensure(rows3);
+    launch_gather<GATHER_L1W>(d);
+    rig_reduce<1>(g, ws->lap_diag.get(), rw->diag.get());
+    double last_norm = 0.0, curr_norm = 0.0;
+    rig_residuals(g, false, 0, 0.0);
+    const double rows_total = 3.0 * (double)E + 3.0;
+    for (int it = 0; it < opt->max_num_l1_iterations; ++it) {
+      last_norm = curr_norm;
+      GSFM_HIP_CHECK(hipMemsetAsync(ws->z.get(), 0, rows3 * sizeof(double), s));
+      GSFM_HIP_CHECK(hipMemsetAsync(ws->u.get(), 0, rows3 * sizeof(double), s));
+      GSFM_HIP_CHECK(hipMemsetAsync(ws->dz.get(), 0, rows3 * sizeof(double), s));
+      GSFM_HIP_CHECK(hipMemsetAsync(rw->x.get(), 0, n3 * sizeof(double), s));
+      launch_gather<GATHER_L1RHS>(d);
+      rig_reduce<3>(g, ws->rhs.get(), rw->rhs.get());
+      for (int a = 0; a < opt->l1_admm_max_num_iterations; ++a) {
+        lin_iters += rig_pcg_solve(g, a > 0, a > 0 ? opt->pcg_relative_tolerance_admm : opt->pcg_relative_tolerance,
+                                   opt->pcg_max_iterations);
+        rig_expand(g, rw->x.get(), ws->x.get());  // A x per edge from the image-level step
+        hipLaunchKernelGGL(k_admm_edge, dim3(d.gridE), dim3(kBlock), 0, s, E, d.has_gauge, d.fixed, ws->ei.get(), ws->ej.get(),
+                           d.ew, ws->res.get(), ws->x.get(), ws->z.get(), ws->u.get(), ws->dz.get(), opt->l1_admm_alpha,
+                           1.0 / opt->l1_admm_rho, ws->part_misc.get(), nullptr);
+        hipLaunchKernelGGL((k_finalize<4>), dim3(1), dim3(kBlock), 0, s, ws->part_misc.get(), d.gridE, ws->scal.get());
+        launch_gather<GATHER_L1RHS>(d);
+        rig_reduce<3>(g, ws->rhs.get(), rw->rhs.get());
+        rig_reduce<3>(g, ws->gat_s.get(), rw->gat_s.get());
+        rig_reduce<3>(g, ws->gat_t.get(), rw->gat_t.get());
+        hipLaunchKernelGGL(k_sumsq2, dim3(g.gridR), dim3(kBlock), 0, s, (long)n3, rw->gat_s.get(), rw->gat_t.get(),
+                           ws->part_misc.get());
+        hipLaunchKernelGGL((k_finalize<2>), dim3(1), dim3(kBlock), 0, s, ws->part_misc.get(), g.gridR, ws->scal.get() + 4);
+        GSFM_HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 16, ws->scal.get(), 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+        GSFM_HIP_CHECK(hipStreamSynchronize(s));
+        const double* h = ctx->h_pinned + 16;
+        const double r_norm = std::sqrt(h[0]), Ax_norm = std::sqrt(h[1]), z_norm = std::sqrt(h[2]), b_norm = std::sqrt(h[3]);
+        const double rho = opt->l1_admm_rho;
+        const double s_norm = rho * std::sqrt(h[4]);
+        const double dual_norm = rho * std::sqrt(h[5]);
+        const double primal_eps = std::sqrt(rows_total) * opt->l1_admm_absolute_tolerance +
+                                  opt->l1_admm_relative_tolerance * std::max({Ax_norm, z_norm, b_norm});
+        const double dual_eps = std::sqrt((double)n3) * opt->l1_admm_absolute_tolerance + opt->l1_admm_relative_tolerance * dual_norm;
+        if (r_norm < primal_eps && s_norm < dual_eps) break;
+      }
+      rig_update(g, upd);
+      it_l1 = it + 1;
+      if (upd[2] > 0) {
+        if (rep) rep->iterations_l1 = it_l1;
+        return GSFM_ERR_NUMERICAL;
+      }
+      curr_norm = upd[1];
+      last_step = upd[0];
+      rig_residuals(g, false, 0, 0.0);
+      if (upd[0] < opt->l1_step_convergence_threshold || std::fabs(last_norm - curr_norm) < 1e-12) break;
+    }
+  }
+
+  // ---------------- IRLS stage (gra.cc:543-625)
+  if (opt->max_num_irls_iterations > 0) {
+    const double sigma = opt->irls_loss_parameter_sigma * M_PI / 180.0;
+    rig_residuals(g, true, opt->weight_type, sigma * sigma);
+    for (int it = 0; it < opt->max_num_irls_iterations; ++it) {
+      if (read_nan_flag(d)) {
+        if (rep) rep->iterations_irls = it_irls;
+        return GSFM_ERR_NUMERICAL;
+      }
+      launch_gather<GATHER_IRLS>(d);
+      rig_reduce<3>(g, ws->rhs.get(), rw->rhs.get());
+      rig_reduce<1>(g, ws->lap_diag.get(), rw->diag.get());
+      lin_iters += rig_pcg_solve(g, false, opt->pcg_relative_tolerance, opt->pcg_max_iterations);
+      rig_update(g, upd);
+      it_irls = it + 1;
+      last_step = upd[0];
+      rig_residuals(g, true, opt->weight_type, sigma * sigma);
+      if (upd[0] < opt->irls_step_convergence_threshold) break;
+    }
+  }
+  copy_out(ctx, rot_inout, rw->rotf.get(), 3 * (size_t)N, mem);
+  if (C > 0)
+    GSFM_HIP_CHECK(hipMemcpyAsync(prob->cam_rot_aa, rw->rotc.get(), 3 * (size_t)C * sizeof(double), hipMemcpyDeviceToHost, s));
   GSFM_HIP_CHECK(hipStreamSynchronize(s));
   const double t2 = now_seconds();
   if (rep) {

@@ -198,9 +198,20 @@ def ra_solve(p: RaProblem, options: Optional[RotationEstimatorOptions] = None, c
         rot_inout = p.node_aa0.copy() if isinstance(p.node_aa0, np.ndarray) else p.node_aa0.clone()
     rot_inout = _h(rot_inout, np.float64)
     assert _mem_of(rot_inout) == c.mem
+    cams = None
+    if getattr(p, "image_frame", None) is not None:  # cam_from_rig rotations among the unknowns: nodes are images
+        imf, imc = _h(p.image_frame, np.int32), _h(p.image_cam, np.int32)
+        assert _mem_of(imf, imc) == c.mem
+        keep += [imf, imc]
+        cams = np.array(p.cam_aa0, dtype=np.float64, order="C", copy=True).reshape(-1, 3)  # host table, in/out
+        c.num_images, c.image_frame, c.image_cam = int(imf.shape[0]), _lib.ptr(imf), _lib.ptr(imc)
+        c.num_cams, c.cam_rot_aa = int(cams.shape[0]), _lib.ptr(cams)
     rep = _lib.Report()
     rc = ctx.lib.gsfm_ra_solve(ctx.handle, C.byref(c), C.byref(opt), _lib.ptr(rot_inout), C.byref(rep))
-    return rc, rot_inout, rep.as_dict()
+    report = rep.as_dict()
+    if cams is not None:
+        report["cam_rot_aa"] = cams
+    return rc, rot_inout, report
 
 
 def ra_residuals(p: RaProblem, rot_aa: np.ndarray, options: Optional[RotationEstimatorOptions] = None, ctx=None):
@@ -300,6 +311,77 @@ def ra_solve_known_rigs(num_frames: int, image_frame, image_cam_from_rig, pair_i
                   w[keep], ninl[keep], aa0, int(fixed_frame))
     o1 = RotationEstimatorOptions(**{**vars(opt), "skip_initialization": True})
     return ra_solve(p, o1, ctx=ctx)
+
+
+def convert_rotations_from_image_to_rig(R_img: np.ndarray, image_frame, image_cam, num_frames: int, num_cams: int):
+    """ConvertRotationsFromImageToRig (rotation_initializer.cc:7-125) in the flat representation, where an image without
+    a cam block carries a rig-level rotation already (reference sensor, or calibrated sensor folded by the caller):
+      * cam block c: quaternion average over its images of R_image * R_ref(frame)^T, R_ref = the frame's first image
+        without a block; frames that have none are skipped (:26-73);
+      * frame f: quaternion average over its images of R_image (no block) or R_cam^T R_image (:86-121).
+    Returns (R_frame [F,3,3], R_cam [C,3,3]); frames / blocks without images stay the identity."""
+    from . import so3
+
+    imf = np.asarray(image_frame, np.int64)
+    imc = np.asarray(image_cam, np.int64)
+    R_frame = np.tile(np.eye(3), (num_frames, 1, 1))
+    R_cam = np.tile(np.eye(3), (num_cams, 1, 1))
+    ref = -np.ones(num_frames, np.int64)
+    for i in range(imf.shape[0] - 1, -1, -1):
+        if imc[i] < 0:
+            ref[imf[i]] = i
+    for c in range(num_cams):
+        sel = np.nonzero((imc == c) & (ref[imf] >= 0))[0]
+        if sel.size:
+            qs = so3.rotmat_to_quat(R_img[sel] @ np.transpose(R_img[ref[imf[sel]]], (0, 2, 1)))
+            R_cam[c] = so3.quat_to_rotmat(average_quaternions(qs)[None])[0]
+    for f in range(num_frames):
+        sel = np.nonzero(imf == f)[0]
+        if sel.size:
+            Rr = np.where((imc[sel] >= 0)[:, None, None], np.transpose(R_cam[np.maximum(imc[sel], 0)], (0, 2, 1)) @ R_img[sel],
+                          R_img[sel])
+            R_frame[f] = so3.quat_to_rotmat(average_quaternions(so3.rotmat_to_quat(Rr))[None])[0]
+    return R_frame, R_cam
+
+
+def ra_solve_rigs(num_frames: int, image_frame, image_cam, num_cams: int, pair_i, pair_j, pair_q, pair_ninl,
+                  pair_weight=None, options: Optional[RotationEstimatorOptions] = None, ctx=None, fixed_frame: int = 0,
+                  frame_aa0=None, cam_aa0=None):
+    """RotationEstimator::EstimateRotations for rigs whose cam_from_rig ROTATIONS are (partly) unknown
+    (gra.cc:40-85 with the cam blocks of :173-191): image pairs as edges — relative rotations of calibrated sensors
+    already folded (gra.cc:306-309), pairs inside one frame between two images without a block dropped (:300-304) —,
+
+      * initialisation (unless skip_initialization): maximum spanning tree over the images (gra.cc:87-138, a
+        zero-iteration gsfm_ra_solve), then convert_rotations_from_image_to_rig;
+      * the solve: gsfm_ra_solve with the image tables (frames + cam blocks as unknowns).
+
+    Returns (status, frame_aa [F,3], cam_aa [C,3], report)."""
+    from . import so3
+
+    ctx = ctx or default_context()
+    opt = options or RotationEstimatorOptions()
+    imf = np.asarray(image_frame, np.int32)
+    imc = np.asarray(image_cam, np.int32)
+    pi, pj = np.asarray(pair_i, np.int32), np.asarray(pair_j, np.int32)
+    E = pi.shape[0]
+    w = np.ones(E) if pair_weight is None else np.asarray(pair_weight, np.float64)
+    ninl = np.asarray(pair_ninl, np.int32)
+    q = np.asarray(pair_q, np.float64)
+    aa_f = np.zeros((num_frames, 3)) if frame_aa0 is None else np.array(frame_aa0, np.float64)
+    aa_c = np.zeros((num_cams, 3)) if cam_aa0 is None else np.array(cam_aa0, np.float64)
+    if not opt.skip_initialization:
+        img = RaProblem(int(imf.shape[0]), pi, pj, q, w, ninl, np.zeros((imf.shape[0], 3)), 0)
+        o0 = RotationEstimatorOptions(**{**vars(opt), "max_num_l1_iterations": 0, "max_num_irls_iterations": 0})
+        rc, rot_img, _ = ra_solve(img, o0, ctx=ctx)
+        if rc != 0:
+            return rc, aa_f, aa_c, {}
+        R_f, R_c = convert_rotations_from_image_to_rig(so3.aa_to_rotmat(rot_img), imf, imc, num_frames, num_cams)
+        aa_f = so3.quat_to_aa(so3.rotmat_to_quat(R_f))
+        aa_c = so3.quat_to_aa(so3.rotmat_to_quat(R_c)) if num_cams else np.zeros((0, 3))
+    p = RaProblem(int(num_frames), pi, pj, q, w, ninl, aa_f, int(fixed_frame), image_frame=imf, image_cam=imc, cam_aa0=aa_c)
+    o1 = RotationEstimatorOptions(**{**vars(opt), "skip_initialization": True})
+    rc, rot, rep = ra_solve(p, o1, ctx=ctx)
+    return rc, rot, rep.get("cam_rot_aa", aa_c), rep
 
 
 def gp_solve(p: GpProblem, options: Optional[GlobalPositionerOptions] = None, ctx=None):

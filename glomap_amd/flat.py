@@ -37,6 +37,12 @@ class RaProblem:
     fixed_node: int = 0
     gt_R: Optional[np.ndarray] = None  # [N,3,3] ground truth (tests only)
     outlier: Optional[np.ndarray] = None  # [E] bool (tests only)
+    # Rigs with cam_from_rig rotations among the unknowns (gra.cc:173-191, 396-446): when given, edge_i / edge_j index
+    # IMAGES, num_nodes / node_aa0 / fixed_node are the FRAMES, image_cam names the image's cam block (-1: reference or
+    # calibrated sensor, folded into edge_q by the caller), cam_aa0 [C,3] holds the blocks' start values
+    image_frame: Optional[np.ndarray] = None  # [I] int32
+    image_cam: Optional[np.ndarray] = None  # [I] int32
+    cam_aa0: Optional[np.ndarray] = None  # [C,3] f64
 
     @property
     def num_edges(self) -> int:

@@ -191,6 +191,21 @@ typedef struct gsfm_ra_problem {
   const double* edge_weight;/* [E] ImagePair::weight, may be NULL unless use_weight */
   const int32_t* edge_ninl; /* [E] inliers.size() (MST weight, tree.cc:99,124); may be NULL if skip_initialization */
   int32_t fixed_node;       /* gauge node (reference: first registered frame in map order, gra.cc:248-257) */
+  /* Rigs with cam_from_rig ROTATIONS among the unknowns (global_rotation_averaging.cc:173-191, 396-446, 646-693, 718-739).
+   * num_images = 0 (and NULL pointers): every node is a frame, as above.  num_images = I > 0: edge_i / edge_j index
+   * IMAGES, num_nodes / rot_aa_inout / fixed_node are the N FRAMES, and every image carries
+   *   image_frame[i]  its frame,
+   *   image_cam[i]    the block (0..num_cams-1) of its sensor's cam_from_rig rotation, or -1 for the reference sensor and
+   *                   for calibrated sensors, whose cam_from_rig the caller folds into edge_q (gra.cc:306-309).
+   * cam_from_world(i) = Exp(cam) Exp(frame); an edge's rows carry -1 / +1 at the frame AND cam columns of its two
+   * images; the cam blocks are updated by the quaternion average of gra.cc:676-690.  cam_rot_aa [C][3] (host memory) is
+   * in/out like rot_aa_inout.  Needs skip_initialization (the spanning-tree start and ConvertRotationsFromImageToRig,
+   * rotation_initializer.cc:7-125, run on the image-level graph first: see the adapter), one rank, use_gravity = 0. */
+  int32_t num_images;
+  const int32_t* image_frame; /* [I] */
+  const int32_t* image_cam;   /* [I] */
+  int32_t num_cams;           /* C */
+  double* cam_rot_aa;         /* [C][3] host, in/out */
 } gsfm_ra_problem;
 
 /* rot_aa_inout: [N][3] angle-axis of rig_from_world; in = initial estimate, out = result

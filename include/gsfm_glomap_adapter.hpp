@@ -289,6 +289,13 @@ class RotationEstimator {
       if (fr.is_registered) fidx.Add(fid);  // gra.cc:193-227; first one = gauge (gra.cc:248-257)
     const int N = static_cast<int>(fidx.ids.size());
     if (N == 0) return false;
+    if (rigged) {  // sensors whose cam_from_rig is to be estimated (no value, or NaN translation: gra.cc:173-191)
+      for (auto& [id, im] : images) {
+        double cfr[7];
+        if (im.frame_ptr != nullptr && im.IsRegistered() && detail::CamFromRigState(im, rigs, cfr) != 0)
+          return EstimateWithCamBlocks(ctx, view_graph, rigs, frames, images, fidx);
+      }
+    }
     std::vector<int32_t> ei, ej, en;
     std::vector<double> eq, ew;
     // image-level copy of the view graph (calibrated rigs only): the spanning-tree initialisation runs over IMAGES
@@ -427,6 +434,194 @@ class RotationEstimator {
   }
 
  private:
+  struct QuatView {
+    double w_, x_, y_, z_;
+    double w() const { return w_; }
+    double x() const { return x_; }
+    double y() const { return y_; }
+    double z() const { return z_; }
+  };
+
+  // cam_from_rig ROTATIONS among the unknowns (gra.cc:173-191, 396-446, 646-690): the view graph goes to the library
+  // image by image, each image with its frame and — for the sensors to estimate — its cam block (one per camera id,
+  // like camera_id_to_idx_); calibrated sensors are folded into the relative rotations (gra.cc:306-309).
+  bool EstimateWithCamBlocks(gsfm_ctx* ctx, const glomap::ViewGraph& view_graph, std::unordered_map<rig_t, glomap::Rig>& rigs,
+                             std::unordered_map<frame_t, glomap::Frame>& frames,
+                             std::unordered_map<image_t, glomap::Image>& images, detail::FrameIndex& fidx) {
+    const int N = static_cast<int>(fidx.ids.size());
+    std::unordered_map<image_t, int> img_of;
+    std::vector<image_t> img_ids;
+    std::vector<int32_t> image_frame, image_cam, ii, ij, in_;
+    std::vector<uint8_t> image_is_ref;
+    std::vector<std::array<double, 4>> image_fold;  // known cam_from_rig rotation of the image (identity otherwise)
+    std::vector<double> iq, iw;
+    std::unordered_map<camera_t, int> cam_of;
+    std::vector<camera_t> cam_ids;
+    std::vector<rig_t> cam_rig;
+    std::vector<uint8_t> cam_has_start;
+    std::vector<double> cam_rot;  // [C][3]
+    auto image_index = [&](image_t id) {
+      auto it = img_of.find(id);
+      if (it != img_of.end()) return it->second;
+      const auto& im = images.at(id);
+      double cfr[7];
+      const int state = detail::CamFromRigState(im, rigs, cfr);
+      int block = -1;
+      if (state != 0) {
+        auto ct = cam_of.find(im.camera_id);
+        if (ct == cam_of.end()) {
+          ct = cam_of.emplace(im.camera_id, static_cast<int>(cam_ids.size())).first;
+          cam_ids.push_back(im.camera_id);
+          cam_rig.push_back(im.frame_ptr->RigId());
+          cam_has_start.push_back(state == 1 ? 1 : 0);
+          double aa[3] = {0.0, 0.0, 0.0};  // gra.cc:231-242: the stored rotation when there is one, else zero
+          if (state == 1) detail::QuatToAngleAxis(QuatView{cfr[0], cfr[1], cfr[2], cfr[3]}, aa);
+          cam_rot.insert(cam_rot.end(), aa, aa + 3);
+        }
+        block = ct->second;
+      }
+      const int idx = static_cast<int>(img_ids.size());
+      img_of.emplace(id, idx);
+      img_ids.push_back(id);
+      image_frame.push_back(fidx.of.at(im.frame_id));
+      image_cam.push_back(block);
+      image_is_ref.push_back(im.HasTrivialFrame() ? 1 : 0);
+      image_fold.push_back(state == 0 ? std::array<double, 4>{cfr[0], cfr[1], cfr[2], cfr[3]} : std::array<double, 4>{1, 0, 0, 0});
+      return idx;
+    };
+    for (const auto& [pid, pair] : view_graph.image_pairs) {
+      if (!pair.is_valid) continue;
+      const auto& i1 = images.at(pair.image_id1);
+      const auto& i2 = images.at(pair.image_id2);
+      if (!i1.IsRegistered() || !i2.IsRegistered()) continue;
+      const int a = image_index(pair.image_id1), b = image_index(pair.image_id2);
+      if (image_frame[a] == image_frame[b] && image_cam[a] < 0 && image_cam[b] < 0) continue;  // gra.cc:300-304
+      double q21[4], tmp[4], qrel[4];
+      detail::QuatWxyz(pair.cam2_from_cam1.rotation, q21);
+      const double c2inv[4] = {image_fold[b][0], -image_fold[b][1], -image_fold[b][2], -image_fold[b][3]};
+      detail::QuatMul(c2inv, q21, tmp);
+      detail::QuatMul(tmp, image_fold[a].data(), qrel);  // gra.cc:306-309
+      ii.push_back(a);
+      ij.push_back(b);
+      iq.insert(iq.end(), qrel, qrel + 4);
+      iw.push_back(pair.weight);
+      in_.push_back(static_cast<int32_t>(pair.inliers.size()));
+    }
+    const int NI = static_cast<int>(img_ids.size()), C = static_cast<int>(cam_ids.size());
+    if (NI == 0) return false;
+    std::vector<double> rot(3 * static_cast<size_t>(N));
+    for (int n = 0; n < N; ++n) {
+      auto& fr = frames.at(fidx.ids[n]);
+      if (!fr.HasPose()) fr.SetRigFromWorld(glomap::Rigid3d());  // gra.cc:219-222
+      detail::QuatToAngleAxis(fr.RigFromWorld().rotation, &rot[3 * n]);
+    }
+    gsfm_ra_problem p{};
+    p.mem = GSFM_MEM_HOST;
+    p.num_edges = static_cast<int64_t>(ii.size());
+    p.edge_i = ii.data();
+    p.edge_j = ij.data();
+    p.edge_q = iq.data();
+    p.edge_weight = iw.data();
+    p.edge_ninl = in_.data();
+    if (!options_.skip_initialization) {
+      // InitializeFromMaximumSpanningTree over the images (gra.cc:87-138), a zero-iteration solve of the image graph ...
+      std::vector<double> irot(3 * static_cast<size_t>(NI), 0.0);
+      gsfm_ra_options o0;
+      gsfm_ra_options_default(&o0);
+      o0.max_num_l1_iterations = 0;
+      o0.max_num_irls_iterations = 0;
+      p.num_nodes = NI;
+      p.fixed_node = 0;
+      gsfm_report r0;
+      if (gsfm_ra_solve(ctx, &p, &o0, irot.data(), &r0) != GSFM_OK) return false;
+      // ... then ConvertRotationsFromImageToRig (rotation_initializer.cc:7-125).  Images without a block carry rig-level
+      // rotations here (their cam_from_rig is folded into the edges).
+      std::vector<std::array<double, 4>> qimg(static_cast<size_t>(NI));
+      for (int i = 0; i < NI; ++i) detail::AngleAxisToQuatWxyz(&irot[3 * i], qimg[i].data());
+      std::vector<int> ref(static_cast<size_t>(N), -1);
+      for (int i = NI - 1; i >= 0; --i)
+        if (image_is_ref[i]) ref[image_frame[i]] = i;
+      auto push_aligned = [](std::vector<std::array<double, 4>>& list, const double* q) {
+        double s = 1.0;
+        if (!list.empty() && list[0][0] * q[0] + list[0][1] * q[1] + list[0][2] * q[2] + list[0][3] * q[3] < 0.0) s = -1.0;
+        list.push_back({s * q[0], s * q[1], s * q[2], s * q[3]});
+      };
+      std::vector<std::array<double, 4>> qcam(static_cast<size_t>(C), {1, 0, 0, 0});
+      for (int c = 0; c < C; ++c) {
+        if (cam_has_start[c]) {  // a stored rotation is kept (:52-57 skips sensors that have a value)
+          detail::AngleAxisToQuatWxyz(&cam_rot[3 * c], qcam[c].data());
+          continue;
+        }
+        std::vector<std::array<double, 4>> list;
+        for (int i = 0; i < NI; ++i) {
+          if (image_cam[i] != c || ref[image_frame[i]] < 0) continue;
+          const auto& qr = qimg[ref[image_frame[i]]];
+          const double rinv[4] = {qr[0], -qr[1], -qr[2], -qr[3]};
+          double q[4];
+          detail::QuatMul(qimg[i].data(), rinv, q);  // cam_from_ref_cam, :66-72
+          push_aligned(list, q);
+        }
+        if (list.empty()) continue;
+        detail::AverageQuaternions(list, qcam[c].data());
+        detail::QuatToAngleAxis(QuatView{qcam[c][0], qcam[c][1], qcam[c][2], qcam[c][3]}, &cam_rot[3 * c]);
+      }
+      std::vector<std::vector<std::array<double, 4>>> per_frame(static_cast<size_t>(N));
+      for (int i = 0; i < NI; ++i) {
+        double q[4] = {qimg[i][0], qimg[i][1], qimg[i][2], qimg[i][3]};
+        if (image_cam[i] >= 0) {
+          const auto& qc = qcam[image_cam[i]];
+          const double cinv[4] = {qc[0], -qc[1], -qc[2], -qc[3]};
+          detail::QuatMul(cinv, qimg[i].data(), q);  // cam_from_rig^-1 * cam_from_world, :109-111
+        }
+        push_aligned(per_frame[image_frame[i]], q);
+      }
+      for (int n = 0; n < N; ++n) {
+        if (per_frame[n].empty()) continue;
+        double qa[4];
+        detail::AverageQuaternions(per_frame[n], qa);
+        detail::QuatToAngleAxis(QuatView{qa[0], qa[1], qa[2], qa[3]}, &rot[3 * n]);
+      }
+    }
+    gsfm_ra_options o;
+    gsfm_ra_options_default(&o);
+    o.max_num_l1_iterations = options_.max_num_l1_iterations;
+    o.l1_step_convergence_threshold = options_.l1_step_convergence_threshold;
+    o.max_num_irls_iterations = options_.max_num_irls_iterations;
+    o.irls_step_convergence_threshold = options_.irls_step_convergence_threshold;
+    o.irls_loss_parameter_sigma = options_.irls_loss_parameter_sigma;
+    o.weight_type = static_cast<int>(options_.weight_type);
+    o.skip_initialization = 1;
+    o.use_weight = options_.use_weight;
+    p.num_nodes = N;
+    p.fixed_node = 0;
+    p.num_images = NI;
+    p.image_frame = image_frame.data();
+    p.image_cam = image_cam.data();
+    p.num_cams = C;
+    p.cam_rot_aa = cam_rot.data();
+    gsfm_report rep;
+    if (gsfm_ra_solve(ctx, &p, &o, rot.data(), &rep) != GSFM_OK) return false;
+    for (int n = 0; n < N; ++n) {  // ConvertResults (gra.cc:774-799)
+      double q[4];
+      detail::AngleAxisToQuatWxyz(&rot[3 * n], q);
+      auto& fr = frames.at(fidx.ids[n]);
+      auto pose = fr.RigFromWorld();
+      pose.rotation = decltype(pose.rotation)(q[0], q[1], q[2], q[3]);
+      pose.translation = decltype(pose.translation)(0.0, 0.0, 0.0);
+      fr.SetRigFromWorld(pose);
+    }
+    const double nan = std::nan("");
+    for (int c = 0; c < C; ++c) {  // gra.cc:801-815: rotation set, translation NaN ("no translation yet")
+      double q[4];
+      detail::AngleAxisToQuatWxyz(&cam_rot[3 * c], q);
+      glomap::Rigid3d cfr;
+      cfr.rotation = decltype(cfr.rotation)(q[0], q[1], q[2], q[3]);
+      cfr.translation = decltype(cfr.translation)(nan, nan, nan);
+      rigs.at(cam_rig[c]).SetSensorFromRig(glomap::sensor_t(glomap::SensorType::CAMERA, cam_ids[c]), cfr);
+    }
+    return true;
+  }
+
   const glomap::RotationEstimatorOptions& options_;  // reference keeps a reference too (global_rotation_averaging.h:140)
 };
 

@@ -275,3 +275,129 @@ def estimate_rotations(
             if avg < opt.irls_step_convergence_threshold:
                 break
     return True, rot
+
+
+# ------------------------------------------------------------------------------------------
+# Rigs with unknown cam_from_rig rotations (gra.cc:173-191, 396-446, 646-693, 718-739)
+# ------------------------------------------------------------------------------------------
+def average_quaternions(q):
+    """colmap::AverageQuaternions with unit weights: principal eigenvector of sum q q^T (sign-free)."""
+    q = np.asarray(q, dtype=np.float64)
+    w, v = np.linalg.eigh(q.T @ q)
+    return v[:, -1]
+
+
+def estimate_rotations_rig(num_frames, num_cams, image_frame, image_cam, edge_i, edge_j, edge_q, edge_weight, frame_aa0,
+                           cam_aa0, fixed_frame=0, options: RotationEstimatorOptions | None = None,
+                           trace: RaTrace | None = None):
+    """RotationEstimator::EstimateRotations with cam_from_rig rotations among the unknowns, skip_initialization = true
+    (the spanning-tree start and ConvertRotationsFromImageToRig are the caller's, rotation_averager.cc:66-172).
+
+    Nodes of the view graph are IMAGES: image i belongs to frame image_frame[i] and, when its sensor's cam_from_rig is to be
+    estimated, to block image_cam[i] (else -1: reference sensor, or a calibrated sensor whose cam_from_rig the caller has
+    folded into the relative rotations, gra.cc:306-309).  cam_from_world(i) = Exp(cam) Exp(frame) (gra.cc:729-738); the
+    row of an edge carries -1 / +1 at the frame columns and at the cam columns of its two images (gra.cc:396-446; equal
+    columns cancel).  Unknowns: [frames | cams]; gauge rows on `fixed_frame`.  Returns (ok, frame_aa [N,3], cam_aa [C,3])."""
+    opt = options or RotationEstimatorOptions()
+    N, C = int(num_frames), int(num_cams)
+    imf = np.asarray(image_frame, dtype=np.int64)
+    imc = np.asarray(image_cam, dtype=np.int64)
+    I = imf.shape[0]
+    edge_i = np.asarray(edge_i, dtype=np.int64)
+    edge_j = np.asarray(edge_j, dtype=np.int64)
+    edge_R = so3.quat_wxyz_to_rotmat(np.asarray(edge_q, dtype=np.float64))
+    E = edge_i.shape[0]
+    rot_f = np.array(frame_aa0, dtype=np.float64, copy=True).reshape(N, 3)
+    rot_c = np.array(cam_aa0, dtype=np.float64, copy=True).reshape(C, 3)
+    fixed_rot = rot_f[fixed_frame].copy()
+
+    # V: image tangent = frame tangent + cam tangent
+    has = imc >= 0
+    Vs = sp.csr_matrix((np.ones(I + int(has.sum())), (np.concatenate([np.arange(I), np.arange(I)[has]]),
+                                                      np.concatenate([imf, N + imc[has]]))), shape=(I, N + C))
+    V3 = sp.kron(Vs, sp.eye(3), format="csr")
+    A_img = setup_linear_system(I, edge_i, edge_j, 0)[: 3 * E]
+    gauge = sp.csr_matrix((np.ones(3), (np.arange(3), 3 * fixed_frame + np.arange(3))), shape=(3, 3 * (N + C)))
+    A = sp.vstack([A_img @ V3, gauge]).tocsr()
+    A.eliminate_zeros()
+    if opt.use_weight:
+        ew = np.where(np.asarray(edge_weight) >= 0, edge_weight, 1.0)
+        weights = np.concatenate([np.repeat(ew, 3), np.ones(3)])
+    else:
+        weights = np.ones(3 * E + 3)
+    cam_images = [np.nonzero(imc == c)[0] for c in range(C)]
+
+    def residuals(rf, rc):
+        Rf, Rc = so3.exp_aa(rf), so3.exp_aa(rc)
+        Ri = Rf[imf].copy()
+        Ri[has] = Rc[imc[has]] @ Ri[has]  # gra.cc:729-738
+        M = np.transpose(Ri[edge_j], (0, 2, 1)) @ edge_R @ Ri[edge_i]
+        b = -so3.log_rot(M)
+        g = so3.log_rot(so3.exp_aa(fixed_rot).T @ Rf[fixed_frame])
+        return np.concatenate([b.reshape(-1), g])
+
+    def update(rf, rc, step):
+        sf, sc = step[:N], step[N:]
+        rf = so3.log_rot(so3.exp_aa(rf) @ so3.exp_aa(-sf))  # gra.cc:632-645
+        Rf = so3.exp_aa(rf)  # the UPDATED frames enter the cam update (gra.cc:651-671)
+        rc_new = rc.copy()
+        for c in range(C):
+            if cam_images[c].shape[0] == 0:
+                continue
+            R_ori = so3.exp_aa(rc[c][None])[0]
+            R_upd = so3.exp_aa(-sc[c][None])[0]
+            Rs = Rf[imf[cam_images[c]]]
+            qs = so3.rotmat_to_quat_eigen(R_ori @ Rs @ R_upd @ np.transpose(Rs, (0, 2, 1)))  # gra.cc:676-686
+            rc_new[c] = so3.log_rot(so3.quat_wxyz_to_rotmat(average_quaternions(qs)[None]))[0]
+        return rf, rc_new
+
+    def avg_step(step):  # frames only, over the number of frames (gra.cc:758-772)
+        return float(np.linalg.norm(step[:N], axis=1).sum() / N)
+
+    if opt.max_num_l1_iterations > 0:
+        l1 = LeastAbsoluteDeviationSolver(sp.diags(weights) @ A, opt)
+        last_norm = curr_norm = 0.0
+        b = residuals(rot_f, rot_c)
+        for it in range(opt.max_num_l1_iterations):
+            last_norm = curr_norm
+            step = l1.solve(weights * b)
+            if np.isnan(step).any():
+                return False, rot_f, rot_c
+            curr_norm = float(np.linalg.norm(step))
+            step3 = step.reshape(-1, 3)
+            rot_f, rot_c = update(rot_f, rot_c, step3)
+            b = residuals(rot_f, rot_c)
+            avg = avg_step(step3)
+            if trace is not None:
+                trace.l1_steps.append(avg)
+                trace.l1_iterations = it + 1
+            if avg < opt.l1_step_convergence_threshold or abs(last_norm - curr_norm) < so3.EPS:
+                break
+    if opt.max_num_irls_iterations > 0:
+        sigma = np.radians(opt.irls_loss_parameter_sigma)
+        At = A.T.tocsr()
+        b = residuals(rot_f, rot_c)
+        w_irls = np.ones(3 * E + 3)
+        for it in range(opt.max_num_irls_iterations):
+            e2 = (b[: 3 * E].reshape(-1, 3) ** 2).sum(axis=1)
+            if opt.weight_type == GEMAN_MCCLURE:
+                tmp = e2 + sigma * sigma
+                w = sigma * sigma / (tmp * tmp)
+            else:
+                with np.errstate(divide="ignore"):
+                    w = np.power(e2, (0.5 - 2) / 2)
+            if np.isnan(w).any():
+                return False, rot_f, rot_c
+            w_irls[: 3 * E] = np.repeat(w, 3)
+            at_weight = At @ sp.diags(w_irls * weights)
+            step = spla.splu((at_weight @ A).tocsc()).solve(at_weight @ b)
+            step3 = step.reshape(-1, 3)
+            rot_f, rot_c = update(rot_f, rot_c, step3)
+            b = residuals(rot_f, rot_c)
+            avg = avg_step(step3)
+            if trace is not None:
+                trace.irls_steps.append(avg)
+                trace.irls_iterations = it + 1
+            if avg < opt.irls_step_convergence_threshold:
+                break
+    return True, rot_f, rot_c

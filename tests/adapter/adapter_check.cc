@@ -299,7 +299,7 @@ int main() {
   // 6) calibrated rigs (the shape of global_mapper_test.cc:89-126): 12 frames of a 2-camera rig — reference sensor
   //    (camera 11) and a second sensor (camera 12) with a KNOWN cam_from_rig (10 degrees about y, a metric baseline).
   //    RotationEstimator, GlobalPositioner and BundleAdjuster must handle them through the same three calls.
-  double rig_ra = 0, rig_gp = 0, rig_ba = 0, rig_sens = 0, rig_unk = 0;
+  double rig_ra = 0, rig_gp = 0, rig_ba = 0, rig_sens = 0, rig_unk = 0, rig_unk_rot = 0;
   {
     const int NF = 12, NP = 300;
     std::unordered_map<rig_t, Rig> rigs2;
@@ -479,13 +479,30 @@ int main() {
     // unknown cam_from_rig translation (NaN, what rotation averaging leaves behind for an estimated sensor):
     // GlobalPositioner estimates it (RigUnknownBATAPairwiseDirectionError, gp.cc:354-368) in the scale of the solution
     {
-      Rigid3d unk;
-      unk.rotation = quat_of(Rs);
-      const double nan = std::nan("");
-      unk.translation = mock_eigen::Vector3d(nan, nan, nan);
-      rigs2[1].SetSensorFromRig(sensor_t(SensorType::CAMERA, 12), unk);
-      auto fr_u = fr_gp;  // ground-truth rotations, positions from the previous run (re-drawn anyway)
+      // first the rotation: a sensor without any cam_from_rig (rotation_averager_test.cc:214-263) gets a cam block in
+      // RotationEstimator (gra.cc:173-191); noise-free data: exact after the spanning-tree start, translation left NaN
+      rigs2[1].ResetSensorFromRig(sensor_t(SensorType::CAMERA, 12));
+      auto fr_u = fr2;
+      for (auto& [id, fr] : fr_u) {
+        Rigid3d p0;
+        fr.SetRigFromWorld(p0);
+      }
       for (int id = 0; id < 2 * NF; ++id) im2[id].frame_ptr = &fr_u[id / 2];
+      gsfm_glomap::RotationEstimator ra3(ro2);
+      if (!ra3.EstimateRotations(vg2, rigs2, fr_u, im2)) return std::printf("RA with an unknown cam_from_rig failed\n"), 1;
+      const auto est = rigs2[1].MaybeSensorFromRig(sensor_t(SensorType::CAMERA, 12));
+      if (!est.has_value() || !std::isnan(est->translation[0])) return std::printf("RA: cam_from_rig not written as (rotation, NaN)\n"), 1;
+      rig_unk_rot = std::fabs(2.0 * std::atan2(est->rotation.y(), est->rotation.w()) - s_ang);
+      if (rig_unk_rot > 1e-6 || std::fabs(est->rotation.x()) > 1e-7 || std::fabs(est->rotation.z()) > 1e-7)
+        return std::printf("RA: estimated cam_from_rig rotation off by %.3e rad\n", rig_unk_rot), 1;
+      for (int f = 1; f < NF; ++f) {
+        auto q0 = fr_u[0].RigFromWorld().rotation, qn = fr_u[f].RigFromWorld().rotation;
+        double dd = std::fmod(2.0 * (std::atan2(qn.y(), qn.w()) - std::atan2(q0.y(), q0.w())) - 2.0 * M_PI * f / NF, 2.0 * M_PI);
+        if (dd > M_PI) dd -= 2.0 * M_PI;
+        if (dd < -M_PI) dd += 2.0 * M_PI;
+        if (std::fabs(dd) > 1e-6) return std::printf("RA with an unknown cam_from_rig: frame %d off by %.3e rad\n", f, dd), 1;
+      }
+      // then the translation, with the rotations just estimated
       auto tr_u = tr2;
       gsfm_glomap::GlobalPositioner gp3(go2);
       if (!gp3.Solve(vg2, rigs2, cams2, fr_u, im2, tr_u)) return std::printf("GP with an unknown cam_from_rig failed\n"), 1;
@@ -502,7 +519,7 @@ int main() {
     rigs2[1].ResetSensorFromRig(sensor_t(SensorType::CAMERA, 12));
     if (ba2.Solve(rigs2, cams2, fr2, im2, tr2)) return std::printf("BA accepted an uncalibrated rig\n"), 1;
   }
-  std::printf("ADAPTER OK ra=%.2e rad gp_ratio_err=%.2e ba=%.2e px | rigs: ra=%.2e rad gp_scale_err=%.2e ba=%.2e px cam_from_rig=%.2e rad unknown_t=%.2e\n",
-              worst, std::fabs(ratio / ratio_ref - 1.0), maxerr, rig_ra, rig_gp, rig_ba, rig_sens, rig_unk);
+  std::printf("ADAPTER OK ra=%.2e rad gp_ratio_err=%.2e ba=%.2e px | rigs: ra=%.2e rad gp_scale_err=%.2e ba=%.2e px cam_from_rig=%.2e rad unknown_R=%.2e rad unknown_t=%.2e\n",
+              worst, std::fabs(ratio / ratio_ref - 1.0), maxerr, rig_ra, rig_gp, rig_ba, rig_sens, rig_unk_rot, rig_unk);
   return 0;
 }
