@@ -2044,6 +2044,11 @@ extern "C" int gsfm_ra_solve(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const g
     dump.array("edge_weight", prob->edge_weight, {E}, prob->mem);
     dump.array("edge_ninl", prob->edge_ninl, {E}, prob->mem);
     dump.array("node_aa0", rot_aa_inout, {N, 3}, prob->mem);
+    if (prob->num_images > 0 && prob->image_frame && prob->image_cam) {
+      dump.array("image_frame", prob->image_frame, {(int64_t)prob->num_images}, prob->mem);
+      dump.array("image_cam", prob->image_cam, {(int64_t)prob->num_images}, prob->mem);
+      if (prob->num_cams > 0 && prob->cam_rot_aa) dump.array("cam_aa0", prob->cam_rot_aa, {(int64_t)prob->num_cams, 3}, GSFM_MEM_HOST);
+    }
     GSFM_DUMP_OPT(dump, opt, max_num_l1_iterations);
     GSFM_DUMP_OPT(dump, opt, l1_step_convergence_threshold);
     GSFM_DUMP_OPT(dump, opt, max_num_irls_iterations);
@@ -2066,6 +2071,8 @@ extern "C" int gsfm_ra_solve(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const g
   const int rc = guarded(ctx, report, [&] { return ra_solve_impl(ctx, prob, opt, rot_aa_inout, report); });
   if (dump.active() && prob && rot_aa_inout) {
     dump.array("out_rot_aa", rot_aa_inout, {(int64_t)prob->num_nodes, 3}, prob->mem);
+    if (prob->num_images > 0 && prob->num_cams > 0 && prob->cam_rot_aa)
+      dump.array("out_cam_rot_aa", prob->cam_rot_aa, {(int64_t)prob->num_cams, 3}, GSFM_MEM_HOST);
     dump.write(report, rc);
   }
   return rc;

@@ -84,7 +84,9 @@ def to_problem(rec: FlatRecord):
     if rec.kind == "ra":
         E = len(a["edge_i"])
         p = RaProblem(int(s["num_nodes"]), a["edge_i"], a["edge_j"], a["edge_q"], a.get("edge_weight", np.ones(E)),
-                      a.get("edge_ninl", np.ones(E, np.int32)), a["node_aa0"], int(s["fixed_node"]))
+                      a.get("edge_ninl", np.ones(E, np.int32)), a["node_aa0"], int(s["fixed_node"]),
+                      image_frame=a.get("image_frame"), image_cam=a.get("image_cam"),  # cam_from_rig rotations unknown
+                      cam_aa0=a.get("cam_aa0", np.zeros((0, 3)) if "image_frame" in a else None))
         return p, _fill(estimators.RotationEstimatorOptions(), o)
     if rec.kind == "gp":
         M = len(a["obs_cam"])
@@ -116,6 +118,9 @@ def from_problem(p, options=None) -> FlatRecord:
         arrs = dict(edge_i=np.asarray(p.edge_i, np.int32), edge_j=np.asarray(p.edge_j, np.int32), edge_q=np.asarray(p.edge_q, np.float64),
                     edge_weight=np.asarray(p.edge_weight, np.float64), edge_ninl=np.asarray(p.edge_ninl, np.int32),
                     node_aa0=np.asarray(p.node_aa0, np.float64))
+        if p.image_frame is not None:
+            arrs.update(image_frame=np.asarray(p.image_frame, np.int32), image_cam=np.asarray(p.image_cam, np.int32),
+                        cam_aa0=np.asarray(p.cam_aa0, np.float64).reshape(-1, 3))
         return FlatRecord("ra", {"num_nodes": p.num_nodes, "fixed_node": p.fixed_node}, _opts(options), arrays=arrs)
     if isinstance(p, GpProblem):
         arrs = dict(pt_offset=np.asarray(p.pt_offset, np.int64), obs_cam=np.asarray(p.obs_cam, np.int32),

@@ -118,3 +118,64 @@ def test_rig_mode_needs_an_initial_estimate(gsfm_ctx):
                   image_frame=s["imf"], image_cam=s["imc"], cam_aa0=np.zeros((s["C"], 3)))
     rc_, _, _ = estimators.ra_solve(p, estimators.RotationEstimatorOptions(), ctx=gsfm_ctx)
     assert rc_ != 0  # GSFM_ERR_UNSUPPORTED: the library does not build the image-level start itself
+
+
+@pytest.mark.gpu
+def test_unknown_rig_pipeline_recovers_the_scene(gsfm_ctx):
+    """RA -> GP -> BA on a noise-free scene of 2 rigs x 3 cameras x 7 frames whose non-reference cam_from_rig are all
+    UNKNOWN — the configuration and the pins (rotations 1e-2 degrees, projection centres 1e-4) of the reference's
+    GlobalMapper.WithoutNoiseWithNonTrivialUnknownRig (global_mapper_test.cc:128-175): rotation averaging estimates the
+    cam_from_rig rotations, global positioning their translations (RigUnknownBATA), bundle adjustment then runs with
+    the estimated rigs held constant (optimize_rig_poses = false, as the mapper leaves it)."""
+    from glomap_amd.flat import BaProblem, GpProblem
+
+    gp, ba, info = synthetic.make_rig_problems(14, 3, 600, seed=9)
+    N, I = gp.num_cams, gp.num_images
+    R_cw = info["R_cw"]
+    imf = gp.image_frame.astype(np.int32)
+    imc = info["sensor_block"].astype(np.int32)
+    C = int(imc.max()) + 1
+    ii, jj = np.triu_indices(I, 1)
+    d = np.abs(imf[ii].astype(np.int64) - imf[jj])
+    near = (np.minimum(d, N - d) <= 3) & ~((imf[ii] == imf[jj]) & (imc[ii] < 0) & (imc[jj] < 0))
+    ii, jj = ii[near].astype(np.int32), jj[near].astype(np.int32)
+    q_rel = so3.rotmat_to_quat(R_cw[jj] @ np.transpose(R_cw[ii], (0, 2, 1)))
+    ninl = np.random.default_rng(0).integers(30, 300, ii.shape[0]).astype(np.int32)
+    rc, rot, cam, rep = estimators.ra_solve_rigs(N, imf, imc, C, ii, jj, q_rel, ninl, ctx=gsfm_ctx)
+    assert rc == 0
+    R_f, R_c = so3.aa_to_rotmat(rot), so3.aa_to_rotmat(cam)
+    assert synthetic.rotation_errors_deg(R_f, gp.cam_R).max() < 1e-2
+    # global positioning: rays rotated by the ESTIMATED cam_from_world rotations, every cam_from_rig translation unknown
+    R_s_est = np.where((imc >= 0)[:, None, None], R_c[np.maximum(imc, 0)], np.eye(3))
+    Rcw_est = R_s_est @ R_f[imf]
+    ray_cam = np.einsum("mij,mj->mi", R_cw[gp.obs_cam], gp.obs_dir)  # back to camera-frame rays (features_undist)
+    gp2 = GpProblem(num_cams=N, num_pts=gp.num_pts, pt_offset=gp.pt_offset, obs_cam=gp.obs_cam,
+                    obs_dir=np.ascontiguousarray(np.einsum("mji,mj->mi", Rcw_est[gp.obs_cam], ray_cam)),
+                    obs_calibrated=gp.obs_calibrated, cam_center=np.zeros((N, 3)), pt_xyz=np.zeros((gp.num_pts, 3)),
+                    image_frame=gp.image_frame, image_offset=np.zeros((I, 3)), image_sensor=imc,
+                    image_sensor_rot=np.ascontiguousarray(R_f[imf]), sensor_center=np.zeros((C, 3)))
+    rc, cen, xyz, rep = estimators.gp_solve(gp2, ctx=gsfm_ctx)
+    assert rc == 0
+    t_s_est = -np.einsum("cij,cj->ci", R_c, rep["sensor_center"])  # t = -R c (gp.cc:576-582)
+    # bundle adjustment from the positioning result with the estimated rigs as constants
+    cfr = np.zeros((I, 7))
+    cfr[:, 0] = 1.0
+    has = imc >= 0
+    cfr[has] = np.concatenate([so3.rotmat_to_quat(R_c[imc[has]]), t_s_est[imc[has]]], axis=1)
+    ba2 = BaProblem(num_cams=N, num_pts=ba.num_pts, num_intr=ba.num_intr, pt_offset=ba.pt_offset, obs_cam=ba.obs_cam,
+                    obs_xy=ba.obs_xy, cam_intr=ba.cam_intr, cam_q=so3.rotmat_to_quat(R_f), cam_t=-np.einsum("nij,nj->ni", R_f, cen),
+                    pt_xyz=xyz, intr_model=ba.intr_model, intr_params=ba.intr_params, fixed_cam=0, image_frame=ba.image_frame,
+                    image_cam_from_rig=cfr, image_intr=ba.image_intr)
+    rc, q, t, X, intr, rep = estimators.ba_solve(ba2, estimators.BundleAdjusterOptions(optimize_rotations=False), ctx=gsfm_ctx)
+    assert rc == 0
+    ba2.cam_t, ba2.pt_xyz, ba2.intr_params = t, X, intr
+    rc, q, t, X, intr, rep = estimators.ba_solve(ba2, ctx=gsfm_ctx)
+    assert rc == 0
+    R_fin = so3.quat_to_rotmat(q)
+    # image level, like ComputeImageAlignmentError: cam_from_world = cam_from_rig * rig_from_world
+    R_img = so3.quat_to_rotmat(cfr[:, :4]) @ R_fin[imf]
+    t_img = np.einsum("iab,ib->ia", so3.quat_to_rotmat(cfr[:, :4]), t[imf]) + cfr[:, 4:]
+    c_img = -np.einsum("iba,ib->ia", R_img, t_img)
+    c_gt = -np.einsum("iba,ib->ia", R_cw, info["t_cw"])
+    assert synthetic.rotation_errors_deg(R_img, R_cw).max() < 1e-2
+    assert synthetic.center_errors_after_sim3(c_img, c_gt).max() < 1e-4
