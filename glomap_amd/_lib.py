@@ -92,6 +92,7 @@ class RaProblemC(C.Structure):
         ("image_cam", C.c_void_p),
         ("num_cams", C.c_int32),
         ("cam_rot_aa", C.c_void_p),
+        ("node_gravity", C.c_void_p),
     ]
 
 

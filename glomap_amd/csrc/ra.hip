@@ -68,19 +68,36 @@ __global__ void __launch_bounds__(kBlock)
     k_edge_residual(long E, const int* __restrict__ ei, const int* __restrict__ ej,
                     const double* __restrict__ eq, const double* __restrict__ nq,
                     double* __restrict__ res, double* __restrict__ wirls, int weight_type,
-                    double sigma2, int* __restrict__ nan_flag) {
+                    double sigma2, int* __restrict__ nan_flag,
+                    const unsigned char* __restrict__ grav /* use_gravity: [N] frame has gravity, else null */,
+                    const double* __restrict__ rot /* node angle-axis (gravity frames: (0, angle, 0)) */) {
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long)gridDim.x * blockDim.x) {
     const Quat qi = load_quat(nq + 4 * (long)ei[e]);
     const Quat qj = load_quat(nq + 4 * (long)ej[e]);
     const Quat qr = load_quat(eq + 4 * e);
-    const Quat m = qmul(qmul(qconj(qj), qr), qi);
-    double ax, ay, az;
-    quat_to_aa(m, ax, ay, az);
+    double ax, ay, az, xz = 0.0;
+    if (grav != nullptr && grav[ei[e]] && grav[ej[e]]) {
+      // both frames gravity aligned: ONE row, RelAngleError of the angles against the y component of the (aligned)
+      // relative rotation; its x / z components are a constant of the IRLS weight (gra.cc:19-36, 329-338, 571-573, 709-713)
+      double rx, ry, rz;
+      quat_to_aa(qr, rx, ry, rz);
+      double est = (rot[3 * (long)ej[e] + 1] - rot[3 * (long)ei[e] + 1]) - ry;
+      est = fmod(est + M_PI, 2.0 * M_PI);
+      if (est < 0.0) est += 2.0 * M_PI;
+      est -= M_PI;  // [-pi, pi)
+      ax = 0.0;
+      ay = -est;
+      az = 0.0;
+      xz = rx * rx + rz * rz;
+    } else {
+      const Quat m = qmul(qmul(qconj(qj), qr), qi);
+      quat_to_aa(m, ax, ay, az);
+    }
     res[3 * e] = -ax;
     res[3 * e + 1] = -ay;
     res[3 * e + 2] = -az;
     if (wirls != nullptr) {
-      const double e2 = ax * ax + ay * ay + az * az;
+      const double e2 = ax * ax + ay * ay + az * az + xz;
       double w;
       if (weight_type == 0) {  // GEMAN_MCCLURE
         const double t = e2 + sigma2;
@@ -287,7 +304,7 @@ template <int LPR>
 __global__ void __launch_bounds__(kBlock)
     k_ra_apply(int N, const int* __restrict__ rowptr, const int* __restrict__ nbr,
                const double* __restrict__ inc_w, const double* __restrict__ lap_diag_loc, CgVec v, int it,
-               double tol2) {
+               double tol2, const unsigned char* __restrict__ grav) {
   __shared__ double smem[4 * 2 + 2];
   if (cg_converged(v, it, tol2, smem)) return;
   const int gpb = kBlock / LPR;
@@ -296,6 +313,10 @@ __global__ void __launch_bounds__(kBlock)
   for (int n = blockIdx.x * gpb + g; n < N; n += gridDim.x * gpb) {
     double w0, w1, w2;
     laplacian_row<LPR>(n, l, rowptr, nbr, inc_w, lap_diag_loc, v.z, w0, w1, w2);
+    if (grav != nullptr && grav[n]) {  // a gravity frame has no x / z unknowns (k_ra_mask3)
+      w0 = 0.0;
+      w2 = 0.0;
+    }
     if (l == 0) {
       const long i = 3 * (long)n;
       v.w[i] = w0;
@@ -306,6 +327,28 @@ __global__ void __launch_bounds__(kBlock)
   }
   block_sum<1>(acc, smem);
   if (threadIdx.x == 0) v.dpart[blockIdx.x] = acc[0];
+}
+
+// use_gravity: the x and z components of a gravity-aligned frame are not unknowns (its one column sits in the y rows,
+// gra.cc:390-418): every vector of the normal equations carries zeros there.  With them masked the ordinary Laplacian
+// machinery solves the reference's mixed 1-DoF / 3-DoF system: the y components see the whole graph, the x / z components
+// the graph of the other frames with their edges to gravity frames acting as anchors.
+__global__ void __launch_bounds__(kBlock)
+    k_ra_mask3(int N, const unsigned char* __restrict__ grav, double* __restrict__ a, double* __restrict__ b,
+               double* __restrict__ c) {
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+    if (!grav[n]) continue;
+    a[3 * (long)n] = 0.0;
+    a[3 * (long)n + 2] = 0.0;
+    if (b) {
+      b[3 * (long)n] = 0.0;
+      b[3 * (long)n + 2] = 0.0;
+    }
+    if (c) {
+      c[3 * (long)n] = 0.0;
+      c[3 * (long)n + 2] = 0.0;
+    }
+  }
 }
 
 // Jacobi preconditioner as 3 x 3 blocks for cg.hpp: minv[n] = (1 / d_n) I3
@@ -581,6 +624,7 @@ __global__ void __launch_bounds__(kBlock)
 // ------------------------------------------------------------------------------------------
 struct RaWs {
   DevBuf<int> ei, ej, rowptr, inc, nbr, inc_row, flags;
+  DevBuf<unsigned char> grav;
   DevBuf<double> dense_a, dense_b, dense_pinv, rot_out;
   DevBuf<float> bd_inv;
   DevBuf<int> order;
@@ -695,6 +739,9 @@ struct RaDevice {
   int has_gauge;
   int lpr;
   const double* ew;  // device edge weights or nullptr
+  const unsigned char* grav = nullptr;  // use_gravity: [N] frame has gravity (1-DoF unknown), else nullptr
+  double rows_edges = 0.0, cols = 0.0;  // rows of A contributed by this rank's edges; columns of A
+  int gauge_rows = 3;
   int gridN, gridE, gridRow;
   // direct (dense) solves for small graphs, ra_dense.hpp
   bool dense = false;
@@ -996,6 +1043,7 @@ int pcg_solve(RaDevice& d, bool warm, double tol, int max_iter) {
                          ws->nbr.get(), ws->inc_w.get(), ws->lap_diag_loc.get(), ws->x.get(), ws->wbuf.get());
     });
     allreduce_sum(ctx, ws->wbuf.get(), (size_t)n3);
+    if (d.grav) hipLaunchKernelGGL(k_ra_mask3, dim3(d.gridN), dim3(kBlock), 0, s, N, d.grav, ws->wbuf.get(), (double*)nullptr, (double*)nullptr);
     hipLaunchKernelGGL(k_dense_residual, dim3(d.gridN), dim3(kBlock), 0, s, n3, ws->rhs.get(), ws->wbuf.get(), ws->cg_b.get());
     b = ws->cg_b.get();
   }
@@ -1024,7 +1072,7 @@ int pcg_solve(RaDevice& d, bool warm, double tol, int max_iter) {
       const bool timed = ctx->prof.begin(s, GSFM_KERNEL_RA_LAPLACIAN);
       dispatch_lpr(d.lpr, [&](auto L) {
         hipLaunchKernelGGL((k_ra_apply<decltype(L)::value>), dim3(gA), dim3(kBlock), 0, s, N, ws->rowptr.get(),
-                           ws->nbr.get(), ws->inc_w.get(), ws->lap_diag_loc.get(), v, it, tol_pass * tol_pass);
+                           ws->nbr.get(), ws->inc_w.get(), ws->lap_diag_loc.get(), v, it, tol_pass * tol_pass, d.grav);
       });
       if (timed) ctx->prof.end(s);
     });
@@ -1042,6 +1090,7 @@ int pcg_solve(RaDevice& d, bool warm, double tol, int max_iter) {
                          ws->nbr.get(), ws->inc_w.get(), ws->lap_diag_loc.get(), ws->x.get(), ws->wbuf.get());
     });
     allreduce_sum(ctx, ws->wbuf.get(), (size_t)n3);
+    if (d.grav) hipLaunchKernelGGL(k_ra_mask3, dim3(d.gridN), dim3(kBlock), 0, s, N, d.grav, ws->wbuf.get(), (double*)nullptr, (double*)nullptr);
     hipLaunchKernelGGL(k_dense_residual, dim3(d.gridN), dim3(kBlock), 0, s, n3, ws->rhs.get(), ws->wbuf.get(), ws->r.get());
     hipLaunchKernelGGL(k_sumsq2, dim3(d.gridN), dim3(kBlock), 0, s, n3, ws->r.get(), bref, ws->part_misc.get());
     hipLaunchKernelGGL((k_finalize<2>), dim3(1), dim3(kBlock), 0, s, ws->part_misc.get(), d.gridN, ws->scal.get() + 16);
@@ -1065,7 +1114,7 @@ void launch_residuals(RaDevice& d, bool with_weights, int weight_type, double si
                      d.fixed, ws->fixed_rot0.get(), ws->res.get() + 3 * d.E, d.has_gauge);
   hipLaunchKernelGGL(k_edge_residual, dim3(d.gridE), dim3(kBlock), 0, s, d.E, ws->ei.get(), ws->ej.get(),
                      ws->eq.get(), ws->nq.get(), ws->res.get(), with_weights ? ws->wirls.get() : nullptr,
-                     weight_type, sigma2, ws->flags.get());
+                     weight_type, sigma2, ws->flags.get(), d.grav, ws->rot.get());
 }
 
 // Applies ws->x as the tangent step, returns {mean |delta|, |delta|_2, #NaN}.
@@ -1139,11 +1188,26 @@ void setup_device(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
   d.fixed = prob->fixed_node;
   d.has_gauge = ctx->comm.rank == 0 ? 1 : 0;
   d.lpr = choose_lpr(E, N);
-  d.dense = ctx->comm.world == 1 && N <= kDenseMaxN && opt->pcg_max_iterations > 0 && !opt->force_iterative;
+  d.grav = nullptr;
+  d.rows_edges = 3.0 * (double)E;
+  d.cols = 3.0 * (double)N;
+  d.gauge_rows = 3;
+  std::vector<unsigned char> h_grav;
+  if (opt->use_gravity && prob->node_gravity != nullptr) {
+    to_host(ctx, h_grav, prob->node_gravity, (size_t)N, prob->mem);
+    GSFM_HIP_CHECK(hipMemcpyAsync(ws->grav.ensure(N), h_grav.data(), (size_t)N, hipMemcpyHostToDevice, ctx->stream));
+    GSFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    d.grav = ws->grav.get();
+    d.cols = 0.0;
+    for (int n = 0; n < N; ++n) d.cols += h_grav[n] ? 1.0 : 3.0;
+    d.gauge_rows = h_grav[prob->fixed_node] ? 1 : 3;
+  }
+  // mixed 1-DoF / 3-DoF systems are not ONE scalar Laplacian any more: the masked Jacobi-PCG path solves them
+  d.dense = d.grav == nullptr && ctx->comm.world == 1 && N <= kDenseMaxN && opt->pcg_max_iterations > 0 && !opt->force_iterative;
   d.dense_valid = false;
   d.dense_have = false;
   d.dense_refresh = false;
-  d.blockdense = allow_blockdense && !d.dense && ctx->comm.world == 1 && N <= kBlockDenseMaxN && opt->pcg_max_iterations > 0 &&
+  d.blockdense = allow_blockdense && d.grav == nullptr && !d.dense && ctx->comm.world == 1 && N <= kBlockDenseMaxN && opt->pcg_max_iterations > 0 &&
                  !opt->force_iterative && getenv("GSFM_RA_NO_BLOCKDENSE") == nullptr;
   d.bd_have = d.bd_refresh = d.bd_fresh = false;
   d.bd_base_iters = 0;
@@ -1203,6 +1267,13 @@ void setup_device(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
   std::vector<int>&h_ei = hi.h_ei, &h_ej = hi.h_ej;
   to_host(ctx, h_ei, prob->edge_i, E, mem);
   to_host(ctx, h_ej, prob->edge_j, E, mem);
+  if (d.grav != nullptr) {  // a pair of two gravity frames contributes one row (gra.cc:390-397)
+    d.rows_edges = 0.0;
+    for (long e = 0; e < E; ++e) {
+      GSFM_REQUIRE(h_ei[e] >= 0 && h_ei[e] < N && h_ej[e] >= 0 && h_ej[e] < N, "RA: edge index out of range");
+      d.rows_edges += (h_grav[h_ei[e]] && h_grav[h_ej[e]]) ? 1.0 : 3.0;
+    }
+  }
   std::vector<int>& pos = hi.pos;
   pos.clear();
   hi.mst_root = 0;
@@ -1226,7 +1297,7 @@ void setup_device(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
 
   // device-to-host copies for the initialisation, all BEFORE any solver kernel is enqueued
   to_host(ctx, hi.h_rot, rot_in, 3 * (size_t)N, mem);
-  if (!opt->skip_initialization) {
+  if (!opt->skip_initialization && !opt->use_gravity) {
     GSFM_REQUIRE(prob->edge_ninl != nullptr, "RA: MST initialisation requires edge_ninl");
     GSFM_REQUIRE(ctx->comm.world == 1, "RA: MST initialisation needs the whole graph; initialise before sharding");
     to_host(ctx, hi.h_eq, prob->edge_q, 4 * (size_t)E, mem);
@@ -1247,7 +1318,7 @@ void finish_init(gsfm_ctx* ctx, const gsfm_ra_options* opt, RaDevice& d, RaHostI
       for (int c = 0; c < 3; ++c) tmp[3 * (size_t)hi.pos[n] + c] = h_rot[3 * (size_t)n + c];
     h_rot.swap(tmp);
   }
-  if (!opt->skip_initialization)
+  if (!opt->skip_initialization && !opt->use_gravity)  // gra.cc:60-62: no spanning-tree start with use_gravity
     mst_init(N, E, hi.h_ei.data(), hi.h_ej.data(), hi.h_eq.data(), hi.h_ninl.data(), h_rot.data(), hi.mst_root);
   GSFM_HIP_CHECK(hipMemcpyAsync(ws->rot.ensure(3 * (size_t)N), h_rot.data(), 3 * (size_t)N * sizeof(double), hipMemcpyHostToDevice, s));
   // the gauge node is held at its (post-initialisation) rotation (gra.cc:248-257)
@@ -1284,6 +1355,9 @@ void launch_gather(RaDevice& d, const int* stop = nullptr) {
                        ws->lap_diag.get(), ws->lap_diag_loc.get(), ws->rhs.get(), ws->gat_s.get(), ws->gat_t.get(),
                        d.fixed, d.has_gauge, stop);
   });
+  if (d.grav != nullptr && MODE != GATHER_L1W)  // A^T(...) has no x / z rows at gravity frames
+    hipLaunchKernelGGL(k_ra_mask3, dim3(d.gridN), dim3(kBlock), 0, d.ctx->stream, d.N, d.grav, ws->rhs.get(),
+                       MODE == GATHER_L1RHS ? ws->gat_s.get() : nullptr, MODE == GATHER_L1RHS ? ws->gat_t.get() : nullptr);
 }
 
 int ra_solve_rig_impl(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_options* opt, double* rot_inout,
@@ -1292,7 +1366,8 @@ int ra_solve_rig_impl(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_
 int ra_solve_impl(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_options* opt,
                   double* rot_inout, gsfm_report* rep) {
   GSFM_REQUIRE(prob && opt && rot_inout, "RA: null argument");
-  if (opt->use_gravity) throw StatusError(GSFM_ERR_UNSUPPORTED, "RA: gravity-aligned (1-DoF) path not implemented");
+  if (opt->use_gravity && prob->num_images > 0)
+    throw StatusError(GSFM_ERR_UNSUPPORTED, "RA: use_gravity with cam_from_rig unknowns (the reference refuses it too, gra.cc:47-58)");
   if (prob->num_nodes <= 0) throw StatusError(GSFM_ERR_EMPTY_PROBLEM, "RA: no nodes");
   GSFM_REQUIRE(prob->fixed_node >= 0 && prob->fixed_node < prob->num_nodes, "RA: fixed_node out of range");
   if (prob->num_images > 0) return ra_solve_rig_impl(ctx, prob, opt, rot_inout, rep);  // cam_from_rig rotations unknown
@@ -1334,7 +1409,7 @@ int ra_solve_impl(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
     double last_norm = 0.0, curr_norm = 0.0;
     launch_residuals(d, false, 0, 0.0);
     // A.rows() incl. the gauge rows — of the WHOLE graph when the edges are sharded over ranks
-    double e_glob = (double)E;
+    double e_glob = d.rows_edges;  // rows of A from the edges: 3 each, 1 for a pair of two gravity frames
     if (multi) {
       ctx->h_pinned[80] = e_glob;
       GSFM_HIP_CHECK(hipMemcpyAsync(ws->scal.get() + 8, ctx->h_pinned + 80, sizeof(double), hipMemcpyHostToDevice, s));
@@ -1343,7 +1418,7 @@ int ra_solve_impl(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
       GSFM_HIP_CHECK(hipStreamSynchronize(s));
       e_glob = ctx->h_pinned[80];
     }
-    const double rows_total = 3.0 * e_glob + 3.0;
+    const double rows_total = e_glob + (double)d.gauge_rows;
     for (int it = 0; it < opt->max_num_l1_iterations; ++it) {
       last_norm = curr_norm;
       // --- colmap::LeastAbsoluteDeviationSolver::Solve(b' = W b, &x), x starts at 0
@@ -1408,7 +1483,7 @@ int ra_solve_impl(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
         const double dual_norm = rho * std::sqrt(h[5]);
         const double primal_eps = std::sqrt(rows_glob) * opt->l1_admm_absolute_tolerance +
                                   opt->l1_admm_relative_tolerance * std::max({Ax_norm, z_norm, b_norm});
-        const double dual_eps = std::sqrt(3.0 * N) * opt->l1_admm_absolute_tolerance +
+        const double dual_eps = std::sqrt(d.cols) * opt->l1_admm_absolute_tolerance +
                                 opt->l1_admm_relative_tolerance * dual_norm;
         if (r_norm < primal_eps && s_norm < dual_eps) break;
       }
@@ -1750,7 +1825,7 @@ void rig_residuals(RigSolve& g, bool with_weights, int weight_type, double sigma
                      ws->nq.get(), d.fixed, ws->fixed_rot0.get(), ws->res.get() + 3 * d.E);
   hipLaunchKernelGGL(k_edge_residual, dim3(d.gridE), dim3(kBlock), 0, s, d.E, ws->ei.get(), ws->ej.get(), ws->eq.get(),
                      ws->nq.get(), ws->res.get(), with_weights ? ws->wirls.get() : nullptr, weight_type, sigma2,
-                     ws->flags.get());
+                     ws->flags.get(), (const unsigned char*)nullptr, (const double*)nullptr);
 }
 
 // frames: r <- Log(Exp(r) Exp(-step)), then the cam blocks from the UPDATED frames.  out = {mean |step| over the FRAMES
@@ -2049,6 +2124,7 @@ extern "C" int gsfm_ra_solve(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const g
       dump.array("image_cam", prob->image_cam, {(int64_t)prob->num_images}, prob->mem);
       if (prob->num_cams > 0 && prob->cam_rot_aa) dump.array("cam_aa0", prob->cam_rot_aa, {(int64_t)prob->num_cams, 3}, GSFM_MEM_HOST);
     }
+    if (prob->node_gravity) dump.array("node_gravity", prob->node_gravity, {N}, prob->mem);
     GSFM_DUMP_OPT(dump, opt, max_num_l1_iterations);
     GSFM_DUMP_OPT(dump, opt, l1_step_convergence_threshold);
     GSFM_DUMP_OPT(dump, opt, max_num_irls_iterations);
@@ -2123,7 +2199,8 @@ extern "C" int gsfm_ra_residuals_timed(gsfm_ctx* ctx, const gsfm_ra_problem* pro
     GSFM_HIP_CHECK(hipEventRecord(ctx->ev0, s));
     for (int r = 0; r < reps; ++r)
       hipLaunchKernelGGL(k_edge_residual, dim3(d.gridE), dim3(kBlock), 0, s, d.E, ws->ei.get(), ws->ej.get(), ws->eq.get(),
-                         ws->nq.get(), ws->res.get(), ws->wirls.get(), o.weight_type, sigma * sigma, ws->flags.get());
+                         ws->nq.get(), ws->res.get(), ws->wirls.get(), o.weight_type, sigma * sigma, ws->flags.get(),
+                         (const unsigned char*)nullptr, (const double*)nullptr);
     GSFM_HIP_CHECK(hipEventRecord(ctx->ev1, s));
     GSFM_HIP_CHECK(hipStreamSynchronize(s));
     if (avg_kernel_ms) {

@@ -185,6 +185,11 @@ def _ra_problem_c(p: RaProblem, keep: list) -> _lib.RaProblemC:
     c.edge_i, c.edge_j, c.edge_q = _lib.ptr(ei), _lib.ptr(ej), _lib.ptr(eq)
     c.edge_weight, c.edge_ninl = _lib.ptr(ew), _lib.ptr(en)
     c.fixed_node = int(p.fixed_node)
+    if getattr(p, "node_gravity", None) is not None:
+        ng = _h(p.node_gravity, np.uint8)
+        assert _mem_of(ng) == c.mem
+        keep.append(ng)
+        c.node_gravity = _lib.ptr(ng)
     return c
 
 

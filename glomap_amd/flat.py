@@ -43,6 +43,8 @@ class RaProblem:
     image_frame: Optional[np.ndarray] = None  # [I] int32
     image_cam: Optional[np.ndarray] = None  # [I] int32
     cam_aa0: Optional[np.ndarray] = None  # [C,3] f64
+    # use_gravity (gra.cc:207-217, 376-418): 1 = the frame has gravity: one unknown, node_aa0[n] = (0, angle, 0); edge_q aligned
+    node_gravity: Optional[np.ndarray] = None  # [N] uint8
 
     @property
     def num_edges(self) -> int:

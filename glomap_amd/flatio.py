@@ -86,7 +86,8 @@ def to_problem(rec: FlatRecord):
         p = RaProblem(int(s["num_nodes"]), a["edge_i"], a["edge_j"], a["edge_q"], a.get("edge_weight", np.ones(E)),
                       a.get("edge_ninl", np.ones(E, np.int32)), a["node_aa0"], int(s["fixed_node"]),
                       image_frame=a.get("image_frame"), image_cam=a.get("image_cam"),  # cam_from_rig rotations unknown
-                      cam_aa0=a.get("cam_aa0", np.zeros((0, 3)) if "image_frame" in a else None))
+                      cam_aa0=a.get("cam_aa0", np.zeros((0, 3)) if "image_frame" in a else None),
+                      node_gravity=a.get("node_gravity"))
         return p, _fill(estimators.RotationEstimatorOptions(), o)
     if rec.kind == "gp":
         M = len(a["obs_cam"])
@@ -121,6 +122,8 @@ def from_problem(p, options=None) -> FlatRecord:
         if p.image_frame is not None:
             arrs.update(image_frame=np.asarray(p.image_frame, np.int32), image_cam=np.asarray(p.image_cam, np.int32),
                         cam_aa0=np.asarray(p.cam_aa0, np.float64).reshape(-1, 3))
+        if p.node_gravity is not None:
+            arrs.update(node_gravity=np.asarray(p.node_gravity, np.uint8))
         return FlatRecord("ra", {"num_nodes": p.num_nodes, "fixed_node": p.fixed_node}, _opts(options), arrays=arrs)
     if isinstance(p, GpProblem):
         arrs = dict(pt_offset=np.asarray(p.pt_offset, np.int64), obs_cam=np.asarray(p.obs_cam, np.int32),

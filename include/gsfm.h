@@ -155,7 +155,7 @@ typedef struct gsfm_ra_options {
   int32_t weight_type;                     /* 0 = GEMAN_MCCLURE, 1 = HALF_NORM */
   int32_t skip_initialization;             /* 0: maximum-spanning-tree init (gra.cc:87-138) */
   int32_t use_weight;                      /* 0 */
-  int32_t use_gravity;                     /* must be 0 (1-DoF path not implemented -> GSFM_ERR_UNSUPPORTED) */
+  int32_t use_gravity;                     /* 0; 1: frames flagged in gsfm_ra_problem.node_gravity have a 1-DoF rotation */
   /* colmap::LeastAbsoluteDeviationSolver::Options as set at gra.cc:483-486 */
   int32_t l1_admm_max_num_iterations;      /* 10 */
   double l1_admm_rho;                      /* 1.0 */
@@ -206,6 +206,16 @@ typedef struct gsfm_ra_problem {
   const int32_t* image_cam;   /* [I] */
   int32_t num_cams;           /* C */
   double* cam_rot_aa;         /* [C][3] host, in/out */
+  /* Gravity-aligned frames (use_gravity, global_rotation_averaging.cc:19-36, 207-217, 312-341, 376-418, 455-460,
+   * 639-645, 709-713, 746-749).  node_gravity [N] (NULL = no frame has gravity): 1 = frame.HasGravity(); such a frame
+   * has ONE unknown, the angle about the aligned vertical, carried in rot_aa_inout as (0, angle, 0)
+   * [AngleToRotUp(angle) = Exp((0, angle, 0)), math/gravity.cc:30-33; in: RotUpToAngle(R_align^T R_rig_from_world),
+   * gra.cc:207-211; out: the caller writes R_align * AngleToRotUp(angle) back, gra.cc:786-793].  edge_q must already be
+   * aligned, R_align2^T R_rel R_align1 for the images that have gravity (gra.cc:315-327).  A pair of two gravity
+   * frames is one row (RelAngleError of the y components; its x / z components only enter the IRLS weight), the gauge
+   * is one row when the fixed frame has gravity.  No spanning-tree start in this mode (gra.cc:60-62).  The rand()
+   * jitter RelAngleError adds within 0.01 rad of +-pi is not reproduced. */
+  const uint8_t* node_gravity;
 } gsfm_ra_problem;
 
 /* rot_aa_inout: [N][3] angle-axis of rig_from_world; in = initial estimate, out = result

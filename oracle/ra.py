@@ -401,3 +401,140 @@ def estimate_rotations_rig(num_frames, num_cams, image_frame, image_cam, edge_i,
             if avg < opt.irls_step_convergence_threshold:
                 break
     return True, rot_f, rot_c
+
+
+# ------------------------------------------------------------------------------------------
+# Gravity-aligned frames: 1-DoF unknowns (gra.cc:19-36, 207-217, 312-341, 376-446, 455-468, 639-645, 709-713, 746-749)
+# ------------------------------------------------------------------------------------------
+def rel_angle_error(angle_12, angle_1, angle_2):
+    """RelAngleError (gra.cc:19-36) without the rand() jitter near +-pi (not reproducible by construction)."""
+    est = (angle_2 - angle_1) - angle_12
+    return (est + np.pi) % (2.0 * np.pi) - np.pi  # [-pi, pi)
+
+
+def estimate_rotations_gravity(num_nodes, edge_i, edge_j, edge_q, edge_weight, node_gravity, node_aa0, fixed_node=0,
+                               options: RotationEstimatorOptions | None = None, trace: RaTrace | None = None):
+    """RotationEstimator::EstimateRotations with use_gravity: a frame with gravity has ONE unknown, the angle about the
+    (aligned) vertical, stored here as node_aa0[n] = (0, angle, 0) — AngleToRotUp(angle) = Exp((0, angle, 0)),
+    math/gravity.cc:30-33 —, the others three.  edge_q are the relative rotations ALREADY aligned by the caller
+    (R_align2^T R_rel R_align1, gra.cc:315-327).  No spanning-tree start in this mode (gra.cc:60-62).
+
+    Rows exactly as SetupLinearSystem writes them: a pair of two gravity frames has one row, -1 / +1 on the two angles
+    (gra.cc:390-397), residual RelAngleError of the y components, constant xz_error in the IRLS weight (gra.cc:329-338,
+    571-573); other pairs have three rows where a gravity frame only appears in the y row (gra.cc:399-418); the gauge is
+    one row when the fixed frame has gravity (gra.cc:455-460).  Returns (ok, rot_aa [N,3])."""
+    opt = options or RotationEstimatorOptions()
+    N = int(num_nodes)
+    grav = np.asarray(node_gravity).astype(bool)
+    edge_i = np.asarray(edge_i, dtype=np.int64)
+    edge_j = np.asarray(edge_j, dtype=np.int64)
+    edge_R = so3.quat_wxyz_to_rotmat(np.asarray(edge_q, dtype=np.float64))
+    E = edge_i.shape[0]
+    rot = np.array(node_aa0, dtype=np.float64, copy=True)
+    # unknown layout: one column per gravity frame, three per other frame
+    col0 = np.concatenate([[0], np.cumsum(np.where(grav, 1, 3))])
+    ncol = int(col0[-1])
+    aa_rel = so3.log_rot(edge_R)
+    both = grav[edge_i] & grav[edge_j]
+    xz_err = aa_rel[:, 0] ** 2 + aa_rel[:, 2] ** 2
+    angle_rel = aa_rel[:, 1]
+    row0 = np.concatenate([[0], np.cumsum(np.where(both, 1, 3))])
+    nrow_e = int(row0[-1])
+    gauge_rows = 1 if grav[fixed_node] else 3
+    ri, ci, vi = [], [], []
+    for e in range(E):
+        i, j, r = int(edge_i[e]), int(edge_j[e]), int(row0[e])
+        if both[e]:
+            ri += [r, r]; ci += [col0[i], col0[j]]; vi += [-1.0, 1.0]
+            continue
+        for node, sgn in ((i, -1.0), (j, 1.0)):
+            if grav[node]:
+                ri.append(r + 1); ci.append(col0[node]); vi.append(sgn)
+            else:
+                for c in range(3):
+                    ri.append(r + c); ci.append(col0[node] + c); vi.append(sgn)
+    for c in range(gauge_rows):
+        ri.append(nrow_e + c); ci.append(col0[fixed_node] + c); vi.append(1.0)
+    A = sp.csr_matrix((vi, (ri, ci)), shape=(nrow_e + gauge_rows, ncol))
+    ew = np.where(np.asarray(edge_weight) >= 0, edge_weight, 1.0) if opt.use_weight else np.ones(E)
+    weights = np.concatenate([np.repeat(ew, np.where(both, 1, 3)), np.ones(gauge_rows)])
+    fixed_rot = rot[fixed_node].copy()
+    rows_of = [np.arange(row0[e], row0[e + 1]) for e in range(E)]
+
+    def residuals(r):
+        Rn = so3.exp_aa(r)
+        M = np.transpose(Rn[edge_j], (0, 2, 1)) @ edge_R @ Rn[edge_i]
+        b3 = -so3.log_rot(M)
+        b1 = rel_angle_error(angle_rel, r[edge_i, 1], r[edge_j, 1])
+        b = np.empty(nrow_e + gauge_rows)
+        for e in range(E):
+            b[rows_of[e]] = b1[e] if both[e] else b3[e]
+        if grav[fixed_node]:
+            b[nrow_e] = r[fixed_node, 1] - fixed_rot[1]  # gra.cc:746-749
+        else:
+            b[nrow_e:] = so3.log_rot(so3.exp_aa(fixed_rot).T @ Rn[fixed_node])
+        return b
+
+    def update(r, step):
+        r = r.copy()
+        for n in range(N):
+            s = step[col0[n] : col0[n + 1]]
+            if grav[n]:
+                r[n, 1] -= s[0]  # gra.cc:643-644
+            else:
+                r[n] = so3.log_rot(so3.exp_aa(r[n][None]) @ so3.exp_aa(-s[None]))[0]
+        return r
+
+    def avg_step(step):
+        tot = 0.0
+        for n in range(N):
+            s = step[col0[n] : col0[n + 1]]
+            tot += abs(s[0]) if grav[n] else np.linalg.norm(s)
+        return tot / N
+
+    if opt.max_num_l1_iterations > 0:
+        l1 = LeastAbsoluteDeviationSolver(sp.diags(weights) @ A, opt)
+        last_norm = curr_norm = 0.0
+        b = residuals(rot)
+        for it in range(opt.max_num_l1_iterations):
+            last_norm = curr_norm
+            step = l1.solve(weights * b)
+            if np.isnan(step).any():
+                return False, rot
+            curr_norm = float(np.linalg.norm(step))
+            rot = update(rot, step)
+            b = residuals(rot)
+            avg = avg_step(step)
+            if trace is not None:
+                trace.l1_steps.append(avg)
+                trace.l1_iterations = it + 1
+            if avg < opt.l1_step_convergence_threshold or abs(last_norm - curr_norm) < so3.EPS:
+                break
+    if opt.max_num_irls_iterations > 0:
+        sigma = np.radians(opt.irls_loss_parameter_sigma)
+        At = A.T.tocsr()
+        b = residuals(rot)
+        w_irls = np.ones(nrow_e + gauge_rows)
+        for it in range(opt.max_num_irls_iterations):
+            for e in range(E):
+                rr = rows_of[e]
+                e2 = b[rr[0]] ** 2 + xz_err[e] if both[e] else float((b[rr] ** 2).sum())
+                if opt.weight_type == GEMAN_MCCLURE:
+                    tmp = e2 + sigma * sigma
+                    w = sigma * sigma / (tmp * tmp)
+                else:
+                    w = np.power(e2, (0.5 - 2) / 2) if e2 > 0 else np.inf
+                w_irls[rr] = w
+            if np.isnan(w_irls).any():
+                return False, rot
+            at_weight = At @ sp.diags(w_irls * weights)
+            step = spla.splu((at_weight @ A).tocsc()).solve(at_weight @ b)
+            rot = update(rot, step)
+            b = residuals(rot)
+            avg = avg_step(step)
+            if trace is not None:
+                trace.irls_steps.append(avg)
+                trace.irls_iterations = it + 1
+            if avg < opt.irls_step_convergence_threshold:
+                break
+    return True, rot
