@@ -174,6 +174,29 @@ inline int CamFromRigState(const glomap::Image& im, std::unordered_map<rig_t, gl
   return 0;
 }
 
+// quaternion (w,x,y,z) of a rotation matrix given through (row, col) access (Eigen::Matrix3d)
+template <typename Mat>
+inline void MatToQuatWxyz(const Mat& R, double* q) {
+  const double tr = R(0, 0) + R(1, 1) + R(2, 2);
+  if (tr > 0.0) {
+    const double t = std::sqrt(tr + 1.0);
+    q[0] = 0.5 * t;
+    q[1] = (R(2, 1) - R(1, 2)) * 0.5 / t;
+    q[2] = (R(0, 2) - R(2, 0)) * 0.5 / t;
+    q[3] = (R(1, 0) - R(0, 1)) * 0.5 / t;
+    return;
+  }
+  int i = 0;
+  if (R(1, 1) > R(0, 0)) i = 1;
+  if (R(2, 2) > R(i, i)) i = 2;
+  const int j = (i + 1) % 3, k = (j + 1) % 3;
+  const double t = std::sqrt(R(i, i) - R(j, j) - R(k, k) + 1.0);
+  q[1 + i] = 0.5 * t;
+  q[0] = (R(k, j) - R(j, k)) * 0.5 / t;
+  q[1 + j] = (R(j, i) + R(i, j)) * 0.5 / t;
+  q[1 + k] = (R(k, i) + R(i, k)) * 0.5 / t;
+}
+
 // colmap::AverageQuaternions with unit weights: principal eigenvector of sum q q^T (cyclic Jacobi on the 4 x 4).
 inline void AverageQuaternions(const std::vector<std::array<double, 4>>& qs, double* out) {
   double A[4][4] = {{0}}, V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
@@ -282,14 +305,19 @@ class RotationEstimator {
                          std::unordered_map<frame_t, glomap::Frame>& frames,
                          std::unordered_map<image_t, glomap::Image>& images) {
     gsfm_ctx* ctx = Context();
-    if (ctx == nullptr || options_.use_gravity) return false;
+    if (ctx == nullptr) return false;
     const bool rigged = !detail::AllTrivial(images);
+    if (options_.use_gravity) {  // gra.cc:47-58: gravity needs every cam_from_rig
+      for (auto& [rig_id, rig] : rigs)
+        for (const auto& [sid, sensor] : rig.NonRefSensors())
+          if (!sensor.has_value()) return false;
+    }
     detail::FrameIndex fidx;
     for (auto& [fid, fr] : frames)
       if (fr.is_registered) fidx.Add(fid);  // gra.cc:193-227; first one = gauge (gra.cc:248-257)
     const int N = static_cast<int>(fidx.ids.size());
     if (N == 0) return false;
-    if (rigged) {  // sensors whose cam_from_rig is to be estimated (no value, or NaN translation: gra.cc:173-191)
+    if (rigged && !options_.use_gravity) {  // sensors whose cam_from_rig is to be estimated (no value, or NaN translation: gra.cc:173-191)
       for (auto& [id, im] : images) {
         double cfr[7];
         if (im.frame_ptr != nullptr && im.IsRegistered() && detail::CamFromRigState(im, rigs, cfr) != 0)
@@ -333,6 +361,20 @@ class RotationEstimator {
         detail::QuatMul(c2inv, q21, tmp);
         detail::QuatMul(tmp, c1, qrel);
       }
+      if (options_.use_gravity) {  // R_align2^T * R_rel * R_align1 for the images that have gravity (gra.cc:315-327)
+        double qa[4], tmp[4];
+        if (i1.HasGravity()) {
+          detail::MatToQuatWxyz(i1.frame_ptr->gravity_info.GetRAlign(), qa);
+          detail::QuatMul(qrel, qa, tmp);
+          for (int j = 0; j < 4; ++j) qrel[j] = tmp[j];
+        }
+        if (i2.HasGravity()) {
+          detail::MatToQuatWxyz(i2.frame_ptr->gravity_info.GetRAlign(), qa);
+          const double qinv[4] = {qa[0], -qa[1], -qa[2], -qa[3]};
+          detail::QuatMul(qinv, qrel, tmp);
+          for (int j = 0; j < 4; ++j) qrel[j] = tmp[j];
+        }
+      }
       ei.push_back(fidx.of.at(i1.frame_id));
       ej.push_back(fidx.of.at(i2.frame_id));
       eq.insert(eq.end(), qrel, qrel + 4);
@@ -340,12 +382,30 @@ class RotationEstimator {
       en.push_back(static_cast<int32_t>(pair.inliers.size()));
     }
     std::vector<double> rot(3 * static_cast<size_t>(N));
+    std::vector<uint8_t> node_gravity(static_cast<size_t>(N), 0);
+    int fixed_node = 0, first_gravity = -1;
     for (int n = 0; n < N; ++n) {
       auto& fr = frames.at(fidx.ids[n]);
+      if (options_.use_gravity && fr.gravity_info.has_gravity) {
+        // one unknown: the angle of R_align^T * R_rig_from_world about the vertical (gra.cc:207-211), carried as (0, angle, 0)
+        double qa[4], qw[4], qp[4], aa[3];
+        detail::MatToQuatWxyz(fr.gravity_info.GetRAlign(), qa);
+        detail::QuatWxyz(fr.RigFromWorld().rotation, qw);
+        const double qinv[4] = {qa[0], -qa[1], -qa[2], -qa[3]};
+        detail::QuatMul(qinv, qw, qp);
+        detail::QuatToAngleAxis(QuatView{qp[0], qp[1], qp[2], qp[3]}, aa);
+        rot[3 * n] = 0.0;
+        rot[3 * n + 1] = aa[1];
+        rot[3 * n + 2] = 0.0;
+        node_gravity[n] = 1;
+        if (first_gravity < 0) first_gravity = n;  // the gauge goes to the first gravity frame (gra.cc:212-216)
+        continue;
+      }
       if (!fr.HasPose()) fr.SetRigFromWorld(glomap::Rigid3d());  // gra.cc:219-222 (colmap::Frame::RigFromWorld() throws without a pose)
       detail::QuatToAngleAxis(fr.RigFromWorld().rotation, &rot[3 * n]);
     }
-    bool skip_init = options_.skip_initialization;
+    if (first_gravity >= 0) fixed_node = first_gravity;
+    bool skip_init = options_.skip_initialization || options_.use_gravity;  // gra.cc:60-62: no spanning tree with gravity
     if (rigged && !skip_init) {
       // InitializeFromMaximumSpanningTree over the images (gra.cc:87-138) — a zero-iteration gsfm_ra_solve of the
       // image-level graph — then ConvertRotationsFromImageToRig (rotation_initializer.cc:86-121): rig_from_world of a
@@ -408,16 +468,18 @@ class RotationEstimator {
     o.weight_type = static_cast<int>(options_.weight_type);
     o.skip_initialization = skip_init;
     o.use_weight = options_.use_weight;
+    o.use_gravity = options_.use_gravity ? 1 : 0;
     gsfm_ra_problem p{};
     p.mem = GSFM_MEM_HOST;
     p.num_nodes = N;
+    p.node_gravity = first_gravity >= 0 ? node_gravity.data() : nullptr;
     p.num_edges = static_cast<int64_t>(ei.size());
     p.edge_i = ei.data();
     p.edge_j = ej.data();
     p.edge_q = eq.data();
     p.edge_weight = ew.data();
     p.edge_ninl = en.data();
-    p.fixed_node = 0;
+    p.fixed_node = fixed_node;
     gsfm_report rep;
     if (gsfm_ra_solve(ctx, &p, &o, rot.data(), &rep) != GSFM_OK) return false;
     // ConvertResults (gra.cc:774-816): rotation written, translation zeroed
@@ -425,6 +487,12 @@ class RotationEstimator {
       double q[4];
       detail::AngleAxisToQuatWxyz(&rot[3 * n], q);
       auto& fr = frames.at(fidx.ids[n]);
+      if (node_gravity[n]) {  // R_align * AngleToRotUp(angle), gra.cc:786-793
+        double qa[4], qr[4];
+        detail::MatToQuatWxyz(fr.gravity_info.GetRAlign(), qa);
+        detail::QuatMul(qa, q, qr);
+        for (int j = 0; j < 4; ++j) q[j] = qr[j];
+      }
       auto pose = fr.RigFromWorld();
       pose.rotation = decltype(pose.rotation)(q[0], q[1], q[2], q[3]);
       pose.translation = decltype(pose.translation)(0.0, 0.0, 0.0);

@@ -519,7 +519,76 @@ int main() {
     rigs2[1].ResetSensorFromRig(sensor_t(SensorType::CAMERA, 12));
     if (ba2.Solve(rigs2, cams2, fr2, im2, tr2)) return std::printf("BA accepted an uncalibrated rig\n"), 1;
   }
-  std::printf("ADAPTER OK ra=%.2e rad gp_ratio_err=%.2e ba=%.2e px | rigs: ra=%.2e rad gp_scale_err=%.2e ba=%.2e px cam_from_rig=%.2e rad unknown_R=%.2e rad unknown_t=%.2e\n",
+  // 7) gravity-aligned rotation averaging (use_gravity, rotation_averager_test.cc:171-212): 10 trivial frames with general
+  //    rotations, every frame carries its gravity (the world's y axis seen from the rig) and starts at R_align times a
+  //    slightly wrong angle like PrepareGravity leaves them (:58-60); the 1-DoF solve must bring the exact rotations back.
+  double grav_err = 0;
+  {
+    const int NG = 10;
+    std::unordered_map<rig_t, Rig> rigs3;
+    std::unordered_map<frame_t, Frame> fr3;
+    std::unordered_map<image_t, Image> im3;
+    ViewGraph vg3;
+    auto qmul = [](const mock_eigen::Quaterniond& a, const mock_eigen::Quaterniond& b) {
+      return mock_eigen::Quaterniond(a.w() * b.w() - a.x() * b.x() - a.y() * b.y() - a.z() * b.z(),
+                                     a.w() * b.x() + a.x() * b.w() + a.y() * b.z() - a.z() * b.y(),
+                                     a.w() * b.y() - a.x() * b.z() + a.y() * b.w() + a.z() * b.x(),
+                                     a.w() * b.z() + a.x() * b.y() - a.y() * b.x() + a.z() * b.w());
+    };
+    auto qinv = [](const mock_eigen::Quaterniond& a) { return mock_eigen::Quaterniond(a.w(), -a.x(), -a.y(), -a.z()); };
+    std::vector<mock_eigen::Quaterniond> qgt(NG);
+    for (int f = 0; f < NG; ++f) {
+      // R_f = RotX(tilt) * RotZ(roll) * RotY(heading): a tilted, rolled camera
+      const double hd = 0.55 * f, tilt = 0.3 * std::sin(1.3 * f), roll = 0.2 * std::cos(0.7 * f);
+      const mock_eigen::Quaterniond qy(std::cos(0.5 * hd), 0, std::sin(0.5 * hd), 0), qx(std::cos(0.5 * tilt), std::sin(0.5 * tilt), 0, 0),
+          qz(std::cos(0.5 * roll), 0, 0, std::sin(0.5 * roll));
+      qgt[f] = qmul(qx, qmul(qz, qy));
+      Frame fr;
+      fr.is_registered = true;
+      const double ey[3] = {0.0, 1.0, 0.0};
+      double g[3];
+      gsfm_glomap::detail::Rotate(qgt[f], ey, g);  // gravity in the rig = R_f * (0, 1, 0)
+      fr.gravity_info.SetGravity(mock_eigen::Vector3d(g[0], g[1], g[2]));
+      // start: R_align * RotY(true angle + offset); R_align^T R_f is a pure rotation about y by construction
+      double qa[4];
+      gsfm_glomap::detail::MatToQuatWxyz(fr.gravity_info.GetRAlign(), qa);
+      const mock_eigen::Quaterniond qal(qa[0], qa[1], qa[2], qa[3]);
+      const mock_eigen::Quaterniond qrel = qmul(qinv(qal), qgt[f]);
+      const double ang = 2.0 * std::atan2(qrel.y(), qrel.w()) + (f == 0 ? 0.0 : 0.15 * std::sin(2.1 * f));
+      Rigid3d pose;
+      pose.rotation = qmul(qal, mock_eigen::Quaterniond(std::cos(0.5 * ang), 0, std::sin(0.5 * ang), 0));
+      fr.SetRigFromWorld(pose);
+      fr3[f] = fr;
+      Image im;
+      im.image_id = f;
+      im.camera_id = 1;
+      im.frame_id = f;
+      im3[f] = im;
+    }
+    for (int f = 0; f < NG; ++f) im3[f].frame_ptr = &fr3[f];
+    for (int a = 0; a < NG; ++a)
+      for (int b = a + 1; b < NG; ++b) {
+        if (b - a > 3 && b - a < NG - 3) continue;
+        ImagePair pr;
+        pr.image_id1 = a;
+        pr.image_id2 = b;
+        pr.cam2_from_cam1.rotation = qmul(qgt[b], qinv(qgt[a]));
+        pr.inliers.resize(60);
+        vg3.image_pairs[(uint64_t)a * 1000 + b] = pr;
+      }
+    RotationEstimatorOptions rog;
+    rog.use_gravity = true;
+    gsfm_glomap::RotationEstimator rag(rog);
+    if (!rag.EstimateRotations(vg3, rigs3, fr3, im3)) return std::printf("gravity RA failed\n"), 1;
+    for (int a = 0; a < NG; ++a)
+      for (int b = a + 1; b < NG; ++b) {
+        const auto e = qmul(qmul(fr3[b].RigFromWorld().rotation, qinv(fr3[a].RigFromWorld().rotation)), qinv(qmul(qgt[b], qinv(qgt[a]))));
+        grav_err = std::fmax(grav_err, 2.0 * std::asin(std::fmin(1.0, std::sqrt(e.x() * e.x() + e.y() * e.y() + e.z() * e.z()))));
+      }
+    if (grav_err > 1e-6) return std::printf("gravity RA: relative rotation off by %.3e rad\n", grav_err), 1;
+  }
+  std::printf("ADAPTER OK gravity_ra=%.2e rad ", grav_err);
+  std::printf("ra=%.2e rad gp_ratio_err=%.2e ba=%.2e px | rigs: ra=%.2e rad gp_scale_err=%.2e ba=%.2e px cam_from_rig=%.2e rad unknown_R=%.2e rad unknown_t=%.2e\n",
               worst, std::fabs(ratio / ratio_ref - 1.0), maxerr, rig_ra, rig_gp, rig_ba, rig_sens, rig_unk_rot, rig_unk);
   return 0;
 }

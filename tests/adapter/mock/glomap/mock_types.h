@@ -3,6 +3,7 @@
 // colmap / Eigen types they expose).  They exist only so that the adapter can be compiled and run in
 // a repository that does not vendor GLOMAP: nothing here is reference code.
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <map>
@@ -36,6 +37,11 @@ struct MatrixXi {  // Eigen::MatrixXi shape used by ImagePair::matches: (row, co
     d.push_back(a);
     d.push_back(b);
   }
+};
+struct Matrix3d {  // (row, col) access like Eigen::Matrix3d; identity by default
+  double m[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  double& operator()(int r, int c) { return m[3 * r + c]; }
+  const double& operator()(int r, int c) const { return m[3 * r + c]; }
 };
 struct Quaterniond {  // Eigen's constructor order: (w, x, y, z)
   double w_ = 1, x_ = 0, y_ = 0, z_ = 0;
@@ -124,7 +130,38 @@ struct Camera {
   std::vector<double> params;
   bool has_prior_focal_length = true;
 };
+// glomap::GravityInfo (scene/frame.h:11-27): R_align's second column is the gravity direction (math/gravity.cc:10-24);
+// the stand-in completes the basis with a cross product instead of Eigen's Householder QR (any right-handed completion
+// gives a valid alignment)
+struct GravityInfo {
+  bool has_gravity = false;
+  const mock_eigen::Matrix3d& GetRAlign() const { return R_align_; }
+  mock_eigen::Vector3d GetGravity() const { return gravity_in_rig_; }
+  void SetGravity(const mock_eigen::Vector3d& g) {
+    gravity_in_rig_ = g;
+    const double n = std::sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+    const double v[3] = {g[0] / n, g[1] / n, g[2] / n};
+    double a[3] = {1, 0, 0};
+    if (std::fabs(v[0]) > 0.9) { a[0] = 0; a[2] = 1; }
+    double x[3] = {a[1] * v[2] - a[2] * v[1], a[2] * v[0] - a[0] * v[2], a[0] * v[1] - a[1] * v[0]};  // a x v
+    const double xn = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    for (double& c : x) c /= xn;
+    const double z[3] = {x[1] * v[2] - x[2] * v[1], x[2] * v[0] - x[0] * v[2], x[0] * v[1] - x[1] * v[0]};  // x x v
+    for (int r = 0; r < 3; ++r) {
+      R_align_(r, 0) = x[r];
+      R_align_(r, 1) = v[r];
+      R_align_(r, 2) = z[r];
+    }
+    has_gravity = true;
+  }
+
+ private:
+  mock_eigen::Vector3d gravity_in_rig_;
+  mock_eigen::Matrix3d R_align_;
+};
 struct Frame {
+  GravityInfo gravity_info;
+  bool HasGravity() const { return gravity_info.has_gravity; }
   bool is_registered = false;
   bool has_pose = false;
   Rigid3d pose;
@@ -167,6 +204,10 @@ struct Image {
   bool HasTrivialFrame() const {
     return frame_ptr == nullptr || frame_ptr->RigPtr() == nullptr ||
            frame_ptr->RigPtr()->IsRefSensor(sensor_t(SensorType::CAMERA, camera_id));
+  }
+  bool HasGravity() const {  // scene/image.h:78-84
+    return frame_ptr->HasGravity() &&
+           (HasTrivialFrame() || frame_ptr->RigPtr()->MaybeSensorFromRig(sensor_t(SensorType::CAMERA, camera_id)).has_value());
   }
   // CamFromWorld() = cam_from_rig * rig_from_world (image.h:62-65 through colmap::Frame::SensorFromWorld)
   Rigid3d CamFromWorld() const {
