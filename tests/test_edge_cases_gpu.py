@@ -1,6 +1,8 @@
 """Edge cases through the C ABI on the GPU: long tracks (> 64 observations: the multi-round path of the
 wave tiles), ragged tracks incl. empty and too-short ones, empty problems and bad indices (status codes
 instead of crashes), a single camera."""
+import copy
+
 import numpy as np
 import pytest
 
@@ -97,9 +99,12 @@ def test_empty_and_invalid_inputs_return_status_codes(gsfm_ctx):
     b.intr_model = np.array([17], np.int32)
     rc, *_ = estimators.ba_solve(b, ctx=gsfm_ctx)
     assert rc == -7  # GSFM_ERR_UNSUPPORTED
-    # rotation averaging: gravity path is refused like the reference refuses unsupported rigs (gra.cc:47-58)
+    # rotation averaging: gravity together with cam_from_rig unknowns is refused like the reference refuses it (gra.cc:47-58)
     g = synthetic.make_ring_view_graph(20, 3, seed=0)
-    rc, *_ = estimators.ra_solve(g, estimators.RotationEstimatorOptions(use_gravity=True), ctx=gsfm_ctx)
+    gr = copy.deepcopy(g)
+    gr.image_frame, gr.image_cam = np.arange(20, dtype=np.int32), np.where(np.arange(20) % 2 == 1, 0, -1).astype(np.int32)
+    gr.cam_aa0 = np.zeros((1, 3))
+    rc, *_ = estimators.ra_solve(gr, estimators.RotationEstimatorOptions(use_gravity=True, skip_initialization=True), ctx=gsfm_ctx)
     assert rc == -7
     # the context is still usable afterwards
     rc, rot, rep = estimators.ra_solve(g, ctx=gsfm_ctx)
