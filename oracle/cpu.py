@@ -78,6 +78,7 @@ class _BaOptions(C.Structure):
         ("optimize_principal_point", C.c_int32),
         ("optimize_points", C.c_int32),
         ("min_num_view_per_track", C.c_int32),
+        ("optimize_rig_poses", C.c_int32),
     ]
 
 
@@ -264,15 +265,16 @@ def gp_solve(num_cams, pt_offset, obs_cam, obs_dir, obs_calibrated, cam_center, 
 def ba_solve(num_cams, pt_offset, obs_cam, obs_xy, cam_intr, intr_model, fixed_cam, cam_q, cam_t, pt_xyz, intr_params,
              options: _ba.BundleAdjusterOptions | None = None, threads: int = 0, pcg_tol: float = 1e-14,
              pcg_max: int = 20000, order: int = 0, verbose: bool = False, image_frame=None, image_cam_from_rig=None,
-             image_intr=None):
-    """Same contract as oracle.ba.solve: returns (ok, q [N,4], t [N,3], X [P,3], intr [K,8], CpuSummary)."""
+             image_intr=None, image_sensor=None, sensor_cam_from_rig=None):
+    """Same contract as oracle.ba.solve: returns (ok, q [N,4], t [N,3], X [P,3], intr [K,8], CpuSummary); with sensor
+    blocks (options.optimize_rig_poses) the summary carries their result as summary.sensor_cam_from_rig."""
     opt = options or _ba.BundleAdjusterOptions()
     lib = load()
     o = _BaOptions()
     _fill_lm(o, opt.lm, pcg_tol, pcg_max, order, verbose)
     o.thres_loss_function = opt.thres_loss_function
     for name in ("optimize_rotations", "optimize_translation", "optimize_intrinsics", "optimize_principal_point",
-                 "optimize_points", "min_num_view_per_track"):
+                 "optimize_points", "min_num_view_per_track", "optimize_rig_poses"):
         setattr(o, name, int(getattr(opt, name)))
     off = np.ascontiguousarray(pt_offset, dtype=np.int64)
     cam = np.ascontiguousarray(obs_cam, dtype=np.int32)
@@ -281,6 +283,8 @@ def ba_solve(num_cams, pt_offset, obs_cam, obs_xy, cam_intr, intr_model, fixed_c
     imf = None if image_frame is None else np.ascontiguousarray(image_frame, dtype=np.int32)
     imc = None if image_frame is None else np.ascontiguousarray(image_cam_from_rig, dtype=np.float64)
     imi = None if image_frame is None else np.ascontiguousarray(image_intr, dtype=np.int32)
+    ims = None if image_sensor is None else np.ascontiguousarray(image_sensor, dtype=np.int32)
+    sen = None if image_sensor is None else np.array(sensor_cam_from_rig, dtype=np.float64, copy=True, order="C")
     mdl = np.ascontiguousarray(intr_model, dtype=np.int32)
     q = np.array(cam_q, dtype=np.float64, copy=True, order="C")
     t = np.array(cam_t, dtype=np.float64, copy=True, order="C")
@@ -292,10 +296,13 @@ def ba_solve(num_cams, pt_offset, obs_cam, obs_xy, cam_intr, intr_model, fixed_c
                           _p(ci, C.c_int32), _p(mdl, C.c_int32), C.byref(o), _p(q, C.c_double), _p(t, C.c_double),
                           _p(X, C.c_double), _p(intr, C.c_double), C.byref(rep), C.c_int32(_threads(threads)),
                           None if imf is None else _p(imf, C.c_int32), None if imc is None else _p(imc, C.c_double),
-                          None if imi is None else _p(imi, C.c_int32))
+                          None if imi is None else _p(imi, C.c_int32), C.c_int32(0 if sen is None else sen.shape[0]),
+                          None if ims is None else _p(ims, C.c_int32), None if sen is None else _p(sen, C.c_double))
     s = _summary(rep)
     if rc == -5:
         s.usable = False
+    if sen is not None and opt.optimize_rig_poses:
+        s.sensor_cam_from_rig = sen
     return rc == 0, q, t, X, intr, s
 
 

@@ -39,6 +39,7 @@ struct BaOptionsC {
   double thres_loss_function;
   int32_t optimize_rotations, optimize_translation, optimize_intrinsics, optimize_principal_point, optimize_points;
   int32_t min_num_view_per_track;
+  int32_t optimize_rig_poses;
 };
 
 struct BaReport {
@@ -147,13 +148,21 @@ struct Ba : LmProblem {
   std::vector<i64> poff;
   std::vector<double> xy;
   std::vector<double> sens;           // [M][12] known rigs: cam_from_rig (R row-major 9 | t 3) of the observation's image, else empty
+  // optimize_rig_poses (RigReprojErrorCostFunctor, ba.cc:161-179): S cam_from_rig blocks, stored as pose blocks N .. N+S-1
+  // of q / t and of the reduced vector; sblk[k] = block of observation k's sensor or -1
+  i64 S = 0;
+  std::vector<int32_t> sblk;
+  std::vector<int32_t> sobs, sown;    // observations that have a block, and their block (owner lists of the blocks)
+  OwnerLists bysens;
+  std::vector<double> Js;             // [M][2][6] Jacobian w.r.t. the sensor block
+  std::vector<double> Msblk;          // block-Jacobi: 6x6 per sensor block
   std::vector<int32_t> cam_intr, model;
   OwnerLists bycam, byintr;
   Huber loss;
   std::vector<uint8_t> rot_free, trn_free;
   std::vector<uint8_t> free_par;      // [K][8]
   std::vector<int32_t> icol;          // [K][8] -> compact column or -1
-  i64 nfree = 0, nred = 0;            // reduced system = 6N + nfree
+  i64 nfree = 0, nred = 0;            // reduced system = 6 (N + S) + nfree
   double mpt;                         // optimize_points
   double lm_lo, lm_hi;
   bool rev;
@@ -182,20 +191,35 @@ struct Ba : LmProblem {
     return std::min(std::max(j2 * h, lm_lo), lm_hi) / (radius * j2);
   }
 
+  // Jcam / arig (optional): d(uv)/d(x_c) before the chain through R_s, and R_s x_rig — what the sensor block's rotation acts on
   void residual(i64 k, const std::vector<double>& qq, const std::vector<double>& tt, const std::vector<double>& XX,
-                const std::vector<double>& in, double* r, double* R, double* RX, double* Jx, double* Jpar, bool* valid) const {
+                const std::vector<double>& in, double* r, double* R, double* RX, double* Jx, double* Jpar, bool* valid,
+                double* Jcam = nullptr, double* arig = nullptr) const {
     const i64 n = cam[k], p = pt[k], b = ik[k];
     quat_to_rot(&qq[4 * n], R);
     const double* x = &XX[3 * p];
     for (int i = 0; i < 3; ++i) RX[i] = R[3 * i] * x[0] + R[3 * i + 1] * x[1] + R[3 * i + 2] * x[2];
     double xc[3] = {RX[0] + tt[3 * n], RX[1] + tt[3 * n + 1], RX[2] + tt[3 * n + 2]};
     const double* S = sens.empty() ? nullptr : &sens[12 * k];
-    if (S) {  // RigReprojErrorConstantRigCostFunctor (bundle_adjustment.cc:147-160): x_c = cam_from_rig * (rig_from_world * X)
+    double Sv[12];
+    if (!sblk.empty() && sblk[k] >= 0) {  // the cam_from_rig is the sensor block's current value
+      const i64 sb = N + sblk[k];
+      quat_to_rot(&qq[4 * sb], Sv);
+      for (int i = 0; i < 3; ++i) Sv[9 + i] = tt[3 * sb + i];
+      S = Sv;
+    }
+    if (S) {  // RigReprojError*CostFunctor (bundle_adjustment.cc:147-179): x_c = cam_from_rig * (rig_from_world * X)
       const double xr[3] = {xc[0], xc[1], xc[2]};
-      for (int i = 0; i < 3; ++i) xc[i] = S[3 * i] * xr[0] + S[3 * i + 1] * xr[1] + S[3 * i + 2] * xr[2] + S[9 + i];
+      for (int i = 0; i < 3; ++i) {
+        const double a = S[3 * i] * xr[0] + S[3 * i + 1] * xr[1] + S[3 * i + 2] * xr[2];
+        if (arig) arig[i] = a;
+        xc[i] = a + S[9 + i];
+      }
     }
     double uv[2];
     *valid = project(model[b], &in[MAXP * b], xc, uv, Jx, Jpar);
+    if (Jcam)
+      for (int i = 0; i < 6; ++i) Jcam[i] = *valid ? Jx[i] : 0.0;
     if (*valid && S) {  // d(uv)/d(x_rig) = d(uv)/d(x_c) R_s: everything downstream differentiates through the rig-frame point
       double J2[6];
       for (int i = 0; i < 2; ++i)
@@ -228,12 +252,13 @@ struct Ba : LmProblem {
     Jc.resize(12 * M);
     Jp.resize(6 * M);
     Ji.resize(16 * M);
+    if (S > 0) Js.assign(12 * M, 0.0);
     std::vector<double> rho(M);
 #pragma omp parallel for schedule(static)
     for (i64 k = 0; k < M; ++k) {
-      double r[2], R[9], RX[3], Jx[6], Jpar[16];
+      double r[2], R[9], RX[3], Jx[6], Jpar[16], Jcam[6], arig[3] = {0, 0, 0};
       bool valid;
-      residual(k, q, t, X, intr, r, R, RX, Jx, Jpar, &valid);
+      residual(k, q, t, X, intr, r, R, RX, Jx, Jpar, &valid, Jcam, arig);
       double r0, r1;
       loss.eval(r[0] * r[0] + r[1] * r[1], r0, r1);
       rho[k] = r0;
@@ -255,6 +280,15 @@ struct Ba : LmProblem {
         Jc[12 * k + 6 * i + 5] = ft * j2;
         for (int j = 0; j < 3; ++j) Jp[6 * k + 3 * i + j] = mpt * (j0 * R[j] + j1 * R[3 + j] + j2 * R[6 + j]);
         for (int j = 0; j < MAXP; ++j) Ji[16 * k + 8 * i + j] = free_par[MAXP * b + j] ? sw * Jpar[8 * i + j] : 0.0;
+        if (S > 0 && sblk[k] >= 0) {  // x_c = Exp(2 d_rot) (R_s x_rig) + t_s + d_trn: always free (ba.cc:296-309)
+          const double c0 = sw * Jcam[3 * i], c1 = sw * Jcam[3 * i + 1], c2 = sw * Jcam[3 * i + 2];
+          Js[12 * k + 6 * i + 0] = -2.0 * (c1 * arig[2] - c2 * arig[1]);
+          Js[12 * k + 6 * i + 1] = -2.0 * (-c0 * arig[2] + c2 * arig[0]);
+          Js[12 * k + 6 * i + 2] = -2.0 * (c0 * arig[1] - c1 * arig[0]);
+          Js[12 * k + 6 * i + 3] = c0;
+          Js[12 * k + 6 * i + 4] = c1;
+          Js[12 * k + 6 * i + 5] = c2;
+        }
       }
     }
     const double cost = 0.5 * chunked_sum(M, [&](i64 k) { return rho[k]; });
@@ -292,6 +326,21 @@ struct Ba : LmProblem {
         gred[6 * n + j] = acc[12 * n + j];
         hred[6 * n + j] = acc[12 * n + 6 + j];
       }
+    if (S > 0) {
+      std::vector<double> accs(12 * S);
+      bysens.reduce<12>(accs.data(), rev, [&](i64 e, double* a) {
+        const i64 k = sobs[e];
+        for (int j = 0; j < 6; ++j) {
+          a[j] += Js[12 * k + j] * rt[2 * k] + Js[12 * k + 6 + j] * rt[2 * k + 1];
+          a[6 + j] += Js[12 * k + j] * Js[12 * k + j] + Js[12 * k + 6 + j] * Js[12 * k + 6 + j];
+        }
+      });
+      for (i64 sb = 0; sb < S; ++sb)
+        for (int j = 0; j < 6; ++j) {
+          gred[6 * (N + sb) + j] = accs[12 * sb + j];
+          hred[6 * (N + sb) + j] = accs[12 * sb + 6 + j];
+        }
+    }
     std::vector<double> acci(16 * K);
     byintr.reduce<16>(acci.data(), rev, [&](i64 k, double* a) {
       for (int j = 0; j < 8; ++j) {
@@ -327,6 +376,13 @@ struct Ba : LmProblem {
     for (int j = 0; j < 6; ++j) {
       a[0] += Jc[12 * k + j] * z[6 * n + j];
       a[1] += Jc[12 * k + 6 + j] * z[6 * n + j];
+    }
+    if (S > 0 && sblk[k] >= 0) {
+      const i64 o = 6 * (N + sblk[k]);
+      for (int j = 0; j < 6; ++j) {
+        a[0] += Js[12 * k + j] * z[o + j];
+        a[1] += Js[12 * k + 6 + j] * z[o + j];
+      }
     }
     for (int j = 0; j < MAXP; ++j) {
       const int32_t col = icol[MAXP * b + j];
@@ -372,6 +428,14 @@ struct Ba : LmProblem {
       for (int j = 0; j < 6; ++j) a[j] += Jc[12 * k + j] * e[2 * k] + Jc[12 * k + 6 + j] * e[2 * k + 1];
     });
     std::copy(acc.begin(), acc.end(), out.begin());
+    if (S > 0) {
+      std::vector<double> accs(6 * S);
+      bysens.reduce<6>(accs.data(), rev, [&](i64 ee, double* a) {
+        const i64 k = sobs[ee];
+        for (int j = 0; j < 6; ++j) a[j] += Js[12 * k + j] * e[2 * k] + Js[12 * k + 6 + j] * e[2 * k + 1];
+      });
+      std::copy(accs.begin(), accs.end(), out.begin() + 6 * N);
+    }
     if (nfree > 0) {
       std::vector<double> acci(8 * K);
       byintr.reduce<8>(acci.data(), rev, [&](i64 k, double* a) {
@@ -460,7 +524,7 @@ struct Ba : LmProblem {
     t2 = t;
     X2 = X;
     intr2 = intr;
-    for (i64 n = 0; n < N; ++n) {
+    for (i64 n = 0; n < N + S; ++n) {
       const double* d = &dy[6 * n];
       const double nr = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
       const double kk = nr > 0 ? std::sin(nr) / nr : 1.0;
@@ -549,6 +613,35 @@ struct Ba : LmProblem {
       std::memcpy(&Mblk[(size_t)196 * n], B, sizeof B);
     }
     if (!ok) return false;
+    if (S > 0) {  // one 6 x 6 block per sensor block: Js^T (I - Jp Hpp^-1 Jp^T) Js summed per observation + damping
+      std::vector<double> accs((size_t)36 * S);
+      bysens.reduce<36>(accs.data(), rev, [&](i64 ee, double* a) {
+        const i64 k = sobs[ee];
+        const double* H = &Hinv[9 * (i64)pt[k]];
+        double JH[2][3];
+        for (int i = 0; i < 2; ++i)
+          for (int j = 0; j < 3; ++j)
+            JH[i][j] = Jp[6 * k + 3 * i] * H[j] + Jp[6 * k + 3 * i + 1] * H[3 + j] + Jp[6 * k + 3 * i + 2] * H[6 + j];
+        double G[2][2];
+        for (int i = 0; i < 2; ++i)
+          for (int j = 0; j < 2; ++j)
+            G[i][j] = JH[i][0] * Jp[6 * k + 3 * j] + JH[i][1] * Jp[6 * k + 3 * j + 1] + JH[i][2] * Jp[6 * k + 3 * j + 2];
+        const double A00 = 1.0 - G[0][0], A01 = -G[0][1], A10 = -G[1][0], A11 = 1.0 - G[1][1];
+        for (int i = 0; i < 6; ++i) {
+          const double l0 = Js[12 * k + i] * A00 + Js[12 * k + 6 + i] * A10, l1 = Js[12 * k + i] * A01 + Js[12 * k + 6 + i] * A11;
+          for (int j = 0; j < 6; ++j) a[6 * i + j] += l0 * Js[12 * k + j] + l1 * Js[12 * k + 6 + j];
+        }
+      });
+      Msblk.assign((size_t)36 * S, 0.0);
+      for (i64 sb = 0; sb < S; ++sb) {
+        double B[36];
+        for (int i = 0; i < 6; ++i)
+          for (int j = 0; j < 6; ++j) B[6 * i + j] = 0.5 * (accs[(size_t)36 * sb + 6 * i + j] + accs[(size_t)36 * sb + 6 * j + i]);
+        for (int j = 0; j < 6; ++j) B[7 * j] += dred[6 * (N + sb) + j];
+        if (!spd_inverse(B, 6)) return false;
+        std::memcpy(&Msblk[(size_t)36 * sb], B, sizeof B);
+      }
+    }
     Miblk.assign((size_t)64 * K, 0.0);
     bool any_shared = false;
     for (i64 b = 0; b < K; ++b) any_shared = any_shared || intr_owner[b] < 0;
@@ -615,6 +708,15 @@ struct Ba : LmProblem {
         if (col >= 0) z[col] = zv[6 + j];
       }
     }
+    for (i64 sb = 0; sb < S; ++sb) {
+      const double* B = &Msblk[(size_t)36 * sb];
+      const i64 o = 6 * (N + sb);
+      for (int i = 0; i < 6; ++i) {
+        double sum = 0.0;
+        for (int j = 0; j < 6; ++j) sum += B[6 * i + j] * r[o + j];
+        z[o + i] = sum;
+      }
+    }
     for (i64 b = 0; b < K; ++b) {
       if (intr_owner[b] >= 0) continue;
       const double* B = &Miblk[(size_t)64 * b];
@@ -652,13 +754,16 @@ int orc_ba_solve(int32_t num_cams, int32_t num_intr, int32_t fixed_cam, i64 num_
                  const int32_t* obs_cam, const double* obs_xy, const int32_t* cam_intr, const int32_t* intr_model,
                  const orc::BaOptionsC* o, double* cam_q_inout, double* cam_t_inout, double* pt_xyz_inout,
                  double* intr_params_inout, orc::BaReport* rep, int32_t num_threads, const int32_t* image_frame,
-                 const double* image_cam_from_rig, const int32_t* image_intr) {
+                 const double* image_cam_from_rig, const int32_t* image_intr, int32_t num_sensors,
+                 const int32_t* image_sensor, double* sensor_cam_from_rig_inout) {
   using namespace orc;
   const double t0 = omp_get_wtime();
   if (num_threads > 0) omp_set_num_threads(num_threads);
   Ba g;
   g.N = num_cams;
   g.K = num_intr;
+  const bool have_sens = image_frame && num_sensors > 0 && image_sensor && sensor_cam_from_rig_inout;
+  g.S = (have_sens && o->optimize_rig_poses) ? num_sensors : 0;
   std::vector<i64> used_pts;
   g.poff.push_back(0);
   for (i64 p = 0; p < num_pts; ++p) {
@@ -671,10 +776,20 @@ int orc_ba_solve(int32_t num_cams, int32_t num_intr, int32_t fixed_cam, i64 num_
         const i64 im = obs_cam[k];
         g.cam.push_back(image_frame[im]);
         g.ik.push_back(image_intr[im]);
+        // the cam_from_rig of an image with a sensor entry is the table's value (constant, or the start of its block)
+        const double* cfr = (have_sens && image_sensor[im] >= 0) ? sensor_cam_from_rig_inout + 7 * image_sensor[im]
+                                                                   : image_cam_from_rig + 7 * im;
         double R[9];
-        quat_to_rot(image_cam_from_rig + 7 * im, R);
+        quat_to_rot(cfr, R);
         for (int j = 0; j < 9; ++j) g.sens.push_back(R[j]);
-        for (int j = 0; j < 3; ++j) g.sens.push_back(image_cam_from_rig[7 * im + 4 + j]);
+        for (int j = 0; j < 3; ++j) g.sens.push_back(cfr[4 + j]);
+        if (g.S > 0) {
+          g.sblk.push_back(image_sensor[im]);
+          if (image_sensor[im] >= 0) {
+            g.sobs.push_back((int32_t)g.cam.size() - 1);
+            g.sown.push_back(image_sensor[im]);
+          }
+        }
       } else {
         g.cam.push_back(obs_cam[k]);
         g.ik.push_back(cam_intr[obs_cam[k]]);
@@ -698,6 +813,7 @@ int orc_ba_solve(int32_t num_cams, int32_t num_intr, int32_t fixed_cam, i64 num_
     if (g.model[b] < 0 || g.model[b] > 4) return -7;
   g.bycam.build(g.N, g.M, g.cam.data());
   g.byintr.build(g.K, g.M, g.ik.data());
+  if (g.S > 0) g.bysens.build(g.S, (i64)g.sobs.size(), g.sown.data());
   g.loss = {o->thres_loss_function, 1.0};
   g.rot_free.assign(g.N, o->optimize_rotations ? 1 : 0);
   g.trn_free.assign(g.N, o->optimize_translation ? 1 : 0);
@@ -711,9 +827,9 @@ int orc_ba_solve(int32_t num_cams, int32_t num_intr, int32_t fixed_cam, i64 num_
     for (int j = 0; j < kNumParams[m]; ++j) g.free_par[MAXP * b + j] = 1;
     if (o->optimize_intrinsics && !o->optimize_principal_point) g.free_par[MAXP * b + kPP[m][0]] = g.free_par[MAXP * b + kPP[m][1]] = 0;
     for (int j = 0; j < MAXP; ++j)
-      if (g.free_par[MAXP * b + j]) g.icol[MAXP * b + j] = (int32_t)(6 * g.N + g.nfree++);
+      if (g.free_par[MAXP * b + j]) g.icol[MAXP * b + j] = (int32_t)(6 * (g.N + g.S) + g.nfree++);
   }
-  g.nred = 6 * g.N + g.nfree;
+  g.nred = 6 * (g.N + g.S) + g.nfree;
   g.intr_owner.assign(g.K, -2);
   if (!image_frame)
     for (i64 n = 0; n < g.N; ++n) {
@@ -730,6 +846,10 @@ int orc_ba_solve(int32_t num_cams, int32_t num_intr, int32_t fixed_cam, i64 num_
   g.pcg_max = o->pcg_max_iterations;
   g.q.assign(cam_q_inout, cam_q_inout + 4 * g.N);
   g.t.assign(cam_t_inout, cam_t_inout + 3 * g.N);
+  for (i64 sb = 0; sb < g.S; ++sb) {
+    for (int j = 0; j < 4; ++j) g.q.push_back(sensor_cam_from_rig_inout[7 * sb + j]);
+    for (int j = 0; j < 3; ++j) g.t.push_back(sensor_cam_from_rig_inout[7 * sb + 4 + j]);
+  }
   g.intr.assign(intr_params_inout, intr_params_inout + MAXP * g.K);
   g.X.resize(3 * g.P);
   for (i64 i = 0; i < g.P; ++i)
@@ -752,6 +872,10 @@ int orc_ba_solve(int32_t num_cams, int32_t num_intr, int32_t fixed_cam, i64 num_
   lm_minimize(g, lo, &s);
   std::memcpy(cam_q_inout, g.q.data(), sizeof(double) * 4 * g.N);
   std::memcpy(cam_t_inout, g.t.data(), sizeof(double) * 3 * g.N);
+  for (i64 sb = 0; sb < g.S; ++sb) {
+    for (int j = 0; j < 4; ++j) sensor_cam_from_rig_inout[7 * sb + j] = g.q[4 * (g.N + sb) + j];
+    for (int j = 0; j < 3; ++j) sensor_cam_from_rig_inout[7 * sb + 4 + j] = g.t[3 * (g.N + sb) + j];
+  }
   std::memcpy(intr_params_inout, g.intr.data(), sizeof(double) * MAXP * g.K);
   for (i64 i = 0; i < g.P; ++i)
     for (int j = 0; j < 3; ++j) pt_xyz_inout[3 * used_pts[i] + j] = g.X[3 * i + j];

@@ -147,6 +147,25 @@ def test_gp_with_unknown_rig_translations_matches_oracle(gsfm_ctx, frames, cams,
         assert np.abs(cs * sc - info["sensor_center"]).max() < 1e-4
 
 
+@pytest.mark.parametrize("frames,cams,pts,noise,rot", [(14, 2, 400, 0.0, True), (30, 3, 3000, 0.5, True)])
+def test_cpp_oracle_agrees_on_optimised_rig_poses(frames, cams, pts, noise, rot):
+    """The two restatements of RigReprojErrorCostFunctor against each other (numpy: sparse direct solves; C++: dense or PCG
+    solves of the reduced system with sensor blocks behind the frames)."""
+    _, ba, info = synthetic.make_rig_problems(frames, cams, pts, seed=11, pixel_noise=noise)
+    p = _with_sensors(ba, info, _miscalibrated(info, 12, rot_deg=0.5, trans=0.03))
+    opt = oba.BundleAdjusterOptions(optimize_rig_poses=True, optimize_rotations=rot)
+    a = oba.solve(*_ba_args(p), options=opt, **_sens_kw(p))
+    b = cpu.ba_solve(*_ba_args(p), options=opt, **_sens_kw(p))
+    assert a[0] and b[0] and a[5].iterations == b[5].iterations
+    assert abs(a[5].final_cost - b[5].final_cost) <= 1e-9 * max(a[5].final_cost, 1e-6)
+    assert np.abs(a[1] - b[1]).max() < 1e-9 and np.abs(a[2] - b[2]).max() < 1e-7
+    assert np.abs(a[5].sensor_cam_from_rig - b[5].sensor_cam_from_rig).max() < 1e-8
+    # and a table without the option is a constant in both
+    c = cpu.ba_solve(*_ba_args(p), **_sens_kw(p))
+    d = oba.solve(*_ba_args(p), **_sens_kw(p))
+    assert c[0] and d[0] and c[5].iterations == d[5].iterations and np.abs(c[1] - d[1]).max() < 1e-8
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("frames,cams,pts,noise,rot", [(14, 2, 400, 0.0, True), (30, 3, 3000, 0.5, True), (16, 3, 800, 0.3, False)])
 def test_ba_with_optimised_rig_poses_matches_oracle(gsfm_ctx, frames, cams, pts, noise, rot):
