@@ -233,8 +233,10 @@ def _summary(rep) -> CpuSummary:
 
 def gp_solve(num_cams, pt_offset, obs_cam, obs_dir, obs_calibrated, cam_center, pt_xyz,
              options: _gp.GlobalPositionerOptions | None = None, threads: int = 0, pcg_tol: float = 1e-14,
-             pcg_max: int = 20000, order: int = 0, verbose: bool = False, image_frame=None, image_offset=None):
-    """Same contract as oracle.gp.solve: returns (ok, cam_center [N,3], pt_xyz [P,3], CpuSummary)."""
+             pcg_max: int = 20000, order: int = 0, verbose: bool = False, image_frame=None, image_offset=None,
+             image_sensor=None, image_sensor_rot=None, sensor_center=None):
+    """Same contract as oracle.gp.solve: returns (ok, cam_center [N,3], pt_xyz [P,3], CpuSummary); with unknown
+    cam_from_rig centres the summary carries the estimates as summary.sensor_center."""
     opt = options or _gp.GlobalPositionerOptions()
     lib = load()
     o = _GpOptions()
@@ -252,13 +254,20 @@ def gp_solve(num_cams, pt_offset, obs_cam, obs_dir, obs_calibrated, cam_center, 
     rep = _Report()
     imf = None if image_frame is None else np.ascontiguousarray(image_frame, dtype=np.int32)
     imo = None if image_frame is None else np.ascontiguousarray(image_offset, dtype=np.float64)
+    ims = None if image_sensor is None else np.ascontiguousarray(image_sensor, dtype=np.int32)
+    imr = None if image_sensor is None else np.ascontiguousarray(image_sensor_rot, dtype=np.float64)
+    sc = None if image_sensor is None else np.array(sensor_center, dtype=np.float64, copy=True, order="C")
     rc = lib.orc_gp_solve(C.c_int32(int(num_cams)), C.c_int64(off.shape[0] - 1), _p(off, C.c_int64), _p(cam, C.c_int32),
                           _p(v, C.c_double), None if cal is None else _p(cal, C.c_uint8), C.byref(o), _p(c, C.c_double),
                           _p(X, C.c_double), C.byref(rep), C.c_int32(_threads(threads)),
-                          None if imf is None else _p(imf, C.c_int32), None if imo is None else _p(imo, C.c_double))
+                          None if imf is None else _p(imf, C.c_int32), None if imo is None else _p(imo, C.c_double),
+                          C.c_int32(0 if sc is None else sc.shape[0]), None if ims is None else _p(ims, C.c_int32),
+                          None if imr is None else _p(imr, C.c_double), None if sc is None else _p(sc, C.c_double))
     s = _summary(rep)
     if rc == -5:
         s.usable = False
+    if sc is not None:
+        s.sensor_center = sc
     return rc == 0, c, X, s
 
 

@@ -57,6 +57,14 @@ struct Gp : LmProblem {
   std::vector<double> vbuf;
   std::vector<double> off;        // [M][3] known rigs: R_cw^T t_cam_from_rig of the observation's image (else empty)
   std::vector<uint8_t> cal;
+  // unknown cam_from_rig translations (RigUnknownBATAPairwiseDirectionError, cost_function.h:90-136, gp.cc:354-368):
+  // S centre blocks c_s behind the N frames in c / the reduced vector; observation k of such a sensor has sblk[k] >= 0 and
+  // Rf[k] = R_rig_from_world of its frame:  d = X - c_frame - Rf^T c_s
+  i64 S = 0;
+  std::vector<int32_t> sblk;
+  std::vector<double> Rf;             // [M][9]
+  std::vector<int32_t> sobs, sown;
+  OwnerLists bysens;
   OwnerLists bycam;
   Huber loss_cal, loss_unc;
   double mc, mx, ms;  // 1 / 0: optimize_positions / points / scales
@@ -82,8 +90,23 @@ struct Gp : LmProblem {
   // d = X - c, or X - c_rig + t_rig for an image of a calibrated rig (RigBATAPairwiseDirectionError,
   // cost_function.h:49-82, with the rig scale constant at 1: global_positioning.cc:470-478)
   inline V3 dvec(i64 k, const std::vector<double>& cc, const std::vector<double>& XX) const {
-    const V3 d = ld3(&XX[3 * (i64)pt[k]]) - ld3(&cc[3 * (i64)cam[k]]);
+    V3 d = ld3(&XX[3 * (i64)pt[k]]) - ld3(&cc[3 * (i64)cam[k]]);
+    if (S > 0 && sblk[k] >= 0) d = d - rot_t(k, ld3(&cc[3 * (N + sblk[k])]));
     return off.empty() ? d : d + ld3(&off[3 * k]);
+  }
+  inline V3 rot_t(i64 k, const V3& a) const {  // Rf^T a
+    const double* R = &Rf[9 * k];
+    return V3{R[0] * a.x + R[3] * a.y + R[6] * a.z, R[1] * a.x + R[4] * a.y + R[7] * a.z, R[2] * a.x + R[5] * a.y + R[8] * a.z};
+  }
+  inline V3 rot(i64 k, const V3& a) const {  // Rf a
+    const double* R = &Rf[9 * k];
+    return V3{R[0] * a.x + R[1] * a.y + R[2] * a.z, R[3] * a.x + R[4] * a.y + R[5] * a.z, R[6] * a.x + R[7] * a.y + R[8] * a.z};
+  }
+  // the camera-side tangent an observation sees: z_frame + Rf^T z_sensor
+  inline V3 zcam(i64 k, const std::vector<double>& z) const {
+    V3 a = ld3(&z[3 * (i64)cam[k]]);
+    if (S > 0 && sblk[k] >= 0) a = a + rot_t(k, ld3(&z[3 * (N + sblk[k])]));
+    return a;
   }
   inline double damp(double h, double j, double radius) const {
     const double j2 = j * j;
@@ -103,9 +126,9 @@ struct Gp : LmProblem {
 
   double linearize(double* gmax_out) override {
     w.resize(M);
-    gc.assign(3 * N, 0.0);
+    gc.assign(3 * (N + S), 0.0);
     gX.assign(3 * P, 0.0);
-    hc.assign(N, 0.0);
+    hc.assign(N + S, 0.0);
     hx.assign(P, 0.0);
     std::vector<double> rho(M), gs(M);
 #pragma omp parallel for schedule(static)
@@ -159,19 +182,37 @@ struct Gp : LmProblem {
       gc[3 * n + 1] = mc * acc[4 * n + 2];
       gc[3 * n + 2] = mc * acc[4 * n + 3];
     }
+    if (S > 0) {  // d r / d c_s = s Rf^T: same squared column norms, gradient rotated by Rf
+      std::vector<double> accs(4 * S);
+      bysens.reduce<4>(accs.data(), rev, [&](i64 e, double* a) {
+        const i64 k = sobs[e];
+        const V3 d = dvec(k, c, X);
+        const V3 r = ld3(v + 3 * k) - s[k] * d;
+        const double ws = w[k] * s[k];
+        const V3 g = rot(k, ws * r);
+        a[0] += ws * s[k];
+        a[1] += g.x;
+        a[2] += g.y;
+        a[3] += g.z;
+      });
+      for (i64 sb = 0; sb < S; ++sb) {
+        hc[N + sb] = mc * accs[4 * sb];
+        for (int j = 0; j < 3; ++j) gc[3 * (N + sb) + j] = mc * accs[4 * sb + 1 + j];
+      }
+    }
     double gmax = chunked_max(M, [&](i64 k) { return std::fabs(gs[k]); });
-    gmax = std::max(gmax, chunked_max(3 * N, [&](i64 i) { return std::fabs(gc[i]); }));
+    gmax = std::max(gmax, chunked_max(3 * (N + S), [&](i64 i) { return std::fabs(gc[i]); }));
     gmax = std::max(gmax, chunked_max(3 * P, [&](i64 i) { return std::fabs(gX[i]); }));
     *gmax_out = gmax;
     return cost;
   }
 
   void set_jacobi_scaling(bool enabled) override {
-    jc.assign(N, 1.0);
+    jc.assign(N + S, 1.0);
     jx.assign(P, 1.0);
     js.assign(M, 1.0);
     if (enabled) {
-      for (i64 n = 0; n < N; ++n) jc[n] = 1.0 / (1.0 + std::sqrt(hc[n]));
+      for (i64 n = 0; n < N + S; ++n) jc[n] = 1.0 / (1.0 + std::sqrt(hc[n]));
       for (i64 p = 0; p < P; ++p) jx[p] = 1.0 / (1.0 + std::sqrt(hx[p]));
 #pragma omp parallel for schedule(static)
       for (i64 k = 0; k < M; ++k) {
@@ -190,7 +231,7 @@ struct Gp : LmProblem {
       double a[3] = {0, 0, 0};
       auto body = [&](i64 k) {
         const V3 d = dvec(k, c, X);
-        const V3 zc = ld3(&z[3 * (i64)cam[k]]);
+        const V3 zc = zcam(k, z);
         const V3 q = qa[k] * (zc - (qb[k] * dot(d, zc)) * d);
         a[0] += q.x;
         a[1] += q.y;
@@ -210,7 +251,7 @@ struct Gp : LmProblem {
     std::vector<double> acc(3 * N);
     bycam.reduce<3>(acc.data(), rev, [&](i64 k, double* a) {
       const V3 d = dvec(k, c, X);
-      const V3 e = mc * ld3(&z[3 * (i64)cam[k]]) - mx * ld3(&tp[3 * (i64)pt[k]]);
+      const V3 e = mc * zcam(k, z) - mx * ld3(&tp[3 * (i64)pt[k]]);
       const V3 q = qa[k] * (e - (qb[k] * dot(d, e)) * d);
       a[0] += q.x;
       a[1] += q.y;
@@ -219,6 +260,20 @@ struct Gp : LmProblem {
 #pragma omp parallel for schedule(static)
     for (i64 n = 0; n < N; ++n)
       for (int j = 0; j < 3; ++j) out[3 * n + j] = mc * acc[3 * n + j] + dcam[n] * z[3 * n + j];
+    if (S > 0) {
+      std::vector<double> accs(3 * S);
+      bysens.reduce<3>(accs.data(), rev, [&](i64 ee, double* a) {
+        const i64 k = sobs[ee];
+        const V3 d = dvec(k, c, X);
+        const V3 e = mc * zcam(k, z) - mx * ld3(&tp[3 * (i64)pt[k]]);
+        const V3 q = rot(k, qa[k] * (e - (qb[k] * dot(d, e)) * d));
+        a[0] += q.x;
+        a[1] += q.y;
+        a[2] += q.z;
+      });
+      for (i64 sb = 0; sb < S; ++sb)
+        for (int j = 0; j < 3; ++j) out[3 * (N + sb) + j] = mc * accs[3 * sb + j] + dcam[N + sb] * z[3 * (N + sb) + j];
+    }
   }
 
   bool step(double radius, double* model_change, double* cand_cost, double* step_norm, double* x_norm, i64* lin,
@@ -291,8 +346,8 @@ struct Gp : LmProblem {
     }
     if (!ok) return false;
     // cameras: damping, rhs = -(g_c' - H_cp Hpp^-1 g_X'), g_c' = mc sum q,  H_cp = -mc mx Q
-    dcam.resize(N);
-    for (i64 n = 0; n < N; ++n) dcam[n] = damp(hc[n], jc[n], radius);
+    dcam.resize(N + S);
+    for (i64 n = 0; n < N + S; ++n) dcam[n] = damp(hc[n], jc[n], radius);
     std::vector<double> u(3 * P);  // Hpp^-1 gX'
 #pragma omp parallel for schedule(static)
     for (i64 p = 0; p < P; ++p) {
@@ -302,8 +357,8 @@ struct Gp : LmProblem {
       u[3 * p + 1] = H[1] * g[0] + H[3] * g[1] + H[4] * g[2];
       u[3 * p + 2] = H[2] * g[0] + H[4] * g[1] + H[5] * g[2];
     }
-    std::vector<double> acc(12 * N);
-    bycam.reduce<12>(acc.data(), rev, [&](i64 k, double* a) {
+    // gradient share and diagonal Schur block of observation k, in world coordinates (a[0..3) | a[3..12))
+    auto cam_block = [&](i64 k, double* a) {
       const V3 d = dvec(k, c, X);
       const double qa_ = qa[k], ab = qa[k] * qb[k];
       // gradient share: q_k + mx Q_k u_p   (rhs = -(mc sum q + mc mx sum Q u))
@@ -327,10 +382,31 @@ struct Gp : LmProblem {
       for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j)
           a[3 + 3 * i + j] += Q[3 * i + j] - f * (Q[3 * i] * HQ[j] + Q[3 * i + 1] * HQ[3 + j] + Q[3 * i + 2] * HQ[6 + j]);
-    });
-    std::vector<double> rhs(3 * N);
-    Minv.resize(9 * N);
-    for (i64 n = 0; n < N; ++n) {
+    };
+    std::vector<double> acc(12 * (N + S));
+    bycam.reduce<12>(acc.data(), rev, cam_block);
+    if (S > 0) {  // sensor blocks: the same quantities through the tangent map Rf^T (gradient Rf g, block Rf B Rf^T)
+      std::vector<double> accs(12 * S);
+      bysens.reduce<12>(accs.data(), rev, [&](i64 ee, double* a) {
+        const i64 k = sobs[ee];
+        double b[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        cam_block(k, b);
+        const double* R = &Rf[9 * k];
+        const V3 g = rot(k, V3{b[0], b[1], b[2]});
+        a[0] += g.x;
+        a[1] += g.y;
+        a[2] += g.z;
+        double RB[9];
+        for (int i = 0; i < 3; ++i)
+          for (int j = 0; j < 3; ++j) RB[3 * i + j] = R[3 * i] * b[3 + j] + R[3 * i + 1] * b[6 + j] + R[3 * i + 2] * b[9 + j];
+        for (int i = 0; i < 3; ++i)
+          for (int j = 0; j < 3; ++j) a[3 + 3 * i + j] += RB[3 * i] * R[3 * j] + RB[3 * i + 1] * R[3 * j + 1] + RB[3 * i + 2] * R[3 * j + 2];
+      });
+      std::copy(accs.begin(), accs.end(), acc.begin() + 12 * N);
+    }
+    std::vector<double> rhs(3 * (N + S));
+    Minv.resize(9 * (N + S));
+    for (i64 n = 0; n < N + S; ++n) {
       for (int j = 0; j < 3; ++j) rhs[3 * n + j] = -mc * acc[12 * n + j];
       double B[9];
       for (int j = 0; j < 9; ++j) B[j] = mc * mc * acc[12 * n + 3 + j];
@@ -344,13 +420,13 @@ struct Gp : LmProblem {
       if (!spd_inverse(B, 3)) return false;
       std::memcpy(&Minv[9 * n], B, sizeof B);
     }
-    std::vector<double> dc(3 * N, 0.0);
+    std::vector<double> dc(3 * (N + S), 0.0);
     *relres = 0.0;
     *lin = solve_reduced(
-        3 * N, rhs, dc, pcg_tol, pcg_max, [&](const std::vector<double>& z, std::vector<double>& o) { apply(z, o); },
+        3 * (N + S), rhs, dc, pcg_tol, pcg_max, [&](const std::vector<double>& z, std::vector<double>& o) { apply(z, o); },
         [&](const std::vector<double>& r, std::vector<double>& z) {
 #pragma omp parallel for schedule(static)
-          for (i64 n = 0; n < N; ++n) {
+          for (i64 n = 0; n < N + S; ++n) {
             const double* B = &Minv[9 * n];
             for (int i = 0; i < 3; ++i) z[3 * n + i] = B[3 * i] * r[3 * n] + B[3 * i + 1] * r[3 * n + 1] + B[3 * i + 2] * r[3 * n + 2];
           }
@@ -367,7 +443,7 @@ struct Gp : LmProblem {
     for (i64 k = 0; k < M; ++k) {
       const V3 d = dvec(k, c, X);
       const V3 r = ld3(v + 3 * k) - s[k] * d;
-      const V3 e = mc * ld3(&dc[3 * (i64)cam[k]]) - mx * ld3(&dX[3 * (i64)pt[k]]);
+      const V3 e = mc * zcam(k, dc) - mx * ld3(&dX[3 * (i64)pt[k]]);
       const double m = (k == 0 ? 0.0 : ms);
       ds[k] = qb[k] * dot(d, r + s[k] * e);  // qb = m w / h~ss
       (void)m;
@@ -377,18 +453,18 @@ struct Gp : LmProblem {
     }
     *model_change = -chunked_sum(M, [&](i64 k) { return mterm[k]; });
     // candidate = Plus(x, delta), scales projected on their lower bound
-    c2.resize(3 * N);
+    c2.resize(3 * (N + S));
     X2.resize(3 * P);
     s2.resize(M);
-    for (i64 i = 0; i < 3 * N; ++i) c2[i] = c[i] + mc * dc[i];
+    for (i64 i = 0; i < 3 * (N + S); ++i) c2[i] = c[i] + mc * dc[i];
 #pragma omp parallel for schedule(static)
     for (i64 i = 0; i < 3 * P; ++i) X2[i] = X[i] + mx * dX[i];
 #pragma omp parallel for schedule(static)
     for (i64 k = 0; k < M; ++k) s2[k] = std::max(s[k] + (k == 0 ? 0.0 : ms) * ds[k], 1e-5);
-    double sn = chunked_sum(3 * N, [&](i64 i) { const double d = c2[i] - c[i]; return d * d; });
+    double sn = chunked_sum(3 * (N + S), [&](i64 i) { const double d = c2[i] - c[i]; return d * d; });
     sn += chunked_sum(3 * P, [&](i64 i) { const double d = X2[i] - X[i]; return d * d; });
     sn += chunked_sum(M, [&](i64 k) { const double d = s2[k] - s[k]; return d * d; });
-    double xn = chunked_sum(3 * N, [&](i64 i) { return c[i] * c[i]; });
+    double xn = chunked_sum(3 * (N + S), [&](i64 i) { return c[i] * c[i]; });
     xn += chunked_sum(3 * P, [&](i64 i) { return X[i] * X[i]; });
     xn += chunked_sum(M, [&](i64 k) { return s[k] * s[k]; });
     *step_norm = std::sqrt(sn);
@@ -404,7 +480,7 @@ struct Gp : LmProblem {
       double a[3] = {0, 0, 0};
       auto body = [&](i64 k) {
         const V3 d = dvec(k, c, X);
-        const V3 zc = ld3(&z[3 * (i64)cam[k]]);
+        const V3 zc = zcam(k, z);
         const V3 q = qa[k] * (zc - (qb[k] * dot(d, zc)) * d);
         a[0] += q.x;
         a[1] += q.y;
@@ -440,12 +516,16 @@ using orc::i64;
 // Known rigs: image_frame [I] / image_offset [I][3] (NULL = trivial rigs): obs_cam then indexes images.
 int orc_gp_solve(int32_t num_cams, i64 num_pts, const i64* pt_offset, const int32_t* obs_cam, const double* obs_dir,
                  const uint8_t* obs_calibrated, const orc::GpOptionsC* o, double* cam_center_inout, double* pt_xyz_inout,
-                 orc::GpReport* rep, int32_t num_threads, const int32_t* image_frame, const double* image_offset) {
+                 orc::GpReport* rep, int32_t num_threads, const int32_t* image_frame, const double* image_offset,
+                 int32_t num_sensors, const int32_t* image_sensor, const double* image_sensor_rot,
+                 double* sensor_center_inout) {
   using namespace orc;
   const double t0 = omp_get_wtime();
   if (num_threads > 0) omp_set_num_threads(num_threads);
   Gp g;
   g.N = num_cams;
+  g.S = (image_frame && num_sensors > 0 && image_sensor && image_sensor_rot && sensor_center_inout) ? num_sensors : 0;
+  if (g.S > 0 && !o->optimize_positions) return -7;
   std::vector<i64> used_pts;
   g.poff.push_back(0);
   for (i64 p = 0; p < num_pts; ++p) {
@@ -457,6 +537,15 @@ int orc_gp_solve(int32_t num_cams, i64 num_pts, const i64* pt_offset, const int3
       if (image_frame) {
         g.cam.push_back(image_frame[obs_cam[k]]);
         for (int j = 0; j < 3; ++j) g.off.push_back(image_offset[3 * (i64)obs_cam[k] + j]);
+        if (g.S > 0) {
+          const i64 im = obs_cam[k];
+          g.sblk.push_back(image_sensor[im]);
+          for (int j = 0; j < 9; ++j) g.Rf.push_back(image_sensor_rot[9 * im + j]);
+          if (image_sensor[im] >= 0) {
+            g.sobs.push_back((int32_t)g.cam.size() - 1);
+            g.sown.push_back(image_sensor[im]);
+          }
+        }
       } else {
         g.cam.push_back(obs_cam[k]);
       }
@@ -475,6 +564,7 @@ int orc_gp_solve(int32_t num_cams, i64 num_pts, const i64* pt_offset, const int3
   if (g.M == 0) return -5;
   g.v = g.vbuf.data();
   g.bycam.build(g.N, g.M, g.cam.data());
+  if (g.S > 0) g.bysens.build(g.S, (i64)g.sobs.size(), g.sown.data());
   g.loss_cal = {o->thres_loss_function, 1.0};
   g.loss_unc = {o->thres_loss_function, 0.5};
   g.mc = o->optimize_positions ? 1.0 : 0.0;
@@ -486,6 +576,7 @@ int orc_gp_solve(int32_t num_cams, i64 num_pts, const i64* pt_offset, const int3
   g.pcg_tol = o->pcg_relative_tolerance;
   g.pcg_max = o->pcg_max_iterations;
   g.c.assign(cam_center_inout, cam_center_inout + 3 * g.N);
+  for (i64 i = 0; i < 3 * g.S; ++i) g.c.push_back(sensor_center_inout[i]);
   g.X.resize(3 * g.P);
   for (i64 i = 0; i < g.P; ++i)
     for (int j = 0; j < 3; ++j) g.X[3 * i + j] = pt_xyz_inout[3 * used_pts[i] + j];
@@ -501,6 +592,7 @@ int orc_gp_solve(int32_t num_cams, i64 num_pts, const i64* pt_offset, const int3
   }
   if (o->generate_random_points && o->optimize_points)
     for (i64 i = 0; i < 3 * g.P; ++i) g.X[i] = 100.0 * uni(gen);
+  for (i64 i = 0; i < 3 * g.S; ++i) g.c[3 * g.N + i] = uni(gen);  // ParameterizeVariables, gp.cc:442-456 (after every other draw)
   g.s.assign(g.M, 1.0);
   if (!o->generate_scales)
     for (i64 k = 0; k < g.M; ++k) {
@@ -524,6 +616,7 @@ int orc_gp_solve(int32_t num_cams, i64 num_pts, const i64* pt_offset, const int3
   LmSummary s;
   lm_minimize(g, lo, &s);
   std::memcpy(cam_center_inout, g.c.data(), sizeof(double) * 3 * g.N);
+  for (i64 i = 0; i < 3 * g.S; ++i) sensor_center_inout[i] = g.c[3 * g.N + i];
   for (i64 i = 0; i < g.P; ++i)
     for (int j = 0; j < 3; ++j) pt_xyz_inout[3 * used_pts[i] + j] = g.X[3 * i + j];
   rep->iterations = s.iterations;

@@ -120,6 +120,17 @@ def test_oracle_estimates_unknown_rig_translations():
     assert np.abs(summ.sensor_center * scale - info["sensor_center"]).max() < 1e-5
 
 
+@pytest.mark.parametrize("frames,cams,pts,noise", [(14, 3, 500, 0.0), (30, 3, 3000, 1.0)])
+def test_cpp_oracle_agrees_on_unknown_rig_translations(frames, cams, pts, noise):
+    gp, _, info = synthetic.make_rig_problems(frames, cams, pts, seed=4, dir_noise=1e-3 * noise, outlier_ratio=0.01 * noise)
+    p = synthetic.forget_rig_translations(gp, info)
+    a = ogp.solve(*_gp_args(p), **_unk_kw(p))
+    b = cpu.gp_solve(*_gp_args(p), **_unk_kw(p))
+    assert a[0] and b[0] and a[3].iterations == b[3].iterations
+    assert abs(a[3].initial_cost - b[3].initial_cost) <= 1e-12 * a[3].initial_cost  # same draws, sensor centres included
+    assert np.abs(a[1] - b[1]).max() < 1e-7 and np.abs(a[3].sensor_center - b[3].sensor_center).max() < 1e-9
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("frames,cams,pts,noise", [(14, 3, 500, 0.0), (30, 3, 3000, 1.0)])
 def test_gp_with_unknown_rig_translations_matches_oracle(gsfm_ctx, frames, cams, pts, noise):
