@@ -501,7 +501,7 @@ struct Ba : LmProblem {
     *relres = 0.0;
     *lin = solve_reduced(
         nred, rhs, dy, pcg_tol, pcg_max, [&](const std::vector<double>& z, std::vector<double>& o) { apply(z, o); },
-        [&](const std::vector<double>& r, std::vector<double>& z) { precond(r, z); }, relres);
+        [&](const std::vector<double>& r, std::vector<double>& z) { precond(r, z); }, relres, (double)M);
     // back-substitution: dX = -u - tp(dy)
     point_pass(dy);
     std::vector<double> dX(3 * P);

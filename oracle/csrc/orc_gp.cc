@@ -431,7 +431,7 @@ struct Gp : LmProblem {
             for (int i = 0; i < 3; ++i) z[3 * n + i] = B[3 * i] * r[3 * n] + B[3 * i + 1] * r[3 * n + 1] + B[3 * i + 2] * r[3 * n + 2];
           }
         },
-        relres);
+        relres, (double)M);
     // back-substitution: dX_p = Hpp^-1 (-gX' + mc mx sum Q dc) ; ds_k = beta (d.(r + s (mc dc - mx dX)))
     std::vector<double> dX(3 * P);
     apply_points_only(dc);  // tp = mc mx Hpp^-1 sum Q dc

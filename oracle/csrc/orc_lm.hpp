@@ -246,10 +246,14 @@ i64 pcg(i64 n, const std::vector<double>& b, std::vector<double>& x, double tol,
 
 // The reduced-system solve of one LM step: direct when small, PCG otherwise.  Returns the PCG iteration count (0 for
 // the direct solve).
+// `apply_cost` = work of one operator application (observations swept): the direct path applies the operator n times to
+// assemble the matrix, so it is only taken while n * apply_cost stays small — beyond that PCG to 1e-14 is the "exact" solve
+// (as it is for every system larger than kDenseMax).
+constexpr double kDenseMaxWork = 2e8;
 template <class Apply, class Precond>
 i64 solve_reduced(i64 n, const std::vector<double>& b, std::vector<double>& x, double tol, int max_it, Apply apply,
-                  Precond precond, double* true_relres) {
-  if (n <= kDenseMax) {
+                  Precond precond, double* true_relres, double apply_cost = 0.0) {
+  if (n <= kDenseMax && (double)n * apply_cost <= kDenseMaxWork) {
     bool nonzero = false;
     for (double v : b) nonzero = nonzero || v != 0.0;
     if (!nonzero) {
