@@ -441,34 +441,40 @@ def estimate_rotations_gravity(num_nodes, edge_i, edge_j, edge_q, edge_weight, n
     row0 = np.concatenate([[0], np.cumsum(np.where(both, 1, 3))])
     nrow_e = int(row0[-1])
     gauge_rows = 1 if grav[fixed_node] else 3
-    ri, ci, vi = [], [], []
-    for e in range(E):
-        i, j, r = int(edge_i[e]), int(edge_j[e]), int(row0[e])
-        if both[e]:
-            ri += [r, r]; ci += [col0[i], col0[j]]; vi += [-1.0, 1.0]
-            continue
-        for node, sgn in ((i, -1.0), (j, 1.0)):
-            if grav[node]:
-                ri.append(r + 1); ci.append(col0[node]); vi.append(sgn)
-            else:
-                for c in range(3):
-                    ri.append(r + c); ci.append(col0[node] + c); vi.append(sgn)
-    for c in range(gauge_rows):
-        ri.append(nrow_e + c); ci.append(col0[fixed_node] + c); vi.append(1.0)
-    A = sp.csr_matrix((vi, (ri, ci)), shape=(nrow_e + gauge_rows, ncol))
+    # rows (vectorised): one-row pairs, then per endpoint of the three-row pairs either its y entry or all three
+    e1 = np.nonzero(both)[0]
+    e3 = np.nonzero(~both)[0]
+    ri = [row0[e1], row0[e1]]
+    ci = [col0[edge_i[e1]], col0[edge_j[e1]]]
+    vi = [-np.ones(e1.size), np.ones(e1.size)]
+    for node_arr, sgn in ((edge_i[e3], -1.0), (edge_j[e3], 1.0)):
+        g1 = grav[node_arr]
+        ri.append(row0[e3][g1] + 1)
+        ci.append(col0[node_arr[g1]])
+        vi.append(np.full(int(g1.sum()), sgn))
+        for c in range(3):
+            ri.append(row0[e3][~g1] + c)
+            ci.append(col0[node_arr[~g1]] + c)
+            vi.append(np.full(int((~g1).sum()), sgn))
+    ri.append(nrow_e + np.arange(gauge_rows))
+    ci.append(col0[fixed_node] + np.arange(gauge_rows))
+    vi.append(np.ones(gauge_rows))
+    A = sp.csr_matrix((np.concatenate(vi), (np.concatenate(ri), np.concatenate(ci))), shape=(nrow_e + gauge_rows, ncol))
     ew = np.where(np.asarray(edge_weight) >= 0, edge_weight, 1.0) if opt.use_weight else np.ones(E)
     weights = np.concatenate([np.repeat(ew, np.where(both, 1, 3)), np.ones(gauge_rows)])
     fixed_rot = rot[fixed_node].copy()
-    rows_of = [np.arange(row0[e], row0[e + 1]) for e in range(E)]
+    rows3 = (row0[e3][:, None] + np.arange(3)[None, :]).ravel()
+    gidx = np.nonzero(grav)[0]
+    nidx = np.nonzero(~grav)[0]
+    ncols3 = (col0[nidx][:, None] + np.arange(3)[None, :]).ravel()
 
     def residuals(r):
         Rn = so3.exp_aa(r)
-        M = np.transpose(Rn[edge_j], (0, 2, 1)) @ edge_R @ Rn[edge_i]
-        b3 = -so3.log_rot(M)
-        b1 = rel_angle_error(angle_rel, r[edge_i, 1], r[edge_j, 1])
         b = np.empty(nrow_e + gauge_rows)
-        for e in range(E):
-            b[rows_of[e]] = b1[e] if both[e] else b3[e]
+        if e3.size:
+            M = np.transpose(Rn[edge_j[e3]], (0, 2, 1)) @ edge_R[e3] @ Rn[edge_i[e3]]
+            b[rows3] = -so3.log_rot(M).ravel()
+        b[row0[e1]] = rel_angle_error(angle_rel[e1], r[edge_i[e1], 1], r[edge_j[e1], 1])
         if grav[fixed_node]:
             b[nrow_e] = r[fixed_node, 1] - fixed_rot[1]  # gra.cc:746-749
         else:
@@ -477,21 +483,32 @@ def estimate_rotations_gravity(num_nodes, edge_i, edge_j, edge_q, edge_weight, n
 
     def update(r, step):
         r = r.copy()
-        for n in range(N):
-            s = step[col0[n] : col0[n + 1]]
-            if grav[n]:
-                r[n, 1] -= s[0]  # gra.cc:643-644
-            else:
-                r[n] = so3.log_rot(so3.exp_aa(r[n][None]) @ so3.exp_aa(-s[None]))[0]
+        r[gidx, 1] -= step[col0[gidx]]  # gra.cc:643-644
+        if nidx.size:
+            s3 = step[ncols3].reshape(-1, 3)
+            r[nidx] = so3.log_rot(so3.exp_aa(r[nidx]) @ so3.exp_aa(-s3))
         return r
 
     def avg_step(step):
-        tot = 0.0
-        for n in range(N):
-            s = step[col0[n] : col0[n + 1]]
-            tot += abs(s[0]) if grav[n] else np.linalg.norm(s)
-        return tot / N
+        tot = np.abs(step[col0[gidx]]).sum()
+        if nidx.size:
+            tot += np.linalg.norm(step[ncols3].reshape(-1, 3), axis=1).sum()
+        return float(tot / N)
 
+    def irls_weights(b):
+        e2 = np.empty(E)
+        e2[e1] = b[row0[e1]] ** 2 + xz_err[e1]
+        if e3.size:
+            e2[e3] = (b[rows3].reshape(-1, 3) ** 2).sum(axis=1)
+        if opt.weight_type == GEMAN_MCCLURE:
+            tmp = e2 + sigma * sigma
+            w = sigma * sigma / (tmp * tmp)
+        else:
+            with np.errstate(divide="ignore"):
+                w = np.power(e2, (0.5 - 2) / 2)
+        return np.concatenate([np.repeat(w, np.where(both, 1, 3)), np.ones(gauge_rows)])
+
+    sigma = np.radians(opt.irls_loss_parameter_sigma)
     if opt.max_num_l1_iterations > 0:
         l1 = LeastAbsoluteDeviationSolver(sp.diags(weights) @ A, opt)
         last_norm = curr_norm = 0.0
@@ -514,17 +531,8 @@ def estimate_rotations_gravity(num_nodes, edge_i, edge_j, edge_q, edge_weight, n
         sigma = np.radians(opt.irls_loss_parameter_sigma)
         At = A.T.tocsr()
         b = residuals(rot)
-        w_irls = np.ones(nrow_e + gauge_rows)
         for it in range(opt.max_num_irls_iterations):
-            for e in range(E):
-                rr = rows_of[e]
-                e2 = b[rr[0]] ** 2 + xz_err[e] if both[e] else float((b[rr] ** 2).sum())
-                if opt.weight_type == GEMAN_MCCLURE:
-                    tmp = e2 + sigma * sigma
-                    w = sigma * sigma / (tmp * tmp)
-                else:
-                    w = np.power(e2, (0.5 - 2) / 2) if e2 > 0 else np.inf
-                w_irls[rr] = w
+            w_irls = irls_weights(b)
             if np.isnan(w_irls).any():
                 return False, rot
             at_weight = At @ sp.diags(w_irls * weights)
