@@ -1,6 +1,8 @@
 // ba.hip — global bundle adjustment on MI355X (gfx950).
 //
-// Replaces BundleAdjuster::Solve (glomap/estimators/bundle_adjustment.cc:11-106) for trivial rigs:
+// Replaces BundleAdjuster::Solve (glomap/estimators/bundle_adjustment.cc:11-106); trivial rigs below, calibrated rigs
+// (RigReprojErrorConstantRigCostFunctor) and optimised cam_from_rig blocks (RigReprojErrorCostFunctor, optimize_rig_poses)
+// in the "calibrated rigs" section further down — the sweeps never change, images play the cameras:
 //   residual   colmap::ReprojErrorCostFunctor<CameraModel> (ba.cc:135-146): r = ImgFromCam(params, R(q) X + t) - obs
 //   unknowns   frame pose (EigenQuaternionManifold tangent 3 + translation 3), point (3),
 //              shared intrinsics blocks (principal point frozen unless optimize_principal_point)

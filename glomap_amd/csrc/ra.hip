@@ -1,7 +1,8 @@
 // ra.hip — rotation averaging on MI355X (gfx950).
 //
-// Replaces RotationEstimator::EstimateRotations (glomap/estimators/global_rotation_averaging.cc:40-85),
-// 3-DoF path with trivial rigs:
+// Replaces RotationEstimator::EstimateRotations (glomap/estimators/global_rotation_averaging.cc:40-85).  The 3-DoF path
+// on frames is described here; gravity-aligned frames (use_gravity: 1-DoF unknowns, k_ra_mask3) and cam_from_rig
+// rotations among the unknowns (image-level graph + cam blocks, ra_solve_rig_impl) reuse it, see their sections below:
 //   host  : maximum-spanning-tree initialisation            gra.cc:87-138, math/tree.cc:78-153
 //   device: ComputeResiduals                                gra.cc:696-756      -> k_node_quat, k_edge_residual
 //           L1 stage, colmap::LeastAbsoluteDeviationSolver  gra.cc:479-541      -> k_admm_edge, k_node_gather<L1*>
