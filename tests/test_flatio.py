@@ -28,6 +28,38 @@ def test_python_round_trip(tmp_path):
             assert o2.optimize_rotations is False and p2.num_obs == p.num_obs
 
 
+def test_python_round_trip_of_rig_and_gravity_tables(tmp_path):
+    """The optional tables of the three problems — RA image / cam blocks and gravity flags, GP image offsets and centre
+    blocks, BA image cam_from_rig and sensor blocks — survive the file format."""
+    gp, ba, info = synthetic.make_rig_problems(8, 3, 120, seed=4)
+    gpu = synthetic.forget_rig_translations(gp, info)
+    bas = ba.copy()
+    bas.image_sensor, bas.sensor_cam_from_rig = info["sensor_block"].copy(), info["sensor_cam_from_rig"].copy()
+    ra = synthetic.make_ring_view_graph(24, 4, seed=1)
+    ra.image_frame = (np.arange(24) // 3).astype(np.int32)
+    ra.image_cam = np.where(np.arange(24) % 3 == 2, 0, -1).astype(np.int32)
+    ra.cam_aa0 = np.array([[0.1, -0.2, 0.05]])
+    ra.num_nodes, ra.node_aa0 = 8, ra.node_aa0[:8].copy()
+    rg = synthetic.make_ring_view_graph(12, 3, seed=2)
+    rg.node_gravity = (np.arange(12) % 2).astype(np.uint8)
+    for p, opt, fields in ((ra, estimators.RotationEstimatorOptions(skip_initialization=True), ("image_frame", "image_cam", "cam_aa0")),
+                           (rg, estimators.RotationEstimatorOptions(use_gravity=True), ("node_gravity",)),
+                           (gpu, estimators.GlobalPositionerOptions(), ("image_frame", "image_offset", "image_sensor", "image_sensor_rot", "sensor_center")),
+                           (bas, estimators.BundleAdjusterOptions(optimize_rig_poses=True),
+                            ("image_frame", "image_cam_from_rig", "image_intr", "image_sensor", "sensor_cam_from_rig"))):
+        rec = flatio.from_problem(p, opt)
+        path = tmp_path / f"{rec.kind}_{fields[0]}.gsfm"
+        flatio.save(path, rec)
+        p2, o2 = flatio.to_problem(flatio.load(path))
+        for f in fields:
+            a, b = np.asarray(getattr(p, f)), np.asarray(getattr(p2, f))
+            assert a.shape == b.shape and np.array_equal(a, b), f
+        if rec.kind == "ba":
+            assert o2.optimize_rig_poses is True
+        if rec.kind == "ra":
+            assert o2.use_gravity == opt.use_gravity and o2.skip_initialization == opt.skip_initialization
+
+
 @pytest.mark.gpu
 def test_dump_and_replay(gsfm_ctx, tmp_path):
     ra = synthetic.make_ring_view_graph(80, 8, seed=1)
