@@ -140,7 +140,7 @@ inline void QuatWxyz(const Quat& q, double* o) {
 
 // cam_from_rig of an image as (qw,qx,qy,qz,tx,ty,tz): identity for the reference sensor of its rig.  Returns false
 // when the sensor is not calibrated (no value, or the NaN translation RotationEstimator leaves behind for estimated
-// sensors, gra.cc:803-815) — those cases (RigUnknownBATA, cam-from-rig unknowns of RA) are not implemented.
+// sensors, gra.cc:803-815): the callers that can estimate it ask CamFromRigState below instead.
 inline bool KnownCamFromRig(const glomap::Image& im, std::unordered_map<rig_t, glomap::Rig>& rigs, double* cfr) {
   cfr[0] = 1.0;
   for (int j = 1; j < 7; ++j) cfr[j] = 0.0;
@@ -347,8 +347,8 @@ class RotationEstimator {
       detail::QuatWxyz(pair.cam2_from_cam1.rotation, q21);
       for (int j = 0; j < 4; ++j) qrel[j] = q21[j];
       if (rigged) {
-        // R_rel = R_cam2_from_rig2^T * R_cam2_from_cam1 * R_cam1_from_rig1 (gra.cc:306-309); the cam-from-rig unknowns of
-        // uncalibrated sensors (gra.cc:173-191, 311-340) are not implemented
+        // R_rel = R_cam2_from_rig2^T * R_cam2_from_cam1 * R_cam1_from_rig1 (gra.cc:306-309); uncalibrated sensors took the
+        // EstimateWithCamBlocks path above (with use_gravity they are refused, gra.cc:47-58)
         double c1[7], c2[7], tmp[4];
         if (!detail::KnownCamFromRig(i1, rigs, c1) || !detail::KnownCamFromRig(i2, rigs, c2)) return false;
         ii.push_back(image_index(pair.image_id1));
