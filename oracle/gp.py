@@ -1,7 +1,9 @@
 """ORACLE (test infrastructure only — never imported by the product path).
 
-CPU restatement of GLOMAP's global positioning, ONLY_POINTS with trivial rigs — the only mode
-`glomap mapper` accepts (global_mapper.cc:145-149):
+CPU restatement of GLOMAP's global positioning.  ONLY_POINTS is the mode `glomap mapper` accepts
+(global_mapper.cc:145-149) and the one the HIP path implements; the camera-to-camera constraint types of the estimator
+(ONLY_CAMERAS, POINTS_AND_CAMERAS_BALANCED, POINTS_AND_CAMERAS: gp.cc:42-64, 167-210, 223-253) are restated here as well
+(`pair_*` arguments of solve) so that the oracle covers the whole of GlobalPositioner::Solve:
 
   residual            BATAPairwiseDirectionError          cost_function.h:15-41   r = v - s (X - c)
   problem build       AddPointToCameraConstraints/AddTrackToProblem   gp.cc:212-375
@@ -40,7 +42,12 @@ class GlobalPositionerOptions:
     min_num_view_per_track: int = 3
     seed: int = 1
     thres_loss_function: float = 1e-1
+    constraint_type: int = 0  # ONLY_POINTS, ONLY_CAMERAS, POINTS_AND_CAMERAS_BALANCED, POINTS_AND_CAMERAS (global_positioning.h:11-20)
+    constraint_reweight_scale: float = 1.0  # only for POINTS_AND_CAMERAS_BALANCED
     lm: lm.LmOptions = field(default_factory=lambda: lm.LmOptions(max_num_iterations=100))
+
+
+ONLY_POINTS, ONLY_CAMERAS, POINTS_AND_CAMERAS_BALANCED, POINTS_AND_CAMERAS = 0, 1, 2, 3
 
 
 def mt19937_uniform(seed: int, count: int, low: float, high: float) -> np.ndarray:
@@ -54,7 +61,8 @@ def mt19937_uniform(seed: int, count: int, low: float, high: float) -> np.ndarra
 
 
 class _GpProblem:
-    def __init__(self, N, cam, pt, v, calibrated, opt: GlobalPositionerOptions, npts, off=None, sens=None, Rf=None):
+    def __init__(self, N, cam, pt, v, calibrated, opt: GlobalPositionerOptions, npts, off=None, sens=None, Rf=None,
+                 pair_i=None, pair_j=None, pair_v=None, weight_scale_pt=1.0):
         # N counts ALL 3-vector blocks: the frames and, behind them, the cam_from_rig centres that are estimated
         self.N, self.P, self.M = N, npts, cam.shape[0]
         self.cam, self.pt, self.v = cam, pt, v
@@ -67,15 +75,29 @@ class _GpProblem:
         # r = v - s (X - c_rig + t_rig), t_rig = R_cw^T t_cam_from_rig — a constant per-observation offset
         self.off = np.zeros((self.M, 3)) if off is None else off
         self.opt = opt
-        self.loss_cal = lm.HuberLoss(opt.thres_loss_function, 1.0)
-        self.loss_unc = lm.HuberLoss(opt.thres_loss_function, 0.5)
+        # point-to-camera losses (gp.cc:242-255): ScaledLoss(Huber, 0.5 w) without prior focal, Huber (ScaledLoss(Huber, w)
+        # for POINTS_AND_CAMERAS_BALANCED) with; w = 1 unless BALANCED
+        self.loss_cal = lm.HuberLoss(opt.thres_loss_function, weight_scale_pt if opt.constraint_type == POINTS_AND_CAMERAS_BALANCED else 1.0)
+        self.loss_unc = lm.HuberLoss(opt.thres_loss_function, 0.5 * weight_scale_pt)
         self.cal = calibrated.astype(bool)
-        # ordering groups of the reference (gp.cc:388-429): scales first, then points
-        self.elimination = [(3 * N + 3 * npts, self.M, 1), (3 * N, npts, 3)]
+        # camera-to-camera BATA (gp.cc:167-210): r = t - s (c_j - c_i), its own scale per pair, plain Huber
+        self.E = 0 if pair_i is None else int(np.asarray(pair_i).shape[0])
+        self.pi, self.pj, self.pv = pair_i, pair_j, pair_v
+        self.loss_pair = lm.HuberLoss(opt.thres_loss_function, 1.0)
+        # ordering groups of the reference (gp.cc:388-429): scales first (observation and pair scales), then points
+        self.elimination = [g for g in [(3 * N + 3 * npts, self.M + self.E, 1), (3 * N, npts, 3)] if g[1] > 0]
 
     def _split(self, x):
-        N, P = self.N, self.P
-        return x[: 3 * N].reshape(N, 3), x[3 * N : 3 * N + 3 * P].reshape(P, 3), x[3 * N + 3 * P :]
+        N, P, M = self.N, self.P, self.M
+        return x[: 3 * N].reshape(N, 3), x[3 * N : 3 * N + 3 * P].reshape(P, 3), x[3 * N + 3 * P : 3 * N + 3 * P + M]
+
+    def _pair_res(self, x):
+        c = x[: 3 * self.N].reshape(self.N, 3)
+        se = x[3 * self.N + 3 * self.P + self.M :]
+        d = c[self.pj] - c[self.pi]
+        r = self.pv - se[:, None] * d
+        rho0, rho1 = self.loss_pair.evaluate((r * r).sum(1))
+        return r, d, se, rho0, rho1
 
     def _res(self, x):
         c, X, s = self._split(x)
@@ -93,7 +115,10 @@ class _GpProblem:
 
     def cost(self, x):
         _, _, _, rho0, _ = self._res(x)
-        return 0.5 * float(rho0.sum())
+        tot = float(rho0.sum())
+        if self.E:
+            tot += float(self._pair_res(x)[3].sum())
+        return 0.5 * tot
 
     def evaluate(self, x):
         N, P, M, o = self.N, self.P, self.M, self.opt
@@ -118,16 +143,37 @@ class _GpProblem:
             vi.append(np.repeat(-sw * s, 3))
         if o.optimize_scales:  # d r / d s = -(X - c); the first scale is constant (gp.cc:484-489)
             js = -(sw[:, None] * d)
-            js[0] = 0.0
+            if self.E == 0 and M:
+                js[0] = 0.0  # the first scale of scales_ is constant: a pair's when there are pairs (they are added first)
             ri.append(rows.ravel())
             ci.append(np.repeat(3 * N + 3 * P + np.arange(M), 3))
             vi.append(js.ravel())
-        n = 3 * N + 3 * P + M
+        E = self.E
+        n = 3 * N + 3 * P + M + E
+        res = (sw[:, None] * r).ravel()
+        total = float(rho0.sum())
+        if E:
+            re, de, se, rho0e, rho1e = self._pair_res(x)
+            swe = np.sqrt(rho1e)
+            rows_e = 3 * M + np.arange(3 * E).reshape(E, 3)
+            if o.optimize_positions:  # d r / d c_i = +s I, d r / d c_j = -s I
+                for idx, sgn in ((self.pi, 1.0), (self.pj, -1.0)):
+                    ri.append(rows_e.ravel())
+                    ci.append((3 * idx[:, None] + comp).ravel())
+                    vi.append(np.repeat(sgn * swe * se, 3))
+            if o.optimize_scales:
+                jse = -(swe[:, None] * de)
+                jse[0] = 0.0  # gp.cc:484-489
+                ri.append(rows_e.ravel())
+                ci.append(np.repeat(3 * N + 3 * P + M + np.arange(E), 3))
+                vi.append(jse.ravel())
+            res = np.concatenate([res, (swe[:, None] * re).ravel()])
+            total += float(rho0e.sum())
         if ri:
-            J = sp.csr_matrix((np.concatenate(vi), (np.concatenate(ri), np.concatenate(ci))), shape=(3 * M, n))
+            J = sp.csr_matrix((np.concatenate(vi), (np.concatenate(ri), np.concatenate(ci))), shape=(3 * (M + E), n))
         else:
-            J = sp.csr_matrix((3 * M, n))
-        return 0.5 * float(rho0.sum()), (sw[:, None] * r).ravel(), J
+            J = sp.csr_matrix((3 * (M + E), n))
+        return 0.5 * total, res, J
 
     def plus(self, x, delta):
         y = x + delta
@@ -144,13 +190,15 @@ class _GpProblem:
 
 def solve(num_cams, pt_offset, obs_cam, obs_dir, obs_calibrated, cam_center, pt_xyz,
           options: GlobalPositionerOptions | None = None, image_frame=None, image_offset=None, image_sensor=None,
-          image_sensor_rot=None, sensor_center=None):
+          image_sensor_rot=None, sensor_center=None, pair_i=None, pair_j=None, pair_dir=None):
     """Returns (ok, cam_center [N,3], pt_xyz [P,3], LmSummary).  Arrays follow glomap_amd.flat.GpProblem.
     Known rigs (gp.cc:318-350): with `image_frame` [I] / `image_offset` [I,3] given, obs_cam indexes IMAGES, the
     unknown centre is the one of the image's frame (rig) and image_offset = R_cam_from_world^T t_cam_from_rig.
     Unknown cam_from_rig (gp.cc:354-368): `image_sensor` [I] names the centre block of the image's sensor (-1: none),
     `image_sensor_rot` [I,3,3] is R_rig_from_world of its frame, `sensor_center` [S,3] the start values (re-drawn in
-    [-1,1]^3 when optimize_positions, gp.cc:442-456); the result is summary.sensor_center."""
+    [-1,1]^3 when optimize_positions, gp.cc:442-456); the result is summary.sensor_center.
+    Camera-to-camera constraints (constraint_type != ONLY_POINTS, trivial frames only, gp.cc:167-210): `pair_i`, `pair_j`
+    [E] frame indices of the valid pairs' two images and `pair_dir` [E,3] = -R_cam2_from_world^T t_cam2_from_cam1."""
     opt = options or GlobalPositionerOptions()
     N = int(num_cams)
     pt_offset = np.asarray(pt_offset, dtype=np.int64)
@@ -179,15 +227,34 @@ def solve(num_cams, pt_offset, obs_cam, obs_dir, obs_calibrated, cam_center, pt_
     M = cam.shape[0]
     c = np.array(cam_center, dtype=np.float64, copy=True)
     X_all = np.array(pt_xyz, dtype=np.float64, copy=True)
-    if M == 0:
+    ctype = int(opt.constraint_type)
+    E = 0
+    if ctype != ONLY_POINTS:
+        assert image_frame is None, "camera-to-camera constraints support trivial frames only (gp.cc:169-176)"
+        pair_i = np.asarray(pair_i, dtype=np.int64).reshape(-1)
+        pair_j = np.asarray(pair_j, dtype=np.int64).reshape(-1)
+        pair_dir = np.asarray(pair_dir, dtype=np.float64).reshape(-1, 3)
+        E = pair_i.shape[0]
+        if E == 0:  # gp.cc:41-45
+            return False, c, X_all, lm.LmSummary(usable=False)
+    if M == 0 and ctype != ONLY_CAMERAS:  # gp.cc:46-50
         return False, c, X_all, lm.LmSummary(usable=False)
 
+    # InitializeRandomPositions (gp.cc:121-163) marks the frames of the valid pairs and of the kept tracks, whatever the
+    # constraint type
     constrained = np.zeros(N, dtype=bool)
     constrained[cam] = True
+    if E:
+        constrained[pair_i] = True
+        constrained[pair_j] = True
+    with_points = ctype != ONLY_CAMERAS  # AddPointToCameraConstraints is skipped (gp.cc:69-71): no draws, no residuals
+    if not with_points:
+        cam, pt, v, cal = cam[:0], pt[:0], v[:0], cal[:0]
+        P = M = 0
     n_draw = 0
     if opt.generate_random_positions and opt.optimize_positions:
         n_draw += 3 * int(constrained.sum())
-    if opt.generate_random_points and opt.optimize_points:
+    if opt.generate_random_points and opt.optimize_points and with_points:
         n_draw += 3 * P
     if S and opt.optimize_positions:
         n_draw += 3 * S
@@ -197,8 +264,8 @@ def solve(num_cams, pt_offset, obs_cam, obs_dir, obs_calibrated, cam_center, pt_
         nc = int(constrained.sum())
         c[constrained] = 100.0 * u[: 3 * nc].reshape(nc, 3)
         k = 3 * nc
-    X = X_all[used].copy()
-    if opt.generate_random_points and opt.optimize_points:
+    X = X_all[used].copy() if with_points else np.zeros((0, 3))
+    if opt.generate_random_points and opt.optimize_points and with_points:
         X = 100.0 * u[k : k + 3 * P].reshape(P, 3)
         k += 3 * P
     if S:
@@ -214,11 +281,15 @@ def solve(num_cams, pt_offset, obs_cam, obs_dir, obs_calibrated, cam_center, pt_
             d[sens >= 0] -= np.einsum("mji,mj->mi", Rf[sens >= 0], c[sens[sens >= 0]])
         s = np.maximum(1e-5, (v * d).sum(1) / (d * d).sum(1))
 
-    prob = _GpProblem(N + S, cam, pt, v, cal, opt, P, off, sens, Rf)
-    x0 = np.concatenate([c.ravel(), X.ravel(), s])
+    # weight of the point-to-camera losses (gp.cc:223-233): tracks.size() counts every track, kept or not
+    w_pt = opt.constraint_reweight_scale * E / P_all if (E and ctype == POINTS_AND_CAMERAS_BALANCED) else 1.0
+    prob = _GpProblem(N + S, cam, pt, v, cal, opt, P, off, sens, Rf,
+                      pair_i if E else None, pair_j if E else None, pair_dir if E else None, w_pt)
+    x0 = np.concatenate([c.ravel(), X.ravel(), s, np.ones(E)])
     x, summ = lm.solve(prob, x0, opt.lm)
     c_out, X_out, _ = prob._split(x)
-    X_all[used] = X_out
+    if with_points:
+        X_all[used] = X_out
     if S:
         summ.sensor_center = c_out[N:].copy()
     return summ.usable, c_out[:N].copy(), X_all, summ

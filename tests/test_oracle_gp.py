@@ -76,3 +76,56 @@ def test_short_tracks_are_left_untouched():
     p.pt_xyz[0] = [7.0, 8.0, 9.0]
     ok, c, X, s = _solve(p)
     assert ok and np.all(X[0] == [7.0, 8.0, 9.0])
+
+
+def _pairs(p, rng, num_succ=4, noise=0.0):
+    """Camera-to-camera directions as GlobalPositioner::AddCameraToCameraConstraints sees them (gp.cc:195-197):
+    -R_cw2^T t_21 = c_2 - c_1 in the scale of the two-view geometry (unit translation)."""
+    N = p.num_cams
+    i = np.repeat(np.arange(N), num_succ)
+    j = (i + np.tile(np.arange(1, num_succ + 1), N)) % N
+    d = p.gt_center[j] - p.gt_center[i]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d += noise * rng.normal(size=d.shape)
+    return i, j, d / np.linalg.norm(d, axis=1, keepdims=True)
+
+
+def test_constraint_types_recover_ground_truth():
+    # the estimator's other constraint types (gp.cc:42-64, 167-210, 223-253); the mapper only runs ONLY_POINTS
+    p = synthetic.make_gp_problem(num_cams=24, num_pts=300, seed=3, dir_noise=0.0, outlier_ratio=0.0)
+    pi, pj, pd = _pairs(p, np.random.default_rng(0))
+    for ctype in (gp.ONLY_CAMERAS, gp.POINTS_AND_CAMERAS_BALANCED, gp.POINTS_AND_CAMERAS):
+        opt = gp.GlobalPositionerOptions(constraint_type=ctype)
+        ok, c, X, s = gp.solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated, p.cam_center, p.pt_xyz,
+                               opt, pair_i=pi, pair_j=pj, pair_dir=pd)
+        assert ok and s.final_cost < 1e-10, (ctype, s.final_cost)
+        assert synthetic.center_errors_after_sim3(c, p.gt_center).max() < 1e-4, ctype
+        if ctype == gp.ONLY_CAMERAS:  # points are not part of the problem: left as they came in
+            assert np.array_equal(X, p.pt_xyz)
+
+
+def test_only_cameras_needs_pairs_and_points_need_tracks():
+    p = synthetic.make_gp_problem(num_cams=10, num_pts=60, seed=4)
+    opt = gp.GlobalPositionerOptions(constraint_type=gp.ONLY_CAMERAS)
+    e = np.zeros(0, dtype=np.int64)
+    ok, *_ = gp.solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated, p.cam_center, p.pt_xyz, opt,
+                      pair_i=e, pair_j=e, pair_dir=np.zeros((0, 3)))
+    assert not ok  # gp.cc:41-45
+
+
+def test_balanced_weight_scales_point_losses():
+    # POINTS_AND_CAMERAS_BALANCED: rho_pt = w * huber with w = reweight * #pairs / #tracks (gp.cc:223-253); at the start
+    # point the cost must be  sum_pairs huber + w * sum_obs huber
+    p = synthetic.make_gp_problem(num_cams=12, num_pts=80, seed=5)
+    pi, pj, pd = _pairs(p, np.random.default_rng(1), noise=0.05)
+    common = dict(generate_random_positions=False, generate_random_points=False, generate_scales=True)
+    costs = {}
+    for ctype, rw in ((gp.POINTS_AND_CAMERAS, 1.0), (gp.POINTS_AND_CAMERAS_BALANCED, 3.0), (gp.ONLY_CAMERAS, 1.0), (gp.ONLY_POINTS, 1.0)):
+        opt = gp.GlobalPositionerOptions(constraint_type=ctype, constraint_reweight_scale=rw, **common)
+        opt.lm.max_num_iterations = 0
+        kw = {} if ctype == gp.ONLY_POINTS else dict(pair_i=pi, pair_j=pj, pair_dir=pd)
+        _, _, _, s = gp.solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated, p.gt_center.copy(), p.pt_xyz, opt, **kw)
+        costs[ctype] = s.initial_cost
+    w = 3.0 * len(pi) / (p.pt_offset.shape[0] - 1)
+    assert np.isclose(costs[gp.POINTS_AND_CAMERAS], costs[gp.ONLY_CAMERAS] + costs[gp.ONLY_POINTS], rtol=1e-12)
+    assert np.isclose(costs[gp.POINTS_AND_CAMERAS_BALANCED], costs[gp.ONLY_CAMERAS] + w * costs[gp.ONLY_POINTS], rtol=1e-12)
