@@ -399,6 +399,124 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// A/B variant of k_gp_phaseA, OFF by default (GSFM_GP_PHASEA_CHAIN=1 selects it; written at the end of round 2 from the
+// ISA of k_gp_phaseA, not yet measured — DESIGN.md section 7 item 4).  Same arithmetic in the same order, so the
+// results are bit-identical; what changes is the chain of DEPENDENT memory trips one wave makes for its tile:
+//   k_gp_phaseA:  [partial sums, done] -> barriers -> [bb] -> [tile_k, a vector load] -> [obs_pt, cam, qa, qb]
+//                 -> [gathers] -> scan -> [used, H_pp^-1 of the tail lanes] -> store                      (6 trips)
+//   here:         [partial sums, done, bb, tile_k through the scalar cache] -> [obs_pt, cam, qa, qb] -> barriers
+//                 -> [gathers, used and H_pp^-1 of the tail lanes] -> scan -> store                      (3 trips)
+// Needs one wave per tile (gridTile_ is sized that way).
+__device__ __forceinline__ bool cg_converged_early(const CgVec& v, int it, double tol2, double* smem /* >= 4*2+2 */) {
+  if (v.single) return v.st->done != 0;
+  double t[2] = {0.0, 0.0};
+  {
+    const double* vp = v.vpart + (size_t)(it & 1) * kCgMaxBlocks * 2;
+    for (int b = threadIdx.x; b < v.nb_update; b += blockDim.x) {
+      t[0] += vp[2 * b];
+      t[1] += vp[2 * b + 1];
+    }
+  }
+  const int done0 = v.st->done;
+  const double bb_st = v.st->bb;  // same cache line as `done`; written at it == 0 only, read at it > 0 only
+  if (done0) return true;
+  block_sum<2>(t, smem);
+  if (threadIdx.x == 0) {
+    smem[8] = t[0];
+    smem[9] = t[1];
+  }
+  __syncthreads();
+  t[0] = smem[8];
+  t[1] = smem[9];
+  __syncthreads();
+  const double bb = it == 0 ? t[1] : bb_st;
+  const bool finite = isfinite(t[0]) && isfinite(t[1]);
+  const bool done = !finite || t[1] <= tol2 * bb;
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (it == 0) v.st->bb = bb;
+    v.st->rr = t[1];
+    v.st->iters = it;
+    if (!finite) v.st->bad = 1;
+    if (done) v.st->done = 1;
+  }
+  return done;
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_gp_phaseA_chain(GpDev g, CgVec v, int it, double tol2, const double* __restrict__ cz,
+                      const double* __restrict__ qa, const double* __restrict__ qb,
+                      const double* __restrict__ pth, double* __restrict__ ptrec) {
+  __shared__ double smem[4 * 2 + 2];
+  const int lane = threadIdx.x & 63;
+  const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+  const bool have = tile < g.g.T;
+  long k0 = 0, k1 = 0;
+  if (have) {
+    k0 = g.g.tile_k[tile];
+    k1 = g.g.tile_k[tile + 1];
+  }
+  long k = k0 + lane;
+  int p = -1;
+  long n = 0;
+  double ak = 0.0, bk = 0.0;
+  if (k < k1) {
+    p = g.g.obs_pt[k];
+    n = g.g.cam[k];
+    ak = qa[k];
+    bk = qb[k];
+  }
+  if (cg_converged_early(v, it, tol2, smem)) return;
+  if (!have) return;
+  // a tile of at most 64 observations (every tile but those of tracks longer than a wave): the keys are final, so the
+  // tail lanes know themselves now and their `used` flag and H_pp^-1 travel together with the gathers
+  const bool one_trip = k1 - k0 <= 64;  // wave-uniform
+  const int key0 = k < k1 ? p : -1 - lane;
+  const bool tail0 = seg_is_tail(key0, lane) && key0 >= 0;
+  double acc[3] = {0, 0, 0};
+  int key = -1 - lane;
+  unsigned char u0 = 0;
+  double hb[6] = {0, 0, 0, 0, 0, 0};
+  bool first = true;
+  while (k < k1) {
+    key = p;
+    V3 cn, zn;
+    ld6(cz + 6 * n, cn, zn);
+    const V3 Xp = ld3a(ptrec + 8 * (long)p);
+    if (first && one_trip && tail0) {
+      u0 = g.g.used[key0];
+      const double* b = pth + 6 * (long)key0;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) hb[j] = b[j];
+    }
+    first = false;
+    const V3 d = Xp - cn;
+    const V3 y = applyQ(ak, bk, d, zn);
+    acc[0] += y.x;
+    acc[1] += y.y;
+    acc[2] += y.z;
+    k += 64;
+    if (k < k1) {
+      p = g.g.obs_pt[k];
+      n = g.g.cam[k];
+      ak = qa[k];
+      bk = qb[k];
+    }
+  }
+  seg_scan<3>(acc, key, lane);
+  const bool tail = seg_is_tail(key, lane) && key >= 0;
+  if (one_trip) {
+    if (tail && u0) {
+      const V3 t = mul(S3{hb[0], hb[1], hb[2], hb[3], hb[4], hb[5]}, V3{acc[0], acc[1], acc[2]});
+      st3(ptrec + 8 * (long)key + 3, t);
+    }
+  } else if (tail && g.g.used[key]) {
+    const double* b = pth + 6 * (long)key;
+    const V3 t = mul(S3{b[0], b[1], b[2], b[3], b[4], b[5]}, V3{acc[0], acc[1], acc[2]});
+    st3(ptrec + 8 * (long)key + 3, t);
+  }
+}
+
 // Phase B, camera-major, one wave per camera: w_n = sum_k Q_k (z_n - t_{p(k)}) + D_n z_n and the
 // partial delta = z.w of this block.  Algorithmic bytes per observation: c_qa, c_qb (16) + c_pt (4)
 // + the 64-byte point record gather (X_p, t_p).
@@ -1202,8 +1320,13 @@ class GpSolver final : public LmProblem {
         vk.w = ws->wimg.get();
       }
       bool timed = ctx_->prof.begin(s, GSFM_KERNEL_GP_SCHUR);
-      hipLaunchKernelGGL(k_gp_phaseA, dim3(gridTile_), dim3(kBlock), 0, s, g_, vk, it, tol * tol, ws->cz.get(), ws->qa.get(),
-                         ws->qb.get(), ws->pth.get(), ws->ptrec.get());
+      static const bool chain = std::getenv("GSFM_GP_PHASEA_CHAIN") != nullptr;  // A/B switch, see k_gp_phaseA_chain
+      if (chain && (long)gridTile_ * (kBlock / 64) >= g_.g.T)
+        hipLaunchKernelGGL(k_gp_phaseA_chain, dim3(gridTile_), dim3(kBlock), 0, s, g_, vk, it, tol * tol, ws->cz.get(),
+                           ws->qa.get(), ws->qb.get(), ws->pth.get(), ws->ptrec.get());
+      else
+        hipLaunchKernelGGL(k_gp_phaseA, dim3(gridTile_), dim3(kBlock), 0, s, g_, vk, it, tol * tol, ws->cz.get(), ws->qa.get(),
+                           ws->qb.get(), ws->pth.get(), ws->ptrec.get());
       if (timed) ctx_->prof.end(s);
       timed = ctx_->prof.begin(s, GSFM_KERNEL_GP_SCHUR_B);
       // rigs: the damping D z is a frame-space term, added by k_rig_reduce_w (the sweep runs with a zero diagonal)
