@@ -182,6 +182,8 @@ struct Ba : LmProblem {
   std::vector<double> jred, jpt;      // Jacobi scales
   // per step
   std::vector<double> dred, Hinv /*[P][9]*/, tp, ak /*[M][2]*/;
+  std::vector<double> dy_prev;  // ORC_WARM_START experiment: the reduced step of the last solve ...
+  bool same_lin = false;        // ... and whether it belongs to the current linearisation
   std::vector<double> Mblk;           // block-Jacobi: per camera 14x14 (joint) ...
   std::vector<double> Miblk;          // ... per shared intrinsics block 8x8
 
@@ -248,6 +250,7 @@ struct Ba : LmProblem {
   }
 
   double linearize(double* gmax_out) override {
+    same_lin = false;
     rt.resize(2 * M);
     Jc.resize(12 * M);
     Jp.resize(6 * M);
@@ -499,9 +502,18 @@ struct Ba : LmProblem {
     if (!build_preconditioner()) return false;
     std::vector<double> dy(nred, 0.0);
     *relres = 0.0;
+    // experiment (ORC_WARM_START=1, tools/exp_lm_warm_start.py): after a rejected step the linearisation is the same and
+    // only the damping moved, so the rejected step is a starting guess for the next solve.  Off: the oracle's solves
+    // start from zero.
+    static const bool warm = std::getenv("ORC_WARM_START") != nullptr;
+    const std::vector<double>* guess = warm && same_lin && (i64)dy_prev.size() == nred ? &dy_prev : nullptr;
     *lin = solve_reduced(
         nred, rhs, dy, pcg_tol, pcg_max, [&](const std::vector<double>& z, std::vector<double>& o) { apply(z, o); },
-        [&](const std::vector<double>& r, std::vector<double>& z) { precond(r, z); }, relres, (double)M);
+        [&](const std::vector<double>& r, std::vector<double>& z) { precond(r, z); }, relres, (double)M, guess);
+    if (warm) {
+      dy_prev = dy;
+      same_lin = true;
+    }
     // back-substitution: dX = -u - tp(dy)
     point_pass(dy);
     std::vector<double> dX(3 * P);

@@ -190,14 +190,27 @@ bool dense_solve(i64 n, const std::vector<double>& b, std::vector<double>& x, Ap
 // Stops at |r| <= tol |b| (recurrence residual), at max_it, or when the residual has not improved
 // by a factor 0.999 over 200 iterations (rounding floor; PCG residuals are not monotone, so the window is wide).  Returns the iteration count and writes the
 // TRUE relative residual |b - S x| / |b| of the returned x.
+// `x0` (optional, experiments only — tools/exp_lm_warm_start.py): start from gamma * x0 with the gamma that minimises the
+// energy norm of the error along x0 (one more operator application); the stopping rule stays |r| <= tol |b|.
 template <class Apply, class Precond>
 i64 pcg(i64 n, const std::vector<double>& b, std::vector<double>& x, double tol, int max_it, Apply apply, Precond precond,
-        double* true_relres) {
+        double* true_relres, const std::vector<double>* x0 = nullptr) {
   std::vector<double> r(b), z(n), p(n), w(n);
   std::fill(x.begin(), x.end(), 0.0);
   const double bnorm = std::sqrt(vdot(b, b));
   *true_relres = 0.0;
   if (!(bnorm > 0.0)) return 0;
+  if (x0 != nullptr && (i64)x0->size() == n) {
+    apply(*x0, w);
+    const double xb = vdot(*x0, b), xw = vdot(*x0, w);
+    if (xw > 0.0 && std::isfinite(xw)) {
+      const double gamma = xb / xw;
+      for (i64 i = 0; i < n; ++i) {
+        x[i] = gamma * (*x0)[i];
+        r[i] = b[i] - gamma * w[i];
+      }
+    }
+  }
   precond(r, z);
   p = z;
   double rz = vdot(r, z);
@@ -252,7 +265,7 @@ i64 pcg(i64 n, const std::vector<double>& b, std::vector<double>& x, double tol,
 constexpr double kDenseMaxWork = 2e8;
 template <class Apply, class Precond>
 i64 solve_reduced(i64 n, const std::vector<double>& b, std::vector<double>& x, double tol, int max_it, Apply apply,
-                  Precond precond, double* true_relres, double apply_cost = 0.0) {
+                  Precond precond, double* true_relres, double apply_cost = 0.0, const std::vector<double>* x0 = nullptr) {
   if (n <= kDenseMax && (double)n * apply_cost <= kDenseMaxWork) {
     bool nonzero = false;
     for (double v : b) nonzero = nonzero || v != 0.0;
@@ -263,7 +276,7 @@ i64 solve_reduced(i64 n, const std::vector<double>& b, std::vector<double>& x, d
     }
     if (dense_solve(n, b, x, apply, true_relres)) return 0;
   }
-  return pcg(n, b, x, tol, max_it, apply, precond, true_relres);
+  return pcg(n, b, x, tol, max_it, apply, precond, true_relres, x0);
 }
 
 }  // namespace orc
