@@ -507,9 +507,33 @@ struct Ba : LmProblem {
     // start from zero.
     static const bool warm = std::getenv("ORC_WARM_START") != nullptr;
     const std::vector<double>* guess = warm && same_lin && (i64)dy_prev.size() == nred ? &dy_prev : nullptr;
+    // experiment (ORC_DEFLATE=1, tools/exp_deflation.py): deflate the seven similarity modes of the scene — world
+    // translation (dt_n = -R_n a), world rotation (left tangent d_n = -R_n w / 2: the quaternion manifold turns by
+    // 2 |d|), scale (dt_n = t_n) — from the PCG.  They are the near-null space of the reduced system: one constant frame
+    // anchors six of them with a stiffness of O(1/N), the scale only through the LM damping.
+    // ORC_DEFLATE=6 leaves the scale out: it is an EXACT gauge of the cost (held by the LM damping alone), so "solving"
+    // its component divides rounding noise by the damping and sends the iterate along the gauge.
+    static const int deflate = std::getenv("ORC_DEFLATE") ? std::atoi(std::getenv("ORC_DEFLATE")) : 0;
+    std::vector<std::vector<double>> W;
+    if (deflate && S == 0) {
+      W.assign(deflate == 6 ? 6 : 7, std::vector<double>(nred, 0.0));
+      for (i64 n = 0; n < N; ++n) {
+        double R[9];
+        quat_to_rot(&q[4 * n], R);
+        const double fr = rot_free[n] ? 1.0 : 0.0, ft = trn_free[n] ? 1.0 : 0.0;
+        for (int a = 0; a < 3; ++a)
+          for (int i = 0; i < 3; ++i) {
+            W[a][6 * n + 3 + i] = -ft * R[3 * i + a];
+            W[3 + a][6 * n + i] = -0.5 * fr * R[3 * i + a];
+          }
+        if (W.size() > 6)
+          for (int i = 0; i < 3; ++i) W[6][6 * n + 3 + i] = ft * t[3 * n + i];
+      }
+    }
     *lin = solve_reduced(
         nred, rhs, dy, pcg_tol, pcg_max, [&](const std::vector<double>& z, std::vector<double>& o) { apply(z, o); },
-        [&](const std::vector<double>& r, std::vector<double>& z) { precond(r, z); }, relres, (double)M, guess);
+        [&](const std::vector<double>& r, std::vector<double>& z) { precond(r, z); }, relres, (double)M, guess,
+        W.empty() ? nullptr : &W);
     if (warm) {
       dy_prev = dy;
       same_lin = true;

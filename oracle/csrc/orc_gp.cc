@@ -422,6 +422,19 @@ struct Gp : LmProblem {
     }
     std::vector<double> dc(3 * (N + S), 0.0);
     *relres = 0.0;
+    // experiment (ORC_DEFLATE, tools/exp_deflation.py): deflate the four gauge modes of global positioning — world
+    // translation (dc_n = a) and scale (dc_n = c_n) — from the PCG.  Nothing anchors them but the LM damping (no frame is
+    // constant, gp.cc:437-439), so the PCG drops them again when W^T A W cannot be inverted.
+    static const bool deflate = std::getenv("ORC_DEFLATE") != nullptr;
+    std::vector<std::vector<double>> W;
+    if (deflate && S == 0 && mc != 0.0) {
+      W.assign(4, std::vector<double>(3 * N, 0.0));
+      for (i64 n = 0; n < N; ++n)
+        for (int a = 0; a < 3; ++a) {
+          W[a][3 * n + a] = 1.0;
+          W[3][3 * n + a] = c[3 * n + a];
+        }
+    }
     *lin = solve_reduced(
         3 * (N + S), rhs, dc, pcg_tol, pcg_max, [&](const std::vector<double>& z, std::vector<double>& o) { apply(z, o); },
         [&](const std::vector<double>& r, std::vector<double>& z) {
@@ -431,7 +444,7 @@ struct Gp : LmProblem {
             for (int i = 0; i < 3; ++i) z[3 * n + i] = B[3 * i] * r[3 * n] + B[3 * i + 1] * r[3 * n + 1] + B[3 * i + 2] * r[3 * n + 2];
           }
         },
-        relres, (double)M);
+        relres, (double)M, nullptr, W.empty() ? nullptr : &W);
     // back-substitution: dX_p = Hpp^-1 (-gX' + mc mx sum Q dc) ; ds_k = beta (d.(r + s (mc dc - mx dX)))
     std::vector<double> dX(3 * P);
     apply_points_only(dc);  // tp = mc mx Hpp^-1 sum Q dc

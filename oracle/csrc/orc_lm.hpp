@@ -193,13 +193,61 @@ bool dense_solve(i64 n, const std::vector<double>& b, std::vector<double>& x, Ap
 // `x0` (optional, experiments only — tools/exp_lm_warm_start.py): start from gamma * x0 with the gamma that minimises the
 // energy norm of the error along x0 (one more operator application); the stopping rule stays |r| <= tol |b|.
 template <class Apply, class Precond>
+// `defl` (optional, experiments only — tools/exp_deflation.py): deflated PCG (Saad, Yeung, Erhel, Guyomarc'h 2000) on
+// the span of the given vectors W: x starts at W (W^T A W)^-1 W^T b and every preconditioned residual is projected,
+// z <- z - W (W^T A W)^-1 (A W)^T z.  Same system, same stopping rule; the k applications of the operator that form A W
+// are counted in the returned iteration count.
 i64 pcg(i64 n, const std::vector<double>& b, std::vector<double>& x, double tol, int max_it, Apply apply, Precond precond,
-        double* true_relres, const std::vector<double>* x0 = nullptr) {
+        double* true_relres, const std::vector<double>* x0 = nullptr, const std::vector<std::vector<double>>* defl = nullptr) {
   std::vector<double> r(b), z(n), p(n), w(n);
   std::fill(x.begin(), x.end(), 0.0);
   const double bnorm = std::sqrt(vdot(b, b));
   *true_relres = 0.0;
   if (!(bnorm > 0.0)) return 0;
+  const int kd = defl ? (int)defl->size() : 0;
+  std::vector<std::vector<double>> AW(kd, std::vector<double>(n));
+  std::vector<double> Einv((size_t)kd * kd, 0.0);
+  bool deflate = kd > 0;
+  if (deflate) {
+    for (int j = 0; j < kd; ++j) apply((*defl)[j], AW[j]);
+    for (int i = 0; i < kd; ++i)
+      for (int j = 0; j < kd; ++j) Einv[(size_t)i * kd + j] = vdot((*defl)[i], AW[j]);
+    for (int i = 0; i < kd; ++i)
+      for (int j = i + 1; j < kd; ++j) Einv[(size_t)i * kd + j] = Einv[(size_t)j * kd + i] = 0.5 * (Einv[(size_t)i * kd + j] + Einv[(size_t)j * kd + i]);
+    // a mode whose preconditioned Rayleigh quotient theta = (w^T A w)(w^T M^-1 w) / (w^T w)^2 (the bulk of the spectrum is
+    // ~1) has fallen to rounding level is an exact gauge held by nothing: "solving" it divides noise by nothing.  Such
+    // a solve runs undeflated.
+    static const bool dbg = std::getenv("ORC_DEFLATE_DEBUG") != nullptr;
+    static const double theta_min = std::getenv("ORC_DEFLATE_MIN") ? std::atof(std::getenv("ORC_DEFLATE_MIN")) : 0.0;
+    for (int j = 0; j < kd && deflate; ++j) {
+      precond((*defl)[j], z);
+      const double ww = vdot((*defl)[j], (*defl)[j]);
+      const double theta = Einv[(size_t)j * kd + j] * vdot((*defl)[j], z) / (ww * ww);
+      if (dbg) fprintf(stderr, "[orc deflate] mode %d theta %.3e\n", j, theta);
+      if (!(theta > theta_min)) deflate = false;
+    }
+    deflate = deflate && spd_inverse(Einv.data(), kd);
+  }
+  // v <- v - W E^-1 (Q^T v)   with Q = W (start) or A W (projection of z)
+  auto correct = [&](std::vector<double>& v, const std::vector<std::vector<double>>& Q, double sign, std::vector<double>* into) {
+    std::vector<double> c(kd), y(kd, 0.0);
+    for (int j = 0; j < kd; ++j) c[j] = vdot(Q[j], v);
+    for (int i = 0; i < kd; ++i)
+      for (int j = 0; j < kd; ++j) y[i] += Einv[(size_t)i * kd + j] * c[j];
+    std::vector<double>& dst = into ? *into : v;
+    for (int j = 0; j < kd; ++j) {
+      const double a = sign * y[j];
+      const std::vector<double>& wj = (*defl)[j];
+      for (i64 i = 0; i < n; ++i) dst[i] += a * wj[i];
+    }
+    return y;
+  };
+  if (deflate) {
+    std::vector<double> bb(b);
+    const std::vector<double> y = correct(bb, *defl, +1.0, &x);  // x = W E^-1 W^T b
+    for (int j = 0; j < kd; ++j)
+      for (i64 i = 0; i < n; ++i) r[i] -= y[j] * AW[j][i];
+  }
   if (x0 != nullptr && (i64)x0->size() == n) {
     apply(*x0, w);
     const double xb = vdot(*x0, b), xw = vdot(*x0, w);
@@ -212,6 +260,7 @@ i64 pcg(i64 n, const std::vector<double>& b, std::vector<double>& x, double tol,
     }
   }
   precond(r, z);
+  if (deflate) correct(z, AW, -1.0, nullptr);
   p = z;
   double rz = vdot(r, z);
   double best = bnorm;
@@ -239,6 +288,7 @@ i64 pcg(i64 n, const std::vector<double>& b, std::vector<double>& x, double tol,
       break;
     }
     precond(r, z);
+    if (deflate) correct(z, AW, -1.0, nullptr);
     const double rz_new = vdot(r, z);
     const double beta = rz_new / rz;
     rz = rz_new;
@@ -254,7 +304,7 @@ i64 pcg(i64 n, const std::vector<double>& b, std::vector<double>& x, double tol,
     return d * d;
   });
   *true_relres = std::sqrt(rr) / bnorm;
-  return it;
+  return it + (deflate ? kd : 0);
 }
 
 // The reduced-system solve of one LM step: direct when small, PCG otherwise.  Returns the PCG iteration count (0 for
@@ -265,7 +315,8 @@ i64 pcg(i64 n, const std::vector<double>& b, std::vector<double>& x, double tol,
 constexpr double kDenseMaxWork = 2e8;
 template <class Apply, class Precond>
 i64 solve_reduced(i64 n, const std::vector<double>& b, std::vector<double>& x, double tol, int max_it, Apply apply,
-                  Precond precond, double* true_relres, double apply_cost = 0.0, const std::vector<double>* x0 = nullptr) {
+                  Precond precond, double* true_relres, double apply_cost = 0.0, const std::vector<double>* x0 = nullptr,
+                  const std::vector<std::vector<double>>* defl = nullptr) {
   if (n <= kDenseMax && (double)n * apply_cost <= kDenseMaxWork) {
     bool nonzero = false;
     for (double v : b) nonzero = nonzero || v != 0.0;
@@ -276,7 +327,7 @@ i64 solve_reduced(i64 n, const std::vector<double>& b, std::vector<double>& x, d
     }
     if (dense_solve(n, b, x, apply, true_relres)) return 0;
   }
-  return pcg(n, b, x, tol, max_it, apply, precond, true_relres, x0);
+  return pcg(n, b, x, tol, max_it, apply, precond, true_relres, x0, defl);
 }
 
 }  // namespace orc
