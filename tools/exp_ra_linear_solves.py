@@ -13,6 +13,7 @@ iterations per stage for a few variants:
   interface    block inverses + an exact Schur complement on the nodes that couple the blocks (substructuring) as
                preconditioner, abs stopping rule
   interface-stale   the same, factored ONCE for the unit-weight Laplacian of the L1 stage and kept for the IRLS weights
+  abs+deflate  as abs, with the constant vector (the global rotation, held by the gauge row alone) deflated from the PCG
 
 and reports, against `exact`, the largest difference of the resulting rotations.
 Usage: python tools/exp_ra_linear_solves.py [num_cams] [successors | geometric | hub | chords] [variant ...]"""
@@ -100,10 +101,19 @@ class Laplacian:
         return out
 
 
-def pcg(A, B, X0, precond, tol_abs2, max_it=2000, keep=None):
-    """Joint PCG over the columns of B; stops at |r|^2 <= tol_abs2.  keep: list collecting (p, Ap, pAp)."""
+def pcg(A, B, X0, precond, tol_abs2, max_it=2000, keep=None, deflate=False):
+    """Joint PCG over the columns of B; stops at |r|^2 <= tol_abs2.  keep: list collecting (p, Ap, pAp).
+    deflate: project the constant vector (the global rotation, anchored by the gauge row alone) out of every column."""
     X = X0.copy()
     R = B - A @ X
+    if deflate:
+        one = np.ones(A.shape[0])
+        a1 = A @ one
+        e = float(one @ a1)
+        X = X + np.outer(one, one @ R) / e
+        R = B - A @ X
+        inner = precond
+        precond = lambda r: (lambda z: z - np.outer(one, a1 @ z) / e)(inner(r))  # noqa: E731
     it = 0
     rr = float((R * R).sum())
     if rr <= tol_abs2:
@@ -174,7 +184,7 @@ class Solver:
             ref2 = float((R0 * R0).sum())
         else:
             ref2 = bb
-        X, it = pcg(lap.L, B, X0, precond, tol * tol * ref2, keep=keep)
+        X, it = pcg(lap.L, B, X0, precond, tol * tol * ref2, keep=keep, deflate=self.variant.endswith("+deflate"))
         self.iters[stage] += it
         return X
 
