@@ -1117,6 +1117,31 @@ __global__ void __launch_bounds__(kBlock)
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+// GSFM_DEFLATE experiment (CgDeflation in cg.hpp): the similarity gauge of the scene in the
+// pose unknowns of the reduced system (6 per camera: left quaternion tangent — the manifold turns by 2 |d| — then
+// translation; the intrinsics part of the modes is zero and W was cleared by the caller):
+//   world translation a:  dt_n = -R_n a          world rotation w:  drot_n = -R_n w / 2          scale:  dt_n = t_n
+// The constant frame has zero entries.  with_rot = 1: [3 translations | 3 rotations | scale] (7 modes);
+// with_rot = 0 (rotations frozen): [3 translations | scale] (4 modes).
+__global__ void __launch_bounds__(kBlock) k_ba_defl_modes(int N, long n, const double* __restrict__ R, const double* __restrict__ t,
+                                                          int fixed_cam, int with_rot, double* __restrict__ W) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < N; c += gridDim.x * blockDim.x) {
+    if (c == fixed_cam) continue;
+    const double* R9 = R + 9L * c;
+    const long o = 6L * c;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        W[(size_t)a * n + o + 3 + i] = -R9[3 * i + a];
+        if (with_rot) W[(size_t)(3 + a) * n + o + i] = -0.5 * R9[3 * i + a];
+      }
+    const int js = with_rot ? 6 : 3;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) W[(size_t)js * n + o + 3 + i] = t[3L * c + i];
+  }
+}
+
 struct BaWs {
   ObsGraphWs og;
   DevBuf<long> off;
@@ -1133,6 +1158,7 @@ struct BaWs {
   DevBuf<int> img_frame, foff, fimg, img_sensor, soff, simg;
   DevBuf<unsigned char> img_fixed, fmask;
   DevBuf<double> sens, Ri, Rin, ti, tin, diag_i, grad_i, gred_i, spose_i, dvec_i, zimg, wimg, ximg, lever, gram_i;
+  DevBuf<double> defl_w, defl_aw, defl_b2, defl_part, defl_small;  // GSFM_DEFLATE experiment (CgDeflation, cg.hpp)
   static void destroy(void* p) { delete static_cast<BaWs*>(p); }
 };
 
@@ -2095,7 +2121,26 @@ class BaSolver final : public LmProblem {
     hipStream_t s = ctx_->stream;
     const double yscale = ctx_->comm.rank == 0 ? 1.0 : 0.0;
     const double tol = opt_.lm.pcg_relative_tolerance;
-    return cg_solve<6, true>(ctx_, cg_, tol, opt_.lm.pcg_max_iterations, [&](int it) {
+    // experiment, off unless GSFM_DEFLATE is set: the similarity gauge deflated from the PCG (CgDeflation, cg.hpp).  One
+    // rank, trivial rigs, joint pose + intrinsics blocks, translations among the unknowns; skipped while the solves are
+    // short anyway (strongly damped LM steps).
+    static const bool want_defl = std::getenv("GSFM_DEFLATE") != nullptr;
+    CgDeflation defl;
+    if (want_defl && !rig_ && joint_ && ctx_->comm.world == 1 && g_.opt_trn && last_pcg_ > 20) {
+      const int with_rot = g_.opt_rot ? 1 : 0;
+      defl.k = with_rot ? 7 : 4;
+      const size_t n = (size_t)n_;
+      double* W = ws->defl_w.ensure(defl.k * n);
+      defl.AW = ws->defl_aw.ensure(defl.k * n);
+      defl.b2 = ws->defl_b2.ensure(n);
+      defl.part = ws->defl_part.ensure((size_t)kCgdBlocks * 2 * kCgMaxModes);
+      defl.small = ws->defl_small.ensure(80);
+      GSFM_HIP_CHECK(hipMemsetAsync(W, 0, defl.k * n * sizeof(double), s));
+      hipLaunchKernelGGL(k_ba_defl_modes, dim3(gridN_), dim3(kBlock), 0, s, N_, (long)n_, (const double*)Rk_, (const double*)tk_,
+                         g_.fixed_cam, with_rot, W);
+      defl.W = W;
+    }
+    const long iters = cg_solve<6, true>(ctx_, cg_, tol, opt_.lm.pcg_max_iterations, [&](int it) {
       // rigs: the sweeps run on per-image vectors (z_image = T_s z_frame) with a zero pose diagonal; everything else of
       // the PCG state (partials, status, scalars — set by cg_solve on cg_) is shared with the frame-space solve
       CgVec vk = cg_;
@@ -2133,7 +2178,9 @@ class BaSolver final : public LmProblem {
       if (rig_)
         hipLaunchKernelGGL(k_ba_rig_reduce_w, dim3(1), dim3(kBlock), 0, s, cg_, rg_, yscale, ws->wimg.get(), ws->dvec.get(),
                            gridCam_ + gridK_ + gridMulti_);
-    });
+    }, defl.k ? &defl : nullptr);
+    last_pcg_ = iters;
+    return iters;
   }
 
   gsfm_ctx* ctx_;
@@ -2148,6 +2195,7 @@ class BaSolver final : public LmProblem {
   RigDev rg_{};
   double *Rk_ = nullptr, *Rkn_ = nullptr, *tk_ = nullptr, *tkn_ = nullptr;  // poses the sweeps see (frames or images)
   bool small_groups_ = false, joint_ = false;
+  long last_pcg_ = 1 << 20;  // iterations of the previous reduced solve (GSFM_DEFLATE experiment: skip short solves)
   long P_ = 0, M_ = 0, Mp_ = 0, m_used_ = 0;
   int gridP_ = 1, gridN_ = 1, gridM_ = 1, gridCam_ = 1, gridMulti_ = 0, gridTile_ = 1, gridTileP_ = 1, gridK_ = 1;
   double *q_ = nullptr, *qn_ = nullptr, *t_ = nullptr, *tn_ = nullptr, *R_ = nullptr, *Rn_ = nullptr, *X_ = nullptr,

@@ -525,24 +525,234 @@ static __global__ void __launch_bounds__(kBlock) k_cg_delta_to_w(CgVec v) {
   if (threadIdx.x == 0) v.w[v.n] = d[0];
 }
 
+// ---- deflation of known near-null modes (EXPERIMENT, off unless a solver passes a CgDeflation) ---------------------
+// The block-Jacobi-preconditioned reduced systems of BA / GP have a tight spectrum plus the similarity gauge of the
+// scene (CPU evidence tools/exp_deflation.py; executable specification: pcg(..., defl) in
+// oracle/csrc/orc_lm.hpp).  Deflated PCG (Saad, Yeung, Erhel, Guyomarc'h 2000) on the span of k given modes W:
+//     E = W^T A W,   x = W E^-1 W^T b + x',   A x' = b2 := b - A W E^-1 W^T b,
+//     every preconditioned residual is projected:  z <- z - W E^-1 (A W)^T z   (r.z is patched by -(W^T r).(E^-1 (AW)^T z))
+// Same system, same stopping rule (relative to |b2| <= |b|).  Written at the end of round 2 without a GPU to run it on:
+// nothing here executes unless GSFM_DEFLATE is set (gp.hip / ba.hip), single rank, multi-block vector kernels only.
+constexpr int kCgMaxModes = 8;
+constexpr int kCgdBlocks = 128;  // grid of the dot-product kernel
+
+struct CgDeflation {
+  int k = 0;                   // modes in use (<= kCgMaxModes)
+  const double* W = nullptr;   // [k][n] the modes (zero in constant components)
+  double* AW = nullptr;        // [k][n]
+  double* b2 = nullptr;        // [n]   deflated right-hand side
+  double* part = nullptr;      // [kCgdBlocks][2 * kCgMaxModes] partial dot products
+  double* small = nullptr;     // [64] E^-1 | [8] y0 = E^-1 W^T b | [1] ok (1.0 / 0.0)
+};
+
+// the element list of the unknown vector with its gather mirrors: f(o, n, i) for every unknown o; (n, i) = camera and
+// index inside its joint block when JOINT, else (camera block or -1, index)
+template <int PB, bool JOINT, typename F>
+__device__ __forceinline__ void cgd_for_each(const CgVec& v, F f) {
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long)gridDim.x * blockDim.x;
+  if constexpr (JOINT) {
+    for (long e = tid; e < (long)v.N * 16; e += nth) {
+      const int n = (int)(e >> 4), i = (int)(e & 15);
+      if (i < PB + 8) f(cg_joint_index<PB>(v, n, i), n, i);
+    }
+  } else {
+    for (long o = tid; o < (long)v.n; o += nth) {
+      const bool cam = o < (long)PB * v.N;
+      f(o, cam ? (int)(o / PB) : -1, cam ? (int)(o % PB) : 0);
+    }
+  }
+}
+template <int PB, bool JOINT>
+__device__ __forceinline__ void cgd_store_z(const CgVec& v, long o, int n, int i, double zi) {
+  v.z[o] = zi;
+  if constexpr (JOINT) {
+    cg_joint_mirror<PB>(v, n, i, zi);
+  } else {
+    if (v.zmir && n >= 0) v.zmir[(long)n * v.zmir_stride + v.zmir_off + i] = zi;
+  }
+}
+
+// z := vec (with mirrors): the input of one operator application
+template <int PB, bool JOINT>
+static __global__ void __launch_bounds__(kBlock) k_cgd_set_z(CgVec v, const double* __restrict__ vec) {
+  cgd_for_each<PB, JOINT>(v, [&](long o, int n, int i) { cgd_store_z<PB, JOINT>(v, o, n, i, vec[o]); });
+}
+static __global__ void __launch_bounds__(kBlock) k_cgd_copy(long n, const double* __restrict__ src, double* __restrict__ dst) {
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x) dst[o] = src[o];
+}
+
+// E = W^T A W (symmetrised), E^-1 by Gauss-Jordan with a positivity test, y0 = E^-1 W^T b, b2 = b - A W y0.  One
+// workgroup: k^2 + k dot products over n <= a few 10^5 doubles, once per solve.
+static __global__ void __launch_bounds__(kCgSingleThreads) k_cgd_gram(CgVec v, CgDeflation d) {
+  __shared__ double smem[16 * 1 + 1];
+  __shared__ double E[kCgMaxModes][kCgMaxModes + 1];  // last column: W^T b
+  __shared__ double sy[kCgMaxModes];
+  __shared__ int sok;
+  const int k = d.k;
+  for (int i = 0; i < k; ++i)
+    for (int j = 0; j <= k; ++j) {
+      const double* a = d.W + (size_t)i * v.n;
+      const double* c = j < k ? d.AW + (size_t)j * v.n : v.b;
+      double t[1] = {0.0};
+      for (long o = threadIdx.x; o < (long)v.n; o += blockDim.x) t[0] += a[o] * c[o];
+      block_sum_1024<1>(t, smem);
+      if (threadIdx.x == 0) E[i][j] = t[0];
+    }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double A[kCgMaxModes][2 * kCgMaxModes];
+    bool ok = true;
+    for (int i = 0; i < k; ++i)
+      for (int j = 0; j < k; ++j) {
+        A[i][j] = 0.5 * (E[i][j] + E[j][i]);
+        A[i][k + j] = i == j ? 1.0 : 0.0;
+      }
+    for (int c = 0; c < k && ok; ++c) {  // SPD: the pivots are the diagonal
+      const double piv = A[c][c];
+      if (!(piv > 0.0) || !isfinite(piv)) {
+        ok = false;
+        break;
+      }
+      const double ip = 1.0 / piv;
+      for (int j = 0; j < 2 * k; ++j) A[c][j] *= ip;
+      for (int r = 0; r < k; ++r) {
+        if (r == c) continue;
+        const double f = A[r][c];
+        for (int j = 0; j < 2 * k; ++j) A[r][j] -= f * A[c][j];
+      }
+    }
+    for (int i = 0; i < k; ++i) {
+      double y = 0.0;
+      for (int j = 0; j < k; ++j) {
+        const double e = ok ? A[i][k + j] : 0.0;
+        d.small[i * kCgMaxModes + j] = e;
+        y += e * E[j][k];
+      }
+      if (!isfinite(y)) ok = false;
+      sy[i] = y;
+    }
+    if (!ok)
+      for (int i = 0; i < k; ++i) sy[i] = 0.0;
+    for (int i = 0; i < k; ++i) d.small[64 + i] = sy[i];
+    d.small[72] = ok ? 1.0 : 0.0;
+    sok = ok ? 1 : 0;
+  }
+  __syncthreads();
+  for (long o = threadIdx.x; o < (long)v.n; o += blockDim.x) {
+    double t = v.b[o];
+    if (sok)
+      for (int j = 0; j < k; ++j) t -= sy[j] * d.AW[(size_t)j * v.n + o];
+    d.b2[o] = t;
+  }
+}
+
+// partial dot products  c_j = (A W_j) . z,  dd_j = W_j . r   of the current iterate
+static __global__ void __launch_bounds__(kBlock) k_cgd_dots(CgVec v, CgDeflation d) {
+  __shared__ double smem[4 * 2 * kCgMaxModes];
+  if (v.st->done || d.small[72] == 0.0) return;
+  double acc[2 * kCgMaxModes];
+#pragma unroll
+  for (int j = 0; j < 2 * kCgMaxModes; ++j) acc[j] = 0.0;
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < (long)v.n; o += (long)gridDim.x * blockDim.x) {
+    const double zo = v.z[o], ro = v.r[o];
+#pragma unroll
+    for (int j = 0; j < kCgMaxModes; ++j)
+      if (j < d.k) {
+        acc[j] += d.AW[(size_t)j * v.n + o] * zo;
+        acc[kCgMaxModes + j] += d.W[(size_t)j * v.n + o] * ro;
+      }
+  }
+  block_sum<2 * kCgMaxModes>(acc, smem);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < 2 * kCgMaxModes; ++j) d.part[blockIdx.x * 2 * kCgMaxModes + j] = acc[j];
+  }
+}
+
+// z <- z - W E^-1 c (vector and mirrors); block 0 patches the r.z partial of parity slot (it + 1) & 1 by -dd . (E^-1 c)
+template <int PB, bool JOINT>
+static __global__ void __launch_bounds__(kBlock) k_cgd_project(CgVec v, CgDeflation d, int it, int nparts) {
+  __shared__ double smem[5 * 2 * kCgMaxModes];
+  __shared__ double sy[kCgMaxModes];
+  if (v.st->done || d.small[72] == 0.0) return;
+  double cd[2 * kCgMaxModes];
+  reduce_partials<2 * kCgMaxModes>(d.part, nparts, cd, smem);
+  if (threadIdx.x == 0) {
+    double corr = 0.0;
+    for (int i = 0; i < d.k; ++i) {
+      double y = 0.0;
+      for (int j = 0; j < d.k; ++j) y += d.small[i * kCgMaxModes + j] * cd[j];
+      sy[i] = y;
+      corr += y * cd[kCgMaxModes + i];
+    }
+    if (blockIdx.x == 0) v.vpart[(size_t)((it + 1) & 1) * kCgMaxBlocks * 2] -= corr;
+  }
+  __syncthreads();
+  cgd_for_each<PB, JOINT>(v, [&](long o, int n, int i) {
+    double zi = v.z[o];
+    for (int j = 0; j < d.k; ++j) zi -= sy[j] * d.W[(size_t)j * v.n + o];
+    cgd_store_z<PB, JOINT>(v, o, n, i, zi);
+  });
+}
+
+// x <- x + W y0
+static __global__ void __launch_bounds__(kBlock) k_cgd_finish(CgVec v, CgDeflation d) {
+  if (d.small[72] == 0.0) return;
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < (long)v.n; o += (long)gridDim.x * blockDim.x) {
+    double xo = v.x[o];
+    for (int j = 0; j < d.k; ++j) xo += d.small[64 + j] * d.W[(size_t)j * v.n + o];
+    v.x[o] = xo;
+  }
+}
+
 // Host driver.  `apply(it)` must enqueue the kernels computing w = A z and the delta partials
 // (its first kernel calls cg_converged); it is also responsible for timing its dominant kernel.
 template <int PB, bool HAS_INTR, typename Apply>
-inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& apply) {
+inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& apply, const CgDeflation* defl = nullptr) {
   hipStream_t s = ctx->stream;
   const bool multi = ctx->comm.world > 1;
   v.delta_in_w = multi ? 1 : 0;
   const bool joint = HAS_INTR && v.joint_map != nullptr;
   v.tol2 = tol * tol;
   v.single = (!HAS_INTR && v.N <= kCgSingleMaxBlocks) ? 1 : 0;
-  if constexpr (HAS_INTR) {
-    if (joint) hipLaunchKernelGGL((k_cg_init_joint<PB>), dim3(v.nb_update), dim3(kBlock), 0, s, v);
-  } else {
-    if (v.single) hipLaunchKernelGGL((k_cg_init1<PB>), dim3(1), dim3(kCgSingleThreads), 0, s, v);
+  auto init = [&]() {
+    if constexpr (HAS_INTR) {
+      if (joint) hipLaunchKernelGGL((k_cg_init_joint<PB>), dim3(v.nb_update), dim3(kBlock), 0, s, v);
+    } else {
+      if (v.single) hipLaunchKernelGGL((k_cg_init1<PB>), dim3(1), dim3(kCgSingleThreads), 0, s, v);
+    }
+    if (!joint && !v.single) hipLaunchKernelGGL((k_cg_init<PB, HAS_INTR>), dim3(v.nb_update), dim3(kBlock), 0, s, v);
+  };
+  init();
+  // experiment (see CgDeflation): only the multi-block vector kernels on one rank, and not the non-joint BA layout
+  const bool deflate = defl != nullptr && defl->k > 0 && !multi && !v.single && (joint || !HAS_INTR);
+  const double* b_caller = v.b;
+  const int gdot = std::min(kCgdBlocks, grid_for((size_t)v.n, kBlock));
+  const int gvec = std::min(256, grid_for((size_t)std::max((long)v.n, (long)v.N * 16), kBlock));
+  auto project = [&](int it) {
+    hipLaunchKernelGGL(k_cgd_dots, dim3(gdot), dim3(kBlock), 0, s, v, *defl);
+    if constexpr (HAS_INTR)
+      hipLaunchKernelGGL((k_cgd_project<PB, true>), dim3(gvec), dim3(kBlock), 0, s, v, *defl, it, gdot);
+    else
+      hipLaunchKernelGGL((k_cgd_project<PB, false>), dim3(gvec), dim3(kBlock), 0, s, v, *defl, it, gdot);
+  };
+  if (deflate) {
+    for (int j = 0; j < defl->k; ++j) {  // A W_j: the operator reads z (and its mirrors), writes w
+      if constexpr (HAS_INTR)
+        hipLaunchKernelGGL((k_cgd_set_z<PB, true>), dim3(gvec), dim3(kBlock), 0, s, v, defl->W + (size_t)j * v.n);
+      else
+        hipLaunchKernelGGL((k_cgd_set_z<PB, false>), dim3(gvec), dim3(kBlock), 0, s, v, defl->W + (size_t)j * v.n);
+      apply(0);
+      hipLaunchKernelGGL(k_cgd_copy, dim3(gdot), dim3(kBlock), 0, s, (long)v.n, (const double*)v.w, defl->AW + (size_t)j * v.n);
+    }
+    hipLaunchKernelGGL(k_cgd_gram, dim3(1), dim3(kCgSingleThreads), 0, s, v, *defl);
+    v.b = defl->b2;
+    init();
+    project(-1);
   }
-  if (!joint && !v.single) hipLaunchKernelGGL((k_cg_init<PB, HAS_INTR>), dim3(v.nb_update), dim3(kBlock), 0, s, v);
   CgStatus* h = reinterpret_cast<CgStatus*>(ctx->h_pinned + 400);
   const int chunk = 8;
+  long iters = max_iter;
   for (int it = 0; it < max_iter; ++it) {
     apply(it);
     if (multi) {
@@ -555,15 +765,24 @@ inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& 
       if (v.single) hipLaunchKernelGGL((k_cg_update1<PB>), dim3(1), dim3(kCgSingleThreads), 0, s, v, it);
     }
     if (!joint && !v.single) hipLaunchKernelGGL((k_cg_update<PB, HAS_INTR>), dim3(v.nb_update), dim3(kBlock), 0, s, v, it);
+    if (deflate) project(it);
     if ((it + 1) % chunk == 0 || it == max_iter - 1) {
       GSFM_HIP_CHECK(hipMemcpyAsync(h, v.st, sizeof(CgStatus), hipMemcpyDeviceToHost, s));
       GSFM_HIP_CHECK(hipStreamSynchronize(s));
       GSFM_HIP_CHECK(hipGetLastError());
       ctx->prof.harvest();
-      if (h->done) return h->iters;
+      if (h->done) {
+        iters = h->iters;
+        break;
+      }
     }
   }
-  return max_iter;
+  if (deflate) {
+    hipLaunchKernelGGL(k_cgd_finish, dim3(gdot), dim3(kBlock), 0, s, v, *defl);
+    v.b = b_caller;
+    iters += defl->k;  // the operator applications that formed A W
+  }
+  return iters;
 }
 
 }  // namespace gsfm

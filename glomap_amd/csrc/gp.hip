@@ -399,6 +399,18 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// GSFM_DEFLATE experiment (CgDeflation in cg.hpp): the four gauge modes of global positioning
+// in the unknowns of the reduced system — world translation (dc_n = e_a) and scale (dc_n = c_n).  W[j][3 n + a].
+__global__ void __launch_bounds__(kBlock) k_gp_defl_modes(int N, const double* __restrict__ c, double* __restrict__ W) {
+  const long n3 = 3L * N;
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < n3; o += (long)gridDim.x * blockDim.x) {
+    const int a = (int)(o % 3);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) W[(size_t)j * n3 + o] = a == j ? 1.0 : 0.0;
+    W[(size_t)3 * n3 + o] = c[o];
+  }
+}
+
 // A/B variant of k_gp_phaseA, OFF by default (GSFM_GP_PHASEA_CHAIN=1 selects it; written at the end of round 2 from the
 // ISA of k_gp_phaseA, not yet measured — DESIGN.md section 7 item 4).  Same arithmetic in the same order, so the
 // results are bit-identical; what changes is the chain of DEPENDENT memory trips one wave makes for its tile:
@@ -887,6 +899,7 @@ struct GpWs {
   // calibrated rigs: image tables and the image-space twins of the per-camera arrays
   DevBuf<int> img_frame, foff, fimg, img_sensor, soff, simg;
   DevBuf<double> img_off, ci, cin, hcc_i, gc_i, gred_i, scc_i, zimg, wimg, ximg, zero_i, cz_f, img_rot;
+  DevBuf<double> defl_w, defl_aw, defl_b2, defl_part, defl_small;  // GSFM_DEFLATE experiment (CgDeflation, cg.hpp)
   static void destroy(void* p) { delete static_cast<GpWs*>(p); }
 };
 
@@ -1310,7 +1323,22 @@ class GpSolver final : public LmProblem {
     hipStream_t s = ctx_->stream;
     const double yscale = ctx_->comm.rank == 0 ? 1.0 : 0.0;
     const double tol = opt_.lm.pcg_relative_tolerance;
-    return cg_solve<3, false>(ctx_, cg_, tol, opt_.lm.pcg_max_iterations, [&](int it) {
+    // experiment, off unless GSFM_DEFLATE is set: the gauge modes deflated from the PCG (CgDeflation, cg.hpp).  One rank,
+    // trivial rigs, positions among the unknowns; skipped while the solves are short anyway.
+    static const bool want_defl = std::getenv("GSFM_DEFLATE") != nullptr;
+    CgDeflation defl;
+    if (want_defl && !rig_ && ctx_->comm.world == 1 && g_.opt_c && last_pcg_ > 12) {
+      const size_t n3 = 3 * (size_t)N_;
+      defl.k = 4;
+      double* W = ws->defl_w.ensure(4 * n3);
+      defl.AW = ws->defl_aw.ensure(4 * n3);
+      defl.b2 = ws->defl_b2.ensure(n3);
+      defl.part = ws->defl_part.ensure((size_t)kCgdBlocks * 2 * kCgMaxModes);
+      defl.small = ws->defl_small.ensure(80);
+      hipLaunchKernelGGL(k_gp_defl_modes, dim3(gridN_), dim3(kBlock), 0, s, N_, (const double*)ci_, W);
+      defl.W = W;
+    }
+    const long iters = cg_solve<3, false>(ctx_, cg_, tol, opt_.lm.pcg_max_iterations, [&](int it) {
       if (rig_)  // z of an image = z of its frame: into the per-image vector and the (c | z) gather records
         hipLaunchKernelGGL(k_rig_expand3, dim3(gridNI_), dim3(kBlock), 0, s, rg_, cg_.z, (const double*)nullptr,
                            ws->zimg.get(), ws->cz.get(), 3);
@@ -1341,7 +1369,9 @@ class GpSolver final : public LmProblem {
       if (rig_)
         hipLaunchKernelGGL(k_rig_reduce_w, dim3(1), dim3(kBlock), 0, s, cg_, rg_, yscale, ws->wimg.get(), ws->dcam.get(),
                            gridCam_ + gridMulti_);
-    });
+    }, defl.k ? &defl : nullptr);
+    last_pcg_ = iters;
+    return iters;
   }
 
   gsfm_ctx* ctx_;
@@ -1358,6 +1388,7 @@ class GpSolver final : public LmProblem {
   double *ci_ = nullptr, *cin_ = nullptr;
   long P_ = 0, M_ = 0, m_used_ = 0;
   int gridP_ = 1, gridN_ = 1, gridM_ = 1, gridCam_ = 1, gridMulti_ = 0, gridTile_ = 1, gridTileP_ = 1;
+  long last_pcg_ = 1 << 20;  // iterations of the previous reduced solve (GSFM_DEFLATE experiment: skip short solves)
   double *c_ = nullptr, *cn_ = nullptr, *X_ = nullptr, *Xn_ = nullptr, *s_ = nullptr, *sn_ = nullptr;
 };
 

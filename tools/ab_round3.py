@@ -6,6 +6,11 @@
    launch from the library's own HIP events (DESIGN.md section 7 item 4 expects 105 -> 60-65 us at configs[3]).
 2. BA with the reduced solves stopped at 1e-6 instead of 1e-8: same LM trajectory expected,
    rotations within 1e-6 rad of the 1e-8 run, about a quarter fewer PCG iterations.
+3. GSFM_DEFLATE=1 (CgDeflation in cg.hpp): the similarity gauge deflated from the PCG of GP
+   and BA.  Expected from the CPU oracle (tools/exp_deflation.py): same LM iteration counts, BA linear iterations
+   688 -> ~410 (the count includes the k applications that form A W), GP configs[3] 1254 -> ~760; BA result within
+   1e-7 rad / 1e-4 of the default run, GP within 1e-3 relative after Sim(3) alignment.  THIS CODE HAS NEVER RUN: if a
+   variant fails, the default path is untouched by it (every default kernel was diffed against its pre-change ISA).
 Each variant runs in its own process because the switches are read once per process."""
 import json
 import os
@@ -93,6 +98,18 @@ def main():
     print("BA  pcg tol 1e-8:", r8)
     print("BA  pcg tol 1e-6:", r6)
     print("BA  max rotation difference (rad):", float(ang.max()), " max |t| difference:", float(np.abs(x8[4 * n :] - x6[4 * n :]).max()))
+    from glomap_amd import synthetic
+
+    gd = run(["gp", os.path.join(tmp, "ab_gp_d.npy")], {"GSFM_DEFLATE": "1"})
+    cd = np.load(os.path.join(tmp, "ab_gp_d.npy"))
+    ext = np.linalg.norm(ca - ca.mean(0), axis=1).max()
+    print("GP  GSFM_DEFLATE=1:", gd)
+    print("GP  deflated vs default, max centre distance after Sim(3) / extent:", float(synthetic.center_errors_after_sim3(cd, ca).max() / ext))
+    bd = run(["ba", os.path.join(tmp, "ab_ba_d.npy"), "1e-8"], {"GSFM_DEFLATE": "1"})
+    xd = np.load(os.path.join(tmp, "ab_ba_d.npy"))
+    ang = np.radians(so3.rotation_angle_deg(so3.quat_to_rotmat(x8[: 4 * n].reshape(n, 4)), so3.quat_to_rotmat(xd[: 4 * n].reshape(n, 4))))
+    print("BA  GSFM_DEFLATE=1:", bd)
+    print("BA  deflated vs default: max rotation difference (rad):", float(ang.max()), " max |t| difference:", float(np.abs(x8[4 * n :] - xd[4 * n :]).max()))
 
 
 if __name__ == "__main__":
