@@ -10,6 +10,7 @@ stopping rule, k extra operator applications per solve to form A W.
     python tools/exp_deflation.py ba [num_cams num_pts]     # configs[3]: 10000 1000000
     python tools/exp_deflation.py gp [num_cams num_pts]     # configs[2]:  5000  500000
     python tools/exp_deflation.py spectrum                   # dense eigenvalues of a 400-camera BA / 500-camera GP system
+    python tools/exp_deflation.py variant                    # the algorithm exactly as cg.hpp runs it (numpy, dense 500-camera GP system)
 
 `ba` / `gp` run the C++ oracle at the GPU's PCG tolerance (1e-8) without and with ORC_DEFLATE (two subprocesses; the
 switch is read once per process), print the PCG count of every LM iteration (the k applications for A W are INCLUDED
@@ -119,6 +120,86 @@ def spectrum():
               f"1 % / 50 % / 99 % quantiles {np.quantile(w, 0.01):.2f} / {np.quantile(w, 0.5):.2f} / {np.quantile(w, 0.99):.2f}; largest {w[-1]:.2f}")
 
 
+def variant():
+    """Chronopoulos-Gear PCG as cg.hpp runs it (gamma = r.z and delta = z.Az per iteration, p = z + beta p, s = w + beta s,
+    alpha = gamma / (delta - beta gamma / alpha_prev)) with the k_cgd_* steps: deflated right-hand side b2 = b - AW E^-1 W^T b,
+    start from zero, z <- z - W E^-1 (AW)^T z after every preconditioner application with r.z patched by -(W^T r).(E^-1 (AW)^T z),
+    x += W E^-1 W^T b at the end.  Checks iterations and the error against a direct solve."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import exp_precond as G
+    from glomap_amd import synthetic
+    from oracle import gp as ogp
+
+    N, P = 500, 50_000
+    p = synthetic.make_gp_problem(num_cams=N, num_pts=P, seed=0)
+    opt = ogp.GlobalPositionerOptions()
+    lens = np.diff(p.pt_offset)
+    used = lens >= opt.min_num_view_per_track
+    obs_pt = np.repeat(np.arange(P), lens)
+    keep = used[obs_pt]
+    remap = -np.ones(P, dtype=np.int64)
+    remap[used] = np.arange(int(used.sum()))
+    prob = ogp._GpProblem(N, p.obs_cam[keep].astype(np.int64), remap[obs_pt[keep]], p.obs_dir[keep], p.obs_calibrated[keep], opt, int(used.sum()))
+    rng = np.random.default_rng(0)
+    x = np.concatenate([100 * rng.uniform(-1, 1, 3 * N), 100 * rng.uniform(-1, 1, 3 * prob.P), np.ones(prob.M)])
+    S, b = G.schur_system(prob, x, 1e-6)
+    A = S.toarray()
+    n = A.shape[0]
+    Minv = np.zeros_like(A)
+    for c in range(N):
+        sl = slice(3 * c, 3 * c + 3)
+        Minv[sl, sl] = np.linalg.inv(A[sl, sl])
+    W = np.zeros((4, n))
+    for a in range(3):
+        W[a, a::3] = 1.0
+    W[3] = x[: 3 * N]
+
+    def cg_gear(W, tol=1e-8, max_it=500):
+        k = 0 if W is None else W.shape[0]
+        y0 = None
+        b2 = b
+        if k:
+            AW = (A @ W.T).T
+            E = W @ AW.T
+            Einv = np.linalg.inv(0.5 * (E + E.T))
+            y0 = Einv @ (W @ b)
+            b2 = b - AW.T @ y0
+
+        def project(z, gamma, r):
+            y = Einv @ (AW @ z)
+            return z - W.T @ y, gamma - y @ (W @ r)
+
+        xx, r, pv, sv = np.zeros(n), b2.copy(), np.zeros(n), np.zeros(n)
+        z = Minv @ r
+        gamma, rr = r @ z, r @ r
+        if k:
+            z, gamma = project(z, gamma, r)
+        bb, pg, pa = rr, 0.0, 0.0
+        for it in range(max_it):
+            if rr <= tol * tol * bb:  # cg_converged at the top of the apply
+                break
+            w = A @ z
+            delta = z @ w
+            beta = gamma / pg if it else 0.0
+            alpha = gamma / (delta - beta * gamma / pa if it else delta)
+            pv, sv = z + beta * pv, w + beta * sv
+            xx, r = xx + alpha * pv, r - alpha * sv
+            rr, pg, pa = r @ r, gamma, alpha
+            z = Minv @ r
+            gamma = r @ z
+            if k:
+                z, gamma = project(z, gamma, r)
+        return (xx + W.T @ y0 if k else xx), it
+
+    xs = np.linalg.solve(A, b)
+    for Wk, name in ((None, "plain"), (W, "deflated")):
+        xr, it = cg_gear(Wk)
+        print(f"{name:9s}: {it:3d} iterations, |A x - b| / |b| = {np.linalg.norm(A @ xr - b) / np.linalg.norm(b):.1e}, "
+              f"|x - x*| / |x*| = {np.linalg.norm(xr - xs) / np.linalg.norm(xs):.1e}")
+
+
 def main():
     import numpy as np
 
@@ -127,6 +208,8 @@ def main():
     stage = sys.argv[1] if len(sys.argv) > 1 else "ba"
     if stage == "spectrum":
         return spectrum()
+    if stage == "variant":
+        return variant()
     N = int(sys.argv[2]) if len(sys.argv) > 2 else (10_000 if stage == "ba" else 5_000)
     P = int(sys.argv[3]) if len(sys.argv) > 3 else (1_000_000 if stage == "ba" else 500_000)
     res = {}
