@@ -2122,11 +2122,11 @@ class BaSolver final : public LmProblem {
     const double yscale = ctx_->comm.rank == 0 ? 1.0 : 0.0;
     const double tol = opt_.lm.pcg_relative_tolerance;
     // experiment, off unless GSFM_DEFLATE is set: the similarity gauge deflated from the PCG (CgDeflation, cg.hpp).  One
-    // rank, trivial rigs, joint pose + intrinsics blocks, translations among the unknowns; skipped while the solves are
-    // short anyway (strongly damped LM steps).
+    // rank, trivial rigs, translations among the unknowns; skipped while the solves are short anyway (strongly damped
+    // LM steps).
     static const bool want_defl = std::getenv("GSFM_DEFLATE") != nullptr;
     CgDeflation defl;
-    if (want_defl && !rig_ && joint_ && ctx_->comm.world == 1 && g_.opt_trn && last_pcg_ > 20) {
+    if (want_defl && !rig_ && ctx_->comm.world == 1 && g_.opt_trn && last_pcg_ > 20) {
       const int with_rot = g_.opt_rot ? 1 : 0;
       defl.k = with_rot ? 7 : 4;
       const size_t n = (size_t)n_;

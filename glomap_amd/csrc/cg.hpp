@@ -724,21 +724,21 @@ inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& 
     if (!joint && !v.single) hipLaunchKernelGGL((k_cg_init<PB, HAS_INTR>), dim3(v.nb_update), dim3(kBlock), 0, s, v);
   };
   init();
-  // experiment (see CgDeflation): only the multi-block vector kernels on one rank, and not the non-joint BA layout
-  const bool deflate = defl != nullptr && defl->k > 0 && !multi && !v.single && (joint || !HAS_INTR);
+  // experiment (see CgDeflation): only the multi-block vector kernels on one rank
+  const bool deflate = defl != nullptr && defl->k > 0 && !multi && !v.single;
   const double* b_caller = v.b;
   const int gdot = std::min(kCgdBlocks, grid_for((size_t)v.n, kBlock));
   const int gvec = std::min(256, grid_for((size_t)std::max((long)v.n, (long)v.N * 16), kBlock));
   auto project = [&](int it) {
     hipLaunchKernelGGL(k_cgd_dots, dim3(gdot), dim3(kBlock), 0, s, v, *defl);
-    if constexpr (HAS_INTR)
+    if (joint)
       hipLaunchKernelGGL((k_cgd_project<PB, true>), dim3(gvec), dim3(kBlock), 0, s, v, *defl, it, gdot);
     else
       hipLaunchKernelGGL((k_cgd_project<PB, false>), dim3(gvec), dim3(kBlock), 0, s, v, *defl, it, gdot);
   };
   if (deflate) {
     for (int j = 0; j < defl->k; ++j) {  // A W_j: the operator reads z (and its mirrors), writes w
-      if constexpr (HAS_INTR)
+      if (joint)
         hipLaunchKernelGGL((k_cgd_set_z<PB, true>), dim3(gvec), dim3(kBlock), 0, s, v, defl->W + (size_t)j * v.n);
       else
         hipLaunchKernelGGL((k_cgd_set_z<PB, false>), dim3(gvec), dim3(kBlock), 0, s, v, defl->W + (size_t)j * v.n);

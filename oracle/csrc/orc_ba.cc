@@ -529,6 +529,13 @@ struct Ba : LmProblem {
         if (W.size() > 6)
           for (int i = 0; i < 3; ++i) W[6][6 * n + 3 + i] = ft * t[3 * n + i];
       }
+      // ORC_DEFLATE=9: a few intrinsics blocks shared by many images are a dense border of the reduced system; their
+      // unit vectors as modes treat that border exactly (what a Schur complement on the border would do)
+      if (deflate == 9 && nfree <= 8)
+        for (i64 c = 6 * (N + S); c < nred; ++c) {
+          W.emplace_back(nred, 0.0);
+          W.back()[c] = 1.0;
+        }
     }
     *lin = solve_reduced(
         nred, rhs, dy, pcg_tol, pcg_max, [&](const std::vector<double>& z, std::vector<double>& o) { apply(z, o); },
