@@ -2126,7 +2126,7 @@ class BaSolver final : public LmProblem {
     // LM steps).
     static const bool want_defl = std::getenv("GSFM_DEFLATE") != nullptr;
     CgDeflation defl;
-    if (want_defl && !rig_ && ctx_->comm.world == 1 && g_.opt_trn && last_pcg_ > 20) {
+    if (want_defl && !rig_ && ctx_->comm.world == 1 && g_.opt_trn && defl_on_) {
       const int with_rot = g_.opt_rot ? 1 : 0;
       defl.k = with_rot ? 7 : 4;
       const size_t n = (size_t)n_;
@@ -2179,7 +2179,8 @@ class BaSolver final : public LmProblem {
         hipLaunchKernelGGL(k_ba_rig_reduce_w, dim3(1), dim3(kBlock), 0, s, cg_, rg_, yscale, ws->wimg.get(), ws->dvec.get(),
                            gridCam_ + gridK_ + gridMulti_);
     }, defl.k ? &defl : nullptr);
-    last_pcg_ = iters;
+    // deflation pays while a plain solve needs more than ~3 k iterations (iters includes the k applications for A W)
+    defl_on_ = defl.k ? iters - defl.k > defl.k : iters > 3 * 7;
     return iters;
   }
 
@@ -2195,7 +2196,7 @@ class BaSolver final : public LmProblem {
   RigDev rg_{};
   double *Rk_ = nullptr, *Rkn_ = nullptr, *tk_ = nullptr, *tkn_ = nullptr;  // poses the sweeps see (frames or images)
   bool small_groups_ = false, joint_ = false;
-  long last_pcg_ = 1 << 20;  // iterations of the previous reduced solve (GSFM_DEFLATE experiment: skip short solves)
+  bool defl_on_ = true;  // GSFM_DEFLATE experiment: deflate the next reduced solve (short solves run plain)
   long P_ = 0, M_ = 0, Mp_ = 0, m_used_ = 0;
   int gridP_ = 1, gridN_ = 1, gridM_ = 1, gridCam_ = 1, gridMulti_ = 0, gridTile_ = 1, gridTileP_ = 1, gridK_ = 1;
   double *q_ = nullptr, *qn_ = nullptr, *t_ = nullptr, *tn_ = nullptr, *R_ = nullptr, *Rn_ = nullptr, *X_ = nullptr,

@@ -1327,7 +1327,7 @@ class GpSolver final : public LmProblem {
     // trivial rigs, positions among the unknowns; skipped while the solves are short anyway.
     static const bool want_defl = std::getenv("GSFM_DEFLATE") != nullptr;
     CgDeflation defl;
-    if (want_defl && !rig_ && ctx_->comm.world == 1 && g_.opt_c && last_pcg_ > 12) {
+    if (want_defl && !rig_ && ctx_->comm.world == 1 && g_.opt_c && defl_on_) {
       const size_t n3 = 3 * (size_t)N_;
       defl.k = 4;
       double* W = ws->defl_w.ensure(4 * n3);
@@ -1370,7 +1370,8 @@ class GpSolver final : public LmProblem {
         hipLaunchKernelGGL(k_rig_reduce_w, dim3(1), dim3(kBlock), 0, s, cg_, rg_, yscale, ws->wimg.get(), ws->dcam.get(),
                            gridCam_ + gridMulti_);
     }, defl.k ? &defl : nullptr);
-    last_pcg_ = iters;
+    // deflation pays while a plain solve needs more than ~3 k iterations (iters includes the k applications for A W)
+    defl_on_ = defl.k ? iters - defl.k > defl.k : iters > 3 * 4;
     return iters;
   }
 
@@ -1388,7 +1389,7 @@ class GpSolver final : public LmProblem {
   double *ci_ = nullptr, *cin_ = nullptr;
   long P_ = 0, M_ = 0, m_used_ = 0;
   int gridP_ = 1, gridN_ = 1, gridM_ = 1, gridCam_ = 1, gridMulti_ = 0, gridTile_ = 1, gridTileP_ = 1;
-  long last_pcg_ = 1 << 20;  // iterations of the previous reduced solve (GSFM_DEFLATE experiment: skip short solves)
+  bool defl_on_ = true;  // GSFM_DEFLATE experiment: deflate the next reduced solve (short solves run plain)
   double *c_ = nullptr, *cn_ = nullptr, *X_ = nullptr, *Xn_ = nullptr, *s_ = nullptr, *sn_ = nullptr;
 };
 

@@ -184,6 +184,7 @@ struct Ba : LmProblem {
   std::vector<double> dred, Hinv /*[P][9]*/, tp, ak /*[M][2]*/;
   std::vector<double> dy_prev;  // ORC_WARM_START experiment: the reduced step of the last solve ...
   bool same_lin = false;        // ... and whether it belongs to the current linearisation
+  bool defl_on = true;          // ORC_DEFLATE experiment: deflate the next reduced solve
   std::vector<double> Mblk;           // block-Jacobi: per camera 14x14 (joint) ...
   std::vector<double> Miblk;          // ... per shared intrinsics block 8x8
 
@@ -515,7 +516,7 @@ struct Ba : LmProblem {
     // its component divides rounding noise by the damping and sends the iterate along the gauge.
     static const int deflate = std::getenv("ORC_DEFLATE") ? std::atoi(std::getenv("ORC_DEFLATE")) : 0;
     std::vector<std::vector<double>> W;
-    if (deflate && S == 0) {
+    if (deflate && S == 0 && defl_on) {  // like ba.hip: short (strongly damped) solves run undeflated
       W.assign(deflate == 6 ? 6 : 7, std::vector<double>(nred, 0.0));
       for (i64 n = 0; n < N; ++n) {
         double R[9];
@@ -541,6 +542,8 @@ struct Ba : LmProblem {
         nred, rhs, dy, pcg_tol, pcg_max, [&](const std::vector<double>& z, std::vector<double>& o) { apply(z, o); },
         [&](const std::vector<double>& r, std::vector<double>& z) { precond(r, z); }, relres, (double)M, guess,
         W.empty() ? nullptr : &W);
+    // deflation pays while a plain solve needs more than ~3 k iterations
+    defl_on = W.empty() ? *lin > 3 * 7 : *lin - (i64)W.size() > (i64)W.size();
     if (warm) {
       dy_prev = dy;
       same_lin = true;

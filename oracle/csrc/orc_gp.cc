@@ -66,6 +66,7 @@ struct Gp : LmProblem {
   std::vector<int32_t> sobs, sown;
   OwnerLists bysens;
   OwnerLists bycam;
+  bool defl_on = true;  // ORC_DEFLATE experiment: deflate the next reduced solve
   Huber loss_cal, loss_unc;
   double mc, mx, ms;  // 1 / 0: optimize_positions / points / scales
   double lm_lo, lm_hi;
@@ -427,7 +428,7 @@ struct Gp : LmProblem {
     // constant, gp.cc:437-439), so the PCG drops them again when W^T A W cannot be inverted.
     static const bool deflate = std::getenv("ORC_DEFLATE") != nullptr;
     std::vector<std::vector<double>> W;
-    if (deflate && S == 0 && mc != 0.0) {
+    if (deflate && S == 0 && mc != 0.0 && defl_on) {  // like gp.hip: short solves run undeflated
       W.assign(4, std::vector<double>(3 * N, 0.0));
       for (i64 n = 0; n < N; ++n)
         for (int a = 0; a < 3; ++a) {
@@ -445,6 +446,7 @@ struct Gp : LmProblem {
           }
         },
         relres, (double)M, nullptr, W.empty() ? nullptr : &W);
+    defl_on = W.empty() ? *lin > 3 * 4 : *lin - (i64)W.size() > (i64)W.size();
     // back-substitution: dX_p = Hpp^-1 (-gX' + mc mx sum Q dc) ; ds_k = beta (d.(r + s (mc dc - mx dX)))
     std::vector<double> dX(3 * P);
     apply_points_only(dc);  // tp = mc mx Hpp^-1 sum Q dc
