@@ -271,6 +271,8 @@ i64 pcg(i64 n, const std::vector<double>& b, std::vector<double>& x, double tol,
     const double pw = vdot(p, w);
     if (!(pw > 0.0) || !std::isfinite(pw)) break;
     const double alpha = rz / pw;
+    static const bool cg_trace = std::getenv("ORC_CG_TRACE") != nullptr;  // Lanczos coefficients for Ritz-value estimates
+    if (cg_trace) fprintf(stderr, "[orc cg] it %lld alpha %.17g rz %.17g\n", (long long)it, alpha, rz);
     double *px = x.data(), *pr = r.data();
     const double *pp = p.data(), *pwv = w.data();
 #pragma omp parallel for schedule(static)
