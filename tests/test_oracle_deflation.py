@@ -1,0 +1,50 @@
+"""The oracle's deflated PCG (ORC_DEFLATE, oracle/csrc/orc_lm.hpp) — the executable specification of the CgDeflation
+experiment in glomap_amd/csrc/cg.hpp: same system, same tolerance, fewer operator
+applications, same solution.  The switch is read once per process, so the two runs are subprocesses."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from glomap_amd import synthetic
+from oracle import cpu, gp as ogp
+p = synthetic.make_gp_problem(num_cams=700, num_pts=30000, seed=3)
+ok, c, X, s = cpu.gp_solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated, p.cam_center, p.pt_xyz,
+                           ogp.GlobalPositionerOptions(), pcg_tol=1e-8, threads=2)
+np.save(sys.argv[1], c)
+print("RESULT " + json.dumps(dict(ok=bool(ok), lm=int(s.iterations), pcg=int(s.linear_iterations), cost=float(s.final_cost))))
+"""
+
+
+def _run(tmp_path, name, deflate):
+    env = dict(os.environ)
+    env.pop("ORC_DEFLATE", None)
+    if deflate:
+        env["ORC_DEFLATE"] = "1"
+    out = str(tmp_path / name)
+    p = subprocess.run([sys.executable, "-c", WORKER.format(root=ROOT), out], env=env, capture_output=True, text=True, timeout=600)
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert line, p.stdout[-1000:] + p.stderr[-2000:]
+    return json.loads(line[0][7:]), np.load(out)
+
+
+def test_gauge_deflation_keeps_the_solution_and_saves_operator_applications(tmp_path):
+    from glomap_amd import synthetic
+
+    plain, c0 = _run(tmp_path, "plain.npy", False)
+    defl, c1 = _run(tmp_path, "defl.npy", True)
+    assert plain["ok"] and defl["ok"]
+    assert abs(plain["lm"] - defl["lm"]) <= 2
+    assert abs(plain["cost"] - defl["cost"]) <= 1e-3 * plain["cost"]
+    # the count of the deflated run includes the four applications per solve that form A W
+    assert defl["pcg"] < 0.85 * plain["pcg"], (plain, defl)
+    extent = np.linalg.norm(c0 - c0.mean(0), axis=1).max()
+    assert synthetic.center_errors_after_sim3(c1, c0).max() / extent < 1e-3
