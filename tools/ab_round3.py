@@ -8,7 +8,7 @@
    rotations within 1e-6 rad of the 1e-8 run, about a quarter fewer PCG iterations.
 3. GSFM_DEFLATE=1 (CgDeflation in cg.hpp): the similarity gauge deflated from the PCG of GP
    and BA.  Expected from the CPU oracle (tools/exp_deflation.py): same LM iteration counts, BA linear iterations
-   688 -> ~410 (the count includes the k applications that form A W), GP configs[3] 1254 -> ~760; BA result within
+   688 -> ~330 (the count includes the k applications that form A W), GP at 10k cameras 1254 -> ~880; BA result within
    1e-7 rad / 1e-4 of the default run, GP within 1e-3 relative after Sim(3) alignment.  THIS CODE HAS NEVER RUN: if a
    variant fails, the default path is untouched by it (every default kernel was diffed against its pre-change ISA).
 Each variant runs in its own process because the switches are read once per process."""
