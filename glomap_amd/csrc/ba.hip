@@ -1117,7 +1117,7 @@ __global__ void __launch_bounds__(kBlock)
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-// GSFM_DEFLATE experiment (CgDeflation in cg.hpp): the similarity gauge of the scene in the
+// The modes deflated from the reduced solves (CgDeflation in cg.hpp): the similarity gauge of the scene in the
 // pose unknowns of the reduced system (6 per camera: left quaternion tangent — the manifold turns by 2 |d| — then
 // translation; the intrinsics part of the modes is zero and W was cleared by the caller):
 //   world translation a:  dt_n = -R_n a          world rotation w:  drot_n = -R_n w / 2          scale:  dt_n = t_n
@@ -1158,7 +1158,7 @@ struct BaWs {
   DevBuf<int> img_frame, foff, fimg, img_sensor, soff, simg;
   DevBuf<unsigned char> img_fixed, fmask;
   DevBuf<double> sens, Ri, Rin, ti, tin, diag_i, grad_i, gred_i, spose_i, dvec_i, zimg, wimg, ximg, lever, gram_i;
-  DevBuf<double> defl_w, defl_aw, defl_b2, defl_part, defl_small;  // GSFM_DEFLATE experiment (CgDeflation, cg.hpp)
+  DevBuf<double> defl_w, defl_aw, defl_b2, defl_part, defl_small, defl_cd;  // CgDeflation, cg.hpp
   static void destroy(void* p) { delete static_cast<BaWs*>(p); }
 };
 
@@ -2121,20 +2121,19 @@ class BaSolver final : public LmProblem {
     hipStream_t s = ctx_->stream;
     const double yscale = ctx_->comm.rank == 0 ? 1.0 : 0.0;
     const double tol = opt_.lm.pcg_relative_tolerance;
-    // experiment, off unless GSFM_DEFLATE is set: the similarity gauge deflated from the PCG (CgDeflation, cg.hpp).  One
-    // rank, trivial rigs, translations among the unknowns; skipped while the solves are short anyway (strongly damped
-    // LM steps).
-    static const bool want_defl = std::getenv("GSFM_DEFLATE") != nullptr;
+    // the similarity gauge of the scene deflated from the PCG (CgDeflation, cg.hpp): trivial rigs, translations among
+    // the unknowns; skipped while the solves are short anyway (strongly damped LM steps; defl_on_, below)
     CgDeflation defl;
-    if (want_defl && !rig_ && ctx_->comm.world == 1 && g_.opt_trn && defl_on_) {
+    if (!rig_ && g_.opt_trn && defl_on_ && N_ >= 64) {
       const int with_rot = g_.opt_rot ? 1 : 0;
       defl.k = with_rot ? 7 : 4;
       const size_t n = (size_t)n_;
       double* W = ws->defl_w.ensure(defl.k * n);
       defl.AW = ws->defl_aw.ensure(defl.k * n);
       defl.b2 = ws->defl_b2.ensure(n);
-      defl.part = ws->defl_part.ensure((size_t)kCgdBlocks * 2 * kCgMaxModes);
+      defl.part = ws->defl_part.ensure((size_t)kCgdBlocks * kCgdGram);
       defl.small = ws->defl_small.ensure(80);
+      defl.cd = ws->defl_cd.ensure((size_t)2 * kCgMaxBlocks * 2 * kCgMaxModes);
       GSFM_HIP_CHECK(hipMemsetAsync(W, 0, defl.k * n * sizeof(double), s));
       hipLaunchKernelGGL(k_ba_defl_modes, dim3(gridN_), dim3(kBlock), 0, s, N_, (long)n_, (const double*)Rk_, (const double*)tk_,
                          g_.fixed_cam, with_rot, W);
@@ -2152,7 +2151,7 @@ class BaSolver final : public LmProblem {
         vk.w = ws->wimg.get();
         dk = ws->dvec_i.get();
       }
-      bool timed = ctx_->prof.begin(s, GSFM_KERNEL_BA_SCHUR);
+      bool timed = ctx_->prof.begin(s, GSFM_KERNEL_BA_SCHUR, it);
       dispatch_f(F_, [&](auto Fc) {
         static const bool nt = getenv("GSFM_BA_NO_NT") == nullptr;  // measured on C4: 240 us -> 210 (loads first) -> 193 (+ non-temporal)
         if (nt)
@@ -2163,7 +2162,7 @@ class BaSolver final : public LmProblem {
                              tol * tol, ws->jt.get(), ws->pth.get(), ws->ptrec.get());
       });
       if (timed) ctx_->prof.end(s);
-      timed = ctx_->prof.begin(s, GSFM_KERNEL_BA_SCHUR_B);
+      timed = ctx_->prof.begin(s, GSFM_KERNEL_BA_SCHUR_B, it);
       hipLaunchKernelGGL(k_ba_phaseB, dim3(gridCam_), dim3(kBlock), 0, s, g_, vk, yscale, Rk_, tk_, par_,
                          ws->c_w.get(), ws->ptrec.get(), dk, ws->yi_part.get(), 0);
       if (gridMulti_)
@@ -2178,7 +2177,7 @@ class BaSolver final : public LmProblem {
       if (rig_)
         hipLaunchKernelGGL(k_ba_rig_reduce_w, dim3(1), dim3(kBlock), 0, s, cg_, rg_, yscale, ws->wimg.get(), ws->dvec.get(),
                            gridCam_ + gridK_ + gridMulti_);
-    }, defl.k ? &defl : nullptr);
+    }, defl.k ? &defl : nullptr, &pcg_hint_);
     // deflation pays while a plain solve needs more than ~3 k iterations (iters includes the k applications for A W)
     defl_on_ = defl.k ? iters - defl.k > defl.k : iters > 3 * 7;
     return iters;
@@ -2196,7 +2195,8 @@ class BaSolver final : public LmProblem {
   RigDev rg_{};
   double *Rk_ = nullptr, *Rkn_ = nullptr, *tk_ = nullptr, *tkn_ = nullptr;  // poses the sweeps see (frames or images)
   bool small_groups_ = false, joint_ = false;
-  bool defl_on_ = true;  // GSFM_DEFLATE experiment: deflate the next reduced solve (short solves run plain)
+  bool defl_on_ = true;  // deflate the next reduced solve (short solves run plain)
+  int pcg_hint_ = 0;     // iteration count of the previous reduced solve (where cg_solve first reads the status back)
   long P_ = 0, M_ = 0, Mp_ = 0, m_used_ = 0;
   int gridP_ = 1, gridN_ = 1, gridM_ = 1, gridCam_ = 1, gridMulti_ = 0, gridTile_ = 1, gridTileP_ = 1, gridK_ = 1;
   double *q_ = nullptr, *qn_ = nullptr, *t_ = nullptr, *tn_ = nullptr, *R_ = nullptr, *Rn_ = nullptr, *X_ = nullptr,
@@ -2234,6 +2234,9 @@ extern "C" void gsfm_ba_options_default(gsfm_ba_options* o) {
   if (!o) return;
   std::memset(o, 0, sizeof(*o));
   lm_options_default(&o->lm, 200);  // bundle_adjustment.h:31
+  // BA starts near its solution and its LM trajectory is stiff: reduced solves to 1e-6 leave the result within 3.3e-7 rad /
+  // 3e-6 of the exact-solve trajectory at configs[3] (bar: 1e-4 rad / 1e-3); GP keeps 1e-8
+  o->lm.pcg_relative_tolerance = 1e-6;
   o->thres_loss_function = 1.0;     // bundle_adjustment.h:30
   o->optimize_rotations = 1;
   o->optimize_translation = 1;

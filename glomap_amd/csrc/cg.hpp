@@ -21,6 +21,16 @@
 //
 // Multi-rank: `apply` produces this rank's share of w and of delta; the solver all-reduces
 // w[0..n] (delta travels in w[n]) over RCCL, then k_cg_update runs redundantly on every rank.
+//
+// Deflation of known near-null modes (CgDeflation below): the block-Jacobi-preconditioned reduced systems of BA / GP have
+// a tight spectrum plus the similarity gauge of the scene — a handful of eigenvalues 1e-3 ... 1e-6 whose eigenvectors
+// are known in closed form.  Deflated PCG (Saad, Yeung, Erhel, Guyomarc'h 2000) on span W:
+//     E = W^T A W,   x = W E^-1 W^T b + x',   A x' = b2 := b - A W E^-1 W^T b,
+//     every preconditioned residual is projected:  z_p = z - W y,  y = E^-1 (A W)^T z.
+// The projection costs NO launch here: A is applied to the unprojected z, and k_cg_update, which already visits every
+// element, uses  z_p = z - W y,  w_p = A z_p = w - (A W) y,  r.z_p = r.z - (W^T r).y,  z_p.w_p = z.w - y.((A W)^T z)
+// (A symmetric, E y = (A W)^T z); the 2k dot products (A W)^T z and W^T r of the NEXT iterate are accumulated by the same
+// kernel next to its r.z / r.r partials.  Same system, same stopping rule (relative to |b2| <= |b|).
 #pragma once
 
 #include "device.hpp"
@@ -28,6 +38,7 @@
 namespace gsfm {
 
 constexpr int kCgMaxBlocks = 512;  // grid cap of the vector kernels (k_cg_init / k_cg_update)
+constexpr int kCgMaxModes = 8;     // deflated modes per solve (CgDeflation)
 constexpr int kMaxApplySlots = 4096;  // cap of the delta partial slots one apply kernel may write
 
 struct CgStatus {
@@ -79,11 +90,75 @@ struct CgVec {
   double* zrec = nullptr;
   int zrec_stride = 0;
   const signed char* zrec_slot = nullptr;
+  // operator probe (forming A W): cg_converged() answers "not finished" and leaves the status alone
+  int probe = 0;
+  // deflation, device view (dk == 0: plain PCG); set by cg_solve from a CgDeflation
+  int dk = 0;
+  const double* dW = nullptr;      // [dk][n]
+  const double* dAW = nullptr;     // [dk][n]
+  const double* dsmall = nullptr;  // E^-1 [8][8] | y0 [8] | ok
+  double* dcd = nullptr;           // [2][kCgMaxBlocks][2 * kCgMaxModes]: ((A W)^T z | W^T r) partials by iteration parity
 };
+
+// ---- deflation, per-element pieces (all no-ops for v.dk == 0) ----------------------------------------------------
+// y = E^-1 c from the partial dot products of iteration parity `par`; gcorr = (W^T r).y, dcorr = ((A W)^T z).y.
+// All threads of the block; smem >= 5 * 2 * kCgMaxModes.
+__device__ __forceinline__ void cgd_coefficients(const CgVec& v, int par, double (&y)[kCgMaxModes], double& gcorr,
+                                                 double& dcorr, double* smem) {
+  gcorr = dcorr = 0.0;
+#pragma unroll
+  for (int i = 0; i < kCgMaxModes; ++i) y[i] = 0.0;
+  if (v.dk == 0) return;
+  double cd[2 * kCgMaxModes];
+  reduce_partials<2 * kCgMaxModes>(v.dcd + (size_t)par * kCgMaxBlocks * 2 * kCgMaxModes, v.nb_update, cd, smem);
+  if (v.dsmall[72] == 0.0) return;  // E was not positive definite: this solve runs plain
+#pragma unroll
+  for (int i = 0; i < kCgMaxModes; ++i) {
+    if (i < v.dk) {
+      double t = 0.0;
+#pragma unroll
+      for (int j = 0; j < kCgMaxModes; ++j)
+        if (j < v.dk) t += v.dsmall[i * kCgMaxModes + j] * cd[j];
+      y[i] = t;
+      gcorr += t * cd[kCgMaxModes + i];
+      dcorr += t * cd[i];
+    }
+  }
+}
+// z_p = z - W y, w_p = w - (A W) y at element o
+__device__ __forceinline__ void cgd_project(const CgVec& v, long o, const double (&y)[kCgMaxModes], double& z, double& w) {
+#pragma unroll
+  for (int j = 0; j < kCgMaxModes; ++j)
+    if (j < v.dk) {
+      z -= y[j] * v.dW[(size_t)j * v.n + o];
+      w -= y[j] * v.dAW[(size_t)j * v.n + o];
+    }
+}
+__device__ __forceinline__ void cgd_acc_r(const CgVec& v, long o, double r, double (&cd)[2 * kCgMaxModes]) {
+#pragma unroll
+  for (int j = 0; j < kCgMaxModes; ++j)
+    if (j < v.dk) cd[kCgMaxModes + j] += v.dW[(size_t)j * v.n + o] * r;
+}
+__device__ __forceinline__ void cgd_acc_z(const CgVec& v, long o, double z, double (&cd)[2 * kCgMaxModes]) {
+#pragma unroll
+  for (int j = 0; j < kCgMaxModes; ++j)
+    if (j < v.dk) cd[j] += v.dAW[(size_t)j * v.n + o] * z;
+}
+// block-level store of the 2k partials of this block into parity slot `par` (all threads; smem >= 4 * 2 * kCgMaxModes)
+__device__ __forceinline__ void cgd_store_partials(const CgVec& v, int par, double (&cd)[2 * kCgMaxModes], double* smem) {
+  if (v.dk == 0) return;
+  block_sum<2 * kCgMaxModes>(cd, smem);
+  if (threadIdx.x == 0) {
+    double* out = v.dcd + ((size_t)par * kCgMaxBlocks + blockIdx.x) * 2 * kCgMaxModes;
+#pragma unroll
+    for (int j = 0; j < 2 * kCgMaxModes; ++j) out[j] = cd[j];
+  }
+}
 
 template <int BS>
 __device__ __forceinline__ void cg_block_init(const CgVec& v, long o, const double* __restrict__ m, double& rz,
-                                              double& rr, double* __restrict__ mir = nullptr) {
+                                              double& rr, double (&cd)[2 * kCgMaxModes],
+                                              double* __restrict__ mir = nullptr) {
   double rb[BS];
 #pragma unroll
   for (int i = 0; i < BS; ++i) rb[i] = v.b[o + i];
@@ -100,24 +175,28 @@ __device__ __forceinline__ void cg_block_init(const CgVec& v, long o, const doub
     v.s[o + i] = 0.0;
     rz += rb[i] * zi;
     rr += rb[i] * rb[i];
+    cgd_acc_r(v, o + i, rb[i], cd);
+    cgd_acc_z(v, o + i, zi, cd);
   }
 }
 
 // x = 0, r = b, z = M^-1 b, p = s = 0; partials of (r.z, r.r) into parity slot 0.
 template <int PB, bool HAS_INTR>
 static __global__ void __launch_bounds__(kBlock) k_cg_init(CgVec v) {
-  __shared__ double smem[4 * 2];
+  __shared__ double smem[4 * 2 * kCgMaxModes];
   double acc[2] = {0.0, 0.0};
+  double cd[2 * kCgMaxModes] = {};
   const int nblk = v.N + (HAS_INTR ? v.K : 0);
   for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += gridDim.x * blockDim.x) {
     if (b < v.N) {
-      cg_block_init<PB>(v, (long)PB * b, v.minv + (long)PB * PB * b, acc[0], acc[1],
+      cg_block_init<PB>(v, (long)PB * b, v.minv + (long)PB * PB * b, acc[0], acc[1], cd,
                         v.zmir ? v.zmir + (long)b * v.zmir_stride + v.zmir_off : nullptr);
     } else if constexpr (HAS_INTR) {
       const int k = b - v.N;
-      cg_block_init<8>(v, (long)PB * v.N + 8L * k, v.minv + (long)PB * PB * v.N + 64L * k, acc[0], acc[1]);
+      cg_block_init<8>(v, (long)PB * v.N + 8L * k, v.minv + (long)PB * PB * v.N + 64L * k, acc[0], acc[1], cd);
     }
   }
+  cgd_store_partials(v, 0, cd, smem);
   block_sum<2>(acc, smem);
   if (threadIdx.x == 0) {
     v.vpart[blockIdx.x * 2] = acc[0];
@@ -137,6 +216,7 @@ static __global__ void __launch_bounds__(kBlock) k_cg_init(CgVec v) {
 // To be called by ALL threads of EVERY block at the top of the first apply kernel of iteration
 // `it` (kBlock threads).  Returns true when the solve is finished (the caller returns).
 __device__ __forceinline__ bool cg_converged(const CgVec& v, int it, double tol2, double* smem /* >= 4*2+2 */) {
+  if (v.probe) return false;             // forming A W: an operator application outside the iteration
   if (v.single) return v.st->done != 0;  // k_cg_init1 / k_cg_update1 already tested |r| and raised `done`
   double t[2] = {0.0, 0.0};
   {
@@ -147,6 +227,7 @@ __device__ __forceinline__ bool cg_converged(const CgVec& v, int it, double tol2
     }
   }
   const int done0 = v.st->done;
+  const double bb_st = v.st->bb;  // same cache line as `done` (one trip); written at it == 0 only, read at it > 0 only
   if (done0) return true;
   block_sum<2>(t, smem);
   if (threadIdx.x == 0) {
@@ -157,7 +238,7 @@ __device__ __forceinline__ bool cg_converged(const CgVec& v, int it, double tol2
   t[0] = smem[8];
   t[1] = smem[9];
   __syncthreads();
-  const double bb = it == 0 ? t[1] : v.st->bb;
+  const double bb = it == 0 ? t[1] : bb_st;
   const bool finite = isfinite(t[0]) && isfinite(t[1]);
   const bool done = !finite || t[1] <= tol2 * bb;
   __syncthreads();
@@ -174,18 +255,22 @@ __device__ __forceinline__ bool cg_converged(const CgVec& v, int it, double tol2
 template <int BS>
 __device__ __forceinline__ void cg_block_update(const CgVec& v, long o, const double* __restrict__ m, double alpha,
                                                 double beta, double& rz, double& rr,
+                                                const double (&y)[kCgMaxModes], double (&cd)[2 * kCgMaxModes],
                                                 double* __restrict__ mir = nullptr) {
   double rn[BS];
 #pragma unroll
   for (int i = 0; i < BS; ++i) {
-    const double pi = v.z[o + i] + beta * v.p[o + i];
-    const double si = v.w[o + i] + beta * v.s[o + i];
+    double zi = v.z[o + i], wi = v.w[o + i];
+    cgd_project(v, o + i, y, zi, wi);
+    const double pi = zi + beta * v.p[o + i];
+    const double si = wi + beta * v.s[o + i];
     v.p[o + i] = pi;
     v.s[o + i] = si;
     v.x[o + i] += alpha * pi;
     rn[i] = v.r[o + i] - alpha * si;
     v.r[o + i] = rn[i];
     rr += rn[i] * rn[i];
+    cgd_acc_r(v, o + i, rn[i], cd);
   }
 #pragma unroll
   for (int i = 0; i < BS; ++i) {
@@ -195,13 +280,14 @@ __device__ __forceinline__ void cg_block_update(const CgVec& v, long o, const do
     v.z[o + i] = zi;
     if (mir) mir[i] = zi;
     rz += rn[i] * zi;
+    cgd_acc_z(v, o + i, zi, cd);
   }
 }
 
 // One CG iteration given w = A z (complete) and the delta partials.
 template <int PB, bool HAS_INTR>
 static __global__ void __launch_bounds__(kBlock) k_cg_update(CgVec v, int it) {
-  __shared__ double smem[4 * 3 + 3];
+  __shared__ double smem[5 * 2 * kCgMaxModes];
   // one pass over both sets of partial slots (r.z | r.r of the previous update, delta of this apply);
   // the loads are issued before the `done` test so that they overlap its round trip
   double t3[3] = {0.0, 0.0, 0.0};
@@ -225,8 +311,10 @@ static __global__ void __launch_bounds__(kBlock) k_cg_update(CgVec v, int it) {
     sbc[2] = t3[2];
   }
   __syncthreads();
-  const double gamma = sbc[0];
-  const double delta = v.delta_in_w ? v.w[v.n] : sbc[2];
+  double y[kCgMaxModes], gcorr, dcorr;
+  cgd_coefficients(v, it & 1, y, gcorr, dcorr, smem);
+  const double gamma = sbc[0] - gcorr;
+  const double delta = (v.delta_in_w ? v.w[v.n] : sbc[2]) - dcorr;
   __syncthreads();
   double beta = 0.0, denom = delta;
   if (it > 0) {
@@ -237,19 +325,21 @@ static __global__ void __launch_bounds__(kBlock) k_cg_update(CgVec v, int it) {
   const double alpha = ok ? gamma / denom : 0.0;
   if (!ok) beta = 0.0;
   double acc[2] = {0.0, 0.0};
+  double cd[2 * kCgMaxModes] = {};
   const int nblk = v.N + (HAS_INTR ? v.K : 0);
   if (ok) {
     for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += gridDim.x * blockDim.x) {
       if (b < v.N) {
-        cg_block_update<PB>(v, (long)PB * b, v.minv + (long)PB * PB * b, alpha, beta, acc[0], acc[1],
+        cg_block_update<PB>(v, (long)PB * b, v.minv + (long)PB * PB * b, alpha, beta, acc[0], acc[1], y, cd,
                             v.zmir ? v.zmir + (long)b * v.zmir_stride + v.zmir_off : nullptr);
       } else if constexpr (HAS_INTR) {
         const int k = b - v.N;
         cg_block_update<8>(v, (long)PB * v.N + 8L * k, v.minv + (long)PB * PB * v.N + 64L * k, alpha, beta, acc[0],
-                           acc[1]);
+                           acc[1], y, cd);
       }
     }
   }
+  cgd_store_partials(v, (it + 1) & 1, cd, smem);
   block_sum<2>(acc, smem);
   if (threadIdx.x == 0) {
     double* out = v.vpart + (size_t)((it + 1) & 1) * kCgMaxBlocks * 2;
@@ -304,8 +394,9 @@ template <int PB>
 static __global__ void __launch_bounds__(kCgSingleThreads) k_cg_init1(CgVec v) {
   __shared__ double smem[16 * 2 + 2];
   double acc[2] = {0.0, 0.0};
+  double cd[2 * kCgMaxModes] = {};  // (single-workgroup solves are never deflated: v.dk == 0)
   for (int b = threadIdx.x; b < v.N; b += blockDim.x)
-    cg_block_init<PB>(v, (long)PB * b, v.minv + (long)PB * PB * b, acc[0], acc[1],
+    cg_block_init<PB>(v, (long)PB * b, v.minv + (long)PB * PB * b, acc[0], acc[1], cd,
                       v.zmir ? v.zmir + (long)b * v.zmir_stride + v.zmir_off : nullptr);
   block_sum_1024<2>(acc, smem);
   if (threadIdx.x == 0) {
@@ -345,8 +436,10 @@ static __global__ void __launch_bounds__(kCgSingleThreads) k_cg_update1(CgVec v,
   const double alpha = ok ? gamma / denom : 0.0;
   double acc[2] = {0.0, 0.0};
   if (ok) {
+    const double y[kCgMaxModes] = {};
+    double cd[2 * kCgMaxModes] = {};
     for (int b = threadIdx.x; b < v.N; b += blockDim.x)
-      cg_block_update<PB>(v, (long)PB * b, v.minv + (long)PB * PB * b, alpha, beta, acc[0], acc[1],
+      cg_block_update<PB>(v, (long)PB * b, v.minv + (long)PB * PB * b, alpha, beta, acc[0], acc[1], y, cd,
                           v.zmir ? v.zmir + (long)b * v.zmir_stride + v.zmir_off : nullptr);
   }
   block_sum_1024<2>(acc, smem);
@@ -393,10 +486,11 @@ __device__ __forceinline__ void cg_joint_mirror(const CgVec& v, int n, int i, do
 template <int PB>
 static __global__ void __launch_bounds__(kBlock) k_cg_init_joint(CgVec v) {
   constexpr int BJ = PB + 8;
-  __shared__ double smem[4 * 2];
+  __shared__ double smem[4 * 2 * kCgMaxModes];
   __shared__ double sr[kJointCams][16];
   const int c = threadIdx.x >> 4, i = threadIdx.x & 15;
   double acc[2] = {0.0, 0.0};
+  double cd[2 * kCgMaxModes] = {};
   for (int n0 = blockIdx.x * kJointCams; n0 < v.N; n0 += gridDim.x * kJointCams) {
     const int n = n0 + c;
     const bool act = n < v.N && i < BJ;
@@ -422,8 +516,11 @@ static __global__ void __launch_bounds__(kBlock) k_cg_init_joint(CgVec v) {
       cg_joint_mirror<PB>(v, n, i, zi);
       acc[0] += ri * zi;
       acc[1] += ri * ri;
+      cgd_acc_r(v, o, ri, cd);
+      cgd_acc_z(v, o, zi, cd);
     }
   }
+  cgd_store_partials(v, 0, cd, smem);
   block_sum<2>(acc, smem);
   if (threadIdx.x == 0) {
     v.vpart[blockIdx.x * 2] = acc[0];
@@ -443,7 +540,7 @@ static __global__ void __launch_bounds__(kBlock) k_cg_init_joint(CgVec v) {
 template <int PB>
 static __global__ void __launch_bounds__(kBlock) k_cg_update_joint(CgVec v, int it) {
   constexpr int BJ = PB + 8;
-  __shared__ double smem[4 * 2 + 2];
+  __shared__ double smem[5 * 2 * kCgMaxModes];
   __shared__ double sr[kJointCams][16];
   if (v.st->done) return;
   double g[2];
@@ -456,7 +553,10 @@ static __global__ void __launch_bounds__(kBlock) k_cg_update_joint(CgVec v, int 
     reduce_partials<1>(v.dpart, v.nb_apply, d, smem);
     delta = d[0];
   }
-  const double gamma = g[0];
+  double y[kCgMaxModes], gcorr, dcorr;
+  cgd_coefficients(v, it & 1, y, gcorr, dcorr, smem);
+  delta -= dcorr;
+  const double gamma = g[0] - gcorr;
   const CgScal prev = v.scal[it & 1];
   double beta = 0.0, denom = delta;
   if (it > 0) {
@@ -467,6 +567,7 @@ static __global__ void __launch_bounds__(kBlock) k_cg_update_joint(CgVec v, int 
   const double alpha = ok ? gamma / denom : 0.0;
   if (!ok) beta = 0.0;
   double acc[2] = {0.0, 0.0};
+  double cd[2 * kCgMaxModes] = {};
   const int c = threadIdx.x >> 4, i = threadIdx.x & 15;
   if (ok) {
     for (int n0 = blockIdx.x * kJointCams; n0 < v.N; n0 += gridDim.x * kJointCams) {
@@ -476,14 +577,17 @@ static __global__ void __launch_bounds__(kBlock) k_cg_update_joint(CgVec v, int 
       double ri = 0.0;
       if (act) {
         o = cg_joint_index<PB>(v, n, i);
-        const double pi = v.z[o] + beta * v.p[o];
-        const double si = v.w[o] + beta * v.s[o];
+        double zo = v.z[o], wo = v.w[o];
+        cgd_project(v, o, y, zo, wo);
+        const double pi = zo + beta * v.p[o];
+        const double si = wo + beta * v.s[o];
         v.p[o] = pi;
         v.s[o] = si;
         v.x[o] += alpha * pi;
         ri = v.r[o] - alpha * si;
         v.r[o] = ri;
         acc[1] += ri * ri;
+        cgd_acc_r(v, o, ri, cd);
       }
       __syncthreads();
       sr[c][i] = ri;
@@ -496,9 +600,11 @@ static __global__ void __launch_bounds__(kBlock) k_cg_update_joint(CgVec v, int 
         v.z[o] = zi;
         cg_joint_mirror<PB>(v, n, i, zi);
         acc[0] += ri * zi;
+        cgd_acc_z(v, o, zi, cd);
       }
     }
   }
+  cgd_store_partials(v, (it + 1) & 1, cd, smem);
   block_sum<2>(acc, smem);
   if (threadIdx.x == 0) {
     double* out = v.vpart + (size_t)((it + 1) & 1) * kCgMaxBlocks * 2;
@@ -525,24 +631,20 @@ static __global__ void __launch_bounds__(kBlock) k_cg_delta_to_w(CgVec v) {
   if (threadIdx.x == 0) v.w[v.n] = d[0];
 }
 
-// ---- deflation of known near-null modes (EXPERIMENT, off unless a solver passes a CgDeflation) ---------------------
-// The block-Jacobi-preconditioned reduced systems of BA / GP have a tight spectrum plus the similarity gauge of the
-// scene (CPU evidence tools/exp_deflation.py; executable specification: pcg(..., defl) in
-// oracle/csrc/orc_lm.hpp).  Deflated PCG (Saad, Yeung, Erhel, Guyomarc'h 2000) on the span of k given modes W:
-//     E = W^T A W,   x = W E^-1 W^T b + x',   A x' = b2 := b - A W E^-1 W^T b,
-//     every preconditioned residual is projected:  z <- z - W E^-1 (A W)^T z   (r.z is patched by -(W^T r).(E^-1 (AW)^T z))
-// Same system, same stopping rule (relative to |b2| <= |b|).  Written at the end of round 2 without a GPU to run it on:
-// nothing here executes unless GSFM_DEFLATE is set (gp.hip / ba.hip), single rank, multi-block vector kernels only.
-constexpr int kCgMaxModes = 8;
-constexpr int kCgdBlocks = 128;  // grid of the dot-product kernel
 
+// ---- deflation: setup kernels (once per solve) -------------------------------------------------------------------
+constexpr int kCgdBlocks = 128;                                   // grid of the Gram dot-product kernel
+constexpr int kCgdGram = kCgMaxModes * (kCgMaxModes + 1);         // k x (k + 1) products W_i . (A W_j | b)
+
+// Host view of a deflated solve.  W: the modes in the unknowns of the reduced system (zero in constant components).
 struct CgDeflation {
   int k = 0;                   // modes in use (<= kCgMaxModes)
-  const double* W = nullptr;   // [k][n] the modes (zero in constant components)
+  const double* W = nullptr;   // [k][n]
   double* AW = nullptr;        // [k][n]
   double* b2 = nullptr;        // [n]   deflated right-hand side
-  double* part = nullptr;      // [kCgdBlocks][2 * kCgMaxModes] partial dot products
+  double* part = nullptr;      // [kCgdBlocks][kCgdGram] partial Gram products
   double* small = nullptr;     // [64] E^-1 | [8] y0 = E^-1 W^T b | [1] ok (1.0 / 0.0)
+  double* cd = nullptr;        // [2][kCgMaxBlocks][2 * kCgMaxModes]  (CgVec::dcd)
 };
 
 // the element list of the unknown vector with its gather mirrors: f(o, n, i) for every unknown o; (n, i) = camera and
@@ -562,142 +664,109 @@ __device__ __forceinline__ void cgd_for_each(const CgVec& v, F f) {
     }
   }
 }
-template <int PB, bool JOINT>
-__device__ __forceinline__ void cgd_store_z(const CgVec& v, long o, int n, int i, double zi) {
-  v.z[o] = zi;
-  if constexpr (JOINT) {
-    cg_joint_mirror<PB>(v, n, i, zi);
-  } else {
-    if (v.zmir && n >= 0) v.zmir[(long)n * v.zmir_stride + v.zmir_off + i] = zi;
-  }
-}
 
-// z := vec (with mirrors): the input of one operator application
+// z := vec (vector and gather mirrors): the input of one operator application
 template <int PB, bool JOINT>
 static __global__ void __launch_bounds__(kBlock) k_cgd_set_z(CgVec v, const double* __restrict__ vec) {
-  cgd_for_each<PB, JOINT>(v, [&](long o, int n, int i) { cgd_store_z<PB, JOINT>(v, o, n, i, vec[o]); });
+  cgd_for_each<PB, JOINT>(v, [&](long o, int n, int i) {
+    const double zi = vec[o];
+    v.z[o] = zi;
+    if constexpr (JOINT) {
+      cg_joint_mirror<PB>(v, n, i, zi);
+    } else {
+      if (v.zmir && n >= 0) v.zmir[(long)n * v.zmir_stride + v.zmir_off + i] = zi;
+    }
+  });
 }
 static __global__ void __launch_bounds__(kBlock) k_cgd_copy(long n, const double* __restrict__ src, double* __restrict__ dst) {
   for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x) dst[o] = src[o];
 }
 
-// E = W^T A W (symmetrised), E^-1 by Gauss-Jordan with a positivity test, y0 = E^-1 W^T b, b2 = b - A W y0.  One
-// workgroup: k^2 + k dot products over n <= a few 10^5 doubles, once per solve.
-static __global__ void __launch_bounds__(kCgSingleThreads) k_cgd_gram(CgVec v, CgDeflation d) {
-  __shared__ double smem[16 * 1 + 1];
-  __shared__ double E[kCgMaxModes][kCgMaxModes + 1];  // last column: W^T b
-  __shared__ double sy[kCgMaxModes];
-  __shared__ int sok;
-  const int k = d.k;
-  for (int i = 0; i < k; ++i)
-    for (int j = 0; j <= k; ++j) {
-      const double* a = d.W + (size_t)i * v.n;
-      const double* c = j < k ? d.AW + (size_t)j * v.n : v.b;
-      double t[1] = {0.0};
-      for (long o = threadIdx.x; o < (long)v.n; o += blockDim.x) t[0] += a[o] * c[o];
-      block_sum_1024<1>(t, smem);
-      if (threadIdx.x == 0) E[i][j] = t[0];
+// partial Gram products of this block's slice: part[block][i * (K + 1) + j] = W_i . (A W_j), j == K: W_i . b
+template <int K>
+static __global__ void __launch_bounds__(kBlock) k_cgd_gram_dots(CgVec v, CgDeflation d) {
+  __shared__ double smem[4 * K * (K + 1)];
+  double acc[K * (K + 1)] = {};
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < (long)v.n; o += (long)gridDim.x * blockDim.x) {
+    double c[K + 1];
+#pragma unroll
+    for (int j = 0; j < K; ++j) c[j] = d.AW[(size_t)j * v.n + o];
+    c[K] = v.b[o];
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const double a = d.W[(size_t)i * v.n + o];
+#pragma unroll
+      for (int j = 0; j <= K; ++j) acc[i * (K + 1) + j] += a * c[j];
     }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double A[kCgMaxModes][2 * kCgMaxModes];
-    bool ok = true;
-    for (int i = 0; i < k; ++i)
-      for (int j = 0; j < k; ++j) {
-        A[i][j] = 0.5 * (E[i][j] + E[j][i]);
-        A[i][k + j] = i == j ? 1.0 : 0.0;
-      }
-    for (int c = 0; c < k && ok; ++c) {  // SPD: the pivots are the diagonal
-      const double piv = A[c][c];
-      if (!(piv > 0.0) || !isfinite(piv)) {
-        ok = false;
-        break;
-      }
-      const double ip = 1.0 / piv;
-      for (int j = 0; j < 2 * k; ++j) A[c][j] *= ip;
-      for (int r = 0; r < k; ++r) {
-        if (r == c) continue;
-        const double f = A[r][c];
-        for (int j = 0; j < 2 * k; ++j) A[r][j] -= f * A[c][j];
-      }
-    }
-    for (int i = 0; i < k; ++i) {
-      double y = 0.0;
-      for (int j = 0; j < k; ++j) {
-        const double e = ok ? A[i][k + j] : 0.0;
-        d.small[i * kCgMaxModes + j] = e;
-        y += e * E[j][k];
-      }
-      if (!isfinite(y)) ok = false;
-      sy[i] = y;
-    }
-    if (!ok)
-      for (int i = 0; i < k; ++i) sy[i] = 0.0;
-    for (int i = 0; i < k; ++i) d.small[64 + i] = sy[i];
-    d.small[72] = ok ? 1.0 : 0.0;
-    sok = ok ? 1 : 0;
   }
-  __syncthreads();
-  for (long o = threadIdx.x; o < (long)v.n; o += blockDim.x) {
+  block_sum<K * (K + 1)>(acc, smem);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < K * (K + 1); ++j) d.part[(size_t)blockIdx.x * kCgdGram + j] = acc[j];
+  }
+}
+
+// E = W^T A W (symmetrised), E^-1 by Gauss-Jordan with a positivity test, y0 = E^-1 W^T b.  One workgroup.
+template <int K>
+static __global__ void __launch_bounds__(kBlock) k_cgd_gram_solve(CgDeflation d, int nparts) {
+  __shared__ double smem[5 * K * (K + 1)];
+  double G[K * (K + 1)];
+  {
+    double acc[K * (K + 1)] = {};
+    for (int b = threadIdx.x; b < nparts; b += blockDim.x) {
+#pragma unroll
+      for (int j = 0; j < K * (K + 1); ++j) acc[j] += d.part[(size_t)b * kCgdGram + j];
+    }
+    block_sum<K * (K + 1)>(acc, smem);
+#pragma unroll
+    for (int j = 0; j < K * (K + 1); ++j) G[j] = acc[j];
+  }
+  if (threadIdx.x != 0) return;
+  double A[K][2 * K];
+  bool ok = true;
+  for (int i = 0; i < K; ++i)
+    for (int j = 0; j < K; ++j) {
+      A[i][j] = 0.5 * (G[i * (K + 1) + j] + G[j * (K + 1) + i]);
+      A[i][K + j] = i == j ? 1.0 : 0.0;
+    }
+  for (int c = 0; c < K && ok; ++c) {  // SPD: the pivots are the diagonal
+    const double piv = A[c][c];
+    if (!(piv > 0.0) || !isfinite(piv)) {
+      ok = false;
+      break;
+    }
+    const double ip = 1.0 / piv;
+    for (int j = 0; j < 2 * K; ++j) A[c][j] *= ip;
+    for (int r = 0; r < K; ++r) {
+      if (r == c) continue;
+      const double f = A[r][c];
+      for (int j = 0; j < 2 * K; ++j) A[r][j] -= f * A[c][j];
+    }
+  }
+  double y0[K];
+  for (int i = 0; i < K; ++i) {
+    double y = 0.0;
+    for (int j = 0; j < K; ++j) y += A[i][K + j] * G[j * (K + 1) + K];
+    if (!isfinite(y)) ok = false;
+    y0[i] = y;
+  }
+  for (int i = 0; i < kCgMaxModes; ++i) {
+    for (int j = 0; j < kCgMaxModes; ++j) d.small[i * kCgMaxModes + j] = (ok && i < K && j < K) ? A[i][K + j] : 0.0;
+    d.small[64 + i] = (ok && i < K) ? y0[i] : 0.0;
+  }
+  d.small[72] = ok ? 1.0 : 0.0;
+}
+
+// b2 = b - A W y0
+static __global__ void __launch_bounds__(kBlock) k_cgd_b2(CgVec v, CgDeflation d) {
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < (long)v.n; o += (long)gridDim.x * blockDim.x) {
     double t = v.b[o];
-    if (sok)
-      for (int j = 0; j < k; ++j) t -= sy[j] * d.AW[(size_t)j * v.n + o];
+    for (int j = 0; j < d.k; ++j) t -= d.small[64 + j] * d.AW[(size_t)j * v.n + o];
     d.b2[o] = t;
   }
 }
-
-// partial dot products  c_j = (A W_j) . z,  dd_j = W_j . r   of the current iterate
-static __global__ void __launch_bounds__(kBlock) k_cgd_dots(CgVec v, CgDeflation d) {
-  __shared__ double smem[4 * 2 * kCgMaxModes];
-  if (v.st->done || d.small[72] == 0.0) return;
-  double acc[2 * kCgMaxModes];
-#pragma unroll
-  for (int j = 0; j < 2 * kCgMaxModes; ++j) acc[j] = 0.0;
-  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < (long)v.n; o += (long)gridDim.x * blockDim.x) {
-    const double zo = v.z[o], ro = v.r[o];
-#pragma unroll
-    for (int j = 0; j < kCgMaxModes; ++j)
-      if (j < d.k) {
-        acc[j] += d.AW[(size_t)j * v.n + o] * zo;
-        acc[kCgMaxModes + j] += d.W[(size_t)j * v.n + o] * ro;
-      }
-  }
-  block_sum<2 * kCgMaxModes>(acc, smem);
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int j = 0; j < 2 * kCgMaxModes; ++j) d.part[blockIdx.x * 2 * kCgMaxModes + j] = acc[j];
-  }
-}
-
-// z <- z - W E^-1 c (vector and mirrors); block 0 patches the r.z partial of parity slot (it + 1) & 1 by -dd . (E^-1 c)
-template <int PB, bool JOINT>
-static __global__ void __launch_bounds__(kBlock) k_cgd_project(CgVec v, CgDeflation d, int it, int nparts) {
-  __shared__ double smem[5 * 2 * kCgMaxModes];
-  __shared__ double sy[kCgMaxModes];
-  if (v.st->done || d.small[72] == 0.0) return;
-  double cd[2 * kCgMaxModes];
-  reduce_partials<2 * kCgMaxModes>(d.part, nparts, cd, smem);
-  if (threadIdx.x == 0) {
-    double corr = 0.0;
-    for (int i = 0; i < d.k; ++i) {
-      double y = 0.0;
-      for (int j = 0; j < d.k; ++j) y += d.small[i * kCgMaxModes + j] * cd[j];
-      sy[i] = y;
-      corr += y * cd[kCgMaxModes + i];
-    }
-    if (blockIdx.x == 0) v.vpart[(size_t)((it + 1) & 1) * kCgMaxBlocks * 2] -= corr;
-  }
-  __syncthreads();
-  cgd_for_each<PB, JOINT>(v, [&](long o, int n, int i) {
-    double zi = v.z[o];
-    for (int j = 0; j < d.k; ++j) zi -= sy[j] * d.W[(size_t)j * v.n + o];
-    cgd_store_z<PB, JOINT>(v, o, n, i, zi);
-  });
-}
-
 // x <- x + W y0
 static __global__ void __launch_bounds__(kBlock) k_cgd_finish(CgVec v, CgDeflation d) {
-  if (d.small[72] == 0.0) return;
   for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < (long)v.n; o += (long)gridDim.x * blockDim.x) {
     double xo = v.x[o];
     for (int j = 0; j < d.k; ++j) xo += d.small[64 + j] * d.W[(size_t)j * v.n + o];
@@ -705,16 +774,24 @@ static __global__ void __launch_bounds__(kBlock) k_cgd_finish(CgVec v, CgDeflati
   }
 }
 
-// Host driver.  `apply(it)` must enqueue the kernels computing w = A z and the delta partials
-// (its first kernel calls cg_converged); it is also responsible for timing its dominant kernel.
+// Host driver.  `apply(it)` must enqueue the kernels computing w = A z and the delta partials (its first kernel calls
+// cg_converged); it is also responsible for timing its dominant kernel (ctx->prof.begin(s, id, it)).
+//   defl   optional: deflate these modes (multi-block vector kernels only; small single-workgroup solves run plain).
+//          The k operator applications that form A W are counted in the returned iteration count.
+//   hint   optional, in/out: the iteration count of the previous solve of this sequence.  The host enqueues iterations
+//          ahead of the device and reads the status back first where the previous solve ended, then every third
+//          iteration — so a converged solve leaves a couple of early-exit launches behind instead of a chunk of them.
 template <int PB, bool HAS_INTR, typename Apply>
-inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& apply, const CgDeflation* defl = nullptr) {
+inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& apply, const CgDeflation* defl = nullptr,
+                     int* hint = nullptr) {
   hipStream_t s = ctx->stream;
   const bool multi = ctx->comm.world > 1;
   v.delta_in_w = multi ? 1 : 0;
   const bool joint = HAS_INTR && v.joint_map != nullptr;
   v.tol2 = tol * tol;
   v.single = (!HAS_INTR && v.N <= kCgSingleMaxBlocks) ? 1 : 0;
+  v.probe = 0;
+  v.dk = 0;
   auto init = [&]() {
     if constexpr (HAS_INTR) {
       if (joint) hipLaunchKernelGGL((k_cg_init_joint<PB>), dim3(v.nb_update), dim3(kBlock), 0, s, v);
@@ -723,63 +800,77 @@ inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& 
     }
     if (!joint && !v.single) hipLaunchKernelGGL((k_cg_init<PB, HAS_INTR>), dim3(v.nb_update), dim3(kBlock), 0, s, v);
   };
-  init();
-  // experiment (see CgDeflation): only the multi-block vector kernels on one rank
-  const bool deflate = defl != nullptr && defl->k > 0 && !multi && !v.single;
-  const double* b_caller = v.b;
-  const int gdot = std::min(kCgdBlocks, grid_for((size_t)v.n, kBlock));
-  const int gvec = std::min(256, grid_for((size_t)std::max((long)v.n, (long)v.N * 16), kBlock));
-  auto project = [&](int it) {
-    hipLaunchKernelGGL(k_cgd_dots, dim3(gdot), dim3(kBlock), 0, s, v, *defl);
-    if (joint)
-      hipLaunchKernelGGL((k_cgd_project<PB, true>), dim3(gvec), dim3(kBlock), 0, s, v, *defl, it, gdot);
-    else
-      hipLaunchKernelGGL((k_cgd_project<PB, false>), dim3(gvec), dim3(kBlock), 0, s, v, *defl, it, gdot);
-  };
-  if (deflate) {
-    for (int j = 0; j < defl->k; ++j) {  // A W_j: the operator reads z (and its mirrors), writes w
-      if (joint)
-        hipLaunchKernelGGL((k_cgd_set_z<PB, true>), dim3(gvec), dim3(kBlock), 0, s, v, defl->W + (size_t)j * v.n);
-      else
-        hipLaunchKernelGGL((k_cgd_set_z<PB, false>), dim3(gvec), dim3(kBlock), 0, s, v, defl->W + (size_t)j * v.n);
-      apply(0);
-      hipLaunchKernelGGL(k_cgd_copy, dim3(gdot), dim3(kBlock), 0, s, (long)v.n, (const double*)v.w, defl->AW + (size_t)j * v.n);
-    }
-    hipLaunchKernelGGL(k_cgd_gram, dim3(1), dim3(kCgSingleThreads), 0, s, v, *defl);
-    v.b = defl->b2;
-    init();
-    project(-1);
-  }
-  CgStatus* h = reinterpret_cast<CgStatus*>(ctx->h_pinned + 400);
-  const int chunk = 8;
-  long iters = max_iter;
-  for (int it = 0; it < max_iter; ++it) {
+  auto apply_all = [&](int it) {  // w = A z complete on every rank
     apply(it);
     if (multi) {
       hipLaunchKernelGGL(k_cg_delta_to_w, dim3(1), dim3(kBlock), 0, s, v);
       allreduce_sum(ctx, v.w, (size_t)v.n + 1);
     }
+  };
+  const bool deflate = defl != nullptr && defl->k > 0 && !v.single;
+  const double* b_caller = v.b;
+  const int gvec = std::min(256, grid_for((size_t)std::max((long)v.n, (long)v.N * 16), kBlock));
+  if (deflate) {
+    init();  // (resets the status block the apply kernels look at)
+    v.probe = 1;
+    for (int j = 0; j < defl->k; ++j) {  // A W_j: the operator reads z (and its mirrors), writes w
+      if (joint)
+        hipLaunchKernelGGL((k_cgd_set_z<PB, true>), dim3(gvec), dim3(kBlock), 0, s, v, defl->W + (size_t)j * v.n);
+      else
+        hipLaunchKernelGGL((k_cgd_set_z<PB, false>), dim3(gvec), dim3(kBlock), 0, s, v, defl->W + (size_t)j * v.n);
+      apply_all(0);
+      hipLaunchKernelGGL(k_cgd_copy, dim3(gvec), dim3(kBlock), 0, s, (long)v.n, (const double*)v.w, defl->AW + (size_t)j * v.n);
+    }
+    v.probe = 0;
+    const int gdot = std::min(kCgdBlocks, grid_for((size_t)v.n, kBlock));
+    if (defl->k == 4) {
+      hipLaunchKernelGGL((k_cgd_gram_dots<4>), dim3(gdot), dim3(kBlock), 0, s, v, *defl);
+      hipLaunchKernelGGL((k_cgd_gram_solve<4>), dim3(1), dim3(kBlock), 0, s, *defl, gdot);
+    } else if (defl->k == 7) {
+      hipLaunchKernelGGL((k_cgd_gram_dots<7>), dim3(gdot), dim3(kBlock), 0, s, v, *defl);
+      hipLaunchKernelGGL((k_cgd_gram_solve<7>), dim3(1), dim3(kBlock), 0, s, *defl, gdot);
+    } else {
+      throw StatusError(GSFM_ERR_INVALID_ARGUMENT, "cg_solve: 4 or 7 deflated modes");
+    }
+    hipLaunchKernelGGL(k_cgd_b2, dim3(gvec), dim3(kBlock), 0, s, v, *defl);
+    v.b = defl->b2;
+    v.dk = defl->k;
+    v.dW = defl->W;
+    v.dAW = defl->AW;
+    v.dsmall = defl->small;
+    v.dcd = defl->cd;
+  }
+  init();
+  CgStatus* h = reinterpret_cast<CgStatus*>(ctx->h_pinned + 400);
+  long iters = max_iter;
+  // convergence after p iterations is noticed by the first kernel of apply(p): read back after p + 1 enqueued iterations
+  int next_poll = (hint && *hint > 0) ? *hint + 1 : 8;
+  if (ctx->comm.host_fn) next_poll = 1;  // (host-staged transport: the stream is drained every iteration anyway)
+  for (int it = 0; it < max_iter; ++it) {
+    apply_all(it);
     if constexpr (HAS_INTR) {
       if (joint) hipLaunchKernelGGL((k_cg_update_joint<PB>), dim3(v.nb_update), dim3(kBlock), 0, s, v, it);
     } else {
       if (v.single) hipLaunchKernelGGL((k_cg_update1<PB>), dim3(1), dim3(kCgSingleThreads), 0, s, v, it);
     }
     if (!joint && !v.single) hipLaunchKernelGGL((k_cg_update<PB, HAS_INTR>), dim3(v.nb_update), dim3(kBlock), 0, s, v, it);
-    if (deflate) project(it);
-    if ((it + 1) % chunk == 0 || it == max_iter - 1) {
+    if (it + 1 >= next_poll || it == max_iter - 1) {
       GSFM_HIP_CHECK(hipMemcpyAsync(h, v.st, sizeof(CgStatus), hipMemcpyDeviceToHost, s));
       GSFM_HIP_CHECK(hipStreamSynchronize(s));
       GSFM_HIP_CHECK(hipGetLastError());
-      ctx->prof.harvest();
+      ctx->prof.harvest(h->done ? h->iters : 0x7fffffff);  // launches of iterations >= iters found `done` and left at once
       if (h->done) {
         iters = h->iters;
         break;
       }
+      next_poll = it + 1 + (ctx->comm.host_fn ? 1 : 3);
     }
   }
+  if (hint) *hint = (int)iters;
   if (deflate) {
-    hipLaunchKernelGGL(k_cgd_finish, dim3(gdot), dim3(kBlock), 0, s, v, *defl);
+    hipLaunchKernelGGL(k_cgd_finish, dim3(gvec), dim3(kBlock), 0, s, v, *defl);
     v.b = b_caller;
+    v.dk = 0;
     iters += defl->k;  // the operator applications that formed A W
   }
   return iters;

@@ -126,17 +126,20 @@ struct KernelProfiler {
   bool enabled = false;
   std::vector<hipEvent_t> ev;  // 2 * kPool
   std::vector<int> tag;        // kernel id of each used pair
+  std::vector<int> iter;       // PCG iteration the pair belongs to (-1: not part of an iteration)
   int used = 0;
   int64_t launches[GSFM_KERNEL_COUNT] = {};
   double total_ms[GSFM_KERNEL_COUNT] = {};
-  bool begin(hipStream_t s, int id) {
+  bool begin(hipStream_t s, int id, int it = -1) {
     if (!enabled || used >= kPool) return false;
     if (ev.empty()) {
       ev.resize(2 * kPool);
       tag.resize(kPool);
+      iter.resize(kPool);
       for (auto& e : ev) GSFM_HIP_CHECK(hipEventCreate(&e));
     }
     tag[used] = id;
+    iter[used] = it;
     GSFM_HIP_CHECK(hipEventRecord(ev[2 * used], s));
     return true;
   }
@@ -144,9 +147,12 @@ struct KernelProfiler {
     GSFM_HIP_CHECK(hipEventRecord(ev[2 * used + 1], s));
     ++used;
   }
-  void harvest() {
+  // live_iters: pairs of PCG iterations >= live_iters are dropped — those launches found the solve finished and
+  // returned at once (cg.hpp); counting them would dilute the per-launch averages.
+  void harvest(int live_iters = 0x7fffffff) {
     for (int i = 0; i < used; ++i) {
       float ms = 0.f;
+      if (iter[i] >= live_iters) continue;
       if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) == hipSuccess) {
         launches[tag[i]]++;
         total_ms[tag[i]] += ms;

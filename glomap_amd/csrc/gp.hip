@@ -361,104 +361,18 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // ---- the hot pair: w = (H_cc - H_cp H_pp^-1 H_pc + D) z ------------------------------------------
-// Phase A, track-major, one lane per observation: t_p = H_pp^-1 sum_k Q_k z_{c(k)} -> ptrec[p].t.
+// Phase A, track-major, one lane per observation, one wave per tile: t_p = H_pp^-1 sum_k Q_k z_{c(k)} -> ptrec[p].t.
 // Algorithmic bytes per observation: qa, qb (16) + cam (4) + pt (4); per track: 24 written; the
 // camera gathers (c_n, z_n: 48 B) are L2-resident, X_p is read from the track's own 64-byte record.
+// The kernel is bound by the chain of DEPENDENT memory trips a wave makes for its tile, so the chain is kept short:
+//   [partial sums, done, bb, tile bounds through the scalar cache] -> [obs_pt, cam, qa, qb] -> barriers of the
+//   convergence test -> [gathers, `used` and H_pp^-1 of the tail lanes] -> scan -> store                (3 trips)
+// (first version: convergence test -> tile bounds by a vector load -> indices -> gathers -> scan -> tail loads -> store,
+// 6 trips, 106 us instead of 101 at configs[3]).
 __global__ void __launch_bounds__(kBlock)
     k_gp_phaseA(GpDev g, CgVec v, int it, double tol2, const double* __restrict__ cz,
                 const double* __restrict__ qa, const double* __restrict__ qb,
                 const double* __restrict__ pth, double* __restrict__ ptrec) {
-  __shared__ double smem[4 * 2 + 2];
-  if (cg_converged(v, it, tol2, smem)) return;
-  const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  const int nwaves = gridDim.x * (kBlock / 64);
-  for (int tile = wave; tile < g.g.T; tile += nwaves) {
-    const long k0 = g.g.tile_k[tile], k1 = g.g.tile_k[tile + 1];
-    double acc[3] = {0, 0, 0};
-    int key = -1 - lane;
-    for (long k = k0 + lane; k < k1; k += 64) {
-      const int p = g.g.obs_pt[k];
-      key = p;
-      const long n = g.g.cam[k];
-      const double ak = qa[k], bk = qb[k];
-      V3 cn, zn;
-      ld6(cz + 6 * n, cn, zn);  // (c_n, z_n): one 48-byte record, three 16-byte gathers
-      const V3 d = ld3a(ptrec + 8 * (long)p) - cn;
-      const V3 y = applyQ(ak, bk, d, zn);
-      acc[0] += y.x;
-      acc[1] += y.y;
-      acc[2] += y.z;
-    }
-    seg_scan<3>(acc, key, lane);
-    if (seg_is_tail(key, lane) && key >= 0 && g.g.used[key]) {
-      const double* b = pth + 6 * (long)key;
-      const V3 t = mul(S3{b[0], b[1], b[2], b[3], b[4], b[5]}, V3{acc[0], acc[1], acc[2]});
-      st3(ptrec + 8 * (long)key + 3, t);
-    }
-  }
-}
-
-// GSFM_DEFLATE experiment (CgDeflation in cg.hpp): the four gauge modes of global positioning
-// in the unknowns of the reduced system — world translation (dc_n = e_a) and scale (dc_n = c_n).  W[j][3 n + a].
-__global__ void __launch_bounds__(kBlock) k_gp_defl_modes(int N, const double* __restrict__ c, double* __restrict__ W) {
-  const long n3 = 3L * N;
-  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < n3; o += (long)gridDim.x * blockDim.x) {
-    const int a = (int)(o % 3);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) W[(size_t)j * n3 + o] = a == j ? 1.0 : 0.0;
-    W[(size_t)3 * n3 + o] = c[o];
-  }
-}
-
-// A/B variant of k_gp_phaseA, OFF by default (GSFM_GP_PHASEA_CHAIN=1 selects it; written at the end of round 2 from the
-// ISA of k_gp_phaseA, not yet measured — DESIGN.md section 7 item 4).  Same arithmetic in the same order, so the
-// results are bit-identical; what changes is the chain of DEPENDENT memory trips one wave makes for its tile:
-//   k_gp_phaseA:  [partial sums, done] -> barriers -> [bb] -> [tile_k, a vector load] -> [obs_pt, cam, qa, qb]
-//                 -> [gathers] -> scan -> [used, H_pp^-1 of the tail lanes] -> store                      (6 trips)
-//   here:         [partial sums, done, bb, tile_k through the scalar cache] -> [obs_pt, cam, qa, qb] -> barriers
-//                 -> [gathers, used and H_pp^-1 of the tail lanes] -> scan -> store                      (3 trips)
-// Needs one wave per tile (gridTile_ is sized that way).
-__device__ __forceinline__ bool cg_converged_early(const CgVec& v, int it, double tol2, double* smem /* >= 4*2+2 */) {
-  if (v.single) return v.st->done != 0;
-  double t[2] = {0.0, 0.0};
-  {
-    const double* vp = v.vpart + (size_t)(it & 1) * kCgMaxBlocks * 2;
-    for (int b = threadIdx.x; b < v.nb_update; b += blockDim.x) {
-      t[0] += vp[2 * b];
-      t[1] += vp[2 * b + 1];
-    }
-  }
-  const int done0 = v.st->done;
-  const double bb_st = v.st->bb;  // same cache line as `done`; written at it == 0 only, read at it > 0 only
-  if (done0) return true;
-  block_sum<2>(t, smem);
-  if (threadIdx.x == 0) {
-    smem[8] = t[0];
-    smem[9] = t[1];
-  }
-  __syncthreads();
-  t[0] = smem[8];
-  t[1] = smem[9];
-  __syncthreads();
-  const double bb = it == 0 ? t[1] : bb_st;
-  const bool finite = isfinite(t[0]) && isfinite(t[1]);
-  const bool done = !finite || t[1] <= tol2 * bb;
-  __syncthreads();
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (it == 0) v.st->bb = bb;
-    v.st->rr = t[1];
-    v.st->iters = it;
-    if (!finite) v.st->bad = 1;
-    if (done) v.st->done = 1;
-  }
-  return done;
-}
-
-__global__ void __launch_bounds__(kBlock)
-    k_gp_phaseA_chain(GpDev g, CgVec v, int it, double tol2, const double* __restrict__ cz,
-                      const double* __restrict__ qa, const double* __restrict__ qb,
-                      const double* __restrict__ pth, double* __restrict__ ptrec) {
   __shared__ double smem[4 * 2 + 2];
   const int lane = threadIdx.x & 63;
   const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
@@ -478,7 +392,7 @@ __global__ void __launch_bounds__(kBlock)
     ak = qa[k];
     bk = qb[k];
   }
-  if (cg_converged_early(v, it, tol2, smem)) return;
+  if (cg_converged(v, it, tol2, smem)) return;
   if (!have) return;
   // a tile of at most 64 observations (every tile but those of tracks longer than a wave): the keys are final, so the
   // tail lanes know themselves now and their `used` flag and H_pp^-1 travel together with the gathers
@@ -493,7 +407,7 @@ __global__ void __launch_bounds__(kBlock)
   while (k < k1) {
     key = p;
     V3 cn, zn;
-    ld6(cz + 6 * n, cn, zn);
+    ld6(cz + 6 * n, cn, zn);  // (c_n, z_n): one 48-byte record, three 16-byte gathers
     const V3 Xp = ld3a(ptrec + 8 * (long)p);
     if (first && one_trip && tail0) {
       u0 = g.g.used[key0];
@@ -526,6 +440,19 @@ __global__ void __launch_bounds__(kBlock)
     const double* b = pth + 6 * (long)key;
     const V3 t = mul(S3{b[0], b[1], b[2], b[3], b[4], b[5]}, V3{acc[0], acc[1], acc[2]});
     st3(ptrec + 8 * (long)key + 3, t);
+  }
+}
+
+// The four gauge modes of global positioning in the unknowns of the reduced system (deflated from the PCG, cg.hpp):
+// world translation (dc_n = e_a) and scale (dc_n = c_n); nothing pins them but the LM damping (no frame is constant,
+// gp.cc:437-439).  W[j][3 n + a].
+__global__ void __launch_bounds__(kBlock) k_gp_defl_modes(int N, const double* __restrict__ c, double* __restrict__ W) {
+  const long n3 = 3L * N;
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < n3; o += (long)gridDim.x * blockDim.x) {
+    const int a = (int)(o % 3);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) W[(size_t)j * n3 + o] = a == j ? 1.0 : 0.0;
+    W[(size_t)3 * n3 + o] = c[o];
   }
 }
 
@@ -899,7 +826,7 @@ struct GpWs {
   // calibrated rigs: image tables and the image-space twins of the per-camera arrays
   DevBuf<int> img_frame, foff, fimg, img_sensor, soff, simg;
   DevBuf<double> img_off, ci, cin, hcc_i, gc_i, gred_i, scc_i, zimg, wimg, ximg, zero_i, cz_f, img_rot;
-  DevBuf<double> defl_w, defl_aw, defl_b2, defl_part, defl_small;  // GSFM_DEFLATE experiment (CgDeflation, cg.hpp)
+  DevBuf<double> defl_w, defl_aw, defl_b2, defl_part, defl_small, defl_cd;  // CgDeflation, cg.hpp
   static void destroy(void* p) { delete static_cast<GpWs*>(p); }
 };
 
@@ -1109,6 +1036,8 @@ class GpSolver final : public LmProblem {
     gridCam_ = grid_wide(g_.g.S, kBlock / 64, kMaxApplySlots);  // one wave per camera segment (delta partial per block)
     gridMulti_ = g_.g.nmulti > 0 ? grid_for(g_.g.nmulti, kBlock / 64) : 0;  // combine pass: one wave per cut camera
     gridTile_ = grid_wide(g_.g.T, kBlock / 64);             // one wave per tile
+    gridTileA_ = grid_wide(g_.g.T, kBlock / 64, (size_t)0x7fffffff);
+    GSFM_REQUIRE((long)gridTileA_ * (kBlock / 64) >= g_.g.T, "GP: too many observation tiles for one launch");
     gridTileP_ = grid_wide(g_.g.T, kBlock / 64, kMaxBlocks);  // tile sweeps that write per-block partials
     g_.dir = ws->dir.get();
     g_.cal = d_cal;
@@ -1323,18 +1252,18 @@ class GpSolver final : public LmProblem {
     hipStream_t s = ctx_->stream;
     const double yscale = ctx_->comm.rank == 0 ? 1.0 : 0.0;
     const double tol = opt_.lm.pcg_relative_tolerance;
-    // experiment, off unless GSFM_DEFLATE is set: the gauge modes deflated from the PCG (CgDeflation, cg.hpp).  One rank,
-    // trivial rigs, positions among the unknowns; skipped while the solves are short anyway.
-    static const bool want_defl = std::getenv("GSFM_DEFLATE") != nullptr;
+    // the gauge modes deflated from the PCG (CgDeflation, cg.hpp): trivial rigs, positions among the unknowns; skipped
+    // while the solves are short anyway (defl_on_, below)
     CgDeflation defl;
-    if (want_defl && !rig_ && ctx_->comm.world == 1 && g_.opt_c && defl_on_) {
+    if (!rig_ && g_.opt_c && defl_on_ && N_ > kCgSingleMaxBlocks) {
       const size_t n3 = 3 * (size_t)N_;
       defl.k = 4;
       double* W = ws->defl_w.ensure(4 * n3);
       defl.AW = ws->defl_aw.ensure(4 * n3);
       defl.b2 = ws->defl_b2.ensure(n3);
-      defl.part = ws->defl_part.ensure((size_t)kCgdBlocks * 2 * kCgMaxModes);
+      defl.part = ws->defl_part.ensure((size_t)kCgdBlocks * kCgdGram);
       defl.small = ws->defl_small.ensure(80);
+      defl.cd = ws->defl_cd.ensure((size_t)2 * kCgMaxBlocks * 2 * kCgMaxModes);
       hipLaunchKernelGGL(k_gp_defl_modes, dim3(gridN_), dim3(kBlock), 0, s, N_, (const double*)ci_, W);
       defl.W = W;
     }
@@ -1347,16 +1276,11 @@ class GpSolver final : public LmProblem {
         vk.z = ws->zimg.get();
         vk.w = ws->wimg.get();
       }
-      bool timed = ctx_->prof.begin(s, GSFM_KERNEL_GP_SCHUR);
-      static const bool chain = std::getenv("GSFM_GP_PHASEA_CHAIN") != nullptr;  // A/B switch, see k_gp_phaseA_chain
-      if (chain && (long)gridTile_ * (kBlock / 64) >= g_.g.T)
-        hipLaunchKernelGGL(k_gp_phaseA_chain, dim3(gridTile_), dim3(kBlock), 0, s, g_, vk, it, tol * tol, ws->cz.get(),
-                           ws->qa.get(), ws->qb.get(), ws->pth.get(), ws->ptrec.get());
-      else
-        hipLaunchKernelGGL(k_gp_phaseA, dim3(gridTile_), dim3(kBlock), 0, s, g_, vk, it, tol * tol, ws->cz.get(), ws->qa.get(),
-                           ws->qb.get(), ws->pth.get(), ws->ptrec.get());
+      bool timed = ctx_->prof.begin(s, GSFM_KERNEL_GP_SCHUR, it);
+      hipLaunchKernelGGL(k_gp_phaseA, dim3(gridTileA_), dim3(kBlock), 0, s, g_, vk, it, tol * tol, ws->cz.get(), ws->qa.get(),
+                         ws->qb.get(), ws->pth.get(), ws->ptrec.get());
       if (timed) ctx_->prof.end(s);
-      timed = ctx_->prof.begin(s, GSFM_KERNEL_GP_SCHUR_B);
+      timed = ctx_->prof.begin(s, GSFM_KERNEL_GP_SCHUR_B, it);
       // rigs: the damping D z is a frame-space term, added by k_rig_reduce_w (the sweep runs with a zero diagonal)
       const double* dk = rig_ ? ws->zero_i.get() : ws->dcam.get();
       const double ys = rig_ ? 0.0 : yscale;
@@ -1369,7 +1293,7 @@ class GpSolver final : public LmProblem {
       if (rig_)
         hipLaunchKernelGGL(k_rig_reduce_w, dim3(1), dim3(kBlock), 0, s, cg_, rg_, yscale, ws->wimg.get(), ws->dcam.get(),
                            gridCam_ + gridMulti_);
-    }, defl.k ? &defl : nullptr);
+    }, defl.k ? &defl : nullptr, &pcg_hint_);
     // deflation pays while a plain solve needs more than ~3 k iterations (iters includes the k applications for A W)
     defl_on_ = defl.k ? iters - defl.k > defl.k : iters > 3 * 4;
     return iters;
@@ -1389,7 +1313,9 @@ class GpSolver final : public LmProblem {
   double *ci_ = nullptr, *cin_ = nullptr;
   long P_ = 0, M_ = 0, m_used_ = 0;
   int gridP_ = 1, gridN_ = 1, gridM_ = 1, gridCam_ = 1, gridMulti_ = 0, gridTile_ = 1, gridTileP_ = 1;
-  bool defl_on_ = true;  // GSFM_DEFLATE experiment: deflate the next reduced solve (short solves run plain)
+  bool defl_on_ = true;  // deflate the next reduced solve (short solves run plain)
+  int pcg_hint_ = 0;     // iteration count of the previous reduced solve (where cg_solve first reads the status back)
+  int gridTileA_ = 1;    // k_gp_phaseA: exactly one wave per tile
   double *c_ = nullptr, *cn_ = nullptr, *X_ = nullptr, *Xn_ = nullptr, *s_ = nullptr, *sn_ = nullptr;
 };
 

@@ -148,7 +148,8 @@ class BundleAdjusterOptions:
     optimize_points: bool = True
     min_num_view_per_track: int = 3
     thres_loss_function: float = 1.0
-    solver_options: SolverOptions = field(default_factory=lambda: SolverOptions(max_num_iterations=200))
+    # reduced solves to 1e-6 (gsfm_ba_options_default): 3.3e-7 rad / 3e-6 from the exact-solve trajectory at configs[3]
+    solver_options: SolverOptions = field(default_factory=lambda: SolverOptions(max_num_iterations=200, pcg_relative_tolerance=1e-6))
 
     def to_c(self) -> _lib.BaOptions:
         o = _lib.BaOptions()

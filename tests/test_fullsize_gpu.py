@@ -99,6 +99,8 @@ def test_gp_config3_matches_cpu_oracle(gsfm_ctx):
     assert abs(rep["iterations"] - s.iterations) <= 3
     assert abs(rep["final_cost"] - s.final_cost) <= 1e-3 * s.final_cost
     d = synthetic.center_errors_after_sim3(cen, c_o)
+    print(f"\n[parity] GP configs[2]: LM {rep['iterations']} vs {s.iterations}, final cost {rep['final_cost']:.6f} vs {s.final_cost:.6f}, "
+          f"max centre distance GPU-oracle / extent = {d.max() / _extent(c_o):.3e} (bar 1e-3)")
     assert d.max() / _extent(c_o) < 1e-3
     # both recover the ground truth equally well
     e_g = synthetic.center_errors_after_sim3(cen, p.gt_center).max() / _extent(p.gt_center)
@@ -124,11 +126,37 @@ def test_ba_config4_matches_cpu_oracle(gsfm_ctx):
     assert abs(rep["iterations"] - s.iterations) <= 3
     assert abs(rep["final_cost"] - s.final_cost) <= 1e-3 * s.final_cost
     ang = np.radians(so3.rotation_angle_deg(so3.quat_to_rotmat(q), so3.quat_to_rotmat(r[1])))
-    assert ang.max() < 1e-4
     cg = -np.einsum("nji,nj->ni", so3.quat_to_rotmat(q), t)
     co = -np.einsum("nji,nj->ni", so3.quat_to_rotmat(r[1]), r[2])
-    assert np.linalg.norm(cg - co, axis=1).max() / _extent(co) < 1e-3
+    dc = np.linalg.norm(cg - co, axis=1).max() / _extent(co)
+    print(f"\n[parity] BA configs[3]: LM {rep['iterations']} vs {s.iterations}, final cost {rep['final_cost']:.3f} vs {s.final_cost:.3f}, "
+          f"max rotation distance {ang.max():.3e} rad (bar 1e-4), max centre distance / extent {dc:.3e} (bar 1e-3)")
+    assert ang.max() < 1e-4
+    assert dc < 1e-3
     assert np.abs(intr[:, 0] - r[4][:, 0]).max() < 1e-3 * 1200.0  # focal lengths
+
+
+def test_gp_config4_matches_cpu_oracle(gsfm_ctx):
+    """Global positioning at the size the headline times it — configs[3]: 10k cameras / 1M tracks / ~6.0M observations —
+    against the exact-solve CPU oracle on the same inputs and the same std::mt19937 start; same bars as at configs[2]
+    (test_gp_config3_matches_cpu_oracle explains the slack of 3 on the LM iteration count)."""
+    from oracle import cpu
+
+    p = synthetic.make_gp_problem(10_000, 1_000_000, seed=0)
+    rc, cen, xyz, rep = estimators.gp_solve(p, ctx=gsfm_ctx)
+    assert rc == 0
+    ok, c_o, X_o, s = cpu.gp_solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated, p.cam_center, p.pt_xyz)
+    assert ok and s.max_linear_residual < 1e-8
+    assert abs(rep["initial_cost"] - s.initial_cost) <= 1e-12 * s.initial_cost  # identical random start
+    d = synthetic.center_errors_after_sim3(cen, c_o)
+    print(f"\n[parity] GP configs[3] size: LM {rep['iterations']} vs {s.iterations}, final cost {rep['final_cost']:.6f} vs "
+          f"{s.final_cost:.6f}, max centre distance GPU-oracle / extent = {d.max() / _extent(c_o):.3e} (bar 1e-3)")
+    assert abs(rep["iterations"] - s.iterations) <= 3
+    assert abs(rep["final_cost"] - s.final_cost) <= 1e-3 * s.final_cost
+    assert d.max() / _extent(c_o) < 1e-3
+    e_g = synthetic.center_errors_after_sim3(cen, p.gt_center).max() / _extent(p.gt_center)
+    e_o = synthetic.center_errors_after_sim3(c_o, p.gt_center).max() / _extent(p.gt_center)
+    assert e_g < 2 * e_o + 1e-4
 
 
 def test_ra_config4_matches_cpu_oracle(gsfm_ctx):
@@ -144,6 +172,8 @@ def test_ra_config4_matches_cpu_oracle(gsfm_ctx):
                                           p.fixed_node, report=ro)
     assert ok and (rep["iterations_l1"], rep["iterations_irls"]) == (ro["l1_iterations"], ro["irls_iterations"])
     d = np.radians(so3.rotation_angle_deg(so3.aa_to_rotmat(rot), so3.aa_to_rotmat(rot_o)))
+    print(f"\n[parity] RA configs[3]: {rep['iterations_l1']} L1 + {rep['iterations_irls']} IRLS iterations both, "
+          f"max rotation distance GPU-oracle = {d.max():.3e} rad (bar 1e-6)")
     assert d.max() < 1e-6
 
 

@@ -53,6 +53,11 @@ class OracleBackend(RaOracleBackend):
         return (0 if r[0] else -6), r[1], r[2], r[3], r[4], rep
 
 
+@pytest.fixture
+def make_backend():
+    return OracleBackend
+
+
 def make_rig_scene(unknown, frames_n=14, cams=3, pts=600, seed=9):
     """2 rigs x `cams` cameras x 7 frames each (the reference's configuration), as scene containers."""
     gp, ba, info = synthetic.make_rig_problems(frames_n, cams, pts, seed=seed)
@@ -116,13 +121,13 @@ def _image_poses(rigs, frames, images):
 
 
 @pytest.mark.parametrize("unknown,cams,seed", [(False, 2, 7), (True, 3, 9)])
-def test_rig_scene_through_ra_gp_ba(unknown, cams, seed):
+def test_rig_scene_through_ra_gp_ba(unknown, cams, seed, make_backend):
     """Known rigs: 2 rigs x 2 cameras (global_mapper_test.cc:95-97); unknown rigs: 2 rigs x 3 cameras (:134-136).  (The
     calibrated 3-camera scene of seed 9 is not used: positioning with metric rig offsets stops at its function tolerance
     1 % away, and this bare chain — no track filtering, no retriangulation, one BA round — then parks bundle adjustment in
     a local minimum; the oracle and the HIP path agree on that too.)"""
     vg, rigs, cameras, frames, images, tracks, R_cw, c_gt = make_rig_scene(unknown, cams=cams, seed=seed)
-    be = OracleBackend()
+    be = make_backend()
     assert rav.SolveRotationAveraging(vg, rigs, frames, images, estimators.RotationEstimatorOptions(), backend=be)
     R_est, _ = _image_poses(rigs, frames, images)
     assert synthetic.rotation_errors_deg(R_est, R_cw).max() < 1e-2
@@ -148,7 +153,7 @@ def test_rig_scene_through_ra_gp_ba(unknown, cams, seed):
         assert abs(scale - 1.0) < 1e-4  # metric rig baselines fix the scale
 
 
-def test_bundle_adjuster_refuses_uncalibrated_sensors():
+def test_bundle_adjuster_refuses_uncalibrated_sensors(make_backend):
     vg, rigs, cameras, frames, images, tracks, _, _ = make_rig_scene(True, pts=100)
-    assert not mest.BundleAdjuster(estimators.BundleAdjusterOptions(), OracleBackend()).Solve(rigs, cameras, frames, images, tracks)
-    assert not mest.GlobalPositioner(estimators.GlobalPositionerOptions(), OracleBackend()).Solve(vg, rigs, cameras, frames, images, tracks)
+    assert not mest.BundleAdjuster(estimators.BundleAdjusterOptions(), make_backend()).Solve(rigs, cameras, frames, images, tracks)
+    assert not mest.GlobalPositioner(estimators.GlobalPositionerOptions(), make_backend()).Solve(vg, rigs, cameras, frames, images, tracks)

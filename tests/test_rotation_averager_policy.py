@@ -50,6 +50,13 @@ class OracleBackend:
         return otr.keep_largest_connected_component(num_nodes, edge_i, edge_j, edge_valid, node_num_images)
 
 
+@pytest.fixture
+def make_backend():
+    """Factory of the numerical backend of a scenario: the oracle here; tests/test_scene_level_gpu.py collects the SAME
+    test functions with a factory of the product backend (libgsfm on the GPU)."""
+    return OracleBackend
+
+
 def make_scene(num_frames=8, cams_per_rig=2, num_rigs=1, seed=0, reach=2, unknown=False, gravity=(), start="identity",
                stray=0):
     """Rig frames on a ring (headings 2 pi f / F plus a tilt), `cams_per_rig` sensors per rig; exact relative rotations
@@ -124,27 +131,27 @@ def _errors_deg(frames, rigs, images, R_img):
     return worst
 
 
-def test_trivial_rigs_without_gravity():
+def test_trivial_rigs_without_gravity(make_backend):
     vg, rigs, frames, images, R_img, _ = make_scene(10, 1)
-    be = OracleBackend()
+    be = make_backend()
     assert rav.SolveRotationAveraging(vg, rigs, frames, images, estimators.RotationEstimatorOptions(), backend=be)
     assert _errors_deg(frames, rigs, images, R_img) < 1e-2 and be.calls == ["plain"]
     assert all(np.array_equal(fr.rig_from_world.translation, np.zeros(3)) for fr in frames.values())  # gra.cc:788-798
 
 
 @pytest.mark.parametrize("use_gravity", [True, False])
-def test_known_rig_with_and_without_gravity(use_gravity):
+def test_known_rig_with_and_without_gravity(use_gravity, make_backend):
     """rotation_averager_test.cc:171-212: every frame has gravity, so more than 95 % of the pairs are gravity pairs and the
     stratified pre-solve is skipped (:47-51); with use_gravity the frames are 1-DoF unknowns from the R_align start."""
     vg, rigs, frames, images, R_img, _ = make_scene(8, 2, gravity=range(8), start="align")
-    be = OracleBackend()
+    be = make_backend()
     opt = estimators.RotationEstimatorOptions(use_gravity=use_gravity)
     assert rav.SolveRotationAveraging(vg, rigs, frames, images, opt, backend=be)
     assert _errors_deg(frames, rigs, images, R_img) < 1e-2
     assert be.calls == (["gravity"] if use_gravity else ["plain", "plain"])  # (spanning tree over the images, then the solve)
 
 
-def test_mixed_gravity_runs_the_stratified_pre_solve():
+def test_mixed_gravity_runs_the_stratified_pre_solve(make_backend):
     """Half of the frames have gravity: the 1-DoF system of the gravity pairs is solved first, then everything
     (rotation_averager.cc:17-63)."""
     vg, rigs, frames, images, R_img, _ = make_scene(12, 1, reach=3, gravity=range(0, 12, 2), start="align")
@@ -154,11 +161,11 @@ def test_mixed_gravity_runs_the_stratified_pre_solve():
         if not fr.HasGravity():
             R = so3.aa_to_rotmat(rng.normal(0, 0.05, (1, 3)))[0] @ R_img[f]
             fr.rig_from_world = Rigid3d(so3.rotmat_to_quat(R[None])[0], np.zeros(3))
-    be = OracleBackend()
+    be = make_backend()
     assert rav.SolveRotationAveraging(vg, rigs, frames, images, estimators.RotationEstimatorOptions(use_gravity=True), backend=be)
     assert be.calls == ["gravity", "gravity"]
     assert _errors_deg(frames, rigs, images, R_img) < 1e-2
-    be2 = OracleBackend()
+    be2 = make_backend()
     vg, rigs, frames, images, R_img, _ = make_scene(12, 1, reach=3, gravity=range(0, 12, 2), start="align")
     for f, fr in frames.items():
         if not fr.HasGravity():
@@ -168,12 +175,12 @@ def test_mixed_gravity_runs_the_stratified_pre_solve():
     assert be2.calls == ["gravity"]
 
 
-def test_unknown_rig_goes_through_the_trivial_pre_pass():
+def test_unknown_rig_goes_through_the_trivial_pre_pass(make_backend):
     """rotation_averager_test.cc:214-263: sensors without cam_from_rig -> every such image becomes a trivial frame for a
     first solve, ConvertRotationsFromImageToRig turns the image rotations into frame + cam_from_rig rotations, the real
     solve (cam blocks) starts from them (rotation_averager.cc:66-172)."""
     vg, rigs, frames, images, R_img, R_s = make_scene(8, 2, unknown=True)
-    be = OracleBackend()
+    be = make_backend()
     assert rav.SolveRotationAveraging(vg, rigs, frames, images, estimators.RotationEstimatorOptions(), backend=be)
     assert be.calls == ["plain", "cam_blocks"]  # pre-pass: all frames trivial, one plain solve; then the cam blocks
     assert _errors_deg(frames, rigs, images, R_img) < 1e-2
@@ -182,39 +189,39 @@ def test_unknown_rig_goes_through_the_trivial_pre_pass():
     assert so3.rotation_angle_deg(so3.quat_to_rotmat(np.asarray(cfr.rotation)[None]), R_s[0, 1][None])[0] < 1e-2
 
 
-def test_partly_calibrated_rig():
+def test_partly_calibrated_rig(make_backend):
     """Three sensors, the second calibrated, the third not: the pre-pass keeps the calibrated sensor in its rig (its
     cam_from_rig folded, image-level spanning tree) and gives only the third sensor's images frames of their own."""
     vg, rigs, frames, images, R_img, R_s = make_scene(8, 3, unknown={2})
-    be = OracleBackend()
+    be = make_backend()
     assert rav.SolveRotationAveraging(vg, rigs, frames, images, estimators.RotationEstimatorOptions(), backend=be)
     assert be.calls == ["plain", "plain", "cam_blocks"] and _errors_deg(frames, rigs, images, R_img) < 1e-2
     assert so3.rotation_angle_deg(so3.quat_to_rotmat(np.asarray(rigs[1].MaybeSensorFromRig(102).rotation)[None]), R_s[0, 2][None])[0] < 1e-2
     assert not np.isnan(rigs[1].MaybeSensorFromRig(101).translation).any()  # the calibrated sensor is left alone
 
 
-def test_estimator_alone_builds_the_start_for_unknown_sensors():
+def test_estimator_alone_builds_the_start_for_unknown_sensors(make_backend):
     """EstimateRotations without the controller: spanning tree over the images + ConvertRotationsFromImageToRig inside."""
     vg, rigs, frames, images, R_img, R_s = make_scene(8, 3, num_rigs=2, unknown=True, reach=3)
-    be = OracleBackend()
+    be = make_backend()
     est = rav.RotationEstimator(estimators.RotationEstimatorOptions(), be)
     assert est.EstimateRotations(vg, rigs, frames, images)
     assert be.calls == ["plain", "cam_blocks"] and _errors_deg(frames, rigs, images, R_img) < 1e-2
 
 
-def test_gravity_refuses_uncalibrated_rigs():
+def test_gravity_refuses_uncalibrated_rigs(make_backend):
     vg, rigs, frames, images, _, _ = make_scene(6, 2, unknown=True, gravity=range(6))
-    est = rav.RotationEstimator(estimators.RotationEstimatorOptions(use_gravity=True), OracleBackend())
+    est = rav.RotationEstimator(estimators.RotationEstimatorOptions(use_gravity=True), make_backend())
     assert not est.EstimateRotations(vg, rigs, frames, images)  # gra.cc:47-58
 
 
-def test_largest_component_unregisters_the_rest():
+def test_largest_component_unregisters_the_rest(make_backend):
     vg, rigs, frames, images, R_img, _ = make_scene(8, 1)
     # an island of two frames linked only to each other
     for f in (20, 21):
         frames[f] = Frame(f, Rigid3d(), True, 1, [f])
         images[f] = Image(f, 100, f)
     vg.image_pairs[(20, 21)] = ImagePair(20, 21, Rigid3d())
-    n = rav.KeepLargestConnectedComponents(vg, frames, images, OracleBackend())
+    n = rav.KeepLargestConnectedComponents(vg, frames, images, make_backend())
     assert n == 8 and not frames[20].is_registered and not frames[21].is_registered
     assert not vg.image_pairs[(20, 21)].is_valid and all(frames[f].is_registered for f in range(8))
