@@ -1561,36 +1561,18 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // w_frame (pose) = sum_images T_s^T w_image + D z_frame, w_sensor = sum_images U_i^T w_image + D z_sensor; intrinsics rows
-// copied; the damping share of delta goes to its own partial slot.  One workgroup: the number of frames is small.
+// copied; the damping share of delta goes to one partial slot per block.  Blocks [0, gf): frames and the intrinsics copy;
+// block gf + sb: sensor block sb.
 // v is the frame-space vector set: v.N = pose blocks (frames + sensor blocks).
 __global__ void __launch_bounds__(kBlock)
     k_ba_rig_reduce_w(CgVec v, RigDev rg, double yscale, const double* __restrict__ w_img, const double* __restrict__ dvec,
-                      int dslot) {
+                      int dslot, int gf) {
   __shared__ double smem[4 + 4 * 6];
   if (v.st->done) return;
   const double* sens = rg.sens;
   double d[1] = {0.0};
-  for (int f = threadIdx.x; f < rg.N; f += blockDim.x) {
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    for (int a = rg.foff[f]; a < rg.foff[f + 1]; ++a) {
-      const int im = rg.fimg[a];
-      const double* S = sens + 12 * (long)im;
-      const double* wi = w_img + 6 * (long)im;
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc[3 * h + j] += S[j] * wi[3 * h] + S[3 + j] * wi[3 * h + 1] + S[6 + j] * wi[3 * h + 2];
-    }
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const double z = v.z[6 * (long)f + j];
-      const double dz = yscale * dvec[6 * (long)f + j] * z;
-      v.w[6 * (long)f + j] = (frame_free(rg, f, j) ? acc[j] : 0.0) + dz;
-      d[0] += z * dz;
-    }
-  }
-  for (int i = threadIdx.x; i < 8 * v.K; i += blockDim.x) v.w[6 * (long)v.N + i] = w_img[6 * (long)rg.NI + i];
-  for (int sb = 0; sb < rg.S; ++sb) {
+  if ((int)blockIdx.x >= gf) {  // one block per sensor block
+    const int sb = blockIdx.x - gf;
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (int a = rg.soff[sb] + threadIdx.x; a < rg.soff[sb + 1]; a += blockDim.x) {
       const int im = rg.simg[a];
@@ -1613,10 +1595,33 @@ __global__ void __launch_bounds__(kBlock)
         v.w[o + j] = acc[j] + dz;
         d[0] += z * dz;
       }
+      v.dpart[dslot + blockIdx.x] = d[0];
+    }
+    return;
+  }
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gf * blockDim.x;
+  for (int f = tid; f < rg.N; f += nth) {  // frames: one thread each
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int a = rg.foff[f]; a < rg.foff[f + 1]; ++a) {
+      const int im = rg.fimg[a];
+      const double* S = sens + 12 * (long)im;
+      const double* wi = w_img + 6 * (long)im;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[3 * h + j] += S[j] * wi[3 * h] + S[3 + j] * wi[3 * h + 1] + S[6 + j] * wi[3 * h + 2];
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const double z = v.z[6 * (long)f + j];
+      const double dz = yscale * dvec[6 * (long)f + j] * z;
+      v.w[6 * (long)f + j] = (frame_free(rg, f, j) ? acc[j] : 0.0) + dz;
+      d[0] += z * dz;
     }
   }
+  for (int i = tid; i < 8 * v.K; i += nth) v.w[6 * (long)v.N + i] = w_img[6 * (long)rg.NI + i];
   block_sum<1>(d, smem);
-  if (threadIdx.x == 0) v.dpart[dslot] = d[0];
+  if (threadIdx.x == 0) v.dpart[dslot + blockIdx.x] = d[0];
 }
 
 class BaSolver final : public LmProblem {
@@ -1905,7 +1910,7 @@ class BaSolver final : public LmProblem {
     cg_.zrec_slot = joint_ ? ws->intr_slot.get() : nullptr;
     cg_.joint_map = joint_ ? ws->cam_intr.get() : nullptr;
     cg_.minv_joint = joint_ ? ws->minvj.get() : nullptr;
-    cg_.nb_apply = gridCam_ + gridK_ + gridMulti_ + (rig_ ? 1 : 0);  // per-block | phase-I | combine pass | rig damping share
+    cg_.nb_apply = gridCam_ + gridK_ + gridMulti_ + (rig_ ? gridN_ + S_ : 0);  // per-block | phase-I | combine pass | rig damping shares
     cg_.b = ws->rhs.get();
     cg_.x = ws->cg_x.get();
     cg_.r = ws->cg_r.get();
@@ -1915,7 +1920,7 @@ class BaSolver final : public LmProblem {
     cg_.w = ws->cg_w.get();
     cg_.minv = ws->minv.get();
     cg_.vpart = ws->vpart.get();
-    cg_.dpart = ws->dpart.get();
+    cg_.dpart = ws->dpart.ensure(std::max((size_t)2 * kMaxApplySlots, (size_t)cg_.nb_apply + 8));
     cg_.scal = ws->cgsc.get();
     cg_.st = ws->cgst.get();
   }
@@ -2175,8 +2180,8 @@ class BaSolver final : public LmProblem {
         hipLaunchKernelGGL(k_ba_phaseI, dim3(gridK_), dim3(kBlock), 0, s, g_, vk, yscale, ws->yi_part.get(), dk, gridCam_);
       }
       if (rig_)
-        hipLaunchKernelGGL(k_ba_rig_reduce_w, dim3(1), dim3(kBlock), 0, s, cg_, rg_, yscale, ws->wimg.get(), ws->dvec.get(),
-                           gridCam_ + gridK_ + gridMulti_);
+        hipLaunchKernelGGL(k_ba_rig_reduce_w, dim3(gridN_ + S_), dim3(kBlock), 0, s, cg_, rg_, yscale, ws->wimg.get(), ws->dvec.get(),
+                           gridCam_ + gridK_ + gridMulti_, gridN_);
     }, defl.k ? &defl : nullptr, &pcg_hint_);
     // deflation pays while a plain solve needs more than ~3 k iterations (iters includes the k applications for A W)
     defl_on_ = defl.k ? iters - defl.k > defl.k : iters > 3 * 7;

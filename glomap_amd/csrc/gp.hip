@@ -761,16 +761,16 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // w_frame = sum over the frame's images of w_image + D_frame z_frame (the image-space sweep ran without the damping
-// term); the damping share of delta, sum_f z_f . D_f z_f, goes to its own partial slot.  One workgroup: N is small.
+// term); the damping share of delta, sum_f z_f . D_f z_f, goes to one partial slot per block.  Blocks [0, gf): frames,
+// one thread each; block gf + sb: sensor block sb (w_sensor = sum R_rig w_image + D z).
 __global__ void __launch_bounds__(kBlock)
     k_rig_reduce_w(CgVec v, GpRig rg, double yscale, const double* __restrict__ w_img, const double* __restrict__ dcam,
-                   int dslot) {
+                   int dslot, int gf) {
   __shared__ double smem[4 + 4 * 3];
   if (v.st->done) return;
-  const int* foff = rg.foff;
-  const int* fimg = rg.fimg;
   double d[1] = {0.0};
-  for (int sb = 0; sb < rg.S; ++sb) {  // w_sensor = sum R_rig w_image + D z
+  if ((int)blockIdx.x >= gf) {
+    const int sb = blockIdx.x - gf;
     double acc[3] = {0, 0, 0};
     for (int a = rg.soff[sb] + threadIdx.x; a < rg.soff[sb + 1]; a += blockDim.x) {
       const int im = rg.simg[a];
@@ -789,9 +789,13 @@ __global__ void __launch_bounds__(kBlock)
         v.w[o + j] = acc[j] + dz;
         d[0] += z * dz;
       }
+      v.dpart[dslot + blockIdx.x] = d[0];
     }
+    return;
   }
-  for (int f = threadIdx.x; f < rg.N; f += blockDim.x) {
+  const int* foff = rg.foff;
+  const int* fimg = rg.fimg;
+  for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < rg.N; f += gf * blockDim.x) {
     double acc[3] = {0, 0, 0};
     for (int a = foff[f]; a < foff[f + 1]; ++a) {
       const double* sp = w_img + 3 * (long)fimg[a];
@@ -808,7 +812,7 @@ __global__ void __launch_bounds__(kBlock)
     }
   }
   block_sum<1>(d, smem);
-  if (threadIdx.x == 0) v.dpart[dslot] = d[0];
+  if (threadIdx.x == 0) v.dpart[dslot + blockIdx.x] = d[0];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1088,7 +1092,8 @@ class GpSolver final : public LmProblem {
     cg_.zmir_stride = 6;
     cg_.zmir_off = 3;
     if (rig_) {
-      cg_.nb_apply = gridCam_ + gridMulti_ + 1;  // + the damping share of delta (k_rig_reduce_w)
+      cg_.nb_apply = gridCam_ + gridMulti_ + gridN_ + S_;  // + the damping shares of delta (k_rig_reduce_w: one per block)
+      cg_.dpart = ws->dpart.ensure(std::max((size_t)2 * kMaxApplySlots, (size_t)cg_.nb_apply + 8));
     }
   }
 
@@ -1291,8 +1296,8 @@ class GpSolver final : public LmProblem {
                            ws->c_qb.get(), ws->ptrec.get(), dk, gridCam_);
       if (timed) ctx_->prof.end(s);
       if (rig_)
-        hipLaunchKernelGGL(k_rig_reduce_w, dim3(1), dim3(kBlock), 0, s, cg_, rg_, yscale, ws->wimg.get(), ws->dcam.get(),
-                           gridCam_ + gridMulti_);
+        hipLaunchKernelGGL(k_rig_reduce_w, dim3(gridN_ + S_), dim3(kBlock), 0, s, cg_, rg_, yscale, ws->wimg.get(), ws->dcam.get(),
+                           gridCam_ + gridMulti_, gridN_);
     }, defl.k ? &defl : nullptr, &pcg_hint_);
     // deflation pays while a plain solve needs more than ~3 k iterations (iters includes the k applications for A W)
     defl_on_ = defl.k ? iters - defl.k > defl.k : iters > 3 * 4;

@@ -60,9 +60,9 @@ struct ObsGraph {  // device view, passed to kernels by value
   const int* seg_k = nullptr;          // [S+1] first camera-major slot of the segment (seg_k[S] = Mu)
   const int* seg_first = nullptr;      // [S]   first segment of this segment's camera
   const int* seg_cnt = nullptr;        // [S]   number of segments of this segment's camera
-  const int* seg_multi = nullptr;      // [S]   index of the camera among the cut ones, -1 for whole cameras
+  const int* seg_multi = nullptr;      // [S]   slot of the segment among the slices of cut cameras (consecutive per camera), -1 for whole cameras
   const int* multi_first = nullptr;    // [nmulti] first segment of each cut camera
-  double* segpart = nullptr;           // [S][kSegPartW] partial sums of cut cameras
+  double* segpart = nullptr;           // [#slices of cut cameras][kSegPartW] parked partial sums (slot: seg_multi)
   int pass = 0;                        // 0: sweep over the segments; 1: combine pass over the cut cameras (see cam_seg_*)
 };
 
@@ -129,14 +129,14 @@ __device__ __forceinline__ bool cam_seg_total(const ObsGraph& g, int sg, double 
   if (g.pass == 0) {
     if (cnt == 1) return true;
     if (lane == 0) {
-      double* dst = g.segpart + (size_t)sg * kSegPartW;
+      double* dst = g.segpart + (size_t)g.seg_multi[sg] * kSegPartW;
 #pragma unroll
       for (int j = 0; j < W; ++j) dst[j] = acc[j];
     }
     return false;
   }
   if (lane == 0) {
-    const double* src = g.segpart + (size_t)sg * kSegPartW;  // sg = the camera's first segment in pass 1
+    const double* src = g.segpart + (size_t)g.seg_multi[sg] * kSegPartW;  // sg = the camera's first segment in pass 1
 #pragma unroll
     for (int j = 0; j < W; ++j) acc[j] = 0.0;
     for (int q = 0; q < cnt; ++q) {
@@ -277,7 +277,7 @@ inline long build_obs_graph(gsfm_ctx* ctx, ObsGraphWs& ws, int N, long P, long M
     }
     // host layout: 5 arrays back to back (cam | k | first | cnt | multi), S + 1 entries each
     std::vector<int> cam, k0, first, cnt, multi, mfirst;
-    int nmulti = 0;
+    int nmulti = 0, nslots = 0;
     for (int n = 0; n < N; ++n) {
       const int len = co[n + 1] - co[n];
       const int c = len > seg_len ? (len + seg_len - 1) / seg_len : 1;
@@ -287,7 +287,7 @@ inline long build_obs_graph(gsfm_ctx* ctx, ObsGraphWs& ws, int N, long P, long M
         k0.push_back(co[n] + (int)(((long)len * q) / c));  // equal slices
         first.push_back(f);
         cnt.push_back(c);
-        multi.push_back(c > 1 ? nmulti : -1);
+        multi.push_back(c > 1 ? nslots++ : -1);
       }
       if (c > 1) {
         mfirst.push_back(f);
@@ -304,7 +304,7 @@ inline long build_obs_graph(gsfm_ctx* ctx, ObsGraphWs& ws, int N, long P, long M
     ws.multi_first.ensure(nmulti + 1);
     if (nmulti > 0)
       GSFM_HIP_CHECK(hipMemcpyAsync(ws.multi_first.get(), mfirst.data(), (size_t)nmulti * sizeof(int), hipMemcpyHostToDevice, s));
-    ws.segpart.ensure(nmulti > 0 ? (size_t)S * kSegPartW : 1);
+    ws.segpart.ensure(std::max((size_t)1, (size_t)nslots * kSegPartW));  // only slices of cut cameras park sums
     GSFM_HIP_CHECK(hipStreamSynchronize(s));  // the host vectors above go out of scope
     g.S = S;
     g.nmulti = nmulti;

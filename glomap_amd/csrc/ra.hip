@@ -1186,6 +1186,7 @@ void setup_device(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
   d.ws = ws;
   d.N = N;
   d.E = E;
+  GSFM_REQUIRE(prob->fixed_node >= 0 && prob->fixed_node < N, "RA: fixed_node out of range");  // (every entry point lands here)
   d.fixed = prob->fixed_node;
   d.has_gauge = ctx->comm.rank == 0 ? 1 : 0;
   d.lpr = choose_lpr(E, N);

@@ -46,8 +46,10 @@ def _q(R) -> np.ndarray:
     return so3.rotmat_to_quat(np.asarray(R)[None])[0]
 
 
-def _pack_tracks(images, frames, tracks, node, min_views, keep):
-    """Track-major observations; `min_views` is tested on the RAW observation count (gp.cc:258, ba.cc:122)."""
+def _pack_tracks(images, frames, tracks, node, min_views, keep, keep_empty=False):
+    """Track-major observations; `min_views` is tested on the RAW observation count (gp.cc:258, ba.cc:122).  keep_empty
+    (global positioning): a track that passes the raw count without one usable observation stays as a zero-length track —
+    the reference still draws its random start and marks it initialised (gp.cc:258-264)."""
     tids, off, oimg, ofeat = [], [0], [], []
     for tid, tr in tracks.items():
         if len(tr.observations) < min_views:
@@ -58,7 +60,7 @@ def _pack_tracks(images, frames, tracks, node, min_views, keep):
                 continue
             oimg.append(iid)
             ofeat.append(feat)
-        if len(oimg) == n0:
+        if len(oimg) == n0 and not keep_empty:
             continue
         tids.append(tid)
         off.append(len(oimg))
@@ -87,8 +89,8 @@ class GlobalPositioner:
         def keep(im, feat):  # gp.cc:279-292
             return is_registered(im, frames) and not np.isnan(im.features_undist[feat]).any()
 
-        tids, off, oimg, ofeat = _pack_tracks(images, frames, tracks, node, o.min_num_view_per_track, keep)
-        if not tids:
+        tids, off, oimg, ofeat = _pack_tracks(images, frames, tracks, node, o.min_num_view_per_track, keep, keep_empty=True)
+        if not tids or not oimg:
             return False
         rigged = any(not has_trivial_frame(images[i], frames, rigs) for i in set(oimg))
         R_f = {f: _R(frames[f].rig_from_world.rotation) for f in fids}
@@ -137,7 +139,8 @@ class GlobalPositioner:
                 p.image_sensor = np.array([block[image_key[i]] if image_state[i] == 1 else -1 for i in range(len(image_key))], np.int32)
                 p.image_sensor_rot = np.asarray(image_rot, np.float64).reshape(-1, 3, 3)
                 p.sensor_center = np.zeros((len(sensor_ids), 3))
-        opt = GlobalPositionerOptions(**{**vars(o), "min_num_view_per_track": 1})  # the raw-count rule is applied above
+        # the raw-count rule is applied above; with 0 every packed track — the zero-length ones too — takes its random draw
+        opt = GlobalPositionerOptions(**{**vars(o), "min_num_view_per_track": 0})
         rc, cen_out, xyz_out, self.report = self.backend.gp_solve(p, opt)
         if rc != 0:
             return False
@@ -148,7 +151,8 @@ class GlobalPositioner:
             rigs[rid].SetSensorFromRig(cam_id, Rigid3d(np.asarray(cfr.rotation), -_R(cfr.rotation) @ self.report["sensor_center"][b]))
         for t, x in zip(tids, xyz_out):
             tracks[t].xyz = np.array(x)
-            tracks[t].is_initialized = True  # gp.cc:262-263
+            if o.optimize_points and o.generate_random_points:
+                tracks[t].is_initialized = True  # gp.cc:261-264
         return True
 
 

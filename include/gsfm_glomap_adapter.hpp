@@ -262,12 +262,15 @@ struct TrackPack {
 
 // `min_views` is tested on the RAW observation count like the reference does (track.observations.size(), gp.cc:258 /
 // ba.cc:122) — BEFORE unregistered images / failed undistortions are dropped — so a track with 3 raw observations of
-// which one is unusable is still optimised.  Shorter tracks are not packed at all (the estimators leave them untouched);
-// the library is then called with min_num_view_per_track = 1.
+// which one is unusable is still optimised.  Shorter tracks are not packed at all (the estimators leave them untouched).
+// keep_empty (global positioning): a track that passes the raw count but has NO usable observation is packed as a
+// zero-length track — the reference still draws its random start and marks it initialised (gp.cc:258-264), so it has
+// to take its turn in the random stream; the library is then called with min_num_view_per_track = 0 (every packed
+// track is "used").  Bundle adjustment drops such tracks (nothing happens to them in ba.cc:121-133) and calls with 1.
 template <typename Keep>
 inline TrackPack PackTracks(std::unordered_map<image_t, glomap::Image>& images,
                             std::unordered_map<track_t, glomap::Track>& tracks, FrameIndex& fidx, Keep keep,
-                            size_t min_views = 0) {
+                            size_t min_views = 0, bool keep_empty = false) {
   TrackPack tp;
   for (auto& [tid, track] : tracks) {
     if (track.observations.size() < min_views) continue;
@@ -279,7 +282,7 @@ inline TrackPack PackTracks(std::unordered_map<image_t, glomap::Image>& images,
       tp.obs_image.push_back(obs.first);
       tp.obs_feature.push_back(obs.second);
     }
-    if (tp.obs_cam.size() == before) continue;
+    if (tp.obs_cam.size() == before && !keep_empty) continue;
     tp.track_ids.push_back(tid);
     tp.pt_offset.push_back(static_cast<int64_t>(tp.obs_cam.size()));
   }
@@ -716,10 +719,11 @@ class GlobalPositioner {
       const auto& v = im.features_undist[f];
       return !(std::isnan(v[0]) || std::isnan(v[1]) || std::isnan(v[2]));
     };
-    detail::TrackPack tp = detail::PackTracks(images, tracks, fidx, keep, static_cast<size_t>(options_.min_num_view_per_track));
+    detail::TrackPack tp = detail::PackTracks(images, tracks, fidx, keep, static_cast<size_t>(options_.min_num_view_per_track),
+                                              /*keep_empty=*/true);
     const int N = static_cast<int>(fidx.ids.size());
     const int64_t P = static_cast<int64_t>(tp.track_ids.size()), M = static_cast<int64_t>(tp.obs_cam.size());
-    if (P == 0) return false;
+    if (P == 0 || M == 0) return false;
     std::vector<double> dir(3 * static_cast<size_t>(M)), cen(3 * static_cast<size_t>(N)), xyz(3 * static_cast<size_t>(P));
     std::vector<uint8_t> cal(static_cast<size_t>(M));
     // known rigs (gp.cc:318-350, RigBATAPairwiseDirectionError with the rig scale constant at 1, :470-478): images become
@@ -793,7 +797,7 @@ class GlobalPositioner {
     o.optimize_positions = options_.optimize_positions;
     o.optimize_points = options_.optimize_points;
     o.optimize_scales = options_.optimize_scales;
-    o.min_num_view_per_track = 1;  // the raw-count rule was applied by PackTracks
+    o.min_num_view_per_track = 0;  // the raw-count rule was applied by PackTracks; zero-length tracks take their draw
     o.seed = options_.seed;
     gsfm_gp_problem pr{};
     pr.mem = GSFM_MEM_HOST;
@@ -834,7 +838,7 @@ class GlobalPositioner {
     for (int64_t p = 0; p < P; ++p) {  // every packed track passed the raw-count rule (gp.cc:258)
       auto& tr = tracks.at(tp.track_ids[p]);
       tr.xyz = decltype(tr.xyz)(xyz[3 * p], xyz[3 * p + 1], xyz[3 * p + 2]);
-      tr.is_initialized = true;  // gp.cc:262-263
+      if (options_.optimize_points && options_.generate_random_points) tr.is_initialized = true;  // gp.cc:261-264
     }
     return true;
   }

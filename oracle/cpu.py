@@ -19,6 +19,7 @@ parity unpinned: see oracle/__init__.py.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import subprocess
 from dataclasses import dataclass
 from pathlib import Path
@@ -225,6 +226,29 @@ def _fill_lm(o, lmo: _lm.LmOptions, pcg_tol, pcg_max, order, verbose):
     o.verbose = int(verbose)
 
 
+class _deflate_env:
+    """`deflate` of gp_solve / ba_solve: the gauge modes deflated from the reduced solves (ORC_DEFLATE, read per solve by
+    orc_gp.cc / orc_ba.cc) — same systems, same tolerance, fewer operator applications; what libgsfm does by default."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = os.environ.get("ORC_DEFLATE")
+        if self.mode:
+            os.environ["ORC_DEFLATE"] = str(int(self.mode))
+        elif self.mode is not None:
+            os.environ.pop("ORC_DEFLATE", None)
+
+    def __exit__(self, *a):
+        if self.mode is None:
+            return
+        if self.prev is None:
+            os.environ.pop("ORC_DEFLATE", None)
+        else:
+            os.environ["ORC_DEFLATE"] = self.prev
+
+
 def _summary(rep) -> CpuSummary:
     return CpuSummary(rep.iterations, rep.successful_steps, rep.linear_iterations, rep.initial_cost, rep.final_cost,
                       rep.termination, bool(rep.usable), rep.max_linear_residual, rep.seconds_total, rep.seconds_linear,
@@ -234,7 +258,7 @@ def _summary(rep) -> CpuSummary:
 def gp_solve(num_cams, pt_offset, obs_cam, obs_dir, obs_calibrated, cam_center, pt_xyz,
              options: _gp.GlobalPositionerOptions | None = None, threads: int = 0, pcg_tol: float = 1e-14,
              pcg_max: int = 20000, order: int = 0, verbose: bool = False, image_frame=None, image_offset=None,
-             image_sensor=None, image_sensor_rot=None, sensor_center=None):
+             image_sensor=None, image_sensor_rot=None, sensor_center=None, deflate=None):
     """Same contract as oracle.gp.solve: returns (ok, cam_center [N,3], pt_xyz [P,3], CpuSummary); with unknown
     cam_from_rig centres the summary carries the estimates as summary.sensor_center."""
     opt = options or _gp.GlobalPositionerOptions()
@@ -257,12 +281,13 @@ def gp_solve(num_cams, pt_offset, obs_cam, obs_dir, obs_calibrated, cam_center, 
     ims = None if image_sensor is None else np.ascontiguousarray(image_sensor, dtype=np.int32)
     imr = None if image_sensor is None else np.ascontiguousarray(image_sensor_rot, dtype=np.float64)
     sc = None if image_sensor is None else np.array(sensor_center, dtype=np.float64, copy=True, order="C")
-    rc = lib.orc_gp_solve(C.c_int32(int(num_cams)), C.c_int64(off.shape[0] - 1), _p(off, C.c_int64), _p(cam, C.c_int32),
-                          _p(v, C.c_double), None if cal is None else _p(cal, C.c_uint8), C.byref(o), _p(c, C.c_double),
-                          _p(X, C.c_double), C.byref(rep), C.c_int32(_threads(threads)),
-                          None if imf is None else _p(imf, C.c_int32), None if imo is None else _p(imo, C.c_double),
-                          C.c_int32(0 if sc is None else sc.shape[0]), None if ims is None else _p(ims, C.c_int32),
-                          None if imr is None else _p(imr, C.c_double), None if sc is None else _p(sc, C.c_double))
+    with _deflate_env(deflate):
+        rc = lib.orc_gp_solve(C.c_int32(int(num_cams)), C.c_int64(off.shape[0] - 1), _p(off, C.c_int64), _p(cam, C.c_int32),
+                              _p(v, C.c_double), None if cal is None else _p(cal, C.c_uint8), C.byref(o), _p(c, C.c_double),
+                              _p(X, C.c_double), C.byref(rep), C.c_int32(_threads(threads)),
+                              None if imf is None else _p(imf, C.c_int32), None if imo is None else _p(imo, C.c_double),
+                              C.c_int32(0 if sc is None else sc.shape[0]), None if ims is None else _p(ims, C.c_int32),
+                              None if imr is None else _p(imr, C.c_double), None if sc is None else _p(sc, C.c_double))
     s = _summary(rep)
     if rc == -5:
         s.usable = False
@@ -274,7 +299,7 @@ def gp_solve(num_cams, pt_offset, obs_cam, obs_dir, obs_calibrated, cam_center, 
 def ba_solve(num_cams, pt_offset, obs_cam, obs_xy, cam_intr, intr_model, fixed_cam, cam_q, cam_t, pt_xyz, intr_params,
              options: _ba.BundleAdjusterOptions | None = None, threads: int = 0, pcg_tol: float = 1e-14,
              pcg_max: int = 20000, order: int = 0, verbose: bool = False, image_frame=None, image_cam_from_rig=None,
-             image_intr=None, image_sensor=None, sensor_cam_from_rig=None):
+             image_intr=None, image_sensor=None, sensor_cam_from_rig=None, deflate=None):
     """Same contract as oracle.ba.solve: returns (ok, q [N,4], t [N,3], X [P,3], intr [K,8], CpuSummary); with sensor
     blocks (options.optimize_rig_poses) the summary carries their result as summary.sensor_cam_from_rig."""
     opt = options or _ba.BundleAdjusterOptions()
@@ -300,13 +325,14 @@ def ba_solve(num_cams, pt_offset, obs_cam, obs_xy, cam_intr, intr_model, fixed_c
     X = np.array(pt_xyz, dtype=np.float64, copy=True, order="C")
     intr = np.array(intr_params, dtype=np.float64, copy=True, order="C")
     rep = _Report()
-    rc = lib.orc_ba_solve(C.c_int32(int(num_cams)), C.c_int32(mdl.shape[0]), C.c_int32(int(fixed_cam)),
-                          C.c_int64(off.shape[0] - 1), _p(off, C.c_int64), _p(cam, C.c_int32), _p(xy, C.c_double),
-                          _p(ci, C.c_int32), _p(mdl, C.c_int32), C.byref(o), _p(q, C.c_double), _p(t, C.c_double),
-                          _p(X, C.c_double), _p(intr, C.c_double), C.byref(rep), C.c_int32(_threads(threads)),
-                          None if imf is None else _p(imf, C.c_int32), None if imc is None else _p(imc, C.c_double),
-                          None if imi is None else _p(imi, C.c_int32), C.c_int32(0 if sen is None else sen.shape[0]),
-                          None if ims is None else _p(ims, C.c_int32), None if sen is None else _p(sen, C.c_double))
+    with _deflate_env(deflate):
+        rc = lib.orc_ba_solve(C.c_int32(int(num_cams)), C.c_int32(mdl.shape[0]), C.c_int32(int(fixed_cam)),
+                              C.c_int64(off.shape[0] - 1), _p(off, C.c_int64), _p(cam, C.c_int32), _p(xy, C.c_double),
+                              _p(ci, C.c_int32), _p(mdl, C.c_int32), C.byref(o), _p(q, C.c_double), _p(t, C.c_double),
+                              _p(X, C.c_double), _p(intr, C.c_double), C.byref(rep), C.c_int32(_threads(threads)),
+                              None if imf is None else _p(imf, C.c_int32), None if imc is None else _p(imc, C.c_double),
+                              None if imi is None else _p(imi, C.c_int32), C.c_int32(0 if sen is None else sen.shape[0]),
+                              None if ims is None else _p(ims, C.c_int32), None if sen is None else _p(sen, C.c_double))
     s = _summary(rep)
     if rc == -5:
         s.usable = False

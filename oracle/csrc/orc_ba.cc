@@ -514,7 +514,7 @@ struct Ba : LmProblem {
     // anchors six of them with a stiffness of O(1/N), the scale only through the LM damping.
     // ORC_DEFLATE=6 leaves the scale out: it is an EXACT gauge of the cost (held by the LM damping alone), so "solving"
     // its component divides rounding noise by the damping and sends the iterate along the gauge.
-    static const int deflate = std::getenv("ORC_DEFLATE") ? std::atoi(std::getenv("ORC_DEFLATE")) : 0;
+    const int deflate = std::getenv("ORC_DEFLATE") ? std::atoi(std::getenv("ORC_DEFLATE")) : 0;  // (read per solve)
     std::vector<std::vector<double>> W;
     if (deflate && S == 0 && defl_on) {  // like ba.hip: short (strongly damped) solves run undeflated
       W.assign(deflate == 6 ? 6 : 7, std::vector<double>(nred, 0.0));

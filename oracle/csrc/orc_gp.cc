@@ -426,7 +426,7 @@ struct Gp : LmProblem {
     // experiment (ORC_DEFLATE, tools/exp_deflation.py): deflate the four gauge modes of global positioning — world
     // translation (dc_n = a) and scale (dc_n = c_n) — from the PCG.  Nothing anchors them but the LM damping (no frame is
     // constant, gp.cc:437-439), so the PCG drops them again when W^T A W cannot be inverted.
-    static const bool deflate = std::getenv("ORC_DEFLATE") != nullptr;
+    const bool deflate = std::getenv("ORC_DEFLATE") != nullptr;  // (read per solve: oracle.cpu toggles it between legs)
     std::vector<std::vector<double>> W;
     if (deflate && S == 0 && mc != 0.0 && defl_on) {  // like gp.hip: short solves run undeflated
       W.assign(4, std::vector<double>(3 * N, 0.0));
