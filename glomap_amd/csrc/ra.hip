@@ -31,6 +31,7 @@
 #include "device.hpp"
 #include "dump.hpp"
 #include "ra_dense.hpp"
+#include "ra_sub.hpp"
 
 namespace gsfm {
 namespace {
@@ -629,6 +630,11 @@ struct RaWs {
   DevBuf<double> dense_a, dense_b, dense_pinv, rot_out;
   DevBuf<float> bd_inv;
   DevBuf<int> order;
+  // substructured preconditioner (ra_sub.hpp)
+  DevBuf<double> sub_a, sub_b, sub_pinv, sub_work, sub_y, sub_t;
+  DevBuf<int> sub_ioff, sub_ipad, sub_rowblk, sub_tz, sub_coff, sub_goff, sub_cloc, sub_gloc, sub_eoff, sub_ec, sub_eg, sub_eslot;
+  DevBuf<long> sub_invoff, sub_woff;
+  DevBuf<unsigned char> sub_inc;
   DevBuf<double> eq, ew, inc_w, lap_diag, lap_diag_loc, rot, nq, res, wirls, z, u, dz, rhs, x, r, wbuf,
       gat_s, gat_t, fixed_rot0, part_misc, z2, u2, scal, cg_b, cg_x, cg_r, cg_z, cg_p, cg_s, cg_w, cg_minv, vpart, dpart;
   DevBuf<CgStatus> cgst;
@@ -757,6 +763,11 @@ struct RaDevice {
   int bd_base_iters = 0;   // iterations of the first cold solve with a matching preconditioner (stale budget = 2.5x)
   int bd_skip_stale = 0;   // after a stale preconditioner ran out of budget: re-invert directly for this many solves
   int bd_nb = 0, bd_nblk = 0;
+  // ... with the interface between the blocks eliminated exactly (ra_sub.hpp) when it is small enough
+  bool sub = false;
+  SubPlan plan;
+  SubDev sd;
+  SubCouple sc;
   bool dense_always_factor = false;  // GSFM_RA_DENSE_REFACTOR=1: re-invert for every new weighting (the round-1 behaviour)
   int Np = 0, T = 0;          // padded size, tiles per side
   double* dense_inv = nullptr;
@@ -783,7 +794,8 @@ int choose_lpr(long E, int N) {
 }
 
 // Builds the CSR-by-node incidence structure on the host (counting sort, O(E)) and uploads it.
-void build_incidence(RaDevice& d, const int* h_ei, const int* h_ej) {
+void build_incidence(RaDevice& d, const int* h_ei, const int* h_ej, std::vector<int>* keep_rowptr = nullptr,
+                     std::vector<int>* keep_nbr = nullptr) {
   const int N = d.N;
   const long E = d.E;
   GSFM_REQUIRE(2 * E < (1L << 31), "RA: 2*num_edges must fit int32");
@@ -815,6 +827,8 @@ void build_incidence(RaDevice& d, const int* h_ei, const int* h_ej) {
   if (d.dense || d.blockdense)
     GSFM_HIP_CHECK(hipMemcpyAsync(ws->inc_row.ensure(2 * E + 1), inc_row.data(), 2 * E * sizeof(int), hipMemcpyHostToDevice, s));
   GSFM_HIP_CHECK(hipStreamSynchronize(s));  // host vectors go out of scope
+  if (keep_rowptr) keep_rowptr->swap(rowptr);
+  if (keep_nbr) keep_nbr->swap(nbr);
 }
 
 // Solves (L_w (x) I3 + gauge) x = rhs with the weights currently in ws->inc_w / lap_diag.
@@ -832,14 +846,14 @@ void dense_factor(RaDevice& d) {
   hipLaunchKernelGGL(k_dense_fill_offdiag, dim3(grid_for(2 * d.E, kBlock)), dim3(kBlock), 0, s, 2 * d.E,
                      ws->inc_row.get(), ws->nbr.get(), ws->inc_w.get(), Np, cur);
   hipLaunchKernelGGL(k_dense_fill_diag, dim3(grid_for(Np, kBlock)), dim3(kBlock), 0, s, d.N, Np, ws->lap_diag.get(), Np, cur);
-  hipLaunchKernelGGL(k_dense_pivot0, dim3(1), dim3(kBlock), 0, s, cur, Np, pinv);
+  hipLaunchKernelGGL(k_gj_pivot0, dim3(1), dim3(kBlock), 0, s, cur, Np, (size_t)0, pinv);
   for (int k = 0; k < T; ++k) {
     const bool timed = d.ctx->prof.begin(s, GSFM_KERNEL_RA_GJ);
-    hipLaunchKernelGGL(k_dense_gj_step, dim3(T, T), dim3(kBlock), 0, s, cur, oth, Np, T, k,
-                       pinv + (k & 1) * kTile * kTile, pinv + ((k + 1) & 1) * kTile * kTile);
+    hipLaunchKernelGGL(k_gj_sweep_step, dim3(gj_tiles(T)), dim3(kBlock), 0, s, cur, oth, Np, (size_t)0, (const int*)nullptr, T, k, pinv);
     if (timed) d.ctx->prof.end(s);
     std::swap(cur, oth);
   }
+  hipLaunchKernelGGL(k_gj_finish_full, dim3(grid_wide(nn, kBlock, 1 << 12)), dim3(kBlock), 0, s, cur, Np, Np);
   if (d.ctx->prof.enabled) {
     GSFM_HIP_CHECK(hipStreamSynchronize(s));
     d.ctx->prof.harvest();
@@ -903,31 +917,152 @@ int dense_pcg_solve(RaDevice& d, double tol) {
   return h.iters;
 }
 
-// Inverts the diagonal blocks of the CURRENT weighted Laplacian (ra_dense.hpp), block by block through the two
-// ping-pong buffers of the Gauss-Jordan sweep.
-void bd_factor(RaDevice& d) {
+// ---- substructured preconditioner (ra_sub.hpp): tables, factorisation --------------------------------------------------
+template <typename T>
+const T* sub_up(gsfm_ctx* ctx, DevBuf<T>& buf, const std::vector<T>& h) {
+  T* p = buf.ensure(h.size() + 1);
+  if (!h.empty()) GSFM_HIP_CHECK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  return p;
+}
+
+// Coupling tables from the final CSR, everything to the device.  Falls back to the plain block preconditioner (d.sub =
+// false; the node order stays — it is a BFS order with the interface moved to the end) when the coupling is too dense.
+void sub_upload(RaDevice& d, const std::vector<int>& h_rowptr, const std::vector<int>& h_nbr) {
+  RaWs* ws = d.ws;
+  gsfm_ctx* ctx = d.ctx;
+  SubPlan& sp = d.plan;
+  if (!sub_build_coupling(d.N, h_rowptr.data(), h_nbr.data(), sp)) {
+    d.sub = false;
+    return;
+  }
+  std::vector<int> tz(sp.nblk);
+  for (int b = 0; b < sp.nblk; ++b) tz[b] = sp.ipad[b] / kTile;
+  d.sd.N = d.N;
+  d.sd.NI = sp.NI;
+  d.sd.nblk = sp.nblk;
+  d.sd.ioff = sub_up(ctx, ws->sub_ioff, sp.ioff);
+  d.sd.ipad = sub_up(ctx, ws->sub_ipad, sp.ipad);
+  d.sd.invoff = sub_up(ctx, ws->sub_invoff, sp.invoff);
+  d.sd.row_blk = sub_up(ctx, ws->sub_rowblk, sp.row_blk);
+  d.sd.in_c = sub_up(ctx, ws->sub_inc, sp.in_c);
+  d.sd.inv = ws->bd_inv.ensure((size_t)sp.inv_total);
+  sub_up(ctx, ws->sub_tz, tz);
+  d.sc.coff = sub_up(ctx, ws->sub_coff, sp.coff);
+  d.sc.goff = sub_up(ctx, ws->sub_goff, sp.goff);
+  d.sc.cloc = sub_up(ctx, ws->sub_cloc, sp.cloc);
+  d.sc.gloc = sub_up(ctx, ws->sub_gloc, sp.gloc);
+  d.sc.eoff = sub_up(ctx, ws->sub_eoff, sp.eoff);
+  d.sc.ec = sub_up(ctx, ws->sub_ec, sp.ec);
+  d.sc.eg = sub_up(ctx, ws->sub_eg, sp.eg);
+  d.sc.eslot = sub_up(ctx, ws->sub_eslot, sp.eslot);
+  d.sc.woff = sub_up(ctx, ws->sub_woff, sp.woff);
+  d.sc.work = ws->sub_work.ensure((size_t)sp.work_total + 1);
+  ws->sub_y.ensure(3 * (size_t)d.N);
+  ws->sub_t.ensure(3 * (size_t)d.N);
+  GSFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // the host tables may go away
+  static const bool trace = getenv("GSFM_RA_TRACE") != nullptr;
+  if (trace)
+    fprintf(stderr, "[ra] substructured: %d interiors (largest %d padded) + interface %d, boundary layers <= %d, adjacent interface <= %d\n",
+            sp.nblk, sp.pmax, sp.G, sp.cmax, sp.gmax);
+}
+
+// Inverts every interior block of the CURRENT weighted Laplacian in one batched Gauss-Jordan sweep, assembles the Schur
+// complement of the interface from the boundary layers and inverts it.
+void sub_factor(RaDevice& d) {
   RaWs* ws = d.ws;
   hipStream_t s = d.ctx->stream;
-  const int nb = d.bd_nb, T = nb / kTile;
-  const size_t nn = (size_t)nb * nb;
-  float* inv = ws->bd_inv.ensure((size_t)d.bd_nblk * nn);
-  double* pinv = ws->dense_pinv.ensure(2 * kTile * kTile);
-  double* bufa = ws->dense_a.ensure(nn);
-  double* bufb = ws->dense_b.ensure(nn);
-  for (int b = 0; b < d.bd_nblk; ++b) {
-    double *cur = bufa, *oth = bufb;
-    GSFM_HIP_CHECK(hipMemsetAsync(cur, 0, nn * sizeof(double), s));
-    hipLaunchKernelGGL(k_bd_fill_offdiag, dim3(grid_for(2 * d.E, kBlock)), dim3(kBlock), 0, s, 2 * d.E, ws->inc_row.get(),
-                       ws->nbr.get(), ws->inc_w.get(), b * nb, nb, cur);
-    hipLaunchKernelGGL(k_bd_fill_diag, dim3(grid_for(nb, kBlock)), dim3(kBlock), 0, s, d.N, b * nb, nb, ws->lap_diag.get(), cur);
-    hipLaunchKernelGGL(k_dense_pivot0, dim3(1), dim3(kBlock), 0, s, cur, nb, pinv);
-    for (int k = 0; k < T; ++k) {
-      hipLaunchKernelGGL(k_dense_gj_step, dim3(T, T), dim3(kBlock), 0, s, cur, oth, nb, T, k, pinv + (k & 1) * kTile * kTile,
-                         pinv + ((k + 1) & 1) * kTile * kTile);
-      std::swap(cur, oth);
-    }
-    hipLaunchKernelGGL(k_bd_to_f32, dim3(grid_wide(nn, kBlock, 1 << 14)), dim3(kBlock), 0, s, nb, cur, inv + (size_t)b * nn);
+  const SubPlan& sp = d.plan;
+  const int nblk = sp.nblk, ld = sp.pmax, Tmax = ld / kTile;
+  const int Gp = sp.ipad[nblk], Tg = Gp / kTile;
+  const size_t zs = (size_t)ld * ld;
+  const size_t need = std::max(zs * nblk, (size_t)Gp * Gp);
+  double* cur = ws->sub_a.ensure(need);
+  double* oth = ws->sub_b.ensure(need);
+  double* Sa = ws->dense_a.ensure((size_t)Gp * Gp);
+  double* Sb = ws->dense_b.ensure((size_t)Gp * Gp);
+  double* pinv = ws->sub_pinv.ensure((size_t)(nblk + 1) * 2 * kTile * kTile);
+  GSFM_HIP_CHECK(hipMemsetAsync(cur, 0, zs * nblk * sizeof(double), s));
+  GSFM_HIP_CHECK(hipMemsetAsync(Sa, 0, (size_t)Gp * Gp * sizeof(double), s));
+  GSFM_HIP_CHECK(hipMemsetAsync(d.sc.work, 0, (size_t)sp.work_total * sizeof(double), s));
+  hipLaunchKernelGGL(k_sub_fill_offdiag, dim3(grid_for(2 * d.E, kBlock)), dim3(kBlock), 0, s, 2 * d.E, ws->inc_row.get(),
+                     ws->nbr.get(), ws->inc_w.get(), d.sd, cur, ld, zs, Sa, Gp);
+  hipLaunchKernelGGL(k_sub_fill_diag, dim3(grid_for(std::max(ld, Gp), kBlock), nblk + 1), dim3(kBlock), 0, s, d.sd,
+                     ws->lap_diag.get(), cur, ld, zs, Sa, Gp);
+  // interiors
+  hipLaunchKernelGGL(k_gj_pivot0, dim3(1, 1, nblk), dim3(kBlock), 0, s, cur, ld, zs, pinv);
+  for (int k = 0; k < Tmax; ++k) {
+    const bool timed = d.ctx->prof.begin(s, GSFM_KERNEL_RA_GJ);
+    hipLaunchKernelGGL(k_gj_sweep_step, dim3(gj_tiles(Tmax), 1, nblk), dim3(kBlock), 0, s, cur, oth, ld, zs,
+                       (const int*)ws->sub_tz.get(), Tmax, k, pinv);
+    if (timed) d.ctx->prof.end(s);
+    std::swap(cur, oth);
   }
+  hipLaunchKernelGGL(k_sub_to_f32, dim3(grid_wide(zs, kBlock, 1 << 12), nblk), dim3(kBlock), 0, s, d.sd, 0, cur, ld, zs,
+                     ws->bd_inv.get());
+  // Schur complement of the interface: S = A_GG - sum_b E_b^T (A_bb^-1)[C_b, C_b] E_b
+  const int gEM = grid_for((size_t)std::max((long)sp.cmax * sp.cmax, (long)(sp.eoff[nblk] / std::max(1, nblk) + 1)), kBlock);
+  hipLaunchKernelGGL(k_sub_couple_EM, dim3(gEM, nblk), dim3(kBlock), 0, s, d.sd, d.sc, ws->inc_w.get(), cur, ld, zs);
+  hipLaunchKernelGGL(k_sub_couple_Y, dim3(grid_for((size_t)sp.cmax * sp.gmax, kBlock), nblk), dim3(kBlock), 0, s, d.sc);
+  hipLaunchKernelGGL(k_sub_couple_S, dim3(grid_for((size_t)sp.gmax * sp.gmax, kBlock), nblk), dim3(kBlock), 0, s, d.sc, Sa, Gp);
+  double* pS = pinv + (size_t)nblk * 2 * kTile * kTile;
+  hipLaunchKernelGGL(k_gj_pivot0, dim3(1), dim3(kBlock), 0, s, Sa, Gp, (size_t)0, pS);
+  for (int k = 0; k < Tg; ++k) {
+    hipLaunchKernelGGL(k_gj_sweep_step, dim3(gj_tiles(Tg)), dim3(kBlock), 0, s, Sa, Sb, Gp, (size_t)0, (const int*)nullptr, Tg, k, pS);
+    std::swap(Sa, Sb);
+  }
+  hipLaunchKernelGGL(k_sub_to_f32, dim3(grid_wide((size_t)Gp * Gp, kBlock, 1 << 12), 1), dim3(kBlock), 0, s, d.sd, nblk, Sa, Gp,
+                     (size_t)0, ws->bd_inv.get());
+  if (d.ctx->prof.enabled) {
+    GSFM_HIP_CHECK(hipStreamSynchronize(s));
+    d.ctx->prof.harvest();
+  }
+  d.bd_have = true;
+  d.bd_refresh = false;
+  d.bd_fresh = true;
+  d.bd_base_iters = 0;
+}
+
+// u = M^-1 r with the substructured preconditioner: two sweeps over the interior inverses around the interface solve
+void sub_apply(RaDevice& d, const double* r, double* u, int it, double tol2, const double* rpart, DpcgState* st) {
+  RaWs* ws = d.ws;
+  hipStream_t s = d.ctx->stream;
+  const int N = d.N, NI = d.plan.NI;
+  const int gI = grid_wide(NI, kBlock / 64, 1 << 14), gG = grid_wide(N - NI, kBlock / 64, 1 << 14);
+  double* y = ws->sub_y.get();
+  double* t = ws->sub_t.get();
+  hipLaunchKernelGGL(k_sub_apply3, dim3(gI), dim3(kBlock), 0, s, d.sd, 0, NI, r, y, 1, it, tol2, rpart, st);        // y_I = A_II^-1 r_I
+  hipLaunchKernelGGL((k_sub_couple<true>), dim3(gG), dim3(kBlock), 0, s, d.sd, ws->rowptr.get(), ws->nbr.get(),
+                     ws->inc_w.get(), r, (const double*)y, t, (const DpcgState*)st);                                        // t_G = r_G - A_GI y_I
+  hipLaunchKernelGGL(k_sub_apply3, dim3(gG), dim3(kBlock), 0, s, d.sd, NI, N, (const double*)t, u, 0, it, tol2, rpart, st);  // u_G = S^-1 t_G
+  hipLaunchKernelGGL((k_sub_couple<false>), dim3(gI), dim3(kBlock), 0, s, d.sd, ws->rowptr.get(), ws->nbr.get(),
+                     ws->inc_w.get(), r, (const double*)u, t, (const DpcgState*)st);                                        // t_I = r_I - A_IG u_G
+  hipLaunchKernelGGL(k_sub_apply3, dim3(gI), dim3(kBlock), 0, s, d.sd, 0, NI, (const double*)t, u, 0, it, tol2, rpart, st);  // u_I = A_II^-1 t_I
+}
+
+// Inverts the diagonal blocks of the CURRENT weighted Laplacian (ra_dense.hpp): all blocks through one batched sweep.
+void bd_factor(RaDevice& d) {
+  if (d.sub) return sub_factor(d);
+  RaWs* ws = d.ws;
+  hipStream_t s = d.ctx->stream;
+  const int nb = d.bd_nb, T = nb / kTile, nblk = d.bd_nblk;
+  const size_t nn = (size_t)nb * nb;
+  float* inv = ws->bd_inv.ensure((size_t)nblk * nn);
+  double* pinv = ws->sub_pinv.ensure((size_t)nblk * 2 * kTile * kTile);
+  double* cur = ws->sub_a.ensure(nn * nblk);
+  double* oth = ws->sub_b.ensure(nn * nblk);
+  GSFM_HIP_CHECK(hipMemsetAsync(cur, 0, nn * nblk * sizeof(double), s));
+  for (int b = 0; b < nblk; ++b) {
+    hipLaunchKernelGGL(k_bd_fill_offdiag, dim3(grid_for(2 * d.E, kBlock)), dim3(kBlock), 0, s, 2 * d.E, ws->inc_row.get(),
+                       ws->nbr.get(), ws->inc_w.get(), b * nb, nb, cur + nn * b);
+    hipLaunchKernelGGL(k_bd_fill_diag, dim3(grid_for(nb, kBlock)), dim3(kBlock), 0, s, d.N, b * nb, nb, ws->lap_diag.get(), cur + nn * b);
+  }
+  // all blocks through one batched symmetric sweep
+  hipLaunchKernelGGL(k_gj_pivot0, dim3(1, 1, nblk), dim3(kBlock), 0, s, cur, nb, nn, pinv);
+  for (int k = 0; k < T; ++k) {
+    hipLaunchKernelGGL(k_gj_sweep_step, dim3(gj_tiles(T), 1, nblk), dim3(kBlock), 0, s, cur, oth, nb, nn, (const int*)nullptr, T, k, pinv);
+    std::swap(cur, oth);
+  }
+  hipLaunchKernelGGL(k_bd_to_f32, dim3(grid_wide(nn, kBlock, 1 << 12), nblk), dim3(kBlock), 0, s, nb, cur, nn, inv);
   d.bd_have = true;
   d.bd_refresh = false;
   d.bd_fresh = true;
@@ -949,6 +1084,9 @@ int bd_pcg_solve(RaDevice& d, bool warm, double tol, int max_iter) {
     --d.bd_skip_stale;
     d.bd_refresh = true;
   }
+  // the substructured factorisation is cheap and only pays when it matches the weights (kept through the IRLS weights it
+  // needs 1 140 instead of 11 iterations, tools/exp_ra_linear_solves.py): always re-factor for a new weighting
+  if (d.sub && !d.bd_fresh) d.bd_refresh = true;
   if (!d.bd_have || d.bd_refresh) bd_factor(d);
   const double* b = ws->rhs.get();
   double* x = ws->x.get();
@@ -969,18 +1107,24 @@ int bd_pcg_solve(RaDevice& d, bool warm, double tol, int max_iter) {
   double* dpart = ws->dpart.get();
   const int gA = grid_wide(N, kBlock / 64, 1 << 14);
   const int gS = std::min(d.gridRow, kMaxApplySlots / 2);
-  const int batch = tol > 1e-6 ? 6 : 12;  // inexact (ADMM) solves stop after a handful of iterations
+  // iterations enqueued per status read-back: the substructured preconditioner converges in two or three
+  const int batch = d.sub ? 3 : (tol > 1e-6 ? 6 : 12);  // (inexact ADMM solves stop after a handful of iterations)
   DpcgState h{};
   int total = 0;
   for (int attempt = 0; attempt < 2; ++attempt) {
     // a stale preconditioner gets a bounded budget; a fresh one the caller's
     const int budget = d.bd_fresh ? max_iter : std::min(max_iter, std::max(40, (5 * d.bd_base_iters) / 2));
-    hipLaunchKernelGGL(k_dpcg_init, dim3(1), dim3(1024), 0, s, n3, b, x, ws->cg_r.get(), ws->cg_p.get(), ws->cg_s.get(), st);
+    hipLaunchKernelGGL(k_dpcg_init_mb, dim3(kBdUpdateBlocks), dim3(kBlock), 0, s, n3, b, x, ws->cg_r.get(), ws->cg_p.get(),
+                       ws->cg_s.get(), rpart);
+    hipLaunchKernelGGL(k_dpcg_init_fin, dim3(1), dim3(64), 0, s, (const double*)rpart, kBdUpdateBlocks, st);
     h = DpcgState{};
     for (int done = 0; done < budget && !h.done; done += batch) {
       for (int it = done; it < done + batch; ++it) {
-        hipLaunchKernelGGL(k_bd_apply3, dim3(gA), dim3(kBlock), 0, s, N, d.bd_nb, ws->bd_inv.get(), ws->cg_r.get(), u, it,
-                           tol * tol, rpart, st);
+        if (d.sub)
+          sub_apply(d, ws->cg_r.get(), u, it, tol * tol, rpart, st);
+        else
+          hipLaunchKernelGGL(k_bd_apply3, dim3(gA), dim3(kBlock), 0, s, N, d.bd_nb, ws->bd_inv.get(), ws->cg_r.get(), u, it,
+                             tol * tol, rpart, st);
         const bool timed = ctx->prof.begin(s, GSFM_KERNEL_RA_LAPLACIAN);
         dispatch_lpr(d.lpr, [&](auto L) {
           hipLaunchKernelGGL((k_bd_spmv<decltype(L)::value>), dim3(gS), dim3(kBlock), 0, s, N, ws->rowptr.get(), ws->nbr.get(),
@@ -1288,6 +1432,21 @@ void setup_device(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
       h_ei[e] = pos[h_ei[e]];
       h_ej[e] = pos[h_ej[e]];
     }
+    // substructuring (ra_sub.hpp): interiors of more, smaller BFS blocks first, the interface between them last
+    static const bool no_sub = getenv("GSFM_RA_NO_SUBSTRUCTURE") != nullptr;  // A/B switch: the plain block preconditioner
+    if (!no_sub) sub_plan(N, E, h_ei.data(), h_ej.data(), d.plan);
+    d.sub = !no_sub && d.plan.ok;
+    if (d.sub) {
+      const std::vector<int>& np = d.plan.newpos;
+      for (long e = 0; e < E; ++e) {
+        h_ei[e] = np[h_ei[e]];
+        h_ej[e] = np[h_ej[e]];
+      }
+      std::vector<int> order2(N);
+      for (int p = 0; p < N; ++p) order2[np[p]] = order[p];
+      order.swap(order2);
+      for (int n = 0; n < N; ++n) pos[n] = np[pos[n]];
+    }
     GSFM_HIP_CHECK(hipMemcpyAsync(ws->ei.get(), h_ei.data(), E * sizeof(int), hipMemcpyHostToDevice, s));
     GSFM_HIP_CHECK(hipMemcpyAsync(ws->ej.get(), h_ej.data(), E * sizeof(int), hipMemcpyHostToDevice, s));
     GSFM_HIP_CHECK(hipMemcpyAsync(ws->order.ensure(N), order.data(), N * sizeof(int), hipMemcpyHostToDevice, s));
@@ -1295,7 +1454,13 @@ void setup_device(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
     d.fixed = pos[d.fixed];
     hi.mst_root = pos[0];
   }
-  build_incidence(d, h_ei.data(), h_ej.data());
+  if (d.sub) {
+    std::vector<int> h_rowptr, h_nbr;
+    build_incidence(d, h_ei.data(), h_ej.data(), &h_rowptr, &h_nbr);
+    sub_upload(d, h_rowptr, h_nbr);
+  } else {
+    build_incidence(d, h_ei.data(), h_ej.data());
+  }
 
   // device-to-host copies for the initialisation, all BEFORE any solver kernel is enqueued
   to_host(ctx, hi.h_rot, rot_in, 3 * (size_t)N, mem);

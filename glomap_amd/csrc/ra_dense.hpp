@@ -10,10 +10,9 @@
 // dense (A^-1)[N x N] x rhs[N x 3] product plus one step of iterative refinement against the sparse
 // operator.  SPD input => the block pivots are Schur complements of an SPD matrix, no pivoting.
 //
-// Block Gauss-Jordan step k (P = A_kk^-1), out-of-place between two buffers so that no tile is
-// read after it was overwritten:
-//     A_kk <- P,   A_kj <- P A_kj,   A_ik <- -A_ik P,   A_ij <- A_ij - A_ik P A_kj      (i, j != k)
-// The workgroup that produces tile (k+1, k+1) also inverts it (in LDS) for the next step.
+// Block Gauss-Jordan step k (P = A_kk^-1), out-of-place between two buffers so that no tile is read after it was
+// overwritten, in the symmetric (sweep-operator) form — see k_gj_sweep_step.  The workgroup that produces tile
+// (k+1, k+1) also inverts it (in LDS) for the next step.
 #pragma once
 
 #include "device.hpp"
@@ -116,54 +115,92 @@ __device__ __forceinline__ void tile_store(double* __restrict__ A, int ld, int b
   }
 }
 
-// P = inverse of tile (0, 0) of A  ->  pinv[32][32] (row-major, ld 32)
-static __global__ void __launch_bounds__(kBlock) k_dense_pivot0(const double* __restrict__ A, int ld, double* __restrict__ pinv) {
-  __shared__ double S[kTile * kTileLd], srow[kTile], scol[kTile];
-  tile_load(A, ld, 0, 0, S);
-  tile_inverse_lds(S, srow, scol);
+// transposed tile load: S = A(bi, bj)^T
+__device__ __forceinline__ void tile_load_t(const double* __restrict__ A, int ld, int bi, int bj, double* __restrict__ S) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int idx = threadIdx.x + 256 * e;
-    pinv[idx] = S[(idx >> 5) * kTileLd + (idx & 31)];
+    const int r = idx >> 5, c = idx & 31;
+    S[c * kTileLd + r] = A[(size_t)(bi * kTile + r) * ld + bj * kTile + c];
   }
 }
 
-// One block Gauss-Jordan step: out = GJ_k(in), grid (T, T); pinv_in = (in_kk)^-1; the workgroup of
-// tile (k+1, k+1) writes the inverse of its result to pinv_out.
+// ---- symmetric block sweep (batched) ------------------------------------------------------------------------------
+// The matrices are SPD, so the block Gauss-Jordan iteration is run in its SYMMETRIC form (the sweep operator):
+//     B_kk = -P,   B_ik = A_ik P,   B_kj = P A_kj,   B_ij = A_ij - A_ik P A_kj          (P = A_kk^-1; i, j != k)
+// keeps every iterate symmetric, so only the tiles of the lower triangle (bi >= bj) are computed and stored — half the
+// tile products and half the traffic of the general iteration; a tile of the upper triangle is read as the transpose of
+// its mirror image.  After all T sweeps the buffer holds  -A^-1  (gj_inv_at() below undoes the sign).
+// One launch serves nz matrices (blockIdx.z; matrix z at in + z * zstride, T = Tz[z] tile rows or `Tu` when Tz is null);
+// blockIdx.x enumerates the lower triangle of the LARGEST matrix.
 static __global__ void __launch_bounds__(kBlock)
-    k_dense_gj_step(const double* __restrict__ in, double* __restrict__ out, int ld, int T, int k,
-                    const double* __restrict__ pinv_in, double* __restrict__ pinv_out) {
-  __shared__ double sP[kTile * kTileLd], sX[kTile * kTileLd], sY[kTile * kTileLd], sC[kTile * kTileLd],
-      sM[kTile * kTileLd], srow[kTile], scol[kTile];
-  const int bi = blockIdx.y, bj = blockIdx.x;
+    k_gj_pivot0(const double* __restrict__ A, int ld, size_t zstride, double* __restrict__ pinv) {
+  __shared__ double S[kTile * kTileLd], srow[kTile], scol[kTile];
+  tile_load(A + zstride * blockIdx.z, ld, 0, 0, S);
+  tile_inverse_lds(S, srow, scol);
+  double* pz = pinv + (size_t)blockIdx.z * 2 * kTile * kTile;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int idx = threadIdx.x + 256 * e;
-    sP[(idx >> 5) * kTileLd + (idx & 31)] = pinv_in[idx];
+    pz[idx] = S[(idx >> 5) * kTileLd + (idx & 31)];
+  }
+}
+
+// pinv: [nz][2][32 x 32], the inverse of the pivot tile of step k in slot k & 1 (k_gj_pivot0 fills slot 0; the workgroup
+// that produces tile (k+1, k+1) inverts it for the next step).  Matrices with fewer tile rows than the launch has steps
+// are carried along unchanged (k >= T), so that all of them end in the same ping-pong buffer.
+static __global__ void __launch_bounds__(kBlock)
+    k_gj_sweep_step(const double* __restrict__ in, double* __restrict__ out, int ld, size_t zstride, const int* __restrict__ Tz,
+                    int Tu, int k, double* __restrict__ pinv) {
+  __shared__ double sP[kTile * kTileLd], sX[kTile * kTileLd], sY[kTile * kTileLd], sC[kTile * kTileLd],
+      sM[kTile * kTileLd], srow[kTile], scol[kTile];
+  const int z = blockIdx.z, T = Tz ? Tz[z] : Tu;
+  // lower-triangle enumeration: t = bi (bi + 1) / 2 + bj
+  const int t = blockIdx.x;
+  int bi = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+  while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+  while (bi * (bi + 1) / 2 > t) --bi;
+  const int bj = t - bi * (bi + 1) / 2;
+  if (bi >= T) return;
+  const double* inz = in + zstride * z;
+  double* outz = out + zstride * z;
+  if (k >= T) {  // finished: carry the result along
+    tile_load(inz, ld, bi, bj, sC);
+    __syncthreads();
+    tile_store(outz, ld, bi, bj, sC);
+    return;
+  }
+  const double* pinv_in = pinv + ((size_t)z * 2 + (k & 1)) * kTile * kTile;
+  double* pinv_out = pinv + ((size_t)z * 2 + ((k + 1) & 1)) * kTile * kTile;
+  const double sgn = (bi == k && bj == k) ? -1.0 : 1.0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = threadIdx.x + 256 * e;
+    sP[(idx >> 5) * kTileLd + (idx & 31)] = sgn * pinv_in[idx];
   }
   double* res = sC;
   if (bi == k && bj == k) {
-    res = sP;
+    res = sP;  // -P
     __syncthreads();
-  } else if (bi == k) {
-    tile_load(in, ld, k, bj, sY);
+  } else if (bi == k) {  // bj < k: row tile, P A_kj
+    tile_load(inz, ld, k, bj, sY);
     __syncthreads();
-    tile_mma(sP, sY, nullptr, 1.0, sC);  // P A_kj
-  } else if (bj == k) {
-    tile_load(in, ld, bi, k, sX);
+    tile_mma(sP, sY, nullptr, 1.0, sC);
+  } else if (bj == k) {  // bi > k: column tile, A_ik P
+    tile_load(inz, ld, bi, k, sX);
     __syncthreads();
-    tile_mma(sX, sP, nullptr, -1.0, sC);  // -A_ik P
+    tile_mma(sX, sP, nullptr, 1.0, sC);
   } else {
-    tile_load(in, ld, bi, k, sX);
-    tile_load(in, ld, k, bj, sY);
-    tile_load(in, ld, bi, bj, sC);
+    if (bi > k) tile_load(inz, ld, bi, k, sX); else tile_load_t(inz, ld, k, bi, sX);  // A_ik
+    if (k > bj) tile_load(inz, ld, k, bj, sY); else tile_load_t(inz, ld, bj, k, sY);  // A_kj
+    tile_load(inz, ld, bi, bj, sC);
     __syncthreads();
     tile_mma(sX, sP, nullptr, 1.0, sM);  // A_ik P
     __syncthreads();
     tile_mma(sM, sY, sC, -1.0, sC);  // A_ij - (A_ik P) A_kj   (each element read and written by its own lane)
   }
   __syncthreads();
-  tile_store(out, ld, bi, bj, res);
+  tile_store(outz, ld, bi, bj, res);
   if (bi == k + 1 && bj == k + 1) {  // next pivot
     tile_inverse_lds(res, srow, scol);
 #pragma unroll
@@ -171,6 +208,25 @@ static __global__ void __launch_bounds__(kBlock)
       const int idx = threadIdx.x + 256 * e;
       pinv_out[idx] = res[(idx >> 5) * kTileLd + (idx & 31)];
     }
+  }
+}
+inline int gj_tiles(int T) { return T * (T + 1) / 2; }
+
+// Element (r, c) of A^-1 from a swept buffer: lower tile triangle stored, diagonal tiles complete, sign flipped.
+__device__ __forceinline__ double gj_inv_at(const double* __restrict__ A, int ld, int r, int c) {
+  const int tr = r / kTile, tc = c / kTile;
+  if (tr == tc) return -0.5 * (A[(size_t)r * ld + c] + A[(size_t)c * ld + r]);
+  return tr > tc ? -A[(size_t)r * ld + c] : -A[(size_t)c * ld + r];
+}
+// In place: the complete symmetric A^-1 from a swept buffer (dense direct path: the apply streams full rows).
+static __global__ void __launch_bounds__(kBlock) k_gj_finish_full(double* __restrict__ A, int ld, int n) {
+  const size_t nn = (size_t)n * n;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / n), c = (int)(i % n);
+    if (r < c) continue;  // one thread per unordered pair
+    const double v = gj_inv_at(A, ld, r, c);
+    A[(size_t)r * ld + c] = v;
+    A[(size_t)c * ld + r] = v;
   }
 }
 
@@ -265,6 +321,39 @@ static __global__ void __launch_bounds__(1024)
     st->alpha_old = 0.0;
     st->bb = acc[0];
     st->rr = acc[0];
+  }
+}
+
+// The same start on many workgroups (block-preconditioned PCG, 3N = 30 000 .. 100 000 doubles: one workgroup takes 20 us):
+// vectors and per-block |b|^2 partials here, the state in k_dpcg_init_fin.
+static __global__ void __launch_bounds__(kBlock)
+    k_dpcg_init_mb(int n3, const double* __restrict__ b, double* __restrict__ x, double* __restrict__ r, double* __restrict__ p,
+                   double* __restrict__ s, double* __restrict__ part) {
+  __shared__ double smem[4];
+  double acc[1] = {0.0};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += gridDim.x * blockDim.x) {
+    const double bi = b[i];
+    x[i] = 0.0;
+    r[i] = bi;
+    p[i] = 0.0;
+    s[i] = 0.0;
+    acc[0] += bi * bi;
+  }
+  block_sum<1>(acc, smem);
+  if (threadIdx.x == 0) part[blockIdx.x] = acc[0];
+}
+static __global__ void __launch_bounds__(64) k_dpcg_init_fin(const double* __restrict__ part, int nparts, DpcgState* st) {
+  double v = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 64) v += part[i];
+  v = wave_sum(v);
+  if (threadIdx.x == 0) {
+    st->done = v > 0.0 ? 0 : 1;  // b = 0 -> x = 0
+    st->iters = 0;
+    st->bad = 0;
+    st->gamma_old = 0.0;
+    st->alpha_old = 0.0;
+    st->bb = v;
+    st->rr = v;
   }
 }
 
@@ -365,12 +454,12 @@ __device__ __forceinline__ double bd_reduce1(const double* __restrict__ part, in
 // The block inverses are only a preconditioner, so they are stored in fp32 (symmetrised before rounding: CG needs a
 // symmetric M) — the apply is a pure stream of the blocks, half the bytes is nearly half the time; sums stay in f64.
 static __global__ void __launch_bounds__(kBlock)
-    k_bd_to_f32(int nb, const double* __restrict__ inv, float* __restrict__ out) {
+    k_bd_to_f32(int nb, const double* __restrict__ swept, size_t zstride, float* __restrict__ out) {
   const size_t nn = (size_t)nb * nb;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t r = i / nb, c = i % nb;
-    out[i] = (float)(0.5 * (inv[i] + inv[c * nb + r]));
-  }
+  const double* A = swept + zstride * blockIdx.y;
+  float* o = out + nn * blockIdx.y;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += (size_t)gridDim.x * blockDim.x)
+    o[i] = (float)gj_inv_at(A, nb, (int)(i / nb), (int)(i % nb));
 }
 
 static __global__ void __launch_bounds__(kBlock)

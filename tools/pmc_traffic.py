@@ -20,11 +20,20 @@ from pathlib import Path
 
 
 def per_kernel(db, counter):
+    """kernel -> (launches, avg, min, max, working launches, avg over the working launches).  A launch of a PCG kernel
+    that finds the solve converged returns at once and moves (almost) nothing; "working" = at least a quarter of the
+    kernel's median counter value (same rule as tools/rocpd_stats.py applies to durations)."""
     c = sqlite3.connect(db)
-    rows = c.execute(
-        "select kernel_name, count(*), avg(value), min(value), max(value) from counters_collection "
-        "where counter_name = ? group by kernel_name", (counter,)).fetchall()
-    return {r[0]: r[1:] for r in rows}
+    vals = {}
+    for name, v in c.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
+        vals.setdefault(name, []).append(v)
+    out = {}
+    for name, v in vals.items():
+        v.sort()
+        med = v[len(v) // 2]
+        work = [x for x in v if x >= 0.25 * med] or v
+        out[name] = (len(v), sum(v) / len(v), v[0], v[-1], len(work), sum(work) / len(work))
+    return out
 
 
 def short(name):
@@ -36,16 +45,16 @@ def main(prefix):
     fetch = per_kernel(f"{prefix}_FETCH_SIZE_results.db", "FETCH_SIZE")
     write = per_kernel(f"{prefix}_WRITE_SIZE_results.db", "WRITE_SIZE")
     out = {}
-    print("kernel,launches,fetch_KiB_raw_avg,fetch_bytes_x2_avg,write_bytes_avg,bytes_per_launch")
+    print("kernel,launches,working_launches,fetch_KiB_raw_avg,fetch_bytes_x2_avg,write_bytes_avg,bytes_per_launch")
     for k in sorted(fetch, key=lambda k: -fetch[k][0] * fetch[k][1]):
-        n, favg = fetch[k][0], fetch[k][1]
-        wavg = write.get(k, (0, 0.0))[1]
+        n, nwork, favg = fetch[k][0], fetch[k][4], fetch[k][5]  # averages over the working launches
+        wavg = write.get(k, (0, 0.0, 0, 0, 0, 0.0))[5]
         fb2 = 2.0 * favg * 1024.0
         wb = wavg * 1024.0
         name = short(k)
-        print(f'"{name}",{n},{favg:.1f},{fb2:.0f},{wb:.0f},{fb2 + wb:.0f}')
-        out[name] = {"launches": n, "fetch_bytes_raw": favg * 1024.0, "fetch_bytes_x2": fb2, "write_bytes": wb,
-                     "bytes_per_launch": fb2 + wb}
+        print(f'"{name}",{n},{nwork},{favg:.1f},{fb2:.0f},{wb:.0f},{fb2 + wb:.0f}')
+        out[name] = {"launches": n, "working_launches": nwork, "fetch_bytes_raw": favg * 1024.0, "fetch_bytes_x2": fb2,
+                     "write_bytes": wb, "bytes_per_launch": fb2 + wb}
     dst = Path(__file__).resolve().parent.parent / "profiles" / "pmc_traffic.json"
     merged = json.loads(dst.read_text()) if dst.exists() else {}
     merged.update(out)

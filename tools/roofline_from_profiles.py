@@ -1,10 +1,12 @@
 """Recomputes the roofline fractions of the sweep kernels from the committed evidence alone:
 
   algorithmic bytes per launch (the formulas of DESIGN.md section 4.3 = bench.py's *_bytes functions, at the configs[3]
-  sizes recorded in profiles/r02_bench_default.json)  /  average kernel duration (profiles/r02_pipeline_c4_kernel_stats.csv,
-  rocprofv3 --kernel-trace)  /  8 TB/s,   next to the PMC traffic of profiles/r02_pipeline_c4_pmc.csv.
+  sizes recorded in profiles/<tag>_bench_default.json)  /  average duration of the WORKING launches
+  (profiles/<tag>_pipeline_c4_kernel_stats.csv, rocprofv3 --kernel-trace; `work_avg_us` of tools/rocpd_stats.py: launches
+  that only found the solve converged and returned are left out)  /  8 TB/s,   next to the PMC traffic per working launch
+  of profiles/<tag>_pipeline_c4_pmc.csv.
 
-Usage: python tools/roofline_from_profiles.py [> profiles/r02_rooflines.md]"""
+Usage: python tools/roofline_from_profiles.py r03 [> profiles/r03_rooflines.md]"""
 import csv
 import json
 import os
@@ -17,8 +19,8 @@ import bench  # noqa: E402  (only its byte formulas)
 PEAK = 8000.0  # GB/s, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def main():
-    line = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_default.json")))
+def main(tag):
+    line = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_bench_default.json")))
     cfg = line["config"]
     N, Mg, Mb = cfg["cameras"], cfg["observations_gp"], cfg["observations_ba"]
     P = cfg["tracks"]
@@ -30,29 +32,31 @@ def main():
         "k_gp_phaseB": ("68 M + 96 N", bench.gp_phaseB_bytes(Mg, N)),
     }
     dur = {}
-    with open(os.path.join(ROOT, "profiles", "r02_pipeline_c4_kernel_stats.csv")) as f:
+    with open(os.path.join(ROOT, "profiles", f"{tag}_pipeline_c4_kernel_stats.csv")) as f:
         for row in csv.DictReader(f):
             for k in formulas:
                 if k in row["kernel"] and k not in dur:
-                    dur[k] = (float(row["avg_us"]), int(row["calls"]), int(row["vgpr"]))
+                    dur[k] = (float(row["work_avg_us"]), int(row["work_calls"]), int(row["calls"]), float(row["avg_us"]), int(row["vgpr"]))
     traffic = {}
-    with open(os.path.join(ROOT, "profiles", "r02_pipeline_c4_pmc.csv")) as f:
+    with open(os.path.join(ROOT, "profiles", f"{tag}_pipeline_c4_pmc.csv")) as f:
         for row in csv.reader(f):
             for k in formulas:
                 if row and row[0].startswith(k) and k not in traffic:
                     traffic[k] = float(row[-1])
-    print("| kernel | algorithmic bytes / launch | formula | avg us (rocprofv3) | launches | VGPRs | GB/s | frac of 8 TB/s | PMC traffic / launch | traffic / algorithmic |")
-    print("|---|---|---|---|---|---|---|---|---|---|")
+    print("| kernel | algorithmic bytes / launch | formula | avg us, working launches (rocprofv3) | working / all launches | avg us, all | VGPRs | GB/s | frac of 8 TB/s | PMC traffic / working launch | traffic / algorithmic |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|")
     for k, (form, nbytes) in formulas.items():
-        us, calls, vgpr = dur[k]
+        us, wcalls, calls, us_all, vgpr = dur[k]
         gbps = nbytes / us / 1e3
         tr = traffic.get(k)
-        print(f"| `{k}` | {nbytes / 1e6:.1f} MB | `{form}` | {us:.1f} | {calls} | {vgpr} | {gbps:.0f} | {gbps / PEAK:.3f} | "
+        print(f"| `{k}` | {nbytes / 1e6:.1f} MB | `{form}` | {us:.1f} | {wcalls} / {calls} | {us_all:.1f} | {vgpr} | {gbps:.0f} | {gbps / PEAK:.3f} | "
               f"{'' if tr is None else f'{tr / 1e6:.0f} MB'} | {'' if tr is None else f'{tr / nbytes:.2f}'} |")
     r = line["roofline"]
-    print(f"\nbench.py's own line (HIP events, other box): `{r['kernel'].split(' ')[0]}` {r['avg_kernel_us']:.1f} us -> frac {r['frac']:.3f}; "
-          f"step {line['ms_per_step']:.1f} ms, value {line['value'] / 1e6:.2f} M obs/s.")
+    print(f"\nbench.py's own line (HIP events over the working launches, other box): `{r['kernel'].split(' ')[0]}` {r['avg_kernel_us']:.1f} us -> "
+          f"frac {r['frac']:.3f}; step {line['ms_per_step']:.1f} ms, value {line['value'] / 1e6:.2f} M obs/s.")
+    for o in r.get("other_kernels", []):
+        print(f"  `{o['kernel'].split(' ')[0]}` {o['avg_kernel_us']:.1f} us -> frac {o['frac']:.3f} ({o['launches']} launches)")
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else "r03")
