@@ -101,27 +101,121 @@ struct CgVec {
 };
 
 // ---- deflation, per-element pieces (all no-ops for v.dk == 0) ----------------------------------------------------
-// y = E^-1 c from the partial dot products of iteration parity `par`; gcorr = (W^T r).y, dcorr = ((A W)^T z).y.
-// All threads of the block; smem >= 5 * 2 * kCgMaxModes.
-__device__ __forceinline__ void cgd_coefficients(const CgVec& v, int par, double (&y)[kCgMaxModes], double& gcorr,
-                                                 double& dcorr, double* smem) {
-  gcorr = dcorr = 0.0;
+// One PCG step's scalars, identical in every thread of every block (all of them re-reduce the same partial slots in the
+// same order).  y = E^-1 ((A W)^T z): the coefficients of the deflation projection (zero without deflation).
+struct CgStep {
+  double gamma, delta, alpha, beta;
+  bool ok;
+  double y[kCgMaxModes];
+};
+constexpr int kCgStepSmem = 4 * (3 + 2 * kCgMaxModes) + 16 + kCgMaxModes * kCgMaxModes;
+
+// Prologue of the vector update of iteration `it`: ONE block reduction over all partial slots (r.z | r.r of the previous
+// update, delta of this apply, the 2k deflation dot products), then alpha / beta.  Returns false when the solve is finished.
+// The loads are issued before the `done` test so that they overlap its round trip.
+__device__ __forceinline__ bool cg_step_prologue(const CgVec& v, int it, CgStep& o, double* smem /* >= kCgStepSmem */) {
+  constexpr int KD = 2 * kCgMaxModes;
+  double t[3 + KD];
 #pragma unroll
-  for (int i = 0; i < kCgMaxModes; ++i) y[i] = 0.0;
-  if (v.dk == 0) return;
-  double cd[2 * kCgMaxModes];
-  reduce_partials<2 * kCgMaxModes>(v.dcd + (size_t)par * kCgMaxBlocks * 2 * kCgMaxModes, v.nb_update, cd, smem);
-  if (v.dsmall[72] == 0.0) return;  // E was not positive definite: this solve runs plain
+  for (int j = 0; j < 3 + KD; ++j) t[j] = 0.0;
+  const int par = it & 1;
+  {
+    const double* vp = v.vpart + (size_t)par * kCgMaxBlocks * 2;
+    const double* cp = v.dcd + (size_t)par * kCgMaxBlocks * KD;
+    for (int b = threadIdx.x; b < v.nb_update; b += blockDim.x) {
+      t[0] += vp[2 * b];
+      t[1] += vp[2 * b + 1];
+      if (v.dk) {
 #pragma unroll
-  for (int i = 0; i < kCgMaxModes; ++i) {
-    if (i < v.dk) {
-      double t = 0.0;
+        for (int j = 0; j < KD; ++j) t[3 + j] += cp[(size_t)b * KD + j];
+      }
+    }
+    if (!v.delta_in_w)
+      for (int b = threadIdx.x; b < v.nb_apply; b += blockDim.x) t[2] += v.dpart[b];
+  }
+  double* sE = smem + 4 * (3 + KD) + 16;  // E^-1, staged by the first 64 threads
+  if (v.dk && threadIdx.x < kCgMaxModes * kCgMaxModes) sE[threadIdx.x] = v.dsmall[threadIdx.x];
+  const double dok = v.dk ? v.dsmall[72] : 0.0;
+  const CgScal prev = v.scal[par];
+  const double wn = v.delta_in_w ? v.w[v.n] : 0.0;
+  const int done = v.st->done;
+  if (done) return false;
+  if (v.dk) block_sum<3 + KD>(t, smem); else block_sum<3>(reinterpret_cast<double(&)[3]>(t), smem);
+  double* sb = smem + 4 * (3 + KD);
+  if (threadIdx.x == 0) {
+    double gamma = t[0], delta = v.delta_in_w ? wn : t[2];
+    double y[kCgMaxModes];
 #pragma unroll
-      for (int j = 0; j < kCgMaxModes; ++j)
-        if (j < v.dk) t += v.dsmall[i * kCgMaxModes + j] * cd[j];
-      y[i] = t;
-      gcorr += t * cd[kCgMaxModes + i];
-      dcorr += t * cd[i];
+    for (int i = 0; i < kCgMaxModes; ++i) y[i] = 0.0;
+    if (v.dk && dok != 0.0) {
+#pragma unroll
+      for (int i = 0; i < kCgMaxModes; ++i)
+        if (i < v.dk) {
+          double a = 0.0;
+#pragma unroll
+          for (int j = 0; j < kCgMaxModes; ++j)
+            if (j < v.dk) a += sE[i * kCgMaxModes + j] * t[3 + j];
+          y[i] = a;
+          gamma -= a * t[3 + kCgMaxModes + i];  // r.z_p = r.z - (W^T r).y
+          delta -= a * t[3 + i];                // z_p.w_p = z.w - y.((A W)^T z)
+        }
+    }
+    double beta = 0.0, denom = delta;
+    if (it > 0) {
+      beta = prev.gamma > 0.0 ? gamma / prev.gamma : 0.0;
+      denom = delta - beta * gamma / prev.alpha;
+    }
+    const bool ok = isfinite(denom) && denom > 0.0 && isfinite(gamma) && gamma >= 0.0;
+    sb[0] = gamma;
+    sb[1] = delta;
+    sb[2] = ok ? gamma / denom : 0.0;
+    sb[3] = ok ? beta : 0.0;
+    sb[4] = ok ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = 0; i < kCgMaxModes; ++i) sb[5 + i] = y[i];
+  }
+  __syncthreads();
+  o.gamma = sb[0];
+  o.delta = sb[1];
+  o.alpha = sb[2];
+  o.beta = sb[3];
+  o.ok = sb[4] != 0.0;
+#pragma unroll
+  for (int i = 0; i < kCgMaxModes; ++i) o.y[i] = sb[5 + i];
+  __syncthreads();
+  return true;
+}
+
+// Epilogue: this block's partials of the NEXT iterate (r.z | r.r | the 2k deflation products) in one block reduction; block
+// 0 records the step's scalars and a breakdown.
+__device__ __forceinline__ void cg_step_epilogue(const CgVec& v, int it, const CgStep& o, double rz, double rr,
+                                                 double (&cd)[2 * kCgMaxModes], double* smem) {
+  constexpr int KD = 2 * kCgMaxModes;
+  double t[2 + KD];
+  t[0] = rz;
+  t[1] = rr;
+#pragma unroll
+  for (int j = 0; j < KD; ++j) t[2 + j] = cd[j];
+  if (v.dk) block_sum<2 + KD>(t, smem); else block_sum<2>(reinterpret_cast<double(&)[2]>(t), smem);
+  if (threadIdx.x == 0) {
+    const int par = (it + 1) & 1;
+    double* out = v.vpart + (size_t)par * kCgMaxBlocks * 2;
+    out[blockIdx.x * 2] = t[0];
+    out[blockIdx.x * 2 + 1] = t[1];
+    if (v.dk) {
+      double* oc = v.dcd + ((size_t)par * kCgMaxBlocks + blockIdx.x) * KD;
+#pragma unroll
+      for (int j = 0; j < KD; ++j) oc[j] = t[2 + j];
+    }
+    if (blockIdx.x == 0) {
+      v.scal[par].gamma = o.gamma;
+      v.scal[par].alpha = o.alpha;
+      if (!o.ok) {
+        // gamma == 0 with a zero residual is plain convergence, anything else is a breakdown
+        if (!(o.gamma == 0.0 && isfinite(o.delta))) v.st->bad = 1;
+        v.st->done = 1;
+        v.st->iters = it;
+      }
     }
   }
 }
@@ -144,17 +238,6 @@ __device__ __forceinline__ void cgd_acc_z(const CgVec& v, long o, double z, doub
   for (int j = 0; j < kCgMaxModes; ++j)
     if (j < v.dk) cd[j] += v.dAW[(size_t)j * v.n + o] * z;
 }
-// block-level store of the 2k partials of this block into parity slot `par` (all threads; smem >= 4 * 2 * kCgMaxModes)
-__device__ __forceinline__ void cgd_store_partials(const CgVec& v, int par, double (&cd)[2 * kCgMaxModes], double* smem) {
-  if (v.dk == 0) return;
-  block_sum<2 * kCgMaxModes>(cd, smem);
-  if (threadIdx.x == 0) {
-    double* out = v.dcd + ((size_t)par * kCgMaxBlocks + blockIdx.x) * 2 * kCgMaxModes;
-#pragma unroll
-    for (int j = 0; j < 2 * kCgMaxModes; ++j) out[j] = cd[j];
-  }
-}
-
 template <int BS>
 __device__ __forceinline__ void cg_block_init(const CgVec& v, long o, const double* __restrict__ m, double& rz,
                                               double& rr, double (&cd)[2 * kCgMaxModes],
@@ -183,7 +266,7 @@ __device__ __forceinline__ void cg_block_init(const CgVec& v, long o, const doub
 // x = 0, r = b, z = M^-1 b, p = s = 0; partials of (r.z, r.r) into parity slot 0.
 template <int PB, bool HAS_INTR>
 static __global__ void __launch_bounds__(kBlock) k_cg_init(CgVec v) {
-  __shared__ double smem[4 * 2 * kCgMaxModes];
+  __shared__ double smem[4 * (2 + 2 * kCgMaxModes)];
   double acc[2] = {0.0, 0.0};
   double cd[2 * kCgMaxModes] = {};
   const int nblk = v.N + (HAS_INTR ? v.K : 0);
@@ -196,8 +279,22 @@ static __global__ void __launch_bounds__(kBlock) k_cg_init(CgVec v) {
       cg_block_init<8>(v, (long)PB * v.N + 8L * k, v.minv + (long)PB * PB * v.N + 64L * k, acc[0], acc[1], cd);
     }
   }
-  cgd_store_partials(v, 0, cd, smem);
-  block_sum<2>(acc, smem);
+  {
+    constexpr int KD = 2 * kCgMaxModes;
+    double t[2 + KD];
+    t[0] = acc[0];
+    t[1] = acc[1];
+#pragma unroll
+    for (int j = 0; j < KD; ++j) t[2 + j] = cd[j];
+    if (v.dk) block_sum<2 + KD>(t, smem); else block_sum<2>(reinterpret_cast<double(&)[2]>(t), smem);
+    acc[0] = t[0];
+    acc[1] = t[1];
+    if (v.dk && threadIdx.x == 0) {
+      double* oc = v.dcd + (size_t)blockIdx.x * KD;  // parity slot 0
+#pragma unroll
+      for (int j = 0; j < KD; ++j) oc[j] = t[2 + j];
+    }
+  }
   if (threadIdx.x == 0) {
     v.vpart[blockIdx.x * 2] = acc[0];
     v.vpart[blockIdx.x * 2 + 1] = acc[1];
@@ -287,75 +384,25 @@ __device__ __forceinline__ void cg_block_update(const CgVec& v, long o, const do
 // One CG iteration given w = A z (complete) and the delta partials.
 template <int PB, bool HAS_INTR>
 static __global__ void __launch_bounds__(kBlock) k_cg_update(CgVec v, int it) {
-  __shared__ double smem[5 * 2 * kCgMaxModes];
-  // one pass over both sets of partial slots (r.z | r.r of the previous update, delta of this apply);
-  // the loads are issued before the `done` test so that they overlap its round trip
-  double t3[3] = {0.0, 0.0, 0.0};
-  {
-    const double* vp = v.vpart + (size_t)(it & 1) * kCgMaxBlocks * 2;
-    for (int b = threadIdx.x; b < v.nb_update; b += blockDim.x) {
-      t3[0] += vp[2 * b];
-      t3[1] += vp[2 * b + 1];
-    }
-    if (!v.delta_in_w)
-      for (int b = threadIdx.x; b < v.nb_apply; b += blockDim.x) t3[2] += v.dpart[b];
-  }
-  const CgScal prev = v.scal[it & 1];
-  const int done = v.st->done;
-  if (done) return;
-  __shared__ double sbc[3];
-  block_sum<3>(t3, smem);
-  if (threadIdx.x == 0) {
-    sbc[0] = t3[0];
-    sbc[1] = t3[1];
-    sbc[2] = t3[2];
-  }
-  __syncthreads();
-  double y[kCgMaxModes], gcorr, dcorr;
-  cgd_coefficients(v, it & 1, y, gcorr, dcorr, smem);
-  const double gamma = sbc[0] - gcorr;
-  const double delta = (v.delta_in_w ? v.w[v.n] : sbc[2]) - dcorr;
-  __syncthreads();
-  double beta = 0.0, denom = delta;
-  if (it > 0) {
-    beta = prev.gamma > 0.0 ? gamma / prev.gamma : 0.0;
-    denom = delta - beta * gamma / prev.alpha;
-  }
-  const bool ok = isfinite(denom) && denom > 0.0 && isfinite(gamma) && gamma >= 0.0;
-  const double alpha = ok ? gamma / denom : 0.0;
-  if (!ok) beta = 0.0;
+  __shared__ double smem[kCgStepSmem];
+  CgStep st;
+  if (!cg_step_prologue(v, it, st, smem)) return;
   double acc[2] = {0.0, 0.0};
   double cd[2 * kCgMaxModes] = {};
   const int nblk = v.N + (HAS_INTR ? v.K : 0);
-  if (ok) {
+  if (st.ok) {
     for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += gridDim.x * blockDim.x) {
       if (b < v.N) {
-        cg_block_update<PB>(v, (long)PB * b, v.minv + (long)PB * PB * b, alpha, beta, acc[0], acc[1], y, cd,
+        cg_block_update<PB>(v, (long)PB * b, v.minv + (long)PB * PB * b, st.alpha, st.beta, acc[0], acc[1], st.y, cd,
                             v.zmir ? v.zmir + (long)b * v.zmir_stride + v.zmir_off : nullptr);
       } else if constexpr (HAS_INTR) {
         const int k = b - v.N;
-        cg_block_update<8>(v, (long)PB * v.N + 8L * k, v.minv + (long)PB * PB * v.N + 64L * k, alpha, beta, acc[0],
-                           acc[1], y, cd);
+        cg_block_update<8>(v, (long)PB * v.N + 8L * k, v.minv + (long)PB * PB * v.N + 64L * k, st.alpha, st.beta, acc[0],
+                           acc[1], st.y, cd);
       }
     }
   }
-  cgd_store_partials(v, (it + 1) & 1, cd, smem);
-  block_sum<2>(acc, smem);
-  if (threadIdx.x == 0) {
-    double* out = v.vpart + (size_t)((it + 1) & 1) * kCgMaxBlocks * 2;
-    out[blockIdx.x * 2] = acc[0];
-    out[blockIdx.x * 2 + 1] = acc[1];
-    if (blockIdx.x == 0) {
-      v.scal[(it + 1) & 1].gamma = gamma;
-      v.scal[(it + 1) & 1].alpha = alpha;
-      if (!ok) {
-        // gamma == 0 with a zero residual is plain convergence, anything else is a breakdown
-        if (!(gamma == 0.0 && isfinite(delta))) v.st->bad = 1;
-        v.st->done = 1;
-        v.st->iters = it;
-      }
-    }
-  }
+  cg_step_epilogue(v, it, st, acc[0], acc[1], cd, smem);
 }
 
 
@@ -486,7 +533,7 @@ __device__ __forceinline__ void cg_joint_mirror(const CgVec& v, int n, int i, do
 template <int PB>
 static __global__ void __launch_bounds__(kBlock) k_cg_init_joint(CgVec v) {
   constexpr int BJ = PB + 8;
-  __shared__ double smem[4 * 2 * kCgMaxModes];
+  __shared__ double smem[4 * (2 + 2 * kCgMaxModes)];
   __shared__ double sr[kJointCams][16];
   const int c = threadIdx.x >> 4, i = threadIdx.x & 15;
   double acc[2] = {0.0, 0.0};
@@ -520,8 +567,22 @@ static __global__ void __launch_bounds__(kBlock) k_cg_init_joint(CgVec v) {
       cgd_acc_z(v, o, zi, cd);
     }
   }
-  cgd_store_partials(v, 0, cd, smem);
-  block_sum<2>(acc, smem);
+  {
+    constexpr int KD = 2 * kCgMaxModes;
+    double t[2 + KD];
+    t[0] = acc[0];
+    t[1] = acc[1];
+#pragma unroll
+    for (int j = 0; j < KD; ++j) t[2 + j] = cd[j];
+    if (v.dk) block_sum<2 + KD>(t, smem); else block_sum<2>(reinterpret_cast<double(&)[2]>(t), smem);
+    acc[0] = t[0];
+    acc[1] = t[1];
+    if (v.dk && threadIdx.x == 0) {
+      double* oc = v.dcd + (size_t)blockIdx.x * KD;  // parity slot 0
+#pragma unroll
+      for (int j = 0; j < KD; ++j) oc[j] = t[2 + j];
+    }
+  }
   if (threadIdx.x == 0) {
     v.vpart[blockIdx.x * 2] = acc[0];
     v.vpart[blockIdx.x * 2 + 1] = acc[1];
@@ -540,36 +601,15 @@ static __global__ void __launch_bounds__(kBlock) k_cg_init_joint(CgVec v) {
 template <int PB>
 static __global__ void __launch_bounds__(kBlock) k_cg_update_joint(CgVec v, int it) {
   constexpr int BJ = PB + 8;
-  __shared__ double smem[5 * 2 * kCgMaxModes];
+  __shared__ double smem[kCgStepSmem];
   __shared__ double sr[kJointCams][16];
-  if (v.st->done) return;
-  double g[2];
-  reduce_partials<2>(v.vpart + (size_t)(it & 1) * kCgMaxBlocks * 2, v.nb_update, g, smem);
-  double delta;
-  if (v.delta_in_w) {
-    delta = v.w[v.n];
-  } else {
-    double d[1];
-    reduce_partials<1>(v.dpart, v.nb_apply, d, smem);
-    delta = d[0];
-  }
-  double y[kCgMaxModes], gcorr, dcorr;
-  cgd_coefficients(v, it & 1, y, gcorr, dcorr, smem);
-  delta -= dcorr;
-  const double gamma = g[0] - gcorr;
-  const CgScal prev = v.scal[it & 1];
-  double beta = 0.0, denom = delta;
-  if (it > 0) {
-    beta = prev.gamma > 0.0 ? gamma / prev.gamma : 0.0;
-    denom = delta - beta * gamma / prev.alpha;
-  }
-  const bool ok = isfinite(denom) && denom > 0.0 && isfinite(gamma) && gamma >= 0.0;
-  const double alpha = ok ? gamma / denom : 0.0;
-  if (!ok) beta = 0.0;
+  CgStep st;
+  if (!cg_step_prologue(v, it, st, smem)) return;
+  const double alpha = st.alpha, beta = st.beta;
   double acc[2] = {0.0, 0.0};
   double cd[2 * kCgMaxModes] = {};
   const int c = threadIdx.x >> 4, i = threadIdx.x & 15;
-  if (ok) {
+  if (st.ok) {
     for (int n0 = blockIdx.x * kJointCams; n0 < v.N; n0 += gridDim.x * kJointCams) {
       const int n = n0 + c;
       const bool act = n < v.N && i < BJ;
@@ -578,7 +618,7 @@ static __global__ void __launch_bounds__(kBlock) k_cg_update_joint(CgVec v, int 
       if (act) {
         o = cg_joint_index<PB>(v, n, i);
         double zo = v.z[o], wo = v.w[o];
-        cgd_project(v, o, y, zo, wo);
+        cgd_project(v, o, st.y, zo, wo);
         const double pi = zo + beta * v.p[o];
         const double si = wo + beta * v.s[o];
         v.p[o] = pi;
@@ -604,22 +644,7 @@ static __global__ void __launch_bounds__(kBlock) k_cg_update_joint(CgVec v, int 
       }
     }
   }
-  cgd_store_partials(v, (it + 1) & 1, cd, smem);
-  block_sum<2>(acc, smem);
-  if (threadIdx.x == 0) {
-    double* out = v.vpart + (size_t)((it + 1) & 1) * kCgMaxBlocks * 2;
-    out[blockIdx.x * 2] = acc[0];
-    out[blockIdx.x * 2 + 1] = acc[1];
-    if (blockIdx.x == 0) {
-      v.scal[(it + 1) & 1].gamma = gamma;
-      v.scal[(it + 1) & 1].alpha = alpha;
-      if (!ok) {
-        if (!(gamma == 0.0 && isfinite(delta))) v.st->bad = 1;
-        v.st->done = 1;
-        v.st->iters = it;
-      }
-    }
-  }
+  cg_step_epilogue(v, it, st, acc[0], acc[1], cd, smem);
 }
 
 // Single-block reduction of the delta partials into w[n] (multi-rank: w[0..n] is all-reduced next).
@@ -682,79 +707,80 @@ static __global__ void __launch_bounds__(kBlock) k_cgd_copy(long n, const double
   for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x) dst[o] = src[o];
 }
 
-// partial Gram products of this block's slice: part[block][i * (K + 1) + j] = W_i . (A W_j), j == K: W_i . b
+// partial Gram products of this block's slice, one row of E per blockIdx.y:
+// part[block][i * (K + 1) + j] = W_i . (A W_j), j == K: W_i . b        (i = blockIdx.y)
 template <int K>
 static __global__ void __launch_bounds__(kBlock) k_cgd_gram_dots(CgVec v, CgDeflation d) {
-  __shared__ double smem[4 * K * (K + 1)];
-  double acc[K * (K + 1)] = {};
+  __shared__ double smem[4 * (K + 1)];
+  const int i = blockIdx.y;
+  double acc[K + 1] = {};
+  const double* wi = d.W + (size_t)i * v.n;
   for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < (long)v.n; o += (long)gridDim.x * blockDim.x) {
-    double c[K + 1];
+    const double a = wi[o];
 #pragma unroll
-    for (int j = 0; j < K; ++j) c[j] = d.AW[(size_t)j * v.n + o];
-    c[K] = v.b[o];
-#pragma unroll
-    for (int i = 0; i < K; ++i) {
-      const double a = d.W[(size_t)i * v.n + o];
-#pragma unroll
-      for (int j = 0; j <= K; ++j) acc[i * (K + 1) + j] += a * c[j];
-    }
+    for (int j = 0; j < K; ++j) acc[j] += a * d.AW[(size_t)j * v.n + o];
+    acc[K] += a * v.b[o];
   }
-  block_sum<K * (K + 1)>(acc, smem);
+  block_sum<K + 1>(acc, smem);
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int j = 0; j < K * (K + 1); ++j) d.part[(size_t)blockIdx.x * kCgdGram + j] = acc[j];
+    for (int j = 0; j <= K; ++j) d.part[(size_t)blockIdx.x * kCgdGram + i * (K + 1) + j] = acc[j];
   }
 }
 
-// E = W^T A W (symmetrised), E^-1 by Gauss-Jordan with a positivity test, y0 = E^-1 W^T b.  One workgroup.
+// E = W^T A W (symmetrised), E^-1 by Gauss-Jordan with a positivity test, y0 = E^-1 W^T b.  One wave: lane j < 2K holds
+// column j of [E | I], the K pivot steps run on registers with wave broadcasts.
 template <int K>
-static __global__ void __launch_bounds__(kBlock) k_cgd_gram_solve(CgDeflation d, int nparts) {
-  __shared__ double smem[5 * K * (K + 1)];
-  double G[K * (K + 1)];
-  {
-    double acc[K * (K + 1)] = {};
-    for (int b = threadIdx.x; b < nparts; b += blockDim.x) {
+static __global__ void __launch_bounds__(64) k_cgd_gram_solve(CgDeflation d, int nparts) {
+  const int lane = threadIdx.x;
+  // column sums of the partial Gram products: lane l < K (K + 1) owns entry l
+  double g = 0.0;
+  if (lane < K * (K + 1))
+    for (int b = 0; b < nparts; ++b) g += d.part[(size_t)b * kCgdGram + lane];
+  // a[r] = entry (r, lane) of [E_sym | I]
+  double a[K];
+  double rhs[K];  // W^T b, the same in every lane
 #pragma unroll
-      for (int j = 0; j < K * (K + 1); ++j) acc[j] += d.part[(size_t)b * kCgdGram + j];
-    }
-    block_sum<K * (K + 1)>(acc, smem);
-#pragma unroll
-    for (int j = 0; j < K * (K + 1); ++j) G[j] = acc[j];
+  for (int r = 0; r < K; ++r) {
+    const double e_rc = __shfl(g, r * (K + 1) + (lane < K ? lane : 0), 64);
+    const double e_cr = __shfl(g, (lane < K ? lane : 0) * (K + 1) + r, 64);
+    a[r] = lane < K ? 0.5 * (e_rc + e_cr) : (lane - K == r ? 1.0 : 0.0);
+    rhs[r] = __shfl(g, r * (K + 1) + K, 64);
   }
-  if (threadIdx.x != 0) return;
-  double A[K][2 * K];
   bool ok = true;
-  for (int i = 0; i < K; ++i)
-    for (int j = 0; j < K; ++j) {
-      A[i][j] = 0.5 * (G[i * (K + 1) + j] + G[j * (K + 1) + i]);
-      A[i][K + j] = i == j ? 1.0 : 0.0;
-    }
-  for (int c = 0; c < K && ok; ++c) {  // SPD: the pivots are the diagonal
-    const double piv = A[c][c];
-    if (!(piv > 0.0) || !isfinite(piv)) {
-      ok = false;
-      break;
-    }
+#pragma unroll
+  for (int c = 0; c < K; ++c) {  // SPD: the pivots are the diagonal
+    const double piv = __shfl(a[c], c, 64);
+    if (!(piv > 0.0) || !isfinite(piv)) ok = false;
     const double ip = 1.0 / piv;
-    for (int j = 0; j < 2 * K; ++j) A[c][j] *= ip;
+    const double rowc = a[c] * ip;  // scaled pivot row, this lane's column
+#pragma unroll
     for (int r = 0; r < K; ++r) {
-      if (r == c) continue;
-      const double f = A[r][c];
-      for (int j = 0; j < 2 * K; ++j) A[r][j] -= f * A[c][j];
+      const double f = __shfl(a[r], c, 64);  // entry (r, c) before the step
+      a[r] = r == c ? rowc : a[r] - f * rowc;
     }
   }
-  double y0[K];
-  for (int i = 0; i < K; ++i) {
-    double y = 0.0;
-    for (int j = 0; j < K; ++j) y += A[i][K + j] * G[j * (K + 1) + K];
-    if (!isfinite(y)) ok = false;
-    y0[i] = y;
+  // lanes K .. 2K-1 hold the columns of E^-1: lane K + j has (E^-1)[r][j] in a[r]
+  double y0 = 0.0;  // lane K + j contributes (E^-1)[i][j] rhs[j] to y0[i]: sum over lanes per row
+  double yv[K];
+#pragma unroll
+  for (int r = 0; r < K; ++r) {
+    double t = (lane >= K && lane < 2 * K) ? a[r] * rhs[lane - K] : 0.0;
+    t = wave_sum(t);
+    yv[r] = __shfl(t, 0, 64);
+    if (!isfinite(yv[r])) ok = false;
   }
-  for (int i = 0; i < kCgMaxModes; ++i) {
-    for (int j = 0; j < kCgMaxModes; ++j) d.small[i * kCgMaxModes + j] = (ok && i < K && j < K) ? A[i][K + j] : 0.0;
-    d.small[64 + i] = (ok && i < K) ? y0[i] : 0.0;
+  (void)y0;
+  if (lane >= K && lane < 2 * K) {
+#pragma unroll
+    for (int r = 0; r < K; ++r) d.small[r * kCgMaxModes + (lane - K)] = ok ? a[r] : 0.0;
   }
-  d.small[72] = ok ? 1.0 : 0.0;
+  if (lane == 0) {
+    for (int i = 0; i < kCgMaxModes; ++i) d.small[64 + i] = 0.0;
+#pragma unroll
+    for (int r = 0; r < K; ++r) d.small[64 + r] = ok ? yv[r] : 0.0;
+    d.small[72] = ok ? 1.0 : 0.0;
+  }
 }
 
 // b2 = b - A W y0
@@ -824,11 +850,11 @@ inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& 
     v.probe = 0;
     const int gdot = std::min(kCgdBlocks, grid_for((size_t)v.n, kBlock));
     if (defl->k == 4) {
-      hipLaunchKernelGGL((k_cgd_gram_dots<4>), dim3(gdot), dim3(kBlock), 0, s, v, *defl);
-      hipLaunchKernelGGL((k_cgd_gram_solve<4>), dim3(1), dim3(kBlock), 0, s, *defl, gdot);
+      hipLaunchKernelGGL((k_cgd_gram_dots<4>), dim3(gdot, 4), dim3(kBlock), 0, s, v, *defl);
+      hipLaunchKernelGGL((k_cgd_gram_solve<4>), dim3(1), dim3(64), 0, s, *defl, gdot);
     } else if (defl->k == 7) {
-      hipLaunchKernelGGL((k_cgd_gram_dots<7>), dim3(gdot), dim3(kBlock), 0, s, v, *defl);
-      hipLaunchKernelGGL((k_cgd_gram_solve<7>), dim3(1), dim3(kBlock), 0, s, *defl, gdot);
+      hipLaunchKernelGGL((k_cgd_gram_dots<7>), dim3(gdot, 7), dim3(kBlock), 0, s, v, *defl);
+      hipLaunchKernelGGL((k_cgd_gram_solve<7>), dim3(1), dim3(64), 0, s, *defl, gdot);
     } else {
       throw StatusError(GSFM_ERR_INVALID_ARGUMENT, "cg_solve: 4 or 7 deflated modes");
     }
