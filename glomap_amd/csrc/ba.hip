@@ -1904,7 +1904,7 @@ class BaSolver final : public LmProblem {
     cg_.n = n_;
     cg_.N = Np_;
     cg_.K = K_;
-    cg_.nb_update = joint_ ? std::min(kCgMaxBlocks, grid_for(N_, kJointCams)) : std::min(kCgMaxBlocks, grid_for(Np_ + K_, kBlock));
+    cg_.nb_update = joint_ ? std::min(kCgUpdateBlocks, grid_for(N_, kJointCams)) : std::min(kCgUpdateBlocks, grid_for(Np_ + K_, kBlock));
     cg_.zrec = joint_ ? ws->zrec.get() : nullptr;
     cg_.zrec_stride = 6 + F_;
     cg_.zrec_slot = joint_ ? ws->intr_slot.get() : nullptr;

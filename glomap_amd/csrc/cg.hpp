@@ -37,7 +37,8 @@
 
 namespace gsfm {
 
-constexpr int kCgMaxBlocks = 512;  // grid cap of the vector kernels (k_cg_init / k_cg_update)
+constexpr int kCgMaxBlocks = 512;  // partial-slot capacity of the vector kernels (k_cg_init / k_cg_update)
+constexpr int kCgUpdateBlocks = 128;  // their grid: every block re-reduces the slots of all blocks, so few, fat blocks
 constexpr int kCgMaxModes = 8;     // deflated modes per solve (CgDeflation)
 constexpr int kMaxApplySlots = 4096;  // cap of the delta partial slots one apply kernel may write
 
@@ -108,42 +109,57 @@ struct CgStep {
   bool ok;
   double y[kCgMaxModes];
 };
-constexpr int kCgStepSmem = 4 * (3 + 2 * kCgMaxModes) + 16 + kCgMaxModes * kCgMaxModes;
 
-// Prologue of the vector update of iteration `it`: ONE block reduction over all partial slots (r.z | r.r of the previous
-// update, delta of this apply, the 2k deflation dot products), then alpha / beta.  Returns false when the solve is finished.
+constexpr int kCgStepSmem = 8 * 32 + 32 + 16 + kCgMaxModes * kCgMaxModes;
+
+// Prologue of the vector update of iteration `it`: totals of all partial slots (r.z | r.r of the previous update, delta of
+// this apply, the 2k deflation dot products), then alpha / beta.  Returns false when the solve is finished.
+// The slot arrays are summed "transposed" — thread (g, l) adds column l of the slots b = g, g + 8, ... — so the totals
+// need no cross-lane shuffles at all (first version: a 19-value block reduction, 230 LDS permutes per wave; the kernel
+// took 50 us in deflated solves).  Only delta, one value spread over up to 4 096 slots, goes through a wave reduction.
 // The loads are issued before the `done` test so that they overlap its round trip.
 __device__ __forceinline__ bool cg_step_prologue(const CgVec& v, int it, CgStep& o, double* smem /* >= kCgStepSmem */) {
   constexpr int KD = 2 * kCgMaxModes;
-  double t[3 + KD];
-#pragma unroll
-  for (int j = 0; j < 3 + KD; ++j) t[j] = 0.0;
   const int par = it & 1;
+  const int g = threadIdx.x >> 5, l = threadIdx.x & 31;  // 8 groups of 32 lanes: column l of the slots b = g (mod 8)
+  double col = 0.0, dl = 0.0;
   {
     const double* vp = v.vpart + (size_t)par * kCgMaxBlocks * 2;
     const double* cp = v.dcd + (size_t)par * kCgMaxBlocks * KD;
-    for (int b = threadIdx.x; b < v.nb_update; b += blockDim.x) {
-      t[0] += vp[2 * b];
-      t[1] += vp[2 * b + 1];
-      if (v.dk) {
-#pragma unroll
-        for (int j = 0; j < KD; ++j) t[3 + j] += cp[(size_t)b * KD + j];
-      }
+    if (l < 2) {
+      for (int b = g; b < v.nb_update; b += 8) col += vp[2 * b + l];
+    } else if (v.dk && l >= 3 && l < 3 + KD) {
+      for (int b = g; b < v.nb_update; b += 8) col += cp[(size_t)b * KD + (l - 3)];
     }
     if (!v.delta_in_w)
-      for (int b = threadIdx.x; b < v.nb_apply; b += blockDim.x) t[2] += v.dpart[b];
+      for (int b = threadIdx.x; b < v.nb_apply; b += blockDim.x) dl += v.dpart[b];
   }
-  double* sE = smem + 4 * (3 + KD) + 16;  // E^-1, staged by the first 64 threads
+  double* sg = smem;                 // [8][32] group partials
+  double* stot = smem + 8 * 32;      // [32] totals (column 2 = delta)
+  double* sb = smem + 8 * 32 + 32;   // [16] the step's scalars
+  double* sE = sb + 16;              // E^-1, staged by the first 64 threads
   if (v.dk && threadIdx.x < kCgMaxModes * kCgMaxModes) sE[threadIdx.x] = v.dsmall[threadIdx.x];
   const double dok = v.dk ? v.dsmall[72] : 0.0;
   const CgScal prev = v.scal[par];
   const double wn = v.delta_in_w ? v.w[v.n] : 0.0;
   const int done = v.st->done;
   if (done) return false;
-  if (v.dk) block_sum<3 + KD>(t, smem); else block_sum<3>(reinterpret_cast<double(&)[3]>(t), smem);
-  double* sb = smem + 4 * (3 + KD);
+  sg[g * 32 + l] = col;
+  dl = wave_sum_dpp(dl);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 63) sg[(threadIdx.x >> 6) * 32 + 2] = dl;  // column 2 of groups 0..3: the waves' delta sums
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    double t = 0.0;
+    const int ng = threadIdx.x == 2 ? (int)(blockDim.x >> 6) : 8;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (q < ng) t += sg[q * 32 + threadIdx.x];
+    stot[threadIdx.x] = t;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    double gamma = t[0], delta = v.delta_in_w ? wn : t[2];
+    double gamma = stot[0], delta = v.delta_in_w ? wn : stot[2];
     double y[kCgMaxModes];
 #pragma unroll
     for (int i = 0; i < kCgMaxModes; ++i) y[i] = 0.0;
@@ -154,10 +170,10 @@ __device__ __forceinline__ bool cg_step_prologue(const CgVec& v, int it, CgStep&
           double a = 0.0;
 #pragma unroll
           for (int j = 0; j < kCgMaxModes; ++j)
-            if (j < v.dk) a += sE[i * kCgMaxModes + j] * t[3 + j];
+            if (j < v.dk) a += sE[i * kCgMaxModes + j] * stot[3 + j];
           y[i] = a;
-          gamma -= a * t[3 + kCgMaxModes + i];  // r.z_p = r.z - (W^T r).y
-          delta -= a * t[3 + i];                // z_p.w_p = z.w - y.((A W)^T z)
+          gamma -= a * stot[3 + kCgMaxModes + i];  // r.z_p = r.z - (W^T r).y
+          delta -= a * stot[3 + i];                // z_p.w_p = z.w - y.((A W)^T z)
         }
     }
     double beta = 0.0, denom = delta;
@@ -196,7 +212,7 @@ __device__ __forceinline__ void cg_step_epilogue(const CgVec& v, int it, const C
   t[1] = rr;
 #pragma unroll
   for (int j = 0; j < KD; ++j) t[2 + j] = cd[j];
-  if (v.dk) block_sum<2 + KD>(t, smem); else block_sum<2>(reinterpret_cast<double(&)[2]>(t), smem);
+  if (v.dk) block_sum_dpp<2 + KD>(t, smem); else block_sum_dpp<2>(reinterpret_cast<double(&)[2]>(t), smem);
   if (threadIdx.x == 0) {
     const int par = (it + 1) & 1;
     double* out = v.vpart + (size_t)par * kCgMaxBlocks * 2;
@@ -349,35 +365,92 @@ __device__ __forceinline__ bool cg_converged(const CgVec& v, int it, double tol2
   return done;
 }
 
+// All loads of a block are issued BEFORE its first store: the vectors may alias as far as the compiler knows, so a load
+// placed after a store waits for it — per element that was a chain of dependent round trips (36 us for 10 000 camera
+// blocks with four deflated modes; the whole kernel is a handful of round trips now).
 template <int BS>
 __device__ __forceinline__ void cg_block_update(const CgVec& v, long o, const double* __restrict__ m, double alpha,
                                                 double beta, double& rz, double& rr,
                                                 const double (&y)[kCgMaxModes], double (&cd)[2 * kCgMaxModes],
                                                 double* __restrict__ mir = nullptr) {
-  double rn[BS];
+  double zi[BS], wi[BS], pi[BS], si[BS], xi[BS], ri[BS], mm[BS * BS];
 #pragma unroll
   for (int i = 0; i < BS; ++i) {
-    double zi = v.z[o + i], wi = v.w[o + i];
-    cgd_project(v, o + i, y, zi, wi);
-    const double pi = zi + beta * v.p[o + i];
-    const double si = wi + beta * v.s[o + i];
-    v.p[o + i] = pi;
-    v.s[o + i] = si;
-    v.x[o + i] += alpha * pi;
-    rn[i] = v.r[o + i] - alpha * si;
-    v.r[o + i] = rn[i];
-    rr += rn[i] * rn[i];
-    cgd_acc_r(v, o + i, rn[i], cd);
+    zi[i] = v.z[o + i];
+    wi[i] = v.w[o + i];
+    pi[i] = v.p[o + i];
+    si[i] = v.s[o + i];
+    xi[i] = v.x[o + i];
+    ri[i] = v.r[o + i];
+  }
+#pragma unroll
+  for (int i = 0; i < BS * BS; ++i) mm[i] = m[i];
+  double rn[BS], zn[BS];
+  if constexpr (BS <= 3) {
+    // deflation: W and A W of the block's elements in registers, used for the projection and for the new dot products
+    double Wv[BS][kCgMaxModes], AWv[BS][kCgMaxModes];
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < kCgMaxModes; ++j) {
+        Wv[i][j] = j < v.dk ? v.dW[(size_t)j * v.n + o + i] : 0.0;
+        AWv[i][j] = j < v.dk ? v.dAW[(size_t)j * v.n + o + i] : 0.0;
+      }
+#pragma unroll
+    for (int i = 0; i < BS; ++i) {
+#pragma unroll
+      for (int j = 0; j < kCgMaxModes; ++j) {
+        zi[i] -= y[j] * Wv[i][j];
+        wi[i] -= y[j] * AWv[i][j];
+      }
+      pi[i] = zi[i] + beta * pi[i];
+      si[i] = wi[i] + beta * si[i];
+      xi[i] += alpha * pi[i];
+      rn[i] = ri[i] - alpha * si[i];
+      rr += rn[i] * rn[i];
+#pragma unroll
+      for (int j = 0; j < kCgMaxModes; ++j) cd[kCgMaxModes + j] += Wv[i][j] * rn[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BS; ++i) {
+      double t = 0.0;
+#pragma unroll
+      for (int j = 0; j < BS; ++j) t += mm[i * BS + j] * rn[j];
+      zn[i] = t;
+      rz += rn[i] * t;
+#pragma unroll
+      for (int j = 0; j < kCgMaxModes; ++j) cd[j] += AWv[i][j] * t;
+    }
+  } else {
+    // wide blocks (pose 6 / intrinsics 8 of the separate-block layout): the mode values are fetched per element
+#pragma unroll
+    for (int i = 0; i < BS; ++i) {
+      cgd_project(v, o + i, y, zi[i], wi[i]);
+      pi[i] = zi[i] + beta * pi[i];
+      si[i] = wi[i] + beta * si[i];
+      xi[i] += alpha * pi[i];
+      rn[i] = ri[i] - alpha * si[i];
+      rr += rn[i] * rn[i];
+      cgd_acc_r(v, o + i, rn[i], cd);
+    }
+#pragma unroll
+    for (int i = 0; i < BS; ++i) {
+      double t = 0.0;
+#pragma unroll
+      for (int j = 0; j < BS; ++j) t += mm[i * BS + j] * rn[j];
+      zn[i] = t;
+      rz += rn[i] * t;
+      cgd_acc_z(v, o + i, t, cd);
+    }
   }
 #pragma unroll
   for (int i = 0; i < BS; ++i) {
-    double zi = 0.0;
-#pragma unroll
-    for (int j = 0; j < BS; ++j) zi += m[i * BS + j] * rn[j];
-    v.z[o + i] = zi;
-    if (mir) mir[i] = zi;
-    rz += rn[i] * zi;
-    cgd_acc_z(v, o + i, zi, cd);
+    v.p[o + i] = pi[i];
+    v.s[o + i] = si[i];
+    v.x[o + i] = xi[i];
+    v.r[o + i] = rn[i];
+    v.z[o + i] = zn[i];
+    if (mir) mir[i] = zn[i];
   }
 }
 
@@ -615,32 +688,49 @@ static __global__ void __launch_bounds__(kBlock) k_cg_update_joint(CgVec v, int 
       const bool act = n < v.N && i < BJ;
       long o = 0;
       double ri = 0.0;
+      double mrow[BJ], awv[kCgMaxModes];
       if (act) {
         o = cg_joint_index<PB>(v, n, i);
+        // every load of this element first (see cg_block_update): vectors, its preconditioner row, its mode values
         double zo = v.z[o], wo = v.w[o];
-        cgd_project(v, o, st.y, zo, wo);
-        const double pi = zo + beta * v.p[o];
-        const double si = wo + beta * v.s[o];
+        const double po = v.p[o], so = v.s[o], xo = v.x[o], ro = v.r[o];
+        const double* m = v.minv_joint + n;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) mrow[j] = m[(size_t)(i * BJ + j) * v.N];
+        double wv[kCgMaxModes];
+#pragma unroll
+        for (int j = 0; j < kCgMaxModes; ++j) {
+          wv[j] = j < v.dk ? v.dW[(size_t)j * v.n + o] : 0.0;
+          awv[j] = j < v.dk ? v.dAW[(size_t)j * v.n + o] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < kCgMaxModes; ++j) {
+          zo -= st.y[j] * wv[j];
+          wo -= st.y[j] * awv[j];
+        }
+        const double pi = zo + beta * po;
+        const double si = wo + beta * so;
+        ri = ro - alpha * si;
         v.p[o] = pi;
         v.s[o] = si;
-        v.x[o] += alpha * pi;
-        ri = v.r[o] - alpha * si;
+        v.x[o] = xo + alpha * pi;
         v.r[o] = ri;
         acc[1] += ri * ri;
-        cgd_acc_r(v, o, ri, cd);
+#pragma unroll
+        for (int j = 0; j < kCgMaxModes; ++j) cd[kCgMaxModes + j] += wv[j] * ri;
       }
       __syncthreads();
       sr[c][i] = ri;
       __syncthreads();
       if (act) {
-        const double* m = v.minv_joint + n;
         double zi = 0.0;
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) zi += m[(size_t)(i * BJ + j) * v.N] * sr[c][j];
+        for (int j = 0; j < BJ; ++j) zi += mrow[j] * sr[c][j];
         v.z[o] = zi;
         cg_joint_mirror<PB>(v, n, i, zi);
         acc[0] += ri * zi;
-        cgd_acc_z(v, o, zi, cd);
+#pragma unroll
+        for (int j = 0; j < kCgMaxModes; ++j) cd[j] += awv[j] * zi;
       }
     }
   }
@@ -731,12 +821,20 @@ static __global__ void __launch_bounds__(kBlock) k_cgd_gram_dots(CgVec v, CgDefl
 // E = W^T A W (symmetrised), E^-1 by Gauss-Jordan with a positivity test, y0 = E^-1 W^T b.  One wave: lane j < 2K holds
 // column j of [E | I], the K pivot steps run on registers with wave broadcasts.
 template <int K>
-static __global__ void __launch_bounds__(64) k_cgd_gram_solve(CgDeflation d, int nparts) {
-  const int lane = threadIdx.x;
-  // column sums of the partial Gram products: lane l < K (K + 1) owns entry l
-  double g = 0.0;
-  if (lane < K * (K + 1))
-    for (int b = 0; b < nparts; ++b) g += d.part[(size_t)b * kCgdGram + lane];
+static __global__ void __launch_bounds__(kBlock) k_cgd_gram_solve(CgDeflation d, int nparts) {
+  __shared__ double sg[4][64];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  // column sums of the partial Gram products: lane l < K (K + 1) owns entry l; the four waves take a quarter of the
+  // partial slots each (fixed order), wave 0 finishes
+  {
+    double gq = 0.0;
+    if (lane < K * (K + 1))
+      for (int b = q; b < nparts; b += 4) gq += d.part[(size_t)b * kCgdGram + lane];
+    sg[q][lane] = gq;
+  }
+  __syncthreads();
+  if (q != 0) return;
+  const double g = (sg[0][lane] + sg[1][lane]) + (sg[2][lane] + sg[3][lane]);
   // a[r] = entry (r, lane) of [E_sym | I]
   double a[K];
   double rhs[K];  // W^T b, the same in every lane
@@ -851,10 +949,10 @@ inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& 
     const int gdot = std::min(kCgdBlocks, grid_for((size_t)v.n, kBlock));
     if (defl->k == 4) {
       hipLaunchKernelGGL((k_cgd_gram_dots<4>), dim3(gdot, 4), dim3(kBlock), 0, s, v, *defl);
-      hipLaunchKernelGGL((k_cgd_gram_solve<4>), dim3(1), dim3(64), 0, s, *defl, gdot);
+      hipLaunchKernelGGL((k_cgd_gram_solve<4>), dim3(1), dim3(kBlock), 0, s, *defl, gdot);
     } else if (defl->k == 7) {
       hipLaunchKernelGGL((k_cgd_gram_dots<7>), dim3(gdot, 7), dim3(kBlock), 0, s, v, *defl);
-      hipLaunchKernelGGL((k_cgd_gram_solve<7>), dim3(1), dim3(64), 0, s, *defl, gdot);
+      hipLaunchKernelGGL((k_cgd_gram_solve<7>), dim3(1), dim3(kBlock), 0, s, *defl, gdot);
     } else {
       throw StatusError(GSFM_ERR_INVALID_ARGUMENT, "cg_solve: 4 or 7 deflated modes");
     }

@@ -15,6 +15,48 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;  // valid in lane 0
 }
 
+// The same sum through the DPP network (row shifts inside the 16-lane rows, then the two row broadcasts): VALU moves
+// instead of twelve LDS permutes per double — for kernels that reduce many values per thread.  Valid in lane 63.
+// (Other summation tree than wave_sum: not interchangeable where bit-identical partials are compared.)
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_move_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, BANK_MASK, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, BANK_MASK, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v += dpp_move_f64<0x111, 0xf, 0xf>(v);  // row_shr:1
+  v += dpp_move_f64<0x112, 0xf, 0xf>(v);  // row_shr:2
+  v += dpp_move_f64<0x114, 0xf, 0xe>(v);  // row_shr:4
+  v += dpp_move_f64<0x118, 0xf, 0xc>(v);  // row_shr:8   -> lane 15 of every row holds the row's sum
+  v += dpp_move_f64<0x142, 0xa, 0xf>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_move_f64<0x143, 0xc, 0xf>(v);  // row_bcast:31 into rows 2 and 3
+  return v;  // valid in lane 63
+}
+// Block-wide sum of K values per thread through wave_sum_dpp; result valid in thread 0.  kBlock threads (4 waves).
+template <int K>
+__device__ __forceinline__ void block_sum_dpp(double (&v)[K], double* smem /* >= 4*K doubles */) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = wave_sum_dpp(v[k]);
+  __syncthreads();  // protect smem reuse across consecutive calls
+  if (lane == 63) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) smem[wave * K + k] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = blockDim.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      double s = 0.0;
+      for (int w = 0; w < nw; ++w) s += smem[w * K + k];
+      v[k] = s;
+    }
+  }
+}
+
 // Sum over the `W`-lane aligned group the lane belongs to; result valid in every lane of the group.
 template <int W>
 __device__ __forceinline__ double group_sum(double v) {

@@ -1074,7 +1074,7 @@ class GpSolver final : public LmProblem {
     cg_.n = 3 * Np_;
     cg_.N = Np_;
     cg_.K = 0;
-    cg_.nb_update = std::min(kCgMaxBlocks, grid_for(Np_, kBlock));
+    cg_.nb_update = std::min(kCgUpdateBlocks, grid_for(Np_, kBlock));
     cg_.nb_apply = gridCam_ + gridMulti_;  // + the delta slots of the combine pass (k_gp_phaseB)
     cg_.b = ws->rhs.get();
     cg_.x = ws->cg_x.get();

@@ -1197,7 +1197,7 @@ int pcg_solve(RaDevice& d, bool warm, double tol, int max_iter) {
   v.n = (int)n3;
   v.N = N;
   v.K = 0;
-  v.nb_update = std::min(kCgMaxBlocks, grid_for(N, kBlock));
+  v.nb_update = std::min(kCgUpdateBlocks, grid_for(N, kBlock));
   const int gA = grid_wide(N, kBlock / d.lpr, kMaxApplySlots);
   v.nb_apply = gA;
   v.b = b;
@@ -1936,7 +1936,7 @@ int rig_pcg_solve(RigSolve& g, bool warm, double tol, int max_iter) {
   v.n = (int)n3;
   v.N = n;
   v.K = 0;
-  v.nb_update = std::min(kCgMaxBlocks, grid_for(n, kBlock));
+  v.nb_update = std::min(kCgUpdateBlocks, grid_for(n, kBlock));
   const int gD = std::min(64, grid_for((size_t)n3, kBlock));
   v.nb_apply = gD;
   v.b = b;
