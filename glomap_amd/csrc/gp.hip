@@ -477,16 +477,50 @@ __global__ void __launch_bounds__(kBlock)
     const V3 cn = ld3(c + 3 * (long)n);
     const V3 zn = ld3(v.z + 3 * (long)n);
     double acc[3] = {0, 0, 0};
-    for (int k = cam_seg_k0(g.g, sg) + lane; k < cam_seg_k1(g.g, sg); k += 64) {
-      const long p = g.g.c_pt[k];
-      const double ak = c_qa[k], bk = c_qb[k];
-      V3 Xp, tp;
-      ld6(ptrec + 8 * p, Xp, tp);  // 64-byte aligned record, three 16-byte gathers
-      const V3 d = Xp - cn;
-      const V3 y = applyQ(ak, bk, d, zn - tp);
+    // software pipeline over the 64-wide trips of the list: the index / coefficient loads run two trips ahead, the
+    // dependent 64-byte record gathers one trip ahead of the arithmetic (same operations in the same order as the
+    // plain loop; the kernel is bound by this chain of dependent round trips, not by bytes)
+    const int kend = cam_seg_k1(g.g, sg);
+    int k = cam_seg_k0(g.g, sg) + lane;
+    long p1 = 0, p2 = 0;
+    double a0 = 0, b0 = 0, a1 = 0, b1 = 0, a2 = 0, b2 = 0;
+    V3 X0{0, 0, 0}, t0{0, 0, 0}, X1{0, 0, 0}, t1{0, 0, 0};
+    bool h0 = k < kend, h1 = k + 64 < kend, h2 = false;
+    if (h0) {
+      p1 = g.g.c_pt[k];
+      a0 = c_qa[k];
+      b0 = c_qb[k];
+    }
+    if (h1) {
+      p2 = g.g.c_pt[k + 64];
+      a1 = c_qa[k + 64];
+      b1 = c_qb[k + 64];
+    }
+    if (h0) ld6(ptrec + 8 * p1, X0, t0);  // 64-byte aligned record, three 16-byte gathers
+    while (h0) {
+      h2 = k + 128 < kend;
+      long p3 = 0;
+      if (h2) {
+        p3 = g.g.c_pt[k + 128];
+        a2 = c_qa[k + 128];
+        b2 = c_qb[k + 128];
+      }
+      if (h1) ld6(ptrec + 8 * p2, X1, t1);
+      const V3 d = X0 - cn;
+      const V3 y = applyQ(a0, b0, d, zn - t0);
       acc[0] += y.x;
       acc[1] += y.y;
       acc[2] += y.z;
+      k += 64;
+      h0 = h1;
+      h1 = h2;
+      a0 = a1;
+      b0 = b1;
+      a1 = a2;
+      b1 = b2;
+      X0 = X1;
+      t0 = t1;
+      p2 = p3;
     }
     wave_allsum<3>(acc);
     if (!cam_seg_total<3>(g.g, sg, acc, lane)) continue;
