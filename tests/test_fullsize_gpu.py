@@ -148,8 +148,9 @@ def test_ba_config4_shared_intrinsics_matches_cpu_oracle(gsfm_ctx):
 
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ba_c4_shared_oracle.npz"))
     p = synthetic.make_ba_problem(10_000, 1_000_000, seed=0, shared_intrinsics=True)
-    assert p.num_obs == int(g["num_obs"]) and float(np.sum(p.obs_xy)) == float(g["obs_xy_checksum"])  # same input
-    assert float(np.sum(p.cam_t)) == float(g["cam_t_checksum"])
+    # same input (numpy's pairwise sums may group differently on another CPU: compare to rounding)
+    assert p.num_obs == int(g["num_obs"]) and abs(float(np.sum(p.obs_xy)) / float(g["obs_xy_checksum"]) - 1) < 1e-12
+    assert abs(float(np.sum(p.cam_t)) / float(g["cam_t_checksum"]) - 1) < 1e-12
     rc, q, t, X, intr, rep = estimators.ba_solve(p, ctx=gsfm_ctx)
     assert rc == 0
     assert abs(rep["initial_cost"] - float(g["out_initial_cost"])) <= 1e-10 * float(g["out_initial_cost"])
