@@ -1177,13 +1177,19 @@ int num_params_of(int model) {
     case GSFM_CAMERA_SIMPLE_RADIAL: return 4;
     case GSFM_CAMERA_RADIAL: return 5;
     case GSFM_CAMERA_OPENCV: return 8;
-    default: return -1;
+    case GSFM_CAMERA_OPENCV_FISHEYE: return 8;
+    case GSFM_CAMERA_FOV: return 5;
+    case GSFM_CAMERA_SIMPLE_RADIAL_FISHEYE: return 4;
+    case GSFM_CAMERA_RADIAL_FISHEYE: return 5;
+    default: return -1;  // FULL_OPENCV, THIN_PRISM_FISHEYE, RAD_TAN_THIN_PRISM_FISHEYE: more than 8 parameters
   }
 }
 unsigned pp_mask_of(int model) {
   switch (model) {
     case GSFM_CAMERA_PINHOLE:
-    case GSFM_CAMERA_OPENCV: return (1u << 2) | (1u << 3);
+    case GSFM_CAMERA_OPENCV:
+    case GSFM_CAMERA_OPENCV_FISHEYE:
+    case GSFM_CAMERA_FOV: return (1u << 2) | (1u << 3);
     default: return (1u << 1) | (1u << 2);
   }
 }

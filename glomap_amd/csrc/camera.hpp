@@ -5,7 +5,13 @@
 // COLMAP (pinned b6b7b54e, thirdparty/CMakeLists.txt:23-28) is un-vendored; the models follow
 // their published definitions (colmap/sensor/models.h), parameter order as in COLMAP:
 //   SIMPLE_PINHOLE f,cx,cy | PINHOLE fx,fy,cx,cy | SIMPLE_RADIAL f,cx,cy,k | RADIAL f,cx,cy,k1,k2
-//   OPENCV fx,fy,cx,cy,k1,k2,p1,p2
+//   OPENCV fx,fy,cx,cy,k1,k2,p1,p2 | OPENCV_FISHEYE fx,fy,cx,cy,k1,k2,k3,k4 | FOV fx,fy,cx,cy,omega
+//   SIMPLE_RADIAL_FISHEYE f,cx,cy,k | RADIAL_FISHEYE f,cx,cy,k1,k2
+// Fisheye models: (u, v) = (x/z, y/z), r = |(u, v)|, theta = atan(r); the equidistant coordinates (u, v) theta / r are
+// distorted radially in theta: pixel = f (u, v) theta_d / r + c, theta_d = theta (1 + k1 theta^2 + k2 theta^4 + ...)
+// (r <= eps: (u, v) itself).  FOV: pixel = f (u, v) factor + c, factor = atan(2 r tan(omega / 2)) / (r omega) with COLMAP's
+// two series branches for omega^2 < 1e-4 and r^2 < 1e-4.  FULL_OPENCV / THIN_PRISM_FISHEYE (12 parameters) and
+// RAD_TAN_THIN_PRISM_FISHEYE (16) do not fit the 8-parameter intrinsics block and are refused at the boundary.
 #pragma once
 
 #include "../../include/gsfm.h"
@@ -68,6 +74,95 @@ __device__ __forceinline__ void distort_project(int model, const double* __restr
         Jp[0][4] = f * u * r2 * r2;
         Jp[1][4] = f * v * r2 * r2;
       }
+      break;
+    }
+    case GSFM_CAMERA_OPENCV_FISHEYE:
+    case GSFM_CAMERA_SIMPLE_RADIAL_FISHEYE:
+    case GSFM_CAMERA_RADIAL_FISHEYE: {
+      const bool full = model == GSFM_CAMERA_OPENCV_FISHEYE;
+      const double fx = p[0], fy = full ? p[1] : p[0];
+      const int ic = full ? 2 : 1, ik = full ? 4 : 3;                                   // first principal-point / distortion slot
+      const int nk = full ? 4 : (model == GSFM_CAMERA_RADIAL_FISHEYE ? 2 : 1);          // distortion coefficients
+      const double r = sqrt(r2);
+      double m = 1.0, dm_r = 0.0;  // (xd, yd) = m (u, v);  dm_r = (dm/dr) / r
+      double th = r, th2 = r2;
+      if (r > 2.220446049250313e-16) {
+        th = atan(r);
+        th2 = th * th;
+      }
+      double poly = 1.0, dpoly = 1.0, tp = 1.0;  // theta_d = theta * poly(theta^2); d theta_d / d theta = dpoly
+      double tpow[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        tp *= th2;
+        tpow[j] = tp;  // theta^(2 (j + 1))
+        if (j < nk) {
+          poly += p[ik + j] * tp;
+          dpoly += (2.0 * j + 3.0) * p[ik + j] * tp;
+        }
+      }
+      if (r > 2.220446049250313e-16) {
+        m = th * poly / r;
+        dm_r = (dpoly / (1.0 + r2) - m) / r2;  // ((d theta_d / d theta)(d theta / dr) r - theta_d) / r^2, divided by r
+      } else {
+        m = poly;
+      }
+      px = fx * u * m + p[ic];
+      py = fy * v * m + p[ic + 1];
+      Juv[0] = fx * (m + u * u * dm_r);
+      Juv[1] = fx * (u * v * dm_r);
+      Juv[2] = fy * (u * v * dm_r);
+      Juv[3] = fy * (m + v * v * dm_r);
+      if (full) {
+        Jp[0][0] = u * m;
+        Jp[1][1] = v * m;
+      } else {
+        Jp[0][0] = u * m;
+        Jp[1][0] = v * m;
+      }
+      Jp[0][ic] = 1.0;
+      Jp[1][ic + 1] = 1.0;
+      const double s = r > 2.220446049250313e-16 ? th / r : 1.0;  // d m / d k_j = s theta^(2 (j + 1))
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < nk) {
+          Jp[0][ik + j] = fx * u * s * tpow[j];
+          Jp[1][ik + j] = fy * v * s * tpow[j];
+        }
+      break;
+    }
+    case GSFM_CAMERA_FOV: {
+      const double fx = p[0], fy = p[1], om = p[4];
+      const double om2 = om * om;
+      double fac, dfac_r2, dfac_om;  // factor, d factor / d r^2, d factor / d omega
+      if (om2 < 1e-4) {
+        fac = om2 * r2 / 3.0 - om2 / 12.0 + 1.0;
+        dfac_r2 = om2 / 3.0;
+        dfac_om = 2.0 * om * (r2 / 3.0 - 1.0 / 12.0);
+      } else if (r2 < 1e-4) {
+        const double t = tan(0.5 * om), t2 = t * t;
+        fac = (-2.0 * t * (4.0 * r2 * t2 - 3.0)) / (3.0 * om);
+        dfac_r2 = -8.0 * t * t2 / (3.0 * om);
+        const double dt = 0.5 * (1.0 + t2);  // d tan(omega / 2) / d omega
+        dfac_om = (-2.0 * dt * (12.0 * r2 * t2 - 3.0)) / (3.0 * om) - fac / om;
+      } else {
+        const double r = sqrt(r2), t = tan(0.5 * om);
+        const double a = 2.0 * r * t, num = atan(a);
+        fac = num / (r * om);
+        const double da = 1.0 / (1.0 + a * a);
+        // d/dr: (da 2 t r - num) / (r^2 om); d r^2 = 2 r dr
+        dfac_r2 = (da * 2.0 * t * r - num) / (r2 * om) / (2.0 * r);
+        dfac_om = da * 2.0 * r * 0.5 * (1.0 + t * t) / (r * om) - fac / om;
+      }
+      px = fx * u * fac + p[2];
+      py = fy * v * fac + p[3];
+      Juv[0] = fx * (fac + 2.0 * u * u * dfac_r2);
+      Juv[1] = fx * (2.0 * u * v * dfac_r2);
+      Juv[2] = fy * (2.0 * u * v * dfac_r2);
+      Juv[3] = fy * (fac + 2.0 * v * v * dfac_r2);
+      Jp[0][0] = u * fac; Jp[1][1] = v * fac;
+      Jp[0][2] = 1.0; Jp[1][3] = 1.0;
+      Jp[0][4] = fx * u * dfac_om; Jp[1][4] = fy * v * dfac_om;
       break;
     }
     default: {  // GSFM_CAMERA_OPENCV

@@ -756,6 +756,7 @@ struct CgDeflation {
   int k = 0;                   // modes in use (<= kCgMaxModes)
   const double* W = nullptr;   // [k][n]
   double* AW = nullptr;        // [k][n]
+  int aw_ready = 0;            // the first aw_ready rows of AW were filled by the caller (closed-form products)
   double* b2 = nullptr;        // [n]   deflated right-hand side
   double* part = nullptr;      // [kCgdBlocks][kCgdGram] partial Gram products
   double* small = nullptr;     // [64] E^-1 | [8] y0 = E^-1 W^T b | [1] ok (1.0 / 0.0)
@@ -937,7 +938,7 @@ inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& 
   if (deflate) {
     init();  // (resets the status block the apply kernels look at)
     v.probe = 1;
-    for (int j = 0; j < defl->k; ++j) {  // A W_j: the operator reads z (and its mirrors), writes w
+    for (int j = defl->aw_ready; j < defl->k; ++j) {  // A W_j: the operator reads z (and its mirrors), writes w
       if (joint)
         hipLaunchKernelGGL((k_cgd_set_z<PB, true>), dim3(gvec), dim3(kBlock), 0, s, v, defl->W + (size_t)j * v.n);
       else
@@ -995,7 +996,7 @@ inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& 
     hipLaunchKernelGGL(k_cgd_finish, dim3(gvec), dim3(kBlock), 0, s, v, *defl);
     v.b = b_caller;
     v.dk = 0;
-    iters += defl->k;  // the operator applications that formed A W
+    iters += defl->k - defl->aw_ready;  // the operator applications that formed A W
   }
   return iters;
 }

@@ -28,7 +28,7 @@
 //                 s[M] (+ candidate), wrob[M], qa[M], qb[M], jss[M]                      per observation
 //   camera-major: coff[N+2], c_src[M], c_pt[M] i32, c_dir[M][3], c_cal[M] u8, c_jss[M]  static per solve
 //                 c_qa[M], c_qb[M]                                                       per LM iteration
-//   per track   : X[P][3] (+ candidate), ptb[P][12] = (X, e, H_pp^-1) build record,
+//   per track   : X[P][3] (+ candidate), ptb[P][16] = (X, e, H_pp^-1, D_p, pad) 128-byte build record,
 //                 ptrec[P][8] = (X, t_p, pad) 64-byte PCG record, hppd[P], jsx[P], used[P] u8
 //   per camera  : c[N][3] (+ candidate), hcc[N], jsc[N], dcam[3N], gc[3N], gred[3N], scc[N][6], minv[N][9]
 //   PCG vectors : x, r, z, p, s, w [3N] (cg.hpp)
@@ -42,6 +42,8 @@
 
 namespace gsfm {
 namespace {
+
+constexpr int kPtb = 16;  // doubles per point build record: X (3) | e (3) | H_pp^-1 (6) | D_p | pad -> one 128-byte line
 
 struct GpDev {
   ObsGraph g;
@@ -254,18 +256,21 @@ __global__ void __launch_bounds__(kBlock)
       S3 H{acc[0], acc[1], acc[2], acc[3], acc[4], acc[5]};
       S3 Hi{0, 0, 0, 0, 0, 0};
       V3 e{0, 0, 0};
+      double Dp_rec = 0.0;
       if (g.opt_x) {
         const double Dp = lm_damping(hppd[p], jsx[p], radius, g.lm_lo, g.lm_hi);
+        Dp_rec = Dp;
         H.xx += Dp;
         H.yy += Dp;
         H.zz += Dp;
         Hi = inv3(H);
         e = mul(Hi, V3{acc[6], acc[7], acc[8]});
       }
-      double* b = ptb + 12 * p;
+      double* b = ptb + kPtb * p;
       st3(b, Xp);
       st3(b + 3, e);
       b[6] = Hi.xx; b[7] = Hi.xy; b[8] = Hi.xz; b[9] = Hi.yy; b[10] = Hi.yz; b[11] = Hi.zz;
+      b[12] = Dp_rec;
       double* hc = pth + 6 * p;  // compact copy for phase A: consecutive tracks -> one coalesced 48-byte stream
       hc[0] = Hi.xx; hc[1] = Hi.xy; hc[2] = Hi.xz; hc[3] = Hi.yy; hc[4] = Hi.yz; hc[5] = Hi.zz;
       double* pr = ptrec + 8 * p;
@@ -291,7 +296,7 @@ __global__ void __launch_bounds__(kBlock)
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int k = cam_seg_k0(g.g, sg) + lane; k < cam_seg_k1(g.g, sg); k += 64) {
       const long src = g.g.c_src[k];
-      const double* b = ptb + 12 * (long)g.g.c_pt[k];
+      const double* b = ptb + kPtb * (long)g.g.c_pt[k];
       const V3 d = ld3(b) - cn;
       const V3 e = ld3(b + 3);
       const S3 Hi{b[6], b[7], b[8], b[9], b[10], b[11]};
@@ -456,6 +461,47 @@ __global__ void __launch_bounds__(kBlock) k_gp_defl_modes(int N, const double* _
   }
 }
 
+// A W_a for the three TRANSLATION modes (W_a = e_a at every camera) without the track-major sweep.  H_p = sum_k Q_k + D_p I
+// is exactly what k_gp_build_track inverts, so for a field that is the same at every camera the point elimination is
+// closed-form:  t_p = H_p^-1 (sum_k Q_k) e_a = e_a - D_p H_p^-1 e_a,  z_n - t_p = D_p H_p^-1 e_a,  and
+//     (A W_a)_n = sum_k Q_k (D_p H_p^-1)[:, a] + D_n e_a
+// — ONE camera-major sweep for all three modes (one 128-byte point record per observation) instead of three full operator
+// applications per deflated solve.  Needs optimised points (otherwise nothing is eliminated and the identity is void).
+__global__ void __launch_bounds__(kBlock)
+    k_gp_aw_translations(GpDev g, double yscale, const double* __restrict__ c, const double* __restrict__ c_qa,
+                         const double* __restrict__ c_qb, const double* __restrict__ ptb, const double* __restrict__ dcam,
+                         double* __restrict__ AW, long n3) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (kBlock / 64);
+  for (int it = wave; it < cam_seg_count(g.g); it += nwaves) {
+    const int sg = cam_seg_index(g.g, it);
+    const int n = g.g.seg_cam[sg];
+    const V3 cn = ld3(c + 3 * (long)n);
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = cam_seg_k0(g.g, sg) + lane; k < cam_seg_k1(g.g, sg); k += 64) {
+      const double* b = ptb + kPtb * (long)g.g.c_pt[k];
+      const double ak = c_qa[k], bk = c_qb[k];
+      const V3 d = ld3(b) - cn;
+      const double Dp = b[12];
+      const V3 u0{Dp * b[6], Dp * b[7], Dp * b[8]}, u1{Dp * b[7], Dp * b[9], Dp * b[10]}, u2{Dp * b[8], Dp * b[10], Dp * b[11]};
+      const V3 y0 = applyQ(ak, bk, d, u0), y1 = applyQ(ak, bk, d, u1), y2 = applyQ(ak, bk, d, u2);
+      acc[0] += y0.x; acc[1] += y0.y; acc[2] += y0.z;
+      acc[3] += y1.x; acc[4] += y1.y; acc[5] += y1.z;
+      acc[6] += y2.x; acc[7] += y2.y; acc[8] += y2.z;
+    }
+    wave_allsum<9>(acc);
+    if (!cam_seg_total<9>(g.g, sg, acc, lane)) continue;
+    if (lane == 0) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          AW[(size_t)a * n3 + 3 * (long)n + j] = acc[3 * a + j] + (a == j ? yscale * dcam[3 * (long)n + a] : 0.0);
+    }
+  }
+}
+
 // Phase B, camera-major, one wave per camera: w_n = sum_k Q_k (z_n - t_{p(k)}) + D_n z_n and the
 // partial delta = z.w of this block.  Algorithmic bytes per observation: c_qa, c_qb (16) + c_pt (4)
 // + the 64-byte point record gather (X_p, t_p).
@@ -576,7 +622,7 @@ __global__ void __launch_bounds__(kBlock)
       const V3 Xp = ld3(X + 3 * p);
       if (g.g.used[p]) {
         if (g.opt_x) {
-          const double* b = ptb + 12 * p;
+          const double* b = ptb + kPtb * p;
           dX = mul(S3{b[6], b[7], b[8], b[9], b[10], b[11]}, V3{acc[0], acc[1], acc[2]}) - ld3(b + 3);
         }
         acc3[1] += dot(dX, dX);
@@ -997,7 +1043,7 @@ class GpSolver final : public LmProblem {
     ws->Xn.ensure(3 * (size_t)P_ + 3);
     for (DevBuf<double>* b : {&ws->s, &ws->sn, &ws->wrob, &ws->qa, &ws->qb, &ws->jss, &ws->c_jss, &ws->c_qa, &ws->c_qb})
       b->ensure(M_ + 1);
-    ws->ptb.ensure(12 * (size_t)P_ + 12);
+    ws->ptb.ensure(kPtb * (size_t)P_ + kPtb);
     ws->pth.ensure(6 * (size_t)P_ + 6);
     ws->ptrec.ensure(8 * (size_t)P_ + 8);
     // observations of unused tracks keep a = beta = 0 (no contribution, no `used` test in phase A)
@@ -1305,6 +1351,17 @@ class GpSolver final : public LmProblem {
       defl.cd = ws->defl_cd.ensure((size_t)2 * kCgMaxBlocks * 2 * kCgMaxModes);
       hipLaunchKernelGGL(k_gp_defl_modes, dim3(gridN_), dim3(kBlock), 0, s, N_, (const double*)ci_, W);
       defl.W = W;
+      if (g_.opt_x) {  // the three translation modes in one camera-major sweep (k_gp_aw_translations); the scale mode is applied
+        hipLaunchKernelGGL(k_gp_aw_translations, dim3(gridCam_), dim3(kBlock), 0, s, g_, yscale, (const double*)ci_,
+                           (const double*)ws->c_qa.get(), (const double*)ws->c_qb.get(), (const double*)ws->ptb.get(),
+                           (const double*)ws->dcam.get(), defl.AW, (long)n3);
+        if (gridMulti_)
+          hipLaunchKernelGGL(k_gp_aw_translations, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, yscale, (const double*)ci_,
+                             (const double*)ws->c_qa.get(), (const double*)ws->c_qb.get(), (const double*)ws->ptb.get(),
+                             (const double*)ws->dcam.get(), defl.AW, (long)n3);
+        if (ctx_->comm.world > 1) allreduce_sum(ctx_, defl.AW, 3 * n3);
+        defl.aw_ready = 3;
+      }
     }
     const long iters = cg_solve<3, false>(ctx_, cg_, tol, opt_.lm.pcg_max_iterations, [&](int it) {
       if (rig_)  // z of an image = z of its frame: into the per-image vector and the (c | z) gather records
@@ -1334,7 +1391,9 @@ class GpSolver final : public LmProblem {
                            gridCam_ + gridMulti_, gridN_);
     }, defl.k ? &defl : nullptr, &pcg_hint_);
     // deflation pays while a plain solve needs more than ~3 k iterations (iters includes the k applications for A W)
-    defl_on_ = defl.k ? iters - defl.k > defl.k : iters > 3 * 4;
+    // (with the closed-form translation products the price of A W is about two applications instead of four)
+    const int napp = defl.k - defl.aw_ready, cost = g_.opt_x ? 2 : 4;
+    defl_on_ = defl.k ? iters - napp > cost : iters > 3 * cost;
     return iters;
   }
 

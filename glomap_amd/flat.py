@@ -18,7 +18,11 @@ CAMERA_PINHOLE = 1  # fx, fy, cx, cy
 CAMERA_SIMPLE_RADIAL = 2  # f, cx, cy, k
 CAMERA_RADIAL = 3  # f, cx, cy, k1, k2
 CAMERA_OPENCV = 4  # fx, fy, cx, cy, k1, k2, p1, p2
-CAMERA_NUM_PARAMS = {0: 3, 1: 4, 2: 4, 3: 5, 4: 8}
+CAMERA_OPENCV_FISHEYE = 5  # fx, fy, cx, cy, k1, k2, k3, k4
+CAMERA_FOV = 7  # fx, fy, cx, cy, omega
+CAMERA_SIMPLE_RADIAL_FISHEYE = 8  # f, cx, cy, k
+CAMERA_RADIAL_FISHEYE = 9  # f, cx, cy, k1, k2
+CAMERA_NUM_PARAMS = {0: 3, 1: 4, 2: 4, 3: 5, 4: 8, 5: 8, 7: 5, 8: 4, 9: 5}
 CAMERA_PP_IDXS = {0: (1, 2), 1: (2, 3), 2: (1, 2), 3: (1, 2), 4: (2, 3)}
 CAMERA_MAX_PARAMS = 8
 

@@ -323,7 +323,13 @@ enum {
   GSFM_CAMERA_PINHOLE = 1,        /* fx, fy, cx, cy */
   GSFM_CAMERA_SIMPLE_RADIAL = 2,  /* f, cx, cy, k */
   GSFM_CAMERA_RADIAL = 3,         /* f, cx, cy, k1, k2 */
-  GSFM_CAMERA_OPENCV = 4          /* fx, fy, cx, cy, k1, k2, p1, p2 */
+  GSFM_CAMERA_OPENCV = 4,         /* fx, fy, cx, cy, k1, k2, p1, p2 */
+  GSFM_CAMERA_OPENCV_FISHEYE = 5, /* fx, fy, cx, cy, k1, k2, k3, k4 */
+  /* 6 = FULL_OPENCV (12 parameters): not supported, an intrinsics block holds GSFM_CAMERA_MAX_PARAMS = 8 */
+  GSFM_CAMERA_FOV = 7,            /* fx, fy, cx, cy, omega */
+  GSFM_CAMERA_SIMPLE_RADIAL_FISHEYE = 8, /* f, cx, cy, k */
+  GSFM_CAMERA_RADIAL_FISHEYE = 9  /* f, cx, cy, k1, k2 */
+  /* 10 = THIN_PRISM_FISHEYE (12), 11 = RAD_TAN_THIN_PRISM_FISHEYE (16): not supported */
 };
 #define GSFM_CAMERA_MAX_PARAMS 8
 

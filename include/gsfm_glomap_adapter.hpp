@@ -74,7 +74,11 @@ inline int ModelOf(const glomap::Camera& cam) {
     case 2: return GSFM_CAMERA_SIMPLE_RADIAL;
     case 3: return GSFM_CAMERA_RADIAL;
     case 4: return GSFM_CAMERA_OPENCV;
-    default: return -1;
+    case 5: return GSFM_CAMERA_OPENCV_FISHEYE;
+    case 7: return GSFM_CAMERA_FOV;
+    case 8: return GSFM_CAMERA_SIMPLE_RADIAL_FISHEYE;
+    case 9: return GSFM_CAMERA_RADIAL_FISHEYE;
+    default: return -1;  // FULL_OPENCV (6), THIN_PRISM_FISHEYE (10), RAD_TAN_THIN_PRISM_FISHEYE (11): > 8 parameters
   }
 }
 

@@ -7,7 +7,8 @@ CPU restatement of GLOMAP's global bundle adjustment for trivial rigs:
                   un-vendored; restated from its published definition:
                   x_c = R(q) X + t;  (u,v) = CameraModel::ImgFromCam(params, x_c);  r = (u,v) - obs   [pixels]
                   (residual and Jacobian zero when the point is not in front of the camera)
-  camera models   SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL, RADIAL, OPENCV (colmap/sensor/models.h)
+  camera models   SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL, RADIAL, OPENCV, OPENCV_FISHEYE, FOV, SIMPLE_RADIAL_FISHEYE,
+                  RADIAL_FISHEYE (colmap/sensor/models.h; every COLMAP model with at most 8 parameters)
   parameterisation ba.cc:244-317: EigenQuaternionManifold (q <- [sin|d| d/|d|, cos|d|] * q), first
                   frame constant, optimize_rotations / optimize_translation flags, principal point
                   frozen by a SubsetManifold unless optimize_principal_point
@@ -26,8 +27,9 @@ import scipy.sparse as sp
 from . import lm
 
 SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL, RADIAL, OPENCV = 0, 1, 2, 3, 4
-NUM_PARAMS = {0: 3, 1: 4, 2: 4, 3: 5, 4: 8}
-PP_IDXS = {0: (1, 2), 1: (2, 3), 2: (1, 2), 3: (1, 2), 4: (2, 3)}
+OPENCV_FISHEYE, FOV, SIMPLE_RADIAL_FISHEYE, RADIAL_FISHEYE = 5, 7, 8, 9  # COLMAP's CameraModelId values
+NUM_PARAMS = {0: 3, 1: 4, 2: 4, 3: 5, 4: 8, 5: 8, 7: 5, 8: 4, 9: 5}
+PP_IDXS = {0: (1, 2), 1: (2, 3), 2: (1, 2), 3: (1, 2), 4: (2, 3), 5: (2, 3), 7: (2, 3), 8: (1, 2), 9: (1, 2)}
 MAXP = 8
 
 
@@ -141,6 +143,78 @@ def project(model, params, xc):
             Jp[s, 0, 5], Jp[s, 1, 5] = fx * us * r2s * r2s, fy * vs * r2s * r2s
             Jp[s, 0, 6], Jp[s, 1, 6] = fx * 2 * us * vs, fy * (r2s + 2 * vs * vs)
             Jp[s, 0, 7], Jp[s, 1, 7] = fx * (r2s + 2 * us * us), fy * 2 * us * vs
+        elif mid in (OPENCV_FISHEYE, SIMPLE_RADIAL_FISHEYE, RADIAL_FISHEYE):
+            # equidistant fisheye: theta = atan(r), pixel = f (u, v) theta_d / r + c, theta_d = theta (1 + sum k_j theta^(2j+2))
+            full = mid == OPENCV_FISHEYE
+            fx = ps[:, 0]
+            fy = ps[:, 1] if full else ps[:, 0]
+            ic, ik0 = (2, 4) if full else (1, 3)
+            nk = 4 if full else (2 if mid == RADIAL_FISHEYE else 1)
+            rs = np.sqrt(r2s)
+            big = rs > np.finfo(np.float64).eps
+            th = np.where(big, np.arctan(rs), rs)
+            th2 = th * th
+            poly = np.ones_like(th)
+            dpoly = np.ones_like(th)
+            tpow = []
+            tp = np.ones_like(th)
+            for j in range(nk):
+                tp = tp * th2
+                tpow.append(tp)
+                poly = poly + ps[:, ik0 + j] * tp
+                dpoly = dpoly + (2 * j + 3) * ps[:, ik0 + j] * tp
+            rsafe = np.where(big, rs, 1.0)
+            mfac = np.where(big, th * poly / rsafe, poly)
+            dm_r = np.where(big, (dpoly / (1 + r2s) - mfac) / np.where(big, r2s, 1.0), 0.0)
+            uv[s] = np.stack([fx * us * mfac + ps[:, ic], fy * vs * mfac + ps[:, ic + 1]], 1)
+            Juv[s, 0, 0] = fx * (mfac + us * us * dm_r)
+            Juv[s, 0, 1] = fx * us * vs * dm_r
+            Juv[s, 1, 0] = fy * us * vs * dm_r
+            Juv[s, 1, 1] = fy * (mfac + vs * vs * dm_r)
+            if full:
+                Jp[s, 0, 0] = us * mfac
+                Jp[s, 1, 1] = vs * mfac
+            else:
+                Jp[s, 0, 0], Jp[s, 1, 0] = us * mfac, vs * mfac
+            Jp[s, 0, ic] = 1
+            Jp[s, 1, ic + 1] = 1
+            sfac = np.where(big, th / rsafe, 1.0)
+            for j in range(nk):
+                Jp[s, 0, ik0 + j] = fx * us * sfac * tpow[j]
+                Jp[s, 1, ik0 + j] = fy * vs * sfac * tpow[j]
+        elif mid == FOV:
+            fx, fy, cx, cy, om = (ps[:, i] for i in range(5))
+            om2 = om * om
+            fac = np.empty_like(om)
+            dfac_r2 = np.empty_like(om)
+            dfac_om = np.empty_like(om)
+            a_ = om2 < 1e-4                       # COLMAP's series branches (FOVCameraModel::Distortion)
+            b_ = ~a_ & (r2s < 1e-4)
+            c_ = ~a_ & ~b_
+            fac[a_] = om2[a_] * r2s[a_] / 3 - om2[a_] / 12 + 1
+            dfac_r2[a_] = om2[a_] / 3
+            dfac_om[a_] = 2 * om[a_] * (r2s[a_] / 3 - 1 / 12)
+            t = np.tan(0.5 * om)
+            fac[b_] = (-2 * t[b_] * (4 * r2s[b_] * t[b_] ** 2 - 3)) / (3 * om[b_])
+            dfac_r2[b_] = -8 * t[b_] ** 3 / (3 * om[b_])
+            dfac_om[b_] = (-2 * 0.5 * (1 + t[b_] ** 2) * (12 * r2s[b_] * t[b_] ** 2 - 3)) / (3 * om[b_]) - fac[b_] / om[b_]
+            rc_ = np.sqrt(r2s[c_])
+            ac = 2 * rc_ * t[c_]
+            num = np.arctan(ac)
+            fac[c_] = num / (rc_ * om[c_])
+            da = 1 / (1 + ac * ac)
+            dfac_r2[c_] = (da * 2 * t[c_] * rc_ - num) / (r2s[c_] * om[c_]) / (2 * rc_)
+            dfac_om[c_] = da * 2 * rc_ * 0.5 * (1 + t[c_] ** 2) / (rc_ * om[c_]) - fac[c_] / om[c_]
+            uv[s] = np.stack([fx * us * fac + cx, fy * vs * fac + cy], 1)
+            Juv[s, 0, 0] = fx * (fac + 2 * us * us * dfac_r2)
+            Juv[s, 0, 1] = fx * 2 * us * vs * dfac_r2
+            Juv[s, 1, 0] = fy * 2 * us * vs * dfac_r2
+            Juv[s, 1, 1] = fy * (fac + 2 * vs * vs * dfac_r2)
+            Jp[s, 0, 0] = us * fac
+            Jp[s, 1, 1] = vs * fac
+            Jp[s, 0, 2] = 1
+            Jp[s, 1, 3] = 1
+            Jp[s, 0, 4], Jp[s, 1, 4] = fx * us * dfac_om, fy * vs * dfac_om
         else:
             raise ValueError(f"camera model {mid} not supported")
     # d(u,v)/d x_c

@@ -10,7 +10,8 @@
 //                is un-vendored; restated from its published definition):
 //                x_c = R(q) X + t; (u, v) = CameraModel::ImgFromCam(params, x_c); r = (u, v) - obs  [pixels];
 //                residual and Jacobian are zero when the point is not in front of the camera
-//   models       SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL, RADIAL, OPENCV (colmap/sensor/models.h)
+//   models       SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL, RADIAL, OPENCV, OPENCV_FISHEYE, FOV, SIMPLE_RADIAL_FISHEYE,
+//                RADIAL_FISHEYE (colmap/sensor/models.h; the models with at most 8 parameters)
 //   manifolds    bundle_adjustment.cc:244-317: EigenQuaternionManifold (q <- [sin|d| d/|d|, cos|d|] * q), first frame
 //                constant, optimize_rotations / optimize_translation, principal point frozen by a SubsetManifold
 //   loss         Huber(1 px), bundle_adjustment.h:30,34-36
@@ -24,9 +25,10 @@
 namespace orc {
 
 constexpr int MAXP = 8;
-enum { SIMPLE_PINHOLE = 0, PINHOLE = 1, SIMPLE_RADIAL = 2, RADIAL = 3, OPENCV = 4 };
-const int kNumParams[5] = {3, 4, 4, 5, 8};
-const int kPP[5][2] = {{1, 2}, {2, 3}, {1, 2}, {1, 2}, {2, 3}};
+enum { SIMPLE_PINHOLE = 0, PINHOLE = 1, SIMPLE_RADIAL = 2, RADIAL = 3, OPENCV = 4, OPENCV_FISHEYE = 5, FOV = 7,
+       SIMPLE_RADIAL_FISHEYE = 8, RADIAL_FISHEYE = 9 };  // COLMAP's CameraModelId values
+const int kNumParams[10] = {3, 4, 4, 5, 8, 8, -1, 5, 4, 5};  // -1: FULL_OPENCV (12 parameters) not restated
+const int kPP[10][2] = {{1, 2}, {2, 3}, {1, 2}, {1, 2}, {2, 3}, {2, 3}, {0, 0}, {2, 3}, {1, 2}, {1, 2}};
 
 struct BaOptionsC {
   int32_t max_num_iterations;
@@ -130,6 +132,68 @@ inline bool project(int model, const double* p, const double* xc, double* uv, do
       Jp[5] = fx * u * r2 * r2; Jp[8 + 5] = fy * v * r2 * r2;
       Jp[6] = fx * 2 * u * v; Jp[8 + 6] = fy * (r2 + 2 * v * v);
       Jp[7] = fx * (r2 + 2 * u * u); Jp[8 + 7] = fy * 2 * u * v;
+      break;
+    }
+    case OPENCV_FISHEYE:
+    case SIMPLE_RADIAL_FISHEYE:
+    case RADIAL_FISHEYE: {
+      // equidistant fisheye: theta = atan(r); pixel = f (u, v) theta_d / r + c, theta_d = theta (1 + sum_j k_j theta^(2j+2))
+      const bool full = model == OPENCV_FISHEYE;
+      const double fx = p[0], fy = full ? p[1] : p[0];
+      const int ic = full ? 2 : 1, ik0 = full ? 4 : 3, nk = full ? 4 : (model == RADIAL_FISHEYE ? 2 : 1);
+      const double r = std::sqrt(r2);
+      const bool big = r > 2.220446049250313e-16;
+      const double th = big ? std::atan(r) : r, th2 = th * th;
+      double poly = 1.0, dpoly = 1.0, tp = 1.0, tpow[4] = {0, 0, 0, 0};
+      for (int j = 0; j < nk; ++j) {
+        tp *= th2;
+        tpow[j] = tp;
+        poly += p[ik0 + j] * tp;
+        dpoly += (2.0 * j + 3.0) * p[ik0 + j] * tp;
+      }
+      const double m = big ? th * poly / r : poly;
+      const double dm_r = big ? (dpoly / (1.0 + r2) - m) / r2 : 0.0;
+      uv[0] = fx * u * m + p[ic];
+      uv[1] = fy * v * m + p[ic + 1];
+      J00 = fx * (m + u * u * dm_r); J01 = fx * u * v * dm_r; J10 = fy * u * v * dm_r; J11 = fy * (m + v * v * dm_r);
+      if (full) {
+        Jp[0] = u * m; Jp[8 + 1] = v * m;
+      } else {
+        Jp[0] = u * m; Jp[8] = v * m;
+      }
+      Jp[ic] = 1; Jp[8 + ic + 1] = 1;
+      const double sf = big ? th / r : 1.0;
+      for (int j = 0; j < nk; ++j) {
+        Jp[ik0 + j] = fx * u * sf * tpow[j];
+        Jp[8 + ik0 + j] = fy * v * sf * tpow[j];
+      }
+      break;
+    }
+    case FOV: {
+      const double fx = p[0], fy = p[1], om = p[4], om2 = om * om;
+      double fac, dfac_r2, dfac_om;
+      if (om2 < 1e-4) {  // COLMAP's series branches (FOVCameraModel::Distortion)
+        fac = om2 * r2 / 3.0 - om2 / 12.0 + 1.0;
+        dfac_r2 = om2 / 3.0;
+        dfac_om = 2.0 * om * (r2 / 3.0 - 1.0 / 12.0);
+      } else if (r2 < 1e-4) {
+        const double t = std::tan(0.5 * om), t2 = t * t;
+        fac = (-2.0 * t * (4.0 * r2 * t2 - 3.0)) / (3.0 * om);
+        dfac_r2 = -8.0 * t * t2 / (3.0 * om);
+        dfac_om = (-2.0 * 0.5 * (1.0 + t2) * (12.0 * r2 * t2 - 3.0)) / (3.0 * om) - fac / om;
+      } else {
+        const double r = std::sqrt(r2), t = std::tan(0.5 * om), a = 2.0 * r * t, num = std::atan(a), da = 1.0 / (1.0 + a * a);
+        fac = num / (r * om);
+        dfac_r2 = (da * 2.0 * t * r - num) / (r2 * om) / (2.0 * r);
+        dfac_om = da * 2.0 * r * 0.5 * (1.0 + t * t) / (r * om) - fac / om;
+      }
+      uv[0] = fx * u * fac + p[2];
+      uv[1] = fy * v * fac + p[3];
+      J00 = fx * (fac + 2 * u * u * dfac_r2); J01 = fx * 2 * u * v * dfac_r2; J10 = fy * 2 * u * v * dfac_r2;
+      J11 = fy * (fac + 2 * v * v * dfac_r2);
+      Jp[0] = u * fac; Jp[8 + 1] = v * fac;
+      Jp[2] = 1; Jp[8 + 3] = 1;
+      Jp[4] = fx * u * dfac_om; Jp[8 + 4] = fy * v * dfac_om;
       break;
     }
     default:
@@ -856,7 +920,7 @@ int orc_ba_solve(int32_t num_cams, int32_t num_intr, int32_t fixed_cam, i64 num_
     g.cam_intr.assign(cam_intr, cam_intr + g.N);
   g.model.assign(intr_model, intr_model + g.K);
   for (i64 b = 0; b < g.K; ++b)
-    if (g.model[b] < 0 || g.model[b] > 4) return -7;
+    if (g.model[b] < 0 || g.model[b] > 9 || kNumParams[g.model[b]] < 0) return -7;
   g.bycam.build(g.N, g.M, g.cam.data());
   g.byintr.build(g.K, g.M, g.ik.data());
   if (g.S > 0) g.bysens.build(g.S, (i64)g.sobs.size(), g.sown.data());

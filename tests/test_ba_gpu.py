@@ -48,6 +48,21 @@ def _set_model(p, name):
         p.intr_model[:] = 0
         p.intr_params[:] = 0
         p.intr_params[:, :3] = [1200, 640, 480]
+    elif name == "opencv_fisheye":
+        p.intr_model[:] = 5
+        p.intr_params[:, :8] = [1200, 1190, 640, 480, 0.02, -0.01, 0.004, -0.002]
+    elif name == "fov":
+        p.intr_model[:] = 7
+        p.intr_params[:] = 0
+        p.intr_params[:, :5] = [1200, 1190, 640, 480, 0.6]
+    elif name == "simple_radial_fisheye":
+        p.intr_model[:] = 8
+        p.intr_params[:] = 0
+        p.intr_params[:, :4] = [1200, 640, 480, 0.02]
+    elif name == "radial_fisheye":
+        p.intr_model[:] = 9
+        p.intr_params[:] = 0
+        p.intr_params[:, :5] = [1200, 640, 480, 0.02, -0.01]
 
 
 @pytest.mark.parametrize(
@@ -74,7 +89,8 @@ def test_ba_matches_oracle(gsfm_ctx, ncam, npts, noise, outl, shared, seed):
     assert np.array_equal(q_g[p.fixed_cam], p.cam_q[p.fixed_cam]) and np.array_equal(t_g[p.fixed_cam], p.cam_t[p.fixed_cam])
 
 
-@pytest.mark.parametrize("model", ["opencv", "pinhole", "radial", "simple_pinhole"])
+@pytest.mark.parametrize("model", ["opencv", "pinhole", "radial", "simple_pinhole", "opencv_fisheye", "fov", "simple_radial_fisheye",
+                                   "radial_fisheye"])
 def test_ba_camera_models(gsfm_ctx, model):
     p = synthetic.make_ba_problem(num_cams=15, num_pts=300, seed=5, pixel_noise=0.0, outlier_ratio=0.0,
                                   shared_intrinsics=True)

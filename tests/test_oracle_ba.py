@@ -24,6 +24,25 @@ def _set_model(p, name):
         p.intr_model[:] = ba.SIMPLE_PINHOLE
         p.intr_params[:] = 0
         p.intr_params[:, :3] = [1200, 640, 480]
+    elif name == "opencv_fisheye":
+        p.intr_model[:] = ba.OPENCV_FISHEYE
+        p.intr_params[:, :8] = [1200, 1190, 640, 480, 0.02, -0.01, 0.004, -0.002]
+    elif name == "fov":
+        p.intr_model[:] = ba.FOV
+        p.intr_params[:] = 0
+        p.intr_params[:, :5] = [1200, 1190, 640, 480, 0.6]
+    elif name == "simple_radial_fisheye":
+        p.intr_model[:] = ba.SIMPLE_RADIAL_FISHEYE
+        p.intr_params[:] = 0
+        p.intr_params[:, :4] = [1200, 640, 480, 0.02]
+    elif name == "radial_fisheye":
+        p.intr_model[:] = ba.RADIAL_FISHEYE
+        p.intr_params[:] = 0
+        p.intr_params[:, :5] = [1200, 640, 480, 0.02, -0.01]
+
+
+ALL_MODELS = ["simple_radial", "opencv", "pinhole", "radial", "simple_pinhole", "opencv_fisheye", "fov", "simple_radial_fisheye",
+              "radial_fisheye"]
 
 
 def _problem(p, opt, fixed=-1):
@@ -36,7 +55,57 @@ def _problem(p, opt, fixed=-1):
     return prob, prob.pack(p.cam_q, p.cam_t, p.pt_xyz[used], p.intr_params)
 
 
-@pytest.mark.parametrize("model", ["simple_radial", "opencv", "pinhole", "radial", "simple_pinhole"])
+@pytest.mark.parametrize("mid,par,pts", [
+    # every model on generic rays, plus the special branches: FOV's two series (omega^2 < 1e-4, r^2 < 1e-4) and the fisheye
+    # models on the optical axis (r <= eps)
+    (ba.SIMPLE_PINHOLE, [1200, 640, 480], "generic"), (ba.PINHOLE, [1200, 1190, 640, 480], "generic"),
+    (ba.SIMPLE_RADIAL, [1200, 640, 480, 0.02], "generic"), (ba.RADIAL, [1200, 640, 480, 0.02, -0.01], "generic"),
+    (ba.OPENCV, [1200, 1190, 640, 480, 0.02, -0.01, 0.001, -0.002], "generic"),
+    (ba.OPENCV_FISHEYE, [1200, 1190, 640, 480, 0.02, -0.01, 0.004, -0.002], "generic"),
+    (ba.SIMPLE_RADIAL_FISHEYE, [1200, 640, 480, 0.02], "generic"), (ba.RADIAL_FISHEYE, [1200, 640, 480, 0.02, -0.01], "generic"),
+    (ba.FOV, [1200, 1190, 640, 480, 0.6], "generic"), (ba.FOV, [1200, 1190, 640, 480, 5e-3], "generic"),
+    (ba.FOV, [1200, 1190, 640, 480, 0.6], "near_axis"), (ba.OPENCV_FISHEYE, [1200, 1190, 640, 480, 0.02, -0.01, 0.004, -0.002], "near_axis"),
+])
+def test_projection_jacobians_match_finite_differences(mid, par, pts):
+    """oracle.ba.project (ImgFromCam + analytic derivatives) against central differences, ray by ray."""
+    rng = np.random.default_rng(3)
+    m = 64
+    if pts == "generic":
+        xc = np.column_stack([rng.uniform(-0.8, 0.8, m), rng.uniform(-0.6, 0.6, m), rng.uniform(1.0, 3.0, m)])
+    else:
+        xc = np.column_stack([rng.uniform(-4e-3, 4e-3, m), rng.uniform(-4e-3, 4e-3, m), rng.uniform(1.0, 3.0, m)])
+    P = np.zeros((m, ba.MAXP))
+    P[:, : len(par)] = par
+    model = np.full(m, mid)
+    uv, Jx, Jp, valid = ba.project(model, P, xc)
+    assert valid.all()
+    h = 1e-6
+    for j in range(3):
+        d = np.zeros(3)
+        d[j] = h
+        num = (ba.project(model, P, xc + d)[0] - ba.project(model, P, xc - d)[0]) / (2 * h)
+        assert np.abs(num - Jx[:, :, j]).max() < 1e-6 * max(1.0, np.abs(Jx).max())
+    for j in range(len(par)):
+        hj = h * max(1.0, abs(par[j]))
+        d = np.zeros(ba.MAXP)
+        d[j] = hj
+        num = (ba.project(model, P + d, xc)[0] - ba.project(model, P - d, xc)[0]) / (2 * hj)
+        assert np.abs(num - Jp[:, :, j]).max() < 1e-6 * max(1.0, np.abs(Jp[:, :, j]).max())
+    assert np.all(Jp[:, :, len(par):] == 0)
+
+
+def test_fisheye_on_the_optical_axis():
+    """r <= eps: the equidistant mapping is the identity there and the derivative stays finite."""
+    xc = np.array([[0.0, 0.0, 2.0]])
+    for mid, par in ((ba.OPENCV_FISHEYE, [1200, 1190, 640, 480, 0.02, -0.01, 0.004, -0.002]), (ba.RADIAL_FISHEYE, [1200, 640, 480, 0.02, -0.01])):
+        P = np.zeros((1, ba.MAXP))
+        P[0, : len(par)] = par
+        uv, Jx, Jp, valid = ba.project(np.array([mid]), P, xc)
+        assert valid[0] and np.allclose(uv[0], [640, 480]) and np.isfinite(Jx).all()
+        assert np.isclose(Jx[0, 0, 0], 1200 / 2.0)
+
+
+@pytest.mark.parametrize("model", ALL_MODELS)
 def test_analytic_jacobian_matches_finite_differences(model):
     p = synthetic.make_ba_problem(num_cams=8, num_pts=60, seed=1, pixel_noise=0.0, outlier_ratio=0.0,
                                   shared_intrinsics=(model != "simple_radial"))

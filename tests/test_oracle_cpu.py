@@ -78,28 +78,46 @@ def test_ba_cpp_matches_numpy_oracle(shared):
     assert np.abs(r[4] - r2[4]).max() < 1e-6      # intrinsics
 
 
-@pytest.mark.parametrize("model", [0, 1, 3, 4])
+@pytest.mark.parametrize("model", [0, 1, 3, 4, 5, 7, 8, 9])
 def test_ba_cpp_camera_models(model):
     from glomap_amd.flat import CAMERA_NUM_PARAMS
 
     p = synthetic.make_ba_problem(12, 250, seed=model)
     K = p.intr_params.shape[0]
     f, cx, cy = 1200.0, 640.0, 480.0
-    par = {0: [f, cx, cy], 1: [f, f * 1.01, cx, cy], 3: [f, cx, cy, 0.02, 0.0], 4: [f, f, cx, cy, 0.02, 0.0, 0.0, 0.0]}[model]
+    par = {0: [f, cx, cy], 1: [f, f * 1.01, cx, cy], 3: [f, cx, cy, 0.02, 0.0], 4: [f, f, cx, cy, 0.02, 0.0, 0.0, 0.0],
+           5: [f, f, cx, cy, 0.3, 0.0, 0.0, 0.0], 7: [f, f, cx, cy, 0.3], 8: [f, cx, cy, 0.3], 9: [f, cx, cy, 0.3, 0.0]}[model]
     p.intr_model[:] = model
     p.intr_params[:] = 0.0
     p.intr_params[:, : CAMERA_NUM_PARAMS[model]] = par
     # observations were generated with SIMPLE_RADIAL k = 0.02: every model here starts from a slightly wrong
-    # projection, which is what BA is for
+    # projection, which is what BA is for.  (The fisheye / FOV models cannot imitate that projection at all — the solve
+    # then wanders for 50 ill-conditioned iterations in which rounding differences between the two oracles grow — so
+    # their observations are regenerated through the model itself.)
+    if model >= 5:
+        from glomap_amd import so3
+
+        obs_pt = np.repeat(np.arange(p.num_pts), np.diff(p.pt_offset))
+        xc = np.einsum("mij,mj->mi", so3.quat_to_rotmat(p.gt_q)[p.obs_cam], p.gt_xyz[obs_pt]) + p.gt_t[p.obs_cam]
+        ik = p.cam_intr[p.obs_cam]
+        uv, _, _, valid = oba.project(p.intr_model[ik], p.intr_params[ik], xc)
+        assert valid.all()
+        p.obs_xy = uv + np.random.default_rng(model).normal(0, 0.3, uv.shape)
     for staged in (dict(optimize_rotations=False), dict()):
         opt = oba.BundleAdjusterOptions(**staged)
         r = oba.solve(*_ba_args(p), options=opt)
         r2 = cpu.ba_solve(*_ba_args(p), options=opt)
         assert r[0] == r2[0]
         assert r2[5].iterations == r[5].iterations
-        assert abs(r2[5].final_cost - r[5].final_cost) <= 1e-8 * r[5].final_cost
-        assert np.abs(r[1] - r2[1]).max() < 1e-8
-        assert np.abs(r[4] - r2[4]).max() < 1e-5 * 1200.0
+        # (OPENCV_FISHEYE: theta^6 / theta^8 coefficients on a 40-degree field of view are barely determined — the trust
+        # region runs to its 1e16 cap — and the two implementations' rounding shows at 3e-8 in the final cost)
+        tol = 1e-8 if model < 5 else 1e-6
+        assert abs(r2[5].final_cost - r[5].final_cost) <= tol * r[5].final_cost
+        assert np.abs(r[1] - r2[1]).max() < tol
+        if model != 5:
+            assert np.abs(r[4] - r2[4]).max() < 1e-5 * 1200.0
+        else:
+            assert np.abs(r[4][:, :4] - r2[4][:, :4]).max() < 1e-5 * 1200.0  # focal lengths, principal point
 
 
 def test_ba_cpp_order_switch_changes_only_rounding():
