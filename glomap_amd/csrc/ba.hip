@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(kBlock)
 // One lane per observation (track-major tiles): cost, the stored Jacobian planes (scaled by sqrt(w)),
 // and H_pp / g_p per track through a segmented wave scan.  All plane writes are coalesced.
 // part[block][2] = {cost, max |g_pt|}.
-template <int F>
+template <int F, bool WIDE>
 __global__ void __launch_bounds__(kBlock)
     k_ba_lin_track(BaDev g, const double* __restrict__ camR, const double* __restrict__ t,
                    const double* __restrict__ X, const double* __restrict__ par, double2* __restrict__ jt,
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(kBlock)
       const int ik = g.cam_intr[n];
       const double* R9 = camR + 9 * (long)n;
       ObsGeom o;
-      obs_geom(R9, t + 3 * (long)n, ld3(X + 3 * (long)p), g.intr_model[ik], par + 8 * (long)ik, o);
+      obs_geom<WIDE>(R9, t + 3 * (long)n, ld3(X + 3 * (long)p), g.intr_model[ik], par + 8 * (long)ik, o);
       const double2 ob = *reinterpret_cast<const double2*>(g.xy + 2 * k);
       const double r0 = o.valid ? o.px - ob.x : 0.0;
       const double r1 = o.valid ? o.py - ob.y : 0.0;
@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(kBlock)
 // GRAM (optimised cam_from_rig blocks): the pose part is the full 6 x 6 Gram matrix sum w J^T J of the IMAGE's own
 // tangent (upper triangle, sym6 order) in diag[n][21] and its gradient in grad[n][6]; the frame / sensor column norms
 // and gradients are congruences of it (k_ba_rig_frame_lin, k_ba_rig_sensor_lin).
-template <bool GRAM>
+template <bool GRAM, bool WIDE>
 __global__ void __launch_bounds__(kBlock)
     k_ba_lin_cam(BaDev g, const double* __restrict__ camR, const double* __restrict__ t,
                  const double* __restrict__ X, const double* __restrict__ par, double* __restrict__ c_w,
@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(kBlock)
     for (int j = 0; j < W; ++j) acc[j] = 0.0;
     for (int k = cam_seg_k0(g.g, sg) + lane; k < cam_seg_k1(g.g, sg); k += 64) {
       ObsGeom o;
-      obs_geom(R9, t3, ld3(X + 3 * (long)g.g.c_pt[k]), model, pp, o);
+      obs_geom<WIDE>(R9, t3, ld3(X + 3 * (long)g.g.c_pt[k]), model, pp, o);
       const double r0 = o.valid ? o.px - g.c_xy[2 * (long)k] : 0.0;
       const double r1 = o.valid ? o.py - g.c_xy[2 * (long)k + 1] : 0.0;
       double rho, w;
@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(kBlock)
 // One wave per camera: reduced gradient J_a^T w (r - J_pt e) and the diagonal Schur blocks
 // J_a^T W_k J_a, W_k = w (I - w J_pt H_pp^-1 J_pt^T), for the pose block (6 + 21) and this camera's
 // share of its intrinsics block (ipart[n][44] = gred 8 | S 36).
-template <bool JOINT>
+template <bool JOINT, bool WIDE>
 __global__ void __launch_bounds__(kBlock)
     k_ba_build_cam(BaDev g, const double* __restrict__ camR, const double* __restrict__ t,
                    const double* __restrict__ par, const double* __restrict__ c_w,
@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(kBlock)
       const V3 e = ld3(b + 3);
       const S3 Hi{b[6], b[7], b[8], b[9], b[10], b[11]};
       ObsGeom o;
-      obs_geom(R9, t3, ld3(b), model, pp, o);
+      obs_geom<WIDE>(R9, t3, ld3(b), model, pp, o);
       const double r0 = o.px - g.c_xy[2 * (long)k], r1 = o.py - g.c_xy[2 * (long)k + 1];
       ObsJac J;
       build_jac(g, n, R9, o, J);
@@ -772,6 +772,7 @@ __global__ void __launch_bounds__(kBlock)
 // Phase B, camera-major, one wave per camera, Jacobian recomputed from the gathered point record:
 //   w_n = sum_k J_a^T w_k (J_a z_a - J_pt t_p) + D_n z_n,   yi_part[n] = this camera's intrinsics rows.
 // Algorithmic bytes per observation: c_w 8 + c_pt 4 + the 64-byte point record (X_p, t_p).
+template <bool WIDE>
 __global__ void __launch_bounds__(kBlock)
     k_ba_phaseB(BaDev g, CgVec v, double yscale, const double* __restrict__ camR, const double* __restrict__ t,
                 const double* __restrict__ par, const double* __restrict__ c_w,
@@ -822,7 +823,7 @@ __global__ void __launch_bounds__(kBlock)
       }
       if (w == 0.0) continue;
       ObsGeom o;
-      obs_geom(R9, t3, Xp, model, pp, o);
+      obs_geom<WIDE>(R9, t3, Xp, model, pp, o);
       V3 om = V3{0, 0, 0} - R_mul(R9, tp);  // - J_pt t_p = - Jx (R t_p)
       if (rf) om = om + 2.0 * cross(zr, o.a);
       if (tf) om = om + zt;
@@ -1080,6 +1081,7 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // candidate cost, one lane per observation; part[block][1]
+template <bool WIDE>
 __global__ void __launch_bounds__(kBlock)
     k_ba_cost(BaDev g, const double* __restrict__ camR, const double* __restrict__ t,
               const double* __restrict__ X, const double* __restrict__ par, double* __restrict__ part) {
@@ -1091,7 +1093,7 @@ __global__ void __launch_bounds__(kBlock)
     const int n = g.g.cam[k];
     const int ik = g.cam_intr[n];
     ObsGeom o;
-    obs_geom(camR + 9 * (long)n, t + 3 * (long)n, ld3(X + 3 * p), g.intr_model[ik], par + 8 * (long)ik, o);
+    obs_geom<WIDE>(camR + 9 * (long)n, t + 3 * (long)n, ld3(X + 3 * p), g.intr_model[ik], par + 8 * (long)ik, o);
     if (!o.valid) continue;
     const double r0 = o.px - g.xy[2 * k], r1 = o.py - g.xy[2 * k + 1];
     double rho, w;
@@ -1193,6 +1195,19 @@ unsigned pp_mask_of(int model) {
     default: return (1u << 1) | (1u << 2);
   }
 }
+
+// Launch of a kernel that projects: the instance without the fisheye / FOV branches unless a camera needs them
+// (camera.hpp: distort_project<WIDE>).  `wide_` is the solver's flag.
+#define WIDE_LAUNCH(kernel, ...)                                    \
+  do {                                                              \
+    if (wide_) {                                                    \
+      constexpr bool WIDE = true;                                   \
+      hipLaunchKernelGGL(kernel, __VA_ARGS__);                      \
+    } else {                                                        \
+      constexpr bool WIDE = false;                                  \
+      hipLaunchKernelGGL(kernel, __VA_ARGS__);                      \
+    }                                                               \
+  } while (0)
 
 template <typename Fn>
 void dispatch_f(int F, Fn&& fn) {
@@ -1680,6 +1695,7 @@ class BaSolver final : public LmProblem {
     int fmax = 0;
     for (int k = 0; k < K_; ++k) {
       const int np = num_params_of(h_model[k]);
+      wide_ = wide_ || h_model[k] >= GSFM_CAMERA_OPENCV_FISHEYE;
       if (np < 0) throw StatusError(GSFM_ERR_UNSUPPORTED, "BA: camera model not supported");
       unsigned bits = 0;
       // ba.cc:273-293: SubsetManifold on the principal point / constant block / everything free
@@ -1949,24 +1965,24 @@ class BaSolver final : public LmProblem {
       diag_k = ws->gram_i.get();
     }
     dispatch_f(F_, [&](auto Fc) {
-      hipLaunchKernelGGL((k_ba_lin_track<decltype(Fc)::value>), dim3(gridTileP_), dim3(kBlock), 0, s, g_, Rk_, tk_, X_, par_,
+      WIDE_LAUNCH((k_ba_lin_track<decltype(Fc)::value, WIDE>), dim3(gridTileP_), dim3(kBlock), 0, s, g_, Rk_, tk_, X_, par_,
                          ws->jt.get(), ws->ptdiag.get(), ws->ptH.get(), ws->part.get());
     });
     if (sens_) {
-      hipLaunchKernelGGL((k_ba_lin_cam<true>), dim3(gridCam_), dim3(kBlock), 0, s, g_, Rk_, tk_, X_, par_, ws->c_w.get(),
+      WIDE_LAUNCH((k_ba_lin_cam<true, WIDE>), dim3(gridCam_), dim3(kBlock), 0, s, g_, Rk_, tk_, X_, par_, ws->c_w.get(),
                          diag_k, grad_k, ws->ipart.get(), sens);
       if (gridMulti_)
-        hipLaunchKernelGGL((k_ba_lin_cam<true>), dim3(gridMulti_), dim3(kBlock), 0, s, g1_, Rk_, tk_, X_, par_,
+        WIDE_LAUNCH((k_ba_lin_cam<true, WIDE>), dim3(gridMulti_), dim3(kBlock), 0, s, g1_, Rk_, tk_, X_, par_,
                            ws->c_w.get(), diag_k, grad_k, ws->ipart.get(), sens);
       hipLaunchKernelGGL(k_ba_rig_frame_lin, dim3(gridN_), dim3(kBlock), 0, s, rg_, diag_k, grad_k, ws->diag.get(),
                          ws->grad.get());
       hipLaunchKernelGGL(k_ba_rig_sensor_lin, dim3(S_), dim3(kBlock), 0, s, rg_, diag_k, grad_k, ws->diag.get(),
                          ws->grad.get());
     } else {
-      hipLaunchKernelGGL((k_ba_lin_cam<false>), dim3(gridCam_), dim3(kBlock), 0, s, g_, Rk_, tk_, X_, par_, ws->c_w.get(),
+      WIDE_LAUNCH((k_ba_lin_cam<false, WIDE>), dim3(gridCam_), dim3(kBlock), 0, s, g_, Rk_, tk_, X_, par_, ws->c_w.get(),
                          diag_k, grad_k, ws->ipart.get(), sens);
       if (gridMulti_)  // combine pass over the cameras whose lists were cut into slices
-        hipLaunchKernelGGL((k_ba_lin_cam<false>), dim3(gridMulti_), dim3(kBlock), 0, s, g1_, Rk_, tk_, X_, par_,
+        WIDE_LAUNCH((k_ba_lin_cam<false, WIDE>), dim3(gridMulti_), dim3(kBlock), 0, s, g1_, Rk_, tk_, X_, par_,
                            ws->c_w.get(), diag_k, grad_k, ws->ipart.get(), sens);
     }
     if (rig_ && !sens_) {  // lin_cam accumulated in the frame tangent: the frame's values are plain sums over its images
@@ -2012,18 +2028,18 @@ class BaSolver final : public LmProblem {
     hipLaunchKernelGGL(k_ba_build_track, dim3(gridP_), dim3(kBlock), 0, s, g_, radius, X_, ws->ptH.get(),
                        ws->ptdiag.get(), ws->ptjs.get(), ws->ptb.get(), ws->ptrec.get(), ws->pth.get());
     if (joint_) {
-      hipLaunchKernelGGL((k_ba_build_cam<true>), dim3(gridCam_), dim3(kBlock), 0, s, g_, R_, t_, par_, ws->c_w.get(),
+      WIDE_LAUNCH((k_ba_build_cam<true, WIDE>), dim3(gridCam_), dim3(kBlock), 0, s, g_, R_, t_, par_, ws->c_w.get(),
                          ws->ptb.get(), ws->gred.get(), ws->spose.get(), ws->ipart.get(), ws->scross.get());
       if (gridMulti_)
-        hipLaunchKernelGGL((k_ba_build_cam<true>), dim3(gridMulti_), dim3(kBlock), 0, s, g1_, R_, t_, par_, ws->c_w.get(),
+        WIDE_LAUNCH((k_ba_build_cam<true, WIDE>), dim3(gridMulti_), dim3(kBlock), 0, s, g1_, R_, t_, par_, ws->c_w.get(),
                            ws->ptb.get(), ws->gred.get(), ws->spose.get(), ws->ipart.get(), ws->scross.get());
     } else {
       double* gred_k = rig_ ? ws->gred_i.get() : ws->gred.get();
       double* spose_k = rig_ ? ws->spose_i.get() : ws->spose.get();
-      hipLaunchKernelGGL((k_ba_build_cam<false>), dim3(gridCam_), dim3(kBlock), 0, s, g_, Rk_, tk_, par_, ws->c_w.get(),
+      WIDE_LAUNCH((k_ba_build_cam<false, WIDE>), dim3(gridCam_), dim3(kBlock), 0, s, g_, Rk_, tk_, par_, ws->c_w.get(),
                          ws->ptb.get(), gred_k, spose_k, ws->ipart.get(), (double*)nullptr);
       if (gridMulti_)
-        hipLaunchKernelGGL((k_ba_build_cam<false>), dim3(gridMulti_), dim3(kBlock), 0, s, g1_, Rk_, tk_, par_, ws->c_w.get(),
+        WIDE_LAUNCH((k_ba_build_cam<false, WIDE>), dim3(gridMulti_), dim3(kBlock), 0, s, g1_, Rk_, tk_, par_, ws->c_w.get(),
                            ws->ptb.get(), gred_k, spose_k, ws->ipart.get(), (double*)nullptr);
       if (rig_)  // frame blocks: sum over the frame's images of T^T g and T^T S T (cross blocks between two images of
                  // one frame are left to the PCG: this is the preconditioner and the right-hand side)
@@ -2071,7 +2087,7 @@ class BaSolver final : public LmProblem {
     hipLaunchKernelGGL(k_ba_cam_prepare, dim3(gridNp_), dim3(kBlock), 0, s, Np_, qn_, Rn_);
     if (rig_) image_poses(Rn_, tn_, Rkn_, tkn_);
     double* part3 = ws->part.get() + kMaxBlocks * 4;
-    hipLaunchKernelGGL(k_ba_cost, dim3(gridM_), dim3(kBlock), 0, s, g_, Rkn_, tkn_, Xn_, parn_, part3);
+    WIDE_LAUNCH((k_ba_cost<WIDE>), dim3(gridM_), dim3(kBlock), 0, s, g_, Rkn_, tkn_, Xn_, parn_, part3);
     hipLaunchKernelGGL((k_ba_sum_partials<1>), dim3(1), dim3(kBlock), 0, s, part3, gridM_, ws->scal.get() + 6);
     if (multi) {
       allreduce_sum(ctx_, ws->scal.get(), 3);
@@ -2174,10 +2190,10 @@ class BaSolver final : public LmProblem {
       });
       if (timed) ctx_->prof.end(s);
       timed = ctx_->prof.begin(s, GSFM_KERNEL_BA_SCHUR_B, it);
-      hipLaunchKernelGGL(k_ba_phaseB, dim3(gridCam_), dim3(kBlock), 0, s, g_, vk, yscale, Rk_, tk_, par_,
+      WIDE_LAUNCH((k_ba_phaseB<WIDE>), dim3(gridCam_), dim3(kBlock), 0, s, g_, vk, yscale, Rk_, tk_, par_,
                          ws->c_w.get(), ws->ptrec.get(), dk, ws->yi_part.get(), 0);
       if (gridMulti_)
-        hipLaunchKernelGGL(k_ba_phaseB, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, vk, yscale, Rk_, tk_, par_,
+        WIDE_LAUNCH((k_ba_phaseB<WIDE>), dim3(gridMulti_), dim3(kBlock), 0, s, g1_, vk, yscale, Rk_, tk_, par_,
                            ws->c_w.get(), ws->ptrec.get(), dk, ws->yi_part.get(), gridCam_ + gridK_);
       if (timed) ctx_->prof.end(s);
       if (small_groups_) {
@@ -2206,6 +2222,7 @@ class BaSolver final : public LmProblem {
   RigDev rg_{};
   double *Rk_ = nullptr, *Rkn_ = nullptr, *tk_ = nullptr, *tkn_ = nullptr;  // poses the sweeps see (frames or images)
   bool small_groups_ = false, joint_ = false;
+  bool wide_ = false;  // some camera uses a fisheye / FOV model: the sweeps run their WIDE instances
   bool defl_on_ = true;  // deflate the next reduced solve (short solves run plain)
   int pcg_hint_ = 0;     // iteration count of the previous reduced solve (where cg_solve first reads the status back)
   long P_ = 0, M_ = 0, Mp_ = 0, m_used_ = 0;

@@ -27,7 +27,120 @@ struct ObsGeom {
   bool valid;       // point in front of the camera; otherwise residual and Jacobians are zero
 };
 
+// Equidistant fisheye with radial distortion in theta: (xd, yd) = m (u, v), m = theta_d / r, theta = atan(r),
+// theta_d = theta (1 + k1 theta^2 + k2 theta^4 + k3 theta^6 + k4 theta^8); dm_r = (dm/dr) / r; sk = theta / r (d m / d k_j =
+// sk theta^(2j)); t2 .. t8 = the even powers of theta.  r <= eps: the mapping is the identity there.
+__device__ __forceinline__ void fisheye_core(double r2, double k1, double k2, double k3, double k4, double& m, double& dm_r,
+                                             double& sk, double& t2, double& t4, double& t6, double& t8) {
+  const double r = sqrt(r2);
+  const bool big = r > 2.220446049250313e-16;
+  const double th = big ? atan(r) : r;
+  t2 = th * th;
+  t4 = t2 * t2;
+  t6 = t4 * t2;
+  t8 = t4 * t4;
+  const double poly = 1.0 + k1 * t2 + k2 * t4 + k3 * t6 + k4 * t8;
+  const double dpoly = 1.0 + 3.0 * k1 * t2 + 5.0 * k2 * t4 + 7.0 * k3 * t6 + 9.0 * k4 * t8;  // d theta_d / d theta
+  if (big) {
+    m = th * poly / r;
+    dm_r = (dpoly / (1.0 + r2) - m) / r2;
+    sk = th / r;
+  } else {
+    m = poly;
+    dm_r = 0.0;
+    sk = 1.0;
+  }
+}
+
 // pixel = f(u, v; params) and its derivatives w.r.t. (u, v) -> Juv[4] = {du/du, du/dv, dv/du, dv/dv}
+// The fisheye / FOV models (ids >= 5).  Kept out of the sweeps that never see them: every kernel that projects is
+// instantiated twice (template parameter WIDE) and the host picks the lean instance when all cameras use the five polynomial
+// models — with the transcendental branches inlined k_ba_phaseB needs 278 instead of 219 registers (1 wave per SIMD) and
+// runs three times slower on configs[3].
+__device__ __forceinline__ void distort_project_wide(int model, const double* __restrict__ p, double u, double v, double r2,
+                                                     double& px, double& py, double (&Juv)[4], double (&Jp)[2][8]) {
+  switch (model) {
+    case GSFM_CAMERA_OPENCV_FISHEYE: {
+      const double fx = p[0], fy = p[1];
+      double m, dm_r, sk, t2, t4, t6, t8;
+      fisheye_core(r2, p[4], p[5], p[6], p[7], m, dm_r, sk, t2, t4, t6, t8);
+      px = fx * u * m + p[2];
+      py = fy * v * m + p[3];
+      Juv[0] = fx * (m + u * u * dm_r);
+      Juv[1] = fx * (u * v * dm_r);
+      Juv[2] = fy * (u * v * dm_r);
+      Juv[3] = fy * (m + v * v * dm_r);
+      Jp[0][0] = u * m; Jp[1][1] = v * m;
+      Jp[0][2] = 1.0; Jp[1][3] = 1.0;
+      Jp[0][4] = fx * u * sk * t2; Jp[1][4] = fy * v * sk * t2;
+      Jp[0][5] = fx * u * sk * t4; Jp[1][5] = fy * v * sk * t4;
+      Jp[0][6] = fx * u * sk * t6; Jp[1][6] = fy * v * sk * t6;
+      Jp[0][7] = fx * u * sk * t8; Jp[1][7] = fy * v * sk * t8;
+      break;
+    }
+    case GSFM_CAMERA_SIMPLE_RADIAL_FISHEYE:
+    case GSFM_CAMERA_RADIAL_FISHEYE: {
+      const double f = p[0];
+      const double k2 = model == GSFM_CAMERA_RADIAL_FISHEYE ? p[4] : 0.0;
+      double m, dm_r, sk, t2, t4, t6, t8;
+      fisheye_core(r2, p[3], k2, 0.0, 0.0, m, dm_r, sk, t2, t4, t6, t8);
+      px = f * u * m + p[1];
+      py = f * v * m + p[2];
+      Juv[0] = f * (m + u * u * dm_r);
+      Juv[1] = f * (u * v * dm_r);
+      Juv[2] = Juv[1];
+      Juv[3] = f * (m + v * v * dm_r);
+      Jp[0][0] = u * m; Jp[1][0] = v * m;
+      Jp[0][1] = 1.0; Jp[1][2] = 1.0;
+      Jp[0][3] = f * u * sk * t2; Jp[1][3] = f * v * sk * t2;
+      if (model == GSFM_CAMERA_RADIAL_FISHEYE) {
+        Jp[0][4] = f * u * sk * t4;
+        Jp[1][4] = f * v * sk * t4;
+      }
+      break;
+    }
+    case GSFM_CAMERA_FOV: {
+      const double fx = p[0], fy = p[1], om = p[4];
+      const double om2 = om * om;
+      double fac, dfac_r2, dfac_om;  // factor, d factor / d r^2, d factor / d omega
+      if (om2 < 1e-4) {
+        fac = om2 * r2 / 3.0 - om2 / 12.0 + 1.0;
+        dfac_r2 = om2 / 3.0;
+        dfac_om = 2.0 * om * (r2 / 3.0 - 1.0 / 12.0);
+      } else if (r2 < 1e-4) {
+        const double t = tan(0.5 * om), t2 = t * t;
+        fac = (-2.0 * t * (4.0 * r2 * t2 - 3.0)) / (3.0 * om);
+        dfac_r2 = -8.0 * t * t2 / (3.0 * om);
+        const double dt = 0.5 * (1.0 + t2);  // d tan(omega / 2) / d omega
+        dfac_om = (-2.0 * dt * (12.0 * r2 * t2 - 3.0)) / (3.0 * om) - fac / om;
+      } else {
+        const double r = sqrt(r2), t = tan(0.5 * om);
+        const double a = 2.0 * r * t, num = atan(a);
+        fac = num / (r * om);
+        const double da = 1.0 / (1.0 + a * a);
+        // d/dr: (da 2 t r - num) / (r^2 om); d r^2 = 2 r dr
+        dfac_r2 = (da * 2.0 * t * r - num) / (r2 * om) / (2.0 * r);
+        dfac_om = da * 2.0 * r * 0.5 * (1.0 + t * t) / (r * om) - fac / om;
+      }
+      px = fx * u * fac + p[2];
+      py = fy * v * fac + p[3];
+      Juv[0] = fx * (fac + 2.0 * u * u * dfac_r2);
+      Juv[1] = fx * (2.0 * u * v * dfac_r2);
+      Juv[2] = fy * (2.0 * u * v * dfac_r2);
+      Juv[3] = fy * (fac + 2.0 * v * v * dfac_r2);
+      Jp[0][0] = u * fac; Jp[1][1] = v * fac;
+      Jp[0][2] = 1.0; Jp[1][3] = 1.0;
+      Jp[0][4] = fx * u * dfac_om; Jp[1][4] = fy * v * dfac_om;
+      break;
+    }
+    default:
+      px = py = 0.0;
+      Juv[0] = Juv[1] = Juv[2] = Juv[3] = 0.0;
+      break;
+  }
+}
+
+template <bool WIDE>
 __device__ __forceinline__ void distort_project(int model, const double* __restrict__ p, double u, double v,
                                                 double& px, double& py, double (&Juv)[4], double (&Jp)[2][8]) {
 #pragma unroll
@@ -36,6 +149,12 @@ __device__ __forceinline__ void distort_project(int model, const double* __restr
     Jp[1][j] = 0.0;
   }
   const double r2 = u * u + v * v;
+  if constexpr (WIDE) {
+    if (model >= GSFM_CAMERA_OPENCV_FISHEYE) {
+      distort_project_wide(model, p, u, v, r2, px, py, Juv, Jp);
+      return;
+    }
+  }
   switch (model) {
     case GSFM_CAMERA_SIMPLE_PINHOLE: {
       const double f = p[0];
@@ -76,95 +195,6 @@ __device__ __forceinline__ void distort_project(int model, const double* __restr
       }
       break;
     }
-    case GSFM_CAMERA_OPENCV_FISHEYE:
-    case GSFM_CAMERA_SIMPLE_RADIAL_FISHEYE:
-    case GSFM_CAMERA_RADIAL_FISHEYE: {
-      const bool full = model == GSFM_CAMERA_OPENCV_FISHEYE;
-      const double fx = p[0], fy = full ? p[1] : p[0];
-      const int ic = full ? 2 : 1, ik = full ? 4 : 3;                                   // first principal-point / distortion slot
-      const int nk = full ? 4 : (model == GSFM_CAMERA_RADIAL_FISHEYE ? 2 : 1);          // distortion coefficients
-      const double r = sqrt(r2);
-      double m = 1.0, dm_r = 0.0;  // (xd, yd) = m (u, v);  dm_r = (dm/dr) / r
-      double th = r, th2 = r2;
-      if (r > 2.220446049250313e-16) {
-        th = atan(r);
-        th2 = th * th;
-      }
-      double poly = 1.0, dpoly = 1.0, tp = 1.0;  // theta_d = theta * poly(theta^2); d theta_d / d theta = dpoly
-      double tpow[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        tp *= th2;
-        tpow[j] = tp;  // theta^(2 (j + 1))
-        if (j < nk) {
-          poly += p[ik + j] * tp;
-          dpoly += (2.0 * j + 3.0) * p[ik + j] * tp;
-        }
-      }
-      if (r > 2.220446049250313e-16) {
-        m = th * poly / r;
-        dm_r = (dpoly / (1.0 + r2) - m) / r2;  // ((d theta_d / d theta)(d theta / dr) r - theta_d) / r^2, divided by r
-      } else {
-        m = poly;
-      }
-      px = fx * u * m + p[ic];
-      py = fy * v * m + p[ic + 1];
-      Juv[0] = fx * (m + u * u * dm_r);
-      Juv[1] = fx * (u * v * dm_r);
-      Juv[2] = fy * (u * v * dm_r);
-      Juv[3] = fy * (m + v * v * dm_r);
-      if (full) {
-        Jp[0][0] = u * m;
-        Jp[1][1] = v * m;
-      } else {
-        Jp[0][0] = u * m;
-        Jp[1][0] = v * m;
-      }
-      Jp[0][ic] = 1.0;
-      Jp[1][ic + 1] = 1.0;
-      const double s = r > 2.220446049250313e-16 ? th / r : 1.0;  // d m / d k_j = s theta^(2 (j + 1))
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (j < nk) {
-          Jp[0][ik + j] = fx * u * s * tpow[j];
-          Jp[1][ik + j] = fy * v * s * tpow[j];
-        }
-      break;
-    }
-    case GSFM_CAMERA_FOV: {
-      const double fx = p[0], fy = p[1], om = p[4];
-      const double om2 = om * om;
-      double fac, dfac_r2, dfac_om;  // factor, d factor / d r^2, d factor / d omega
-      if (om2 < 1e-4) {
-        fac = om2 * r2 / 3.0 - om2 / 12.0 + 1.0;
-        dfac_r2 = om2 / 3.0;
-        dfac_om = 2.0 * om * (r2 / 3.0 - 1.0 / 12.0);
-      } else if (r2 < 1e-4) {
-        const double t = tan(0.5 * om), t2 = t * t;
-        fac = (-2.0 * t * (4.0 * r2 * t2 - 3.0)) / (3.0 * om);
-        dfac_r2 = -8.0 * t * t2 / (3.0 * om);
-        const double dt = 0.5 * (1.0 + t2);  // d tan(omega / 2) / d omega
-        dfac_om = (-2.0 * dt * (12.0 * r2 * t2 - 3.0)) / (3.0 * om) - fac / om;
-      } else {
-        const double r = sqrt(r2), t = tan(0.5 * om);
-        const double a = 2.0 * r * t, num = atan(a);
-        fac = num / (r * om);
-        const double da = 1.0 / (1.0 + a * a);
-        // d/dr: (da 2 t r - num) / (r^2 om); d r^2 = 2 r dr
-        dfac_r2 = (da * 2.0 * t * r - num) / (r2 * om) / (2.0 * r);
-        dfac_om = da * 2.0 * r * 0.5 * (1.0 + t * t) / (r * om) - fac / om;
-      }
-      px = fx * u * fac + p[2];
-      py = fy * v * fac + p[3];
-      Juv[0] = fx * (fac + 2.0 * u * u * dfac_r2);
-      Juv[1] = fx * (2.0 * u * v * dfac_r2);
-      Juv[2] = fy * (2.0 * u * v * dfac_r2);
-      Juv[3] = fy * (fac + 2.0 * v * v * dfac_r2);
-      Jp[0][0] = u * fac; Jp[1][1] = v * fac;
-      Jp[0][2] = 1.0; Jp[1][3] = 1.0;
-      Jp[0][4] = fx * u * dfac_om; Jp[1][4] = fy * v * dfac_om;
-      break;
-    }
     default: {  // GSFM_CAMERA_OPENCV
       const double fx = p[0], fy = p[1], k1 = p[4], k2 = p[5], p1 = p[6], p2 = p[7];
       const double rad = k1 * r2 + k2 * r2 * r2;
@@ -189,6 +219,7 @@ __device__ __forceinline__ void distort_project(int model, const double* __restr
 }
 
 // x_cam = R X + t; pixel = ImgFromCam(params, x_cam).  R9 row-major.
+template <bool WIDE>
 __device__ __forceinline__ void obs_geom(const double* __restrict__ R9, const double* __restrict__ t3, const V3& X,
                                          int model, const double* __restrict__ par, ObsGeom& g) {
   g.a = V3{R9[0] * X.x + R9[1] * X.y + R9[2] * X.z, R9[3] * X.x + R9[4] * X.y + R9[5] * X.z,
@@ -198,7 +229,7 @@ __device__ __forceinline__ void obs_geom(const double* __restrict__ R9, const do
   const double iz = 1.0 / (g.valid ? zc : 1.0);
   const double u = xc * iz, v = yc * iz;
   double Juv[4];
-  distort_project(model, par, u, v, g.px, g.py, Juv, g.Jp);
+  distort_project<WIDE>(model, par, u, v, g.px, g.py, Juv, g.Jp);
   // d(u,v)/d x_cam = [1/z, 0, -u/z; 0, 1/z, -v/z]
   g.Jx[0][0] = Juv[0] * iz;
   g.Jx[0][1] = Juv[1] * iz;

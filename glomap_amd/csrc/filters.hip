@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(kBlock)
         double px = 0.0, py = 0.0, Juv[4], Jp[2][8];
         // Camera::ImgFromCam(...).value_or(Zero): projection fails for points at / behind the camera
         if (pc.z > 2.220446049250313e-16)
-          distort_project(v.intr_model[ik], v.intr_params + 8 * (long)ik, pc.x * iz, pc.y * iz, px, py, Juv, Jp);
+          distort_project<true>(v.intr_model[ik], v.intr_params + 8 * (long)ik, pc.x * iz, pc.y * iz, px, py, Juv, Jp);
         const double ex = px - v.xy[2 * k], ey = py - v.xy[2 * k + 1];
         ok = sqrt(ex * ex + ey * ey) < thr;
       } else {
