@@ -28,7 +28,7 @@
 //                 s[M] (+ candidate), wrob[M], qa[M], qb[M], jss[M]                      per observation
 //   camera-major: coff[N+2], c_src[M], c_pt[M] i32, c_dir[M][3], c_cal[M] u8, c_jss[M]  static per solve
 //                 c_qa[M], c_qb[M]                                                       per LM iteration
-//   per track   : X[P][3] (+ candidate), ptb[P][16] = (X, e, H_pp^-1, D_p, pad) 128-byte build record,
+//   per track   : X[P][3] (+ candidate), ptb[P][16] = (X, e, H_pp^-1, D_p, sum_k Q_k d_k) 128-byte build record,
 //                 ptrec[P][8] = (X, t_p, pad) 64-byte PCG record, hppd[P], jsx[P], used[P] u8
 //   per camera  : c[N][3] (+ candidate), hcc[N], jsc[N], dcam[3N], gc[3N], gred[3N], scc[N][6], minv[N][9]
 //   PCG vectors : x, r, z, p, s, w [3N] (cg.hpp)
@@ -43,7 +43,7 @@
 namespace gsfm {
 namespace {
 
-constexpr int kPtb = 16;  // doubles per point build record: X (3) | e (3) | H_pp^-1 (6) | D_p | pad -> one 128-byte line
+constexpr int kPtb = 16;  // doubles per point build record: X (3) | e (3) | H_pp^-1 (6) | D_p | sum_k Q_k d_k (3) -> one 128-byte line
 
 struct GpDev {
   ObsGraph g;
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(kBlock)
   const int nwaves = gridDim.x * (kBlock / 64);
   for (int tile = wave; tile < g.g.T; tile += nwaves) {
     const long k0 = g.g.tile_k[tile], k1 = g.g.tile_k[tile + 1];
-    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // H (xx xy xz yy yz zz) | g_p
+    double acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // H (xx xy xz yy yz zz) | g_p | sum_k Q_k d_k (scale mode)
     int key = -1 - lane;
     for (long k = k0 + lane; k < k1; k += 64) {
       const int p = g.g.obs_pt[k];
@@ -248,8 +248,12 @@ __global__ void __launch_bounds__(kBlock)
       acc[6] -= q.x;
       acc[7] -= q.y;
       acc[8] -= q.z;
+      const V3 qd = applyQ(a, beta, d, d);  // Q_k d_k
+      acc[9] += qd.x;
+      acc[10] += qd.y;
+      acc[11] += qd.z;
     }
-    seg_scan<9>(acc, key, lane);
+    seg_scan<12>(acc, key, lane);
     if (seg_is_tail(key, lane) && key >= 0 && g.g.used[key]) {
       const long p = key;
       const V3 Xp = ld3(X + 3 * p);
@@ -271,6 +275,9 @@ __global__ void __launch_bounds__(kBlock)
       st3(b + 3, e);
       b[6] = Hi.xx; b[7] = Hi.xy; b[8] = Hi.xz; b[9] = Hi.yy; b[10] = Hi.yz; b[11] = Hi.zz;
       b[12] = Dp_rec;
+      b[13] = acc[9];
+      b[14] = acc[10];
+      b[15] = acc[11];
       double* hc = pth + 6 * p;  // compact copy for phase A: consecutive tracks -> one coalesced 48-byte stream
       hc[0] = Hi.xx; hc[1] = Hi.xy; hc[2] = Hi.xz; hc[3] = Hi.yy; hc[4] = Hi.yz; hc[5] = Hi.zz;
       double* pr = ptrec + 8 * p;
@@ -461,16 +468,19 @@ __global__ void __launch_bounds__(kBlock) k_gp_defl_modes(int N, const double* _
   }
 }
 
-// A W_a for the three TRANSLATION modes (W_a = e_a at every camera) without the track-major sweep.  H_p = sum_k Q_k + D_p I
-// is exactly what k_gp_build_track inverts, so for a field that is the same at every camera the point elimination is
-// closed-form:  t_p = H_p^-1 (sum_k Q_k) e_a = e_a - D_p H_p^-1 e_a,  z_n - t_p = D_p H_p^-1 e_a,  and
-//     (A W_a)_n = sum_k Q_k (D_p H_p^-1)[:, a] + D_n e_a
-// — ONE camera-major sweep for all three modes (one 128-byte point record per observation) instead of three full operator
-// applications per deflated solve.  Needs optimised points (otherwise nothing is eliminated and the identity is void).
+// A W for ALL FOUR gauge modes without a single operator application.  H_p = sum_k Q_k + D_p I is exactly what
+// k_gp_build_track inverts, so the point elimination of the mode fields is closed-form:
+//   translation, W_a = e_a at every camera:  t_p = H_p^-1 (sum_k Q_k) e_a = e_a - D_p H_p^-1 e_a,   z_n - t_p = D_p H_p^-1 e_a
+//       (A W_a)_n = sum_k Q_k (D_p H_p^-1)[:, a] + D_n e_a
+//   scale, W_3 = c_n = X_p - d_k:  sum_k Q_k c_n = (H_p - D_p) X_p - g_p,  g_p = sum_k Q_k d_k  (stored by the build sweep),
+//       t_p = X_p - v_p,  v_p = H_p^-1 (D_p X_p + g_p),   z_n - t_p = v_p - d_k
+//       (A W_3)_n = sum_k Q_k (v_p - d_k) + D_n c_n
+// — ONE camera-major sweep (one 128-byte point record per observation) instead of four operator applications per deflated
+// solve.  Needs optimised points (otherwise nothing is eliminated and the identities are void).
 __global__ void __launch_bounds__(kBlock)
-    k_gp_aw_translations(GpDev g, double yscale, const double* __restrict__ c, const double* __restrict__ c_qa,
-                         const double* __restrict__ c_qb, const double* __restrict__ ptb, const double* __restrict__ dcam,
-                         double* __restrict__ AW, long n3) {
+    k_gp_aw_modes(GpDev g, double yscale, const double* __restrict__ c, const double* __restrict__ c_qa,
+                  const double* __restrict__ c_qb, const double* __restrict__ ptb, const double* __restrict__ dcam,
+                  double* __restrict__ AW, long n3) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (kBlock / 64);
@@ -478,26 +488,33 @@ __global__ void __launch_bounds__(kBlock)
     const int sg = cam_seg_index(g.g, it);
     const int n = g.g.seg_cam[sg];
     const V3 cn = ld3(c + 3 * (long)n);
-    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int k = cam_seg_k0(g.g, sg) + lane; k < cam_seg_k1(g.g, sg); k += 64) {
       const double* b = ptb + kPtb * (long)g.g.c_pt[k];
       const double ak = c_qa[k], bk = c_qb[k];
-      const V3 d = ld3(b) - cn;
+      const V3 Xp = ld3(b);
+      const V3 d = Xp - cn;
       const double Dp = b[12];
-      const V3 u0{Dp * b[6], Dp * b[7], Dp * b[8]}, u1{Dp * b[7], Dp * b[9], Dp * b[10]}, u2{Dp * b[8], Dp * b[10], Dp * b[11]};
-      const V3 y0 = applyQ(ak, bk, d, u0), y1 = applyQ(ak, bk, d, u1), y2 = applyQ(ak, bk, d, u2);
+      const S3 Hi{b[6], b[7], b[8], b[9], b[10], b[11]};
+      const V3 u0{Dp * Hi.xx, Dp * Hi.xy, Dp * Hi.xz}, u1{Dp * Hi.xy, Dp * Hi.yy, Dp * Hi.yz}, u2{Dp * Hi.xz, Dp * Hi.yz, Dp * Hi.zz};
+      const V3 vp = mul(Hi, Dp * Xp + V3{b[13], b[14], b[15]});
+      const V3 y0 = applyQ(ak, bk, d, u0), y1 = applyQ(ak, bk, d, u1), y2 = applyQ(ak, bk, d, u2), y3 = applyQ(ak, bk, d, vp - d);
       acc[0] += y0.x; acc[1] += y0.y; acc[2] += y0.z;
       acc[3] += y1.x; acc[4] += y1.y; acc[5] += y1.z;
       acc[6] += y2.x; acc[7] += y2.y; acc[8] += y2.z;
+      acc[9] += y3.x; acc[10] += y3.y; acc[11] += y3.z;
     }
-    wave_allsum<9>(acc);
-    if (!cam_seg_total<9>(g.g, sg, acc, lane)) continue;
+    wave_allsum<12>(acc);
+    if (!cam_seg_total<12>(g.g, sg, acc, lane)) continue;
     if (lane == 0) {
 #pragma unroll
       for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int j = 0; j < 3; ++j)
           AW[(size_t)a * n3 + 3 * (long)n + j] = acc[3 * a + j] + (a == j ? yscale * dcam[3 * (long)n + a] : 0.0);
+      AW[(size_t)3 * n3 + 3 * (long)n] = acc[9] + yscale * dcam[3 * (long)n] * cn.x;
+      AW[(size_t)3 * n3 + 3 * (long)n + 1] = acc[10] + yscale * dcam[3 * (long)n + 1] * cn.y;
+      AW[(size_t)3 * n3 + 3 * (long)n + 2] = acc[11] + yscale * dcam[3 * (long)n + 2] * cn.z;
     }
   }
 }
@@ -1351,16 +1368,16 @@ class GpSolver final : public LmProblem {
       defl.cd = ws->defl_cd.ensure((size_t)2 * kCgMaxBlocks * 2 * kCgMaxModes);
       hipLaunchKernelGGL(k_gp_defl_modes, dim3(gridN_), dim3(kBlock), 0, s, N_, (const double*)ci_, W);
       defl.W = W;
-      if (g_.opt_x) {  // the three translation modes in one camera-major sweep (k_gp_aw_translations); the scale mode is applied
-        hipLaunchKernelGGL(k_gp_aw_translations, dim3(gridCam_), dim3(kBlock), 0, s, g_, yscale, (const double*)ci_,
+      if (g_.opt_x) {  // A W of all four modes in one camera-major sweep (k_gp_aw_modes): no operator application
+        hipLaunchKernelGGL(k_gp_aw_modes, dim3(gridCam_), dim3(kBlock), 0, s, g_, yscale, (const double*)ci_,
                            (const double*)ws->c_qa.get(), (const double*)ws->c_qb.get(), (const double*)ws->ptb.get(),
                            (const double*)ws->dcam.get(), defl.AW, (long)n3);
         if (gridMulti_)
-          hipLaunchKernelGGL(k_gp_aw_translations, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, yscale, (const double*)ci_,
+          hipLaunchKernelGGL(k_gp_aw_modes, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, yscale, (const double*)ci_,
                              (const double*)ws->c_qa.get(), (const double*)ws->c_qb.get(), (const double*)ws->ptb.get(),
                              (const double*)ws->dcam.get(), defl.AW, (long)n3);
-        if (ctx_->comm.world > 1) allreduce_sum(ctx_, defl.AW, 3 * n3);
-        defl.aw_ready = 3;
+        if (ctx_->comm.world > 1) allreduce_sum(ctx_, defl.AW, 4 * n3);
+        defl.aw_ready = 4;
       }
     }
     const long iters = cg_solve<3, false>(ctx_, cg_, tol, opt_.lm.pcg_max_iterations, [&](int it) {
@@ -1391,8 +1408,8 @@ class GpSolver final : public LmProblem {
                            gridCam_ + gridMulti_, gridN_);
     }, defl.k ? &defl : nullptr, &pcg_hint_);
     // deflation pays while a plain solve needs more than ~3 k iterations (iters includes the k applications for A W)
-    // (with the closed-form translation products the price of A W is about two applications instead of four)
-    const int napp = defl.k - defl.aw_ready, cost = g_.opt_x ? 2 : 4;
+    // (with the closed-form mode products the price of A W is one camera-major sweep — say one application — instead of four)
+    const int napp = defl.k - defl.aw_ready, cost = g_.opt_x ? 1 : 4;
     defl_on_ = defl.k ? iters - napp > cost : iters > 3 * cost;
     return iters;
   }
