@@ -368,7 +368,7 @@ __device__ __forceinline__ bool cg_converged(const CgVec& v, int it, double tol2
 // All loads of a block are issued BEFORE its first store: the vectors may alias as far as the compiler knows, so a load
 // placed after a store waits for it — per element that was a chain of dependent round trips (36 us for 10 000 camera
 // blocks with four deflated modes; the whole kernel is a handful of round trips now).
-template <int BS>
+template <int BS, bool DEFL = true>
 __device__ __forceinline__ void cg_block_update(const CgVec& v, long o, const double* __restrict__ m, double alpha,
                                                 double beta, double& rz, double& rr,
                                                 const double (&y)[kCgMaxModes], double (&cd)[2 * kCgMaxModes],
@@ -386,7 +386,24 @@ __device__ __forceinline__ void cg_block_update(const CgVec& v, long o, const do
 #pragma unroll
   for (int i = 0; i < BS * BS; ++i) mm[i] = m[i];
   double rn[BS], zn[BS];
-  if constexpr (BS <= 3) {
+  if constexpr (!DEFL) {  // single-workgroup solves are never deflated (1 024-thread kernels: 128 registers)
+#pragma unroll
+    for (int i = 0; i < BS; ++i) {
+      pi[i] = zi[i] + beta * pi[i];
+      si[i] = wi[i] + beta * si[i];
+      xi[i] += alpha * pi[i];
+      rn[i] = ri[i] - alpha * si[i];
+      rr += rn[i] * rn[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BS; ++i) {
+      double t = 0.0;
+#pragma unroll
+      for (int j = 0; j < BS; ++j) t += mm[i * BS + j] * rn[j];
+      zn[i] = t;
+      rz += rn[i] * t;
+    }
+  } else if constexpr (BS <= 3) {
     // deflation: W and A W of the block's elements in registers, used for the projection and for the new dot products
     double Wv[BS][kCgMaxModes], AWv[BS][kCgMaxModes];
 #pragma unroll
@@ -559,8 +576,8 @@ static __global__ void __launch_bounds__(kCgSingleThreads) k_cg_update1(CgVec v,
     const double y[kCgMaxModes] = {};
     double cd[2 * kCgMaxModes] = {};
     for (int b = threadIdx.x; b < v.N; b += blockDim.x)
-      cg_block_update<PB>(v, (long)PB * b, v.minv + (long)PB * PB * b, alpha, beta, acc[0], acc[1], y, cd,
-                          v.zmir ? v.zmir + (long)b * v.zmir_stride + v.zmir_off : nullptr);
+      cg_block_update<PB, false>(v, (long)PB * b, v.minv + (long)PB * PB * b, alpha, beta, acc[0], acc[1], y, cd,
+                                 v.zmir ? v.zmir + (long)b * v.zmir_stride + v.zmir_off : nullptr);
   }
   block_sum_1024<2>(acc, smem);
   if (threadIdx.x == 0) {
