@@ -296,6 +296,8 @@ def load():
     lib.gsfm_comm_init.argtypes = [vp, C.c_char_p, ip, ip]
     lib.gsfm_comm_selftest.restype = ip
     lib.gsfm_comm_selftest.argtypes = [vp, dp]
+    lib.gsfm_selftest_mt19937.restype = ip
+    lib.gsfm_selftest_mt19937.argtypes = [C.c_uint32, C.c_uint64, C.c_int64, C.c_double, dp, dp]
     lib.gsfm_comm_destroy.restype = ip
     lib.gsfm_comm_destroy.argtypes = [vp]
     lib.gsfm_comm_init_host.restype = ip

@@ -1,5 +1,8 @@
 // api.hip — context, communicator and misc entry points of the C ABI (include/gsfm.h).
+#include <random>
+
 #include "common.hpp"
+#include "mt19937.hpp"
 
 using namespace gsfm;
 
@@ -171,6 +174,23 @@ extern "C" int gsfm_comm_init(gsfm_ctx* ctx, const char id[GSFM_COMM_ID_BYTES], 
     ctx->comm.world = world_size;
     return (int)GSFM_OK;
   });
+}
+
+extern "C" int gsfm_selftest_mt19937(uint32_t seed, uint64_t skip, int64_t count, double scale, double* out_fast,
+                                     double* out_std) {
+  if (count < 0 || (count > 0 && (!out_fast || !out_std))) return GSFM_ERR_INVALID_ARGUMENT;
+  gsfm::FastMt19937 fast(seed);
+  fast.discard(skip);
+  // in two calls with an odd first length: exercises the phase handling of the block path
+  const size_t first = count > 3 ? 3 : (size_t)count;
+  fast.fill_uniform_pm1(out_fast, first, scale);
+  fast.fill_uniform_pm1(out_fast + first, (size_t)count - first, scale);
+  std::mt19937 ref;
+  ref.seed(seed);
+  ref.discard(skip);
+  std::uniform_real_distribution<double> uni(-1.0, 1.0);
+  for (int64_t i = 0; i < count; ++i) out_std[i] = scale * uni(ref);
+  return GSFM_OK;
 }
 
 // One RCCL all-reduce of a small device buffer on the ctx stream (works for world_size == 1 too): checks that the

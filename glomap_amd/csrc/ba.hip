@@ -402,6 +402,14 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// max_i |vec[i]| per block -> mpart[block]  (the gradient has 10^4 .. 10^6 entries: one workgroup took 140 us)
+__global__ void __launch_bounds__(kBlock) k_ba_absmax(const double* __restrict__ vec, int nvec, double* __restrict__ mpart) {
+  __shared__ double smem[4];
+  double m = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += gridDim.x * blockDim.x) m = fmax(m, fabs(vec[i]));
+  m = block_max(m, smem);
+  if (threadIdx.x == 0) mpart[blockIdx.x] = m;
+}
 // out[0] = sum part[.][0]; out[1] = max(part[.][1], max |vec|)
 __global__ void __launch_bounds__(kBlock)
     k_ba_finalize_lin(const double* __restrict__ part, int nblocks, const double* __restrict__ vec, int nvec,
@@ -983,17 +991,27 @@ __global__ void __launch_bounds__(kBlock)
   const int nwaves = gridDim.x * (kBlock / 64);
   for (int tile = wave; tile < g.g.T; tile += nwaves) {
     const long k0 = g.g.tile_k[tile], k1 = g.g.tile_k[tile + 1];
+    // a tile of at most 64 observations (all but the tiles of tracks longer than a wave): every lane keeps its
+    // observation's u and B planes in registers between the per-track sum and the per-observation model term — ONE
+    // trip over the Jacobian planes instead of two (same operations in the same order)
+    const bool one_trip = k1 - k0 <= 64;
     double acc[3] = {0, 0, 0};
     int key = -1 - lane;
+    double ku0 = 0.0, ku1 = 0.0;
+    double2 kb0{0, 0}, kb1{0, 0}, kb2{0, 0};
     for (long k = k0 + lane; k < k1; k += 64) {
       key = g.g.obs_pt[k];
       double u0, u1;
       ba_obs_u<F>(g, jt, dv, dintr, k, u0, u1);  // planes of unused tracks are zero
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const double2 b = jt[(PL_B + j) * g.Mp + k];
-        acc[j] += b.x * u0 + b.y * u1;
-      }
+      const double2 b0 = jt[(PL_B + 0) * g.Mp + k], b1 = jt[(PL_B + 1) * g.Mp + k], b2 = jt[(PL_B + 2) * g.Mp + k];
+      acc[0] += b0.x * u0 + b0.y * u1;
+      acc[1] += b1.x * u0 + b1.y * u1;
+      acc[2] += b2.x * u0 + b2.y * u1;
+      ku0 = u0;
+      ku1 = u1;
+      kb0 = b0;
+      kb1 = b1;
+      kb2 = b2;
     }
     seg_scan<3>(acc, key, lane);
     const bool tail = seg_is_tail(key, lane) && key >= 0;
@@ -1018,14 +1036,24 @@ __global__ void __launch_bounds__(kBlock)
     dX.x = __shfl(dX.x, src, 64);
     dX.y = __shfl(dX.y, src, 64);
     dX.z = __shfl(dX.z, src, 64);
-    for (long k = k0 + lane; k < k1; k += 64) {
-      double u0, u1;
-      ba_obs_u<F>(g, jt, dv, dintr, k, u0, u1);
-      const double2 b0 = jt[(PL_B + 0) * g.Mp + k], b1 = jt[(PL_B + 1) * g.Mp + k], b2 = jt[(PL_B + 2) * g.Mp + k];
-      u0 += b0.x * dX.x + b1.x * dX.y + b2.x * dX.z;
-      u1 += b0.y * dX.x + b1.y * dX.y + b2.y * dX.z;
-      const double2 rw = jt[(PL_I + F) * g.Mp + k];
-      acc3[0] -= u0 * rw.x + u1 * rw.y + 0.5 * (u0 * u0 + u1 * u1);
+    if (one_trip) {
+      const long k = k0 + lane;
+      if (k < k1) {
+        const double u0 = ku0 + (kb0.x * dX.x + kb1.x * dX.y + kb2.x * dX.z);
+        const double u1 = ku1 + (kb0.y * dX.x + kb1.y * dX.y + kb2.y * dX.z);
+        const double2 rw = jt[(PL_I + F) * g.Mp + k];
+        acc3[0] -= u0 * rw.x + u1 * rw.y + 0.5 * (u0 * u0 + u1 * u1);
+      }
+    } else {
+      for (long k = k0 + lane; k < k1; k += 64) {
+        double u0, u1;
+        ba_obs_u<F>(g, jt, dv, dintr, k, u0, u1);
+        const double2 b0 = jt[(PL_B + 0) * g.Mp + k], b1 = jt[(PL_B + 1) * g.Mp + k], b2 = jt[(PL_B + 2) * g.Mp + k];
+        u0 += b0.x * dX.x + b1.x * dX.y + b2.x * dX.z;
+        u1 += b0.y * dX.x + b1.y * dX.y + b2.y * dX.z;
+        const double2 rw = jt[(PL_I + F) * g.Mp + k];
+        acc3[0] -= u0 * rw.x + u1 * rw.y + 0.5 * (u0 * u0 + u1 * u1);
+      }
     }
   }
   block_sum<3>(acc3, smem);
@@ -1161,6 +1189,7 @@ struct BaWs {
   DevBuf<unsigned char> img_fixed, fmask;
   DevBuf<double> sens, Ri, Rin, ti, tin, diag_i, grad_i, gred_i, spose_i, dvec_i, zimg, wimg, ximg, lever, gram_i;
   DevBuf<double> defl_w, defl_aw, defl_b2, defl_part, defl_small, defl_cd;  // CgDeflation, cg.hpp
+  DevBuf<double> maxpart;
   static void destroy(void* p) { delete static_cast<BaWs*>(p); }
 };
 
@@ -1998,7 +2027,9 @@ class BaSolver final : public LmProblem {
       allreduce_sum(ctx_, ws->diag.get(), n_);
       allreduce_sum(ctx_, ws->grad.get(), n_);
     }
-    hipLaunchKernelGGL(k_ba_finalize_lin, dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridTileP_, ws->grad.get(), n_,
+    const int gmx = std::min(64, grid_for((size_t)n_, kBlock));
+    hipLaunchKernelGGL(k_ba_absmax, dim3(gmx), dim3(kBlock), 0, s, (const double*)ws->grad.get(), n_, ws->maxpart.ensure(64));
+    hipLaunchKernelGGL(k_ba_finalize_lin, dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridTileP_, (const double*)ws->maxpart.get(), gmx,
                        ws->scal.get());
     if (ctx_->comm.world > 1) {
       allreduce_sum(ctx_, ws->scal.get(), 1);

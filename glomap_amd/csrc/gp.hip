@@ -38,6 +38,7 @@
 #include "dump.hpp"
 #include "linalg.hpp"
 #include "lm.hpp"
+#include "mt19937.hpp"
 #include "obsgraph.hpp"
 
 namespace gsfm {
@@ -160,6 +161,14 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// max_i |vec[i]| per block -> mpart[block]  (the gradient has 10^4 .. 10^6 entries: one workgroup took 140 us)
+__global__ void __launch_bounds__(kBlock) k_gp_absmax(const double* __restrict__ vec, int nvec, double* __restrict__ mpart) {
+  __shared__ double smem[4];
+  double m = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += gridDim.x * blockDim.x) m = fmax(m, fabs(vec[i]));
+  m = block_max(m, smem);
+  if (threadIdx.x == 0) mpart[blockIdx.x] = m;
+}
 // out[0] = sum part[.][0], out[1] = max(part[.][1], max_i |vec[i]|)
 __global__ void __launch_bounds__(kBlock)
     k_gp_finalize_lin(const double* __restrict__ part, int nblocks, const double* __restrict__ vec, int nvec,
@@ -619,14 +628,26 @@ __global__ void __launch_bounds__(kBlock)
   const int nwaves = gridDim.x * (kBlock / 64);
   for (int tile = wave; tile < g.g.T; tile += nwaves) {
     const long k0 = g.g.tile_k[tile], k1 = g.g.tile_k[tile + 1];
+    // tiles of at most 64 observations (all but the tiles of tracks longer than a wave): d, the camera step, beta and the
+    // used flag stay in registers between the per-track sum and the per-observation part — one set of gathers instead
+    // of two (same operations in the same order)
+    const bool one_trip = k1 - k0 <= 64;
     double acc[3] = {0, 0, 0};
     int key = -1 - lane;
+    V3 kd{0, 0, 0}, kdc{0, 0, 0};
+    double kqb = 0.0;
+    bool kused = false;
     for (long k = k0 + lane; k < k1; k += 64) {
       const int p = g.g.obs_pt[k];
       key = p;
-      if (!g.g.used[p] || !g.opt_x) continue;
+      kused = g.g.used[p] != 0;
+      if (!kused) continue;
       const long n = g.g.cam[k];
-      const V3 y = applyQ(qa[k], qb[k], ld3(X + 3 * (long)p) - ld3(c + 3 * n), ld3(dc + 3 * n));
+      kd = ld3(X + 3 * (long)p) - ld3(c + 3 * n);
+      kdc = ld3(dc + 3 * n);
+      kqb = qb[k];
+      if (!g.opt_x) continue;
+      const V3 y = applyQ(qa[k], kqb, kd, kdc);
       acc[0] += y.x;
       acc[1] += y.y;
       acc[2] += y.z;
@@ -654,19 +675,32 @@ __global__ void __launch_bounds__(kBlock)
     dX.y = __shfl(dX.y, src, 64);
     dX.z = __shfl(dX.z, src, 64);
     for (long k = k0 + lane; k < k1; k += 64) {
-      const int p = g.g.obs_pt[k];
       const double sk = s[k];
-      if (!g.g.used[p]) {
+      bool used;
+      V3 d, dcn;
+      double beta;
+      if (one_trip) {
+        used = kused;
+        d = kd;
+        dcn = kdc;
+        beta = kqb;
+      } else {
+        const int p = g.g.obs_pt[k];
+        used = g.g.used[p] != 0;
+        const long n = g.g.cam[k];
+        d = used ? ld3(X + 3 * (long)p) - ld3(c + 3 * n) : V3{0, 0, 0};
+        dcn = used ? ld3(dc + 3 * n) : V3{0, 0, 0};
+        beta = qb[k];
+      }
+      if (!used) {
         sn[k] = sk;
         continue;
       }
-      const long n = g.g.cam[k];
-      const V3 d = ld3(X + 3 * (long)p) - ld3(c + 3 * n);
       const double w = wrob[k];
       const V3 r = ld3(g.dir + 3 * k) - sk * d;
-      const V3 dcx = ld3(dc + 3 * n) - dX;
+      const V3 dcx = dcn - dX;
       // delta_s = beta (d.r + s d.(dc - dX)),  beta = w / h_ss (0 for a constant scale)
-      const double ds = qb[k] * (dot(d, r) + sk * dot(d, dcx));
+      const double ds = beta * (dot(d, r) + sk * dot(d, dcx));
       const V3 m = sk * dcx - ds * d;  // J delta (un-robustified)
       acc3[0] -= w * (dot(m, r) + 0.5 * dot(m, m));
       const double s_new = fmax(1e-5, sk + ds);  // SetParameterLowerBound(&scale, 0, 1e-5), gp.cc:373
@@ -928,6 +962,7 @@ struct GpWs {
   DevBuf<int> img_frame, foff, fimg, img_sensor, soff, simg;
   DevBuf<double> img_off, ci, cin, hcc_i, gc_i, gred_i, scc_i, zimg, wimg, ximg, zero_i, cz_f, img_rot;
   DevBuf<double> defl_w, defl_aw, defl_b2, defl_part, defl_small, defl_cd;  // CgDeflation, cg.hpp
+  DevBuf<double> maxpart;
   static void destroy(void* p) { delete static_cast<GpWs*>(p); }
 };
 
@@ -983,6 +1018,8 @@ class GpSolver final : public LmProblem {
       copy_in(ctx_, ws->cal.ensure(M_ + 1), prob->obs_calibrated, (size_t)M_, mem);
       d_cal = ws->cal.get();
     }
+    static const bool trace = std::getenv("GSFM_TRACE_SETUP") != nullptr;  // host-side phases of the setup on stderr
+    const double ts0 = now_seconds();
     long fixed_obs = -1;
     m_used_ = build_obs_graph(ctx_, ws->og, NI_, P_, M_, h_off, ws->off.get(), ws->cam.get(),
                               opt_.min_num_view_per_track /* gp.cc:258 */, g_.g, &fixed_obs);
@@ -1008,9 +1045,8 @@ class GpSolver final : public LmProblem {
     for (int k = 0; k < 3 * S_; ++k) h_c[3 * (size_t)N_ + k] = prob->sensor_center[k];  // host table by contract
     to_host(ctx_, h_X, pt_xyz, 3 * (size_t)P_, mem);
     GSFM_HIP_CHECK(hipStreamSynchronize(s));
-    std::mt19937 rng;
-    rng.seed(opt_.seed);
-    std::uniform_real_distribution<double> uni(-1.0, 1.0);
+    const double ts1 = now_seconds();
+    FastMt19937 rng(opt_.seed);  // std::mt19937 + std::uniform_real_distribution<double>(-1, 1), bit for bit (mt19937.hpp)
     // Track shards over several ranks draw EXACTLY the numbers the unsharded problem would: a camera is constrained when
     // any rank observes it, and a rank's point draws start where the lower ranks' used tracks end in the one global
     // std::mt19937 stream (two 32-bit outputs per double, libstdc++ generate_canonical).
@@ -1040,19 +1076,27 @@ class GpSolver final : public LmProblem {
     if (opt_.generate_random_positions && opt_.optimize_positions) {
       for (int n = 0; n < N_; ++n) {
         if (!constrained[n]) continue;
-        for (int j = 0; j < 3; ++j) h_c[3 * (size_t)n + j] = 100.0 * uni(rng);
+        rng.fill_uniform_pm1(&h_c[3 * (size_t)n], 3, 100.0);
       }
     }
     if (used_before > 0 && opt_.generate_random_points && opt_.optimize_points) rng.discard(6ull * (unsigned long long)used_before);
     if (opt_.generate_random_points && opt_.optimize_points) {
-      for (long p = 0; p < P_; ++p) {
-        if (h_off[p + 1] - h_off[p] < opt_.min_num_view_per_track) continue;
-        for (int j = 0; j < 3; ++j) h_X[3 * (size_t)p + j] = 100.0 * uni(rng);
+      for (long p = 0; p < P_;) {  // runs of consecutive used tracks are drawn in one call
+        if (h_off[p + 1] - h_off[p] < opt_.min_num_view_per_track) {
+          ++p;
+          continue;
+        }
+        long q = p + 1;
+        while (q < P_ && h_off[q + 1] - h_off[q] >= opt_.min_num_view_per_track) ++q;
+        rng.fill_uniform_pm1(&h_X[3 * (size_t)p], 3 * (size_t)(q - p), 100.0);
+        p = q;
       }
       if (used_after > 0) rng.discard(6ull * (unsigned long long)used_after);  // the higher ranks' tracks
     }
     // ParameterizeVariables, gp.cc:442-456: the centres to estimate start at RandVector3d(-1, 1), after every other draw
-    for (int k = 0; k < 3 * S_; ++k) h_c[3 * (size_t)N_ + k] = uni(rng);
+    for (int k = 0; k < 3 * S_; ++k) h_c[3 * (size_t)N_ + k] = rng.uniform_pm1();
+    const double ts2 = now_seconds();
+    if (trace) fprintf(stderr, "[gsfm gp setup] obs graph + copies %.2f ms, random start %.2f ms\n", (ts1 - ts0) * 1e3, (ts2 - ts1) * 1e3);
     GSFM_HIP_CHECK(hipMemcpyAsync(ws->c.ensure(3 * (size_t)Np_), h_c.data(), 3 * (size_t)Np_ * sizeof(double), hipMemcpyHostToDevice, s));
     GSFM_HIP_CHECK(hipMemcpyAsync(ws->X.ensure(3 * (size_t)P_ + 3), h_X.data(), 3 * (size_t)P_ * sizeof(double), hipMemcpyHostToDevice, s));
     GSFM_HIP_CHECK(hipStreamSynchronize(s));
@@ -1228,8 +1272,11 @@ class GpSolver final : public LmProblem {
       allreduce_sum(ctx_, ws->hcc.get(), Np_);
       allreduce_sum(ctx_, ws->gc.get(), 3 * (size_t)Np_);
     }
-    hipLaunchKernelGGL(k_gp_finalize_lin, dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridTileP_, ws->gc.get(),
-                       g_.opt_c ? 3 * Np_ : 0, ws->scal.get());
+    const int nvec = g_.opt_c ? 3 * Np_ : 0;
+    const int gmx = nvec ? std::min(64, grid_for((size_t)nvec, kBlock)) : 0;
+    if (gmx) hipLaunchKernelGGL(k_gp_absmax, dim3(gmx), dim3(kBlock), 0, s, (const double*)ws->gc.get(), nvec, ws->maxpart.ensure(64));
+    hipLaunchKernelGGL(k_gp_finalize_lin, dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridTileP_, (const double*)ws->maxpart.ensure(64), gmx,
+                       ws->scal.get());
     double h[2];
     read_scalars(ws->scal.get(), h, 2, /*sum_first=*/1, /*max_from=*/1);
     *grad_max_norm = h[1];

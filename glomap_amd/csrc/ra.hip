@@ -1423,6 +1423,8 @@ void setup_device(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
   std::vector<int>& pos = hi.pos;
   pos.clear();
   hi.mst_root = 0;
+  static const bool trace_setup = getenv("GSFM_TRACE_SETUP") != nullptr;
+  const double ts0 = now_seconds();
   if (d.blockdense) {  // relabel the nodes in BFS order for the whole solve: index-contiguous blocks become graph-local
     for (long e = 0; e < E; ++e)
       GSFM_REQUIRE(h_ei[e] >= 0 && h_ei[e] < N && h_ej[e] >= 0 && h_ej[e] < N, "RA: edge index out of range");
@@ -1454,10 +1456,15 @@ void setup_device(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
     d.fixed = pos[d.fixed];
     hi.mst_root = pos[0];
   }
+  const double ts1 = now_seconds();
   if (d.sub) {
     std::vector<int> h_rowptr, h_nbr;
     build_incidence(d, h_ei.data(), h_ej.data(), &h_rowptr, &h_nbr);
+    const double ts2 = now_seconds();
     sub_upload(d, h_rowptr, h_nbr);
+    if (trace_setup)
+      fprintf(stderr, "[gsfm ra setup] BFS + plan %.2f ms, incidence %.2f ms, coupling tables %.2f ms\n", (ts1 - ts0) * 1e3,
+              (ts2 - ts1) * 1e3, (now_seconds() - ts2) * 1e3);
   } else {
     build_incidence(d, h_ei.data(), h_ej.data());
   }
@@ -1556,8 +1563,10 @@ int ra_solve_impl(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
     if (d.dense) dense_factor(d); else bd_factor(d);
     l1w_ready = true;
   }
+  const double tf0 = now_seconds();
   finish_init(ctx, opt, d, hi);
   const double t1 = now_seconds();
+  if (getenv("GSFM_TRACE_SETUP")) fprintf(stderr, "[gsfm ra setup] total before init %.2f ms, spanning tree + upload %.2f ms\n", (tf0 - t0) * 1e3, (t1 - tf0) * 1e3);
   long lin_iters = 0;
   int it_l1 = 0, it_irls = 0;
   double last_step = 0.0;

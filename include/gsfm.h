@@ -137,6 +137,11 @@ int gsfm_comm_destroy(gsfm_ctx* ctx);
 /* One small RCCL all-reduce (sum of 1 + i over the ranks) on the ctx stream, checked: a cheap probe that communicator,
  * stream and device memory work together in this process (world_size 1 included).  *sum_out = world_size. */
 int gsfm_comm_selftest(gsfm_ctx* ctx, double* sum_out);
+/* Host-only self test of the generator behind global positioning's random start (global_positioning.cc:135,261,449:
+ * std::mt19937 + std::uniform_real_distribution<double>(-1, 1)): after skipping `skip` 32-bit outputs, `count` values
+ * scale * U(-1, 1) from the library's block generator into out_fast and from the C++ standard library into out_std.  The
+ * two must be bit-identical.  Needs no GPU. */
+int gsfm_selftest_mt19937(uint32_t seed, uint64_t skip, int64_t count, double scale, double* out_fast, double* out_std);
 /* Host-staged transport for validation only (several ranks sharing ONE device, or a box without
  * xGMI): every collective becomes D2H, fn(buf, n, op, user) — which must all-reduce buf in place
  * across the ranks (op 0 = sum, 1 = max) and return 0 — and H2D.  Same sharding semantics as the

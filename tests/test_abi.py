@@ -125,3 +125,18 @@ def test_python_option_defaults_match_the_library():
         assert want.keys() == got.keys()
         for k in want:
             assert want[k] == got[k], (ctype.__name__, k, want[k], got[k])
+
+
+def test_block_mt19937_reproduces_the_standard_library_stream(lib):
+    """Global positioning's random start (gp.cc:135,261,449: std::mt19937 + std::uniform_real_distribution<double>(-1, 1))
+    is drawn by a block generator (csrc/mt19937.hpp); host-only self test of the library: the two streams are bit-identical,
+    across state refills, odd phases and discards."""
+    import ctypes as C
+
+    import numpy as np
+
+    for seed, skip, count in ((1, 0, 5000), (1, 7, 4001), (12345, 623, 1300), (0, 6 * 1000003, 2000)):
+        a, b = np.empty(count), np.empty(count)
+        rc = lib.gsfm_selftest_mt19937(C.c_uint32(seed), C.c_uint64(skip), C.c_int64(count), C.c_double(100.0),
+                                       a.ctypes.data_as(C.POINTER(C.c_double)), b.ctypes.data_as(C.POINTER(C.c_double)))
+        assert rc == 0 and np.array_equal(a, b) and np.abs(a).max() <= 100.0 and a.std() > 50.0
