@@ -156,6 +156,10 @@ def run_extras(env, args, world, rank, main_line):
             ("ba_c4_shared_intrinsics", lambda: {k: v for k, v in bench_ba(**{**env, "args": sub(shared_intrinsics=True)}).items()
                                                  if k in keys}),
             ("gp_c3_skewed_visibility", lambda: {k: v for k, v in bench_gp(**{**env, "args": sub(zipf=0.8)}).items() if k in keys}),
+            # the same two solves on scenes with the locality of a walk-around capture (runs of consecutive cameras per
+            # point, tracks in capture order): what the camera-major gathers cost when co-visible points share cache lines
+            ("gp_c3_sequential_capture", lambda: {k: v for k, v in bench_gp(**{**env, "args": sub(capture="sequential")}).items() if k in keys}),
+            ("ba_c4_sequential_capture", lambda: {k: v for k, v in bench_ba(**{**env, "args": sub(capture="sequential")}).items() if k in keys}),
             ("ra_large", lambda: bench_ra_large(ctx)),
             ("ra_c3", lambda: bench_ra_sized(ctx, 5000, 50)),
             ("ra_c4_non_ring_graphs", lambda: bench_ra_nonring(ctx)),
@@ -777,10 +781,11 @@ def bench_gp(args, ctx, rank, world, barrier, dist):
     npts_rank = int(500_000 * args.scale)  # weak scaling: tracks per GPU fixed
     npts = npts_rank * world
     zipf = float(getattr(args, "zipf", 0.0))  # > 0: Zipf-distributed per-camera observation counts (skewed visibility)
+    capture = getattr(args, "capture", "random")
     if world == 1:
-        p = synthetic.make_gp_problem(ncam, npts, seed=0, zipf=zipf)
+        p = synthetic.make_gp_problem(ncam, npts, seed=0, zipf=zipf, capture=capture)
     else:  # every rank generates only its own shard (cameras identical everywhere)
-        p = synthetic.make_gp_problem(ncam, npts_rank, seed=0, shard=(rank, world), zipf=zipf)
+        p = synthetic.make_gp_problem(ncam, npts_rank, seed=0, shard=(rank, world), zipf=zipf, capture=capture)
     lo, hi = 0, p.num_pts
     o0, o1 = 0, p.num_obs
     M_total = p.num_obs
@@ -874,9 +879,10 @@ def bench_ba(args, ctx, rank, world, barrier, dist):
     npts = npts_rank * world
     shared = bool(getattr(args, "shared_intrinsics", False))  # configs[3] has both variants
     if world == 1:
-        p = synthetic.make_ba_problem(ncam, npts, seed=0, shared_intrinsics=shared)
+        p = synthetic.make_ba_problem(ncam, npts, seed=0, shared_intrinsics=shared, capture=getattr(args, "capture", "random"))
     else:  # every rank generates only its own shard (cameras / intrinsics / start identical everywhere)
-        p = synthetic.make_ba_problem(ncam, npts_rank, seed=0, shared_intrinsics=shared, shard=(rank, world))
+        p = synthetic.make_ba_problem(ncam, npts_rank, seed=0, shared_intrinsics=shared, shard=(rank, world),
+                                      capture=getattr(args, "capture", "random"))
     lo, hi = 0, p.num_pts
     o0, o1 = 0, p.num_obs
     M_total = p.num_obs

@@ -208,7 +208,7 @@ def _zipf_popularity(N, zipf, seed):
 
 
 def _sample_tracks(rng, centers, R_cw, X, mean_extra, min_len=3, max_len=100, half_fov_deg=30.0, ncand=None,
-                   chunk=65536, cam_popularity=None):
+                   chunk=65536, cam_popularity=None, sequential=False):
     """Pick, per point, L = min(min_len + Poisson(mean_extra), max_len) distinct cameras that see it
     inside the field of view.  Returns CSR (pt_offset, obs_cam) in track-major order; points that
     end up with fewer than ``min_len`` views keep what they have (the estimators skip them,
@@ -225,20 +225,30 @@ def _sample_tracks(rng, centers, R_cw, X, mean_extra, min_len=3, max_len=100, ha
         Pc = Xc.shape[0]
         L = np.minimum(min_len + rng.poisson(mean_extra, Pc), min(max_len, N))
         nc = ncand if ncand is not None else int(min(N, max(16, 3 * int(L.max()))))
-        if cam_popularity is None:
+        if sequential:
+            # sequential capture: a point is seen by a RUN of consecutive cameras (ring order) that starts at a random camera
+            # near the one whose optical axis passes closest — what a walk-around capture produces, instead of L random
+            # cameras among all that have the point in view
+            # (the ring lies in the x-z plane, camera i at azimuth 2 pi i / N: a point is nearest to the optical axes of
+            # the cameras at its own azimuth)
+            az = np.arctan2(Xc[:, 2], Xc[:, 0])
+            c0 = np.rint(az / (2 * np.pi) * N).astype(np.int64) + rng.integers(-nc // 2, 1, Pc)
+            cand = (c0[:, None] + np.arange(nc)[None, :]) % N
+        elif cam_popularity is None:
             cand = rng.integers(0, N, (Pc, nc))
         else:  # skewed visibility: candidates drawn with probability proportional to the camera's popularity
             cdf = np.cumsum(cam_popularity / cam_popularity.sum())
             cand = np.minimum(np.searchsorted(cdf, rng.random((Pc, nc))), N - 1)
-        cand.sort(axis=1)
+        if not sequential:
+            cand.sort(axis=1)
         dup = np.zeros_like(cand, dtype=bool)
         dup[:, 1:] = cand[:, 1:] == cand[:, :-1]
         d = Xc[:, None, :] - centers[cand]  # [Pc,nc,3]
         depth = np.einsum("pkj,pkj->pk", d, zaxis[cand])
         nrm = np.linalg.norm(d, axis=2)
         vis = (depth > cosfov * nrm) & ~dup
-        # random order among the visible candidates, invisible ones last
-        score = rng.random((Pc, nc)) + (~vis) * 10.0
+        # random order among the visible candidates (sequential: the run's own order), invisible ones last
+        score = (np.arange(nc)[None, :] / (nc + 1.0) if sequential else rng.random((Pc, nc))) + (~vis) * 10.0
         order = np.argsort(score, axis=1)
         cand = np.take_along_axis(cand, order, axis=1)
         vis = np.take_along_axis(vis, order, axis=1)
@@ -251,6 +261,21 @@ def _sample_tracks(rng, centers, R_cw, X, mean_extra, min_len=3, max_len=100, ha
     return pt_offset, obs_cam
 
 
+def _sort_tracks_by_first_camera(pt_offset, obs_cam, X):
+    """Track order of an incremental capture: tracks sorted by the first camera that sees them (stable).  Returns the
+    permuted CSR, points and the permutation."""
+    P = X.shape[0]
+    lens = np.diff(pt_offset)
+    first = np.full(P, np.iinfo(np.int32).max, dtype=np.int64)
+    has = lens > 0
+    first[has] = np.minimum.reduceat(obs_cam, pt_offset[:-1][has])
+    perm = np.argsort(first, kind="stable")
+    new_off = np.zeros(P + 1, dtype=np.int64)
+    np.cumsum(lens[perm], out=new_off[1:])
+    idx = np.repeat(pt_offset[:-1][perm] - new_off[:-1], lens[perm]) + np.arange(new_off[-1])  # the observation ranges, gathered
+    return new_off, obs_cam[idx], X[perm], perm
+
+
 def make_gp_problem(
     num_cams: int = 5000,
     num_pts: int = 500_000,
@@ -261,8 +286,12 @@ def make_gp_problem(
     seed: int = 0,
     shard=None,
     zipf: float = 0.0,
+    capture: str = "random",
 ) -> GpProblem:
     """C3-style global positioning problem (cameras on a radius-50 ring, points in a radius-30 ball).
+    capture = "sequential": every point is seen by a run of consecutive cameras and the tracks come in the order of the
+    first camera that sees them (a walk-around capture: co-visible points are neighbours in memory), instead of L random
+    cameras among the ~1/6 of the ring that has the point in view and tracks in random order.
 
     shard = (rank, world): generate only this rank's `num_pts` tracks of a `world * num_pts`-track
     problem — the cameras come from `seed` alone (identical on every rank), the points from a
@@ -273,7 +302,10 @@ def make_gp_problem(
         calibrated_all = (rng.random(num_cams) >= uncalibrated_ratio).astype(np.uint8)
         rng = np.random.default_rng([seed, 7919, int(shard[0])])
     X = _ball_points(rng, num_pts, 30.0)
-    pt_offset, obs_cam = _sample_tracks(rng, centers, R_cw, X, mean_extra, cam_popularity=_zipf_popularity(num_cams, zipf, seed))
+    pt_offset, obs_cam = _sample_tracks(rng, centers, R_cw, X, mean_extra, cam_popularity=_zipf_popularity(num_cams, zipf, seed),
+                                        sequential=capture == "sequential")
+    if capture == "sequential":
+        pt_offset, obs_cam, X, _ = _sort_tracks_by_first_camera(pt_offset, obs_cam, X)
     M = obs_cam.shape[0]
     obs_pt = np.repeat(np.arange(num_pts), np.diff(pt_offset))
     d = X[obs_pt] - centers[obs_cam]
@@ -327,9 +359,10 @@ def make_ba_problem(
     seed: int = 0,
     shard=None,
     zipf: float = 0.0,
+    capture: str = "random",
 ) -> BaProblem:
     """C4-style bundle-adjustment problem: SIMPLE_RADIAL (f=1200,cx=640,cy=480,k=0.02), state =
-    ground truth perturbed by rotation / position / depth noise.
+    ground truth perturbed by rotation / position / depth noise.  capture = "sequential": see make_gp_problem.
 
     shard = (rank, world): only this rank's `num_pts` tracks are generated; cameras, intrinsics and
     their perturbed start come from `seed` alone and are identical on every rank."""
@@ -343,7 +376,9 @@ def make_ba_problem(
         rng = np.random.default_rng([seed, 7919, int(shard[0])])
     X = _ball_points(rng, P, 30.0)
     pt_offset, obs_cam = _sample_tracks(rng, centers, R_cw, X, mean_extra, half_fov_deg=25.0,
-                                        cam_popularity=_zipf_popularity(N, zipf, seed))
+                                        cam_popularity=_zipf_popularity(N, zipf, seed), sequential=capture == "sequential")
+    if capture == "sequential":
+        pt_offset, obs_cam, X, _ = _sort_tracks_by_first_camera(pt_offset, obs_cam, X)
     M = obs_cam.shape[0]
     obs_pt = np.repeat(np.arange(P), np.diff(pt_offset))
     t_gt = -np.einsum("nij,nj->ni", R_cw, centers)
