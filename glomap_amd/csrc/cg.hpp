@@ -764,6 +764,14 @@ static __global__ void __launch_bounds__(kBlock) k_cg_delta_to_w(CgVec v) {
 }
 
 
+// Operator probes outside a solve (a solver applying A to vectors of its own, e.g. to build a coarse matrix): reset the status
+// block the apply kernels look at, and set v.probe = 1 on the host view while probing.
+static __global__ void k_cg_reset_status(CgVec v) {
+  v.st->done = 0;
+  v.st->iters = 0;
+  v.st->bad = 0;
+}
+
 // ---- deflation: setup kernels (once per solve) -------------------------------------------------------------------
 constexpr int kCgdBlocks = 128;                                   // grid of the Gram dot-product kernel
 constexpr int kCgdGram = kCgMaxModes * (kCgMaxModes + 1);         // k x (k + 1) products W_i . (A W_j | b)
@@ -923,9 +931,15 @@ static __global__ void __launch_bounds__(kBlock) k_cgd_finish(CgVec v, CgDeflati
 //   hint   optional, in/out: the iteration count of the previous solve of this sequence.  The host enqueues iterations
 //          ahead of the device and reads the status back first where the previous solve ended, then every third
 //          iteration — so a converged solve leaves a couple of early-exit launches behind instead of a chunk of them.
-template <int PB, bool HAS_INTR, typename Apply>
+struct CgNoPostZ {
+  void operator()(int) const {}
+};
+// post_z(par): optional hook enqueued after every kernel that produces a new z = M^-1 r (k_cg_init*: par = 0;
+// k_cg_update* of iteration it: par = (it + 1) & 1) — a second-level preconditioner adds its coarse correction to z (and to
+// the gather mirrors) there and rewrites the r.z partials of parity slot `par` (gp.hip: GpCoarse).
+template <int PB, bool HAS_INTR, typename Apply, typename PostZ = CgNoPostZ>
 inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& apply, const CgDeflation* defl = nullptr,
-                     int* hint = nullptr) {
+                     int* hint = nullptr, PostZ&& post_z = PostZ()) {
   hipStream_t s = ctx->stream;
   const bool multi = ctx->comm.world > 1;
   v.delta_in_w = multi ? 1 : 0;
@@ -983,6 +997,7 @@ inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& 
     v.dcd = defl->cd;
   }
   init();
+  post_z(0);
   CgStatus* h = reinterpret_cast<CgStatus*>(ctx->h_pinned + 400);
   long iters = max_iter;
   // convergence after p iterations is noticed by the first kernel of apply(p): read back after p + 1 enqueued iterations
@@ -996,6 +1011,7 @@ inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& 
       if (v.single) hipLaunchKernelGGL((k_cg_update1<PB>), dim3(1), dim3(kCgSingleThreads), 0, s, v, it);
     }
     if (!joint && !v.single) hipLaunchKernelGGL((k_cg_update<PB, HAS_INTR>), dim3(v.nb_update), dim3(kBlock), 0, s, v, it);
+    post_z((it + 1) & 1);
     if (it + 1 >= next_poll || it == max_iter - 1) {
       GSFM_HIP_CHECK(hipMemcpyAsync(h, v.st, sizeof(CgStatus), hipMemcpyDeviceToHost, s));
       GSFM_HIP_CHECK(hipStreamSynchronize(s));

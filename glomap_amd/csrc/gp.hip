@@ -40,6 +40,7 @@
 #include "lm.hpp"
 #include "mt19937.hpp"
 #include "obsgraph.hpp"
+#include "ra_dense.hpp"  // the batched symmetric block sweep (k_gj_*) inverts the coarse matrix
 
 namespace gsfm {
 namespace {
@@ -462,6 +463,196 @@ __global__ void __launch_bounds__(kBlock)
     const V3 t = mul(S3{b[0], b[1], b[2], b[3], b[4], b[5]}, V3{acc[0], acc[1], acc[2]});
     st3(ptrec + 8 * (long)key + 3, t);
   }
+}
+
+// ---- second-level preconditioner for scenes with chain-like co-visibility ----------------------------------------------
+// The random-visibility benchmark scenes give a reduced camera system whose block-Jacobi-preconditioned spectrum is tight
+// apart from the global gauge.  Scenes with the locality of a real capture do not: a point is seen by a run
+// of neighbouring cameras, the system is a long chain, and block-Jacobi PCG needs hundreds of iterations per solve (bench
+// extra gp_c3_sequential_capture: 9 491 instead of 507 applications; CPU study tools/exp_coarse_space.py).  The remedy is a
+// two-level ADDITIVE preconditioner with a piecewise coarse space (Nicolaides):
+//     M^-1 = blockdiag(S_nn)^-1 + W E^-1 W^T,     E = W^T A W,
+// W = per cluster of m consecutive cameras the three translations and the local scale (c_n - mean of the cluster): the
+// per-cluster copy of the gauge that the chain transmits so slowly.  Additive, not deflated: E only shapes the
+// preconditioner, so it may be approximate without touching the solution — and it is, because it is PROBED: A is applied to
+// the sum of one mode type over every third cluster (12 applications per LM step) and each cluster reads its neighbours'
+// columns off the result, which is exact as long as no point is seen from two clusters that are not neighbours.
+// E (4 nc x 4 nc) is inverted by the symmetric block sweep of ra_dense.hpp.  Per PCG iteration three small kernels after
+// k_cg_update: c = W^T r per cluster, y = E^-1 c, z += W y (vector, (c | z) gather records, r.z partials).
+// Cameras are clustered by INDEX: frames are expected in capture order (a graph ordering of the cameras is the missing
+// generalisation).  Switched on by GpSolver::pcg when a solve needs more than kCoarseTrigger iterations.
+struct GpCoarseDev {
+  int N = 0, m = 0, nc = 0, k = 0, kp = 0;
+  const double* c = nullptr;     // [N][3] camera centres of this LM step
+  const double* cbar = nullptr;  // [nc][3] cluster means
+};
+constexpr int kCoarseTrigger = 60;    // iterations of a reduced solve beyond which the coarse space is switched on
+constexpr int kCoarseMaxModes = 4096;
+
+// Probe colour of cluster q: q % 3, except that the last nc % 3 clusters get colours of their own — the clusters are treated
+// as a RING (cluster nc-1 next to cluster 0: loop closures, and harmless for an open chain), and a ring of nc clusters can be
+// 3-coloured with same-coloured clusters three apart only when 3 divides nc.
+__host__ __device__ __forceinline__ int gpc_colour(int q, int nc) {
+  const int r = nc % 3;
+  return q < nc - r ? q % 3 : 3 + (q - (nc - r));
+}
+__device__ __forceinline__ void gpc_cluster(const GpCoarseDev& cs, int q, int& n0, int& n1) {
+  // balanced: N cameras over nc clusters, sizes differ by at most one (a short last cluster would make its two
+  // neighbours, which may share a colour, effectively adjacent)
+  n0 = (int)((long)q * cs.N / cs.nc);
+  n1 = (int)((long)(q + 1) * cs.N / cs.nc);
+}
+__device__ __forceinline__ int gpc_cluster_of(const GpCoarseDev& cs, int n) {
+  int q = (int)(((long)n * cs.nc) / cs.N);
+  while ((long)q * cs.N / cs.nc > n) --q;
+  while ((long)(q + 1) * cs.N / cs.nc <= n) ++q;
+  return q;
+}
+// cbar[q] = mean centre of cluster q (one wave per cluster)
+__global__ void __launch_bounds__(64) k_gpc_means(GpCoarseDev cs, double* __restrict__ cbar) {
+  const int q = blockIdx.x, lane = threadIdx.x;
+  int n0, n1;
+  gpc_cluster(cs, q, n0, n1);
+  double a[3] = {0, 0, 0};
+  for (int n = n0 + lane; n < n1; n += 64) {
+    a[0] += cs.c[3 * (long)n];
+    a[1] += cs.c[3 * (long)n + 1];
+    a[2] += cs.c[3 * (long)n + 2];
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) a[j] = wave_sum(a[j]);
+  if (lane == 0) {
+    const double inv = 1.0 / (double)(n1 - n0);
+    cbar[3 * q] = a[0] * inv;
+    cbar[3 * q + 1] = a[1] * inv;
+    cbar[3 * q + 2] = a[2] * inv;
+  }
+}
+// column t of B_n = [I_3 | c_n - cbar_q]
+__device__ __forceinline__ V3 gpc_mode(const GpCoarseDev& cs, int n, int q, int t) {
+  if (t < 3) return V3{t == 0 ? 1.0 : 0.0, t == 1 ? 1.0 : 0.0, t == 2 ? 1.0 : 0.0};
+  return ld3(cs.c + 3 * (long)n) - ld3(cs.cbar + 3 * (long)q);
+}
+// probe input: z := sum over the clusters of colour col of mode type t (vector and gather records)
+__global__ void __launch_bounds__(kBlock) k_gpc_set_z(CgVec v, GpCoarseDev cs, int col, int t) {
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < cs.N; n += gridDim.x * blockDim.x) {
+    const int q = gpc_cluster_of(cs, n);
+    V3 z{0, 0, 0};
+    if (gpc_colour(q, cs.nc) == col) z = gpc_mode(cs, n, q, t);
+    st3(v.z + 3 * (long)n, z);
+    if (v.zmir) st3(v.zmir + (long)n * v.zmir_stride + v.zmir_off, z);
+  }
+}
+// probe output: with w = A (sum of the type-t modes of the clusters of colour col), cluster qq (one wave) writes
+// E[4 qq + t'][4 q + t] = sum_{n in qq} B_n[:, t'] . w_n for the cluster q of that colour among its (cyclic) neighbours
+// {qq-1, qq, qq+1}
+__global__ void __launch_bounds__(64)
+    k_gpc_probe_E(CgVec v, GpCoarseDev cs, int col, int t, double* __restrict__ E) {
+  const int qq = blockIdx.x, lane = threadIdx.x;
+  int q = -1;
+  for (int d = -1; d <= 1; ++d) {
+    const int c = (qq + d + cs.nc) % cs.nc;
+    if (gpc_colour(c, cs.nc) == col) q = c;
+  }
+  if (q < 0) return;
+  int n0, n1;
+  gpc_cluster(cs, qq, n0, n1);
+  double a[4] = {0, 0, 0, 0};
+  for (int n = n0 + lane; n < n1; n += 64) {
+    const V3 w = ld3(v.w + 3 * (long)n);
+    const V3 dc = gpc_mode(cs, n, qq, 3);
+    a[0] += w.x;
+    a[1] += w.y;
+    a[2] += w.z;
+    a[3] += dot(dc, w);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) a[j] = wave_sum(a[j]);
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) E[(size_t)(4 * qq + j) * cs.kp + 4 * q + t] = a[j];
+  }
+}
+// symmetrise E in place, identity on the padding
+__global__ void __launch_bounds__(kBlock) k_gpc_finish_E(GpCoarseDev cs, double* __restrict__ E) {
+  const size_t nn = (size_t)cs.kp * cs.kp;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cs.kp), c = (int)(i % cs.kp);
+    if (r < c) continue;
+    double vlo, vup;
+    if (r >= cs.k) {
+      vlo = vup = r == c ? 1.0 : 0.0;
+    } else {
+      vlo = vup = 0.5 * (E[(size_t)r * cs.kp + c] + E[(size_t)c * cs.kp + r]);
+      // the cluster modes add up to the global gauge, which at a wide trust region has (almost) nothing behind it: a
+      // relative 1e-9 on the diagonal keeps the unpivoted sweep away from pivots of rounding size (E only shapes the
+      // preconditioner)
+      if (r == c) vlo = vup = vlo * (1.0 + 1e-9);
+    }
+    E[(size_t)r * cs.kp + c] = vlo;
+    E[(size_t)c * cs.kp + r] = vup;
+  }
+}
+// flag[0] = 1 when the inverse has a non-positive or non-finite diagonal entry (E was not positive definite)
+__global__ void __launch_bounds__(kBlock) k_gpc_check(GpCoarseDev cs, const double* __restrict__ Einv, int* __restrict__ flag) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cs.k; i += gridDim.x * blockDim.x) {
+    const double d = Einv[(size_t)i * cs.kp + i];
+    if (!(d > 0.0) || !isfinite(d)) atomicOr(flag, 1);
+  }
+}
+// c[4 q + t'] = sum_{n in q} B_n[:, t'] . r_n   (one wave per cluster)
+__global__ void __launch_bounds__(64) k_gpc_rsum(CgVec v, GpCoarseDev cs, double* __restrict__ cvec) {
+  if (v.st->done) return;
+  const int q = blockIdx.x, lane = threadIdx.x;
+  int n0, n1;
+  gpc_cluster(cs, q, n0, n1);
+  double a[4] = {0, 0, 0, 0};
+  for (int n = n0 + lane; n < n1; n += 64) {
+    const V3 r = ld3(v.r + 3 * (long)n);
+    const V3 dc = gpc_mode(cs, n, q, 3);
+    a[0] += r.x;
+    a[1] += r.y;
+    a[2] += r.z;
+    a[3] += dot(dc, r);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) a[j] = wave_sum(a[j]);
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cvec[4 * q + j] = a[j];
+  }
+}
+// y = E^-1 c   (one wave per row)
+__global__ void __launch_bounds__(kBlock)
+    k_gpc_solve(CgVec v, GpCoarseDev cs, const double* __restrict__ Einv, const double* __restrict__ cvec, double* __restrict__ y) {
+  if (v.st->done) return;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (row >= cs.k) return;
+  double a = 0.0;
+  for (int j = lane; j < cs.k; j += 64) a += Einv[(size_t)row * cs.kp + j] * cvec[j];
+  a = wave_sum(a);
+  if (lane == 0) y[row] = a;
+}
+// z_n += B_n y_q(n) (vector and gather records); the r.z partials of parity slot `par` are rewritten
+__global__ void __launch_bounds__(kBlock) k_gpc_correct(CgVec v, GpCoarseDev cs, const double* __restrict__ y, int par) {
+  __shared__ double smem[4];
+  if (v.st->done) return;
+  double acc[1] = {0.0};
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < cs.N; n += gridDim.x * blockDim.x) {
+    const int q = gpc_cluster_of(cs, n);
+    const V3 dc = gpc_mode(cs, n, q, 3);
+    const double s = y[4 * q + 3];
+    V3 z = ld3(v.z + 3 * (long)n);
+    z.x += y[4 * q] + s * dc.x;
+    z.y += y[4 * q + 1] + s * dc.y;
+    z.z += y[4 * q + 2] + s * dc.z;
+    st3(v.z + 3 * (long)n, z);
+    if (v.zmir) st3(v.zmir + (long)n * v.zmir_stride + v.zmir_off, z);
+    acc[0] += dot(ld3(v.r + 3 * (long)n), z);
+  }
+  block_sum<1>(acc, smem);
+  if (threadIdx.x == 0) v.vpart[((size_t)par * kCgMaxBlocks + blockIdx.x) * 2] = acc[0];
 }
 
 // The four gauge modes of global positioning in the unknowns of the reduced system (deflated from the PCG, cg.hpp):
@@ -963,6 +1154,8 @@ struct GpWs {
   DevBuf<double> img_off, ci, cin, hcc_i, gc_i, gred_i, scc_i, zimg, wimg, ximg, zero_i, cz_f, img_rot;
   DevBuf<double> defl_w, defl_aw, defl_b2, defl_part, defl_small, defl_cd;  // CgDeflation, cg.hpp
   DevBuf<double> maxpart;
+  DevBuf<double> cs_cbar, cs_E, cs_E2, cs_pinv, cs_c, cs_y;  // second-level preconditioner (GpCoarse*)
+  DevBuf<int> cs_flag;
   static void destroy(void* p) { delete static_cast<GpWs*>(p); }
 };
 
@@ -1396,38 +1589,98 @@ class GpSolver final : public LmProblem {
     std::memcpy(out, ctx_->h_pinned + 300, n * sizeof(double));
   }
 
+  // Coarse matrix of this LM step: cluster means, 12 - 20 operator probes (3 - 5 colours x 4 mode types), symmetric block sweep.
+  // Returns false (the solve then runs without the second level) when E turns out not to be positive definite.
+  template <typename Apply>
+  bool coarse_setup(GpCoarseDev& cs, Apply& apply) {
+    GpWs* ws = ws_;
+    hipStream_t s = ctx_->stream;
+    static const int m_env = std::getenv("GSFM_GP_COARSE_M") ? std::atoi(std::getenv("GSFM_GP_COARSE_M")) : 0;  // A/B: cluster size
+    cs.N = N_;
+    cs.m = std::max((m_env > 0 ? m_env : 32) << coarse_grow_, (4 * N_ + kCoarseMaxModes - 1) / kCoarseMaxModes);
+    cs.nc = (N_ + cs.m - 1) / cs.m;
+    cs.k = 4 * cs.nc;
+    cs.kp = ((cs.k + kTile - 1) / kTile) * kTile;
+    if (cs.nc < 6) return false;
+    cs.c = ci_;
+    double* cbar = ws->cs_cbar.ensure(3 * (size_t)cs.nc);
+    cs.cbar = cbar;
+    const size_t nn = (size_t)cs.kp * cs.kp;
+    double* E = ws->cs_E.ensure(nn);
+    double* E2 = ws->cs_E2.ensure(nn);
+    double* pinv = ws->cs_pinv.ensure(2 * kTile * kTile);
+    int* flag = ws->cs_flag.ensure(4);
+    ws->cs_c.ensure(cs.kp);
+    ws->cs_y.ensure(cs.kp);
+    hipLaunchKernelGGL(k_gpc_means, dim3(cs.nc), dim3(64), 0, s, cs, cbar);
+    GSFM_HIP_CHECK(hipMemsetAsync(E, 0, nn * sizeof(double), s));
+    GSFM_HIP_CHECK(hipMemsetAsync(flag, 0, 4 * sizeof(int), s));
+    hipLaunchKernelGGL(k_cg_reset_status, dim3(1), dim3(1), 0, s, cg_);
+    cg_.probe = 1;
+    cg_.delta_in_w = 0;
+    coarse_probes_ = 4 * (3 + cs.nc % 3);
+    for (int col = 0; col < 3 + cs.nc % 3; ++col)
+      for (int t = 0; t < 4; ++t) {
+        hipLaunchKernelGGL(k_gpc_set_z, dim3(gridN_), dim3(kBlock), 0, s, cg_, cs, col, t);
+        apply(0);
+        if (ctx_->comm.world > 1) allreduce_sum(ctx_, cg_.w, 3 * (size_t)N_);
+        hipLaunchKernelGGL(k_gpc_probe_E, dim3(cs.nc), dim3(64), 0, s, cg_, cs, col, t, E);
+      }
+    cg_.probe = 0;
+    hipLaunchKernelGGL(k_gpc_finish_E, dim3(grid_wide(nn, kBlock, 1 << 12)), dim3(kBlock), 0, s, cs, E);
+    const int T = cs.kp / kTile;
+    double *cur = E, *oth = E2;
+    hipLaunchKernelGGL(k_gj_pivot0, dim3(1), dim3(kBlock), 0, s, (const double*)cur, cs.kp, (size_t)0, pinv);
+    for (int k = 0; k < T; ++k) {
+      hipLaunchKernelGGL(k_gj_sweep_step, dim3(gj_tiles(T)), dim3(kBlock), 0, s, (const double*)cur, oth, cs.kp, (size_t)0,
+                         (const int*)nullptr, T, k, pinv);
+      std::swap(cur, oth);
+    }
+    hipLaunchKernelGGL(k_gj_finish_full, dim3(grid_wide(nn, kBlock, 1 << 12)), dim3(kBlock), 0, s, cur, cs.kp, cs.kp);
+    hipLaunchKernelGGL(k_gpc_check, dim3(grid_for((size_t)cs.k, kBlock)), dim3(kBlock), 0, s, cs, (const double*)cur, flag);
+    int* h = reinterpret_cast<int*>(ctx_->h_pinned + 520);
+    GSFM_HIP_CHECK(hipMemcpyAsync(h, flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    GSFM_HIP_CHECK(hipStreamSynchronize(s));
+    cs_einv_ = cur;
+    static const bool verbose = std::getenv("GSFM_VERBOSE") != nullptr;
+    if (h[0] != 0) {  // not positive definite (probing contaminated by long-range tracks, or a degenerate step): plain solves
+      // tracks longer than a cluster put products of second neighbours into the same probe: twice the cluster size, twice,
+      // before giving up
+      if (verbose)
+        fprintf(stderr, "[gsfm gp] second-level preconditioner (%d clusters of %d cameras): E not positive definite, %s\n", cs.nc, cs.m,
+                coarse_grow_ < 2 ? "clusters doubled" : "switched off");
+      if (coarse_grow_ < 2) {
+        ++coarse_grow_;
+        coarse_said_ = false;
+        return coarse_setup(cs, apply);
+      }
+      coarse_ok_ = false;
+      coarse_on_ = false;
+      return false;
+    }
+    if (verbose && !coarse_said_) {
+      fprintf(stderr, "[gsfm gp] second-level preconditioner on: %d clusters of %d cameras, %d modes, %d probes per LM step\n", cs.nc,
+              cs.m, cs.k, coarse_probes_);
+      coarse_said_ = true;
+    }
+    return true;
+  }
+  // z += W E^-1 W^T r  after k_cg_init / k_cg_update (cg_solve's post_z hook)
+  void coarse_correct(const GpCoarseDev& cs, int par) {
+    GpWs* ws = ws_;
+    hipStream_t s = ctx_->stream;
+    hipLaunchKernelGGL(k_gpc_rsum, dim3(cs.nc), dim3(64), 0, s, cg_, cs, ws->cs_c.get());
+    hipLaunchKernelGGL(k_gpc_solve, dim3(grid_for((size_t)cs.k, kBlock / 64)), dim3(kBlock), 0, s, cg_, cs, (const double*)cs_einv_,
+                       (const double*)ws->cs_c.get(), ws->cs_y.get());
+    hipLaunchKernelGGL(k_gpc_correct, dim3(cg_.nb_update), dim3(kBlock), 0, s, cg_, cs, (const double*)ws->cs_y.get(), par);
+  }
+
   long pcg() {
     GpWs* ws = ws_;
     hipStream_t s = ctx_->stream;
     const double yscale = ctx_->comm.rank == 0 ? 1.0 : 0.0;
     const double tol = opt_.lm.pcg_relative_tolerance;
-    // the gauge modes deflated from the PCG (CgDeflation, cg.hpp): trivial rigs, positions among the unknowns; skipped
-    // while the solves are short anyway (defl_on_, below)
-    CgDeflation defl;
-    if (!rig_ && g_.opt_c && defl_on_ && N_ > kCgSingleMaxBlocks) {
-      const size_t n3 = 3 * (size_t)N_;
-      defl.k = 4;
-      double* W = ws->defl_w.ensure(4 * n3);
-      defl.AW = ws->defl_aw.ensure(4 * n3);
-      defl.b2 = ws->defl_b2.ensure(n3);
-      defl.part = ws->defl_part.ensure((size_t)kCgdBlocks * kCgdGram);
-      defl.small = ws->defl_small.ensure(80);
-      defl.cd = ws->defl_cd.ensure((size_t)2 * kCgMaxBlocks * 2 * kCgMaxModes);
-      hipLaunchKernelGGL(k_gp_defl_modes, dim3(gridN_), dim3(kBlock), 0, s, N_, (const double*)ci_, W);
-      defl.W = W;
-      if (g_.opt_x) {  // A W of all four modes in one camera-major sweep (k_gp_aw_modes): no operator application
-        hipLaunchKernelGGL(k_gp_aw_modes, dim3(gridCam_), dim3(kBlock), 0, s, g_, yscale, (const double*)ci_,
-                           (const double*)ws->c_qa.get(), (const double*)ws->c_qb.get(), (const double*)ws->ptb.get(),
-                           (const double*)ws->dcam.get(), defl.AW, (long)n3);
-        if (gridMulti_)
-          hipLaunchKernelGGL(k_gp_aw_modes, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, yscale, (const double*)ci_,
-                             (const double*)ws->c_qa.get(), (const double*)ws->c_qb.get(), (const double*)ws->ptb.get(),
-                             (const double*)ws->dcam.get(), defl.AW, (long)n3);
-        if (ctx_->comm.world > 1) allreduce_sum(ctx_, defl.AW, 4 * n3);
-        defl.aw_ready = 4;
-      }
-    }
-    const long iters = cg_solve<3, false>(ctx_, cg_, tol, opt_.lm.pcg_max_iterations, [&](int it) {
+    auto apply = [&](int it) {
       if (rig_)  // z of an image = z of its frame: into the per-image vector and the (c | z) gather records
         hipLaunchKernelGGL(k_rig_expand3, dim3(gridNI_), dim3(kBlock), 0, s, rg_, cg_.z, (const double*)nullptr,
                            ws->zimg.get(), ws->cz.get(), 3);
@@ -1453,7 +1706,50 @@ class GpSolver final : public LmProblem {
       if (rig_)
         hipLaunchKernelGGL(k_rig_reduce_w, dim3(gridN_ + S_), dim3(kBlock), 0, s, cg_, rg_, yscale, ws->wimg.get(), ws->dcam.get(),
                            gridCam_ + gridMulti_, gridN_);
-    }, defl.k ? &defl : nullptr, &pcg_hint_);
+    };
+    // second level for chain-like scenes (GpCoarseDev): replaces the deflation of the four global modes, which its coarse
+    // space contains
+    GpCoarseDev cs;
+    const bool coarse = coarse_on_ && !rig_ && g_.opt_c && N_ > kCgSingleMaxBlocks && coarse_setup(cs, apply);
+    // the gauge modes deflated from the PCG (CgDeflation, cg.hpp): trivial rigs, positions among the unknowns; skipped
+    // while the solves are short anyway (defl_on_, below)
+    CgDeflation defl;
+    if (!coarse && !rig_ && g_.opt_c && defl_on_ && N_ > kCgSingleMaxBlocks) {
+      const size_t n3 = 3 * (size_t)N_;
+      defl.k = 4;
+      double* W = ws->defl_w.ensure(4 * n3);
+      defl.AW = ws->defl_aw.ensure(4 * n3);
+      defl.b2 = ws->defl_b2.ensure(n3);
+      defl.part = ws->defl_part.ensure((size_t)kCgdBlocks * kCgdGram);
+      defl.small = ws->defl_small.ensure(80);
+      defl.cd = ws->defl_cd.ensure((size_t)2 * kCgMaxBlocks * 2 * kCgMaxModes);
+      hipLaunchKernelGGL(k_gp_defl_modes, dim3(gridN_), dim3(kBlock), 0, s, N_, (const double*)ci_, W);
+      defl.W = W;
+      if (g_.opt_x) {  // A W of all four modes in one camera-major sweep (k_gp_aw_modes): no operator application
+        hipLaunchKernelGGL(k_gp_aw_modes, dim3(gridCam_), dim3(kBlock), 0, s, g_, yscale, (const double*)ci_,
+                           (const double*)ws->c_qa.get(), (const double*)ws->c_qb.get(), (const double*)ws->ptb.get(),
+                           (const double*)ws->dcam.get(), defl.AW, (long)n3);
+        if (gridMulti_)
+          hipLaunchKernelGGL(k_gp_aw_modes, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, yscale, (const double*)ci_,
+                             (const double*)ws->c_qa.get(), (const double*)ws->c_qb.get(), (const double*)ws->ptb.get(),
+                             (const double*)ws->dcam.get(), defl.AW, (long)n3);
+        if (ctx_->comm.world > 1) allreduce_sum(ctx_, defl.AW, 4 * n3);
+        defl.aw_ready = 4;
+      }
+    }
+    // chain-like co-visibility shows as a solve that is still running after kCoarseTrigger iterations: it is abandoned there,
+    // and this and the later solves of the LM problem get the second-level preconditioner (GpCoarseDev)
+    const bool may_switch = !coarse && coarse_ok_ && !coarse_on_ && !rig_ && g_.opt_c && N_ > kCgSingleMaxBlocks &&
+                            opt_.lm.pcg_max_iterations > kCoarseTrigger;
+    const long iters0 = cg_solve<3, false>(ctx_, cg_, tol, may_switch ? kCoarseTrigger : opt_.lm.pcg_max_iterations, apply,
+                                           defl.k ? &defl : nullptr, &pcg_hint_, [&](int par) {
+                                             if (coarse) coarse_correct(cs, par);
+                                           });
+    if (may_switch && iters0 >= kCoarseTrigger) {
+      coarse_on_ = true;
+      return iters0 + pcg();
+    }
+    const long iters = iters0 + (coarse ? coarse_probes_ : 0);  // + the operator applications that probed the coarse matrix
     // deflation pays while a plain solve needs more than ~3 k iterations (iters includes the k applications for A W)
     // (with the closed-form mode products the price of A W is one camera-major sweep — say one application — instead of four)
     const int napp = defl.k - defl.aw_ready, cost = g_.opt_x ? 1 : 4;
@@ -1476,6 +1772,11 @@ class GpSolver final : public LmProblem {
   long P_ = 0, M_ = 0, m_used_ = 0;
   int gridP_ = 1, gridN_ = 1, gridM_ = 1, gridCam_ = 1, gridMulti_ = 0, gridTile_ = 1, gridTileP_ = 1;
   bool defl_on_ = true;  // deflate the next reduced solve (short solves run plain)
+  bool coarse_on_ = false, coarse_ok_ = true;  // second-level preconditioner (GpCoarseDev): on after a long solve; ok until E fails
+  double* cs_einv_ = nullptr;
+  int coarse_probes_ = 12;
+  bool coarse_said_ = false;
+  int coarse_grow_ = 0;
   int pcg_hint_ = 0;     // iteration count of the previous reduced solve (where cg_solve first reads the status back)
   int gridTileA_ = 1;    // k_gp_phaseA: exactly one wave per tile
   double *c_ = nullptr, *cn_ = nullptr, *X_ = nullptr, *Xn_ = nullptr, *s_ = nullptr, *sn_ = nullptr;
