@@ -124,17 +124,47 @@ def main():
 
 
 def comm_init(ctx, dist, rank, world):
-    """RCCL communicator of libgsfm (one rank per GPU): rank 0 creates the unique id, gloo carries it."""
+    """Transport of the sharded solves (one rank per GPU).  Default: the peer-mailbox all-reduce of libgsfm (csrc/peer.hpp; gloo
+    carries the memory handles), checked by its collective self test on every rank; if any rank fails to map a peer or the
+    self test fails, all ranks fall back to an RCCL communicator (rank 0 creates the unique id).  GSFM_BENCH_TRANSPORT =
+    peer | rccl | host (host = the validation transport, never the measured configuration) overrides."""
     if world <= 1 or getattr(ctx, "_comm_ready", False):
         return
+    import torch
+
     from glomap_amd import _lib, sharding
 
-    if os.environ.get("GSFM_BENCH_HOST_COMM"):  # validation transport, never the measured configuration
+    want = os.environ.get("GSFM_BENCH_TRANSPORT", "host" if os.environ.get("GSFM_BENCH_HOST_COMM") else "peer")
+    ctx._transport = None
+    if want == "host":
         ctx.comm_init_host(sharding.host_allreduce(dist), rank, world)
-    else:
+        ctx._transport = "host-staged"
+    if want == "peer":
+        ok = 1
+        try:
+            os.environ.setdefault("GSFM_PEER_TIMEOUT_S", "20")
+
+            def allgather(b):
+                out = [None] * world
+                dist.all_gather_object(out, b)
+                return out
+
+            ctx.comm_init_peer(allgather, rank, world, 1 << 18)
+            ctx.comm_peer_selftest()
+        except Exception as e:  # noqa: BLE001 (any failure means: not this transport)
+            print(f"[bench] rank {rank}: peer transport unavailable ({e}); RCCL instead", file=sys.stderr)
+            ok = 0
+        t = torch.tensor([ok])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t.item()) == 1:
+            ctx._transport = "peer mailboxes (one-shot all-reduce)"
+        else:
+            ctx.comm_destroy()
+    if ctx._transport is None:
         uid = [_lib.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(uid[0], rank, world)
+        ctx._transport = "RCCL"
     ctx._comm_ready = True
 
 
@@ -395,8 +425,8 @@ def bench_pipeline(args, ctx, rank, world, barrier, dist):
         "observations, random start) + BA (%d tracks / %d observations, one SIMPLE_RADIAL camera per image, start = GT + "
         "noise), reference default options; inputs per SURVEY.md section 8d" % (E, npts, M_gp, npts, M_ba),
         "cameras": ncam, "edges": E, "tracks": npts, "observations_gp": M_gp, "observations_ba": M_ba,
-        "parallelism": "single GPU" if world == 1 else f"strong scaling: GP/BA track-shard x{world} (RCCL all-reduce per PCG iteration), RA replicated",
-        "rccl_ranks": world,
+        "parallelism": "single GPU" if world == 1 else f"strong scaling: GP/BA track-shard x{world} (one all-reduce per PCG iteration), RA replicated",
+        "rccl_ranks": world, "transport": getattr(ctx, "_transport", None),
         "ms_per_stage_median": med,
         "ms_per_step_each": timed["total"],
         "iterations": {"ra_l1": rep["ra"]["iterations_l1"], "ra_irls": rep["ra"]["iterations_irls"],

@@ -302,6 +302,16 @@ def load():
     lib.gsfm_comm_destroy.argtypes = [vp]
     lib.gsfm_comm_init_host.restype = ip
     lib.gsfm_comm_init_host.argtypes = [vp, HOST_ALLREDUCE_FN, vp, ip, ip]
+    lib.gsfm_ctx_last_error.restype = C.c_char_p
+    lib.gsfm_ctx_last_error.argtypes = [vp]
+    lib.gsfm_comm_peer_open.restype = ip
+    lib.gsfm_comm_peer_open.argtypes = [vp, ip, ip, C.c_int64, C.c_char_p]
+    lib.gsfm_comm_peer_connect.restype = ip
+    lib.gsfm_comm_peer_connect.argtypes = [vp, C.c_char_p]
+    lib.gsfm_comm_allreduce_bench.restype = ip
+    lib.gsfm_comm_allreduce_bench.argtypes = [vp, C.c_int64, ip, dp]
+    lib.gsfm_comm_peer_selftest.restype = ip
+    lib.gsfm_comm_peer_selftest.argtypes = [vp, dp]
     lib.gsfm_ra_options_default.restype = None
     lib.gsfm_ra_options_default.argtypes = [C.POINTER(RaOptions)]
     lib.gsfm_ra_solve.restype = ip
@@ -483,6 +493,16 @@ class Context:
             raise GsfmError(rc, "gsfm_ctx_profile_read")
         return n.value, ms.value
 
+    def comm_destroy(self):
+        """Detach whatever transport is attached (collective in effect: every rank must be done with its solves)."""
+        rc = self.lib.gsfm_comm_destroy(self.handle)
+        if rc != 0:
+            raise GsfmError(rc, "gsfm_comm_destroy")
+        self.rank, self.world = 0, 1
+
+    def last_error(self) -> str:
+        return (self.lib.gsfm_ctx_last_error(self.handle) or b"").decode(errors="replace")
+
     def comm_init(self, unique_id: bytes, rank: int, world: int):
         rc = self.lib.gsfm_comm_init(self.handle, unique_id, rank, world)
         if rc != 0:
@@ -519,6 +539,46 @@ def _comm_init_host(self, allreduce, rank: int, world: int):
 
 
 Context.comm_init_host = _comm_init_host
+
+GSFM_PEER_HANDLE_BYTES = 64
+
+
+def _comm_init_peer(self, allgather, rank: int, world: int, capacity_doubles: int = 1 << 18):
+    """Peer-mailbox transport (gsfm_comm_peer_*): `allgather(bytes) -> list of the bytes of every rank, in rank order`
+    carries the 64-byte memory handles (e.g. torch.distributed.all_gather_object on gloo).  At most 8 ranks of one node."""
+    buf = C.create_string_buffer(GSFM_PEER_HANDLE_BYTES)
+    rc = self.lib.gsfm_comm_peer_open(self.handle, rank, world, capacity_doubles, buf)
+    if rc != 0:
+        raise GsfmError(rc, "gsfm_comm_peer_open: " + self.last_error())
+    handles = allgather(buf.raw)
+    if len(handles) != world or any(len(h) != GSFM_PEER_HANDLE_BYTES for h in handles):
+        raise ValueError("peer transport: all-gather must return one 64-byte handle per rank")
+    rc = self.lib.gsfm_comm_peer_connect(self.handle, b"".join(handles))
+    if rc != 0:
+        raise GsfmError(rc, "gsfm_comm_peer_connect: " + self.last_error())
+    self.rank, self.world = rank, world
+
+
+def _comm_peer_selftest(self) -> float:
+    out = C.c_double(0.0)
+    rc = self.lib.gsfm_comm_peer_selftest(self.handle, C.byref(out))
+    if rc != 0:
+        raise GsfmError(rc, "gsfm_comm_peer_selftest: " + self.last_error())
+    return out.value
+
+
+def _comm_allreduce_bench(self, n: int, repeats: int = 200) -> float:
+    """Microseconds per all-reduce of n doubles through the attached transport (collective)."""
+    out = C.c_double(0.0)
+    rc = self.lib.gsfm_comm_allreduce_bench(self.handle, n, repeats, C.byref(out))
+    if rc != 0:
+        raise GsfmError(rc, "gsfm_comm_allreduce_bench: " + self.last_error())
+    return out.value
+
+
+Context.comm_allreduce_bench = _comm_allreduce_bench
+Context.comm_init_peer = _comm_init_peer
+Context.comm_peer_selftest = _comm_peer_selftest
 
 
 def comm_unique_id() -> bytes:

@@ -58,6 +58,8 @@ extern "C" int gsfm_ctx_create(int device_id, gsfm_ctx** out) {
   return GSFM_OK;
 }
 
+static void peer_close(gsfm_ctx* ctx);
+
 extern "C" void gsfm_ctx_destroy(gsfm_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
@@ -69,6 +71,7 @@ extern "C" void gsfm_ctx_destroy(gsfm_ctx* ctx) {
   if (ctx->fl_ws && ctx->fl_ws_free) ctx->fl_ws_free(ctx->fl_ws);
   if (ctx->tr_ws && ctx->tr_ws_free) ctx->tr_ws_free(ctx->tr_ws);
   if (ctx->comm.nccl) (void)ncclCommDestroy(ctx->comm.nccl);
+  peer_close(ctx);
   ctx->prof.destroy();
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -76,6 +79,8 @@ extern "C" void gsfm_ctx_destroy(gsfm_ctx* ctx) {
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
+
+extern "C" const char* gsfm_ctx_last_error(gsfm_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 
 extern "C" void* gsfm_ctx_stream(gsfm_ctx* ctx) { return ctx ? static_cast<void*>(ctx->stream) : nullptr; }
 
@@ -167,6 +172,7 @@ extern "C" int gsfm_comm_init(gsfm_ctx* ctx, const char id[GSFM_COMM_ID_BYTES], 
       GSFM_NCCL_CHECK(ncclCommDestroy(ctx->comm.nccl));
       ctx->comm.nccl = nullptr;
     }
+    peer_close(ctx);
     ncclUniqueId uid;
     std::memcpy(&uid, id, sizeof(uid));
     GSFM_NCCL_CHECK(ncclCommInitRank(&ctx->comm.nccl, world_size, uid, rank));
@@ -228,10 +234,166 @@ extern "C" int gsfm_comm_init_host(gsfm_ctx* ctx, gsfm_host_allreduce_fn fn, voi
       GSFM_NCCL_CHECK(ncclCommDestroy(ctx->comm.nccl));
       ctx->comm.nccl = nullptr;
     }
+    peer_close(ctx);
     ctx->comm.host_fn = fn;
     ctx->comm.host_user = user;
     ctx->comm.rank = rank;
     ctx->comm.world = world_size;
+    return (int)GSFM_OK;
+  });
+}
+
+// ---- peer-mailbox transport (peer.hpp) -------------------------------------------------------------
+static_assert(sizeof(hipIpcMemHandle_t) <= GSFM_PEER_HANDLE_BYTES, "hipIpcMemHandle_t does not fit GSFM_PEER_HANDLE_BYTES");
+
+static void peer_close(gsfm_ctx* ctx) {
+  PeerLink& L = ctx->comm.peer;
+  if (!L.open) return;
+  (void)hipStreamSynchronize(ctx->stream);
+  for (int r = 0; r < L.dev.world; ++r)
+    if (r != L.dev.rank && L.connected && L.dev.box[r]) (void)hipIpcCloseMemHandle(L.dev.box[r]);
+  if (L.dev.box[L.dev.rank]) (void)hipFree(L.dev.box[L.dev.rank]);
+  if (L.counter) (void)hipFree(L.counter);
+  if (L.h_err) (void)hipHostFree(L.h_err);
+  L = PeerLink{};
+}
+
+extern "C" int gsfm_comm_peer_open(gsfm_ctx* ctx, int rank, int world_size, int64_t capacity_doubles,
+                                   char handle_out[GSFM_PEER_HANDLE_BYTES]) {
+  if (!ctx || !handle_out) return GSFM_ERR_INVALID_ARGUMENT;
+  return guarded(ctx, nullptr, [&] {
+    GSFM_REQUIRE(world_size >= 1 && world_size <= kPeerMaxRanks && rank >= 0 && rank < world_size,
+                 "peer comm: rank / world_size out of range (at most 8 ranks)");
+    GSFM_REQUIRE(capacity_doubles >= 1024, "peer comm: capacity below 1024 doubles");
+    GSFM_HIP_CHECK(hipSetDevice(ctx->device));
+    peer_close(ctx);
+    PeerLink& L = ctx->comm.peer;
+    L.dev.world = world_size;
+    L.dev.rank = rank;
+    L.dev.cap = ((size_t)capacity_doubles + 511) / 512 * 512;
+    for (int r = 0; r < kPeerMaxRanks; ++r) L.dev.box[r] = nullptr;
+    const size_t bytes = kPeerHeaderBytes + 2 * (size_t)world_size * L.dev.cap * sizeof(double);
+    void* box = nullptr;
+    // uncached in L2: the slots are written by the peers over the fabric and read here
+    if (hipExtMallocWithFlags(&box, bytes, hipDeviceMallocUncached) != hipSuccess) {
+      (void)hipGetLastError();
+      GSFM_HIP_CHECK(hipExtMallocWithFlags(&box, bytes, hipDeviceMallocFinegrained));
+    }
+    L.dev.box[rank] = static_cast<unsigned char*>(box);
+    L.open = true;
+    GSFM_HIP_CHECK(hipMemset(box, 0, kPeerHeaderBytes));
+    GSFM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&L.counter), sizeof(unsigned)));
+    GSFM_HIP_CHECK(hipMemset(L.counter, 0, sizeof(unsigned)));
+    GSFM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&L.h_err), sizeof(int), hipHostMallocMapped));
+    *L.h_err = 0;
+    GSFM_HIP_CHECK(hipDeviceSynchronize());
+    const char* to = std::getenv("GSFM_PEER_TIMEOUT_S");
+    const double seconds = to && std::atof(to) > 0 ? std::atof(to) : 60.0;
+    L.timeout_ticks = (long long)(seconds * 1e8);  // wall_clock64: 100 MHz
+    hipIpcMemHandle_t h;
+    GSFM_HIP_CHECK(hipIpcGetMemHandle(&h, box));
+    std::memset(handle_out, 0, GSFM_PEER_HANDLE_BYTES);
+    std::memcpy(handle_out, &h, sizeof(h));
+    return (int)GSFM_OK;
+  });
+}
+
+extern "C" int gsfm_comm_peer_connect(gsfm_ctx* ctx, const char* handles) {
+  if (!ctx || !handles) return GSFM_ERR_INVALID_ARGUMENT;
+  return guarded(ctx, nullptr, [&] {
+    PeerLink& L = ctx->comm.peer;
+    GSFM_REQUIRE(L.open && !L.connected, "peer comm: gsfm_comm_peer_open first (once)");
+    GSFM_HIP_CHECK(hipSetDevice(ctx->device));
+    L.connected = true;  // (from here on peer_close releases what was mapped)
+    for (int r = 0; r < L.dev.world; ++r) {
+      if (r == L.dev.rank) continue;
+      hipIpcMemHandle_t h;
+      std::memcpy(&h, handles + (size_t)r * GSFM_PEER_HANDLE_BYTES, sizeof(h));
+      void* p = nullptr;
+      const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        peer_close(ctx);
+        throw StatusError(GSFM_ERR_COMM, std::string("peer comm: hipIpcOpenMemHandle failed: ") + hipGetErrorString(e));
+      }
+      L.dev.box[r] = static_cast<unsigned char*>(p);
+    }
+    if (ctx->comm.nccl) {
+      GSFM_NCCL_CHECK(ncclCommDestroy(ctx->comm.nccl));
+      ctx->comm.nccl = nullptr;
+    }
+    ctx->comm.host_fn = nullptr;
+    ctx->comm.rank = L.dev.rank;
+    ctx->comm.world = L.dev.world;
+    return (int)GSFM_OK;
+  });
+}
+
+// Checked all-reduce through whatever transport is attached (RCCL, peer mailboxes, host-staged): 256 values, twice in a row
+// (both slot sets of the peer transport), sum and max.
+static void comm_selftest_any(gsfm_ctx* ctx, double* sum_out) {
+  GSFM_HIP_CHECK(hipSetDevice(ctx->device));
+  double* dev = nullptr;
+  GSFM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dev), 256 * sizeof(double)));
+  std::vector<double> h(256);
+  bool ok = true;
+  const int R = ctx->comm.world, me = ctx->comm.rank;
+  try {
+    for (int round = 0; round < 4; ++round) {
+      const int op = round & 1;
+      for (int i = 0; i < 256; ++i) h[i] = (1.0 + i) * (me + 1) + round;
+      GSFM_HIP_CHECK(hipMemcpyAsync(dev, h.data(), 256 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      allreduce(ctx, dev, 256, op);
+      GSFM_HIP_CHECK(hipMemcpyAsync(h.data(), dev, 256 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      GSFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      for (int i = 0; i < 256; ++i) {
+        const double want = op == 0 ? (1.0 + i) * (R * (R + 1) / 2) + (double)round * R : (1.0 + i) * R + round;
+        ok = ok && h[i] == want;
+      }
+    }
+  } catch (...) {
+    (void)hipFree(dev);
+    throw;
+  }
+  (void)hipFree(dev);
+  if (sum_out) *sum_out = (double)R;
+  if (ctx->comm.peer.connected && *ctx->comm.peer.h_err) throw StatusError(GSFM_ERR_COMM, "peer all-reduce: a rank did not arrive");
+  if (!ok) throw StatusError(GSFM_ERR_COMM, "comm selftest: wrong all-reduce result");
+}
+
+extern "C" int gsfm_comm_peer_selftest(gsfm_ctx* ctx, double* world_out) {
+  if (!ctx) return GSFM_ERR_INVALID_ARGUMENT;
+  return guarded(ctx, nullptr, [&] {
+    GSFM_REQUIRE(ctx->comm.peer.connected, "peer selftest: no peer transport attached");
+    comm_selftest_any(ctx, world_out);
+    return (int)GSFM_OK;
+  });
+}
+
+// `repeats` back-to-back all-reduces of n doubles on the ctx stream through the attached transport, timed with HIP events
+// around the whole train (after one untimed warm-up): the per-collective cost as a PCG loop sees it.  Collective.
+extern "C" int gsfm_comm_allreduce_bench(gsfm_ctx* ctx, int64_t n, int repeats, double* avg_us_out) {
+  if (!ctx || n < 1 || repeats < 1 || !avg_us_out) return GSFM_ERR_INVALID_ARGUMENT;
+  return guarded(ctx, nullptr, [&] {
+    GSFM_HIP_CHECK(hipSetDevice(ctx->device));
+    double* dev = nullptr;
+    GSFM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dev), (size_t)n * sizeof(double)));
+    float ms = 0.f;
+    try {
+      GSFM_HIP_CHECK(hipMemsetAsync(dev, 0, (size_t)n * sizeof(double), ctx->stream));
+      allreduce(ctx, dev, (size_t)n, 0);
+      GSFM_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
+      for (int i = 0; i < repeats; ++i) allreduce(ctx, dev, (size_t)n, 0);
+      GSFM_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
+      GSFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      GSFM_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    } catch (...) {
+      (void)hipFree(dev);
+      throw;
+    }
+    (void)hipFree(dev);
+    if (ctx->comm.peer.connected && *ctx->comm.peer.h_err) throw StatusError(GSFM_ERR_COMM, "peer all-reduce: a rank did not arrive");
+    *avg_us_out = 1e3 * ms / repeats;
     return (int)GSFM_OK;
   });
 }
@@ -243,6 +405,7 @@ extern "C" int gsfm_comm_destroy(gsfm_ctx* ctx) {
       GSFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
       GSFM_NCCL_CHECK(ncclCommDestroy(ctx->comm.nccl));
     }
+    peer_close(ctx);
     ctx->comm = Comm{};
     return (int)GSFM_OK;
   });

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/gsfm.h"
+#include "peer.hpp"
 
 namespace gsfm {
 
@@ -113,6 +114,8 @@ struct Comm {
   gsfm_host_allreduce_fn host_fn = nullptr;
   void* host_user = nullptr;
   std::vector<double> host_buf;
+  // one-shot all-reduce over peer-mapped mailboxes (gsfm_comm_peer_*, peer.hpp): takes every collective once connected
+  PeerLink peer;
 };
 
 }  // namespace gsfm
@@ -200,6 +203,11 @@ namespace gsfm {
 // ctx stream.  No-op for a single rank.
 inline void allreduce(gsfm_ctx* ctx, double* dev, size_t n, int op /* 0 = sum, 1 = max */) {
   if (ctx->comm.world <= 1 || n == 0) return;
+  if (ctx->comm.peer.connected) {
+    if (*ctx->comm.peer.h_err) throw StatusError(GSFM_ERR_COMM, "peer all-reduce: a rank did not arrive within the time limit");
+    peer_allreduce(ctx->comm.peer, ctx->stream, dev, n, op);
+    return;
+  }
   if (ctx->comm.host_fn) {
     std::vector<double>& h = ctx->comm.host_buf;
     h.resize(n);

@@ -118,6 +118,9 @@ enum {
 int gsfm_ctx_profile_enable(gsfm_ctx* ctx, int enable);
 /* Reads and resets the accumulated launch count / total milliseconds of one kernel id. */
 int gsfm_ctx_profile_read(gsfm_ctx* ctx, int kernel_id, int64_t* launches, double* total_ms);
+/* Text of the last failure on this ctx (what the HIP / RCCL call or the argument check said); "" when there was none.  The
+ * pointer stays valid until the next failing call on the ctx. */
+const char* gsfm_ctx_last_error(gsfm_ctx* ctx);
 
 /* Flat on-disk problem format.  With a directory set — here, or through GSFM_DUMP_DIR in the
  * environment when the ctx is created — every gsfm_{ra,gp,ba}_solve on this ctx writes <directory>/<kind>_<seq>.gsfm:
@@ -148,6 +151,26 @@ int gsfm_selftest_mt19937(uint32_t seed, uint64_t skip, int64_t count, double sc
  * RCCL transport; never the measured path. */
 typedef int (*gsfm_host_allreduce_fn)(double* buf, int64_t n, int op, void* user);
 int gsfm_comm_init_host(gsfm_ctx* ctx, gsfm_host_allreduce_fn fn, void* user, int rank, int world_size);
+
+/* Peer-mailbox transport: a one-shot all-reduce for the small per-iteration vectors of the sharded solves (csrc/peer.hpp).
+ * Every rank owns a mailbox in its HBM with one slot per rank; the ranks map each other's mailboxes (hipIpc*: peer access
+ * over xGMI between the GPUs of a node, plain device memory between processes that share one GPU), push their vector into
+ * every mailbox, and add the slots of their own mailbox in rank order — two launches, no ring, the same bits on every rank.
+ *   every rank:  gsfm_comm_peer_open(ctx, rank, world, capacity, handle)      (at most 8 ranks; one node)
+ *   out of band: all-gather the GSFM_PEER_HANDLE_BYTES of every rank, in rank order
+ *   every rank:  gsfm_comm_peer_connect(ctx, all_handles)
+ * From then on every collective of this ctx goes through the mailboxes (vectors longer than `capacity_doubles` in pieces);
+ * an RCCL communicator or host transport attached before is released.  A rank that does not arrive within
+ * GSFM_PEER_TIMEOUT_S seconds (environment, default 60) makes the next collective fail with GSFM_ERR_COMM.
+ * gsfm_comm_destroy releases it; all ranks must have finished their solves before any of them does. */
+#define GSFM_PEER_HANDLE_BYTES 64
+int gsfm_comm_peer_open(gsfm_ctx* ctx, int rank, int world_size, int64_t capacity_doubles, char handle_out[GSFM_PEER_HANDLE_BYTES]);
+int gsfm_comm_peer_connect(gsfm_ctx* ctx, const char* all_handles /* world_size x GSFM_PEER_HANDLE_BYTES */);
+/* Checked sum / max all-reduces through the mailboxes (both slot sets); *world_out = world_size.  Collective. */
+int gsfm_comm_peer_selftest(gsfm_ctx* ctx, double* world_out);
+/* `repeats` back-to-back all-reduces of n doubles through the attached transport (RCCL, peer mailboxes or host-staged), HIP
+ * events around the train: *avg_us_out = microseconds per collective as a PCG loop pays it.  Collective. */
+int gsfm_comm_allreduce_bench(gsfm_ctx* ctx, int64_t n, int repeats, double* avg_us_out);
 
 /* ---- rotation averaging ------------------------------------------------------------------- */
 /* Options: mirror of RotationEstimatorOptions, global_rotation_averaging.h:39-75. */

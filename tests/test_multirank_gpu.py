@@ -1,8 +1,10 @@
-"""Sharded (N > 1) path on the GPU: two / four ranks share the one MI355X of the test box, every collective
-goes through the host-staged validation transport (gsfm_comm_init_host over gloo) instead of RCCL —
-same sharding, same kernels, same reduction points.  The sharded solves must reproduce the
-single-rank solves of the same problems: same LM / IRLS iteration counts, poses equal to solver precision,
-replicated state bit-identical on every rank."""
+"""Sharded (N > 1) path on the GPU: two / four ranks share the one MI355X of the test box.  Two transports carry the
+collectives: the host-staged validation transport (gsfm_comm_init_host over gloo) and the library's own peer-mailbox
+all-reduce (gsfm_comm_peer_*, csrc/peer.hpp) — between processes on one GPU its mailboxes are mapped with the same
+hipIpc* calls as between GPUs, and its push / flag / ordered-sum kernels are the ones a multi-GPU node runs.  RCCL cannot
+be exercised with several ranks on one device.  Same sharding, same kernels, same reduction points: the sharded solves
+must reproduce the single-rank solves of the same problems — same LM / IRLS iteration counts, poses equal to solver
+precision, replicated state bit-identical on every rank."""
 import os
 import socket
 
@@ -27,15 +29,27 @@ def _problems():
     return ra, gp, ba
 
 
-def _worker(rank, world, port, ra_init, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+def _worker(rank, world, port, ra_init, q, transport="host"):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      GSFM_PEER_TIMEOUT_S="30")
     import torch.distributed as dist
 
     from glomap_amd import _lib
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ctx = _lib.Context(0)
-    ctx.comm_init_host(sharding.host_allreduce(dist), rank, world)
+    if transport == "peer":
+        def allgather(b):
+            out = [None] * world
+            dist.all_gather_object(out, b)
+            return out
+
+        # the smallest capacity: the per-iteration vectors fit (RA 600, GP 121, BA 189 doubles), BA's per-LM-step cross
+        # blocks (48 N = 1 440 doubles) go in two pieces — both the one-piece and the chunked path run
+        ctx.comm_init_peer(allgather, rank, world, 1024)
+        assert ctx.comm_peer_selftest() == world
+    else:
+        ctx.comm_init_host(sharding.host_allreduce(dist), rank, world)
     ra, gp, ba = _problems()
     out = {}
     # RA: edges sharded, nodes replicated; initial rotations = the MST initialisation of the whole graph
@@ -58,8 +72,8 @@ def _worker(rank, world, port, ra_init, q):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world", [2, 4])
-def test_ranks_reproduce_single_rank(gsfm_ctx, world):
+@pytest.mark.parametrize("world,transport", [(2, "host"), (4, "host"), (2, "peer"), (4, "peer")])
+def test_ranks_reproduce_single_rank(gsfm_ctx, world, transport):
     import multiprocessing as mp
 
     ra, gp, ba = _problems()
@@ -80,7 +94,7 @@ def test_ranks_reproduce_single_rank(gsfm_ctx, world):
     mpc = mp.get_context("spawn")
     queue = mpc.Queue()
     port = _free_port()
-    procs = [mpc.Process(target=_worker, args=(r, world, port, ra_init, queue)) for r in range(world)]
+    procs = [mpc.Process(target=_worker, args=(r, world, port, ra_init, queue, transport)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(queue.get(timeout=800) for _ in range(world))
