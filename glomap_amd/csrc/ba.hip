@@ -473,13 +473,21 @@ __global__ void __launch_bounds__(kBlock)
 // One wave per camera: reduced gradient J_a^T w (r - J_pt e) and the diagonal Schur blocks
 // J_a^T W_k J_a, W_k = w (I - w J_pt H_pp^-1 J_pt^T), for the pose block (6 + 21) and this camera's
 // share of its intrinsics block (ipart[n][44] = gred 8 | S 36).
-template <bool JOINT, bool WIDE>
+// The intrinsics part is accumulated over the F COMPACT columns (the free parameters of the block, intr_map) and
+// scattered to the 8-wide layout at the end: with SIMPLE_RADIAL and a fixed principal point (F = 2) that is 44
+// accumulators per lane instead of 119 — the full-width version sat at 252 registers, one wave per SIMD, 600 - 800 us
+// per launch on configs[3].
+template <int F>
+__device__ __forceinline__ int symF(int i, int j) { return i * F - (i * (i - 1)) / 2 + (j - i); }
+template <bool JOINT, bool WIDE, int F>
 __global__ void __launch_bounds__(kBlock)
     k_ba_build_cam(BaDev g, const double* __restrict__ camR, const double* __restrict__ t,
                    const double* __restrict__ par, const double* __restrict__ c_w,
                    const double* __restrict__ ptb, double* __restrict__ gred, double* __restrict__ spose,
                    double* __restrict__ ipart, double* __restrict__ scross /* [N][48], JOINT only */) {
-  constexpr int NACC = JOINT ? 71 + 48 : 71;
+  constexpr int NI = F + (F * (F + 1)) / 2;       // compact intrinsics gradient | upper triangle
+  constexpr int OI = 27, OS = 27 + F, OC = 27 + NI;
+  constexpr int NACC = JOINT ? OC + 6 * F : (OC > 27 ? OC : 27);
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (kBlock / 64);
@@ -488,11 +496,16 @@ __global__ void __launch_bounds__(kBlock)
     const int n = g.g.seg_cam[sg];
     const int ik = g.cam_intr[n];
     const int model = g.intr_model[ik];
-    const unsigned char bits = g.intr_free[ik];
     const double* R9 = camR + 9 * (long)n;
     const double* t3 = t + 3 * (long)n;
     const double* pp = par + 8 * (long)ik;
-    double acc[NACC];  // gred 6 | spose 21 | igred 8 | sii 36 | (JOINT) pose x intrinsics cross block 6 x 8
+    Map8 mp = load_map(g.intr_map + 8 * (long)ik);
+    const unsigned char bits = g.intr_free[ik];
+    if constexpr (F == 8) {  // full width: the columns ARE the parameters, fixed ones masked (no select chains)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mp.m[j] = ((bits >> j) & 1) ? (signed char)j : (signed char)-1;
+    }
+    double acc[NACC];  // gred 6 | spose 21 | igred F | sii F (F + 1) / 2 | (JOINT) pose x intrinsics cross block 6 x F
 #pragma unroll
     for (int j = 0; j < NACC; ++j) acc[j] = 0.0;
     for (int k = cam_seg_k0(g.g, sg) + lane; k < cam_seg_k1(g.g, sg); k += 64) {
@@ -506,7 +519,6 @@ __global__ void __launch_bounds__(kBlock)
       const double r0 = o.px - g.c_xy[2 * (long)k], r1 = o.py - g.c_xy[2 * (long)k + 1];
       ObsJac J;
       build_jac(g, n, R9, o, J);
-      mask_intr(bits, o.Jp);
       // r - J_pt e
       const double q0 = r0 - (J.Jpt[0][0] * e.x + J.Jpt[0][1] * e.y + J.Jpt[0][2] * e.z);
       const double q1 = r1 - (J.Jpt[1][0] * e.x + J.Jpt[1][1] * e.y + J.Jpt[1][2] * e.z);
@@ -517,6 +529,22 @@ __global__ void __launch_bounds__(kBlock)
       const double T01 = J.Jpt[0][0] * h1.x + J.Jpt[0][1] * h1.y + J.Jpt[0][2] * h1.z;
       const double T11 = J.Jpt[1][0] * h1.x + J.Jpt[1][1] * h1.y + J.Jpt[1][2] * h1.z;
       const double W00 = w * (1.0 - w * T00), W01 = -w * w * T01, W11 = w * (1.0 - w * T11);
+      double Jc[2][F > 0 ? F : 1];  // the free columns of d(projection) / d(intrinsics); unused columns (-1) are zero
+      if constexpr (F == 8) {
+        mask_intr(bits, o.Jp);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          Jc[0][j] = o.Jp[0][j];
+          Jc[1][j] = o.Jp[1][j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+          const int pm = mp.m[j];
+          Jc[0][j] = sel8(o.Jp[0], pm);
+          Jc[1][j] = sel8(o.Jp[1], pm);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         acc[i] += w * (J.Jpose[0][i] * q0 + J.Jpose[1][i] * q1);
@@ -526,33 +554,48 @@ __global__ void __launch_bounds__(kBlock)
         for (int j = i; j < 6; ++j) acc[6 + sym6(i, j)] += a0 * J.Jpose[0][j] + a1 * J.Jpose[1][j];
         if constexpr (JOINT) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[71 + 8 * i + j] += a0 * o.Jp[0][j] + a1 * o.Jp[1][j];  // Jp masked above
+          for (int j = 0; j < F; ++j) acc[OC + F * i + j] += a0 * Jc[0][j] + a1 * Jc[1][j];
         }
       }
-      if (bits) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          acc[27 + i] += w * (o.Jp[0][i] * q0 + o.Jp[1][i] * q1);
-          const double a0 = W00 * o.Jp[0][i] + W01 * o.Jp[1][i];
-          const double a1 = W01 * o.Jp[0][i] + W11 * o.Jp[1][i];
+      for (int i = 0; i < F; ++i) {
+        acc[OI + i] += w * (Jc[0][i] * q0 + Jc[1][i] * q1);
+        const double a0 = W00 * Jc[0][i] + W01 * Jc[1][i];
+        const double a1 = W01 * Jc[0][i] + W11 * Jc[1][i];
 #pragma unroll
-          for (int j = i; j < 8; ++j) acc[35 + sym8(i, j)] += a0 * o.Jp[0][j] + a1 * o.Jp[1][j];
-        }
+        for (int j = i; j < F; ++j) acc[OS + symF<F>(i, j)] += a0 * Jc[0][j] + a1 * Jc[1][j];
       }
     }
     wave_allsum<NACC>(acc);
     if (!cam_seg_total<NACC>(g.g, sg, acc, lane)) continue;
     if (lane == 0) {
-      if constexpr (JOINT) {
-#pragma unroll
-        for (int j = 0; j < 48; ++j) scross[48 * (long)n + j] = acc[71 + j];
-      }
 #pragma unroll
       for (int j = 0; j < 6; ++j) gred[6 * (long)n + j] = acc[j];
 #pragma unroll
       for (int j = 0; j < 21; ++j) spose[21 * (long)n + j] = acc[6 + j];
+      // compact -> 8-wide (intr_map is increasing: column i < column j means parameter index p_i < p_j)
+      double* ip = ipart + 44 * (long)n;
 #pragma unroll
-      for (int j = 0; j < 44; ++j) ipart[44 * (long)n + j] = acc[27 + j];
+      for (int j = 0; j < 44; ++j) ip[j] = 0.0;
+      if constexpr (JOINT) {
+#pragma unroll
+        for (int j = 0; j < 48; ++j) scross[48 * (long)n + j] = 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < F; ++i) {
+        const int pi = mp.m[i];
+        if (pi < 0) continue;
+        ip[pi] = acc[OI + i];
+#pragma unroll
+        for (int j = i; j < F; ++j) {
+          const int pj = mp.m[j];
+          if (pj >= 0) ip[8 + sym8(pi, pj)] = acc[OS + symF<F>(i, j)];
+        }
+        if constexpr (JOINT) {
+#pragma unroll
+          for (int a = 0; a < 6; ++a) scross[48 * (long)n + 8 * a + pi] = acc[OC + F * a + i];
+        }
+      }
     }
   }
 }
@@ -2059,19 +2102,25 @@ class BaSolver final : public LmProblem {
     hipLaunchKernelGGL(k_ba_build_track, dim3(gridP_), dim3(kBlock), 0, s, g_, radius, X_, ws->ptH.get(),
                        ws->ptdiag.get(), ws->ptjs.get(), ws->ptb.get(), ws->ptrec.get(), ws->pth.get());
     if (joint_) {
-      WIDE_LAUNCH((k_ba_build_cam<true, WIDE>), dim3(gridCam_), dim3(kBlock), 0, s, g_, R_, t_, par_, ws->c_w.get(),
-                         ws->ptb.get(), ws->gred.get(), ws->spose.get(), ws->ipart.get(), ws->scross.get());
-      if (gridMulti_)
-        WIDE_LAUNCH((k_ba_build_cam<true, WIDE>), dim3(gridMulti_), dim3(kBlock), 0, s, g1_, R_, t_, par_, ws->c_w.get(),
-                           ws->ptb.get(), ws->gred.get(), ws->spose.get(), ws->ipart.get(), ws->scross.get());
+      dispatch_f(F_, [&](auto Fc) {
+        constexpr int F = decltype(Fc)::value;
+        WIDE_LAUNCH((k_ba_build_cam<true, WIDE, F>), dim3(gridCam_), dim3(kBlock), 0, s, g_, R_, t_, par_, ws->c_w.get(),
+                    ws->ptb.get(), ws->gred.get(), ws->spose.get(), ws->ipart.get(), ws->scross.get());
+        if (gridMulti_)
+          WIDE_LAUNCH((k_ba_build_cam<true, WIDE, F>), dim3(gridMulti_), dim3(kBlock), 0, s, g1_, R_, t_, par_, ws->c_w.get(),
+                      ws->ptb.get(), ws->gred.get(), ws->spose.get(), ws->ipart.get(), ws->scross.get());
+      });
     } else {
       double* gred_k = rig_ ? ws->gred_i.get() : ws->gred.get();
       double* spose_k = rig_ ? ws->spose_i.get() : ws->spose.get();
-      WIDE_LAUNCH((k_ba_build_cam<false, WIDE>), dim3(gridCam_), dim3(kBlock), 0, s, g_, Rk_, tk_, par_, ws->c_w.get(),
-                         ws->ptb.get(), gred_k, spose_k, ws->ipart.get(), (double*)nullptr);
-      if (gridMulti_)
-        WIDE_LAUNCH((k_ba_build_cam<false, WIDE>), dim3(gridMulti_), dim3(kBlock), 0, s, g1_, Rk_, tk_, par_, ws->c_w.get(),
-                           ws->ptb.get(), gred_k, spose_k, ws->ipart.get(), (double*)nullptr);
+      dispatch_f(F_, [&](auto Fc) {
+        constexpr int F = decltype(Fc)::value;
+        WIDE_LAUNCH((k_ba_build_cam<false, WIDE, F>), dim3(gridCam_), dim3(kBlock), 0, s, g_, Rk_, tk_, par_, ws->c_w.get(),
+                    ws->ptb.get(), gred_k, spose_k, ws->ipart.get(), (double*)nullptr);
+        if (gridMulti_)
+          WIDE_LAUNCH((k_ba_build_cam<false, WIDE, F>), dim3(gridMulti_), dim3(kBlock), 0, s, g1_, Rk_, tk_, par_, ws->c_w.get(),
+                      ws->ptb.get(), gred_k, spose_k, ws->ipart.get(), (double*)nullptr);
+      });
       if (rig_)  // frame blocks: sum over the frame's images of T^T g and T^T S T (cross blocks between two images of
                  // one frame are left to the PCG: this is the preconditioner and the right-hand side)
         hipLaunchKernelGGL(k_ba_rig_reduce_blocks, dim3(gridN_), dim3(kBlock), 0, s, rg_, gred_k, spose_k, ws->gred.get(),

@@ -21,6 +21,7 @@ BUDGET = {
     "k_ba_phaseA<2, true>": 104,
     "k_ba_phaseB<false>": 224,          # 2 waves per SIMD; the WIDE instance (fisheye / FOV) is allowed 1
     "k_ba_cost<false>": 64,
+    "k_ba_build_cam<true, false, 2>": 256,   # compact intrinsics columns: 2 waves per SIMD (full width: 504, one wave)
     "k_ba_lin_track<2, false>": 176,
     "k_ba_lin_cam<false, false>": 208,
     "k_cg_update1<3>": 128,             # __launch_bounds__(1024)
