@@ -128,6 +128,7 @@ class GpOptions(C.Structure):
         ("min_num_view_per_track", C.c_int32),
         ("seed", C.c_uint32),
         ("constraint_type", C.c_int32),
+        ("constraint_reweight_scale", C.c_double),
     ]
 
 
@@ -148,6 +149,10 @@ class GpProblemC(C.Structure):
         ("image_sensor", C.c_void_p),
         ("image_sensor_rot", C.c_void_p),
         ("sensor_center", C.c_void_p),
+        ("num_pairs", C.c_int64),
+        ("pair_i", C.c_void_p),
+        ("pair_j", C.c_void_p),
+        ("pair_dir", C.c_void_p),
     ]
 
 

@@ -56,6 +56,7 @@ struct GpDev {
   const double* c_jss;          // [M]     camera-major copy of the scale Jacobi factors
   long fixed_obs;               // observation whose scale is constant (-1: none on this rank)
   double huber_a;
+  double wpt;                   // weight of the point-to-camera losses (1; POINTS_AND_CAMERAS_BALANCED: gp.cc:223-255)
   int opt_c, opt_x, opt_s;
   double lm_lo, lm_hi;
 };
@@ -100,7 +101,7 @@ __global__ void __launch_bounds__(kBlock)
       const double sk = s[k];
       const V3 r = ld3(g.dir + 3 * k) - sk * d;
       double rho, w;
-      huber(g.huber_a, (g.cal == nullptr || g.cal[k]) ? 1.0 : 0.5, dot(r, r), rho, w);
+      huber(g.huber_a, (g.cal == nullptr || g.cal[k]) ? g.wpt : 0.5 * g.wpt, dot(r, r), rho, w);
       wrob[k] = w;
       cost += 0.5 * rho;
       const double ws = w * sk;
@@ -144,7 +145,7 @@ __global__ void __launch_bounds__(kBlock)
       const double sk = s[src];
       const V3 r = ld3(g.c_dir + 3 * (long)k) - sk * d;
       double rho, w;
-      huber(g.huber_a, (g.c_cal == nullptr || g.c_cal[k]) ? 1.0 : 0.5, dot(r, r), rho, w);
+      huber(g.huber_a, (g.c_cal == nullptr || g.c_cal[k]) ? g.wpt : 0.5 * g.wpt, dot(r, r), rho, w);
       const double ws = w * sk;
       acc[0] += ws * sk;
       acc[1] += ws * r.x;
@@ -320,7 +321,7 @@ __global__ void __launch_bounds__(kBlock)
       const double sk = s[src];
       const V3 r = ld3(g.c_dir + 3 * (long)k) - sk * d;
       double rho, w;
-      huber(g.huber_a, (g.c_cal == nullptr || g.c_cal[k]) ? 1.0 : 0.5, dot(r, r), rho, w);
+      huber(g.huber_a, (g.c_cal == nullptr || g.c_cal[k]) ? g.wpt : 0.5 * g.wpt, dot(r, r), rho, w);
       double beta = 0.0;
       if (g.opt_s && src != g.fixed_obs) {
         const double hraw = w * dot(d, d);
@@ -939,7 +940,7 @@ __global__ void __launch_bounds__(kBlock)
     const V3 d = ld3(X + 3 * p) - ld3(c + 3 * (long)g.g.cam[k]);
     const V3 r = ld3(g.dir + 3 * k) - s[k] * d;
     double rho, w;
-    huber(g.huber_a, (g.cal == nullptr || g.cal[k]) ? 1.0 : 0.5, dot(r, r), rho, w);
+    huber(g.huber_a, (g.cal == nullptr || g.cal[k]) ? g.wpt : 0.5 * g.wpt, dot(r, r), rho, w);
     v[0] += 0.5 * rho;
   }
   block_sum<1>(v, smem);
@@ -970,6 +971,254 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
     for (int k = 0; k < K; ++k) out[k] = tot[k];
   }
+}
+
+// ---- camera-to-camera constraints (constraint_type != ONLY_POINTS) ---------------------------------------------------
+// GlobalPositioner::AddCameraToCameraConstraints (global_positioning.cc:167-210): one BATAPairwiseDirectionError per valid
+// image pair, r = t_ij - s_ij (c_j - c_i) with a scale of its own (start 1, lower bound 1e-5, the FIRST pair's scale
+// constant: gp.cc:484-489) and a plain Huber loss.  In the elimination order of the reference (gp.cc:388-429) the pair
+// scales go with the observation scales, so a pair is an observation whose "point" is camera j: it leaves
+//     Q_e = a (I - beta d d^T),  a = w s^2,  beta = w / (w d.d + D_s),  d = c_j - c_i
+// on the (i, i) and (j, j) blocks of the reduced camera system and -Q_e on (i, j).  There are few pairs next to the
+// observations (E ~ 50 N against M ~ 600 N), so the layout is the simplest deterministic one: per-pair quantities by one
+// thread per pair, camera-side sums by one wave per camera over its incidence list (pairs in input order; each pair is
+// evaluated at both of its cameras), added to what the observation sweeps wrote.  Deflation, the closed-form A W and the
+// second-level preconditioner are switched off when pairs are present (plain block-Jacobi PCG).
+struct GpPairs {
+  long E = 0;
+  const int* pi = nullptr;    // [E]
+  const int* pj = nullptr;    // [E]
+  const double* pv = nullptr; // [E][3]
+  const int* row = nullptr;   // [N+1] incidence lists: camera n owns ent[row[n] .. row[n+1])
+  const int* ent = nullptr;   // [2E]  pair index
+  long fixed = -1;            // pair whose scale is constant
+  double huber_a = 0.0;
+  int opt_c = 1, opt_s = 1;
+  double lm_lo = 0.0, lm_hi = 0.0;
+};
+struct PairGeom {
+  V3 d, r;
+};
+__device__ __forceinline__ PairGeom pair_geom(const GpPairs& q, long e, const double* __restrict__ c, double se) {
+  PairGeom g;
+  g.d = ld3(c + 3 * (long)q.pj[e]) - ld3(c + 3 * (long)q.pi[e]);
+  g.r = ld3(q.pv + 3 * e) - se * g.d;
+  return g;
+}
+// linearise: robust weights; part[block][2] = {cost, max |scale gradient|}
+__global__ void __launch_bounds__(kBlock)
+    k_gpp_lin(GpPairs q, const double* __restrict__ c, const double* __restrict__ se, double* __restrict__ we,
+              double* __restrict__ part) {
+  __shared__ double smem[8];
+  double cost = 0.0, gmax = 0.0;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < q.E; e += (long)gridDim.x * blockDim.x) {
+    const PairGeom g = pair_geom(q, e, c, se[e]);
+    double rho, w;
+    huber(q.huber_a, 1.0, dot(g.r, g.r), rho, w);
+    we[e] = w;
+    cost += 0.5 * rho;
+    if (q.opt_s && e != q.fixed) gmax = fmax(gmax, fabs(w * dot(g.d, g.r)));
+  }
+  double v[1] = {cost};
+  block_sum<1>(v, smem);
+  const double m = block_max(gmax, smem + 4);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x * 2] = v[0];
+    part[blockIdx.x * 2 + 1] = m;
+  }
+}
+// scal[0] += sum part[.][0];  scal[1] = max(scal[1], part[.][1])      (one workgroup)
+__global__ void __launch_bounds__(kBlock) k_gpp_fold_lin(const double* __restrict__ part, int nblocks, double* __restrict__ scal) {
+  __shared__ double smem[8];
+  double cost = 0.0, gmax = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+    cost += part[2 * b];
+    gmax = fmax(gmax, part[2 * b + 1]);
+  }
+  double v[1] = {cost};
+  block_sum<1>(v, smem);
+  const double m = block_max(gmax, smem + 4);
+  if (threadIdx.x == 0) {
+    scal[0] += v[0];
+    scal[1] = fmax(scal[1], m);
+  }
+}
+// scal[idx[j]] += sum_b part[b][j]     (one workgroup)
+template <int K>
+__global__ void __launch_bounds__(kBlock)
+    k_gpp_fold_sum(const double* __restrict__ part, int nblocks, double* __restrict__ scal, int i0, int i1, int i2) {
+  __shared__ double smem[4 * K + K];
+  double tot[K];
+  reduce_partials<K>(part, nblocks, tot, smem);
+  if (threadIdx.x == 0) {
+    const int idx[3] = {i0, i1, i2};
+#pragma unroll
+    for (int k = 0; k < K; ++k) scal[idx[k]] += tot[k];
+  }
+}
+// camera side of the linearisation: h_cc += sum w s^2, g_c += sum +- w s r   (one wave per camera)
+__global__ void __launch_bounds__(kBlock)
+    k_gpp_cam_lin(GpPairs q, int N, const double* __restrict__ c, const double* __restrict__ se,
+                  const double* __restrict__ we, double* __restrict__ hcc, double* __restrict__ gc) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (kBlock / 64);
+  for (int n = wave; n < N; n += nwaves) {
+    double acc[4] = {0, 0, 0, 0};
+    for (int a = q.row[n] + lane; a < q.row[n + 1]; a += 64) {
+      const long e = q.ent[a];
+      const double sk = se[e], w = we[e];
+      const PairGeom g = pair_geom(q, e, c, sk);
+      const double sg = q.pi[e] == n ? 1.0 : -1.0;  // d r / d c_i = +s I, d r / d c_j = -s I
+      const double ws = w * sk;
+      acc[0] += ws * sk;
+      acc[1] += sg * ws * g.r.x;
+      acc[2] += sg * ws * g.r.y;
+      acc[3] += sg * ws * g.r.z;
+    }
+    wave_allsum<4>(acc);
+    if (lane == 0 && q.row[n + 1] > q.row[n]) {
+      hcc[n] += acc[0];
+      gc[3 * (long)n] += acc[1];
+      gc[3 * (long)n + 1] += acc[2];
+      gc[3 * (long)n + 2] += acc[3];
+    }
+  }
+}
+__global__ void __launch_bounds__(kBlock)
+    k_gpp_jacobi(GpPairs q, int enabled, const double* __restrict__ c, const double* __restrict__ we, double* __restrict__ jse) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < q.E; e += (long)gridDim.x * blockDim.x) {
+    const V3 d = ld3(c + 3 * (long)q.pj[e]) - ld3(c + 3 * (long)q.pi[e]);
+    const bool free_s = q.opt_s && e != q.fixed;
+    jse[e] = (enabled && free_s) ? 1.0 / (1.0 + sqrt(we[e] * dot(d, d))) : 1.0;
+  }
+}
+// build (radius dependent): a_e, beta_e
+__global__ void __launch_bounds__(kBlock)
+    k_gpp_build(GpPairs q, double radius, const double* __restrict__ c, const double* __restrict__ se,
+                const double* __restrict__ we, const double* __restrict__ jse, double* __restrict__ qa, double* __restrict__ qb) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < q.E; e += (long)gridDim.x * blockDim.x) {
+    const V3 d = ld3(c + 3 * (long)q.pj[e]) - ld3(c + 3 * (long)q.pi[e]);
+    const double w = we[e], sk = se[e];
+    double beta = 0.0;
+    if (q.opt_s && e != q.fixed) {
+      const double hraw = w * dot(d, d);
+      beta = w / (hraw + lm_damping(hraw, jse[e], radius, q.lm_lo, q.lm_hi));
+    }
+    qa[e] = w * sk * sk;
+    qb[e] = beta;
+  }
+}
+// camera side of the build: g'_c += sum +- Q-weighted residual, S_cc += sum Q_e   (one wave per camera)
+__global__ void __launch_bounds__(kBlock)
+    k_gpp_cam_build(GpPairs q, int N, const double* __restrict__ c, const double* __restrict__ se,
+                    const double* __restrict__ we, const double* __restrict__ qa, const double* __restrict__ qb,
+                    double* __restrict__ gred, double* __restrict__ scc) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (kBlock / 64);
+  for (int n = wave; n < N; n += nwaves) {
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int a = q.row[n] + lane; a < q.row[n + 1]; a += 64) {
+      const long e = q.ent[a];
+      const double sk = se[e], w = we[e], ak = qa[e], bk = qb[e];
+      const PairGeom g = pair_geom(q, e, c, sk);
+      const double sg = q.pi[e] == n ? 1.0 : -1.0;
+      const V3 y = applyQ(w * sk, bk, g.d, g.r);  // s w (r - beta d (d.r))
+      acc[0] += sg * y.x;
+      acc[1] += sg * y.y;
+      acc[2] += sg * y.z;
+      const double ab = ak * bk;
+      acc[3] += ak - ab * g.d.x * g.d.x;
+      acc[4] += -ab * g.d.x * g.d.y;
+      acc[5] += -ab * g.d.x * g.d.z;
+      acc[6] += ak - ab * g.d.y * g.d.y;
+      acc[7] += -ab * g.d.y * g.d.z;
+      acc[8] += ak - ab * g.d.z * g.d.z;
+    }
+    wave_allsum<9>(acc);
+    if (lane == 0 && q.row[n + 1] > q.row[n]) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) gred[3 * (long)n + j] += acc[j];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) scc[6 * (long)n + j] += acc[3 + j];
+    }
+  }
+}
+// operator: w_n += sum +- Q_e (z_i - z_j) and this workgroup's share of delta = z.w  (after k_gp_phaseB)
+__global__ void __launch_bounds__(kBlock)
+    k_gpp_apply(GpPairs q, CgVec v, int N, const double* __restrict__ c, const double* __restrict__ qa,
+                const double* __restrict__ qb, int dslot0) {
+  __shared__ double sdelta[kBlock / 64];
+  if (v.st->done) return;
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int wave = blockIdx.x * (kBlock / 64) + wid;
+  const int nwaves = gridDim.x * (kBlock / 64);
+  double delta = 0.0;
+  for (int n = wave; n < N; n += nwaves) {
+    double acc[3] = {0, 0, 0};
+    for (int a = q.row[n] + lane; a < q.row[n + 1]; a += 64) {
+      const long e = q.ent[a];
+      const long i = q.pi[e], j = q.pj[e];
+      const V3 d = ld3(c + 3 * j) - ld3(c + 3 * i);
+      const V3 y = applyQ(qa[e], qb[e], d, ld3(v.z + 3 * i) - ld3(v.z + 3 * j));
+      const double sg = i == n ? 1.0 : -1.0;
+      acc[0] += sg * y.x;
+      acc[1] += sg * y.y;
+      acc[2] += sg * y.z;
+    }
+    wave_allsum<3>(acc);
+    if (lane == 0 && q.row[n + 1] > q.row[n]) {
+      const V3 zn = ld3(v.z + 3 * (long)n);
+      v.w[3 * (long)n] += acc[0];
+      v.w[3 * (long)n + 1] += acc[1];
+      v.w[3 * (long)n + 2] += acc[2];
+      delta += zn.x * acc[0] + zn.y * acc[1] + zn.z * acc[2];
+    }
+  }
+  if (lane == 0) sdelta[wid] = delta;
+  __syncthreads();
+  if (threadIdx.x == 0) v.dpart[dslot0 + blockIdx.x] = (sdelta[0] + sdelta[1]) + (sdelta[2] + sdelta[3]);
+}
+// back-substitution of the pair scales, model cost change, candidate scales; part[block][3] as k_gp_backsub
+__global__ void __launch_bounds__(kBlock)
+    k_gpp_backsub(GpPairs q, const double* __restrict__ c, const double* __restrict__ se, const double* __restrict__ we,
+                  const double* __restrict__ qb, const double* __restrict__ dc, double* __restrict__ sn,
+                  double* __restrict__ part) {
+  __shared__ double smem[4 * 3];
+  double acc3[3] = {0, 0, 0};
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < q.E; e += (long)gridDim.x * blockDim.x) {
+    const double sk = se[e], w = we[e];
+    const PairGeom g = pair_geom(q, e, c, sk);
+    const V3 dcx = ld3(dc + 3 * (long)q.pi[e]) - ld3(dc + 3 * (long)q.pj[e]);
+    const double ds = qb[e] * (dot(g.d, g.r) + sk * dot(g.d, dcx));
+    const V3 m = sk * dcx - ds * g.d;
+    acc3[0] -= w * (dot(m, g.r) + 0.5 * dot(m, m));
+    const double s_new = fmax(1e-5, sk + ds);
+    sn[e] = s_new;
+    acc3[1] += (s_new - sk) * (s_new - sk);
+    acc3[2] += sk * sk;
+  }
+  block_sum<3>(acc3, smem);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) part[blockIdx.x * 3 + k] = acc3[k];
+  }
+}
+// candidate cost of the pairs; part[block][1]
+__global__ void __launch_bounds__(kBlock)
+    k_gpp_cost(GpPairs q, const double* __restrict__ c, const double* __restrict__ se, double* __restrict__ part) {
+  __shared__ double smem[4];
+  double v[1] = {0.0};
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < q.E; e += (long)gridDim.x * blockDim.x) {
+    const PairGeom g = pair_geom(q, e, c, se[e]);
+    double rho, w;
+    huber(q.huber_a, 1.0, dot(g.r, g.r), rho, w);
+    v[0] += 0.5 * rho;
+  }
+  block_sum<1>(v, smem);
+  if (threadIdx.x == 0) part[blockIdx.x] = v[0];
 }
 
 // ---- calibrated rigs -----------------------------------------------------------------------------------------
@@ -1154,6 +1403,8 @@ struct GpWs {
   DevBuf<double> img_off, ci, cin, hcc_i, gc_i, gred_i, scc_i, zimg, wimg, ximg, zero_i, cz_f, img_rot;
   DevBuf<double> defl_w, defl_aw, defl_b2, defl_part, defl_small, defl_cd;  // CgDeflation, cg.hpp
   DevBuf<double> maxpart;
+  DevBuf<int> pr_i, pr_j, pr_row, pr_ent;                       // camera-to-camera constraints (GpPairs)
+  DevBuf<double> pr_v, pr_s, pr_sn, pr_w, pr_js, pr_qa, pr_qb, pr_part;
   DevBuf<double> cs_cbar, cs_E, cs_E2, cs_pinv, cs_c, cs_y;  // second-level preconditioner (GpCoarse*)
   DevBuf<int> cs_flag;
   static void destroy(void* p) { delete static_cast<GpWs*>(p); }
@@ -1200,6 +1451,17 @@ class GpSolver final : public LmProblem {
       }
     }
     Np_ = N_ + S_;  // 3-vector blocks: frame centres, then the cam_from_rig centres to estimate
+    // constraint types (global_positioning.h:11-20): camera-to-camera pairs next to / instead of the tracks
+    const int ctype = opt_.constraint_type;
+    GSFM_REQUIRE(ctype >= 0 && ctype <= 3, "GP: constraint_type out of range");
+    E_ = ctype != 0 ? prob->num_pairs : 0;
+    with_points_ = ctype != 1;  // ONLY_CAMERAS: AddPointToCameraConstraints is skipped (gp.cc:69-71)
+    if (ctype != 0) {
+      if (rig_) throw StatusError(GSFM_ERR_UNSUPPORTED, "GP: camera-to-camera constraints support trivial frames only (gp.cc:169-176)");
+      if (ctx_->comm.world > 1) throw StatusError(GSFM_ERR_UNSUPPORTED, "GP: camera-to-camera constraints are solved on one rank");
+      if (E_ <= 0) throw StatusError(GSFM_ERR_EMPTY_PROBLEM, "GP: no camera-to-camera constraints (gp.cc:41-45)");
+      GSFM_REQUIRE(prob->pair_i && prob->pair_j && prob->pair_dir, "GP: pair tables missing");
+    }
     std::vector<long> h_off;
     to_host(ctx_, h_off, reinterpret_cast<const long*>(prob->pt_offset), (size_t)P_ + 1, mem);
     GSFM_REQUIRE(h_off[0] == 0 && h_off[P_] == M_, "GP: pt_offset must start at 0 and end at num_obs");
@@ -1214,9 +1476,11 @@ class GpSolver final : public LmProblem {
     static const bool trace = std::getenv("GSFM_TRACE_SETUP") != nullptr;  // host-side phases of the setup on stderr
     const double ts0 = now_seconds();
     long fixed_obs = -1;
-    m_used_ = build_obs_graph(ctx_, ws->og, NI_, P_, M_, h_off, ws->off.get(), ws->cam.get(),
-                              opt_.min_num_view_per_track /* gp.cc:258 */, g_.g, &fixed_obs);
+    // ONLY_CAMERAS: no track is part of the problem — every track counts as too short, the sweeps see no observation
+    const int min_views = with_points_ ? opt_.min_num_view_per_track /* gp.cc:258 */ : 0x3fffffff;
+    m_used_ = build_obs_graph(ctx_, ws->og, NI_, P_, M_, h_off, ws->off.get(), ws->cam.get(), min_views, g_.g, &fixed_obs);
     if (ctx_->comm.rank != 0) fixed_obs = -1;  // one constant scale in the whole problem
+    if (E_ > 0) fixed_obs = -1;                // ... and with pairs it is the first PAIR's (they are added first, gp.cc:484-489)
     // camera-major copies of the per-observation inputs
     const long Mu = g_.g.Mu;
     ws->c_dir.ensure(3 * (size_t)M_ + 3);
@@ -1250,6 +1514,28 @@ class GpSolver final : public LmProblem {
       for (long p = 0; p < P_; ++p) used_here += (h_off[p + 1] - h_off[p] >= opt_.min_num_view_per_track) ? 1 : 0;
       for (int i = 0; i < NI_; ++i)  // a frame is constrained when one of its images carries a used observation
         if (h_coff[i + 1] > h_coff[i]) constrained[rig_ ? h_imf[i] : i] = 1;
+      if (E_ > 0) {
+        // InitializeRandomPositions (gp.cc:121-163) marks the frames of the valid pairs and of the kept tracks, whatever
+        // the constraint type
+        to_host(ctx_, h_pi_, prob->pair_i, (size_t)E_, mem);
+        to_host(ctx_, h_pj_, prob->pair_j, (size_t)E_, mem);
+        for (long e = 0; e < E_; ++e) {
+          GSFM_REQUIRE(h_pi_[e] >= 0 && h_pi_[e] < N_ && h_pj_[e] >= 0 && h_pj_[e] < N_ && h_pi_[e] != h_pj_[e],
+                       "GP: pair_i / pair_j out of range");
+          constrained[h_pi_[e]] = 1;
+          constrained[h_pj_[e]] = 1;
+        }
+        if (!with_points_) {
+          std::vector<int> h_cam;
+          to_host(ctx_, h_cam, prob->obs_cam, (size_t)M_, mem);
+          for (long p = 0; p < P_; ++p)
+            if (h_off[p + 1] - h_off[p] >= opt_.min_num_view_per_track)
+              for (long k = h_off[p]; k < h_off[p + 1]; ++k) {
+                GSFM_REQUIRE(h_cam[k] >= 0 && h_cam[k] < N_, "obs_cam out of range");
+                constrained[h_cam[k]] = 1;
+              }
+        }
+      }
       const int W = ctx_->comm.world;
       if (W > 1) {
         std::vector<double> h((size_t)N_ + W, 0.0);
@@ -1273,7 +1559,7 @@ class GpSolver final : public LmProblem {
       }
     }
     if (used_before > 0 && opt_.generate_random_points && opt_.optimize_points) rng.discard(6ull * (unsigned long long)used_before);
-    if (opt_.generate_random_points && opt_.optimize_points) {
+    if (opt_.generate_random_points && opt_.optimize_points && with_points_) {
       for (long p = 0; p < P_;) {  // runs of consecutive used tracks are drawn in one call
         if (h_off[p + 1] - h_off[p] < opt_.min_num_view_per_track) {
           ++p;
@@ -1389,6 +1675,49 @@ class GpSolver final : public LmProblem {
     g_.opt_s = opt_.optimize_scales ? 1 : 0;
     g_.lm_lo = opt_.lm.min_lm_diagonal;
     g_.lm_hi = opt_.lm.max_lm_diagonal;
+    // POINTS_AND_CAMERAS_BALANCED: the point-to-camera losses are scaled by reweight * #pairs / #tracks, where tracks.size()
+    // counts every track, kept or not (gp.cc:223-233)
+    g_.wpt = (E_ > 0 && ctype == 2 && P_ > 0) ? opt_.constraint_reweight_scale * (double)E_ / (double)P_ : 1.0;
+    q_ = GpPairs{};
+    if (E_ > 0) {
+      std::vector<int> row((size_t)N_ + 1, 0), ent(2 * (size_t)E_);
+      for (long e = 0; e < E_; ++e) {
+        row[h_pi_[e] + 1]++;
+        row[h_pj_[e] + 1]++;
+      }
+      for (int n = 0; n < N_; ++n) row[n + 1] += row[n];
+      std::vector<int> cur(row.begin(), row.end() - 1);
+      for (long e = 0; e < E_; ++e) {  // pairs in input order within every list: a fixed summation order
+        ent[cur[h_pi_[e]]++] = (int)e;
+        ent[cur[h_pj_[e]]++] = (int)e;
+      }
+      GSFM_HIP_CHECK(hipMemcpyAsync(ws->pr_i.ensure(E_), h_pi_.data(), (size_t)E_ * sizeof(int), hipMemcpyHostToDevice, s));
+      GSFM_HIP_CHECK(hipMemcpyAsync(ws->pr_j.ensure(E_), h_pj_.data(), (size_t)E_ * sizeof(int), hipMemcpyHostToDevice, s));
+      GSFM_HIP_CHECK(hipMemcpyAsync(ws->pr_row.ensure(N_ + 1), row.data(), (size_t)(N_ + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+      GSFM_HIP_CHECK(hipMemcpyAsync(ws->pr_ent.ensure(2 * (size_t)E_), ent.data(), 2 * (size_t)E_ * sizeof(int), hipMemcpyHostToDevice, s));
+      copy_in(ctx_, ws->pr_v.ensure(3 * (size_t)E_), prob->pair_dir, 3 * (size_t)E_, mem);
+      std::vector<double> ones((size_t)E_, 1.0);  // the pair scales start at 1 (gp.cc:186)
+      GSFM_HIP_CHECK(hipMemcpyAsync(ws->pr_s.ensure(E_), ones.data(), (size_t)E_ * sizeof(double), hipMemcpyHostToDevice, s));
+      GSFM_HIP_CHECK(hipStreamSynchronize(s));  // the host tables go out of scope
+      for (DevBuf<double>* b : {&ws->pr_sn, &ws->pr_w, &ws->pr_js, &ws->pr_qa, &ws->pr_qb}) b->ensure(E_);
+      gridPair_ = std::min(256, grid_for((size_t)E_, kBlock));
+      gridPairCam_ = std::min(kMaxApplySlots / 4, grid_for((size_t)N_, kBlock / 64));
+      ws->pr_part.ensure(3 * (size_t)gridPair_ + 8);
+      q_.E = E_;
+      q_.pi = ws->pr_i.get();
+      q_.pj = ws->pr_j.get();
+      q_.pv = ws->pr_v.get();
+      q_.row = ws->pr_row.get();
+      q_.ent = ws->pr_ent.get();
+      q_.fixed = 0;
+      q_.huber_a = opt_.thres_loss_function;
+      q_.opt_c = g_.opt_c;
+      q_.opt_s = g_.opt_s;
+      q_.lm_lo = g_.lm_lo;
+      q_.lm_hi = g_.lm_hi;
+      ps_ = ws->pr_s.get();
+      psn_ = ws->pr_sn.get();
+    }
     g1_ = g_;
     g1_.g.pass = 1;  // device view of the combine pass of the camera-major kernels
     c_ = ws->c.get();
@@ -1409,7 +1738,7 @@ class GpSolver final : public LmProblem {
     cg_.N = Np_;
     cg_.K = 0;
     cg_.nb_update = std::min(kCgUpdateBlocks, grid_for(Np_, kBlock));
-    cg_.nb_apply = gridCam_ + gridMulti_;  // + the delta slots of the combine pass (k_gp_phaseB)
+    cg_.nb_apply = gridCam_ + gridMulti_ + (E_ > 0 ? gridPairCam_ : 0);  // + the delta slots of the combine pass (k_gp_phaseB) and of the pair terms
     cg_.b = ws->rhs.get();
     cg_.x = ws->cg_x.get();
     cg_.r = ws->cg_r.get();
@@ -1425,8 +1754,8 @@ class GpSolver final : public LmProblem {
     cg_.zmir = rig_ ? nullptr : ws->cz.get();  // rigs: z reaches the (c | z) records through expand_z()
     cg_.zmir_stride = 6;
     cg_.zmir_off = 3;
-    if (rig_) {
-      cg_.nb_apply = gridCam_ + gridMulti_ + gridN_ + S_;  // + the damping shares of delta (k_rig_reduce_w: one per block)
+    if (rig_ || E_ > 0) {
+      if (rig_) cg_.nb_apply = gridCam_ + gridMulti_ + gridN_ + S_;  // + the damping shares of delta (k_rig_reduce_w: one per block)
       cg_.dpart = ws->dpart.ensure(std::max((size_t)2 * kMaxApplySlots, (size_t)cg_.nb_apply + 8));
     }
   }
@@ -1461,6 +1790,11 @@ class GpSolver final : public LmProblem {
       reduce_to_frames<1>(hcc_k, ws->hcc.get());
       reduce_to_frames<3>(gc_k, ws->gc.get());
     }
+    if (E_ > 0) {
+      hipLaunchKernelGGL(k_gpp_lin, dim3(gridPair_), dim3(kBlock), 0, s, q_, c_, (const double*)ps_, ws->pr_w.get(), ws->pr_part.get());
+      hipLaunchKernelGGL(k_gpp_cam_lin, dim3(gridPairCam_), dim3(kBlock), 0, s, q_, N_, c_, (const double*)ps_,
+                         (const double*)ws->pr_w.get(), ws->hcc.get(), ws->gc.get());
+    }
     if (ctx_->comm.world > 1) {
       allreduce_sum(ctx_, ws->hcc.get(), Np_);
       allreduce_sum(ctx_, ws->gc.get(), 3 * (size_t)Np_);
@@ -1470,6 +1804,7 @@ class GpSolver final : public LmProblem {
     if (gmx) hipLaunchKernelGGL(k_gp_absmax, dim3(gmx), dim3(kBlock), 0, s, (const double*)ws->gc.get(), nvec, ws->maxpart.ensure(64));
     hipLaunchKernelGGL(k_gp_finalize_lin, dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridTileP_, (const double*)ws->maxpart.ensure(64), gmx,
                        ws->scal.get());
+    if (E_ > 0) hipLaunchKernelGGL(k_gpp_fold_lin, dim3(1), dim3(kBlock), 0, s, (const double*)ws->pr_part.get(), gridPair_, ws->scal.get());
     double h[2];
     read_scalars(ws->scal.get(), h, 2, /*sum_first=*/1, /*max_from=*/1);
     *grad_max_norm = h[1];
@@ -1485,6 +1820,9 @@ class GpSolver final : public LmProblem {
                        ws->jss.get(), ws->c_jss.get());
     hipLaunchKernelGGL(k_gp_jacobi_cam, dim3(gridNp_), dim3(kBlock), 0, s, Np_, enabled ? 1 : 0, ws->hcc.get(),
                        ws->jsc.get());
+    if (E_ > 0)
+      hipLaunchKernelGGL(k_gpp_jacobi, dim3(gridPair_), dim3(kBlock), 0, s, q_, enabled ? 1 : 0, c_, (const double*)ws->pr_w.get(),
+                         ws->pr_js.get());
   }
 
   bool step(double radius, double* model_change, double* cand_cost, double* step_norm, double* x_norm,
@@ -1503,6 +1841,13 @@ class GpSolver final : public LmProblem {
     if (gridMulti_)
       hipLaunchKernelGGL(k_gp_build_cam, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, radius, ci_, s_, ws->ptb.get(),
                          ws->c_qa.get(), ws->c_qb.get(), gred_k, scc_k);
+    if (E_ > 0) {
+      hipLaunchKernelGGL(k_gpp_build, dim3(gridPair_), dim3(kBlock), 0, s, q_, radius, c_, (const double*)ps_,
+                         (const double*)ws->pr_w.get(), (const double*)ws->pr_js.get(), ws->pr_qa.get(), ws->pr_qb.get());
+      hipLaunchKernelGGL(k_gpp_cam_build, dim3(gridPairCam_), dim3(kBlock), 0, s, q_, N_, c_, (const double*)ps_,
+                         (const double*)ws->pr_w.get(), (const double*)ws->pr_qa.get(), (const double*)ws->pr_qb.get(),
+                         ws->gred.get(), ws->scc.get());
+    }
     if (rig_) {
       // reduced gradient of a frame = sum over its images; its block-Jacobi block = sum of the images' diagonal Schur
       // blocks (the cross blocks between two images of one frame are left to the PCG: it is a preconditioner)
@@ -1532,6 +1877,11 @@ class GpSolver final : public LmProblem {
     hipLaunchKernelGGL(k_gp_backsub, dim3(gridTileP_), dim3(kBlock), 0, s, g_, ci_, X_, s_, ws->wrob.get(),
                        ws->qa.get(), ws->qb.get(), ws->ptb.get(), dc_k, Xn_, sn_, ws->part.get());
     hipLaunchKernelGGL((k_sum_partials<3>), dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridTileP_, ws->scal.get());
+    if (E_ > 0) {
+      hipLaunchKernelGGL(k_gpp_backsub, dim3(gridPair_), dim3(kBlock), 0, s, q_, c_, (const double*)ps_, (const double*)ws->pr_w.get(),
+                         (const double*)ws->pr_qb.get(), (const double*)ws->cg_x.get(), psn_, ws->pr_part.get());
+      hipLaunchKernelGGL((k_gpp_fold_sum<3>), dim3(1), dim3(kBlock), 0, s, (const double*)ws->pr_part.get(), gridPair_, ws->scal.get(), 0, 1, 2);
+    }
     const int gridU = std::min(64, grid_for(n3, kBlock));
     double* part2 = ws->part.get() + kMaxBlocks * 3;
     hipLaunchKernelGGL(k_gp_cam_update, dim3(gridU), dim3(kBlock), 0, s, n3, c_, ws->cg_x.get(), cn_, part2);
@@ -1540,6 +1890,10 @@ class GpSolver final : public LmProblem {
     if (rig_) expand_centres(cn_, cin_, /*also_cz=*/false);
     hipLaunchKernelGGL(k_gp_cost, dim3(gridM_), dim3(kBlock), 0, s, g_, cin_, Xn_, sn_, part3);
     hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(kBlock), 0, s, part3, gridM_, ws->scal.get() + 6);
+    if (E_ > 0) {
+      hipLaunchKernelGGL(k_gpp_cost, dim3(gridPair_), dim3(kBlock), 0, s, q_, (const double*)cn_, (const double*)psn_, ws->pr_part.get());
+      hipLaunchKernelGGL((k_gpp_fold_sum<1>), dim3(1), dim3(kBlock), 0, s, (const double*)ws->pr_part.get(), gridPair_, ws->scal.get(), 6, 6, 6);
+    }
     if (multi) {
       // track-local sums: model change, |dX|^2+|ds|^2, |X|^2+|s|^2 and the candidate cost
       allreduce_sum(ctx_, ws->scal.get(), 3);
@@ -1563,6 +1917,7 @@ class GpSolver final : public LmProblem {
     std::swap(ci_, cin_);  // (trivial rigs: the same two buffers)
     std::swap(X_, Xn_);
     std::swap(s_, sn_);
+    std::swap(ps_, psn_);
   }
 
   void write_back(const gsfm_gp_problem* prob, double* cam_center, double* pt_xyz) {
@@ -1706,15 +2061,18 @@ class GpSolver final : public LmProblem {
       if (rig_)
         hipLaunchKernelGGL(k_rig_reduce_w, dim3(gridN_ + S_), dim3(kBlock), 0, s, cg_, rg_, yscale, ws->wimg.get(), ws->dcam.get(),
                            gridCam_ + gridMulti_, gridN_);
+      if (E_ > 0)  // camera-to-camera terms on top of what the sweep wrote
+        hipLaunchKernelGGL(k_gpp_apply, dim3(gridPairCam_), dim3(kBlock), 0, s, q_, cg_, N_, (const double*)c_,
+                           (const double*)ws->pr_qa.get(), (const double*)ws->pr_qb.get(), gridCam_ + gridMulti_);
     };
     // second level for chain-like scenes (GpCoarseDev): replaces the deflation of the four global modes, which its coarse
     // space contains
     GpCoarseDev cs;
-    const bool coarse = coarse_on_ && !rig_ && g_.opt_c && N_ > kCgSingleMaxBlocks && coarse_setup(cs, apply);
+    const bool coarse = coarse_on_ && !rig_ && E_ == 0 && g_.opt_c && N_ > kCgSingleMaxBlocks && coarse_setup(cs, apply);
     // the gauge modes deflated from the PCG (CgDeflation, cg.hpp): trivial rigs, positions among the unknowns; skipped
     // while the solves are short anyway (defl_on_, below)
     CgDeflation defl;
-    if (!coarse && !rig_ && g_.opt_c && defl_on_ && N_ > kCgSingleMaxBlocks) {
+    if (!coarse && !rig_ && E_ == 0 && g_.opt_c && defl_on_ && N_ > kCgSingleMaxBlocks) {
       const size_t n3 = 3 * (size_t)N_;
       defl.k = 4;
       double* W = ws->defl_w.ensure(4 * n3);
@@ -1739,7 +2097,7 @@ class GpSolver final : public LmProblem {
     }
     // chain-like co-visibility shows as a solve that is still running after kCoarseTrigger iterations: it is abandoned there,
     // and this and the later solves of the LM problem get the second-level preconditioner (GpCoarseDev)
-    const bool may_switch = !coarse && coarse_ok_ && !coarse_on_ && !rig_ && g_.opt_c && N_ > kCgSingleMaxBlocks &&
+    const bool may_switch = !coarse && coarse_ok_ && !coarse_on_ && !rig_ && E_ == 0 && g_.opt_c && N_ > kCgSingleMaxBlocks &&
                             opt_.lm.pcg_max_iterations > kCoarseTrigger;
     const long iters0 = cg_solve<3, false>(ctx_, cg_, tol, may_switch ? kCoarseTrigger : opt_.lm.pcg_max_iterations, apply,
                                            defl.k ? &defl : nullptr, &pcg_hint_, [&](int par) {
@@ -1772,6 +2130,12 @@ class GpSolver final : public LmProblem {
   long P_ = 0, M_ = 0, m_used_ = 0;
   int gridP_ = 1, gridN_ = 1, gridM_ = 1, gridCam_ = 1, gridMulti_ = 0, gridTile_ = 1, gridTileP_ = 1;
   bool defl_on_ = true;  // deflate the next reduced solve (short solves run plain)
+  long E_ = 0;                 // camera-to-camera constraints (constraint_type != ONLY_POINTS)
+  bool with_points_ = true;    // false: ONLY_CAMERAS
+  GpPairs q_{};
+  double *ps_ = nullptr, *psn_ = nullptr;  // pair scales: current, candidate
+  std::vector<int> h_pi_, h_pj_;
+  int gridPair_ = 1, gridPairCam_ = 1;
   bool coarse_on_ = false, coarse_ok_ = true;  // second-level preconditioner (GpCoarseDev): on after a long solve; ok until E fails
   double* cs_einv_ = nullptr;
   int coarse_probes_ = 12;
@@ -1785,15 +2149,17 @@ class GpSolver final : public LmProblem {
 int gp_solve_impl(gsfm_ctx* ctx, const gsfm_gp_problem* prob, const gsfm_gp_options* opt, double* cam_center,
                   double* pt_xyz, gsfm_report* rep) {
   GSFM_REQUIRE(prob && opt && cam_center && pt_xyz, "GP: null argument");
-  if (opt->constraint_type != 0)
-    throw StatusError(GSFM_ERR_UNSUPPORTED, "GP: only ONLY_POINTS is implemented (the mode glomap mapper accepts)");
+  GSFM_REQUIRE(opt->constraint_type >= 0 && opt->constraint_type <= 3, "GP: constraint_type out of range");
   if (prob->num_cams <= 0) throw StatusError(GSFM_ERR_EMPTY_PROBLEM, "GP: no images");   // gp.cc:37-40
-  if (prob->num_pts <= 0 || prob->num_obs <= 0) throw StatusError(GSFM_ERR_EMPTY_PROBLEM, "GP: no tracks");  // gp.cc:46-50
+  if (opt->constraint_type != 0 && prob->num_pairs <= 0)
+    throw StatusError(GSFM_ERR_EMPTY_PROBLEM, "GP: no camera-to-camera constraints");  // gp.cc:41-45
+  if (opt->constraint_type != 1 /* ONLY_CAMERAS */ && (prob->num_pts <= 0 || prob->num_obs <= 0))
+    throw StatusError(GSFM_ERR_EMPTY_PROBLEM, "GP: no tracks");  // gp.cc:46-50
   const double t0 = now_seconds();
   GSFM_HIP_CHECK(hipSetDevice(ctx->device));
   GpSolver solver(ctx, *opt);
   solver.setup(prob, cam_center, pt_xyz);
-  if (solver.used_observations() == 0 && ctx->comm.world == 1)
+  if (solver.used_observations() == 0 && ctx->comm.world == 1 && opt->constraint_type != 1)
     throw StatusError(GSFM_ERR_EMPTY_PROBLEM, "GP: no track with enough views");
   const double t1 = now_seconds();
   const int rc = lm_minimize(solver, opt->lm, rep);
@@ -1825,6 +2191,7 @@ extern "C" void gsfm_gp_options_default(gsfm_gp_options* o) {
   o->min_num_view_per_track = 3;
   o->seed = 1;
   o->constraint_type = 0;
+  o->constraint_reweight_scale = 1.0;  // global_positioning.h:40-41
 }
 
 extern "C" int gsfm_gp_solve(gsfm_ctx* ctx, const gsfm_gp_problem* prob, const gsfm_gp_options* opt,
@@ -1866,6 +2233,12 @@ extern "C" int gsfm_gp_solve(gsfm_ctx* ctx, const gsfm_gp_problem* prob, const g
     GSFM_DUMP_OPT(dump, opt, min_num_view_per_track);
     GSFM_DUMP_OPT(dump, opt, seed);
     GSFM_DUMP_OPT(dump, opt, constraint_type);
+    GSFM_DUMP_OPT(dump, opt, constraint_reweight_scale);
+    if (opt->constraint_type != 0 && prob->num_pairs > 0 && prob->pair_i && prob->pair_j && prob->pair_dir) {
+      dump.array("pair_i", prob->pair_i, {(int64_t)prob->num_pairs}, prob->mem);
+      dump.array("pair_j", prob->pair_j, {(int64_t)prob->num_pairs}, prob->mem);
+      dump.array("pair_dir", prob->pair_dir, {(int64_t)prob->num_pairs, 3}, prob->mem);
+    }
   }
   const int rc = guarded(ctx, report, [&] { return gp_solve_impl(ctx, prob, opt, cam_center_inout, pt_xyz_inout, report); });
   if (dumping) {

@@ -119,7 +119,8 @@ class GlobalPositionerOptions:
     optimize_scales: bool = True
     min_num_view_per_track: int = 3
     seed: int = 1
-    constraint_type: int = 0  # ONLY_POINTS
+    constraint_type: int = 0  # ONLY_POINTS, 1 = ONLY_CAMERAS, 2 = POINTS_AND_CAMERAS_BALANCED, 3 = POINTS_AND_CAMERAS
+    constraint_reweight_scale: float = 1.0  # POINTS_AND_CAMERAS_BALANCED only (global_positioning.h:40-41)
     thres_loss_function: float = 1e-1
     solver_options: SolverOptions = field(default_factory=lambda: SolverOptions(max_num_iterations=100))
 
@@ -132,6 +133,7 @@ class GlobalPositionerOptions:
         ).split():
             setattr(o, name, int(getattr(self, name)))
         o.thres_loss_function = self.thres_loss_function
+        o.constraint_reweight_scale = self.constraint_reweight_scale
         _fill_lm(o.lm, self.solver_options)
         return o
 
@@ -416,6 +418,10 @@ def gp_solve(p: GpProblem, options: Optional[GlobalPositionerOptions] = None, ct
         sens = np.array(p.sensor_center, dtype=np.float64, order="C", copy=True)
         c.num_sensors, c.image_sensor, c.image_sensor_rot = int(sens.shape[0]), _lib.ptr(ims), _lib.ptr(imr)
         c.sensor_center = _lib.ptr(sens)
+    if getattr(p, "pair_i", None) is not None:  # camera-to-camera constraints (constraint_type != ONLY_POINTS)
+        pi, pj, pd = _h(p.pair_i, np.int32), _h(p.pair_j, np.int32), _h(p.pair_dir, np.float64)
+        assert _mem_of(pi, pj, pd) == c.mem
+        c.num_pairs, c.pair_i, c.pair_j, c.pair_dir = int(pi.shape[0]), _lib.ptr(pi), _lib.ptr(pj), _lib.ptr(pd)
     rep = _lib.Report()
     rc = ctx.lib.gsfm_gp_solve(ctx.handle, C.byref(c), C.byref(opt), _lib.ptr(cen), _lib.ptr(xyz), C.byref(rep))
     report = rep.as_dict()

@@ -57,7 +57,8 @@ class RaProblem:
 
 @dataclass
 class GpProblem:
-    """Global-positioning problem, ONLY_POINTS, trivial rigs (reference: gp.cc:212-375).
+    """Global-positioning problem (reference: gp.cc:167-375): tracks and, for the constraint types other than ONLY_POINTS,
+    camera-to-camera pairs.
 
     Observations are stored track-major: track p owns observations
     [pt_offset[p], pt_offset[p+1]).
@@ -83,6 +84,11 @@ class GpProblem:
     image_sensor: Optional[np.ndarray] = None  # [I] int32, -1 = no block
     image_sensor_rot: Optional[np.ndarray] = None  # [I,3,3] f64
     sensor_center: Optional[np.ndarray] = None  # [S,3] f64 in/out: camera centre in rig coordinates, -R_cfr^T t_cfr
+    # Camera-to-camera constraints, gp.cc:167-210 (constraint_type != ONLY_POINTS, trivial frames): frame indices of the
+    # valid pairs' two images and pair_dir = -R_cam2_from_world^T t_cam2_from_cam1
+    pair_i: Optional[np.ndarray] = None  # [E] int32
+    pair_j: Optional[np.ndarray] = None  # [E] int32
+    pair_dir: Optional[np.ndarray] = None  # [E,3] f64
 
     @property
     def num_obs(self) -> int:

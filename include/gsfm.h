@@ -297,12 +297,17 @@ typedef struct gsfm_gp_options {
   int32_t optimize_scales;           /* 1 */
   int32_t min_num_view_per_track;    /* 3 */
   uint32_t seed;                     /* 1 */
-  int32_t constraint_type;           /* 0 = ONLY_POINTS (the only mode `mapper` accepts, gm.cc:145-149) */
+  int32_t constraint_type;           /* GlobalPositionerOptions::ConstraintType (global_positioning.h:11-20): 0 = ONLY_POINTS
+                                        (the only mode `mapper` accepts, gm.cc:145-149), 1 = ONLY_CAMERAS,
+                                        2 = POINTS_AND_CAMERAS_BALANCED, 3 = POINTS_AND_CAMERAS; 1-3 need gsfm_gp_problem.num_pairs > 0,
+                                        trivial frames and one rank */
+  double constraint_reweight_scale;  /* 1.0; POINTS_AND_CAMERAS_BALANCED only: the point-to-camera losses are scaled by
+                                        constraint_reweight_scale * num_pairs / num_pts (gp.cc:223-255) */
 } gsfm_gp_options;
 
 void gsfm_gp_options_default(gsfm_gp_options* opt);
 
-/* Tracks (ONLY_POINTS, trivial rigs). Observations are track-major: track p owns observations
+/* Tracks. Observations are track-major: track p owns observations
  * [pt_offset[p], pt_offset[p+1]).  Only observations of registered images with finite rays are
  * passed (gp.cc:279-292); tracks shorter than min_num_view_per_track are skipped by the library
  * (gp.cc:258) and their xyz left untouched. */
@@ -336,6 +341,15 @@ typedef struct gsfm_gp_problem {
   const int32_t* image_sensor;     /* [I] */
   const double* image_sensor_rot;  /* [I][9] */
   double* sensor_center;           /* [S][3] host, in/out */
+  /* Camera-to-camera constraints — BATAPairwiseDirectionError per valid image pair, AddCameraToCameraConstraints,
+   * global_positioning.cc:167-210 (read when constraint_type != 0): residual pair_dir - s (c_j - c_i) with a scale of its own
+   * per pair (start 1, lower bound 1e-5; the first pair's is the constant one, gp.cc:484-489) and a plain Huber loss.
+   * pair_i / pair_j: frame indices of image 1 / image 2 of the pair, pair_dir = -R_cam2_from_world^T t_cam2_from_cam1
+   * (gp.cc:195-197).  With ONLY_CAMERAS the tracks only mark which frames are re-drawn at random; pt_xyz is left untouched. */
+  int64_t num_pairs;               /* E */
+  const int32_t* pair_i;           /* [E] */
+  const int32_t* pair_j;           /* [E] */
+  const double* pair_dir;          /* [E][3] */
 } gsfm_gp_problem;
 
 /* cam_center_inout [N][3]: camera centres c = -R^T t (in: used when !generate_random_positions;

@@ -96,3 +96,59 @@ def test_gp_config3_scaled_properties(gsfm_ctx):
     assert np.median(synthetic.center_errors_after_sim3(c1, p.gt_center)) < 5e-3
     rc, c2, X2, rep2 = estimators.gp_solve(p, ctx=gsfm_ctx)
     assert _rel_diff(c2, c1) < 1e-6
+
+
+def _pairs(p, rng, num_succ=4, noise=0.0):
+    """Camera-to-camera directions as GlobalPositioner::AddCameraToCameraConstraints sees them (gp.cc:195-197):
+    -R_cw2^T t_21 = c_2 - c_1 in the scale of the two-view geometry (unit translation); each camera with its next
+    `num_succ` neighbours on the ring."""
+    N = p.num_cams
+    i = np.repeat(np.arange(N), num_succ)
+    j = (i + np.tile(np.arange(1, num_succ + 1), N)) % N
+    d = p.gt_center[j] - p.gt_center[i]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d += noise * rng.normal(size=d.shape)
+    return i.astype(np.int32), j.astype(np.int32), d / np.linalg.norm(d, axis=1, keepdims=True)
+
+
+@pytest.mark.parametrize("ctype", [ogp.ONLY_CAMERAS, ogp.POINTS_AND_CAMERAS_BALANCED, ogp.POINTS_AND_CAMERAS])
+@pytest.mark.parametrize("ncam,npts,noise,seed", [(24, 300, 0.0, 3), (60, 1500, 2e-3, 7)])
+def test_gp_constraint_types_match_oracle(gsfm_ctx, ctype, ncam, npts, noise, seed):
+    """The estimator's other constraint types (gp.cc:42-64, 167-210, 223-253: camera-to-camera BATA pairs with a scale per
+    pair, alone or next to the tracks, the point losses re-weighted in the BALANCED type) against the numpy oracle on the
+    same seeded inputs: same start (same draws, same cost to 1e-9), same final cost, centres within 1e-3 after Sim(3)."""
+    p = synthetic.make_gp_problem(num_cams=ncam, num_pts=npts, seed=seed, dir_noise=noise, outlier_ratio=0.02 if noise else 0.0)
+    p.pair_i, p.pair_j, p.pair_dir = _pairs(p, np.random.default_rng(seed), noise=noise)
+    kw = dict(constraint_type=int(ctype), constraint_reweight_scale=2.0)
+    ok, c_o, X_o, summ = _oracle_pairs(p, **kw)
+    assert ok
+    rc, c_g, X_g, rep = estimators.gp_solve(p, estimators.GlobalPositionerOptions(**kw), ctx=gsfm_ctx)
+    assert rc == 0
+    print("oracle", summ.iterations, summ.successful_steps, summ.initial_cost, summ.final_cost, "gpu", rep)
+    assert abs(rep["initial_cost"] - summ.initial_cost) <= 1e-9 * summ.initial_cost
+    if noise == 0.0:
+        assert rep["final_cost"] < 1e-10
+    else:
+        assert abs(rep["final_cost"] - summ.final_cost) <= 1e-3 * summ.final_cost
+    assert _rel_diff(c_g, c_o) < TOL_REL
+    assert _rel_diff(c_g, p.gt_center) < (1e-4 if noise == 0.0 else 0.1)
+    if ctype == ogp.ONLY_CAMERAS:  # points are not part of the problem: left as they came in
+        assert np.array_equal(X_g, p.pt_xyz)
+
+
+def _oracle_pairs(p, **kw):
+    opt = ogp.GlobalPositionerOptions(**kw)
+    return ogp.solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated, p.cam_center, p.pt_xyz, opt,
+                     pair_i=p.pair_i, pair_j=p.pair_j, pair_dir=p.pair_dir)
+
+
+def test_gp_constraint_types_reject_what_the_reference_rejects(gsfm_ctx):
+    p = synthetic.make_gp_problem(num_cams=10, num_pts=60, seed=4)
+    rc, *_ = estimators.gp_solve(p, estimators.GlobalPositionerOptions(constraint_type=1), ctx=gsfm_ctx)
+    assert rc == _lib_status("GSFM_ERR_EMPTY_PROBLEM")  # no pairs: gp.cc:41-45
+
+
+def _lib_status(name):
+    from glomap_amd import _lib
+
+    return {v: k for k, v in _lib.STATUS_NAMES.items()}[name]
