@@ -95,7 +95,8 @@ def to_problem(rec: FlatRecord):
                       a.get("obs_calibrated", np.ones(M, np.uint8)), a["cam_center"], a["pt_xyz"],
                       image_frame=a.get("image_frame"), image_offset=a.get("image_offset"),  # calibrated rigs
                       image_sensor=a.get("image_sensor"), image_sensor_rot=a.get("image_sensor_rot"),
-                      sensor_center=a.get("sensor_center"))  # unknown cam_from_rig centres
+                      sensor_center=a.get("sensor_center"),  # unknown cam_from_rig centres
+                      pair_i=a.get("pair_i"), pair_j=a.get("pair_j"), pair_dir=a.get("pair_dir"))  # camera-to-camera constraints
         opt = _fill(estimators.GlobalPositionerOptions(), o)
         _lm(opt.solver_options, o)
         return p, opt
@@ -134,6 +135,9 @@ def from_problem(p, options=None) -> FlatRecord:
         if p.sensor_center is not None:
             arrs.update(image_sensor=np.asarray(p.image_sensor, np.int32), image_sensor_rot=np.asarray(p.image_sensor_rot, np.float64),
                         sensor_center=np.asarray(p.sensor_center, np.float64))
+        if p.pair_i is not None:
+            arrs.update(pair_i=np.asarray(p.pair_i, np.int32), pair_j=np.asarray(p.pair_j, np.int32),
+                        pair_dir=np.asarray(p.pair_dir, np.float64))
         return FlatRecord("gp", {"num_cams": p.num_cams}, _opts(options), arrays=arrs)
     if isinstance(p, BaProblem):
         arrs = dict(pt_offset=np.asarray(p.pt_offset, np.int64), obs_cam=np.asarray(p.obs_cam, np.int32), obs_xy=np.asarray(p.obs_xy, np.float64),

@@ -80,8 +80,10 @@ class GlobalPositioner:
         from .estimators import GlobalPositionerOptions
 
         o = self.options_
-        if not images or not tracks or o.constraint_type != 0:
-            return False  # gp.cc:37-50; ONLY_POINTS is what the mapper accepts (global_mapper.cc:145-149)
+        ctype = int(o.constraint_type)
+        pairs_in = getattr(view_graph, "image_pairs", None) or {}
+        if not images or (not pairs_in and ctype != 0) or (not tracks and ctype != 1):
+            return False  # gp.cc:37-50
         fids = list(frames.keys())  # every frame: ConvertResults rewrites them all (gp.cc:566-572)
         node = {f: n for n, f in enumerate(fids)}
         N = len(fids)
@@ -90,9 +92,25 @@ class GlobalPositioner:
             return is_registered(im, frames) and not np.isnan(im.features_undist[feat]).any()
 
         tids, off, oimg, ofeat = _pack_tracks(images, frames, tracks, node, o.min_num_view_per_track, keep, keep_empty=True)
-        if not tids or not oimg:
+        if (not tids or not oimg) and ctype != 1:
             return False
         rigged = any(not has_trivial_frame(images[i], frames, rigs) for i in set(oimg))
+        # AddCameraToCameraConstraints (gp.cc:167-210): one pair per valid image pair whose two images are known, in the
+        # view graph's iteration order (the first one's scale is the constant one, gp.cc:484-489)
+        pair_i, pair_j, pair_dir = [], [], []
+        if ctype != 0:
+            if rigged or any(is_registered(im, frames) and not has_trivial_frame(im, frames, rigs) for im in images.values()):
+                return False  # "only trivial frames are supported for the camera to camera constraints" (gp.cc:169-176)
+            for pair in pairs_in.values():
+                if not pair.is_valid or pair.image_id1 not in images or pair.image_id2 not in images:
+                    continue
+                im1, im2 = images[pair.image_id1], images[pair.image_id2]
+                R_cw2 = _R(frames[im2.frame_id].rig_from_world.rotation)  # trivial frame: cam_from_world = rig_from_world
+                pair_i.append(node[im1.frame_id])
+                pair_j.append(node[im2.frame_id])
+                pair_dir.append(-(R_cw2.T @ np.asarray(pair.cam2_from_cam1.translation, dtype=np.float64)))  # gp.cc:195-197
+            if not pair_i:
+                return False
         R_f = {f: _R(frames[f].rig_from_world.rotation) for f in fids}
         img_idx: Dict[int, int] = {}
         image_frame, image_offset, image_rot, image_key, image_state = [], [], [], [], []
@@ -129,7 +147,7 @@ class GlobalPositioner:
         cen = np.zeros((N, 3))
         for f, n in node.items():  # c = -R^T t
             cen[n] = -R_f[f].T @ np.asarray(frames[f].rig_from_world.translation, dtype=np.float64)
-        xyz = np.array([tracks[t].xyz for t in tids], dtype=np.float64)
+        xyz = np.array([tracks[t].xyz for t in tids], dtype=np.float64).reshape(-1, 3)
         p = GpProblem(num_cams=N, num_pts=len(tids), pt_offset=off, obs_cam=obs_cam, obs_dir=dirs, obs_calibrated=cal,
                       cam_center=cen, pt_xyz=xyz)
         if rigged:
@@ -141,6 +159,13 @@ class GlobalPositioner:
                 p.sensor_center = np.zeros((len(sensor_ids), 3))
         # the raw-count rule is applied above; with 0 every packed track — the zero-length ones too — takes its random draw
         opt = GlobalPositionerOptions(**{**vars(o), "min_num_view_per_track": 0})
+        if pair_i:
+            p.pair_i, p.pair_j = np.asarray(pair_i, np.int32), np.asarray(pair_j, np.int32)
+            p.pair_dir = np.asarray(pair_dir, np.float64).reshape(-1, 3)
+            # POINTS_AND_CAMERAS_BALANCED weighs the point losses by reweight * #pairs / tracks.size() — every track, not
+            # only the packed ones (gp.cc:220-233); the library divides by the tracks it is given
+            if ctype == 2 and len(tracks) > 0:
+                opt.constraint_reweight_scale = o.constraint_reweight_scale * len(tids) / len(tracks)
         rc, cen_out, xyz_out, self.report = self.backend.gp_solve(p, opt)
         if rc != 0:
             return False
@@ -150,6 +175,8 @@ class GlobalPositioner:
             cfr = rigs[rid].MaybeSensorFromRig(cam_id)
             rigs[rid].SetSensorFromRig(cam_id, Rigid3d(np.asarray(cfr.rotation), -_R(cfr.rotation) @ self.report["sensor_center"][b]))
         for t, x in zip(tids, xyz_out):
+            if ctype == 1:
+                break  # ONLY_CAMERAS: AddPointToCameraConstraints never ran (gp.cc:69-71)
             tracks[t].xyz = np.array(x)
             if o.optimize_points and o.generate_random_points:
                 tracks[t].is_initialized = True  # gp.cc:261-264

@@ -701,21 +701,25 @@ class RotationEstimator {
 };
 
 // ---------------------------------------------------------------------------------------------
-// GlobalPositioner (global_positioning.h:56-137), ONLY_POINTS
+// GlobalPositioner (global_positioning.h:56-137), all four constraint types
 // ---------------------------------------------------------------------------------------------
 class GlobalPositioner {
  public:
   explicit GlobalPositioner(const glomap::GlobalPositionerOptions& options) : options_(options) {}
   glomap::GlobalPositionerOptions& GetOptions() { return options_; }
 
-  bool Solve(const glomap::ViewGraph& /*view_graph*/, std::unordered_map<rig_t, glomap::Rig>& rigs,
+  bool Solve(const glomap::ViewGraph& view_graph, std::unordered_map<rig_t, glomap::Rig>& rigs,
              std::unordered_map<camera_t, glomap::Camera>& cameras, std::unordered_map<frame_t, glomap::Frame>& frames,
              std::unordered_map<image_t, glomap::Image>& images, std::unordered_map<track_t, glomap::Track>& tracks) {
     gsfm_ctx* ctx = Context(options_.gpu_index);
     if (ctx == nullptr) return false;
-    if (images.empty() || tracks.empty()) return false;  // gp.cc:37-50
-    if (options_.constraint_type != glomap::GlobalPositionerOptions::ONLY_POINTS) return false;
+    const bool with_pairs = options_.constraint_type != glomap::GlobalPositionerOptions::ONLY_POINTS;
+    const bool with_points = options_.constraint_type != glomap::GlobalPositionerOptions::ONLY_CAMERAS;
+    if (images.empty()) return false;                                  // gp.cc:37-40
+    if (view_graph.image_pairs.empty() && with_pairs) return false;   // gp.cc:41-45
+    if (tracks.empty() && with_points) return false;                   // gp.cc:46-50
     const bool rigged = !detail::AllTrivial(images);  // calibrated multi-camera rigs: observations are keyed by image
+    if (with_pairs && rigged) return false;  // "only trivial frames are supported for the camera to camera constraints" (gp.cc:169-176)
     detail::FrameIndex fidx;
     for (auto& [fid, fr] : frames) fidx.Add(fid);  // every frame: ConvertResults rewrites all of them (gp.cc:566-572)
     auto keep = [](const glomap::Image& im, uint32_t f) {  // gp.cc:279-292
@@ -727,7 +731,24 @@ class GlobalPositioner {
                                               /*keep_empty=*/true);
     const int N = static_cast<int>(fidx.ids.size());
     const int64_t P = static_cast<int64_t>(tp.track_ids.size()), M = static_cast<int64_t>(tp.obs_cam.size());
-    if (P == 0 || M == 0) return false;
+    if ((P == 0 || M == 0) && with_points) return false;
+    // AddCameraToCameraConstraints (gp.cc:167-210): one BATA pair per valid image pair whose images are known, in the view
+    // graph's iteration order (the first one's scale is the constant one, gp.cc:484-489)
+    std::vector<int32_t> pair_i, pair_j;
+    std::vector<double> pair_dir;
+    if (with_pairs) {
+      for (const auto& [pid, pair] : view_graph.image_pairs) {
+        if (!pair.is_valid) continue;
+        auto i1 = images.find(pair.image_id1), i2 = images.find(pair.image_id2);
+        if (i1 == images.end() || i2 == images.end()) continue;
+        double t[3];
+        detail::RotateInv(i2->second.CamFromWorld().rotation, pair.cam2_from_cam1.translation, t);  // gp.cc:195-197
+        pair_i.push_back(fidx.of.at(i1->second.frame_id));
+        pair_j.push_back(fidx.of.at(i2->second.frame_id));
+        for (int j = 0; j < 3; ++j) pair_dir.push_back(-t[j]);
+      }
+      if (pair_i.empty()) return false;
+    }
     std::vector<double> dir(3 * static_cast<size_t>(M)), cen(3 * static_cast<size_t>(N)), xyz(3 * static_cast<size_t>(P));
     std::vector<uint8_t> cal(static_cast<size_t>(M));
     // known rigs (gp.cc:318-350, RigBATAPairwiseDirectionError with the rig scale constant at 1, :470-478): images become
@@ -803,6 +824,10 @@ class GlobalPositioner {
     o.optimize_scales = options_.optimize_scales;
     o.min_num_view_per_track = 0;  // the raw-count rule was applied by PackTracks; zero-length tracks take their draw
     o.seed = options_.seed;
+    o.constraint_type = static_cast<int32_t>(options_.constraint_type);
+    // POINTS_AND_CAMERAS_BALANCED weighs the point losses by reweight * #pairs / tracks.size() — every track, not only the
+    // packed ones (gp.cc:220-233); the library divides by the tracks it is given
+    o.constraint_reweight_scale = options_.constraint_reweight_scale * (tracks.empty() ? 1.0 : static_cast<double>(P) / static_cast<double>(tracks.size()));
     gsfm_gp_problem pr{};
     pr.mem = GSFM_MEM_HOST;
     pr.num_cams = N;
@@ -823,6 +848,12 @@ class GlobalPositioner {
         pr.sensor_center = sensor_center.data();
       }
     }
+    if (with_pairs) {
+      pr.num_pairs = static_cast<int64_t>(pair_i.size());
+      pr.pair_i = pair_i.data();
+      pr.pair_j = pair_j.data();
+      pr.pair_dir = pair_dir.data();
+    }
     gsfm_report rep;
     if (gsfm_gp_solve(ctx, &pr, &o, cen.data(), xyz.data(), &rep) != GSFM_OK) return false;
     for (size_t k = 0; k < sensor_ids.size(); ++k) {  // ConvertResults: centre -> translation, t = -R c (gp.cc:576-582)
@@ -839,7 +870,7 @@ class GlobalPositioner {
       pose.translation = decltype(pose.translation)(-t[0], -t[1], -t[2]);
       fr.SetRigFromWorld(pose);
     }
-    for (int64_t p = 0; p < P; ++p) {  // every packed track passed the raw-count rule (gp.cc:258)
+    for (int64_t p = 0; p < P && with_points; ++p) {  // every packed track passed the raw-count rule (gp.cc:258)
       auto& tr = tracks.at(tp.track_ids[p]);
       tr.xyz = decltype(tr.xyz)(xyz[3 * p], xyz[3 * p + 1], xyz[3 * p + 2]);
       if (options_.optimize_points && options_.generate_random_points) tr.is_initialized = true;  // gp.cc:261-264

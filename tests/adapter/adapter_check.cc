@@ -142,6 +142,48 @@ int main() {
   if (std::fabs(ratio / ratio_ref - 1.0) > 1e-3) return std::printf("GP ratio %.6f vs %.6f\n", ratio, ratio_ref), 1;
   for (int n = 0; n < N; ++n) images[n].frame_ptr = &frames[n];
 
+  // 2b) the other constraint types (gp.cc:55-71, 167-210): camera-to-camera BATA pairs from the view graph's relative
+  //     translations (unit length, exact), alone and next to the tracks
+  {
+    auto vg_t = vg;
+    for (auto& [pid, pr] : vg_t.image_pairs) {
+      const int i = (int)pr.image_id1, j = (int)pr.image_id2;
+      double ci[3], cj[3], t[3];
+      for (int a = 0; a < 3; ++a) {  // c = -R^T t
+        ci[a] = -(Rg[9 * i + a] * tg[3 * i] + Rg[9 * i + 3 + a] * tg[3 * i + 1] + Rg[9 * i + 6 + a] * tg[3 * i + 2]);
+        cj[a] = -(Rg[9 * j + a] * tg[3 * j] + Rg[9 * j + 3 + a] * tg[3 * j + 1] + Rg[9 * j + 6 + a] * tg[3 * j + 2]);
+      }
+      for (int a = 0; a < 3; ++a)  // t_21 = R_2 (c_1 - c_2)
+        t[a] = Rg[9 * j + 3 * a] * (ci[0] - cj[0]) + Rg[9 * j + 3 * a + 1] * (ci[1] - cj[1]) + Rg[9 * j + 3 * a + 2] * (ci[2] - cj[2]);
+      const double nrm = std::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+      pr.cam2_from_cam1.translation = mock_eigen::Vector3d(t[0] / nrm, t[1] / nrm, t[2] / nrm);
+    }
+    for (auto ctype : {GlobalPositionerOptions::ONLY_CAMERAS, GlobalPositionerOptions::POINTS_AND_CAMERAS_BALANCED,
+                       GlobalPositionerOptions::POINTS_AND_CAMERAS}) {
+      GlobalPositionerOptions gc;
+      gc.constraint_type = ctype;
+      gc.constraint_reweight_scale = 2.0;
+      gsfm_glomap::GlobalPositioner gpc(gc);
+      auto frames_c = frames;
+      for (int n = 0; n < N; ++n) images[n].frame_ptr = &frames_c[n];
+      auto tracks_c = tracks;
+      if (!gpc.Solve(vg_t, rigs, cameras, frames_c, images, tracks_c)) return std::printf("GP constraint type %d failed\n", (int)ctype), 1;
+      double a0[3], a1[3], a8[3];
+      center(frames_c[0], a0);
+      center(frames_c[1], a1);
+      center(frames_c[8], a8);
+      const double rc = dist(a0, a8) / dist(a0, a1);
+      if (std::fabs(rc / ratio_ref - 1.0) > 1e-3) return std::printf("GP constraint type %d: ratio %.6f vs %.6f\n", (int)ctype, rc, ratio_ref), 1;
+      if (ctype == GlobalPositionerOptions::ONLY_CAMERAS)  // the tracks are not part of the problem: untouched
+        for (auto& [tid, tr] : tracks_c)
+          if (tr.xyz[0] != tracks[tid].xyz[0] || tr.is_initialized != tracks[tid].is_initialized) return std::printf("ONLY_CAMERAS touched a track\n"), 1;
+      GlobalPositionerOptions none = gc;  // no image pairs at all: refused (gp.cc:41-45)
+      ViewGraph empty;
+      if (gsfm_glomap::GlobalPositioner(none).Solve(empty, rigs, cameras, frames_c, images, tracks_c)) return std::printf("GP accepted an empty view graph\n"), 1;
+    }
+    for (int n = 0; n < N; ++n) images[n].frame_ptr = &frames[n];
+  }
+
   // 3) bundle adjustment from perturbed points: must reach (numerically) zero reprojection error.
   //    A posed frame that no track observes is added LAST (libstdc++ iterates it FIRST): the reference's gauge is the first
   //    frame that owns a parameter block (bundle_adjustment.cc:253-269), so exactly one OBSERVED frame must stay bit-identical

@@ -284,6 +284,7 @@ struct GlobalPositionerOptions : public OptimizationBaseOptions {
   int min_num_view_per_track = 3;
   unsigned seed = 1;
   ConstraintType constraint_type = ONLY_POINTS;
+  double constraint_reweight_scale = 1.0;
 };
 struct BundleAdjusterOptions : public OptimizationBaseOptions {
   bool optimize_rig_poses = false, optimize_rotations = true, optimize_translation = true, optimize_intrinsics = true,

@@ -29,7 +29,11 @@ class OracleBackend(RaOracleBackend):
             kw.update(image_frame=p.image_frame, image_offset=p.image_offset)
         if p.sensor_center is not None:
             kw.update(image_sensor=p.image_sensor, image_sensor_rot=p.image_sensor_rot, sensor_center=p.sensor_center)
-        ok, c, X, s = cpu.gp_solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated, p.cam_center, p.pt_xyz, oo, **kw)
+        if p.pair_i is not None:  # camera-to-camera constraints: the numpy oracle restates them (the C++ one does not)
+            ok, c, X, s = ogp.solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated, p.cam_center, p.pt_xyz, oo,
+                                    pair_i=p.pair_i, pair_j=p.pair_j, pair_dir=p.pair_dir)
+        else:
+            ok, c, X, s = cpu.gp_solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated, p.cam_center, p.pt_xyz, oo, **kw)
         rep = {"iterations": s.iterations, "final_cost": s.final_cost}
         if p.sensor_center is not None:
             rep["sensor_center"] = s.sensor_center
@@ -157,3 +161,28 @@ def test_bundle_adjuster_refuses_uncalibrated_sensors(make_backend):
     vg, rigs, cameras, frames, images, tracks, _, _ = make_rig_scene(True, pts=100)
     assert not mest.BundleAdjuster(estimators.BundleAdjusterOptions(), make_backend()).Solve(rigs, cameras, frames, images, tracks)
     assert not mest.GlobalPositioner(estimators.GlobalPositionerOptions(), make_backend()).Solve(vg, rigs, cameras, frames, images, tracks)
+
+
+@pytest.mark.parametrize("ctype", [1, 2, 3])  # ONLY_CAMERAS, POINTS_AND_CAMERAS_BALANCED, POINTS_AND_CAMERAS
+def test_global_positioner_constraint_types_on_a_trivial_scene(ctype, make_backend):
+    """GlobalPositioner::Solve with camera-to-camera constraints (gp.cc:55-71, 167-210) on scene containers: trivial frames,
+    rotations known, every valid image pair a BATA constraint built from cam2_from_cam1; noise-free, so the centres come
+    back exactly (same pin as the mapper tests: 1e-4 after a similarity alignment)."""
+    vg, rigs, cameras, frames, images, tracks, R_cw, c_gt = make_rig_scene(False, frames_n=12, cams=1, pts=300, seed=5)
+    assert all(rav.has_trivial_frame(im, frames, rigs) for im in images.values())
+    for i, im in images.items():  # rotations as rotation averaging would leave them
+        frames[im.frame_id].rig_from_world = Rigid3d(so3.rotmat_to_quat(R_cw[i][None])[0], np.zeros(3))
+    for (a, b), pr in vg.image_pairs.items():  # relative poses of the two-view geometry: unit translations
+        t = R_cw[b] @ (c_gt[a] - c_gt[b])
+        pr.cam2_from_cam1 = Rigid3d(np.asarray(pr.cam2_from_cam1.rotation), t / np.linalg.norm(t))
+    xyz0 = {t: np.array(tr.xyz) for t, tr in tracks.items()}
+    opt = estimators.GlobalPositionerOptions(constraint_type=ctype, constraint_reweight_scale=2.0)
+    eng = mest.GlobalPositioner(opt, make_backend())
+    assert eng.Solve(vg, rigs, cameras, frames, images, tracks)
+    assert eng.report["final_cost"] < 1e-10
+    _, c_fin = _image_poses(rigs, frames, images)
+    assert synthetic.center_errors_after_sim3(c_fin, c_gt).max() < 1e-4
+    if ctype == 1:  # the tracks are not part of the problem
+        assert all(np.array_equal(tracks[t].xyz, xyz0[t]) for t in tracks)
+    # what the reference refuses: no image pairs at all (gp.cc:41-45)
+    assert not mest.GlobalPositioner(opt, make_backend()).Solve(ViewGraph(), rigs, cameras, frames, images, tracks)

@@ -55,6 +55,7 @@ test_largest_component_unregisters_the_rest = cpu_policy.test_largest_component_
 # ---- RA -> GP -> BA on rig scenes ---------------------------------------------------------------------------------
 test_rig_scene_through_ra_gp_ba = cpu_mapper.test_rig_scene_through_ra_gp_ba
 test_bundle_adjuster_refuses_uncalibrated_sensors = cpu_mapper.test_bundle_adjuster_refuses_uncalibrated_sensors
+test_global_positioner_constraint_types_on_a_trivial_scene = cpu_mapper.test_global_positioner_constraint_types_on_a_trivial_scene
 
 
 def test_default_backend_is_the_gpu_library():
