@@ -29,7 +29,7 @@
 //   camera-major: coff[N+2], c_src[M], c_pt[M] i32, c_xy[M][2]                 static per solve
 //                 c_w[M] robust weights                                         per linearisation
 //   per track   : X[P][3] (+ candidate), ptH[P][9] = (H_pp, g_p), ptdiag[P][3], ptjs[P][3],
-//                 ptb[P][12] = (X, e, H_pp^-1) build record, ptrec[P][8] = (X, t_p, pad) PCG record
+//                 ptb[P][16] = (X, e, H_pp^-1, D_p, slot) build record (one 128-byte line), ptrec[P][8] = (X, t_p, pad) PCG record
 //   per camera  : q[N][4], t[N][3], camR[N][9] (+ candidates), cam_intr[N] i32, yi_part[N][8]
 //   per intr    : par[K][8] (+ candidate), intr_model[K] i32, intr_free[K] u8, intr_map[K][8] i8,
 //                 ioff[K+1], icams[N] (cameras grouped by intrinsics block)
@@ -69,6 +69,8 @@ struct BaDev {
 };
 
 // plane indices of the stored Jacobians
+constexpr int kPtbBa = 16;  // doubles per point build record: X (3) | e (3) | H_pp^-1 (6) | D_p (3) | slot in the constant camera's table (-1: not seen by it)
+
 constexpr int PL_A = 0;  // 6 pose columns
 constexpr int PL_B = 6;  // 3 point columns
 constexpr int PL_I = 9;  // F free-intrinsics columns, then the residual plane
@@ -450,17 +452,23 @@ __global__ void __launch_bounds__(kBlock)
     S3 H{hp[0], hp[1], hp[2], hp[3], hp[4], hp[5]};
     S3 Hi{0, 0, 0, 0, 0, 0};
     V3 e{0, 0, 0};
+    V3 D{0, 0, 0};
     if (g.opt_pts) {
-      H.xx += lm_damping(ptdiag[3 * p], ptjs[3 * p], radius, g.lm_lo, g.lm_hi);
-      H.yy += lm_damping(ptdiag[3 * p + 1], ptjs[3 * p + 1], radius, g.lm_lo, g.lm_hi);
-      H.zz += lm_damping(ptdiag[3 * p + 2], ptjs[3 * p + 2], radius, g.lm_lo, g.lm_hi);
+      D.x = lm_damping(ptdiag[3 * p], ptjs[3 * p], radius, g.lm_lo, g.lm_hi);
+      D.y = lm_damping(ptdiag[3 * p + 1], ptjs[3 * p + 1], radius, g.lm_lo, g.lm_hi);
+      D.z = lm_damping(ptdiag[3 * p + 2], ptjs[3 * p + 2], radius, g.lm_lo, g.lm_hi);
+      H.xx += D.x;
+      H.yy += D.y;
+      H.zz += D.z;
       Hi = inv3(H);
       e = mul(Hi, ld3(hp + 6));
     }
-    double* b = ptb + 12 * p;
+    double* b = ptb + kPtbBa * p;
     st3(b, Xp);
     st3(b + 3, e);
     b[6] = Hi.xx; b[7] = Hi.xy; b[8] = Hi.xz; b[9] = Hi.yy; b[10] = Hi.yz; b[11] = Hi.zz;
+    st3(b + 12, D);
+    b[15] = -1.0;  // k_ba_fixed_share marks the points the constant camera sees
     double* hc = pth + 6 * p;  // compact copy for phase A: consecutive tracks -> one coalesced 48-byte stream
     hc[0] = Hi.xx; hc[1] = Hi.xy; hc[2] = Hi.xz; hc[3] = Hi.yy; hc[4] = Hi.yz; hc[5] = Hi.zz;
     double* pr = ptrec + 8 * p;
@@ -511,7 +519,7 @@ __global__ void __launch_bounds__(kBlock)
     for (int k = cam_seg_k0(g.g, sg) + lane; k < cam_seg_k1(g.g, sg); k += 64) {
       const double w = c_w[k];
       if (w == 0.0) continue;
-      const double* b = ptb + 12 * (long)g.g.c_pt[k];
+      const double* b = ptb + kPtbBa * (long)g.g.c_pt[k];
       const V3 e = ld3(b + 3);
       const S3 Hi{b[6], b[7], b[8], b[9], b[10], b[11]};
       ObsGeom o;
@@ -1063,7 +1071,7 @@ __global__ void __launch_bounds__(kBlock)
       const long p = key;
       const V3 Xp = ld3(X + 3 * p);
       if (g.g.used[p] && g.opt_pts) {
-        const double* b = ptb + 12 * p;
+        const double* b = ptb + kPtbBa * p;
         dX = V3{0, 0, 0} - ld3(b + 3) - mul(S3{b[6], b[7], b[8], b[9], b[10], b[11]}, V3{acc[0], acc[1], acc[2]});
       }
       st3(Xn + 3 * p, Xp + dX);
@@ -1215,6 +1223,140 @@ __global__ void __launch_bounds__(kBlock) k_ba_defl_modes(int N, long n, const d
   }
 }
 
+// ---- A W of the gauge modes in closed form ------------------------------------------------------------------------------
+// The deflated modes (k_ba_defl_modes) are exact symmetries of the reprojection error: moving the cameras by W_j and the
+// points by m_j(p) — e_a, e_a x X_p, X_p for world translation, rotation, scale — leaves every residual unchanged to first
+// order, J_cam W_j + J_pt m_j = 0 per observation.  Hence, with u the unknowns of the reduced system (poses but the constant
+// one, intrinsics), F_p the constant camera's share J_pt^T w J_pt of H_p and D_p the point damping,
+//     H_uu W + H_up m = -r_u,   H_pu W + H_p m = F_p m      =>      S W = H_uu W - H_up (H_p + D_p)^-1 H_pu W
+//                                                                        = -r_u - H_up (H_p + D_p)^-1 (D_p + F_p) m
+// where r_u is non-zero only on the intrinsics of the constant camera and equals -sum_k J_i^T w J_pt m there.  Per
+// observation of camera n:   (A W_j)_u += J_u^T w J_pt g_j,   g_j = [n is the constant camera] m_j - H_pp^-1 (D_p + F_p) m_j
+// (H_pp^-1 = the damped inverse of the build record) — ONE camera-major sweep over the point build records instead of one
+// operator application per mode (7 x 340 us per deflated solve at configs[3]).  Needs optimised points (nothing is
+// eliminated otherwise) and intrinsics blocks that belong to one camera each (or none free): group sums are not formed here.
+
+// F_p of the points the constant camera sees: one thread per observation of that camera (camera-major slots
+// [k0, k1)); slot = k - k0, recorded in the point's build record.
+template <bool WIDE>
+__global__ void __launch_bounds__(kBlock)
+    k_ba_fixed_share(BaDev g, int k0, int k1, const double* __restrict__ camR, const double* __restrict__ t,
+                     const double* __restrict__ par, const double* __restrict__ c_w, double* __restrict__ ptb,
+                     double* __restrict__ ftab) {
+  const int n = g.fixed_cam;
+  const int ik = g.cam_intr[n];
+  const double* R9 = camR + 9 * (long)n;
+  for (int k = k0 + blockIdx.x * blockDim.x + threadIdx.x; k < k1; k += gridDim.x * blockDim.x) {
+    double* b = ptb + kPtbBa * (long)g.g.c_pt[k];
+    const double w = c_w[k];
+    ObsGeom o;
+    obs_geom<WIDE>(R9, t + 3 * (long)n, ld3(b), g.intr_model[ik], par + 8 * (long)ik, o);
+    ObsJac J;
+    build_jac(g, n, R9, o, J);
+    double* f = ftab + 6 * (long)(k - k0);
+    f[0] = w * (J.Jpt[0][0] * J.Jpt[0][0] + J.Jpt[1][0] * J.Jpt[1][0]);
+    f[1] = w * (J.Jpt[0][0] * J.Jpt[0][1] + J.Jpt[1][0] * J.Jpt[1][1]);
+    f[2] = w * (J.Jpt[0][0] * J.Jpt[0][2] + J.Jpt[1][0] * J.Jpt[1][2]);
+    f[3] = w * (J.Jpt[0][1] * J.Jpt[0][1] + J.Jpt[1][1] * J.Jpt[1][1]);
+    f[4] = w * (J.Jpt[0][1] * J.Jpt[0][2] + J.Jpt[1][1] * J.Jpt[1][2]);
+    f[5] = w * (J.Jpt[0][2] * J.Jpt[0][2] + J.Jpt[1][2] * J.Jpt[1][2]);
+    b[15] = (double)(k - k0);
+  }
+}
+
+template <bool ROT, bool WIDE, int F>
+__global__ void __launch_bounds__(kBlock)
+    k_ba_aw_modes(BaDev g, double yscale, const double* __restrict__ camR, const double* __restrict__ t,
+                  const double* __restrict__ par, const double* __restrict__ c_w, const double* __restrict__ ptb,
+                  const double* __restrict__ ftab, const double* __restrict__ dvec, const double* __restrict__ W,
+                  double* __restrict__ AW, long nvec) {
+  constexpr int NM = ROT ? 7 : 4;  // [3 translations | 3 rotations | scale] or [3 translations | scale]
+  constexpr int U = 6 + F;
+  constexpr int NACC = NM * U;
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (kBlock / 64);
+  for (int it = wave; it < cam_seg_count(g.g); it += nwaves) {
+    const int sg = cam_seg_index(g.g, it);
+    const int n = g.g.seg_cam[sg];
+    const int ik = g.cam_intr[n];
+    const int model = g.intr_model[ik];
+    const double* R9 = camR + 9 * (long)n;
+    const double* t3 = t + 3 * (long)n;
+    const double* pp = par + 8 * (long)ik;
+    const Map8 mp = load_map(g.intr_map + 8 * (long)ik);
+    const double own = n == g.fixed_cam ? 1.0 : 0.0;
+    double acc[NACC];
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) acc[j] = 0.0;
+    for (int k = cam_seg_k0(g.g, sg) + lane; k < cam_seg_k1(g.g, sg); k += 64) {
+      const double w = c_w[k];
+      if (w == 0.0) continue;
+      const double* b = ptb + kPtbBa * (long)g.g.c_pt[k];
+      const V3 Xp = ld3(b);
+      const S3 Hi{b[6], b[7], b[8], b[9], b[10], b[11]};
+      S3 B{b[12], 0.0, 0.0, b[13], 0.0, b[14]};  // D_p + F_p
+      const int slot = (int)b[15];
+      if (slot >= 0) {
+        const double* f = ftab + 6 * (long)slot;
+        B.xx += f[0]; B.xy += f[1]; B.xz += f[2]; B.yy += f[3]; B.yz += f[4]; B.zz += f[5];
+      }
+      ObsGeom o;
+      obs_geom<WIDE>(R9, t3, Xp, model, pp, o);
+      ObsJac J;
+      build_jac(g, n, R9, o, J);
+      double Jc[2][F > 0 ? F : 1];
+#pragma unroll
+      for (int j = 0; j < F; ++j) {
+        const int pm = mp.m[j];
+        Jc[0][j] = sel8(o.Jp[0], pm);
+        Jc[1][j] = sel8(o.Jp[1], pm);
+      }
+#pragma unroll
+      for (int j = 0; j < NM; ++j) {
+        V3 m;
+        if (j < 3) {
+          m = V3{j == 0 ? 1.0 : 0.0, j == 1 ? 1.0 : 0.0, j == 2 ? 1.0 : 0.0};
+        } else if (ROT && j < 6) {  // e_a x X_p
+          const int a = j - 3;
+          m = a == 0 ? V3{0.0, -Xp.z, Xp.y} : (a == 1 ? V3{Xp.z, 0.0, -Xp.x} : V3{-Xp.y, Xp.x, 0.0});
+        } else {
+          m = Xp;
+        }
+        const V3 gj = own * m - mul(Hi, mul(B, m));
+        const double q0 = w * (J.Jpt[0][0] * gj.x + J.Jpt[0][1] * gj.y + J.Jpt[0][2] * gj.z);
+        const double q1 = w * (J.Jpt[1][0] * gj.x + J.Jpt[1][1] * gj.y + J.Jpt[1][2] * gj.z);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[j * U + i] += J.Jpose[0][i] * q0 + J.Jpose[1][i] * q1;
+#pragma unroll
+        for (int i = 0; i < F; ++i) acc[j * U + 6 + i] += Jc[0][i] * q0 + Jc[1][i] * q1;
+      }
+    }
+    wave_allsum<NACC>(acc);
+    if (!cam_seg_total<NACC>(g.g, sg, acc, lane)) continue;
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < NM; ++j) {
+        double* out = AW + (size_t)j * nvec;
+        const double* wj = W + (size_t)j * nvec;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) out[6 * (long)n + i] = acc[j * U + i] + yscale * dvec[6 * (long)n + i] * wj[6 * (long)n + i];
+#pragma unroll
+        for (int i = 0; i < F; ++i) {
+          const int pm = mp.m[i];
+          if (pm >= 0) out[6 * (long)g.g.N + 8 * (long)ik + pm] = acc[j * U + 6 + i];
+        }
+      }
+    }
+  }
+}
+
+// flag[0] = 1 when two consecutive camera-major slots in [k0, k1) name the same point (a camera's list is in track order)
+__global__ void __launch_bounds__(kBlock) k_ba_dup_check(const int* __restrict__ c_pt, int k0, int k1, int* __restrict__ flag) {
+  for (int k = k0 + 1 + blockIdx.x * blockDim.x + threadIdx.x; k < k1; k += gridDim.x * blockDim.x)
+    if (c_pt[k] == c_pt[k - 1]) atomicOr(flag, 1);
+}
+
 struct BaWs {
   ObsGraphWs og;
   DevBuf<long> off;
@@ -1232,6 +1374,7 @@ struct BaWs {
   DevBuf<unsigned char> img_fixed, fmask;
   DevBuf<double> sens, Ri, Rin, ti, tin, diag_i, grad_i, gred_i, spose_i, dvec_i, zimg, wimg, ximg, lever, gram_i;
   DevBuf<double> defl_w, defl_aw, defl_b2, defl_part, defl_small, defl_cd;  // CgDeflation, cg.hpp
+  DevBuf<double> ftab;  // [observations of the constant camera][6]: its share of H_pp (k_ba_fixed_share)
   DevBuf<double> maxpart;
   static void destroy(void* p) { delete static_cast<BaWs*>(p); }
 };
@@ -1840,7 +1983,7 @@ class BaSolver final : public LmProblem {
     ws->Xn.ensure(3 * (size_t)P_ + 3);
     ws->parn.ensure(8 * (size_t)K_);
     ws->ptH.ensure(9 * (size_t)P_ + 9);
-    ws->ptb.ensure(12 * (size_t)P_ + 12);
+    ws->ptb.ensure(kPtbBa * (size_t)P_ + kPtbBa);
     ws->pth.ensure(6 * (size_t)P_ + 6);
     ws->ptrec.ensure(8 * (size_t)P_ + 8);
     for (DevBuf<double>* b : {&ws->ptdiag, &ws->ptjs}) b->ensure(3 * (size_t)P_ + 3);
@@ -1980,6 +2123,19 @@ class BaSolver final : public LmProblem {
     g_.lm_hi = opt_.lm.max_lm_diagonal;
     g1_ = g_;
     g1_.g.pass = 1;  // device view of the combine pass of the camera-major kernels (obsgraph.hpp)
+    aw_closed_ok_ = true;
+    if (g_.fixed_cam >= 0 && g_.fixed_cam < N_ && !rig_) {  // k_ba_aw_modes keeps ONE slot per point for the constant camera's share
+      const int k0 = ws->og.h_coff[g_.fixed_cam], k1 = ws->og.h_coff[g_.fixed_cam + 1];
+      if (k1 - k0 > 1) {
+        int* flag = ws->og.flag.ensure(4);
+        GSFM_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), s));
+        hipLaunchKernelGGL(k_ba_dup_check, dim3(grid_for((size_t)(k1 - k0), kBlock)), dim3(kBlock), 0, s, g_.g.c_pt, k0, k1, flag);
+        int* h = reinterpret_cast<int*>(ctx_->h_pinned + 512);
+        GSFM_HIP_CHECK(hipMemcpyAsync(h, flag, sizeof(int), hipMemcpyDeviceToHost, s));
+        GSFM_HIP_CHECK(hipStreamSynchronize(s));
+        aw_closed_ok_ = h[0] == 0;
+      }
+    }
     q_ = ws->q.get(); qn_ = ws->qn.get();
     t_ = ws->t.get(); tn_ = ws->tn.get();
     R_ = ws->camR.get(); Rn_ = ws->camRn.get();
@@ -2245,6 +2401,43 @@ class BaSolver final : public LmProblem {
       hipLaunchKernelGGL(k_ba_defl_modes, dim3(gridN_), dim3(kBlock), 0, s, N_, (long)n_, (const double*)Rk_, (const double*)tk_,
                          g_.fixed_cam, with_rot, W);
       defl.W = W;
+      // A W in closed form (k_ba_aw_modes): points optimised, every intrinsics block owned by one camera (or none free),
+      // the constant camera's observations found in one piece of the camera-major list
+      const bool no_closed = getenv("GSFM_BA_AW_APPLY") != nullptr;  // A/B and tests: form A W by operator applications (read per solve)
+      if (!no_closed && g_.opt_pts && (joint_ || F_ == 0) && aw_closed_ok_) {
+        GSFM_HIP_CHECK(hipMemsetAsync(defl.AW, 0, defl.k * n * sizeof(double), s));
+        const int fc = g_.fixed_cam;
+        const int k0 = fc >= 0 ? ws->og.h_coff[fc] : 0, k1 = fc >= 0 ? ws->og.h_coff[fc + 1] : 0;
+        double* ftab = ws->ftab.ensure(6 * (size_t)std::max(1, k1 - k0));
+        if (k1 > k0)
+          WIDE_LAUNCH((k_ba_fixed_share<WIDE>), dim3(grid_for((size_t)(k1 - k0), kBlock)), dim3(kBlock), 0, s, g_, k0, k1, Rk_, tk_,
+                      par_, ws->c_w.get(), ws->ptb.get(), ftab);
+        dispatch_f(F_, [&](auto Fc) {
+          constexpr int F = decltype(Fc)::value;
+          auto launch = [&](auto rot, const BaDev& gd, int grid) {
+            constexpr bool ROT = decltype(rot)::value;
+            WIDE_LAUNCH((k_ba_aw_modes<ROT, WIDE, F>), dim3(grid), dim3(kBlock), 0, s, gd, yscale, Rk_, tk_, par_, ws->c_w.get(),
+                        (const double*)ws->ptb.get(), (const double*)ftab, (const double*)ws->dvec.get(), (const double*)W,
+                        defl.AW, (long)n_);
+          };
+          if (with_rot) {
+            launch(std::true_type{}, g_, gridCam_);
+            if (gridMulti_) launch(std::true_type{}, g1_, gridMulti_);
+          } else {
+            launch(std::false_type{}, g_, gridCam_);
+            if (gridMulti_) launch(std::false_type{}, g1_, gridMulti_);
+          }
+        });
+        if (ctx_->comm.world > 1) allreduce_sum(ctx_, defl.AW, defl.k * n);
+        defl.aw_ready = defl.k;
+        // diagnostics: keep the closed-form products, let cg_solve form them by operator applications as well, compare below
+        if (getenv("GSFM_BA_AW_CHECK") != nullptr) {
+          aw_check_.resize(defl.k * n);
+          GSFM_HIP_CHECK(hipMemcpyAsync(aw_check_.data(), defl.AW, defl.k * n * sizeof(double), hipMemcpyDeviceToHost, s));
+          GSFM_HIP_CHECK(hipStreamSynchronize(s));
+          defl.aw_ready = 0;
+        }
+      }
     }
     const long iters = cg_solve<6, true>(ctx_, cg_, tol, opt_.lm.pcg_max_iterations, [&](int it) {
       // rigs: the sweeps run on per-image vectors (z_image = T_s z_frame) with a zero pose diagonal; everything else of
@@ -2285,8 +2478,24 @@ class BaSolver final : public LmProblem {
         hipLaunchKernelGGL(k_ba_rig_reduce_w, dim3(gridN_ + S_), dim3(kBlock), 0, s, cg_, rg_, yscale, ws->wimg.get(), ws->dvec.get(),
                            gridCam_ + gridK_ + gridMulti_, gridN_);
     }, defl.k ? &defl : nullptr, &pcg_hint_);
-    // deflation pays while a plain solve needs more than ~3 k iterations (iters includes the k applications for A W)
-    defl_on_ = defl.k ? iters - defl.k > defl.k : iters > 3 * 7;
+    if (!aw_check_.empty() && defl.k) {
+      std::vector<double> applied(aw_check_.size());
+      GSFM_HIP_CHECK(hipMemcpyAsync(applied.data(), defl.AW, applied.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+      GSFM_HIP_CHECK(hipStreamSynchronize(s));
+      for (int j = 0; j < defl.k; ++j) {
+        double dmax = 0.0, amax = 0.0;
+        long where = -1;
+        for (long i = 0; i < n_; ++i) {
+          const double a = applied[(size_t)j * n_ + i], d = std::fabs(a - aw_check_[(size_t)j * n_ + i]);
+          amax = std::max(amax, std::fabs(a));
+          if (d > dmax) dmax = d, where = i;
+        }
+        fprintf(stderr, "[gsfm ba] A W mode %d: max |closed - applied| = %.3e at %ld (max |applied| = %.3e)\n", j, dmax, where, amax);
+      }
+      aw_check_.clear();
+    }
+    // deflation pays while a plain solve needs more than ~3 k iterations (iters includes the applications that formed A W, if any)
+    defl_on_ = defl.k ? iters - (defl.k - defl.aw_ready) > defl.k : iters > 3 * 7;
     return iters;
   }
 
@@ -2303,6 +2512,8 @@ class BaSolver final : public LmProblem {
   double *Rk_ = nullptr, *Rkn_ = nullptr, *tk_ = nullptr, *tkn_ = nullptr;  // poses the sweeps see (frames or images)
   bool small_groups_ = false, joint_ = false;
   bool wide_ = false;  // some camera uses a fisheye / FOV model: the sweeps run their WIDE instances
+  std::vector<double> aw_check_;  // GSFM_BA_AW_CHECK: the closed-form products of the running solve
+  bool aw_closed_ok_ = true;  // false: a point is observed twice by the constant camera (k_ba_aw_modes keeps one slot per point)
   bool defl_on_ = true;  // deflate the next reduced solve (short solves run plain)
   int pcg_hint_ = 0;     // iteration count of the previous reduced solve (where cg_solve first reads the status back)
   long P_ = 0, M_ = 0, Mp_ = 0, m_used_ = 0;

@@ -183,3 +183,31 @@ def test_scene_level_bundle_adjuster_and_positioner(gsfm_ctx):
     cen = np.array([-so3.quat_to_rotmat(frames[n].rig_from_world.rotation).T @ frames[n].rig_from_world.translation for n in range(N)])
     assert synthetic.center_errors_after_sim3(cen, cg).max() < 1e-4
     assert abs(cameras[1].params[0] - 1200) < 1e-2 * 1200
+
+
+@pytest.mark.parametrize("kw,opts", [
+    (dict(), dict()),                                                   # one camera per image: joint 14 x 14 blocks, 7 modes
+    (dict(), dict(optimize_rotations=False)),                           # rotations frozen: 4 modes
+    (dict(shared_intrinsics=True), dict(optimize_intrinsics=False)),    # no free intrinsics
+])
+def test_ba_closed_form_gauge_products_equal_operator_applications(gsfm_ctx, kw, opts, monkeypatch):
+    """The deflated solves need A W for the gauge modes.  k_ba_aw_modes forms it in one camera-major sweep from the identity
+    J_cam W + J_pt m = 0 (ba.hip); GSFM_BA_AW_APPLY=1 forms it by one operator application per mode.  Same system, same
+    modes: the two runs must walk the same LM path to the same result, the closed form with fewer operator applications."""
+    p = synthetic.make_ba_problem(num_cams=150, num_pts=6000, seed=11, **kw)
+    o = estimators.BundleAdjusterOptions(**opts)
+    rc, q_c, t_c, X_c, intr_c, rep_c = estimators.ba_solve(p, o, ctx=gsfm_ctx)
+    assert rc == 0
+    monkeypatch.setenv("GSFM_BA_AW_APPLY", "1")
+    rc, q_a, t_a, X_a, intr_a, rep_a = estimators.ba_solve(p, o, ctx=gsfm_ctx)
+    assert rc == 0
+    print("closed", rep_c["iterations"], rep_c["linear_iterations"], rep_c["final_cost"], "applied", rep_a["iterations"],
+          rep_a["linear_iterations"], rep_a["final_cost"])
+    assert rep_c["iterations"] == rep_a["iterations"]
+    assert abs(rep_c["final_cost"] - rep_a["final_cost"]) <= 1e-9 * rep_a["final_cost"] + 1e-12
+    # poses to the tolerance of the reduced solves (1e-6) — the scale of the scene is a free gauge of bundle adjustment, and
+    # what two solves leave along it differs at that level (tools/exp_ba_aw_check.py with GSFM_BA_AW_CHECK=1 compares the
+    # products themselves: 1e-13 relative)
+    assert np.abs(q_c - q_a).max() < 1e-6 and np.abs(t_c - t_a).max() < 1e-5 * (1 + np.abs(t_a).max())
+    assert np.abs(intr_c - intr_a).max() < 1e-4
+    assert rep_c["linear_iterations"] < rep_a["linear_iterations"]  # the deflated solves did not pay for A W
