@@ -116,6 +116,8 @@ def main():
     else:
         comm_init(ctx, dist, rank, world)
         out = bench_ba(**env)
+    if world > 1 and isinstance(out.get("config"), dict):
+        out["config"].setdefault("transport", getattr(ctx, "_transport", None))
     if rank == 0:
         emit_result(out)
     if dist is not None:
