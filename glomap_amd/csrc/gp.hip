@@ -1,9 +1,10 @@
 // gp.hip — global positioning (translation averaging) on MI355X (gfx950).
 //
-// Replaces GlobalPositioner::Solve (glomap/estimators/global_positioning.cc:28-93) for the mode
-// `glomap mapper` uses: ONLY_POINTS (global_mapper.cc:145-149) — trivial rigs, calibrated rigs
-// (RigBATAPairwiseDirectionError: a constant per-image offset) and sensors whose cam_from_rig translation is
-// unknown (RigUnknownBATAPairwiseDirectionError: centre blocks behind the frames); see "calibrated rigs" below.
+// Replaces GlobalPositioner::Solve (glomap/estimators/global_positioning.cc:28-93).  The mode `glomap mapper` uses is
+// ONLY_POINTS (global_mapper.cc:145-149) — trivial rigs, calibrated rigs (RigBATAPairwiseDirectionError: a constant
+// per-image offset) and sensors whose cam_from_rig translation is unknown (RigUnknownBATAPairwiseDirectionError: centre
+// blocks behind the frames); see "calibrated rigs" below.  The estimator's other constraint types (ONLY_CAMERAS,
+// POINTS_AND_CAMERAS[_BALANCED]: camera-to-camera BATA pairs, gp.cc:167-210) are the GpPairs section.
 //   residual   BATAPairwiseDirectionError (cost_function.h:15-41):  r_k = v_k - s_k (X_p - c_i)
 //   unknowns   camera centres c_i (3), points X_p (3), one scale s_k >= 1e-5 per observation
 //   loss       Huber(0.1); ScaledLoss(Huber, 0.5) for cameras without prior focal (gp.cc:242-255,313-316)

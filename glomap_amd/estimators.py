@@ -549,7 +549,9 @@ def _pack_tracks(images, frames, tracks, min_views, need_registered, node_of_fra
 
 
 class GlobalPositioner:
-    """GlobalPositioner (global_positioning.h:56-133), ONLY_POINTS, trivial rigs."""
+    """GlobalPositioner (global_positioning.h:56-133), trivial rigs.  ONLY_POINTS is handled here; the constraint types with
+    camera-to-camera pairs (and every rig configuration) by mapper_estimators.GlobalPositioner, to which Solve delegates
+    them."""
 
     def __init__(self, options: GlobalPositionerOptions, ctx=None):
         self.options_ = options
@@ -560,6 +562,13 @@ class GlobalPositioner:
         return self.options_
 
     def Solve(self, view_graph, rigs, cameras, frames, images, tracks) -> bool:
+        if self.options_.constraint_type != 0:
+            from . import mapper_estimators as mest
+
+            eng = mest.GlobalPositioner(self.options_, mest.GpuBackend(self.ctx))
+            ok = eng.Solve(view_graph, rigs, cameras, frames, images, tracks)
+            self.report = eng.report
+            return ok
         if not images:
             return False  # gp.cc:37-40
         if not tracks:

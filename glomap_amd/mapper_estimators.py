@@ -1,8 +1,9 @@
 """Scene-level GlobalPositioner and BundleAdjuster for every rig configuration — the Python counterpart of the two
 classes in include/gsfm_glomap_adapter.hpp, next to rotation_averager.RotationEstimator:
 
-  GlobalPositioner.Solve   glomap/estimators/global_positioning.cc:28-93, ONLY_POINTS: trivial frames (BATA), calibrated
-                           rigs (RigBATA, :318-350), sensors whose cam_from_rig translation is NaN (RigUnknownBATA, :354-368)
+  GlobalPositioner.Solve   glomap/estimators/global_positioning.cc:28-93: trivial frames (BATA), calibrated rigs (RigBATA,
+                           :318-350), sensors whose cam_from_rig translation is NaN (RigUnknownBATA, :354-368); the constraint
+                           types with camera-to-camera pairs (:167-210; trivial frames only)
   BundleAdjuster.Solve     glomap/estimators/bundle_adjustment.cc:11-106: trivial frames, calibrated rigs (:147-160),
                            optimize_rig_poses (:161-179)
 

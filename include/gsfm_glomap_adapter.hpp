@@ -13,8 +13,9 @@
 // flatten the unordered_map containers into the SoA problems of include/gsfm.h, call the C ABI, write
 // the results back in place.  Scope = what `glomap mapper` exercises: trivial rigs and rigs whose
 // cam_from_rig is KNOWN (calibrated multi-camera rigs; BundleAdjuster also refines them with optimize_rig_poses),
-// 3-DoF rotation averaging, ONLY_POINTS positioning; anything else (unknown cam_from_rig, the 1-DoF gravity branch)
-// returns false after logging, mirroring the reference's own early returns (gra.cc:47-58, gm.cc:145-149).
+// 3-DoF and gravity-aligned rotation averaging, unknown cam_from_rig (cam blocks / centre blocks / optimize_rig_poses),
+// positioning with all four constraint types; what the reference itself refuses (gravity with uncalibrated rigs,
+// gra.cc:47-58; camera-to-camera constraints with non-trivial frames, gp.cc:169-176) returns false.
 //
 // NOTE: this header cannot be compiled in the libgsfm repository itself (GLOMAP / COLMAP / Eigen are
 // not vendored); tests/adapter/ compiles it against interface-shaped stand-ins of those headers.
