@@ -166,6 +166,7 @@ def load():
     if _LIB is None:
         lib = C.CDLL(str(build()))
         lib.orc_gp_solve.restype = C.c_int
+        lib.orc_gp_solve_pairs.restype = C.c_int
         lib.orc_ba_solve.restype = C.c_int
         lib.orc_ra_solve.restype = C.c_int
         lib.orc_num_threads.restype = C.c_int
@@ -258,9 +259,11 @@ def _summary(rep) -> CpuSummary:
 def gp_solve(num_cams, pt_offset, obs_cam, obs_dir, obs_calibrated, cam_center, pt_xyz,
              options: _gp.GlobalPositionerOptions | None = None, threads: int = 0, pcg_tol: float = 1e-14,
              pcg_max: int = 20000, order: int = 0, verbose: bool = False, image_frame=None, image_offset=None,
-             image_sensor=None, image_sensor_rot=None, sensor_center=None, deflate=None):
+             image_sensor=None, image_sensor_rot=None, sensor_center=None, deflate=None, pair_i=None, pair_j=None,
+             pair_dir=None):
     """Same contract as oracle.gp.solve: returns (ok, cam_center [N,3], pt_xyz [P,3], CpuSummary); with unknown
-    cam_from_rig centres the summary carries the estimates as summary.sensor_center."""
+    cam_from_rig centres the summary carries the estimates as summary.sensor_center.  Camera-to-camera constraints
+    (options.constraint_type != ONLY_POINTS): pair_i / pair_j [E], pair_dir [E,3] as in oracle.gp.solve."""
     opt = options or _gp.GlobalPositionerOptions()
     lib = load()
     o = _GpOptions()
@@ -281,13 +284,23 @@ def gp_solve(num_cams, pt_offset, obs_cam, obs_dir, obs_calibrated, cam_center, 
     ims = None if image_sensor is None else np.ascontiguousarray(image_sensor, dtype=np.int32)
     imr = None if image_sensor is None else np.ascontiguousarray(image_sensor_rot, dtype=np.float64)
     sc = None if image_sensor is None else np.array(sensor_center, dtype=np.float64, copy=True, order="C")
+    ctype = int(getattr(opt, "constraint_type", 0))
+    pi = pj = pd = None
+    if ctype != 0:
+        pi = np.ascontiguousarray(np.zeros(0) if pair_i is None else pair_i, dtype=np.int32)
+        pj = np.ascontiguousarray(np.zeros(0) if pair_j is None else pair_j, dtype=np.int32)
+        pd = np.ascontiguousarray(np.zeros((0, 3)) if pair_dir is None else pair_dir, dtype=np.float64)
     with _deflate_env(deflate):
-        rc = lib.orc_gp_solve(C.c_int32(int(num_cams)), C.c_int64(off.shape[0] - 1), _p(off, C.c_int64), _p(cam, C.c_int32),
-                              _p(v, C.c_double), None if cal is None else _p(cal, C.c_uint8), C.byref(o), _p(c, C.c_double),
-                              _p(X, C.c_double), C.byref(rep), C.c_int32(_threads(threads)),
-                              None if imf is None else _p(imf, C.c_int32), None if imo is None else _p(imo, C.c_double),
-                              C.c_int32(0 if sc is None else sc.shape[0]), None if ims is None else _p(ims, C.c_int32),
-                              None if imr is None else _p(imr, C.c_double), None if sc is None else _p(sc, C.c_double))
+        rc = lib.orc_gp_solve_pairs(
+            C.c_int32(int(num_cams)), C.c_int64(off.shape[0] - 1), _p(off, C.c_int64), _p(cam, C.c_int32),
+            _p(v, C.c_double), None if cal is None else _p(cal, C.c_uint8), C.byref(o), _p(c, C.c_double),
+            _p(X, C.c_double), C.byref(rep), C.c_int32(_threads(threads)),
+            None if imf is None else _p(imf, C.c_int32), None if imo is None else _p(imo, C.c_double),
+            C.c_int32(0 if sc is None else sc.shape[0]), None if ims is None else _p(ims, C.c_int32),
+            None if imr is None else _p(imr, C.c_double), None if sc is None else _p(sc, C.c_double),
+            C.c_int32(ctype), C.c_double(float(getattr(opt, "constraint_reweight_scale", 1.0))),
+            C.c_int64(0 if pi is None else pi.shape[0]), None if pi is None or pi.size == 0 else _p(pi, C.c_int32),
+            None if pj is None or pj.size == 0 else _p(pj, C.c_int32), None if pd is None or pd.size == 0 else _p(pd, C.c_double))
     s = _summary(rep)
     if rc == -5:
         s.usable = False

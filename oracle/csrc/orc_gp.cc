@@ -66,6 +66,17 @@ struct Gp : LmProblem {
   std::vector<int32_t> sobs, sown;
   OwnerLists bysens;
   OwnerLists bycam;
+  // camera-to-camera constraints (constraint_type != ONLY_POINTS; AddCameraToCameraConstraints, gp.cc:167-210):
+  // r_e = pv_e - s_e (c_j - c_i), a scale of its own per pair (ps), plain Huber; pair 0's scale is the constant one
+  // (the pairs are added before the tracks: gp.cc:484-489), no observation's then (fixed_obs = -1)
+  i64 E = 0;
+  i64 fixed_obs = 0;
+  std::vector<int32_t> pi, pj;
+  std::vector<double> pv, ps, ps2, pw, pjs, pqa, pqb;
+  Huber loss_pair;
+  inline V3 pair_d(i64 e, const std::vector<double>& cc) const { return ld3(&cc[3 * (i64)pj[e]]) - ld3(&cc[3 * (i64)pi[e]]); }
+  inline double mscale(i64 k) const { return k == fixed_obs ? 0.0 : ms; }
+  inline double mpair(i64 e) const { return e == 0 ? 0.0 : ms; }
   bool defl_on = true;  // ORC_DEFLATE experiment: deflate the next reduced solve
   Huber loss_cal, loss_unc;
   double mc, mx, ms;  // 1 / 0: optimize_positions / points / scales
@@ -114,15 +125,23 @@ struct Gp : LmProblem {
     return std::min(std::max(j2 * h, lm_lo), lm_hi) / (radius * j2);
   }
 
-  double cost_at(const std::vector<double>& cc, const std::vector<double>& XX, const std::vector<double>& ss) const {
+  double cost_at(const std::vector<double>& cc, const std::vector<double>& XX, const std::vector<double>& ss,
+                 const std::vector<double>& pss) const {
     const Gp* g = this;
-    return 0.5 * chunked_sum(M, [=, &cc, &XX, &ss](i64 k) {
+    double tot = chunked_sum(M, [=, &cc, &XX, &ss](i64 k) {
       const V3 d = g->dvec(k, cc, XX);
       const V3 r = ld3(g->v + 3 * k) - ss[k] * d;
       double r0, r1;
       (g->cal[k] ? g->loss_cal : g->loss_unc).eval(dot(r, r), r0, r1);
       return r0;
     });
+    for (i64 e = 0; e < E; ++e) {
+      const V3 r = ld3(&pv[3 * e]) - pss[e] * pair_d(e, cc);
+      double r0, r1;
+      loss_pair.eval(dot(r, r), r0, r1);
+      tot += r0;
+    }
+    return 0.5 * tot;
   }
 
   double linearize(double* gmax_out) override {
@@ -140,7 +159,7 @@ struct Gp : LmProblem {
       (cal[k] ? loss_cal : loss_unc).eval(dot(r, r), r0, r1);
       rho[k] = r0;
       w[k] = r1;
-      gs[k] = (k == 0 ? 0.0 : ms) * (-r1 * dot(d, r));  // the first scale is constant
+      gs[k] = mscale(k) * (-r1 * dot(d, r));  // the first scale is constant
     }
     const double cost = 0.5 * chunked_sum(M, [&](i64 k) { return rho[k]; });
     // point side: g_X = -sum w s r, h_X = sum w s^2  (track-major, serial inside a track)
@@ -201,11 +220,31 @@ struct Gp : LmProblem {
         for (int j = 0; j < 3; ++j) gc[3 * (N + sb) + j] = mc * accs[4 * sb + 1 + j];
       }
     }
-    double gmax = chunked_max(M, [&](i64 k) { return std::fabs(gs[k]); });
+    double pair_cost = 0.0, pair_gs = 0.0;
+    pw.resize(E);
+    for (i64 e = 0; e < E; ++e) {  // few pairs: serial, a fixed summation order
+      const V3 d = pair_d(e, c);
+      const V3 r = ld3(&pv[3 * e]) - ps[e] * d;
+      double r0, r1;
+      loss_pair.eval(dot(r, r), r0, r1);
+      pw[e] = r1;
+      pair_cost += r0;
+      pair_gs = std::max(pair_gs, std::fabs(mpair(e) * r1 * dot(d, r)));
+      const double ws = r1 * ps[e];
+      // d r / d c_i = +s I, d r / d c_j = -s I
+      hc[pi[e]] += mc * ws * ps[e];
+      hc[pj[e]] += mc * ws * ps[e];
+      for (int j = 0; j < 3; ++j) {
+        const double g = mc * ws * (&r.x)[j];
+        gc[3 * (i64)pi[e] + j] += g;
+        gc[3 * (i64)pj[e] + j] -= g;
+      }
+    }
+    double gmax = std::max(pair_gs, chunked_max(M, [&](i64 k) { return std::fabs(gs[k]); }));
     gmax = std::max(gmax, chunked_max(3 * (N + S), [&](i64 i) { return std::fabs(gc[i]); }));
     gmax = std::max(gmax, chunked_max(3 * P, [&](i64 i) { return std::fabs(gX[i]); }));
     *gmax_out = gmax;
-    return cost;
+    return cost + 0.5 * pair_cost;
   }
 
   void set_jacobi_scaling(bool enabled) override {
@@ -218,10 +257,16 @@ struct Gp : LmProblem {
 #pragma omp parallel for schedule(static)
       for (i64 k = 0; k < M; ++k) {
         const V3 d = dvec(k, c, X);
-        const double h = (k == 0 ? 0.0 : ms) * w[k] * dot(d, d);
+        const double h = mscale(k) * w[k] * dot(d, d);
         js[k] = 1.0 / (1.0 + std::sqrt(h));
       }
     }
+    pjs.assign(E, 1.0);
+    if (enabled)
+      for (i64 e = 0; e < E; ++e) {
+        const V3 d = pair_d(e, c);
+        pjs[e] = 1.0 / (1.0 + std::sqrt(mpair(e) * pw[e] * dot(d, d)));
+      }
     have_scale = true;
   }
 
@@ -258,6 +303,15 @@ struct Gp : LmProblem {
       a[1] += q.y;
       a[2] += q.z;
     });
+    for (i64 e = 0; e < E; ++e) {  // Q_e (z_i - z_j) on i, minus that on j
+      const V3 d = pair_d(e, c);
+      const V3 zz = mc * (ld3(&z[3 * (i64)pi[e]]) - ld3(&z[3 * (i64)pj[e]]));
+      const V3 q = pqa[e] * (zz - (pqb[e] * dot(d, zz)) * d);
+      for (int j = 0; j < 3; ++j) {
+        acc[3 * (i64)pi[e] + j] += (&q.x)[j];
+        acc[3 * (i64)pj[e] + j] -= (&q.x)[j];
+      }
+    }
 #pragma omp parallel for schedule(static)
     for (i64 n = 0; n < N; ++n)
       for (int j = 0; j < 3; ++j) out[3 * n + j] = mc * acc[3 * n + j] + dcam[n] * z[3 * n + j];
@@ -287,7 +341,7 @@ struct Gp : LmProblem {
     for (i64 k = 0; k < M; ++k) {
       const V3 d = dvec(k, c, X);
       const V3 r = ld3(v + 3 * k) - s[k] * d;
-      const double m = (k == 0 ? 0.0 : ms);
+      const double m = mscale(k);
       const double h = m * w[k] * dot(d, d);
       const double ht = h + damp(h, js[k], radius);
       hss[k] = ht;
@@ -386,6 +440,30 @@ struct Gp : LmProblem {
     };
     std::vector<double> acc(12 * (N + S));
     bycam.reduce<12>(acc.data(), rev, cam_block);
+    pqa.resize(E);
+    pqb.resize(E);
+    for (i64 e = 0; e < E; ++e) {
+      const V3 d = pair_d(e, c);
+      const V3 r = ld3(&pv[3 * e]) - ps[e] * d;
+      const double m = mpair(e);
+      const double h = m * pw[e] * dot(d, d);
+      const double beta = m * pw[e] / (h + damp(h, pjs[e], radius));
+      const double a = pw[e] * ps[e] * ps[e];
+      pqa[e] = a;
+      pqb[e] = beta;
+      const V3 q = (ps[e] * pw[e]) * (r - (beta * dot(d, r)) * d);
+      const double ab = a * beta;
+      const double Q[9] = {a - ab * d.x * d.x, -ab * d.x * d.y, -ab * d.x * d.z, -ab * d.x * d.y, a - ab * d.y * d.y, -ab * d.y * d.z,
+                           -ab * d.x * d.z,    -ab * d.y * d.z, a - ab * d.z * d.z};
+      for (int j = 0; j < 3; ++j) {
+        acc[12 * (i64)pi[e] + j] += (&q.x)[j];
+        acc[12 * (i64)pj[e] + j] -= (&q.x)[j];
+      }
+      for (int j = 0; j < 9; ++j) {
+        acc[12 * (i64)pi[e] + 3 + j] += Q[j];
+        acc[12 * (i64)pj[e] + 3 + j] += Q[j];
+      }
+    }
     if (S > 0) {  // sensor blocks: the same quantities through the tangent map Rf^T (gradient Rf g, block Rf B Rf^T)
       std::vector<double> accs(12 * S);
       bysens.reduce<12>(accs.data(), rev, [&](i64 ee, double* a) {
@@ -428,7 +506,7 @@ struct Gp : LmProblem {
     // constant, gp.cc:437-439), so the PCG drops them again when W^T A W cannot be inverted.
     const bool deflate = std::getenv("ORC_DEFLATE") != nullptr;  // (read per solve: oracle.cpu toggles it between legs)
     std::vector<std::vector<double>> W;
-    if (deflate && S == 0 && mc != 0.0 && defl_on) {  // like gp.hip: short solves run undeflated
+    if (deflate && S == 0 && E == 0 && mc != 0.0 && defl_on) {  // like gp.hip: short solves run undeflated
       W.assign(4, std::vector<double>(3 * N, 0.0));
       for (i64 n = 0; n < N; ++n)
         for (int a = 0; a < 3; ++a) {
@@ -459,14 +537,27 @@ struct Gp : LmProblem {
       const V3 d = dvec(k, c, X);
       const V3 r = ld3(v + 3 * k) - s[k] * d;
       const V3 e = mc * zcam(k, dc) - mx * ld3(&dX[3 * (i64)pt[k]]);
-      const double m = (k == 0 ? 0.0 : ms);
+      const double m = mscale(k);
       ds[k] = qb[k] * dot(d, r + s[k] * e);  // qb = m w / h~ss
       (void)m;
       // model: J delta = sqrt(w) (s e - m d ds), r~ = sqrt(w) r
       const V3 jd = s[k] * e - (m * ds[k]) * d;
       mterm[k] = w[k] * (dot(jd, r) + 0.5 * dot(jd, jd));
     }
-    *model_change = -chunked_sum(M, [&](i64 k) { return mterm[k]; });
+    double pair_model = 0.0, pair_sn = 0.0, pair_xn = 0.0;
+    ps2.resize(E);
+    for (i64 e = 0; e < E; ++e) {
+      const V3 d = pair_d(e, c);
+      const V3 r = ld3(&pv[3 * e]) - ps[e] * d;
+      const V3 ee = mc * (ld3(&dc[3 * (i64)pi[e]]) - ld3(&dc[3 * (i64)pj[e]]));
+      const double dse = pqb[e] * dot(d, r + ps[e] * ee);
+      const V3 jd = ps[e] * ee - (mpair(e) * dse) * d;
+      pair_model += pw[e] * (dot(jd, r) + 0.5 * dot(jd, jd));
+      ps2[e] = std::max(ps[e] + mpair(e) * dse, 1e-5);
+      pair_sn += (ps2[e] - ps[e]) * (ps2[e] - ps[e]);
+      pair_xn += ps[e] * ps[e];
+    }
+    *model_change = -(chunked_sum(M, [&](i64 k) { return mterm[k]; }) + pair_model);
     // candidate = Plus(x, delta), scales projected on their lower bound
     c2.resize(3 * (N + S));
     X2.resize(3 * P);
@@ -475,16 +566,16 @@ struct Gp : LmProblem {
 #pragma omp parallel for schedule(static)
     for (i64 i = 0; i < 3 * P; ++i) X2[i] = X[i] + mx * dX[i];
 #pragma omp parallel for schedule(static)
-    for (i64 k = 0; k < M; ++k) s2[k] = std::max(s[k] + (k == 0 ? 0.0 : ms) * ds[k], 1e-5);
+    for (i64 k = 0; k < M; ++k) s2[k] = std::max(s[k] + mscale(k) * ds[k], 1e-5);
     double sn = chunked_sum(3 * (N + S), [&](i64 i) { const double d = c2[i] - c[i]; return d * d; });
     sn += chunked_sum(3 * P, [&](i64 i) { const double d = X2[i] - X[i]; return d * d; });
     sn += chunked_sum(M, [&](i64 k) { const double d = s2[k] - s[k]; return d * d; });
     double xn = chunked_sum(3 * (N + S), [&](i64 i) { return c[i] * c[i]; });
     xn += chunked_sum(3 * P, [&](i64 i) { return X[i] * X[i]; });
     xn += chunked_sum(M, [&](i64 k) { return s[k] * s[k]; });
-    *step_norm = std::sqrt(sn);
-    *x_norm = std::sqrt(xn);
-    *cand_cost = cost_at(c2, X2, s2);
+    *step_norm = std::sqrt(sn + pair_sn);
+    *x_norm = std::sqrt(xn + pair_xn);
+    *cand_cost = cost_at(c2, X2, s2, ps2);
     bool finite = std::isfinite(sn);
     return finite;
   }
@@ -517,6 +608,7 @@ struct Gp : LmProblem {
     c.swap(c2);
     X.swap(X2);
     s.swap(s2);
+    ps.swap(ps2);
   }
 };
 
@@ -529,16 +621,22 @@ using orc::i64;
 // Arrays as gsfm_gp_problem (include/gsfm.h).  cam_center_inout [N][3], pt_xyz_inout [P][3].
 // Returns 0 when the solution is usable, -5 for an empty problem, -6 when not usable.
 // Known rigs: image_frame [I] / image_offset [I][3] (NULL = trivial rigs): obs_cam then indexes images.
-int orc_gp_solve(int32_t num_cams, i64 num_pts, const i64* pt_offset, const int32_t* obs_cam, const double* obs_dir,
-                 const uint8_t* obs_calibrated, const orc::GpOptionsC* o, double* cam_center_inout, double* pt_xyz_inout,
-                 orc::GpReport* rep, int32_t num_threads, const int32_t* image_frame, const double* image_offset,
-                 int32_t num_sensors, const int32_t* image_sensor, const double* image_sensor_rot,
-                 double* sensor_center_inout) {
+// Camera-to-camera constraints (constraint_type 1 = ONLY_CAMERAS, 2 = POINTS_AND_CAMERAS_BALANCED, 3 = POINTS_AND_CAMERAS;
+// global_positioning.h:11-20, gp.cc:42-71, 167-255): pair_i / pair_j [E] frame indices, pair_dir [E][3]; trivial frames only.
+int orc_gp_solve_pairs(int32_t num_cams, i64 num_pts, const i64* pt_offset, const int32_t* obs_cam, const double* obs_dir,
+                       const uint8_t* obs_calibrated, const orc::GpOptionsC* o, double* cam_center_inout, double* pt_xyz_inout,
+                       orc::GpReport* rep, int32_t num_threads, const int32_t* image_frame, const double* image_offset,
+                       int32_t num_sensors, const int32_t* image_sensor, const double* image_sensor_rot,
+                       double* sensor_center_inout, int32_t constraint_type, double constraint_reweight_scale, i64 num_pairs,
+                       const int32_t* pair_i, const int32_t* pair_j, const double* pair_dir) {
   using namespace orc;
   const double t0 = omp_get_wtime();
   if (num_threads > 0) omp_set_num_threads(num_threads);
   Gp g;
   g.N = num_cams;
+  const bool with_pairs = constraint_type != 0;
+  const bool with_points = constraint_type != 1;
+  if (with_pairs && (image_frame || num_pairs <= 0 || !pair_i || !pair_j || !pair_dir)) return with_pairs && num_pairs <= 0 ? -5 : -7;
   g.S = (image_frame && num_sensors > 0 && image_sensor && image_sensor_rot && sensor_center_inout) ? num_sensors : 0;
   if (g.S > 0 && !o->optimize_positions) return -7;
   std::vector<i64> used_pts;
@@ -576,12 +674,40 @@ int orc_gp_solve(int32_t num_cams, i64 num_pts, const i64* pt_offset, const int3
   g.M = (i64)g.cam.size();
   std::memset(rep, 0, sizeof *rep);
   rep->threads = omp_get_max_threads();
-  if (g.M == 0) return -5;
+  if (g.M == 0 && with_points) return -5;
+  // InitializeRandomPositions (gp.cc:121-163) marks the frames of the valid pairs and of the kept tracks, whatever the type
+  std::vector<uint8_t> constrained(g.N, 0);
+  for (i64 k = 0; k < g.M; ++k) constrained[g.cam[k]] = 1;
+  if (with_pairs) {
+    g.E = num_pairs;
+    g.fixed_obs = -1;
+    g.pi.assign(pair_i, pair_i + num_pairs);
+    g.pj.assign(pair_j, pair_j + num_pairs);
+    g.pv.assign(pair_dir, pair_dir + 3 * num_pairs);
+    g.ps.assign(num_pairs, 1.0);
+    for (i64 e = 0; e < num_pairs; ++e) {
+      if (pair_i[e] < 0 || pair_i[e] >= num_cams || pair_j[e] < 0 || pair_j[e] >= num_cams) return -1;
+      constrained[pair_i[e]] = 1;
+      constrained[pair_j[e]] = 1;
+    }
+  }
+  if (!with_points) {  // AddPointToCameraConstraints is skipped (gp.cc:69-71): no draws for the points, no residuals
+    g.cam.clear();
+    g.pt.clear();
+    g.vbuf.clear();
+    g.cal.clear();
+    g.poff.assign(1, 0);
+    used_pts.clear();
+    g.P = g.M = 0;
+  }
   g.v = g.vbuf.data();
   g.bycam.build(g.N, g.M, g.cam.data());
   if (g.S > 0) g.bysens.build(g.S, (i64)g.sobs.size(), g.sown.data());
-  g.loss_cal = {o->thres_loss_function, 1.0};
-  g.loss_unc = {o->thres_loss_function, 0.5};
+  // POINTS_AND_CAMERAS_BALANCED: the point-to-camera losses are scaled by reweight * #pairs / tracks.size() (gp.cc:223-255)
+  const double wpt = (constraint_type == 2 && num_pairs > 0 && num_pts > 0) ? constraint_reweight_scale * (double)num_pairs / (double)num_pts : 1.0;
+  g.loss_cal = {o->thres_loss_function, wpt};
+  g.loss_unc = {o->thres_loss_function, 0.5 * wpt};
+  g.loss_pair = {o->thres_loss_function, 1.0};
   g.mc = o->optimize_positions ? 1.0 : 0.0;
   g.mx = o->optimize_points ? 1.0 : 0.0;
   g.ms = o->optimize_scales ? 1.0 : 0.0;
@@ -599,8 +725,6 @@ int orc_gp_solve(int32_t num_cams, i64 num_pts, const i64* pt_offset, const int3
   std::mt19937 gen(o->seed);
   std::uniform_real_distribution<double> uni(-1.0, 1.0);
   if (o->generate_random_positions && o->optimize_positions) {
-    std::vector<uint8_t> constrained(g.N, 0);
-    for (i64 k = 0; k < g.M; ++k) constrained[g.cam[k]] = 1;
     for (i64 n = 0; n < g.N; ++n)
       if (constrained[n])
         for (int j = 0; j < 3; ++j) g.c[3 * n + j] = 100.0 * uni(gen);
@@ -645,6 +769,16 @@ int orc_gp_solve(int32_t num_cams, i64 num_pts, const i64* pt_offset, const int3
   rep->seconds_linear = s.seconds_linear;
   rep->seconds_total = omp_get_wtime() - t0;
   return s.usable ? 0 : -6;
+}
+
+int orc_gp_solve(int32_t num_cams, i64 num_pts, const i64* pt_offset, const int32_t* obs_cam, const double* obs_dir,
+                 const uint8_t* obs_calibrated, const orc::GpOptionsC* o, double* cam_center_inout, double* pt_xyz_inout,
+                 orc::GpReport* rep, int32_t num_threads, const int32_t* image_frame, const double* image_offset,
+                 int32_t num_sensors, const int32_t* image_sensor, const double* image_sensor_rot,
+                 double* sensor_center_inout) {
+  return orc_gp_solve_pairs(num_cams, num_pts, pt_offset, obs_cam, obs_dir, obs_calibrated, o, cam_center_inout, pt_xyz_inout, rep,
+                            num_threads, image_frame, image_offset, num_sensors, image_sensor, image_sensor_rot,
+                            sensor_center_inout, 0, 1.0, 0, nullptr, nullptr, nullptr);
 }
 
 int orc_num_threads(void) { return omp_get_max_threads(); }

@@ -213,6 +213,32 @@ def test_gp_sequential_capture_matches_cpu_oracle(gsfm_ctx):
     assert rep["linear_iterations"] < 0.5 * s.linear_iterations
 
 
+def test_gp_points_and_cameras_balanced_matches_cpu_oracle(gsfm_ctx):
+    """Camera-to-camera constraints next to the tracks (POINTS_AND_CAMERAS_BALANCED, gp.cc:42-71, 167-255) above the size
+    where one workgroup runs the PCG (1 024 cameras): the multi-workgroup vector update with the pair terms' delta slots.
+    Against the exact-solve C++ oracle on the same seeded inputs; same bars as the other GP parity tests."""
+    from oracle import cpu
+    from test_gp_gpu import _pairs
+
+    p = synthetic.make_gp_problem(1_200, 40_000, seed=2, dir_noise=1e-3, outlier_ratio=0.02)
+    p.pair_i, p.pair_j, p.pair_dir = _pairs(p, np.random.default_rng(2), num_succ=4, noise=1e-3)
+    kw = dict(constraint_type=2, constraint_reweight_scale=2.0)
+    rc, cen, xyz, rep = estimators.gp_solve(p, estimators.GlobalPositionerOptions(**kw), ctx=gsfm_ctx)
+    assert rc == 0
+    from oracle import gp as ogp
+
+    ok, c_o, X_o, s = cpu.gp_solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated, p.cam_center, p.pt_xyz,
+                                   ogp.GlobalPositionerOptions(**kw), pair_i=p.pair_i, pair_j=p.pair_j, pair_dir=p.pair_dir)
+    assert ok and s.max_linear_residual < 1e-8
+    assert abs(rep["initial_cost"] - s.initial_cost) <= 1e-12 * s.initial_cost
+    d = synthetic.center_errors_after_sim3(cen, c_o)
+    print(f"\n[parity] GP POINTS_AND_CAMERAS_BALANCED 1.2k / 40k / 4.8k pairs: LM {rep['iterations']} vs {s.iterations}, final cost "
+          f"{rep['final_cost']:.6f} vs {s.final_cost:.6f}, max centre distance GPU-oracle / extent = {d.max() / _extent(c_o):.3e} (bar 1e-3)")
+    assert abs(rep["iterations"] - s.iterations) <= 3
+    assert abs(rep["final_cost"] - s.final_cost) <= 1e-3 * s.final_cost
+    assert d.max() / _extent(c_o) < 1e-3
+
+
 def test_ra_config4_matches_cpu_oracle(gsfm_ctx):
     """The rotation-averaging stage of configs[3] (10k cameras / 500k edges) against the C++ oracle (direct skyline
     Cholesky solves): same L1 / IRLS iteration counts, rotations to 1e-6 rad."""

@@ -173,3 +173,26 @@ def test_ra_cpp_matches_numpy_oracle_on_non_ring_graphs(kind):
     assert ok and ok2
     assert (rep["l1_iterations"], rep["irls_iterations"]) == (tr.l1_iterations, tr.irls_iterations)
     assert np.abs(rot - rot2).max() < 1e-9
+
+
+@pytest.mark.parametrize("ctype", [1, 2, 3])  # ONLY_CAMERAS, POINTS_AND_CAMERAS_BALANCED, POINTS_AND_CAMERAS
+def test_cpp_gp_constraint_types_match_the_numpy_oracle(ctype):
+    """The camera-to-camera constraint types (gp.cc:42-71, 167-255) in the C++ oracle against their numpy restatement: same
+    start, same LM path, same result."""
+    from test_oracle_gp import _pairs
+
+    p = synthetic.make_gp_problem(num_cams=60, num_pts=1500, seed=7, dir_noise=2e-3, outlier_ratio=0.02)
+    pi, pj, pd = _pairs(p, np.random.default_rng(7), noise=2e-3)
+    opt = ogp.GlobalPositionerOptions(constraint_type=ctype, constraint_reweight_scale=2.0)
+    args = (p.num_cams, p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated, p.cam_center, p.pt_xyz, opt)
+    ok_n, c_n, X_n, s_n = ogp.solve(*args, pair_i=pi, pair_j=pj, pair_dir=pd)
+    ok_c, c_c, X_c, s_c = cpu.gp_solve(*args, pair_i=pi, pair_j=pj, pair_dir=pd)
+    assert ok_n and ok_c and s_n.iterations == s_c.iterations
+    assert abs(s_n.initial_cost - s_c.initial_cost) <= 1e-12 * s_n.initial_cost
+    assert abs(s_n.final_cost - s_c.final_cost) <= 1e-9 * s_n.final_cost
+    assert synthetic.center_errors_after_sim3(c_c, c_n).max() < 1e-9
+    assert np.abs(X_c - X_n).max() <= 1e-7 * np.abs(X_n).max()
+    if ctype == 1:
+        assert np.array_equal(X_c, p.pt_xyz)
+    ok, *_ = cpu.gp_solve(*args)  # no pairs: gp.cc:41-45
+    assert not ok
