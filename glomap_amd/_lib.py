@@ -295,6 +295,8 @@ def load():
     lib.gsfm_ctx_profile_enable.argtypes = [vp, ip]
     lib.gsfm_ctx_profile_read.restype = ip
     lib.gsfm_ctx_profile_read.argtypes = [vp, ip, C.POINTER(C.c_int64), dp]
+    lib.gsfm_ctx_stats.restype = ip
+    lib.gsfm_ctx_stats.argtypes = [vp, C.POINTER(C.c_int64), ip, ip]
     lib.gsfm_comm_unique_id.restype = ip
     lib.gsfm_comm_unique_id.argtypes = [C.c_char_p]
     lib.gsfm_comm_init.restype = ip
@@ -497,6 +499,17 @@ class Context:
         if rc != 0:
             raise GsfmError(rc, "gsfm_ctx_profile_read")
         return n.value, ms.value
+
+    STAT_NAMES = ("pcg_solves", "pcg_deflated", "pcg_closed_form_aw", "pcg_single_workgroup", "pcg_joint_blocks",
+                  "pcg_second_level", "allreduces", "pcg_iterations")
+
+    def stats(self, reset: bool = False) -> dict:
+        """Which solver paths ran on this context (gsfm_ctx_stats)."""
+        buf = (C.c_int64 * len(self.STAT_NAMES))()
+        rc = self.lib.gsfm_ctx_stats(self.handle, buf, len(self.STAT_NAMES), int(reset))
+        if rc != 0:
+            raise GsfmError(rc, "gsfm_ctx_stats")
+        return dict(zip(self.STAT_NAMES, (int(v) for v in buf)))
 
     def comm_destroy(self):
         """Detach whatever transport is attached (collective in effect: every rank must be done with its solves)."""

@@ -136,6 +136,13 @@ extern "C" int gsfm_ctx_profile_enable(gsfm_ctx* ctx, int enable) {
   return GSFM_OK;
 }
 
+extern "C" int gsfm_ctx_stats(gsfm_ctx* ctx, int64_t* out, int n, int reset) {
+  if (!ctx || (n > 0 && !out)) return GSFM_ERR_INVALID_ARGUMENT;
+  for (int i = 0; i < n && i < GSFM_STAT_COUNT; ++i) out[i] = ctx->stats[i];
+  if (reset) std::memset(ctx->stats, 0, sizeof(ctx->stats));
+  return GSFM_OK;
+}
+
 extern "C" int gsfm_ctx_profile_read(gsfm_ctx* ctx, int kernel_id, int64_t* launches, double* total_ms) {
   if (!ctx || kernel_id < 0 || kernel_id >= GSFM_KERNEL_COUNT) return GSFM_ERR_INVALID_ARGUMENT;
   return guarded(ctx, nullptr, [&] {

@@ -1025,7 +1025,13 @@ inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& 
     }
   }
   if (hint) *hint = (int)iters;
+  ctx->stats[GSFM_STAT_PCG_SOLVES]++;
+  ctx->stats[GSFM_STAT_PCG_ITERATIONS] += iters;
+  if (v.single) ctx->stats[GSFM_STAT_PCG_SINGLE_WORKGROUP]++;
+  if (joint) ctx->stats[GSFM_STAT_PCG_JOINT_BLOCKS]++;
   if (deflate) {
+    ctx->stats[GSFM_STAT_PCG_DEFLATED]++;
+    if (defl->aw_ready == defl->k) ctx->stats[GSFM_STAT_PCG_CLOSED_FORM_AW]++;
     hipLaunchKernelGGL(k_cgd_finish, dim3(gvec), dim3(kBlock), 0, s, v, *defl);
     v.b = b_caller;
     v.dk = 0;

@@ -178,6 +178,7 @@ struct gsfm_ctx {
   gsfm::Comm comm;
   int num_cus = 256;
   std::string last_error;
+  int64_t stats[GSFM_STAT_COUNT] = {};  // which solver paths ran (gsfm_ctx_stats)
   std::string dump_dir;  // non-empty: every solve writes its flat problem + result there (dump.hpp)
   int dump_seq = 0;
   // pinned host staging for small status read-backs
@@ -203,6 +204,7 @@ namespace gsfm {
 // ctx stream.  No-op for a single rank.
 inline void allreduce(gsfm_ctx* ctx, double* dev, size_t n, int op /* 0 = sum, 1 = max */) {
   if (ctx->comm.world <= 1 || n == 0) return;
+  ctx->stats[GSFM_STAT_ALLREDUCES]++;
   if (ctx->comm.peer.connected) {
     if (*ctx->comm.peer.h_err) throw StatusError(GSFM_ERR_COMM, "peer all-reduce: a rank did not arrive within the time limit");
     peer_allreduce(ctx->comm.peer, ctx->stream, dev, n, op);

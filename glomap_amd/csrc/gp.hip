@@ -2108,6 +2108,7 @@ class GpSolver final : public LmProblem {
       coarse_on_ = true;
       return iters0 + pcg();
     }
+    if (coarse) ctx_->stats[GSFM_STAT_PCG_SECOND_LEVEL]++;
     const long iters = iters0 + (coarse ? coarse_probes_ : 0);  // + the operator applications that probed the coarse matrix
     // deflation pays while a plain solve needs more than ~3 k iterations (iters includes the k applications for A W)
     // (with the closed-form mode products the price of A W is one camera-major sweep — say one application — instead of four)

@@ -118,6 +118,22 @@ enum {
 int gsfm_ctx_profile_enable(gsfm_ctx* ctx, int enable);
 /* Reads and resets the accumulated launch count / total milliseconds of one kernel id. */
 int gsfm_ctx_profile_read(gsfm_ctx* ctx, int kernel_id, int64_t* launches, double* total_ms);
+/* Which solver paths ran on this ctx (counters since creation or the last reset): lets a test assert that a solve took
+ * the path it was meant to cover (deflated multi-block PCG, closed-form gauge products, joint pose / intrinsics blocks,
+ * second-level preconditioner, collectives). */
+enum gsfm_stat {
+  GSFM_STAT_PCG_SOLVES = 0,          /* reduced-system solves (cg_solve calls) */
+  GSFM_STAT_PCG_DEFLATED = 1,        /* ... with the gauge modes deflated */
+  GSFM_STAT_PCG_CLOSED_FORM_AW = 2,  /* ... whose A W products came from k_gp_aw_modes / k_ba_aw_modes (no operator applications) */
+  GSFM_STAT_PCG_SINGLE_WORKGROUP = 3,/* ... run by the single-workgroup vector kernels (small GP problems) */
+  GSFM_STAT_PCG_JOINT_BLOCKS = 4,    /* ... with joint pose + intrinsics blocks (BA, one intrinsics block per camera) */
+  GSFM_STAT_PCG_SECOND_LEVEL = 5,    /* ... with the second-level (cluster) preconditioner */
+  GSFM_STAT_ALLREDUCES = 6,          /* collectives issued (any transport) */
+  GSFM_STAT_PCG_ITERATIONS = 7,      /* PCG iterations (operator applications of the iterations proper) */
+  GSFM_STAT_COUNT = 8
+};
+/* Copies min(n, GSFM_STAT_COUNT) counters to out; reset != 0 zeroes them afterwards. */
+int gsfm_ctx_stats(gsfm_ctx* ctx, int64_t* out, int n, int reset);
 /* Text of the last failure on this ctx (what the HIP / RCCL call or the argument check said); "" when there was none.  The
  * pointer stays valid until the next failing call on the ctx. */
 const char* gsfm_ctx_last_error(gsfm_ctx* ctx);

@@ -138,6 +138,107 @@ def test_ranks_reproduce_single_rank(gsfm_ctx, world, transport):
     assert all(np.array_equal(res[0]["ba"][1], res[r]["ba"][1]) for r in ranks)
 
 
+def _big_problems():
+    """Above the single-workgroup PCG size (1 024 cameras), one intrinsics block per image: the code configs[3] runs at N > 1."""
+    gp = synthetic.make_gp_problem(1200, 40_000, seed=5)
+    ba = synthetic.make_ba_problem(num_cams=1200, num_pts=40_000, seed=6)
+    return gp, ba
+
+
+def _big_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      GSFM_PEER_TIMEOUT_S="60")
+    import torch.distributed as dist
+
+    from glomap_amd import _lib
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = _lib.Context(0)
+
+    def allgather(b):
+        out = [None] * world
+        dist.all_gather_object(out, b)
+        return out
+
+    ctx.comm_init_peer(allgather, rank, world, 1 << 18)
+    assert ctx.comm_peer_selftest() == world
+    gp, ba = _big_problems()
+    out = {}
+    s, _ = sharding.shard_gp_problem(gp, rank, world)
+    ctx.stats(reset=True)
+    rc, cen, xyz, rep = estimators.gp_solve(s, ctx=ctx)
+    out["gp"] = (rc, cen, rep, ctx.stats(reset=True))
+    s, (lo, hi) = sharding.shard_ba_problem(ba, rank, world)
+    rc, q_, t_, X_, intr_, rep = estimators.ba_solve(s, ctx=ctx)
+    out["ba"] = (rc, q_, t_, intr_, rep, ctx.stats(reset=True))
+    q.put((rank, out))
+    dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_reproduce_single_rank_above_the_single_workgroup_size(gsfm_ctx, world):
+    """1 200 cameras / 40 k tracks, one intrinsics block per image, peer transport: GP takes the multi-block k_cg_update<3>
+    with the gauge modes deflated and the all-reduced closed-form k_gp_aw_modes products, BA the joint 14 x 14 blocks with
+    k_ba_aw_modes — the paths bench.py --gpus N runs on configs[3].  The counters of gsfm_ctx_stats prove they ran."""
+    import multiprocessing as mp
+
+    gp, ba = _big_problems()
+    gsfm_ctx.stats(reset=True)
+    rc, cen1, xyz1, rep_gp1 = estimators.gp_solve(gp, ctx=gsfm_ctx)
+    assert rc == 0
+    st_gp1 = gsfm_ctx.stats(reset=True)
+    rc, q1, t1, X1, intr1, rep_ba1 = estimators.ba_solve(ba, ctx=gsfm_ctx)
+    assert rc == 0
+    st_ba1 = gsfm_ctx.stats(reset=True)
+    assert st_gp1["pcg_deflated"] > 0 and st_gp1["pcg_closed_form_aw"] == st_gp1["pcg_deflated"]
+    assert st_ba1["pcg_joint_blocks"] == st_ba1["pcg_solves"] and st_ba1["pcg_closed_form_aw"] > 0
+
+    mpc = mp.get_context("spawn")
+    queue = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_big_worker, args=(r, world, port, queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(queue.get(timeout=800) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ranks = range(world)
+    for r in ranks:
+        rc, cen, rep, st = res[r]["gp"]
+        assert rc == 0
+        # the paths: no single-workgroup solve, deflated solves with closed-form products, collectives issued
+        assert st["pcg_single_workgroup"] == 0 and st["pcg_solves"] == st_gp1["pcg_solves"]
+        assert st["pcg_deflated"] == st_gp1["pcg_deflated"] > 0
+        assert st["pcg_closed_form_aw"] == st["pcg_deflated"]
+        assert st["allreduces"] > st["pcg_iterations"]
+        assert abs(rep["initial_cost"] - rep_gp1["initial_cost"]) <= 1e-12 * rep_gp1["initial_cost"]
+        assert rep["iterations"] == rep_gp1["iterations"] and rep["successful_steps"] == rep_gp1["successful_steps"]
+        assert abs(rep["linear_iterations"] - rep_gp1["linear_iterations"]) <= 0.02 * rep_gp1["linear_iterations"] + 2
+        assert abs(rep["final_cost"] - rep_gp1["final_cost"]) <= 1e-8 * rep_gp1["final_cost"]
+        assert np.abs(cen - cen1).max() <= 1e-6 * np.abs(cen1).max()
+    assert all(np.array_equal(res[0]["gp"][1], res[r]["gp"][1]) for r in ranks)  # replicated state is bit-identical
+    for r in ranks:
+        rc, q_, t_, intr_, rep, st = res[r]["ba"]
+        assert rc == 0
+        assert st["pcg_joint_blocks"] == st["pcg_solves"] == st_ba1["pcg_solves"]
+        assert st["pcg_deflated"] == st_ba1["pcg_deflated"] > 0
+        assert st["pcg_closed_form_aw"] == st_ba1["pcg_closed_form_aw"] > 0
+        assert st["allreduces"] > st["pcg_iterations"]
+        assert rep["iterations"] == rep_ba1["iterations"] and rep["successful_steps"] == rep_ba1["successful_steps"]
+        assert abs(rep["linear_iterations"] - rep_ba1["linear_iterations"]) <= 0.02 * rep_ba1["linear_iterations"] + 2
+        assert abs(rep["final_cost"] - rep_ba1["final_cost"]) <= 1e-9 * rep_ba1["final_cost"]
+        ang = np.radians(so3.rotation_angle_deg(so3.quat_to_rotmat(q_), so3.quat_to_rotmat(q1)))
+        assert ang.max() < 1e-6
+        assert np.abs(t_ - t1).max() < 1e-7 * (1 + np.abs(t1).max())
+        assert np.abs(intr_ - intr1).max() < 1e-6 * (1 + np.abs(intr1).max())
+    assert all(np.array_equal(res[0]["ba"][1], res[r]["ba"][1]) for r in ranks)
+    assert all(np.array_equal(res[0]["ba"][2], res[r]["ba"][2]) for r in ranks)
+
+
 @pytest.mark.gpu
 def test_rccl_transport_in_a_process_that_also_imports_torch():
     """bench.py imports torch (rendezvous) and libgsfm (RCCL inside the library) into one process.  PyTorch wheels
