@@ -602,6 +602,39 @@ struct Ba : LmProblem {
           W.back()[c] = 1.0;
         }
     }
+    // Intrinsics blocks shared by many images are a dense border of the reduced system: eliminated densely (solve_bordered,
+    // orc_lm.hpp) — what SPARSE_SCHUR's factorisation does to the arrowhead.  ORC_BORDER=0 (experiments) keeps round 3's plain
+    // block-Jacobi PCG on the whole system.  The A-solves deflate the similarity modes (same solutions, fewer iterations).
+    static const bool border_on = !(std::getenv("ORC_BORDER") && std::atoi(std::getenv("ORC_BORDER")) == 0);
+    bool shared_border = false;
+    for (i64 b = 0; b < K; ++b) shared_border = shared_border || intr_owner[b] < 0;
+    bool all_shared = true;
+    for (i64 b = 0; b < K; ++b) all_shared = all_shared && intr_owner[b] < 0;
+    if (border_on && shared_border && all_shared && nfree > 0 && nfree <= 32 && nred > kDenseMax) {
+      std::vector<std::vector<double>> Wb;
+      if (S == 0) {
+        Wb.assign(7, std::vector<double>(nred, 0.0));
+        for (i64 n = 0; n < N; ++n) {
+          double R[9];
+          quat_to_rot(&q[4 * n], R);
+          const double fr = rot_free[n] ? 1.0 : 0.0, ft = trn_free[n] ? 1.0 : 0.0;
+          for (int a = 0; a < 3; ++a)
+            for (int i = 0; i < 3; ++i) {
+              Wb[a][6 * n + 3 + i] = -ft * R[3 * i + a];
+              Wb[3 + a][6 * n + i] = -0.5 * fr * R[3 * i + a];
+            }
+          for (int i = 0; i < 3; ++i) Wb[6][6 * n + 3 + i] = ft * t[3 * n + i];
+        }
+        // frozen rotations / translations leave some modes identically zero: drop them
+        std::vector<std::vector<double>> keep;
+        for (auto& w : Wb)
+          if (vdot(w, w) > 0.0) keep.push_back(std::move(w));
+        Wb.swap(keep);
+      }
+      *lin = solve_bordered(
+          nred, nfree, rhs, dy, pcg_tol, pcg_max, [&](const std::vector<double>& z, std::vector<double>& o) { apply(z, o); },
+          [&](const std::vector<double>& r, std::vector<double>& z) { precond(r, z); }, relres, Wb.empty() ? nullptr : &Wb);
+    } else
     *lin = solve_reduced(
         nred, rhs, dy, pcg_tol, pcg_max, [&](const std::vector<double>& z, std::vector<double>& o) { apply(z, o); },
         [&](const std::vector<double>& r, std::vector<double>& z) { precond(r, z); }, relres, (double)M, guess,

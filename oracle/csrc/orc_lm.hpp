@@ -198,7 +198,8 @@ template <class Apply, class Precond>
 // z <- z - W (W^T A W)^-1 (A W)^T z.  Same system, same stopping rule; the k applications of the operator that form A W
 // are counted in the returned iteration count.
 i64 pcg(i64 n, const std::vector<double>& b, std::vector<double>& x, double tol, int max_it, Apply apply, Precond precond,
-        double* true_relres, const std::vector<double>* x0 = nullptr, const std::vector<std::vector<double>>* defl = nullptr) {
+        double* true_relres, const std::vector<double>* x0 = nullptr, const std::vector<std::vector<double>>* defl = nullptr,
+        int stall_window = 200) {
   std::vector<double> r(b), z(n), p(n), w(n);
   std::fill(x.begin(), x.end(), 0.0);
   const double bnorm = std::sqrt(vdot(b, b));
@@ -286,7 +287,7 @@ i64 pcg(i64 n, const std::vector<double>& b, std::vector<double>& x, double tol,
     if (rnorm < 0.999 * best) {
       best = rnorm;
       since_best = 0;
-    } else if (++since_best >= 200) {
+    } else if (++since_best >= stall_window) {
       break;
     }
     precond(r, z);
@@ -307,6 +308,122 @@ i64 pcg(i64 n, const std::vector<double>& b, std::vector<double>& x, double tol,
   });
   *true_relres = std::sqrt(rr) / bnorm;
   return it + (deflate ? kd : 0);
+}
+
+// Exact treatment of a dense border.  A few intrinsics blocks shared by many images make the reduced system an arrowhead
+//
+//     S = [ A   B ]   A: poses (sparse, n0 = n - nb unknowns),   B: n0 x nb,   C: nb x nb (dense border, nb <= 32)
+//         [ B^T C ]
+//
+// which SPARSE_SCHUR + a sparse Cholesky factors exactly.  Block-Jacobi PCG on S does not get there (the border couples
+// every camera with every other; on configs[3] with one shared camera it stalls at a TRUE relative residual of 0.08 in
+// some LM steps), so the border is eliminated densely here:
+//
+//     A Z = B,  A y = b_a   (nb + 1 solves with the pose part alone),   (C - B^T Z) x_c = b_c - B^T y,   x_a = y - Z x_c.
+//
+// Every A-solve is PCG to `tol` followed by iterative refinement on the TRUE residual (restart from b - A x until
+// |b - A x| <= 1e-13 |b| or a restart no longer gains a factor of four): "exact" as a factorisation is — to the backward
+// error of double precision, not to a recurrence residual.  `defl` (optional): modes deflated from the A-solves (their
+// border entries must be zero).  Returns the total PCG iteration count plus the nb + refinement operator applications.
+template <class Apply, class Precond>
+i64 solve_bordered(i64 n, i64 nb, const std::vector<double>& b, std::vector<double>& x, double tol, int max_it, Apply apply,
+                   Precond precond, double* true_relres, const std::vector<std::vector<double>>* defl = nullptr) {
+  const i64 n0 = n - nb;
+  i64 work = 0;
+  std::vector<double> tmp(n), tmp2(n);
+  auto applyA = [&](const std::vector<double>& z, std::vector<double>& w) {
+    tmp = z;
+    for (i64 i = n0; i < n; ++i) tmp[i] = 0.0;
+    apply(tmp, w);
+    for (i64 i = n0; i < n; ++i) w[i] = 0.0;
+  };
+  auto precondA = [&](const std::vector<double>& r, std::vector<double>& z) {
+    tmp2 = r;
+    for (i64 i = n0; i < n; ++i) tmp2[i] = 0.0;
+    precond(tmp2, z);
+    for (i64 i = n0; i < n; ++i) z[i] = 0.0;
+  };
+  // out = A^-1 rhs (border entries of rhs are ignored, those of out are zero)
+  auto solveA = [&](const std::vector<double>& rhs_in, std::vector<double>& out) {
+    std::vector<double> rhs(rhs_in), res, d(n), w(n);
+    for (i64 i = n0; i < n; ++i) rhs[i] = 0.0;
+    out.assign(n, 0.0);
+    const double bn = std::sqrt(vdot(rhs, rhs));
+    if (!(bn > 0.0)) return;
+    res = rhs;
+    double prev = bn;
+    for (int pass = 0; pass < 8; ++pass) {
+      double rel = 0.0;
+      // every pass solves to 1e-10 of ITS right-hand side (the true residual of the previous pass): two or three passes reach
+      // the 1e-13 target without ever asking a recurrence residual for more digits than it can deliver (a PCG run that is
+      // asked for 1e-14 and stalls at 2e-14 burns its whole 200-iteration stagnation window)
+      const double pass_tol = std::max(tol, 1e-10);
+      const i64 its = pcg(n, res, d, pass_tol, max_it, applyA, precondA, &rel, nullptr, defl, 25);
+      work += its;
+      static const bool dbg = std::getenv("ORC_BORDER_DEBUG") != nullptr;
+      if (dbg) fprintf(stderr, "[orc border] A-solve pass %d: %lld iterations, tol %.1e, true relres of the pass %.2e\n", pass, (long long)its, pass_tol, rel);
+      for (i64 i = 0; i < n0; ++i) out[i] += d[i];
+      applyA(out, w);
+      ++work;
+      for (i64 i = 0; i < n0; ++i) res[i] = rhs[i] - w[i];
+      const double rn = std::sqrt(vdot(res, res));
+      if (rn <= 1e-13 * bn || rn > 0.25 * prev) break;
+      prev = rn;
+    }
+  };
+  // border columns of S
+  std::vector<std::vector<double>> col(nb, std::vector<double>(n)), Z(nb);
+  std::vector<double> e(n, 0.0);
+  for (i64 j = 0; j < nb; ++j) {
+    e[n0 + j] = 1.0;
+    apply(e, col[j]);
+    e[n0 + j] = 0.0;
+    ++work;
+  }
+  for (i64 j = 0; j < nb; ++j) solveA(col[j], Z[j]);
+  std::vector<double> Sc((size_t)nb * nb);
+  for (i64 i = 0; i < nb; ++i)
+    for (i64 j = 0; j < nb; ++j) {
+      double bz = 0.0;  // (B^T Z)_ij = B_i . Z_j over the pose part
+      for (i64 k = 0; k < n0; ++k) bz += col[i][k] * Z[j][k];
+      Sc[(size_t)i * nb + j] = col[j][n0 + i] - bz;
+    }
+  for (i64 i = 0; i < nb; ++i)
+    for (i64 j = 0; j < i; ++j) Sc[(size_t)i * nb + j] = Sc[(size_t)j * nb + i] = 0.5 * (Sc[(size_t)i * nb + j] + Sc[(size_t)j * nb + i]);
+  if (!spd_inverse(Sc.data(), (int)nb)) {  // not positive definite: leave it to plain PCG on the whole system
+    return work + pcg(n, b, x, tol, max_it, apply, precond, true_relres, nullptr, defl);
+  }
+  std::fill(x.begin(), x.end(), 0.0);
+  std::vector<double> r(b), y, w(n);
+  const double bnorm = std::sqrt(vdot(b, b));
+  *true_relres = 0.0;
+  if (!(bnorm > 0.0)) return work;
+  double prev = bnorm;
+  for (int round = 0; round < 4; ++round) {  // the bordered solve, then refinement of the whole system on its true residual
+    solveA(r, y);
+    std::vector<double> rc(nb), xc(nb, 0.0);
+    for (i64 i = 0; i < nb; ++i) {
+      double by = 0.0;
+      for (i64 k = 0; k < n0; ++k) by += col[i][k] * y[k];
+      rc[i] = r[n0 + i] - by;
+    }
+    for (i64 i = 0; i < nb; ++i)
+      for (i64 j = 0; j < nb; ++j) xc[i] += Sc[(size_t)i * nb + j] * rc[j];
+    for (i64 k = 0; k < n0; ++k) {
+      double v = y[k];
+      for (i64 j = 0; j < nb; ++j) v -= Z[j][k] * xc[j];
+      x[k] += v;
+    }
+    for (i64 j = 0; j < nb; ++j) x[n0 + j] += xc[j];
+    apply(x, w);
+    ++work;
+    for (i64 i = 0; i < n; ++i) r[i] = b[i] - w[i];
+    const double rn = std::sqrt(vdot(r, r));
+    *true_relres = rn / bnorm;
+    if (rn <= 1e-13 * bnorm || rn > 0.25 * prev) break;
+    prev = rn;
+  }
+  return work;
 }
 
 // The reduced-system solve of one LM step: direct when small, PCG otherwise.  Returns the PCG iteration count (0 for
