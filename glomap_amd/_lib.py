@@ -3,6 +3,7 @@ a hard error — the product path never runs on the CPU."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 import numpy as np
@@ -295,6 +296,8 @@ def load():
     lib.gsfm_ctx_profile_enable.argtypes = [vp, ip]
     lib.gsfm_ctx_profile_read.restype = ip
     lib.gsfm_ctx_profile_read.argtypes = [vp, ip, C.POINTER(C.c_int64), dp]
+    lib.gsfm_ctx_set_knob.restype = ip
+    lib.gsfm_ctx_set_knob.argtypes = [vp, ip, ip]
     lib.gsfm_ctx_stats.restype = ip
     lib.gsfm_ctx_stats.argtypes = [vp, C.POINTER(C.c_int64), ip, ip]
     lib.gsfm_comm_unique_id.restype = ip
@@ -373,6 +376,8 @@ def ptr(a):
         return None
     if isinstance(a, np.ndarray):
         assert a.flags["C_CONTIGUOUS"], "array must be C-contiguous"
+        if a.size == 0:
+            return None  # what std::vector<T>(0).data() hands the C ABI from the C++ adapter
         return a.ctypes.data
     return a.data_ptr()
 
@@ -453,6 +458,9 @@ class Context:
         self.handle = h
         self.rank = 0
         self.world = 1
+        for item in filter(None, os.environ.get("GSFM_KNOBS", "").split(",")):  # experiments: "name=value,..."
+            name, _, val = item.partition("=")
+            self.set_knob(name.strip(), int(val or 1))
 
     def close(self):
         if getattr(self, "handle", None):
@@ -499,6 +507,16 @@ class Context:
         if rc != 0:
             raise GsfmError(rc, "gsfm_ctx_profile_read")
         return n.value, ms.value
+
+    KNOBS = ("ba_aw_by_application", "ba_aw_check", "ba_separate_blocks", "ba_no_nontemporal", "ra_no_blockdense",
+             "ra_no_substructure", "ra_dense_refactor", "gp_coarse_cluster", "seg_len")
+
+    def set_knob(self, name: str, value: int = 1):
+        """Diagnostic / A-B knobs (gsfm_ctx_set_knob); 0 restores the default.  The library reads no environment variable
+        for these: experiments that want one set GSFM_KNOBS="name=value,..." and the Python mirror applies it here."""
+        rc = self.lib.gsfm_ctx_set_knob(self.handle, self.KNOBS.index(name), int(value))
+        if rc != 0:
+            raise GsfmError(rc, "gsfm_ctx_set_knob")
 
     STAT_NAMES = ("pcg_solves", "pcg_deflated", "pcg_closed_form_aw", "pcg_single_workgroup", "pcg_joint_blocks",
                   "pcg_second_level", "allreduces", "pcg_iterations")

@@ -143,6 +143,12 @@ extern "C" int gsfm_ctx_stats(gsfm_ctx* ctx, int64_t* out, int n, int reset) {
   return GSFM_OK;
 }
 
+extern "C" int gsfm_ctx_set_knob(gsfm_ctx* ctx, int knob, int value) {
+  if (!ctx || knob < 0 || knob >= GSFM_KNOB_COUNT) return GSFM_ERR_INVALID_ARGUMENT;
+  ctx->knob[knob] = value;
+  return GSFM_OK;
+}
+
 extern "C" int gsfm_ctx_profile_read(gsfm_ctx* ctx, int kernel_id, int64_t* launches, double* total_ms) {
   if (!ctx || kernel_id < 0 || kernel_id >= GSFM_KERNEL_COUNT) return GSFM_ERR_INVALID_ARGUMENT;
   return guarded(ctx, nullptr, [&] {

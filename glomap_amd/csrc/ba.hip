@@ -1240,27 +1240,28 @@ __global__ void __launch_bounds__(kBlock) k_ba_defl_modes(int N, long n, const d
 // [k0, k1)); slot = k - k0, recorded in the point's build record.
 template <bool WIDE>
 __global__ void __launch_bounds__(kBlock)
-    k_ba_fixed_share(BaDev g, int k0, int k1, const double* __restrict__ camR, const double* __restrict__ t,
+    k_ba_fixed_share(BaDev g, const int* __restrict__ slots, int ns, const double* __restrict__ camR, const double* __restrict__ t,
                      const double* __restrict__ par, const double* __restrict__ c_w, double* __restrict__ ptb,
                      double* __restrict__ ftab) {
   const int n = g.fixed_cam;
   const int ik = g.cam_intr[n];
   const double* R9 = camR + 9 * (long)n;
-  for (int k = k0 + blockIdx.x * blockDim.x + threadIdx.x; k < k1; k += gridDim.x * blockDim.x) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
+    const int k = slots[i];
     double* b = ptb + kPtbBa * (long)g.g.c_pt[k];
     const double w = c_w[k];
     ObsGeom o;
     obs_geom<WIDE>(R9, t + 3 * (long)n, ld3(b), g.intr_model[ik], par + 8 * (long)ik, o);
     ObsJac J;
     build_jac(g, n, R9, o, J);
-    double* f = ftab + 6 * (long)(k - k0);
+    double* f = ftab + 6 * (long)i;
     f[0] = w * (J.Jpt[0][0] * J.Jpt[0][0] + J.Jpt[1][0] * J.Jpt[1][0]);
     f[1] = w * (J.Jpt[0][0] * J.Jpt[0][1] + J.Jpt[1][0] * J.Jpt[1][1]);
     f[2] = w * (J.Jpt[0][0] * J.Jpt[0][2] + J.Jpt[1][0] * J.Jpt[1][2]);
     f[3] = w * (J.Jpt[0][1] * J.Jpt[0][1] + J.Jpt[1][1] * J.Jpt[1][1]);
     f[4] = w * (J.Jpt[0][1] * J.Jpt[0][2] + J.Jpt[1][1] * J.Jpt[1][2]);
     f[5] = w * (J.Jpt[0][2] * J.Jpt[0][2] + J.Jpt[1][2] * J.Jpt[1][2]);
-    b[15] = (double)(k - k0);
+    b[15] = (double)i;
   }
 }
 
@@ -1352,15 +1353,16 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // flag[0] = 1 when two consecutive camera-major slots in [k0, k1) name the same point (a camera's list is in track order)
-__global__ void __launch_bounds__(kBlock) k_ba_dup_check(const int* __restrict__ c_pt, int k0, int k1, int* __restrict__ flag) {
-  for (int k = k0 + 1 + blockIdx.x * blockDim.x + threadIdx.x; k < k1; k += gridDim.x * blockDim.x)
-    if (c_pt[k] == c_pt[k - 1]) atomicOr(flag, 1);
+__global__ void __launch_bounds__(kBlock) k_ba_dup_check(const int* __restrict__ c_pt, const int* __restrict__ slots, int ns,
+                                                         int* __restrict__ flag) {
+  for (int i = 1 + blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x)
+    if (c_pt[slots[i]] == c_pt[slots[i - 1]]) atomicOr(flag, 1);  // (the list is in track order)
 }
 
 struct BaWs {
   ObsGraphWs og;
   DevBuf<long> off;
-  DevBuf<int> cam, cam_intr, intr_model, ioff, icams, obs_ik;
+  DevBuf<int> cam, cam_intr, intr_model, ioff, icams, obs_ik, fix_slots;
   DevBuf<unsigned char> intr_free;
   DevBuf<signed char> intr_map, intr_slot;
   DevBuf<double2> jt;
@@ -1942,7 +1944,7 @@ class BaSolver final : public LmProblem {
     small_groups_ = max_group_ <= 64;
     // one intrinsics block per camera (COLMAP's default for unordered photo collections): pose and
     // intrinsics of a camera are strongly coupled, so they share ONE 14 x 14 block-Jacobi block
-    joint_ = !rig_ && K_ == N_ && max_group_ == 1 && F_ > 0 && std::getenv("GSFM_BA_SEPARATE_BLOCKS") == nullptr;
+    joint_ = !rig_ && K_ == N_ && max_group_ == 1 && F_ > 0 && !ctx_->knob[GSFM_KNOB_BA_SEPARATE_BLOCKS];
     {
       std::vector<int> fill(h_ioff.begin(), h_ioff.end() - 1);
       for (int n = 0; n < NI_; ++n) h_icams[fill[h_ci[n]]++] = n;
@@ -2124,12 +2126,20 @@ class BaSolver final : public LmProblem {
     g1_ = g_;
     g1_.g.pass = 1;  // device view of the combine pass of the camera-major kernels (obsgraph.hpp)
     aw_closed_ok_ = true;
+    nfix_ = 0;
     if (g_.fixed_cam >= 0 && g_.fixed_cam < N_ && !rig_) {  // k_ba_aw_modes keeps ONE slot per point for the constant camera's share
-      const int k0 = ws->og.h_coff[g_.fixed_cam], k1 = ws->og.h_coff[g_.fixed_cam + 1];
-      if (k1 - k0 > 1) {
+      const std::vector<int> slots = cam_slots(ws->og, g_.fixed_cam);  // the constant camera's camera-major slots
+      nfix_ = (int)slots.size();
+      fix_slots_ = ws->fix_slots.ensure(slots.size() + 1);
+      if (nfix_ > 0) {
+        GSFM_HIP_CHECK(hipMemcpyAsync(ws->fix_slots.get(), slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        GSFM_HIP_CHECK(hipStreamSynchronize(s));
+      }
+      if (nfix_ > 1) {
         int* flag = ws->og.flag.ensure(4);
         GSFM_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), s));
-        hipLaunchKernelGGL(k_ba_dup_check, dim3(grid_for((size_t)(k1 - k0), kBlock)), dim3(kBlock), 0, s, g_.g.c_pt, k0, k1, flag);
+        hipLaunchKernelGGL(k_ba_dup_check, dim3(grid_for((size_t)nfix_, kBlock)), dim3(kBlock), 0, s, g_.g.c_pt, (const int*)fix_slots_,
+                           nfix_, flag);
         int* h = reinterpret_cast<int*>(ctx_->h_pinned + 512);
         GSFM_HIP_CHECK(hipMemcpyAsync(h, flag, sizeof(int), hipMemcpyDeviceToHost, s));
         GSFM_HIP_CHECK(hipStreamSynchronize(s));
@@ -2237,6 +2247,7 @@ class BaSolver final : public LmProblem {
     GSFM_HIP_CHECK(hipMemcpyAsync(ctx_->h_pinned + 300, ws->scal.get(), 2 * sizeof(double), hipMemcpyDeviceToHost, s));
     GSFM_HIP_CHECK(hipStreamSynchronize(s));
     GSFM_HIP_CHECK(hipGetLastError());
+    comm_check(ctx_);
     *grad_max_norm = ctx_->h_pinned[301];
     return ctx_->h_pinned[300];
   }
@@ -2333,6 +2344,7 @@ class BaSolver final : public LmProblem {
     GSFM_HIP_CHECK(hipMemcpyAsync(ctx_->h_pinned + 256, ws->scal.get(), 7 * sizeof(double), hipMemcpyDeviceToHost, s));
     GSFM_HIP_CHECK(hipStreamSynchronize(s));
     GSFM_HIP_CHECK(hipGetLastError());
+    comm_check(ctx_);
     std::memcpy(h, ctx_->h_pinned + 256, sizeof(h));
     *model_change = h[0];
     *step_norm = std::sqrt(h[1] + h[3]);
@@ -2403,15 +2415,13 @@ class BaSolver final : public LmProblem {
       defl.W = W;
       // A W in closed form (k_ba_aw_modes): points optimised, every intrinsics block owned by one camera (or none free),
       // the constant camera's observations found in one piece of the camera-major list
-      const bool no_closed = getenv("GSFM_BA_AW_APPLY") != nullptr;  // A/B and tests: form A W by operator applications (read per solve)
+      const bool no_closed = ctx_->knob[GSFM_KNOB_BA_AW_BY_APPLICATION] != 0;  // A/B and tests: form A W by operator applications
       if (!no_closed && g_.opt_pts && (joint_ || F_ == 0) && aw_closed_ok_) {
         GSFM_HIP_CHECK(hipMemsetAsync(defl.AW, 0, defl.k * n * sizeof(double), s));
-        const int fc = g_.fixed_cam;
-        const int k0 = fc >= 0 ? ws->og.h_coff[fc] : 0, k1 = fc >= 0 ? ws->og.h_coff[fc + 1] : 0;
-        double* ftab = ws->ftab.ensure(6 * (size_t)std::max(1, k1 - k0));
-        if (k1 > k0)
-          WIDE_LAUNCH((k_ba_fixed_share<WIDE>), dim3(grid_for((size_t)(k1 - k0), kBlock)), dim3(kBlock), 0, s, g_, k0, k1, Rk_, tk_,
-                      par_, ws->c_w.get(), ws->ptb.get(), ftab);
+        double* ftab = ws->ftab.ensure(6 * (size_t)std::max(1, nfix_));
+        if (nfix_ > 0)
+          WIDE_LAUNCH((k_ba_fixed_share<WIDE>), dim3(grid_for((size_t)nfix_, kBlock)), dim3(kBlock), 0, s, g_, (const int*)fix_slots_, nfix_,
+                      Rk_, tk_, par_, ws->c_w.get(), ws->ptb.get(), ftab);
         dispatch_f(F_, [&](auto Fc) {
           constexpr int F = decltype(Fc)::value;
           auto launch = [&](auto rot, const BaDev& gd, int grid) {
@@ -2431,7 +2441,7 @@ class BaSolver final : public LmProblem {
         if (ctx_->comm.world > 1) allreduce_sum(ctx_, defl.AW, defl.k * n);
         defl.aw_ready = defl.k;
         // diagnostics: keep the closed-form products, let cg_solve form them by operator applications as well, compare below
-        if (getenv("GSFM_BA_AW_CHECK") != nullptr) {
+        if (ctx_->knob[GSFM_KNOB_BA_AW_CHECK]) {
           aw_check_.resize(defl.k * n);
           GSFM_HIP_CHECK(hipMemcpyAsync(aw_check_.data(), defl.AW, defl.k * n * sizeof(double), hipMemcpyDeviceToHost, s));
           GSFM_HIP_CHECK(hipStreamSynchronize(s));
@@ -2453,7 +2463,7 @@ class BaSolver final : public LmProblem {
       }
       bool timed = ctx_->prof.begin(s, GSFM_KERNEL_BA_SCHUR, it);
       dispatch_f(F_, [&](auto Fc) {
-        static const bool nt = getenv("GSFM_BA_NO_NT") == nullptr;  // measured on C4: 240 us -> 210 (loads first) -> 193 (+ non-temporal)
+        const bool nt = !ctx_->knob[GSFM_KNOB_BA_NO_NONTEMPORAL];  // measured on C4: 240 us -> 210 (loads first) -> 193 (+ non-temporal)
         if (nt)
           hipLaunchKernelGGL((k_ba_phaseA<decltype(Fc)::value, true>), dim3(gridTile_), dim3(kBlock), 0, s, g_, vk, it,
                              tol * tol, ws->jt.get(), ws->pth.get(), ws->ptrec.get());
@@ -2513,6 +2523,8 @@ class BaSolver final : public LmProblem {
   bool small_groups_ = false, joint_ = false;
   bool wide_ = false;  // some camera uses a fisheye / FOV model: the sweeps run their WIDE instances
   std::vector<double> aw_check_;  // GSFM_BA_AW_CHECK: the closed-form products of the running solve
+  int nfix_ = 0;              // observations of the constant camera, their camera-major slots (k_ba_fixed_share)
+  int* fix_slots_ = nullptr;
   bool aw_closed_ok_ = true;  // false: a point is observed twice by the constant camera (k_ba_aw_modes keeps one slot per point)
   bool defl_on_ = true;  // deflate the next reduced solve (short solves run plain)
   int pcg_hint_ = 0;     // iteration count of the previous reduced solve (where cg_solve first reads the status back)

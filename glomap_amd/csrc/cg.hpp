@@ -15,9 +15,9 @@
 // with every scalar resident on the device: partial sums go to fixed per-block slots and each
 // consumer block re-reduces them in a fixed order (deterministic; no atomics, no host round trip).
 //
-// Convergence (|r|^2 <= tol^2 |b|^2) is tested by cg_converged(), which the solver calls at the top
-// of its first apply kernel; it raises status->done and every later kernel of the stream returns
-// at once, so the host only polls the status every few iterations.
+// Convergence (|r|^2 <= tol^2 |b|^2) is tested by the vector kernel that produces an iterate (cg_status_tail: the
+// workgroup that finishes last adds the |r|^2 partials); it raises status->done and every later kernel of the stream
+// returns at once, so the host only polls the status every few iterations.
 //
 // Multi-rank: `apply` produces this rank's share of w and of delta; the solver all-reduces
 // w[0..n] (delta travels in w[n]) over RCCL, then k_cg_update runs redundantly on every rank.
@@ -46,7 +46,7 @@ struct CgStatus {
   int done;
   int iters;
   int bad;  // non-finite or non-positive curvature encountered
-  int pad;
+  int pad;  // ticket of cg_status_tail (zero between kernels)
   double bb;  // |b|^2
   double rr;  // |r|^2 of the last tested iterate
   double gamma;  // single-workgroup mode: r.z of the current iterate
@@ -202,6 +202,48 @@ __device__ __forceinline__ bool cg_step_prologue(const CgVec& v, int it, CgStep&
   return true;
 }
 
+// Tail of k_cg_init* / k_cg_update*, called by all threads of every block after thread 0 has written the block's partial
+// slots of parity `par`: the block that arrives LAST (ticket in st->pad; release fence before the ticket, acquire fence
+// after it — agent scope, the per-XCD L2s are not coherent with each other) adds the r.r slots in slot order and records the
+// status of iteration `next_it`: |r|^2, the iteration count, and `done` when |r|^2 <= tol^2 |b|^2.  The apply kernels then
+// only look at st->done — until round 4 every workgroup of the first apply kernel re-reduced the slots itself (a dependent
+// round trip, a block reduction and five barriers in front of a kernel that is three round trips long).
+// `breakdown`: the step that led here had no positive curvature (identical in every block): the solve ends at `next_it - 1`.
+__device__ __forceinline__ void cg_status_tail(const CgVec& v, int next_it, int par, bool breakdown, bool bad, double* smem /* >= 6 */) {
+  __shared__ int s_last;
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const int t = atomicAdd(&v.st->pad, 1);
+    s_last = (t == (int)gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  double t[1] = {0.0};
+  const double* vp = v.vpart + (size_t)par * kCgMaxBlocks * 2;
+  for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) t[0] += vp[2 * b + 1];
+  block_sum<1>(t, smem);
+  if (threadIdx.x == 0) {
+    v.st->pad = 0;
+    if (breakdown) {
+      if (bad) v.st->bad = 1;
+      v.st->done = 1;
+      v.st->iters = next_it - 1;
+      return;
+    }
+    const double bb = next_it == 0 ? t[0] : v.st->bb;
+    const bool finite = isfinite(t[0]);
+    if (next_it == 0) {
+      v.st->bb = bb;
+      v.st->bad = 0;
+    }
+    v.st->rr = t[0];
+    v.st->iters = next_it;
+    if (!finite) v.st->bad = 1;
+    v.st->done = (!finite || t[0] <= v.tol2 * bb) ? 1 : 0;
+  }
+}
+
 // Epilogue: this block's partials of the NEXT iterate (r.z | r.r | the 2k deflation products) in one block reduction; block
 // 0 records the step's scalars and a breakdown.
 __device__ __forceinline__ void cg_step_epilogue(const CgVec& v, int it, const CgStep& o, double rz, double rr,
@@ -226,14 +268,10 @@ __device__ __forceinline__ void cg_step_epilogue(const CgVec& v, int it, const C
     if (blockIdx.x == 0) {
       v.scal[par].gamma = o.gamma;
       v.scal[par].alpha = o.alpha;
-      if (!o.ok) {
-        // gamma == 0 with a zero residual is plain convergence, anything else is a breakdown
-        if (!(o.gamma == 0.0 && isfinite(o.delta))) v.st->bad = 1;
-        v.st->done = 1;
-        v.st->iters = it;
-      }
     }
   }
+  // gamma == 0 with a zero residual is plain convergence, anything else is a breakdown
+  cg_status_tail(v, it + 1, (it + 1) & 1, !o.ok, !(o.gamma == 0.0 && isfinite(o.delta)), smem);
 }
 // z_p = z - W y, w_p = w - (A W) y at element o
 __device__ __forceinline__ void cgd_project(const CgVec& v, long o, const double (&y)[kCgMaxModes], double& z, double& w) {
@@ -315,54 +353,20 @@ static __global__ void __launch_bounds__(kBlock) k_cg_init(CgVec v) {
     v.vpart[blockIdx.x * 2] = acc[0];
     v.vpart[blockIdx.x * 2 + 1] = acc[1];
     if (blockIdx.x == 0) {
-      v.st->done = 0;
-      v.st->iters = 0;
-      v.st->bad = 0;
-      v.st->bb = 0.0;
-      v.st->rr = 0.0;
       v.scal[0].gamma = 0.0;
       v.scal[0].alpha = 0.0;
     }
   }
+  cg_status_tail(v, 0, 0, false, false, smem);
 }
 
-// To be called by ALL threads of EVERY block at the top of the first apply kernel of iteration
-// `it` (kBlock threads).  Returns true when the solve is finished (the caller returns).
-__device__ __forceinline__ bool cg_converged(const CgVec& v, int it, double tol2, double* smem /* >= 4*2+2 */) {
-  if (v.probe) return false;             // forming A W: an operator application outside the iteration
-  if (v.single) return v.st->done != 0;  // k_cg_init1 / k_cg_update1 already tested |r| and raised `done`
-  double t[2] = {0.0, 0.0};
-  {
-    const double* vp = v.vpart + (size_t)(it & 1) * kCgMaxBlocks * 2;
-    for (int b = threadIdx.x; b < v.nb_update; b += blockDim.x) {  // issued before the `done` round trip
-      t[0] += vp[2 * b];
-      t[1] += vp[2 * b + 1];
-    }
-  }
-  const int done0 = v.st->done;
-  const double bb_st = v.st->bb;  // same cache line as `done` (one trip); written at it == 0 only, read at it > 0 only
-  if (done0) return true;
-  block_sum<2>(t, smem);
-  if (threadIdx.x == 0) {
-    smem[8] = t[0];
-    smem[9] = t[1];
-  }
-  __syncthreads();
-  t[0] = smem[8];
-  t[1] = smem[9];
-  __syncthreads();
-  const double bb = it == 0 ? t[1] : bb_st;
-  const bool finite = isfinite(t[0]) && isfinite(t[1]);
-  const bool done = !finite || t[1] <= tol2 * bb;
-  __syncthreads();
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (it == 0) v.st->bb = bb;
-    v.st->rr = t[1];
-    v.st->iters = it;
-    if (!finite) v.st->bad = 1;
-    if (done) v.st->done = 1;
-  }
-  return done;
+// Top of the first apply kernel of iteration `it`: true when the solve is finished (the caller returns).
+__device__ __forceinline__ bool cg_converged(const CgVec& v, int it, double tol2, double* smem /* unused */) {
+  (void)it;
+  (void)tol2;
+  (void)smem;
+  if (v.probe) return false;  // forming A W: an operator application outside the iteration
+  return v.st->done != 0;     // the vector kernel that produced this iterate has tested |r| (cg_status_tail, k_cg_*1)
 }
 
 // All loads of a block are issued BEFORE its first store: the vectors may alias as far as the compiler knows, so a load
@@ -677,15 +681,11 @@ static __global__ void __launch_bounds__(kBlock) k_cg_init_joint(CgVec v) {
     v.vpart[blockIdx.x * 2] = acc[0];
     v.vpart[blockIdx.x * 2 + 1] = acc[1];
     if (blockIdx.x == 0) {
-      v.st->done = 0;
-      v.st->iters = 0;
-      v.st->bad = 0;
-      v.st->bb = 0.0;
-      v.st->rr = 0.0;
       v.scal[0].gamma = 0.0;
       v.scal[0].alpha = 0.0;
     }
   }
+  cg_status_tail(v, 0, 0, false, false, smem);
 }
 
 template <int PB>
@@ -928,6 +928,7 @@ static __global__ void __launch_bounds__(kBlock) k_cgd_finish(CgVec v, CgDeflati
 // cg_converged); it is also responsible for timing its dominant kernel (ctx->prof.begin(s, id, it)).
 //   defl   optional: deflate these modes (multi-block vector kernels only; small single-workgroup solves run plain).
 //          The k operator applications that form A W are counted in the returned iteration count.
+//   finished  optional, out: set when the solve ended by itself (convergence / breakdown) rather than at max_iter.
 //   hint   optional, in/out: the iteration count of the previous solve of this sequence.  The host enqueues iterations
 //          ahead of the device and reads the status back first where the previous solve ended, then every third
 //          iteration — so a converged solve leaves a couple of early-exit launches behind instead of a chunk of them.
@@ -939,7 +940,7 @@ struct CgNoPostZ {
 // the gather mirrors) there and rewrites the r.z partials of parity slot `par` (gp.hip: GpCoarse).
 template <int PB, bool HAS_INTR, typename Apply, typename PostZ = CgNoPostZ>
 inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& apply, const CgDeflation* defl = nullptr,
-                     int* hint = nullptr, PostZ&& post_z = PostZ()) {
+                     int* hint = nullptr, PostZ&& post_z = PostZ(), bool* finished = nullptr) {
   hipStream_t s = ctx->stream;
   const bool multi = ctx->comm.world > 1;
   v.delta_in_w = multi ? 1 : 0;
@@ -963,6 +964,7 @@ inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& 
       allreduce_sum(ctx, v.w, (size_t)v.n + 1);
     }
   };
+  GSFM_HIP_CHECK(hipMemsetAsync(v.st, 0, sizeof(CgStatus), s));  // (the ticket of cg_status_tail starts at zero)
   const bool deflate = defl != nullptr && defl->k > 0 && !v.single;
   const double* b_caller = v.b;
   const int gvec = std::min(256, grid_for((size_t)std::max((long)v.n, (long)v.N * 16), kBlock));
@@ -1000,8 +1002,8 @@ inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& 
   post_z(0);
   CgStatus* h = reinterpret_cast<CgStatus*>(ctx->h_pinned + 400);
   long iters = max_iter;
-  // convergence after p iterations is noticed by the first kernel of apply(p): read back after p + 1 enqueued iterations
-  int next_poll = (hint && *hint > 0) ? *hint + 1 : 8;
+  // convergence after p iterations is recorded by the vector kernel of iteration p - 1: read back after p enqueued iterations
+  int next_poll = (hint && *hint > 0) ? *hint : 8;
   if (ctx->comm.host_fn) next_poll = 1;  // (host-staged transport: the stream is drained every iteration anyway)
   for (int it = 0; it < max_iter; ++it) {
     apply_all(it);
@@ -1016,9 +1018,11 @@ inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& 
       GSFM_HIP_CHECK(hipMemcpyAsync(h, v.st, sizeof(CgStatus), hipMemcpyDeviceToHost, s));
       GSFM_HIP_CHECK(hipStreamSynchronize(s));
       GSFM_HIP_CHECK(hipGetLastError());
+      comm_check(ctx);
       ctx->prof.harvest(h->done ? h->iters : 0x7fffffff);  // launches of iterations >= iters found `done` and left at once
       if (h->done) {
         iters = h->iters;
+        if (finished) *finished = true;  // (converged or broke down — not "ran into max_iter")
         break;
       }
       next_poll = it + 1 + (ctx->comm.host_fn ? 1 : 3);

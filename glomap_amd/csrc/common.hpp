@@ -179,6 +179,7 @@ struct gsfm_ctx {
   int num_cus = 256;
   std::string last_error;
   int64_t stats[GSFM_STAT_COUNT] = {};  // which solver paths ran (gsfm_ctx_stats)
+  int knob[GSFM_KNOB_COUNT] = {};       // diagnostic / A-B knobs (gsfm_ctx_set_knob); 0 = default
   std::string dump_dir;  // non-empty: every solve writes its flat problem + result there (dump.hpp)
   int dump_seq = 0;
   // pinned host staging for small status read-backs
@@ -222,6 +223,12 @@ inline void allreduce(gsfm_ctx* ctx, double* dev, size_t n, int op /* 0 = sum, 1
     return;
   }
   GSFM_NCCL_CHECK(ncclAllReduce(dev, dev, n, ncclDouble, op == 0 ? ncclSum : ncclMax, ctx->comm.nccl, ctx->stream));
+}
+// After a stream synchronisation that follows collectives: a peer all-reduce that timed out has poisoned its output with
+// NaN and raised the host-mapped flag — fail here instead of returning a result computed from it.
+inline void comm_check(gsfm_ctx* ctx) {
+  if (ctx->comm.world > 1 && ctx->comm.peer.connected && *ctx->comm.peer.h_err)
+    throw StatusError(GSFM_ERR_COMM, "peer all-reduce: a rank did not arrive within the time limit");
 }
 inline void allreduce_sum(gsfm_ctx* ctx, double* dev, size_t n) { allreduce(ctx, dev, n, 0); }
 inline void allreduce_max(gsfm_ctx* ctx, double* dev, size_t n) { allreduce(ctx, dev, n, 1); }

@@ -1463,10 +1463,20 @@ class GpSolver final : public LmProblem {
       if (E_ <= 0) throw StatusError(GSFM_ERR_EMPTY_PROBLEM, "GP: no camera-to-camera constraints (gp.cc:41-45)");
       GSFM_REQUIRE(prob->pair_i && prob->pair_j && prob->pair_dir, "GP: pair tables missing");
     }
+    // An empty track set (ONLY_CAMERAS positions the cameras from the view graph alone, gp.cc:46-50) may come with null
+    // arrays: std::vector<T>(0).data() is nullptr.
+    GSFM_REQUIRE(P_ == 0 || prob->pt_offset, "GP: pt_offset missing");
+    GSFM_REQUIRE(M_ == 0 || (prob->obs_cam && prob->obs_dir), "GP: observation arrays missing");
+    GSFM_REQUIRE(P_ == 0 || pt_xyz, "GP: pt_xyz missing");
     std::vector<long> h_off;
-    to_host(ctx_, h_off, reinterpret_cast<const long*>(prob->pt_offset), (size_t)P_ + 1, mem);
+    if (prob->pt_offset) {
+      to_host(ctx_, h_off, reinterpret_cast<const long*>(prob->pt_offset), (size_t)P_ + 1, mem);
+      copy_in(ctx_, ws->off.ensure(P_ + 1), reinterpret_cast<const long*>(prob->pt_offset), (size_t)P_ + 1, mem);
+    } else {
+      h_off.assign(1, 0);
+      GSFM_HIP_CHECK(hipMemsetAsync(ws->off.ensure(1), 0, sizeof(long), s));
+    }
     GSFM_REQUIRE(h_off[0] == 0 && h_off[P_] == M_, "GP: pt_offset must start at 0 and end at num_obs");
-    copy_in(ctx_, ws->off.ensure(P_ + 1), reinterpret_cast<const long*>(prob->pt_offset), (size_t)P_ + 1, mem);
     copy_in(ctx_, ws->cam.ensure(M_ + 1), prob->obs_cam, (size_t)M_, mem);
     copy_in(ctx_, ws->dir.ensure(3 * (size_t)M_ + 3), prob->obs_dir, 3 * (size_t)M_, mem);
     const unsigned char* d_cal = nullptr;
@@ -1494,8 +1504,7 @@ class GpSolver final : public LmProblem {
       d_ccal = ws->c_cal.get();
     }
     // which cameras carry at least one used observation (gp.cc:128-162: only those are re-drawn)
-    std::vector<int> h_coff(NI_ + 2);
-    GSFM_HIP_CHECK(hipMemcpyAsync(h_coff.data(), g_.g.coff, (size_t)(NI_ + 2) * sizeof(int), hipMemcpyDeviceToHost, s));
+    const std::vector<int>& h_coff = ws->og.h_coff;  // host copy of the camera-major offsets (build_obs_graph)
     // state init (gp.cc:123-165, 261-264): cameras by index, then used tracks by index
     std::vector<double> h_c, h_X;
     to_host(ctx_, h_c, cam_center, 3 * (size_t)N_, mem);
@@ -1904,6 +1913,7 @@ class GpSolver final : public LmProblem {
     GSFM_HIP_CHECK(hipMemcpyAsync(ctx_->h_pinned + 256, ws->scal.get(), 7 * sizeof(double), hipMemcpyDeviceToHost, s));
     GSFM_HIP_CHECK(hipStreamSynchronize(s));
     GSFM_HIP_CHECK(hipGetLastError());
+    comm_check(ctx_);
     std::memcpy(h, ctx_->h_pinned + 256, sizeof(h));
     *model_change = h[0];
     *step_norm = std::sqrt(h[1] + h[3]);
@@ -1942,6 +1952,7 @@ class GpSolver final : public LmProblem {
     GSFM_HIP_CHECK(hipMemcpyAsync(ctx_->h_pinned + 300, dev, n * sizeof(double), hipMemcpyDeviceToHost, s));
     GSFM_HIP_CHECK(hipStreamSynchronize(s));
     GSFM_HIP_CHECK(hipGetLastError());
+    comm_check(ctx_);
     std::memcpy(out, ctx_->h_pinned + 300, n * sizeof(double));
   }
 
@@ -1951,7 +1962,7 @@ class GpSolver final : public LmProblem {
   bool coarse_setup(GpCoarseDev& cs, Apply& apply) {
     GpWs* ws = ws_;
     hipStream_t s = ctx_->stream;
-    static const int m_env = std::getenv("GSFM_GP_COARSE_M") ? std::atoi(std::getenv("GSFM_GP_COARSE_M")) : 0;  // A/B: cluster size
+    const int m_env = ctx_->knob[GSFM_KNOB_GP_COARSE_CLUSTER];  // A/B: cluster size
     cs.N = N_;
     cs.m = std::max((m_env > 0 ? m_env : 32) << coarse_grow_, (4 * N_ + kCoarseMaxModes - 1) / kCoarseMaxModes);
     cs.nc = (N_ + cs.m - 1) / cs.m;
@@ -2100,11 +2111,12 @@ class GpSolver final : public LmProblem {
     // and this and the later solves of the LM problem get the second-level preconditioner (GpCoarseDev)
     const bool may_switch = !coarse && coarse_ok_ && !coarse_on_ && !rig_ && E_ == 0 && g_.opt_c && N_ > kCgSingleMaxBlocks &&
                             opt_.lm.pcg_max_iterations > kCoarseTrigger;
+    bool finished = false;
     const long iters0 = cg_solve<3, false>(ctx_, cg_, tol, may_switch ? kCoarseTrigger : opt_.lm.pcg_max_iterations, apply,
                                            defl.k ? &defl : nullptr, &pcg_hint_, [&](int par) {
                                              if (coarse) coarse_correct(cs, par);
-                                           });
-    if (may_switch && iters0 >= kCoarseTrigger) {
+                                           }, &finished);
+    if (may_switch && !finished) {  // still running at the cap (a solve that converged just below it is kept)
       coarse_on_ = true;
       return iters0 + pcg();
     }
@@ -2150,7 +2162,7 @@ class GpSolver final : public LmProblem {
 
 int gp_solve_impl(gsfm_ctx* ctx, const gsfm_gp_problem* prob, const gsfm_gp_options* opt, double* cam_center,
                   double* pt_xyz, gsfm_report* rep) {
-  GSFM_REQUIRE(prob && opt && cam_center && pt_xyz, "GP: null argument");
+  GSFM_REQUIRE(prob && opt && cam_center && (pt_xyz || prob->num_pts == 0), "GP: null argument");
   GSFM_REQUIRE(opt->constraint_type >= 0 && opt->constraint_type <= 3, "GP: constraint_type out of range");
   if (prob->num_cams <= 0) throw StatusError(GSFM_ERR_EMPTY_PROBLEM, "GP: no images");   // gp.cc:37-40
   if (opt->constraint_type != 0 && prob->num_pairs <= 0)

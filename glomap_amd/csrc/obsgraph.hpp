@@ -62,7 +62,7 @@ struct ObsGraph {  // device view, passed to kernels by value
   const int* seg_cnt = nullptr;        // [S]   number of segments of this segment's camera
   const int* seg_multi = nullptr;      // [S]   slot of the segment among the slices of cut cameras (consecutive per camera), -1 for whole cameras
   const int* multi_first = nullptr;    // [nmulti] first segment of each cut camera
-  double* segpart = nullptr;           // [#slices of cut cameras][kSegPartW] parked partial sums (slot: seg_multi)
+  double* segpart = nullptr;           // [#slices of cut cameras][W] parked partial sums (slot: seg_multi; W = the kernel's accumulator width)
   int pass = 0;                        // 0: sweep over the segments; 1: combine pass over the cut cameras (see cam_seg_*)
 };
 
@@ -122,6 +122,9 @@ __device__ __forceinline__ int cam_seg_k0(const ObsGraph& g, int sg) { return g.
 __device__ __forceinline__ int cam_seg_k1(const ObsGraph& g, int sg) { return g.pass == 0 ? g.seg_k[sg + 1] : g.seg_k[sg]; }
 
 // Returns true when lane 0's `acc` holds the camera's complete sum (call after wave_allsum).
+// Parked sums are W doubles per slot (the kernel's own accumulator width: pass 0 and pass 1 of a kernel agree on it).  In
+// pass 1 lane j adds column j of the camera's slots in slice order (coalesced rows), then the totals are broadcast into
+// `acc` — the same sums in the same order as a serial loop, without one lane walking cnt x W values.
 template <int W>
 __device__ __forceinline__ bool cam_seg_total(const ObsGraph& g, int sg, double (&acc)[W], int lane) {
   static_assert(W <= kSegPartW, "accumulator wider than the partial-sum slots");
@@ -129,21 +132,20 @@ __device__ __forceinline__ bool cam_seg_total(const ObsGraph& g, int sg, double 
   if (g.pass == 0) {
     if (cnt == 1) return true;
     if (lane == 0) {
-      double* dst = g.segpart + (size_t)g.seg_multi[sg] * kSegPartW;
+      double* dst = g.segpart + (size_t)g.seg_multi[sg] * W;
 #pragma unroll
       for (int j = 0; j < W; ++j) dst[j] = acc[j];
     }
     return false;
   }
-  if (lane == 0) {
-    const double* src = g.segpart + (size_t)g.seg_multi[sg] * kSegPartW;  // sg = the camera's first segment in pass 1
-#pragma unroll
-    for (int j = 0; j < W; ++j) acc[j] = 0.0;
-    for (int q = 0; q < cnt; ++q) {
-#pragma unroll
-      for (int j = 0; j < W; ++j) acc[j] += src[(size_t)q * kSegPartW + j];
-    }
+  const double* src = g.segpart + (size_t)g.seg_multi[sg] * W;  // sg = the camera's first segment in pass 1
+  double col0 = 0.0, col1 = 0.0;
+  for (int q = 0; q < cnt; ++q) {
+    if (lane < W) col0 += src[(size_t)q * W + lane];
+    if (W > 64 && lane + 64 < W) col1 += src[(size_t)q * W + lane + 64];
   }
+#pragma unroll
+  for (int j = 0; j < W; ++j) acc[j] = __shfl(j < 64 ? col0 : col1, j & 63, 64);
   return true;
 }
 
@@ -268,7 +270,7 @@ inline long build_obs_graph(gsfm_ctx* ctx, ObsGraphWs& ws, int N, long P, long M
   {
     const std::vector<int>& co = ws.h_coff;
     int seg_len = kSegLenMin;
-    if (const char* e = std::getenv("GSFM_SEG_LEN")) seg_len = std::max(64, std::atoi(e));  // diagnostics / A-B runs
+    if (ctx->knob[GSFM_KNOB_SEG_LEN] > 0) seg_len = std::max(64, ctx->knob[GSFM_KNOB_SEG_LEN]);  // diagnostics / A-B runs
     for (;;) {
       int cut = 0;
       for (int n = 0; n < N; ++n) cut += (co[n + 1] - co[n] > seg_len) ? 1 : 0;
@@ -332,6 +334,13 @@ inline long build_obs_graph(gsfm_ctx* ctx, ObsGraphWs& ws, int N, long P, long M
   g.c_src = ws.c_src.get();
   g.c_pt = ws.c_pt.get();
   return m_used;
+}
+
+// Camera-major slots of camera n (host).
+inline std::vector<int> cam_slots(const ObsGraphWs& ws, int n) {
+  std::vector<int> out;
+  for (int k = ws.h_coff[n]; k < ws.h_coff[n + 1]; ++k) out.push_back(k);
+  return out;
 }
 
 }  // namespace gsfm

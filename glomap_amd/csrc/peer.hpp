@@ -62,7 +62,7 @@ static __global__ void __launch_bounds__(256) k_peer_push(PeerDev pd, const doub
   __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned done = atomicAdd(counter, 1u);
+    const unsigned done = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (done == gridDim.x - 1) {
       *counter = 0;
       __threadfence_system();
@@ -92,12 +92,16 @@ static __global__ void __launch_bounds__(256) k_peer_sum(PeerDev pd, double* __r
     }
   }
   __syncthreads();
-  if (late) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  if (late) {  // a rank never arrived: the result must not look like one (NaN poisons every later decision), the host is told
     if (threadIdx.x == 0) *err = 1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] = __builtin_nan("");
     return;
   }
+  // the threads that read the slots are not the ones that acquired the flags: every one of them orders its loads behind the
+  // peers' stores itself (system scope; outside the formal model otherwise once the mailboxes are L2-cached allocations)
+  __threadfence_system();
   const double* s0 = peer_slot(mine, parity, 0, pd.world, pd.cap);
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     double acc = __builtin_nontemporal_load(s0 + i);
     for (int r = 1; r < pd.world; ++r) {

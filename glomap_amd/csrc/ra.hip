@@ -1354,7 +1354,7 @@ void setup_device(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
   d.dense_have = false;
   d.dense_refresh = false;
   d.blockdense = allow_blockdense && d.grav == nullptr && !d.dense && ctx->comm.world == 1 && N <= kBlockDenseMaxN && opt->pcg_max_iterations > 0 &&
-                 !opt->force_iterative && getenv("GSFM_RA_NO_BLOCKDENSE") == nullptr;
+                 !opt->force_iterative && !ctx->knob[GSFM_KNOB_RA_NO_BLOCKDENSE];
   d.bd_have = d.bd_refresh = d.bd_fresh = false;
   d.bd_base_iters = 0;
   d.bd_skip_stale = 0;
@@ -1363,7 +1363,7 @@ void setup_device(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
     d.bd_nb = (((N + d.bd_nblk - 1) / d.bd_nblk + kTile - 1) / kTile) * kTile;
   }
   {
-    static const bool always = getenv("GSFM_RA_DENSE_REFACTOR") != nullptr;
+    const bool always = ctx->knob[GSFM_KNOB_RA_DENSE_REFACTOR] != 0;
     d.dense_always_factor = always;
   }
   d.T = (N + kTile - 1) / kTile;
@@ -1435,7 +1435,7 @@ void setup_device(gsfm_ctx* ctx, const gsfm_ra_problem* prob, const gsfm_ra_opti
       h_ej[e] = pos[h_ej[e]];
     }
     // substructuring (ra_sub.hpp): interiors of more, smaller BFS blocks first, the interface between them last
-    static const bool no_sub = getenv("GSFM_RA_NO_SUBSTRUCTURE") != nullptr;  // A/B switch: the plain block preconditioner
+    const bool no_sub = ctx->knob[GSFM_KNOB_RA_NO_SUBSTRUCTURE] != 0;  // A/B knob: the plain block preconditioner
     if (!no_sub) sub_plan(N, E, h_ei.data(), h_ej.data(), d.plan);
     d.sub = !no_sub && d.plan.ok;
     if (d.sub) {

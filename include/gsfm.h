@@ -134,6 +134,21 @@ enum gsfm_stat {
 };
 /* Copies min(n, GSFM_STAT_COUNT) counters to out; reset != 0 zeroes them afterwards. */
 int gsfm_ctx_stats(gsfm_ctx* ctx, int64_t* out, int n, int reset);
+/* Diagnostic / A-B knobs of a context, for tests and measurements (0 = what the library ships).  The library itself reads no
+ * environment variable for any of them: a caller that wants to compare two variants says so through this call. */
+enum gsfm_knob {
+  GSFM_KNOB_BA_AW_BY_APPLICATION = 0, /* BA: form the gauge products A W by operator applications, not in closed form */
+  GSFM_KNOB_BA_AW_CHECK = 1,          /* BA: form them both ways and print the difference (stderr) */
+  GSFM_KNOB_BA_SEPARATE_BLOCKS = 2,   /* BA: 6x6 + 8x8 block-Jacobi instead of the joint pose + intrinsics blocks */
+  GSFM_KNOB_BA_NO_NONTEMPORAL = 3,    /* BA phase A: plain instead of non-temporal plane loads */
+  GSFM_KNOB_RA_NO_BLOCKDENSE = 4,     /* RA, 2048 < N <= 32768: Jacobi-PCG instead of the dense block preconditioners */
+  GSFM_KNOB_RA_NO_SUBSTRUCTURE = 5,   /* RA: plain block-diagonal instead of the substructured preconditioner */
+  GSFM_KNOB_RA_DENSE_REFACTOR = 6,    /* RA, N <= 2048: re-invert at every IRLS iteration */
+  GSFM_KNOB_GP_COARSE_CLUSTER = 7,    /* GP second level: cameras per cluster (0: 32) */
+  GSFM_KNOB_SEG_LEN = 8,              /* camera-major order: observations per camera segment (0: 1024) */
+  GSFM_KNOB_COUNT = 9
+};
+int gsfm_ctx_set_knob(gsfm_ctx* ctx, int knob, int value);
 /* Text of the last failure on this ctx (what the HIP / RCCL call or the argument check said); "" when there was none.  The
  * pointer stays valid until the next failing call on the ctx. */
 const char* gsfm_ctx_last_error(gsfm_ctx* ctx);

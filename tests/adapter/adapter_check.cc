@@ -177,6 +177,22 @@ int main() {
       if (ctype == GlobalPositionerOptions::ONLY_CAMERAS)  // the tracks are not part of the problem: untouched
         for (auto& [tid, tr] : tracks_c)
           if (tr.xyz[0] != tracks[tid].xyz[0] || tr.is_initialized != tracks[tid].is_initialized) return std::printf("ONLY_CAMERAS touched a track\n"), 1;
+      if (ctype == GlobalPositionerOptions::ONLY_CAMERAS) {
+        // ... and they may be absent altogether (gp.cc:46-50 asks for tracks only when the type uses them): the packed track
+        // arrays are then empty vectors, i.e. null pointers at the C ABI
+        auto frames_e = frames;
+        for (int n = 0; n < N; ++n) images[n].frame_ptr = &frames_e[n];
+        std::unordered_map<track_t, Track> no_tracks;
+        if (!gsfm_glomap::GlobalPositioner(gc).Solve(vg_t, rigs, cameras, frames_e, images, no_tracks))
+          return std::printf("ONLY_CAMERAS without tracks failed\n"), 1;
+        double e0[3], e1[3], e8[3];
+        center(frames_e[0], e0);
+        center(frames_e[1], e1);
+        center(frames_e[8], e8);
+        const double re = dist(e0, e8) / dist(e0, e1);
+        if (std::fabs(re / ratio_ref - 1.0) > 1e-3) return std::printf("ONLY_CAMERAS without tracks: ratio %.6f vs %.6f\n", re, ratio_ref), 1;
+        for (int n = 0; n < N; ++n) images[n].frame_ptr = &frames_c[n];
+      }
       GlobalPositionerOptions none = gc;  // no image pairs at all: refused (gp.cc:41-45)
       ViewGraph empty;
       if (gsfm_glomap::GlobalPositioner(none).Solve(empty, rigs, cameras, frames_c, images, tracks_c)) return std::printf("GP accepted an empty view graph\n"), 1;

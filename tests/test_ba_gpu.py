@@ -190,23 +190,26 @@ def test_scene_level_bundle_adjuster_and_positioner(gsfm_ctx):
     (dict(), dict(optimize_rotations=False)),                           # rotations frozen: 4 modes
     (dict(shared_intrinsics=True), dict(optimize_intrinsics=False)),    # no free intrinsics
 ])
-def test_ba_closed_form_gauge_products_equal_operator_applications(gsfm_ctx, kw, opts, monkeypatch):
+def test_ba_closed_form_gauge_products_equal_operator_applications(gsfm_ctx, kw, opts):
     """The deflated solves need A W for the gauge modes.  k_ba_aw_modes forms it in one camera-major sweep from the identity
-    J_cam W + J_pt m = 0 (ba.hip); GSFM_BA_AW_APPLY=1 forms it by one operator application per mode.  Same system, same
+    J_cam W + J_pt m = 0 (ba.hip); the knob ba_aw_by_application forms it by one operator application per mode.  Same system, same
     modes: the two runs must walk the same LM path to the same result, the closed form with fewer operator applications."""
     p = synthetic.make_ba_problem(num_cams=150, num_pts=6000, seed=11, **kw)
     o = estimators.BundleAdjusterOptions(**opts)
     rc, q_c, t_c, X_c, intr_c, rep_c = estimators.ba_solve(p, o, ctx=gsfm_ctx)
     assert rc == 0
-    monkeypatch.setenv("GSFM_BA_AW_APPLY", "1")
-    rc, q_a, t_a, X_a, intr_a, rep_a = estimators.ba_solve(p, o, ctx=gsfm_ctx)
+    gsfm_ctx.set_knob("ba_aw_by_application", 1)
+    try:
+        rc, q_a, t_a, X_a, intr_a, rep_a = estimators.ba_solve(p, o, ctx=gsfm_ctx)
+    finally:
+        gsfm_ctx.set_knob("ba_aw_by_application", 0)
     assert rc == 0
     print("closed", rep_c["iterations"], rep_c["linear_iterations"], rep_c["final_cost"], "applied", rep_a["iterations"],
           rep_a["linear_iterations"], rep_a["final_cost"])
     assert rep_c["iterations"] == rep_a["iterations"]
     assert abs(rep_c["final_cost"] - rep_a["final_cost"]) <= 1e-9 * rep_a["final_cost"] + 1e-12
     # poses to the tolerance of the reduced solves (1e-6) — the scale of the scene is a free gauge of bundle adjustment, and
-    # what two solves leave along it differs at that level (tools/exp_ba_aw_check.py with GSFM_BA_AW_CHECK=1 compares the
+    # what two solves leave along it differs at that level (tools/exp_ba_aw_check.py (knob ba_aw_check) compares the
     # products themselves: 1e-13 relative)
     assert np.abs(q_c - q_a).max() < 1e-6 and np.abs(t_c - t_a).max() < 1e-5 * (1 + np.abs(t_a).max())
     assert np.abs(intr_c - intr_a).max() < 1e-4

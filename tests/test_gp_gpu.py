@@ -136,6 +136,29 @@ def test_gp_constraint_types_match_oracle(gsfm_ctx, ctype, ncam, npts, noise, se
         assert np.array_equal(X_g, p.pt_xyz)
 
 
+def test_gp_only_cameras_without_any_track(gsfm_ctx):
+    """ONLY_CAMERAS positions the cameras from the view graph alone: the reference asks for tracks only when the constraint
+    type uses them (gp.cc:46-50).  An empty track set reaches the C ABI as null arrays (std::vector<T>(0).data())."""
+    p = synthetic.make_gp_problem(num_cams=24, num_pts=300, seed=3, dir_noise=0.0, outlier_ratio=0.0)
+    p.pair_i, p.pair_j, p.pair_dir = _pairs(p, np.random.default_rng(3), noise=0.0)
+    kw = dict(constraint_type=int(ogp.ONLY_CAMERAS))
+    rc, c_ref, _, rep_ref = estimators.gp_solve(p, estimators.GlobalPositionerOptions(**kw), ctx=gsfm_ctx)
+    assert rc == 0
+    e = type(p)(num_cams=p.num_cams, num_pts=0, pt_offset=np.zeros(1, np.int64), obs_cam=np.zeros(0, np.int32),
+                obs_dir=np.zeros((0, 3)), obs_calibrated=np.zeros(0, np.uint8), cam_center=p.cam_center, pt_xyz=np.zeros((0, 3)))
+    e.pair_i, e.pair_j, e.pair_dir = p.pair_i, p.pair_j, p.pair_dir
+    rc, c_e, X_e, rep = estimators.gp_solve(e, estimators.GlobalPositionerOptions(**kw), ctx=gsfm_ctx)
+    assert rc == 0 and X_e.shape == (0, 3)
+    assert rep["final_cost"] < 1e-10
+    assert _rel_diff(c_e, p.gt_center) < 1e-4
+    # with tracks present the frames the kept tracks touch are re-drawn too (gp.cc:121-163), so the random starts differ;
+    # both recover the noise-free scene
+    assert _rel_diff(c_ref, p.gt_center) < 1e-4
+    # the other types still refuse an empty track set (gp.cc:46-50)
+    rc, *_ = estimators.gp_solve(e, estimators.GlobalPositionerOptions(constraint_type=int(ogp.POINTS_AND_CAMERAS)), ctx=gsfm_ctx)
+    assert rc == _lib_status("GSFM_ERR_EMPTY_PROBLEM")
+
+
 def _oracle_pairs(p, **kw):
     opt = ogp.GlobalPositionerOptions(**kw)
     return ogp.solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated, p.cam_center, p.pt_xyz, opt,

@@ -1,9 +1,9 @@
-"""Skewed-visibility problems of tests/test_edge_cases_gpu.py: GPU (camera lists cut into slices, or with GSFM_SEG_LEN set
+"""Skewed-visibility problems of tests/test_edge_cases_gpu.py: GPU (camera lists cut into slices, or with the knob seg_len set
 so large that nothing is cut) against the C++ CPU oracle — LM iterations, final cost, pose differences."""
 import os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) < 2:
-    for env in ({}, {"GSFM_SEG_LEN": "1000000000"}, {"GSFM_SEG_LEN": "256"}):
+    for env in ({}, {"GSFM_KNOBS": "seg_len=1000000000"}, {"GSFM_KNOBS": "seg_len=256"}):
         print("=== env", env, flush=True)
         subprocess.run([sys.executable, __file__, "run"], env={**os.environ, **env})
     sys.exit(0)
