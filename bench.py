@@ -478,7 +478,9 @@ def cpu_baseline_pipeline(p_ra, p_gp, p_ba, gpu_rep):
                                (the oracle configuration tests/test_fullsize_gpu.py compares against)."""
     from oracle import cpu
 
-    out = {"unit": "obs/s", "cores": cpu.num_threads(), "host_hw_threads": os.cpu_count(), "kind": "port",
+    cpu.load_native()  # -march=native build of the restatement, made on this box (oracle/Makefile `native`)
+
+    out = {"unit": "obs/s", "cores": cpu.num_threads(), "host_hw_threads": os.cpu_count(), "kind": "port", "build": cpu.BUILD_FLAGS,
            "cores_note": "cores = the CPUs this process may use (scheduler affinity capped by the cgroup CPU quota of the box)"}
 
     def leg(gp_tol, ba_tol, deflate):
@@ -505,8 +507,9 @@ def cpu_baseline_pipeline(p_ra, p_gp, p_ba, gpu_rep):
         out["exact_solves"] = leg(1e-14, 1e-14, 0)
     out["sample"] = ("ONE pass of the same configs[3] inputs the GPU line is timed on (RA %d edges + GP %d obs + BA %d obs), "
                      "restated C++/OpenMP CPU oracle on %d threads (RA factorisation single-threaded) with the GPU's linear-solver "
-                     "settings (PCG 1e-8 / 1e-6, gauge modes deflated) — not Ceres; `exact_solves` = the same pass with PCG to 1e-14"
-                     % (p_ra.num_edges, p_gp.num_obs, p_ba.num_obs, out["cores"]))
+                     "settings (PCG 1e-8 / 1e-6, gauge modes deflated) — not Ceres; `exact_solves` = the same pass with PCG to 1e-14; "
+                     "compiler flags: %s"
+                     % (p_ra.num_edges, p_gp.num_obs, p_ba.num_obs, out["cores"], cpu.BUILD_FLAGS))
     return out
 
 
@@ -780,6 +783,8 @@ def cpu_baseline_ra(p):
     same view graph."""
     from oracle import cpu
 
+    cpu.load_native()  # -march=native build of the restatement, made on this box (oracle/Makefile `native`)
+
     t0 = time.perf_counter()
     n = 0
     while True:
@@ -789,7 +794,7 @@ def cpu_baseline_ra(p):
         if dt > 10.0 or n >= 8:
             break
     return {"value": p.num_edges * n / dt, "unit": "edges/s", "cores": cpu.num_threads(), "host_hw_threads": os.cpu_count(),
-            "kind": "port",
+            "kind": "port", "build": cpu.BUILD_FLAGS,
             "sample": f"{n} full RA solves of the same view graph (restated C++/OpenMP CPU oracle, single-threaded skyline "
                       "Cholesky; not Ceres/CHOLMOD)"}
 
@@ -888,11 +893,13 @@ def bench_gp(args, ctx, rank, world, barrier, dist):
 def cpu_baseline_gp(p):
     from oracle import cpu
 
+    cpu.load_native()  # -march=native build of the restatement, made on this box (oracle/Makefile `native`)
+
     t0 = time.perf_counter()
     ok, c, X, s = cpu.gp_solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated, p.cam_center, p.pt_xyz)
     dt = time.perf_counter() - t0
     return {"value": p.num_obs * max(1, s.iterations) / dt, "unit": "obs/s", "cores": cpu.num_threads(),
-            "host_hw_threads": os.cpu_count(), "kind": "port", "seconds": dt,
+            "host_hw_threads": os.cpu_count(), "kind": "port", "seconds": dt, "build": cpu.BUILD_FLAGS,
             "sample": f"one GP solve of the SAME input ({p.num_obs} observations, {s.iterations} LM iterations; restated "
                       "C++/OpenMP CPU oracle with exact elimination, not Ceres)"}
 
@@ -998,12 +1005,14 @@ def bench_ba(args, ctx, rank, world, barrier, dist):
 def cpu_baseline_ba(p):
     from oracle import cpu
 
+    cpu.load_native()  # -march=native build of the restatement, made on this box (oracle/Makefile `native`)
+
     t0 = time.perf_counter()
     r = cpu.ba_solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_xy, p.cam_intr, p.intr_model, p.fixed_cam, p.cam_q, p.cam_t,
                      p.pt_xyz, p.intr_params)
     dt = time.perf_counter() - t0
     return {"value": p.num_obs * max(1, r[5].iterations) / dt, "unit": "obs/s", "cores": cpu.num_threads(),
-            "host_hw_threads": os.cpu_count(), "kind": "port", "seconds": dt,
+            "host_hw_threads": os.cpu_count(), "kind": "port", "seconds": dt, "build": cpu.BUILD_FLAGS,
             "sample": f"one BA solve of the SAME input ({p.num_obs} observations, {r[5].iterations} LM iterations; restated "
                       "C++/OpenMP CPU oracle with exact elimination, not Ceres)"}
 

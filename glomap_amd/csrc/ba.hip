@@ -1270,7 +1270,8 @@ __global__ void __launch_bounds__(kBlock)
     k_ba_aw_modes(BaDev g, double yscale, const double* __restrict__ camR, const double* __restrict__ t,
                   const double* __restrict__ par, const double* __restrict__ c_w, const double* __restrict__ ptb,
                   const double* __restrict__ ftab, const double* __restrict__ dvec, const double* __restrict__ W,
-                  double* __restrict__ AW, long nvec) {
+                  double* __restrict__ AW, long nvec,
+                  double* __restrict__ ipart /* [N][NM][8]: the camera's share of its (shared) intrinsics block's rows, or null */) {
   constexpr int NM = ROT ? 7 : 4;  // [3 translations | 3 rotations | scale] or [3 translations | scale]
   constexpr int U = 6 + F;
   constexpr int NACC = NM * U;
@@ -1342,13 +1343,34 @@ __global__ void __launch_bounds__(kBlock)
         const double* wj = W + (size_t)j * nvec;
 #pragma unroll
         for (int i = 0; i < 6; ++i) out[6 * (long)n + i] = acc[j * U + i] + yscale * dvec[6 * (long)n + i] * wj[6 * (long)n + i];
+        if (ipart == nullptr) {  // the block is this camera's own
 #pragma unroll
-        for (int i = 0; i < F; ++i) {
-          const int pm = mp.m[i];
-          if (pm >= 0) out[6 * (long)g.g.N + 8 * (long)ik + pm] = acc[j * U + 6 + i];
+          for (int i = 0; i < F; ++i) {
+            const int pm = mp.m[i];
+            if (pm >= 0) out[6 * (long)g.g.N + 8 * (long)ik + pm] = acc[j * U + 6 + i];
+          }
+        } else {  // a block shared by several cameras: the shares are added per block in camera order (k_ba_group_sum)
+          double* ip = ipart + ((size_t)n * NM + j) * 8;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) ip[i] = 0.0;
+#pragma unroll
+          for (int i = 0; i < F; ++i) {
+            const int pm = mp.m[i];
+            if (pm >= 0) ip[pm] = acc[j * U + 6 + i];
+          }
         }
       }
     }
+  }
+}
+
+// AW[j][6 N + 8 k + i] = gsum[k][j][i]: the per-block sums of the cameras' shares (shared intrinsics blocks)
+__global__ void __launch_bounds__(kBlock)
+    k_ba_aw_intr_scatter(int N, int K, int nm, const double* __restrict__ gsum, double* __restrict__ AW, long nvec) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)K * nm * 8; i += (long)gridDim.x * blockDim.x) {
+    const long k = i / (nm * 8);
+    const int j = (int)((i / 8) % nm), c = (int)(i % 8);
+    AW[(size_t)j * nvec + 6 * (long)N + 8 * k + c] = gsum[i];
   }
 }
 
@@ -1367,7 +1389,7 @@ struct BaWs {
   DevBuf<signed char> intr_map, intr_slot;
   DevBuf<double2> jt;
   DevBuf<double> xy, c_xy, c_w, q, qn, t, tn, camR, camRn, X, Xn, par, parn, ptH, ptb, pth, ptrec, ptdiag, ptjs, diag, js,
-      dvec, grad, gred, rhs, spose, scross, minvj, zrec, ipart, iacc16, iacc44, yi_part, minv, cg_x, cg_r, cg_z, cg_p, cg_s, cg_w, vpart,
+      awi_part, awi_sum, dvec, grad, gred, rhs, spose, scross, minvj, zrec, ipart, iacc16, iacc44, yi_part, minv, cg_x, cg_r, cg_z, cg_p, cg_s, cg_w, vpart,
       dpart, part, scal;
   DevBuf<CgStatus> cgst;
   DevBuf<CgScal> cgsc;
@@ -2413,10 +2435,12 @@ class BaSolver final : public LmProblem {
       hipLaunchKernelGGL(k_ba_defl_modes, dim3(gridN_), dim3(kBlock), 0, s, N_, (long)n_, (const double*)Rk_, (const double*)tk_,
                          g_.fixed_cam, with_rot, W);
       defl.W = W;
-      // A W in closed form (k_ba_aw_modes): points optimised, every intrinsics block owned by one camera (or none free),
-      // the constant camera's observations found in one piece of the camera-major list
+      // A W in closed form (k_ba_aw_modes): points optimised, no point observed twice by the constant camera
       const bool no_closed = ctx_->knob[GSFM_KNOB_BA_AW_BY_APPLICATION] != 0;  // A/B and tests: form A W by operator applications
-      if (!no_closed && g_.opt_pts && (joint_ || F_ == 0) && aw_closed_ok_) {
+      if (!no_closed && g_.opt_pts && aw_closed_ok_) {
+        // intrinsics blocks shared by several cameras (not the joint layout): per-camera shares, then per-block sums
+        const bool shared_blocks = !joint_ && F_ > 0;
+        double* ipart = shared_blocks ? ws->awi_part.ensure((size_t)N_ * defl.k * 8) : nullptr;
         GSFM_HIP_CHECK(hipMemsetAsync(defl.AW, 0, defl.k * n * sizeof(double), s));
         double* ftab = ws->ftab.ensure(6 * (size_t)std::max(1, nfix_));
         if (nfix_ > 0)
@@ -2428,7 +2452,7 @@ class BaSolver final : public LmProblem {
             constexpr bool ROT = decltype(rot)::value;
             WIDE_LAUNCH((k_ba_aw_modes<ROT, WIDE, F>), dim3(grid), dim3(kBlock), 0, s, gd, yscale, Rk_, tk_, par_, ws->c_w.get(),
                         (const double*)ws->ptb.get(), (const double*)ftab, (const double*)ws->dvec.get(), (const double*)W,
-                        defl.AW, (long)n_);
+                        defl.AW, (long)n_, ipart);
           };
           if (with_rot) {
             launch(std::true_type{}, g_, gridCam_);
@@ -2438,6 +2462,12 @@ class BaSolver final : public LmProblem {
             if (gridMulti_) launch(std::false_type{}, g1_, gridMulti_);
           }
         });
+        if (shared_blocks) {
+          double* gsum = ws->awi_sum.ensure((size_t)K_ * defl.k * 8);
+          if (with_rot) group_sum<56>(ipart, gsum); else group_sum<32>(ipart, gsum);
+          hipLaunchKernelGGL(k_ba_aw_intr_scatter, dim3(grid_for((size_t)K_ * defl.k * 8, kBlock)), dim3(kBlock), 0, s, N_, K_, defl.k,
+                             (const double*)gsum, defl.AW, (long)n_);
+        }
         if (ctx_->comm.world > 1) allreduce_sum(ctx_, defl.AW, defl.k * n);
         defl.aw_ready = defl.k;
         // diagnostics: keep the closed-form products, let cg_solve form them by operator applications as well, compare below

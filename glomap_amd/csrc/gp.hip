@@ -131,7 +131,8 @@ __global__ void __launch_bounds__(kBlock)
 // One wave per camera over the camera-major lists; wave reduction, no atomics.
 __global__ void __launch_bounds__(kBlock)
     k_gp_lin_cam(GpDev g, const double* __restrict__ c, const double* __restrict__ X,
-                 const double* __restrict__ s, double* __restrict__ hcc, double* __restrict__ gc) {
+                 const double* __restrict__ s, double* __restrict__ hcc, double* __restrict__ gc,
+                 double* __restrict__ c_s /* camera-major mirror of the scales, for k_gp_build_cam */) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (kBlock / 64);
@@ -143,7 +144,8 @@ __global__ void __launch_bounds__(kBlock)
     for (int k = cam_seg_k0(g.g, sg) + lane; k < cam_seg_k1(g.g, sg); k += 64) {
       const long src = g.g.c_src[k];
       const V3 d = ld3(X + 3 * (long)g.g.c_pt[k]) - cn;
-      const double sk = s[src];
+      const double sk = s[src];  // a random 8-byte gather = one fabric request per observation: paid here, once per accepted
+      c_s[k] = sk;               // step, and handed on in camera order to every k_gp_build_cam until the next one
       const V3 r = ld3(g.c_dir + 3 * (long)k) - sk * d;
       double rho, w;
       huber(g.huber_a, (g.c_cal == nullptr || g.c_cal[k]) ? g.wpt : 0.5 * g.wpt, dot(r, r), rho, w);
@@ -226,12 +228,14 @@ __global__ void __launch_bounds__(kBlock)
                      const double* __restrict__ s, const double* __restrict__ wrob,
                      const double* __restrict__ jss, const double* __restrict__ jsx,
                      const double* __restrict__ hppd, double* __restrict__ qa, double* __restrict__ qb,
-                     double* __restrict__ ptb, double* __restrict__ ptrec, double* __restrict__ pth) {
+                     double* __restrict__ ptb, double* __restrict__ ptrec, double* __restrict__ pth,
+                     double2* __restrict__ tq /* [T][64] (a, beta) in the padded tile layout of k_gp_phaseA */) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (kBlock / 64);
   for (int tile = wave; tile < g.g.T; tile += nwaves) {
     const long k0 = g.g.tile_k[tile], k1 = g.g.tile_k[tile + 1];
+    const bool one_trip = k1 - k0 <= 64;
     double acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // H (xx xy xz yy yz zz) | g_p | sum_k Q_k d_k (scale mode)
     int key = -1 - lane;
     for (long k = k0 + lane; k < k1; k += 64) {
@@ -249,6 +253,7 @@ __global__ void __launch_bounds__(kBlock)
       const double a = w * sk * sk;
       qa[k] = a;
       qb[k] = beta;
+      if (one_trip) tq[(long)tile * 64 + lane] = make_double2(a, beta);
       const double ab = a * beta;
       acc[0] += a - ab * d.x * d.x;
       acc[1] += -ab * d.x * d.y;
@@ -302,7 +307,7 @@ __global__ void __launch_bounds__(kBlock)
 // ---- build, camera side: (a_k, beta_k) in camera-major order, reduced gradient, S_cc blocks -----
 // One wave per camera.  g'_c = sum_k q_k + Q_k e_p;  S_cc = sum_k Q_k - Q_k H_pp^-1 Q_k.
 __global__ void __launch_bounds__(kBlock)
-    k_gp_build_cam(GpDev g, double radius, const double* __restrict__ c, const double* __restrict__ s,
+    k_gp_build_cam(GpDev g, double radius, const double* __restrict__ c, const double* __restrict__ c_s,
                    const double* __restrict__ ptb, double* __restrict__ c_qa, double* __restrict__ c_qb,
                    double* __restrict__ gred, double* __restrict__ scc) {
   const int lane = threadIdx.x & 63;
@@ -319,7 +324,7 @@ __global__ void __launch_bounds__(kBlock)
       const V3 d = ld3(b) - cn;
       const V3 e = ld3(b + 3);
       const S3 Hi{b[6], b[7], b[8], b[9], b[10], b[11]};
-      const double sk = s[src];
+      const double sk = c_s[k];  // (the scales in camera order: k_gp_lin_cam)
       const V3 r = ld3(g.c_dir + 3 * (long)k) - sk * d;
       double rho, w;
       huber(g.huber_a, (g.c_cal == nullptr || g.c_cal[k]) ? g.wpt : 0.5 * g.wpt, dot(r, r), rho, w);
@@ -393,74 +398,90 @@ __global__ void __launch_bounds__(kBlock)
 //   convergence test -> [gathers, `used` and H_pp^-1 of the tail lanes] -> scan -> store                (3 trips)
 // (first version: convergence test -> tile bounds by a vector load -> indices -> gathers -> scan -> tail loads -> store,
 // 6 trips, 106 us instead of 101 at configs[3]).
+// Padded tile layout (tidx / tq, 64 slots per tile whatever its fill): slot (tile, lane) = the tile's lane-th observation
+// as (track, camera) — (-1, 0) for padding and for observations of unused tracks, (-2, 0) in lane 0 of a tile that holds a
+// track longer than a wave — and its (a, beta).  The sweep is a chain of dependent round trips (tile table -> indices and
+// coefficients -> gathers), and with the padded copies the first link is gone: the slot address follows from the wave's
+// index alone.  k_gp_tile_idx fills tidx once per solve, k_gp_build_track writes tq with every linearisation.
+__global__ void __launch_bounds__(kBlock) k_gp_tile_idx(GpDev g, int2* __restrict__ tidx) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (kBlock / 64);
+  for (int tile = wave; tile < g.g.T; tile += nwaves) {
+    const long k0 = g.g.tile_k[tile], k1 = g.g.tile_k[tile + 1];
+    int2 ix = make_int2(-1, 0);
+    if (k1 - k0 > 64) {
+      if (lane == 0) ix.x = -2;
+    } else if (k0 + lane < k1) {
+      const int p = g.g.obs_pt[k0 + lane];
+      if (g.g.used[p]) ix = make_int2(p, g.g.cam[k0 + lane]);
+    }
+    tidx[(long)tile * 64 + lane] = ix;
+  }
+}
+
 __global__ void __launch_bounds__(kBlock)
     k_gp_phaseA(GpDev g, CgVec v, int it, double tol2, const double* __restrict__ cz,
                 const double* __restrict__ qa, const double* __restrict__ qb,
-                const double* __restrict__ pth, double* __restrict__ ptrec) {
+                const double* __restrict__ pth, double* __restrict__ ptrec, const int2* __restrict__ tidx,
+                const double2* __restrict__ tq) {
   __shared__ double smem[4 * 2 + 2];
   const int lane = threadIdx.x & 63;
   const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
   const bool have = tile < g.g.T;
-  long k0 = 0, k1 = 0;
+  int2 ix = make_int2(-1, 0);
+  double2 q2 = make_double2(0.0, 0.0);
   if (have) {
-    k0 = g.g.tile_k[tile];
-    k1 = g.g.tile_k[tile + 1];
-  }
-  long k = k0 + lane;
-  int p = -1;
-  long n = 0;
-  double ak = 0.0, bk = 0.0;
-  if (k < k1) {
-    p = g.g.obs_pt[k];
-    n = g.g.cam[k];
-    ak = qa[k];
-    bk = qb[k];
+    ix = tidx[(long)tile * 64 + lane];
+    q2 = tq[(long)tile * 64 + lane];
   }
   if (cg_converged(v, it, tol2, smem)) return;
   if (!have) return;
-  // a tile of at most 64 observations (every tile but those of tracks longer than a wave): the keys are final, so the
-  // tail lanes know themselves now and their `used` flag and H_pp^-1 travel together with the gathers
-  const bool one_trip = k1 - k0 <= 64;  // wave-uniform
-  const int key0 = k < k1 ? p : -1 - lane;
-  const bool tail0 = seg_is_tail(key0, lane) && key0 >= 0;
-  double acc[3] = {0, 0, 0};
-  int key = -1 - lane;
-  unsigned char u0 = 0;
-  double hb[6] = {0, 0, 0, 0, 0, 0};
-  bool first = true;
-  while (k < k1) {
-    key = p;
-    V3 cn, zn;
-    ld6(cz + 6 * n, cn, zn);  // (c_n, z_n): one 48-byte record, three 16-byte gathers
-    const V3 Xp = ld3a(ptrec + 8 * (long)p);
-    if (first && one_trip && tail0) {
-      u0 = g.g.used[key0];
-      const double* b = pth + 6 * (long)key0;
+  if (__builtin_amdgcn_readfirstlane(ix.x) != -2) {
+    // at most 64 observations: the keys are final, the tail lanes know themselves now and H_pp^-1 travels with the gathers
+    const int p = ix.x;
+    const int key = p >= 0 ? p : -1 - lane;
+    const bool tail = seg_is_tail(key, lane) && key >= 0;
+    double acc[3] = {0, 0, 0};
+    double hb[6] = {0, 0, 0, 0, 0, 0};
+    if (p >= 0) {
+      V3 cn, zn;
+      ld6(cz + 6 * (long)ix.y, cn, zn);  // (c_n, z_n): one 48-byte record, three 16-byte gathers
+      const V3 Xp = ld3a(ptrec + 8 * (long)p);
+      if (tail) {
+        const double* b = pth + 6 * (long)p;
 #pragma unroll
-      for (int j = 0; j < 6; ++j) hb[j] = b[j];
+        for (int j = 0; j < 6; ++j) hb[j] = b[j];
+      }
+      const V3 y = applyQ(q2.x, q2.y, Xp - cn, zn);
+      acc[0] = y.x;
+      acc[1] = y.y;
+      acc[2] = y.z;
     }
-    first = false;
-    const V3 d = Xp - cn;
-    const V3 y = applyQ(ak, bk, d, zn);
-    acc[0] += y.x;
-    acc[1] += y.y;
-    acc[2] += y.z;
-    k += 64;
-    if (k < k1) {
-      p = g.g.obs_pt[k];
-      n = g.g.cam[k];
-      ak = qa[k];
-      bk = qb[k];
-    }
-  }
-  seg_scan<3>(acc, key, lane);
-  const bool tail = seg_is_tail(key, lane) && key >= 0;
-  if (one_trip) {
-    if (tail && u0) {
+    seg_scan<3>(acc, key, lane);
+    if (tail) {
       const V3 t = mul(S3{hb[0], hb[1], hb[2], hb[3], hb[4], hb[5]}, V3{acc[0], acc[1], acc[2]});
       st3(ptrec + 8 * (long)key + 3, t);
     }
-  } else if (tail && g.g.used[key]) {
+    return;
+  }
+  // a track longer than a wave: its tile is walked in trips through the plain (unpadded) arrays
+  const long k0 = g.g.tile_k[tile], k1 = g.g.tile_k[tile + 1];
+  double acc[3] = {0, 0, 0};
+  int key = -1 - lane;
+  for (long k = k0 + lane; k < k1; k += 64) {
+    const int p = g.g.obs_pt[k];
+    key = p;
+    V3 cn, zn;
+    ld6(cz + 6 * (long)g.g.cam[k], cn, zn);
+    const V3 Xp = ld3a(ptrec + 8 * (long)p);
+    const V3 y = applyQ(qa[k], qb[k], Xp - cn, zn);
+    acc[0] += y.x;
+    acc[1] += y.y;
+    acc[2] += y.z;
+  }
+  seg_scan<3>(acc, key, lane);
+  if (seg_is_tail(key, lane) && key >= 0 && g.g.used[key]) {
     const double* b = pth + 6 * (long)key;
     const V3 t = mul(S3{b[0], b[1], b[2], b[3], b[4], b[5]}, V3{acc[0], acc[1], acc[2]});
     st3(ptrec + 8 * (long)key + 3, t);
@@ -813,9 +834,9 @@ __global__ void __launch_bounds__(kBlock)
                  const double* __restrict__ s, const double* __restrict__ wrob,
                  const double* __restrict__ qa, const double* __restrict__ qb,
                  const double* __restrict__ ptb, const double* __restrict__ dc, double* __restrict__ Xn,
-                 double* __restrict__ sn, double* __restrict__ part) {
-  __shared__ double smem[4 * 3];
-  double acc3[3] = {0, 0, 0};
+                 double* __restrict__ sn, double* __restrict__ part, double* __restrict__ cost_part) {
+  __shared__ double smem[4 * 4];
+  double acc3[4] = {0, 0, 0, 0};  // model change | step norm | x norm | cost at the candidate (what k_gp_cost summed until round 4)
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (kBlock / 64);
@@ -900,12 +921,18 @@ __global__ void __launch_bounds__(kBlock)
       sn[k] = s_new;
       acc3[1] += (s_new - sk) * (s_new - sk);
       acc3[2] += sk * sk;
+      // the cost at the candidate point, while everything it needs is in registers: X' - c' = d - (dc - dX)
+      const V3 rc = ld3(g.dir + 3 * k) - s_new * (d - dcx);
+      double rho, wl;
+      huber(g.huber_a, (g.cal == nullptr || g.cal[k]) ? g.wpt : 0.5 * g.wpt, dot(rc, rc), rho, wl);
+      acc3[3] += 0.5 * rho;
     }
   }
-  block_sum<3>(acc3, smem);
+  block_sum<4>(acc3, smem);
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) part[blockIdx.x * 3 + k] = acc3[k];
+    cost_part[blockIdx.x] = acc3[3];
   }
 }
 
@@ -927,25 +954,6 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
     for (int k = 0; k < 3; ++k) part[blockIdx.x * 3 + k] = acc[k];
   }
-}
-
-// candidate cost, one lane per observation (coalesced); part[block][1]
-__global__ void __launch_bounds__(kBlock)
-    k_gp_cost(GpDev g, const double* __restrict__ c, const double* __restrict__ X,
-              const double* __restrict__ s, double* __restrict__ part) {
-  __shared__ double smem[4];
-  double v[1] = {0.0};
-  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < g.g.M; k += (long)gridDim.x * blockDim.x) {
-    const long p = g.g.obs_pt[k];
-    if (!g.g.used[p]) continue;
-    const V3 d = ld3(X + 3 * p) - ld3(c + 3 * (long)g.g.cam[k]);
-    const V3 r = ld3(g.dir + 3 * k) - s[k] * d;
-    double rho, w;
-    huber(g.huber_a, (g.cal == nullptr || g.cal[k]) ? g.wpt : 0.5 * g.wpt, dot(r, r), rho, w);
-    v[0] += 0.5 * rho;
-  }
-  block_sum<1>(v, smem);
-  if (threadIdx.x == 0) part[blockIdx.x] = v[0];
 }
 
 // s_k = max(1e-5, v.d / d.d) when !generate_scales (gp.cc:300-305)
@@ -1395,6 +1403,9 @@ struct GpWs {
   DevBuf<long> off;
   DevBuf<int> cam;
   DevBuf<unsigned char> cal, c_cal;
+  DevBuf<int2> tidx;    // [T][64] padded tile layout of k_gp_phaseA: (track, camera) per slot
+  DevBuf<double2> tq;   // [T][64] (a, beta) per slot
+  DevBuf<double> c_s;   // [M] the scales in camera-major order (written by k_gp_lin_cam, read by k_gp_build_cam)
   DevBuf<double> dir, c_dir, c_jss, c_qa, c_qb, c, cn, X, Xn, s, sn, wrob, qa, qb, jss, ptb, pth, ptrec, hppd, jsx, hcc,
       jsc, dcam, gc, gred, scc, minv, rhs, cz, cg_x, cg_r, cg_z, cg_p, cg_s, cg_w, vpart, dpart, part, scal;
   DevBuf<CgStatus> cgst;
@@ -1591,7 +1602,7 @@ class GpSolver final : public LmProblem {
     GSFM_HIP_CHECK(hipStreamSynchronize(s));
     ws->cn.ensure(3 * (size_t)Np_);
     ws->Xn.ensure(3 * (size_t)P_ + 3);
-    for (DevBuf<double>* b : {&ws->s, &ws->sn, &ws->wrob, &ws->qa, &ws->qb, &ws->jss, &ws->c_jss, &ws->c_qa, &ws->c_qb})
+    for (DevBuf<double>* b : {&ws->s, &ws->sn, &ws->wrob, &ws->qa, &ws->qb, &ws->jss, &ws->c_jss, &ws->c_qa, &ws->c_qb, &ws->c_s})
       b->ensure(M_ + 1);
     ws->ptb.ensure(kPtb * (size_t)P_ + kPtb);
     ws->pth.ensure(6 * (size_t)P_ + 6);
@@ -1673,6 +1684,9 @@ class GpSolver final : public LmProblem {
     gridTileA_ = grid_wide(g_.g.T, kBlock / 64, (size_t)0x7fffffff);
     GSFM_REQUIRE((long)gridTileA_ * (kBlock / 64) >= g_.g.T, "GP: too many observation tiles for one launch");
     gridTileP_ = grid_wide(g_.g.T, kBlock / 64, kMaxBlocks);  // tile sweeps that write per-block partials
+    // padded tile layout of k_gp_phaseA (the tq slots of padding / unused lanes are never read)
+    ws->tq.ensure((size_t)std::max(1, g_.g.T) * 64);
+    hipLaunchKernelGGL(k_gp_tile_idx, dim3(gridTile_), dim3(kBlock), 0, s, g_, ws->tidx.ensure((size_t)std::max(1, g_.g.T) * 64));
     g_.dir = ws->dir.get();
     g_.cal = d_cal;
     g_.c_dir = ws->c_dir.get();
@@ -1793,9 +1807,9 @@ class GpSolver final : public LmProblem {
     double* gc_k = rig_ ? ws->gc_i.get() : ws->gc.get();
     hipLaunchKernelGGL(k_gp_lin_track, dim3(gridTileP_), dim3(kBlock), 0, s, g_, ci_, X_, s_, ws->wrob.get(),
                        ws->hppd.get(), ws->part.get());
-    hipLaunchKernelGGL(k_gp_lin_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, ci_, X_, s_, hcc_k, gc_k);
+    hipLaunchKernelGGL(k_gp_lin_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, ci_, X_, s_, hcc_k, gc_k, ws->c_s.get());
     if (gridMulti_)  // combine pass over the cameras whose lists were cut into slices (obsgraph.hpp)
-      hipLaunchKernelGGL(k_gp_lin_cam, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, ci_, X_, s_, hcc_k, gc_k);
+      hipLaunchKernelGGL(k_gp_lin_cam, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, ci_, X_, s_, hcc_k, gc_k, ws->c_s.get());
     if (rig_) {
       reduce_to_frames<1>(hcc_k, ws->hcc.get());
       reduce_to_frames<3>(gc_k, ws->gc.get());
@@ -1845,11 +1859,11 @@ class GpSolver final : public LmProblem {
     double* scc_k = rig_ ? ws->scc_i.get() : ws->scc.get();
     hipLaunchKernelGGL(k_gp_build_track, dim3(gridTile_), dim3(kBlock), 0, s, g_, radius, ci_, X_, s_, ws->wrob.get(),
                        ws->jss.get(), ws->jsx.get(), ws->hppd.get(), ws->qa.get(), ws->qb.get(), ws->ptb.get(),
-                       ws->ptrec.get(), ws->pth.get());
-    hipLaunchKernelGGL(k_gp_build_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, radius, ci_, s_, ws->ptb.get(),
+                       ws->ptrec.get(), ws->pth.get(), ws->tq.get());
+    hipLaunchKernelGGL(k_gp_build_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, radius, ci_, (const double*)ws->c_s.get(), ws->ptb.get(),
                        ws->c_qa.get(), ws->c_qb.get(), gred_k, scc_k);
     if (gridMulti_)
-      hipLaunchKernelGGL(k_gp_build_cam, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, radius, ci_, s_, ws->ptb.get(),
+      hipLaunchKernelGGL(k_gp_build_cam, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, radius, ci_, (const double*)ws->c_s.get(), ws->ptb.get(),
                          ws->c_qa.get(), ws->c_qb.get(), gred_k, scc_k);
     if (E_ > 0) {
       hipLaunchKernelGGL(k_gpp_build, dim3(gridPair_), dim3(kBlock), 0, s, q_, radius, c_, (const double*)ps_,
@@ -1884,9 +1898,11 @@ class GpSolver final : public LmProblem {
                          ws->ximg.get(), (double*)nullptr, 0);
       dc_k = ws->ximg.get();
     }
+    double* part3 = ws->part.get() + kMaxBlocks * 4;  // cost at the candidate point (summed by the back-substitution sweep)
     hipLaunchKernelGGL(k_gp_backsub, dim3(gridTileP_), dim3(kBlock), 0, s, g_, ci_, X_, s_, ws->wrob.get(),
-                       ws->qa.get(), ws->qb.get(), ws->ptb.get(), dc_k, Xn_, sn_, ws->part.get());
+                       ws->qa.get(), ws->qb.get(), ws->ptb.get(), dc_k, Xn_, sn_, ws->part.get(), part3);
     hipLaunchKernelGGL((k_sum_partials<3>), dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridTileP_, ws->scal.get());
+    hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(kBlock), 0, s, part3, gridTileP_, ws->scal.get() + 6);
     if (E_ > 0) {
       hipLaunchKernelGGL(k_gpp_backsub, dim3(gridPair_), dim3(kBlock), 0, s, q_, c_, (const double*)ps_, (const double*)ws->pr_w.get(),
                          (const double*)ws->pr_qb.get(), (const double*)ws->cg_x.get(), psn_, ws->pr_part.get());
@@ -1896,10 +1912,7 @@ class GpSolver final : public LmProblem {
     double* part2 = ws->part.get() + kMaxBlocks * 3;
     hipLaunchKernelGGL(k_gp_cam_update, dim3(gridU), dim3(kBlock), 0, s, n3, c_, ws->cg_x.get(), cn_, part2);
     hipLaunchKernelGGL((k_sum_partials<3>), dim3(1), dim3(kBlock), 0, s, part2, gridU, ws->scal.get() + 3);
-    double* part3 = ws->part.get() + kMaxBlocks * 4;
     if (rig_) expand_centres(cn_, cin_, /*also_cz=*/false);
-    hipLaunchKernelGGL(k_gp_cost, dim3(gridM_), dim3(kBlock), 0, s, g_, cin_, Xn_, sn_, part3);
-    hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(kBlock), 0, s, part3, gridM_, ws->scal.get() + 6);
     if (E_ > 0) {
       hipLaunchKernelGGL(k_gpp_cost, dim3(gridPair_), dim3(kBlock), 0, s, q_, (const double*)cn_, (const double*)psn_, ws->pr_part.get());
       hipLaunchKernelGGL((k_gpp_fold_sum<1>), dim3(1), dim3(kBlock), 0, s, (const double*)ws->pr_part.get(), gridPair_, ws->scal.get(), 6, 6, 6);
@@ -2058,7 +2071,7 @@ class GpSolver final : public LmProblem {
       }
       bool timed = ctx_->prof.begin(s, GSFM_KERNEL_GP_SCHUR, it);
       hipLaunchKernelGGL(k_gp_phaseA, dim3(gridTileA_), dim3(kBlock), 0, s, g_, vk, it, tol * tol, ws->cz.get(), ws->qa.get(),
-                         ws->qb.get(), ws->pth.get(), ws->ptrec.get());
+                         ws->qb.get(), ws->pth.get(), ws->ptrec.get(), (const int2*)ws->tidx.get(), (const double2*)ws->tq.get());
       if (timed) ctx_->prof.end(s);
       timed = ctx_->prof.begin(s, GSFM_KERNEL_GP_SCHUR_B, it);
       // rigs: the damping D z is a frame-space term, added by k_rig_reduce_w (the sweep runs with a zero diagonal)

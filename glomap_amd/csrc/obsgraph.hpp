@@ -123,8 +123,12 @@ __device__ __forceinline__ int cam_seg_k1(const ObsGraph& g, int sg) { return g.
 
 // Returns true when lane 0's `acc` holds the camera's complete sum (call after wave_allsum).
 // Parked sums are W doubles per slot (the kernel's own accumulator width: pass 0 and pass 1 of a kernel agree on it).  In
-// pass 1 lane j adds column j of the camera's slots in slice order (coalesced rows), then the totals are broadcast into
-// `acc` — the same sums in the same order as a serial loop, without one lane walking cnt x W values.
+// pass 1 lane c adds column c of the camera's slots in slice order (coalesced rows) and leaves the total in the first slot;
+// lane 0 then reads that one row back — the same sums in the same order as a serial loop, without one lane walking
+// cnt x W values.  Two things here are about the register allocator, not the arithmetic (tests/test_kernel_resources.py):
+// broadcasting the totals into every lane's `acc` cost k_ba_build_cam its second wave per SIMD (251 -> 404 registers), and
+// plain stores in both passes get merged by the compiler into one store through a select of a global and a private
+// pointer, which pins `acc` in scratch — hence the atomic (relaxed, same instruction) stores when parking.
 template <int W>
 __device__ __forceinline__ bool cam_seg_total(const ObsGraph& g, int sg, double (&acc)[W], int lane) {
   static_assert(W <= kSegPartW, "accumulator wider than the partial-sum slots");
@@ -134,18 +138,21 @@ __device__ __forceinline__ bool cam_seg_total(const ObsGraph& g, int sg, double 
     if (lane == 0) {
       double* dst = g.segpart + (size_t)g.seg_multi[sg] * W;
 #pragma unroll
-      for (int j = 0; j < W; ++j) dst[j] = acc[j];
+      for (int j = 0; j < W; ++j) __hip_atomic_store(dst + j, acc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     return false;
   }
-  const double* src = g.segpart + (size_t)g.seg_multi[sg] * W;  // sg = the camera's first segment in pass 1
-  double col0 = 0.0, col1 = 0.0;
-  for (int q = 0; q < cnt; ++q) {
-    if (lane < W) col0 += src[(size_t)q * W + lane];
-    if (W > 64 && lane + 64 < W) col1 += src[(size_t)q * W + lane + 64];
+  double* src = g.segpart + (size_t)g.seg_multi[sg] * W;  // sg = the camera's first segment in pass 1
+  for (int c = lane; c < W; c += 64) {
+    double col = 0.0;
+    for (int q = 0; q < cnt; ++q) col += src[(size_t)q * W + c];
+    src[c] = col;  // the first slot becomes the total
   }
+  __threadfence();  // the wave's own stores are in L2 and its L1 lines dropped before lane 0 reads the row back
+  if (lane == 0) {
 #pragma unroll
-  for (int j = 0; j < W; ++j) acc[j] = __shfl(j < 64 ? col0 : col1, j & 63, 64);
+    for (int j = 0; j < W; ++j) acc[j] = src[j];
+  }
   return true;
 }
 

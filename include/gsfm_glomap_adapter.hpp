@@ -242,7 +242,7 @@ inline void AverageQuaternions(const std::vector<std::array<double, 4>>& qs, dou
   for (int i = 0; i < 4; ++i) out[i] = sg * V[i][best];
 }
 
-// Dense frame index over the frames the estimators touch.// Dense frame index over the frames the estimators touch.
+// Dense frame index over the frames the estimators touch.
 struct FrameIndex {
   std::unordered_map<frame_t, int> of;
   std::vector<frame_t> ids;
@@ -712,6 +712,12 @@ class GlobalPositioner {
   bool Solve(const glomap::ViewGraph& view_graph, std::unordered_map<rig_t, glomap::Rig>& rigs,
              std::unordered_map<camera_t, glomap::Camera>& cameras, std::unordered_map<frame_t, glomap::Frame>& frames,
              std::unordered_map<image_t, glomap::Image>& images, std::unordered_map<track_t, glomap::Track>& tracks) {
+    // use_gpu == false: the caller asked for the CPU solver (gp.cc:506-549 picks Ceres' CPU linear algebra then) — that IS
+    // the reference class, so the solve goes there unchanged instead of silently running on the device.
+    // min_num_images_gpu_solver is NOT consulted: in the reference it keeps small problems away from cuDSS / CUDA dense
+    // factorisations whose set-up outweighs them; libgsfm has its own small-problem path (single-workgroup PCG), so a
+    // caller that leaves use_gpu on gets the device at every size.
+    if (!options_.use_gpu) return glomap::GlobalPositioner(options_).Solve(view_graph, rigs, cameras, frames, images, tracks);
     gsfm_ctx* ctx = Context(options_.gpu_index);
     if (ctx == nullptr) return false;
     const bool with_pairs = options_.constraint_type != glomap::GlobalPositionerOptions::ONLY_POINTS;
@@ -894,6 +900,8 @@ class BundleAdjuster {
   bool Solve(std::unordered_map<rig_t, glomap::Rig>& rigs, std::unordered_map<camera_t, glomap::Camera>& cameras,
              std::unordered_map<frame_t, glomap::Frame>& frames, std::unordered_map<image_t, glomap::Image>& images,
              std::unordered_map<track_t, glomap::Track>& tracks) {
+    // use_gpu == false: the reference class solves on the CPU (ba.cc:49-92); see GlobalPositioner::Solve above
+    if (!options_.use_gpu) return glomap::BundleAdjuster(options_).Solve(rigs, cameras, frames, images, tracks);
     gsfm_ctx* ctx = Context(options_.gpu_index);
     if (ctx == nullptr) return false;
     if (images.empty() || tracks.empty()) return false;  // ba.cc:17-24

@@ -161,10 +161,30 @@ def build(force: bool = False) -> Path:
     return so
 
 
-def load():
+BUILD_FLAGS = "g++ -O3 -fopenmp, baseline x86-64"   # of the library load() returned (load_native() rewrites it)
+
+
+def load_native():
+    """bench.py's cpu_baseline legs only: rebuild the restatement with -march=native ON THIS BOX (oracle/_native/, never
+    shipped: a native build of the build container may not run on the GPU box's host CPU) and make it the library every
+    later call uses.  Falls back to the portable prebuilt library when g++ / make are missing."""
+    global _LIB, BUILD_FLAGS
+    try:
+        subprocess.run(["make", "-C", str(_DIR), "-s", "native"], check=True, capture_output=True, timeout=300)
+        flags = subprocess.run(["make", "-C", str(_DIR), "-s", "flags"], check=True, capture_output=True, text=True).stdout.strip()
+        _LIB = None
+        load(_DIR / "_native" / "liboracle_cpu.so")
+        BUILD_FLAGS = flags + " -march=native (built on this box)"
+    except Exception as e:  # noqa: BLE001
+        BUILD_FLAGS = "g++ -O3 -fopenmp, baseline x86-64 (prebuilt; native rebuild failed: %s)" % type(e).__name__
+        load()
+    return _LIB
+
+
+def load(path=None):
     global _LIB
     if _LIB is None:
-        lib = C.CDLL(str(build()))
+        lib = C.CDLL(str(path or build()))
         lib.orc_gp_solve.restype = C.c_int
         lib.orc_gp_solve_pairs.restype = C.c_int
         lib.orc_ba_solve.restype = C.c_int

@@ -645,6 +645,20 @@ int main() {
       }
     if (grav_err > 1e-6) return std::printf("gravity RA: relative rotation off by %.3e rad\n", grav_err), 1;
   }
+  // use_gpu == false: the solve goes to the reference class (here: the counting stand-ins), nothing is touched by libgsfm
+  {
+    GlobalPositionerOptions go;
+    go.use_gpu = false;
+    BundleAdjusterOptions bo;
+    bo.use_gpu = false;
+    const int g0 = glomap::GlobalPositioner::calls(), b0 = glomap::BundleAdjuster::calls();
+    gsfm_glomap::GlobalPositioner gp_cpu(go);
+    gsfm_glomap::BundleAdjuster ba_cpu(bo);
+    if (!gp_cpu.Solve(vg, rigs, cameras, frames, images, tracks) || !ba_cpu.Solve(rigs, cameras, frames, images, tracks))
+      return std::printf("use_gpu = false: delegated solve failed\n"), 1;
+    if (glomap::GlobalPositioner::calls() != g0 + 1 || glomap::BundleAdjuster::calls() != b0 + 1)
+      return std::printf("use_gpu = false did not reach the reference estimators\n"), 1;
+  }
   std::printf("ADAPTER OK gravity_ra=%.2e rad ", grav_err);
   std::printf("ra=%.2e rad gp_ratio_err=%.2e ba=%.2e px | rigs: ra=%.2e rad gp_scale_err=%.2e ba=%.2e px cam_from_rig=%.2e rad unknown_R=%.2e rad unknown_t=%.2e\n",
               worst, std::fabs(ratio / ratio_ref - 1.0), maxerr, rig_ra, rig_gp, rig_ba, rig_sens, rig_unk_rot, rig_unk);

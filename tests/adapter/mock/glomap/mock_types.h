@@ -281,6 +281,7 @@ struct GlobalPositionerOptions : public OptimizationBaseOptions {
   bool optimize_positions = true, optimize_points = true, optimize_scales = true;
   bool use_gpu = true;
   std::string gpu_index = "-1";
+  int min_num_images_gpu_solver = 50;
   int min_num_view_per_track = 3;
   unsigned seed = 1;
   ConstraintType constraint_type = ONLY_POINTS;
@@ -291,10 +292,45 @@ struct BundleAdjusterOptions : public OptimizationBaseOptions {
        optimize_principal_point = false, optimize_points = true;
   bool use_gpu = true;
   std::string gpu_index = "-1";
+  int min_num_images_gpu_solver = 50;
   int min_num_view_per_track = 3;
   BundleAdjusterOptions() {
     thres_loss_function = 1.0;
     solver_options.max_num_iterations = 200;
   }
+};
+// The reference estimators themselves (global_positioning.h:56-137, bundle_adjustment.h:38-98): the adapter hands a solve
+// to them when the caller asked for the CPU (`use_gpu == false`).  Stand-ins: they only count their calls.
+class GlobalPositioner {
+ public:
+  explicit GlobalPositioner(const GlobalPositionerOptions& options) : options_(options) {}
+  bool Solve(const ViewGraph&, std::unordered_map<rig_t, Rig>&, std::unordered_map<camera_t, Camera>&,
+             std::unordered_map<frame_t, Frame>&, std::unordered_map<image_t, Image>&, std::unordered_map<track_t, Track>&) {
+    ++calls();
+    return true;
+  }
+  static int& calls() {
+    static int n = 0;
+    return n;
+  }
+
+ private:
+  GlobalPositionerOptions options_;
+};
+class BundleAdjuster {
+ public:
+  explicit BundleAdjuster(const BundleAdjusterOptions& options) : options_(options) {}
+  bool Solve(std::unordered_map<rig_t, Rig>&, std::unordered_map<camera_t, Camera>&, std::unordered_map<frame_t, Frame>&,
+             std::unordered_map<image_t, Image>&, std::unordered_map<track_t, Track>&) {
+    ++calls();
+    return true;
+  }
+  static int& calls() {
+    static int n = 0;
+    return n;
+  }
+
+ private:
+  BundleAdjusterOptions options_;
 };
 }  // namespace glomap

@@ -28,7 +28,7 @@ from oracle import cpu  # noqa: E402
 def main():
     p = synthetic.make_ba_problem(10_000, 1_000_000, seed=0, shared_intrinsics=True)
     r = cpu.ba_solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_xy, p.cam_intr, p.intr_model, p.fixed_cam, p.cam_q, p.cam_t,
-                     p.pt_xyz, p.intr_params)
+                     p.pt_xyz, p.intr_params, verbose=True)
     assert r[0]
     s = r[5]
     print("LM", s.iterations, "final cost", s.final_cost, "max true relative residual of a reduced solve", s.max_linear_residual)

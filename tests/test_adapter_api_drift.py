@@ -67,6 +67,8 @@ API = [
     ("constraint_type", "glomap/estimators/global_positioning.h", r"constraint_type"),
     ("seed", "glomap/estimators/global_positioning.h", r"unsigned\s+seed"),
     ("gpu_index", "glomap/estimators/global_positioning.h", r"gpu_index"),
+    ("use_gpu", "glomap/estimators/global_positioning.h", r"bool\s+use_gpu"),
+    ("min_num_images_gpu_solver", "glomap/estimators/bundle_adjustment.h", r"int\s+min_num_images_gpu_solver"),
     ("optimize_rig_poses", "glomap/estimators/bundle_adjustment.h", r"optimize_rig_poses"),
     ("optimize_principal_point", "glomap/estimators/bundle_adjustment.h", r"optimize_principal_point"),
     ("min_num_view_per_track", "glomap/estimators/bundle_adjustment.h", r"min_num_view_per_track"),

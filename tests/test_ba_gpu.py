@@ -189,6 +189,7 @@ def test_scene_level_bundle_adjuster_and_positioner(gsfm_ctx):
     (dict(), dict()),                                                   # one camera per image: joint 14 x 14 blocks, 7 modes
     (dict(), dict(optimize_rotations=False)),                           # rotations frozen: 4 modes
     (dict(shared_intrinsics=True), dict(optimize_intrinsics=False)),    # no free intrinsics
+    (dict(shared_intrinsics=True), dict()),                             # ONE block shared by all images: per-block sums of the shares
 ])
 def test_ba_closed_form_gauge_products_equal_operator_applications(gsfm_ctx, kw, opts):
     """The deflated solves need A W for the gauge modes.  k_ba_aw_modes forms it in one camera-major sweep from the identity
