@@ -46,6 +46,7 @@
 namespace gsfm {
 namespace {
 
+constexpr int kCz = 8;    // doubles per (c_n | z_n | pad) gather record: one 64-byte line (48-byte records straddled two lines half the time)
 constexpr int kPtb = 16;  // doubles per point build record: X (3) | e (3) | H_pp^-1 (6) | D_p | sum_k Q_k d_k (3) -> one 128-byte line
 
 struct GpDev {
@@ -309,7 +310,8 @@ __global__ void __launch_bounds__(kBlock)
 __global__ void __launch_bounds__(kBlock)
     k_gp_build_cam(GpDev g, double radius, const double* __restrict__ c, const double* __restrict__ c_s,
                    const double* __restrict__ ptb, double* __restrict__ c_qa, double* __restrict__ c_qb,
-                   double* __restrict__ gred, double* __restrict__ scc) {
+                   double* __restrict__ gred, double* __restrict__ scc,
+                   const int* __restrict__ c_xslot, double2* __restrict__ xq /* chunked order (or null): slot of k, (a, beta) there */) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (kBlock / 64);
@@ -336,6 +338,7 @@ __global__ void __launch_bounds__(kBlock)
       const double a = w * sk * sk;
       c_qa[k] = a;
       c_qb[k] = beta;
+      if (xq != nullptr) xq[c_xslot[k]] = make_double2(a, beta);  // runs of consecutive slots per (chunk, camera)
       if (!g.opt_c) continue;
       const V3 q = applyQ(w * sk, beta, d, r) + applyQ(a, beta, d, e);
       acc[0] += q.x;
@@ -384,7 +387,7 @@ __global__ void __launch_bounds__(kBlock)
     for (int j = 0; j < 3; ++j) {
       dcam[3 * (long)n + j] = D;
       rhs[3 * (long)n + j] = -gred[3 * (long)n + j];
-      cz[6 * (long)n + j] = c[3 * (long)n + j];  // gather record of PCG phase A: (c_n | z_n)
+      cz[kCz * (long)n + j] = c[3 * (long)n + j];  // gather record of PCG phase A: (c_n | z_n)
     }
   }
 }
@@ -446,7 +449,7 @@ __global__ void __launch_bounds__(kBlock)
     double hb[6] = {0, 0, 0, 0, 0, 0};
     if (p >= 0) {
       V3 cn, zn;
-      ld6(cz + 6 * (long)ix.y, cn, zn);  // (c_n, z_n): one 48-byte record, three 16-byte gathers
+      ld6(cz + kCz * (long)ix.y, cn, zn);  // (c_n, z_n): 48 bytes of one 64-byte line, three 16-byte gathers
       const V3 Xp = ld3a(ptrec + 8 * (long)p);
       if (tail) {
         const double* b = pth + 6 * (long)p;
@@ -473,7 +476,7 @@ __global__ void __launch_bounds__(kBlock)
     const int p = g.g.obs_pt[k];
     key = p;
     V3 cn, zn;
-    ld6(cz + 6 * (long)g.g.cam[k], cn, zn);
+    ld6(cz + kCz * (long)g.g.cam[k], cn, zn);
     const V3 Xp = ld3a(ptrec + 8 * (long)p);
     const V3 y = applyQ(qa[k], qb[k], Xp - cn, zn);
     acc[0] += y.x;
@@ -823,6 +826,74 @@ __global__ void __launch_bounds__(kBlock)
   if (lane == 0) sdelta[wid] = delta;
   __syncthreads();
   if (threadIdx.x == 0) v.dpart[dslot0 + blockIdx.x] = (sdelta[0] + sdelta[1]) + (sdelta[2] + sdelta[3]);
+}
+
+// Phase B in the chunked order (obsgraph.hpp, ObsX): one lane per observation, 64-slot tiles sorted by (point chunk,
+// camera), every XCD on its own chunks — the 64-byte (X_p, t_p) gathers hit the XCD's L2 instead of the fabric
+// (tools/exp_chunk_gather.hip: 116 -> 65 us for the 6.0 M gathers of configs[3]).  The camera constants come with z in the
+// 48-byte (c_n | z_n) records phase A uses (480 KB, cache resident; lanes of one camera read the same record).  A wave
+// segmented scan over the camera key sums every (camera, tile) piece; its last lane writes the 24-byte partial.
+// Algorithmic bytes per observation: (track, camera) 8 + (a, beta) 16 + the 64-byte record.
+__global__ void __launch_bounds__(kBlock)
+    k_gp_phaseB_x(ObsX x, CgVec v, const double* __restrict__ cz, const double2* __restrict__ xq,
+                  const double* __restrict__ ptrec, double* __restrict__ wpart) {
+  if (v.st->done) return;
+  const int lane = threadIdx.x & 63;
+  const int tile = x_tile_of_wave(x);
+  if (tile < 0) return;
+  const long slot = (long)tile * 64 + lane;
+  const int2 ix = x.ix[slot];
+  const double2 q = xq[slot];
+  double acc[3] = {0, 0, 0};
+  int key = -1 - lane;
+  if (ix.x >= 0) {
+    key = ix.y;
+    V3 cn, zn, Xp, tp;
+    ld6(cz + kCz * (long)ix.y, cn, zn);
+    ld6(ptrec + 8 * (long)ix.x, Xp, tp);
+    const V3 y = applyQ(q.x, q.y, Xp - cn, zn - tp);
+    acc[0] = y.x;
+    acc[1] = y.y;
+    acc[2] = y.z;
+  }
+  seg_scan<3>(acc, key, lane);
+  if (x_piece_tail(key, lane)) st3(wpart + 3 * (long)x.out[slot], V3{acc[0], acc[1], acc[2]});
+}
+
+// w_n = sum of the pieces of camera n (contiguous, fixed order) + D_n z_n, and this block's share of delta = z.w.
+// One wave per camera.
+__global__ void __launch_bounds__(kBlock)
+    k_gp_wsum(ObsX x, int N, CgVec v, double yscale, const double* __restrict__ wpart, const double* __restrict__ dcam) {
+  __shared__ double sdelta[kBlock / 64];
+  if (v.st->done) return;
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int nwaves = gridDim.x * (kBlock / 64);
+  double delta = 0.0;
+  for (int n = blockIdx.x * (kBlock / 64) + wid; n < N; n += nwaves) {
+    double acc[3] = {0, 0, 0};
+    const int p1 = x.piece_off[n + 1];
+    for (int i = x.piece_off[n] + lane; i < p1; i += 64) {
+      const V3 a = ld3(wpart + 3 * (long)i);
+      acc[0] += a.x;
+      acc[1] += a.y;
+      acc[2] += a.z;
+    }
+    wave_allsum<3>(acc);
+    if (lane == 0) {
+      const V3 zn = ld3(v.z + 3 * (long)n);
+      const double w0 = acc[0] + yscale * dcam[3 * (long)n] * zn.x;
+      const double w1 = acc[1] + yscale * dcam[3 * (long)n + 1] * zn.y;
+      const double w2 = acc[2] + yscale * dcam[3 * (long)n + 2] * zn.z;
+      v.w[3 * (long)n] = w0;
+      v.w[3 * (long)n + 1] = w1;
+      v.w[3 * (long)n + 2] = w2;
+      delta += zn.x * w0 + zn.y * w1 + zn.z * w2;
+    }
+  }
+  if (lane == 0) sdelta[wid] = delta;
+  __syncthreads();
+  if (threadIdx.x == 0) v.dpart[blockIdx.x] = (sdelta[0] + sdelta[1]) + (sdelta[2] + sdelta[3]);
 }
 
 // ---- back-substitution, model cost change, candidate point ------------------------------------
@@ -1276,7 +1347,7 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       dst_img[3 * (long)i + j] = v[j];
-      if (cz) cz[6 * (long)i + cz_slot + j] = v[j];
+      if (cz) cz[kCz * (long)i + cz_slot + j] = v[j];
     }
   }
 }
@@ -1406,6 +1477,9 @@ struct GpWs {
   DevBuf<int2> tidx;    // [T][64] padded tile layout of k_gp_phaseA: (track, camera) per slot
   DevBuf<double2> tq;   // [T][64] (a, beta) per slot
   DevBuf<double> c_s;   // [M] the scales in camera-major order (written by k_gp_lin_cam, read by k_gp_build_cam)
+  ObsXWs xw;            // chunked order of the camera-side PCG sweep (obsgraph.hpp, ObsX)
+  DevBuf<double2> xq;   // [tiles][64] (a, beta) per slot of the chunked order (written by k_gp_build_cam)
+  DevBuf<double> wpart; // [pieces][3] partial sums of k_gp_phaseB_x
   DevBuf<double> dir, c_dir, c_jss, c_qa, c_qb, c, cn, X, Xn, s, sn, wrob, qa, qb, jss, ptb, pth, ptrec, hppd, jsx, hcc,
       jsc, dcam, gc, gred, scc, minv, rhs, cz, cg_x, cg_r, cg_z, cg_p, cg_s, cg_w, vpart, dpart, part, scal;
   DevBuf<CgStatus> cgst;
@@ -1617,7 +1691,7 @@ class GpSolver final : public LmProblem {
     ws->jsc.ensure(Np_);
     ws->scc.ensure(6 * (size_t)Np_);
     ws->minv.ensure(9 * (size_t)Np_);
-    ws->cz.ensure(6 * (size_t)NI_ + 2);
+    ws->cz.ensure(kCz * (size_t)NI_ + 2);
     if (rig_) {
       // image tables + frame -> images lists (images of a frame in ascending image order: a fixed summation order)
       std::vector<int> foff((size_t)N_ + 1, 0), fimg((size_t)NI_);
@@ -1661,7 +1735,7 @@ class GpSolver final : public LmProblem {
       ws->wimg.ensure(3 * (size_t)NI_ + 2);
       ws->hcc_i.ensure(NI_);
       ws->scc_i.ensure(6 * (size_t)NI_);
-      ws->cz_f.ensure(6 * (size_t)Np_ + 2);
+      ws->cz_f.ensure(kCz * (size_t)Np_ + 2);
       GSFM_HIP_CHECK(hipMemsetAsync(ws->zero_i.get(), 0, 3 * (size_t)NI_ * sizeof(double), s));
     }
     for (DevBuf<double>* b : {&ws->dcam, &ws->gc, &ws->gred, &ws->rhs, &ws->cg_x, &ws->cg_r, &ws->cg_z, &ws->cg_p, &ws->cg_s})
@@ -1680,6 +1754,19 @@ class GpSolver final : public LmProblem {
     gridM_ = grid_for(M_, kBlock);
     gridCam_ = grid_wide(g_.g.S, kBlock / 64, kMaxApplySlots);  // one wave per camera segment (delta partial per block)
     gridMulti_ = g_.g.nmulti > 0 ? grid_for(g_.g.nmulti, kBlock / 64) : 0;  // combine pass: one wave per cut camera
+    // chunked order for the camera-side PCG sweep: pays when the 64-byte point records overflow an XCD's L2 (trivial rigs only)
+    {
+      const int knob = ctx_->knob[GSFM_KNOB_CHUNKED_SWEEPS];
+      const bool want = knob == 1 || (knob == 0 && (size_t)P_ * 64 >= ((size_t)8 << 20) && m_used_ >= 500000);
+      xon_ = want && !rig_ && knob != 2 && build_x_order(ctx_, ws->og, ws->xw, g_.g, 64, x_);
+      if (xon_) {
+        ws->xq.ensure((size_t)x_.tiles * 64 + 64);
+        ws->wpart.ensure(3 * (size_t)std::max(1, x_.npieces) + 8);
+        gridX_ = x_grid(x_);
+        gridWsum_ = std::min(kMaxApplySlots, grid_for((size_t)Np_, kBlock / 64));
+      }
+      sweepSlots_ = xon_ ? gridWsum_ : gridCam_ + gridMulti_;  // delta partial slots the sweep of `apply` writes
+    }
     gridTile_ = grid_wide(g_.g.T, kBlock / 64);             // one wave per tile
     gridTileA_ = grid_wide(g_.g.T, kBlock / 64, (size_t)0x7fffffff);
     GSFM_REQUIRE((long)gridTileA_ * (kBlock / 64) >= g_.g.T, "GP: too many observation tiles for one launch");
@@ -1762,7 +1849,7 @@ class GpSolver final : public LmProblem {
     cg_.N = Np_;
     cg_.K = 0;
     cg_.nb_update = std::min(kCgUpdateBlocks, grid_for(Np_, kBlock));
-    cg_.nb_apply = gridCam_ + gridMulti_ + (E_ > 0 ? gridPairCam_ : 0);  // + the delta slots of the combine pass (k_gp_phaseB) and of the pair terms
+    cg_.nb_apply = sweepSlots_ + (E_ > 0 ? gridPairCam_ : 0);  // + the delta slots of the combine pass (k_gp_phaseB) and of the pair terms
     cg_.b = ws->rhs.get();
     cg_.x = ws->cg_x.get();
     cg_.r = ws->cg_r.get();
@@ -1776,7 +1863,7 @@ class GpSolver final : public LmProblem {
     cg_.scal = ws->cgsc.get();
     cg_.st = ws->cgst.get();
     cg_.zmir = rig_ ? nullptr : ws->cz.get();  // rigs: z reaches the (c | z) records through expand_z()
-    cg_.zmir_stride = 6;
+    cg_.zmir_stride = kCz;
     cg_.zmir_off = 3;
     if (rig_ || E_ > 0) {
       if (rig_) cg_.nb_apply = gridCam_ + gridMulti_ + gridN_ + S_;  // + the damping shares of delta (k_rig_reduce_w: one per block)
@@ -1861,10 +1948,10 @@ class GpSolver final : public LmProblem {
                        ws->jss.get(), ws->jsx.get(), ws->hppd.get(), ws->qa.get(), ws->qb.get(), ws->ptb.get(),
                        ws->ptrec.get(), ws->pth.get(), ws->tq.get());
     hipLaunchKernelGGL(k_gp_build_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, radius, ci_, (const double*)ws->c_s.get(), ws->ptb.get(),
-                       ws->c_qa.get(), ws->c_qb.get(), gred_k, scc_k);
+                       ws->c_qa.get(), ws->c_qb.get(), gred_k, scc_k, x_.c_xslot, xon_ ? ws->xq.get() : nullptr);
     if (gridMulti_)
       hipLaunchKernelGGL(k_gp_build_cam, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, radius, ci_, (const double*)ws->c_s.get(), ws->ptb.get(),
-                         ws->c_qa.get(), ws->c_qb.get(), gred_k, scc_k);
+                         ws->c_qa.get(), ws->c_qb.get(), gred_k, scc_k, x_.c_xslot, xon_ ? ws->xq.get() : nullptr);
     if (E_ > 0) {
       hipLaunchKernelGGL(k_gpp_build, dim3(gridPair_), dim3(kBlock), 0, s, q_, radius, c_, (const double*)ps_,
                          (const double*)ws->pr_w.get(), (const double*)ws->pr_js.get(), ws->pr_qa.get(), ws->pr_qb.get());
@@ -2077,18 +2164,25 @@ class GpSolver final : public LmProblem {
       // rigs: the damping D z is a frame-space term, added by k_rig_reduce_w (the sweep runs with a zero diagonal)
       const double* dk = rig_ ? ws->zero_i.get() : ws->dcam.get();
       const double ys = rig_ ? 0.0 : yscale;
-      hipLaunchKernelGGL(k_gp_phaseB, dim3(gridCam_), dim3(kBlock), 0, s, g_, vk, ys, ci_, ws->c_qa.get(),
-                         ws->c_qb.get(), ws->ptrec.get(), dk, 0);
-      if (gridMulti_)
-        hipLaunchKernelGGL(k_gp_phaseB, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, vk, ys, ci_, ws->c_qa.get(),
-                           ws->c_qb.get(), ws->ptrec.get(), dk, gridCam_);
-      if (timed) ctx_->prof.end(s);
+      if (xon_) {
+        hipLaunchKernelGGL(k_gp_phaseB_x, dim3(gridX_), dim3(kBlock), 0, s, x_, vk, (const double*)ws->cz.get(),
+                           (const double2*)ws->xq.get(), (const double*)ws->ptrec.get(), ws->wpart.get());
+        if (timed) ctx_->prof.end(s);
+        hipLaunchKernelGGL(k_gp_wsum, dim3(gridWsum_), dim3(kBlock), 0, s, x_, Np_, vk, ys, (const double*)ws->wpart.get(), dk);
+      } else {
+        hipLaunchKernelGGL(k_gp_phaseB, dim3(gridCam_), dim3(kBlock), 0, s, g_, vk, ys, ci_, ws->c_qa.get(),
+                           ws->c_qb.get(), ws->ptrec.get(), dk, 0);
+        if (gridMulti_)
+          hipLaunchKernelGGL(k_gp_phaseB, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, vk, ys, ci_, ws->c_qa.get(),
+                             ws->c_qb.get(), ws->ptrec.get(), dk, gridCam_);
+        if (timed) ctx_->prof.end(s);
+      }
       if (rig_)
         hipLaunchKernelGGL(k_rig_reduce_w, dim3(gridN_ + S_), dim3(kBlock), 0, s, cg_, rg_, yscale, ws->wimg.get(), ws->dcam.get(),
                            gridCam_ + gridMulti_, gridN_);
       if (E_ > 0)  // camera-to-camera terms on top of what the sweep wrote
         hipLaunchKernelGGL(k_gpp_apply, dim3(gridPairCam_), dim3(kBlock), 0, s, q_, cg_, N_, (const double*)c_,
-                           (const double*)ws->pr_qa.get(), (const double*)ws->pr_qb.get(), gridCam_ + gridMulti_);
+                           (const double*)ws->pr_qa.get(), (const double*)ws->pr_qb.get(), sweepSlots_);
     };
     // second level for chain-like scenes (GpCoarseDev): replaces the deflation of the four global modes, which its coarse
     // space contains
@@ -2134,6 +2228,7 @@ class GpSolver final : public LmProblem {
       return iters0 + pcg();
     }
     if (coarse) ctx_->stats[GSFM_STAT_PCG_SECOND_LEVEL]++;
+    if (xon_) ctx_->stats[GSFM_STAT_PCG_CHUNKED_SWEEPS]++;
     const long iters = iters0 + (coarse ? coarse_probes_ : 0);  // + the operator applications that probed the coarse matrix
     // deflation pays while a plain solve needs more than ~3 k iterations (iters includes the k applications for A W)
     // (with the closed-form mode products the price of A W is one camera-major sweep — say one application — instead of four)
@@ -2156,6 +2251,9 @@ class GpSolver final : public LmProblem {
   double *ci_ = nullptr, *cin_ = nullptr;
   long P_ = 0, M_ = 0, m_used_ = 0;
   int gridP_ = 1, gridN_ = 1, gridM_ = 1, gridCam_ = 1, gridMulti_ = 0, gridTile_ = 1, gridTileP_ = 1;
+  ObsX x_;            // chunked order of the camera-side PCG sweep (xon_)
+  bool xon_ = false;
+  int gridX_ = 0, gridWsum_ = 0, sweepSlots_ = 0;
   bool defl_on_ = true;  // deflate the next reduced solve (short solves run plain)
   long E_ = 0;                 // camera-to-camera constraints (constraint_type != ONLY_POINTS)
   bool with_points_ = true;    // false: ONLY_CAMERAS

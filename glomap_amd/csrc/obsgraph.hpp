@@ -343,6 +343,164 @@ inline long build_obs_graph(gsfm_ctx* ctx, ObsGraphWs& ws, int N, long P, long M
   return m_used;
 }
 
+// ---- the chunked order of the camera-side sweeps --------------------------------------------------------------------
+// A camera-major sweep gathers one point record per observation, and on scenes without locality every gather is an L2 miss:
+// the sweep runs at the ~54 G line requests/s of the fabric whatever the record size (tools/exp_gather_calib.hip; 6.0 M
+// gathers = 111 us, k_gp_phaseB measured 118).  The third copy of the observation graph turns those misses into hits
+// (tools/exp_chunk_gather.hip: 116 -> 65 us for the same gathers): the tracks are cut into C = 8 R index ranges ("chunks")
+// of at most ~2.7 MB of point records, the used camera-major slots are re-sorted by (chunk, camera) — stable, so points
+// stay ascending inside a (chunk, camera) run — and laid out in 64-slot tiles, every chunk starting on a tile boundary.
+// The tile list is cut into 8 equal parts and workgroup b works on part b % 8: with the observed dispatch rule (block b on
+// XCD b % 8; used for speed only, any placement gives the same sums) every XCD walks its own R chunks one after the other
+// and the records it gathers are resident in its own 4 MB L2.
+// One lane per slot; per-camera sums are a wave segmented scan over the camera key.  A (camera, tile) run is a "piece":
+// its last lane writes the piece's partial sum to out[slot] = position of the piece in (camera, slot) order, so that the
+// per-camera totals are one contiguous, fixed-order sum over piece_off[n] .. piece_off[n + 1] (k_*_wsum kernels).
+struct ObsX {  // device view
+  int tiles = 0;                      // 64-slot tiles
+  int per = 0;                        // tiles per part: part x = tiles [x per, (x + 1) per)
+  int npieces = 0;
+  const int2* ix = nullptr;           // [tiles * 64] (track, camera); (-1, 0): padding
+  const int* src = nullptr;           // [tiles * 64] camera-major slot of the entry (-1: padding)
+  const int* out = nullptr;           // [tiles * 64] piece index, valid in the last lane of a piece
+  const int* piece_off = nullptr;     // [N + 2] pieces of camera n: piece_off[n] .. piece_off[n + 1]
+  const int* c_xslot = nullptr;       // [Mu] slot of every used camera-major entry
+};
+struct ObsXWs {
+  DevBuf<int> key, key_sorted, val, src_sorted, choff, xbase, src, out, piece_off, c_xslot, tkey, tkey_sorted, tval, tval_sorted;
+  DevBuf<int2> ix;
+  int chunks = 0;
+};
+
+// wave tile of this workgroup's wave in the XCD-affine walk (-1: none)
+__device__ __forceinline__ int x_tile_of_wave(const ObsX& x) {
+  const int j = (int)(blockIdx.x >> 3) * (kBlock / 64) + (int)(threadIdx.x >> 6);
+  if (j >= x.per) return -1;
+  const int t = (int)(blockIdx.x & 7) * x.per + j;
+  return t < x.tiles ? t : -1;
+}
+inline int x_grid(const ObsX& x) { return 8 * ((x.per + kBlock / 64 - 1) / (kBlock / 64)); }
+// last lane of a piece (key: camera of a valid slot, distinct negative values on padding)
+__device__ __forceinline__ bool x_piece_tail(int key, int lane) { return seg_is_tail(key, lane) && key >= 0; }
+
+static __global__ void __launch_bounds__(kBlock)
+    k_ox_keys(long n, long pc, const int* __restrict__ c_pt, int* __restrict__ key, int* __restrict__ val) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    key[i] = (int)(c_pt[i] / pc);
+    val[i] = (int)i;
+  }
+}
+static __global__ void __launch_bounds__(kBlock)
+    k_ox_fill(long n, const int* __restrict__ key_sorted, const int* __restrict__ src_sorted, const int* __restrict__ choff,
+              const int* __restrict__ xbase, const int* __restrict__ c_pt, const int* __restrict__ c_cam,
+              int2* __restrict__ ix, int* __restrict__ src, int* __restrict__ c_xslot) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = key_sorted[i], k = src_sorted[i];
+    const int slot = xbase[c] + (int)(i - choff[c]);
+    ix[slot] = make_int2(c_pt[k], c_cam[k]);
+    src[slot] = k;
+    c_xslot[k] = slot;
+  }
+}
+static __global__ void __launch_bounds__(kBlock)
+    k_ox_tails(long nslots, int N, const int2* __restrict__ ix, int* __restrict__ tkey, int* __restrict__ tval) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += (long)gridDim.x * blockDim.x) {
+    const int2 a = ix[i];
+    bool tail = false;
+    if (a.x >= 0) {
+      if ((i & 63) == 63) {
+        tail = true;
+      } else {
+        const int2 b = ix[i + 1];
+        tail = b.x < 0 || b.y != a.y;
+      }
+    }
+    tkey[i] = tail ? a.y : N;
+    tval[i] = (int)i;
+  }
+}
+static __global__ void __launch_bounds__(kBlock)
+    k_ox_out(long npieces, const int* __restrict__ tval_sorted, int* __restrict__ out) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npieces; i += (long)gridDim.x * blockDim.x) out[tval_sorted[i]] = (int)i;
+}
+
+// Builds the chunked order from the camera-major one (build_obs_graph first).  rec_bytes: bytes of point record a sweep
+// gathers per observation (sizes the chunks).  Returns false (and leaves x empty) when there is nothing to order.
+inline bool build_x_order(gsfm_ctx* ctx, ObsGraphWs& ws, ObsXWs& xw, const ObsGraph& g, int rec_bytes, ObsX& x) {
+  x = ObsX{};
+  const long Mu = ws.h_coff[(size_t)g.N];
+  if (Mu <= 0 || g.P <= 0) return false;
+  hipStream_t s = ctx->stream;
+  // chunks: C = 8 R, R such that a chunk's records are <= ~2.7 MB (measured optimum 2 - 4 MB at 64-byte records)
+  const double per_xcd = (double)g.P * rec_bytes / 8.0;
+  int R = (int)std::ceil(per_xcd / (2.75 * 1024 * 1024));
+  R = std::max(1, std::min(R, 32));
+  const int C = 8 * R;
+  xw.chunks = C;
+  const long pc = (g.P + C - 1) / C;
+  int bits = 1;
+  while ((1 << bits) < C) ++bits;
+  xw.key.ensure(Mu + 1);
+  xw.key_sorted.ensure(Mu + 1);
+  xw.val.ensure(Mu + 1);
+  xw.src_sorted.ensure(Mu + 1);
+  xw.choff.ensure(C + 3);
+  xw.xbase.ensure(C + 3);
+  xw.c_xslot.ensure(Mu + 1);
+  hipLaunchKernelGGL(k_ox_keys, dim3(grid_for(Mu, kBlock)), dim3(kBlock), 0, s, Mu, pc, g.c_pt, xw.key.get(), xw.val.get());
+  sort_pairs_i32(ctx, ws.sort_tmp, xw.key.get(), xw.key_sorted.get(), xw.val.get(), xw.src_sorted.get(), (size_t)Mu, bits);
+  hipLaunchKernelGGL(k_og_offsets, dim3(grid_for(Mu + 1, kBlock)), dim3(kBlock), 0, s, C - 1, Mu, xw.key_sorted.get(), xw.choff.get());
+  std::vector<int> h_choff((size_t)C + 1), h_base((size_t)C + 1);
+  GSFM_HIP_CHECK(hipMemcpyAsync(h_choff.data(), xw.choff.get(), (size_t)(C + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+  GSFM_HIP_CHECK(hipStreamSynchronize(s));
+  long nslots = 0;
+  for (int c = 0; c < C; ++c) {
+    h_base[c] = (int)nslots;
+    nslots += ((long)(h_choff[c + 1] - h_choff[c]) + 63) / 64 * 64;  // every chunk starts on a tile boundary
+  }
+  h_base[C] = (int)nslots;
+  GSFM_REQUIRE(nslots < (1L << 31) - 64, "observation count must fit int32");
+  GSFM_HIP_CHECK(hipMemcpyAsync(xw.xbase.get(), h_base.data(), (size_t)(C + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+  xw.ix.ensure(nslots + 64);
+  xw.src.ensure(nslots + 64);
+  xw.out.ensure(nslots + 64);
+  GSFM_HIP_CHECK(hipMemsetAsync(xw.ix.get(), 0xff, (size_t)nslots * sizeof(int2), s));   // (-1, -1): padding
+  GSFM_HIP_CHECK(hipMemsetAsync(xw.src.get(), 0xff, (size_t)nslots * sizeof(int), s));
+  GSFM_HIP_CHECK(hipMemsetAsync(xw.out.get(), 0xff, (size_t)nslots * sizeof(int), s));
+  // camera of every camera-major entry: the sorted keys of build_obs_graph (ws.keys_sorted)
+  hipLaunchKernelGGL(k_ox_fill, dim3(grid_for(Mu, kBlock)), dim3(kBlock), 0, s, Mu, (const int*)xw.key_sorted.get(),
+                     (const int*)xw.src_sorted.get(), (const int*)xw.choff.get(), (const int*)xw.xbase.get(), g.c_pt,
+                     (const int*)ws.keys_sorted.get(), xw.ix.get(), xw.src.get(), xw.c_xslot.get());
+  // pieces in (camera, slot) order: a stable sort of the slots by (camera of a piece tail | N)
+  xw.tkey.ensure(nslots + 1);
+  xw.tkey_sorted.ensure(nslots + 1);
+  xw.tval.ensure(nslots + 1);
+  xw.tval_sorted.ensure(nslots + 1);
+  xw.piece_off.ensure(g.N + 3);
+  hipLaunchKernelGGL(k_ox_tails, dim3(grid_for(nslots, kBlock)), dim3(kBlock), 0, s, nslots, g.N, (const int2*)xw.ix.get(),
+                     xw.tkey.get(), xw.tval.get());
+  int cbits = 1;
+  while ((1L << cbits) <= g.N) ++cbits;
+  sort_pairs_i32(ctx, ws.sort_tmp, xw.tkey.get(), xw.tkey_sorted.get(), xw.tval.get(), xw.tval_sorted.get(), (size_t)nslots, cbits);
+  hipLaunchKernelGGL(k_og_offsets, dim3(grid_for(nslots + 1, kBlock)), dim3(kBlock), 0, s, g.N, nslots, xw.tkey_sorted.get(),
+                     xw.piece_off.get());
+  int* h_np = reinterpret_cast<int*>(ctx->h_pinned + 512);
+  GSFM_HIP_CHECK(hipMemcpyAsync(h_np, xw.piece_off.get() + g.N, sizeof(int), hipMemcpyDeviceToHost, s));
+  GSFM_HIP_CHECK(hipStreamSynchronize(s));  // (the host tables above go out of scope as well)
+  const int npieces = h_np[0];
+  hipLaunchKernelGGL(k_ox_out, dim3(grid_for(std::max(1, npieces), kBlock)), dim3(kBlock), 0, s, (long)npieces,
+                     (const int*)xw.tval_sorted.get(), xw.out.get());
+  x.tiles = (int)(nslots / 64);
+  x.per = (x.tiles + 7) / 8;
+  x.npieces = npieces;
+  x.ix = xw.ix.get();
+  x.src = xw.src.get();
+  x.out = xw.out.get();
+  x.piece_off = xw.piece_off.get();
+  x.c_xslot = xw.c_xslot.get();
+  return true;
+}
+
 // Camera-major slots of camera n (host).
 inline std::vector<int> cam_slots(const ObsGraphWs& ws, int n) {
   std::vector<int> out;

@@ -130,7 +130,8 @@ enum gsfm_stat {
   GSFM_STAT_PCG_SECOND_LEVEL = 5,    /* ... with the second-level (cluster) preconditioner */
   GSFM_STAT_ALLREDUCES = 6,          /* collectives issued (any transport) */
   GSFM_STAT_PCG_ITERATIONS = 7,      /* PCG iterations (operator applications of the iterations proper) */
-  GSFM_STAT_COUNT = 8
+  GSFM_STAT_PCG_CHUNKED_SWEEPS = 8,  /* reduced-system solves whose camera-side sweep ran in the chunked (XCD-partitioned) order */
+  GSFM_STAT_COUNT = 9
 };
 /* Copies min(n, GSFM_STAT_COUNT) counters to out; reset != 0 zeroes them afterwards. */
 int gsfm_ctx_stats(gsfm_ctx* ctx, int64_t* out, int n, int reset);
@@ -146,7 +147,9 @@ enum gsfm_knob {
   GSFM_KNOB_RA_DENSE_REFACTOR = 6,    /* RA, N <= 2048: re-invert at every IRLS iteration */
   GSFM_KNOB_GP_COARSE_CLUSTER = 7,    /* GP second level: cameras per cluster (0: 32) */
   GSFM_KNOB_SEG_LEN = 8,              /* camera-major order: observations per camera segment (0: 1024) */
-  GSFM_KNOB_COUNT = 9
+  GSFM_KNOB_CHUNKED_SWEEPS = 9,       /* camera-side sweeps of the PCG in the chunked order: 0 = when the point records exceed the
+                                         L2 (default), 1 = always, 2 = never (plain camera-major order) */
+  GSFM_KNOB_COUNT = 10
 };
 int gsfm_ctx_set_knob(gsfm_ctx* ctx, int knob, int value);
 /* Text of the last failure on this ctx (what the HIP / RCCL call or the argument check said); "" when there was none.  The
