@@ -399,7 +399,7 @@ def bench_pipeline(args, ctx, rank, world, barrier, dist):
                     ba_phaseA_bytes(Mb, Pb, ncam, F)),
         kernel_line(ctx, KERNEL_BA_B, "k_ba_phaseB (BA, camera-major half)", ba_phaseB_bytes(Mb, ncam, p_ba.num_intr)),
         kernel_line(ctx, KERNEL_GP, "k_gp_phaseA (GP, track-major half)", gp_phaseA_bytes(Mg, Pg, ncam)),
-        kernel_line(ctx, KERNEL_GP_B, "k_gp_phaseB (GP, camera-major half)", gp_phaseB_bytes(Mg, ncam)),
+        kernel_line(ctx, KERNEL_GP_B, gp_phaseB_name(ctx), gp_phaseB_bytes(Mg, ncam)),
     ]
     for o in lines:
         o["ms_per_step"] = (o["avg_kernel_us"] or 0.0) * (o["launches"] or 0) * 1e-3
@@ -410,7 +410,7 @@ def bench_pipeline(args, ctx, rank, world, barrier, dist):
         "the sweep kernel with the most time per step (launches x avg = %.0f ms of the %.0f ms step); averages are over the "
         "launches that ran the sweep (HIP events on the library's stream; the one launch per solve that finds it converged and "
         "returns is not counted); one BA PCG iteration = k_ba_phaseA + k_ba_phaseB + k_ba_phaseI + k_cg_update, one GP PCG "
-        "iteration = k_gp_phaseA + k_gp_phaseB + k_cg_update" % (top["ms_per_step"], med["total"]),
+        "iteration = k_gp_phaseA + k_gp_phaseB[_x + k_gp_wsum] + k_cg_update" % (top["ms_per_step"], med["total"]),
         others=lines[1:])
     roof["ms_per_step"] = top["ms_per_step"]
     err_ra = synthetic.rotation_errors_deg(so3.aa_to_rotmat(rot.numpy()), p_ra.gt_R)
@@ -457,7 +457,16 @@ def gp_phaseA_bytes(M, P, N):
 
 
 def gp_phaseB_bytes(M, N):
+    # per observation: point index 4 + (a, beta) 16 + the (X_p, t_p) record 48.  The chunked order (k_gp_phaseB_x) streams a
+    # camera index per observation as well and writes 24-byte piece partials; those extra bytes are NOT counted as useful.
     return 68.0 * M + 96.0 * N
+
+
+def gp_phaseB_name(ctx):
+    """Which camera-side sweep the library ran (it picks the chunked order when the point records overflow an XCD's L2)."""
+    if ctx.stats().get("pcg_chunked_sweeps", 0) > 0:
+        return "k_gp_phaseB_x (GP, camera-side half in the chunked, XCD-partitioned order; + k_gp_wsum, not in this time)"
+    return "k_gp_phaseB (GP, camera-major half)"
 
 
 def ba_phaseA_bytes(M, P, N, F):
@@ -864,8 +873,7 @@ def bench_gp(args, ctx, rank, world, barrier, dist):
         launches,
         avg_ms,
         "one PCG iteration = k_gp_phaseA + k_gp_phaseB + k_cg_update",
-        others=[kernel_line(ctx, KERNEL_GP_B, "k_gp_phaseB (camera-major half, 64-byte point-record gathers)",
-                            68.0 * M_loc + 96.0 * ncam)],
+        others=[kernel_line(ctx, KERNEL_GP_B, gp_phaseB_name(ctx), 68.0 * M_loc + 96.0 * ncam)],
     )
     err = synthetic.center_errors_after_sim3(res["cen"].numpy(), p.gt_center)
     cpu = None if (args.no_cpu_baseline or rank != 0 or world > 1) else cpu_baseline_gp(p)

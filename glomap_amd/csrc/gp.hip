@@ -46,6 +46,7 @@
 namespace gsfm {
 namespace {
 
+constexpr int kXTilesPerWave = 2;  // k_gp_phaseB_x
 constexpr int kCz = 8;    // doubles per (c_n | z_n | pad) gather record: one 64-byte line (48-byte records straddled two lines half the time)
 constexpr int kPtb = 16;  // doubles per point build record: X (3) | e (3) | H_pp^-1 (6) | D_p | sum_k Q_k d_k (3) -> one 128-byte line
 
@@ -834,30 +835,61 @@ __global__ void __launch_bounds__(kBlock)
 // 48-byte (c_n | z_n) records phase A uses (480 KB, cache resident; lanes of one camera read the same record).  A wave
 // segmented scan over the camera key sums every (camera, tile) piece; its last lane writes the 24-byte partial.
 // Algorithmic bytes per observation: (track, camera) 8 + (a, beta) 16 + the 64-byte record.
+template <int TPW /* tiles per wave: their loads are in flight together */>
 __global__ void __launch_bounds__(kBlock)
     k_gp_phaseB_x(ObsX x, CgVec v, const double* __restrict__ cz, const double2* __restrict__ xq,
                   const double* __restrict__ ptrec, double* __restrict__ wpart) {
-  if (v.st->done) return;
+  // A wave lives for a chain of dependent round trips — [slots, coefficients, done flag] -> [records, piece index] -> store —
+  // and every wave carries TPW tiles through it at once (TPW = 2: 90 -> 83 us at configs[3]).
+  // (Measured and dropped, here and in k_gp_phaseA: fetching what lanes share — the (c_n | z_n) record of a piece's camera,
+  // X_p of a track — once per camera / track and handing it out through LDS.  No change: lanes that name the same address
+  // do not cost the gather path extra.  Two tiles per wave in k_gp_phaseA: 86 registers, 5 waves per SIMD, no faster.)
   const int lane = threadIdx.x & 63;
-  const int tile = x_tile_of_wave(x);
-  if (tile < 0) return;
-  const long slot = (long)tile * 64 + lane;
-  const int2 ix = x.ix[slot];
-  const double2 q = xq[slot];
-  double acc[3] = {0, 0, 0};
-  int key = -1 - lane;
-  if (ix.x >= 0) {
-    key = ix.y;
-    V3 cn, zn, Xp, tp;
-    ld6(cz + kCz * (long)ix.y, cn, zn);
-    ld6(ptrec + 8 * (long)ix.x, Xp, tp);
-    const V3 y = applyQ(q.x, q.y, Xp - cn, zn - tp);
-    acc[0] = y.x;
-    acc[1] = y.y;
-    acc[2] = y.z;
+  const int j = ((int)(blockIdx.x >> 3) * (kBlock / 64) + (int)(threadIdx.x >> 6)) * TPW;
+  const int part = (int)(blockIdx.x & 7);
+  long slot[TPW];
+  int2 ix[TPW];
+  double2 q[TPW];
+#pragma unroll
+  for (int u = 0; u < TPW; ++u) {
+    const bool have = j + u < x.per && part * x.per + j + u < x.tiles;
+    slot[u] = ((long)part * x.per + j + u) * 64 + lane;
+    ix[u] = make_int2(-1, -1);
+    q[u] = make_double2(0.0, 0.0);
+    if (have) {
+      ix[u] = x.ix[slot[u]];
+      q[u] = xq[slot[u]];
+    }
   }
-  seg_scan<3>(acc, key, lane);
-  if (x_piece_tail(key, lane)) st3(wpart + 3 * (long)x.out[slot], V3{acc[0], acc[1], acc[2]});
+  const int done = v.st->done;
+  int key[TPW], out[TPW];
+  V3 cn[TPW], zn[TPW], Xp[TPW], tp[TPW];
+#pragma unroll
+  for (int u = 0; u < TPW; ++u) {
+    key[u] = ix[u].x >= 0 ? ix[u].y : -1 - lane;
+    out[u] = -1;
+    if (x_piece_tail(key[u], lane)) out[u] = x.out[slot[u]];
+  }
+  if (done) return;
+#pragma unroll
+  for (int u = 0; u < TPW; ++u) {
+    if (ix[u].x >= 0) {
+      ld6(cz + kCz * (long)ix[u].y, cn[u], zn[u]);
+      ld6(ptrec + 8 * (long)ix[u].x, Xp[u], tp[u]);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < TPW; ++u) {
+    double acc[3] = {0, 0, 0};
+    if (ix[u].x >= 0) {
+      const V3 y = applyQ(q[u].x, q[u].y, Xp[u] - cn[u], zn[u] - tp[u]);
+      acc[0] = y.x;
+      acc[1] = y.y;
+      acc[2] = y.z;
+    }
+    seg_scan<3>(acc, key[u], lane);
+    if (out[u] >= 0) st3(wpart + 3 * (long)out[u], V3{acc[0], acc[1], acc[2]});
+  }
 }
 
 // w_n = sum of the pieces of camera n (contiguous, fixed order) + D_n z_n, and this block's share of delta = z.w.
@@ -1757,12 +1789,12 @@ class GpSolver final : public LmProblem {
     // chunked order for the camera-side PCG sweep: pays when the 64-byte point records overflow an XCD's L2 (trivial rigs only)
     {
       const int knob = ctx_->knob[GSFM_KNOB_CHUNKED_SWEEPS];
-      const bool want = knob == 1 || (knob == 0 && (size_t)P_ * 64 >= ((size_t)8 << 20) && m_used_ >= 500000);
-      xon_ = want && !rig_ && knob != 2 && build_x_order(ctx_, ws->og, ws->xw, g_.g, 64, x_);
+      const bool want = knob == 1 || knob >= 8 || (knob == 0 && (size_t)P_ * 64 >= ((size_t)8 << 20) && m_used_ >= 500000);
+      xon_ = want && !rig_ && knob != 2 && build_x_order(ctx_, ws->og, ws->xw, g_.g, 64, x_, knob >= 8 ? knob : 0);
       if (xon_) {
         ws->xq.ensure((size_t)x_.tiles * 64 + 64);
         ws->wpart.ensure(3 * (size_t)std::max(1, x_.npieces) + 8);
-        gridX_ = x_grid(x_);
+        gridX_ = x_grid(x_, kXTilesPerWave);
         gridWsum_ = std::min(kMaxApplySlots, grid_for((size_t)Np_, kBlock / 64));
       }
       sweepSlots_ = xon_ ? gridWsum_ : gridCam_ + gridMulti_;  // delta partial slots the sweep of `apply` writes
@@ -2165,7 +2197,7 @@ class GpSolver final : public LmProblem {
       const double* dk = rig_ ? ws->zero_i.get() : ws->dcam.get();
       const double ys = rig_ ? 0.0 : yscale;
       if (xon_) {
-        hipLaunchKernelGGL(k_gp_phaseB_x, dim3(gridX_), dim3(kBlock), 0, s, x_, vk, (const double*)ws->cz.get(),
+        hipLaunchKernelGGL((k_gp_phaseB_x<kXTilesPerWave>), dim3(gridX_), dim3(kBlock), 0, s, x_, vk, (const double*)ws->cz.get(),
                            (const double2*)ws->xq.get(), (const double*)ws->ptrec.get(), ws->wpart.get());
         if (timed) ctx_->prof.end(s);
         hipLaunchKernelGGL(k_gp_wsum, dim3(gridWsum_), dim3(kBlock), 0, s, x_, Np_, vk, ys, (const double*)ws->wpart.get(), dk);

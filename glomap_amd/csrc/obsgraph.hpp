@@ -379,7 +379,10 @@ __device__ __forceinline__ int x_tile_of_wave(const ObsX& x) {
   const int t = (int)(blockIdx.x & 7) * x.per + j;
   return t < x.tiles ? t : -1;
 }
-inline int x_grid(const ObsX& x) { return 8 * ((x.per + kBlock / 64 - 1) / (kBlock / 64)); }
+inline int x_grid(const ObsX& x, int tiles_per_wave = 1) {
+  const int waves = (x.per + tiles_per_wave - 1) / tiles_per_wave;  // per part
+  return 8 * ((waves + kBlock / 64 - 1) / (kBlock / 64));
+}
 // last lane of a piece (key: camera of a valid slot, distinct negative values on padding)
 __device__ __forceinline__ bool x_piece_tail(int key, int lane) { return seg_is_tail(key, lane) && key >= 0; }
 
@@ -426,7 +429,7 @@ static __global__ void __launch_bounds__(kBlock)
 
 // Builds the chunked order from the camera-major one (build_obs_graph first).  rec_bytes: bytes of point record a sweep
 // gathers per observation (sizes the chunks).  Returns false (and leaves x empty) when there is nothing to order.
-inline bool build_x_order(gsfm_ctx* ctx, ObsGraphWs& ws, ObsXWs& xw, const ObsGraph& g, int rec_bytes, ObsX& x) {
+inline bool build_x_order(gsfm_ctx* ctx, ObsGraphWs& ws, ObsXWs& xw, const ObsGraph& g, int rec_bytes, ObsX& x, int force_chunks = 0) {
   x = ObsX{};
   const long Mu = ws.h_coff[(size_t)g.N];
   if (Mu <= 0 || g.P <= 0) return false;
@@ -435,6 +438,7 @@ inline bool build_x_order(gsfm_ctx* ctx, ObsGraphWs& ws, ObsXWs& xw, const ObsGr
   const double per_xcd = (double)g.P * rec_bytes / 8.0;
   int R = (int)std::ceil(per_xcd / (2.75 * 1024 * 1024));
   R = std::max(1, std::min(R, 32));
+  if (force_chunks >= 8) R = std::min(32, force_chunks / 8);  // A/B runs (GSFM_KNOB_CHUNKED_SWEEPS >= 8)
   const int C = 8 * R;
   xw.chunks = C;
   const long pc = (g.P + C - 1) / C;

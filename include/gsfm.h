@@ -148,7 +148,8 @@ enum gsfm_knob {
   GSFM_KNOB_GP_COARSE_CLUSTER = 7,    /* GP second level: cameras per cluster (0: 32) */
   GSFM_KNOB_SEG_LEN = 8,              /* camera-major order: observations per camera segment (0: 1024) */
   GSFM_KNOB_CHUNKED_SWEEPS = 9,       /* camera-side sweeps of the PCG in the chunked order: 0 = when the point records exceed the
-                                         L2 (default), 1 = always, 2 = never (plain camera-major order) */
+                                         L2 (default), 1 = always, 2 = never (plain camera-major order),
+                                         >= 8 = always, with that many point chunks (A/B runs) */
   GSFM_KNOB_COUNT = 10
 };
 int gsfm_ctx_set_knob(gsfm_ctx* ctx, int knob, int value);

@@ -26,14 +26,25 @@ from oracle import cpu  # noqa: E402
 
 
 def main():
+    cap = None
+    if "--max-iterations" in sys.argv:
+        cap = int(sys.argv[sys.argv.index("--max-iterations") + 1])
     p = synthetic.make_ba_problem(10_000, 1_000_000, seed=0, shared_intrinsics=True)
+    opt = None
+    if cap is not None:
+        from oracle import ba as oba
+
+        opt = oba.BundleAdjusterOptions()
+        opt.lm.max_num_iterations = cap
     r = cpu.ba_solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_xy, p.cam_intr, p.intr_model, p.fixed_cam, p.cam_q, p.cam_t,
-                     p.pt_xyz, p.intr_params, verbose=True)
+                     p.pt_xyz, p.intr_params, options=opt, verbose=True)
     assert r[0]
     s = r[5]
     print("LM", s.iterations, "final cost", s.final_cost, "max true relative residual of a reduced solve", s.max_linear_residual)
-    np.savez_compressed(Path(__file__).resolve().parent / "ba_c4_shared_oracle.npz", out_q=r[1], out_t=r[2], out_intr=r[4],
+    name = "ba_c4_shared_oracle.npz" if cap is None else "ba_c4_shared_oracle_it%d.npz" % cap
+    np.savez_compressed(Path(__file__).resolve().parent / name, out_q=r[1], out_t=r[2], out_intr=r[4],
                         out_final_cost=s.final_cost, out_initial_cost=s.initial_cost, out_iterations=s.iterations,
+                        out_max_linear_residual=s.max_linear_residual,
                         num_obs=p.num_obs, obs_xy_checksum=float(np.sum(p.obs_xy)), cam_t_checksum=float(np.sum(p.cam_t)))
 
 

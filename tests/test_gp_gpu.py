@@ -175,3 +175,50 @@ def _lib_status(name):
     from glomap_amd import _lib
 
     return {v: k for k, v in _lib.STATUS_NAMES.items()}[name]
+
+
+@pytest.mark.parametrize("case", ["uniform", "skewed", "short_tracks", "pairs"])
+def test_gp_chunked_camera_side_sweep_equals_camera_major(gsfm_ctx, case):
+    """The PCG's camera-side sweep has two layouts: one wave per camera over the camera-major lists (k_gp_phaseB) and one lane
+    per observation over the (point chunk, camera) order with every XCD on its own chunks (k_gp_phaseB_x + k_gp_wsum,
+    obsgraph.hpp ObsX) — chosen by the library when the point records overflow an XCD's L2.  Same operator, another
+    summation order: forced on (default chunk count, and 8 / 64 chunks) on problems far below that size, the solve must
+    follow the camera-major one — same accept / reject decisions over 8 LM iterations, centres equal to 1e-7 of the extent — use the chunked kernels (stats), leave what the
+    camera-major solve leaves untouched, and repeat bit for bit."""
+    kw = {}
+    if case == "skewed":  # busiest camera far above the median: many pieces per camera, pieces longer than a tile
+        p = synthetic.make_gp_problem(num_cams=80, num_pts=25_000, seed=4, zipf=1.3)
+    elif case == "short_tracks":  # tracks below min_num_view_per_track are not part of any order
+        p = synthetic.make_gp_problem(num_cams=120, num_pts=6_000, seed=2)
+        kw = dict(min_num_view_per_track=6)
+    else:
+        p = synthetic.make_gp_problem(num_cams=300, num_pts=20_000, seed=5, uncalibrated_ratio=0.1)
+    opt = estimators.GlobalPositionerOptions(**kw)
+    if case == "pairs":  # camera-to-camera terms on top of the sweep (their delta slots follow the sweep's)
+        p.pair_i, p.pair_j, p.pair_dir = _pairs(p, np.random.default_rng(0), noise=1e-3)
+        opt.constraint_type = 3  # POINTS_AND_CAMERAS
+    # a fixed number of LM iterations: both layouts stop at the same iterate (function_tolerance would end the two
+    # trajectories wherever rounding puts them)
+    opt.solver_options.max_num_iterations = 8
+    try:
+        gsfm_ctx.set_knob("chunked_sweeps", 2)
+        rc, c0, X0, rep0 = estimators.gp_solve(p, opt, ctx=gsfm_ctx)
+        assert rc == 0
+        for knob in (1, 8, 64):
+            gsfm_ctx.stats(reset=True)
+            gsfm_ctx.set_knob("chunked_sweeps", knob)
+            rc, c1, X1, rep1 = estimators.gp_solve(p, opt, ctx=gsfm_ctx)
+            assert rc == 0
+            st = gsfm_ctx.stats()
+            assert st["pcg_chunked_sweeps"] == st["pcg_solves"] > 0
+            print(case, knob, rep0["iterations"], rep1["iterations"], rep0["final_cost"], rep1["final_cost"])
+            assert rep1["iterations"] == rep0["iterations"] and rep1["successful_steps"] == rep0["successful_steps"]
+            assert abs(rep1["final_cost"] - rep0["final_cost"]) <= 1e-8 * rep0["final_cost"]
+            ext = np.linalg.norm(c0 - c0.mean(0), axis=1).max()
+            assert np.abs(c1 - c0).max() <= 1e-7 * ext
+            assert np.array_equal(X1[np.diff(p.pt_offset) < opt.min_num_view_per_track],
+                                  X0[np.diff(p.pt_offset) < opt.min_num_view_per_track])
+            rc, c2, X2, rep2 = estimators.gp_solve(p, opt, ctx=gsfm_ctx)
+            assert np.array_equal(c1, c2) and np.array_equal(X1, X2)
+    finally:
+        gsfm_ctx.set_knob("chunked_sweeps", 0)

@@ -178,18 +178,26 @@ def _big_worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world", [2, 4])
-def test_ranks_reproduce_single_rank_above_the_single_workgroup_size(gsfm_ctx, world):
+@pytest.mark.parametrize("world,chunked", [(2, 0), (4, 0), (2, 1)])
+def test_ranks_reproduce_single_rank_above_the_single_workgroup_size(gsfm_ctx, world, chunked, monkeypatch):
     """1 200 cameras / 40 k tracks, one intrinsics block per image, peer transport: GP takes the multi-block k_cg_update<3>
     with the gauge modes deflated and the all-reduced closed-form k_gp_aw_modes products, BA the joint 14 x 14 blocks with
-    k_ba_aw_modes — the paths bench.py --gpus N runs on configs[3].  The counters of gsfm_ctx_stats prove they ran."""
+    k_ba_aw_modes — the paths bench.py --gpus N runs on configs[3] (chunked = 1: with GP's camera-side sweep in the chunked,
+    XCD-partitioned order, which every rank builds over its own tracks).  The counters of gsfm_ctx_stats prove they ran."""
     import multiprocessing as mp
 
     gp, ba = _big_problems()
     gsfm_ctx.stats(reset=True)
-    rc, cen1, xyz1, rep_gp1 = estimators.gp_solve(gp, ctx=gsfm_ctx)
+    if chunked:  # GP's camera-side sweep in the chunked order (forced: the library picks it only above ~130 k tracks per rank)
+        gsfm_ctx.set_knob("chunked_sweeps", 1)
+        monkeypatch.setenv("GSFM_KNOBS", "chunked_sweeps=1")  # the spawned ranks read it when they create their context
+    try:
+        rc, cen1, xyz1, rep_gp1 = estimators.gp_solve(gp, ctx=gsfm_ctx)
+    finally:
+        gsfm_ctx.set_knob("chunked_sweeps", 0)
     assert rc == 0
     st_gp1 = gsfm_ctx.stats(reset=True)
+    assert (st_gp1["pcg_chunked_sweeps"] > 0) == bool(chunked)
     rc, q1, t1, X1, intr1, rep_ba1 = estimators.ba_solve(ba, ctx=gsfm_ctx)
     assert rc == 0
     st_ba1 = gsfm_ctx.stats(reset=True)
@@ -215,6 +223,7 @@ def test_ranks_reproduce_single_rank_above_the_single_workgroup_size(gsfm_ctx, w
         assert st["pcg_deflated"] == st_gp1["pcg_deflated"] > 0
         assert st["pcg_closed_form_aw"] == st["pcg_deflated"]
         assert st["allreduces"] > st["pcg_iterations"]
+        assert (st["pcg_chunked_sweeps"] == st["pcg_solves"]) if chunked else st["pcg_chunked_sweeps"] == 0
         assert abs(rep["initial_cost"] - rep_gp1["initial_cost"]) <= 1e-12 * rep_gp1["initial_cost"]
         assert rep["iterations"] == rep_gp1["iterations"] and rep["successful_steps"] == rep_gp1["successful_steps"]
         assert abs(rep["linear_iterations"] - rep_gp1["linear_iterations"]) <= 0.02 * rep_gp1["linear_iterations"] + 2

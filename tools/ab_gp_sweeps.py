@@ -1,0 +1,36 @@
+"""GP at configs[3] size (10 k cameras / 1 M tracks / 6.0 M observations) under several settings of the chunked-sweep knob:
+solve time, LM / PCG counts, final cost and the HIP-event averages of the two PCG sweeps (k_gp_phaseA, k_gp_phaseB[_x]).
+Usage: python tools/ab_gp_sweeps.py [knob values ...]      (default: 2 0 16 32 48)"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from glomap_amd import _lib, estimators, synthetic  # noqa: E402
+
+vals = [int(a) for a in sys.argv[1:]] or [2, 0, 16, 32, 48]
+ctx = _lib.Context(0)
+p = synthetic.make_gp_problem(10_000, 1_000_000, seed=0)
+print("problem:", p.num_cams, "cameras", p.num_pts, "tracks", p.num_obs, "observations", flush=True)
+for v in vals:
+    ctx.set_knob("chunked_sweeps", v)
+    best = None
+    for rep_i in range(3):
+        ctx.profile_enable(True)
+        ctx.profile_read(1)
+        ctx.profile_read(3)
+        t0 = time.perf_counter()
+        rc, cen, xyz, rep = estimators.gp_solve(p, ctx=ctx)
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        nA, msA = ctx.profile_read(1)
+        nB, msB = ctx.profile_read(3)
+        ctx.profile_enable(False)
+        if best is None or dt < best[0]:
+            best = (dt, rep, nA, msA, nB, msB)
+    dt, rep, nA, msA, nB, msB = best
+    print("chunked_sweeps=%-3d solve %.1f ms  LM %d  PCG %d  cost %.6f | phaseA %.1f us (%d)  phaseB %.1f us (%d)" % (
+        v, dt * 1e3, rep["iterations"], rep["linear_iterations"], rep["final_cost"], 1e3 * msA / max(1, nA), nA,
+        1e3 * msB / max(1, nB), nB), flush=True)
