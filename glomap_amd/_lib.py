@@ -154,6 +154,8 @@ class GpProblemC(C.Structure):
         ("pair_i", C.c_void_p),
         ("pair_j", C.c_void_p),
         ("pair_dir", C.c_void_p),
+        ("cam_draw_order", C.c_void_p),
+        ("pt_draw_order", C.c_void_p),
     ]
 
 

@@ -168,6 +168,15 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// out[0] = max of n partial maxima (one wave)
+__global__ void __launch_bounds__(64) k_gp_fold_max(const double* __restrict__ mpart, int n, double* __restrict__ out) {
+  double m = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) m = fmax(m, mpart[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
+  if (threadIdx.x == 0) out[0] = m;
+}
+
 // max_i |vec[i]| per block -> mpart[block]  (the gradient has 10^4 .. 10^6 entries: one workgroup took 140 us)
 __global__ void __launch_bounds__(kBlock) k_gp_absmax(const double* __restrict__ vec, int nvec, double* __restrict__ mpart) {
   __shared__ double smem[4];
@@ -308,11 +317,21 @@ __global__ void __launch_bounds__(kBlock)
 
 // ---- build, camera side: (a_k, beta_k) in camera-major order, reduced gradient, S_cc blocks -----
 // One wave per camera.  g'_c = sum_k q_k + Q_k e_p;  S_cc = sum_k Q_k - Q_k H_pp^-1 Q_k.
+// Two more jobs ride on the same sweep — they want the same per-observation gathers (the 128-byte point build record, the
+// observation's scale) and each was a sweep of its own until round 4:
+//   LIN  the camera half of the linearisation at a newly accepted point (k_gp_lin_cam: h_cc = sum w s^2, g_c = sum w s r
+//        and the camera-major mirror of the scales), run with the first build that follows the acceptance;
+//   AW   the closed-form products A W of the four gauge modes (k_gp_aw_modes; without the D_n W term, which needs the
+//        damping of k_gp_cam_finalize and is added by k_gp_aw_finish).
+template <bool LIN, bool AW>
 __global__ void __launch_bounds__(kBlock)
-    k_gp_build_cam(GpDev g, double radius, const double* __restrict__ c, const double* __restrict__ c_s,
-                   const double* __restrict__ ptb, double* __restrict__ c_qa, double* __restrict__ c_qb,
-                   double* __restrict__ gred, double* __restrict__ scc,
-                   const int* __restrict__ c_xslot, double2* __restrict__ xq /* chunked order (or null): slot of k, (a, beta) there */) {
+    k_gp_build_cam(GpDev g, double radius, const double* __restrict__ c, const double* __restrict__ s_trk,
+                   double* __restrict__ c_s, const double* __restrict__ ptb, double* __restrict__ c_qa,
+                   double* __restrict__ c_qb, double* __restrict__ gred, double* __restrict__ scc,
+                   const int* __restrict__ c_xslot, double2* __restrict__ xq /* chunked order (or null): slot of k, (a, beta) there */,
+                   double* __restrict__ hcc, double* __restrict__ gc /* LIN */, double* __restrict__ awraw /* AW: [4][n3] */,
+                   long n3) {
+  constexpr int OL = 9, OA = 9 + (LIN ? 4 : 0), W = OA + (AW ? 12 : 0);
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (kBlock / 64);
@@ -320,14 +339,23 @@ __global__ void __launch_bounds__(kBlock)
     const int sg = cam_seg_index(g.g, it);
     const int n = g.g.seg_cam[sg];
     const V3 cn = ld3(c + 3 * (long)n);
-    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double acc[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) acc[j] = 0.0;
     for (int k = cam_seg_k0(g.g, sg) + lane; k < cam_seg_k1(g.g, sg); k += 64) {
       const long src = g.g.c_src[k];
       const double* b = ptb + kPtb * (long)g.g.c_pt[k];
-      const V3 d = ld3(b) - cn;
+      const V3 Xp = ld3(b);
+      const V3 d = Xp - cn;
       const V3 e = ld3(b + 3);
       const S3 Hi{b[6], b[7], b[8], b[9], b[10], b[11]};
-      const double sk = c_s[k];  // (the scales in camera order: k_gp_lin_cam)
+      double sk;
+      if constexpr (LIN) {
+        sk = s_trk[src];  // a random 8-byte gather = one fabric request per observation: paid once per accepted step and
+        c_s[k] = sk;      // handed on in camera order to every build until the next one
+      } else {
+        sk = c_s[k];
+      }
       const V3 r = ld3(g.c_dir + 3 * (long)k) - sk * d;
       double rho, w;
       huber(g.huber_a, (g.c_cal == nullptr || g.c_cal[k]) ? g.wpt : 0.5 * g.wpt, dot(r, r), rho, w);
@@ -340,6 +368,13 @@ __global__ void __launch_bounds__(kBlock)
       c_qa[k] = a;
       c_qb[k] = beta;
       if (xq != nullptr) xq[c_xslot[k]] = make_double2(a, beta);  // runs of consecutive slots per (chunk, camera)
+      if constexpr (LIN) {
+        const double ws = w * sk;
+        acc[OL] += ws * sk;
+        acc[OL + 1] += ws * r.x;
+        acc[OL + 2] += ws * r.y;
+        acc[OL + 3] += ws * r.z;
+      }
       if (!g.opt_c) continue;
       const V3 q = applyQ(w * sk, beta, d, r) + applyQ(a, beta, d, e);
       acc[0] += q.x;
@@ -357,15 +392,50 @@ __global__ void __launch_bounds__(kBlock)
       acc[6] += Q.yy - c1.y;
       acc[7] += Q.yz - c2.y;
       acc[8] += Q.zz - c2.z;
+      if constexpr (AW) {  // k_gp_aw_modes, term by term
+        const double Dp = b[12];
+        const V3 u0{Dp * Hi.xx, Dp * Hi.xy, Dp * Hi.xz}, u1{Dp * Hi.xy, Dp * Hi.yy, Dp * Hi.yz}, u2{Dp * Hi.xz, Dp * Hi.yz, Dp * Hi.zz};
+        const V3 vp = mul(Hi, Dp * Xp + V3{b[13], b[14], b[15]});
+        const V3 y0 = applyQ(a, beta, d, u0), y1 = applyQ(a, beta, d, u1), y2 = applyQ(a, beta, d, u2), y3 = applyQ(a, beta, d, vp - d);
+        acc[OA] += y0.x; acc[OA + 1] += y0.y; acc[OA + 2] += y0.z;
+        acc[OA + 3] += y1.x; acc[OA + 4] += y1.y; acc[OA + 5] += y1.z;
+        acc[OA + 6] += y2.x; acc[OA + 7] += y2.y; acc[OA + 8] += y2.z;
+        acc[OA + 9] += y3.x; acc[OA + 10] += y3.y; acc[OA + 11] += y3.z;
+      }
     }
-    wave_allsum<9>(acc);
-    if (!cam_seg_total<9>(g.g, sg, acc, lane)) continue;
+    wave_allsum<W>(acc);
+    if (!cam_seg_total<W>(g.g, sg, acc, lane)) continue;
     if (lane == 0) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) gred[3 * (long)n + j] = acc[j];
 #pragma unroll
       for (int j = 0; j < 6; ++j) scc[6 * (long)n + j] = acc[3 + j];
+      if constexpr (LIN) {
+        hcc[n] = acc[OL];
+        gc[3 * (long)n] = acc[OL + 1];
+        gc[3 * (long)n + 1] = acc[OL + 2];
+        gc[3 * (long)n + 2] = acc[OL + 3];
+      }
+      if constexpr (AW) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) awraw[(size_t)m * n3 + 3 * (long)n + j] = acc[OA + 3 * m + j];
+      }
     }
+  }
+}
+
+// A W_j = (what k_gp_build_cam<., true> summed, all-reduced) + D_n W_j: translations W_a = e_a, scale W_3 = c_n
+__global__ void __launch_bounds__(kBlock)
+    k_gp_aw_finish(int N, const double* __restrict__ c, const double* __restrict__ dcam, const double* __restrict__ awraw,
+                   double* __restrict__ AW) {
+  const long n3 = 3L * N;
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < n3; o += (long)gridDim.x * blockDim.x) {
+    const int a = (int)(o % 3);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) AW[(size_t)j * n3 + o] = awraw[(size_t)j * n3 + o] + (a == j ? dcam[o] : 0.0);
+    AW[(size_t)3 * n3 + o] = awraw[(size_t)3 * n3 + o] + dcam[o] * c[o];
   }
 }
 
@@ -1519,7 +1589,7 @@ struct GpWs {
   // calibrated rigs: image tables and the image-space twins of the per-camera arrays
   DevBuf<int> img_frame, foff, fimg, img_sensor, soff, simg;
   DevBuf<double> img_off, ci, cin, hcc_i, gc_i, gred_i, scc_i, zimg, wimg, ximg, zero_i, cz_f, img_rot;
-  DevBuf<double> defl_w, defl_aw, defl_b2, defl_part, defl_small, defl_cd;  // CgDeflation, cg.hpp
+  DevBuf<double> defl_w, defl_aw, defl_awraw, defl_b2, defl_part, defl_small, defl_cd;  // CgDeflation, cg.hpp
   DevBuf<double> maxpart;
   DevBuf<int> pr_i, pr_j, pr_row, pr_ent;                       // camera-to-camera constraints (GpPairs)
   DevBuf<double> pr_v, pr_s, pr_sn, pr_w, pr_js, pr_qa, pr_qb, pr_part;
@@ -1607,6 +1677,18 @@ class GpSolver final : public LmProblem {
     // ONLY_CAMERAS: no track is part of the problem — every track counts as too short, the sweeps see no observation
     const int min_views = with_points_ ? opt_.min_num_view_per_track /* gp.cc:258 */ : 0x3fffffff;
     m_used_ = build_obs_graph(ctx_, ws->og, NI_, P_, M_, h_off, ws->off.get(), ws->cam.get(), min_views, g_.g, &fixed_obs);
+    if (prob->pt_draw_order != nullptr && fixed_obs >= 0) {
+      // the reference's constant scale is the first one it ADDS (gp.cc:484-489), i.e. the first observation of the first kept,
+      // non-empty track in its own walk over the tracks — the draw order when the caller numbered the tracks differently
+      for (long i = 0; i < P_; ++i) {
+        const long p = prob->pt_draw_order[i];
+        GSFM_REQUIRE(p >= 0 && p < P_, "GP: pt_draw_order is not a permutation");
+        if (h_off[p + 1] - h_off[p] >= std::max(1, min_views)) {
+          fixed_obs = h_off[p];
+          break;
+        }
+      }
+    }
     if (ctx_->comm.rank != 0) fixed_obs = -1;  // one constant scale in the whole problem
     if (E_ > 0) fixed_obs = -1;                // ... and with pairs it is the first PAIR's (they are added first, gp.cc:484-489)
     // camera-major copies of the per-observation inputs
@@ -1679,14 +1761,34 @@ class GpSolver final : public LmProblem {
         for (int r = ctx_->comm.rank + 1; r < W; ++r) used_after += (long)h[(size_t)N_ + r];
       }
     }
+    // the draws visit cameras / tracks in index order, or in the caller's container order (gsfm_gp_problem::*_draw_order)
+    const int32_t* cam_order = prob->cam_draw_order;
+    const int32_t* pt_order = prob->pt_draw_order;
+    GSFM_REQUIRE((cam_order == nullptr && pt_order == nullptr) || ctx_->comm.world == 1, "GP: draw orders need a single rank");
+    if (cam_order) {
+      std::vector<char> seen(N_, 0);
+      for (int i = 0; i < N_; ++i) {
+        GSFM_REQUIRE(cam_order[i] >= 0 && cam_order[i] < N_ && !seen[cam_order[i]], "GP: cam_draw_order is not a permutation");
+        seen[cam_order[i]] = 1;
+      }
+    }
     if (opt_.generate_random_positions && opt_.optimize_positions) {
-      for (int n = 0; n < N_; ++n) {
+      for (int i = 0; i < N_; ++i) {
+        const int n = cam_order ? cam_order[i] : i;
         if (!constrained[n]) continue;
         rng.fill_uniform_pm1(&h_c[3 * (size_t)n], 3, 100.0);
       }
     }
     if (used_before > 0 && opt_.generate_random_points && opt_.optimize_points) rng.discard(6ull * (unsigned long long)used_before);
-    if (opt_.generate_random_points && opt_.optimize_points && with_points_) {
+    if (pt_order && opt_.generate_random_points && opt_.optimize_points && with_points_) {
+      std::vector<char> seen(P_, 0);
+      for (long i = 0; i < P_; ++i) {
+        const long p = pt_order[i];
+        GSFM_REQUIRE(p >= 0 && p < P_ && !seen[p], "GP: pt_draw_order is not a permutation");
+        seen[p] = 1;
+        if (h_off[p + 1] - h_off[p] >= opt_.min_num_view_per_track) rng.fill_uniform_pm1(&h_X[3 * (size_t)p], 3, 100.0);
+      }
+    } else if (opt_.generate_random_points && opt_.optimize_points && with_points_) {
       for (long p = 0; p < P_;) {  // runs of consecutive used tracks are drawn in one call
         if (h_off[p + 1] - h_off[p] < opt_.min_num_view_per_track) {
           ++p;
@@ -1926,6 +2028,20 @@ class GpSolver final : public LmProblem {
     double* gc_k = rig_ ? ws->gc_i.get() : ws->gc.get();
     hipLaunchKernelGGL(k_gp_lin_track, dim3(gridTileP_), dim3(kBlock), 0, s, g_, ci_, X_, s_, ws->wrob.get(),
                        ws->hppd.get(), ws->part.get());
+    // The camera half (h_cc, g_c, the camera-major mirror of the scales) wants the gathers the build sweep makes anyway:
+    // after the first linearisation (whose h_cc fixes the Jacobi scaling before any build) it rides on the first
+    // k_gp_build_cam of the next step() and the gradient test waits for it (lm.hpp: gradient_pending).
+    lin_pending_ = lin_count_ > 0 && !rig_ && E_ == 0;
+    ++lin_count_;
+    if (lin_pending_) {
+      hipLaunchKernelGGL(k_gp_finalize_lin, dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridTileP_, (const double*)ws->maxpart.ensure(64), 0,
+                         ws->scal.get());
+      double h[2];
+      read_scalars(ws->scal.get(), h, 2, /*sum_first=*/1, /*max_from=*/1);
+      gmax_track_ = h[1];
+      *grad_max_norm = h[1];
+      return h[0];
+    }
     hipLaunchKernelGGL(k_gp_lin_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, ci_, X_, s_, hcc_k, gc_k, ws->c_s.get());
     if (gridMulti_)  // combine pass over the cameras whose lists were cut into slices (obsgraph.hpp)
       hipLaunchKernelGGL(k_gp_lin_cam, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, ci_, X_, s_, hcc_k, gc_k, ws->c_s.get());
@@ -1979,11 +2095,36 @@ class GpSolver final : public LmProblem {
     hipLaunchKernelGGL(k_gp_build_track, dim3(gridTile_), dim3(kBlock), 0, s, g_, radius, ci_, X_, s_, ws->wrob.get(),
                        ws->jss.get(), ws->jsx.get(), ws->hppd.get(), ws->qa.get(), ws->qb.get(), ws->ptb.get(),
                        ws->ptrec.get(), ws->pth.get(), ws->tq.get());
-    hipLaunchKernelGGL(k_gp_build_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, radius, ci_, (const double*)ws->c_s.get(), ws->ptb.get(),
-                       ws->c_qa.get(), ws->c_qb.get(), gred_k, scc_k, x_.c_xslot, xon_ ? ws->xq.get() : nullptr);
-    if (gridMulti_)
-      hipLaunchKernelGGL(k_gp_build_cam, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, radius, ci_, (const double*)ws->c_s.get(), ws->ptb.get(),
-                         ws->c_qa.get(), ws->c_qb.get(), gred_k, scc_k, x_.c_xslot, xon_ ? ws->xq.get() : nullptr);
+    // riders of the camera-side build sweep (k_gp_build_cam): the camera half of a pending linearisation, and the closed-form
+    // gauge products when this step's solve will deflate them (the conditions of pcg())
+    const bool lin = lin_pending_;
+    aw_built_ = !rig_ && E_ == 0 && g_.opt_c && g_.opt_x && defl_on_ && !coarse_on_ && N_ > kCgSingleMaxBlocks;
+    const long n3l = 3L * Np_;
+    double* awraw = aw_built_ ? ws->defl_awraw.ensure(4 * (size_t)n3l) : nullptr;
+    auto build_cam = [&](auto lin_c, auto aw_c) {
+      constexpr bool L = decltype(lin_c)::value, A = decltype(aw_c)::value;
+      hipLaunchKernelGGL((k_gp_build_cam<L, A>), dim3(gridCam_), dim3(kBlock), 0, s, g_, radius, ci_, (const double*)s_, ws->c_s.get(),
+                         ws->ptb.get(), ws->c_qa.get(), ws->c_qb.get(), gred_k, scc_k, x_.c_xslot, xon_ ? ws->xq.get() : nullptr,
+                         ws->hcc.get(), ws->gc.get(), awraw, n3l);
+      if (gridMulti_)
+        hipLaunchKernelGGL((k_gp_build_cam<L, A>), dim3(gridMulti_), dim3(kBlock), 0, s, g1_, radius, ci_, (const double*)s_, ws->c_s.get(),
+                           ws->ptb.get(), ws->c_qa.get(), ws->c_qb.get(), gred_k, scc_k, x_.c_xslot, xon_ ? ws->xq.get() : nullptr,
+                           ws->hcc.get(), ws->gc.get(), awraw, n3l);
+    };
+    if (lin && aw_built_) build_cam(std::true_type{}, std::true_type{});
+    else if (lin) build_cam(std::true_type{}, std::false_type{});
+    else if (aw_built_) build_cam(std::false_type{}, std::true_type{});
+    else build_cam(std::false_type{}, std::false_type{});
+    if (lin) {  // what linearize() left open: all-reduce, max-norm of the camera gradient (read back with the step's scalars)
+      if (multi) {
+        allreduce_sum(ctx_, ws->hcc.get(), Np_);
+        allreduce_sum(ctx_, ws->gc.get(), 3 * (size_t)Np_);
+      }
+      const int nvec = g_.opt_c ? 3 * Np_ : 0;
+      const int gmx = nvec ? std::min(64, grid_for((size_t)nvec, kBlock)) : 0;
+      if (gmx) hipLaunchKernelGGL(k_gp_absmax, dim3(gmx), dim3(kBlock), 0, s, (const double*)ws->gc.get(), nvec, ws->maxpart.ensure(64));
+      hipLaunchKernelGGL(k_gp_fold_max, dim3(1), dim3(64), 0, s, (const double*)ws->maxpart.get(), gmx, ws->scal.get() + 7);
+    }
     if (E_ > 0) {
       hipLaunchKernelGGL(k_gpp_build, dim3(gridPair_), dim3(kBlock), 0, s, q_, radius, c_, (const double*)ps_,
                          (const double*)ws->pr_w.get(), (const double*)ws->pr_js.get(), ws->pr_qa.get(), ws->pr_qb.get());
@@ -2041,8 +2182,8 @@ class GpSolver final : public LmProblem {
       allreduce_sum(ctx_, ws->scal.get(), 3);
       allreduce_sum(ctx_, ws->scal.get() + 6, 1);
     }
-    double h[7];
-    GSFM_HIP_CHECK(hipMemcpyAsync(ctx_->h_pinned + 256, ws->scal.get(), 7 * sizeof(double), hipMemcpyDeviceToHost, s));
+    double h[8];
+    GSFM_HIP_CHECK(hipMemcpyAsync(ctx_->h_pinned + 256, ws->scal.get(), 8 * sizeof(double), hipMemcpyDeviceToHost, s));
     GSFM_HIP_CHECK(hipStreamSynchronize(s));
     GSFM_HIP_CHECK(hipGetLastError());
     comm_check(ctx_);
@@ -2051,8 +2192,20 @@ class GpSolver final : public LmProblem {
     *step_norm = std::sqrt(h[1] + h[3]);
     *x_norm = std::sqrt(h[2] + h[4]);
     *cand_cost = h[6];
+    if (lin) {
+      lin_pending_ = false;
+      gmax_ready_ = true;
+      gmax_full_ = std::max(gmax_track_, h[7]);
+    }
     const bool finite = h[5] == 0.0 && std::isfinite(h[0]) && std::isfinite(h[1]) && std::isfinite(h[6]);
     return finite;
+  }
+  bool gradient_pending() const override { return lin_pending_; }
+  bool take_pending_gradient(double* grad_max_norm) override {
+    if (!gmax_ready_) return false;
+    gmax_ready_ = false;
+    *grad_max_norm = gmax_full_;
+    return true;
   }
 
   void accept() override {
@@ -2234,7 +2387,12 @@ class GpSolver final : public LmProblem {
       defl.cd = ws->defl_cd.ensure((size_t)2 * kCgMaxBlocks * 2 * kCgMaxModes);
       hipLaunchKernelGGL(k_gp_defl_modes, dim3(gridN_), dim3(kBlock), 0, s, N_, (const double*)ci_, W);
       defl.W = W;
-      if (g_.opt_x) {  // A W of all four modes in one camera-major sweep (k_gp_aw_modes): no operator application
+      if (g_.opt_x && aw_built_) {  // the sums rode on this step's k_gp_build_cam: all-reduce, add D_n W
+        if (ctx_->comm.world > 1) allreduce_sum(ctx_, ws->defl_awraw.get(), 4 * n3);
+        hipLaunchKernelGGL(k_gp_aw_finish, dim3(gridN_), dim3(kBlock), 0, s, N_, (const double*)ci_, (const double*)ws->dcam.get(),
+                           (const double*)ws->defl_awraw.get(), defl.AW);
+        defl.aw_ready = 4;
+      } else if (g_.opt_x) {  // A W of all four modes in one camera-major sweep (k_gp_aw_modes): no operator application
         hipLaunchKernelGGL(k_gp_aw_modes, dim3(gridCam_), dim3(kBlock), 0, s, g_, yscale, (const double*)ci_,
                            (const double*)ws->c_qa.get(), (const double*)ws->c_qb.get(), (const double*)ws->ptb.get(),
                            (const double*)ws->dcam.get(), defl.AW, (long)n3);
@@ -2283,6 +2441,9 @@ class GpSolver final : public LmProblem {
   double *ci_ = nullptr, *cin_ = nullptr;
   long P_ = 0, M_ = 0, m_used_ = 0;
   int gridP_ = 1, gridN_ = 1, gridM_ = 1, gridCam_ = 1, gridMulti_ = 0, gridTile_ = 1, gridTileP_ = 1;
+  bool lin_pending_ = false, aw_built_ = false, gmax_ready_ = false;  // riders of k_gp_build_cam (step())
+  int lin_count_ = 0;
+  double gmax_track_ = 0.0, gmax_full_ = 0.0;
   ObsX x_;            // chunked order of the camera-side PCG sweep (xon_)
   bool xon_ = false;
   int gridX_ = 0, gridWsum_ = 0, sweepSlots_ = 0;
@@ -2396,6 +2557,8 @@ extern "C" int gsfm_gp_solve(gsfm_ctx* ctx, const gsfm_gp_problem* prob, const g
       dump.array("pair_j", prob->pair_j, {(int64_t)prob->num_pairs}, prob->mem);
       dump.array("pair_dir", prob->pair_dir, {(int64_t)prob->num_pairs, 3}, prob->mem);
     }
+    if (prob->cam_draw_order) dump.array("cam_draw_order", prob->cam_draw_order, {N}, GSFM_MEM_HOST);
+    if (prob->pt_draw_order) dump.array("pt_draw_order", prob->pt_draw_order, {P}, GSFM_MEM_HOST);
   }
   const int rc = guarded(ctx, report, [&] { return gp_solve_impl(ctx, prob, opt, cam_center_inout, pt_xyz_inout, report); });
   if (dumping) {

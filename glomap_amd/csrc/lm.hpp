@@ -32,6 +32,12 @@ struct LmProblem {
                     double* x_norm, long* linear_iterations) = 0;
   // Make the candidate the current point.
   virtual void accept() = 0;
+  // A problem may finish the linearisation of a newly accepted point inside the first step() that follows (global
+  // positioning folds the camera half into its build sweep: same gathers).  gradient_pending(): the max-norm linearize()
+  // returned is incomplete, so the gradient-tolerance test waits; take_pending_gradient(): after step(), the complete
+  // max-norm of that point when it became known in this call.
+  virtual bool gradient_pending() const { return false; }
+  virtual bool take_pending_gradient(double* grad_max_norm) { (void)grad_max_norm; return false; }
 };
 
 inline void lm_options_default(gsfm_lm_options* o, int max_iterations) {
@@ -82,6 +88,13 @@ inline int lm_minimize(LmProblem& prob, const gsfm_lm_options& o, gsfm_report* r
       long lin = 0;
       bool valid = prob.step(radius, &model_change, &cand_cost, &step_norm, &x_norm, &lin);
       lin_total += lin;
+      if (prob.take_pending_gradient(&gmax) && !(gmax > o.gradient_tolerance)) {
+        // the gradient test of the point accepted in the previous iteration (trust_region_minimizer.cc tests it right after
+        // the acceptance): the step just computed is not taken and does not count
+        --iterations;
+        termination = GSFM_TERM_CONVERGENCE;
+        break;
+      }
       if (verbose)
         fprintf(stderr, "[gsfm lm] it %d radius %.3e pcg %ld model %.6e cand %.9e (cost %.9e) step %.3e\n", iterations,
                 radius, lin, model_change, cand_cost, cost, step_norm);
@@ -111,7 +124,7 @@ inline int lm_minimize(LmProblem& prob, const gsfm_lm_options& o, gsfm_report* r
         prob.accept();
         cost = prob.linearize(&gmax);
         ++successful;
-        if (!(gmax > o.gradient_tolerance)) {
+        if (!prob.gradient_pending() && !(gmax > o.gradient_tolerance)) {
           termination = GSFM_TERM_CONVERGENCE;
           break;
         }

@@ -422,6 +422,13 @@ def gp_solve(p: GpProblem, options: Optional[GlobalPositionerOptions] = None, ct
         pi, pj, pd = _h(p.pair_i, np.int32), _h(p.pair_j, np.int32), _h(p.pair_dir, np.float64)
         assert _mem_of(pi, pj, pd) == c.mem
         c.num_pairs, c.pair_i, c.pair_j, c.pair_dir = int(pi.shape[0]), _lib.ptr(pi), _lib.ptr(pj), _lib.ptr(pd)
+    orders = []  # host permutations: the order of the random draws
+    for name in ("cam_draw_order", "pt_draw_order"):
+        v = getattr(p, name, None)
+        if v is not None:
+            a = np.ascontiguousarray(np.asarray(v.cpu() if hasattr(v, "cpu") else v), dtype=np.int32)
+            orders.append(a)
+            setattr(c, name, a.ctypes.data)
     rep = _lib.Report()
     rc = ctx.lib.gsfm_gp_solve(ctx.handle, C.byref(c), C.byref(opt), _lib.ptr(cen), _lib.ptr(xyz), C.byref(rep))
     report = rep.as_dict()

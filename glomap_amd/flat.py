@@ -89,6 +89,10 @@ class GpProblem:
     pair_i: Optional[np.ndarray] = None  # [E] int32
     pair_j: Optional[np.ndarray] = None  # [E] int32
     pair_dir: Optional[np.ndarray] = None  # [E,3] f64
+    # Order of the random draws (host int32 permutations, optional): the reference's container iteration order when frames /
+    # tracks are numbered differently (include/gsfm.h, gsfm_gp_problem)
+    cam_draw_order: Optional[np.ndarray] = None  # [N] int32
+    pt_draw_order: Optional[np.ndarray] = None  # [P] int32
 
     @property
     def num_obs(self) -> int:

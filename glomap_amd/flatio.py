@@ -96,7 +96,8 @@ def to_problem(rec: FlatRecord):
                       image_frame=a.get("image_frame"), image_offset=a.get("image_offset"),  # calibrated rigs
                       image_sensor=a.get("image_sensor"), image_sensor_rot=a.get("image_sensor_rot"),
                       sensor_center=a.get("sensor_center"),  # unknown cam_from_rig centres
-                      pair_i=a.get("pair_i"), pair_j=a.get("pair_j"), pair_dir=a.get("pair_dir"))  # camera-to-camera constraints
+                      pair_i=a.get("pair_i"), pair_j=a.get("pair_j"), pair_dir=a.get("pair_dir"),  # camera-to-camera constraints
+                      cam_draw_order=a.get("cam_draw_order"), pt_draw_order=a.get("pt_draw_order"))
         opt = _fill(estimators.GlobalPositionerOptions(), o)
         _lm(opt.solver_options, o)
         return p, opt
@@ -138,6 +139,9 @@ def from_problem(p, options=None) -> FlatRecord:
         if p.pair_i is not None:
             arrs.update(pair_i=np.asarray(p.pair_i, np.int32), pair_j=np.asarray(p.pair_j, np.int32),
                         pair_dir=np.asarray(p.pair_dir, np.float64))
+        for name in ("cam_draw_order", "pt_draw_order"):
+            if getattr(p, name, None) is not None:
+                arrs[name] = np.asarray(getattr(p, name), np.int32)
         return FlatRecord("gp", {"num_cams": p.num_cams}, _opts(options), arrays=arrs)
     if isinstance(p, BaProblem):
         arrs = dict(pt_offset=np.asarray(p.pt_offset, np.int64), obs_cam=np.asarray(p.obs_cam, np.int32), obs_xy=np.asarray(p.obs_xy, np.float64),

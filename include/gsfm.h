@@ -385,6 +385,16 @@ typedef struct gsfm_gp_problem {
   const int32_t* pair_i;           /* [E] */
   const int32_t* pair_j;           /* [E] */
   const double* pair_dir;          /* [E][3] */
+  /* Order of the random draws (HOST memory, both optional; NULL = index order).  The reference draws the random start while
+   * it iterates its own containers (frames: gp.cc:128-162, tracks: gp.cc:258-264) — hash maps, whose iteration order has
+   * nothing to do with capture order.  A caller that numbers frames and tracks for memory locality (sorted ids: co-visible
+   * cameras next to each other, which is also what the second-level preconditioner's index clusters want) passes the
+   * container order here and still gets the reference's start bit for bit: camera draws visit cam_draw_order[0],
+   * cam_draw_order[1], ... (a permutation of 0 .. N-1), then the kept tracks in the order pt_draw_order[0], ... (a
+   * permutation of 0 .. P-1); the constant scale (gp.cc:484-489: the first one the reference adds) is then the first
+   * observation of the first kept, non-empty track of that walk.  Single rank only (a sharded problem draws in index order). */
+  const int32_t* cam_draw_order;   /* [N] host */
+  const int32_t* pt_draw_order;    /* [P] host */
 } gsfm_gp_problem;
 
 /* cam_center_inout [N][3]: camera centres c = -R^T t (in: used when !generate_random_positions;

@@ -254,6 +254,20 @@ struct FrameIndex {
     ids.push_back(f);
     return n;
   }
+  // Dense indices in ASCENDING id order for the given frames (COLMAP ids grow in import = capture order, so co-visible
+  // frames become neighbours in memory and the second-level preconditioner's index clusters are clusters of the scene),
+  // instead of the iteration order of the caller's hash map.  `map_order` = the frames as the reference would walk them;
+  // returns the dense index of each of them in that order (gsfm_gp_problem::cam_draw_order; gauge choices that follow the
+  // reference's walk are made from it as well).
+  std::vector<int32_t> AddSorted(const std::vector<frame_t>& map_order) {
+    std::vector<frame_t> sorted(map_order);
+    std::sort(sorted.begin(), sorted.end());
+    for (frame_t f : sorted) Add(f);
+    std::vector<int32_t> walk;
+    walk.reserve(map_order.size());
+    for (frame_t f : map_order) walk.push_back(of.at(f));
+    return walk;
+  }
 };
 
 // Track-major observation lists shared by GP and BA (gp.cc:270-375, ba.cc:115-190).
@@ -272,12 +286,21 @@ struct TrackPack {
 // zero-length track — the reference still draws its random start and marks it initialised (gp.cc:258-264), so it has
 // to take its turn in the random stream; the library is then called with min_num_view_per_track = 0 (every packed
 // track is "used").  Bundle adjustment drops such tracks (nothing happens to them in ba.cc:121-133) and calls with 1.
+// Tracks are packed in ASCENDING id order (track establishment numbers tracks by their first image / feature, so sorted ids
+// keep tracks of neighbouring images together — the caller's hash map does not); draw_order, when asked for, receives the
+// packed index of every packed track in the hash map's own iteration order (gsfm_gp_problem::pt_draw_order).
 template <typename Keep>
 inline TrackPack PackTracks(std::unordered_map<image_t, glomap::Image>& images,
                             std::unordered_map<track_t, glomap::Track>& tracks, FrameIndex& fidx, Keep keep,
-                            size_t min_views = 0, bool keep_empty = false) {
+                            size_t min_views = 0, bool keep_empty = false, std::vector<int32_t>* draw_order = nullptr) {
   TrackPack tp;
-  for (auto& [tid, track] : tracks) {
+  std::vector<track_t> map_order;
+  map_order.reserve(tracks.size());
+  for (auto& [tid, track] : tracks) map_order.push_back(tid);
+  std::vector<track_t> sorted(map_order);
+  std::sort(sorted.begin(), sorted.end());
+  for (track_t tid : sorted) {
+    auto& track = tracks.at(tid);
     if (track.observations.size() < min_views) continue;
     const size_t before = tp.obs_cam.size();
     for (const auto& obs : track.observations) {
@@ -290,6 +313,13 @@ inline TrackPack PackTracks(std::unordered_map<image_t, glomap::Image>& images,
     if (tp.obs_cam.size() == before && !keep_empty) continue;
     tp.track_ids.push_back(tid);
     tp.pt_offset.push_back(static_cast<int64_t>(tp.obs_cam.size()));
+  }
+  if (draw_order != nullptr) {
+    draw_order->clear();
+    for (track_t tid : map_order) {
+      auto it = std::lower_bound(tp.track_ids.begin(), tp.track_ids.end(), tid);  // packed ids are ascending
+      if (it != tp.track_ids.end() && *it == tid) draw_order->push_back(static_cast<int32_t>(it - tp.track_ids.begin()));
+    }
   }
   return tp;
 }
@@ -728,14 +758,18 @@ class GlobalPositioner {
     const bool rigged = !detail::AllTrivial(images);  // calibrated multi-camera rigs: observations are keyed by image
     if (with_pairs && rigged) return false;  // "only trivial frames are supported for the camera to camera constraints" (gp.cc:169-176)
     detail::FrameIndex fidx;
-    for (auto& [fid, fr] : frames) fidx.Add(fid);  // every frame: ConvertResults rewrites all of them (gp.cc:566-572)
+    std::vector<frame_t> frame_walk;
+    for (auto& [fid, fr] : frames) frame_walk.push_back(fid);  // every frame: ConvertResults rewrites all of them (gp.cc:566-572)
+    // dense indices by ascending id; the random start is still drawn in the hash maps' iteration order (gp.cc:128-162, 258-264)
+    const std::vector<int32_t> cam_draw_order = fidx.AddSorted(frame_walk);
+    std::vector<int32_t> pt_draw_order;
     auto keep = [](const glomap::Image& im, uint32_t f) {  // gp.cc:279-292
       if (!im.IsRegistered()) return false;
       const auto& v = im.features_undist[f];
       return !(std::isnan(v[0]) || std::isnan(v[1]) || std::isnan(v[2]));
     };
     detail::TrackPack tp = detail::PackTracks(images, tracks, fidx, keep, static_cast<size_t>(options_.min_num_view_per_track),
-                                              /*keep_empty=*/true);
+                                              /*keep_empty=*/true, &pt_draw_order);
     const int N = static_cast<int>(fidx.ids.size());
     const int64_t P = static_cast<int64_t>(tp.track_ids.size()), M = static_cast<int64_t>(tp.obs_cam.size());
     if ((P == 0 || M == 0) && with_points) return false;
@@ -855,6 +889,8 @@ class GlobalPositioner {
         pr.sensor_center = sensor_center.data();
       }
     }
+    pr.cam_draw_order = cam_draw_order.data();
+    pr.pt_draw_order = pt_draw_order.data();
     if (with_pairs) {
       pr.num_pairs = static_cast<int64_t>(pair_i.size());
       pr.pair_i = pair_i.data();
@@ -913,9 +949,10 @@ class BundleAdjuster {
     std::vector<int32_t> image_sensor;
     std::vector<double> sensor_cfr;
     detail::FrameIndex fidx;
+    std::vector<frame_t> frame_walk;
     for (auto& [fid, fr] : frames)
-      if (fr.HasPose()) fidx.Add(fid);  // dense indices in map order, the order ParameterizeVariables walks (ba.cc:253)
-    const int num_posed = static_cast<int>(fidx.ids.size());
+      if (fr.HasPose()) frame_walk.push_back(fid);  // the order ParameterizeVariables walks (ba.cc:253)
+    const std::vector<int32_t> walk_index = fidx.AddSorted(frame_walk);  // dense indices by ascending id
     auto keep = [](const glomap::Image& im, uint32_t) { return im.frame_ptr != nullptr; };  // ba.cc:124-127: no IsRegistered test
     detail::TrackPack tp = detail::PackTracks(images, tracks, fidx, keep, static_cast<size_t>(options_.min_num_view_per_track));
     const int N = static_cast<int>(fidx.ids.size());
@@ -929,8 +966,8 @@ class BundleAdjuster {
     {
       std::vector<uint8_t> in_problem(static_cast<size_t>(N), 0);
       for (int32_t n : tp.obs_cam) in_problem[n] = 1;
-      for (int n = 0; n < num_posed && fixed < 0; ++n)
-        if (in_problem[n]) fixed = n;
+      for (size_t i = 0; i < walk_index.size() && fixed < 0; ++i)
+        if (in_problem[walk_index[i]]) fixed = walk_index[i];
     }
     // intrinsics blocks = COLMAP cameras
     std::unordered_map<camera_t, int> intr_of;

@@ -222,3 +222,43 @@ def test_gp_chunked_camera_side_sweep_equals_camera_major(gsfm_ctx, case):
             assert np.array_equal(c1, c2) and np.array_equal(X1, X2)
     finally:
         gsfm_ctx.set_knob("chunked_sweeps", 0)
+
+
+def test_gp_draw_orders_keep_the_start_under_renumbering(gsfm_ctx):
+    """gsfm_gp_problem::cam_draw_order / pt_draw_order: a caller that numbers frames and tracks for locality (the C++ adapter:
+    ascending ids instead of hash-map order) hands over the order in which the reference's containers are walked, and the
+    random start is the one the reference draws — here: a problem with cameras and tracks renumbered at random plus the
+    draw orders of the original numbering starts from the SAME cost (1e-12: other summation order) and ends at the same
+    cameras; without the draw orders it is another start."""
+    import copy
+
+    p = synthetic.make_gp_problem(num_cams=60, num_pts=1500, seed=7)
+    rc, c0, X0, rep0 = estimators.gp_solve(p, ctx=gsfm_ctx)
+    assert rc == 0
+    rng = np.random.default_rng(1)
+    N, P = p.num_cams, p.num_pts
+    cam_new = rng.permutation(N).astype(np.int32)      # new index of old camera n
+    trk_old = rng.permutation(P)                       # new track i = old track trk_old[i]
+    trk_new = np.empty(P, np.int64)
+    trk_new[trk_old] = np.arange(P)                    # new index of old track p
+    lens = np.diff(p.pt_offset)
+    q = copy.copy(p)
+    q.pt_offset = np.concatenate([[0], np.cumsum(lens[trk_old])]).astype(np.int64)
+    idx = np.concatenate([np.arange(p.pt_offset[t], p.pt_offset[t + 1]) for t in trk_old])
+    q.obs_cam = cam_new[p.obs_cam[idx]].astype(np.int32)
+    q.obs_dir = np.ascontiguousarray(p.obs_dir[idx])
+    q.obs_calibrated = np.ascontiguousarray(p.obs_calibrated[idx])
+    q.cam_center = np.zeros_like(p.cam_center)
+    q.pt_xyz = np.zeros_like(p.pt_xyz)
+    q.cam_draw_order = cam_new.copy()                  # the i-th camera draw goes to old camera i = new index cam_new[i]
+    q.pt_draw_order = trk_new.astype(np.int32)         # the i-th track draw goes to old track i = new index trk_new[i]
+    rc, c1, X1, rep1 = estimators.gp_solve(q, ctx=gsfm_ctx)
+    assert rc == 0
+    assert abs(rep1["initial_cost"] - rep0["initial_cost"]) <= 1e-12 * rep0["initial_cost"]
+    assert _rel_diff(c1[cam_new], c0) < TOL_REL
+    q.cam_draw_order = q.pt_draw_order = None
+    rc, c2, X2, rep2 = estimators.gp_solve(q, ctx=gsfm_ctx)
+    assert rc == 0 and abs(rep2["initial_cost"] - rep0["initial_cost"]) > 1e-6 * rep0["initial_cost"]
+    q.cam_draw_order = np.zeros(N, np.int32)           # not a permutation
+    rc, *_ = estimators.gp_solve(q, ctx=gsfm_ctx)
+    assert rc != 0

@@ -13,6 +13,20 @@ from glomap_amd import _lib, estimators, synthetic  # noqa: E402
 vals = [int(a) for a in sys.argv[1:]] or [2, 0, 16, 32, 48]
 ctx = _lib.Context(0)
 p = synthetic.make_gp_problem(10_000, 1_000_000, seed=0)
+if os.environ.get("AB_SORT_TRACKS"):  # what a library-side track ordering would give: tracks by the smallest camera that sees them
+    key = os.environ["AB_SORT_TRACKS"]
+    lens = np.diff(p.pt_offset)
+    if key == "min":
+        k = np.minimum.reduceat(p.obs_cam, p.pt_offset[:-1])
+    else:  # circular mean of the cameras on the ring
+        ang = 2 * np.pi * p.obs_cam / p.num_cams
+        sx = np.add.reduceat(np.cos(ang), p.pt_offset[:-1]); sy = np.add.reduceat(np.sin(ang), p.pt_offset[:-1])
+        k = np.arctan2(sy, sx)
+    perm = np.argsort(k, kind="stable")
+    new_off = np.zeros(p.num_pts + 1, np.int64); np.cumsum(lens[perm], out=new_off[1:])
+    idx = np.repeat(p.pt_offset[:-1][perm] - new_off[:-1], lens[perm]) + np.arange(new_off[-1])
+    p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated = new_off, p.obs_cam[idx], np.ascontiguousarray(p.obs_dir[idx]), p.obs_calibrated[idx]
+    print("tracks sorted by", key)
 print("problem:", p.num_cams, "cameras", p.num_pts, "tracks", p.num_obs, "observations", flush=True)
 for v in vals:
     ctx.set_knob("chunked_sweeps", v)
