@@ -1616,6 +1616,7 @@ class GpSolver final : public LmProblem {
     const int mem = prob->mem;
     N_ = prob->num_cams;
     P_ = prob->num_pts;
+    P_total_ = P_;
     M_ = prob->num_obs;
     GSFM_REQUIRE(N_ > 0 && P_ >= 0 && M_ >= 0, "GP: bad sizes");
     // calibrated rigs: the observation graph is over IMAGES (NI_ cameras), the unknowns are the N_ frames
@@ -1646,7 +1647,6 @@ class GpSolver final : public LmProblem {
     with_points_ = ctype != 1;  // ONLY_CAMERAS: AddPointToCameraConstraints is skipped (gp.cc:69-71)
     if (ctype != 0) {
       if (rig_) throw StatusError(GSFM_ERR_UNSUPPORTED, "GP: camera-to-camera constraints support trivial frames only (gp.cc:169-176)");
-      if (ctx_->comm.world > 1) throw StatusError(GSFM_ERR_UNSUPPORTED, "GP: camera-to-camera constraints are solved on one rank");
       if (E_ <= 0) throw StatusError(GSFM_ERR_EMPTY_PROBLEM, "GP: no camera-to-camera constraints (gp.cc:41-45)");
       GSFM_REQUIRE(prob->pair_i && prob->pair_j && prob->pair_dir, "GP: pair tables missing");
     }
@@ -1747,9 +1747,10 @@ class GpSolver final : public LmProblem {
       }
       const int W = ctx_->comm.world;
       if (W > 1) {
-        std::vector<double> h((size_t)N_ + W, 0.0);
+        std::vector<double> h((size_t)N_ + W + 1, 0.0);
         for (int n = 0; n < N_; ++n) h[n] = constrained[n] ? 1.0 : 0.0;
         h[(size_t)N_ + ctx_->comm.rank] = (double)used_here;
+        h[(size_t)N_ + W] = (double)P_;  // tracks of the whole problem (POINTS_AND_CAMERAS_BALANCED weighs by it)
         DevBuf<double> tmp;
         tmp.ensure(h.size());
         GSFM_HIP_CHECK(hipMemcpyAsync(tmp.get(), h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, s));
@@ -1759,6 +1760,7 @@ class GpSolver final : public LmProblem {
         for (int n = 0; n < N_; ++n) constrained[n] = h[n] > 0.0;
         for (int r = 0; r < ctx_->comm.rank; ++r) used_before += (long)h[(size_t)N_ + r];
         for (int r = ctx_->comm.rank + 1; r < W; ++r) used_after += (long)h[(size_t)N_ + r];
+        P_total_ = (long)h[(size_t)N_ + W];
       }
     }
     // the draws visit cameras / tracks in index order, or in the caller's container order (gsfm_gp_problem::*_draw_order)
@@ -1922,7 +1924,11 @@ class GpSolver final : public LmProblem {
     g_.lm_hi = opt_.lm.max_lm_diagonal;
     // POINTS_AND_CAMERAS_BALANCED: the point-to-camera losses are scaled by reweight * #pairs / #tracks, where tracks.size()
     // counts every track, kept or not (gp.cc:223-233)
-    g_.wpt = (E_ > 0 && ctype == 2 && P_ > 0) ? opt_.constraint_reweight_scale * (double)E_ / (double)P_ : 1.0;
+    g_.wpt = (E_ > 0 && ctype == 2 && P_total_ > 0) ? opt_.constraint_reweight_scale * (double)E_ / (double)P_total_ : 1.0;
+    // Several ranks: the pairs live in camera space, which is replicated — every rank carries their state (weights, scales,
+    // candidate scales: the same arithmetic on the same replicated centres), rank 0 alone adds their terms to what is
+    // all-reduced (gradients, blocks, operator products, cost and model sums).
+    pair_owner_ = ctx_->comm.rank == 0;
     q_ = GpPairs{};
     if (E_ > 0) {
       std::vector<int> row((size_t)N_ + 1, 0), ent(2 * (size_t)E_);
@@ -1983,7 +1989,7 @@ class GpSolver final : public LmProblem {
     cg_.N = Np_;
     cg_.K = 0;
     cg_.nb_update = std::min(kCgUpdateBlocks, grid_for(Np_, kBlock));
-    cg_.nb_apply = sweepSlots_ + (E_ > 0 ? gridPairCam_ : 0);  // + the delta slots of the combine pass (k_gp_phaseB) and of the pair terms
+    cg_.nb_apply = sweepSlots_ + (E_ > 0 && pair_owner_ ? gridPairCam_ : 0);  // + the delta slots of the combine pass (k_gp_phaseB) and of the pair terms
     cg_.b = ws->rhs.get();
     cg_.x = ws->cg_x.get();
     cg_.r = ws->cg_r.get();
@@ -2051,7 +2057,7 @@ class GpSolver final : public LmProblem {
     }
     if (E_ > 0) {
       hipLaunchKernelGGL(k_gpp_lin, dim3(gridPair_), dim3(kBlock), 0, s, q_, c_, (const double*)ps_, ws->pr_w.get(), ws->pr_part.get());
-      hipLaunchKernelGGL(k_gpp_cam_lin, dim3(gridPairCam_), dim3(kBlock), 0, s, q_, N_, c_, (const double*)ps_,
+      if (pair_owner_) hipLaunchKernelGGL(k_gpp_cam_lin, dim3(gridPairCam_), dim3(kBlock), 0, s, q_, N_, c_, (const double*)ps_,
                          (const double*)ws->pr_w.get(), ws->hcc.get(), ws->gc.get());
     }
     if (ctx_->comm.world > 1) {
@@ -2063,7 +2069,7 @@ class GpSolver final : public LmProblem {
     if (gmx) hipLaunchKernelGGL(k_gp_absmax, dim3(gmx), dim3(kBlock), 0, s, (const double*)ws->gc.get(), nvec, ws->maxpart.ensure(64));
     hipLaunchKernelGGL(k_gp_finalize_lin, dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridTileP_, (const double*)ws->maxpart.ensure(64), gmx,
                        ws->scal.get());
-    if (E_ > 0) hipLaunchKernelGGL(k_gpp_fold_lin, dim3(1), dim3(kBlock), 0, s, (const double*)ws->pr_part.get(), gridPair_, ws->scal.get());
+    if (E_ > 0 && pair_owner_) hipLaunchKernelGGL(k_gpp_fold_lin, dim3(1), dim3(kBlock), 0, s, (const double*)ws->pr_part.get(), gridPair_, ws->scal.get());
     double h[2];
     read_scalars(ws->scal.get(), h, 2, /*sum_first=*/1, /*max_from=*/1);
     *grad_max_norm = h[1];
@@ -2128,7 +2134,7 @@ class GpSolver final : public LmProblem {
     if (E_ > 0) {
       hipLaunchKernelGGL(k_gpp_build, dim3(gridPair_), dim3(kBlock), 0, s, q_, radius, c_, (const double*)ps_,
                          (const double*)ws->pr_w.get(), (const double*)ws->pr_js.get(), ws->pr_qa.get(), ws->pr_qb.get());
-      hipLaunchKernelGGL(k_gpp_cam_build, dim3(gridPairCam_), dim3(kBlock), 0, s, q_, N_, c_, (const double*)ps_,
+      if (pair_owner_) hipLaunchKernelGGL(k_gpp_cam_build, dim3(gridPairCam_), dim3(kBlock), 0, s, q_, N_, c_, (const double*)ps_,
                          (const double*)ws->pr_w.get(), (const double*)ws->pr_qa.get(), (const double*)ws->pr_qb.get(),
                          ws->gred.get(), ws->scc.get());
     }
@@ -2166,7 +2172,7 @@ class GpSolver final : public LmProblem {
     if (E_ > 0) {
       hipLaunchKernelGGL(k_gpp_backsub, dim3(gridPair_), dim3(kBlock), 0, s, q_, c_, (const double*)ps_, (const double*)ws->pr_w.get(),
                          (const double*)ws->pr_qb.get(), (const double*)ws->cg_x.get(), psn_, ws->pr_part.get());
-      hipLaunchKernelGGL((k_gpp_fold_sum<3>), dim3(1), dim3(kBlock), 0, s, (const double*)ws->pr_part.get(), gridPair_, ws->scal.get(), 0, 1, 2);
+      if (pair_owner_) hipLaunchKernelGGL((k_gpp_fold_sum<3>), dim3(1), dim3(kBlock), 0, s, (const double*)ws->pr_part.get(), gridPair_, ws->scal.get(), 0, 1, 2);
     }
     const int gridU = std::min(64, grid_for(n3, kBlock));
     double* part2 = ws->part.get() + kMaxBlocks * 3;
@@ -2175,7 +2181,7 @@ class GpSolver final : public LmProblem {
     if (rig_) expand_centres(cn_, cin_, /*also_cz=*/false);
     if (E_ > 0) {
       hipLaunchKernelGGL(k_gpp_cost, dim3(gridPair_), dim3(kBlock), 0, s, q_, (const double*)cn_, (const double*)psn_, ws->pr_part.get());
-      hipLaunchKernelGGL((k_gpp_fold_sum<1>), dim3(1), dim3(kBlock), 0, s, (const double*)ws->pr_part.get(), gridPair_, ws->scal.get(), 6, 6, 6);
+      if (pair_owner_) hipLaunchKernelGGL((k_gpp_fold_sum<1>), dim3(1), dim3(kBlock), 0, s, (const double*)ws->pr_part.get(), gridPair_, ws->scal.get(), 6, 6, 6);
     }
     if (multi) {
       // track-local sums: model change, |dX|^2+|ds|^2, |X|^2+|s|^2 and the candidate cost
@@ -2365,7 +2371,7 @@ class GpSolver final : public LmProblem {
       if (rig_)
         hipLaunchKernelGGL(k_rig_reduce_w, dim3(gridN_ + S_), dim3(kBlock), 0, s, cg_, rg_, yscale, ws->wimg.get(), ws->dcam.get(),
                            gridCam_ + gridMulti_, gridN_);
-      if (E_ > 0)  // camera-to-camera terms on top of what the sweep wrote
+      if (E_ > 0 && pair_owner_)  // camera-to-camera terms on top of what the sweep wrote
         hipLaunchKernelGGL(k_gpp_apply, dim3(gridPairCam_), dim3(kBlock), 0, s, q_, cg_, N_, (const double*)c_,
                            (const double*)ws->pr_qa.get(), (const double*)ws->pr_qb.get(), sweepSlots_);
     };
@@ -2439,7 +2445,8 @@ class GpSolver final : public LmProblem {
   GpRig rg_{};
   int gridNI_ = 1;
   double *ci_ = nullptr, *cin_ = nullptr;
-  long P_ = 0, M_ = 0, m_used_ = 0;
+  long P_ = 0, M_ = 0, m_used_ = 0, P_total_ = 0;
+  bool pair_owner_ = true;
   int gridP_ = 1, gridN_ = 1, gridM_ = 1, gridCam_ = 1, gridMulti_ = 0, gridTile_ = 1, gridTileP_ = 1;
   bool lin_pending_ = false, aw_built_ = false, gmax_ready_ = false;  // riders of k_gp_build_cam (step())
   int lin_count_ = 0;

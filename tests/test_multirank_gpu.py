@@ -29,6 +29,21 @@ def _problems():
     return ra, gp, ba
 
 
+def _gp_with_pairs():
+    """Tracks + camera-to-camera constraints (POINTS_AND_CAMERAS_BALANCED: the point losses are weighed by #pairs / #tracks of
+    the WHOLE problem, gp.cc:223-233): the tracks are sharded, the pairs replicated."""
+    gp = synthetic.make_gp_problem(40, 2000, seed=2)
+    rng = np.random.default_rng(5)
+    i = np.repeat(np.arange(gp.num_cams), 3)
+    j = (i + np.tile(np.arange(1, 4), gp.num_cams)) % gp.num_cams
+    d = gp.gt_center[j] - gp.gt_center[i]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d += 1e-3 * rng.normal(size=d.shape)
+    gp.pair_i, gp.pair_j = i.astype(np.int32), j.astype(np.int32)
+    gp.pair_dir = d / np.linalg.norm(d, axis=1, keepdims=True)
+    return gp, estimators.GlobalPositionerOptions(constraint_type=2, constraint_reweight_scale=2.0)
+
+
 def _worker(rank, world, port, ra_init, q, transport="host"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       GSFM_PEER_TIMEOUT_S="30")
@@ -61,6 +76,10 @@ def _worker(rank, world, port, ra_init, q, transport="host"):
     s, (lo, hi) = sharding.shard_gp_problem(gp, rank, world)
     rc, cen, xyz, rep = estimators.gp_solve(s, ctx=ctx)
     out["gp"] = (rc, cen, rep)
+    gpp, gpp_opt = _gp_with_pairs()
+    s, _ = sharding.shard_gp_problem(gpp, rank, world)
+    rc, cen, xyz, rep = estimators.gp_solve(s, gpp_opt, ctx=ctx)
+    out["gp_pairs"] = (rc, cen, rep)
     # BA: tracks sharded, poses and intrinsics replicated
     s, (lo, hi) = sharding.shard_ba_problem(ba, rank, world)
     rc, q_, t_, X_, intr_, rep = estimators.ba_solve(s, ctx=ctx)
@@ -89,6 +108,9 @@ def test_ranks_reproduce_single_rank(gsfm_ctx, world, transport):
     rc, cen1, xyz1, rep_gp1 = estimators.gp_solve(gp, ctx=gsfm_ctx)
     assert rc == 0
     rc, q1, t1, X1, intr1, rep_ba1 = estimators.ba_solve(ba, ctx=gsfm_ctx)
+    assert rc == 0
+    gpp, gpp_opt = _gp_with_pairs()
+    rc, cenp1, _, rep_gpp1 = estimators.gp_solve(gpp, gpp_opt, ctx=gsfm_ctx)
     assert rc == 0
 
     mpc = mp.get_context("spawn")
@@ -123,6 +145,15 @@ def test_ranks_reproduce_single_rank(gsfm_ctx, world, transport):
         assert abs(rep["final_cost"] - rep_gp1["final_cost"]) <= 1e-8 * rep_gp1["final_cost"]
         assert np.abs(cen - cen1).max() <= 1e-6 * np.abs(cen1).max()
     assert all(np.array_equal(res[0]["gp"][1], res[r]["gp"][1]) for r in ranks)
+    # ... and with camera-to-camera constraints next to the tracks (pairs replicated, rank 0 adds their terms)
+    for r in ranks:
+        rc, cen, rep = res[r]["gp_pairs"]
+        assert rc == 0
+        assert abs(rep["initial_cost"] - rep_gpp1["initial_cost"]) <= 1e-12 * rep_gpp1["initial_cost"]
+        assert rep["iterations"] == rep_gpp1["iterations"] and rep["successful_steps"] == rep_gpp1["successful_steps"]
+        assert abs(rep["final_cost"] - rep_gpp1["final_cost"]) <= 1e-8 * rep_gpp1["final_cost"]
+        assert np.abs(cen - cenp1).max() <= 1e-6 * np.abs(cenp1).max()
+    assert all(np.array_equal(res[0]["gp_pairs"][1], res[r]["gp_pairs"][1]) for r in ranks)
 
     # --- BA: deterministic start => the sharded solve follows the single-rank solve
     for r in ranks:
