@@ -67,6 +67,9 @@ __global__ void __launch_bounds__(kBlock)
 // mode 0: reprojection error in normalised image coordinates; 1: in pixels; 2: angle test.
 // One lane per observation: coalesced ray / pixel / index reads, L2-resident camera gathers, the point of
 // the track read by its consecutive lanes.
+// WIDE: some camera uses a fisheye / FOV model (ids >= OPENCV_FISHEYE); the lean instance leaves their transcendental
+// branches out, as the BA kernels do (camera.hpp: with them inlined this sweep fell from 0.35 to 0.28 of the HBM rate).
+template <bool WIDE>
 __global__ void __launch_bounds__(kBlock)
     k_filter_obs(ViewDev v, const int* __restrict__ obs_pt, int mode, double thr, double thr_uncalib,
                  unsigned char* __restrict__ keep) {
@@ -91,7 +94,7 @@ __global__ void __launch_bounds__(kBlock)
         double px = 0.0, py = 0.0, Juv[4], Jp[2][8];
         // Camera::ImgFromCam(...).value_or(Zero): projection fails for points at / behind the camera
         if (pc.z > 2.220446049250313e-16)
-          distort_project<true>(v.intr_model[ik], v.intr_params + 8 * (long)ik, pc.x * iz, pc.y * iz, px, py, Juv, Jp);
+          distort_project<WIDE>(v.intr_model[ik], v.intr_params + 8 * (long)ik, pc.x * iz, pc.y * iz, px, py, Juv, Jp);
         const double ex = px - v.xy[2 * k], ey = py - v.xy[2 * k + 1];
         ok = sqrt(ex * ex + ey * ey) < thr;
       } else {
@@ -334,8 +337,18 @@ int filter_obs_impl(gsfm_ctx* ctx, const gsfm_scene_view* view, int mode, double
   GSFM_HIP_CHECK(hipMemsetAsync(ws->counter.get(), 0, sizeof(unsigned long long), s));
   if (d.M > 0) {
     hipLaunchKernelGGL(k_fill_obs_pt, dim3(grid_wide(d.P, kBlock, 1 << 16)), dim3(kBlock), 0, s, d.P, d.off, ws->obs_pt.ensure(d.M + 1));
+    bool wide = false;
+    if (mode == 1) {  // which projection instance: a handful of model ids, read back with the validation flag's sync behind us
+      std::vector<int> h_model;
+      to_host(ctx, h_model, view->intr_model, (size_t)view->num_intr, view->mem);
+      GSFM_HIP_CHECK(hipStreamSynchronize(s));
+      for (int m : h_model) wide = wide || m >= GSFM_CAMERA_OPENCV_FISHEYE;
+    }
     const bool timed = ctx->prof.begin(s, GSFM_KERNEL_FILTER_OBS);
-    hipLaunchKernelGGL(k_filter_obs, dim3(grid_wide(d.M, kBlock, 1 << 16)), dim3(kBlock), 0, s, d, ws->obs_pt.get(), mode, thr, thr2, keep);
+    if (wide)
+      hipLaunchKernelGGL((k_filter_obs<true>), dim3(grid_wide(d.M, kBlock, 1 << 16)), dim3(kBlock), 0, s, d, ws->obs_pt.get(), mode, thr, thr2, keep);
+    else
+      hipLaunchKernelGGL((k_filter_obs<false>), dim3(grid_wide(d.M, kBlock, 1 << 16)), dim3(kBlock), 0, s, d, ws->obs_pt.get(), mode, thr, thr2, keep);
     if (timed) ctx->prof.end(s);
     hipLaunchKernelGGL(k_count_changed, dim3(grid_for(d.P, kBlock)), dim3(kBlock), 0, s, d.P, d.off, keep, ws->counter.get());
   }

@@ -234,28 +234,53 @@ __global__ void __launch_bounds__(kBlock)
 // ---- build, point side (radius dependent): eliminate scales and points --------------------------
 // One lane per observation: (a_k, beta_k) per observation (coalesced writes); H_pp and g_p per track by a
 // segmented wave scan; the tail lane of a track inverts H_pp and writes the two point records.
+// LIN: the point half of the linearisation at a newly accepted point rides on the first build that follows (k_gp_lin_track:
+// robust weights, h_pp = sum w s^2, the max-norm of the point and scale gradients; the cost itself is the candidate cost
+// the back-substitution sweep of the accepted step already summed) — the same per-observation reads, one sweep less.
+template <bool LIN>
 __global__ void __launch_bounds__(kBlock)
     k_gp_build_track(GpDev g, double radius, const double* __restrict__ c, const double* __restrict__ X,
-                     const double* __restrict__ s, const double* __restrict__ wrob,
+                     const double* __restrict__ s, double* __restrict__ wrob /* LIN: written */,
                      const double* __restrict__ jss, const double* __restrict__ jsx,
-                     const double* __restrict__ hppd, double* __restrict__ qa, double* __restrict__ qb,
+                     double* __restrict__ hppd /* LIN: written */, double* __restrict__ qa, double* __restrict__ qb,
                      double* __restrict__ ptb, double* __restrict__ ptrec, double* __restrict__ pth,
-                     double2* __restrict__ tq /* [T][64] (a, beta) in the padded tile layout of k_gp_phaseA */) {
+                     double2* __restrict__ tq /* [T][64] (a, beta) in the padded tile layout of k_gp_phaseA */,
+                     double* __restrict__ part /* LIN: [grid][2] = {cost, max gradient entry} */) {
+  constexpr int W = LIN ? 16 : 12;
+  __shared__ double smem[8];
+  double cost = 0.0, gmax = 0.0;
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (kBlock / 64);
   for (int tile = wave; tile < g.g.T; tile += nwaves) {
     const long k0 = g.g.tile_k[tile], k1 = g.g.tile_k[tile + 1];
     const bool one_trip = k1 - k0 <= 64;
-    double acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // H (xx xy xz yy yz zz) | g_p | sum_k Q_k d_k (scale mode)
+    double acc[W];  // H (xx xy xz yy yz zz) | g_p | sum_k Q_k d_k (scale mode) | LIN: h_pp, raw point gradient
+#pragma unroll
+    for (int j = 0; j < W; ++j) acc[j] = 0.0;
     int key = -1 - lane;
     for (long k = k0 + lane; k < k1; k += 64) {
       const int p = g.g.obs_pt[k];
       key = p;
       if (!g.g.used[p]) continue;
       const V3 d = ld3(X + 3 * (long)p) - ld3(c + 3 * (long)g.g.cam[k]);
-      const double sk = s[k], w = wrob[k];
+      const double sk = s[k];
       const V3 r = ld3(g.dir + 3 * k) - sk * d;
+      double w;
+      if constexpr (LIN) {
+        double rho;
+        huber(g.huber_a, (g.cal == nullptr || g.cal[k]) ? g.wpt : 0.5 * g.wpt, dot(r, r), rho, w);
+        wrob[k] = w;
+        cost += 0.5 * rho;
+        const double ws = w * sk;
+        acc[12] += ws * sk;
+        acc[13] -= ws * r.x;
+        acc[14] -= ws * r.y;
+        acc[15] -= ws * r.z;
+        if (g.opt_s && k != g.fixed_obs) gmax = fmax(gmax, fabs(w * dot(d, r)));
+      } else {
+        w = wrob[k];
+      }
       double beta = 0.0;
       if (g.opt_s && k != g.fixed_obs) {
         const double hraw = w * dot(d, d);
@@ -281,7 +306,7 @@ __global__ void __launch_bounds__(kBlock)
       acc[10] += qd.y;
       acc[11] += qd.z;
     }
-    seg_scan<12>(acc, key, lane);
+    seg_scan<W>(acc, key, lane);
     if (seg_is_tail(key, lane) && key >= 0 && g.g.used[key]) {
       const long p = key;
       const V3 Xp = ld3(X + 3 * p);
@@ -289,8 +314,12 @@ __global__ void __launch_bounds__(kBlock)
       S3 Hi{0, 0, 0, 0, 0, 0};
       V3 e{0, 0, 0};
       double Dp_rec = 0.0;
+      if constexpr (LIN) {
+        hppd[p] = acc[12];
+        if (g.opt_x) gmax = fmax(gmax, fmax(fabs(acc[13]), fmax(fabs(acc[14]), fabs(acc[15]))));
+      }
       if (g.opt_x) {
-        const double Dp = lm_damping(hppd[p], jsx[p], radius, g.lm_lo, g.lm_hi);
+        const double Dp = lm_damping(LIN ? acc[12] : hppd[p], jsx[p], radius, g.lm_lo, g.lm_hi);
         Dp_rec = Dp;
         H.xx += Dp;
         H.yy += Dp;
@@ -311,6 +340,15 @@ __global__ void __launch_bounds__(kBlock)
       double* pr = ptrec + 8 * p;
       st3(pr, Xp);
       pr[3] = pr[4] = pr[5] = 0.0;
+    }
+  }
+  if constexpr (LIN) {
+    double v[1] = {cost};
+    block_sum<1>(v, smem);
+    const double m = block_max(gmax, smem + 4);
+    if (threadIdx.x == 0) {
+      part[blockIdx.x * 2] = v[0];
+      part[blockIdx.x * 2 + 1] = m;
     }
   }
 }
@@ -2032,22 +2070,17 @@ class GpSolver final : public LmProblem {
     hipStream_t s = ctx_->stream;
     double* hcc_k = rig_ ? ws->hcc_i.get() : ws->hcc.get();  // per graph camera (image); reduced to frames below
     double* gc_k = rig_ ? ws->gc_i.get() : ws->gc.get();
-    hipLaunchKernelGGL(k_gp_lin_track, dim3(gridTileP_), dim3(kBlock), 0, s, g_, ci_, X_, s_, ws->wrob.get(),
-                       ws->hppd.get(), ws->part.get());
     // The camera half (h_cc, g_c, the camera-major mirror of the scales) wants the gathers the build sweep makes anyway:
     // after the first linearisation (whose h_cc fixes the Jacobi scaling before any build) it rides on the first
     // k_gp_build_cam of the next step() and the gradient test waits for it (lm.hpp: gradient_pending).
     lin_pending_ = lin_count_ > 0 && !rig_ && E_ == 0;
     ++lin_count_;
     if (lin_pending_) {
-      hipLaunchKernelGGL(k_gp_finalize_lin, dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridTileP_, (const double*)ws->maxpart.ensure(64), 0,
-                         ws->scal.get());
-      double h[2];
-      read_scalars(ws->scal.get(), h, 2, /*sum_first=*/1, /*max_from=*/1);
-      gmax_track_ = h[1];
-      *grad_max_norm = h[1];
-      return h[0];
+      *grad_max_norm = gmax_full_;  // (of the previous point; the test waits: gradient_pending())
+      return last_cand_cost_;       // the cost at the accepted point IS the candidate cost the accepted step summed
     }
+    hipLaunchKernelGGL(k_gp_lin_track, dim3(gridTileP_), dim3(kBlock), 0, s, g_, ci_, X_, s_, ws->wrob.get(),
+                       ws->hppd.get(), ws->part.get());
     hipLaunchKernelGGL(k_gp_lin_cam, dim3(gridCam_), dim3(kBlock), 0, s, g_, ci_, X_, s_, hcc_k, gc_k, ws->c_s.get());
     if (gridMulti_)  // combine pass over the cameras whose lists were cut into slices (obsgraph.hpp)
       hipLaunchKernelGGL(k_gp_lin_cam, dim3(gridMulti_), dim3(kBlock), 0, s, g1_, ci_, X_, s_, hcc_k, gc_k, ws->c_s.get());
@@ -2098,9 +2131,19 @@ class GpSolver final : public LmProblem {
     const int n3 = 3 * Np_;
     double* gred_k = rig_ ? ws->gred_i.get() : ws->gred.get();
     double* scc_k = rig_ ? ws->scc_i.get() : ws->scc.get();
-    hipLaunchKernelGGL(k_gp_build_track, dim3(gridTile_), dim3(kBlock), 0, s, g_, radius, ci_, X_, s_, ws->wrob.get(),
-                       ws->jss.get(), ws->jsx.get(), ws->hppd.get(), ws->qa.get(), ws->qb.get(), ws->ptb.get(),
-                       ws->ptrec.get(), ws->pth.get(), ws->tq.get());
+    double* part_lin = ws->part.get() + kMaxBlocks * 5;  // {cost, max gradient entry} per block of the LIN build
+    if (lin_pending_) {
+      hipLaunchKernelGGL((k_gp_build_track<true>), dim3(gridTileP_), dim3(kBlock), 0, s, g_, radius, ci_, X_, s_, ws->wrob.get(),
+                         ws->jss.get(), ws->jsx.get(), ws->hppd.get(), ws->qa.get(), ws->qb.get(), ws->ptb.get(),
+                         ws->ptrec.get(), ws->pth.get(), ws->tq.get(), part_lin);
+      hipLaunchKernelGGL(k_gp_finalize_lin, dim3(1), dim3(kBlock), 0, s, (const double*)part_lin, gridTileP_,
+                         (const double*)ws->maxpart.ensure(64), 0, ws->scal.get() + 8);  // scal[8] = cost (unused), scal[9] = max-norm
+      if (multi) allreduce_max(ctx_, ws->scal.get() + 9, 1);
+    } else {
+      hipLaunchKernelGGL((k_gp_build_track<false>), dim3(gridTile_), dim3(kBlock), 0, s, g_, radius, ci_, X_, s_, ws->wrob.get(),
+                         ws->jss.get(), ws->jsx.get(), ws->hppd.get(), ws->qa.get(), ws->qb.get(), ws->ptb.get(),
+                         ws->ptrec.get(), ws->pth.get(), ws->tq.get(), (double*)nullptr);
+    }
     // riders of the camera-side build sweep (k_gp_build_cam): the camera half of a pending linearisation, and the closed-form
     // gauge products when this step's solve will deflate them (the conditions of pcg())
     const bool lin = lin_pending_;
@@ -2188,8 +2231,8 @@ class GpSolver final : public LmProblem {
       allreduce_sum(ctx_, ws->scal.get(), 3);
       allreduce_sum(ctx_, ws->scal.get() + 6, 1);
     }
-    double h[8];
-    GSFM_HIP_CHECK(hipMemcpyAsync(ctx_->h_pinned + 256, ws->scal.get(), 8 * sizeof(double), hipMemcpyDeviceToHost, s));
+    double h[10];
+    GSFM_HIP_CHECK(hipMemcpyAsync(ctx_->h_pinned + 256, ws->scal.get(), 10 * sizeof(double), hipMemcpyDeviceToHost, s));
     GSFM_HIP_CHECK(hipStreamSynchronize(s));
     GSFM_HIP_CHECK(hipGetLastError());
     comm_check(ctx_);
@@ -2198,10 +2241,11 @@ class GpSolver final : public LmProblem {
     *step_norm = std::sqrt(h[1] + h[3]);
     *x_norm = std::sqrt(h[2] + h[4]);
     *cand_cost = h[6];
+    last_cand_cost_ = h[6];
     if (lin) {
       lin_pending_ = false;
       gmax_ready_ = true;
-      gmax_full_ = std::max(gmax_track_, h[7]);
+      gmax_full_ = std::max(h[9], h[7]);
     }
     const bool finite = h[5] == 0.0 && std::isfinite(h[0]) && std::isfinite(h[1]) && std::isfinite(h[6]);
     return finite;
@@ -2450,7 +2494,7 @@ class GpSolver final : public LmProblem {
   int gridP_ = 1, gridN_ = 1, gridM_ = 1, gridCam_ = 1, gridMulti_ = 0, gridTile_ = 1, gridTileP_ = 1;
   bool lin_pending_ = false, aw_built_ = false, gmax_ready_ = false;  // riders of k_gp_build_cam (step())
   int lin_count_ = 0;
-  double gmax_track_ = 0.0, gmax_full_ = 0.0;
+  double gmax_full_ = 0.0, last_cand_cost_ = 0.0;
   ObsX x_;            // chunked order of the camera-side PCG sweep (xon_)
   bool xon_ = false;
   int gridX_ = 0, gridWsum_ = 0, sweepSlots_ = 0;
