@@ -385,6 +385,35 @@ def bench_pipeline(args, ctx, rank, world, barrier, dist):
         for k, v in (("ra", t1 - t0), ("gp", t2 - t1), ("ba", t3 - t2), ("total", t3 - t0)):
             stage_ms[k].append(v * 1e3)
 
+    if world > 1 and getattr(ctx, "_transport", "").startswith("peer"):
+        # The peer-mailbox transport has only ever run with all ranks on ONE device (the harness has one GPU); the first time
+        # it crosses xGMI is here.  One untimed step is its acceptance test: it must complete on every rank and leave the
+        # replicated state bit-identical on all of them (that is what the transport guarantees by construction); otherwise
+        # every rank detaches it and the run goes through RCCL.
+        import torch
+
+        ok, sums = 1, torch.zeros(2, dtype=torch.float64)
+        try:
+            step()
+            sig = np.concatenate([res["cen"].numpy().ravel(), res["q"].numpy().ravel(), res["t"].numpy().ravel()])
+            ok = int(np.isfinite(sig).all())
+            sums = torch.tensor([float(sig.sum()), float(np.abs(sig).sum())], dtype=torch.float64)
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] rank {rank}: sharded step failed on the peer transport ({e}); RCCL instead", file=sys.stderr)
+            ok = 0
+        lo, hi = sums.clone(), sums.clone()  # (every rank takes part in every rendezvous collective, failed step or not)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        ok = int(ok and bool((lo == hi).all()))
+        t = torch.tensor([ok])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        for v in stage_ms.values():
+            v.clear()
+        if int(t.item()) != 1:
+            ctx.comm_destroy()
+            ctx._comm_ready = False
+            os.environ["GSFM_BENCH_TRANSPORT"] = "rccl"
+            comm_init(ctx, dist, rank, world)
     dt = timed_steps(step, args.steps, args.warmup, barrier, dist)
     timed = {k: v[args.warmup:] for k, v in stage_ms.items()}  # the warm-up steps are not part of the statistics
     med = {k: float(np.median(v)) for k, v in timed.items()}
