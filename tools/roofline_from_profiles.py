@@ -42,15 +42,20 @@ def main(tag):
         for row in csv.reader(f):
             for k in formulas:
                 if row and row[0].startswith(k) and k not in traffic:
-                    traffic[k] = float(row[-1])
-    print("| kernel | algorithmic bytes / launch | formula | avg us, working launches (rocprofv3) | working / all launches | avg us, all | VGPRs | GB/s | frac of 8 TB/s | PMC traffic / working launch | traffic / algorithmic |")
+                    hi = float(row[6])                       # 2 x raw FETCH_SIZE + writes
+                    lo = 0.5 * float(row[4]) + float(row[5])  # raw FETCH_SIZE + writes (tools/pmc_traffic.py: gathers)
+                    traffic[k] = (hi, lo)
+    print("| kernel | algorithmic bytes / launch | formula | avg us, working launches (rocprofv3) | working / all launches | avg us, all | VGPRs | GB/s | frac of 8 TB/s | PMC traffic / working launch: raw ... 2 x raw FETCH_SIZE (+ writes) | traffic / algorithmic |")
     print("|---|---|---|---|---|---|---|---|---|---|---|")
     for k, (form, nbytes) in formulas.items():
         us, wcalls, calls, us_all, vgpr = dur[k]
         gbps = nbytes / us / 1e3
         tr = traffic.get(k)
         print(f"| `{k}` | {nbytes / 1e6:.1f} MB | `{form}` | {us:.1f} | {wcalls} / {calls} | {us_all:.1f} | {vgpr} | {gbps:.0f} | {gbps / PEAK:.3f} | "
-              f"{'' if tr is None else f'{tr / 1e6:.0f} MB'} | {'' if tr is None else f'{tr / nbytes:.2f}'} |")
+              f"{'' if tr is None else f'{tr[1] / 1e6:.0f} ... {tr[0] / 1e6:.0f} MB'} | {'' if tr is None else f'{tr[1] / nbytes:.2f} ... {tr[0] / nbytes:.2f}'} |")
+    print("\nTraffic: the upper value doubles the raw FETCH_SIZE (right for coalesced 16 B/lane streams: `k_ba_phaseA`), the lower "
+          "one takes it as it is (right for record gathers, one 64-byte request each: `k_ba_phaseB`, the old `k_gp_phaseB`); the sweeps "
+          "that mix both lie in between (tools/pmc_traffic.py, tools/exp_gather_calib.hip).")
     r = line["roofline"]
     print(f"\nbench.py's own line (HIP events over the working launches, other box): `{r['kernel'].split(' ')[0]}` {r['avg_kernel_us']:.1f} us -> "
           f"frac {r['frac']:.3f}; step {line['ms_per_step']:.1f} ms, value {line['value'] / 1e6:.2f} M obs/s.")
