@@ -251,8 +251,9 @@ def profiled_step(ctx, kernel_id, step_fn, also=(), read=True):
 
 def pmc_traffic(kernel):
     """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (collected by
-    tools/pmc_traffic.py; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  None when no
-    PMC pass exists for this kernel."""
+    tools/pmc_traffic.py; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md: right for the coalesced streams, an
+    upper bound where record gathers are mixed in — `bytes_per_launch_raw` in the same file is the lower bound, see that
+    tool's header).  None when no PMC pass exists for this kernel."""
     try:
         d = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
         for name, rec in d.items():  # template instances carry their arguments: "k_ba_phaseA<2>"
