@@ -965,8 +965,13 @@ __global__ void __launch_bounds__(kBlock)
     ix[u] = make_int2(-1, -1);
     q[u] = make_double2(0.0, 0.0);
     if (have) {
-      ix[u] = x.ix[slot[u]];
-      q[u] = xq[slot[u]];
+      // the two slot streams are read once: keep them from pushing the chunk's point records out of the L2
+      typedef int gp_i2v __attribute__((ext_vector_type(2)));
+      typedef double gp_d2v __attribute__((ext_vector_type(2)));
+      const gp_i2v iv = __builtin_nontemporal_load(reinterpret_cast<const gp_i2v*>(x.ix + slot[u]));
+      const gp_d2v qv = __builtin_nontemporal_load(reinterpret_cast<const gp_d2v*>(xq + slot[u]));
+      ix[u] = make_int2(iv.x, iv.y);
+      q[u] = make_double2(qv.x, qv.y);
     }
   }
   const int done = v.st->done;
