@@ -511,7 +511,7 @@ class Context:
         return n.value, ms.value
 
     KNOBS = ("ba_aw_by_application", "ba_aw_check", "ba_separate_blocks", "ba_no_nontemporal", "ra_no_blockdense",
-             "ra_no_substructure", "ra_dense_refactor", "gp_coarse_cluster", "seg_len", "chunked_sweeps")
+             "ra_no_substructure", "ra_dense_refactor", "gp_coarse_cluster", "seg_len", "chunked_sweeps", "experiment")
 
     def set_knob(self, name: str, value: int = 1):
         """Diagnostic / A-B knobs (gsfm_ctx_set_knob); 0 restores the default.  The library reads no environment variable

@@ -532,6 +532,7 @@ __global__ void __launch_bounds__(kBlock) k_gp_tile_idx(GpDev g, int2* __restric
   }
 }
 
+template <bool NT>
 __global__ void __launch_bounds__(kBlock)
     k_gp_phaseA(GpDev g, CgVec v, int it, double tol2, const double* __restrict__ cz,
                 const double* __restrict__ qa, const double* __restrict__ qb,
@@ -544,8 +545,17 @@ __global__ void __launch_bounds__(kBlock)
   int2 ix = make_int2(-1, 0);
   double2 q2 = make_double2(0.0, 0.0);
   if (have) {
-    ix = tidx[(long)tile * 64 + lane];
-    q2 = tq[(long)tile * 64 + lane];
+    if constexpr (NT) {
+      typedef int gp_i2v __attribute__((ext_vector_type(2)));
+      typedef double gp_d2v __attribute__((ext_vector_type(2)));
+      const gp_i2v iv = __builtin_nontemporal_load(reinterpret_cast<const gp_i2v*>(tidx + (long)tile * 64 + lane));
+      const gp_d2v qv = __builtin_nontemporal_load(reinterpret_cast<const gp_d2v*>(tq + (long)tile * 64 + lane));
+      ix = make_int2(iv.x, iv.y);
+      q2 = make_double2(qv.x, qv.y);
+    } else {
+      ix = tidx[(long)tile * 64 + lane];
+      q2 = tq[(long)tile * 64 + lane];
+    }
   }
   if (cg_converged(v, it, tol2, smem)) return;
   if (!have) return;
@@ -948,7 +958,7 @@ __global__ void __launch_bounds__(kBlock)
     k_gp_phaseB_x(ObsX x, CgVec v, const double* __restrict__ cz, const double2* __restrict__ xq,
                   const double* __restrict__ ptrec, double* __restrict__ wpart) {
   // A wave lives for a chain of dependent round trips — [slots, coefficients, done flag] -> [records, piece index] -> store —
-  // and every wave carries TPW tiles through it at once (TPW = 2: 90 -> 83 us at configs[3]).
+  // and every wave carries TPW tiles through it at once (TPW = 2: 90 -> 83 us at configs[3]; TPW = 4: 80.2 instead of 78.8 us).
   // (Measured and dropped, here and in k_gp_phaseA: fetching what lanes share — the (c_n | z_n) record of a piece's camera,
   // X_p of a track — once per camera / track and handing it out through LDS.  No change: lanes that name the same address
   // do not cost the gather path extra.  Two tiles per wave in k_gp_phaseA: 86 registers, 5 waves per SIMD, no faster.)
@@ -1942,7 +1952,7 @@ class GpSolver final : public LmProblem {
         ws->xq.ensure((size_t)x_.tiles * 64 + 64);
         ws->wpart.ensure(3 * (size_t)std::max(1, x_.npieces) + 8);
         gridX_ = x_grid(x_, kXTilesPerWave);
-        gridWsum_ = std::min(kMaxApplySlots, grid_for((size_t)Np_, kBlock / 64));
+        gridWsum_ = std::min(kMaxApplySlots, grid_for((size_t)Np_, kBlock / 64));  // (256 fat blocks measured: 214 instead of 210 ms per solve)
       }
       sweepSlots_ = xon_ ? gridWsum_ : gridCam_ + gridMulti_;  // delta partial slots the sweep of `apply` writes
     }
@@ -2397,8 +2407,14 @@ class GpSolver final : public LmProblem {
         vk.w = ws->wimg.get();
       }
       bool timed = ctx_->prof.begin(s, GSFM_KERNEL_GP_SCHUR, it);
-      hipLaunchKernelGGL(k_gp_phaseA, dim3(gridTileA_), dim3(kBlock), 0, s, g_, vk, it, tol * tol, ws->cz.get(), ws->qa.get(),
-                         ws->qb.get(), ws->pth.get(), ws->ptrec.get(), (const int2*)ws->tidx.get(), (const double2*)ws->tq.get());
+      // the two tile streams are read once per sweep: non-temporal, so that they do not push the (c | z) table and the point
+      // records out of the L2 (same box, tools/ab_gp_sweeps.py: 90.0 -> 82.3 us, and the camera-side sweep behind it 78.8 -> 76.6)
+      if (!(ctx_->knob[GSFM_KNOB_EXPERIMENT] & 2))
+        hipLaunchKernelGGL((k_gp_phaseA<true>), dim3(gridTileA_), dim3(kBlock), 0, s, g_, vk, it, tol * tol, ws->cz.get(), ws->qa.get(),
+                           ws->qb.get(), ws->pth.get(), ws->ptrec.get(), (const int2*)ws->tidx.get(), (const double2*)ws->tq.get());
+      else
+        hipLaunchKernelGGL((k_gp_phaseA<false>), dim3(gridTileA_), dim3(kBlock), 0, s, g_, vk, it, tol * tol, ws->cz.get(), ws->qa.get(),
+                           ws->qb.get(), ws->pth.get(), ws->ptrec.get(), (const int2*)ws->tidx.get(), (const double2*)ws->tq.get());
       if (timed) ctx_->prof.end(s);
       timed = ctx_->prof.begin(s, GSFM_KERNEL_GP_SCHUR_B, it);
       // rigs: the damping D z is a frame-space term, added by k_rig_reduce_w (the sweep runs with a zero diagonal)

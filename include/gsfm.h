@@ -150,7 +150,9 @@ enum gsfm_knob {
   GSFM_KNOB_CHUNKED_SWEEPS = 9,       /* camera-side sweeps of the PCG in the chunked order: 0 = when the point records exceed the
                                          L2 (default), 1 = always, 2 = never (plain camera-major order),
                                          >= 8 = always, with that many point chunks (A/B runs) */
-  GSFM_KNOB_COUNT = 10
+  GSFM_KNOB_EXPERIMENT = 10,          /* bit mask of kernel variants kept for A/B measurements (tools/ab_gp_sweeps.py); 0 = shipped.
+                                         2: k_gp_phaseA reads its tile streams with plain instead of non-temporal loads */
+  GSFM_KNOB_COUNT = 11
 };
 int gsfm_ctx_set_knob(gsfm_ctx* ctx, int knob, int value);
 /* Text of the last failure on this ctx (what the HIP / RCCL call or the argument check said); "" when there was none.  The

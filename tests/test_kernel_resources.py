@@ -16,7 +16,7 @@ ROOT = pathlib.Path(__file__).resolve().parent.parent
 
 # kernel (demangled prefix, as tools/kernel_resources.py prints it) -> (max VGPR + AGPR, scratch must be zero)
 BUDGET = {
-    "k_gp_phaseA": 64,
+    "k_gp_phaseA<true>": 64,           # (non-temporal tile streams; <false> is the A/B twin)
     "k_gp_phaseB": 96,
     "k_gp_phaseB_x<2>": 72,             # two tiles per wave: 7 waves per SIMD
     "k_gp_wsum": 48,

@@ -28,7 +28,33 @@ if os.environ.get("AB_SORT_TRACKS"):  # what a library-side track ordering would
     p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated = new_off, p.obs_cam[idx], np.ascontiguousarray(p.obs_dir[idx]), p.obs_calibrated[idx]
     print("tracks sorted by", key)
 print("problem:", p.num_cams, "cameras", p.num_pts, "tracks", p.num_obs, "observations", flush=True)
-for v in vals:
+exps = [int(a) for a in os.environ.get("AB_EXPERIMENT", "0").split(",")]
+if os.environ.get("AB_BA"):  # the same A/B on bundle adjustment at configs[3] size: sweeps k_ba_phaseA (id 2) / k_ba_phaseB (id 4)
+    b = synthetic.make_ba_problem(10_000, 1_000_000, seed=0)
+    for e in exps:
+        ctx.set_knob("experiment", e)
+        best = None
+        for rep_i in range(3):
+            ctx.profile_enable(True)
+            ctx.profile_read(2)
+            ctx.profile_read(4)
+            t0 = time.perf_counter()
+            rc, q, t, X, intr, rep = estimators.ba_solve(b, ctx=ctx)
+            ctx.synchronize()
+            dt = time.perf_counter() - t0
+            nA, msA = ctx.profile_read(2)
+            nB, msB = ctx.profile_read(4)
+            ctx.profile_enable(False)
+            if best is None or dt < best[0]:
+                best = (dt, rep, nA, msA, nB, msB)
+        dt, rep, nA, msA, nB, msB = best
+        print("BA experiment=%d solve %.1f ms  LM %d  PCG %d  cost %.3f | phaseA %.1f us (%d)  phaseB %.1f us (%d)" % (
+            e, dt * 1e3, rep["iterations"], rep["linear_iterations"], rep["final_cost"], 1e3 * msA / max(1, nA), nA,
+            1e3 * msB / max(1, nB), nB), flush=True)
+    sys.exit(0)
+for v in [(a, e) for a in vals for e in exps]:
+    v, e = v
+    ctx.set_knob("experiment", e)
     ctx.set_knob("chunked_sweeps", v)
     best = None
     for rep_i in range(3):
@@ -45,6 +71,6 @@ for v in vals:
         if best is None or dt < best[0]:
             best = (dt, rep, nA, msA, nB, msB)
     dt, rep, nA, msA, nB, msB = best
-    print("chunked_sweeps=%-3d solve %.1f ms  LM %d  PCG %d  cost %.6f | phaseA %.1f us (%d)  phaseB %.1f us (%d)" % (
-        v, dt * 1e3, rep["iterations"], rep["linear_iterations"], rep["final_cost"], 1e3 * msA / max(1, nA), nA,
+    print("experiment=%d chunked_sweeps=%-3d solve %.1f ms  LM %d  PCG %d  cost %.6f | phaseA %.1f us (%d)  phaseB %.1f us (%d)" % (
+        e, v, dt * 1e3, rep["iterations"], rep["linear_iterations"], rep["final_cost"], 1e3 * msA / max(1, nA), nA,
         1e3 * msB / max(1, nB), nB), flush=True)
