@@ -108,3 +108,23 @@ def test_sharded_reduced_system_equals_whole_gloo_world2():
     g2 = buf[1 + n * n :]
     assert np.abs(S2 - S).max() <= 1e-9 * np.abs(S).max()
     assert np.abs(g2 - g).max() <= 1e-9 * np.abs(g).max()
+
+
+def test_gp_shards_carry_every_pair_and_their_tracks_only():
+    """Camera-to-camera constraints live in camera space, which is replicated: shard_gp_problem hands EVERY rank the whole
+    pair list (rank 0 adds their terms inside the library) next to its own contiguous range of tracks; together the shards
+    hold every observation exactly once."""
+    p = synthetic.make_gp_problem(num_cams=30, num_pts=500, seed=3)
+    rng = np.random.default_rng(0)
+    p.pair_i = rng.integers(0, 30, 80).astype(np.int32)
+    p.pair_j = ((p.pair_i + rng.integers(1, 5, 80)) % 30).astype(np.int32)
+    p.pair_dir = rng.normal(size=(80, 3))
+    for world in (2, 3):
+        shards = [sharding.shard_gp_problem(p, r, world) for r in range(world)]
+        assert sum(s.num_obs for s, _ in shards) == p.num_obs
+        assert np.array_equal(np.concatenate([s.obs_cam for s, _ in shards]), p.obs_cam)
+        assert np.array_equal(np.concatenate([s.obs_dir for s, _ in shards]), p.obs_dir)
+        for s, (lo, hi) in shards:
+            assert s.num_pts == hi - lo and s.pt_offset[0] == 0 and s.pt_offset[-1] == s.num_obs
+            assert np.array_equal(s.pair_i, p.pair_i) and np.array_equal(s.pair_j, p.pair_j) and np.array_equal(s.pair_dir, p.pair_dir)
+            assert s.num_cams == p.num_cams
