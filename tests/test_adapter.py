@@ -34,3 +34,16 @@ def test_adapter_runs_end_to_end(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     print(out.stdout, out.stderr)
     assert out.returncode == 0 and "ADAPTER OK" in out.stdout
+
+
+def test_adapter_numbering_on_the_host(tmp_path):
+    """Ascending-id numbering of frames / tracks and the walk orders handed to the library (tests/adapter/pack_check.cc):
+    host-only, no libgsfm call."""
+    exe = tmp_path / "pack_check"
+    cmd = [shutil.which("g++") or "g++", "-std=c++17", "-O1", "-Wall", "-Werror", f"-I{ROOT / 'tests' / 'adapter' / 'mock'}",
+           f"-I{ROOT / 'include'}", str(ROOT / "tests" / "adapter" / "pack_check.cc"), "-o", str(exe), f"-L{LIBDIR}", "-lgsfm",
+           f"-Wl,-rpath,{LIBDIR}"]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0 and "PACK OK" in out.stdout
