@@ -970,6 +970,10 @@ inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& 
   const int gvec = std::min(256, grid_for((size_t)std::max((long)v.n, (long)v.N * 16), kBlock));
   if (deflate) {
     init();  // (resets the status block the apply kernels look at)
+    // k_cg_init's status tail has already tested |b|: a zero or non-finite right-hand side raises `done` here, and the
+    // sweeps of the probes below look at st->done directly — they would return early and leave A W stale for the Gram
+    // kernels.  The probes run with the flag cleared; the second init() (on b2) raises it again where it belongs.
+    if (defl->aw_ready < defl->k) hipLaunchKernelGGL(k_cg_reset_status, dim3(1), dim3(1), 0, s, v);
     v.probe = 1;
     for (int j = defl->aw_ready; j < defl->k; ++j) {  // A W_j: the operator reads z (and its mirrors), writes w
       if (joint)

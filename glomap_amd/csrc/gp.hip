@@ -2088,7 +2088,7 @@ class GpSolver final : public LmProblem {
     // The camera half (h_cc, g_c, the camera-major mirror of the scales) wants the gathers the build sweep makes anyway:
     // after the first linearisation (whose h_cc fixes the Jacobi scaling before any build) it rides on the first
     // k_gp_build_cam of the next step() and the gradient test waits for it (lm.hpp: gradient_pending).
-    lin_pending_ = lin_count_ > 0 && !rig_ && E_ == 0;
+    lin_pending_ = lin_count_ > 0 && !rig_ && E_ == 0 && !force_full_lin_;
     ++lin_count_;
     if (lin_pending_) {
       *grad_max_norm = gmax_full_;  // (of the previous point; the test waits: gradient_pending())
@@ -2266,6 +2266,13 @@ class GpSolver final : public LmProblem {
     return finite;
   }
   bool gradient_pending() const override { return lin_pending_; }
+  bool finish_pending_gradient(double* grad_max_norm) override {
+    if (!lin_pending_) return false;
+    force_full_lin_ = true;  // the plain k_gp_lin_track + k_gp_lin_cam path at the accepted point, no step
+    linearize(grad_max_norm);
+    force_full_lin_ = false;
+    return true;
+  }
   bool take_pending_gradient(double* grad_max_norm) override {
     if (!gmax_ready_) return false;
     gmax_ready_ = false;
@@ -2513,6 +2520,7 @@ class GpSolver final : public LmProblem {
   long P_ = 0, M_ = 0, m_used_ = 0, P_total_ = 0;
   bool pair_owner_ = true;
   int gridP_ = 1, gridN_ = 1, gridM_ = 1, gridCam_ = 1, gridMulti_ = 0, gridTile_ = 1, gridTileP_ = 1;
+  bool force_full_lin_ = false;  // finish_pending_gradient(): linearize() must not defer its camera half
   bool lin_pending_ = false, aw_built_ = false, gmax_ready_ = false;  // riders of k_gp_build_cam (step())
   int lin_count_ = 0;
   double gmax_full_ = 0.0, last_cand_cost_ = 0.0;

@@ -38,6 +38,10 @@ struct LmProblem {
   // max-norm of that point when it became known in this call.
   virtual bool gradient_pending() const { return false; }
   virtual bool take_pending_gradient(double* grad_max_norm) { (void)grad_max_norm; return false; }
+  // The loop is about to end (iteration cap, minimum radius) while gradient_pending(): complete the linearisation of the
+  // accepted point now, without a step, so that its gradient test is not lost (Ceres tests it right after the acceptance
+  // and would report CONVERGENCE).  Returns true when *grad_max_norm was produced.
+  virtual bool finish_pending_gradient(double* grad_max_norm) { (void)grad_max_norm; return false; }
 };
 
 inline void lm_options_default(gsfm_lm_options* o, int max_iterations) {
@@ -77,6 +81,8 @@ inline int lm_minimize(LmProblem& prob, const gsfm_lm_options& o, gsfm_report* r
     while (true) {
       if (iterations >= o.max_num_iterations) {
         termination = GSFM_TERM_NO_CONVERGENCE;
+        if (prob.gradient_pending() && prob.finish_pending_gradient(&gmax) && !(gmax > o.gradient_tolerance))
+          termination = GSFM_TERM_CONVERGENCE;  // the point accepted last satisfies the gradient tolerance
         break;
       }
       if (radius < o.min_trust_region_radius) {
@@ -87,14 +93,14 @@ inline int lm_minimize(LmProblem& prob, const gsfm_lm_options& o, gsfm_report* r
       double model_change = 0.0, cand_cost = 0.0, step_norm = 0.0, x_norm = 0.0;
       long lin = 0;
       bool valid = prob.step(radius, &model_change, &cand_cost, &step_norm, &x_norm, &lin);
-      lin_total += lin;
       if (prob.take_pending_gradient(&gmax) && !(gmax > o.gradient_tolerance)) {
         // the gradient test of the point accepted in the previous iteration (trust_region_minimizer.cc tests it right after
-        // the acceptance): the step just computed is not taken and does not count
+        // the acceptance): the step just computed is not taken and does not count, nor do its linear iterations
         --iterations;
         termination = GSFM_TERM_CONVERGENCE;
         break;
       }
+      lin_total += lin;
       if (verbose)
         fprintf(stderr, "[gsfm lm] it %d radius %.3e pcg %ld model %.6e cand %.9e (cost %.9e) step %.3e\n", iterations,
                 radius, lin, model_change, cand_cost, cost, step_norm);

@@ -123,9 +123,9 @@ __device__ __forceinline__ int cam_seg_k1(const ObsGraph& g, int sg) { return g.
 
 // Returns true when lane 0's `acc` holds the camera's complete sum (call after wave_allsum).
 // Parked sums are W doubles per slot (the kernel's own accumulator width: pass 0 and pass 1 of a kernel agree on it).  In
-// pass 1 lane c adds column c of the camera's slots in slice order (coalesced rows) and leaves the total in the first slot;
-// lane 0 then reads that one row back — the same sums in the same order as a serial loop, without one lane walking
-// cnt x W values.  Two things here are about the register allocator, not the arithmetic (tests/test_kernel_resources.py):
+// pass 1 lane c adds column c of the camera's slots in slice order (coalesced rows); the totals are handed to `acc` with
+// readlane — the same sums in the same order as a serial loop, without one lane walking cnt x W values, and without
+// touching the slots.  Two things here are about the register allocator, not the arithmetic (tests/test_kernel_resources.py):
 // broadcasting the totals into every lane's `acc` cost k_ba_build_cam its second wave per SIMD (251 -> 404 registers), and
 // plain stores in both passes get merged by the compiler into one store through a select of a global and a private
 // pointer, which pins `acc` in scratch — hence the atomic (relaxed, same instruction) stores when parking.
@@ -142,16 +142,26 @@ __device__ __forceinline__ bool cam_seg_total(const ObsGraph& g, int sg, double 
     }
     return false;
   }
-  double* src = g.segpart + (size_t)g.seg_multi[sg] * W;  // sg = the camera's first segment in pass 1
-  for (int c = lane; c < W; c += 64) {
-    double col = 0.0;
-    for (int q = 0; q < cnt; ++q) col += src[(size_t)q * W + c];
-    src[c] = col;  // the first slot becomes the total
-  }
-  __threadfence();  // the wave's own stores are in L2 and its L1 lines dropped before lane 0 reads the row back
-  if (lane == 0) {
+  // pass 1 (sg = the camera's first segment) only READS the parked slots: it can be repeated, and nothing depends on pass 0
+  // and pass 1 sharing more than the slot width W.  Lane c sums column c (and c + 64) over the slices in slice order — the
+  // same sums in the same order as a serial loop — and the totals reach `acc` through readlane (wave-uniform values: no
+  // memory round trip, no fence; until round 5 the totals overwrote the first slot and lane 0 read the row back).
+  const double* src = g.segpart + (size_t)g.seg_multi[sg] * W;
+  constexpr int TR = (W + 63) / 64;
+  double col[TR];
 #pragma unroll
-    for (int j = 0; j < W; ++j) acc[j] = src[j];
+  for (int t = 0; t < TR; ++t) {
+    const int c = lane + 64 * t;
+    col[t] = 0.0;
+    if (c < W)
+      for (int q = 0; q < cnt; ++q) col[t] += src[(size_t)q * W + c];
+  }
+#pragma unroll
+  for (int j = 0; j < W; ++j) {
+    const double v = col[j / 64];
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), j % 64);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), j % 64);
+    if (lane == 0) acc[j] = __hiloint2double(hi, lo);  // (every lane taking the totals costs k_ba_build_cam 60 registers)
   }
   return true;
 }

@@ -427,6 +427,9 @@ def gp_solve(p: GpProblem, options: Optional[GlobalPositionerOptions] = None, ct
         v = getattr(p, name, None)
         if v is not None:
             a = np.ascontiguousarray(np.asarray(v.cpu() if hasattr(v, "cpu") else v), dtype=np.int32)
+            want = int(c.num_cams) if name == "cam_draw_order" else int(c.num_pts)
+            if a.shape != (want,):  # the library reads exactly that many entries from a raw pointer
+                raise ValueError(f"{name} must have shape ({want},), got {a.shape}")
             orders.append(a)
             setattr(c, name, a.ctypes.data)
     rep = _lib.Report()

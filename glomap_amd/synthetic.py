@@ -6,6 +6,8 @@ un-vendored; this module is the stand-in generator.  Pure numpy, deterministic f
 """
 from __future__ import annotations
 
+from dataclasses import dataclass
+
 import numpy as np
 
 from . import so3
@@ -426,6 +428,103 @@ def make_ba_problem(
 
 
 # --------------------------------------------------------------------------------------------
+# One scene for the whole hot path: RA -> GP -> BA chained as GlobalMapper::Solve chains them
+# (global_mapper.cc:92-223: rotations from RA orient the bearings GP reads, GP's centres / points start BA)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class ChainedScene:
+    """View graph + pixel observations of ONE synthetic scene; the three stage problems are derived from it by
+    chain_gp_problem / chain_ba_problem, each from the previous stage's RESULT (not from ground truth)."""
+
+    ra: RaProblem
+    num_cams: int
+    num_pts: int
+    pt_offset: np.ndarray  # [P+1]
+    obs_cam: np.ndarray  # [M] int32
+    obs_xy: np.ndarray  # [M,2] pixels (SIMPLE_RADIAL, noise, gross outliers)
+    intr: np.ndarray  # [N,8] intrinsics BA starts from (the calibration GP undistorts with)
+    gt_R: np.ndarray  # [N,3,3] cam_from_world
+    gt_center: np.ndarray  # [N,3]
+    gt_xyz: np.ndarray  # [P,3]
+
+
+def unproject_simple_radial(params, xy, iterations=12):
+    """Pixel -> unit bearing in the camera frame for SIMPLE_RADIAL (what image_undistorter.cc:33-38 stores in
+    features_undist): Newton on r_d = r (1 + k r^2), a fixed number of iterations (r_d < 0.7, k = 0.02: converged to
+    rounding after 5)."""
+    f, cx, cy, k = params[..., 0], params[..., 1], params[..., 2], params[..., 3]
+    ud = (xy[..., 0] - cx) / f
+    vd = (xy[..., 1] - cy) / f
+    rd = np.sqrt(ud * ud + vd * vd)
+    r = rd.copy()
+    for _ in range(iterations):
+        r = r - (r * (1.0 + k * r * r) - rd) / (1.0 + 3.0 * k * r * r)
+    sc = np.where(rd > 0, r / np.where(rd > 0, rd, 1.0), 1.0)
+    b = np.stack([ud * sc, vd * sc, np.ones_like(ud)], axis=-1)
+    return b / np.linalg.norm(b, axis=-1, keepdims=True)
+
+
+def make_chained_scene(num_cams=10_000, num_pts=1_000_000, seed=0, num_succ=50, rot_noise_deg=1.0, rot_outlier_ratio=0.05,
+                       mean_extra=2.0, pixel_noise=0.5, outlier_ratio=0.01) -> ChainedScene:
+    """configs[3]-shaped scene for the chained parity test: the ring cameras / ball points of make_ba_problem, a ring view
+    graph whose relative rotations come from THESE cameras' rotations (make_ring_view_graph's noise model), SIMPLE_RADIAL
+    pixel observations with noise and gross outliers."""
+    rng = np.random.default_rng([seed, 271828])
+    N, P = int(num_cams), int(num_pts)
+    centers, R_cw = _ring_cameras(rng, N, 50.0)
+    num_succ = min(num_succ, (N - 1) // 2)
+    ii = np.repeat(np.arange(N), num_succ)
+    jj = (ii + np.tile(np.arange(1, num_succ + 1), N)) % N
+    lo, hi = np.minimum(ii, jj), np.maximum(ii, jj)
+    E = lo.shape[0]
+    R_rel = R_cw[hi] @ np.transpose(R_cw[lo], (0, 2, 1)) @ so3.aa_to_rotmat(rng.normal(0.0, np.radians(rot_noise_deg), (E, 3)))
+    bad = rng.random(E) < rot_outlier_ratio
+    if bad.any():
+        qr = rng.normal(size=(int(bad.sum()), 4))
+        R_rel[bad] = so3.quat_to_rotmat(qr / np.linalg.norm(qr, axis=1, keepdims=True))
+    ra = RaProblem(num_nodes=N, edge_i=lo.astype(np.int32), edge_j=hi.astype(np.int32), edge_q=so3.rotmat_to_quat(R_rel),
+                   edge_weight=np.ones(E), edge_ninl=rng.integers(30, 501, E).astype(np.int32), node_aa0=np.zeros((N, 3)),
+                   fixed_node=0, gt_R=R_cw, outlier=bad)
+    X = _ball_points(rng, P, 30.0)
+    pt_offset, obs_cam = _sample_tracks(rng, centers, R_cw, X, mean_extra, half_fov_deg=25.0)
+    M = obs_cam.shape[0]
+    obs_pt = np.repeat(np.arange(P), np.diff(pt_offset))
+    intr = np.zeros((N, CAMERA_MAX_PARAMS))
+    intr[:, :4] = np.array([1200.0, 640.0, 480.0, 0.02])
+    xc = np.einsum("mij,mj->mi", R_cw[obs_cam], X[obs_pt] - centers[obs_cam])
+    xy = project_simple_radial(intr[obs_cam], xc) + rng.normal(0, pixel_noise, (M, 2))
+    out = rng.random(M) < outlier_ratio
+    if out.any():
+        xy[out] = np.stack([rng.uniform(0, 1280, int(out.sum())), rng.uniform(0, 960, int(out.sum()))], 1)
+    return ChainedScene(ra=ra, num_cams=N, num_pts=P, pt_offset=pt_offset, obs_cam=obs_cam, obs_xy=np.ascontiguousarray(xy),
+                        intr=intr, gt_R=R_cw, gt_center=centers, gt_xyz=X)
+
+
+def chain_gp_problem(scene: ChainedScene, R_est: np.ndarray) -> GpProblem:
+    """Global positioning as global_mapper.cc:157-163 poses it: bearings = the undistorted features rotated into the world
+    frame by the rotations ROTATION AVERAGING returned (cost_function.h:15-41 reads R^T * feature_undist), centres and points
+    drawn at random by the solver."""
+    b = unproject_simple_radial(scene.intr[scene.obs_cam], scene.obs_xy)
+    d = np.einsum("mji,mj->mi", R_est[scene.obs_cam], b)
+    return GpProblem(num_cams=scene.num_cams, num_pts=scene.num_pts, pt_offset=scene.pt_offset, obs_cam=scene.obs_cam,
+                     obs_dir=np.ascontiguousarray(d), obs_calibrated=np.ones(scene.obs_cam.shape[0], np.uint8),
+                     cam_center=np.zeros((scene.num_cams, 3)), pt_xyz=np.zeros((scene.num_pts, 3)), cam_R=R_est,
+                     gt_center=scene.gt_center, gt_xyz=scene.gt_xyz)
+
+
+def chain_ba_problem(scene: ChainedScene, R_est: np.ndarray, centers: np.ndarray, xyz: np.ndarray) -> BaProblem:
+    """Bundle adjustment as global_mapper.cc:201-223 starts it: rotations from rotation averaging, translations
+    t = -R c and points from GLOBAL POSITIONING's result, one SIMPLE_RADIAL camera per image, first frame constant."""
+    N = scene.num_cams
+    return BaProblem(num_cams=N, num_pts=scene.num_pts, num_intr=N, pt_offset=scene.pt_offset, obs_cam=scene.obs_cam,
+                     obs_xy=scene.obs_xy, cam_intr=np.arange(N, dtype=np.int32), cam_q=so3.rotmat_to_quat(R_est),
+                     cam_t=-np.einsum("nij,nj->ni", R_est, centers), pt_xyz=np.array(xyz, copy=True),
+                     intr_model=np.full(N, CAMERA_SIMPLE_RADIAL, dtype=np.int32), intr_params=scene.intr.copy(), fixed_cam=0,
+                     gt_q=so3.rotmat_to_quat(scene.gt_R), gt_t=-np.einsum("nij,nj->ni", scene.gt_R, scene.gt_center),
+                     gt_xyz=scene.gt_xyz, gt_intr=scene.intr.copy())
+
+
+# --------------------------------------------------------------------------------------------
 # Calibrated multi-camera rigs (the shape of global_mapper_test.cc:89-126 WithoutNoiseWithNonTrivialKnownRig)
 # --------------------------------------------------------------------------------------------
 def make_rig_problems(
@@ -561,12 +660,24 @@ def align_sim3(src: np.ndarray, dst: np.ndarray):
     return s, R, t
 
 
+def scene_extent(c: np.ndarray) -> float:
+    """Largest distance of a camera centre from the centroid: the length north_star's "1e-3 relative" is relative to."""
+    return float(np.linalg.norm(c - c.mean(0), axis=1).max())
+
+
 def center_errors_after_sim3(est: np.ndarray, ref: np.ndarray) -> np.ndarray:
-    """Per-camera centre error after Sim(3) alignment, relative to the extent of ``ref``."""
+    """Per-camera centre error after Sim(3) alignment, ALREADY divided by the extent of ``ref`` (scene_extent): callers
+    compare the returned numbers with a relative bar directly and must not divide by the extent a second time
+    (rounds 1-4 did at a dozen call sites, which made the GP gauge extent of ~20 hide a factor of 20)."""
     s, R, t = align_sim3(est, ref)
     al = (s * (R @ est.T)).T + t
-    extent = np.linalg.norm(ref - ref.mean(0), axis=1).max()
-    return np.linalg.norm(al - ref, axis=1) / extent
+    return np.linalg.norm(al - ref, axis=1) / scene_extent(ref)
+
+
+def center_distance_stats(est: np.ndarray, ref: np.ndarray) -> dict:
+    """max / 99th percentile / median of center_errors_after_sim3 (relative to the extent of ``ref``, divided once)."""
+    d = center_errors_after_sim3(est, ref)
+    return {"max": float(d.max()), "p99": float(np.percentile(d, 99)), "median": float(np.median(d))}
 
 
 def make_match_graph(n_images=200, n_tracks=5000, seed=0, max_gap=12, ring=50, match_prob=0.7, false_match_frac=0.01,

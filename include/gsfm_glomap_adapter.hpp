@@ -889,6 +889,9 @@ class GlobalPositioner {
         pr.sensor_center = sensor_center.data();
       }
     }
+    // the library reads N and P entries from the two permutations: an image whose frame is missing from `frames` would
+    // have grown the index (PackTracks / the pair loop add unknown frames) past what was drawn — refuse such a scene
+    if (cam_draw_order.size() != static_cast<size_t>(N) || pt_draw_order.size() != static_cast<size_t>(P)) return false;
     pr.cam_draw_order = cam_draw_order.data();
     pr.pt_draw_order = pt_draw_order.data();
     if (with_pairs) {

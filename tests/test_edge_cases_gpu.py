@@ -35,9 +35,8 @@ def test_gp_long_and_ragged_tracks_match_oracle(gsfm_ctx):
     ok, c_o, X_o, s = ogp.solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated, p.cam_center, p.pt_xyz)
     rc, c_g, X_g, rep = estimators.gp_solve(p, ctx=gsfm_ctx)
     assert ok and rc == 0
-    extent = np.linalg.norm(c_o - c_o.mean(0), axis=1).max()
-    assert synthetic.center_errors_after_sim3(c_g, c_o).max() / extent < 1e-3
-    assert synthetic.center_errors_after_sim3(c_g, p.gt_center).max() / extent < 1e-6  # noise-free
+    assert synthetic.center_errors_after_sim3(c_g, c_o).max() < 1e-3  # relative to the extent (the helper divides)
+    assert synthetic.center_errors_after_sim3(c_g, p.gt_center).max() < 1e-6  # noise-free
     # tracks shorter than min_num_view_per_track (gp.cc:258), the empty ones included, are left untouched
     untouched = lens < 3
     assert untouched.any() and np.array_equal(X_g[untouched], p.pt_xyz[untouched])
@@ -144,8 +143,7 @@ def test_gp_skewed_visibility_matches_oracle(gsfm_ctx):
     ok, c_o, X_o, s = cpu.gp_solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated, p.cam_center, p.pt_xyz)
     assert ok and (rep["iterations"], rep["successful_steps"]) == (s.iterations, s.successful_steps)
     assert abs(rep["final_cost"] - s.final_cost) <= 1e-5 * s.final_cost
-    ext = np.linalg.norm(c_o - c_o.mean(0), axis=1).max()
-    assert synthetic.center_errors_after_sim3(cen, c_o).max() / ext < 1e-4
+    assert synthetic.center_errors_after_sim3(cen, c_o).max() < 1e-4  # relative to the extent (the helper divides)
     rc, cen2, xyz2, rep2 = estimators.gp_solve(p, opt, ctx=gsfm_ctx)
     assert np.array_equal(cen, cen2) and np.array_equal(xyz, xyz2) and rep2["final_cost"] == rep["final_cost"]
 

@@ -43,9 +43,8 @@ def test_gp_config3_full(gsfm_ctx):
     rc, cen, xyz, rep = estimators.gp_solve(p, ctx=gsfm_ctx)
     assert rc == 0 and rep["termination"] == 0
     assert rep["final_cost"] < 1e-3 * rep["initial_cost"]
-    err = synthetic.center_errors_after_sim3(cen, p.gt_center)
-    extent = np.linalg.norm(p.gt_center - p.gt_center.mean(0), axis=1).max()
-    assert np.median(err) / extent < 1e-3  # ray noise 1e-3
+    err = synthetic.center_errors_after_sim3(cen, p.gt_center)  # relative to the extent of the ground truth
+    assert np.median(err) < 1e-3  # ray noise 1e-3
     # idempotence: from the solution (no random re-draw; the per-observation scales are re-derived from the
     # geometry, gp.cc:300-305, so this is not a bit-exact restart) the solver stops quickly at the same cost
     p2 = type(p)(**{**p.__dict__, "cam_center": cen, "pt_xyz": xyz})
@@ -54,7 +53,7 @@ def test_gp_config3_full(gsfm_ctx):
     rc, cen2, xyz2, rep2 = estimators.gp_solve(p2, opt, ctx=gsfm_ctx)
     assert rc == 0 and rep2["iterations"] <= 12
     assert rep2["final_cost"] <= rep["final_cost"] * (1 + 1e-4)
-    assert synthetic.center_errors_after_sim3(cen2, cen).max() / extent < 1e-3
+    assert synthetic.center_errors_after_sim3(cen2, cen).max() < 1e-3
 
 
 def test_ba_config4_full(gsfm_ctx):

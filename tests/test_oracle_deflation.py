@@ -46,5 +46,4 @@ def test_gauge_deflation_keeps_the_solution_and_saves_operator_applications(tmp_
     assert abs(plain["cost"] - defl["cost"]) <= 1e-3 * plain["cost"]
     # the count of the deflated run includes the four applications per solve that form A W
     assert defl["pcg"] < 0.85 * plain["pcg"], (plain, defl)
-    extent = np.linalg.norm(c0 - c0.mean(0), axis=1).max()
-    assert synthetic.center_errors_after_sim3(c1, c0).max() / extent < 1e-3
+    assert synthetic.center_errors_after_sim3(c1, c0).max() < 1e-3  # relative to the extent (the helper divides)

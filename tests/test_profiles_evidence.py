@@ -7,7 +7,10 @@ import json
 import pathlib
 
 ROOT = pathlib.Path(__file__).resolve().parent.parent
-TAG = "r04"
+# the newest round that has committed its default bench line AND the rocprofv3 summaries that go with it
+TAG = max(p.name[:3] for p in (ROOT / "profiles").glob("r??_bench_default.json")
+          if (ROOT / "profiles" / f"{p.name[:3]}_pipeline_c4_kernel_stats.csv").exists()
+          and (ROOT / "profiles" / f"{p.name[:3]}_pipeline_c4_pmc.csv").exists())
 
 
 def test_bench_line_roofline_follows_from_its_fields():

@@ -242,8 +242,7 @@ def test_gp_with_known_rigs_matches_oracle(gsfm_ctx, frames, cams, pts, noise):
     assert abs(rep["initial_cost"] - s.initial_cost) <= 1e-12 * s.initial_cost  # same random start
     assert abs(rep["iterations"] - s.iterations) <= 2
     assert abs(rep["final_cost"] - s.final_cost) <= 1e-3 * s.final_cost + 1e-9
-    ext = np.linalg.norm(c_o - c_o.mean(0), axis=1).max()
-    assert synthetic.center_errors_after_sim3(cen, c_o).max() / ext < 1e-3
+    assert synthetic.center_errors_after_sim3(cen, c_o).max() < 1e-3  # relative to the extent (the helper divides)
     scale, _, _ = synthetic.align_sim3(cen, gp.gt_center)
     assert abs(scale - 1.0) < 3e-2  # metric rig offsets fix the scale
 

@@ -63,7 +63,7 @@ def main():
         gt = synthetic.center_errors_after_sim3(c, p.gt_center)
         print(json.dumps(dict(pcg_tol=tol, ok=bool(ok), lm_iterations=int(s.iterations), accepted=int(s.successful_steps),
                               final_cost=float(s.final_cost),
-                              max_rel_vs_exact=float(synthetic.center_errors_after_sim3(c, ref).max() / extent),
+                              max_rel_vs_exact=float(synthetic.center_errors_after_sim3(c, ref).max()),
                               median_err_vs_gt=float(np.median(gt)), seconds=round(sec, 1))), flush=True)
 
 
