@@ -122,7 +122,7 @@ class GlobalPositionerOptions:
     constraint_type: int = 0  # ONLY_POINTS, 1 = ONLY_CAMERAS, 2 = POINTS_AND_CAMERAS_BALANCED, 3 = POINTS_AND_CAMERAS
     constraint_reweight_scale: float = 1.0  # POINTS_AND_CAMERAS_BALANCED only (global_positioning.h:40-41)
     thres_loss_function: float = 1e-1
-    solver_options: SolverOptions = field(default_factory=lambda: SolverOptions(max_num_iterations=100))
+    solver_options: SolverOptions = field(default_factory=lambda: SolverOptions(max_num_iterations=100, pcg_relative_tolerance=1e-12))
 
     def to_c(self) -> _lib.GpOptions:
         o = _lib.GpOptions()

@@ -512,18 +512,6 @@ def chain_gp_problem(scene: ChainedScene, R_est: np.ndarray) -> GpProblem:
                      gt_center=scene.gt_center, gt_xyz=scene.gt_xyz)
 
 
-def chain_ba_problem(scene: ChainedScene, R_est: np.ndarray, centers: np.ndarray, xyz: np.ndarray) -> BaProblem:
-    """Bundle adjustment as global_mapper.cc:201-223 starts it: rotations from rotation averaging, translations
-    t = -R c and points from GLOBAL POSITIONING's result, one SIMPLE_RADIAL camera per image, first frame constant."""
-    N = scene.num_cams
-    return BaProblem(num_cams=N, num_pts=scene.num_pts, num_intr=N, pt_offset=scene.pt_offset, obs_cam=scene.obs_cam,
-                     obs_xy=scene.obs_xy, cam_intr=np.arange(N, dtype=np.int32), cam_q=so3.rotmat_to_quat(R_est),
-                     cam_t=-np.einsum("nij,nj->ni", R_est, centers), pt_xyz=np.array(xyz, copy=True),
-                     intr_model=np.full(N, CAMERA_SIMPLE_RADIAL, dtype=np.int32), intr_params=scene.intr.copy(), fixed_cam=0,
-                     gt_q=so3.rotmat_to_quat(scene.gt_R), gt_t=-np.einsum("nij,nj->ni", scene.gt_R, scene.gt_center),
-                     gt_xyz=scene.gt_xyz, gt_intr=scene.intr.copy())
-
-
 # --------------------------------------------------------------------------------------------
 # Calibrated multi-camera rigs (the shape of global_mapper_test.cc:89-126 WithoutNoiseWithNonTrivialKnownRig)
 # --------------------------------------------------------------------------------------------

@@ -319,7 +319,7 @@ typedef struct gsfm_lm_options {
   int32_t jacobi_scaling;            /* 1 */
   int32_t max_num_consecutive_invalid_steps; /* 5 */
   /* linear solver replacing SPARSE_SCHUR + sparse Cholesky: implicit-Schur block-Jacobi PCG */
-  double pcg_relative_tolerance;     /* |r|_2 <= tol * |b|_2 on the reduced camera system: 1e-8 (gsfm_gp_options_default), 1e-6 (gsfm_ba_options_default) */
+  double pcg_relative_tolerance;     /* |r|_2 <= tol * |b|_2 on the reduced camera system: 1e-12 (gsfm_gp_options_default), 1e-6 (gsfm_ba_options_default) */
   int32_t pcg_max_iterations;        /* 1000 */
 } gsfm_lm_options;
 

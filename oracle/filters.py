@@ -81,6 +81,33 @@ def filter_tracks_triangulation_angle(pt_offset, obs_cam, cam_q, cam_t, pt_xyz, 
     return keep, int((~keep).sum())
 
 
+def filter_tracks_triangulation_angle_grouped(pt_offset, obs_cam, cam_q, cam_t, pt_xyz, min_angle_deg=1.0):
+    """filter_tracks_triangulation_angle for millions of tracks: the same pairwise test, tracks grouped by length so that
+    each group is one batched Gram product (tests/test_filters.py pins it to the per-track loop above)."""
+    R = so3.quat_wxyz_to_rotmat(np.asarray(cam_q, dtype=np.float64))
+    centers = -np.einsum("nji,nj->ni", R, cam_t)
+    thr = np.cos(np.radians(min_angle_deg))
+    off = np.asarray(pt_offset, dtype=np.int64)
+    lens = np.diff(off)
+    P = len(lens)
+    keep = np.zeros(P, bool)
+    pt = np.repeat(np.arange(P), lens)
+    d = pt_xyz[pt] - centers[obs_cam]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    for L in np.unique(lens):
+        if L < 2:
+            continue
+        trk = np.nonzero(lens == L)[0]
+        idx = off[trk][:, None] + np.arange(L)[None, :]
+        D = d[idx]  # [n, L, 3]
+        for c0 in range(0, len(trk), 1 << 16):  # bounded memory for long tracks
+            Dc = D[c0 : c0 + (1 << 16)]
+            G = np.einsum("nij,nkj->nik", Dc, Dc)
+            iu = np.triu_indices(int(L), 1)
+            keep[trk[c0 : c0 + (1 << 16)]] = (G[:, iu[0], iu[1]] < thr).any(axis=1)
+    return keep, int((~keep).sum())
+
+
 def normalize_reconstruction(cam_q, cam_t, pt_xyz, cam_registered=None, fixed_scale=False, extent=10.0, p0=0.1, p1=0.9):
     """reconstruction_normalizer.cc:5-85.  Returns (cam_t', pt_xyz', (scale, translation))."""
     R = so3.quat_wxyz_to_rotmat(np.asarray(cam_q, dtype=np.float64))

@@ -1,13 +1,17 @@
 #!/usr/bin/env python
-"""Generates tests/golden/chain_c4_oracle.npz: the CPU oracle's result for the WHOLE hot path chained on one configs[3]-size
-scene — rotation averaging -> global positioning (bearings oriented by the rotations RA returned, random start) -> bundle
-adjustment (started from GP's centres and points) — as GlobalMapper::Solve chains the three estimators
-(global_mapper.cc:92-223).  Scene: synthetic.make_chained_scene(10_000, 1_000_000, seed=0).
+"""Generates tests/golden/chain_c4_oracle.npz (and chain_2k_oracle.npz): the CPU oracle's result for the WHOLE hot path
+chained on one scene the way GlobalMapper::Solve chains it (global_mapper.cc:92-223; driver: tests/chain_util.py run_chain):
 
-Why a fixture: three exact-solve oracle stages at this size are ~15 minutes on 8 cores; every reduction of oracle/csrc runs
+    rotation averaging -> global positioning (bearings oriented by RA's rotations, random start)
+    -> FilterTracksByAngle / FilterTrackTriangulationAngle / FilterTracksByReprojection(10 x) -> NormalizeReconstruction
+    -> bundle adjustment, positions only -> bundle adjustment with rotations.
+
+Scene: synthetic.make_chained_scene(10_000, 1_000_000, seed=0).
+
+Why a fixture: the exact-solve oracle stages at this size are ~15 minutes on 8 cores; every reduction of oracle/csrc runs
 in a fixed order, so the numbers generated here ARE what the GPU box would compute.  The test regenerates the scene from the
-seed (pinned by checksums) and runs the HIP chain; only the oracle's stage results travel (RA rotations, GP centres, final
-poses).  Reduced systems solved to 1e-14, true residuals recorded.
+seed (pinned by checksums) and runs the HIP chain; only the oracle's stage results travel (RA rotations, GP centres, the
+observation counts after each filter, final poses).  Reduced systems solved to 1e-14, true residuals recorded.
 
 Usage: python tests/golden/make_chain_golden.py [cams tracks name]"""
 import sys
@@ -18,32 +22,10 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
 
-from glomap_amd import so3, synthetic  # noqa: E402
-from oracle import cpu  # noqa: E402
-
-
-def oracle_chain(sc, verbose=False):
-    """The three oracle stages chained; returns a dict of stage results and reports."""
-    p = sc.ra
-    rep_ra = {}
-    ok, rot = cpu.ra_estimate_rotations(p.num_nodes, p.edge_i, p.edge_j, p.edge_q, p.edge_weight, p.edge_ninl, p.node_aa0,
-                                        p.fixed_node, report=rep_ra)
-    assert ok
-    R = so3.aa_to_rotmat(rot)
-    g = synthetic.chain_gp_problem(sc, R)
-    ok, c, X, sg = cpu.gp_solve(g.num_cams, g.pt_offset, g.obs_cam, g.obs_dir, g.obs_calibrated, g.cam_center, g.pt_xyz, verbose=verbose)
-    assert ok
-    b = synthetic.chain_ba_problem(sc, R, c, X)
-    r = cpu.ba_solve(b.num_cams, b.pt_offset, b.obs_cam, b.obs_xy, b.cam_intr, b.intr_model, b.fixed_cam, b.cam_q, b.cam_t, b.pt_xyz,
-                     b.intr_params, verbose=verbose)
-    assert r[0]
-    sb = r[5]
-    return dict(ra_rot=rot, ra_l1=rep_ra["l1_iterations"], ra_irls=rep_ra["irls_iterations"], gp_center=c,
-                gp_iterations=sg.iterations, gp_initial_cost=sg.initial_cost, gp_final_cost=sg.final_cost,
-                gp_max_linear_residual=sg.max_linear_residual, ba_q=r[1], ba_t=r[2], ba_intr_f=r[4][:, 0].copy(),
-                ba_iterations=sb.iterations, ba_successful=sb.successful_steps, ba_initial_cost=sb.initial_cost,
-                ba_final_cost=sb.final_cost, ba_max_linear_residual=sb.max_linear_residual)
+from chain_util import OracleBackend, run_chain  # noqa: E402
+from glomap_amd import synthetic  # noqa: E402
 
 
 def scene_checksums(sc):
@@ -57,11 +39,19 @@ def main():
         N, P, name = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     sc = synthetic.make_chained_scene(N, P, seed=0)
     t0 = time.time()
-    out = oracle_chain(sc, verbose=True)
-    print("RA %d+%d  GP LM %d cost %.6f (max true relres %.1e)  BA LM %d (%d accepted) cost %.3f -> %.3f (max true relres %.1e)  %.0f s"
-          % (out["ra_l1"], out["ra_irls"], out["gp_iterations"], out["gp_final_cost"], out["gp_max_linear_residual"],
-             out["ba_iterations"], out["ba_successful"], out["ba_initial_cost"], out["ba_final_cost"],
-             out["ba_max_linear_residual"], time.time() - t0))
+    r = run_chain(sc, OracleBackend(verbose=True))
+    g, b1, b2 = r["rep_gp"], r["rep_ba1"], r["rep_ba2"]
+    print("RA %d+%d | GP LM %d cost %.6f (max true relres %.1e) | observations kept %s | BA positions-only LM %d (%d accepted) cost "
+          "%.3f -> %.3f (max true relres %.1e) | BA full LM %d (%d accepted) cost %.3f -> %.3f (max true relres %.1e) | %.0f s"
+          % (r["rep_ra"]["l1"], r["rep_ra"]["irls"], g["iterations"], g["final_cost"], g["max_linear_residual"], r["observations_kept"],
+             b1["iterations"], b1["successful"], b1["initial_cost"], b1["final_cost"], b1["max_linear_residual"],
+             b2["iterations"], b2["successful"], b2["initial_cost"], b2["final_cost"], b2["max_linear_residual"], time.time() - t0))
+    out = dict(ra_rot=r["ra_rot"], ra_l1=r["rep_ra"]["l1"], ra_irls=r["rep_ra"]["irls"], gp_center=r["gp_center"],
+               observations_kept=np.array(r["observations_kept"], dtype=np.int64), ba_q=r["ba_q"], ba_t=r["ba_t"],
+               ba_intr_f=r["ba_intr"][:, 0].copy())
+    for stage, rep in (("gp", g), ("ba1", b1), ("ba2", b2)):
+        for k, v in rep.items():
+            out[f"{stage}_{k}"] = v
     np.savez_compressed(Path(__file__).resolve().parent / name, **out, **scene_checksums(sc))
 
 

@@ -44,6 +44,11 @@ def test_oracle_triangulation_angle():
     X2[0] = X[0] * 1e6
     keep2, _ = of.filter_tracks_triangulation_angle(p.pt_offset, p.obs_cam, q, t, X2, 1.0)
     assert not keep2[0]
+    # the batched form used on millions of tracks (tests/chain_util.py) is the same test
+    for pts in (X, X2, X * 40.0):
+        a = of.filter_tracks_triangulation_angle(p.pt_offset, p.obs_cam, q, t, pts, 1.0)
+        b = of.filter_tracks_triangulation_angle_grouped(p.pt_offset, p.obs_cam, q, t, pts, 1.0)
+        assert np.array_equal(a[0], b[0]) and a[1] == b[1]
 
 
 def test_oracle_normalizer_properties():

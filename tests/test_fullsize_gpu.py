@@ -77,34 +77,115 @@ def test_ba_config4_full(gsfm_ctx):
 
 
 def _extent(c):
-    return np.linalg.norm(c - c.mean(0), axis=1).max()
+    return synthetic.scene_extent(c)
 
 
-def test_gp_config3_matches_cpu_oracle(gsfm_ctx):
-    """configs[2] (5k cameras / 500k tracks / ~3M observations): the HIP solve against the exact-solve CPU oracle on
-    the same inputs and the same std::mt19937 start.  Bar = north_star's 1e-3 relative on the camera centres (after
-    Sim(3) alignment: GP has a free similarity gauge).  For scale: two runs of the CPU oracle ALONE that differ only
-    in the summation order of their reductions (rounding-level perturbation) end 6e-5 apart and take 42 vs 41 LM
-    iterations — the algorithm stops on function_tolerance 1e-5 before the iterate has settled — so the iteration
-    counts are compared with a slack of 3, not for equality."""
+def _gp_full_size_problem(ncam, npts, seed):
+    # seed 1 carries uncalibrated cameras (the half-weight loss branch of gp.cc:212-231) on top of the 2 % outlier rays
+    return synthetic.make_gp_problem(ncam, npts, seed=seed, uncalibrated_ratio=0.1 if seed == 1 else 0.0)
+
+
+def _gp_parity(tag, p, ctx, lm_kw=None, orders=(0, "1 if apart")):
+    """HIP solve vs exact-solve C++ oracle on the same input and the same std::mt19937 start.  Prints and returns the
+    camera-centre distance statistics (Sim(3)-aligned, relative to the extent of the oracle's solution — divided ONCE).
+
+    orders: the oracle's reductions summed forwards (0) and backwards (1) — two restatements of the same algorithm that
+    differ in rounding only.  On some inputs THE ORACLE ITSELF ends in two places ~1e-3 apart on its worst camera depending
+    on that order alone (configs[2] seed 0: 42 / 41 LM iterations, final cost 5101.143 / 5100.742, 1.23e-3 apart): the
+    stalled LM iteration of this problem amplifies a perturbation ~1e6-fold and a rounding-level difference can flip an
+    accept / reject decision.  Parity on such an input can only mean: the HIP solve ends where ONE of the oracle's
+    rounding-level variants ends.  So when the forward-summed oracle is more than 1e-4 away, the reversed one is run too,
+    every distance is printed, and the closer one is returned."""
     from oracle import cpu
+    from oracle import gp as ogp
 
-    p = synthetic.make_gp_problem(5000, 500_000, seed=0)
-    rc, cen, xyz, rep = estimators.gp_solve(p, ctx=gsfm_ctx)
+    opt = estimators.GlobalPositionerOptions()
+    oopt = ogp.GlobalPositionerOptions()
+    for k, v in (lm_kw or {}).items():
+        setattr(opt.solver_options, k, v)
+        setattr(oopt.lm, k, v)
+    rc, cen, xyz, rep = estimators.gp_solve(p, opt, ctx=ctx)
     assert rc == 0
-    ok, c_o, X_o, s = cpu.gp_solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated, p.cam_center, p.pt_xyz)
-    assert ok and s.max_linear_residual < 1e-8
-    assert abs(rep["initial_cost"] - s.initial_cost) <= 1e-12 * s.initial_cost  # identical random start
-    assert abs(rep["iterations"] - s.iterations) <= 3
-    assert abs(rep["final_cost"] - s.final_cost) <= 1e-3 * s.final_cost
-    d = synthetic.center_errors_after_sim3(cen, c_o)
-    print(f"\n[parity] GP configs[2]: LM {rep['iterations']} vs {s.iterations}, final cost {rep['final_cost']:.6f} vs {s.final_cost:.6f}, "
-          f"max centre distance GPU-oracle / extent = {d.max() / _extent(c_o):.3e} (bar 1e-3)")
-    assert d.max() / _extent(c_o) < 1e-3
+    best = None
+    runs = []
+    for order in orders:
+        if order == "1 if apart" and (not runs or runs[0][3]["max"] < 1e-4):
+            continue  # the forward-summed oracle and the HIP solve took the same branch: nothing to disambiguate
+        order = 1 if order == "1 if apart" else order
+        ok, c_o, X_o, s = cpu.gp_solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated, p.cam_center, p.pt_xyz, oopt,
+                                       order=order)
+        assert ok and s.max_linear_residual < 1e-8  # the oracle's reduced solves really were exact (true residual)
+        assert abs(rep["initial_cost"] - s.initial_cost) <= 1e-12 * s.initial_cost  # identical random start
+        st = synthetic.center_distance_stats(cen, c_o)
+        runs.append((order, c_o, s, st))
+        print(f"\n[parity] GP {tag}{' (oracle sums reversed)' if order else ''}: LM {rep['iterations']} vs {s.iterations}, final cost "
+              f"{rep['final_cost']:.6f} vs {s.final_cost:.6f}, PCG {rep['linear_iterations']}, centre distance GPU-oracle / extent: max "
+              f"{st['max']:.3e} p99 {st['p99']:.3e} median {st['median']:.3e} (bar: max 1e-3; oracle's gauge extent {_extent(c_o):.2f})")
+        if best is None or st["max"] < best[3]["max"]:
+            best = runs[-1]
+    if len(runs) == 2:
+        oo = synthetic.center_distance_stats(runs[1][1], runs[0][1])
+        print(f"[parity] GP {tag}: the oracle against itself, sums reversed vs forwards: LM {runs[1][2].iterations} vs {runs[0][2].iterations}, "
+              f"centre distance max {oo['max']:.3e} p99 {oo['p99']:.3e} median {oo['median']:.3e}")
+    return cen, best[1], rep, best[2], best[3]
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_gp_config3_matches_cpu_oracle(gsfm_ctx, seed):
+    """configs[2] (5k cameras / 500k tracks / ~3M observations), three seeds: the HIP solve against the exact-solve CPU
+    oracle.  Bar = north_star's 1e-3 on the camera centres relative to the scene extent, after Sim(3) alignment (GP has a
+    free similarity gauge), on the WORST camera.
+
+    Round 5: this test used to divide the (already relative) distances by the extent a second time; with the right metric
+    the round-4 library was 1.3e-2 away.  Cause: the reduced solves stopped at a relative residual of 1e-8.  The LM
+    trajectory of this problem ends in a stall — 2 % of the rays are outliers whose scales sit on their lower bound, the
+    model keeps promising a decrease that the projected step does not deliver, the radius collapses — and WHERE it stalls
+    depends on every accept / reject decision before; an error of 1e-8 per solve is enough to flip one
+    (tools/exp_gp_same_minimiser.py: the oracle against itself, PCG 1e-8 vs 1e-14: 2.2e-2; 1e-12 vs 1e-14: 1e-8; reversed
+    summation order: 6e-9).  The library now solves to 1e-12 and follows the oracle's trajectory decision for decision."""
+    p = _gp_full_size_problem(5000, 500_000, seed)
+    # (seed 0 is the input on which the oracle itself has two end points: _gp_parity runs both summation orders there)
+    cen, c_o, rep, s, st = _gp_parity(f"configs[2] seed {seed}", p, gsfm_ctx)
+    assert abs(rep["iterations"] - s.iterations) <= 1
+    assert abs(rep["final_cost"] - s.final_cost) <= 1e-4 * s.final_cost
+    assert st["max"] < 1e-3
     # both recover the ground truth equally well
-    e_g = synthetic.center_errors_after_sim3(cen, p.gt_center).max() / _extent(p.gt_center)
-    e_o = synthetic.center_errors_after_sim3(c_o, p.gt_center).max() / _extent(p.gt_center)
-    assert e_g < 2 * e_o + 1e-4
+    e_g = synthetic.center_errors_after_sim3(cen, p.gt_center).max()
+    e_o = synthetic.center_errors_after_sim3(c_o, p.gt_center).max()
+    assert e_g < 1.05 * e_o + 1e-5
+
+
+def test_gp_config3_same_minimiser_at_tight_function_tolerance(gsfm_ctx):
+    """Stopping noise or solver error?  Both sides with function_tolerance 1e-10 (reference: 1e-5, optimization_base.h:22)
+    and the iteration cap raised: if the default-tolerance distance were only a matter of where the iteration is cut off,
+    the two would meet here.  They do, to far below the bar — and so do the default-tolerance runs
+    (test_gp_config3_matches_cpu_oracle), because the LM ends in the stall described there, not on the function tolerance."""
+    p = _gp_full_size_problem(5000, 500_000, 2)
+    cen, c_o, rep, s, st = _gp_parity("configs[2] seed 2, function_tolerance 1e-10", p, gsfm_ctx,
+                                      dict(function_tolerance=1e-10, max_num_iterations=400))
+    assert abs(rep["iterations"] - s.iterations) <= 1
+    assert abs(rep["final_cost"] - s.final_cost) <= 1e-4 * s.final_cost
+    assert st["max"] < 1e-3
+
+
+def test_gp_config3_sensitivity_to_the_linear_solver_tolerance(gsfm_ctx):
+    """The documented sensitivity (not a parity claim): the same solve with the reduced systems stopped at 1e-8 — round 4's
+    setting.  Typical cameras agree with the tight solve to 1e-5; the worst few, poorly constrained, end 1e-3 ... 1e-2 away
+    because the stalled LM iteration took another branch.  Asserted: the median, and that the tight setting is what the
+    library defaults to."""
+    assert estimators.GlobalPositionerOptions().solver_options.pcg_relative_tolerance <= 1e-11
+    p = _gp_full_size_problem(5000, 500_000, 0)
+    rc, c_tight, _, rep_t = estimators.gp_solve(p, ctx=gsfm_ctx)
+    loose = estimators.GlobalPositionerOptions()
+    loose.solver_options.pcg_relative_tolerance = 1e-8
+    rc2, c_loose, _, rep_l = estimators.gp_solve(p, loose, ctx=gsfm_ctx)
+    assert rc == 0 and rc2 == 0
+    st = synthetic.center_distance_stats(c_loose, c_tight)
+    print(f"\n[parity] GP configs[2] seed 0, PCG 1e-8 vs the default: LM {rep_l['iterations']} vs {rep_t['iterations']}, PCG "
+          f"{rep_l['linear_iterations']} vs {rep_t['linear_iterations']}, centre distance / extent: max {st['max']:.3e} p99 "
+          f"{st['p99']:.3e} median {st['median']:.3e}")
+    assert st["median"] < 1e-3
+    assert rep_l["linear_iterations"] < rep_t["linear_iterations"]
 
 
 def test_ba_config4_matches_cpu_oracle(gsfm_ctx):
@@ -200,27 +281,19 @@ def test_ba_config4_shared_intrinsics_follows_the_exact_oracle_trajectory(gsfm_c
     assert abs(intr[0, 0] - g["out_intr"][0, 0]) < 1e-4 * 1200.0
 
 
-def test_gp_config4_matches_cpu_oracle(gsfm_ctx):
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_gp_config4_matches_cpu_oracle(gsfm_ctx, seed):
     """Global positioning at the size the headline times it — configs[3]: 10k cameras / 1M tracks / ~6.0M observations —
-    against the exact-solve CPU oracle on the same inputs and the same std::mt19937 start; same bars as at configs[2]
-    (test_gp_config3_matches_cpu_oracle explains the slack of 3 on the LM iteration count)."""
-    from oracle import cpu
-
-    p = synthetic.make_gp_problem(10_000, 1_000_000, seed=0)
-    rc, cen, xyz, rep = estimators.gp_solve(p, ctx=gsfm_ctx)
-    assert rc == 0
-    ok, c_o, X_o, s = cpu.gp_solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated, p.cam_center, p.pt_xyz)
-    assert ok and s.max_linear_residual < 1e-8
-    assert abs(rep["initial_cost"] - s.initial_cost) <= 1e-12 * s.initial_cost  # identical random start
-    d = synthetic.center_errors_after_sim3(cen, c_o)
-    print(f"\n[parity] GP configs[3] size: LM {rep['iterations']} vs {s.iterations}, final cost {rep['final_cost']:.6f} vs "
-          f"{s.final_cost:.6f}, max centre distance GPU-oracle / extent = {d.max() / _extent(c_o):.3e} (bar 1e-3)")
-    assert abs(rep["iterations"] - s.iterations) <= 3
-    assert abs(rep["final_cost"] - s.final_cost) <= 1e-3 * s.final_cost
-    assert d.max() / _extent(c_o) < 1e-3
-    e_g = synthetic.center_errors_after_sim3(cen, p.gt_center).max() / _extent(p.gt_center)
-    e_o = synthetic.center_errors_after_sim3(c_o, p.gt_center).max() / _extent(p.gt_center)
-    assert e_g < 2 * e_o + 1e-4
+    against the exact-solve CPU oracle on the same inputs and the same std::mt19937 start, three seeds; same bars as at
+    configs[2] (test_gp_config3_matches_cpu_oracle has the story of the metric and of the solver tolerance)."""
+    p = _gp_full_size_problem(10_000, 1_000_000, seed)
+    cen, c_o, rep, s, st = _gp_parity(f"configs[3] size, seed {seed}", p, gsfm_ctx)
+    assert abs(rep["iterations"] - s.iterations) <= 1
+    assert abs(rep["final_cost"] - s.final_cost) <= 1e-4 * s.final_cost
+    assert st["max"] < 1e-3
+    e_g = synthetic.center_errors_after_sim3(cen, p.gt_center).max()
+    e_o = synthetic.center_errors_after_sim3(c_o, p.gt_center).max()
+    assert e_g < 1.05 * e_o + 1e-5
 
 
 def test_gp_sequential_capture_matches_cpu_oracle(gsfm_ctx):
@@ -240,9 +313,9 @@ def test_gp_sequential_capture_matches_cpu_oracle(gsfm_ctx):
     d = synthetic.center_errors_after_sim3(cen, c_o)
     print(f"\n[parity] GP sequential capture 2.5k / 125k: LM {rep['iterations']} vs {s.iterations}, final cost "
           f"{rep['final_cost']:.6f} vs {s.final_cost:.6f}, operator applications {rep['linear_iterations']} vs "
-          f"{s.linear_iterations}, max centre distance GPU-oracle / extent = {d.max() / _extent(c_o):.3e} (bar 1e-3)")
+          f"{s.linear_iterations}, max centre distance GPU-oracle / extent = {d.max():.3e} (bar 1e-3)")
     assert abs(rep["final_cost"] - s.final_cost) <= 1e-3 * s.final_cost
-    assert d.max() / _extent(c_o) < 1e-3
+    assert d.max() < 1e-3
     assert rep["linear_iterations"] < 0.5 * s.linear_iterations
 
 
@@ -266,10 +339,10 @@ def test_gp_points_and_cameras_balanced_matches_cpu_oracle(gsfm_ctx):
     assert abs(rep["initial_cost"] - s.initial_cost) <= 1e-12 * s.initial_cost
     d = synthetic.center_errors_after_sim3(cen, c_o)
     print(f"\n[parity] GP POINTS_AND_CAMERAS_BALANCED 1.2k / 40k / 4.8k pairs: LM {rep['iterations']} vs {s.iterations}, final cost "
-          f"{rep['final_cost']:.6f} vs {s.final_cost:.6f}, max centre distance GPU-oracle / extent = {d.max() / _extent(c_o):.3e} (bar 1e-3)")
+          f"{rep['final_cost']:.6f} vs {s.final_cost:.6f}, max centre distance GPU-oracle / extent = {d.max():.3e} (bar 1e-3)")
     assert abs(rep["iterations"] - s.iterations) <= 3
     assert abs(rep["final_cost"] - s.final_cost) <= 1e-3 * s.final_cost
-    assert d.max() / _extent(c_o) < 1e-3
+    assert d.max() < 1e-3
 
 
 def test_ra_config4_matches_cpu_oracle(gsfm_ctx):
@@ -349,3 +422,67 @@ def test_track_establishment_config3_full(gsfm_ctx):
         want = ot.find_tracks_for_problem(*ref[:4], reg, **kw)
         for a, b in zip((sel.track_id, sel.track_offset, sel.obs_image, sel.obs_feature), want):
             assert np.array_equal(a, b)
+
+
+def _chain_against_fixture(name, ncam, npts, ctx):
+    """GPU chain vs the frozen oracle chain (tests/golden/make_chain_golden.py): returns the stage distances."""
+    import os
+
+    from chain_util import GpuBackend, final_pose_distance, run_chain
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+    sc = synthetic.make_chained_scene(ncam, npts, seed=0)
+    # same scene as the one the oracle chain ran on (numpy's pairwise sums may group differently on another CPU)
+    assert sc.obs_cam.shape[0] == int(g["num_obs"]) and int(np.sum(sc.obs_cam.astype(np.int64))) == int(g["obs_cam_checksum"])
+    assert abs(float(np.sum(sc.obs_xy)) / float(g["obs_xy_checksum"]) - 1) < 1e-12
+    assert abs(float(np.sum(sc.ra.edge_q)) / float(g["edge_q_checksum"]) - 1) < 1e-10
+    assert float(g["ba1_max_linear_residual"]) < 1e-8 and float(g["ba2_max_linear_residual"]) < 1e-8  # the oracle's solves were exact
+    r = run_chain(sc, GpuBackend(ctx))
+    d_ra = float(np.radians(so3.rotation_angle_deg(so3.aa_to_rotmat(r["ra_rot"]), so3.aa_to_rotmat(g["ra_rot"]))).max())
+    st_gp = synthetic.center_distance_stats(r["gp_center"], g["gp_center"])
+    ang, st_ba = final_pose_distance(r["ba_q"], r["ba_t"], g["ba_q"], g["ba_t"])
+    # how good the result is against ground truth (context for the distances): rotations and Sim(3)-aligned centres
+    Rf = so3.quat_to_rotmat(r["ba_q"])
+    cf = -np.einsum("nji,nj->ni", Rf, r["ba_t"])
+    gt_rot = float(np.median(synthetic.rotation_errors_deg(Rf, sc.gt_R)))
+    gt_cen = synthetic.center_distance_stats(cf, sc.gt_center)
+    b1, b2 = r["rep_ba1"], r["rep_ba2"]
+    print(f"\n[parity] chain RA->GP->filters->BA {ncam} cameras / {npts} tracks / {sc.obs_cam.shape[0]} observations: RA {r['rep_ra']['l1']}+"
+          f"{r['rep_ra']['irls']} vs {int(g['ra_l1'])}+{int(g['ra_irls'])} iterations, rotations {d_ra:.3e} rad apart | GP LM "
+          f"{r['rep_gp']['iterations']} vs {int(g['gp_iterations'])}, cost {r['rep_gp']['final_cost']:.6f} vs {float(g['gp_final_cost']):.6f}, "
+          f"centres max {st_gp['max']:.3e} p99 {st_gp['p99']:.3e} | observations kept by the filters {r['observations_kept']} vs "
+          f"{g['observations_kept'].tolist()} | BA positions-only LM {b1['iterations']} ({b1['successful']}) vs {int(g['ba1_iterations'])} "
+          f"({int(g['ba1_successful'])}), BA full LM {b2['iterations']} ({b2['successful']}) vs {int(g['ba2_iterations'])} "
+          f"({int(g['ba2_successful'])}), cost {b2['final_cost']:.3f} vs {float(g['ba2_final_cost']):.3f} | FINAL POSES GPU-oracle: rotations max "
+          f"{ang:.3e} rad (bar 1e-4), centres / extent max {st_ba['max']:.3e} p99 {st_ba['p99']:.3e} median {st_ba['median']:.3e} (bar 1e-3) "
+          f"| vs ground truth: median rotation error {gt_rot:.4f} deg, centres median {gt_cen['median']:.2e}")
+    return r, g, d_ra, st_gp, ang, st_ba
+
+
+def test_chain_config4_final_poses_match_the_oracle_chain(gsfm_ctx):
+    """north_star's bar is on the FINAL camera poses: rotation averaging -> global positioning (bearings oriented by the
+    rotations RA returned, random start) -> the three track filters and the normalisation -> bundle adjustment (positions
+    only, then with rotations; started from GP's centres and points), chained on ONE configs[3]-size scene as
+    GlobalMapper::Solve chains estimators and processors (global_mapper.cc:92-223; driver tests/chain_util.py) — every stage
+    through the C ABI on the GPU, against the same chain run by the exact-solve CPU oracle (frozen:
+    tests/golden/chain_c4_oracle.npz, tests/golden/make_chain_golden.py).  Rotations <= 1e-4 rad (no alignment: node 0 is
+    RA's gauge and BA's constant frame in both chains), camera centres <= 1e-3 of the scene extent after Sim(3) alignment
+    (BA inherits the scale the normaliser set).  The filters are integer decisions: the kept-observation counts must agree
+    exactly after each of the three."""
+    r, g, d_ra, st_gp, ang, st_ba = _chain_against_fixture("chain_c4_oracle.npz", 10_000, 1_000_000, gsfm_ctx)
+    assert (r["rep_ra"]["l1"], r["rep_ra"]["irls"]) == (int(g["ra_l1"]), int(g["ra_irls"]))
+    assert d_ra < 1e-6
+    assert st_gp["max"] < 1e-3
+    assert r["observations_kept"] == g["observations_kept"].tolist()
+    assert ang < 1e-4
+    assert st_ba["max"] < 1e-3
+
+
+def test_chain_2k_final_poses_match_the_oracle_chain(gsfm_ctx):
+    """The same chain on a 2 000-camera / 200 000-track scene (fixture tests/golden/chain_2k_oracle.npz)."""
+    r, g, d_ra, st_gp, ang, st_ba = _chain_against_fixture("chain_2k_oracle.npz", 2_000, 200_000, gsfm_ctx)
+    assert d_ra < 1e-6
+    assert st_gp["max"] < 1e-3
+    assert r["observations_kept"] == g["observations_kept"].tolist()
+    assert ang < 1e-4
+    assert st_ba["max"] < 1e-3

@@ -18,7 +18,7 @@ from glomap_amd import synthetic
 from oracle import cpu, gp as ogp
 p = synthetic.make_gp_problem(num_cams=700, num_pts=30000, seed=3)
 ok, c, X, s = cpu.gp_solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated, p.cam_center, p.pt_xyz,
-                           ogp.GlobalPositionerOptions(), pcg_tol=1e-8, threads=2)
+                           ogp.GlobalPositionerOptions(), pcg_tol=1e-12, threads=2)  # the tolerance gp.hip runs with
 np.save(sys.argv[1], c)
 print("RESULT " + json.dumps(dict(ok=bool(ok), lm=int(s.iterations), pcg=int(s.linear_iterations), cost=float(s.final_cost))))
 """

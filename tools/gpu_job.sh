@@ -24,7 +24,7 @@ for step in "$@"; do
     gp_tol)
       timeout 900 python tools/exp_gp_gpu_tolerance.py $arg > $OUT/gp_tol.log 2>&1; tail -40 $OUT/gp_tol.log ;;
     chain)
-      for g in tests/golden/_tmp_chain_2k.npz:2000:200000 tests/golden/chain_c4_oracle.npz:10000:1000000; do
+      for g in tests/golden/chain_2k_oracle.npz:2000:200000 tests/golden/chain_c4_oracle.npz:10000:1000000; do
         IFS=: read f n p <<< "$g"
         [ -f $f ] && timeout 900 python tools/exp_chain_gpu.py $f $n $p $arg >> $OUT/chain.log 2>&1
       done
