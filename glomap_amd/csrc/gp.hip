@@ -2431,7 +2431,9 @@ class GpSolver final : public LmProblem {
         hipLaunchKernelGGL((k_gp_phaseB_x<kXTilesPerWave>), dim3(gridX_), dim3(kBlock), 0, s, x_, vk, (const double*)ws->cz.get(),
                            (const double2*)ws->xq.get(), (const double*)ws->ptrec.get(), ws->wpart.get());
         if (timed) ctx_->prof.end(s);
+        timed = ctx_->prof.begin(s, GSFM_KERNEL_GP_WSUM, it);
         hipLaunchKernelGGL(k_gp_wsum, dim3(gridWsum_), dim3(kBlock), 0, s, x_, Np_, vk, ys, (const double*)ws->wpart.get(), dk);
+        if (timed) ctx_->prof.end(s);
       } else {
         hipLaunchKernelGGL(k_gp_phaseB, dim3(gridCam_), dim3(kBlock), 0, s, g_, vk, ys, ci_, ws->c_qa.get(),
                            ws->c_qb.get(), ws->ptrec.get(), dk, 0);

@@ -113,7 +113,8 @@ enum {
   GSFM_KERNEL_RA_GJ = 5,        /* k_dense_gj_step: one block Gauss-Jordan step of the dense RA inverse (f64 MFMA) */
   GSFM_KERNEL_FILTER_OBS = 6,   /* k_filter_obs: per-observation reprojection / angle test of the track filters */
   GSFM_KERNEL_TRACK_HOOK = 7,   /* k_uf_hook: union-find hooking sweep over the inlier matches (track establishment) */
-  GSFM_KERNEL_COUNT = 8
+  GSFM_KERNEL_GP_WSUM = 8,      /* k_gp_wsum: per-camera fixed-order sum of the chunked sweep's piece partials (second half of the camera side) */
+  GSFM_KERNEL_COUNT = 9
 };
 int gsfm_ctx_profile_enable(gsfm_ctx* ctx, int enable);
 /* Reads and resets the accumulated launch count / total milliseconds of one kernel id. */

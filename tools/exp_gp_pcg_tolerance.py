@@ -52,18 +52,18 @@ def main():
     p = synthetic.make_gp_problem(num_cams=N, num_pts=P, seed=0)
     print(f"cameras {N} tracks {P} observations {p.num_obs}", flush=True)
     ref = None
-    for tol in (1e-14, 1e-8, 1e-6, 1e-4, 1e-3, 1e-2, 1e-1):
+    for tol in (1e-14, 1e-13, 1e-12, 1e-11, 1e-10, 1e-8, 1e-6, 1e-4, 1e-2):
         t0 = time.time()
         ok, c, X, s = cpu.gp_solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated, p.cam_center, p.pt_xyz,
                                    ogp.GlobalPositionerOptions(), pcg_tol=tol)
         sec = time.time() - t0
         if ref is None:
             ref = c
-        extent = np.linalg.norm(ref - ref.mean(0), axis=1).max()
         gt = synthetic.center_errors_after_sim3(c, p.gt_center)
+        # (round 5: this column used to be divided by the extent a second time — center_errors_after_sim3 already is relative)
         print(json.dumps(dict(pcg_tol=tol, ok=bool(ok), lm_iterations=int(s.iterations), accepted=int(s.successful_steps),
-                              final_cost=float(s.final_cost),
-                              max_rel_vs_exact=float(synthetic.center_errors_after_sim3(c, ref).max()),
+                              pcg_iterations=int(s.linear_iterations), final_cost=float(s.final_cost),
+                              vs_exact=synthetic.center_distance_stats(c, ref),
                               median_err_vs_gt=float(np.median(gt)), seconds=round(sec, 1))), flush=True)
 
 

@@ -5,6 +5,7 @@
 #   gp_tol        GP PCG-tolerance sweep against the cached oracle results (tools/exp_gp_gpu_tolerance.py)
 #   chain[:args]  chained RA->GP->BA against the frozen oracle chain(s) (tools/exp_chain_gpu.py)
 #   tests[:expr]  pytest -m gpu (optionally -k expr)
+#   testfiles:a.py:b.py   pytest -m gpu on those files, without -x
 #   bench         python bench.py (default line)
 #   bench_fast    python bench.py --no-extra --no-cpu-baseline
 #   profile       tools/profile_all.sh <tag> (kernel trace + the two PMC passes of the headline workload)
@@ -33,6 +34,9 @@ for step in "$@"; do
       if [ -n "$arg" ]; then timeout 2400 python -m pytest tests -m gpu -x -q -s -k "$arg" > $OUT/tests.log 2>&1
       else timeout 2400 python -m pytest tests -m gpu -x -q -s > $OUT/tests.log 2>&1; fi
       grep "\[parity\]" $OUT/tests.log > $OUT/tests_parity.txt; tail -15 $OUT/tests.log ;;
+    testfiles)   # pytest -m gpu on the given files (colon-separated), every failure reported (no -x)
+      timeout 2400 python -m pytest ${arg//:/ } -m gpu -q -s > $OUT/testfiles.log 2>&1
+      grep "\[parity\]" $OUT/testfiles.log > $OUT/testfiles_parity.txt; grep -E "^(FAILED|ERROR)" $OUT/testfiles.log; tail -5 $OUT/testfiles.log ;;
     bench)
       timeout 1500 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cut -c1-600 $OUT/bench.json; tail -3 $OUT/bench.err ;;
     bench_fast)
