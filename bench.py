@@ -442,6 +442,19 @@ def bench_pipeline(args, ctx, rank, world, barrier, dist):
     ]
     for o in lines:
         o["ms_per_step"] = (o["avg_kernel_us"] or 0.0) * (o["launches"] or 0) * 1e-3
+    # Second bound of the three sweeps whose lanes each fetch one 64-byte record from a table (tools/exp_gather_calib.hip,
+    # profiles/r04_gather_calibration_times.txt): a CU's vector memory path sustains a fixed number of outstanding line
+    # requests, which caps record gathers at ~103 G requests/s chip-wide when the table sits in the L2 (64 KB ... 1 MB windows:
+    # 106.7 / 101.5 G/s) and ~54 G/s when every gather misses it — whatever the record size.  A sweep of M observations cannot
+    # run faster than M / that rate, however few bytes it moves; `frac` (of HBM) alone hides that.
+    for o, req, peak, why in ((lines[2], Mg, 103.0, "(c | z) records, 640 KB table: L2-resident"),
+                              (lines[3], Mg, 103.0 if "phaseB_x" in lines[3]["kernel"] else 54.6,
+                               "point records, chunk windows <= 2.75 MB per XCD" if "phaseB_x" in lines[3]["kernel"] else "point records, no locality: L2 misses"),
+                              (lines[1], Mb, 54.6, "point records, no locality: L2 misses")):
+        if o["avg_kernel_us"]:
+            g = req / (o["avg_kernel_us"] * 1e-6) / 1e9
+            o["gather_bound"] = {"record_gathers_per_launch": req, "achieved_G_per_s": g, "calibrated_peak_G_per_s": peak,
+                                 "frac": g / peak, "table": why, "source": "profiles/r04_gather_calibration_times.txt"}
     # the camera side of a GP iteration in the chunked order is two launches: the sweep and the per-camera sum of its pieces
     wl, wms = ctx.profile_read(KERNEL_GP_WSUM)
     if wl:
@@ -460,6 +473,9 @@ def bench_pipeline(args, ctx, rank, world, barrier, dist):
         "iteration = k_gp_phaseA + k_gp_phaseB[_x + k_gp_wsum] + k_cg_update" % (top["ms_per_step"], med["total"]),
         others=lines[1:])
     roof["ms_per_step"] = top["ms_per_step"]
+    for k in ("gather_bound", "traffic_raw", "frac_of_hbm_on_pmc_bytes"):
+        if k in top:
+            roof[k] = top[k]
     err_ra = synthetic.rotation_errors_deg(so3.aa_to_rotmat(rot.numpy()), p_ra.gt_R)
     err_gp = synthetic.center_errors_after_sim3(res["cen"].numpy(), p_gp.gt_center)
     err_ba = synthetic.rotation_errors_deg(so3.quat_to_rotmat(res["q"].numpy()), so3.quat_to_rotmat(p_ba.gt_q))

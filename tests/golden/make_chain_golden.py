@@ -13,7 +13,7 @@ in a fixed order, so the numbers generated here ARE what the GPU box would compu
 seed (pinned by checksums) and runs the HIP chain; only the oracle's stage results travel (RA rotations, GP centres, the
 observation counts after each filter, final poses).  Reduced systems solved to 1e-14, true residuals recorded.
 
-Usage: python tests/golden/make_chain_golden.py [cams tracks name]"""
+Usage: python tests/golden/make_chain_golden.py [cams tracks name [seed]]"""
 import sys
 import time
 from pathlib import Path
@@ -34,10 +34,12 @@ def scene_checksums(sc):
 
 
 def main():
-    N, P, name = 10_000, 1_000_000, "chain_c4_oracle.npz"
+    N, P, name, seed = 10_000, 1_000_000, "chain_c4_oracle.npz", 0
     if len(sys.argv) > 3:
         N, P, name = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
-    sc = synthetic.make_chained_scene(N, P, seed=0)
+    if len(sys.argv) > 4:
+        seed = int(sys.argv[4])
+    sc = synthetic.make_chained_scene(N, P, seed=seed)
     t0 = time.time()
     r = run_chain(sc, OracleBackend(verbose=True))
     g, b1, b2 = r["rep_gp"], r["rep_ba1"], r["rep_ba2"]
@@ -52,7 +54,7 @@ def main():
     for stage, rep in (("gp", g), ("ba1", b1), ("ba2", b2)):
         for k, v in rep.items():
             out[f"{stage}_{k}"] = v
-    np.savez_compressed(Path(__file__).resolve().parent / name, **out, **scene_checksums(sc))
+    np.savez_compressed(Path(__file__).resolve().parent / name, **out, seed=seed, **scene_checksums(sc))
 
 
 if __name__ == "__main__":

@@ -429,14 +429,14 @@ def test_track_establishment_config3_full(gsfm_ctx):
             assert np.array_equal(a, b)
 
 
-def _chain_against_fixture(name, ncam, npts, ctx):
+def _chain_against_fixture(name, ncam, npts, ctx, seed=0):
     """GPU chain vs the frozen oracle chain (tests/golden/make_chain_golden.py): returns the stage distances."""
     import os
 
     from chain_util import GpuBackend, final_pose_distance, run_chain
 
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", name))
-    sc = synthetic.make_chained_scene(ncam, npts, seed=0)
+    sc = synthetic.make_chained_scene(ncam, npts, seed=seed)
     # same scene as the one the oracle chain ran on (numpy's pairwise sums may group differently on another CPU)
     assert sc.obs_cam.shape[0] == int(g["num_obs"]) and int(np.sum(sc.obs_cam.astype(np.int64))) == int(g["obs_cam_checksum"])
     assert abs(float(np.sum(sc.obs_xy)) / float(g["obs_xy_checksum"]) - 1) < 1e-12
@@ -483,9 +483,14 @@ def test_chain_config4_final_poses_match_the_oracle_chain(gsfm_ctx):
     assert st_ba["max"] < 1e-3
 
 
-def test_chain_2k_final_poses_match_the_oracle_chain(gsfm_ctx):
-    """The same chain on a 2 000-camera / 200 000-track scene (fixture tests/golden/chain_2k_oracle.npz)."""
-    r, g, d_ra, st_gp, ang, st_ba = _chain_against_fixture("chain_2k_oracle.npz", 2_000, 200_000, gsfm_ctx)
+@pytest.mark.parametrize("seed", [0, 1])
+def test_chain_2k_final_poses_match_the_oracle_chain(gsfm_ctx, seed):
+    """The same chain on 2 000-camera / 200 000-track scenes (fixtures tests/golden/chain_2k_oracle.npz, chain_2k_s1_oracle.npz).
+    Seed 2 of this generator is not a fixture: its positions-only BA creeps along the free scale gauge with trust-region radii
+    of 1e8 ... 1e9, where the oracle's own reduced solves break down (true relative residual 5.0 in one LM step) — the
+    situation of DESIGN.md section 2 "BA, one camera shared by all images"; there is no exact reference on that stretch."""
+    name = "chain_2k_oracle.npz" if seed == 0 else f"chain_2k_s{seed}_oracle.npz"
+    r, g, d_ra, st_gp, ang, st_ba = _chain_against_fixture(name, 2_000, 200_000, gsfm_ctx, seed=seed)
     assert d_ra < 1e-6
     assert st_gp["max"] < 1e-3
     assert r["observations_kept"] == g["observations_kept"].tolist()
