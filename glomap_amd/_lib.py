@@ -356,6 +356,8 @@ def load():
                                                   C.c_double, C.c_double, dp]
     lib.gsfm_filter_rotations.restype = ip
     lib.gsfm_filter_rotations.argtypes = [vp, C.c_int32, C.c_int32, vp, C.c_int64, vp, vp, vp, C.c_double, vp, i64p]
+    lib.gsfm_tracks_compact.restype = ip
+    lib.gsfm_tracks_compact.argtypes = [vp, C.c_int32, C.c_int64, C.c_int64, vp, vp, vp, C.c_int32, C.POINTER(vp), C.POINTER(C.c_int32), i64p]
     lib.gsfm_ctx_set_dump_dir.restype = ip
     lib.gsfm_ctx_set_dump_dir.argtypes = [vp, C.c_char_p]
     lib.gsfm_track_options_default.restype = None
@@ -411,6 +413,8 @@ class DeviceArray:
 
     def numpy(self) -> np.ndarray:
         out = np.empty(self.shape, dtype=self.dtype)
+        if self.nbytes == 0:
+            return out
         rc = self.ctx.lib.gsfm_memcpy_d2h(self.ctx.handle, out.ctypes.data, self._ptr, self.nbytes)
         if rc != 0:
             raise GsfmError(rc, "gsfm_memcpy_d2h")
@@ -436,7 +440,19 @@ class DeviceArray:
     def contiguous(self) -> "DeviceArray":
         return self
 
+    def prefix(self, n: int) -> "DeviceArray":
+        """The first n rows as a DeviceArray that shares this one's memory (no copy; this array must outlive the view)."""
+        assert 0 <= n <= self.shape[0]
+        v = DeviceArray.__new__(DeviceArray)
+        v.ctx, v.dtype, v.shape = self.ctx, self.dtype, (int(n),) + self.shape[1:]
+        v.nbytes = int(np.prod(v.shape, dtype=np.int64)) * v.dtype.itemsize
+        v._ptr, v._base = self._ptr, self  # keeps the owner alive
+        return v
+
     def free(self):
+        if getattr(self, "_base", None) is not None:  # a prefix() view does not own its memory
+            self._ptr = None
+            return
         if getattr(self, "_ptr", None) and getattr(self.ctx, "handle", None):
             self.ctx.lib.gsfm_device_free(self.ctx.handle, self._ptr)
         self._ptr = None

@@ -20,6 +20,8 @@
 #include "device.hpp"
 
 namespace gsfm {
+// sort.hip (rocPRIM plumbing, instantiated once there)
+void exclusive_scan_i64(gsfm_ctx* ctx, DevBuf<unsigned char>& tmp, const long* in, long* out, size_t n);
 namespace {
 
 constexpr double kEps = 1e-12;  // glomap/types.h:14
@@ -229,6 +231,8 @@ struct FilterWs {
   DevBuf<float> cen;
   DevBuf<unsigned char> cal, keep, reg;
   DevBuf<unsigned long long> counter;
+  DevBuf<long> cflag, cpos;             // gsfm_tracks_compact: survivor flags and their exclusive scan
+  DevBuf<unsigned char> ctmp, cscan;    // ... scatter target, rocPRIM scratch
   static void destroy(void* p) { delete static_cast<FilterWs*>(p); }
 };
 
@@ -257,7 +261,7 @@ __global__ void __launch_bounds__(kBlock)
   const long stride = (long)gridDim.x * blockDim.x;
   bool err = false;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < M || i <= P || i < N; i += stride) {
-    if (i < M && (cam[i] < 0 || cam[i] >= N)) err = true;
+    if (cam != nullptr && i < M && (cam[i] < 0 || cam[i] >= N)) err = true;
     if (i < P && (off[i] > off[i + 1] || off[i] < 0)) err = true;
     if (i == P && (off[P] != M || off[0] != 0)) err = true;
     if (cam_intr != nullptr && i < N && (cam_intr[i] < 0 || cam_intr[i] >= K)) err = true;
@@ -358,6 +362,32 @@ int filter_obs_impl(gsfm_ctx* ctx, const gsfm_scene_view* view, int mode, double
   return GSFM_OK;
 }
 
+
+// ---- compaction after a filter (gsfm_tracks_compact) ---------------------------------------------------------------
+// flag[k] = 1 when observation k survives its own keep flag and its track's; flag[M] = 0 (the scan's total slot)
+__global__ void __launch_bounds__(kBlock)
+    k_compact_flags(long M, const int* __restrict__ obs_pt, const unsigned char* __restrict__ obs_keep,
+                    const unsigned char* __restrict__ track_keep, long* __restrict__ flag) {
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k <= M; k += (long)gridDim.x * blockDim.x) {
+    long f = 0;
+    if (k < M) f = ((obs_keep == nullptr || obs_keep[k] != 0) && (track_keep == nullptr || track_keep[obs_pt[k]] != 0)) ? 1 : 0;
+    flag[k] = f;
+  }
+}
+// new start of track p = number of surviving observations in front of its old start (pos[M] = total for p = P)
+__global__ void __launch_bounds__(kBlock) k_compact_offsets(long P, const long* __restrict__ pos, long* __restrict__ off) {
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p <= P; p += (long)gridDim.x * blockDim.x) off[p] = pos[off[p]];
+}
+// one thread per (observation, 4-byte word): dst[pos[k]] = src[k] for the survivors
+__global__ void __launch_bounds__(kBlock)
+    k_compact_scatter(long M, int words, const long* __restrict__ flag, const long* __restrict__ pos,
+                      const unsigned* __restrict__ src, unsigned* __restrict__ dst) {
+  const long n = M * words;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long k = i / words;
+    if (flag[k]) dst[pos[k] * words + (i - k * words)] = src[i];
+  }
+}
 }  // namespace
 }  // namespace gsfm
 
@@ -500,6 +530,80 @@ extern "C" int gsfm_filter_rotations(gsfm_ctx* ctx, int32_t mem, int32_t num_nod
     copy_out(ctx, edge_keep_out, ws->keep.get(), (size_t)E, mem);
     const long c = read_counter(ctx, ws);
     if (num_invalid) *num_invalid = c;
+    return (int)GSFM_OK;
+  });
+}
+
+// Compaction after a filter.  The reference erases the dropped observations from Track::observations (track_filter.cc:36-44,
+// 75-83) or clears the list of a whole track (:120-123); in the flat layout the survivors move up, in order.  Device memory
+// stays on the device — only the new observation count is read back — which is what lets the BA outer loop of
+// global_mapper.cc:201-275 (solve, solve, normalise, filter, and again) run without the per-call pack / unpack.
+extern "C" int gsfm_tracks_compact(gsfm_ctx* ctx, int32_t mem, int64_t num_pts, int64_t num_obs, int64_t* pt_offset_inout,
+                                   const uint8_t* obs_keep, const uint8_t* track_keep, int32_t num_arrays,
+                                   void* const* arrays_inout, const int32_t* elem_bytes, int64_t* num_obs_out) {
+  if (!ctx) return GSFM_ERR_INVALID_ARGUMENT;
+  return guarded(ctx, nullptr, [&] {
+    const long P = num_pts, M = num_obs;
+    GSFM_REQUIRE(pt_offset_inout != nullptr && P >= 0 && M >= 0 && num_arrays >= 0 && num_arrays <= 16, "compact: bad argument");
+    GSFM_REQUIRE(num_arrays == 0 || (arrays_inout != nullptr && elem_bytes != nullptr), "compact: null array table");
+    for (int a = 0; a < num_arrays; ++a)
+      GSFM_REQUIRE((arrays_inout[a] != nullptr || M == 0) && elem_bytes[a] > 0 && elem_bytes[a] % 4 == 0,
+                   "compact: per-observation arrays of 4-byte words");
+    long* off = reinterpret_cast<long*>(pt_offset_inout);
+    if (mem != GSFM_MEM_DEVICE) {  // host arrays: a plain loop (nothing here is worth a round trip over PCIe)
+      GSFM_REQUIRE(off[0] == 0 && off[P] == M, "compact: pt_offset does not span the observations");
+      long w = 0;
+      for (long p = 0; p < P; ++p) {
+        const long k0 = off[p], k1 = off[p + 1];
+        GSFM_REQUIRE(k0 <= k1 && k1 <= M, "compact: pt_offset not monotone");
+        off[p] = w;
+        for (long k = k0; k < k1; ++k) {
+          if ((obs_keep != nullptr && obs_keep[k] == 0) || (track_keep != nullptr && track_keep[p] == 0)) continue;
+          if (w != k)
+            for (int a = 0; a < num_arrays; ++a)
+              std::memmove(static_cast<char*>(arrays_inout[a]) + (size_t)w * elem_bytes[a],
+                           static_cast<const char*>(arrays_inout[a]) + (size_t)k * elem_bytes[a], (size_t)elem_bytes[a]);
+          ++w;
+        }
+      }
+      off[P] = w;
+      if (num_obs_out) *num_obs_out = w;
+      return (int)GSFM_OK;
+    }
+    GSFM_HIP_CHECK(hipSetDevice(ctx->device));
+    FilterWs* ws = filter_ws(ctx);
+    hipStream_t s = ctx->stream;
+    // index sanity first: a malformed pt_offset must not become an out-of-bounds scatter
+    ws->counter.ensure(1);
+    GSFM_HIP_CHECK(hipMemsetAsync(ws->counter.get(), 0, sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(k_validate_view, dim3(grid_wide(std::max<long>(M, P + 1), kBlock, 1 << 16)), dim3(kBlock), 0, s, P, M, 1,
+                       (const long*)off, (const int*)nullptr, (const int*)nullptr, 0, ws->counter.get());
+    require_valid(ctx, ws, "compact: pt_offset out of range");
+    long total = 0;
+    if (M > 0) {
+      int* obs_pt = ws->obs_pt.ensure(M + 1);
+      hipLaunchKernelGGL(k_fill_obs_pt, dim3(grid_wide(P, kBlock, 1 << 16)), dim3(kBlock), 0, s, P, (const long*)off, obs_pt);
+      long* flag = ws->cflag.ensure(M + 2);
+      long* pos = ws->cpos.ensure(M + 2);
+      hipLaunchKernelGGL(k_compact_flags, dim3(grid_wide(M + 1, kBlock, 1 << 16)), dim3(kBlock), 0, s, M, (const int*)obs_pt, obs_keep,
+                         track_keep, flag);
+      exclusive_scan_i64(ctx, ws->cscan, flag, pos, (size_t)M + 1);
+      for (int a = 0; a < num_arrays; ++a) {
+        const int words = elem_bytes[a] / 4;
+        unsigned* tmp = reinterpret_cast<unsigned*>(ws->ctmp.ensure((size_t)M * elem_bytes[a] + 16));
+        hipLaunchKernelGGL(k_compact_scatter, dim3(grid_wide(M * words, kBlock, 1 << 16)), dim3(kBlock), 0, s, M, words, (const long*)flag,
+                           (const long*)pos, static_cast<const unsigned*>(arrays_inout[a]), tmp);
+        // (the whole prefix is copied back: its length is known on the device only; the tail beyond the new count is dead)
+        GSFM_HIP_CHECK(hipMemcpyAsync(arrays_inout[a], tmp, (size_t)M * elem_bytes[a], hipMemcpyDeviceToDevice, s));
+      }
+      hipLaunchKernelGGL(k_compact_offsets, dim3(grid_wide(P + 1, kBlock, 1 << 16)), dim3(kBlock), 0, s, P, (const long*)pos, off);
+      long* h = reinterpret_cast<long*>(ctx->h_pinned + 616);
+      GSFM_HIP_CHECK(hipMemcpyAsync(h, pos + M, sizeof(long), hipMemcpyDeviceToHost, s));
+      GSFM_HIP_CHECK(hipStreamSynchronize(s));
+      GSFM_HIP_CHECK(hipGetLastError());
+      total = h[0];
+    }
+    if (num_obs_out) *num_obs_out = total;
     return (int)GSFM_OK;
   });
 }

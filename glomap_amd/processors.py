@@ -105,6 +105,35 @@ class TrackFilter:
         return out, n.value
 
 
+def CompactObservations(pt_offset, arrays, obs_keep=None, track_keep=None, ctx=None):
+    """gsfm_tracks_compact: drops the observations a filter flagged (obs_keep [M] and / or track_keep [P], 0 = drop) from a
+    track-major observation set, IN PLACE — what the reference does by erasing from Track::observations
+    (track_filter.cc:36-44, 75-83, 120-123).  pt_offset [P+1] int64 is rewritten; every array of `arrays` ([M] or [M, k],
+    4- or 8-byte items) is compacted.  numpy arrays (host) or DeviceArrays (HBM, nothing but the new count leaves the
+    device).  Returns (new observation count, [the arrays cut to that length: numpy slices / DeviceArray.prefix views])."""
+    ctx = ctx or default_context()
+    if isinstance(pt_offset, np.ndarray):
+        assert pt_offset.dtype == np.int64 and pt_offset.flags["C_CONTIGUOUS"], "pt_offset is rewritten in place: contiguous int64"
+    off = _h(pt_offset, np.int64)
+    arrs = list(arrays)
+    for a in arrs:
+        if isinstance(a, np.ndarray):
+            assert a.flags["C_CONTIGUOUS"] and a.flags["WRITEABLE"], "compaction is in place: contiguous writable arrays"
+    mem = _mem_of(off, *arrs)
+    ok_, tk_ = _h(obs_keep, np.uint8), _h(track_keep, np.uint8)
+    M = int(arrs[0].shape[0]) if arrs else int(off.numpy()[-1] if not isinstance(off, np.ndarray) else off[-1])
+    P = int(off.shape[0]) - 1
+    nbytes = [int(np.prod(a.shape[1:], dtype=np.int64)) * np.dtype(a.dtype).itemsize for a in arrs]
+    ptrs = (C.c_void_p * max(1, len(arrs)))(*[_lib.ptr(a) for a in arrs])
+    eb = (C.c_int32 * max(1, len(arrs)))(*nbytes)
+    n = C.c_int64(0)
+    rc = ctx.lib.gsfm_tracks_compact(ctx.handle, mem, P, M, _lib.ptr(off), _lib.ptr(ok_), _lib.ptr(tk_), len(arrs), ptrs, eb, C.byref(n))
+    if rc != 0:
+        raise _lib.GsfmError(rc, "gsfm_tracks_compact")
+    cut = [a[: n.value] if isinstance(a, np.ndarray) else a.prefix(n.value) for a in arrs]
+    return n.value, cut
+
+
 def NormalizeReconstruction(cam_q, cam_t, pt_xyz, cam_registered=None, fixed_scale=False, extent=10.0, p0=0.1, p1=0.9,
                             ctx=None):
     """reconstruction_normalizer.cc:5-85.  Returns (cam_t', pt_xyz', (scale, translation[3])); inputs untouched."""

@@ -513,6 +513,17 @@ int gsfm_filter_tracks_by_angle(gsfm_ctx* ctx, const gsfm_scene_view* view, doub
 /* track_keep_out [P]: 0 = the reference clears the track's observations; *tracks_removed counts them. */
 int gsfm_filter_tracks_triangulation_angle(gsfm_ctx* ctx, const gsfm_scene_view* view, double min_angle_deg,
                                            uint8_t* track_keep_out, int64_t* tracks_removed);
+/* Compaction after a filter: the reference erases the dropped observations from Track::observations
+ * (track_filter.cc:36-44, 75-83) or clears a whole track's list (:120-123); in the flat layout the survivors move up, in
+ * order.  Observation k of track p survives when obs_keep[k] != 0 (NULL: all) and track_keep[p] != 0 (NULL: all).
+ * pt_offset_inout [P+1] is rewritten; each of the num_arrays (<= 16) per-observation arrays — elem_bytes[a] bytes per
+ * observation, a multiple of 4: obs_cam 4, obs_xy 16, obs_undist 24, ... — is compacted in place (entries past the new
+ * count are unspecified).  mem == GSFM_MEM_DEVICE: everything stays in HBM, only *num_obs_out crosses PCIe — with the
+ * filters, the normaliser and gsfm_ba_solve on device arrays this keeps the BA outer loop of global_mapper.cc:201-275
+ * device-resident (tests/test_pipeline_gpu.py::test_ba_outer_loop_device_resident). */
+int gsfm_tracks_compact(gsfm_ctx* ctx, int32_t mem, int64_t num_pts, int64_t num_obs, int64_t* pt_offset_inout,
+                        const uint8_t* obs_keep, const uint8_t* track_keep, int32_t num_arrays, void* const* arrays_inout,
+                        const int32_t* elem_bytes, int64_t* num_obs_out);
 /* Robust-bounding-box similarity of the registered camera centres (extent 10, 10-90 percentiles by default);
  * cam_t and pt_xyz are transformed in place, sim3_out = {scale, tx, ty, tz} with X' = scale * X + t. */
 int gsfm_normalize_reconstruction(gsfm_ctx* ctx, int32_t mem, int32_t num_cams, const uint8_t* cam_registered,

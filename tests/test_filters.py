@@ -158,3 +158,64 @@ def test_gpu_filters_reject_malformed_views(gsfm_ctx):
     view = pr.SceneView(p.num_cams, p.pt_offset, p.obs_cam, q, t, X, obs_undist=undist)
     k, c = pr.TrackFilter.FilterTracksByAngle(view, 1.0, ctx=gsfm_ctx)
     assert k.shape[0] == p.num_obs
+
+
+def _compact_reference(off, obs_keep, track_keep, arrays):
+    """What gsfm_tracks_compact has to produce (numpy): survivors in order, new offsets."""
+    lens = np.diff(off)
+    trk = np.repeat(np.arange(len(lens)), lens)
+    keep = np.ones(int(off[-1]), bool)
+    if obs_keep is not None:
+        keep &= obs_keep.astype(bool)
+    if track_keep is not None:
+        keep &= track_keep.astype(bool)[trk]
+    new_off = np.zeros(len(lens) + 1, dtype=np.int64)
+    new_off[1:] = np.cumsum(np.bincount(trk[keep], minlength=len(lens)))
+    return new_off, [a[keep] for a in arrays]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["mixed", "obs_only", "tracks_only", "all_dropped", "none_dropped", "empty"])
+def test_gpu_tracks_compact_matches_numpy(gsfm_ctx, case):
+    """gsfm_tracks_compact (the erase of track_filter.cc:36-44, 75-83, 120-123 in the flat layout), host and device memory,
+    ragged tracks with empty ones among them: offsets and every per-observation array equal to the numpy compaction."""
+    from glomap_amd import _lib
+    from glomap_amd import processors as pr
+
+    rng = np.random.default_rng(7)
+    P = 0 if case == "empty" else 5000
+    lens = rng.integers(0, 9, P)
+    lens[rng.random(P) < 0.1] = 0
+    off = np.zeros(P + 1, dtype=np.int64)
+    off[1:] = np.cumsum(lens)
+    M = int(off[-1])
+    cam = rng.integers(0, 100, M).astype(np.int32)
+    xy = rng.normal(size=(M, 2))
+    und = rng.normal(size=(M, 3))
+    ids = rng.integers(0, 1 << 40, M).astype(np.int64)
+    obs_keep = (rng.random(M) < 0.7).astype(np.uint8)
+    track_keep = (rng.random(P) < 0.8).astype(np.uint8)
+    if case == "obs_only":
+        track_keep = None
+    elif case == "tracks_only":
+        obs_keep = None
+    elif case == "all_dropped":
+        obs_keep[:] = 0
+    elif case == "none_dropped":
+        obs_keep, track_keep = None, np.ones(P, np.uint8)
+    want_off, want = _compact_reference(off, obs_keep, track_keep, [cam, xy, und, ids])
+    # host memory
+    h_off, h_arr = off.copy(), [cam.copy(), xy.copy(), und.copy(), ids.copy()]
+    n, cut = pr.CompactObservations(h_off, h_arr, obs_keep=obs_keep, track_keep=track_keep, ctx=gsfm_ctx)
+    assert n == int(want_off[-1]) and np.array_equal(h_off, want_off)
+    for a, b in zip(cut, want):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    # device memory: nothing but the count comes back until we ask for it
+    if M == 0:
+        return  # zero-byte device allocations are not part of the contract
+    up = lambda a: None if a is None else _lib.DeviceArray.from_numpy(gsfm_ctx, a)  # noqa: E731
+    d_off, d_arr = up(off), [up(cam), up(xy), up(und), up(ids)]
+    n, cut = pr.CompactObservations(d_off, d_arr, obs_keep=up(obs_keep), track_keep=up(track_keep), ctx=gsfm_ctx)
+    assert n == int(want_off[-1]) and np.array_equal(d_off.numpy(), want_off)
+    for a, b in zip(cut, want):
+        assert a.shape == b.shape and np.array_equal(a.numpy(), b)

@@ -13,7 +13,7 @@ reference's own end-to-end tests on synthetic scenes — rotations 1e-2 deg and 
 import numpy as np
 import pytest
 
-from glomap_amd import estimators, processors, so3, synthetic
+from glomap_amd import _lib, estimators, processors, so3, synthetic
 from glomap_amd.flat import BaProblem, GpProblem, RaProblem
 from glomap_amd.tracks import KeepLargestConnectedComponents, MatchGraph, TrackEngine, TrackEstablishmentOptions
 
@@ -33,7 +33,7 @@ def _drop_observations(off, keep, *arrays):
     return (off2, *[a[keep] for a in arrays])
 
 
-def run_pipeline(s, ctx, log=None):
+def run_pipeline(s, ctx, log=None, ba_on_device=False):
     """Returns (registered image mask, R_est [Nr,3,3], centre_est [Nr,3], stats)."""
     N = s["num_images"]
     stats = {}
@@ -103,23 +103,54 @@ def run_pipeline(s, ctx, log=None):
     t, X, _ = processors.NormalizeReconstruction(q, t, X, ctx=ctx)
 
     # ---- 6. bundle adjustment, staged, three rounds (:201-275)
-    intr = s["intr_params"].copy()
-    ci = s["cam_intr"][regb]
-    for ite in range(3):
-        for optimize_rotations in (False, True):
-            ba = BaProblem(num_cams=Nr, num_pts=len(off) - 1, num_intr=len(intr), pt_offset=off, obs_cam=ocam,
-                           obs_xy=s["feat_xy"][ofeat], cam_intr=ci, cam_q=q, cam_t=t, pt_xyz=X, intr_model=s["intr_model"],
-                           intr_params=intr, fixed_cam=0)
-            rc, q, t, X, intr, rep = estimators.ba_solve(ba, estimators.BundleAdjusterOptions(optimize_rotations=optimize_rotations), ctx=ctx)
-            assert rc == 0, rc
-        t, X, _ = processors.NormalizeReconstruction(q, t, X, ctx=ctx)
-        keep, changed = processors.TrackFilter.FilterTracksByReprojection(view(), max(3 - ite, 1) * 1e-2, True, ctx=ctx)
-        apply_obs(keep)
-        stats.setdefault("ba_filtered_tracks", []).append(int(changed))
-    stats["final_cost"] = rep["final_cost"]
+    q, t, X, intr, off, ocam, ofeat, ba_stats = ba_outer_loop(ctx, Nr, off, ocam, ofeat, q, t, X, s["intr_params"].copy(), s["cam_intr"][regb],
+                                                              s["intr_model"], s["feat_xy"], s["feat_undist"], device=ba_on_device)
+    stats.update(ba_stats)
     stats["observations"] = int(len(ocam))
     Rf = so3.quat_to_rotmat(q)
     return regb, Rf, -np.einsum("nji,nj->ni", Rf, t), stats
+
+
+def ba_outer_loop(ctx, Nr, off, ocam, ofeat, q, t, X, intr, ci, intr_model, feat_xy, feat_undist, device):
+    """[BundleAdjuster positions-only, BundleAdjuster full, NormalizeReconstruction, FilterTracksByReprojection] x 3
+    (global_mapper.cc:201-275).
+
+    device = False: every call takes host arrays (the library stages them, solves, copies back) and the dropped observations
+    are removed with numpy — the per-call pack / unpack pattern of the C++ adapter.
+    device = True : the state is uploaded ONCE; bundle adjustment, normaliser and filter run on DeviceArrays, the filter's keep
+    mask stays in HBM and gsfm_tracks_compact removes the dropped observations there (processors.CompactObservations); one
+    download at the end.  Same kernels on the same numbers in the same order: the two must agree bit for bit."""
+    stats = {}
+    xy = np.ascontiguousarray(feat_xy[ofeat])
+    und = np.ascontiguousarray(feat_undist[ofeat])
+    ofeat = np.ascontiguousarray(ofeat, dtype=np.int64)
+    if device:
+        up = lambda a: _lib.DeviceArray.from_numpy(ctx, np.ascontiguousarray(a))  # noqa: E731
+        off, ocam, xy, und, ofeat_d = up(off.astype(np.int64)), up(ocam.astype(np.int32)), up(xy), up(und), up(ofeat)
+        q, t, X, intr_d, ci_d, model_d = up(q), up(t), up(X), up(intr), up(ci.astype(np.int32)), up(intr_model.astype(np.int32))
+    else:
+        ofeat_d, intr_d, ci_d, model_d = ofeat, intr, ci, intr_model
+    P = int(off.shape[0]) - 1
+    rep = None
+    for ite in range(3):
+        for optimize_rotations in (False, True):
+            ba = BaProblem(num_cams=Nr, num_pts=P, num_intr=int(intr_d.shape[0]), pt_offset=off, obs_cam=ocam, obs_xy=xy, cam_intr=ci_d,
+                           cam_q=q, cam_t=t, pt_xyz=X, intr_model=model_d, intr_params=intr_d, fixed_cam=0)
+            rc, q, t, X, intr_d, rep = estimators.ba_solve(ba, estimators.BundleAdjusterOptions(optimize_rotations=optimize_rotations), ctx=ctx)
+            assert rc == 0, rc
+        t, X, _ = processors.NormalizeReconstruction(q, t, X, ctx=ctx)
+        view = processors.SceneView(Nr, off, ocam, q, t, X, obs_undist=und)
+        keep, changed = processors.TrackFilter.FilterTracksByReprojection(view, max(3 - ite, 1) * 1e-2, True, ctx=ctx)
+        if device:
+            assert isinstance(keep, _lib.DeviceArray)  # the mask never leaves the device
+            n, (ocam, xy, und, ofeat_d) = processors.CompactObservations(off, [ocam, xy, und, ofeat_d], obs_keep=keep, ctx=ctx)
+        else:
+            off, ocam, xy, und, ofeat_d = _drop_observations(off, np.asarray(keep, bool), ocam, xy, und, ofeat_d)
+        stats.setdefault("ba_filtered_tracks", []).append(int(changed))
+    stats["final_cost"] = rep["final_cost"]
+    if device:
+        q, t, X, intr_d, off, ocam, ofeat_d = (a.numpy() for a in (q, t, X, intr_d, off, ocam, ofeat_d))
+    return q, t, X, intr_d, off, ocam, ofeat_d, stats
 
 
 @pytest.mark.gpu
@@ -152,3 +183,18 @@ def test_pipeline_with_noise_outliers_and_a_stray_component(gsfm_ctx):
     print(rot_err.max(), cen_err.max())
     assert rot_err.max() < 0.1
     assert cen_err.max() < 1e-2
+
+
+@pytest.mark.gpu
+def test_ba_outer_loop_device_resident(gsfm_ctx):
+    """The BA outer loop of GlobalMapper::Solve (global_mapper.cc:201-275: solve, solve, normalise, filter, three rounds) with
+    the whole state resident in HBM — one upload, DeviceArray problems, the filter's keep mask consumed on the device by
+    gsfm_tracks_compact, one download — against the same loop through host arrays: identical poses, points, intrinsics and
+    surviving observations, bit for bit ("keeping poses/points device-resident across the BA outer loop")."""
+    s = synthetic.make_pipeline_scene(40, 1500, seed=1, pixel_noise=0.5, rot_outlier_pairs=6, false_match_frac=2e-4, isolated_pair=True)
+    regb_h, R_h, C_h, st_h = run_pipeline(s, gsfm_ctx, ba_on_device=False)
+    regb_d, R_d, C_d, st_d = run_pipeline(s, gsfm_ctx, ba_on_device=True)
+    assert np.array_equal(regb_h, regb_d)
+    assert st_h["ba_filtered_tracks"] == st_d["ba_filtered_tracks"] and sum(st_h["ba_filtered_tracks"]) > 0  # the filter did drop something
+    assert st_h["observations"] == st_d["observations"] and st_h["final_cost"] == st_d["final_cost"]
+    assert np.array_equal(R_h, R_d) and np.array_equal(C_h, C_d)
