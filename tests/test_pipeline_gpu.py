@@ -33,7 +33,7 @@ def _drop_observations(off, keep, *arrays):
     return (off2, *[a[keep] for a in arrays])
 
 
-def run_pipeline(s, ctx, log=None, ba_on_device=False):
+def run_pipeline(s, ctx, log=None, ba_on_device=False, ba_max_reprojection_error=1e-2):
     """Returns (registered image mask, R_est [Nr,3,3], centre_est [Nr,3], stats)."""
     N = s["num_images"]
     stats = {}
@@ -104,14 +104,15 @@ def run_pipeline(s, ctx, log=None, ba_on_device=False):
 
     # ---- 6. bundle adjustment, staged, three rounds (:201-275)
     q, t, X, intr, off, ocam, ofeat, ba_stats = ba_outer_loop(ctx, Nr, off, ocam, ofeat, q, t, X, s["intr_params"].copy(), s["cam_intr"][regb],
-                                                              s["intr_model"], s["feat_xy"], s["feat_undist"], device=ba_on_device)
+                                                              s["intr_model"], s["feat_xy"], s["feat_undist"], device=ba_on_device,
+                                                              max_reprojection_error=ba_max_reprojection_error)
     stats.update(ba_stats)
     stats["observations"] = int(len(ocam))
     Rf = so3.quat_to_rotmat(q)
     return regb, Rf, -np.einsum("nji,nj->ni", Rf, t), stats
 
 
-def ba_outer_loop(ctx, Nr, off, ocam, ofeat, q, t, X, intr, ci, intr_model, feat_xy, feat_undist, device):
+def ba_outer_loop(ctx, Nr, off, ocam, ofeat, q, t, X, intr, ci, intr_model, feat_xy, feat_undist, device, max_reprojection_error=1e-2):
     """[BundleAdjuster positions-only, BundleAdjuster full, NormalizeReconstruction, FilterTracksByReprojection] x 3
     (global_mapper.cc:201-275).
 
@@ -140,7 +141,7 @@ def ba_outer_loop(ctx, Nr, off, ocam, ofeat, q, t, X, intr, ci, intr_model, feat
             assert rc == 0, rc
         t, X, _ = processors.NormalizeReconstruction(q, t, X, ctx=ctx)
         view = processors.SceneView(Nr, off, ocam, q, t, X, obs_undist=und)
-        keep, changed = processors.TrackFilter.FilterTracksByReprojection(view, max(3 - ite, 1) * 1e-2, True, ctx=ctx)
+        keep, changed = processors.TrackFilter.FilterTracksByReprojection(view, max(3 - ite, 1) * max_reprojection_error, True, ctx=ctx)
         if device:
             assert isinstance(keep, _lib.DeviceArray)  # the mask never leaves the device
             n, (ocam, xy, und, ofeat_d) = processors.CompactObservations(off, [ocam, xy, und, ofeat_d], obs_keep=keep, ctx=ctx)
@@ -192,9 +193,13 @@ def test_ba_outer_loop_device_resident(gsfm_ctx):
     gsfm_tracks_compact, one download — against the same loop through host arrays: identical poses, points, intrinsics and
     surviving observations, bit for bit ("keeping poses/points device-resident across the BA outer loop")."""
     s = synthetic.make_pipeline_scene(40, 1500, seed=1, pixel_noise=0.5, rot_outlier_pairs=6, false_match_frac=2e-4, isolated_pair=True)
-    regb_h, R_h, C_h, st_h = run_pipeline(s, gsfm_ctx, ba_on_device=False)
-    regb_d, R_d, C_d, st_d = run_pipeline(s, gsfm_ctx, ba_on_device=True)
+    # a threshold of 1.5 sigma of the pixel noise (0.5 px / f = 1200) in the last round: every round of the loop drops
+    # observations, so the compaction has work to do (the reference's 1e-2 drops nothing on this scene)
+    kw = dict(ba_max_reprojection_error=6e-4)
+    regb_h, R_h, C_h, st_h = run_pipeline(s, gsfm_ctx, ba_on_device=False, **kw)
+    regb_d, R_d, C_d, st_d = run_pipeline(s, gsfm_ctx, ba_on_device=True, **kw)
     assert np.array_equal(regb_h, regb_d)
-    assert st_h["ba_filtered_tracks"] == st_d["ba_filtered_tracks"] and sum(st_h["ba_filtered_tracks"]) > 0  # the filter did drop something
+    print(st_h["ba_filtered_tracks"], st_h["observations"])
+    assert st_h["ba_filtered_tracks"] == st_d["ba_filtered_tracks"] and min(st_h["ba_filtered_tracks"]) > 0  # every round dropped something
     assert st_h["observations"] == st_d["observations"] and st_h["final_cost"] == st_d["final_cost"]
     assert np.array_equal(R_h, R_d) and np.array_equal(C_h, C_d)
