@@ -8,6 +8,7 @@
 #   testfiles:a.py:b.py   pytest -m gpu on those files, without -x
 #   bench         python bench.py (default line)
 #   bench_fast    python bench.py --no-extra --no-cpu-baseline
+#   multirank:2:4 bench.py --gpus N, N ranks sharing this device (peer transport)
 #   profile       tools/profile_all.sh <tag> (kernel trace + the two PMC passes of the headline workload)
 #   py:<script>   python <script> (arguments after further colons)
 set -u
@@ -41,6 +42,13 @@ for step in "$@"; do
       timeout 1500 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cut -c1-600 $OUT/bench.json; tail -3 $OUT/bench.err ;;
     bench_fast)
       timeout 600 python bench.py --no-extra --no-cpu-baseline $arg > $OUT/bench_fast.json 2> $OUT/bench_fast.err; cut -c1-1500 $OUT/bench_fast.json; tail -3 $OUT/bench_fast.err ;;
+    multirank)   # bench.py --gpus N with all N ranks on this one device (control flow + numerics of the N > 1 path, not speed)
+      for n in ${arg//:/ }; do
+        GSFM_BENCH_SINGLE_DEVICE=1 GSFM_BENCH_TRANSPORT=peer timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n \
+          --master-addr 127.0.0.1 --master-port $((29500 + n)) bench.py --gpus $n --steps 2 --warmup 1 --no-extra --no-cpu-baseline \
+          > $OUT/multirank_$n.log 2>&1
+        grep "\"metric\"" $OUT/multirank_$n.log >> $OUT/bench_gpus_N_on_one_device.jsonl; tail -2 $OUT/multirank_$n.log | cut -c1-400
+      done ;;
     profile)
       bash tools/profile_all.sh $TAG/prof pipeline_c4 > $OUT/profile.log 2>&1; tail -5 $OUT/profile.log ;;
     py)
