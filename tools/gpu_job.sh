@@ -33,7 +33,7 @@ for step in "$@"; do
       tail -20 $OUT/chain.log ;;
     tests)
       if [ -n "$arg" ]; then timeout 2400 python -m pytest tests -m gpu -x -q -s -k "$arg" > $OUT/tests.log 2>&1
-      else timeout 2400 python -m pytest tests -m gpu -x -q -s > $OUT/tests.log 2>&1; fi
+      else timeout 2400 python -m pytest tests -m gpu -x -q -s --durations=14 > $OUT/tests.log 2>&1; fi
       grep "\[parity\]" $OUT/tests.log > $OUT/tests_parity.txt; tail -15 $OUT/tests.log ;;
     testfiles)   # pytest -m gpu on the given files (colon-separated), every failure reported (no -x)
       timeout 2400 python -m pytest ${arg//:/ } -m gpu -q -s > $OUT/testfiles.log 2>&1
