@@ -13,6 +13,7 @@ iterations per stage for a few variants:
   interface    block inverses + an exact Schur complement on the nodes that couple the blocks (substructuring) as
                preconditioner, abs stopping rule
   interface-stale   the same, factored ONCE for the unit-weight Laplacian of the L1 stage and kept for the IRLS weights
+  coarse<m>    block inverses + an additive piecewise-constant coarse space over aggregates of m BFS-consecutive nodes (round 5)
   abs+deflate  as abs, with the constant vector (the global rotation, held by the gauge row alone) deflated from the PCG
 
 and reports, against `exact`, the largest difference of the resulting rotations.
@@ -63,6 +64,20 @@ class Laplacian:
         for b, Bi in zip(self.blocks, self.inv):
             out[b] = Bi.astype(np.float64) @ R[b]
         return out
+
+    def factor_coarse(self, agg):
+        """Two-level additive: block inverses + a piecewise-constant coarse space over aggregates of `agg` consecutive nodes
+        of the BFS order (aggregation AMG's tentative prolongator): M^-1 = blockdiag^-1 + W (W^T L W)^-1 W^T."""
+        self.factor_blocks()
+        self.agg_of = np.empty(self.N, dtype=np.int64)
+        self.agg_of[self.order] = np.arange(self.N) // agg
+        self.nagg = int(self.agg_of.max()) + 1
+        W = sp.csr_matrix((np.ones(self.N), (np.arange(self.N), self.agg_of)), shape=(self.N, self.nagg))
+        self.W = W
+        self.Einv = np.linalg.inv((W.T @ self.L @ W).toarray())
+
+    def apply_coarse(self, R):
+        return self.apply_blocks(R) + self.W @ (self.Einv @ (self.W.T @ R))
 
     def factor_interface(self):
         """Substructuring: I = nodes all of whose neighbours are in their own block, B = the rest."""
@@ -157,6 +172,8 @@ class Solver:
             self.lu = spla.splu(self.lap.L.tocsc())
         elif self.variant.startswith("interface"):
             self.lap.factor_interface()
+        elif self.variant.startswith("coarse"):
+            self.lap.factor_coarse(int(self.variant[6:] or 32))
         else:
             self.lap.factor_blocks()
         self.factorizations += 1
@@ -165,7 +182,7 @@ class Solver:
         lap = self.lap
         if self.variant == "exact":
             return self.lu.solve(B)
-        precond = lap.apply_interface if self.variant.startswith("interface") else lap.apply_blocks
+        precond = lap.apply_interface if self.variant.startswith("interface") else (lap.apply_coarse if self.variant.startswith("coarse") else lap.apply_blocks)
         bb = float((B * B).sum())
         X0 = np.zeros_like(B) if X_warm is None else X_warm
         keep = None
