@@ -1265,8 +1265,11 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// (the lean instance with two free intrinsics columns takes 272 registers left alone = ONE wave per SIMD; bounded to 256 it
+// spills 18 and runs 375 -> 286 us at configs[3]: profiles/r05_ab_small_experiments.txt.  The same medicine made
+// k_gp_build_cam<LIN, AW> (169 -> 162, third wave) and k_ba_lin_track (172 -> 162, third wave) SLOWER: 374 -> 404, 487 -> 510 us.)
 template <bool ROT, bool WIDE, int F>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, (!WIDE && F <= 2) ? 2 : 1)
     k_ba_aw_modes(BaDev g, double yscale, const double* __restrict__ camR, const double* __restrict__ t,
                   const double* __restrict__ par, const double* __restrict__ c_w, const double* __restrict__ ptb,
                   const double* __restrict__ ftab, const double* __restrict__ dvec, const double* __restrict__ W,
