@@ -74,16 +74,16 @@ def test_gp_end_point_is_stationary_for_an_independent_optimizer():
     assert abs(cost_star - summ.final_cost) <= 1e-6 * max(summ.final_cost, 1e-12)
     # (1) nothing to improve at the oracle's point
     kw = dict(bounds=(lo, np.inf), method="trf", loss="huber", f_scale=a, jac="3-point", xtol=1e-15, ftol=1e-15, gtol=1e-15)
-    r0 = least_squares(fun, x_star, max_nfev=400, **kw)
+    r0 = least_squares(fun, x_star, max_nfev=40, **kw)
     assert r0.cost <= cost_star * (1 + 1e-12)
     assert cost_star - r0.cost <= 1e-7 * cost_star, (cost_star, r0.cost)
     # (2) and a perturbed point has a visibly higher cost that SciPy brings most of the way back (trust-region reflective on
     #     |r| residuals converges slowly — the norm is not smooth at 0 — so this is a direction check, not a convergence test)
     rng = np.random.default_rng(0)
-    x1 = x_star + np.concatenate([rng.normal(0, 1e-3, 3 * N + 3 * P), np.zeros(M - 1)])
+    x1 = x_star + np.concatenate([rng.normal(0, 3e-3, 3 * N + 3 * P), np.zeros(M - 1)])
     cost1 = _huber_cost(fun(x1), a)
     assert cost1 > 1.5 * cost_star
-    r1 = least_squares(fun, np.maximum(x1, lo + 1e-9), max_nfev=150, **kw)
+    r1 = least_squares(fun, np.maximum(x1, lo + 1e-9), max_nfev=60, **kw)
     assert cost_star * (1 - 1e-9) <= r1.cost < cost_star + 0.05 * (cost1 - cost_star), (cost_star, cost1, r1.cost)
 
 
@@ -139,13 +139,13 @@ def test_ba_end_point_is_stationary_for_an_independent_optimizer():
     scale = np.concatenate([np.full(3 * (N - 1), 1e-3), np.full(3 * (N - 1), 1.0), np.full(3 * P, 1.0), np.tile([100.0, 1e-2], N)])
     kw = dict(method="trf", loss="huber", f_scale=a, jac="3-point", x_scale=scale, xtol=1e-15, ftol=1e-15, gtol=1e-15)
     # (1) nothing to improve at the oracle's point (the scale gauge is free: a flat direction, not a descent direction)
-    r0 = least_squares(fun, x_star, max_nfev=100, **kw)
+    r0 = least_squares(fun, x_star, max_nfev=30, **kw)
     assert r0.cost <= cost_star * (1 + 1e-12)
     assert cost_star - r0.cost <= 1e-7 * cost_star, (cost_star, r0.cost)
     # (2) from a perturbed start SciPy reaches the same cost, and the same cameras up to the free scale about the fixed camera
     rng = np.random.default_rng(1)
     x1 = x_star + rng.normal(0, 1.0, x_star.shape) * scale * 1e-2
-    r1 = least_squares(fun, x1, max_nfev=3000, **kw)
+    r1 = least_squares(fun, x1, max_nfev=400, **kw)
     assert abs(r1.cost - cost_star) <= 1e-6 * cost_star, (cost_star, r1.cost)
     free = np.array([n for n in range(N) if n != p.fixed_cam])
     R1 = R0.copy()
