@@ -1,0 +1,5 @@
+#pragma once
+// shadows glomap/scene/types_sfm.h: the stand-in types, then the REFERENCE'S view_graph.h (struct ViewGraph) on top of them
+#include "ref_shim_types.h"
+
+#include "glomap/scene/view_graph.h"

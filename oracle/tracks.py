@@ -27,6 +27,12 @@ path):
 Everything else (the partition into tracks, which tracks are discarded, lengths, the selected set given
 the ids) is order-independent and reproduced exactly.
 
+PINNED TO REFERENCE CODE (round 5): track_establishment.cc and view_graph.cc are pure container / integer logic and compile
+in this image — `make -C oracle ref` builds them FROM /root/reference, unmodified, against the stand-in scene types of
+oracle/ref_shim/ into oracle/_ref/libref_glomap.so (oracle/ref_glue.cc, oracle/ref.py), and tests/test_oracle_ref.py holds
+both restatements of this file to it: same partition, same discarded count, same selection for every option combination,
+same largest component and pair flags.  (Still restated, not compiled: colmap::UnionFind, above.)
+
 Only tests/, smoke() and bench.py's cpu_baseline leg may import this module."""
 from __future__ import annotations
 
