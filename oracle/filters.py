@@ -7,7 +7,12 @@
   RelPoseFilter::FilterRotations              glomap/processors/relpose_filter.cc:7-33
 
 Flat arrays as in include/gsfm.h (gsfm_scene_view).  Only tests/, smoke() and bench.py's cpu_baseline leg
-may import this module."""
+may import this module.
+
+PINNED TO REFERENCE CODE (round 5): the three .cc files above compile in this image against the stand-in types of
+oracle/ref_shim/ (`make -C oracle ref` -> oracle/_ref/libref_glomap.so, from /root/reference, unmodified); tests/test_oracle_ref.py
+holds every function of this file to them — keep masks and counters bit for bit, the normaliser's scale and translation bit
+for bit."""
 from __future__ import annotations
 
 import numpy as np

@@ -97,3 +97,59 @@ def find_tracks_for_problem(num_images, image_registered, track_id, track_offset
                                         int(min_num_view_per_track), int(max_num_view_per_track), int(max_num_tracks), _p(sel), _p(kept))
     assert n >= 0
     return sel.astype(bool), kept[: len(oi)].astype(bool), int(n)
+
+
+def _load_processors():
+    lib = load()
+    if lib is not None and not getattr(lib, "_proc_ready", False):
+        vp, ip, lp, d = C.c_void_p, C.c_int, C.c_long, C.c_double
+        lib.ref_filter_tracks.restype = ip
+        lib.ref_filter_tracks.argtypes = [ip, ip, vp, vp, vp, lp, vp, vp, vp, vp, d, vp]
+        lib.ref_normalize_reconstruction.restype = ip
+        lib.ref_normalize_reconstruction.argtypes = [ip, vp, vp, vp, lp, vp, ip, d, d, d, vp]
+        lib._proc_ready = True
+    return lib
+
+
+def filter_tracks(mode, cam_q, cam_t, pt_offset, obs_cam, obs_undist, pt_xyz, threshold, cam_calibrated=None):
+    """TrackFilter::FilterTracksByReprojection (mode 0, normalised image coordinates) / FilterTracksByAngle (1) /
+    FilterTrackTriangulationAngle (2), track_filter.cc:7-127, trivial frames.  Returns (keep [M] bool: the observation is still
+    in its track, the reference's return value = tracks changed / removed)."""
+    lib = _load_processors()
+    q, t = np.ascontiguousarray(cam_q, dtype=np.float64), np.ascontiguousarray(cam_t, dtype=np.float64)
+    off, oc = np.ascontiguousarray(pt_offset, dtype=np.int64), np.ascontiguousarray(obs_cam, dtype=np.int32)
+    und = None if obs_undist is None else np.ascontiguousarray(obs_undist, dtype=np.float64)
+    X = np.ascontiguousarray(pt_xyz, dtype=np.float64)
+    cal = None if cam_calibrated is None else np.ascontiguousarray(cam_calibrated, dtype=np.uint8)
+    keep = np.zeros(max(1, len(oc)), dtype=np.uint8)
+    n = lib.ref_filter_tracks(int(mode), len(q), _p(q), _p(t), _p(cal), len(off) - 1, _p(off), _p(oc), _p(und), _p(X), float(threshold), _p(keep))
+    assert n >= 0
+    return keep[: len(oc)].astype(bool), int(n)
+
+
+def normalize_reconstruction(cam_q, cam_t, pt_xyz, cam_registered=None, fixed_scale=False, extent=10.0, p0=0.1, p1=0.9):
+    """NormalizeReconstruction (reconstruction_normalizer.cc:5-85).  Returns (cam_t', pt_xyz', (scale, translation))."""
+    lib = _load_processors()
+    q = np.ascontiguousarray(cam_q, dtype=np.float64)
+    t = np.array(cam_t, dtype=np.float64, order="C", copy=True)
+    X = np.array(pt_xyz, dtype=np.float64, order="C", copy=True)
+    reg = None if cam_registered is None else np.ascontiguousarray(cam_registered, dtype=np.uint8)
+    sim = np.zeros(4)
+    rc = lib.ref_normalize_reconstruction(len(q), _p(q), _p(t), _p(reg), len(X), _p(X), int(fixed_scale), float(extent), float(p0), float(p1), _p(sim))
+    assert rc == 0
+    return t, X, (float(sim[0]), sim[1:].copy())
+
+
+def filter_rotations(node_q, edge_i, edge_j, edge_q, max_angle_deg, node_registered=None, edge_valid=None):
+    """RelPoseFilter::FilterRotations (relpose_filter.cc:7-33).  Returns (edge_valid' [E] bool, number invalidated)."""
+    lib = _load_processors()
+    if not getattr(lib, "_rot_ready", False):
+        lib.ref_filter_rotations.restype = C.c_long
+        lib.ref_filter_rotations.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+        lib._rot_ready = True
+    nq, eq = np.ascontiguousarray(node_q, dtype=np.float64), np.ascontiguousarray(edge_q, dtype=np.float64)
+    ei, ej = np.ascontiguousarray(edge_i, dtype=np.int32), np.ascontiguousarray(edge_j, dtype=np.int32)
+    reg = None if node_registered is None else np.ascontiguousarray(node_registered, dtype=np.uint8)
+    ev = np.ones(len(ei), dtype=np.uint8) if edge_valid is None else np.ascontiguousarray(edge_valid, dtype=np.uint8).copy()
+    n = lib.ref_filter_rotations(len(nq), _p(nq), _p(reg), len(ei), _p(ei), _p(ej), _p(eq), float(max_angle_deg), _p(ev))
+    return ev.astype(bool), int(n)

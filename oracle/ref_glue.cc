@@ -4,12 +4,18 @@
 //   ViewGraph::KeepLargestConnectedComponents      glomap/scene/view_graph.cc:56-97
 //   TrackEngine::EstablishFullTracks               glomap/controllers/track_establishment.cc:5-152
 //   TrackEngine::FindTracksForProblem              glomap/controllers/track_establishment.cc:154-227
+//   TrackFilter::FilterTracksByReprojection / ByAngle / FilterTrackTriangulationAngle   glomap/processors/track_filter.cc:7-127
+//   NormalizeReconstruction                        glomap/processors/reconstruction_normalizer.cc:5-85
+//   RelPoseFilter::FilterRotations                 glomap/processors/relpose_filter.cc:7-33
 // and flattens the results.  Images are indices 0..N-1 (= image ids), frames indices 0..F-1.
 #include <algorithm>
 #include <cstring>
 #include <sstream>
 
 #include "glomap/controllers/track_establishment.h"
+#include "glomap/processors/reconstruction_normalizer.h"
+#include "glomap/processors/relpose_filter.h"
+#include "glomap/processors/track_filter.h"
 #include "glomap/scene/types_sfm.h"
 
 using namespace glomap;
@@ -163,3 +169,122 @@ long ref_find_tracks_for_problem(int num_images, const uint8_t* image_registered
 }
 
 }  // extern "C"
+
+namespace {
+// cameras with poses (trivial frames: image i = frame i = camera i), tracks from the flat CSR; returns the obs -> slot map
+void make_posed_scene(Scene& s, std::unordered_map<camera_t, Camera>& cameras, std::unordered_map<track_t, Track>& tracks, int num_cams,
+                      const double* cam_q, const double* cam_t, const uint8_t* cam_calibrated, const uint8_t* cam_registered,
+                      long num_pts, const long* pt_offset, const int32_t* obs_cam, const double* obs_undist, const double* pt_xyz) {
+  make_images(s, num_cams, nullptr, cam_registered, num_cams);
+  for (int n = 0; n < num_cams; ++n) {
+    Frame& f = s.frames.at(n);
+    f.has_pose = true;
+    f.rig_from_world.rotation = Eigen::Quaterniond(cam_q[4 * n], cam_q[4 * n + 1], cam_q[4 * n + 2], cam_q[4 * n + 3]);
+    f.rig_from_world.translation = Eigen::Vector3d(cam_t[3 * n], cam_t[3 * n + 1], cam_t[3 * n + 2]);
+    s.images.at(n).camera_id = n;
+    cameras[n].has_prior_focal_length = cam_calibrated ? cam_calibrated[n] != 0 : true;
+  }
+  for (long p = 0; p < num_pts; ++p) {
+    Track tr;
+    tr.track_id = p;
+    tr.xyz = Eigen::Vector3d(pt_xyz[3 * p], pt_xyz[3 * p + 1], pt_xyz[3 * p + 2]);
+    for (long k = pt_offset[p]; k < pt_offset[p + 1]; ++k) {
+      Image& im = s.images.at(obs_cam[k]);
+      // the observation's feature id = its slot in the image's feature list (unique per observation: the keep mask is per slot)
+      const feature_t fid = static_cast<feature_t>(im.features_undist.size());
+      if (obs_undist) im.features_undist.emplace_back(obs_undist[3 * k], obs_undist[3 * k + 1], obs_undist[3 * k + 2]);
+      else im.features_undist.emplace_back(0.0, 0.0, 1.0);
+      tr.observations.emplace_back(static_cast<image_t>(obs_cam[k]), fid);
+    }
+    tracks.emplace(static_cast<track_t>(p), std::move(tr));
+  }
+}
+}  // namespace
+
+extern "C" {
+
+// mode 0: FilterTracksByReprojection (normalised image coordinates), 1: FilterTracksByAngle, 2: FilterTrackTriangulationAngle.
+// obs_keep_out [M]: 1 = the observation is still in its track afterwards.  Returns the reference's return value (tracks changed).
+int ref_filter_tracks(int mode, int num_cams, const double* cam_q, const double* cam_t, const uint8_t* cam_calibrated, long num_pts,
+                      const long* pt_offset, const int32_t* obs_cam, const double* obs_undist, const double* pt_xyz, double threshold,
+                      uint8_t* obs_keep_out) {
+  QuietCout quiet;
+  Scene s;
+  std::unordered_map<camera_t, Camera> cameras;
+  std::unordered_map<track_t, Track> tracks;
+  make_posed_scene(s, cameras, tracks, num_cams, cam_q, cam_t, cam_calibrated, nullptr, num_pts, pt_offset, obs_cam, obs_undist, pt_xyz);
+  // remember every observation's (image, feature) to find it again afterwards
+  std::vector<std::pair<image_t, feature_t>> key(static_cast<size_t>(pt_offset[num_pts]));
+  for (long p = 0; p < num_pts; ++p) {
+    const Track& tr = tracks.at(p);
+    for (long k = pt_offset[p]; k < pt_offset[p + 1]; ++k) key[k] = tr.observations[k - pt_offset[p]];
+  }
+  int counter = 0;
+  if (mode == 0) counter = TrackFilter::FilterTracksByReprojection(s.vg, cameras, s.images, tracks, threshold, true);
+  else if (mode == 1) counter = TrackFilter::FilterTracksByAngle(s.vg, cameras, s.images, tracks, threshold);
+  else counter = TrackFilter::FilterTrackTriangulationAngle(s.vg, s.images, tracks, threshold);
+  for (long p = 0; p < num_pts; ++p) {
+    const Track& tr = tracks.at(p);
+    size_t j = 0;  // the filters keep a subsequence
+    for (long k = pt_offset[p]; k < pt_offset[p + 1]; ++k) {
+      const bool kept = j < tr.observations.size() && tr.observations[j] == key[k];
+      obs_keep_out[k] = kept ? 1 : 0;
+      if (kept) ++j;
+    }
+    if (j != tr.observations.size()) return -1;
+  }
+  return counter;
+}
+
+// NormalizeReconstruction: cam_t [N][3] and pt_xyz [P][3] transformed in place, sim3_out = {scale, tx, ty, tz}.
+int ref_normalize_reconstruction(int num_cams, const double* cam_q, double* cam_t_inout, const uint8_t* cam_registered, long num_pts,
+                                 double* pt_xyz_inout, int fixed_scale, double extent, double p0, double p1, double* sim3_out) {
+  QuietCout quiet;
+  Scene s;
+  std::unordered_map<camera_t, Camera> cameras;
+  std::unordered_map<track_t, Track> tracks;
+  std::unordered_map<rig_t, Rig> rigs;
+  std::vector<long> off(static_cast<size_t>(num_pts) + 1, 0);
+  make_posed_scene(s, cameras, tracks, num_cams, cam_q, cam_t_inout, nullptr, cam_registered, num_pts, off.data(), nullptr, nullptr, pt_xyz_inout);
+  const colmap::Sim3d t = NormalizeReconstruction(rigs, cameras, s.frames, s.images, tracks, fixed_scale != 0, extent, p0, p1);
+  for (int n = 0; n < num_cams; ++n)
+    for (int j = 0; j < 3; ++j) cam_t_inout[3 * n + j] = s.frames.at(n).rig_from_world.translation(j);
+  for (long p = 0; p < num_pts; ++p)
+    for (int j = 0; j < 3; ++j) pt_xyz_inout[3 * p + j] = tracks.at(p).xyz(j);
+  sim3_out[0] = t.scale;
+  for (int j = 0; j < 3; ++j) sim3_out[1 + j] = t.translation(j);
+  return 0;
+}
+
+}  // extern "C"
+
+// RelPoseFilter::FilterRotations: node_q [N][4] cam_from_world rotations (w, x, y, z), edge_q [E][4] cam2_from_cam1;
+// edge_valid_inout [E].  Returns the number of pairs the reference invalidated.
+extern "C" long ref_filter_rotations(int num_nodes, const double* node_q, const uint8_t* node_registered, long num_edges, const int32_t* edge_i,
+                                     const int32_t* edge_j, const double* edge_q, double max_angle_deg, uint8_t* edge_valid_inout) {
+  QuietCout quiet;
+  Scene s;
+  make_images(s, num_nodes, nullptr, node_registered, num_nodes);
+  for (int n = 0; n < num_nodes; ++n) {
+    Frame& f = s.frames.at(n);
+    f.has_pose = true;
+    f.rig_from_world.rotation = Eigen::Quaterniond(node_q[4 * n], node_q[4 * n + 1], node_q[4 * n + 2], node_q[4 * n + 3]);
+  }
+  long before = 0;
+  for (long e = 0; e < num_edges; ++e) {
+    ImagePair p;
+    p.image_id1 = edge_i[e];
+    p.image_id2 = edge_j[e];
+    p.is_valid = edge_valid_inout[e] != 0;
+    before += p.is_valid ? 1 : 0;
+    p.cam2_from_cam1.rotation = Eigen::Quaterniond(edge_q[4 * e], edge_q[4 * e + 1], edge_q[4 * e + 2], edge_q[4 * e + 3]);
+    s.vg.image_pairs.emplace(static_cast<image_pair_t>(e), p);
+  }
+  RelPoseFilter::FilterRotations(s.vg, s.images, max_angle_deg);
+  long after = 0;
+  for (long e = 0; e < num_edges; ++e) {
+    edge_valid_inout[e] = s.vg.image_pairs.at(static_cast<image_pair_t>(e)).is_valid ? 1 : 0;
+    after += edge_valid_inout[e];
+  }
+  return before - after;
+}

@@ -3,7 +3,8 @@
 // GLOMAP's containers live in headers that pull in Eigen, COLMAP and glog, none of which exist in this image, so the
 // reference cannot be built as a whole.  Two of its translation units, though, are pure container /
 // integer logic — glomap/scene/view_graph.cc (connected components) and glomap/controllers/track_establishment.cc (union-find
-// track building and the greedy selection) — and touch their types through a handful of members only.  This header declares
+// track building and the greedy selection) — and two more are decision logic over three-vectors — glomap/processors/
+// track_filter.cc and reconstruction_normalizer.cc; they touch their types through a handful of members only.  This header declares
 // exactly those members, with the reference's names and semantics (cited per member), so that `oracle/Makefile ref` can compile
 // the two .cc files FROM /root/reference, unmodified, against it.  Nothing here is reference code; the logic under test is.
 // The reference's own view_graph.h and track_establishment.h ARE used (struct ViewGraph, class TrackEngine): -I order puts
@@ -16,6 +17,8 @@
 #include <functional>
 #include <iostream>
 #include <limits>
+#include <map>
+#include <optional>
 #include <queue>
 #include <unordered_map>
 #include <unordered_set>
@@ -23,12 +26,59 @@
 #include <vector>
 
 namespace Eigen {
-struct Vector2d {  // what TrackCollection needs: (a - b).norm()   (track_establishment.cc:127-128)
+// Arithmetic stand-ins: the handful of Eigen expressions the four translation units use, in plain doubles evaluated left
+// to right as written (no expression templates; the reference's own operation ORDER is in its source files, not here).
+struct Vector2d {  // (a - b).norm(), a / s   (track_establishment.cc:127-128, track_filter.cc:26-37)
   double x = 0.0, y = 0.0;
   Vector2d() = default;
   Vector2d(double a, double b) : x(a), y(b) {}
+  static Vector2d Zero() { return Vector2d(); }
   Vector2d operator-(const Vector2d& o) const { return Vector2d(x - o.x, y - o.y); }
+  Vector2d operator/(double s) const { return Vector2d(x / s, y / s); }
   double norm() const { return std::sqrt(x * x + y * y); }
+};
+struct Vector3d {
+  double v[3] = {0.0, 0.0, 0.0};
+  Vector3d() = default;
+  Vector3d(double a, double b, double c) : v{a, b, c} {}
+  static Vector3d Zero() { return Vector3d(); }
+  double& operator()(int i) { return v[i]; }
+  const double& operator()(int i) const { return v[i]; }
+  Vector2d head(int /*2*/) const { return Vector2d(v[0], v[1]); }
+  Vector3d operator-(const Vector3d& o) const { return Vector3d(v[0] - o.v[0], v[1] - o.v[1], v[2] - o.v[2]); }
+  Vector3d operator+(const Vector3d& o) const { return Vector3d(v[0] + o.v[0], v[1] + o.v[1], v[2] + o.v[2]); }
+  Vector3d operator-() const { return Vector3d(-v[0], -v[1], -v[2]); }
+  Vector3d operator*(double s) const { return Vector3d(v[0] * s, v[1] * s, v[2] * s); }
+  Vector3d& operator*=(double s) { v[0] *= s; v[1] *= s; v[2] *= s; return *this; }
+  Vector3d& operator/=(double s) { v[0] /= s; v[1] /= s; v[2] /= s; return *this; }
+  double dot(const Vector3d& o) const { return v[0] * o.v[0] + v[1] * o.v[1] + v[2] * o.v[2]; }
+  double norm() const { return std::sqrt(dot(*this)); }
+  Vector3d normalized() const { const double n = norm(); return Vector3d(v[0] / n, v[1] / n, v[2] / n); }
+};
+inline Vector3d operator*(double s, const Vector3d& a) { return a * s; }
+struct Quaterniond {  // (w, x, y, z); q * v = R(q) v
+  double w_ = 1.0, x_ = 0.0, y_ = 0.0, z_ = 0.0;
+  Quaterniond() = default;
+  Quaterniond(double w, double x, double y, double z) : w_(w), x_(x), y_(y), z_(z) {}
+  static Quaterniond Identity() { return Quaterniond(); }
+  Quaterniond inverse() const { return Quaterniond(w_, -x_, -y_, -z_); }  // unit quaternions
+  Quaterniond conjugate() const { return Quaterniond(w_, -x_, -y_, -z_); }
+  Quaterniond operator*(const Quaterniond& b) const {  // Hamilton product
+    return Quaterniond(w_ * b.w_ - x_ * b.x_ - y_ * b.y_ - z_ * b.z_, w_ * b.x_ + x_ * b.w_ + y_ * b.z_ - z_ * b.y_,
+                       w_ * b.y_ - x_ * b.z_ + y_ * b.w_ + z_ * b.x_, w_ * b.z_ + x_ * b.y_ - y_ * b.x_ + z_ * b.w_);
+  }
+  // Eigen/src/Geometry/Quaternion.h: d = *this * other.conjugate(); 2 * atan2(d.vec().norm(), abs(d.w()))
+  double angularDistance(const Quaterniond& other) const {
+    const Quaterniond d = (*this) * other.conjugate();
+    return 2.0 * std::atan2(std::sqrt(d.x_ * d.x_ + d.y_ * d.y_ + d.z_ * d.z_), std::fabs(d.w_));
+  }
+  Vector3d operator*(const Vector3d& p) const {
+    const double w = w_, x = x_, y = y_, z = z_;
+    const double r00 = 1 - 2 * (y * y + z * z), r01 = 2 * (x * y - w * z), r02 = 2 * (x * z + w * y);
+    const double r10 = 2 * (x * y + w * z), r11 = 1 - 2 * (x * x + z * z), r12 = 2 * (y * z - w * x);
+    const double r20 = 2 * (x * z - w * y), r21 = 2 * (y * z + w * x), r22 = 1 - 2 * (x * x + y * y);
+    return Vector3d(r00 * p(0) + r01 * p(1) + r02 * p(2), r10 * p(0) + r11 * p(1) + r12 * p(2), r20 * p(0) + r21 * p(1) + r22 * p(2));
+  }
 };
 struct MatrixXi {  // ImagePair::matches: (row, col) access and rows()   (image_pair.h:46-47, track_establishment.cc:36-47)
   std::vector<int> d;
@@ -47,25 +97,78 @@ typedef uint32_t feature_t;     // scene/types.h:35
 typedef uint64_t track_t;       // scene/types.h:40
 using Observation = std::pair<image_t, feature_t>;  // scene/track.h:9
 
-struct Frame {  // scene/frame.h:29-42: the two flags the view-graph code writes
+constexpr double EPS = 1e-12;  // glomap/types.h:14
+// glomap/math/rigid3d.cc:29-31 (that file needs Eigen::AngleAxis and cannot be compiled here): degree * EIGEN_PI / 180, and
+// EIGEN_PI is a long double literal (Eigen/src/Core/util/Macros.h), so the product is formed in extended precision
+#define REF_SHIM_EIGEN_PI 3.141592653589793238462643383279502884197169399375105820974944592307816406L
+inline double DegToRad(double degree) { return degree * REF_SHIM_EIGEN_PI / 180; }
+inline double RadToDeg(double radian) { return radian * 180 / REF_SHIM_EIGEN_PI; }
+
+struct Rigid3d {  // colmap/geometry/rigid3.h: x_b = rotation * x_a + translation
+  Eigen::Quaterniond rotation;
+  Eigen::Vector3d translation;
+};
+inline Eigen::Vector3d operator*(const Rigid3d& t, const Eigen::Vector3d& x) { return t.rotation * x + t.translation; }
+inline Rigid3d operator*(const Rigid3d& c_from_b, const Rigid3d& b_from_a) {  // colmap/geometry/rigid3.h: composition
+  Rigid3d out;
+  out.rotation = c_from_b.rotation * b_from_a.rotation;
+  out.translation = c_from_b.translation + (c_from_b.rotation * b_from_a.translation);
+  return out;
+}
+inline Rigid3d Inverse(const Rigid3d& b_from_a) {  // colmap/geometry/rigid3.h
+  Rigid3d out;
+  out.rotation = b_from_a.rotation.inverse();
+  out.translation = out.rotation * -b_from_a.translation;
+  return out;
+}
+inline double CalcAngle(const Rigid3d& pose1, const Rigid3d& pose2) {  // glomap/math/rigid3d.cc:7-9
+  return pose1.rotation.angularDistance(pose2.rotation) * 180 / REF_SHIM_EIGEN_PI;
+}
+
+struct sensor_t {  // only what Rig's map needs
+  int type = 0;
+  uint32_t id = 0;
+  bool operator<(const sensor_t& o) const { return type != o.type ? type < o.type : id < o.id; }
+};
+struct Rig {  // colmap/sensor/rig.h: the two calls of reconstruction_normalizer.cc:64-72
+  std::map<sensor_t, std::optional<Rigid3d>> sensors;
+  std::map<sensor_t, std::optional<Rigid3d>>& NonRefSensors() { return sensors; }
+  void SetSensorFromRig(const sensor_t& s, const Rigid3d& t) { sensors[s] = t; }
+};
+struct Camera {  // colmap::Camera + scene/camera.h: the two members the filters read
+  bool has_prior_focal_length = true;
+  std::optional<Eigen::Vector2d> ImgFromCam(const Eigen::Vector3d&) const { return std::nullopt; }  // pixel branch: not exercised
+};
+struct Frame {  // scene/frame.h:29-42 + colmap::Frame: flags, pose
   bool is_registered = false;
   int cluster_id = -1;
+  bool has_pose = false;
+  Rigid3d rig_from_world;
+  bool HasPose() const { return has_pose; }
+  Rigid3d& RigFromWorld() { return rig_from_world; }
+  const Rigid3d& RigFromWorld() const { return rig_from_world; }
 };
-struct Image {  // scene/image.h:10-53
+struct Image {  // scene/image.h:10-53 (trivial frames: cam_from_world = the frame's rig_from_world)
   image_t image_id = 0;
+  camera_t camera_id = 0;
   frame_t frame_id = 0;
   Frame* frame_ptr = nullptr;
   std::vector<Eigen::Vector2d> features;
+  std::vector<Eigen::Vector3d> features_undist;
   bool IsRegistered() const { return frame_ptr != nullptr && frame_ptr->is_registered; }  // image.h:65-67
+  Rigid3d CamFromWorld() const { return frame_ptr->RigFromWorld(); }                          // image.h:60-63
+  Eigen::Vector3d Center() const { return CamFromWorld().rotation.inverse() * -CamFromWorld().translation; }  // image.h:55-57
 };
 struct ImagePair {  // scene/image_pair.h:13-57
   image_t image_id1 = 0, image_id2 = 0;
   bool is_valid = true;
+  Rigid3d cam2_from_cam1;
   std::vector<int> inliers;
   Eigen::MatrixXi matches;
 };
 struct Track {  // scene/track.h:12-27
   track_t track_id = 0;
+  Eigen::Vector3d xyz;
   std::vector<Observation> observations;
 };
 }  // namespace glomap

@@ -133,3 +133,88 @@ def test_find_tracks_for_problem_equals_the_reference(kw):
             want[int(tid[t])] = list(zip(img[k].tolist(), ft[k].tolist()))
         got = {int(s_tid[j]): list(zip(s_img[s_off[j] : s_off[j + 1]].tolist(), s_ft[s_off[j] : s_off[j + 1]].tolist())) for j in range(len(s_tid))}
         assert got == want
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the processors between the solves: track_filter.cc, reconstruction_normalizer.cc
+# ---------------------------------------------------------------------------------------------------------------
+def _posed_scene(seed, ncam=40, npts=3000, noise=2e-3, outliers=0.05):
+    from glomap_amd import so3
+
+    p = synthetic.make_gp_problem(ncam, npts, seed=seed, dir_noise=noise, outlier_ratio=outliers)
+    q = so3.rotmat_to_quat(p.cam_R)
+    t = -np.einsum("nij,nj->ni", p.cam_R, p.gt_center)
+    undist = np.einsum("mij,mj->mi", p.cam_R[p.obs_cam], p.obs_dir)  # world rays -> camera rays
+    rng = np.random.default_rng(seed)
+    X = p.gt_xyz + rng.normal(0, 0.02, p.gt_xyz.shape)
+    X[rng.random(npts) < 0.02] *= 400.0  # a few far points: no triangulation angle left
+    X[rng.random(npts) < 0.01] *= -1.0   # and a few behind most of their cameras
+    return p, q, t, undist, X
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_track_filters_equal_the_reference(seed):
+    """Keep masks and counters of the three filters, bit for bit, against the reference's own track_filter.cc (compiled against
+    the stand-in vector types of oracle/ref_shim: every dot product / norm it takes is evaluated in plain doubles in the order
+    its source writes them).  csrc/filters.hip is bit-exact against oracle/filters.py on the GPU (tests/test_filters.py)."""
+    from oracle import filters as of
+
+    p, q, t, undist, X = _posed_scene(seed)
+    cal = (np.random.default_rng(seed).random(p.num_cams) > 0.3).astype(np.uint8)
+    for thr in (1e-2, 2e-3):
+        k_r, c_r = ref.filter_tracks(0, q, t, p.pt_offset, p.obs_cam, undist, X, thr)
+        k_o, c_o = of.filter_tracks_by_reprojection(p.pt_offset, p.obs_cam, q, t, X, thr, True, obs_undist=undist)
+        assert np.array_equal(k_r, k_o) and c_r == c_o and 0 < c_r < p.num_pts
+    for ang in (1.0, 0.2):
+        k_r, c_r = ref.filter_tracks(1, q, t, p.pt_offset, p.obs_cam, undist, X, ang, cam_calibrated=cal)
+        k_o, c_o = of.filter_tracks_by_angle(p.pt_offset, p.obs_cam, q, t, X, undist, ang, cam_calibrated=cal)
+        assert np.array_equal(k_r, k_o) and c_r == c_o and 0 < c_r < p.num_pts
+    for ang in (1.0, 5.0):
+        k_r, c_r = ref.filter_tracks(2, q, t, p.pt_offset, p.obs_cam, None, X, ang)
+        for fn in (of.filter_tracks_triangulation_angle, of.filter_tracks_triangulation_angle_grouped):
+            tk_o, c_o = fn(p.pt_offset, p.obs_cam, q, t, X, ang)
+            # the reference clears the observation list of a removed track; an EMPTY track has no pair either: removed as well
+            assert c_r == c_o > 0
+            assert np.array_equal(k_r, np.repeat(tk_o, np.diff(p.pt_offset)))
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+@pytest.mark.parametrize("kw", [dict(), dict(fixed_scale=True), dict(extent=3.0, p0=0.2, p1=0.7)])
+def test_normalize_reconstruction_equals_the_reference(seed, kw):
+    """The robust bounding box of reconstruction_normalizer.cc — float copies of the registered centres, one sort per axis, the
+    p0 / p1 order statistics, the mean accumulated over the sorted floats in order — and the similarity built from it."""
+    from oracle import filters as of
+
+    p, q, t, undist, X = _posed_scene(seed, ncam=37 + seed)
+    reg = (np.random.default_rng(10 + seed).random(p.num_cams) > 0.2).astype(np.uint8)
+    t_r, X_r, (s_r, tr_r) = ref.normalize_reconstruction(q, t, X, cam_registered=reg, **kw)
+    t_o, X_o, (s_o, tr_o) = of.normalize_reconstruction(q, t, X, cam_registered=reg, **kw)
+    assert s_r == s_o and np.array_equal(tr_r, tr_o)  # the selection logic: bit for bit
+    assert np.abs(t_r - t_o).max() <= 1e-12 * (1 + np.abs(t_o).max()) and np.abs(X_r - X_o).max() <= 1e-12 * (1 + np.abs(X_o).max())
+    # three cameras or fewer: the whole range (reconstruction_normalizer.cc:35-38)
+    t_r, X_r, (s_r, tr_r) = ref.normalize_reconstruction(q[:3], t[:3], X[:10], **kw)
+    t_o, X_o, (s_o, tr_o) = of.normalize_reconstruction(q[:3], t[:3], X[:10], **kw)
+    assert s_r == s_o and np.array_equal(tr_r, tr_o)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+@pytest.mark.parametrize("max_angle", [5.0, 10.0, 1.5])
+def test_filter_rotations_equals_the_reference(seed, max_angle):
+    """RelPoseFilter::FilterRotations, relpose_filter.cc:7-33: the reference measures the angle as Eigen's
+    Quaternion::angularDistance (2 atan2(|vec|, |w|)), the oracle through the trace of the rotation matrix — two formulas for
+    the same angle, so the keep masks are compared (identical on these graphs) and the angles are not."""
+    from glomap_amd import so3
+    from oracle import filters as of
+
+    g = synthetic.make_ring_view_graph(300, 10, seed=seed, noise_deg=2.0, outlier_ratio=0.1)
+    nq = so3.rotmat_to_quat(g.gt_R)
+    ev_r, n_r = ref.filter_rotations(nq, g.edge_i, g.edge_j, g.edge_q, max_angle)
+    keep_o, n_o = of.filter_rotations(nq, g.edge_i, g.edge_j, g.edge_q, max_angle)
+    assert n_r == n_o > 0 and np.array_equal(ev_r, keep_o)
+    # pairs with an unregistered image and pairs that are already invalid are left alone (:13-21)
+    reg = np.ones(300, np.uint8)
+    reg[::9] = 0
+    ev0 = (np.random.default_rng(seed).random(len(g.edge_i)) > 0.2).astype(np.uint8)
+    ev_r, n_r = ref.filter_rotations(nq, g.edge_i, g.edge_j, g.edge_q, max_angle, node_registered=reg, edge_valid=ev0)
+    touch = ev0.astype(bool) & reg[g.edge_i].astype(bool) & reg[g.edge_j].astype(bool)
+    assert np.array_equal(ev_r, np.where(touch, keep_o, ev0.astype(bool)))
