@@ -490,7 +490,8 @@ def _chain_against_fixture(name, ncam, npts, ctx, seed=0):
     return r, g, d_ra, st_gp, ang, st_ba
 
 
-def test_chain_config4_final_poses_match_the_oracle_chain(gsfm_ctx):
+@pytest.mark.parametrize("seed", [0, 1])
+def test_chain_config4_final_poses_match_the_oracle_chain(gsfm_ctx, seed):
     """north_star's bar is on the FINAL camera poses: rotation averaging -> global positioning (bearings oriented by the
     rotations RA returned, random start) -> the three track filters and the normalisation -> bundle adjustment (positions
     only, then with rotations; started from GP's centres and points), chained on ONE configs[3]-size scene as
@@ -500,7 +501,8 @@ def test_chain_config4_final_poses_match_the_oracle_chain(gsfm_ctx):
     RA's gauge and BA's constant frame in both chains), camera centres <= 1e-3 of the scene extent after Sim(3) alignment
     (BA inherits the scale the normaliser set).  The filters are integer decisions: the kept-observation counts must agree
     exactly after each of the three."""
-    r, g, d_ra, st_gp, ang, st_ba = _chain_against_fixture("chain_c4_oracle.npz", 10_000, 1_000_000, gsfm_ctx)
+    name = "chain_c4_oracle.npz" if seed == 0 else f"chain_c4_s{seed}_oracle.npz"  # two scenes
+    r, g, d_ra, st_gp, ang, st_ba = _chain_against_fixture(name, 10_000, 1_000_000, gsfm_ctx, seed=seed)
     assert (r["rep_ra"]["l1"], r["rep_ra"]["irls"]) == (int(g["ra_l1"]), int(g["ra_irls"]))
     assert d_ra < 1e-6
     assert st_gp["max"] < 1e-3
