@@ -130,6 +130,7 @@ class GpOptions(C.Structure):
         ("seed", C.c_uint32),
         ("constraint_type", C.c_int32),
         ("constraint_reweight_scale", C.c_double),
+        ("rand_vector_order", C.c_int32),
     ]
 
 

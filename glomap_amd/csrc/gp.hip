@@ -1857,7 +1857,20 @@ class GpSolver final : public LmProblem {
       if (used_after > 0) rng.discard(6ull * (unsigned long long)used_after);  // the higher ranks' tracks
     }
     // ParameterizeVariables, gp.cc:442-456: the centres to estimate start at RandVector3d(-1, 1), after every other draw
-    for (int k = 0; k < 3 * S_; ++k) h_c[3 * (size_t)N_ + k] = rng.uniform_pm1();
+    if (opt_.optimize_positions)
+      for (int k = 0; k < 3 * S_; ++k) h_c[3 * (size_t)N_ + k] = rng.uniform_pm1();
+    if (opt_.rand_vector_order == 1) {
+      // RandVector3d evaluates its three draws as constructor ARGUMENTS (gp.cc:12-19): unspecified order in C++, right to left
+      // with g++ — the first draw of a vector is its z.  Same stream, same vectors drawn: x and z of every drawn vector swap.
+      if (opt_.generate_random_positions && opt_.optimize_positions)
+        for (int n = 0; n < N_; ++n)
+          if (constrained[n]) std::swap(h_c[3 * (size_t)n], h_c[3 * (size_t)n + 2]);
+      if (opt_.generate_random_points && opt_.optimize_points && with_points_)
+        for (long p = 0; p < P_; ++p)
+          if (h_off[p + 1] - h_off[p] >= opt_.min_num_view_per_track) std::swap(h_X[3 * (size_t)p], h_X[3 * (size_t)p + 2]);
+      if (opt_.optimize_positions)
+        for (int k = 0; k < S_; ++k) std::swap(h_c[3 * (size_t)(N_ + k)], h_c[3 * (size_t)(N_ + k) + 2]);
+    }
     const double ts2 = now_seconds();
     if (trace) fprintf(stderr, "[gsfm gp setup] obs graph + copies %.2f ms, random start %.2f ms\n", (ts1 - ts0) * 1e3, (ts2 - ts1) * 1e3);
     GSFM_HIP_CHECK(hipMemcpyAsync(ws->c.ensure(3 * (size_t)Np_), h_c.data(), 3 * (size_t)Np_ * sizeof(double), hipMemcpyHostToDevice, s));
@@ -2599,6 +2612,7 @@ extern "C" void gsfm_gp_options_default(gsfm_gp_options* o) {
   o->seed = 1;
   o->constraint_type = 0;
   o->constraint_reweight_scale = 1.0;  // global_positioning.h:40-41
+  o->rand_vector_order = 0;            // first draw -> x (include/gsfm.h)
 }
 
 extern "C" int gsfm_gp_solve(gsfm_ctx* ctx, const gsfm_gp_problem* prob, const gsfm_gp_options* opt,
@@ -2641,6 +2655,7 @@ extern "C" int gsfm_gp_solve(gsfm_ctx* ctx, const gsfm_gp_problem* prob, const g
     GSFM_DUMP_OPT(dump, opt, seed);
     GSFM_DUMP_OPT(dump, opt, constraint_type);
     GSFM_DUMP_OPT(dump, opt, constraint_reweight_scale);
+    GSFM_DUMP_OPT(dump, opt, rand_vector_order);
     if (opt->constraint_type != 0 && prob->num_pairs > 0 && prob->pair_i && prob->pair_j && prob->pair_dir) {
       dump.array("pair_i", prob->pair_i, {(int64_t)prob->num_pairs}, prob->mem);
       dump.array("pair_j", prob->pair_j, {(int64_t)prob->num_pairs}, prob->mem);

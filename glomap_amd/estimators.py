@@ -122,6 +122,8 @@ class GlobalPositionerOptions:
     constraint_type: int = 0  # ONLY_POINTS, 1 = ONLY_CAMERAS, 2 = POINTS_AND_CAMERAS_BALANCED, 3 = POINTS_AND_CAMERAS
     constraint_reweight_scale: float = 1.0  # POINTS_AND_CAMERAS_BALANCED only (global_positioning.h:40-41)
     thres_loss_function: float = 1e-1
+    # first of the three draws of a random start vector -> x (0: clang-built reference) or -> z (1: g++-built); include/gsfm.h
+    rand_vector_order: int = 0
     solver_options: SolverOptions = field(default_factory=lambda: SolverOptions(max_num_iterations=100, pcg_relative_tolerance=1e-12))
 
     def to_c(self) -> _lib.GpOptions:
@@ -129,7 +131,7 @@ class GlobalPositionerOptions:
         _lib.load().gsfm_gp_options_default(C.byref(o))
         for name in (
             "generate_random_positions generate_random_points generate_scales optimize_positions "
-            "optimize_points optimize_scales min_num_view_per_track seed constraint_type"
+            "optimize_points optimize_scales min_num_view_per_track seed constraint_type rand_vector_order"
         ).split():
             setattr(o, name, int(getattr(self, name)))
         o.thres_loss_function = self.thres_loss_function

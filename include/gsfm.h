@@ -341,6 +341,12 @@ typedef struct gsfm_gp_options {
                                         trivial frames and one rank */
   double constraint_reweight_scale;  /* 1.0; POINTS_AND_CAMERAS_BALANCED only: the point-to-camera losses are scaled by
                                         constraint_reweight_scale * num_pairs / num_pts (gp.cc:223-255) */
+  int32_t rand_vector_order;         /* Which coordinate of a random start vector takes the FIRST of its three draws.  The reference
+                                        writes Eigen::Vector3d(dist(gen), dist(gen), dist(gen)) (gp.cc:12-19): C++ leaves the evaluation
+                                        order of the three arguments unspecified, and compilers differ — clang evaluates left to right
+                                        (first draw -> x), g++ right to left (first draw -> z).  0 (default) = x, y, z; 1 = z, y, x.
+                                        Found in round 5 by compiling the reference's own builder with g++ (oracle/_ref,
+                                        tests/test_oracle_ref.py); the C++ adapter picks the order of the compiler it is built with. */
 } gsfm_gp_options;
 
 void gsfm_gp_options_default(gsfm_gp_options* opt);

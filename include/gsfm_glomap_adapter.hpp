@@ -869,6 +869,13 @@ class GlobalPositioner {
     // POINTS_AND_CAMERAS_BALANCED weighs the point losses by reweight * #pairs / tracks.size() — every track, not only the
     // packed ones (gp.cc:220-233); the library divides by the tracks it is given
     o.constraint_reweight_scale = options_.constraint_reweight_scale * (tracks.empty() ? 1.0 : static_cast<double>(P) / static_cast<double>(tracks.size()));
+    // RandVector3d's three draws are constructor arguments (gp.cc:12-19): the compiler that builds GLOMAP decides their order,
+    // so the drop-in follows the compiler that builds THIS header (g++: right to left, the first draw is z)
+#if defined(__GNUC__) && !defined(__clang__)
+    o.rand_vector_order = 1;
+#else
+    o.rand_vector_order = 0;
+#endif
     gsfm_gp_problem pr{};
     pr.mem = GSFM_MEM_HOST;
     pr.num_cams = N;

@@ -44,6 +44,10 @@ class GlobalPositionerOptions:
     thres_loss_function: float = 1e-1
     constraint_type: int = 0  # ONLY_POINTS, ONLY_CAMERAS, POINTS_AND_CAMERAS_BALANCED, POINTS_AND_CAMERAS (global_positioning.h:11-20)
     constraint_reweight_scale: float = 1.0  # only for POINTS_AND_CAMERAS_BALANCED
+    # RandVector3d (gp.cc:12-19) evaluates its three draws as constructor arguments — unspecified order in C++: 0 = left to
+    # right (clang: first draw -> x), 1 = right to left (g++: first draw -> z).  Found by compiling the reference's builder
+    # with g++ (oracle/_ref, tests/test_oracle_ref.py).
+    rand_vector_order: int = 0
     lm: lm.LmOptions = field(default_factory=lambda: lm.LmOptions(max_num_iterations=100))
 
 
@@ -262,16 +266,16 @@ def solve(num_cams, pt_offset, obs_cam, obs_dir, obs_calibrated, cam_center, pt_
     k = 0
     if opt.generate_random_positions and opt.optimize_positions:
         nc = int(constrained.sum())
-        c[constrained] = 100.0 * u[: 3 * nc].reshape(nc, 3)
+        c[constrained] = 100.0 * u[: 3 * nc].reshape(nc, 3)[:, ::(-1 if opt.rand_vector_order == 1 else 1)]
         k = 3 * nc
     X = X_all[used].copy() if with_points else np.zeros((0, 3))
     if opt.generate_random_points and opt.optimize_points and with_points:
-        X = 100.0 * u[k : k + 3 * P].reshape(P, 3)
+        X = 100.0 * u[k : k + 3 * P].reshape(P, 3)[:, ::(-1 if opt.rand_vector_order == 1 else 1)]
         k += 3 * P
     if S:
         cs = np.array(sensor_center, dtype=np.float64, copy=True).reshape(S, 3)
         if opt.optimize_positions:  # ParameterizeVariables, gp.cc:442-456: RandVector3d(-1, 1), after every other draw
-            cs = u[k : k + 3 * S].reshape(S, 3).copy()
+            cs = u[k : k + 3 * S].reshape(S, 3)[:, ::(-1 if opt.rand_vector_order == 1 else 1)].copy()
         c = np.concatenate([c, cs])
     s = np.ones(M)
     if not opt.generate_scales:

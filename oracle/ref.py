@@ -153,3 +153,67 @@ def filter_rotations(node_q, edge_i, edge_j, edge_q, max_angle_deg, node_registe
     ev = np.ones(len(ei), dtype=np.uint8) if edge_valid is None else np.ascontiguousarray(edge_valid, dtype=np.uint8).copy()
     n = lib.ref_filter_rotations(len(nq), _p(nq), _p(reg), len(ei), _p(ei), _p(ej), _p(eq), float(max_angle_deg), _p(ev))
     return ev.astype(bool), int(n)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the reference's global positioning PROBLEM BUILDER (global_positioning.cc + cost_function.h) on a recording Ceres
+# ---------------------------------------------------------------------------------------------------------------
+LIB_GP = HERE / "_ref" / "libref_glomap_gp.so"
+_lib_gp = None
+
+
+class _GpOptions(C.Structure):
+    _fields_ = [("generate_random_positions", C.c_int), ("generate_random_points", C.c_int), ("generate_scales", C.c_int),
+                ("optimize_positions", C.c_int), ("optimize_points", C.c_int), ("optimize_scales", C.c_int),
+                ("min_num_view_per_track", C.c_int), ("seed", C.c_uint), ("constraint_type", C.c_int),
+                ("constraint_reweight_scale", C.c_double), ("thres_loss_function", C.c_double)]
+
+
+def load_gp():
+    global _lib_gp
+    if _lib_gp is None:
+        load()  # (runs `make ref` where the reference tree exists)
+        if LIB_GP.exists():
+            _lib_gp = C.CDLL(str(LIB_GP))
+            _lib_gp.ref_gp_build.restype = C.c_long
+    return _lib_gp
+
+
+def gp_build(cam_q, cam_t, pt_offset, obs_cam, obs_undist, pt_xyz, cam_calibrated=None, cam_registered=None, pt_initialized=None,
+             pair_i=None, pair_j=None, pair_valid=None, pair_t=None, **options):
+    """GlobalPositioner::Solve of the reference with a Ceres that records instead of minimising (global_positioning.cc:28-93).
+    Returns a dict: frame_order / track_order (the reference's container walks = its draw order), center_start [N,3] and
+    xyz_start [P,3] (the start point handed to Ceres), cam_t_after [N,3] (after ConvertResults), initial_cost, and per
+    residual block: cam, cam2, pt, scale, loss_scale, lower, scale_const, dir."""
+    lib = load_gp()
+    q, t = np.ascontiguousarray(cam_q, dtype=np.float64), np.ascontiguousarray(cam_t, dtype=np.float64)
+    off, oc = np.ascontiguousarray(pt_offset, dtype=np.int64), np.ascontiguousarray(obs_cam, dtype=np.int32)
+    und, X = np.ascontiguousarray(obs_undist, dtype=np.float64), np.ascontiguousarray(pt_xyz, dtype=np.float64)
+    u8 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.uint8)  # noqa: E731
+    cal, reg, ini, pv = u8(cam_calibrated), u8(cam_registered), u8(pt_initialized), u8(pair_valid)
+    E = 0 if pair_i is None else len(pair_i)
+    pi = None if pair_i is None else np.ascontiguousarray(pair_i, dtype=np.int32)
+    pj = None if pair_j is None else np.ascontiguousarray(pair_j, dtype=np.int32)
+    pt = None if pair_t is None else np.ascontiguousarray(pair_t, dtype=np.float64)
+    o = _GpOptions(1, 1, 1, 1, 1, 1, 3, 1, 0, 1.0, 0.1)
+    for k, v in options.items():
+        setattr(o, k, type(getattr(o, k))(v))
+    N, P, M = len(q), len(off) - 1, len(oc)
+    cap = M + E + 8
+    out = dict(frame_order=np.zeros(N, np.int32), track_order=np.zeros(max(P, 1), np.int64), center_start=np.zeros((N, 3)),
+               xyz_start=np.zeros((max(P, 1), 3)), cam_t_after=np.zeros((N, 3)), cam=np.zeros(cap, np.int32), cam2=np.zeros(cap, np.int32),
+               pt=np.zeros(cap, np.int64), scale=np.zeros(cap), loss_scale=np.zeros(cap), lower=np.zeros(cap), scale_const=np.zeros(cap, np.uint8),
+               dir=np.zeros((cap, 3)))
+    cost = C.c_double(0.0)
+    args = [C.c_int(N), _p(q), _p(t), _p(cal), _p(reg), C.c_long(P), _p(off), _p(oc), _p(und), _p(X), _p(ini), C.c_long(E), _p(pi), _p(pj), _p(pv),
+            _p(pt), C.byref(o), _p(out["frame_order"]), _p(out["track_order"]), _p(out["center_start"]), _p(out["xyz_start"]),
+            _p(out["cam_t_after"]), C.c_long(cap), _p(out["cam"]), _p(out["cam2"]), _p(out["pt"]), _p(out["scale"]), _p(out["loss_scale"]),
+            _p(out["lower"]), _p(out["scale_const"]), _p(out["dir"]), C.byref(cost)]
+    R = lib.ref_gp_build(*[a if not isinstance(a, int) and a is not None else C.c_void_p(a) for a in args])
+    assert R >= 0, R
+    for k in ("cam", "cam2", "pt", "scale", "loss_scale", "lower", "scale_const", "dir"):
+        out[k] = out[k][:R]
+    out["track_order"], out["xyz_start"] = out["track_order"][:P], out["xyz_start"][:P]
+    out["initial_cost"] = float(cost.value)
+    out["num_residual_blocks"] = int(R)
+    return out

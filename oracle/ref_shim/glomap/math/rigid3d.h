@@ -1,3 +1,6 @@
 #pragma once
-// shadows glomap/math/rigid3d.h (Eigen-based helpers; track_filter.cc needs none of them beyond the types)
+// shadows glomap/math/rigid3d.h (its .cc needs Eigen::AngleAxis): the helpers the compiled files call are restated, with
+// their source lines, in ref_shim_types.h (CalcAngle, DegToRad, CenterFromPose)
 #include "ref_shim_types.h"
+
+#include "glomap/types.h"

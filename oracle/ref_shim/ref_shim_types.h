@@ -35,6 +35,7 @@ struct Vector2d {  // (a - b).norm(), a / s   (track_establishment.cc:127-128, t
   static Vector2d Zero() { return Vector2d(); }
   Vector2d operator-(const Vector2d& o) const { return Vector2d(x - o.x, y - o.y); }
   Vector2d operator/(double s) const { return Vector2d(x / s, y / s); }
+  double operator()(int i) const { return i == 0 ? x : y; }
   double norm() const { return std::sqrt(x * x + y * y); }
 };
 struct Vector3d {
@@ -53,7 +54,18 @@ struct Vector3d {
   Vector3d& operator/=(double s) { v[0] /= s; v[1] /= s; v[2] /= s; return *this; }
   double dot(const Vector3d& o) const { return v[0] * o.v[0] + v[1] * o.v[1] + v[2] * o.v[2]; }
   double norm() const { return std::sqrt(dot(*this)); }
+  double squaredNorm() const { return dot(*this); }
   Vector3d normalized() const { const double n = norm(); return Vector3d(v[0] / n, v[1] / n, v[2] / n); }
+  // what global_positioning.cc / cost_function.h use on top (ref_shim_eigen_extra.h)
+  double* data() { return v; }
+  const double* data() const { return v; }
+  double& operator[](int i) { return v[i]; }
+  const double& operator[](int i) const { return v[i]; }
+  bool hasNaN() const { return std::isnan(v[0]) || std::isnan(v[1]) || std::isnan(v[2]); }
+  struct NaNView { bool any_; const NaNView& isNaN() const { return *this; } bool any() const { return any_; } };
+  NaNView array() const { return NaNView{hasNaN()}; }
+  void setConstant(double c) { v[0] = v[1] = v[2] = c; }
+  template <typename T> Vector3d cast() const { return *this; }  // (T = double: the mock AutoDiffCostFunction evaluates in doubles)
 };
 inline Vector3d operator*(double s, const Vector3d& a) { return a * s; }
 struct Quaterniond {  // (w, x, y, z); q * v = R(q) v
@@ -68,6 +80,8 @@ struct Quaterniond {  // (w, x, y, z); q * v = R(q) v
                        w_ * b.y_ - x_ * b.z_ + y_ * b.w_ + z_ * b.x_, w_ * b.z_ + x_ * b.y_ - y_ * b.x_ + z_ * b.w_);
   }
   // Eigen/src/Geometry/Quaternion.h: d = *this * other.conjugate(); 2 * atan2(d.vec().norm(), abs(d.w()))
+  struct RotMat;  // toRotationMatrix(): ref_shim_eigen_extra.h
+  inline RotMat toRotationMatrix() const;
   double angularDistance(const Quaterniond& other) const {
     const Quaterniond d = (*this) * other.conjugate();
     return 2.0 * std::atan2(std::sqrt(d.x_ * d.x_ + d.y_ * d.y_ + d.z_ * d.z_), std::fabs(d.w_));
@@ -97,7 +111,6 @@ typedef uint32_t feature_t;     // scene/types.h:35
 typedef uint64_t track_t;       // scene/types.h:40
 using Observation = std::pair<image_t, feature_t>;  // scene/track.h:9
 
-constexpr double EPS = 1e-12;  // glomap/types.h:14
 // glomap/math/rigid3d.cc:29-31 (that file needs Eigen::AngleAxis and cannot be compiled here): degree * EIGEN_PI / 180, and
 // EIGEN_PI is a long double literal (Eigen/src/Core/util/Macros.h), so the product is formed in extended precision
 #define REF_SHIM_EIGEN_PI 3.141592653589793238462643383279502884197169399375105820974944592307816406L
@@ -121,19 +134,29 @@ inline Rigid3d Inverse(const Rigid3d& b_from_a) {  // colmap/geometry/rigid3.h
   out.translation = out.rotation * -b_from_a.translation;
   return out;
 }
+inline Eigen::Vector3d CenterFromPose(const Rigid3d& pose) { return pose.rotation.inverse() * -pose.translation; }  // rigid3d.cc:65-67
 inline double CalcAngle(const Rigid3d& pose1, const Rigid3d& pose2) {  // glomap/math/rigid3d.cc:7-9
   return pose1.rotation.angularDistance(pose2.rotation) * 180 / REF_SHIM_EIGEN_PI;
 }
 
-struct sensor_t {  // only what Rig's map needs
-  int type = 0;
+enum class SensorType { INVALID = -1, CAMERA = 0, IMU = 1 };  // colmap/sensor/rig.h
+struct sensor_t {
+  SensorType type = SensorType::INVALID;
   uint32_t id = 0;
+  sensor_t() = default;
+  sensor_t(SensorType t, uint32_t i) : type(t), id(i) {}
   bool operator<(const sensor_t& o) const { return type != o.type ? type < o.type : id < o.id; }
+  bool operator==(const sensor_t& o) const { return type == o.type && id == o.id; }
 };
-struct Rig {  // colmap/sensor/rig.h: the two calls of reconstruction_normalizer.cc:64-72
+struct Rig {  // colmap/sensor/rig.h: what reconstruction_normalizer.cc:64-72 and global_positioning.cc touch
+  sensor_t ref;
   std::map<sensor_t, std::optional<Rigid3d>> sensors;
   std::map<sensor_t, std::optional<Rigid3d>>& NonRefSensors() { return sensors; }
   void SetSensorFromRig(const sensor_t& s, const Rigid3d& t) { sensors[s] = t; }
+  Rigid3d& SensorFromRig(const sensor_t& s) { return sensors.at(s).value(); }
+  std::optional<Rigid3d>& MaybeSensorFromRig(const sensor_t& s) { return sensors.at(s); }
+  sensor_t RefSensorId() const { return ref; }
+  bool IsRefSensor(const sensor_t& s) const { return s == ref; }
 };
 struct Camera {  // colmap::Camera + scene/camera.h: the two members the filters read
   bool has_prior_focal_length = true;
@@ -147,6 +170,10 @@ struct Frame {  // scene/frame.h:29-42 + colmap::Frame: flags, pose
   bool HasPose() const { return has_pose; }
   Rigid3d& RigFromWorld() { return rig_from_world; }
   const Rigid3d& RigFromWorld() const { return rig_from_world; }
+  rig_t rig_id = 0;
+  Rig* rig_ptr = nullptr;
+  rig_t RigId() const { return rig_id; }
+  Rig* RigPtr() const { return rig_ptr; }
 };
 struct Image {  // scene/image.h:10-53 (trivial frames: cam_from_world = the frame's rig_from_world)
   image_t image_id = 0;
@@ -157,6 +184,9 @@ struct Image {  // scene/image.h:10-53 (trivial frames: cam_from_world = the fra
   std::vector<Eigen::Vector3d> features_undist;
   bool IsRegistered() const { return frame_ptr != nullptr && frame_ptr->is_registered; }  // image.h:65-67
   Rigid3d CamFromWorld() const { return frame_ptr->RigFromWorld(); }                          // image.h:60-63
+  bool HasTrivialFrame() const {  // image.h:73-76
+    return frame_ptr->RigPtr() == nullptr || frame_ptr->RigPtr()->IsRefSensor(sensor_t(SensorType::CAMERA, camera_id));
+  }
   Eigen::Vector3d Center() const { return CamFromWorld().rotation.inverse() * -CamFromWorld().translation; }  // image.h:55-57
 };
 struct ImagePair {  // scene/image_pair.h:13-57
@@ -169,6 +199,7 @@ struct ImagePair {  // scene/image_pair.h:13-57
 struct Track {  // scene/track.h:12-27
   track_t track_id = 0;
   Eigen::Vector3d xyz;
+  bool is_initialized = false;
   std::vector<Observation> observations;
 };
 }  // namespace glomap
@@ -182,4 +213,8 @@ struct NullLog {
 }  // namespace ref_shim
 #ifndef LOG
 #define LOG(severity) ::ref_shim::NullLog()
+#define VLOG(n) ::ref_shim::NullLog()
+#define VLOG_IS_ON(n) false
+#define LOG_FIRST_N(severity, n) ::ref_shim::NullLog()
+#define CHECK_GE(a, b) ::ref_shim::NullLog()
 #endif

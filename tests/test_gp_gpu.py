@@ -265,3 +265,20 @@ def test_gp_draw_orders_keep_the_start_under_renumbering(gsfm_ctx):
     q.cam_draw_order = np.zeros(N, np.int32)           # not a permutation
     rc, *_ = estimators.gp_solve(q, ctx=gsfm_ctx)
     assert rc != 0
+
+
+def test_gp_rand_vector_order_of_a_gcc_built_reference(gsfm_ctx):
+    """RandVector3d's three draws are constructor ARGUMENTS (global_positioning.cc:21-23): a g++-built GLOMAP evaluates them
+    right to left, so the first draw of each vector lands in z (tests/test_oracle_ref.py pins this against the reference's
+    own translation unit).  rand_vector_order = 1 reproduces that start on both sides; the default stays x-first."""
+    p = synthetic.make_gp_problem(num_cams=40, num_pts=800, seed=1, dir_noise=1e-3, outlier_ratio=0.02, uncalibrated_ratio=0.2)
+    ok, c_o, X_o, summ = _oracle(p, rand_vector_order=1)
+    assert ok
+    rc, c_g, X_g, rep = estimators.gp_solve(p, estimators.GlobalPositionerOptions(rand_vector_order=1), ctx=gsfm_ctx)
+    assert rc == 0
+    assert abs(rep["initial_cost"] - summ.initial_cost) <= 1e-9 * summ.initial_cost
+    assert abs(rep["final_cost"] - summ.final_cost) <= 1e-3 * summ.final_cost
+    assert _rel_diff(c_g, c_o) < TOL_REL
+    # and it IS a different start from the default order
+    rc, _, _, rep0 = estimators.gp_solve(p, ctx=gsfm_ctx)
+    assert rc == 0 and abs(rep0["initial_cost"] - rep["initial_cost"]) > 1e-6 * rep["initial_cost"]

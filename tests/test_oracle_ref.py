@@ -218,3 +218,158 @@ def test_filter_rotations_equals_the_reference(seed, max_angle):
     ev_r, n_r = ref.filter_rotations(nq, g.edge_i, g.edge_j, g.edge_q, max_angle, node_registered=reg, edge_valid=ev0)
     touch = ev0.astype(bool) & reg[g.edge_i].astype(bool) & reg[g.edge_j].astype(bool)
     assert np.array_equal(ev_r, np.where(touch, keep_o, ev0.astype(bool)))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the problem global positioning poses: the reference's own builder (global_positioning.cc + cost_function.h on a recording
+# Ceres) against oracle/gp.py
+# ---------------------------------------------------------------------------------------------------------------
+needs_gp = pytest.mark.skipif(ref.load_gp() is None, reason="oracle/_ref/libref_glomap_gp.so not available")
+
+
+def _renumbered(p, frame_order, track_order):
+    """The flat problem with cameras and tracks numbered in the order the REFERENCE walks its unordered_maps — the oracle (like
+    the C ABI without *_draw_order) draws its random start in index order, so this makes the two draw orders coincide."""
+    from glomap_amd.flat import GpProblem
+
+    new_cam = np.empty(p.num_cams, dtype=np.int64)
+    new_cam[frame_order] = np.arange(p.num_cams)
+    lens = np.diff(p.pt_offset)[track_order]
+    off = np.zeros(p.num_pts + 1, dtype=np.int64)
+    off[1:] = np.cumsum(lens)
+    idx = np.concatenate([np.arange(p.pt_offset[t], p.pt_offset[t + 1]) for t in track_order]) if p.num_obs else np.zeros(0, np.int64)
+    return GpProblem(num_cams=p.num_cams, num_pts=p.num_pts, pt_offset=off, obs_cam=new_cam[p.obs_cam[idx]].astype(np.int32),
+                     obs_dir=np.ascontiguousarray(p.obs_dir[idx]), obs_calibrated=p.obs_calibrated[idx], cam_center=p.cam_center[frame_order],
+                     pt_xyz=p.pt_xyz[track_order]), new_cam, idx
+
+
+def _gp_scene(seed, uncal=0.3):
+    from glomap_amd import so3
+
+    p = synthetic.make_gp_problem(num_cams=14, num_pts=90, seed=seed, uncalibrated_ratio=uncal, dir_noise=2e-3, outlier_ratio=0.05)
+    # tracks below min_num_view_per_track and a camera nobody constrains are part of the walk but not of the problem
+    keep = np.ones(p.num_obs, bool)
+    lens = np.diff(p.pt_offset)
+    for t in (3, 17, 40):
+        keep[p.pt_offset[t] + 2 : p.pt_offset[t + 1]] = False  # cut to two views
+    keep[p.obs_cam == 5] = False  # camera 5 sees nothing
+    trk = np.repeat(np.arange(p.num_pts), lens)
+    off = np.zeros(p.num_pts + 1, dtype=np.int64)
+    off[1:] = np.cumsum(np.bincount(trk[keep], minlength=p.num_pts))
+    p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated = off, p.obs_cam[keep], np.ascontiguousarray(p.obs_dir[keep]), p.obs_calibrated[keep]
+    q = so3.rotmat_to_quat(p.cam_R)
+    t = -np.einsum("nij,nj->ni", p.cam_R, p.gt_center)
+    und = np.einsum("mij,mj->mi", p.cam_R[p.obs_cam], p.obs_dir)
+    cal = np.ones(p.num_cams, np.uint8)
+    cal[p.obs_cam] = p.obs_calibrated
+    p.cam_center = p.gt_center.copy()  # CenterFromPose of the input poses (global_positioning.cc:149,161)
+    p.pt_xyz = np.random.default_rng(seed).normal(size=(p.num_pts, 3))
+    return p, q, t, und, cal
+
+
+@needs_gp
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_global_positioning_problem_equals_the_reference(seed):
+    """GlobalPositioner::Solve of the reference, run as written up to (and through) ceres::Solve on a Ceres that records and
+    does not minimise, against oracle/gp.py stopped before its first iteration: the SAME random start bit for bit (which frames
+    and tracks are drawn, in which order, 100 x U(-1, 1) from std::mt19937 seeded with options.seed), the same residual blocks
+    (one per observation of a track with >= min_num_view_per_track views), the same observed directions R^T v, Huber(0.1) bare
+    for calibrated cameras and scaled by 0.5 for uncalibrated ones, every scale bounded below by 1e-5, the FIRST scale constant,
+    and the same initial cost."""
+    from oracle import gp as ogp
+
+    p, q, t, und, cal = _gp_scene(seed)
+    r = ref.gp_build(q, t, p.pt_offset, p.obs_cam, und, p.pt_xyz, cam_calibrated=cal)
+    lens = np.diff(p.pt_offset)
+    used = lens >= 3
+    assert r["num_residual_blocks"] == int(lens[used].sum())
+    # --- the oracle on the same problem, numbered in the reference's walk order, zero LM iterations
+    pr, new_cam, idx = _renumbered(p, r["frame_order"], r["track_order"])
+    # oracle/_ref is built with g++, which evaluates the three draws of RandVector3d(...) right to left: the first draw of a
+    # start vector is its z (rand_vector_order = 1; a clang-built reference gives 0 — the language leaves it open).  This test
+    # is what found that: with the oracle's historical x-first order every start vector came out with x and z swapped.
+    opt = ogp.GlobalPositionerOptions(rand_vector_order=1)
+    opt.lm.max_num_iterations = 0
+    ok, c0, X0, summ = ogp.solve(pr.num_cams, pr.pt_offset, pr.obs_cam, pr.obs_dir, pr.obs_calibrated, pr.cam_center, pr.pt_xyz, opt)
+    assert summ.iterations == 0
+    ok, c0_x, _, _ = ogp.solve(pr.num_cams, pr.pt_offset, pr.obs_cam, pr.obs_dir, pr.obs_calibrated, pr.cam_center, pr.pt_xyz,
+                               ogp.GlobalPositionerOptions(rand_vector_order=0, lm=opt.lm))
+    drawn = np.arange(p.num_cams) != new_cam[5]
+    assert np.array_equal(c0_x[drawn], c0[drawn][:, ::-1])  # the same draws, the other argument order
+    # start point: bit for bit (camera 5 is unconstrained: it keeps its centre and takes no draw)
+    ref_c0 = r["center_start"][r["frame_order"]]
+    assert np.array_equal(c0[drawn], ref_c0[drawn])
+    # the unconstrained camera keeps CenterFromPose of its input pose (global_positioning.cc:161): -R^T t, equal to rounding
+    assert np.array_equal(c0[new_cam[5]], p.gt_center[5]) and np.abs(ref_c0[new_cam[5]] - p.gt_center[5]).max() < 1e-12
+    used_r = used[r["track_order"]]
+    assert np.array_equal(X0[used_r], r["xyz_start"][r["track_order"]][used_r])
+    assert np.array_equal(r["xyz_start"][~used], p.pt_xyz[~used])  # short tracks keep their input
+    assert np.abs(r["center_start"][np.arange(p.num_cams) != 5]).max() <= 100.0 and np.abs(r["center_start"]).max() > 50.0
+    # initial cost
+    assert abs(summ.initial_cost - r["initial_cost"]) <= 1e-12 * r["initial_cost"]
+    # residual blocks, in the order the reference added them = track walk order, observation order inside a track
+    want_pt = np.repeat(r["track_order"][used_r], lens[r["track_order"]][used_r])
+    assert np.array_equal(r["pt"], want_pt) and (r["cam2"] == -1).all()
+    obs_of_block = np.concatenate([np.arange(p.pt_offset[tt], p.pt_offset[tt + 1]) for tt in r["track_order"][used_r]])
+    assert np.array_equal(r["cam"], p.obs_cam[obs_of_block])
+    assert np.abs(r["dir"] - p.obs_dir[obs_of_block]).max() < 1e-15  # R^T feature_undist (global_positioning.cc:292-294)
+    assert np.array_equal(r["loss_scale"], np.where(p.obs_calibrated[obs_of_block] != 0, 1.0, 0.5))  # :244-246, 312-315
+    assert (r["lower"] == 1e-5).all() and (r["scale"] == 1.0).all()  # :204 / :376, generate_scales
+    assert r["scale_const"][0] == 1 and not r["scale_const"][1:].any()  # :484-489
+    # ConvertResults without a minimisation in between: t = -R c (global_positioning.cc:557-559)
+    from glomap_amd import so3
+
+    R = so3.quat_to_rotmat(q)
+    assert np.abs(r["cam_t_after"] + np.einsum("nij,nj->ni", R, r["center_start"])).max() < 1e-12
+
+
+@needs_gp
+@pytest.mark.parametrize("ctype", [1, 2, 3])
+def test_global_positioning_pair_constraints_equal_the_reference(ctype):
+    """ONLY_CAMERAS / POINTS_AND_CAMERAS_BALANCED / POINTS_AND_CAMERAS: camera-to-camera blocks first (one per valid pair, the
+    first PAIR's scale constant), the point blocks re-weighted by constraint_reweight_scale * #pairs / #TRACKS in the balanced
+    mode (global_positioning.cc:230-252), the same initial cost as oracle/gp.py."""
+    from glomap_amd import so3
+    from oracle import gp as ogp
+
+    p, q, t, und, cal = _gp_scene(4, uncal=0.2)
+    rng = np.random.default_rng(ctype)
+    allp = np.array([(a, b) for a in range(p.num_cams) for b in range(p.num_cams) if a != b])
+    sel = rng.choice(len(allp), 30, replace=False)  # distinct ordered pairs
+    E = len(sel)
+    pi, pj = allp[sel, 0].astype(np.int32), allp[sel, 1].astype(np.int32)
+    pv = (rng.random(E) > 0.2).astype(np.uint8)
+    pt = rng.normal(size=(E, 3))
+    pt /= np.linalg.norm(pt, axis=1, keepdims=True)
+    kw = dict(constraint_type=ctype, constraint_reweight_scale=2.0)
+    r = ref.gp_build(q, t, p.pt_offset, p.obs_cam, und, p.pt_xyz, cam_calibrated=cal, pair_i=pi, pair_j=pj, pair_valid=pv, pair_t=pt, **kw)
+    npair = int(pv.sum())
+    is_pair = r["pt"] < 0
+    # the pairs come first, in the view graph's walk order; their direction: -R_2^T t_21 (:195-197)
+    assert is_pair[:npair].all() and not is_pair[npair:].any()
+    R = so3.quat_to_rotmat(q)
+    got = {(int(a), int(b)): d for a, b, d in zip(r["cam"][:npair], r["cam2"][:npair], r["dir"][:npair])}
+    for e in np.nonzero(pv)[0]:
+        assert np.abs(got[(int(pi[e]), int(pj[e]))] + R[pj[e]].T @ pt[e]).max() < 1e-15
+    assert (r["loss_scale"][:npair] == 1.0).all() and r["scale_const"][0] == 1 and not r["scale_const"][1:].any()
+    if ctype == 1:
+        assert len(r["pt"]) == npair  # ONLY_CAMERAS: no point blocks
+    else:
+        w = 2.0 * npair / p.num_pts if ctype == 2 else 1.0  # (#TRACKS in the map, not the used ones: :222)
+        cal_blk = p.obs_calibrated[np.concatenate([np.arange(p.pt_offset[tt], p.pt_offset[tt + 1])
+                                                   for tt in r["track_order"] if p.pt_offset[tt + 1] - p.pt_offset[tt] >= 3])] != 0
+        want = np.where(cal_blk, w if ctype == 2 else 1.0, 0.5 * w)
+        assert np.allclose(r["loss_scale"][npair:], want, rtol=1e-15, atol=0)
+    # the oracle poses the same problem: same initial cost from the same start
+    pr, new_cam, idx = _renumbered(p, r["frame_order"], r["track_order"])
+    walk = [e for e in range(E)]  # the view graph is walked in the unordered_map's order too; the glue inserts pairs 0..E-1
+    opt = ogp.GlobalPositionerOptions(rand_vector_order=1, **kw)  # (g++-built reference: see the test above)
+    opt.lm.max_num_iterations = 0
+    # pairs in the reference's walk order = the order of its first npair residual blocks
+    order = [next(e for e in np.nonzero(pv)[0] if (int(pi[e]), int(pj[e])) == (int(a), int(b)) and np.abs(d + R[pj[e]].T @ pt[e]).max() < 1e-15)
+             for a, b, d in zip(r["cam"][:npair], r["cam2"][:npair], r["dir"][:npair])]
+    pdir = np.array([-(R[pj[e]].T @ pt[e]) for e in order])
+    ok, c0, X0, summ = ogp.solve(pr.num_cams, pr.pt_offset, pr.obs_cam, pr.obs_dir, pr.obs_calibrated, pr.cam_center, pr.pt_xyz, opt,
+                                 pair_i=new_cam[pi[order]], pair_j=new_cam[pj[order]], pair_dir=pdir)
+    assert np.abs(c0 - r["center_start"][r["frame_order"]]).max() < 1e-12  # (bit-equal where drawn: test above)
+    assert abs(summ.initial_cost - r["initial_cost"]) <= 1e-12 * r["initial_cost"]
