@@ -63,7 +63,7 @@ class RaTrace:
 
 
 # ------------------------------------------------------------------------------------------
-def maximum_spanning_tree_init(num_nodes, edge_i, edge_j, edge_R, edge_ninl, aa0):
+def maximum_spanning_tree_init(num_nodes, edge_i, edge_j, edge_R, edge_ninl, aa0, root=0):
     """Kruskal maximum spanning tree on #inliers (tree.cc:78-153), BFS from node 0, then
     R_child = R_rel * R_parent or R_rel^T * R_parent (gra.cc:125-134).  The root is never
     assigned in the reference loop (gra.cc:120 `continue`), so `cam_from_worlds[root]` is the
@@ -92,8 +92,8 @@ def maximum_spanning_tree_init(num_nodes, edge_i, edge_j, edge_R, edge_ninl, aa0
             adj[b].append((a, int(e)))
     R = np.tile(np.eye(3), (num_nodes, 1, 1))
     visited = np.zeros(num_nodes, dtype=bool)
-    visited[0] = True
-    queue = [0]
+    visited[root] = True  # the reference's root is the first image its unordered_map yields (tree.cc:84-88, 141); 0 in the flat form
+    queue = [root]
     head = 0
     while head < len(queue):
         cur = queue[head]
@@ -198,6 +198,7 @@ def estimate_rotations(
     fixed_node=0,
     options: RotationEstimatorOptions | None = None,
     trace: RaTrace | None = None,
+    tree_root: int = 0,
 ):
     """Returns (ok, rot_aa[N,3])."""
     opt = options or RotationEstimatorOptions()
@@ -207,7 +208,7 @@ def estimate_rotations(
     E = edge_i.shape[0]
     rot = np.array(node_aa0, dtype=np.float64, copy=True)
     if not opt.skip_initialization:
-        rot = maximum_spanning_tree_init(num_nodes, edge_i, edge_j, edge_R, edge_ninl, rot)
+        rot = maximum_spanning_tree_init(num_nodes, edge_i, edge_j, edge_R, edge_ninl, rot, tree_root)
     # fixed camera keeps its initial (post-MST) rotation (gra.cc:248-257)
     fixed_rot = rot[fixed_node].copy()
 

@@ -217,3 +217,68 @@ def gp_build(cam_q, cam_t, pt_offset, obs_cam, obs_undist, pt_xyz, cam_calibrate
     out["initial_cost"] = float(cost.value)
     out["num_residual_blocks"] = int(R)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the reference's ROTATION AVERAGING (global_rotation_averaging.cc, rotation_initializer.cc, rigid3d.cc, tree.cc)
+# ---------------------------------------------------------------------------------------------------------------
+LIB_RA = HERE / "_ref" / "libref_glomap_ra.so"
+_lib_ra = None
+
+
+class _RaOptions(C.Structure):
+    _fields_ = [("max_num_l1_iterations", C.c_int), ("l1_step_convergence_threshold", C.c_double),
+                ("max_num_irls_iterations", C.c_int), ("irls_step_convergence_threshold", C.c_double),
+                ("irls_loss_parameter_sigma", C.c_double), ("weight_type", C.c_int), ("skip_initialization", C.c_int),
+                ("use_weight", C.c_int), ("use_gravity", C.c_int)]
+
+
+def load_ra():
+    global _lib_ra
+    if _lib_ra is None:
+        load()
+        if LIB_RA.exists():
+            _lib_ra = C.CDLL(str(LIB_RA))
+            _lib_ra.ref_ra_estimate.restype = C.c_int
+    return _lib_ra
+
+
+def ra_estimate(rig_ref_cam, frame_rig, image_frame, image_cam, pair_i, pair_j, pair_q, pair_weight=None, pair_ninl=None,
+                pair_valid=None, sensor_rig=(), sensor_cam=(), sensor_state=(), sensor_q=None, frame_q=None, frame_R_align=None,
+                frame_registered=None, **options):
+    """RotationEstimator::EstimateRotations of the reference (global_rotation_averaging.cc:40-85) on containers built from flat
+    arrays (ids = indices).  frame_q None = frames without a pose; frame_R_align [F,3,3] with NaN rows = no gravity.  Returns a
+    dict: ok, frame_q [F,4] (rig_from_world, wxyz), sensor_q [S,4] / sensor_has [S], fixed_image, tree_root (-1: no tree),
+    l1_iterations, admm_iterations, irls_iterations, first_frame."""
+    lib = load_ra()
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)  # noqa: E731
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+    rr, fr, imf, imc = i32(rig_ref_cam), i32(frame_rig), i32(image_frame), i32(image_cam)
+    pi, pj, pq = i32(pair_i), i32(pair_j), f64(pair_q)
+    E, F, S = len(pi), len(fr), len(sensor_rig)
+    pw = f64(np.full(E, -1.0) if pair_weight is None else pair_weight)
+    pn = i32(np.full(E, 100) if pair_ninl is None else pair_ninl)
+    pv = np.ascontiguousarray(np.ones(E) if pair_valid is None else pair_valid, dtype=np.uint8)
+    sr, sc, ss = i32(sensor_rig), i32(sensor_cam), i32(sensor_state)
+    sq = f64(np.tile([1.0, 0, 0, 0], (max(S, 1), 1)) if sensor_q is None else sensor_q)
+    has_pose = np.ascontiguousarray(np.zeros(F) if frame_q is None else np.ones(F), dtype=np.uint8)
+    fq = f64(np.tile([1.0, 0, 0, 0], (F, 1)) if frame_q is None else frame_q)
+    if frame_R_align is None:
+        has_g, Ra = np.zeros(F, np.uint8), np.zeros((F, 9))
+    else:
+        Ra = f64(frame_R_align).reshape(F, 9).copy()
+        has_g = np.ascontiguousarray(~np.isnan(Ra).any(axis=1), dtype=np.uint8)
+        Ra[has_g == 0] = 0.0
+    reg = np.ascontiguousarray(np.ones(F) if frame_registered is None else frame_registered, dtype=np.uint8)
+    o = _RaOptions(5, 1e-3, 100, 1e-3, 5.0, 0, 0, 0, 0)
+    for k, v in options.items():
+        setattr(o, k, type(getattr(o, k))(v))
+    out_fq, out_sq, out_sh, info = np.zeros((F, 4)), np.zeros((max(S, 1), 4)), np.zeros(max(S, 1), np.uint8), np.zeros(8, np.int64)
+    vp = C.c_void_p
+    ok = lib.ref_ra_estimate(C.c_int(len(rr)), vp(_p(rr)), C.c_int(S), vp(_p(sr)), vp(_p(sc)), vp(_p(ss)), vp(_p(sq)), C.c_int(F), vp(_p(fr)),
+                             vp(_p(has_pose)), vp(_p(fq)), vp(_p(has_g)), vp(_p(Ra)), vp(_p(reg)), C.c_int(len(imf)), vp(_p(imf)), vp(_p(imc)),
+                             C.c_long(E), vp(_p(pi)), vp(_p(pj)), vp(_p(pq)), vp(_p(pw)), vp(_p(pn)), vp(_p(pv)), C.byref(o), vp(_p(out_fq)),
+                             vp(_p(out_sq)), vp(_p(out_sh)), vp(_p(info)))
+    return dict(ok=bool(ok), frame_q=out_fq, sensor_q=out_sq[:S], sensor_has=out_sh[:S].astype(bool), fixed_image=int(info[0]),
+                tree_root=int(info[1]), l1_iterations=int(info[2]), admm_iterations=int(info[3]), irls_iterations=int(info[4]),
+                first_frame=int(info[5]))

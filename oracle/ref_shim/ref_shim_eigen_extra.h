@@ -27,28 +27,7 @@ struct Matrix<double, 3, 1> : Vector3d {
   CommaInit operator<<(double x) { v[0] = x; return CommaInit{this, 1}; }
 };
 
-struct Matrix3d {
-  double m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  static Matrix3d Identity(int = 3, int = 3) { Matrix3d r; r.m[0] = r.m[4] = r.m[8] = 1.0; return r; }
-  double& operator()(int r, int c) { return m[3 * r + c]; }
-  const double& operator()(int r, int c) const { return m[3 * r + c]; }
-  Matrix3d transpose() const { Matrix3d t; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) t.m[3 * i + j] = m[3 * j + i]; return t; }
-  Vector3d operator*(const Vector3d& x) const {
-    return Vector3d(m[0] * x(0) + m[1] * x(1) + m[2] * x(2), m[3] * x(0) + m[4] * x(1) + m[5] * x(2), m[6] * x(0) + m[7] * x(1) + m[8] * x(2));
-  }
-  Matrix3d operator*(const Matrix3d& b) const {
-    Matrix3d r;
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) r.m[3 * i + j] += m[3 * i + k] * b.m[3 * k + j];
-    return r;
-  }
-  Vector3d col(int j) const { return Vector3d(m[j], m[3 + j], m[6 + j]); }
-};
-inline Matrix3d to_rotation_matrix(const Quaterniond& q) {
-  Matrix3d R;
-  const Vector3d c0 = q * Vector3d(1, 0, 0), c1 = q * Vector3d(0, 1, 0), c2 = q * Vector3d(0, 0, 1);
-  for (int i = 0; i < 3; ++i) { R(i, 0) = c0(i); R(i, 1) = c1(i); R(i, 2) = c2(i); }
-  return R;
-}
+inline Matrix3d to_rotation_matrix(const Quaterniond& q) { return q.toRotationMatrix(); }
 
 template <typename T, int N>
 struct VectorN {
@@ -86,11 +65,4 @@ struct Map<const Matrix<double, 3, 1>> {
 };
 inline Vector3d operator-(const Vector3d& a, const Map<const Matrix<double, 3, 1>>& b) { return a - static_cast<Vector3d>(b); }
 inline Vector3d operator*(const Matrix3d& R, const Map<const Matrix<double, 3, 1>>& x) { return R * static_cast<Vector3d>(x); }
-}  // namespace Eigen
-
-namespace Eigen {
-struct Quaterniond::RotMat : Matrix3d {
-  RotMat(const Matrix3d& o) : Matrix3d(o) {}
-};
-inline Quaterniond::RotMat Quaterniond::toRotationMatrix() const { return RotMat(to_rotation_matrix(*this)); }
 }  // namespace Eigen

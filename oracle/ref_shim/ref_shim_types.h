@@ -20,6 +20,7 @@
 #include <map>
 #include <optional>
 #include <queue>
+#include <set>
 #include <unordered_map>
 #include <unordered_set>
 #include <utility>
@@ -68,6 +69,24 @@ struct Vector3d {
   template <typename T> Vector3d cast() const { return *this; }  // (T = double: the mock AutoDiffCostFunction evaluates in doubles)
 };
 inline Vector3d operator*(double s, const Vector3d& a) { return a * s; }
+struct Matrix3d {  // 3 x 3 in plain doubles, products evaluated as the usual triple loop
+  double m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  static Matrix3d Identity(int = 3, int = 3) { Matrix3d r; r.m[0] = r.m[4] = r.m[8] = 1.0; return r; }
+  static Matrix3d Zero() { return Matrix3d(); }
+  double& operator()(int r, int c) { return m[3 * r + c]; }
+  const double& operator()(int r, int c) const { return m[3 * r + c]; }
+  Matrix3d transpose() const { Matrix3d t; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) t.m[3 * i + j] = m[3 * j + i]; return t; }
+  Vector3d operator*(const Vector3d& x) const {
+    return Vector3d(m[0] * x(0) + m[1] * x(1) + m[2] * x(2), m[3] * x(0) + m[4] * x(1) + m[5] * x(2), m[6] * x(0) + m[7] * x(1) + m[8] * x(2));
+  }
+  Matrix3d operator*(const Matrix3d& b) const {
+    Matrix3d r;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) r.m[3 * i + j] += m[3 * i + k] * b.m[3 * k + j];
+    return r;
+  }
+  Vector3d col(int j) const { return Vector3d(m[j], m[3 + j], m[6 + j]); }
+  double trace() const { return m[0] + m[4] + m[8]; }
+};
 struct Quaterniond {  // (w, x, y, z); q * v = R(q) v
   double w_ = 1.0, x_ = 0.0, y_ = 0.0, z_ = 0.0;
   Quaterniond() = default;
@@ -80,8 +99,44 @@ struct Quaterniond {  // (w, x, y, z); q * v = R(q) v
                        w_ * b.y_ - x_ * b.z_ + y_ * b.w_ + z_ * b.x_, w_ * b.z_ + x_ * b.y_ - y_ * b.x_ + z_ * b.w_);
   }
   // Eigen/src/Geometry/Quaternion.h: d = *this * other.conjugate(); 2 * atan2(d.vec().norm(), abs(d.w()))
-  struct RotMat;  // toRotationMatrix(): ref_shim_eigen_extra.h
-  inline RotMat toRotationMatrix() const;
+  // Eigen/src/Geometry/Quaternion.h, quaternionbase_assign_impl<Other, 3, 3>: the trace branch, else the largest diagonal
+  explicit Quaterniond(const Matrix3d& mat) {
+    double q[3] = {0, 0, 0};
+    double t = mat.trace();
+    if (t > 0.0) {
+      t = std::sqrt(t + 1.0);
+      w_ = 0.5 * t;
+      t = 0.5 / t;
+      q[0] = (mat(2, 1) - mat(1, 2)) * t;
+      q[1] = (mat(0, 2) - mat(2, 0)) * t;
+      q[2] = (mat(1, 0) - mat(0, 1)) * t;
+    } else {
+      int i = 0;
+      if (mat(1, 1) > mat(0, 0)) i = 1;
+      if (mat(2, 2) > mat(i, i)) i = 2;
+      const int j = (i + 1) % 3, k = (j + 1) % 3;
+      t = std::sqrt(mat(i, i) - mat(j, j) - mat(k, k) + 1.0);
+      q[i] = 0.5 * t;
+      t = 0.5 / t;
+      w_ = (mat(k, j) - mat(j, k)) * t;
+      q[j] = (mat(j, i) + mat(i, j)) * t;
+      q[k] = (mat(k, i) + mat(i, k)) * t;
+    }
+    x_ = q[0]; y_ = q[1]; z_ = q[2];
+  }
+  Quaterniond& operator=(const Matrix3d& mat) { return *this = Quaterniond(mat); }
+  using RotMat = Matrix3d;
+  // the rotation matrix the quaternion's operator* applies (same twelve products), column by column
+  Matrix3d toRotationMatrix() const {
+    Matrix3d R;
+    const Vector3d c0 = (*this) * Vector3d(1, 0, 0), c1 = (*this) * Vector3d(0, 1, 0), c2 = (*this) * Vector3d(0, 0, 1);
+    for (int i = 0; i < 3; ++i) { R(i, 0) = c0(i); R(i, 1) = c1(i); R(i, 2) = c2(i); }
+    return R;
+  }
+  double w() const { return w_; }
+  double x() const { return x_; }
+  double y() const { return y_; }
+  double z() const { return z_; }
   double angularDistance(const Quaterniond& other) const {
     const Quaterniond d = (*this) * other.conjugate();
     return 2.0 * std::atan2(std::sqrt(d.x_ * d.x_ + d.y_ * d.y_ + d.z_ * d.z_), std::fabs(d.w_));
@@ -114,12 +169,16 @@ using Observation = std::pair<image_t, feature_t>;  // scene/track.h:9
 // glomap/math/rigid3d.cc:29-31 (that file needs Eigen::AngleAxis and cannot be compiled here): degree * EIGEN_PI / 180, and
 // EIGEN_PI is a long double literal (Eigen/src/Core/util/Macros.h), so the product is formed in extended precision
 #define REF_SHIM_EIGEN_PI 3.141592653589793238462643383279502884197169399375105820974944592307816406L
+#ifndef REF_SHIM_REAL_RIGID3D  // (the rotation averaging library compiles the reference's rigid3d.cc instead)
 inline double DegToRad(double degree) { return degree * REF_SHIM_EIGEN_PI / 180; }
 inline double RadToDeg(double radian) { return radian * 180 / REF_SHIM_EIGEN_PI; }
+#endif
 
 struct Rigid3d {  // colmap/geometry/rigid3.h: x_b = rotation * x_a + translation
   Eigen::Quaterniond rotation;
   Eigen::Vector3d translation;
+  Rigid3d() = default;
+  Rigid3d(const Eigen::Quaterniond& r, const Eigen::Vector3d& t) : rotation(r), translation(t) {}
 };
 inline Eigen::Vector3d operator*(const Rigid3d& t, const Eigen::Vector3d& x) { return t.rotation * x + t.translation; }
 inline Rigid3d operator*(const Rigid3d& c_from_b, const Rigid3d& b_from_a) {  // colmap/geometry/rigid3.h: composition
@@ -134,10 +193,12 @@ inline Rigid3d Inverse(const Rigid3d& b_from_a) {  // colmap/geometry/rigid3.h
   out.translation = out.rotation * -b_from_a.translation;
   return out;
 }
+#ifndef REF_SHIM_REAL_RIGID3D
 inline Eigen::Vector3d CenterFromPose(const Rigid3d& pose) { return pose.rotation.inverse() * -pose.translation; }  // rigid3d.cc:65-67
 inline double CalcAngle(const Rigid3d& pose1, const Rigid3d& pose2) {  // glomap/math/rigid3d.cc:7-9
   return pose1.rotation.angularDistance(pose2.rotation) * 180 / REF_SHIM_EIGEN_PI;
 }
+#endif
 
 enum class SensorType { INVALID = -1, CAMERA = 0, IMU = 1 };  // colmap/sensor/rig.h
 struct sensor_t {
@@ -162,14 +223,38 @@ struct Camera {  // colmap::Camera + scene/camera.h: the two members the filters
   bool has_prior_focal_length = true;
   std::optional<Eigen::Vector2d> ImgFromCam(const Eigen::Vector3d&) const { return std::nullopt; }  // pixel branch: not exercised
 };
-struct Frame {  // scene/frame.h:29-42 + colmap::Frame: flags, pose
+struct data_t {  // colmap/sensor/rig.h: (sensor, id of the datum = the image id), ordered by sensor then id
+  sensor_t sensor_id;
+  uint32_t id = 0;
+  data_t() = default;
+  data_t(const sensor_t& s, uint32_t i) : sensor_id(s), id(i) {}
+  bool operator<(const data_t& o) const { return sensor_id == o.sensor_id ? id < o.id : sensor_id < o.sensor_id; }
+};
+struct GravityInfo {  // scene/frame.h:12-28; R_align is handed in ready-made (math/gravity.cc:12-27 needs Eigen's Householder QR)
+  bool has_gravity = false;
+  Eigen::Matrix3d R_align = Eigen::Matrix3d::Identity();
+  const Eigen::Matrix3d& GetRAlign() const { return R_align; }
+};
+struct Frame {  // scene/frame.h:29-42 + colmap::Frame: flags, pose, data ids
   bool is_registered = false;
   int cluster_id = -1;
   bool has_pose = false;
   Rigid3d rig_from_world;
+  GravityInfo gravity_info;
+  bool HasGravity() const { return gravity_info.has_gravity; }  // frame.h:44
+  std::set<data_t> data_ids;  // colmap::Frame::DataIds(): a std::set ordered as above
+  const std::set<data_t>& DataIds() const { return data_ids; }
+  std::vector<data_t> ImageIds() const {  // colmap::Frame::ImageIds(): the camera data, in set order
+    std::vector<data_t> out;
+    for (const data_t& d : data_ids)
+      if (d.sensor_id.type == SensorType::CAMERA) out.push_back(d);
+    return out;
+  }
   bool HasPose() const { return has_pose; }
   Rigid3d& RigFromWorld() { return rig_from_world; }
   const Rigid3d& RigFromWorld() const { return rig_from_world; }
+  std::optional<Rigid3d> MaybeRigFromWorld() const { return has_pose ? std::optional<Rigid3d>(rig_from_world) : std::nullopt; }
+  void SetRigFromWorld(const Rigid3d& t) { rig_from_world = t; has_pose = true; }
   rig_t rig_id = 0;
   Rig* rig_ptr = nullptr;
   rig_t RigId() const { return rig_id; }
@@ -188,10 +273,15 @@ struct Image {  // scene/image.h:10-53 (trivial frames: cam_from_world = the fra
     return frame_ptr->RigPtr() == nullptr || frame_ptr->RigPtr()->IsRefSensor(sensor_t(SensorType::CAMERA, camera_id));
   }
   Eigen::Vector3d Center() const { return CamFromWorld().rotation.inverse() * -CamFromWorld().translation; }  // image.h:55-57
+  bool HasGravity() const {  // image.h:78-84
+    return frame_ptr->HasGravity() &&
+           (HasTrivialFrame() || frame_ptr->RigPtr()->MaybeSensorFromRig(sensor_t(SensorType::CAMERA, camera_id)).has_value());
+  }
 };
 struct ImagePair {  // scene/image_pair.h:13-57
   image_t image_id1 = 0, image_id2 = 0;
   bool is_valid = true;
+  double weight = -1;  // image_pair.h:34-35
   Rigid3d cam2_from_cam1;
   std::vector<int> inliers;
   Eigen::MatrixXi matches;
@@ -209,6 +299,7 @@ namespace ref_shim {
 struct NullLog {
   template <typename T>
   NullLog& operator<<(const T&) { return *this; }
+  NullLog& operator<<(std::ostream& (*)(std::ostream&)) { return *this; }  // std::endl
 };
 }  // namespace ref_shim
 #ifndef LOG

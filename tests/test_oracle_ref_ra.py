@@ -1,0 +1,214 @@
+"""oracle/ra.py against the REFERENCE'S OWN rotation averaging.
+
+oracle/_ref/libref_glomap_ra.so is glomap/estimators/global_rotation_averaging.cc, estimators/rotation_initializer.cc,
+math/rigid3d.cc and math/tree.cc compiled from /root/reference, unmodified (`make -C oracle ref`; flat entry point
+oracle/ref_glue_ra.cc).  Eigen, CHOLMOD, COLMAP and Boost are not in this image: the vector / sparse-matrix / Cholesky /
+AngleAxis types, colmap::LeastAbsoluteDeviationSolver, colmap::AverageQuaternions and Boost's Kruskal are stand-ins
+(oracle/ref_shim_ra/) — so what is pinned here is everything the reference itself wrote on top of them:
+
+  SetupLinearSystem       gra.cc:141-477   unknown layout, rows, weights, gauge rows, cam blocks, 1-DoF gravity rows
+  ComputeResiduals        gra.cc:696-756   UpdateGlobalRotations gra.cc:627-693   ComputeAverageStepSize gra.cc:758-772
+  SolveL1Regression       gra.cc:479-541   (both stopping tests; the doubling of the ADMM budget that never reaches the solver)
+  SolveIRLS               gra.cc:543-625   (Geman-McClure / half-norm weights, sigma in radians)
+  InitializeFromMaximumSpanningTree gra.cc:87-138 + tree.cc:78-153, ConvertRotationsFromImageToRig rotation_initializer.cc:7-125
+  Rigid3dToAngleAxis / RotationToAngleAxis / AngleAxisToRotation   rigid3d.cc:33-63
+
+against oracle.ra.estimate_rotations (trivial frames), estimate_rotations_rig (cam_from_rig rotations among the unknowns),
+estimate_rotations_gravity (1-DoF frames) and estimators.convert_rotations_from_image_to_rig: same iteration counts, rotations
+equal to rounding.  The HIP path is held to those oracle functions on the GPU (tests/test_ra_*.py, test_fullsize_gpu.py), so the
+chain ends at reference code; what stays a restatement is the LAD solver's ADMM itself (un-vendored COLMAP)."""
+import numpy as np
+import pytest
+
+from glomap_amd import estimators, so3, synthetic
+from oracle import ra as ora
+from oracle import ref
+
+pytestmark = pytest.mark.skipif(ref.load_ra() is None, reason="neither /root/reference nor a prebuilt oracle/_ref/libref_glomap_ra.so")
+
+TOL = 1e-10  # rad; the two sides differ by the order of their sums only
+
+
+def _dist(q_a, q_b):
+    """Rotation distance in rad from the vector part of q_a^-1 q_b (accurate near zero, unlike acos of a trace)."""
+    d = so3.quat_mul(so3.quat_conj(np.atleast_2d(q_a)), np.atleast_2d(q_b))
+    return 2.0 * np.arcsin(np.minimum(1.0, np.linalg.norm(d[:, 1:], axis=1)))
+
+
+def _distinct_inliers(rng, E):
+    return (rng.permutation(E) + 30).astype(np.int32)  # no ties: the spanning tree is unique
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# trivial frames: image = frame, one camera
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("skip,use_weight,weight_type,seed", [(0, 0, 0, 1), (1, 0, 0, 2), (0, 1, 0, 3), (1, 1, 1, 4), (0, 0, 1, 5)])
+def test_trivial_frames_equal_the_reference(skip, use_weight, weight_type, seed):
+    p = synthetic.make_ring_view_graph(40, 6, seed=seed)
+    N, E = p.num_nodes, len(p.edge_i)
+    rng = np.random.default_rng(seed)
+    ninl = _distinct_inliers(rng, E)
+    w = rng.uniform(0.2, 1.0, E)
+    w[rng.random(E) < 0.2] = -1.0  # "no weight": counted as 1 (gra.cc:417-420)
+    r = ref.ra_estimate([0], np.zeros(N), np.arange(N), np.zeros(N), p.edge_i, p.edge_j, p.edge_q, pair_weight=w, pair_ninl=ninl,
+                        frame_q=so3.aa_to_quat(p.node_aa0), skip_initialization=skip, use_weight=use_weight, weight_type=weight_type)
+    assert r["ok"] and r["fixed_image"] == r["first_frame"]  # gra.cc:248-257: the first frame the map yields
+    assert (r["tree_root"] >= 0) == (skip == 0)
+    tr = ora.RaTrace()
+    opt = ora.RotationEstimatorOptions(skip_initialization=bool(skip), use_weight=bool(use_weight), weight_type=weight_type)
+    ok, rot = ora.estimate_rotations(N, p.edge_i, p.edge_j, p.edge_q, w, ninl, p.node_aa0, fixed_node=r["fixed_image"], options=opt,
+                                     trace=tr, tree_root=max(r["tree_root"], 0))
+    assert ok
+    assert (tr.l1_iterations, tr.irls_iterations) == (r["l1_iterations"], r["irls_iterations"])
+    assert r["admm_iterations"] <= 10 * r["l1_iterations"]  # the budget stays 10 per solve: the doubling at gra.cc:536-537 is lost
+    d = _dist(so3.aa_to_quat(rot), r["frame_q"])
+    print(f"[ref ra] trivial skip={skip} weight={use_weight} type={weight_type}: L1 {tr.l1_iterations} IRLS {tr.irls_iterations} max {d.max():.2e} rad")
+    # half-norm weights |r|^-1.5 reach 1e6 and more against the gauge rows' 1: the gauge is held to ~1e-8 only, on both sides,
+    # and what is left is one common rotation (every frame ~2.8e-8 here) — compared relative to the fixed frame then
+    if weight_type == ora.HALF_NORM:
+        rel = lambda q: so3.quat_mul(q, so3.quat_conj(q[r["fixed_image"]][None]))  # noqa: E731
+        d = _dist(rel(so3.aa_to_quat(rot)), rel(r["frame_q"]))
+    assert d.max() < TOL
+
+
+def test_invalid_pairs_and_the_l1_only_and_irls_only_paths():
+    p = synthetic.make_ring_view_graph(30, 5, seed=7)
+    N, E = p.num_nodes, len(p.edge_i)
+    rng = np.random.default_rng(7)
+    valid = rng.random(E) > 0.15
+    for l1, irls in ((0, 100), (5, 0)):
+        r = ref.ra_estimate([0], np.zeros(N), np.arange(N), np.zeros(N), p.edge_i, p.edge_j, p.edge_q, pair_valid=valid,
+                            frame_q=so3.aa_to_quat(p.node_aa0), skip_initialization=1, max_num_l1_iterations=l1,
+                            max_num_irls_iterations=irls)
+        tr = ora.RaTrace()
+        opt = ora.RotationEstimatorOptions(skip_initialization=True, max_num_l1_iterations=l1, max_num_irls_iterations=irls)
+        ok, rot = ora.estimate_rotations(N, p.edge_i[valid], p.edge_j[valid], p.edge_q[valid], np.ones(int(valid.sum())),
+                                         np.ones(int(valid.sum()), np.int32), p.node_aa0, fixed_node=r["fixed_image"], options=opt, trace=tr)
+        assert r["ok"] and ok and (tr.l1_iterations, tr.irls_iterations) == (r["l1_iterations"], r["irls_iterations"])
+        assert _dist(so3.aa_to_quat(rot), r["frame_q"]).max() < TOL
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# rigs
+# ---------------------------------------------------------------------------------------------------------------
+def _rig_scene(frames, cams, seed, noise_deg, outlier):
+    from test_ra_rigs import make_rig_view_graph
+
+    s = make_rig_view_graph(frames, cams, seed=seed, noise_deg=noise_deg, outlier=outlier)
+    rng = np.random.default_rng(seed)
+    s["ninl"] = _distinct_inliers(rng, s["ii"].size)
+    S = cams
+    rig_of_frame = np.arange(frames) % 2  # synthetic.make_rig_problems: frames alternate between two rigs
+    sensor = np.tile(np.arange(S), frames)
+    s["frame_rig"] = rig_of_frame
+    s["image_camera"] = rig_of_frame[s["imf"]] * S + sensor  # one camera per (rig, sensor); sensor 0 is the reference sensor
+    s["rig_ref_cam"] = np.array([0, S])
+    s["sensor_rig"] = np.repeat([0, 1], S - 1)
+    s["sensor_cam"] = np.concatenate([r * S + np.arange(1, S) for r in (0, 1)])  # block index = r (S - 1) + sensor - 1: this order
+    return s
+
+
+@pytest.mark.parametrize("frames,cams,noise,outlier,seed", [(14, 3, 0.5, 0.05, 2), (20, 2, 1.0, 0.1, 3), (14, 3, 0.0, 0.0, 4)])
+def test_unknown_cam_from_rig_rotations_equal_the_reference(frames, cams, noise, outlier, seed):
+    """skip_initialization: frames and cam blocks start from given values (translation NaN marks a cam_from_rig as unknown,
+    gra.cc:176-178)."""
+    s = _rig_scene(frames, cams, seed, noise, outlier)
+    rng = np.random.default_rng(seed + 50)
+    aa_f = so3.quat_to_aa(so3.rotmat_to_quat(so3.aa_to_rotmat(rng.normal(0, 0.05, (s["N"], 3))) @ s["R_f"]))
+    aa_c = so3.quat_to_aa(so3.rotmat_to_quat(so3.aa_to_rotmat(rng.normal(0, 0.05, (s["C"], 3))) @ s["R_c"]))
+    r = ref.ra_estimate(s["rig_ref_cam"], s["frame_rig"], s["imf"], s["image_camera"], s["ii"], s["jj"], s["q"], pair_ninl=s["ninl"],
+                        sensor_rig=s["sensor_rig"], sensor_cam=s["sensor_cam"], sensor_state=np.full(s["C"], 2),
+                        sensor_q=so3.aa_to_quat(aa_c), frame_q=so3.aa_to_quat(aa_f), skip_initialization=1)
+    assert r["ok"] and r["sensor_has"].all()
+    fixed_frame = int(s["imf"][r["fixed_image"]])
+    tr = ora.RaTrace()
+    ok, rf, rc = ora.estimate_rotations_rig(s["N"], s["C"], s["imf"], s["imc"], s["ii"], s["jj"], s["q"], np.ones(s["ii"].size), aa_f, aa_c,
+                                            fixed_frame, ora.RotationEstimatorOptions(skip_initialization=True), trace=tr)
+    assert ok and (tr.l1_iterations, tr.irls_iterations) == (r["l1_iterations"], r["irls_iterations"])
+    df, dc = _dist(so3.aa_to_quat(rf), r["frame_q"]), _dist(so3.aa_to_quat(rc), r["sensor_q"])
+    print(f"[ref ra] unknown rig {frames}x{cams}: L1 {tr.l1_iterations} IRLS {tr.irls_iterations} frames {df.max():.2e} cams {dc.max():.2e} rad")
+    assert df.max() < 1e-9 and dc.max() < 1e-9  # (the quaternion average of gra.cc:676-686 goes through an eigen-decomposition)
+
+
+def test_spanning_tree_start_and_image_to_rig_conversion_equal_the_reference():
+    """skip_initialization = false with every cam_from_rig unknown (nullopt): spanning tree over the IMAGES, then
+    ConvertRotationsFromImageToRig, then the solve.  Zero iterations on both sides isolate the start."""
+    s = _rig_scene(14, 3, 6, 0.5, 0.05)
+    kw = dict(max_num_l1_iterations=0, max_num_irls_iterations=0)
+    r = ref.ra_estimate(s["rig_ref_cam"], s["frame_rig"], s["imf"], s["image_camera"], s["ii"], s["jj"], s["q"], pair_ninl=s["ninl"],
+                        sensor_rig=s["sensor_rig"], sensor_cam=s["sensor_cam"], sensor_state=np.zeros(s["C"]), **kw)
+    assert r["ok"] and r["sensor_has"].all() and r["tree_root"] >= 0
+    I = s["imf"].size
+    aa_img = ora.maximum_spanning_tree_init(I, s["ii"], s["jj"], so3.quat_to_rotmat(s["q"]), s["ninl"], np.zeros((I, 3)), root=r["tree_root"])
+    R_f, R_c = estimators.convert_rotations_from_image_to_rig(so3.aa_to_rotmat(aa_img), s["imf"], s["imc"], s["N"], s["C"])
+    assert _dist(so3.rotmat_to_quat(R_f), r["frame_q"]).max() < 1e-9
+    assert _dist(so3.rotmat_to_quat(R_c), r["sensor_q"]).max() < 1e-9
+    # and the full run from that start
+    r = ref.ra_estimate(s["rig_ref_cam"], s["frame_rig"], s["imf"], s["image_camera"], s["ii"], s["jj"], s["q"], pair_ninl=s["ninl"],
+                        sensor_rig=s["sensor_rig"], sensor_cam=s["sensor_cam"], sensor_state=np.zeros(s["C"]))
+    tr = ora.RaTrace()
+    ok, rf, rc = ora.estimate_rotations_rig(s["N"], s["C"], s["imf"], s["imc"], s["ii"], s["jj"], s["q"], np.ones(s["ii"].size),
+                                            so3.quat_to_aa(so3.rotmat_to_quat(R_f)), so3.quat_to_aa(so3.rotmat_to_quat(R_c)),
+                                            int(s["imf"][r["fixed_image"]]), ora.RotationEstimatorOptions(skip_initialization=True), trace=tr)
+    assert ok and (tr.l1_iterations, tr.irls_iterations) == (r["l1_iterations"], r["irls_iterations"])
+    assert _dist(so3.aa_to_quat(rf), r["frame_q"]).max() < 1e-9 and _dist(so3.aa_to_quat(rc), r["sensor_q"]).max() < 1e-9
+
+
+def test_calibrated_rigs_fold_into_the_relative_rotations():
+    """Known cam_from_rig (gra.cc:286-309): R_rel' = cam2_from_rig2^-1 cam2_from_cam1 cam1_from_rig1 between FRAMES, pairs inside
+    one frame dropped — the plain oracle on the frame graph."""
+    s = _rig_scene(16, 3, 8, 0.5, 0.05)
+    q_c = so3.rotmat_to_quat(s["R_c"])
+    rng = np.random.default_rng(1)
+    aa_f = so3.quat_to_aa(so3.rotmat_to_quat(so3.aa_to_rotmat(rng.normal(0, 0.05, (s["N"], 3))) @ s["R_f"]))
+    r = ref.ra_estimate(s["rig_ref_cam"], s["frame_rig"], s["imf"], s["image_camera"], s["ii"], s["jj"], s["q"], pair_ninl=s["ninl"],
+                        sensor_rig=s["sensor_rig"], sensor_cam=s["sensor_cam"], sensor_state=np.ones(s["C"]), sensor_q=q_c,
+                        frame_q=so3.aa_to_quat(aa_f), skip_initialization=1)
+    assert r["ok"]
+    ident = np.array([1.0, 0, 0, 0])
+    q_img = np.where((s["imc"] >= 0)[:, None], q_c[np.maximum(s["imc"], 0)], ident)  # cam_from_rig of every image
+    q_fold = so3.quat_mul(so3.quat_mul(so3.quat_conj(q_img[s["jj"]]), s["q"]), q_img[s["ii"]])
+    fi, fj = s["imf"][s["ii"]], s["imf"][s["jj"]]
+    keep = fi != fj
+    tr = ora.RaTrace()
+    ok, rot = ora.estimate_rotations(s["N"], fi[keep], fj[keep], q_fold[keep], np.ones(int(keep.sum())), np.ones(int(keep.sum()), np.int32),
+                                     aa_f, fixed_node=int(s["imf"][r["fixed_image"]]),
+                                     options=ora.RotationEstimatorOptions(skip_initialization=True), trace=tr)
+    assert ok and (tr.l1_iterations, tr.irls_iterations) == (r["l1_iterations"], r["irls_iterations"])
+    assert _dist(so3.aa_to_quat(rot), r["frame_q"]).max() < TOL
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# gravity
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("frac,seed,use_weight", [(0.6, 3, 0), (0.3, 4, 1), (1.0, 5, 0), (0.0, 6, 0)])
+def test_gravity_aligned_frames_equal_the_reference(frac, seed, use_weight):
+    """Gravity frames with a NON-trivial alignment: rig_from_world = R_align Ry(angle).  The flat oracle takes the relative
+    rotations already aligned (R_align_j^T R_rel R_align_i, gra.cc:312-327) and the angle as (0, angle, 0)."""
+    from test_ra_gravity import make_gravity_graph
+
+    p = make_gravity_graph(40, 6, seed=seed, frac=frac)
+    N, E = p.num_nodes, len(p.edge_i)
+    rng = np.random.default_rng(seed + 11)
+    g = p.node_gravity.astype(bool)
+    R_align = so3.aa_to_rotmat(rng.normal(0, 0.7, (N, 3)))
+    R_align[~g] = np.eye(3)
+    R0 = R_align @ so3.aa_to_rotmat(p.node_aa0)  # the start the reference reads the angle back from (gra.cc:207-211)
+    R_rel = R_align[p.edge_j] @ so3.quat_to_rotmat(p.edge_q) @ np.transpose(R_align[p.edge_i], (0, 2, 1))  # un-aligned measurements
+    Ra = R_align.copy()
+    Ra[~g] = np.nan
+    w = rng.uniform(0.2, 1.0, E)
+    r = ref.ra_estimate([0], np.zeros(N), np.arange(N), np.zeros(N), p.edge_i, p.edge_j, so3.rotmat_to_quat(R_rel), pair_weight=w,
+                        frame_q=so3.rotmat_to_quat(R0), frame_R_align=Ra, use_gravity=1, use_weight=use_weight)
+    assert r["ok"] and r["tree_root"] == -1  # no spanning-tree start in this mode (gra.cc:60-62)
+    if g.any():
+        assert g[r["fixed_image"]]  # the first gravity frame the map yields becomes the gauge (gra.cc:213-217)
+    tr = ora.RaTrace()
+    # (the oracle's measurements: the aligned ones, recomputed from what the reference was given)
+    q_al = so3.rotmat_to_quat(np.transpose(R_align[p.edge_j], (0, 2, 1)) @ R_rel @ R_align[p.edge_i])
+    ok, rot = ora.estimate_rotations_gravity(N, p.edge_i, p.edge_j, q_al, w, p.node_gravity, p.node_aa0, r["fixed_image"],
+                                             ora.RotationEstimatorOptions(use_weight=bool(use_weight)), tr)
+    assert ok and (tr.l1_iterations, tr.irls_iterations) == (r["l1_iterations"], r["irls_iterations"])
+    d = _dist(so3.rotmat_to_quat(R_align @ so3.aa_to_rotmat(rot)), r["frame_q"])
+    print(f"[ref ra] gravity frac={frac}: L1 {tr.l1_iterations} IRLS {tr.irls_iterations} max {d.max():.2e} rad")
+    assert d.max() < 1e-9
