@@ -400,6 +400,26 @@ def solve(num_cams, pt_offset, obs_cam, obs_xy, cam_intr, intr_model, fixed_cam,
     With `image_sensor` [I] (-1 = reference sensor) and `sensor_cam_from_rig` [S,7] the cam_from_rig of image i is the
     sensor's entry: constant unless options.optimize_rig_poses, else S more pose blocks (RigReprojErrorCostFunctor,
     ba.cc:161-179) whose result is returned as summary.sensor_cam_from_rig."""
+    b = build_problem(num_cams, pt_offset, obs_cam, obs_xy, cam_intr, intr_model, fixed_cam, cam_q, cam_t, pt_xyz, intr_params, options,
+                      image_frame, image_cam_from_rig, image_intr, image_sensor, sensor_cam_from_rig)
+    opt, N, S, used, X_all = b["opt"], int(num_cams), b["num_sensors"], b["used"], b["X_all"]
+    if b["problem"] is None:
+        return False, b["q0"][:N], b["t0"][:N], X_all, b["intr0"], lm.LmSummary(usable=False)
+    prob = b["problem"]
+    x, summ = lm.solve(prob, b["x0"], opt.lm)
+    q, t, X, intr = prob.unpack(x)
+    X_all[used] = X
+    if S:
+        summ.sensor_cam_from_rig = np.concatenate([q[N:], t[N:]], axis=1)
+    return summ.usable, q[:N].copy(), t[:N].copy(), X_all, intr.copy(), summ
+
+
+def build_problem(num_cams, pt_offset, obs_cam, obs_xy, cam_intr, intr_model, fixed_cam, cam_q, cam_t, pt_xyz, intr_params,
+                  options: BundleAdjusterOptions | None = None, image_frame=None, image_cam_from_rig=None, image_intr=None,
+                  image_sensor=None, sensor_cam_from_rig=None):
+    """The problem BundleAdjuster::Solve poses (ba.cc:115-317), without minimising it: dict with `problem` (None when no
+    observation is left), `x0`, `used` (tracks in the problem), the start arrays.  tests/test_oracle_ref_ba.py holds it to
+    the reference's own builder."""
     opt = options or BundleAdjusterOptions()
     N = int(num_cams)
     pt_offset = np.asarray(pt_offset, dtype=np.int64)
@@ -434,15 +454,11 @@ def solve(num_cams, pt_offset, obs_cam, obs_xy, cam_intr, intr_model, fixed_cam,
     xy = np.asarray(obs_xy, dtype=np.float64)[keep]
     X_all = np.array(pt_xyz, dtype=np.float64, copy=True)
     intr0 = np.array(intr_params, dtype=np.float64, copy=True)
+    out = dict(opt=opt, num_sensors=S, used=used, X_all=X_all, q0=q0, t0=t0, intr0=intr0, problem=None, x0=None)
     if cam.shape[0] == 0:
-        return False, q0[:N], t0[:N], X_all, intr0, lm.LmSummary(usable=False)
+        return out
     prob = _BaProblem(N + S, cam, pt, xy, None if cam_intr is None else np.asarray(cam_intr, dtype=np.int64),
                       np.asarray(intr_model, dtype=np.int64), int(fixed_cam), int(used.sum()), opt, obs_ik, Rs, ts,
                       obs_sens, S)
-    x0 = prob.pack(q0, t0, X_all[used], intr0)
-    x, summ = lm.solve(prob, x0, opt.lm)
-    q, t, X, intr = prob.unpack(x)
-    X_all[used] = X
-    if S:
-        summ.sensor_cam_from_rig = np.concatenate([q[N:], t[N:]], axis=1)
-    return summ.usable, q[:N].copy(), t[:N].copy(), X_all, intr.copy(), summ
+    out["problem"], out["x0"] = prob, prob.pack(q0, t0, X_all[used], intr0)
+    return out

@@ -282,3 +282,83 @@ def ra_estimate(rig_ref_cam, frame_rig, image_frame, image_cam, pair_i, pair_j, 
     return dict(ok=bool(ok), frame_q=out_fq, sensor_q=out_sq[:S], sensor_has=out_sh[:S].astype(bool), fixed_image=int(info[0]),
                 tree_root=int(info[1]), l1_iterations=int(info[2]), admm_iterations=int(info[3]), irls_iterations=int(info[4]),
                 first_frame=int(info[5]))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the reference's bundle adjustment PROBLEM BUILDER (bundle_adjustment.cc) on the recording Ceres
+# ---------------------------------------------------------------------------------------------------------------
+LIB_BA = HERE / "_ref" / "libref_glomap_ba.so"
+_lib_ba = None
+
+
+class _BaOptions(C.Structure):
+    _fields_ = [("optimize_rig_poses", C.c_int), ("optimize_rotations", C.c_int), ("optimize_translation", C.c_int),
+                ("optimize_intrinsics", C.c_int), ("optimize_principal_point", C.c_int), ("optimize_points", C.c_int),
+                ("min_num_view_per_track", C.c_int), ("thres_loss_function", C.c_double)]
+
+
+def load_ba():
+    global _lib_ba
+    if _lib_ba is None:
+        load()
+        if LIB_BA.exists():
+            _lib_ba = C.CDLL(str(LIB_BA))
+            _lib_ba.ref_ba_build.restype = C.c_long
+    return _lib_ba
+
+
+def ba_build(cam_model, cam_params, frame_q, frame_t, image_frame, image_cam, pt_offset, obs_image, obs_xy, pt_xyz, rig_ref_cam=(0,),
+             frame_rig=None, sensor_rig=(), sensor_cam=(), sensor_pose=None, frame_has_pose=None, image_present=None, **options):
+    """BundleAdjuster::Solve of the reference with a Ceres that records instead of minimising (bundle_adjustment.cc:9-113).
+    Every observation becomes its own feature of its image.  Returns a dict: per residual block kind / frame / track / camera /
+    sensor; frame_flags, camera_flags, sensor_flags, track_flags (bit 0 in the problem, 1 rotation-or-block constant,
+    2 translation constant, 3 quaternion manifold, 4 ordering group 0, 5 in no group), camera_subset [K,8], frame_order,
+    linear_solver_type, preconditioner_type, initial_cost."""
+    lib = load_ba()
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)  # noqa: E731
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+    cm, cp = i32(cam_model), np.zeros((len(cam_model), 8))
+    cp[:, : np.shape(cam_params)[1]] = cam_params
+    fq, ft = f64(frame_q), f64(frame_t)
+    F, I, K, S = len(fq), len(image_frame), len(cm), len(sensor_rig)
+    fr = i32(np.zeros(F) if frame_rig is None else frame_rig)
+    hp = np.ascontiguousarray(np.ones(F) if frame_has_pose is None else frame_has_pose, dtype=np.uint8)
+    imf, imc = i32(image_frame), i32(image_cam)
+    pres = np.ascontiguousarray(np.ones(I) if image_present is None else image_present, dtype=np.uint8)
+    off, oi = np.ascontiguousarray(pt_offset, dtype=np.int64), i32(obs_image)
+    M, P = len(oi), len(off) - 1
+    # features: the observations of an image, in observation order
+    order = np.argsort(oi, kind="stable")
+    feat_off = np.zeros(I + 1, dtype=np.int64)
+    feat_off[1:] = np.cumsum(np.bincount(oi, minlength=I))
+    feat_xy = f64(np.asarray(obs_xy, dtype=np.float64)[order])
+    obs_feature = np.empty(M, dtype=np.int32)
+    obs_feature[order] = (np.arange(M) - feat_off[oi[order]]).astype(np.int32)
+    X = f64(pt_xyz)
+    rr, sr, sc = i32(rig_ref_cam), i32(sensor_rig), i32(sensor_cam)
+    sp = f64(np.zeros((max(S, 1), 7)) if sensor_pose is None else sensor_pose)
+    o = _BaOptions(0, 1, 1, 1, 0, 1, 3, 1.0)
+    for k, v in options.items():
+        setattr(o, k, type(getattr(o, k))(v))
+    cap = M + 8
+    out = dict(kind=np.zeros(cap, np.int32), frame=np.zeros(cap, np.int32), track=np.zeros(cap, np.int64), camera=np.zeros(cap, np.int32),
+               sensor=np.zeros(cap, np.int32), frame_flags=np.zeros(F, np.uint8), camera_flags=np.zeros(K, np.uint8),
+               camera_subset=np.zeros((K, 8), np.uint8), sensor_flags=np.zeros(max(S, 1), np.uint8), track_flags=np.zeros(max(P, 1), np.uint8),
+               frame_order=np.zeros(F, np.int32))
+    info, cost = np.zeros(4, np.int64), C.c_double(0.0)
+    vp = C.c_void_p
+    R = lib.ref_ba_build(C.c_int(K), vp(_p(cm)), vp(_p(cp)), C.c_int(len(rr)), vp(_p(rr)), C.c_int(S), vp(_p(sr)), vp(_p(sc)), vp(_p(sp)),
+                         C.c_int(F), vp(_p(fr)), vp(_p(hp)), vp(_p(fq)), vp(_p(ft)), C.c_int(I), vp(_p(imf)), vp(_p(imc)), vp(_p(pres)),
+                         vp(_p(feat_off)), vp(_p(feat_xy)), C.c_long(P), vp(_p(off)), vp(_p(oi)), vp(_p(obs_feature)), vp(_p(X)), C.byref(o),
+                         C.c_long(cap), vp(_p(out["kind"])), vp(_p(out["frame"])), vp(_p(out["track"])), vp(_p(out["camera"])),
+                         vp(_p(out["sensor"])), vp(_p(out["frame_flags"])), vp(_p(out["camera_flags"])), vp(_p(out["camera_subset"])),
+                         vp(_p(out["sensor_flags"])), vp(_p(out["track_flags"])), vp(_p(out["frame_order"])), vp(_p(info)), C.byref(cost))
+    out["num_residual_blocks"] = int(R)
+    if R < 0:
+        return out
+    for k in ("kind", "frame", "track", "camera", "sensor"):
+        out[k] = out[k][:R]
+    out["sensor_flags"], out["track_flags"] = out["sensor_flags"][:S], out["track_flags"][:P]
+    out["linear_solver_type"], out["preconditioner_type"] = int(info[0]), int(info[1])
+    out["initial_cost"] = float(cost.value)
+    return out

@@ -149,6 +149,14 @@ class Problem {
   const std::vector<ResidualBlock>& residual_blocks() const { return residuals_; }
   const std::map<std::pair<double*, int>, double>& lower_bounds() const { return lower_; }
   bool IsConstant(const double* values) const { return constant_.count(values) != 0; }
+  // manifolds, as the COLMAP helpers of ref_shim_ba/colmap/estimators/manifold.h record them: 0 = quaternion manifold,
+  // 1 = subset manifold with the listed constant coordinates
+  struct ManifoldTag {
+    int kind;
+    std::vector<int> constant_idxs;
+  };
+  void RecordManifold(const double* values, int kind, const std::vector<int>& idxs) { manifold_[values] = ManifoldTag{kind, idxs}; }
+  const std::map<const double*, ManifoldTag>& manifolds() const { return manifold_; }
   // parameter values at the moment ceres::Solve was called (the start point), per block pointer
   std::map<const double*, std::vector<double>>& start_values() { return start_; }
   const std::map<const double*, std::vector<double>>& start_values() const { return start_; }
@@ -159,6 +167,7 @@ class Problem {
   std::map<std::pair<double*, int>, double> lower_;
   std::set<const double*> constant_;
   std::map<const double*, std::vector<double>> start_;
+  std::map<const double*, ManifoldTag> manifold_;
 };
 
 class Solver {

@@ -88,7 +88,13 @@ struct Matrix3d {  // 3 x 3 in plain doubles, products evaluated as the usual tr
   double trace() const { return m[0] + m[4] + m[8]; }
 };
 struct Quaterniond {  // (w, x, y, z); q * v = R(q) v
-  double w_ = 1.0, x_ = 0.0, y_ = 0.0, z_ = 0.0;
+  double x_ = 0.0, y_ = 0.0, z_ = 0.0, w_ = 1.0;  // Eigen's coefficient order: coeffs() = (x, y, z, w)
+  struct Coeffs {
+    double* p;
+    double* data() { return p; }
+    double& operator()(int i) { return p[i]; }
+  };
+  Coeffs coeffs() { return Coeffs{&x_}; }  // (four consecutive doubles: the parameter block the reference hands to Ceres)
   Quaterniond() = default;
   Quaterniond(double w, double x, double y, double z) : w_(w), x_(x), y_(y), z_(z) {}
   static Quaterniond Identity() { return Quaterniond(); }
@@ -156,6 +162,13 @@ struct MatrixXi {  // ImagePair::matches: (row, col) access and rows()   (image_
 };
 }  // namespace Eigen
 
+namespace colmap {
+enum class CameraModelId {  // colmap/sensor/models.h
+  kInvalid = -1, kSimplePinhole = 0, kPinhole = 1, kSimpleRadial = 2, kRadial = 3, kOpenCV = 4, kOpenCVFisheye = 5, kFullOpenCV = 6,
+  kFOV = 7, kSimpleRadialFisheye = 8, kRadialFisheye = 9, kThinPrismFisheye = 10, kRadTanThinPrismFisheye = 11
+};
+}  // namespace colmap
+
 namespace glomap {
 using camera_t = uint32_t;  // colmap/util/types.h
 using image_t = uint32_t;
@@ -219,8 +232,19 @@ struct Rig {  // colmap/sensor/rig.h: what reconstruction_normalizer.cc:64-72 an
   sensor_t RefSensorId() const { return ref; }
   bool IsRefSensor(const sensor_t& s) const { return s == ref; }
 };
-struct Camera {  // colmap::Camera + scene/camera.h: the two members the filters read
+struct Camera {  // colmap::Camera + scene/camera.h: the two members the filters read, and what bundle_adjustment.cc touches
   bool has_prior_focal_length = true;
+  colmap::CameraModelId model_id = colmap::CameraModelId::kSimpleRadial;
+  std::vector<double> params;
+  std::vector<size_t> PrincipalPointIdxs() const {  // colmap/sensor/models.h: (cx, cy) of every model
+    switch (model_id) {
+      case colmap::CameraModelId::kSimplePinhole: case colmap::CameraModelId::kSimpleRadial: case colmap::CameraModelId::kRadial:
+      case colmap::CameraModelId::kSimpleRadialFisheye: case colmap::CameraModelId::kRadialFisheye:
+        return {1, 2};
+      default:
+        return {2, 3};
+    }
+  }
   std::optional<Eigen::Vector2d> ImgFromCam(const Eigen::Vector3d&) const { return std::nullopt; }  // pixel branch: not exercised
 };
 struct data_t {  // colmap/sensor/rig.h: (sensor, id of the datum = the image id), ordered by sensor then id
