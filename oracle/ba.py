@@ -15,7 +15,12 @@ CPU restatement of GLOMAP's global bundle adjustment for trivial rigs:
   loss            Huber(1 px)                                       bundle_adjustment.h:30,34-36
   solver          Ceres LM (oracle/lm.py), points eliminated first (ba.cc:204-208)
 
-parity unpinned: compared through converged solutions.
+PROBLEM BUILDER PINNED TO REFERENCE CODE (round 5): bundle_adjustment.cc compiles, unmodified, against the recording Ceres and
+stand-ins for COLMAP's cost-function factory / manifold helpers (oracle/_ref/libref_glomap_ba.so); tests/test_oracle_ref_ba.py
+holds build_problem() — residual blocks and their functor, constant blocks, principal-point subset, manifolds, elimination
+order, initial cost, trivial frames and both rig modes — to BundleAdjuster::Solve as the reference wrote it.  The projection
+functions (un-vendored COLMAP) and the minimiser (oracle/lm.py, Ceres' trust-region loop) are restatements: parity unpinned for
+those parts, compared through converged solutions.
 """
 from __future__ import annotations
 

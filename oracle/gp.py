@@ -17,7 +17,11 @@ CPU restatement of GLOMAP's global positioning.  ONLY_POINTS is the mode `glomap
   gauge               first scale constant                 gp.cc:484-489
   solver              Ceres LM (oracle/lm.py), exact linear solves
 
-parity unpinned: compared through converged solutions after Sim(3) alignment.
+PROBLEM BUILDER PINNED TO REFERENCE CODE (round 5): global_positioning.cc + cost_function.h compile, unmodified, against a
+recording Ceres (oracle/_ref/libref_glomap_gp.so); tests/test_oracle_ref.py holds the problem posed here — random start incl. the
+compiler-dependent draw order (rand_vector_order), residual blocks, losses, bounds, the constant scale, the initial cost — to
+GlobalPositioner::Solve as the reference wrote it.  The minimiser (oracle/lm.py) is a restatement of Ceres' trust-region loop:
+parity unpinned for that part, compared through converged solutions after Sim(3) alignment.
 """
 from __future__ import annotations
 

@@ -16,9 +16,13 @@ Follows, function by function:
   solve_irls                 : gra.cc:543-625
   estimate_rotations         : gra.cc:40-85
 
-parity unpinned: the reference stores no numeric vectors for RA; its tests only pin ground-truth
-recovery tolerances on synthetic scenes (rotation_averager_test.cc:166-167, 309-310), which
-tests/test_oracle_ra.py reproduces with glomap_amd.synthetic.
+PINNED TO REFERENCE CODE (round 5): global_rotation_averaging.cc, rotation_initializer.cc, math/rigid3d.cc and math/tree.cc
+compile, unmodified, against the Eigen / COLMAP / Boost stand-ins of oracle/ref_shim_ra/ (oracle/_ref/libref_glomap_ra.so);
+tests/test_oracle_ref_ra.py holds all three variants below to RotationEstimator::EstimateRotations as the reference wrote it:
+same L1 / IRLS iteration counts, rotations equal to 1e-14 rad.  What stays a restatement is the ADMM inside
+colmap::LeastAbsoluteDeviationSolver (un-vendored COLMAP; the stand-in and this file state it identically) — "parity unpinned"
+for that part.  The reference stores no numeric vectors for RA; its tests pin ground-truth recovery tolerances on synthetic
+scenes (rotation_averager_test.cc:166-167, 309-310), which tests/test_oracle_ra.py reproduces with glomap_amd.synthetic.
 """
 from __future__ import annotations
 
