@@ -88,6 +88,18 @@ def make_ring_view_graph(
     )
 
 
+def break_inlier_ties_by_index(edge_ninl: np.ndarray) -> np.ndarray:
+    """Distinct inlier counts with the order (count descending, edge index ascending): the maximum spanning tree of the
+    reference's start (tree.cc:78-153) is then unique.  With tied counts it depends on the order in which Boost's Kruskal
+    pops equal-weight edges off its priority queue — an implementation detail of the Boost version the reference is built
+    with; this library and the oracle break ties by edge index, which is what the returned counts encode."""
+    E = edge_ninl.shape[0]
+    order = np.lexsort((np.arange(E), -edge_ninl.astype(np.int64)))  # best edge first
+    out = np.empty(E, dtype=np.int32)
+    out[order] = np.arange(E, 0, -1, dtype=np.int32) + 10
+    return out
+
+
 def make_view_graph(
     kind: str = "geometric",
     num_cams: int = 1000,

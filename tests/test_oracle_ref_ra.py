@@ -212,3 +212,30 @@ def test_gravity_aligned_frames_equal_the_reference(frac, seed, use_weight):
     d = _dist(so3.rotmat_to_quat(R_align @ so3.aa_to_rotmat(rot)), r["frame_q"])
     print(f"[ref ra] gravity frac={frac}: L1 {tr.l1_iterations} IRLS {tr.irls_iterations} max {d.max():.2e} rad")
     assert d.max() < 1e-9
+
+
+def test_config2_oracle_equals_the_reference_code_golden():
+    """BASELINE configs[1] (1 000 cameras / 50 000 relative rotations): the C++ oracle (sparse direct solves, what the GPU parity
+    tests and bench.py's cpu_baseline run) against the rotations the reference's own code returned for the same view graph
+    (tests/golden/ra_c2_reference_code.npz, frozen by tests/golden/make_reference_code_golden.py)."""
+    from pathlib import Path
+
+    from oracle import cpu
+
+    g = np.load(Path(__file__).resolve().parent / "golden" / "ra_c2_reference_code.npz")
+    p = synthetic.make_ring_view_graph(1000, 50, seed=0)
+    N, f = p.num_nodes, int(g["fixed_image"])
+    lab = np.arange(N)
+    lab[[0, f]] = lab[[f, 0]]  # the reference roots its tree at, and fixes, image f; the flat form uses node 0
+    inv = np.empty(N, np.int64)
+    inv[lab] = np.arange(N)
+    rep = {}
+    # the benchmark's inlier counts are full of ties; the reference code ran on the counts made distinct in the order the oracle
+    # (and the HIP path) break ties — by edge index — so the oracle gives the same result on either set
+    for ninl in (p.edge_ninl, synthetic.break_inlier_ties_by_index(p.edge_ninl)):
+        ok, rot = cpu.ra_estimate_rotations(N, inv[p.edge_i].astype(np.int32), inv[p.edge_j].astype(np.int32), p.edge_q, p.edge_weight, ninl,
+                                            p.node_aa0[lab], 0, report=rep)
+        assert ok and (rep["l1_iterations"], rep["irls_iterations"]) == (int(g["l1_iterations"]), int(g["irls_iterations"]))
+        d = _dist(so3.aa_to_quat(rot), g["frame_q"][lab])
+        print(f"[ref ra] configs[1]: C++ oracle vs reference code max {d.max():.2e} rad")
+        assert d.max() < 1e-9
