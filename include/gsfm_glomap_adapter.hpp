@@ -350,9 +350,25 @@ class RotationEstimator {
         for (const auto& [sid, sensor] : rig.NonRefSensors())
           if (!sensor.has_value()) return false;
     }
+    // Two choices of the reference follow the iteration order of two DIFFERENT hash maps: the spanning tree of the start is
+    // rooted at the first registered image `images` yields (tree.cc:84-88, 141 — it keeps the identity rotation), the gauge is
+    // the first registered frame `frames` yields (gra.cc:248-257).  The library roots its tree at node 0 and takes the gauge as
+    // fixed_node: the root's frame is numbered first, the others in the order of `frames`.
+    const bool tree_start = !options_.skip_initialization && !options_.use_gravity;  // gra.cc:60-62
+    tree_root_ = kNoImage;
+    for (const auto& [id, im] : images)
+      if (im.frame_ptr != nullptr && im.IsRegistered()) {
+        tree_root_ = id;
+        break;
+      }
     detail::FrameIndex fidx;
+    if (tree_start && tree_root_ != kNoImage) fidx.Add(images.at(tree_root_).frame_id);
+    gauge_node_ = -1;
     for (auto& [fid, fr] : frames)
-      if (fr.is_registered) fidx.Add(fid);  // gra.cc:193-227; first one = gauge (gra.cc:248-257)
+      if (fr.is_registered) {
+        const int n = fidx.Add(fid);  // gra.cc:193-227
+        if (gauge_node_ < 0) gauge_node_ = n;  // gra.cc:248-257
+      }
     const int N = static_cast<int>(fidx.ids.size());
     if (N == 0) return false;
     if (rigged && !options_.use_gravity) {  // sensors whose cam_from_rig is to be estimated (no value, or NaN translation: gra.cc:173-191)
@@ -376,6 +392,7 @@ class RotationEstimator {
       img_ids.push_back(id);
       return static_cast<int>(img_ids.size()) - 1;
     };
+    if (rigged && tree_start && tree_root_ != kNoImage) image_index(tree_root_);  // node 0 of the image-level graph = the tree's root
     for (const auto& [pid, pair] : view_graph.image_pairs) {
       if (!pair.is_valid) continue;
       const auto& i1 = images.at(pair.image_id1);
@@ -421,7 +438,7 @@ class RotationEstimator {
     }
     std::vector<double> rot(3 * static_cast<size_t>(N));
     std::vector<uint8_t> node_gravity(static_cast<size_t>(N), 0);
-    int fixed_node = 0, first_gravity = -1;
+    int fixed_node = gauge_node_, first_gravity = -1;
     for (int n = 0; n < N; ++n) {
       auto& fr = frames.at(fidx.ids[n]);
       if (options_.use_gravity && fr.gravity_info.has_gravity) {
@@ -595,6 +612,7 @@ class RotationEstimator {
       image_fold.push_back(state == 0 ? std::array<double, 4>{cfr[0], cfr[1], cfr[2], cfr[3]} : std::array<double, 4>{1, 0, 0, 0});
       return idx;
     };
+    if (!options_.skip_initialization && tree_root_ != kNoImage) image_index(tree_root_);  // node 0 = the spanning tree's root
     for (const auto& [pid, pair] : view_graph.image_pairs) {
       if (!pair.is_valid) continue;
       const auto& i1 = images.at(pair.image_id1);
@@ -699,7 +717,7 @@ class RotationEstimator {
     o.skip_initialization = 1;
     o.use_weight = options_.use_weight;
     p.num_nodes = N;
-    p.fixed_node = 0;
+    p.fixed_node = gauge_node_;
     p.num_images = NI;
     p.image_frame = image_frame.data();
     p.image_cam = image_cam.data();
@@ -729,6 +747,9 @@ class RotationEstimator {
   }
 
   const glomap::RotationEstimatorOptions& options_;  // reference keeps a reference too (global_rotation_averaging.h:140)
+  static constexpr image_t kNoImage = static_cast<image_t>(-1);
+  image_t tree_root_ = kNoImage;  // first registered image of `images` (tree.cc:84-88)
+  int gauge_node_ = 0;            // node of the first registered frame of `frames` (gra.cc:248-257)
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -362,3 +362,66 @@ def ba_build(cam_model, cam_params, frame_q, frame_t, image_frame, image_cam, pt
     out["linear_solver_type"], out["preconditioner_type"] = int(info[0]), int(info[1])
     out["initial_cost"] = float(cost.value)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the reference's rotation-averaging CONTROLLER on either estimator: its own, or libgsfm's adapter class (the drop-in)
+# ---------------------------------------------------------------------------------------------------------------
+LIB_DROPIN = HERE / "_ref" / "libref_dropin_ra.so"
+_lib_dropin = None
+
+
+def load_dropin():
+    """oracle/_ref/libref_dropin_ra.so (links glomap_amd/csrc/libgsfm.so): built where the reference tree and the built
+    libgsfm.so exist, else the prebuilt file, else None."""
+    global _lib_dropin
+    if _lib_dropin is None:
+        load()
+        if (REFERENCE / "glomap" / "controllers" / "rotation_averager.cc").exists() and (HERE.parent / "glomap_amd" / "csrc" / "libgsfm.so").exists():
+            subprocess.run(["make", "-C", str(HERE), "-s", "ref_dropin", f"REF={REFERENCE}"], check=True)
+        if LIB_DROPIN.exists():
+            _lib_dropin = C.CDLL(str(LIB_DROPIN))
+            _lib_dropin.ref_ra_policy.restype = C.c_int
+    return _lib_dropin
+
+
+def ra_policy(which, rig_ref_cam, frame_rig, image_frame, image_cam, pair_i, pair_j, pair_q, pair_weight=None, pair_ninl=None,
+              pair_valid=None, sensor_rig=(), sensor_cam=(), sensor_state=(), sensor_q=None, frame_q=None, frame_R_align=None,
+              frame_registered=None, use_stratified=True, images_reversed=False, **options):
+    """glomap::SolveRotationAveraging (controllers/rotation_averager.cc:8-198), the reference's source compiled unmodified:
+    which = 0 on the reference's own RotationEstimator (CPU), which = 1 on include/gsfm_glomap_adapter.hpp's class (libgsfm, GPU).
+    Arguments as ra_estimate; images_reversed fills the images map in descending id order (another iteration order than the
+    frames map: tree root and gauge frame differ).  Returns a dict: ok, frame_q [F,4], sensor_q [S,4], sensor_has [S], frame_registered [F],
+    pair_valid [E]."""
+    lib = load_dropin()
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)  # noqa: E731
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+    rr, fr, imf, imc = i32(rig_ref_cam), i32(frame_rig), i32(image_frame), i32(image_cam)
+    pi, pj, pq = i32(pair_i), i32(pair_j), f64(pair_q)
+    E, F, S = len(pi), len(fr), len(sensor_rig)
+    pw = f64(np.full(E, -1.0) if pair_weight is None else pair_weight)
+    pn = i32(np.full(E, 100) if pair_ninl is None else pair_ninl)
+    pv = np.ascontiguousarray(np.ones(E) if pair_valid is None else pair_valid, dtype=np.uint8)
+    sr, sc, ss = i32(sensor_rig), i32(sensor_cam), i32(sensor_state)
+    sq = f64(np.tile([1.0, 0, 0, 0], (max(S, 1), 1)) if sensor_q is None else sensor_q)
+    has_pose = np.ascontiguousarray(np.zeros(F) if frame_q is None else np.ones(F), dtype=np.uint8)
+    fq = f64(np.tile([1.0, 0, 0, 0], (F, 1)) if frame_q is None else frame_q)
+    if frame_R_align is None:
+        has_g, Ra = np.zeros(F, np.uint8), np.zeros((F, 9))
+    else:
+        Ra = f64(frame_R_align).reshape(F, 9).copy()
+        has_g = np.ascontiguousarray(~np.isnan(Ra).any(axis=1), dtype=np.uint8)
+        Ra[has_g == 0] = 0.0
+    reg = np.ascontiguousarray(np.ones(F) if frame_registered is None else frame_registered, dtype=np.uint8)
+    o = _RaOptions(5, 1e-3, 100, 1e-3, 5.0, 0, 0, 0, 0)
+    for k, v in options.items():
+        setattr(o, k, type(getattr(o, k))(v))
+    out_fq, out_sq, out_sh = np.zeros((F, 4)), np.zeros((max(S, 1), 4)), np.zeros(max(S, 1), np.uint8)
+    out_reg, out_pv = np.zeros(F, np.uint8), np.zeros(max(E, 1), np.uint8)
+    vp = C.c_void_p
+    ok = lib.ref_ra_policy(C.c_int(int(which)), C.c_int(len(rr)), vp(_p(rr)), C.c_int(S), vp(_p(sr)), vp(_p(sc)), vp(_p(ss)), vp(_p(sq)), C.c_int(F),
+                           vp(_p(fr)), vp(_p(has_pose)), vp(_p(fq)), vp(_p(has_g)), vp(_p(Ra)), vp(_p(reg)), C.c_int(len(imf)), vp(_p(imf)),
+                           vp(_p(imc)), C.c_long(E), vp(_p(pi)), vp(_p(pj)), vp(_p(pq)), vp(_p(pw)), vp(_p(pn)), vp(_p(pv)), C.byref(o),
+                           C.c_int(int(bool(use_stratified))), C.c_int(int(bool(images_reversed))), vp(_p(out_fq)), vp(_p(out_sq)), vp(_p(out_sh)), vp(_p(out_reg)), vp(_p(out_pv)))
+    return dict(ok=bool(ok), frame_q=out_fq, sensor_q=out_sq[:S], sensor_has=out_sh[:S].astype(bool), frame_registered=out_reg.astype(bool),
+                pair_valid=out_pv[:E].astype(bool))

@@ -21,6 +21,7 @@
 #include <optional>
 #include <queue>
 #include <set>
+#include <string>
 #include <unordered_map>
 #include <unordered_set>
 #include <utility>
@@ -37,6 +38,7 @@ struct Vector2d {  // (a - b).norm(), a / s   (track_establishment.cc:127-128, t
   Vector2d operator-(const Vector2d& o) const { return Vector2d(x - o.x, y - o.y); }
   Vector2d operator/(double s) const { return Vector2d(x / s, y / s); }
   double operator()(int i) const { return i == 0 ? x : y; }
+  double operator[](int i) const { return i == 0 ? x : y; }
   double norm() const { return std::sqrt(x * x + y * y); }
 };
 struct Vector3d {
@@ -222,13 +224,21 @@ struct sensor_t {
   bool operator<(const sensor_t& o) const { return type != o.type ? type < o.type : id < o.id; }
   bool operator==(const sensor_t& o) const { return type == o.type && id == o.id; }
 };
-struct Rig {  // colmap/sensor/rig.h: what reconstruction_normalizer.cc:64-72 and global_positioning.cc touch
+struct Rig {  // colmap/sensor/rig.h: what reconstruction_normalizer.cc:64-72, the estimators and rotation_averager.cc touch
   sensor_t ref;
   std::map<sensor_t, std::optional<Rigid3d>> sensors;
+  rig_t rig_id = 0xffffffffu;
+  rig_t RigId() const { return rig_id; }
+  void SetRigId(rig_t id) { rig_id = id; }
+  void AddRefSensor(const sensor_t& s) { ref = s; }
+  void AddSensor(const sensor_t& s, const std::optional<Rigid3d>& sensor_from_rig = std::nullopt) { sensors[s] = sensor_from_rig; }
   std::map<sensor_t, std::optional<Rigid3d>>& NonRefSensors() { return sensors; }
+  const std::map<sensor_t, std::optional<Rigid3d>>& NonRefSensors() const { return sensors; }
   void SetSensorFromRig(const sensor_t& s, const Rigid3d& t) { sensors[s] = t; }
   Rigid3d& SensorFromRig(const sensor_t& s) { return sensors.at(s).value(); }
+  const Rigid3d& SensorFromRig(const sensor_t& s) const { return sensors.at(s).value(); }
   std::optional<Rigid3d>& MaybeSensorFromRig(const sensor_t& s) { return sensors.at(s); }
+  const std::optional<Rigid3d>& MaybeSensorFromRig(const sensor_t& s) const { return sensors.at(s); }
   sensor_t RefSensorId() const { return ref; }
   bool IsRefSensor(const sensor_t& s) const { return s == ref; }
 };
@@ -281,20 +291,33 @@ struct Frame {  // scene/frame.h:29-42 + colmap::Frame: flags, pose, data ids
   void SetRigFromWorld(const Rigid3d& t) { rig_from_world = t; has_pose = true; }
   rig_t rig_id = 0;
   Rig* rig_ptr = nullptr;
+  frame_t frame_id = 0xffffffffu;
   rig_t RigId() const { return rig_id; }
   Rig* RigPtr() const { return rig_ptr; }
+  void SetRigId(rig_t id) { rig_id = id; }
+  void SetRigPtr(Rig* p) { rig_ptr = p; }
+  frame_t FrameId() const { return frame_id; }
+  void SetFrameId(frame_t id) { frame_id = id; }
+  void AddDataId(const data_t& d) { data_ids.insert(d); }
 };
 struct Image {  // scene/image.h:10-53 (trivial frames: cam_from_world = the frame's rig_from_world)
   image_t image_id = 0;
   camera_t camera_id = 0;
   frame_t frame_id = 0;
   Frame* frame_ptr = nullptr;
+  std::string file_name;
   std::vector<Eigen::Vector2d> features;
   std::vector<Eigen::Vector3d> features_undist;
+  Image() = default;
+  Image(image_t img_id, camera_t cam_id, const std::string& file) : image_id(img_id), camera_id(cam_id), file_name(file) {}  // image.h:12-17
+  data_t DataId() const { return data_t(sensor_t(SensorType::CAMERA, camera_id), image_id); }  // image.h:101-103
   bool IsRegistered() const { return frame_ptr != nullptr && frame_ptr->is_registered; }  // image.h:65-67
-  Rigid3d CamFromWorld() const { return frame_ptr->RigFromWorld(); }                          // image.h:60-63
   bool HasTrivialFrame() const {  // image.h:73-76
     return frame_ptr->RigPtr() == nullptr || frame_ptr->RigPtr()->IsRefSensor(sensor_t(SensorType::CAMERA, camera_id));
+  }
+  Rigid3d CamFromWorld() const {  // image.h:60-63 -> colmap::Frame::SensorFromWorld: the frame's pose, through cam_from_rig if any
+    if (HasTrivialFrame()) return frame_ptr->RigFromWorld();
+    return frame_ptr->RigPtr()->SensorFromRig(sensor_t(SensorType::CAMERA, camera_id)) * frame_ptr->RigFromWorld();
   }
   Eigen::Vector3d Center() const { return CamFromWorld().rotation.inverse() * -CamFromWorld().translation; }  // image.h:55-57
   bool HasGravity() const {  // image.h:78-84
@@ -303,6 +326,8 @@ struct Image {  // scene/image.h:10-53 (trivial frames: cam_from_world = the fra
   }
 };
 struct ImagePair {  // scene/image_pair.h:13-57
+  ImagePair() = default;
+  ImagePair(image_t id1, image_t id2, const Rigid3d& pose = Rigid3d()) : image_id1(id1), image_id2(id2), cam2_from_cam1(pose) {}  // :16-27
   image_t image_id1 = 0, image_id2 = 0;
   bool is_valid = true;
   double weight = -1;  // image_pair.h:34-35
@@ -332,4 +357,9 @@ struct NullLog {
 #define VLOG_IS_ON(n) false
 #define LOG_FIRST_N(severity, n) ::ref_shim::NullLog()
 #define CHECK_GE(a, b) ::ref_shim::NullLog()
+#define THROW_CHECK_NE(a, b) ::ref_shim::NullLog()
 #endif
+namespace colmap {
+constexpr glomap::frame_t kInvalidFrameId = 0xffffffffu;  // colmap/util/types.h: std::numeric_limits<uint32_t>::max()
+constexpr glomap::rig_t kInvalidRigId = 0xffffffffu;
+}  // namespace colmap
