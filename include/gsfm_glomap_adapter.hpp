@@ -928,7 +928,7 @@ class GlobalPositioner {
       pr.pair_j = pair_j.data();
       pr.pair_dir = pair_dir.data();
     }
-    gsfm_report rep;
+    gsfm_report& rep = report_;
     if (gsfm_gp_solve(ctx, &pr, &o, cen.data(), xyz.data(), &rep) != GSFM_OK) return false;
     for (size_t k = 0; k < sensor_ids.size(); ++k) {  // ConvertResults: centre -> translation, t = -R c (gp.cc:576-582)
       auto& cfr = rigs.at(sensor_ids[k].first).SensorFromRig(glomap::sensor_t(glomap::SensorType::CAMERA, sensor_ids[k].second));
@@ -952,8 +952,12 @@ class GlobalPositioner {
     return true;
   }
 
+  // Not part of the reference's interface: what the library reported for the last Solve (iterations, initial / final cost)
+  const gsfm_report& LastReport() const { return report_; }
+
  private:
   glomap::GlobalPositionerOptions options_;
+  gsfm_report report_{};
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1101,7 +1105,7 @@ class BundleAdjuster {
         pr.sensor_cam_from_rig = sensor_cfr.data();
       }
     }
-    gsfm_report rep;
+    gsfm_report& rep = report_;
     if (gsfm_ba_solve(ctx, &pr, &o, q.data(), t.data(), xyz.data(), intr.data(), &rep) != GSFM_OK) return false;
     for (size_t k = 0; k < sensor_ids.size(); ++k) {  // the cam_from_rig blocks are the rigs' own storage (ba.cc:163-175)
       auto& cfr = rigs.at(sensor_ids[k].first).SensorFromRig(glomap::sensor_t(glomap::SensorType::CAMERA, sensor_ids[k].second));
@@ -1127,8 +1131,12 @@ class BundleAdjuster {
     return true;
   }
 
+  // Not part of the reference's interface: what the library reported for the last Solve
+  const gsfm_report& LastReport() const { return report_; }
+
  private:
   glomap::BundleAdjusterOptions options_;
+  gsfm_report report_{};
 };
 
 

@@ -186,6 +186,14 @@ def gp_build(cam_q, cam_t, pt_offset, obs_cam, obs_undist, pt_xyz, cam_calibrate
     xyz_start [P,3] (the start point handed to Ceres), cam_t_after [N,3] (after ConvertResults), initial_cost, and per
     residual block: cam, cam2, pt, scale, loss_scale, lower, scale_const, dir."""
     lib = load_gp()
+    pre, keep, (N, P, M, E), o = _gp_prefix(cam_q, cam_t, pt_offset, obs_cam, obs_undist, pt_xyz, cam_calibrated, cam_registered, pt_initialized,
+                                             pair_i, pair_j, pair_valid, pair_t, options)
+    return _gp_build_call(lib, pre, N, P, M, E)
+
+
+def _gp_prefix(cam_q, cam_t, pt_offset, obs_cam, obs_undist, pt_xyz, cam_calibrated, cam_registered, pt_initialized, pair_i, pair_j, pair_valid,
+               pair_t, options):
+    """The flat arguments shared by ref_gp_build and ref_gp_adapter_solve (oracle/ref_glue_gp_scene.h)."""
     q, t = np.ascontiguousarray(cam_q, dtype=np.float64), np.ascontiguousarray(cam_t, dtype=np.float64)
     off, oc = np.ascontiguousarray(pt_offset, dtype=np.int64), np.ascontiguousarray(obs_cam, dtype=np.int32)
     und, X = np.ascontiguousarray(obs_undist, dtype=np.float64), np.ascontiguousarray(pt_xyz, dtype=np.float64)
@@ -199,17 +207,26 @@ def gp_build(cam_q, cam_t, pt_offset, obs_cam, obs_undist, pt_xyz, cam_calibrate
     for k, v in options.items():
         setattr(o, k, type(getattr(o, k))(v))
     N, P, M = len(q), len(off) - 1, len(oc)
+    pre = [C.c_int(N), _p(q), _p(t), _p(cal), _p(reg), C.c_long(P), _p(off), _p(oc), _p(und), _p(X), _p(ini), C.c_long(E), _p(pi), _p(pj), _p(pv),
+           _p(pt), C.byref(o)]
+    return pre, (q, t, off, oc, und, X, cal, reg, ini, pv, pi, pj, pt, o), (N, P, M, E), o
+
+
+def _cv(args):
+    return [a if not isinstance(a, int) and a is not None else C.c_void_p(a) for a in args]
+
+
+def _gp_build_call(lib, pre, N, P, M, E):
     cap = M + E + 8
     out = dict(frame_order=np.zeros(N, np.int32), track_order=np.zeros(max(P, 1), np.int64), center_start=np.zeros((N, 3)),
                xyz_start=np.zeros((max(P, 1), 3)), cam_t_after=np.zeros((N, 3)), cam=np.zeros(cap, np.int32), cam2=np.zeros(cap, np.int32),
                pt=np.zeros(cap, np.int64), scale=np.zeros(cap), loss_scale=np.zeros(cap), lower=np.zeros(cap), scale_const=np.zeros(cap, np.uint8),
                dir=np.zeros((cap, 3)))
     cost = C.c_double(0.0)
-    args = [C.c_int(N), _p(q), _p(t), _p(cal), _p(reg), C.c_long(P), _p(off), _p(oc), _p(und), _p(X), _p(ini), C.c_long(E), _p(pi), _p(pj), _p(pv),
-            _p(pt), C.byref(o), _p(out["frame_order"]), _p(out["track_order"]), _p(out["center_start"]), _p(out["xyz_start"]),
-            _p(out["cam_t_after"]), C.c_long(cap), _p(out["cam"]), _p(out["cam2"]), _p(out["pt"]), _p(out["scale"]), _p(out["loss_scale"]),
-            _p(out["lower"]), _p(out["scale_const"]), _p(out["dir"]), C.byref(cost)]
-    R = lib.ref_gp_build(*[a if not isinstance(a, int) and a is not None else C.c_void_p(a) for a in args])
+    args = pre + [_p(out["frame_order"]), _p(out["track_order"]), _p(out["center_start"]), _p(out["xyz_start"]),
+                  _p(out["cam_t_after"]), C.c_long(cap), _p(out["cam"]), _p(out["cam2"]), _p(out["pt"]), _p(out["scale"]), _p(out["loss_scale"]),
+                  _p(out["lower"]), _p(out["scale_const"]), _p(out["dir"]), C.byref(cost)]
+    R = lib.ref_gp_build(*_cv(args))
     assert R >= 0, R
     for k in ("cam", "cam2", "pt", "scale", "loss_scale", "lower", "scale_const", "dir"):
         out[k] = out[k][:R]
@@ -315,6 +332,14 @@ def ba_build(cam_model, cam_params, frame_q, frame_t, image_frame, image_cam, pt
     2 translation constant, 3 quaternion manifold, 4 ordering group 0, 5 in no group), camera_subset [K,8], frame_order,
     linear_solver_type, preconditioner_type, initial_cost."""
     lib = load_ba()
+    pre, keep, (F, I, K, S, P, M) = _ba_prefix(cam_model, cam_params, frame_q, frame_t, image_frame, image_cam, pt_offset, obs_image, obs_xy, pt_xyz,
+                                               rig_ref_cam, frame_rig, sensor_rig, sensor_cam, sensor_pose, frame_has_pose, image_present, options)
+    return _ba_build_call(lib, pre, F, K, S, P, M)
+
+
+def _ba_prefix(cam_model, cam_params, frame_q, frame_t, image_frame, image_cam, pt_offset, obs_image, obs_xy, pt_xyz, rig_ref_cam, frame_rig,
+               sensor_rig, sensor_cam, sensor_pose, frame_has_pose, image_present, options):
+    """The flat arguments shared by ref_ba_build and ref_ba_adapter_solve (oracle/ref_glue_ba_scene.h)."""
     i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)  # noqa: E731
     f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
     cm, cp = i32(cam_model), np.zeros((len(cam_model), 8))
@@ -340,6 +365,14 @@ def ba_build(cam_model, cam_params, frame_q, frame_t, image_frame, image_cam, pt
     o = _BaOptions(0, 1, 1, 1, 0, 1, 3, 1.0)
     for k, v in options.items():
         setattr(o, k, type(getattr(o, k))(v))
+    vp = C.c_void_p
+    pre = [C.c_int(K), vp(_p(cm)), vp(_p(cp)), C.c_int(len(rr)), vp(_p(rr)), C.c_int(S), vp(_p(sr)), vp(_p(sc)), vp(_p(sp)), C.c_int(F), vp(_p(fr)),
+           vp(_p(hp)), vp(_p(fq)), vp(_p(ft)), C.c_int(I), vp(_p(imf)), vp(_p(imc)), vp(_p(pres)), vp(_p(feat_off)), vp(_p(feat_xy)), C.c_long(P),
+           vp(_p(off)), vp(_p(oi)), vp(_p(obs_feature)), vp(_p(X)), C.byref(o)]
+    return pre, (cm, cp, rr, sr, sc, sp, fr, hp, fq, ft, imf, imc, pres, feat_off, feat_xy, off, oi, obs_feature, X, o), (F, I, K, S, P, M)
+
+
+def _ba_build_call(lib, pre, F, K, S, P, M):
     cap = M + 8
     out = dict(kind=np.zeros(cap, np.int32), frame=np.zeros(cap, np.int32), track=np.zeros(cap, np.int64), camera=np.zeros(cap, np.int32),
                sensor=np.zeros(cap, np.int32), frame_flags=np.zeros(F, np.uint8), camera_flags=np.zeros(K, np.uint8),
@@ -347,10 +380,7 @@ def ba_build(cam_model, cam_params, frame_q, frame_t, image_frame, image_cam, pt
                frame_order=np.zeros(F, np.int32))
     info, cost = np.zeros(4, np.int64), C.c_double(0.0)
     vp = C.c_void_p
-    R = lib.ref_ba_build(C.c_int(K), vp(_p(cm)), vp(_p(cp)), C.c_int(len(rr)), vp(_p(rr)), C.c_int(S), vp(_p(sr)), vp(_p(sc)), vp(_p(sp)),
-                         C.c_int(F), vp(_p(fr)), vp(_p(hp)), vp(_p(fq)), vp(_p(ft)), C.c_int(I), vp(_p(imf)), vp(_p(imc)), vp(_p(pres)),
-                         vp(_p(feat_off)), vp(_p(feat_xy)), C.c_long(P), vp(_p(off)), vp(_p(oi)), vp(_p(obs_feature)), vp(_p(X)), C.byref(o),
-                         C.c_long(cap), vp(_p(out["kind"])), vp(_p(out["frame"])), vp(_p(out["track"])), vp(_p(out["camera"])),
+    R = lib.ref_ba_build(*pre, C.c_long(cap), vp(_p(out["kind"])), vp(_p(out["frame"])), vp(_p(out["track"])), vp(_p(out["camera"])),
                          vp(_p(out["sensor"])), vp(_p(out["frame_flags"])), vp(_p(out["camera_flags"])), vp(_p(out["camera_subset"])),
                          vp(_p(out["sensor_flags"])), vp(_p(out["track_flags"])), vp(_p(out["frame_order"])), vp(_p(info)), C.byref(cost))
     out["num_residual_blocks"] = int(R)
@@ -425,3 +455,33 @@ def ra_policy(which, rig_ref_cam, frame_rig, image_frame, image_cam, pair_i, pai
                            C.c_int(int(bool(use_stratified))), C.c_int(int(bool(images_reversed))), vp(_p(out_fq)), vp(_p(out_sq)), vp(_p(out_sh)), vp(_p(out_reg)), vp(_p(out_pv)))
     return dict(ok=bool(ok), frame_q=out_fq, sensor_q=out_sq[:S], sensor_has=out_sh[:S].astype(bool), frame_registered=out_reg.astype(bool),
                 pair_valid=out_pv[:E].astype(bool))
+
+
+def gp_adapter_solve(cam_q, cam_t, pt_offset, obs_cam, obs_undist, pt_xyz, cam_calibrated=None, cam_registered=None, pt_initialized=None,
+                     pair_i=None, pair_j=None, pair_valid=None, pair_t=None, **options):
+    """include/gsfm_glomap_adapter.hpp's GlobalPositioner::Solve (libgsfm, GPU) on the containers gp_build hands to the reference's
+    class — same arguments.  Returns a dict: ok, initial_cost, final_cost, iterations, center [N,3], xyz [P,3], initialized [P]."""
+    lib = load_dropin()
+    pre, keep, (N, P, M, E), o = _gp_prefix(cam_q, cam_t, pt_offset, obs_cam, obs_undist, pt_xyz, cam_calibrated, cam_registered, pt_initialized,
+                                             pair_i, pair_j, pair_valid, pair_t, options)
+    rep, cen, xyz, ini = np.zeros(4), np.zeros((N, 3)), np.zeros((max(P, 1), 3)), np.zeros(max(P, 1), np.uint8)
+    lib.ref_gp_adapter_solve.restype = C.c_int
+    ok = lib.ref_gp_adapter_solve(*_cv(pre + [_p(rep), _p(cen), _p(xyz), _p(ini)]))
+    return dict(ok=bool(ok), initial_cost=float(rep[0]), final_cost=float(rep[1]), iterations=int(rep[2]), center=cen, xyz=xyz[:P],
+                initialized=ini[:P].astype(bool))
+
+
+def ba_adapter_solve(cam_model, cam_params, frame_q, frame_t, image_frame, image_cam, pt_offset, obs_image, obs_xy, pt_xyz, rig_ref_cam=(0,),
+                     frame_rig=None, sensor_rig=(), sensor_cam=(), sensor_pose=None, frame_has_pose=None, image_present=None, **options):
+    """include/gsfm_glomap_adapter.hpp's BundleAdjuster::Solve (libgsfm, GPU) on the containers ba_build hands to the reference's
+    class — same arguments.  Returns a dict: ok, initial_cost, final_cost, iterations, frame_q [F,4], frame_t [F,3], cam_params
+    [K,8], xyz [P,3]."""
+    lib = load_dropin()
+    pre, keep, (F, I, K, S, P, M) = _ba_prefix(cam_model, cam_params, frame_q, frame_t, image_frame, image_cam, pt_offset, obs_image, obs_xy, pt_xyz,
+                                               rig_ref_cam, frame_rig, sensor_rig, sensor_cam, sensor_pose, frame_has_pose, image_present, options)
+    rep, fq, ft, cp, xyz = np.zeros(4), np.zeros((F, 4)), np.zeros((F, 3)), np.zeros((K, 8)), np.zeros((max(P, 1), 3))
+    vp = C.c_void_p
+    lib.ref_ba_adapter_solve.restype = C.c_int
+    ok = lib.ref_ba_adapter_solve(*pre, vp(_p(rep)), vp(_p(fq)), vp(_p(ft)), vp(_p(cp)), vp(_p(xyz)))
+    return dict(ok=bool(ok), initial_cost=float(rep[0]), final_cost=float(rep[1]), iterations=int(rep[2]), frame_q=fq, frame_t=ft,
+                cam_params=cp, xyz=xyz[:P])

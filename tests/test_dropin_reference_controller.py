@@ -195,3 +195,73 @@ def test_reference_controller_on_libgsfm_equals_reference_controller_on_referenc
     ds = dist(r0["sensor_q"][r0["sensor_has"]], r1["sensor_q"][r1["sensor_has"]]).max() if r0["sensor_has"].any() else 0.0
     print(f"[parity] DROP-IN {name}{' (images walk differs)' if images_reversed else ''}: reference controller on libgsfm vs on the reference estimator: frames {df:.2e} rad, sensors {ds:.2e} rad")
     assert df < 1e-6 and ds < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GlobalPositioner / BundleAdjuster of the adapter on the containers the reference's own classes get
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1])
+def test_adapter_global_positioner_on_reference_containers(seed):
+    """Same flat arrays -> same std::unordered_map containers (oracle/ref_glue_gp_scene.h), once into the reference's
+    GlobalPositioner::Solve on the recording Ceres (ref.gp_build) and once into the adapter's (ref.gp_adapter_solve, libgsfm):
+    the cost of the start is the same number — the adapter walked the hash maps the way the reference does, drew in its order
+    (g++ argument order included: both sides are g++ builds), kept the same tracks — and the results come back through the
+    containers the way ConvertResults leaves them."""
+    from glomap_amd import synthetic
+
+    p = synthetic.make_gp_problem(num_cams=60, num_pts=2000, seed=seed, uncalibrated_ratio=0.2, dir_noise=1e-3, outlier_ratio=0.02)
+    # two-view tracks and an unobserved camera: in the walk, not in the problem
+    keep = np.ones(p.num_obs, bool)
+    for t in (3, 17, 40):
+        keep[p.pt_offset[t] + 2 : p.pt_offset[t + 1]] = False
+    keep[p.obs_cam == 5] = False
+    lens = np.diff(p.pt_offset)
+    trk = np.repeat(np.arange(p.num_pts), lens)
+    off = np.zeros(p.num_pts + 1, dtype=np.int64)
+    off[1:] = np.cumsum(np.bincount(trk[keep], minlength=p.num_pts))
+    obs_cam, obs_dir, obs_cal = p.obs_cam[keep], p.obs_dir[keep], p.obs_calibrated[keep]
+    q = so3.rotmat_to_quat(p.cam_R)
+    t = -np.einsum("nij,nj->ni", p.cam_R, p.gt_center)
+    und = np.einsum("mij,mj->mi", p.cam_R[obs_cam], obs_dir)
+    cal = np.ones(p.num_cams, np.uint8)
+    cal[obs_cam] = obs_cal
+    X0 = np.random.default_rng(seed).normal(size=(p.num_pts, 3))
+    r = ref.gp_build(q, t, off, obs_cam, und, X0, cam_calibrated=cal)
+    a = ref.gp_adapter_solve(q, t, off, obs_cam, und, X0, cam_calibrated=cal)
+    assert a["ok"]
+    rel = abs(a["initial_cost"] - r["initial_cost"]) / r["initial_cost"]
+    print(f"[parity] DROP-IN GP seed={seed}: adapter start cost {a['initial_cost']:.12e} vs reference builder {r['initial_cost']:.12e} (rel {rel:.1e})")
+    assert rel < 1e-12
+    short = np.diff(off) < 3
+    assert not a["initialized"][short].any() and a["initialized"][~short].all()      # gp.cc:258-264
+    assert np.array_equal(a["xyz"][short], X0[short])                                # tracks outside the problem keep their point
+    assert np.abs(a["center"][5] - p.gt_center[5]).max() < 1e-12                     # the unconstrained camera keeps its centre (gp.cc:161)
+    from glomap_amd import synthetic as syn
+
+    ok_cams = np.arange(p.num_cams) != 5
+    assert syn.center_errors_after_sim3(a["center"][ok_cams], p.gt_center[ok_cams]).max() < 0.1  # and the scene is recovered
+
+
+@pytest.mark.gpu
+def test_adapter_bundle_adjuster_on_reference_containers():
+    """BundleAdjuster: the adapter's start cost equals the reference builder's on the same containers (which frame is constant
+    follows the reference's walk of `frames`), the constant frame comes back bit-identical, the cost goes down."""
+    from glomap_amd import synthetic
+
+    p = synthetic.make_ba_problem(num_cams=40, num_pts=1500, seed=2, pixel_noise=0.7, outlier_ratio=0.02, intr_noise=0.01)
+    args = (p.intr_model, p.intr_params, p.cam_q, p.cam_t, np.arange(p.num_cams), p.cam_intr, p.pt_offset, p.obs_cam, p.obs_xy, p.pt_xyz)
+    kw = dict(rig_ref_cam=np.arange(p.num_intr), frame_rig=p.cam_intr)
+    r = ref.ba_build(*args, **kw)
+    a = ref.ba_adapter_solve(*args, **kw)
+    assert a["ok"]
+    rel = abs(a["initial_cost"] - r["initial_cost"]) / r["initial_cost"]
+    print(f"[parity] DROP-IN BA: adapter start cost {a['initial_cost']:.12e} vs reference builder {r['initial_cost']:.12e} (rel {rel:.1e})")
+    assert rel < 1e-12 and a["final_cost"] < 0.5 * a["initial_cost"]
+    order = r["frame_order"]
+    fixed = int(order[(r["frame_flags"][order] & 1) != 0][0])
+    assert np.array_equal(a["frame_q"][fixed], p.cam_q[fixed]) and np.array_equal(a["frame_t"][fixed], p.cam_t[fixed])
+    moved = np.abs(a["frame_t"] - p.cam_t).max(axis=1) > 0
+    assert moved.sum() == p.num_cams - 1
+    # principal points are held by the subset manifold (ba.cc:273-285)
+    assert np.array_equal(a["cam_params"][:, 1:3], p.intr_params[:, 1:3]) and not np.array_equal(a["cam_params"][:, 0], p.intr_params[:, 0])
