@@ -14,6 +14,7 @@ GSFM_MEM_HOST = 0
 GSFM_MEM_DEVICE = 1
 GSFM_COMM_ID_BYTES = 128
 GSFM_CAMERA_MAX_PARAMS = 8
+GSFM_CAMERA_MAX_PARAMS_WIDE = 16
 
 STATUS_NAMES = {
     0: "GSFM_OK",
@@ -194,6 +195,7 @@ class BaProblemC(C.Structure):
         ("num_sensors", C.c_int32),
         ("image_sensor", C.c_void_p),
         ("sensor_cam_from_rig", C.c_void_p),
+        ("intr_stride", C.c_int32),
     ]
 
 
@@ -217,6 +219,7 @@ class SceneViewC(C.Structure):
         ("cam_intr", C.c_void_p),
         ("intr_model", C.c_void_p),
         ("intr_params", C.c_void_p),
+        ("intr_stride", C.c_int32),
     ]
 
 

@@ -68,6 +68,7 @@ extern "C" void gsfm_ctx_destroy(gsfm_ctx* ctx) {
   if (ctx->ra_rig_ws && ctx->ra_rig_ws_free) ctx->ra_rig_ws_free(ctx->ra_rig_ws);
   if (ctx->gp_ws && ctx->gp_ws_free) ctx->gp_ws_free(ctx->gp_ws);
   if (ctx->ba_ws && ctx->ba_ws_free) ctx->ba_ws_free(ctx->ba_ws);
+  if (ctx->ba_ws_wide && ctx->ba_ws_wide_free) ctx->ba_ws_wide_free(ctx->ba_ws_wide);
   if (ctx->fl_ws && ctx->fl_ws_free) ctx->fl_ws_free(ctx->fl_ws);
   if (ctx->tr_ws && ctx->tr_ws_free) ctx->tr_ws_free(ctx->tr_ws);
   if (ctx->comm.nccl) (void)ncclCommDestroy(ctx->comm.nccl);

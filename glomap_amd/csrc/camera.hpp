@@ -10,8 +10,17 @@
 // Fisheye models: (u, v) = (x/z, y/z), r = |(u, v)|, theta = atan(r); the equidistant coordinates (u, v) theta / r are
 // distorted radially in theta: pixel = f (u, v) theta_d / r + c, theta_d = theta (1 + k1 theta^2 + k2 theta^4 + ...)
 // (r <= eps: (u, v) itself).  FOV: pixel = f (u, v) factor + c, factor = atan(2 r tan(omega / 2)) / (r omega) with COLMAP's
-// two series branches for omega^2 < 1e-4 and r^2 < 1e-4.  FULL_OPENCV / THIN_PRISM_FISHEYE (12 parameters) and
-// RAD_TAN_THIN_PRISM_FISHEYE (16) do not fit the 8-parameter intrinsics block and are refused at the boundary.
+// two series branches for omega^2 < 1e-4 and r^2 < 1e-4.
+//
+// Intrinsics blocks are KP doubles wide: KP = 8 (GSFM_CAMERA_MAX_PARAMS, the nine models above) or KP = 16
+// (GSFM_CAMERA_MAX_PARAMS_WIDE) for the models with more than eight parameters, which exist only in the KP = 16 instances:
+//   FULL_OPENCV fx,fy,cx,cy,k1,k2,p1,p2,k3,k4,k5,k6: (u, v) (1 + k1 r^2 + k2 r^4 + k3 r^6) / (1 + k4 r^2 + k5 r^4 + k6 r^6)
+//     + tangential (2 p1 u v + p2 (r^2 + 2 u^2), 2 p2 u v + p1 (r^2 + 2 v^2))
+//   THIN_PRISM_FISHEYE fx,fy,cx,cy,k1,k2,p1,p2,k3,k4,sx1,sy1: equidistant (u, v) theta / r, then polynomial radial
+//     (k1 r^2 + k2 r^4 + k3 r^6 + k4 r^8) + tangential + thin prism (sx1 r^2, sy1 r^2) in the equidistant coordinates
+//   RAD_TAN_THIN_PRISM_FISHEYE fx,fy,cx,cy,k0..k5,p0,p1,s0..s3: equidistant (u, v) theta / r, radial
+//     (uh, vh) = (u, v) (1 + k0 r^2 + ... + k5 r^12), then tangential (p0 (2 uh^2 + rh^2) + 2 p1 uh vh,
+//     p1 (2 vh^2 + rh^2) + 2 p0 uh vh) and thin prism (s0 rh^2 + s1 rh^4, s2 rh^2 + s3 rh^4) on the radially distorted (uh, vh)
 #pragma once
 
 #include "../../include/gsfm.h"
@@ -19,11 +28,12 @@
 
 namespace gsfm {
 
-struct ObsGeom {
+template <int KP>
+struct ObsGeomT {
   V3 a;             // R X  (camera-frame point minus translation)
   double px, py;    // projected pixel
   double Jx[2][3];  // d pixel / d x_cam
-  double Jp[2][8];  // d pixel / d params
+  double Jp[2][KP]; // d pixel / d params
   bool valid;       // point in front of the camera; otherwise residual and Jacobians are zero
 };
 
@@ -52,13 +62,136 @@ __device__ __forceinline__ void fisheye_core(double r2, double k1, double k2, do
   }
 }
 
+// The models with more than eight parameters (KP = 16 instances only).  All three are "(a, b) -> (ad, bd)" distortions of
+// either (u, v) itself (FULL_OPENCV) or of the equidistant coordinates (a, b) = (u, v) theta / r (the two thin-prism fisheye
+// models); J = d(ad, bd) / d(a, b) is chained with the equidistant map's Jacobian E = s I + (s' / r) (u, v)(u, v)^T, s = theta / r.
+// Returns false for the other model ids.
+template <int KP>
+__device__ __forceinline__ bool distort_project_wide16(int model, const double* __restrict__ p, double u, double v, double r2,
+                                                       double& px, double& py, double (&Juv)[4], double (&Jp)[2][KP]) {
+  static_assert(KP >= 16, "the 12 / 16-parameter models need the wide intrinsics block");
+  if (model != GSFM_CAMERA_FULL_OPENCV && model != GSFM_CAMERA_THIN_PRISM_FISHEYE &&
+      model != GSFM_CAMERA_RAD_TAN_THIN_PRISM_FISHEYE)
+    return false;
+  const double fx = p[0], fy = p[1];
+  double a = u, b = v;          // input of the distortion
+  double e0 = 1.0, e1 = 0.0, e2 = 0.0, e3 = 1.0;  // d(a, b) / d(u, v)
+  if (model != GSFM_CAMERA_FULL_OPENCV) {
+    const double r = sqrt(r2);
+    if (r > 2.220446049250313e-16) {
+      const double s = atan(r) / r;
+      const double sp = (1.0 / (1.0 + r2) - s) / r2;  // s' / r
+      a = s * u;
+      b = s * v;
+      e0 = s + u * u * sp;
+      e1 = u * v * sp;
+      e2 = e1;
+      e3 = s + v * v * sp;
+    }
+  }
+  const double a2 = a * a, b2 = b * b, ab = a * b, q2 = a2 + b2;
+  double ad, bd, j0, j1, j2, j3;  // distorted point, d(ad, bd) / d(a, b)
+  if (model == GSFM_CAMERA_FULL_OPENCV) {
+    const double k1 = p[4], k2 = p[5], p1 = p[6], p2 = p[7], k3 = p[8], k4 = p[9], k5 = p[10], k6 = p[11];
+    const double q4 = q2 * q2, q6 = q4 * q2;
+    const double num = 1.0 + k1 * q2 + k2 * q4 + k3 * q6, den = 1.0 + k4 * q2 + k5 * q4 + k6 * q6;
+    const double iden = 1.0 / den, rad = num * iden;
+    const double drad = ((k1 + 2.0 * k2 * q2 + 3.0 * k3 * q4) - rad * (k4 + 2.0 * k5 * q2 + 3.0 * k6 * q4)) * iden;
+    ad = a * rad + 2.0 * p1 * ab + p2 * (q2 + 2.0 * a2);
+    bd = b * rad + 2.0 * p2 * ab + p1 * (q2 + 2.0 * b2);
+    j0 = rad + 2.0 * a2 * drad + 2.0 * p1 * b + 6.0 * p2 * a;
+    j1 = 2.0 * ab * drad + 2.0 * p1 * a + 2.0 * p2 * b;
+    j2 = 2.0 * ab * drad + 2.0 * p2 * b + 2.0 * p1 * a;
+    j3 = rad + 2.0 * b2 * drad + 2.0 * p2 * a + 6.0 * p1 * b;
+    const double n1 = q2 * iden, n2 = q4 * iden, n3 = q6 * iden;  // d rad / d (k1, k2, k3); d rad / d (k4, k5, k6) = -rad (n1, n2, n3)
+    Jp[0][4] = fx * a * n1; Jp[1][4] = fy * b * n1;
+    Jp[0][5] = fx * a * n2; Jp[1][5] = fy * b * n2;
+    Jp[0][6] = fx * 2.0 * ab; Jp[1][6] = fy * (q2 + 2.0 * b2);
+    Jp[0][7] = fx * (q2 + 2.0 * a2); Jp[1][7] = fy * 2.0 * ab;
+    Jp[0][8] = fx * a * n3; Jp[1][8] = fy * b * n3;
+    Jp[0][9] = -fx * a * rad * n1; Jp[1][9] = -fy * b * rad * n1;
+    Jp[0][10] = -fx * a * rad * n2; Jp[1][10] = -fy * b * rad * n2;
+    Jp[0][11] = -fx * a * rad * n3; Jp[1][11] = -fy * b * rad * n3;
+  } else if (model == GSFM_CAMERA_THIN_PRISM_FISHEYE) {
+    const double k1 = p[4], k2 = p[5], p1 = p[6], p2 = p[7], k3 = p[8], k4 = p[9], sx1 = p[10], sy1 = p[11];
+    const double q4 = q2 * q2, q6 = q4 * q2, q8 = q4 * q4;
+    const double rad = k1 * q2 + k2 * q4 + k3 * q6 + k4 * q8;
+    const double drad = k1 + 2.0 * k2 * q2 + 3.0 * k3 * q4 + 4.0 * k4 * q6;
+    ad = a + a * rad + 2.0 * p1 * ab + p2 * (q2 + 2.0 * a2) + sx1 * q2;
+    bd = b + b * rad + 2.0 * p2 * ab + p1 * (q2 + 2.0 * b2) + sy1 * q2;
+    j0 = 1.0 + rad + 2.0 * a2 * drad + 2.0 * p1 * b + 6.0 * p2 * a + 2.0 * sx1 * a;
+    j1 = 2.0 * ab * drad + 2.0 * p1 * a + 2.0 * p2 * b + 2.0 * sx1 * b;
+    j2 = 2.0 * ab * drad + 2.0 * p2 * b + 2.0 * p1 * a + 2.0 * sy1 * a;
+    j3 = 1.0 + rad + 2.0 * b2 * drad + 2.0 * p2 * a + 6.0 * p1 * b + 2.0 * sy1 * b;
+    Jp[0][4] = fx * a * q2; Jp[1][4] = fy * b * q2;
+    Jp[0][5] = fx * a * q4; Jp[1][5] = fy * b * q4;
+    Jp[0][6] = fx * 2.0 * ab; Jp[1][6] = fy * (q2 + 2.0 * b2);
+    Jp[0][7] = fx * (q2 + 2.0 * a2); Jp[1][7] = fy * 2.0 * ab;
+    Jp[0][8] = fx * a * q6; Jp[1][8] = fy * b * q6;
+    Jp[0][9] = fx * a * q8; Jp[1][9] = fy * b * q8;
+    Jp[0][10] = fx * q2;
+    Jp[1][11] = fy * q2;
+  } else {  // GSFM_CAMERA_RAD_TAN_THIN_PRISM_FISHEYE
+    const double p0 = p[10], p1 = p[11], s0 = p[12], s1 = p[13], s2 = p[14], s3 = p[15];
+    double qp[6];  // q2^(i + 1)
+    qp[0] = q2;
+#pragma unroll
+    for (int i = 1; i < 6; ++i) qp[i] = qp[i - 1] * q2;
+    double R = 1.0, dR = p[4];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) R += p[4 + i] * qp[i];
+#pragma unroll
+    for (int i = 1; i < 6; ++i) dR += (double)(i + 1) * p[4 + i] * qp[i - 1];
+    const double uh = R * a, vh = R * b;
+    const double uh2 = uh * uh, vh2 = vh * vh, uhvh = uh * vh, h2 = uh2 + vh2, h4 = h2 * h2;
+    ad = uh + p0 * (2.0 * uh2 + h2) + 2.0 * p1 * uhvh + s0 * h2 + s1 * h4;
+    bd = vh + p1 * (2.0 * vh2 + h2) + 2.0 * p0 * uhvh + s2 * h2 + s3 * h4;
+    // T = d(ad, bd) / d(uh, vh), then the radial stage d(uh, vh) / d(a, b) = R I + 2 dR (a, b)(a, b)^T
+    const double sx = s0 + 2.0 * s1 * h2, sy = s2 + 2.0 * s3 * h2;
+    const double T0 = 1.0 + 6.0 * p0 * uh + 2.0 * p1 * vh + 2.0 * uh * sx;
+    const double T1 = 2.0 * p0 * vh + 2.0 * p1 * uh + 2.0 * vh * sx;
+    const double T2 = 2.0 * p1 * uh + 2.0 * p0 * vh + 2.0 * uh * sy;
+    const double T3 = 1.0 + 6.0 * p1 * vh + 2.0 * p0 * uh + 2.0 * vh * sy;
+    const double r0 = R + 2.0 * a2 * dR, r1 = 2.0 * ab * dR, r3 = R + 2.0 * b2 * dR;
+    j0 = T0 * r0 + T1 * r1;
+    j1 = T0 * r1 + T1 * r3;
+    j2 = T2 * r0 + T3 * r1;
+    j3 = T2 * r1 + T3 * r3;
+    const double ta = T0 * a + T1 * b, tb = T2 * a + T3 * b;  // T (a, b): d(ad, bd) / d k_i = T (a, b) q2^(i + 1)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      Jp[0][4 + i] = fx * ta * qp[i];
+      Jp[1][4 + i] = fy * tb * qp[i];
+    }
+    Jp[0][10] = fx * (2.0 * uh2 + h2); Jp[1][10] = fy * 2.0 * uhvh;
+    Jp[0][11] = fx * 2.0 * uhvh; Jp[1][11] = fy * (2.0 * vh2 + h2);
+    Jp[0][12] = fx * h2;
+    Jp[0][13] = fx * h4;
+    Jp[1][14] = fy * h2;
+    Jp[1][15] = fy * h4;
+  }
+  px = fx * ad + p[2];
+  py = fy * bd + p[3];
+  Jp[0][0] = ad; Jp[1][1] = bd;
+  Jp[0][2] = 1.0; Jp[1][3] = 1.0;
+  Juv[0] = fx * (j0 * e0 + j1 * e2);
+  Juv[1] = fx * (j0 * e1 + j1 * e3);
+  Juv[2] = fy * (j2 * e0 + j3 * e2);
+  Juv[3] = fy * (j2 * e1 + j3 * e3);
+  return true;
+}
+
 // pixel = f(u, v; params) and its derivatives w.r.t. (u, v) -> Juv[4] = {du/du, du/dv, dv/du, dv/dv}
 // The fisheye / FOV models (ids >= 5).  Kept out of the sweeps that never see them: every kernel that projects is
 // instantiated twice (template parameter WIDE) and the host picks the lean instance when all cameras use the five polynomial
 // models — with the transcendental branches inlined k_ba_phaseB needs 278 instead of 219 registers (1 wave per SIMD) and
 // runs three times slower on configs[3].
+template <int KP>
 __device__ __forceinline__ void distort_project_wide(int model, const double* __restrict__ p, double u, double v, double r2,
-                                                     double& px, double& py, double (&Juv)[4], double (&Jp)[2][8]) {
+                                                     double& px, double& py, double (&Juv)[4], double (&Jp)[2][KP]) {
+  if constexpr (KP >= 16) {
+    if (distort_project_wide16(model, p, u, v, r2, px, py, Juv, Jp)) return;
+  }
   switch (model) {
     case GSFM_CAMERA_OPENCV_FISHEYE: {
       const double fx = p[0], fy = p[1];
@@ -140,18 +273,18 @@ __device__ __forceinline__ void distort_project_wide(int model, const double* __
   }
 }
 
-template <bool WIDE>
+template <bool WIDE, int KP = 8>
 __device__ __forceinline__ void distort_project(int model, const double* __restrict__ p, double u, double v,
-                                                double& px, double& py, double (&Juv)[4], double (&Jp)[2][8]) {
+                                                double& px, double& py, double (&Juv)[4], double (&Jp)[2][KP]) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < KP; ++j) {
     Jp[0][j] = 0.0;
     Jp[1][j] = 0.0;
   }
   const double r2 = u * u + v * v;
   if constexpr (WIDE) {
     if (model >= GSFM_CAMERA_OPENCV_FISHEYE) {
-      distort_project_wide(model, p, u, v, r2, px, py, Juv, Jp);
+      distort_project_wide<KP>(model, p, u, v, r2, px, py, Juv, Jp);
       return;
     }
   }
@@ -219,9 +352,9 @@ __device__ __forceinline__ void distort_project(int model, const double* __restr
 }
 
 // x_cam = R X + t; pixel = ImgFromCam(params, x_cam).  R9 row-major.
-template <bool WIDE>
+template <bool WIDE, int KP>
 __device__ __forceinline__ void obs_geom(const double* __restrict__ R9, const double* __restrict__ t3, const V3& X,
-                                         int model, const double* __restrict__ par, ObsGeom& g) {
+                                         int model, const double* __restrict__ par, ObsGeomT<KP>& g) {
   g.a = V3{R9[0] * X.x + R9[1] * X.y + R9[2] * X.z, R9[3] * X.x + R9[4] * X.y + R9[5] * X.z,
            R9[6] * X.x + R9[7] * X.y + R9[8] * X.z};
   const double xc = g.a.x + t3[0], yc = g.a.y + t3[1], zc = g.a.z + t3[2];
@@ -229,7 +362,7 @@ __device__ __forceinline__ void obs_geom(const double* __restrict__ R9, const do
   const double iz = 1.0 / (g.valid ? zc : 1.0);
   const double u = xc * iz, v = yc * iz;
   double Juv[4];
-  distort_project<WIDE>(model, par, u, v, g.px, g.py, Juv, g.Jp);
+  distort_project<WIDE, KP>(model, par, u, v, g.px, g.py, Juv, g.Jp);
   // d(u,v)/d x_cam = [1/z, 0, -u/z; 0, 1/z, -v/z]
   g.Jx[0][0] = Juv[0] * iz;
   g.Jx[0][1] = Juv[1] * iz;

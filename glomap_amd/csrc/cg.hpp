@@ -56,8 +56,9 @@ struct CgScal {
   double alpha;  // step length of the previous iteration
 };
 
-// Device view.  Unknown layout: [PB per camera | 8 per intrinsics block]; block-Jacobi blocks are
-// the PB x PB camera blocks (minv + PB*PB*n) followed by 8 x 8 intrinsics blocks.
+// Device view.  Unknown layout: [PB per camera | IW per intrinsics block]; block-Jacobi blocks are
+// the PB x PB camera blocks (minv + PB*PB*n) followed by IW x IW intrinsics blocks (IW = 8; 16 in the wide BA unit,
+// ba_wide.hip — the joint and single-workgroup kernels below exist for IW = 8 / no intrinsics only).
 struct CgVec {
   int n = 0;   // PB*N + 8*K
   int N = 0, K = 0;
@@ -318,7 +319,7 @@ __device__ __forceinline__ void cg_block_init(const CgVec& v, long o, const doub
 }
 
 // x = 0, r = b, z = M^-1 b, p = s = 0; partials of (r.z, r.r) into parity slot 0.
-template <int PB, bool HAS_INTR>
+template <int PB, bool HAS_INTR, int IW = 8>
 static __global__ void __launch_bounds__(kBlock) k_cg_init(CgVec v) {
   __shared__ double smem[4 * (2 + 2 * kCgMaxModes)];
   double acc[2] = {0.0, 0.0};
@@ -330,7 +331,7 @@ static __global__ void __launch_bounds__(kBlock) k_cg_init(CgVec v) {
                         v.zmir ? v.zmir + (long)b * v.zmir_stride + v.zmir_off : nullptr);
     } else if constexpr (HAS_INTR) {
       const int k = b - v.N;
-      cg_block_init<8>(v, (long)PB * v.N + 8L * k, v.minv + (long)PB * PB * v.N + 64L * k, acc[0], acc[1], cd);
+      cg_block_init<IW>(v, (long)PB * v.N + (long)IW * k, v.minv + (long)PB * PB * v.N + (long)(IW * IW) * k, acc[0], acc[1], cd);
     }
   }
   {
@@ -476,7 +477,7 @@ __device__ __forceinline__ void cg_block_update(const CgVec& v, long o, const do
 }
 
 // One CG iteration given w = A z (complete) and the delta partials.
-template <int PB, bool HAS_INTR>
+template <int PB, bool HAS_INTR, int IW = 8>
 static __global__ void __launch_bounds__(kBlock) k_cg_update(CgVec v, int it) {
   __shared__ double smem[kCgStepSmem];
   CgStep st;
@@ -491,8 +492,8 @@ static __global__ void __launch_bounds__(kBlock) k_cg_update(CgVec v, int it) {
                             v.zmir ? v.zmir + (long)b * v.zmir_stride + v.zmir_off : nullptr);
       } else if constexpr (HAS_INTR) {
         const int k = b - v.N;
-        cg_block_update<8>(v, (long)PB * v.N + 8L * k, v.minv + (long)PB * PB * v.N + 64L * k, st.alpha, st.beta, acc[0],
-                           acc[1], st.y, cd);
+        cg_block_update<IW>(v, (long)PB * v.N + (long)IW * k, v.minv + (long)PB * PB * v.N + (long)(IW * IW) * k, st.alpha, st.beta,
+                            acc[0], acc[1], st.y, cd);
       }
     }
   }
@@ -938,13 +939,13 @@ struct CgNoPostZ {
 // post_z(par): optional hook enqueued after every kernel that produces a new z = M^-1 r (k_cg_init*: par = 0;
 // k_cg_update* of iteration it: par = (it + 1) & 1) — a second-level preconditioner adds its coarse correction to z (and to
 // the gather mirrors) there and rewrites the r.z partials of parity slot `par` (gp.hip: GpCoarse).
-template <int PB, bool HAS_INTR, typename Apply, typename PostZ = CgNoPostZ>
+template <int PB, bool HAS_INTR, int IW = 8, typename Apply, typename PostZ = CgNoPostZ>
 inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& apply, const CgDeflation* defl = nullptr,
                      int* hint = nullptr, PostZ&& post_z = PostZ(), bool* finished = nullptr) {
   hipStream_t s = ctx->stream;
   const bool multi = ctx->comm.world > 1;
   v.delta_in_w = multi ? 1 : 0;
-  const bool joint = HAS_INTR && v.joint_map != nullptr;
+  const bool joint = HAS_INTR && IW == 8 && v.joint_map != nullptr;
   v.tol2 = tol * tol;
   v.single = (!HAS_INTR && v.N <= kCgSingleMaxBlocks) ? 1 : 0;
   v.probe = 0;
@@ -955,7 +956,7 @@ inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& 
     } else {
       if (v.single) hipLaunchKernelGGL((k_cg_init1<PB>), dim3(1), dim3(kCgSingleThreads), 0, s, v);
     }
-    if (!joint && !v.single) hipLaunchKernelGGL((k_cg_init<PB, HAS_INTR>), dim3(v.nb_update), dim3(kBlock), 0, s, v);
+    if (!joint && !v.single) hipLaunchKernelGGL((k_cg_init<PB, HAS_INTR, IW>), dim3(v.nb_update), dim3(kBlock), 0, s, v);
   };
   auto apply_all = [&](int it) {  // w = A z complete on every rank
     apply(it);
@@ -1016,7 +1017,7 @@ inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& 
     } else {
       if (v.single) hipLaunchKernelGGL((k_cg_update1<PB>), dim3(1), dim3(kCgSingleThreads), 0, s, v, it);
     }
-    if (!joint && !v.single) hipLaunchKernelGGL((k_cg_update<PB, HAS_INTR>), dim3(v.nb_update), dim3(kBlock), 0, s, v, it);
+    if (!joint && !v.single) hipLaunchKernelGGL((k_cg_update<PB, HAS_INTR, IW>), dim3(v.nb_update), dim3(kBlock), 0, s, v, it);
     post_z((it + 1) & 1);
     if (it + 1 >= next_poll || it == max_iter - 1) {
       GSFM_HIP_CHECK(hipMemcpyAsync(h, v.st, sizeof(CgStatus), hipMemcpyDeviceToHost, s));

@@ -188,6 +188,7 @@ struct gsfm_ctx {
   void* ra_ws = nullptr;
   void* gp_ws = nullptr;
   void* ba_ws = nullptr;
+  void* ba_ws_wide = nullptr;  // workspace of the 16-wide BA unit (ba_wide.hip)
   void* fl_ws = nullptr;
   void* tr_ws = nullptr;
   void* ra_rig_ws = nullptr;
@@ -197,6 +198,7 @@ struct gsfm_ctx {
   void (*ra_ws_free)(void*) = nullptr;
   void (*gp_ws_free)(void*) = nullptr;
   void (*ba_ws_free)(void*) = nullptr;
+  void (*ba_ws_wide_free)(void*) = nullptr;
 };
 
 namespace gsfm {

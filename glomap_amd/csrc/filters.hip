@@ -71,7 +71,8 @@ __global__ void __launch_bounds__(kBlock)
 // the track read by its consecutive lanes.
 // WIDE: some camera uses a fisheye / FOV model (ids >= OPENCV_FISHEYE); the lean instance leaves their transcendental
 // branches out, as the BA kernels do (camera.hpp: with them inlined this sweep fell from 0.35 to 0.28 of the HBM rate).
-template <bool WIDE>
+// KP: doubles per intrinsics row (8, or 16 for the camera models with more than eight parameters: gsfm_scene_view::intr_stride).
+template <bool WIDE, int KP>
 __global__ void __launch_bounds__(kBlock)
     k_filter_obs(ViewDev v, const int* __restrict__ obs_pt, int mode, double thr, double thr_uncalib,
                  unsigned char* __restrict__ keep) {
@@ -93,10 +94,10 @@ __global__ void __launch_bounds__(kBlock)
       } else if (mode == 1) {
         const int ik = v.cam_intr[n];
         const double iz = 1.0 / pc.z;
-        double px = 0.0, py = 0.0, Juv[4], Jp[2][8];
+        double px = 0.0, py = 0.0, Juv[4], Jp[2][KP];
         // Camera::ImgFromCam(...).value_or(Zero): projection fails for points at / behind the camera
         if (pc.z > 2.220446049250313e-16)
-          distort_project<WIDE>(v.intr_model[ik], v.intr_params + 8 * (long)ik, pc.x * iz, pc.y * iz, px, py, Juv, Jp);
+          distort_project<WIDE, KP>(v.intr_model[ik], v.intr_params + KP * (long)ik, pc.x * iz, pc.y * iz, px, py, Juv, Jp);
         const double ex = px - v.xy[2 * k], ey = py - v.xy[2 * k + 1];
         ok = sqrt(ex * ex + ey * ey) < thr;
       } else {
@@ -308,7 +309,9 @@ void stage_view(gsfm_ctx* ctx, FilterWs* ws, const gsfm_scene_view* v, bool need
     d.xy = dev_in(ctx, ws->xy, v->obs_xy, 2 * (size_t)M, mem);
     d.cam_intr = dev_in(ctx, ws->cam_intr, v->cam_intr, (size_t)N, mem);
     d.intr_model = dev_in(ctx, ws->intr_model, v->intr_model, (size_t)v->num_intr, mem);
-    d.intr_params = dev_in(ctx, ws->intr, v->intr_params, 8 * (size_t)v->num_intr, mem);
+    const int stride = v->intr_stride == 0 ? GSFM_CAMERA_MAX_PARAMS : v->intr_stride;
+    GSFM_REQUIRE(stride == GSFM_CAMERA_MAX_PARAMS || stride == GSFM_CAMERA_MAX_PARAMS_WIDE, "filter: intr_stride must be 0, 8 or 16");
+    d.intr_params = dev_in(ctx, ws->intr, v->intr_params, (size_t)stride * (size_t)v->num_intr, mem);
   }
   if (v->cam_calibrated) d.calibrated = dev_in(ctx, ws->cal, v->cam_calibrated, (size_t)N, mem);
   ws->counter.ensure(1);
@@ -346,13 +349,23 @@ int filter_obs_impl(gsfm_ctx* ctx, const gsfm_scene_view* view, int mode, double
       std::vector<int> h_model;
       to_host(ctx, h_model, view->intr_model, (size_t)view->num_intr, view->mem);
       GSFM_HIP_CHECK(hipStreamSynchronize(s));
-      for (int m : h_model) wide = wide || m >= GSFM_CAMERA_OPENCV_FISHEYE;
+      for (int m : h_model) {
+        wide = wide || m >= GSFM_CAMERA_OPENCV_FISHEYE;
+        const bool known = m >= GSFM_CAMERA_SIMPLE_PINHOLE && m <= GSFM_CAMERA_RAD_TAN_THIN_PRISM_FISHEYE;
+        const bool needs16 = m == GSFM_CAMERA_FULL_OPENCV || m == GSFM_CAMERA_THIN_PRISM_FISHEYE || m == GSFM_CAMERA_RAD_TAN_THIN_PRISM_FISHEYE;
+        if (!known || (needs16 && view->intr_stride != GSFM_CAMERA_MAX_PARAMS_WIDE))
+          throw StatusError(GSFM_ERR_UNSUPPORTED, needs16 ? "filter: camera models with more than 8 parameters need intr_stride = 16"
+                                                          : "filter: camera model not supported");
+      }
     }
+    const bool wide16 = mode == 1 && view->intr_stride == GSFM_CAMERA_MAX_PARAMS_WIDE;
     const bool timed = ctx->prof.begin(s, GSFM_KERNEL_FILTER_OBS);
-    if (wide)
-      hipLaunchKernelGGL((k_filter_obs<true>), dim3(grid_wide(d.M, kBlock, 1 << 16)), dim3(kBlock), 0, s, d, ws->obs_pt.get(), mode, thr, thr2, keep);
+    if (wide16)
+      hipLaunchKernelGGL((k_filter_obs<true, 16>), dim3(grid_wide(d.M, kBlock, 1 << 16)), dim3(kBlock), 0, s, d, ws->obs_pt.get(), mode, thr, thr2, keep);
+    else if (wide)
+      hipLaunchKernelGGL((k_filter_obs<true, 8>), dim3(grid_wide(d.M, kBlock, 1 << 16)), dim3(kBlock), 0, s, d, ws->obs_pt.get(), mode, thr, thr2, keep);
     else
-      hipLaunchKernelGGL((k_filter_obs<false>), dim3(grid_wide(d.M, kBlock, 1 << 16)), dim3(kBlock), 0, s, d, ws->obs_pt.get(), mode, thr, thr2, keep);
+      hipLaunchKernelGGL((k_filter_obs<false, 8>), dim3(grid_wide(d.M, kBlock, 1 << 16)), dim3(kBlock), 0, s, d, ws->obs_pt.get(), mode, thr, thr2, keep);
     if (timed) ctx->prof.end(s);
     hipLaunchKernelGGL(k_count_changed, dim3(grid_for(d.P, kBlock)), dim3(kBlock), 0, s, d.P, d.off, keep, ws->counter.get());
   }

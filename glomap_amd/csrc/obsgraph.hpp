@@ -66,7 +66,7 @@ struct ObsGraph {  // device view, passed to kernels by value
   int pass = 0;                        // 0: sweep over the segments; 1: combine pass over the cut cameras (see cam_seg_*)
 };
 
-constexpr int kSegPartW = 128;     // widest per-camera accumulator (k_ba_build_cam<true>: 119 values)
+constexpr int kSegPartW = 192;     // widest per-camera accumulator (k_ba_build_cam<false, ., 16> of the 16-wide BA unit: 179 values; 8-wide joint: 119)
 constexpr int kSegLenMin = 1024;   // observations per segment: 16 trips of a wave
 constexpr int kMaxMultiCams = 1024;
 

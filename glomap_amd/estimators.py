@@ -470,6 +470,8 @@ def ba_solve(p: BaProblem, options: Optional[BundleAdjusterOptions] = None, ctx=
     for a in (p.cam_q, p.cam_t, p.pt_xyz, p.intr_params):
         a = _h(a, np.float64)
         outs.append(a.copy() if isinstance(a, np.ndarray) else a.clone())
+    # doubles per intrinsics row: 8, or 16 when a camera model has more than eight parameters (gsfm_ba_problem::intr_stride)
+    c.intr_stride = int(outs[3].shape[1]) if len(outs[3].shape) == 2 else 0
     rep = _lib.Report()
     rc = ctx.lib.gsfm_ba_solve(ctx.handle, C.byref(c), C.byref(opt), *[_lib.ptr(a) for a in outs], C.byref(rep))
     report = rep.as_dict()

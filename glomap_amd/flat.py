@@ -22,9 +22,13 @@ CAMERA_OPENCV_FISHEYE = 5  # fx, fy, cx, cy, k1, k2, k3, k4
 CAMERA_FOV = 7  # fx, fy, cx, cy, omega
 CAMERA_SIMPLE_RADIAL_FISHEYE = 8  # f, cx, cy, k
 CAMERA_RADIAL_FISHEYE = 9  # f, cx, cy, k1, k2
-CAMERA_NUM_PARAMS = {0: 3, 1: 4, 2: 4, 3: 5, 4: 8, 5: 8, 7: 5, 8: 4, 9: 5}
+CAMERA_FULL_OPENCV = 6  # fx, fy, cx, cy, k1, k2, p1, p2, k3, k4, k5, k6               ([K,16] intrinsics rows)
+CAMERA_THIN_PRISM_FISHEYE = 10  # fx, fy, cx, cy, k1, k2, p1, p2, k3, k4, sx1, sy1     ([K,16])
+CAMERA_RAD_TAN_THIN_PRISM_FISHEYE = 11  # fx, fy, cx, cy, k0 .. k5, p0, p1, s0 .. s3   ([K,16])
+CAMERA_NUM_PARAMS = {0: 3, 1: 4, 2: 4, 3: 5, 4: 8, 5: 8, 7: 5, 8: 4, 9: 5, 6: 12, 10: 12, 11: 16}
 CAMERA_PP_IDXS = {0: (1, 2), 1: (2, 3), 2: (1, 2), 3: (1, 2), 4: (2, 3)}
 CAMERA_MAX_PARAMS = 8
+CAMERA_MAX_PARAMS_WIDE = 16  # FULL_OPENCV, THIN_PRISM_FISHEYE, RAD_TAN_THIN_PRISM_FISHEYE: [K,16] intrinsics rows
 
 
 @dataclass
@@ -118,7 +122,7 @@ class BaProblem:
     cam_t: np.ndarray  # [N,3] f64 in/out
     pt_xyz: np.ndarray  # [P,3] f64 in/out
     intr_model: np.ndarray  # [K] int32 camera model id
-    intr_params: np.ndarray  # [K,8] f64 in/out
+    intr_params: np.ndarray  # [K,8] f64 in/out ([K,16] when a camera model has more than 8 parameters)
     fixed_cam: int = 0  # frame whose q and t are held constant (ba.cc:261-266); -1 = none
     gt_q: Optional[np.ndarray] = None
     gt_t: Optional[np.ndarray] = None

@@ -35,7 +35,7 @@ class SceneView:
     cam_calibrated: Optional[np.ndarray] = None  # [N] uint8
     cam_intr: Optional[np.ndarray] = None  # [N] int32
     intr_model: Optional[np.ndarray] = None  # [K] int32
-    intr_params: Optional[np.ndarray] = None  # [K,8]
+    intr_params: Optional[np.ndarray] = None  # [K,8]; [K,16] when a camera model has more than 8 parameters
 
 
 def _view_c(v: SceneView, keep: list) -> _lib.SceneViewC:
@@ -56,6 +56,7 @@ def _view_c(v: SceneView, keep: list) -> _lib.SceneViewC:
     c.cam_calibrated = _lib.ptr(cal)
     c.num_intr = 0 if im is None else int(im.shape[0])
     c.cam_intr, c.intr_model, c.intr_params = _lib.ptr(ci), _lib.ptr(im), _lib.ptr(ip_)
+    c.intr_stride = 0 if ip_ is None or len(ip_.shape) != 2 else int(ip_.shape[1])  # 8, or 16 (wide camera models)
     return c
 
 

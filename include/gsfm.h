@@ -413,7 +413,12 @@ int gsfm_gp_solve(gsfm_ctx* ctx, const gsfm_gp_problem* prob, const gsfm_gp_opti
                   double* cam_center_inout, double* pt_xyz_inout, gsfm_report* report);
 
 /* ---- bundle adjustment --------------------------------------------------------------------- */
-/* COLMAP camera model ids (colmap/sensor/models.h) of the supported models. */
+/* COLMAP camera model ids (colmap/sensor/models.h) of the supported models: every model the reference's
+ * colmap::CreateCameraCostFunction dispatches on at bundle_adjustment.cc:136-139,149-152,167-170 with a perspective or
+ * fisheye projection.  The nine models with at most 8 parameters live in 8-wide intrinsics blocks
+ * (GSFM_CAMERA_MAX_PARAMS); FULL_OPENCV, THIN_PRISM_FISHEYE and RAD_TAN_THIN_PRISM_FISHEYE need the 16-wide blocks
+ * (GSFM_CAMERA_MAX_PARAMS_WIDE): a problem that contains one of them passes intr_stride = 16 and [K][16] parameter arrays
+ * (unused tail entries are ignored and returned unchanged), and is solved by the library's 16-wide instances. */
 enum {
   GSFM_CAMERA_SIMPLE_PINHOLE = 0, /* f, cx, cy */
   GSFM_CAMERA_PINHOLE = 1,        /* fx, fy, cx, cy */
@@ -421,13 +426,15 @@ enum {
   GSFM_CAMERA_RADIAL = 3,         /* f, cx, cy, k1, k2 */
   GSFM_CAMERA_OPENCV = 4,         /* fx, fy, cx, cy, k1, k2, p1, p2 */
   GSFM_CAMERA_OPENCV_FISHEYE = 5, /* fx, fy, cx, cy, k1, k2, k3, k4 */
-  /* 6 = FULL_OPENCV (12 parameters): not supported, an intrinsics block holds GSFM_CAMERA_MAX_PARAMS = 8 */
+  GSFM_CAMERA_FULL_OPENCV = 6,    /* fx, fy, cx, cy, k1, k2, p1, p2, k3, k4, k5, k6 (intr_stride 16) */
   GSFM_CAMERA_FOV = 7,            /* fx, fy, cx, cy, omega */
   GSFM_CAMERA_SIMPLE_RADIAL_FISHEYE = 8, /* f, cx, cy, k */
-  GSFM_CAMERA_RADIAL_FISHEYE = 9  /* f, cx, cy, k1, k2 */
-  /* 10 = THIN_PRISM_FISHEYE (12), 11 = RAD_TAN_THIN_PRISM_FISHEYE (16): not supported */
+  GSFM_CAMERA_RADIAL_FISHEYE = 9, /* f, cx, cy, k1, k2 */
+  GSFM_CAMERA_THIN_PRISM_FISHEYE = 10,         /* fx, fy, cx, cy, k1, k2, p1, p2, k3, k4, sx1, sy1 (intr_stride 16) */
+  GSFM_CAMERA_RAD_TAN_THIN_PRISM_FISHEYE = 11  /* fx, fy, cx, cy, k0 .. k5, p0, p1, s0 .. s3 (intr_stride 16) */
 };
 #define GSFM_CAMERA_MAX_PARAMS 8
+#define GSFM_CAMERA_MAX_PARAMS_WIDE 16
 
 /* Options: mirror of BundleAdjusterOptions (bundle_adjustment.h:12-37). */
 typedef struct gsfm_ba_options {
@@ -474,11 +481,14 @@ typedef struct gsfm_ba_problem {
   int32_t num_sensors;
   const int32_t* image_sensor;       /* [I] */
   double* sensor_cam_from_rig;       /* [S][7] host, in/out */
+  /* doubles per row of intr_params_inout: 0 or GSFM_CAMERA_MAX_PARAMS (8), or GSFM_CAMERA_MAX_PARAMS_WIDE (16) — required
+   * when intr_model holds a model with more than 8 parameters (GSFM_ERR_UNSUPPORTED otherwise) */
+  int32_t intr_stride;
 } gsfm_ba_problem;
 
 /* cam_q_inout [N][4] (w,x,y,z), cam_t_inout [N][3], pt_xyz_inout [P][3],
- * intr_params_inout [K][GSFM_CAMERA_MAX_PARAMS]: updated in place like the reference's parameter
- * blocks (ba.cc:143-146). */
+ * intr_params_inout [K][intr_stride] (GSFM_CAMERA_MAX_PARAMS unless the problem says 16): updated in place like the
+ * reference's parameter blocks (ba.cc:143-146). */
 int gsfm_ba_solve(gsfm_ctx* ctx, const gsfm_ba_problem* prob, const gsfm_ba_options* opt,
                   double* cam_q_inout, double* cam_t_inout, double* pt_xyz_inout,
                   double* intr_params_inout, gsfm_report* report);
@@ -508,7 +518,8 @@ typedef struct gsfm_scene_view {
   int32_t num_intr;               /* pixel-space reprojection only */
   const int32_t* cam_intr;        /* [N] */
   const int32_t* intr_model;      /* [K] GSFM_CAMERA_* */
-  const double* intr_params;      /* [K][GSFM_CAMERA_MAX_PARAMS] */
+  const double* intr_params;      /* [K][GSFM_CAMERA_MAX_PARAMS], or [K][intr_stride] */
+  int32_t intr_stride;            /* 0 / 8, or 16 when intr_model holds a model with more than 8 parameters */
 } gsfm_scene_view;
 
 /* obs_keep_out [M]; *tracks_changed = number of tracks that lost at least one observation. */

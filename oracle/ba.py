@@ -8,7 +8,9 @@ CPU restatement of GLOMAP's global bundle adjustment for trivial rigs:
                   x_c = R(q) X + t;  (u,v) = CameraModel::ImgFromCam(params, x_c);  r = (u,v) - obs   [pixels]
                   (residual and Jacobian zero when the point is not in front of the camera)
   camera models   SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL, RADIAL, OPENCV, OPENCV_FISHEYE, FOV, SIMPLE_RADIAL_FISHEYE,
-                  RADIAL_FISHEYE (colmap/sensor/models.h; every COLMAP model with at most 8 parameters)
+                  RADIAL_FISHEYE (colmap/sensor/models.h; every COLMAP model with at most 8 parameters) in [K, 8] blocks, and
+                  FULL_OPENCV, THIN_PRISM_FISHEYE (12 parameters), RAD_TAN_THIN_PRISM_FISHEYE (16) in [K, 16] blocks — the
+                  width of an intrinsics block is the second dimension of the intr_params array
   parameterisation ba.cc:244-317: EigenQuaternionManifold (q <- [sin|d| d/|d|, cos|d|] * q), first
                   frame constant, optimize_rotations / optimize_translation flags, principal point
                   frozen by a SubsetManifold unless optimize_principal_point
@@ -33,9 +35,12 @@ from . import lm
 
 SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL, RADIAL, OPENCV = 0, 1, 2, 3, 4
 OPENCV_FISHEYE, FOV, SIMPLE_RADIAL_FISHEYE, RADIAL_FISHEYE = 5, 7, 8, 9  # COLMAP's CameraModelId values
-NUM_PARAMS = {0: 3, 1: 4, 2: 4, 3: 5, 4: 8, 5: 8, 7: 5, 8: 4, 9: 5}
-PP_IDXS = {0: (1, 2), 1: (2, 3), 2: (1, 2), 3: (1, 2), 4: (2, 3), 5: (2, 3), 7: (2, 3), 8: (1, 2), 9: (1, 2)}
-MAXP = 8
+FULL_OPENCV, THIN_PRISM_FISHEYE, RAD_TAN_THIN_PRISM_FISHEYE = 6, 10, 11    # more than 8 parameters: [K, 16] blocks
+NUM_PARAMS = {0: 3, 1: 4, 2: 4, 3: 5, 4: 8, 5: 8, 7: 5, 8: 4, 9: 5, 6: 12, 10: 12, 11: 16}
+PP_IDXS = {0: (1, 2), 1: (2, 3), 2: (1, 2), 3: (1, 2), 4: (2, 3), 5: (2, 3), 7: (2, 3), 8: (1, 2), 9: (1, 2),
+           6: (2, 3), 10: (2, 3), 11: (2, 3)}
+MAXP = 8        # width of an intrinsics block unless a model needs more
+MAXP_WIDE = 16  # FULL_OPENCV, THIN_PRISM_FISHEYE, RAD_TAN_THIN_PRISM_FISHEYE
 
 
 @dataclass
@@ -76,7 +81,7 @@ def quat_mul(a, b):
 
 
 def project(model, params, xc):
-    """ImgFromCam for per-row model ids.  Returns (uv [m,2], J_xc [m,2,3], J_par [m,2,8], valid [m])."""
+    """ImgFromCam for per-row model ids; params [m, W], W = 8 or 16.  Returns (uv [m,2], J_xc [m,2,3], J_par [m,2,W], valid [m])."""
     m = xc.shape[0]
     x, y, z = xc[:, 0], xc[:, 1], xc[:, 2]
     valid = z > np.finfo(np.float64).eps
@@ -85,7 +90,7 @@ def project(model, params, xc):
     r2 = u * u + v * v
     uv = np.zeros((m, 2))
     Juv = np.zeros((m, 2, 2))  # d(pixel) / d(u, v)
-    Jp = np.zeros((m, 2, MAXP))
+    Jp = np.zeros((m, 2, params.shape[1]))
     p = params
     for mid in np.unique(model):
         s = model == mid
@@ -220,6 +225,114 @@ def project(model, params, xc):
             Jp[s, 0, 2] = 1
             Jp[s, 1, 3] = 1
             Jp[s, 0, 4], Jp[s, 1, 4] = fx * us * dfac_om, fy * vs * dfac_om
+        elif mid in (FULL_OPENCV, THIN_PRISM_FISHEYE, RAD_TAN_THIN_PRISM_FISHEYE):
+            # (a, b) -> (ad, bd) distortions of (u, v) itself (FULL_OPENCV) or of the equidistant coordinates
+            # (a, b) = (u, v) theta / r, theta = atan(r) (the thin-prism fisheye models); E = d(a, b) / d(u, v)
+            assert ps.shape[1] >= MAXP_WIDE, "camera models with more than 8 parameters need [K, 16] intrinsics blocks"
+            fx, fy, cx, cy = ps[:, 0], ps[:, 1], ps[:, 2], ps[:, 3]
+            n = us.shape[0]
+            a, b = us.copy(), vs.copy()
+            E = np.zeros((n, 2, 2))
+            E[:, 0, 0] = E[:, 1, 1] = 1.0
+            if mid != FULL_OPENCV:
+                rs = np.sqrt(r2s)
+                big = rs > np.finfo(np.float64).eps
+                rsafe = np.where(big, rs, 1.0)
+                sfac = np.where(big, np.arctan(rsafe) / rsafe, 1.0)
+                sp_ = np.where(big, (1 / (1 + r2s) - sfac) / np.where(big, r2s, 1.0), 0.0)  # s' / r
+                a, b = sfac * us, sfac * vs
+                E[:, 0, 0] = sfac + us * us * sp_
+                E[:, 0, 1] = E[:, 1, 0] = us * vs * sp_
+                E[:, 1, 1] = sfac + vs * vs * sp_
+            a2, b2, ab = a * a, b * b, a * b
+            q2 = a2 + b2
+            D = np.zeros((n, 2, 2))  # d(ad, bd) / d(a, b)
+            dpar = {}                # parameter index -> (d ad, d bd)
+            zero = np.zeros(n)
+            if mid == FULL_OPENCV:
+                k1, k2, p1, p2, k3, k4, k5, k6 = (ps[:, i] for i in range(4, 12))
+                q4, q6 = q2 * q2, q2 * q2 * q2
+                num = 1 + k1 * q2 + k2 * q4 + k3 * q6
+                den = 1 + k4 * q2 + k5 * q4 + k6 * q6
+                rad = num / den
+                drad = ((k1 + 2 * k2 * q2 + 3 * k3 * q4) - rad * (k4 + 2 * k5 * q2 + 3 * k6 * q4)) / den
+                ad = a * rad + 2 * p1 * ab + p2 * (q2 + 2 * a2)
+                bd = b * rad + 2 * p2 * ab + p1 * (q2 + 2 * b2)
+                D[:, 0, 0] = rad + 2 * a2 * drad + 2 * p1 * b + 6 * p2 * a
+                D[:, 0, 1] = 2 * ab * drad + 2 * p1 * a + 2 * p2 * b
+                D[:, 1, 0] = 2 * ab * drad + 2 * p2 * b + 2 * p1 * a
+                D[:, 1, 1] = rad + 2 * b2 * drad + 2 * p2 * a + 6 * p1 * b
+                for idx, qq in ((4, q2), (5, q4), (8, q6)):
+                    dpar[idx] = (a * qq / den, b * qq / den)
+                for idx, qq in ((9, q2), (10, q4), (11, q6)):
+                    dpar[idx] = (-a * rad * qq / den, -b * rad * qq / den)
+                dpar[6] = (2 * ab, q2 + 2 * b2)
+                dpar[7] = (q2 + 2 * a2, 2 * ab)
+            elif mid == THIN_PRISM_FISHEYE:
+                k1, k2, p1, p2, k3, k4, sx1, sy1 = (ps[:, i] for i in range(4, 12))
+                q4 = q2 * q2
+                q6, q8 = q4 * q2, q4 * q4
+                rad = k1 * q2 + k2 * q4 + k3 * q6 + k4 * q8
+                drad = k1 + 2 * k2 * q2 + 3 * k3 * q4 + 4 * k4 * q6
+                ad = a + a * rad + 2 * p1 * ab + p2 * (q2 + 2 * a2) + sx1 * q2
+                bd = b + b * rad + 2 * p2 * ab + p1 * (q2 + 2 * b2) + sy1 * q2
+                D[:, 0, 0] = 1 + rad + 2 * a2 * drad + 2 * p1 * b + 6 * p2 * a + 2 * sx1 * a
+                D[:, 0, 1] = 2 * ab * drad + 2 * p1 * a + 2 * p2 * b + 2 * sx1 * b
+                D[:, 1, 0] = 2 * ab * drad + 2 * p2 * b + 2 * p1 * a + 2 * sy1 * a
+                D[:, 1, 1] = 1 + rad + 2 * b2 * drad + 2 * p2 * a + 6 * p1 * b + 2 * sy1 * b
+                for idx, qq in ((4, q2), (5, q4), (8, q6), (9, q8)):
+                    dpar[idx] = (a * qq, b * qq)
+                dpar[6] = (2 * ab, q2 + 2 * b2)
+                dpar[7] = (q2 + 2 * a2, 2 * ab)
+                dpar[10] = (q2, zero)
+                dpar[11] = (zero, q2)
+            else:
+                # radial stage (uh, vh) = (a, b) (1 + k0 q2 + ... + k5 q2^6); tangential (p0, p1) and thin prism (s0 .. s3)
+                # on the radially distorted coordinates
+                kk = [ps[:, 4 + i] for i in range(6)]
+                p0, p1, s0, s1, s2, s3 = (ps[:, i] for i in range(10, 16))
+                qp = [q2]
+                for i in range(1, 6):
+                    qp.append(qp[-1] * q2)
+                Rr = 1 + sum(kk[i] * qp[i] for i in range(6))
+                dR = kk[0] + sum((i + 1) * kk[i] * qp[i - 1] for i in range(1, 6))
+                uh, vh = Rr * a, Rr * b
+                uh2, vh2, uhvh = uh * uh, vh * vh, uh * vh
+                h2 = uh2 + vh2
+                h4 = h2 * h2
+                ad = uh + p0 * (2 * uh2 + h2) + 2 * p1 * uhvh + s0 * h2 + s1 * h4
+                bd = vh + p1 * (2 * vh2 + h2) + 2 * p0 * uhvh + s2 * h2 + s3 * h4
+                sx, sy = s0 + 2 * s1 * h2, s2 + 2 * s3 * h2
+                T = np.zeros((n, 2, 2))
+                T[:, 0, 0] = 1 + 6 * p0 * uh + 2 * p1 * vh + 2 * uh * sx
+                T[:, 0, 1] = 2 * p0 * vh + 2 * p1 * uh + 2 * vh * sx
+                T[:, 1, 0] = 2 * p1 * uh + 2 * p0 * vh + 2 * uh * sy
+                T[:, 1, 1] = 1 + 6 * p1 * vh + 2 * p0 * uh + 2 * vh * sy
+                Rj = np.zeros((n, 2, 2))
+                Rj[:, 0, 0] = Rr + 2 * a2 * dR
+                Rj[:, 0, 1] = Rj[:, 1, 0] = 2 * ab * dR
+                Rj[:, 1, 1] = Rr + 2 * b2 * dR
+                D = T @ Rj
+                ta = T[:, 0, 0] * a + T[:, 0, 1] * b
+                tb = T[:, 1, 0] * a + T[:, 1, 1] * b
+                for i in range(6):
+                    dpar[4 + i] = (ta * qp[i], tb * qp[i])
+                dpar[10] = (2 * uh2 + h2, 2 * uhvh)
+                dpar[11] = (2 * uhvh, 2 * vh2 + h2)
+                dpar[12] = (h2, zero)
+                dpar[13] = (h4, zero)
+                dpar[14] = (zero, h2)
+                dpar[15] = (zero, h4)
+            uv[s] = np.stack([fx * ad + cx, fy * bd + cy], 1)
+            DE = D @ E
+            Juv[s, 0, :] = fx[:, None] * DE[:, 0, :]
+            Juv[s, 1, :] = fy[:, None] * DE[:, 1, :]
+            Jp[s, 0, 0] = ad
+            Jp[s, 1, 1] = bd
+            Jp[s, 0, 2] = 1
+            Jp[s, 1, 3] = 1
+            for idx, (da_, db_) in dpar.items():
+                Jp[s, 0, idx], Jp[s, 1, idx] = fx * da_, fy * db_
         else:
             raise ValueError(f"camera model {mid} not supported")
     # d(u,v)/d x_c
@@ -232,10 +345,10 @@ def project(model, params, xc):
     return uv, Jx, Jp, valid
 
 
-def free_param_mask(model, opt: BundleAdjusterOptions):
+def free_param_mask(model, opt: BundleAdjusterOptions, width: int = MAXP):
     """Which entries of each intrinsics block are optimised (ba.cc:273-293)."""
     K = model.shape[0]
-    mask = np.zeros((K, MAXP), dtype=bool)
+    mask = np.zeros((K, width), dtype=bool)
     for k in range(K):
         n = NUM_PARAMS[int(model[k])]
         if not opt.optimize_intrinsics and not opt.optimize_principal_point:
@@ -248,7 +361,8 @@ def free_param_mask(model, opt: BundleAdjusterOptions):
 
 class _BaProblem:
     def __init__(self, N, cam, pt, xy, cam_intr, model, fixed_cam, P, opt, obs_ik=None, Rs=None, ts=None, obs_sens=None,
-                 num_sensors=0):
+                 num_sensors=0, width=MAXP):
+        self.W = int(width)  # doubles per intrinsics block (8, or 16 with a 12 / 16-parameter model)
         # N counts ALL pose blocks: the frames and, behind them, the `num_sensors` optimised cam_from_rig blocks
         self.N, self.P, self.M = N, P, cam.shape[0]
         self.cam, self.pt, self.xy = cam, pt, xy
@@ -263,9 +377,9 @@ class _BaProblem:
         self.K = model.shape[0]
         self.opt = opt
         self.loss = lm.HuberLoss(opt.thres_loss_function)
-        self.fmask = free_param_mask(model, opt)
+        self.fmask = free_param_mask(model, opt, self.W)
         # column layout: [6 per pose | free intrinsics | 3 per point]
-        self.intr_col = -np.ones((self.K, MAXP), dtype=np.int64)
+        self.intr_col = -np.ones((self.K, self.W), dtype=np.int64)
         nfree = int(self.fmask.sum())
         self.intr_col[self.fmask] = 6 * N + np.arange(nfree)
         self.pt_col0 = 6 * N + nfree
@@ -286,7 +400,7 @@ class _BaProblem:
         q = x[o : o + 4 * N].reshape(N, 4); o += 4 * N
         t = x[o : o + 3 * N].reshape(N, 3); o += 3 * N
         X = x[o : o + 3 * P].reshape(P, 3); o += 3 * P
-        intr = x[o : o + MAXP * K].reshape(K, MAXP)
+        intr = x[o : o + self.W * K].reshape(K, self.W)
         return q, t, X, intr
 
     @staticmethod
@@ -363,7 +477,7 @@ class _BaProblem:
             vi.append(w_.ravel())
         add(Jpt, self.pt_col0 + 3 * self.pt)
         cols = self.intr_col[ik]  # [M,8], -1 where constant
-        for j in range(MAXP):
+        for j in range(self.W):
             sel = cols[:, j] >= 0
             if not sel.any():
                 continue
@@ -464,6 +578,6 @@ def build_problem(num_cams, pt_offset, obs_cam, obs_xy, cam_intr, intr_model, fi
         return out
     prob = _BaProblem(N + S, cam, pt, xy, None if cam_intr is None else np.asarray(cam_intr, dtype=np.int64),
                       np.asarray(intr_model, dtype=np.int64), int(fixed_cam), int(used.sum()), opt, obs_ik, Rs, ts,
-                      obs_sens, S)
+                      obs_sens, S, width=intr0.shape[1])
     out["problem"], out["x0"] = prob, prob.pack(q0, t0, X_all[used], intr0)
     return out

@@ -51,7 +51,7 @@ def _problem(p, opt, fixed=-1):
     sel = np.repeat(used, lens)
     pt = (np.cumsum(used) - 1)[np.repeat(np.arange(p.num_pts), lens)][sel]
     prob = ba._BaProblem(p.num_cams, p.obs_cam.astype(np.int64)[sel], pt, p.obs_xy[sel], p.cam_intr.astype(np.int64),
-                         p.intr_model.astype(np.int64), fixed, int(used.sum()), opt)
+                         p.intr_model.astype(np.int64), fixed, int(used.sum()), opt, width=p.intr_params.shape[1])
     return prob, prob.pack(p.cam_q, p.cam_t, p.pt_xyz[used], p.intr_params)
 
 
@@ -65,6 +65,14 @@ def _problem(p, opt, fixed=-1):
     (ba.SIMPLE_RADIAL_FISHEYE, [1200, 640, 480, 0.02], "generic"), (ba.RADIAL_FISHEYE, [1200, 640, 480, 0.02, -0.01], "generic"),
     (ba.FOV, [1200, 1190, 640, 480, 0.6], "generic"), (ba.FOV, [1200, 1190, 640, 480, 5e-3], "generic"),
     (ba.FOV, [1200, 1190, 640, 480, 0.6], "near_axis"), (ba.OPENCV_FISHEYE, [1200, 1190, 640, 480, 0.02, -0.01, 0.004, -0.002], "near_axis"),
+    # the models with more than 8 parameters ([K, 16] intrinsics rows)
+    (ba.FULL_OPENCV, [1200, 1190, 640, 480, 0.02, -0.01, 0.001, -0.002, 0.003, 0.01, -0.004, 0.002], "generic"),
+    (ba.THIN_PRISM_FISHEYE, [1200, 1190, 640, 480, 0.02, -0.01, 0.001, -0.002, 0.004, -0.002, 0.0015, -0.001], "generic"),
+    (ba.THIN_PRISM_FISHEYE, [1200, 1190, 640, 480, 0.02, -0.01, 0.001, -0.002, 0.004, -0.002, 0.0015, -0.001], "near_axis"),
+    (ba.RAD_TAN_THIN_PRISM_FISHEYE, [1200, 1190, 640, 480, 0.02, -0.01, 0.004, -0.002, 0.001, -0.0005, 0.001, -0.002, 0.0015, -0.0008,
+                                     -0.001, 0.0005], "generic"),
+    (ba.RAD_TAN_THIN_PRISM_FISHEYE, [1200, 1190, 640, 480, 0.02, -0.01, 0.004, -0.002, 0.001, -0.0005, 0.001, -0.002, 0.0015, -0.0008,
+                                     -0.001, 0.0005], "near_axis"),
 ])
 def test_projection_jacobians_match_finite_differences(mid, par, pts):
     """oracle.ba.project (ImgFromCam + analytic derivatives) against central differences, ray by ray."""
@@ -74,11 +82,12 @@ def test_projection_jacobians_match_finite_differences(mid, par, pts):
         xc = np.column_stack([rng.uniform(-0.8, 0.8, m), rng.uniform(-0.6, 0.6, m), rng.uniform(1.0, 3.0, m)])
     else:
         xc = np.column_stack([rng.uniform(-4e-3, 4e-3, m), rng.uniform(-4e-3, 4e-3, m), rng.uniform(1.0, 3.0, m)])
-    P = np.zeros((m, ba.MAXP))
+    W = ba.MAXP_WIDE if len(par) > ba.MAXP else ba.MAXP
+    P = np.zeros((m, W))
     P[:, : len(par)] = par
     model = np.full(m, mid)
     uv, Jx, Jp, valid = ba.project(model, P, xc)
-    assert valid.all()
+    assert valid.all() and Jp.shape == (m, 2, W)
     h = 1e-6
     for j in range(3):
         d = np.zeros(3)
@@ -87,7 +96,7 @@ def test_projection_jacobians_match_finite_differences(mid, par, pts):
         assert np.abs(num - Jx[:, :, j]).max() < 1e-6 * max(1.0, np.abs(Jx).max())
     for j in range(len(par)):
         hj = h * max(1.0, abs(par[j]))
-        d = np.zeros(ba.MAXP)
+        d = np.zeros(W)
         d[j] = hj
         num = (ba.project(model, P + d, xc)[0] - ba.project(model, P - d, xc)[0]) / (2 * hj)
         assert np.abs(num - Jp[:, :, j]).max() < 1e-6 * max(1.0, np.abs(Jp[:, :, j]).max())
@@ -170,3 +179,59 @@ def test_with_noise_and_outliers_two_stage():
     c, R = _centers(q, t)
     cg, Rg = _centers(p.gt_q, p.gt_t)
     assert synthetic.center_errors_after_sim3(c, cg).max() < 0.1 and synthetic.rotation_errors_deg(R, Rg).max() < 0.1
+
+
+def test_wide_models_reduce_to_their_narrow_relatives():
+    """Definitions cross-checked against the 8-parameter models they extend: FULL_OPENCV with k3 .. k6 = 0 is OPENCV;
+    THIN_PRISM_FISHEYE without tangential / thin-prism terms and RAD_TAN_THIN_PRISM_FISHEYE with k4 = k5 = p = s = 0 are the
+    equidistant fisheye with a polynomial in theta^2, i.e. OPENCV_FISHEYE with the same k1 .. k4 (theta_d = theta (1 + k1 theta^2
+    + ...), models.h)."""
+    rng = np.random.default_rng(5)
+    m = 50
+    xc = np.column_stack([rng.uniform(-0.8, 0.8, m), rng.uniform(-0.6, 0.6, m), rng.uniform(1.0, 3.0, m)])
+    base = [1200, 1190, 640, 480]
+    P8 = np.zeros((m, 8))
+    P8[:] = base + [0.02, -0.01, 0.001, -0.002]
+    P16 = np.zeros((m, 16))
+    P16[:, :8] = P8
+    a = ba.project(np.full(m, ba.OPENCV), P8, xc)
+    b = ba.project(np.full(m, ba.FULL_OPENCV), P16, xc)
+    assert np.allclose(a[0], b[0], rtol=0, atol=1e-9) and np.allclose(a[1], b[1], rtol=1e-12, atol=1e-9)
+    assert np.allclose(a[2], b[2][:, :, :8], rtol=1e-12, atol=1e-9)
+    P8[:] = base + [0.02, -0.01, 0.004, -0.002]           # OPENCV_FISHEYE k1 .. k4
+    a = ba.project(np.full(m, ba.OPENCV_FISHEYE), P8, xc)
+    P16[:] = 0
+    P16[:, :4] = base
+    P16[:, [4, 5, 8, 9]] = [0.02, -0.01, 0.004, -0.002]   # THIN_PRISM_FISHEYE k1, k2, (p1, p2,) k3, k4
+    b = ba.project(np.full(m, ba.THIN_PRISM_FISHEYE), P16, xc)
+    assert np.allclose(a[0], b[0], rtol=0, atol=1e-9) and np.allclose(a[1], b[1], rtol=1e-12, atol=1e-9)
+    assert np.allclose(a[2][:, :, 4:8], b[2][:, :, [4, 5, 8, 9]], rtol=1e-12, atol=1e-9)
+    P16[:] = 0
+    P16[:, :4] = base
+    P16[:, 4:8] = [0.02, -0.01, 0.004, -0.002]            # RAD_TAN_THIN_PRISM_FISHEYE k0 .. k3
+    b = ba.project(np.full(m, ba.RAD_TAN_THIN_PRISM_FISHEYE), P16, xc)
+    assert np.allclose(a[0], b[0], rtol=0, atol=1e-9) and np.allclose(a[1], b[1], rtol=1e-12, atol=1e-9)
+    assert np.allclose(a[2][:, :, 4:8], b[2][:, :, 4:8], rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.parametrize("mid,par", [
+    (ba.FULL_OPENCV, [1200, 1190, 640, 480, 0.02, -0.01, 0.001, -0.002, 0.003, 0.01, -0.004, 0.002]),
+    (ba.RAD_TAN_THIN_PRISM_FISHEYE, [1200, 1190, 640, 480, 0.02, -0.01, 0.004, -0.002, 0.001, -0.0005, 0.001, -0.002, 0.0015, -0.0008,
+                                     -0.001, 0.0005])])
+def test_wide_model_problem_jacobian_and_masks(mid, par):
+    """[K, 16] intrinsics blocks through the whole problem: free-parameter mask (12 / 16 parameters, principal point frozen by
+    the SubsetManifold, ba.cc:273-287), column layout, J d against central differences."""
+    p = synthetic.make_ba_problem(num_cams=8, num_pts=60, seed=1, pixel_noise=0.0, outlier_ratio=0.0, shared_intrinsics=False)
+    p.intr_model[:] = mid
+    wide = np.zeros((p.num_intr, 16))
+    wide[:, : len(par)] = par
+    p.intr_params = wide
+    prob, x0 = _problem(p, ba.BundleAdjusterOptions(thres_loss_function=1e9))
+    assert prob.fmask.shape == (p.num_intr, 16)
+    assert np.array_equal(prob.fmask.sum(1), np.full(p.num_intr, len(par) - 2)) and not prob.fmask[:, 2:4].any()
+    assert not prob.fmask[:, len(par):].any()
+    _, _, J = prob.evaluate(x0)
+    d = np.random.default_rng(0).normal(size=prob.n) * 1e-6
+    num = (prob.evaluate(prob.plus(x0, d))[1] - prob.evaluate(prob.plus(x0, -d))[1]) / 2
+    ana = J @ d
+    assert np.abs(num - ana).max() < 1e-8 * np.abs(ana).max()
