@@ -20,7 +20,7 @@ from typing import Dict, Optional
 import numpy as np
 
 from . import _lib, so3
-from .flat import CAMERA_MAX_PARAMS, BaProblem, GpProblem, RaProblem
+from .flat import CAMERA_MAX_PARAMS, CAMERA_MAX_PARAMS_WIDE, BaProblem, GpProblem, RaProblem
 
 _default_ctx: Optional[_lib.Context] = None
 
@@ -667,7 +667,8 @@ class BundleAdjuster:
             q[n] = frames[fid].rig_from_world.rotation
             t[n] = frames[fid].rig_from_world.translation
         model = np.zeros(K, dtype=np.int32)
-        params = np.zeros((K, CAMERA_MAX_PARAMS))
+        width = CAMERA_MAX_PARAMS_WIDE if any(len(c.params) > CAMERA_MAX_PARAMS for c in cameras.values()) else CAMERA_MAX_PARAMS
+        params = np.zeros((K, width))  # 16-wide rows when a camera model has more than 8 parameters
         for cid, k in intr_of_cam.items():
             model[k] = cameras[cid].model_id
             params[k, : len(cameras[cid].params)] = cameras[cid].params

@@ -19,7 +19,7 @@ from typing import Dict, List
 import numpy as np
 
 from . import so3
-from .flat import CAMERA_MAX_PARAMS, BaProblem, GpProblem
+from .flat import CAMERA_MAX_PARAMS, CAMERA_MAX_PARAMS_WIDE, BaProblem, GpProblem
 from .rotation_averager import _cam_from_rig_state, has_trivial_frame, is_registered
 from .scene import Rigid3d
 
@@ -258,7 +258,9 @@ class BundleAdjuster:
         fixed = int(np.nonzero(in_problem)[0][0])  # first frame that owns a parameter block (ba.cc:253-269)
         K = len(intr_ids)
         model = np.array([cameras[c].model_id for c in intr_ids], dtype=np.int32)
-        params = np.zeros((K, CAMERA_MAX_PARAMS))
+        # 16-wide rows when a camera model has more than 8 parameters (FULL_OPENCV, THIN_PRISM_FISHEYE, RAD_TAN_THIN_PRISM_FISHEYE)
+        width = CAMERA_MAX_PARAMS_WIDE if any(len(cameras[c].params) > CAMERA_MAX_PARAMS for c in intr_ids) else CAMERA_MAX_PARAMS
+        params = np.zeros((K, width))
         for k, c in enumerate(intr_ids):
             params[k, : len(cameras[c].params)] = cameras[c].params
         q0 = np.array([frames[f].rig_from_world.rotation for f in fids], dtype=np.float64)

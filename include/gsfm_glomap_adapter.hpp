@@ -79,8 +79,15 @@ inline int ModelOf(const glomap::Camera& cam) {
     case 7: return GSFM_CAMERA_FOV;
     case 8: return GSFM_CAMERA_SIMPLE_RADIAL_FISHEYE;
     case 9: return GSFM_CAMERA_RADIAL_FISHEYE;
-    default: return -1;  // FULL_OPENCV (6), THIN_PRISM_FISHEYE (10), RAD_TAN_THIN_PRISM_FISHEYE (11): > 8 parameters
+    // more than 8 parameters: the problem is packed with 16-wide intrinsics rows (gsfm_ba_problem::intr_stride)
+    case 6: return GSFM_CAMERA_FULL_OPENCV;
+    case 10: return GSFM_CAMERA_THIN_PRISM_FISHEYE;
+    case 11: return GSFM_CAMERA_RAD_TAN_THIN_PRISM_FISHEYE;
+    default: return -1;
   }
+}
+inline bool NeedsWideRows(int model) {
+  return model == GSFM_CAMERA_FULL_OPENCV || model == GSFM_CAMERA_THIN_PRISM_FISHEYE || model == GSFM_CAMERA_RAD_TAN_THIN_PRISM_FISHEYE;
 }
 
 template <typename Quat>
@@ -1008,7 +1015,7 @@ class BundleAdjuster {
     std::unordered_map<camera_t, int> intr_of;
     std::vector<camera_t> intr_ids;
     std::vector<int32_t> cam_intr(static_cast<size_t>(N), 0), intr_model;
-    std::vector<double> intr;
+    std::vector<double> intr;  // rows of GSFM_CAMERA_MAX_PARAMS_WIDE while packing; narrowed to 8 below unless a model needs 16
     auto intr_index = [&](camera_t cid) {
       auto it = intr_of.find(cid);
       if (it != intr_of.end()) return it->second;
@@ -1017,7 +1024,7 @@ class BundleAdjuster {
       intr_ids.push_back(cid);
       const auto& cam = cameras.at(cid);
       intr_model.push_back(detail::ModelOf(cam));
-      for (int j = 0; j < GSFM_CAMERA_MAX_PARAMS; ++j) intr.push_back(j < static_cast<int>(cam.params.size()) ? cam.params[j] : 0.0);
+      for (int j = 0; j < GSFM_CAMERA_MAX_PARAMS_WIDE; ++j) intr.push_back(j < static_cast<int>(cam.params.size()) ? cam.params[j] : 0.0);
       return k;
     };
     std::vector<double> xy(2 * static_cast<size_t>(M)), q(4 * static_cast<size_t>(N)), t(3 * static_cast<size_t>(N)),
@@ -1058,8 +1065,16 @@ class BundleAdjuster {
       }
       tp.obs_cam[k] = it->second;
     }
-    for (int m : intr_model)
+    int intr_stride = GSFM_CAMERA_MAX_PARAMS;
+    for (int m : intr_model) {
       if (m < 0) return false;  // unsupported camera model
+      if (detail::NeedsWideRows(m)) intr_stride = GSFM_CAMERA_MAX_PARAMS_WIDE;
+    }
+    if (intr_stride == GSFM_CAMERA_MAX_PARAMS) {  // the common case: 8-wide rows, the library's 8-wide unit
+      for (size_t k = 0; k < intr_model.size(); ++k)
+        for (int j = 0; j < GSFM_CAMERA_MAX_PARAMS; ++j) intr[GSFM_CAMERA_MAX_PARAMS * k + j] = intr[GSFM_CAMERA_MAX_PARAMS_WIDE * k + j];
+      intr.resize(GSFM_CAMERA_MAX_PARAMS * intr_model.size());
+    }
     for (int n = 0; n < N; ++n) {
       const auto& pose = frames.at(fidx.ids[n]).RigFromWorld();
       q[4 * n] = pose.rotation.w();
@@ -1094,6 +1109,7 @@ class BundleAdjuster {
     pr.obs_xy = xy.data();
     pr.cam_intr = cam_intr.data();
     pr.intr_model = intr_model.data();
+    pr.intr_stride = intr_stride;
     if (rigged) {
       pr.num_images = static_cast<int32_t>(image_frame.size());
       pr.image_frame = image_frame.data();
@@ -1126,7 +1142,7 @@ class BundleAdjuster {
     }
     for (size_t k = 0; k < intr_ids.size(); ++k) {
       auto& cam = cameras.at(intr_ids[k]);
-      for (size_t j = 0; j < cam.params.size(); ++j) cam.params[j] = intr[GSFM_CAMERA_MAX_PARAMS * k + j];
+      for (size_t j = 0; j < cam.params.size(); ++j) cam.params[j] = intr[static_cast<size_t>(intr_stride) * k + j];
     }
     return true;
   }

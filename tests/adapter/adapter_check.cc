@@ -252,6 +252,44 @@ int main() {
       maxerr = std::fmax(maxerr, std::hypot(u - f[0], v - f[1]));
     }
   if (maxerr > 1e-3) return std::printf("BA reprojection error %.3e px\n", maxerr), 1;
+  // 3b) a camera model with more than 8 parameters: FULL_OPENCV (12) with zero distortion projects like the PINHOLE above;
+  //     the adapter packs 16-wide intrinsics rows (gsfm_ba_problem::intr_stride) and the library's 16-wide unit solves
+  //     (colmap::CreateCameraCostFunction dispatches on any CameraModelId, bundle_adjustment.cc:136-139).
+  {
+    const auto cam_before = cameras[1];
+    const auto tracks_before = tracks;
+    const auto frames_b = frames;
+    cameras[1].model_id = 6;
+    cameras[1].params.resize(12, 0.0);
+    for (auto& [tid, tr] : tracks)
+      if (tr.observations.size() >= 3)  // (shorter tracks are not part of the problem, bundle_adjustment.cc:122)
+        for (int i = 0; i < 3; ++i) tr.xyz[i] += 2e-3 * U(rng);
+    gsfm_glomap::BundleAdjuster ba12(bo);
+    if (!ba12.Solve(rigs, cameras, frames, images, tracks)) return std::printf("BA (FULL_OPENCV) failed\n"), 1;
+    const auto& par = cameras[1].params;
+    if (par.size() != 12) return std::printf("BA (FULL_OPENCV) resized the parameter block\n"), 1;
+    if (par[2] != 320.0 || par[3] != 240.0) return std::printf("BA (FULL_OPENCV) moved the principal point\n"), 1;
+    double e12 = 0;
+    for (auto& [tid, tr] : tracks)
+      for (auto& ob : tr.observations) {
+        Frame& fr = frames[images[ob.first].frame_id];
+        double xc[3];
+        const double X[3] = {tr.xyz[0], tr.xyz[1], tr.xyz[2]};
+        gsfm_glomap::detail::Rotate(fr.RigFromWorld().rotation, X, xc);
+        for (int i = 0; i < 3; ++i) xc[i] += fr.RigFromWorld().translation[i];
+        const double u = xc[0] / xc[2], v = xc[1] / xc[2], r2 = u * u + v * v;
+        const double rad = (1 + par[4] * r2 + par[5] * r2 * r2 + par[8] * r2 * r2 * r2) / (1 + par[9] * r2 + par[10] * r2 * r2 + par[11] * r2 * r2 * r2);
+        const double ud = u * rad + 2 * par[6] * u * v + par[7] * (r2 + 2 * u * u), vd = v * rad + 2 * par[7] * u * v + par[6] * (r2 + 2 * v * v);
+        const auto& f = images[ob.first].features[ob.second];
+        e12 = std::fmax(e12, std::hypot(par[0] * ud + par[2] - f[0], par[1] * vd + par[3] - f[1]));
+      }
+    if (e12 > 1e-3) return std::printf("BA (FULL_OPENCV) reprojection error %.3e px\n", e12), 1;
+    std::printf("BA with a 12-parameter camera model: reprojection error %.2e px, %d LM iterations\n", e12, ba12.LastReport().iterations);
+    cameras[1] = cam_before;  // the scenarios below continue on the PINHOLE scene
+    tracks = tracks_before;
+    frames = frames_b;
+    for (int n = 0; n < N; ++n) images[n].frame_ptr = &frames[n];
+  }
   // 4) processors: a corrupted observation is filtered, a far point has no triangulation angle,
   //    a wrong relative rotation is invalidated, normalisation scales the ring of centres to extent 10
   {

@@ -183,3 +183,33 @@ def test_pixel_reprojection_filter_reads_wide_rows(gsfm_ctx):
     k_g, c_g = pr.TrackFilter.FilterTracksByReprojection(view, 4.0, False, ctx=gsfm_ctx)
     assert np.array_equal(k_g.astype(bool), k_o) and c_g == c_o
     assert 0.02 < 1 - k_o.mean() < 0.1
+
+
+@pytest.mark.parametrize("sensors", [False, True])
+def test_wide_unit_equals_narrow_unit_on_rigs(gsfm_ctx, sensors):
+    """The rig branches of ba_impl.hpp (constant cam_from_rig, bundle_adjustment.cc:147-160; optimised cam_from_rig blocks,
+    :161-179) in the 16-wide unit: same rig problem with [K,8] and zero-padded [K,16] intrinsics rows."""
+    _, ba, info = synthetic.make_rig_problems(20, 3, 1500, seed=4, pixel_noise=0.5)
+    opt = estimators.BundleAdjusterOptions(optimize_rig_poses=sensors)
+    if sensors:
+        rng = np.random.default_rng(9)
+        s0 = info["sensor_cam_from_rig"].copy()
+        dq = so3.rotmat_to_quat(so3.aa_to_rotmat(rng.normal(0, np.radians(0.5), (s0.shape[0], 3))))
+        s0[:, :4] = oba.quat_mul(dq, s0[:, :4])
+        s0[:, 4:] += rng.normal(0, 0.03, (s0.shape[0], 3))
+        ba = ba.copy()
+        ba.image_sensor = info["sensor_block"].copy()
+        ba.sensor_cam_from_rig = s0
+    rc8, q8, t8, X8, i8, rep8 = estimators.ba_solve(ba, opt, ctx=gsfm_ctx)
+    rc16, q16, t16, X16, i16, rep16 = estimators.ba_solve(_widen(ba), opt, ctx=gsfm_ctx)
+    assert rc8 == 0 and rc16 == 0
+    ang, pos = _pose_diff(q16, t16, q8, t8)
+    print(f"[parity] wide vs narrow unit, rigs (sensor blocks: {sensors}): iterations {rep16['iterations']} / {rep8['iterations']}, "
+          f"initial cost {rep16['initial_cost']:.12e} / {rep8['initial_cost']:.12e}, final {rep16['final_cost']:.12e} / "
+          f"{rep8['final_cost']:.12e}, rotations {ang:.2e} rad, centres {pos:.2e}")
+    assert abs(rep16["initial_cost"] - rep8["initial_cost"]) <= 1e-12 * rep8["initial_cost"]
+    assert rep16["iterations"] == rep8["iterations"]
+    assert abs(rep16["final_cost"] - rep8["final_cost"]) <= 1e-7 * rep8["final_cost"]
+    assert ang < 1e-6 and pos < 1e-6 and np.abs(i16[:, :8] - i8).max() < 1e-3
+    if sensors:
+        assert np.abs(rep16["sensor_cam_from_rig"] - rep8["sensor_cam_from_rig"]).max() < 1e-6
