@@ -188,6 +188,7 @@ def load(path=None):
         lib.orc_gp_solve.restype = C.c_int
         lib.orc_gp_solve_pairs.restype = C.c_int
         lib.orc_ba_solve.restype = C.c_int
+        lib.orc_ba_solve_wide.restype = C.c_int  # orc_ba_wide.cc: [K,16] intrinsics rows
         lib.orc_ra_solve.restype = C.c_int
         lib.orc_num_threads.restype = C.c_int
         _LIB = lib
@@ -358,8 +359,12 @@ def ba_solve(num_cams, pt_offset, obs_cam, obs_xy, cam_intr, intr_model, fixed_c
     X = np.array(pt_xyz, dtype=np.float64, copy=True, order="C")
     intr = np.array(intr_params, dtype=np.float64, copy=True, order="C")
     rep = _Report()
+    if intr.ndim != 2 or intr.shape[1] not in (_ba.MAXP, _ba.MAXP_WIDE):
+        raise ValueError("intr_params must be [K, 8] or [K, 16]")
+    # the width of the intrinsics rows picks the unit: orc_ba.cc (8) or orc_ba_wide.cc (16: the 12 / 16-parameter camera models)
+    entry = lib.orc_ba_solve if intr.shape[1] == _ba.MAXP else lib.orc_ba_solve_wide
     with _deflate_env(deflate):
-        rc = lib.orc_ba_solve(C.c_int32(int(num_cams)), C.c_int32(mdl.shape[0]), C.c_int32(int(fixed_cam)),
+        rc = entry(C.c_int32(int(num_cams)), C.c_int32(mdl.shape[0]), C.c_int32(int(fixed_cam)),
                               C.c_int64(off.shape[0] - 1), _p(off, C.c_int64), _p(cam, C.c_int32), _p(xy, C.c_double),
                               _p(ci, C.c_int32), _p(mdl, C.c_int32), C.byref(o), _p(q, C.c_double), _p(t, C.c_double),
                               _p(X, C.c_double), _p(intr, C.c_double), C.byref(rep), C.c_int32(_threads(threads)),

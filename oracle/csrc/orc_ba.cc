@@ -11,7 +11,8 @@
 //                x_c = R(q) X + t; (u, v) = CameraModel::ImgFromCam(params, x_c); r = (u, v) - obs  [pixels];
 //                residual and Jacobian are zero when the point is not in front of the camera
 //   models       SIMPLE_PINHOLE, PINHOLE, SIMPLE_RADIAL, RADIAL, OPENCV, OPENCV_FISHEYE, FOV, SIMPLE_RADIAL_FISHEYE,
-//                RADIAL_FISHEYE (colmap/sensor/models.h; the models with at most 8 parameters)
+//                RADIAL_FISHEYE (colmap/sensor/models.h; the models with at most 8 parameters); FULL_OPENCV, THIN_PRISM_FISHEYE
+//                and RAD_TAN_THIN_PRISM_FISHEYE in the 16-wide unit (orc_ba_wide.cc compiles this file with ORC_BA_MAXP 16)
 //   manifolds    bundle_adjustment.cc:244-317: EigenQuaternionManifold (q <- [sin|d| d/|d|, cos|d|] * q), first frame
 //                constant, optimize_rotations / optimize_translation, principal point frozen by a SubsetManifold
 //   loss         Huber(1 px), bundle_adjustment.h:30,34-36
@@ -24,11 +25,25 @@
 
 namespace orc {
 
-constexpr int MAXP = 8;
-enum { SIMPLE_PINHOLE = 0, PINHOLE = 1, SIMPLE_RADIAL = 2, RADIAL = 3, OPENCV = 4, OPENCV_FISHEYE = 5, FOV = 7,
-       SIMPLE_RADIAL_FISHEYE = 8, RADIAL_FISHEYE = 9 };  // COLMAP's CameraModelId values
-const int kNumParams[10] = {3, 4, 4, 5, 8, 8, -1, 5, 4, 5};  // -1: FULL_OPENCV (12 parameters) not restated
-const int kPP[10][2] = {{1, 2}, {2, 3}, {1, 2}, {1, 2}, {2, 3}, {2, 3}, {0, 0}, {2, 3}, {1, 2}, {1, 2}};
+// This file is compiled twice into liboracle_cpu.so: as it stands (intrinsics blocks of MAXP = 8 doubles, entry orc_ba_solve)
+// and through orc_ba_wide.cc with ORC_BA_MAXP 16 (entry orc_ba_solve_wide) for the camera models with more than eight
+// parameters — FULL_OPENCV, THIN_PRISM_FISHEYE (12), RAD_TAN_THIN_PRISM_FISHEYE (16); everything but the two option / report
+// structs (identical in both units) is in the anonymous namespace below.
+#ifndef ORC_BA_MAXP
+#define ORC_BA_MAXP 8
+#define ORC_BA_ENTRY orc_ba_solve
+#endif
+constexpr int MAXP = ORC_BA_MAXP;  // doubles per intrinsics block
+constexpr int MP2 = 2 * MAXP;      // a 2 x MAXP Jacobian row pair
+constexpr int MPP = MAXP * MAXP;
+constexpr int BJ = 6 + MAXP;       // joint pose + intrinsics block of the preconditioner
+constexpr int BJ2 = BJ * BJ;
+enum { SIMPLE_PINHOLE = 0, PINHOLE = 1, SIMPLE_RADIAL = 2, RADIAL = 3, OPENCV = 4, OPENCV_FISHEYE = 5, FULL_OPENCV = 6, FOV = 7,
+       SIMPLE_RADIAL_FISHEYE = 8, RADIAL_FISHEYE = 9, THIN_PRISM_FISHEYE = 10, RAD_TAN_THIN_PRISM_FISHEYE = 11 };  // COLMAP's CameraModelId values
+constexpr int kNumModels = 12;
+// (-1 in the 8-wide unit: the models with more than 8 parameters)
+const int kNumParams[kNumModels] = {3, 4, 4, 5, 8, 8, MAXP >= 16 ? 12 : -1, 5, 4, 5, MAXP >= 16 ? 12 : -1, MAXP >= 16 ? 16 : -1};
+const int kPP[kNumModels][2] = {{1, 2}, {2, 3}, {1, 2}, {1, 2}, {2, 3}, {2, 3}, {2, 3}, {2, 3}, {1, 2}, {1, 2}, {2, 3}, {2, 3}};
 
 struct BaOptionsC {
   int32_t max_num_iterations;
@@ -68,7 +83,7 @@ inline void quat_to_rot(const double* q, double* R) {
 
 // ImgFromCam with analytic Jacobians: uv[2], Jx[2][3] = d(uv)/d(x_c), Jp[2][8] = d(uv)/d(params).
 inline bool project(int model, const double* p, const double* xc, double* uv, double* Jx, double* Jp) {
-  for (int i = 0; i < 16; ++i) Jp[i] = 0.0;
+  for (int i = 0; i < MP2; ++i) Jp[i] = 0.0;
   const double z = xc[2];
   if (!(z > 2.220446049250313e-16)) return false;
   const double u = xc[0] / z, v = xc[1] / z;
@@ -80,16 +95,16 @@ inline bool project(int model, const double* p, const double* xc, double* uv, do
       uv[0] = f * u + p[1];
       uv[1] = f * v + p[2];
       J00 = f; J01 = 0; J10 = 0; J11 = f;
-      Jp[0] = u; Jp[8] = v;
-      Jp[1] = 1; Jp[8 + 2] = 1;
+      Jp[0] = u; Jp[MAXP] = v;
+      Jp[1] = 1; Jp[MAXP + 2] = 1;
       break;
     }
     case PINHOLE: {
       uv[0] = p[0] * u + p[2];
       uv[1] = p[1] * v + p[3];
       J00 = p[0]; J01 = 0; J10 = 0; J11 = p[1];
-      Jp[0] = u; Jp[8 + 1] = v;
-      Jp[2] = 1; Jp[8 + 3] = 1;
+      Jp[0] = u; Jp[MAXP + 1] = v;
+      Jp[2] = 1; Jp[MAXP + 3] = 1;
       break;
     }
     case SIMPLE_RADIAL:
@@ -104,12 +119,12 @@ inline bool project(int model, const double* p, const double* xc, double* uv, do
       J01 = f * (2 * u * v * drad);
       J10 = J01;
       J11 = f * (1 + rad + 2 * v * v * drad);
-      Jp[0] = ud; Jp[8] = vd;
-      Jp[1] = 1; Jp[8 + 2] = 1;
-      Jp[3] = f * u * r2; Jp[8 + 3] = f * v * r2;
+      Jp[0] = ud; Jp[MAXP] = vd;
+      Jp[1] = 1; Jp[MAXP + 2] = 1;
+      Jp[3] = f * u * r2; Jp[MAXP + 3] = f * v * r2;
       if (model == RADIAL) {
         Jp[4] = f * u * r2 * r2;
-        Jp[8 + 4] = f * v * r2 * r2;
+        Jp[MAXP + 4] = f * v * r2 * r2;
       }
       break;
     }
@@ -126,12 +141,12 @@ inline bool project(int model, const double* p, const double* xc, double* uv, do
       const double ddv_du = 2 * u * v * drad + 2 * p2 * v + 2 * p1 * u;
       const double ddv_dv = rad + 2 * v * v * drad + 2 * p2 * u + 6 * p1 * v;
       J00 = fx * (1 + ddu_du); J01 = fx * ddu_dv; J10 = fy * ddv_du; J11 = fy * (1 + ddv_dv);
-      Jp[0] = u + du; Jp[8 + 1] = v + dv;
-      Jp[2] = 1; Jp[8 + 3] = 1;
-      Jp[4] = fx * u * r2; Jp[8 + 4] = fy * v * r2;
-      Jp[5] = fx * u * r2 * r2; Jp[8 + 5] = fy * v * r2 * r2;
-      Jp[6] = fx * 2 * u * v; Jp[8 + 6] = fy * (r2 + 2 * v * v);
-      Jp[7] = fx * (r2 + 2 * u * u); Jp[8 + 7] = fy * 2 * u * v;
+      Jp[0] = u + du; Jp[MAXP + 1] = v + dv;
+      Jp[2] = 1; Jp[MAXP + 3] = 1;
+      Jp[4] = fx * u * r2; Jp[MAXP + 4] = fy * v * r2;
+      Jp[5] = fx * u * r2 * r2; Jp[MAXP + 5] = fy * v * r2 * r2;
+      Jp[6] = fx * 2 * u * v; Jp[MAXP + 6] = fy * (r2 + 2 * v * v);
+      Jp[7] = fx * (r2 + 2 * u * u); Jp[MAXP + 7] = fy * 2 * u * v;
       break;
     }
     case OPENCV_FISHEYE:
@@ -157,15 +172,15 @@ inline bool project(int model, const double* p, const double* xc, double* uv, do
       uv[1] = fy * v * m + p[ic + 1];
       J00 = fx * (m + u * u * dm_r); J01 = fx * u * v * dm_r; J10 = fy * u * v * dm_r; J11 = fy * (m + v * v * dm_r);
       if (full) {
-        Jp[0] = u * m; Jp[8 + 1] = v * m;
+        Jp[0] = u * m; Jp[MAXP + 1] = v * m;
       } else {
-        Jp[0] = u * m; Jp[8] = v * m;
+        Jp[0] = u * m; Jp[MAXP] = v * m;
       }
-      Jp[ic] = 1; Jp[8 + ic + 1] = 1;
+      Jp[ic] = 1; Jp[MAXP + ic + 1] = 1;
       const double sf = big ? th / r : 1.0;
       for (int j = 0; j < nk; ++j) {
         Jp[ik0 + j] = fx * u * sf * tpow[j];
-        Jp[8 + ik0 + j] = fy * v * sf * tpow[j];
+        Jp[MAXP + ik0 + j] = fy * v * sf * tpow[j];
       }
       break;
     }
@@ -191,11 +206,100 @@ inline bool project(int model, const double* p, const double* xc, double* uv, do
       uv[1] = fy * v * fac + p[3];
       J00 = fx * (fac + 2 * u * u * dfac_r2); J01 = fx * 2 * u * v * dfac_r2; J10 = fy * 2 * u * v * dfac_r2;
       J11 = fy * (fac + 2 * v * v * dfac_r2);
-      Jp[0] = u * fac; Jp[8 + 1] = v * fac;
-      Jp[2] = 1; Jp[8 + 3] = 1;
-      Jp[4] = fx * u * dfac_om; Jp[8 + 4] = fy * v * dfac_om;
+      Jp[0] = u * fac; Jp[MAXP + 1] = v * fac;
+      Jp[2] = 1; Jp[MAXP + 3] = 1;
+      Jp[4] = fx * u * dfac_om; Jp[MAXP + 4] = fy * v * dfac_om;
       break;
     }
+#if ORC_BA_MAXP >= 16
+    case FULL_OPENCV:
+    case THIN_PRISM_FISHEYE:
+    case RAD_TAN_THIN_PRISM_FISHEYE: {
+      // (a, b) -> (ad, bd) distortions of (u, v) itself (FULL_OPENCV) or of the equidistant coordinates (a, b) = (u, v) theta / r
+      // (the thin-prism fisheye models); D = d(ad, bd) / d(a, b), E = d(a, b) / d(u, v).  Same formulas as oracle/ba.py.
+      const double fx = p[0], fy = p[1];
+      double a = u, b = v, e0 = 1.0, e1 = 0.0, e2 = 0.0, e3 = 1.0;
+      if (model != FULL_OPENCV) {
+        const double r = std::sqrt(r2);
+        if (r > 2.220446049250313e-16) {
+          const double s = std::atan(r) / r, sp = (1.0 / (1.0 + r2) - s) / r2;
+          a = s * u; b = s * v;
+          e0 = s + u * u * sp; e1 = u * v * sp; e2 = e1; e3 = s + v * v * sp;
+        }
+      }
+      const double a2 = a * a, b2 = b * b, ab = a * b, q2 = a2 + b2;
+      double ad, bd, d0, d1, d2, d3;
+      double dpa[MAXP], dpb[MAXP];  // d(ad) / d(param), d(bd) / d(param)
+      for (int j = 0; j < MAXP; ++j) dpa[j] = dpb[j] = 0.0;
+      if (model == FULL_OPENCV) {
+        const double k1 = p[4], k2 = p[5], p1 = p[6], p2 = p[7], k3 = p[8], k4 = p[9], k5 = p[10], k6 = p[11];
+        const double q4 = q2 * q2, q6 = q4 * q2;
+        const double num = 1.0 + k1 * q2 + k2 * q4 + k3 * q6, den = 1.0 + k4 * q2 + k5 * q4 + k6 * q6, rad = num / den;
+        const double drad = ((k1 + 2.0 * k2 * q2 + 3.0 * k3 * q4) - rad * (k4 + 2.0 * k5 * q2 + 3.0 * k6 * q4)) / den;
+        ad = a * rad + 2.0 * p1 * ab + p2 * (q2 + 2.0 * a2);
+        bd = b * rad + 2.0 * p2 * ab + p1 * (q2 + 2.0 * b2);
+        d0 = rad + 2.0 * a2 * drad + 2.0 * p1 * b + 6.0 * p2 * a;
+        d1 = 2.0 * ab * drad + 2.0 * p1 * a + 2.0 * p2 * b;
+        d2 = 2.0 * ab * drad + 2.0 * p2 * b + 2.0 * p1 * a;
+        d3 = rad + 2.0 * b2 * drad + 2.0 * p2 * a + 6.0 * p1 * b;
+        const double qq[3] = {q2, q4, q6};
+        const int inum[3] = {4, 5, 8}, iden[3] = {9, 10, 11};
+        for (int j = 0; j < 3; ++j) {
+          dpa[inum[j]] = a * qq[j] / den; dpb[inum[j]] = b * qq[j] / den;
+          dpa[iden[j]] = -a * rad * qq[j] / den; dpb[iden[j]] = -b * rad * qq[j] / den;
+        }
+        dpa[6] = 2.0 * ab; dpb[6] = q2 + 2.0 * b2;
+        dpa[7] = q2 + 2.0 * a2; dpb[7] = 2.0 * ab;
+      } else if (model == THIN_PRISM_FISHEYE) {
+        const double k1 = p[4], k2 = p[5], p1 = p[6], p2 = p[7], k3 = p[8], k4 = p[9], sx1 = p[10], sy1 = p[11];
+        const double q4 = q2 * q2, q6 = q4 * q2, q8 = q4 * q4;
+        const double rad = k1 * q2 + k2 * q4 + k3 * q6 + k4 * q8, drad = k1 + 2.0 * k2 * q2 + 3.0 * k3 * q4 + 4.0 * k4 * q6;
+        ad = a + a * rad + 2.0 * p1 * ab + p2 * (q2 + 2.0 * a2) + sx1 * q2;
+        bd = b + b * rad + 2.0 * p2 * ab + p1 * (q2 + 2.0 * b2) + sy1 * q2;
+        d0 = 1.0 + rad + 2.0 * a2 * drad + 2.0 * p1 * b + 6.0 * p2 * a + 2.0 * sx1 * a;
+        d1 = 2.0 * ab * drad + 2.0 * p1 * a + 2.0 * p2 * b + 2.0 * sx1 * b;
+        d2 = 2.0 * ab * drad + 2.0 * p2 * b + 2.0 * p1 * a + 2.0 * sy1 * a;
+        d3 = 1.0 + rad + 2.0 * b2 * drad + 2.0 * p2 * a + 6.0 * p1 * b + 2.0 * sy1 * b;
+        const double qq[4] = {q2, q4, q6, q8};
+        const int ik[4] = {4, 5, 8, 9};
+        for (int j = 0; j < 4; ++j) { dpa[ik[j]] = a * qq[j]; dpb[ik[j]] = b * qq[j]; }
+        dpa[6] = 2.0 * ab; dpb[6] = q2 + 2.0 * b2;
+        dpa[7] = q2 + 2.0 * a2; dpb[7] = 2.0 * ab;
+        dpa[10] = q2;
+        dpb[11] = q2;
+      } else {
+        const double p0 = p[10], p1 = p[11], s0 = p[12], s1 = p[13], s2 = p[14], s3 = p[15];
+        double qp[6];
+        qp[0] = q2;
+        for (int i = 1; i < 6; ++i) qp[i] = qp[i - 1] * q2;
+        double Rr = 1.0, dR = p[4];
+        for (int i = 0; i < 6; ++i) Rr += p[4 + i] * qp[i];
+        for (int i = 1; i < 6; ++i) dR += (i + 1.0) * p[4 + i] * qp[i - 1];
+        const double uh = Rr * a, vh = Rr * b, uh2 = uh * uh, vh2 = vh * vh, uhvh = uh * vh, h2 = uh2 + vh2, h4 = h2 * h2;
+        ad = uh + p0 * (2.0 * uh2 + h2) + 2.0 * p1 * uhvh + s0 * h2 + s1 * h4;
+        bd = vh + p1 * (2.0 * vh2 + h2) + 2.0 * p0 * uhvh + s2 * h2 + s3 * h4;
+        const double sx = s0 + 2.0 * s1 * h2, sy = s2 + 2.0 * s3 * h2;
+        const double T0 = 1.0 + 6.0 * p0 * uh + 2.0 * p1 * vh + 2.0 * uh * sx, T1 = 2.0 * p0 * vh + 2.0 * p1 * uh + 2.0 * vh * sx;
+        const double T2 = 2.0 * p1 * uh + 2.0 * p0 * vh + 2.0 * uh * sy, T3 = 1.0 + 6.0 * p1 * vh + 2.0 * p0 * uh + 2.0 * vh * sy;
+        const double r0 = Rr + 2.0 * a2 * dR, r1 = 2.0 * ab * dR, r3 = Rr + 2.0 * b2 * dR;
+        d0 = T0 * r0 + T1 * r1; d1 = T0 * r1 + T1 * r3; d2 = T2 * r0 + T3 * r1; d3 = T2 * r1 + T3 * r3;
+        const double ta = T0 * a + T1 * b, tb = T2 * a + T3 * b;
+        for (int i = 0; i < 6; ++i) { dpa[4 + i] = ta * qp[i]; dpb[4 + i] = tb * qp[i]; }
+        dpa[10] = 2.0 * uh2 + h2; dpb[10] = 2.0 * uhvh;
+        dpa[11] = 2.0 * uhvh; dpb[11] = 2.0 * vh2 + h2;
+        dpa[12] = h2; dpa[13] = h4;
+        dpb[14] = h2; dpb[15] = h4;
+      }
+      uv[0] = fx * ad + p[2];
+      uv[1] = fy * bd + p[3];
+      J00 = fx * (d0 * e0 + d1 * e2); J01 = fx * (d0 * e1 + d1 * e3);
+      J10 = fy * (d2 * e0 + d3 * e2); J11 = fy * (d2 * e1 + d3 * e3);
+      for (int j = 4; j < MAXP; ++j) { Jp[j] = fx * dpa[j]; Jp[MAXP + j] = fy * dpb[j]; }
+      Jp[0] = ad; Jp[MAXP + 1] = bd;
+      Jp[2] = 1; Jp[MAXP + 3] = 1;
+      break;
+    }
+#endif
     default:
       return false;
   }
@@ -305,7 +409,7 @@ struct Ba : LmProblem {
   double cost_at(const std::vector<double>& qq, const std::vector<double>& tt, const std::vector<double>& XX,
                  const std::vector<double>& in) const {
     return 0.5 * chunked_sum(M, [&](i64 k) {
-      double r[2], R[9], RX[3], Jx[6], Jpar[16];
+      double r[2], R[9], RX[3], Jx[6], Jpar[MP2];
       bool valid;
       residual(k, qq, tt, XX, in, r, R, RX, Jx, Jpar, &valid);
       double r0, r1;
@@ -319,12 +423,12 @@ struct Ba : LmProblem {
     rt.resize(2 * M);
     Jc.resize(12 * M);
     Jp.resize(6 * M);
-    Ji.resize(16 * M);
+    Ji.resize((size_t)MP2 * M);
     if (S > 0) Js.assign(12 * M, 0.0);
     std::vector<double> rho(M);
 #pragma omp parallel for schedule(static)
     for (i64 k = 0; k < M; ++k) {
-      double r[2], R[9], RX[3], Jx[6], Jpar[16], Jcam[6], arig[3] = {0, 0, 0};
+      double r[2], R[9], RX[3], Jx[6], Jpar[MP2], Jcam[6], arig[3] = {0, 0, 0};
       bool valid;
       residual(k, q, t, X, intr, r, R, RX, Jx, Jpar, &valid, Jcam, arig);
       double r0, r1;
@@ -347,7 +451,7 @@ struct Ba : LmProblem {
         Jc[12 * k + 6 * i + 4] = ft * j1;
         Jc[12 * k + 6 * i + 5] = ft * j2;
         for (int j = 0; j < 3; ++j) Jp[6 * k + 3 * i + j] = mpt * (j0 * R[j] + j1 * R[3 + j] + j2 * R[6 + j]);
-        for (int j = 0; j < MAXP; ++j) Ji[16 * k + 8 * i + j] = free_par[MAXP * b + j] ? sw * Jpar[8 * i + j] : 0.0;
+        for (int j = 0; j < MAXP; ++j) Ji[MP2 * k + MAXP * i + j] = free_par[MAXP * b + j] ? sw * Jpar[MAXP * i + j] : 0.0;
         if (S > 0 && sblk[k] >= 0) {  // x_c = Exp(2 d_rot) (R_s x_rig) + t_s + d_trn: always free (ba.cc:296-309)
           const double c0 = sw * Jcam[3 * i], c1 = sw * Jcam[3 * i + 1], c2 = sw * Jcam[3 * i + 2];
           Js[12 * k + 6 * i + 0] = -2.0 * (c1 * arig[2] - c2 * arig[1]);
@@ -409,18 +513,18 @@ struct Ba : LmProblem {
           hred[6 * (N + sb) + j] = accs[12 * sb + 6 + j];
         }
     }
-    std::vector<double> acci(16 * K);
-    byintr.reduce<16>(acci.data(), rev, [&](i64 k, double* a) {
-      for (int j = 0; j < 8; ++j) {
-        a[j] += Ji[16 * k + j] * rt[2 * k] + Ji[16 * k + 8 + j] * rt[2 * k + 1];
-        a[8 + j] += Ji[16 * k + j] * Ji[16 * k + j] + Ji[16 * k + 8 + j] * Ji[16 * k + 8 + j];
+    std::vector<double> acci((size_t)MP2 * K);
+    byintr.reduce<MP2>(acci.data(), rev, [&](i64 k, double* a) {
+      for (int j = 0; j < MAXP; ++j) {
+        a[j] += Ji[MP2 * k + j] * rt[2 * k] + Ji[MP2 * k + MAXP + j] * rt[2 * k + 1];
+        a[MAXP + j] += Ji[MP2 * k + j] * Ji[MP2 * k + j] + Ji[MP2 * k + MAXP + j] * Ji[MP2 * k + MAXP + j];
       }
     });
     for (i64 b = 0; b < K; ++b)
-      for (int j = 0; j < 8; ++j)
+      for (int j = 0; j < MAXP; ++j)
         if (icol[MAXP * b + j] >= 0) {
-          gred[icol[MAXP * b + j]] = acci[16 * b + j];
-          hred[icol[MAXP * b + j]] = acci[16 * b + 8 + j];
+          gred[icol[MAXP * b + j]] = acci[MP2 * b + j];
+          hred[icol[MAXP * b + j]] = acci[MP2 * b + MAXP + j];
         }
     double gmax = chunked_max(nred, [&](i64 i) { return std::fabs(gred[i]); });
     gmax = std::max(gmax, chunked_max(3 * P, [&](i64 i) { return std::fabs(gpt[i]); }));
@@ -455,8 +559,8 @@ struct Ba : LmProblem {
     for (int j = 0; j < MAXP; ++j) {
       const int32_t col = icol[MAXP * b + j];
       if (col >= 0) {
-        a[0] += Ji[16 * k + j] * z[col];
-        a[1] += Ji[16 * k + 8 + j] * z[col];
+        a[0] += Ji[MP2 * k + j] * z[col];
+        a[1] += Ji[MP2 * k + MAXP + j] * z[col];
       }
     }
   }
@@ -505,13 +609,13 @@ struct Ba : LmProblem {
       std::copy(accs.begin(), accs.end(), out.begin() + 6 * N);
     }
     if (nfree > 0) {
-      std::vector<double> acci(8 * K);
-      byintr.reduce<8>(acci.data(), rev, [&](i64 k, double* a) {
-        for (int j = 0; j < 8; ++j) a[j] += Ji[16 * k + j] * e[2 * k] + Ji[16 * k + 8 + j] * e[2 * k + 1];
+      std::vector<double> acci((size_t)MAXP * K);
+      byintr.reduce<MAXP>(acci.data(), rev, [&](i64 k, double* a) {
+        for (int j = 0; j < MAXP; ++j) a[j] += Ji[MP2 * k + j] * e[2 * k] + Ji[MP2 * k + MAXP + j] * e[2 * k + 1];
       });
       for (i64 b = 0; b < K; ++b)
-        for (int j = 0; j < 8; ++j)
-          if (icol[MAXP * b + j] >= 0) out[icol[MAXP * b + j]] = acci[8 * b + j];
+        for (int j = 0; j < MAXP; ++j)
+          if (icol[MAXP * b + j] >= 0) out[icol[MAXP * b + j]] = acci[MAXP * b + j];
     }
   }
 
@@ -700,19 +804,19 @@ struct Ba : LmProblem {
   // Diagonal blocks of S assembled per observation: W^T W - W^T Jp Hpp^-1 Jp^T W, W = [Jc Ji] (exact for the pose
   // part; for shared intrinsics it drops the cross terms between observations of one point — it is a preconditioner).
   bool build_preconditioner() {
-    Mblk.assign((size_t)196 * N, 0.0);
-    std::vector<double> acc((size_t)196 * N);
-    bycam.reduce<196>(acc.data(), rev, [&](i64 k, double* a) {
+    Mblk.assign((size_t)BJ2 * N, 0.0);
+    std::vector<double> acc((size_t)BJ2 * N);
+    bycam.reduce<BJ2>(acc.data(), rev, [&](i64 k, double* a) {
       const i64 n = cam[k], b = ik[k];
       const bool joint = intr_owner[b] == n;
-      double W[2][14];
+      double W[2][BJ];
       for (int j = 0; j < 6; ++j) {
         W[0][j] = Jc[12 * k + j];
         W[1][j] = Jc[12 * k + 6 + j];
       }
-      for (int j = 0; j < 8; ++j) {
-        W[0][6 + j] = joint ? Ji[16 * k + j] : 0.0;
-        W[1][6 + j] = joint ? Ji[16 * k + 8 + j] : 0.0;
+      for (int j = 0; j < MAXP; ++j) {
+        W[0][6 + j] = joint ? Ji[MP2 * k + j] : 0.0;
+        W[1][6 + j] = joint ? Ji[MP2 * k + MAXP + j] : 0.0;
       }
       const double* H = &Hinv[9 * (i64)pt[k]];
       // G = Jp Hpp^-1 Jp^T (2x2)
@@ -725,35 +829,35 @@ struct Ba : LmProblem {
         for (int j = 0; j < 2; ++j)
           G[i][j] = JH[i][0] * Jp[6 * k + 3 * j] + JH[i][1] * Jp[6 * k + 3 * j + 1] + JH[i][2] * Jp[6 * k + 3 * j + 2];
       const double A00 = 1.0 - G[0][0], A01 = -G[0][1], A10 = -G[1][0], A11 = 1.0 - G[1][1];
-      const int w = joint ? 14 : 6;
+      const int w = joint ? BJ : 6;
       for (int i = 0; i < w; ++i) {
         const double l0 = W[0][i] * A00 + W[1][i] * A10, l1 = W[0][i] * A01 + W[1][i] * A11;
-        for (int j = 0; j < w; ++j) a[14 * i + j] += l0 * W[0][j] + l1 * W[1][j];
+        for (int j = 0; j < w; ++j) a[BJ * i + j] += l0 * W[0][j] + l1 * W[1][j];
       }
     });
     bool ok = true;
 #pragma omp parallel for schedule(static)
     for (i64 n = 0; n < N; ++n) {
-      double B[196];
-      for (int i = 0; i < 14; ++i)
-        for (int j = 0; j < 14; ++j) B[14 * i + j] = 0.5 * (acc[(size_t)196 * n + 14 * i + j] + acc[(size_t)196 * n + 14 * j + i]);
+      double B[BJ2];
+      for (int i = 0; i < BJ; ++i)
+        for (int j = 0; j < BJ; ++j) B[BJ * i + j] = 0.5 * (acc[(size_t)BJ2 * n + BJ * i + j] + acc[(size_t)BJ2 * n + BJ * j + i]);
       const i64 b = cam_intr[n];
       const bool joint = intr_owner[b] == n;
-      for (int j = 0; j < 6; ++j) B[15 * j] += dred[6 * n + j];
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < 6; ++j) B[(BJ + 1) * j] += dred[6 * n + j];
+      for (int j = 0; j < MAXP; ++j) {
         const int32_t col = joint ? icol[MAXP * b + j] : -1;
         if (col >= 0)
-          B[15 * (6 + j)] += dred[col];
+          B[(BJ + 1) * (6 + j)] += dred[col];
         else {  // not part of this block: identity row / column
-          for (int i = 0; i < 14; ++i) B[14 * (6 + j) + i] = B[14 * i + 6 + j] = 0.0;
-          B[15 * (6 + j)] = 1.0;
+          for (int i = 0; i < BJ; ++i) B[BJ * (6 + j) + i] = B[BJ * i + 6 + j] = 0.0;
+          B[(BJ + 1) * (6 + j)] = 1.0;
         }
       }
-      if (!spd_inverse(B, 14)) {
+      if (!spd_inverse(B, BJ)) {
 #pragma omp atomic write
         ok = false;
       }
-      std::memcpy(&Mblk[(size_t)196 * n], B, sizeof B);
+      std::memcpy(&Mblk[(size_t)BJ2 * n], B, sizeof B);
     }
     if (!ok) return false;
     if (S > 0) {  // one 6 x 6 block per sensor block: Js^T (I - Jp Hpp^-1 Jp^T) Js summed per observation + damping
@@ -785,12 +889,12 @@ struct Ba : LmProblem {
         std::memcpy(&Msblk[(size_t)36 * sb], B, sizeof B);
       }
     }
-    Miblk.assign((size_t)64 * K, 0.0);
+    Miblk.assign((size_t)MPP * K, 0.0);
     bool any_shared = false;
     for (i64 b = 0; b < K; ++b) any_shared = any_shared || intr_owner[b] < 0;
     if (any_shared && nfree > 0) {
-      std::vector<double> acci((size_t)64 * K);
-      byintr.reduce<64>(acci.data(), rev, [&](i64 k, double* a) {
+      std::vector<double> acci((size_t)MPP * K);
+      byintr.reduce<MPP>(acci.data(), rev, [&](i64 k, double* a) {
         if (intr_owner[ik[k]] >= 0) return;
         const double* H = &Hinv[9 * (i64)pt[k]];
         double JH[2][3];
@@ -802,27 +906,27 @@ struct Ba : LmProblem {
           for (int j = 0; j < 2; ++j)
             G[i][j] = JH[i][0] * Jp[6 * k + 3 * j] + JH[i][1] * Jp[6 * k + 3 * j + 1] + JH[i][2] * Jp[6 * k + 3 * j + 2];
         const double A00 = 1.0 - G[0][0], A01 = -G[0][1], A10 = -G[1][0], A11 = 1.0 - G[1][1];
-        for (int i = 0; i < 8; ++i) {
-          const double l0 = Ji[16 * k + i] * A00 + Ji[16 * k + 8 + i] * A10, l1 = Ji[16 * k + i] * A01 + Ji[16 * k + 8 + i] * A11;
-          for (int j = 0; j < 8; ++j) a[8 * i + j] += l0 * Ji[16 * k + j] + l1 * Ji[16 * k + 8 + j];
+        for (int i = 0; i < MAXP; ++i) {
+          const double l0 = Ji[MP2 * k + i] * A00 + Ji[MP2 * k + MAXP + i] * A10, l1 = Ji[MP2 * k + i] * A01 + Ji[MP2 * k + MAXP + i] * A11;
+          for (int j = 0; j < MAXP; ++j) a[MAXP * i + j] += l0 * Ji[MP2 * k + j] + l1 * Ji[MP2 * k + MAXP + j];
         }
       });
       for (i64 b = 0; b < K; ++b) {
         if (intr_owner[b] >= 0) continue;
-        double B[64];
-        for (int i = 0; i < 8; ++i)
-          for (int j = 0; j < 8; ++j) B[8 * i + j] = 0.5 * (acci[(size_t)64 * b + 8 * i + j] + acci[(size_t)64 * b + 8 * j + i]);
-        for (int j = 0; j < 8; ++j) {
+        double B[MPP];
+        for (int i = 0; i < MAXP; ++i)
+          for (int j = 0; j < MAXP; ++j) B[MAXP * i + j] = 0.5 * (acci[(size_t)MPP * b + MAXP * i + j] + acci[(size_t)MPP * b + MAXP * j + i]);
+        for (int j = 0; j < MAXP; ++j) {
           const int32_t col = icol[MAXP * b + j];
           if (col >= 0)
-            B[9 * j] += dred[col];
+            B[(MAXP + 1) * j] += dred[col];
           else {
-            for (int i = 0; i < 8; ++i) B[8 * j + i] = B[8 * i + j] = 0.0;
-            B[9 * j] = 1.0;
+            for (int i = 0; i < MAXP; ++i) B[MAXP * j + i] = B[MAXP * i + j] = 0.0;
+            B[(MAXP + 1) * j] = 1.0;
           }
         }
-        if (!spd_inverse(B, 8)) return false;
-        std::memcpy(&Miblk[(size_t)64 * b], B, sizeof B);
+        if (!spd_inverse(B, MAXP)) return false;
+        std::memcpy(&Miblk[(size_t)MPP * b], B, sizeof B);
       }
     }
     return true;
@@ -833,20 +937,20 @@ struct Ba : LmProblem {
     for (i64 n = 0; n < N; ++n) {
       const i64 b = cam_intr[n];
       const bool joint = intr_owner[b] == n;
-      double rv[14], zv[14];
+      double rv[BJ], zv[BJ];
       for (int j = 0; j < 6; ++j) rv[j] = r[6 * n + j];
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < MAXP; ++j) {
         const int32_t col = joint ? icol[MAXP * b + j] : -1;
         rv[6 + j] = col >= 0 ? r[col] : 0.0;
       }
-      const double* B = &Mblk[(size_t)196 * n];
-      for (int i = 0; i < 14; ++i) {
+      const double* B = &Mblk[(size_t)BJ2 * n];
+      for (int i = 0; i < BJ; ++i) {
         double s = 0.0;
-        for (int j = 0; j < 14; ++j) s += B[14 * i + j] * rv[j];
+        for (int j = 0; j < BJ; ++j) s += B[BJ * i + j] * rv[j];
         zv[i] = s;
       }
       for (int j = 0; j < 6; ++j) z[6 * n + j] = zv[j];
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < MAXP; ++j) {
         const int32_t col = joint ? icol[MAXP * b + j] : -1;
         if (col >= 0) z[col] = zv[6 + j];
       }
@@ -862,14 +966,14 @@ struct Ba : LmProblem {
     }
     for (i64 b = 0; b < K; ++b) {
       if (intr_owner[b] >= 0) continue;
-      const double* B = &Miblk[(size_t)64 * b];
-      for (int i = 0; i < 8; ++i) {
+      const double* B = &Miblk[(size_t)MPP * b];
+      for (int i = 0; i < MAXP; ++i) {
         const int32_t ci = icol[MAXP * b + i];
         if (ci < 0) continue;
         double s = 0.0;
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < MAXP; ++j) {
           const int32_t cj = icol[MAXP * b + j];
-          if (cj >= 0) s += B[8 * i + j] * r[cj];
+          if (cj >= 0) s += B[MAXP * i + j] * r[cj];
         }
         z[ci] = s;
       }
@@ -890,10 +994,10 @@ struct Ba : LmProblem {
 extern "C" {
 using orc::i64;
 
-// Arrays as gsfm_ba_problem (include/gsfm.h); cam_q (w,x,y,z), intr_params [K][8].
+// Arrays as gsfm_ba_problem (include/gsfm.h); cam_q (w,x,y,z), intr_params [K][MAXP] (8; 16 in the unit of orc_ba_wide.cc).
 // Known rigs: image_frame [I], image_cam_from_rig [I][7] (qw,qx,qy,qz,tx,ty,tz), image_intr [I] (all NULL = trivial
 // rigs): obs_cam then indexes images and cam_intr is ignored.
-int orc_ba_solve(int32_t num_cams, int32_t num_intr, int32_t fixed_cam, i64 num_pts, const i64* pt_offset,
+int ORC_BA_ENTRY(int32_t num_cams, int32_t num_intr, int32_t fixed_cam, i64 num_pts, const i64* pt_offset,
                  const int32_t* obs_cam, const double* obs_xy, const int32_t* cam_intr, const int32_t* intr_model,
                  const orc::BaOptionsC* o, double* cam_q_inout, double* cam_t_inout, double* pt_xyz_inout,
                  double* intr_params_inout, orc::BaReport* rep, int32_t num_threads, const int32_t* image_frame,
@@ -953,7 +1057,7 @@ int orc_ba_solve(int32_t num_cams, int32_t num_intr, int32_t fixed_cam, i64 num_
     g.cam_intr.assign(cam_intr, cam_intr + g.N);
   g.model.assign(intr_model, intr_model + g.K);
   for (i64 b = 0; b < g.K; ++b)
-    if (g.model[b] < 0 || g.model[b] > 9 || kNumParams[g.model[b]] < 0) return -7;
+    if (g.model[b] < 0 || g.model[b] >= kNumModels || kNumParams[g.model[b]] < 0) return -7;
   g.bycam.build(g.N, g.M, g.cam.data());
   g.byintr.build(g.K, g.M, g.ik.data());
   if (g.S > 0) g.bysens.build(g.S, (i64)g.sobs.size(), g.sown.data());

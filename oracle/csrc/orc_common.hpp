@@ -134,10 +134,10 @@ struct OwnerLists {
   }
 };
 
-// In-place inverse of a symmetric positive definite n x n matrix (row-major, n <= 16) by Cholesky.
+// In-place inverse of a symmetric positive definite n x n matrix (row-major, n <= 24: the 6 + 16 joint block of orc_ba_wide.cc) by Cholesky.
 // Returns false when a pivot is not positive.
 inline bool spd_inverse(double* A, int n) {
-  double L[16 * 16];
+  double L[24 * 24];
   for (int j = 0; j < n; ++j) {
     double d = A[j * n + j];
     for (int k = 0; k < j; ++k) d -= L[j * n + k] * L[j * n + k];
@@ -151,7 +151,7 @@ inline bool spd_inverse(double* A, int n) {
     }
   }
   // invert L (lower), then A^-1 = L^-T L^-1
-  double Li[16 * 16];
+  double Li[24 * 24];
   for (int i = 0; i < n * n; ++i) Li[i] = 0.0;
   for (int j = 0; j < n; ++j) {
     Li[j * n + j] = 1.0 / L[j * n + j];

@@ -120,6 +120,52 @@ def test_ba_cpp_camera_models(model):
             assert np.abs(r[4][:, :4] - r2[4][:, :4]).max() < 1e-5 * 1200.0  # focal lengths, principal point
 
 
+@pytest.mark.parametrize("shared", [True, False])
+@pytest.mark.parametrize("model,par", [
+    (6, [1200, 1190, 640, 480, 0.02, -0.01, 0.001, -0.002, 0.003, 0.01, -0.004, 0.002]),                      # FULL_OPENCV
+    (10, [1200, 1190, 640, 480, 0.02, -0.01, 0.001, -0.002, 0.004, -0.002, 0.0015, -0.001]),                   # THIN_PRISM_FISHEYE
+    (11, [1200, 1190, 640, 480, 0.02, -0.01, 0.004, -0.002, 0.001, -0.0005, 0.001, -0.002, 0.0015, -0.0008, -0.001, 0.0005]),
+])
+def test_ba_cpp_wide_camera_models(model, par, shared):
+    """The 16-wide unit of the C++ oracle (orc_ba_wide.cc: orc_ba.cc compiled with ORC_BA_MAXP 16) against the numpy oracle on
+    the camera models with more than eight parameters: same LM decisions, solutions to solver precision."""
+    from glomap_amd import so3
+
+    p = synthetic.make_ba_problem(15, 300, seed=5, pixel_noise=0.0, outlier_ratio=0.0, shared_intrinsics=shared)
+    p.intr_model[:] = model
+    p.intr_params = np.zeros((p.num_intr, 16))
+    p.intr_params[:, : len(par)] = par
+    obs_pt = np.repeat(np.arange(p.num_pts), np.diff(p.pt_offset))
+    xc = np.einsum("mij,mj->mi", so3.quat_to_rotmat(p.gt_q)[p.obs_cam], p.gt_xyz[obs_pt]) + p.gt_t[p.obs_cam]
+    ik = p.cam_intr[p.obs_cam]
+    uv, _, _, valid = oba.project(p.intr_model[ik], p.intr_params[ik], xc)
+    assert valid.all()
+    p.obs_xy = uv + np.random.default_rng(0).normal(0, 0.3, uv.shape)
+    r = oba.solve(*_ba_args(p))
+    r2 = cpu.ba_solve(*_ba_args(p))
+    assert r[0] and r2[0] and r2[4].shape == (p.num_intr, 16)
+    assert (r2[5].iterations, r2[5].successful_steps) == (r[5].iterations, r[5].successful_steps)
+    assert abs(r2[5].initial_cost - r[5].initial_cost) <= 1e-12 * r[5].initial_cost
+    assert abs(r2[5].final_cost - r[5].final_cost) <= 1e-8 * r[5].final_cost
+    assert np.abs(r[1] - r2[1]).max() < 1e-7 and np.abs(r[2] - r2[2]).max() < 1e-5
+    assert np.array_equal(r2[4][:, len(par):], np.zeros((p.num_intr, 16 - len(par))))  # the unused tail of the rows
+
+
+def test_ba_cpp_wide_unit_equals_the_narrow_unit_on_padded_rows():
+    """orc_ba_solve on [K, 8] rows and orc_ba_solve_wide on the same rows zero-padded to 16: the same arithmetic, bit for bit
+    (every width of orc_ba.cc scales with ORC_BA_MAXP)."""
+    for shared in (True, False):
+        p = synthetic.make_ba_problem(30, 800, seed=3, pixel_noise=0.5, outlier_ratio=0.01, shared_intrinsics=shared, intr_noise=0.01)
+        a = cpu.ba_solve(*_ba_args(p), threads=4)
+        w = p.copy()
+        w.intr_params = np.zeros((p.num_intr, 16))
+        w.intr_params[:, :8] = p.intr_params
+        b = cpu.ba_solve(*_ba_args(w), threads=4)
+        assert a[0] and b[0] and a[5].iterations == b[5].iterations and a[5].final_cost == b[5].final_cost
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+        assert np.array_equal(a[4], b[4][:, :8]) and not b[4][:, 8:].any()
+
+
 def test_ba_cpp_order_switch_changes_only_rounding():
     p = synthetic.make_ba_problem(25, 600, seed=2)
     a = cpu.ba_solve(*_ba_args(p))
