@@ -1,4 +1,5 @@
-// ba.hip — global bundle adjustment on MI355X (gfx950).
+// ba_impl.hpp — global bundle adjustment on MI355X (gfx950): the solver behind gsfm_ba_solve, compiled as ba.hip (8-wide
+// intrinsics blocks) and ba_wide.hip (16-wide) — see the note on GSFM_BA_KP below the layout tables.
 //
 // Replaces BundleAdjuster::Solve (glomap/estimators/bundle_adjustment.cc:11-106); trivial rigs below, calibrated rigs
 // (RigReprojErrorConstantRigCostFunctor) and optimised cam_from_rig blocks (RigReprojErrorCostFunctor, optimize_rig_poses)
