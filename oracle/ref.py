@@ -329,7 +329,7 @@ def ba_build(cam_model, cam_params, frame_q, frame_t, image_frame, image_cam, pt
     """BundleAdjuster::Solve of the reference with a Ceres that records instead of minimising (bundle_adjustment.cc:9-113).
     Every observation becomes its own feature of its image.  Returns a dict: per residual block kind / frame / track / camera /
     sensor; frame_flags, camera_flags, sensor_flags, track_flags (bit 0 in the problem, 1 rotation-or-block constant,
-    2 translation constant, 3 quaternion manifold, 4 ordering group 0, 5 in no group), camera_subset [K,8], frame_order,
+    2 translation constant, 3 quaternion manifold, 4 ordering group 0, 5 in no group), camera_subset [K,16], frame_order,
     linear_solver_type, preconditioner_type, initial_cost."""
     lib = load_ba()
     pre, keep, (F, I, K, S, P, M) = _ba_prefix(cam_model, cam_params, frame_q, frame_t, image_frame, image_cam, pt_offset, obs_image, obs_xy, pt_xyz,
@@ -342,7 +342,7 @@ def _ba_prefix(cam_model, cam_params, frame_q, frame_t, image_frame, image_cam, 
     """The flat arguments shared by ref_ba_build and ref_ba_adapter_solve (oracle/ref_glue_ba_scene.h)."""
     i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)  # noqa: E731
     f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
-    cm, cp = i32(cam_model), np.zeros((len(cam_model), 8))
+    cm, cp = i32(cam_model), np.zeros((len(cam_model), 16))  # rows of 16 doubles (ref_glue_ba_scene.h: kCamRow)
     cp[:, : np.shape(cam_params)[1]] = cam_params
     fq, ft = f64(frame_q), f64(frame_t)
     F, I, K, S = len(fq), len(image_frame), len(cm), len(sensor_rig)
@@ -376,7 +376,7 @@ def _ba_build_call(lib, pre, F, K, S, P, M):
     cap = M + 8
     out = dict(kind=np.zeros(cap, np.int32), frame=np.zeros(cap, np.int32), track=np.zeros(cap, np.int64), camera=np.zeros(cap, np.int32),
                sensor=np.zeros(cap, np.int32), frame_flags=np.zeros(F, np.uint8), camera_flags=np.zeros(K, np.uint8),
-               camera_subset=np.zeros((K, 8), np.uint8), sensor_flags=np.zeros(max(S, 1), np.uint8), track_flags=np.zeros(max(P, 1), np.uint8),
+               camera_subset=np.zeros((K, 16), np.uint8), sensor_flags=np.zeros(max(S, 1), np.uint8), track_flags=np.zeros(max(P, 1), np.uint8),
                frame_order=np.zeros(F, np.int32))
     info, cost = np.zeros(4, np.int64), C.c_double(0.0)
     vp = C.c_void_p
@@ -479,7 +479,7 @@ def ba_adapter_solve(cam_model, cam_params, frame_q, frame_t, image_frame, image
     lib = load_dropin()
     pre, keep, (F, I, K, S, P, M) = _ba_prefix(cam_model, cam_params, frame_q, frame_t, image_frame, image_cam, pt_offset, obs_image, obs_xy, pt_xyz,
                                                rig_ref_cam, frame_rig, sensor_rig, sensor_cam, sensor_pose, frame_has_pose, image_present, options)
-    rep, fq, ft, cp, xyz = np.zeros(4), np.zeros((F, 4)), np.zeros((F, 3)), np.zeros((K, 8)), np.zeros((max(P, 1), 3))
+    rep, fq, ft, cp, xyz = np.zeros(4), np.zeros((F, 4)), np.zeros((F, 3)), np.zeros((K, 16)), np.zeros((max(P, 1), 3))
     vp = C.c_void_p
     lib.ref_ba_adapter_solve.restype = C.c_int
     ok = lib.ref_ba_adapter_solve(*pre, vp(_p(rep)), vp(_p(fq)), vp(_p(ft)), vp(_p(cp)), vp(_p(xyz)))

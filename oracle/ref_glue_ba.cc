@@ -23,7 +23,7 @@ extern "C" {
 // Outputs (caller-allocated): per residual block r < R: res_kind (0 trivial frame, 1 constant rig, 2 optimised rig), res_frame,
 // res_track, res_camera, res_sensor (-1 unless kind 2); frame_flags [F] / camera_flags [K] / sensor_flags [S] / track_flags [P]:
 // bit 0 in the problem, bit 1 rotation (or the whole block) constant, bit 2 translation constant, bit 3 quaternion manifold,
-// bit 4 ordering group is 0 (points) rather than 1; camera_subset [K][8]: 1 where the subset manifold holds a coordinate;
+// bit 4 ordering group is 0 (points) rather than 1; camera_subset [K][16]: 1 where the subset manifold holds a coordinate (cam_params is [K][16] as well);
 // frame_order [F]: the walk of the frames map; info [4] = {linear solver type, preconditioner type, 0, 0}.
 // Returns R, -1 (capacity) or -2 (Solve returned false).
 long ref_ba_build(int num_cameras, const int32_t* cam_model, const double* cam_params, int num_rigs, const int32_t* rig_ref_cam,
@@ -77,10 +77,10 @@ long ref_ba_build(int num_cameras, const int32_t* cam_model, const double* cam_p
     Camera& c = cameras.at(static_cast<camera_t>(k));
     camera_flags[k] = flags(c.params.data(), nullptr);
     camera_of[c.params.data()] = k;
-    for (int j = 0; j < 8; ++j) camera_subset[8 * k + j] = 0;
+    for (int j = 0; j < ref_glue::kCamRow; ++j) camera_subset[ref_glue::kCamRow * k + j] = 0;
     const auto m = problem.manifolds().find(c.params.data());
     if (m != problem.manifolds().end() && m->second.kind == 1)
-      for (int j : m->second.constant_idxs) camera_subset[8 * k + j] = 1;
+      for (int j : m->second.constant_idxs) camera_subset[ref_glue::kCamRow * k + j] = 1;
   }
   for (int s = 0; s < num_sensors; ++s) {
     Rigid3d& t = rigs.at(static_cast<rig_t>(sensor_rig[s])).SensorFromRig(sensor_t(SensorType::CAMERA, static_cast<uint32_t>(sensor_cam[s])));

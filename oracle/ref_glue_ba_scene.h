@@ -17,6 +17,8 @@ struct ref_ba_options {
 namespace ref_glue {
 using namespace glomap;
 
+constexpr int kCamRow = 16;  // doubles per camera row of the flat interface (FULL_OPENCV: 12 parameters)
+
 struct BaScene {
   std::unordered_map<rig_t, Rig> rigs;
   std::unordered_map<camera_t, Camera> cameras;
@@ -32,7 +34,7 @@ struct BaScene {
     for (int k = 0; k < num_cameras; ++k) {
       Camera& c = cameras[static_cast<camera_t>(k)];
       c.model_id = static_cast<colmap::CameraModelId>(cam_model[k]);
-      c.params.assign(cam_params + 8 * k, cam_params + 8 * k + colmap::NumParams(c.model_id));
+      c.params.assign(cam_params + kCamRow * k, cam_params + kCamRow * k + colmap::NumParams(c.model_id));  // rows of 16 doubles
     }
     for (int r = 0; r < num_rigs; ++r) rigs[static_cast<rig_t>(r)].ref = sensor_t(SensorType::CAMERA, static_cast<uint32_t>(rig_ref_cam[r]));
     for (int s = 0; s < num_sensors; ++s) {

@@ -48,7 +48,7 @@ int ref_gp_adapter_solve(int num_cams, const double* cam_q, const double* cam_t_
   return ok ? 1 : 0;
 }
 
-// out_report as above; out_frame_q [F][4] (w, x, y, z), out_frame_t [F][3], out_cam_params [K][8], out_xyz [P][3].
+// out_report as above; out_frame_q [F][4] (w, x, y, z), out_frame_t [F][3], out_cam_params [K][16], out_xyz [P][3].
 int ref_ba_adapter_solve(int num_cameras, const int32_t* cam_model, const double* cam_params, int num_rigs, const int32_t* rig_ref_cam,
                          int num_sensors, const int32_t* sensor_rig, const int32_t* sensor_cam, const double* sensor_pose, int num_frames,
                          const int32_t* frame_rig, const uint8_t* frame_has_pose, const double* frame_q, const double* frame_trn, int num_images,
@@ -80,7 +80,7 @@ int ref_ba_adapter_solve(int num_cameras, const int32_t* cam_model, const double
   }
   for (int k = 0; k < num_cameras; ++k) {
     const Camera& c = sc.cameras.at(static_cast<camera_t>(k));
-    for (size_t j = 0; j < c.params.size(); ++j) out_cam_params[8 * k + j] = c.params[j];
+    for (size_t j = 0; j < c.params.size(); ++j) out_cam_params[ref_glue::kCamRow * k + j] = c.params[j];
   }
   for (long p = 0; p < num_tracks; ++p)
     for (int j = 0; j < 3; ++j) out_xyz[3 * p + j] = sc.tracks.at(static_cast<track_t>(p)).xyz(j);

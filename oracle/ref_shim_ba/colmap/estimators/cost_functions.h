@@ -5,7 +5,8 @@
 //   RigReprojErrorConstantRigCostFunctor  (q, t, X, params), cam_from_rig:   x_c = cam_from_rig * (R(q) X + t)
 //   RigReprojErrorCostFunctor             (q_s, t_s, q, t, X, params):       x_c = R(q_s) (R(q) X + t) + t_s
 //   r = CameraModel::ImgFromCam(params, x_c) - point2D, zero when the point is not in front of the camera.
-// Quaternion blocks are Eigen coefficient order (x, y, z, w).  Camera models: the five perspective ones up to OPENCV.
+// Quaternion blocks are Eigen coefficient order (x, y, z, w).  Camera models: the five perspective ones up to OPENCV, and FULL_OPENCV
+// (12 parameters: the block size and the SubsetManifold of a model with more than eight parameters come from the reference's code).
 #pragma once
 #include <cmath>
 #include <limits>
@@ -27,6 +28,7 @@ inline int NumParams(CameraModelId id) {
     case CameraModelId::kSimpleRadial: return 4;
     case CameraModelId::kRadial: return 5;
     case CameraModelId::kOpenCV: return 8;
+    case CameraModelId::kFullOpenCV: return 12;
     default: return -1;
   }
 }
@@ -61,6 +63,12 @@ class RefShimReprojCost final : public ceres::CostFunction {
         const double rad = k[4] * r2 + k[5] * r2 * r2, uv = u * v;
         const double du = u * rad + 2.0 * k[6] * uv + k[7] * (r2 + 2.0 * u * u), dv = v * rad + 2.0 * k[7] * uv + k[6] * (r2 + 2.0 * v * v);
         r[0] = k[0] * (u + du) + k[2]; r[1] = k[1] * (v + dv) + k[3]; break;
+      }
+      case CameraModelId::kFullOpenCV: {  // fx, fy, cx, cy, k1, k2, p1, p2, k3, k4, k5, k6
+        const double r4 = r2 * r2, r6 = r4 * r2, uv = u * v;
+        const double rad = (1.0 + k[4] * r2 + k[5] * r4 + k[8] * r6) / (1.0 + k[9] * r2 + k[10] * r4 + k[11] * r6);
+        const double ud = u * rad + 2.0 * k[6] * uv + k[7] * (r2 + 2.0 * u * u), vd = v * rad + 2.0 * k[7] * uv + k[6] * (r2 + 2.0 * v * v);
+        r[0] = k[0] * ud + k[2]; r[1] = k[1] * vd + k[3]; break;
       }
       default: return false;
     }

@@ -90,6 +90,36 @@ def test_trivial_frames_problem_equals_the_reference(kw):
     assert abs(prob.cost(b["x0"]) - r["initial_cost"]) <= 1e-12 * r["initial_cost"]
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(optimize_intrinsics=False), dict(optimize_principal_point=True)],
+                         ids=lambda kw: ",".join(f"{k}={int(v)}" for k, v in kw.items()) or "default")
+def test_a_camera_model_with_more_than_eight_parameters(kw):
+    """FULL_OPENCV (12 parameters) through BundleAdjuster::Solve as the reference wrote it: the parameter block it adds for such a
+    camera (all 12 entries of Camera::params), the SubsetManifold it puts on the principal point (indices 2, 3 of 12,
+    bundle_adjustment.cc:273-287) and the initial cost — against oracle/ba.py on [K, 16] intrinsics rows, the layout the 16-wide
+    units of libgsfm and of the C++ oracle take.  Half of the cameras stay SIMPLE_RADIAL: both widths in one problem."""
+    p = synthetic.make_ba_problem(num_cams=12, num_pts=160, seed=3, pixel_noise=0.7, outlier_ratio=0.03, intr_noise=0.01)
+    model = p.intr_model.copy()
+    params = np.zeros((p.num_intr, 16))
+    params[:, :8] = p.intr_params
+    h = p.num_intr // 2
+    model[h:] = oba.FULL_OPENCV
+    params[h:, :12] = [1200, 1190, 640, 480, 0.02, -0.01, 0.001, -0.002, 0.003, 0.01, -0.004, 0.002]
+    r = ref.ba_build(model, params, p.cam_q, p.cam_t, np.arange(p.num_cams), p.cam_intr, p.pt_offset, p.obs_cam, p.obs_xy, p.pt_xyz,
+                     rig_ref_cam=np.arange(p.num_intr), frame_rig=p.cam_intr, **kw)
+    assert r["num_residual_blocks"] > 0
+    fixed = _first_in_problem(r)
+    opt = oba.BundleAdjusterOptions(**kw)
+    b = oba.build_problem(p.num_cams, p.pt_offset, p.obs_cam, p.obs_xy, p.cam_intr, model, fixed, p.cam_q, p.cam_t, p.pt_xyz, params, opt)
+    prob, used = b["problem"], b["used"]
+    assert prob.fmask.shape == (p.num_intr, 16)
+    _check_blocks(r, prob, used, opt, p.num_cams)
+    if not kw:  # the default: 10 of the 12 FULL_OPENCV parameters are optimised, the principal point is held by the subset manifold
+        assert np.array_equal(prob.fmask[h:].sum(1), np.full(p.num_intr - h, 10)) and np.array_equal(r["camera_subset"][h:, :12].sum(1),
+                                                                                                   np.full(p.num_intr - h, 2))
+        assert r["camera_subset"][h:, 2:4].all()
+    assert abs(prob.cost(b["x0"]) - r["initial_cost"]) <= 1e-12 * r["initial_cost"]
+
+
 def test_observations_of_absent_images_and_frames_without_pose():
     """ba.cc:125: an observation whose image is not in the map is skipped (the track stays); a frame that then has no residual
     is not part of the problem and the FIRST frame that is becomes the constant one (ba.cc:252-270)."""
