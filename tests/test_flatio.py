@@ -28,6 +28,21 @@ def test_python_round_trip(tmp_path):
             assert o2.optimize_rotations is False and p2.num_obs == p.num_obs
 
 
+def test_python_round_trip_of_16_wide_intrinsics_rows(tmp_path):
+    """A BA problem with a camera model of more than 8 parameters: the [K, 16] rows survive the flat file (their width is what
+    estimators.ba_solve hands over as gsfm_ba_problem::intr_stride)."""
+    ba = synthetic.make_ba_problem(num_cams=6, num_pts=50, seed=4)
+    ba.intr_model[:] = 11  # RAD_TAN_THIN_PRISM_FISHEYE
+    wide = np.zeros((ba.num_intr, 16))
+    wide[:, :4] = [1200, 1190, 640, 480]
+    wide[:, 4:] = np.linspace(0.01, -0.01, 12)
+    ba.intr_params = wide
+    path = tmp_path / "ba16.gsfm"
+    flatio.save(path, flatio.from_problem(ba, estimators.BundleAdjusterOptions()))
+    q, _ = flatio.to_problem(flatio.load(path))
+    assert q.intr_params.shape == (ba.num_intr, 16) and np.array_equal(q.intr_params, wide) and np.array_equal(q.intr_model, ba.intr_model)
+
+
 def test_python_round_trip_of_rig_and_gravity_tables(tmp_path):
     """The optional tables of the three problems — RA image / cam blocks and gravity flags, GP image offsets and centre
     blocks, BA image cam_from_rig and sensor blocks — survive the file format."""
