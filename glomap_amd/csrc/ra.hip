@@ -683,6 +683,7 @@ void mst_init(int N, long E, const int* ei, const int* ej, const double* eq, con
     return v;
   };
   std::vector<std::vector<std::pair<int, long>>> adj(N);
+  int tree_edges = 0;
   for (long e : order) {
     const int a = ei[e], b = ej[e];
     const int ra = find(a), rb = find(b);
@@ -690,6 +691,9 @@ void mst_init(int N, long E, const int* ei, const int* ej, const double* eq, con
       parent[ra] = rb;
       adj[a].emplace_back(b, e);
       adj[b].emplace_back(a, e);
+      // spanning: every later edge joins two nodes of the one component and would be rejected (a 10 k / 500 k view graph is
+      // spanned after ~ 10 % of its edges; disconnected graphs never get here and are scanned to the end as before)
+      if (++tree_edges == N - 1) break;
     }
   }
   struct Q {
