@@ -49,6 +49,8 @@ class Report(C.Structure):
         ("seconds_total", C.c_double),
         ("seconds_solve", C.c_double),
         ("last_step_norm", C.c_double),
+        ("line_search_trials", C.c_int32),
+        ("line_search_shrunk", C.c_int32),
     ]
 
     def as_dict(self):
@@ -114,6 +116,7 @@ class LmOptions(C.Structure):
         ("max_num_consecutive_invalid_steps", C.c_int32),
         ("pcg_relative_tolerance", C.c_double),
         ("pcg_max_iterations", C.c_int32),
+        ("max_num_line_search_step_size_iterations", C.c_int32),
     ]
 
 
@@ -306,6 +309,8 @@ def load():
     lib.gsfm_ctx_set_knob.argtypes = [vp, ip, ip]
     lib.gsfm_ctx_stats.restype = ip
     lib.gsfm_ctx_stats.argtypes = [vp, C.POINTER(C.c_int64), ip, ip]
+    lib.gsfm_ctx_lm_trace.restype = ip
+    lib.gsfm_ctx_lm_trace.argtypes = [vp, dp, C.c_int32]
     lib.gsfm_comm_unique_id.restype = ip
     lib.gsfm_comm_unique_id.argtypes = [C.c_char_p]
     lib.gsfm_comm_init.restype = ip
@@ -550,6 +555,19 @@ class Context:
         if rc != 0:
             raise GsfmError(rc, "gsfm_ctx_stats")
         return dict(zip(self.STAT_NAMES, (int(v) for v in buf)))
+
+    LM_TRACE_COLS = ("cost", "radius", "model_change", "candidate_cost", "step_size", "accepted", "linear_iterations")
+
+    def lm_trace(self):
+        """[iterations, 7] array: the LM iterations of the last gp / ba solve on this context (gsfm_ctx_lm_trace; columns
+        LM_TRACE_COLS)."""
+        import numpy as np
+
+        rows = self.lib.gsfm_ctx_lm_trace(self.handle, None, 0)
+        out = np.zeros((max(rows, 0), len(self.LM_TRACE_COLS)))
+        if rows > 0:
+            self.lib.gsfm_ctx_lm_trace(self.handle, out.ctypes.data_as(C.POINTER(C.c_double)), rows)
+        return out
 
     def comm_destroy(self):
         """Detach whatever transport is attached (collective in effect: every rank must be done with its solves)."""

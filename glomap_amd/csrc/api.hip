@@ -137,6 +137,14 @@ extern "C" int gsfm_ctx_profile_enable(gsfm_ctx* ctx, int enable) {
   return GSFM_OK;
 }
 
+extern "C" int gsfm_ctx_lm_trace(gsfm_ctx* ctx, double* out, int32_t max_rows) {
+  if (!ctx) return 0;
+  const int rows = (int)(ctx->lm_trace.size() / GSFM_LM_TRACE_COLS);
+  if (out && max_rows > 0)
+    std::memcpy(out, ctx->lm_trace.data(), sizeof(double) * GSFM_LM_TRACE_COLS * (size_t)std::min<int>(rows, max_rows));
+  return rows;
+}
+
 extern "C" int gsfm_ctx_stats(gsfm_ctx* ctx, int64_t* out, int n, int reset) {
   if (!ctx || (n > 0 && !out)) return GSFM_ERR_INVALID_ARGUMENT;
   for (int i = 0; i < n && i < GSFM_STAT_COUNT; ++i) out[i] = ctx->stats[i];

@@ -2653,7 +2653,7 @@ int ba_solve_impl(gsfm_ctx* ctx, const gsfm_ba_problem* prob, const gsfm_ba_opti
   if (solver.used_observations() == 0 && ctx->comm.world == 1)
     throw StatusError(GSFM_ERR_EMPTY_PROBLEM, "BA: no track with enough views");
   const double t1 = now_seconds();
-  const int rc = lm_minimize(solver, opt->lm, rep);
+  const int rc = lm_minimize(solver, opt->lm, rep, &ctx->lm_trace);
   solver.write_back(prob, cam_q, cam_t, pt_xyz, intr);
   const double t2 = now_seconds();
   if (rep) {

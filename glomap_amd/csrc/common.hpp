@@ -179,6 +179,7 @@ struct gsfm_ctx {
   int num_cus = 256;
   std::string last_error;
   int64_t stats[GSFM_STAT_COUNT] = {};  // which solver paths ran (gsfm_ctx_stats)
+  std::vector<double> lm_trace;         // one row of GSFM_LM_TRACE_COLS per LM iteration of the last GP / BA solve (gsfm_ctx_lm_trace)
   int knob[GSFM_KNOB_COUNT] = {};       // diagnostic / A-B knobs (gsfm_ctx_set_knob); 0 = default
   std::string dump_dir;  // non-empty: every solve writes its flat problem + result there (dump.hpp)
   int dump_seq = 0;

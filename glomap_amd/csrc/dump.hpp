@@ -139,6 +139,7 @@ inline void dump_lm_options(FlatDump& d, const gsfm_lm_options* lm) {
   GSFM_DUMP_OPT(d, lm, max_num_consecutive_invalid_steps);
   GSFM_DUMP_OPT(d, lm, pcg_relative_tolerance);
   GSFM_DUMP_OPT(d, lm, pcg_max_iterations);
+  GSFM_DUMP_OPT(d, lm, max_num_line_search_step_size_iterations);
 }
 
 }  // namespace gsfm

@@ -79,6 +79,10 @@ __device__ __forceinline__ double block_max(double v, double* smem /* >= 4 */) {
   return fmax(fmax(smem[0], smem[1]), fmax(smem[2], smem[3]));  // valid in every thread
 }
 
+// The scales carry a lower bound (gp.cc:204,373), so Ceres tests the PROJECTED gradient x - Plus(x, -g) of such a program
+// (trust_region_minimizer.cc EvaluateGradientAndJacobian): the part of -g the bound lets through.
+__device__ __forceinline__ double proj_grad_scale(double g, double s) { return s - g < 1e-5 ? s - 1e-5 : g; }
+
 // ---- linearize, point side: cost, robust weights, |g_s|, |g_X| max-norms, H_pp trace ----------
 // One lane per observation (track-major tiles), per-track sums by segmented wave scan.
 // part[block][2] = {cost, max gradient entry}.
@@ -112,7 +116,7 @@ __global__ void __launch_bounds__(kBlock)
       acc[1] -= ws * r.x;
       acc[2] -= ws * r.y;
       acc[3] -= ws * r.z;
-      if (g.opt_s && k != g.fixed_obs) gmax = fmax(gmax, fabs(w * dot(d, r)));
+      if (g.opt_s && k != g.fixed_obs) gmax = fmax(gmax, fabs(proj_grad_scale(-(w * dot(d, r)), sk)));
     }
     seg_scan<4>(acc, key, lane);
     if (seg_is_tail(key, lane) && key >= 0 && g.g.used[key]) {
@@ -277,7 +281,7 @@ __global__ void __launch_bounds__(kBlock)
         acc[13] -= ws * r.x;
         acc[14] -= ws * r.y;
         acc[15] -= ws * r.z;
-        if (g.opt_s && k != g.fixed_obs) gmax = fmax(gmax, fabs(w * dot(d, r)));
+        if (g.opt_s && k != g.fixed_obs) gmax = fmax(gmax, fabs(proj_grad_scale(-(w * dot(d, r)), sk)));
       } else {
         w = wrob[k];
       }
@@ -1054,15 +1058,21 @@ __global__ void __launch_bounds__(kBlock)
 // ---- back-substitution, model cost change, candidate point ------------------------------------
 // One lane per observation: dX_p = H_pp^-1 sum_k Q_k dc - e_p (segmented scan, broadcast back to the
 // track's lanes), then per observation the scale step, the model decrease and the candidate scale.
-// part[block][3] = {model_cost_change, |dX|^2 + |ds|^2, |X|^2 + |s|^2}
+// The candidate is Plus(x, t delta): t = 1 is the LM step; t < 1 a trial of the projected line search Ceres runs because
+// the scales are bounded (linesearch.hpp) — the same sweep, the direction recomputed and scaled, so that no per-observation
+// copy of delta has to be kept.
+// part[block][3] = {model_cost_change (of the FULL step), |t dX|^2 + |s' - s|^2, |X|^2 + |s|^2};  cost_part[block] = cost at
+// the candidate;  ls_part[block][2] = {phi'(0) = g . delta,  phi'(t) = g(candidate) . delta};  dmax_part[block] = max |dX|, |ds|
 __global__ void __launch_bounds__(kBlock)
-    k_gp_backsub(GpDev g, const double* __restrict__ c, const double* __restrict__ X,
+    k_gp_backsub(GpDev g, double t, const double* __restrict__ c, const double* __restrict__ X,
                  const double* __restrict__ s, const double* __restrict__ wrob,
                  const double* __restrict__ qa, const double* __restrict__ qb,
                  const double* __restrict__ ptb, const double* __restrict__ dc, double* __restrict__ Xn,
-                 double* __restrict__ sn, double* __restrict__ part, double* __restrict__ cost_part) {
-  __shared__ double smem[4 * 4];
-  double acc3[4] = {0, 0, 0, 0};  // model change | step norm | x norm | cost at the candidate (what k_gp_cost summed until round 4)
+                 double* __restrict__ sn, double* __restrict__ part, double* __restrict__ cost_part,
+                 double* __restrict__ ls_part, double* __restrict__ dmax_part) {
+  __shared__ double smem[4 * 6 + 4];
+  double acc3[6] = {0, 0, 0, 0, 0, 0};  // model change | step norm | x norm | cost at the candidate | phi'(0) | phi'(t)
+  double dmax = 0.0;
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (kBlock / 64);
@@ -1103,10 +1113,11 @@ __global__ void __launch_bounds__(kBlock)
           const double* b = ptb + kPtb * p;
           dX = mul(S3{b[6], b[7], b[8], b[9], b[10], b[11]}, V3{acc[0], acc[1], acc[2]}) - ld3(b + 3);
         }
-        acc3[1] += dot(dX, dX);
+        dmax = fmax(dmax, fmax(fabs(dX.x), fmax(fabs(dX.y), fabs(dX.z))));
+        acc3[1] += dot(t * dX, t * dX);
         acc3[2] += dot(Xp, Xp);
       }
-      st3(Xn + 3 * p, Xp + dX);
+      st3(Xn + 3 * p, Xp + t * dX);
     }
     const unsigned long long tmask = __ballot(tail);
     const unsigned long long above = tmask >> lane;
@@ -1143,42 +1154,55 @@ __global__ void __launch_bounds__(kBlock)
       const double ds = beta * (dot(d, r) + sk * dot(d, dcx));
       const V3 m = sk * dcx - ds * d;  // J delta (un-robustified)
       acc3[0] -= w * (dot(m, r) + 0.5 * dot(m, m));
-      const double s_new = fmax(1e-5, sk + ds);  // SetParameterLowerBound(&scale, 0, 1e-5), gp.cc:373
+      acc3[4] += w * dot(m, r);  // this block's share of g . delta
+      dmax = fmax(dmax, fabs(ds));
+      const double s_new = fmax(1e-5, sk + t * ds);  // SetParameterLowerBound(&scale, 0, 1e-5), gp.cc:373
       sn[k] = s_new;
       acc3[1] += (s_new - sk) * (s_new - sk);
       acc3[2] += sk * sk;
-      // the cost at the candidate point, while everything it needs is in registers: X' - c' = d - (dc - dX)
-      const V3 rc = ld3(g.dir + 3 * k) - s_new * (d - dcx);
+      // the cost at the candidate point, while everything it needs is in registers: X' - c' = d - t (dc - dX)
+      const V3 dt = d - t * dcx;
+      const V3 rc = ld3(g.dir + 3 * k) - s_new * dt;
       double rho, wl;
       huber(g.huber_a, (g.cal == nullptr || g.cal[k]) ? g.wpt : 0.5 * g.wpt, dot(rc, rc), rho, wl);
       acc3[3] += 0.5 * rho;
+      // ... and the slope there: rho' r . (J delta) with J of the candidate point (LineSearchFunction::Evaluate)
+      acc3[5] += wl * dot(s_new * dcx - ds * dt, rc);
     }
   }
-  block_sum<4>(acc3, smem);
+  block_sum<6>(acc3, smem);
+  const double dm = block_max(dmax, smem + 24);
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) part[blockIdx.x * 3 + k] = acc3[k];
     cost_part[blockIdx.x] = acc3[3];
+    ls_part[blockIdx.x * 2] = acc3[4];
+    ls_part[blockIdx.x * 2 + 1] = acc3[5];
+    dmax_part[blockIdx.x] = dm;
   }
 }
 
-// cn = c + dc; part[block][3] = {|dc|^2, |c|^2, #non-finite}
+// cn = c + t dc; part[block][3] = {|t dc|^2, |c|^2, #non-finite}; dmax_part[block] = max |dc|
 __global__ void __launch_bounds__(kBlock)
-    k_gp_cam_update(int n3, const double* __restrict__ c, const double* __restrict__ dc,
-                    double* __restrict__ cn, double* __restrict__ part) {
-  __shared__ double smem[4 * 3];
+    k_gp_cam_update(int n3, double t, const double* __restrict__ c, const double* __restrict__ dc,
+                    double* __restrict__ cn, double* __restrict__ part, double* __restrict__ dmax_part) {
+  __shared__ double smem[4 * 3 + 4];
   double acc[3] = {0, 0, 0};
+  double dmax = 0.0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += gridDim.x * blockDim.x) {
-    const double d = dc[i];
+    const double d = t * dc[i];
     cn[i] = c[i] + d;
     acc[0] += d * d;
     acc[1] += c[i] * c[i];
     acc[2] += isfinite(d) ? 0.0 : 1.0;
+    dmax = fmax(dmax, fabs(dc[i]));
   }
   block_sum<3>(acc, smem);
+  const double dm = block_max(dmax, smem + 12);
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) part[blockIdx.x * 3 + k] = acc[k];
+    dmax_part[blockIdx.x] = dm;
   }
 }
 
@@ -1252,7 +1276,7 @@ __global__ void __launch_bounds__(kBlock)
     huber(q.huber_a, 1.0, dot(g.r, g.r), rho, w);
     we[e] = w;
     cost += 0.5 * rho;
-    if (q.opt_s && e != q.fixed) gmax = fmax(gmax, fabs(w * dot(g.d, g.r)));
+    if (q.opt_s && e != q.fixed) gmax = fmax(gmax, fabs(proj_grad_scale(-(w * dot(g.d, g.r)), se[e])));
   }
   double v[1] = {cost};
   block_sum<1>(v, smem);
@@ -1416,13 +1440,15 @@ __global__ void __launch_bounds__(kBlock)
   __syncthreads();
   if (threadIdx.x == 0) v.dpart[dslot0 + blockIdx.x] = (sdelta[0] + sdelta[1]) + (sdelta[2] + sdelta[3]);
 }
-// back-substitution of the pair scales, model cost change, candidate scales; part[block][3] as k_gp_backsub
+// back-substitution of the pair scales, model cost change, candidate scales at Plus(x, t delta); part[block][3] as
+// k_gp_backsub, ls_part[block][3] = {phi'(0), phi'(t), max |ds|} of the pairs
 __global__ void __launch_bounds__(kBlock)
-    k_gpp_backsub(GpPairs q, const double* __restrict__ c, const double* __restrict__ se, const double* __restrict__ we,
+    k_gpp_backsub(GpPairs q, double t, const double* __restrict__ c, const double* __restrict__ se, const double* __restrict__ we,
                   const double* __restrict__ qb, const double* __restrict__ dc, double* __restrict__ sn,
-                  double* __restrict__ part) {
-  __shared__ double smem[4 * 3];
-  double acc3[3] = {0, 0, 0};
+                  double* __restrict__ part, double* __restrict__ ls_part) {
+  __shared__ double smem[4 * 5 + 4];
+  double acc3[5] = {0, 0, 0, 0, 0};
+  double dmax = 0.0;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < q.E; e += (long)gridDim.x * blockDim.x) {
     const double sk = se[e], w = we[e];
     const PairGeom g = pair_geom(q, e, c, sk);
@@ -1430,15 +1456,46 @@ __global__ void __launch_bounds__(kBlock)
     const double ds = qb[e] * (dot(g.d, g.r) + sk * dot(g.d, dcx));
     const V3 m = sk * dcx - ds * g.d;
     acc3[0] -= w * (dot(m, g.r) + 0.5 * dot(m, m));
-    const double s_new = fmax(1e-5, sk + ds);
+    acc3[3] += w * dot(m, g.r);
+    dmax = fmax(dmax, fabs(ds));
+    const double s_new = fmax(1e-5, sk + t * ds);
     sn[e] = s_new;
     acc3[1] += (s_new - sk) * (s_new - sk);
     acc3[2] += sk * sk;
+    // slope at the candidate: c_j' - c_i' = d - t dcx
+    const V3 dt = g.d - t * dcx;
+    const V3 rc = ld3(q.pv + 3 * e) - s_new * dt;
+    double rho, wl;
+    huber(q.huber_a, 1.0, dot(rc, rc), rho, wl);
+    acc3[4] += wl * dot(s_new * dcx - ds * dt, rc);
   }
-  block_sum<3>(acc3, smem);
+  block_sum<5>(acc3, smem);
+  const double dm = block_max(dmax, smem + 20);
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) part[blockIdx.x * 3 + k] = acc3[k];
+    ls_part[blockIdx.x * 3] = acc3[3];
+    ls_part[blockIdx.x * 3 + 1] = acc3[4];
+    ls_part[blockIdx.x * 3 + 2] = dm;
+  }
+}
+// scal[i0] += sum_b part[b][0], scal[i1] += sum_b part[b][1], scal[i2] = max(scal[i2], max_b part[b][2])   (one workgroup)
+__global__ void __launch_bounds__(kBlock)
+    k_gpp_fold_ls(const double* __restrict__ part, int nblocks, double* __restrict__ scal, int i0, int i1, int i2) {
+  __shared__ double smem[4 * 2 + 4];
+  double v[2] = {0, 0};
+  double m = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+    v[0] += part[3 * b];
+    v[1] += part[3 * b + 1];
+    m = fmax(m, part[3 * b + 2]);
+  }
+  block_sum<2>(v, smem);
+  m = block_max(m, smem + 8);
+  if (threadIdx.x == 0) {
+    scal[i0] += v[0];
+    scal[i1] += v[1];
+    scal[i2] = fmax(scal[i2], m);
   }
 }
 // candidate cost of the pairs; part[block][1]
@@ -1799,8 +1856,10 @@ class GpSolver final : public LmProblem {
         }
       }
       const int W = ctx_->comm.world;
+      m_used_total_ = with_points_ ? m_used_ : 0;  // scales of the whole problem (constrained(): is there a free, bounded one?)
       if (W > 1) {
-        std::vector<double> h((size_t)N_ + W + 1, 0.0);
+        std::vector<double> h((size_t)N_ + W + 2, 0.0);
+        h[(size_t)N_ + W + 1] = (double)m_used_total_;
         for (int n = 0; n < N_; ++n) h[n] = constrained[n] ? 1.0 : 0.0;
         h[(size_t)N_ + ctx_->comm.rank] = (double)used_here;
         h[(size_t)N_ + W] = (double)P_;  // tracks of the whole problem (POINTS_AND_CAMERAS_BALANCED weighs by it)
@@ -1814,6 +1873,7 @@ class GpSolver final : public LmProblem {
         for (int r = 0; r < ctx_->comm.rank; ++r) used_before += (long)h[(size_t)N_ + r];
         for (int r = ctx_->comm.rank + 1; r < W; ++r) used_after += (long)h[(size_t)N_ + r];
         P_total_ = (long)h[(size_t)N_ + W];
+        m_used_total_ = (long)h[(size_t)N_ + W + 1];
       }
     }
     // the draws visit cameras / tracks in index order, or in the caller's container order (gsfm_gp_problem::*_draw_order)
@@ -1945,7 +2005,7 @@ class GpSolver final : public LmProblem {
     ws->cg_w.ensure(3 * (size_t)Np_ + 2);
     ws->vpart.ensure(2 * kCgMaxBlocks * 2);
     ws->dpart.ensure(2 * kMaxApplySlots);
-    ws->part.ensure(kMaxBlocks * 8);
+    ws->part.ensure(kMaxBlocks * 12);
     ws->scal.ensure(64);
     ws->cgst.ensure(1);
     ws->cgsc.ensure(2);
@@ -2019,7 +2079,7 @@ class GpSolver final : public LmProblem {
       for (DevBuf<double>* b : {&ws->pr_sn, &ws->pr_w, &ws->pr_js, &ws->pr_qa, &ws->pr_qb}) b->ensure(E_);
       gridPair_ = std::min(256, grid_for((size_t)E_, kBlock));
       gridPairCam_ = std::min(kMaxApplySlots / 4, grid_for((size_t)N_, kBlock / 64));
-      ws->pr_part.ensure(3 * (size_t)gridPair_ + 8);
+      ws->pr_part.ensure(6 * (size_t)gridPair_ + 16);
       q_.E = E_;
       q_.pi = ws->pr_i.get();
       q_.pj = ws->pr_j.get();
@@ -2229,47 +2289,19 @@ class GpSolver final : public LmProblem {
     } else {
       GSFM_HIP_CHECK(hipMemsetAsync(ws->cg_x.get(), 0, (size_t)n3 * sizeof(double), s));
     }
-    const double* dc_k = ws->cg_x.get();
-    if (rig_) {  // the step of an image's centre is the step of its frame
+    if (rig_)  // the step of an image's centre is the step of its frame
       hipLaunchKernelGGL(k_rig_expand3, dim3(gridNI_), dim3(kBlock), 0, s, rg_, ws->cg_x.get(), (const double*)nullptr,
                          ws->ximg.get(), (double*)nullptr, 0);
-      dc_k = ws->ximg.get();
-    }
-    double* part3 = ws->part.get() + kMaxBlocks * 4;  // cost at the candidate point (summed by the back-substitution sweep)
-    hipLaunchKernelGGL(k_gp_backsub, dim3(gridTileP_), dim3(kBlock), 0, s, g_, ci_, X_, s_, ws->wrob.get(),
-                       ws->qa.get(), ws->qb.get(), ws->ptb.get(), dc_k, Xn_, sn_, ws->part.get(), part3);
-    hipLaunchKernelGGL((k_sum_partials<3>), dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridTileP_, ws->scal.get());
-    hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(kBlock), 0, s, part3, gridTileP_, ws->scal.get() + 6);
-    if (E_ > 0) {
-      hipLaunchKernelGGL(k_gpp_backsub, dim3(gridPair_), dim3(kBlock), 0, s, q_, c_, (const double*)ps_, (const double*)ws->pr_w.get(),
-                         (const double*)ws->pr_qb.get(), (const double*)ws->cg_x.get(), psn_, ws->pr_part.get());
-      if (pair_owner_) hipLaunchKernelGGL((k_gpp_fold_sum<3>), dim3(1), dim3(kBlock), 0, s, (const double*)ws->pr_part.get(), gridPair_, ws->scal.get(), 0, 1, 2);
-    }
-    const int gridU = std::min(64, grid_for(n3, kBlock));
-    double* part2 = ws->part.get() + kMaxBlocks * 3;
-    hipLaunchKernelGGL(k_gp_cam_update, dim3(gridU), dim3(kBlock), 0, s, n3, c_, ws->cg_x.get(), cn_, part2);
-    hipLaunchKernelGGL((k_sum_partials<3>), dim3(1), dim3(kBlock), 0, s, part2, gridU, ws->scal.get() + 3);
-    if (rig_) expand_centres(cn_, cin_, /*also_cz=*/false);
-    if (E_ > 0) {
-      hipLaunchKernelGGL(k_gpp_cost, dim3(gridPair_), dim3(kBlock), 0, s, q_, (const double*)cn_, (const double*)psn_, ws->pr_part.get());
-      if (pair_owner_) hipLaunchKernelGGL((k_gpp_fold_sum<1>), dim3(1), dim3(kBlock), 0, s, (const double*)ws->pr_part.get(), gridPair_, ws->scal.get(), 6, 6, 6);
-    }
-    if (multi) {
-      // track-local sums: model change, |dX|^2+|ds|^2, |X|^2+|s|^2 and the candidate cost
-      allreduce_sum(ctx_, ws->scal.get(), 3);
-      allreduce_sum(ctx_, ws->scal.get() + 6, 1);
-    }
-    double h[10];
-    GSFM_HIP_CHECK(hipMemcpyAsync(ctx_->h_pinned + 256, ws->scal.get(), 10 * sizeof(double), hipMemcpyDeviceToHost, s));
-    GSFM_HIP_CHECK(hipStreamSynchronize(s));
-    GSFM_HIP_CHECK(hipGetLastError());
-    comm_check(ctx_);
-    std::memcpy(h, ctx_->h_pinned + 256, sizeof(h));
+    double h[14];
+    make_candidate(1.0, h);
     *model_change = h[0];
     *step_norm = std::sqrt(h[1] + h[3]);
     *x_norm = std::sqrt(h[2] + h[4]);
     *cand_cost = h[6];
     last_cand_cost_ = h[6];
+    slope0_ = h[10];
+    slope1_ = h[11];
+    dmax_ = std::max(h[12], h[13]);
     if (lin) {
       lin_pending_ = false;
       gmax_ready_ = true;
@@ -2278,6 +2310,78 @@ class GpSolver final : public LmProblem {
     const bool finite = h[5] == 0.0 && std::isfinite(h[0]) && std::isfinite(h[1]) && std::isfinite(h[6]);
     return finite;
   }
+
+  // The candidate Plus(x, t delta) of the step the last solve produced — scales projected on their lower bound — with
+  // everything the LM loop and the projected line search read of it: h[0] model change (of the full step), h[1] + h[3]
+  // |candidate - x|^2, h[2] + h[4] |x|^2, h[5] non-finite entries, h[6] cost, h[10] phi'(0), h[11] phi'(t), h[12], h[13] |delta|_inf.
+  void make_candidate(double t, double* h) {
+    GpWs* ws = ws_;
+    hipStream_t s = ctx_->stream;
+    const bool multi = ctx_->comm.world > 1;
+    const int n3 = 3 * Np_;
+    const double* dc_k = rig_ ? ws->ximg.get() : ws->cg_x.get();
+    double* part3 = ws->part.get() + kMaxBlocks * 4;  // cost at the candidate point (summed by the back-substitution sweep)
+    double* part_ls = ws->part.get() + kMaxBlocks * 8;  // [grid][2] slopes, then [grid] max |direction|
+    double* part_dm = ws->part.get() + kMaxBlocks * 10;
+    hipLaunchKernelGGL(k_gp_backsub, dim3(gridTileP_), dim3(kBlock), 0, s, g_, t, ci_, X_, s_, ws->wrob.get(),
+                       ws->qa.get(), ws->qb.get(), ws->ptb.get(), dc_k, Xn_, sn_, ws->part.get(), part3, part_ls, part_dm);
+    hipLaunchKernelGGL((k_sum_partials<3>), dim3(1), dim3(kBlock), 0, s, ws->part.get(), gridTileP_, ws->scal.get());
+    hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(kBlock), 0, s, part3, gridTileP_, ws->scal.get() + 6);
+    hipLaunchKernelGGL((k_sum_partials<2>), dim3(1), dim3(kBlock), 0, s, part_ls, gridTileP_, ws->scal.get() + 10);
+    hipLaunchKernelGGL(k_gp_fold_max, dim3(1), dim3(64), 0, s, (const double*)part_dm, gridTileP_, ws->scal.get() + 12);
+    if (E_ > 0) {
+      double* pr_ls = ws->pr_part.get() + 3 * (size_t)gridPair_ + 8;
+      hipLaunchKernelGGL(k_gpp_backsub, dim3(gridPair_), dim3(kBlock), 0, s, q_, t, c_, (const double*)ps_, (const double*)ws->pr_w.get(),
+                         (const double*)ws->pr_qb.get(), (const double*)ws->cg_x.get(), psn_, ws->pr_part.get(), pr_ls);
+      if (pair_owner_) {
+        hipLaunchKernelGGL((k_gpp_fold_sum<3>), dim3(1), dim3(kBlock), 0, s, (const double*)ws->pr_part.get(), gridPair_, ws->scal.get(), 0, 1, 2);
+        hipLaunchKernelGGL(k_gpp_fold_ls, dim3(1), dim3(kBlock), 0, s, (const double*)pr_ls, gridPair_, ws->scal.get(), 10, 11, 12);
+      }
+    }
+    const int gridU = std::min(64, grid_for(n3, kBlock));
+    double* part2 = ws->part.get() + kMaxBlocks * 3;
+    hipLaunchKernelGGL(k_gp_cam_update, dim3(gridU), dim3(kBlock), 0, s, n3, t, c_, ws->cg_x.get(), cn_, part2, part_dm + kMaxBlocks);
+    hipLaunchKernelGGL((k_sum_partials<3>), dim3(1), dim3(kBlock), 0, s, part2, gridU, ws->scal.get() + 3);
+    hipLaunchKernelGGL(k_gp_fold_max, dim3(1), dim3(64), 0, s, (const double*)(part_dm + kMaxBlocks), gridU, ws->scal.get() + 13);
+    if (rig_) expand_centres(cn_, cin_, /*also_cz=*/false);
+    if (E_ > 0) {
+      hipLaunchKernelGGL(k_gpp_cost, dim3(gridPair_), dim3(kBlock), 0, s, q_, (const double*)cn_, (const double*)psn_, ws->pr_part.get());
+      if (pair_owner_) hipLaunchKernelGGL((k_gpp_fold_sum<1>), dim3(1), dim3(kBlock), 0, s, (const double*)ws->pr_part.get(), gridPair_, ws->scal.get(), 6, 6, 6);
+    }
+    if (multi) {
+      // track-local sums: model change, |dX|^2+|ds|^2, |X|^2+|s|^2, the candidate cost, the two slopes; max |dX|, |ds|
+      allreduce_sum(ctx_, ws->scal.get(), 3);
+      allreduce_sum(ctx_, ws->scal.get() + 6, 1);
+      allreduce_sum(ctx_, ws->scal.get() + 10, 2);
+      allreduce_max(ctx_, ws->scal.get() + 12, 1);
+    }
+    GSFM_HIP_CHECK(hipMemcpyAsync(ctx_->h_pinned + 256, ws->scal.get(), 14 * sizeof(double), hipMemcpyDeviceToHost, s));
+    GSFM_HIP_CHECK(hipStreamSynchronize(s));
+    GSFM_HIP_CHECK(hipGetLastError());
+    comm_check(ctx_);
+    std::memcpy(h, ctx_->h_pinned + 256, 14 * sizeof(double));
+  }
+
+  // ---- the projected line search of bounds-constrained programs (lm.hpp, linesearch.hpp) ----
+  // Program::IsBoundsConstrained: a NON-constant parameter block with a bound.  Every scale carries the lower bound of
+  // gp.cc:204,373; they are constant when optimize_scales is off (gp.cc:476-482), and one of them always is (gp.cc:484-489).
+  bool constrained() const override { return opt_.optimize_scales != 0 && m_used_total_ + E_ > 1; }
+  void step_line_data(double* slope0, double* slope1, double* direction_max_norm) override {
+    *slope0 = slope0_;
+    *slope1 = slope1_;
+    *direction_max_norm = dmax_;
+  }
+  bool trial(double t, double* cost, double* slope, double* step_norm) override {
+    double h[14];
+    make_candidate(t, h);
+    *cost = h[6];
+    *slope = h[11];
+    *step_norm = std::sqrt(h[1] + h[3]);
+    last_cand_cost_ = h[6];
+    ++ls_trials_;
+    return h[5] == 0.0 && std::isfinite(h[1]) && std::isfinite(h[6]);
+  }
+  long line_search_trials() const { return ls_trials_; }
   bool gradient_pending() const override { return lin_pending_; }
   bool finish_pending_gradient(double* grad_max_norm) override {
     if (!lin_pending_) return false;
@@ -2539,6 +2643,8 @@ class GpSolver final : public LmProblem {
   bool lin_pending_ = false, aw_built_ = false, gmax_ready_ = false;  // riders of k_gp_build_cam (step())
   int lin_count_ = 0;
   double gmax_full_ = 0.0, last_cand_cost_ = 0.0;
+  double slope0_ = 0.0, slope1_ = 0.0, dmax_ = 0.0;  // of the last step(): phi'(0), phi'(1), |delta|_inf
+  long ls_trials_ = 0, m_used_total_ = 0;
   ObsX x_;            // chunked order of the camera-side PCG sweep (xon_)
   bool xon_ = false;
   int gridX_ = 0, gridWsum_ = 0, sweepSlots_ = 0;
@@ -2575,7 +2681,7 @@ int gp_solve_impl(gsfm_ctx* ctx, const gsfm_gp_problem* prob, const gsfm_gp_opti
   if (solver.used_observations() == 0 && ctx->comm.world == 1 && opt->constraint_type != 1)
     throw StatusError(GSFM_ERR_EMPTY_PROBLEM, "GP: no track with enough views");
   const double t1 = now_seconds();
-  const int rc = lm_minimize(solver, opt->lm, rep);
+  const int rc = lm_minimize(solver, opt->lm, rep, &ctx->lm_trace);
   solver.write_back(prob, cam_center, pt_xyz);
   const double t2 = now_seconds();
   if (rep) {
@@ -2594,13 +2700,14 @@ extern "C" void gsfm_gp_options_default(gsfm_gp_options* o) {
   if (!o) return;
   std::memset(o, 0, sizeof(*o));
   lm_options_default(&o->lm, 100);  // optimization_base.h:20
-  // The reference solves the reduced systems exactly (SPARSE_SCHUR); this LM problem amplifies a perturbation of its steps
-  // ~1e6-fold (the iteration ends stalled on the outlier rays' scale bounds, and where it stalls depends on every accept /
-  // reject decision before).  With 1e-8 — rounds 1-4 — the worst camera of configs[2] / [3] ended 1e-2 of the scene extent
-  // away from the exact-solve trajectory; 1e-11 still flips a decision on one of six full-size problems; 1e-12 follows the
-  // exact trajectory to 1e-5 ... 1e-6 wherever the oracle's own rounding-level variants agree with each other
-  // (profiles/r05_gp_pcg_tolerance_gpu.txt).  Price: +40 % PCG iterations.
-  o->lm.pcg_relative_tolerance = 1e-12;
+  // The reference solves the reduced systems exactly (SPARSE_SCHUR).  Round 6, with Ceres' projected line search in the loop
+  // (lm.hpp) and measured against the exact-solve oracle (profiles/r06_gp_line_search_gpu_vs_oracle.txt):
+  //   * on inputs whose trajectory is STABLE (the oracle summed forwards and backwards ends in the same place to 1e-9) the end
+  //     point follows the solver tolerance: 1e-12 -> 7e-7 of the extent, 1e-10 -> 3e-5, 1e-8 -> 3.7e-4, 1e-6 -> 2.4e-3 (bar 1e-3);
+  //   * on the full-size problems the trajectory is chaotic for the reference algorithm itself (the oracle against itself:
+  //     p99 2e-3, median 2e-5, one camera 3e-2) and every tolerance from 1e-6 to 1e-14 ends inside that scatter.
+  // 1e-10 keeps a factor 30 to the bar where the bar means something, for 8 % fewer PCG iterations than round 5's 1e-12.
+  o->lm.pcg_relative_tolerance = 1e-10;
   o->thres_loss_function = 1e-1;    // global_positioning.h:47-49
   o->generate_random_positions = 1;
   o->generate_random_points = 1;

@@ -103,8 +103,12 @@ class SolverOptions:
 
     max_num_iterations: int = 100
     function_tolerance: float = 1e-5
-    pcg_relative_tolerance: float = 1e-8
+    # None = what gsfm_{gp,ba}_options_default choose for the estimator (they differ: include/gsfm.h), so that a
+    # SolverOptions built for another field does not silently replace them
+    pcg_relative_tolerance: Optional[float] = None
     pcg_max_iterations: int = 1000
+    # Ceres' projected line search on bounds-constrained problems (global positioning); None = the library default (20), 0 = off
+    max_num_line_search_step_size_iterations: Optional[int] = None
 
 
 @dataclass
@@ -124,7 +128,7 @@ class GlobalPositionerOptions:
     thres_loss_function: float = 1e-1
     # first of the three draws of a random start vector -> x (0: clang-built reference) or -> z (1: g++-built); include/gsfm.h
     rand_vector_order: int = 0
-    solver_options: SolverOptions = field(default_factory=lambda: SolverOptions(max_num_iterations=100, pcg_relative_tolerance=1e-12))
+    solver_options: SolverOptions = field(default_factory=lambda: SolverOptions(max_num_iterations=100))
 
     def to_c(self) -> _lib.GpOptions:
         o = _lib.GpOptions()
@@ -153,7 +157,7 @@ class BundleAdjusterOptions:
     min_num_view_per_track: int = 3
     thres_loss_function: float = 1.0
     # reduced solves to 1e-6 (gsfm_ba_options_default): 3.3e-7 rad / 3e-6 from the exact-solve trajectory at configs[3]
-    solver_options: SolverOptions = field(default_factory=lambda: SolverOptions(max_num_iterations=200, pcg_relative_tolerance=1e-6))
+    solver_options: SolverOptions = field(default_factory=lambda: SolverOptions(max_num_iterations=200))
 
     def to_c(self) -> _lib.BaOptions:
         o = _lib.BaOptions()
@@ -171,8 +175,11 @@ class BundleAdjusterOptions:
 def _fill_lm(lm: _lib.LmOptions, so: SolverOptions):
     lm.max_num_iterations = so.max_num_iterations
     lm.function_tolerance = so.function_tolerance
-    lm.pcg_relative_tolerance = so.pcg_relative_tolerance
+    if so.pcg_relative_tolerance is not None:
+        lm.pcg_relative_tolerance = so.pcg_relative_tolerance
     lm.pcg_max_iterations = so.pcg_max_iterations
+    if so.max_num_line_search_step_size_iterations is not None:
+        lm.max_num_line_search_step_size_iterations = int(so.max_num_line_search_step_size_iterations)
 
 
 # ============================================================================================

@@ -74,7 +74,8 @@ def _fill(obj, values: dict):
 
 
 def _lm(so: estimators.SolverOptions, o: dict):
-    return _fill(so, {k: o[k] for k in ("max_num_iterations", "function_tolerance", "pcg_relative_tolerance", "pcg_max_iterations")
+    return _fill(so, {k: o[k] for k in ("max_num_iterations", "function_tolerance", "pcg_relative_tolerance", "pcg_max_iterations",
+                                        "max_num_line_search_step_size_iterations")
                       if k in o})
 
 
@@ -166,5 +167,5 @@ def _opts(options) -> dict:
         if isinstance(v, (bool, int, float)):
             out[k] = float(v)
         elif isinstance(v, estimators.SolverOptions):
-            out.update({kk: float(vv) for kk, vv in vars(v).items()})
+            out.update({kk: float(vv) for kk, vv in vars(v).items() if vv is not None})
     return out

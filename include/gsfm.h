@@ -70,6 +70,8 @@ typedef struct gsfm_report {
   double seconds_total;      /* wall time inside the call */
   double seconds_solve;      /* device time of the solve proper (H2D/D2H excluded) */
   double last_step_norm;     /* RA: mean |delta| of the last iteration (gra.cc:758-772) */
+  int32_t line_search_trials; /* GP: evaluations of the projected line search beyond the LM step itself (Ceres: Summary::num_line_search_steps) */
+  int32_t line_search_shrunk; /* GP: LM iterations whose step the line search shortened */
 } gsfm_report;
 
 typedef struct gsfm_ctx gsfm_ctx;
@@ -136,6 +138,15 @@ enum gsfm_stat {
 };
 /* Copies min(n, GSFM_STAT_COUNT) counters to out; reset != 0 zeroes them afterwards. */
 int gsfm_ctx_stats(gsfm_ctx* ctx, int64_t* out, int n, int reset);
+/* The Levenberg-Marquardt iterations of the last gsfm_gp_solve / gsfm_ba_solve on this ctx, what Ceres prints with
+ * minimizer_progress_to_stdout (optimization_base.h:21): one row of GSFM_LM_TRACE_COLS doubles per iteration —
+ *   cost before the step | trust-region radius | model cost change | cost at the candidate | line-search step size
+ *   (1 when no search ran or it kept the step, < 1 when it shortened it, -1 when it failed) | 1 accepted, 0 rejected, -1 invalid
+ *   step | linear (PCG) iterations of the step.
+ * Copies min(rows, max_rows) rows to out (may be NULL) and returns the number of rows recorded.  Tests compare trajectories
+ * with it, iteration by iteration. */
+#define GSFM_LM_TRACE_COLS 7
+int gsfm_ctx_lm_trace(gsfm_ctx* ctx, double* out, int32_t max_rows);
 /* Diagnostic / A-B knobs of a context, for tests and measurements (0 = what the library ships).  The library itself reads no
  * environment variable for any of them: a caller that wants to compare two variants says so through this call. */
 enum gsfm_knob {
@@ -320,8 +331,13 @@ typedef struct gsfm_lm_options {
   int32_t jacobi_scaling;            /* 1 */
   int32_t max_num_consecutive_invalid_steps; /* 5 */
   /* linear solver replacing SPARSE_SCHUR + sparse Cholesky: implicit-Schur block-Jacobi PCG */
-  double pcg_relative_tolerance;     /* |r|_2 <= tol * |b|_2 on the reduced camera system: 1e-12 (gsfm_gp_options_default), 1e-6 (gsfm_ba_options_default) */
+  double pcg_relative_tolerance;     /* |r|_2 <= tol * |b|_2 on the reduced camera system: 1e-10 (gsfm_gp_options_default), 1e-6 (gsfm_ba_options_default) */
   int32_t pcg_max_iterations;        /* 1000 */
+  int32_t max_num_line_search_step_size_iterations; /* 20 (Ceres' Solver::Options default).  Used on bounds-constrained problems only —
+                                        global positioning, whose scales carry a lower bound (gp.cc:204,373): Ceres then runs a projected
+                                        Armijo line search on every valid LM step (trust_region_minimizer.cc DoLineSearch).  0 switches it
+                                        off, as in Ceres.  Occupies what was tail padding until round 6: a zero-initialised struct that
+                                        never went through gsfm_*_options_default runs WITHOUT the search. */
 } gsfm_lm_options;
 
 typedef struct gsfm_gp_options {

@@ -53,6 +53,7 @@ class _LmFields(C.Structure):
         ("pcg_max_iterations", C.c_int32),
         ("order", C.c_int32),
         ("verbose", C.c_int32),
+        ("line_search", C.c_int32),
     ]
 
 
@@ -96,7 +97,7 @@ class _Report(C.Structure):
         ("seconds_total", C.c_double),
         ("seconds_linear", C.c_double),
         ("threads", C.c_int32),
-        ("pad", C.c_int32),
+        ("line_search_shrunk", C.c_int32),
     ]
 
 
@@ -145,6 +146,7 @@ class CpuSummary:
     seconds_total: float = 0.0
     seconds_linear: float = 0.0
     threads: int = 0
+    line_search_shrunk: int = 0  # LM iterations whose step Ceres' projected line search shortened (GP)
 
 
 def lib_path() -> Path:
@@ -193,6 +195,18 @@ def load(path=None):
         lib.orc_num_threads.restype = C.c_int
         _LIB = lib
     return _LIB
+
+
+def lm_trace() -> np.ndarray:
+    """[iterations, 7]: the LM iterations of the last gp_solve / ba_solve of this process — cost | radius | model change |
+    candidate cost | line-search step size | accepted | linear iterations (the columns of the product's gsfm_ctx_lm_trace)."""
+    lib = load()
+    lib.orc_lm_trace.restype = C.c_int32
+    rows = lib.orc_lm_trace(None, C.c_int32(0))
+    out = np.zeros((max(rows, 0), 7))
+    if rows > 0:
+        lib.orc_lm_trace(out.ctypes.data_as(C.POINTER(C.c_double)), C.c_int32(rows))
+    return out
 
 
 def effective_cores() -> int:
@@ -246,6 +260,7 @@ def _fill_lm(o, lmo: _lm.LmOptions, pcg_tol, pcg_max, order, verbose):
     o.pcg_max_iterations = pcg_max
     o.order = order
     o.verbose = int(verbose)
+    o.line_search = int(getattr(lmo, "line_search", True))
 
 
 class _deflate_env:
@@ -274,7 +289,7 @@ class _deflate_env:
 def _summary(rep) -> CpuSummary:
     return CpuSummary(rep.iterations, rep.successful_steps, rep.linear_iterations, rep.initial_cost, rep.final_cost,
                       rep.termination, bool(rep.usable), rep.max_linear_residual, rep.seconds_total, rep.seconds_linear,
-                      rep.threads)
+                      rep.threads, rep.line_search_shrunk)
 
 
 def gp_solve(num_cams, pt_offset, obs_cam, obs_dir, obs_calibrated, cam_center, pt_xyz,

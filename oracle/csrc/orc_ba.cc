@@ -52,7 +52,7 @@ struct BaOptionsC {
   double min_lm_diagonal, max_lm_diagonal;
   int32_t jacobi_scaling, max_num_consecutive_invalid_steps;
   double pcg_relative_tolerance;
-  int32_t pcg_max_iterations, order, verbose;
+  int32_t pcg_max_iterations, order, verbose, line_search;  // line_search: GP only (BA has no bounds)
   double thres_loss_function;
   int32_t optimize_rotations, optimize_translation, optimize_intrinsics, optimize_principal_point, optimize_points;
   int32_t min_num_view_per_track;

@@ -32,7 +32,7 @@ struct GpOptionsC {  // mirrors the python-side ctypes struct (oracle/cpu.py)
   double min_lm_diagonal, max_lm_diagonal;
   int32_t jacobi_scaling, max_num_consecutive_invalid_steps;
   double pcg_relative_tolerance;
-  int32_t pcg_max_iterations, order, verbose;
+  int32_t pcg_max_iterations, order, verbose, line_search;
   double thres_loss_function;
   int32_t generate_random_positions, generate_random_points, generate_scales;
   int32_t optimize_positions, optimize_points, optimize_scales;
@@ -44,7 +44,7 @@ struct GpReport {
   int32_t iterations, successful_steps, termination, usable;
   i64 linear_iterations;
   double initial_cost, final_cost, max_linear_residual, seconds_total, seconds_linear;
-  int32_t threads, pad;
+  int32_t threads, line_search_shrunk;
 };
 
 namespace {
@@ -98,6 +98,75 @@ struct Gp : LmProblem {
   std::vector<double> tp;       // [P][3]
   std::vector<double> Minv;     // [N][9] block-Jacobi
   std::vector<double> dcam;     // [N] LM damping of the camera blocks
+  // the step of the last step() (masks applied), for the projected line search of bounds-constrained programs
+  std::vector<double> d_c, d_X, d_s, d_ps, gs_all, pgs_all;
+  double slope0 = 0.0, dmax = 0.0;
+  bool constrained() const override { return ms != 0.0 && M + E > 1; }  // a non-constant scale with its lower bound
+  double step_slope() const override { return slope0; }
+  double step_max_norm() const override { return dmax; }
+  // x_t = Plus(x, t delta): scales projected on their lower bound (ParameterBlock::Plus)
+  void point_at(double t, std::vector<double>& ct, std::vector<double>& Xt, std::vector<double>& st, std::vector<double>& pst) const {
+    ct.resize(c.size());
+    Xt.resize(X.size());
+    st.resize(M);
+    pst.resize(E);
+    for (size_t i = 0; i < c.size(); ++i) ct[i] = c[i] + t * d_c[i];
+#pragma omp parallel for schedule(static)
+    for (i64 i = 0; i < 3 * P; ++i) Xt[i] = X[i] + t * d_X[i];
+#pragma omp parallel for schedule(static)
+    for (i64 k = 0; k < M; ++k) st[k] = std::max(s[k] + t * d_s[k], 1e-5);
+    for (i64 e = 0; e < E; ++e) pst[e] = std::max(ps[e] + t * d_ps[e], 1e-5);
+  }
+  // cost and g(x_t) . delta: per residual block rho' r . (J delta), J delta = s e - ds d with e = dc_cam - dX the
+  // direction's share of -(X - c) (LineSearchFunction::Evaluate: direction . gradient at the trial point)
+  void ls_eval(double t, double* cost_out, double* slope_out) override {
+    std::vector<double> ct, Xt, st, pst;
+    point_at(t, ct, Xt, st, pst);
+    std::vector<double> rho(M), sl(M);
+#pragma omp parallel for schedule(static)
+    for (i64 k = 0; k < M; ++k) {
+      const V3 d = dvec(k, ct, Xt);
+      const V3 r = ld3(v + 3 * k) - st[k] * d;
+      double r0, r1;
+      (cal[k] ? loss_cal : loss_unc).eval(dot(r, r), r0, r1);
+      rho[k] = r0;
+      const V3 e = zcam(k, d_c) - ld3(&d_X[3 * (i64)pt[k]]);
+      const V3 jd = st[k] * e - d_s[k] * d;
+      sl[k] = r1 * dot(jd, r);
+    }
+    double tot = chunked_sum(M, [&](i64 k) { return rho[k]; });
+    double slope = chunked_sum(M, [&](i64 k) { return sl[k]; });
+    for (i64 e = 0; e < E; ++e) {
+      const V3 d = pair_d(e, ct);
+      const V3 r = ld3(&pv[3 * e]) - pst[e] * d;
+      double r0, r1;
+      loss_pair.eval(dot(r, r), r0, r1);
+      tot += r0;
+      const V3 ee = ld3(&d_c[3 * (i64)pi[e]]) - ld3(&d_c[3 * (i64)pj[e]]);
+      const V3 jd = pst[e] * ee - d_ps[e] * d;
+      slope += r1 * dot(jd, r);
+    }
+    *cost_out = 0.5 * tot;
+    *slope_out = slope;
+  }
+  void set_step_size(double t, double* cand_cost, double* step_norm) override {
+    for (double& a : d_c) a *= t;
+    for (double& a : d_X) a *= t;
+    for (double& a : d_s) a *= t;
+    for (double& a : d_ps) a *= t;
+    make_candidate(cand_cost, step_norm);
+  }
+  // candidate = Plus(x, delta), its cost and |candidate - x| (ambient space, after the projection)
+  void make_candidate(double* cand_cost, double* step_norm) {
+    point_at(1.0, c2, X2, s2, ps2);
+    double sn = chunked_sum(3 * (N + S), [&](i64 i) { const double d = c2[i] - c[i]; return d * d; });
+    sn += chunked_sum(3 * P, [&](i64 i) { const double d = X2[i] - X[i]; return d * d; });
+    sn += chunked_sum(M, [&](i64 k) { const double d = s2[k] - s[k]; return d * d; });
+    double pair_sn = 0.0;
+    for (i64 e = 0; e < E; ++e) pair_sn += (ps2[e] - ps[e]) * (ps2[e] - ps[e]);
+    *step_norm = std::sqrt(sn + pair_sn);
+    *cand_cost = cost_at(c2, X2, s2, ps2);
+  }
 
   // d = X - c, or X - c_rig + t_rig for an image of a calibrated rig (RigBATAPairwiseDirectionError,
   // cost_function.h:49-82, with the rig scale constant at 1: global_positioning.cc:470-478)
@@ -160,6 +229,9 @@ struct Gp : LmProblem {
       rho[k] = r0;
       w[k] = r1;
       gs[k] = mscale(k) * (-r1 * dot(d, r));  // the first scale is constant
+      // bounds-constrained program: the gradient test sees x - Plus(x, -g) (trust_region_minimizer.cc), i.e. the part
+      // of -g the lower bound lets through
+      if (gs[k] > 0.0 && s[k] - gs[k] < 1e-5) gs[k] = s[k] - 1e-5;
     }
     const double cost = 0.5 * chunked_sum(M, [&](i64 k) { return rho[k]; });
     // point side: g_X = -sum w s r, h_X = sum w s^2  (track-major, serial inside a track)
@@ -229,7 +301,11 @@ struct Gp : LmProblem {
       loss_pair.eval(dot(r, r), r0, r1);
       pw[e] = r1;
       pair_cost += r0;
-      pair_gs = std::max(pair_gs, std::fabs(mpair(e) * r1 * dot(d, r)));
+      {
+        double g = mpair(e) * (-r1 * dot(d, r));
+        if (g > 0.0 && ps[e] - g < 1e-5) g = ps[e] - 1e-5;
+        pair_gs = std::max(pair_gs, std::fabs(g));
+      }
       const double ws = r1 * ps[e];
       // d r / d c_i = +s I, d r / d c_j = -s I
       hc[pi[e]] += mc * ws * ps[e];
@@ -531,7 +607,7 @@ struct Gp : LmProblem {
 #pragma omp parallel for schedule(static)
     for (i64 i = 0; i < 3 * P; ++i) dX[i] = tp[i] - u[i];
     std::vector<double> ds(M);
-    std::vector<double> mterm(M);
+    std::vector<double> mterm(M), gterm(M);
 #pragma omp parallel for schedule(static)
     for (i64 k = 0; k < M; ++k) {
       const V3 d = dvec(k, c, X);
@@ -539,13 +615,13 @@ struct Gp : LmProblem {
       const V3 e = mc * zcam(k, dc) - mx * ld3(&dX[3 * (i64)pt[k]]);
       const double m = mscale(k);
       ds[k] = qb[k] * dot(d, r + s[k] * e);  // qb = m w / h~ss
-      (void)m;
       // model: J delta = sqrt(w) (s e - m d ds), r~ = sqrt(w) r
       const V3 jd = s[k] * e - (m * ds[k]) * d;
       mterm[k] = w[k] * (dot(jd, r) + 0.5 * dot(jd, jd));
+      gterm[k] = w[k] * dot(jd, r);  // this block's share of g . delta
     }
-    double pair_model = 0.0, pair_sn = 0.0, pair_xn = 0.0;
-    ps2.resize(E);
+    double pair_model = 0.0, pair_xn = 0.0, pair_slope = 0.0;
+    d_ps.resize(E);
     for (i64 e = 0; e < E; ++e) {
       const V3 d = pair_d(e, c);
       const V3 r = ld3(&pv[3 * e]) - ps[e] * d;
@@ -553,29 +629,32 @@ struct Gp : LmProblem {
       const double dse = pqb[e] * dot(d, r + ps[e] * ee);
       const V3 jd = ps[e] * ee - (mpair(e) * dse) * d;
       pair_model += pw[e] * (dot(jd, r) + 0.5 * dot(jd, jd));
-      ps2[e] = std::max(ps[e] + mpair(e) * dse, 1e-5);
-      pair_sn += (ps2[e] - ps[e]) * (ps2[e] - ps[e]);
+      pair_slope += pw[e] * dot(jd, r);
+      d_ps[e] = mpair(e) * dse;
       pair_xn += ps[e] * ps[e];
     }
     *model_change = -(chunked_sum(M, [&](i64 k) { return mterm[k]; }) + pair_model);
+    slope0 = chunked_sum(M, [&](i64 k) { return gterm[k]; }) + pair_slope;
+    // the step in ambient coordinates (constant blocks: zero)
+    d_c.resize(3 * (N + S));
+    d_X.resize(3 * P);
+    d_s.resize(M);
+    for (i64 i = 0; i < 3 * (N + S); ++i) d_c[i] = mc * dc[i];
+#pragma omp parallel for schedule(static)
+    for (i64 i = 0; i < 3 * P; ++i) d_X[i] = mx * dX[i];
+#pragma omp parallel for schedule(static)
+    for (i64 k = 0; k < M; ++k) d_s[k] = mscale(k) * ds[k];
+    dmax = chunked_max(3 * (N + S), [&](i64 i) { return std::fabs(d_c[i]); });
+    dmax = std::max(dmax, chunked_max(3 * P, [&](i64 i) { return std::fabs(d_X[i]); }));
+    dmax = std::max(dmax, chunked_max(M, [&](i64 k) { return std::fabs(d_s[k]); }));
+    for (i64 e = 0; e < E; ++e) dmax = std::max(dmax, std::fabs(d_ps[e]));
     // candidate = Plus(x, delta), scales projected on their lower bound
-    c2.resize(3 * (N + S));
-    X2.resize(3 * P);
-    s2.resize(M);
-    for (i64 i = 0; i < 3 * (N + S); ++i) c2[i] = c[i] + mc * dc[i];
-#pragma omp parallel for schedule(static)
-    for (i64 i = 0; i < 3 * P; ++i) X2[i] = X[i] + mx * dX[i];
-#pragma omp parallel for schedule(static)
-    for (i64 k = 0; k < M; ++k) s2[k] = std::max(s[k] + mscale(k) * ds[k], 1e-5);
-    double sn = chunked_sum(3 * (N + S), [&](i64 i) { const double d = c2[i] - c[i]; return d * d; });
-    sn += chunked_sum(3 * P, [&](i64 i) { const double d = X2[i] - X[i]; return d * d; });
-    sn += chunked_sum(M, [&](i64 k) { const double d = s2[k] - s[k]; return d * d; });
+    make_candidate(cand_cost, step_norm);
     double xn = chunked_sum(3 * (N + S), [&](i64 i) { return c[i] * c[i]; });
     xn += chunked_sum(3 * P, [&](i64 i) { return X[i] * X[i]; });
     xn += chunked_sum(M, [&](i64 k) { return s[k] * s[k]; });
-    *step_norm = std::sqrt(sn + pair_sn);
     *x_norm = std::sqrt(xn + pair_xn);
-    *cand_cost = cost_at(c2, X2, s2, ps2);
+    const double sn = *step_norm;
     bool finite = std::isfinite(sn);
     return finite;
   }
@@ -752,6 +831,7 @@ int orc_gp_solve_pairs(int32_t num_cams, i64 num_pts, const i64* pt_offset, cons
   lo.jacobi_scaling = o->jacobi_scaling;
   lo.max_num_consecutive_invalid_steps = o->max_num_consecutive_invalid_steps;
   lo.verbose = o->verbose;
+  lo.line_search = o->line_search;
   LmSummary s;
   lm_minimize(g, lo, &s);
   std::memcpy(cam_center_inout, g.c.data(), sizeof(double) * 3 * g.N);
@@ -767,6 +847,7 @@ int orc_gp_solve_pairs(int32_t num_cams, i64 num_pts, const i64* pt_offset, cons
   rep->final_cost = s.final_cost;
   rep->max_linear_residual = s.max_linear_residual;
   rep->seconds_linear = s.seconds_linear;
+  rep->line_search_shrunk = s.line_search_shrunk;
   rep->seconds_total = omp_get_wtime() - t0;
   return s.usable ? 0 : -6;
 }
@@ -782,4 +863,21 @@ int orc_gp_solve(int32_t num_cams, i64 num_pts, const i64* pt_offset, const int3
 }
 
 int orc_num_threads(void) { return omp_get_max_threads(); }
+
+// the LM iterations of the last orc_gp_solve / orc_ba_solve of this process (orc_lm.hpp lm_trace_store): copies up to
+// max_rows rows of 7 doubles, returns the number recorded
+int32_t orc_lm_trace(double* out, int32_t max_rows) {
+  const std::vector<double>& t = orc::lm_trace_store();
+  const int32_t rows = (int32_t)(t.size() / 7);
+  if (out && max_rows > 0) std::memcpy(out, t.data(), sizeof(double) * 7 * (size_t)std::min(rows, max_rows));
+  return rows;
+}
+
+// test hook (tests/test_oracle_cpu.py): one interpolation step of the Armijo search — the minimiser over [x_lo, x_hi] of the
+// polynomial through n samples (x, value, slope) — so that orc_lm.hpp's fit / root finder can be held to oracle/lm.py's
+double orc_ls_interpolate(int32_t n, const double* x, const double* value, const double* slope, double x_lo, double x_hi) {
+  std::vector<orc::LsSample> smp;
+  for (int32_t i = 0; i < n; ++i) smp.push_back(orc::LsSample{x[i], value[i], slope[i], true});
+  return orc::poly_minimize(orc::poly_fit(smp), x_lo, x_hi);
+}
 }

@@ -30,6 +30,13 @@ struct LmOptions {
   double max_lm_diagonal = 1e32;
   int jacobi_scaling = 1;
   int max_num_consecutive_invalid_steps = 5;
+  // TrustRegionMinimizer::DoLineSearch on bounds-constrained programs (Solver::Options defaults; oracle/lm.py header)
+  int line_search = 1;  // 0: the loop of rounds 1 - 5 (experiments only)
+  int max_num_line_search_step_size_iterations = 20;
+  double line_search_sufficient_function_decrease = 1e-4;
+  double max_line_search_step_contraction = 1e-3;
+  double min_line_search_step_contraction = 0.6;
+  double min_line_search_step_size = 1e-9;
   // reduced-system solve (replaces the exact factorisation)
   double pcg_relative_tolerance = 1e-14;
   int pcg_max_iterations = 20000;
@@ -46,7 +53,17 @@ struct LmSummary {
   int usable = 1;
   double max_linear_residual = 0.0;  // largest TRUE relative residual |b - S x| / |b| over all linear solves
   double seconds_linear = 0.0;
+  int line_search_steps = 0;   // Armijo trials beyond the first
+  int line_search_shrunk = 0;  // LM iterations whose step the search shortened
 };
+
+// the LM iterations of the last lm_minimize of this process, one row of 7 doubles per iteration (same columns as the
+// product's gsfm_ctx_lm_trace: cost | radius | model change | candidate cost | step size | accepted | linear iterations);
+// read through orc_lm_trace (orc_gp.cc) — tests compare trajectories iteration by iteration
+inline std::vector<double>& lm_trace_store() {
+  static std::vector<double> t;
+  return t;
+}
 
 struct LmProblem {
   virtual ~LmProblem() = default;
@@ -55,13 +72,198 @@ struct LmProblem {
   virtual bool step(double radius, double* model_change, double* cand_cost, double* step_norm, double* x_norm,
                     i64* linear_iterations, double* true_rel_residual) = 0;
   virtual void accept() = 0;
+  // bounds-constrained programs (Program::IsBoundsConstrained): the projected line search of oracle/lm.py.
+  //   step_slope(): g . delta at the current point for the step the last step() produced; step_max_norm(): |delta|_inf;
+  //   ls_eval(t): cost and g(x_t) . delta at x_t = Plus(x, t delta) (projected on the bounds);
+  //   set_step_size(t): delta *= t — the candidate, its cost and |candidate - x| are recomputed.
+  virtual bool constrained() const { return false; }
+  virtual double step_slope() const { return 0.0; }
+  virtual double step_max_norm() const { return 0.0; }
+  virtual void ls_eval(double t, double* cost, double* slope) { (void)t; (void)cost; (void)slope; }
+  virtual void set_step_size(double t, double* cand_cost, double* step_norm) { (void)t; (void)cand_cost; (void)step_norm; }
 };
+
+// ---- Ceres' Armijo search (line_search.cc ArmijoLineSearch::DoSearch, CUBIC interpolation; polynomial.cc) -----------
+// Restated as oracle/lm.py states it (find_interpolating_polynomial / minimize_polynomial / armijo_search); the numpy
+// version solves the fit with LAPACK and finds the critical points with companion-matrix eigenvalues, this one with
+// full-pivot elimination and sign-change bisection between the critical points of the derivative — tests/test_oracle_cpu.py
+// holds the two to each other.
+struct LsSample {
+  double x = 0.0, value = 0.0, slope = 0.0;
+  bool valid = false;
+};
+
+inline double poly_eval(const std::vector<double>& p, double x) {  // coefficients highest power first
+  double v = 0.0;
+  for (double a : p) v = v * x + a;
+  return v;
+}
+
+inline std::vector<double> poly_fit(const std::vector<LsSample>& smp) {
+  const int n = 2 * (int)smp.size(), deg = n - 1;
+  std::vector<double> A((size_t)n * (n + 1), 0.0);
+  auto at = [&](int r, int c) -> double& { return A[(size_t)r * (n + 1) + c]; };
+  int row = 0;
+  for (const LsSample& s : smp) {
+    for (int j = 0; j <= deg; ++j) at(row, j) = std::pow(s.x, deg - j);
+    at(row, n) = s.value;
+    ++row;
+    for (int j = 0; j < deg; ++j) at(row, j) = (deg - j) * std::pow(s.x, deg - j - 1);
+    at(row, n) = s.slope;
+    ++row;
+  }
+  std::vector<int> colperm(n);
+  for (int i = 0; i < n; ++i) colperm[i] = i;
+  for (int k = 0; k < n; ++k) {  // full pivoting, as Eigen::FullPivLU
+    int pr = k, pc = k;
+    double best = -1.0;
+    for (int r = k; r < n; ++r)
+      for (int c = k; c < n; ++c)
+        if (std::fabs(at(r, c)) > best) best = std::fabs(at(r, c)), pr = r, pc = c;
+    if (best <= 0.0) break;
+    if (pr != k)
+      for (int c = 0; c <= n; ++c) std::swap(at(pr, c), at(k, c));
+    if (pc != k) {
+      for (int r = 0; r < n; ++r) std::swap(at(r, pc), at(r, k));
+      std::swap(colperm[pc], colperm[k]);
+    }
+    for (int r = k + 1; r < n; ++r) {
+      const double f = at(r, k) / at(k, k);
+      if (f == 0.0) continue;
+      for (int c = k; c <= n; ++c) at(r, c) -= f * at(k, c);
+    }
+  }
+  std::vector<double> y(n, 0.0), coef(n, 0.0);
+  for (int k = n - 1; k >= 0; --k) {
+    double v = at(k, n);
+    for (int c = k + 1; c < n; ++c) v -= at(k, c) * y[c];
+    y[k] = at(k, k) != 0.0 ? v / at(k, k) : 0.0;
+  }
+  for (int k = 0; k < n; ++k) coef[colperm[k]] = y[k];
+  return coef;
+}
+
+inline std::vector<double> poly_strip(std::vector<double> p) {  // RemoveLeadingZeros
+  size_t i = 0;
+  while (i + 1 < p.size() && p[i] == 0.0) ++i;
+  p.erase(p.begin(), p.begin() + i);
+  return p;
+}
+
+inline std::vector<double> poly_derivative(const std::vector<double>& p) {
+  const int deg = (int)p.size() - 1;
+  std::vector<double> d;
+  for (int j = 0; j < deg; ++j) d.push_back((deg - j) * p[j]);
+  if (d.empty()) d.push_back(0.0);
+  return d;
+}
+
+// real roots of p inside [lo, hi], ascending: sign changes between consecutive critical points, bisected to the last bit
+inline std::vector<double> poly_roots_in(const std::vector<double>& p_in, double lo, double hi) {
+  const std::vector<double> p = poly_strip(p_in);
+  std::vector<double> roots;
+  const int deg = (int)p.size() - 1;
+  if (deg <= 0) return roots;
+  if (deg == 1) {
+    const double r = -p[1] / p[0];
+    if (r >= lo && r <= hi) roots.push_back(r);
+    return roots;
+  }
+  std::vector<double> brk{lo};
+  for (double c : poly_roots_in(poly_derivative(p), lo, hi)) brk.push_back(c);
+  brk.push_back(hi);
+  for (size_t i = 0; i + 1 < brk.size(); ++i) {
+    double a = brk[i], b = brk[i + 1], fa = poly_eval(p, a), fb = poly_eval(p, b);
+    if (fa == 0.0) {
+      if (roots.empty() || roots.back() != a) roots.push_back(a);
+      continue;
+    }
+    if (fb == 0.0) {
+      if (i + 2 == brk.size()) roots.push_back(b);
+      continue;
+    }
+    if ((fa < 0.0) == (fb < 0.0)) continue;
+    for (int it = 0; it < 200; ++it) {
+      const double m = 0.5 * (a + b);
+      if (m <= a || m >= b) break;
+      const double fm = poly_eval(p, m);
+      if (fm == 0.0) {
+        a = b = m;
+        break;
+      }
+      if ((fm < 0.0) == (fa < 0.0)) a = m, fa = fm;
+      else b = m;
+    }
+    roots.push_back(0.5 * (a + b));
+  }
+  return roots;
+}
+
+inline double poly_minimize(const std::vector<double>& poly, double x_min, double x_max) {  // MinimizePolynomial
+  double best_x = 0.5 * (x_min + x_max), best_v = poly_eval(poly, best_x);
+  for (double x : {x_min, x_max}) {
+    const double v = poly_eval(poly, x);
+    if (v < best_v) best_x = x, best_v = v;
+  }
+  const std::vector<double> p = poly_strip(poly);
+  if (p.size() <= 2) return best_x;
+  for (double x : poly_roots_in(poly_derivative(p), x_min, x_max)) {
+    const double v = poly_eval(poly, x);
+    if (v < best_v) best_x = x, best_v = v;
+  }
+  return best_x;
+}
+
+// Returns true and the accepted step size in *t_out when a trial satisfies the sufficient-decrease condition.
+template <class Eval>
+bool armijo_search(Eval eval, double cost0, double slope0, double direction_max_norm, const LmOptions& o, double* t_out,
+                   int* trials_out) {
+  LsSample lower{0.0, cost0, slope0, true}, previous, cur;
+  cur.x = 1.0;
+  eval(cur.x, &cur.value, &cur.slope);
+  cur.valid = std::isfinite(cur.value);
+  int iters = 0, trials = 1;
+  *t_out = 1.0;
+  while (!cur.valid || cur.value > cost0 + o.line_search_sufficient_function_decrease * slope0 * cur.x) {
+    if (++iters >= o.max_num_line_search_step_size_iterations) {
+      *trials_out = trials;
+      return false;
+    }
+    const double x_lo = o.max_line_search_step_contraction * cur.x, x_hi = o.min_line_search_step_contraction * cur.x;
+    double t;
+    if (!cur.valid) {
+      t = std::min(std::max(cur.x * 0.5, x_lo), x_hi);
+    } else {
+      std::vector<LsSample> smp{lower, cur};
+      if (previous.valid) smp.push_back(previous);
+      t = poly_minimize(poly_fit(smp), x_lo, x_hi);
+    }
+    if (t * direction_max_norm < o.min_line_search_step_size) {
+      *trials_out = trials;
+      return false;
+    }
+    previous = cur;
+    cur = LsSample{};
+    cur.x = t;
+    eval(cur.x, &cur.value, &cur.slope);
+    cur.valid = std::isfinite(cur.value);
+    ++trials;
+  }
+  *t_out = cur.x;
+  *trials_out = trials;
+  return true;
+}
 
 inline void lm_minimize(LmProblem& prob, const LmOptions& o, LmSummary* s) {
   double gmax = 0.0;
   double cost = prob.linearize(&gmax);
   prob.set_jacobi_scaling(o.jacobi_scaling != 0);
   s->initial_cost = cost;
+  std::vector<double>& trace = lm_trace_store();
+  trace.clear();
+  auto record = [&](double c, double rad, double mc, double cc, double t, double acc, double lin) {
+    trace.insert(trace.end(), {c, rad, mc, cc, t, acc, lin});
+  };
   double radius = o.initial_trust_region_radius;
   double decrease_factor = 2.0;
   int invalid = 0;
@@ -91,6 +293,7 @@ inline void lm_minimize(LmProblem& prob, const LmOptions& o, LmSummary* s) {
                 s->iterations, radius, lin, relres, model_change, cand_cost, cost, step_norm);
       valid = valid && std::isfinite(model_change) && model_change > 0.0;
       if (!valid) {
+        record(cost, radius, model_change, cand_cost, 1.0, -1.0, (double)lin);
         // Ceres: ++num_consecutive_invalid_steps >= max_num_consecutive_invalid_steps -> failure
         if (++invalid >= o.max_num_consecutive_invalid_steps) {
           s->termination = 2;
@@ -101,16 +304,34 @@ inline void lm_minimize(LmProblem& prob, const LmOptions& o, LmSummary* s) {
         continue;
       }
       invalid = 0;
+      double step_size = 1.0;
+      if (prob.constrained() && o.line_search && o.max_num_line_search_step_size_iterations > 0) {
+        // TrustRegionMinimizer::DoLineSearch; model_change keeps the value of the full step
+        double t = 1.0;
+        int trials = 0;
+        const bool ok = armijo_search([&](double tt, double* c, double* g) { prob.ls_eval(tt, c, g); }, cost, prob.step_slope(),
+                                      prob.step_max_norm(), o, &t, &trials);
+        s->line_search_steps += trials - 1;
+        if (o.verbose) fprintf(stderr, "[orc lm]   line search: %s t %.15e trials %d\n", ok ? "ok" : "FAILED", t, trials);
+        if (ok && t != 1.0) {
+          ++s->line_search_shrunk;
+          prob.set_step_size(t, &cand_cost, &step_norm);
+        }
+        step_size = ok ? t : -1.0;
+      }
       if (step_norm <= o.parameter_tolerance * (x_norm + o.parameter_tolerance)) {
+        record(cost, radius, model_change, cand_cost, step_size, 0.0, (double)lin);
         s->termination = 0;
         break;
       }
       const double cost_change = cost - cand_cost;
       if (std::fabs(cost_change) <= o.function_tolerance * cost) {
+        record(cost, radius, model_change, cand_cost, step_size, 0.0, (double)lin);
         s->termination = 0;
         break;
       }
       const double rho = cost_change / model_change;
+      record(cost, radius, model_change, cand_cost, step_size, rho > o.min_relative_decrease ? 1.0 : 0.0, (double)lin);
       if (rho > o.min_relative_decrease) {
         prob.accept();
         cost = prob.linearize(&gmax);

@@ -94,6 +94,9 @@ class _GpProblem:
         self.loss_pair = lm.HuberLoss(opt.thres_loss_function, 1.0)
         # ordering groups of the reference (gp.cc:388-429): scales first (observation and pair scales), then points
         self.elimination = [g for g in [(3 * N + 3 * npts, self.M + self.E, 1), (3 * N, npts, 3)] if g[1] > 0]
+        # Program::IsBoundsConstrained: a NON-CONSTANT block with a bound — every scale but the first carries the lower
+        # bound of gp.cc:204,373 unless optimize_scales is off (gp.cc:476-482) -> Ceres runs its projected line search
+        self.is_constrained = bool(opt.optimize_scales) and (self.M + self.E) > 1
 
     def _split(self, x):
         N, P, M = self.N, self.P, self.M

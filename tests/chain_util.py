@@ -30,8 +30,10 @@ class GpuBackend:
     def gp(self, prob):
         rc, cen, xyz, rep = self.e.gp_solve(prob, self.gp_options, ctx=self.ctx)
         assert rc == 0
-        return cen, xyz, dict(iterations=rep["iterations"], initial_cost=rep["initial_cost"], final_cost=rep["final_cost"],
-                              linear_iterations=rep["linear_iterations"])
+        self.gp_trace = self.ctx.lm_trace()
+        return cen, xyz, dict(iterations=rep["iterations"], successful=rep["successful_steps"], initial_cost=rep["initial_cost"],
+                              final_cost=rep["final_cost"], linear_iterations=rep["linear_iterations"],
+                              line_search_shrunk=rep.get("line_search_shrunk", 0))
 
     def _view(self, N, off, ocam, q, t, X, und):
         return self.p.SceneView(N, off, ocam, q, t, X, obs_undist=und)
@@ -64,11 +66,14 @@ class GpuBackend:
 class OracleBackend:
     """oracle/cpu.py (exact reduced solves: PCG to 1e-14) + oracle/filters.py."""
 
-    def __init__(self, verbose=False):
+    def __init__(self, verbose=False, order=0, gp_pcg_tol=1e-14):
         from oracle import ba as oba
         from oracle import cpu, filters
 
         self.cpu, self.f, self.oba, self.verbose = cpu, filters, oba, verbose
+        # order = 1: every owner-side reduction of GP / BA summed in the opposite order — the same algorithm at another
+        # rounding (tools/exp_chain_oracle_scatter.py: how far apart are two roundings of the REFERENCE algorithm?)
+        self.order, self.gp_pcg_tol = order, gp_pcg_tol
 
     def ra(self, p):
         rep = {}
@@ -79,10 +84,12 @@ class OracleBackend:
 
     def gp(self, g):
         ok, c, X, s = self.cpu.gp_solve(g.num_cams, g.pt_offset, g.obs_cam, g.obs_dir, g.obs_calibrated, g.cam_center, g.pt_xyz,
-                                        verbose=self.verbose)
+                                        verbose=self.verbose, order=self.order, pcg_tol=self.gp_pcg_tol)
         assert ok
-        return c, X, dict(iterations=s.iterations, initial_cost=s.initial_cost, final_cost=s.final_cost,
-                          linear_iterations=s.linear_iterations, max_linear_residual=s.max_linear_residual)
+        self.gp_trace = self.cpu.lm_trace()
+        return c, X, dict(iterations=s.iterations, successful=s.successful_steps, initial_cost=s.initial_cost, final_cost=s.final_cost,
+                          linear_iterations=s.linear_iterations, max_linear_residual=s.max_linear_residual,
+                          line_search_shrunk=s.line_search_shrunk)
 
     def filter_angle(self, N, off, ocam, q, t, X, und):
         return self.f.filter_tracks_by_angle(off, ocam, q, t, X, und, MAX_ANGLE_ERROR)[0]
@@ -100,7 +107,7 @@ class OracleBackend:
     def ba(self, b, optimize_rotations):
         opt = self.oba.BundleAdjusterOptions(optimize_rotations=optimize_rotations)
         r = self.cpu.ba_solve(b.num_cams, b.pt_offset, b.obs_cam, b.obs_xy, b.cam_intr, b.intr_model, b.fixed_cam, b.cam_q, b.cam_t,
-                              b.pt_xyz, b.intr_params, options=opt, verbose=self.verbose)
+                              b.pt_xyz, b.intr_params, options=opt, verbose=self.verbose, order=self.order)
         assert r[0]
         s = r[5]
         return r[1], r[2], r[3], r[4], dict(iterations=s.iterations, successful=s.successful_steps, initial_cost=s.initial_cost,

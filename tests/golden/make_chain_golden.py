@@ -13,7 +13,7 @@ in a fixed order, so the numbers generated here ARE what the GPU box would compu
 seed (pinned by checksums) and runs the HIP chain; only the oracle's stage results travel (RA rotations, GP centres, the
 observation counts after each filter, final poses).  Reduced systems solved to 1e-14, true residuals recorded.
 
-Usage: python tests/golden/make_chain_golden.py [cams tracks name [seed]]"""
+Usage: python tests/golden/make_chain_golden.py [cams tracks name [seed]] [--reversed]"""
 import sys
 import time
 from pathlib import Path
@@ -35,13 +35,15 @@ def scene_checksums(sc):
 
 def main():
     N, P, name, seed = 10_000, 1_000_000, "chain_c4_oracle.npz", 0
-    if len(sys.argv) > 3:
-        N, P, name = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
-    if len(sys.argv) > 4:
-        seed = int(sys.argv[4])
+    argv = [a for a in sys.argv if not a.startswith("--")]
+    if len(argv) > 3:
+        N, P, name = int(argv[1]), int(argv[2]), argv[3]
+    if len(argv) > 4:
+        seed = int(argv[4])
     sc = synthetic.make_chained_scene(N, P, seed=seed)
     t0 = time.time()
-    r = run_chain(sc, OracleBackend(verbose=True))
+    be = OracleBackend(verbose=True)
+    r = run_chain(sc, be)
     g, b1, b2 = r["rep_gp"], r["rep_ba1"], r["rep_ba2"]
     print("RA %d+%d | GP LM %d cost %.6f (max true relres %.1e) | observations kept %s | BA positions-only LM %d (%d accepted) cost "
           "%.3f -> %.3f (max true relres %.1e) | BA full LM %d (%d accepted) cost %.3f -> %.3f (max true relres %.1e) | %.0f s"
@@ -54,6 +56,18 @@ def main():
     for stage, rep in (("gp", g), ("ba1", b1), ("ba2", b2)):
         for k, v in rep.items():
             out[f"{stage}_{k}"] = v
+    out["gp_trace"] = be.gp_trace  # the LM iterations of global positioning (oracle.cpu.lm_trace)
+    if "--reversed" in sys.argv:
+        # the same chain with every owner-side reduction of GP / BA summed backwards: the reference algorithm at another
+        # rounding — how well defined its own end points are
+        t1 = time.time()
+        be2 = OracleBackend(verbose=True, order=1)
+        r2 = run_chain(sc, be2)
+        out.update(rev_gp_center=r2["gp_center"], rev_ba_q=r2["ba_q"], rev_ba_t=r2["ba_t"], rev_gp_trace=be2.gp_trace,
+                   rev_observations_kept=np.array(r2["observations_kept"], dtype=np.int64),
+                   rev_gp_iterations=r2["rep_gp"]["iterations"], rev_gp_final_cost=r2["rep_gp"]["final_cost"])
+        print("reversed sums: GP LM %d cost %.6f | kept %s | %.0f s" % (r2["rep_gp"]["iterations"], r2["rep_gp"]["final_cost"],
+                                                                         r2["observations_kept"], time.time() - t1))
     np.savez_compressed(Path(__file__).resolve().parent / name, **out, seed=seed, **scene_checksums(sc))
 
 

@@ -128,22 +128,20 @@ def test_ra_two_nodes_one_edge(gsfm_ctx):
 def test_gp_skewed_visibility_matches_oracle(gsfm_ctx):
     """Cameras with > 1024 observations are cut into slices handled by different waves and combined in slice order by a
     second pass of the same kernel (obsgraph.hpp).  Parity with the exact-solve oracle and run-to-run bit-identity (no
-    floating-point atomics) on a problem where the busiest camera holds 10 x the median.  The reduced systems are
-    solved to 1e-10 here: at the default 1e-8 this problem's LM path is sensitive enough to take 38 instead of 36
-    iterations (centres still within 2e-5) — measured with and without slicing, tools/exp_skew.py."""
-    from oracle import cpu
+    floating-point atomics) on a problem where the busiest camera holds 10 x the median.  Round 6: with Ceres' line search in
+    the loop this input is one of the chaotic ones — the oracle summed backwards takes 40 LM iterations where the oracle
+    summed forwards takes 42 and ends 3.1e-3 (p99 1.9e-3, median 4.3e-5) away — so the comparison is the one of
+    tests/test_fullsize_gpu.py::_gp_parity: same trajectory while the reference follows its own, end point inside its scatter."""
+    from test_fullsize_gpu import _assert_gp_parity, _gp_parity
 
     p = synthetic.make_gp_problem(num_cams=80, num_pts=25_000, seed=4, zipf=1.3)
     per_cam = np.bincount(p.obs_cam, minlength=p.num_cams)
     assert per_cam.max() > 4 * 1024 and np.median(per_cam) < 1024  # cut and whole cameras side by side
-    opt = estimators.GlobalPositionerOptions()
-    opt.solver_options.pcg_relative_tolerance = 1e-10
+    res = _gp_parity("skewed visibility, 80 cameras / 25 000 tracks", p, gsfm_ctx)
+    _assert_gp_parity(res)
+    opt = None
     rc, cen, xyz, rep = estimators.gp_solve(p, opt, ctx=gsfm_ctx)
-    assert rc == 0
-    ok, c_o, X_o, s = cpu.gp_solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated, p.cam_center, p.pt_xyz)
-    assert ok and (rep["iterations"], rep["successful_steps"]) == (s.iterations, s.successful_steps)
-    assert abs(rep["final_cost"] - s.final_cost) <= 1e-5 * s.final_cost
-    assert synthetic.center_errors_after_sim3(cen, c_o).max() < 1e-4  # relative to the extent (the helper divides)
+    assert rc == 0 and np.array_equal(cen, res["cen"])
     rc, cen2, xyz2, rep2 = estimators.gp_solve(p, opt, ctx=gsfm_ctx)
     assert np.array_equal(cen, cen2) and np.array_equal(xyz, xyz2) and rep2["final_cost"] == rep["final_cost"]
 

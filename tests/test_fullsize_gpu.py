@@ -89,23 +89,36 @@ class _FrozenSummary:
     def __init__(self, g, order):
         self.iterations, self.final_cost = int(g[f"iterations_{order}"]), float(g[f"final_cost_{order}"])
         self.initial_cost, self.max_linear_residual = float(g[f"initial_cost_{order}"]), float(g[f"max_linear_residual_{order}"])
+        self.successful_steps, self.line_search_shrunk = int(g[f"successful_{order}"]), int(g[f"line_search_shrunk_{order}"])
 
 
-def _gp_parity(tag, p, ctx, lm_kw=None, orders=(0, "1 if apart"), frozen=None):
-    """HIP solve vs exact-solve C++ oracle on the same input and the same std::mt19937 start.  Prints and returns the
-    camera-centre distance statistics (Sim(3)-aligned, relative to the extent of the oracle's solution — divided ONCE).
+def _same_prefix(tr, ref, col, rtol):
+    """Number of leading LM iterations in which column `col` of two LM traces (gsfm_ctx_lm_trace / oracle.cpu.lm_trace: cost |
+    radius | model change | candidate cost | line-search step size | accepted | linear iterations) agrees to rtol."""
+    n = min(len(tr), len(ref))
+    bad = np.abs(tr[:n, col] - ref[:n, col]) > rtol * np.maximum(np.abs(ref[:n, col]), 1e-300)
+    return int(np.argmax(bad)) if bad.any() else n
 
-    orders: the oracle's reductions summed forwards (0) and backwards (1) — two restatements of the same algorithm that
-    differ in rounding only.  On some inputs THE ORACLE ITSELF ends in two places ~1e-3 apart on its worst camera depending
-    on that order alone (configs[2] seed 0: 42 / 41 LM iterations, final cost 5101.143 / 5100.742, 1.23e-3 apart): the
-    stalled LM iteration of this problem amplifies a perturbation ~1e6-fold and a rounding-level difference can flip an
-    accept / reject decision.  Parity on such an input can only mean: the HIP solve ends where ONE of the oracle's
-    rounding-level variants ends.  So when the forward-summed oracle is more than 1e-4 away, the reversed one is run too,
-    every distance is printed, and the closer one is returned.
 
-    frozen: name of a fixture under tests/golden/ with both variants' results (tests/golden/make_gp_c4_golden.py) instead of
-    live oracle runs — the oracle's reductions are thread-count independent, so the fixture is what the box would compute;
-    the input is pinned by the fixture's checksums."""
+def _gp_parity(tag, p, ctx, lm_kw=None, frozen=None):
+    """HIP solve vs the exact-solve C++ oracle on the same input and the same std::mt19937 start — end points AND trajectories —
+    next to the oracle against ITSELF with every reduction summed in the opposite order (the same algorithm at another
+    rounding).  Distances: camera centres, Sim(3)-aligned, relative to the extent of the reference solution — divided ONCE.
+
+    Round 6.  The reference's GP problem is bounds-constrained (every scale has a lower bound, gp.cc:204,373), so Ceres runs a
+    projected Armijo line search on every LM step (oracle/lm.py header); rounds 1 - 5 had left it out of oracle and product
+    (VERDICT r5).  With it in both, the question "how far is the HIP solve from the reference" has two different answers:
+      * on inputs where the reference algorithm's end point is DEFINED — the oracle summed forwards and backwards ends in the
+        same place — the HIP solve has to end there too (north_star's 1e-3 on the worst camera, same iteration counts);
+      * on the full-size benchmark inputs the algorithm is chaotic for ANY implementation: the two oracle roundings agree on the
+        first ~11 LM iterations to nine digits, then drift apart ~10 x per iteration and end 2e-3 (p99) / 2e-5 (median) /
+        3e-2 (one camera) apart with different iteration counts (profiles/r06_gp_line_search_gpu_vs_oracle.txt;
+        tools/exp_gp_pcg_tolerance.py: every solver tolerance from 1e-6 to 1e-14 lands inside that scatter).  There parity
+        can only mean: the same trajectory for as long as the reference follows its own, and an end point inside the
+        reference's own scatter.  The FINAL poses after bundle adjustment are defined again (the chain tests below).
+
+    frozen: fixture under tests/golden/ with both oracle variants (tests/golden/make_gp_c4_golden.py; the oracle's reductions
+    are thread-count independent, so the fixture is what the box would compute; the input is pinned by its checksums)."""
     from oracle import cpu
     from oracle import gp as ogp
 
@@ -125,94 +138,119 @@ def _gp_parity(tag, p, ctx, lm_kw=None, orders=(0, "1 if apart"), frozen=None):
         assert int(np.sum(p.obs_calibrated.astype(np.int64))) == int(g["calibrated_checksum"])
     rc, cen, xyz, rep = estimators.gp_solve(p, opt, ctx=ctx)
     assert rc == 0
-    best = None
-    runs = []
-    for order in orders:
-        if order == "1 if apart" and (not runs or runs[0][3]["max"] < 1e-4):
-            continue  # the forward-summed oracle and the HIP solve took the same branch: nothing to disambiguate
-        order = 1 if order == "1 if apart" else order
+    tr = ctx.lm_trace()
+    assert len(tr) == rep["iterations"]
+    o = []
+    for order in (0, 1):
         if g is not None:
-            c_o, s = g[f"center_{order}"], _FrozenSummary(g, order)
+            c_o, s, tr_o = g[f"center_{order}"], _FrozenSummary(g, order), g[f"trace_{order}"]
         else:
             ok, c_o, X_o, s = cpu.gp_solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_dir, p.obs_calibrated, p.cam_center, p.pt_xyz, oopt,
                                            order=order)
             assert ok
+            tr_o = cpu.lm_trace()
         assert s.max_linear_residual < 1e-8  # the oracle's reduced solves really were exact (true residual)
         assert abs(rep["initial_cost"] - s.initial_cost) <= 1e-12 * s.initial_cost  # identical random start
-        st = synthetic.center_distance_stats(cen, c_o)
-        runs.append((order, c_o, s, st))
-        print(f"\n[parity] GP {tag}{' (oracle sums reversed)' if order else ''}{' [frozen oracle result]' if g is not None else ''}: LM "
-              f"{rep['iterations']} vs {s.iterations}, final cost "
-              f"{rep['final_cost']:.6f} vs {s.final_cost:.6f}, PCG {rep['linear_iterations']}, centre distance GPU-oracle / extent: max "
-              f"{st['max']:.3e} p99 {st['p99']:.3e} median {st['median']:.3e} (bar: max 1e-3; oracle's gauge extent {_extent(c_o):.2f})")
-        if best is None or st["max"] < best[3]["max"]:
-            best = runs[-1]
-    if len(runs) == 2:
-        oo = synthetic.center_distance_stats(runs[1][1], runs[0][1])
-        print(f"[parity] GP {tag}: the oracle against itself, sums reversed vs forwards: LM {runs[1][2].iterations} vs {runs[0][2].iterations}, "
-              f"centre distance max {oo['max']:.3e} p99 {oo['p99']:.3e} median {oo['median']:.3e}")
-    return cen, best[1], rep, best[2], best[3]
+        o.append((c_o, s, tr_o))
+    res = dict(cen=cen, rep=rep, trace=tr, oracle=o, self=synthetic.center_distance_stats(o[1][0], o[0][0]),
+               self_prefix=_same_prefix(o[1][2], o[0][2], 0, 1e-6),
+               vs=[synthetic.center_distance_stats(cen, o[k][0]) for k in (0, 1)],
+               prefix=[_same_prefix(tr, o[k][2], 0, 1e-6) for k in (0, 1)],
+               prefix_step=[_same_prefix(tr, o[k][2], 4, 1e-5) for k in (0, 1)],
+               gt=[float(np.median(synthetic.center_errors_after_sim3(c, p.gt_center))) for c in (cen, o[0][0], o[1][0])])
+    src = " [frozen oracle results]" if g is not None else ""
+    for k, name in ((0, "forwards"), (1, "backwards")):
+        s, st = o[k][1], res["vs"][k]
+        print(f"\n[parity] GP {tag} vs the oracle summed {name}{src}: LM {rep['iterations']} ({rep['successful_steps']} accepted, "
+              f"{rep['line_search_shrunk']} shortened by the line search) vs {s.iterations} ({s.successful_steps}, {s.line_search_shrunk}), "
+              f"final cost {rep['final_cost']:.6f} vs {s.final_cost:.6f}, PCG {rep['linear_iterations']}, same cost to 1e-6 for the first "
+              f"{res['prefix'][k]} LM iterations (same step size: {res['prefix_step'][k]}), centre distance / extent: max {st['max']:.3e} "
+              f"p99 {st['p99']:.3e} median {st['median']:.3e}")
+    st = res["self"]
+    print(f"[parity] GP {tag}: the ORACLE against itself, sums backwards vs forwards: LM {o[1][1].iterations} vs {o[0][1].iterations}, final "
+          f"cost {o[1][1].final_cost:.6f} vs {o[0][1].final_cost:.6f}, same cost to 1e-6 for the first {res['self_prefix']} LM iterations, "
+          f"centre distance / extent: max {st['max']:.3e} p99 {st['p99']:.3e} median {st['median']:.3e} | median error vs ground truth: "
+          f"GPU {res['gt'][0]:.3e}, oracle {res['gt'][1]:.3e} / {res['gt'][2]:.3e}")
+    return res
+
+
+def _assert_gp_parity(res):
+    """The two regimes of _gp_parity's docstring, decided by the oracle's own two roundings."""
+    rep, o, me = res["rep"], res["oracle"], res["self"]
+    if me["max"] < 1e-5:
+        # the reference's end point is defined on this input: north_star's bar on the worst camera
+        s = o[0][1]
+        assert res["vs"][0]["max"] < 1e-3
+        assert abs(rep["iterations"] - s.iterations) <= 1
+        assert abs(rep["final_cost"] - s.final_cost) <= 1e-4 * s.final_cost
+        return
+    # chaotic input: (1) the same trajectory for (almost) as long as the reference follows its own ...
+    assert max(res["prefix"]) >= min(8, res["self_prefix"] - 3), (res["prefix"], res["self_prefix"])
+    # (2) ... an end point inside the reference's own scatter: typical cameras (median), the tail (p99) ...
+    k = 0 if res["vs"][0]["p99"] <= res["vs"][1]["p99"] else 1
+    assert res["vs"][k]["median"] <= 2.0 * me["median"] + 1e-5, (res["vs"], me)
+    assert res["vs"][k]["p99"] <= 2.0 * me["p99"] + 1e-4, (res["vs"], me)
+    # ... the final cost, and the quality against ground truth
+    spread = abs(o[1][1].final_cost - o[0][1].final_cost)
+    assert min(abs(rep["final_cost"] - o[j][1].final_cost) for j in (0, 1)) <= 3.0 * spread + 1e-3 * o[0][1].final_cost
+    assert res["gt"][0] <= 1.05 * max(res["gt"][1], res["gt"][2]) + 1e-5
+
+
+def test_gp_stable_input_ends_where_the_oracle_ends(gsfm_ctx):
+    """An input on which the reference algorithm's end point IS defined (150 cameras / 6 000 tracks, seed 0: the oracle summed
+    forwards and backwards ends in the same place to 6e-10, 28 LM iterations / 27 accepted / 12 shortened by the line search on
+    both): the HIP solve takes the same 28 / 27 / 12, the same line-search step sizes, and ends 3e-5 of the extent away with
+    the default solver tolerance (1e-10; 7e-7 at 1e-12, 3.7e-4 at 1e-8, 2.4e-3 at 1e-6 —
+    profiles/r06_gp_line_search_gpu_vs_oracle.txt).  Bar: north_star's 1e-3 on the worst camera."""
+    p = synthetic.make_gp_problem(num_cams=150, num_pts=6000, seed=0)
+    res = _gp_parity("150 cameras / 6 000 tracks, seed 0", p, gsfm_ctx)
+    assert res["self"]["max"] < 1e-6  # the premise: a stable input
+    _assert_gp_parity(res)
+    rep, s = res["rep"], res["oracle"][0][1]
+    assert (rep["iterations"], rep["successful_steps"], rep["line_search_shrunk"]) == (s.iterations, s.successful_steps, s.line_search_shrunk)
+    assert res["vs"][0]["max"] < 2e-4
+    # the line search ran and took the oracle's step sizes for the first dozen iterations at least
+    tr, tr_o = res["trace"], res["oracle"][0][2]
+    assert (tr[:, 4] < 1.0).sum() == s.line_search_shrunk and res["prefix_step"][0] >= 12
+    assert np.array_equal(tr[:, 5], tr_o[:, 5])  # the same accept / reject decisions
+    # ... and switched off (max_num_line_search_step_size_iterations = 0, as in Ceres) the library runs the loop of rounds 1 - 5
+    off = estimators.GlobalPositionerOptions()
+    off.solver_options.max_num_line_search_step_size_iterations = 0
+    rc, c2, _, rep2 = estimators.gp_solve(p, off, ctx=gsfm_ctx)
+    assert rc == 0 and rep2["line_search_trials"] == 0 and rep2["line_search_shrunk"] == 0
+    assert (rep2["iterations"], rep2["successful_steps"]) == (34, 19)  # tools/exp_gp_line_search.py: the committed oracle of round 5
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_gp_config3_matches_cpu_oracle(gsfm_ctx, seed):
-    """configs[2] (5k cameras / 500k tracks / ~3M observations), three seeds: the HIP solve against the exact-solve CPU
-    oracle.  Bar = north_star's 1e-3 on the camera centres relative to the scene extent, after Sim(3) alignment (GP has a
-    free similarity gauge), on the WORST camera.
-
-    Round 5: this test used to divide the (already relative) distances by the extent a second time; with the right metric
-    the round-4 library was 1.3e-2 away.  Cause: the reduced solves stopped at a relative residual of 1e-8.  The LM
-    trajectory of this problem ends in a stall — 2 % of the rays are outliers whose scales sit on their lower bound, the
-    model keeps promising a decrease that the projected step does not deliver, the radius collapses — and WHERE it stalls
-    depends on every accept / reject decision before; an error of 1e-8 per solve is enough to flip one
-    (tools/exp_gp_same_minimiser.py, 1 000 cameras: the oracle against itself, PCG 1e-8 vs 1e-14: 2.2e-2; 1e-12 vs 1e-14:
-    1e-8; reversed summation order: 6e-9).  The library now solves to 1e-12.  Measured (profiles/r05_gpu_tests_parity.txt):
-    seed 1: 6.1e-7, seed 2: 1.3e-5, same LM iteration counts as the oracle; seed 0 is an input on which the oracle itself has
-    two end points 1.23e-3 apart (see _gp_parity) and the HIP solve is 1.2e-4 from one of them."""
+    """configs[2] (5k cameras / 500k tracks / ~3M observations), three seeds (seed 1 with 10 % uncalibrated cameras): the HIP
+    solve against the exact-solve CPU oracle — see _gp_parity for what is compared and why.  Seed 0 runs the oracle live
+    (both summation orders, 2 x 45 s on the box's 16 cores), seeds 1 and 2 use its frozen results."""
     p = _gp_full_size_problem(5000, 500_000, seed)
-    # (seed 0 is the input on which the oracle itself has two end points: _gp_parity runs both summation orders there)
-    cen, c_o, rep, s, st = _gp_parity(f"configs[2] seed {seed}", p, gsfm_ctx)
-    assert abs(rep["iterations"] - s.iterations) <= 1
-    assert abs(rep["final_cost"] - s.final_cost) <= 1e-4 * s.final_cost
-    assert st["max"] < 1e-3
-    # both recover the ground truth equally well
-    e_g = synthetic.center_errors_after_sim3(cen, p.gt_center).max()
-    e_o = synthetic.center_errors_after_sim3(c_o, p.gt_center).max()
-    assert e_g < 1.05 * e_o + 1e-5
+    res = _gp_parity(f"configs[2] seed {seed}", p, gsfm_ctx, frozen=None if seed == 0 else f"gp_c3_s{seed}_oracle.npz")
+    _assert_gp_parity(res)
 
 
-def test_gp_config3_same_minimiser_at_tight_function_tolerance(gsfm_ctx):
-    """Stopping noise or solver error?  Both sides with function_tolerance 1e-10 (reference: 1e-5, optimization_base.h:22)
-    and the iteration cap raised (46 instead of 44 LM iterations, both sides): if the distance between two runs were a
-    matter of where the iteration is cut off, it would shrink here.  It does not change — 1.3e-5 with either tolerance —
-    because the LM iteration of this problem ends in the stall described in test_gp_config3_matches_cpu_oracle, not on the
-    function tolerance: what separates two runs is which branch their accept / reject decisions took, not how long they ran."""
-    p = _gp_full_size_problem(5000, 500_000, 2)
-    cen, c_o, rep, s, st = _gp_parity("configs[2] seed 2, function_tolerance 1e-10", p, gsfm_ctx,
-                                      dict(function_tolerance=1e-10, max_num_iterations=400))
-    assert abs(rep["iterations"] - s.iterations) <= 1
-    assert abs(rep["final_cost"] - s.final_cost) <= 1e-4 * s.final_cost
-    assert st["max"] < 1e-3
-
-
-def test_gp_config3_sensitivity_to_the_linear_solver_tolerance(gsfm_ctx):
-    """The documented sensitivity (not a parity claim): the same solve with the reduced systems stopped at 1e-8 — round 4's
-    setting.  Typical cameras agree with the tight solve to 1e-5; the worst few, poorly constrained, end 1e-3 ... 1e-2 away
-    because the stalled LM iteration took another branch.  Asserted: the median, and that the tight setting is what the
-    library defaults to."""
-    assert estimators.GlobalPositionerOptions().solver_options.pcg_relative_tolerance <= 1e-11
+def test_gp_solver_tolerance_inside_the_reference_scatter(gsfm_ctx):
+    """Why the reduced systems are solved to 1e-10 and not to round 5's 1e-12: on configs[2] the HIP solve at 1e-8 and at 1e-12
+    are as far from each other as the oracle is from itself under another summation order — the tolerance is not what
+    decides the end point here (tools/exp_gp_pcg_tolerance.py: the same on the CPU for 1e-6 ... 1e-14) — and the stable-input
+    test above pins what it does decide.  Asserted: the median and p99 of the distance between the two HIP solves stay
+    inside twice the documented scatter, and the looser solve does less linear work."""
     p = _gp_full_size_problem(5000, 500_000, 0)
-    rc, c_tight, _, rep_t = estimators.gp_solve(p, ctx=gsfm_ctx)
-    loose = estimators.GlobalPositionerOptions()
-    loose.solver_options.pcg_relative_tolerance = 1e-8
-    rc2, c_loose, _, rep_l = estimators.gp_solve(p, loose, ctx=gsfm_ctx)
-    assert rc == 0 and rc2 == 0
-    st = synthetic.center_distance_stats(c_loose, c_tight)
-    print(f"\n[parity] GP configs[2] seed 0, PCG 1e-8 vs the default: LM {rep_l['iterations']} vs {rep_t['iterations']}, PCG "
-          f"{rep_l['linear_iterations']} vs {rep_t['linear_iterations']}, centre distance / extent: max {st['max']:.3e} p99 "
-          f"{st['p99']:.3e} median {st['median']:.3e}")
-    assert st["median"] < 1e-3
-    assert rep_l["linear_iterations"] < rep_t["linear_iterations"]
+    out = []
+    for tol in (1e-12, 1e-8):
+        o = estimators.GlobalPositionerOptions()
+        o.solver_options.pcg_relative_tolerance = tol
+        rc, c, _, rep = estimators.gp_solve(p, o, ctx=gsfm_ctx)
+        assert rc == 0
+        out.append((c, rep))
+    st = synthetic.center_distance_stats(out[1][0], out[0][0])
+    print(f"\n[parity] GP configs[2] seed 0, PCG 1e-8 vs 1e-12: LM {out[1][1]['iterations']} vs {out[0][1]['iterations']}, PCG "
+          f"{out[1][1]['linear_iterations']} vs {out[0][1]['linear_iterations']}, centre distance / extent: max {st['max']:.3e} p99 "
+          f"{st['p99']:.3e} median {st['median']:.3e} (the oracle against itself: p99 2.0e-3, median 1.8e-5)")
+    assert st["median"] < 5e-5 and st["p99"] < 5e-3
+    assert out[1][1]["linear_iterations"] < out[0][1]["linear_iterations"]
 
 
 def test_ba_config4_matches_cpu_oracle(gsfm_ctx):
@@ -311,20 +349,12 @@ def test_ba_config4_shared_intrinsics_follows_the_exact_oracle_trajectory(gsfm_c
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_gp_config4_matches_cpu_oracle(gsfm_ctx, seed):
     """Global positioning at the size the headline times it — configs[3]: 10k cameras / 1M tracks / ~6.0M observations —
-    against the exact-solve CPU oracle on the same inputs and the same std::mt19937 start, three seeds; same bars as at
-    configs[2] (test_gp_config3_matches_cpu_oracle has the story of the metric and of the solver tolerance).  Measured:
-    2.6e-5 (seed 0, the headline's GP problem), 3.3e-4 (seed 1), 7.5e-4 (seed 2 — an input on which the oracle summed
-    backwards ends 2.5e-3 from the oracle summed forwards); LM iteration counts equal to the oracle's on all three."""
+    against the exact-solve CPU oracle on the same inputs and the same std::mt19937 start, three seeds (seed 0 is the
+    headline's GP problem); oracle results frozen by tests/golden/make_gp_c4_golden.py (both summation orders, with their LM
+    traces; six four-minute oracle runs otherwise).  _gp_parity says what is compared."""
     p = _gp_full_size_problem(10_000, 1_000_000, seed)
-    # seed 0 — the GP problem the headline times — against a live oracle run; seeds 1 and 2 against the oracle's results frozen
-    # by tests/golden/make_gp_c4_golden.py (both summation orders; five more two-minute oracle runs otherwise)
-    cen, c_o, rep, s, st = _gp_parity(f"configs[3] size, seed {seed}", p, gsfm_ctx, frozen=None if seed == 0 else f"gp_c4_s{seed}_oracle.npz")
-    assert abs(rep["iterations"] - s.iterations) <= 1
-    assert abs(rep["final_cost"] - s.final_cost) <= 1e-4 * s.final_cost
-    assert st["max"] < 1e-3
-    e_g = synthetic.center_errors_after_sim3(cen, p.gt_center).max()
-    e_o = synthetic.center_errors_after_sim3(c_o, p.gt_center).max()
-    assert e_g < 1.05 * e_o + 1e-5
+    res = _gp_parity(f"configs[3] size, seed {seed}", p, gsfm_ctx, frozen=f"gp_c4_s{seed}_oracle.npz")
+    _assert_gp_parity(res)
 
 
 def test_gp_sequential_capture_matches_cpu_oracle(gsfm_ctx):
@@ -487,7 +517,30 @@ def _chain_against_fixture(name, ncam, npts, ctx, seed=0):
           f"({int(g['ba2_successful'])}), cost {b2['final_cost']:.3f} vs {float(g['ba2_final_cost']):.3f} | FINAL POSES GPU-oracle: rotations max "
           f"{ang:.3e} rad (bar 1e-4), centres / extent max {st_ba['max']:.3e} p99 {st_ba['p99']:.3e} median {st_ba['median']:.3e} (bar 1e-3) "
           f"| vs ground truth: median rotation error {gt_rot:.4f} deg, centres median {gt_cen['median']:.2e}")
+    if "rev_ba_q" in g:  # the oracle chain with every GP / BA reduction summed backwards: the reference against itself
+        ang_o, st_o = final_pose_distance(g["rev_ba_q"], g["rev_ba_t"], g["ba_q"], g["ba_t"])
+        st_gpo = synthetic.center_distance_stats(g["rev_gp_center"], g["gp_center"])
+        print(f"[parity] chain {ncam} / {npts}: the ORACLE chain against itself (sums backwards vs forwards): GP LM {int(g['rev_gp_iterations'])} vs "
+              f"{int(g['gp_iterations'])}, GP centres max {st_gpo['max']:.3e} p99 {st_gpo['p99']:.3e} median {st_gpo['median']:.3e}, "
+              f"observations kept {g['rev_observations_kept'].tolist()} vs {g['observations_kept'].tolist()} | FINAL POSES: rotations max "
+              f"{ang_o:.3e} rad, centres / extent max {st_o['max']:.3e} p99 {st_o['p99']:.3e} median {st_o['median']:.3e}")
     return r, g, d_ra, st_gp, ang, st_ba
+
+
+def _assert_chain(r, g, d_ra, st_gp, ang, st_ba):
+    """What a chain test asserts (round 6).  Rotation averaging is a contraction: equal iteration counts, 1e-6 rad.  Global
+    positioning with Ceres' line search is chaotic on these scenes for the reference algorithm itself (_gp_parity) — two
+    roundings of the ORACLE chain end 1.6e-3 apart after GP, with 54 vs 38 LM iterations, on the 2 000-camera scene
+    (tools/exp_chain_oracle_scatter.py) — so after GP only the bulk is held (p99, median).  The filters then keep a few dozen
+    of a million observations differently, and bundle adjustment contracts again: the FINAL poses of the two oracle roundings
+    are 1e-5 rad / 6e-5 apart, and north_star's bar — 1e-4 rad, 1e-3 of the extent — is asserted on the worst camera."""
+    assert (r["rep_ra"]["l1"], r["rep_ra"]["irls"]) == (int(g["ra_l1"]), int(g["ra_irls"]))
+    assert d_ra < 1e-6
+    assert st_gp["p99"] < 5e-3 and st_gp["median"] < 1e-4
+    for a, b in zip(r["observations_kept"], g["observations_kept"].tolist()):
+        assert abs(a - b) <= max(2, int(2e-4 * b)), (r["observations_kept"], g["observations_kept"].tolist())
+    assert ang < 1e-4
+    assert st_ba["max"] < 1e-3
 
 
 @pytest.mark.parametrize("seed", [0, 1])
@@ -501,18 +554,7 @@ def test_chain_config4_final_poses_match_the_oracle_chain(gsfm_ctx, seed):
     RA's gauge and BA's constant frame in both chains), camera centres <= 1e-3 of the scene extent after Sim(3) alignment
     (BA inherits the scale the normaliser set).  Two scenes (seeds 0, 1)."""
     name = "chain_c4_oracle.npz" if seed == 0 else f"chain_c4_s{seed}_oracle.npz"  # two scenes
-    r, g, d_ra, st_gp, ang, st_ba = _chain_against_fixture(name, 10_000, 1_000_000, gsfm_ctx, seed=seed)
-    assert (r["rep_ra"]["l1"], r["rep_ra"]["irls"]) == (int(g["ra_l1"]), int(g["ra_irls"]))
-    assert d_ra < 1e-6
-    assert st_gp["max"] < 1e-3
-    # The filters are integer decisions on GP's result.  Scene 0: GP ends 1.9e-9 from the oracle's and the three filters keep
-    # exactly the same observations.  Scene 1: GP ends 2.3e-4 away (within its bar; another branch of the stalled iteration,
-    # DESIGN.md section 2) and ONE of 4.99 M observations lands on the other side of the 1-degree angle threshold — the final
-    # poses still agree to 5e-6 rad / 4e-6.  Asserted: the counts agree to 1e-5 (and exactly where GP agrees to 1e-6).
-    for a, b in zip(r["observations_kept"], g["observations_kept"].tolist()):
-        assert abs(a - b) <= (0 if st_gp["max"] < 1e-6 else max(2, int(1e-5 * b))), (r["observations_kept"], g["observations_kept"].tolist())
-    assert ang < 1e-4
-    assert st_ba["max"] < 1e-3
+    _assert_chain(*_chain_against_fixture(name, 10_000, 1_000_000, gsfm_ctx, seed=seed))
 
 
 @pytest.mark.parametrize("seed", [0, 1])
@@ -522,9 +564,4 @@ def test_chain_2k_final_poses_match_the_oracle_chain(gsfm_ctx, seed):
     of 1e8 ... 1e9, where the oracle's own reduced solves break down (true relative residual 5.0 in one LM step) — the
     situation of DESIGN.md section 2 "BA, one camera shared by all images"; there is no exact reference on that stretch."""
     name = "chain_2k_oracle.npz" if seed == 0 else f"chain_2k_s{seed}_oracle.npz"
-    r, g, d_ra, st_gp, ang, st_ba = _chain_against_fixture(name, 2_000, 200_000, gsfm_ctx, seed=seed)
-    assert d_ra < 1e-6
-    assert st_gp["max"] < 1e-3
-    assert r["observations_kept"] == g["observations_kept"].tolist()
-    assert ang < 1e-4
-    assert st_ba["max"] < 1e-3
+    _assert_chain(*_chain_against_fixture(name, 2_000, 200_000, gsfm_ctx, seed=seed))
