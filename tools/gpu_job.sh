@@ -6,6 +6,7 @@
 #   chain[:args]  chained RA->GP->BA against the frozen oracle chain(s) (tools/exp_chain_gpu.py)
 #   tests[:expr]  pytest -m gpu (optionally -k expr)
 #   testfiles:a.py:b.py   pytest -m gpu on those files, without -x
+#   testsk:expr   pytest -m gpu -k expr, without -x
 #   bench         python bench.py (default line)
 #   bench_fast    python bench.py --no-extra --no-cpu-baseline
 #   multirank:2:4 bench.py --gpus N, N ranks sharing this device (peer transport)
@@ -35,6 +36,9 @@ for step in "$@"; do
       if [ -n "$arg" ]; then timeout 2400 python -m pytest tests -m gpu -x -q -s -k "$arg" > $OUT/tests.log 2>&1
       else timeout 2400 python -m pytest tests -m gpu -x -q -s --durations=14 > $OUT/tests.log 2>&1; fi
       grep "\[parity\]" $OUT/tests.log > $OUT/tests_parity.txt; tail -15 $OUT/tests.log ;;
+    testsk)      # pytest -m gpu -k <expr>, every failure reported (no -x)
+      timeout 2400 python -m pytest tests -m gpu -q -s -k "$arg" > $OUT/testsk.log 2>&1
+      grep "\[parity\]" $OUT/testsk.log > $OUT/testsk_parity.txt; grep -E "^(FAILED|ERROR)" $OUT/testsk.log; tail -3 $OUT/testsk.log ;;
     testfiles)   # pytest -m gpu on the given files (colon-separated), every failure reported (no -x)
       timeout 2400 python -m pytest ${arg//:/ } -m gpu -q -s > $OUT/testfiles.log 2>&1
       grep "\[parity\]" $OUT/testfiles.log > $OUT/testfiles_parity.txt; grep -E "^(FAILED|ERROR)" $OUT/testfiles.log; tail -5 $OUT/testfiles.log ;;
