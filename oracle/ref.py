@@ -24,7 +24,7 @@ def load():
     if _lib is not None:
         return _lib
     if (REFERENCE / "glomap" / "scene" / "view_graph.cc").exists():
-        subprocess.run(["make", "-C", str(HERE), "-s", "ref", f"REF={REFERENCE}"], check=True)
+        subprocess.run(["make", "-C", str(HERE), "-s", "ref", "ref_solve", f"REF={REFERENCE}"], check=True)
     if not LIB.exists():
         return None
     lib = C.CDLL(str(LIB))
@@ -189,6 +189,46 @@ def gp_build(cam_q, cam_t, pt_offset, obs_cam, obs_undist, pt_xyz, cam_calibrate
     pre, keep, (N, P, M, E), o = _gp_prefix(cam_q, cam_t, pt_offset, obs_cam, obs_undist, pt_xyz, cam_calibrated, cam_registered, pt_initialized,
                                              pair_i, pair_j, pair_valid, pair_t, options)
     return _gp_build_call(lib, pre, N, P, M, E)
+
+
+LIB_GP_SOLVE = HERE / "_ref" / "libref_glomap_gp_solve.so"
+_lib_gp_solve = None
+
+
+def load_gp_solve():
+    global _lib_gp_solve
+    if _lib_gp_solve is None:
+        load()
+        if LIB_GP_SOLVE.exists():
+            _lib_gp_solve = C.CDLL(str(LIB_GP_SOLVE))
+            _lib_gp_solve.ref_gp_solve.restype = C.c_long
+    return _lib_gp_solve
+
+
+def gp_solve(cam_q, cam_t, pt_offset, obs_cam, obs_undist, pt_xyz, cam_calibrated=None, cam_registered=None, pt_initialized=None,
+             pair_i=None, pair_j=None, pair_valid=None, pair_t=None, max_num_iterations=0, **options):
+    """GlobalPositioner::Solve of the reference (global_positioning.cc:28-93, compiled unmodified) run TO ITS END POINT on the
+    solving Ceres stand-in (oracle/ref_shim_solve/ceres/ceres.h: Jacobians = dual-number derivatives of the reference's own
+    functors; the trust-region loop incl. the projected line search restated from Ceres' sources).  Returns a dict:
+    frame_order / track_order (the reference's draw order), center [N,3] (camera centres after ConvertResults), xyz [P,3],
+    initial_cost, final_cost, iterations, successful_steps, line_search_trials, line_search_shrunk, termination, constrained,
+    trace [iterations,7] (columns of gsfm_ctx_lm_trace)."""
+    lib = load_gp_solve()
+    pre, keep, (N, P, M, E), o = _gp_prefix(cam_q, cam_t, pt_offset, obs_cam, obs_undist, pt_xyz, cam_calibrated, cam_registered, pt_initialized,
+                                             pair_i, pair_j, pair_valid, pair_t, options)
+    cap = 512
+    out = dict(frame_order=np.zeros(N, np.int32), track_order=np.zeros(max(P, 1), np.int64), center=np.zeros((N, 3)),
+               xyz=np.zeros((max(P, 1), 3)))
+    summ, trace = np.zeros(8), np.zeros((cap, 7))
+    args = pre + [C.c_int(int(max_num_iterations)), _p(out["frame_order"]), _p(out["track_order"]), _p(out["center"]), _p(out["xyz"]),
+                  _p(summ), C.c_long(cap), _p(trace)]
+    rows = lib.ref_gp_solve(*_cv(args))
+    out["ok"] = rows >= 0
+    out["track_order"], out["xyz"] = out["track_order"][:P], out["xyz"][:P]
+    out.update(initial_cost=float(summ[0]), final_cost=float(summ[1]), iterations=int(summ[2]), successful_steps=int(summ[3]),
+               line_search_trials=int(summ[4]), line_search_shrunk=int(summ[5]), termination=int(summ[6]), constrained=bool(summ[7]),
+               trace=trace[:max(int(rows), 0)].copy())
+    return out
 
 
 def _gp_prefix(cam_q, cam_t, pt_offset, obs_cam, obs_undist, pt_xyz, cam_calibrated, cam_registered, pt_initialized, pair_i, pair_j, pair_valid,

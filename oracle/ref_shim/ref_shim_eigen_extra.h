@@ -11,6 +11,10 @@
 
 namespace Eigen {
 enum { ComputeFullU = 1, ComputeFullV = 2 };
+template <> struct RefShimCast3<double> {  // (T = double: the recording AutoDiffCostFunction evaluates in doubles)
+  using type = Vector3d;
+  static Vector3d make(const Vector3d& v) { return v; }
+};
 
 template <typename T, int R, int C>
 struct Matrix;

@@ -41,6 +41,8 @@ struct Vector2d {  // (a - b).norm(), a / s   (track_establishment.cc:127-128, t
   double operator[](int i) const { return i == 0 ? x : y; }
   double norm() const { return std::sqrt(x * x + y * y); }
 };
+template <typename T> struct RefShimCast3;  // what Vector3d::cast<T>() returns: specialised by ref_shim_eigen_extra.h (T = double: a Vector3d;
+                                            // ref_shim_solve/: a Matrix<T, 3, 1> of dual numbers for the solving Ceres stand-in)
 struct Vector3d {
   double v[3] = {0.0, 0.0, 0.0};
   Vector3d() = default;
@@ -68,7 +70,7 @@ struct Vector3d {
   struct NaNView { bool any_; const NaNView& isNaN() const { return *this; } bool any() const { return any_; } };
   NaNView array() const { return NaNView{hasNaN()}; }
   void setConstant(double c) { v[0] = v[1] = v[2] = c; }
-  template <typename T> Vector3d cast() const { return *this; }  // (T = double: the mock AutoDiffCostFunction evaluates in doubles)
+  template <typename T> typename RefShimCast3<T>::type cast() const { return RefShimCast3<T>::make(*this); }
 };
 inline Vector3d operator*(double s, const Vector3d& a) { return a * s; }
 struct Matrix3d {  // 3 x 3 in plain doubles, products evaluated as the usual triple loop
