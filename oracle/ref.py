@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -24,7 +25,9 @@ def load():
     if _lib is not None:
         return _lib
     if (REFERENCE / "glomap" / "scene" / "view_graph.cc").exists():
-        subprocess.run(["make", "-C", str(HERE), "-s", "ref", "ref_solve", f"REF={REFERENCE}"], check=True)
+        r = subprocess.run(["make", "-C", str(HERE), "-s", "ref", "ref_solve", f"REF={REFERENCE}"], capture_output=True, text=True)
+        if r.returncode != 0:  # a shim compile error skips the tests that need the library instead of breaking collection
+            print("[oracle/ref] make ref failed:\n" + r.stderr[-2000:], file=sys.stderr)
     if not LIB.exists():
         return None
     lib = C.CDLL(str(LIB))

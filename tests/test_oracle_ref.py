@@ -373,3 +373,42 @@ def test_global_positioning_pair_constraints_equal_the_reference(ctype):
                                  pair_i=new_cam[pi[order]], pair_j=new_cam[pj[order]], pair_dir=pdir)
     assert np.abs(c0 - r["center_start"][r["frame_order"]]).max() < 1e-12  # (bit-equal where drawn: test above)
     assert abs(summ.initial_cost - r["initial_cost"]) <= 1e-12 * r["initial_cost"]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 6: the reference's GlobalPositioner::Solve run to its END POINT (oracle/_ref/libref_glomap_gp_solve.so)
+# ---------------------------------------------------------------------------------------------------------------
+needs_gp_solve = pytest.mark.skipif(ref.load_gp_solve() is None, reason="oracle/_ref/libref_glomap_gp_solve.so not built")
+
+
+@needs_gp_solve
+@pytest.mark.parametrize("N,P,seed", [(14, 90, 0), (40, 800, 1), (60, 2000, 2)])
+def test_global_positioning_end_point_equals_the_reference(N, P, seed):
+    """global_positioning.cc + cost_function.h, unmodified, on the SOLVING Ceres stand-in (oracle/ref_shim_solve/ceres/ceres.h:
+    dual-number Jacobians of the reference's own BATA functors; Ceres' trust-region loop with the projected line search of
+    bounds-constrained programs, restated a third time on small dense blocks with exact variable elimination) against
+    oracle/gp.py + oracle/lm.py (numpy, sparse Schur complements) from the same std::mt19937 start: the same LM iterations,
+    accepted steps and line-search contractions, the same costs, the same camera centres — what pins the oracle's MINIMISER
+    to something that shares no code with it and whose residuals / Jacobians come from the reference's source."""
+    from glomap_amd import so3
+    from oracle import gp as ogp
+
+    p = synthetic.make_gp_problem(num_cams=N, num_pts=P, seed=seed, uncalibrated_ratio=0.2)
+    q = so3.rotmat_to_quat(p.cam_R)
+    t = -np.einsum("nij,nj->ni", p.cam_R, p.gt_center)
+    und = np.einsum("mij,mj->mi", p.cam_R[p.obs_cam], p.obs_dir)
+    cal = np.ones(p.num_cams, np.uint8)
+    cal[p.obs_cam] = p.obs_calibrated
+    p.cam_center = p.gt_center.copy()
+    r = ref.gp_solve(q, t, p.pt_offset, p.obs_cam, und, p.pt_xyz, cam_calibrated=cal)
+    assert r["ok"] and r["constrained"] and r["line_search_shrunk"] > 0
+    pr, new_cam, idx = _renumbered(p, r["frame_order"], r["track_order"])
+    ok, c, X, s = ogp.solve(pr.num_cams, pr.pt_offset, pr.obs_cam, pr.obs_dir, pr.obs_calibrated, pr.cam_center, pr.pt_xyz,
+                            ogp.GlobalPositionerOptions(rand_vector_order=1))
+    assert ok
+    assert (s.iterations, s.successful_steps, s.line_search_shrunk) == (r["iterations"], r["successful_steps"], r["line_search_shrunk"])
+    assert abs(s.initial_cost - r["initial_cost"]) <= 1e-12 * r["initial_cost"]
+    assert abs(s.final_cost - r["final_cost"]) <= 1e-8 * r["final_cost"]
+    assert np.allclose(np.array(s.step_sizes), r["trace"][:, 4], rtol=1e-6)  # the line search's step sizes, iteration by iteration
+    c_ref = r["center"][r["frame_order"]]
+    assert np.abs(c - c_ref).max() <= 1e-7 * np.abs(c_ref).max()  # same start, same gauge: no alignment

@@ -9,7 +9,9 @@ close the triangle on the GPU box itself, same inputs on both sides:
       trivial frames, cam_from_rig rotations among the unknowns, and gravity-aligned frames
   GlobalPositioner::Solve up to the first cost evaluation (reference code on a recording Ceres)  vs  gsfm_gp_solve: the
       initial cost of the reference's random start — draws in the reference's container walk, g++'s argument order
-  BundleAdjuster::Solve up to the first cost evaluation  vs  gsfm_ba_solve: the initial cost, with the reference's constant frame"""
+  BundleAdjuster::Solve up to the first cost evaluation  vs  gsfm_ba_solve: the initial cost, with the reference's constant frame
+  GlobalPositioner::Solve TO ITS END POINT (round 6: reference code on a SOLVING Ceres stand-in, oracle/ref_shim_solve/)  vs
+      gsfm_gp_solve: final camera centres and the LM trajectory"""
 import numpy as np
 import pytest
 
@@ -124,6 +126,45 @@ def test_global_positioning_start_equals_the_reference_code(gsfm_ctx, seed):
     print(f"[parity] GP start vs REFERENCE CODE seed={seed}: initial cost {rep['initial_cost']:.12e} vs {r['initial_cost']:.12e} (rel {rel:.1e})")
     assert rel < 1e-12
     assert synthetic.center_errors_after_sim3(c, p.gt_center).max() < 0.1  # and the solve from that start recovers the scene
+
+
+@pytest.mark.skipif(ref.load_gp_solve() is None, reason="oracle/_ref/libref_glomap_gp_solve.so not built (it comes with the snapshot)")
+@pytest.mark.parametrize("N,P,seed,uncal", [(40, 800, 1, 0.2), (60, 2000, 2, 0.2), (60, 2000, 3, 0.0), (150, 6000, 0, 0.0)])
+def test_global_positioning_end_point_equals_the_reference_code(gsfm_ctx, N, P, seed, uncal):
+    """GlobalPositioner::Solve of the reference run TO ITS END POINT (global_positioning.cc compiled unmodified on the solving
+    Ceres stand-in of oracle/ref_shim_solve/: the reference's own BATA functors differentiated by dual numbers, its losses, its
+    bounds and constant blocks, its ordering; the trust-region loop with the projected line search restated from Ceres' sources
+    — a third writing that shares no code with the oracle's or the product's) against gsfm_gp_solve from the same random start
+    (the reference's container walk, g++ argument order): FINAL camera centres, LM iteration for LM iteration."""
+    p = synthetic.make_gp_problem(num_cams=N, num_pts=P, seed=seed, uncalibrated_ratio=uncal)
+    q = so3.rotmat_to_quat(p.cam_R)
+    t = -np.einsum("nij,nj->ni", p.cam_R, p.gt_center)
+    und = np.einsum("mij,mj->mi", p.cam_R[p.obs_cam], p.obs_dir)
+    cal = np.ones(p.num_cams, np.uint8)
+    cal[p.obs_cam] = p.obs_calibrated
+    r = ref.gp_solve(q, t, p.pt_offset, p.obs_cam, und, p.pt_xyz, cam_calibrated=cal)
+    assert r["ok"] and r["constrained"] and r["termination"] == 0
+    pg = GpProblem(num_cams=p.num_cams, num_pts=p.num_pts, pt_offset=p.pt_offset, obs_cam=p.obs_cam, obs_dir=p.obs_dir,
+                   obs_calibrated=p.obs_calibrated, cam_center=p.gt_center.copy(), pt_xyz=p.pt_xyz.copy(),
+                   cam_draw_order=r["frame_order"].astype(np.int32), pt_draw_order=r["track_order"].astype(np.int32))
+    rc, c, X, rep = estimators.gp_solve(pg, estimators.GlobalPositionerOptions(rand_vector_order=1), ctx=gsfm_ctx)
+    assert rc == 0
+    tr, tr_r = gsfm_ctx.lm_trace(), r["trace"]
+    n = min(len(tr), len(tr_r))
+    bad = np.abs(tr[:n, 0] - tr_r[:n, 0]) > 1e-6 * np.abs(tr_r[:n, 0])
+    same = int(np.argmax(bad)) if bad.any() else n
+    st = synthetic.center_distance_stats(c, r["center"])
+    raw = np.abs(c - r["center"]).max() / synthetic.scene_extent(r["center"])  # same start, same gauge: no alignment needed
+    print(f"[parity] GP END POINT vs REFERENCE CODE {N} cameras / {P} tracks, seed {seed}: LM {rep['iterations']} ({rep['successful_steps']} accepted, "
+          f"{rep['line_search_shrunk']} shortened) vs {r['iterations']} ({r['successful_steps']}, {r['line_search_shrunk']}), initial cost rel "
+          f"{abs(rep['initial_cost'] - r['initial_cost']) / r['initial_cost']:.1e}, final cost {rep['final_cost']:.9f} vs {r['final_cost']:.9f}, same cost "
+          f"to 1e-6 for the first {same} LM iterations, centres / extent: max {st['max']:.3e} p99 {st['p99']:.3e} median {st['median']:.3e} "
+          f"(without alignment: {raw:.3e})")
+    assert abs(rep["initial_cost"] - r["initial_cost"]) <= 1e-12 * r["initial_cost"]
+    assert same >= min(10, n)
+    assert abs(rep["iterations"] - r["iterations"]) <= 2 and abs(rep["successful_steps"] - r["successful_steps"]) <= 2
+    assert abs(rep["final_cost"] - r["final_cost"]) <= 1e-4 * r["final_cost"]
+    assert st["max"] < 1e-3  # north_star's bar on the worst camera
 
 
 def test_bundle_adjustment_start_equals_the_reference_code(gsfm_ctx):
