@@ -380,6 +380,45 @@ def ba_build(cam_model, cam_params, frame_q, frame_t, image_frame, image_cam, pt
     return _ba_build_call(lib, pre, F, K, S, P, M)
 
 
+LIB_BA_SOLVE = HERE / "_ref" / "libref_glomap_ba_solve.so"
+_lib_ba_solve = None
+
+
+def load_ba_solve():
+    global _lib_ba_solve
+    if _lib_ba_solve is None:
+        load()
+        if LIB_BA_SOLVE.exists():
+            _lib_ba_solve = C.CDLL(str(LIB_BA_SOLVE))
+            _lib_ba_solve.ref_ba_solve.restype = C.c_long
+    return _lib_ba_solve
+
+
+def ba_solve(cam_model, cam_params, frame_q, frame_t, image_frame, image_cam, pt_offset, obs_image, obs_xy, pt_xyz, rig_ref_cam=(0,),
+             frame_rig=None, sensor_rig=(), sensor_cam=(), sensor_pose=None, frame_has_pose=None, image_present=None, max_num_iterations=0,
+             **options):
+    """BundleAdjuster::Solve of the reference (bundle_adjustment.cc, compiled unmodified) run TO ITS END POINT on the solving
+    Ceres stand-in (oracle/ref_shim_solve/ceres/ceres.h).  Returns a dict: frame_q [F,4] (w, x, y, z), frame_t [F,3], xyz [P,3],
+    cam_params [K,16], sensor_pose [S,7], frame_order, frame_const [F], initial_cost, final_cost, iterations, successful_steps,
+    termination, trace [iterations,7]."""
+    lib = load_ba_solve()
+    pre, keep, (F, I, K, S, P, M) = _ba_prefix(cam_model, cam_params, frame_q, frame_t, image_frame, image_cam, pt_offset, obs_image, obs_xy, pt_xyz,
+                                               rig_ref_cam, frame_rig, sensor_rig, sensor_cam, sensor_pose, frame_has_pose, image_present, options)
+    cap = 512
+    out = dict(frame_q=np.zeros((F, 4)), frame_t=np.zeros((F, 3)), xyz=np.zeros((max(P, 1), 3)), cam_params=np.zeros((K, 16)),
+               sensor_pose=np.zeros((max(S, 1), 7)), frame_order=np.zeros(F, np.int32), frame_const=np.zeros(F, np.uint8))
+    summ, trace = np.zeros(8), np.zeros((cap, 7))
+    vp = C.c_void_p
+    rows = lib.ref_ba_solve(*pre, C.c_int(int(max_num_iterations)), vp(_p(out["frame_q"])), vp(_p(out["frame_t"])), vp(_p(out["xyz"])),
+                            vp(_p(out["cam_params"])), vp(_p(out["sensor_pose"])), vp(_p(out["frame_order"])), vp(_p(out["frame_const"])),
+                            vp(_p(summ)), C.c_long(cap), vp(_p(trace)))
+    out["ok"] = rows >= 0
+    out["xyz"], out["sensor_pose"] = out["xyz"][:P], out["sensor_pose"][:S]
+    out.update(initial_cost=float(summ[0]), final_cost=float(summ[1]), iterations=int(summ[2]), successful_steps=int(summ[3]),
+               termination=int(summ[6]), constrained=bool(summ[7]), trace=trace[:max(int(rows), 0)].copy())
+    return out
+
+
 def _ba_prefix(cam_model, cam_params, frame_q, frame_t, image_frame, image_cam, pt_offset, obs_image, obs_xy, pt_xyz, rig_ref_cam, frame_rig,
                sensor_rig, sensor_cam, sensor_pose, frame_has_pose, image_present, options):
     """The flat arguments shared by ref_ba_build and ref_ba_adapter_solve (oracle/ref_glue_ba_scene.h)."""

@@ -1,6 +1,6 @@
 // colmap/estimators/cost_functions.h (un-vendored COLMAP @ b6b7b54e): the three reprojection cost functors that
 // glomap/estimators/bundle_adjustment.cc instantiates through CreateCameraCostFunction, restated from their published
-// definitions for the recording Ceres (values only, no Jacobians):
+// definitions (values for the recording Ceres; values + dual-number Jacobians for the solving one):
 //   ReprojErrorCostFunctor                (q, t, X, params):                 x_c = R(q) X + t
 //   RigReprojErrorConstantRigCostFunctor  (q, t, X, params), cam_from_rig:   x_c = cam_from_rig * (R(q) X + t)
 //   RigReprojErrorCostFunctor             (q_s, t_s, q, t, X, params):       x_c = R(q_s) (R(q) X + t) + t_s
@@ -44,36 +44,89 @@ class RefShimReprojCost final : public ceres::CostFunction {
   int kind() const { return kind_; }
   const Eigen::Vector2d& point2D() const { return xy_; }
   const glomap::Rigid3d& cam_from_rig() const { return cam_from_rig_; }
-  bool Evaluate(double const* const* p, double* r, double**) const override {
+  // values in doubles; with the SOLVING Ceres stand-in (ref_shim_solve/ceres/ceres.h defines CERES_SHIM_SOLVING) also the
+  // Jacobians, as dual-number derivatives of the same templated evaluation
+  bool Evaluate(double const* const* p, double* r, double** jac) const override {
+#ifdef CERES_SHIM_SOLVING
+    if (jac != nullptr) {
+      constexpr int kMax = 32;  // 4 + 3 + 4 + 3 + 3 + 12 at most
+      using J = ceres::Jet<kMax>;
+      J x[kMax];
+      const J* px[6];
+      int off = 0;
+      for (size_t b = 0; b < sizes_.size(); ++b) {
+        px[b] = x + off;
+        for (int i = 0; i < sizes_[b]; ++i) x[off + i] = J(p[b][i], off + i);
+        off += sizes_[b];
+      }
+      J rj[2];
+      if (!Eval<J>(px, rj)) return false;
+      r[0] = rj[0].a;
+      r[1] = rj[1].a;
+      off = 0;
+      for (size_t b = 0; b < sizes_.size(); ++b) {
+        if (jac[b] != nullptr)
+          for (int k = 0; k < 2; ++k)
+            for (int i = 0; i < sizes_[b]; ++i) jac[b][k * sizes_[b] + i] = rj[k].v[off + i];
+        off += sizes_[b];
+      }
+      return true;
+    }
+#endif
+    return Eval<double>(p, r);
+  }
+
+  // R(q) v for a quaternion block in Eigen coefficient order (x, y, z, w), as Eigen's operator*: v + 2 w (u x v) + 2 u x (u x v)
+  template <typename T>
+  static void Rotate(const T* q, const T v[3], T out[3]) {
+    const T uv0 = (q[1] * v[2] - q[2] * v[1]) * 2.0, uv1 = (q[2] * v[0] - q[0] * v[2]) * 2.0, uv2 = (q[0] * v[1] - q[1] * v[0]) * 2.0;
+    out[0] = v[0] + q[3] * uv0 + (q[1] * uv2 - q[2] * uv1);
+    out[1] = v[1] + q[3] * uv1 + (q[2] * uv0 - q[0] * uv2);
+    out[2] = v[2] + q[3] * uv2 + (q[0] * uv1 - q[1] * uv0);
+  }
+
+  template <typename T>
+  bool Eval(T const* const* p, T* r) const {
     const int o = kind_ == 2 ? 2 : 0;
-    const Eigen::Quaterniond q(p[o][3], p[o][0], p[o][1], p[o][2]);
-    Eigen::Vector3d x = q * Eigen::Vector3d(p[o + 2][0], p[o + 2][1], p[o + 2][2]) + Eigen::Vector3d(p[o + 1][0], p[o + 1][1], p[o + 1][2]);
-    if (kind_ == 1) x = cam_from_rig_.rotation * x + cam_from_rig_.translation;
-    if (kind_ == 2) x = Eigen::Quaterniond(p[0][3], p[0][0], p[0][1], p[0][2]) * x + Eigen::Vector3d(p[1][0], p[1][1], p[1][2]);
-    const double* k = p[o + 3];
-    r[0] = r[1] = 0.0;
-    if (x(2) < std::numeric_limits<double>::epsilon()) return true;
-    const double u = x(0) / x(2), v = x(1) / x(2), r2 = u * u + v * v;
+    T X[3] = {p[o + 2][0], p[o + 2][1], p[o + 2][2]}, x[3];
+    Rotate<T>(p[o], X, x);
+    for (int j = 0; j < 3; ++j) x[j] = x[j] + p[o + 1][j];
+    if (kind_ == 1) {
+      const T qc[4] = {T(cam_from_rig_.rotation.x()), T(cam_from_rig_.rotation.y()), T(cam_from_rig_.rotation.z()), T(cam_from_rig_.rotation.w())};
+      T y[3];
+      Rotate<T>(qc, x, y);
+      for (int j = 0; j < 3; ++j) x[j] = y[j] + cam_from_rig_.translation(j);
+    }
+    if (kind_ == 2) {
+      T y[3];
+      Rotate<T>(p[0], x, y);
+      for (int j = 0; j < 3; ++j) x[j] = y[j] + p[1][j];
+    }
+    const T* k = p[o + 3];
+    r[0] = T(0.0);
+    r[1] = T(0.0);
+    if (x[2] < std::numeric_limits<double>::epsilon()) return true;
+    const T u = x[0] / x[2], v = x[1] / x[2], r2 = u * u + v * v;
     switch (model_) {
       case CameraModelId::kSimplePinhole: r[0] = k[0] * u + k[1]; r[1] = k[0] * v + k[2]; break;
       case CameraModelId::kPinhole: r[0] = k[0] * u + k[2]; r[1] = k[1] * v + k[3]; break;
-      case CameraModelId::kSimpleRadial: { const double d = k[3] * r2; r[0] = k[0] * (u + u * d) + k[1]; r[1] = k[0] * (v + v * d) + k[2]; break; }
-      case CameraModelId::kRadial: { const double d = k[3] * r2 + k[4] * r2 * r2; r[0] = k[0] * (u + u * d) + k[1]; r[1] = k[0] * (v + v * d) + k[2]; break; }
+      case CameraModelId::kSimpleRadial: { const T d = k[3] * r2; r[0] = k[0] * (u + u * d) + k[1]; r[1] = k[0] * (v + v * d) + k[2]; break; }
+      case CameraModelId::kRadial: { const T d = k[3] * r2 + k[4] * r2 * r2; r[0] = k[0] * (u + u * d) + k[1]; r[1] = k[0] * (v + v * d) + k[2]; break; }
       case CameraModelId::kOpenCV: {
-        const double rad = k[4] * r2 + k[5] * r2 * r2, uv = u * v;
-        const double du = u * rad + 2.0 * k[6] * uv + k[7] * (r2 + 2.0 * u * u), dv = v * rad + 2.0 * k[7] * uv + k[6] * (r2 + 2.0 * v * v);
+        const T rad = k[4] * r2 + k[5] * r2 * r2, uv = u * v;
+        const T du = u * rad + k[6] * uv * 2.0 + k[7] * (r2 + u * u * 2.0), dv = v * rad + k[7] * uv * 2.0 + k[6] * (r2 + v * v * 2.0);
         r[0] = k[0] * (u + du) + k[2]; r[1] = k[1] * (v + dv) + k[3]; break;
       }
       case CameraModelId::kFullOpenCV: {  // fx, fy, cx, cy, k1, k2, p1, p2, k3, k4, k5, k6
-        const double r4 = r2 * r2, r6 = r4 * r2, uv = u * v;
-        const double rad = (1.0 + k[4] * r2 + k[5] * r4 + k[8] * r6) / (1.0 + k[9] * r2 + k[10] * r4 + k[11] * r6);
-        const double ud = u * rad + 2.0 * k[6] * uv + k[7] * (r2 + 2.0 * u * u), vd = v * rad + 2.0 * k[7] * uv + k[6] * (r2 + 2.0 * v * v);
+        const T r4 = r2 * r2, r6 = r4 * r2, uv = u * v;
+        const T rad = (k[4] * r2 + k[5] * r4 + k[8] * r6 + 1.0) / (k[9] * r2 + k[10] * r4 + k[11] * r6 + 1.0);
+        const T ud = u * rad + k[6] * uv * 2.0 + k[7] * (r2 + u * u * 2.0), vd = v * rad + k[7] * uv * 2.0 + k[6] * (r2 + v * v * 2.0);
         r[0] = k[0] * ud + k[2]; r[1] = k[1] * vd + k[3]; break;
       }
       default: return false;
     }
-    r[0] -= xy_(0);
-    r[1] -= xy_(1);
+    r[0] = r[0] - xy_(0);
+    r[1] = r[1] - xy_(1);
     return true;
   }
 

@@ -21,6 +21,7 @@
 // Manifolds as colmap's helpers tag them (ref_shim_ba/colmap/estimators/manifold.h): EigenQuaternionManifold (x, y, z, w;
 // Plus(x, d) = [sin|d| d / |d|, cos|d|] * x) and SubsetManifold.  Small problems only (dense camera system).
 #pragma once
+#define CERES_SHIM_SOLVING 1
 #include <algorithm>
 #include <cmath>
 #include <cstdio>

@@ -185,3 +185,36 @@ def test_rig_problems_equal_the_reference():
             assert ((r["sensor_flags"] & IN) == 0).all()
         _check_blocks(r, prob, used, opt, ba.num_cams)
         assert abs(prob.cost(b["x0"]) - r["initial_cost"]) <= 1e-12 * r["initial_cost"]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 6: the reference's BundleAdjuster::Solve run to its END POINT (oracle/_ref/libref_glomap_ba_solve.so)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.skipif(ref.load_ba_solve() is None, reason="oracle/_ref/libref_glomap_ba_solve.so not built")
+@pytest.mark.parametrize("N,P,seed,kw", [(15, 300, 23, dict(shared_intrinsics=True, intr_noise=0.01)),
+                                         (40, 1500, 2, dict(pixel_noise=0.7, outlier_ratio=0.02, intr_noise=0.01)),
+                                         (60, 3000, 5, dict(pixel_noise=0.5, outlier_ratio=0.02))])
+def test_bundle_adjustment_end_point_equals_the_reference(N, P, seed, kw):
+    """bundle_adjustment.cc, unmodified, on the SOLVING Ceres stand-in (oracle/ref_shim_solve/ceres/ceres.h; COLMAP's reprojection
+    functor restated in ref_shim_ba/ and differentiated by dual numbers; quaternion / subset manifolds, the constant frame the
+    reference's hash map yields, points eliminated exactly, dense Cholesky on the rest) against oracle/ba.py + oracle/lm.py
+    (analytic Jacobians, left-multiplicative tangent, sparse Schur complement): the same LM iterations and accepted steps, the
+    same costs to nine digits, the same poses."""
+    from glomap_amd import so3, synthetic
+    from oracle import ba as oba
+
+    p = synthetic.make_ba_problem(num_cams=N, num_pts=P, seed=seed, **kw)
+    r = ref.ba_solve(p.intr_model, p.intr_params, p.cam_q, p.cam_t, np.arange(p.num_cams), p.cam_intr, p.pt_offset, p.obs_cam, p.obs_xy, p.pt_xyz,
+                     rig_ref_cam=np.arange(p.num_intr), frame_rig=p.cam_intr)
+    assert r["ok"] and not r["constrained"] and r["frame_const"].sum() == 1
+    fixed = int(np.nonzero(r["frame_const"])[0][0])
+    assert fixed == int(r["frame_order"][0])  # the first frame the map yields (ba.cc:252-270)
+    ok, q, t, X, intr, s = oba.solve(p.num_cams, p.pt_offset, p.obs_cam, p.obs_xy, p.cam_intr, p.intr_model, fixed, p.cam_q, p.cam_t, p.pt_xyz,
+                                     p.intr_params)
+    assert ok and (s.iterations, s.successful_steps) == (r["iterations"], r["successful_steps"])
+    assert abs(s.initial_cost - r["initial_cost"]) <= 1e-12 * r["initial_cost"]
+    assert abs(s.final_cost - r["final_cost"]) <= 1e-8 * r["final_cost"]
+    ang = np.radians(so3.rotation_angle_deg(so3.quat_to_rotmat(q), so3.quat_to_rotmat(r["frame_q"])))
+    assert ang.max() < 1e-6 and np.abs(t - r["frame_t"]).max() < 1e-3 * (1 + np.abs(t).max())
+    assert np.abs(intr - r["cam_params"][:, : intr.shape[1]]).max() < 1e-6 * 1200
+    assert np.array_equal(q[fixed], p.cam_q[fixed]) and np.allclose(r["frame_q"][fixed], p.cam_q[fixed], atol=1e-15)

@@ -10,8 +10,8 @@ close the triangle on the GPU box itself, same inputs on both sides:
   GlobalPositioner::Solve up to the first cost evaluation (reference code on a recording Ceres)  vs  gsfm_gp_solve: the
       initial cost of the reference's random start — draws in the reference's container walk, g++'s argument order
   BundleAdjuster::Solve up to the first cost evaluation  vs  gsfm_ba_solve: the initial cost, with the reference's constant frame
-  GlobalPositioner::Solve TO ITS END POINT (round 6: reference code on a SOLVING Ceres stand-in, oracle/ref_shim_solve/)  vs
-      gsfm_gp_solve: final camera centres and the LM trajectory"""
+  GlobalPositioner::Solve / BundleAdjuster::Solve TO THEIR END POINTS (round 6: reference code on a SOLVING Ceres stand-in,
+      oracle/ref_shim_solve/)  vs  gsfm_gp_solve / gsfm_ba_solve: final camera centres / poses and the LM trajectory"""
 import numpy as np
 import pytest
 
@@ -179,6 +179,34 @@ def test_bundle_adjustment_start_equals_the_reference_code(gsfm_ctx):
     print(f"[parity] BA start vs REFERENCE CODE: initial cost {rep['initial_cost']:.12e} vs {r['initial_cost']:.12e} (rel {rel:.1e})")
     assert rel < 1e-12
     assert np.array_equal(q[p.fixed_cam], p.cam_q[p.fixed_cam]) and np.array_equal(t[p.fixed_cam], p.cam_t[p.fixed_cam])
+
+
+@pytest.mark.skipif(ref.load_ba_solve() is None, reason="oracle/_ref/libref_glomap_ba_solve.so not built (it comes with the snapshot)")
+@pytest.mark.parametrize("N,P,seed,kw", [(15, 300, 23, dict(shared_intrinsics=True, intr_noise=0.01)),
+                                         (40, 1500, 2, dict(pixel_noise=0.7, outlier_ratio=0.02, intr_noise=0.01)),
+                                         (60, 3000, 5, dict(pixel_noise=0.5, outlier_ratio=0.02)),
+                                         (120, 8000, 7, dict(pixel_noise=0.5, outlier_ratio=0.01, intr_noise=0.005))])
+def test_bundle_adjustment_end_point_equals_the_reference_code(gsfm_ctx, N, P, seed, kw):
+    """BundleAdjuster::Solve of the reference run TO ITS END POINT (bundle_adjustment.cc compiled unmodified on the solving Ceres
+    stand-in, oracle/ref_shim_solve/) against gsfm_ba_solve with the reference's constant frame: FINAL rotations (bar 1e-4 rad)
+    and camera centres (bar 1e-3 of the extent; no alignment, the constant frame fixes the gauge), equal LM iteration counts."""
+    p = synthetic.make_ba_problem(num_cams=N, num_pts=P, seed=seed, **kw)
+    r = ref.ba_solve(p.intr_model, p.intr_params, p.cam_q, p.cam_t, np.arange(p.num_cams), p.cam_intr, p.pt_offset, p.obs_cam, p.obs_xy, p.pt_xyz,
+                     rig_ref_cam=np.arange(p.num_intr), frame_rig=p.cam_intr)
+    assert r["ok"] and r["frame_const"].sum() == 1
+    p.fixed_cam = int(np.nonzero(r["frame_const"])[0][0])
+    rc, q, t, X, intr, rep = estimators.ba_solve(p, ctx=gsfm_ctx)
+    assert rc == 0
+    ang = _dist(q, r["frame_q"])
+    Rg, Rr = so3.quat_to_rotmat(q), so3.quat_to_rotmat(r["frame_q"])
+    cg, cr = -np.einsum("nji,nj->ni", Rg, t), -np.einsum("nji,nj->ni", Rr, r["frame_t"])
+    dc = np.linalg.norm(cg - cr, axis=1).max() / synthetic.scene_extent(cr)
+    print(f"[parity] BA END POINT vs REFERENCE CODE {N} cameras / {P} tracks: LM {rep['iterations']} ({rep['successful_steps']} accepted) vs "
+          f"{r['iterations']} ({r['successful_steps']}), final cost {rep['final_cost']:.9f} vs {r['final_cost']:.9f}, rotations max {ang.max():.3e} rad "
+          f"(bar 1e-4), centres / extent max {dc:.3e} (bar 1e-3), focal max {np.abs(intr[:, 0] - r['cam_params'][:, 0]).max():.3e}")
+    assert abs(rep["initial_cost"] - r["initial_cost"]) <= 1e-12 * r["initial_cost"]
+    assert abs(rep["iterations"] - r["iterations"]) <= 1 and abs(rep["final_cost"] - r["final_cost"]) <= 1e-6 * r["final_cost"]
+    assert ang.max() < 1e-4 and dc < 1e-3
 
 
 # ---------------------------------------------------------------------------------------------------------------
