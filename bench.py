@@ -575,6 +575,7 @@ def cpu_baseline_pipeline(p_ra, p_gp, p_ba, gpu_rep):
 
     like = leg(1e-10, 1e-6, 1)
     out.update(like)
+    out["reference_code_ra"] = reference_code_ra(p_ra)
     # the second leg doubles the CPU time of the run: on a slow box it is left out so that the default run stays within minutes
     if os.environ.get("GSFM_BENCH_NO_EXACT_CPU_LEG"):
         out["exact_solves_skipped"] = "GSFM_BENCH_NO_EXACT_CPU_LEG"
@@ -853,6 +854,33 @@ def bench_ra_large(ctx):
                            "(every edge from both endpoints)"},
     }
     return out
+
+
+def reference_code_ra(p):
+    """The REFERENCE'S OWN rotation averaging on the same view graph: glomap/estimators/global_rotation_averaging.cc (+
+    rotation_initializer.cc, tree.cc, rigid3d.cc) compiled unmodified into oracle/_ref/libref_glomap_ra.so (built in the build
+    container, travels with the snapshot) — on stand-ins for Eigen / CHOLMOD (an envelope Cholesky after reverse Cuthill-McKee) /
+    COLMAP's LAD solver / Boost, one thread.  Reported next to the restated oracle's time: reference CODE, not the reference
+    BUILD (no SuiteSparse, no Eigen vectorisation)."""
+    try:
+        import numpy as np
+
+        from glomap_amd import so3, synthetic
+        from oracle import ref
+
+        if ref.load_ra() is None:
+            return {"skipped": "oracle/_ref/libref_glomap_ra.so not present"}
+        N = p.num_nodes
+        t0 = time.perf_counter()
+        r = ref.ra_estimate([0], np.zeros(N), np.arange(N), np.zeros(N), p.edge_i, p.edge_j, p.edge_q, pair_weight=p.edge_weight,
+                            pair_ninl=synthetic.break_inlier_ties_by_index(p.edge_ninl), frame_q=so3.aa_to_quat(p.node_aa0))
+        dt = time.perf_counter() - t0
+        return {"seconds": dt, "value": p.num_edges / dt, "unit": "edges/s", "cores": 1, "kind": "reference", "ok": bool(r["ok"]),
+                "iterations": {"l1": r["l1_iterations"], "irls": r["irls_iterations"], "admm": r["admm_iterations"]},
+                "sample": "ONE RotationEstimator::EstimateRotations of the reference's own source on the pipeline's view graph, stand-in "
+                          "linear algebra (envelope Cholesky for CHOLMOD), single thread"}
+    except Exception as e:  # noqa: BLE001 — a checker-side problem must not take the bench line down
+        return {"skipped": f"{type(e).__name__}: {e}"}
 
 
 def cpu_baseline_ra(p):

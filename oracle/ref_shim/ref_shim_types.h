@@ -327,6 +327,20 @@ struct Image {  // scene/image.h:10-53 (trivial frames: cam_from_world = the fra
            (HasTrivialFrame() || frame_ptr->RigPtr()->MaybeSensorFromRig(sensor_t(SensorType::CAMERA, camera_id)).has_value());
   }
 };
+#ifdef REF_SHIM_INLIER_COUNT_ONLY
+// The rotation-averaging libraries only ever ask image_pair.inliers for its size() (tree.cc:99,124,128): a count instead of a
+// vector<int> of that length — with inlier counts made distinct by rank (synthetic.break_inlier_ties_by_index) a configs[3]
+// view graph would otherwise need 500 000 vectors of up to 500 000 ints.
+struct RefShimInlierList {
+  size_t n = 0;
+  size_t size() const { return n; }
+  void assign(size_t count, int) { n = count; }
+  void resize(size_t count) { n = count; }
+  void clear() { n = 0; }
+};
+#else
+using RefShimInlierList = std::vector<int>;
+#endif
 struct ImagePair {  // scene/image_pair.h:13-57
   ImagePair() = default;
   ImagePair(image_t id1, image_t id2, const Rigid3d& pose = Rigid3d()) : image_id1(id1), image_id2(id2), cam2_from_cam1(pose) {}  // :16-27
@@ -334,7 +348,7 @@ struct ImagePair {  // scene/image_pair.h:13-57
   bool is_valid = true;
   double weight = -1;  // image_pair.h:34-35
   Rigid3d cam2_from_cam1;
-  std::vector<int> inliers;
+  RefShimInlierList inliers;
   Eigen::MatrixXi matches;
 };
 struct Track {  // scene/track.h:12-27

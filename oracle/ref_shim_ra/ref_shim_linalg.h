@@ -5,15 +5,18 @@
 // stand-in written for this purpose, none of it reference code:
 //   VectorXd / ArrayXd            dynamic vector of doubles with the segment / array / asDiagonal expressions the file uses
 //   SparseMatrix<double>, Triplet row lists; products with diagonals, vectors and each other, evaluated eagerly
-//   CholmodSupernodalLLT          dense Cholesky of the (small) normal matrix; counts its factorisations (= IRLS iterations)
+//   CholmodSupernodalLLT          envelope Cholesky after reverse Cuthill-McKee; counts its factorisations (= IRLS iterations)
 //   AngleAxis<double>             Eigen/src/Geometry/AngleAxis.h restated: from a quaternion (2 atan2(|vec|, |w|), axis
 //                                 flipped for w < 0), from a matrix (through the quaternion), toRotationMatrix (Rodrigues)
 // What is pinned by compiling the reference against this is the reference's own logic ABOVE these types: unknown layout, rows
 // and weights of the linear system, residuals, the update on the manifold, the IRLS weights, the two convergence tests, the
 // start from the spanning tree and the conversion between image and rig rotations.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstddef>
+#include <cstdio>
+#include <cstdlib>
 #include <utility>
 #include <vector>
 
@@ -176,50 +179,123 @@ inline SparseMatrix<T> operator*(const DiagonalWrapper& D, const SparseMatrix<T>
 
 enum ComputationInfo { Success = 0, NumericalIssue = 1 };
 
-// Cholesky of a symmetric positive definite matrix given as a SparseMatrix; dense underneath (the systems of the tests have a
-// few hundred unknowns).  analyzePattern is a no-op, factorize counts itself.
+// Cholesky of a symmetric positive definite matrix given as a SparseMatrix.  Round 6: an ENVELOPE (skyline) factorisation
+// after a reverse Cuthill-McKee ordering of the pattern instead of a dense one, so that the reference's rotation averaging also
+// runs at BASELINE configs[3] size here (30 000 unknowns; a ring view graph orders to a band of a few hundred) — CHOLMOD's
+// supernodal factorisation computes the same factor up to rounding.  analyzePattern is a no-op (the ordering is computed with the
+// first factorisation and kept while the pattern's size does not change); factorize counts itself.
 template <typename M>
 struct CholmodSupernodalLLT {
   long n = 0;
-  std::vector<double> L;  // row-major lower triangle
+  std::vector<long> perm, inv;    // perm[new] = old
+  std::vector<long> first, off;   // envelope: row i (new numbering) holds columns first[i] .. i at L[off[i] ...]
+  std::vector<double> L;
   ComputationInfo info_ = Success;
   void analyzePattern(const M&) {}
   void compute(const M& A) { factorize(A); }
-  void factorize(const M& A) {
-    ++ref_shim::ra_counters().llt_factorizations;
+  void order(const M& A) {  // reverse Cuthill-McKee on the pattern, components in index order, neighbours by degree
     n = A.rows();
-    L.assign(static_cast<size_t>(n * n), 0.0);
+    std::vector<std::vector<long>> adj(static_cast<size_t>(n));
     for (long i = 0; i < n; ++i)
       for (const auto& cv : A.row[static_cast<size_t>(i)])
-        if (cv.first <= i) L[static_cast<size_t>(i * n + cv.first)] = cv.second;
+        if (cv.first != i) {
+          adj[static_cast<size_t>(i)].push_back(cv.first);
+          adj[static_cast<size_t>(cv.first)].push_back(i);
+        }
+    for (auto& a : adj) {
+      std::sort(a.begin(), a.end());
+      a.erase(std::unique(a.begin(), a.end()), a.end());
+    }
+    std::vector<char> seen(static_cast<size_t>(n), 0);
+    std::vector<long> ord;
+    ord.reserve(static_cast<size_t>(n));
+    for (long s0 = 0; s0 < n; ++s0) {
+      if (seen[static_cast<size_t>(s0)]) continue;
+      // start from a node far from s0 (one BFS sweep to a last-level node of small degree)
+      long start = s0;
+      {
+        std::vector<long> q{s0};
+        std::vector<char> vis(static_cast<size_t>(n), 0);
+        vis[static_cast<size_t>(s0)] = 1;
+        for (size_t h = 0; h < q.size(); ++h)
+          for (long w : adj[static_cast<size_t>(q[h])])
+            if (!vis[static_cast<size_t>(w)] && !seen[static_cast<size_t>(w)]) { vis[static_cast<size_t>(w)] = 1; q.push_back(w); }
+        start = q.back();
+      }
+      size_t h = ord.size();
+      ord.push_back(start);
+      seen[static_cast<size_t>(start)] = 1;
+      for (; h < ord.size(); ++h) {
+        std::vector<long> nb;
+        for (long w : adj[static_cast<size_t>(ord[h])])
+          if (!seen[static_cast<size_t>(w)]) { seen[static_cast<size_t>(w)] = 1; nb.push_back(w); }
+        std::stable_sort(nb.begin(), nb.end(), [&](long x, long y) { return adj[static_cast<size_t>(x)].size() < adj[static_cast<size_t>(y)].size(); });
+        for (long w : nb) ord.push_back(w);
+      }
+    }
+    std::reverse(ord.begin(), ord.end());
+    perm = ord;
+    inv.assign(static_cast<size_t>(n), 0);
+    for (long k = 0; k < n; ++k) inv[static_cast<size_t>(perm[static_cast<size_t>(k)])] = k;
+  }
+  void factorize(const M& A) {
+    ++ref_shim::ra_counters().llt_factorizations;
+    if (A.rows() != n || perm.empty()) order(A);
+    first.assign(static_cast<size_t>(n), 0);
+    for (long k = 0; k < n; ++k) {
+      long f = k;
+      for (const auto& cv : A.row[static_cast<size_t>(perm[static_cast<size_t>(k)])]) f = std::min(f, inv[static_cast<size_t>(cv.first)]);
+      first[static_cast<size_t>(k)] = f;
+    }
+    // (a symmetric pattern is assumed for the envelope; entries above it would be the transposes of entries inside it)
+    off.assign(static_cast<size_t>(n) + 1, 0);
+    for (long k = 0; k < n; ++k) off[static_cast<size_t>(k) + 1] = off[static_cast<size_t>(k)] + (k - first[static_cast<size_t>(k)] + 1);
+    if (std::getenv("REF_SHIM_LLT_DEBUG")) std::fprintf(stderr, "[llt] n %ld envelope %ld\n", n, off[static_cast<size_t>(n)]);
+    L.assign(static_cast<size_t>(off[static_cast<size_t>(n)]), 0.0);
+    for (long k = 0; k < n; ++k)
+      for (const auto& cv : A.row[static_cast<size_t>(perm[static_cast<size_t>(k)])]) {
+        const long j = inv[static_cast<size_t>(cv.first)];
+        if (j <= k) L[static_cast<size_t>(off[static_cast<size_t>(k)] + j - first[static_cast<size_t>(k)])] = cv.second;
+      }
     info_ = Success;
-    for (long j = 0; j < n; ++j) {
-      double d = L[static_cast<size_t>(j * n + j)];
-      for (long k = 0; k < j; ++k) d -= L[static_cast<size_t>(j * n + k)] * L[static_cast<size_t>(j * n + k)];
-      if (!(d > 0.0)) { info_ = NumericalIssue; d = std::nan(""); }
-      d = std::sqrt(d);
-      L[static_cast<size_t>(j * n + j)] = d;
-      for (long i = j + 1; i < n; ++i) {
-        double s = L[static_cast<size_t>(i * n + j)];
-        for (long k = 0; k < j; ++k) s -= L[static_cast<size_t>(i * n + k)] * L[static_cast<size_t>(j * n + k)];
-        L[static_cast<size_t>(i * n + j)] = s / d;
+    for (long i = 0; i < n; ++i) {
+      const long fi = first[static_cast<size_t>(i)];
+      double* li = &L[static_cast<size_t>(off[static_cast<size_t>(i)])];
+      for (long j = fi; j <= i; ++j) {
+        const long fj = first[static_cast<size_t>(j)];
+        const double* lj = &L[static_cast<size_t>(off[static_cast<size_t>(j)])];
+        double s = li[j - fi];
+        for (long k = std::max(fi, fj); k < j; ++k) s -= li[k - fi] * lj[k - fj];
+        if (j < i) {
+          li[j - fi] = s / lj[j - fj];
+        } else {
+          if (!(s > 0.0)) { info_ = NumericalIssue; s = std::nan(""); }
+          li[j - fi] = std::sqrt(s);
+        }
       }
     }
   }
   ComputationInfo info() const { return info_; }
   VectorXd solve(const VectorXd& b) const {
-    VectorXd y = b;
-    for (long i = 0; i < n; ++i) {
-      double s = y.a[static_cast<size_t>(i)];
-      for (long k = 0; k < i; ++k) s -= L[static_cast<size_t>(i * n + k)] * y.a[static_cast<size_t>(k)];
-      y.a[static_cast<size_t>(i)] = s / L[static_cast<size_t>(i * n + i)];
+    std::vector<double> y(static_cast<size_t>(n));
+    for (long k = 0; k < n; ++k) y[static_cast<size_t>(k)] = b.a[static_cast<size_t>(perm[static_cast<size_t>(k)])];
+    for (long i = 0; i < n; ++i) {  // L y = b
+      const long fi = first[static_cast<size_t>(i)];
+      const double* li = &L[static_cast<size_t>(off[static_cast<size_t>(i)])];
+      double s = y[static_cast<size_t>(i)];
+      for (long k = fi; k < i; ++k) s -= li[k - fi] * y[static_cast<size_t>(k)];
+      y[static_cast<size_t>(i)] = s / li[i - fi];
     }
-    for (long i = n - 1; i >= 0; --i) {
-      double s = y.a[static_cast<size_t>(i)];
-      for (long k = i + 1; k < n; ++k) s -= L[static_cast<size_t>(k * n + i)] * y.a[static_cast<size_t>(k)];
-      y.a[static_cast<size_t>(i)] = s / L[static_cast<size_t>(i * n + i)];
+    for (long i = n - 1; i >= 0; --i) {  // L^T x = y, column sweep over the row storage
+      const long fi = first[static_cast<size_t>(i)];
+      const double* li = &L[static_cast<size_t>(off[static_cast<size_t>(i)])];
+      const double xi = y[static_cast<size_t>(i)] / li[i - fi];
+      y[static_cast<size_t>(i)] = xi;
+      for (long k = fi; k < i; ++k) y[static_cast<size_t>(k)] -= li[k - fi] * xi;
     }
-    return y;
+    VectorXd x(static_cast<size_t>(n));
+    for (long k = 0; k < n; ++k) x.a[static_cast<size_t>(perm[static_cast<size_t>(k)])] = y[static_cast<size_t>(k)];
+    return x;
   }
 };
 template <typename M>

@@ -9,6 +9,7 @@ cases take minutes of CPU there (dense Cholesky stand-in for CHOLMOD), so their 
                              depends on Boost's priority queue (a different tree moves the end point by 6e-5 rad: the IRLS
                              loop stops at a mean step of 1e-3 rad): the counts are made distinct in the order this
                              library breaks ties (synthetic.break_inlier_ties_by_index), which leaves its own result unchanged
+  ra_c4_reference_code.npz   BASELINE configs[3]'s view graph (10 000 cameras / 500 000 relative rotations), the same way
   gp_start_reference_code.npz  BASELINE configs[2] size (5 000 cameras / 500 000 tracks / 3.0 M observations, seed 0):
                              GlobalPositioner::Solve on the recording Ceres -> the walk orders of its hash maps (= its draw
                              order) and the initial cost of its random start  (13 s, 2.2 GB)
@@ -41,6 +42,23 @@ def ra_c2():
     print("ra_c2", N, len(p.edge_i), f"{time.time() - t0:.1f} s", {k: v for k, v in r.items() if not hasattr(v, "shape")})
     np.savez_compressed(OUT / "ra_c2_reference_code.npz", frame_q=r["frame_q"], fixed_image=r["fixed_image"], tree_root=r["tree_root"],
                         l1_iterations=r["l1_iterations"], irls_iterations=r["irls_iterations"], admm_iterations=r["admm_iterations"])
+
+
+def ra_c4():
+    """BASELINE configs[3]'s view graph (10 000 cameras / 500 000 relative rotations, seed 0) through the reference's own
+    RotationEstimator::EstimateRotations (round 6: the CHOLMOD stand-in factors an envelope after reverse Cuthill-McKee, so the
+    30 000-unknown systems of gra.cc:543-625 are tractable here) -> ra_c4_reference_code.npz, with the wall time of the run."""
+    p = synthetic.make_ring_view_graph(10_000, 50, seed=0)
+    N = p.num_nodes
+    t0 = time.time()
+    r = ref.ra_estimate([0], np.zeros(N), np.arange(N), np.zeros(N), p.edge_i, p.edge_j, p.edge_q, pair_weight=p.edge_weight,
+                        pair_ninl=synthetic.break_inlier_ties_by_index(p.edge_ninl), frame_q=so3.aa_to_quat(p.node_aa0))
+    sec = time.time() - t0
+    assert r["ok"]
+    print("ra_c4", N, len(p.edge_i), f"{sec:.1f} s", {k: v for k, v in r.items() if not hasattr(v, "shape")})
+    np.savez_compressed(OUT / "ra_c4_reference_code.npz", frame_q=r["frame_q"], fixed_image=r["fixed_image"], tree_root=r["tree_root"],
+                        l1_iterations=r["l1_iterations"], irls_iterations=r["irls_iterations"], admm_iterations=r["admm_iterations"],
+                        seconds_one_thread=sec)
 
 
 def gp_start():

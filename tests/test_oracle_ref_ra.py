@@ -26,7 +26,7 @@ from oracle import ref
 
 pytestmark = pytest.mark.skipif(ref.load_ra() is None, reason="neither /root/reference nor a prebuilt oracle/_ref/libref_glomap_ra.so")
 
-TOL = 1e-10  # rad; the two sides differ by the order of their sums only
+TOL = 1e-9  # rad (1e-10 until the stand-in factorisation became an envelope Cholesky: another elimination order, 4e-10 on the L1-only case)
 
 
 def _dist(q_a, q_b):

@@ -239,6 +239,30 @@ def test_ra_config2_equals_the_reference_code(gsfm_ctx):
     assert d.max() < 1e-6
 
 
+def test_ra_config4_equals_the_reference_code(gsfm_ctx):
+    """BASELINE configs[3]'s view graph (10 000 cameras / 500 000 relative rotations) — the size at which the HIP path runs its
+    substructured PCG instead of the dense direct solve: against the rotations the reference's own
+    RotationEstimator::EstimateRotations returned (global_rotation_averaging.cc:543-625 on 30 000-unknown systems; round 6: the
+    CHOLMOD stand-in factors an envelope, tests/golden/make_reference_code_golden.py ra_c4, 17 s on one thread)."""
+    g = _golden("ra_c4_reference_code.npz")
+    p = synthetic.make_ring_view_graph(10_000, 50, seed=0)
+    N = p.num_nodes
+    f = int(g["fixed_image"])
+    assert int(g["tree_root"]) == f
+    lab = np.arange(N)
+    lab[[0, f]] = lab[[f, 0]]
+    inv = np.empty(N, np.int64)
+    inv[lab] = np.arange(N)
+    pg = RaProblem(N, inv[p.edge_i].astype(np.int32), inv[p.edge_j].astype(np.int32), p.edge_q, p.edge_weight, p.edge_ninl, p.node_aa0[lab], 0)
+    rc, rot, rep = estimators.ra_solve(pg, ctx=gsfm_ctx)
+    assert rc == 0
+    assert (rep["iterations_l1"], rep["iterations_irls"]) == (int(g["l1_iterations"]), int(g["irls_iterations"]))
+    d = _dist(so3.aa_to_quat(rot), g["frame_q"][lab])
+    print(f"[parity] RA configs[3] vs REFERENCE CODE: L1 {rep['iterations_l1']} IRLS {rep['iterations_irls']} both, max {d.max():.2e} rad (bar 1e-4); "
+          f"reference code took {float(g['seconds_one_thread']):.1f} s on one thread of the build container")
+    assert d.max() < 1e-6
+
+
 def test_gp_config3_start_equals_the_reference_code(gsfm_ctx):
     """BASELINE configs[2] size: the cost of the reference's random start, 3.0 M BATA residuals summed by reference code on the
     recording Ceres, against the HIP path's initial cost for the same draw orders."""
