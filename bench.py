@@ -197,6 +197,7 @@ def run_extras(env, args, world, rank, main_line):
             ("ra_c4_non_ring_graphs", lambda: bench_ra_nonring(ctx)),
             ("track_filters_c3", lambda: bench_filters(ctx)),
             ("track_establishment_c3", lambda: bench_tracks(ctx, no_cpu=True)),
+            ("chain_c4", lambda: bench_chain(ctx)),
         )
         for name, fn in jobs:
             try:
@@ -214,6 +215,58 @@ def run_extras(env, args, world, rank, main_line):
             emit_result(main_line)
         os._exit(0)
     return extra
+
+
+def bench_chain(ctx, ncam=10_000, npts=1_000_000):
+    """What GlobalMapper::Solve actually runs between its first rotation averaging and the end of its first bundle-adjustment
+    round (global_mapper.cc:92-223), chained on ONE configs[3]-size scene, every stage started from the previous stage's result:
+    RA -> GP (bearings oriented by RA's rotations, random start) -> FilterTracksByAngle / FilterTrackTriangulationAngle /
+    FilterTracksByReprojection(10 x) -> NormalizeReconstruction -> BA positions-only -> BA with rotations (driver
+    tests/chain_util.py, the one the parity tests use).  The headline step times the three estimators on three independent
+    inputs; this is the same work with the processors inside the timed region and BA starting where GP ended.  Stage times
+    are wall times of the calls through the C ABI with HOST arrays (one H2D / D2H per stage, the drop-in case); `solve_ms` is
+    the library's own time of the solve proper.  Second of two runs (the first grows the workspaces)."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import chain_util
+    from glomap_amd import synthetic
+
+    sc = synthetic.make_chained_scene(ncam, npts, seed=0)
+    stages = {}
+
+    class Timed(chain_util.GpuBackend):
+        pass
+
+    def wrap(name):
+        fn = getattr(chain_util.GpuBackend, name)
+
+        def timed(self, *a, **k):
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            out = fn(self, *a, **k)
+            ctx.synchronize()
+            stages.setdefault(name, []).append(1e3 * (time.perf_counter() - t0))
+            return out
+
+        setattr(Timed, name, timed)
+
+    for name in ("ra", "gp", "filter_angle", "filter_triangulation", "filter_reprojection", "normalize", "ba"):
+        wrap(name)
+    res = None
+    for _ in range(2):
+        stages.clear()
+        t0 = time.perf_counter()
+        res = chain_util.run_chain(sc, Timed(ctx))
+        wall = 1e3 * (time.perf_counter() - t0)
+    est = sum(sum(v) for k, v in stages.items())
+    return {"cameras": ncam, "tracks": npts, "observations": int(sc.obs_cam.shape[0]),
+            "ms_stage_calls": {k: [round(x, 2) for x in v] for k, v in stages.items()},
+            "ms_estimators_and_processors": round(est, 1), "ms_wall_including_host_glue": round(wall, 1),
+            "observations_kept": res["observations_kept"],
+            "iterations": {"ra": res["rep_ra"], "gp_lm": res["rep_gp"]["iterations"], "gp_pcg": res["rep_gp"]["linear_iterations"],
+                           "ba1_lm": res["rep_ba1"]["iterations"], "ba1_pcg": res["rep_ba1"]["linear_iterations"],
+                           "ba2_lm": res["rep_ba2"]["iterations"], "ba2_pcg": res["rep_ba2"]["linear_iterations"]},
+            "note": "host glue between the stages (numpy compaction of the filtered observations, bearing rotation) is in the wall time, "
+                    "not in the stage sum; the device-resident variant of the BA outer loop is tests/test_pipeline_gpu.py::test_ba_outer_loop_device_resident"}
 
 
 def timed_steps(step_fn, steps, warmup, barrier, dist):

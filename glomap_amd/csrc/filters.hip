@@ -565,10 +565,11 @@ extern "C" int gsfm_tracks_compact(gsfm_ctx* ctx, int32_t mem, int64_t num_pts, 
     long* off = reinterpret_cast<long*>(pt_offset_inout);
     if (mem != GSFM_MEM_DEVICE) {  // host arrays: a plain loop (nothing here is worth a round trip over PCIe)
       GSFM_REQUIRE(off[0] == 0 && off[P] == M, "compact: pt_offset does not span the observations");
+      for (long p = 0; p < P; ++p)  // validate BEFORE the first write: a malformed table must leave the caller's arrays untouched
+        GSFM_REQUIRE(off[p] <= off[p + 1] && off[p + 1] <= M, "compact: pt_offset not monotone");
       long w = 0;
       for (long p = 0; p < P; ++p) {
         const long k0 = off[p], k1 = off[p + 1];
-        GSFM_REQUIRE(k0 <= k1 && k1 <= M, "compact: pt_offset not monotone");
         off[p] = w;
         for (long k = k0; k < k1; ++k) {
           if ((obs_keep != nullptr && obs_keep[k] == 0) || (track_keep != nullptr && track_keep[p] == 0)) continue;

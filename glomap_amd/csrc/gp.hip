@@ -2669,6 +2669,9 @@ int gp_solve_impl(gsfm_ctx* ctx, const gsfm_gp_problem* prob, const gsfm_gp_opti
                   double* pt_xyz, gsfm_report* rep) {
   GSFM_REQUIRE(prob && opt && cam_center && (pt_xyz || prob->num_pts == 0), "GP: null argument");
   GSFM_REQUIRE(opt->constraint_type >= 0 && opt->constraint_type <= 3, "GP: constraint_type out of range");
+  GSFM_REQUIRE(opt->rand_vector_order == 0 || opt->rand_vector_order == 1,
+               "GP: rand_vector_order must be 0 or 1 (options structs come from gsfm_gp_options_default, problem structs zero-initialised)");
+  GSFM_REQUIRE(opt->lm.max_num_line_search_step_size_iterations >= 0, "GP: max_num_line_search_step_size_iterations negative");
   if (prob->num_cams <= 0) throw StatusError(GSFM_ERR_EMPTY_PROBLEM, "GP: no images");   // gp.cc:37-40
   if (opt->constraint_type != 0 && prob->num_pairs <= 0)
     throw StatusError(GSFM_ERR_EMPTY_PROBLEM, "GP: no camera-to-camera constraints");  // gp.cc:41-45

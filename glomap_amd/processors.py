@@ -17,7 +17,7 @@ from typing import Optional
 import numpy as np
 
 from . import _lib
-from .estimators import _h, _mem_of, default_context
+from .estimators import _h, _is_dev, _mem_of, default_context
 
 
 @dataclass
@@ -124,6 +124,11 @@ def CompactObservations(pt_offset, arrays, obs_keep=None, track_keep=None, ctx=N
     ok_, tk_ = _h(obs_keep, np.uint8), _h(track_keep, np.uint8)
     M = int(arrs[0].shape[0]) if arrs else int(off.numpy()[-1] if not isinstance(off, np.ndarray) else off[-1])
     P = int(off.shape[0]) - 1
+    # the library trusts these lengths: check them here
+    assert all(int(a.shape[0]) == M for a in arrs), "every per-observation array needs M rows"
+    assert ok_ is None or int(ok_.shape[0]) == M, "obs_keep needs one byte per observation"
+    assert tk_ is None or int(tk_.shape[0]) == P, "track_keep needs one byte per track"
+    assert len({_is_dev(a) for a in (off, ok_, tk_, *arrs) if a is not None}) == 1, "host and device arrays mixed"
     nbytes = [int(np.prod(a.shape[1:], dtype=np.int64)) * np.dtype(a.dtype).itemsize for a in arrs]
     ptrs = (C.c_void_p * max(1, len(arrs)))(*[_lib.ptr(a) for a in arrs])
     eb = (C.c_int32 * max(1, len(arrs)))(*nbytes)

@@ -26,7 +26,7 @@ from glomap_amd.scene import Rigid3d
 from oracle import ref
 from test_rotation_averager_policy import OracleBackend, _errors_deg, make_scene
 
-pytestmark = pytest.mark.skipif(ref.load_dropin() is None, reason="neither /root/reference + libgsfm.so nor a prebuilt oracle/_ref/libref_dropin_ra.so")
+pytestmark = pytest.mark.skipif(ref.load_dropin() is None, reason="oracle/_ref: neither /root/reference + libgsfm.so nor a prebuilt oracle/_ref/libref_dropin_ra.so")
 
 
 def _flat(vg, rigs, frames, images):

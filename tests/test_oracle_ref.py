@@ -18,7 +18,7 @@ import pytest
 from glomap_amd import synthetic
 from oracle import ref, tracks as ot
 
-pytestmark = pytest.mark.skipif(ref.load() is None, reason="neither /root/reference nor a prebuilt oracle/_ref/libref_glomap.so")
+pytestmark = pytest.mark.skipif(ref.load() is None, reason="oracle/_ref: neither /root/reference nor a prebuilt oracle/_ref/libref_glomap.so")
 
 
 def _random_view_graph(rng, num_frames, images_per_frame, comps, p_invalid):

@@ -17,7 +17,7 @@ from glomap_amd import synthetic
 from oracle import ba as oba
 from oracle import ref
 
-pytestmark = pytest.mark.skipif(ref.load_ba() is None, reason="neither /root/reference nor a prebuilt oracle/_ref/libref_glomap_ba.so")
+pytestmark = pytest.mark.skipif(ref.load_ba() is None, reason="oracle/_ref: neither /root/reference nor a prebuilt oracle/_ref/libref_glomap_ba.so")
 
 IN, ROT_CONST, TRN_CONST, QUAT, GROUP0, NO_GROUP = 1, 2, 4, 8, 16, 32
 SPARSE_SCHUR, CLUSTER_TRIDIAGONAL = 4, 4  # ceres/types.h order, ba.cc:98-99

@@ -24,7 +24,7 @@ from glomap_amd import estimators, so3, synthetic
 from oracle import ra as ora
 from oracle import ref
 
-pytestmark = pytest.mark.skipif(ref.load_ra() is None, reason="neither /root/reference nor a prebuilt oracle/_ref/libref_glomap_ra.so")
+pytestmark = pytest.mark.skipif(ref.load_ra() is None, reason="oracle/_ref: neither /root/reference nor a prebuilt oracle/_ref/libref_glomap_ra.so")
 
 TOL = 1e-9  # rad (1e-10 until the stand-in factorisation became an envelope Cholesky: another elimination order, 4e-10 on the L1-only case)
 

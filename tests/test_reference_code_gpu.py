@@ -21,7 +21,7 @@ from oracle import ref
 
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(ref.load_ra() is None or ref.load_gp() is None or ref.load_ba() is None,
-                                 reason="oracle/_ref libraries not built (they come with the snapshot)")]
+                                 reason="oracle/_ref: libraries not built (they come with the snapshot)")]
 
 
 def _dist(q_a, q_b):
