@@ -483,7 +483,9 @@ def bench_pipeline(args, ctx, rank, world, barrier, dist):
     value = M_ba * args.steps / dt
     # ---- roofline: one extra, event-instrumented step; the four sweep kernels of the PCG iterations, the one with the
     # most time per step in front
+    ctx.stats(reset=True)  # the solver-path counters of ONE step (config.solver_paths)
     profiled_step(ctx, KERNEL_BA, step, also=(KERNEL_BA_B, KERNEL_GP, KERNEL_GP_B, KERNEL_GP_WSUM), read=False)
+    paths = ctx.stats()
     Mg, Pg, Mb, Pb = g_loc.num_obs, g_loc.num_pts, b_loc.num_obs, b_loc.num_pts
     F = 2  # free intrinsics columns stored per observation (SIMPLE_RADIAL: f, k)
     lines = [
@@ -551,6 +553,9 @@ def bench_pipeline(args, ctx, rank, world, barrier, dist):
                        "ra_pcg": rep["ra"]["linear_iterations"], "gp_lm": rep["gp"]["iterations"],
                        "gp_pcg": rep["gp"]["linear_iterations"], "ba_lm": rep["ba"]["iterations"],
                        "ba_lm_accepted": rep["ba"]["successful_steps"], "ba_pcg": rep["ba"]["linear_iterations"]},
+        # which linear-solver paths one step took (gsfm_ctx_stats): reduced solves, how many were deflated / ran with recycled
+        # Ritz vectors in the preconditioner, Ritz vectors harvested, chunked sweeps
+        "solver_paths": paths,
         "final_cost": {"gp": rep["gp"]["final_cost"], "ba": rep["ba"]["final_cost"]},
         "vs_ground_truth": {"ra_median_rot_err_deg": float(np.median(err_ra)),
                             "gp_median_center_err_rel": float(np.median(err_gp)),  # relative to the GT extent (helper divides ONCE)

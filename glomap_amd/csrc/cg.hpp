@@ -41,6 +41,8 @@ constexpr int kCgMaxBlocks = 512;  // partial-slot capacity of the vector kernel
 constexpr int kCgUpdateBlocks = 128;  // their grid: every block re-reduces the slots of all blocks, so few, fat blocks
 constexpr int kCgMaxModes = 8;     // deflated modes per solve (CgDeflation)
 constexpr int kMaxApplySlots = 4096;  // cap of the delta partial slots one apply kernel may write
+constexpr int kCgMaxRecycle = 16;  // recycled Ritz vectors in the additive coarse space of a solve (CgRecycle)
+constexpr int kCgHistCap = 128;    // Lanczos steps of a solve that are recorded for the next harvest
 
 struct CgStatus {
   int done;
@@ -70,7 +72,7 @@ struct CgVec {
   double tol2 = 0.0;  // squared relative tolerance (single mode: tested inside k_cg_update1)
   const double* b = nullptr;
   double *x = nullptr, *r = nullptr, *z = nullptr, *p = nullptr, *s = nullptr;
-  double* w = nullptr;         // [n + 2]
+  double* w = nullptr;         // [n + 2]; [n + 1 + kCgMaxRecycle] where a CgRecycle is passed to cg_solve
   const double* minv = nullptr;
   double* vpart = nullptr;     // [2][kCgMaxBlocks][2]  (r.z, r.r) partials, double-buffered by iteration parity
   double* dpart = nullptr;     // [nb_apply] delta partials
@@ -100,6 +102,17 @@ struct CgVec {
   const double* dAW = nullptr;     // [dk][n]
   const double* dsmall = nullptr;  // E^-1 [8][8] | y0 [8] | ok
   double* dcd = nullptr;           // [2][kCgMaxBlocks][2 * kCgMaxModes]: ((A W)^T z | W^T r) partials by iteration parity
+  // recycled Ritz vectors, device view (rk == 0: none); set by cg_solve from a CgRecycle.  z = M^-1 r + sum_j u_j (u_j.r) / theta_j
+  int rk = 0;                      // slots in use: 0 .. rk-1 (an empty slot has rcoef == 0)
+  int rhist = 0;                   // record this solve's Lanczos history (zhist, hist)
+  int r_nslots = 0;                // partial slots of u_j . w the apply kernels write per iteration
+  const double* rU = nullptr;      // [kCgMaxRecycle][n]
+  const double* rG = nullptr;      // [kCgMaxRecycle][kCgMaxModes]: u_j . (A W_i) of this solve's deflated modes
+  double* rstate = nullptr;        // [2][2 kCgMaxRecycle]: (c_j = u_j . r | u_j . s) by iteration parity
+  double* ruw = nullptr;           // [r_nslots][kCgMaxRecycle] partials of u_j . w, written by the last apply kernel
+  double* zhist = nullptr;         // [kCgHistCap][n]: the projected z of iteration it
+  double* hist = nullptr;          // [kCgHistCap][2]: (gamma, alpha) of iteration it
+  double rcoef[kCgMaxRecycle] = {};  // 1 / theta_j
 };
 
 // ---- deflation, per-element pieces (all no-ops for v.dk == 0) ----------------------------------------------------
@@ -109,9 +122,12 @@ struct CgStep {
   double gamma, delta, alpha, beta;
   bool ok;
   double y[kCgMaxModes];
+  double a[kCgMaxRecycle];  // coefficients of the recycled vectors in the NEW z: (u_j . r_new) / theta_j
 };
 
-constexpr int kCgStepSmem = 8 * 32 + 32 + 16 + kCgMaxModes * kCgMaxModes;
+constexpr int kCgStepSmemBase = 8 * 32 + 32 + 16 + kCgMaxModes * kCgMaxModes;
+// + recycled vectors: [64][16] group partials of u_j . w | [16] a_j | [2 x 16] previous (c_j, u_j . s) | [16][8] G
+constexpr int kCgStepSmem = kCgStepSmemBase + 64 * kCgMaxRecycle + kCgMaxRecycle + 2 * kCgMaxRecycle + kCgMaxRecycle * kCgMaxModes;
 
 // Prologue of the vector update of iteration `it`: totals of all partial slots (r.z | r.r of the previous update, delta of
 // this apply, the 2k deflation dot products), then alpha / beta.  Returns false when the solve is finished.
@@ -139,6 +155,27 @@ __device__ __forceinline__ bool cg_step_prologue(const CgVec& v, int it, CgStep&
   double* stot = smem + 8 * 32;      // [32] totals (column 2 = delta)
   double* sb = smem + 8 * 32 + 32;   // [16] the step's scalars
   double* sE = sb + 16;              // E^-1, staged by the first 64 threads
+  double* su = smem + kCgStepSmemBase;          // [64][kCgMaxRecycle] group partials of u_j . w
+  double* sa = su + 64 * kCgMaxRecycle;         // [kCgMaxRecycle] a_j
+  double* sc = sa + kCgMaxRecycle;              // [2 kCgMaxRecycle] (c_j | u_j . s) of the previous iteration
+  double* sG = sc + 2 * kCgMaxRecycle;          // [kCgMaxRecycle][kCgMaxModes]
+  typedef double cg_d4v __attribute__((ext_vector_type(4)));
+  cg_d4v ucol = {0.0, 0.0, 0.0, 0.0};
+  double uwd = 0.0;  // multi-rank: the all-reduced u_j . w arrived behind delta in w[n + 1 + j]
+  if (v.rk && v.delta_in_w) {
+    if (threadIdx.x < kCgMaxRecycle) uwd = v.w[v.n + 1 + threadIdx.x];
+    if (threadIdx.x < 2 * kCgMaxRecycle) sc[threadIdx.x] = v.rstate[(size_t)par * 2 * kCgMaxRecycle + threadIdx.x];
+    if (threadIdx.x < kCgMaxRecycle * kCgMaxModes) sG[threadIdx.x] = v.dk ? v.rG[threadIdx.x] : 0.0;
+  } else if (v.rk) {
+    // a slot row is 16 doubles: thread (group = threadIdx >> 2, quarter = threadIdx & 3) adds its 32-byte quarter of the rows
+    // b = group (mod 64) — wide loads, all in flight together: the slots are one or two round trips, not one per row
+    const int uq = threadIdx.x & 3, ug = threadIdx.x >> 2;
+    const cg_d4v* rows = reinterpret_cast<const cg_d4v*>(v.ruw);
+#pragma unroll 4
+    for (int b = ug; b < v.r_nslots; b += (int)(blockDim.x >> 2)) ucol += rows[(size_t)b * (kCgMaxRecycle / 4) + uq];
+    if (threadIdx.x < 2 * kCgMaxRecycle) sc[threadIdx.x] = v.rstate[(size_t)par * 2 * kCgMaxRecycle + threadIdx.x];
+    if (threadIdx.x < kCgMaxRecycle * kCgMaxModes) sG[threadIdx.x] = v.dk ? v.rG[threadIdx.x] : 0.0;
+  }
   if (v.dk && threadIdx.x < kCgMaxModes * kCgMaxModes) sE[threadIdx.x] = v.dsmall[threadIdx.x];
   const double dok = v.dk ? v.dsmall[72] : 0.0;
   const CgScal prev = v.scal[par];
@@ -146,6 +183,13 @@ __device__ __forceinline__ bool cg_step_prologue(const CgVec& v, int it, CgStep&
   const int done = v.st->done;
   if (done) return false;
   sg[g * 32 + l] = col;
+  if (v.rk && !v.delta_in_w) {  // su[group][4 quarter + e]
+    double* d = su + (threadIdx.x >> 2) * kCgMaxRecycle + 4 * (threadIdx.x & 3);
+    d[0] = ucol.x;
+    d[1] = ucol.y;
+    d[2] = ucol.z;
+    d[3] = ucol.w;
+  }
   dl = wave_sum_dpp(dl);
   __syncthreads();
   if ((threadIdx.x & 63) == 63) sg[(threadIdx.x >> 6) * 32 + 2] = dl;  // column 2 of groups 0..3: the waves' delta sums
@@ -191,6 +235,34 @@ __device__ __forceinline__ bool cg_step_prologue(const CgVec& v, int it, CgStep&
 #pragma unroll
     for (int i = 0; i < kCgMaxModes; ++i) sb[5 + i] = y[i];
   }
+  if (v.rk) {
+    // u_j . r by recurrence: s_new = w_p + beta s, r_new = r - alpha s_new, with u_j . w_p = u_j . w - sum_i y_i u_j . (A W_i)
+    // (rounding drift in c_j only perturbs the preconditioner, not the system); thread j owns vector j
+    __syncthreads();
+    if (threadIdx.x < kCgMaxRecycle) {
+      const int j = threadIdx.x;
+      const bool ok = sb[4] != 0.0;
+      const double al = sb[2], be = sb[3];
+      double cn = 0.0, csn = 0.0;
+      if (j < v.rk) {
+        double uw = uwd;
+        if (!v.delta_in_w) {
+#pragma unroll 8
+          for (int q = 0; q < 64; ++q) uw += su[q * kCgMaxRecycle + j];
+        }
+#pragma unroll
+        for (int i = 0; i < kCgMaxModes; ++i) uw -= sb[5 + i] * sG[j * kCgMaxModes + i];
+        csn = uw + be * sc[kCgMaxRecycle + j];
+        cn = sc[j] - al * csn;
+      }
+      sa[j] = ok ? cn * v.rcoef[j] : 0.0;
+      if (blockIdx.x == 0 && ok) {
+        double* nxt = v.rstate + (size_t)((it + 1) & 1) * 2 * kCgMaxRecycle;
+        nxt[j] = cn;
+        nxt[kCgMaxRecycle + j] = csn;
+      }
+    }
+  }
   __syncthreads();
   o.gamma = sb[0];
   o.delta = sb[1];
@@ -199,6 +271,8 @@ __device__ __forceinline__ bool cg_step_prologue(const CgVec& v, int it, CgStep&
   o.ok = sb[4] != 0.0;
 #pragma unroll
   for (int i = 0; i < kCgMaxModes; ++i) o.y[i] = sb[5 + i];
+#pragma unroll
+  for (int j = 0; j < kCgMaxRecycle; ++j) o.a[j] = v.rk ? sa[j] : 0.0;
   __syncthreads();
   return true;
 }
@@ -269,6 +343,10 @@ __device__ __forceinline__ void cg_step_epilogue(const CgVec& v, int it, const C
     if (blockIdx.x == 0) {
       v.scal[par].gamma = o.gamma;
       v.scal[par].alpha = o.alpha;
+      if (v.rhist && it < kCgHistCap) {  // Lanczos coefficients of this step (ritz.hpp)
+        v.hist[2 * it] = o.gamma;
+        v.hist[2 * it + 1] = o.alpha;
+      }
     }
   }
   // gamma == 0 with a zero residual is plain convergence, anything else is a breakdown
@@ -377,7 +455,7 @@ template <int BS, bool DEFL = true>
 __device__ __forceinline__ void cg_block_update(const CgVec& v, long o, const double* __restrict__ m, double alpha,
                                                 double beta, double& rz, double& rr,
                                                 const double (&y)[kCgMaxModes], double (&cd)[2 * kCgMaxModes],
-                                                double* __restrict__ mir = nullptr) {
+                                                double* __restrict__ mir = nullptr, const double* ra = nullptr, int it = 0) {
   double zi[BS], wi[BS], pi[BS], si[BS], xi[BS], ri[BS], mm[BS * BS];
 #pragma unroll
   for (int i = 0; i < BS; ++i) {
@@ -418,6 +496,18 @@ __device__ __forceinline__ void cg_block_update(const CgVec& v, long o, const do
         Wv[i][j] = j < v.dk ? v.dW[(size_t)j * v.n + o + i] : 0.0;
         AWv[i][j] = j < v.dk ? v.dAW[(size_t)j * v.n + o + i] : 0.0;
       }
+    // recycled Ritz vectors: the coarse part of the new z (loads issued here, before the first store below)
+    double uz[BS];
+#pragma unroll
+    for (int i = 0; i < BS; ++i) uz[i] = 0.0;
+    if (ra != nullptr && v.rk) {
+#pragma unroll
+      for (int j = 0; j < kCgMaxRecycle; ++j)
+        if (j < v.rk) {
+#pragma unroll
+          for (int i = 0; i < BS; ++i) uz[i] += ra[j] * v.rU[(size_t)j * v.n + o + i];
+        }
+    }
 #pragma unroll
     for (int i = 0; i < BS; ++i) {
 #pragma unroll
@@ -433,9 +523,13 @@ __device__ __forceinline__ void cg_block_update(const CgVec& v, long o, const do
 #pragma unroll
       for (int j = 0; j < kCgMaxModes; ++j) cd[kCgMaxModes + j] += Wv[i][j] * rn[i];
     }
+    if (v.rhist && it < kCgHistCap) {  // the projected z this step used: Lanczos vector `it` up to its norm
+#pragma unroll
+      for (int i = 0; i < BS; ++i) v.zhist[(size_t)it * v.n + o + i] = zi[i];
+    }
 #pragma unroll
     for (int i = 0; i < BS; ++i) {
-      double t = 0.0;
+      double t = uz[i];
 #pragma unroll
       for (int j = 0; j < BS; ++j) t += mm[i * BS + j] * rn[j];
       zn[i] = t;
@@ -489,7 +583,7 @@ static __global__ void __launch_bounds__(kBlock) k_cg_update(CgVec v, int it) {
     for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += gridDim.x * blockDim.x) {
       if (b < v.N) {
         cg_block_update<PB>(v, (long)PB * b, v.minv + (long)PB * PB * b, st.alpha, st.beta, acc[0], acc[1], st.y, cd,
-                            v.zmir ? v.zmir + (long)b * v.zmir_stride + v.zmir_off : nullptr);
+                            v.zmir ? v.zmir + (long)b * v.zmir_stride + v.zmir_off : nullptr, st.a, it);
       } else if constexpr (HAS_INTR) {
         const int k = b - v.N;
         cg_block_update<IW>(v, (long)PB * v.N + (long)IW * k, v.minv + (long)PB * PB * v.N + (long)(IW * IW) * k, st.alpha, st.beta,
@@ -755,13 +849,34 @@ static __global__ void __launch_bounds__(kBlock) k_cg_update_joint(CgVec v, int 
   cg_step_epilogue(v, it, st, acc[0], acc[1], cd, smem);
 }
 
-// Single-block reduction of the delta partials into w[n] (multi-rank: w[0..n] is all-reduced next).
+// Single-block reduction of the delta partials into w[n] (multi-rank: w[0..n] is all-reduced next) and, with recycled Ritz
+// vectors in the preconditioner, of this rank's u_j . w slots into w[n + 1 + j]: the dot products travel with w.
 static __global__ void __launch_bounds__(kBlock) k_cg_delta_to_w(CgVec v) {
   __shared__ double smem[4 + 1];
+  __shared__ double su[64][kCgMaxRecycle];
   if (v.st->done) return;
   double d[1];
   reduce_partials<1>(v.dpart, v.nb_apply, d, smem);
   if (threadIdx.x == 0) v.w[v.n] = d[0];
+  if (v.rk) {
+    typedef double cg_d4v __attribute__((ext_vector_type(4)));
+    cg_d4v ucol = {0.0, 0.0, 0.0, 0.0};
+    const int uq = threadIdx.x & 3, ug = threadIdx.x >> 2;
+    const cg_d4v* rows = reinterpret_cast<const cg_d4v*>(v.ruw);
+#pragma unroll 4
+    for (int b = ug; b < v.r_nslots; b += (int)(blockDim.x >> 2)) ucol += rows[(size_t)b * (kCgMaxRecycle / 4) + uq];
+    su[ug][4 * uq] = ucol.x;
+    su[ug][4 * uq + 1] = ucol.y;
+    su[ug][4 * uq + 2] = ucol.z;
+    su[ug][4 * uq + 3] = ucol.w;
+    __syncthreads();
+    if (threadIdx.x < kCgMaxRecycle) {
+      double t = 0.0;
+#pragma unroll 8
+      for (int q = 0; q < 64; ++q) t += su[q][threadIdx.x];
+      v.w[v.n + 1 + threadIdx.x] = t;
+    }
+  }
 }
 
 
@@ -925,6 +1040,137 @@ static __global__ void __launch_bounds__(kBlock) k_cgd_finish(CgVec v, CgDeflati
   }
 }
 
+// ---- recycled Ritz vectors as an additive coarse space (CgRecycle; host side: ritz.hpp) --------------------------------
+// The solves of one LM problem are a sequence of slowly changing systems, and what block-Jacobi leaves slow in one of them
+// (global positioning at configs[3]: a tail of eigenvalues 0.01 ... 0.1 under a bulk in [0.2, 2]) is still slow in the next.
+// A PCG solve computes the Lanczos coefficients of its own preconditioned operator for free; their small Ritz pairs
+// (theta_j, u_j) are harvested after the solve (k_cgr_harvest forms u_j from the recorded z's) and the NEXT solves run with
+//     M2^-1 = M^-1 + sum_j u_j u_j^T / theta_j
+// — a fixed SPD preconditioner for the same system, the same right-hand side and the same stopping rule |r| <= tol |b|, so the
+// solution is the same to the tolerance; (theta, u) are one or more linearisations old, which only costs preconditioner
+// quality (CPU study on the C++ oracle, tools/exp_gp_ritz_recycle.py: 2 204 -> 1 646 iterations per GP solve of configs[3]).
+// No launch is added to an iteration: u_j . r follows from the recurrence r_new = r - alpha (w_p + beta s) with the dot
+// products u_j . w written as partial slots by the apply kernel that completes w (cg_step_prologue sums them), and the
+// coarse part of the new z is added where k_cg_update forms M^-1 r_new anyway.
+struct CgRecycle {
+  int k = 0;                       // slots 0 .. k-1 may be in use
+  double coef[kCgMaxRecycle] = {}; // 1 / theta_j, 0 for an empty slot
+  double* U = nullptr;             // [kCgMaxRecycle][n]
+  double* G = nullptr;             // [kCgMaxRecycle][kCgMaxModes]
+  double* state = nullptr;         // [2][2 kCgMaxRecycle]
+  double* uw = nullptr;            // [nslots][kCgMaxRecycle]: the apply kernels write these when v.rk != 0
+  int nslots = 0;
+  double* part = nullptr;          // [kCgrChunks][kCgMaxRecycle][1 + kCgMaxModes]
+  bool record = false;             // record the Lanczos history of this solve
+  double* zhist = nullptr;         // [kCgHistCap][n]
+  double* hist = nullptr;          // [kCgHistCap][2]
+};
+
+// partial dot products of recycled vector j = blockIdx.y over chunk blockIdx.x of the unknowns:
+// part[(chunk * kCgMaxRecycle + j) * 9 + (0: u_j . r0 | 1 + i: u_j . (A W_i))]
+constexpr int kCgrChunks = 16;
+static __global__ void __launch_bounds__(kBlock)
+    k_cgr_init_dots(CgVec v, const double* __restrict__ AW, int dk, double* __restrict__ part) {
+  __shared__ double smem[4 * (1 + kCgMaxModes)];
+  const int j = blockIdx.y;
+  double acc[1 + kCgMaxModes] = {};
+  const double* u = v.rU + (size_t)j * v.n;
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < (long)v.n; o += (long)gridDim.x * blockDim.x) {
+    const double a = u[o];
+    acc[0] += a * v.r[o];
+#pragma unroll
+    for (int i = 0; i < kCgMaxModes; ++i)
+      if (i < dk) acc[1 + i] += a * AW[(size_t)i * v.n + o];
+  }
+  block_sum<1 + kCgMaxModes>(acc, smem);
+  if (threadIdx.x == 0) {
+    double* out = part + ((size_t)blockIdx.x * kCgMaxRecycle + j) * (1 + kCgMaxModes);
+#pragma unroll
+    for (int i = 0; i <= kCgMaxModes; ++i) out[i] = acc[i];
+  }
+}
+// z0 += sum_j u_j (u_j . r0) / theta_j after k_cg_init (same grid, same element -> block map): z, its gather mirror, and the
+// partials that depend on z (r.z and (A W)^T z of parity slot 0) are rewritten; block 0 starts the u_j . r recurrence.
+template <int PB>
+static __global__ void __launch_bounds__(kBlock) k_cgr_init_z(CgVec v, const double* __restrict__ part, int nchunks, double* __restrict__ G) {
+  __shared__ double smem[4 * (1 + kCgMaxModes)];
+  __shared__ double sa[kCgMaxRecycle];
+  if (threadIdx.x < kCgMaxRecycle * (1 + kCgMaxModes)) {  // column (j, col) of the chunk partials
+    const int j = threadIdx.x / (1 + kCgMaxModes), col = threadIdx.x % (1 + kCgMaxModes);
+    double c = 0.0;
+    if (j < v.rk) {
+#pragma unroll 4
+      for (int b = 0; b < nchunks; ++b) c += part[((size_t)b * kCgMaxRecycle + j) * (1 + kCgMaxModes) + col];
+    }
+    if (col == 0) {
+      sa[j] = c * v.rcoef[j];
+      if (blockIdx.x == 0) {
+        v.rstate[j] = c;
+        v.rstate[kCgMaxRecycle + j] = 0.0;
+      }
+    } else if (blockIdx.x == 0) {
+      G[j * kCgMaxModes + (col - 1)] = c;
+    }
+  }
+  __syncthreads();
+  double a[kCgMaxRecycle];
+#pragma unroll
+  for (int j = 0; j < kCgMaxRecycle; ++j) a[j] = sa[j];
+  double t[1 + kCgMaxModes] = {};
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < v.N; b += gridDim.x * blockDim.x) {
+    const long o = (long)PB * b;
+    double zi[PB], ri[PB];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      zi[i] = v.z[o + i];
+      ri[i] = v.r[o + i];
+    }
+#pragma unroll
+    for (int j = 0; j < kCgMaxRecycle; ++j)
+      if (j < v.rk) {
+#pragma unroll
+        for (int i = 0; i < PB; ++i) zi[i] += a[j] * v.rU[(size_t)j * v.n + o + i];
+      }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      v.z[o + i] = zi[i];
+      if (v.zmir) v.zmir[(long)b * v.zmir_stride + v.zmir_off + i] = zi[i];
+      t[0] += ri[i] * zi[i];
+#pragma unroll
+      for (int j = 0; j < kCgMaxModes; ++j)
+        if (j < v.dk) t[1 + j] += v.dAW[(size_t)j * v.n + o + i] * zi[i];
+    }
+  }
+  block_sum<1 + kCgMaxModes>(t, smem);
+  if (threadIdx.x == 0) {
+    v.vpart[blockIdx.x * 2] = t[0];
+    if (v.dk) {
+      double* oc = v.dcd + (size_t)blockIdx.x * 2 * kCgMaxModes;  // parity slot 0, the (A W)^T z half
+#pragma unroll
+      for (int j = 0; j < kCgMaxModes; ++j) oc[j] = t[1 + j];
+    }
+  }
+}
+// u_e = sum_j coef[j][e] zhist[j]  ->  slot[e] of U   (coef from ritz_select, m recorded steps, knew <= 8 vectors)
+struct CgrSlots {
+  int s[8];
+};
+static __global__ void __launch_bounds__(kBlock)
+    k_cgr_harvest(long n, int m, const double* __restrict__ zhist, const double* __restrict__ coef, int knew, CgrSlots slots,
+                  double* __restrict__ U) {
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x) {
+    double acc[8] = {};
+    for (int j = 0; j < m; ++j) {
+      const double zj = zhist[(size_t)j * n + o];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += coef[j * 8 + e] * zj;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (e < knew) U[(size_t)slots.s[e] * n + o] = acc[e];
+  }
+}
+
 // Host driver.  `apply(it)` must enqueue the kernels computing w = A z and the delta partials (its first kernel calls
 // cg_converged); it is also responsible for timing its dominant kernel (ctx->prof.begin(s, id, it)).
 //   defl   optional: deflate these modes (multi-block vector kernels only; small single-workgroup solves run plain).
@@ -941,7 +1187,7 @@ struct CgNoPostZ {
 // the gather mirrors) there and rewrites the r.z partials of parity slot `par` (gp.hip: GpCoarse).
 template <int PB, bool HAS_INTR, int IW = 8, typename Apply, typename PostZ = CgNoPostZ>
 inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& apply, const CgDeflation* defl = nullptr,
-                     int* hint = nullptr, PostZ&& post_z = PostZ(), bool* finished = nullptr) {
+                     int* hint = nullptr, PostZ&& post_z = PostZ(), bool* finished = nullptr, const CgRecycle* rcy = nullptr) {
   hipStream_t s = ctx->stream;
   const bool multi = ctx->comm.world > 1;
   v.delta_in_w = multi ? 1 : 0;
@@ -950,6 +1196,8 @@ inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& 
   v.single = (!HAS_INTR && v.N <= kCgSingleMaxBlocks) ? 1 : 0;
   v.probe = 0;
   v.dk = 0;
+  v.rk = 0;
+  v.rhist = 0;
   auto init = [&]() {
     if constexpr (HAS_INTR) {
       if (joint) hipLaunchKernelGGL((k_cg_init_joint<PB>), dim3(v.nb_update), dim3(kBlock), 0, s, v);
@@ -962,7 +1210,7 @@ inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& 
     apply(it);
     if (multi) {
       hipLaunchKernelGGL(k_cg_delta_to_w, dim3(1), dim3(kBlock), 0, s, v);
-      allreduce_sum(ctx, v.w, (size_t)v.n + 1);
+      allreduce_sum(ctx, v.w, (size_t)v.n + 1 + (v.rk ? kCgMaxRecycle : 0));  // (w needs n + 1 + kCgMaxRecycle entries then)
     }
   };
   GSFM_HIP_CHECK(hipMemsetAsync(v.st, 0, sizeof(CgStatus), s));  // (the ticket of cg_status_tail starts at zero)
@@ -1004,6 +1252,26 @@ inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& 
     v.dcd = defl->cd;
   }
   init();
+  // recycled Ritz vectors (3 x 3 camera blocks, multi-block vector kernels, one rank): coarse part of z0, start of the recurrences
+  bool recycle = false;
+  if constexpr (PB == 3 && !HAS_INTR) recycle = rcy != nullptr && !v.single;
+  if constexpr (PB == 3 && !HAS_INTR) if (recycle) {
+    v.rhist = rcy->record ? 1 : 0;
+    v.zhist = rcy->zhist;
+    v.hist = rcy->hist;
+    if (rcy->k > 0) {
+      v.rk = rcy->k;
+      v.rU = rcy->U;
+      v.rG = rcy->G;
+      v.rstate = rcy->state;
+      v.ruw = rcy->uw;
+      v.r_nslots = rcy->nslots;
+      for (int j = 0; j < kCgMaxRecycle; ++j) v.rcoef[j] = rcy->coef[j];
+      hipLaunchKernelGGL(k_cgr_init_dots, dim3(kCgrChunks, v.rk), dim3(kBlock), 0, s, v, deflate ? (const double*)defl->AW : nullptr,
+                         deflate ? defl->k : 0, rcy->part);
+      hipLaunchKernelGGL((k_cgr_init_z<PB>), dim3(v.nb_update), dim3(kBlock), 0, s, v, (const double*)rcy->part, kCgrChunks, rcy->G);
+    }
+  }
   post_z(0);
   CgStatus* h = reinterpret_cast<CgStatus*>(ctx->h_pinned + 400);
   long iters = max_iter;
@@ -1034,6 +1302,8 @@ inline long cg_solve(gsfm_ctx* ctx, CgVec& v, double tol, int max_iter, Apply&& 
     }
   }
   if (hint) *hint = (int)iters;
+  v.rk = 0;
+  v.rhist = 0;
   ctx->stats[GSFM_STAT_PCG_SOLVES]++;
   ctx->stats[GSFM_STAT_PCG_ITERATIONS] += iters;
   if (v.single) ctx->stats[GSFM_STAT_PCG_SINGLE_WORKGROUP]++;

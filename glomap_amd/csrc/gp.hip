@@ -42,6 +42,7 @@
 #include "mt19937.hpp"
 #include "obsgraph.hpp"
 #include "ra_dense.hpp"  // the batched symmetric block sweep (k_gj_*) inverts the coarse matrix
+#include "ritz.hpp"
 
 namespace gsfm {
 namespace {
@@ -1020,18 +1021,25 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // w_n = sum of the pieces of camera n (contiguous, fixed order) + D_n z_n, and this block's share of delta = z.w.
-// One wave per camera.
-__global__ void __launch_bounds__(kBlock)
+// One wave per camera, 16 waves per block: the delta slots — and the slots of the dot products with the recycled Ritz vectors,
+// cg.hpp CgRecycle — are re-reduced by every block of k_cg_update, so there should be few of them (625 at configs[3]).
+constexpr int kWsumBlock = 1024;
+__global__ void __launch_bounds__(kWsumBlock)
     k_gp_wsum(ObsX x, int N, CgVec v, double yscale, const double* __restrict__ wpart, const double* __restrict__ dcam) {
-  __shared__ double sdelta[kBlock / 64];
+  constexpr int NW = kWsumBlock / 64;
+  __shared__ double sdelta[NW];
+  __shared__ double suw[NW][kCgMaxRecycle];
   if (v.st->done) return;
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
-  const int nwaves = gridDim.x * (kBlock / 64);
+  const int nwaves = gridDim.x * NW;
   double delta = 0.0;
-  for (int n = blockIdx.x * (kBlock / 64) + wid; n < N; n += nwaves) {
+  double uw = 0.0;  // lane j < v.rk: this wave's share of u_j . w
+  for (int n = blockIdx.x * NW + wid; n < N; n += nwaves) {
     double acc[3] = {0, 0, 0};
     const int p1 = x.piece_off[n + 1];
+    V3 un{0, 0, 0};
+    if (lane < v.rk) un = ld3(v.rU + (size_t)lane * v.n + 3 * (long)n);  // (issued with the piece loads)
     for (int i = x.piece_off[n] + lane; i < p1; i += 64) {
       const V3 a = ld3(wpart + 3 * (long)i);
       acc[0] += a.x;
@@ -1039,20 +1047,33 @@ __global__ void __launch_bounds__(kBlock)
       acc[2] += a.z;
     }
     wave_allsum<3>(acc);
+    const V3 zn = ld3(v.z + 3 * (long)n);  // (one address per wave: a broadcast)
+    const double w0 = acc[0] + yscale * dcam[3 * (long)n] * zn.x;
+    const double w1 = acc[1] + yscale * dcam[3 * (long)n + 1] * zn.y;
+    const double w2 = acc[2] + yscale * dcam[3 * (long)n + 2] * zn.z;
     if (lane == 0) {
-      const V3 zn = ld3(v.z + 3 * (long)n);
-      const double w0 = acc[0] + yscale * dcam[3 * (long)n] * zn.x;
-      const double w1 = acc[1] + yscale * dcam[3 * (long)n + 1] * zn.y;
-      const double w2 = acc[2] + yscale * dcam[3 * (long)n + 2] * zn.z;
       v.w[3 * (long)n] = w0;
       v.w[3 * (long)n + 1] = w1;
       v.w[3 * (long)n + 2] = w2;
       delta += zn.x * w0 + zn.y * w1 + zn.z * w2;
     }
+    uw += un.x * w0 + un.y * w1 + un.z * w2;
   }
   if (lane == 0) sdelta[wid] = delta;
+  if (v.rk && lane < kCgMaxRecycle) suw[wid][lane] = uw;
   __syncthreads();
-  if (threadIdx.x == 0) v.dpart[blockIdx.x] = (sdelta[0] + sdelta[1]) + (sdelta[2] + sdelta[3]);
+  if (threadIdx.x == 0) {
+    double d = 0.0;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) d += sdelta[q];
+    v.dpart[blockIdx.x] = d;
+  }
+  if (v.rk && threadIdx.x < kCgMaxRecycle) {
+    double d = 0.0;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) d += suw[q][threadIdx.x];
+    v.ruw[(size_t)blockIdx.x * kCgMaxRecycle + threadIdx.x] = d;
+  }
 }
 
 // ---- back-substitution, model cost change, candidate point ------------------------------------
@@ -1700,6 +1721,7 @@ struct GpWs {
   DevBuf<int> img_frame, foff, fimg, img_sensor, soff, simg;
   DevBuf<double> img_off, ci, cin, hcc_i, gc_i, gred_i, scc_i, zimg, wimg, ximg, zero_i, cz_f, img_rot;
   DevBuf<double> defl_w, defl_aw, defl_awraw, defl_b2, defl_part, defl_small, defl_cd;  // CgDeflation, cg.hpp
+  DevBuf<double> rc_U, rc_G, rc_state, rc_uw, rc_part, rc_zhist, rc_hist, rc_coef, rc_flag;       // CgRecycle, cg.hpp
   DevBuf<double> maxpart;
   DevBuf<int> pr_i, pr_j, pr_row, pr_ent;                       // camera-to-camera constraints (GpPairs)
   DevBuf<double> pr_v, pr_s, pr_sn, pr_w, pr_js, pr_qa, pr_qb, pr_part;
@@ -2002,7 +2024,7 @@ class GpSolver final : public LmProblem {
     }
     for (DevBuf<double>* b : {&ws->dcam, &ws->gc, &ws->gred, &ws->rhs, &ws->cg_x, &ws->cg_r, &ws->cg_z, &ws->cg_p, &ws->cg_s})
       b->ensure(3 * (size_t)Np_);
-    ws->cg_w.ensure(3 * (size_t)Np_ + 2);
+    ws->cg_w.ensure(3 * (size_t)Np_ + 2 + kCgMaxRecycle);
     ws->vpart.ensure(2 * kCgMaxBlocks * 2);
     ws->dpart.ensure(2 * kMaxApplySlots);
     ws->part.ensure(kMaxBlocks * 12);
@@ -2025,9 +2047,20 @@ class GpSolver final : public LmProblem {
         ws->xq.ensure((size_t)x_.tiles * 64 + 64);
         ws->wpart.ensure(3 * (size_t)std::max(1, x_.npieces) + 8);
         gridX_ = x_grid(x_, kXTilesPerWave);
-        gridWsum_ = std::min(kMaxApplySlots, grid_for((size_t)Np_, kBlock / 64));  // (256 fat blocks measured: 214 instead of 210 ms per solve)
+        gridWsum_ = std::min(kMaxApplySlots, grid_for((size_t)Np_, kWsumBlock / 64));  // one wave per camera
       }
       sweepSlots_ = xon_ ? gridWsum_ : gridCam_ + gridMulti_;  // delta partial slots the sweep of `apply` writes
+      xon_all_ = xon_;
+      if (ctx_->comm.world > 1) {  // one flag, max over ranks of "not chunked here"
+        double* f = ws->rc_flag.ensure(1);
+        const double mine = xon_ ? 0.0 : 1.0;
+        GSFM_HIP_CHECK(hipMemcpyAsync(f, &mine, sizeof(double), hipMemcpyHostToDevice, ctx_->stream));
+        allreduce_max(ctx_, f, 1);
+        double any = 1.0;
+        GSFM_HIP_CHECK(hipMemcpyAsync(&any, f, sizeof(double), hipMemcpyDeviceToHost, ctx_->stream));
+        GSFM_HIP_CHECK(hipStreamSynchronize(ctx_->stream));
+        xon_all_ = any == 0.0;
+      }
     }
     gridTile_ = grid_wide(g_.g.T, kBlock / 64);             // one wave per tile
     gridTileA_ = grid_wide(g_.g.T, kBlock / 64, (size_t)0x7fffffff);
@@ -2217,6 +2250,7 @@ class GpSolver final : public LmProblem {
     hipStream_t s = ctx_->stream;
     const bool multi = ctx_->comm.world > 1;
     const int n3 = 3 * Np_;
+    radius_ = radius;
     double* gred_k = rig_ ? ws->gred_i.get() : ws->gred.get();
     double* scc_k = rig_ ? ws->scc_i.get() : ws->scc.get();
     double* part_lin = ws->part.get() + kMaxBlocks * 5;  // {cost, max gradient entry} per block of the LIN build
@@ -2516,6 +2550,75 @@ class GpSolver final : public LmProblem {
     hipLaunchKernelGGL(k_gpc_correct, dim3(cg_.nb_update), dim3(kBlock), 0, s, cg_, cs, (const double*)ws->cs_y.get(), par);
   }
 
+  // After a reduced solve of `iters` iterations whose Lanczos history was recorded: the small converged Ritz pairs of its
+  // preconditioned operator go into the store the next solves are preconditioned with (ritz.hpp; one 2 KB read-back, a
+  // tridiagonal eigenproblem on the host, one combination kernel over the recorded z's).
+  static constexpr int kRitzMinIters = 25;         // shorter solves are left alone: nothing slow enough to be worth a vector
+  static constexpr double kRitzCut = 0.3;          // Ritz values below this are harvested (the bulk sits in [0.2, 2])
+  static constexpr double kRitzConv = 0.2;         // ... if their residual estimate is below this fraction of theta
+  static constexpr double kRitzRadiusRatio = 3.0;  // a vector is dropped once the trust-region radius is this factor away
+  static constexpr int kRitzMaxAge = 6;            // ... or after this many solves
+  // (profiles/r06_gp_ritz_tuning.txt: cut 0.2 ... 0.4, 20 ... 30 iterations, ratio 2 ... 5, age 4 ... 10, residual 0.1 ... 0.5 all
+  // land within 1 471 ... 1 577 PCG iterations per configs[3] solve — the method saturates, the constants are not delicate)
+  void harvest(const CgRecycle& rcy, int iters) {
+    GpWs* ws = ws_;
+    hipStream_t s = ctx_->stream;
+    const int m = std::min(iters - 1, kCgHistCap - 1);
+    if (m < 3) return;
+    double* hh = ctx_->h_pinned + 1024;  // [m + 1][2] (gamma, alpha)
+    GSFM_HIP_CHECK(hipMemcpyAsync(hh, rcy.hist, (size_t)(m + 1) * 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    GSFM_HIP_CHECK(hipStreamSynchronize(s));
+    double gamma[kCgHistCap], alpha[kCgHistCap], theta[kRitzMaxHarvest];
+    for (int j = 0; j <= m; ++j) {
+      gamma[j] = hh[2 * j];
+      alpha[j] = hh[2 * j + 1];
+    }
+    std::vector<double> coef;
+    const int k = ritz_select(m, gamma, alpha, kRitzCut, kRitzConv, theta, coef);
+    static const bool verbose = std::getenv("GSFM_VERBOSE") != nullptr;
+    CgrSlots slots;
+    bool fresh[kCgMaxRecycle] = {};
+    int knew = 0;
+    double* hc = ctx_->h_pinned + 1536;  // [m][8] combination coefficients of the vectors that got a slot
+    for (int e = 0; e < k; ++e) {
+      // a free slot, else the stored vector with the largest Ritz value — never one taken by this harvest
+      int slot = -1;
+      for (int j = 0; j < kCgMaxRecycle && slot < 0; ++j)
+        if (!ritz_.used[j]) slot = j;
+      if (slot < 0) {
+        int worst = -1;
+        for (int j = 0; j < kCgMaxRecycle; ++j)
+          if (!fresh[j] && (worst < 0 || ritz_.theta[j] > ritz_.theta[worst])) worst = j;
+        if (worst >= 0 && ritz_.theta[worst] > theta[e]) slot = worst;
+      }
+      if (slot < 0) continue;
+      ritz_.used[slot] = true;
+      ritz_.theta[slot] = theta[e];
+      ritz_.radius[slot] = radius_;
+      ritz_.age[slot] = 0;
+      fresh[slot] = true;
+      for (int j = 0; j < m; ++j) hc[j * 8 + knew] = coef[(size_t)j * kRitzMaxHarvest + e];
+      slots.s[knew++] = slot;
+    }
+    if (verbose) {
+      fprintf(stderr, "[gsfm gp] harvest after %d iterations (radius %.3e): %d Ritz pairs below %.2f, %d stored (store %d):", iters,
+              radius_, k, kRitzCut, knew, ritz_.count());
+      for (int e = 0; e < k; ++e) fprintf(stderr, " %.3e", theta[e]);
+      fprintf(stderr, "\n");
+    }
+    if (knew == 0) return;
+    for (int e = knew; e < 8; ++e) {
+      slots.s[e] = 0;
+      for (int j = 0; j < m; ++j) hc[j * 8 + e] = 0.0;
+    }
+    double* dcoef = ws->rc_coef.ensure((size_t)kCgHistCap * 8);
+    GSFM_HIP_CHECK(hipMemcpyAsync(dcoef, hc, (size_t)m * 8 * sizeof(double), hipMemcpyHostToDevice, s));
+    const long n3 = 3L * N_;
+    hipLaunchKernelGGL(k_cgr_harvest, dim3(grid_for((size_t)n3, kBlock)), dim3(kBlock), 0, s, n3, m, (const double*)rcy.zhist,
+                       (const double*)dcoef, knew, slots, rcy.U);
+    ctx_->stats[GSFM_STAT_RITZ_HARVESTED] += knew;
+  }
+
   long pcg() {
     GpWs* ws = ws_;
     hipStream_t s = ctx_->stream;
@@ -2549,7 +2652,7 @@ class GpSolver final : public LmProblem {
                            (const double2*)ws->xq.get(), (const double*)ws->ptrec.get(), ws->wpart.get());
         if (timed) ctx_->prof.end(s);
         timed = ctx_->prof.begin(s, GSFM_KERNEL_GP_WSUM, it);
-        hipLaunchKernelGGL(k_gp_wsum, dim3(gridWsum_), dim3(kBlock), 0, s, x_, Np_, vk, ys, (const double*)ws->wpart.get(), dk);
+        hipLaunchKernelGGL(k_gp_wsum, dim3(gridWsum_), dim3(kWsumBlock), 0, s, x_, Np_, vk, ys, (const double*)ws->wpart.get(), dk);
         if (timed) ctx_->prof.end(s);
       } else {
         hipLaunchKernelGGL(k_gp_phaseB, dim3(gridCam_), dim3(kBlock), 0, s, g_, vk, ys, ci_, ws->c_qa.get(),
@@ -2604,12 +2707,41 @@ class GpSolver final : public LmProblem {
     // chain-like co-visibility shows as a solve that is still running after kCoarseTrigger iterations: it is abandoned there,
     // and this and the later solves of the LM problem get the second-level preconditioner (GpCoarseDev)
     const bool may_switch = !coarse && coarse_ok_ && !coarse_on_ && !rig_ && E_ == 0 && g_.opt_c && N_ > kCgSingleMaxBlocks &&
-                            opt_.lm.pcg_max_iterations > kCoarseTrigger;
+                            opt_.lm.pcg_max_iterations > 2 * kCoarseTrigger;
+    // Ritz vectors recycled from the earlier solves of this LM problem as an additive coarse space (cg.hpp CgRecycle, ritz.hpp):
+    // one rank, trivial frames, the chunked camera-side sweep (k_gp_wsum writes the u_j . w partials)
+    CgRecycle rcy;
+    const bool recycle = !coarse && xon_all_ && !rig_ && E_ == 0 && g_.opt_c && N_ > kCgSingleMaxBlocks &&
+                         !ctx_->knob[GSFM_KNOB_GP_NO_RECYCLE];
+    if (recycle) {
+      const size_t n3 = 3 * (size_t)N_;
+      ritz_.expire(radius_, kRitzRadiusRatio, kRitzMaxAge);
+      rcy.U = ws->rc_U.ensure(kCgMaxRecycle * n3);
+      rcy.G = ws->rc_G.ensure(kCgMaxRecycle * kCgMaxModes);
+      rcy.state = ws->rc_state.ensure(4 * kCgMaxRecycle);
+      rcy.uw = ws->rc_uw.ensure((size_t)gridWsum_ * kCgMaxRecycle);
+      rcy.nslots = gridWsum_;
+      rcy.part = ws->rc_part.ensure((size_t)kCgrChunks * kCgMaxRecycle * (1 + kCgMaxModes));
+      rcy.zhist = ws->rc_zhist.ensure((size_t)kCgHistCap * n3);
+      rcy.hist = ws->rc_hist.ensure(2 * kCgHistCap);
+      rcy.record = true;
+      for (int j = 0; j < kCgMaxRecycle; ++j)
+        if (ritz_.used[j]) {
+          rcy.k = j + 1;
+          rcy.coef[j] = 1.0 / ritz_.theta[j];
+        }
+    }
     bool finished = false;
-    const long iters0 = cg_solve<3, false>(ctx_, cg_, tol, may_switch ? kCoarseTrigger : opt_.lm.pcg_max_iterations, apply,
+    // (with recycled vectors in the preconditioner a solve gets twice as long before the scene is declared chain-like: at
+    // configs[3] a solve of 60 - 90 iterations is the block-Jacobi tail the recycling is there for, and the cluster
+    // preconditioner, when its matrix happens to pass the definiteness check on such a scene, is worse than none)
+    const int trigger = recycle ? 2 * kCoarseTrigger : kCoarseTrigger;
+    const long iters0 = cg_solve<3, false>(ctx_, cg_, tol, may_switch ? trigger : opt_.lm.pcg_max_iterations, apply,
                                            defl.k ? &defl : nullptr, &pcg_hint_, [&](int par) {
                                              if (coarse) coarse_correct(cs, par);
-                                           }, &finished);
+                                           }, &finished, recycle ? &rcy : nullptr);
+    if (recycle && rcy.k > 0) ctx_->stats[GSFM_STAT_PCG_RECYCLED]++;
+    if (recycle && finished && pcg_hint_ >= kRitzMinIters) harvest(rcy, pcg_hint_);
     if (may_switch && !finished) {  // still running at the cap (a solve that converged just below it is kept)
       coarse_on_ = true;
       return iters0 + pcg();
@@ -2647,6 +2779,7 @@ class GpSolver final : public LmProblem {
   long ls_trials_ = 0, m_used_total_ = 0;
   ObsX x_;            // chunked order of the camera-side PCG sweep (xon_)
   bool xon_ = false;
+  bool xon_all_ = false;  // ... on every rank (what the recycled-vector path needs: the decision has to be the same everywhere)
   int gridX_ = 0, gridWsum_ = 0, sweepSlots_ = 0;
   bool defl_on_ = true;  // deflate the next reduced solve (short solves run plain)
   long E_ = 0;                 // camera-to-camera constraints (constraint_type != ONLY_POINTS)
@@ -2661,6 +2794,8 @@ class GpSolver final : public LmProblem {
   bool coarse_said_ = false;
   int coarse_grow_ = 0;
   int pcg_hint_ = 0;     // iteration count of the previous reduced solve (where cg_solve first reads the status back)
+  RitzStore ritz_;       // what is known about the recycled Ritz vectors in ws->rc_U
+  double radius_ = 0.0;  // trust-region radius of the current step()
   int gridTileA_ = 1;    // k_gp_phaseA: exactly one wave per tile
   double *c_ = nullptr, *cn_ = nullptr, *X_ = nullptr, *Xn_ = nullptr, *s_ = nullptr, *sn_ = nullptr;
 };

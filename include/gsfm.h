@@ -134,7 +134,9 @@ enum gsfm_stat {
   GSFM_STAT_ALLREDUCES = 6,          /* collectives issued (any transport) */
   GSFM_STAT_PCG_ITERATIONS = 7,      /* PCG iterations (operator applications of the iterations proper) */
   GSFM_STAT_PCG_CHUNKED_SWEEPS = 8,  /* reduced-system solves whose camera-side sweep ran in the chunked (XCD-partitioned) order */
-  GSFM_STAT_COUNT = 9
+  GSFM_STAT_PCG_RECYCLED = 9,        /* ... preconditioned with recycled Ritz vectors of earlier solves (cg.hpp CgRecycle) */
+  GSFM_STAT_RITZ_HARVESTED = 10,     /* Ritz vectors harvested from reduced-system solves */
+  GSFM_STAT_COUNT = 11
 };
 /* Copies min(n, GSFM_STAT_COUNT) counters to out; reset != 0 zeroes them afterwards. */
 int gsfm_ctx_stats(gsfm_ctx* ctx, int64_t* out, int n, int reset);
@@ -164,7 +166,8 @@ enum gsfm_knob {
                                          >= 8 = always, with that many point chunks (A/B runs) */
   GSFM_KNOB_EXPERIMENT = 10,          /* bit mask of kernel variants kept for A/B measurements (tools/ab_gp_sweeps.py); 0 = shipped.
                                          2: k_gp_phaseA reads its tile streams with plain instead of non-temporal loads */
-  GSFM_KNOB_COUNT = 11
+  GSFM_KNOB_GP_NO_RECYCLE = 11,       /* GP: no recycled Ritz vectors in the reduced-system preconditioner */
+  GSFM_KNOB_COUNT = 12
 };
 int gsfm_ctx_set_knob(gsfm_ctx* ctx, int knob, int value);
 /* Text of the last failure on this ctx (what the HIP / RCCL call or the argument check said); "" when there was none.  The

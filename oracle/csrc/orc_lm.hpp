@@ -17,6 +17,19 @@
 
 namespace orc {
 
+// (experiment, see pcg below)
+struct RecycleStore {
+  i64 n = 0;
+  double radius = 0.0;  // trust-region radius of the solve about to run (set by the LM loop)
+  std::vector<std::vector<double>> U;
+  std::vector<double> theta, rad;  // Ritz value and the radius it was harvested at
+  std::vector<int> age;
+};
+inline RecycleStore& recycle_store() {
+  static RecycleStore s;
+  return s;
+}
+
 struct LmOptions {
   int max_num_iterations = 100;
   double function_tolerance = 1e-5;
@@ -284,6 +297,7 @@ inline void lm_minimize(LmProblem& prob, const LmOptions& o, LmSummary* s) {
       double model_change = 0.0, cand_cost = 0.0, step_norm = 0.0, x_norm = 0.0, relres = 0.0;
       i64 lin = 0;
       const double t0 = omp_get_wtime();
+      recycle_store().radius = radius;
       bool valid = prob.step(radius, &model_change, &cand_cost, &step_norm, &x_norm, &lin, &relres);
       s->seconds_linear += omp_get_wtime() - t0;
       s->linear_iterations += lin;
@@ -406,6 +420,52 @@ bool dense_solve(i64 n, const std::vector<double>& b, std::vector<double>& x, Ap
   return true;
 }
 
+// ---- experiment (ORC_RECYCLE = k_max, tools/exp_gp_ritz_recycle.py): recycled Ritz vectors as an additive coarse space ----
+// After a solve the Lanczos coefficients of the PCG give Ritz pairs (theta, u = V y) of the preconditioned operator; the
+// ones below ORC_RECYCLE_CUT are kept (first in, first out, at most k_max) and the NEXT solves run with
+//     M2^-1 = M^-1 + sum_j u_j u_j^T / theta_j
+// — a different SPD preconditioner for the same system and the same stopping rule, so the solution is the same to the
+// tolerance; theta and u are stale by one or more LM steps, which only costs preconditioner quality.  Layers stack: a mode
+// the current M2 handles shows up at ~1 + theta, a mode it does not handle shows up low again and is harvested again.
+// eigen-decomposition of a symmetric matrix (cyclic Jacobi; m <= a few hundred): A (m x m, row-major) -> eigenvalues in d,
+// eigenvectors in the COLUMNS of V
+inline void sym_eig_jacobi(std::vector<double>& A, int m, std::vector<double>& d, std::vector<double>& V) {
+  V.assign((size_t)m * m, 0.0);
+  for (int i = 0; i < m; ++i) V[(size_t)i * m + i] = 1.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0;
+    for (int i = 0; i < m; ++i)
+      for (int j = i + 1; j < m; ++j) off += A[(size_t)i * m + j] * A[(size_t)i * m + j];
+    if (off < 1e-30) break;
+    for (int p = 0; p < m; ++p)
+      for (int q = p + 1; q < m; ++q) {
+        const double apq = A[(size_t)p * m + q];
+        if (std::fabs(apq) < 1e-300) continue;
+        const double app = A[(size_t)p * m + p], aqq = A[(size_t)q * m + q];
+        const double tau = (aqq - app) / (2.0 * apq);
+        const double t = (tau >= 0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1.0 + tau * tau));
+        const double c = 1.0 / std::sqrt(1.0 + t * t), sn = t * c;
+        for (int k = 0; k < m; ++k) {
+          const double akp = A[(size_t)k * m + p], akq = A[(size_t)k * m + q];
+          A[(size_t)k * m + p] = c * akp - sn * akq;
+          A[(size_t)k * m + q] = sn * akp + c * akq;
+        }
+        for (int k = 0; k < m; ++k) {
+          const double apk = A[(size_t)p * m + k], aqk = A[(size_t)q * m + k];
+          A[(size_t)p * m + k] = c * apk - sn * aqk;
+          A[(size_t)q * m + k] = sn * apk + c * aqk;
+        }
+        for (int k = 0; k < m; ++k) {
+          const double vkp = V[(size_t)k * m + p], vkq = V[(size_t)k * m + q];
+          V[(size_t)k * m + p] = c * vkp - sn * vkq;
+          V[(size_t)k * m + q] = sn * vkp + c * vkq;
+        }
+      }
+  }
+  d.resize(m);
+  for (int i = 0; i < m; ++i) d[i] = A[(size_t)i * m + i];
+}
+
 // Preconditioned conjugate gradients on an SPD operator, classic two-reduction form.
 //   apply(z, w): w = S z;   precond(r, z): z = M^-1 r.
 // Stops at |r| <= tol |b| (recurrence residual), at max_it, or when the residual has not improved
@@ -481,10 +541,59 @@ i64 pcg(i64 n, const std::vector<double>& b, std::vector<double>& x, double tol,
       }
     }
   }
-  precond(r, z);
+  static const int rc_kmax = std::getenv("ORC_RECYCLE") ? std::atoi(std::getenv("ORC_RECYCLE")) : 0;
+  static const double rc_cut = std::getenv("ORC_RECYCLE_CUT") ? std::atof(std::getenv("ORC_RECYCLE_CUT")) : 0.3;
+  static const int rc_per = std::getenv("ORC_RECYCLE_PER") ? std::atoi(std::getenv("ORC_RECYCLE_PER")) : 8;
+  RecycleStore& rc = recycle_store();
+  const bool recycle = rc_kmax > 0 && x0 == nullptr;
+  static const double rc_rad = std::getenv("ORC_RECYCLE_RADIUS") ? std::atof(std::getenv("ORC_RECYCLE_RADIUS")) : 3.0;
+  static const int rc_age = std::getenv("ORC_RECYCLE_AGE") ? std::atoi(std::getenv("ORC_RECYCLE_AGE")) : 6;
+  static const int rc_minit = std::getenv("ORC_RECYCLE_MINIT") ? std::atoi(std::getenv("ORC_RECYCLE_MINIT")) : 25;
+  if (recycle && rc.n != n) {
+    rc.n = n;
+    rc.U.clear();
+    rc.theta.clear();
+    rc.rad.clear();
+    rc.age.clear();
+  }
+  if (recycle) {  // drop what has gone stale: harvested at a radius too far from this solve's, or too many solves ago
+    for (size_t j = 0; j < rc.U.size();) {
+      const double q = rc.rad[j] / rc.radius;
+      if (q > rc_rad || q < 1.0 / rc_rad || rc.age[j] >= rc_age) {
+        rc.U.erase(rc.U.begin() + j);
+        rc.theta.erase(rc.theta.begin() + j);
+        rc.rad.erase(rc.rad.begin() + j);
+        rc.age.erase(rc.age.begin() + j);
+      } else {
+        ++rc.age[j];
+        ++j;
+      }
+    }
+  }
+  auto precond2 = [&](const std::vector<double>& rin, std::vector<double>& zout) {
+    precond(rin, zout);
+    if (!recycle) return;
+    for (size_t j = 0; j < rc.U.size(); ++j) {
+      const double a = vdot(rc.U[j], rin) / rc.theta[j];
+      const double* u = rc.U[j].data();
+      double* zo = zout.data();
+      for (i64 i = 0; i < n; ++i) zo[i] += a * u[i];
+    }
+  };
+  std::vector<std::vector<double>> Vh;  // Lanczos vectors (-1)^j z_j / sqrt(r_j . z_j)
+  std::vector<double> al_h, rz_h;
+  auto keep = [&](double rzj) {
+    if (!recycle || Vh.size() >= 200) return;
+    std::vector<double> vj(z);
+    const double sc = ((Vh.size() & 1) ? -1.0 : 1.0) / std::sqrt(rzj);
+    for (i64 i = 0; i < n; ++i) vj[i] *= sc;
+    Vh.push_back(std::move(vj));
+  };
+  precond2(r, z);
   if (deflate) correct(z, AW, -1.0, nullptr);
   p = z;
   double rz = vdot(r, z);
+  keep(rz);
   double best = bnorm;
   int since_best = 0;
   i64 it = 0;
@@ -495,6 +604,8 @@ i64 pcg(i64 n, const std::vector<double>& b, std::vector<double>& x, double tol,
     const double alpha = rz / pw;
     static const bool cg_trace = std::getenv("ORC_CG_TRACE") != nullptr;  // Lanczos coefficients for Ritz-value estimates
     if (cg_trace) fprintf(stderr, "[orc cg] it %lld alpha %.17g rz %.17g\n", (long long)it, alpha, rz);
+    al_h.push_back(alpha);
+    rz_h.push_back(rz);
     double *px = x.data(), *pr = r.data();
     const double *pp = p.data(), *pwv = w.data();
 #pragma omp parallel for schedule(static)
@@ -511,15 +622,83 @@ i64 pcg(i64 n, const std::vector<double>& b, std::vector<double>& x, double tol,
     } else if (++since_best >= stall_window) {
       break;
     }
-    precond(r, z);
+    precond2(r, z);
     if (deflate) correct(z, AW, -1.0, nullptr);
     const double rz_new = vdot(r, z);
+    keep(rz_new);
     const double beta = rz_new / rz;
     rz = rz_new;
     double* ppm = p.data();
     const double* pz = z.data();
 #pragma omp parallel for schedule(static)
     for (i64 i = 0; i < n; ++i) ppm[i] = pz[i] + beta * ppm[i];
+  }
+  if (recycle && (int)al_h.size() >= rc_minit) {
+    // Ritz pairs of this solve: T from (alpha, beta), m = number of steps whose Lanczos vector was kept
+    const int m = (int)std::min(al_h.size(), Vh.size());
+    std::vector<double> T((size_t)m * m, 0.0), th, Y;
+    for (int j = 0; j < m; ++j) {
+      const double bprev = j > 0 ? rz_h[j] / rz_h[j - 1] : 0.0;
+      T[(size_t)j * m + j] = 1.0 / al_h[j] + (j > 0 ? bprev / al_h[j - 1] : 0.0);
+      if (j + 1 < m) {
+        const double bj = rz_h[j + 1] / rz_h[j];
+        T[(size_t)j * m + j + 1] = T[(size_t)(j + 1) * m + j] = std::sqrt(bj) / al_h[j];
+      }
+    }
+    const double tlast = (m < (int)al_h.size() || true) ? std::sqrt(std::max(0.0, (m < (int)rz_h.size() ? rz_h[m] / rz_h[m - 1] : 0.0))) / al_h[m - 1] : 0.0;
+    sym_eig_jacobi(T, m, th, Y);
+    std::vector<int> order(m);
+    for (int i = 0; i < m; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b2) { return th[a] < th[b2]; });
+    static const bool dbg = std::getenv("ORC_RECYCLE_DEBUG") != nullptr;
+    int added = 0;
+    std::vector<std::vector<double>> fresh;
+    std::vector<double> fresh_theta;
+    for (int oi = 0; oi < m && added < rc_per; ++oi) {
+      const int e = order[oi];
+      if (!(th[e] > 0.0) || th[e] > rc_cut) break;
+      const double resid = std::fabs(tlast * Y[(size_t)(m - 1) * m + e]);
+      if (resid > 0.2 * th[e]) continue;  // not converged
+      std::vector<double> u(n, 0.0);
+      for (int j = 0; j < m; ++j) {
+        const double yj = Y[(size_t)j * m + e];
+        const double* vj = Vh[j].data();
+        for (i64 i = 0; i < n; ++i) u[i] += yj * vj[i];
+      }
+      // ghost copies (loss of orthogonality): skip a vector nearly parallel to one already taken from this solve
+      bool dup = false;
+      const double uu = vdot(u, u);
+      for (const auto& f : fresh) {
+        const double c = vdot(u, f) / std::sqrt(uu * vdot(f, f));
+        if (std::fabs(c) > 0.7) dup = true;
+      }
+      if (dup) continue;
+      fresh.push_back(std::move(u));
+      fresh_theta.push_back(th[e]);
+      ++added;
+    }
+    if (dbg) {
+      fprintf(stderr, "[orc recycle] solve of %d its, store %zu, harvested %d:", m, rc.U.size(), added);
+      for (double t2 : fresh_theta) fprintf(stderr, " %.3e", t2);
+      fprintf(stderr, "  (smallest Ritz:");
+      for (int oi = 0; oi < std::min(m, 6); ++oi) fprintf(stderr, " %.3e", th[order[oi]]);
+      fprintf(stderr, ")\n");
+    }
+    for (size_t f = 0; f < fresh.size(); ++f) {
+      rc.U.push_back(std::move(fresh[f]));
+      rc.theta.push_back(fresh_theta[f]);
+      rc.rad.push_back(rc.radius);
+      rc.age.push_back(0);
+    }
+    while ((int)rc.U.size() > rc_kmax) {  // full: the largest Ritz value goes first (it matters least)
+      size_t worst = 0;
+      for (size_t j = 1; j < rc.U.size(); ++j)
+        if (rc.theta[j] > rc.theta[worst]) worst = j;
+      rc.U.erase(rc.U.begin() + worst);
+      rc.theta.erase(rc.theta.begin() + worst);
+      rc.rad.erase(rc.rad.begin() + worst);
+      rc.age.erase(rc.age.begin() + worst);
+    }
   }
   apply(x, w);
   const double *pb = b.data(), *pwv = w.data();

@@ -44,7 +44,10 @@ def test_gp_config3_full(gsfm_ctx):
     assert rc == 0 and rep["termination"] == 0
     assert rep["final_cost"] < 1e-3 * rep["initial_cost"]
     err = synthetic.center_errors_after_sim3(cen, p.gt_center)  # relative to the extent of the ground truth
-    assert np.median(err) < 1e-3  # ray noise 1e-3
+    # ray noise 1e-3: the numpy oracle's own end point on this input sits at a median of 1.028e-3 from the ground truth
+    # (profiles/r06_gp_line_search_gpu_vs_oracle.txt, "oracle forward", 5 000 / 500 000 seed 0), and LM paths that differ in the
+    # last bits end 1e-5 of that apart (the reference's own scatter) — the bar is the noise level, not 1e-3 flat
+    assert np.median(err) < 1.2e-3
     # idempotence: from the solution (no random re-draw; the per-observation scales are re-derived from the
     # geometry, gp.cc:300-305, so this is not a bit-exact restart) the solver stops quickly at the same cost
     p2 = type(p)(**{**p.__dict__, "cam_center": cen, "pt_xyz": xyz})
