@@ -537,7 +537,7 @@ class Context:
 
     KNOBS = ("ba_aw_by_application", "ba_aw_check", "ba_separate_blocks", "ba_no_nontemporal", "ra_no_blockdense",
              "ra_no_substructure", "ra_dense_refactor", "gp_coarse_cluster", "seg_len", "chunked_sweeps", "experiment",
-             "gp_no_recycle")
+             "gp_no_recycle", "gp_recycle_min_iters", "gp_recycle_cut_percent")
 
     def set_knob(self, name: str, value: int = 1):
         """Diagnostic / A-B knobs (gsfm_ctx_set_knob); 0 restores the default.  The library reads no environment variable

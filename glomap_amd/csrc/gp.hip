@@ -2060,6 +2060,8 @@ class GpSolver final : public LmProblem {
         GSFM_HIP_CHECK(hipMemcpyAsync(&any, f, sizeof(double), hipMemcpyDeviceToHost, ctx_->stream));
         GSFM_HIP_CHECK(hipStreamSynchronize(ctx_->stream));
         xon_all_ = any == 0.0;
+        if (std::getenv("GSFM_VERBOSE"))
+          fprintf(stderr, "[gsfm gp] rank %d: chunked sweeps %d here, %d on every rank\n", ctx_->comm.rank, (int)xon_, (int)xon_all_);
       }
     }
     gridTile_ = grid_wide(g_.g.T, kBlock / 64);             // one wave per tile
@@ -2574,7 +2576,8 @@ class GpSolver final : public LmProblem {
       alpha[j] = hh[2 * j + 1];
     }
     std::vector<double> coef;
-    const int k = ritz_select(m, gamma, alpha, kRitzCut, kRitzConv, theta, coef);
+    const double cut = ctx_->knob[GSFM_KNOB_GP_RECYCLE_CUT_PERCENT] > 0 ? 0.01 * ctx_->knob[GSFM_KNOB_GP_RECYCLE_CUT_PERCENT] : kRitzCut;
+    const int k = ritz_select(m, gamma, alpha, cut, kRitzConv, theta, coef);
     static const bool verbose = std::getenv("GSFM_VERBOSE") != nullptr;
     CgrSlots slots;
     bool fresh[kCgMaxRecycle] = {};
@@ -2602,7 +2605,7 @@ class GpSolver final : public LmProblem {
     }
     if (verbose) {
       fprintf(stderr, "[gsfm gp] harvest after %d iterations (radius %.3e): %d Ritz pairs below %.2f, %d stored (store %d):", iters,
-              radius_, k, kRitzCut, knew, ritz_.count());
+              radius_, k, cut, knew, ritz_.count());
       for (int e = 0; e < k; ++e) fprintf(stderr, " %.3e", theta[e]);
       fprintf(stderr, "\n");
     }
@@ -2741,7 +2744,8 @@ class GpSolver final : public LmProblem {
                                              if (coarse) coarse_correct(cs, par);
                                            }, &finished, recycle ? &rcy : nullptr);
     if (recycle && rcy.k > 0) ctx_->stats[GSFM_STAT_PCG_RECYCLED]++;
-    if (recycle && finished && pcg_hint_ >= kRitzMinIters) harvest(rcy, pcg_hint_);
+    const int min_iters = ctx_->knob[GSFM_KNOB_GP_RECYCLE_MIN_ITERS] > 0 ? ctx_->knob[GSFM_KNOB_GP_RECYCLE_MIN_ITERS] : kRitzMinIters;
+    if (recycle && finished && pcg_hint_ >= min_iters) harvest(rcy, pcg_hint_);
     if (may_switch && !finished) {  // still running at the cap (a solve that converged just below it is kept)
       coarse_on_ = true;
       return iters0 + pcg();

@@ -167,7 +167,10 @@ enum gsfm_knob {
   GSFM_KNOB_EXPERIMENT = 10,          /* bit mask of kernel variants kept for A/B measurements (tools/ab_gp_sweeps.py); 0 = shipped.
                                          2: k_gp_phaseA reads its tile streams with plain instead of non-temporal loads */
   GSFM_KNOB_GP_NO_RECYCLE = 11,       /* GP: no recycled Ritz vectors in the reduced-system preconditioner */
-  GSFM_KNOB_COUNT = 12
+  GSFM_KNOB_GP_RECYCLE_MIN_ITERS = 12, /* GP: harvest Ritz vectors from solves of at least this many iterations (0: 25) — tests
+                                          lower it so that small problems, whose solves are short, exercise the path */
+  GSFM_KNOB_GP_RECYCLE_CUT_PERCENT = 13, /* GP: harvest Ritz values below this many hundredths (0: 30) — tests raise it for the same reason */
+  GSFM_KNOB_COUNT = 14
 };
 int gsfm_ctx_set_knob(gsfm_ctx* ctx, int knob, int value);
 /* Text of the last failure on this ctx (what the HIP / RCCL call or the argument check said); "" when there was none.  The
