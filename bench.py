@@ -187,6 +187,8 @@ def run_extras(env, args, world, rank, main_line):
             ("gp_c3", lambda: {k: v for k, v in bench_gp(**{**env, "args": sub()}).items() if k in keys}),
             ("ba_c4_shared_intrinsics", lambda: {k: v for k, v in bench_ba(**{**env, "args": sub(shared_intrinsics=True)}).items()
                                                  if k in keys}),
+            # the same solve through a 12-parameter camera model: the 16-wide unit (bundle_adjustment.cc:136-139 dispatches any model)
+            ("ba_c4_full_opencv", lambda: {k: v for k, v in bench_ba(**{**env, "args": sub(wide_model="full_opencv")}).items() if k in keys}),
             ("gp_c3_skewed_visibility", lambda: {k: v for k, v in bench_gp(**{**env, "args": sub(zipf=0.8)}).items() if k in keys}),
             # the same two solves on scenes with the locality of a walk-around capture (runs of consecutive cameras per
             # point, tracks in capture order): what the camera-major gathers cost when co-visible points share cache lines
@@ -1079,7 +1081,10 @@ def bench_ba(args, ctx, rank, world, barrier, dist):
     npts_rank = int(1_000_000 * args.scale)  # weak scaling: tracks per GPU fixed
     npts = npts_rank * world
     shared = bool(getattr(args, "shared_intrinsics", False))  # configs[3] has both variants
-    if world == 1:
+    wide = getattr(args, "wide_model", None)  # a camera model with more than 8 parameters: the 16-wide unit (csrc/ba_wide.hip)
+    if world == 1 and wide:
+        p = synthetic.make_ba_problem_wide(ncam, npts, wide, seed=0, shared_intrinsics=shared)
+    elif world == 1:
         p = synthetic.make_ba_problem(ncam, npts, seed=0, shared_intrinsics=shared, capture=getattr(args, "capture", "random"))
     else:  # every rank generates only its own shard (cameras / intrinsics / start identical everywhere)
         p = synthetic.make_ba_problem(ncam, npts_rank, seed=0, shared_intrinsics=shared, shard=(rank, world),
@@ -1124,7 +1129,7 @@ def bench_ba(args, ctx, rank, world, barrier, dist):
     value = M_total * iters * args.steps / dt
     launches, avg_ms = profiled_step(ctx, KERNEL_BA, step, also=(KERNEL_BA_B,))
     M_loc, P_loc = o1 - o0, hi - lo
-    F = 2  # free intrinsics columns stored per observation (SIMPLE_RADIAL: f, k)
+    F = 10 if wide else 2  # free intrinsics columns stored per observation (SIMPLE_RADIAL: f, k; FULL_OPENCV: all but cx, cy)
     roof = roofline(
         "k_ba_phaseA (implicit Schur product, track-major half over the stored Jacobian planes)",
         (16.0 * (9 + F) + 12.0) * M_loc + 96.0 * P_loc + 48.0 * ncam,
@@ -1146,7 +1151,8 @@ def bench_ba(args, ctx, rank, world, barrier, dist):
     cpu = None if (args.no_cpu_baseline or rank != 0 or world > 1) else cpu_baseline_ba(p)
     config = {
         "workload": "configs[3] on one GPU per rank: synthetic 10k cameras / 1M tracks / ~5M observations per GPU, "
-        f"bundle adjustment (SIMPLE_RADIAL, {'ONE camera shared by all images' if shared else 'one camera per image'}, Huber 1 px, "
+        f"bundle adjustment ({'FULL_OPENCV (12 parameters, 16-wide intrinsics blocks)' if wide else 'SIMPLE_RADIAL'}, "
+        f"{'ONE camera shared by all images' if shared else 'one camera per image'}, Huber 1 px, "
         "reference defaults), start = GT + noise",
         "intrinsics_blocks": int(p.num_intr),
         "cameras": ncam,

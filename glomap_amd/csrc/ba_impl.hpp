@@ -2497,7 +2497,7 @@ class BaSolver final : public LmProblem {
     // the similarity gauge of the scene deflated from the PCG (CgDeflation, cg.hpp): trivial rigs, translations among
     // the unknowns; skipped while the solves are short anyway (strongly damped LM steps; defl_on_, below)
     CgDeflation defl;
-    if constexpr (KP == 8)  // (deflation and its closed-form A W sweep: the 8-wide unit only)
+    // (the closed-form A W sweep exists in the 8-wide unit only; the 16-wide unit forms the products by operator applications)
     if (!rig_ && g_.opt_trn && defl_on_ && N_ >= 64) {
       const int with_rot = g_.opt_rot ? 1 : 0;
       defl.k = with_rot ? 7 : 4;
@@ -2513,7 +2513,8 @@ class BaSolver final : public LmProblem {
                          g_.fixed_cam, with_rot, W);
       defl.W = W;
       // A W in closed form (k_ba_aw_modes): points optimised, no point observed twice by the constant camera
-      const bool no_closed = ctx_->knob[GSFM_KNOB_BA_AW_BY_APPLICATION] != 0;  // A/B and tests: form A W by operator applications
+      const bool no_closed = KP > 8 || ctx_->knob[GSFM_KNOB_BA_AW_BY_APPLICATION] != 0;  // A/B and tests: form A W by operator applications
+      if constexpr (KP == 8)
       if (!no_closed && g_.opt_pts && aw_closed_ok_) {
         // intrinsics blocks shared by several cameras (not the joint layout): per-camera shares, then per-block sums
         const bool shared_blocks = !joint_ && F_ > 0;

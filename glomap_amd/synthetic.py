@@ -359,6 +359,46 @@ def project_simple_radial(params, xc):
     return np.stack([f * u * rad + cx, f * v * rad + cy], axis=-1)
 
 
+def project_full_opencv(params, xc):
+    """COLMAP FULL_OPENCV (models.h): params [M,12+] = fx, fy, cx, cy, k1, k2, p1, p2, k3, k4, k5, k6; xc [M,3] in the camera frame."""
+    u, v = xc[:, 0] / xc[:, 2], xc[:, 1] / xc[:, 2]
+    fx, fy, cx, cy, k1, k2, p1, p2, k3, k4, k5, k6 = (params[:, i] for i in range(12))
+    u2, v2, uv = u * u, v * v, u * v
+    r2 = u2 + v2
+    r4, r6 = r2 * r2, r2 * r2 * r2
+    radial = (1.0 + k1 * r2 + k2 * r4 + k3 * r6) / (1.0 + k4 * r2 + k5 * r4 + k6 * r6)
+    du = u * radial + 2.0 * p1 * uv + p2 * (r2 + 2.0 * u2) - u
+    dv = v * radial + 2.0 * p2 * uv + p1 * (r2 + 2.0 * v2) - v
+    return np.stack([fx * (u + du) + cx, fy * (v + dv) + cy], 1)
+
+
+def make_ba_problem_wide(num_cams: int = 10_000, num_pts: int = 1_000_000, model: str = "full_opencv", seed: int = 0,
+                         shared_intrinsics: bool = False, pixel_noise: float = 0.5, **kw) -> BaProblem:
+    """make_ba_problem's scene observed through a 12-parameter FULL_OPENCV camera (16-wide intrinsics rows: the unit of
+    csrc/ba_wide.hip; the reference dispatches any CameraModelId, bundle_adjustment.cc:136-139): same cameras, points, tracks,
+    perturbed start and outliers; the observations of the inlier tracks re-projected through the wide model + pixel noise."""
+    from .flat import CAMERA_FULL_OPENCV, CAMERA_MAX_PARAMS_WIDE
+
+    assert model == "full_opencv"
+    p = make_ba_problem(num_cams, num_pts, seed=seed, shared_intrinsics=shared_intrinsics, pixel_noise=pixel_noise, **kw)
+    K = p.num_intr
+    vals = np.array([1200.0, 1190.0, 640.0, 480.0, 0.02, -0.01, 0.001, -0.002, 0.003, 0.01, -0.004, 0.002])
+    wide = np.zeros((K, CAMERA_MAX_PARAMS_WIDE))
+    wide[:, :12] = vals
+    obs_pt = np.repeat(np.arange(p.num_pts), np.diff(p.pt_offset))
+    R = so3.quat_to_rotmat(p.gt_q)
+    xc = np.einsum("mij,mj->mi", R[p.obs_cam], p.gt_xyz[obs_pt]) + p.gt_t[p.obs_cam]
+    old = project_simple_radial(p.gt_intr[p.cam_intr[p.obs_cam]], xc)
+    resid = p.obs_xy - old  # the noise / outlier offsets of the original observations, kept
+    inl = np.abs(resid).max(1) < 10.0 * max(pixel_noise, 1e-9) + 1e-9
+    xy = project_full_opencv(wide[p.cam_intr[p.obs_cam]], xc)
+    p.obs_xy = np.ascontiguousarray(np.where(inl[:, None], xy + resid, p.obs_xy))
+    p.intr_model = np.full(K, CAMERA_FULL_OPENCV, dtype=np.int32)
+    p.intr_params = wide.copy()
+    p.gt_intr = wide
+    return p
+
+
 def make_ba_problem(
     num_cams: int = 10_000,
     num_pts: int = 1_000_000,
