@@ -356,6 +356,8 @@ def load():
     i64p = C.POINTER(C.c_int64)
     lib.gsfm_filter_tracks_by_reprojection.restype = ip
     lib.gsfm_filter_tracks_by_reprojection.argtypes = [vp, C.POINTER(SceneViewC), C.c_double, ip, vp, i64p]
+    lib.gsfm_undistort_features.restype = ip
+    lib.gsfm_undistort_features.argtypes = [vp, ip, C.c_int64, vp, vp, ip, vp, vp, ip, vp]
     lib.gsfm_filter_tracks_by_angle.restype = ip
     lib.gsfm_filter_tracks_by_angle.argtypes = [vp, C.POINTER(SceneViewC), C.c_double, vp, i64p]
     lib.gsfm_filter_tracks_triangulation_angle.restype = ip

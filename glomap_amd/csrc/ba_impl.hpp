@@ -43,8 +43,9 @@
 // colmap/sensor/models.h).  Everything below is in an anonymous namespace, so each unit has its own kernels, solver class
 // and ba_solve_impl(); gsfm_ba_solve (ba.hip) picks the unit by gsfm_ba_problem::intr_stride.  The layouts written above
 // for KP = 8 scale as: reduced vector [6 per frame | KP per block], per-camera shares 2 KP (linearise) and
-// kIntrAcc = KP + KP (KP + 1) / 2 (build), block inverses KP x KP.  The 16-wide unit runs the plain configuration only: no
-// joint pose + intrinsics blocks (the 16-lane kernels hold 6 + 8 rows), no deflation, one projection instance (WIDE).
+// kIntrAcc = KP + KP (KP + 1) / 2 (build), block inverses KP x KP.  The 16-wide unit runs separate pose / intrinsics blocks only (no
+// joint blocks: the 16-lane kernels hold 6 + 8 rows), deflates the gauge modes with A W formed by operator applications (the
+// closed-form sweep is 8-wide), and has one projection instance (WIDE).
 #include <algorithm>
 #include <numeric>
 #include <type_traits>

@@ -5,7 +5,7 @@
 // The solver is ba_impl.hpp with GSFM_BA_KP = 16: the same kernels, LM problem class and reductions as the 8-wide unit of
 // ba.hip with every intrinsics width scaled (reduced vector [6 per frame | 16 per block], 16 x 16 block-Jacobi blocks, 16
 // stored intrinsics planes), one projection instance (camera.hpp: distort_project_wide16), separate pose / intrinsics
-// blocks and plain PCG.  A unit of its own rather than template parameters on forty kernels: the measured 8-wide unit
+// blocks, PCG with the seven gauge modes deflated (A W by operator applications).  A unit of its own rather than template parameters on forty kernels: the measured 8-wide unit
 // compiles to the same instructions as before, and everything here is in ba_impl.hpp's anonymous namespace.
 #define GSFM_BA_KP 16
 #include "ba_impl.hpp"

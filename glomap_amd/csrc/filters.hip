@@ -278,6 +278,15 @@ __global__ void __launch_bounds__(kBlock)
   if (err) *bad = 1ull;
 }
 
+// every idx[i] in [0, K)
+__global__ void __launch_bounds__(kBlock)
+    k_validate_index(long n, const int* __restrict__ idx, int K, unsigned long long* __restrict__ bad) {
+  unsigned long long c = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    c += (idx[i] < 0 || idx[i] >= K) ? 1 : 0;
+  if (c) atomicAdd(bad, c);
+}
+
 long read_counter(gsfm_ctx* ctx, FilterWs* ws);
 
 void require_valid(gsfm_ctx* ctx, FilterWs* ws, const char* what) {
@@ -421,6 +430,95 @@ extern "C" int gsfm_filter_tracks_by_angle(gsfm_ctx* ctx, const gsfm_scene_view*
     const double thr = std::cos(max_angle_error_deg * M_PI / 180.0);
     const double thr_u = std::cos(2.0 * max_angle_error_deg * M_PI / 180.0);  // track_filter.cc:61-62
     return filter_obs_impl(ctx, view, 2, thr, thr_u, obs_keep_out, tracks_changed);
+  });
+}
+
+// ---- UndistortImages (processors/image_undistorter.cc:7-46) -----------------------------------------------------------
+// features_undist[i] = camera.CamFromImg(features[i]).value_or(Zero).homogeneous().normalized(): the unit ray of a pixel.
+// COLMAP's CamFromImg of a model with distortion is a Newton iteration on its own ImgFromCam (BaseCameraModel::
+// IterativeUndistortion: at most 100 steps, stop at |step|^2 < 1e-10; COLMAP is un-vendored, its scheme restated).  Here:
+// Newton on camera.hpp's distort_project — the projection the bundle adjustment uses, with its ANALYTIC Jacobian
+// d pixel / d (u, v) where COLMAP differentiates numerically — from the pinhole guess J(0,0)^-1 (pixel - c), the same step
+// limit and stopping rule.  Both iterations converge quadratically to the same root; what differs is below the stop's 1e-10.
+// One lane per feature; rows of KP doubles (8, or 16 for the models with more than eight parameters).
+template <int KP>
+__global__ void __launch_bounds__(kBlock)
+    k_undistort(long F, const double* __restrict__ xy, const int* __restrict__ feat_intr, const int* __restrict__ intr_model,
+                const double* __restrict__ intr_params, double* __restrict__ rays) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < F; i += (long)gridDim.x * blockDim.x) {
+    const int ik = feat_intr[i];
+    const int model = intr_model[ik];
+    double par[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) par[j] = j < KP ? intr_params[KP * (long)ik + j] : 0.0;
+    const double ox = xy[2 * i], oy = xy[2 * i + 1];
+    double px, py, J[4], Jp[2][16];
+    distort_project<true, 16>(model, par, 0.0, 0.0, px, py, J, Jp);
+    double det = J[0] * J[3] - J[1] * J[2];
+    double u = (J[3] * (ox - px) - J[1] * (oy - py)) / det;
+    double v = (J[0] * (oy - py) - J[2] * (ox - px)) / det;
+    for (int it = 0; it < 100; ++it) {
+      distort_project<true, 16>(model, par, u, v, px, py, J, Jp);
+      det = J[0] * J[3] - J[1] * J[2];
+      const double rx = px - ox, ry = py - oy;
+      const double su = (J[3] * rx - J[1] * ry) / det, sv = (J[0] * ry - J[2] * rx) / det;
+      u -= su;
+      v -= sv;
+      // (in the units of the normalised plane, as COLMAP's: its residual is x + dx(x) - x0)
+      if (!(su * su + sv * sv >= 1e-10)) break;
+    }
+    V3 r{0.0, 0.0, 1.0};  // value_or(Zero).homogeneous().normalized()
+    if (isfinite(u) && isfinite(v)) {
+      const double inv = 1.0 / sqrt(u * u + v * v + 1.0);
+      r = V3{u * inv, v * inv, inv};
+    }
+    st3(rays + 3 * i, r);
+  }
+}
+
+extern "C" int gsfm_undistort_features(gsfm_ctx* ctx, int32_t mem, int64_t num_feat, const double* feat_xy, const int32_t* feat_intr,
+                                       int32_t num_intr, const int32_t* intr_model, const double* intr_params, int32_t intr_stride,
+                                       double* rays_out) {
+  if (!ctx) return GSFM_ERR_INVALID_ARGUMENT;
+  return guarded(ctx, nullptr, [&] {
+    GSFM_REQUIRE(num_feat >= 0 && num_intr > 0, "undistort: bad sizes");
+    GSFM_REQUIRE(num_feat == 0 || (feat_xy && feat_intr && rays_out), "undistort: null argument");
+    GSFM_REQUIRE(intr_model && intr_params, "undistort: null intrinsics");
+    const int stride = intr_stride == 0 ? GSFM_CAMERA_MAX_PARAMS : intr_stride;
+    GSFM_REQUIRE(stride == GSFM_CAMERA_MAX_PARAMS || stride == GSFM_CAMERA_MAX_PARAMS_WIDE, "undistort: intr_stride must be 0, 8 or 16");
+    GSFM_HIP_CHECK(hipSetDevice(ctx->device));
+    FilterWs* ws = filter_ws(ctx);
+    hipStream_t s = ctx->stream;
+    const long F = num_feat;
+    if (F == 0) return (int)GSFM_OK;
+    const double* d_xy = dev_in(ctx, ws->xy, feat_xy, 2 * (size_t)F, mem);
+    const int* d_fi = dev_in(ctx, ws->cam, feat_intr, (size_t)F, mem);
+    const int* d_model = dev_in(ctx, ws->intr_model, intr_model, (size_t)num_intr, mem);
+    const double* d_par = dev_in(ctx, ws->intr, intr_params, (size_t)stride * (size_t)num_intr, mem);
+    // index and model sanity before any gather (a malformed call comes back as INVALID_ARGUMENT / UNSUPPORTED)
+    std::vector<int> h_model;
+    to_host(ctx, h_model, intr_model, (size_t)num_intr, mem);
+    for (int k = 0; k < num_intr; ++k) {
+      GSFM_REQUIRE(h_model[k] >= 0 && h_model[k] <= GSFM_CAMERA_RAD_TAN_THIN_PRISM_FISHEYE, "undistort: unknown camera model");
+      const bool wide = h_model[k] == GSFM_CAMERA_FULL_OPENCV || h_model[k] == GSFM_CAMERA_THIN_PRISM_FISHEYE ||
+                        h_model[k] == GSFM_CAMERA_RAD_TAN_THIN_PRISM_FISHEYE;
+      if (wide && stride != GSFM_CAMERA_MAX_PARAMS_WIDE)
+        throw StatusError(GSFM_ERR_UNSUPPORTED, "undistort: camera models with more than 8 parameters need intr_stride = 16");
+    }
+    ws->counter.ensure(1);
+    GSFM_HIP_CHECK(hipMemsetAsync(ws->counter.get(), 0, sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(k_validate_index, dim3(grid_wide(F, kBlock, 1 << 16)), dim3(kBlock), 0, s, F, d_fi, num_intr, ws->counter.get());
+    require_valid(ctx, ws, "undistort: feat_intr out of range");
+    double* d_out = mem == GSFM_MEM_DEVICE ? rays_out : ws->undist.ensure(3 * (size_t)F + 3);
+    const int grid = grid_wide(F, kBlock, 1 << 16);
+    if (stride == GSFM_CAMERA_MAX_PARAMS)
+      hipLaunchKernelGGL((k_undistort<8>), dim3(grid), dim3(kBlock), 0, s, F, d_xy, d_fi, d_model, d_par, d_out);
+    else
+      hipLaunchKernelGGL((k_undistort<16>), dim3(grid), dim3(kBlock), 0, s, F, d_xy, d_fi, d_model, d_par, d_out);
+    if (mem != GSFM_MEM_DEVICE) copy_out(ctx, rays_out, d_out, 3 * (size_t)F, mem);
+    GSFM_HIP_CHECK(hipStreamSynchronize(s));
+    GSFM_HIP_CHECK(hipGetLastError());
+    return (int)GSFM_OK;
   });
 }
 

@@ -2714,6 +2714,9 @@ class GpSolver final : public LmProblem {
     // Ritz vectors recycled from the earlier solves of this LM problem as an additive coarse space (cg.hpp CgRecycle, ritz.hpp):
     // one rank, trivial frames, the chunked camera-side sweep (k_gp_wsum writes the u_j . w partials)
     CgRecycle rcy;
+    // (Not on top of the second level — measured on the sequential capture of configs[2] size, tools/exp_gp_sequential_recycle.py:
+    // 6 139 instead of 6 243 iterations but 698 instead of 628 ms; the probed cluster matrix changes with every LM step, and
+    // vectors that are Ritz vectors with respect to the previous step's preconditioner make several early solves longer.)
     const bool recycle = !coarse && xon_all_ && !rig_ && E_ == 0 && g_.opt_c && N_ > kCgSingleMaxBlocks &&
                          !ctx_->knob[GSFM_KNOB_GP_NO_RECYCLE];
     if (recycle) {
@@ -2738,14 +2741,20 @@ class GpSolver final : public LmProblem {
     // (with recycled vectors in the preconditioner a solve gets twice as long before the scene is declared chain-like: at
     // configs[3] a solve of 60 - 90 iterations is the block-Jacobi tail the recycling is there for, and the cluster
     // preconditioner, when its matrix happens to pass the definiteness check on such a scene, is worse than none)
-    const int trigger = recycle ? 2 * kCoarseTrigger : kCoarseTrigger;
+    // A chain-like scene shows at once (the sequential capture's FIRST solve is still running after 60 iterations), the
+    // benchmark scene's tail only in the middle of the trajectory: the doubled trigger applies from the ninth solve on.
+    const int trigger = (recycle && pcg_calls_ >= 8) ? 2 * kCoarseTrigger : kCoarseTrigger;
+    ++pcg_calls_;
     const long iters0 = cg_solve<3, false>(ctx_, cg_, tol, may_switch ? trigger : opt_.lm.pcg_max_iterations, apply,
                                            defl.k ? &defl : nullptr, &pcg_hint_, [&](int par) {
                                              if (coarse) coarse_correct(cs, par);
                                            }, &finished, recycle ? &rcy : nullptr);
     if (recycle && rcy.k > 0) ctx_->stats[GSFM_STAT_PCG_RECYCLED]++;
     const int min_iters = ctx_->knob[GSFM_KNOB_GP_RECYCLE_MIN_ITERS] > 0 ? ctx_->knob[GSFM_KNOB_GP_RECYCLE_MIN_ITERS] : kRitzMinIters;
-    if (recycle && finished && pcg_hint_ >= min_iters) harvest(rcy, pcg_hint_);
+    // (a solve that met a non-finite value or lost positive curvature leaves nothing worth keeping — and nothing kept is trusted)
+    const bool solve_bad = reinterpret_cast<const CgStatus*>(ctx_->h_pinned + 400)->bad != 0;
+    if (recycle && solve_bad) ritz_.clear();
+    if (recycle && finished && !solve_bad && pcg_hint_ >= min_iters) harvest(rcy, pcg_hint_);
     if (may_switch && !finished) {  // still running at the cap (a solve that converged just below it is kept)
       coarse_on_ = true;
       return iters0 + pcg();
@@ -2798,6 +2807,7 @@ class GpSolver final : public LmProblem {
   bool coarse_said_ = false;
   int coarse_grow_ = 0;
   int pcg_hint_ = 0;     // iteration count of the previous reduced solve (where cg_solve first reads the status back)
+  int pcg_calls_ = 0;    // reduced solves of this LM problem so far
   RitzStore ritz_;       // what is known about the recycled Ritz vectors in ws->rc_U
   double radius_ = 0.0;  // trust-region radius of the current step()
   int gridTileA_ = 1;    // k_gp_phaseA: exactly one wave per tile

@@ -4,7 +4,7 @@
   TrackFilter.FilterTracksByReprojection / FilterTracksByAngle / FilterTrackTriangulationAngle
       (glomap/processors/track_filter.h:9-31), NormalizeReconstruction
       (glomap/processors/reconstruction_normalizer.h), RelPoseFilter.FilterRotations
-      (glomap/processors/relpose_filter.h).
+      (glomap/processors/relpose_filter.h), UndistortFeatures (glomap/processors/image_undistorter.cc:7-46).
 
 Flat level only: arrays as in gsfm_scene_view (numpy on the host or DeviceArrays in HBM); results are keep
 masks + the counter the reference returns.  Nothing here computes on the CPU."""
@@ -104,6 +104,24 @@ class TrackFilter:
         if rc != 0:
             raise _lib.GsfmError(rc, "gsfm_filter_tracks_triangulation_angle")
         return out, n.value
+
+
+def UndistortFeatures(feat_xy, feat_intr, intr_model, intr_params, ctx=None):
+    """gsfm_undistort_features — what UndistortImages (image_undistorter.cc:7-46) stores in Image::features_undist: the unit
+    bearing camera.CamFromImg(xy).value_or(Zero).homogeneous().normalized() of every pixel feat_xy [F,2] seen through intrinsics
+    row feat_intr [F] of intr_model [K] / intr_params [K,8] or [K,16].  numpy arrays (host) or DeviceArrays (the rays stay in
+    HBM).  Returns rays [F,3]."""
+    ctx = ctx or default_context()
+    xy, fi = _h(feat_xy, np.float64), _h(feat_intr, np.int32)
+    im, ip_ = _h(intr_model, np.int32), _h(intr_params, np.float64)
+    mem = _mem_of(xy, fi, im, ip_)
+    F = int(xy.shape[0])
+    out = np.zeros((F, 3)) if mem == _lib.GSFM_MEM_HOST else _lib.DeviceArray(ctx, (F, 3), np.float64)
+    rc = ctx.lib.gsfm_undistort_features(ctx.handle, mem, F, _lib.ptr(xy), _lib.ptr(fi), int(im.shape[0]), _lib.ptr(im), _lib.ptr(ip_),
+                                         int(ip_.shape[1]), _lib.ptr(out))
+    if rc != 0:
+        raise _lib.GsfmError(rc, "gsfm_undistort_features")
+    return out
 
 
 def CompactObservations(pt_offset, arrays, obs_keep=None, track_keep=None, ctx=None):

@@ -373,10 +373,11 @@ def project_full_opencv(params, xc):
 
 
 def make_ba_problem_wide(num_cams: int = 10_000, num_pts: int = 1_000_000, model: str = "full_opencv", seed: int = 0,
-                         shared_intrinsics: bool = False, pixel_noise: float = 0.5, **kw) -> BaProblem:
+                         shared_intrinsics: bool = False, pixel_noise: float = 0.5, num_intr_groups: int = 0, **kw) -> BaProblem:
     """make_ba_problem's scene observed through a 12-parameter FULL_OPENCV camera (16-wide intrinsics rows: the unit of
     csrc/ba_wide.hip; the reference dispatches any CameraModelId, bundle_adjustment.cc:136-139): same cameras, points, tracks,
-    perturbed start and outliers; the observations of the inlier tracks re-projected through the wide model + pixel noise."""
+    perturbed start and outliers; the observations of the inlier tracks re-projected through the wide model + pixel noise.
+    num_intr_groups = G > 0: G cameras shared by the images round-robin (default: one camera per image)."""
     from .flat import CAMERA_FULL_OPENCV, CAMERA_MAX_PARAMS_WIDE
 
     assert model == "full_opencv"
@@ -393,6 +394,13 @@ def make_ba_problem_wide(num_cams: int = 10_000, num_pts: int = 1_000_000, model
     inl = np.abs(resid).max(1) < 10.0 * max(pixel_noise, 1e-9) + 1e-9
     xy = project_full_opencv(wide[p.cam_intr[p.obs_cam]], xc)
     p.obs_xy = np.ascontiguousarray(np.where(inl[:, None], xy + resid, p.obs_xy))
+    if num_intr_groups > 0 and not shared_intrinsics:
+        # G physical cameras, image n taken with camera n mod G (a capture with a handful of devices): twelve parameters per
+        # camera are determined by N / G images each instead of by one image's few hundred observations
+        K = min(num_intr_groups, num_cams)
+        p.cam_intr = (np.arange(num_cams) % K).astype(np.int32)
+        p.num_intr = K
+        wide = wide[:K]
     p.intr_model = np.full(K, CAMERA_FULL_OPENCV, dtype=np.int32)
     p.intr_params = wide.copy()
     p.gt_intr = wide

@@ -552,6 +552,16 @@ int gsfm_filter_tracks_by_angle(gsfm_ctx* ctx, const gsfm_scene_view* view, doub
 /* track_keep_out [P]: 0 = the reference clears the track's observations; *tracks_removed counts them. */
 int gsfm_filter_tracks_triangulation_angle(gsfm_ctx* ctx, const gsfm_scene_view* view, double min_angle_deg,
                                            uint8_t* track_keep_out, int64_t* tracks_removed);
+/* UndistortImages (glomap/processors/image_undistorter.cc:7-46; called at global_mapper.cc:62,155,237,263,307,325 — before GP
+ * and again after every bundle-adjustment round that moved the intrinsics): rays_out[i] [F][3] =
+ * camera.CamFromImg(feat_xy[i]).value_or(Zero).homogeneous().normalized(), the unit bearing of pixel feat_xy[i] [F][2] seen
+ * through intrinsics row feat_intr[i] [F] of intr_model [K] / intr_params [K][intr_stride] (0 / 8, or 16 for the models with
+ * more than eight parameters).  A pixel whose iteration does not converge to finite coordinates gets (0, 0, 1), as
+ * value_or(Zero) gives.  mem == GSFM_MEM_DEVICE: all five arrays in HBM, nothing crosses PCIe — the bearings for the filters
+ * of the BA outer loop (global_mapper.cc:229-263) are refreshed where the intrinsics live. */
+int gsfm_undistort_features(gsfm_ctx* ctx, int32_t mem, int64_t num_feat, const double* feat_xy, const int32_t* feat_intr,
+                            int32_t num_intr, const int32_t* intr_model, const double* intr_params, int32_t intr_stride,
+                            double* rays_out);
 /* Compaction after a filter: the reference erases the dropped observations from Track::observations
  * (track_filter.cc:36-44, 75-83) or clears a whole track's list (:120-123); in the flat layout the survivors move up, in
  * order.  Observation k of track p survives when obs_keep[k] != 0 (NULL: all) and track_keep[p] != 0 (NULL: all).

@@ -147,3 +147,59 @@ def filter_rotations(node_q, edge_i, edge_j, edge_q, max_angle_deg):
     ang = np.degrees(np.arccos(cos))
     keep = ~(ang > max_angle_deg)
     return keep, int((~keep).sum())
+
+
+def undistort_features(feat_xy, feat_intr, intr_model, intr_params, max_iter=100, max_step_sq=1e-10, rel_step=1e-6):
+    """UndistortImages, glomap/processors/image_undistorter.cc:7-46: rays [F,3] =
+    camera.CamFromImg(xy).value_or(Zero).homogeneous().normalized().
+
+    CamFromImg of a COLMAP camera model (colmap/sensor/models.h — un-vendored; restated as published, PARITY UNPINNED for this
+    function) maps the pixel to the normalised plane through the model's (f, c) and, for a model with distortion, inverts
+    x + dx(x) = x0 by BaseCameraModel::IterativeUndistortion: Newton with a CENTRAL-DIFFERENCE Jacobian (relative step 1e-6,
+    floor machine epsilon), at most 100 iterations, stop when |step|^2 < 1e-10.  Written here on top of oracle.ba.project (the
+    forward model ImgFromCam the bundle adjustment is pinned with): x + dx(x) = K^-1 (project((x, 1)) - c).  The product
+    (filters.hip k_undistort) runs the same iteration with the analytic Jacobian of its own projection; the two agree to the
+    stop's precision and both satisfy project(ray) = pixel (tests/test_filters.py)."""
+    xy = np.asarray(feat_xy, dtype=np.float64)
+    ik = np.asarray(feat_intr, dtype=np.int64)
+    model = np.asarray(intr_model)[ik]
+    par = np.asarray(intr_params, dtype=np.float64)[ik]
+    F = xy.shape[0]
+
+    def img(x):  # pixel of the ray (x, 1)
+        uv, _, _, _ = oba.project(model, par, np.concatenate([x, np.ones((F, 1))], 1))
+        return uv
+
+    zero = np.zeros((F, 2))
+    c = img(zero)
+    h = 1e-6
+    fx = (img(zero + [h, 0.0]) - img(zero - [h, 0.0]))[:, 0] / (2 * h)  # the model's focal lengths, read off its own projection
+    fy = (img(zero + [0.0, h]) - img(zero - [0.0, h]))[:, 1] / (2 * h)
+    K = np.stack([fx, fy], 1)
+    x0 = (xy - c) / K
+    x = x0.copy()
+    active = np.ones(F, dtype=bool)
+    for _ in range(max_iter):
+        if not active.any():
+            break
+        step = np.maximum(np.finfo(np.float64).eps, np.abs(rel_step * x))
+        d = lambda y: (img(y) - c) / K - y  # dx(y)
+        dx = d(x)
+        e0, e1 = np.zeros((F, 2)), np.zeros((F, 2))
+        e0[:, 0], e1[:, 1] = step[:, 0], step[:, 1]
+        d0f, d0b, d1f, d1b = d(x + e0), d(x - e0), d(x + e1), d(x - e1)
+        J = np.empty((F, 2, 2))
+        J[:, 0, 0] = 1 + (d0f[:, 0] - d0b[:, 0]) / (2 * step[:, 0])
+        J[:, 0, 1] = (d1f[:, 0] - d1b[:, 0]) / (2 * step[:, 1])
+        J[:, 1, 0] = (d0f[:, 1] - d0b[:, 1]) / (2 * step[:, 0])
+        J[:, 1, 1] = 1 + (d1f[:, 1] - d1b[:, 1]) / (2 * step[:, 1])
+        rhs = x + dx - x0
+        det = J[:, 0, 0] * J[:, 1, 1] - J[:, 0, 1] * J[:, 1, 0]
+        sx = np.stack([(J[:, 1, 1] * rhs[:, 0] - J[:, 0, 1] * rhs[:, 1]) / det, (J[:, 0, 0] * rhs[:, 1] - J[:, 1, 0] * rhs[:, 0]) / det], 1)
+        sx = np.where(active[:, None], sx, 0.0)
+        x = x - sx
+        active &= ~((sx * sx).sum(1) < max_step_sq)
+    ok = np.isfinite(x).all(1)
+    x = np.where(ok[:, None], x, 0.0)
+    ray = np.concatenate([x, np.ones((F, 1))], 1)
+    return ray / np.linalg.norm(ray, axis=1, keepdims=True)

@@ -337,6 +337,16 @@ struct RefShimInlierList {
   void assign(size_t count, int) { n = count; }
   void resize(size_t count) { n = count; }
   void clear() { n = 0; }
+  // Iteration (the adapter header's track establishment walks pair.inliers; it is compiled into these translation units but never
+  // called by the rotation-averaging controller): the count stands for the first n rows of `matches`.
+  struct It {
+    int i;
+    int operator*() const { return i; }
+    It& operator++() { ++i; return *this; }
+    bool operator!=(const It& o) const { return i != o.i; }
+  };
+  It begin() const { return It{0}; }
+  It end() const { return It{static_cast<int>(n)}; }
 };
 #else
 using RefShimInlierList = std::vector<int>;

@@ -219,3 +219,78 @@ def test_gpu_tracks_compact_matches_numpy(gsfm_ctx, case):
     assert n == int(want_off[-1]) and np.array_equal(d_off.numpy(), want_off)
     for a, b in zip(cut, want):
         assert a.shape == b.shape and np.array_equal(a.numpy(), b)
+
+
+# every COLMAP camera model of include/gsfm.h with parameters that bend the image noticeably
+_MODELS = {
+    0: [1200, 640, 480], 1: [1200, 1190, 640, 480], 2: [1200, 640, 480, 0.02], 3: [1200, 640, 480, 0.02, -0.01],
+    4: [1200, 1190, 640, 480, 0.02, -0.01, 0.001, -0.002], 5: [1200, 1190, 640, 480, 0.02, -0.01, 0.004, -0.002],
+    7: [1200, 1190, 640, 480, 0.8], 8: [1200, 640, 480, 0.02], 9: [1200, 640, 480, 0.02, -0.01],
+    6: [1200, 1190, 640, 480, 0.02, -0.01, 0.001, -0.002, 0.003, 0.01, -0.004, 0.002],
+    10: [1200, 1190, 640, 480, 0.02, -0.01, 0.001, -0.002, 0.004, -0.002, 0.0015, -0.001],
+    11: [1200, 1190, 640, 480, 0.02, -0.01, 0.004, -0.002, 0.001, -0.0005, 0.001, -0.002, 0.0015, -0.0008, -0.001, 0.0005],
+}
+
+
+def _undistort_case(models, F, width, seed=0):
+    """F pixels = projections of random rays (|u|, |v| <= 0.5) through cameras of the given models, round-robin."""
+    from oracle import ba as oba
+
+    rng = np.random.default_rng(seed)
+    K = len(models)
+    par = np.zeros((K, width))
+    for k, m in enumerate(models):
+        par[k, : len(_MODELS[m])] = _MODELS[m]
+        par[k, 0] *= 1.0 + 0.01 * k  # (not all cameras alike)
+    model = np.array(models, dtype=np.int32)
+    fi = (np.arange(F) % K).astype(np.int32)
+    ray = np.concatenate([rng.uniform(-0.5, 0.5, (F, 2)), np.ones((F, 1))], 1)
+    uv, _, _, valid = oba.project(model[fi], np.pad(par, ((0, 0), (0, 16 - width)))[fi], ray)
+    assert valid.all()
+    return uv, fi, model, par, ray / np.linalg.norm(ray, axis=1, keepdims=True)
+
+
+def test_oracle_undistortion_inverts_the_projection_of_every_camera_model():
+    """oracle.filters.undistort_features (UndistortImages, image_undistorter.cc:7-46, COLMAP's IterativeUndistortion restated):
+    project(undistort(pixel)) = pixel for the twelve models."""
+    for m in _MODELS:
+        uv, fi, model, par, ray = _undistort_case([m], 300, 16, seed=m)
+        out = of.undistort_features(uv, fi, model, par)
+        assert np.allclose(np.linalg.norm(out, axis=1), 1.0, atol=1e-14)
+        assert np.abs(out - ray).max() < 1e-9, (m, np.abs(out - ray).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("width", [8, 16])
+def test_gpu_undistortion_matches_oracle(gsfm_ctx, width):
+    """gsfm_undistort_features against the oracle on a mix of camera models (8-wide rows: the nine models with at most eight
+    parameters; 16-wide: all twelve), host arrays and device arrays; a pixel far outside any image converges or comes back
+    as (0, 0, 1) on both sides."""
+    from glomap_amd import processors
+
+    models = [m for m in sorted(_MODELS) if width == 16 or len(_MODELS[m]) <= 8]
+    uv, fi, model, par, ray = _undistort_case(models, 20_000, width, seed=3)
+    want = of.undistort_features(uv, fi, model, par)
+    got = processors.UndistortFeatures(uv, fi, model, par, ctx=gsfm_ctx)
+    d = np.abs(got - want).max()
+    print(f"[parity] undistortion, {len(models)} camera models, {width}-wide rows: max |ray - oracle| {d:.2e}, max |ray - truth| {np.abs(got - ray).max():.2e}")
+    assert d < 1e-9 and np.abs(got - ray).max() < 1e-9
+    dev = processors.UndistortFeatures(gsfm_ctx.to_device(uv), gsfm_ctx.to_device(fi), gsfm_ctx.to_device(model),
+                                       gsfm_ctx.to_device(par), ctx=gsfm_ctx)
+    assert np.array_equal(dev.numpy(), got)
+
+
+@pytest.mark.gpu
+def test_gpu_undistortion_rejects_malformed_input_and_scales(gsfm_ctx):
+    from glomap_amd import _lib, processors
+
+    uv, fi, model, par, ray = _undistort_case([2], 3_000_000, 8, seed=5)  # configs[2]-size feature set, SIMPLE_RADIAL
+    got = processors.UndistortFeatures(uv, fi, model, par, ctx=gsfm_ctx)
+    assert np.abs(got - ray).max() < 1e-9
+    bad = fi.copy()
+    bad[17] = 4
+    with pytest.raises(_lib.GsfmError):
+        processors.UndistortFeatures(uv[:100], bad[:100], model, par, ctx=gsfm_ctx)
+    with pytest.raises(_lib.GsfmError):  # a 12-parameter model in 8-wide rows
+        processors.UndistortFeatures(uv[:100], fi[:100], np.array([6], dtype=np.int32), par, ctx=gsfm_ctx)
+    assert processors.UndistortFeatures(uv[:0], fi[:0], model, par, ctx=gsfm_ctx).shape == (0, 3)

@@ -587,3 +587,34 @@ def test_chain_2k_final_poses_match_the_oracle_chain(gsfm_ctx, seed):
     situation of DESIGN.md section 2 "BA, one camera shared by all images"; there is no exact reference on that stretch."""
     name = "chain_2k_oracle.npz" if seed == 0 else f"chain_2k_s{seed}_oracle.npz"
     _assert_chain(*_chain_against_fixture(name, 2_000, 200_000, gsfm_ctx, seed=seed))
+
+
+def test_ba_config4_full_opencv_matches_cpu_oracle(gsfm_ctx):
+    """configs[3] size through a 12-parameter camera model (the 16-wide unit, csrc/ba_wide.hip; the reference dispatches any
+    CameraModelId, bundle_adjustment.cc:136-139): 10k images / 1M tracks / ~5M observations, 100 FULL_OPENCV cameras shared
+    round-robin, against the C++ oracle's result frozen in tests/golden/ba_c4_full_opencv_oracle.npz
+    (tests/golden/make_ba_wide_golden.py says why a fixture and why 100 cameras).  Bar = north_star."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ba_c4_full_opencv_oracle.npz"))
+    p = synthetic.make_ba_problem_wide(10_000, 1_000_000, "full_opencv", seed=0, num_intr_groups=100)
+    assert p.num_obs == int(g["num_obs"]) and abs(float(np.sum(p.obs_xy)) / float(g["obs_xy_checksum"]) - 1) < 1e-12
+    assert abs(float(np.sum(p.cam_t)) / float(g["cam_t_checksum"]) - 1) < 1e-12
+    gsfm_ctx.stats(reset=True)
+    rc, q, t, X, intr, rep = estimators.ba_solve(p, ctx=gsfm_ctx)
+    st = gsfm_ctx.stats(reset=True)
+    assert rc == 0 and intr.shape == (100, 16)
+    assert st["pcg_deflated"] > 0 and st["pcg_joint_blocks"] == 0  # the wide unit: separate blocks, gauge deflated by application
+    assert abs(rep["initial_cost"] - float(g["out_initial_cost"])) <= 1e-10 * float(g["out_initial_cost"])
+    assert abs(rep["iterations"] - int(g["out_iterations"])) <= 3
+    assert abs(rep["final_cost"] - float(g["out_final_cost"])) <= 1e-4 * float(g["out_final_cost"])
+    ang = np.radians(so3.rotation_angle_deg(so3.quat_to_rotmat(q), so3.quat_to_rotmat(g["out_q"])))
+    cg = -np.einsum("nji,nj->ni", so3.quat_to_rotmat(q), t)
+    co = -np.einsum("nji,nj->ni", so3.quat_to_rotmat(g["out_q"]), g["out_t"])
+    dc = np.linalg.norm(cg - co, axis=1).max() / _extent(co)
+    print(f"\n[parity] BA configs[3] FULL_OPENCV (100 cameras): LM {rep['iterations']} vs {int(g['out_iterations'])}, final cost "
+          f"{rep['final_cost']:.3f} vs {float(g['out_final_cost']):.3f}, max rotation distance {ang.max():.3e} rad (bar 1e-4), max centre "
+          f"distance / extent {dc:.3e} (bar 1e-3), focal lengths {np.abs(intr[:, :2] - g['out_intr'][:, :2]).max():.3e} px")
+    assert ang.max() < 1e-4
+    assert dc < 1e-3
+    assert np.array_equal(intr[:, 2:4], p.intr_params[:, 2:4]) and np.array_equal(intr[:, 12:], np.zeros((100, 4)))

@@ -19,7 +19,7 @@ BUDGET = {
     "k_gp_phaseA<true>": 64,           # (non-temporal tile streams; <false> is the A/B twin)
     "k_gp_phaseB": 96,
     "k_gp_phaseB_x<2>": 72,             # two tiles per wave: 7 waves per SIMD
-    "k_gp_wsum": 48,
+    "k_gp_wsum": 64,                    # 1 024-thread blocks (16 waves); + the dot products with the recycled Ritz vectors
     "k_ba_phaseA<2, true>": 104,
     "k_ba_phaseB<false>": 224,          # 2 waves per SIMD; the WIDE instance (fisheye / FOV) is allowed 1
     "k_ba_cost<false>": 64,

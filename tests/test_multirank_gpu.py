@@ -65,6 +65,10 @@ def _gp_with_pairs():
     return gp, estimators.GlobalPositionerOptions(constraint_type=2, constraint_reweight_scale=2.0)
 
 
+def _ba_wide():
+    return synthetic.make_ba_problem_wide(30, 1500, "full_opencv", seed=4, num_intr_groups=3)
+
+
 def _worker(rank, world, port, ra_init, q, transport="host"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       GSFM_PEER_TIMEOUT_S="30")
@@ -107,6 +111,11 @@ def _worker(rank, world, port, ra_init, q, transport="host"):
     s, (lo, hi) = sharding.shard_ba_problem(ba, rank, world)
     rc, q_, t_, X_, intr_, rep = estimators.ba_solve(s, ctx=ctx)
     out["ba"] = (rc, q_, t_, intr_, X_, (lo, hi), rep)
+    # BA through a 12-parameter camera model: the 16-wide unit (csrc/ba_wide.hip), tracks sharded like the narrow one
+    baw = _ba_wide()
+    s, _ = sharding.shard_ba_problem(baw, rank, world)
+    rc, q_, t_, X_, intr_, rep = estimators.ba_solve(s, ctx=ctx)
+    out["ba_wide"] = (rc, q_, t_, intr_, rep)
     q.put((rank, out))
     dist.barrier()
     ctx.close()
@@ -186,6 +195,22 @@ def test_ranks_reproduce_single_rank(gsfm_ctx, world, transport):
         assert np.abs(intr_ - intr1).max() < 1e-6
         assert np.abs(X_ - X1[lo:hi]).max() < 1e-6 * (1 + np.abs(X1).max())
     assert all(np.array_equal(res[0]["ba"][1], res[r]["ba"][1]) for r in ranks)
+
+    # --- BA, 16-wide unit (FULL_OPENCV): the same sharding through ba_wide.hip
+    baw = _ba_wide()
+    rc, qw1, tw1, Xw1, iw1, rep_w1 = estimators.ba_solve(baw, ctx=gsfm_ctx)
+    assert rc == 0 and iw1.shape[1] == 16
+    for r in ranks:
+        rc, q_, t_, intr_, rep = res[r]["ba_wide"]
+        assert rc == 0 and intr_.shape == iw1.shape
+        assert rep["iterations"] == rep_w1["iterations"]
+        assert abs(rep["final_cost"] - rep_w1["final_cost"]) <= 1e-8 * rep_w1["final_cost"]
+        ang = np.radians(so3.rotation_angle_deg(so3.quat_to_rotmat(q_), so3.quat_to_rotmat(qw1)))
+        assert ang.max() < 1e-6
+        assert np.abs(t_ - tw1).max() < 1e-6 * (1 + np.abs(tw1).max())
+        assert np.abs(intr_ - iw1).max() < 1e-4 * (1 + np.abs(iw1).max())
+    assert all(np.array_equal(res[0]["ba_wide"][1], res[r]["ba_wide"][1]) for r in ranks)
+    assert all(np.array_equal(res[0]["ba_wide"][3], res[r]["ba_wide"][3]) for r in ranks)
 
 
 def _big_problems():

@@ -1,7 +1,8 @@
 """GPU vs C++ oracle: bundle adjustment with a 12-parameter camera model (FULL_OPENCV, the 16-wide unit ba_wide.hip /
 orc_ba_wide.cc) at BASELINE sizes — one camera per image, start = ground truth + noise, the library's default options.
 
-Usage: python tools/exp_ba_wide_fullsize.py [cams tracks]...      default: 2000 200000   10000 1000000"""
+Usage: python tools/exp_ba_wide_fullsize.py [cams tracks groups]...      default: 2000 200000 20   10000 1000000 100
+(groups = physical cameras shared by the images round-robin; 0 = one camera per image)"""
 import json
 import os
 import sys
@@ -19,10 +20,10 @@ from oracle import cpu  # noqa: E402
 
 def main():
     a = [int(v) for v in sys.argv[1:]]
-    cases = [tuple(a[i:i + 2]) for i in range(0, len(a), 2)] or [(2000, 200000), (10000, 1000000)]
+    cases = [tuple(a[i:i + 3]) for i in range(0, len(a), 3)] or [(2000, 200000, 20), (10000, 1000000, 100)]
     ctx = Context()
-    for (N, P) in cases:
-        p = synthetic.make_ba_problem_wide(N, P, "full_opencv", seed=0)
+    for (N, P, G) in cases:
+        p = synthetic.make_ba_problem_wide(N, P, "full_opencv", seed=0, num_intr_groups=G)
         best = None
         for _ in range(2):
             ctx.stats(reset=True)
@@ -40,7 +41,7 @@ def main():
         ang = np.radians(so3.rotation_angle_deg(Rg, Ro))
         cg, co = -np.einsum("nji,nj->ni", Rg, t), -np.einsum("nji,nj->ni", Ro, r[2])
         ext = np.linalg.norm(co - co.mean(0), axis=1).max()
-        print(json.dumps(dict(cams=N, tracks=P, observations=int(p.num_obs), rc=rc, gpu_lm=rep["iterations"], gpu_accepted=rep["successful_steps"],
+        print(json.dumps(dict(cams=N, tracks=P, intrinsics_blocks=int(p.num_intr), observations=int(p.num_obs), rc=rc, gpu_lm=rep["iterations"], gpu_accepted=rep["successful_steps"],
                               gpu_pcg=rep["linear_iterations"], gpu_ms_incl_h2d=round(best, 1), gpu_final_cost=rep["final_cost"],
                               initial_cost=(rep["initial_cost"], s.initial_cost), oracle_lm=s.iterations, oracle_final_cost=s.final_cost,
                               oracle_seconds=round(sec, 1), oracle_max_linear_residual=s.max_linear_residual, solver_paths=st,
