@@ -1337,6 +1337,62 @@ inline std::array<double, 4> NormalizeReconstruction(std::unordered_map<rig_t, g
   return sim;
 }
 
+// image_undistorter.cc:7-46: features_undist[i] = camera.CamFromImg(features[i]).value_or(Zero).homogeneous().normalized() for every
+// image whose bearings are missing — or for all of them with clean_points (what global_mapper.cc:237,263,307,325 asks for after
+// the intrinsics moved).  One gsfm_undistort_features sweep over all features of all those images instead of a thread pool.
+inline void UndistortImages(std::unordered_map<camera_t, glomap::Camera>& cameras,
+                            std::unordered_map<image_t, glomap::Image>& images, bool clean_points = true) {
+  gsfm_ctx* ctx = Context();
+  if (ctx == nullptr) return;
+  std::vector<image_t> ids;
+  for (auto& [iid, im] : images) {
+    if (im.features_undist.size() == im.features.size() && !clean_points) continue;  // already undistorted (:13-15)
+    ids.push_back(iid);
+  }
+  if (ids.empty()) return;
+  std::unordered_map<camera_t, int32_t> row;
+  std::vector<int32_t> model;
+  std::vector<double> intr;
+  int stride = GSFM_CAMERA_MAX_PARAMS;
+  for (const image_t iid : ids) {
+    const camera_t cid = images.at(iid).camera_id;
+    if (row.count(cid)) continue;
+    const int m = detail::ModelOf(cameras.at(cid));
+    if (m < 0) return;  // a camera model the library does not know: leave the images to the caller
+    if (detail::NeedsWideRows(m)) stride = GSFM_CAMERA_MAX_PARAMS_WIDE;
+    row.emplace(cid, static_cast<int32_t>(model.size()));
+    model.push_back(m);
+  }
+  intr.assign(static_cast<size_t>(stride) * model.size(), 0.0);
+  for (const auto& [cid, k] : row) {
+    const auto& cam = cameras.at(cid);
+    for (size_t j = 0; j < cam.params.size() && j < static_cast<size_t>(stride); ++j) intr[static_cast<size_t>(stride) * k + j] = cam.params[j];
+  }
+  std::vector<double> xy;
+  std::vector<int32_t> fi;
+  for (const image_t iid : ids) {
+    const auto& im = images.at(iid);
+    const int32_t k = row.at(im.camera_id);
+    for (const auto& f : im.features) {
+      xy.push_back(f[0]);
+      xy.push_back(f[1]);
+      fi.push_back(k);
+    }
+  }
+  std::vector<double> rays(3 * fi.size());
+  if (gsfm_undistort_features(ctx, GSFM_MEM_HOST, static_cast<int64_t>(fi.size()), xy.data(), fi.data(), static_cast<int32_t>(model.size()),
+                              model.data(), intr.data(), stride, rays.data()) != GSFM_OK)
+    return;
+  size_t o = 0;
+  for (const image_t iid : ids) {
+    auto& im = images.at(iid);
+    im.features_undist.clear();
+    im.features_undist.reserve(im.features.size());
+    for (size_t i = 0; i < im.features.size(); ++i, ++o)
+      im.features_undist.emplace_back(rays[3 * o], rays[3 * o + 1], rays[3 * o + 2]);
+  }
+}
+
 struct RelPoseFilter {
   // relpose_filter.cc:7-33: invalidates pairs whose measured rotation disagrees with the estimated one
   static void FilterRotations(glomap::ViewGraph& view_graph, const std::unordered_map<image_t, glomap::Image>& images,

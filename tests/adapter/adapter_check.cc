@@ -293,6 +293,41 @@ int main() {
     frames = frames_b;
     for (int n = 0; n < N; ++n) images[n].frame_ptr = &frames[n];
   }
+  // 3c) UndistortImages (image_undistorter.cc:7-46) on the adapter: the bearings of the PINHOLE scene are recomputed from its
+  //     pixels (clean_points), then the same rays are pushed through a SIMPLE_RADIAL camera with k = 0.05 and recovered; with
+  //     clean_points = false an image that already has its bearings is left alone.
+  {
+    auto imgs = images;
+    const auto cams_before = cameras;
+    for (auto& [iid, im] : imgs) im.features_undist.clear();
+    gsfm_glomap::UndistortImages(cameras, imgs, true);
+    double e = 0;
+    for (auto& [iid, im] : imgs) {
+      if (im.features_undist.size() != im.features.size()) return std::printf("UndistortImages left image %d without bearings\n", (int)iid), 1;
+      for (size_t i = 0; i < im.features.size(); ++i)
+        for (int j = 0; j < 3; ++j) e = std::fmax(e, std::fabs(im.features_undist[i][j] - images[iid].features_undist[i][j]));
+    }
+    if (e > 1e-12) return std::printf("UndistortImages (PINHOLE): %.3e\n", e), 1;
+    cameras[1].model_id = 2;  // SIMPLE_RADIAL f, cx, cy, k
+    cameras[1].params = {800.0, 320.0, 240.0, 0.05};
+    for (auto& [iid, im] : imgs)
+      for (size_t i = 0; i < im.features.size(); ++i) {
+        const auto& r = images[iid].features_undist[i];
+        const double u = r[0] / r[2], v = r[1] / r[2], d = 1.0 + 0.05 * (u * u + v * v);
+        im.features[i] = mock_eigen::Vector2d(800.0 * u * d + 320.0, 800.0 * v * d + 240.0);
+      }
+    imgs[0].features_undist[0] = mock_eigen::Vector3d(0.0, 0.6, 0.8);  // a stale bearing
+    gsfm_glomap::UndistortImages(cameras, imgs, false);  // nothing to do: every image has as many bearings as features
+    if (imgs[0].features_undist[0][1] != 0.6) return std::printf("UndistortImages(clean_points = false) recomputed a complete image\n"), 1;
+    gsfm_glomap::UndistortImages(cameras, imgs, true);
+    double e2 = 0;
+    for (auto& [iid, im] : imgs)
+      for (size_t i = 0; i < im.features.size(); ++i)
+        for (int j = 0; j < 3; ++j) e2 = std::fmax(e2, std::fabs(im.features_undist[i][j] - images[iid].features_undist[i][j]));
+    if (e2 > 1e-10) return std::printf("UndistortImages (SIMPLE_RADIAL): %.3e\n", e2), 1;
+    std::printf("UndistortImages: PINHOLE %.1e, SIMPLE_RADIAL (k = 0.05) %.1e from the true bearings\n", e, e2);
+    cameras = cams_before;
+  }
   // 4) processors: a corrupted observation is filtered, a far point has no triangulation angle,
   //    a wrong relative rotation is invalidated, normalisation scales the ring of centres to extent 10
   {
