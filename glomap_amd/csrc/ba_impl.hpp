@@ -1989,8 +1989,6 @@ class BaSolver final : public LmProblem {
     // optimize_rig_poses (ba.cc:161-179): the sensor blocks are pose blocks N_ .. N_ + S_ - 1 behind the frames
     S_ = opt_.optimize_rig_poses ? num_sensors : 0;
     sens_ = S_ > 0;
-    if (sens_ && ctx_->comm.world > 1)
-      throw StatusError(GSFM_ERR_UNSUPPORTED, "BA: optimize_rig_poses is solved on one rank");
     Np_ = N_ + S_;
     n_ = 6 * Np_ + KP * K_;
     std::vector<long> h_off;

@@ -1765,8 +1765,6 @@ class GpSolver final : public LmProblem {
         GSFM_REQUIRE(prob->image_sensor && prob->image_sensor_rot && prob->sensor_center, "GP: sensor tables missing");
         if (!opt_.optimize_positions)
           throw StatusError(GSFM_ERR_UNSUPPORTED, "GP: unknown cam_from_rig centres need optimize_positions");
-        if (ctx_->comm.world > 1)
-          throw StatusError(GSFM_ERR_UNSUPPORTED, "GP: unknown cam_from_rig centres are solved on one rank");
         to_host(ctx_, h_ims, prob->image_sensor, (size_t)NI_, mem);
         for (int i = 0; i < NI_; ++i) GSFM_REQUIRE(h_ims[i] >= -1 && h_ims[i] < S_, "GP: image_sensor out of range");
       }

@@ -35,13 +35,18 @@ def shard_gp_problem(p, rank: int, world: int):
 
     lo, hi = shard_tracks(p.pt_offset, rank, world)
     o0, o1 = int(p.pt_offset[lo]), int(p.pt_offset[hi])
-    return GpProblem(
+    s = GpProblem(
         num_cams=p.num_cams, num_pts=hi - lo, pt_offset=(p.pt_offset[lo : hi + 1] - o0).astype(np.int64),
         obs_cam=p.obs_cam[o0:o1].copy(), obs_dir=p.obs_dir[o0:o1].copy(), obs_calibrated=p.obs_calibrated[o0:o1].copy(),
         cam_center=p.cam_center.copy(), pt_xyz=p.pt_xyz[lo:hi].copy(),
         # camera-to-camera constraints live in camera space: every rank carries all of them (rank 0 adds their terms)
         pair_i=getattr(p, "pair_i", None), pair_j=getattr(p, "pair_j", None), pair_dir=getattr(p, "pair_dir", None),
-    ), (lo, hi)
+    )
+    # rig tables are per image / per sensor block: replicated like the cameras
+    for name in ("image_frame", "image_offset", "image_sensor", "image_sensor_rot", "sensor_center"):
+        if getattr(p, name, None) is not None:
+            setattr(s, name, getattr(p, name))
+    return s, (lo, hi)
 
 
 def shard_ba_problem(p, rank: int, world: int):

@@ -299,6 +299,7 @@ int main() {
   {
     auto imgs = images;
     const auto cams_before = cameras;
+    cameras[1].params = {800.0, 800.0, 320.0, 240.0};  // the intrinsics the scene's pixels and bearings were made with (BA moved them)
     for (auto& [iid, im] : imgs) im.features_undist.clear();
     gsfm_glomap::UndistortImages(cameras, imgs, true);
     double e = 0;

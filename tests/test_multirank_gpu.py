@@ -353,3 +353,124 @@ def test_rccl_transport_in_a_process_that_also_imports_torch():
         assert rc == 0 and np.isfinite(cen).all()
     finally:
         ctx.close()
+
+
+def _rig_problems():
+    """Known rigs (GP image offsets, BA constant cam_from_rig), unknown cam_from_rig centres (GP sensor blocks) and
+    optimize_rig_poses (BA sensor blocks) — the rig branches of gp.cc:318-368 and ba.cc:147-179 — on one scene."""
+    import copy
+
+    gp, ba, info = synthetic.make_rig_problems(30, 3, 3000, seed=4, dir_noise=1e-3, pixel_noise=0.5, outlier_ratio=0.01)
+    gp_unk = synthetic.forget_rig_translations(gp, info)
+    rng = np.random.default_rng(12)
+    s0 = info["sensor_cam_from_rig"].copy()
+    s0[:, :4] = so3.rotmat_to_quat(so3.aa_to_rotmat(rng.normal(0, np.radians(0.5), (s0.shape[0], 3))) @ so3.quat_to_rotmat(s0[:, :4]))
+    s0[:, 4:] += rng.normal(0, 0.03, (s0.shape[0], 3))
+    ba_sens = copy.copy(ba)
+    ba_sens.image_sensor = info["sensor_block"].copy()
+    ba_sens.sensor_cam_from_rig = s0
+    return gp, gp_unk, ba, ba_sens
+
+
+def _rig_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      GSFM_PEER_TIMEOUT_S="60")
+    import torch.distributed as dist
+
+    from glomap_amd import _lib
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = _lib.Context(0)
+
+    def allgather(b):
+        out = [None] * world
+        dist.all_gather_object(out, b)
+        return out
+
+    ctx.comm_init_peer(allgather, rank, world, 1 << 16)
+    gp, gp_unk, ba, ba_sens = _rig_problems()
+    out = {}
+    opt = estimators.GlobalPositionerOptions()
+    opt.solver_options.pcg_relative_tolerance = 1e-10
+    for name, prob in (("gp_known", gp), ("gp_unknown", gp_unk)):
+        s, _ = sharding.shard_gp_problem(prob, rank, world)
+        rc, cen, xyz, rep = estimators.gp_solve(s, opt, ctx=ctx)
+        rep["lm_trace"] = ctx.lm_trace()
+        out[name] = (rc, cen, rep)
+    for name, prob, o in (("ba_known", ba, estimators.BundleAdjusterOptions()),
+                          ("ba_sensors", ba_sens, estimators.BundleAdjusterOptions(optimize_rig_poses=True))):
+        o.solver_options.pcg_relative_tolerance = 1e-10
+        s, _ = sharding.shard_ba_problem(prob, rank, world)
+        rc, q_, t_, X_, intr_, rep = estimators.ba_solve(s, o, ctx=ctx)
+        out[name] = (rc, q_, t_, intr_, rep)
+    q.put((rank, out))
+    dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_reproduce_single_rank_on_rig_problems(gsfm_ctx, world):
+    """Multi-camera rigs with the tracks sharded over the ranks: the image-space quantities of the rig kernels enter frame /
+    sensor space through linear maps in front of the all-reduces the solvers do anyway, so known rigs, unknown cam_from_rig
+    centres (GP sensor blocks, their random start drawn after every rank's points) and optimize_rig_poses (BA sensor blocks)
+    reproduce the single-rank solves."""
+    import multiprocessing as mp
+
+    gp, gp_unk, ba, ba_sens = _rig_problems()
+    opt = estimators.GlobalPositionerOptions()
+    opt.solver_options.pcg_relative_tolerance = 1e-10
+    ref = {}
+    for name, prob in (("gp_known", gp), ("gp_unknown", gp_unk)):
+        rc, cen, xyz, rep = estimators.gp_solve(prob, opt, ctx=gsfm_ctx)
+        assert rc == 0
+        rep["lm_trace"] = gsfm_ctx.lm_trace()
+        ref[name] = (cen, rep)
+    for name, prob, o in (("ba_known", ba, estimators.BundleAdjusterOptions()),
+                          ("ba_sensors", ba_sens, estimators.BundleAdjusterOptions(optimize_rig_poses=True))):
+        o.solver_options.pcg_relative_tolerance = 1e-10
+        rc, q_, t_, X_, intr_, rep = estimators.ba_solve(prob, o, ctx=gsfm_ctx)
+        assert rc == 0
+        ref[name] = (q_, t_, intr_, rep)
+    mpc = mp.get_context("spawn")
+    queue = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_rig_worker, args=(r, world, port, queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(queue.get(timeout=800) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        for name in ("gp_known", "gp_unknown"):
+            rc, cen, rep = res[r][name]
+            cen1, rep1 = ref[name]
+            assert rc == 0
+            assert abs(rep["initial_cost"] - rep1["initial_cost"]) <= 1e-12 * rep1["initial_cost"]  # the same random start
+            assert abs(rep["iterations"] - rep1["iterations"]) <= 3
+            assert abs(rep["final_cost"] - rep1["final_cost"]) <= 1e-3 * rep1["final_cost"]
+            assert synthetic.center_errors_after_sim3(cen, cen1).max() < 1e-3
+            if name == "gp_unknown":
+                sc, _, _ = synthetic.align_sim3(cen, cen1)
+                assert np.abs(rep["sensor_center"] * sc - rep1["sensor_center"]).max() < 1e-3 * np.abs(rep1["sensor_center"]).max()
+            print(f"[parity] {name} on {world} ranks: LM {rep['iterations']} / {rep1['iterations']}, final cost {rep['final_cost']:.9g} / "
+                  f"{rep1['final_cost']:.9g}, centres {synthetic.center_errors_after_sim3(cen, cen1).max():.2e}")
+        for name in ("ba_known", "ba_sensors"):
+            rc, q_, t_, intr_, rep = res[r][name]
+            q1, t1, intr1, rep1 = ref[name]
+            assert rc == 0
+            assert abs(rep["initial_cost"] - rep1["initial_cost"]) <= 1e-12 * rep1["initial_cost"]
+            assert rep["iterations"] == rep1["iterations"]
+            assert abs(rep["final_cost"] - rep1["final_cost"]) <= 1e-8 * rep1["final_cost"]
+            ang = np.radians(so3.rotation_angle_deg(so3.quat_to_rotmat(q_), so3.quat_to_rotmat(q1)))
+            assert ang.max() < 1e-6 and np.abs(t_ - t1).max() < 1e-6 * (1 + np.abs(t1).max())
+            if name == "ba_sensors":
+                sc, sc1 = rep["sensor_cam_from_rig"], rep1["sensor_cam_from_rig"]
+                assert np.abs(sc - sc1).max() < 1e-6
+            print(f"[parity] {name} on {world} ranks: LM {rep['iterations']} / {rep1['iterations']}, final cost {rep['final_cost']:.12g} / "
+                  f"{rep1['final_cost']:.12g}, rotations {ang.max():.2e} rad")
+    for name in ("gp_known", "gp_unknown", "ba_known", "ba_sensors"):
+        assert all(np.array_equal(res[0][name][1], res[r][name][1]) for r in range(world))  # replicated state bit-identical
