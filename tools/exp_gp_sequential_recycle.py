@@ -1,3 +1,7 @@
+"""GPU: global positioning on the sequential capture of configs[2] size (the scene whose reduced solves switch the second-level
+cluster preconditioner on) with and without the knob gp_no_recycle — the experiment behind `!coarse` in GpSolver::pcg's
+`recycle` condition (recycling on top of the second level: 6 139 instead of 6 243 iterations, 698 instead of 628 ms).
+Usage: python tools/exp_gp_sequential_recycle.py"""
 import sys, time, json, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 from glomap_amd import estimators, synthetic

@@ -1,3 +1,4 @@
+# Round 6: rocprofv3 kernel trace of configs[3] GP with the recycled-vector preconditioner on and off (gpurun_out/r06k/).
 set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r06k
 mkdir -p $OUT

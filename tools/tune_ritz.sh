@@ -1,3 +1,5 @@
+# Round 6: sweep of the Ritz-harvest policy constants on configs[3] GP (GSFM_RITZ_* were temporary environment overrides of
+# gp.hip while tuning; the shipped constants are static: this script documents how profiles/r06_gp_ritz_tuning.txt was made).
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r06l
 run() { echo "== $*"; env "$@" python tools/exp_gp_recycle_gpu.py --only on 10000 1000000 0 2>&1 | grep "^{" | python -c "
