@@ -124,6 +124,34 @@ def UndistortFeatures(feat_xy, feat_intr, intr_model, intr_params, ctx=None):
     return out
 
 
+def UndistortImages(cameras, images, clean_points: bool = True, ctx=None):
+    """UndistortImages (glomap/processors/image_undistorter.cc:7-46) on the scene containers of glomap_amd.scene: for every image
+    whose bearings are missing (or for all of them with clean_points) features_undist [F,3] is recomputed from features [F,2]
+    through the image's camera — ONE gsfm_undistort_features sweep over all of them.  `cameras`: {camera_id: scene.Camera},
+    `images`: {image_id: scene.Image}; modified in place."""
+    from .flat import CAMERA_MAX_PARAMS, CAMERA_MAX_PARAMS_WIDE
+
+    todo = [im for im in images.values()
+            if im.features is not None and (clean_points or im.features_undist is None or len(im.features_undist) != len(im.features))]
+    if not todo:
+        return
+    cam_ids = sorted({im.camera_id for im in todo})
+    row = {cid: k for k, cid in enumerate(cam_ids)}
+    width = CAMERA_MAX_PARAMS_WIDE if any(len(cameras[c].params) > CAMERA_MAX_PARAMS for c in cam_ids) else CAMERA_MAX_PARAMS
+    par = np.zeros((len(cam_ids), width))
+    for c, k in row.items():
+        par[k, : len(cameras[c].params)] = cameras[c].params
+    model = np.array([cameras[c].model_id for c in cam_ids], dtype=np.int32)
+    xy = np.concatenate([np.asarray(im.features, dtype=np.float64).reshape(-1, 2) for im in todo])
+    fi = np.concatenate([np.full(len(im.features), row[im.camera_id], dtype=np.int32) for im in todo])
+    rays = UndistortFeatures(xy, fi, model, par, ctx=ctx)
+    o = 0
+    for im in todo:
+        n = len(im.features)
+        im.features_undist = rays[o : o + n].copy()
+        o += n
+
+
 def CompactObservations(pt_offset, arrays, obs_keep=None, track_keep=None, ctx=None):
     """gsfm_tracks_compact: drops the observations a filter flagged (obs_keep [M] and / or track_keep [P], 0 = drop) from a
     track-major observation set, IN PLACE — what the reference does by erasing from Track::observations

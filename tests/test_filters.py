@@ -294,3 +294,25 @@ def test_gpu_undistortion_rejects_malformed_input_and_scales(gsfm_ctx):
     with pytest.raises(_lib.GsfmError):  # a 12-parameter model in 8-wide rows
         processors.UndistortFeatures(uv[:100], fi[:100], np.array([6], dtype=np.int32), par, ctx=gsfm_ctx)
     assert processors.UndistortFeatures(uv[:0], fi[:0], model, par, ctx=gsfm_ctx).shape == (0, 3)
+
+
+@pytest.mark.gpu
+def test_gpu_undistort_images_on_scene_containers(gsfm_ctx):
+    """processors.UndistortImages — the reference's UndistortImages(cameras, images, clean_points) on the containers of
+    glomap_amd.scene: two cameras of different models (8- and 12-parameter: 16-wide rows), clean_points semantics."""
+    from glomap_amd import processors, scene
+
+    uv, fi, model, par, ray = _undistort_case([4, 6], 4000, 16, seed=9)
+    cams = {10: scene.Camera(10, 4, par[0, :8].copy()), 20: scene.Camera(20, 6, par[1, :12].copy())}
+    imgs = {}
+    for i in range(8):
+        sel = np.nonzero(fi == (i % 2))[0][i // 2 :: 4]
+        imgs[i] = scene.Image(i, 10 if i % 2 == 0 else 20, i, features=uv[sel].copy())
+        imgs[i]._truth = ray[sel]
+    imgs[3].features_undist = np.tile([0.0, 0.6, 0.8], (len(imgs[3].features), 1))  # complete, stale
+    processors.UndistortImages(cams, imgs, clean_points=False, ctx=gsfm_ctx)
+    assert np.array_equal(imgs[3].features_undist[0], [0.0, 0.6, 0.8])  # image_undistorter.cc:13-15: already undistorted
+    for i in (0, 1, 2, 4, 5, 6, 7):
+        assert np.abs(imgs[i].features_undist - imgs[i]._truth).max() < 1e-9
+    processors.UndistortImages(cams, imgs, clean_points=True, ctx=gsfm_ctx)
+    assert np.abs(imgs[3].features_undist - imgs[3]._truth).max() < 1e-9
