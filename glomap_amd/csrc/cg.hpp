@@ -1089,6 +1089,18 @@ static __global__ void __launch_bounds__(kBlock)
     for (int i = 0; i <= kCgMaxModes; ++i) out[i] = acc[i];
   }
 }
+// u_j . w of a COMPLETE w, for apply kernels that do not write the partial slots themselves (GP's plain camera-major sweep):
+// one more launch per iteration, kCgrChunks slot rows.  Block (chunk, j) writes ruw[chunk][j]; columns j >= rk stay zero.
+static __global__ void __launch_bounds__(kBlock) k_cgr_dots_w(CgVec v) {
+  __shared__ double smem[4];
+  if (v.st->done) return;
+  const int j = blockIdx.y;
+  double acc[1] = {0.0};
+  const double* u = v.rU + (size_t)j * v.n;
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < (long)v.n; o += (long)gridDim.x * blockDim.x) acc[0] += u[o] * v.w[o];
+  block_sum<1>(acc, smem);
+  if (threadIdx.x == 0) v.ruw[(size_t)blockIdx.x * kCgMaxRecycle + j] = acc[0];
+}
 // z0 += sum_j u_j (u_j . r0) / theta_j after k_cg_init (same grid, same element -> block map): z, its gather mirror, and the
 // partials that depend on z (r.z and (A W)^T z of parity slot 0) are rewritten; block 0 starts the u_j . r recurrence.
 template <int PB>

@@ -1721,7 +1721,7 @@ struct GpWs {
   DevBuf<int> img_frame, foff, fimg, img_sensor, soff, simg;
   DevBuf<double> img_off, ci, cin, hcc_i, gc_i, gred_i, scc_i, zimg, wimg, ximg, zero_i, cz_f, img_rot;
   DevBuf<double> defl_w, defl_aw, defl_awraw, defl_b2, defl_part, defl_small, defl_cd;  // CgDeflation, cg.hpp
-  DevBuf<double> rc_U, rc_G, rc_state, rc_uw, rc_part, rc_zhist, rc_hist, rc_coef, rc_flag;       // CgRecycle, cg.hpp
+  DevBuf<double> rc_U, rc_G, rc_state, rc_uw, rc_part, rc_zhist, rc_hist, rc_coef;       // CgRecycle, cg.hpp
   DevBuf<double> maxpart;
   DevBuf<int> pr_i, pr_j, pr_row, pr_ent;                       // camera-to-camera constraints (GpPairs)
   DevBuf<double> pr_v, pr_s, pr_sn, pr_w, pr_js, pr_qa, pr_qb, pr_part;
@@ -2048,19 +2048,6 @@ class GpSolver final : public LmProblem {
         gridWsum_ = std::min(kMaxApplySlots, grid_for((size_t)Np_, kWsumBlock / 64));  // one wave per camera
       }
       sweepSlots_ = xon_ ? gridWsum_ : gridCam_ + gridMulti_;  // delta partial slots the sweep of `apply` writes
-      xon_all_ = xon_;
-      if (ctx_->comm.world > 1) {  // one flag, max over ranks of "not chunked here"
-        double* f = ws->rc_flag.ensure(1);
-        const double mine = xon_ ? 0.0 : 1.0;
-        GSFM_HIP_CHECK(hipMemcpyAsync(f, &mine, sizeof(double), hipMemcpyHostToDevice, ctx_->stream));
-        allreduce_max(ctx_, f, 1);
-        double any = 1.0;
-        GSFM_HIP_CHECK(hipMemcpyAsync(&any, f, sizeof(double), hipMemcpyDeviceToHost, ctx_->stream));
-        GSFM_HIP_CHECK(hipStreamSynchronize(ctx_->stream));
-        xon_all_ = any == 0.0;
-        if (std::getenv("GSFM_VERBOSE"))
-          fprintf(stderr, "[gsfm gp] rank %d: chunked sweeps %d here, %d on every rank\n", ctx_->comm.rank, (int)xon_, (int)xon_all_);
-      }
     }
     gridTile_ = grid_wide(g_.g.T, kBlock / 64);             // one wave per tile
     gridTileA_ = grid_wide(g_.g.T, kBlock / 64, (size_t)0x7fffffff);
@@ -2669,6 +2656,9 @@ class GpSolver final : public LmProblem {
       if (E_ > 0 && pair_owner_)  // camera-to-camera terms on top of what the sweep wrote
         hipLaunchKernelGGL(k_gpp_apply, dim3(gridPairCam_), dim3(kBlock), 0, s, q_, cg_, N_, (const double*)c_,
                            (const double*)ws->pr_qa.get(), (const double*)ws->pr_qb.get(), sweepSlots_);
+      // recycled Ritz vectors without the chunked sweep (whose k_gp_wsum writes the u_j . w slots on the way): one small launch
+      if (!xon_ && cg_.rk > 0 && !cg_.probe)
+        hipLaunchKernelGGL(k_cgr_dots_w, dim3(kCgrChunks, cg_.rk), dim3(kBlock), 0, s, cg_);
     };
     // second level for chain-like scenes (GpCoarseDev): replaces the deflation of the four global modes, which its coarse
     // space contains
@@ -2715,16 +2705,19 @@ class GpSolver final : public LmProblem {
     // (Not on top of the second level — measured on the sequential capture of configs[2] size, tools/exp_gp_sequential_recycle.py:
     // 6 139 instead of 6 243 iterations but 698 instead of 628 ms; the probed cluster matrix changes with every LM step, and
     // vectors that are Ritz vectors with respect to the previous step's preconditioner make several early solves longer.)
-    const bool recycle = !coarse && xon_all_ && !rig_ && E_ == 0 && g_.opt_c && N_ > kCgSingleMaxBlocks &&
-                         !ctx_->knob[GSFM_KNOB_GP_NO_RECYCLE];
+    // With the chunked sweep the dot products u_j . w ride on k_gp_wsum; without it (smaller shards: eight ranks on configs[3])
+    // they cost one small launch per iteration (k_cgr_dots_w) — still a third fewer iterations.
+    const bool recycle = !coarse && !rig_ && E_ == 0 && g_.opt_c && N_ > kCgSingleMaxBlocks && !ctx_->knob[GSFM_KNOB_GP_NO_RECYCLE];
     if (recycle) {
       const size_t n3 = 3 * (size_t)N_;
       ritz_.expire(radius_, kRitzRadiusRatio, kRitzMaxAge);
       rcy.U = ws->rc_U.ensure(kCgMaxRecycle * n3);
       rcy.G = ws->rc_G.ensure(kCgMaxRecycle * kCgMaxModes);
       rcy.state = ws->rc_state.ensure(4 * kCgMaxRecycle);
-      rcy.uw = ws->rc_uw.ensure((size_t)gridWsum_ * kCgMaxRecycle);
-      rcy.nslots = gridWsum_;
+      rcy.nslots = xon_ ? gridWsum_ : kCgrChunks;
+      rcy.uw = ws->rc_uw.ensure((size_t)rcy.nslots * kCgMaxRecycle);
+      if (!xon_)  // (k_cgr_dots_w writes the columns in use only: the others have to be zero)
+        GSFM_HIP_CHECK(hipMemsetAsync(rcy.uw, 0, (size_t)rcy.nslots * kCgMaxRecycle * sizeof(double), s));
       rcy.part = ws->rc_part.ensure((size_t)kCgrChunks * kCgMaxRecycle * (1 + kCgMaxModes));
       rcy.zhist = ws->rc_zhist.ensure((size_t)kCgHistCap * n3);
       rcy.hist = ws->rc_hist.ensure(2 * kCgHistCap);
@@ -2790,7 +2783,6 @@ class GpSolver final : public LmProblem {
   long ls_trials_ = 0, m_used_total_ = 0;
   ObsX x_;            // chunked order of the camera-side PCG sweep (xon_)
   bool xon_ = false;
-  bool xon_all_ = false;  // ... on every rank (what the recycled-vector path needs: the decision has to be the same everywhere)
   int gridX_ = 0, gridWsum_ = 0, sweepSlots_ = 0;
   bool defl_on_ = true;  // deflate the next reduced solve (short solves run plain)
   long E_ = 0;                 // camera-to-camera constraints (constraint_type != ONLY_POINTS)

@@ -254,8 +254,8 @@ def _big_worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world,chunked", [(2, 0), (4, 0), (2, 1)])
-def test_ranks_reproduce_single_rank_above_the_single_workgroup_size(gsfm_ctx, world, chunked, monkeypatch):
+@pytest.mark.parametrize("world,chunked,recycle", [(2, 0, 1), (4, 0, 0), (2, 1, 1)])
+def test_ranks_reproduce_single_rank_above_the_single_workgroup_size(gsfm_ctx, world, chunked, recycle, monkeypatch):
     """1 200 cameras / 40 k tracks, one intrinsics block per image, peer transport: GP takes the multi-block k_cg_update<3>
     with the gauge modes deflated and the all-reduced closed-form k_gp_aw_modes products, BA the joint 14 x 14 blocks with
     k_ba_aw_modes — the paths bench.py --gpus N runs on configs[3] (chunked = 1: with GP's camera-side sweep in the chunked,
@@ -264,21 +264,25 @@ def test_ranks_reproduce_single_rank_above_the_single_workgroup_size(gsfm_ctx, w
 
     gp, ba = _big_problems()
     gsfm_ctx.stats(reset=True)
+    knobs = {}
     if chunked:  # GP's camera-side sweep in the chunked order (forced: the library picks it only above ~130 k tracks per rank)
-        # ... and Ritz vectors harvested from solves of 8 iterations on, Ritz values below 0.9 (defaults 25 / 0.3: this
-        # problem's solves take ~12 and its spectrum has no tail), so that the recycled-vector preconditioner and its
-        # all-reduced dot products run
-        gsfm_ctx.set_knob("chunked_sweeps", 1)
-        gsfm_ctx.set_knob("gp_recycle_min_iters", 8)
-        gsfm_ctx.set_knob("gp_recycle_cut_percent", 90)
-        monkeypatch.setenv("GSFM_KNOBS", "chunked_sweeps=1,gp_recycle_min_iters=8,gp_recycle_cut_percent=90")  # the spawned ranks read it when they create their context
+        knobs["chunked_sweeps"] = 1
+    if recycle:
+        # Ritz vectors harvested from solves of 8 iterations on, Ritz values below 0.9 (defaults 25 / 0.3: this problem's solves
+        # take ~12 and its spectrum has no tail), so that the recycled-vector preconditioner and its all-reduced dot products
+        # run — with the chunked sweep (they ride on k_gp_wsum) and without it (k_cgr_dots_w)
+        knobs["gp_recycle_min_iters"] = 8
+        knobs["gp_recycle_cut_percent"] = 90
+    for k, v in knobs.items():
+        gsfm_ctx.set_knob(k, v)
+    if knobs:  # the spawned ranks read it when they create their context
+        monkeypatch.setenv("GSFM_KNOBS", ",".join(f"{k}={v}" for k, v in knobs.items()))
     try:
         rc, cen1, xyz1, rep_gp1 = estimators.gp_solve(gp, ctx=gsfm_ctx)
         rep_gp1["lm_trace"] = gsfm_ctx.lm_trace()
     finally:
-        gsfm_ctx.set_knob("chunked_sweeps", 0)
-        gsfm_ctx.set_knob("gp_recycle_min_iters", 0)
-        gsfm_ctx.set_knob("gp_recycle_cut_percent", 0)
+        for k in knobs:
+            gsfm_ctx.set_knob(k, 0)
     assert rc == 0
     st_gp1 = gsfm_ctx.stats(reset=True)
     assert (st_gp1["pcg_chunked_sweeps"] > 0) == bool(chunked)
@@ -308,10 +312,10 @@ def test_ranks_reproduce_single_rank_above_the_single_workgroup_size(gsfm_ctx, w
         assert st["pcg_closed_form_aw"] == st["pcg_deflated"]
         assert st["allreduces"] > st["pcg_iterations"]
         assert (st["pcg_chunked_sweeps"] == st["pcg_solves"]) if chunked else st["pcg_chunked_sweeps"] == 0
-        # recycled Ritz vectors (chunked sweeps only): the dot products with them travel with w through the all-reduce, the
+        # recycled Ritz vectors: the dot products with them travel with w through the all-reduce, the
         # harvest is a function of replicated scalars — every rank harvests what one rank harvests
         assert st["pcg_recycled"] == res[0]["gp"][3]["pcg_recycled"] and st["ritz_harvested"] == res[0]["gp"][3]["ritz_harvested"]
-        assert (st["pcg_recycled"] >= 10) == bool(chunked) == (st_gp1["pcg_recycled"] >= 10)
+        assert (st["pcg_recycled"] >= 10) == bool(recycle) == (st_gp1["pcg_recycled"] >= 10)
         _gp_follows(rep, cen, rep_gp1, cen1)
         assert abs(rep["linear_iterations"] - rep_gp1["linear_iterations"]) <= 0.15 * rep_gp1["linear_iterations"] + 2
     assert all(np.array_equal(res[0]["gp"][1], res[r]["gp"][1]) for r in ranks)  # replicated state is bit-identical
