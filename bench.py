@@ -1083,7 +1083,8 @@ def bench_ba(args, ctx, rank, world, barrier, dist):
     shared = bool(getattr(args, "shared_intrinsics", False))  # configs[3] has both variants
     wide = getattr(args, "wide_model", None)  # a camera model with more than 8 parameters: the 16-wide unit (csrc/ba_wide.hip)
     if world == 1 and wide:
-        p = synthetic.make_ba_problem_wide(ncam, npts, wide, seed=0, shared_intrinsics=shared)
+        # 100 physical cameras shared round-robin (one 12-parameter camera per IMAGE is not a well-posed problem: DESIGN.md 3.1)
+        p = synthetic.make_ba_problem_wide(ncam, npts, wide, seed=0, shared_intrinsics=shared, num_intr_groups=max(1, ncam // 100))
     elif world == 1:
         p = synthetic.make_ba_problem(ncam, npts, seed=0, shared_intrinsics=shared, capture=getattr(args, "capture", "random"))
     else:  # every rank generates only its own shard (cameras / intrinsics / start identical everywhere)
@@ -1152,7 +1153,7 @@ def bench_ba(args, ctx, rank, world, barrier, dist):
     config = {
         "workload": "configs[3] on one GPU per rank: synthetic 10k cameras / 1M tracks / ~5M observations per GPU, "
         f"bundle adjustment ({'FULL_OPENCV (12 parameters, 16-wide intrinsics blocks)' if wide else 'SIMPLE_RADIAL'}, "
-        f"{'ONE camera shared by all images' if shared else 'one camera per image'}, Huber 1 px, "
+        f"{'ONE camera shared by all images' if shared else ('%d cameras shared round-robin' % p.num_intr if wide else 'one camera per image')}, Huber 1 px, "
         "reference defaults), start = GT + noise",
         "intrinsics_blocks": int(p.num_intr),
         "cameras": ncam,

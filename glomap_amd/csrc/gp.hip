@@ -2751,6 +2751,16 @@ class GpSolver final : public LmProblem {
       return iters0 + pcg();
     }
     if (coarse) ctx_->stats[GSFM_STAT_PCG_SECOND_LEVEL]++;
+    // The second level is switched on by a symptom (a long solve), and its probed matrix can pass the definiteness check on a
+    // scene that is not chain-like at all — configs[3] seed 1 without recycled vectors: 626, 552, 512 ... iterations per solve
+    // where plain block-Jacobi needs 60 - 90 (tools/exp_gp_recycle_gpu.py 10000 1000000 1).  A second-level solve that is
+    // itself four times longer than the trigger is not helping: off for the rest of this LM problem.
+    if (coarse && iters0 > 4 * kCoarseTrigger) {
+      coarse_ok_ = false;
+      coarse_on_ = false;
+      static const bool verbose = std::getenv("GSFM_VERBOSE") != nullptr;
+      if (verbose) fprintf(stderr, "[gsfm gp] second-level preconditioner: %ld iterations in one solve, switched off\n", iters0);
+    }
     if (xon_) ctx_->stats[GSFM_STAT_PCG_CHUNKED_SWEEPS]++;
     const long iters = iters0 + (coarse ? coarse_probes_ : 0);  // + the operator applications that probed the coarse matrix
     // deflation pays while a plain solve needs more than ~3 k iterations (iters includes the k applications for A W)
