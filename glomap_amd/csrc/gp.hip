@@ -2728,6 +2728,7 @@ class GpSolver final : public LmProblem {
           rcy.coef[j] = 1.0 / ritz_.theta[j];
         }
     }
+    const int iters_before = pcg_hint_;  // the previous solve of this LM problem
     bool finished = false;
     // (with recycled vectors in the preconditioner a solve gets twice as long before the scene is declared chain-like: at
     // configs[3] a solve of 60 - 90 iterations is the block-Jacobi tail the recycling is there for, and the cluster
@@ -2745,6 +2746,9 @@ class GpSolver final : public LmProblem {
     // (a solve that met a non-finite value or lost positive curvature leaves nothing worth keeping — and nothing kept is trusted)
     const bool solve_bad = reinterpret_cast<const CgStatus*>(ctx_->h_pinned + 400)->bad != 0;
     if (recycle && solve_bad) ritz_.clear();
+    // insurance: a solve with recycled vectors that is suddenly 2.5 x as long as its predecessor has been handed vectors that no
+    // longer fit (the staleness rule should have caught them) — the store starts again from this solve's own harvest
+    if (recycle && rcy.k > 0 && iters_before > 0 && pcg_hint_ > 60 && pcg_hint_ > (5 * iters_before) / 2) ritz_.clear();
     if (recycle && finished && !solve_bad && pcg_hint_ >= min_iters) harvest(rcy, pcg_hint_);
     if (may_switch && !finished) {  // still running at the cap (a solve that converged just below it is kept)
       coarse_on_ = true;
