@@ -1432,6 +1432,16 @@ struct RelPoseFilter {
     for (size_t e = 0; e < pairs.size(); ++e)
       if (!keep[e]) pairs[e]->is_valid = false;
   }
+  // relpose_filter.cc:34-47 / :49-64: the two tests on a pair's inlier list (a count per pair: nothing for a device to do) —
+  // here so that `RelPoseFilter` can be switched as a whole (global_mapper.cc:69-72 names them behind the relative-pose stage)
+  static void FilterInlierNum(glomap::ViewGraph& view_graph, int min_inlier_num) {
+    for (auto& [pid, pair] : view_graph.image_pairs)
+      if (pair.is_valid && pair.inliers.size() < static_cast<size_t>(min_inlier_num)) pair.is_valid = false;  // (size_t comparison, as written there)
+  }
+  static void FilterInlierRatio(glomap::ViewGraph& view_graph, double min_inlier_ratio) {
+    for (auto& [pid, pair] : view_graph.image_pairs)
+      if (pair.is_valid && pair.inliers.size() / double(pair.matches.rows()) < min_inlier_ratio) pair.is_valid = false;
+  }
 };
 
 // ---------------------------------------------------------------------------------------------

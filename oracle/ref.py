@@ -567,3 +567,73 @@ def ba_adapter_solve(cam_model, cam_params, frame_q, frame_t, image_frame, image
     ok = lib.ref_ba_adapter_solve(*pre, vp(_p(rep)), vp(_p(fq)), vp(_p(ft)), vp(_p(cp)), vp(_p(xyz)))
     return dict(ok=bool(ok), initial_cost=float(rep[0]), final_cost=float(rep[1]), iterations=int(rep[2]), frame_q=fq, frame_t=ft,
                 cam_params=cp, xyz=xyz[:P])
+
+
+# ---- the reference's top-level controller, glomap/controllers/global_mapper.cc, on either set of estimators ----------------
+LIB_MAPPER = HERE / "_ref" / "libref_dropin_mapper.so"
+_lib_mapper = None
+
+
+class _MapperOptions(C.Structure):
+    _fields_ = [("num_iteration_bundle_adjustment", C.c_int), ("skip_rotation_averaging", C.c_int), ("skip_track_establishment", C.c_int),
+                ("skip_global_positioning", C.c_int), ("skip_bundle_adjustment", C.c_int), ("min_num_view_per_track", C.c_int),
+                ("optimize_intrinsics", C.c_int), ("gp_seed", C.c_uint), ("max_angle_error", C.c_double),
+                ("max_reprojection_error", C.c_double), ("min_triangulation_angle", C.c_double), ("max_rotation_error", C.c_double),
+                ("thres_inconsistency", C.c_double)]
+
+
+def load_mapper():
+    """oracle/_ref/libref_dropin_mapper.so (links glomap_amd/csrc/libgsfm.so): built where the reference tree and the built
+    libgsfm.so exist, else the prebuilt file, else None."""
+    global _lib_mapper
+    if _lib_mapper is None:
+        if (REFERENCE / "glomap" / "controllers" / "global_mapper.cc").exists() and (HERE.parent / "glomap_amd" / "csrc" / "libgsfm.so").exists():
+            r = subprocess.run(["make", "-C", str(HERE), "-s", "ref_mapper", f"REF={REFERENCE}"], capture_output=True, text=True)
+            if r.returncode != 0:
+                print("[oracle/ref] make ref_mapper failed:\n" + r.stderr[-2000:], file=sys.stderr)
+        if LIB_MAPPER.exists():
+            _lib_mapper = C.CDLL(str(LIB_MAPPER))
+            _lib_mapper.ref_mapper_solve.restype = C.c_int
+    return _lib_mapper
+
+
+def mapper_solve(which, cam_model, cam_params, image_cam, feat_offset, feat_xy, pair_i, pair_j, pair_q, pair_t, match_offset, match_f1,
+                 match_f2, frame_q=None, frame_t=None, pair_weight=None, pair_valid=None, cam_has_prior=None, cap_tracks=None, **options):
+    """glomap::GlobalMapper::Solve (controllers/global_mapper.cc:18-356), the reference's source compiled unmodified, with the stages
+    outside SURVEY section 8 skipped by its own skip_* options: which = 0 on the reference's own estimators and processors (CPU),
+    1 = RotationEstimator / GlobalPositioner / BundleAdjuster / UndistortImages of include/gsfm_glomap_adapter.hpp (libgsfm, GPU),
+    2 = the track filters, the normaliser and the rotation filter on libgsfm as well.  Trivial frames (image i = frame i).
+    cam_params [K,12] padded.  Returns a dict: ok, frame_q [N,4] (wxyz), frame_t [N,3], frame_registered [N], cam_params [K,12],
+    pair_valid [E], num_tracks, num_observations, num_initialized, track_id / track_len / track_xyz (sorted by id)."""
+    lib = load_mapper()
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)  # noqa: E731
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+    i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)  # noqa: E731
+    cm, cp, ic = i32(cam_model), f64(cam_params), i32(image_cam)
+    K, N = len(cm), len(ic)
+    assert cp.shape == (K, 12)
+    fo, fxy = i64(feat_offset), f64(feat_xy)
+    pi, pj, pq, pt = i32(pair_i), i32(pair_j), f64(pair_q), f64(pair_t)
+    E = len(pi)
+    mo, m1, m2 = i64(match_offset), i32(match_f1), i32(match_f2)
+    fq = f64(np.tile([1.0, 0, 0, 0], (N, 1)) if frame_q is None else frame_q)
+    ft = f64(np.zeros((N, 3)) if frame_t is None else frame_t)
+    pw = f64(np.full(E, -1.0) if pair_weight is None else pair_weight)
+    pv = np.ascontiguousarray(np.ones(E) if pair_valid is None else pair_valid, dtype=np.uint8)
+    hp = np.ascontiguousarray(np.ones(K) if cam_has_prior is None else cam_has_prior, dtype=np.uint8)
+    o = _MapperOptions(3, 0, 0, 0, 0, 3, 1, 1, -1.0, -1.0, -1.0, -1.0, -1.0)
+    for k, v in options.items():
+        setattr(o, k, type(getattr(o, k))(v))
+    cap = int(len(m1) + 1 if cap_tracks is None else cap_tracks)
+    out_q, out_t, out_reg = np.zeros((N, 4)), np.zeros((N, 3)), np.zeros(N, np.uint8)
+    out_cp, out_pv, counts = np.zeros((K, 12)), np.zeros(max(E, 1), np.uint8), np.zeros(4, np.int64)
+    tid, tlen, txyz = np.zeros(cap, np.uint64), np.zeros(cap, np.int32), np.zeros((cap, 3))
+    vp = C.c_void_p
+    ok = lib.ref_mapper_solve(C.c_int(int(which)), C.c_int(K), vp(_p(cm)), vp(_p(cp)), vp(_p(hp)), C.c_int(N), vp(_p(ic)), vp(_p(fo)), vp(_p(fxy)),
+                              vp(_p(fq)), vp(_p(ft)), C.c_long(E), vp(_p(pi)), vp(_p(pj)), vp(_p(pq)), vp(_p(pt)), vp(_p(pw)), vp(_p(pv)),
+                              vp(_p(mo)), vp(_p(m1)), vp(_p(m2)), C.byref(o), vp(_p(out_q)), vp(_p(out_t)), vp(_p(out_reg)), vp(_p(out_cp)),
+                              vp(_p(out_pv)), vp(_p(counts)), C.c_long(cap), vp(_p(tid)), vp(_p(tlen)), vp(_p(txyz)))
+    T = int(min(counts[0], cap))
+    return dict(ok=ok == 1, rc=int(ok), frame_q=out_q, frame_t=out_t, frame_registered=out_reg.astype(bool), cam_params=out_cp,
+                pair_valid=out_pv[:E].astype(bool), num_tracks=int(counts[0]), num_observations=int(counts[1]),
+                num_initialized=int(counts[2]), track_id=tid[:T], track_len=tlen[:T], track_xyz=txyz[:T])

@@ -40,6 +40,7 @@ struct Vector2d {  // (a - b).norm(), a / s   (track_establishment.cc:127-128, t
   double operator()(int i) const { return i == 0 ? x : y; }
   double operator[](int i) const { return i == 0 ? x : y; }
   double norm() const { return std::sqrt(x * x + y * y); }
+  struct Vector3d homogeneous() const;  // (x, y, 1)   (image_undistorter.cc:37; defined behind Vector3d)
 };
 template <typename T> struct RefShimCast3;  // what Vector3d::cast<T>() returns: specialised by ref_shim_eigen_extra.h (T = double: a Vector3d;
                                             // ref_shim_solve/: a Matrix<T, 3, 1> of dual numbers for the solving Ceres stand-in)
@@ -73,6 +74,7 @@ struct Vector3d {
   template <typename T> typename RefShimCast3<T>::type cast() const { return RefShimCast3<T>::make(*this); }
 };
 inline Vector3d operator*(double s, const Vector3d& a) { return a * s; }
+inline Vector3d Vector2d::homogeneous() const { return Vector3d(x, y, 1.0); }
 struct Matrix3d {  // 3 x 3 in plain doubles, products evaluated as the usual triple loop
   double m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   static Matrix3d Identity(int = 3, int = 3) { Matrix3d r; r.m[0] = r.m[4] = r.m[8] = 1.0; return r; }
@@ -258,6 +260,54 @@ struct Camera {  // colmap::Camera + scene/camera.h: the two members the filters
     }
   }
   std::optional<Eigen::Vector2d> ImgFromCam(const Eigen::Vector3d&) const { return std::nullopt; }  // pixel branch: not exercised
+  // colmap::Camera::CamFromImg (colmap/sensor/models.h, un-vendored; restated as published — the same reading as
+  // oracle/filters.py::undistort_features): pixel -> normalised plane through (f, c) and, for a model with distortion,
+  // BaseCameraModel::IterativeUndistortion — Newton on x + dx(x) = x0 with a central-difference Jacobian (relative step 1e-6,
+  // floor machine epsilon), at most 100 iterations, stop when |step|^2 < 1e-10.  The five perspective models up to OPENCV
+  // (what glomap/processors/image_undistorter.cc:35 reaches in the mapper library, oracle/Makefile ref_mapper).
+  static void RefShimDistortion(colmap::CameraModelId id, const double* k, double u, double v, double* du, double* dv) {
+    const double r2 = u * u + v * v;
+    switch (id) {
+      case colmap::CameraModelId::kSimpleRadial: { const double d = k[3] * r2; *du = u * d; *dv = v * d; return; }
+      case colmap::CameraModelId::kRadial: { const double d = k[3] * r2 + k[4] * r2 * r2; *du = u * d; *dv = v * d; return; }
+      case colmap::CameraModelId::kOpenCV: {
+        const double rad = k[4] * r2 + k[5] * r2 * r2, uv = u * v;
+        *du = u * rad + 2.0 * k[6] * uv + k[7] * (r2 + 2.0 * u * u);
+        *dv = v * rad + 2.0 * k[7] * uv + k[6] * (r2 + 2.0 * v * v);
+        return;
+      }
+      default: *du = 0.0; *dv = 0.0; return;
+    }
+  }
+  std::optional<Eigen::Vector2d> CamFromImg(const Eigen::Vector2d& xy) const {
+    const double* k = params.data();
+    double u, v;
+    switch (model_id) {
+      case colmap::CameraModelId::kSimplePinhole: return Eigen::Vector2d((xy.x - k[1]) / k[0], (xy.y - k[2]) / k[0]);
+      case colmap::CameraModelId::kPinhole: return Eigen::Vector2d((xy.x - k[2]) / k[0], (xy.y - k[3]) / k[1]);
+      case colmap::CameraModelId::kSimpleRadial: case colmap::CameraModelId::kRadial:
+        u = (xy.x - k[1]) / k[0]; v = (xy.y - k[2]) / k[0]; break;
+      case colmap::CameraModelId::kOpenCV: u = (xy.x - k[2]) / k[0]; v = (xy.y - k[3]) / k[1]; break;
+      default: return std::nullopt;
+    }
+    const double x0 = u, y0 = v, eps = std::numeric_limits<double>::epsilon();
+    for (int it = 0; it < 100; ++it) {
+      const double s0 = std::max(eps, std::fabs(1e-6 * u)), s1 = std::max(eps, std::fabs(1e-6 * v));
+      double dx, dy, a0, a1, b0, b1, c0, c1, d0, d1;
+      RefShimDistortion(model_id, k, u, v, &dx, &dy);
+      RefShimDistortion(model_id, k, u - s0, v, &a0, &a1);
+      RefShimDistortion(model_id, k, u + s0, v, &b0, &b1);
+      RefShimDistortion(model_id, k, u, v - s1, &c0, &c1);
+      RefShimDistortion(model_id, k, u, v + s1, &d0, &d1);
+      const double J00 = 1 + (b0 - a0) / (2 * s0), J01 = (d0 - c0) / (2 * s1), J10 = (b1 - a1) / (2 * s0), J11 = 1 + (d1 - c1) / (2 * s1);
+      const double r0 = u + dx - x0, r1 = v + dy - y0, det = J00 * J11 - J01 * J10;
+      const double sx = (J11 * r0 - J01 * r1) / det, sy = (J00 * r1 - J10 * r0) / det;
+      u -= sx;
+      v -= sy;
+      if (sx * sx + sy * sy < 1e-10) break;
+    }
+    return Eigen::Vector2d(u, v);
+  }
 };
 struct data_t {  // colmap/sensor/rig.h: (sensor, id of the datum = the image id), ordered by sensor then id
   sensor_t sensor_id;

@@ -124,6 +124,19 @@ class HuberLoss final : public LossFunction {
  private:
   double a_, b_;
 };
+class CauchyLoss final : public LossFunction {  // rho(s) = b log(1 + s / b), b = a^2 (named by view_graph_calibration.h:26; that stage is skipped)
+ public:
+  explicit CauchyLoss(double a) : b_(a * a), c_(1.0 / (a * a)) {}
+  void Evaluate(double s, double rho[3]) const override {
+    const double sum = 1.0 + s * c_, inv = 1.0 / sum;
+    rho[0] = b_ * std::log(sum);
+    rho[1] = std::max(std::numeric_limits<double>::min(), inv);
+    rho[2] = -c_ * (inv * inv);
+  }
+
+ private:
+  double b_, c_;
+};
 class ScaledLoss final : public LossFunction {
  public:
   ScaledLoss(const LossFunction* rho, double a, Ownership) : rho_(rho), a_(a) {}
