@@ -24,7 +24,7 @@ def gsfm_ctx():
 
 # ---- oracle/_ref: make its absence LOUD (Weak 9) -----------------------------------------------------------
 # A third of the parity evidence compares against the reference's own sources compiled into oracle/_ref/*.so — git-ignored
-# libraries built from /root/reference by `make -C oracle ref ref_solve ref_dropin`.  Where they are missing those tests skip;
+# libraries built from /root/reference by `make -C oracle ref ref_solve ref_dropin ref_mapper`.  Where they are missing those tests skip;
 # a green bar must not hide that: the session ends with a line that counts them, and where the reference tree EXISTS (the build
 # container) a missing library is a build failure of the shims, reported as an error instead of a skip.
 _REF_SKIPS = []
@@ -39,7 +39,7 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     if _REF_SKIPS:
         terminalreporter.write_line(
             f"[oracle/_ref] {len(_REF_SKIPS)} reference-code tests SKIPPED: libraries under oracle/_ref/ absent (built from /root/reference "
-            f"by `make -C oracle ref ref_solve ref_dropin`; they travel with the gpurun snapshot)", red=True, bold=True)
+            f"by `make -C oracle ref ref_solve ref_dropin ref_mapper`; they travel with the gpurun snapshot)", red=True, bold=True)
 
 
 def pytest_sessionfinish(session, exitstatus):
