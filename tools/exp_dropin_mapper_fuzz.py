@@ -1,0 +1,65 @@
+"""GPU: the reference's GlobalMapper::Solve on the adapter classes (which = 1 / 2) against the same source on the reference's own
+estimators (which = 0), oracle/_ref/libref_dropin_mapper.so, on RANDOM small scenes and options — a fuzz of the drop-in beyond the six
+scenes of tests/test_dropin_reference_mapper.py.  Prints one line per scene and a summary; exit code 1 on any disagreement
+beyond north_star's bar or any differing discrete decision.
+Usage: python tools/exp_dropin_mapper_fuzz.py [num_scenes] [first_seed]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
+sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "tests"))
+import numpy as np
+
+from glomap_amd import so3, synthetic
+import test_dropin_reference_mapper as T
+
+n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+worst = dict(rot=0.0, cen=0.0, xyz=0.0)
+bad = 0
+for k in range(n_scenes):
+    rng = np.random.default_rng(seed0 + k)
+    gen = dict(n_images=int(rng.integers(8, 41)), n_points=int(rng.integers(40, 401)), seed=seed0 + k,
+               pixel_noise=float(rng.choice([0.0, 0.2, 0.5, 1.0])), num_succ=int(rng.integers(3, 9)))
+    if rng.random() < 0.4:
+        gen["rot_outlier_pairs"] = int(rng.integers(1, 4))
+    if rng.random() < 0.3:
+        gen["false_match_frac"] = 0.0005
+    if rng.random() < 0.3:
+        gen["isolated_pair"] = True
+    if rng.random() < 0.4:
+        gen["simple_radial"] = float(rng.uniform(-0.1, 0.05))
+    opt = dict(optimize_intrinsics=int(rng.random() < 0.7), num_iteration_bundle_adjustment=int(rng.integers(1, 4)),
+               gp_seed=int(rng.integers(1, 1000)), min_num_view_per_track=int(rng.choice([3, 3, 4])))
+    s = T._scene(gen)
+    t0 = time.perf_counter()
+    a = T._solve(0, s, **opt)
+    t1 = time.perf_counter()
+    line = f"scene {seed0 + k}: {gen} {opt} ref ok={a['ok']} {t1 - t0:.2f}s tracks={a['num_tracks']}"
+    for which in (1, 2):
+        t2 = time.perf_counter()
+        b = T._solve(which, s, **opt)
+        dt = time.perf_counter() - t2
+        same = (a["ok"] == b["ok"] and np.array_equal(a["frame_registered"], b["frame_registered"]) and np.array_equal(a["pair_valid"], b["pair_valid"])
+                and a["num_tracks"] == b["num_tracks"] and np.array_equal(a["track_id"], b["track_id"]) and np.array_equal(a["track_len"], b["track_len"]))
+        if not same or not a["ok"]:
+            line += f" | which={which}: discrete decisions {'EQUAL' if same else 'DIFFER'} (ok {a['ok']} / {b['ok']}, tracks {a['num_tracks']} / {b['num_tracks']})"
+            bad += 0 if same else 1
+            continue
+        reg = a["frame_registered"]
+        Ra, ca = T._poses(a)
+        Rb, cb = T._poses(b)
+        rot = np.linalg.norm(so3.quat_to_aa(so3.rotmat_to_quat(np.einsum("nij,nkj->nik", Ra[reg], Rb[reg]))), axis=1).max()
+        ext = synthetic.scene_extent(ca[reg])
+        cen = np.linalg.norm(ca[reg] - cb[reg], axis=1).max() / ext
+        xyz = np.linalg.norm(a["track_xyz"] - b["track_xyz"], axis=1).max() / ext if a["num_tracks"] else 0.0
+        worst["rot"], worst["cen"], worst["xyz"] = max(worst["rot"], rot), max(worst["cen"], cen), max(worst["xyz"], xyz)
+        line += f" | which={which}: {dt:.2f}s rot {rot:.1e} cen {cen:.1e} xyz {xyz:.1e}"
+        if not (rot < 1e-4 and cen < 1e-3 and xyz < 1e-3):
+            line += " BEYOND THE BAR"
+            bad += 1
+    print(line, flush=True)
+print(f"[parity] DROP-IN GlobalMapper::Solve fuzz: {n_scenes} random scenes x 2 drop-in builds, worst rotations {worst['rot']:.2e} rad, centres {worst['cen']:.2e}, "
+      f"points {worst['xyz']:.2e} of the extent; disagreements: {bad}")
+sys.exit(1 if bad else 0)
