@@ -539,7 +539,7 @@ class Context:
 
     KNOBS = ("ba_aw_by_application", "ba_aw_check", "ba_separate_blocks", "ba_no_nontemporal", "ra_no_blockdense",
              "ra_no_substructure", "ra_dense_refactor", "gp_coarse_cluster", "seg_len", "chunked_sweeps", "experiment",
-             "gp_no_recycle", "gp_recycle_min_iters", "gp_recycle_cut_percent")
+             "gp_no_recycle", "gp_recycle_min_iters", "gp_recycle_cut_percent", "gp_dense")
 
     def set_knob(self, name: str, value: int = 1):
         """Diagnostic / A-B knobs (gsfm_ctx_set_knob); 0 restores the default.  The library reads no environment variable
@@ -549,7 +549,7 @@ class Context:
             raise GsfmError(rc, "gsfm_ctx_set_knob")
 
     STAT_NAMES = ("pcg_solves", "pcg_deflated", "pcg_closed_form_aw", "pcg_single_workgroup", "pcg_joint_blocks",
-                  "pcg_second_level", "allreduces", "pcg_iterations", "pcg_chunked_sweeps", "pcg_recycled", "ritz_harvested")
+                  "pcg_second_level", "allreduces", "pcg_iterations", "pcg_chunked_sweeps", "pcg_recycled", "ritz_harvested", "dense_solves")
 
     def stats(self, reset: bool = False) -> dict:
         """Which solver paths ran on this context (gsfm_ctx_stats)."""

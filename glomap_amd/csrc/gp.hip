@@ -615,6 +615,98 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// ---- the reduced camera system as a DENSE matrix: small problems with chain-like co-visibility ---------------------------
+// A capture in which every image sees the points of its own neighbourhood gives a reduced system that is a long chain, and on a
+// FEW HUNDRED cameras block-Jacobi PCG is the wrong tool altogether: the reference's mapper on a 300-image ring looking outward
+// (tools/exp_capture_gp.py) runs 100 LM iterations of ~570 PCG iterations each on a system of 900 unknowns — 1.2 s, all of it
+// launch latency.  The reference factorises that system (SPARSE_SCHUR, global_positioning.cc:553); for at most kGpDenseMaxCams
+// cameras (1 024) so does this path:  S = blockdiag(sum_k Q_k + D_n) - sum over tracks of  Q_k H_pp^-1 Q_k'  is assembled as a dense
+// 3N x 3N matrix — one workgroup per camera with its three rows in LDS, the camera's observations spread over the threads, each
+// walking the members of its track (k_gp_dense_assemble) —, inverted by the symmetric block sweep of ra_dense.hpp (the matrix cores,
+// T = 3N / 32 launches) and applied to the right-hand side with two steps of iterative refinement against the assembled matrix.
+// Trivial frames, tracks only (the mapper's configuration: global_mapper.cc:144-149), one rank.  Switched on by the symptom — a PCG
+// solve of the LM problem that ran past kGpDenseTrigger iterations (knob gp_dense: 1 = never, 2 = from the first solve).
+// LDS sums are atomic (ds_add_f64): the order of the terms of one entry is not fixed, i.e. S is reproducible to rounding, like
+// the dense Laplacian of the rotation averaging (k_dense_fill_offdiag).
+constexpr int kGpDenseMaxCams = kCgSingleMaxBlocks;  // 1 024 cameras: where the PCG runs in one workgroup and has no second level.  (Measured at
+                                                    // 1 200 cameras, sequential capture: 49 dense solves 255 ms, second-level PCG 221 ms — the sweep is n^3.)
+constexpr int kGpDenseTrigger = 100;
+
+__global__ void __launch_bounds__(kBlock)
+    k_gp_dense_assemble(GpDev g, const double* __restrict__ c, const double* __restrict__ qa, const double* __restrict__ qb,
+                        const double* __restrict__ ptb, const double* __restrict__ dcam, int n3, int ld, double* __restrict__ S) {
+  extern __shared__ double srow[];  // [3][ld]
+  const int n = blockIdx.x;
+  for (int i = threadIdx.x; i < 3 * ld; i += blockDim.x) srow[i] = 0.0;
+  __syncthreads();
+  if (n < g.g.N) {
+    const V3 cn = ld3(c + 3 * (long)n);
+    for (int k = g.g.coff[n] + threadIdx.x; k < g.g.coff[n + 1]; k += blockDim.x) {
+      const long src = g.g.c_src[k];
+      const long p = g.g.c_pt[k];
+      const double* b = ptb + kPtb * p;
+      const V3 Xp = ld3(b);
+      const S3 Hi{b[6], b[7], b[8], b[9], b[10], b[11]};
+      const V3 d = Xp - cn;
+      const double a = qa[src], ab = a * qb[src];
+      const S3 Q{a - ab * d.x * d.x, -ab * d.x * d.y, -ab * d.x * d.z, a - ab * d.y * d.y, -ab * d.y * d.z, a - ab * d.z * d.z};
+      // + Q_k on the camera's own block
+      double* dg = srow + 3 * n;
+      atomicAdd(dg, Q.xx); atomicAdd(dg + 1, Q.xy); atomicAdd(dg + 2, Q.xz);
+      atomicAdd(dg + ld, Q.xy); atomicAdd(dg + ld + 1, Q.yy); atomicAdd(dg + ld + 2, Q.yz);
+      atomicAdd(dg + 2 * ld, Q.xz); atomicAdd(dg + 2 * ld + 1, Q.yz); atomicAdd(dg + 2 * ld + 2, Q.zz);
+      // - Q_k H_pp^-1 Q_k' on the block of every member k' of the track (k' = k included)
+      for (long m = g.g.off[p]; m < g.g.off[p + 1]; ++m) {
+        const int j = g.g.cam[m];
+        const V3 dj = Xp - ld3(c + 3 * (long)j);
+        const double aj = qa[m], abj = aj * qb[m];
+        const S3 Qj{aj - abj * dj.x * dj.x, -abj * dj.x * dj.y, -abj * dj.x * dj.z, aj - abj * dj.y * dj.y, -abj * dj.y * dj.z,
+                    aj - abj * dj.z * dj.z};
+        // columns of Q_k (H_pp^-1 Q_k')
+        const V3 c0 = mul(Q, mul(Hi, V3{Qj.xx, Qj.xy, Qj.xz}));
+        const V3 c1 = mul(Q, mul(Hi, V3{Qj.xy, Qj.yy, Qj.yz}));
+        const V3 c2 = mul(Q, mul(Hi, V3{Qj.xz, Qj.yz, Qj.zz}));
+        double* o = srow + 3 * j;
+        atomicAdd(o, -c0.x); atomicAdd(o + 1, -c1.x); atomicAdd(o + 2, -c2.x);
+        atomicAdd(o + ld, -c0.y); atomicAdd(o + ld + 1, -c1.y); atomicAdd(o + ld + 2, -c2.y);
+        atomicAdd(o + 2 * ld, -c0.z); atomicAdd(o + 2 * ld + 1, -c1.z); atomicAdd(o + 2 * ld + 2, -c2.z);
+      }
+    }
+  }
+  __syncthreads();
+  // rows 3n .. 3n+2 (+ the damping on the diagonal); rows and columns of the padding: the identity
+  for (int i = threadIdx.x; i < 3 * ld; i += blockDim.x) {
+    const int r = 3 * n + i / ld, col = i % ld;
+    if (r >= ld) continue;
+    double v = srow[i];
+    if (r < n3) {
+      if (col == r) v += dcam[r];
+    } else {
+      v = col == r ? 1.0 : 0.0;
+    }
+    S[(size_t)r * ld + col] = v;
+  }
+}
+
+// y = A v (A: n x n, leading dimension ld), one wave per row; with `b`: y = b - A v
+__global__ void __launch_bounds__(kBlock)
+    k_gp_dense_matvec(int n, int ld, const double* __restrict__ A, const double* __restrict__ v, const double* __restrict__ b,
+                      double* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (kBlock / 64);
+  for (int r = wave; r < n; r += nwaves) {
+    const double* row = A + (size_t)r * ld;
+    double acc = 0.0;
+    for (int m = lane; m < n; m += 64) acc += row[m] * v[m];
+    acc = wave_sum(acc);
+    if (lane == 0) y[r] = b != nullptr ? b[r] - acc : acc;
+  }
+}
+__global__ void __launch_bounds__(kBlock) k_gp_dense_axpy(int n, const double* __restrict__ dx, double* __restrict__ x) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) x[i] += dx[i];
+}
+
 // ---- second-level preconditioner for scenes with chain-like co-visibility ----------------------------------------------
 // The random-visibility benchmark scenes give a reduced camera system whose block-Jacobi-preconditioned spectrum is tight
 // apart from the global gauge.  Scenes with the locality of a real capture do not: a point is seen by a run
@@ -1726,6 +1818,7 @@ struct GpWs {
   DevBuf<int> pr_i, pr_j, pr_row, pr_ent;                       // camera-to-camera constraints (GpPairs)
   DevBuf<double> pr_v, pr_s, pr_sn, pr_w, pr_js, pr_qa, pr_qb, pr_part;
   DevBuf<double> cs_cbar, cs_E, cs_E2, cs_pinv, cs_c, cs_y;  // second-level preconditioner (GpCoarse*)
+  DevBuf<double> dn_S, dn_a, dn_b, dn_pinv, dn_r, dn_dx;     // dense reduced system (k_gp_dense_*)
   DevBuf<int> cs_flag;
   static void destroy(void* p) { delete static_cast<GpWs*>(p); }
 };
@@ -2607,9 +2700,59 @@ class GpSolver final : public LmProblem {
     ctx_->stats[GSFM_STAT_RITZ_HARVESTED] += knew;
   }
 
+  // (S + D) x = rhs by a dense inverse (k_gp_dense_assemble, the block sweep of ra_dense.hpp, two refinement steps): into cg_x
+  void dense_solve() {
+    GpWs* ws = ws_;
+    hipStream_t s = ctx_->stream;
+    const int n3 = 3 * N_;
+    const int ld = (n3 + kTile - 1) / kTile * kTile, T = ld / kTile;
+    const size_t nn = (size_t)ld * ld;
+    double* S0 = ws->dn_S.ensure(nn);
+    double* cur = ws->dn_a.ensure(nn);
+    double* oth = ws->dn_b.ensure(nn);
+    double* pinv = ws->dn_pinv.ensure(2 * kTile * kTile);
+    double* r = ws->dn_r.ensure(ld);
+    double* dx = ws->dn_dx.ensure(ld);
+    const size_t lds = 3 * (size_t)ld * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+      GSFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gp_dense_assemble), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         3 * ((3 * kGpDenseMaxCams + kTile - 1) / kTile * kTile) * (int)sizeof(double)));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(k_gp_dense_assemble, dim3((ld + 2) / 3), dim3(kBlock), lds, s, g_, (const double*)ci_, (const double*)ws->qa.get(),
+                       (const double*)ws->qb.get(), (const double*)ws->ptb.get(), (const double*)ws->dcam.get(), n3, ld, S0);
+    GSFM_HIP_CHECK(hipMemcpyAsync(cur, S0, nn * sizeof(double), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_gj_pivot0, dim3(1), dim3(kBlock), 0, s, cur, ld, (size_t)0, pinv);
+    for (int k = 0; k < T; ++k) {
+      hipLaunchKernelGGL(k_gj_sweep_step, dim3(gj_tiles(T)), dim3(kBlock), 0, s, cur, oth, ld, (size_t)0, (const int*)nullptr, T, k, pinv);
+      std::swap(cur, oth);
+    }
+    hipLaunchKernelGGL(k_gj_finish_full, dim3(grid_wide(nn, kBlock, 1 << 12)), dim3(kBlock), 0, s, cur, ld, ld);
+    const int gridR = grid_wide((size_t)n3, kBlock / 64, 1 << 12), gridV = grid_for((size_t)n3, kBlock);
+    double* x = ws->cg_x.get();
+    hipLaunchKernelGGL(k_gp_dense_matvec, dim3(gridR), dim3(kBlock), 0, s, n3, ld, (const double*)cur, (const double*)ws->rhs.get(),
+                       (const double*)nullptr, x);
+    for (int it = 0; it < 2; ++it) {  // x += A^-1 (rhs - S x): the sweep's rounding (no pivoting, condition up to 1 / min damping)
+      hipLaunchKernelGGL(k_gp_dense_matvec, dim3(gridR), dim3(kBlock), 0, s, n3, ld, (const double*)S0, (const double*)x,
+                         (const double*)ws->rhs.get(), r);
+      hipLaunchKernelGGL(k_gp_dense_matvec, dim3(gridR), dim3(kBlock), 0, s, n3, ld, (const double*)cur, (const double*)r,
+                         (const double*)nullptr, dx);
+      hipLaunchKernelGGL(k_gp_dense_axpy, dim3(gridV), dim3(kBlock), 0, s, n3, (const double*)dx, x);
+    }
+    ctx_->stats[GSFM_STAT_DENSE_SOLVES]++;
+  }
+  bool dense_ok() const {
+    return !rig_ && E_ == 0 && g_.opt_c && ctx_->comm.world == 1 && N_ <= kGpDenseMaxCams && ctx_->knob[GSFM_KNOB_GP_DENSE] != 1;
+  }
+
   long pcg() {
     GpWs* ws = ws_;
     hipStream_t s = ctx_->stream;
+    if (dense_ok() && (dense_on_ || ctx_->knob[GSFM_KNOB_GP_DENSE] == 2)) {
+      dense_solve();
+      return 0;
+    }
     const double yscale = ctx_->comm.rank == 0 ? 1.0 : 0.0;
     const double tol = opt_.lm.pcg_relative_tolerance;
     auto apply = [&](int it) {
@@ -2697,7 +2840,8 @@ class GpSolver final : public LmProblem {
     }
     // chain-like co-visibility shows as a solve that is still running after kCoarseTrigger iterations: it is abandoned there,
     // and this and the later solves of the LM problem get the second-level preconditioner (GpCoarseDev)
-    const bool may_switch = !coarse && coarse_ok_ && !coarse_on_ && !rig_ && E_ == 0 && g_.opt_c && N_ > kCgSingleMaxBlocks &&
+    const bool may_dense = dense_ok() && opt_.lm.pcg_max_iterations > kGpDenseTrigger;  // (the dense path replaces the second level where it applies)
+    const bool may_switch = !may_dense && !coarse && coarse_ok_ && !coarse_on_ && !rig_ && E_ == 0 && g_.opt_c && N_ > kCgSingleMaxBlocks &&
                             opt_.lm.pcg_max_iterations > 2 * kCoarseTrigger;
     // Ritz vectors recycled from the earlier solves of this LM problem as an additive coarse space (cg.hpp CgRecycle, ritz.hpp):
     // one rank, trivial frames, the chunked camera-side sweep (k_gp_wsum writes the u_j . w partials)
@@ -2737,7 +2881,7 @@ class GpSolver final : public LmProblem {
     // benchmark scene's tail only in the middle of the trajectory: the doubled trigger applies from the ninth solve on.
     const int trigger = (recycle && pcg_calls_ >= 8) ? 2 * kCoarseTrigger : kCoarseTrigger;
     ++pcg_calls_;
-    const long iters0 = cg_solve<3, false>(ctx_, cg_, tol, may_switch ? trigger : opt_.lm.pcg_max_iterations, apply,
+    const long iters0 = cg_solve<3, false>(ctx_, cg_, tol, may_dense ? kGpDenseTrigger : may_switch ? trigger : opt_.lm.pcg_max_iterations, apply,
                                            defl.k ? &defl : nullptr, &pcg_hint_, [&](int par) {
                                              if (coarse) coarse_correct(cs, par);
                                            }, &finished, recycle ? &rcy : nullptr);
@@ -2750,6 +2894,11 @@ class GpSolver final : public LmProblem {
     // longer fit (the staleness rule should have caught them) — the store starts again from this solve's own harvest
     if (recycle && rcy.k > 0 && iters_before > 0 && pcg_hint_ > 60 && pcg_hint_ > (5 * iters_before) / 2) ritz_.clear();
     if (recycle && finished && !solve_bad && pcg_hint_ >= min_iters) harvest(rcy, pcg_hint_);
+    if (may_dense && !finished) {  // still running after kGpDenseTrigger iterations: this and the later solves of the LM problem are direct
+      dense_on_ = true;
+      dense_solve();
+      return iters0;
+    }
     if (may_switch && !finished) {  // still running at the cap (a solve that converged just below it is kept)
       coarse_on_ = true;
       return iters0 + pcg();
@@ -2810,6 +2959,7 @@ class GpSolver final : public LmProblem {
   int coarse_probes_ = 12;
   bool coarse_said_ = false;
   int coarse_grow_ = 0;
+  bool dense_on_ = false;  // the reduced systems of this LM problem are solved densely (dense_solve)
   int pcg_hint_ = 0;     // iteration count of the previous reduced solve (where cg_solve first reads the status back)
   int pcg_calls_ = 0;    // reduced solves of this LM problem so far
   RitzStore ritz_;       // what is known about the recycled Ritz vectors in ws->rc_U

@@ -830,7 +830,8 @@ def make_match_graph(n_images=200, n_tracks=5000, seed=0, max_gap=12, ring=50, m
 
 
 def make_pipeline_scene(n_images=14, n_points=50, seed=0, pixel_noise=0.0, num_succ=6, rot_outlier_pairs=0,
-                        false_match_frac=0.0, isolated_pair=False, radius=10.0, ball=2.5, focal=1200.0):
+                        false_match_frac=0.0, isolated_pair=False, radius=10.0, ball=2.5, focal=1200.0, layout="inward",
+                        shell=(1.0, 3.0)):
     """A whole-pipeline scene in flat form (what `GlobalMapper::Solve` holds after relative-pose estimation,
     global_mapper.cc:85): images on a ring looking at the origin, two shared PINHOLE cameras, 3-D points seen by
     every image that has them in view, per-image feature lists (pixels + undistorted rays), a view graph linking
@@ -838,11 +839,20 @@ def make_pipeline_scene(n_images=14, n_points=50, seed=0, pixel_noise=0.0, num_s
     points.  `rot_outlier_pairs` pairs get a random relative rotation (RelPoseFilter::FilterRotations must drop
     them), `false_match_frac` adds matches between unrelated features, `isolated_pair` appends two images that are
     linked only to each other (KeepLargestConnectedComponents must drop them).  Mirrors the role of
-    colmap::SynthesizeDataset in global_mapper_test.cc:56-66 (un-vendored; own generator)."""
+    colmap::SynthesizeDataset in global_mapper_test.cc:56-66 (un-vendored; own generator).
+    layout="outward": the ring looks OUTWARD at points on a cylindrical shell `shell[0] .. shell[1]` beyond it, so that an image
+    sees only the points of its own sector and a point is seen by a run of neighbouring images (the locality of a capture:
+    track length ~ n_images * 35 deg-cone / ring, instead of every image seeing every point) — the scale tests of the drop-in."""
     rng = np.random.default_rng(seed)
     N0 = int(n_images)
     centers, R_cw = _ring_cameras(rng, N0, radius, jitter_deg=3.0)
-    X = _ball_points(rng, n_points, ball)
+    if layout == "outward":
+        R_cw = np.diag([-1.0, 1.0, -1.0]) @ R_cw  # half a turn about the camera's y axis
+        ang = rng.uniform(0, 2 * np.pi, n_points)
+        rad = radius + rng.uniform(shell[0], shell[1], n_points)
+        X = np.stack([rad * np.cos(ang), rng.uniform(-0.5, 0.5, n_points) * shell[1], rad * np.sin(ang)], 1)
+    else:
+        X = _ball_points(rng, n_points, ball)
     extra = 2 if isolated_pair else 0
     if extra:  # far away, looking elsewhere: they share no point with the ring
         c2 = np.array([[100.0, 0.0, 0.0], [101.0, 0.0, 0.0]])

@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -65,7 +66,58 @@ inline gsfm_ctx* Context(const std::string& gpu_index = "-1") {
   return ctx;
 }
 
+// Not part of the reference's interface: where the wall time of the adapter's calls went, per entry point, accumulated since the
+// process started (or the last ResetTimings()).  pack = flattening the reference's containers into the SoA problem, call = inside
+// libgsfm (upload, solve, download), unpack = writing the results back in place.  A GLOMAP build that wants the numbers prints
+// AdapterTimings() after GlobalMapper::Solve; oracle/ref_glue_mapper.cc does, for the reference's own controller.
+struct Timing {
+  double pack = 0.0, call = 0.0, unpack = 0.0;
+  long calls = 0;
+  long iterations = 0, linear_iterations = 0;  // estimators: what gsfm_report said (outer iterations, PCG iterations)
+};
+inline std::map<std::string, Timing>& AdapterTimings() {
+  static std::map<std::string, Timing> t;
+  return t;
+}
+inline void ResetTimings() { AdapterTimings().clear(); }
+
 namespace detail {
+
+class CallClock {  // one per adapter call: construction .. first Call() = pack, Call() = call, last Call() .. destruction = unpack
+ public:
+  explicit CallClock(const char* name) : name_(name), last_(Now()) {}
+  ~CallClock() {
+    Timing& t = AdapterTimings()[name_];
+    const double rest = Now() - last_;
+    t.pack += pack_ + (called_ ? 0.0 : rest);
+    t.call += call_;
+    t.unpack += called_ ? rest : 0.0;
+    ++t.calls;
+    t.iterations += iterations_;
+    t.linear_iterations += linear_iterations_;
+  }
+  void Note(const gsfm_report& rep) {
+    iterations_ += rep.iterations;
+    linear_iterations_ += static_cast<long>(rep.linear_iterations);
+  }
+  template <typename F>
+  auto Call(F&& f) -> decltype(f()) {
+    const double a = Now();
+    pack_ += a - last_;  // host work since the construction, or between two library calls of one adapter call
+    auto rc = f();
+    last_ = Now();
+    call_ += last_ - a;
+    called_ = true;
+    return rc;
+  }
+
+ private:
+  static double Now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  const char* name_;
+  double last_, pack_ = 0.0, call_ = 0.0;
+  long iterations_ = 0, linear_iterations_ = 0;
+  bool called_ = false;
+};
 
 // COLMAP CameraModelId -> GSFM_CAMERA_* (colmap/sensor/models.h; the ids coincide for the supported models)
 inline int ModelOf(const glomap::Camera& cam) {
@@ -350,6 +402,7 @@ class RotationEstimator {
                          std::unordered_map<frame_t, glomap::Frame>& frames,
                          std::unordered_map<image_t, glomap::Image>& images) {
     gsfm_ctx* ctx = Context();
+    detail::CallClock clk("RotationEstimator::EstimateRotations");
     if (ctx == nullptr) return false;
     const bool rigged = !detail::AllTrivial(images);
     if (options_.use_gravity) {  // gra.cc:47-58: gravity needs every cam_from_rig
@@ -382,7 +435,7 @@ class RotationEstimator {
       for (auto& [id, im] : images) {
         double cfr[7];
         if (im.frame_ptr != nullptr && im.IsRegistered() && detail::CamFromRigState(im, rigs, cfr) != 0)
-          return EstimateWithCamBlocks(ctx, view_graph, rigs, frames, images, fidx);
+          return EstimateWithCamBlocks(ctx, view_graph, rigs, frames, images, fidx, clk);
       }
     }
     std::vector<int32_t> ei, ej, en;
@@ -490,7 +543,8 @@ class RotationEstimator {
         p0.edge_ninl = in_.data();
         p0.fixed_node = 0;
         gsfm_report r0;
-        if (gsfm_ra_solve(ctx, &p0, &o0, irot.data(), &r0) != GSFM_OK) return false;
+        if (clk.Call([&] { return gsfm_ra_solve(ctx, &p0, &o0, irot.data(), &r0); }) != GSFM_OK) return false;
+    clk.Note(r0);
         std::vector<std::vector<std::array<double, 4>>> per_frame(static_cast<size_t>(N));
         for (int i = 0; i < NI; ++i) {
           const auto& im = images.at(img_ids[i]);
@@ -543,7 +597,8 @@ class RotationEstimator {
     p.edge_ninl = en.data();
     p.fixed_node = fixed_node;
     gsfm_report rep;
-    if (gsfm_ra_solve(ctx, &p, &o, rot.data(), &rep) != GSFM_OK) return false;
+    if (clk.Call([&] { return gsfm_ra_solve(ctx, &p, &o, rot.data(), &rep); }) != GSFM_OK) return false;
+    clk.Note(rep);
     // ConvertResults (gra.cc:774-816): rotation written, translation zeroed
     for (int n = 0; n < N; ++n) {
       double q[4];
@@ -577,7 +632,7 @@ class RotationEstimator {
   // like camera_id_to_idx_); calibrated sensors are folded into the relative rotations (gra.cc:306-309).
   bool EstimateWithCamBlocks(gsfm_ctx* ctx, const glomap::ViewGraph& view_graph, std::unordered_map<rig_t, glomap::Rig>& rigs,
                              std::unordered_map<frame_t, glomap::Frame>& frames,
-                             std::unordered_map<image_t, glomap::Image>& images, detail::FrameIndex& fidx) {
+                             std::unordered_map<image_t, glomap::Image>& images, detail::FrameIndex& fidx, detail::CallClock& clk) {
     const int N = static_cast<int>(fidx.ids.size());
     std::unordered_map<image_t, int> img_of;
     std::vector<image_t> img_ids;
@@ -664,7 +719,8 @@ class RotationEstimator {
       p.num_nodes = NI;
       p.fixed_node = 0;
       gsfm_report r0;
-      if (gsfm_ra_solve(ctx, &p, &o0, irot.data(), &r0) != GSFM_OK) return false;
+      if (clk.Call([&] { return gsfm_ra_solve(ctx, &p, &o0, irot.data(), &r0); }) != GSFM_OK) return false;
+    clk.Note(r0);
       // ... then ConvertRotationsFromImageToRig (rotation_initializer.cc:7-125).  Images without a block carry rig-level
       // rotations here (their cam_from_rig is folded into the edges).
       std::vector<std::array<double, 4>> qimg(static_cast<size_t>(NI));
@@ -731,7 +787,8 @@ class RotationEstimator {
     p.num_cams = C;
     p.cam_rot_aa = cam_rot.data();
     gsfm_report rep;
-    if (gsfm_ra_solve(ctx, &p, &o, rot.data(), &rep) != GSFM_OK) return false;
+    if (clk.Call([&] { return gsfm_ra_solve(ctx, &p, &o, rot.data(), &rep); }) != GSFM_OK) return false;
+    clk.Note(rep);
     for (int n = 0; n < N; ++n) {  // ConvertResults (gra.cc:774-799)
       double q[4];
       detail::AngleAxisToQuatWxyz(&rot[3 * n], q);
@@ -777,6 +834,7 @@ class GlobalPositioner {
     // caller that leaves use_gpu on gets the device at every size.
     if (!options_.use_gpu) return glomap::GlobalPositioner(options_).Solve(view_graph, rigs, cameras, frames, images, tracks);
     gsfm_ctx* ctx = Context(options_.gpu_index);
+    detail::CallClock clk("GlobalPositioner::Solve");
     if (ctx == nullptr) return false;
     const bool with_pairs = options_.constraint_type != glomap::GlobalPositionerOptions::ONLY_POINTS;
     const bool with_points = options_.constraint_type != glomap::GlobalPositionerOptions::ONLY_CAMERAS;
@@ -936,7 +994,8 @@ class GlobalPositioner {
       pr.pair_dir = pair_dir.data();
     }
     gsfm_report& rep = report_;
-    if (gsfm_gp_solve(ctx, &pr, &o, cen.data(), xyz.data(), &rep) != GSFM_OK) return false;
+    if (clk.Call([&] { return gsfm_gp_solve(ctx, &pr, &o, cen.data(), xyz.data(), &rep); }) != GSFM_OK) return false;
+    clk.Note(rep);
     for (size_t k = 0; k < sensor_ids.size(); ++k) {  // ConvertResults: centre -> translation, t = -R c (gp.cc:576-582)
       auto& cfr = rigs.at(sensor_ids[k].first).SensorFromRig(glomap::sensor_t(glomap::SensorType::CAMERA, sensor_ids[k].second));
       double t[3];
@@ -981,6 +1040,7 @@ class BundleAdjuster {
     // use_gpu == false: the reference class solves on the CPU (ba.cc:49-92); see GlobalPositioner::Solve above
     if (!options_.use_gpu) return glomap::BundleAdjuster(options_).Solve(rigs, cameras, frames, images, tracks);
     gsfm_ctx* ctx = Context(options_.gpu_index);
+    detail::CallClock clk("BundleAdjuster::Solve");
     if (ctx == nullptr) return false;
     if (images.empty() || tracks.empty()) return false;  // ba.cc:17-24
     const bool rigged = !detail::AllTrivial(images);  // RigReprojErrorConstantRigCostFunctor, ba.cc:147-160
@@ -1122,7 +1182,8 @@ class BundleAdjuster {
       }
     }
     gsfm_report& rep = report_;
-    if (gsfm_ba_solve(ctx, &pr, &o, q.data(), t.data(), xyz.data(), intr.data(), &rep) != GSFM_OK) return false;
+    if (clk.Call([&] { return gsfm_ba_solve(ctx, &pr, &o, q.data(), t.data(), xyz.data(), intr.data(), &rep); }) != GSFM_OK) return false;
+    clk.Note(rep);
     for (size_t k = 0; k < sensor_ids.size(); ++k) {  // the cam_from_rig blocks are the rigs' own storage (ba.cc:163-175)
       auto& cfr = rigs.at(sensor_ids[k].first).SensorFromRig(glomap::sensor_t(glomap::SensorType::CAMERA, sensor_ids[k].second));
       const double* v = &sensor_cfr[7 * k];
@@ -1241,13 +1302,14 @@ struct TrackFilter {
                                         std::unordered_map<track_t, glomap::Track>& tracks,
                                         double max_reprojection_error = 1e-2, bool in_normalized_image = true) {
     gsfm_ctx* ctx = Context();
+    detail::CallClock clk("TrackFilter::FilterTracksByReprojection");
     if (ctx == nullptr || !in_normalized_image) return -1;
     detail::ViewPack vp;
     detail::PackView(&cameras, images, tracks, true, vp);
     if (vp.view.num_obs == 0) return 0;
     std::vector<uint8_t> keep(static_cast<size_t>(vp.view.num_obs));
     int64_t changed = 0;
-    if (gsfm_filter_tracks_by_reprojection(ctx, &vp.view, max_reprojection_error, 1, keep.data(), &changed) != GSFM_OK) return -1;
+    if (clk.Call([&] { return gsfm_filter_tracks_by_reprojection(ctx, &vp.view, max_reprojection_error, 1, keep.data(), &changed); }) != GSFM_OK) return -1;
     detail::ApplyObsMask(vp, keep, tracks);
     return static_cast<int>(changed);
   }
@@ -1258,13 +1320,14 @@ struct TrackFilter {
                                  const std::unordered_map<image_t, glomap::Image>& images,
                                  std::unordered_map<track_t, glomap::Track>& tracks, double max_angle_error = 1.) {
     gsfm_ctx* ctx = Context();
+    detail::CallClock clk("TrackFilter::FilterTracksByAngle");
     if (ctx == nullptr) return -1;
     detail::ViewPack vp;
     detail::PackView(&cameras, images, tracks, true, vp);
     if (vp.view.num_obs == 0) return 0;
     std::vector<uint8_t> keep(static_cast<size_t>(vp.view.num_obs));
     int64_t changed = 0;
-    if (gsfm_filter_tracks_by_angle(ctx, &vp.view, max_angle_error, keep.data(), &changed) != GSFM_OK) return -1;
+    if (clk.Call([&] { return gsfm_filter_tracks_by_angle(ctx, &vp.view, max_angle_error, keep.data(), &changed); }) != GSFM_OK) return -1;
     detail::ApplyObsMask(vp, keep, tracks);
     return static_cast<int>(changed);
   }
@@ -1274,13 +1337,14 @@ struct TrackFilter {
                                            const std::unordered_map<image_t, glomap::Image>& images,
                                            std::unordered_map<track_t, glomap::Track>& tracks, double min_angle = 1.) {
     gsfm_ctx* ctx = Context();
+    detail::CallClock clk("TrackFilter::FilterTrackTriangulationAngle");
     if (ctx == nullptr) return -1;
     detail::ViewPack vp;
     detail::PackView(nullptr, images, tracks, false, vp);
     if (vp.view.num_pts == 0) return 0;
     std::vector<uint8_t> keep(static_cast<size_t>(vp.view.num_pts));
     int64_t removed = 0;
-    if (gsfm_filter_tracks_triangulation_angle(ctx, &vp.view, min_angle, keep.data(), &removed) != GSFM_OK) return -1;
+    if (clk.Call([&] { return gsfm_filter_tracks_triangulation_angle(ctx, &vp.view, min_angle, keep.data(), &removed); }) != GSFM_OK) return -1;
     for (size_t p = 0; p < vp.tp.track_ids.size(); ++p)
       if (!keep[p]) tracks.at(vp.tp.track_ids[p]).observations.clear();
     return static_cast<int>(removed);
@@ -1297,6 +1361,7 @@ inline std::array<double, 4> NormalizeReconstruction(std::unordered_map<rig_t, g
                                                      double p1 = 0.9) {
   std::array<double, 4> sim{1.0, 0.0, 0.0, 0.0};
   gsfm_ctx* ctx = Context();
+  detail::CallClock clk("NormalizeReconstruction");
   if (ctx == nullptr) return sim;
   detail::FrameIndex fidx;
   for (auto& [fid, fr] : frames)
@@ -1321,8 +1386,8 @@ inline std::array<double, 4> NormalizeReconstruction(std::unordered_map<rig_t, g
     tids.push_back(tid);
     for (int j = 0; j < 3; ++j) xyz.push_back(tr.xyz[j]);
   }
-  if (gsfm_normalize_reconstruction(ctx, GSFM_MEM_HOST, static_cast<int32_t>(N), reg.data(), q.data(), t.data(),
-                                    static_cast<int64_t>(tids.size()), xyz.data(), fixed_scale, extent, p0, p1, sim.data()) != GSFM_OK)
+  if (clk.Call([&] { return gsfm_normalize_reconstruction(ctx, GSFM_MEM_HOST, static_cast<int32_t>(N), reg.data(), q.data(), t.data(),
+                                    static_cast<int64_t>(tids.size()), xyz.data(), fixed_scale, extent, p0, p1, sim.data()); }) != GSFM_OK)
     return sim;
   for (size_t n = 0; n < N; ++n) {
     auto& fr = frames.at(fidx.ids[n]);
@@ -1343,6 +1408,7 @@ inline std::array<double, 4> NormalizeReconstruction(std::unordered_map<rig_t, g
 inline void UndistortImages(std::unordered_map<camera_t, glomap::Camera>& cameras,
                             std::unordered_map<image_t, glomap::Image>& images, bool clean_points = true) {
   gsfm_ctx* ctx = Context();
+  detail::CallClock clk("UndistortImages");
   if (ctx == nullptr) return;
   std::vector<image_t> ids;
   for (auto& [iid, im] : images) {
@@ -1380,8 +1446,8 @@ inline void UndistortImages(std::unordered_map<camera_t, glomap::Camera>& camera
     }
   }
   std::vector<double> rays(3 * fi.size());
-  if (gsfm_undistort_features(ctx, GSFM_MEM_HOST, static_cast<int64_t>(fi.size()), xy.data(), fi.data(), static_cast<int32_t>(model.size()),
-                              model.data(), intr.data(), stride, rays.data()) != GSFM_OK)
+  if (clk.Call([&] { return gsfm_undistort_features(ctx, GSFM_MEM_HOST, static_cast<int64_t>(fi.size()), xy.data(), fi.data(), static_cast<int32_t>(model.size()),
+                              model.data(), intr.data(), stride, rays.data()); }) != GSFM_OK)
     return;
   size_t o = 0;
   for (const image_t iid : ids) {
@@ -1398,6 +1464,7 @@ struct RelPoseFilter {
   static void FilterRotations(glomap::ViewGraph& view_graph, const std::unordered_map<image_t, glomap::Image>& images,
                               double max_angle = 5.0) {
     gsfm_ctx* ctx = Context();
+    detail::CallClock clk("RelPoseFilter::FilterRotations");
     if (ctx == nullptr) return;
     detail::FrameIndex fidx;
     std::vector<int32_t> ei, ej;
@@ -1426,8 +1493,8 @@ struct RelPoseFilter {
     if (pairs.empty()) return;
     std::vector<uint8_t> keep(pairs.size());
     int64_t ninv = 0;
-    if (gsfm_filter_rotations(ctx, GSFM_MEM_HOST, static_cast<int32_t>(fidx.ids.size()), nq.data(), static_cast<int64_t>(pairs.size()),
-                              ei.data(), ej.data(), eq.data(), max_angle, keep.data(), &ninv) != GSFM_OK)
+    if (clk.Call([&] { return gsfm_filter_rotations(ctx, GSFM_MEM_HOST, static_cast<int32_t>(fidx.ids.size()), nq.data(), static_cast<int64_t>(pairs.size()),
+                              ei.data(), ej.data(), eq.data(), max_angle, keep.data(), &ninv); }) != GSFM_OK)
       return;
     for (size_t e = 0; e < pairs.size(); ++e)
       if (!keep[e]) pairs[e]->is_valid = false;

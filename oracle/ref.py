@@ -634,6 +634,13 @@ def mapper_solve(which, cam_model, cam_params, image_cam, feat_offset, feat_xy, 
                               vp(_p(mo)), vp(_p(m1)), vp(_p(m2)), C.byref(o), vp(_p(out_q)), vp(_p(out_t)), vp(_p(out_reg)), vp(_p(out_cp)),
                               vp(_p(out_pv)), vp(_p(counts)), C.c_long(cap), vp(_p(tid)), vp(_p(tlen)), vp(_p(txyz)))
     T = int(min(counts[0], cap))
-    return dict(ok=ok == 1, rc=int(ok), frame_q=out_q, frame_t=out_t, frame_registered=out_reg.astype(bool), cam_params=out_cp,
+    buf = C.create_string_buffer(4096)
+    lib.ref_mapper_timings.restype = C.c_long
+    lib.ref_mapper_timings(buf, C.c_long(4096))
+    timings = {}
+    for ln in buf.value.decode().splitlines():  # adapter entry point -> calls, seconds packing / inside libgsfm / unpacking
+        name, calls, pk, cl, up, its, lin = ln.split()
+        timings[name] = dict(calls=int(calls), pack=float(pk), call=float(cl), unpack=float(up), iterations=int(its), linear_iterations=int(lin))
+    return dict(ok=ok == 1, rc=int(ok), seconds=counts[3] * 1e-6, adapter_timings=timings, frame_q=out_q, frame_t=out_t, frame_registered=out_reg.astype(bool), cam_params=out_cp,
                 pair_valid=out_pv[:E].astype(bool), num_tracks=int(counts[0]), num_observations=int(counts[1]),
                 num_initialized=int(counts[2]), track_id=tid[:T], track_len=tlen[:T], track_xyz=txyz[:T])

@@ -21,6 +21,12 @@
 
 #include <colmap/geometry/pose.h>
 
+#include <chrono>
+#include <cstdio>
+#include <string>
+
+#include "gsfm_glomap_adapter.hpp"  // (gsfm_glomap::AdapterTimings: where the drop-in builds' wall time went)
+
 namespace glomap {
 #define REF_DECLARE_MAPPER(NAME)                                                                                                    \
   class NAME {                                                                                                                      \
@@ -65,7 +71,7 @@ struct ref_mapper_options {
 // frame poses to start from (frame_q_in wxyz, frame_t_in; used when rotation averaging is skipped, otherwise overwritten);
 // pairs [E]: cam2_from_cam1 (q wxyz, t), weight, validity, matches (match_offset [E + 1], feature indices in image 1 / 2; every
 // match is an inlier).  Outputs: frame_q_out [N][4], frame_t_out [N][3], frame_registered_out [N], cam_params_out [K][12],
-// pair_valid_out [E], counts_out [4] = {tracks, observations, initialised tracks, 0}; the tracks sorted by id, up to cap_tracks:
+// pair_valid_out [E], counts_out [4] = {tracks, observations, initialised tracks, wall time of Solve in microseconds}; the tracks sorted by id, up to cap_tracks:
 // track_id_out, track_len_out, track_xyz_out [.][3].  Returns GlobalMapper::Solve's bool (1 / 0), -1 on a bad `which`.
 int ref_mapper_solve(int which, int num_cams, const int32_t* cam_model, const double* cam_params, const uint8_t* cam_has_prior,
                      int num_images, const int32_t* image_cam, const long* feat_offset, const double* feat_xy, const double* frame_q_in,
@@ -160,10 +166,13 @@ int ref_mapper_solve(int which, int num_cams, const int32_t* cam_model, const do
 
   const colmap::Database database;
   bool ok = false;
+  gsfm_glomap::ResetTimings();
+  const auto wall0 = std::chrono::steady_clock::now();
   if (which == 0) ok = GlobalMapper(opt).Solve(database, vg, rigs, cameras, frames, images, tracks);
   else if (which == 1) ok = GlobalMapperOnGsfm(opt).Solve(database, vg, rigs, cameras, frames, images, tracks);
   else if (which == 2) ok = GlobalMapperOnGsfmAll(opt).Solve(database, vg, rigs, cameras, frames, images, tracks);
   else return -1;
+  const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
 
   for (int n = 0; n < num_images; ++n) {
     const Frame& fr = frames.at(static_cast<frame_t>(n));
@@ -193,7 +202,7 @@ int ref_mapper_solve(int which, int num_cams, const int32_t* cam_model, const do
   counts_out[0] = static_cast<long>(tracks.size());
   counts_out[1] = nobs;
   counts_out[2] = ninit;
-  counts_out[3] = 0;
+  counts_out[3] = static_cast<long>(wall * 1e6);  // wall time of GlobalMapper::Solve, microseconds
   for (long t = 0; t < static_cast<long>(ids.size()) && t < cap_tracks; ++t) {
     const Track& tr = tracks.at(ids[t]);
     track_id_out[t] = ids[t];
@@ -201,6 +210,23 @@ int ref_mapper_solve(int which, int num_cams, const int32_t* cam_model, const do
     for (int j = 0; j < 3; ++j) track_xyz_out[3 * t + j] = tr.xyz(j);
   }
   return ok ? 1 : 0;
+}
+
+
+// Where the wall time of the last drop-in run went inside the adapter (gsfm_glomap::AdapterTimings): one line per entry point,
+// "name calls pack call unpack iterations linear_iterations" (seconds; the counts are what the estimators reported).  Returns the number of bytes written (0 after a which = 0 run: no adapter involved).
+long ref_mapper_timings(char* buf, long cap) {
+  std::string out;
+  char line[256];
+  for (const auto& [name, t] : gsfm_glomap::AdapterTimings()) {
+    std::snprintf(line, sizeof line, "%s %ld %.6f %.6f %.6f %ld %ld\n", name.c_str(), t.calls, t.pack, t.call, t.unpack, t.iterations, t.linear_iterations);
+    out += line;
+  }
+  const long n = std::min<long>(cap - 1, static_cast<long>(out.size()));
+  if (n < 0) return 0;
+  std::memcpy(buf, out.data(), static_cast<size_t>(n));
+  buf[n] = 0;
+  return n;
 }
 
 }  // extern "C"

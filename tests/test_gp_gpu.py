@@ -329,3 +329,46 @@ def test_gp_recycled_ritz_vectors_same_solution_fewer_iterations(gsfm_ctx, ncam,
     assert abs(r1["final_cost"] - r0["final_cost"]) <= 1e-3 * r0["final_cost"]
     assert med < 1e-4
     assert _rel_diff(c1, p.gt_center) < 0.1 and _rel_diff(c0, p.gt_center) < 0.1
+
+
+@pytest.mark.parametrize("ncam,npts,outliers", [(200, 12_000, 0.0), (800, 40_000, 0.0), (200, 12_000, 0.02)])
+def test_gp_dense_reduced_system_on_a_capture_like_scene(gsfm_ctx, ncam, npts, outliers):
+    """The dense direct path of the reduced camera system (gp.hip k_gp_dense_assemble + the block sweep of ra_dense.hpp): on a
+    sequential capture — every point seen by a run of neighbouring cameras, the reduced system a long chain — block-Jacobi PCG
+    needs hundreds of iterations per solve on a few hundred unknowns, and up to 1 024 cameras the library switches to assembling
+    and inverting the system once a solve runs past 100 iterations.  Knob gp_dense: 1 = never (PCG all the way, as before), 2 =
+    every solve dense, 0 = the shipped rule.  The same systems, solved exactly instead of to 1e-10: without outlier bearings the
+    three runs make the same LM decisions and end at the same cameras; with the benchmark's 2 % outliers the trajectory is the
+    chaotic one of DESIGN.md section 2 (two exact solvers end apart as well) and the end points are compared by their cost.
+    The counters prove which path ran."""
+    p = synthetic.make_gp_problem(num_cams=ncam, num_pts=npts, seed=3, capture="sequential", outlier_ratio=outliers)
+    runs = {}
+    try:
+        for knob in (1, 2, 0):
+            gsfm_ctx.set_knob("gp_dense", knob)
+            gsfm_ctx.stats(reset=True)
+            rc, cen, _, rep = estimators.gp_solve(p, ctx=gsfm_ctx)
+            assert rc == 0
+            runs[knob] = (cen, rep, gsfm_ctx.stats(reset=True), gsfm_ctx.lm_trace())
+    finally:
+        gsfm_ctx.set_knob("gp_dense", 0)
+    (c1, r1, s1, t1), (c2, r2, s2, t2), (c0, r0, s0, t0) = runs[1], runs[2], runs[0]
+    print("[parity] gp dense never/always/auto %d cams, outliers %.2f: lm %d/%d/%d pcg %d/%d/%d dense solves %d/%d/%d seconds %.3f/%.3f/%.3f cost %.9g/%.9g/%.9g "
+          "always vs never %.2e, auto vs never %.2e" % (ncam, outliers, r1["iterations"], r2["iterations"], r0["iterations"], r1["linear_iterations"],
+                                                         r2["linear_iterations"], r0["linear_iterations"], s1["dense_solves"], s2["dense_solves"],
+                                                         s0["dense_solves"], r1["seconds_solve"], r2["seconds_solve"], r0["seconds_solve"],
+                                                         r1["final_cost"], r2["final_cost"], r0["final_cost"], _rel_diff(c2, c1), _rel_diff(c0, c1)))
+    assert s1["dense_solves"] == 0 and r1["linear_iterations"] > 100 * 10  # the scene IS chain-like for block-Jacobi
+    assert s2["dense_solves"] >= r2["iterations"] - 1 and r2["linear_iterations"] == 0
+    assert s0["dense_solves"] >= r0["iterations"] - 3 and r0["linear_iterations"] <= 3 * 100  # switched on by the first long solve
+    if outliers == 0.0:
+        n = min(8, len(t1), len(t2), len(t0))
+        for t in (t2, t0):
+            assert np.allclose(t1[:n, 0], t[:n, 0], rtol=1e-6) and np.array_equal(t1[:n, 5], t[:n, 5])
+        for c, r in ((c2, r2), (c0, r0)):
+            assert abs(r["final_cost"] - r1["final_cost"]) <= 1e-6 * r1["final_cost"]
+            assert _rel_diff(c, c1) < 1e-5
+    else:
+        for r in (r2, r0):
+            assert abs(r["final_cost"] - r1["final_cost"]) <= 2e-3 * r1["final_cost"]
+    assert r0["seconds_solve"] < 0.5 * r1["seconds_solve"]
