@@ -2714,12 +2714,8 @@ class GpSolver final : public LmProblem {
     double* r = ws->dn_r.ensure(ld);
     double* dx = ws->dn_dx.ensure(ld);
     const size_t lds = 3 * (size_t)ld * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-      GSFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gp_dense_assemble), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         3 * ((3 * kGpDenseMaxCams + kTile - 1) / kTile * kTile) * (int)sizeof(double)));
-      attr_set = true;
-    }
+    if (lds > 64 * 1024)  // (per device function: set whenever it is needed, a context may sit on any device)
+      GSFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gp_dense_assemble), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_gp_dense_assemble, dim3((ld + 2) / 3), dim3(kBlock), lds, s, g_, (const double*)ci_, (const double*)ws->qa.get(),
                        (const double*)ws->qb.get(), (const double*)ws->ptb.get(), (const double*)ws->dcam.get(), n3, ld, S0);
     GSFM_HIP_CHECK(hipMemcpyAsync(cur, S0, nn * sizeof(double), hipMemcpyDeviceToDevice, s));

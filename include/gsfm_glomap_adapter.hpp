@@ -1526,6 +1526,7 @@ class TrackEngine {
   size_t EstablishFullTracks(std::unordered_map<track_t, glomap::Track>& tracks) {
     tracks.clear();
     gsfm_ctx* ctx = Context();
+    detail::CallClock clk("TrackEngine::EstablishFullTracks");
     if (ctx == nullptr) return 0;
     std::vector<image_t> ids = SortedImageIds();
     std::unordered_map<image_t, int32_t> dense;
@@ -1564,7 +1565,7 @@ class TrackEngine {
     g.match_feat2 = f2.data();
     const gsfm_track_options o = Options();
     int64_t nt = 0, no = 0, nd = 0;
-    if (g.num_images == 0 || gsfm_tracks_establish(ctx, &g, &o, &nt, &no, &nd) != GSFM_OK) return 0;
+    if (g.num_images == 0 || clk.Call([&] { return gsfm_tracks_establish(ctx, &g, &o, &nt, &no, &nd); }) != GSFM_OK) return 0;
     Fetch(ctx, GSFM_TRACKS_FULL, nt, no, ids, /*set_track_id=*/false, tracks);
     return tracks.size();
   }
@@ -1573,6 +1574,7 @@ class TrackEngine {
                               std::unordered_map<track_t, glomap::Track>& tracks_selected) {
     tracks_selected.clear();
     gsfm_ctx* ctx = Context();
+    detail::CallClock clk("TrackEngine::FindTracksForProblem");
     if (ctx == nullptr || tracks_full.empty()) return 0;
     std::vector<image_t> ids = SortedImageIds();
     std::unordered_map<image_t, int32_t> dense;
@@ -1608,7 +1610,7 @@ class TrackEngine {
     full.obs_feature = ofeat.data();
     const gsfm_track_options o = Options();
     int64_t nt = 0, no = 0;
-    if (gsfm_tracks_select(ctx, &full, static_cast<int32_t>(ids.size()), reg.data(), GSFM_MEM_HOST, &o, &nt, &no) != GSFM_OK) return 0;
+    if (clk.Call([&] { return gsfm_tracks_select(ctx, &full, static_cast<int32_t>(ids.size()), reg.data(), GSFM_MEM_HOST, &o, &nt, &no); }) != GSFM_OK) return 0;
     Fetch(ctx, GSFM_TRACKS_SELECTED, nt, no, ids, /*set_track_id=*/true, tracks_selected);
     return tracks_selected.size();
   }

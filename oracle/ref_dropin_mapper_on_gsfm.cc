@@ -44,4 +44,10 @@
 #define NormalizeReconstruction gsfm_glomap::NormalizeReconstruction
 #define RelPoseFilter gsfm_glomap::RelPoseFilter
 #endif
+#ifdef REF_MAPPER_TRACKS_ON_GSFM
+// Track establishment as well: the same tracks under OTHER ids (smallest member instead of union-find root), hence another walk of
+// the `tracks` map and another draw of GlobalPositioner's random start — an equally valid run, compared with ground truth and not
+// with the all-reference build.
+#define TrackEngine gsfm_glomap::TrackEngine
+#endif
 #include REF_GLOBAL_MAPPER_CC

@@ -8,6 +8,8 @@
 //   which = 1   THE DROP-IN: the same controller source with RotationEstimator / GlobalPositioner / BundleAdjuster /
 //               UndistortImages switched to include/gsfm_glomap_adapter.hpp — libgsfm on the GPU (ref_dropin_mapper_on_gsfm.cc)
 //   which = 2   as 1, and TrackFilter / NormalizeReconstruction / RelPoseFilter on libgsfm as well
+//   which = 3   as 2, and TrackEngine (track establishment and selection) too — the same tracks under other ids, i.e. another random
+//               start of global positioning: an equally valid run, not comparable with which = 0 entry by entry
 // The stages outside SURVEY section 8 (preprocessing, view-graph calibration, relative-pose estimation, retriangulation, pruning)
 // are skipped by GlobalMapperOptions::skip_* — the reference's own switches — and abort if reached (ref_glue_mapper_stubs.cc).
 // Part of oracle/_ref/libref_dropin_mapper.so (`make -C oracle ref_mapper`; links libgsfm.so).  tests/test_dropin_reference_mapper.py.
@@ -42,6 +44,7 @@ namespace glomap {
 // (the declaration of glomap/controllers/global_mapper.h:43-59 under the two names ref_dropin_mapper_on_gsfm.cc compiles it as)
 REF_DECLARE_MAPPER(GlobalMapperOnGsfm)
 REF_DECLARE_MAPPER(GlobalMapperOnGsfmAll)
+REF_DECLARE_MAPPER(GlobalMapperOnGsfmTracks)
 }  // namespace glomap
 
 using namespace glomap;
@@ -171,6 +174,7 @@ int ref_mapper_solve(int which, int num_cams, const int32_t* cam_model, const do
   if (which == 0) ok = GlobalMapper(opt).Solve(database, vg, rigs, cameras, frames, images, tracks);
   else if (which == 1) ok = GlobalMapperOnGsfm(opt).Solve(database, vg, rigs, cameras, frames, images, tracks);
   else if (which == 2) ok = GlobalMapperOnGsfmAll(opt).Solve(database, vg, rigs, cameras, frames, images, tracks);
+  else if (which == 3) ok = GlobalMapperOnGsfmTracks(opt).Solve(database, vg, rigs, cameras, frames, images, tracks);
   else return -1;
   const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
 

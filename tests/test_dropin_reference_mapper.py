@@ -12,6 +12,8 @@ normaliser, the bundle adjustment rounds (positions only, then everything) with 
               INTEGRATION.md section 2's diff — to the classes of include/gsfm_glomap_adapter.hpp: the reference's controller
               driving libgsfm on the GPU from the reference's own std::unordered_map containers and option structs
   which = 2   as 1, and TrackFilter / NormalizeReconstruction / RelPoseFilter switched to libgsfm as well
+  which = 3   as 2, and TrackEngine too: the same tracks under other ids — another walk of the `tracks` map, another draw of the
+              random start of global positioning — an equally valid run, held to ground truth and to the track SETS of which = 0
 
 The stages outside SURVEY section 8 (preprocessing, view-graph calibration, relative-pose estimation, retriangulation, pruning)
 are skipped with the reference's own GlobalMapperOptions::skip_* switches.
@@ -125,3 +127,30 @@ def test_reference_mapper_drives_libgsfm_to_the_reference_poses(name, which, gsf
           f"points {xyz:.2e} of the extent, intrinsics {intr:.2e} rel; {a['num_tracks']} tracks / {a['num_observations']} observations both")
     assert same_tracks and a["num_observations"] == b["num_observations"]
     assert rot < 1e-4 and cen < 1e-3 and xyz < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(SCENES))
+def test_reference_mapper_with_every_switchable_stage_on_libgsfm(name, gsfm_ctx):
+    """which = 3: track establishment and selection on libgsfm as well.  gsfm_glomap::TrackEngine names a track by its smallest
+    member where the reference uses the union-find root, so the `tracks` map walks in another order and GlobalPositioner's random
+    start is another draw: the run is held to the reference's own pins against ground truth, and to the all-reference build in what
+    does not depend on the draw — registered frames, valid pairs, the number of tracks and observations entering the pipeline."""
+    gen, opt, pin_deg, pin_c = SCENES[name]
+    s = _scene(gen)
+    a = _solve(0, s, **opt)
+    b = _solve(3, s, **opt)
+    assert a["ok"] and b["ok"]
+    assert np.array_equal(a["frame_registered"], b["frame_registered"]) and np.array_equal(a["pair_valid"], b["pair_valid"])
+    reg = b["frame_registered"]
+    R, c = _poses(b)
+    rot = synthetic.rotation_errors_deg(R[reg], s["gt_R"][reg]).max()
+    cen = synthetic.center_errors_after_sim3(c[reg], s["gt_center"][reg]).max() / synthetic.scene_extent(s["gt_center"][reg])
+    Ra, ca = _poses(a)
+    rot_a = synthetic.rotation_errors_deg(Ra[reg], s["gt_R"][reg]).max()
+    cen_a = synthetic.center_errors_after_sim3(ca[reg], s["gt_center"][reg]).max() / synthetic.scene_extent(s["gt_center"][reg])
+    print(f"[parity] DROP-IN GlobalMapper::Solve {name}, every switchable stage on libgsfm (other track ids, another random start): vs ground truth "
+          f"{rot:.2e} deg / {cen:.2e} (all-reference build: {rot_a:.2e} deg / {cen_a:.2e}); tracks {b['num_tracks']} / {a['num_tracks']}, "
+          f"observations {b['num_observations']} / {a['num_observations']}")
+    assert rot < pin_deg and cen < pin_c
+    assert abs(b["num_tracks"] - a["num_tracks"]) <= 0.01 * a["num_tracks"] and abs(b["num_observations"] - a["num_observations"]) <= 0.01 * a["num_observations"]

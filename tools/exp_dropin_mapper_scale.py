@@ -24,7 +24,7 @@ for N, P, succ in sizes:
     print(f"scene: {N} images, {P} points, {int(s['feat_offset'][-1])} features, {len(s['pair_image1'])} pairs, {int(s['pair_offset'][-1])} matches "
           f"(generated in {time.perf_counter() - t0:.1f} s)", flush=True)
     res = {}
-    for which in ([0] if with_ref and N <= 300 else []) + [1, 2, 1, 2]:
+    for which in ([0] if with_ref and N <= 300 else []) + [1, 2, 3, 1, 2, 3]:
         r = T._solve(which, s)
         res[which] = r
         R, c = T._poses(r)
