@@ -28,6 +28,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <stdexcept>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -329,6 +330,44 @@ struct FrameIndex {
   }
 };
 
+// image id -> image (and its dense frame index, once known) for the packers' inner loops, which look an image up once per
+// OBSERVATION: a plain vector when the ids are small integers (COLMAP numbers images 1 .. N), the caller's hash map otherwise.
+// At 1.5 M observations the three hash lookups per observation were most of the packing time (tools/exp_dropin_mapper_scale.py).
+class ImageTable {
+ public:
+  explicit ImageTable(const std::unordered_map<image_t, glomap::Image>& images) : images_(images) {
+    image_t max_id = 0;
+    for (const auto& [id, im] : images) max_id = std::max(max_id, id);
+    if (!images.empty() && static_cast<size_t>(max_id) <= 4 * images.size() + 1024) {
+      dense_.assign(static_cast<size_t>(max_id) + 1, nullptr);
+      node_.assign(static_cast<size_t>(max_id) + 1, -1);
+      for (const auto& [id, im] : images) dense_[id] = &im;
+    }
+  }
+  const glomap::Image* Find(image_t id) const {
+    if (!dense_.empty()) return id < dense_.size() ? dense_[id] : nullptr;
+    auto it = images_.find(id);
+    return it == images_.end() ? nullptr : &it->second;
+  }
+  const glomap::Image& At(image_t id) const {  // std::unordered_map::at semantics
+    const glomap::Image* im = Find(id);
+    if (im == nullptr) throw std::out_of_range("gsfm_glomap: image id not in the images map");
+    return *im;
+  }
+  // fidx.Add(im.frame_id), remembered per image
+  int Node(image_t id, const glomap::Image& im, FrameIndex& fidx) {
+    if (node_.empty()) return fidx.Add(im.frame_id);
+    int& n = node_[id];
+    if (n < 0) n = fidx.Add(im.frame_id);
+    return n;
+  }
+
+ private:
+  const std::unordered_map<image_t, glomap::Image>& images_;
+  std::vector<const glomap::Image*> dense_;
+  std::vector<int> node_;
+};
+
 // Track-major observation lists shared by GP and BA (gp.cc:270-375, ba.cc:115-190).
 struct TrackPack {
   std::vector<track_t> track_ids;
@@ -358,14 +397,15 @@ inline TrackPack PackTracks(std::unordered_map<image_t, glomap::Image>& images,
   for (auto& [tid, track] : tracks) map_order.push_back(tid);
   std::vector<track_t> sorted(map_order);
   std::sort(sorted.begin(), sorted.end());
+  ImageTable table(images);
   for (track_t tid : sorted) {
     auto& track = tracks.at(tid);
     if (track.observations.size() < min_views) continue;
     const size_t before = tp.obs_cam.size();
     for (const auto& obs : track.observations) {
-      auto it = images.find(obs.first);
-      if (it == images.end() || !keep(it->second, obs.second)) continue;
-      tp.obs_cam.push_back(fidx.Add(it->second.frame_id));
+      const glomap::Image* im = table.Find(obs.first);
+      if (im == nullptr || !keep(*im, obs.second)) continue;
+      tp.obs_cam.push_back(table.Node(obs.first, *im, fidx));
       tp.obs_image.push_back(obs.first);
       tp.obs_feature.push_back(obs.second);
     }
@@ -886,11 +926,18 @@ class GlobalPositioner {
     std::vector<double> image_offset, image_rot;
     std::vector<std::pair<rig_t, camera_t>> image_key;  // sensor of the images that need a block
     std::map<std::pair<rig_t, camera_t>, int> sensor_of;
+    detail::ImageTable table(images);
+    camera_t last_cam = 0;  // (shared cameras: the flag of the previous observation's camera is usually the one asked for)
+    int last_cal = -1;
     for (int64_t k = 0; k < M; ++k) {
-      const auto& im = images.at(tp.obs_image[k]);
+      const auto& im = table.At(tp.obs_image[k]);
       const auto cam_from_world = im.CamFromWorld();
       detail::RotateInv(cam_from_world.rotation, im.features_undist[tp.obs_feature[k]], &dir[3 * k]);  // gp.cc:294-296
-      cal[k] = cameras.at(im.camera_id).has_prior_focal_length ? 1 : 0;                                 // gp.cc:313-316
+      if (last_cal < 0 || im.camera_id != last_cam) {
+        last_cam = im.camera_id;
+        last_cal = cameras.at(im.camera_id).has_prior_focal_length ? 1 : 0;
+      }
+      cal[k] = static_cast<uint8_t>(last_cal);  // gp.cc:313-316
       if (!rigged) continue;
       auto it = img_of.find(tp.obs_image[k]);
       if (it == img_of.end()) {
@@ -1093,13 +1140,18 @@ class BundleAdjuster {
     std::unordered_map<image_t, int> img_of;
     std::vector<int32_t> image_frame, image_intr;
     std::vector<double> image_cfr;
+    detail::ImageTable table(images);
+    std::vector<uint8_t> have_intr(static_cast<size_t>(N), 0);  // trivial frames: one image, one camera per frame
     for (int64_t k = 0; k < M; ++k) {
-      const auto& im = images.at(tp.obs_image[k]);
+      const auto& im = table.At(tp.obs_image[k]);
       const auto& f = im.features[tp.obs_feature[k]];  // distorted pixels (ba.cc:139)
       xy[2 * k] = f[0];
       xy[2 * k + 1] = f[1];
       if (!rigged) {
-        cam_intr[tp.obs_cam[k]] = intr_index(im.camera_id);
+        if (!have_intr[tp.obs_cam[k]]) {
+          cam_intr[tp.obs_cam[k]] = intr_index(im.camera_id);
+          have_intr[tp.obs_cam[k]] = 1;
+        }
         continue;
       }
       auto it = img_of.find(tp.obs_image[k]);
@@ -1236,26 +1288,33 @@ struct ViewPack {
 inline void PackView(const std::unordered_map<camera_t, glomap::Camera>* cameras,
                      const std::unordered_map<image_t, glomap::Image>& images,
                      std::unordered_map<track_t, glomap::Track>& tracks, bool with_undist, ViewPack& vp) {
+  ImageTable table(images);
+  std::vector<const glomap::Image*> node_image;  // one image of every packed frame (trivial rigs: THE image)
   for (auto& [tid, track] : tracks) {
     if (track.observations.empty()) continue;
     for (const auto& obs : track.observations) {
-      const auto& im = images.at(obs.first);
-      vp.tp.obs_cam.push_back(vp.fidx.Add(im.frame_id));
+      const auto& im = table.At(obs.first);
+      const int n = table.Node(obs.first, im, vp.fidx);
+      if (static_cast<size_t>(n) >= node_image.size()) node_image.resize(static_cast<size_t>(n) + 1, nullptr);
+      node_image[n] = &im;
+      vp.tp.obs_cam.push_back(n);
       vp.tp.obs_image.push_back(obs.first);
       vp.tp.obs_feature.push_back(obs.second);
+      if (with_undist) {
+        const auto& f = im.features_undist[obs.second];
+        vp.undist.insert(vp.undist.end(), {f[0], f[1], f[2]});
+      }
     }
     vp.tp.track_ids.push_back(tid);
     vp.tp.pt_offset.push_back(static_cast<int64_t>(vp.tp.obs_cam.size()));
+    for (int j = 0; j < 3; ++j) vp.xyz.push_back(track.xyz[j]);
   }
   const size_t N = vp.fidx.ids.size(), P = vp.tp.track_ids.size(), M = vp.tp.obs_cam.size();
   vp.q.resize(4 * N);
   vp.t.resize(3 * N);
   vp.cal.assign(N, 1);
-  vp.xyz.resize(3 * P);
-  if (with_undist) vp.undist.resize(3 * M);
-  for (size_t k = 0; k < M; ++k) {
-    const auto& im = images.at(vp.tp.obs_image[k]);
-    const int n = vp.tp.obs_cam[k];
+  for (size_t n = 0; n < N; ++n) {  // per frame, not per observation
+    const glomap::Image& im = *node_image[n];
     const auto& pose = im.frame_ptr->RigFromWorld();  // trivial rigs: cam_from_world
     vp.q[4 * n] = pose.rotation.w();
     vp.q[4 * n + 1] = pose.rotation.x();
@@ -1263,11 +1322,7 @@ inline void PackView(const std::unordered_map<camera_t, glomap::Camera>* cameras
     vp.q[4 * n + 3] = pose.rotation.z();
     for (int j = 0; j < 3; ++j) vp.t[3 * n + j] = pose.translation[j];
     if (cameras) vp.cal[n] = cameras->at(im.camera_id).has_prior_focal_length ? 1 : 0;
-    if (with_undist)
-      for (int j = 0; j < 3; ++j) vp.undist[3 * k + j] = im.features_undist[vp.tp.obs_feature[k]][j];
   }
-  for (size_t p = 0; p < P; ++p)
-    for (int j = 0; j < 3; ++j) vp.xyz[3 * p + j] = tracks.at(vp.tp.track_ids[p]).xyz[j];
   vp.view.mem = GSFM_MEM_HOST;
   vp.view.num_cams = static_cast<int32_t>(N);
   vp.view.num_pts = static_cast<int64_t>(P);
