@@ -55,6 +55,7 @@
 #include "dump.hpp"
 #include "lm.hpp"
 #include "obsgraph.hpp"
+#include "ra_dense.hpp"  // dense_spd_solve: the reduced system of small chain-like problems, inverted by the block sweep
 
 #ifndef GSFM_BA_KP
 #error "ba_impl.hpp is included by ba.hip (GSFM_BA_KP 8) and ba_wide.hip (GSFM_BA_KP 16)"
@@ -1048,6 +1049,108 @@ __global__ void __launch_bounds__(kBlock)
   if (threadIdx.x == 0) v.dpart[slot0 + blockIdx.x] = delta[0];
 }
 
+// ---- the reduced camera system as a DENSE matrix: small problems with chain-like co-visibility ---------------------------
+// The counterpart of gp.hip's k_gp_dense_assemble (see there): the reference's mapper on a 300-image ring looking outward spends
+// 5 500 joint-block PCG iterations on 11 LM steps of a bundle adjustment with 1 816 reduced unknowns.  With the stored planes
+// U_k = [A_k | I_k] (2 x (6 + F), scaled by sqrt(w)) and B_k (2 x 3) of every observation,
+//     S = sum over tracks p, observations k, k' of p:   U_k^T (delta_kk' I_2 - B_k H_pp^-1 B_k'^T) U_k'   + D
+// in the unknown layout of the PCG ([6 per camera | KP per intrinsics block]).  One workgroup per camera n owns the six pose rows
+// (LDS, 6 x ld doubles) and, for the intrinsics rows of the camera's block, the intrinsics COLUMNS only (KP x KP K doubles, added to
+// the global matrix by atomics at the end); the intrinsics rows' pose columns are the transpose of what the pose rows' owners
+// computed (k_ba_dense_finish, which also adds the damping and puts 1 on the diagonal of unknowns nothing touches: the constant
+// camera, parameters that are not optimised, the padding).  Trivial frames, the 8-wide unit, at most kBaDenseMaxUnknowns reduced
+// unknowns and kBaDenseMaxIntr intrinsics blocks, one rank; switched on like GP's (knob gp_dense).
+constexpr int kBaDenseMaxUnknowns = 3072;  // 6 x 3072 doubles of LDS per workgroup (144 KB) + the intrinsics rows
+constexpr int kBaDenseMaxIntr = 16;
+constexpr int kBaDenseTrigger = 100;
+
+__global__ void __launch_bounds__(kBlock)
+    k_ba_dense_assemble(BaDev g, const double2* __restrict__ jt, const double* __restrict__ pth, int ld, double* __restrict__ S) {
+  extern __shared__ double srow[];  // [6][ld] | [KP][KP K]
+  const int n = blockIdx.x, N = g.g.N, F = g.F, nik = KP * g.K;
+  double* sint = srow + 6 * (size_t)ld;
+  for (int i = threadIdx.x; i < 6 * ld + KP * nik; i += blockDim.x) srow[i] = 0.0;
+  __syncthreads();
+  const int ikn = g.cam_intr[n];
+  const Map8 mpn = load_map(g.intr_map + KP * (long)ikn);
+  for (int slot = g.g.coff[n] + threadIdx.x; slot < g.g.coff[n + 1]; slot += blockDim.x) {
+    const long k = g.g.c_src[slot];
+    const long p = g.g.c_pt[slot];
+    double2 ak[6], ik[KP], bk[3];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) ak[j] = jt[(PL_A + j) * g.Mp + k];
+#pragma unroll
+    for (int j = 0; j < KP; ++j) ik[j] = j < F ? jt[(PL_I + j) * g.Mp + k] : make_double2(0.0, 0.0);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) bk[j] = jt[(PL_B + j) * g.Mp + k];
+    const double* h = pth + 6 * p;
+    const S3 Hi{h[0], h[1], h[2], h[3], h[4], h[5]};
+    // M = B_k H_pp^-1 (2 x 3), row r = H_pp^-1 (B_k row r)^T
+    const V3 m0 = mul(Hi, V3{bk[0].x, bk[1].x, bk[2].x}), m1 = mul(Hi, V3{bk[0].y, bk[1].y, bk[2].y});
+    for (long m = g.g.off[p]; m < g.g.off[p + 1]; ++m) {
+      const int j = g.g.cam[m];
+      const int ikj = g.obs_ik[m];
+      const double2 b0 = jt[(PL_B + 0) * g.Mp + m], b1 = jt[(PL_B + 1) * g.Mp + m], b2 = jt[(PL_B + 2) * g.Mp + m];
+      const double d = m == k ? 1.0 : 0.0;
+      // W = delta I - M B_m^T
+      const double w00 = d - (m0.x * b0.x + m0.y * b1.x + m0.z * b2.x), w01 = -(m0.x * b0.y + m0.y * b1.y + m0.z * b2.y);
+      const double w10 = -(m1.x * b0.x + m1.y * b1.x + m1.z * b2.x), w11 = d - (m1.x * b0.y + m1.y * b1.y + m1.z * b2.y);
+      const Map8 mpj = load_map(g.intr_map + KP * (long)ikj);
+      // T = W U_m, column by column; pose rows += A_k^T T, intrinsics rows (their intrinsics columns) += I_k^T T
+      for (int c = 0; c < 6 + F; ++c) {
+        const double2 u = c < 6 ? jt[(PL_A + c) * g.Mp + m] : jt[(PL_I + (c - 6)) * g.Mp + m];
+        int col;
+        if (c < 6) {
+          col = 6 * j + c;
+        } else {
+          const int pm = mpj.m[c - 6];
+          if (pm < 0) continue;
+          col = 6 * N + KP * ikj + pm;
+        }
+        const double t0 = w00 * u.x + w01 * u.y, t1 = w10 * u.x + w11 * u.y;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          const double v = ak[a].x * t0 + ak[a].y * t1;
+          if (v != 0.0) atomicAdd(srow + (size_t)a * ld + col, v);
+        }
+        if (c >= 6) {
+#pragma unroll
+          for (int a = 0; a < KP; ++a) {
+            const int pa = mpn.m[a];
+            if (a < F && pa >= 0) {
+              const double v = ik[a].x * t0 + ik[a].y * t1;
+              if (v != 0.0) atomicAdd(sint + (size_t)pa * nik + (col - 6 * N), v);
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 6 * ld; i += blockDim.x) S[((size_t)6 * n + i / ld) * ld + i % ld] = srow[i];
+  for (int i = threadIdx.x; i < KP * nik; i += blockDim.x) {
+    const double v = sint[i];
+    if (v != 0.0) unsafeAtomicAdd(S + ((size_t)6 * N + KP * ikn + i / nik) * ld + 6 * N + i % nik, v);
+  }
+}
+// rows >= 6 N: the pose columns of the intrinsics rows by symmetry; every row: + D, 1 on an empty diagonal; the padding: identity
+__global__ void __launch_bounds__(kBlock)
+    k_ba_dense_finish(int N, int n_a, int ld, const double* __restrict__ dvec, double* __restrict__ S) {
+  const size_t total = (size_t)ld * ld;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / ld), c = (int)(i % ld);
+    if (r >= n_a || c >= n_a) {
+      S[i] = r == c ? 1.0 : 0.0;
+      continue;
+    }
+    if (r >= 6 * N && c < 6 * N) S[i] = S[(size_t)c * ld + r];
+    if (r == c) {
+      const double v = S[i] + dvec[r];
+      S[i] = v != 0.0 ? v : 1.0;
+    }
+  }
+}
+
 // ---- back-substitution, model cost change, candidate points ------------------------------------
 // One lane per observation over the stored planes: dX_p = -e_p - H_pp^-1 sum_k B_k^T u_k (segmented wave
 // scan), broadcast back to the track's lanes for the model decrease  -sum_k (m.rw + m.m / 2),
@@ -1454,6 +1557,7 @@ struct BaWs {
   DevBuf<double> sens, Ri, Rin, ti, tin, diag_i, grad_i, gred_i, spose_i, dvec_i, zimg, wimg, ximg, lever, gram_i;
   DevBuf<double> defl_w, defl_aw, defl_b2, defl_part, defl_small, defl_cd;  // CgDeflation, cg.hpp
   DevBuf<double> ftab;  // [observations of the constant camera][6]: its share of H_pp (k_ba_fixed_share)
+  DevBuf<double> dn_S, dn_a, dn_b, dn_pinv, dn_r, dn_dx;  // dense reduced system (k_ba_dense_*)
   DevBuf<double> maxpart;
   static void destroy(void* p) { delete static_cast<BaWs*>(p); }
 };
@@ -2488,9 +2592,43 @@ class BaSolver final : public LmProblem {
     }
   }
 
+  // (S + D) x = rhs by a dense inverse (k_ba_dense_assemble / _finish, dense_spd_solve of ra_dense.hpp): into cg_x
+  void dense_solve() {
+    if constexpr (KP == 8) {
+      BaWs* ws = ws_;
+      hipStream_t s = ctx_->stream;
+      const int ld = (n_ + kTile - 1) / kTile * kTile;
+      const size_t nn = (size_t)ld * ld;
+      double* S0 = ws->dn_S.ensure(nn);
+      double* bufA = ws->dn_a.ensure(nn);
+      double* bufB = ws->dn_b.ensure(nn);
+      double* pinv = ws->dn_pinv.ensure(2 * kTile * kTile);
+      double* r = ws->dn_r.ensure(ld);
+      double* dx = ws->dn_dx.ensure(ld);
+      const size_t lds = (6 * (size_t)ld + (size_t)KP * KP * K_) * sizeof(double);
+      if (lds > 64 * 1024)
+        GSFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_dense_assemble), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      GSFM_HIP_CHECK(hipMemsetAsync(S0, 0, nn * sizeof(double), s));
+      hipLaunchKernelGGL(k_ba_dense_assemble, dim3(N_), dim3(kBlock), lds, s, g_, (const double2*)ws->jt.get(), (const double*)ws->pth.get(), ld, S0);
+      hipLaunchKernelGGL(k_ba_dense_finish, dim3(grid_wide(nn, kBlock, 1 << 12)), dim3(kBlock), 0, s, N_, n_, ld, (const double*)ws->dvec.get(), S0);
+      dense_spd_solve(s, n_, ld, S0, bufA, bufB, pinv, r, dx, (const double*)ws->rhs.get(), ws->cg_x.get());
+      ctx_->stats[GSFM_STAT_DENSE_SOLVES]++;
+    }
+  }
+  bool dense_ok() const {
+    return KP == 8 && !rig_ && ctx_->comm.world == 1 && n_ <= kBaDenseMaxUnknowns && K_ <= kBaDenseMaxIntr &&
+           ctx_->knob[GSFM_KNOB_GP_DENSE] != 1;
+  }
+
   long pcg() {
     BaWs* ws = ws_;
     hipStream_t s = ctx_->stream;
+    if (dense_ok() && (dense_on_ || ctx_->knob[GSFM_KNOB_GP_DENSE] == 2)) {
+      dense_solve();
+      return 0;
+    }
+    const bool may_dense = dense_ok() && opt_.lm.pcg_max_iterations > kBaDenseTrigger;
+    bool finished = true;
     const double yscale = ctx_->comm.rank == 0 ? 1.0 : 0.0;
     const double tol = opt_.lm.pcg_relative_tolerance;
     // the similarity gauge of the scene deflated from the PCG (CgDeflation, cg.hpp): trivial rigs, translations among
@@ -2556,7 +2694,7 @@ class BaSolver final : public LmProblem {
         }
       }
     }
-    const long iters = cg_solve<6, true, KP>(ctx_, cg_, tol, opt_.lm.pcg_max_iterations, [&](int it) {
+    const long iters = cg_solve<6, true, KP>(ctx_, cg_, tol, may_dense ? kBaDenseTrigger : opt_.lm.pcg_max_iterations, [&](int it) {
       // rigs: the sweeps run on per-image vectors (z_image = T_s z_frame) with a zero pose diagonal; everything else of
       // the PCG state (partials, status, scalars — set by cg_solve on cg_) is shared with the frame-space solve
       CgVec vk = cg_;
@@ -2594,7 +2732,12 @@ class BaSolver final : public LmProblem {
       if (rig_)
         hipLaunchKernelGGL(k_ba_rig_reduce_w, dim3(gridN_ + S_), dim3(kBlock), 0, s, cg_, rg_, yscale, ws->wimg.get(), ws->dvec.get(),
                            gridCam_ + gridK_ + gridMulti_, gridN_);
-    }, defl.k ? &defl : nullptr, &pcg_hint_);
+    }, defl.k ? &defl : nullptr, &pcg_hint_, [](int) {}, &finished);
+    if (may_dense && !finished) {  // still running after kBaDenseTrigger iterations: this and the later solves of the LM problem are direct
+      dense_on_ = true;
+      dense_solve();
+      return iters;
+    }
     if (!aw_check_.empty() && defl.k) {
       std::vector<double> applied(aw_check_.size());
       GSFM_HIP_CHECK(hipMemcpyAsync(applied.data(), defl.AW, applied.size() * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -2633,6 +2776,7 @@ class BaSolver final : public LmProblem {
   int nfix_ = 0;              // observations of the constant camera, their camera-major slots (k_ba_fixed_share)
   int* fix_slots_ = nullptr;
   bool aw_closed_ok_ = true;  // false: a point is observed twice by the constant camera (k_ba_aw_modes keeps one slot per point)
+  bool dense_on_ = false;  // the reduced systems of this LM problem are solved densely (dense_solve)
   bool defl_on_ = true;  // deflate the next reduced solve (short solves run plain)
   int pcg_hint_ = 0;     // iteration count of the previous reduced solve (where cg_solve first reads the status back)
   long P_ = 0, M_ = 0, Mp_ = 0, m_used_ = 0;

@@ -688,25 +688,6 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
-// y = A v (A: n x n, leading dimension ld), one wave per row; with `b`: y = b - A v
-__global__ void __launch_bounds__(kBlock)
-    k_gp_dense_matvec(int n, int ld, const double* __restrict__ A, const double* __restrict__ v, const double* __restrict__ b,
-                      double* __restrict__ y) {
-  const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  const int nwaves = gridDim.x * (kBlock / 64);
-  for (int r = wave; r < n; r += nwaves) {
-    const double* row = A + (size_t)r * ld;
-    double acc = 0.0;
-    for (int m = lane; m < n; m += 64) acc += row[m] * v[m];
-    acc = wave_sum(acc);
-    if (lane == 0) y[r] = b != nullptr ? b[r] - acc : acc;
-  }
-}
-__global__ void __launch_bounds__(kBlock) k_gp_dense_axpy(int n, const double* __restrict__ dx, double* __restrict__ x) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) x[i] += dx[i];
-}
-
 // ---- second-level preconditioner for scenes with chain-like co-visibility ----------------------------------------------
 // The random-visibility benchmark scenes give a reduced camera system whose block-Jacobi-preconditioned spectrum is tight
 // apart from the global gauge.  Scenes with the locality of a real capture do not: a point is seen by a run
@@ -2705,7 +2686,7 @@ class GpSolver final : public LmProblem {
     GpWs* ws = ws_;
     hipStream_t s = ctx_->stream;
     const int n3 = 3 * N_;
-    const int ld = (n3 + kTile - 1) / kTile * kTile, T = ld / kTile;
+    const int ld = (n3 + kTile - 1) / kTile * kTile;
     const size_t nn = (size_t)ld * ld;
     double* S0 = ws->dn_S.ensure(nn);
     double* cur = ws->dn_a.ensure(nn);
@@ -2718,24 +2699,7 @@ class GpSolver final : public LmProblem {
       GSFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gp_dense_assemble), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_gp_dense_assemble, dim3((ld + 2) / 3), dim3(kBlock), lds, s, g_, (const double*)ci_, (const double*)ws->qa.get(),
                        (const double*)ws->qb.get(), (const double*)ws->ptb.get(), (const double*)ws->dcam.get(), n3, ld, S0);
-    GSFM_HIP_CHECK(hipMemcpyAsync(cur, S0, nn * sizeof(double), hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(k_gj_pivot0, dim3(1), dim3(kBlock), 0, s, cur, ld, (size_t)0, pinv);
-    for (int k = 0; k < T; ++k) {
-      hipLaunchKernelGGL(k_gj_sweep_step, dim3(gj_tiles(T)), dim3(kBlock), 0, s, cur, oth, ld, (size_t)0, (const int*)nullptr, T, k, pinv);
-      std::swap(cur, oth);
-    }
-    hipLaunchKernelGGL(k_gj_finish_full, dim3(grid_wide(nn, kBlock, 1 << 12)), dim3(kBlock), 0, s, cur, ld, ld);
-    const int gridR = grid_wide((size_t)n3, kBlock / 64, 1 << 12), gridV = grid_for((size_t)n3, kBlock);
-    double* x = ws->cg_x.get();
-    hipLaunchKernelGGL(k_gp_dense_matvec, dim3(gridR), dim3(kBlock), 0, s, n3, ld, (const double*)cur, (const double*)ws->rhs.get(),
-                       (const double*)nullptr, x);
-    for (int it = 0; it < 2; ++it) {  // x += A^-1 (rhs - S x): the sweep's rounding (no pivoting, condition up to 1 / min damping)
-      hipLaunchKernelGGL(k_gp_dense_matvec, dim3(gridR), dim3(kBlock), 0, s, n3, ld, (const double*)S0, (const double*)x,
-                         (const double*)ws->rhs.get(), r);
-      hipLaunchKernelGGL(k_gp_dense_matvec, dim3(gridR), dim3(kBlock), 0, s, n3, ld, (const double*)cur, (const double*)r,
-                         (const double*)nullptr, dx);
-      hipLaunchKernelGGL(k_gp_dense_axpy, dim3(gridV), dim3(kBlock), 0, s, n3, (const double*)dx, x);
-    }
+    dense_spd_solve(s, n3, ld, S0, cur, oth, pinv, r, dx, (const double*)ws->rhs.get(), ws->cg_x.get());
     ctx_->stats[GSFM_STAT_DENSE_SOLVES]++;
   }
   bool dense_ok() const {

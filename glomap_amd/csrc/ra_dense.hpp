@@ -285,6 +285,49 @@ static __global__ void __launch_bounds__(kBlock)
 }
 
 
+// ---- one SPD system solved densely: the reduced camera systems of small GP / BA problems (gp.hip, ba_impl.hpp) ------------------
+// y = A v (A: n x n, leading dimension ld), one wave per row; with `b`: y = b - A v
+static __global__ void __launch_bounds__(kBlock)
+    k_dense_matvec(int n, int ld, const double* __restrict__ A, const double* __restrict__ v, const double* __restrict__ b,
+                   double* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (kBlock / 64);
+  for (int r = wave; r < n; r += nwaves) {
+    const double* row = A + (size_t)r * ld;
+    double acc = 0.0;
+    for (int m = lane; m < n; m += 64) acc += row[m] * v[m];
+    acc = wave_sum(acc);
+    if (lane == 0) y[r] = b != nullptr ? b[r] - acc : acc;
+  }
+}
+static __global__ void __launch_bounds__(kBlock) k_dense_axpy(int n, const double* __restrict__ dx, double* __restrict__ x) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) x[i] += dx[i];
+}
+// x = S0^-1 rhs: S0 (ld x ld, SPD, identity on the padding rows / columns beyond n; left intact) is copied, inverted by the
+// symmetric block sweep (ld / 32 launches, the matrix cores) and applied, followed by `refine` steps x += S0^-1 (rhs - S0 x)
+// against the matrix itself (the sweep does not pivot; the condition is 1 / the smallest LM damping).  bufA / bufB: ld x ld scratch.
+inline void dense_spd_solve(hipStream_t s, int n, int ld, const double* S0, double* bufA, double* bufB, double* pinv /* [2][32 x 32] */,
+                            double* r /* [ld] */, double* dx /* [ld] */, const double* rhs, double* x, int refine = 2) {
+  const int T = ld / kTile;
+  const size_t nn = (size_t)ld * ld;
+  double *cur = bufA, *oth = bufB;
+  GSFM_HIP_CHECK(hipMemcpyAsync(cur, S0, nn * sizeof(double), hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(k_gj_pivot0, dim3(1), dim3(kBlock), 0, s, cur, ld, (size_t)0, pinv);
+  for (int k = 0; k < T; ++k) {
+    hipLaunchKernelGGL(k_gj_sweep_step, dim3(gj_tiles(T)), dim3(kBlock), 0, s, cur, oth, ld, (size_t)0, (const int*)nullptr, T, k, pinv);
+    std::swap(cur, oth);
+  }
+  hipLaunchKernelGGL(k_gj_finish_full, dim3(grid_wide(nn, kBlock, 1 << 12)), dim3(kBlock), 0, s, cur, ld, ld);
+  const int gridR = grid_wide((size_t)n, kBlock / 64, 1 << 12), gridV = grid_for((size_t)n, kBlock);
+  hipLaunchKernelGGL(k_dense_matvec, dim3(gridR), dim3(kBlock), 0, s, n, ld, (const double*)cur, rhs, (const double*)nullptr, x);
+  for (int it = 0; it < refine; ++it) {
+    hipLaunchKernelGGL(k_dense_matvec, dim3(gridR), dim3(kBlock), 0, s, n, ld, S0, (const double*)x, rhs, r);
+    hipLaunchKernelGGL(k_dense_matvec, dim3(gridR), dim3(kBlock), 0, s, n, ld, (const double*)cur, (const double*)r, (const double*)nullptr, dx);
+    hipLaunchKernelGGL(k_dense_axpy, dim3(gridV), dim3(kBlock), 0, s, n, (const double*)dx, x);
+  }
+}
+
 // ---- PCG preconditioned by a STALE dense inverse --------------------------------------------------
 // The IRLS systems (L_w + gauge) x = rhs differ from the L1-stage matrix only by the edge weights, and
 // the Geman-McClure weights of the inliers are nearly equal: (L_1 + gauge)^-1 is an excellent

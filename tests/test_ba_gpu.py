@@ -215,3 +215,42 @@ def test_ba_closed_form_gauge_products_equal_operator_applications(gsfm_ctx, kw,
     assert np.abs(q_c - q_a).max() < 1e-6 and np.abs(t_c - t_a).max() < 1e-5 * (1 + np.abs(t_a).max())
     assert np.abs(intr_c - intr_a).max() < 1e-4
     assert rep_c["linear_iterations"] < rep_a["linear_iterations"]  # the deflated solves did not pay for A W
+
+
+@pytest.mark.parametrize("ncam,npts,outliers", [(150, 9_000, 0.0), (400, 24_000, 0.0), (150, 9_000, 0.01)])
+def test_ba_dense_reduced_system_on_a_capture_like_scene(gsfm_ctx, ncam, npts, outliers):
+    """The dense direct path of bundle adjustment's reduced camera system (ba_impl.hpp k_ba_dense_assemble / _finish + the block
+    sweep of ra_dense.hpp), the counterpart of test_gp_gpu.py::test_gp_dense_reduced_system_on_a_capture_like_scene: on a
+    sequential capture with ONE shared camera the joint-block PCG needs hundreds of iterations per solve on a few hundred to a
+    few thousand unknowns; up to 3 072 reduced unknowns (and 16 intrinsics blocks) the library assembles and inverts the system
+    once a solve runs past 100 iterations.  Knob gp_dense: 1 = never, 2 = every solve, 0 = the shipped rule.  Same systems,
+    solved exactly instead of to the PCG tolerance: same LM decisions and end points without outliers; with them the runs are
+    compared by their final cost."""
+    p = synthetic.make_ba_problem(num_cams=ncam, num_pts=npts, seed=5, capture="sequential", shared_intrinsics=True, outlier_ratio=outliers)
+    runs = {}
+    try:
+        for knob in (1, 2, 0):
+            gsfm_ctx.set_knob("gp_dense", knob)
+            gsfm_ctx.stats(reset=True)
+            rc, q, t, X, intr, rep = estimators.ba_solve(p, ctx=gsfm_ctx)
+            assert rc == 0
+            runs[knob] = (q, t, intr, rep, gsfm_ctx.stats(reset=True))
+    finally:
+        gsfm_ctx.set_knob("gp_dense", 0)
+    (q1, t1, i1, r1, s1), (q2, t2, i2, r2, s2), (q0, t0, i0, r0, s0) = runs[1], runs[2], runs[0]
+    rot = lambda a, b: float(np.radians(so3.rotation_angle_deg(so3.quat_to_rotmat(a), so3.quat_to_rotmat(b))).max())  # noqa: E731
+    ext = float(np.linalg.norm(t1 - t1.mean(0), axis=1).max())
+    print("[parity] ba dense never/always/auto %d cams, outliers %.2f: lm %d/%d/%d pcg %d/%d/%d dense solves %d/%d/%d seconds %.3f/%.3f/%.3f cost %.9g/%.9g/%.9g "
+          "always vs never %.2e rad %.2e, auto vs never %.2e rad %.2e" % (
+              ncam, outliers, r1["iterations"], r2["iterations"], r0["iterations"], r1["linear_iterations"], r2["linear_iterations"], r0["linear_iterations"],
+              s1["dense_solves"], s2["dense_solves"], s0["dense_solves"], r1["seconds_solve"], r2["seconds_solve"], r0["seconds_solve"], r1["final_cost"],
+              r2["final_cost"], r0["final_cost"], rot(q2, q1), np.abs(t2 - t1).max() / ext, rot(q0, q1), np.abs(t0 - t1).max() / ext))
+    assert s1["dense_solves"] == 0 and r1["linear_iterations"] > 100 * 5
+    assert s2["dense_solves"] >= r2["iterations"] - 1 and r2["linear_iterations"] == 0
+    assert s0["dense_solves"] >= 1
+    for q, t, i, r in ((q2, t2, i2, r2), (q0, t0, i0, r0)):
+        assert abs(r["final_cost"] - r1["final_cost"]) <= (1e-6 if outliers == 0.0 else 2e-3) * r1["final_cost"]
+        if outliers == 0.0:
+            assert r["iterations"] == r1["iterations"]
+            assert rot(q, q1) < 1e-6 and np.abs(t - t1).max() / ext < 1e-5 and np.abs(i - i1).max() / np.abs(i1).max() < 1e-6
+    assert r0["seconds_solve"] < 0.7 * r1["seconds_solve"]
