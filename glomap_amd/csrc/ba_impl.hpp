@@ -1557,7 +1557,7 @@ struct BaWs {
   DevBuf<double> sens, Ri, Rin, ti, tin, diag_i, grad_i, gred_i, spose_i, dvec_i, zimg, wimg, ximg, lever, gram_i;
   DevBuf<double> defl_w, defl_aw, defl_b2, defl_part, defl_small, defl_cd;  // CgDeflation, cg.hpp
   DevBuf<double> ftab;  // [observations of the constant camera][6]: its share of H_pp (k_ba_fixed_share)
-  DevBuf<double> dn_S, dn_a, dn_b, dn_pinv, dn_r, dn_dx;  // dense reduced system (k_ba_dense_*)
+  DevBuf<double> dn_S, dn_a, dn_b, dn_pinv, dn_r, dn_dx, dn_sc, dn_nrm;  // dense reduced system (k_ba_dense_*)
   DevBuf<double> maxpart;
   static void destroy(void* p) { delete static_cast<BaWs*>(p); }
 };
@@ -2593,7 +2593,7 @@ class BaSolver final : public LmProblem {
   }
 
   // (S + D) x = rhs by a dense inverse (k_ba_dense_assemble / _finish, dense_spd_solve of ra_dense.hpp): into cg_x
-  void dense_solve() {
+  bool dense_solve() {  // false: the dense inverse did not reach the tolerance (cg_x is then not a solution)
     if constexpr (KP == 8) {
       BaWs* ws = ws_;
       hipStream_t s = ctx_->stream;
@@ -2605,15 +2605,19 @@ class BaSolver final : public LmProblem {
       double* pinv = ws->dn_pinv.ensure(2 * kTile * kTile);
       double* r = ws->dn_r.ensure(ld);
       double* dx = ws->dn_dx.ensure(ld);
+    double* sc = ws->dn_sc.ensure(ld);
       const size_t lds = (6 * (size_t)ld + (size_t)KP * KP * K_) * sizeof(double);
       if (lds > 64 * 1024)
         GSFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_dense_assemble), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       GSFM_HIP_CHECK(hipMemsetAsync(S0, 0, nn * sizeof(double), s));
       hipLaunchKernelGGL(k_ba_dense_assemble, dim3(N_), dim3(kBlock), lds, s, g_, (const double2*)ws->jt.get(), (const double*)ws->pth.get(), ld, S0);
       hipLaunchKernelGGL(k_ba_dense_finish, dim3(grid_wide(nn, kBlock, 1 << 12)), dim3(kBlock), 0, s, N_, n_, ld, (const double*)ws->dvec.get(), S0);
-      dense_spd_solve(s, n_, ld, S0, bufA, bufB, pinv, r, dx, (const double*)ws->rhs.get(), ws->cg_x.get());
-      ctx_->stats[GSFM_STAT_DENSE_SOLVES]++;
+      const bool ok = dense_spd_solve(s, n_, ld, S0, bufA, bufB, pinv, r, dx, sc, ws->dn_nrm.ensure(2), (const double*)ws->rhs.get(), ws->cg_x.get(),
+                                      opt_.lm.pcg_relative_tolerance);
+      if (ok) ctx_->stats[GSFM_STAT_DENSE_SOLVES]++;
+      return ok;
     }
+    return false;
   }
   bool dense_ok() const {
     return KP == 8 && !rig_ && ctx_->comm.world == 1 && n_ <= kBaDenseMaxUnknowns && K_ <= kBaDenseMaxIntr &&
@@ -2623,12 +2627,13 @@ class BaSolver final : public LmProblem {
   long pcg() {
     BaWs* ws = ws_;
     hipStream_t s = ctx_->stream;
+    bool dense_failed = false;  // this system is beyond the dense inverse (dense_spd_solve): PCG, uncapped
     if (dense_ok() && (dense_on_ || ctx_->knob[GSFM_KNOB_GP_DENSE] == 2)) {
-      dense_solve();
-      return 0;
+      if (dense_solve()) return 0;
+      dense_failed = true;
     }
-    const bool may_dense = dense_ok() && opt_.lm.pcg_max_iterations > kBaDenseTrigger;
-    bool finished = true;
+    const bool may_dense = !dense_failed && dense_ok() && opt_.lm.pcg_max_iterations > kBaDenseTrigger;
+    bool finished = false;  // (cg_solve only ever sets it)
     const double yscale = ctx_->comm.rank == 0 ? 1.0 : 0.0;
     const double tol = opt_.lm.pcg_relative_tolerance;
     // the similarity gauge of the scene deflated from the PCG (CgDeflation, cg.hpp): trivial rigs, translations among
@@ -2735,8 +2740,8 @@ class BaSolver final : public LmProblem {
     }, defl.k ? &defl : nullptr, &pcg_hint_, [](int) {}, &finished);
     if (may_dense && !finished) {  // still running after kBaDenseTrigger iterations: this and the later solves of the LM problem are direct
       dense_on_ = true;
-      dense_solve();
-      return iters;
+      if (dense_solve()) return iters;
+      return iters + pcg();  // (enters with dense_on_ set: the dense path fails the same way once more and the PCG runs uncapped)
     }
     if (!aw_check_.empty() && defl.k) {
       std::vector<double> applied(aw_check_.size());

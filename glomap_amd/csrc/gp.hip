@@ -1799,7 +1799,7 @@ struct GpWs {
   DevBuf<int> pr_i, pr_j, pr_row, pr_ent;                       // camera-to-camera constraints (GpPairs)
   DevBuf<double> pr_v, pr_s, pr_sn, pr_w, pr_js, pr_qa, pr_qb, pr_part;
   DevBuf<double> cs_cbar, cs_E, cs_E2, cs_pinv, cs_c, cs_y;  // second-level preconditioner (GpCoarse*)
-  DevBuf<double> dn_S, dn_a, dn_b, dn_pinv, dn_r, dn_dx;     // dense reduced system (k_gp_dense_*)
+  DevBuf<double> dn_S, dn_a, dn_b, dn_pinv, dn_r, dn_dx, dn_sc, dn_nrm;     // dense reduced system (k_gp_dense_*)
   DevBuf<int> cs_flag;
   static void destroy(void* p) { delete static_cast<GpWs*>(p); }
 };
@@ -2682,7 +2682,7 @@ class GpSolver final : public LmProblem {
   }
 
   // (S + D) x = rhs by a dense inverse (k_gp_dense_assemble, the block sweep of ra_dense.hpp, two refinement steps): into cg_x
-  void dense_solve() {
+  bool dense_solve() {  // false: the dense inverse did not reach the tolerance (cg_x is then not a solution)
     GpWs* ws = ws_;
     hipStream_t s = ctx_->stream;
     const int n3 = 3 * N_;
@@ -2694,13 +2694,16 @@ class GpSolver final : public LmProblem {
     double* pinv = ws->dn_pinv.ensure(2 * kTile * kTile);
     double* r = ws->dn_r.ensure(ld);
     double* dx = ws->dn_dx.ensure(ld);
+    double* sc = ws->dn_sc.ensure(ld);
     const size_t lds = 3 * (size_t)ld * sizeof(double);
     if (lds > 64 * 1024)  // (per device function: set whenever it is needed, a context may sit on any device)
       GSFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gp_dense_assemble), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_gp_dense_assemble, dim3((ld + 2) / 3), dim3(kBlock), lds, s, g_, (const double*)ci_, (const double*)ws->qa.get(),
                        (const double*)ws->qb.get(), (const double*)ws->ptb.get(), (const double*)ws->dcam.get(), n3, ld, S0);
-    dense_spd_solve(s, n3, ld, S0, cur, oth, pinv, r, dx, (const double*)ws->rhs.get(), ws->cg_x.get());
-    ctx_->stats[GSFM_STAT_DENSE_SOLVES]++;
+    const bool ok = dense_spd_solve(s, n3, ld, S0, cur, oth, pinv, r, dx, sc, ws->dn_nrm.ensure(2), (const double*)ws->rhs.get(), ws->cg_x.get(),
+                                    opt_.lm.pcg_relative_tolerance);
+    if (ok) ctx_->stats[GSFM_STAT_DENSE_SOLVES]++;
+    return ok;
   }
   bool dense_ok() const {
     return !rig_ && E_ == 0 && g_.opt_c && ctx_->comm.world == 1 && N_ <= kGpDenseMaxCams && ctx_->knob[GSFM_KNOB_GP_DENSE] != 1;
@@ -2709,9 +2712,10 @@ class GpSolver final : public LmProblem {
   long pcg() {
     GpWs* ws = ws_;
     hipStream_t s = ctx_->stream;
+    bool dense_failed = false;  // this system is beyond the dense inverse (dense_spd_solve): PCG, uncapped
     if (dense_ok() && (dense_on_ || ctx_->knob[GSFM_KNOB_GP_DENSE] == 2)) {
-      dense_solve();
-      return 0;
+      if (dense_solve()) return 0;
+      dense_failed = true;
     }
     const double yscale = ctx_->comm.rank == 0 ? 1.0 : 0.0;
     const double tol = opt_.lm.pcg_relative_tolerance;
@@ -2800,7 +2804,7 @@ class GpSolver final : public LmProblem {
     }
     // chain-like co-visibility shows as a solve that is still running after kCoarseTrigger iterations: it is abandoned there,
     // and this and the later solves of the LM problem get the second-level preconditioner (GpCoarseDev)
-    const bool may_dense = dense_ok() && opt_.lm.pcg_max_iterations > kGpDenseTrigger;  // (the dense path replaces the second level where it applies)
+    const bool may_dense = !dense_failed && dense_ok() && opt_.lm.pcg_max_iterations > kGpDenseTrigger;  // (the dense path replaces the second level where it applies)
     const bool may_switch = !may_dense && !coarse && coarse_ok_ && !coarse_on_ && !rig_ && E_ == 0 && g_.opt_c && N_ > kCgSingleMaxBlocks &&
                             opt_.lm.pcg_max_iterations > 2 * kCoarseTrigger;
     // Ritz vectors recycled from the earlier solves of this LM problem as an additive coarse space (cg.hpp CgRecycle, ritz.hpp):
@@ -2856,8 +2860,8 @@ class GpSolver final : public LmProblem {
     if (recycle && finished && !solve_bad && pcg_hint_ >= min_iters) harvest(rcy, pcg_hint_);
     if (may_dense && !finished) {  // still running after kGpDenseTrigger iterations: this and the later solves of the LM problem are direct
       dense_on_ = true;
-      dense_solve();
-      return iters0;
+      if (dense_solve()) return iters0;
+      return iters0 + pcg();  // (enters with dense_on_ set: tries the dense path once more, fails the same way, runs the PCG uncapped)
     }
     if (may_switch && !finished) {  // still running at the cap (a solve that converged just below it is kept)
       coarse_on_ = true;

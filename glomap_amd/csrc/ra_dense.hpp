@@ -15,6 +15,11 @@
 // (k+1, k+1) also inverts it (in LDS) for the next step.
 #pragma once
 
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
 #include "device.hpp"
 
 namespace gsfm {
@@ -286,33 +291,82 @@ static __global__ void __launch_bounds__(kBlock)
 
 
 // ---- one SPD system solved densely: the reduced camera systems of small GP / BA problems (gp.hip, ba_impl.hpp) ------------------
-// y = A v (A: n x n, leading dimension ld), one wave per row; with `b`: y = b - A v
+// y = sc (.) A (sc (.) v) (A: n x n, leading dimension ld; sc: optional diagonal scaling), one wave per row; with `b`: y = b - A v
 static __global__ void __launch_bounds__(kBlock)
     k_dense_matvec(int n, int ld, const double* __restrict__ A, const double* __restrict__ v, const double* __restrict__ b,
-                   double* __restrict__ y) {
+                   const double* __restrict__ sc, double* __restrict__ y) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * (kBlock / 64);
   for (int r = wave; r < n; r += nwaves) {
     const double* row = A + (size_t)r * ld;
     double acc = 0.0;
-    for (int m = lane; m < n; m += 64) acc += row[m] * v[m];
+    if (sc != nullptr) {
+      for (int m = lane; m < n; m += 64) acc += row[m] * (sc[m] * v[m]);
+    } else {
+      for (int m = lane; m < n; m += 64) acc += row[m] * v[m];
+    }
     acc = wave_sum(acc);
+    if (sc != nullptr) acc *= sc[r];
     if (lane == 0) y[r] = b != nullptr ? b[r] - acc : acc;
   }
 }
 static __global__ void __launch_bounds__(kBlock) k_dense_axpy(int n, const double* __restrict__ dx, double* __restrict__ x) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) x[i] += dx[i];
 }
-// x = S0^-1 rhs: S0 (ld x ld, SPD, identity on the padding rows / columns beyond n; left intact) is copied, inverted by the
-// symmetric block sweep (ld / 32 launches, the matrix cores) and applied, followed by `refine` steps x += S0^-1 (rhs - S0 x)
-// against the matrix itself (the sweep does not pivot; the condition is 1 / the smallest LM damping).  bufA / bufB: ld x ld scratch.
-inline void dense_spd_solve(hipStream_t s, int n, int ld, const double* S0, double* bufA, double* bufB, double* pinv /* [2][32 x 32] */,
-                            double* r /* [ld] */, double* dx /* [ld] */, const double* rhs, double* x, int refine = 2) {
+// sc_i = 1 / sqrt(S_ii) (1 on the padding and where the diagonal is not positive)
+static __global__ void __launch_bounds__(kBlock) k_dense_diag_scale(int n, int ld, const double* __restrict__ S, double* __restrict__ sc) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ld; i += gridDim.x * blockDim.x) {
+    const double d = i < n ? S[(size_t)i * ld + i] : 1.0;
+    sc[i] = d > 0.0 ? 1.0 / sqrt(d) : 1.0;
+  }
+}
+// out_ij = sc_i S_ij sc_j
+static __global__ void __launch_bounds__(kBlock)
+    k_dense_scale_copy(int ld, const double* __restrict__ S, const double* __restrict__ sc, double* __restrict__ out) {
+  const size_t nn = (size_t)ld * ld;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = sc[i / ld] * S[i] * sc[i % ld];
+}
+// out[0] = |r|^2, out[1] = |b|^2 (one workgroup; n is a few thousand)
+static __global__ void __launch_bounds__(kBlock)
+    k_dense_norms(int n, const double* __restrict__ r, const double* __restrict__ b, double* __restrict__ out) {
+  __shared__ double sm[2 * (kBlock / 64)];
+  double a0 = 0.0, a1 = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    a0 += r[i] * r[i];
+    a1 += b[i] * b[i];
+  }
+  a0 = wave_sum(a0);
+  a1 = wave_sum(a1);
+  if ((threadIdx.x & 63) == 0) {
+    sm[threadIdx.x >> 6] = a0;
+    sm[kBlock / 64 + (threadIdx.x >> 6)] = a1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t0 = 0.0, t1 = 0.0;
+    for (int w = 0; w < kBlock / 64; ++w) t0 += sm[w], t1 += sm[kBlock / 64 + w];
+    out[0] = t0;
+    out[1] = t1;
+  }
+}
+// x = S0^-1 rhs: S0 (ld x ld, SPD, identity on the padding rows / columns beyond n; left intact) is equilibrated symmetrically
+// (unit diagonal — Ceres' Jacobi scaling: the unknowns of a bundle adjustment differ by many orders of magnitude), inverted by the
+// symmetric block sweep (ld / 32 launches, the matrix cores) and applied; then iterative refinement x += S0^-1 (rhs - S0 x)
+// against the matrix itself until |rhs - S0 x| <= tol |rhs|.  The sweep forms an explicit inverse without pivoting, whose error
+// grows like the SQUARE of the condition number: a bundle adjustment at a large trust-region radius (condition ~ radius) is
+// beyond it — measured on the mapper's second BA of the 300-image ring: first residual 1.6e-7 / 4e-3 / 9.7 at radius 1e4 / 3e4 /
+// 9e4, and from there the refinement diverges.  So the residual is CHECKED (one small read-back per step): returns false when it
+// has not reached tol after max_refine steps or grows — the caller then solves this system by PCG.  bufA / bufB: ld x ld
+// scratch; r, dx, sc: ld each; nrm: 2 doubles on the device.
+inline bool dense_spd_solve(hipStream_t s, int n, int ld, const double* S0, double* bufA, double* bufB, double* pinv /* [2][32 x 32] */,
+                            double* r, double* dx, double* sc, double* nrm, const double* rhs, double* x, double tol, int max_refine = 8) {
   const int T = ld / kTile;
   const size_t nn = (size_t)ld * ld;
   double *cur = bufA, *oth = bufB;
-  GSFM_HIP_CHECK(hipMemcpyAsync(cur, S0, nn * sizeof(double), hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(k_dense_diag_scale, dim3(grid_for((size_t)ld, kBlock)), dim3(kBlock), 0, s, n, ld, S0, sc);
+  hipLaunchKernelGGL(k_dense_scale_copy, dim3(grid_wide(nn, kBlock, 1 << 12)), dim3(kBlock), 0, s, ld, S0, (const double*)sc, cur);
   hipLaunchKernelGGL(k_gj_pivot0, dim3(1), dim3(kBlock), 0, s, cur, ld, (size_t)0, pinv);
   for (int k = 0; k < T; ++k) {
     hipLaunchKernelGGL(k_gj_sweep_step, dim3(gj_tiles(T)), dim3(kBlock), 0, s, cur, oth, ld, (size_t)0, (const int*)nullptr, T, k, pinv);
@@ -320,12 +374,26 @@ inline void dense_spd_solve(hipStream_t s, int n, int ld, const double* S0, doub
   }
   hipLaunchKernelGGL(k_gj_finish_full, dim3(grid_wide(nn, kBlock, 1 << 12)), dim3(kBlock), 0, s, cur, ld, ld);
   const int gridR = grid_wide((size_t)n, kBlock / 64, 1 << 12), gridV = grid_for((size_t)n, kBlock);
-  hipLaunchKernelGGL(k_dense_matvec, dim3(gridR), dim3(kBlock), 0, s, n, ld, (const double*)cur, rhs, (const double*)nullptr, x);
-  for (int it = 0; it < refine; ++it) {
-    hipLaunchKernelGGL(k_dense_matvec, dim3(gridR), dim3(kBlock), 0, s, n, ld, S0, (const double*)x, rhs, r);
-    hipLaunchKernelGGL(k_dense_matvec, dim3(gridR), dim3(kBlock), 0, s, n, ld, (const double*)cur, (const double*)r, (const double*)nullptr, dx);
+  hipLaunchKernelGGL(k_dense_matvec, dim3(gridR), dim3(kBlock), 0, s, n, ld, (const double*)cur, rhs, (const double*)nullptr, (const double*)sc, x);
+  const bool verbose = std::getenv("GSFM_VERBOSE") != nullptr;
+  double prev = -1.0;
+  for (int it = 0; it <= max_refine; ++it) {
+    hipLaunchKernelGGL(k_dense_matvec, dim3(gridR), dim3(kBlock), 0, s, n, ld, S0, (const double*)x, rhs, (const double*)nullptr, r);
+    hipLaunchKernelGGL(k_dense_norms, dim3(1), dim3(kBlock), 0, s, n, (const double*)r, rhs, nrm);
+    double h[2];
+    GSFM_HIP_CHECK(hipMemcpyAsync(h, nrm, sizeof h, hipMemcpyDeviceToHost, s));
+    GSFM_HIP_CHECK(hipStreamSynchronize(s));
+    const double rel = h[1] > 0.0 ? std::sqrt(h[0] / h[1]) : 0.0;
+    if (verbose) fprintf(stderr, "[gsfm dense] n %d, %d refinement steps: |rhs - S x| / |rhs| = %.3e\n", n, it, rel);
+    if (!std::isfinite(rel)) return false;
+    if (rel <= tol) return true;
+    if (it == max_refine || (prev >= 0.0 && rel > 0.5 * prev)) return false;  // not converging (fast enough): the inverse is no good
+    prev = rel;
+    hipLaunchKernelGGL(k_dense_matvec, dim3(gridR), dim3(kBlock), 0, s, n, ld, (const double*)cur, (const double*)r, (const double*)nullptr,
+                       (const double*)sc, dx);
     hipLaunchKernelGGL(k_dense_axpy, dim3(gridV), dim3(kBlock), 0, s, n, (const double*)dx, x);
   }
+  return false;
 }
 
 // ---- PCG preconditioned by a STALE dense inverse --------------------------------------------------

@@ -29,6 +29,24 @@ del os.environ["GSFM_DUMP_DIR"]
 ctx = _lib.Context(-1)
 for path in files:
     rec = flatio.load(path)
+    if rec.kind == "ba":  # the two bundle adjustments of the mapper's first round: positions only, then everything
+        p, opt = flatio.to_problem(rec)
+        res = {}
+        for knob in (1, 2):
+            ctx.set_knob("gp_dense", knob)
+            ctx.stats(reset=True)
+            t0 = time.perf_counter()
+            rc, q, t, X, intr, rep = estimators.ba_solve(p, opt, ctx=ctx)
+            ms = (time.perf_counter() - t0) * 1e3
+            tr = ctx.lm_trace()
+            res[knob] = (q, t, intr, rep, tr)
+            print(json.dumps(dict(file=os.path.basename(path), cams=p.num_cams, pts=p.num_pts, obs=p.num_obs, gp_dense=knob, rc=rc, lm=rep["iterations"],
+                                  pcg=rep["linear_iterations"], ms=round(ms, 1), final_cost=rep["final_cost"], stats=ctx.stats(),
+                                  costs=[float(x[0]) for x in tr], accepted=[int(x[5]) for x in tr])), flush=True)
+        ctx.set_knob("gp_dense", 0)
+        print("   never vs always: |dq| %.3e |dt| %.3e |dintr| %.3e" % (np.abs(res[1][0] - res[2][0]).max(), np.abs(res[1][1] - res[2][1]).max(),
+                                                                         np.abs(res[1][2] - res[2][2]).max()), flush=True)
+        continue
     if rec.kind != "gp":
         continue
     p, opt = flatio.to_problem(rec)
