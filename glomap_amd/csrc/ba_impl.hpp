@@ -2602,7 +2602,7 @@ class BaSolver final : public LmProblem {
       double* S0 = ws->dn_S.ensure(nn);
       double* bufA = ws->dn_a.ensure(nn);
       double* bufB = ws->dn_b.ensure(nn);
-      double* pinv = ws->dn_pinv.ensure(2 * kTile * kTile);
+      double* pinv = ws->dn_pinv.ensure((size_t)(ld / kTile) * kTile * kTile);
       double* r = ws->dn_r.ensure(ld);
       double* dx = ws->dn_dx.ensure(ld);
     double* sc = ws->dn_sc.ensure(ld);

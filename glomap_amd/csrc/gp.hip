@@ -2691,7 +2691,7 @@ class GpSolver final : public LmProblem {
     double* S0 = ws->dn_S.ensure(nn);
     double* cur = ws->dn_a.ensure(nn);
     double* oth = ws->dn_b.ensure(nn);
-    double* pinv = ws->dn_pinv.ensure(2 * kTile * kTile);
+    double* pinv = ws->dn_pinv.ensure((size_t)(ld / kTile) * kTile * kTile);
     double* r = ws->dn_r.ensure(ld);
     double* dx = ws->dn_dx.ensure(ld);
     double* sc = ws->dn_sc.ensure(ld);
@@ -2700,7 +2700,7 @@ class GpSolver final : public LmProblem {
       GSFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gp_dense_assemble), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_gp_dense_assemble, dim3((ld + 2) / 3), dim3(kBlock), lds, s, g_, (const double*)ci_, (const double*)ws->qa.get(),
                        (const double*)ws->qb.get(), (const double*)ws->ptb.get(), (const double*)ws->dcam.get(), n3, ld, S0);
-    const bool ok = dense_spd_solve(s, n3, ld, S0, cur, oth, pinv, r, dx, sc, ws->dn_nrm.ensure(2), (const double*)ws->rhs.get(), ws->cg_x.get(),
+    const bool ok = dense_spd_solve_by_inverse(s, n3, ld, S0, cur, oth, pinv, r, dx, sc, ws->dn_nrm.ensure(2), (const double*)ws->rhs.get(), ws->cg_x.get(),
                                     opt_.lm.pcg_relative_tolerance);
     if (ok) ctx_->stats[GSFM_STAT_DENSE_SOLVES]++;
     return ok;

@@ -351,16 +351,150 @@ static __global__ void __launch_bounds__(kBlock)
     out[1] = t1;
   }
 }
+// ---- block elimination WITHOUT forming the inverse -----------------------------------------------------------------------------
+// The sweep above ends with an explicit inverse, whose error grows like the SQUARE of the condition number — enough for the
+// Laplacians and coarse matrices it was written for, not for a bundle adjustment at a large trust-region radius (measured on the
+// mapper's second BA of a 300-image ring: first residual 1.6e-7 / 4e-3 / 9.7 at radius 1e4 / 3e4 / 9e4).  Plain block Gaussian
+// elimination of an SPD matrix — the factorisation the reference's SPARSE_SCHUR performs — is backward stable: for k = 0 .. T-1
+//     P_k = A_kk^-1 (32 x 32, tile_inverse_lds),   M_ik = A_ik P_k (i > k, kept in a second buffer),
+//     A_ij -= M_ik A_jk^T   (i >= j > k: only the lower triangle is kept; A_kj = A_jk^T by symmetry)
+// two launches per step, the matrix cores in both; the workgroup that updates tile (k+1, k+1) inverts it for the next step.
+// The solve is one workgroup walking the tiles (n^2 / 2 multiply-adds: microseconds at these sizes):
+//     forward   b_i -= M_ik b_k (i > k),     backward   x_k = P_k (b_k - sum_{i > k} A_ik^T x_i).
+static __global__ void __launch_bounds__(kBlock)
+    k_be_panel(const double* __restrict__ A, double* __restrict__ Mm, int ld, int k, const double* __restrict__ P) {
+  __shared__ double sP[kTile * kTileLd], sX[kTile * kTileLd], sC[kTile * kTileLd];
+  const int i = k + 1 + blockIdx.x;
+  const double* pk = P + (size_t)k * kTile * kTile;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = threadIdx.x + 256 * e;
+    sP[(idx >> 5) * kTileLd + (idx & 31)] = pk[idx];
+  }
+  tile_load(A, ld, i, k, sX);
+  __syncthreads();
+  tile_mma(sX, sP, nullptr, 1.0, sC);
+  __syncthreads();
+  tile_store(Mm, ld, i, k, sC);
+}
+static __global__ void __launch_bounds__(kBlock)
+    k_be_update(double* __restrict__ A, const double* __restrict__ Mm, int ld, int k, double* __restrict__ P) {
+  __shared__ double sX[kTile * kTileLd], sY[kTile * kTileLd], sC[kTile * kTileLd], srow[kTile], scol[kTile];
+  // lower-triangle enumeration of the trailing matrix: t = bi (bi + 1) / 2 + bj
+  const int t = blockIdx.x;
+  int bi = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+  while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+  while (bi * (bi + 1) / 2 > t) --bi;
+  const int bj = t - bi * (bi + 1) / 2;
+  const int i = k + 1 + bi, j = k + 1 + bj;
+  tile_load(Mm, ld, i, k, sX);    // M_ik
+  tile_load_t(A, ld, j, k, sY);   // A_jk^T
+  tile_load(A, ld, i, j, sC);
+  __syncthreads();
+  tile_mma(sX, sY, sC, -1.0, sC);
+  __syncthreads();
+  tile_store(A, ld, i, j, sC);
+  if (bi == 0 && bj == 0) {  // the next pivot
+    tile_inverse_lds(sC, srow, scol);
+    double* pn = P + (size_t)(k + 1) * kTile * kTile;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = threadIdx.x + 256 * e;
+      pn[idx] = sC[(idx >> 5) * kTileLd + (idx & 31)];
+    }
+  }
+}
+// out (+)= sc (.) A^-1 (sc (.) b) from the eliminated matrix (A: its lower triangle after all steps, Mm: the multipliers, P: the
+// pivot inverses); b and out have n entries, the work vector y has ld; one workgroup of 1024 threads.
+static __global__ void __launch_bounds__(1024)
+    k_be_solve(int ld, int n, const double* __restrict__ A, const double* __restrict__ Mm, const double* __restrict__ P,
+               const double* __restrict__ sc, const double* __restrict__ b, double* __restrict__ y, double* __restrict__ out,
+               int accumulate) {
+  __shared__ double sk[kTile], part[32][kTile + 1];
+  const int T = ld / kTile, tid = threadIdx.x;
+  for (int r = tid; r < ld; r += blockDim.x) y[r] = r < n ? sc[r] * b[r] : 0.0;
+  __syncthreads();
+  for (int k = 0; k < T - 1; ++k) {  // forward
+    if (tid < kTile) sk[tid] = y[k * kTile + tid];
+    __syncthreads();
+    for (int r = (k + 1) * kTile + tid; r < ld; r += blockDim.x) {
+      const double* m = Mm + (size_t)r * ld + k * kTile;
+      double acc = 0.0;
+#pragma unroll
+      for (int c = 0; c < kTile; ++c) acc += m[c] * sk[c];
+      y[r] -= acc;
+    }
+    __syncthreads();
+  }
+  for (int k = T - 1; k >= 0; --k) {  // backward: column c of the tiles below the pivot, 32 row groups
+    const int c = tid & 31, g = tid >> 5;
+    double acc = 0.0;
+    for (int r = (k + 1) * kTile + g; r < ld; r += 32) acc += A[(size_t)r * ld + k * kTile + c] * y[r];
+    part[g][c] = acc;
+    __syncthreads();
+    if (tid < kTile) {
+      double s0 = y[k * kTile + tid];
+      for (int q = 0; q < 32; ++q) s0 -= part[q][tid];
+      sk[tid] = s0;
+    }
+    __syncthreads();
+    if (tid < kTile) {
+      const double* pk = P + (size_t)k * kTile * kTile + tid * kTile;
+      double x = 0.0;
+#pragma unroll
+      for (int q = 0; q < kTile; ++q) x += pk[q] * sk[q];
+      y[k * kTile + tid] = x;
+    }
+    __syncthreads();
+  }
+  for (int r = tid; r < n; r += blockDim.x) out[r] = (accumulate ? out[r] : 0.0) + sc[r] * y[r];
+}
+
 // x = S0^-1 rhs: S0 (ld x ld, SPD, identity on the padding rows / columns beyond n; left intact) is equilibrated symmetrically
-// (unit diagonal — Ceres' Jacobi scaling: the unknowns of a bundle adjustment differ by many orders of magnitude), inverted by the
-// symmetric block sweep (ld / 32 launches, the matrix cores) and applied; then iterative refinement x += S0^-1 (rhs - S0 x)
-// against the matrix itself until |rhs - S0 x| <= tol |rhs|.  The sweep forms an explicit inverse without pivoting, whose error
-// grows like the SQUARE of the condition number: a bundle adjustment at a large trust-region radius (condition ~ radius) is
-// beyond it — measured on the mapper's second BA of the 300-image ring: first residual 1.6e-7 / 4e-3 / 9.7 at radius 1e4 / 3e4 /
-// 9e4, and from there the refinement diverges.  So the residual is CHECKED (one small read-back per step): returns false when it
-// has not reached tol after max_refine steps or grows — the caller then solves this system by PCG.  bufA / bufB: ld x ld
-// scratch; r, dx, sc: ld each; nrm: 2 doubles on the device.
-inline bool dense_spd_solve(hipStream_t s, int n, int ld, const double* S0, double* bufA, double* bufB, double* pinv /* [2][32 x 32] */,
+// (unit diagonal — Ceres' Jacobi scaling: the unknowns of a bundle adjustment differ by many orders of magnitude), eliminated by
+// blocks (above) and solved; then iterative refinement x += S0^-1 (rhs - S0 x) against the matrix itself until
+// |rhs - S0 x| <= tol |rhs|.  The residual is CHECKED (one small read-back per step): returns false when it has not reached tol
+// after max_refine steps or stops halving — the caller then solves this system by PCG, so a failure here costs time, never an
+// answer.  bufA / bufB: ld x ld scratch; P: (ld / 32) x 32 x 32; r, dx, sc: ld each; nrm: 2 doubles on the device.
+inline bool dense_spd_solve(hipStream_t s, int n, int ld, const double* S0, double* bufA, double* bufB, double* P,
+                            double* r, double* dx, double* sc, double* nrm, const double* rhs, double* x, double tol, int max_refine = 6) {
+  const int T = ld / kTile;
+  const size_t nn = (size_t)ld * ld;
+  hipLaunchKernelGGL(k_dense_diag_scale, dim3(grid_for((size_t)ld, kBlock)), dim3(kBlock), 0, s, n, ld, S0, sc);
+  hipLaunchKernelGGL(k_dense_scale_copy, dim3(grid_wide(nn, kBlock, 1 << 12)), dim3(kBlock), 0, s, ld, S0, (const double*)sc, bufA);
+  hipLaunchKernelGGL(k_gj_pivot0, dim3(1), dim3(kBlock), 0, s, bufA, ld, (size_t)0, P);  // P_0
+  for (int k = 0; k + 1 < T; ++k) {
+    const int m = T - k - 1;
+    hipLaunchKernelGGL(k_be_panel, dim3(m), dim3(kBlock), 0, s, (const double*)bufA, bufB, ld, k, (const double*)P);
+    hipLaunchKernelGGL(k_be_update, dim3(m * (m + 1) / 2), dim3(kBlock), 0, s, bufA, (const double*)bufB, ld, k, P);
+  }
+  const int gridR = grid_wide((size_t)n, kBlock / 64, 1 << 12);
+  hipLaunchKernelGGL(k_be_solve, dim3(1), dim3(1024), 0, s, ld, n, (const double*)bufA, (const double*)bufB, (const double*)P, (const double*)sc, rhs,
+                     dx, x, 0);
+  const bool verbose = std::getenv("GSFM_VERBOSE") != nullptr;
+  double prev = -1.0;
+  for (int it = 0; it <= max_refine; ++it) {
+    hipLaunchKernelGGL(k_dense_matvec, dim3(gridR), dim3(kBlock), 0, s, n, ld, S0, (const double*)x, rhs, (const double*)nullptr, r);
+    hipLaunchKernelGGL(k_dense_norms, dim3(1), dim3(kBlock), 0, s, n, (const double*)r, rhs, nrm);
+    double h[2];
+    GSFM_HIP_CHECK(hipMemcpyAsync(h, nrm, sizeof h, hipMemcpyDeviceToHost, s));
+    GSFM_HIP_CHECK(hipStreamSynchronize(s));
+    const double rel = h[1] > 0.0 ? std::sqrt(h[0] / h[1]) : 0.0;
+    if (verbose) fprintf(stderr, "[gsfm dense] n %d, %d refinement steps: |rhs - S x| / |rhs| = %.3e\n", n, it, rel);
+    if (!std::isfinite(rel)) return false;
+    if (rel <= tol) return true;
+    if (it == max_refine || (prev >= 0.0 && rel > 0.5 * prev)) return false;  // not converging (fast enough)
+    prev = rel;
+    hipLaunchKernelGGL(k_be_solve, dim3(1), dim3(1024), 0, s, ld, n, (const double*)bufA, (const double*)bufB, (const double*)P, (const double*)sc,
+                       (const double*)r, dx, x, 1);
+  }
+  return false;
+}
+
+// The same with the EXPLICIT inverse of the symmetric block sweep (one launch per step instead of two, the solves two dense
+// matrix-vector products instead of a single-workgroup substitution) — faster where the condition number allows it: global
+// positioning's reduced systems (no rotations, no intrinsics).  pinv: [2][32 x 32].
+inline bool dense_spd_solve_by_inverse(hipStream_t s, int n, int ld, const double* S0, double* bufA, double* bufB, double* pinv /* [2][32 x 32] */,
                             double* r, double* dx, double* sc, double* nrm, const double* rhs, double* x, double tol, int max_refine = 8) {
   const int T = ld / kTile;
   const size_t nn = (size_t)ld * ld;
