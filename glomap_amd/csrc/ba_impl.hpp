@@ -2612,6 +2612,19 @@ class BaSolver final : public LmProblem {
       GSFM_HIP_CHECK(hipMemsetAsync(S0, 0, nn * sizeof(double), s));
       hipLaunchKernelGGL(k_ba_dense_assemble, dim3(N_), dim3(kBlock), lds, s, g_, (const double2*)ws->jt.get(), (const double*)ws->pth.get(), ld, S0);
       hipLaunchKernelGGL(k_ba_dense_finish, dim3(grid_wide(nn, kBlock, 1 << 12)), dim3(kBlock), 0, s, N_, n_, ld, (const double*)ws->dvec.get(), S0);
+      if (const char* dd = std::getenv("GSFM_DUMP_DENSE")) {  // diagnostics (tools/exp_capture_ba_verbose.py): the assembled matrix and rhs
+        static int counter = 0;
+        std::vector<double> h(nn + (size_t)ld);
+        GSFM_HIP_CHECK(hipMemcpyAsync(h.data(), S0, nn * sizeof(double), hipMemcpyDeviceToHost, s));
+        GSFM_HIP_CHECK(hipMemcpyAsync(h.data() + nn, ws->rhs.get(), (size_t)n_ * sizeof(double), hipMemcpyDeviceToHost, s));
+        GSFM_HIP_CHECK(hipStreamSynchronize(s));
+        char path[512];
+        snprintf(path, sizeof path, "%s/dense_%d_%d_%d.bin", dd, n_, ld, counter++);
+        if (FILE* f = fopen(path, "wb")) {
+          fwrite(h.data(), sizeof(double), h.size(), f);
+          fclose(f);
+        }
+      }
       const bool ok = dense_spd_solve(s, n_, ld, S0, bufA, bufB, pinv, r, dx, sc, ws->dn_nrm.ensure(2), (const double*)ws->rhs.get(), ws->cg_x.get(),
                                       opt_.lm.pcg_relative_tolerance);
       if (ok) ctx_->stats[GSFM_STAT_DENSE_SOLVES]++;

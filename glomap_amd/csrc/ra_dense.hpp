@@ -351,35 +351,81 @@ static __global__ void __launch_bounds__(kBlock)
     out[1] = t1;
   }
 }
-// ---- block elimination WITHOUT forming the inverse -----------------------------------------------------------------------------
+// ---- blocked Cholesky: no inverse of anything but a triangle is ever formed ---------------------------------------------------
 // The sweep above ends with an explicit inverse, whose error grows like the SQUARE of the condition number — enough for the
-// Laplacians and coarse matrices it was written for, not for a bundle adjustment at a large trust-region radius (measured on the
-// mapper's second BA of a 300-image ring: first residual 1.6e-7 / 4e-3 / 9.7 at radius 1e4 / 3e4 / 9e4).  Plain block Gaussian
-// elimination of an SPD matrix — the factorisation the reference's SPARSE_SCHUR performs — is backward stable: for k = 0 .. T-1
-//     P_k = A_kk^-1 (32 x 32, tile_inverse_lds),   M_ik = A_ik P_k (i > k, kept in a second buffer),
-//     A_ij -= M_ik A_jk^T   (i >= j > k: only the lower triangle is kept; A_kj = A_jk^T by symmetry)
-// two launches per step, the matrix cores in both; the workgroup that updates tile (k+1, k+1) inverts it for the next step.
-// The solve is one workgroup walking the tiles (n^2 / 2 multiply-adds: microseconds at these sizes):
-//     forward   b_i -= M_ik b_k (i > k),     backward   x_k = P_k (b_k - sum_{i > k} A_ik^T x_i).
-static __global__ void __launch_bounds__(kBlock)
-    k_be_panel(const double* __restrict__ A, double* __restrict__ Mm, int ld, int k, const double* __restrict__ P) {
-  __shared__ double sP[kTile * kTileLd], sX[kTile * kTileLd], sC[kTile * kTileLd];
-  const int i = k + 1 + blockIdx.x;
-  const double* pk = P + (size_t)k * kTile * kTile;
+// Laplacians and coarse matrices it was written for, not for a bundle adjustment at a large trust-region radius.  Measured on the
+// mapper's second BA of a 300-image ring, whose equilibrated reduced systems have condition numbers 2.8e4 ... 1.3e6 (numpy on the
+// dumped matrices, tools/exp_capture_ba_verbose.py: SPD, symmetric to 3e-16, LU residual 1e-13): the sweep's first residual is
+// 1.6e-7 / 4e-3 / 9.7 at radius 1e4 / 3e4 / 9e4; a block Gaussian elimination that still multiplied by explicitly inverted 32 x 32
+// pivots reached 5.5e-10 / 4.3e-5 / 7e-4 and stalled two radius steps later (the pivots are Schur complements as ill-conditioned
+// as the matrix, and their inverses enter every trailing update).  The factorisation the reference's SPARSE_SCHUR performs is
+// backward stable because it only ever divides by a TRIANGLE:  A = L L^T by 32-column panels,
+//     L_kk = chol(A_kk), W_k = L_kk^-1 (one workgroup, in LDS),   L_ik = A_ik W_k^T (i > k),   A_ij -= L_ik L_jk^T (i >= j > k)
+// two launches per step, the matrix cores in both; the workgroup that updates tile (k+1, k+1) factorises it for the next step.
+// The solve is one workgroup walking the tiles (n^2 multiply-adds: microseconds at these sizes):
+//     forward   y_k = W_k (b_k - sum_{j < k} L_kj y_j),     backward   x_k = W_k^T (y_k - sum_{i > k} L_ik^T x_i).
+// S: SPD tile in LDS (leading dimension kTileLd), overwritten by its Cholesky factor (lower triangle); W: its inverse (lower
+// triangle, zeros above).  All 256 threads of the workgroup.
+__device__ __forceinline__ void tile_cholesky_lds(double* __restrict__ S, double* __restrict__ W) {
+  const int tid = threadIdx.x;
+  __syncthreads();
+  for (int p = 0; p < kTile; ++p) {
+    if (tid == 0) S[p * kTileLd + p] = sqrt(S[p * kTileLd + p]);
+    __syncthreads();
+    if (tid > p && tid < kTile) S[tid * kTileLd + p] /= S[p * kTileLd + p];
+    __syncthreads();
+    for (int e = tid; e < kTile * kTile; e += kBlock) {
+      const int r = e >> 5, c = e & 31;
+      if (c > p && r >= c) S[r * kTileLd + c] -= S[r * kTileLd + p] * S[c * kTileLd + p];
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < kTile * kTile; e += kBlock) W[(e >> 5) * kTileLd + (e & 31)] = 0.0;
+  __syncthreads();
+  if (tid < kTile) {  // column `tid` of L^-1 by forward substitution (each thread reads only what it wrote)
+    const int c = tid;
+    W[c * kTileLd + c] = 1.0 / S[c * kTileLd + c];
+    for (int r = c + 1; r < kTile; ++r) {
+      double acc = 0.0;
+      for (int q = c; q < r; ++q) acc += S[r * kTileLd + q] * W[q * kTileLd + c];
+      W[r * kTileLd + c] = -acc / S[r * kTileLd + r];
+    }
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void tile_store_w(double* __restrict__ Wall, int k, const double* __restrict__ W) {
+  double* w = Wall + (size_t)k * kTile * kTile;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int idx = threadIdx.x + 256 * e;
-    sP[(idx >> 5) * kTileLd + (idx & 31)] = pk[idx];
+    w[idx] = W[(idx >> 5) * kTileLd + (idx & 31)];
+  }
+}
+static __global__ void __launch_bounds__(kBlock) k_ch_pivot0(const double* __restrict__ A, int ld, double* __restrict__ Wall) {
+  __shared__ double sC[kTile * kTileLd], sW[kTile * kTileLd];
+  tile_load(A, ld, 0, 0, sC);
+  tile_cholesky_lds(sC, sW);
+  tile_store_w(Wall, 0, sW);
+}
+static __global__ void __launch_bounds__(kBlock)
+    k_ch_panel(const double* __restrict__ A, double* __restrict__ L, int ld, int k, const double* __restrict__ Wall) {
+  __shared__ double sY[kTile * kTileLd], sX[kTile * kTileLd], sC[kTile * kTileLd];
+  const int i = k + 1 + blockIdx.x;
+  const double* w = Wall + (size_t)k * kTile * kTile;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {  // sY = W_k^T
+    const int idx = threadIdx.x + 256 * e;
+    sY[(idx & 31) * kTileLd + (idx >> 5)] = w[idx];
   }
   tile_load(A, ld, i, k, sX);
   __syncthreads();
-  tile_mma(sX, sP, nullptr, 1.0, sC);
+  tile_mma(sX, sY, nullptr, 1.0, sC);  // A_ik L_kk^-T
   __syncthreads();
-  tile_store(Mm, ld, i, k, sC);
+  tile_store(L, ld, i, k, sC);
 }
 static __global__ void __launch_bounds__(kBlock)
-    k_be_update(double* __restrict__ A, const double* __restrict__ Mm, int ld, int k, double* __restrict__ P) {
-  __shared__ double sX[kTile * kTileLd], sY[kTile * kTileLd], sC[kTile * kTileLd], srow[kTile], scol[kTile];
+    k_ch_update(double* __restrict__ A, const double* __restrict__ L, int ld, int k, double* __restrict__ Wall) {
+  __shared__ double sX[kTile * kTileLd], sY[kTile * kTileLd], sC[kTile * kTileLd];
   // lower-triangle enumeration of the trailing matrix: t = bi (bi + 1) / 2 + bj
   const int t = blockIdx.x;
   int bi = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
@@ -387,38 +433,38 @@ static __global__ void __launch_bounds__(kBlock)
   while (bi * (bi + 1) / 2 > t) --bi;
   const int bj = t - bi * (bi + 1) / 2;
   const int i = k + 1 + bi, j = k + 1 + bj;
-  tile_load(Mm, ld, i, k, sX);    // M_ik
-  tile_load_t(A, ld, j, k, sY);   // A_jk^T
+  tile_load(L, ld, i, k, sX);    // L_ik
+  tile_load_t(L, ld, j, k, sY);  // L_jk^T
   tile_load(A, ld, i, j, sC);
   __syncthreads();
   tile_mma(sX, sY, sC, -1.0, sC);
   __syncthreads();
   tile_store(A, ld, i, j, sC);
-  if (bi == 0 && bj == 0) {  // the next pivot
-    tile_inverse_lds(sC, srow, scol);
-    double* pn = P + (size_t)(k + 1) * kTile * kTile;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int idx = threadIdx.x + 256 * e;
-      pn[idx] = sC[(idx >> 5) * kTileLd + (idx & 31)];
-    }
+  if (bi == 0 && bj == 0) {  // the next diagonal tile: factorise it (sX is free: its inverse goes there)
+    tile_cholesky_lds(sC, sX);
+    tile_store_w(Wall, k + 1, sX);
   }
 }
-// out (+)= sc (.) A^-1 (sc (.) b) from the eliminated matrix (A: its lower triangle after all steps, Mm: the multipliers, P: the
-// pivot inverses); b and out have n entries, the work vector y has ld; one workgroup of 1024 threads.
+// out (+)= sc (.) A^-1 (sc (.) b) from the factor (L: the tiles below the diagonal, Wall: the inverted diagonal factors); b and
+// out have n entries, the work vector y has ld; one workgroup of 1024 threads.
 static __global__ void __launch_bounds__(1024)
-    k_be_solve(int ld, int n, const double* __restrict__ A, const double* __restrict__ Mm, const double* __restrict__ P,
-               const double* __restrict__ sc, const double* __restrict__ b, double* __restrict__ y, double* __restrict__ out,
-               int accumulate) {
+    k_ch_solve(int ld, int n, const double* __restrict__ L, const double* __restrict__ Wall, const double* __restrict__ sc,
+               const double* __restrict__ b, double* __restrict__ y, double* __restrict__ out, int accumulate) {
   __shared__ double sk[kTile], part[32][kTile + 1];
   const int T = ld / kTile, tid = threadIdx.x;
   for (int r = tid; r < ld; r += blockDim.x) y[r] = r < n ? sc[r] * b[r] : 0.0;
   __syncthreads();
-  for (int k = 0; k < T - 1; ++k) {  // forward
-    if (tid < kTile) sk[tid] = y[k * kTile + tid];
+  for (int k = 0; k < T; ++k) {  // forward
+    if (tid < kTile) {
+      const double* w = Wall + (size_t)k * kTile * kTile + tid * kTile;
+      double acc = 0.0;
+      for (int q = 0; q <= tid; ++q) acc += w[q] * y[k * kTile + q];
+      sk[tid] = acc;
+    }
     __syncthreads();
+    if (tid < kTile) y[k * kTile + tid] = sk[tid];
     for (int r = (k + 1) * kTile + tid; r < ld; r += blockDim.x) {
-      const double* m = Mm + (size_t)r * ld + k * kTile;
+      const double* m = L + (size_t)r * ld + k * kTile;
       double acc = 0.0;
 #pragma unroll
       for (int c = 0; c < kTile; ++c) acc += m[c] * sk[c];
@@ -426,10 +472,10 @@ static __global__ void __launch_bounds__(1024)
     }
     __syncthreads();
   }
-  for (int k = T - 1; k >= 0; --k) {  // backward: column c of the tiles below the pivot, 32 row groups
+  for (int k = T - 1; k >= 0; --k) {  // backward: column c of the tiles below the diagonal, 32 row groups
     const int c = tid & 31, g = tid >> 5;
     double acc = 0.0;
-    for (int r = (k + 1) * kTile + g; r < ld; r += 32) acc += A[(size_t)r * ld + k * kTile + c] * y[r];
+    for (int r = (k + 1) * kTile + g; r < ld; r += 32) acc += L[(size_t)r * ld + k * kTile + c] * y[r];
     part[g][c] = acc;
     __syncthreads();
     if (tid < kTile) {
@@ -438,11 +484,10 @@ static __global__ void __launch_bounds__(1024)
       sk[tid] = s0;
     }
     __syncthreads();
-    if (tid < kTile) {
-      const double* pk = P + (size_t)k * kTile * kTile + tid * kTile;
+    if (tid < kTile) {  // W_k^T s
+      const double* w = Wall + (size_t)k * kTile * kTile;
       double x = 0.0;
-#pragma unroll
-      for (int q = 0; q < kTile; ++q) x += pk[q] * sk[q];
+      for (int q = tid; q < kTile; ++q) x += w[q * kTile + tid] * sk[q];
       y[k * kTile + tid] = x;
     }
     __syncthreads();
@@ -451,8 +496,8 @@ static __global__ void __launch_bounds__(1024)
 }
 
 // x = S0^-1 rhs: S0 (ld x ld, SPD, identity on the padding rows / columns beyond n; left intact) is equilibrated symmetrically
-// (unit diagonal — Ceres' Jacobi scaling: the unknowns of a bundle adjustment differ by many orders of magnitude), eliminated by
-// blocks (above) and solved; then iterative refinement x += S0^-1 (rhs - S0 x) against the matrix itself until
+// (unit diagonal — Ceres' Jacobi scaling: the unknowns of a bundle adjustment differ by many orders of magnitude), factorised
+// (above) and solved; then iterative refinement x += S0^-1 (rhs - S0 x) against the matrix itself until
 // |rhs - S0 x| <= tol |rhs|.  The residual is CHECKED (one small read-back per step): returns false when it has not reached tol
 // after max_refine steps or stops halving — the caller then solves this system by PCG, so a failure here costs time, never an
 // answer.  bufA / bufB: ld x ld scratch; P: (ld / 32) x 32 x 32; r, dx, sc: ld each; nrm: 2 doubles on the device.
@@ -462,15 +507,14 @@ inline bool dense_spd_solve(hipStream_t s, int n, int ld, const double* S0, doub
   const size_t nn = (size_t)ld * ld;
   hipLaunchKernelGGL(k_dense_diag_scale, dim3(grid_for((size_t)ld, kBlock)), dim3(kBlock), 0, s, n, ld, S0, sc);
   hipLaunchKernelGGL(k_dense_scale_copy, dim3(grid_wide(nn, kBlock, 1 << 12)), dim3(kBlock), 0, s, ld, S0, (const double*)sc, bufA);
-  hipLaunchKernelGGL(k_gj_pivot0, dim3(1), dim3(kBlock), 0, s, bufA, ld, (size_t)0, P);  // P_0
+  hipLaunchKernelGGL(k_ch_pivot0, dim3(1), dim3(kBlock), 0, s, (const double*)bufA, ld, P);
   for (int k = 0; k + 1 < T; ++k) {
     const int m = T - k - 1;
-    hipLaunchKernelGGL(k_be_panel, dim3(m), dim3(kBlock), 0, s, (const double*)bufA, bufB, ld, k, (const double*)P);
-    hipLaunchKernelGGL(k_be_update, dim3(m * (m + 1) / 2), dim3(kBlock), 0, s, bufA, (const double*)bufB, ld, k, P);
+    hipLaunchKernelGGL(k_ch_panel, dim3(m), dim3(kBlock), 0, s, (const double*)bufA, bufB, ld, k, (const double*)P);
+    hipLaunchKernelGGL(k_ch_update, dim3(m * (m + 1) / 2), dim3(kBlock), 0, s, bufA, (const double*)bufB, ld, k, P);
   }
   const int gridR = grid_wide((size_t)n, kBlock / 64, 1 << 12);
-  hipLaunchKernelGGL(k_be_solve, dim3(1), dim3(1024), 0, s, ld, n, (const double*)bufA, (const double*)bufB, (const double*)P, (const double*)sc, rhs,
-                     dx, x, 0);
+  hipLaunchKernelGGL(k_ch_solve, dim3(1), dim3(1024), 0, s, ld, n, (const double*)bufB, (const double*)P, (const double*)sc, rhs, dx, x, 0);
   const bool verbose = std::getenv("GSFM_VERBOSE") != nullptr;
   double prev = -1.0;
   for (int it = 0; it <= max_refine; ++it) {
@@ -485,8 +529,8 @@ inline bool dense_spd_solve(hipStream_t s, int n, int ld, const double* S0, doub
     if (rel <= tol) return true;
     if (it == max_refine || (prev >= 0.0 && rel > 0.5 * prev)) return false;  // not converging (fast enough)
     prev = rel;
-    hipLaunchKernelGGL(k_be_solve, dim3(1), dim3(1024), 0, s, ld, n, (const double*)bufA, (const double*)bufB, (const double*)P, (const double*)sc,
-                       (const double*)r, dx, x, 1);
+    hipLaunchKernelGGL(k_ch_solve, dim3(1), dim3(1024), 0, s, ld, n, (const double*)bufB, (const double*)P, (const double*)sc, (const double*)r,
+                       dx, x, 1);
   }
   return false;
 }

@@ -18,4 +18,18 @@ ctx = _lib.Context(-1)
 rec = flatio.load(files[1])
 p, opt = flatio.to_problem(rec)
 ctx.set_knob("gp_dense", int(sys.argv[1]) if len(sys.argv) > 1 else 2)
+dd = tempfile.mkdtemp(prefix="gsfm_dense_")
+os.environ["GSFM_DUMP_DENSE"] = dd
 print(estimators.ba_solve(p, opt, ctx=ctx)[-1])
+import numpy as np
+for f in sorted(glob.glob(os.path.join(dd, "dense_*.bin")), key=lambda x: int(x.rsplit("_", 1)[1][:-4])):
+    n, ld = (int(v) for v in os.path.basename(f).split("_")[1:3])
+    a = np.fromfile(f)
+    S, b = a[:ld * ld].reshape(ld, ld)[:n, :n], a[ld * ld:ld * ld + n]
+    asym = np.abs(S - S.T).max() / np.abs(S).max()
+    d = 1.0 / np.sqrt(np.where(np.diag(S) > 0, np.diag(S), 1.0))
+    E = (S + S.T) * 0.5 * d[:, None] * d[None, :]
+    w = np.linalg.eigvalsh(E)
+    x = np.linalg.solve(S, b)
+    print(os.path.basename(f), "asymmetry %.1e" % asym, "equilibrated eigenvalues min %.3e max %.3e (negative: %d), condition %.2e" % (w[0], w[-1], int((w < 0).sum()), w[-1] / abs(w[0])),
+          "numpy LU residual %.1e" % (np.linalg.norm(b - S @ x) / np.linalg.norm(b)), flush=True)
