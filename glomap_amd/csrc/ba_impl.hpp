@@ -1059,17 +1059,23 @@ __global__ void __launch_bounds__(kBlock)
 // the global matrix by atomics at the end); the intrinsics rows' pose columns are the transpose of what the pose rows' owners
 // computed (k_ba_dense_finish, which also adds the damping and puts 1 on the diagonal of unknowns nothing touches: the constant
 // camera, parameters that are not optimised, the padding).  Trivial frames, the 8-wide unit, at most kBaDenseMaxUnknowns reduced
-// unknowns and kBaDenseMaxIntr intrinsics blocks, one rank; switched on like GP's (knob gp_dense).
-constexpr int kBaDenseMaxUnknowns = 3072;  // 6 x 3072 doubles of LDS per workgroup (144 KB) + the intrinsics rows
+// unknowns (assembled in column windows of kBaDenseWindow) and kBaDenseMaxIntr intrinsics blocks, one rank; switched on like GP's
+// (knob gp_dense).
+constexpr int kBaDenseMaxUnknowns = 6144;  // (the factorisation is n^3: 1 000 images are ~10 ms per solve, still six times the PCG's pace)
+constexpr int kBaDenseWindow = 3072;       // columns per assembly window: 6 x 3072 doubles of LDS per workgroup (144 KB) + the intrinsics rows
 constexpr int kBaDenseMaxIntr = 16;
 constexpr int kBaDenseTrigger = 100;
 
 __global__ void __launch_bounds__(kBlock)
-    k_ba_dense_assemble(BaDev g, const double2* __restrict__ jt, const double* __restrict__ pth, int ld, double* __restrict__ S) {
-  extern __shared__ double srow[];  // [6][ld] | [KP][KP K]
+    k_ba_dense_assemble(BaDev g, const double2* __restrict__ jt, const double* __restrict__ pth, int ld, int cw, double* __restrict__ S) {
+  // blockIdx.y: the window of cw columns this workgroup accumulates (a row of ld doubles x 6 does not fit the LDS beyond
+  // ld = 3072; wider systems are assembled in several column windows, every window walking the observations again)
+  extern __shared__ double srow[];  // [6][cw] | [KP][KP K]
   const int n = blockIdx.x, N = g.g.N, F = g.F, nik = KP * g.K;
-  double* sint = srow + 6 * (size_t)ld;
-  for (int i = threadIdx.x; i < 6 * ld + KP * nik; i += blockDim.x) srow[i] = 0.0;
+  const int c0 = blockIdx.y * cw, c1 = min(ld, c0 + cw);
+  const bool first = blockIdx.y == 0;  // (the intrinsics rows' intrinsics columns: once)
+  double* sint = srow + 6 * (size_t)cw;
+  for (int i = threadIdx.x; i < 6 * cw + KP * nik; i += blockDim.x) srow[i] = 0.0;
   __syncthreads();
   const int ikn = g.cam_intr[n];
   const Map8 mpn = load_map(g.intr_map + KP * (long)ikn);
@@ -1108,12 +1114,14 @@ __global__ void __launch_bounds__(kBlock)
           col = 6 * N + KP * ikj + pm;
         }
         const double t0 = w00 * u.x + w01 * u.y, t1 = w10 * u.x + w11 * u.y;
+        if (col >= c0 && col < c1) {
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {
-          const double v = ak[a].x * t0 + ak[a].y * t1;
-          if (v != 0.0) atomicAdd(srow + (size_t)a * ld + col, v);
+          for (int a = 0; a < 6; ++a) {
+            const double v = ak[a].x * t0 + ak[a].y * t1;
+            if (v != 0.0) atomicAdd(srow + (size_t)a * cw + (col - c0), v);
+          }
         }
-        if (c >= 6) {
+        if (c >= 6 && first) {
 #pragma unroll
           for (int a = 0; a < KP; ++a) {
             const int pa = mpn.m[a];
@@ -1127,7 +1135,9 @@ __global__ void __launch_bounds__(kBlock)
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 6 * ld; i += blockDim.x) S[((size_t)6 * n + i / ld) * ld + i % ld] = srow[i];
+  for (int i = threadIdx.x; i < 6 * cw; i += blockDim.x)
+    if (c0 + i % cw < c1) S[((size_t)6 * n + i / cw) * ld + c0 + i % cw] = srow[i];
+  if (first)
   for (int i = threadIdx.x; i < KP * nik; i += blockDim.x) {
     const double v = sint[i];
     if (v != 0.0) unsafeAtomicAdd(S + ((size_t)6 * N + KP * ikn + i / nik) * ld + 6 * N + i % nik, v);
@@ -2606,11 +2616,12 @@ class BaSolver final : public LmProblem {
       double* r = ws->dn_r.ensure(ld);
       double* dx = ws->dn_dx.ensure(ld);
     double* sc = ws->dn_sc.ensure(ld);
-      const size_t lds = (6 * (size_t)ld + (size_t)KP * KP * K_) * sizeof(double);
+      const int cw = std::min(ld, kBaDenseWindow), nwin = (ld + cw - 1) / cw;
+      const size_t lds = (6 * (size_t)cw + (size_t)KP * KP * K_) * sizeof(double);
       if (lds > 64 * 1024)
         GSFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_dense_assemble), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       GSFM_HIP_CHECK(hipMemsetAsync(S0, 0, nn * sizeof(double), s));
-      hipLaunchKernelGGL(k_ba_dense_assemble, dim3(N_), dim3(kBlock), lds, s, g_, (const double2*)ws->jt.get(), (const double*)ws->pth.get(), ld, S0);
+      hipLaunchKernelGGL(k_ba_dense_assemble, dim3(N_, nwin), dim3(kBlock), lds, s, g_, (const double2*)ws->jt.get(), (const double*)ws->pth.get(), ld, cw, S0);
       hipLaunchKernelGGL(k_ba_dense_finish, dim3(grid_wide(nn, kBlock, 1 << 12)), dim3(kBlock), 0, s, N_, n_, ld, (const double*)ws->dvec.get(), S0);
       if (const char* dd = std::getenv("GSFM_DUMP_DENSE")) {  // diagnostics (tools/exp_capture_ba_verbose.py): the assembled matrix and rhs
         static int counter = 0;

@@ -171,7 +171,7 @@ enum gsfm_knob {
   GSFM_KNOB_GP_RECYCLE_MIN_ITERS = 12, /* GP: harvest Ritz vectors from solves of at least this many iterations (0: 25) — tests
                                           lower it so that small problems, whose solves are short, exercise the path */
   GSFM_KNOB_GP_RECYCLE_CUT_PERCENT = 13, /* GP: harvest Ritz values below this many hundredths (0: 30) — tests raise it for the same reason */
-  GSFM_KNOB_GP_DENSE = 14,            /* GP (at most 1024 cameras) and BA (at most 3072 reduced unknowns, 16 intrinsics blocks): 0 = assemble and invert the reduced system densely once a PCG solve of the LM
+  GSFM_KNOB_GP_DENSE = 14,            /* GP (at most 1024 cameras) and BA (at most 6144 reduced unknowns, 16 intrinsics blocks): 0 = assemble and invert the reduced system densely once a PCG solve of the LM
                                        * problem ran past 100 iterations; 1 = never; 2 = always (every solve, A/B and tests) */
   GSFM_KNOB_COUNT = 15
 };
