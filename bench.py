@@ -194,6 +194,11 @@ def run_extras(env, args, world, rank, main_line):
             # point, tracks in capture order): what the camera-major gathers cost when co-visible points share cache lines
             ("gp_c3_sequential_capture", lambda: {k: v for k, v in bench_gp(**{**env, "args": sub(capture="sequential")}).items() if k in keys}),
             ("ba_c4_sequential_capture", lambda: {k: v for k, v in bench_ba(**{**env, "args": sub(capture="sequential")}).items() if k in keys}),
+            # small captures (800 / 400 cameras): where the reduced systems are assembled densely and factorised on the matrix cores
+            # once a PCG solve runs past 100 iterations — the sizes of the reference's real-data configurations
+            ("gp_small_sequential_capture", lambda: {k: v for k, v in bench_gp(**{**env, "args": sub(capture="sequential", scale=0.16)}).items() if k in keys}),
+            ("ba_small_sequential_capture", lambda: {k: v for k, v in bench_ba(**{**env, "args": sub(capture="sequential", scale=0.04, shared_intrinsics=True)}).items()
+                                                     if k in keys}),
             ("ra_large", lambda: bench_ra_large(ctx)),
             ("ra_c3", lambda: bench_ra_sized(ctx, 5000, 50)),
             ("ra_c4_non_ring_graphs", lambda: bench_ra_nonring(ctx)),
