@@ -252,7 +252,7 @@ def test_ba_dense_reduced_system_on_a_capture_like_scene(gsfm_ctx, ncam, npts, o
     for q, t, i, r in ((q2, t2, i2, r2), (q0, t0, i0, r0)):
         assert abs(r["final_cost"] - r1["final_cost"]) <= (1e-6 if outliers == 0.0 else 2e-3) * r1["final_cost"]
         if outliers == 0.0:
-            assert r["iterations"] == r1["iterations"]
+            assert abs(r["iterations"] - r1["iterations"]) <= 1  # (exact solves against 1e-6 ones: the last LM test may fall either way)
             # (the PCG runs stop at a relative residual of 1e-6; the direct solves are the exact ones)
             assert rot(q, q1) < 2e-5 and np.abs(t - t1).max() / ext < 1e-4 and np.abs(i - i1).max() / np.abs(i1).max() < 1e-5
     assert r0["seconds_solve"] < 0.7 * r1["seconds_solve"]
