@@ -2700,8 +2700,13 @@ class GpSolver final : public LmProblem {
       GSFM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gp_dense_assemble), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_gp_dense_assemble, dim3((ld + 2) / 3), dim3(kBlock), lds, s, g_, (const double*)ci_, (const double*)ws->qa.get(),
                        (const double*)ws->qb.get(), (const double*)ws->ptb.get(), (const double*)ws->dcam.get(), n3, ld, S0);
-    const bool ok = dense_spd_solve_by_inverse(s, n3, ld, S0, cur, oth, pinv, r, dx, sc, ws->dn_nrm.ensure(2), (const double*)ws->rhs.get(), ws->cg_x.get(),
-                                    opt_.lm.pcg_relative_tolerance);
+    // the sweep's explicit inverse first (one launch per step; enough for most of positioning's systems), the blocked Cholesky
+    // when its residual check fails (seen on outward rings of ~150 images late in the trajectory), the PCG after that
+    bool ok = dense_spd_solve_by_inverse(s, n3, ld, S0, cur, oth, pinv, r, dx, sc, ws->dn_nrm.ensure(2), (const double*)ws->rhs.get(), ws->cg_x.get(),
+                                         opt_.lm.pcg_relative_tolerance);
+    if (!ok)
+      ok = dense_spd_solve(s, n3, ld, S0, cur, oth, pinv, r, dx, sc, ws->dn_nrm.get(), (const double*)ws->rhs.get(), ws->cg_x.get(),
+                           opt_.lm.pcg_relative_tolerance);
     if (ok) ctx_->stats[GSFM_STAT_DENSE_SOLVES]++;
     return ok;
   }
